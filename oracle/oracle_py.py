@@ -1,0 +1,164 @@
+"""ctypes binding of the CPU parity oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (swarmmap_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ORC_MAX_LEVELS = 16
+ORC_FAST_CAP = 10000
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class OrcTables(C.Structure):
+    _fields_ = [("scale", C.c_float * ORC_MAX_LEVELS), ("inv_scale", C.c_float * ORC_MAX_LEVELS),
+                ("sigma2", C.c_float * ORC_MAX_LEVELS), ("inv_sigma2", C.c_float * ORC_MAX_LEVELS),
+                ("features_per_level", C.c_int32 * ORC_MAX_LEVELS), ("umax", C.c_int32 * 16)]
+
+
+def build(force=False):
+    """Compile oracle/*.c into oracle/liboracle.so when missing or stale (needs gcc + make)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_ic_angle.restype = C.c_float
+        _LIB.orc_atan2f.restype = C.c_float
+        _LIB.orc_atan2f.argtypes = [C.c_float, C.c_float]
+        _LIB.orc_sincosf_deg.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def config(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+    return OrcConfig(nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+
+def make_tables(cfg):
+    t = OrcTables()
+    lib().orc_make_tables(C.byref(cfg), C.byref(t))
+    return t
+
+
+def level_sizes(cfg, w, h):
+    t = make_tables(cfg)
+    out = []
+    for l in range(cfg.nlevels):
+        lw, lh = C.c_int(), C.c_int()
+        lib().orc_level_size(w, h, C.c_float(t.inv_scale[l]), C.byref(lw), C.byref(lh))
+        out.append((lw.value, lh.value))
+    return out
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_linear(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian7(src):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.empty_like(src)
+    lib().orc_gaussian7(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def border_reflect101(src, border=19):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape
+    dst = np.empty((h + 2 * border, w + 2 * border), np.uint8)
+    lib().orc_border_reflect101(_p(src), w, h, src.strides[0], _p(dst), border, dst.strides[0])
+    return dst
+
+
+def fast_score(img, x, y, th):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    return int(lib().orc_fast_score(_p(img), img.strides[0], int(x), int(y), int(th)))
+
+
+def fast_detect(level, th_high=20, th_low=7, cap=ORC_FAST_CAP):
+    level = np.ascontiguousarray(level, dtype=np.uint8)
+    xs = np.empty(cap, np.int16)
+    ys = np.empty(cap, np.int16)
+    sc = np.empty(cap, np.uint8)
+    n = lib().orc_fast_detect(_p(level), level.shape[1], level.shape[0], level.strides[0], th_high, th_low,
+                              _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def distribute_octree(xs, ys, scores, roi_w, roi_h, n_target):
+    xs = np.ascontiguousarray(xs, np.int16)
+    ys = np.ascontiguousarray(ys, np.int16)
+    scores = np.ascontiguousarray(scores, np.uint8)
+    out = np.empty(n_target + 64, np.int32)
+    n = lib().orc_distribute_octree(_p(xs), _p(ys), _p(scores), len(xs), roi_w, roi_h, n_target, _p(out),
+                                    len(out))
+    return out[:n].copy()
+
+
+def ic_angle(level, x, y, umax):
+    level = np.ascontiguousarray(level, dtype=np.uint8)
+    um = np.ascontiguousarray(umax, np.int32)
+    return float(lib().orc_ic_angle(_p(level), level.strides[0], int(x), int(y), _p(um)))
+
+
+def brief(blurred, x, y, angle_deg):
+    blurred = np.ascontiguousarray(blurred, dtype=np.uint8)
+    d = np.empty(32, np.uint8)
+    lib().orc_brief(_p(blurred), blurred.strides[0], int(x), int(y), C.c_float(angle_deg), _p(d))
+    return d
+
+
+def extract(cfg, img, debug=False, cand_cap=ORC_FAST_CAP):
+    """Returns (keypoints[KP_DTYPE], descriptors[n,32]); with debug also per-level candidates + pyramid."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = cfg.nfeatures + 2 * cfg.nlevels + 64
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    if not debug:
+        n = lib().orc_extract(C.byref(cfg), _p(img), w, h, img.strides[0], _p(kps), _p(desc), cap)
+        return kps[:n].copy(), desc[:n].copy()
+    nl = cfg.nlevels
+    cx = np.zeros((nl, cand_cap), np.int16)
+    cy = np.zeros((nl, cand_cap), np.int16)
+    cs = np.zeros((nl, cand_cap), np.uint8)
+    cnt = np.zeros(nl, np.int32)
+    sizes = level_sizes(cfg, w, h)
+    pyr = np.zeros(sum(a * b for a, b in sizes), np.uint8)
+    n = lib().orc_extract_debug(C.byref(cfg), _p(img), w, h, img.strides[0], _p(kps), _p(desc), cap, _p(cx),
+                                _p(cy), _p(cs), _p(cnt), cand_cap, _p(pyr))
+    levels, off = [], 0
+    for (lw, lh) in sizes:
+        levels.append(pyr[off:off + lw * lh].reshape(lh, lw))
+        off += lw * lh
+    cands = [(cx[l, :cnt[l]].copy(), cy[l, :cnt[l]].copy(), cs[l, :cnt[l]].copy()) for l in range(nl)]
+    return kps[:n].copy(), desc[:n].copy(), cands, levels
