@@ -1,0 +1,76 @@
+"""Loader for libswarmorb.so (in-tree build; fails loudly when it is missing)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class SwarmOrbError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libswarmorb.so")
+
+
+def build_library(force=False):
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j4"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return library_path()
+
+
+class SoKeypoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
+
+
+class SoExtractorConfig(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("device", C.c_int32)]
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise SwarmOrbError(
+            "libswarmorb.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C swarmmap_amd/csrc`. There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    lib.so_status_string.restype = C.c_char_p
+    lib.so_status_string.argtypes = [C.c_int]
+    lib.so_last_error.restype = C.c_char_p
+    lib.so_device_count.restype = C.c_int
+    lib.so_extractor_create.argtypes = [C.POINTER(SoExtractorConfig), C.POINTER(vp)]
+    lib.so_extractor_destroy.argtypes = [vp]
+    lib.so_extractor_destroy.restype = None
+    lib.so_extractor_capacity.argtypes = [vp]
+    lib.so_extractor_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
+    lib.so_extractor_run_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
+    lib.so_extractor_tables.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.so_extractor_level_size.argtypes = [vp, C.c_int, ip, ip]
+    lib.so_extractor_get_level.argtypes = [vp, C.c_int, vp, C.c_int]
+    lib.so_extractor_get_candidates.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, ip]
+    lib.so_extractor_set_profiling.argtypes = [vp, C.c_int]
+    lib.so_extractor_get_profile.argtypes = [vp, vp]
+    _LIB = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        lib = load_library()
+        raise SwarmOrbError("%s: %s" % (lib.so_status_string(status).decode(), lib.so_last_error().decode()))
+
+
+def device_count():
+    return int(load_library().so_device_count())

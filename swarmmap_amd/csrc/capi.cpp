@@ -1,0 +1,36 @@
+// capi.cpp — library-wide pieces of the C ABI (include/swarmorb.h): status strings, last error, device probe.
+#include <hip/hip_runtime.h>
+
+#include "so_common.h"
+
+namespace so {
+std::string& last_error_ref() {
+    static thread_local std::string err;
+    return err;
+}
+}  // namespace so
+
+extern "C" {
+
+const char* so_status_string(int status) {
+    switch (status) {
+        case SO_OK: return "ok";
+        case SO_ERR_INVALID_ARG: return "invalid argument";
+        case SO_ERR_NO_DEVICE: return "no usable HIP device";
+        case SO_ERR_HIP: return "HIP runtime error";
+        case SO_ERR_CAPACITY: return "output buffer too small";
+        case SO_ERR_SIZE_CHANGED: return "image size changed between frames";
+        case SO_ERR_NUMERIC: return "numeric failure";
+        default: return "unknown status";
+    }
+}
+
+const char* so_last_error(void) { return so::last_error_ref().c_str(); }
+
+int so_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+// extractor.cpp — host driver + C ABI of the ORB extractor (include/swarmorb.h).
+//
+// Replaces ORB_SLAM2::ORBextractor (code/src/ORBextractor.cc:340-855).  Per frame, on ONE HIP stream:
+//   upload -> 7 resize launches -> FAST score+NMS (all levels, 1 launch) -> low-threshold pass (1 launch)
+//   -> compaction straight into host-mapped memory (1 launch) -> [sync #1]
+//   -> host quadtree per level -> H2D of the survivors -> fused angle+blur+BRIEF (1 launch) -> D2H -> [sync #2]
+// i.e. 2 host syncs per frame instead of the reference's 25.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "orb_device.h"
+#include "quadtree.h"
+#include "so_common.h"
+
+using namespace so;
+
+struct so_extractor {
+    so_extractor_config cfg{};
+    float scale[kMaxLevels]{}, inv_scale[kMaxLevels]{}, sigma2[kMaxLevels]{}, inv_sigma2[kMaxLevels]{};
+    int features_per_level[kMaxLevels]{};
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8]{};
+    bool profiling = false;
+    float prof_ms[SO_EXTRACTOR_N_STAGES]{};
+
+    // sized at the first frame
+    bool allocated = false;
+    int width = 0, height = 0;
+    PyramidParams P{};
+    std::vector<void*> dev_allocs;
+    Candidate* d_cands = nullptr;
+    Candidate* h_cands = nullptr;      // host-mapped
+    Candidate* h_cands_dev = nullptr;  // device view of h_cands
+    CandidateHeader* h_header = nullptr;
+    CandidateHeader* h_header_dev = nullptr;
+    int cand_capacity = 0;
+    SelectedKp* h_sel = nullptr;  // pinned
+    SelectedKp* d_sel = nullptr;
+    uint8_t* d_desc = nullptr;   // [cap*32 desc][cap*4 angle] in one allocation
+    uint8_t* h_desc = nullptr;   // pinned mirror
+    int out_capacity = 0;
+
+    KeypointQuadtree qt;
+    std::vector<int> picked;
+    std::vector<int> sel_cand;  // candidate index of each selected keypoint
+};
+
+namespace {
+
+int cv_round(float v) { return (int)lrintf(v); }
+
+// ORBextractor::ORBextractor, code/src/ORBextractor.cc:340-378
+void make_tables(so_extractor* ex) {
+    const int nl = ex->cfg.nlevels;
+    const double sf = (double)ex->cfg.scale_factor;
+    ex->scale[0] = 1.0f;
+    ex->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) {
+        ex->scale[i] = (float)((double)ex->scale[i - 1] * sf);
+        ex->sigma2[i] = ex->scale[i] * ex->scale[i];
+    }
+    for (int i = 0; i < nl; i++) {
+        ex->inv_scale[i] = 1.0f / ex->scale[i];
+        ex->inv_sigma2[i] = 1.0f / ex->sigma2[i];
+    }
+    const float factor = (float)(1.0 / sf);
+    float desired =
+        (float)((double)((float)ex->cfg.nfeatures * (1.0f - factor)) / (1.0 - std::pow((double)factor, (double)nl)));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        ex->features_per_level[l] = cv_round(desired);
+        sum += ex->features_per_level[l];
+        desired *= factor;
+    }
+    ex->features_per_level[nl - 1] = std::max(ex->cfg.nfeatures - sum, 0);
+}
+
+template <typename T>
+int dev_alloc(so_extractor* ex, T** p, size_t bytes, bool zero) {
+    void* q = nullptr;
+    SO_HIP(hipMalloc(&q, bytes));
+    ex->dev_allocs.push_back(q);
+    if (zero) SO_HIP(hipMemsetAsync(q, 0, bytes, ex->stream));
+    *p = reinterpret_cast<T*>(q);
+    return SO_OK;
+}
+
+int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// ComputePyramid's first-frame allocation, code/src/ORBextractor.cc:822-837 (no 19-px border: see orb_device.h)
+int allocate(so_extractor* ex, int w, int h) {
+    PyramidParams& P = ex->P;
+    P.nlevels = ex->cfg.nlevels;
+    P.th_high = ex->cfg.ini_th_fast;
+    P.th_low = ex->cfg.min_th_fast;
+    int tile_base = 0, row_base = 0;
+    for (int l = 0; l < P.nlevels; l++) {
+        LevelDesc& L = P.lv[l];
+        L.w = cv_round((float)w * ex->inv_scale[l]);
+        L.h = cv_round((float)h * ex->inv_scale[l]);
+        if (L.w < 1 || L.h < 1) {
+            last_error_ref() = "image too small for the requested number of pyramid levels";
+            return SO_ERR_INVALID_ARG;
+        }
+        L.pitch = round_up(L.w + 64, 64);
+        const int rw = L.w - 2 * kFastBorder, rh = L.h - 2 * kFastBorder;
+        L.ntx = rw >= 7 ? (rw - 6 + kTile - 1) / kTile : 0;
+        L.nty = rh >= 7 ? (rh - 6 + kTile - 1) / kTile : 0;
+        if (L.ntx == 0 || L.nty == 0) L.ntx = L.nty = 0;
+        L.spitch = round_up(L.ntx * kTile + 8, 64);
+        L.tile_base = tile_base;
+        L.row_base = row_base;
+        tile_base += L.ntx * L.nty;
+        row_base += L.nty * kTile;
+        // +4 rows of slack: FAST tiles at the bottom edge clamp rows, the slack only guards dword over-reads
+        int rc = dev_alloc(ex, &L.img, (size_t)L.pitch * (L.h + 4), true);
+        if (rc) return rc;
+        rc = dev_alloc(ex, &L.score, (size_t)L.spitch * (L.nty * kTile + 2) + 64, true);
+        if (rc) return rc;
+        rc = dev_alloc(ex, &L.tileflag, (size_t)L.ntx * L.nty + 64, true);
+        if (rc) return rc;
+        rc = dev_alloc(ex, &L.bitmap, sizeof(uint32_t) * ((size_t)L.ntx * L.nty * kTile + 64), true);
+        if (rc) return rc;
+    }
+    P.total_tiles = tile_base;
+    P.total_rows = row_base;
+
+    ex->cand_capacity = P.nlevels * kFastCap;
+    int rc = dev_alloc(ex, &ex->d_cands, sizeof(Candidate) * (size_t)ex->cand_capacity + 64, true);
+    if (rc) return rc;
+    SO_HIP(hipHostMalloc((void**)&ex->h_cands, sizeof(Candidate) * (size_t)ex->cand_capacity + 64, hipHostMallocMapped));
+    SO_HIP(hipHostGetDevicePointer((void**)&ex->h_cands_dev, ex->h_cands, 0));
+    SO_HIP(hipHostMalloc((void**)&ex->h_header, sizeof(CandidateHeader), hipHostMallocMapped));
+    SO_HIP(hipHostGetDevicePointer((void**)&ex->h_header_dev, ex->h_header, 0));
+    memset(ex->h_header, 0, sizeof(CandidateHeader));
+
+    ex->out_capacity = so_extractor_capacity(ex);
+    SO_HIP(hipHostMalloc((void**)&ex->h_sel, sizeof(SelectedKp) * (size_t)ex->out_capacity, hipHostMallocDefault));
+    rc = dev_alloc(ex, &ex->d_sel, sizeof(SelectedKp) * (size_t)ex->out_capacity, false);
+    if (rc) return rc;
+    rc = dev_alloc(ex, &ex->d_desc, (size_t)ex->out_capacity * 36, false);
+    if (rc) return rc;
+    SO_HIP(hipHostMalloc((void**)&ex->h_desc, (size_t)ex->out_capacity * 36, hipHostMallocDefault));
+    SO_HIP(hipStreamSynchronize(ex->stream));
+    ex->width = w;
+    ex->height = h;
+    ex->allocated = true;
+    return SO_OK;
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int h, int stride, so_keypoint* kps,
+             uint8_t* desc, int capacity, int* n_out) {
+    if (!ex || !n_out) return SO_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (!image || w <= 0 || h <= 0) return SO_OK;  // ORBextractor.cc:750-751
+    if (stride < w || !kps || !desc) return SO_ERR_INVALID_ARG;
+    const double t_begin = now_ms();
+    SO_HIP(hipSetDevice(ex->cfg.device));
+    if (!ex->allocated) {
+        int rc = allocate(ex, w, h);
+        if (rc) return rc;
+    } else if (w != ex->width || h != ex->height) {
+        last_error_ref() = "image size changed between frames";
+        return SO_ERR_SIZE_CHANGED;
+    }
+    if (capacity < ex->out_capacity) return SO_ERR_CAPACITY;
+    PyramidParams& P = ex->P;
+    hipStream_t s = ex->stream;
+    const bool prof = ex->profiling;
+
+    if (prof) SO_HIP(hipEventRecord(ex->ev[0], s));
+    // ComputePyramid, code/src/ORBextractor.cc:837-853
+    SO_HIP(hipMemcpy2DAsync(P.lv[0].img, (size_t)P.lv[0].pitch, image, (size_t)stride, (size_t)w, (size_t)h,
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    for (int l = 1; l < P.nlevels; l++) launch_resize(P.lv[l - 1], P.lv[l], s);
+    if (prof) SO_HIP(hipEventRecord(ex->ev[1], s));
+    // ComputeKeyPointsOctTree, code/src/ORBextractor.cc:691-744 (all levels batched)
+    if (P.total_tiles > 0) {
+        launch_fast_score(P, s);
+        if (prof) SO_HIP(hipEventRecord(ex->ev[2], s));
+        launch_fast_low(P, s);
+        if (prof) SO_HIP(hipEventRecord(ex->ev[3], s));
+        launch_compact(P, ex->d_cands, ex->h_cands_dev, ex->h_header_dev, ex->cand_capacity, s);
+        if (prof) SO_HIP(hipEventRecord(ex->ev[4], s));
+        SO_HIP(hipGetLastError());
+        SO_HIP(hipStreamSynchronize(s));  // sync #1: candidates + header are in host memory now
+    } else {
+        memset(ex->h_header, 0, sizeof(CandidateHeader));
+        SO_HIP(hipStreamSynchronize(s));
+    }
+
+    // DistributeOctTree per level (host), code/src/ORBextractor.cc:725-727
+    const CandidateHeader& H = *ex->h_header;
+    int n = 0;
+    ex->sel_cand.clear();
+    for (int l = 0; l < P.nlevels; l++) {
+        const Candidate* c = ex->h_cands + H.offset[l];
+        const LevelDesc& L = P.lv[l];
+        ex->qt.distribute(c, H.count[l], L.w - 2 * kFastBorder, L.h - 2 * kFastBorder, ex->features_per_level[l],
+                          ex->picked);
+        for (int idx : ex->picked) {
+            if (n >= ex->out_capacity) break;
+            const Candidate& k = c[idx];
+            ex->h_sel[n].x = (int16_t)(k.x + kFastBorder);  // addBorder_kernel, Fast_gpu.cu:461-470
+            ex->h_sel[n].y = (int16_t)(k.y + kFastBorder);
+            ex->h_sel[n].level = (uint16_t)l;
+            ex->h_sel[n].pad = 0;
+            ex->sel_cand.push_back(H.offset[l] + idx);
+            n++;
+        }
+    }
+    if (n > 0) {
+        SO_HIP(hipMemcpyAsync(ex->d_sel, ex->h_sel, sizeof(SelectedKp) * (size_t)n, hipMemcpyHostToDevice, s));
+        if (prof) SO_HIP(hipEventRecord(ex->ev[5], s));
+        float* d_angle = reinterpret_cast<float*>(ex->d_desc + (size_t)ex->out_capacity * 32);
+        launch_describe(P, ex->d_sel, n, ex->d_desc, d_angle, s);
+        if (prof) SO_HIP(hipEventRecord(ex->ev[6], s));
+        SO_HIP(hipGetLastError());
+        SO_HIP(hipMemcpyAsync(ex->h_desc, ex->d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        SO_HIP(hipMemcpyAsync(ex->h_desc + (size_t)ex->out_capacity * 32, d_angle, (size_t)n * 4, hipMemcpyDeviceToHost,
+                              s));
+        SO_HIP(hipStreamSynchronize(s));  // sync #2
+        memcpy(desc, ex->h_desc, (size_t)n * 32);
+        const float* angles = reinterpret_cast<const float*>(ex->h_desc + (size_t)ex->out_capacity * 32);
+        for (int i = 0; i < n; i++) {
+            const SelectedKp& sk = ex->h_sel[i];
+            const Candidate& k = ex->h_cands[ex->sel_cand[(size_t)i]];
+            so_keypoint& o = kps[i];
+            const int l = sk.level;
+            o.x = (float)sk.x;
+            o.y = (float)sk.y;
+            if (l != 0) {  // ORBextractor.cc:808-814
+                o.x *= ex->scale[l];
+                o.y *= ex->scale[l];
+            }
+            o.size = (float)(int)(31.0f * ex->scale[l]);  // PATCH_SIZE*scale passed through an int parameter
+            o.angle = angles[i];
+            o.response = (float)k.score;
+            o.octave = l;
+            o.class_id = -1;
+        }
+    }
+    *n_out = n;
+    if (prof) {
+        float ms = 0.f;
+        for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) ex->prof_ms[i] = 0.f;
+        if (P.total_tiles > 0) {
+            (void)hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1]); ex->prof_ms[0] = ms;
+            (void)hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2]); ex->prof_ms[1] = ms;
+            (void)hipEventElapsedTime(&ms, ex->ev[2], ex->ev[3]); ex->prof_ms[2] = ms;
+            (void)hipEventElapsedTime(&ms, ex->ev[3], ex->ev[4]); ex->prof_ms[3] = ms;
+        }
+        if (n > 0) {
+            (void)hipEventElapsedTime(&ms, ex->ev[5], ex->ev[6]); ex->prof_ms[4] = ms;
+        }
+        ex->prof_ms[5] = (float)(now_ms() - t_begin);
+    }
+    return SO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int so_extractor_create(const so_extractor_config* cfg, so_extractor** out) {
+    if (!cfg || !out) return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->nlevels < 1 || cfg->nlevels > SO_MAX_LEVELS || cfg->nfeatures < 1 || !(cfg->scale_factor > 1.0f) ||
+        cfg->ini_th_fast < cfg->min_th_fast || cfg->min_th_fast < 1 || cfg->ini_th_fast > 254) {
+        last_error_ref() = "bad extractor configuration";
+        return SO_ERR_INVALID_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        last_error_ref() = "no usable HIP device";
+        return SO_ERR_NO_DEVICE;
+    }
+    SO_HIP(hipSetDevice(cfg->device));
+    so_extractor* ex = new so_extractor();
+    ex->cfg = *cfg;
+    make_tables(ex);
+    hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ex;
+        return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
+    }
+    for (auto& v : ex->ev) {
+        e = hipEventCreate(&v);
+        if (e != hipSuccess) {
+            delete ex;
+            return hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+        }
+    }
+    *out = ex;
+    return SO_OK;
+}
+
+void so_extractor_destroy(so_extractor* ex) {
+    if (!ex) return;
+    (void)hipSetDevice(ex->cfg.device);
+    if (ex->stream) (void)hipStreamSynchronize(ex->stream);
+    for (void* p : ex->dev_allocs) (void)hipFree(p);
+    if (ex->h_cands) (void)hipHostFree(ex->h_cands);
+    if (ex->h_header) (void)hipHostFree(ex->h_header);
+    if (ex->h_sel) (void)hipHostFree(ex->h_sel);
+    if (ex->h_desc) (void)hipHostFree(ex->h_desc);
+    for (auto& v : ex->ev)
+        if (v) (void)hipEventDestroy(v);
+    if (ex->stream) (void)hipStreamDestroy(ex->stream);
+    delete ex;
+}
+
+int so_extractor_capacity(const so_extractor* ex) {
+    if (!ex) return 0;
+    return ex->cfg.nfeatures + 3 * ex->cfg.nlevels;
+}
+
+int so_extractor_run(so_extractor* ex, const uint8_t* image, int width, int height, int stride,
+                     so_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out) {
+    return run_impl(ex, image, false, width, height, stride, keypoints, descriptors, capacity, n_out);
+}
+
+int so_extractor_run_device(so_extractor* ex, const uint8_t* d_image, int width, int height, int stride,
+                            so_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out) {
+    return run_impl(ex, d_image, true, width, height, stride, keypoints, descriptors, capacity, n_out);
+}
+
+int so_extractor_tables(const so_extractor* ex, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                        int32_t* features_per_level) {
+    if (!ex) return SO_ERR_INVALID_ARG;
+    for (int l = 0; l < ex->cfg.nlevels; l++) {
+        if (scale) scale[l] = ex->scale[l];
+        if (inv_scale) inv_scale[l] = ex->inv_scale[l];
+        if (sigma2) sigma2[l] = ex->sigma2[l];
+        if (inv_sigma2) inv_sigma2[l] = ex->inv_sigma2[l];
+        if (features_per_level) features_per_level[l] = ex->features_per_level[l];
+    }
+    return SO_OK;
+}
+
+int so_extractor_level_size(const so_extractor* ex, int level, int* w, int* h) {
+    if (!ex || !ex->allocated || level < 0 || level >= ex->cfg.nlevels || !w || !h) return SO_ERR_INVALID_ARG;
+    *w = ex->P.lv[level].w;
+    *h = ex->P.lv[level].h;
+    return SO_OK;
+}
+
+int so_extractor_get_level(so_extractor* ex, int level, uint8_t* out, int out_bytes) {
+    if (!ex || !ex->allocated || level < 0 || level >= ex->cfg.nlevels || !out) return SO_ERR_INVALID_ARG;
+    const LevelDesc& L = ex->P.lv[level];
+    if (out_bytes < L.w * L.h) return SO_ERR_CAPACITY;
+    SO_HIP(hipSetDevice(ex->cfg.device));
+    SO_HIP(hipMemcpy2DAsync(out, (size_t)L.w, L.img, (size_t)L.pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost,
+                            ex->stream));
+    SO_HIP(hipStreamSynchronize(ex->stream));
+    return SO_OK;
+}
+
+int so_extractor_get_candidates(so_extractor* ex, int level, int16_t* xs, int16_t* ys, uint8_t* scores, int capacity,
+                                int* n_out) {
+    if (!ex || !ex->allocated || level < 0 || level >= ex->cfg.nlevels || !n_out) return SO_ERR_INVALID_ARG;
+    const CandidateHeader& H = *ex->h_header;
+    const int n = H.count[level];
+    *n_out = n;
+    if (capacity < n) return SO_ERR_CAPACITY;
+    const Candidate* c = ex->h_cands + H.offset[level];
+    for (int i = 0; i < n; i++) {
+        if (xs) xs[i] = c[i].x;
+        if (ys) ys[i] = c[i].y;
+        if (scores) scores[i] = (uint8_t)c[i].score;
+    }
+    return SO_OK;
+}
+
+int so_extractor_set_profiling(so_extractor* ex, int enabled) {
+    if (!ex) return SO_ERR_INVALID_ARG;
+    ex->profiling = enabled != 0;
+    return SO_OK;
+}
+
+int so_extractor_get_profile(so_extractor* ex, float* ms) {
+    if (!ex || !ms) return SO_ERR_INVALID_ARG;
+    for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) ms[i] = ex->prof_ms[i];
+    return SO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// orb_device.h — device-side data layout shared by the ORB front-end kernels and their host driver.
+//
+// HBM layout (one so_extractor = one agent's front-end context; everything is allocated once at the
+// first frame and stays resident):
+//   level l image     u8   h_l rows x pitch_l bytes, pitch_l = round_up(w_l + 64, 64), base 256-B aligned
+//                          (un-blurred; the 19-px reflect-101 border the reference materialises is never
+//                          read by FAST / angle / BRIEF — the blur applies reflect-101 by index instead)
+//   level l score map u8   (nty_l*32 + 2) rows x spitch_l bytes; pixel ROI(3+c, 3+r) lives at
+//                          [(r+1)*spitch + 4 + c]; a zero frame (1 row top/bottom, 4 cols left, >=1 right)
+//                          lets the low-threshold pass read neighbours without bounds checks
+//   level l tile flag u8   nty_l x ntx_l  "tile kept a corner at the high threshold"
+//   level l keep bitmap u32 (nty_l*32) rows x ntx_l words, bit c of word (row, tx) = ROI pixel
+//                          (3 + 32*tx + c, 3 + row) survived NMS
+//   candidates        8 B records {i16 x, i16 y, u16 score, u16 level}, levels concatenated, raster order
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace so {
+
+constexpr int kMaxLevels = 8;
+constexpr int kFastBorder = 16;  // ROI origin inside a level (EDGE_THRESHOLD-3, ORBextractor.cc:695)
+constexpr int kTile = 32;        // tileCalcKeypoints_kernel tile (Fast_gpu.cu:373-374)
+constexpr int kFastCap = 10000;  // per-level candidate cap (Fast.hpp:32)
+constexpr int kScoreXOff = 4;    // left zero frame of the score map (keeps dword stores aligned)
+
+struct LevelDesc {
+    uint8_t* img;       // level image
+    uint8_t* score;     // score map (see layout above)
+    uint8_t* tileflag;  // nty*ntx
+    uint32_t* bitmap;   // (nty*32)*ntx
+    int w, h, pitch;
+    int spitch;
+    int ntx, nty;
+    int tile_base;  // first global tile index of this level
+    int row_base;   // first global bitmap row of this level
+};
+
+struct PyramidParams {
+    LevelDesc lv[kMaxLevels];
+    int nlevels;
+    int total_tiles;
+    int total_rows;
+    int th_high, th_low;
+};
+
+struct Candidate {  // 8 bytes
+    int16_t x, y;   // ROI-relative, like GpuFast's kpLoc (Fast_gpu.cu:303,309)
+    uint16_t score;
+    uint16_t level;
+};
+
+struct CandidateHeader {  // written to host-mapped memory by the compaction kernel
+    int32_t count[kMaxLevels];   // per level, capped at kFastCap
+    int32_t offset[kMaxLevels];  // start of the level inside the record array
+    int32_t total;
+    int32_t uncapped_total;
+    int32_t pad[2];
+};
+
+struct SelectedKp {  // host -> device after the quadtree: level coordinates (ROI + 16)
+    int16_t x, y;
+    uint16_t level;
+    uint16_t pad;
+};
+
+// launchers (orb_kernels.hip)
+void launch_resize(const LevelDesc& src, const LevelDesc& dst, hipStream_t s);
+void launch_fast_score(const PyramidParams& p, hipStream_t s);
+void launch_fast_low(const PyramidParams& p, hipStream_t s);
+void launch_compact(const PyramidParams& p, Candidate* d_cands, Candidate* h_cands_mapped,
+                    CandidateHeader* h_header_mapped, int cand_capacity, hipStream_t s);
+void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,
+                     hipStream_t s);
+
+}  // namespace so

@@ -1,0 +1,527 @@
+// orb_kernels.hip — gfx950 kernels of the ORB front-end (pyramid, FAST-9/16 + NMS, candidate compaction,
+// fused orientation + Gaussian + rBRIEF).  Written for CDNA4: 64-lane waves, LDS-staged tiles, ballot
+// compaction, all pyramid levels batched into one launch per stage.
+//
+// Built with -ffp-contract=off: the float stages (bilinear resize, separable Gaussian, BRIEF rotation) are
+// defined without implicit FMA so results are bit-identical to the CPU oracle; explicit __builtin_fmaf is
+// used where a fused op is part of the definition (polynomial atan2 / sincos).
+//
+// Reference behaviour followed (files under /root/reference/code):
+//   src/cuda/Fast_gpu.cu:63-341   FAST ring layout, corner score, 32x32 tiles with threshold fallback, NMS
+//   src/cuda/Fast_gpu.cu:402-470  intensity-centroid angle, addBorder
+//   src/cuda/Orb_gpu.cu:63-100    steered BRIEF
+//   src/ORBextractor.cc:821-855   pyramid (level l from level l-1), Gaussian 7x7 sigma 2
+#include "orb_device.h"
+
+namespace so {
+
+// ------------------------------------------------------------------------------------------------
+// pyramid: INTER_LINEAR in the OpenCV-CUDA convention (src = dst * (1/f), floor, 4 float taps, rn)
+// one thread = 4 horizontally adjacent destination pixels = one aligned dword store
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
+                                                      uint8_t* __restrict__ dst, int dw, int dh, int dpitch,
+                                                      float fx, float fy) {
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= dw || y >= dh) return;
+    const float src_y = (float)y * fy;
+    const int y1 = (int)floorf(src_y);
+    const int y2 = y1 + 1;
+    const int y2r = min(y2, sh - 1);
+    const float wy2 = (float)y2 - src_y;
+    const float wy1 = src_y - (float)y1;
+    const uint8_t* r1 = src + (size_t)y1 * spitch;
+    const uint8_t* r2 = src + (size_t)y2r * spitch;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x4 + k;
+        const float src_x = (float)x * fx;
+        int x1 = (int)floorf(src_x);
+        x1 = min(x1, sw - 1);  // only reachable for the padding lanes x >= dw
+        const int x2 = x1 + 1;
+        const int x2r = min(x2, sw - 1);
+        const float wx2 = (float)x2 - src_x;
+        const float wx1 = src_x - (float)x1;
+        float out = (float)r1[x1] * (wx2 * wy2);
+        out = out + (float)r1[x2r] * (wx1 * wy2);
+        out = out + (float)r2[x1] * (wx2 * wy1);
+        out = out + (float)r2[x2r] * (wx1 * wy1);
+        int v = (int)__builtin_rintf(out);
+        v = min(max(v, 0), 255);
+        packed |= (uint32_t)v << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * dpitch + x4) = packed;
+}
+
+void launch_resize(const LevelDesc& s, const LevelDesc& d, hipStream_t st) {
+    const float fx = (float)(1.0 / ((double)d.w / (double)s.w));
+    const float fy = (float)(1.0 / ((double)d.h / (double)s.h));
+    dim3 block(64, 4);
+    dim3 grid((d.w + 255) / 256, (d.h + 3) / 4);
+    hipLaunchKernelGGL(resize_kernel, grid, block, 0, st, s.img, s.w, s.h, s.pitch, d.img, d.w, d.h, d.pitch, fx,
+                       fy);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
+
+// Largest threshold t at which the pixel is still a FAST-9 corner (== cornerScore's binary search,
+// Fast_gpu.cu:195-218), from the 16 ring differences d[k] = ring[k] - centre:
+//   bright run: all 9 consecutive d > t  <=>  t < min over the run   -> max over runs of (min) - 1
+//   dark   run: all 9 consecutive d < -t <=>  t < min over run of -d -> -(min over runs of (max)) - 1
+__device__ __forceinline__ int fast_corner_score(const int (&d)[16]) {
+    int mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        mx3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    }
+    int best_b = -1000, best_d = 1000;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        best_b = max(best_b, min3i(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
+        best_d = min(best_d, max3i(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
+    }
+    return max(best_b, -best_d) - 1;
+}
+
+__device__ __forceinline__ int find_level_by_tile(const PyramidParams& P, int tile) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; i++)
+        if (i < P.nlevels && tile >= P.lv[i].tile_base) l = i;
+    return l;
+}
+
+constexpr int kImgRows = 40, kImgPitchW = 12;  // 40 x 48-byte LDS image tile (dword granularity)
+constexpr int kScRows = 34, kScPitch = 36;     // 34 x 34 scores (tile + 1-px halo)
+
+// One workgroup (4 waves) per 32x32 tile of one pyramid level; all levels in one launch.
+// Stage the 40x40 neighbourhood in LDS with aligned dword loads, score the 34x34 halo'd tile, NMS at the
+// high threshold inside LDS (halo scores are recomputed here, which removes the reference's cross-block
+// race on scoreMat), write the u8 score tile + tile flag + keep-bitmap words.
+__global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
+    __shared__ uint32_t simg32[kImgRows * kImgPitchW];
+    __shared__ uint8_t ssc[kScRows * kScPitch];
+    const uint8_t* simg = reinterpret_cast<const uint8_t*>(simg32);
+
+    const int tid = threadIdx.x;
+    const int lvl = find_level_by_tile(P, blockIdx.x);
+    const LevelDesc& L = P.lv[lvl];
+    const int t = blockIdx.x - L.tile_base;
+    const int ty = t / L.ntx, tx = t - ty * L.ntx;
+    const int x0 = 19 + kTile * tx, y0 = 19 + kTile * ty;  // tile origin in level coordinates
+    const int ax = 12 + kTile * tx;                         // (x0 - 4) rounded down to a dword
+
+    for (int i = tid; i < kImgRows * kImgPitchW; i += 256) {
+        const int r = i / kImgPitchW, dc = i - r * kImgPitchW;
+        const int gy = min(y0 - 4 + r, L.h - 1);
+        simg32[i] = *reinterpret_cast<const uint32_t*>(L.img + (size_t)gy * L.pitch + ax + 4 * dc);
+    }
+    __syncthreads();
+
+    const int th_low = P.th_low, th_high = P.th_high;
+    for (int p = tid; p < kScRows * kScRows; p += 256) {
+        const int r = p / kScRows, c = p - r * kScRows;
+        const int x = x0 - 1 + c, y = y0 - 1 + r;
+        int score = 0;
+        if (x >= 19 && x < L.w - 19 && y >= 19 && y < L.h - 19) {
+            const uint8_t* ctr = simg + (r + 3) * (kImgPitchW * 4) + (c + 6);
+            constexpr int PW = kImgPitchW * 4;
+            const int v = ctr[0];
+            int d[16];
+            d[0] = ctr[3 * PW + 0] - v;   d[1] = ctr[3 * PW + 1] - v;   d[2] = ctr[2 * PW + 2] - v;
+            d[3] = ctr[1 * PW + 3] - v;   d[4] = ctr[3] - v;            d[5] = ctr[-1 * PW + 3] - v;
+            d[6] = ctr[-2 * PW + 2] - v;  d[7] = ctr[-3 * PW + 1] - v;  d[8] = ctr[-3 * PW + 0] - v;
+            d[9] = ctr[-3 * PW - 1] - v;  d[10] = ctr[-2 * PW - 2] - v; d[11] = ctr[-1 * PW - 3] - v;
+            d[12] = ctr[-3] - v;          d[13] = ctr[1 * PW - 3] - v;  d[14] = ctr[2 * PW - 2] - v;
+            d[15] = ctr[3 * PW - 1] - v;
+            const int s = fast_corner_score(d);
+            score = s >= th_low ? s : 0;
+        }
+        ssc[r * kScPitch + c] = (uint8_t)score;
+    }
+    __syncthreads();
+
+    // NMS at the high threshold: each wave covers two tile rows per round -> one ballot = two bitmap words
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long keep[4];
+    int any = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int row = 8 * k + 2 * wave + (lane >> 5), col = lane & 31;
+        const uint8_t* q = ssc + (row + 1) * kScPitch + (col + 1);
+        const int s = q[0];
+        const int m = max(max(max((int)q[-kScPitch - 1], (int)q[-kScPitch]), max((int)q[-kScPitch + 1], (int)q[-1])),
+                          max(max((int)q[1], (int)q[kScPitch - 1]), max((int)q[kScPitch], (int)q[kScPitch + 1])));
+        const bool kp = (s >= th_high) && (s > m);
+        keep[k] = __ballot(kp);
+        any |= (keep[k] != 0ull);
+    }
+    const int has1 = __syncthreads_or(any);
+
+    // u8 score tile -> global (aligned dword per thread)
+    {
+        const int row = tid >> 3, c4 = (tid & 7) * 4;
+        const uint8_t* q = ssc + (row + 1) * kScPitch + (c4 + 1);
+        const uint32_t v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        *reinterpret_cast<uint32_t*>(L.score + (size_t)(ty * kTile + row + 1) * L.spitch + kScoreXOff + tx * kTile +
+                                     c4) = v;
+    }
+    if (tid == 0) L.tileflag[t] = (uint8_t)has1;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int row = 8 * k + 2 * wave;
+            uint32_t* b = L.bitmap + (size_t)(ty * kTile + row) * L.ntx + tx;
+            b[0] = has1 ? (uint32_t)keep[k] : 0u;
+            b[L.ntx] = has1 ? (uint32_t)(keep[k] >> 32) : 0u;
+        }
+    }
+}
+
+// Low-threshold pass for the tiles that kept nothing at the high threshold (Fast_gpu.cu:317-339),
+// with the deterministic neighbour rule of the oracle: a neighbour in a non-empty tile competes with
+// its high-threshold score, a neighbour in an empty tile with its low-threshold score.
+__global__ __launch_bounds__(256) void fast_low_kernel(PyramidParams P) {
+    __shared__ uint8_t ssc[kScRows * kScPitch];
+    const int tid = threadIdx.x;
+    const int lvl = find_level_by_tile(P, blockIdx.x);
+    const LevelDesc& L = P.lv[lvl];
+    const int t = blockIdx.x - L.tile_base;
+    if (L.tileflag[t]) return;  // uniform
+    const int ty = t / L.ntx, tx = t - ty * L.ntx;
+    const int th_high = P.th_high;
+
+    for (int p = tid; p < kScRows * kScRows; p += 256) {
+        const int r = p / kScRows, c = p - r * kScRows;
+        int s = L.score[(size_t)(ty * kTile + r) * L.spitch + tx * kTile + c + (kScoreXOff - 1)];
+        const int tyq = ty + (r == 0 ? -1 : (r == kScRows - 1 ? 1 : 0));
+        const int txq = tx + (c == 0 ? -1 : (c == kScRows - 1 ? 1 : 0));
+        if (tyq >= 0 && tyq < L.nty && txq >= 0 && txq < L.ntx) {
+            if (L.tileflag[tyq * L.ntx + txq] && s < th_high) s = 0;
+        }
+        ssc[r * kScPitch + c] = (uint8_t)s;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int row = 8 * k + 2 * wave + (lane >> 5), col = lane & 31;
+        const uint8_t* q = ssc + (row + 1) * kScPitch + (col + 1);
+        const int s = q[0];
+        const int m = max(max(max((int)q[-kScPitch - 1], (int)q[-kScPitch]), max((int)q[-kScPitch + 1], (int)q[-1])),
+                          max(max((int)q[1], (int)q[kScPitch - 1]), max((int)q[kScPitch], (int)q[kScPitch + 1])));
+        const unsigned long long keep = __ballot(s > 0 && s > m);
+        if (lane == 0) {
+            uint32_t* b = L.bitmap + (size_t)(ty * kTile + 8 * k + 2 * wave) * L.ntx + tx;
+            b[0] = (uint32_t)keep;
+            b[L.ntx] = (uint32_t)(keep >> 32);
+        }
+    }
+}
+
+void launch_fast_score(const PyramidParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(fast_score_kernel, dim3(p.total_tiles), dim3(256), 0, s, p);
+}
+void launch_fast_low(const PyramidParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(fast_low_kernel, dim3(p.total_tiles), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Candidate compaction: keep-bitmaps of all levels -> records in (level, y, x) raster order, per-level
+// cap of 10000 (first in raster order), written to host-mapped memory in one coalesced sweep.
+// Single workgroup of 1024 threads: thread t owns a contiguous chunk of bitmap rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCompactThreads = 1024;
+
+__global__ __launch_bounds__(kCompactThreads) void compact_kernel(PyramidParams P, Candidate* __restrict__ d_cands,
+                                                                   Candidate* __restrict__ h_cands,
+                                                                   CandidateHeader* __restrict__ h_header,
+                                                                   int cand_capacity) {
+    __shared__ int s_wave[16];
+    __shared__ int s_lvl_start[kMaxLevels + 1];  // exclusive prefix at the first row of each level
+    __shared__ int s_lvl_out[kMaxLevels + 1];    // output offset of each level after capping
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = P.total_rows;
+    const int rpt = (R + kCompactThreads - 1) / kCompactThreads;
+    const int g0 = min(tid * rpt, R), g1 = min(g0 + rpt, R);
+
+    // pass 1: popcount my rows
+    int mine = 0;
+    for (int g = g0; g < g1; g++) {
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < kMaxLevels; i++)
+            if (i < P.nlevels && g >= P.lv[i].row_base) l = i;
+        const LevelDesc& L = P.lv[l];
+        const uint32_t* b = L.bitmap + (size_t)(g - L.row_base) * L.ntx;
+        for (int w = 0; w < L.ntx; w++) mine += __popc(b[w]);
+    }
+    // block exclusive scan of `mine`
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int v = lane < 16 ? s_wave[lane] : 0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int u = __shfl_up(v, off);
+            if (lane >= off) v += u;
+        }
+        if (lane < 16) s_wave[lane] = v;  // inclusive over waves
+    }
+    __syncthreads();
+    const int excl = incl - mine + (wave > 0 ? s_wave[wave - 1] : 0);
+    const int total = s_wave[15];
+
+    // level starts: the thread that owns the first row of a level publishes the prefix at that row
+    {
+        int run = excl;
+        for (int g = g0; g < g1; g++) {
+            int l = 0;
+#pragma unroll
+            for (int i = 1; i < kMaxLevels; i++)
+                if (i < P.nlevels && g >= P.lv[i].row_base) l = i;
+            const LevelDesc& L = P.lv[l];
+            if (g == L.row_base) s_lvl_start[l] = run;
+            const uint32_t* b = L.bitmap + (size_t)(g - L.row_base) * L.ntx;
+            for (int w = 0; w < L.ntx; w++) run += __popc(b[w]);
+        }
+    }
+    if (tid == 0) s_lvl_start[P.nlevels] = total;
+    __syncthreads();
+    if (tid == 0) {
+        for (int l = P.nlevels - 1; l >= 0; l--)  // a level too small to hold a FAST tile owns no rows
+            if (P.lv[l].nty == 0) s_lvl_start[l] = s_lvl_start[l + 1];
+        int off = 0;
+        for (int l = 0; l < P.nlevels; l++) {
+            const int cnt = min(s_lvl_start[l + 1] - s_lvl_start[l], kFastCap);
+            s_lvl_out[l] = off;
+            h_header->count[l] = cnt;
+            h_header->offset[l] = off;
+            off += cnt;
+        }
+        for (int l = P.nlevels; l < kMaxLevels; l++) {
+            h_header->count[l] = 0;
+            h_header->offset[l] = off;
+        }
+        s_lvl_out[P.nlevels] = off;
+        h_header->total = off;
+        h_header->uncapped_total = total;
+    }
+    __syncthreads();
+
+    // pass 2: emit my rows
+    {
+        int run = excl;
+        for (int g = g0; g < g1; g++) {
+            int l = 0;
+#pragma unroll
+            for (int i = 1; i < kMaxLevels; i++)
+                if (i < P.nlevels && g >= P.lv[i].row_base) l = i;
+            const LevelDesc& L = P.lv[l];
+            const int lr = g - L.row_base;
+            const uint32_t* b = L.bitmap + (size_t)lr * L.ntx;
+            const uint8_t* srow = L.score + (size_t)(lr + 1) * L.spitch + kScoreXOff;
+            for (int w = 0; w < L.ntx; w++) {
+                uint32_t word = b[w];
+                while (word) {
+                    const int bit = __ffs(word) - 1;
+                    word &= word - 1;
+                    const int rank = run - s_lvl_start[l];
+                    if (rank < kFastCap) {
+                        const int o = s_lvl_out[l] + rank;
+                        if (o < cand_capacity) {
+                            Candidate c;
+                            c.x = (int16_t)(3 + 32 * w + bit);
+                            c.y = (int16_t)(3 + lr);
+                            c.score = srow[32 * w + bit];
+                            c.level = (uint16_t)l;
+                            d_cands[o] = c;
+                        }
+                    }
+                    run++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // coalesced sweep device -> host-mapped (16 B per lane)
+    const int n_out = min(s_lvl_out[P.nlevels], cand_capacity);
+    const int n16 = (n_out + 1) / 2;
+    const uint4* src = reinterpret_cast<const uint4*>(d_cands);
+    uint4* dst = reinterpret_cast<uint4*>(h_cands);
+    for (int i = tid; i < n16; i += kCompactThreads) dst[i] = src[i];
+}
+
+void launch_compact(const PyramidParams& p, Candidate* d_cands, Candidate* h_cands, CandidateHeader* h_header,
+                    int cand_capacity, hipStream_t s) {
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(kCompactThreads), 0, s, p, d_cands, h_cands, h_header,
+                       cand_capacity);
+}
+
+// ------------------------------------------------------------------------------------------------
+// describe: orientation + 7x7 Gaussian + steered BRIEF fused, one wave per keypoint.
+// The 43x43 source patch (radius 18 samples + 3 blur taps, reflect-101 at the image edge) is staged in LDS
+// once; the blur is evaluated only on the 37x37 window BRIEF can reach, so the full-frame blur pass and its
+// HBM round trip disappear.  256 tests = 4 ballots of 64 lanes -> the four 64-bit descriptor words.
+// ------------------------------------------------------------------------------------------------
+__constant__ int8_t c_pattern[1024] = {
+#include "brief_pattern.inc"
+};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+__constant__ float c_gauss7[7] = {0x1.1f5f62p-4f, 0x1.0c70fcp-3f, 0x1.869472p-3f, 0x1.ba95c0p-3f,
+                                  0x1.869472p-3f, 0x1.0c70fcp-3f, 0x1.1f5f62p-4f};
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * (n - 1) - p;
+    return p;
+}
+
+// deterministic atan2 / sincos (same polynomials as the oracle; only +,*,/,fma -> bit-identical)
+__device__ __forceinline__ float det_atan2f(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    if (mx == 0.f) return 0.f;
+    const float a = mn / mx;
+    const float s = a * a;
+    float p = 0.0028340641874819994f;
+    p = __builtin_fmaf(p, s, -0.016005029901862144f);
+    p = __builtin_fmaf(p, s, 0.042587608098983765f);
+    p = __builtin_fmaf(p, s, -0.07495445758104324f);
+    p = __builtin_fmaf(p, s, 0.10636754333972931f);
+    p = __builtin_fmaf(p, s, -0.14202570915222168f);
+    p = __builtin_fmaf(p, s, 0.19992484152317047f);
+    p = __builtin_fmaf(p, s, -0.3333306610584259f);
+    p = __builtin_fmaf(p, s, 1.0f);
+    float r = a * p;
+    if (ay > ax) r = 0x1.921fb6p+0f - r;
+    if (x < 0.f) r = 0x1.921fb6p+1f - r;
+    if (y < 0.f) r = -r;
+    return r;
+}
+
+__device__ __forceinline__ void det_sincosf(float a, float& sn, float& cs) {
+    const float k = __builtin_rintf(a * 0x1.45f306p-1f);
+    float r = __builtin_fmaf(-k, 0x1.921fb6p+0f, a);
+    r = __builtin_fmaf(-k, -0x1.777a5cp-25f, r);
+    const float s = r * r;
+    float ps = 2.716587005124893e-06f;
+    ps = __builtin_fmaf(ps, s, -0.0001983911934075877f);
+    ps = __builtin_fmaf(ps, s, 0.008333328180015087f);
+    ps = __builtin_fmaf(ps, s, -0.1666666716337204f);
+    ps = __builtin_fmaf(ps, s, 1.0f);
+    const float sinr = r * ps;
+    float pc = 2.4371513063670136e-05f;
+    pc = __builtin_fmaf(pc, s, -0.001388652715831995f);
+    pc = __builtin_fmaf(pc, s, 0.04166661202907562f);
+    pc = __builtin_fmaf(pc, s, -0.5f);
+    pc = __builtin_fmaf(pc, s, 1.0f);
+    const float cosr = pc;
+    const int q = ((int)k) & 3;
+    sn = (q == 0) ? sinr : (q == 1) ? cosr : (q == 2) ? -sinr : -cosr;
+    cs = (q == 0) ? cosr : (q == 1) ? -sinr : (q == 2) ? -cosr : sinr;
+}
+
+constexpr int kPatch = 43, kPatchPitch = 44;  // source patch
+constexpr int kBlur = 37, kBlurPitch = 40;    // blurred window
+
+__global__ __launch_bounds__(64) void describe_kernel(PyramidParams P, const SelectedKp* __restrict__ sel, int n,
+                                                       uint8_t* __restrict__ desc, float* __restrict__ angle_out) {
+    __shared__ uint8_t patch[kPatch * kPatchPitch];
+    __shared__ float rowp[kPatch * kBlur];
+    __shared__ uint8_t blur[kBlur * kBlurPitch];
+    const int id = blockIdx.x;
+    if (id >= n) return;
+    const int lane = threadIdx.x;
+    const SelectedKp kp = sel[id];
+    const LevelDesc& L = P.lv[kp.level];
+    const int x = kp.x, y = kp.y;
+
+    for (int i = lane; i < kPatch * kPatch; i += 64) {
+        const int r = i / kPatch, c = i - r * kPatch;
+        const int gy = reflect101(y - 21 + r, L.h), gx = reflect101(x - 21 + c, L.w);
+        patch[r * kPatchPitch + c] = L.img[(size_t)gy * L.pitch + gx];
+    }
+    __syncthreads();
+
+    // intensity centroid over the radius-15 disc (749 px), integer moments
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int r = i / 31, c = i - r * 31;
+        const int v = r - 15, u = c - 15;
+        if (abs(u) <= c_umax[abs(v)]) {
+            const int val = patch[(21 + v) * kPatchPitch + 21 + u];
+            m10 += u * val;
+            m01 += v * val;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        m10 += __shfl_xor(m10, off);
+        m01 += __shfl_xor(m01, off);
+    }
+    float kp_dir = det_atan2f((float)m01, (float)m10);
+    kp_dir += (float)(kp_dir < 0) * 0x1.921fb6p+2f;
+    kp_dir *= 0x1.ca5dcp+5f;
+
+    // separable Gaussian: row pass (float), column pass, round-half-even
+    for (int i = lane; i < kPatch * kBlur; i += 64) {
+        const int r = i / kBlur, c = i - r * kBlur;
+        const uint8_t* q = patch + r * kPatchPitch + c;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; k++) sum = sum + (float)q[k] * c_gauss7[k];
+        rowp[i] = sum;
+    }
+    __syncthreads();
+    for (int i = lane; i < kBlur * kBlur; i += 64) {
+        const int r = i / kBlur, c = i - r * kBlur;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; k++) sum = sum + rowp[(r + k) * kBlur + c] * c_gauss7[k];
+        int v = (int)__builtin_rintf(sum);
+        blur[r * kBlurPitch + c] = (uint8_t)min(max(v, 0), 255);
+    }
+    __syncthreads();
+
+    float a, b;  // a = cos, b = sin  (Orb_gpu.cu:77-79)
+    det_sincosf(kp_dir * 0x1.1df46ap-6f, b, a);
+    unsigned long long words[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int bit = lane + 64 * q;
+        const int8_t* pp = c_pattern + bit * 4;
+        const float p0x = (float)pp[0], p0y = (float)pp[1], p1x = (float)pp[2], p1y = (float)pp[3];
+        const int r0 = (int)__builtin_rintf(p0x * b + p0y * a), c0 = (int)__builtin_rintf(p0x * a - p0y * b);
+        const int r1 = (int)__builtin_rintf(p1x * b + p1y * a), c1 = (int)__builtin_rintf(p1x * a - p1y * b);
+        const int t0 = blur[(18 + r0) * kBlurPitch + 18 + c0];
+        const int t1 = blur[(18 + r1) * kBlurPitch + 18 + c1];
+        words[q] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(desc + (size_t)id * 32);
+        o[0] = words[0]; o[1] = words[1]; o[2] = words[2]; o[3] = words[3];
+        angle_out[id] = kp_dir;
+    }
+}
+
+void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,
+                     hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(describe_kernel, dim3(n), dim3(64), 0, s, p, d_sel, n, d_desc, d_angle);
+}
+
+}  // namespace so

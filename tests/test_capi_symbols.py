@@ -1,0 +1,48 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/swarmorb.h declares, and
+fails loudly (no CPU fallback) when asked to compute without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "swarmorb.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(so_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_declares_entry_points():
+    syms = _declared_symbols()
+    for must in ("so_extractor_create", "so_extractor_run", "so_extractor_run_device", "so_extractor_destroy",
+                 "so_extractor_tables", "so_status_string", "so_device_count"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import swarmmap_amd
+    lib = ctypes.CDLL(swarmmap_amd.library_path())
+    missing = [s for s in _declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_gpu():
+    import swarmmap_amd
+    if swarmmap_amd.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(swarmmap_amd.SwarmOrbError):
+        swarmmap_amd.ORBextractor(1000, 1.2, 8, 20, 7)
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never reach into oracle/ (it is test infrastructure)."""
+    pkg = os.path.join(ROOT, "swarmmap_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".cc")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_py" not in txt and "liboracle" not in txt and "orb_oracle" not in txt, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
