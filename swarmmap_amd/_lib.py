@@ -44,6 +44,14 @@ def load_library():
         raise SwarmOrbError(
             "libswarmorb.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C swarmmap_amd/csrc`. There is no CPU fallback." % path)
+    # One HIP/HSA runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 + libhsa-runtime64.so.
+    # If /opt/rocm's copy were loaded first, torch would later bring up a second HSA runtime and see no GPU.
+    # Importing torch first makes the dynamic loader bind our DT_NEEDED libamdhip64.so.7 to torch's copy.
+    if os.environ.get("SWARMORB_STANDALONE_HIP", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch absent: use /opt/rocm's runtime
+            pass
     lib = C.CDLL(path)
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
     lib.so_status_string.restype = C.c_char_p
