@@ -99,6 +99,80 @@ int so_extractor_get_candidates(so_extractor* ex, int level, int16_t* xs, int16_
 int so_extractor_set_profiling(so_extractor* ex, int enabled);
 int so_extractor_get_profile(so_extractor* ex, float* ms_per_stage /* [SO_EXTRACTOR_N_STAGES] */);
 
+/* ------------------------------------------------------------------------------------------------
+ * Hamming matcher — replaces the data-parallel part of ORB_SLAM2::ORBmatcher (code/include/ORBmatcher.h:41-83,
+ * code/src/ORBmatcher.cc) for the tracking thread: candidate gathering (Frame::GetFeaturesInArea,
+ * code/src/Frame.cc:377-431), DescriptorDistance (ORBmatcher.cc:1511-1525) and best/second selection run
+ * on the GPU for ALL queries of a call at once; the order-dependent greedy resolve, ratio tests and the
+ * rotation histogram (ComputeThreeMaxima, ORBmatcher.cc:1475-1506) run on the host inside the library,
+ * exactly in the reference's order.  Monocular only (mvuRight < 0), as every SwarmMap binary is.
+ * Object-graph side effects (F.mvpMapPoints[idx] = pMP ...) stay in the caller's adapter.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct so_matcher so_matcher;
+
+/* The parts of ORB_SLAM2::Frame the matcher reads (code/include/Frame.h), flattened. */
+typedef struct {
+    int32_t n;               /* N */
+    const float* x;          /* mvKeysUn[i].pt.x */
+    const float* y;          /* mvKeysUn[i].pt.y */
+    const int32_t* octave;   /* mvKeysUn[i].octave */
+    const float* angle;      /* mvKeysUn[i].angle (degrees); may be NULL when orientation is not checked */
+    const uint8_t* desc;     /* mDescriptors, n x 32 */
+    const uint8_t* excluded; /* 1 iff mvpMapPoints[i] && mvpMapPoints[i]->Observations() > 0 on entry; may be NULL */
+    float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+    float grid_inv_w, grid_inv_h;     /* mfGridElementWidthInv, mfGridElementHeightInv */
+    const float* scale_factors;       /* mvScaleFactors */
+    int32_t nlevels;
+} so_frame_view;
+
+int so_matcher_create(int device, so_matcher** out);
+void so_matcher_destroy(so_matcher* m);
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) — code/src/ORBmatcher.cc:44-121.
+ * in_view[i] = pMP->mbTrackInView && !pMP->isBad(); proj_x/proj_y/view_cos/pred_level = mTrackProjX/Y,
+ * mTrackViewCos, mnTrackScaleLevel; mp_desc = GetDescriptor() (n_mp x 32); mp_has_obs[i] = Observations() > 0.
+ * nn_ratio = mfNNratio.  Out: kp_to_mp[k] = map point bound to keypoint k by this call, or -1. */
+int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int32_t n_mp, const uint8_t* in_view,
+                                      const float* proj_x, const float* proj_y, const float* view_cos,
+                                      const int32_t* pred_level, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                                      float th, float nn_ratio, int32_t* kp_to_mp, int32_t* nmatches);
+
+/* ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono=true) — ORBmatcher.cc:1223-1354,
+ * from the projection onwards: valid[i] = pMP && !mvbOutlier[i] && invzc >= 0 && (u,v) inside the bounds.
+ * Out: kp_to_last[k] = index in the last frame whose map point is bound to keypoint k, or -1. */
+int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, int32_t n_last, const uint8_t* valid,
+                                      const float* u, const float* v, const int32_t* last_octave,
+                                      const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                                      float th, int check_orientation, int32_t* kp_to_last, int32_t* nmatches);
+
+/* ORBmatcher::SearchForInitialization — ORBmatcher.cc:375-479.  prev_matched: n1 x 2 floats (vbPrevMatched),
+ * updated in place; matches12: n1 ints (vnMatches12). */
+int so_search_for_initialization(so_matcher* m, const so_frame_view* F1, const so_frame_view* F2,
+                                 float* prev_matched, int window, float nn_ratio, int check_orientation,
+                                 int32_t* matches12, int32_t* nmatches);
+
+/* Building block exposed for the other matcher routines and for tests: for every query the K best
+ * candidates of `F` inside the GetFeaturesInArea window (u,v,r,[min_level,max_level]), ordered as the
+ * reference's sequential scan would rank them (distance, then grid traversal order).
+ * limit (optional, n ints): candidate k only competes when dist < limit[k] (0 excludes it).
+ * out_idx/out_dist: nq x K (idx -1 / dist 256 padding); out_count: candidates inside each window. */
+int so_matcher_topk(so_matcher* m, const so_frame_view* F, const int32_t* limit, int32_t nq, const float* u,
+                    const float* v, const float* r, const int32_t* min_level, const int32_t* max_level,
+                    const uint8_t* active, const uint8_t* qdesc, int32_t K, int32_t* out_idx, int32_t* out_dist,
+                    int32_t* out_count);
+
+/* Brute-force best / second-best Hamming match of every row of A (na x 32) against all rows of B (nb x 32);
+ * ties go to the lowest index in B.  Used for the cross-agent keyframe search after the RCCL descriptor
+ * all-gather (replaces the BoW candidate query of code/src/AgentMediator.cc:177-191). */
+int so_hamming_top2(so_matcher* m, const uint8_t* A, int32_t na, const uint8_t* B, int32_t nb, int32_t* best_idx,
+                    int32_t* best_dist, int32_t* second_dist);
+/* Same with A and B already in device memory (e.g. the all-gathered descriptor slots). */
+int so_hamming_top2_device(so_matcher* m, const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb,
+                           int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+
+/* HIP-event time (ms) of the kernels of the last matcher call on the matcher's stream. */
+int so_matcher_last_kernel_ms(so_matcher* m, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

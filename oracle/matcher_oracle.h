@@ -1,0 +1,76 @@
+/*
+ * matcher_oracle.h — CPU restatement (parity oracle) of SwarmMap's ORBmatcher tracking routines on
+ * flattened inputs.  TEST INFRASTRUCTURE ONLY (see orb_oracle.h).
+ *
+ * Parity status: integer work, fully determined by the reference source (no third-party arithmetic):
+ * code/src/ORBmatcher.cc + Frame grid helpers code/src/Frame.cc:277-292,377-443.  Pinned by the KATs in
+ * tests/test_matcher_oracle.py (DescriptorDistance == popcount(a^b); literal 64x48 grid traversal).
+ * Monocular only (mvuRight < 0 everywhere), which is all SwarmMap builds (Examples/Monocular).
+ */
+#ifndef MATCHER_ORACLE_H
+#define MATCHER_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_GRID_COLS 64 /* FRAME_GRID_COLS, code/include/Frame.h:38 */
+#define ORC_GRID_ROWS 48 /* FRAME_GRID_ROWS, code/include/Frame.h:37 */
+
+/* Flattened view of the parts of ORB_SLAM2::Frame the matcher reads. */
+typedef struct {
+    int32_t n;              /* N */
+    const float* x;         /* mvKeysUn[i].pt.x */
+    const float* y;         /* mvKeysUn[i].pt.y */
+    const int32_t* octave;  /* mvKeysUn[i].octave */
+    const float* angle;     /* mvKeysUn[i].angle (degrees) */
+    const uint8_t* desc;    /* mDescriptors, n x 32 */
+    const uint8_t* excluded; /* 1 iff mvpMapPoints[i] && mvpMapPoints[i]->Observations() > 0 on entry; may be NULL */
+    float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+    float grid_inv_w, grid_inv_h;     /* mfGridElementWidthInv / HeightInv */
+    const float* scale_factors;       /* mvScaleFactors */
+    int32_t nlevels;
+} orc_frame_view;
+
+/* ORBmatcher::DescriptorDistance, code/src/ORBmatcher.cc:1511-1525 (SWAR popcount, literal) */
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+
+/* Frame::GetFeaturesInArea through a literal 64x48 grid, code/src/Frame.cc:377-443.  Returns count. */
+int orc_features_in_area(const orc_frame_view* F, float x, float y, float r, int min_level, int max_level,
+                         int32_t* out_idx, int cap);
+
+/* ORBmatcher::ComputeThreeMaxima, code/src/ORBmatcher.cc:1475-1506 (on bin populations) */
+void orc_three_maxima(const int32_t* histo_sizes, int L, int* ind1, int* ind2, int* ind3);
+
+/* M1: ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), code/src/ORBmatcher.cc:44-121.
+ * in_view[i] = pMP->mbTrackInView && !pMP->isBad().  kp_to_mp[k] = index of the map point bound to
+ * keypoint k by this call, or -1.  Returns nmatches. */
+int orc_search_by_projection_mappoints(const orc_frame_view* F, int32_t n_mp, const uint8_t* in_view,
+                                       const float* proj_x, const float* proj_y, const float* view_cos,
+                                       const int32_t* pred_level, const uint8_t* mp_desc,
+                                       const uint8_t* mp_has_obs, float th, float nn_ratio, int32_t* kp_to_mp);
+
+/* M2: ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono=true),
+ * code/src/ORBmatcher.cc:1223-1354, from the projection onwards: valid[i] = pMP && !outlier && invzc >= 0 &&
+ * (u,v) inside the image bounds.  kp_to_last[k] = index i in the last frame, or -1. */
+int orc_search_by_projection_lastframe(const orc_frame_view* cur, int32_t n_last, const uint8_t* valid,
+                                       const float* u, const float* v, const int32_t* last_octave,
+                                       const float* last_angle, const uint8_t* mp_desc,
+                                       const uint8_t* mp_has_obs, float th, int check_orientation,
+                                       int32_t* kp_to_last);
+
+/* M4: ORBmatcher::SearchForInitialization, code/src/ORBmatcher.cc:375-479.
+ * prev_matched: n1 x 2 floats, updated in place.  matches12: n1 ints out. */
+int orc_search_for_initialization(const orc_frame_view* F1, const orc_frame_view* F2, float* prev_matched,
+                                  int window, float nn_ratio, int check_orientation, int32_t* matches12);
+
+/* Brute-force best / second-best Hamming match of every row of A against all rows of B (the cross-agent
+ * keyframe search after the descriptor all-gather).  Ties: lowest index in B wins. */
+void orc_hamming_top2(const uint8_t* A, int na, const uint8_t* B, int nb, int32_t* best_idx, int32_t* best_dist,
+                      int32_t* second_dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -162,3 +162,76 @@ def extract(cfg, img, debug=False, cand_cap=ORC_FAST_CAP):
         off += lw * lh
     cands = [(cx[l, :cnt[l]].copy(), cy[l, :cnt[l]].copy(), cs[l, :cnt[l]].copy()) for l in range(nl)]
     return kps[:n].copy(), desc[:n].copy(), cands, levels
+
+
+# ------------------------------------------------------------------------------------------------
+# matcher oracle (matcher_oracle.c); FrameView objects come from swarmmap_amd.matcher (plain data holder)
+# ------------------------------------------------------------------------------------------------
+class OrcFrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p),
+                ("angle", C.c_void_p), ("desc", C.c_void_p), ("excluded", C.c_void_p),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("scale_factors", C.c_void_p),
+                ("nlevels", C.c_int32)]
+
+
+def _fv(F):
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    return OrcFrameView(F.n, p(F.x), p(F.y), p(F.octave), p(F.angle), p(F.desc), p(F.excluded), F.min_x, F.max_x,
+                        F.min_y, F.max_y, F.grid_inv_w, F.grid_inv_h, p(F.scale_factors), len(F.scale_factors))
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().orc_descriptor_distance(_p(a), _p(b)))
+
+
+def features_in_area(F, x, y, r, min_level=-1, max_level=-1):
+    out = np.zeros(max(F.n, 1), np.int32)
+    fs = _fv(F)
+    n = lib().orc_features_in_area(C.byref(fs), C.c_float(x), C.c_float(y), C.c_float(r), int(min_level),
+                                   int(max_level), _p(out), len(out))
+    return out[:n].copy()
+
+
+def search_by_projection_mappoints(F, mps, th, nn_ratio):
+    a = {k: np.ascontiguousarray(mps[k], t) for k, t in
+         (("in_view", np.uint8), ("proj_x", np.float32), ("proj_y", np.float32), ("view_cos", np.float32),
+          ("pred_level", np.int32), ("desc", np.uint8), ("has_obs", np.uint8))}
+    out = np.full(F.n, -1, np.int32)
+    fs = _fv(F)
+    nm = lib().orc_search_by_projection_mappoints(C.byref(fs), len(a["proj_x"]), _p(a["in_view"]), _p(a["proj_x"]),
+                                                  _p(a["proj_y"]), _p(a["view_cos"]), _p(a["pred_level"]),
+                                                  _p(a["desc"]), _p(a["has_obs"]), C.c_float(th), C.c_float(nn_ratio),
+                                                  _p(out))
+    return nm, out
+
+
+def search_by_projection_lastframe(cur, last, th, check_ori=True):
+    a = {k: np.ascontiguousarray(last[k], t) for k, t in
+         (("valid", np.uint8), ("u", np.float32), ("v", np.float32), ("octave", np.int32), ("angle", np.float32),
+          ("desc", np.uint8), ("has_obs", np.uint8))}
+    out = np.full(cur.n, -1, np.int32)
+    fs = _fv(cur)
+    nm = lib().orc_search_by_projection_lastframe(C.byref(fs), len(a["u"]), _p(a["valid"]), _p(a["u"]), _p(a["v"]),
+                                                  _p(a["octave"]), _p(a["angle"]), _p(a["desc"]), _p(a["has_obs"]),
+                                                  C.c_float(th), int(check_ori), _p(out))
+    return nm, out
+
+
+def search_for_initialization(F1, F2, prev_matched, window, nn_ratio, check_ori=True):
+    pm = np.ascontiguousarray(prev_matched, np.float32).reshape(-1, 2).copy()
+    out = np.full(F1.n, -1, np.int32)
+    f1, f2 = _fv(F1), _fv(F2)
+    nm = lib().orc_search_for_initialization(C.byref(f1), C.byref(f2), _p(pm), int(window), C.c_float(nn_ratio),
+                                             int(check_ori), _p(out))
+    return nm, out, pm
+
+
+def hamming_top2(A, B):
+    A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32)
+    B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+    bi, bd, sd = [np.zeros(len(A), np.int32) for _ in range(3)]
+    lib().orc_hamming_top2(_p(A), len(A), _p(B), len(B), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd

@@ -1,0 +1,35 @@
+// match_device.h — device-side layout of the Hamming matcher.
+//
+// HBM layout (one so_matcher = one agent's matcher context, buffers grow on demand and stay resident):
+//   candidate frame, SoA in grid-traversal order (cell x, cell y, keypoint index):
+//     xy      float2  undistorted keypoint position (mvKeysUn[i].pt)
+//     octave  i8
+//     desc    2 x uint4 (32 B) per keypoint
+//     limit   i32 optional dynamic gate: candidate is eligible iff dist < limit (0 = taken, INT_MAX = free)
+//   queries: MatchQuery (24 B) + 32-B descriptor each; results: K u32 keys (dist << 16 | position) per query.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace so {
+
+struct MatchFrameDev {
+    const float2* xy;
+    const int8_t* octave;
+    const uint4* desc;
+    const int32_t* limit;  // may be null
+    int n;
+};
+
+struct MatchQuery {
+    float u, v, r;
+    int32_t min_level, max_level;
+    int32_t active;
+};
+
+void launch_topk_window(const MatchFrameDev& F, const MatchQuery* d_q, const uint4* d_qdesc, int nq, int K,
+                        uint32_t* d_keys, int32_t* d_count, hipStream_t s);
+void launch_hamming_top2(const uint4* d_A, int na, const uint4* d_B, int nb, int32_t* d_best_idx, int32_t* d_best_dist,
+                         int32_t* d_second_dist, hipStream_t s);
+
+}  // namespace so

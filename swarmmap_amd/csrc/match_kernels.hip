@@ -1,0 +1,174 @@
+// match_kernels.hip — gfx950 Hamming matching kernels.
+//
+// Two kernels:
+//   topk_window_kernel  one wave per query: scan ALL candidate keypoints of the frame (brute force, coalesced SoA
+//                       reads; the 64x48 grid of the reference is only a CPU acceleration structure), apply the
+//                       exact GetFeaturesInArea predicate (code/src/Frame.cc:377-431) as a per-pair mask, compute
+//                       256-bit Hamming distances for the survivors, and return the K best in the order the
+//                       reference's sequential "dist < bestDist" scan induces: (distance, grid traversal rank).
+//   hamming_top2_kernel one wave per query against every row of B (cross-agent keyframe search), best/second.
+//
+// Candidates are stored in grid-traversal order (cell x, cell y, keypoint index) by the host, so a candidate's
+// array position IS its tie-break rank and key = dist << 16 | position sorts exactly like the reference visits.
+#include "match_device.h"
+
+namespace so {
+
+__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+    // DescriptorDistance (code/src/ORBmatcher.cc:1511-1525) == popcount(a ^ b) over 256 bits (KAT-pinned)
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off));
+    return v;
+}
+
+constexpr int kListCap = 1024;  // per-wave LDS list of (dist<<16 | rank) keys
+
+__device__ __forceinline__ bool window_pred(const MatchFrameDev& F, int c, float u, float v, float r, int min_l,
+                                            int max_l, bool check_levels) {
+    const float2 xy = F.xy[c];
+    const float dx = xy.x - u, dy = xy.y - v;
+    bool ok = fabsf(dx) < r && fabsf(dy) < r;
+    if (check_levels) {
+        const int o = F.octave[c];
+        if (o < min_l) ok = false;
+        if (max_l >= 0 && o > max_l) ok = false;
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const MatchQuery* __restrict__ q,
+                                                           const uint4* __restrict__ qdesc, int nq, int K,
+                                                           uint32_t* __restrict__ out_keys,
+                                                           int32_t* __restrict__ out_count) {
+    __shared__ uint32_t s_keys[4][kListCap];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 4 + w;
+    if (qi >= nq) return;
+    const MatchQuery Q = q[qi];
+    if (!Q.active) {
+        if (lane == 0) out_count[qi] = 0;
+        for (int k = lane; k < K; k += 64) out_keys[(size_t)qi * K + k] = 0xFFFFFFFFu;
+        return;
+    }
+    const uint4 qd0 = qdesc[2 * qi], qd1 = qdesc[2 * qi + 1];
+    const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int m = 0;
+    for (int base = 0; base < F.n; base += 64) {
+        const int c = base + lane;
+        bool ok = c < F.n;
+        int dist = 0;
+        if (ok) ok = window_pred(F, c, Q.u, Q.v, Q.r, Q.min_level, Q.max_level, check_levels);
+        if (ok) {
+            dist = hamming256(F.desc[2 * c], F.desc[2 * c + 1], qd0, qd1);
+            if (F.limit && !(dist < F.limit[c])) ok = false;
+        }
+        const unsigned long long mask = __ballot(ok);
+        if (mask) {
+            const int pos = m + __popcll(mask & lt_mask);
+            if (ok && pos < kListCap) s_keys[w][pos] = ((uint32_t)dist << 16) | (uint32_t)c;
+            m += __popcll(mask);
+        }
+    }
+    if (lane == 0) out_count[qi] = m;
+    if (m <= kListCap) {
+        // K smallest keys of the list: round k = min over keys greater than the previous minimum (keys are unique)
+        uint32_t prev = 0;
+        for (int k = 0; k < K; k++) {
+            uint32_t cur = 0xFFFFFFFFu;
+            for (int i = lane; i < m; i += 64) {
+                const uint32_t key = s_keys[w][i];
+                if ((k == 0 || key > prev) && key < cur) cur = key;
+            }
+            cur = wave_min_u32(cur);
+            if (lane == 0) out_keys[(size_t)qi * K + k] = cur;
+            if (cur == 0xFFFFFFFFu) {
+                for (int k2 = k + 1 + lane; k2 < K; k2 += 64) out_keys[(size_t)qi * K + k2] = 0xFFFFFFFFu;
+                break;
+            }
+            prev = cur;
+        }
+    } else {
+        // window larger than the LDS list: rescan the candidates once per output rank (exact, slower)
+        uint32_t prev = 0;
+        for (int k = 0; k < K; k++) {
+            uint32_t cur = 0xFFFFFFFFu;
+            for (int base = 0; base < F.n; base += 64) {
+                const int c = base + lane;
+                if (c < F.n && window_pred(F, c, Q.u, Q.v, Q.r, Q.min_level, Q.max_level, check_levels)) {
+                    const int dist = hamming256(F.desc[2 * c], F.desc[2 * c + 1], qd0, qd1);
+                    if (!F.limit || dist < F.limit[c]) {
+                        const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)c;
+                        if ((k == 0 || key > prev) && key < cur) cur = key;
+                    }
+                }
+            }
+            cur = wave_min_u32(cur);
+            if (lane == 0) out_keys[(size_t)qi * K + k] = cur;
+            prev = cur;
+            if (cur == 0xFFFFFFFFu) {
+                for (int k2 = k + 1 + lane; k2 < K; k2 += 64) out_keys[(size_t)qi * K + k2] = 0xFFFFFFFFu;
+                break;
+            }
+        }
+    }
+}
+
+void launch_topk_window(const MatchFrameDev& F, const MatchQuery* d_q, const uint4* d_qdesc, int nq, int K,
+                        uint32_t* d_keys, int32_t* d_count, hipStream_t s) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(topk_window_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, F, d_q, d_qdesc, nq, K, d_keys,
+                       d_count);
+}
+
+// Brute-force best / second-best of each row of A against all rows of B; ties: lowest index in B.
+// One wave per query row; each lane strides over B keeping its own (best, second) keys, then a wave merge.
+__global__ __launch_bounds__(256) void hamming_top2_kernel(const uint4* __restrict__ A, int na,
+                                                            const uint4* __restrict__ B, int nb,
+                                                            int32_t* __restrict__ best_idx,
+                                                            int32_t* __restrict__ best_dist,
+                                                            int32_t* __restrict__ second_dist) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 4 + w;
+    if (qi >= na) return;
+    const uint4 a0 = A[2 * qi], a1 = A[2 * qi + 1];
+    // key = dist << 20 | index (nb < 2^20); the two smallest keys give best + second in reference scan order
+    uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+    for (int c = lane; c < nb; c += 64) {
+        const uint32_t key = ((uint32_t)hamming256(B[2 * c], B[2 * c + 1], a0, a1) << 20) | (uint32_t)c;
+        if (key < k1) {
+            k2 = k1;
+            k1 = key;
+        } else if (key < k2) {
+            k2 = key;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, off), o2 = (uint32_t)__shfl_xor((int)k2, off);
+        // merge two sorted pairs, keep the two smallest
+        const uint32_t n1 = min(k1, o1);
+        const uint32_t n2 = min(max(k1, o1), min(k2, o2));
+        k1 = n1;
+        k2 = n2;
+    }
+    if (lane == 0) {
+        best_idx[qi] = k1 == 0xFFFFFFFFu ? -1 : (int32_t)(k1 & 0xFFFFFu);
+        best_dist[qi] = k1 == 0xFFFFFFFFu ? 256 : (int32_t)(k1 >> 20);
+        second_dist[qi] = k2 == 0xFFFFFFFFu ? 256 : (int32_t)(k2 >> 20);
+    }
+}
+
+void launch_hamming_top2(const uint4* d_A, int na, const uint4* d_B, int nb, int32_t* d_best_idx,
+                         int32_t* d_best_dist, int32_t* d_second_dist, hipStream_t s) {
+    if (na <= 0) return;
+    hipLaunchKernelGGL(hamming_top2_kernel, dim3((na + 3) / 4), dim3(256), 0, s, d_A, na, d_B, nb, d_best_idx,
+                       d_best_dist, d_second_dist);
+}
+
+}  // namespace so

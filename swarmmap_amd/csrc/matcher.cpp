@@ -1,0 +1,670 @@
+// matcher.cpp — host driver + C ABI of the Hamming matcher (include/swarmorb.h).
+//
+// Replaces the tracking-thread routines of ORB_SLAM2::ORBmatcher (code/src/ORBmatcher.cc).  Per call:
+//   flatten the frame into grid-traversal order -> H2D -> ONE top-K launch for all queries -> D2H -> the
+//   reference's order-dependent resolve on the host.  When a query's K-list is exhausted by keypoints that
+//   earlier queries took (possible only if more than K candidates were in its window) that single query is
+//   re-evaluated on the GPU with the current "taken" gate, so distances never come from the CPU.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "match_device.h"
+#include "so_common.h"
+
+using namespace so;
+
+namespace {
+
+constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS/ROWS, code/include/Frame.h:37-38
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // code/src/ORBmatcher.cc:37-39
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SO_OK;
+        if (p) SO_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 2 + 256;
+        SO_HIP(hipMalloc(&p, want));
+        cap = want;
+        return SO_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SO_OK;
+        if (p) SO_HIP(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 2 + 256;
+        SO_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return SO_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct so_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float last_ms = 0.f;
+
+    DevBuf d_xy, d_oct, d_desc, d_limit, d_q, d_qdesc, d_keys, d_count, d_A, d_B, d_res;
+    PinBuf h_xy, h_oct, h_desc, h_limit, h_q, h_qdesc, h_keys, h_count, h_res;
+
+    int n_cand = 0;           // keypoints that are inside the grid (PosInGrid true)
+    bool has_limit = false;
+    std::vector<int> perm;     // rank -> keypoint index
+    std::vector<int> rank_of;  // keypoint index -> rank (-1: not in grid)
+    std::vector<int> cell_count;
+};
+
+namespace {
+
+// Frame::PosInGrid, code/src/Frame.cc:433-443
+inline bool pos_in_grid(const so_frame_view* F, int i, int& px, int& py) {
+    px = (int)roundf((F->x[i] - F->min_x) * F->grid_inv_w);
+    py = (int)roundf((F->y[i] - F->min_y) * F->grid_inv_h);
+    return !(px < 0 || px >= kGridCols || py < 0 || py >= kGridRows);
+}
+
+// Order the frame's keypoints the way GetFeaturesInArea visits them (cell x outer, cell y inner, insertion
+// order inside a cell = keypoint index; code/src/Frame.cc:277-292,401-427) and upload the SoA.
+int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_idx) {
+    const int n = F->n;
+    if (n > 65535) {
+        last_error_ref() = "matcher supports at most 65535 keypoints per frame";
+        return SO_ERR_INVALID_ARG;
+    }
+    m->cell_count.assign((size_t)kGridCols * kGridRows + 1, 0);
+    m->rank_of.assign((size_t)n, -1);
+    std::vector<int>& cc = m->cell_count;
+    std::vector<int> cell((size_t)n, -1);
+    for (int i = 0; i < n; i++) {
+        int px, py;
+        if (pos_in_grid(F, i, px, py)) {
+            cell[(size_t)i] = px * kGridRows + py;
+            cc[(size_t)cell[(size_t)i] + 1]++;
+        }
+    }
+    for (size_t c = 1; c < cc.size(); c++) cc[c] += cc[c - 1];
+    const int nc = cc.back();
+    m->perm.assign((size_t)nc, 0);
+    {
+        std::vector<int> fill(cc.begin(), cc.end() - 1);
+        for (int i = 0; i < n; i++)
+            if (cell[(size_t)i] >= 0) {
+                const int r = fill[(size_t)cell[(size_t)i]]++;
+                m->perm[(size_t)r] = i;
+                m->rank_of[(size_t)i] = r;
+            }
+    }
+    m->n_cand = nc;
+    const bool want_limit = (F->excluded != nullptr) || (limit_by_idx != nullptr);
+    m->has_limit = want_limit;
+    int rc;
+    if ((rc = m->h_xy.ensure(sizeof(float2) * (size_t)nc + 16))) return rc;
+    if ((rc = m->h_oct.ensure((size_t)nc + 16))) return rc;
+    if ((rc = m->h_desc.ensure((size_t)nc * 32 + 16))) return rc;
+    if ((rc = m->d_xy.ensure(sizeof(float2) * (size_t)nc + 16))) return rc;
+    if ((rc = m->d_oct.ensure((size_t)nc + 16))) return rc;
+    if ((rc = m->d_desc.ensure((size_t)nc * 32 + 16))) return rc;
+    float2* hxy = (float2*)m->h_xy.p;
+    int8_t* hoct = (int8_t*)m->h_oct.p;
+    uint8_t* hdesc = (uint8_t*)m->h_desc.p;
+    for (int r = 0; r < nc; r++) {
+        const int i = m->perm[(size_t)r];
+        hxy[r] = make_float2(F->x[i], F->y[i]);
+        hoct[r] = (int8_t)F->octave[i];
+        memcpy(hdesc + (size_t)r * 32, F->desc + (size_t)i * 32, 32);
+    }
+    if (nc > 0) {
+        SO_HIP(hipMemcpyAsync(m->d_xy.p, hxy, sizeof(float2) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
+        SO_HIP(hipMemcpyAsync(m->d_oct.p, hoct, (size_t)nc, hipMemcpyHostToDevice, m->stream));
+        SO_HIP(hipMemcpyAsync(m->d_desc.p, hdesc, (size_t)nc * 32, hipMemcpyHostToDevice, m->stream));
+    }
+    if (want_limit) {
+        if ((rc = m->h_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
+        if ((rc = m->d_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
+        int32_t* hl = (int32_t*)m->h_limit.p;
+        for (int r = 0; r < nc; r++) {
+            const int i = m->perm[(size_t)r];
+            int32_t lim = limit_by_idx ? limit_by_idx[i] : INT_MAX;
+            if (F->excluded && F->excluded[i]) lim = 0;
+            hl[r] = lim;
+        }
+        if (nc > 0)
+            SO_HIP(hipMemcpyAsync(m->d_limit.p, hl, sizeof(int32_t) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
+    }
+    return SO_OK;
+}
+
+int upload_limit_only(so_matcher* m, const std::vector<int32_t>& limit_by_idx) {
+    const int nc = m->n_cand;
+    int rc;
+    if ((rc = m->h_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
+    if ((rc = m->d_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
+    int32_t* hl = (int32_t*)m->h_limit.p;
+    for (int r = 0; r < nc; r++) hl[r] = limit_by_idx[(size_t)m->perm[(size_t)r]];
+    if (nc > 0)
+        SO_HIP(hipMemcpyAsync(m->d_limit.p, hl, sizeof(int32_t) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
+    m->has_limit = true;
+    return SO_OK;
+}
+
+MatchFrameDev frame_dev(const so_matcher* m) {
+    MatchFrameDev F;
+    F.xy = (const float2*)m->d_xy.p;
+    F.octave = (const int8_t*)m->d_oct.p;
+    F.desc = (const uint4*)m->d_desc.p;
+    F.limit = m->has_limit ? (const int32_t*)m->d_limit.p : nullptr;
+    F.n = m->n_cand;
+    return F;
+}
+
+// queries must already be in m->h_q / m->h_qdesc (pinned).  Results land in m->h_keys / m->h_count.
+int run_topk(so_matcher* m, int nq, int K) {
+    if (nq <= 0) return SO_OK;
+    int rc;
+    if ((rc = m->d_q.ensure(sizeof(MatchQuery) * (size_t)nq))) return rc;
+    if ((rc = m->d_qdesc.ensure((size_t)nq * 32))) return rc;
+    if ((rc = m->d_keys.ensure(sizeof(uint32_t) * (size_t)nq * K))) return rc;
+    if ((rc = m->d_count.ensure(sizeof(int32_t) * (size_t)nq))) return rc;
+    if ((rc = m->h_keys.ensure(sizeof(uint32_t) * (size_t)nq * K))) return rc;
+    if ((rc = m->h_count.ensure(sizeof(int32_t) * (size_t)nq))) return rc;
+    hipStream_t s = m->stream;
+    SO_HIP(hipMemcpyAsync(m->d_q.p, m->h_q.p, sizeof(MatchQuery) * (size_t)nq, hipMemcpyHostToDevice, s));
+    SO_HIP(hipMemcpyAsync(m->d_qdesc.p, m->h_qdesc.p, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    SO_HIP(hipEventRecord(m->e0, s));
+    launch_topk_window(frame_dev(m), (const MatchQuery*)m->d_q.p, (const uint4*)m->d_qdesc.p, nq, K,
+                       (uint32_t*)m->d_keys.p, (int32_t*)m->d_count.p, s);
+    SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipMemcpyAsync(m->h_keys.p, m->d_keys.p, sizeof(uint32_t) * (size_t)nq * K, hipMemcpyDeviceToHost, s));
+    SO_HIP(hipMemcpyAsync(m->h_count.p, m->d_count.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, s));
+    SO_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    return SO_OK;
+}
+
+int ensure_queries(so_matcher* m, int nq) {
+    int rc;
+    if ((rc = m->h_q.ensure(sizeof(MatchQuery) * (size_t)(nq > 0 ? nq : 1)))) return rc;
+    return m->h_qdesc.ensure((size_t)(nq > 0 ? nq : 1) * 32);
+}
+
+struct Entry {
+    int idx, dist;
+};
+
+// Exact top-K of ONE query under a dynamic per-keypoint gate (rare path, see file header).
+int rerun_single(so_matcher* m, const MatchQuery& q, const uint8_t* qdesc, const std::vector<int32_t>& limit_by_idx,
+                 int K, Entry* out, int* n_found) {
+    int rc = upload_limit_only(m, limit_by_idx);
+    if (rc) return rc;
+    // h_q / h_qdesc / h_keys / h_count are reused: callers copy the batch results out before resolving
+    ((MatchQuery*)m->h_q.p)[0] = q;
+    memcpy(m->h_qdesc.p, qdesc, 32);
+    if ((rc = run_topk(m, 1, K))) return rc;
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
+    *n_found = 0;
+    for (int k = 0; k < K; k++) {
+        if (keys[k] == 0xFFFFFFFFu) break;
+        out[*n_found].dist = (int)(keys[k] >> 16);
+        out[*n_found].idx = m->perm[(size_t)(keys[k] & 0xFFFFu)];
+        (*n_found)++;
+    }
+    return SO_OK;
+}
+
+// ORBmatcher::ComputeThreeMaxima, code/src/ORBmatcher.cc:1475-1506 (on bin populations)
+void three_maxima(const int* sizes, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if ((float)max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if ((float)max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+}
+
+inline int rot_bin(float a1, float a2) {  // ORBmatcher.cc:1319-1325
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * (1.0f / HISTO_LENGTH));
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+bool frame_ok(const so_frame_view* F) {
+    return F && F->n >= 0 && (F->n == 0 || (F->x && F->y && F->octave && F->desc));
+}
+
+}  // namespace
+
+extern "C" {
+
+int so_matcher_create(int device, so_matcher** out) {
+    if (!out) return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        last_error_ref() = "no usable HIP device";
+        return SO_ERR_NO_DEVICE;
+    }
+    SO_HIP(hipSetDevice(device));
+    so_matcher* m = new so_matcher();
+    m->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&m->e0);
+    if (e == hipSuccess) e = hipEventCreate(&m->e1);
+    if (e != hipSuccess) {
+        delete m;
+        return hip_fail(e, "matcher init", __FILE__, __LINE__);
+    }
+    *out = m;
+    return SO_OK;
+}
+
+void so_matcher_destroy(so_matcher* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (DevBuf* b : {&m->d_xy, &m->d_oct, &m->d_desc, &m->d_limit, &m->d_q, &m->d_qdesc, &m->d_keys, &m->d_count,
+                      &m->d_A, &m->d_B, &m->d_res})
+        b->release();
+    for (PinBuf* b : {&m->h_xy, &m->h_oct, &m->h_desc, &m->h_limit, &m->h_q, &m->h_qdesc, &m->h_keys, &m->h_count,
+                      &m->h_res})
+        b->release();
+    if (m->e0) (void)hipEventDestroy(m->e0);
+    if (m->e1) (void)hipEventDestroy(m->e1);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int so_matcher_last_kernel_ms(so_matcher* m, float* ms) {
+    if (!m || !ms) return SO_ERR_INVALID_ARG;
+    *ms = m->last_ms;
+    return SO_OK;
+}
+
+int so_matcher_topk(so_matcher* m, const so_frame_view* F, const int32_t* limit, int32_t nq, const float* u,
+                    const float* v, const float* r, const int32_t* min_level, const int32_t* max_level,
+                    const uint8_t* active, const uint8_t* qdesc, int32_t K, int32_t* out_idx, int32_t* out_dist,
+                    int32_t* out_count) {
+    if (!m || !frame_ok(F) || nq < 0 || K < 1 || K > 64) return SO_ERR_INVALID_ARG;
+    if (nq > 0 && (!u || !v || !r || !min_level || !max_level || !qdesc || !out_idx || !out_dist || !out_count))
+        return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    int rc = upload_frame(m, F, limit);
+    if (rc) return rc;
+    if ((rc = ensure_queries(m, nq))) return rc;
+    MatchQuery* hq = (MatchQuery*)m->h_q.p;
+    for (int i = 0; i < nq; i++) {
+        hq[i].u = u[i];
+        hq[i].v = v[i];
+        hq[i].r = r[i];
+        hq[i].min_level = min_level[i];
+        hq[i].max_level = max_level[i];
+        hq[i].active = active ? (active[i] != 0) : 1;
+    }
+    if (nq > 0) memcpy(m->h_qdesc.p, qdesc, (size_t)nq * 32);
+    if ((rc = run_topk(m, nq, K))) return rc;
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
+    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    for (int i = 0; i < nq; i++) {
+        out_count[i] = cnt[i];
+        for (int k = 0; k < K; k++) {
+            const uint32_t key = keys[(size_t)i * K + k];
+            if (key == 0xFFFFFFFFu) {
+                out_idx[(size_t)i * K + k] = -1;
+                out_dist[(size_t)i * K + k] = 256;
+            } else {
+                out_idx[(size_t)i * K + k] = m->perm[(size_t)(key & 0xFFFFu)];
+                out_dist[(size_t)i * K + k] = (int32_t)(key >> 16);
+            }
+        }
+    }
+    return SO_OK;
+}
+
+// M1 — ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), code/src/ORBmatcher.cc:44-121
+int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int32_t n_mp, const uint8_t* in_view,
+                                      const float* proj_x, const float* proj_y, const float* view_cos,
+                                      const int32_t* pred_level, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                                      float th, float nn_ratio, int32_t* kp_to_mp, int32_t* nmatches) {
+    if (!m || !frame_ok(F) || n_mp < 0 || !kp_to_mp || !nmatches || !F->scale_factors) return SO_ERR_INVALID_ARG;
+    if (n_mp > 0 && (!in_view || !proj_x || !proj_y || !view_cos || !pred_level || !mp_desc || !mp_has_obs))
+        return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    *nmatches = 0;
+    for (int k = 0; k < F->n; k++) kp_to_mp[k] = -1;
+    if (n_mp == 0 || F->n == 0) return SO_OK;
+    constexpr int K = 8;
+    int rc = upload_frame(m, F, nullptr);
+    if (rc) return rc;
+    if ((rc = ensure_queries(m, n_mp))) return rc;
+    MatchQuery* hq = (MatchQuery*)m->h_q.p;
+    const bool bFactor = th != 1.0f;
+    for (int i = 0; i < n_mp; i++) {
+        MatchQuery& q = hq[i];
+        q.active = in_view[i] != 0;
+        const int lvl = pred_level[i];
+        float r = view_cos[i] > 0.998f ? 2.5f : 4.0f;  // RadiusByViewingCos, :123-128
+        if (bFactor) r *= th;
+        q.u = proj_x[i];
+        q.v = proj_y[i];
+        q.r = (q.active && lvl >= 0 && lvl < F->nlevels) ? r * F->scale_factors[lvl] : 0.f;
+        if (!(lvl >= 0 && lvl < F->nlevels)) q.active = 0;
+        q.min_level = lvl - 1;
+        q.max_level = lvl;
+    }
+    memcpy(m->h_qdesc.p, mp_desc, (size_t)n_mp * 32);
+    if ((rc = run_topk(m, n_mp, K))) return rc;
+    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)n_mp * K);
+    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + n_mp);
+    std::vector<MatchQuery> queries(hq, hq + n_mp);
+    std::vector<int32_t> gate;
+    int nm = 0;
+    for (int i = 0; i < n_mp; i++) {
+        if (!queries[(size_t)i].active || cnt[(size_t)i] == 0) continue;
+        Entry e[2];
+        int found = 0, walked = 0;
+        for (; walked < K && found < 2; walked++) {
+            const uint32_t key = keys[(size_t)i * K + walked];
+            if (key == 0xFFFFFFFFu) break;
+            const int idx = m->perm[(size_t)(key & 0xFFFFu)];
+            // F.mvpMapPoints[idx] bound earlier in this call to a point with observations (:83-85)
+            if (kp_to_mp[idx] >= 0 && mp_has_obs[kp_to_mp[idx]]) continue;
+            e[found].idx = idx;
+            e[found].dist = (int)(key >> 16);
+            found++;
+        }
+        if (found < 2 && walked == K && cnt[(size_t)i] > K) {  // list exhausted by taken keypoints: exact re-run
+            gate.assign((size_t)F->n, INT_MAX);
+            for (int k = 0; k < F->n; k++)
+                if ((F->excluded && F->excluded[k]) || (kp_to_mp[k] >= 0 && mp_has_obs[kp_to_mp[k]])) gate[(size_t)k] = 0;
+            if ((rc = rerun_single(m, queries[(size_t)i], mp_desc + (size_t)i * 32, gate, 2, e, &found))) return rc;
+        }
+        if (found == 0) continue;
+        const int bestDist = e[0].dist, bestIdx = e[0].idx, bestLevel = F->octave[bestIdx];
+        const int bestDist2 = found > 1 ? e[1].dist : 256;
+        const int bestLevel2 = found > 1 ? F->octave[e[1].idx] : -1;
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;
+            kp_to_mp[bestIdx] = i;
+            nm++;
+        }
+    }
+    *nmatches = nm;
+    return SO_OK;
+}
+
+// M2 — ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), code/src/ORBmatcher.cc:1223-1354
+int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, int32_t n_last, const uint8_t* valid,
+                                      const float* u, const float* v, const int32_t* last_octave,
+                                      const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                                      float th, int check_orientation, int32_t* kp_to_last, int32_t* nmatches) {
+    if (!m || !frame_ok(cur) || n_last < 0 || !kp_to_last || !nmatches || !cur->scale_factors)
+        return SO_ERR_INVALID_ARG;
+    if (n_last > 0 && (!valid || !u || !v || !last_octave || !mp_desc || !mp_has_obs)) return SO_ERR_INVALID_ARG;
+    if (check_orientation && n_last > 0 && (!last_angle || !cur->angle)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    *nmatches = 0;
+    for (int k = 0; k < cur->n; k++) kp_to_last[k] = -1;
+    if (n_last == 0 || cur->n == 0) return SO_OK;
+    constexpr int K = 4;
+    int rc = upload_frame(m, cur, nullptr);
+    if (rc) return rc;
+    if ((rc = ensure_queries(m, n_last))) return rc;
+    MatchQuery* hq = (MatchQuery*)m->h_q.p;
+    for (int i = 0; i < n_last; i++) {
+        MatchQuery& q = hq[i];
+        const int oct = last_octave[i];
+        q.active = valid[i] != 0 && oct >= 0 && oct < cur->nlevels;
+        q.u = u[i];
+        q.v = v[i];
+        q.r = q.active ? th * cur->scale_factors[oct] : 0.f;  // :1276
+        q.min_level = oct - 1;                                 // :1285
+        q.max_level = oct + 1;
+    }
+    memcpy(m->h_qdesc.p, mp_desc, (size_t)n_last * 32);
+    if ((rc = run_topk(m, n_last, K))) return rc;
+    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)n_last * K);
+    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + n_last);
+    std::vector<MatchQuery> queries(hq, hq + n_last);
+    std::vector<int32_t> gate;
+    std::vector<int> rot_item, rot_b;
+    int hist[HISTO_LENGTH] = {0};
+    int nm = 0;
+    for (int i = 0; i < n_last; i++) {
+        if (!queries[(size_t)i].active || cnt[(size_t)i] == 0) continue;
+        Entry e[1];
+        int found = 0, walked = 0;
+        for (; walked < K && found < 1; walked++) {
+            const uint32_t key = keys[(size_t)i * K + walked];
+            if (key == 0xFFFFFFFFu) break;
+            const int idx = m->perm[(size_t)(key & 0xFFFFu)];
+            if (kp_to_last[idx] >= 0 && mp_has_obs[kp_to_last[idx]]) continue;
+            e[0].idx = idx;
+            e[0].dist = (int)(key >> 16);
+            found++;
+        }
+        if (found < 1 && walked == K && cnt[(size_t)i] > K) {
+            gate.assign((size_t)cur->n, INT_MAX);
+            for (int k = 0; k < cur->n; k++)
+                if ((cur->excluded && cur->excluded[k]) || (kp_to_last[k] >= 0 && mp_has_obs[kp_to_last[k]]))
+                    gate[(size_t)k] = 0;
+            if ((rc = rerun_single(m, queries[(size_t)i], mp_desc + (size_t)i * 32, gate, 1, e, &found))) return rc;
+        }
+        if (found == 0) continue;
+        if (e[0].dist <= TH_HIGH) {
+            kp_to_last[e[0].idx] = i;
+            nm++;
+            if (check_orientation) {
+                const int b = rot_bin(last_angle[i], cur->angle[e[0].idx]);
+                rot_item.push_back(e[0].idx);
+                rot_b.push_back(b);
+                hist[b]++;
+            }
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        three_maxima(hist, HISTO_LENGTH, i1, i2, i3);
+        for (size_t j = 0; j < rot_item.size(); j++)
+            if (rot_b[j] != i1 && rot_b[j] != i2 && rot_b[j] != i3) {
+                kp_to_last[rot_item[j]] = -1;
+                nm--;
+            }
+    }
+    *nmatches = nm;
+    return SO_OK;
+}
+
+// M4 — ORBmatcher::SearchForInitialization, code/src/ORBmatcher.cc:375-479
+int so_search_for_initialization(so_matcher* m, const so_frame_view* F1, const so_frame_view* F2,
+                                 float* prev_matched, int window, float nn_ratio, int check_orientation,
+                                 int32_t* matches12, int32_t* nmatches) {
+    if (!m || !frame_ok(F1) || !frame_ok(F2) || !matches12 || !nmatches || (F1->n > 0 && !prev_matched))
+        return SO_ERR_INVALID_ARG;
+    if (check_orientation && ((F1->n > 0 && !F1->angle) || (F2->n > 0 && !F2->angle))) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    *nmatches = 0;
+    const int n1 = F1->n, n2 = F2->n;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return SO_OK;
+    constexpr int K = 8;
+    so_frame_view F2v = *F2;
+    F2v.excluded = nullptr;  // SearchForInitialization never looks at mvpMapPoints
+    int rc = upload_frame(m, &F2v, nullptr);
+    if (rc) return rc;
+    if ((rc = ensure_queries(m, n1))) return rc;
+    MatchQuery* hq = (MatchQuery*)m->h_q.p;
+    for (int i = 0; i < n1; i++) {
+        MatchQuery& q = hq[i];
+        const int level1 = F1->octave[i];
+        q.active = !(level1 > 0);  // :393-395
+        q.u = prev_matched[2 * i];
+        q.v = prev_matched[2 * i + 1];
+        q.r = (float)window;
+        q.min_level = level1;
+        q.max_level = level1;
+    }
+    memcpy(m->h_qdesc.p, F1->desc, (size_t)n1 * 32);
+    if ((rc = run_topk(m, n1, K))) return rc;
+    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)n1 * K);
+    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + n1);
+    std::vector<MatchQuery> queries(hq, hq + n1);
+    std::vector<int32_t> matched_dist((size_t)n2, INT_MAX);
+    std::vector<int32_t> matches21((size_t)n2, -1);
+    std::vector<int> rot_item, rot_b;
+    int hist[HISTO_LENGTH] = {0};
+    int nm = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (!queries[(size_t)i1].active || cnt[(size_t)i1] == 0) continue;
+        Entry e[2];
+        int found = 0, walked = 0;
+        for (; walked < K && found < 2; walked++) {
+            const uint32_t key = keys[(size_t)i1 * K + walked];
+            if (key == 0xFFFFFFFFu) break;
+            const int i2 = m->perm[(size_t)(key & 0xFFFFu)];
+            const int dist = (int)(key >> 16);
+            if (matched_dist[(size_t)i2] <= dist) continue;  // :413-414
+            e[found].idx = i2;
+            e[found].dist = dist;
+            found++;
+        }
+        if (found < 2 && walked == K && cnt[(size_t)i1] > K) {
+            if ((rc = rerun_single(m, queries[(size_t)i1], F1->desc + (size_t)i1 * 32, matched_dist, 2, e, &found)))
+                return rc;
+        }
+        if (found == 0) continue;
+        const int bestDist = e[0].dist, bestIdx2 = e[0].idx;
+        const int bestDist2 = found > 1 ? e[1].dist : INT_MAX;
+        if (bestDist <= TH_LOW) {
+            if ((float)bestDist < (float)bestDist2 * nn_ratio) {
+                if (matches21[(size_t)bestIdx2] >= 0) {
+                    matches12[matches21[(size_t)bestIdx2]] = -1;
+                    nm--;
+                }
+                matches12[i1] = bestIdx2;
+                matches21[(size_t)bestIdx2] = i1;
+                matched_dist[(size_t)bestIdx2] = bestDist;
+                nm++;
+                if (check_orientation) {
+                    const int b = rot_bin(F1->angle[i1], F2->angle[bestIdx2]);
+                    rot_item.push_back(i1);
+                    rot_b.push_back(b);
+                    hist[b]++;
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int a, b, c;
+        three_maxima(hist, HISTO_LENGTH, a, b, c);
+        for (size_t j = 0; j < rot_item.size(); j++) {
+            if (rot_b[j] == a || rot_b[j] == b || rot_b[j] == c) continue;
+            if (matches12[rot_item[j]] >= 0) {
+                matches12[rot_item[j]] = -1;
+                nm--;
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)  // :472-475
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = F2->x[matches12[i1]];
+            prev_matched[2 * i1 + 1] = F2->y[matches12[i1]];
+        }
+    *nmatches = nm;
+    return SO_OK;
+}
+
+static int top2_common(so_matcher* m, const uint4* dA, int na, const uint4* dB, int nb, int32_t* best_idx,
+                       int32_t* best_dist, int32_t* second_dist) {
+    if (nb >= (1 << 20)) return SO_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = m->d_res.ensure(sizeof(int32_t) * 3 * (size_t)na))) return rc;
+    if ((rc = m->h_res.ensure(sizeof(int32_t) * 3 * (size_t)na))) return rc;
+    int32_t* dr = (int32_t*)m->d_res.p;
+    hipStream_t s = m->stream;
+    SO_HIP(hipEventRecord(m->e0, s));
+    launch_hamming_top2(dA, na, dB, nb, dr, dr + na, dr + 2 * (size_t)na, s);
+    SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipMemcpyAsync(m->h_res.p, dr, sizeof(int32_t) * 3 * (size_t)na, hipMemcpyDeviceToHost, s));
+    SO_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms = ms;
+    const int32_t* hr = (const int32_t*)m->h_res.p;
+    memcpy(best_idx, hr, sizeof(int32_t) * (size_t)na);
+    memcpy(best_dist, hr + na, sizeof(int32_t) * (size_t)na);
+    memcpy(second_dist, hr + 2 * (size_t)na, sizeof(int32_t) * (size_t)na);
+    return SO_OK;
+}
+
+int so_hamming_top2(so_matcher* m, const uint8_t* A, int32_t na, const uint8_t* B, int32_t nb, int32_t* best_idx,
+                    int32_t* best_dist, int32_t* second_dist) {
+    if (!m || na < 0 || nb < 0 || (na > 0 && (!A || !best_idx || !best_dist || !second_dist)) || (nb > 0 && !B))
+        return SO_ERR_INVALID_ARG;
+    if (na == 0) return SO_OK;
+    SO_HIP(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->d_A.ensure((size_t)na * 32))) return rc;
+    if ((rc = m->d_B.ensure((size_t)(nb > 0 ? nb : 1) * 32))) return rc;
+    SO_HIP(hipMemcpyAsync(m->d_A.p, A, (size_t)na * 32, hipMemcpyHostToDevice, m->stream));
+    if (nb > 0) SO_HIP(hipMemcpyAsync(m->d_B.p, B, (size_t)nb * 32, hipMemcpyHostToDevice, m->stream));
+    return top2_common(m, (const uint4*)m->d_A.p, na, (const uint4*)m->d_B.p, nb, best_idx, best_dist, second_dist);
+}
+
+int so_hamming_top2_device(so_matcher* m, const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb,
+                           int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+    if (!m || na < 0 || nb < 0 || (na > 0 && (!d_A || !best_idx || !best_dist || !second_dist)) || (nb > 0 && !d_B))
+        return SO_ERR_INVALID_ARG;
+    if (na == 0) return SO_OK;
+    SO_HIP(hipSetDevice(m->device));
+    return top2_common(m, (const uint4*)d_A, na, (const uint4*)d_B, nb, best_idx, best_dist, second_dist);
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+"""Python mirror of ORB_SLAM2::ORBmatcher's tracking routines (code/include/ORBmatcher.h:41-83) over the C ABI.
+
+Frames and map points are passed as flat numpy arrays (FrameView / dicts); the object-graph side effects of
+the reference (F.mvpMapPoints[idx] = pMP) are represented by the returned assignment arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+FRAME_GRID_COLS, FRAME_GRID_ROWS = 64, 48  # code/include/Frame.h:37-38
+
+
+class SoFrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p),
+                ("angle", C.c_void_p), ("desc", C.c_void_p), ("excluded", C.c_void_p),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("scale_factors", C.c_void_p),
+                ("nlevels", C.c_int32)]
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class FrameView:
+    """The parts of ORB_SLAM2::Frame the matcher reads (mvKeysUn, mDescriptors, bounds, grid, scale factors)."""
+
+    def __init__(self, x, y, octave, angle, desc, bounds, scale_factors, excluded=None):
+        self.x = np.ascontiguousarray(x, np.float32)
+        self.y = np.ascontiguousarray(y, np.float32)
+        self.octave = np.ascontiguousarray(octave, np.int32)
+        self.angle = None if angle is None else np.ascontiguousarray(angle, np.float32)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.excluded = None if excluded is None else np.ascontiguousarray(excluded, np.uint8)
+        self.min_x, self.max_x, self.min_y, self.max_y = [np.float32(b) for b in bounds]
+        self.scale_factors = np.ascontiguousarray(scale_factors, np.float32)
+        self.n = len(self.x)
+        # Frame ctor, code/src/Frame.cc:259-260
+        self.grid_inv_w = np.float32(FRAME_GRID_COLS) / np.float32(self.max_x - self.min_x)
+        self.grid_inv_h = np.float32(FRAME_GRID_ROWS) / np.float32(self.max_y - self.min_y)
+
+    def as_struct(self, cls=SoFrameView):
+        return cls(self.n, _vp(self.x), _vp(self.y), _vp(self.octave), _vp(self.angle), _vp(self.desc),
+                   _vp(self.excluded), self.min_x, self.max_x, self.min_y, self.max_y, self.grid_inv_w,
+                   self.grid_inv_h, _vp(self.scale_factors), len(self.scale_factors))
+
+
+def _bind(lib):
+    vp, ip, f = C.c_void_p, C.POINTER(C.c_int32), C.c_float
+    fv = C.POINTER(SoFrameView)
+    lib.so_matcher_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.so_matcher_destroy.argtypes = [vp]
+    lib.so_matcher_destroy.restype = None
+    lib.so_search_by_projection_mappoints.argtypes = [vp, fv, C.c_int32, vp, vp, vp, vp, vp, vp, vp, f, f, vp, ip]
+    lib.so_search_by_projection_lastframe.argtypes = [vp, fv, C.c_int32, vp, vp, vp, vp, vp, vp, vp, f, C.c_int, vp, ip]
+    lib.so_search_for_initialization.argtypes = [vp, fv, fv, vp, C.c_int, f, C.c_int, vp, ip]
+    lib.so_matcher_topk.argtypes = [vp, fv, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
+    lib.so_hamming_top2.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, vp, vp]
+    lib.so_hamming_top2_device.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, vp, vp]
+    lib.so_matcher_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # code/src/ORBmatcher.cc:37-39
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self._lib = _lib.load_library()
+        _bind(self._lib)
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.so_matcher_create(int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.so_matcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """ORBmatcher::DescriptorDistance (ORBmatcher.cc:1511-1525) for one pair, on the host like the reference."""
+        x = np.bitwise_xor(np.frombuffer(np.ascontiguousarray(a, np.uint8), np.uint8),
+                           np.frombuffer(np.ascontiguousarray(b, np.uint8), np.uint8))
+        return int(np.unpackbits(x).sum())
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _lib.check(self._lib.so_matcher_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    # SearchByProjection(Frame&, const vector<MapPoint*>&, th) — ORBmatcher.cc:44-121
+    def SearchByProjectionMapPoints(self, F, mps, th=1.0):
+        n_mp = len(mps["proj_x"])
+        a = {k: np.ascontiguousarray(mps[k], t) for k, t in
+             (("in_view", np.uint8), ("proj_x", np.float32), ("proj_y", np.float32), ("view_cos", np.float32),
+              ("pred_level", np.int32), ("desc", np.uint8), ("has_obs", np.uint8))}
+        out = np.full(F.n, -1, np.int32)
+        nm = C.c_int32(0)
+        fs = F.as_struct()
+        _lib.check(self._lib.so_search_by_projection_mappoints(
+            self._h, C.byref(fs), n_mp, _vp(a["in_view"]), _vp(a["proj_x"]), _vp(a["proj_y"]), _vp(a["view_cos"]),
+            _vp(a["pred_level"]), _vp(a["desc"]), _vp(a["has_obs"]), th, self.mfNNratio, _vp(out), C.byref(nm)))
+        return nm.value, out
+
+    # SearchByProjection(Frame& cur, const Frame& last, th, bMono) — ORBmatcher.cc:1223-1354
+    def SearchByProjectionLastFrame(self, cur, last, th):
+        n = len(last["u"])
+        a = {k: np.ascontiguousarray(last[k], t) for k, t in
+             (("valid", np.uint8), ("u", np.float32), ("v", np.float32), ("octave", np.int32),
+              ("angle", np.float32), ("desc", np.uint8), ("has_obs", np.uint8))}
+        out = np.full(cur.n, -1, np.int32)
+        nm = C.c_int32(0)
+        fs = cur.as_struct()
+        _lib.check(self._lib.so_search_by_projection_lastframe(
+            self._h, C.byref(fs), n, _vp(a["valid"]), _vp(a["u"]), _vp(a["v"]), _vp(a["octave"]), _vp(a["angle"]),
+            _vp(a["desc"]), _vp(a["has_obs"]), th, int(self.mbCheckOrientation), _vp(out), C.byref(nm)))
+        return nm.value, out
+
+    # SearchForInitialization — ORBmatcher.cc:375-479
+    def SearchForInitialization(self, F1, F2, prev_matched, windowSize=10):
+        pm = np.ascontiguousarray(prev_matched, np.float32).reshape(-1, 2).copy()
+        out = np.full(F1.n, -1, np.int32)
+        nm = C.c_int32(0)
+        f1, f2 = F1.as_struct(), F2.as_struct()
+        _lib.check(self._lib.so_search_for_initialization(self._h, C.byref(f1), C.byref(f2), _vp(pm), int(windowSize),
+                                                           self.mfNNratio, int(self.mbCheckOrientation), _vp(out),
+                                                           C.byref(nm)))
+        return nm.value, out, pm
+
+    def topk(self, F, u, v, r, min_level, max_level, qdesc, K, active=None, limit=None):
+        nq = len(u)
+        u, v, r = [np.ascontiguousarray(t, np.float32) for t in (u, v, r)]
+        mn, mx = np.ascontiguousarray(min_level, np.int32), np.ascontiguousarray(max_level, np.int32)
+        qd = np.ascontiguousarray(qdesc, np.uint8)
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        lim = None if limit is None else np.ascontiguousarray(limit, np.int32)
+        idx = np.zeros((nq, K), np.int32)
+        dist = np.zeros((nq, K), np.int32)
+        cnt = np.zeros(nq, np.int32)
+        fs = F.as_struct()
+        _lib.check(self._lib.so_matcher_topk(self._h, C.byref(fs), _vp(lim), nq, _vp(u), _vp(v), _vp(r), _vp(mn),
+                                              _vp(mx), _vp(act), _vp(qd), K, _vp(idx), _vp(dist), _vp(cnt)))
+        return idx, dist, cnt
+
+    def hamming_top2(self, A, B):
+        A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32)
+        B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+        bi, bd, sd = [np.zeros(len(A), np.int32) for _ in range(3)]
+        _lib.check(self._lib.so_hamming_top2(self._h, _vp(A), len(A), _vp(B), len(B), _vp(bi), _vp(bd), _vp(sd)))
+        return bi, bd, sd
+
+    def hamming_top2_device(self, dA_ptr, na, dB_ptr, nb):
+        bi, bd, sd = [np.zeros(na, np.int32) for _ in range(3)]
+        _lib.check(self._lib.so_hamming_top2_device(self._h, C.c_void_p(dA_ptr), na, C.c_void_p(dB_ptr), nb,
+                                                     _vp(bi), _vp(bd), _vp(sd)))
+        return bi, bd, sd

@@ -1,0 +1,165 @@
+"""GPU parity of the HIP matcher against the CPU oracle, through the C ABI.  Integer work: bit-exact."""
+import numpy as np
+import pytest
+
+from swarmmap_amd import synth
+from swarmmap_amd.matcher import FrameView
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import swarmmap_amd
+    assert swarmmap_amd.device_count() > 0, "these tests need a GPU"
+    return swarmmap_amd
+
+
+def _frame(fr, excluded=True):
+    return FrameView(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["bounds"], fr["scale_factors"],
+                     fr.get("excluded") if excluded else None)
+
+
+@pytest.mark.parametrize("seed,n_kp,n_mp,th,ratio", [(1, 1000, 2000, 1.0, 0.8), (2, 1000, 3000, 3.0, 0.8),
+                                                     (3, 2000, 3000, 5.0, 0.8), (4, 500, 300, 1.0, 0.6)])
+def test_m1_search_by_projection_mappoints(S, oracle, seed, n_kp, n_mp, th, ratio):
+    fr, mps = synth.make_m1_case(seed, n_kp, n_mp)
+    F = _frame(fr)
+    m = S.ORBmatcher(ratio)
+    nm, kp_to_mp = m.SearchByProjectionMapPoints(F, mps, th)
+    onm, okp = oracle.search_by_projection_mappoints(F, mps, th, ratio)
+    assert nm == onm and np.array_equal(kp_to_mp, okp)
+    assert nm > 0
+    m.close()
+
+
+@pytest.mark.parametrize("seed,th,ori", [(11, 15.0, True), (12, 30.0, True), (13, 7.0, False)])
+def test_m2_search_by_projection_lastframe(S, oracle, seed, th, ori):
+    fr, last = synth.make_m2_case(seed)
+    F = _frame(fr)
+    m = S.ORBmatcher(0.9, ori)
+    nm, kp_to_last = m.SearchByProjectionLastFrame(F, last, th)
+    onm, okp = oracle.search_by_projection_lastframe(F, last, th, ori)
+    assert nm == onm and np.array_equal(kp_to_last, okp)
+    assert nm > 50
+    m.close()
+
+
+@pytest.mark.parametrize("seed,n_kp,window", [(21, 2000, 100), (22, 1000, 50), (23, 4000, 100)])
+def test_m4_search_for_initialization(S, oracle, seed, n_kp, window):
+    f1, f2, prev = synth.make_m4_case(seed, n_kp)
+    F1, F2 = _frame(f1), _frame(f2)
+    m = S.ORBmatcher(0.9, True)
+    nm, m12, pm = m.SearchForInitialization(F1, F2, prev, window)
+    onm, om12, opm = oracle.search_for_initialization(F1, F2, prev, window, 0.9, True)
+    assert nm == onm and np.array_equal(m12, om12) and np.array_equal(pm, opm)
+    assert nm > 100
+    m.close()
+
+
+def test_exhausted_topk_list_is_rerun_on_gpu(S, oracle):
+    """A tight cluster: 40 near-identical keypoints, 40 map points all projecting onto it with a wide window, so
+    every later map point finds its whole K-list taken by earlier ones and needs the exact single-query re-run."""
+    rng = np.random.default_rng(5)
+    fr = synth.make_frame_arrays(rng, 600, dup_frac=0.0)
+    base = rng.integers(0, 256, 32).astype(np.uint8)
+    for k in range(40):
+        fr["x"][k] = 300 + rng.uniform(-6, 6)
+        fr["y"][k] = 200 + rng.uniform(-6, 6)
+        fr["octave"][k] = 1
+        fr["desc"][k] = synth.flip_bits(rng, base[None, :], 0.02)[0]
+    n_mp = 40
+    mps = dict(in_view=np.ones(n_mp, np.uint8), proj_x=np.full(n_mp, 300, np.float32),
+               proj_y=np.full(n_mp, 200, np.float32), view_cos=np.full(n_mp, 0.9, np.float32),
+               pred_level=np.full(n_mp, 1, np.int32), desc=synth.flip_bits(rng, np.tile(base, (n_mp, 1)), 0.02),
+               has_obs=np.ones(n_mp, np.uint8))
+    F = _frame(fr, excluded=False)
+    m = S.ORBmatcher(1.0)  # ratio 1.0: the ratio test never rejects, so all 40 get bound one after another
+    nm, kp_to_mp = m.SearchByProjectionMapPoints(F, mps, 5.0)
+    onm, okp = oracle.search_by_projection_mappoints(F, mps, 5.0, 1.0)
+    assert nm == onm and np.array_equal(kp_to_mp, okp)
+    assert nm >= 30
+    # same for the last-frame variant
+    last = dict(valid=np.ones(n_mp, np.uint8), u=mps["proj_x"], v=mps["proj_y"], octave=np.full(n_mp, 1, np.int32),
+                angle=np.zeros(n_mp, np.float32), desc=mps["desc"], has_obs=np.ones(n_mp, np.uint8))
+    nm2, k2 = m.SearchByProjectionLastFrame(F, last, 20.0)
+    onm2, ok2 = oracle.search_by_projection_lastframe(F, last, 20.0, True)
+    assert nm2 == onm2 and np.array_equal(k2, ok2)
+    m.close()
+
+
+def test_topk_building_block_matches_grid_scan(S, oracle):
+    rng = np.random.default_rng(9)
+    fr = synth.make_frame_arrays(rng, 1200)
+    F = _frame(fr, excluded=False)
+    nq = 200
+    u = rng.uniform(0, 752, nq).astype(np.float32)
+    v = rng.uniform(0, 480, nq).astype(np.float32)
+    r = rng.uniform(5, 150, nq).astype(np.float32)
+    mn = rng.integers(-1, 3, nq).astype(np.int32)
+    mx = rng.integers(-1, 8, nq).astype(np.int32)
+    qd = rng.integers(0, 256, (nq, 32)).astype(np.uint8)
+    m = S.ORBmatcher()
+    K = 6
+    idx, dist, cnt = m.topk(F, u, v, r, mn, mx, qd, K)
+    for i in range(nq):
+        cand = oracle.features_in_area(F, u[i], v[i], r[i], mn[i], mx[i])
+        assert cnt[i] == len(cand)
+        d = np.array([oracle.descriptor_distance(qd[i], fr["desc"][c]) for c in cand], np.int64)
+        order = np.argsort(d, kind="stable")[:K]  # stable: ties keep grid-traversal order
+        want_idx = cand[order].tolist() + [-1] * (K - len(order))
+        want_d = d[order].tolist() + [256] * (K - len(order))
+        assert idx[i].tolist() == want_idx and dist[i].tolist() == want_d
+    # a window bigger than the LDS list (brute force over everything) takes the exact re-scan path
+    big = synth.make_frame_arrays(rng, 3000, dup_frac=0.0)
+    FB = _frame(big, excluded=False)
+    idx, dist, cnt = m.topk(FB, [376.0], [240.0], [5000.0], [-1], [-1], qd[:1], 5)
+    in_grid = len(oracle.features_in_area(FB, 376.0, 240.0, 5000.0, -1, -1))
+    assert cnt[0] == in_grid and in_grid > 1024
+    cand = oracle.features_in_area(FB, 376.0, 240.0, 5000.0, -1, -1)
+    d = np.array([oracle.descriptor_distance(qd[0], big["desc"][c]) for c in cand])
+    order = np.argsort(d, kind="stable")[:5]
+    assert idx[0].tolist() == cand[order].tolist() and dist[0].tolist() == d[order].tolist()
+    m.close()
+
+
+@pytest.mark.parametrize("na,nb", [(1000, 2000), (37, 5), (3, 0), (2000, 16000)])
+def test_bruteforce_top2(S, oracle, na, nb):
+    rng = np.random.default_rng(na + nb)
+    B = rng.integers(0, 256, (nb, 32)).astype(np.uint8)
+    if nb:
+        A = synth.flip_bits(rng, B[rng.integers(0, nb, na)], 0.15)
+        A[::7] = B[rng.integers(0, nb, len(A[::7]))]  # exact duplicates -> distance 0 and ties
+    else:
+        A = rng.integers(0, 256, (na, 32)).astype(np.uint8)
+    m = S.ORBmatcher()
+    bi, bd, sd = m.hamming_top2(A, B)
+    obi, obd, osd = oracle.hamming_top2(A, B)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+    if nb:
+        import torch
+        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        torch.cuda.synchronize()
+        bi2, bd2, sd2 = m.hamming_top2_device(dA.data_ptr(), na, dB.data_ptr(), nb)
+        assert np.array_equal(bi2, obi) and np.array_equal(bd2, obd) and np.array_equal(sd2, osd)
+    m.close()
+
+
+def test_matcher_edge_cases(S, oracle):
+    rng = np.random.default_rng(2)
+    fr = synth.make_frame_arrays(rng, 50)
+    F = _frame(fr, excluded=False)
+    m = S.ORBmatcher(0.8)
+    empty = dict(in_view=np.zeros(0, np.uint8), proj_x=np.zeros(0, np.float32), proj_y=np.zeros(0, np.float32),
+                 view_cos=np.zeros(0, np.float32), pred_level=np.zeros(0, np.int32),
+                 desc=np.zeros((0, 32), np.uint8), has_obs=np.zeros(0, np.uint8))
+    nm, k = m.SearchByProjectionMapPoints(F, empty, 1.0)
+    assert nm == 0 and np.all(k == -1)
+    # every query out of view / projected far outside the image
+    fr2, mps = synth.make_m1_case(8, 300, 200)
+    mps["proj_x"][:] = 5000.0
+    F2 = _frame(fr2)
+    nm, k = m.SearchByProjectionMapPoints(F2, mps, 1.0)
+    onm, ok = oracle.search_by_projection_mappoints(F2, mps, 1.0, 0.8)
+    assert nm == onm == 0 and np.array_equal(k, ok)
+    m.close()
