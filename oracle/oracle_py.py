@@ -235,3 +235,55 @@ def hamming_top2(A, B):
     bi, bd, sd = [np.zeros(len(A), np.int32) for _ in range(3)]
     lib().orc_hamming_top2(_p(A), len(A), _p(B), len(B), _p(bi), _p(bd), _p(sd))
     return bi, bd, sd
+
+
+# ------------------------------------------------------------------------------------------------
+# bundle-adjustment oracle (ba_oracle.c)
+# ------------------------------------------------------------------------------------------------
+class OrcBaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("Tcw", C.c_void_p), ("fixed", C.c_void_p), ("intr", C.c_void_p),
+                ("n_points", C.c_int32), ("Xw", C.c_void_p), ("n_edges", C.c_int32), ("edge_pose", C.c_void_p),
+                ("edge_point", C.c_void_p), ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p)]
+
+
+class OrcBaOptions(C.Structure):
+    _fields_ = [("its_stage1", C.c_int32), ("its_stage2", C.c_int32), ("robust", C.c_int32),
+                ("huber_delta", C.c_float), ("chi2_threshold", C.c_float)]
+
+
+class OrcBaInfo(C.Structure):
+    _fields_ = [("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+                ("iterations_stage1", C.c_int32), ("iterations_stage2", C.c_int32), ("lm_trials", C.c_int32),
+                ("aborted", C.c_int32), ("n_outliers", C.c_int32)]
+
+
+def ba_arrays(prob):
+    """Normalise a problem dict (see swarmmap_amd.synth.make_ba_problem) to contiguous arrays of the ABI dtypes."""
+    return dict(Tcw=np.ascontiguousarray(prob["Tcw"], np.float32).reshape(-1, 12),
+                fixed=np.ascontiguousarray(prob["fixed"], np.uint8),
+                intr=np.ascontiguousarray(prob["intr"], np.float32).reshape(-1, 4),
+                Xw=np.ascontiguousarray(prob["Xw"], np.float32).reshape(-1, 3),
+                edge_pose=np.ascontiguousarray(prob["edge_pose"], np.int32),
+                edge_point=np.ascontiguousarray(prob["edge_point"], np.int32),
+                obs=np.ascontiguousarray(prob["obs"], np.float32).reshape(-1, 2),
+                inv_sigma2=np.ascontiguousarray(prob["inv_sigma2"], np.float32))
+
+
+def bundle_adjust(prob, its1=5, its2=10, robust=True, huber_delta=None, chi2_threshold=5.991, stop=None):
+    """Optimizer::LocalBundleAdjustment (its2 > 0) / BundleAdjustment (its2 == 0) on a flattened problem."""
+    a = ba_arrays(prob)
+    P = OrcBaProblem(len(a["Tcw"]), _p(a["Tcw"]), _p(a["fixed"]), _p(a["intr"]), len(a["Xw"]), _p(a["Xw"]),
+                     len(a["edge_pose"]), _p(a["edge_pose"]), _p(a["edge_point"]), _p(a["obs"]), _p(a["inv_sigma2"]))
+    if huber_delta is None:
+        huber_delta = np.float32(np.sqrt(5.991))  # const float thHuberMono = sqrt(5.991), Optimizer.cc:547
+    O = OrcBaOptions(its1, its2, int(robust), float(huber_delta), float(chi2_threshold))
+    Tout = np.zeros_like(a["Tcw"])
+    Xout = np.zeros_like(a["Xw"])
+    outl = np.zeros(len(a["edge_pose"]), np.uint8)
+    chi2 = np.zeros(len(a["edge_pose"]), np.float64)
+    info = OrcBaInfo()
+    stop_p = None if stop is None else stop.ctypes.data_as(C.c_void_p)
+    rc = lib().orc_bundle_adjust(C.byref(P), C.byref(O), stop_p, _p(Tout), _p(Xout), _p(outl), _p(chi2), C.byref(info))
+    assert rc == 0
+    return dict(Tcw=Tout, Xw=Xout, outlier=outl, chi2=chi2,
+                info={k: getattr(info, k) for k, _ in OrcBaInfo._fields_})

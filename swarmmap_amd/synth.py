@@ -141,3 +141,87 @@ def make_m4_case(seed, n_kp=2000, p_flip=0.05, size=EUROC, shift=(12.0, -7.0)):
               scale_factors=f1["scale_factors"])
     prev = np.stack([f1["x"], f1["y"]], 1).astype(np.float32)
     return f1, f2, prev
+
+
+# ------------------------------------------------------------------------------------------------
+# bundle-adjustment windows: LBA-S / LBA-M / LBA-L / GBA-1 / GBA-2
+# ------------------------------------------------------------------------------------------------
+EUROC_K = (458.654, 457.296, 367.215, 248.375)  # code/Examples/Monocular/EuRoC.yaml
+BA_CASES = {  # name: (free KFs, fixed KFs, points)
+    "LBA-S": (8, 10, 800), "LBA-M": (25, 40, 3000), "LBA-L": (40, 60, 6000),
+    "GBA-1": (299, 1, 30000), "GBA-2": (1499, 1, 120000),
+}
+
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def make_ba_problem(seed, n_free=8, n_fixed=10, n_points=800, size=EUROC, K=EUROC_K, pixel_sigma=1.0,
+                    outlier_frac=0.05, pose_noise=(0.02, 0.5), point_noise=0.03, max_obs=None):
+    """A seeded local-BA window: cameras on an arc looking at a point cloud; returns the flattened problem
+    (float32 like the map stores it) plus the generating ground truth."""
+    rng = np.random.default_rng(seed)
+    n_poses = n_free + n_fixed
+    w, h = size
+    fx, fy, cx, cy = K
+    Rs, ts = [], []
+    for i in range(n_poses):  # camera centres on a slowly advancing arc, all looking towards +z
+        c = np.array([0.25 * i - 0.125 * n_poses + rng.normal(0, 0.05), rng.normal(0, 0.08), rng.normal(0, 0.1)])
+        R = _rodrigues(np.array([rng.normal(0, 0.03), 0.02 * (i - n_poses / 2) + rng.normal(0, 0.02),
+                                 rng.normal(0, 0.02)]))
+        Rs.append(R)  # Rcw
+        ts.append(-R @ c)
+    X = np.stack([rng.uniform(-0.15 * n_poses - 2, 0.15 * n_poses + 2, n_points), rng.uniform(-2, 2, n_points),
+                  rng.uniform(3, 12, n_points)], 1)
+    scale = 1.2 ** np.arange(8)
+    e_pose, e_pt, obs, inv_s2, is_out = [], [], [], [], []
+    order = np.arange(n_poses)
+    for j in range(n_points):
+        rng.shuffle(order)  # the reference iterates a std::map<KeyFrame*,...>: arbitrary keyframe order
+        seen = 0
+        cap = int(rng.integers(3, 11)) if max_obs == "auto" else max_obs
+        for i in order:
+            pc = Rs[i] @ X[j] + ts[i]
+            if pc[2] < 0.5:
+                continue
+            u, v = fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy
+            if not (20 < u < w - 20 and 20 < v < h - 20):
+                continue
+            if cap is not None and seen >= cap:
+                break
+            octave = int(np.clip(np.floor(np.log(pc[2] / 3.0) / np.log(1.2)), 0, 7))
+            noise = rng.normal(0, pixel_sigma * scale[octave], 2)
+            out = rng.random() < outlier_frac
+            if out:
+                noise = rng.uniform(-40, 40, 2)
+            e_pose.append(i); e_pt.append(j); obs.append([u + noise[0], v + noise[1]])
+            inv_s2.append(1.0 / (scale[octave] ** 2)); is_out.append(out)
+            seen += 1
+    e_pose, e_pt = np.array(e_pose, np.int32), np.array(e_pt, np.int32)
+    # poses sorted by "mnId": free keyframes are the most recent ones -> highest ids; keep the first one fixed
+    fixed = np.zeros(n_poses, np.uint8)
+    fixed[:n_fixed] = 1
+    Tcw_gt = np.stack([np.hstack([Rs[i], ts[i][:, None]]).reshape(12) for i in range(n_poses)])
+    Tcw0 = Tcw_gt.copy()
+    for i in range(n_poses):
+        if fixed[i]:
+            continue
+        dR = _rodrigues(rng.normal(0, np.deg2rad(pose_noise[1]), 3))
+        T = np.hstack([dR @ Rs[i], (dR @ ts[i] + rng.normal(0, pose_noise[0], 3))[:, None]])
+        Tcw0[i] = T.reshape(12)
+    X0 = X + rng.normal(0, point_noise, X.shape)
+    return dict(Tcw=Tcw0.astype(np.float32), fixed=fixed, intr=np.tile(np.array(K, np.float32), (n_poses, 1)),
+                Xw=X0.astype(np.float32), edge_pose=e_pose, edge_point=e_pt, obs=np.array(obs, np.float32),
+                inv_sigma2=np.array(inv_s2, np.float32), gt_Tcw=Tcw_gt, gt_Xw=X, gt_outlier=np.array(is_out, bool))
+
+
+def make_ba_case(name, seed=0, **kw):
+    nf, nx, npnt = BA_CASES[name]
+    kw.setdefault("max_obs", "auto")  # ~6.5 observations per point -> the edge counts of SURVEY.md 8d
+    return make_ba_problem(seed, nf, nx, npnt, **kw)

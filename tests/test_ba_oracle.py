@@ -1,0 +1,153 @@
+"""CPU tests that pin the BA oracle (SURVEY.md 8c (6),(7)): the reference's g2o cannot be built here (Eigen is
+absent), so the restated pieces are checked against independent mathematics."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.linalg import expm
+from scipy.optimize import least_squares
+
+from swarmmap_amd import synth
+
+
+def _d(a):
+    return np.ascontiguousarray(a, np.float64).ctypes.data_as(C.c_void_p)
+
+
+def _T_from(lib, q, t):
+    out = np.zeros(12, np.float32)
+    lib.orc_se3_to_Tcw(_d(q), _d(t), out.ctypes.data_as(C.c_void_p))
+    return out.reshape(3, 4).astype(np.float64)
+
+
+def _quat_from_T(lib, T12):
+    q, t = np.zeros(4), np.zeros(3)
+    lib.orc_se3_from_Tcw(np.ascontiguousarray(T12, np.float32).ctypes.data_as(C.c_void_p), _d(q), _d(t))
+    return q, t
+
+
+def test_huber_formulas(oracle):
+    lib = oracle.lib()
+    lib.orc_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
+    delta = float(np.float32(np.sqrt(5.991)))
+    dsqr = float(np.float32(delta * delta))  # stored as float in the reference
+    rho = np.zeros(3)
+    for e in (0.0, 1.0, dsqr, dsqr * 1.0000001, 6.0, 50.0, 1e4):
+        lib.orc_huber(e, delta, _d(rho))
+        if e <= dsqr:
+            assert rho.tolist() == [e, 1.0, 0.0]
+        else:
+            assert rho[0] == pytest.approx(2 * np.sqrt(e) * delta - dsqr, rel=1e-15)
+            assert rho[1] == pytest.approx(delta / np.sqrt(e), rel=1e-15)
+            assert rho[2] == pytest.approx(-0.5 * rho[1] / e, rel=1e-15)
+
+
+def test_se3_exp_matches_matrix_exponential(oracle):
+    lib = oracle.lib()
+    rng = np.random.default_rng(0)
+    for scale in (1e-7, 1e-3, 0.3, 2.0):
+        u = rng.normal(0, scale, 6)
+        q, t = _quat_from_T(lib, np.hstack([synth._rodrigues(rng.normal(0, 0.5, 3)), rng.normal(0, 1, (3, 1))]).reshape(12))
+        T0 = np.vstack([_T_from(lib, q, t), [0, 0, 0, 1]])
+        lib.orc_se3_exp_mul(_d(u), _d(q), _d(t))  # in place (q, t are float64 arrays)
+        T1 = np.vstack([_T_from(lib, q, t), [0, 0, 0, 1]])
+        w, v = u[:3], u[3:]
+        xi = np.zeros((4, 4))
+        xi[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+        xi[:3, 3] = v
+        want = expm(xi) @ T0
+        assert np.abs(T1 - want).max() < 5e-7  # float32 round trip of the 3x4 output dominates
+
+
+def test_jacobians_match_central_differences(oracle):
+    lib = oracle.lib()
+    lib.orc_edge_project.restype = C.c_double
+    rng = np.random.default_rng(1)
+    intr = np.array(synth.EUROC_K, np.float64)
+    for _ in range(50):
+        R = synth._rodrigues(rng.normal(0, 0.15, 3))
+        t = rng.normal(0, 0.5, 3)
+        q, tt = _quat_from_T(lib, np.hstack([R, t[:, None]]).reshape(12))
+        X = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(3, 9)])
+        obs = rng.uniform(100, 400, 2)
+        err, Jp, Jc = np.zeros(2), np.zeros(6), np.zeros(12)
+        z = lib.orc_edge_project(_d(q), _d(tt), _d(X), _d(obs), _d(intr), _d(err), _d(Jp), _d(Jc))
+        assert z > 0
+
+        def err_at(dq=None, dX=None):
+            q2, t2, X2 = q.copy(), tt.copy(), X.copy()
+            if dq is not None:
+                lib.orc_se3_exp_mul(_d(dq), _d(q2), _d(t2))
+            if dX is not None:
+                X2 = X2 + dX
+            e = np.zeros(2)
+            lib.orc_edge_project(_d(q2), _d(t2), _d(X2), _d(obs), _d(intr), _d(e), None, None)
+            return e
+        h = 1e-6
+        num_p = np.stack([(err_at(dX=h * np.eye(3)[k]) - err_at(dX=-h * np.eye(3)[k])) / (2 * h) for k in range(3)], 1)
+        num_c = np.stack([(err_at(dq=h * np.eye(6)[k]) - err_at(dq=-h * np.eye(6)[k])) / (2 * h) for k in range(6)], 1)
+        assert np.abs(num_p - Jp.reshape(2, 3)).max() < 1e-4 * max(1.0, np.abs(Jp).max())
+        assert np.abs(num_c - Jc.reshape(2, 6)).max() < 1e-4 * max(1.0, np.abs(Jc).max())
+
+
+def test_noise_free_window_recovers_ground_truth(oracle):
+    p = synth.make_ba_problem(3, 6, 4, 300, pixel_sigma=0.0, outlier_frac=0.0, max_obs="auto")
+    r = oracle.bundle_adjust(p, its1=30, its2=0, robust=False)
+    assert r["info"]["chi2_final"] < 1e-3 * r["info"]["chi2_initial"]
+    free = p["fixed"] == 0
+    # gauge is fixed by the 4 fixed keyframes; float32 observations limit the attainable accuracy
+    assert np.abs(r["Tcw"][free] - p["gt_Tcw"][free]).max() < 2e-3
+    assert np.abs(r["Tcw"][~free] - p["Tcw"][~free]).max() < 1e-6
+
+
+def test_oracle_minimum_matches_independent_solver(oracle):
+    """Non-robust BA to convergence == scipy's trust-region least squares on the same residuals."""
+    p = synth.make_ba_problem(5, 3, 3, 60, outlier_frac=0.0, max_obs=6)
+    r = oracle.bundle_adjust(p, its1=60, its2=0, robust=False)
+    lib = oracle.lib()
+    a = oracle.ba_arrays(p)
+    free = np.nonzero(a["fixed"] == 0)[0]
+    q0 = [_quat_from_T(lib, a["Tcw"][i]) for i in range(len(a["Tcw"]))]
+    intr = a["intr"].astype(np.float64)
+    sq = np.sqrt(a["inv_sigma2"].astype(np.float64))
+
+    def residuals(x):
+        res = np.zeros((len(a["edge_pose"]), 2))
+        poses = [(q.copy(), t.copy()) for q, t in q0]
+        for k, i in enumerate(free):
+            lib.orc_se3_exp_mul(_d(x[6 * k:6 * k + 6]), _d(poses[i][0]), _d(poses[i][1]))
+        X = a["Xw"].astype(np.float64) + x[6 * len(free):].reshape(-1, 3)
+        e = np.zeros(2)
+        for n in range(len(res)):
+            ip = a["edge_pose"][n]
+            lib.orc_edge_project(_d(poses[ip][0]), _d(poses[ip][1]), _d(X[a["edge_point"][n]]),
+                                 _d(a["obs"][n].astype(np.float64)), _d(intr[ip]), _d(e), None, None)
+            res[n] = e * sq[n]
+        return res.ravel()
+    sol = least_squares(residuals, np.zeros(6 * len(free) + 3 * len(a["Xw"])), method="lm", xtol=1e-14, ftol=1e-14)
+    chi_scipy = float((sol.fun ** 2).sum())
+    assert r["info"]["chi2_final"] == pytest.approx(chi_scipy, rel=1e-6)
+    assert float(r["chi2"].sum()) == pytest.approx(chi_scipy, rel=1e-6)
+
+
+def test_two_stage_flags_gross_outliers(oracle):
+    p = synth.make_ba_case("LBA-S", 7)
+    r = oracle.bundle_adjust(p)  # optimize(5) -> outlier pass -> optimize(10)
+    gt = p["gt_outlier"]
+    flagged = r["outlier"].astype(bool)
+    assert (flagged & gt).sum() >= 0.9 * gt.sum()  # gross (40 px) outliers are caught
+    assert r["info"]["chi2_final"] < 0.25 * r["info"]["chi2_initial"]
+    free = p["fixed"] == 0
+    assert np.abs(r["Tcw"][free] - p["gt_Tcw"][free]).max() < 0.6 * np.abs(p["Tcw"][free] - p["gt_Tcw"][free]).max()
+    # deterministic
+    r2 = oracle.bundle_adjust(p)
+    assert np.array_equal(r["Tcw"], r2["Tcw"]) and np.array_equal(r["Xw"], r2["Xw"])
+
+
+def test_stop_flag_semantics(oracle):
+    p = synth.make_ba_case("LBA-S", 2)
+    stop = np.ones(1, np.uint8)
+    r = oracle.bundle_adjust(p, stop=stop)  # Optimizer.cc:631-633: return before optimising
+    assert r["info"]["aborted"] == 1 and r["info"]["lm_trials"] == 0
+    assert np.abs(r["Xw"] - p["Xw"]).max() == 0 and r["outlier"].sum() == 0
+    assert np.abs(r["Tcw"] - p["Tcw"]).max() < 1e-6  # only the quaternion round trip
