@@ -173,6 +173,66 @@ int so_hamming_top2_device(so_matcher* m, const uint8_t* d_A, int32_t na, const 
 /* HIP-event time (ms) of the kernels of the last matcher call on the matcher's stream. */
 int so_matcher_last_kernel_ms(so_matcher* m, float* ms);
 
+/* ------------------------------------------------------------------------------------------------
+ * Bundle adjustment — replaces Optimizer::LocalBundleAdjustment / BundleAdjustment / GlobalBundleAdjustment
+ * (code/include/Optimizer.h:41-46, code/src/Optimizer.cc:42-237,436-740) and the g2o machinery they drive
+ * (OptimizationAlgorithmLevenberg, BlockSolver_6_3 with Schur complement, LinearSolverEigen, RobustKernelHuber,
+ * EdgeSE3ProjectXYZ, VertexSE3Expmap, VertexSBAPointXYZ; code/Thirdparty/g2o/g2o/...) on a FLATTENED problem.
+ * The caller's adapter gathers the local window from the KeyFrame/MapPoint graph (Optimizer.cc:437-482) and
+ * writes the results back under the map mutex (Optimizer.cc:713-739); everything in between runs here, on
+ * the GPU in FP64.  Map storage types cross the boundary unchanged (float poses / points / observations).
+ * Monocular edges only, which is all SwarmMap builds.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct so_ba so_ba;
+
+typedef struct {
+    int32_t n_poses;       /* keyframe vertices, ascending vertex id (KeyFrame::mnId): defines the Hessian order */
+    const float* Tcw;      /* n_poses x 12, row-major [R|t] of KeyFrame::GetPose() */
+    const uint8_t* fixed;  /* n_poses: vSE3->setFixed(...) (fixed keyframes and pKFi->isFirst()) */
+    const float* intr;     /* n_poses x 4: fx, fy, cx, cy */
+    int32_t n_points;      /* map point vertices, ascending vertex id */
+    const float* Xw;       /* n_points x 3, MapPoint::GetWorldPos() */
+    int32_t n_edges;       /* EdgeSE3ProjectXYZ in insertion order */
+    const int32_t* edge_pose;
+    const int32_t* edge_point;
+    const float* obs;         /* n_edges x 2: kpUn.pt */
+    const float* inv_sigma2;  /* n_edges: pKFi->mvInvLevelSigma2[kpUn.octave] */
+} so_ba_problem;
+
+typedef struct {
+    int32_t its_stage1;   /* optimizer.optimize(5)  (LocalBA) / optimize(nIterations) (BundleAdjustment) */
+    int32_t its_stage2;   /* optimizer.optimize(10) after the outlier pass; 0 = single stage */
+    int32_t robust;       /* Huber kernel in stage 1 (bRobust) */
+    float huber_delta;    /* sqrt(5.991) as float */
+    float chi2_threshold; /* 5.991 */
+} so_ba_options;
+
+typedef struct {
+    double chi2_initial, chi2_final;
+    double lambda_final;
+    int32_t iterations_stage1, iterations_stage2;
+    int32_t lm_trials;
+    int32_t aborted;    /* *stop was observed set */
+    int32_t n_outliers;
+    float gpu_ms;       /* HIP-event time from the first to the last kernel of the call */
+    float wall_ms;      /* host wall time of the call */
+} so_ba_info;
+
+int so_ba_create(int device, so_ba** out);
+void so_ba_destroy(so_ba* ba);
+/* LocalBundleAdjustment's schedule: {5, 10, robust, sqrt(5.991)f, 5.991f} (Optimizer.cc:547,635-660) */
+void so_ba_options_local(so_ba_options* opt);
+/* BundleAdjustment's schedule: one stage of n_iterations, optional Huber (Optimizer.cc:49-52,190-192) */
+void so_ba_options_global(so_ba_options* opt, int32_t n_iterations, int32_t robust);
+
+/* stop: the reference's bool* pbStopFlag (may be NULL); polled between LM iterations and trials.
+ * Outputs: Tcw_out n_poses x 12 (Converter::toCvMat of every pose vertex), Xw_out n_points x 3,
+ * edge_outlier n_edges (e->chi2() > threshold || !e->isDepthPositive(), Optimizer.cc:682-695),
+ * edge_chi2 n_edges (may be NULL). */
+int so_bundle_adjust(so_ba* ba, const so_ba_problem* problem, const so_ba_options* options,
+                     const volatile uint8_t* stop, float* Tcw_out, float* Xw_out, uint8_t* edge_outlier,
+                     double* edge_chi2, so_ba_info* info);
+
 #ifdef __cplusplus
 }
 #endif

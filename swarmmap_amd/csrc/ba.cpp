@@ -1,0 +1,627 @@
+// ba.cpp — host driver + C ABI of the bundle-adjustment solver (include/swarmorb.h).
+//
+// Replaces Optimizer::LocalBundleAdjustment / BundleAdjustment (code/src/Optimizer.cc:42-237,436-740) from
+// "build g2o graph" to "recover optimized data", on a flattened problem.  The Levenberg-Marquardt control
+// flow (code/Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-164, sparse_optimizer.cpp:354-419)
+// runs on the host and reads back three scalars per trial (chi2, scale, solve-ok); all arithmetic on residuals,
+// Jacobians, the Schur complement, the reduced solve and the manifold updates runs in the kernels of
+// ba_kernels.hip.  Estimates live in a current/trial buffer pair, so g2o's push/pop/discardTop is a pointer swap.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "ba_device.h"
+#include "so_common.h"
+
+using namespace so;
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SO_OK;
+        if (p) SO_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        SO_HIP(hipMalloc(&p, want));
+        cap = want;
+        return SO_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+constexpr int kMaxReducedDim = 6144;  // dense reduced camera system: 6 * n_free <= this (301 MB of FP64)
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- host copies of the SE3Quat conversions at the map boundary (Converter.cc:37-47,49-74; se3quat.h:58-60) ----
+void quat_from_R(const double* R, double* q) {  // Eigen::Quaterniond(Matrix3d), published algorithm
+    double t = R[0] + R[4] + R[8];
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t;
+        q[1] = (R[2] - R[6]) * t;
+        q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    }
+}
+
+void pose_from_Tcw(const float* T, BaPose& P) {
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    quat_from_R(R, P.q);
+    if (P.q[3] < 0) for (double& v : P.q) v = -v;  // normalizeRotation
+    const double n = std::sqrt(P.q[0] * P.q[0] + P.q[1] * P.q[1] + P.q[2] * P.q[2] + P.q[3] * P.q[3]);
+    for (double& v : P.q) v /= n;
+    P.t[0] = T[3];
+    P.t[1] = T[7];
+    P.t[2] = T[11];
+    P.pad = 0;
+}
+
+void pose_to_Tcw(const BaPose& P, float* T) {  // to_homogeneous_matrix cast to float
+    const double* q = P.q;
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    T[0] = (float)(1 - (tyy + tzz)); T[1] = (float)(txy - twz);       T[2] = (float)(txz + twy);        T[3] = (float)P.t[0];
+    T[4] = (float)(txy + twz);       T[5] = (float)(1 - (txx + tzz)); T[6] = (float)(tyz - twx);        T[7] = (float)P.t[1];
+    T[8] = (float)(txz - twy);       T[9] = (float)(tyz + twx);       T[10] = (float)(1 - (txx + tyy)); T[11] = (float)P.t[2];
+}
+
+}  // namespace
+
+struct so_ba {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+
+    Buf d_pose[2], d_pt[2], d_intr, d_epose, d_ept, d_obs, d_w, d_active, d_err, d_chi2, d_ptoff, d_ptact, d_hidx,
+        d_freepose, d_poseoff, d_poseedges, d_blkoff, d_blki1, d_blki2, d_pk1, d_pk2, d_Hpp, d_bp, d_Hll, d_bl, d_W,
+        d_Dinv, d_db, d_BDinv, d_S, d_bs, d_xl, d_partial, d_depth;
+    double* h_partial = nullptr;  // pinned
+    std::vector<Buf*> all() {
+        return {&d_pose[0], &d_pose[1], &d_pt[0], &d_pt[1], &d_intr, &d_epose, &d_ept, &d_obs, &d_w, &d_active, &d_err,
+                &d_chi2, &d_ptoff, &d_ptact, &d_hidx, &d_freepose, &d_poseoff, &d_poseedges, &d_blkoff, &d_blki1,
+                &d_blki2, &d_pk1, &d_pk2, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv, &d_db, &d_BDinv, &d_S, &d_bs,
+                &d_xl, &d_partial, &d_depth};
+    }
+};
+
+namespace {
+
+template <typename T>
+int upload(so_ba* b, Buf& buf, const std::vector<T>& v) {
+    int rc = buf.ensure(sizeof(T) * std::max<size_t>(v.size(), 1));
+    if (rc) return rc;
+    if (!v.empty()) SO_HIP(hipMemcpyAsync(buf.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, b->stream));
+    return SO_OK;
+}
+
+struct Problem {  // host-side working copy, edges sorted by point
+    int n_poses = 0, n_points = 0, n_edges = 0;
+    std::vector<int> perm;  // sorted position -> original edge index
+    std::vector<int> e_pose, e_point;
+    std::vector<int> pt_off;
+    std::vector<uint8_t> fixed;
+    std::vector<int> level;  // per sorted edge
+};
+
+struct Stage {
+    int n_free = 0, n_blk = 0, n_active_edges = 0;
+    std::vector<uint8_t> e_active, pt_active;
+    std::vector<int> pose_hidx, free_pose, pose_off, pose_edges, blk_off, blk_i1, blk_i2, pair_k1, pair_k2;
+};
+
+// SparseOptimizer::initializeOptimization(0) + buildIndexMapping (sparse_optimizer.cpp:166-270) and the CSR
+// lists the kernels reduce over.
+void build_stage(const Problem& P, Stage& S) {
+    S.e_active.assign((size_t)P.n_edges, 0);
+    S.pt_active.assign((size_t)P.n_points, 0);
+    std::vector<uint8_t> pose_touched((size_t)P.n_poses, 0);
+    S.n_active_edges = 0;
+    for (int e = 0; e < P.n_edges; e++)
+        if (P.level[(size_t)e] == 0) {
+            S.e_active[(size_t)e] = 1;
+            S.pt_active[(size_t)P.e_point[(size_t)e]] = 1;
+            pose_touched[(size_t)P.e_pose[(size_t)e]] = 1;
+            S.n_active_edges++;
+        }
+    S.pose_hidx.assign((size_t)P.n_poses, -1);
+    S.free_pose.clear();
+    for (int i = 0; i < P.n_poses; i++)
+        if (pose_touched[(size_t)i] && !P.fixed[(size_t)i]) {
+            S.pose_hidx[(size_t)i] = (int)S.free_pose.size();
+            S.free_pose.push_back(i);
+        }
+    S.n_free = (int)S.free_pose.size();
+    // free pose -> active edges (ascending sorted-edge index)
+    S.pose_off.assign((size_t)S.n_free + 1, 0);
+    for (int e = 0; e < P.n_edges; e++)
+        if (S.e_active[(size_t)e]) {
+            const int h = S.pose_hidx[(size_t)P.e_pose[(size_t)e]];
+            if (h >= 0) S.pose_off[(size_t)h + 1]++;
+        }
+    for (int i = 0; i < S.n_free; i++) S.pose_off[(size_t)i + 1] += S.pose_off[(size_t)i];
+    S.pose_edges.assign((size_t)S.pose_off[(size_t)S.n_free], 0);
+    {
+        std::vector<int> fill(S.pose_off.begin(), S.pose_off.end() - 1);
+        for (int e = 0; e < P.n_edges; e++)
+            if (S.e_active[(size_t)e]) {
+                const int h = S.pose_hidx[(size_t)P.e_pose[(size_t)e]];
+                if (h >= 0) S.pose_edges[(size_t)fill[(size_t)h]++] = e;
+            }
+    }
+    // upper blocks of the reduced camera system and the edge pairs that feed them
+    const int nf = S.n_free;
+    S.n_blk = nf * (nf + 1) / 2;
+    S.blk_i1.resize((size_t)S.n_blk);
+    S.blk_i2.resize((size_t)S.n_blk);
+    {
+        int g = 0;
+        for (int i1 = 0; i1 < nf; i1++)
+            for (int i2 = i1; i2 < nf; i2++, g++) {
+                S.blk_i1[(size_t)g] = i1;
+                S.blk_i2[(size_t)g] = i2;
+            }
+    }
+    auto blk_id = [nf](int i1, int i2) { return i1 * nf - i1 * (i1 - 1) / 2 + (i2 - i1); };
+    S.blk_off.assign((size_t)S.n_blk + 1, 0);
+    std::vector<std::pair<int, int>> obs;  // (hessian index, edge) of one landmark
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<int> fill;
+        if (pass == 1) {
+            for (int g = 0; g < S.n_blk; g++) S.blk_off[(size_t)g + 1] += S.blk_off[(size_t)g];
+            S.pair_k1.assign((size_t)S.blk_off[(size_t)S.n_blk], 0);
+            S.pair_k2.assign((size_t)S.blk_off[(size_t)S.n_blk], 0);
+            fill.assign(S.blk_off.begin(), S.blk_off.end() - 1);
+        }
+        for (int il = 0; il < P.n_points; il++) {
+            if (!S.pt_active[(size_t)il]) continue;
+            obs.clear();
+            for (int e = P.pt_off[(size_t)il]; e < P.pt_off[(size_t)il + 1]; e++)
+                if (S.e_active[(size_t)e]) {
+                    const int h = S.pose_hidx[(size_t)P.e_pose[(size_t)e]];
+                    if (h >= 0) obs.emplace_back(h, e);
+                }
+            std::sort(obs.begin(), obs.end());
+            for (size_t a = 0; a < obs.size(); a++)
+                for (size_t c = a; c < obs.size(); c++) {
+                    const int g = blk_id(obs[a].first, obs[c].first);
+                    if (pass == 0) {
+                        S.blk_off[(size_t)g + 1]++;
+                    } else {
+                        const int o = fill[(size_t)g]++;
+                        S.pair_k1[(size_t)o] = obs[a].second;
+                        S.pair_k2[(size_t)o] = obs[c].second;
+                    }
+                }
+        }
+    }
+}
+
+struct Run {
+    so_ba* b;
+    BaDev d{};
+    Problem P;
+    Stage S;
+    int cur = 0;  // index of the "current" estimate buffers
+    int nb_err = 1, nb_upd = 1;
+    double lambda = -1.0, ni = 2.0;
+    int nBad = 0, trials = 0;
+    const volatile uint8_t* stop = nullptr;
+    bool terminate() const { return stop && *stop; }
+    BaPose* poses(int which) { return b->d_pose[which].as<BaPose>(); }
+    double* points(int which) { return b->d_pt[which].as<double>(); }
+};
+
+int upload_stage(Run& r) {
+    so_ba* b = r.b;
+    Stage& S = r.S;
+    int rc;
+    if ((rc = upload(b, b->d_active, S.e_active))) return rc;
+    if ((rc = upload(b, b->d_ptact, S.pt_active))) return rc;
+    if ((rc = upload(b, b->d_hidx, S.pose_hidx))) return rc;
+    if ((rc = upload(b, b->d_freepose, S.free_pose))) return rc;
+    if ((rc = upload(b, b->d_poseoff, S.pose_off))) return rc;
+    if ((rc = upload(b, b->d_poseedges, S.pose_edges))) return rc;
+    if ((rc = upload(b, b->d_blkoff, S.blk_off))) return rc;
+    if ((rc = upload(b, b->d_blki1, S.blk_i1))) return rc;
+    if ((rc = upload(b, b->d_blki2, S.blk_i2))) return rc;
+    if ((rc = upload(b, b->d_pk1, S.pair_k1))) return rc;
+    if ((rc = upload(b, b->d_pk2, S.pair_k2))) return rc;
+    const size_t nf = (size_t)std::max(S.n_free, 1), n = 6 * nf;
+    if ((rc = b->d_Hpp.ensure(sizeof(double) * 36 * nf))) return rc;
+    if ((rc = b->d_bp.ensure(sizeof(double) * 6 * nf))) return rc;
+    if ((rc = b->d_S.ensure(sizeof(double) * n * n))) return rc;
+    if ((rc = b->d_bs.ensure(sizeof(double) * n))) return rc;
+    BaDev& d = r.d;
+    d.n_free = S.n_free;
+    d.e_active = b->d_active.as<uint8_t>();
+    d.pt_active = b->d_ptact.as<uint8_t>();
+    d.pose_hidx = b->d_hidx.as<int>();
+    d.free_pose = b->d_freepose.as<int>();
+    d.pose_off = b->d_poseoff.as<int>();
+    d.pose_edges = b->d_poseedges.as<int>();
+    d.blk_off = b->d_blkoff.as<int>();
+    d.pair_k1 = b->d_pk1.as<int>();
+    d.pair_k2 = b->d_pk2.as<int>();
+    d.Hpp = b->d_Hpp.as<double>();
+    d.bp = b->d_bp.as<double>();
+    d.S = b->d_S.as<double>();
+    d.bs = b->d_bs.as<double>();
+    return SO_OK;
+}
+
+int fetch_partials(Run& r) {
+    SO_HIP(hipMemcpyAsync(r.b->h_partial, r.b->d_partial.p, sizeof(double) * kBaPartialCount, hipMemcpyDeviceToHost,
+                          r.b->stream));
+    SO_HIP(hipStreamSynchronize(r.b->stream));
+    return SO_OK;
+}
+
+double sum_partials(const double* p, int n) {
+    double t = 0.0;
+    for (int i = 0; i < n; i++) t += p[i];
+    return t;
+}
+
+// SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve
+int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
+    so_ba* b = r.b;
+    hipStream_t s = b->stream;
+    *done_out = 0;
+    if (r.S.n_free + (r.S.n_active_edges > 0 ? 1 : 0) == 0) return SO_OK;  // 0 vertices to optimize
+    int rc;
+    bool ok = true, errors_fresh = false;
+    double carried_chi = 0.0;
+    for (int it = 0; it < iterations && !r.terminate() && ok; it++) {
+        double currentChi;
+        if (!errors_fresh) {
+            launch_ba_errors(r.d, r.poses(r.cur), r.points(r.cur), r.nb_err, s);
+        }
+        launch_ba_build(r.d, r.poses(r.cur), r.points(r.cur), s);
+        if (it == 0) launch_ba_maxdiag(r.d, s);
+        SO_HIP(hipGetLastError());
+        if (!errors_fresh || it == 0) {
+            if ((rc = fetch_partials(r))) return rc;
+            if (!errors_fresh) carried_chi = sum_partials(b->h_partial + kBaPartialChi, r.nb_err);
+        }
+        currentChi = carried_chi;
+        double tempChi = currentChi;
+        const double iniChi = currentChi;
+        if (it == 0) {  // computeLambdaInit
+            r.lambda = 1e-5 * b->h_partial[kBaMaxDiag];
+            r.ni = 2;
+            r.nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            const int trial = r.cur ^ 1;
+            launch_ba_schur(r.d, r.lambda, b->d_blki1.as<int>(), b->d_blki2.as<int>(), r.S.n_blk, s);
+            launch_ba_solve(r.d, s);
+            launch_ba_update(r.d, r.lambda, r.poses(r.cur), r.points(r.cur), r.poses(trial), r.points(trial), r.nb_upd, s);
+            launch_ba_errors(r.d, r.poses(trial), r.points(trial), r.nb_err, s);
+            SO_HIP(hipGetLastError());
+            if ((rc = fetch_partials(r))) return rc;
+            const bool ok2 = b->h_partial[kBaSolveOk] != 0.0;
+            tempChi = sum_partials(b->h_partial + kBaPartialChi, r.nb_err);
+            if (!ok2) tempChi = DBL_MAX;
+            rho = currentChi - tempChi;
+            double scale = sum_partials(b->h_partial + kBaPartialScale, r.nb_upd);
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                const double scaleFactor = std::max(1. / 3., alpha);
+                r.lambda *= scaleFactor;
+                r.ni = 2;
+                currentChi = tempChi;
+                r.cur = trial;  // discardTop: the trial becomes the estimate
+                errors_fresh = true;
+                carried_chi = tempChi;
+            } else {
+                r.lambda *= r.ni;
+                r.ni *= 2;
+                errors_fresh = false;  // pop: stored errors now describe the rejected trial
+            }
+            qmax++;
+            r.trials++;
+        } while (rho < 0 && qmax < 10 && !r.terminate());
+        (*done_out)++;
+        *chi_out = errors_fresh ? carried_chi : tempChi;
+        if (qmax == 10 || rho == 0) {
+            ok = false;
+            continue;
+        }
+        if ((iniChi - currentChi) * 1e3 < iniChi) r.nBad++; else r.nBad = 0;
+        if (r.nBad >= 3) ok = false;
+    }
+    return SO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int so_ba_create(int device, so_ba** out) {
+    if (!out) return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        last_error_ref() = "no usable HIP device";
+        return SO_ERR_NO_DEVICE;
+    }
+    SO_HIP(hipSetDevice(device));
+    so_ba* b = new so_ba();
+    b->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&b->e0);
+    if (e == hipSuccess) e = hipEventCreate(&b->e1);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_partial, sizeof(double) * kBaPartialCount, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        delete b;
+        return hip_fail(e, "ba init", __FILE__, __LINE__);
+    }
+    *out = b;
+    return SO_OK;
+}
+
+void so_ba_destroy(so_ba* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (Buf* q : b->all()) q->release();
+    if (b->h_partial) (void)hipHostFree(b->h_partial);
+    if (b->e0) (void)hipEventDestroy(b->e0);
+    if (b->e1) (void)hipEventDestroy(b->e1);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+void so_ba_options_local(so_ba_options* o) {
+    if (!o) return;
+    o->its_stage1 = 5;
+    o->its_stage2 = 10;
+    o->robust = 1;
+    o->huber_delta = std::sqrt(5.991f);  // const float thHuberMono = sqrt(5.991), Optimizer.cc:547
+    o->chi2_threshold = 5.991f;
+}
+
+void so_ba_options_global(so_ba_options* o, int32_t n_iterations, int32_t robust) {
+    if (!o) return;
+    o->its_stage1 = n_iterations;
+    o->its_stage2 = 0;
+    o->robust = robust;
+    o->huber_delta = std::sqrt(5.99f);  // const float thHuber2D = sqrt(5.99), Optimizer.cc:91
+    o->chi2_threshold = 5.991f;
+}
+
+int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt, const volatile uint8_t* stop,
+                     float* Tcw_out, float* Xw_out, uint8_t* edge_outlier, double* edge_chi2, so_ba_info* info) {
+    if (!b || !p || !opt || !Tcw_out || !Xw_out) return SO_ERR_INVALID_ARG;
+    if (p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0) return SO_ERR_INVALID_ARG;
+    if ((p->n_poses > 0 && (!p->Tcw || !p->fixed || !p->intr)) || (p->n_points > 0 && !p->Xw) ||
+        (p->n_edges > 0 && (!p->edge_pose || !p->edge_point || !p->obs || !p->inv_sigma2)))
+        return SO_ERR_INVALID_ARG;
+    for (int e = 0; e < p->n_edges; e++)
+        if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) {
+            last_error_ref() = "edge references a vertex out of range";
+            return SO_ERR_INVALID_ARG;
+        }
+    const double t_begin = now_ms();
+    SO_HIP(hipSetDevice(b->device));
+    so_ba_info inf;
+    memset(&inf, 0, sizeof(inf));
+    Run r;
+    r.b = b;
+    r.stop = stop;
+    Problem& P = r.P;
+    P.n_poses = p->n_poses;
+    P.n_points = p->n_points;
+    P.n_edges = p->n_edges;
+    P.fixed.assign(p->fixed, p->fixed + p->n_poses);
+
+    std::vector<BaPose> h_pose((size_t)P.n_poses);
+    for (int i = 0; i < P.n_poses; i++) pose_from_Tcw(p->Tcw + 12 * (size_t)i, h_pose[(size_t)i]);  // toSE3Quat
+    std::vector<double> h_pt((size_t)P.n_points * 3);
+    for (size_t i = 0; i < h_pt.size(); i++) h_pt[i] = (double)p->Xw[i];  // toVector3d
+
+    auto finish_untouched = [&]() {  // Optimizer.cc:631-633: return before optimising
+        for (int i = 0; i < P.n_poses; i++) pose_to_Tcw(h_pose[(size_t)i], Tcw_out + 12 * (size_t)i);
+        for (size_t i = 0; i < h_pt.size(); i++) Xw_out[i] = (float)h_pt[i];
+        if (edge_outlier) memset(edge_outlier, 0, (size_t)P.n_edges);
+        if (edge_chi2) for (int e = 0; e < P.n_edges; e++) edge_chi2[e] = 0.0;
+        inf.wall_ms = (float)(now_ms() - t_begin);
+        if (info) *info = inf;
+    };
+    if (r.terminate()) {
+        inf.aborted = 1;
+        finish_untouched();
+        return SO_OK;
+    }
+    if (P.n_edges == 0) {
+        finish_untouched();
+        return SO_OK;
+    }
+
+    // stable counting sort of the edges by landmark: a landmark's observations become contiguous
+    P.pt_off.assign((size_t)P.n_points + 1, 0);
+    for (int e = 0; e < P.n_edges; e++) P.pt_off[(size_t)p->edge_point[e] + 1]++;
+    for (int i = 0; i < P.n_points; i++) P.pt_off[(size_t)i + 1] += P.pt_off[(size_t)i];
+    P.perm.assign((size_t)P.n_edges, 0);
+    {
+        std::vector<int> fill(P.pt_off.begin(), P.pt_off.end() - 1);
+        for (int e = 0; e < P.n_edges; e++) P.perm[(size_t)fill[(size_t)p->edge_point[e]]++] = e;
+    }
+    P.e_pose.resize((size_t)P.n_edges);
+    P.e_point.resize((size_t)P.n_edges);
+    std::vector<double> h_obs((size_t)P.n_edges * 2), h_w((size_t)P.n_edges);
+    for (int k = 0; k < P.n_edges; k++) {
+        const int e = P.perm[(size_t)k];
+        P.e_pose[(size_t)k] = p->edge_pose[e];
+        P.e_point[(size_t)k] = p->edge_point[e];
+        h_obs[2 * (size_t)k] = (double)p->obs[2 * (size_t)e];
+        h_obs[2 * (size_t)k + 1] = (double)p->obs[2 * (size_t)e + 1];
+        h_w[(size_t)k] = (double)p->inv_sigma2[e];
+    }
+    P.level.assign((size_t)P.n_edges, 0);
+    std::vector<double> h_intr((size_t)P.n_poses * 4);
+    for (size_t i = 0; i < h_intr.size(); i++) h_intr[i] = (double)p->intr[i];
+
+    build_stage(P, r.S);
+    if (6 * r.S.n_free > kMaxReducedDim) {
+        last_error_ref() = "reduced camera system too large for the dense solver (6*n_free > 6144)";
+        return SO_ERR_CAPACITY;
+    }
+
+    int rc;
+    hipStream_t s = b->stream;
+    if ((rc = upload(b, b->d_pose[0], h_pose))) return rc;
+    if ((rc = b->d_pose[1].ensure(sizeof(BaPose) * std::max<size_t>(h_pose.size(), 1)))) return rc;
+    if ((rc = upload(b, b->d_pt[0], h_pt))) return rc;
+    if ((rc = b->d_pt[1].ensure(sizeof(double) * std::max<size_t>(h_pt.size(), 1)))) return rc;
+    if ((rc = upload(b, b->d_intr, h_intr))) return rc;
+    if ((rc = upload(b, b->d_epose, P.e_pose))) return rc;
+    if ((rc = upload(b, b->d_ept, P.e_point))) return rc;
+    if ((rc = upload(b, b->d_obs, h_obs))) return rc;
+    if ((rc = upload(b, b->d_w, h_w))) return rc;
+    if ((rc = upload(b, b->d_ptoff, P.pt_off))) return rc;
+    const size_t nE = (size_t)P.n_edges, nL = (size_t)std::max(P.n_points, 1);
+    if ((rc = b->d_err.ensure(sizeof(double) * 2 * nE))) return rc;
+    if ((rc = b->d_chi2.ensure(sizeof(double) * nE))) return rc;
+    if ((rc = b->d_depth.ensure(sizeof(double) * nE))) return rc;
+    if ((rc = b->d_Hll.ensure(sizeof(double) * 9 * nL))) return rc;
+    if ((rc = b->d_bl.ensure(sizeof(double) * 3 * nL))) return rc;
+    if ((rc = b->d_Dinv.ensure(sizeof(double) * 9 * nL))) return rc;
+    if ((rc = b->d_db.ensure(sizeof(double) * 3 * nL))) return rc;
+    if ((rc = b->d_xl.ensure(sizeof(double) * 3 * nL))) return rc;
+    if ((rc = b->d_W.ensure(sizeof(double) * 18 * nE))) return rc;
+    if ((rc = b->d_BDinv.ensure(sizeof(double) * 18 * nE))) return rc;
+    if ((rc = b->d_partial.ensure(sizeof(double) * kBaPartialCount))) return rc;
+    SO_HIP(hipMemsetAsync(b->d_err.p, 0, sizeof(double) * 2 * nE, s));   // _error of a fresh edge
+    SO_HIP(hipMemsetAsync(b->d_chi2.p, 0, sizeof(double) * nE, s));
+    SO_HIP(hipMemsetAsync(b->d_partial.p, 0, sizeof(double) * kBaPartialCount, s));
+
+    BaDev& d = r.d;
+    d.n_poses = P.n_poses;
+    d.n_points = P.n_points;
+    d.n_edges = P.n_edges;
+    d.intr = b->d_intr.as<double>();
+    d.e_pose = b->d_epose.as<int>();
+    d.e_point = b->d_ept.as<int>();
+    d.e_obs = b->d_obs.as<double>();
+    d.e_w = b->d_w.as<double>();
+    d.e_err = b->d_err.as<double>();
+    d.e_chi2 = b->d_chi2.as<double>();
+    d.pt_off = b->d_ptoff.as<int>();
+    d.Hll = b->d_Hll.as<double>();
+    d.bl = b->d_bl.as<double>();
+    d.W = b->d_W.as<double>();
+    d.Dinv = b->d_Dinv.as<double>();
+    d.db = b->d_db.as<double>();
+    d.BDinv = b->d_BDinv.as<double>();
+    d.xl = b->d_xl.as<double>();
+    d.partial = b->d_partial.as<double>();
+    d.robust = opt->robust;
+    d.huber_delta = (double)opt->huber_delta;
+    d.huber_dsqr = (float)((double)opt->huber_delta * (double)opt->huber_delta);  // RobustKernelHuber::setDelta
+    r.nb_err = std::min(1024, std::max(1, (P.n_edges + 255) / 256));
+    r.nb_upd = std::min(1024, std::max(1, (P.n_points + P.n_poses + 255) / 256));
+    if ((rc = upload_stage(r))) return rc;
+
+    SO_HIP(hipEventRecord(b->e0, s));
+    double chi = 0.0;
+    int done = 0;
+    // chi2 before optimising (information only)
+    launch_ba_errors(r.d, r.poses(r.cur), r.points(r.cur), r.nb_err, s);
+    if ((rc = fetch_partials(r))) return rc;
+    inf.chi2_initial = sum_partials(b->h_partial + kBaPartialChi, r.nb_err);
+    inf.chi2_final = inf.chi2_initial;
+
+    if ((rc = optimize(r, opt->its_stage1, &done, &chi))) return rc;  // optimizer.optimize(5)
+    inf.iterations_stage1 = done;
+    if (done > 0) inf.chi2_final = chi;
+    bool do_more = opt->its_stage2 > 0;
+    if (r.terminate()) {
+        do_more = false;
+        inf.aborted = 1;
+    }
+    std::vector<double> h_chi2(nE), h_depth(nE);
+    auto fetch_edge_state = [&]() -> int {
+        launch_ba_depth(r.d, r.poses(r.cur), r.points(r.cur), b->d_depth.as<double>(), s);  // isDepthPositive()
+        SO_HIP(hipMemcpyAsync(h_chi2.data(), b->d_chi2.p, sizeof(double) * nE, hipMemcpyDeviceToHost, s));
+        SO_HIP(hipMemcpyAsync(h_depth.data(), b->d_depth.p, sizeof(double) * nE, hipMemcpyDeviceToHost, s));
+        SO_HIP(hipStreamSynchronize(s));
+        return SO_OK;
+    };
+    if (do_more) {
+        if ((rc = fetch_edge_state())) return rc;
+        for (int k = 0; k < P.n_edges; k++)  // Optimizer.cc:644-656
+            if (h_chi2[(size_t)k] > (double)opt->chi2_threshold || !(h_depth[(size_t)k] > 0.0)) P.level[(size_t)k] = 1;
+        r.d.robust = 0;  // e->setRobustKernel(nullptr)
+        build_stage(P, r.S);  // optimizer.initializeOptimization(0)
+        if ((rc = upload_stage(r))) return rc;
+        if ((rc = optimize(r, opt->its_stage2, &done, &chi))) return rc;  // optimizer.optimize(10)
+        inf.iterations_stage2 = done;
+        if (done > 0) inf.chi2_final = chi;
+        if (r.terminate()) inf.aborted = 1;
+    }
+    // Optimizer.cc:682-739: outlier flags from the edges' stored errors, then recover the optimised data
+    if ((rc = fetch_edge_state())) return rc;
+    SO_HIP(hipMemcpyAsync(h_pose.data(), r.poses(r.cur), sizeof(BaPose) * h_pose.size(), hipMemcpyDeviceToHost, s));
+    if (!h_pt.empty())
+        SO_HIP(hipMemcpyAsync(h_pt.data(), r.points(r.cur), sizeof(double) * h_pt.size(), hipMemcpyDeviceToHost, s));
+    SO_HIP(hipEventRecord(b->e1, s));
+    SO_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < P.n_edges; k++) {
+        const int e = P.perm[(size_t)k];
+        const int out = (h_chi2[(size_t)k] > (double)opt->chi2_threshold || !(h_depth[(size_t)k] > 0.0)) ? 1 : 0;
+        if (edge_outlier) edge_outlier[e] = (uint8_t)out;
+        if (edge_chi2) edge_chi2[e] = h_chi2[(size_t)k];
+        inf.n_outliers += out;
+    }
+    for (int i = 0; i < P.n_poses; i++) pose_to_Tcw(h_pose[(size_t)i], Tcw_out + 12 * (size_t)i);
+    for (size_t i = 0; i < h_pt.size(); i++) Xw_out[i] = (float)h_pt[i];
+    inf.lambda_final = r.lambda;
+    inf.lm_trials = r.trials;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->e0, b->e1) == hipSuccess) inf.gpu_ms = ms;
+    inf.wall_ms = (float)(now_ms() - t_begin);
+    if (info) *info = inf;
+    return SO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,521 @@
+// ba_kernels.hip — gfx950 kernels of the bundle-adjustment hot path (FP64).
+//
+// One Levenberg-Marquardt trial = schur (per-landmark 3x3 inverse + per-block gather of the reduced camera
+// system) -> dense Cholesky solve of the reduced system -> back-substitution + manifold update into the trial
+// buffers -> residuals + chi2 of the trial state.  One iteration additionally linearises (build).
+// Reductions are segmented by vertex through host-built CSR lists (edges pre-sorted by landmark): no
+// floating-point atomics, fixed summation order, deterministic results.
+//
+// Reference behaviour followed (files under /root/reference/code/Thirdparty/g2o/g2o):
+//   types/types_six_dof_expmap.{h,cpp}  EdgeSE3ProjectXYZ error + analytic Jacobians, VertexSE3Expmap oplus
+//   types/se3quat.h                     SE3Quat exp / product / map
+//   core/base_binary_edge.hpp:55-120    constructQuadraticForm (+ Huber weights, robust_kernel_impl.cpp:78-91)
+//   core/block_solver.hpp:354-486       Schur complement, back-substitution
+#include "ba_device.h"
+
+namespace so {
+
+// ---------------- SE3Quat pieces (se3quat.h), same formulas as the CPU oracle ----------------
+__device__ __forceinline__ void quat_rotate(const double* q, const double* v, double* out) {
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux; uy += uy; uz += uz;
+    out[0] = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+    out[1] = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+    out[2] = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+}
+
+__device__ __forceinline__ void quat_to_R(const double* q, double* R) {
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+__device__ __forceinline__ void quat_from_R(const double* R, double* q) {
+    double t = R[0] + R[4] + R[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t;
+        q[1] = (R[2] - R[6]) * t;
+        q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        double qq[3];
+        qq[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        qq[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        qq[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2];
+    }
+}
+
+__device__ __forceinline__ void quat_normalize_rotation(double* q) {
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+// pose <- SE3Quat::exp(u) * pose   (VertexSE3Expmap::oplusImpl)
+__device__ void se3_exp_mul(const double* u, const BaPose& in, BaPose& out) {
+    const double w0 = u[0], w1 = u[1], w2 = u[2];
+    const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    const double Om[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    double Om2[9], R[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Om2[i * 3 + j] = Om[i * 3] * Om[j] + Om[i * 3 + 1] * Om[3 + j] + Om[i * 3 + 2] * Om[6 + j];
+    if (theta < 0.00001) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i];
+            V[i] = R[i];
+        }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
+        const double c = (theta - sin(theta)) / (theta * theta * theta);
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
+            V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * Om[i] + c * Om2[i];
+        }
+    }
+    double qa[4], ta[3], rt[3];
+    quat_from_R(R, qa);
+    quat_normalize_rotation(qa);
+#pragma unroll
+    for (int i = 0; i < 3; i++) ta[i] = V[i * 3] * u[3] + V[i * 3 + 1] * u[4] + V[i * 3 + 2] * u[5];
+    quat_rotate(qa, in.t, rt);
+    out.t[0] = ta[0] + rt[0]; out.t[1] = ta[1] + rt[1]; out.t[2] = ta[2] + rt[2];
+    const double* b = in.q;
+    double qn[4];
+    qn[3] = qa[3] * b[3] - qa[0] * b[0] - qa[1] * b[1] - qa[2] * b[2];
+    qn[0] = qa[3] * b[0] + qa[0] * b[3] + qa[1] * b[2] - qa[2] * b[1];
+    qn[1] = qa[3] * b[1] + qa[1] * b[3] + qa[2] * b[0] - qa[0] * b[2];
+    qn[2] = qa[3] * b[2] + qa[2] * b[3] + qa[0] * b[1] - qa[1] * b[0];
+    quat_normalize_rotation(qn);
+    out.q[0] = qn[0]; out.q[1] = qn[1]; out.q[2] = qn[2]; out.q[3] = qn[3];
+    out.pad = 0;
+}
+
+struct EdgeLin {
+    double err0, err1;
+    double Jp[6];   // 2x3 d err / d point
+    double Jc[12];  // 2x6 d err / d pose [omega, upsilon]
+    double z;
+};
+
+__device__ __forceinline__ void camera_point(const BaPose& P, const double* X, double* pc) {
+    quat_rotate(P.q, X, pc);
+    pc[0] += P.t[0]; pc[1] += P.t[1]; pc[2] += P.t[2];
+}
+
+__device__ __forceinline__ void edge_error(const BaPose& P, const double* X, const double* obs, const double* K,
+                                           double& e0, double& e1) {
+    double pc[3];
+    camera_point(P, X, pc);
+    e0 = obs[0] - (pc[0] / pc[2] * K[0] + K[2]);
+    e1 = obs[1] - (pc[1] / pc[2] * K[1] + K[3]);
+}
+
+__device__ __forceinline__ void edge_jacobians(const BaPose& P, const double* X, const double* K, double* Jp, double* Jc) {
+    double pc[3], R[9];
+    camera_point(P, X, pc);
+    quat_to_R(P.q, R);
+    const double x = pc[0], y = pc[1], z = pc[2], z_2 = z * z, fx = K[0], fy = K[1];
+    const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            Jp[r * 3 + c] = -1. / z * (tmp[r * 3] * R[c] + tmp[r * 3 + 1] * R[3 + c] + tmp[r * 3 + 2] * R[6 + c]);
+    Jc[0] = x * y / z_2 * fx;       Jc[1] = -(1 + (x * x / z_2)) * fx; Jc[2] = y / z * fx;
+    Jc[3] = -1. / z * fx;           Jc[4] = 0;                         Jc[5] = x / z_2 * fx;
+    Jc[6] = (1 + y * y / z_2) * fy; Jc[7] = -x * y / z_2 * fy;         Jc[8] = -x / z * fy;
+    Jc[9] = 0;                      Jc[10] = -1. / z * fy;             Jc[11] = y / z_2 * fy;
+}
+
+__device__ __forceinline__ double huber_rho0(double e, double delta, float dsqr) {
+    return (e <= dsqr) ? e : 2 * sqrt(e) * delta - dsqr;
+}
+__device__ __forceinline__ double huber_rho1(double e, double delta, float dsqr) {
+    return (e <= dsqr) ? 1.0 : delta / sqrt(e);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// block-wide deterministic sum (fixed tree: xor-butterfly inside a wave, then waves in index order)
+__device__ __forceinline__ double block_sum(double v, double* s_tmp /* >= 16 doubles */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) s_tmp[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; i++) t += s_tmp[i];
+    return t;
+}
+
+// ---------------- residuals + chi2 (computeActiveErrors + activeRobustChi2) ----------------
+__global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, const BaPose* __restrict__ poses,
+                                                         const double* __restrict__ points) {
+    __shared__ double s_tmp[16];
+    double acc = 0.0;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < d.n_edges; e += gridDim.x * 256) {
+        if (!d.e_active[e]) continue;
+        const int ip = d.e_pose[e], il = d.e_point[e];
+        double e0, e1;
+        const double obs[2] = {d.e_obs[2 * e], d.e_obs[2 * e + 1]};
+        const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+        edge_error(poses[ip], X, obs, d.intr + 4 * ip, e0, e1);
+        const double w = d.e_w[e];
+        const double chi2 = e0 * (w * e0) + e1 * (w * e1);
+        d.e_err[2 * e] = e0;
+        d.e_err[2 * e + 1] = e1;
+        d.e_chi2[e] = chi2;
+        acc += d.robust ? huber_rho0(chi2, d.huber_delta, d.huber_dsqr) : chi2;
+    }
+    const double t = block_sum(acc, s_tmp);
+    if (threadIdx.x == 0) d.partial[kBaPartialChi + blockIdx.x] = t;
+}
+
+void launch_ba_errors(const BaDev& d, const BaPose* poses, const double* points, int n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(ba_errors_kernel, dim3(n_blocks), dim3(256), 0, s, d, poses, points);
+}
+
+__global__ __launch_bounds__(256) void ba_depth_kernel(BaDev d, const BaPose* __restrict__ poses,
+                                                        const double* __restrict__ points, double* __restrict__ depth) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.n_edges) return;
+    const int il = d.e_point[e];
+    const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+    double pc[3];
+    camera_point(poses[d.e_pose[e]], X, pc);
+    depth[e] = pc[2];
+}
+
+void launch_ba_depth(const BaDev& d, const BaPose* poses, const double* points, double* depth, hipStream_t s) {
+    if (d.n_edges <= 0) return;
+    hipLaunchKernelGGL(ba_depth_kernel, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, poses, points, depth);
+}
+
+// ---------------- linearisation: Hpp/bp per free pose (one workgroup each), Hll/bl/W per landmark ----------------
+__global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, const BaPose* __restrict__ poses,
+                                                        const double* __restrict__ points) {
+    __shared__ double s_red[4][28];
+    if ((int)blockIdx.x < d.n_free) {
+        // pose role: reduce J_c^T w J_c (upper 21) and J_c^T omega_r (6) over this pose's active edges
+        const int hi = blockIdx.x, ip = d.free_pose[hi];
+        const BaPose P = poses[ip];
+        const double* K = d.intr + 4 * ip;
+        double acc[27];
+#pragma unroll
+        for (int i = 0; i < 27; i++) acc[i] = 0.0;
+        for (int k = d.pose_off[hi] + threadIdx.x; k < d.pose_off[hi + 1]; k += 256) {
+            const int e = d.pose_edges[k];
+            const int il = d.e_point[e];
+            const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+            double Jp[6], Jc[12];
+            edge_jacobians(P, X, K, Jp, Jc);
+            const double om = d.e_w[e];
+            const double r1 = d.robust ? huber_rho1(d.e_chi2[e], d.huber_delta, d.huber_dsqr) : 1.0;
+            const double w = r1 * om;
+            const double o0 = -om * d.e_err[2 * e] * r1, o1 = -om * d.e_err[2 * e + 1] * r1;
+            int t = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = r; c < 6; c++) acc[t++] += Jc[r] * w * Jc[c] + Jc[6 + r] * w * Jc[6 + c];
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[21 + r] += Jc[r] * o0 + Jc[6 + r] * o1;
+        }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 27; i++) {
+            const double v = wave_sum(acc[i]);
+            if (lane == 0) s_red[wv][i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 27) {
+            const double v = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+            if (threadIdx.x < 21) {
+                int r = 0, t = threadIdx.x;  // unrank the upper-triangular index
+                while (t >= 6 - r) { t -= 6 - r; r++; }
+                const int c = r + t;
+                d.Hpp[36 * (size_t)hi + r * 6 + c] = v;
+                d.Hpp[36 * (size_t)hi + c * 6 + r] = v;
+            } else {
+                d.bp[6 * (size_t)hi + (threadIdx.x - 21)] = v;
+            }
+        }
+        return;
+    }
+    // landmark role: one thread per landmark, its edges are contiguous
+    const int il = (blockIdx.x - d.n_free) * 256 + threadIdx.x;
+    if (il >= d.n_points || !d.pt_active[il]) return;
+    const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int e = d.pt_off[il]; e < d.pt_off[il + 1]; e++) {
+        if (!d.e_active[e]) continue;
+        const int ip = d.e_pose[e];
+        double Jp[6], Jc[12];
+        edge_jacobians(poses[ip], X, d.intr + 4 * ip, Jp, Jc);
+        const double om = d.e_w[e];
+        const double r1 = d.robust ? huber_rho1(d.e_chi2[e], d.huber_delta, d.huber_dsqr) : 1.0;
+        const double w = r1 * om;
+        const double o0 = -om * d.e_err[2 * e] * r1, o1 = -om * d.e_err[2 * e + 1] * r1;
+        H[0] += Jp[0] * w * Jp[0] + Jp[3] * w * Jp[3];
+        H[1] += Jp[0] * w * Jp[1] + Jp[3] * w * Jp[4];
+        H[2] += Jp[0] * w * Jp[2] + Jp[3] * w * Jp[5];
+        H[3] += Jp[1] * w * Jp[1] + Jp[4] * w * Jp[4];
+        H[4] += Jp[1] * w * Jp[2] + Jp[4] * w * Jp[5];
+        H[5] += Jp[2] * w * Jp[2] + Jp[5] * w * Jp[5];
+#pragma unroll
+        for (int r = 0; r < 3; r++) b[r] += Jp[r] * o0 + Jp[3 + r] * o1;
+        if (d.pose_hidx[ip] >= 0) {
+            double* W = d.W + 18 * (size_t)e;  // pose x point = J_c^T w J_p
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) W[r * 3 + c] = Jc[r] * w * Jp[c] + Jc[6 + r] * w * Jp[3 + c];
+        }
+    }
+    double* Hl = d.Hll + 9 * (size_t)il;
+    Hl[0] = H[0]; Hl[1] = H[1]; Hl[2] = H[2];
+    Hl[3] = H[1]; Hl[4] = H[3]; Hl[5] = H[4];
+    Hl[6] = H[2]; Hl[7] = H[4]; Hl[8] = H[5];
+    d.bl[3 * (size_t)il] = b[0]; d.bl[3 * (size_t)il + 1] = b[1]; d.bl[3 * (size_t)il + 2] = b[2];
+}
+
+void launch_ba_build(const BaDev& d, const BaPose* poses, const double* points, hipStream_t s) {
+    const int nb = d.n_free + (d.n_points + 255) / 256;
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(ba_build_kernel, dim3(nb), dim3(256), 0, s, d, poses, points);
+}
+
+// max |diagonal| over Hpp and Hll (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
+__global__ __launch_bounds__(1024) void ba_maxdiag_kernel(BaDev d) {
+    __shared__ double s_m[16];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < 6 * d.n_free; i += 1024) m = fmax(m, fabs(d.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
+    for (int i = threadIdx.x; i < 3 * d.n_points; i += 1024)
+        if (d.pt_active[i / 3]) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; i++) t = fmax(t, s_m[i]);
+        d.partial[kBaMaxDiag] = t;
+    }
+}
+
+void launch_ba_maxdiag(const BaDev& d, hipStream_t s) {
+    hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(1024), 0, s, d);
+}
+
+// ---------------- Schur complement ----------------
+// prep: per landmark Dinv = (Hll + lambda I)^-1 (cofactors), db = Dinv bl, BDinv_e = W_e Dinv
+__global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d, double lambda) {
+    const int il = blockIdx.x * 256 + threadIdx.x;
+    if (il >= d.n_points || !d.pt_active[il]) return;
+    const double* Hl = d.Hll + 9 * (size_t)il;
+    const double m0 = Hl[0] + lambda, m1 = Hl[1], m2 = Hl[2], m3 = Hl[3], m4 = Hl[4] + lambda, m5 = Hl[5], m6 = Hl[6],
+                 m7 = Hl[7], m8 = Hl[8] + lambda;
+    const double c00 = m4 * m8 - m5 * m7, c01 = m5 * m6 - m3 * m8, c02 = m3 * m7 - m4 * m6;
+    const double invdet = 1.0 / (m0 * c00 + m1 * c01 + m2 * c02);
+    double Di[9];
+    Di[0] = c00 * invdet; Di[1] = (m2 * m7 - m1 * m8) * invdet; Di[2] = (m1 * m5 - m2 * m4) * invdet;
+    Di[3] = c01 * invdet; Di[4] = (m0 * m8 - m2 * m6) * invdet; Di[5] = (m2 * m3 - m0 * m5) * invdet;
+    Di[6] = c02 * invdet; Di[7] = (m1 * m6 - m0 * m7) * invdet; Di[8] = (m0 * m4 - m1 * m3) * invdet;
+    double* Do = d.Dinv + 9 * (size_t)il;
+#pragma unroll
+    for (int i = 0; i < 9; i++) Do[i] = Di[i];
+    const double* bl = d.bl + 3 * (size_t)il;
+#pragma unroll
+    for (int r = 0; r < 3; r++) d.db[3 * (size_t)il + r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
+    for (int e = d.pt_off[il]; e < d.pt_off[il + 1]; e++) {
+        if (!d.e_active[e] || d.pose_hidx[d.e_pose[e]] < 0) continue;
+        const double* W = d.W + 18 * (size_t)e;
+        double* B = d.BDinv + 18 * (size_t)e;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) B[r * 3 + c] = W[r * 3] * Di[c] + W[r * 3 + 1] * Di[3 + c] + W[r * 3 + 2] * Di[6 + c];
+    }
+}
+
+// gather: one wave per upper block (i1 <= i2) of the reduced camera system, 36 lanes = the 6x6 entries;
+//         S(i1,i2) = [i1 == i2] (Hpp + lambda I) - sum over shared landmarks BDinv_{k1} W_{k2}^T ; mirrored.
+//         extra waves: b_schur(i) = bp(i) - sum over the pose's edges W_e db_{landmark(e)}
+__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, double lambda, const int* __restrict__ blk_i1,
+                                                               const int* __restrict__ blk_i2, int n_blk) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = 6 * d.n_free;
+    if (g < n_blk) {
+        if (lane >= 36) return;
+        const int i1 = blk_i1[g], i2 = blk_i2[g];
+        const int r = lane / 6, c = lane - 6 * r;
+        double acc = 0.0;
+        if (i1 == i2) acc = d.Hpp[36 * (size_t)i1 + lane] + (r == c ? lambda : 0.0);
+        for (int p = d.blk_off[g]; p < d.blk_off[g + 1]; p++) {
+            const double* B = d.BDinv + 18 * (size_t)d.pair_k1[p] + 3 * r;
+            const double* W = d.W + 18 * (size_t)d.pair_k2[p] + 3 * c;
+            acc -= B[0] * W[0] + B[1] * W[1] + B[2] * W[2];
+        }
+        d.S[(size_t)(6 * i1 + r) * n + 6 * i2 + c] = acc;
+        if (i1 != i2) d.S[(size_t)(6 * i2 + c) * n + 6 * i1 + r] = acc;
+        return;
+    }
+    const int hi = g - n_blk;
+    if (hi >= d.n_free) return;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = d.pose_off[hi] + lane; k < d.pose_off[hi + 1]; k += 64) {
+        const int e = d.pose_edges[k];
+        const double* W = d.W + 18 * (size_t)e;
+        const double* db = d.db + 3 * (size_t)d.e_point[e];
+#pragma unroll
+        for (int r = 0; r < 6; r++) acc[r] += W[r * 3] * db[0] + W[r * 3 + 1] * db[1] + W[r * 3 + 2] * db[2];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const double v = wave_sum(acc[r]);
+        if (lane == 0) d.bs[6 * (size_t)hi + r] = d.bp[6 * (size_t)hi + r] - v;
+    }
+}
+
+// ---------------- dense Cholesky solve of the reduced camera system (single workgroup) ----------------
+// Right-looking LL^T on the lower triangle of S with the right-hand side carried as an extra row, then the
+// backward substitution.  Replaces LinearSolverEigen's SimplicialLDLT (linear_solver_eigen.h:94-124): same
+// solution up to rounding.  The local-BA systems are 6 * (10..100) unknowns; latency-bound by design.
+__global__ __launch_bounds__(1024) void ba_solve_kernel(BaDev d) {
+    __shared__ int s_fail;
+    const int n = 6 * d.n_free;
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    double* S = d.S;
+    double* y = d.bs;  // becomes L^-1 b, then x
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) {
+            const double dj = S[(size_t)j * n + j];
+            if (!(dj > 0.0)) s_fail = 1;
+            else S[(size_t)j * n + j] = sqrt(dj);
+        }
+        __syncthreads();
+        if (s_fail) break;
+        const double djj = S[(size_t)j * n + j];
+        for (int i = j + 1 + tid; i < n; i += 1024) S[(size_t)i * n + j] /= djj;
+        if (tid == 0) y[j] /= djj;
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = j + 1 + ty; i < n; i += 32) {
+            const double lij = S[(size_t)i * n + j];
+            for (int k = j + 1 + tx; k <= i; k += 32) S[(size_t)i * n + k] -= lij * S[(size_t)k * n + j];
+            if (tx == 0) y[i] -= lij * yj;
+        }
+        __syncthreads();
+    }
+    if (!s_fail) {
+        for (int j = n - 1; j >= 0; j--) {  // L^T x = y
+            if (tid == 0) y[j] /= S[(size_t)j * n + j];
+            __syncthreads();
+            const double xj = y[j];
+            for (int i = tid; i < j; i += 1024) y[i] -= S[(size_t)j * n + i] * xj;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) d.partial[kBaSolveOk] = s_fail ? 0.0 : 1.0;
+}
+
+void launch_ba_schur(const BaDev& d, double lambda, const int* blk_i1, const int* blk_i2, int n_blk, hipStream_t s) {
+    if (d.n_points > 0)
+        hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((d.n_points + 255) / 256), dim3(256), 0, s, d, lambda);
+    const int waves = n_blk + d.n_free;
+    if (waves > 0)
+        hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d, lambda, blk_i1, blk_i2,
+                           n_blk);
+}
+
+void launch_ba_solve(const BaDev& d, hipStream_t s) { hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(1024), 0, s, d); }
+
+// ---------------- back-substitution + manifold update into the trial buffers + scale partials ----------------
+__global__ __launch_bounds__(256) void ba_update_kernel(BaDev d, double lambda, const BaPose* __restrict__ poses,
+                                                         const double* __restrict__ points,
+                                                         BaPose* __restrict__ poses_trial,
+                                                         double* __restrict__ points_trial) {
+    __shared__ double s_tmp[16];
+    double scale = 0.0;  // computeScale: sum x (lambda x + b)
+    const double* xp = d.bs;
+    const int total = d.n_points + d.n_poses;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        if (i < d.n_points) {
+            const int il = i;
+            double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+            if (d.pt_active[il]) {
+                const double* bl = d.bl + 3 * (size_t)il;
+                double cl[3] = {bl[0], bl[1], bl[2]};
+                for (int e = d.pt_off[il]; e < d.pt_off[il + 1]; e++) {
+                    if (!d.e_active[e]) continue;
+                    const int hi = d.pose_hidx[d.e_pose[e]];
+                    if (hi < 0) continue;
+                    const double* W = d.W + 18 * (size_t)e;
+                    const double* x = xp + 6 * (size_t)hi;
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+#pragma unroll
+                        for (int r = 0; r < 6; r++) cl[c] -= W[r * 3 + c] * x[r];
+                }
+                const double* Di = d.Dinv + 9 * (size_t)il;
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
+                    d.xl[3 * (size_t)il + r] = xl;
+                    scale += xl * (lambda * xl + bl[r]);
+                    X[r] += xl;
+                }
+            }
+            points_trial[3 * il] = X[0]; points_trial[3 * il + 1] = X[1]; points_trial[3 * il + 2] = X[2];
+        } else {
+            const int ip = i - d.n_points;
+            const int hi = d.pose_hidx[ip];
+            if (hi >= 0) {
+                const double* x = xp + 6 * (size_t)hi;
+                const double u[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
+                BaPose out;
+                se3_exp_mul(u, poses[ip], out);
+                poses_trial[ip] = out;
+#pragma unroll
+                for (int r = 0; r < 6; r++) scale += u[r] * (lambda * u[r] + d.bp[6 * (size_t)hi + r]);
+            } else {
+                poses_trial[ip] = poses[ip];
+            }
+        }
+    }
+    const double t = block_sum(scale, s_tmp);
+    if (threadIdx.x == 0) d.partial[kBaPartialScale + blockIdx.x] = t;
+}
+
+void launch_ba_update(const BaDev& d, double lambda, const BaPose* poses, const double* points, BaPose* poses_trial,
+                      double* points_trial, int n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(ba_update_kernel, dim3(n_blocks), dim3(256), 0, s, d, lambda, poses, points, poses_trial,
+                       points_trial);
+}
+
+}  // namespace so
