@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py — frames/s of the per-frame hot path (one agent per GPU) on synthetic EuRoC-sized streams.
+"""bench.py — frames/s per agent of the per-frame hot path (tracking front-end + matching + local BA) on
+synthetic EuRoC-sized streams, one agent per GPU.
 
-Contract (see the task prompt): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+Contract (task prompt): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
-A step = one frame of one agent through the hot path, inputs already resident in HBM.  Rank 0 prints ONE
-JSON line.  Agents are independent: weak scaling, no data-path collective per frame.
+A step = ONE FRAME of one agent through the hot path, image already resident in HBM:
+    HIP ORB extract (E0-E9)  ->  SearchByProjection(cur, last) (M2)  ->  SearchByProjection(F, local map) (M1)
+    and, every 5th frame, one local bundle adjustment of an LBA-M window (B1) on the same GPU.
+Agents are independent: weak scaling, no per-frame collective.  Every `--exchange-every` frames
+the ranks all-gather their newest keyframe's descriptor slot over RCCL and brute-force match it (the cross-agent
+loop/merge candidate search); that exchange is inside the timed region.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -21,39 +27,103 @@ import torch  # noqa: E402  (device memory, barrier, RCCL plumbing only)
 
 import swarmmap_amd  # noqa: E402
 from swarmmap_amd import synth  # noqa: E402
+from swarmmap_amd.matcher import FrameView  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+LBA_EVERY = 5          # one LBA-M window per ~5 frames (SURVEY.md 8d end-to-end replay)
+N_LOCAL_HISTORY = 4    # local map = keypoints of the previous 4 frames (~2000-4000 map points)
 
 
 def level_pixels(ex, w, h):
-    """Sum of pyramid level pixels = algorithmic bytes the FAST kernel must read once."""
+    """Sum of pyramid level pixels = bytes the FAST kernel must read at least once."""
     inv = ex.GetInverseScaleFactors()
     return int(sum(int(np.rint(np.float32(w) * s)) * int(np.rint(np.float32(h) * s)) for s in inv))
 
 
-def cpu_baseline(frames, nfeatures, budget_s=12.0):
-    """The CPU oracle ("port": the reference has no CPU extractor) timed on the host, 1 thread."""
+class TrackingWorkload:
+    """Synthetic tracking inputs derived from the extractor's real output on a sliding-window stream: the
+    scene is static and the window offset is known, so last-frame / local-map points project to
+    (x + dx, y + dy) in the current frame (plus sub-pixel jitter), carrying their real ORB descriptors."""
+
+    def __init__(self, stream, size, seed):
+        self.stream, self.size = stream, size
+        self.rng = np.random.default_rng(seed)
+        self.history = []  # (offset, kps, desc)
+        self.bounds = (0.0, float(size[0]), 0.0, float(size[1]))
+
+    def offset(self, t):
+        m = self.stream.margin
+        return (int(round(m + (m - 1) * np.sin(0.013 * t))), int(round(m + (m - 1) * np.sin(0.021 * t + 0.5))))
+
+    def frame_view(self, kps, desc):
+        return FrameView(kps["x"], kps["y"], kps["octave"], kps["angle"], desc, self.bounds, synth.SCALE_FACTORS)
+
+    def queries(self, t, prepared=None):
+        """(last, mps) dictionaries for M2 / M1 on frame t from the history of frames < t."""
+        ox, oy = self.offset(t)
+        (lo, lk, ld) = self.history[-1]
+        n = len(lk)
+        jit = self.rng.normal(0, 0.5, (2, n)).astype(np.float32)
+        last = dict(valid=(self.rng.random(n) < 0.6).astype(np.uint8), u=lk["x"] + (lo[0] - ox) + jit[0],
+                    v=lk["y"] + (lo[1] - oy) + jit[1], octave=lk["octave"], angle=lk["angle"], desc=ld,
+                    has_obs=np.ones(n, np.uint8))
+        xs, ys, lv, ds = [], [], [], []
+        for (o, k, d) in self.history[-N_LOCAL_HISTORY:]:
+            xs.append(k["x"] + (o[0] - ox)); ys.append(k["y"] + (o[1] - oy)); lv.append(k["octave"]); ds.append(d)
+        x = np.concatenate(xs).astype(np.float32); y = np.concatenate(ys).astype(np.float32)
+        nm = len(x)
+        jit = self.rng.normal(0, 0.5, (2, nm)).astype(np.float32)
+        w, h = self.size
+        inview = ((x > 0) & (x < w) & (y > 0) & (y < h)).astype(np.uint8)
+        mps = dict(in_view=inview, proj_x=x + jit[0], proj_y=y + jit[1],
+                   view_cos=np.where(self.rng.random(nm) < 0.5, 0.9995, 0.9).astype(np.float32),
+                   pred_level=np.concatenate(lv).astype(np.int32), desc=np.concatenate(ds),
+                   has_obs=np.ones(nm, np.uint8))
+        return last, mps
+
+    def push(self, t, kps, desc):
+        self.history.append((self.offset(t), kps.copy(), desc.copy()))
+        if len(self.history) > N_LOCAL_HISTORY:
+            self.history.pop(0)
+
+
+def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window, budget_s=20.0):
+    """The same per-frame workload through the CPU oracle ("port": the reference has no CPU extractor and its
+    g2o needs Eigen), one thread like the reference's Tracking / LocalMapping, bounded sample."""
     from oracle import oracle_py
     cfg = oracle_py.config(nfeatures)
-    oracle_py.extract(cfg, frames[0])  # warm
-    n, t0 = 0, time.perf_counter()
+    wl = TrackingWorkload(stream, size, workload_seed)
+    k, d = oracle_py.extract(cfg, host_frames[0])
+    wl.push(0, k, d)
+    n, t0, n_lba = 0, time.perf_counter(), 0
     while True:
-        oracle_py.extract(cfg, frames[n % len(frames)])
+        t = n + 1
+        kps, desc = oracle_py.extract(cfg, host_frames[t % len(host_frames)])
+        F = wl.frame_view(kps, desc)
+        last, mps = wl.queries(t)
+        oracle_py.search_by_projection_lastframe(F, last, 15.0, True)
+        oracle_py.search_by_projection_mappoints(F, mps, 1.0, 0.8)
+        if t % LBA_EVERY == 0:
+            oracle_py.bundle_adjust(lba_window)
+            n_lba += 1
+        wl.push(t, kps, desc)
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 400:
+        if time.perf_counter() - t0 > budget_s or n >= 600:
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames 752x480, ORB extract (nFeatures %d, 8 levels, FAST 20/7), CPU oracle -O2, "
-                      "1 thread, host has %d cores" % (n, nfeatures, os.cpu_count())}
+            "sample": "%d frames %dx%d: CPU oracle extract (nFeatures %d) + M2 + M1 per frame, %d LBA-M windows "
+                      "(1 per %d frames); gcc -O2, 1 thread; host has %d cores"
+                      % (n, size[0], size[1], nfeatures, n_lba, LBA_EVERY, os.cpu_count())}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--size", default="euroc", choices=["euroc", "kitti"])
+    ap.add_argument("--exchange-every", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -71,24 +141,63 @@ def main():
     size = synth.EUROC if args.size == "euroc" else synth.KITTI
     nfeatures = 1000 if args.size == "euroc" else 2000
     w, h = size
-    # each agent sees its own seeded stream; 32 distinct frames cycle, resident in HBM before timing
+    # each agent sees its own seeded stream; 64 distinct frames cycle, resident in HBM before timing
     stream = synth.FrameStream(seed=20221001 + rank, size=size)
-    host_frames = [stream.frame(t) for t in range(32)]
+    n_distinct = 64
+    host_frames = [stream.frame(t) for t in range(n_distinct)]
     dev_frames = [torch.from_numpy(f).cuda(dev) for f in host_frames]
+    lba_window = synth.make_ba_case("LBA-M", seed=100 + rank)
     torch.cuda.synchronize()
 
     ex = swarmmap_amd.ORBextractor(nfeatures, 1.2, 8, 20, 7, device=dev)
+    m2 = swarmmap_amd.ORBmatcher(0.9, True, device=dev)   # Tracking.cc:715
+    m1 = swarmmap_amd.ORBmatcher(0.8, True, device=dev)   # Tracking.cc:998
+    ba = swarmmap_amd.Optimizer(device=dev)
+    from swarmmap_amd.parallel import KeyframeExchange
+    xchg = KeyframeExchange(slot_keypoints=nfeatures + 24, device=dev) if distributed else None
 
-    def step(i):
-        d = dev_frames[i % len(dev_frames)]
-        return ex.run_device(d.data_ptr(), w, h, w)
-
-    for i in range(args.warmup):
-        step(i)
-    ex.set_profiling(True)
+    wl = TrackingWorkload(stream, size, seed=7 + rank)
+    k0, d0 = ex.run_device(dev_frames[0].data_ptr(), w, h, w)
+    wl.push(0, k0, d0)
+    acc = {"extract_ms": 0.0, "match_ms": 0.0, "lba_ms": 0.0, "xchg_ms": 0.0, "n_kp": 0, "n_m2": 0, "n_m1": 0,
+           "n_lba": 0, "lba_gpu_ms": 0.0, "match_kernel_ms": 0.0, "n_xchg": 0}
     stage_ms = {}
-    n_kp = 0
-    n_cand = 0
+
+    def step(t, timed):
+        t0 = time.perf_counter()
+        kps, desc = ex.run_device(dev_frames[t % n_distinct].data_ptr(), w, h, w)
+        t1 = time.perf_counter()
+        F = wl.frame_view(kps, desc)
+        last, mps = wl.queries(t)
+        nm2, _ = m2.SearchByProjectionLastFrame(F, last, 15.0)
+        k2 = m2.last_kernel_ms()
+        nm1, _ = m1.SearchByProjectionMapPoints(F, mps, 1.0)
+        k1 = m1.last_kernel_ms()
+        t2 = time.perf_counter()
+        lba_info = None
+        if t % LBA_EVERY == 0:
+            lba_info = ba.LocalBundleAdjustment(lba_window)["info"]
+        t3 = time.perf_counter()
+        if xchg is not None and t % args.exchange_every == 0:
+            xchg.exchange_and_match(desc, m1)
+            acc["n_xchg"] += timed
+        t4 = time.perf_counter()
+        wl.push(t, kps, desc)
+        if timed:
+            acc["extract_ms"] += (t1 - t0) * 1e3; acc["match_ms"] += (t2 - t1) * 1e3
+            acc["lba_ms"] += (t3 - t2) * 1e3; acc["xchg_ms"] += (t4 - t3) * 1e3
+            acc["n_kp"] += len(kps); acc["n_m2"] += nm2; acc["n_m1"] += nm1
+            acc["match_kernel_ms"] += k1 + k2
+            if lba_info:
+                acc["n_lba"] += 1; acc["lba_gpu_ms"] += lba_info["gpu_ms"]
+            for k, v in ex.profile().items():
+                stage_ms[k] = stage_ms.get(k, 0.0) + v
+
+    t = 1
+    for _ in range(args.warmup):
+        step(t, False)
+        t += 1
+    ex.set_profiling(True)
 
     def barrier():
         if distributed:
@@ -97,55 +206,53 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        kps, _ = step(i)
-        n_kp += len(kps)
-        for k, v in ex.profile().items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    for _ in range(args.steps):
+        step(t, True)
+        t += 1
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    for l in range(8):
-        n_cand += len(ex.candidates(l)[0])
+    n_cand = sum(len(ex.candidates(l)[0]) for l in range(8))
 
     if rank == 0:
         steps = args.steps
-        total_frames = steps * world
         fast_ms = stage_ms["fast_score"] / steps
-        alg_bytes = level_pixels(ex, w, h) + 8 * n_cand  # read every level pixel once + 8 B per candidate
+        alg_bytes = level_pixels(ex, w, h) + 8 * n_cand  # every level pixel read once + 8 B per candidate written
         achieved = alg_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
         out = {
-            "metric": "frames/sec (ORB front-end per frame; aggregate over agents, per-agent = value/n_gpus)",
-            "value": total_frames / dt,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
+            "metric": "frames/sec (tracking front-end + matching + local BA per frame; aggregate over agents, "
+                      "per-agent = value/n_gpus)",
+            "value": steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (extract, match) + f64 (local BA)", "data": "synthetic",
             "fps_per_agent": steps / dt,
-            "config": {"workload": "EuRoC-sized 752x480 single-agent-per-GPU stream, HIP ORB extract "
-                                   "(nFeatures %d, 8 levels, 1.2, FAST 20/7); BASELINE.json configs[1]" % nfeatures
-                       if args.size == "euroc" else
-                       "KITTI-sized 1241x376 stream, HIP ORB extract (nFeatures %d)" % nfeatures,
-                       "agents": world, "frame": [w, h], "keypoints_per_frame": n_kp / steps,
-                       "stage_ms_per_frame": {k: v / steps for k, v in stage_ms.items()}},
-            "roofline": {"bound": "hbm", "kernel": "fast_score_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": fast_ms},
+            "config": {
+                "workload": "BASELINE.json configs[1] (single agent per GPU, 752x480 EuRoC-sized stream, HIP ORB "
+                            "extract nFeatures %d + HIP match M2+M1) plus HIP LocalBA (LBA-M window every %d frames)"
+                            % (nfeatures, LBA_EVERY) if args.size == "euroc" else
+                            "KITTI-sized 1241x376 stream, nFeatures %d, same per-frame path" % nfeatures,
+                "agents": world, "frame": [w, h], "keypoints_per_frame": acc["n_kp"] / steps,
+                "m2_matches_per_frame": acc["n_m2"] / steps, "m1_matches_per_frame": acc["n_m1"] / steps,
+                "lba_windows": acc["n_lba"], "lba_edges": int(len(lba_window["edge_pose"])),
+                "descriptor_exchanges": acc["n_xchg"],
+                "host_ms_per_frame": {"extract": acc["extract_ms"] / steps, "match": acc["match_ms"] / steps,
+                                      "lba_amortised": acc["lba_ms"] / steps, "exchange_amortised": acc["xchg_ms"] / steps},
+                "lba_ms_per_window": {"wall": acc["lba_ms"] / max(acc["n_lba"], 1),
+                                      "gpu": acc["lba_gpu_ms"] / max(acc["n_lba"], 1)},
+                "match_kernel_ms_per_frame": acc["match_kernel_ms"] / steps,
+                "extract_stage_ms_per_frame": {k: v / steps for k, v in stage_ms.items()}},
+            "roofline": {"bound": "hbm", "kernel": "fast_score_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host_frames, nfeatures)
+            out["cpu_baseline"] = cpu_baseline(host_frames, 7, stream, size, nfeatures, lba_window)
         print(json.dumps(out), flush=True)
-    ex.close()
+    for o in (ex, m1, m2, ba):
+        o.close()
     if distributed:
         torch.distributed.destroy_process_group()
 

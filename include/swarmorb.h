@@ -93,9 +93,11 @@ int so_extractor_get_candidates(so_extractor* ex, int level, int16_t* xs, int16_
                                 int capacity, int* n_out);
 
 /* Per-stage GPU timing with HIP events on the extractor's own stream (off by default).
- * Stages: 0 upload+pyramid, 1 FAST score+NMS (high threshold), 2 FAST low-threshold pass,
- * 3 candidate compaction, 4 angle+blur+rBRIEF, 5 whole run wall time on the host (ms). */
-#define SO_EXTRACTOR_N_STAGES 6
+ * GPU stages (HIP events): 0 upload+pyramid, 1 FAST score+NMS (high threshold), 2 FAST low-threshold pass +
+ * row counts, 3 candidate emission, 4 angle+blur+rBRIEF.  Host stages (steady clock): 5 whole call,
+ * 6 enqueue of phase 1, 7 wait for the candidates, 8 quadtree, 9 phase 2 (H2D + describe + D2H + wait),
+ * 10 keypoint assembly.  All in ms. */
+#define SO_EXTRACTOR_N_STAGES 11
 int so_extractor_set_profiling(so_extractor* ex, int enabled);
 int so_extractor_get_profile(so_extractor* ex, float* ms_per_stage /* [SO_EXTRACTOR_N_STAGES] */);
 

@@ -33,16 +33,18 @@ struct so_extractor {
     int width = 0, height = 0;
     PyramidParams P{};
     std::vector<void*> dev_allocs;
-    Candidate* d_cands = nullptr;
+    int32_t* d_rowcount = nullptr;
     Candidate* h_cands = nullptr;      // host-mapped
     Candidate* h_cands_dev = nullptr;  // device view of h_cands
     CandidateHeader* h_header = nullptr;
     CandidateHeader* h_header_dev = nullptr;
     int cand_capacity = 0;
-    SelectedKp* h_sel = nullptr;  // pinned
-    SelectedKp* d_sel = nullptr;
-    uint8_t* d_desc = nullptr;   // [cap*32 desc][cap*4 angle] in one allocation
-    uint8_t* h_desc = nullptr;   // pinned mirror
+    // phase 2 is zero-copy: the describe kernel reads the survivors from, and writes descriptors + angles to,
+    // host-mapped memory (a few tens of KB per frame), so there is no H2D / D2H copy to enqueue and wait for
+    SelectedKp* h_sel = nullptr;      // host-mapped
+    SelectedKp* h_sel_dev = nullptr;  // device view
+    uint8_t* h_desc = nullptr;        // host-mapped [cap*32 desc][cap*4 angle]
+    uint8_t* h_desc_dev = nullptr;
     int out_capacity = 0;
 
     KeypointQuadtree qt;
@@ -112,6 +114,10 @@ int allocate(so_extractor* ex, int w, int h) {
         L.ntx = rw >= 7 ? (rw - 6 + kTile - 1) / kTile : 0;
         L.nty = rh >= 7 ? (rh - 6 + kTile - 1) / kTile : 0;
         if (L.ntx == 0 || L.nty == 0) L.ntx = L.nty = 0;
+        if (L.ntx > 128) {
+            last_error_ref() = "image wider than 4128 pixels is not supported";
+            return SO_ERR_INVALID_ARG;
+        }
         L.spitch = round_up(L.ntx * kTile + 8, 64);
         L.tile_base = tile_base;
         L.row_base = row_base;
@@ -129,9 +135,13 @@ int allocate(so_extractor* ex, int w, int h) {
     }
     P.total_tiles = tile_base;
     P.total_rows = row_base;
+    if (P.total_rows > 8192) {
+        last_error_ref() = "image too tall for the candidate compaction (sum of level heights > 8192)";
+        return SO_ERR_INVALID_ARG;
+    }
 
     ex->cand_capacity = P.nlevels * kFastCap;
-    int rc = dev_alloc(ex, &ex->d_cands, sizeof(Candidate) * (size_t)ex->cand_capacity + 64, true);
+    int rc = dev_alloc(ex, &ex->d_rowcount, sizeof(int32_t) * ((size_t)P.total_rows + 64), true);
     if (rc) return rc;
     SO_HIP(hipHostMalloc((void**)&ex->h_cands, sizeof(Candidate) * (size_t)ex->cand_capacity + 64, hipHostMallocMapped));
     SO_HIP(hipHostGetDevicePointer((void**)&ex->h_cands_dev, ex->h_cands, 0));
@@ -140,12 +150,10 @@ int allocate(so_extractor* ex, int w, int h) {
     memset(ex->h_header, 0, sizeof(CandidateHeader));
 
     ex->out_capacity = so_extractor_capacity(ex);
-    SO_HIP(hipHostMalloc((void**)&ex->h_sel, sizeof(SelectedKp) * (size_t)ex->out_capacity, hipHostMallocDefault));
-    rc = dev_alloc(ex, &ex->d_sel, sizeof(SelectedKp) * (size_t)ex->out_capacity, false);
-    if (rc) return rc;
-    rc = dev_alloc(ex, &ex->d_desc, (size_t)ex->out_capacity * 36, false);
-    if (rc) return rc;
-    SO_HIP(hipHostMalloc((void**)&ex->h_desc, (size_t)ex->out_capacity * 36, hipHostMallocDefault));
+    SO_HIP(hipHostMalloc((void**)&ex->h_sel, sizeof(SelectedKp) * (size_t)ex->out_capacity, hipHostMallocMapped));
+    SO_HIP(hipHostGetDevicePointer((void**)&ex->h_sel_dev, ex->h_sel, 0));
+    SO_HIP(hipHostMalloc((void**)&ex->h_desc, (size_t)ex->out_capacity * 36, hipHostMallocMapped));
+    SO_HIP(hipHostGetDevicePointer((void**)&ex->h_desc_dev, ex->h_desc, 0));
     SO_HIP(hipStreamSynchronize(ex->stream));
     ex->width = w;
     ex->height = h;
@@ -188,18 +196,24 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
     if (P.total_tiles > 0) {
         launch_fast_score(P, s);
         if (prof) SO_HIP(hipEventRecord(ex->ev[2], s));
-        launch_fast_low(P, s);
+        launch_fast_low_count(P, ex->d_rowcount, s);
         if (prof) SO_HIP(hipEventRecord(ex->ev[3], s));
-        launch_compact(P, ex->d_cands, ex->h_cands_dev, ex->h_header_dev, ex->cand_capacity, s);
+        launch_emit(P, ex->d_rowcount, ex->h_cands_dev, ex->h_header_dev, ex->cand_capacity, s);
         if (prof) SO_HIP(hipEventRecord(ex->ev[4], s));
         SO_HIP(hipGetLastError());
+        const double t_enq = now_ms();
         SO_HIP(hipStreamSynchronize(s));  // sync #1: candidates + header are in host memory now
+        if (prof) {
+            ex->prof_ms[6] = (float)(t_enq - t_begin);
+            ex->prof_ms[7] = (float)(now_ms() - t_enq);
+        }
     } else {
         memset(ex->h_header, 0, sizeof(CandidateHeader));
         SO_HIP(hipStreamSynchronize(s));
     }
 
     // DistributeOctTree per level (host), code/src/ORBextractor.cc:725-727
+    const double t_tree = now_ms();
     const CandidateHeader& H = *ex->h_header;
     int n = 0;
     ex->sel_cand.clear();
@@ -219,17 +233,16 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
             n++;
         }
     }
+    const double t_phase2 = now_ms();
+    double t_asm = t_phase2;
     if (n > 0) {
-        SO_HIP(hipMemcpyAsync(ex->d_sel, ex->h_sel, sizeof(SelectedKp) * (size_t)n, hipMemcpyHostToDevice, s));
         if (prof) SO_HIP(hipEventRecord(ex->ev[5], s));
-        float* d_angle = reinterpret_cast<float*>(ex->d_desc + (size_t)ex->out_capacity * 32);
-        launch_describe(P, ex->d_sel, n, ex->d_desc, d_angle, s);
+        float* angle_dev = reinterpret_cast<float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);
+        launch_describe(P, ex->h_sel_dev, n, ex->h_desc_dev, angle_dev, s);
         if (prof) SO_HIP(hipEventRecord(ex->ev[6], s));
         SO_HIP(hipGetLastError());
-        SO_HIP(hipMemcpyAsync(ex->h_desc, ex->d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, s));
-        SO_HIP(hipMemcpyAsync(ex->h_desc + (size_t)ex->out_capacity * 32, d_angle, (size_t)n * 4, hipMemcpyDeviceToHost,
-                              s));
-        SO_HIP(hipStreamSynchronize(s));  // sync #2
+        SO_HIP(hipStreamSynchronize(s));  // sync #2: descriptors + angles are in host memory now
+        t_asm = now_ms();
         memcpy(desc, ex->h_desc, (size_t)n * 32);
         const float* angles = reinterpret_cast<const float*>(ex->h_desc + (size_t)ex->out_capacity * 32);
         for (int i = 0; i < n; i++) {
@@ -253,7 +266,10 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
     *n_out = n;
     if (prof) {
         float ms = 0.f;
-        for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) ex->prof_ms[i] = 0.f;
+        for (int i = 0; i < 6; i++) ex->prof_ms[i] = 0.f;
+        ex->prof_ms[8] = (float)(t_phase2 - t_tree);
+        ex->prof_ms[9] = (float)(t_asm - t_phase2);
+        ex->prof_ms[10] = (float)(now_ms() - t_asm);
         if (P.total_tiles > 0) {
             (void)hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1]); ex->prof_ms[0] = ms;
             (void)hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2]); ex->prof_ms[1] = ms;

@@ -67,9 +67,9 @@ struct SelectedKp {  // host -> device after the quadtree: level coordinates (RO
 // launchers (orb_kernels.hip)
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, hipStream_t s);
 void launch_fast_score(const PyramidParams& p, hipStream_t s);
-void launch_fast_low(const PyramidParams& p, hipStream_t s);
-void launch_compact(const PyramidParams& p, Candidate* d_cands, Candidate* h_cands_mapped,
-                    CandidateHeader* h_header_mapped, int cand_capacity, hipStream_t s);
+void launch_fast_low_count(const PyramidParams& p, int32_t* d_rowcount, hipStream_t s);
+void launch_emit(const PyramidParams& p, const int32_t* d_rowcount, Candidate* h_cands_mapped,
+                 CandidateHeader* h_header_mapped, int cand_capacity, hipStream_t s);
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,
                      hipStream_t s);
 

@@ -185,85 +185,130 @@ __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
     }
 }
 
-// Low-threshold pass for the tiles that kept nothing at the high threshold (Fast_gpu.cu:317-339),
-// with the deterministic neighbour rule of the oracle: a neighbour in a non-empty tile competes with
-// its high-threshold score, a neighbour in an empty tile with its low-threshold score.
-__global__ __launch_bounds__(256) void fast_low_kernel(PyramidParams P) {
-    __shared__ uint8_t ssc[kScRows * kScPitch];
-    const int tid = threadIdx.x;
-    const int lvl = find_level_by_tile(P, blockIdx.x);
+// ------------------------------------------------------------------------------------------------
+// Band kernels.  A "band" is one row of tiles (32 pixel rows) of one level; all bands of all levels form one
+// grid (72 workgroups for 752x480).  Two launches replace a per-tile low pass + a single-workgroup compaction:
+//   fast_low_count_kernel  low-threshold pass for the band's empty tiles (Fast_gpu.cu:317-339) with the
+//                          deterministic neighbour rule of the oracle (a neighbour in a non-empty tile competes
+//                          with its high-threshold score, one in an empty tile with its low-threshold score),
+//                          then one popcount per pixel row -> rowcount[]
+//   emit_kernel            every band scans rowcount[] (a few thousand ints, L2-resident) to find where its rows
+//                          start in the (level, y, x) raster order, applies the per-level cap of 10000, and writes
+//                          its 8-byte records straight into host-mapped memory.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_level_by_band(const PyramidParams& P, int band) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; i++)
+        if (i < P.nlevels && band * kTile >= P.lv[i].row_base) l = i;
+    return l;
+}
+
+constexpr int kMaxTilesX = 128;  // tiles per band (images up to 4k pixels wide)
+constexpr int kMaxRows = 8192;   // bitmap rows over all levels (sum of level heights; ~2300 for 752x480)
+
+constexpr int kLowPitch = 40;  // bytes per row of the per-wave score window (10 aligned dwords)
+
+__global__ __launch_bounds__(256) void fast_low_count_kernel(PyramidParams P, int32_t* __restrict__ rowcount) {
+    __shared__ uint32_t ssc32[4][kScRows * (kLowPitch / 4)];  // one 34-row score window per wave
+    __shared__ uint32_t sbm[kTile][kMaxTilesX];                // the band's keep-bitmap
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lvl = find_level_by_band(P, blockIdx.x);
     const LevelDesc& L = P.lv[lvl];
-    const int t = blockIdx.x - L.tile_base;
-    if (L.tileflag[t]) return;  // uniform
-    const int ty = t / L.ntx, tx = t - ty * L.ntx;
+    const int ty = blockIdx.x - L.row_base / kTile;
     const int th_high = P.th_high;
 
-    for (int p = tid; p < kScRows * kScRows; p += 256) {
-        const int r = p / kScRows, c = p - r * kScRows;
-        int s = L.score[(size_t)(ty * kTile + r) * L.spitch + tx * kTile + c + (kScoreXOff - 1)];
-        const int tyq = ty + (r == 0 ? -1 : (r == kScRows - 1 ? 1 : 0));
-        const int txq = tx + (c == 0 ? -1 : (c == kScRows - 1 ? 1 : 0));
-        if (tyq >= 0 && tyq < L.nty && txq >= 0 && txq < L.ntx) {
-            if (L.tileflag[tyq * L.ntx + txq] && s < th_high) s = 0;
-        }
-        ssc[r * kScPitch + c] = (uint8_t)s;
+    // the band's words are contiguous in memory ([row][tile]): one coalesced sweep (empty tiles hold zeros)
+    for (int i = tid; i < kTile * L.ntx; i += 256) {
+        const int row = i / L.ntx, tx = i - row * L.ntx;
+        sbm[row][tx] = L.bitmap[(size_t)(ty * kTile) * L.ntx + i];
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int row = 8 * k + 2 * wave + (lane >> 5), col = lane & 31;
-        const uint8_t* q = ssc + (row + 1) * kScPitch + (col + 1);
-        const int s = q[0];
-        const int m = max(max(max((int)q[-kScPitch - 1], (int)q[-kScPitch]), max((int)q[-kScPitch + 1], (int)q[-1])),
-                          max(max((int)q[1], (int)q[kScPitch - 1]), max((int)q[kScPitch], (int)q[kScPitch + 1])));
-        const unsigned long long keep = __ballot(s > 0 && s > m);
-        if (lane == 0) {
-            uint32_t* b = L.bitmap + (size_t)(ty * kTile + 8 * k + 2 * wave) * L.ntx + tx;
-            b[0] = (uint32_t)keep;
-            b[L.ntx] = (uint32_t)(keep >> 32);
+    for (int tx = wave; tx < L.ntx; tx += 4) {  // wave-uniform loop: one tile per wave per round
+        if (L.tileflag[ty * L.ntx + tx]) continue;  // kept corners at the high threshold: words are final
+        uint32_t* gb = L.bitmap + (size_t)(ty * kTile) * L.ntx + tx;
+        uint32_t* sc32 = ssc32[wave];
+        uint8_t* sc = reinterpret_cast<uint8_t*>(sc32);
+        // 34 rows x 10 aligned dwords cover score-map columns [32 tx, 32 tx + 40); window pixel (r, c) of the
+        // 34x34 neighbourhood sits at byte (c + 3) of row r.  All loads are independent -> one memory latency.
+        for (int i = lane; i < kScRows * (kLowPitch / 4); i += 64) {
+            const int r = i / (kLowPitch / 4), dc = i - r * (kLowPitch / 4);
+            sc32[i] = *reinterpret_cast<const uint32_t*>(L.score + (size_t)(ty * kTile + r) * L.spitch + tx * kTile + 4 * dc);
         }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // halo pixels belong to neighbour tiles: one that kept high-threshold corners competes with its
+        // high-threshold score only (132 halo pixels: rows 0 / 33 and columns 0 / 33)
+        for (int i = lane; i < 4 * kScRows; i += 64) {
+            const int side = i / kScRows, k = i - side * kScRows;
+            const int r = side == 0 ? 0 : (side == 1 ? kScRows - 1 : k);
+            const int c = side == 2 ? 0 : (side == 3 ? kScRows - 1 : k);
+            const int tyq = ty + (r == 0 ? -1 : (r == kScRows - 1 ? 1 : 0));
+            const int txq = tx + (c == 0 ? -1 : (c == kScRows - 1 ? 1 : 0));
+            if (tyq >= 0 && tyq < L.nty && txq >= 0 && txq < L.ntx) {
+                uint8_t* q = sc + r * kLowPitch + c + 3;
+                if (L.tileflag[tyq * L.ntx + txq] && *q < th_high) *q = 0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int k = 0; k < 16; k++) {  // two tile rows per ballot
+            const int row = 2 * k + (lane >> 5), col = lane & 31;
+            const uint8_t* q = sc + (row + 1) * kLowPitch + (col + 1) + 3;
+            const int s = q[0];
+            const int m = max(max(max((int)q[-kLowPitch - 1], (int)q[-kLowPitch]), max((int)q[-kLowPitch + 1], (int)q[-1])),
+                              max(max((int)q[1], (int)q[kLowPitch - 1]), max((int)q[kLowPitch], (int)q[kLowPitch + 1])));
+            const unsigned long long keep = __ballot(s > 0 && s > m);
+            if (lane == 0) {
+                sbm[2 * k][tx] = (uint32_t)keep;
+                sbm[2 * k + 1][tx] = (uint32_t)(keep >> 32);
+                gb[(size_t)(2 * k) * L.ntx] = (uint32_t)keep;
+                gb[(size_t)(2 * k + 1) * L.ntx] = (uint32_t)(keep >> 32);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // 8 threads per row: popcount of the row's words
+    {
+        const int row = tid >> 3, part = tid & 7;
+        int cnt = 0;
+        for (int w = part; w < L.ntx; w += 8) cnt += __popc(sbm[row][w]);
+        cnt += __shfl_xor(cnt, 1);
+        cnt += __shfl_xor(cnt, 2);
+        cnt += __shfl_xor(cnt, 4);
+        if (part == 0) rowcount[L.row_base + ty * kTile + row] = cnt;
     }
 }
 
-void launch_fast_score(const PyramidParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(fast_score_kernel, dim3(p.total_tiles), dim3(256), 0, s, p);
-}
-void launch_fast_low(const PyramidParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(fast_low_kernel, dim3(p.total_tiles), dim3(256), 0, s, p);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Candidate compaction: keep-bitmaps of all levels -> records in (level, y, x) raster order, per-level
-// cap of 10000 (first in raster order), written to host-mapped memory in one coalesced sweep.
-// Single workgroup of 1024 threads: thread t owns a contiguous chunk of bitmap rows.
-// ------------------------------------------------------------------------------------------------
-constexpr int kCompactThreads = 1024;
-
-__global__ __launch_bounds__(kCompactThreads) void compact_kernel(PyramidParams P, Candidate* __restrict__ d_cands,
-                                                                   Candidate* __restrict__ h_cands,
-                                                                   CandidateHeader* __restrict__ h_header,
-                                                                   int cand_capacity) {
-    __shared__ int s_wave[16];
-    __shared__ int s_lvl_start[kMaxLevels + 1];  // exclusive prefix at the first row of each level
-    __shared__ int s_lvl_out[kMaxLevels + 1];    // output offset of each level after capping
+__global__ __launch_bounds__(256) void emit_kernel(PyramidParams P, const int32_t* __restrict__ rowcount,
+                                                    Candidate* __restrict__ h_cands,
+                                                    CandidateHeader* __restrict__ h_header, int cand_capacity) {
+    __shared__ int s_wave[4];
+    __shared__ int s_lvl_start[kMaxLevels + 1];
+    __shared__ int s_lvl_out[kMaxLevels + 1];
+    __shared__ int s_row_start[kTile];
+    __shared__ int s_rc[kMaxRows];
+    __shared__ uint32_t sbm[kTile][kMaxTilesX];   // the band's words
+    __shared__ int s_rank[kTile][kMaxTilesX];      // rank (inside the level) of each word's first keypoint
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = P.total_rows;
-    const int rpt = (R + kCompactThreads - 1) / kCompactThreads;
-    const int g0 = min(tid * rpt, R), g1 = min(g0 + rpt, R);
+    const int lvl = find_level_by_band(P, blockIdx.x);
+    const LevelDesc& L = P.lv[lvl];
+    const int my_row0 = blockIdx.x * kTile;  // global bitmap row of this band's first row
+    const int ty = blockIdx.x - L.row_base / kTile;
 
-    // pass 1: popcount my rows
-    int mine = 0;
-    for (int g = g0; g < g1; g++) {
-        int l = 0;
-#pragma unroll
-        for (int i = 1; i < kMaxLevels; i++)
-            if (i < P.nlevels && g >= P.lv[i].row_base) l = i;
-        const LevelDesc& L = P.lv[l];
-        const uint32_t* b = L.bitmap + (size_t)(g - L.row_base) * L.ntx;
-        for (int w = 0; w < L.ntx; w++) mine += __popc(b[w]);
+    for (int g = tid; g < R; g += 256) s_rc[g] = rowcount[g];
+    for (int i = tid; i < kTile * L.ntx; i += 256) {
+        const int row = i / L.ntx, tx = i - row * L.ntx;
+        sbm[row][tx] = L.bitmap[(size_t)(ty * kTile) * L.ntx + i];
     }
-    // block exclusive scan of `mine`
+    __syncthreads();
+    // exclusive prefix over all rows (thread t owns a contiguous chunk), redundantly in every band
+    const int rpt = (R + 255) / 256;
+    const int g0 = min(tid * rpt, R), g1 = min(g0 + rpt, R);
+    int mine = 0;
+    for (int g = g0; g < g1; g++) mine += s_rc[g];
     int incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -272,31 +317,17 @@ __global__ __launch_bounds__(kCompactThreads) void compact_kernel(PyramidParams 
     }
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    if (wave == 0) {
-        int v = lane < 16 ? s_wave[lane] : 0;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const int u = __shfl_up(v, off);
-            if (lane >= off) v += u;
-        }
-        if (lane < 16) s_wave[lane] = v;  // inclusive over waves
-    }
-    __syncthreads();
-    const int excl = incl - mine + (wave > 0 ? s_wave[wave - 1] : 0);
-    const int total = s_wave[15];
-
-    // level starts: the thread that owns the first row of a level publishes the prefix at that row
+    int wave_base = 0;
+    for (int i = 0; i < wave; i++) wave_base += s_wave[i];
+    const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     {
-        int run = excl;
+        int run = incl - mine + wave_base;
         for (int g = g0; g < g1; g++) {
-            int l = 0;
 #pragma unroll
-            for (int i = 1; i < kMaxLevels; i++)
-                if (i < P.nlevels && g >= P.lv[i].row_base) l = i;
-            const LevelDesc& L = P.lv[l];
-            if (g == L.row_base) s_lvl_start[l] = run;
-            const uint32_t* b = L.bitmap + (size_t)(g - L.row_base) * L.ntx;
-            for (int w = 0; w < L.ntx; w++) run += __popc(b[w]);
+            for (int l = 0; l < kMaxLevels; l++)
+                if (l < P.nlevels && P.lv[l].nty > 0 && g == P.lv[l].row_base) s_lvl_start[l] = run;
+            if (g >= my_row0 && g < my_row0 + kTile) s_row_start[g - my_row0] = run;
+            run += s_rc[g];
         }
     }
     if (tid == 0) s_lvl_start[P.nlevels] = total;
@@ -306,68 +337,75 @@ __global__ __launch_bounds__(kCompactThreads) void compact_kernel(PyramidParams 
             if (P.lv[l].nty == 0) s_lvl_start[l] = s_lvl_start[l + 1];
         int off = 0;
         for (int l = 0; l < P.nlevels; l++) {
-            const int cnt = min(s_lvl_start[l + 1] - s_lvl_start[l], kFastCap);
             s_lvl_out[l] = off;
-            h_header->count[l] = cnt;
-            h_header->offset[l] = off;
-            off += cnt;
-        }
-        for (int l = P.nlevels; l < kMaxLevels; l++) {
-            h_header->count[l] = 0;
-            h_header->offset[l] = off;
+            off += min(s_lvl_start[l + 1] - s_lvl_start[l], kFastCap);
         }
         s_lvl_out[P.nlevels] = off;
-        h_header->total = off;
-        h_header->uncapped_total = total;
-    }
-    __syncthreads();
-
-    // pass 2: emit my rows
-    {
-        int run = excl;
-        for (int g = g0; g < g1; g++) {
-            int l = 0;
-#pragma unroll
-            for (int i = 1; i < kMaxLevels; i++)
-                if (i < P.nlevels && g >= P.lv[i].row_base) l = i;
-            const LevelDesc& L = P.lv[l];
-            const int lr = g - L.row_base;
-            const uint32_t* b = L.bitmap + (size_t)lr * L.ntx;
-            const uint8_t* srow = L.score + (size_t)(lr + 1) * L.spitch + kScoreXOff;
-            for (int w = 0; w < L.ntx; w++) {
-                uint32_t word = b[w];
-                while (word) {
-                    const int bit = __ffs(word) - 1;
-                    word &= word - 1;
-                    const int rank = run - s_lvl_start[l];
-                    if (rank < kFastCap) {
-                        const int o = s_lvl_out[l] + rank;
-                        if (o < cand_capacity) {
-                            Candidate c;
-                            c.x = (int16_t)(3 + 32 * w + bit);
-                            c.y = (int16_t)(3 + lr);
-                            c.score = srow[32 * w + bit];
-                            c.level = (uint16_t)l;
-                            d_cands[o] = c;
-                        }
-                    }
-                    run++;
-                }
+        if (blockIdx.x == 0) {
+            for (int l = 0; l < kMaxLevels; l++) {
+                h_header->count[l] = l < P.nlevels ? min(s_lvl_start[l + 1] - s_lvl_start[l], kFastCap) : 0;
+                h_header->offset[l] = l < P.nlevels ? s_lvl_out[l] : off;
             }
+            h_header->total = off;
+            h_header->uncapped_total = total;
         }
     }
     __syncthreads();
-    // coalesced sweep device -> host-mapped (16 B per lane)
-    const int n_out = min(s_lvl_out[P.nlevels], cand_capacity);
-    const int n16 = (n_out + 1) / 2;
-    const uint4* src = reinterpret_cast<const uint4*>(d_cands);
-    uint4* dst = reinterpret_cast<uint4*>(h_cands);
-    for (int i = tid; i < n16; i += kCompactThreads) dst[i] = src[i];
+
+    // per-word ranks: one wave per row (8 rows per wave), all in LDS
+    const int lvl_start = s_lvl_start[lvl], lvl_out = s_lvl_out[lvl];
+    for (int rr = wave; rr < kTile; rr += 4) {
+        int base = s_row_start[rr] - lvl_start;
+        for (int w0 = 0; w0 < L.ntx; w0 += 64) {
+            const int w = w0 + lane;
+            const int c = w < L.ntx ? __popc(sbm[rr][w]) : 0;
+            int incl2 = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl2, off);
+                if (lane >= off) incl2 += v;
+            }
+            if (w < L.ntx) s_rank[rr][w] = base + incl2 - c;
+            base += __shfl(incl2, 63);
+        }
+    }
+    __syncthreads();
+    // emission: every thread takes words round-robin; score gathers and host stores of different threads overlap
+    for (int i = tid; i < kTile * L.ntx; i += 256) {
+        const int rr = i / L.ntx, w = i - rr * L.ntx;
+        uint32_t word = sbm[rr][w];
+        if (!word) continue;
+        const int lr = ty * kTile + rr;
+        const uint8_t* srow = L.score + (size_t)(lr + 1) * L.spitch + kScoreXOff + 32 * w;
+        int rank = s_rank[rr][w];
+        while (word) {
+            const int bit = __ffs(word) - 1;
+            word &= word - 1;
+            if (rank < kFastCap) {
+                const int o = lvl_out + rank;
+                if (o < cand_capacity) {
+                    Candidate cd;
+                    cd.x = (int16_t)(3 + 32 * w + bit);
+                    cd.y = (int16_t)(3 + lr);
+                    cd.score = srow[bit];
+                    cd.level = (uint16_t)lvl;
+                    h_cands[o] = cd;
+                }
+            }
+            rank++;
+        }
+    }
 }
 
-void launch_compact(const PyramidParams& p, Candidate* d_cands, Candidate* h_cands, CandidateHeader* h_header,
-                    int cand_capacity, hipStream_t s) {
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(kCompactThreads), 0, s, p, d_cands, h_cands, h_header,
+void launch_fast_score(const PyramidParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(fast_score_kernel, dim3(p.total_tiles), dim3(256), 0, s, p);
+}
+void launch_fast_low_count(const PyramidParams& p, int32_t* d_rowcount, hipStream_t s) {
+    hipLaunchKernelGGL(fast_low_count_kernel, dim3(p.total_rows / kTile), dim3(256), 0, s, p, d_rowcount);
+}
+void launch_emit(const PyramidParams& p, const int32_t* d_rowcount, Candidate* h_cands, CandidateHeader* h_header,
+                 int cand_capacity, hipStream_t s) {
+    hipLaunchKernelGGL(emit_kernel, dim3(p.total_rows / kTile), dim3(256), 0, s, p, d_rowcount, h_cands, h_header,
                        cand_capacity);
 }
 

@@ -9,11 +9,12 @@ namespace so {
 int KeypointQuadtree::new_node(int x0, int y0, int x1, int y1, int cap) {
     Node nd;
     nd.x0 = x0; nd.y0 = y0; nd.x1 = x1; nd.y1 = y1;
-    nd.off = (int)pool_.size();
+    nd.off = pool_used_;
     nd.n = 0;
     nd.prev = nd.next = -1;
     nd.leaf = false;
-    pool_.resize(pool_.size() + (size_t)cap);
+    pool_used_ += cap;
+    if ((size_t)pool_used_ > pool_.size()) pool_.resize((size_t)pool_used_ * 2 + 1024);  // grows only in the first frames
     nodes_.push_back(nd);
     return (int)nodes_.size() - 1;
 }
@@ -50,15 +51,22 @@ void KeypointQuadtree::split(int id, const Candidate* c, int child[4]) {
     const int half_x = (int)std::ceil((float)(P.x1 - P.x0) / 2);
     const int half_y = (int)std::ceil((float)(P.y1 - P.y0) / 2);
     const int xm = P.x0 + half_x, ym = P.y0 + half_y;
-    child[0] = new_node(P.x0, P.y0, xm, ym, P.n);
-    child[1] = new_node(xm, P.y0, P.x1, ym, P.n);
-    child[2] = new_node(P.x0, ym, xm, P.y1, P.n);
-    child[3] = new_node(xm, ym, P.x1, P.y1, P.n);
+    // two passes: count the quadrant populations, then place -> the children use exactly P.n pool slots
+    if ((int)quad_.size() < P.n) quad_.resize((size_t)P.n * 2 + 64);
+    int cnt[4] = {0, 0, 0, 0};
     for (int i = 0; i < P.n; i++) {
         const int ci = pool_[P.off + i];
         const int q = (c[ci].x < xm ? 0 : 1) + (c[ci].y < ym ? 0 : 2);
-        Node& d = nodes_[child[q]];
-        pool_[d.off + d.n++] = ci;
+        quad_[(size_t)i] = (uint8_t)q;
+        cnt[q]++;
+    }
+    child[0] = new_node(P.x0, P.y0, xm, ym, cnt[0]);
+    child[1] = new_node(xm, P.y0, P.x1, ym, cnt[1]);
+    child[2] = new_node(P.x0, ym, xm, P.y1, cnt[2]);
+    child[3] = new_node(xm, ym, P.x1, P.y1, cnt[3]);
+    for (int i = 0; i < P.n; i++) {
+        Node& d = nodes_[child[quad_[(size_t)i]]];
+        pool_[d.off + d.n++] = pool_[P.off + i];
     }
     for (int k = 0; k < 4; k++)
         if (nodes_[child[k]].n == 1) nodes_[child[k]].leaf = true;
@@ -81,9 +89,8 @@ int KeypointQuadtree::distribute(const Candidate* c, int n, int roi_w, int roi_h
     out.clear();
     if (n <= 0) return 0;
     nodes_.clear();
-    pool_.clear();
-    nodes_.reserve(4096);
-    pool_.reserve((size_t)n * 12 + 64);
+    if (nodes_.capacity() < 8192) nodes_.reserve(8192);
+    pool_used_ = 0;
     head_ = tail_ = -1;
     size_ = 0;
 
@@ -91,15 +98,15 @@ int KeypointQuadtree::distribute(const Candidate* c, int n, int roi_w, int roi_h
     int n_ini = (int)std::round((float)roi_w / (float)roi_h);
     if (n_ini < 1) n_ini = 1;  // reference divides by zero here for very tall images
     const float hx = (float)roi_w / (float)n_ini;
-    std::vector<int> roots((size_t)n_ini);
+    roots_.resize((size_t)n_ini);
     for (int i = 0; i < n_ini; i++) {
-        roots[(size_t)i] = new_node((int)(hx * (float)i), 0, (int)(hx * (float)(i + 1)), roi_h, n);
-        push_back(roots[(size_t)i]);
+        roots_[(size_t)i] = new_node((int)(hx * (float)i), 0, (int)(hx * (float)(i + 1)), roi_h, n);
+        push_back(roots_[(size_t)i]);
     }
     for (int i = 0; i < n; i++) {
         int r = (int)((float)c[i].x / hx);
         if (r >= n_ini) r = n_ini - 1;
-        Node& d = nodes_[roots[(size_t)r]];
+        Node& d = nodes_[roots_[(size_t)r]];
         pool_[d.off + d.n++] = i;
     }
     for (int it = head_; it >= 0;) {  // :498-511

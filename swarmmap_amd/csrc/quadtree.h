@@ -29,7 +29,10 @@ private:
         bool leaf;  // bNoMore
     };
     std::vector<Node> nodes_;
-    std::vector<int> pool_;
+    std::vector<int> pool_;   // key slices; high-water sized, reused frame after frame
+    int pool_used_ = 0;
+    std::vector<uint8_t> quad_;  // scratch: quadrant of each key of the node being split
+    std::vector<int> roots_;
     std::vector<std::pair<int, int>> expand_, prev_expand_;  // (population, creation seq == node id)
     int head_ = -1, tail_ = -1, size_ = 0;
 

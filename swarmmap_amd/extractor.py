@@ -12,7 +12,8 @@ from . import _lib
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 
-STAGES = ("pyramid", "fast_score", "fast_low", "compact", "describe", "host_wall")
+STAGES = ("pyramid", "fast_score", "fast_low", "compact", "describe", "host_wall", "host_enqueue1", "host_wait1",
+          "host_quadtree", "host_phase2", "host_assemble")
 
 
 def _vp(a):
