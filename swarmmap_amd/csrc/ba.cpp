@@ -559,7 +559,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.huber_delta = (double)opt->huber_delta;
     d.huber_dsqr = (float)((double)opt->huber_delta * (double)opt->huber_delta);  // RobustKernelHuber::setDelta
     r.nb_err = std::min(1024, std::max(1, (P.n_edges + 255) / 256));
-    r.nb_upd = std::min(1024, std::max(1, (P.n_points + P.n_poses + 255) / 256));
+    r.nb_upd = std::min(1024, std::max(1, (8 * P.n_points + P.n_poses + 255) / 256));
     if ((rc = upload_stage(r))) return rc;
 
     SO_HIP(hipEventRecord(b->e0, s));

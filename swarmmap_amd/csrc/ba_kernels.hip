@@ -13,6 +13,10 @@
 //   core/block_solver.hpp:354-486       Schur complement, back-substitution
 #include "ba_device.h"
 
+// FP64 solver: parity with the oracle is tolerance-based (see tests/test_ba_gpu.py), so let the compiler fuse
+// multiply-adds here (the ORB translation unit stays contraction-free for bit parity).
+#pragma clang fp contract(fast)
+
 namespace so {
 
 // ---------------- SE3Quat pieces (se3quat.h), same formulas as the CPU oracle ----------------
@@ -264,45 +268,58 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, const BaPose* __
         }
         return;
     }
-    // landmark role: one thread per landmark, its edges are contiguous
-    const int il = (blockIdx.x - d.n_free) * 256 + threadIdx.x;
-    if (il >= d.n_points || !d.pt_active[il]) return;
-    const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+    // landmark role: 8 lanes per landmark (32 landmarks per workgroup); a landmark's edges are contiguous, each
+    // lane linearises every 8th one, then a fixed xor-butterfly over the 8 lanes sums Hll (6 unique) and bl (3)
+    const int il = (blockIdx.x - d.n_free) * 32 + (threadIdx.x >> 3);
+    const int sub = threadIdx.x & 7;
+    const bool live = il < d.n_points && d.pt_active[il];
     double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    for (int e = d.pt_off[il]; e < d.pt_off[il + 1]; e++) {
-        if (!d.e_active[e]) continue;
-        const int ip = d.e_pose[e];
-        double Jp[6], Jc[12];
-        edge_jacobians(poses[ip], X, d.intr + 4 * ip, Jp, Jc);
-        const double om = d.e_w[e];
-        const double r1 = d.robust ? huber_rho1(d.e_chi2[e], d.huber_delta, d.huber_dsqr) : 1.0;
-        const double w = r1 * om;
-        const double o0 = -om * d.e_err[2 * e] * r1, o1 = -om * d.e_err[2 * e + 1] * r1;
-        H[0] += Jp[0] * w * Jp[0] + Jp[3] * w * Jp[3];
-        H[1] += Jp[0] * w * Jp[1] + Jp[3] * w * Jp[4];
-        H[2] += Jp[0] * w * Jp[2] + Jp[3] * w * Jp[5];
-        H[3] += Jp[1] * w * Jp[1] + Jp[4] * w * Jp[4];
-        H[4] += Jp[1] * w * Jp[2] + Jp[4] * w * Jp[5];
-        H[5] += Jp[2] * w * Jp[2] + Jp[5] * w * Jp[5];
+    if (live) {
+        const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+        for (int e = d.pt_off[il] + sub; e < d.pt_off[il + 1]; e += 8) {
+            if (!d.e_active[e]) continue;
+            const int ip = d.e_pose[e];
+            double Jp[6], Jc[12];
+            edge_jacobians(poses[ip], X, d.intr + 4 * ip, Jp, Jc);
+            const double om = d.e_w[e];
+            const double r1 = d.robust ? huber_rho1(d.e_chi2[e], d.huber_delta, d.huber_dsqr) : 1.0;
+            const double w = r1 * om;
+            const double o0 = -om * d.e_err[2 * e] * r1, o1 = -om * d.e_err[2 * e + 1] * r1;
+            H[0] += Jp[0] * w * Jp[0] + Jp[3] * w * Jp[3];
+            H[1] += Jp[0] * w * Jp[1] + Jp[3] * w * Jp[4];
+            H[2] += Jp[0] * w * Jp[2] + Jp[3] * w * Jp[5];
+            H[3] += Jp[1] * w * Jp[1] + Jp[4] * w * Jp[4];
+            H[4] += Jp[1] * w * Jp[2] + Jp[4] * w * Jp[5];
+            H[5] += Jp[2] * w * Jp[2] + Jp[5] * w * Jp[5];
 #pragma unroll
-        for (int r = 0; r < 3; r++) b[r] += Jp[r] * o0 + Jp[3 + r] * o1;
-        if (d.pose_hidx[ip] >= 0) {
-            double* W = d.W + 18 * (size_t)e;  // pose x point = J_c^T w J_p
+            for (int r = 0; r < 3; r++) b[r] += Jp[r] * o0 + Jp[3 + r] * o1;
+            if (d.pose_hidx[ip] >= 0) {
+                double* W = d.W + 18 * (size_t)e;  // pose x point = J_c^T w J_p
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+                for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) W[r * 3 + c] = Jc[r] * w * Jp[c] + Jc[6 + r] * w * Jp[3 + c];
+                    for (int c = 0; c < 3; c++) W[r * 3 + c] = Jc[r] * w * Jp[c] + Jc[6 + r] * w * Jp[3 + c];
+            }
         }
     }
-    double* Hl = d.Hll + 9 * (size_t)il;
-    Hl[0] = H[0]; Hl[1] = H[1]; Hl[2] = H[2];
-    Hl[3] = H[1]; Hl[4] = H[3]; Hl[5] = H[4];
-    Hl[6] = H[2]; Hl[7] = H[4]; Hl[8] = H[5];
-    d.bl[3 * (size_t)il] = b[0]; d.bl[3 * (size_t)il + 1] = b[1]; d.bl[3 * (size_t)il + 2] = b[2];
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) H[k] += __shfl_xor(H[k], off);
+#pragma unroll
+        for (int k = 0; k < 3; k++) b[k] += __shfl_xor(b[k], off);
+    }
+    if (live && sub == 0) {
+        double* Hl = d.Hll + 9 * (size_t)il;
+        Hl[0] = H[0]; Hl[1] = H[1]; Hl[2] = H[2];
+        Hl[3] = H[1]; Hl[4] = H[3]; Hl[5] = H[4];
+        Hl[6] = H[2]; Hl[7] = H[4]; Hl[8] = H[5];
+        d.bl[3 * (size_t)il] = b[0]; d.bl[3 * (size_t)il + 1] = b[1]; d.bl[3 * (size_t)il + 2] = b[2];
+    }
 }
 
 void launch_ba_build(const BaDev& d, const BaPose* poses, const double* points, hipStream_t s) {
-    const int nb = d.n_free + (d.n_points + 255) / 256;
+    const int nb = d.n_free + (d.n_points + 31) / 32;
     if (nb <= 0) return;
     hipLaunchKernelGGL(ba_build_kernel, dim3(nb), dim3(256), 0, s, d, poses, points);
 }
@@ -330,29 +347,36 @@ void launch_ba_maxdiag(const BaDev& d, hipStream_t s) {
 }
 
 // ---------------- Schur complement ----------------
-// prep: per landmark Dinv = (Hll + lambda I)^-1 (cofactors), db = Dinv bl, BDinv_e = W_e Dinv
-__global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d, double lambda) {
-    const int il = blockIdx.x * 256 + threadIdx.x;
-    if (il >= d.n_points || !d.pt_active[il]) return;
-    const double* Hl = d.Hll + 9 * (size_t)il;
+__device__ __forceinline__ void damped_inverse3(const double* Hl, double lambda, double* Di) {
     const double m0 = Hl[0] + lambda, m1 = Hl[1], m2 = Hl[2], m3 = Hl[3], m4 = Hl[4] + lambda, m5 = Hl[5], m6 = Hl[6],
                  m7 = Hl[7], m8 = Hl[8] + lambda;
     const double c00 = m4 * m8 - m5 * m7, c01 = m5 * m6 - m3 * m8, c02 = m3 * m7 - m4 * m6;
     const double invdet = 1.0 / (m0 * c00 + m1 * c01 + m2 * c02);
-    double Di[9];
     Di[0] = c00 * invdet; Di[1] = (m2 * m7 - m1 * m8) * invdet; Di[2] = (m1 * m5 - m2 * m4) * invdet;
     Di[3] = c01 * invdet; Di[4] = (m0 * m8 - m2 * m6) * invdet; Di[5] = (m2 * m3 - m0 * m5) * invdet;
     Di[6] = c02 * invdet; Di[7] = (m1 * m6 - m0 * m7) * invdet; Di[8] = (m0 * m4 - m1 * m3) * invdet;
-    double* Do = d.Dinv + 9 * (size_t)il;
+}
+
+// prep: thread i < n_points: Dinv = (Hll + lambda I)^-1 (cofactors, like Eigen's 3x3 inverse), db = Dinv bl;
+//       thread i < n_edges : BDinv_e = W_e Dinv (recomputing the 3x3 inverse of its landmark: no dependency
+//       between the two roles, so everything is one memory latency deep)
+__global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d, double lambda) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.n_points && d.pt_active[i]) {
+        double Di[9];
+        damped_inverse3(d.Hll + 9 * (size_t)i, lambda, Di);
+        double* Do = d.Dinv + 9 * (size_t)i;
 #pragma unroll
-    for (int i = 0; i < 9; i++) Do[i] = Di[i];
-    const double* bl = d.bl + 3 * (size_t)il;
+        for (int k = 0; k < 9; k++) Do[k] = Di[k];
+        const double* bl = d.bl + 3 * (size_t)i;
 #pragma unroll
-    for (int r = 0; r < 3; r++) d.db[3 * (size_t)il + r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
-    for (int e = d.pt_off[il]; e < d.pt_off[il + 1]; e++) {
-        if (!d.e_active[e] || d.pose_hidx[d.e_pose[e]] < 0) continue;
-        const double* W = d.W + 18 * (size_t)e;
-        double* B = d.BDinv + 18 * (size_t)e;
+        for (int r = 0; r < 3; r++) d.db[3 * (size_t)i + r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
+    }
+    if (i < d.n_edges && d.e_active[i] && d.pose_hidx[d.e_pose[i]] >= 0) {
+        double Di[9];
+        damped_inverse3(d.Hll + 9 * (size_t)d.e_point[i], lambda, Di);
+        const double* W = d.W + 18 * (size_t)i;
+        double* B = d.BDinv + 18 * (size_t)i;
 #pragma unroll
         for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -360,8 +384,9 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d, double lamb
     }
 }
 
-// gather: one wave per upper block (i1 <= i2) of the reduced camera system, 36 lanes = the 6x6 entries;
-//         S(i1,i2) = [i1 == i2] (Hpp + lambda I) - sum over shared landmarks BDinv_{k1} W_{k2}^T ; mirrored.
+// gather: one wave per upper block (i1 <= i2) of the reduced camera system.  The block's (edge, edge) pairs are
+//         strided over the 64 lanes, each lane accumulates a full 6x6 partial, then a fixed xor-butterfly sums the
+//         lanes: S(i1,i2) = [i1 == i2] (Hpp + lambda I) - sum over shared landmarks BDinv_{k1} W_{k2}^T ; mirrored.
 //         extra waves: b_schur(i) = bp(i) - sum over the pose's edges W_e db_{landmark(e)}
 __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, double lambda, const int* __restrict__ blk_i1,
                                                                const int* __restrict__ blk_i2, int n_blk) {
@@ -369,18 +394,34 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, double la
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = 6 * d.n_free;
     if (g < n_blk) {
-        if (lane >= 36) return;
         const int i1 = blk_i1[g], i2 = blk_i2[g];
-        const int r = lane / 6, c = lane - 6 * r;
-        double acc = 0.0;
-        if (i1 == i2) acc = d.Hpp[36 * (size_t)i1 + lane] + (r == c ? lambda : 0.0);
-        for (int p = d.blk_off[g]; p < d.blk_off[g + 1]; p++) {
-            const double* B = d.BDinv + 18 * (size_t)d.pair_k1[p] + 3 * r;
-            const double* W = d.W + 18 * (size_t)d.pair_k2[p] + 3 * c;
-            acc -= B[0] * W[0] + B[1] * W[1] + B[2] * W[2];
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; k++) acc[k] = 0.0;
+        for (int p = d.blk_off[g] + lane; p < d.blk_off[g + 1]; p += 64) {
+            const double* B = d.BDinv + 18 * (size_t)d.pair_k1[p];
+            const double* W = d.W + 18 * (size_t)d.pair_k2[p];
+            double b[18], w[18];
+#pragma unroll
+            for (int k = 0; k < 18; k++) { b[k] = B[k]; w[k] = W[k]; }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    acc[r * 6 + c] += b[r * 3] * w[c * 3] + b[r * 3 + 1] * w[c * 3 + 1] + b[r * 3 + 2] * w[c * 3 + 2];
         }
-        d.S[(size_t)(6 * i1 + r) * n + 6 * i2 + c] = acc;
-        if (i1 != i2) d.S[(size_t)(6 * i2 + c) * n + 6 * i1 + r] = acc;
+#pragma unroll
+        for (int k = 0; k < 36; k++) acc[k] = wave_sum(acc[k]);
+        if (lane < 36) {
+            const int r = lane / 6, c = lane - 6 * r;
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 36; k++) v = (k == lane) ? acc[k] : v;  // select without dynamic register indexing
+            double out = -v;
+            if (i1 == i2) out += d.Hpp[36 * (size_t)i1 + lane] + (r == c ? lambda : 0.0);
+            d.S[(size_t)(6 * i1 + r) * n + 6 * i2 + c] = out;
+            if (i1 != i2) d.S[(size_t)(6 * i2 + c) * n + 6 * i1 + r] = out;
+        }
         return;
     }
     const int hi = g - n_blk;
@@ -401,10 +442,201 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, double la
 }
 
 // ---------------- dense Cholesky solve of the reduced camera system (single workgroup) ----------------
-// Right-looking LL^T on the lower triangle of S with the right-hand side carried as an extra row, then the
-// backward substitution.  Replaces LinearSolverEigen's SimplicialLDLT (linear_solver_eigen.h:94-124): same
-// solution up to rounding.  The local-BA systems are 6 * (10..100) unknowns; latency-bound by design.
-__global__ __launch_bounds__(1024) void ba_solve_kernel(BaDev d) {
+// Replaces LinearSolverEigen's SimplicialLDLT (linear_solver_eigen.h:94-124): same solution up to rounding.
+//
+// Fast path (n_free <= 43): 6x6-block right-looking Cholesky held entirely in REGISTERS.  The lower block
+// triangle of S plus one extra block row carrying the right-hand side is dealt out to 256 threads (<= 4 blocks
+// of 36 doubles each); per block step k the owner of (k,k) factors its 6x6 block, the owners of column k solve
+// against it and publish their blocks through LDS, and every owner of a trailing block applies its rank-6
+// update from two LDS blocks.  Two barriers per 6 columns instead of three per column, and no global memory
+// between the initial load and the final store.  The forward substitution falls out of the extra block row; the
+// backward substitution walks the block columns right to left (again two barriers per block).
+constexpr int kSolveThreads = 256, kSolveBPT = 4, kSolveMaxNB = 44;
+
+__device__ __forceinline__ void decode_lower_block(int p, int& I, int& J) {
+    int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= p) i++;
+    while (i * (i + 1) / 2 > p) i--;
+    I = i;
+    J = p - i * (i + 1) / 2;
+}
+
+__global__ __launch_bounds__(kSolveThreads) void ba_solve_blocked_kernel(BaDev d) {
+    __shared__ double s_diag[36];
+    __shared__ double s_panel[2][kSolveMaxNB][36];
+    __shared__ double s_Ld[kSolveMaxNB][36];
+    __shared__ double s_y[kSolveMaxNB][6];
+    __shared__ double s_x[6];
+    __shared__ double s_dinv[6];
+    __shared__ double s_Ldinv[kSolveMaxNB][6];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int nf = d.n_free, NB = nf + 1, n = 6 * nf, nblk = NB * (NB + 1) / 2;
+    double a[kSolveBPT][36];
+    int bI[kSolveBPT], bJ[kSolveBPT];
+    if (tid == 0) s_fail = 0;
+#pragma unroll
+    for (int s = 0; s < kSolveBPT; s++) {
+        const int p = tid + s * kSolveThreads;
+        bI[s] = -1;
+        bJ[s] = -1;
+#pragma unroll
+        for (int k = 0; k < 36; k++) a[s][k] = 0.0;
+        if (p < nblk) {
+            int I, J;
+            decode_lower_block(p, I, J);
+            if (!(I == nf && J == nf)) {
+                bI[s] = I;
+                bJ[s] = J;
+                if (I < nf) {
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c < 6; c++) a[s][r * 6 + c] = d.S[(size_t)(6 * I + r) * n + 6 * J + c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) a[s][c] = d.bs[6 * J + c];  // right-hand side rides as row 0
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < nf; k++) {
+        const int buf = k & 1;
+#pragma unroll
+        for (int s = 0; s < kSolveBPT; s++) {
+            if (bI[s] == k && bJ[s] == k) {  // factor the diagonal block in place (lower), publish it
+                double* A = a[s];
+                bool bad = false;
+                double rinv[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double v = A[c * 6 + c];
+#pragma unroll
+                    for (int m = 0; m < c; m++) v -= A[c * 6 + m] * A[c * 6 + m];
+                    if (!(v > 0.0)) bad = true;
+                    const double l = sqrt(v);
+                    rinv[c] = 1.0 / l;  // one division per column; everything else multiplies by it
+                    A[c * 6 + c] = l;
+#pragma unroll
+                    for (int r = c + 1; r < 6; r++) {
+                        double u = A[r * 6 + c];
+#pragma unroll
+                        for (int m = 0; m < c; m++) u -= A[r * 6 + m] * A[c * 6 + m];
+                        A[r * 6 + c] = u * rinv[c];
+                    }
+#pragma unroll
+                    for (int r = 0; r < c; r++) A[r * 6 + c] = 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 36; q++) {
+                    s_diag[q] = A[q];
+                    s_Ld[k][q] = A[q];
+                }
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    s_dinv[c] = rinv[c];
+                    s_Ldinv[k][c] = rinv[c];
+                }
+                if (bad) s_fail = 1;
+            }
+        }
+        __syncthreads();
+        if (s_fail) break;
+#pragma unroll
+        for (int s = 0; s < kSolveBPT; s++) {
+            if (bJ[s] == k && bI[s] > k) {  // X = A L_kk^-T, row by row
+                double* A = a[s];
+                double L[36], ri[6];
+#pragma unroll
+                for (int q = 0; q < 36; q++) L[q] = s_diag[q];
+#pragma unroll
+                for (int c = 0; c < 6; c++) ri[c] = s_dinv[c];
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double v = A[r * 6 + c];
+#pragma unroll
+                        for (int m = 0; m < c; m++) v -= A[r * 6 + m] * L[c * 6 + m];
+                        A[r * 6 + c] = v * ri[c];
+                    }
+#pragma unroll
+                for (int q = 0; q < 36; q++) s_panel[buf][bI[s]][q] = A[q];
+                if (bI[s] == nf) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) s_y[k][c] = A[c];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < kSolveBPT; s++) {
+            if (bJ[s] > k) {  // trailing update A_IJ -= L_Ik L_Jk^T  (bI >= bJ > k)
+                double* A = a[s];
+                const double* Pj = s_panel[buf][bJ[s]];
+                const double* Pi = s_panel[buf][bI[s]];
+                double pj[36];
+#pragma unroll
+                for (int q = 0; q < 36; q++) pj[q] = Pj[q];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    double pi[6];
+#pragma unroll
+                    for (int m = 0; m < 6; m++) pi[m] = Pi[r * 6 + m];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 6; m++) v += pi[m] * pj[c * 6 + m];
+                        A[r * 6 + c] -= v;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_fail) {
+        for (int K = nf - 1; K >= 0; K--) {  // L^T x = y, block columns right to left
+            if (tid == 0) {
+                double x[6];
+#pragma unroll
+                for (int c = 5; c >= 0; c--) {
+                    double v = s_y[K][c];
+#pragma unroll
+                    for (int m = c + 1; m < 6; m++) v -= s_Ld[K][m * 6 + c] * x[m];
+                    x[c] = v * s_Ldinv[K][c];
+                }
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    s_x[c] = x[c];
+                    d.bs[6 * K + c] = x[c];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < kSolveBPT; s++) {
+                if (bI[s] == K && bJ[s] < K) {  // y_J -= L_KJ^T x_K (one block per J in this step)
+                    const double* A = a[s];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 6; r++) v += A[r * 6 + c] * s_x[r];
+                        s_y[bJ[s]][c] -= v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) d.partial[kBaSolveOk] = s_fail ? 0.0 : 1.0;
+}
+
+// General path (any n_free): unblocked right-looking LL^T on the lower triangle of S in global memory with the
+// right-hand side carried as an extra row.  Latency-bound (three global round trips per column); only used for
+// windows with more than 43 free keyframes.
+__global__ __launch_bounds__(1024) void ba_solve_global_kernel(BaDev d) {
     __shared__ int s_fail;
     const int n = 6 * d.n_free;
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
@@ -445,15 +677,21 @@ __global__ __launch_bounds__(1024) void ba_solve_kernel(BaDev d) {
 }
 
 void launch_ba_schur(const BaDev& d, double lambda, const int* blk_i1, const int* blk_i2, int n_blk, hipStream_t s) {
-    if (d.n_points > 0)
-        hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((d.n_points + 255) / 256), dim3(256), 0, s, d, lambda);
+    const int nthreads = d.n_points > d.n_edges ? d.n_points : d.n_edges;
+    if (nthreads > 0)
+        hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d, lambda);
     const int waves = n_blk + d.n_free;
     if (waves > 0)
         hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d, lambda, blk_i1, blk_i2,
                            n_blk);
 }
 
-void launch_ba_solve(const BaDev& d, hipStream_t s) { hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(1024), 0, s, d); }
+void launch_ba_solve(const BaDev& d, hipStream_t s) {
+    if (d.n_free + 1 <= kSolveMaxNB)
+        hipLaunchKernelGGL(ba_solve_blocked_kernel, dim3(1), dim3(kSolveThreads), 0, s, d);
+    else
+        hipLaunchKernelGGL(ba_solve_global_kernel, dim3(1), dim3(1024), 0, s, d);
+}
 
 // ---------------- back-substitution + manifold update into the trial buffers + scale partials ----------------
 __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d, double lambda, const BaPose* __restrict__ poses,
@@ -463,15 +701,15 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d, double lambda, 
     __shared__ double s_tmp[16];
     double scale = 0.0;  // computeScale: sum x (lambda x + b)
     const double* xp = d.bs;
-    const int total = d.n_points + d.n_poses;
+    // landmarks: 8 lanes each (xl = Dinv (bl - sum_e W_e^T x_pose(e))), then one thread per keyframe
+    const int total = 8 * d.n_points + d.n_poses;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        if (i < d.n_points) {
-            const int il = i;
-            double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
-            if (d.pt_active[il]) {
-                const double* bl = d.bl + 3 * (size_t)il;
-                double cl[3] = {bl[0], bl[1], bl[2]};
-                for (int e = d.pt_off[il]; e < d.pt_off[il + 1]; e++) {
+        if (i < 8 * d.n_points) {
+            const int il = i >> 3, sub = i & 7;
+            const bool act = d.pt_active[il];
+            double cl[3] = {0, 0, 0};
+            if (act) {
+                for (int e = d.pt_off[il] + sub; e < d.pt_off[il + 1]; e += 8) {
                     if (!d.e_active[e]) continue;
                     const int hi = d.pose_hidx[d.e_pose[e]];
                     if (hi < 0) continue;
@@ -482,18 +720,30 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d, double lambda, 
 #pragma unroll
                         for (int r = 0; r < 6; r++) cl[c] -= W[r * 3 + c] * x[r];
                 }
-                const double* Di = d.Dinv + 9 * (size_t)il;
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
-                    d.xl[3 * (size_t)il + r] = xl;
-                    scale += xl * (lambda * xl + bl[r]);
-                    X[r] += xl;
-                }
             }
-            points_trial[3 * il] = X[0]; points_trial[3 * il + 1] = X[1]; points_trial[3 * il + 2] = X[2];
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) cl[c] += __shfl_xor(cl[c], off);
+            }
+            if (sub == 0) {
+                double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+                if (act) {
+                    const double* bl = d.bl + 3 * (size_t)il;
+                    cl[0] += bl[0]; cl[1] += bl[1]; cl[2] += bl[2];
+                    const double* Di = d.Dinv + 9 * (size_t)il;
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
+                        d.xl[3 * (size_t)il + r] = xl;
+                        scale += xl * (lambda * xl + bl[r]);
+                        X[r] += xl;
+                    }
+                }
+                points_trial[3 * il] = X[0]; points_trial[3 * il + 1] = X[1]; points_trial[3 * il + 2] = X[2];
+            }
         } else {
-            const int ip = i - d.n_points;
+            const int ip = i - 8 * d.n_points;
             const int hi = d.pose_hidx[ip];
             if (hi >= 0) {
                 const double* x = xp + 6 * (size_t)hi;

@@ -1,0 +1,66 @@
+// ORBmatcher.cc — see ORBmatcher.h.
+#include "ORBmatcher.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+namespace ORB_SLAM2 {
+
+static void check(int status, const char* what) {
+    if (status != SO_OK)
+        throw std::runtime_error(std::string(what) + ": " + so_status_string(status) + " (" + so_last_error() + ")");
+}
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri, int device) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
+    check(so_matcher_create(device, &handle_), "so_matcher_create");
+}
+
+ORBmatcher::~ORBmatcher() { so_matcher_destroy(handle_); }
+
+int ORBmatcher::DescriptorDistance(const uint8_t* a, const uint8_t* b) {  // ORBmatcher.cc:1511-1525
+    int dist = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t x, y;
+        std::memcpy(&x, a + 8 * i, 8);
+        std::memcpy(&y, b + 8 * i, 8);
+        dist += __builtin_popcountll(x ^ y);
+    }
+    return dist;
+}
+
+int ORBmatcher::SearchByProjection(const so_frame_view& F, const MapPointViews& mp, float th,
+                                   std::vector<int32_t>& kp_to_mp) {
+    kp_to_mp.assign((size_t)F.n, -1);
+    int32_t nmatches = 0;
+    check(so_search_by_projection_mappoints(handle_, &F, (int32_t)mp.proj_x.size(), mp.in_view.data(), mp.proj_x.data(),
+                                            mp.proj_y.data(), mp.view_cos.data(), mp.pred_level.data(), mp.desc.data(),
+                                            mp.has_obs.data(), th, mfNNratio, kp_to_mp.data(), &nmatches),
+          "so_search_by_projection_mappoints");
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(const so_frame_view& cur, const LastFrameViews& last, float th,
+                                   std::vector<int32_t>& kp_to_last) {
+    kp_to_last.assign((size_t)cur.n, -1);
+    int32_t nmatches = 0;
+    check(so_search_by_projection_lastframe(handle_, &cur, (int32_t)last.u.size(), last.valid.data(), last.u.data(),
+                                            last.v.data(), last.octave.data(), last.angle.data(), last.desc.data(),
+                                            last.has_obs.data(), th, mbCheckOrientation ? 1 : 0, kp_to_last.data(),
+                                            &nmatches),
+          "so_search_by_projection_lastframe");
+    return nmatches;
+}
+
+int ORBmatcher::SearchForInitialization(const so_frame_view& F1, const so_frame_view& F2,
+                                        std::vector<float>& vbPrevMatched, std::vector<int32_t>& vnMatches12,
+                                        int windowSize) {
+    vnMatches12.assign((size_t)F1.n, -1);
+    int32_t nmatches = 0;
+    check(so_search_for_initialization(handle_, &F1, &F2, vbPrevMatched.data(), windowSize, mfNNratio,
+                                       mbCheckOrientation ? 1 : 0, vnMatches12.data(), &nmatches),
+          "so_search_for_initialization");
+    return nmatches;
+}
+
+}  // namespace ORB_SLAM2

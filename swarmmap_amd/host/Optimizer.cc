@@ -1,0 +1,51 @@
+// Optimizer.cc — see Optimizer.h.
+#include "Optimizer.h"
+
+#include <stdexcept>
+#include <string>
+
+namespace ORB_SLAM2 {
+
+static void check(int status, const char* what) {
+    if (status != SO_OK)
+        throw std::runtime_error(std::string(what) + ": " + so_status_string(status) + " (" + so_last_error() + ")");
+}
+
+Optimizer::Optimizer(int device) { check(so_ba_create(device, &handle_), "so_ba_create"); }
+Optimizer::~Optimizer() { so_ba_destroy(handle_); }
+
+void Optimizer::solve(const BAWindow& w, const so_ba_options& opt, bool* pbStopFlag, BAResult& out) {
+    static_assert(sizeof(bool) == 1, "pbStopFlag is polled as a byte");
+    so_ba_problem p{};
+    p.n_poses = (int32_t)w.fixed.size();
+    p.Tcw = w.Tcw.data();
+    p.fixed = w.fixed.data();
+    p.intr = w.intr.data();
+    p.n_points = (int32_t)(w.Xw.size() / 3);
+    p.Xw = w.Xw.data();
+    p.n_edges = (int32_t)w.edge_kf.size();
+    p.edge_pose = w.edge_kf.data();
+    p.edge_point = w.edge_mp.data();
+    p.obs = w.obs.data();
+    p.inv_sigma2 = w.inv_sigma2.data();
+    out.Tcw.assign(w.Tcw.size(), 0.f);
+    out.Xw.assign(w.Xw.size(), 0.f);
+    out.edge_outlier.assign(w.edge_kf.size(), 0);
+    check(so_bundle_adjust(handle_, &p, &opt, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), out.Tcw.data(),
+                           out.Xw.data(), out.edge_outlier.data(), nullptr, &out.info),
+          "so_bundle_adjust");
+}
+
+void Optimizer::LocalBundleAdjustment(const BAWindow& window, bool* pbStopFlag, BAResult& out) {
+    so_ba_options opt;
+    so_ba_options_local(&opt);
+    solve(window, opt, pbStopFlag, out);
+}
+
+void Optimizer::BundleAdjustment(const BAWindow& map, int nIterations, bool* pbStopFlag, bool bRobust, BAResult& out) {
+    so_ba_options opt;
+    so_ba_options_global(&opt, nIterations, bRobust ? 1 : 0);
+    solve(map, opt, pbStopFlag, out);
+}
+
+}  // namespace ORB_SLAM2
