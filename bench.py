@@ -30,6 +30,7 @@ from swarmmap_amd import synth  # noqa: E402
 from swarmmap_amd.matcher import FrameView  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP64_PEAK_TF = 78.6    # MI355X FP64 vector/matrix peak (AMD datasheet; not tabulated in the guide)
 LBA_EVERY = 5          # one LBA-M window per ~5 frames (SURVEY.md 8d end-to-end replay)
 N_LOCAL_HISTORY = 4    # local map = keypoints of the previous 4 frames (~2000-4000 map points)
 
@@ -160,7 +161,7 @@ def main():
     k0, d0 = ex.run_device(dev_frames[0].data_ptr(), w, h, w)
     wl.push(0, k0, d0)
     acc = {"extract_ms": 0.0, "match_ms": 0.0, "lba_ms": 0.0, "xchg_ms": 0.0, "n_kp": 0, "n_m2": 0, "n_m1": 0,
-           "n_lba": 0, "lba_gpu_ms": 0.0, "match_kernel_ms": 0.0, "n_xchg": 0}
+           "n_lba": 0, "lba_gpu_ms": 0.0, "match_kernel_ms": 0.0, "n_xchg": 0, "solve_ms": 0.0, "n_solves": 0}
     stage_ms = {}
 
     def step(t, timed):
@@ -190,6 +191,7 @@ def main():
             acc["match_kernel_ms"] += k1 + k2
             if lba_info:
                 acc["n_lba"] += 1; acc["lba_gpu_ms"] += lba_info["gpu_ms"]
+                acc["solve_ms"] += lba_info["solve_ms"]; acc["n_solves"] += lba_info["n_solves"]
             for k, v in ex.profile().items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v
 
@@ -222,6 +224,28 @@ def main():
         fast_ms = stage_ms["fast_score"] / steps
         alg_bytes = level_pixels(ex, w, h) + 8 * n_cand  # every level pixel read once + 8 B per candidate written
         achieved = alg_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
+        traffic = None  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (profiles/)
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("fast_score_kernel", {}).get("hbm_bytes_per_launch")
+        roof_fast = {"bound": "hbm", "kernel": "fast_score_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms,
+                     "total_ms_in_timed_region": stage_ms["fast_score"]}
+        # reduced-camera-system solve of local BA: dense Cholesky of a (6 n_free)^2 FP64 system, n^3/3 + 2 n^2 flop
+        n_red = 6 * int((lba_window["fixed"] == 0).sum())
+        solve_flop = n_red ** 3 / 3.0 + 2.0 * n_red ** 2
+        solve_ms = acc["solve_ms"] / max(acc["n_solves"], 1)
+        solve_tf = solve_flop / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0
+        roof_solve = {"bound": "mfma", "kernel": "ba_solve_blocked_kernel", "achieved": solve_tf, "peak": FP64_PEAK_TF,
+                      "unit": "TFLOP/s", "frac": solve_tf / FP64_PEAK_TF, "traffic": None,
+                      "algorithmic_flop_per_launch": solve_flop, "avg_launch_ms": solve_ms,
+                      "total_ms_in_timed_region": acc["solve_ms"],
+                      "note": "150x150 FP64 system per launch: latency-bound by construction (DESIGN.md 5); peak is "
+                              "AMD's FP64 datasheet figure (the guide lists no FP64 MFMA peak)"}
+        # the dominant kernel = the one with the largest accumulated HIP-event time inside the timed region
+        dominant = roof_solve if acc["solve_ms"] > stage_ms["fast_score"] else roof_fast
+        secondary = roof_fast if dominant is roof_solve else roof_solve
         out = {
             "metric": "frames/sec (tracking front-end + matching + local BA per frame; aggregate over agents, "
                       "per-agent = value/n_gpus)",
@@ -244,9 +268,8 @@ def main():
                                       "gpu": acc["lba_gpu_ms"] / max(acc["n_lba"], 1)},
                 "match_kernel_ms_per_frame": acc["match_kernel_ms"] / steps,
                 "extract_stage_ms_per_frame": {k: v / steps for k, v in stage_ms.items()}},
-            "roofline": {"bound": "hbm", "kernel": "fast_score_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms},
+            "roofline": dominant,
+            "roofline_secondary": secondary,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_frames, 7, stream, size, nfeatures, lba_window)

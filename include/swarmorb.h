@@ -101,6 +101,11 @@ int so_extractor_get_candidates(so_extractor* ex, int level, int16_t* xs, int16_
 int so_extractor_set_profiling(so_extractor* ex, int enabled);
 int so_extractor_get_profile(so_extractor* ex, float* ms_per_stage /* [SO_EXTRACTOR_N_STAGES] */);
 
+/* PMC calibration helper (tools/pmc_calibrate.py): streams n_bytes of device memory with one aligned 4-byte
+ * load per lane (the access shape of the FAST tile staging) so rocprofv3's FETCH_SIZE can be compared with a
+ * known byte count.  d_sink_4k: 4 KiB of device scratch.  Not part of the SLAM path. */
+int so_debug_stream_read(const void* d_src, unsigned long long n_bytes, void* d_sink_4k);
+
 /* ------------------------------------------------------------------------------------------------
  * Hamming matcher — replaces the data-parallel part of ORB_SLAM2::ORBmatcher (code/include/ORBmatcher.h:41-83,
  * code/src/ORBmatcher.cc) for the tracking thread: candidate gathering (Frame::GetFeaturesInArea,
@@ -218,6 +223,8 @@ typedef struct {
     int32_t n_outliers;
     float gpu_ms;       /* HIP-event time from the first to the last kernel of the call */
     float wall_ms;      /* host wall time of the call */
+    float solve_ms;     /* HIP-event time summed over the reduced-system solve kernel launches */
+    int32_t n_solves;
 } so_ba_info;
 
 int so_ba_create(int device, so_ba** out);

@@ -104,7 +104,9 @@ void pose_to_Tcw(const BaPose& P, float* T) {  // to_homogeneous_matrix cast to 
 struct so_ba {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    float solve_ms = 0.f;
+    int n_solves = 0;
 
     Buf d_pose[2], d_pt[2], d_intr, d_epose, d_ept, d_obs, d_w, d_active, d_err, d_chi2, d_ptoff, d_ptact, d_hidx,
         d_freepose, d_poseoff, d_poseedges, d_blkoff, d_blki1, d_blki2, d_pk1, d_pk2, d_Hpp, d_bp, d_Hll, d_bl, d_W,
@@ -330,11 +332,18 @@ int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
         do {
             const int trial = r.cur ^ 1;
             launch_ba_schur(r.d, r.lambda, b->d_blki1.as<int>(), b->d_blki2.as<int>(), r.S.n_blk, s);
+            SO_HIP(hipEventRecord(b->e2, s));
             launch_ba_solve(r.d, s);
+            SO_HIP(hipEventRecord(b->e3, s));
             launch_ba_update(r.d, r.lambda, r.poses(r.cur), r.points(r.cur), r.poses(trial), r.points(trial), r.nb_upd, s);
             launch_ba_errors(r.d, r.poses(trial), r.points(trial), r.nb_err, s);
             SO_HIP(hipGetLastError());
             if ((rc = fetch_partials(r))) return rc;
+            {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, b->e2, b->e3) == hipSuccess) b->solve_ms += ms;
+                b->n_solves++;
+            }
             const bool ok2 = b->h_partial[kBaSolveOk] != 0.0;
             tempChi = sum_partials(b->h_partial + kBaPartialChi, r.nb_err);
             if (!ok2) tempChi = DBL_MAX;
@@ -390,6 +399,8 @@ int so_ba_create(int device, so_ba** out) {
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&b->e0);
     if (e == hipSuccess) e = hipEventCreate(&b->e1);
+    if (e == hipSuccess) e = hipEventCreate(&b->e2);
+    if (e == hipSuccess) e = hipEventCreate(&b->e3);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_partial, sizeof(double) * kBaPartialCount, hipHostMallocDefault);
     if (e != hipSuccess) {
         delete b;
@@ -407,6 +418,8 @@ void so_ba_destroy(so_ba* b) {
     if (b->h_partial) (void)hipHostFree(b->h_partial);
     if (b->e0) (void)hipEventDestroy(b->e0);
     if (b->e1) (void)hipEventDestroy(b->e1);
+    if (b->e2) (void)hipEventDestroy(b->e2);
+    if (b->e3) (void)hipEventDestroy(b->e3);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -443,6 +456,8 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         }
     const double t_begin = now_ms();
     SO_HIP(hipSetDevice(b->device));
+    b->solve_ms = 0.f;
+    b->n_solves = 0;
     so_ba_info inf;
     memset(&inf, 0, sizeof(inf));
     Run r;
@@ -619,6 +634,8 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     inf.lm_trials = r.trials;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->e0, b->e1) == hipSuccess) inf.gpu_ms = ms;
+    inf.solve_ms = b->solve_ms;
+    inf.n_solves = b->n_solves;
     inf.wall_ms = (float)(now_ms() - t_begin);
     if (info) *info = inf;
     return SO_OK;

@@ -111,9 +111,20 @@ __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
     const uint8_t* simg = reinterpret_cast<const uint8_t*>(simg32);
 
     const int tid = threadIdx.x;
-    const int lvl = find_level_by_tile(P, blockIdx.x);
+    // XCD-aware block -> tile map.  Workgroup b runs on XCD b % 8 and each XCD has a private L2; four horizontally
+    // adjacent tiles share their 128-byte image / score lines, so deal tiles to XCDs in groups of four (measured
+    // with FETCH_SIZE / WRITE_SIZE: a plain b -> tile map re-fetched every line once per XCD that touched it).
+    int tile = blockIdx.x;
+    {
+        const int t32 = P.total_tiles & ~31;
+        if (tile < t32) {
+            const int xcd = tile & 7, k = tile >> 3;
+            tile = (((k >> 2) * 8 + xcd) << 2) + (k & 3);
+        }
+    }
+    const int lvl = find_level_by_tile(P, tile);
     const LevelDesc& L = P.lv[lvl];
-    const int t = blockIdx.x - L.tile_base;
+    const int t = tile - L.tile_base;
     const int ty = t / L.ntx, tx = t - ty * L.ntx;
     const int x0 = 19 + kTile * tx, y0 = 19 + kTile * ty;  // tile origin in level coordinates
     const int ax = 12 + kTile * tx;                         // (x0 - 4) rounded down to a dword
@@ -563,3 +574,25 @@ void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uin
 }
 
 }  // namespace so
+
+// ------------------------------------------------------------------------------------------------
+// PMC calibration helper (tools/pmc_calibrate.py): streams `n_dwords` aligned dwords with the same access
+// shape as fast_score_kernel's tile staging (one 4-byte load per lane, consecutive lanes -> consecutive
+// dwords) and stores one word per workgroup, so FETCH_SIZE / WRITE_SIZE can be compared with known byte counts.
+// ------------------------------------------------------------------------------------------------
+namespace so {
+__global__ __launch_bounds__(256) void calib_read_dwords_kernel(const uint32_t* __restrict__ src, size_t n_dwords,
+                                                                 uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_dwords; i += (size_t)gridDim.x * 256) acc ^= src[i];
+    acc ^= __shfl_xor((int)acc, 32);
+    if ((threadIdx.x & 63) == 0) atomicXor(&sink[blockIdx.x & 1023], acc);
+}
+}  // namespace so
+
+extern "C" int so_debug_stream_read(const void* d_src, unsigned long long n_bytes, void* d_sink_4k) {
+    const size_t n = (size_t)(n_bytes / 4);
+    hipLaunchKernelGGL(so::calib_read_dwords_kernel, dim3(4096), dim3(256), 0, 0, (const uint32_t*)d_src, n,
+                       (uint32_t*)d_sink_4k);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : 3;
+}

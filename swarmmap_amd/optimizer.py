@@ -21,7 +21,8 @@ class SoBaOptions(C.Structure):
 class SoBaInfo(C.Structure):
     _fields_ = [("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
                 ("iterations_stage1", C.c_int32), ("iterations_stage2", C.c_int32), ("lm_trials", C.c_int32),
-                ("aborted", C.c_int32), ("n_outliers", C.c_int32), ("gpu_ms", C.c_float), ("wall_ms", C.c_float)]
+                ("aborted", C.c_int32), ("n_outliers", C.c_int32), ("gpu_ms", C.c_float), ("wall_ms", C.c_float),
+                ("solve_ms", C.c_float), ("n_solves", C.c_int32)]
 
 
 def _vp(a):
