@@ -177,6 +177,60 @@ int so_hamming_top2(so_matcher* m, const uint8_t* A, int32_t na, const uint8_t* 
 int so_hamming_top2_device(so_matcher* m, const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb,
                            int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
 
+/* ---- the remaining ORBmatcher routines (LocalMapping / loop closing / relocalisation), same division of labour:
+ *      distances + candidate selection on the GPU, order-dependent resolve in the library, object-graph side
+ *      effects in the caller. ---- */
+
+/* DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened: nodes ascending by id; node k owns
+ * idx[off[k] .. off[k+1]) in the order DBoW2 stored the feature indices. */
+typedef struct {
+    int32_t n_nodes;
+    const int32_t* node_id;
+    const int32_t* off; /* n_nodes + 1 */
+    const int32_t* idx;
+} so_featvec;
+
+/* ORBmatcher::SearchByBoW.  variant 0 = (KeyFrame* pKF, Frame& F, vpMapPointMatches), code/src/ORBmatcher.cc:150-262;
+ * variant 1 = (KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12), :481-597.  Set 1 is the keyframe whose map points
+ * are being matched (valid1[i] = pMP && !pMP->isBad()); set 2 the target (variant 1: valid2[i] likewise; variant
+ * 0: ignored, may be NULL).  match_of_2[k2] = index in set 1 bound to target feature k2 (variant 0's
+ * vpMapPointMatches), match_of_1[k1] = target feature of k1 (variant 1's vpMatches12); either may be NULL. */
+int so_search_by_bow(so_matcher* m, int variant, int32_t n1, const uint8_t* desc1, const float* angle1,
+                     const uint8_t* valid1, const so_featvec* fv1, int32_t n2, const uint8_t* desc2,
+                     const float* angle2, const uint8_t* valid2, const so_featvec* fv2, float nn_ratio,
+                     int check_orientation, int32_t* match_of_2, int32_t* match_of_1, int32_t* nmatches);
+
+/* ORBmatcher::SearchForTriangulation (monocular) — ORBmatcher.cc:599-749 with CheckDistEpipolarLine :131-148.
+ * free1/free2[i] = !pKF->GetMapPoint(i); F12 row-major 3x3; (ex, ey) the epipole in image 2 (:607-613);
+ * scale_factors2 / level_sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2 (nlevels2 entries, <= 8).
+ * matches12[i1] = index in keyframe 2 or -1 (vMatchedPairs). */
+int so_search_for_triangulation(so_matcher* m, int32_t n1, const float* x1, const float* y1, const float* angle1,
+                                const uint8_t* desc1, const uint8_t* free1, const so_featvec* fv1, int32_t n2,
+                                const float* x2, const float* y2, const int32_t* octave2, const float* angle2,
+                                const uint8_t* desc2, const uint8_t* free2, const so_featvec* fv2, const float* F12,
+                                float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                int32_t nlevels2, int check_orientation, int32_t* matches12, int32_t* nmatches);
+
+/* Core of ORBmatcher::Fuse (both overloads, ORBmatcher.cc:751-891 and :893-1009) and of each pass of
+ * SearchBySim3 (:1011-1221): for every valid query the first minimum-distance keypoint of
+ * KeyFrame::GetFeaturesInArea(u, v, radius) (code/src/KeyFrame.cc:779-814) with octave in [pred_level-1,
+ * pred_level]; chi2_gate != 0 additionally requires e2 * inv_sigma2[octave] <= 5.99 (:853-860).  Queries are
+ * independent; thresholds (TH_LOW / TH_HIGH) and Replace/AddObservation stay with the caller.
+ * best_idx[i] = keypoint or -1, best_dist[i] = distance (256 when none). */
+int so_search_window_best(so_matcher* m, const so_frame_view* KF, int32_t nq, const uint8_t* valid, const float* u,
+                          const float* v, const float* radius, const int32_t* pred_level, const uint8_t* qdesc,
+                          int chi2_gate, const float* inv_sigma2, int32_t* best_idx, int32_t* best_dist);
+
+/* Sequential greedy window search: SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) — :264-373
+ * (levels [pred-1, pred], max_dist TH_LOW, no orientation) — and SearchByProjection(Frame&, KeyFrame*,
+ * sAlreadyFound, th, ORBdist) — :1356-1473 (levels [pred-1, pred+1], max_dist ORBdist, orientation).
+ * A keypoint is skipped when F->excluded[k] (bound on entry) or when an earlier query of this call took it.
+ * kp_to_query[k] = query bound to keypoint k, or -1. */
+int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, const uint8_t* valid, const float* u,
+                            const float* v, const float* radius, const int32_t* min_level, const int32_t* max_level,
+                            const uint8_t* qdesc, const float* q_angle, int32_t max_dist, int check_orientation,
+                            int32_t* kp_to_query, int32_t* nmatches);
+
 /* HIP-event time (ms) of the kernels of the last matcher call on the matcher's stream. */
 int so_matcher_last_kernel_ms(so_matcher* m, float* ms);
 

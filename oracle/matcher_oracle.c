@@ -360,3 +360,264 @@ void orc_hamming_top2(const uint8_t* A, int na, const uint8_t* B, int nb, int32_
         second_dist[i] = sd;
     }
 }
+
+/* ================= M3, M5, M6, M7 ================= */
+static void apply_rot_hist(const int32_t* hist, const int32_t* items, const int32_t* bins, int n_rot, int32_t* target,
+                           int* nmatches) {
+    int ind1, ind2, ind3;
+    orc_three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int j = 0; j < n_rot; j++) {
+        const int b = bins[j];
+        if (b == ind1 || b == ind2 || b == ind3) continue;
+        target[items[j]] = -1;
+        (*nmatches)--;
+    }
+}
+
+static int rot_bin(float a1, float a2) {
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * (1.0f / HISTO_LENGTH));
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+/* lower_bound over the flattened node ids (std::map::lower_bound) */
+static int fv_lower_bound(const orc_featvec* fv, int from, int id) {
+    int k = from;
+    while (k < fv->n_nodes && fv->node_id[k] < id) k++;
+    return k;
+}
+
+int orc_search_by_bow(int variant, int32_t n1, const uint8_t* desc1, const float* angle1, const uint8_t* valid1,
+                      const orc_featvec* fv1, int32_t n2, const uint8_t* desc2, const float* angle2,
+                      const uint8_t* valid2, const orc_featvec* fv2, float nn_ratio, int check_orientation,
+                      int32_t* match_of_2, int32_t* match_of_1) {
+    int32_t* m2 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1)); /* target -> source */
+    int32_t* m1 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n1 > 0 ? n1 : 1)); /* source -> target */
+    int32_t* rot_items = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n1 > 0 ? n1 : 1));
+    int32_t* rot_bins = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n1 > 0 ? n1 : 1));
+    int32_t hist[HISTO_LENGTH];
+    memset(hist, 0, sizeof(hist));
+    for (int i = 0; i < n2; i++) m2[i] = -1;
+    for (int i = 0; i < n1; i++) m1[i] = -1;
+    int nmatches = 0, n_rot = 0;
+    int k1 = 0, k2 = 0;
+    while (k1 < fv1->n_nodes && k2 < fv2->n_nodes) {
+        if (fv1->node_id[k1] == fv2->node_id[k2]) {
+            for (int a = fv1->off[k1]; a < fv1->off[k1 + 1]; a++) {
+                const int idx1 = fv1->idx[a];
+                if (!valid1[idx1]) continue;
+                const uint8_t* d1 = desc1 + (size_t)idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int b = fv2->off[k2]; b < fv2->off[k2 + 1]; b++) {
+                    const int idx2 = fv2->idx[b];
+                    if (m2[idx2] >= 0) continue; /* vpMapPointMatches[realIdxF] / vbMatched2[idx2] */
+                    if (variant == 1 && !valid2[idx2]) continue;
+                    const int dist = orc_descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                const int pass = variant == 0 ? (bestDist1 <= TH_LOW) : (bestDist1 < TH_LOW);
+                if (pass && (float)bestDist1 < nn_ratio * (float)bestDist2) {
+                    m2[bestIdx2] = idx1;
+                    m1[idx1] = bestIdx2;
+                    if (check_orientation) {
+                        const int bin = rot_bin(angle1[idx1], angle2[bestIdx2]);
+                        rot_items[n_rot] = variant == 0 ? bestIdx2 : idx1; /* :226 vs :563 */
+                        rot_bins[n_rot] = bin;
+                        n_rot++;
+                        hist[bin]++;
+                    }
+                    nmatches++;
+                }
+            }
+            k1++;
+            k2++;
+        } else if (fv1->node_id[k1] < fv2->node_id[k2]) {
+            k1 = fv_lower_bound(fv1, k1, fv2->node_id[k2]);
+        } else {
+            k2 = fv_lower_bound(fv2, k2, fv1->node_id[k1]);
+        }
+    }
+    if (check_orientation) {
+        /* variant 0 clears vpMapPointMatches[target]; variant 1 clears vpMatches12[source]; the taken flags of
+         * variant 1 (vbMatched2) are not reset, and the loop is over anyway */
+        if (variant == 0) {
+            int ind1, ind2, ind3;
+            orc_three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+            for (int j = 0; j < n_rot; j++) {
+                const int b = rot_bins[j];
+                if (b == ind1 || b == ind2 || b == ind3) continue;
+                const int t = rot_items[j];
+                if (m2[t] >= 0) m1[m2[t]] = -1;
+                m2[t] = -1;
+                nmatches--;
+            }
+        } else {
+            int ind1, ind2, ind3;
+            orc_three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+            for (int j = 0; j < n_rot; j++) {
+                const int b = rot_bins[j];
+                if (b == ind1 || b == ind2 || b == ind3) continue;
+                m1[rot_items[j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    if (match_of_2) memcpy(match_of_2, m2, sizeof(int32_t) * (size_t)n2);
+    if (match_of_1) memcpy(match_of_1, m1, sizeof(int32_t) * (size_t)n1);
+    free(m2); free(m1); free(rot_items); free(rot_bins);
+    return nmatches;
+}
+
+int orc_search_for_triangulation(int32_t n1, const float* x1, const float* y1, const float* angle1,
+                                 const uint8_t* desc1, const uint8_t* free1, const orc_featvec* fv1, int32_t n2,
+                                 const float* x2, const float* y2, const int32_t* octave2, const float* angle2,
+                                 const uint8_t* desc2, const uint8_t* free2, const orc_featvec* fv2,
+                                 const float* F12, float ex, float ey, const float* scale_factors2,
+                                 const float* level_sigma2_2, int check_orientation, int32_t* matches12) {
+    int nmatches = 0, n_rot = 0;
+    int32_t* rot_items = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n1 > 0 ? n1 : 1));
+    int32_t* rot_bins = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n1 > 0 ? n1 : 1));
+    int32_t hist[HISTO_LENGTH];
+    memset(hist, 0, sizeof(hist));
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    int k1 = 0, k2 = 0;
+    while (k1 < fv1->n_nodes && k2 < fv2->n_nodes) {
+        if (fv1->node_id[k1] == fv2->node_id[k2]) {
+            for (int a = fv1->off[k1]; a < fv1->off[k1 + 1]; a++) {
+                const int idx1 = fv1->idx[a];
+                if (!free1[idx1]) continue; /* already a MapPoint */
+                const uint8_t* d1 = desc1 + (size_t)idx1 * 32;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int b = fv2->off[k2]; b < fv2->off[k2 + 1]; b++) {
+                    const int idx2 = fv2->idx[b];
+                    if (!free2[idx2]) continue; /* vbMatched2 is never set in the reference (:634-720) */
+                    const int dist = orc_descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const float distex = ex - x2[idx2];
+                    const float distey = ey - y2[idx2];
+                    if (distex * distex + distey * distey < 100 * scale_factors2[octave2[idx2]]) continue;
+                    { /* CheckDistEpipolarLine :131-148 */
+                        const float a_ = x1[idx1] * F12[0] + y1[idx1] * F12[3] + F12[6];
+                        const float b_ = x1[idx1] * F12[1] + y1[idx1] * F12[4] + F12[7];
+                        const float c_ = x1[idx1] * F12[2] + y1[idx1] * F12[5] + F12[8];
+                        const float num = a_ * x2[idx2] + b_ * y2[idx2] + c_;
+                        const float den = a_ * a_ + b_ * b_;
+                        if (den == 0) continue;
+                        const float dsqr = num * num / den;
+                        if (!(dsqr < 3.84 * level_sigma2_2[octave2[idx2]])) continue;
+                    }
+                    bestIdx2 = idx2;
+                    bestDist = dist;
+                }
+                if (bestIdx2 >= 0) {
+                    matches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        const int bin = rot_bin(angle1[idx1], angle2[bestIdx2]);
+                        rot_items[n_rot] = idx1;
+                        rot_bins[n_rot] = bin;
+                        n_rot++;
+                        hist[bin]++;
+                    }
+                }
+            }
+            k1++;
+            k2++;
+        } else if (fv1->node_id[k1] < fv2->node_id[k2]) {
+            k1 = fv_lower_bound(fv1, k1, fv2->node_id[k2]);
+        } else {
+            k2 = fv_lower_bound(fv2, k2, fv1->node_id[k1]);
+        }
+    }
+    if (check_orientation) apply_rot_hist(hist, rot_items, rot_bins, n_rot, matches12, &nmatches);
+    free(rot_items); free(rot_bins);
+    return nmatches;
+}
+
+void orc_search_window_best(const orc_frame_view* KF, int32_t nq, const uint8_t* valid, const float* u,
+                            const float* v, const float* radius, const int32_t* pred_level, const uint8_t* qdesc,
+                            int chi2_gate, const float* inv_sigma2, int32_t* best_idx, int32_t* best_dist) {
+    orc_grid g;
+    grid_build(KF, &g);
+    int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (size_t)(KF->n > 0 ? KF->n : 1));
+    for (int i = 0; i < nq; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+        if (!valid[i]) continue;
+        const int lvl = pred_level[i];
+        const int nv = features_in_area(KF, &g, u[i], v[i], radius[i], -1, -1, vIndices, KF->n);
+        int bestDist = 256, bestIdx = -1;
+        for (int j = 0; j < nv; j++) {
+            const int idx = vIndices[j];
+            const int kpLevel = KF->octave[idx];
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            if (chi2_gate) {
+                const float exx = u[i] - KF->x[idx];
+                const float eyy = v[i] - KF->y[idx];
+                const float e2 = exx * exx + eyy * eyy;
+                if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc_descriptor_distance(qdesc + (size_t)i * 32, KF->desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        best_idx[i] = bestIdx;
+        best_dist[i] = bestDist;
+    }
+    free(vIndices);
+    free(g.items);
+}
+
+int orc_search_window_greedy(const orc_frame_view* F, int32_t nq, const uint8_t* valid, const float* u,
+                             const float* v, const float* radius, const int32_t* min_level,
+                             const int32_t* max_level, const uint8_t* qdesc, const float* q_angle, int max_dist,
+                             int check_orientation, int32_t* kp_to_query) {
+    orc_grid g;
+    grid_build(F, &g);
+    int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (size_t)(F->n > 0 ? F->n : 1));
+    int32_t* rot_items = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nq > 0 ? nq : 1));
+    int32_t* rot_bins = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nq > 0 ? nq : 1));
+    int32_t hist[HISTO_LENGTH];
+    memset(hist, 0, sizeof(hist));
+    int nmatches = 0, n_rot = 0;
+    for (int k = 0; k < F->n; k++) kp_to_query[k] = -1;
+    for (int i = 0; i < nq; i++) {
+        if (!valid[i]) continue;
+        const int nv = features_in_area(F, &g, u[i], v[i], radius[i], min_level[i], max_level[i], vIndices, F->n);
+        int bestDist = 256, bestIdx = -1;
+        for (int j = 0; j < nv; j++) {
+            const int idx = vIndices[j];
+            if (F->excluded && F->excluded[idx]) continue;
+            if (kp_to_query[idx] >= 0) continue;
+            const int dist = orc_descriptor_distance(qdesc + (size_t)i * 32, F->desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        if (bestDist <= max_dist) {
+            kp_to_query[bestIdx] = i;
+            nmatches++;
+            if (check_orientation) {
+                const int bin = rot_bin(q_angle[i], F->angle[bestIdx]);
+                rot_items[n_rot] = bestIdx;
+                rot_bins[n_rot] = bin;
+                n_rot++;
+                hist[bin]++;
+            }
+        }
+    }
+    if (check_orientation) apply_rot_hist(hist, rot_items, rot_bins, n_rot, kp_to_query, &nmatches);
+    free(vIndices); free(rot_items); free(rot_bins); free(g.items);
+    return nmatches;
+}

@@ -74,3 +74,61 @@ void orc_hamming_top2(const uint8_t* A, int na, const uint8_t* B, int nb, int32_
 }
 #endif
 #endif
+
+/* ---- additional routines (M3, M5, M6, M7); declared after the include guard's closing on purpose ---- */
+#ifndef MATCHER_ORACLE_EXT_H
+#define MATCHER_ORACLE_EXT_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* DBoW2::FeatureVector flattened: nodes ascending by id, node k owns idx[off[k] .. off[k+1]) (feature indices in
+ * the order DBoW2 stored them). */
+typedef struct {
+    int32_t n_nodes;
+    const int32_t* node_id;
+    const int32_t* off; /* n_nodes + 1 */
+    const int32_t* idx;
+} orc_featvec;
+
+/* M3: ORBmatcher::SearchByBoW.  kf_frame = 0: (KeyFrame*, Frame&) variant, code/src/ORBmatcher.cc:150-262
+ * (accept best <= TH_LOW; a target is taken once matched).  kf_frame = 1: (KeyFrame*, KeyFrame*) variant,
+ * :481-597 (accept best < TH_LOW; targets need valid2[idx2] = pMP2 && !pMP2->isBad()).
+ * valid1[i] = pMP1 && !pMP1->isBad().  Variant 0 returns match_of_2[k2] = index in set 1 bound to target k2;
+ * variant 1 returns match_of_1[k1] = target index.  Unused output may be NULL. */
+int orc_search_by_bow(int variant, int32_t n1, const uint8_t* desc1, const float* angle1, const uint8_t* valid1,
+                      const orc_featvec* fv1, int32_t n2, const uint8_t* desc2, const float* angle2,
+                      const uint8_t* valid2, const orc_featvec* fv2, float nn_ratio, int check_orientation,
+                      int32_t* match_of_2, int32_t* match_of_1);
+
+/* M5: ORBmatcher::SearchForTriangulation (monocular), code/src/ORBmatcher.cc:599-749 + CheckDistEpipolarLine
+ * :131-148.  free1/free2[i] = !GetMapPoint(i).  F12 row-major 3x3 float; (ex, ey) epipole in image 2.
+ * matches12[i1] = index in 2 or -1.  Returns nmatches. */
+int orc_search_for_triangulation(int32_t n1, const float* x1, const float* y1, const float* angle1,
+                                 const uint8_t* desc1, const uint8_t* free1, const orc_featvec* fv1, int32_t n2,
+                                 const float* x2, const float* y2, const int32_t* octave2, const float* angle2,
+                                 const uint8_t* desc2, const uint8_t* free2, const orc_featvec* fv2,
+                                 const float* F12, float ex, float ey, const float* scale_factors2,
+                                 const float* level_sigma2_2, int check_orientation, int32_t* matches12);
+
+/* M6 / M7 core: for every valid query the first minimum-distance keypoint of KeyFrame::GetFeaturesInArea(u,v,r)
+ * (code/src/KeyFrame.cc:779-814) whose octave is in [pred-1, pred]; chi2_gate: additionally
+ * e2 * inv_sigma2[octave] <= 5.99 (ORBmatcher::Fuse, :829-861).  Independent queries.
+ * Used by Fuse (:751-891, :893-1009) and both passes of SearchBySim3 (:1011-1221). */
+void orc_search_window_best(const orc_frame_view* KF, int32_t nq, const uint8_t* valid, const float* u,
+                            const float* v, const float* radius, const int32_t* pred_level, const uint8_t* qdesc,
+                            int chi2_gate, const float* inv_sigma2, int32_t* best_idx, int32_t* best_dist);
+
+/* M7 (and M2 generalised): sequential greedy window search — SearchByProjection(KeyFrame*, Scw, ...) :264-373
+ * (levels [pred-1,pred], TH_LOW, no orientation) and SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th,
+ * ORBdist) :1356-1473 (levels [pred-1,pred+1], ORBdist, orientation).  A keypoint is skipped when F->excluded
+ * or when an earlier query of this call took it.  kp_to_query[k] = query bound to keypoint k or -1. */
+int orc_search_window_greedy(const orc_frame_view* F, int32_t nq, const uint8_t* valid, const float* u,
+                             const float* v, const float* radius, const int32_t* min_level,
+                             const int32_t* max_level, const uint8_t* qdesc, const float* q_angle, int max_dist,
+                             int check_orientation, int32_t* kp_to_query);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

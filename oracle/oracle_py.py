@@ -287,3 +287,65 @@ def bundle_adjust(prob, its1=5, its2=10, robust=True, huber_delta=None, chi2_thr
     assert rc == 0
     return dict(Tcw=Tout, Xw=Xout, outlier=outl, chi2=chi2,
                 info={k: getattr(info, k) for k, _ in OrcBaInfo._fields_})
+
+
+class OrcFeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("off", C.c_void_p), ("idx", C.c_void_p)]
+
+
+def _fvs(fv):
+    return OrcFeatVec(len(fv.node_id), _p(fv.node_id), _p(fv.off), _p(fv.idx))
+
+
+def search_by_bow(variant, kf1, fv1, kf2, fv2, nn_ratio, check_ori=True):
+    d1, a1, v1 = [np.ascontiguousarray(kf1[k], t) for k, t in (("desc", np.uint8), ("angle", np.float32), ("valid", np.uint8))]
+    d2, a2 = np.ascontiguousarray(kf2["desc"], np.uint8), np.ascontiguousarray(kf2["angle"], np.float32)
+    v2 = np.ascontiguousarray(kf2["valid"], np.uint8) if "valid" in kf2 else np.ones(len(d2), np.uint8)
+    m2, m1 = np.full(len(d2), -1, np.int32), np.full(len(d1), -1, np.int32)
+    s1, s2 = _fvs(fv1), _fvs(fv2)
+    nm = lib().orc_search_by_bow(int(variant), len(d1), _p(d1), _p(a1), _p(v1), C.byref(s1), len(d2), _p(d2), _p(a2),
+                                 _p(v2), C.byref(s2), C.c_float(nn_ratio), int(check_ori), _p(m2), _p(m1))
+    return nm, m2, m1
+
+
+def search_for_triangulation(kf1, fv1, kf2, fv2, F12, epipole, scale_factors2, level_sigma2_2, check_ori=True):
+    g = lambda d, k, t: np.ascontiguousarray(d[k], t)  # noqa: E731
+    x1, y1, a1, d1, f1 = g(kf1, "x", np.float32), g(kf1, "y", np.float32), g(kf1, "angle", np.float32), \
+        g(kf1, "desc", np.uint8), g(kf1, "free", np.uint8)
+    x2, y2, o2, a2, d2, f2 = g(kf2, "x", np.float32), g(kf2, "y", np.float32), g(kf2, "octave", np.int32), \
+        g(kf2, "angle", np.float32), g(kf2, "desc", np.uint8), g(kf2, "free", np.uint8)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sf, ls = np.ascontiguousarray(scale_factors2, np.float32), np.ascontiguousarray(level_sigma2_2, np.float32)
+    out = np.full(len(x1), -1, np.int32)
+    s1, s2 = _fvs(fv1), _fvs(fv2)
+    nm = lib().orc_search_for_triangulation(len(x1), _p(x1), _p(y1), _p(a1), _p(d1), _p(f1), C.byref(s1), len(x2),
+                                            _p(x2), _p(y2), _p(o2), _p(a2), _p(d2), _p(f2), C.byref(s2), _p(F),
+                                            C.c_float(epipole[0]), C.c_float(epipole[1]), _p(sf), _p(ls),
+                                            int(check_ori), _p(out))
+    return nm, out
+
+
+def search_window_best(KF, q, chi2_gate=False, inv_sigma2=None):
+    nq = len(q["u"])
+    a = {k: np.ascontiguousarray(q[k], t) for k, t in
+         (("valid", np.uint8), ("u", np.float32), ("v", np.float32), ("radius", np.float32),
+          ("pred_level", np.int32), ("desc", np.uint8))}
+    inv = np.zeros(8, np.float32) if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    bi, bd = np.full(nq, -1, np.int32), np.full(nq, 256, np.int32)
+    fs = _fv(KF)
+    lib().orc_search_window_best(C.byref(fs), nq, _p(a["valid"]), _p(a["u"]), _p(a["v"]), _p(a["radius"]),
+                                 _p(a["pred_level"]), _p(a["desc"]), int(chi2_gate), _p(inv), _p(bi), _p(bd))
+    return bi, bd
+
+
+def search_window_greedy(F, q, max_dist, check_ori=True):
+    nq = len(q["u"])
+    a = {k: np.ascontiguousarray(q[k], t) for k, t in
+         (("valid", np.uint8), ("u", np.float32), ("v", np.float32), ("radius", np.float32),
+          ("min_level", np.int32), ("max_level", np.int32), ("desc", np.uint8), ("angle", np.float32))}
+    out = np.full(F.n, -1, np.int32)
+    fs = _fv(F)
+    nm = lib().orc_search_window_greedy(C.byref(fs), nq, _p(a["valid"]), _p(a["u"]), _p(a["v"]), _p(a["radius"]),
+                                        _p(a["min_level"]), _p(a["max_level"]), _p(a["desc"]), _p(a["angle"]),
+                                        int(max_dist), int(check_ori), _p(out))
+    return nm, out

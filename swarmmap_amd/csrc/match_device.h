@@ -19,12 +19,29 @@ struct MatchFrameDev {
     const uint4* desc;
     const int32_t* limit;  // may be null
     int n;
+    // per-level tables of the candidate frame and the epipole, used by the optional gates
+    float inv_sigma2[8];  // mvInvLevelSigma2 (Fuse chi2 gate)
+    float sigma2[8];      // mvLevelSigma2    (CheckDistEpipolarLine)
+    float scale[8];       // mvScaleFactors   (epipole distance test)
+    float ex, ey;
+};
+
+enum : uint32_t {
+    kQRange = 1u,       // candidates = positions [c_begin, c_end) (vocabulary-node segment); no window / level test
+    kQChi2Gate = 2u,    // Fuse: e2 * inv_sigma2[octave] > 5.99 -> skip (ORBmatcher.cc:845-861)
+    kQEpipolar = 4u,    // SearchForTriangulation: epipole distance + epipolar line tests (ORBmatcher.cc:131-148,693-706)
+    kQPreferLast = 8u,  // ties go to the LAST candidate in scan order ("dist > bestDist -> continue", :688)
 };
 
 struct MatchQuery {
     float u, v, r;
     int32_t min_level, max_level;
     int32_t active;
+    int32_t c_begin, c_end;
+    uint32_t flags;
+    int32_t max_dist;   // candidates with dist > max_dist never compete (256 = no limit)
+    float la, lb, lc;   // epipolar line of the query keypoint in the candidate image
+    int32_t pad;
 };
 
 void launch_topk_window(const MatchFrameDev& F, const MatchQuery* d_q, const uint4* d_qdesc, int nq, int K,

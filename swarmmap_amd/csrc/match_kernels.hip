@@ -28,17 +28,38 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 
 constexpr int kListCap = 1024;  // per-wave LDS list of (dist<<16 | rank) keys
 
-__device__ __forceinline__ bool window_pred(const MatchFrameDev& F, int c, float u, float v, float r, int min_l,
-                                            int max_l, bool check_levels) {
+// Geometric / structural predicate of one (query, candidate) pair — everything except the descriptor distance.
+__device__ __forceinline__ bool pair_pred(const MatchFrameDev& F, const MatchQuery& Q, int c, bool check_levels) {
     const float2 xy = F.xy[c];
-    const float dx = xy.x - u, dy = xy.y - v;
-    bool ok = fabsf(dx) < r && fabsf(dy) < r;
-    if (check_levels) {
-        const int o = F.octave[c];
-        if (o < min_l) ok = false;
-        if (max_l >= 0 && o > max_l) ok = false;
+    const int o = F.octave[c];
+    bool ok = true;
+    if (!(Q.flags & kQRange)) {  // Frame::GetFeaturesInArea, code/src/Frame.cc:377-431
+        const float dx = xy.x - Q.u, dy = xy.y - Q.v;
+        ok = fabsf(dx) < Q.r && fabsf(dy) < Q.r;
+        if (check_levels) {
+            if (o < Q.min_level) ok = false;
+            if (Q.max_level >= 0 && o > Q.max_level) ok = false;
+        }
+    }
+    if (ok && (Q.flags & kQChi2Gate)) {  // ORBmatcher::Fuse, code/src/ORBmatcher.cc:853-860
+        const float ex = Q.u - xy.x, ey = Q.v - xy.y;
+        const float e2 = ex * ex + ey * ey;
+        if ((double)(e2 * F.inv_sigma2[o]) > 5.99) ok = false;
+    }
+    if (ok && (Q.flags & kQEpipolar)) {  // SearchForTriangulation :693-706 + CheckDistEpipolarLine :131-148
+        const float distex = F.ex - xy.x, distey = F.ey - xy.y;
+        if (distex * distex + distey * distey < 100 * F.scale[o]) ok = false;
+        const float num = Q.la * xy.x + Q.lb * xy.y + Q.lc;
+        const float den = Q.la * Q.la + Q.lb * Q.lb;
+        if (den == 0) ok = false;
+        const float dsqr = num * num / den;
+        if (!((double)dsqr < 3.84 * (double)F.sigma2[o])) ok = false;
     }
     return ok;
+}
+
+__device__ __forceinline__ uint32_t make_key(const MatchQuery& Q, int dist, int c) {
+    return ((uint32_t)dist << 16) | (uint32_t)((Q.flags & kQPreferLast) ? (0xFFFF - c) : c);
 }
 
 __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const MatchQuery* __restrict__ q,
@@ -58,20 +79,23 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
     const uint4 qd0 = qdesc[2 * qi], qd1 = qdesc[2 * qi + 1];
     const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int lo = (Q.flags & kQRange) ? Q.c_begin : 0;
+    const int hi = (Q.flags & kQRange) ? Q.c_end : F.n;
     int m = 0;
-    for (int base = 0; base < F.n; base += 64) {
+    for (int base = lo; base < hi; base += 64) {
         const int c = base + lane;
-        bool ok = c < F.n;
+        bool ok = c < hi;
         int dist = 0;
-        if (ok) ok = window_pred(F, c, Q.u, Q.v, Q.r, Q.min_level, Q.max_level, check_levels);
+        if (ok) ok = pair_pred(F, Q, c, check_levels);
         if (ok) {
             dist = hamming256(F.desc[2 * c], F.desc[2 * c + 1], qd0, qd1);
+            if (dist > Q.max_dist) ok = false;
             if (F.limit && !(dist < F.limit[c])) ok = false;
         }
         const unsigned long long mask = __ballot(ok);
         if (mask) {
             const int pos = m + __popcll(mask & lt_mask);
-            if (ok && pos < kListCap) s_keys[w][pos] = ((uint32_t)dist << 16) | (uint32_t)c;
+            if (ok && pos < kListCap) s_keys[w][pos] = make_key(Q, dist, c);
             m += __popcll(mask);
         }
     }
@@ -98,12 +122,12 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
         uint32_t prev = 0;
         for (int k = 0; k < K; k++) {
             uint32_t cur = 0xFFFFFFFFu;
-            for (int base = 0; base < F.n; base += 64) {
+            for (int base = lo; base < hi; base += 64) {
                 const int c = base + lane;
-                if (c < F.n && window_pred(F, c, Q.u, Q.v, Q.r, Q.min_level, Q.max_level, check_levels)) {
+                if (c < hi && pair_pred(F, Q, c, check_levels)) {
                     const int dist = hamming256(F.desc[2 * c], F.desc[2 * c + 1], qd0, qd1);
-                    if (!F.limit || dist < F.limit[c]) {
-                        const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)c;
+                    if (dist <= Q.max_dist && (!F.limit || dist < F.limit[c])) {
+                        const uint32_t key = make_key(Q, dist, c);
                         if ((k == 0 || key > prev) && key < cur) cur = key;
                     }
                 }

@@ -73,6 +73,7 @@ struct so_matcher {
     DevBuf d_xy, d_oct, d_desc, d_limit, d_q, d_qdesc, d_keys, d_count, d_A, d_B, d_res;
     PinBuf h_xy, h_oct, h_desc, h_limit, h_q, h_qdesc, h_keys, h_count, h_res;
 
+    float inv_sigma2[8] = {0}, sigma2[8] = {0}, scale[8] = {0}, ex = 0.f, ey = 0.f;  // gates of the current candidates
     int n_cand = 0;           // keypoints that are inside the grid (PosInGrid true)
     bool has_limit = false;
     std::vector<int> perm;     // rank -> keypoint index
@@ -89,16 +90,61 @@ inline bool pos_in_grid(const so_frame_view* F, int i, int& px, int& py) {
     return !(px < 0 || px >= kGridCols || py < 0 || py >= kGridRows);
 }
 
+// Upload candidates in a given scan order (perm[position] = keypoint index); positions are the tie-break ranks.
+int upload_ordered(so_matcher* m, int n, const float* x, const float* y, const int32_t* octave, const uint8_t* desc,
+                   const uint8_t* excluded, const int32_t* limit_by_idx) {
+    const int nc = (int)m->perm.size();
+    if (nc > 65535) {
+        last_error_ref() = "matcher supports at most 65535 candidates per call";
+        return SO_ERR_INVALID_ARG;
+    }
+    m->rank_of.assign((size_t)n, -1);
+    for (int r = 0; r < nc; r++) m->rank_of[(size_t)m->perm[(size_t)r]] = r;
+    m->n_cand = nc;
+    const bool want_limit = (excluded != nullptr) || (limit_by_idx != nullptr);
+    m->has_limit = want_limit;
+    int rc;
+    if ((rc = m->h_xy.ensure(sizeof(float2) * (size_t)nc + 16))) return rc;
+    if ((rc = m->h_oct.ensure((size_t)nc + 16))) return rc;
+    if ((rc = m->h_desc.ensure((size_t)nc * 32 + 16))) return rc;
+    if ((rc = m->d_xy.ensure(sizeof(float2) * (size_t)nc + 16))) return rc;
+    if ((rc = m->d_oct.ensure((size_t)nc + 16))) return rc;
+    if ((rc = m->d_desc.ensure((size_t)nc * 32 + 16))) return rc;
+    float2* hxy = (float2*)m->h_xy.p;
+    int8_t* hoct = (int8_t*)m->h_oct.p;
+    uint8_t* hdesc = (uint8_t*)m->h_desc.p;
+    for (int r = 0; r < nc; r++) {
+        const int i = m->perm[(size_t)r];
+        hxy[r] = make_float2(x ? x[i] : 0.f, y ? y[i] : 0.f);
+        hoct[r] = (int8_t)(octave ? octave[i] : 0);
+        memcpy(hdesc + (size_t)r * 32, desc + (size_t)i * 32, 32);
+    }
+    if (nc > 0) {
+        SO_HIP(hipMemcpyAsync(m->d_xy.p, hxy, sizeof(float2) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
+        SO_HIP(hipMemcpyAsync(m->d_oct.p, hoct, (size_t)nc, hipMemcpyHostToDevice, m->stream));
+        SO_HIP(hipMemcpyAsync(m->d_desc.p, hdesc, (size_t)nc * 32, hipMemcpyHostToDevice, m->stream));
+    }
+    if (want_limit) {
+        if ((rc = m->h_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
+        if ((rc = m->d_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
+        int32_t* hl = (int32_t*)m->h_limit.p;
+        for (int r = 0; r < nc; r++) {
+            const int i = m->perm[(size_t)r];
+            int32_t lim = limit_by_idx ? limit_by_idx[i] : INT_MAX;
+            if (excluded && excluded[i]) lim = 0;
+            hl[r] = lim;
+        }
+        if (nc > 0)
+            SO_HIP(hipMemcpyAsync(m->d_limit.p, hl, sizeof(int32_t) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
+    }
+    return SO_OK;
+}
+
 // Order the frame's keypoints the way GetFeaturesInArea visits them (cell x outer, cell y inner, insertion
 // order inside a cell = keypoint index; code/src/Frame.cc:277-292,401-427) and upload the SoA.
 int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_idx) {
     const int n = F->n;
-    if (n > 65535) {
-        last_error_ref() = "matcher supports at most 65535 keypoints per frame";
-        return SO_ERR_INVALID_ARG;
-    }
     m->cell_count.assign((size_t)kGridCols * kGridRows + 1, 0);
-    m->rank_of.assign((size_t)n, -1);
     std::vector<int>& cc = m->cell_count;
     std::vector<int> cell((size_t)n, -1);
     for (int i = 0; i < n; i++) {
@@ -114,50 +160,14 @@ int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_
     {
         std::vector<int> fill(cc.begin(), cc.end() - 1);
         for (int i = 0; i < n; i++)
-            if (cell[(size_t)i] >= 0) {
-                const int r = fill[(size_t)cell[(size_t)i]]++;
-                m->perm[(size_t)r] = i;
-                m->rank_of[(size_t)i] = r;
-            }
+            if (cell[(size_t)i] >= 0) m->perm[(size_t)fill[(size_t)cell[(size_t)i]]++] = i;
     }
-    m->n_cand = nc;
-    const bool want_limit = (F->excluded != nullptr) || (limit_by_idx != nullptr);
-    m->has_limit = want_limit;
-    int rc;
-    if ((rc = m->h_xy.ensure(sizeof(float2) * (size_t)nc + 16))) return rc;
-    if ((rc = m->h_oct.ensure((size_t)nc + 16))) return rc;
-    if ((rc = m->h_desc.ensure((size_t)nc * 32 + 16))) return rc;
-    if ((rc = m->d_xy.ensure(sizeof(float2) * (size_t)nc + 16))) return rc;
-    if ((rc = m->d_oct.ensure((size_t)nc + 16))) return rc;
-    if ((rc = m->d_desc.ensure((size_t)nc * 32 + 16))) return rc;
-    float2* hxy = (float2*)m->h_xy.p;
-    int8_t* hoct = (int8_t*)m->h_oct.p;
-    uint8_t* hdesc = (uint8_t*)m->h_desc.p;
-    for (int r = 0; r < nc; r++) {
-        const int i = m->perm[(size_t)r];
-        hxy[r] = make_float2(F->x[i], F->y[i]);
-        hoct[r] = (int8_t)F->octave[i];
-        memcpy(hdesc + (size_t)r * 32, F->desc + (size_t)i * 32, 32);
-    }
-    if (nc > 0) {
-        SO_HIP(hipMemcpyAsync(m->d_xy.p, hxy, sizeof(float2) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
-        SO_HIP(hipMemcpyAsync(m->d_oct.p, hoct, (size_t)nc, hipMemcpyHostToDevice, m->stream));
-        SO_HIP(hipMemcpyAsync(m->d_desc.p, hdesc, (size_t)nc * 32, hipMemcpyHostToDevice, m->stream));
-    }
-    if (want_limit) {
-        if ((rc = m->h_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
-        if ((rc = m->d_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
-        int32_t* hl = (int32_t*)m->h_limit.p;
-        for (int r = 0; r < nc; r++) {
-            const int i = m->perm[(size_t)r];
-            int32_t lim = limit_by_idx ? limit_by_idx[i] : INT_MAX;
-            if (F->excluded && F->excluded[i]) lim = 0;
-            hl[r] = lim;
-        }
-        if (nc > 0)
-            SO_HIP(hipMemcpyAsync(m->d_limit.p, hl, sizeof(int32_t) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
-    }
-    return SO_OK;
+    return upload_ordered(m, n, F->x, F->y, F->octave, F->desc, F->excluded, limit_by_idx);
+}
+
+inline void init_query(MatchQuery& q) {
+    memset(&q, 0, sizeof(q));
+    q.max_dist = 256;
 }
 
 int upload_limit_only(so_matcher* m, const std::vector<int32_t>& limit_by_idx) {
@@ -180,6 +190,13 @@ MatchFrameDev frame_dev(const so_matcher* m) {
     F.desc = (const uint4*)m->d_desc.p;
     F.limit = m->has_limit ? (const int32_t*)m->d_limit.p : nullptr;
     F.n = m->n_cand;
+    for (int l = 0; l < 8; l++) {
+        F.inv_sigma2[l] = m->inv_sigma2[l];
+        F.sigma2[l] = m->sigma2[l];
+        F.scale[l] = m->scale[l];
+    }
+    F.ex = m->ex;
+    F.ey = m->ey;
     return F;
 }
 
@@ -338,6 +355,7 @@ int so_matcher_topk(so_matcher* m, const so_frame_view* F, const int32_t* limit,
     if ((rc = ensure_queries(m, nq))) return rc;
     MatchQuery* hq = (MatchQuery*)m->h_q.p;
     for (int i = 0; i < nq; i++) {
+        init_query(hq[i]);
         hq[i].u = u[i];
         hq[i].v = v[i];
         hq[i].r = r[i];
@@ -386,6 +404,7 @@ int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int
     const bool bFactor = th != 1.0f;
     for (int i = 0; i < n_mp; i++) {
         MatchQuery& q = hq[i];
+        init_query(q);
         q.active = in_view[i] != 0;
         const int lvl = pred_level[i];
         float r = view_cos[i] > 0.998f ? 2.5f : 4.0f;  // RadiusByViewingCos, :123-128
@@ -459,6 +478,7 @@ int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, i
     MatchQuery* hq = (MatchQuery*)m->h_q.p;
     for (int i = 0; i < n_last; i++) {
         MatchQuery& q = hq[i];
+        init_query(q);
         const int oct = last_octave[i];
         q.active = valid[i] != 0 && oct >= 0 && oct < cur->nlevels;
         q.u = u[i];
@@ -543,6 +563,7 @@ int so_search_for_initialization(so_matcher* m, const so_frame_view* F1, const s
     MatchQuery* hq = (MatchQuery*)m->h_q.p;
     for (int i = 0; i < n1; i++) {
         MatchQuery& q = hq[i];
+        init_query(q);
         const int level1 = F1->octave[i];
         q.active = !(level1 > 0);  // :393-395
         q.u = prev_matched[2 * i];
@@ -665,6 +686,393 @@ int so_hamming_top2_device(so_matcher* m, const uint8_t* d_A, int32_t na, const 
     if (na == 0) return SO_OK;
     SO_HIP(hipSetDevice(m->device));
     return top2_common(m, (const uint4*)d_A, na, (const uint4*)d_B, nb, best_idx, best_dist, second_dist);
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// M3, M5, M6, M7 — the remaining ORBmatcher routines
+// =====================================================================================================
+namespace {
+
+bool featvec_ok(const so_featvec* fv, int n) {
+    if (!fv || fv->n_nodes < 0) return false;
+    if (fv->n_nodes == 0) return true;
+    if (!fv->node_id || !fv->off || !fv->idx) return false;
+    for (int k = 0; k < fv->n_nodes; k++) {
+        if (fv->off[k] > fv->off[k + 1]) return false;
+        if (k > 0 && fv->node_id[k] <= fv->node_id[k - 1]) return false;
+    }
+    for (int a = fv->off[0]; a < fv->off[fv->n_nodes]; a++)
+        if (fv->idx[a] < 0 || fv->idx[a] >= n) return false;
+    return true;
+}
+
+int fv_lower_bound(const so_featvec* fv, int from, int id) {
+    int k = from;
+    while (k < fv->n_nodes && fv->node_id[k] < id) k++;
+    return k;
+}
+
+struct NodeJoin {  // the merge-join of two feature vectors (ORBmatcher.cc:166-240): common nodes in order
+    std::vector<int> k1, k2;
+};
+
+NodeJoin join_nodes(const so_featvec* fv1, const so_featvec* fv2) {
+    NodeJoin j;
+    int k1 = 0, k2 = 0;
+    while (k1 < fv1->n_nodes && k2 < fv2->n_nodes) {
+        if (fv1->node_id[k1] == fv2->node_id[k2]) {
+            j.k1.push_back(k1++);
+            j.k2.push_back(k2++);
+        } else if (fv1->node_id[k1] < fv2->node_id[k2]) {
+            k1 = fv_lower_bound(fv1, k1, fv2->node_id[k2]);
+        } else {
+            k2 = fv_lower_bound(fv2, k2, fv1->node_id[k1]);
+        }
+    }
+    return j;
+}
+
+// candidates = the features of set 2 in feature-vector order; returns position offset of each node of fv2
+int upload_featvec_candidates(so_matcher* m, int n2, const float* x2, const float* y2, const int32_t* octave2,
+                              const uint8_t* desc2, const so_featvec* fv2, const uint8_t* excluded) {
+    const int total = fv2->n_nodes > 0 ? fv2->off[fv2->n_nodes] - fv2->off[0] : 0;
+    m->perm.resize((size_t)total);
+    for (int a = 0; a < total; a++) m->perm[(size_t)a] = fv2->idx[fv2->off[0] + a];
+    return upload_ordered(m, n2, x2, y2, octave2, desc2, excluded, nullptr);
+}
+
+void apply_rot_hist(const int* hist, const std::vector<int>& items, const std::vector<int>& bins, int32_t* target,
+                    int& nm) {
+    int a, b, c;
+    three_maxima(hist, HISTO_LENGTH, a, b, c);
+    for (size_t j = 0; j < items.size(); j++) {
+        if (bins[j] == a || bins[j] == b || bins[j] == c) continue;
+        target[items[j]] = -1;
+        nm--;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int so_search_by_bow(so_matcher* m, int variant, int32_t n1, const uint8_t* desc1, const float* angle1,
+                     const uint8_t* valid1, const so_featvec* fv1, int32_t n2, const uint8_t* desc2,
+                     const float* angle2, const uint8_t* valid2, const so_featvec* fv2, float nn_ratio,
+                     int check_orientation, int32_t* match_of_2, int32_t* match_of_1, int32_t* nmatches) {
+    if (!m || !nmatches || n1 < 0 || n2 < 0 || (variant != 0 && variant != 1)) return SO_ERR_INVALID_ARG;
+    if ((n1 > 0 && (!desc1 || !valid1)) || (n2 > 0 && !desc2) || (variant == 1 && n2 > 0 && !valid2))
+        return SO_ERR_INVALID_ARG;
+    if (check_orientation && ((n1 > 0 && !angle1) || (n2 > 0 && !angle2))) return SO_ERR_INVALID_ARG;
+    if (!featvec_ok(fv1, n1) || !featvec_ok(fv2, n2)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    *nmatches = 0;
+    std::vector<int32_t> m2((size_t)n2, -1), m1((size_t)n1, -1);
+    auto finish = [&]() {
+        if (match_of_2) memcpy(match_of_2, m2.data(), sizeof(int32_t) * (size_t)n2);
+        if (match_of_1) memcpy(match_of_1, m1.data(), sizeof(int32_t) * (size_t)n1);
+    };
+    const NodeJoin J = join_nodes(fv1, fv2);
+    if (J.k1.empty() || n1 == 0 || n2 == 0) {
+        finish();
+        return SO_OK;
+    }
+    constexpr int K = 8;
+    // variant 1: targets without a good map point never compete (static gate)
+    std::vector<uint8_t> excl;
+    if (variant == 1) {
+        excl.resize((size_t)n2);
+        for (int i = 0; i < n2; i++) excl[(size_t)i] = valid2[i] ? 0 : 1;
+    }
+    int rc = upload_featvec_candidates(m, n2, nullptr, nullptr, nullptr, desc2, fv2, variant == 1 ? excl.data() : nullptr);
+    if (rc) return rc;
+    // queries in the reference's visiting order: common nodes ascending, features of set 1 in node order
+    std::vector<int> q_idx1;
+    std::vector<MatchQuery> queries;
+    const int base2 = fv2->off[0];
+    for (size_t j = 0; j < J.k1.size(); j++) {
+        const int k1 = J.k1[j], k2 = J.k2[j];
+        for (int a = fv1->off[k1]; a < fv1->off[k1 + 1]; a++) {
+            const int idx1 = fv1->idx[a];
+            if (!valid1[idx1]) continue;
+            MatchQuery q;
+            init_query(q);
+            q.active = 1;
+            q.flags = kQRange;
+            q.c_begin = fv2->off[k2] - base2;
+            q.c_end = fv2->off[k2 + 1] - base2;
+            queries.push_back(q);
+            q_idx1.push_back(idx1);
+        }
+    }
+    const int nq = (int)queries.size();
+    if (nq == 0) {
+        finish();
+        return SO_OK;
+    }
+    if ((rc = ensure_queries(m, nq))) return rc;
+    memcpy(m->h_q.p, queries.data(), sizeof(MatchQuery) * (size_t)nq);
+    uint8_t* hd = (uint8_t*)m->h_qdesc.p;
+    for (int i = 0; i < nq; i++) memcpy(hd + (size_t)i * 32, desc1 + (size_t)q_idx1[(size_t)i] * 32, 32);
+    if ((rc = run_topk(m, nq, K))) return rc;
+    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)nq * K);
+    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + nq);
+    std::vector<int32_t> gate;
+    std::vector<int> rot_item, rot_b;
+    int hist[HISTO_LENGTH] = {0};
+    int nm = 0;
+    for (int i = 0; i < nq; i++) {
+        if (cnt[(size_t)i] == 0) continue;
+        const int idx1 = q_idx1[(size_t)i];
+        Entry e[2];
+        int found = 0, walked = 0;
+        for (; walked < K && found < 2; walked++) {
+            const uint32_t key = keys[(size_t)i * K + walked];
+            if (key == 0xFFFFFFFFu) break;
+            const int idx2 = m->perm[(size_t)(key & 0xFFFFu)];
+            if (m2[(size_t)idx2] >= 0) continue;  // vpMapPointMatches[realIdxF] / vbMatched2[idx2]
+            e[found].idx = idx2;
+            e[found].dist = (int)(key >> 16);
+            found++;
+        }
+        if (found < 2 && walked == K && cnt[(size_t)i] > K) {
+            gate.assign((size_t)n2, INT_MAX);
+            for (int k = 0; k < n2; k++)
+                if (m2[(size_t)k] >= 0 || (variant == 1 && !valid2[k])) gate[(size_t)k] = 0;
+            if ((rc = rerun_single(m, queries[(size_t)i], desc1 + (size_t)idx1 * 32, gate, 2, e, &found))) return rc;
+        }
+        if (found == 0) continue;
+        const int bestDist1 = e[0].dist, bestIdx2 = e[0].idx, bestDist2 = found > 1 ? e[1].dist : 256;
+        const bool pass = variant == 0 ? (bestDist1 <= TH_LOW) : (bestDist1 < TH_LOW);
+        if (pass && (float)bestDist1 < nn_ratio * (float)bestDist2) {
+            m2[(size_t)bestIdx2] = idx1;
+            m1[(size_t)idx1] = bestIdx2;
+            if (check_orientation) {
+                const int b = rot_bin(angle1[idx1], angle2[bestIdx2]);
+                rot_item.push_back(variant == 0 ? bestIdx2 : idx1);
+                rot_b.push_back(b);
+                hist[b]++;
+            }
+            nm++;
+        }
+    }
+    if (check_orientation) {
+        if (variant == 0) {
+            int a, b, c;
+            three_maxima(hist, HISTO_LENGTH, a, b, c);
+            for (size_t j = 0; j < rot_item.size(); j++) {
+                if (rot_b[j] == a || rot_b[j] == b || rot_b[j] == c) continue;
+                const int t = rot_item[j];
+                if (m2[(size_t)t] >= 0) m1[(size_t)m2[(size_t)t]] = -1;
+                m2[(size_t)t] = -1;
+                nm--;
+            }
+        } else {
+            apply_rot_hist(hist, rot_item, rot_b, m1.data(), nm);
+        }
+    }
+    finish();
+    *nmatches = nm;
+    return SO_OK;
+}
+
+int so_search_for_triangulation(so_matcher* m, int32_t n1, const float* x1, const float* y1, const float* angle1,
+                                const uint8_t* desc1, const uint8_t* free1, const so_featvec* fv1, int32_t n2,
+                                const float* x2, const float* y2, const int32_t* octave2, const float* angle2,
+                                const uint8_t* desc2, const uint8_t* free2, const so_featvec* fv2, const float* F12,
+                                float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                int32_t nlevels2, int check_orientation, int32_t* matches12, int32_t* nmatches) {
+    if (!m || !nmatches || !matches12 || n1 < 0 || n2 < 0 || !F12 || !scale_factors2 || !level_sigma2_2 ||
+        nlevels2 < 1 || nlevels2 > 8)
+        return SO_ERR_INVALID_ARG;
+    if ((n1 > 0 && (!x1 || !y1 || !desc1 || !free1)) || (n2 > 0 && (!x2 || !y2 || !octave2 || !desc2 || !free2)))
+        return SO_ERR_INVALID_ARG;
+    if (check_orientation && ((n1 > 0 && !angle1) || (n2 > 0 && !angle2))) return SO_ERR_INVALID_ARG;
+    if (!featvec_ok(fv1, n1) || !featvec_ok(fv2, n2)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    const NodeJoin J = join_nodes(fv1, fv2);
+    if (J.k1.empty() || n1 == 0 || n2 == 0) return SO_OK;
+    std::vector<uint8_t> excl((size_t)n2);
+    for (int i = 0; i < n2; i++) excl[(size_t)i] = free2[i] ? 0 : 1;  // "|| pMP2" (:662); vbMatched2 is never set
+    for (int l = 0; l < 8; l++) {
+        m->scale[l] = l < nlevels2 ? scale_factors2[l] : 0.f;
+        m->sigma2[l] = l < nlevels2 ? level_sigma2_2[l] : 0.f;
+    }
+    m->ex = ex;
+    m->ey = ey;
+    int rc = upload_featvec_candidates(m, n2, x2, y2, octave2, desc2, fv2, excl.data());
+    if (rc) return rc;
+    std::vector<int> q_idx1;
+    std::vector<MatchQuery> queries;
+    const int base2 = fv2->off[0];
+    for (size_t j = 0; j < J.k1.size(); j++) {
+        const int k1 = J.k1[j], k2 = J.k2[j];
+        for (int a = fv1->off[k1]; a < fv1->off[k1 + 1]; a++) {
+            const int idx1 = fv1->idx[a];
+            if (!free1[idx1]) continue;  // "If there is already a MapPoint skip" (:641-643)
+            MatchQuery q;
+            init_query(q);
+            q.active = 1;
+            q.flags = kQRange | kQEpipolar | kQPreferLast;
+            q.max_dist = TH_LOW;  // "dist > TH_LOW || dist > bestDist -> continue" with bestDist starting at TH_LOW
+            q.c_begin = fv2->off[k2] - base2;
+            q.c_end = fv2->off[k2 + 1] - base2;
+            q.la = x1[idx1] * F12[0] + y1[idx1] * F12[3] + F12[6];  // CheckDistEpipolarLine :134-136
+            q.lb = x1[idx1] * F12[1] + y1[idx1] * F12[4] + F12[7];
+            q.lc = x1[idx1] * F12[2] + y1[idx1] * F12[5] + F12[8];
+            queries.push_back(q);
+            q_idx1.push_back(idx1);
+        }
+    }
+    const int nq = (int)queries.size();
+    if (nq == 0) return SO_OK;
+    if ((rc = ensure_queries(m, nq))) return rc;
+    memcpy(m->h_q.p, queries.data(), sizeof(MatchQuery) * (size_t)nq);
+    uint8_t* hd = (uint8_t*)m->h_qdesc.p;
+    for (int i = 0; i < nq; i++) memcpy(hd + (size_t)i * 32, desc1 + (size_t)q_idx1[(size_t)i] * 32, 32);
+    if ((rc = run_topk(m, nq, 1))) return rc;
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
+    std::vector<int> rot_item, rot_b;
+    int hist[HISTO_LENGTH] = {0};
+    int nm = 0;
+    for (int i = 0; i < nq; i++) {
+        if (keys[i] == 0xFFFFFFFFu) continue;
+        const int idx1 = q_idx1[(size_t)i];
+        const int idx2 = m->perm[(size_t)(0xFFFF - (keys[i] & 0xFFFFu))];  // prefer-last keys store 0xFFFF - position
+        matches12[idx1] = idx2;
+        nm++;
+        if (check_orientation) {
+            const int b = rot_bin(angle1[idx1], angle2[idx2]);
+            rot_item.push_back(idx1);
+            rot_b.push_back(b);
+            hist[b]++;
+        }
+    }
+    if (check_orientation) apply_rot_hist(hist, rot_item, rot_b, matches12, nm);
+    *nmatches = nm;
+    return SO_OK;
+}
+
+int so_search_window_best(so_matcher* m, const so_frame_view* KF, int32_t nq, const uint8_t* valid, const float* u,
+                          const float* v, const float* radius, const int32_t* pred_level, const uint8_t* qdesc,
+                          int chi2_gate, const float* inv_sigma2, int32_t* best_idx, int32_t* best_dist) {
+    if (!m || !frame_ok(KF) || nq < 0) return SO_ERR_INVALID_ARG;
+    if (nq > 0 && (!valid || !u || !v || !radius || !pred_level || !qdesc || !best_idx || !best_dist))
+        return SO_ERR_INVALID_ARG;
+    if (chi2_gate && (!inv_sigma2 || KF->nlevels > 8)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    for (int i = 0; i < nq; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+    }
+    if (nq == 0 || KF->n == 0) return SO_OK;
+    for (int l = 0; l < 8; l++) m->inv_sigma2[l] = (chi2_gate && l < KF->nlevels) ? inv_sigma2[l] : 0.f;
+    so_frame_view view = *KF;
+    view.excluded = nullptr;  // Fuse / SearchBySim3 look at every keypoint of the keyframe
+    int rc = upload_frame(m, &view, nullptr);
+    if (rc) return rc;
+    if ((rc = ensure_queries(m, nq))) return rc;
+    MatchQuery* hq = (MatchQuery*)m->h_q.p;
+    for (int i = 0; i < nq; i++) {
+        MatchQuery& q = hq[i];
+        init_query(q);
+        q.active = valid[i] != 0;
+        q.u = u[i];
+        q.v = v[i];
+        q.r = radius[i];
+        q.min_level = pred_level[i] - 1;  // "kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel" (:838)
+        q.max_level = pred_level[i];
+        if (pred_level[i] < 0) q.active = 0;
+        if (chi2_gate) q.flags |= kQChi2Gate;
+    }
+    memcpy(m->h_qdesc.p, qdesc, (size_t)nq * 32);
+    if ((rc = run_topk(m, nq, 1))) return rc;
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
+    for (int i = 0; i < nq; i++)
+        if (keys[i] != 0xFFFFFFFFu) {
+            best_idx[i] = m->perm[(size_t)(keys[i] & 0xFFFFu)];
+            best_dist[i] = (int32_t)(keys[i] >> 16);
+        }
+    return SO_OK;
+}
+
+int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, const uint8_t* valid, const float* u,
+                            const float* v, const float* radius, const int32_t* min_level, const int32_t* max_level,
+                            const uint8_t* qdesc, const float* q_angle, int32_t max_dist, int check_orientation,
+                            int32_t* kp_to_query, int32_t* nmatches) {
+    if (!m || !frame_ok(F) || nq < 0 || !kp_to_query || !nmatches) return SO_ERR_INVALID_ARG;
+    if (nq > 0 && (!valid || !u || !v || !radius || !min_level || !max_level || !qdesc)) return SO_ERR_INVALID_ARG;
+    if (check_orientation && nq > 0 && (!q_angle || !F->angle)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    *nmatches = 0;
+    for (int k = 0; k < F->n; k++) kp_to_query[k] = -1;
+    if (nq == 0 || F->n == 0) return SO_OK;
+    constexpr int K = 4;
+    int rc = upload_frame(m, F, nullptr);
+    if (rc) return rc;
+    if ((rc = ensure_queries(m, nq))) return rc;
+    MatchQuery* hq = (MatchQuery*)m->h_q.p;
+    for (int i = 0; i < nq; i++) {
+        MatchQuery& q = hq[i];
+        init_query(q);
+        q.active = valid[i] != 0;
+        q.u = u[i];
+        q.v = v[i];
+        q.r = radius[i];
+        q.min_level = min_level[i];
+        q.max_level = max_level[i];
+    }
+    memcpy(m->h_qdesc.p, qdesc, (size_t)nq * 32);
+    if ((rc = run_topk(m, nq, K))) return rc;
+    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)nq * K);
+    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + nq);
+    std::vector<MatchQuery> queries(hq, hq + nq);
+    std::vector<int32_t> gate;
+    std::vector<int> rot_item, rot_b;
+    int hist[HISTO_LENGTH] = {0};
+    int nm = 0;
+    for (int i = 0; i < nq; i++) {
+        if (!queries[(size_t)i].active || cnt[(size_t)i] == 0) continue;
+        Entry e[1];
+        int found = 0, walked = 0;
+        for (; walked < K && found < 1; walked++) {
+            const uint32_t key = keys[(size_t)i * K + walked];
+            if (key == 0xFFFFFFFFu) break;
+            const int idx = m->perm[(size_t)(key & 0xFFFFu)];
+            if (kp_to_query[idx] >= 0) continue;
+            e[0].idx = idx;
+            e[0].dist = (int)(key >> 16);
+            found++;
+        }
+        if (found < 1 && walked == K && cnt[(size_t)i] > K) {
+            gate.assign((size_t)F->n, INT_MAX);
+            for (int k = 0; k < F->n; k++)
+                if ((F->excluded && F->excluded[k]) || kp_to_query[k] >= 0) gate[(size_t)k] = 0;
+            if ((rc = rerun_single(m, queries[(size_t)i], qdesc + (size_t)i * 32, gate, 1, e, &found))) return rc;
+        }
+        if (found == 0) continue;
+        if (e[0].dist <= max_dist) {
+            kp_to_query[e[0].idx] = i;
+            nm++;
+            if (check_orientation) {
+                const int b = rot_bin(q_angle[i], F->angle[e[0].idx]);
+                rot_item.push_back(e[0].idx);
+                rot_b.push_back(b);
+                hist[b]++;
+            }
+        }
+    }
+    if (check_orientation) apply_rot_hist(hist, rot_item, rot_b, kp_to_query, nm);
+    *nmatches = nm;
+    return SO_OK;
 }
 
 }  // extern "C"

@@ -63,4 +63,28 @@ int ORBmatcher::SearchForInitialization(const so_frame_view& F1, const so_frame_
     return nmatches;
 }
 
+int ORBmatcher::SearchByBoW(int variant, int n1, const uint8_t* desc1, const float* angle1, const uint8_t* valid1,
+                            const so_featvec& fv1, int n2, const uint8_t* desc2, const float* angle2,
+                            const uint8_t* valid2, const so_featvec& fv2, std::vector<int32_t>& match_of_2,
+                            std::vector<int32_t>& match_of_1) {
+    match_of_2.assign((size_t)n2, -1);
+    match_of_1.assign((size_t)n1, -1);
+    int32_t nmatches = 0;
+    check(so_search_by_bow(handle_, variant, n1, desc1, angle1, valid1, &fv1, n2, desc2, angle2, valid2, &fv2,
+                           mfNNratio, mbCheckOrientation ? 1 : 0, match_of_2.data(), match_of_1.data(), &nmatches),
+          "so_search_by_bow");
+    return nmatches;
+}
+
+void ORBmatcher::SearchWindowBest(const so_frame_view& KF, int nq, const uint8_t* valid, const float* u, const float* v,
+                                  const float* radius, const int32_t* pred_level, const uint8_t* desc, bool chi2_gate,
+                                  const float* inv_sigma2, std::vector<int32_t>& best_idx,
+                                  std::vector<int32_t>& best_dist) {
+    best_idx.assign((size_t)nq, -1);
+    best_dist.assign((size_t)nq, 256);
+    check(so_search_window_best(handle_, &KF, nq, valid, u, v, radius, pred_level, desc, chi2_gate ? 1 : 0, inv_sigma2,
+                                best_idx.data(), best_dist.data()),
+          "so_search_window_best");
+}
+
 }  // namespace ORB_SLAM2

@@ -48,6 +48,18 @@ public:
     int SearchForInitialization(const so_frame_view& F1, const so_frame_view& F2, std::vector<float>& vbPrevMatched,
                                 std::vector<int32_t>& vnMatches12, int windowSize = 10);
 
+    // SearchByBoW(KeyFrame* pKF, Frame& F, vpMapPointMatches) [variant 0] / (KeyFrame*, KeyFrame*, vpMatches12) [1]
+    // descN/angleN/validN: per feature of each side; match_of_2 = vpMapPointMatches as indices into set 1,
+    // match_of_1 = vpMatches12 as indices into set 2.
+    int SearchByBoW(int variant, int n1, const uint8_t* desc1, const float* angle1, const uint8_t* valid1,
+                    const so_featvec& vFeatVec1, int n2, const uint8_t* desc2, const float* angle2,
+                    const uint8_t* valid2, const so_featvec& vFeatVec2, std::vector<int32_t>& match_of_2,
+                    std::vector<int32_t>& match_of_1);
+    // Fuse / SearchBySim3 core: best keypoint of pKF inside the projection window of every map point
+    void SearchWindowBest(const so_frame_view& KF, int nq, const uint8_t* valid, const float* u, const float* v,
+                          const float* radius, const int32_t* pred_level, const uint8_t* desc, bool chi2_gate,
+                          const float* inv_sigma2, std::vector<int32_t>& best_idx, std::vector<int32_t>& best_dist);
+
 protected:
     float mfNNratio;
     bool mbCheckOrientation;

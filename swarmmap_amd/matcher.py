@@ -157,3 +157,120 @@ class ORBmatcher:
         _lib.check(self._lib.so_hamming_top2_device(self._h, C.c_void_p(dA_ptr), na, C.c_void_p(dB_ptr), nb,
                                                      _vp(bi), _vp(bd), _vp(sd)))
         return bi, bd, sd
+
+
+# ------------------------------------------------------------------------------------------------
+# M3 / M5 / M6 / M7 (LocalMapping, loop closing, relocalisation routines)
+# ------------------------------------------------------------------------------------------------
+class SoFeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("off", C.c_void_p), ("idx", C.c_void_p)]
+
+
+class FeatureVector:
+    """DBoW2::FeatureVector flattened (node ids ascending; per node the feature indices in stored order)."""
+
+    def __init__(self, node_of_feature):
+        node_of_feature = np.asarray(node_of_feature, np.int64)
+        order = np.argsort(node_of_feature, kind="stable")  # DBoW2 appends indices in ascending feature order
+        nodes, counts = np.unique(node_of_feature, return_counts=True)
+        self.node_id = nodes.astype(np.int32)
+        self.off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        self.idx = order.astype(np.int32)
+
+    def as_struct(self, cls=SoFeatVec):
+        return cls(len(self.node_id), _vp(self.node_id), _vp(self.off), _vp(self.idx))
+
+
+def _bind_ext(lib):
+    vp, ip, f = C.c_void_p, C.POINTER(C.c_int32), C.c_float
+    fv, fr = C.POINTER(SoFeatVec), C.POINTER(SoFrameView)
+    lib.so_search_by_bow.argtypes = [vp, C.c_int, C.c_int32, vp, vp, vp, fv, C.c_int32, vp, vp, vp, fv, f, C.c_int,
+                                     vp, vp, ip]
+    lib.so_search_for_triangulation.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, fv, C.c_int32, vp, vp, vp, vp, vp,
+                                                vp, fv, vp, f, f, vp, vp, C.c_int32, C.c_int, vp, ip]
+    lib.so_search_window_best.argtypes = [vp, fr, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    lib.so_search_window_greedy.argtypes = [vp, fr, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int,
+                                            vp, ip]
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def _SearchByBoW(self, variant, kf1, fv1, kf2, fv2):
+    """kf1/kf2: dicts with desc, angle, valid.  Returns (nmatches, match_of_2, match_of_1)."""
+    _bind_ext(self._lib)
+    d1, a1, v1 = _u8(kf1["desc"]), _f32(kf1["angle"]), _u8(kf1["valid"])
+    d2, a2 = _u8(kf2["desc"]), _f32(kf2["angle"])
+    v2 = _u8(kf2["valid"]) if "valid" in kf2 else np.ones(len(d2), np.uint8)
+    n1, n2 = len(d1), len(d2)
+    m2, m1 = np.full(n2, -1, np.int32), np.full(n1, -1, np.int32)
+    nm = C.c_int32(0)
+    s1, s2 = fv1.as_struct(), fv2.as_struct()
+    _lib.check(self._lib.so_search_by_bow(self._h, variant, n1, _vp(d1), _vp(a1), _vp(v1), C.byref(s1), n2, _vp(d2),
+                                          _vp(a2), _vp(v2), C.byref(s2), self.mfNNratio, int(self.mbCheckOrientation),
+                                          _vp(m2), _vp(m1), C.byref(nm)))
+    return nm.value, m2, m1
+
+
+def _SearchForTriangulation(self, kf1, fv1, kf2, fv2, F12, epipole, scale_factors2, level_sigma2_2):
+    _bind_ext(self._lib)
+    x1, y1, a1, d1, f1 = _f32(kf1["x"]), _f32(kf1["y"]), _f32(kf1["angle"]), _u8(kf1["desc"]), _u8(kf1["free"])
+    x2, y2, o2, a2, d2, f2 = (_f32(kf2["x"]), _f32(kf2["y"]), _i32(kf2["octave"]), _f32(kf2["angle"]),
+                              _u8(kf2["desc"]), _u8(kf2["free"]))
+    F = _f32(F12).reshape(9)
+    sf, ls = _f32(scale_factors2), _f32(level_sigma2_2)
+    out = np.full(len(x1), -1, np.int32)
+    nm = C.c_int32(0)
+    s1, s2 = fv1.as_struct(), fv2.as_struct()
+    _lib.check(self._lib.so_search_for_triangulation(
+        self._h, len(x1), _vp(x1), _vp(y1), _vp(a1), _vp(d1), _vp(f1), C.byref(s1), len(x2), _vp(x2), _vp(y2), _vp(o2),
+        _vp(a2), _vp(d2), _vp(f2), C.byref(s2), _vp(F), float(epipole[0]), float(epipole[1]), _vp(sf), _vp(ls),
+        len(sf), int(self.mbCheckOrientation), _vp(out), C.byref(nm)))
+    return nm.value, out
+
+
+def _SearchWindowBest(self, KF, q, chi2_gate=False, inv_sigma2=None):
+    """Core of Fuse / SearchBySim3: q has valid, u, v, radius, pred_level, desc."""
+    _bind_ext(self._lib)
+    nq = len(q["u"])
+    a = dict(valid=_u8(q["valid"]), u=_f32(q["u"]), v=_f32(q["v"]), radius=_f32(q["radius"]),
+             pred_level=_i32(q["pred_level"]), desc=_u8(q["desc"]))
+    inv = None if inv_sigma2 is None else _f32(inv_sigma2)
+    bi, bd = np.full(nq, -1, np.int32), np.full(nq, 256, np.int32)
+    fs = KF.as_struct()
+    _lib.check(self._lib.so_search_window_best(self._h, C.byref(fs), nq, _vp(a["valid"]), _vp(a["u"]), _vp(a["v"]),
+                                               _vp(a["radius"]), _vp(a["pred_level"]), _vp(a["desc"]), int(chi2_gate),
+                                               _vp(inv), _vp(bi), _vp(bd)))
+    return bi, bd
+
+
+def _SearchWindowGreedy(self, F, q, max_dist):
+    """SearchByProjection(KF, Scw, ...) / SearchByProjection(Frame, KF, sAlreadyFound, th, ORBdist) core."""
+    _bind_ext(self._lib)
+    nq = len(q["u"])
+    a = dict(valid=_u8(q["valid"]), u=_f32(q["u"]), v=_f32(q["v"]), radius=_f32(q["radius"]),
+             min_level=_i32(q["min_level"]), max_level=_i32(q["max_level"]), desc=_u8(q["desc"]),
+             angle=_f32(q["angle"]))
+    out = np.full(F.n, -1, np.int32)
+    nm = C.c_int32(0)
+    fs = F.as_struct()
+    _lib.check(self._lib.so_search_window_greedy(self._h, C.byref(fs), nq, _vp(a["valid"]), _vp(a["u"]), _vp(a["v"]),
+                                                 _vp(a["radius"]), _vp(a["min_level"]), _vp(a["max_level"]),
+                                                 _vp(a["desc"]), _vp(a["angle"]), int(max_dist),
+                                                 int(self.mbCheckOrientation), _vp(out), C.byref(nm)))
+    return nm.value, out
+
+
+ORBmatcher.SearchByBoW = _SearchByBoW
+ORBmatcher.SearchForTriangulation = _SearchForTriangulation
+ORBmatcher.SearchWindowBest = _SearchWindowBest
+ORBmatcher.SearchWindowGreedy = _SearchWindowGreedy

@@ -225,3 +225,35 @@ def make_ba_case(name, seed=0, **kw):
     nf, nx, npnt = BA_CASES[name]
     kw.setdefault("max_obs", "auto")  # ~6.5 observations per point -> the edge counts of SURVEY.md 8d
     return make_ba_problem(seed, nf, nx, npnt, **kw)
+
+
+def make_bow_case(seed, n1=1000, n2=1000, n_nodes=100, p_flip=0.1):
+    """Two keyframes with vocabulary-node labels for SearchByBoW / SearchForTriangulation."""
+    rng = np.random.default_rng(seed)
+    f2 = make_frame_arrays(rng, n2, dup_frac=0.02)
+    src = rng.integers(0, n2, n1)
+    desc1 = flip_bits(rng, f2["desc"][src], p_flip)
+    node2 = rng.integers(0, n_nodes, n2) * 7 + 3  # arbitrary increasing ids with gaps
+    node1 = node2[src].copy()
+    stray = rng.random(n1) < 0.1  # quantised into a different node
+    node1[stray] = rng.integers(0, n_nodes + 20, int(stray.sum())) * 7 + 3
+    kf1 = dict(x=f2["x"][src] + rng.normal(0, 2, n1).astype(np.float32), y=f2["y"][src] + rng.normal(0, 2, n1).astype(np.float32),
+               angle=((f2["angle"][src] + rng.choice([4.0, 90.0], n1, p=[0.85, 0.15])) % 360).astype(np.float32),
+               desc=desc1, valid=(rng.random(n1) < 0.7).astype(np.uint8), free=(rng.random(n1) < 0.6).astype(np.uint8))
+    kf2 = dict(x=f2["x"], y=f2["y"], octave=f2["octave"], angle=f2["angle"], desc=f2["desc"],
+               valid=(rng.random(n2) < 0.8).astype(np.uint8), free=(rng.random(n2) < 0.7).astype(np.uint8))
+    return kf1, node1, kf2, node2, src
+
+
+def make_window_queries(seed, fr, nq, jitter=2.0, p_flip=0.12, th=3.0):
+    """Projected map points for the Fuse / SearchBySim3 / SearchByProjection(KF, ...) window searches."""
+    rng = np.random.default_rng(seed)
+    n = len(fr["x"])
+    k = rng.integers(0, n, nq)
+    pred = np.clip(fr["octave"][k] + rng.integers(0, 2, nq), 0, 7).astype(np.int32)
+    return dict(valid=(rng.random(nq) < 0.85).astype(np.uint8),
+                u=(fr["x"][k] + rng.normal(0, jitter, nq)).astype(np.float32),
+                v=(fr["y"][k] + rng.normal(0, jitter, nq)).astype(np.float32),
+                radius=(th * SCALE_FACTORS[pred]).astype(np.float32), pred_level=pred,
+                min_level=(pred - 1).astype(np.int32), max_level=(pred + rng.integers(0, 2, nq)).astype(np.int32),
+                desc=flip_bits(rng, fr["desc"][k], p_flip), angle=((fr["angle"][k] + 3) % 360).astype(np.float32))

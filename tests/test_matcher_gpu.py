@@ -163,3 +163,89 @@ def test_matcher_edge_cases(S, oracle):
     onm, ok = oracle.search_by_projection_mappoints(F2, mps, 1.0, 0.8)
     assert nm == onm == 0 and np.array_equal(k, ok)
     m.close()
+
+
+# ---- M3 / M5 / M6 / M7 -------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,seed,ratio", [(0, 31, 0.7), (1, 32, 0.75), (0, 33, 0.9), (1, 34, 0.6)])
+def test_m3_search_by_bow(S, oracle, variant, seed, ratio):
+    from swarmmap_amd.matcher import FeatureVector
+    kf1, node1, kf2, node2, _ = synth.make_bow_case(seed, 1200, 1000)
+    fv1, fv2 = FeatureVector(node1), FeatureVector(node2)
+    m = S.ORBmatcher(ratio, True)
+    nm, m2, m1 = m.SearchByBoW(variant, kf1, fv1, kf2, fv2)
+    onm, om2, om1 = oracle.search_by_bow(variant, kf1, fv1, kf2, fv2, ratio, True)
+    assert nm == onm and np.array_equal(m2, om2) and np.array_equal(m1, om1)
+    assert nm > 50
+    m.close()
+
+
+def test_m3_dense_node_exhausts_topk(S, oracle):
+    """One vocabulary node holding 60 near-identical features on both sides: later queries find their K-list taken."""
+    from swarmmap_amd.matcher import FeatureVector
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, 32).astype(np.uint8)
+    n = 60
+    d2 = synth.flip_bits(rng, np.tile(base, (n, 1)), 0.01)
+    d1 = synth.flip_bits(rng, d2, 0.01)
+    kf1 = dict(desc=d1, angle=np.zeros(n, np.float32), valid=np.ones(n, np.uint8))
+    kf2 = dict(desc=d2, angle=np.zeros(n, np.float32), valid=np.ones(n, np.uint8))
+    fv = FeatureVector(np.zeros(n, np.int32))
+    m = S.ORBmatcher(1.01, False)  # ratio > 1: the ratio test passes even for equal distances
+    for variant in (0, 1):
+        nm, m2, m1 = m.SearchByBoW(variant, kf1, fv, kf2, fv)
+        onm, om2, om1 = oracle.search_by_bow(variant, kf1, fv, kf2, fv, 1.01, False)
+        assert nm == onm and np.array_equal(m2, om2) and np.array_equal(m1, om1)
+        assert nm > 30
+    m.close()
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_m5_search_for_triangulation(S, oracle, seed):
+    from swarmmap_amd.matcher import FeatureVector
+    rng = np.random.default_rng(seed)
+    kf1, node1, kf2, node2, src = synth.make_bow_case(seed, 1000, 1000, p_flip=0.06)
+    # a fundamental matrix for a sideways translation: epipolar lines are (almost) horizontal, y2 ~ y1
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 1e-6, (3, 3)).astype(np.float32)
+    kf1["y"] = (kf2["y"][src] + rng.normal(0, 0.8, len(src))).astype(np.float32)
+    kf1["x"] = (kf2["x"][src] + rng.uniform(-30, 30, len(src))).astype(np.float32)
+    sf = synth.SCALE_FACTORS
+    m = S.ORBmatcher(0.6, True)
+    fv1, fv2 = FeatureVector(node1), FeatureVector(node2)
+    nm, m12 = m.SearchForTriangulation(kf1, fv1, kf2, fv2, F12, (900.0, 240.0), sf, sf * sf)
+    onm, om12 = oracle.search_for_triangulation(kf1, fv1, kf2, fv2, F12, (900.0, 240.0), sf, sf * sf, True)
+    assert nm == onm and np.array_equal(m12, om12)
+    assert nm > 100
+    m.close()
+
+
+@pytest.mark.parametrize("seed,gate", [(51, False), (52, True), (53, True)])
+def test_m6_m7_window_best(S, oracle, seed, gate):
+    rng = np.random.default_rng(seed)
+    fr = synth.make_frame_arrays(rng, 1500)
+    KF = _frame(fr, excluded=False)
+    q = synth.make_window_queries(seed, fr, 2500, jitter=1.5, th=3.0)
+    inv = (1.0 / (synth.SCALE_FACTORS ** 2)).astype(np.float32)
+    m = S.ORBmatcher()
+    bi, bd = m.SearchWindowBest(KF, q, gate, inv)
+    obi, obd = oracle.search_window_best(KF, q, gate, inv)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    assert (bi >= 0).sum() > 500
+    if gate:  # the chi2 gate removes candidates
+        bi2, _ = m.SearchWindowBest(KF, q, False, inv)
+        assert (bi2 >= 0).sum() >= (bi >= 0).sum()
+    m.close()
+
+
+@pytest.mark.parametrize("seed,max_dist,ori", [(61, 50, False), (62, 100, True), (63, 64, True)])
+def test_m7_window_greedy(S, oracle, seed, max_dist, ori):
+    rng = np.random.default_rng(seed)
+    fr = synth.make_frame_arrays(rng, 1200)
+    fr["excluded"] = (rng.random(1200) < 0.2).astype(np.uint8)
+    F = _frame(fr)
+    q = synth.make_window_queries(seed, fr, 1500, jitter=2.0, th=6.0)
+    m = S.ORBmatcher(0.75, ori)
+    nm, k2q = m.SearchWindowGreedy(F, q, max_dist)
+    onm, ok2q = oracle.search_window_greedy(F, q, max_dist, ori)
+    assert nm == onm and np.array_equal(k2q, ok2q)
+    assert nm > 200
+    m.close()

@@ -99,3 +99,59 @@ def test_top2(oracle):
     assert np.array_equal(bi, D.argmin(1))
     assert np.array_equal(bd, D.min(1))
     assert np.array_equal(sd, np.sort(D, 1)[:, 1])
+
+
+def test_bow_triangulation_window_oracles(oracle):
+    from swarmmap_amd.matcher import FeatureVector
+    kf1, node1, kf2, node2, src = synth.make_bow_case(9, 800, 700)
+    fv1, fv2 = FeatureVector(node1), FeatureVector(node2)
+    # FeatureVector flattening: ascending node ids, ascending feature index inside a node (DBoW2 push order)
+    assert np.all(np.diff(fv1.node_id) > 0)
+    for k in range(len(fv1.node_id)):
+        seg = fv1.idx[fv1.off[k]:fv1.off[k + 1]]
+        assert np.all(np.diff(seg) > 0) and np.all(node1[seg] == fv1.node_id[k])
+    for variant in (0, 1):
+        nm, m2, m1 = oracle.search_by_bow(variant, kf1, fv1, kf2, fv2, 0.75, False)
+        sel = np.nonzero(m1 >= 0)[0]
+        assert nm == len(sel) > 50
+        assert len(set(m1[sel].tolist())) == len(sel)          # a target is bound at most once
+        assert np.all(kf1["valid"][sel] == 1)
+        assert np.all(node1[sel] == node2[m1[sel]])            # only features of the same vocabulary node match
+        if variant == 1:
+            assert np.all(kf2["valid"][m1[sel]] == 1)
+        for i in sel[:100]:
+            d = oracle.descriptor_distance(kf1["desc"][i], kf2["desc"][m1[i]])
+            assert d <= 50 if variant == 0 else d < 50
+    # SearchForTriangulation: ties go to the LAST candidate of the node (":688 dist > bestDist -> continue")
+    d = np.zeros((1, 32), np.uint8)
+    kfa = dict(x=[100.0], y=[50.0], angle=[0.0], desc=d, free=[1])
+    kfb = dict(x=[10.0, 20.0, 30.0], y=[50.0, 50.0, 50.0], octave=[0, 0, 0], angle=[0.0, 0.0, 0.0],
+               desc=np.zeros((3, 32), np.uint8), free=[1, 1, 1])
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    sf = synth.SCALE_FACTORS
+    nm, m12 = oracle.search_for_triangulation(kfa, FeatureVector([5]), kfb, FeatureVector([5, 5, 5]), F12,
+                                              (900.0, 900.0), sf, sf * sf, False)
+    assert nm == 1 and m12[0] == 2
+    # window_best == brute force over the literal grid scan
+    rng = np.random.default_rng(4)
+    fr = synth.make_frame_arrays(rng, 600)
+    KF = _frame(fr)
+    q = synth.make_window_queries(4, fr, 300)
+    inv = (1.0 / synth.SCALE_FACTORS ** 2).astype(np.float32)
+    bi, bd = oracle.search_window_best(KF, q, True, inv)
+    for i in range(300):
+        if not q["valid"][i]:
+            assert bi[i] == -1
+            continue
+        cand = oracle.features_in_area(KF, q["u"][i], q["v"][i], q["radius"][i], -1, -1)
+        best, bdist = -1, 256
+        for c in cand:
+            if not (q["pred_level"][i] - 1 <= fr["octave"][c] <= q["pred_level"][i]):
+                continue
+            e2 = np.float32(np.float32(q["u"][i] - fr["x"][c]) ** 2 + np.float32(q["v"][i] - fr["y"][c]) ** 2)
+            if float(np.float32(e2 * inv[fr["octave"][c]])) > 5.99:
+                continue
+            dd = oracle.descriptor_distance(q["desc"][i], fr["desc"][c])
+            if dd < bdist:
+                best, bdist = int(c), dd
+        assert (bi[i], bd[i]) == (best, bdist)
