@@ -292,6 +292,16 @@ void so_ba_options_global(so_ba_options* opt, int32_t n_iterations, int32_t robu
  * Outputs: Tcw_out n_poses x 12 (Converter::toCvMat of every pose vertex), Xw_out n_points x 3,
  * edge_outlier n_edges (e->chi2() > threshold || !e->isDepthPositive(), Optimizer.cc:682-695),
  * edge_chi2 n_edges (may be NULL). */
+/* Optimizer::PoseOptimization(Frame* pFrame, bGlobal) — code/src/Optimizer.cc:239-434 (monocular): motion-only BA
+ * of one frame, called 2-3 times per frame by Tracking.  The whole schedule (4 rounds x 10 LM iterations, Huber,
+ * outlier re-classification) runs in ONE kernel launch.  Inputs are the n keypoints that have a map point:
+ * Tcw12 = pFrame->mTcw (row-major [R|t]), intr = fx, fy, cx, cy, Xw n x 3 (GetWorldPos / GetGlobalPos),
+ * obs n x 2 (mvKeysUn[i].pt), inv_sigma2 n (mvInvLevelSigma2[octave]).  Outputs: Tcw_out12 (SetPose argument),
+ * outlier[i] (mvbOutlier), *n_inliers = nInitialCorrespondences - nBad (0 with untouched outputs when n < 3). */
+int so_pose_optimization(so_ba* ba, const float* Tcw12, const float* intr, int32_t n, const float* Xw,
+                         const float* obs, const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier,
+                         int32_t* n_inliers, int32_t* info /* [iterations, lm_trials], may be NULL */);
+
 int so_bundle_adjust(so_ba* ba, const so_ba_problem* problem, const so_ba_options* options,
                      const volatile uint8_t* stop, float* Tcw_out, float* Xw_out, uint8_t* edge_outlier,
                      double* edge_chi2, so_ba_info* info);

@@ -548,3 +548,176 @@ int orc_bundle_adjust(const orc_ba_problem* p, const orc_ba_options* opt, const 
     free(s.pose_hidx); free(s.pt_hidx); free(s.active); free(s.Hpp); free(s.Hll); free(s.Hpl); free(s.b); free(s.x);
     return 0;
 }
+
+/* ================= Optimizer::PoseOptimization (code/src/Optimizer.cc:239-434) ================= */
+typedef struct {
+    int n;
+    const double* Xw; const double* obs; const double* w; double K[4];
+    double (*err)[2];
+    uint8_t* level; /* 1 = excluded from the optimisation (outlier of the previous round) */
+    int robust; double delta;
+    se3 pose;
+} po_t;
+
+/* EdgeSE3ProjectXYZOnlyPose::computeError + linearizeOplus (types_six_dof_expmap.h:153-157, .cpp:266-288) */
+static void po_edge(const po_t* s, int e, const se3* T, double* err, double* J) {
+    double pc[3];
+    quat_rotate(T->q, s->Xw + 3 * e, pc);
+    pc[0] += T->t[0]; pc[1] += T->t[1]; pc[2] += T->t[2];
+    if (err) {
+        err[0] = s->obs[2 * e] - (pc[0] / pc[2] * s->K[0] + s->K[2]);
+        err[1] = s->obs[2 * e + 1] - (pc[1] / pc[2] * s->K[1] + s->K[3]);
+    }
+    if (J) {
+        const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz, fx = s->K[0], fy = s->K[1];
+        J[0] = x * y * invz_2 * fx;        J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
+        J[3] = -invz * fx;                 J[4] = 0;                            J[5] = x * invz_2 * fx;
+        J[6] = (1 + y * y * invz_2) * fy;  J[7] = -x * y * invz_2 * fy;         J[8] = -x * invz * fy;
+        J[9] = 0;                          J[10] = -invz * fy;                  J[11] = y * invz_2 * fy;
+    }
+}
+
+static double po_chi2_edge(const po_t* s, int e) {
+    return s->err[e][0] * (s->w[e] * s->err[e][0]) + s->err[e][1] * (s->w[e] * s->err[e][1]);
+}
+
+static void po_errors(po_t* s) {
+    for (int e = 0; e < s->n; e++)
+        if (!s->level[e]) po_edge(s, e, &s->pose, s->err[e], 0);
+}
+
+static double po_robust_chi2(const po_t* s) {
+    double chi = 0, rho[3];
+    for (int e = 0; e < s->n; e++) {
+        if (s->level[e]) continue;
+        if (s->robust) {
+            orc_huber(po_chi2_edge(s, e), s->delta, rho);
+            chi += rho[0];
+        } else chi += po_chi2_edge(s, e);
+    }
+    return chi;
+}
+
+static int po_optimize(po_t* s, int iterations, int* its_done, int* trials) {
+    int n_active = 0;
+    for (int e = 0; e < s->n; e++) n_active += !s->level[e];
+    if (n_active == 0) return -1; /* "0 vertices to optimize" */
+    double H[36], b[6], x[6], lambda = -1, ni = 2;
+    int nBad = 0, ok = 1;
+    for (int it = 0; it < iterations && ok; it++) {
+        po_errors(s);
+        double currentChi = po_robust_chi2(s), tempChi = currentChi;
+        const double iniChi = currentChi;
+        memset(H, 0, sizeof(H));
+        memset(b, 0, sizeof(b));
+        for (int e = 0; e < s->n; e++) { /* BaseUnaryEdge::constructQuadraticForm (base_unary_edge.hpp:43-72) */
+            if (s->level[e]) continue;
+            double J[12];
+            po_edge(s, e, &s->pose, 0, J);
+            double w = s->w[e], r1 = 1.0;
+            if (s->robust) {
+                double rho[3];
+                orc_huber(po_chi2_edge(s, e), s->delta, rho);
+                r1 = rho[1];
+            }
+            const double wo = r1 * w;
+            for (int r = 0; r < 6; r++) {
+                b[r] -= r1 * (J[r] * (w * s->err[e][0]) + J[6 + r] * (w * s->err[e][1]));
+                for (int c = 0; c < 6; c++) H[r * 6 + c] += J[r] * wo * J[c] + J[6 + r] * wo * J[6 + c];
+            }
+        }
+        if (it == 0) {
+            double maxDiagonal = 0.;
+            for (int j = 0; j < 6; j++) maxDiagonal = fmax(fabs(H[7 * j]), maxDiagonal);
+            lambda = 1e-5 * maxDiagonal;
+            ni = 2;
+            nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            const se3 backup = s->pose;
+            double A[36];
+            memcpy(A, H, sizeof(A));
+            for (int j = 0; j < 6; j++) A[7 * j] += lambda;
+            memcpy(x, b, sizeof(b));
+            const int ok2 = cholesky_solve(A, x, 6); /* LinearSolverDense (LDLT), same solution */
+            orc_se3_exp_mul(x, s->pose.q, s->pose.t);
+            po_errors(s);
+            tempChi = po_robust_chi2(s);
+            if (!ok2) tempChi = DBL_MAX;
+            rho = currentChi - tempChi;
+            double scale = 0.;
+            for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                s->pose = backup;
+            }
+            qmax++;
+            (*trials)++;
+        } while (rho < 0 && qmax < 10);
+        (*its_done)++;
+        if (qmax == 10 || rho == 0) { ok = 0; continue; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) ok = 0;
+    }
+    return 0;
+}
+
+int orc_pose_optimization(const float* Tcw12, const float* intr, int32_t n, const float* Xw, const float* obs,
+                          const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier, int32_t* info) {
+    if (info) info[0] = info[1] = 0;
+    if (n < 3) return 0; /* Optimizer.cc:344-345 */
+    po_t s;
+    memset(&s, 0, sizeof(s));
+    s.n = n;
+    double* X = (double*)malloc(sizeof(double) * 3 * (size_t)n);
+    double* O = (double*)malloc(sizeof(double) * 2 * (size_t)n);
+    double* W = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int i = 0; i < 3 * n; i++) X[i] = (double)Xw[i];
+    for (int i = 0; i < 2 * n; i++) O[i] = (double)obs[i];
+    for (int i = 0; i < n; i++) W[i] = (double)inv_sigma2[i];
+    s.Xw = X; s.obs = O; s.w = W;
+    for (int k = 0; k < 4; k++) s.K[k] = (double)intr[k];
+    s.err = calloc((size_t)n, sizeof(double) * 2);
+    s.level = (uint8_t*)calloc((size_t)n, 1);
+    s.robust = 1;
+    s.delta = (double)(float)sqrt(5.991); /* const float deltaMono = sqrt(5.991) */
+    se3 init;
+    orc_se3_from_Tcw(Tcw12, init.q, init.t);
+    memset(outlier, 0, (size_t)n);
+    const float chi2Mono = 5.991f;
+    int nBad = 0, its = 0, trials = 0;
+    for (int round = 0; round < 4; round++) {
+        s.pose = init; /* vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)) */
+        po_optimize(&s, 10, &its, &trials);
+        nBad = 0;
+        for (int e = 0; e < n; e++) {
+            if (outlier[e]) po_edge(&s, e, &s.pose, s.err[e], 0); /* :364-366 */
+            const float chi2 = (float)po_chi2_edge(&s, e);
+            if (chi2 > chi2Mono) {
+                outlier[e] = 1;
+                s.level[e] = 1;
+                nBad++;
+            } else {
+                outlier[e] = 0;
+                s.level[e] = 0;
+            }
+        }
+        if (round == 2) s.robust = 0;
+        if (n < 10) break; /* optimizer.edges().size() < 10 */
+    }
+    orc_se3_to_Tcw(s.pose.q, s.pose.t, Tcw_out12);
+    if (info) { info[0] = its; info[1] = trials; }
+    free(X); free(O); free(W); free(s.err); free(s.level);
+    return n - nBad;
+}

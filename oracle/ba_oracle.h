@@ -74,3 +74,22 @@ void orc_huber(double e, double delta, double* rho3);                       /* R
 }
 #endif
 #endif
+
+/* ---- Optimizer::PoseOptimization (code/src/Optimizer.cc:239-434), monocular, on flattened inputs ---- */
+#ifndef BA_ORACLE_POSE_H
+#define BA_ORACLE_POSE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* One SE3 vertex, n unary EdgeSE3ProjectXYZOnlyPose edges (types_six_dof_expmap.h:143-171, .cpp:266-296), Huber
+ * sqrt(5.991), 4 rounds of optimize(10) each restarted from the input pose, inlier/outlier re-classification after
+ * every round (float chi2 > 5.991f), kernel dropped after round 3, dense 6x6 solve (LinearSolverDense).
+ * Tcw12: row-major [R|t] float (pFrame->mTcw); intr: fx, fy, cx, cy; Xw n x 3, obs n x 2, inv_sigma2 n (floats).
+ * Returns nInitialCorrespondences - nBad (0 and untouched outputs when n < 3).
+ * outlier[i] = pFrame->mvbOutlier of the i-th correspondence; info[0] = LM iterations run, info[1] = LM trials. */
+int orc_pose_optimization(const float* Tcw12, const float* intr, int32_t n, const float* Xw, const float* obs,
+                          const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier, int32_t* info);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -349,3 +349,17 @@ def search_window_greedy(F, q, max_dist, check_ori=True):
                                         _p(a["min_level"]), _p(a["max_level"]), _p(a["desc"]), _p(a["angle"]),
                                         int(max_dist), int(check_ori), _p(out))
     return nm, out
+
+
+def pose_optimization(Tcw, intr, Xw, obs, inv_sigma2):
+    """Optimizer::PoseOptimization on flattened inputs.  Returns (n_inliers, Tcw_out[12], outlier[n], info)."""
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    K = np.ascontiguousarray(intr, np.float32).reshape(4)
+    X = np.ascontiguousarray(Xw, np.float32).reshape(-1, 3)
+    O = np.ascontiguousarray(obs, np.float32).reshape(-1, 2)
+    W = np.ascontiguousarray(inv_sigma2, np.float32)
+    Tout = T.copy()
+    outl = np.zeros(len(X), np.uint8)
+    info = np.zeros(2, np.int32)
+    n = lib().orc_pose_optimization(_p(T), _p(K), len(X), _p(X), _p(O), _p(W), _p(Tout), _p(outl), _p(info))
+    return n, Tout, outl, {"iterations": int(info[0]), "lm_trials": int(info[1])}

@@ -110,13 +110,15 @@ struct so_ba {
 
     Buf d_pose[2], d_pt[2], d_intr, d_epose, d_ept, d_obs, d_w, d_active, d_err, d_chi2, d_ptoff, d_ptact, d_hidx,
         d_freepose, d_poseoff, d_poseedges, d_blkoff, d_blki1, d_blki2, d_pk1, d_pk2, d_Hpp, d_bp, d_Hll, d_bl, d_W,
-        d_Dinv, d_db, d_BDinv, d_S, d_bs, d_xl, d_partial, d_depth;
+        d_Dinv, d_db, d_BDinv, d_S, d_bs, d_xl, d_partial, d_depth, d_po;
     double* h_partial = nullptr;  // pinned
+    uint8_t* h_po = nullptr;      // pinned staging for PoseOptimization
+    size_t h_po_cap = 0;
     std::vector<Buf*> all() {
         return {&d_pose[0], &d_pose[1], &d_pt[0], &d_pt[1], &d_intr, &d_epose, &d_ept, &d_obs, &d_w, &d_active, &d_err,
                 &d_chi2, &d_ptoff, &d_ptact, &d_hidx, &d_freepose, &d_poseoff, &d_poseedges, &d_blkoff, &d_blki1,
                 &d_blki2, &d_pk1, &d_pk2, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv, &d_db, &d_BDinv, &d_S, &d_bs,
-                &d_xl, &d_partial, &d_depth};
+                &d_xl, &d_partial, &d_depth, &d_po};
     }
 };
 
@@ -416,6 +418,7 @@ void so_ba_destroy(so_ba* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (Buf* q : b->all()) q->release();
     if (b->h_partial) (void)hipHostFree(b->h_partial);
+    if (b->h_po) (void)hipHostFree(b->h_po);
     if (b->e0) (void)hipEventDestroy(b->e0);
     if (b->e1) (void)hipEventDestroy(b->e1);
     if (b->e2) (void)hipEventDestroy(b->e2);
@@ -638,6 +641,68 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     inf.n_solves = b->n_solves;
     inf.wall_ms = (float)(now_ms() - t_begin);
     if (info) *info = inf;
+    return SO_OK;
+}
+
+// Optimizer::PoseOptimization — code/src/Optimizer.cc:239-434
+int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_t n, const float* Xw, const float* obs,
+                         const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier, int32_t* n_inliers,
+                         int32_t* info) {
+    if (!b || !Tcw12 || !intr || n < 0 || !Tcw_out12 || !n_inliers) return SO_ERR_INVALID_ARG;
+    if (n > 0 && (!Xw || !obs || !inv_sigma2 || !outlier)) return SO_ERR_INVALID_ARG;
+    *n_inliers = 0;
+    if (info) info[0] = info[1] = 0;
+    if (n < 3) return SO_OK;  // :344-345, nothing is touched
+    SO_HIP(hipSetDevice(b->device));
+    hipStream_t s = b->stream;
+    // one pinned staging block: [Xw 12n | obs 8n | w 4n] in, [pose 64 | info 16 | outlier n] out
+    const size_t in_bytes = (size_t)n * 24, out_bytes = 64 + 16 + (size_t)n;
+    const size_t need = in_bytes + out_bytes + 64;
+    if (need > b->h_po_cap) {
+        if (b->h_po) SO_HIP(hipHostFree(b->h_po));
+        b->h_po = nullptr;
+        b->h_po_cap = 0;
+        SO_HIP(hipHostMalloc((void**)&b->h_po, need * 2, hipHostMallocDefault));
+        b->h_po_cap = need * 2;
+    }
+    int rc;
+    // device block: [inputs 24n | err 16n | pose 64 | info 16 | outlier n]
+    const size_t off_err = ((size_t)n * 24 + 15) / 16 * 16, off_pose = off_err + (size_t)n * 16, off_info = off_pose + 64,
+                 off_out = off_info + 16;
+    if ((rc = b->d_po.ensure(off_out + (size_t)n + 64))) return rc;
+    uint8_t* h = b->h_po;
+    memcpy(h, Xw, (size_t)n * 12);
+    memcpy(h + (size_t)n * 12, obs, (size_t)n * 8);
+    memcpy(h + (size_t)n * 20, inv_sigma2, (size_t)n * 4);
+    uint8_t* d = b->d_po.as<uint8_t>();
+    SO_HIP(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    PoseOptArgs a;
+    a.Xw = reinterpret_cast<const float*>(d);
+    a.obs = reinterpret_cast<const float*>(d + (size_t)n * 12);
+    a.inv_sigma2 = reinterpret_cast<const float*>(d + (size_t)n * 20);
+    for (int k = 0; k < 4; k++) a.K[k] = (double)intr[k];
+    pose_from_Tcw(Tcw12, a.init);  // Converter::toSE3Quat(pFrame->mTcw)
+    a.n = n;
+    a.err = reinterpret_cast<double*>(d + off_err);
+    a.pose_out = reinterpret_cast<BaPose*>(d + off_pose);
+    a.info = reinterpret_cast<int*>(d + off_info);
+    a.outlier = d + off_out;
+    launch_pose_opt(a, s);
+    SO_HIP(hipGetLastError());
+    uint8_t* hout = h + in_bytes;
+    SO_HIP(hipMemcpyAsync(hout, d + off_pose, 64 + 16 + (size_t)n, hipMemcpyDeviceToHost, s));
+    SO_HIP(hipStreamSynchronize(s));
+    BaPose P;
+    memcpy(&P, hout, sizeof(BaPose));
+    int inf[4];
+    memcpy(inf, hout + 64, 16);
+    memcpy(outlier, hout + 80, (size_t)n);
+    pose_to_Tcw(P, Tcw_out12);  // Converter::toCvMat(SE3quat_recov)
+    *n_inliers = n - inf[0];
+    if (info) {
+        info[0] = inf[1];
+        info[1] = inf[2];
+    }
     return SO_OK;
 }
 

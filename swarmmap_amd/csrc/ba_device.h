@@ -70,4 +70,18 @@ void launch_ba_update(const BaDev& d, double lambda, const BaPose* poses, const 
                       double* points_trial, int n_blocks, hipStream_t s);
 void launch_ba_depth(const BaDev& d, const BaPose* poses, const double* points, double* depth, hipStream_t s);
 
+struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.hip)
+    const float* Xw;          // n x 3
+    const float* obs;         // n x 2
+    const float* inv_sigma2;  // n
+    double K[4];
+    BaPose init;
+    int n;
+    double* err;       // n x 2 scratch (stored _error)
+    uint8_t* outlier;  // n (out)
+    BaPose* pose_out;
+    int* info;         // [0] nBad, [1] LM iterations, [2] LM trials
+};
+void launch_pose_opt(const PoseOptArgs& a, hipStream_t s);
+
 }  // namespace so

@@ -769,3 +769,256 @@ void launch_ba_update(const BaDev& d, double lambda, const BaPose* poses, const 
 }
 
 }  // namespace so
+
+// =====================================================================================================
+// Optimizer::PoseOptimization (code/src/Optimizer.cc:239-434): ONE workgroup runs the whole schedule —
+// 4 rounds x optimize(10) of Levenberg-Marquardt on a single SE3 vertex with n unary
+// EdgeSE3ProjectXYZOnlyPose edges (types_six_dof_expmap.{h:143-171,cpp:266-296}), Huber kernel, outlier
+// re-classification between rounds — without a single host round trip.  The 6x6 normal equations are block
+// reductions over the edges (fixed order), the 6x6 solve and the SE3 update run on one lane.
+// =====================================================================================================
+namespace so {
+
+__device__ __forceinline__ void po_edge_err(const PoseOptArgs& a, int e, const BaPose& T, double& e0, double& e1) {
+    const double X[3] = {(double)a.Xw[3 * e], (double)a.Xw[3 * e + 1], (double)a.Xw[3 * e + 2]};
+    double pc[3];
+    camera_point(T, X, pc);
+    e0 = (double)a.obs[2 * e] - (pc[0] / pc[2] * a.K[0] + a.K[2]);
+    e1 = (double)a.obs[2 * e + 1] - (pc[1] / pc[2] * a.K[1] + a.K[3]);
+}
+
+__device__ __forceinline__ void po_edge_jac(const PoseOptArgs& a, int e, const BaPose& T, double* J) {
+    const double X[3] = {(double)a.Xw[3 * e], (double)a.Xw[3 * e + 1], (double)a.Xw[3 * e + 2]};
+    double pc[3];
+    camera_point(T, X, pc);
+    const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz, fx = a.K[0], fy = a.K[1];
+    J[0] = x * y * invz_2 * fx;       J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
+    J[3] = -invz * fx;                J[4] = 0;                            J[5] = x * invz_2 * fx;
+    J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy;         J[8] = -x * invz * fy;
+    J[9] = 0;                         J[10] = -invz * fy;                  J[11] = y * invz_2 * fy;
+}
+
+constexpr int kPoThreads = 256;
+
+__global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(PoseOptArgs a) {
+    __shared__ double s_tmp[16];
+    __shared__ double s_red[4][28];
+    __shared__ double s_H[36], s_b[6], s_x[6];
+    __shared__ BaPose s_cur, s_trial;
+    __shared__ int s_ctrl[4];  // [0] trial accepted, [1] keep trying, [2] stop optimize(), [3] solve ok
+    __shared__ double s_lm[4]; // lambda, ni, currentChi, scale
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = a.n;
+    const double delta = (double)sqrtf(5.991f);  // const float deltaMono = sqrt(5.991)
+    const float dsqr = (float)(delta * delta);
+    int robust = 1, nBad = 0, its_total = 0, trials_total = 0;
+
+    for (int e = tid; e < n; e += kPoThreads) a.outlier[e] = 0;
+    __syncthreads();
+
+    // residuals of the active edges for pose T -> stored error; returns the robustified chi2 (block sum)
+    auto errors = [&](const BaPose& T) -> double {
+        double acc = 0.0;
+        for (int e = tid; e < n; e += kPoThreads) {
+            if (a.outlier[e]) continue;  // level 1
+            double e0, e1;
+            po_edge_err(a, e, T, e0, e1);
+            a.err[2 * e] = e0;
+            a.err[2 * e + 1] = e1;
+            const double w = (double)a.inv_sigma2[e];
+            const double chi2 = e0 * (w * e0) + e1 * (w * e1);
+            acc += robust ? huber_rho0(chi2, delta, dsqr) : chi2;
+        }
+        return block_sum(acc, s_tmp);
+    };
+
+    for (int round = 0; round < 4; round++) {
+        if (tid == 0) s_cur = a.init;  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw))
+        int n_active_local = 0;
+        for (int e = tid; e < n; e += kPoThreads) n_active_local += !a.outlier[e];
+        const int n_active = (int)block_sum((double)n_active_local, s_tmp);
+        __syncthreads();
+        if (n_active > 0) {
+            bool fresh = false;  // stored errors describe s_cur
+            double carried = 0.0;
+            if (tid == 0) { s_ctrl[2] = 0; }
+            int nBadLM = 0;
+            __syncthreads();
+            for (int it = 0; it < 10; it++) {
+                if (s_ctrl[2]) break;
+                const BaPose cur = s_cur;
+                double currentChi = fresh ? carried : errors(cur);
+                const double iniChi = currentChi;
+                // build the 6x6 system: upper 21 of J^T w J and the 6 of -rho' J^T Omega e
+                double acc[27];
+#pragma unroll
+                for (int k = 0; k < 27; k++) acc[k] = 0.0;
+                for (int e = tid; e < n; e += kPoThreads) {
+                    if (a.outlier[e]) continue;
+                    double J[12];
+                    po_edge_jac(a, e, cur, J);
+                    const double w = (double)a.inv_sigma2[e];
+                    const double e0 = a.err[2 * e], e1 = a.err[2 * e + 1];
+                    const double r1 = robust ? huber_rho1(e0 * (w * e0) + e1 * (w * e1), delta, dsqr) : 1.0;
+                    const double wo = r1 * w;
+                    int t = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = r; c < 6; c++) acc[t++] += J[r] * wo * J[c] + J[6 + r] * wo * J[6 + c];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) acc[21 + r] -= r1 * (J[r] * (w * e0) + J[6 + r] * (w * e1));
+                }
+#pragma unroll
+                for (int k = 0; k < 27; k++) {
+                    const double v = wave_sum(acc[k]);
+                    if (lane == 0) s_red[wv][k] = v;
+                }
+                __syncthreads();
+                if (tid < 27) {
+                    const double v = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+                    if (tid < 21) {
+                        int r = 0, t = tid;
+                        while (t >= 6 - r) { t -= 6 - r; r++; }
+                        const int c = r + t;
+                        s_H[r * 6 + c] = v;
+                        s_H[c * 6 + r] = v;
+                    } else {
+                        s_b[tid - 21] = v;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    if (it == 0) {  // computeLambdaInit
+                        double md = 0.0;
+                        for (int j = 0; j < 6; j++) md = fmax(md, fabs(s_H[7 * j]));
+                        s_lm[0] = 1e-5 * md;
+                        s_lm[1] = 2.0;
+                    }
+                    s_lm[2] = currentChi;
+                }
+                if (it == 0) nBadLM = 0;
+                __syncthreads();
+                int qmax = 0;
+                double rho = 0.0;
+                do {
+                    if (tid == 0) {  // (H + lambda I) x = b by Cholesky, then trial = exp(x) * cur
+                        double A[36], x[6];
+                        const double lambda = s_lm[0];
+                        for (int q = 0; q < 36; q++) A[q] = s_H[q];
+                        for (int j = 0; j < 6; j++) A[7 * j] += lambda;
+                        for (int j = 0; j < 6; j++) x[j] = s_b[j];
+                        int ok = 1;
+                        for (int j = 0; j < 6 && ok; j++) {
+                            double dj = A[j * 6 + j];
+                            for (int k = 0; k < j; k++) dj -= A[j * 6 + k] * A[j * 6 + k];
+                            if (!(dj > 0.0)) { ok = 0; break; }
+                            dj = sqrt(dj);
+                            A[j * 6 + j] = dj;
+                            for (int i = j + 1; i < 6; i++) {
+                                double v = A[i * 6 + j];
+                                for (int k = 0; k < j; k++) v -= A[i * 6 + k] * A[j * 6 + k];
+                                A[i * 6 + j] = v / dj;
+                            }
+                        }
+                        if (ok) {
+                            for (int i = 0; i < 6; i++) {
+                                double v = x[i];
+                                for (int k = 0; k < i; k++) v -= A[i * 6 + k] * x[k];
+                                x[i] = v / A[i * 6 + i];
+                            }
+                            for (int i = 5; i >= 0; i--) {
+                                double v = x[i];
+                                for (int k = i + 1; k < 6; k++) v -= A[k * 6 + i] * x[k];
+                                x[i] = v / A[i * 6 + i];
+                            }
+                        }
+                        double scale = 0.0;
+                        for (int j = 0; j < 6; j++) {
+                            s_x[j] = x[j];
+                            scale += x[j] * (lambda * x[j] + s_b[j]);
+                        }
+                        s_lm[3] = scale + 1e-3;
+                        s_ctrl[3] = ok;
+                        BaPose tr;
+                        se3_exp_mul(x, s_cur, tr);
+                        s_trial = tr;
+                    }
+                    __syncthreads();
+                    const BaPose trial = s_trial;
+                    double tempChi = errors(trial);
+                    if (!s_ctrl[3]) tempChi = 1.7976931348623157e308;
+                    if (tid == 0) {
+                        double r = (s_lm[2] - tempChi) / s_lm[3];
+                        if (r > 0 && isfinite(tempChi)) {
+                            double alpha = 1. - pow((2 * r - 1), 3);
+                            alpha = fmin(alpha, 2. / 3.);
+                            s_lm[0] *= fmax(1. / 3., alpha);
+                            s_lm[1] = 2.0;
+                            s_lm[2] = tempChi;
+                            s_cur = s_trial;  // discardTop
+                            s_ctrl[0] = 1;
+                        } else {
+                            s_lm[0] *= s_lm[1];
+                            s_lm[1] *= 2.0;
+                            s_ctrl[0] = 0;  // pop
+                        }
+                        s_red[0][27] = r;
+                    }
+                    __syncthreads();
+                    rho = s_red[0][27];
+                    fresh = s_ctrl[0] != 0;
+                    if (fresh) carried = tempChi;
+                    qmax++;
+                    trials_total++;
+                    __syncthreads();
+                } while (rho < 0 && qmax < 10);
+                its_total++;
+                currentChi = s_lm[2];
+                bool stop = false;
+                if (qmax == 10 || rho == 0) stop = true;
+                else {
+                    if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+                    if (nBadLM >= 3) stop = true;
+                }
+                __syncthreads();
+                if (tid == 0) s_ctrl[2] = stop ? 1 : 0;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        // classify (Optimizer.cc:357-380): outliers of the previous round get a fresh error, inliers keep the stored one
+        const BaPose fin = s_cur;
+        int bad_local = 0;
+        for (int e = tid; e < n; e += kPoThreads) {
+            if (a.outlier[e]) {
+                double e0, e1;
+                po_edge_err(a, e, fin, e0, e1);
+                a.err[2 * e] = e0;
+                a.err[2 * e + 1] = e1;
+            }
+            const double w = (double)a.inv_sigma2[e];
+            const double e0 = a.err[2 * e], e1 = a.err[2 * e + 1];
+            const float chi2 = (float)(e0 * (w * e0) + e1 * (w * e1));
+            const bool out = chi2 > 5.991f;
+            a.outlier[e] = out ? 1 : 0;
+            bad_local += out;
+        }
+        nBad = (int)block_sum((double)bad_local, s_tmp);
+        if (round == 2) robust = 0;
+        __syncthreads();
+        if (n < 10) break;
+    }
+    if (tid == 0) {
+        *a.pose_out = s_cur;
+        a.info[0] = nBad;
+        a.info[1] = its_total;
+        a.info[2] = trials_total;
+    }
+}
+
+void launch_pose_opt(const PoseOptArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(pose_opt_kernel, dim3(1), dim3(kPoThreads), 0, s, a);
+}
+
+}  // namespace so

@@ -89,6 +89,24 @@ class Optimizer:
 
     GlobalBundleAdjustment = BundleAdjustment
 
+    # int Optimizer::PoseOptimization(Frame* pFrame, bGlobal) on the keypoints that have a map point
+    def PoseOptimization(self, Tcw, intr, Xw, obs, inv_sigma2):
+        lib = self._lib
+        vp = C.c_void_p
+        lib.so_pose_optimization.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp]
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+        K = np.ascontiguousarray(intr, np.float32).reshape(4)
+        X = np.ascontiguousarray(Xw, np.float32).reshape(-1, 3)
+        O = np.ascontiguousarray(obs, np.float32).reshape(-1, 2)
+        W = np.ascontiguousarray(inv_sigma2, np.float32)
+        Tout = T.copy()
+        outl = np.zeros(len(X), np.uint8)
+        info = np.zeros(2, np.int32)
+        n_in = C.c_int32(0)
+        _lib.check(lib.so_pose_optimization(self._h, _vp(T), _vp(K), len(X), _vp(X), _vp(O), _vp(W), _vp(Tout),
+                                            _vp(outl), C.byref(n_in), _vp(info)))
+        return n_in.value, Tout, outl, {"iterations": int(info[0]), "lm_trials": int(info[1])}
+
     def solve(self, problem, its1, its2, robust, huber_delta, chi2_threshold=5.991, pbStopFlag=None):
         opt = SoBaOptions(int(its1), int(its2), int(bool(robust)), float(huber_delta), float(chi2_threshold))
         return self._solve(problem, opt, pbStopFlag)

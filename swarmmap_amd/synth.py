@@ -257,3 +257,25 @@ def make_window_queries(seed, fr, nq, jitter=2.0, p_flip=0.12, th=3.0):
                 radius=(th * SCALE_FACTORS[pred]).astype(np.float32), pred_level=pred,
                 min_level=(pred - 1).astype(np.int32), max_level=(pred + rng.integers(0, 2, nq)).astype(np.int32),
                 desc=flip_bits(rng, fr["desc"][k], p_flip), angle=((fr["angle"][k] + 3) % 360).astype(np.float32))
+
+
+def make_pose_case(seed, n=300, K=EUROC_K, size=EUROC, pixel_sigma=1.0, outlier_frac=0.1, pose_noise=(0.05, 1.5)):
+    """Frame pose + matched map points for Optimizer::PoseOptimization."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = K
+    R = _rodrigues(rng.normal(0, 0.1, 3))
+    t = rng.normal(0, 0.3, 3)
+    uv = np.stack([rng.uniform(30, size[0] - 30, n), rng.uniform(30, size[1] - 30, n)], 1)
+    z = rng.uniform(2, 12, n)
+    pc = np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], 1)
+    Xw = (R.T @ (pc - t).T).T
+    octave = np.clip(np.floor(np.log(z / 2.0) / np.log(1.2)), 0, 7).astype(int)
+    scale = 1.2 ** octave
+    obs = uv + rng.normal(0, pixel_sigma, (n, 2)) * scale[:, None]
+    out = rng.random(n) < outlier_frac
+    obs[out] += rng.uniform(-50, 50, (int(out.sum()), 2))
+    dR = _rodrigues(rng.normal(0, np.deg2rad(pose_noise[1]), 3))
+    T0 = np.hstack([dR @ R, (dR @ t + rng.normal(0, pose_noise[0], 3))[:, None]]).reshape(12)
+    return dict(Tcw=T0.astype(np.float32), intr=np.array(K, np.float32), Xw=Xw.astype(np.float32),
+                obs=obs.astype(np.float32), inv_sigma2=(1.0 / scale ** 2).astype(np.float32),
+                gt_Tcw=np.hstack([R, t[:, None]]).reshape(12), gt_outlier=out)

@@ -105,3 +105,23 @@ def test_stop_flag_and_edge_cases(opt, oracle):
         bad["edge_pose"] = p["edge_pose"].copy()
         bad["edge_pose"][0] = 10 ** 6
         opt.LocalBundleAdjustment(bad)
+
+
+# ---- Optimizer::PoseOptimization ----------------------------------------------
+@pytest.mark.parametrize("seed,n", [(1, 300), (2, 600), (3, 120), (4, 1000), (5, 9), (6, 3)])
+def test_pose_optimization_matches_oracle(opt, oracle, seed, n):
+    c = synth.make_pose_case(seed, n)
+    ni, T, outl, info = opt.PoseOptimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
+    oni, oT, ooutl, oinfo = oracle.pose_optimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
+    assert info == oinfo  # same LM iterations and trials
+    assert np.abs(T - oT).max() <= 2e-5  # stated tolerance (FP64 both sides, different summation order / libm)
+    assert ni == oni and np.array_equal(outl, ooutl)
+    if n >= 100:
+        assert np.abs(T - c["gt_Tcw"]).max() < np.abs(c["Tcw"] - c["gt_Tcw"]).max()
+        assert (outl.astype(bool) & c["gt_outlier"]).sum() >= 0.9 * c["gt_outlier"].sum()
+
+
+def test_pose_optimization_too_few_points(opt):
+    c = synth.make_pose_case(9, 2)
+    ni, T, outl, info = opt.PoseOptimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
+    assert ni == 0 and np.array_equal(T, c["Tcw"]) and info["iterations"] == 0  # Optimizer.cc:344-345

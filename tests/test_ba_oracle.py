@@ -151,3 +151,33 @@ def test_stop_flag_semantics(oracle):
     assert r["info"]["aborted"] == 1 and r["info"]["lm_trials"] == 0
     assert np.abs(r["Xw"] - p["Xw"]).max() == 0 and r["outlier"].sum() == 0
     assert np.abs(r["Tcw"] - p["Tcw"]).max() < 1e-6  # only the quaternion round trip
+
+
+def test_pose_optimization_oracle(oracle):
+    """Motion-only BA: converges towards the generating pose, flags the gross outliers, and its minimum equals an
+    independent non-linear least-squares solve on the inlier set it reports."""
+    c = synth.make_pose_case(2, 400)
+    ni, T, outl, info = oracle.pose_optimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
+    assert ni == 400 - outl.sum()
+    assert np.abs(T - c["gt_Tcw"]).max() < 0.2 * np.abs(c["Tcw"] - c["gt_Tcw"]).max()
+    assert (outl.astype(bool) & c["gt_outlier"]).sum() >= 0.95 * c["gt_outlier"].sum()
+    assert info["iterations"] <= 40
+    n0, T0, _, _ = oracle.pose_optimization(c["Tcw"], c["intr"], c["Xw"][:2], c["obs"][:2], c["inv_sigma2"][:2])
+    assert n0 == 0 and np.array_equal(T0, c["Tcw"])
+    # independent check: Gauss-Newton minimum of the plain (non-robust) cost over the final inliers
+    lib = oracle.lib()
+    inl = outl == 0
+    X, O, W = c["Xw"][inl].astype(np.float64), c["obs"][inl].astype(np.float64), c["inv_sigma2"][inl].astype(np.float64)
+    fx, fy, cx, cy = [float(v) for v in c["intr"]]
+
+    def res(x):
+        q, t = np.zeros(4), np.zeros(3)
+        lib.orc_se3_from_Tcw(np.ascontiguousarray(T, np.float32).ctypes.data_as(C.c_void_p), _d(q), _d(t))
+        lib.orc_se3_exp_mul(_d(x), _d(q), _d(t))
+        Tm = _T_from(lib, q, t)
+        pc = X @ Tm[:, :3].T + Tm[:, 3]
+        r = np.stack([O[:, 0] - (fx * pc[:, 0] / pc[:, 2] + cx), O[:, 1] - (fy * pc[:, 1] / pc[:, 2] + cy)], 1)
+        return (r * np.sqrt(W)[:, None]).ravel()
+    sol = least_squares(res, np.zeros(6), method="lm", xtol=1e-14, ftol=1e-14)
+    # the last round (no robust kernel, inliers only) had up to 10 iterations: it sits at that minimum
+    assert np.linalg.norm(sol.x) < 2e-3
