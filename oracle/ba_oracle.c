@@ -6,6 +6,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -651,6 +652,7 @@ static int po_optimize(po_t* s, int iterations, int* its_done, int* trials) {
             for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
             scale += 1e-3;
             rho /= scale;
+            if (getenv("ORC_POSE_TRACE")) fprintf(stderr, "cpu trial %d lambda %.6e temp %.9e rho %.6e cur %.9e\n", *trials, lambda, tempChi, rho, currentChi);
             if (rho > 0 && isfinite(tempChi)) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
                 alpha = fmin(alpha, 2. / 3.);

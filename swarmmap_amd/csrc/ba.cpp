@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -669,7 +670,8 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     // device block: [inputs 24n | err 16n | pose 64 | info 16 | outlier n]
     const size_t off_err = ((size_t)n * 24 + 15) / 16 * 16, off_pose = off_err + (size_t)n * 16, off_info = off_pose + 64,
                  off_out = off_info + 16;
-    if ((rc = b->d_po.ensure(off_out + (size_t)n + 64))) return rc;
+    const size_t off_trace = (off_out + (size_t)n + 15) / 16 * 16;
+    if ((rc = b->d_po.ensure(off_trace + 256 * 32 + 64))) return rc;
     uint8_t* h = b->h_po;
     memcpy(h, Xw, (size_t)n * 12);
     memcpy(h + (size_t)n * 12, obs, (size_t)n * 8);
@@ -687,6 +689,7 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     a.pose_out = reinterpret_cast<BaPose*>(d + off_pose);
     a.info = reinterpret_cast<int*>(d + off_info);
     a.outlier = d + off_out;
+    a.trace = getenv("SWARMORB_POSE_TRACE") ? reinterpret_cast<double*>(d + off_trace) : nullptr;
     launch_pose_opt(a, s);
     SO_HIP(hipGetLastError());
     uint8_t* hout = h + in_bytes;
@@ -697,6 +700,12 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     int inf[4];
     memcpy(inf, hout + 64, 16);
     memcpy(outlier, hout + 80, (size_t)n);
+    if (a.trace) {  // debugging aid: dump the LM trial log
+        std::vector<double> tr(4 * 256);
+        SO_HIP(hipMemcpy(tr.data(), a.trace, sizeof(double) * tr.size(), hipMemcpyDeviceToHost));
+        for (int k = 0; k < inf[2] && k < 256; k++)
+            fprintf(stderr, "gpu trial %d lambda %.6e temp %.9e rho %.6e cur %.9e\n", k, tr[4 * k], tr[4 * k + 1], tr[4 * k + 2], tr[4 * k + 3]);
+    }
     pose_to_Tcw(P, Tcw_out12);  // Converter::toCvMat(SE3quat_recov)
     *n_inliers = n - inf[0];
     if (info) {

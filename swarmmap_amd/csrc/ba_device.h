@@ -81,6 +81,7 @@ struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.
     uint8_t* outlier;  // n (out)
     BaPose* pose_out;
     int* info;         // [0] nBad, [1] LM iterations, [2] LM trials
+    double* trace;     // optional: 4 doubles per LM trial (lambda, tempChi, rho, currentChi), 256 trials max
 };
 void launch_pose_opt(const PoseOptArgs& a, hipStream_t s);
 

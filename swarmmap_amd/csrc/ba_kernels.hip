@@ -950,6 +950,12 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(PoseOptArgs a) {
                     if (!s_ctrl[3]) tempChi = 1.7976931348623157e308;
                     if (tid == 0) {
                         double r = (s_lm[2] - tempChi) / s_lm[3];
+                        if (a.trace && trials_total < 256) {
+                            a.trace[4 * trials_total] = s_lm[0];
+                            a.trace[4 * trials_total + 1] = tempChi;
+                            a.trace[4 * trials_total + 2] = r;
+                            a.trace[4 * trials_total + 3] = s_lm[2];
+                        }
                         if (r > 0 && isfinite(tempChi)) {
                             double alpha = 1. - pow((2 * r - 1), 3);
                             alpha = fmin(alpha, 2. / 3.);
