@@ -69,6 +69,12 @@ void so_extractor_destroy(so_extractor* ex);
  * per-level quota by up to 3, code/src/ORBextractor.cc:656-661). */
 int so_extractor_capacity(const so_extractor* ex);
 
+/* DistributeOctTree (code/src/ORBextractor.cc:534-744) placement after the first frame sized the context:
+ * 1 = HIP kernel (one workgroup per level, whole tree in LDS; one host sync per frame), 0 = host tree
+ * (a level quota above 1020 keypoints or more than 4 root cells, or SWARMORB_HOST_QUADTREE set when the
+ * context was sized).  Both produce identical output. */
+int so_extractor_quadtree_on_device(const so_extractor* ex);
+
 /* ORBextractor::operator() (code/src/ORBextractor.cc:746-819): CV_8UC1 host image in, keypoints
  * (level-0 pixel units, levels concatenated 0..n-1) and 32-byte descriptors out.  An empty image
  * (NULL / w<=0 / h<=0) returns SO_OK with *n_out = 0 and outputs untouched. */

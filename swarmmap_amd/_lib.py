@@ -62,6 +62,7 @@ def load_library():
     lib.so_extractor_destroy.argtypes = [vp]
     lib.so_extractor_destroy.restype = None
     lib.so_extractor_capacity.argtypes = [vp]
+    lib.so_extractor_quadtree_on_device.argtypes = [vp]
     lib.so_extractor_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
     lib.so_extractor_run_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
     lib.so_extractor_tables.argtypes = [vp, vp, vp, vp, vp, vp]

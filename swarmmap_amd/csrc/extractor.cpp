@@ -9,6 +9,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -34,6 +35,18 @@ struct so_extractor {
     PyramidParams P{};
     std::vector<void*> dev_allocs;
     int32_t* d_rowcount = nullptr;
+    // device quadtree path (default): candidates never leave the GPU, one host sync per frame
+    bool device_qt = false;
+    bool cands_on_host = false;        // h_cands holds the last frame's candidates (debug API)
+    Candidate* d_cands = nullptr;
+    CandidateHeader* d_header = nullptr;
+    SelectedKp* d_qt_sel = nullptr;    // [nlevels][qt_stride]
+    int32_t* d_qt_count = nullptr;
+    int qt_stride = 0;
+    SelectedKp* h_meta = nullptr;      // host-mapped: (x, y, level, score) of every output keypoint
+    SelectedKp* h_meta_dev = nullptr;
+    int32_t* h_total = nullptr;        // host-mapped: number of output keypoints
+    int32_t* h_total_dev = nullptr;
     Candidate* h_cands = nullptr;      // host-mapped
     Candidate* h_cands_dev = nullptr;  // device view of h_cands
     CandidateHeader* h_header = nullptr;
@@ -154,6 +167,30 @@ int allocate(so_extractor* ex, int w, int h) {
     SO_HIP(hipHostGetDevicePointer((void**)&ex->h_sel_dev, ex->h_sel, 0));
     SO_HIP(hipHostMalloc((void**)&ex->h_desc, (size_t)ex->out_capacity * 36, hipHostMallocMapped));
     SO_HIP(hipHostGetDevicePointer((void**)&ex->h_desc_dev, ex->h_desc, 0));
+    // DistributeOctTree on the device needs the whole tree of a level in LDS: N <= 1020 nodes, <= 4 root nodes
+    ex->device_qt = getenv("SWARMORB_HOST_QUADTREE") == nullptr;
+    int max_n = 0;
+    for (int l = 0; l < P.nlevels; l++) {
+        max_n = std::max(max_n, ex->features_per_level[l]);
+        const LevelDesc& L = P.lv[l];
+        const int W = L.w - 2 * kFastBorder, H = L.h - 2 * kFastBorder;
+        if (L.ntx > 0 && (H <= 0 || (int)std::round((float)W / (float)H) > 4)) ex->device_qt = false;
+    }
+    if (max_n > 1020) ex->device_qt = false;
+    ex->qt_stride = max_n + 4;
+    rc = dev_alloc(ex, &ex->d_cands, sizeof(Candidate) * (size_t)ex->cand_capacity + 64, true);
+    if (rc) return rc;
+    rc = dev_alloc(ex, &ex->d_header, sizeof(CandidateHeader), true);
+    if (rc) return rc;
+    rc = dev_alloc(ex, &ex->d_qt_sel, sizeof(SelectedKp) * (size_t)ex->qt_stride * kMaxLevels, true);
+    if (rc) return rc;
+    rc = dev_alloc(ex, &ex->d_qt_count, sizeof(int32_t) * kMaxLevels, true);
+    if (rc) return rc;
+    SO_HIP(hipHostMalloc((void**)&ex->h_meta, sizeof(SelectedKp) * (size_t)ex->out_capacity, hipHostMallocMapped));
+    SO_HIP(hipHostGetDevicePointer((void**)&ex->h_meta_dev, ex->h_meta, 0));
+    SO_HIP(hipHostMalloc((void**)&ex->h_total, 64, hipHostMallocMapped));
+    SO_HIP(hipHostGetDevicePointer((void**)&ex->h_total_dev, ex->h_total, 0));
+    *ex->h_total = 0;
     SO_HIP(hipStreamSynchronize(ex->stream));
     ex->width = w;
     ex->height = h;
@@ -198,7 +235,60 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
         if (prof) SO_HIP(hipEventRecord(ex->ev[2], s));
         launch_fast_low_count(P, ex->d_rowcount, s);
         if (prof) SO_HIP(hipEventRecord(ex->ev[3], s));
-        launch_emit(P, ex->d_rowcount, ex->h_cands_dev, ex->h_header_dev, ex->cand_capacity, s);
+        if (ex->device_qt) {
+            // one-sync path: candidates -> device quadtree -> fused describe writing straight to host-mapped memory
+            launch_emit(P, ex->d_rowcount, ex->d_cands, ex->d_header, ex->h_header_dev, ex->cand_capacity, s);
+            if (prof) SO_HIP(hipEventRecord(ex->ev[4], s));
+            launch_quadtree(P, ex->features_per_level, ex->qt_stride, ex->d_cands, ex->d_header, ex->d_qt_sel,
+                            ex->d_qt_count, s);
+            if (prof) SO_HIP(hipEventRecord(ex->ev[5], s));
+            float* angle_dev = reinterpret_cast<float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);
+            launch_describe_qt(P, ex->d_qt_sel, ex->d_qt_count, ex->qt_stride, ex->out_capacity, ex->h_desc_dev,
+                               angle_dev, ex->h_meta_dev, ex->h_total_dev, s);
+            if (prof) SO_HIP(hipEventRecord(ex->ev[6], s));
+            SO_HIP(hipGetLastError());
+            const double t_enq = now_ms();
+            SO_HIP(hipStreamSynchronize(s));  // the only sync of the frame
+            const double t_synced = now_ms();
+            ex->cands_on_host = false;
+            const int n = std::min(*ex->h_total, ex->out_capacity);
+            memcpy(desc, ex->h_desc, (size_t)n * 32);
+            const float* angles = reinterpret_cast<const float*>(ex->h_desc + (size_t)ex->out_capacity * 32);
+            for (int i = 0; i < n; i++) {
+                const SelectedKp& sk = ex->h_meta[i];
+                so_keypoint& o = kps[i];
+                const int l = sk.level;
+                o.x = (float)sk.x;
+                o.y = (float)sk.y;
+                if (l != 0) {  // ORBextractor.cc:808-814
+                    o.x *= ex->scale[l];
+                    o.y *= ex->scale[l];
+                }
+                o.size = (float)(int)(31.0f * ex->scale[l]);
+                o.angle = angles[i];
+                o.response = (float)sk.score;
+                o.octave = l;
+                o.class_id = -1;
+            }
+            *n_out = n;
+            if (prof) {
+                float ms = 0.f;
+                for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) ex->prof_ms[i] = 0.f;
+                (void)hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1]); ex->prof_ms[0] = ms;
+                (void)hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2]); ex->prof_ms[1] = ms;
+                (void)hipEventElapsedTime(&ms, ex->ev[2], ex->ev[3]); ex->prof_ms[2] = ms;
+                (void)hipEventElapsedTime(&ms, ex->ev[3], ex->ev[4]); ex->prof_ms[3] = ms;
+                (void)hipEventElapsedTime(&ms, ex->ev[4], ex->ev[5]); ex->prof_ms[8] = ms;  // quadtree, on the GPU
+                (void)hipEventElapsedTime(&ms, ex->ev[5], ex->ev[6]); ex->prof_ms[4] = ms;
+                ex->prof_ms[6] = (float)(t_enq - t_begin);
+                ex->prof_ms[7] = (float)(t_synced - t_enq);
+                ex->prof_ms[10] = (float)(now_ms() - t_synced);
+                ex->prof_ms[5] = (float)(now_ms() - t_begin);
+            }
+            return SO_OK;
+        }
+        launch_emit(P, ex->d_rowcount, ex->h_cands_dev, ex->h_header_dev, nullptr, ex->cand_capacity, s);
+        ex->cands_on_host = true;
         if (prof) SO_HIP(hipEventRecord(ex->ev[4], s));
         SO_HIP(hipGetLastError());
         const double t_enq = now_ms();
@@ -228,7 +318,7 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
             ex->h_sel[n].x = (int16_t)(k.x + kFastBorder);  // addBorder_kernel, Fast_gpu.cu:461-470
             ex->h_sel[n].y = (int16_t)(k.y + kFastBorder);
             ex->h_sel[n].level = (uint16_t)l;
-            ex->h_sel[n].pad = 0;
+            ex->h_sel[n].score = k.score;
             ex->sel_cand.push_back(H.offset[l] + idx);
             n++;
         }
@@ -330,6 +420,8 @@ void so_extractor_destroy(so_extractor* ex) {
     if (ex->h_header) (void)hipHostFree(ex->h_header);
     if (ex->h_sel) (void)hipHostFree(ex->h_sel);
     if (ex->h_desc) (void)hipHostFree(ex->h_desc);
+    if (ex->h_meta) (void)hipHostFree(ex->h_meta);
+    if (ex->h_total) (void)hipHostFree(ex->h_total);
     for (auto& v : ex->ev)
         if (v) (void)hipEventDestroy(v);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
@@ -340,6 +432,8 @@ int so_extractor_capacity(const so_extractor* ex) {
     if (!ex) return 0;
     return ex->cfg.nfeatures + 3 * ex->cfg.nlevels;
 }
+
+int so_extractor_quadtree_on_device(const so_extractor* ex) { return (ex && ex->allocated && ex->device_qt) ? 1 : 0; }
 
 int so_extractor_run(so_extractor* ex, const uint8_t* image, int width, int height, int stride,
                      so_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out) {
@@ -389,6 +483,11 @@ int so_extractor_get_candidates(so_extractor* ex, int level, int16_t* xs, int16_
     const int n = H.count[level];
     *n_out = n;
     if (capacity < n) return SO_ERR_CAPACITY;
+    if (!ex->cands_on_host && H.total > 0) {  // device-quadtree path: fetch the candidates on demand
+        SO_HIP(hipSetDevice(ex->cfg.device));
+        SO_HIP(hipMemcpy(ex->h_cands, ex->d_cands, sizeof(Candidate) * (size_t)H.total, hipMemcpyDeviceToHost));
+        ex->cands_on_host = true;
+    }
     const Candidate* c = ex->h_cands + H.offset[level];
     for (int i = 0; i < n; i++) {
         if (xs) xs[i] = c[i].x;

@@ -61,15 +61,21 @@ struct CandidateHeader {  // written to host-mapped memory by the compaction ker
 struct SelectedKp {  // host -> device after the quadtree: level coordinates (ROI + 16)
     int16_t x, y;
     uint16_t level;
-    uint16_t pad;
+    uint16_t score;  // FAST response (integer valued)
 };
 
 // launchers (orb_kernels.hip)
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, hipStream_t s);
 void launch_fast_score(const PyramidParams& p, hipStream_t s);
 void launch_fast_low_count(const PyramidParams& p, int32_t* d_rowcount, hipStream_t s);
-void launch_emit(const PyramidParams& p, const int32_t* d_rowcount, Candidate* h_cands_mapped,
-                 CandidateHeader* h_header_mapped, int cand_capacity, hipStream_t s);
+// records go to `cands` (device memory for the device quadtree, or host-mapped memory for the host quadtree);
+// the header is written to both hdr_a and hdr_b (device copy + host-mapped copy; either may be null)
+void launch_emit(const PyramidParams& p, const int32_t* d_rowcount, Candidate* cands, CandidateHeader* hdr_a,
+                 CandidateHeader* hdr_b, int cand_capacity, hipStream_t s);
+void launch_quadtree(const PyramidParams& p, const int* n_target, int sel_stride, const Candidate* d_cands,
+                     const CandidateHeader* d_hdr, SelectedKp* d_sel, int32_t* d_count, hipStream_t s);
+void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, const int32_t* d_qt_count, int qt_stride,
+                        int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total, hipStream_t s);
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,
                      hipStream_t s);
 

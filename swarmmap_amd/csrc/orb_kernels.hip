@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void fast_low_count_kernel(PyramidParams P, in
 
 __global__ __launch_bounds__(256) void emit_kernel(PyramidParams P, const int32_t* __restrict__ rowcount,
                                                     Candidate* __restrict__ h_cands,
-                                                    CandidateHeader* __restrict__ h_header, int cand_capacity) {
+                                                    CandidateHeader* __restrict__ h_header,
+                                                    CandidateHeader* __restrict__ h_header2, int cand_capacity) {
     __shared__ int s_wave[4];
     __shared__ int s_lvl_start[kMaxLevels + 1];
     __shared__ int s_lvl_out[kMaxLevels + 1];
@@ -353,12 +354,16 @@ __global__ __launch_bounds__(256) void emit_kernel(PyramidParams P, const int32_
         }
         s_lvl_out[P.nlevels] = off;
         if (blockIdx.x == 0) {
-            for (int l = 0; l < kMaxLevels; l++) {
-                h_header->count[l] = l < P.nlevels ? min(s_lvl_start[l + 1] - s_lvl_start[l], kFastCap) : 0;
-                h_header->offset[l] = l < P.nlevels ? s_lvl_out[l] : off;
+            for (int which = 0; which < 2; which++) {
+                CandidateHeader* hd = which == 0 ? h_header : h_header2;
+                if (!hd) continue;
+                for (int l = 0; l < kMaxLevels; l++) {
+                    hd->count[l] = l < P.nlevels ? min(s_lvl_start[l + 1] - s_lvl_start[l], kFastCap) : 0;
+                    hd->offset[l] = l < P.nlevels ? s_lvl_out[l] : off;
+                }
+                hd->total = off;
+                hd->uncapped_total = total;
             }
-            h_header->total = off;
-            h_header->uncapped_total = total;
         }
     }
     __syncthreads();
@@ -414,9 +419,9 @@ void launch_fast_score(const PyramidParams& p, hipStream_t s) {
 void launch_fast_low_count(const PyramidParams& p, int32_t* d_rowcount, hipStream_t s) {
     hipLaunchKernelGGL(fast_low_count_kernel, dim3(p.total_rows / kTile), dim3(256), 0, s, p, d_rowcount);
 }
-void launch_emit(const PyramidParams& p, const int32_t* d_rowcount, Candidate* h_cands, CandidateHeader* h_header,
-                 int cand_capacity, hipStream_t s) {
-    hipLaunchKernelGGL(emit_kernel, dim3(p.total_rows / kTile), dim3(256), 0, s, p, d_rowcount, h_cands, h_header,
+void launch_emit(const PyramidParams& p, const int32_t* d_rowcount, Candidate* cands, CandidateHeader* hdr_a,
+                 CandidateHeader* hdr_b, int cand_capacity, hipStream_t s) {
+    hipLaunchKernelGGL(emit_kernel, dim3(p.total_rows / kTile), dim3(256), 0, s, p, d_rowcount, cands, hdr_a, hdr_b,
                        cand_capacity);
 }
 
@@ -487,15 +492,10 @@ __device__ __forceinline__ void det_sincosf(float a, float& sn, float& cs) {
 constexpr int kPatch = 43, kPatchPitch = 44;  // source patch
 constexpr int kBlur = 37, kBlurPitch = 40;    // blurred window
 
-__global__ __launch_bounds__(64) void describe_kernel(PyramidParams P, const SelectedKp* __restrict__ sel, int n,
-                                                       uint8_t* __restrict__ desc, float* __restrict__ angle_out) {
-    __shared__ uint8_t patch[kPatch * kPatchPitch];
-    __shared__ float rowp[kPatch * kBlur];
-    __shared__ uint8_t blur[kBlur * kBlurPitch];
-    const int id = blockIdx.x;
-    if (id >= n) return;
+__device__ __forceinline__ void describe_body(const PyramidParams& P, const SelectedKp kp, const int id,
+                                              uint8_t* __restrict__ desc, float* __restrict__ angle_out,
+                                              uint8_t* patch, float* rowp, uint8_t* blur) {
     const int lane = threadIdx.x;
-    const SelectedKp kp = sel[id];
     const LevelDesc& L = P.lv[kp.level];
     const int x = kp.x, y = kp.y;
 
@@ -565,6 +565,51 @@ __global__ __launch_bounds__(64) void describe_kernel(PyramidParams P, const Sel
         o[0] = words[0]; o[1] = words[1]; o[2] = words[2]; o[3] = words[3];
         angle_out[id] = kp_dir;
     }
+}
+
+__global__ __launch_bounds__(64) void describe_kernel(PyramidParams P, const SelectedKp* __restrict__ sel, int n,
+                                                       uint8_t* __restrict__ desc, float* __restrict__ angle_out) {
+    __shared__ uint8_t patch[kPatch * kPatchPitch];
+    __shared__ float rowp[kPatch * kBlur];
+    __shared__ uint8_t blur[kBlur * kBlurPitch];
+    const int id = blockIdx.x;
+    if (id >= n) return;
+    describe_body(P, sel[id], id, desc, angle_out, patch, rowp, blur);
+}
+
+// Same, fed by the device quadtree: block b finds its (level, k) from the per-level survivor counts, describes
+// qt_sel[level][k] and writes descriptor / angle / keypoint record at the compact output index, straight into
+// host-mapped memory.  Launched with the capacity as grid; surplus blocks exit.
+__global__ __launch_bounds__(64) void describe_qt_kernel(PyramidParams P, const SelectedKp* __restrict__ qt_sel,
+                                                          const int32_t* __restrict__ qt_count, int qt_stride,
+                                                          uint8_t* __restrict__ desc, float* __restrict__ angle_out,
+                                                          SelectedKp* __restrict__ meta_out,
+                                                          int32_t* __restrict__ total_out) {
+    __shared__ uint8_t patch[kPatch * kPatchPitch];
+    __shared__ float rowp[kPatch * kBlur];
+    __shared__ uint8_t blur[kBlur * kBlurPitch];
+    int id = blockIdx.x, lvl = -1, base = 0;
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; l++) {
+        const int c = l < P.nlevels ? qt_count[l] : 0;
+        if (lvl < 0 && id < base + c) lvl = l;
+        if (lvl < 0) base += c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int t = 0;
+        for (int l = 0; l < P.nlevels; l++) t += qt_count[l];
+        *total_out = t;
+    }
+    if (lvl < 0) return;
+    const SelectedKp kp = qt_sel[(size_t)lvl * qt_stride + (id - base)];
+    if (threadIdx.x == 0) meta_out[id] = kp;
+    describe_body(P, kp, id, desc, angle_out, patch, rowp, blur);
+}
+
+void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, const int32_t* d_qt_count, int qt_stride,
+                        int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total, hipStream_t s) {
+    hipLaunchKernelGGL(describe_qt_kernel, dim3(capacity), dim3(64), 0, s, p, d_qt_sel, d_qt_count, qt_stride, desc,
+                       angle, meta, total);
 }
 
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,

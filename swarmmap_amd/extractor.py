@@ -13,7 +13,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 
 STAGES = ("pyramid", "fast_score", "fast_low", "compact", "describe", "host_wall", "host_enqueue1", "host_wait1",
-          "host_quadtree", "host_phase2", "host_assemble")
+          "quadtree", "host_phase2", "host_assemble")
 
 
 def _vp(a):
@@ -32,6 +32,11 @@ class ORBextractor:
         self._cap = int(self._lib.so_extractor_capacity(self._h))
         self._kps = np.zeros(self._cap, KP_DTYPE)
         self._desc = np.zeros((self._cap, 32), np.uint8)
+
+    @property
+    def quadtree_on_device(self):
+        """True once a frame has sized the context and DistributeOctTree runs as a HIP kernel."""
+        return bool(self._lib.so_extractor_quadtree_on_device(self._h))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -17,9 +17,10 @@ def S():
     return swarmmap_amd
 
 
-def _compare(S, oracle, img, nfeatures, ini=20, mn=7, nlevels=8):
+def _compare(S, oracle, img, nfeatures, ini=20, mn=7, nlevels=8, device_qt=True):
     ex = S.ORBextractor(nfeatures, 1.2, nlevels, ini, mn)
     kps, desc = ex(img)
+    assert ex.quadtree_on_device == device_qt
     cfg = oracle.config(nfeatures, 1.2, nlevels, ini, mn)
     okps, odesc, ocands, olevels = oracle.extract(cfg, img, debug=True)
     for l in range(nlevels):
@@ -79,6 +80,15 @@ def test_half_textured_image_mixes_tile_thresholds(S, oracle):
     soft = np.clip(110 + (img.astype(np.float32) - 110) * 0.15, 0, 255).astype(np.uint8)
     img[:, 376:] = soft[:, 376:]
     _compare(S, oracle, img, 1000)
+
+
+def test_host_quadtree_paths_agree(S, oracle, monkeypatch):
+    """The host tree serves quotas / aspect ratios the LDS tree does not hold; same output either way."""
+    from swarmmap_amd import synth
+    _compare(S, oracle, synth.make_image(31, synth.KITTI), 6000, device_qt=False)   # level-0 quota 1302 > 1020
+    _compare(S, oracle, synth.make_canvas(32, 1000, 200), 800, device_qt=False)     # 6 root cells
+    monkeypatch.setenv("SWARMORB_HOST_QUADTREE", "1")
+    _compare(S, oracle, synth.make_image(2, synth.EUROC), 1000, device_qt=False)
 
 
 def test_flat_image_no_keypoints(S, oracle):
