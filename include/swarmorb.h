@@ -240,6 +240,11 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
 /* HIP-event time (ms) of the kernels of the last matcher call on the matcher's stream. */
 int so_matcher_last_kernel_ms(so_matcher* m, float* ms);
 
+/* Host-side view of the last matcher call: stats4[0] = ms spent enqueueing (staging copy + launch), [1] = ms
+ * blocked in stream syncs, [2] = kernel launches (1 + exact re-runs of single queries), [3] = bytes staged
+ * host -> device. */
+int so_matcher_last_stats(so_matcher* m, double* stats4);
+
 /* ------------------------------------------------------------------------------------------------
  * Bundle adjustment — replaces Optimizer::LocalBundleAdjustment / BundleAdjustment / GlobalBundleAdjustment
  * (code/include/Optimizer.h:41-46, code/src/Optimizer.cc:42-237,436-740) and the g2o machinery they drive

@@ -7,6 +7,8 @@
 //   re-evaluated on the GPU with the current "taken" gate, so distances never come from the CPU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -55,12 +57,53 @@ struct PinBuf {
         cap = want;
         return SO_OK;
     }
+    // grow, keeping the first `keep` bytes
+    int ensure_keep(size_t bytes, size_t keep) {
+        if (bytes <= cap) return SO_OK;
+        void* np_ = nullptr;
+        const size_t want = bytes + bytes / 2 + 256;
+        SO_HIP(hipHostMalloc(&np_, want, hipHostMallocDefault));
+        if (p && keep) memcpy(np_, p, keep < cap ? keep : cap);
+        if (p) SO_HIP(hipHostFree(p));
+        p = np_;
+        cap = want;
+        return SO_OK;
+    }
     void release() {
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
     }
 };
+
+// Host memory the kernel writes directly (results are small and read once by the host).
+struct MappedBuf {
+    void* p = nullptr;
+    void* dev = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SO_OK;
+        if (p) SO_HIP(hipHostFree(p));
+        p = dev = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 2 + 256;
+        SO_HIP(hipHostMalloc(&p, want, hipHostMallocMapped));
+        SO_HIP(hipHostGetDevicePointer(&dev, p, 0));
+        cap = want;
+        return SO_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = dev = nullptr;
+        cap = 0;
+    }
+};
+
+struct View {
+    void* p = nullptr;
+};
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
 
@@ -69,9 +112,21 @@ struct so_matcher {
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float last_ms = 0.f;
+    bool profile = true;  // event-timed kernels (so_matcher_last_kernel_ms)
+    // host view of the last call: [0] ms enqueueing copies + launches, [1] ms blocked in stream syncs,
+    // [2] kernel launches (1 + exact re-runs), [3] bytes staged host -> device
+    double stat[4] = {0, 0, 0, 0};
 
-    DevBuf d_xy, d_oct, d_desc, d_limit, d_q, d_qdesc, d_keys, d_count, d_A, d_B, d_res;
-    PinBuf h_xy, h_oct, h_desc, h_limit, h_q, h_qdesc, h_keys, h_count, h_res;
+    // One pinned staging buffer and its device twin per call: [xy | octave | desc | limit | queries | qdesc],
+    // moved with a single H2D copy; the K-lists come back through host-mapped memory the kernel writes.
+    PinBuf h_in;
+    DevBuf d_in;
+    MappedBuf h_out;
+    size_t off_oct = 0, off_desc = 0, off_limit = 0, frame_end = 0, off_q = 0, off_qdesc = 0;
+    size_t dirty_from = SIZE_MAX;  // staging bytes from here on are newer than the device copy
+    View h_q, h_qdesc, h_keys, h_count;
+    DevBuf d_A, d_B, d_res;
+    PinBuf h_res;
 
     float inv_sigma2[8] = {0}, sigma2[8] = {0}, scale[8] = {0}, ex = 0.f, ey = 0.f;  // gates of the current candidates
     int n_cand = 0;           // keypoints that are inside the grid (PosInGrid true)
@@ -104,39 +159,32 @@ int upload_ordered(so_matcher* m, int n, const float* x, const float* y, const i
     const bool want_limit = (excluded != nullptr) || (limit_by_idx != nullptr);
     m->has_limit = want_limit;
     int rc;
-    if ((rc = m->h_xy.ensure(sizeof(float2) * (size_t)nc + 16))) return rc;
-    if ((rc = m->h_oct.ensure((size_t)nc + 16))) return rc;
-    if ((rc = m->h_desc.ensure((size_t)nc * 32 + 16))) return rc;
-    if ((rc = m->d_xy.ensure(sizeof(float2) * (size_t)nc + 16))) return rc;
-    if ((rc = m->d_oct.ensure((size_t)nc + 16))) return rc;
-    if ((rc = m->d_desc.ensure((size_t)nc * 32 + 16))) return rc;
-    float2* hxy = (float2*)m->h_xy.p;
-    int8_t* hoct = (int8_t*)m->h_oct.p;
-    uint8_t* hdesc = (uint8_t*)m->h_desc.p;
+    m->off_oct = align256(sizeof(float2) * (size_t)nc);
+    m->off_desc = align256(m->off_oct + (size_t)nc);
+    m->off_limit = align256(m->off_desc + (size_t)nc * 32);
+    m->frame_end = align256(m->off_limit + sizeof(int32_t) * (size_t)nc);
+    if ((rc = m->h_in.ensure_keep(m->frame_end + 256, 0))) return rc;
+    uint8_t* base = (uint8_t*)m->h_in.p;
+    float2* hxy = (float2*)base;
+    int8_t* hoct = (int8_t*)(base + m->off_oct);
+    uint8_t* hdesc = base + m->off_desc;
     for (int r = 0; r < nc; r++) {
         const int i = m->perm[(size_t)r];
         hxy[r] = make_float2(x ? x[i] : 0.f, y ? y[i] : 0.f);
         hoct[r] = (int8_t)(octave ? octave[i] : 0);
         memcpy(hdesc + (size_t)r * 32, desc + (size_t)i * 32, 32);
     }
-    if (nc > 0) {
-        SO_HIP(hipMemcpyAsync(m->d_xy.p, hxy, sizeof(float2) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
-        SO_HIP(hipMemcpyAsync(m->d_oct.p, hoct, (size_t)nc, hipMemcpyHostToDevice, m->stream));
-        SO_HIP(hipMemcpyAsync(m->d_desc.p, hdesc, (size_t)nc * 32, hipMemcpyHostToDevice, m->stream));
-    }
     if (want_limit) {
-        if ((rc = m->h_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
-        if ((rc = m->d_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
-        int32_t* hl = (int32_t*)m->h_limit.p;
+        int32_t* hl = (int32_t*)(base + m->off_limit);
         for (int r = 0; r < nc; r++) {
             const int i = m->perm[(size_t)r];
             int32_t lim = limit_by_idx ? limit_by_idx[i] : INT_MAX;
             if (excluded && excluded[i]) lim = 0;
             hl[r] = lim;
         }
-        if (nc > 0)
-            SO_HIP(hipMemcpyAsync(m->d_limit.p, hl, sizeof(int32_t) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
     }
+    m->dirty_from = 0;
+    m->h_q.p = m->h_qdesc.p = nullptr;
     return SO_OK;
 }
 
@@ -172,23 +220,20 @@ inline void init_query(MatchQuery& q) {
 
 int upload_limit_only(so_matcher* m, const std::vector<int32_t>& limit_by_idx) {
     const int nc = m->n_cand;
-    int rc;
-    if ((rc = m->h_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
-    if ((rc = m->d_limit.ensure(sizeof(int32_t) * (size_t)nc + 16))) return rc;
-    int32_t* hl = (int32_t*)m->h_limit.p;
+    int32_t* hl = (int32_t*)((uint8_t*)m->h_in.p + m->off_limit);
     for (int r = 0; r < nc; r++) hl[r] = limit_by_idx[(size_t)m->perm[(size_t)r]];
-    if (nc > 0)
-        SO_HIP(hipMemcpyAsync(m->d_limit.p, hl, sizeof(int32_t) * (size_t)nc, hipMemcpyHostToDevice, m->stream));
+    m->dirty_from = std::min(m->dirty_from, m->off_limit);
     m->has_limit = true;
     return SO_OK;
 }
 
 MatchFrameDev frame_dev(const so_matcher* m) {
     MatchFrameDev F;
-    F.xy = (const float2*)m->d_xy.p;
-    F.octave = (const int8_t*)m->d_oct.p;
-    F.desc = (const uint4*)m->d_desc.p;
-    F.limit = m->has_limit ? (const int32_t*)m->d_limit.p : nullptr;
+    const uint8_t* base = (const uint8_t*)m->d_in.p;
+    F.xy = (const float2*)base;
+    F.octave = (const int8_t*)(base + m->off_oct);
+    F.desc = (const uint4*)(base + m->off_desc);
+    F.limit = m->has_limit ? (const int32_t*)(base + m->off_limit) : nullptr;
     F.n = m->n_cand;
     for (int l = 0; l < 8; l++) {
         F.inv_sigma2[l] = m->inv_sigma2[l];
@@ -200,36 +245,53 @@ MatchFrameDev frame_dev(const so_matcher* m) {
     return F;
 }
 
-// queries must already be in m->h_q / m->h_qdesc (pinned).  Results land in m->h_keys / m->h_count.
+// queries must already be in m->h_q / m->h_qdesc (ensure_queries).  Results land in m->h_keys / m->h_count.
 int run_topk(so_matcher* m, int nq, int K) {
     if (nq <= 0) return SO_OK;
     int rc;
-    if ((rc = m->d_q.ensure(sizeof(MatchQuery) * (size_t)nq))) return rc;
-    if ((rc = m->d_qdesc.ensure((size_t)nq * 32))) return rc;
-    if ((rc = m->d_keys.ensure(sizeof(uint32_t) * (size_t)nq * K))) return rc;
-    if ((rc = m->d_count.ensure(sizeof(int32_t) * (size_t)nq))) return rc;
-    if ((rc = m->h_keys.ensure(sizeof(uint32_t) * (size_t)nq * K))) return rc;
-    if ((rc = m->h_count.ensure(sizeof(int32_t) * (size_t)nq))) return rc;
+    const size_t total = m->off_qdesc + (size_t)nq * 32;
+    if (m->d_in.cap < total) {
+        if ((rc = m->d_in.ensure(m->h_in.cap))) return rc;
+        m->dirty_from = 0;
+    }
+    const size_t keys_bytes = align256(sizeof(uint32_t) * (size_t)nq * K);
+    if ((rc = m->h_out.ensure(keys_bytes + sizeof(int32_t) * (size_t)nq))) return rc;
     hipStream_t s = m->stream;
-    SO_HIP(hipMemcpyAsync(m->d_q.p, m->h_q.p, sizeof(MatchQuery) * (size_t)nq, hipMemcpyHostToDevice, s));
-    SO_HIP(hipMemcpyAsync(m->d_qdesc.p, m->h_qdesc.p, (size_t)nq * 32, hipMemcpyHostToDevice, s));
-    SO_HIP(hipEventRecord(m->e0, s));
-    launch_topk_window(frame_dev(m), (const MatchQuery*)m->d_q.p, (const uint4*)m->d_qdesc.p, nq, K,
-                       (uint32_t*)m->d_keys.p, (int32_t*)m->d_count.p, s);
-    SO_HIP(hipEventRecord(m->e1, s));
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t from = std::min(m->dirty_from, m->off_q);
+    SO_HIP(hipMemcpyAsync((uint8_t*)m->d_in.p + from, (const uint8_t*)m->h_in.p + from, total - from,
+                          hipMemcpyHostToDevice, s));
+    m->dirty_from = SIZE_MAX;
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_topk_window(frame_dev(m), (const MatchQuery*)((const uint8_t*)m->d_in.p + m->off_q),
+                       (const uint4*)((const uint8_t*)m->d_in.p + m->off_qdesc), nq, K, (uint32_t*)m->h_out.dev,
+                       (int32_t*)((uint8_t*)m->h_out.dev + keys_bytes), s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
     SO_HIP(hipGetLastError());
-    SO_HIP(hipMemcpyAsync(m->h_keys.p, m->d_keys.p, sizeof(uint32_t) * (size_t)nq * K, hipMemcpyDeviceToHost, s));
-    SO_HIP(hipMemcpyAsync(m->h_count.p, m->d_count.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, s));
+    const auto t1 = std::chrono::steady_clock::now();
     SO_HIP(hipStreamSynchronize(s));
+    const auto t2 = std::chrono::steady_clock::now();
+    m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    m->stat[2] += 1.0;
+    m->stat[3] += (double)(total - from);
+    m->h_keys.p = m->h_out.p;
+    m->h_count.p = (uint8_t*)m->h_out.p + keys_bytes;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
     return SO_OK;
 }
 
+// Reserve the query part of the staging buffer behind the frame part (which is kept).
 int ensure_queries(so_matcher* m, int nq) {
-    int rc;
-    if ((rc = m->h_q.ensure(sizeof(MatchQuery) * (size_t)(nq > 0 ? nq : 1)))) return rc;
-    return m->h_qdesc.ensure((size_t)(nq > 0 ? nq : 1) * 32);
+    const size_t n = (size_t)(nq > 0 ? nq : 1);
+    m->off_q = m->frame_end;
+    m->off_qdesc = align256(m->off_q + sizeof(MatchQuery) * n);
+    int rc = m->h_in.ensure_keep(m->off_qdesc + n * 32 + 256, m->frame_end);
+    if (rc) return rc;
+    m->h_q.p = (uint8_t*)m->h_in.p + m->off_q;
+    m->h_qdesc.p = (uint8_t*)m->h_in.p + m->off_qdesc;
+    return SO_OK;
 }
 
 struct Entry {
@@ -323,12 +385,9 @@ void so_matcher_destroy(so_matcher* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    for (DevBuf* b : {&m->d_xy, &m->d_oct, &m->d_desc, &m->d_limit, &m->d_q, &m->d_qdesc, &m->d_keys, &m->d_count,
-                      &m->d_A, &m->d_B, &m->d_res})
-        b->release();
-    for (PinBuf* b : {&m->h_xy, &m->h_oct, &m->h_desc, &m->h_limit, &m->h_q, &m->h_qdesc, &m->h_keys, &m->h_count,
-                      &m->h_res})
-        b->release();
+    for (DevBuf* b : {&m->d_in, &m->d_A, &m->d_B, &m->d_res}) b->release();
+    for (PinBuf* b : {&m->h_in, &m->h_res}) b->release();
+    m->h_out.release();
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -341,6 +400,12 @@ int so_matcher_last_kernel_ms(so_matcher* m, float* ms) {
     return SO_OK;
 }
 
+int so_matcher_last_stats(so_matcher* m, double* stats4) {
+    if (!m || !stats4) return SO_ERR_INVALID_ARG;
+    for (int i = 0; i < 4; i++) stats4[i] = m->stat[i];
+    return SO_OK;
+}
+
 int so_matcher_topk(so_matcher* m, const so_frame_view* F, const int32_t* limit, int32_t nq, const float* u,
                     const float* v, const float* r, const int32_t* min_level, const int32_t* max_level,
                     const uint8_t* active, const uint8_t* qdesc, int32_t K, int32_t* out_idx, int32_t* out_dist,
@@ -350,6 +415,7 @@ int so_matcher_topk(so_matcher* m, const so_frame_view* F, const int32_t* limit,
         return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     int rc = upload_frame(m, F, limit);
     if (rc) return rc;
     if ((rc = ensure_queries(m, nq))) return rc;
@@ -393,6 +459,7 @@ int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int
         return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     *nmatches = 0;
     for (int k = 0; k < F->n; k++) kp_to_mp[k] = -1;
     if (n_mp == 0 || F->n == 0) return SO_OK;
@@ -468,10 +535,11 @@ int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, i
     if (check_orientation && n_last > 0 && (!last_angle || !cur->angle)) return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     *nmatches = 0;
     for (int k = 0; k < cur->n; k++) kp_to_last[k] = -1;
     if (n_last == 0 || cur->n == 0) return SO_OK;
-    constexpr int K = 4;
+    constexpr int K = 8;  // deep enough that a list exhausted by already-bound keypoints (exact re-run) is rare
     int rc = upload_frame(m, cur, nullptr);
     if (rc) return rc;
     if ((rc = ensure_queries(m, n_last))) return rc;
@@ -550,6 +618,7 @@ int so_search_for_initialization(so_matcher* m, const so_frame_view* F1, const s
     if (check_orientation && ((F1->n > 0 && !F1->angle) || (F2->n > 0 && !F2->angle))) return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     *nmatches = 0;
     const int n1 = F1->n, n2 = F2->n;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
@@ -769,6 +838,7 @@ int so_search_by_bow(so_matcher* m, int variant, int32_t n1, const uint8_t* desc
     if (!featvec_ok(fv1, n1) || !featvec_ok(fv2, n2)) return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     *nmatches = 0;
     std::vector<int32_t> m2((size_t)n2, -1), m1((size_t)n1, -1);
     auto finish = [&]() {
@@ -894,6 +964,7 @@ int so_search_for_triangulation(so_matcher* m, int32_t n1, const float* x1, cons
     if (!featvec_ok(fv1, n1) || !featvec_ok(fv2, n2)) return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     *nmatches = 0;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     const NodeJoin J = join_nodes(fv1, fv2);
@@ -968,6 +1039,7 @@ int so_search_window_best(so_matcher* m, const so_frame_view* KF, int32_t nq, co
     if (chi2_gate && (!inv_sigma2 || KF->nlevels > 8)) return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     for (int i = 0; i < nq; i++) {
         best_idx[i] = -1;
         best_dist[i] = 256;
@@ -1012,6 +1084,7 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
     if (check_orientation && nq > 0 && (!q_angle || !F->angle)) return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     *nmatches = 0;
     for (int k = 0; k < F->n; k++) kp_to_query[k] = -1;
     if (nq == 0 || F->n == 0) return SO_OK;

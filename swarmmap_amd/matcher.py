@@ -60,6 +60,7 @@ def _bind(lib):
     lib.so_hamming_top2.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, vp, vp]
     lib.so_hamming_top2_device.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, vp, vp]
     lib.so_matcher_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.so_matcher_last_stats.argtypes = [vp, C.POINTER(C.c_double)]
 
 
 class ORBmatcher:
@@ -92,6 +93,11 @@ class ORBmatcher:
         return ms.value
 
     # SearchByProjection(Frame&, const vector<MapPoint*>&, th) — ORBmatcher.cc:44-121
+    def last_stats(self):
+        st = (C.c_double * 4)()
+        _lib.check(self._lib.so_matcher_last_stats(self._h, st))
+        return dict(enqueue_ms=st[0], wait_ms=st[1], launches=int(st[2]), staged_bytes=int(st[3]))
+
     def SearchByProjectionMapPoints(self, F, mps, th=1.0):
         n_mp = len(mps["proj_x"])
         a = {k: np.ascontiguousarray(mps[k], t) for k, t in
