@@ -244,7 +244,7 @@ def main():
         solve_flop = n_red ** 3 / 3.0 + 2.0 * n_red ** 2
         solve_ms = acc["solve_ms"] / max(acc["n_solves"], 1)
         solve_tf = solve_flop / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0
-        roof_solve = {"bound": "mfma", "kernel": "ba_solve_blocked_kernel", "achieved": solve_tf, "peak": FP64_PEAK_TF,
+        roof_solve = {"bound": "mfma", "kernel": "ba_solve_reg_kernel", "achieved": solve_tf, "peak": FP64_PEAK_TF,
                       "unit": "TFLOP/s", "frac": solve_tf / FP64_PEAK_TF, "traffic": None,
                       "algorithmic_flop_per_launch": solve_flop, "avg_launch_ms": solve_ms,
                       "total_ms_in_timed_region": acc["solve_ms"],

@@ -105,21 +105,26 @@ void pose_to_Tcw(const BaPose& P, float* T) {  // to_homogeneous_matrix cast to 
 struct so_ba {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    static constexpr int kSolveEvents = 32;  // the first trials of a call are event-timed around the solve kernel
+    hipEvent_t ev_solve[2 * kSolveEvents] = {nullptr};
     float solve_ms = 0.f;
     int n_solves = 0;
+    BaLm* h_lm = nullptr;        // host-mapped copy of the LM state, written by the decision kernels
+    BaLm* h_lm_dev = nullptr;
+    uint8_t* h_abort = nullptr;  // host-mapped forceStopFlag the decision kernel polls
+    uint8_t* h_abort_dev = nullptr;
 
     Buf d_pose[2], d_pt[2], d_intr, d_epose, d_ept, d_obs, d_w, d_active, d_err, d_chi2, d_ptoff, d_ptact, d_hidx,
         d_freepose, d_poseoff, d_poseedges, d_blkoff, d_blki1, d_blki2, d_pk1, d_pk2, d_Hpp, d_bp, d_Hll, d_bl, d_W,
-        d_Dinv, d_db, d_BDinv, d_S, d_bs, d_xl, d_partial, d_depth, d_po;
-    double* h_partial = nullptr;  // pinned
+        d_Dinv, d_db, d_BDinv, d_S, d_bs, d_xl, d_partial, d_depth, d_po, d_lm;
     uint8_t* h_po = nullptr;      // pinned staging for PoseOptimization
     size_t h_po_cap = 0;
     std::vector<Buf*> all() {
         return {&d_pose[0], &d_pose[1], &d_pt[0], &d_pt[1], &d_intr, &d_epose, &d_ept, &d_obs, &d_w, &d_active, &d_err,
                 &d_chi2, &d_ptoff, &d_ptact, &d_hidx, &d_freepose, &d_poseoff, &d_poseedges, &d_blkoff, &d_blki1,
                 &d_blki2, &d_pk1, &d_pk2, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv, &d_db, &d_BDinv, &d_S, &d_bs,
-                &d_xl, &d_partial, &d_depth, &d_po};
+                &d_xl, &d_partial, &d_depth, &d_po, &d_lm};
     }
 };
 
@@ -240,14 +245,10 @@ struct Run {
     BaDev d{};
     Problem P;
     Stage S;
-    int cur = 0;  // index of the "current" estimate buffers
     int nb_err = 1, nb_upd = 1;
-    double lambda = -1.0, ni = 2.0;
-    int nBad = 0, trials = 0;
+    int blocks_enqueued = 0;  // trial blocks of this call so far (indexes the solve-event pool)
     const volatile uint8_t* stop = nullptr;
     bool terminate() const { return stop && *stop; }
-    BaPose* poses(int which) { return b->d_pose[which].as<BaPose>(); }
-    double* points(int which) { return b->d_pt[which].as<double>(); }
 };
 
 int upload_stage(Run& r) {
@@ -288,99 +289,63 @@ int upload_stage(Run& r) {
     return SO_OK;
 }
 
-int fetch_partials(Run& r) {
-    SO_HIP(hipMemcpyAsync(r.b->h_partial, r.b->d_partial.p, sizeof(double) * kBaPartialCount, hipMemcpyDeviceToHost,
-                          r.b->stream));
-    SO_HIP(hipStreamSynchronize(r.b->stream));
-    return SO_OK;
+// Wait for the stream; with a forceStopFlag, poll it meanwhile and forward it to the device.
+int wait_stream(Run& r) {
+    hipStream_t s = r.b->stream;
+    if (!r.stop) {
+        SO_HIP(hipStreamSynchronize(s));
+        return SO_OK;
+    }
+    for (;;) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return SO_OK;
+        if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+        if (*r.stop) *r.b->h_abort = 1;
+    }
 }
 
-double sum_partials(const double* p, int n) {
-    double t = 0.0;
-    for (int i = 0; i < n; i++) t += p[i];
-    return t;
-}
-
-// SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve
+// SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg, driven from the device: the host
+// enqueues the prologue (errors, linearisation, lambda init) and `iterations` trials, waits once and only
+// enqueues more if trials were rejected (each rejected trial needs one more than the iteration count).
 int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
     so_ba* b = r.b;
     hipStream_t s = b->stream;
     *done_out = 0;
     if (r.S.n_free + (r.S.n_active_edges > 0 ? 1 : 0) == 0) return SO_OK;  // 0 vertices to optimize
-    int rc;
-    bool ok = true, errors_fresh = false;
-    double carried_chi = 0.0;
-    for (int it = 0; it < iterations && !r.terminate() && ok; it++) {
-        double currentChi;
-        if (!errors_fresh) {
-            launch_ba_errors(r.d, r.poses(r.cur), r.points(r.cur), r.nb_err, s);
+    launch_ba_errors(r.d, 0, false, r.nb_err, s);
+    launch_ba_build(r.d, false, s);
+    launch_ba_maxdiag(r.d, s);
+    launch_ba_stage_begin(r.d, r.nb_err, iterations, b->h_lm_dev, s);
+    SO_HIP(hipGetLastError());
+    const int trials_before = b->h_lm->trials, first_block = r.blocks_enqueued;  // h_lm: state after the last wait
+    int budget = iterations, rc;
+    for (;;) {
+        for (int i = 0; i < budget; i++) {
+            const int k = r.blocks_enqueued++;
+            const bool timed = k < so_ba::kSolveEvents;
+            launch_ba_trial(r.d, b->d_blki1.as<int>(), b->d_blki2.as<int>(), r.S.n_blk, r.nb_err, r.nb_upd,
+                            r.stop ? b->h_abort_dev : nullptr, b->h_lm_dev, timed ? b->ev_solve[2 * k] : nullptr,
+                            timed ? b->ev_solve[2 * k + 1] : nullptr, s);
         }
-        launch_ba_build(r.d, r.poses(r.cur), r.points(r.cur), s);
-        if (it == 0) launch_ba_maxdiag(r.d, s);
         SO_HIP(hipGetLastError());
-        if (!errors_fresh || it == 0) {
-            if ((rc = fetch_partials(r))) return rc;
-            if (!errors_fresh) carried_chi = sum_partials(b->h_partial + kBaPartialChi, r.nb_err);
-        }
-        currentChi = carried_chi;
-        double tempChi = currentChi;
-        const double iniChi = currentChi;
-        if (it == 0) {  // computeLambdaInit
-            r.lambda = 1e-5 * b->h_partial[kBaMaxDiag];
-            r.ni = 2;
-            r.nBad = 0;
-        }
-        double rho = 0;
-        int qmax = 0;
-        do {
-            const int trial = r.cur ^ 1;
-            launch_ba_schur(r.d, r.lambda, b->d_blki1.as<int>(), b->d_blki2.as<int>(), r.S.n_blk, s);
-            SO_HIP(hipEventRecord(b->e2, s));
-            launch_ba_solve(r.d, s);
-            SO_HIP(hipEventRecord(b->e3, s));
-            launch_ba_update(r.d, r.lambda, r.poses(r.cur), r.points(r.cur), r.poses(trial), r.points(trial), r.nb_upd, s);
-            launch_ba_errors(r.d, r.poses(trial), r.points(trial), r.nb_err, s);
-            SO_HIP(hipGetLastError());
-            if ((rc = fetch_partials(r))) return rc;
-            {
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, b->e2, b->e3) == hipSuccess) b->solve_ms += ms;
-                b->n_solves++;
-            }
-            const bool ok2 = b->h_partial[kBaSolveOk] != 0.0;
-            tempChi = sum_partials(b->h_partial + kBaPartialChi, r.nb_err);
-            if (!ok2) tempChi = DBL_MAX;
-            rho = currentChi - tempChi;
-            double scale = sum_partials(b->h_partial + kBaPartialScale, r.nb_upd);
-            scale += 1e-3;
-            rho /= scale;
-            if (rho > 0 && std::isfinite(tempChi)) {
-                double alpha = 1. - std::pow((2 * rho - 1), 3);
-                alpha = std::min(alpha, 2. / 3.);
-                const double scaleFactor = std::max(1. / 3., alpha);
-                r.lambda *= scaleFactor;
-                r.ni = 2;
-                currentChi = tempChi;
-                r.cur = trial;  // discardTop: the trial becomes the estimate
-                errors_fresh = true;
-                carried_chi = tempChi;
-            } else {
-                r.lambda *= r.ni;
-                r.ni *= 2;
-                errors_fresh = false;  // pop: stored errors now describe the rejected trial
-            }
-            qmax++;
-            r.trials++;
-        } while (rho < 0 && qmax < 10 && !r.terminate());
-        (*done_out)++;
-        *chi_out = errors_fresh ? carried_chi : tempChi;
-        if (qmax == 10 || rho == 0) {
-            ok = false;
-            continue;
-        }
-        if ((iniChi - currentChi) * 1e3 < iniChi) r.nBad++; else r.nBad = 0;
-        if (r.nBad >= 3) ok = false;
+        if ((rc = wait_stream(r))) return rc;
+        BaLm lm;
+        memcpy(&lm, b->h_lm, sizeof(lm));
+        if (!lm.active) break;
+        budget = std::max(1, lm.iterations - lm.it);
     }
+    BaLm lm;
+    memcpy(&lm, b->h_lm, sizeof(lm));
+    const int real = lm.trials - trials_before;  // the first `real` blocks of this stage ran, the rest returned at once
+    for (int k = first_block; k < first_block + real && k < so_ba::kSolveEvents; k++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, b->ev_solve[2 * k], b->ev_solve[2 * k + 1]) == hipSuccess) {
+            b->solve_ms += ms;
+            b->n_solves++;
+        }
+    }
+    *done_out = lm.done;
+    *chi_out = lm.chi_out;
     return SO_OK;
 }
 
@@ -402,9 +367,12 @@ int so_ba_create(int device, so_ba** out) {
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&b->e0);
     if (e == hipSuccess) e = hipEventCreate(&b->e1);
-    if (e == hipSuccess) e = hipEventCreate(&b->e2);
-    if (e == hipSuccess) e = hipEventCreate(&b->e3);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_partial, sizeof(double) * kBaPartialCount, hipHostMallocDefault);
+    for (hipEvent_t& ev : b->ev_solve)
+        if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_lm, sizeof(BaLm), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&b->h_lm_dev, b->h_lm, 0);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_abort, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&b->h_abort_dev, b->h_abort, 0);
     if (e != hipSuccess) {
         delete b;
         return hip_fail(e, "ba init", __FILE__, __LINE__);
@@ -418,12 +386,13 @@ void so_ba_destroy(so_ba* b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (Buf* q : b->all()) q->release();
-    if (b->h_partial) (void)hipHostFree(b->h_partial);
+    if (b->h_lm) (void)hipHostFree(b->h_lm);
+    if (b->h_abort) (void)hipHostFree(b->h_abort);
+    for (hipEvent_t ev : b->ev_solve)
+        if (ev) (void)hipEventDestroy(ev);
     if (b->h_po) (void)hipHostFree(b->h_po);
     if (b->e0) (void)hipEventDestroy(b->e0);
     if (b->e1) (void)hipEventDestroy(b->e1);
-    if (b->e2) (void)hipEventDestroy(b->e2);
-    if (b->e3) (void)hipEventDestroy(b->e3);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -520,7 +489,10 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     std::vector<double> h_intr((size_t)P.n_poses * 4);
     for (size_t i = 0; i < h_intr.size(); i++) h_intr[i] = (double)p->intr[i];
 
+    const bool trace = getenv("SWARMORB_BA_TRACE") != nullptr;
+    const double t_sorted = now_ms();
     build_stage(P, r.S);
+    const double t_stage1 = now_ms();
     if (6 * r.S.n_free > kMaxReducedDim) {
         last_error_ref() = "reduced camera system too large for the dense solver (6*n_free > 6144)";
         return SO_ERR_CAPACITY;
@@ -581,48 +553,50 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     r.nb_upd = std::min(1024, std::max(1, (8 * P.n_points + P.n_poses + 255) / 256));
     if ((rc = upload_stage(r))) return rc;
 
+    if ((rc = b->d_lm.ensure(sizeof(BaLm)))) return rc;
+    SO_HIP(hipMemsetAsync(b->d_lm.p, 0, sizeof(BaLm), s));  // current estimate = buffer 0, no trials yet
+    memset(b->h_lm, 0, sizeof(BaLm));
+    *b->h_abort = 0;
+    d.lm = b->d_lm.as<BaLm>();
+    d.pose[0] = b->d_pose[0].as<BaPose>();
+    d.pose[1] = b->d_pose[1].as<BaPose>();
+    d.pt[0] = b->d_pt[0].as<double>();
+    d.pt[1] = b->d_pt[1].as<double>();
+
+    const double t_uploaded = now_ms();
     SO_HIP(hipEventRecord(b->e0, s));
     double chi = 0.0;
     int done = 0;
-    // chi2 before optimising (information only)
-    launch_ba_errors(r.d, r.poses(r.cur), r.points(r.cur), r.nb_err, s);
-    if ((rc = fetch_partials(r))) return rc;
-    inf.chi2_initial = sum_partials(b->h_partial + kBaPartialChi, r.nb_err);
-    inf.chi2_final = inf.chi2_initial;
-
     if ((rc = optimize(r, opt->its_stage1, &done, &chi))) return rc;  // optimizer.optimize(5)
     inf.iterations_stage1 = done;
-    if (done > 0) inf.chi2_final = chi;
+    inf.chi2_initial = b->h_lm->chi_begin;  // chi2 before optimising (information only)
+    inf.chi2_final = done > 0 ? chi : inf.chi2_initial;
+    const double t_opt1 = now_ms();
     bool do_more = opt->its_stage2 > 0;
     if (r.terminate()) {
         do_more = false;
         inf.aborted = 1;
     }
-    std::vector<double> h_chi2(nE), h_depth(nE);
-    auto fetch_edge_state = [&]() -> int {
-        launch_ba_depth(r.d, r.poses(r.cur), r.points(r.cur), b->d_depth.as<double>(), s);  // isDepthPositive()
-        SO_HIP(hipMemcpyAsync(h_chi2.data(), b->d_chi2.p, sizeof(double) * nE, hipMemcpyDeviceToHost, s));
-        SO_HIP(hipMemcpyAsync(h_depth.data(), b->d_depth.p, sizeof(double) * nE, hipMemcpyDeviceToHost, s));
-        SO_HIP(hipStreamSynchronize(s));
-        return SO_OK;
-    };
     if (do_more) {
-        if ((rc = fetch_edge_state())) return rc;
-        for (int k = 0; k < P.n_edges; k++)  // Optimizer.cc:644-656
-            if (h_chi2[(size_t)k] > (double)opt->chi2_threshold || !(h_depth[(size_t)k] > 0.0)) P.level[(size_t)k] = 1;
+        // Optimizer.cc:644-656 without leaving the device: outlier edges drop to level 1, the robust kernel goes,
+        // initializeOptimization(0) = the same CSR lists with the dropped edges skipped
+        launch_ba_mark_outliers(r.d, (double)opt->chi2_threshold, s);
         r.d.robust = 0;  // e->setRobustKernel(nullptr)
-        build_stage(P, r.S);  // optimizer.initializeOptimization(0)
-        if ((rc = upload_stage(r))) return rc;
         if ((rc = optimize(r, opt->its_stage2, &done, &chi))) return rc;  // optimizer.optimize(10)
         inf.iterations_stage2 = done;
         if (done > 0) inf.chi2_final = chi;
         if (r.terminate()) inf.aborted = 1;
     }
+    const double t_opt2 = now_ms();
     // Optimizer.cc:682-739: outlier flags from the edges' stored errors, then recover the optimised data
-    if ((rc = fetch_edge_state())) return rc;
-    SO_HIP(hipMemcpyAsync(h_pose.data(), r.poses(r.cur), sizeof(BaPose) * h_pose.size(), hipMemcpyDeviceToHost, s));
+    const int cur = b->h_lm->cur;
+    std::vector<double> h_chi2(nE), h_depth(nE);
+    launch_ba_depth(r.d, b->d_depth.as<double>(), s);  // isDepthPositive()
+    SO_HIP(hipMemcpyAsync(h_chi2.data(), b->d_chi2.p, sizeof(double) * nE, hipMemcpyDeviceToHost, s));
+    SO_HIP(hipMemcpyAsync(h_depth.data(), b->d_depth.p, sizeof(double) * nE, hipMemcpyDeviceToHost, s));
+    SO_HIP(hipMemcpyAsync(h_pose.data(), b->d_pose[cur].p, sizeof(BaPose) * h_pose.size(), hipMemcpyDeviceToHost, s));
     if (!h_pt.empty())
-        SO_HIP(hipMemcpyAsync(h_pt.data(), r.points(r.cur), sizeof(double) * h_pt.size(), hipMemcpyDeviceToHost, s));
+        SO_HIP(hipMemcpyAsync(h_pt.data(), b->d_pt[cur].p, sizeof(double) * h_pt.size(), hipMemcpyDeviceToHost, s));
     SO_HIP(hipEventRecord(b->e1, s));
     SO_HIP(hipStreamSynchronize(s));
     for (int k = 0; k < P.n_edges; k++) {
@@ -634,13 +608,17 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     }
     for (int i = 0; i < P.n_poses; i++) pose_to_Tcw(h_pose[(size_t)i], Tcw_out + 12 * (size_t)i);
     for (size_t i = 0; i < h_pt.size(); i++) Xw_out[i] = (float)h_pt[i];
-    inf.lambda_final = r.lambda;
-    inf.lm_trials = r.trials;
+    inf.lambda_final = b->h_lm->lambda;
+    inf.lm_trials = b->h_lm->trials;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->e0, b->e1) == hipSuccess) inf.gpu_ms = ms;
     inf.solve_ms = b->solve_ms;
     inf.n_solves = b->n_solves;
     inf.wall_ms = (float)(now_ms() - t_begin);
+    if (trace)
+        fprintf(stderr, "[ba] sort %.3f lists %.3f upload %.3f opt1 %.3f (%d it) opt2 %.3f (%d it) finish %.3f | trials %d blocks %d\n",
+                t_sorted - t_begin, t_stage1 - t_sorted, t_uploaded - t_stage1, t_opt1 - t_uploaded, inf.iterations_stage1,
+                t_opt2 - t_opt1, inf.iterations_stage2, now_ms() - t_opt2, inf.lm_trials, r.blocks_enqueued);
     if (info) *info = inf;
     return SO_OK;
 }

@@ -6,7 +6,8 @@
 //   edges     sorted by point (stable): pose idx, point idx, obs[2], inv_sigma2, active flag
 //             + stored error[2] (EdgeSE3ProjectXYZ::_error) that only active edges refresh
 //   CSR       point -> its edges (contiguous after the sort); free pose -> its edges; upper block (i1,i2) of the
-//             reduced camera system -> the (edge, edge) pairs that share a landmark (built per stage on the host)
+//             reduced camera system -> the (edge, edge) pairs that share a landmark.  Built once per problem on
+//             the host; the second stage keeps the lists and skips edges whose active flag was cleared.
 //   system    Hpp[n_free][36], bp[n_free][6], Hll[n_pt][9], bl[n_pt][3], W[edge][18] = J_pose^T w J_point,
 //             Dinv[n_pt][9], db[n_pt][3], BDinv[edge][18], S[(6 n_free)^2] dense, bs / x_p[6 n_free], x_l[n_pt][3]
 // Summation orders are fixed (CSR order, fixed reduction trees, no floating-point atomics) so results are
@@ -23,7 +24,30 @@ struct BaPose {
     double pad;
 };
 
+// Levenberg-Marquardt state of one optimize() call (OptimizationAlgorithmLevenberg::solve +
+// SparseOptimizer::optimize), resident in HBM: every kernel of a trial reads it, ba_trial_decide_kernel
+// advances it, so the host enqueues trials back to back without reading anything in between.
+struct BaLm {
+    double lambda, ni;          // _currentLambda, _ni
+    double currentChi, iniChi;  // chi2 of the current estimate; chi2 at the start of the iteration
+    double tempChi, rho;        // last trial
+    double chi_out;             // activeRobustChi2 after the last completed iteration
+    double chi_begin;           // chi2 of the estimate optimize() started from
+    int cur;                    // which of the two estimate buffers is the current one (the other is the trial)
+    int it, iterations;         // iteration counter of this optimize() and its limit
+    int qmax, nBad;
+    int done;                   // iterations completed in this optimize()
+    int trials;                 // trials since the problem was set up (all stages)
+    int active;                 // 1 while optimize() wants another trial; kernels return immediately when 0
+    int need_build;             // the current estimate changed: re-linearise before the next trial
+    int pad[3];
+};
+
 struct BaDev {
+    // estimate buffers and LM state
+    BaPose* pose[2];
+    double* pt[2];
+    BaLm* lm;
     // problem
     int n_poses, n_points, n_edges;
     int n_free;          // poses with a hessian index in the current stage
@@ -33,11 +57,11 @@ struct BaDev {
     const int* e_point;
     const double* e_obs;      // x2
     const double* e_w;        // inv_sigma2
-    const uint8_t* e_active;  // level == 0 in this stage
+    uint8_t* e_active;        // level == 0 in this stage (ba_mark_outliers_kernel clears flags between stages)
     double* e_err;            // x2 stored error
     double* e_chi2;           // stored chi2 (refreshed with the error)
     const int* pt_off;        // n_points + 1
-    const uint8_t* pt_active; // n_points
+    uint8_t* pt_active;       // n_points: has at least one active edge
     const int* pose_hidx;     // n_poses: hessian index or -1
     const int* free_pose;     // n_free: pose index of hessian index i
     const int* pose_off;      // n_free + 1
@@ -61,14 +85,21 @@ constexpr int kBaMaxDiag = 2048;       // [2048]: max |diag|
 constexpr int kBaSolveOk = 2049;       // [2049]: 1.0 if the Cholesky succeeded
 constexpr int kBaPartialCount = 2056;
 
-void launch_ba_errors(const BaDev& d, const BaPose* poses, const double* points, int n_blocks, hipStream_t s);
-void launch_ba_build(const BaDev& d, const BaPose* poses, const double* points, hipStream_t s);
+// which: 0 = current estimate, 1 = trial.  gated: return immediately unless lm->active (and, for build, lm->need_build).
+void launch_ba_errors(const BaDev& d, int which, bool gated, int n_blocks, hipStream_t s);
+void launch_ba_build(const BaDev& d, bool gated, hipStream_t s);
 void launch_ba_maxdiag(const BaDev& d, hipStream_t s);
-void launch_ba_schur(const BaDev& d, double lambda, const int* blk_i1, const int* blk_i2, int n_blk, hipStream_t s);
-void launch_ba_solve(const BaDev& d, hipStream_t s);
-void launch_ba_update(const BaDev& d, double lambda, const BaPose* poses, const double* points, BaPose* poses_trial,
-                      double* points_trial, int n_blocks, hipStream_t s);
-void launch_ba_depth(const BaDev& d, const BaPose* poses, const double* points, double* depth, hipStream_t s);
+// start of optimize(iterations): currentChi from the error partials, computeLambdaInit from the max diagonal
+void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_host, hipStream_t s);
+// one LM trial, seven launches, no host involvement: [build] -> schur prep -> gather -> solve -> update -> errors
+// -> decide.  abort_flag (host-mapped, may be null) = g2o's forceStopFlag; lm_host (host-mapped) receives a copy
+// of the state after every decision; ev0/ev1 (may be null) bracket the solve kernel.
+void launch_ba_trial(const BaDev& d, const int* blk_i1, const int* blk_i2, int n_blk, int nb_err, int nb_upd,
+                     const uint8_t* abort_flag, BaLm* lm_host, hipEvent_t ev0, hipEvent_t ev1, hipStream_t s);
+// Optimizer.cc:644-656 on the device: edges of the current estimate with chi2 > threshold or non-positive depth
+// leave the problem (level 1); landmarks left without an edge become inactive
+void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, hipStream_t s);
+void launch_ba_depth(const BaDev& d, double* depth, hipStream_t s);  // of the current estimate
 
 struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.hip)
     const float* Xw;          // n x 3

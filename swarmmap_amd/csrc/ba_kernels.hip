@@ -2,7 +2,10 @@
 //
 // One Levenberg-Marquardt trial = schur (per-landmark 3x3 inverse + per-block gather of the reduced camera
 // system) -> dense Cholesky solve of the reduced system -> back-substitution + manifold update into the trial
-// buffers -> residuals + chi2 of the trial state.  One iteration additionally linearises (build).
+// buffers -> residuals + chi2 of the trial state -> accept / reject (ba_trial_decide_kernel).  The LM state
+// (lambda, which buffer is current, iteration counters) lives in HBM (BaLm); every kernel reads it and returns
+// at once when the optimize() call has finished, so the host enqueues a whole stage without a round trip.
+// One iteration additionally linearises (build).
 // Reductions are segmented by vertex through host-built CSR lists (edges pre-sorted by landmark): no
 // floating-point atomics, fixed summation order, deterministic results.
 //
@@ -175,9 +178,12 @@ __device__ __forceinline__ double block_sum(double v, double* s_tmp /* >= 16 dou
 }
 
 // ---------------- residuals + chi2 (computeActiveErrors + activeRobustChi2) ----------------
-__global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, const BaPose* __restrict__ poses,
-                                                         const double* __restrict__ points) {
+__global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, int which, int gated) {
     __shared__ double s_tmp[16];
+    const BaLm lm = *d.lm;
+    if (gated && !lm.active) return;
+    const BaPose* __restrict__ poses = d.pose[lm.cur ^ which];
+    const double* __restrict__ points = d.pt[lm.cur ^ which];
     double acc = 0.0;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < d.n_edges; e += gridDim.x * 256) {
         if (!d.e_active[e]) continue;
@@ -197,30 +203,62 @@ __global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, const BaPose* _
     if (threadIdx.x == 0) d.partial[kBaPartialChi + blockIdx.x] = t;
 }
 
-void launch_ba_errors(const BaDev& d, const BaPose* poses, const double* points, int n_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(ba_errors_kernel, dim3(n_blocks), dim3(256), 0, s, d, poses, points);
+void launch_ba_errors(const BaDev& d, int which, bool gated, int n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(ba_errors_kernel, dim3(n_blocks), dim3(256), 0, s, d, which, gated ? 1 : 0);
 }
 
-__global__ __launch_bounds__(256) void ba_depth_kernel(BaDev d, const BaPose* __restrict__ poses,
-                                                        const double* __restrict__ points, double* __restrict__ depth) {
+__global__ __launch_bounds__(256) void ba_depth_kernel(BaDev d, double* __restrict__ depth) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= d.n_edges) return;
+    const int cur = d.lm->cur;
+    const double* points = d.pt[cur];
     const int il = d.e_point[e];
     const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
     double pc[3];
-    camera_point(poses[d.e_pose[e]], X, pc);
+    camera_point(d.pose[cur][d.e_pose[e]], X, pc);
     depth[e] = pc[2];
 }
 
-void launch_ba_depth(const BaDev& d, const BaPose* poses, const double* points, double* depth, hipStream_t s) {
+void launch_ba_depth(const BaDev& d, double* depth, hipStream_t s) {
     if (d.n_edges <= 0) return;
-    hipLaunchKernelGGL(ba_depth_kernel, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, poses, points, depth);
+    hipLaunchKernelGGL(ba_depth_kernel, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, depth);
+}
+
+// Between the two stages of LocalBundleAdjustment (Optimizer.cc:644-656): one thread per landmark walks its
+// (contiguous) edges; an active edge whose stored chi2 exceeds the threshold or whose point is not in front of
+// the camera in the current estimate is dropped (setLevel(1)); a landmark without active edges drops out too.
+__global__ __launch_bounds__(256) void ba_mark_outliers_kernel(BaDev d, double chi2_threshold) {
+    const int il = blockIdx.x * 256 + threadIdx.x;
+    if (il >= d.n_points) return;
+    const int cur = d.lm->cur;
+    const double* points = d.pt[cur];
+    const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+    int alive = 0;
+    for (int e = d.pt_off[il]; e < d.pt_off[il + 1]; e++) {
+        if (!d.e_active[e]) continue;
+        double pc[3];
+        camera_point(d.pose[cur][d.e_pose[e]], X, pc);
+        if (d.e_chi2[e] > chi2_threshold || !(pc[2] > 0.0)) d.e_active[e] = 0;
+        else alive++;
+    }
+    d.pt_active[il] = alive > 0;
+}
+
+void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, hipStream_t s) {
+    if (d.n_points <= 0) return;
+    hipLaunchKernelGGL(ba_mark_outliers_kernel, dim3((d.n_points + 255) / 256), dim3(256), 0, s, d, chi2_threshold);
 }
 
 // ---------------- linearisation: Hpp/bp per free pose (one workgroup each), Hll/bl/W per landmark ----------------
-__global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, const BaPose* __restrict__ poses,
-                                                        const double* __restrict__ points) {
+// The residuals are recomputed here from the current estimate (the same function on the same state as
+// computeActiveErrors, so the same values) rather than read from the stored errors, which describe the last
+// TRIAL and are stale after a rejected one.
+__global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, int gated) {
     __shared__ double s_red[4][28];
+    const BaLm lm = *d.lm;
+    if (gated && !(lm.active && lm.need_build)) return;
+    const BaPose* __restrict__ poses = d.pose[lm.cur];
+    const double* __restrict__ points = d.pt[lm.cur];
     if ((int)blockIdx.x < d.n_free) {
         // pose role: reduce J_c^T w J_c (upper 21) and J_c^T omega_r (6) over this pose's active edges
         const int hi = blockIdx.x, ip = d.free_pose[hi];
@@ -231,14 +269,17 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, const BaPose* __
         for (int i = 0; i < 27; i++) acc[i] = 0.0;
         for (int k = d.pose_off[hi] + threadIdx.x; k < d.pose_off[hi + 1]; k += 256) {
             const int e = d.pose_edges[k];
+            if (!d.e_active[e]) continue;
             const int il = d.e_point[e];
             const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
-            double Jp[6], Jc[12];
+            double Jp[6], Jc[12], e0, e1;
             edge_jacobians(P, X, K, Jp, Jc);
+            const double obs[2] = {d.e_obs[2 * e], d.e_obs[2 * e + 1]};
+            edge_error(P, X, obs, K, e0, e1);
             const double om = d.e_w[e];
-            const double r1 = d.robust ? huber_rho1(d.e_chi2[e], d.huber_delta, d.huber_dsqr) : 1.0;
+            const double r1 = d.robust ? huber_rho1(e0 * (om * e0) + e1 * (om * e1), d.huber_delta, d.huber_dsqr) : 1.0;
             const double w = r1 * om;
-            const double o0 = -om * d.e_err[2 * e] * r1, o1 = -om * d.e_err[2 * e + 1] * r1;
+            const double o0 = -om * e0 * r1, o1 = -om * e1 * r1;
             int t = 0;
 #pragma unroll
             for (int r = 0; r < 6; r++)
@@ -279,12 +320,15 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, const BaPose* __
         for (int e = d.pt_off[il] + sub; e < d.pt_off[il + 1]; e += 8) {
             if (!d.e_active[e]) continue;
             const int ip = d.e_pose[e];
-            double Jp[6], Jc[12];
-            edge_jacobians(poses[ip], X, d.intr + 4 * ip, Jp, Jc);
+            double Jp[6], Jc[12], e0, e1;
+            const BaPose P = poses[ip];
+            edge_jacobians(P, X, d.intr + 4 * ip, Jp, Jc);
+            const double obs[2] = {d.e_obs[2 * e], d.e_obs[2 * e + 1]};
+            edge_error(P, X, obs, d.intr + 4 * ip, e0, e1);
             const double om = d.e_w[e];
-            const double r1 = d.robust ? huber_rho1(d.e_chi2[e], d.huber_delta, d.huber_dsqr) : 1.0;
+            const double r1 = d.robust ? huber_rho1(e0 * (om * e0) + e1 * (om * e1), d.huber_delta, d.huber_dsqr) : 1.0;
             const double w = r1 * om;
-            const double o0 = -om * d.e_err[2 * e] * r1, o1 = -om * d.e_err[2 * e + 1] * r1;
+            const double o0 = -om * e0 * r1, o1 = -om * e1 * r1;
             H[0] += Jp[0] * w * Jp[0] + Jp[3] * w * Jp[3];
             H[1] += Jp[0] * w * Jp[1] + Jp[3] * w * Jp[4];
             H[2] += Jp[0] * w * Jp[2] + Jp[3] * w * Jp[5];
@@ -318,10 +362,10 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, const BaPose* __
     }
 }
 
-void launch_ba_build(const BaDev& d, const BaPose* poses, const double* points, hipStream_t s) {
+void launch_ba_build(const BaDev& d, bool gated, hipStream_t s) {
     const int nb = d.n_free + (d.n_points + 31) / 32;
     if (nb <= 0) return;
-    hipLaunchKernelGGL(ba_build_kernel, dim3(nb), dim3(256), 0, s, d, poses, points);
+    hipLaunchKernelGGL(ba_build_kernel, dim3(nb), dim3(256), 0, s, d, gated ? 1 : 0);
 }
 
 // max |diagonal| over Hpp and Hll (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
@@ -360,7 +404,9 @@ __device__ __forceinline__ void damped_inverse3(const double* Hl, double lambda,
 // prep: thread i < n_points: Dinv = (Hll + lambda I)^-1 (cofactors, like Eigen's 3x3 inverse), db = Dinv bl;
 //       thread i < n_edges : BDinv_e = W_e Dinv (recomputing the 3x3 inverse of its landmark: no dependency
 //       between the two roles, so everything is one memory latency deep)
-__global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d, double lambda) {
+__global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d) {
+    if (!d.lm->active) return;
+    const double lambda = d.lm->lambda;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < d.n_points && d.pt_active[i]) {
         double Di[9];
@@ -388,8 +434,10 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d, double lamb
 //         strided over the 64 lanes, each lane accumulates a full 6x6 partial, then a fixed xor-butterfly sums the
 //         lanes: S(i1,i2) = [i1 == i2] (Hpp + lambda I) - sum over shared landmarks BDinv_{k1} W_{k2}^T ; mirrored.
 //         extra waves: b_schur(i) = bp(i) - sum over the pose's edges W_e db_{landmark(e)}
-__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, double lambda, const int* __restrict__ blk_i1,
+__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, const int* __restrict__ blk_i1,
                                                                const int* __restrict__ blk_i2, int n_blk) {
+    if (!d.lm->active) return;
+    const double lambda = d.lm->lambda;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = 6 * d.n_free;
@@ -399,8 +447,10 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, double la
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
         for (int p = d.blk_off[g] + lane; p < d.blk_off[g + 1]; p += 64) {
-            const double* B = d.BDinv + 18 * (size_t)d.pair_k1[p];
-            const double* W = d.W + 18 * (size_t)d.pair_k2[p];
+            const int k1 = d.pair_k1[p], k2 = d.pair_k2[p];
+            if (!(d.e_active[k1] && d.e_active[k2])) continue;  // dropped between the stages
+            const double* B = d.BDinv + 18 * (size_t)k1;
+            const double* W = d.W + 18 * (size_t)k2;
             double b[18], w[18];
 #pragma unroll
             for (int k = 0; k < 18; k++) { b[k] = B[k]; w[k] = W[k]; }
@@ -429,6 +479,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, double la
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int k = d.pose_off[hi] + lane; k < d.pose_off[hi + 1]; k += 64) {
         const int e = d.pose_edges[k];
+        if (!d.e_active[e]) continue;
         const double* W = d.W + 18 * (size_t)e;
         const double* db = d.db + 3 * (size_t)d.e_point[e];
 #pragma unroll
@@ -445,124 +496,131 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, double la
 // Replaces LinearSolverEigen's SimplicialLDLT (linear_solver_eigen.h:94-124): same solution up to rounding.
 //
 // Fast path (n_free <= 43): 6x6-block right-looking Cholesky held entirely in REGISTERS.  The lower block
-// triangle of S plus one extra block row carrying the right-hand side is dealt out to 256 threads (<= 4 blocks
-// of 36 doubles each); per block step k the owner of (k,k) factors its 6x6 block, the owners of column k solve
+// triangle of S plus one extra block row carrying the right-hand side is dealt out in block-COLUMN order, one
+// block (36 doubles) per thread slot, so the blocks of a finished column form a prefix of the thread range and
+// whole waves retire as the factorisation advances.  Per block step k: the owner of (k,k) factors its block
+// (right-looking inside the block, reciprocal square roots from v_rsq_f64 + Newton steps instead of the IEEE
+// sqrt/div sequences: the step's serial chain is what bounds this kernel), the owners of column k solve
 // against it and publish their blocks through LDS, and every owner of a trailing block applies its rank-6
-// update from two LDS blocks.  Two barriers per 6 columns instead of three per column, and no global memory
-// between the initial load and the final store.  The forward substitution falls out of the extra block row; the
-// backward substitution walks the block columns right to left (again two barriers per block).
-constexpr int kSolveThreads = 256, kSolveBPT = 4, kSolveMaxNB = 44;
+// update from two LDS blocks.  Two barriers per 6 columns, no global memory between the initial load and the
+// final store.  The forward substitution falls out of the extra block row; the backward substitution multiplies
+// by the inverted diagonal blocks (inverted off the critical path, all at once after the factorisation).
+constexpr int kSolveMaxNB = 44;
 
-__device__ __forceinline__ void decode_lower_block(int p, int& I, int& J) {
-    int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= p) i++;
-    while (i * (i + 1) / 2 > p) i--;
-    I = i;
-    J = p - i * (i + 1) / 2;
+// tools/probe/solve_probe.hip defines SO_SOLVE_MARK to log clock64() per phase; the product build compiles it away
+#ifndef SO_SOLVE_MARK
+#define SO_SOLVE_MARK(k, phase)
+#endif
+
+// 1/sqrt(v) to double precision: hardware estimate + two Newton steps (each three dependent FMAs)
+__device__ __forceinline__ double rsqrt_newton(double v) {
+    double y = __builtin_amdgcn_rsq(v);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const double t = v * y;
+        const double e = fma(-t, y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
+    return y;
 }
 
-__global__ __launch_bounds__(kSolveThreads) void ba_solve_blocked_kernel(BaDev d) {
+template <int THREADS, int BPT>
+__global__ __launch_bounds__(THREADS) void ba_solve_reg_kernel(BaDev d) {
     __shared__ double s_diag[36];
-    __shared__ double s_panel[2][kSolveMaxNB][36];
-    __shared__ double s_Ld[kSolveMaxNB][36];
+    __shared__ double s_dinv[kSolveMaxNB][6];
+    __shared__ double s_panel[kSolveMaxNB][37];  // 37: lanes reading the same element of 32 different blocks hit distinct banks
+    __shared__ double s_Linv[kSolveMaxNB][36];
     __shared__ double s_y[kSolveMaxNB][6];
     __shared__ double s_x[6];
-    __shared__ double s_dinv[6];
-    __shared__ double s_Ldinv[kSolveMaxNB][6];
     __shared__ int s_fail;
+    if (!d.lm->active) return;
     const int tid = threadIdx.x;
     const int nf = d.n_free, NB = nf + 1, n = 6 * nf, nblk = NB * (NB + 1) / 2;
-    double a[kSolveBPT][36];
-    int bI[kSolveBPT], bJ[kSolveBPT];
+    double a[BPT][36];
+    int bI[BPT], bJ[BPT];
     if (tid == 0) s_fail = 0;
 #pragma unroll
-    for (int s = 0; s < kSolveBPT; s++) {
-        const int p = tid + s * kSolveThreads;
+    for (int s = 0; s < BPT; s++) {
+        const int p = tid + s * THREADS;
         bI[s] = -1;
         bJ[s] = -1;
 #pragma unroll
         for (int k = 0; k < 36; k++) a[s][k] = 0.0;
-        if (p < nblk) {
-            int I, J;
-            decode_lower_block(p, I, J);
-            if (!(I == nf && J == nf)) {
-                bI[s] = I;
-                bJ[s] = J;
-                if (I < nf) {
+        if (p < nblk - 1) {  // the last block would be (nf, nf): the right-hand side has no diagonal block
+            int J = 0, rem = p;
+            while (rem >= NB - J) {
+                rem -= NB - J;
+                J++;
+            }
+            const int I = J + rem;
+            bI[s] = I;
+            bJ[s] = J;
+            if (I < nf) {
 #pragma unroll
-                    for (int r = 0; r < 6; r++)
+                for (int r = 0; r < 6; r++)
 #pragma unroll
-                        for (int c = 0; c < 6; c++) a[s][r * 6 + c] = d.S[(size_t)(6 * I + r) * n + 6 * J + c];
-                } else {
+                    for (int c = 0; c < 6; c++) a[s][r * 6 + c] = d.S[(size_t)(6 * I + r) * n + 6 * J + c];
+            } else {
 #pragma unroll
-                    for (int c = 0; c < 6; c++) a[s][c] = d.bs[6 * J + c];  // right-hand side rides as row 0
-                }
+                for (int c = 0; c < 6; c++) a[s][c] = d.bs[6 * J + c];  // right-hand side rides as row 0
             }
         }
     }
     __syncthreads();
+    SO_SOLVE_MARK(0, 0);
     for (int k = 0; k < nf; k++) {
-        const int buf = k & 1;
+        SO_SOLVE_MARK(k, 1);
 #pragma unroll
-        for (int s = 0; s < kSolveBPT; s++) {
+        for (int s = 0; s < BPT; s++) {
             if (bI[s] == k && bJ[s] == k) {  // factor the diagonal block in place (lower), publish it
                 double* A = a[s];
                 bool bad = false;
-                double rinv[6];
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
-                    double v = A[c * 6 + c];
-#pragma unroll
-                    for (int m = 0; m < c; m++) v -= A[c * 6 + m] * A[c * 6 + m];
+                    const double v = A[c * 6 + c];
                     if (!(v > 0.0)) bad = true;
-                    const double l = sqrt(v);
-                    rinv[c] = 1.0 / l;  // one division per column; everything else multiplies by it
+                    const double y = rsqrt_newton(v);
+                    double l = v * y;
+                    l = fma(fma(-l, l, v), 0.5 * y, l);  // one correction step: l = sqrt(v) to the last bit or so
                     A[c * 6 + c] = l;
+                    s_dinv[k][c] = y;
 #pragma unroll
-                    for (int r = c + 1; r < 6; r++) {
-                        double u = A[r * 6 + c];
+                    for (int r = c + 1; r < 6; r++) A[r * 6 + c] *= y;
 #pragma unroll
-                        for (int m = 0; m < c; m++) u -= A[r * 6 + m] * A[c * 6 + m];
-                        A[r * 6 + c] = u * rinv[c];
-                    }
+                    for (int r = c + 1; r < 6; r++)
+#pragma unroll
+                        for (int c2 = c + 1; c2 <= r; c2++) A[r * 6 + c2] -= A[r * 6 + c] * A[c2 * 6 + c];
 #pragma unroll
                     for (int r = 0; r < c; r++) A[r * 6 + c] = 0.0;
                 }
 #pragma unroll
-                for (int q = 0; q < 36; q++) {
-                    s_diag[q] = A[q];
-                    s_Ld[k][q] = A[q];
-                }
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    s_dinv[c] = rinv[c];
-                    s_Ldinv[k][c] = rinv[c];
-                }
+                for (int q = 0; q < 36; q++) s_diag[q] = A[q];
                 if (bad) s_fail = 1;
             }
         }
         __syncthreads();
+        SO_SOLVE_MARK(k, 2);
         if (s_fail) break;
 #pragma unroll
-        for (int s = 0; s < kSolveBPT; s++) {
-            if (bJ[s] == k && bI[s] > k) {  // X = A L_kk^-T, row by row
+        for (int s = 0; s < BPT; s++) {
+            if (bJ[s] == k && bI[s] > k) {  // X = A L_kk^-T, column by column (right-looking)
                 double* A = a[s];
                 double L[36], ri[6];
 #pragma unroll
                 for (int q = 0; q < 36; q++) L[q] = s_diag[q];
 #pragma unroll
-                for (int c = 0; c < 6; c++) ri[c] = s_dinv[c];
+                for (int c = 0; c < 6; c++) ri[c] = s_dinv[k][c];
 #pragma unroll
-                for (int r = 0; r < 6; r++)
+                for (int c = 0; c < 6; c++)
 #pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        double v = A[r * 6 + c];
+                    for (int r = 0; r < 6; r++) {
+                        const double x = A[r * 6 + c] * ri[c];
+                        A[r * 6 + c] = x;
 #pragma unroll
-                        for (int m = 0; m < c; m++) v -= A[r * 6 + m] * L[c * 6 + m];
-                        A[r * 6 + c] = v * ri[c];
+                        for (int c2 = c + 1; c2 < 6; c2++) A[r * 6 + c2] -= x * L[c2 * 6 + c];
                     }
 #pragma unroll
-                for (int q = 0; q < 36; q++) s_panel[buf][bI[s]][q] = A[q];
+                for (int q = 0; q < 36; q++) s_panel[bI[s]][q] = A[q];
                 if (bI[s] == nf) {
 #pragma unroll
                     for (int c = 0; c < 6; c++) s_y[k][c] = A[c];
@@ -570,12 +628,13 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_blocked_kernel(BaDev d
             }
         }
         __syncthreads();
+        SO_SOLVE_MARK(k, 3);
 #pragma unroll
-        for (int s = 0; s < kSolveBPT; s++) {
+        for (int s = 0; s < BPT; s++) {
             if (bJ[s] > k) {  // trailing update A_IJ -= L_Ik L_Jk^T  (bI >= bJ > k)
                 double* A = a[s];
-                const double* Pj = s_panel[buf][bJ[s]];
-                const double* Pi = s_panel[buf][bI[s]];
+                const double* Pj = s_panel[bJ[s]];
+                const double* Pi = s_panel[bI[s]];
                 double pj[36];
 #pragma unroll
                 for (int q = 0; q < 36; q++) pj[q] = Pj[q];
@@ -586,50 +645,75 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_blocked_kernel(BaDev d
                     for (int m = 0; m < 6; m++) pi[m] = Pi[r * 6 + m];
 #pragma unroll
                     for (int c = 0; c < 6; c++) {
-                        double v = 0.0;
+                        double v = A[r * 6 + c];
 #pragma unroll
-                        for (int m = 0; m < 6; m++) v += pi[m] * pj[c * 6 + m];
-                        A[r * 6 + c] -= v;
+                        for (int m = 0; m < 6; m++) v = fma(-pi[m], pj[c * 6 + m], v);
+                        A[r * 6 + c] = v;
                     }
                 }
             }
         }
+        // no barrier here: s_panel / s_diag are rewritten only after the next barrier pair
+        SO_SOLVE_MARK(k, 4);
     }
     __syncthreads();
+    SO_SOLVE_MARK(0, 5);
     if (!s_fail) {
+#pragma unroll
+        for (int s = 0; s < BPT; s++) {
+            if (bI[s] == bJ[s] && bI[s] >= 0) {  // invert the factored diagonal block (lower triangular)
+                const double* L = a[s];
+                const int K = bI[s];
+                double ri[6], X[36];
+#pragma unroll
+                for (int c = 0; c < 6; c++) ri[c] = s_dinv[K][c];
+#pragma unroll
+                for (int q = 0; q < 36; q++) X[q] = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    X[j * 6 + j] = ri[j];
+#pragma unroll
+                    for (int i = j + 1; i < 6; i++) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int m = j; m < i; m++) v = fma(L[i * 6 + m], X[m * 6 + j], v);
+                        X[i * 6 + j] = -v * ri[i];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 36; q++) s_Linv[K][q] = X[q];
+            }
+        }
+        __syncthreads();
         for (int K = nf - 1; K >= 0; K--) {  // L^T x = y, block columns right to left
-            if (tid == 0) {
-                double x[6];
+            if (tid < 6) {                   // x_K = L_KK^-T y_K
+                double v = 0.0;
 #pragma unroll
-                for (int c = 5; c >= 0; c--) {
-                    double v = s_y[K][c];
-#pragma unroll
-                    for (int m = c + 1; m < 6; m++) v -= s_Ld[K][m * 6 + c] * x[m];
-                    x[c] = v * s_Ldinv[K][c];
-                }
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    s_x[c] = x[c];
-                    d.bs[6 * K + c] = x[c];
-                }
+                for (int r = 0; r < 6; r++) v = fma(s_Linv[K][r * 6 + tid], s_y[K][r], v);  // zeros above the diagonal
+                s_x[tid] = v;
+                d.bs[6 * K + tid] = v;
             }
             __syncthreads();
 #pragma unroll
-            for (int s = 0; s < kSolveBPT; s++) {
+            for (int s = 0; s < BPT; s++) {
                 if (bI[s] == K && bJ[s] < K) {  // y_J -= L_KJ^T x_K (one block per J in this step)
                     const double* A = a[s];
+                    double x[6];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) x[r] = s_x[r];
 #pragma unroll
                     for (int c = 0; c < 6; c++) {
-                        double v = 0.0;
+                        double v = s_y[bJ[s]][c];
 #pragma unroll
-                        for (int r = 0; r < 6; r++) v += A[r * 6 + c] * s_x[r];
-                        s_y[bJ[s]][c] -= v;
+                        for (int r = 0; r < 6; r++) v = fma(-A[r * 6 + c], x[r], v);
+                        s_y[bJ[s]][c] = v;
                     }
                 }
             }
             __syncthreads();
         }
     }
+    SO_SOLVE_MARK(0, 6);
     if (tid == 0) d.partial[kBaSolveOk] = s_fail ? 0.0 : 1.0;
 }
 
@@ -638,6 +722,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_blocked_kernel(BaDev d
 // windows with more than 43 free keyframes.
 __global__ __launch_bounds__(1024) void ba_solve_global_kernel(BaDev d) {
     __shared__ int s_fail;
+    if (!d.lm->active) return;
     const int n = 6 * d.n_free;
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
     double* S = d.S;
@@ -676,29 +761,36 @@ __global__ __launch_bounds__(1024) void ba_solve_global_kernel(BaDev d) {
     if (tid == 0) d.partial[kBaSolveOk] = s_fail ? 0.0 : 1.0;
 }
 
-void launch_ba_schur(const BaDev& d, double lambda, const int* blk_i1, const int* blk_i2, int n_blk, hipStream_t s) {
+static void launch_ba_schur(const BaDev& d, const int* blk_i1, const int* blk_i2, int n_blk, hipStream_t s) {
     const int nthreads = d.n_points > d.n_edges ? d.n_points : d.n_edges;
-    if (nthreads > 0)
-        hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d, lambda);
+    if (nthreads > 0) hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d);
     const int waves = n_blk + d.n_free;
     if (waves > 0)
-        hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d, lambda, blk_i1, blk_i2,
-                           n_blk);
+        hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d, blk_i1, blk_i2, n_blk);
 }
 
-void launch_ba_solve(const BaDev& d, hipStream_t s) {
-    if (d.n_free + 1 <= kSolveMaxNB)
-        hipLaunchKernelGGL(ba_solve_blocked_kernel, dim3(1), dim3(kSolveThreads), 0, s, d);
+static void launch_ba_solve(const BaDev& d, hipStream_t s) {
+    const int NB = d.n_free + 1, nblk = NB * (NB + 1) / 2 - 1;
+    if (nblk <= 256)
+        hipLaunchKernelGGL((ba_solve_reg_kernel<256, 1>), dim3(1), dim3(256), 0, s, d);
+    else if (nblk <= 512)
+        hipLaunchKernelGGL((ba_solve_reg_kernel<512, 1>), dim3(1), dim3(512), 0, s, d);
+    else if (NB <= kSolveMaxNB)
+        hipLaunchKernelGGL((ba_solve_reg_kernel<512, 2>), dim3(1), dim3(512), 0, s, d);
     else
         hipLaunchKernelGGL(ba_solve_global_kernel, dim3(1), dim3(1024), 0, s, d);
 }
 
 // ---------------- back-substitution + manifold update into the trial buffers + scale partials ----------------
-__global__ __launch_bounds__(256) void ba_update_kernel(BaDev d, double lambda, const BaPose* __restrict__ poses,
-                                                         const double* __restrict__ points,
-                                                         BaPose* __restrict__ poses_trial,
-                                                         double* __restrict__ points_trial) {
+__global__ __launch_bounds__(256) void ba_update_kernel(BaDev d) {
     __shared__ double s_tmp[16];
+    const BaLm lm = *d.lm;
+    if (!lm.active) return;
+    const double lambda = lm.lambda;
+    const BaPose* __restrict__ poses = d.pose[lm.cur];
+    const double* __restrict__ points = d.pt[lm.cur];
+    BaPose* __restrict__ poses_trial = d.pose[lm.cur ^ 1];
+    double* __restrict__ points_trial = d.pt[lm.cur ^ 1];
     double scale = 0.0;  // computeScale: sum x (lambda x + b)
     const double* xp = d.bs;
     // landmarks: 8 lanes each (xl = Dinv (bl - sum_e W_e^T x_pose(e))), then one thread per keyframe
@@ -762,10 +854,108 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d, double lambda, 
     if (threadIdx.x == 0) d.partial[kBaPartialScale + blockIdx.x] = t;
 }
 
-void launch_ba_update(const BaDev& d, double lambda, const BaPose* poses, const double* points, BaPose* poses_trial,
-                      double* points_trial, int n_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(ba_update_kernel, dim3(n_blocks), dim3(256), 0, s, d, lambda, poses, points, poses_trial,
-                       points_trial);
+// ---------------- Levenberg-Marquardt control on the device ----------------
+// Start of SparseOptimizer::optimize(iterations): chi2 of the current estimate (the error kernel ran on it),
+// computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180: tau * max diagonal, tau = 1e-5).
+__global__ __launch_bounds__(256) void ba_stage_begin_kernel(BaDev d, int nb_err, int iterations, BaLm* __restrict__ lm_host) {
+    __shared__ double s_tmp[16];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb_err; i += 256) v += d.partial[kBaPartialChi + i];
+    const double chi = block_sum(v, s_tmp);
+    if (threadIdx.x == 0) {
+        BaLm& lm = *d.lm;
+        lm.currentChi = chi;
+        lm.iniChi = chi;
+        lm.tempChi = chi;
+        lm.chi_out = chi;
+        lm.chi_begin = chi;
+        lm.rho = 0.0;
+        lm.lambda = 1e-5 * d.partial[kBaMaxDiag];
+        lm.ni = 2.0;
+        lm.nBad = 0;
+        lm.it = 0;
+        lm.iterations = iterations;
+        lm.qmax = 0;
+        lm.done = 0;
+        lm.need_build = 0;
+        lm.active = iterations > 0 ? 1 : 0;
+        if (lm_host) *lm_host = lm;
+    }
+}
+
+void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_host, hipStream_t s) {
+    hipLaunchKernelGGL(ba_stage_begin_kernel, dim3(1), dim3(256), 0, s, d, nb_err, iterations, lm_host);
+}
+
+// End of a trial: OptimizationAlgorithmLevenberg::solve's accept / reject (optimization_algorithm_levenberg.cpp:
+// 95-148) and SparseOptimizer::optimize's stopping rules (sparse_optimizer.cpp:355-420).
+__global__ __launch_bounds__(256) void ba_trial_decide_kernel(BaDev d, int nb_err, int nb_upd,
+                                                              const uint8_t* __restrict__ abort_flag,
+                                                              BaLm* __restrict__ lm_host) {
+    __shared__ double s_tmp[16];
+    if (!d.lm->active) return;
+    double c = 0.0, sc = 0.0;
+    for (int i = threadIdx.x; i < nb_err; i += 256) c += d.partial[kBaPartialChi + i];
+    for (int i = threadIdx.x; i < nb_upd; i += 256) sc += d.partial[kBaPartialScale + i];
+    const double chi = block_sum(c, s_tmp);
+    const double scale_sum = block_sum(sc, s_tmp);
+    if (threadIdx.x != 0) return;
+    BaLm lm = *d.lm;
+    const bool abort = abort_flag && *reinterpret_cast<const volatile uint8_t*>(abort_flag);
+    const bool solved = d.partial[kBaSolveOk] != 0.0;
+    double tempChi = solved ? chi : 1.7976931348623157e308;
+    double rho = (lm.currentChi - tempChi) / (scale_sum + 1e-3);
+    const bool accepted = rho > 0 && isfinite(tempChi);
+    if (accepted) {
+        double alpha = 1. - pow(2 * rho - 1, 3);
+        alpha = fmin(alpha, 2. / 3.);
+        lm.lambda *= fmax(1. / 3., alpha);
+        lm.ni = 2;
+        lm.currentChi = tempChi;
+        lm.cur ^= 1;  // discardTop: the trial becomes the estimate
+    } else {
+        lm.lambda *= lm.ni;  // pop: the estimate stays, the stored errors describe the rejected trial
+        lm.ni *= 2;
+    }
+    lm.tempChi = tempChi;
+    lm.rho = rho;
+    lm.qmax++;
+    lm.trials++;
+    if (!(rho < 0 && lm.qmax < 10 && !abort)) {  // the iteration is over
+        lm.done++;
+        lm.chi_out = tempChi;
+        bool ok = true;
+        if (lm.qmax == 10 || rho == 0) {
+            ok = false;
+        } else {
+            if ((lm.iniChi - lm.currentChi) * 1e3 < lm.iniChi) lm.nBad++; else lm.nBad = 0;
+            if (lm.nBad >= 3) ok = false;
+        }
+        lm.it++;
+        if (lm.it < lm.iterations && !abort && ok) {
+            lm.need_build = accepted ? 1 : 0;
+            lm.iniChi = lm.currentChi;
+            lm.qmax = 0;
+        } else {
+            lm.active = 0;
+        }
+    } else {
+        lm.need_build = 0;
+    }
+    *d.lm = lm;
+    if (lm_host) *lm_host = lm;
+}
+
+void launch_ba_trial(const BaDev& d, const int* blk_i1, const int* blk_i2, int n_blk, int nb_err, int nb_upd,
+                     const uint8_t* abort_flag, BaLm* lm_host, hipEvent_t ev0, hipEvent_t ev1, hipStream_t s) {
+    launch_ba_build(d, true, s);
+    launch_ba_schur(d, blk_i1, blk_i2, n_blk, s);
+    if (ev0) (void)hipEventRecord(ev0, s);
+    launch_ba_solve(d, s);
+    if (ev1) (void)hipEventRecord(ev1, s);
+    hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, s, d);
+    launch_ba_errors(d, 1, true, nb_err, s);
+    hipLaunchKernelGGL(ba_trial_decide_kernel, dim3(1), dim3(256), 0, s, d, nb_err, nb_upd, abort_flag, lm_host);
 }
 
 }  // namespace so
