@@ -88,6 +88,43 @@ class TrackingWorkload:
             self.history.pop(0)
 
 
+class LocalMapper:
+    """The reference runs local BA on its own thread (LocalMapping::Run, code/src/LocalMapping.cc:53-110) next to
+    Tracking; this is that thread: windows are queued by the tracking loop and optimised in order, two at most
+    waiting (the tracking loop blocks when local mapping falls behind, so every window is paid for)."""
+
+    def __init__(self, fn):
+        import queue
+        import threading
+        self.fn, self.q = fn, queue.Queue(maxsize=2)
+        self.infos, self.busy_s = [], 0.0
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                self.q.task_done()
+                return
+            t0 = time.perf_counter()
+            info = self.fn()
+            if job:
+                self.busy_s += time.perf_counter() - t0
+                self.infos.append(info)
+            self.q.task_done()
+
+    def submit(self, timed):
+        self.q.put(bool(timed) or 0)
+
+    def drain(self):
+        self.q.join()
+
+    def close(self):
+        self.q.put(None)
+        self.th.join()
+
+
 def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window, budget_s=20.0):
     """The same per-frame workload through the CPU oracle ("port": the reference has no CPU extractor and its
     g2o needs Eigen), one thread like the reference's Tracking / LocalMapping, bounded sample."""
@@ -96,6 +133,7 @@ def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window
     wl = TrackingWorkload(stream, size, workload_seed)
     k, d = oracle_py.extract(cfg, host_frames[0])
     wl.push(0, k, d)
+    lm = LocalMapper(lambda: oracle_py.bundle_adjust(lba_window))
     n, t0, n_lba = 0, time.perf_counter(), 0
     while True:
         t = n + 1
@@ -105,16 +143,18 @@ def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window
         oracle_py.search_by_projection_lastframe(F, last, 15.0, True)
         oracle_py.search_by_projection_mappoints(F, mps, 1.0, 0.8)
         if t % LBA_EVERY == 0:
-            oracle_py.bundle_adjust(lba_window)
+            lm.submit(True)
             n_lba += 1
         wl.push(t, kps, desc)
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 600:
             break
+    lm.drain()
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames %dx%d: CPU oracle extract (nFeatures %d) + M2 + M1 per frame, %d LBA-M windows "
-                      "(1 per %d frames); gcc -O2, 1 thread; host has %d cores"
+    lm.close()
+    return {"value": n / dt, "unit": "frames/s", "cores": 2, "kind": "port",
+            "sample": "%d frames %dx%d: CPU oracle extract (nFeatures %d) + M2 + M1 per frame on the tracking thread, "
+                      "%d LBA-M windows (1 per %d frames) on a local-mapping thread; gcc -O2; host has %d cores"
                       % (n, size[0], size[1], nfeatures, n_lba, LBA_EVERY, os.cpu_count())}
 
 
@@ -172,6 +212,8 @@ def main():
            "n_lba": 0, "lba_gpu_ms": 0.0, "match_kernel_ms": 0.0, "n_xchg": 0, "solve_ms": 0.0, "n_solves": 0}
     stage_ms = {}
 
+    mapper = LocalMapper(lambda: ba.LocalBundleAdjustment(lba_window)["info"])
+
     def step(t, timed):
         t0 = time.perf_counter()
         kps, desc = ex.run_device(dev_frames[t % n_distinct].data_ptr(), w, h, w)
@@ -183,9 +225,8 @@ def main():
         nm1, _ = m1.SearchByProjectionMapPoints(F, mps, 1.0)
         k1 = m1.last_kernel_ms()
         t2 = time.perf_counter()
-        lba_info = None
         if t % LBA_EVERY == 0:
-            lba_info = ba.LocalBundleAdjustment(lba_window)["info"]
+            mapper.submit(timed)  # blocks only when two windows are already waiting
         t3 = time.perf_counter()
         if xchg is not None and t % args.exchange_every == 0:
             xchg.exchange_and_match(desc, m1)
@@ -196,9 +237,6 @@ def main():
             acc["lba_ms"] += (t3 - t2) * 1e3; acc["xchg_ms"] += (t4 - t3) * 1e3
             acc["n_kp"] += len(kps); acc["n_m2"] += nm2; acc["n_m1"] += nm1
             acc["match_kernel_ms"] += k1 + k2
-            if lba_info:
-                acc["n_lba"] += 1; acc["lba_gpu_ms"] += lba_info["gpu_ms"]
-                acc["solve_ms"] += lba_info["solve_ms"]; acc["n_solves"] += lba_info["n_solves"]
             for k, v in ex.profile().items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v
 
@@ -218,8 +256,14 @@ def main():
     for _ in range(args.steps):
         step(t, True)
         t += 1
+    mapper.drain()  # every queued window is optimised inside the timed region
     barrier()
     dt = time.perf_counter() - t0
+    mapper.close()
+    for inf in mapper.infos:
+        acc["n_lba"] += 1; acc["lba_gpu_ms"] += inf["gpu_ms"]
+        acc["solve_ms"] += inf["solve_ms"]; acc["n_solves"] += inf["n_solves"]
+    acc["lba_busy_ms"] = mapper.busy_s * 1e3
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -262,7 +306,8 @@ def main():
             "fps_per_agent": steps / dt,
             "config": {
                 "workload": "BASELINE.json configs[1] (single agent per GPU, 752x480 EuRoC-sized stream, HIP ORB "
-                            "extract nFeatures %d + HIP match M2+M1) plus HIP LocalBA (LBA-M window every %d frames)"
+                            "extract nFeatures %d + HIP match M2+M1 on the tracking thread) plus HIP LocalBA (LBA-M window every "
+                            "%d frames) on a local-mapping thread, as in the reference"
                             % (nfeatures, LBA_EVERY) if args.size == "euroc" else
                             "KITTI-sized 1241x376 stream, nFeatures %d, same per-frame path" % nfeatures,
                 "agents": world, "frame": [w, h], "keypoints_per_frame": acc["n_kp"] / steps,
@@ -270,8 +315,9 @@ def main():
                 "lba_windows": acc["n_lba"], "lba_edges": int(len(lba_window["edge_pose"])),
                 "descriptor_exchanges": acc["n_xchg"],
                 "host_ms_per_frame": {"extract": acc["extract_ms"] / steps, "match": acc["match_ms"] / steps,
-                                      "lba_amortised": acc["lba_ms"] / steps, "exchange_amortised": acc["xchg_ms"] / steps},
-                "lba_ms_per_window": {"wall": acc["lba_ms"] / max(acc["n_lba"], 1),
+                                      "lba_submit_wait": acc["lba_ms"] / steps,
+                                      "lba_thread_busy": acc["lba_busy_ms"] / steps, "exchange_amortised": acc["xchg_ms"] / steps},
+                "lba_ms_per_window": {"wall": acc["lba_busy_ms"] / max(acc["n_lba"], 1),
                                       "gpu": acc["lba_gpu_ms"] / max(acc["n_lba"], 1)},
                 "match_kernel_ms_per_frame": acc["match_kernel_ms"] / steps,
                 "extract_stage_ms_per_frame": {k: v / steps for k, v in stage_ms.items()}},

@@ -115,179 +115,53 @@ struct so_ba {
     uint8_t* h_abort = nullptr;  // host-mapped forceStopFlag the decision kernel polls
     uint8_t* h_abort_dev = nullptr;
 
-    Buf d_pose[2], d_pt[2], d_intr, d_epose, d_ept, d_obs, d_w, d_active, d_err, d_chi2, d_ptoff, d_ptact, d_hidx,
-        d_freepose, d_poseoff, d_poseedges, d_blkoff, d_blki1, d_blki2, d_pk1, d_pk2, d_Hpp, d_bp, d_Hll, d_bl, d_W,
-        d_Dinv, d_db, d_BDinv, d_S, d_bs, d_xl, d_partial, d_depth, d_po, d_lm;
+    // d_in: the problem as one block (see Layout in so_bundle_adjust), staged in pinned h_in and moved with one
+    // copy; d_out / h_out: the result block coming back the same way; the rest is device-only working storage
+    Buf d_in, d_out, d_pose1, d_pt1, d_err, d_chi2, d_tab, d_Hpp, d_bp, d_Hll, d_bl, d_W, d_Dinv, d_db, d_BDinv, d_S,
+        d_bs, d_xl, d_partial, d_po, d_lm;
+    void* h_in = nullptr;
+    size_t h_in_cap = 0;
+    void* h_out = nullptr;
+    size_t h_out_cap = 0;
     uint8_t* h_po = nullptr;      // pinned staging for PoseOptimization
     size_t h_po_cap = 0;
     std::vector<Buf*> all() {
-        return {&d_pose[0], &d_pose[1], &d_pt[0], &d_pt[1], &d_intr, &d_epose, &d_ept, &d_obs, &d_w, &d_active, &d_err,
-                &d_chi2, &d_ptoff, &d_ptact, &d_hidx, &d_freepose, &d_poseoff, &d_poseedges, &d_blkoff, &d_blki1,
-                &d_blki2, &d_pk1, &d_pk2, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv, &d_db, &d_BDinv, &d_S, &d_bs,
-                &d_xl, &d_partial, &d_depth, &d_po, &d_lm};
+        return {&d_in, &d_out, &d_pose1, &d_pt1, &d_err, &d_chi2, &d_tab, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv,
+                &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm};
     }
 };
 
 namespace {
 
-template <typename T>
-int upload(so_ba* b, Buf& buf, const std::vector<T>& v) {
-    int rc = buf.ensure(sizeof(T) * std::max<size_t>(v.size(), 1));
-    if (rc) return rc;
-    if (!v.empty()) SO_HIP(hipMemcpyAsync(buf.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, b->stream));
+int ensure_pinned(void** p, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return SO_OK;
+    if (*p) SO_HIP(hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    SO_HIP(hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
     return SO_OK;
 }
 
-struct Problem {  // host-side working copy, edges sorted by point
-    int n_poses = 0, n_points = 0, n_edges = 0;
-    std::vector<int> perm;  // sorted position -> original edge index
-    std::vector<int> e_pose, e_point;
-    std::vector<int> pt_off;
-    std::vector<uint8_t> fixed;
-    std::vector<int> level;  // per sorted edge
+struct Layout {  // offsets into a staging block, 256-byte aligned
+    size_t total = 0;
+    size_t add(size_t bytes) {
+        const size_t at = total;
+        total = (total + bytes + 255) & ~(size_t)255;
+        return at;
+    }
 };
-
-struct Stage {
-    int n_free = 0, n_blk = 0, n_active_edges = 0;
-    std::vector<uint8_t> e_active, pt_active;
-    std::vector<int> pose_hidx, free_pose, pose_off, pose_edges, blk_off, blk_i1, blk_i2, pair_k1, pair_k2;
-};
-
-// SparseOptimizer::initializeOptimization(0) + buildIndexMapping (sparse_optimizer.cpp:166-270) and the CSR
-// lists the kernels reduce over.
-void build_stage(const Problem& P, Stage& S) {
-    S.e_active.assign((size_t)P.n_edges, 0);
-    S.pt_active.assign((size_t)P.n_points, 0);
-    std::vector<uint8_t> pose_touched((size_t)P.n_poses, 0);
-    S.n_active_edges = 0;
-    for (int e = 0; e < P.n_edges; e++)
-        if (P.level[(size_t)e] == 0) {
-            S.e_active[(size_t)e] = 1;
-            S.pt_active[(size_t)P.e_point[(size_t)e]] = 1;
-            pose_touched[(size_t)P.e_pose[(size_t)e]] = 1;
-            S.n_active_edges++;
-        }
-    S.pose_hidx.assign((size_t)P.n_poses, -1);
-    S.free_pose.clear();
-    for (int i = 0; i < P.n_poses; i++)
-        if (pose_touched[(size_t)i] && !P.fixed[(size_t)i]) {
-            S.pose_hidx[(size_t)i] = (int)S.free_pose.size();
-            S.free_pose.push_back(i);
-        }
-    S.n_free = (int)S.free_pose.size();
-    // free pose -> active edges (ascending sorted-edge index)
-    S.pose_off.assign((size_t)S.n_free + 1, 0);
-    for (int e = 0; e < P.n_edges; e++)
-        if (S.e_active[(size_t)e]) {
-            const int h = S.pose_hidx[(size_t)P.e_pose[(size_t)e]];
-            if (h >= 0) S.pose_off[(size_t)h + 1]++;
-        }
-    for (int i = 0; i < S.n_free; i++) S.pose_off[(size_t)i + 1] += S.pose_off[(size_t)i];
-    S.pose_edges.assign((size_t)S.pose_off[(size_t)S.n_free], 0);
-    {
-        std::vector<int> fill(S.pose_off.begin(), S.pose_off.end() - 1);
-        for (int e = 0; e < P.n_edges; e++)
-            if (S.e_active[(size_t)e]) {
-                const int h = S.pose_hidx[(size_t)P.e_pose[(size_t)e]];
-                if (h >= 0) S.pose_edges[(size_t)fill[(size_t)h]++] = e;
-            }
-    }
-    // upper blocks of the reduced camera system and the edge pairs that feed them
-    const int nf = S.n_free;
-    S.n_blk = nf * (nf + 1) / 2;
-    S.blk_i1.resize((size_t)S.n_blk);
-    S.blk_i2.resize((size_t)S.n_blk);
-    {
-        int g = 0;
-        for (int i1 = 0; i1 < nf; i1++)
-            for (int i2 = i1; i2 < nf; i2++, g++) {
-                S.blk_i1[(size_t)g] = i1;
-                S.blk_i2[(size_t)g] = i2;
-            }
-    }
-    auto blk_id = [nf](int i1, int i2) { return i1 * nf - i1 * (i1 - 1) / 2 + (i2 - i1); };
-    S.blk_off.assign((size_t)S.n_blk + 1, 0);
-    std::vector<std::pair<int, int>> obs;  // (hessian index, edge) of one landmark
-    for (int pass = 0; pass < 2; pass++) {
-        std::vector<int> fill;
-        if (pass == 1) {
-            for (int g = 0; g < S.n_blk; g++) S.blk_off[(size_t)g + 1] += S.blk_off[(size_t)g];
-            S.pair_k1.assign((size_t)S.blk_off[(size_t)S.n_blk], 0);
-            S.pair_k2.assign((size_t)S.blk_off[(size_t)S.n_blk], 0);
-            fill.assign(S.blk_off.begin(), S.blk_off.end() - 1);
-        }
-        for (int il = 0; il < P.n_points; il++) {
-            if (!S.pt_active[(size_t)il]) continue;
-            obs.clear();
-            for (int e = P.pt_off[(size_t)il]; e < P.pt_off[(size_t)il + 1]; e++)
-                if (S.e_active[(size_t)e]) {
-                    const int h = S.pose_hidx[(size_t)P.e_pose[(size_t)e]];
-                    if (h >= 0) obs.emplace_back(h, e);
-                }
-            std::sort(obs.begin(), obs.end());
-            for (size_t a = 0; a < obs.size(); a++)
-                for (size_t c = a; c < obs.size(); c++) {
-                    const int g = blk_id(obs[a].first, obs[c].first);
-                    if (pass == 0) {
-                        S.blk_off[(size_t)g + 1]++;
-                    } else {
-                        const int o = fill[(size_t)g]++;
-                        S.pair_k1[(size_t)o] = obs[a].second;
-                        S.pair_k2[(size_t)o] = obs[c].second;
-                    }
-                }
-        }
-    }
-}
 
 struct Run {
     so_ba* b;
     BaDev d{};
-    Problem P;
-    Stage S;
+    int n_free = 0, n_active_edges = 0;
     int nb_err = 1, nb_upd = 1;
     int blocks_enqueued = 0;  // trial blocks of this call so far (indexes the solve-event pool)
     const volatile uint8_t* stop = nullptr;
     bool terminate() const { return stop && *stop; }
 };
-
-int upload_stage(Run& r) {
-    so_ba* b = r.b;
-    Stage& S = r.S;
-    int rc;
-    if ((rc = upload(b, b->d_active, S.e_active))) return rc;
-    if ((rc = upload(b, b->d_ptact, S.pt_active))) return rc;
-    if ((rc = upload(b, b->d_hidx, S.pose_hidx))) return rc;
-    if ((rc = upload(b, b->d_freepose, S.free_pose))) return rc;
-    if ((rc = upload(b, b->d_poseoff, S.pose_off))) return rc;
-    if ((rc = upload(b, b->d_poseedges, S.pose_edges))) return rc;
-    if ((rc = upload(b, b->d_blkoff, S.blk_off))) return rc;
-    if ((rc = upload(b, b->d_blki1, S.blk_i1))) return rc;
-    if ((rc = upload(b, b->d_blki2, S.blk_i2))) return rc;
-    if ((rc = upload(b, b->d_pk1, S.pair_k1))) return rc;
-    if ((rc = upload(b, b->d_pk2, S.pair_k2))) return rc;
-    const size_t nf = (size_t)std::max(S.n_free, 1), n = 6 * nf;
-    if ((rc = b->d_Hpp.ensure(sizeof(double) * 36 * nf))) return rc;
-    if ((rc = b->d_bp.ensure(sizeof(double) * 6 * nf))) return rc;
-    if ((rc = b->d_S.ensure(sizeof(double) * n * n))) return rc;
-    if ((rc = b->d_bs.ensure(sizeof(double) * n))) return rc;
-    BaDev& d = r.d;
-    d.n_free = S.n_free;
-    d.e_active = b->d_active.as<uint8_t>();
-    d.pt_active = b->d_ptact.as<uint8_t>();
-    d.pose_hidx = b->d_hidx.as<int>();
-    d.free_pose = b->d_freepose.as<int>();
-    d.pose_off = b->d_poseoff.as<int>();
-    d.pose_edges = b->d_poseedges.as<int>();
-    d.blk_off = b->d_blkoff.as<int>();
-    d.pair_k1 = b->d_pk1.as<int>();
-    d.pair_k2 = b->d_pk2.as<int>();
-    d.Hpp = b->d_Hpp.as<double>();
-    d.bp = b->d_bp.as<double>();
-    d.S = b->d_S.as<double>();
-    d.bs = b->d_bs.as<double>();
-    return SO_OK;
-}
 
 // Wait for the stream; with a forceStopFlag, poll it meanwhile and forward it to the device.
 int wait_stream(Run& r) {
@@ -311,7 +185,7 @@ int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
     so_ba* b = r.b;
     hipStream_t s = b->stream;
     *done_out = 0;
-    if (r.S.n_free + (r.S.n_active_edges > 0 ? 1 : 0) == 0) return SO_OK;  // 0 vertices to optimize
+    if (r.n_free + (r.n_active_edges > 0 ? 1 : 0) == 0) return SO_OK;  // 0 vertices to optimize
     launch_ba_errors(r.d, 0, false, r.nb_err, s);
     launch_ba_build(r.d, false, s);
     launch_ba_maxdiag(r.d, s);
@@ -319,23 +193,20 @@ int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
     SO_HIP(hipGetLastError());
     const int trials_before = b->h_lm->trials, first_block = r.blocks_enqueued;  // h_lm: state after the last wait
     int budget = iterations, rc;
+    BaLm lm;
     for (;;) {
         for (int i = 0; i < budget; i++) {
             const int k = r.blocks_enqueued++;
             const bool timed = k < so_ba::kSolveEvents;
-            launch_ba_trial(r.d, b->d_blki1.as<int>(), b->d_blki2.as<int>(), r.S.n_blk, r.nb_err, r.nb_upd,
-                            r.stop ? b->h_abort_dev : nullptr, b->h_lm_dev, timed ? b->ev_solve[2 * k] : nullptr,
-                            timed ? b->ev_solve[2 * k + 1] : nullptr, s);
+            launch_ba_trial(r.d, r.nb_err, r.nb_upd, r.stop ? b->h_abort_dev : nullptr, b->h_lm_dev,
+                            timed ? b->ev_solve[2 * k] : nullptr, timed ? b->ev_solve[2 * k + 1] : nullptr, s);
         }
         SO_HIP(hipGetLastError());
         if ((rc = wait_stream(r))) return rc;
-        BaLm lm;
         memcpy(&lm, b->h_lm, sizeof(lm));
         if (!lm.active) break;
         budget = std::max(1, lm.iterations - lm.it);
     }
-    BaLm lm;
-    memcpy(&lm, b->h_lm, sizeof(lm));
     const int real = lm.trials - trials_before;  // the first `real` blocks of this stage ran, the rest returned at once
     for (int k = first_block; k < first_block + real && k < so_ba::kSolveEvents; k++) {
         float ms = 0.f;
@@ -387,6 +258,8 @@ void so_ba_destroy(so_ba* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (Buf* q : b->all()) q->release();
     if (b->h_lm) (void)hipHostFree(b->h_lm);
+    if (b->h_in) (void)hipHostFree(b->h_in);
+    if (b->h_out) (void)hipHostFree(b->h_out);
     if (b->h_abort) (void)hipHostFree(b->h_abort);
     for (hipEvent_t ev : b->ev_solve)
         if (ev) (void)hipEventDestroy(ev);
@@ -422,8 +295,9 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     if ((p->n_poses > 0 && (!p->Tcw || !p->fixed || !p->intr)) || (p->n_points > 0 && !p->Xw) ||
         (p->n_edges > 0 && (!p->edge_pose || !p->edge_point || !p->obs || !p->inv_sigma2)))
         return SO_ERR_INVALID_ARG;
-    for (int e = 0; e < p->n_edges; e++)
-        if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) {
+    const int nP = p->n_poses, nL = p->n_points, nE = p->n_edges;
+    for (int e = 0; e < nE; e++)
+        if (p->edge_pose[e] < 0 || p->edge_pose[e] >= nP || p->edge_point[e] < 0 || p->edge_point[e] >= nL) {
             last_error_ref() = "edge references a vertex out of range";
             return SO_ERR_INVALID_ARG;
         }
@@ -436,22 +310,16 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     Run r;
     r.b = b;
     r.stop = stop;
-    Problem& P = r.P;
-    P.n_poses = p->n_poses;
-    P.n_points = p->n_points;
-    P.n_edges = p->n_edges;
-    P.fixed.assign(p->fixed, p->fixed + p->n_poses);
-
-    std::vector<BaPose> h_pose((size_t)P.n_poses);
-    for (int i = 0; i < P.n_poses; i++) pose_from_Tcw(p->Tcw + 12 * (size_t)i, h_pose[(size_t)i]);  // toSE3Quat
-    std::vector<double> h_pt((size_t)P.n_points * 3);
-    for (size_t i = 0; i < h_pt.size(); i++) h_pt[i] = (double)p->Xw[i];  // toVector3d
 
     auto finish_untouched = [&]() {  // Optimizer.cc:631-633: return before optimising
-        for (int i = 0; i < P.n_poses; i++) pose_to_Tcw(h_pose[(size_t)i], Tcw_out + 12 * (size_t)i);
-        for (size_t i = 0; i < h_pt.size(); i++) Xw_out[i] = (float)h_pt[i];
-        if (edge_outlier) memset(edge_outlier, 0, (size_t)P.n_edges);
-        if (edge_chi2) for (int e = 0; e < P.n_edges; e++) edge_chi2[e] = 0.0;
+        for (int i = 0; i < nP; i++) {
+            BaPose P;
+            pose_from_Tcw(p->Tcw + 12 * (size_t)i, P);  // toSE3Quat and back, like the reference's recovery loop
+            pose_to_Tcw(P, Tcw_out + 12 * (size_t)i);
+        }
+        for (size_t i = 0; i < (size_t)nL * 3; i++) Xw_out[i] = (float)(double)p->Xw[i];
+        if (edge_outlier) memset(edge_outlier, 0, (size_t)nE);
+        if (edge_chi2) for (int e = 0; e < nE; e++) edge_chi2[e] = 0.0;
         inf.wall_ms = (float)(now_ms() - t_begin);
         if (info) *info = inf;
     };
@@ -460,108 +328,180 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         finish_untouched();
         return SO_OK;
     }
-    if (P.n_edges == 0) {
+    if (nE == 0) {
         finish_untouched();
         return SO_OK;
     }
 
-    // stable counting sort of the edges by landmark: a landmark's observations become contiguous
-    P.pt_off.assign((size_t)P.n_points + 1, 0);
-    for (int e = 0; e < P.n_edges; e++) P.pt_off[(size_t)p->edge_point[e] + 1]++;
-    for (int i = 0; i < P.n_points; i++) P.pt_off[(size_t)i + 1] += P.pt_off[(size_t)i];
-    P.perm.assign((size_t)P.n_edges, 0);
-    {
-        std::vector<int> fill(P.pt_off.begin(), P.pt_off.end() - 1);
-        for (int e = 0; e < P.n_edges; e++) P.perm[(size_t)fill[(size_t)p->edge_point[e]]++] = e;
-    }
-    P.e_pose.resize((size_t)P.n_edges);
-    P.e_point.resize((size_t)P.n_edges);
-    std::vector<double> h_obs((size_t)P.n_edges * 2), h_w((size_t)P.n_edges);
-    for (int k = 0; k < P.n_edges; k++) {
-        const int e = P.perm[(size_t)k];
-        P.e_pose[(size_t)k] = p->edge_pose[e];
-        P.e_point[(size_t)k] = p->edge_point[e];
-        h_obs[2 * (size_t)k] = (double)p->obs[2 * (size_t)e];
-        h_obs[2 * (size_t)k + 1] = (double)p->obs[2 * (size_t)e + 1];
-        h_w[(size_t)k] = (double)p->inv_sigma2[e];
-    }
-    P.level.assign((size_t)P.n_edges, 0);
-    std::vector<double> h_intr((size_t)P.n_poses * 4);
-    for (size_t i = 0; i < h_intr.size(); i++) h_intr[i] = (double)p->intr[i];
-
-    const bool trace = getenv("SWARMORB_BA_TRACE") != nullptr;
-    const double t_sorted = now_ms();
-    build_stage(P, r.S);
-    const double t_stage1 = now_ms();
-    if (6 * r.S.n_free > kMaxReducedDim) {
+    // SparseOptimizer::initializeOptimization(0) + buildIndexMapping (sparse_optimizer.cpp:166-270): every edge is
+    // at level 0, a keyframe gets a hessian index if it is not fixed and has an edge
+    std::vector<uint8_t> touched((size_t)nP, 0);
+    for (int e = 0; e < nE; e++) touched[(size_t)p->edge_pose[e]] = 1;
+    int nf = 0;
+    for (int i = 0; i < nP; i++) nf += (touched[(size_t)i] && !p->fixed[i]) ? 1 : 0;
+    if (6 * nf > kMaxReducedDim) {
         last_error_ref() = "reduced camera system too large for the dense solver (6*n_free > 6144)";
         return SO_ERR_CAPACITY;
     }
+    r.n_free = nf;
+    r.n_active_edges = nE;
 
+    // ---- the problem as ONE staging block (pinned), mirrored by ONE device block ----
+    Layout L;
+    const size_t o_pose = L.add(sizeof(BaPose) * (size_t)nP), o_pt = L.add(sizeof(double) * 3 * (size_t)nL),
+                 o_intr = L.add(sizeof(double) * 4 * (size_t)nP), o_obs = L.add(sizeof(double) * 2 * (size_t)nE),
+                 o_w = L.add(sizeof(double) * (size_t)nE), o_epose = L.add(sizeof(int) * (size_t)nE),
+                 o_ept = L.add(sizeof(int) * (size_t)nE), o_ptoff = L.add(sizeof(int) * ((size_t)nL + 1)),
+                 o_hidx = L.add(sizeof(int) * (size_t)nP), o_free = L.add(sizeof(int) * (size_t)std::max(nf, 1)),
+                 o_poseoff = L.add(sizeof(int) * ((size_t)nf + 1)), o_pedges = L.add(sizeof(int) * (size_t)nE),
+                 o_eact = L.add((size_t)nE), o_ptact = L.add((size_t)std::max(nL, 1));
     int rc;
+    if ((rc = ensure_pinned(&b->h_in, &b->h_in_cap, L.total))) return rc;
+    if ((rc = b->d_in.ensure(L.total))) return rc;
+    uint8_t* hb = (uint8_t*)b->h_in;
+    BaPose* h_pose = (BaPose*)(hb + o_pose);
+    double* h_pt = (double*)(hb + o_pt);
+    double* h_intr = (double*)(hb + o_intr);
+    double* h_obs = (double*)(hb + o_obs);
+    double* h_w = (double*)(hb + o_w);
+    int* h_epose = (int*)(hb + o_epose);
+    int* h_ept = (int*)(hb + o_ept);
+    int* h_ptoff = (int*)(hb + o_ptoff);
+    int* h_hidx = (int*)(hb + o_hidx);
+    int* h_free = (int*)(hb + o_free);
+    int* h_poseoff = (int*)(hb + o_poseoff);
+    int* h_pedges = (int*)(hb + o_pedges);
+    uint8_t* h_eact = hb + o_eact;
+    uint8_t* h_ptact = hb + o_ptact;
+
+    for (int i = 0; i < nP; i++) pose_from_Tcw(p->Tcw + 12 * (size_t)i, h_pose[i]);  // toSE3Quat
+    for (size_t i = 0; i < (size_t)nL * 3; i++) h_pt[i] = (double)p->Xw[i];          // toVector3d
+    for (size_t i = 0; i < (size_t)nP * 4; i++) h_intr[i] = (double)p->intr[i];
+    // stable counting sort of the edges by landmark: a landmark's observations become contiguous
+    for (int i = 0; i <= nL; i++) h_ptoff[i] = 0;
+    for (int e = 0; e < nE; e++) h_ptoff[p->edge_point[e] + 1]++;
+    for (int i = 0; i < nL; i++) h_ptoff[i + 1] += h_ptoff[i];
+    std::vector<int> perm((size_t)nE);  // sorted position -> original edge index
+    {
+        std::vector<int> fill(h_ptoff, h_ptoff + nL);
+        for (int e = 0; e < nE; e++) perm[(size_t)fill[(size_t)p->edge_point[e]]++] = e;
+    }
+    for (int i = 0, h = 0; i < nP; i++) {
+        h_hidx[i] = -1;
+        if (touched[(size_t)i] && !p->fixed[i]) {
+            h_hidx[i] = h;
+            h_free[h++] = i;
+        }
+    }
+    for (int i = 0; i <= nf; i++) h_poseoff[i] = 0;
+    {
+        std::vector<int> seen((size_t)nP, -1);  // the edge table holds one edge per (landmark, keyframe)
+        for (int k = 0; k < nE; k++) {
+            const int e = perm[(size_t)k], ip = p->edge_pose[e], il = p->edge_point[e];
+            h_epose[k] = ip;
+            h_ept[k] = il;
+            h_obs[2 * (size_t)k] = (double)p->obs[2 * (size_t)e];
+            h_obs[2 * (size_t)k + 1] = (double)p->obs[2 * (size_t)e + 1];
+            h_w[k] = (double)p->inv_sigma2[e];
+            h_eact[k] = 1;
+            if (seen[(size_t)ip] == il) {
+                last_error_ref() = "a landmark is observed twice by the same keyframe";
+                return SO_ERR_INVALID_ARG;
+            }
+            seen[(size_t)ip] = il;
+            if (h_hidx[ip] >= 0) h_poseoff[h_hidx[ip] + 1]++;
+        }
+    }
+    for (int i = 0; i < nf; i++) h_poseoff[i + 1] += h_poseoff[i];
+    {
+        std::vector<int> fill(h_poseoff, h_poseoff + nf);  // free keyframe -> its edges, ascending (= by landmark)
+        for (int k = 0; k < nE; k++) {
+            const int h = h_hidx[h_epose[k]];
+            if (h >= 0) h_pedges[fill[(size_t)h]++] = k;
+        }
+    }
+    for (int i = 0; i < nL; i++) h_ptact[i] = h_ptoff[i + 1] > h_ptoff[i];
+    const bool trace = getenv("SWARMORB_BA_TRACE") != nullptr;
+    const double t_staged = now_ms();
+
     hipStream_t s = b->stream;
-    if ((rc = upload(b, b->d_pose[0], h_pose))) return rc;
-    if ((rc = b->d_pose[1].ensure(sizeof(BaPose) * std::max<size_t>(h_pose.size(), 1)))) return rc;
-    if ((rc = upload(b, b->d_pt[0], h_pt))) return rc;
-    if ((rc = b->d_pt[1].ensure(sizeof(double) * std::max<size_t>(h_pt.size(), 1)))) return rc;
-    if ((rc = upload(b, b->d_intr, h_intr))) return rc;
-    if ((rc = upload(b, b->d_epose, P.e_pose))) return rc;
-    if ((rc = upload(b, b->d_ept, P.e_point))) return rc;
-    if ((rc = upload(b, b->d_obs, h_obs))) return rc;
-    if ((rc = upload(b, b->d_w, h_w))) return rc;
-    if ((rc = upload(b, b->d_ptoff, P.pt_off))) return rc;
-    const size_t nE = (size_t)P.n_edges, nL = (size_t)std::max(P.n_points, 1);
-    if ((rc = b->d_err.ensure(sizeof(double) * 2 * nE))) return rc;
-    if ((rc = b->d_chi2.ensure(sizeof(double) * nE))) return rc;
-    if ((rc = b->d_depth.ensure(sizeof(double) * nE))) return rc;
-    if ((rc = b->d_Hll.ensure(sizeof(double) * 9 * nL))) return rc;
-    if ((rc = b->d_bl.ensure(sizeof(double) * 3 * nL))) return rc;
-    if ((rc = b->d_Dinv.ensure(sizeof(double) * 9 * nL))) return rc;
-    if ((rc = b->d_db.ensure(sizeof(double) * 3 * nL))) return rc;
-    if ((rc = b->d_xl.ensure(sizeof(double) * 3 * nL))) return rc;
-    if ((rc = b->d_W.ensure(sizeof(double) * 18 * nE))) return rc;
-    if ((rc = b->d_BDinv.ensure(sizeof(double) * 18 * nE))) return rc;
+    SO_HIP(hipMemcpyAsync(b->d_in.p, b->h_in, L.total, hipMemcpyHostToDevice, s));
+    const size_t sE = (size_t)nE, sL = (size_t)std::max(nL, 1), sF = (size_t)std::max(nf, 1), n = 6 * sF;
+    if ((rc = b->d_pose1.ensure(sizeof(BaPose) * (size_t)std::max(nP, 1)))) return rc;
+    if ((rc = b->d_pt1.ensure(sizeof(double) * 3 * sL))) return rc;
+    if ((rc = b->d_err.ensure(sizeof(double) * 2 * sE))) return rc;
+    if ((rc = b->d_chi2.ensure(sizeof(double) * sE))) return rc;
+    if ((rc = b->d_tab.ensure(sizeof(int) * sL * sF))) return rc;
+    if ((rc = b->d_Hll.ensure(sizeof(double) * 9 * sL))) return rc;
+    if ((rc = b->d_bl.ensure(sizeof(double) * 3 * sL))) return rc;
+    if ((rc = b->d_Dinv.ensure(sizeof(double) * 9 * sL))) return rc;
+    if ((rc = b->d_db.ensure(sizeof(double) * 3 * sL))) return rc;
+    if ((rc = b->d_xl.ensure(sizeof(double) * 3 * sL))) return rc;
+    if ((rc = b->d_W.ensure(sizeof(double) * 18 * sE))) return rc;
+    if ((rc = b->d_BDinv.ensure(sizeof(double) * 18 * sE))) return rc;
     if ((rc = b->d_partial.ensure(sizeof(double) * kBaPartialCount))) return rc;
-    SO_HIP(hipMemsetAsync(b->d_err.p, 0, sizeof(double) * 2 * nE, s));   // _error of a fresh edge
-    SO_HIP(hipMemsetAsync(b->d_chi2.p, 0, sizeof(double) * nE, s));
+    if ((rc = b->d_Hpp.ensure(sizeof(double) * 36 * sF))) return rc;
+    if ((rc = b->d_bp.ensure(sizeof(double) * 6 * sF))) return rc;
+    if ((rc = b->d_S.ensure(sizeof(double) * n * n))) return rc;
+    if ((rc = b->d_bs.ensure(sizeof(double) * n))) return rc;
+    if ((rc = b->d_lm.ensure(sizeof(BaLm)))) return rc;
+    Layout O;  // result block
+    const size_t r_pose = O.add(sizeof(BaPose) * (size_t)nP), r_pt = O.add(sizeof(double) * 3 * (size_t)nL),
+                 r_chi2 = O.add(sizeof(double) * sE), r_out = O.add(sE);
+    if ((rc = ensure_pinned(&b->h_out, &b->h_out_cap, O.total))) return rc;
+    if ((rc = b->d_out.ensure(O.total))) return rc;
+    SO_HIP(hipMemsetAsync(b->d_err.p, 0, sizeof(double) * 2 * sE, s));   // _error of a fresh edge
+    SO_HIP(hipMemsetAsync(b->d_chi2.p, 0, sizeof(double) * sE, s));
     SO_HIP(hipMemsetAsync(b->d_partial.p, 0, sizeof(double) * kBaPartialCount, s));
+    SO_HIP(hipMemsetAsync(b->d_tab.p, 0xFF, sizeof(int) * sL * sF, s));  // -1: keyframe does not observe the landmark
+    SO_HIP(hipMemsetAsync(b->d_lm.p, 0, sizeof(BaLm), s));  // current estimate = buffer 0, no trials yet
+    memset(b->h_lm, 0, sizeof(BaLm));
+    *b->h_abort = 0;
 
     BaDev& d = r.d;
-    d.n_poses = P.n_poses;
-    d.n_points = P.n_points;
-    d.n_edges = P.n_edges;
-    d.intr = b->d_intr.as<double>();
-    d.e_pose = b->d_epose.as<int>();
-    d.e_point = b->d_ept.as<int>();
-    d.e_obs = b->d_obs.as<double>();
-    d.e_w = b->d_w.as<double>();
+    uint8_t* db = (uint8_t*)b->d_in.p;
+    d.n_poses = nP;
+    d.n_points = nL;
+    d.n_edges = nE;
+    d.n_free = nf;
+    d.lm = b->d_lm.as<BaLm>();
+    d.pose[0] = (BaPose*)(db + o_pose);
+    d.pose[1] = b->d_pose1.as<BaPose>();
+    d.pt[0] = (double*)(db + o_pt);
+    d.pt[1] = b->d_pt1.as<double>();
+    d.intr = (const double*)(db + o_intr);
+    d.e_pose = (const int*)(db + o_epose);
+    d.e_point = (const int*)(db + o_ept);
+    d.e_obs = (const double*)(db + o_obs);
+    d.e_w = (const double*)(db + o_w);
+    d.e_active = db + o_eact;
+    d.pt_active = db + o_ptact;
+    d.pt_off = (const int*)(db + o_ptoff);
+    d.pose_hidx = (const int*)(db + o_hidx);
+    d.free_pose = (const int*)(db + o_free);
+    d.pose_off = (const int*)(db + o_poseoff);
+    d.pose_edges = (const int*)(db + o_pedges);
+    d.edge_tab = b->d_tab.as<int>();
     d.e_err = b->d_err.as<double>();
     d.e_chi2 = b->d_chi2.as<double>();
-    d.pt_off = b->d_ptoff.as<int>();
+    d.Hpp = b->d_Hpp.as<double>();
+    d.bp = b->d_bp.as<double>();
     d.Hll = b->d_Hll.as<double>();
     d.bl = b->d_bl.as<double>();
     d.W = b->d_W.as<double>();
     d.Dinv = b->d_Dinv.as<double>();
     d.db = b->d_db.as<double>();
     d.BDinv = b->d_BDinv.as<double>();
+    d.S = b->d_S.as<double>();
+    d.bs = b->d_bs.as<double>();
     d.xl = b->d_xl.as<double>();
     d.partial = b->d_partial.as<double>();
     d.robust = opt->robust;
     d.huber_delta = (double)opt->huber_delta;
     d.huber_dsqr = (float)((double)opt->huber_delta * (double)opt->huber_delta);  // RobustKernelHuber::setDelta
-    r.nb_err = std::min(1024, std::max(1, (P.n_edges + 255) / 256));
-    r.nb_upd = std::min(1024, std::max(1, (8 * P.n_points + P.n_poses + 255) / 256));
-    if ((rc = upload_stage(r))) return rc;
-
-    if ((rc = b->d_lm.ensure(sizeof(BaLm)))) return rc;
-    SO_HIP(hipMemsetAsync(b->d_lm.p, 0, sizeof(BaLm), s));  // current estimate = buffer 0, no trials yet
-    memset(b->h_lm, 0, sizeof(BaLm));
-    *b->h_abort = 0;
-    d.lm = b->d_lm.as<BaLm>();
-    d.pose[0] = b->d_pose[0].as<BaPose>();
-    d.pose[1] = b->d_pose[1].as<BaPose>();
-    d.pt[0] = b->d_pt[0].as<double>();
-    d.pt[1] = b->d_pt[1].as<double>();
+    r.nb_err = std::min(1024, std::max(1, (nE + 255) / 256));
+    r.nb_upd = std::min(1024, std::max(1, (8 * nL + nP + 255) / 256));
+    launch_ba_edge_table(d, s);
 
     const double t_uploaded = now_ms();
     SO_HIP(hipEventRecord(b->e0, s));
@@ -579,7 +519,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     }
     if (do_more) {
         // Optimizer.cc:644-656 without leaving the device: outlier edges drop to level 1, the robust kernel goes,
-        // initializeOptimization(0) = the same CSR lists with the dropped edges skipped
+        // initializeOptimization(0) = the same lists with the dropped edges skipped
         launch_ba_mark_outliers(r.d, (double)opt->chi2_threshold, s);
         r.d.robust = 0;  // e->setRobustKernel(nullptr)
         if ((rc = optimize(r, opt->its_stage2, &done, &chi))) return rc;  // optimizer.optimize(10)
@@ -588,26 +528,27 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         if (r.terminate()) inf.aborted = 1;
     }
     const double t_opt2 = now_ms();
-    // Optimizer.cc:682-739: outlier flags from the edges' stored errors, then recover the optimised data
-    const int cur = b->h_lm->cur;
-    std::vector<double> h_chi2(nE), h_depth(nE);
-    launch_ba_depth(r.d, b->d_depth.as<double>(), s);  // isDepthPositive()
-    SO_HIP(hipMemcpyAsync(h_chi2.data(), b->d_chi2.p, sizeof(double) * nE, hipMemcpyDeviceToHost, s));
-    SO_HIP(hipMemcpyAsync(h_depth.data(), b->d_depth.p, sizeof(double) * nE, hipMemcpyDeviceToHost, s));
-    SO_HIP(hipMemcpyAsync(h_pose.data(), b->d_pose[cur].p, sizeof(BaPose) * h_pose.size(), hipMemcpyDeviceToHost, s));
-    if (!h_pt.empty())
-        SO_HIP(hipMemcpyAsync(h_pt.data(), b->d_pt[cur].p, sizeof(double) * h_pt.size(), hipMemcpyDeviceToHost, s));
+    // Optimizer.cc:682-739: outlier flags from the edges' stored errors and isDepthPositive(), optimised data back
+    uint8_t* ob = (uint8_t*)b->d_out.p;
+    launch_ba_finish(r.d, (double)opt->chi2_threshold, (BaPose*)(ob + r_pose), (double*)(ob + r_pt),
+                     (double*)(ob + r_chi2), ob + r_out, s);
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipMemcpyAsync(b->h_out, b->d_out.p, O.total, hipMemcpyDeviceToHost, s));
     SO_HIP(hipEventRecord(b->e1, s));
     SO_HIP(hipStreamSynchronize(s));
-    for (int k = 0; k < P.n_edges; k++) {
-        const int e = P.perm[(size_t)k];
-        const int out = (h_chi2[(size_t)k] > (double)opt->chi2_threshold || !(h_depth[(size_t)k] > 0.0)) ? 1 : 0;
-        if (edge_outlier) edge_outlier[e] = (uint8_t)out;
-        if (edge_chi2) edge_chi2[e] = h_chi2[(size_t)k];
-        inf.n_outliers += out;
+    const uint8_t* ho = (const uint8_t*)b->h_out;
+    const BaPose* o_poses = (const BaPose*)(ho + r_pose);
+    const double* o_pts = (const double*)(ho + r_pt);
+    const double* o_chi2 = (const double*)(ho + r_chi2);
+    const uint8_t* o_outl = ho + r_out;
+    for (int k = 0; k < nE; k++) {
+        const int e = perm[(size_t)k];
+        if (edge_outlier) edge_outlier[e] = o_outl[k];
+        if (edge_chi2) edge_chi2[e] = o_chi2[k];
+        inf.n_outliers += o_outl[k];
     }
-    for (int i = 0; i < P.n_poses; i++) pose_to_Tcw(h_pose[(size_t)i], Tcw_out + 12 * (size_t)i);
-    for (size_t i = 0; i < h_pt.size(); i++) Xw_out[i] = (float)h_pt[i];
+    for (int i = 0; i < nP; i++) pose_to_Tcw(o_poses[i], Tcw_out + 12 * (size_t)i);
+    for (size_t i = 0; i < (size_t)nL * 3; i++) Xw_out[i] = (float)o_pts[i];
     inf.lambda_final = b->h_lm->lambda;
     inf.lm_trials = b->h_lm->trials;
     float ms = 0.f;
@@ -616,8 +557,8 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     inf.n_solves = b->n_solves;
     inf.wall_ms = (float)(now_ms() - t_begin);
     if (trace)
-        fprintf(stderr, "[ba] sort %.3f lists %.3f upload %.3f opt1 %.3f (%d it) opt2 %.3f (%d it) finish %.3f | trials %d blocks %d\n",
-                t_sorted - t_begin, t_stage1 - t_sorted, t_uploaded - t_stage1, t_opt1 - t_uploaded, inf.iterations_stage1,
+        fprintf(stderr, "[ba] stage %.3f upload+alloc %.3f opt1 %.3f (%d it) opt2 %.3f (%d it) finish %.3f | trials %d blocks %d\n",
+                t_staged - t_begin, t_uploaded - t_staged, t_opt1 - t_uploaded, inf.iterations_stage1,
                 t_opt2 - t_opt1, inf.iterations_stage2, now_ms() - t_opt2, inf.lm_trials, r.blocks_enqueued);
     if (info) *info = inf;
     return SO_OK;

@@ -5,9 +5,10 @@
 //   points    2 buffers (current / trial) of double[3]                        n_points x 24 B
 //   edges     sorted by point (stable): pose idx, point idx, obs[2], inv_sigma2, active flag
 //             + stored error[2] (EdgeSE3ProjectXYZ::_error) that only active edges refresh
-//   CSR       point -> its edges (contiguous after the sort); free pose -> its edges; upper block (i1,i2) of the
-//             reduced camera system -> the (edge, edge) pairs that share a landmark.  Built once per problem on
-//             the host; the second stage keeps the lists and skips edges whose active flag was cleared.
+//   CSR       point -> its edges (contiguous after the sort); free pose -> its edges (ascending, i.e. by landmark);
+//             edge_tab[landmark][hessian index] -> edge, filled on the device: block (i1,i2) of the reduced camera
+//             system walks pose i1's edges and looks the partner edge of pose i2 up.  Built once per problem;
+//             the second stage keeps everything and skips edges whose active flag was cleared.
 //   system    Hpp[n_free][36], bp[n_free][6], Hll[n_pt][9], bl[n_pt][3], W[edge][18] = J_pose^T w J_point,
 //             Dinv[n_pt][9], db[n_pt][3], BDinv[edge][18], S[(6 n_free)^2] dense, bs / x_p[6 n_free], x_l[n_pt][3]
 // Summation orders are fixed (CSR order, fixed reduction trees, no floating-point atomics) so results are
@@ -66,9 +67,7 @@ struct BaDev {
     const int* free_pose;     // n_free: pose index of hessian index i
     const int* pose_off;      // n_free + 1
     const int* pose_edges;    // edge ids per free pose
-    const int* blk_off;       // n_blk + 1, n_blk = n_free (n_free + 1) / 2, block (i1,i2) at i1*n_free - i1(i1-1)/2 + (i2-i1)
-    const int* pair_k1;
-    const int* pair_k2;
+    int* edge_tab;            // n_points x n_free: the edge joining (landmark, hessian index), -1 if none
     // system
     double* Hpp; double* bp; double* Hll; double* bl; double* W;
     double* Dinv; double* db; double* BDinv;
@@ -94,12 +93,16 @@ void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_
 // one LM trial, seven launches, no host involvement: [build] -> schur prep -> gather -> solve -> update -> errors
 // -> decide.  abort_flag (host-mapped, may be null) = g2o's forceStopFlag; lm_host (host-mapped) receives a copy
 // of the state after every decision; ev0/ev1 (may be null) bracket the solve kernel.
-void launch_ba_trial(const BaDev& d, const int* blk_i1, const int* blk_i2, int n_blk, int nb_err, int nb_upd,
-                     const uint8_t* abort_flag, BaLm* lm_host, hipEvent_t ev0, hipEvent_t ev1, hipStream_t s);
+void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abort_flag, BaLm* lm_host,
+                     hipEvent_t ev0, hipEvent_t ev1, hipStream_t s);
+void launch_ba_edge_table(const BaDev& d, hipStream_t s);  // fills edge_tab (memset to -1 beforehand)
 // Optimizer.cc:644-656 on the device: edges of the current estimate with chi2 > threshold or non-positive depth
 // leave the problem (level 1); landmarks left without an edge become inactive
 void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, hipStream_t s);
-void launch_ba_depth(const BaDev& d, double* depth, hipStream_t s);  // of the current estimate
+// Optimizer.cc:682-739: current estimate, stored chi2 and the outlier flag (chi2 > threshold or depth <= 0) of
+// every edge into the result block
+void launch_ba_finish(const BaDev& d, double chi2_threshold, BaPose* pose_out, double* pt_out, double* chi2_out,
+                      uint8_t* outlier_out, hipStream_t s);
 
 struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.hip)
     const float* Xw;          // n x 3

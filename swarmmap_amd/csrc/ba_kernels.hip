@@ -207,21 +207,46 @@ void launch_ba_errors(const BaDev& d, int which, bool gated, int n_blocks, hipSt
     hipLaunchKernelGGL(ba_errors_kernel, dim3(n_blocks), dim3(256), 0, s, d, which, gated ? 1 : 0);
 }
 
-__global__ __launch_bounds__(256) void ba_depth_kernel(BaDev d, double* __restrict__ depth) {
+// edge_tab[landmark][hessian index] = the edge joining them (at most one: a keyframe observes a landmark once)
+__global__ __launch_bounds__(256) void ba_edge_table_kernel(BaDev d) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= d.n_edges) return;
-    const int cur = d.lm->cur;
-    const double* points = d.pt[cur];
-    const int il = d.e_point[e];
-    const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
-    double pc[3];
-    camera_point(d.pose[cur][d.e_pose[e]], X, pc);
-    depth[e] = pc[2];
+    const int h = d.pose_hidx[d.e_pose[e]];
+    if (h >= 0) d.edge_tab[(size_t)d.e_point[e] * d.n_free + h] = e;
 }
 
-void launch_ba_depth(const BaDev& d, double* depth, hipStream_t s) {
-    if (d.n_edges <= 0) return;
-    hipLaunchKernelGGL(ba_depth_kernel, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, depth);
+void launch_ba_edge_table(const BaDev& d, hipStream_t s) {
+    if (d.n_edges <= 0 || d.n_free <= 0) return;
+    hipLaunchKernelGGL(ba_edge_table_kernel, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d);
+}
+
+__global__ __launch_bounds__(256) void ba_finish_kernel(BaDev d, double chi2_threshold, BaPose* __restrict__ pose_out,
+                                                         double* __restrict__ pt_out, double* __restrict__ chi2_out,
+                                                         uint8_t* __restrict__ outlier_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int cur = d.lm->cur;
+    const BaPose* poses = d.pose[cur];
+    const double* points = d.pt[cur];
+    if (i < d.n_edges) {
+        const int il = d.e_point[i];
+        const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+        double pc[3];
+        camera_point(poses[d.e_pose[i]], X, pc);  // isDepthPositive()
+        const double chi2 = d.e_chi2[i];
+        chi2_out[i] = chi2;
+        outlier_out[i] = (chi2 > chi2_threshold || !(pc[2] > 0.0)) ? 1 : 0;
+    }
+    if (i < d.n_poses) pose_out[i] = poses[i];
+    if (i < 3 * d.n_points) pt_out[i] = points[i];
+}
+
+void launch_ba_finish(const BaDev& d, double chi2_threshold, BaPose* pose_out, double* pt_out, double* chi2_out,
+                      uint8_t* outlier_out, hipStream_t s) {
+    int nthreads = d.n_edges > d.n_poses ? d.n_edges : d.n_poses;
+    if (3 * d.n_points > nthreads) nthreads = 3 * d.n_points;
+    if (nthreads <= 0) return;
+    hipLaunchKernelGGL(ba_finish_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d, chi2_threshold, pose_out,
+                       pt_out, chi2_out, outlier_out);
 }
 
 // Between the two stages of LocalBundleAdjustment (Optimizer.cc:644-656): one thread per landmark walks its
@@ -430,25 +455,32 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d) {
     }
 }
 
-// gather: one wave per upper block (i1 <= i2) of the reduced camera system.  The block's (edge, edge) pairs are
-//         strided over the 64 lanes, each lane accumulates a full 6x6 partial, then a fixed xor-butterfly sums the
-//         lanes: S(i1,i2) = [i1 == i2] (Hpp + lambda I) - sum over shared landmarks BDinv_{k1} W_{k2}^T ; mirrored.
+// gather: one wave per upper block (i1 <= i2) of the reduced camera system.  The lanes stride over pose i1's
+//         edges; the partner edge of pose i2 on the same landmark comes from edge_tab (the edge itself on the
+//         diagonal).  Each lane accumulates a full 6x6 partial, then a fixed xor-butterfly sums the lanes:
+//         S(i1,i2) = [i1 == i2] (Hpp + lambda I) - sum over shared landmarks BDinv_{e1} W_{e2}^T ; mirrored.
 //         extra waves: b_schur(i) = bp(i) - sum over the pose's edges W_e db_{landmark(e)}
-__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, const int* __restrict__ blk_i1,
-                                                               const int* __restrict__ blk_i2, int n_blk) {
+__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d) {
     if (!d.lm->active) return;
     const double lambda = d.lm->lambda;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n = 6 * d.n_free;
+    const int nf = d.n_free, n = 6 * nf, n_blk = nf * (nf + 1) / 2;
     if (g < n_blk) {
-        const int i1 = blk_i1[g], i2 = blk_i2[g];
+        int i1 = 0, rem = g;  // upper blocks row by row: (0,0) (0,1) ... (0,nf-1) (1,1) ...
+        while (rem >= nf - i1) {
+            rem -= nf - i1;
+            i1++;
+        }
+        const int i2 = i1 + rem;
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
-        for (int p = d.blk_off[g] + lane; p < d.blk_off[g + 1]; p += 64) {
-            const int k1 = d.pair_k1[p], k2 = d.pair_k2[p];
-            if (!(d.e_active[k1] && d.e_active[k2])) continue;  // dropped between the stages
+        for (int p = d.pose_off[i1] + lane; p < d.pose_off[i1 + 1]; p += 64) {
+            const int k1 = d.pose_edges[p];
+            if (!d.e_active[k1]) continue;  // dropped between the stages
+            const int k2 = (i1 == i2) ? k1 : d.edge_tab[(size_t)d.e_point[k1] * nf + i2];
+            if (k2 < 0 || !d.e_active[k2]) continue;
             const double* B = d.BDinv + 18 * (size_t)k1;
             const double* W = d.W + 18 * (size_t)k2;
             double b[18], w[18];
@@ -761,12 +793,11 @@ __global__ __launch_bounds__(1024) void ba_solve_global_kernel(BaDev d) {
     if (tid == 0) d.partial[kBaSolveOk] = s_fail ? 0.0 : 1.0;
 }
 
-static void launch_ba_schur(const BaDev& d, const int* blk_i1, const int* blk_i2, int n_blk, hipStream_t s) {
+static void launch_ba_schur(const BaDev& d, hipStream_t s) {
     const int nthreads = d.n_points > d.n_edges ? d.n_points : d.n_edges;
     if (nthreads > 0) hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d);
-    const int waves = n_blk + d.n_free;
-    if (waves > 0)
-        hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d, blk_i1, blk_i2, n_blk);
+    const int waves = d.n_free * (d.n_free + 1) / 2 + d.n_free;
+    if (waves > 0) hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d);
 }
 
 static void launch_ba_solve(const BaDev& d, hipStream_t s) {
@@ -946,10 +977,10 @@ __global__ __launch_bounds__(256) void ba_trial_decide_kernel(BaDev d, int nb_er
     if (lm_host) *lm_host = lm;
 }
 
-void launch_ba_trial(const BaDev& d, const int* blk_i1, const int* blk_i2, int n_blk, int nb_err, int nb_upd,
-                     const uint8_t* abort_flag, BaLm* lm_host, hipEvent_t ev0, hipEvent_t ev1, hipStream_t s) {
+void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abort_flag, BaLm* lm_host, hipEvent_t ev0,
+                     hipEvent_t ev1, hipStream_t s) {
     launch_ba_build(d, true, s);
-    launch_ba_schur(d, blk_i1, blk_i2, n_blk, s);
+    launch_ba_schur(d, s);
     if (ev0) (void)hipEventRecord(ev0, s);
     launch_ba_solve(d, s);
     if (ev1) (void)hipEventRecord(ev1, s);

@@ -8,6 +8,17 @@ std::string& last_error_ref() {
     static thread_local std::string err;
     return err;
 }
+
+hipError_t tracking_stream(int device, int role, hipStream_t* s) {
+    static thread_local hipStream_t streams[64][2] = {{nullptr}};
+    if (device < 0 || device >= 64 || role < 0 || role > 1) return hipErrorInvalidDevice;
+    if (!streams[device][role]) {
+        const hipError_t e = hipStreamCreateWithFlags(&streams[device][role], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *s = streams[device][role];
+    return hipSuccess;
+}
 }  // namespace so
 
 extern "C" {

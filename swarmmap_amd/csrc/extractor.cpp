@@ -395,7 +395,7 @@ int so_extractor_create(const so_extractor_config* cfg, so_extractor** out) {
     so_extractor* ex = new so_extractor();
     ex->cfg = *cfg;
     make_tables(ex);
-    hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    hipError_t e = tracking_stream(cfg->device, 0, &ex->stream);
     if (e != hipSuccess) {
         delete ex;
         return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
@@ -424,7 +424,6 @@ void so_extractor_destroy(so_extractor* ex) {
     if (ex->h_total) (void)hipHostFree(ex->h_total);
     for (auto& v : ex->ev)
         if (v) (void)hipEventDestroy(v);
-    if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
 }
 

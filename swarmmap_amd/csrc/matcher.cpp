@@ -370,7 +370,7 @@ int so_matcher_create(int device, so_matcher** out) {
     SO_HIP(hipSetDevice(device));
     so_matcher* m = new so_matcher();
     m->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    hipError_t e = tracking_stream(device, 1, &m->stream);
     if (e == hipSuccess) e = hipEventCreate(&m->e0);
     if (e == hipSuccess) e = hipEventCreate(&m->e1);
     if (e != hipSuccess) {
@@ -390,7 +390,6 @@ void so_matcher_destroy(so_matcher* m) {
     m->h_out.release();
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
 

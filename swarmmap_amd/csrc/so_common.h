@@ -18,6 +18,13 @@ inline int hip_fail(hipError_t e, const char* what, const char* file, int line) 
     return SO_ERR_HIP;
 }
 
+// The runtime multiplexes streams onto a few hardware queues, and a frame's match kernel that shares a queue
+// with the local-mapping solver waits behind ~100 queued bundle-adjustment launches (half a millisecond).  The
+// contexts of the per-frame tracking path are called one after the other by one thread, so per (creating thread,
+// device) all extractors share one stream (role 0) and all matchers another (role 1) instead of holding one
+// each; the solver keeps its own.  The shared streams live as long as the process.
+hipError_t tracking_stream(int device, int role, hipStream_t* s);  // capi.cpp
+
 }  // namespace so
 
 #define SO_HIP(call)                                                          \
