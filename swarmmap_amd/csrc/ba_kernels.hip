@@ -14,6 +14,8 @@
 //   types/se3quat.h                     SE3Quat exp / product / map
 //   core/base_binary_edge.hpp:55-120    constructQuadraticForm (+ Huber weights, robust_kernel_impl.cpp:78-91)
 //   core/block_solver.hpp:354-486       Schur complement, back-substitution
+#include <cstdlib>
+
 #include "ba_device.h"
 
 // FP64 solver: parity with the oracle is tolerance-based (see tests/test_ba_gpu.py), so let the compiler fuse
@@ -542,6 +544,7 @@ constexpr int kSolveMaxNB = 44;
 // tools/probe/solve_probe.hip defines SO_SOLVE_MARK to log clock64() per phase; the product build compiles it away
 #ifndef SO_SOLVE_MARK
 #define SO_SOLVE_MARK(k, phase)
+#define SO_SOLVE_MARK_DECL
 #endif
 
 // 1/sqrt(v) to double precision: hardware estimate + two Newton steps (each three dependent FMAs)
@@ -566,6 +569,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_reg_kernel(BaDev d) {
     __shared__ double s_x[6];
     __shared__ int s_fail;
     if (!d.lm->active) return;
+    SO_SOLVE_MARK_DECL;
     const int tid = threadIdx.x;
     const int nf = d.n_free, NB = nf + 1, n = 6 * nf, nblk = NB * (NB + 1) / 2;
     double a[BPT][36];
@@ -749,6 +753,270 @@ __global__ __launch_bounds__(THREADS) void ba_solve_reg_kernel(BaDev d) {
     if (tid == 0) d.partial[kBaSolveOk] = s_fail ? 0.0 : 1.0;
 }
 
+// ---- look-ahead variant (n_free <= 30): the factorisation's serial chain gets its own waves ----
+// The kernel above spends most of a block step waiting: the diagonal factor (one lane) -> barrier -> the panel
+// solve (one lane per block) -> barrier -> the trailing update (everyone).  Here two teams of waves run
+// decoupled, synchronised through LDS counters instead of workgroup barriers:
+//   panel team  (PW waves, one matrix ROW of the current block column per lane; lanes 0-5 of every panel wave
+//               hold the six rows of the diagonal block, replicated): loads its rows of column k from the LDS
+//               stage, applies the one update they still lack (that of column k-1), then factors and solves in
+//               one pass - per column c the pivot and the five multipliers below it travel by v_readlane, so
+//               there is no cross-lane memory traffic and no barrier - and publishes the finished panel.
+//   update team (UW waves, one 6x6 block per lane in registers, block-column order): waits for panel k,
+//               applies it to its block, and the owners of column k+2 copy their block to the stage, one step
+//               AHEAD of its use, so the panel team never waits for a trailing update that is not its own.
+// Counters are per step / per column: a running total would let waves that are ahead cover for one behind.
+constexpr int kLaMaxNB = 31;
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void lds_wait_ge(int* flag, int target) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+
+__device__ __forceinline__ void lds_signal(int* flag) {  // one increment per wave, after the wave's LDS stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int UW, int PW>
+__global__ __launch_bounds__((UW + PW) * 64) void ba_solve_la_kernel(BaDev d) {
+    __shared__ double s_col[2][kLaMaxNB][37];    // stage: block column k (parity k & 1), lacking the update of k-1
+    __shared__ double s_panel[2][kLaMaxNB][37];  // finished panel of column k (parity k & 1), rows of blocks I > k
+    __shared__ double s_Ldiag[kLaMaxNB][36];
+    __shared__ double s_dinv[kLaMaxNB][6];
+    __shared__ double s_Linv[kLaMaxNB][36];
+    __shared__ double s_y[kLaMaxNB][6];
+    __shared__ double s_x[6];
+    __shared__ int s_colcnt[kLaMaxNB + 2];  // update-team waves that have staged their part of column J
+    __shared__ int s_updcnt[kLaMaxNB + 2];  // update-team waves that have finished step k
+    __shared__ int s_panel_ready, s_fail;
+    if (!d.lm->active) return;
+    SO_SOLVE_MARK_DECL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nf = d.n_free, NB = nf + 1, n = 6 * nf, nblk = NB * (NB + 1) / 2 - 1;
+    const bool panel_team = wave < PW;
+    for (int i = tid; i < kLaMaxNB + 2; i += (UW + PW) * 64) {
+        s_colcnt[i] = 0;
+        s_updcnt[i] = 0;
+    }
+    for (int i = tid; i < 2 * 37; i += (UW + PW) * 64) {  // rows 1-5 of the right-hand-side "block" stay zero
+        s_panel[i / 37][nf][i % 37] = 0.0;
+    }
+    if (tid == 0) {
+        s_panel_ready = 0;
+        s_fail = 0;
+    }
+    // ---- update team: own one block (I, J), J <= I, blocks numbered column by column ----
+    double a[36];
+    int bI = -1, bJ = -1;
+#pragma unroll
+    for (int q = 0; q < 36; q++) a[q] = 0.0;
+    if (!panel_team) {
+        const int p = tid - PW * 64;
+        if (p < nblk) {
+            int J = 0, rem = p;
+            while (rem >= NB - J) {
+                rem -= NB - J;
+                J++;
+            }
+            bI = J + rem;
+            bJ = J;
+            if (bI < nf) {
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++) a[r * 6 + c] = d.S[(size_t)(6 * bI + r) * n + 6 * bJ + c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; c++) a[c] = d.bs[6 * bJ + c];  // right-hand side rides as row 0
+            }
+        }
+    }
+    __syncthreads();  // counters and zero rows are in place
+    SO_SOLVE_MARK(40, 2);
+    if (!panel_team) {
+        // columns 0 and 1 go to the stage as loaded (column 1 lacks the update of column 0, as the stage expects)
+        if (bJ == 0 || bJ == 1) {
+#pragma unroll
+            for (int q = 0; q < 36; q++) s_col[bJ][bI][q] = a[q];
+        }
+        if (__ballot(bJ == 0)) lds_signal(&s_colcnt[0]);
+        if (__ballot(bJ == 1)) lds_signal(&s_colcnt[1]);
+        for (int k = 0; k < nf; k++) {
+            SO_SOLVE_MARK(k, 0);
+            lds_wait_ge(&s_panel_ready, PW * (k + 1));
+            SO_SOLVE_MARK(k, 1);
+            if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            const int buf = k & 1;
+            if (bJ == k && bI > k) {  // my block is final now: keep L_Ik for the backward substitution
+#pragma unroll
+                for (int q = 0; q < 36; q++) a[q] = s_panel[buf][bI][q];
+            }
+            if (bJ >= k + 2) {  // trailing update A_IJ -= L_Ik L_Jk^T  (column k+1 gets it from the panel team)
+                const double* Pj = s_panel[buf][bJ];
+                const double* Pi = s_panel[buf][bI];
+                double pj[36];
+#pragma unroll
+                for (int q = 0; q < 36; q++) pj[q] = Pj[q];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    double pi[6];
+#pragma unroll
+                    for (int m = 0; m < 6; m++) pi[m] = Pi[r * 6 + m];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double v = a[r * 6 + c];
+#pragma unroll
+                        for (int m = 0; m < 6; m++) v = fma(-pi[m], pj[c * 6 + m], v);
+                        a[r * 6 + c] = v;
+                    }
+                }
+                if (bJ == k + 2) {
+#pragma unroll
+                    for (int q = 0; q < 36; q++) s_col[buf][bI][q] = a[q];  // (k + 2) & 1 == k & 1
+                }
+            }
+            if (__ballot(bJ == k + 2)) lds_signal(&s_colcnt[k + 2]);
+            lds_signal(&s_updcnt[k]);
+            SO_SOLVE_MARK(k, 2);
+        }
+    } else {
+        __builtin_amdgcn_s_setprio(3);
+        const int rho = wave * 58 + lane - 6;  // panel row handled by this lane (lanes 0-5: diagonal rows)
+        const int rq = rho / 6, rr = rho - 6 * rq;
+        int col_start = 0;
+        for (int k = 0; k < nf; k++) {
+            // number of update-team waves that hold a piece of column k (its blocks are contiguous in p)
+            const int len = NB - k;
+            const int owners = (col_start + len - 1) / 64 - col_start / 64 + 1;
+            col_start += len;
+            const int buf = k & 1;
+            const bool diag_lane = lane < 6;
+            const bool live = diag_lane || (lane >= 6 && rho <= 6 * (nf - k - 1));
+            const int I = diag_lane ? k : k + 1 + rq, r = diag_lane ? lane : rr;
+            SO_SOLVE_MARK(k, 0);
+            lds_wait_ge(&s_colcnt[k], owners);
+            SO_SOLVE_MARK(k, 1);
+            double x[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) x[c] = live ? s_col[buf][I][r * 6 + c] : 0.0;
+            if (k > 0) {  // the update of column k-1, which the stage copy does not have yet
+                lds_wait_ge(&s_panel_ready, PW * k);
+                SO_SOLVE_MARK(k, 2);
+                const double* Pk = s_panel[buf ^ 1][k];
+                double own[6];
+#pragma unroll
+                for (int m = 0; m < 6; m++) own[m] = live ? s_panel[buf ^ 1][I][r * 6 + m] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double v = x[c];
+#pragma unroll
+                    for (int m = 0; m < 6; m++) v = fma(-own[m], Pk[c * 6 + m], v);
+                    x[c] = v;
+                }
+            }
+            SO_SOLVE_MARK(k, 3);
+            // factor the diagonal block (lanes 0-5) and solve the rows below it in the same pass
+            bool bad = false;
+            double ys[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double v = readlane_f64(x[c], c);
+                if (!(v > 0.0)) bad = true;
+                const double y = rsqrt_newton(v);
+                ys[c] = y;
+                x[c] *= y;
+#pragma unroll
+                for (int c2 = c + 1; c2 < 6; c2++) {
+                    const double l = readlane_f64(x[c], c2);  // L(c2, c)
+                    x[c2] = fma(-x[c], l, x[c2]);
+                }
+            }
+            if (wave == 0 && diag_lane) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s_Ldiag[k][lane * 6 + c] = (c <= lane) ? x[c] : 0.0;
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) s_dinv[k][c] = ys[c];
+                    if (bad) __hip_atomic_store(&s_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            SO_SOLVE_MARK(k, 4);
+            if (k >= 2) lds_wait_ge(&s_updcnt[k - 2], UW);  // nobody reads panel k-2 any more
+            SO_SOLVE_MARK(k, 5);
+            if (live && !diag_lane) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s_panel[buf][I][r * 6 + c] = x[c];
+                if (I == nf) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) s_y[k][c] = x[c];
+                }
+            }
+            lds_signal(&s_panel_ready);
+            SO_SOLVE_MARK(k, 6);
+            if (bad) break;  // uniform: every panel wave factors the same diagonal block
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+    SO_SOLVE_MARK(40, 0);
+    const bool failed = s_fail != 0;
+    if (!failed) {
+        if (tid < nf) {  // invert the diagonal blocks (lower triangular), one per thread
+            const double* L = s_Ldiag[tid];
+            double ri[6], X[36];
+#pragma unroll
+            for (int c = 0; c < 6; c++) ri[c] = s_dinv[tid][c];
+#pragma unroll
+            for (int q = 0; q < 36; q++) X[q] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                X[j * 6 + j] = ri[j];
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = j; m < i; m++) v = fma(L[i * 6 + m], X[m * 6 + j], v);
+                    X[i * 6 + j] = -v * ri[i];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 36; q++) s_Linv[tid][q] = X[q];
+        }
+        __syncthreads();
+        for (int K = nf - 1; K >= 0; K--) {  // L^T x = y, block columns right to left
+            if (tid < 6) {                   // x_K = L_KK^-T y_K
+                double v = 0.0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) v = fma(s_Linv[K][r * 6 + tid], s_y[K][r], v);
+                s_x[tid] = v;
+                d.bs[6 * K + tid] = v;
+            }
+            __syncthreads();
+            if (bI == K && bJ < K) {  // y_J -= L_KJ^T x_K (one block per J in this step)
+                double xk[6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) xk[r] = s_x[r];
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double v = s_y[bJ][c];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) v = fma(-a[r * 6 + c], xk[r], v);
+                    s_y[bJ][c] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    SO_SOLVE_MARK(40, 1);
+    if (tid == 0) d.partial[kBaSolveOk] = failed ? 0.0 : 1.0;
+}
+
 // General path (any n_free): unblocked right-looking LL^T on the lower triangle of S in global memory with the
 // right-hand side carried as an extra row.  Latency-bound (three global round trips per column); only used for
 // windows with more than 43 free keyframes.
@@ -801,8 +1069,15 @@ static void launch_ba_schur(const BaDev& d, hipStream_t s) {
 }
 
 static void launch_ba_solve(const BaDev& d, hipStream_t s) {
-    const int NB = d.n_free + 1, nblk = NB * (NB + 1) / 2 - 1;
-    if (nblk <= 256)
+    const int NB = d.n_free + 1, nblk = NB * (NB + 1) / 2 - 1, rows = 6 * (d.n_free - 1) + 1;
+    static const bool classic = getenv("SWARMORB_BA_CLASSIC_SOLVER") != nullptr;  // A/B switch for profiling
+    if (!classic && nblk <= 256 && rows <= 2 * 58)
+        hipLaunchKernelGGL((ba_solve_la_kernel<4, 2>), dim3(1), dim3(6 * 64), 0, s, d);
+    else if (!classic && nblk <= 384 && rows <= 3 * 58)
+        hipLaunchKernelGGL((ba_solve_la_kernel<6, 3>), dim3(1), dim3(9 * 64), 0, s, d);
+    else if (!classic && nblk <= 512 && rows <= 4 * 58 && NB <= kLaMaxNB)
+        hipLaunchKernelGGL((ba_solve_la_kernel<8, 4>), dim3(1), dim3(12 * 64), 0, s, d);
+    else if (nblk <= 256)
         hipLaunchKernelGGL((ba_solve_reg_kernel<256, 1>), dim3(1), dim3(256), 0, s, d);
     else if (nblk <= 512)
         hipLaunchKernelGGL((ba_solve_reg_kernel<512, 1>), dim3(1), dim3(512), 0, s, d);
