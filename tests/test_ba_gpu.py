@@ -51,6 +51,16 @@ def test_local_bundle_adjustment_matches_oracle(opt, oracle, name, seed):
     assert r["info"]["n_outliers"] >= 0.9 * p["gt_outlier"].sum()
 
 
+@pytest.mark.parametrize("n_free", [1, 2, 9, 20, 21, 24, 27, 30, 31, 43, 50])
+def test_every_reduced_system_solver_path(opt, oracle, n_free):
+    """The dense solve of the reduced camera system switches kernels with the number of free keyframes
+    (look-ahead wave teams <= 30, register-resident <= 43, global beyond): one window per path and boundary."""
+    p = synth.make_ba_problem(100 + n_free, n_free, 3, 500, max_obs="auto")
+    r = opt.LocalBundleAdjustment(p)
+    o = oracle.bundle_adjust(p)
+    _compare(r, o)
+
+
 def test_global_bundle_adjustment_single_stage(opt, oracle):
     p = synth.make_ba_problem(11, 30, 1, 1500, max_obs="auto")  # every keyframe free except the first
     for robust in (True, False):
