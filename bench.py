@@ -125,7 +125,7 @@ class LocalMapper:
         self.th.join()
 
 
-def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window, budget_s=20.0):
+def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window, pose_cases, budget_s=20.0):
     """The same per-frame workload through the CPU oracle ("port": the reference has no CPU extractor and its
     g2o needs Eigen), one thread like the reference's Tracking / LocalMapping, bounded sample."""
     from oracle import oracle_py
@@ -142,6 +142,8 @@ def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window
         last, mps = wl.queries(t)
         oracle_py.search_by_projection_lastframe(F, last, 15.0, True)
         oracle_py.search_by_projection_mappoints(F, mps, 1.0, 0.8)
+        for c in pose_cases[t % len(pose_cases)]:
+            oracle_py.pose_optimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
         if t % LBA_EVERY == 0:
             lm.submit(True)
             n_lba += 1
@@ -153,7 +155,7 @@ def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window
     dt = time.perf_counter() - t0
     lm.close()
     return {"value": n / dt, "unit": "frames/s", "cores": 2, "kind": "port",
-            "sample": "%d frames %dx%d: CPU oracle extract (nFeatures %d) + M2 + M1 per frame on the tracking thread, "
+            "sample": "%d frames %dx%d: CPU oracle extract (nFeatures %d) + M2 + M1 + 3 PoseOptimization per frame on the tracking thread, "
                       "%d LBA-M windows (1 per %d frames) on a local-mapping thread; gcc -O2; host has %d cores"
                       % (n, size[0], size[1], nfeatures, n_lba, LBA_EVERY, os.cpu_count())}
 
@@ -208,11 +210,16 @@ def main():
         kk, dd = ex.run_device(dev_frames[tt % n_distinct].data_ptr(), w, h, w)
         prepared[tt] = wl.queries(tt)
         wl.push(tt, kk, dd)
-    acc = {"extract_ms": 0.0, "match_ms": 0.0, "lba_ms": 0.0, "xchg_ms": 0.0, "n_kp": 0, "n_m2": 0, "n_m1": 0,
+    acc = {"pose_ms": 0.0, "extract_ms": 0.0, "match_ms": 0.0, "lba_ms": 0.0, "xchg_ms": 0.0, "n_kp": 0, "n_m2": 0, "n_m1": 0,
            "n_lba": 0, "lba_gpu_ms": 0.0, "match_kernel_ms": 0.0, "n_xchg": 0, "solve_ms": 0.0, "n_solves": 0}
     stage_ms = {}
 
     mapper = LocalMapper(lambda: ba.LocalBundleAdjustment(lba_window)["info"])
+    # Optimizer::PoseOptimization, 3 per frame (TrackWithMotionModel, TrackLocalMap and one retry: SURVEY 8d):
+    # seeded frame-pose problems of the size the matchers return (~500 map points, 10 % outliers)
+    pose_cases = [[synth.make_pose_case(1000 * rank + 3 * i + j, n=500, K=synth.EUROC_K if args.size == "euroc"
+                                        else synth.KITTI_K, size=size) for j in range(3)] for i in range(16)]
+    tracker_opt = swarmmap_amd.Optimizer(device=dev)
 
     def step(t, timed):
         t0 = time.perf_counter()
@@ -225,6 +232,9 @@ def main():
         nm1, _ = m1.SearchByProjectionMapPoints(F, mps, 1.0)
         k1 = m1.last_kernel_ms()
         t2 = time.perf_counter()
+        for c in pose_cases[t % len(pose_cases)]:
+            tracker_opt.PoseOptimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
+        t2b = time.perf_counter()
         if t % LBA_EVERY == 0:
             mapper.submit(timed)  # blocks only when two windows are already waiting
         t3 = time.perf_counter()
@@ -234,7 +244,7 @@ def main():
         t4 = time.perf_counter()
         if timed:
             acc["extract_ms"] += (t1 - t0) * 1e3; acc["match_ms"] += (t2 - t1) * 1e3
-            acc["lba_ms"] += (t3 - t2) * 1e3; acc["xchg_ms"] += (t4 - t3) * 1e3
+            acc["lba_ms"] += (t3 - t2b) * 1e3; acc["xchg_ms"] += (t4 - t3) * 1e3; acc["pose_ms"] += (t2b - t2) * 1e3
             acc["n_kp"] += len(kps); acc["n_m2"] += nm2; acc["n_m1"] += nm1
             acc["match_kernel_ms"] += k1 + k2
             for k, v in ex.profile().items():
@@ -306,7 +316,7 @@ def main():
             "fps_per_agent": steps / dt,
             "config": {
                 "workload": "BASELINE.json configs[1] (single agent per GPU, 752x480 EuRoC-sized stream, HIP ORB "
-                            "extract nFeatures %d + HIP match M2+M1 on the tracking thread) plus HIP LocalBA (LBA-M window every "
+                            "extract nFeatures %d + HIP match M2+M1 + 3x HIP PoseOptimization on the tracking thread) plus HIP LocalBA (LBA-M window every "
                             "%d frames) on a local-mapping thread, as in the reference"
                             % (nfeatures, LBA_EVERY) if args.size == "euroc" else
                             "KITTI-sized 1241x376 stream, nFeatures %d, same per-frame path" % nfeatures,
@@ -315,6 +325,7 @@ def main():
                 "lba_windows": acc["n_lba"], "lba_edges": int(len(lba_window["edge_pose"])),
                 "descriptor_exchanges": acc["n_xchg"],
                 "host_ms_per_frame": {"extract": acc["extract_ms"] / steps, "match": acc["match_ms"] / steps,
+                                      "pose_optimization_x3": acc["pose_ms"] / steps,
                                       "lba_submit_wait": acc["lba_ms"] / steps,
                                       "lba_thread_busy": acc["lba_busy_ms"] / steps, "exchange_amortised": acc["xchg_ms"] / steps},
                 "lba_ms_per_window": {"wall": acc["lba_busy_ms"] / max(acc["n_lba"], 1),
@@ -325,9 +336,9 @@ def main():
             "roofline_secondary": secondary,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host_frames, 7, stream, size, nfeatures, lba_window)
+            out["cpu_baseline"] = cpu_baseline(host_frames, 7, stream, size, nfeatures, lba_window, pose_cases)
         print(json.dumps(out), flush=True)
-    for o in (ex, m1, m2, ba):
+    for o in (ex, m1, m2, ba, tracker_opt):
         o.close()
     if distributed:
         torch.distributed.destroy_process_group()

@@ -574,7 +574,10 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     if (info) info[0] = info[1] = 0;
     if (n < 3) return SO_OK;  // :344-345, nothing is touched
     SO_HIP(hipSetDevice(b->device));
-    hipStream_t s = b->stream;
+    // PoseOptimization belongs to the tracking thread (Tracking.cc:716,1002): it runs on that thread's matcher
+    // stream, never on the solver's own stream where a local-mapping window may have ~100 launches queued
+    hipStream_t s = nullptr;
+    SO_HIP(tracking_stream(b->device, 1, &s));
     // one pinned staging block: [Xw 12n | obs 8n | w 4n] in, [pose 64 | info 16 | outlier n] out
     const size_t in_bytes = (size_t)n * 24, out_bytes = 64 + 16 + (size_t)n;
     const size_t need = in_bytes + out_bytes + 64;

@@ -1519,8 +1519,299 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(PoseOptArgs a) {
     }
 }
 
+// ---- LDS-resident version (n <= 3072 matched points) ----
+// The kernel above keeps the stored errors and outlier flags in global memory and rebuilds the normal equations
+// in a phase of their own; with ~25 LM trials per call every phase is a memory round trip plus barriers (18 us
+// per trial measured).  Here the edges (inputs, stored errors, flags) live in LDS for the whole schedule, ONE
+// pass over the edges yields the trial's chi2 AND its normal equations (a rejected trial wastes them, an accepted
+// one - the common case - has the next iteration's system ready), the 29 block sums ride a transposed butterfly
+// (32 shuffles per wave instead of 29 x 6), and lane 0 decides and solves for the next trial in one go: two
+// barriers per trial.
+constexpr int kPoLdsMax = 3072;
+
+template <int COUNT>
+__device__ __forceinline__ void po_halve(double* v, int off, int lane) {
+    const bool upper = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < COUNT; i++) {
+        const double keep = upper ? v[i + COUNT] : v[i];
+        const double send = upper ? v[i] : v[i + COUNT];
+        v[i] = keep + __shfl_xor(send, off);
+    }
+}
+
+// 6x6 SPD solve (H + lambda I) x = b by Cholesky with reciprocal square roots; also computeScale
+__device__ void po_solve6(const double* H, const double* b, double lambda, double* x, double& scale, int& ok) {
+    double A[36], ri[6];
+#pragma unroll
+    for (int q = 0; q < 36; q++) A[q] = H[q];
+#pragma unroll
+    for (int j = 0; j < 6; j++) A[7 * j] += lambda;
+    ok = 1;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double dj = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) dj = fma(-A[j * 6 + k], A[j * 6 + k], dj);
+        if (!(dj > 0.0)) ok = 0;
+        const double y = rsqrt_newton(dj);
+        ri[j] = y;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v = fma(-A[i * 6 + k], A[j * 6 + k], v);
+            A[i * 6 + j] = v * y;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v = fma(-A[i * 6 + k], x[k], v);
+        x[i] = v * ri[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double v = x[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) v = fma(-A[k * 6 + i], x[k], v);
+        x[i] = v * ri[i];
+    }
+    scale = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+    if (!ok) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) x[j] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a) {
+    extern __shared__ double s_dyn[];
+    __shared__ double s_red[4][32];
+    __shared__ double s_sys[2][48];  // [0] system of the current estimate, [1] of the trial: H 36 | b 6 | chi | n_active
+    __shared__ BaPose s_cur, s_trial;
+    __shared__ int s_ctrl[2];        // [0] 0 stop, 1 run the trial in s_trial, 2 re-evaluate the current estimate first
+    __shared__ int s_info[3];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = a.n;
+    double* s_err = s_dyn;                                   // 2n
+    float* s_X = reinterpret_cast<float*>(s_dyn + 2 * n);    // 3n
+    float* s_obs = s_X + 3 * n;                              // 2n
+    float* s_w = s_obs + 2 * n;                              // n
+    uint8_t* s_out = reinterpret_cast<uint8_t*>(s_w + n);    // n
+    const double delta = (double)sqrtf(5.991f);  // const float deltaMono = sqrt(5.991)
+    const float dsqr = (float)(delta * delta);
+    const double fx = a.K[0], fy = a.K[1], cx = a.K[2], cy = a.K[3];
+    for (int e = tid; e < n; e += kPoThreads) {
+        s_X[3 * e] = a.Xw[3 * e]; s_X[3 * e + 1] = a.Xw[3 * e + 1]; s_X[3 * e + 2] = a.Xw[3 * e + 2];
+        s_obs[2 * e] = a.obs[2 * e]; s_obs[2 * e + 1] = a.obs[2 * e + 1];
+        s_w[e] = a.inv_sigma2[e];
+        s_out[e] = 0;
+        s_err[2 * e] = 0.0; s_err[2 * e + 1] = 0.0;
+    }
+    if (tid == 0) { s_info[0] = 0; s_info[1] = 0; s_info[2] = 0; }
+    __syncthreads();
+    int robust = 1;
+
+    // One pass over the active edges at pose T: stored errors, robustified chi2, J^T w J (upper 21), -rho' J^T Omega e
+    // (6) and the number of active edges, reduced into s_sys[which].  Two barriers.
+    auto edge_phase = [&](const BaPose& T, int which) {
+        double v[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) v[k] = 0.0;
+        for (int e = tid; e < n; e += kPoThreads) {
+            if (s_out[e]) continue;  // level 1
+            const double X[3] = {(double)s_X[3 * e], (double)s_X[3 * e + 1], (double)s_X[3 * e + 2]};
+            double pc[3];
+            camera_point(T, X, pc);
+            const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
+            const double e0 = (double)s_obs[2 * e] - (pc[0] / pc[2] * fx + cx);
+            const double e1 = (double)s_obs[2 * e + 1] - (pc[1] / pc[2] * fy + cy);
+            s_err[2 * e] = e0;
+            s_err[2 * e + 1] = e1;
+            const double w = (double)s_w[e];
+            const double chi2 = e0 * (w * e0) + e1 * (w * e1);
+            v[27] += robust ? huber_rho0(chi2, delta, dsqr) : chi2;
+            v[28] += 1.0;
+            double J[12];
+            J[0] = x * y * invz_2 * fx;       J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
+            J[3] = -invz * fx;                J[4] = 0;                            J[5] = x * invz_2 * fx;
+            J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy;         J[8] = -x * invz * fy;
+            J[9] = 0;                         J[10] = -invz * fy;                  J[11] = y * invz_2 * fy;
+            const double r1 = robust ? huber_rho1(chi2, delta, dsqr) : 1.0;
+            const double wo = r1 * w;
+            int t = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = r; c < 6; c++) v[t++] += J[r] * wo * J[c] + J[6 + r] * wo * J[6 + c];
+#pragma unroll
+            for (int r = 0; r < 6; r++) v[21 + r] -= r1 * (J[r] * (w * e0) + J[6 + r] * (w * e1));
+        }
+        po_halve<16>(v, 32, lane);
+        po_halve<8>(v, 16, lane);
+        po_halve<4>(v, 8, lane);
+        po_halve<2>(v, 4, lane);
+        po_halve<1>(v, 2, lane);
+        const double tot = v[0] + __shfl_xor(v[0], 1);  // lane holds the wave total of value (lane >> 1)
+        if ((lane & 1) == 0) s_red[wv][lane >> 1] = tot;
+        __syncthreads();
+        if (tid < 29) {
+            const double sum = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+            double* S = s_sys[which];
+            if (tid < 21) {
+                int r = 0, t = tid;  // unrank the upper-triangular index
+                while (t >= 6 - r) { t -= 6 - r; r++; }
+                const int c = r + t;
+                S[r * 6 + c] = sum;
+                S[c * 6 + r] = sum;
+            } else {
+                S[36 + (tid - 21)] = sum;  // b 36..41, chi 42, n_active 43
+            }
+        }
+        __syncthreads();
+    };
+
+    // lane 0: solve the current system with the current lambda and publish the trial pose
+    double lambda = 0.0, ni = 2.0, currentChi = 0.0, iniChi = 0.0, scale = 1.0;
+    int qmax = 0, it = 0, nBadLM = 0, solve_ok = 1, its_total = 0, trials_total = 0;
+    auto propose = [&]() {
+        double x[6];
+        po_solve6(s_sys[0], s_sys[0] + 36, lambda, x, scale, solve_ok);
+        scale += 1e-3;
+        BaPose tr;
+        se3_exp_mul(x, s_cur, tr);
+        s_trial = tr;
+        s_ctrl[0] = 1;
+    };
+
+    for (int round = 0; round < 4; round++) {
+        if (tid == 0) s_cur = a.init;  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw))
+        __syncthreads();
+        {
+            const BaPose cur = s_cur;
+            edge_phase(cur, 0);
+        }
+        if (tid == 0) {
+            if (s_sys[0][43] > 0.0) {  // optimize(10) with at least one active edge
+                double md = 0.0;
+                for (int j = 0; j < 6; j++) md = fmax(md, fabs(s_sys[0][7 * j]));
+                lambda = 1e-5 * md;  // computeLambdaInit
+                ni = 2.0;
+                currentChi = iniChi = s_sys[0][42];
+                qmax = 0; it = 0; nBadLM = 0;
+                propose();
+            } else {
+                s_ctrl[0] = 0;
+            }
+        }
+        __syncthreads();
+        while (s_ctrl[0] != 0) {
+            if (s_ctrl[0] == 2) {  // a trial was neither accepted nor retried: stored errors back to the estimate
+                const BaPose cur = s_cur;
+                edge_phase(cur, 0);
+                if (tid == 0) propose();
+                __syncthreads();
+                continue;
+            }
+            const BaPose trial = s_trial;
+            edge_phase(trial, 1);
+            if (tid == 0) {
+                double tempChi = solve_ok ? s_sys[1][42] : 1.7976931348623157e308;
+                const double rho = (currentChi - tempChi) / scale;
+                if (a.trace && trials_total < 256) {
+                    a.trace[4 * trials_total] = lambda;
+                    a.trace[4 * trials_total + 1] = tempChi;
+                    a.trace[4 * trials_total + 2] = rho;
+                    a.trace[4 * trials_total + 3] = currentChi;
+                }
+                const bool accepted = rho > 0 && isfinite(tempChi);
+                if (accepted) {
+                    double alpha = 1. - pow((2 * rho - 1), 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2.0;
+                    currentChi = tempChi;
+                    s_cur = s_trial;  // discardTop; the trial's system becomes the current one
+                    for (int q = 0; q < 44; q++) s_sys[0][q] = s_sys[1][q];
+                } else {
+                    lambda *= ni;  // pop
+                    ni *= 2.0;
+                }
+                qmax++;
+                trials_total++;
+                if (rho < 0 && qmax < 10) {
+                    propose();  // same system, larger lambda
+                } else {
+                    its_total++;
+                    bool stop = false;
+                    if (qmax == 10 || rho == 0) {
+                        stop = true;
+                    } else {
+                        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+                        if (nBadLM >= 3) stop = true;
+                    }
+                    it++;
+                    if (stop || it >= 10) {
+                        s_ctrl[0] = 0;
+                    } else {
+                        qmax = 0;
+                        iniChi = currentChi;
+                        if (accepted) propose();
+                        else s_ctrl[0] = 2;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // classify (Optimizer.cc:357-380): outliers of the previous round get a fresh error, inliers keep the stored one
+        const BaPose fin = s_cur;
+        double bad_local = 0.0;
+        for (int e = tid; e < n; e += kPoThreads) {
+            double e0 = s_err[2 * e], e1 = s_err[2 * e + 1];
+            if (s_out[e]) {
+                const double X[3] = {(double)s_X[3 * e], (double)s_X[3 * e + 1], (double)s_X[3 * e + 2]};
+                double pc[3];
+                camera_point(fin, X, pc);
+                e0 = (double)s_obs[2 * e] - (pc[0] / pc[2] * fx + cx);
+                e1 = (double)s_obs[2 * e + 1] - (pc[1] / pc[2] * fy + cy);
+                s_err[2 * e] = e0;
+                s_err[2 * e + 1] = e1;
+            }
+            const double w = (double)s_w[e];
+            const float chi2 = (float)(e0 * (w * e0) + e1 * (w * e1));
+            const bool out = chi2 > 5.991f;
+            s_out[e] = out ? 1 : 0;
+            bad_local += out ? 1.0 : 0.0;
+        }
+        const double nbad = block_sum(bad_local, s_red[0]);
+        if (tid == 0) s_info[0] = (int)nbad;
+        if (round == 2) robust = 0;
+        __syncthreads();
+        if (n < 10) break;
+    }
+    for (int e = tid; e < n; e += kPoThreads) a.outlier[e] = s_out[e];
+    if (tid == 0) {
+        *a.pose_out = s_cur;
+        a.info[0] = s_info[0];
+        a.info[1] = its_total;
+        a.info[2] = trials_total;
+    }
+}
+
 void launch_pose_opt(const PoseOptArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(pose_opt_kernel, dim3(1), dim3(kPoThreads), 0, s, a);
+    static const bool classic = getenv("SWARMORB_POSE_CLASSIC") != nullptr;  // A/B switch for profiling
+    if (a.n <= kPoLdsMax && !classic) {
+        const size_t lds = sizeof(double) * 2 * (size_t)a.n + sizeof(float) * 6 * (size_t)a.n + (size_t)a.n + 16;
+        static const hipError_t big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(pose_opt_lds_kernel),
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        (void)big_lds;  // 41 B per edge: 3072 edges = 126 KB of the CU's 160 KB
+        hipLaunchKernelGGL(pose_opt_lds_kernel, dim3(1), dim3(kPoThreads), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(pose_opt_kernel, dim3(1), dim3(kPoThreads), 0, s, a);
+    }
 }
 
 }  // namespace so

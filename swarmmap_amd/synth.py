@@ -147,6 +147,7 @@ def make_m4_case(seed, n_kp=2000, p_flip=0.05, size=EUROC, shift=(12.0, -7.0)):
 # bundle-adjustment windows: LBA-S / LBA-M / LBA-L / GBA-1 / GBA-2
 # ------------------------------------------------------------------------------------------------
 EUROC_K = (458.654, 457.296, 367.215, 248.375)  # code/Examples/Monocular/EuRoC.yaml
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # code/Examples/Monocular/KITTI00-02.yaml
 BA_CASES = {  # name: (free KFs, fixed KFs, points)
     "LBA-S": (8, 10, 800), "LBA-M": (25, 40, 3000), "LBA-L": (40, 60, 6000),
     "GBA-1": (299, 1, 30000), "GBA-2": (1499, 1, 120000),
