@@ -1529,6 +1529,20 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(PoseOptArgs a) {
 // barriers per trial.
 constexpr int kPoLdsMax = 3072;
 
+// the two widest exchanges (lane ^ 32, lane ^ 16) use gfx950's v_permlane32_swap / v_permlane16_swap: the first
+// operand's upper half (odd 16-lane rows) trades places with the second operand's lower half (even rows), so
+// a' + b' is "my half of the values plus my partner's copy of the same half" without touching LDS
+__device__ __forceinline__ double po_swap_add32(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double po_swap_add16(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
 template <int COUNT>
 __device__ __forceinline__ void po_halve(double* v, int off, int lane) {
     const bool upper = (lane & off) != 0;
@@ -1587,12 +1601,15 @@ __device__ void po_solve6(const double* H, const double* b, double lambda, doubl
     }
 }
 
-__global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
     extern __shared__ double s_dyn[];
-    __shared__ double s_red[4][32];
+    constexpr int kPoThreads = THREADS;  // shadows the classic kernel's constant inside this kernel
+    __shared__ double s_red[THREADS / 64][32];
     __shared__ double s_sys[2][48];  // [0] system of the current estimate, [1] of the trial: H 36 | b 6 | chi | n_active
     __shared__ BaPose s_cur, s_trial;
     __shared__ int s_ctrl[2];        // [0] 0 stop, 1 run the trial in s_trial, 2 re-evaluate the current estimate first
+                                     // [1] which of s_sys holds the current estimate's system (the other takes the trial's)
     __shared__ int s_info[3];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = a.n;
@@ -1627,8 +1644,8 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a)
             double pc[3];
             camera_point(T, X, pc);
             const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
-            const double e0 = (double)s_obs[2 * e] - (pc[0] / pc[2] * fx + cx);
-            const double e1 = (double)s_obs[2 * e + 1] - (pc[1] / pc[2] * fy + cy);
+            const double e0 = (double)s_obs[2 * e] - (x * invz * fx + cx);
+            const double e1 = (double)s_obs[2 * e + 1] - (y * invz * fy + cy);
             s_err[2 * e] = e0;
             s_err[2 * e + 1] = e1;
             const double w = (double)s_w[e];
@@ -1650,8 +1667,10 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a)
 #pragma unroll
             for (int r = 0; r < 6; r++) v[21 + r] -= r1 * (J[r] * (w * e0) + J[6 + r] * (w * e1));
         }
-        po_halve<16>(v, 32, lane);
-        po_halve<8>(v, 16, lane);
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = po_swap_add32(v[i], v[i + 16]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = po_swap_add16(v[i], v[i + 8]);
         po_halve<4>(v, 8, lane);
         po_halve<2>(v, 4, lane);
         po_halve<1>(v, 2, lane);
@@ -1659,7 +1678,9 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a)
         if ((lane & 1) == 0) s_red[wv][lane >> 1] = tot;
         __syncthreads();
         if (tid < 29) {
-            const double sum = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+            double sum = s_red[0][tid];
+#pragma unroll
+            for (int w2 = 1; w2 < THREADS / 64; w2++) sum += s_red[w2][tid];
             double* S = s_sys[which];
             if (tid < 21) {
                 int r = 0, t = tid;  // unrank the upper-triangular index
@@ -1679,7 +1700,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a)
     int qmax = 0, it = 0, nBadLM = 0, solve_ok = 1, its_total = 0, trials_total = 0;
     auto propose = [&]() {
         double x[6];
-        po_solve6(s_sys[0], s_sys[0] + 36, lambda, x, scale, solve_ok);
+        po_solve6(s_sys[s_ctrl[1]], s_sys[s_ctrl[1]] + 36, lambda, x, scale, solve_ok);
         scale += 1e-3;
         BaPose tr;
         se3_exp_mul(x, s_cur, tr);
@@ -1688,7 +1709,10 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a)
     };
 
     for (int round = 0; round < 4; round++) {
-        if (tid == 0) s_cur = a.init;  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw))
+        if (tid == 0) {
+            s_cur = a.init;  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw))
+            s_ctrl[1] = 0;
+        }
         __syncthreads();
         {
             const BaPose cur = s_cur;
@@ -1711,15 +1735,16 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a)
         while (s_ctrl[0] != 0) {
             if (s_ctrl[0] == 2) {  // a trial was neither accepted nor retried: stored errors back to the estimate
                 const BaPose cur = s_cur;
-                edge_phase(cur, 0);
+                edge_phase(cur, s_ctrl[1]);
                 if (tid == 0) propose();
                 __syncthreads();
                 continue;
             }
             const BaPose trial = s_trial;
-            edge_phase(trial, 1);
+            const int tsys = s_ctrl[1] ^ 1;
+            edge_phase(trial, tsys);
             if (tid == 0) {
-                double tempChi = solve_ok ? s_sys[1][42] : 1.7976931348623157e308;
+                double tempChi = solve_ok ? s_sys[tsys][42] : 1.7976931348623157e308;
                 const double rho = (currentChi - tempChi) / scale;
                 if (a.trace && trials_total < 256) {
                     a.trace[4 * trials_total] = lambda;
@@ -1729,13 +1754,14 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a)
                 }
                 const bool accepted = rho > 0 && isfinite(tempChi);
                 if (accepted) {
-                    double alpha = 1. - pow((2 * rho - 1), 3);
+                    const double tr = 2 * rho - 1;
+                    double alpha = 1. - tr * tr * tr;
                     alpha = fmin(alpha, 2. / 3.);
                     lambda *= fmax(1. / 3., alpha);
                     ni = 2.0;
                     currentChi = tempChi;
-                    s_cur = s_trial;  // discardTop; the trial's system becomes the current one
-                    for (int q = 0; q < 44; q++) s_sys[0][q] = s_sys[1][q];
+                    s_cur = s_trial;     // discardTop;
+                    s_ctrl[1] = tsys;    // the trial's system becomes the current one
                 } else {
                     lambda *= ni;  // pop
                     ni *= 2.0;
@@ -1786,7 +1812,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_lds_kernel(PoseOptArgs a)
             s_out[e] = out ? 1 : 0;
             bad_local += out ? 1.0 : 0.0;
         }
-        const double nbad = block_sum(bad_local, s_red[0]);
+        const double nbad = block_sum(bad_local, s_red[0]);  // s_red[0] has 32 slots, block_sum needs THREADS / 64
         if (tid == 0) s_info[0] = (int)nbad;
         if (round == 2) robust = 0;
         __syncthreads();
@@ -1805,10 +1831,11 @@ void launch_pose_opt(const PoseOptArgs& a, hipStream_t s) {
     static const bool classic = getenv("SWARMORB_POSE_CLASSIC") != nullptr;  // A/B switch for profiling
     if (a.n <= kPoLdsMax && !classic) {
         const size_t lds = sizeof(double) * 2 * (size_t)a.n + sizeof(float) * 6 * (size_t)a.n + (size_t)a.n + 16;
-        static const hipError_t big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(pose_opt_lds_kernel),
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        static const hipError_t big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(pose_opt_lds_kernel<512>),
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)big_lds;  // 41 B per edge: 3072 edges = 126 KB of the CU's 160 KB
-        hipLaunchKernelGGL(pose_opt_lds_kernel, dim3(1), dim3(kPoThreads), lds, s, a);
+        if (a.n <= 256) hipLaunchKernelGGL(pose_opt_lds_kernel<256>, dim3(1), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL(pose_opt_lds_kernel<512>, dim3(1), dim3(512), lds, s, a);
     } else {
         hipLaunchKernelGGL(pose_opt_kernel, dim3(1), dim3(kPoThreads), 0, s, a);
     }
