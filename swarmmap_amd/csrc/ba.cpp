@@ -46,7 +46,7 @@ struct Buf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-constexpr int kMaxReducedDim = 6144;  // dense reduced camera system: 6 * n_free <= this (301 MB of FP64)
+constexpr int kMaxReducedDim = 12288;  // dense reduced camera system: 6 * n_free <= this (1.2 GB of FP64 in HBM)
 
 double now_ms() {
     using namespace std::chrono;
@@ -118,7 +118,7 @@ struct so_ba {
     // d_in: the problem as one block (see Layout in so_bundle_adjust), staged in pinned h_in and moved with one
     // copy; d_out / h_out: the result block coming back the same way; the rest is device-only working storage
     Buf d_in, d_out, d_pose1, d_pt1, d_err, d_chi2, d_tab, d_Hpp, d_bp, d_Hll, d_bl, d_W, d_Dinv, d_db, d_BDinv, d_S,
-        d_bs, d_xl, d_partial, d_po, d_lm;
+        d_bs, d_xl, d_partial, d_po, d_lm, d_dense_ws, d_dense_x;
     void* h_in = nullptr;
     size_t h_in_cap = 0;
     void* h_out = nullptr;
@@ -127,7 +127,7 @@ struct so_ba {
     size_t h_po_cap = 0;
     std::vector<Buf*> all() {
         return {&d_in, &d_out, &d_pose1, &d_pt1, &d_err, &d_chi2, &d_tab, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv,
-                &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm};
+                &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x};
     }
 };
 
@@ -340,7 +340,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     int nf = 0;
     for (int i = 0; i < nP; i++) nf += (touched[(size_t)i] && !p->fixed[i]) ? 1 : 0;
     if (6 * nf > kMaxReducedDim) {
-        last_error_ref() = "reduced camera system too large for the dense solver (6*n_free > 6144)";
+        last_error_ref() = "reduced camera system too large for the dense solver (6*n_free > 12288)";
         return SO_ERR_CAPACITY;
     }
     r.n_free = nf;
@@ -442,8 +442,15 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     if ((rc = b->d_partial.ensure(sizeof(double) * kBaPartialCount))) return rc;
     if ((rc = b->d_Hpp.ensure(sizeof(double) * 36 * sF))) return rc;
     if ((rc = b->d_bp.ensure(sizeof(double) * 6 * sF))) return rc;
-    if ((rc = b->d_S.ensure(sizeof(double) * n * n))) return rc;
-    if ((rc = b->d_bs.ensure(sizeof(double) * n))) return rc;
+    // single-workgroup solvers up to 43 free keyframes, the blocked solver (S padded to a multiple of 96) beyond
+    const bool dense_path = nf > kBaSmallSolverMaxFree;
+    const size_t ldS = dense_path ? (n + 95) / 96 * 96 : n;
+    if ((rc = b->d_S.ensure(sizeof(double) * ldS * ldS))) return rc;
+    if ((rc = b->d_bs.ensure(sizeof(double) * ldS))) return rc;
+    if (dense_path) {
+        if ((rc = b->d_dense_ws.ensure(sizeof(double) * (ldS / 96) * 96 * 96))) return rc;
+        if ((rc = b->d_dense_x.ensure(sizeof(double) * ldS))) return rc;
+    }
     if ((rc = b->d_lm.ensure(sizeof(BaLm)))) return rc;
     Layout O;  // result block
     const size_t r_pose = O.add(sizeof(BaPose) * (size_t)nP), r_pt = O.add(sizeof(double) * 3 * (size_t)nL),
@@ -494,6 +501,9 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.BDinv = b->d_BDinv.as<double>();
     d.S = b->d_S.as<double>();
     d.bs = b->d_bs.as<double>();
+    d.ldS = (int)ldS;
+    d.dense_ws = b->d_dense_ws.as<double>();
+    d.dense_x = b->d_dense_x.as<double>();
     d.xl = b->d_xl.as<double>();
     d.partial = b->d_partial.as<double>();
     d.robust = opt->robust;
@@ -502,6 +512,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     r.nb_err = std::min(1024, std::max(1, (nE + 255) / 256));
     r.nb_upd = std::min(1024, std::max(1, (8 * nL + nP + 255) / 256));
     launch_ba_edge_table(d, s);
+    if (dense_path) launch_ba_dense_pad(d, s);
 
     const double t_uploaded = now_ms();
     SO_HIP(hipEventRecord(b->e0, s));

@@ -72,6 +72,9 @@ struct BaDev {
     double* Hpp; double* bp; double* Hll; double* bl; double* W;
     double* Dinv; double* db; double* BDinv;
     double* S; double* bs; double* xl;
+    int ldS;           // leading dimension of S: 6 n_free, or that rounded up to 96 on the blocked dense path
+    double* dense_ws;  // blocked dense path: inverted 96x96 diagonal blocks, one per panel
+    double* dense_x;   //                     solution staging (ldS doubles)
     double* partial;  // reduction partials (chi2 | scale) + flags
     int robust;
     double huber_delta;
@@ -95,7 +98,11 @@ void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_
 // of the state after every decision; ev0/ev1 (may be null) bracket the solve kernel.
 void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abort_flag, BaLm* lm_host,
                      hipEvent_t ev0, hipEvent_t ev1, hipStream_t s);
-void launch_ba_edge_table(const BaDev& d, hipStream_t s);  // fills edge_tab (memset to -1 beforehand)
+void launch_ba_edge_table(const BaDev& d, hipStream_t s);
+// blocked dense path (ba_dense.hip), used when the system is too large for one workgroup (n_free > 43)
+constexpr int kBaSmallSolverMaxFree = 43;
+void launch_ba_dense_pad(const BaDev& d, hipStream_t s);    // once per problem: identity padding up to ldS
+void launch_ba_dense_solve(const BaDev& d, hipStream_t s);  // per trial, in place of the single-workgroup solve  // fills edge_tab (memset to -1 beforehand)
 // Optimizer.cc:644-656 on the device: edges of the current estimate with chi2 > threshold or non-positive depth
 // leave the problem (level 1); landmarks left without an edge become inactive
 void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, hipStream_t s);

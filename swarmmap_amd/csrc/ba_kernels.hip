@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d) {
     const double lambda = d.lm->lambda;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nf = d.n_free, n = 6 * nf, n_blk = nf * (nf + 1) / 2;
+    const int nf = d.n_free, n_blk = nf * (nf + 1) / 2;
     if (g < n_blk) {
         int i1 = 0, rem = g;  // upper blocks row by row: (0,0) (0,1) ... (0,nf-1) (1,1) ...
         while (rem >= nf - i1) {
@@ -503,8 +503,8 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d) {
             for (int k = 0; k < 36; k++) v = (k == lane) ? acc[k] : v;  // select without dynamic register indexing
             double out = -v;
             if (i1 == i2) out += d.Hpp[36 * (size_t)i1 + lane] + (r == c ? lambda : 0.0);
-            d.S[(size_t)(6 * i1 + r) * n + 6 * i2 + c] = out;
-            if (i1 != i2) d.S[(size_t)(6 * i2 + c) * n + 6 * i1 + r] = out;
+            d.S[(size_t)(6 * i1 + r) * d.ldS + 6 * i2 + c] = out;
+            if (i1 != i2) d.S[(size_t)(6 * i2 + c) * d.ldS + 6 * i1 + r] = out;
         }
         return;
     }
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d) {
 // sqrt/div sequences: the step's serial chain is what bounds this kernel), the owners of column k solve
 // against it and publish their blocks through LDS, and every owner of a trailing block applies its rank-6
 // update from two LDS blocks.  Two barriers per 6 columns, no global memory between the initial load and the
-// final store.  The forward substitution falls out of the extra block row; the backward substitution multiplies
+// final store.  Larger systems (global bundle adjustment) go to the blocked multi-workgroup solver in ba_dense.hip.  The forward substitution falls out of the extra block row; the backward substitution multiplies
 // by the inverted diagonal blocks (inverted off the critical path, all at once after the factorisation).
 constexpr int kSolveMaxNB = 44;
 
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_reg_kernel(BaDev d) {
     if (!d.lm->active) return;
     SO_SOLVE_MARK_DECL;
     const int tid = threadIdx.x;
-    const int nf = d.n_free, NB = nf + 1, n = 6 * nf, nblk = NB * (NB + 1) / 2;
+    const int nf = d.n_free, NB = nf + 1, nblk = NB * (NB + 1) / 2;
     double a[BPT][36];
     int bI[BPT], bJ[BPT];
     if (tid == 0) s_fail = 0;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_reg_kernel(BaDev d) {
 #pragma unroll
                 for (int r = 0; r < 6; r++)
 #pragma unroll
-                    for (int c = 0; c < 6; c++) a[s][r * 6 + c] = d.S[(size_t)(6 * I + r) * n + 6 * J + c];
+                    for (int c = 0; c < 6; c++) a[s][r * 6 + c] = d.S[(size_t)(6 * I + r) * d.ldS + 6 * J + c];
             } else {
 #pragma unroll
                 for (int c = 0; c < 6; c++) a[s][c] = d.bs[6 * J + c];  // right-hand side rides as row 0
@@ -798,7 +798,7 @@ __global__ __launch_bounds__((UW + PW) * 64) void ba_solve_la_kernel(BaDev d) {
     if (!d.lm->active) return;
     SO_SOLVE_MARK_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nf = d.n_free, NB = nf + 1, n = 6 * nf, nblk = NB * (NB + 1) / 2 - 1;
+    const int nf = d.n_free, NB = nf + 1, nblk = NB * (NB + 1) / 2 - 1;
     const bool panel_team = wave < PW;
     for (int i = tid; i < kLaMaxNB + 2; i += (UW + PW) * 64) {
         s_colcnt[i] = 0;
@@ -830,7 +830,7 @@ __global__ __launch_bounds__((UW + PW) * 64) void ba_solve_la_kernel(BaDev d) {
 #pragma unroll
                 for (int r = 0; r < 6; r++)
 #pragma unroll
-                    for (int c = 0; c < 6; c++) a[r * 6 + c] = d.S[(size_t)(6 * bI + r) * n + 6 * bJ + c];
+                    for (int c = 0; c < 6; c++) a[r * 6 + c] = d.S[(size_t)(6 * bI + r) * d.ldS + 6 * bJ + c];
             } else {
 #pragma unroll
                 for (int c = 0; c < 6; c++) a[c] = d.bs[6 * bJ + c];  // right-hand side rides as row 0
@@ -1017,50 +1017,6 @@ __global__ __launch_bounds__((UW + PW) * 64) void ba_solve_la_kernel(BaDev d) {
     if (tid == 0) d.partial[kBaSolveOk] = failed ? 0.0 : 1.0;
 }
 
-// General path (any n_free): unblocked right-looking LL^T on the lower triangle of S in global memory with the
-// right-hand side carried as an extra row.  Latency-bound (three global round trips per column); only used for
-// windows with more than 43 free keyframes.
-__global__ __launch_bounds__(1024) void ba_solve_global_kernel(BaDev d) {
-    __shared__ int s_fail;
-    if (!d.lm->active) return;
-    const int n = 6 * d.n_free;
-    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-    double* S = d.S;
-    double* y = d.bs;  // becomes L^-1 b, then x
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
-    for (int j = 0; j < n; j++) {
-        if (tid == 0) {
-            const double dj = S[(size_t)j * n + j];
-            if (!(dj > 0.0)) s_fail = 1;
-            else S[(size_t)j * n + j] = sqrt(dj);
-        }
-        __syncthreads();
-        if (s_fail) break;
-        const double djj = S[(size_t)j * n + j];
-        for (int i = j + 1 + tid; i < n; i += 1024) S[(size_t)i * n + j] /= djj;
-        if (tid == 0) y[j] /= djj;
-        __syncthreads();
-        const double yj = y[j];
-        for (int i = j + 1 + ty; i < n; i += 32) {
-            const double lij = S[(size_t)i * n + j];
-            for (int k = j + 1 + tx; k <= i; k += 32) S[(size_t)i * n + k] -= lij * S[(size_t)k * n + j];
-            if (tx == 0) y[i] -= lij * yj;
-        }
-        __syncthreads();
-    }
-    if (!s_fail) {
-        for (int j = n - 1; j >= 0; j--) {  // L^T x = y
-            if (tid == 0) y[j] /= S[(size_t)j * n + j];
-            __syncthreads();
-            const double xj = y[j];
-            for (int i = tid; i < j; i += 1024) y[i] -= S[(size_t)j * n + i] * xj;
-            __syncthreads();
-        }
-    }
-    if (tid == 0) d.partial[kBaSolveOk] = s_fail ? 0.0 : 1.0;
-}
-
 static void launch_ba_schur(const BaDev& d, hipStream_t s) {
     const int nthreads = d.n_points > d.n_edges ? d.n_points : d.n_edges;
     if (nthreads > 0) hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d);
@@ -1084,7 +1040,7 @@ static void launch_ba_solve(const BaDev& d, hipStream_t s) {
     else if (NB <= kSolveMaxNB)
         hipLaunchKernelGGL((ba_solve_reg_kernel<512, 2>), dim3(1), dim3(512), 0, s, d);
     else
-        hipLaunchKernelGGL(ba_solve_global_kernel, dim3(1), dim3(1024), 0, s, d);
+        launch_ba_dense_solve(d, s);  // ba_dense.hip: blocked Cholesky on the FP64 matrix cores
 }
 
 // ---------------- back-substitution + manifold update into the trial buffers + scale partials ----------------

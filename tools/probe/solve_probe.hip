@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     hipMemset(dm, 0, sizeof(long long)*8*64);
     hipMemcpyToSymbol(HIP_SYMBOL(g_marks), &dm, sizeof(dm)); hipMemcpyToSymbol(HIP_SYMBOL(g_mark_tid), &mark_tid, sizeof(int));
     BaLm hl{}; hl.active = 1; BaLm* dl; hipMalloc(&dl, sizeof(BaLm)); hipMemcpy(dl, &hl, sizeof(BaLm), hipMemcpyHostToDevice);
-    BaDev d{}; d.n_free = nf; d.S = dS; d.bs = db; d.partial = dp; d.lm = dl;
+    BaDev d{}; d.n_free = nf; d.S = dS; d.bs = db; d.partial = dp; d.lm = dl; d.ldS = n;
 #ifdef SO_SOLVE_DEBUG
     double* dL; hipMalloc(&dL, sizeof(double) * (nf + 1) * (nf + 1) * 36);
     hipMemcpyToSymbol(HIP_SYMBOL(g_dbgL), &dL, sizeof(dL));
