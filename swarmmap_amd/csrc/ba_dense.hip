@@ -73,20 +73,86 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
         X[r][c] = 0.0;
     }
     __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    for (int j = 0; j < kDNB; j++) {
-        const double piv = A[j][j];
-        const double rinv = dense_rsqrt(piv);
-        if (tid == 0) {
-            if (!(piv > 0.0)) s_bad = 1;
-            s_rinv[j] = rinv;
+    // Blocked inside the workgroup, 16 columns at a time: (1) the 16x16 diagonal sub-block on one wave, a row per
+    // lane, pivots and multipliers by v_readlane (no LDS, no barrier); (2) every row below solves against it on its
+    // own thread; (3) rank-16 update of what is left, 5x5 register patches per thread.  Three barriers per 16
+    // columns instead of three per column.
+    const int ty = tid >> 4, tx = tid & 15, lane = tid & 63, wave = tid >> 6;
+    for (int jb = 0; jb < kDNB; jb += 16) {
+        if (wave == 0) {
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) x[c] = lane < 16 ? A[jb + lane][jb + c] : 0.0;
+            double ys[16];
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(x[c]), c);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(x[c]), c);
+                const double v = __hiloint2double(hi, lo);
+                if (!(v > 0.0)) bad = true;
+                const double y = dense_rsqrt(v);
+                ys[c] = y;
+                x[c] *= y;
+#pragma unroll
+                for (int c2 = c + 1; c2 < 16; c2++) {
+                    const int l0 = __builtin_amdgcn_readlane(__double2loint(x[c]), c2);
+                    const int l1 = __builtin_amdgcn_readlane(__double2hiint(x[c]), c2);
+                    x[c2] = fma(-x[c], __hiloint2double(l1, l0), x[c2]);
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) A[jb + lane][jb + c] = (c <= lane) ? x[c] : 0.0;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) s_rinv[jb + c] = ys[c];
+                if (bad) s_bad = 1;
+            }
         }
-        __syncthreads();  // everybody has read the pivot
-        for (int r = j + tid; r < kDNB; r += 256) A[r][j] = (r == j) ? piv * rinv : A[r][j] * rinv;
         __syncthreads();
-        for (int r = j + 1 + ty; r < kDNB; r += 16) {
-            const double lr = A[r][j];
-            for (int c = j + 1 + tx; c <= r; c += 16) A[r][c] = fma(-lr, A[c][j], A[r][c]);
+        const int below = kDNB - jb - 16;
+        if (tid < below) {  // x L_dd^T = a for one row
+            const int r = jb + 16 + tid;
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) x[c] = A[r][jb + c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                double v = x[c];
+#pragma unroll
+                for (int m = 0; m < c; m++) v = fma(-x[m], A[jb + c][jb + m], v);
+                x[c] = v * s_rinv[jb + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) A[r][jb + c] = x[c];
+        }
+        __syncthreads();
+        const int nb16 = below / 16, base = jb + 16;
+        if (nb16 > 0) {
+            double acc[5][5];
+#pragma unroll
+            for (int a = 0; a < 5; a++)
+#pragma unroll
+                for (int b = 0; b < 5; b++) acc[a][b] = 0.0;
+            for (int kk = 0; kk < 16; kk++) {
+                double pr[5], pc[5];
+#pragma unroll
+                for (int a = 0; a < 5; a++) {
+                    pr[a] = a < nb16 ? A[base + ty + 16 * a][jb + kk] : 0.0;
+                    pc[a] = a < nb16 ? A[base + tx + 16 * a][jb + kk] : 0.0;
+                }
+#pragma unroll
+                for (int a = 0; a < 5; a++)
+#pragma unroll
+                    for (int b = 0; b <= a; b++) acc[a][b] = fma(pr[a], pc[b], acc[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 5; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++)
+                    if (a < nb16) A[base + ty + 16 * a][base + tx + 16 * b] -= acc[a][b];
         }
         __syncthreads();
     }
@@ -286,7 +352,13 @@ __global__ __launch_bounds__(256) void dense_backward_kernel(BaDev d, int k) {
     if (c < k * kDNB) {
         const double* L = d.S + (size_t)k * kDNB * ld + c;
         double v = 0.0;
-        for (int m = 0; m < kDNB; m++) v = fma(L[(size_t)m * ld], s_x[m], v);
+        for (int m0 = 0; m0 < kDNB; m0 += 16) {  // 16 independent loads in flight per thread
+            double l[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) l[m] = L[(size_t)(m0 + m) * ld];
+#pragma unroll
+            for (int m = 0; m < 16; m++) v = fma(l[m], s_x[m0 + m], v);
+        }
         d.bs[c] -= v;
     }
     if (blockIdx.x == 0 && tid < kDNB) d.dense_x[(size_t)k * kDNB + tid] = s_x[tid];

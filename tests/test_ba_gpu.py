@@ -70,6 +70,31 @@ def test_global_bundle_adjustment_single_stage(opt, oracle):
         assert r["info"]["iterations_stage2"] == 0
 
 
+@pytest.mark.parametrize("n_free,n_points", [(60, 3000), (120, 6000), (299, 30000)])
+def test_global_ba_blocked_dense_solver_matches_oracle(opt, oracle, n_free, n_points):
+    """Maps with more free keyframes than one workgroup holds go through the blocked multi-workgroup Cholesky
+    (ba_dense.hip, FP64 MFMA tiles): 96-wide panels with 1, 2 and 19 panels (the last is BASELINE's GBA-1)."""
+    p = synth.make_ba_problem(200 + n_free, n_free, 1, n_points, max_obs="auto")
+    r = opt.BundleAdjustment(p, nIterations=10, bRobust=True)
+    o = oracle.bundle_adjust(p, its1=10, its2=0, robust=True, huber_delta=np.float32(np.sqrt(np.float32(5.99))))
+    _compare(r, o)  # (no ground-truth check: with one fixed keyframe a monocular map keeps its scale freedom)
+
+
+def test_gba2_eight_agent_map_properties(opt):
+    """GBA-2 (1499 free keyframes, 120 k points, ~780 k edges: the eight-agent map of BASELINE configs[4]) is too
+    large for the CPU oracle inside a test; size-independent properties instead: chi2 falls monotonically with the
+    iteration count, the gross outliers planted in the observations are found, the run is deterministic."""
+    p = synth.make_ba_case("GBA-2", 1)
+    r3 = opt.BundleAdjustment(p, nIterations=3, bRobust=True)
+    r6 = opt.BundleAdjustment(p, nIterations=6, bRobust=True)
+    again = opt.BundleAdjustment(p, nIterations=3, bRobust=True)
+    assert r3["info"]["chi2_initial"] == r6["info"]["chi2_initial"]
+    assert r6["info"]["chi2_final"] < r3["info"]["chi2_final"] < 0.7 * r3["info"]["chi2_initial"]
+    assert np.array_equal(r3["Tcw"], again["Tcw"]) and np.array_equal(r3["Xw"], again["Xw"])
+    assert r6["info"]["n_outliers"] >= 0.9 * p["gt_outlier"].sum()
+    assert (r6["outlier"].astype(bool) & p["gt_outlier"]).sum() >= 0.9 * p["gt_outlier"].sum()
+
+
 def test_noise_free_window_recovers_ground_truth(opt):
     p = synth.make_ba_problem(3, 6, 4, 300, pixel_sigma=0.0, outlier_frac=0.0, max_obs="auto")
     r = opt.solve(p, 30, 0, False, np.sqrt(5.991))
