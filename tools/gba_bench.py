@@ -1,0 +1,37 @@
+"""Global bundle adjustment (BASELINE configs[4]: the whole-map optimisation after a merge / loop closure) on one GPU:
+wall time per BundleAdjustment(10 iterations) and the FP64 rate of the blocked reduced-camera-system solve.
+    python tools/gba_bench.py            # GBA-1 and GBA-2 (SURVEY 8d sizes), JSON lines
+Not part of bench.py's per-frame metric; the numbers are quoted in DESIGN.md 5."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import swarmmap_amd  # noqa: E402
+from swarmmap_amd import synth  # noqa: E402
+
+FP64_PEAK_TF = 78.6
+
+def main():
+    o = swarmmap_amd.Optimizer()
+    for name in ("GBA-1", "GBA-2"):
+        p = synth.make_ba_case(name, 1)
+        o.BundleAdjustment(p, nIterations=2, bRobust=True)  # warm-up: buffers
+        t0 = time.perf_counter()
+        r = o.BundleAdjustment(p, nIterations=10, bRobust=True)
+        wall = time.perf_counter() - t0
+        inf = r["info"]
+        n = 6 * int((p["fixed"] == 0).sum())
+        flop = n ** 3 / 3.0 + 2.0 * n ** 2
+        ms = inf["solve_ms"] / max(inf["n_solves"], 1)
+        tf = flop / (ms * 1e-3) / 1e12
+        print(json.dumps({"case": name, "free_keyframes": n // 6, "points": int(len(p["Xw"])), "edges": int(len(p["edge_pose"])),
+                          "wall_ms": wall * 1e3, "gpu_ms": inf["gpu_ms"], "lm_trials": inf["lm_trials"],
+                          "chi2_initial": inf["chi2_initial"], "chi2_final": inf["chi2_final"],
+                          "solve": {"n": n, "ms_per_solve": ms, "algorithmic_flop": flop, "achieved_tflops": tf,
+                                    "peak_tflops": FP64_PEAK_TF, "frac": tf / FP64_PEAK_TF, "bound": "mfma"}}), flush=True)
+    o.close()
+
+if __name__ == "__main__":
+    main()
