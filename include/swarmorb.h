@@ -246,6 +246,40 @@ int so_matcher_last_kernel_ms(so_matcher* m, float* ms);
 int so_matcher_last_stats(so_matcher* m, double* stats4);
 
 /* ------------------------------------------------------------------------------------------------
+ * Frame post-processing between extractor and matcher — replaces, on flattened data,
+ * Frame::UndistortKeyPoints (code/src/Frame.cc:454-486), Frame::ComputeImageBounds (:488-514),
+ * Frame::AssignFeaturesToGrid + PosInGrid (:277-292, 431-443) and Frame::isInFrustum (:316-375) with
+ * MapPoint::PredictScale / Get{Min,Max}DistanceInvariance (code/src/MapPoint.cc:466-485).
+ * Conventions for the arithmetic the reference leaves to un-vendored OpenCV / libm: oracle/frame_oracle.h.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct so_camera {
+    float fx, fy, cx, cy;     /* mK */
+    float k1, k2, p1, p2, k3; /* mDistCoef; k1 == 0 means "no distortion" exactly like Frame.cc:456,490 */
+} so_camera;
+
+typedef struct so_frame_ctx so_frame_ctx;
+int so_frame_create(int device, so_frame_ctx** out);
+void so_frame_destroy(so_frame_ctx* f);
+
+/* The Frame constructor's steps after ExtractORB (Frame.cc:183-192, 230-274), one launch: xy (x0 y0 x1 y1 ...) ->
+ * xy_un; bounds4 = {mnMinX, mnMaxX, mnMinY, mnMaxY} is computed when compute_bounds != 0 (first frame / after a
+ * calibration change, Frame.cc:247-263) and read otherwise; grid outputs (all four non-NULL or all NULL):
+ * cell_of[i] = x * 48 + y or -1 outside, cell_start[64*48+1], cell_items = the cells' keypoints in push_back
+ * order, *n_inside.  At most 16384 keypoints. */
+int so_frame_prepare(so_frame_ctx* f, const so_camera* cam, int32_t width, int32_t height, int compute_bounds,
+                     int32_t n, const float* xy, float* xy_un, float* bounds4, int32_t* cell_of, int32_t* cell_start,
+                     int32_t* cell_items, int32_t* n_inside);
+
+/* Frame::isInFrustum for every local map point (Tracking::SearchLocalPoints, code/src/Tracking.cc:985-996):
+ * in_view[i] = mbTrackInView; proj_x / proj_y / view_cos / pred_level (mTrackProjX, mTrackProjY, mTrackViewCos,
+ * mnTrackScaleLevel) are written only where in_view[i] = 1, as the reference leaves them untouched otherwise.
+ * max_dist / min_dist are the map points' mfMaxDistance / mfMinDistance (the 1.2 / 0.8 factors are applied inside). */
+int so_frame_is_in_frustum(so_frame_ctx* f, const so_camera* cam, const float* bounds4, const float* Tcw12, int32_t n,
+                           const float* Xw, const float* normal, const float* max_dist, const float* min_dist,
+                           float viewing_cos_limit, float log_scale_factor, int32_t n_scale_levels, uint8_t* in_view,
+                           float* proj_x, float* proj_y, float* view_cos, int32_t* pred_level);
+
+/* ------------------------------------------------------------------------------------------------
  * Bundle adjustment — replaces Optimizer::LocalBundleAdjustment / BundleAdjustment / GlobalBundleAdjustment
  * (code/include/Optimizer.h:41-46, code/src/Optimizer.cc:42-237,436-740) and the g2o machinery they drive
  * (OptimizationAlgorithmLevenberg, BlockSolver_6_3 with Schur complement, LinearSolverEigen, RobustKernelHuber,

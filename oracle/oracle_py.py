@@ -363,3 +363,64 @@ def pose_optimization(Tcw, intr, Xw, obs, inv_sigma2):
     info = np.zeros(2, np.int32)
     n = lib().orc_pose_optimization(_p(T), _p(K), len(X), _p(X), _p(O), _p(W), _p(Tout), _p(outl), _p(info))
     return n, Tout, outl, {"iterations": int(info[0]), "lm_trials": int(info[1])}
+
+
+# ---- Frame post-processing (frame_oracle.h) --------------------------------------------------------
+class OrcCamera(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+
+def camera(K, dist=(0, 0, 0, 0, 0)):
+    d = list(dist) + [0.0] * (5 - len(dist))
+    return OrcCamera(*[float(v) for v in K], *[float(v) for v in d])
+
+
+def det_log(x):
+    lib().orc_log.restype = C.c_double
+    lib().orc_log.argtypes = [C.c_double]
+    return float(lib().orc_log(float(x)))
+
+
+def undistort_keypoints(cam, xy):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    lib().orc_undistort_keypoints(C.byref(cam), C.c_int32(len(xy)), _p(xy), _p(out))
+    return out
+
+
+def image_bounds(cam, width, height):
+    b = np.zeros(4, np.float32)
+    lib().orc_image_bounds(C.byref(cam), C.c_int32(width), C.c_int32(height), _p(b))
+    return b
+
+
+def assign_features_to_grid(xy_un, bounds):
+    xy = np.ascontiguousarray(xy_un, np.float32).reshape(-1, 2)
+    n = len(xy)
+    b = np.ascontiguousarray(bounds, np.float32)
+    cell_of = np.zeros(n, np.int32)
+    cell_start = np.zeros(64 * 48 + 1, np.int32)
+    items = np.zeros(max(n, 1), np.int32)
+    lib().orc_assign_features_to_grid.restype = C.c_int32
+    inside = lib().orc_assign_features_to_grid(C.c_int32(n), _p(xy), _p(b), _p(cell_of), _p(cell_start), _p(items))
+    return dict(cell_of=cell_of, cell_start=cell_start, cell_items=items[:inside])
+
+
+def is_in_frustum(cam, bounds, Tcw, Xw, normal, max_dist, min_dist, viewing_cos_limit, log_scale_factor, n_levels,
+                  init=None):
+    b = np.ascontiguousarray(bounds, np.float32)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    X = np.ascontiguousarray(Xw, np.float32).reshape(-1, 3)
+    N = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+    mx = np.ascontiguousarray(max_dist, np.float32)
+    mn = np.ascontiguousarray(min_dist, np.float32)
+    n = len(X)
+    in_view = np.zeros(n, np.uint8)
+    if init is None:
+        px, py, vc, lvl = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    else:
+        px, py, vc, lvl = [np.ascontiguousarray(a, t).copy() for a, t in zip(init, (np.float32,) * 3 + (np.int32,))]
+    lib().orc_is_in_frustum(C.byref(cam), _p(b), _p(T), C.c_int32(n), _p(X), _p(N), _p(mx), _p(mn),
+                            C.c_float(viewing_cos_limit), C.c_float(log_scale_factor), C.c_int32(n_levels), _p(in_view),
+                            _p(px), _p(py), _p(vc), _p(lvl))
+    return dict(in_view=in_view, proj_x=px, proj_y=py, view_cos=vc, pred_level=lvl)

@@ -1,0 +1,51 @@
+// frame_device.h — device side of the Frame post-processing between extractor and matcher:
+// UndistortKeyPoints + ComputeImageBounds + AssignFeaturesToGrid in one launch, isInFrustum in another.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace so {
+
+struct FrameCam {
+    float fx, fy, cx, cy, k1, k2, p1, p2, k3;
+};
+
+constexpr int kFrameGridCols = 64, kFrameGridRows = 48;  // FRAME_GRID_COLS / ROWS, code/include/Frame.h:37-38
+constexpr int kFrameMaxKeypoints = 16384;                // sort capacity of the grid kernel (LDS keys)
+
+struct FramePrepareArgs {
+    FrameCam cam;
+    int width, height, n;
+    int do_bounds;     // 1: ComputeImageBounds into bounds[4]; 0: bounds[] is an input
+    int do_undistort;  // 1: xy -> xy_un; 0: xy_un is an input
+    int do_grid;       // 1: cell_of / cell_start / cell_items / n_inside
+    const float* xy;   // 2n
+    float* xy_un;      // 2n
+    float* bounds;     // 4: mnMinX, mnMaxX, mnMinY, mnMaxY
+    int32_t* cell_of;     // n
+    int32_t* cell_start;  // 64*48+1
+    int32_t* cell_items;  // n
+    int32_t* n_inside;
+};
+void launch_frame_prepare(const FramePrepareArgs& a, hipStream_t s);
+
+struct FrameFrustumArgs {
+    FrameCam cam;
+    float bounds[4];
+    float Tcw[12];
+    int n;
+    const float* Xw;      // 3n
+    const float* normal;  // 3n
+    const float* max_dist;
+    const float* min_dist;
+    float viewing_cos_limit, log_scale_factor;
+    int n_scale_levels;
+    uint8_t* in_view;
+    float* proj_x;
+    float* proj_y;
+    float* view_cos;
+    int32_t* pred_level;
+};
+void launch_frame_frustum(const FrameFrustumArgs& a, hipStream_t s);
+
+}  // namespace so

@@ -1,0 +1,221 @@
+// frame_kernels.hip — gfx950 kernels of the Frame post-processing (code/src/Frame.cc:277-292, 316-375, 431-443,
+// 454-514; code/src/MapPoint.cc:466-485).  Compiled contraction-free like the ORB kernels: every floating-point
+// operation below is the one the CPU oracle performs, in the same order, so results are bit-identical.
+// Conventions for the arithmetic the reference delegates to un-vendored OpenCV / libm (parity unpinned):
+// see oracle/frame_oracle.h.
+#include "frame_device.h"
+
+namespace so {
+
+// ln x, fixed operation sequence (no libm): x = m 2^e, m in [sqrt(1/2), sqrt(2)), 2 atanh((m-1)/(m+1)) by 12 odd terms
+__device__ __forceinline__ double frame_log(double x) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)u);
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e = e + 1;
+    }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+}
+
+// cv::undistortPoints(p, K, D, R = I, P = K), criteria COUNT 5
+__device__ __forceinline__ void frame_undistort_point(const FrameCam& cam, float u, float v, float& uo, float& vo) {
+    const double fx = (double)cam.fx, fy = (double)cam.fy, cx = (double)cam.cx, cy = (double)cam.cy;
+    const double k1 = (double)cam.k1, k2 = (double)cam.k2, p1 = (double)cam.p1, p2 = (double)cam.p2, k3 = (double)cam.k3;
+    const double ifx = 1.0 / fx, ify = 1.0 / fy;
+    double x = ((double)u - cx) * ifx, y = ((double)v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2);
+        const double deltaX = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+        const double deltaY = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    uo = (float)(fx * x + cx);
+    vo = (float)(fy * y + cy);
+}
+
+// One workgroup: bounds (4 corner points), undistortion, cell of every keypoint, per-cell histogram + exclusive scan,
+// and the grid lists as a sort of (cell << 14 | index) keys in LDS — a cell's keypoints come out in index order,
+// which is the push_back order of AssignFeaturesToGrid.
+__global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a) {
+    __shared__ uint32_t s_key[kFrameMaxKeypoints];
+    __shared__ int s_hist[kFrameGridCols * kFrameGridRows + 1];
+    __shared__ int s_scan[1024];
+    __shared__ float s_b[4];
+    const int tid = threadIdx.x, n = a.n;
+    constexpr int ncell = kFrameGridCols * kFrameGridRows;
+    if (a.do_bounds) {
+        __shared__ float s_c[4][2];
+        if (tid < 4) {
+            if (a.cam.k1 != 0.0f) {
+                const float u = (tid & 1) ? (float)a.width : 0.0f, v = (tid & 2) ? (float)a.height : 0.0f;
+                frame_undistort_point(a.cam, u, v, s_c[tid][0], s_c[tid][1]);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (a.cam.k1 != 0.0f) {
+                s_b[0] = fminf(s_c[0][0], s_c[2][0]);
+                s_b[1] = fmaxf(s_c[1][0], s_c[3][0]);
+                s_b[2] = fminf(s_c[0][1], s_c[1][1]);
+                s_b[3] = fmaxf(s_c[2][1], s_c[3][1]);
+            } else {
+                s_b[0] = 0.0f; s_b[1] = (float)a.width; s_b[2] = 0.0f; s_b[3] = (float)a.height;
+            }
+            for (int i = 0; i < 4; i++) a.bounds[i] = s_b[i];
+        }
+    } else if (tid < 4) {
+        s_b[tid] = a.bounds[tid];
+    }
+    for (int c = tid; c <= ncell; c += 1024) s_hist[c] = 0;
+    __syncthreads();
+    if (a.do_undistort) {
+        for (int i = tid; i < n; i += 1024) {
+            float u = a.xy[2 * i], v = a.xy[2 * i + 1];
+            if (a.cam.k1 != 0.0f) frame_undistort_point(a.cam, u, v, u, v);  // else mvKeysUn = mvKeys
+            a.xy_un[2 * i] = u;
+            a.xy_un[2 * i + 1] = v;
+        }
+    }
+    if (!a.do_grid) return;
+    __threadfence_block();
+    __syncthreads();
+    const float inv_w = (float)kFrameGridCols / (s_b[1] - s_b[0]);  // Frame.cc:259-260
+    const float inv_h = (float)kFrameGridRows / (s_b[3] - s_b[2]);
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (int i = tid; i < n2; i += 1024) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (i < n) {
+            const int px = (int)roundf((a.xy_un[2 * i] - s_b[0]) * inv_w);  // PosInGrid
+            const int py = (int)roundf((a.xy_un[2 * i + 1] - s_b[2]) * inv_h);
+            int cell = -1;
+            if (!(px < 0 || px >= kFrameGridCols || py < 0 || py >= kFrameGridRows)) {
+                cell = px * kFrameGridRows + py;
+                key = ((uint32_t)cell << 14) | (uint32_t)i;
+                atomicAdd(&s_hist[cell], 1);
+            }
+            a.cell_of[i] = cell;
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    // exclusive scan of the 3072 cell counts: 3 cells per thread, then a block scan of the per-thread sums
+    int c0 = 0, c1 = 0, c2 = 0;
+    if (3 * tid < ncell) { c0 = s_hist[3 * tid]; c1 = s_hist[3 * tid + 1]; c2 = s_hist[3 * tid + 2]; }
+    s_scan[tid] = c0 + c1 + c2;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const int before = tid > 0 ? s_scan[tid - 1] : 0;
+    if (3 * tid < ncell) {
+        a.cell_start[3 * tid] = before;
+        a.cell_start[3 * tid + 1] = before + c0;
+        a.cell_start[3 * tid + 2] = before + c0 + c1;
+    }
+    if (tid == 1023) {
+        a.cell_start[ncell] = s_scan[1023];
+        *a.n_inside = s_scan[1023];
+    }
+    // bitonic sort of the keys (keys are unique; outside keypoints sort to the end)
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t x = s_key[i], y = s_key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) {
+                        s_key[i] = y;
+                        s_key[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const int inside = s_scan[1023];
+    for (int i = tid; i < inside; i += 1024) a.cell_items[i] = (int32_t)(s_key[i] & 0x3FFFu);
+}
+
+void launch_frame_prepare(const FramePrepareArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(frame_prepare_kernel, dim3(1), dim3(1024), 0, s, a);
+}
+
+// Frame::isInFrustum + MapPoint::PredictScale, one thread per map point
+__global__ __launch_bounds__(256) void frame_frustum_kernel(FrameFrustumArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const float* T = a.Tcw;
+    float Ow[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {  // mOw = -mRcw.t()*mtcw: double accumulation, one rounding
+        const double s = (double)T[0 + j] * (double)T[3] + (double)T[4 + j] * (double)T[7] + (double)T[8 + j] * (double)T[11];
+        Ow[j] = (float)(-s);
+    }
+    uint8_t ok = 0;
+    const float P[3] = {a.Xw[3 * i], a.Xw[3 * i + 1], a.Xw[3 * i + 2]};
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double s = (double)T[4 * r] * (double)P[0] + (double)T[4 * r + 1] * (double)P[1] + (double)T[4 * r + 2] * (double)P[2];
+        Pc[r] = (float)(s + (double)T[4 * r + 3]);
+    }
+    do {
+        if (Pc[2] < 0.0f) break;
+        const float invz = 1.0f / Pc[2];
+        const float u = a.cam.fx * Pc[0] * invz + a.cam.cx;
+        const float v = a.cam.fy * Pc[1] * invz + a.cam.cy;
+        if (u < a.bounds[0] || u > a.bounds[1]) break;
+        if (v < a.bounds[2] || v > a.bounds[3]) break;
+        const float maxD = 1.2f * a.max_dist[i], minD = 0.8f * a.min_dist[i];
+        const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+        const double n2 = (double)PO[0] * (double)PO[0] + (double)PO[1] * (double)PO[1] + (double)PO[2] * (double)PO[2];
+        const float dist = (float)sqrt(n2);
+        if (dist < minD || dist > maxD) break;
+        const double dot = (double)PO[0] * (double)a.normal[3 * i] + (double)PO[1] * (double)a.normal[3 * i + 1] +
+                           (double)PO[2] * (double)a.normal[3 * i + 2];
+        const float vc = (float)(dot / (double)dist);
+        if (vc < a.viewing_cos_limit) break;
+        const float ratio = a.max_dist[i] / dist;
+        const float lr = (float)frame_log((double)ratio);
+        int nScale = (int)ceilf(lr / a.log_scale_factor);
+        if (nScale > a.n_scale_levels - 1) nScale = a.n_scale_levels - 1;
+        if (nScale < 0) nScale = 0;
+        ok = 1;
+        a.proj_x[i] = u;
+        a.proj_y[i] = v;
+        a.view_cos[i] = vc;
+        a.pred_level[i] = nScale;
+    } while (false);
+    a.in_view[i] = ok;
+}
+
+void launch_frame_frustum(const FrameFrustumArgs& a, hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(frame_frustum_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace so

@@ -148,6 +148,7 @@ def make_m4_case(seed, n_kp=2000, p_flip=0.05, size=EUROC, shift=(12.0, -7.0)):
 # ------------------------------------------------------------------------------------------------
 EUROC_K = (458.654, 457.296, 367.215, 248.375)  # code/Examples/Monocular/EuRoC.yaml
 KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # code/Examples/Monocular/KITTI00-02.yaml
+EUROC_DIST = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)  # k1 k2 p1 p2, code/Examples/Monocular/EuRoC.yaml
 BA_CASES = {  # name: (free KFs, fixed KFs, points)
     "LBA-S": (8, 10, 800), "LBA-M": (25, 40, 3000), "LBA-L": (40, 60, 6000),
     "GBA-1": (299, 1, 30000), "GBA-2": (1499, 1, 120000),
@@ -280,3 +281,26 @@ def make_pose_case(seed, n=300, K=EUROC_K, size=EUROC, pixel_sigma=1.0, outlier_
     return dict(Tcw=T0.astype(np.float32), intr=np.array(K, np.float32), Xw=Xw.astype(np.float32),
                 obs=obs.astype(np.float32), inv_sigma2=(1.0 / scale ** 2).astype(np.float32),
                 gt_Tcw=np.hstack([R, t[:, None]]).reshape(12), gt_outlier=out)
+
+
+def make_frustum_case(seed, n=4000, K=EUROC_K, size=EUROC):
+    """A frame pose and local map points for Frame::isInFrustum: points in front / behind / outside the image,
+    inside / outside their scale-invariance range, seen frontally / at grazing angles."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = K
+    R = _rodrigues(rng.normal(0, 0.3, 3))
+    t = rng.normal(0, 1.0, 3)
+    Tcw = np.hstack([R, t[:, None]]).astype(np.float32)
+    uv = np.stack([rng.uniform(-150, size[0] + 150, n), rng.uniform(-150, size[1] + 150, n)], 1)
+    z = rng.uniform(0.5, 20, n) * np.where(rng.random(n) < 0.08, -1, 1)
+    pc = np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], 1)
+    Xw = (R.T @ (pc - t).T).T.astype(np.float32)
+    Ow = -R.T @ t
+    view = Xw - Ow
+    view /= np.linalg.norm(view, axis=1, keepdims=True) + 1e-12
+    tilt = np.stack([_rodrigues(rng.normal(0, 0.6, 3)) @ v for v in view])
+    normal = tilt.astype(np.float32)
+    d = np.linalg.norm(Xw - Ow, axis=1)
+    max_dist = (d * rng.uniform(0.6, 3.0, n)).astype(np.float32)
+    min_dist = (max_dist / (1.2 ** 7) * rng.uniform(0.8, 1.3, n)).astype(np.float32)
+    return dict(Tcw=Tcw.reshape(12), Xw=Xw, normal=normal, max_dist=max_dist, min_dist=min_dist)
