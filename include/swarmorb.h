@@ -237,6 +237,15 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
                             const uint8_t* qdesc, const float* q_angle, int32_t max_dist, int check_orientation,
                             int32_t* kp_to_query, int32_t* nmatches);
 
+/* MapPoint::ComputeDistinctiveDescriptors (code/src/MapPoint.cc:323-392) for a batch of map points (SURVEY 8f rank
+ * 4): point p owns descriptors [offsets[p], offsets[p+1]) (the rows the reference collects from its observing
+ * keyframes, in map order); best_idx[p] = index within the point's own list of the descriptor with the least
+ * median Hamming distance to the others (first one on ties, median = sorted row [int(0.5 (N-1))] with the zero
+ * self-distance included), -1 for a point without descriptors; best_median may be NULL.  At most 512
+ * observations per point. */
+int so_distinctive_descriptors(so_matcher* m, int32_t n_points, const int32_t* offsets, const uint8_t* descriptors,
+                               int32_t* best_idx, int32_t* best_median);
+
 /* HIP-event time (ms) of the kernels of the last matcher call on the matcher's stream. */
 int so_matcher_last_kernel_ms(so_matcher* m, float* ms);
 

@@ -621,3 +621,33 @@ int orc_search_window_greedy(const orc_frame_view* F, int32_t nq, const uint8_t*
     free(vIndices); free(rot_items); free(rot_bins); free(g.items);
     return nmatches;
 }
+
+/* MapPoint::ComputeDistinctiveDescriptors, code/src/MapPoint.cc:361-391 */
+static int cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+
+int orc_distinctive_descriptor(const uint8_t* descs, int32_t n, int32_t* median_out) {
+    int* dist = (int*)malloc(sizeof(int) * (size_t)n * (size_t)n);
+    int* row = (int*)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        dist[(size_t)i * n + i] = 0;
+        for (int j = i + 1; j < n; j++) {
+            const int d = orc_descriptor_distance(descs + 32 * (size_t)i, descs + 32 * (size_t)j);
+            dist[(size_t)i * n + j] = d;
+            dist[(size_t)j * n + i] = d;
+        }
+    }
+    int best_median = 2147483647, best_idx = 0;
+    for (int i = 0; i < n; i++) {
+        memcpy(row, dist + (size_t)i * n, sizeof(int) * (size_t)n);
+        qsort(row, (size_t)n, sizeof(int), cmp_int);
+        const int median = row[(int)(0.5 * (n - 1))];
+        if (median < best_median) {
+            best_median = median;
+            best_idx = i;
+        }
+    }
+    free(dist);
+    free(row);
+    if (median_out) *median_out = best_median;
+    return best_idx;
+}

@@ -128,6 +128,10 @@ int orc_search_window_greedy(const orc_frame_view* F, int32_t nq, const uint8_t*
                              const int32_t* max_level, const uint8_t* qdesc, const float* q_angle, int max_dist,
                              int check_orientation, int32_t* kp_to_query);
 
+/* MapPoint::ComputeDistinctiveDescriptors, code/src/MapPoint.cc:361-391, on the N >= 1 descriptors of one map
+ * point: returns BestIdx (the first row with the least median), *median_out = BestMedian. */
+int orc_distinctive_descriptor(const uint8_t* descs, int32_t n, int32_t* median_out);
+
 #ifdef __cplusplus
 }
 #endif

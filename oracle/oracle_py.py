@@ -424,3 +424,20 @@ def is_in_frustum(cam, bounds, Tcw, Xw, normal, max_dist, min_dist, viewing_cos_
                             C.c_float(viewing_cos_limit), C.c_float(log_scale_factor), C.c_int32(n_levels), _p(in_view),
                             _p(px), _p(py), _p(vc), _p(lvl))
     return dict(in_view=in_view, proj_x=px, proj_y=py, view_cos=vc, pred_level=lvl)
+
+
+def distinctive_descriptors(offsets, descriptors):
+    """MapPoint::ComputeDistinctiveDescriptors per map point: (best_idx, best_median) arrays, -1 for empty points."""
+    off = np.ascontiguousarray(offsets, np.int32)
+    d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+    n = len(off) - 1
+    idx, med = np.full(n, -1, np.int32), np.full(n, 2 ** 31 - 1, np.int32)
+    lib().orc_distinctive_descriptor.restype = C.c_int
+    for p in range(n):
+        k = int(off[p + 1] - off[p])
+        if k > 0:
+            m = C.c_int32(0)
+            blk = np.ascontiguousarray(d[off[p]:off[p + 1]])
+            idx[p] = lib().orc_distinctive_descriptor(_p(blk), C.c_int32(k), C.byref(m))
+            med[p] = m.value
+    return idx, med

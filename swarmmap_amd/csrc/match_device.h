@@ -46,6 +46,9 @@ struct MatchQuery {
 
 void launch_topk_window(const MatchFrameDev& F, const MatchQuery* d_q, const uint4* d_qdesc, int nq, int K,
                         uint32_t* d_keys, int32_t* d_count, hipStream_t s);
+constexpr int kDistinctiveMaxObs = 512;
+void launch_distinctive_desc(const uint4* d_desc, const int32_t* d_off, int n_points, int32_t* d_best_idx,
+                             int32_t* d_best_median, hipStream_t s);
 void launch_hamming_top2(const uint4* d_A, int na, const uint4* d_B, int nb, int32_t* d_best_idx, int32_t* d_best_dist,
                          int32_t* d_second_dist, hipStream_t s);
 

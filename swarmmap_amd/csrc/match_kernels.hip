@@ -188,6 +188,63 @@ __global__ __launch_bounds__(256) void hamming_top2_kernel(const uint4* __restri
     }
 }
 
+// ---------------- MapPoint::ComputeDistinctiveDescriptors (code/src/MapPoint.cc:323-392), batched ----------------
+// One wave per map point.  The point's N observed descriptors sit in LDS; lane i owns row i of the N x N Hamming
+// matrix and never materialises it: it histograms its N distances (self-distance 0 included, as the reference's
+// vDists does) into a private 257-bin LDS histogram and walks the bins to the element of rank int(0.5 (N-1)) — the
+// median the reference reads out of its sorted row.  The winner is the smallest (median, row) pair, i.e. the
+// first row with the least median, found by a wave-min over median << 16 | row.
+constexpr int kDdMaxObs = 512;  // observations per map point handled on the device
+
+__global__ __launch_bounds__(64) void distinctive_desc_kernel(const uint4* __restrict__ desc, const int32_t* __restrict__ off,
+                                                              int n_points, int32_t* __restrict__ best_idx,
+                                                              int32_t* __restrict__ best_median) {
+    __shared__ uint4 s_desc[2 * kDdMaxObs];
+    __shared__ uint16_t s_hist[64][258];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= n_points) return;
+    const int base = off[p], N = off[p + 1] - base;
+    if (N <= 0) {
+        if (lane == 0) { best_idx[p] = -1; best_median[p] = 0x7fffffff; }
+        return;
+    }
+    for (int i = lane; i < 2 * N; i += 64) s_desc[i] = desc[2 * (size_t)base + i];
+    __syncthreads();
+    const int k = (int)(0.5 * (double)(N - 1));  // vDists[0.5*(N-1)]
+    uint32_t best = 0xFFFFFFFFu;
+    for (int row0 = 0; row0 < N; row0 += 64) {
+        const int i = row0 + lane;
+        for (int b = 0; b < 258; b++) s_hist[lane][b] = 0;
+        if (i < N) {
+            const uint4 a0 = s_desc[2 * i], a1 = s_desc[2 * i + 1];
+            for (int j = 0; j < N; j++) s_hist[lane][hamming256(s_desc[2 * j], s_desc[2 * j + 1], a0, a1)]++;
+            int cum = 0, med = 0;
+            for (int b = 0; b <= 256; b++) {
+                cum += s_hist[lane][b];
+                if (cum > k) { med = b; break; }
+            }
+            const uint32_t key = ((uint32_t)med << 16) | (uint32_t)i;
+            best = key < best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)best, o);
+        best = other < best ? other : best;
+    }
+    if (lane == 0) {
+        best_idx[p] = (int32_t)(best & 0xFFFFu);
+        best_median[p] = (int32_t)(best >> 16);
+    }
+}
+
+void launch_distinctive_desc(const uint4* d_desc, const int32_t* d_off, int n_points, int32_t* d_best_idx,
+                             int32_t* d_best_median, hipStream_t s) {
+    if (n_points <= 0) return;
+    hipLaunchKernelGGL(distinctive_desc_kernel, dim3(n_points), dim3(64), 0, s, d_desc, d_off, n_points, d_best_idx,
+                       d_best_median);
+}
+
 void launch_hamming_top2(const uint4* d_A, int na, const uint4* d_B, int nb, int32_t* d_best_idx,
                          int32_t* d_best_dist, int32_t* d_second_dist, hipStream_t s) {
     if (na <= 0) return;

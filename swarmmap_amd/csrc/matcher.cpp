@@ -747,6 +747,44 @@ int so_hamming_top2(so_matcher* m, const uint8_t* A, int32_t na, const uint8_t* 
     return top2_common(m, (const uint4*)m->d_A.p, na, (const uint4*)m->d_B.p, nb, best_idx, best_dist, second_dist);
 }
 
+// MapPoint::ComputeDistinctiveDescriptors for a batch of map points (code/src/MapPoint.cc:323-392)
+int so_distinctive_descriptors(so_matcher* m, int32_t n_points, const int32_t* offsets, const uint8_t* descriptors,
+                               int32_t* best_idx, int32_t* best_median) {
+    if (!m || n_points < 0 || (n_points > 0 && (!offsets || !best_idx))) return SO_ERR_INVALID_ARG;
+    if (n_points == 0) return SO_OK;
+    const int total = offsets[n_points];
+    if (offsets[0] != 0 || total < 0 || (total > 0 && !descriptors)) return SO_ERR_INVALID_ARG;
+    for (int p = 0; p < n_points; p++) {
+        const int N = offsets[p + 1] - offsets[p];
+        if (N < 0) return SO_ERR_INVALID_ARG;
+        if (N > kDistinctiveMaxObs) {
+            last_error_ref() = "a map point has more than 512 observations";
+            return SO_ERR_CAPACITY;
+        }
+    }
+    SO_HIP(hipSetDevice(m->device));
+    int rc;
+    const size_t off_bytes = (sizeof(int32_t) * ((size_t)n_points + 1) + 255) & ~(size_t)255;
+    const size_t in_bytes = off_bytes + (size_t)(total > 0 ? total : 1) * 32;
+    if ((rc = m->h_in.ensure_keep(in_bytes, 0))) return rc;
+    if (m->d_in.cap < in_bytes && (rc = m->d_in.ensure(m->h_in.cap))) return rc;
+    m->dirty_from = 0;  // the staging block no longer holds a candidate frame
+    if ((rc = m->h_out.ensure(sizeof(int32_t) * 2 * (size_t)n_points))) return rc;
+    memcpy(m->h_in.p, offsets, sizeof(int32_t) * ((size_t)n_points + 1));
+    if (total > 0) memcpy((uint8_t*)m->h_in.p + off_bytes, descriptors, (size_t)total * 32);
+    hipStream_t s = m->stream;
+    SO_HIP(hipMemcpyAsync(m->d_in.p, m->h_in.p, in_bytes, hipMemcpyHostToDevice, s));
+    int32_t* out = (int32_t*)m->h_out.dev;
+    launch_distinctive_desc((const uint4*)((const uint8_t*)m->d_in.p + off_bytes), (const int32_t*)m->d_in.p, n_points,
+                            out, out + n_points, s);
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipStreamSynchronize(s));
+    const int32_t* ho = (const int32_t*)m->h_out.p;
+    memcpy(best_idx, ho, sizeof(int32_t) * (size_t)n_points);
+    if (best_median) memcpy(best_median, ho + n_points, sizeof(int32_t) * (size_t)n_points);
+    return SO_OK;
+}
+
 int so_hamming_top2_device(so_matcher* m, const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb,
                            int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
     if (!m || na < 0 || nb < 0 || (na > 0 && (!d_A || !best_idx || !best_dist || !second_dist)) || (nb > 0 && !d_B))

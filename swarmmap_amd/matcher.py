@@ -93,6 +93,16 @@ class ORBmatcher:
         return ms.value
 
     # SearchByProjection(Frame&, const vector<MapPoint*>&, th) — ORBmatcher.cc:44-121
+    # MapPoint::ComputeDistinctiveDescriptors for a batch of map points — MapPoint.cc:323-392
+    def ComputeDistinctiveDescriptors(self, offsets, descriptors):
+        off = np.ascontiguousarray(offsets, np.int32)
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(off) - 1
+        idx, med = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self._lib.so_distinctive_descriptors.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.check(self._lib.so_distinctive_descriptors(self._h, n, _vp(off), _vp(d), _vp(idx), _vp(med)))
+        return idx, med
+
     def last_stats(self):
         st = (C.c_double * 4)()
         _lib.check(self._lib.so_matcher_last_stats(self._h, st))

@@ -249,3 +249,27 @@ def test_m7_window_greedy(S, oracle, seed, max_dist, ori):
     assert nm == onm and np.array_equal(k2q, ok2q)
     assert nm > 200
     m.close()
+
+
+def test_distinctive_descriptors_batch_matches_oracle(S, oracle):
+    """SURVEY 8f rank 4: MapPoint::ComputeDistinctiveDescriptors over a batch of map points, bit-exact (indices,
+    medians), including empty points, single observations, ties and a point with 512 observations."""
+    rng = np.random.default_rng(21)
+    counts = np.concatenate([[0, 1, 2, 2, 3, 64, 65, 130, 512], rng.integers(1, 40, 3000)])
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    descs = np.zeros((off[-1], 32), np.uint8)
+    for p, n in enumerate(counts):
+        if n == 0:
+            continue
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        flips = rng.uniform(0.0, 0.25, n)
+        descs[off[p]:off[p + 1]] = [np.bitwise_xor(base, np.packbits(rng.random(256) < f)) for f in flips]
+    descs[off[3]:off[4]] = descs[off[3]]  # two identical observations: a tie, the first wins
+    m = S.ORBmatcher()
+    idx, med = m.ComputeDistinctiveDescriptors(off, descs)
+    oidx, omed = oracle.distinctive_descriptors(off, descs)
+    assert np.array_equal(idx, oidx) and np.array_equal(med, omed)
+    assert idx[0] == -1 and idx[1] == 0 and idx[3] == 0
+    with pytest.raises(S.SwarmOrbError):
+        m.ComputeDistinctiveDescriptors([0, 513], np.zeros((513, 32), np.uint8))
+    m.close()

@@ -155,3 +155,18 @@ def test_bow_triangulation_window_oracles(oracle):
             if dd < bdist:
                 best, bdist = int(c), dd
         assert (bi[i], bd[i]) == (best, bdist)
+
+
+def test_distinctive_descriptor_against_numpy(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors: least median of the Hamming rows, first index on ties."""
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 4, 9, 30):
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        d = np.stack([np.bitwise_xor(base, np.packbits(rng.random(256) < p)) for p in rng.uniform(0.0, 0.3, n)])
+        bits = np.unpackbits(d, axis=1)
+        D = (bits[:, None, :] != bits[None, :, :]).sum(2)
+        med = np.sort(D, axis=1)[:, int(0.5 * (n - 1))]
+        idx, m = oracle.distinctive_descriptors([0, n], d)
+        assert m[0] == med.min() and idx[0] == int(np.argmax(med == med.min()))
+    idx, m = oracle.distinctive_descriptors([0, 0, 2], np.zeros((2, 32), np.uint8))
+    assert idx.tolist() == [-1, 0] and m[1] == 0
