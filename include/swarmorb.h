@@ -14,6 +14,7 @@
 #ifndef SWARMORB_H
 #define SWARMORB_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -287,6 +288,36 @@ int so_frame_is_in_frustum(so_frame_ctx* f, const so_camera* cam, const float* b
                            const float* Xw, const float* normal, const float* max_dist, const float* min_dist,
                            float viewing_cos_limit, float log_scale_factor, int32_t n_scale_levels, uint8_t* in_view,
                            float* proj_x, float* proj_y, float* view_cos, int32_t* pred_level);
+
+/* ------------------------------------------------------------------------------------------------
+ * Keyframe record — the compact binary form of what a peer needs from a keyframe for the
+ * loop / merge candidate search, replacing the Boost text archive of code/src/MapUpdater.cc:190-230 /
+ * code/include/KeyFrame.h:310-406 on the agent-to-agent path.  Layout (little-endian):
+ *   [so_keyframe_header, 128 B][descriptors n x 32 B][geometry n x {x f32, y f32, angle f32, octave i32}]
+ * The descriptor block starts on a 32-byte row so the Hamming kernels read it in place inside an all-gathered
+ * slot.  Host-side functions, no GPU involved.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct so_keyframe_header {
+    uint32_t magic;        /* "SOKF", filled by pack */
+    uint16_t version;      /* 1, filled by pack */
+    uint16_t header_bytes; /* sizeof(so_keyframe_header), filled by pack */
+    int32_t agent_id;      /* mnClientId */
+    int32_t n_keypoints;   /* N */
+    uint64_t keyframe_id;  /* mnId */
+    double timestamp;      /* mTimeStamp */
+    uint64_t checksum;     /* of the descriptor + geometry blocks, filled by pack */
+    float Tcw[12];         /* pose, 3x4 row-major */
+    float K[4];            /* fx fy cx cy */
+    uint8_t reserved[24];
+} so_keyframe_header;
+
+size_t so_keyframe_record_size(int32_t n_keypoints); /* 128 + 48 n */
+int so_keyframe_record_pack(const so_keyframe_header* hdr, const float* xy, const float* angle, const int32_t* octave,
+                            const uint8_t* descriptors, uint8_t* out, size_t capacity);
+/* Validates magic / version / checksum, fills *hdr, then copies out up to `capacity` keypoints (SO_ERR_CAPACITY
+ * with *hdr filled when the record holds more); output arrays may be NULL. */
+int so_keyframe_record_unpack(const uint8_t* rec, size_t length, so_keyframe_header* hdr, float* xy, float* angle,
+                              int32_t* octave, uint8_t* descriptors, int32_t capacity);
 
 /* ------------------------------------------------------------------------------------------------
  * Bundle adjustment — replaces Optimizer::LocalBundleAdjustment / BundleAdjustment / GlobalBundleAdjustment

@@ -28,6 +28,67 @@ def slot_checksum(desc):
     return int((d.astype(np.uint64) * w).sum() % np.uint64((1 << 61) - 1))
 
 
+# ---- compact binary keyframe record (include/swarmorb.h: so_keyframe_record_*) -------------------------------
+import ctypes as _C
+
+
+class SoKeyframeHeader(_C.Structure):
+    _fields_ = [("magic", _C.c_uint32), ("version", _C.c_uint16), ("header_bytes", _C.c_uint16),
+                ("agent_id", _C.c_int32), ("n_keypoints", _C.c_int32), ("keyframe_id", _C.c_uint64),
+                ("timestamp", _C.c_double), ("checksum", _C.c_uint64), ("Tcw", _C.c_float * 12), ("K", _C.c_float * 4),
+                ("reserved", _C.c_uint8 * 24)]
+
+
+RECORD_HEADER_BYTES = 128
+RECORD_HEADER_ROWS = RECORD_HEADER_BYTES // 32
+
+
+def _rec_lib():
+    from . import _lib
+    lib = _lib.load_library()
+    vp = _C.c_void_p
+    lib.so_keyframe_record_size.restype = _C.c_size_t
+    lib.so_keyframe_record_size.argtypes = [_C.c_int32]
+    lib.so_keyframe_record_pack.argtypes = [_C.POINTER(SoKeyframeHeader), vp, vp, vp, vp, vp, _C.c_size_t]
+    lib.so_keyframe_record_unpack.argtypes = [vp, _C.c_size_t, _C.POINTER(SoKeyframeHeader), vp, vp, vp, vp, _C.c_int32]
+    return lib, _lib
+
+
+def pack_keyframe_record(agent_id, keyframe_id, timestamp, Tcw, K, xy, angle, octave, desc, out=None):
+    """Returns the record as a uint8 array (128 + 48 n bytes), written into `out` when given."""
+    lib, _l = _rec_lib()
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    angle = np.ascontiguousarray(angle, np.float32)
+    octave = np.ascontiguousarray(octave, np.int32)
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    h = SoKeyframeHeader()
+    h.agent_id, h.n_keypoints, h.keyframe_id, h.timestamp = int(agent_id), n, int(keyframe_id), float(timestamp)
+    h.Tcw[:] = [float(v) for v in np.asarray(Tcw, np.float32).reshape(12)]
+    h.K[:] = [float(v) for v in np.asarray(K, np.float32).reshape(4)]
+    size = lib.so_keyframe_record_size(n)
+    if out is None:
+        out = np.zeros(size, np.uint8)
+    _l.check(lib.so_keyframe_record_pack(_C.byref(h), xy.ctypes.data, angle.ctypes.data, octave.ctypes.data,
+                                         desc.ctypes.data, out.ctypes.data, out.nbytes))
+    return out[:size]
+
+
+def unpack_keyframe_record(rec):
+    lib, _l = _rec_lib()
+    rec = np.ascontiguousarray(rec, np.uint8).reshape(-1)
+    h = SoKeyframeHeader()
+    rc = lib.so_keyframe_record_unpack(rec.ctypes.data, rec.nbytes, _C.byref(h), None, None, None, None, 0)
+    if rc not in (0, 4):  # SO_OK or SO_ERR_CAPACITY (header filled, nothing copied)
+        _l.check(rc)
+    n = h.n_keypoints
+    xy, angle, octave, desc = np.zeros((n, 2), np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 32), np.uint8)
+    _l.check(lib.so_keyframe_record_unpack(rec.ctypes.data, rec.nbytes, _C.byref(h), xy.ctypes.data, angle.ctypes.data,
+                                           octave.ctypes.data, desc.ctypes.data, n))
+    return dict(agent_id=h.agent_id, keyframe_id=h.keyframe_id, timestamp=h.timestamp, checksum=h.checksum,
+                Tcw=np.array(h.Tcw[:], np.float32), K=np.array(h.K[:], np.float32), xy=xy, angle=angle, octave=octave, desc=desc)
+
+
 class KeyframeExchange:
     def __init__(self, slot_keypoints=2024, device=None, group=None):
         if not dist.is_initialized():
@@ -82,4 +143,27 @@ class KeyframeExchange:
             theirs = base + peer * row_bytes + HEADER_ROWS * 32
             bi, bd, sd = matcher.hamming_top2_device(mine, int(counts[self.rank]), theirs, int(counts[peer]))
             out[peer] = int(((bd <= max_dist) & (bd < ratio * sd)).sum())
+        return out
+
+    # ---- full keyframe records (geometry + pose travel with the descriptors) ----
+    def exchange_records(self, record):
+        """All-gather one keyframe RECORD per rank (pack_keyframe_record); the slot must have been created with
+        record slots (slot_keypoints x 48 B + 128 B fit in (HEADER_ROWS + slot_keypoints) x 32 B x 1.5).  Returns the
+        list of unpacked records in rank order (None for a rank whose slot is empty)."""
+        rec = np.ascontiguousarray(record, np.uint8).reshape(-1)
+        cap = self.slot.numel()
+        if rec.nbytes > cap:
+            raise ValueError("keyframe record of %d bytes does not fit the %d-byte slot" % (rec.nbytes, cap))
+        hs = self._host_slot.numpy().reshape(-1)
+        hs[:] = 0
+        hs[:rec.nbytes] = rec
+        self.slot.copy_(self._host_slot, non_blocking=True)
+        if self.device.type == "cuda":
+            dist.all_gather_into_tensor(self.gathered, self.slot, group=self.group)
+        else:
+            dist.all_gather(list(self.gathered.unbind(0)), self.slot, group=self.group)
+        flat = self.gathered.reshape(self.world, -1).cpu().numpy()
+        out = []
+        for r in range(self.world):
+            out.append(unpack_keyframe_record(flat[r]) if flat[r, :4].tobytes() == b"SOKF" else None)
         return out

@@ -46,3 +46,32 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_py" not in txt and "liboracle" not in txt and "orb_oracle" not in txt, f
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_keyframe_record_round_trip_and_corruption():
+    """so_keyframe_record_{size,pack,unpack}: host-side format functions, exercised without a GPU."""
+    import numpy as np
+    import pytest
+    import swarmmap_amd
+    from swarmmap_amd.parallel import pack_keyframe_record, unpack_keyframe_record
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 1000):
+        xy = rng.uniform(0, 752, (n, 2)).astype(np.float32)
+        ang = rng.uniform(0, 360, n).astype(np.float32)
+        octv = rng.integers(0, 8, n).astype(np.int32)
+        desc = rng.integers(0, 256, (n, 32)).astype(np.uint8)
+        T = rng.normal(size=12).astype(np.float32)
+        rec = pack_keyframe_record(3, 2 ** 40 + 7, 12.5, T, (1, 2, 3, 4), xy, ang, octv, desc)
+        assert rec.nbytes == 128 + 48 * n and rec[:4].tobytes() == b"SOKF"
+        assert np.array_equal(rec[128:128 + 32 * n].reshape(-1, 32), desc)  # descriptors in place, on a 32-byte row
+        u = unpack_keyframe_record(rec)
+        assert u["agent_id"] == 3 and u["keyframe_id"] == 2 ** 40 + 7 and u["timestamp"] == 12.5
+        assert np.array_equal(u["xy"], xy) and np.array_equal(u["angle"], ang) and np.array_equal(u["octave"], octv)
+        assert np.array_equal(u["desc"], desc) and np.array_equal(u["Tcw"], T) and u["K"].tolist() == [1, 2, 3, 4]
+        if n:
+            bad = rec.copy()
+            bad[130] ^= 1  # a flipped payload bit is caught by the checksum
+            with pytest.raises(swarmmap_amd.SwarmOrbError):
+                unpack_keyframe_record(bad)
+    with pytest.raises(swarmmap_amd.SwarmOrbError):
+        unpack_keyframe_record(np.zeros(128, np.uint8))

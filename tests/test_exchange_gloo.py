@@ -41,6 +41,24 @@ def _worker(rank, world, port, q):
             assert np.array_equal(got, want)
             assert sums[r] == slot_checksum(want)
         results.append((counts.tolist(), [int(s) for s in sums]))
+    # full keyframe records (descriptors + geometry + pose) through the same collective
+    from swarmmap_amd.parallel import pack_keyframe_record
+    xr = KeyframeExchange(slot_keypoints=1600)  # 1601 rows x 32 B hold a record of up to 1064 keypoints
+    for tick, n in enumerate([700, 1 + 300 * rank, 0]):
+        def make(r, nn):
+            g2 = np.random.default_rng(77 * tick + r)
+            return dict(xy=g2.uniform(0, 752, (nn, 2)).astype(np.float32), angle=g2.uniform(0, 360, nn).astype(np.float32),
+                        octave=g2.integers(0, 8, nn).astype(np.int32), desc=g2.integers(0, 256, (nn, 32)).astype(np.uint8),
+                        Tcw=g2.normal(size=12).astype(np.float32))
+        mine = make(rank, n)
+        rec = pack_keyframe_record(rank, 100 * tick + rank, 0.05 * tick, mine["Tcw"], (458.654, 457.296, 367.215, 248.375),
+                                   mine["xy"], mine["angle"], mine["octave"], mine["desc"])
+        got = xr.exchange_records(rec)
+        for r in range(world):
+            want = make(r, [700, 1 + 300 * r, 0][tick])
+            assert got[r] is not None and got[r]["agent_id"] == r and got[r]["keyframe_id"] == 100 * tick + r
+            for k in ("xy", "angle", "octave", "desc", "Tcw"):
+                assert np.array_equal(got[r][k], want[k]), k
     q.put((rank, results))
     dist.destroy_process_group()
 
