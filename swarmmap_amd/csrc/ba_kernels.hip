@@ -1510,6 +1510,67 @@ __device__ __forceinline__ void po_halve(double* v, int off, int lane) {
     }
 }
 
+// pose <- SE3Quat::exp(u) * pose for the LM steps of PoseOptimization, off the libm path: lane 0 evaluates this
+// once per trial while 511 threads wait, so sin / cos / sqrt / the divisions of se3_exp_mul are replaced by the
+// Taylor series of sin(t)/t, (1-cos t)/t^2, (t-sin t)/t^3 in t^2 (|t| < 0.25 rad: 8 terms reach double precision
+// and avoid the cancellation of the closed forms) and by reciprocal-square-root normalisations.  Larger steps
+// (never seen in tracking: 0.25 rad is 14 degrees between consecutive LM trials) take the closed forms.
+__device__ void se3_exp_mul_small(const double* u, const BaPose& in, BaPose& out) {
+    const double w0 = u[0], w1 = u[1], w2 = u[2];
+    const double t2 = w0 * w0 + w1 * w1 + w2 * w2;
+    if (t2 > 0.0625) {
+        se3_exp_mul(u, in, out);
+        return;
+    }
+    double a = 1.0 / 1307674368000.0, b = 1.0 / 20922789888000.0, c = 1.0 / 355687428096000.0;  // 1/15!, 1/16!, 1/17!
+    a = fma(-a, t2, 1.0 / 6227020800.0);  b = fma(-b, t2, 1.0 / 87178291200.0);  c = fma(-c, t2, 1.0 / 1307674368000.0);
+    a = fma(-a, t2, 1.0 / 39916800.0);    b = fma(-b, t2, 1.0 / 479001600.0);    c = fma(-c, t2, 1.0 / 6227020800.0);
+    a = fma(-a, t2, 1.0 / 362880.0);      b = fma(-b, t2, 1.0 / 3628800.0);      c = fma(-c, t2, 1.0 / 39916800.0);
+    a = fma(-a, t2, 1.0 / 5040.0);        b = fma(-b, t2, 1.0 / 40320.0);        c = fma(-c, t2, 1.0 / 362880.0);
+    a = fma(-a, t2, 1.0 / 120.0);         b = fma(-b, t2, 1.0 / 720.0);          c = fma(-c, t2, 1.0 / 5040.0);
+    a = fma(-a, t2, 1.0 / 6.0);           b = fma(-b, t2, 1.0 / 24.0);           c = fma(-c, t2, 1.0 / 120.0);
+    a = fma(-a, t2, 1.0);                 b = fma(-b, t2, 0.5);                  c = fma(-c, t2, 1.0 / 6.0);
+    const double Om[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    double Om2[9], R[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Om2[i * 3 + j] = Om[i * 3] * Om[j] + Om[i * 3 + 1] * Om[3 + j] + Om[i * 3 + 2] * Om[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
+        V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * Om[i] + c * Om2[i];
+    }
+    // Quaterniond(R) for a rotation this close to the identity: trace > 0 branch
+    double qa[4];
+    {
+        const double tr = R[0] + R[4] + R[8] + 1.0;  // = 4 w^2
+        const double y = rsqrt_newton(tr);
+        qa[3] = 0.5 * tr * y;
+        const double h = 0.5 * y;
+        qa[0] = (R[7] - R[5]) * h;
+        qa[1] = (R[2] - R[6]) * h;
+        qa[2] = (R[3] - R[1]) * h;
+        const double n = rsqrt_newton(qa[0] * qa[0] + qa[1] * qa[1] + qa[2] * qa[2] + qa[3] * qa[3]);
+        qa[0] *= n; qa[1] *= n; qa[2] *= n; qa[3] *= n;
+    }
+    double ta[3], rt[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) ta[i] = V[i * 3] * u[3] + V[i * 3 + 1] * u[4] + V[i * 3 + 2] * u[5];
+    quat_rotate(qa, in.t, rt);
+    out.t[0] = ta[0] + rt[0]; out.t[1] = ta[1] + rt[1]; out.t[2] = ta[2] + rt[2];
+    const double* q = in.q;
+    double qn[4];
+    qn[3] = qa[3] * q[3] - qa[0] * q[0] - qa[1] * q[1] - qa[2] * q[2];
+    qn[0] = qa[3] * q[0] + qa[0] * q[3] + qa[1] * q[2] - qa[2] * q[1];
+    qn[1] = qa[3] * q[1] + qa[1] * q[3] + qa[2] * q[0] - qa[0] * q[2];
+    qn[2] = qa[3] * q[2] + qa[2] * q[3] + qa[0] * q[1] - qa[1] * q[0];
+    if (qn[3] < 0) { qn[0] = -qn[0]; qn[1] = -qn[1]; qn[2] = -qn[2]; qn[3] = -qn[3]; }
+    const double n = rsqrt_newton(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    out.q[0] = qn[0] * n; out.q[1] = qn[1] * n; out.q[2] = qn[2] * n; out.q[3] = qn[3] * n;
+    out.pad = 0;
+}
+
 // 6x6 SPD solve (H + lambda I) x = b by Cholesky with reciprocal square roots; also computeScale
 __device__ void po_solve6(const double* H, const double* b, double lambda, double* x, double& scale, int& ok) {
     double A[36], ri[6];
@@ -1599,14 +1660,20 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
             const double X[3] = {(double)s_X[3 * e], (double)s_X[3 * e + 1], (double)s_X[3 * e + 2]};
             double pc[3];
             camera_point(T, X, pc);
-            const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
+            double invz = __builtin_amdgcn_rcp(pc[2]);  // reciprocal + two Newton steps instead of the IEEE division
+            invz = fma(fma(-pc[2], invz, 1.0), invz, invz);
+            invz = fma(fma(-pc[2], invz, 1.0), invz, invz);
+            const double x = pc[0], y = pc[1], invz_2 = invz * invz;
             const double e0 = (double)s_obs[2 * e] - (x * invz * fx + cx);
             const double e1 = (double)s_obs[2 * e + 1] - (y * invz * fy + cy);
             s_err[2 * e] = e0;
             s_err[2 * e + 1] = e1;
             const double w = (double)s_w[e];
             const double chi2 = e0 * (w * e0) + e1 * (w * e1);
-            v[27] += robust ? huber_rho0(chi2, delta, dsqr) : chi2;
+            // Huber through one reciprocal square root: rho = 2 sqrt(e) delta - delta^2, rho' = delta / sqrt(e)
+            const bool clipped = robust && !(chi2 <= (double)dsqr);
+            const double rs = clipped ? rsqrt_newton(chi2) : 0.0;
+            v[27] += clipped ? 2.0 * (chi2 * rs) * delta - (double)dsqr : chi2;
             v[28] += 1.0;
             double J[12];
             J[0] = x * y * invz_2 * fx;       J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
@@ -1659,7 +1726,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
         po_solve6(s_sys[s_ctrl[1]], s_sys[s_ctrl[1]] + 36, lambda, x, scale, solve_ok);
         scale += 1e-3;
         BaPose tr;
-        se3_exp_mul(x, s_cur, tr);
+        se3_exp_mul_small(x, s_cur, tr);
         s_trial = tr;
         s_ctrl[0] = 1;
     };
