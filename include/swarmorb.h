@@ -70,6 +70,15 @@ void so_extractor_destroy(so_extractor* ex);
  * per-level quota by up to 3, code/src/ORBextractor.cc:656-661). */
 int so_extractor_capacity(const so_extractor* ex);
 
+/* Asynchronous form of operator(): so_extractor_submit[_device] enqueues the whole frame on the extractor's stream
+ * and returns; so_extractor_collect waits for it and hands out the keypoints / descriptors.  Between the two the
+ * calling thread is free — the tracking thread submits frame t+1 before it matches and optimises frame t, so the
+ * extraction (which depends on nothing but the image) runs under the matcher / PoseOptimization kernels.  One frame
+ * in flight per extractor; the image must stay valid until collect.  Results are identical to so_extractor_run. */
+int so_extractor_submit(so_extractor* ex, const uint8_t* image, int width, int height, int stride);
+int so_extractor_submit_device(so_extractor* ex, const uint8_t* d_image, int width, int height, int stride);
+int so_extractor_collect(so_extractor* ex, so_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out);
+
 /* DistributeOctTree (code/src/ORBextractor.cc:534-744) placement after the first frame sized the context:
  * 1 = HIP kernel (one workgroup per level, whole tree in LDS; one host sync per frame), 0 = host tree
  * (a level quota above 1020 keypoints or more than 4 root cells, or SWARMORB_HOST_QUADTREE set when the

@@ -65,6 +65,9 @@ def load_library():
     lib.so_extractor_quadtree_on_device.argtypes = [vp]
     lib.so_extractor_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
     lib.so_extractor_run_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
+    lib.so_extractor_submit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.so_extractor_submit_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.so_extractor_collect.argtypes = [vp, vp, vp, C.c_int, ip]
     lib.so_extractor_tables.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.so_extractor_level_size.argtypes = [vp, C.c_int, ip, ip]
     lib.so_extractor_get_level.argtypes = [vp, C.c_int, vp, C.c_int]

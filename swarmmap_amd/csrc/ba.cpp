@@ -123,7 +123,8 @@ struct so_ba {
     size_t h_in_cap = 0;
     void* h_out = nullptr;
     size_t h_out_cap = 0;
-    uint8_t* h_po = nullptr;      // pinned staging for PoseOptimization
+    uint8_t* h_po = nullptr;      // pinned + host-mapped staging for PoseOptimization
+    uint8_t* h_po_dev = nullptr;
     size_t h_po_cap = 0;
     std::vector<Buf*> all() {
         return {&d_in, &d_out, &d_pose1, &d_pt1, &d_err, &d_chi2, &d_tab, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv,
@@ -596,7 +597,8 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
         if (b->h_po) SO_HIP(hipHostFree(b->h_po));
         b->h_po = nullptr;
         b->h_po_cap = 0;
-        SO_HIP(hipHostMalloc((void**)&b->h_po, need * 2, hipHostMallocDefault));
+        SO_HIP(hipHostMalloc((void**)&b->h_po, need * 2, hipHostMallocMapped));
+        SO_HIP(hipHostGetDevicePointer((void**)&b->h_po_dev, b->h_po, 0));
         b->h_po_cap = need * 2;
     }
     int rc;
@@ -610,23 +612,36 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     memcpy(h + (size_t)n * 12, obs, (size_t)n * 8);
     memcpy(h + (size_t)n * 20, inv_sigma2, (size_t)n * 4);
     uint8_t* d = b->d_po.as<uint8_t>();
-    SO_HIP(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    // Frames of ordinary size (<= 3072 matched points) run the LDS-resident kernel, which reads its inputs once and
+    // writes three small results: both go through host-mapped memory, so the call is one launch and one sync with
+    // no copies to enqueue.  Larger problems re-read the edges every trial and therefore get a device copy.
+    const bool zero_copy = n <= kPoseOptLdsMax && !getenv("SWARMORB_POSE_CLASSIC");
+    uint8_t* hout = h + in_bytes;
     PoseOptArgs a;
-    a.Xw = reinterpret_cast<const float*>(d);
-    a.obs = reinterpret_cast<const float*>(d + (size_t)n * 12);
-    a.inv_sigma2 = reinterpret_cast<const float*>(d + (size_t)n * 20);
+    if (zero_copy) {
+        a.Xw = reinterpret_cast<const float*>(b->h_po_dev);
+        a.obs = reinterpret_cast<const float*>(b->h_po_dev + (size_t)n * 12);
+        a.inv_sigma2 = reinterpret_cast<const float*>(b->h_po_dev + (size_t)n * 20);
+        a.pose_out = reinterpret_cast<BaPose*>(b->h_po_dev + in_bytes);
+        a.info = reinterpret_cast<int*>(b->h_po_dev + in_bytes + 64);
+        a.outlier = b->h_po_dev + in_bytes + 80;
+    } else {
+        SO_HIP(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+        a.Xw = reinterpret_cast<const float*>(d);
+        a.obs = reinterpret_cast<const float*>(d + (size_t)n * 12);
+        a.inv_sigma2 = reinterpret_cast<const float*>(d + (size_t)n * 20);
+        a.pose_out = reinterpret_cast<BaPose*>(d + off_pose);
+        a.info = reinterpret_cast<int*>(d + off_info);
+        a.outlier = d + off_out;
+    }
     for (int k = 0; k < 4; k++) a.K[k] = (double)intr[k];
     pose_from_Tcw(Tcw12, a.init);  // Converter::toSE3Quat(pFrame->mTcw)
     a.n = n;
     a.err = reinterpret_cast<double*>(d + off_err);
-    a.pose_out = reinterpret_cast<BaPose*>(d + off_pose);
-    a.info = reinterpret_cast<int*>(d + off_info);
-    a.outlier = d + off_out;
     a.trace = getenv("SWARMORB_POSE_TRACE") ? reinterpret_cast<double*>(d + off_trace) : nullptr;
     launch_pose_opt(a, s);
     SO_HIP(hipGetLastError());
-    uint8_t* hout = h + in_bytes;
-    SO_HIP(hipMemcpyAsync(hout, d + off_pose, 64 + 16 + (size_t)n, hipMemcpyDeviceToHost, s));
+    if (!zero_copy) SO_HIP(hipMemcpyAsync(hout, d + off_pose, 64 + 16 + (size_t)n, hipMemcpyDeviceToHost, s));
     SO_HIP(hipStreamSynchronize(s));
     BaPose P;
     memcpy(&P, hout, sizeof(BaPose));

@@ -124,6 +124,7 @@ struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.
     int* info;         // [0] nBad, [1] LM iterations, [2] LM trials
     double* trace;     // optional: 4 doubles per LM trial (lambda, tempChi, rho, currentChi), 256 trials max
 };
+constexpr int kPoseOptLdsMax = 3072;  // matched points the LDS-resident kernel holds (41 B each)
 void launch_pose_opt(const PoseOptArgs& a, hipStream_t s);
 
 }  // namespace so

@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(PoseOptArgs a) {
 // one - the common case - has the next iteration's system ready), the 29 block sums ride a transposed butterfly
 // (32 shuffles per wave instead of 29 x 6), and lane 0 decides and solves for the next trial in one go: two
 // barriers per trial.
-constexpr int kPoLdsMax = 3072;
+constexpr int kPoLdsMax = kPoseOptLdsMax;
 
 // the two widest exchanges (lane ^ 32, lane ^ 16) use gfx950's v_permlane32_swap / v_permlane16_swap: the first
 // operand's upper half (odd 16-lane rows) trades places with the second operand's lower half (even rows), so

@@ -38,6 +38,12 @@ struct so_extractor {
     // device quadtree path (default): candidates never leave the GPU, one host sync per frame
     bool device_qt = false;
     bool cands_on_host = false;        // h_cands holds the last frame's candidates (debug API)
+    bool pending_prof = false;         // the in-flight frame recorded its stage events
+    int pending = 0;                   // 1: a submitted frame is in flight on the stream, 2: finished into pend_* below
+    double t_begin = 0.0, t_enq = 0.0;
+    std::vector<so_keypoint> pend_kps;  // submit on the host-quadtree path runs to completion into these
+    std::vector<uint8_t> pend_desc;
+    int pend_n = 0;
     Candidate* d_cands = nullptr;
     CandidateHeader* d_header = nullptr;
     SelectedKp* d_qt_sel = nullptr;    // [nlevels][qt_stride]
@@ -203,12 +209,81 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int h, int stride, so_keypoint* kps,
-             uint8_t* desc, int capacity, int* n_out) {
-    if (!ex || !n_out) return SO_ERR_INVALID_ARG;
+// Second half of a frame on the one-sync path: wait for the stream, assemble cv::KeyPoint-compatible records.
+int collect_impl(so_extractor* ex, so_keypoint* kps, uint8_t* desc, int capacity, int* n_out) {
+    if (!ex || !n_out || !kps || !desc) return SO_ERR_INVALID_ARG;
     *n_out = 0;
-    if (!image || w <= 0 || h <= 0) return SO_OK;  // ORBextractor.cc:750-751
-    if (stride < w || !kps || !desc) return SO_ERR_INVALID_ARG;
+    if (ex->pending == 0) {
+        last_error_ref() = "so_extractor_collect without a submitted frame";
+        return SO_ERR_INVALID_ARG;
+    }
+    if (capacity < ex->out_capacity) return SO_ERR_CAPACITY;
+    if (ex->pending == 2) {
+        ex->pending = 0;
+        memcpy(kps, ex->pend_kps.data(), sizeof(so_keypoint) * (size_t)ex->pend_n);
+        memcpy(desc, ex->pend_desc.data(), (size_t)ex->pend_n * 32);
+        *n_out = ex->pend_n;
+        return SO_OK;
+    }
+    SO_HIP(hipSetDevice(ex->cfg.device));
+    const bool prof = ex->pending_prof;
+    SO_HIP(hipStreamSynchronize(ex->stream));  // the only sync of the frame
+    ex->pending = 0;
+    const double t_synced = now_ms();
+    ex->cands_on_host = false;
+    const int n = std::min(*ex->h_total, ex->out_capacity);
+    memcpy(desc, ex->h_desc, (size_t)n * 32);
+    const float* angles = reinterpret_cast<const float*>(ex->h_desc + (size_t)ex->out_capacity * 32);
+    for (int i = 0; i < n; i++) {
+        const SelectedKp& sk = ex->h_meta[i];
+        so_keypoint& o = kps[i];
+        const int l = sk.level;
+        o.x = (float)sk.x;
+        o.y = (float)sk.y;
+        if (l != 0) {  // ORBextractor.cc:808-814
+            o.x *= ex->scale[l];
+            o.y *= ex->scale[l];
+        }
+        o.size = (float)(int)(31.0f * ex->scale[l]);
+        o.angle = angles[i];
+        o.response = (float)sk.score;
+        o.octave = l;
+        o.class_id = -1;
+    }
+    *n_out = n;
+    if (prof) {
+        float ms = 0.f;
+        for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) ex->prof_ms[i] = 0.f;
+        (void)hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1]); ex->prof_ms[0] = ms;
+        (void)hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2]); ex->prof_ms[1] = ms;
+        (void)hipEventElapsedTime(&ms, ex->ev[2], ex->ev[3]); ex->prof_ms[2] = ms;
+        (void)hipEventElapsedTime(&ms, ex->ev[3], ex->ev[4]); ex->prof_ms[3] = ms;
+        (void)hipEventElapsedTime(&ms, ex->ev[4], ex->ev[5]); ex->prof_ms[8] = ms;  // quadtree, on the GPU
+        (void)hipEventElapsedTime(&ms, ex->ev[5], ex->ev[6]); ex->prof_ms[4] = ms;
+        ex->prof_ms[6] = (float)(ex->t_enq - ex->t_begin);
+        ex->prof_ms[7] = (float)(t_synced - ex->t_enq);  // includes whatever the caller did between submit and collect
+        ex->prof_ms[10] = (float)(now_ms() - t_synced);
+        ex->prof_ms[5] = (float)(now_ms() - ex->t_begin);  // submit to collect, whatever the caller did in between
+    }
+    return SO_OK;
+}
+
+int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int h, int stride, so_keypoint* kps,
+             uint8_t* desc, int capacity, int* n_out, bool submit_only = false) {
+    if (!ex || (!submit_only && !n_out)) return SO_ERR_INVALID_ARG;
+    if (ex->pending) {
+        last_error_ref() = "a submitted frame has not been collected";
+        return SO_ERR_INVALID_ARG;
+    }
+    if (n_out) *n_out = 0;
+    if (!image || w <= 0 || h <= 0) {  // ORBextractor.cc:750-751
+        if (submit_only) {
+            ex->pend_n = 0;
+            ex->pending = 2;
+        }
+        return SO_OK;
+    }
+    if (stride < w || (!submit_only && (!kps || !desc))) return SO_ERR_INVALID_ARG;
     const double t_begin = now_ms();
     SO_HIP(hipSetDevice(ex->cfg.device));
     if (!ex->allocated) {
@@ -218,7 +293,19 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
         last_error_ref() = "image size changed between frames";
         return SO_ERR_SIZE_CHANGED;
     }
-    if (capacity < ex->out_capacity) return SO_ERR_CAPACITY;
+    if (submit_only && !(ex->device_qt && ex->P.total_tiles > 0)) {
+        // host-quadtree contexts have a mid-frame sync: run the frame to completion now, hand it out at collect
+        ex->pend_kps.resize((size_t)ex->out_capacity);
+        ex->pend_desc.resize((size_t)ex->out_capacity * 32);
+        int n = 0;
+        const int rc = run_impl(ex, image, on_device, w, h, stride, ex->pend_kps.data(), ex->pend_desc.data(),
+                                ex->out_capacity, &n, false);
+        if (rc) return rc;
+        ex->pend_n = n;
+        ex->pending = 2;
+        return SO_OK;
+    }
+    if (!submit_only && capacity < ex->out_capacity) return SO_ERR_CAPACITY;
     PyramidParams& P = ex->P;
     hipStream_t s = ex->stream;
     const bool prof = ex->profiling;
@@ -247,45 +334,12 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
                                angle_dev, ex->h_meta_dev, ex->h_total_dev, s);
             if (prof) SO_HIP(hipEventRecord(ex->ev[6], s));
             SO_HIP(hipGetLastError());
-            const double t_enq = now_ms();
-            SO_HIP(hipStreamSynchronize(s));  // the only sync of the frame
-            const double t_synced = now_ms();
-            ex->cands_on_host = false;
-            const int n = std::min(*ex->h_total, ex->out_capacity);
-            memcpy(desc, ex->h_desc, (size_t)n * 32);
-            const float* angles = reinterpret_cast<const float*>(ex->h_desc + (size_t)ex->out_capacity * 32);
-            for (int i = 0; i < n; i++) {
-                const SelectedKp& sk = ex->h_meta[i];
-                so_keypoint& o = kps[i];
-                const int l = sk.level;
-                o.x = (float)sk.x;
-                o.y = (float)sk.y;
-                if (l != 0) {  // ORBextractor.cc:808-814
-                    o.x *= ex->scale[l];
-                    o.y *= ex->scale[l];
-                }
-                o.size = (float)(int)(31.0f * ex->scale[l]);
-                o.angle = angles[i];
-                o.response = (float)sk.score;
-                o.octave = l;
-                o.class_id = -1;
-            }
-            *n_out = n;
-            if (prof) {
-                float ms = 0.f;
-                for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) ex->prof_ms[i] = 0.f;
-                (void)hipEventElapsedTime(&ms, ex->ev[0], ex->ev[1]); ex->prof_ms[0] = ms;
-                (void)hipEventElapsedTime(&ms, ex->ev[1], ex->ev[2]); ex->prof_ms[1] = ms;
-                (void)hipEventElapsedTime(&ms, ex->ev[2], ex->ev[3]); ex->prof_ms[2] = ms;
-                (void)hipEventElapsedTime(&ms, ex->ev[3], ex->ev[4]); ex->prof_ms[3] = ms;
-                (void)hipEventElapsedTime(&ms, ex->ev[4], ex->ev[5]); ex->prof_ms[8] = ms;  // quadtree, on the GPU
-                (void)hipEventElapsedTime(&ms, ex->ev[5], ex->ev[6]); ex->prof_ms[4] = ms;
-                ex->prof_ms[6] = (float)(t_enq - t_begin);
-                ex->prof_ms[7] = (float)(t_synced - t_enq);
-                ex->prof_ms[10] = (float)(now_ms() - t_synced);
-                ex->prof_ms[5] = (float)(now_ms() - t_begin);
-            }
-            return SO_OK;
+            ex->t_begin = t_begin;
+            ex->t_enq = now_ms();
+            ex->pending = 1;
+            ex->pending_prof = prof;
+            if (submit_only) return SO_OK;
+            return collect_impl(ex, kps, desc, capacity, n_out);
         }
         launch_emit(P, ex->d_rowcount, ex->h_cands_dev, ex->h_header_dev, nullptr, ex->cand_capacity, s);
         ex->cands_on_host = true;
@@ -430,6 +484,18 @@ void so_extractor_destroy(so_extractor* ex) {
 int so_extractor_capacity(const so_extractor* ex) {
     if (!ex) return 0;
     return ex->cfg.nfeatures + 3 * ex->cfg.nlevels;
+}
+
+int so_extractor_submit(so_extractor* ex, const uint8_t* image, int width, int height, int stride) {
+    return run_impl(ex, image, false, width, height, stride, nullptr, nullptr, 0, nullptr, true);
+}
+
+int so_extractor_submit_device(so_extractor* ex, const uint8_t* d_image, int width, int height, int stride) {
+    return run_impl(ex, d_image, true, width, height, stride, nullptr, nullptr, 0, nullptr, true);
+}
+
+int so_extractor_collect(so_extractor* ex, so_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out) {
+    return collect_impl(ex, keypoints, descriptors, capacity, n_out);
 }
 
 int so_extractor_quadtree_on_device(const so_extractor* ex) { return (ex && ex->allocated && ex->device_qt) ? 1 : 0; }

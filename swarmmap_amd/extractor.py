@@ -67,6 +67,22 @@ class ORBextractor:
                                                       _vp(self._kps), _vp(self._desc), self._cap, C.byref(n)))
         return self._kps[:n.value], self._desc[:n.value]
 
+    # --- asynchronous form: submit frame t+1, match / optimise frame t, collect ---------------------
+    def submit(self, image):
+        if image.dtype != np.uint8 or image.ndim != 2 or image.strides[1] != 1:
+            raise ValueError("image must be a row-contiguous CV_8UC1 array")
+        self._inflight = image  # keep the pixels alive until collect
+        _lib.check(self._lib.so_extractor_submit(self._h, _vp(image), image.shape[1], image.shape[0], image.strides[0]))
+
+    def submit_device(self, d_ptr, width, height, stride):
+        _lib.check(self._lib.so_extractor_submit_device(self._h, C.c_void_p(d_ptr), width, height, stride))
+
+    def collect(self):
+        n = C.c_int(0)
+        _lib.check(self._lib.so_extractor_collect(self._h, _vp(self._kps), _vp(self._desc), self._cap, C.byref(n)))
+        self._inflight = None
+        return self._kps[:n.value], self._desc[:n.value]
+
     # --- getters (ORBextractor.h:60-87) -------------------------------------------------------
     def _tables(self):
         nl = self.nlevels

@@ -135,6 +135,36 @@ def test_device_resident_input(S, oracle):
     ex.close()
 
 
+def test_submit_collect_pipeline(S, oracle):
+    """Asynchronous form: frame t+1 is submitted before frame t's results are used; identical output, one frame in
+    flight, both quadtree placements."""
+    from swarmmap_amd import synth
+    stream = synth.FrameStream(seed=5)
+    frames = [stream.frame(t) for t in range(4)]
+    cfg = oracle.config(1000)
+    want = [oracle.extract(cfg, f) for f in frames]
+    for nf, frames_, want_ in ((1000, frames, want), (6000, [synth.make_image(31, synth.KITTI)], None)):
+        ex = S.ORBextractor(nf, 1.2, 8, 20, 7)
+        if want_ is None:
+            want_ = [oracle.extract(oracle.config(nf), f) for f in frames_]
+        ex.submit(frames_[0])
+        for t in range(len(frames_)):
+            kps, desc = ex.collect()
+            kps, desc = kps.copy(), desc.copy()
+            if t + 1 < len(frames_):
+                ex.submit(frames_[t + 1])  # in flight while frame t is "tracked"
+            assert kps.tobytes() == want_[t][0].tobytes() and np.array_equal(desc, want_[t][1])
+        with pytest.raises(S.SwarmOrbError):
+            ex.collect()  # nothing submitted
+        ex.submit(frames_[0])
+        with pytest.raises(S.SwarmOrbError):
+            ex.submit(frames_[0])  # one frame in flight per extractor
+        with pytest.raises(S.SwarmOrbError):
+            ex(frames_[0])
+        ex.collect()
+        ex.close()
+
+
 def test_errors(S):
     from swarmmap_amd import synth
     ex = S.ORBextractor(500, 1.2, 8, 20, 7)
