@@ -395,6 +395,8 @@ void so_ba_options_global(so_ba_options* opt, int32_t n_iterations, int32_t robu
 int so_pose_optimization(so_ba* ba, const float* Tcw12, const float* intr, int32_t n, const float* Xw,
                          const float* obs, const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier,
                          int32_t* n_inliers, int32_t* info /* [iterations, lm_trials], may be NULL */);
+/* HIP-event time (ms) of the kernel of the last so_pose_optimization call on this handle. */
+int so_pose_optimization_last_kernel_ms(so_ba* ba, float* ms);
 
 int so_bundle_adjust(so_ba* ba, const so_ba_problem* problem, const so_ba_options* options,
                      const volatile uint8_t* stop, float* Tcw_out, float* Xw_out, uint8_t* edge_outlier,

@@ -106,6 +106,8 @@ struct so_ba {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;  // around the PoseOptimization kernel (its own pair: another thread may be in so_bundle_adjust)
+    float pose_kernel_ms = 0.f;
     static constexpr int kSolveEvents = 32;  // the first trials of a call are event-timed around the solve kernel
     hipEvent_t ev_solve[2 * kSolveEvents] = {nullptr};
     float solve_ms = 0.f;
@@ -239,6 +241,8 @@ int so_ba_create(int device, so_ba** out) {
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&b->e0);
     if (e == hipSuccess) e = hipEventCreate(&b->e1);
+    if (e == hipSuccess) e = hipEventCreate(&b->pe0);
+    if (e == hipSuccess) e = hipEventCreate(&b->pe1);
     for (hipEvent_t& ev : b->ev_solve)
         if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_lm, sizeof(BaLm), hipHostMallocMapped);
@@ -267,6 +271,8 @@ void so_ba_destroy(so_ba* b) {
     if (b->h_po) (void)hipHostFree(b->h_po);
     if (b->e0) (void)hipEventDestroy(b->e0);
     if (b->e1) (void)hipEventDestroy(b->e1);
+    if (b->pe0) (void)hipEventDestroy(b->pe0);
+    if (b->pe1) (void)hipEventDestroy(b->pe1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -639,10 +645,13 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     a.n = n;
     a.err = reinterpret_cast<double*>(d + off_err);
     a.trace = getenv("SWARMORB_POSE_TRACE") ? reinterpret_cast<double*>(d + off_trace) : nullptr;
+    SO_HIP(hipEventRecord(b->pe0, s));
     launch_pose_opt(a, s);
+    SO_HIP(hipEventRecord(b->pe1, s));
     SO_HIP(hipGetLastError());
     if (!zero_copy) SO_HIP(hipMemcpyAsync(hout, d + off_pose, 64 + 16 + (size_t)n, hipMemcpyDeviceToHost, s));
     SO_HIP(hipStreamSynchronize(s));
+    (void)hipEventElapsedTime(&b->pose_kernel_ms, b->pe0, b->pe1);
     BaPose P;
     memcpy(&P, hout, sizeof(BaPose));
     int inf[4];
@@ -660,6 +669,12 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
         info[0] = inf[1];
         info[1] = inf[2];
     }
+    return SO_OK;
+}
+
+int so_pose_optimization_last_kernel_ms(so_ba* b, float* ms) {
+    if (!b || !ms) return SO_ERR_INVALID_ARG;
+    *ms = b->pose_kernel_ms;
     return SO_OK;
 }
 

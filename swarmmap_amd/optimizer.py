@@ -107,6 +107,12 @@ class Optimizer:
                                             _vp(outl), C.byref(n_in), _vp(info)))
         return n_in.value, Tout, outl, {"iterations": int(info[0]), "lm_trials": int(info[1])}
 
+    def pose_kernel_ms(self):
+        ms = C.c_float(0)
+        self._lib.so_pose_optimization_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        _lib.check(self._lib.so_pose_optimization_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
     def solve(self, problem, its1, its2, robust, huber_delta, chi2_threshold=5.991, pbStopFlag=None):
         opt = SoBaOptions(int(its1), int(its2), int(bool(robust)), float(huber_delta), float(chi2_threshold))
         return self._solve(problem, opt, pbStopFlag)
