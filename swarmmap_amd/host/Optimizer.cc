@@ -48,4 +48,16 @@ void Optimizer::BundleAdjustment(const BAWindow& map, int nIterations, bool* pbS
     solve(map, opt, pbStopFlag, out);
 }
 
+int Optimizer::PoseOptimization(float Tcw[12], const float K[4], const std::vector<float>& X, const std::vector<float>& obs,
+                                const std::vector<float>& w, std::vector<uint8_t>& outl) {
+    const int n = (int)w.size();
+    outl.assign((size_t)n, 0);
+    float Tout[12];
+    int32_t inliers = 0, info[2] = {0, 0};
+    check(so_pose_optimization(handle_, Tcw, K, n, X.data(), obs.data(), w.data(), Tout, outl.data(), &inliers, info),
+          "so_pose_optimization");
+    if (n >= 3) for (int i = 0; i < 12; i++) Tcw[i] = Tout[i];  // pFrame->SetPose(pose)
+    return inliers;
+}
+
 }  // namespace ORB_SLAM2

@@ -43,6 +43,12 @@ public:
     void GlobalBundleAdjustment(const BAWindow& map, int nIterations, bool* pbStopFlag, bool bRobust, BAResult& out) {
         BundleAdjustment(map, nIterations, pbStopFlag, bRobust, out);
     }
+    // int static PoseOptimization(Frame* pFrame) (Optimizer.cc:239-434): Tcw in / out is pFrame->mTcw ([R|t] 3x4),
+    // one entry per matched keypoint i with pFrame->mvpMapPoints[i] != NULL: world position, mvKeysUn[i].pt,
+    // mvInvLevelSigma2[octave]; mvbOutlier comes back per entry.  Returns nInitialCorrespondences - nBad.
+    int PoseOptimization(float Tcw[12], const float K[4], const std::vector<float>& worldPos,
+                         const std::vector<float>& obs, const std::vector<float>& invSigma2,
+                         std::vector<uint8_t>& mvbOutlier);
 
 private:
     void solve(const BAWindow& w, const so_ba_options& opt, bool* pbStopFlag, BAResult& out);

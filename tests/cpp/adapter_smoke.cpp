@@ -6,6 +6,7 @@
 
 #include "../../swarmmap_amd/host/ORBextractor.h"
 #include "../../swarmmap_amd/host/ORBmatcher.h"
+#include "../../swarmmap_amd/host/Frame.h"
 #include "../../swarmmap_amd/host/Optimizer.h"
 
 static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
@@ -72,5 +73,33 @@ int main(int argc, char** argv) {
     optimizer.LocalBundleAdjustment(win, &stop, res);
     printf("ba chi2 %.3e -> %.3e its %d+%d outliers %d\n", res.info.chi2_initial, res.info.chi2_final,
            res.info.iterations_stage1, res.info.iterations_stage2, res.info.n_outliers);
+    // Frame post-processing on the extracted keypoints with EuRoC's lens
+    const float K[4] = {458.654f, 457.296f, 367.215f, 248.375f};
+    ORB_SLAM2::Frame frame(K, {-0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f});
+    std::vector<swarmorb::KeyPoint> keysUn;
+    frame.UndistortAndAssign(kps, w, h, keysUn);
+    std::vector<float> un(2 * keysUn.size());
+    for (size_t i = 0; i < keysUn.size(); i++) { un[2 * i] = keysUn[i].pt.x; un[2 * i + 1] = keysUn[i].pt.y; }
+    printf("undistorted %zu %016llx bounds %.9g %.9g %.9g %.9g grid %zu %016llx\n", keysUn.size(),
+           (unsigned long long)fnv(un.data(), un.size() * 4), frame.mnMinX, frame.mnMaxX, frame.mnMinY, frame.mnMaxY,
+           frame.GridItems().size(), (unsigned long long)fnv(frame.GridItems().data(), frame.GridItems().size() * 4));
+    // PoseOptimization on exact observations of the 4 BA points + 4 more from a perturbed pose
+    std::vector<float> X, ob, iw;
+    std::vector<uint8_t> outl;
+    for (int j = 0; j < 40; j++) {
+        const float px = -2.f + 0.1f * (float)j, py = -1.f + 0.05f * (float)((j * 7) % 40), pz = 4.f + 0.1f * (float)((j * 3) % 30);
+        X.insert(X.end(), {px, py, pz});
+        ob.push_back(K[0] * px / pz + K[2]);
+        ob.push_back(K[1] * py / pz + K[3]);
+        iw.push_back(1.0f);
+    }
+    float Tcw[12] = {1, 0, 0, 0.05f, 0, 1, 0, -0.03f, 0, 0, 1, 0.02f};  // start off the true identity pose
+    const int inl = optimizer.PoseOptimization(Tcw, K, X, ob, iw, outl);
+    printf("pose inliers %d t %.4f %.4f %.4f\n", inl, Tcw[3], Tcw[7], Tcw[11]);
+    ORB_SLAM2::DistinctiveDescriptors dd;
+    std::vector<int32_t> off = {0, 3, 3, 8};
+    std::vector<uint8_t> dsc(desc.data.begin(), desc.data.begin() + 8 * 32);
+    const std::vector<int32_t> best = dd.Compute(off, dsc);
+    printf("distinctive %d %d %d\n", best[0], best[1], best[2]);
     return 0;
 }

@@ -20,7 +20,7 @@ def _fnv(b):
 def _build(tmp_path):
     exe = str(tmp_path / "adapter_smoke")
     srcs = [os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp")] + \
-           [os.path.join(HOST, f) for f in ("ORBextractor.cc", "ORBmatcher.cc", "Optimizer.cc")]
+           [os.path.join(HOST, f) for f in ("ORBextractor.cc", "ORBmatcher.cc", "Optimizer.cc", "Frame.cc")]
     lib = os.path.join(ROOT, "swarmmap_amd")
     subprocess.check_call(["g++", "-std=c++14", "-O1", "-o", exe] + srcs +
                           ["-L" + lib, "-lswarmorb", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
@@ -52,3 +52,15 @@ def test_adapters_match_python_binding(tmp_path):
     nm, self_m, lvl0 = [int(v) for v in lines["init_matches"].split()[::2]]
     assert self_m == nm and nm > 0.8 * lvl0  # level-0 keypoints re-find themselves
     assert "its" in lines["ba"] and float(lines["ba"].split()[3]) < 1e-3 * float(lines["ba"].split()[1])
+    # Frame post-processing, PoseOptimization, distinctive descriptors through the C++ adapters
+    fp = swarmmap_amd.FramePostProcessor(synth.EUROC_K, synth.EUROC_DIST)
+    pr = fp.prepare(np.stack([kps["x"], kps["y"]], 1), 752, 480)
+    f = lines["undistorted"].split()
+    assert int(f[0]) == len(kps) and f[1] == _fnv(pr["xy_un"].tobytes())
+    assert [np.float32(v) for v in f[3:7]] == pr["bounds"].tolist()
+    assert int(f[8]) == len(pr["cell_items"]) and f[9] == _fnv(pr["cell_items"].tobytes())
+    p = lines["pose"].split()
+    assert int(p[1]) == 40 and max(abs(float(v)) for v in p[3:6]) < 1e-3  # converges back to the identity pose
+    m = swarmmap_amd.ORBmatcher()
+    idx, _ = m.ComputeDistinctiveDescriptors([0, 3, 3, 8], desc[:8])
+    assert [int(v) for v in lines["distinctive"].split()] == idx.tolist()
