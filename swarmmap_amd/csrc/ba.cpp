@@ -112,6 +112,8 @@ struct so_ba {
     hipEvent_t ev_solve[2 * kSolveEvents] = {nullptr};
     float solve_ms = 0.f;
     int n_solves = 0;
+    hipStream_t dense_side = nullptr;       // blocked dense solver: side stream + events of its look-ahead
+    std::vector<hipEvent_t> dense_events;
     BaLm* h_lm = nullptr;        // host-mapped copy of the LM state, written by the decision kernels
     BaLm* h_lm_dev = nullptr;
     uint8_t* h_abort = nullptr;  // host-mapped forceStopFlag the decision kernel polls
@@ -262,6 +264,10 @@ void so_ba_destroy(so_ba* b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (Buf* q : b->all()) q->release();
+    if (b->dense_side) (void)hipStreamSynchronize(b->dense_side);
+    for (hipEvent_t e : b->dense_events)
+        if (e) (void)hipEventDestroy(e);
+    if (b->dense_side) (void)hipStreamDestroy(b->dense_side);
     if (b->h_lm) (void)hipHostFree(b->h_lm);
     if (b->h_in) (void)hipHostFree(b->h_in);
     if (b->h_out) (void)hipHostFree(b->h_out);
@@ -455,6 +461,13 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     if ((rc = b->d_S.ensure(sizeof(double) * ldS * ldS))) return rc;
     if ((rc = b->d_bs.ensure(sizeof(double) * ldS))) return rc;
     if (dense_path) {
+        if (!b->dense_side) {
+            int lo_pri = 0, hi_pri = 0;  // the side stream carries the serial chain: highest priority
+            if (hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess) lo_pri = hi_pri = 0;
+            SO_HIP(hipStreamCreateWithPriority(&b->dense_side, hipStreamNonBlocking, hi_pri));
+            b->dense_events.assign(1 + 2 * kDenseMaxPanels, nullptr);
+            for (hipEvent_t& e : b->dense_events) SO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         if ((rc = b->d_dense_ws.ensure(sizeof(double) * (ldS / 96) * 96 * 96))) return rc;
         if ((rc = b->d_dense_x.ensure(sizeof(double) * ldS))) return rc;
     }
@@ -511,6 +524,8 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.ldS = (int)ldS;
     d.dense_ws = b->d_dense_ws.as<double>();
     d.dense_x = b->d_dense_x.as<double>();
+    d.dense_side = dense_path ? b->dense_side : nullptr;
+    d.dense_events = dense_path ? b->dense_events.data() : nullptr;
     d.xl = b->d_xl.as<double>();
     d.partial = b->d_partial.as<double>();
     d.robust = opt->robust;

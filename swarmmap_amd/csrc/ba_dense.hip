@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void dense_panel_kernel(BaDev d, int k) {
 }
 
 // ---- trailing update: A_ij -= L_ik L_jk^T for i >= j > k; extra blocks: b_j -= L_jk y_k ----
-__global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int n_tiles) {
+// mode 0: every tile; mode 1: the tiles of block column k+1 (what the next panel needs) + the right-hand side;
+// mode 2: the rest (runs while the side stream factors panel k+1)
+__global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int n_tiles, int mode) {
     __shared__ double sA[kDNB][kDStride];
     __shared__ double sB[kDNB][kDStride];
     if (!d.lm->active) return;
@@ -308,11 +310,22 @@ __global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int n
         }
         return;
     }
-    // tile index -> (ti >= tj) within the trailing rem x rem block grid, row by row of the lower triangle
-    int ti = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
-    while (ti * (ti + 1) / 2 > (int)blockIdx.x) ti--;
-    const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
+    // tile index -> (ti >= tj) within the trailing rem x rem block grid
+    int ti, tj;
+    if (mode == 1) {
+        ti = (int)blockIdx.x;
+        tj = 0;
+    } else {
+        int t = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);  // row by row of a lower triangle
+        while ((t + 1) * (t + 2) / 2 <= (int)blockIdx.x) t++;
+        while (t * (t + 1) / 2 > (int)blockIdx.x) t--;
+        ti = t;
+        tj = (int)blockIdx.x - t * (t + 1) / 2;
+        if (mode == 2) {  // the triangle without its first column
+            ti++;
+            tj++;
+        }
+    }
     if (ti >= rem) return;
     const int I = k + 1 + ti, J = k + 1 + tj;
     const double* Pi = d.S + (size_t)I * kDNB * ld + (size_t)k * kDNB;
@@ -336,17 +349,28 @@ __global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int n
 // every workgroup recomputes x_k = Linv_kk^T y_k (96x96 mat-vec) and then updates its 256 entries of y above
 // the panel: y_c -= sum_m L[k*96+m][c] x_k[m]; workgroup 0 stores x_k.
 __global__ __launch_bounds__(256) void dense_backward_kernel(BaDev d, int k) {
-    __shared__ double s_y[kDNB], s_x[kDNB];
+    __shared__ double s_y[kDNB], s_x[kDNB], s_part[2][kDNB];
     if (!d.lm->active) return;
     const int tid = threadIdx.x, ld = d.ldS;
     const double* Linv = d.dense_ws + (size_t)k * kDNB * kDNB;
     if (tid < kDNB) s_y[tid] = d.bs[(size_t)k * kDNB + tid];
     __syncthreads();
-    if (tid < kDNB) {
+    // x_k = Linv^T y: thread (half, col) sums half of the rows of column col; 16 loads in flight per thread
+    if (tid < 2 * kDNB) {
+        const int col = tid % kDNB, half = tid / kDNB;
+        const int m_lo = half == 0 ? col : (col < 48 ? 48 : col), m_hi = half == 0 ? (col < 48 ? 48 : col) : kDNB;
         double v = 0.0;
-        for (int m = tid; m < kDNB; m++) v = fma(Linv[m * kDNB + tid], s_y[m], v);  // (Linv^T)[tid][m] = Linv[m][tid]
-        s_x[tid] = v;
+        for (int m0 = m_lo; m0 < m_hi; m0 += 16) {
+            double l[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) l[m] = (m0 + m < m_hi) ? Linv[(size_t)(m0 + m) * kDNB + col] : 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; m++) v = fma(l[m], (m0 + m < m_hi) ? s_y[m0 + m] : 0.0, v);
+        }
+        s_part[half][col] = v;
     }
+    __syncthreads();
+    if (tid < kDNB) s_x[tid] = s_part[0][tid] + s_part[1][tid];
     __syncthreads();
     const int c = blockIdx.x * 256 + tid;
     if (c < k * kDNB) {
@@ -381,16 +405,37 @@ void launch_ba_dense_pad(const BaDev& d, hipStream_t s) {
     if (np > n) hipLaunchKernelGGL(dense_pad_kernel, dim3(256), dim3(256), 0, s, d.S, d.bs, n, np);
 }
 
+// Look-ahead across launches: the trailing update of panel k is split into the tiles of block column k+1 (U1) and
+// the rest (U2).  As soon as U1 is done the side stream factors the next diagonal block and solves the next panel
+// while the main stream is still busy with U2 - the serial diagonal factor (80 us) hides behind the GEMM work for as
+// long as the trailing matrix is large.  Only for T >= 32 panels: below that the two cross-stream waits per panel
+// (~10 us each) cost more than the overlap returns (measured on GBA-1, 19 panels).
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s) {
     const int T = d.ldS / kDNB;
+    hipStream_t side = d.dense_side;
+    hipEvent_t* ev = d.dense_events;  // [0] start, [1 + 2k] U1(k) done, [2 + 2k] panel(k+1) done
+    const bool lookahead = side && ev && T >= 32 && T <= kDenseMaxPanels && !getenv("SWARMORB_DENSE_NO_LOOKAHEAD");
     hipLaunchKernelGGL(dense_begin_kernel, dim3(1), dim3(1), 0, s, d);
-    for (int k = 0; k < T; k++) {
-        hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, k);
+    hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, 0);
+    hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (T - 1)), dim3(256), 0, s, d, 0);
+    for (int k = 0; k < T - 1; k++) {
         const int rem = T - k - 1;
-        hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + rem), dim3(256), 0, s, d, k);
-        if (rem > 0) {
-            const int n_tiles = rem * (rem + 1) / 2, rhs_blocks = (rem * kDNB + 255) / 256;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(n_tiles + rhs_blocks), dim3(256), 0, s, d, k, n_tiles);
+        const int rhs_blocks = (rem * kDNB + 255) / 256;
+        if (lookahead && rem >= 3) {
+            hipLaunchKernelGGL(dense_update_kernel, dim3(rem + rhs_blocks), dim3(256), 0, s, d, k, rem, 1);
+            (void)hipEventRecord(ev[1 + 2 * k], s);
+            (void)hipStreamWaitEvent(side, ev[1 + 2 * k], 0);
+            hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, side, d, k + 1);
+            hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (rem - 1)), dim3(256), 0, side, d, k + 1);
+            (void)hipEventRecord(ev[2 + 2 * k], side);
+            const int rest = (rem - 1) * rem / 2;
+            hipLaunchKernelGGL(dense_update_kernel, dim3(rest), dim3(256), 0, s, d, k, rest, 2);
+            (void)hipStreamWaitEvent(s, ev[2 + 2 * k], 0);
+        } else {
+            const int n_tiles = rem * (rem + 1) / 2;
+            hipLaunchKernelGGL(dense_update_kernel, dim3(n_tiles + rhs_blocks), dim3(256), 0, s, d, k, n_tiles, 0);
+            hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, k + 1);
+            hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (rem - 1)), dim3(256), 0, s, d, k + 1);
         }
     }
     for (int k = T - 1; k >= 0; k--) {

@@ -75,6 +75,8 @@ struct BaDev {
     int ldS;           // leading dimension of S: 6 n_free, or that rounded up to 96 on the blocked dense path
     double* dense_ws;  // blocked dense path: inverted 96x96 diagonal blocks, one per panel
     double* dense_x;   //                     solution staging (ldS doubles)
+    hipStream_t dense_side;     // host-side handles of the blocked path's look-ahead (not read by kernels)
+    hipEvent_t* dense_events;   // 1 + 2 * kDenseMaxPanels events
     double* partial;  // reduction partials (chi2 | scale) + flags
     int robust;
     double huber_delta;
@@ -101,6 +103,7 @@ void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abor
 void launch_ba_edge_table(const BaDev& d, hipStream_t s);
 // blocked dense path (ba_dense.hip), used when the system is too large for one workgroup (n_free > 43)
 constexpr int kBaSmallSolverMaxFree = 43;
+constexpr int kDenseMaxPanels = 128;  // 12288 / 96
 void launch_ba_dense_pad(const BaDev& d, hipStream_t s);    // once per problem: identity padding up to ldS
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s);  // per trial, in place of the single-workgroup solve  // fills edge_tab (memset to -1 beforehand)
 // Optimizer.cc:644-656 on the device: edges of the current estimate with chi2 > threshold or non-positive depth
