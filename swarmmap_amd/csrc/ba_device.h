@@ -6,7 +6,7 @@
 //   edges     sorted by point (stable): pose idx, point idx, obs[2], inv_sigma2, active flag
 //             + stored error[2] (EdgeSE3ProjectXYZ::_error) that only active edges refresh
 //   CSR       point -> its edges (contiguous after the sort); free pose -> its edges (ascending, i.e. by landmark);
-//             edge_tab[landmark][hessian index] -> edge, filled on the device: block (i1,i2) of the reduced camera
+//             edge_tab[hessian index][landmark] -> edge, filled on the device: block (i1,i2) of the reduced camera
 //             system walks pose i1's edges and looks the partner edge of pose i2 up.  Built once per problem;
 //             the second stage keeps everything and skips edges whose active flag was cleared.
 //   system    Hpp[n_free][36], bp[n_free][6], Hll[n_pt][9], bl[n_pt][3], W[edge][18] = J_pose^T w J_point,
@@ -67,7 +67,7 @@ struct BaDev {
     const int* free_pose;     // n_free: pose index of hessian index i
     const int* pose_off;      // n_free + 1
     const int* pose_edges;    // edge ids per free pose
-    int* edge_tab;            // n_points x n_free: the edge joining (landmark, hessian index), -1 if none
+    int* edge_tab;            // n_free x n_points: the edge joining (hessian index, landmark), -1 if none
     // system
     double* Hpp; double* bp; double* Hll; double* bl; double* W;
     double* Dinv; double* db; double* BDinv;

@@ -209,12 +209,13 @@ void launch_ba_errors(const BaDev& d, int which, bool gated, int n_blocks, hipSt
     hipLaunchKernelGGL(ba_errors_kernel, dim3(n_blocks), dim3(256), 0, s, d, which, gated ? 1 : 0);
 }
 
-// edge_tab[landmark][hessian index] = the edge joining them (at most one: a keyframe observes a landmark once)
+// edge_tab[hessian index][landmark] = the edge joining them (at most one: a keyframe observes a landmark once).
+// One row per keyframe: the blocks (., i2) of the gather, dispatched back to back, all read row i2, which stays in L2.
 __global__ __launch_bounds__(256) void ba_edge_table_kernel(BaDev d) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= d.n_edges) return;
     const int h = d.pose_hidx[d.e_pose[e]];
-    if (h >= 0) d.edge_tab[(size_t)d.e_point[e] * d.n_free + h] = e;
+    if (h >= 0) d.edge_tab[(size_t)h * d.n_points + d.e_point[e]] = e;
 }
 
 void launch_ba_edge_table(const BaDev& d, hipStream_t s) {
@@ -469,19 +470,18 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d) {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nf = d.n_free, n_blk = nf * (nf + 1) / 2;
     if (g < n_blk) {
-        int i1 = 0, rem = g;  // upper blocks row by row: (0,0) (0,1) ... (0,nf-1) (1,1) ...
-        while (rem >= nf - i1) {
-            rem -= nf - i1;
-            i1++;
-        }
-        const int i2 = i1 + rem;
+        // upper blocks column by column: (0,0) (0,1) (1,1) (0,2) (1,2) (2,2) ... - consecutive blocks share i2
+        int i2 = (int)((sqrt(8.0 * (double)g + 1.0) - 1.0) * 0.5);
+        while ((i2 + 1) * (i2 + 2) / 2 <= g) i2++;
+        while (i2 * (i2 + 1) / 2 > g) i2--;
+        const int i1 = g - i2 * (i2 + 1) / 2;
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
         for (int p = d.pose_off[i1] + lane; p < d.pose_off[i1 + 1]; p += 64) {
             const int k1 = d.pose_edges[p];
             if (!d.e_active[k1]) continue;  // dropped between the stages
-            const int k2 = (i1 == i2) ? k1 : d.edge_tab[(size_t)d.e_point[k1] * nf + i2];
+            const int k2 = (i1 == i2) ? k1 : d.edge_tab[(size_t)i2 * d.n_points + d.e_point[k1]];
             if (k2 < 0 || !d.e_active[k2]) continue;
             const double* B = d.BDinv + 18 * (size_t)k1;
             const double* W = d.W + 18 * (size_t)k2;
