@@ -160,6 +160,122 @@ def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window
                       % (n, size[0], size[1], nfeatures, n_lba, LBA_EVERY, os.cpu_count())}
 
 
+class Replay:
+    """ctypes view of swarmmap_amd/host/replay.cc (libswarmorb_replay.so): the tracking thread's per-frame calls and the
+    local-mapping thread as a C++ host loop over the C ABI - the host side a SwarmMap integration has."""
+    STAT = ("steps", "extract_ms", "match_ms", "pose_ms", "lba_ms", "n_kp", "n_m2", "n_m1", "match_kernel_ms",
+            "pose_kernel_ms", "pose_trials", "pose_calls", "n_lba", "lba_busy_ms", "lba_gpu_ms", "solve_ms", "n_solves")
+
+    def __init__(self, dev, w, h, nfeatures, lba_every):
+        import ctypes as C
+        from swarmmap_amd import _lib
+        from swarmmap_amd.optimizer import SoBaProblem
+        self.C, self._lib_mod, self.SoBaProblem = C, _lib, SoBaProblem
+        _lib.load_library()  # binds HIP through torch's runtime first
+        path = os.path.join(ROOT, "swarmmap_amd", "libswarmorb_replay.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libswarmorb_replay.so is missing: run __graft_entry__.build()")
+        self.lib = lib = C.CDLL(path)
+        vp, i32 = C.c_void_p, C.c_int
+        lib.so_replay_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+        lib.so_replay_destroy.argtypes = [vp]; lib.so_replay_destroy.restype = None
+        lib.so_replay_error.argtypes = [vp]; lib.so_replay_error.restype = C.c_char_p
+        lib.so_replay_set_frames.argtypes = [vp, vp, i32]
+        lib.so_replay_set_step.argtypes = [vp, i32, i32] + [vp] * 7 + [i32] + [vp] * 7
+        lib.so_replay_add_pose_case.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+        lib.so_replay_set_window.argtypes = [vp, vp]
+        lib.so_replay_set_profiling.argtypes = [vp, i32]
+        lib.so_replay_prime.argtypes = [vp, i32]
+        lib.so_replay_run.argtypes = [vp, i32, i32, i32]
+        lib.so_replay_drain.argtypes = [vp]
+        lib.so_replay_finish.argtypes = [vp]
+        lib.so_replay_stats.argtypes = [vp, vp]
+        lib.so_replay_last_frame.argtypes = [vp, C.POINTER(vp), C.POINTER(i32)]
+        lib.so_replay_extractor.argtypes = [vp]; lib.so_replay_extractor.restype = vp
+        self.h = vp()
+        self._check(lib.so_replay_create(dev, w, h, nfeatures, lba_every, C.byref(self.h)), "create")
+        self._keep = []
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("so_replay_%s failed (%d): %s" % (what, rc, (self.lib.so_replay_error(self.h) or b"").decode()))
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data
+
+    def set_frames(self, ptrs):
+        a = np.array(ptrs, np.uint64)
+        self._check(self.lib.so_replay_set_frames(self.h, self._p(a), len(a)), "set_frames")
+
+    def set_step(self, t, last, mps):
+        f32, u8, i32 = np.float32, np.uint8, np.int32
+        L = [np.ascontiguousarray(last[k], d) for k, d in (("valid", u8), ("u", f32), ("v", f32), ("octave", i32),
+                                                           ("angle", f32), ("desc", u8), ("has_obs", u8))]
+        M = [np.ascontiguousarray(mps[k], d) for k, d in (("in_view", u8), ("proj_x", f32), ("proj_y", f32),
+                                                          ("view_cos", f32), ("pred_level", i32), ("desc", u8), ("has_obs", u8))]
+        self._check(self.lib.so_replay_set_step(self.h, t, len(L[1]), *[self._p(a) for a in L], len(M[1]),
+                                                *[self._p(a) for a in M]), "set_step")
+
+    def add_pose_case(self, c):
+        f32 = np.float32
+        a = [np.ascontiguousarray(c[k], f32) for k in ("Tcw", "intr", "Xw", "obs", "inv_sigma2")]
+        self._check(self.lib.so_replay_add_pose_case(self.h, self._p(a[0]), self._p(a[1]), len(a[4]), self._p(a[2]),
+                                                     self._p(a[3]), self._p(a[4])), "add_pose_case")
+
+    def set_window(self, prob):
+        from swarmmap_amd.optimizer import problem_struct
+        st, keep = problem_struct(prob)
+        self._keep.append(keep)
+        self._check(self.lib.so_replay_set_window(self.h, self.C.byref(st)), "set_window")
+
+    def set_profiling(self, on):
+        self.lib.so_replay_set_profiling(self.h, int(on))
+
+    def prime(self, t):
+        self._check(self.lib.so_replay_prime(self.h, t), "prime")
+
+    def run(self, first_t, n, timed):
+        self._check(self.lib.so_replay_run(self.h, first_t, n, int(timed)), "run")
+
+    def drain(self):
+        self._check(self.lib.so_replay_drain(self.h), "drain")
+
+    def finish(self):
+        self._check(self.lib.so_replay_finish(self.h), "finish")
+
+    def stats(self):
+        a = np.zeros(32, np.float64)
+        self.lib.so_replay_stats(self.h, self._p(a))
+        d = dict(zip(self.STAT, a[:len(self.STAT)].tolist()))
+        from swarmmap_amd.extractor import STAGES
+        d["stages"] = dict(zip(STAGES, a[len(self.STAT):len(self.STAT) + len(STAGES)].tolist()))
+        return d
+
+    def last_descriptors(self):
+        C = self.C
+        ptr, n = C.c_void_p(), C.c_int(0)
+        self.lib.so_replay_last_frame(self.h, C.byref(ptr), C.byref(n))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (max(n.value, 1) * 32,))[:n.value * 32].reshape(-1, 32).copy()
+
+    def candidates_total(self, nlevels=8, cap=10000):
+        C = self.C
+        exh = self.lib.so_replay_extractor(self.h)
+        base = self._lib_mod.load_library()
+        tot = 0
+        xs, ys, sc = np.zeros(cap, np.int16), np.zeros(cap, np.int16), np.zeros(cap, np.uint8)
+        for l in range(nlevels):
+            n = C.c_int(0)
+            base.so_extractor_get_candidates(C.c_void_p(exh), l, self._p(xs), self._p(ys), self._p(sc), cap, C.byref(n))
+            tot += n.value
+        return tot
+
+    def close(self):
+        if self.h:
+            self.lib.so_replay_destroy(self.h)
+            self.h = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +284,9 @@ def main():
     ap.add_argument("--size", default="euroc", choices=["euroc", "kitti"])
     ap.add_argument("--exchange-every", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--python-loop", action="store_true",
+                    help="drive the timed loop from Python (ctypes wrappers) instead of the C++ host loop "
+                         "swarmmap_amd/host/replay.cc; same calls, interpreter overhead included")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,8 +313,8 @@ def main():
 
     ex = swarmmap_amd.ORBextractor(nfeatures, 1.2, 8, 20, 7, device=dev)
     m2 = swarmmap_amd.ORBmatcher(0.9, True, device=dev)   # Tracking.cc:715
-    m1 = swarmmap_amd.ORBmatcher(0.8, True, device=dev)   # Tracking.cc:998
-    ba = swarmmap_amd.Optimizer(device=dev)
+    m1 = swarmmap_amd.ORBmatcher(0.8, True, device=dev)   # Tracking.cc:998 (also matches the exchanged keyframes)
+    ba = swarmmap_amd.Optimizer(device=dev) if args.python_loop else None
     from swarmmap_amd.parallel import KeyframeExchange
     xchg = KeyframeExchange(slot_keypoints=nfeatures + 24, device=dev) if distributed else None
 
@@ -214,12 +333,12 @@ def main():
            "n_lba": 0, "lba_gpu_ms": 0.0, "match_kernel_ms": 0.0, "n_xchg": 0, "solve_ms": 0.0, "n_solves": 0}
     stage_ms = {}
 
-    mapper = LocalMapper(lambda: ba.LocalBundleAdjustment(lba_window)["info"])
+    mapper = LocalMapper(lambda: ba.LocalBundleAdjustment(lba_window)["info"]) if args.python_loop else None
     # Optimizer::PoseOptimization, 3 per frame (TrackWithMotionModel, TrackLocalMap and one retry: SURVEY 8d):
     # seeded frame-pose problems of the size the matchers return (~500 map points, 10 % outliers)
     pose_cases = [[synth.make_pose_case(1000 * rank + 3 * i + j, n=500, K=synth.EUROC_K if args.size == "euroc"
                                         else synth.KITTI_K, size=size) for j in range(3)] for i in range(16)]
-    tracker_opt = swarmmap_amd.Optimizer(device=dev)
+    tracker_opt = swarmmap_amd.Optimizer(device=dev) if args.python_loop else None
 
     def step(t, timed):
         t0 = time.perf_counter()
@@ -254,37 +373,84 @@ def main():
             for k, v in ex.profile().items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v
 
-    t = 1
-    ex.submit_device(dev_frames[t % n_distinct].data_ptr(), w, h, w)
-    for _ in range(args.warmup):
-        step(t, False)
-        t += 1
-    ex.set_profiling(True)
-
     def barrier():
         if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(t, True)
-        t += 1
-    mapper.drain()  # every queued window is optimised inside the timed region
-    barrier()      # (the frame submitted ahead by the last step finishes inside the timed region too)
-    dt = time.perf_counter() - t0
-    ex.collect()
-    mapper.close()
-    for inf in mapper.infos:
-        acc["n_lba"] += 1; acc["lba_gpu_ms"] += inf["gpu_ms"]
-        acc["solve_ms"] += inf["solve_ms"]; acc["n_solves"] += inf["n_solves"]
-    acc["lba_busy_ms"] = mapper.busy_s * 1e3
+    if args.python_loop:
+        t = 1
+        ex.submit_device(dev_frames[t % n_distinct].data_ptr(), w, h, w)
+        for _ in range(args.warmup):
+            step(t, False)
+            t += 1
+        ex.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(t, True)
+            t += 1
+        mapper.drain()  # every queued window is optimised inside the timed region
+        barrier()      # (the frame submitted ahead by the last step finishes inside the timed region too)
+        dt = time.perf_counter() - t0
+        ex.collect()
+        mapper.close()
+        for inf in mapper.infos:
+            acc["n_lba"] += 1; acc["lba_gpu_ms"] += inf["gpu_ms"]
+            acc["solve_ms"] += inf["solve_ms"]; acc["n_solves"] += inf["n_solves"]
+        acc["lba_busy_ms"] = mapper.busy_s * 1e3
+        n_cand = sum(len(ex.candidates(l)[0]) for l in range(8))
+    else:
+        # The same calls from the C++ host loop (swarmmap_amd/host/replay.cc): tracking thread = this thread inside
+        # so_replay_run, local-mapping thread = a std::thread of the harness.  Python only re-enters for the
+        # cross-agent exchange ticks of a multi-GPU run.
+        rp = Replay(dev, w, h, nfeatures, LBA_EVERY)
+        rp.set_frames([f.data_ptr() for f in dev_frames])
+        for tt, (last, mps) in prepared.items():
+            rp.set_step(tt, last, mps)
+        for group in pose_cases:
+            for c in group:
+                rp.add_pose_case(c)
+        rp.set_window(lba_window)
+
+        def run_span(first, n, timed):
+            t_ = first
+            while t_ < first + n:
+                if xchg is None:
+                    m_ = first + n - t_
+                else:  # stop after the next exchange tick
+                    nxt = (t_ // args.exchange_every + 1) * args.exchange_every
+                    m_ = min(first + n, nxt + 1) - t_
+                rp.run(t_, m_, timed)
+                t_ += m_
+                if xchg is not None and (t_ - 1) % args.exchange_every == 0:
+                    tx = time.perf_counter()
+                    xchg.exchange_and_match(rp.last_descriptors(), m1)
+                    if timed:
+                        acc["n_xchg"] += 1; acc["xchg_ms"] += (time.perf_counter() - tx) * 1e3
+
+        rp.prime(1)
+        run_span(1, args.warmup, False)
+        rp.drain()
+        rp.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        run_span(1 + args.warmup, args.steps, True)
+        rp.drain()     # every queued window is optimised inside the timed region
+        barrier()      # (the frame submitted ahead by the last step finishes inside the timed region too)
+        dt = time.perf_counter() - t0
+        rp.finish()
+        st = rp.stats()
+        for k in ("extract_ms", "match_ms", "pose_ms", "lba_ms", "n_kp", "n_m2", "n_m1", "match_kernel_ms", "pose_kernel_ms",
+                  "pose_trials", "pose_calls", "n_lba", "lba_busy_ms", "lba_gpu_ms", "solve_ms", "n_solves"):
+            acc[k] = st[k]
+        stage_ms.update(st["stages"])
+        n_cand = rp.candidates_total()
+        rp.close()
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    n_cand = sum(len(ex.candidates(l)[0]) for l in range(8))
 
     if rank == 0:
         steps = args.steps
@@ -334,6 +500,7 @@ def main():
             "value": steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (extract, match) + f64 (local BA)", "data": "synthetic",
+            "host_loop": "python (ctypes)" if args.python_loop else "c++ (swarmmap_amd/host/replay.cc)",
             "fps_per_agent": steps / dt,
             "config": {
                 "workload": "BASELINE.json configs[1] (single agent per GPU, 752x480 EuRoC-sized stream, HIP ORB "
@@ -361,7 +528,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host_frames, 7, stream, size, nfeatures, lba_window, pose_cases)
         print(json.dumps(out), flush=True)
     for o in (ex, m1, m2, ba, tracker_opt):
-        o.close()
+        if o is not None:
+            o.close()
     if distributed:
         torch.distributed.destroy_process_group()
 

@@ -240,7 +240,9 @@ int so_ba_create(int device, so_ba** out) {
     SO_HIP(hipSetDevice(device));
     so_ba* b = new so_ba();
     b->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    // the solver's stream is created by the first so_bundle_adjust: a handle used only for PoseOptimization (which runs on
+    // the tracking thread's stream) must not take one of the few hardware queues the runtime multiplexes streams onto
+    hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipEventCreate(&b->e0);
     if (e == hipSuccess) e = hipEventCreate(&b->e1);
     if (e == hipSuccess) e = hipEventCreate(&b->pe0);
@@ -437,6 +439,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     const bool trace = getenv("SWARMORB_BA_TRACE") != nullptr;
     const double t_staged = now_ms();
 
+    if (!b->stream) SO_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     hipStream_t s = b->stream;
     SO_HIP(hipMemcpyAsync(b->d_in.p, b->h_in, L.total, hipMemcpyHostToDevice, s));
     const size_t sE = (size_t)nE, sL = (size_t)std::max(nL, 1), sF = (size_t)std::max(nf, 1), n = 6 * sF;

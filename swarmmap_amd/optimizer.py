@@ -29,6 +29,21 @@ def _vp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def problem_struct(prob):
+    """(SoBaProblem, arrays it points into) for a problem dictionary (synth.make_ba_problem layout)."""
+    a = dict(Tcw=np.ascontiguousarray(prob["Tcw"], np.float32).reshape(-1, 12),
+             fixed=np.ascontiguousarray(prob["fixed"], np.uint8),
+             intr=np.ascontiguousarray(prob["intr"], np.float32).reshape(-1, 4),
+             Xw=np.ascontiguousarray(prob["Xw"], np.float32).reshape(-1, 3),
+             edge_pose=np.ascontiguousarray(prob["edge_pose"], np.int32),
+             edge_point=np.ascontiguousarray(prob["edge_point"], np.int32),
+             obs=np.ascontiguousarray(prob["obs"], np.float32).reshape(-1, 2),
+             inv_sigma2=np.ascontiguousarray(prob["inv_sigma2"], np.float32))
+    P = SoBaProblem(len(a["Tcw"]), _vp(a["Tcw"]), _vp(a["fixed"]), _vp(a["intr"]), len(a["Xw"]), _vp(a["Xw"]),
+                    len(a["edge_pose"]), _vp(a["edge_pose"]), _vp(a["edge_point"]), _vp(a["obs"]), _vp(a["inv_sigma2"]))
+    return P, a
+
+
 class Optimizer:
     """One solver context per LocalMapping thread (device buffers are reused from call to call)."""
 
