@@ -75,3 +75,17 @@ def test_keyframe_record_round_trip_and_corruption():
                 unpack_keyframe_record(bad)
     with pytest.raises(swarmmap_amd.SwarmOrbError):
         unpack_keyframe_record(np.zeros(128, np.uint8))
+
+
+def test_replay_library_loads_and_exports():
+    """The C++ host loop of bench.py (swarmmap_amd/host/replay.cc) is built next to the C-ABI library."""
+    import ctypes
+    import os
+    import swarmmap_amd
+    swarmmap_amd.load_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = ctypes.CDLL(os.path.join(root, "swarmmap_amd", "libswarmorb_replay.so"))
+    for name in ("so_replay_create", "so_replay_destroy", "so_replay_set_frames", "so_replay_set_step",
+                 "so_replay_add_pose_case", "so_replay_set_window", "so_replay_prime", "so_replay_run",
+                 "so_replay_drain", "so_replay_finish", "so_replay_stats", "so_replay_last_frame"):
+        assert hasattr(lib, name), name
