@@ -284,6 +284,9 @@ def main():
     ap.add_argument("--size", default="euroc", choices=["euroc", "kitti"])
     ap.add_argument("--exchange-every", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--agents-per-gpu", type=int, default=1,
+                    help="run this many independent agents (tracking + local-mapping thread pairs, own contexts and "
+                         "streams) on each GPU; value stays the aggregate frames/s over all agents")
     ap.add_argument("--python-loop", action="store_true",
                     help="drive the timed loop from Python (ctypes wrappers) instead of the C++ host loop "
                          "swarmmap_amd/host/replay.cc; same calls, interpreter overhead included")
@@ -404,49 +407,105 @@ def main():
         # The same calls from the C++ host loop (swarmmap_amd/host/replay.cc): tracking thread = this thread inside
         # so_replay_run, local-mapping thread = a std::thread of the harness.  Python only re-enters for the
         # cross-agent exchange ticks of a multi-GPU run.
-        rp = Replay(dev, w, h, nfeatures, LBA_EVERY)
-        rp.set_frames([f.data_ptr() for f in dev_frames])
-        for tt, (last, mps) in prepared.items():
-            rp.set_step(tt, last, mps)
-        for group in pose_cases:
-            for c in group:
-                rp.add_pose_case(c)
-        rp.set_window(lba_window)
+        import threading
+        A = max(1, args.agents_per_gpu)
+        gate = threading.Barrier(A + 1)
+        results, errors = [None] * A, []
+        clock = {}
 
-        def run_span(first, n, timed):
-            t_ = first
-            while t_ < first + n:
-                if xchg is None:
-                    m_ = first + n - t_
-                else:  # stop after the next exchange tick
-                    nxt = (t_ // args.exchange_every + 1) * args.exchange_every
-                    m_ = min(first + n, nxt + 1) - t_
-                rp.run(t_, m_, timed)
-                t_ += m_
-                if xchg is not None and (t_ - 1) % args.exchange_every == 0:
-                    tx = time.perf_counter()
-                    xchg.exchange_and_match(rp.last_descriptors(), m1)
-                    if timed:
-                        acc["n_xchg"] += 1; acc["xchg_ms"] += (time.perf_counter() - tx) * 1e3
+        def sync(tag):
+            """Agent side of the three rendezvous points.  With one agent the loop runs on this (the main) thread, so
+            that no stream beyond the agent's own three exists, and the clock is handled right here."""
+            if A > 1:
+                gate.wait()
+            elif tag == "warm":
+                barrier()
+                clock["t0"] = time.perf_counter()
+            elif tag == "done":
+                barrier()      # (the frame submitted ahead by the last step finishes inside the timed region too)
+                clock["dt"] = time.perf_counter() - clock["t0"]
 
-        rp.prime(1)
-        run_span(1, args.warmup, False)
-        rp.drain()
-        rp.set_profiling(True)
-        barrier()
-        t0 = time.perf_counter()
-        run_span(1 + args.warmup, args.steps, True)
-        rp.drain()     # every queued window is optimised inside the timed region
-        barrier()      # (the frame submitted ahead by the last step finishes inside the timed region too)
-        dt = time.perf_counter() - t0
-        rp.finish()
-        st = rp.stats()
+        def agent(a):
+            # created in the thread that runs it: the library gives every thread its own tracking streams
+            try:
+                rp = Replay(dev, w, h, nfeatures, LBA_EVERY)
+                rp.set_frames([f.data_ptr() for f in dev_frames])
+                for tt, (last, mps) in prepared.items():
+                    rp.set_step(tt, last, mps)
+                for group in pose_cases:
+                    for c in group:
+                        rp.add_pose_case(c)
+                rp.set_window(lba_window)
+
+                def run_span(first, n, timed):
+                    t_ = first
+                    while t_ < first + n:
+                        if xchg is None or a > 0:
+                            m_ = first + n - t_
+                        else:  # agent 0 of the rank stops after the next exchange tick
+                            nxt = (t_ // args.exchange_every + 1) * args.exchange_every
+                            m_ = min(first + n, nxt + 1) - t_
+                        rp.run(t_, m_, timed)
+                        t_ += m_
+                        if xchg is not None and a == 0 and (t_ - 1) % args.exchange_every == 0:
+                            tx = time.perf_counter()
+                            xchg.exchange_and_match(rp.last_descriptors(), m1)
+                            if timed:
+                                acc["n_xchg"] += 1; acc["xchg_ms"] += (time.perf_counter() - tx) * 1e3
+
+                rp.prime(1)
+                run_span(1, args.warmup, False)
+                rp.drain()
+                rp.set_profiling(False)  # stage events off: the frame goes out as one hipGraph launch
+                sync("warm")  # all agents warmed up
+                sync("go")    # the main thread has passed the barrier and started the clock
+                run_span(1 + args.warmup, args.steps, True)
+                rp.drain()    # every queued window is optimised inside the timed region
+                sync("done")
+                rp.finish()
+                results[a] = (rp.stats(), rp.candidates_total())
+                rp.close()
+            except Exception as e:  # noqa: BLE001 - reported by the main thread
+                errors.append(e)
+                if A > 1:
+                    gate.abort()
+
+        if A == 1:
+            agent(0)
+            if errors:
+                raise errors[0]
+            dt = clock["dt"]
+        else:
+            threads = [threading.Thread(target=agent, args=(a,), daemon=True) for a in range(A)]
+            for th in threads:
+                th.start()
+            try:
+                gate.wait()
+                barrier()
+                t0 = time.perf_counter()
+                gate.wait()
+                gate.wait()
+                barrier()      # (the frames submitted ahead by the last steps finish inside the timed region too)
+                dt = time.perf_counter() - t0
+            except threading.BrokenBarrierError:
+                raise errors[0] if errors else RuntimeError("an agent thread failed")
+            for th in threads:
+                th.join()
+            if errors:
+                raise errors[0]
         for k in ("extract_ms", "match_ms", "pose_ms", "lba_ms", "n_kp", "n_m2", "n_m1", "match_kernel_ms", "pose_kernel_ms",
                   "pose_trials", "pose_calls", "n_lba", "lba_busy_ms", "lba_gpu_ms", "solve_ms", "n_solves"):
-            acc[k] = st[k]
-        stage_ms.update(st["stages"])
-        n_cand = rp.candidates_total()
-        rp.close()
+            acc[k] = sum(r[0][k] for r in results) / A  # per-agent averages; counts too
+        n_cand = results[0][1]
+        # per-stage HIP-event times of the extractor: an untimed profiled pass right after the timed region (stage
+        # events split the frame's graph back into single launches, so they stay out of the timed loop)
+        ex.set_profiling(True)
+        n_prof = 64
+        for i in range(n_prof):
+            ex.run_device(dev_frames[i % n_distinct].data_ptr(), w, h, w)
+            for kk, vv in ex.profile().items():
+                stage_ms[kk] = stage_ms.get(kk, 0.0) + vv * (args.steps / n_prof)
+        ex.set_profiling(False)
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -464,6 +523,9 @@ def main():
         roof_fast = {"bound": "hbm", "kernel": "fast_score_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms,
+                     "measured": "in the timed region" if args.python_loop else
+                                 "untimed profiled pass of 64 frames right after the timed region (the timed loop "
+                                 "launches the frame as one hipGraph, without stage events)",
                      "total_ms_in_timed_region": stage_ms["fast_score"]}
         # reduced-camera-system solve of local BA: dense Cholesky of a (6 n_free)^2 FP64 system, n^3/3 + 2 n^2 flop
         n_red = 6 * int((lba_window["fixed"] == 0).sum())
@@ -497,18 +559,18 @@ def main():
         out = {
             "metric": "frames/sec (tracking front-end + matching + local BA per frame; aggregate over agents, "
                       "per-agent = value/n_gpus)",
-            "value": steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "value": steps * world * max(1, args.agents_per_gpu) / dt, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (extract, match) + f64 (local BA)", "data": "synthetic",
             "host_loop": "python (ctypes)" if args.python_loop else "c++ (swarmmap_amd/host/replay.cc)",
-            "fps_per_agent": steps / dt,
+            "fps_per_agent": steps / dt, "agents_per_gpu": max(1, args.agents_per_gpu),
             "config": {
                 "workload": "BASELINE.json configs[1] (single agent per GPU, 752x480 EuRoC-sized stream, HIP ORB "
                             "extract nFeatures %d + HIP match M2+M1 + 3x HIP PoseOptimization on the tracking thread) plus HIP LocalBA (LBA-M window every "
                             "%d frames) on a local-mapping thread, as in the reference"
                             % (nfeatures, LBA_EVERY) if args.size == "euroc" else
                             "KITTI-sized 1241x376 stream, nFeatures %d, same per-frame path" % nfeatures,
-                "agents": world, "frame": [w, h], "keypoints_per_frame": acc["n_kp"] / steps,
+                "agents": world * max(1, args.agents_per_gpu), "frame": [w, h], "keypoints_per_frame": acc["n_kp"] / steps,
                 "m2_matches_per_frame": acc["n_m2"] / steps, "m1_matches_per_frame": acc["n_m1"] / steps,
                 "lba_windows": acc["n_lba"], "lba_edges": int(len(lba_window["edge_pose"])),
                 "descriptor_exchanges": acc["n_xchg"],

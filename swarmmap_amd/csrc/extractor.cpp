@@ -39,6 +39,12 @@ struct so_extractor {
     bool device_qt = false;
     bool cands_on_host = false;        // h_cands holds the last frame's candidates (debug API)
     bool pending_prof = false;         // the in-flight frame recorded its stage events
+    // the frame's twelve launches as one hipGraph (captured on the first unprofiled frame of the one-sync path):
+    // one runtime call per frame instead of twelve - the calls serialise on the runtime's lock when several agents
+    // share a process
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_failed = false;
     int pending = 0;                   // 1: a submitted frame is in flight on the stream, 2: finished into pend_* below
     double t_begin = 0.0, t_enq = 0.0;
     std::vector<so_keypoint> pend_kps;  // submit on the host-quadtree path runs to completion into these
@@ -314,6 +320,39 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
     // ComputePyramid, code/src/ORBextractor.cc:837-853
     SO_HIP(hipMemcpy2DAsync(P.lv[0].img, (size_t)P.lv[0].pitch, image, (size_t)stride, (size_t)w, (size_t)h,
                             on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    static const bool no_graph = getenv("SWARMORB_NO_GRAPH") != nullptr;
+    if (!prof && !no_graph && ex->device_qt && P.total_tiles > 0 && !ex->graph_failed) {
+        float* angle_dev = reinterpret_cast<float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);
+        if (!ex->graph_exec) {  // every launch argument is fixed once the context is sized: capture the chain once
+            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                for (int l = 1; l < P.nlevels; l++) launch_resize(P.lv[l - 1], P.lv[l], s);
+                launch_fast_score(P, s);
+                launch_fast_low_count(P, ex->d_rowcount, s);
+                launch_emit(P, ex->d_rowcount, ex->d_cands, ex->d_header, ex->h_header_dev, ex->cand_capacity, s);
+                launch_quadtree(P, ex->features_per_level, ex->qt_stride, ex->d_cands, ex->d_header, ex->d_qt_sel,
+                                ex->d_qt_count, s);
+                launch_describe_qt(P, ex->d_qt_sel, ex->d_qt_count, ex->qt_stride, ex->out_capacity, ex->h_desc_dev,
+                                   angle_dev, ex->h_meta_dev, ex->h_total_dev, s);
+                e = hipStreamEndCapture(s, &ex->graph);
+            }
+            if (e == hipSuccess) e = hipGraphInstantiate(&ex->graph_exec, ex->graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) {  // run this and later frames launch by launch
+                (void)hipGetLastError();
+                ex->graph_failed = true;
+                ex->graph_exec = nullptr;
+            }
+        }
+        if (ex->graph_exec) {
+            SO_HIP(hipGraphLaunch(ex->graph_exec, s));
+            ex->t_begin = t_begin;
+            ex->t_enq = now_ms();
+            ex->pending = 1;
+            ex->pending_prof = false;
+            if (submit_only) return SO_OK;
+            return collect_impl(ex, kps, desc, capacity, n_out);
+        }
+    }
     for (int l = 1; l < P.nlevels; l++) launch_resize(P.lv[l - 1], P.lv[l], s);
     if (prof) SO_HIP(hipEventRecord(ex->ev[1], s));
     // ComputeKeyPointsOctTree, code/src/ORBextractor.cc:691-744 (all levels batched)
@@ -476,6 +515,8 @@ void so_extractor_destroy(so_extractor* ex) {
     if (ex->h_desc) (void)hipHostFree(ex->h_desc);
     if (ex->h_meta) (void)hipHostFree(ex->h_meta);
     if (ex->h_total) (void)hipHostFree(ex->h_total);
+    if (ex->graph_exec) (void)hipGraphExecDestroy(ex->graph_exec);
+    if (ex->graph) (void)hipGraphDestroy(ex->graph);
     for (auto& v : ex->ev)
         if (v) (void)hipEventDestroy(v);
     delete ex;
