@@ -1,0 +1,64 @@
+"""Several agents in one process (one thread pair each, as SwarmMap runs its clients): contexts are per thread,
+results must not depend on what the other threads are doing."""
+import threading
+
+import numpy as np
+import pytest
+
+from swarmmap_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _agent_work(S, seed, rounds, out):
+    from swarmmap_amd.matcher import FrameView
+    ex = S.ORBextractor(1000, 1.2, 8, 20, 7)
+    m = S.ORBmatcher(0.9, True)
+    opt = S.Optimizer()
+    stream = synth.FrameStream(seed=seed)
+    fr, last = synth.make_m2_case(seed, 800, 800)
+    F = FrameView(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["bounds"], fr["scale_factors"], fr["excluded"])
+    c = synth.make_pose_case(seed, 300)
+    win = synth.make_ba_problem(seed, 5, 4, 250, max_obs="auto")
+    res = []
+    ex.submit(stream.frame(0))
+    for t in range(rounds):
+        kps, desc = ex.collect()
+        kps, desc = kps.copy(), desc.copy()
+        ex.submit(stream.frame(t + 1))
+        nm, k2l = m.SearchByProjectionLastFrame(F, last, 15.0)
+        ni, T, outl, _ = opt.PoseOptimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
+        item = [kps.tobytes(), desc.tobytes(), nm, k2l.tobytes(), ni, T.tobytes(), outl.tobytes()]
+        if t % 4 == 0:
+            r = opt.LocalBundleAdjustment(win)
+            item += [r["Tcw"].tobytes(), r["Xw"].tobytes()]
+        res.append(item)
+    ex.collect()
+    for o in (ex, m, opt):
+        o.close()
+    out[seed] = res
+
+
+def test_four_agents_in_threads_match_sequential_runs():
+    import swarmmap_amd as S
+    assert S.device_count() > 0, "these tests need a GPU"
+    seeds, rounds = [11, 12, 13, 14], 12
+    ref = {}
+    for s in seeds:
+        _agent_work(S, s, rounds, ref)
+    par, errs = {}, []
+
+    def run(s):
+        try:
+            _agent_work(S, s, rounds, par)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=run, args=(s,)) for s in seeds]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    for s in seeds:
+        assert par[s] == ref[s], "agent %d: results depend on concurrency" % s
