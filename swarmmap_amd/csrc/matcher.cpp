@@ -127,6 +127,10 @@ struct so_matcher {
     View h_q, h_qdesc, h_keys, h_count;
     DevBuf d_A, d_B, d_res;
     PinBuf h_res;
+    // exact re-run of ONE query (rerun_single): its own tiny staging, so the batch's queries and K-lists stay valid
+    PinBuf h_rq;
+    DevBuf d_rq;
+    MappedBuf h_rout;
 
     float inv_sigma2[8] = {0}, sigma2[8] = {0}, scale[8] = {0}, ex = 0.f, ey = 0.f;  // gates of the current candidates
     int n_cand = 0;           // keypoints that are inside the grid (PosInGrid true)
@@ -298,16 +302,40 @@ struct Entry {
     int idx, dist;
 };
 
-// Exact top-K of ONE query under a dynamic per-keypoint gate (rare path, see file header).
+// Exact top-K of ONE query under a dynamic per-keypoint gate (rare path, see file header).  Uses its own staging:
+// the batch's queries / K-lists (host-mapped, read in place by the callers) are not touched.
 int rerun_single(so_matcher* m, const MatchQuery& q, const uint8_t* qdesc, const std::vector<int32_t>& limit_by_idx,
                  int K, Entry* out, int* n_found) {
     int rc = upload_limit_only(m, limit_by_idx);
     if (rc) return rc;
-    // h_q / h_qdesc / h_keys / h_count are reused: callers copy the batch results out before resolving
-    ((MatchQuery*)m->h_q.p)[0] = q;
-    memcpy(m->h_qdesc.p, qdesc, 32);
-    if ((rc = run_topk(m, 1, K))) return rc;
-    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
+    constexpr size_t kQ = 256;  // query struct, then its descriptor at +128
+    if ((rc = m->h_rq.ensure_keep(kQ, 0))) return rc;
+    if ((rc = m->d_rq.ensure(kQ))) return rc;
+    if ((rc = m->h_rout.ensure(512))) return rc;
+    memcpy(m->h_rq.p, &q, sizeof(MatchQuery));
+    memcpy((uint8_t*)m->h_rq.p + 128, qdesc, 32);
+    hipStream_t s = m->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    // the limit gate sits at the end of the frame part of the staging block: send it (and whatever else is newer)
+    if (m->dirty_from < m->frame_end)
+        SO_HIP(hipMemcpyAsync((uint8_t*)m->d_in.p + m->dirty_from, (const uint8_t*)m->h_in.p + m->dirty_from,
+                              m->frame_end - m->dirty_from, hipMemcpyHostToDevice, s));
+    m->dirty_from = SIZE_MAX;
+    SO_HIP(hipMemcpyAsync(m->d_rq.p, m->h_rq.p, kQ, hipMemcpyHostToDevice, s));
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_topk_window(frame_dev(m), (const MatchQuery*)m->d_rq.p, (const uint4*)((const uint8_t*)m->d_rq.p + 128), 1, K,
+                       (uint32_t*)m->h_rout.dev, (int32_t*)((uint8_t*)m->h_rout.dev + 256), s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    const auto t1 = std::chrono::steady_clock::now();
+    SO_HIP(hipStreamSynchronize(s));
+    const auto t2 = std::chrono::steady_clock::now();
+    m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    m->stat[2] += 1.0;
+    float ms = 0.f;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    const uint32_t* keys = (const uint32_t*)m->h_rout.p;
     *n_found = 0;
     for (int k = 0; k < K; k++) {
         if (keys[k] == 0xFFFFFFFFu) break;
@@ -386,8 +414,10 @@ void so_matcher_destroy(so_matcher* m) {
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (DevBuf* b : {&m->d_in, &m->d_A, &m->d_B, &m->d_res}) b->release();
-    for (PinBuf* b : {&m->h_in, &m->h_res}) b->release();
+    for (PinBuf* b : {&m->h_in, &m->h_res, &m->h_rq}) b->release();
+    m->d_rq.release();
     m->h_out.release();
+    m->h_rout.release();
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
     delete m;
@@ -484,9 +514,9 @@ int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int
     }
     memcpy(m->h_qdesc.p, mp_desc, (size_t)n_mp * 32);
     if ((rc = run_topk(m, n_mp, K))) return rc;
-    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)n_mp * K);
-    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + n_mp);
-    std::vector<MatchQuery> queries(hq, hq + n_mp);
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
+    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    const MatchQuery* queries = hq;
     std::vector<int32_t> gate;
     int nm = 0;
     for (int i = 0; i < n_mp; i++) {
@@ -556,9 +586,9 @@ int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, i
     }
     memcpy(m->h_qdesc.p, mp_desc, (size_t)n_last * 32);
     if ((rc = run_topk(m, n_last, K))) return rc;
-    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)n_last * K);
-    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + n_last);
-    std::vector<MatchQuery> queries(hq, hq + n_last);
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
+    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    const MatchQuery* queries = hq;
     std::vector<int32_t> gate;
     std::vector<int> rot_item, rot_b;
     int hist[HISTO_LENGTH] = {0};
@@ -642,9 +672,9 @@ int so_search_for_initialization(so_matcher* m, const so_frame_view* F1, const s
     }
     memcpy(m->h_qdesc.p, F1->desc, (size_t)n1 * 32);
     if ((rc = run_topk(m, n1, K))) return rc;
-    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)n1 * K);
-    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + n1);
-    std::vector<MatchQuery> queries(hq, hq + n1);
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
+    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    const MatchQuery* queries = hq;
     std::vector<int32_t> matched_dist((size_t)n2, INT_MAX);
     std::vector<int32_t> matches21((size_t)n2, -1);
     std::vector<int> rot_item, rot_b;
@@ -925,8 +955,8 @@ int so_search_by_bow(so_matcher* m, int variant, int32_t n1, const uint8_t* desc
     uint8_t* hd = (uint8_t*)m->h_qdesc.p;
     for (int i = 0; i < nq; i++) memcpy(hd + (size_t)i * 32, desc1 + (size_t)q_idx1[(size_t)i] * 32, 32);
     if ((rc = run_topk(m, nq, K))) return rc;
-    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)nq * K);
-    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + nq);
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
+    const int32_t* cnt = (const int32_t*)m->h_count.p;
     std::vector<int32_t> gate;
     std::vector<int> rot_item, rot_b;
     int hist[HISTO_LENGTH] = {0};
@@ -1142,9 +1172,9 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
     }
     memcpy(m->h_qdesc.p, qdesc, (size_t)nq * 32);
     if ((rc = run_topk(m, nq, K))) return rc;
-    std::vector<uint32_t> keys((const uint32_t*)m->h_keys.p, (const uint32_t*)m->h_keys.p + (size_t)nq * K);
-    std::vector<int32_t> cnt((const int32_t*)m->h_count.p, (const int32_t*)m->h_count.p + nq);
-    std::vector<MatchQuery> queries(hq, hq + nq);
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
+    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    const MatchQuery* queries = hq;
     std::vector<int32_t> gate;
     std::vector<int> rot_item, rot_b;
     int hist[HISTO_LENGTH] = {0};
