@@ -1650,7 +1650,8 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
     int robust = 1;
 
     // One pass over the active edges at pose T: stored errors, robustified chi2, J^T w J (upper 21), -rho' J^T Omega e
-    // (6) and the number of active edges, reduced into s_sys[which].  Two barriers.
+    // (6) and the number of active edges, reduced into s_sys[which].  One barrier; the caller's barrier after lane 0's
+    // decision is the second.
     auto edge_phase = [&](const BaPose& T, int which) {
         double v[32];
 #pragma unroll
@@ -1682,13 +1683,28 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
             J[9] = 0;                         J[10] = -invz * fy;                  J[11] = y * invz_2 * fy;
             const double r1 = robust ? huber_rho1(chi2, delta, dsqr) : 1.0;
             const double wo = r1 * w;
+            // J[4] and J[9] are structurally zero: their products are left out (same sums, fewer FMAs)
+            double Ju[6], Jv[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) { Ju[r] = J[r] * wo; Jv[r] = J[6 + r] * wo; }
             int t = 0;
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int c = r; c < 6; c++) v[t++] += J[r] * wo * J[c] + J[6 + r] * wo * J[6 + c];
+                for (int c = r; c < 6; c++) {
+                    double acc = v[t];
+                    if (r != 4 && c != 4) acc = fma(Ju[r], J[c], acc);
+                    if (r != 3 && c != 3) acc = fma(Jv[r], J[6 + c], acc);
+                    v[t++] = acc;
+                }
+            const double we0 = r1 * (w * e0), we1 = r1 * (w * e1);
 #pragma unroll
-            for (int r = 0; r < 6; r++) v[21 + r] -= r1 * (J[r] * (w * e0) + J[6 + r] * (w * e1));
+            for (int r = 0; r < 6; r++) {
+                double acc = v[21 + r];
+                if (r != 4) acc = fma(-J[r], we0, acc);
+                if (r != 3) acc = fma(-J[6 + r], we1, acc);
+                v[21 + r] = acc;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = po_swap_add32(v[i], v[i + 16]);
@@ -1715,7 +1731,9 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
                 S[36 + (tid - 21)] = sum;  // b 36..41, chi 42, n_active 43
             }
         }
-        __syncthreads();
+        // no barrier here: only lane 0 (same wave as the 29 summing lanes, LDS in order) reads s_sys before the
+        // barrier that ends lane 0's decision
+        __threadfence_block();
     };
 
     // lane 0: solve the current system with the current lambda and publish the trial pose
