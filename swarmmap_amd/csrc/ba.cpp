@@ -122,7 +122,7 @@ struct so_ba {
     // d_in: the problem as one block (see Layout in so_bundle_adjust), staged in pinned h_in and moved with one
     // copy; d_out / h_out: the result block coming back the same way; the rest is device-only working storage
     Buf d_in, d_out, d_pose1, d_pt1, d_err, d_chi2, d_tab, d_Hpp, d_bp, d_Hll, d_bl, d_W, d_Dinv, d_db, d_BDinv, d_S,
-        d_bs, d_xl, d_partial, d_po, d_lm, d_dense_ws, d_dense_x;
+        d_bs, d_xl, d_partial, d_po, d_lm, d_dense_ws, d_dense_x, d_pr_off, d_pr_cur, d_pr, d_big, d_scan_tmp;
     void* h_in = nullptr;
     size_t h_in_cap = 0;
     void* h_out = nullptr;
@@ -132,7 +132,7 @@ struct so_ba {
     size_t h_po_cap = 0;
     std::vector<Buf*> all() {
         return {&d_in, &d_out, &d_pose1, &d_pt1, &d_err, &d_chi2, &d_tab, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv,
-                &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x};
+                &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x, &d_pr_off, &d_pr_cur, &d_pr, &d_big, &d_scan_tmp};
     }
 };
 
@@ -474,6 +474,22 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         if ((rc = b->d_dense_ws.ensure(sizeof(double) * (ldS / 96) * 96 * 96))) return rc;
         if ((rc = b->d_dense_x.ensure(sizeof(double) * ldS))) return rc;
     }
+    // pair lists of the large-map gather: capacity from the landmarks' observation counts (an upper bound: fixed
+    // keyframes' observations are counted too)
+    size_t pair_cap = 0, n_blk = (size_t)nf * ((size_t)nf + 1) / 2, big_cap = 0, scan_bytes = 0;
+    if (dense_path) {
+        for (int i = 0; i < nL; i++) {
+            const size_t k = (size_t)(h_ptoff[i + 1] - h_ptoff[i]);
+            pair_cap += k * (k - (k > 0 ? 1 : 0)) / 2;
+        }
+        big_cap = (size_t)nf + std::min(n_blk - (size_t)nf, pair_cap / (kBaSmallBlockPairs + 1));
+        scan_bytes = ba_pairs_scan_temp_bytes((int)n_blk);
+        if ((rc = b->d_pr_off.ensure(sizeof(int) * (n_blk + 1)))) return rc;
+        if ((rc = b->d_pr_cur.ensure(sizeof(int) * (n_blk + 1)))) return rc;
+        if ((rc = b->d_pr.ensure(sizeof(int) * 3 * std::max<size_t>(pair_cap, 1)))) return rc;
+        if ((rc = b->d_big.ensure(sizeof(int) * (big_cap + 1)))) return rc;
+        if ((rc = b->d_scan_tmp.ensure(std::max<size_t>(scan_bytes, 16)))) return rc;
+    }
     if ((rc = b->d_lm.ensure(sizeof(BaLm)))) return rc;
     Layout O;  // result block
     const size_t r_pose = O.add(sizeof(BaPose) * (size_t)nP), r_pt = O.add(sizeof(double) * 3 * (size_t)nL),
@@ -527,6 +543,15 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.ldS = (int)ldS;
     d.dense_ws = b->d_dense_ws.as<double>();
     d.dense_x = b->d_dense_x.as<double>();
+    d.use_pairs = dense_path ? 1 : 0;
+    d.pr_off = b->d_pr_off.as<int>();
+    d.pr_cur = b->d_pr_cur.as<int>();
+    d.pr_l = b->d_pr.as<int>();
+    d.pr_k1 = d.pr_l + std::max<size_t>(pair_cap, 1);
+    d.pr_k2 = d.pr_k1 + std::max<size_t>(pair_cap, 1);
+    d.big_list = b->d_big.as<int>();
+    d.big_n = d.big_list ? d.big_list + big_cap : nullptr;
+    d.big_cap = (int)big_cap;
     d.dense_side = dense_path ? b->dense_side : nullptr;
     d.dense_events = dense_path ? b->dense_events.data() : nullptr;
     d.xl = b->d_xl.as<double>();
@@ -537,7 +562,10 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     r.nb_err = std::min(1024, std::max(1, (nE + 255) / 256));
     r.nb_upd = std::min(1024, std::max(1, (8 * nL + nP + 255) / 256));
     launch_ba_edge_table(d, s);
-    if (dense_path) launch_ba_dense_pad(d, s);
+    if (dense_path) {
+        launch_ba_dense_pad(d, s);
+        launch_ba_build_pairs(d, b->d_scan_tmp.p, scan_bytes, s);
+    }
 
     const double t_uploaded = now_ms();
     SO_HIP(hipEventRecord(b->e0, s));

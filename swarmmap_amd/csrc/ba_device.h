@@ -68,6 +68,14 @@ struct BaDev {
     const int* pose_off;      // n_free + 1
     const int* pose_edges;    // edge ids per free pose
     int* edge_tab;            // n_free x n_points: the edge joining (hessian index, landmark), -1 if none
+    // large maps (blocked-solver path): per upper block (i1 < i2) the (edge, edge) pairs of the landmarks both
+    // keyframes see, built on the device; blocks with at most kBaSmallBlockPairs pairs are summed by one thread each
+    int use_pairs;
+    int* pr_off;              // n_blk + 1: exclusive scan of the pair counts (block g = i2 (i2 + 1) / 2 + i1)
+    int* pr_cur;              // n_blk: counts, then fill cursors
+    int* pr_l; int* pr_k1; int* pr_k2;  // landmark, edge of i1, edge of i2
+    int* big_list; int* big_n;          // blocks left to the wave-per-block walk: the diagonal and the crowded ones
+    int big_cap;                        // capacity of big_list = launch bound of the walk
     // system
     double* Hpp; double* bp; double* Hll; double* bl; double* W;
     double* Dinv; double* db; double* BDinv;
@@ -101,6 +109,10 @@ void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_
 void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abort_flag, BaLm* lm_host,
                      hipEvent_t ev0, hipEvent_t ev1, hipStream_t s);
 void launch_ba_edge_table(const BaDev& d, hipStream_t s);
+constexpr int kBaSmallBlockPairs = 8;
+size_t ba_pairs_scan_temp_bytes(int n_blk);
+// once per problem on the blocked-solver path: count, scan, fill the pair lists, classify the blocks
+void launch_ba_build_pairs(const BaDev& d, void* scan_temp, size_t scan_temp_bytes, hipStream_t s);
 // blocked dense path (ba_dense.hip), used when the system is too large for one workgroup (n_free > 43)
 constexpr int kBaSmallSolverMaxFree = 43;
 constexpr int kDenseMaxPanels = 128;  // 12288 / 96

@@ -16,6 +16,8 @@
 //   core/block_solver.hpp:354-486       Schur complement, back-substitution
 #include <cstdlib>
 
+#include <hipcub/hipcub.hpp>
+
 #include "ba_device.h"
 
 // FP64 solver: parity with the oracle is tolerance-based (see tests/test_ba_gpu.py), so let the compiler fuse
@@ -221,6 +223,66 @@ __global__ __launch_bounds__(256) void ba_edge_table_kernel(BaDev d) {
 void launch_ba_edge_table(const BaDev& d, hipStream_t s) {
     if (d.n_edges <= 0 || d.n_free <= 0) return;
     hipLaunchKernelGGL(ba_edge_table_kernel, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d);
+}
+
+// ---------------- pair lists for large maps (global bundle adjustment) ----------------
+// A keyframe pair of a big map shares a handful of landmarks or none; walking a keyframe's ~500 edges per block to
+// find them (the local-window gather) is 200x more lookups than there are pairs.  Per landmark, every pair of its
+// observing free keyframes (h1 < h2) is one entry of block g = h2 (h2 + 1) / 2 + h1.  Count -> scan -> fill; the
+// order inside a block comes out of atomics and is therefore arbitrary: the consumer sorts each short list by
+// landmark before it sums, so results stay deterministic.
+template <bool FILL>
+__global__ __launch_bounds__(256) void ba_pairs_kernel(BaDev d) {
+    const int il = blockIdx.x * 256 + threadIdx.x;
+    if (il >= d.n_points) return;
+    const int e0 = d.pt_off[il], e1 = d.pt_off[il + 1];
+    for (int a = e0; a < e1; a++) {
+        const int ha = d.pose_hidx[d.e_pose[a]];
+        if (ha < 0) continue;
+        for (int c = a + 1; c < e1; c++) {
+            const int hc = d.pose_hidx[d.e_pose[c]];
+            if (hc < 0) continue;
+            const int h1 = ha < hc ? ha : hc, h2 = ha < hc ? hc : ha;
+            const int g = h2 * (h2 + 1) / 2 + h1;
+            if (!FILL) {
+                atomicAdd(&d.pr_cur[g], 1);
+            } else {
+                const int pos = d.pr_off[g] + atomicAdd(&d.pr_cur[g], 1);
+                d.pr_l[pos] = il;
+                d.pr_k1[pos] = ha < hc ? a : c;  // edge of the keyframe with the smaller hessian index
+                d.pr_k2[pos] = ha < hc ? c : a;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ba_pairs_classify_kernel(BaDev d, int n_blk) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_blk) return;
+    d.pr_cur[g] = 0;  // becomes the fill cursor
+    int i2 = (int)((sqrt(8.0 * (double)g + 1.0) - 1.0) * 0.5);
+    while ((i2 + 1) * (i2 + 2) / 2 <= g) i2++;
+    while (i2 * (i2 + 1) / 2 > g) i2--;
+    const int i1 = g - i2 * (i2 + 1) / 2;
+    if (i1 == i2 || d.pr_off[g + 1] - d.pr_off[g] > kBaSmallBlockPairs) d.big_list[atomicAdd(d.big_n, 1)] = g;
+}
+
+size_t ba_pairs_scan_temp_bytes(int n_blk) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int*)nullptr, (int*)nullptr, n_blk + 1);
+    return bytes;
+}
+
+void launch_ba_build_pairs(const BaDev& d, void* scan_temp, size_t scan_temp_bytes, hipStream_t s) {
+    const int nf = d.n_free, n_blk = nf * (nf + 1) / 2;
+    if (n_blk <= 0 || d.n_points <= 0) return;
+    (void)hipMemsetAsync(d.pr_cur, 0, sizeof(int) * ((size_t)n_blk + 1), s);
+    (void)hipMemsetAsync(d.big_n, 0, sizeof(int), s);
+    const dim3 grid((d.n_points + 255) / 256);
+    hipLaunchKernelGGL(ba_pairs_kernel<false>, grid, dim3(256), 0, s, d);
+    (void)hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_temp_bytes, d.pr_cur, d.pr_off, n_blk + 1, s);
+    hipLaunchKernelGGL(ba_pairs_classify_kernel, dim3((n_blk + 255) / 256), dim3(256), 0, s, d, n_blk);
+    hipLaunchKernelGGL(ba_pairs_kernel<true>, grid, dim3(256), 0, s, d);
 }
 
 __global__ __launch_bounds__(256) void ba_finish_kernel(BaDev d, double chi2_threshold, BaPose* __restrict__ pose_out,
@@ -463,12 +525,23 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d) {
 //         diagonal).  Each lane accumulates a full 6x6 partial, then a fixed xor-butterfly sums the lanes:
 //         S(i1,i2) = [i1 == i2] (Hpp + lambda I) - sum over shared landmarks BDinv_{e1} W_{e2}^T ; mirrored.
 //         extra waves: b_schur(i) = bp(i) - sum over the pose's edges W_e db_{landmark(e)}
-__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d) {
+// With pair lists (large maps) only the blocks of big_list are walked here (list_cap = launch bound of the list,
+// *big_n of its entries are real); the others belong to ba_schur_gather_small_kernel.
+__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_cap) {
     if (!d.lm->active) return;
     const double lambda = d.lm->lambda;
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nf = d.n_free, n_blk = nf * (nf + 1) / 2;
+    int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nf = d.n_free;
+    int n_blk = nf * (nf + 1) / 2;
+    if (d.use_pairs) {
+        if (g < list_cap) {
+            if (g >= *d.big_n) return;
+            g = d.big_list[g];
+        } else {
+            g = n_blk + (g - list_cap);  // the right-hand-side waves follow the list
+        }
+    }
     if (g < n_blk) {
         // upper blocks column by column: (0,0) (0,1) (1,1) (0,2) (1,2) (2,2) ... - consecutive blocks share i2
         int i2 = (int)((sqrt(8.0 * (double)g + 1.0) - 1.0) * 0.5);
@@ -1017,11 +1090,76 @@ __global__ __launch_bounds__((UW + PW) * 64) void ba_solve_la_kernel(BaDev d) {
     if (tid == 0) d.partial[kBaSolveOk] = failed ? 0.0 : 1.0;
 }
 
+// One thread per upper block with at most kBaSmallBlockPairs pairs (the common case of a large map, including
+// "no landmark in common"): sorts its pairs by landmark, sums -BDinv W^T in that order, writes the block and its mirror.
+__global__ __launch_bounds__(256) void ba_schur_gather_small_kernel(BaDev d, int n_blk) {
+    if (!d.lm->active) return;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_blk) return;
+    const int o = d.pr_off[g], np = d.pr_off[g + 1] - o;
+    if (np > kBaSmallBlockPairs) return;
+    int i2 = (int)((sqrt(8.0 * (double)g + 1.0) - 1.0) * 0.5);
+    while ((i2 + 1) * (i2 + 2) / 2 <= g) i2++;
+    while (i2 * (i2 + 1) / 2 > g) i2--;
+    const int i1 = g - i2 * (i2 + 1) / 2;
+    if (i1 == i2) return;
+    int l[kBaSmallBlockPairs], k1[kBaSmallBlockPairs], k2[kBaSmallBlockPairs];
+#pragma unroll
+    for (int q = 0; q < kBaSmallBlockPairs; q++) {
+        const bool in = q < np;
+        l[q] = in ? d.pr_l[o + q] : 0x7fffffff;
+        k1[q] = in ? d.pr_k1[o + q] : -1;
+        k2[q] = in ? d.pr_k2[o + q] : -1;
+    }
+    // sorting network-free insertion sort on registers (kBaSmallBlockPairs is a compile-time bound)
+#pragma unroll
+    for (int a = 1; a < kBaSmallBlockPairs; a++)
+#pragma unroll
+        for (int b = a; b > 0; b--) {
+            const bool sw = l[b] < l[b - 1];
+            const int tl = sw ? l[b - 1] : l[b], t1 = sw ? k1[b - 1] : k1[b], t2 = sw ? k2[b - 1] : k2[b];
+            l[b - 1] = sw ? l[b] : l[b - 1]; k1[b - 1] = sw ? k1[b] : k1[b - 1]; k2[b - 1] = sw ? k2[b] : k2[b - 1];
+            l[b] = tl; k1[b] = t1; k2[b] = t2;
+        }
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+#pragma unroll
+    for (int q = 0; q < kBaSmallBlockPairs; q++) {
+        if (k1[q] < 0 || !(d.e_active[k1[q]] && d.e_active[k2[q]])) continue;
+        const double* B = d.BDinv + 18 * (size_t)k1[q];
+        const double* W = d.W + 18 * (size_t)k2[q];
+        double b[18], w[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) { b[k] = B[k]; w[k] = W[k]; }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                acc[r * 6 + c] += b[r * 3] * w[c * 3] + b[r * 3 + 1] * w[c * 3 + 1] + b[r * 3 + 2] * w[c * 3 + 2];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const double out = -acc[r * 6 + c];
+            d.S[(size_t)(6 * i1 + r) * d.ldS + 6 * i2 + c] = out;
+            d.S[(size_t)(6 * i2 + c) * d.ldS + 6 * i1 + r] = out;
+        }
+}
+
 static void launch_ba_schur(const BaDev& d, hipStream_t s) {
     const int nthreads = d.n_points > d.n_edges ? d.n_points : d.n_edges;
     if (nthreads > 0) hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d);
-    const int waves = d.n_free * (d.n_free + 1) / 2 + d.n_free;
-    if (waves > 0) hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d);
+    const int n_blk = d.n_free * (d.n_free + 1) / 2;
+    if (d.use_pairs) {
+        if (n_blk > 0) hipLaunchKernelGGL(ba_schur_gather_small_kernel, dim3((n_blk + 255) / 256), dim3(256), 0, s, d, n_blk);
+        const int waves = d.big_cap + d.n_free;  // the walked blocks, then the right-hand-side waves
+        hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d, d.big_cap);
+        return;
+    }
+    const int waves = n_blk + d.n_free;
+    if (waves > 0) hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d, 0);
 }
 
 static void launch_ba_solve(const BaDev& d, hipStream_t s) {
