@@ -486,7 +486,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         scan_bytes = ba_pairs_scan_temp_bytes((int)n_blk);
         if ((rc = b->d_pr_off.ensure(sizeof(int) * (n_blk + 1)))) return rc;
         if ((rc = b->d_pr_cur.ensure(sizeof(int) * (n_blk + 1)))) return rc;
-        if ((rc = b->d_pr.ensure(sizeof(int) * 3 * std::max<size_t>(pair_cap, 1)))) return rc;
+        if ((rc = b->d_pr.ensure(sizeof(int) * 6 * std::max<size_t>(pair_cap, 1)))) return rc;
         if ((rc = b->d_big.ensure(sizeof(int) * (big_cap + 1)))) return rc;
         if ((rc = b->d_scan_tmp.ensure(std::max<size_t>(scan_bytes, 16)))) return rc;
     }
@@ -549,6 +549,9 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.pr_l = b->d_pr.as<int>();
     d.pr_k1 = d.pr_l + std::max<size_t>(pair_cap, 1);
     d.pr_k2 = d.pr_k1 + std::max<size_t>(pair_cap, 1);
+    d.ps_l = d.pr_k2 + std::max<size_t>(pair_cap, 1);
+    d.ps_k1 = d.ps_l + std::max<size_t>(pair_cap, 1);
+    d.ps_k2 = d.ps_k1 + std::max<size_t>(pair_cap, 1);
     d.big_list = b->d_big.as<int>();
     d.big_n = d.big_list ? d.big_list + big_cap : nullptr;
     d.big_cap = (int)big_cap;

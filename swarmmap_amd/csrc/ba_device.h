@@ -73,7 +73,8 @@ struct BaDev {
     int use_pairs;
     int* pr_off;              // n_blk + 1: exclusive scan of the pair counts (block g = i2 (i2 + 1) / 2 + i1)
     int* pr_cur;              // n_blk: counts, then fill cursors
-    int* pr_l; int* pr_k1; int* pr_k2;  // landmark, edge of i1, edge of i2
+    int* pr_l; int* pr_k1; int* pr_k2;  // landmark, edge of i1, edge of i2 (arrival order)
+    int* ps_l; int* ps_k1; int* ps_k2;  // the same, every block sorted by landmark: what the gathers read
     int* big_list; int* big_n;          // blocks left to the wave-per-block walk: the diagonal and the crowded ones
     int big_cap;                        // capacity of big_list = launch bound of the walk
     // system

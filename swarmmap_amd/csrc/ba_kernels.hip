@@ -267,6 +267,33 @@ __global__ __launch_bounds__(256) void ba_pairs_classify_kernel(BaDev d, int n_b
     if (i1 == i2 || d.pr_off[g + 1] - d.pr_off[g] > kBaSmallBlockPairs) d.big_list[atomicAdd(d.big_n, 1)] = g;
 }
 
+// Once per problem: every block's list sorted by landmark (out of place, rank by counting: the landmark of a pair is
+// unique inside a block), one wave per block.  After this the per-trial kernels read the lists in a fixed order.
+constexpr int kPairSortMax = 4096;  // pairs of one block held in LDS while it is sorted
+
+__global__ __launch_bounds__(64) void ba_pairs_sort_kernel(BaDev d, int n_blk, int* __restrict__ out_l,
+                                                           int* __restrict__ out_k1, int* __restrict__ out_k2) {
+    __shared__ int s_l[kPairSortMax];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= n_blk) return;
+    const int o = d.pr_off[g], np = d.pr_off[g + 1] - o;
+    if (np <= 0) return;
+    if (np > kPairSortMax) {  // cannot happen below ~4096 shared landmarks; keep the arrival order (still a valid list)
+        for (int i = lane; i < np; i += 64) { out_l[o + i] = d.pr_l[o + i]; out_k1[o + i] = d.pr_k1[o + i]; out_k2[o + i] = d.pr_k2[o + i]; }
+        return;
+    }
+    for (int i = lane; i < np; i += 64) s_l[i] = d.pr_l[o + i];
+    __syncthreads();
+    for (int i = lane; i < np; i += 64) {
+        const int li = s_l[i];
+        int rank = 0;
+        for (int j = 0; j < np; j++) rank += s_l[j] < li;
+        out_l[o + rank] = li;
+        out_k1[o + rank] = d.pr_k1[o + i];
+        out_k2[o + rank] = d.pr_k2[o + i];
+    }
+}
+
 size_t ba_pairs_scan_temp_bytes(int n_blk) {
     size_t bytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int*)nullptr, (int*)nullptr, n_blk + 1);
@@ -283,6 +310,7 @@ void launch_ba_build_pairs(const BaDev& d, void* scan_temp, size_t scan_temp_byt
     (void)hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_temp_bytes, d.pr_cur, d.pr_off, n_blk + 1, s);
     hipLaunchKernelGGL(ba_pairs_classify_kernel, dim3((n_blk + 255) / 256), dim3(256), 0, s, d, n_blk);
     hipLaunchKernelGGL(ba_pairs_kernel<true>, grid, dim3(256), 0, s, d);
+    hipLaunchKernelGGL(ba_pairs_sort_kernel, dim3(n_blk), dim3(64), 0, s, d, n_blk, d.ps_l, d.ps_k1, d.ps_k2);
 }
 
 __global__ __launch_bounds__(256) void ba_finish_kernel(BaDev d, double chi2_threshold, BaPose* __restrict__ pose_out,
@@ -551,10 +579,12 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
-        for (int p = d.pose_off[i1] + lane; p < d.pose_off[i1 + 1]; p += 64) {
-            const int k1 = d.pose_edges[p];
+        const bool from_list = d.use_pairs && i1 != i2;  // large maps: the block's own (landmark-sorted) pair list
+        const int p_lo = from_list ? d.pr_off[g] : d.pose_off[i1], p_hi = from_list ? d.pr_off[g + 1] : d.pose_off[i1 + 1];
+        for (int p = p_lo + lane; p < p_hi; p += 64) {
+            const int k1 = from_list ? d.ps_k1[p] : d.pose_edges[p];
             if (!d.e_active[k1]) continue;  // dropped between the stages
-            const int k2 = (i1 == i2) ? k1 : d.edge_tab[(size_t)i2 * d.n_points + d.e_point[k1]];
+            const int k2 = from_list ? d.ps_k2[p] : (i1 == i2) ? k1 : d.edge_tab[(size_t)i2 * d.n_points + d.e_point[k1]];
             if (k2 < 0 || !d.e_active[k2]) continue;
             const double* B = d.BDinv + 18 * (size_t)k1;
             const double* W = d.W + 18 * (size_t)k2;
@@ -1091,7 +1121,7 @@ __global__ __launch_bounds__((UW + PW) * 64) void ba_solve_la_kernel(BaDev d) {
 }
 
 // One thread per upper block with at most kBaSmallBlockPairs pairs (the common case of a large map, including
-// "no landmark in common"): sorts its pairs by landmark, sums -BDinv W^T in that order, writes the block and its mirror.
+// "no landmark in common"): sums -BDinv W^T over its (landmark-sorted) pairs, writes the block and its mirror.
 __global__ __launch_bounds__(256) void ba_schur_gather_small_kernel(BaDev d, int n_blk) {
     if (!d.lm->active) return;
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -1103,24 +1133,13 @@ __global__ __launch_bounds__(256) void ba_schur_gather_small_kernel(BaDev d, int
     while (i2 * (i2 + 1) / 2 > g) i2--;
     const int i1 = g - i2 * (i2 + 1) / 2;
     if (i1 == i2) return;
-    int l[kBaSmallBlockPairs], k1[kBaSmallBlockPairs], k2[kBaSmallBlockPairs];
+    int k1[kBaSmallBlockPairs], k2[kBaSmallBlockPairs];  // the list is sorted by landmark (ba_pairs_sort_kernel)
 #pragma unroll
     for (int q = 0; q < kBaSmallBlockPairs; q++) {
         const bool in = q < np;
-        l[q] = in ? d.pr_l[o + q] : 0x7fffffff;
-        k1[q] = in ? d.pr_k1[o + q] : -1;
-        k2[q] = in ? d.pr_k2[o + q] : -1;
+        k1[q] = in ? d.ps_k1[o + q] : -1;
+        k2[q] = in ? d.ps_k2[o + q] : -1;
     }
-    // sorting network-free insertion sort on registers (kBaSmallBlockPairs is a compile-time bound)
-#pragma unroll
-    for (int a = 1; a < kBaSmallBlockPairs; a++)
-#pragma unroll
-        for (int b = a; b > 0; b--) {
-            const bool sw = l[b] < l[b - 1];
-            const int tl = sw ? l[b - 1] : l[b], t1 = sw ? k1[b - 1] : k1[b], t2 = sw ? k2[b - 1] : k2[b];
-            l[b - 1] = sw ? l[b] : l[b - 1]; k1[b - 1] = sw ? k1[b] : k1[b - 1]; k2[b - 1] = sw ? k2[b] : k2[b - 1];
-            l[b] = tl; k1[b] = t1; k2[b] = t2;
-        }
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
