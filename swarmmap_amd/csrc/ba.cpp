@@ -1,11 +1,14 @@
 // ba.cpp — host driver + C ABI of the bundle-adjustment solver (include/swarmorb.h).
 //
 // Replaces Optimizer::LocalBundleAdjustment / BundleAdjustment (code/src/Optimizer.cc:42-237,436-740) from
-// "build g2o graph" to "recover optimized data", on a flattened problem.  The Levenberg-Marquardt control
-// flow (code/Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-164, sparse_optimizer.cpp:354-419)
-// runs on the host and reads back three scalars per trial (chi2, scale, solve-ok); all arithmetic on residuals,
-// Jacobians, the Schur complement, the reduced solve and the manifold updates runs in the kernels of
-// ba_kernels.hip.  Estimates live in a current/trial buffer pair, so g2o's push/pop/discardTop is a pointer swap.
+// "build g2o graph" to "recover optimized data", and Optimizer::PoseOptimization (:239-434), on flattened problems.
+// The host sorts the edges by landmark, stages the problem as one pinned block (one copy in, one result block out)
+// and enqueues; the Levenberg-Marquardt control flow (code/Thirdparty/g2o/g2o/core/
+// optimization_algorithm_levenberg.cpp:61-164, sparse_optimizer.cpp:354-419) runs ON THE DEVICE (BaLm state +
+// ba_trial_decide_kernel): one host wait per optimize() call, three per local window.  Estimates live in a
+// current/trial buffer pair, so g2o's push/pop/discardTop is an index flip.  Windows up to 43 free keyframes use
+// the single-workgroup solvers of ba_kernels.hip, larger maps the blocked solver of ba_dense.hip with pair-list
+// Schur gathers.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

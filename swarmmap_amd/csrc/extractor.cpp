@@ -1,10 +1,13 @@
 // extractor.cpp — host driver + C ABI of the ORB extractor (include/swarmorb.h).
 //
 // Replaces ORB_SLAM2::ORBextractor (code/src/ORBextractor.cc:340-855).  Per frame, on ONE HIP stream:
-//   upload -> 7 resize launches -> FAST score+NMS (all levels, 1 launch) -> low-threshold pass (1 launch)
-//   -> compaction straight into host-mapped memory (1 launch) -> [sync #1]
-//   -> host quadtree per level -> H2D of the survivors -> fused angle+blur+BRIEF (1 launch) -> D2H -> [sync #2]
-// i.e. 2 host syncs per frame instead of the reference's 25.
+//   image copy -> [7 resize launches -> FAST score+NMS (all levels, 1 launch) -> low-threshold pass -> compaction
+//   -> DistributeOctTree (1 launch, a workgroup per level) -> fused angle+blur+BRIEF writing keypoints and
+//   descriptors straight into host-mapped memory] -> ONE host sync (the reference has 25).
+// The bracketed chain is captured once as a hipGraph and replayed with one launch per frame; so_extractor_submit /
+// _collect split the frame around the sync so that it runs under the caller's other work.  Level quotas above
+// 1020 keypoints (or more than four root cells) take the reference's own placement of DistributeOctTree - on
+// the host, between two syncs (quadtree.cpp) - with identical output.
 #include <hip/hip_runtime.h>
 
 #include <chrono>

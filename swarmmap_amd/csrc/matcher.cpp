@@ -1,8 +1,9 @@
 // matcher.cpp — host driver + C ABI of the Hamming matcher (include/swarmorb.h).
 //
 // Replaces the tracking-thread routines of ORB_SLAM2::ORBmatcher (code/src/ORBmatcher.cc).  Per call:
-//   flatten the frame into grid-traversal order -> H2D -> ONE top-K launch for all queries -> D2H -> the
-//   reference's order-dependent resolve on the host.  When a query's K-list is exhausted by keypoints that
+//   flatten the frame into grid-traversal order and the queries into ONE pinned staging block -> one H2D copy ->
+//   ONE top-K launch for all queries, K-lists written straight into host-mapped memory -> the reference's
+//   order-dependent resolve on the host.  When a query's K-list is exhausted by keypoints that
 //   earlier queries took (possible only if more than K candidates were in its window) that single query is
 //   re-evaluated on the GPU with the current "taken" gate, so distances never come from the CPU.
 #include <hip/hip_runtime.h>
