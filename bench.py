@@ -185,6 +185,7 @@ class Replay:
         lib.so_replay_add_pose_case.argtypes = [vp, vp, vp, i32, vp, vp, vp]
         lib.so_replay_set_window.argtypes = [vp, vp]
         lib.so_replay_set_profiling.argtypes = [vp, i32]
+        lib.so_replay_preallocate.argtypes = [vp]
         lib.so_replay_prime.argtypes = [vp, i32]
         lib.so_replay_run.argtypes = [vp, i32, i32, i32]
         lib.so_replay_drain.argtypes = [vp]
@@ -228,6 +229,9 @@ class Replay:
         st, keep = problem_struct(prob)
         self._keep.append(keep)
         self._check(self.lib.so_replay_set_window(self.h, self.C.byref(st)), "set_window")
+
+    def preallocate(self):
+        self._check(self.lib.so_replay_preallocate(self.h), "preallocate")
 
     def set_profiling(self, on):
         self.lib.so_replay_set_profiling(self.h, int(on))
@@ -436,6 +440,7 @@ def main():
                     for c in group:
                         rp.add_pose_case(c)
                 rp.set_window(lba_window)
+                rp.preallocate()  # device buffers sized once, before any step is counted
 
                 def run_span(first, n, timed):
                     t_ = first

@@ -261,6 +261,27 @@ int so_replay_set_window(so_replay* r, const so_ba_problem* p) {
     return SO_OK;
 }
 
+// Resource allocation before any step is counted: one window through the local-mapping handle and one pose problem
+// through the tracking handle size their device buffers (what a process does once at start-up, not per frame).
+int so_replay_preallocate(so_replay* r) {
+    if (!r || r->window.epose.empty() || r->poses.empty()) return SO_ERR_INVALID_ARG;
+    {
+        std::unique_lock<std::mutex> lk(r->mu);
+        r->queue.push_back(0);
+    }
+    r->cv.notify_all();
+    const PoseCase& c = r->poses[0];
+    std::vector<uint8_t> outl(c.w.size());
+    float Tout[12];
+    int32_t inl = 0;
+    if (so_pose_optimization(r->tracker_opt, c.Tcw, c.K, (int)c.w.size(), c.Xw.data(), c.obs.data(), c.w.data(), Tout,
+                             outl.data(), &inl, nullptr) != SO_OK)
+        return fail(r, "so_pose_optimization");
+    std::unique_lock<std::mutex> lk(r->mu);
+    r->cv.wait(lk, [r] { return r->queue.empty() && !r->running; });
+    return r->error.empty() ? SO_OK : SO_ERR_HIP;
+}
+
 int so_replay_set_profiling(so_replay* r, int enabled) { return r ? so_extractor_set_profiling(r->ex, enabled) : SO_ERR_INVALID_ARG; }
 
 // Runs frames [first_t, first_t + n_steps).  Frame first_t must be in flight (so_replay_prime) - the loop collects
