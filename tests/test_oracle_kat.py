@@ -212,3 +212,27 @@ def test_extract_end_to_end_shape(oracle):
     # deterministic
     kps2, desc2 = oracle.extract(cfg, img)
     assert kps.tobytes() == kps2.tobytes() and np.array_equal(desc, desc2)
+
+
+def test_oracle_regression_pins():
+    """tests/golden/oracle_pins.json (tools/make_oracle_pins.py): the oracle's outputs on seeded inputs have not moved."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_oracle_pins", os.path.join(root, "tools", "make_oracle_pins.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(root, "tests", "golden", "oracle_pins.json")))
+    got = mod.compute()
+    def same(a, b):
+        if isinstance(a, dict):
+            return a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, list):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        if isinstance(a, float):
+            return abs(a - b) <= 1e-6 * max(1.0, abs(a))  # libm may differ in the last bits between hosts
+        return a == b
+
+    for k in want:
+        assert same(got[k], want[k]), (k, got[k], want[k])
