@@ -156,7 +156,7 @@ def cpu_baseline(host_frames, workload_seed, stream, size, nfeatures, lba_window
     lm.close()
     return {"value": n / dt, "unit": "frames/s", "cores": 2, "kind": "port",
             "sample": "%d frames %dx%d: CPU oracle extract (nFeatures %d) + M2 + M1 + 3 PoseOptimization per frame on the tracking thread, "
-                      "%d LBA-M windows (1 per %d frames) on a local-mapping thread; gcc -O2; host has %d cores"
+                      "%d LBA-M windows (1 per %d frames) on a local-mapping thread; gcc -O3; host has %d cores"
                       % (n, size[0], size[1], nfeatures, n_lba, LBA_EVERY, os.cpu_count())}
 
 
