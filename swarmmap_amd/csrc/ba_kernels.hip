@@ -1728,40 +1728,37 @@ __device__ void se3_exp_mul_small(const double* u, const BaPose& in, BaPose& out
     out.pad = 0;
 }
 
-// 6x6 SPD solve (H + lambda I) x = b by Cholesky with reciprocal square roots; also computeScale
+// 6x6 SPD solve (H + lambda I) x = b by Cholesky with reciprocal square roots; also computeScale.  Right-looking
+// with the right-hand side carried as a seventh row: after column j only one reciprocal square root, one scale and
+// one update lie on the dependent chain (about 9 operations per column instead of 2 j + 8), and the forward
+// substitution has happened by the time the factor is complete.
 __device__ void po_solve6(const double* H, const double* b, double lambda, double* x, double& scale, int& ok) {
-    double A[36], ri[6];
+    double A[42], ri[6];  // rows 0-5: the matrix (lower part used), row 6: the right-hand side
 #pragma unroll
     for (int q = 0; q < 36; q++) A[q] = H[q];
 #pragma unroll
-    for (int j = 0; j < 6; j++) A[7 * j] += lambda;
+    for (int j = 0; j < 6; j++) {
+        A[7 * j] += lambda;
+        A[36 + j] = b[j];
+    }
     ok = 1;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        double dj = A[j * 6 + j];
-#pragma unroll
-        for (int k = 0; k < j; k++) dj = fma(-A[j * 6 + k], A[j * 6 + k], dj);
+        const double dj = A[j * 6 + j];
         if (!(dj > 0.0)) ok = 0;
         const double y = rsqrt_newton(dj);
         ri[j] = y;
 #pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-            double v = A[i * 6 + j];
+        for (int i = j + 1; i < 7; i++) A[i * 6 + j] *= y;
 #pragma unroll
-            for (int k = 0; k < j; k++) v = fma(-A[i * 6 + k], A[j * 6 + k], v);
-            A[i * 6 + j] = v * y;
-        }
+        for (int i = j + 1; i < 7; i++)
+#pragma unroll
+            for (int c = j + 1; c < 6; c++)
+                if (c <= i) A[i * 6 + c] = fma(-A[i * 6 + j], A[c * 6 + j], A[i * 6 + c]);
     }
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        double v = b[i];
-#pragma unroll
-        for (int k = 0; k < i; k++) v = fma(-A[i * 6 + k], x[k], v);
-        x[i] = v * ri[i];
-    }
-#pragma unroll
-    for (int i = 5; i >= 0; i--) {
-        double v = x[i];
+    for (int i = 5; i >= 0; i--) {  // L^T x = y, y = row 6
+        double v = A[36 + i];
 #pragma unroll
         for (int k = i + 1; k < 6; k++) v = fma(-A[k * 6 + i], x[k], v);
         x[i] = v * ri[i];
