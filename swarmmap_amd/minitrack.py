@@ -1,0 +1,233 @@
+"""A minimal monocular tracking replay over the hot path: extract -> frame post-processing -> SearchByProjection
+(last frame) -> PoseOptimization -> isInFrustum -> SearchByProjection (local map) -> PoseOptimization.
+
+It is NOT the reference's Tracking state machine (out of scope): it is the shortest host loop that
+chains every per-frame operator the way Tracking::TrackWithMotionModel (code/src/Tracking.cc:984-1050) and
+Tracking::TrackLocalMap (:1052-1100) do, so that a *trajectory* can be produced from images alone and compared
+between two implementations of the operators ("ATE").  The scene is the synthetic stream of
+`synth.FrameStream`: a textured plane at depth `plane_z` seen by a camera translating parallel to it, so map points
+are created by back-projecting keypoints onto the known plane (as an RGB-D front-end would) and ground truth is
+known in closed form.
+
+The operators come from a backend object; `HipBackend` binds the product (C ABI).  tests/ bind the CPU oracle to
+the same interface and compare trajectories.
+"""
+import numpy as np
+
+from .matcher import FrameView
+
+TH_LAST_FRAME = 15.0      # Tracking.cc:1014 (monocular)
+MIN_MATCHES_MOTION = 20   # Tracking.cc:1020
+COS_LIMIT = 0.5           # Tracking.cc:1133 isInFrustum(pMP, 0.5)
+
+
+class HipBackend:
+    """The product's operators (C ABI through the ctypes mirrors)."""
+
+    name = "hip"
+
+    def __init__(self, K, nfeatures=1000, device=0):
+        from .extractor import ORBextractor
+        from .frame import FramePostProcessor
+        from .matcher import ORBmatcher
+        from .optimizer import Optimizer
+        self.ex = ORBextractor(nfeatures, 1.2, 8, 20, 7, device=device)
+        self.fp = FramePostProcessor(K, device=device)
+        self.m_last = ORBmatcher(0.9, True, device=device)    # Tracking.cc:998
+        self.m_map = ORBmatcher(0.8, True, device=device)     # Tracking.cc:1153
+        self.opt = Optimizer(device=device)
+
+    def tables(self):
+        return (self.ex.GetScaleFactors(), self.ex.GetInverseScaleSigmaSquares())
+
+    def extract(self, img):
+        return self.ex(img)
+
+    def prepare(self, xy, w, h):
+        r = self.fp.prepare(xy, w, h, grid=False)
+        return r["xy_un"], r["bounds"]
+
+    def search_last(self, F, last, th):
+        return self.m_last.SearchByProjectionLastFrame(F, last, th)
+
+    def frustum(self, bounds, Tcw, Xw, normal, max_d, min_d, log_sf, nlevels):
+        return self.fp.is_in_frustum(Tcw, Xw, normal, max_d, min_d, COS_LIMIT, log_sf, nlevels, bounds=bounds)
+
+    def search_map(self, F, mps, th):
+        return self.m_map.SearchByProjectionMapPoints(F, mps, th)
+
+    def pose(self, Tcw, intr, Xw, obs, w):
+        n, T, outl, _ = self.opt.PoseOptimization(Tcw, intr, Xw, obs, w)
+        return n, T, outl
+
+    def close(self):
+        for o in (self.ex, self.fp, self.m_last, self.m_map, self.opt):
+            o.close()
+
+
+def _T44(T12):
+    T = np.eye(4)
+    T[:3, :4] = np.asarray(T12, np.float64).reshape(3, 4)
+    return T
+
+
+def ground_truth(stream, n_frames, K, plane_z):
+    """Camera centres of `synth.FrameStream` frames 0..n-1 in the frame-0 camera's coordinates."""
+    fx, fy = float(K[0]), float(K[1])
+    m = stream.margin
+    o = np.array([[int(round(m + (m - 1) * np.sin(0.013 * t))), int(round(m + (m - 1) * np.sin(0.021 * t + 0.5)))]
+                  for t in range(n_frames)], np.float64)
+    c = np.zeros((n_frames, 3))
+    c[:, 0] = (o[:, 0] - o[0, 0]) * plane_z / fx
+    c[:, 1] = (o[:, 1] - o[0, 1]) * plane_z / fy
+    return c
+
+
+def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_ratio=0.7):
+    """Returns dict(centres (n,3), poses (n,12), matches_last, matches_map, inliers, n_map_points)."""
+    intr = np.asarray(K, np.float32)
+    fx, fy, cx, cy = [float(v) for v in intr]
+    sf, inv_sigma2 = backend.tables()
+    sf = np.asarray(sf, np.float32)
+    inv_sigma2 = np.asarray(inv_sigma2, np.float32)
+    nlevels = len(sf)
+    log_sf = float(np.log(np.float32(1.2)))
+    w, h = stream.w, stream.h
+
+    # the map: world position, descriptor, reference normal and scale-invariance distances (MapPoint.cc:395-433)
+    mp_X = np.zeros((0, 3), np.float32)
+    mp_desc = np.zeros((0, 32), np.uint8)
+    mp_normal = np.zeros((0, 3), np.float32)
+    mp_max = np.zeros(0, np.float32)
+    mp_min = np.zeros(0, np.float32)
+
+    def add_points(T, xy_un, kps, desc, sel):
+        nonlocal mp_X, mp_desc, mp_normal, mp_max, mp_min
+        R, t = T[:3, :3], T[:3, 3]
+        rays = np.stack([(xy_un[sel, 0] - cx) / fx, (xy_un[sel, 1] - cy) / fy, np.ones(sel.sum())], 1)
+        Ow = -R.T @ t
+        dirs = rays @ R                                    # R^T r per row
+        d = (plane_z - Ow[2]) / dirs[:, 2]
+        X = Ow[None, :] + dirs * d[:, None]
+        PO = X - Ow[None, :]
+        dist = np.linalg.norm(PO, axis=1)
+        mx = dist * sf[kps["octave"][sel]]
+        first = len(mp_X)
+        mp_X = np.concatenate([mp_X, X.astype(np.float32)])
+        mp_desc = np.concatenate([mp_desc, desc[sel]])
+        mp_normal = np.concatenate([mp_normal, (PO / dist[:, None]).astype(np.float32)])
+        mp_max = np.concatenate([mp_max, (1.2 * mx).astype(np.float32)])                    # GetMaxDistanceInvariance
+        mp_min = np.concatenate([mp_min, (0.8 * mx / sf[nlevels - 1]).astype(np.float32)])  # GetMinDistanceInvariance
+        return first
+
+    poses, centres = [], []
+    log = dict(matches_last=[], matches_map=[], inliers=[], n_map_points=[])
+    T_last = np.eye(4)
+    velocity = np.eye(4)
+    last = None           # (xy_un, kps, desc, kp_mp, outlier)
+    kf_inliers = 0
+
+    for t in range(n_frames):
+        img = stream.frame(t)
+        kps, desc = backend.extract(img)
+        xy = np.stack([kps["x"], kps["y"]], 1).astype(np.float32)
+        xy_un, bounds = backend.prepare(xy, w, h)
+        n = len(kps)
+        kp_mp = np.full(n, -1, np.int64)
+        if t == 0:
+            T = np.eye(4)
+            first = add_points(T, xy_un, kps, desc, np.ones(n, bool))
+            kp_mp[:] = first + np.arange(n)
+            kf_inliers = n
+            outlier = np.zeros(n, bool)
+            log["matches_last"].append(0); log["matches_map"].append(0); log["inliers"].append(n)
+        else:
+            # ---- TrackWithMotionModel: project the last frame's map points with the predicted pose -------------
+            T_pred = (velocity @ T_last)
+            Tp = T_pred[:3, :4].astype(np.float32)
+            lx, lk, ld, lmp, lout = last
+            has = (lmp >= 0) & ~lout
+            Xl = mp_X[np.where(has, lmp, 0)]
+            Xc = Xl @ Tp[:, :3].T + Tp[:, 3]                     # float32, ORBmatcher.cc:1262-1270
+            with np.errstate(divide="ignore", invalid="ignore"):
+                invz = np.float32(1.0) / Xc[:, 2]
+                u = np.float32(fx) * Xc[:, 0] * invz + np.float32(cx)
+                v = np.float32(fy) * Xc[:, 1] * invz + np.float32(cy)
+            valid = has & (invz >= 0) & (u >= bounds[0]) & (u <= bounds[1]) & (v >= bounds[2]) & (v <= bounds[3])
+            u = np.where(valid, u, 0).astype(np.float32); v = np.where(valid, v, 0).astype(np.float32)
+            F = FrameView(xy_un[:, 0], xy_un[:, 1], kps["octave"], kps["angle"], desc, bounds, sf)
+            lastd = dict(valid=valid.astype(np.uint8), u=u, v=v, octave=lk["octave"], angle=lk["angle"],
+                         desc=mp_desc[np.where(has, lmp, 0)], has_obs=np.ones(len(lk), np.uint8))
+            nm, k2l = backend.search_last(F, lastd, TH_LAST_FRAME)
+            if nm < MIN_MATCHES_MOTION:
+                nm, k2l = backend.search_last(F, lastd, 2 * TH_LAST_FRAME)
+            bound = k2l >= 0
+            kp_mp[bound] = lmp[k2l[bound]]
+            log["matches_last"].append(int(nm))
+            idx = np.nonzero(kp_mp >= 0)[0]
+            _, T12, outl = backend.pose(Tp.reshape(12), intr, mp_X[kp_mp[idx]], xy_un[idx],
+                                        inv_sigma2[kps["octave"][idx]])
+            kp_mp[idx[outl.astype(bool)]] = -1              # Tracking.cc:1030-1046 (outliers dropped)
+            T_a = np.asarray(T12, np.float32).reshape(3, 4)
+
+            # ---- TrackLocalMap: SearchLocalPoints + PoseOptimization --------------------------------------------
+            fr = backend.frustum(bounds, T_a.reshape(12), mp_X, mp_normal, mp_max, mp_min, log_sf, nlevels)
+            in_view = fr["in_view"].copy()
+            in_view[kp_mp[kp_mp >= 0]] = 0                  # already matched: mbTrackInView = false (:1117-1124)
+            excluded = (kp_mp >= 0).astype(np.uint8)
+            F2 = FrameView(xy_un[:, 0], xy_un[:, 1], kps["octave"], kps["angle"], desc, bounds, sf, excluded=excluded)
+            mps = dict(in_view=in_view, proj_x=fr["proj_x"], proj_y=fr["proj_y"], view_cos=fr["view_cos"],
+                       pred_level=fr["pred_level"], desc=mp_desc, has_obs=np.ones(len(mp_X), np.uint8))
+            nm2, k2m = backend.search_map(F2, mps, 1.0)
+            newly = k2m >= 0
+            kp_mp[newly] = k2m[newly]
+            log["matches_map"].append(int(nm2))
+            idx = np.nonzero(kp_mp >= 0)[0]
+            n_in, T12, outl = backend.pose(T_a.reshape(12), intr, mp_X[kp_mp[idx]], xy_un[idx],
+                                           inv_sigma2[kps["octave"][idx]])
+            outlier = np.zeros(n, bool)
+            outlier[idx[outl.astype(bool)]] = True
+            T = _T44(np.asarray(T12, np.float32))
+            log["inliers"].append(int(n_in))
+
+            # ---- "keyframe": create map points for the unmatched keypoints --------------------------------------
+            if n_in < keyframe_ratio * kf_inliers or t % keyframe_every == 0:
+                fresh = kp_mp < 0
+                if fresh.any():
+                    first = add_points(T, xy_un, kps, desc, fresh)
+                    kp_mp[fresh] = first + np.arange(int(fresh.sum()))
+                kf_inliers = max(n_in, 1)
+            velocity = T @ np.linalg.inv(T_last)
+
+        poses.append(T[:3, :4].reshape(12).copy())
+        centres.append(-T[:3, :3].T @ T[:3, 3])
+        log["n_map_points"].append(len(mp_X))
+        last = (xy_un, kps, desc, kp_mp, outlier)
+        T_last = T
+    out = dict(centres=np.array(centres), poses=np.array(poses))
+    out.update({k: np.array(v) for k, v in log.items()})
+    return out
+
+
+def umeyama(src, dst, with_scale=False):
+    """Least-squares similarity (or rigid) transform dst ~ s R src + t (Umeyama 1991)."""
+    src = np.asarray(src, np.float64); dst = np.asarray(dst, np.float64)
+    ms, md = src.mean(0), dst.mean(0)
+    a, b = src - ms, dst - md
+    U, S, Vt = np.linalg.svd(b.T @ a / len(src))
+    D = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        D[2, 2] = -1
+    R = U @ D @ Vt
+    var = (a ** 2).sum() / len(src)
+    s = float((S * np.diag(D)).sum() / var) if with_scale and var > 0 else 1.0
+    return s, R, md - s * R @ ms
+
+
+def ate_rmse(est, ref, with_scale=False, align=True):
+    """Absolute trajectory error: RMSE of camera-centre distances after the optimal alignment."""
+    est = np.asarray(est, np.float64); ref = np.asarray(ref, np.float64)
+    if align:
+        s, R, t = umeyama(est, ref, with_scale)
+        est = s * est @ R.T + t
+    return float(np.sqrt(((est - ref) ** 2).sum(1).mean()))

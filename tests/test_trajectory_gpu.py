@@ -1,0 +1,38 @@
+"""Trajectory parity: the HIP operators and the CPU oracle, chained by the same host loop (swarmmap_amd.minitrack),
+must produce the same trajectory from the same images (ATE between the HIP path and the CPU path,
+and against the renderer's ground truth)."""
+import numpy as np
+import pytest
+
+from swarmmap_amd import minitrack, synth
+from trajectory_common import OracleBackend
+
+pytestmark = pytest.mark.gpu
+
+PLANE_Z = 2.0
+# One pixel is plane_z / fx = 4.4 mm (EuRoC) / 2.8 mm (KITTI).  The two paths may differ by PoseOptimization's
+# floating-point tolerance (2e-5 per call, tests/test_pose_gpu.py) which a later match decision can amplify;
+# the bound below is 1/40 of a pixel.
+ATE_HIP_VS_ORACLE = 1e-4
+
+
+@pytest.mark.parametrize("size,K,nfeat,n", [(synth.EUROC, synth.EUROC_K, 1000, 60), (synth.KITTI, synth.KITTI_K, 2000, 30)])
+def test_hip_and_oracle_trajectories_agree(size, K, nfeat, n):
+    st = synth.FrameStream(size=size)
+    hip = minitrack.HipBackend(K, nfeat)
+    a = minitrack.track(hip, st, n, K, plane_z=PLANE_Z)
+    hip.close()
+    b = minitrack.track(OracleBackend(K, nfeat), st, n, K, plane_z=PLANE_Z)
+    gt = minitrack.ground_truth(st, n, K, PLANE_Z)
+    ate = minitrack.ate_rmse(a["centres"], b["centres"], align=False)
+    assert ate < ATE_HIP_VS_ORACLE, ate
+    assert np.abs(a["poses"] - b["poses"]).max() < 5e-4
+    # same integer decisions along the way (extractor and matchers are bit-exact; allow the rare match that flips
+    # because the two pose estimates differ in the last bits)
+    for k in ("matches_last", "matches_map", "inliers"):
+        assert np.abs(a[k].astype(int) - b[k].astype(int)).max() <= 3, (k, a[k], b[k])
+    assert np.array_equal(a["n_map_points"], b["n_map_points"]) or \
+        np.abs(a["n_map_points"] - b["n_map_points"]).max() <= 3
+    px = PLANE_Z / float(K[0])
+    assert minitrack.ate_rmse(a["centres"], gt, align=False) < 0.75 * px
+    assert abs(minitrack.ate_rmse(a["centres"], gt) - minitrack.ate_rmse(b["centres"], gt)) < 0.01 * px
