@@ -31,7 +31,8 @@ from swarmmap_amd.matcher import FrameView  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_PEAK_TF = 78.6    # MI355X FP64 vector/matrix peak (AMD datasheet; not tabulated in the guide)
-LBA_EVERY = 5          # one LBA-M window per ~5 frames (SURVEY.md 8d end-to-end replay)
+# one LBA-M window per ~5 frames (SURVEY.md 8d end-to-end replay); the override is a diagnostic (no local mapping)
+LBA_EVERY = int(os.environ.get("SWARMORB_BENCH_LBA_EVERY", "5"))
 N_LOCAL_HISTORY = 4    # local map = keypoints of the previous 4 frames (~2000-4000 map points)
 
 

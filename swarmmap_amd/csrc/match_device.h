@@ -6,12 +6,15 @@
 //     octave  i8
 //     desc    2 x uint4 (32 B) per keypoint
 //     limit   i32 optional dynamic gate: candidate is eligible iff dist < limit (0 = taken, INT_MAX = free)
+//     cols    i32 x 65 first position of each grid column (window queries scan only their GetFeaturesInArea columns)
 //   queries: MatchQuery (24 B) + 32-B descriptor each; results: K u32 keys (dist << 16 | position) per query.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace so {
+
+constexpr int kMatchGridCols = 64, kMatchGridRows = 48;  // FRAME_GRID_COLS / ROWS, code/include/Frame.h:38-39
 
 struct MatchFrameDev {
     const float2* xy;
@@ -24,6 +27,10 @@ struct MatchFrameDev {
     float sigma2[8];      // mvLevelSigma2    (CheckDistEpipolarLine)
     float scale[8];       // mvScaleFactors   (epipole distance test)
     float ex, ey;
+    // the frame's 64 x 48 grid (Frame.cc:259-260): first candidate position of every cell column (65 entries) when
+    // the candidates are in grid-traversal order, else null (vocabulary-node order: queries carry explicit ranges)
+    const int32_t* col_start;
+    float min_x, min_y, grid_inv_w, grid_inv_h;
 };
 
 enum : uint32_t {
@@ -44,6 +51,7 @@ struct MatchQuery {
     int32_t pad;
 };
 
+void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_t s);
 void launch_topk_window(const MatchFrameDev& F, const MatchQuery* d_q, const uint4* d_qdesc, int nq, int K,
                         uint32_t* d_keys, int32_t* d_count, hipStream_t s);
 constexpr int kDistinctiveMaxObs = 512;

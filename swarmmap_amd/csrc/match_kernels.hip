@@ -1,16 +1,18 @@
 // match_kernels.hip — gfx950 Hamming matching kernels.
 //
 // Two kernels:
-//   topk_window_kernel  one wave per query: scan ALL candidate keypoints of the frame (brute force, coalesced SoA
-//                       reads; the 64x48 grid of the reference is only a CPU acceleration structure), apply the
-//                       exact GetFeaturesInArea predicate (code/src/Frame.cc:377-431) as a per-pair mask, compute
-//                       256-bit Hamming distances for the survivors, and return the K best in the order the
-//                       reference's sequential "dist < bestDist" scan induces: (distance, grid traversal rank).
+//   topk_window_kernel  one wave per query: scan the candidate keypoints in the grid columns GetFeaturesInArea
+//                       would visit (code/src/Frame.cc:377-431; candidates are stored column by column, so that is
+//                       one contiguous range, 64 candidates per step, coalesced SoA reads), apply its row / window /
+//                       level tests as a per-pair mask, compute 256-bit Hamming distances for the survivors, and
+//                       return the K best in the order the reference's sequential "dist < bestDist" scan induces:
+//                       (distance, grid traversal rank).
 //   hamming_top2_kernel one wave per query against every row of B (cross-agent keyframe search), best/second.
 //
 // Candidates are stored in grid-traversal order (cell x, cell y, keypoint index) by the host, so a candidate's
 // array position IS its tie-break rank and key = dist << 16 | position sorts exactly like the reference visits.
 #include "match_device.h"
+#include <algorithm>
 
 namespace so {
 
@@ -28,14 +30,45 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 
 constexpr int kListCap = 1024;  // per-wave LDS list of (dist<<16 | rank) keys
 
+// The cells GetFeaturesInArea visits for one query (Frame.cc:382-396, KeyFrame.cc:784-798): columns as a range of
+// candidate positions, rows as [cy0, cy1].
+struct CellWindow {
+    int lo, hi, cy0, cy1;
+};
+
+__device__ __forceinline__ CellWindow cell_window(const MatchFrameDev& F, const MatchQuery& Q) {
+    CellWindow w;
+    w.lo = 0; w.hi = F.n; w.cy0 = 0; w.cy1 = kMatchGridRows - 1;
+    if (Q.flags & kQRange) {
+        w.lo = Q.c_begin; w.hi = Q.c_end;
+    } else if (F.col_start) {
+        const int cx0 = max(0, (int)floorf((Q.u - F.min_x - Q.r) * F.grid_inv_w));
+        const int cx1 = min(kMatchGridCols - 1, (int)ceilf((Q.u - F.min_x + Q.r) * F.grid_inv_w));
+        w.cy0 = max(0, (int)floorf((Q.v - F.min_y - Q.r) * F.grid_inv_h));
+        w.cy1 = min(kMatchGridRows - 1, (int)ceilf((Q.v - F.min_y + Q.r) * F.grid_inv_h));
+        if (cx0 >= kMatchGridCols || cx1 < 0 || w.cy0 >= kMatchGridRows || w.cy1 < 0 || cx0 > cx1) {
+            w.lo = w.hi = 0;
+        } else {
+            w.lo = F.col_start[cx0];
+            w.hi = F.col_start[cx1 + 1];
+        }
+    }
+    return w;
+}
+
 // Geometric / structural predicate of one (query, candidate) pair — everything except the descriptor distance.
-__device__ __forceinline__ bool pair_pred(const MatchFrameDev& F, const MatchQuery& Q, int c, bool check_levels) {
+__device__ __forceinline__ bool pair_pred(const MatchFrameDev& F, const MatchQuery& Q, const CellWindow& W, int c,
+                                          bool check_levels) {
     const float2 xy = F.xy[c];
     const int o = F.octave[c];
     bool ok = true;
     if (!(Q.flags & kQRange)) {  // Frame::GetFeaturesInArea, code/src/Frame.cc:377-431
         const float dx = xy.x - Q.u, dy = xy.y - Q.v;
         ok = fabsf(dx) < Q.r && fabsf(dy) < Q.r;
+        if (F.col_start) {  // the candidate's cell row (Frame::PosInGrid, :433-443) must be one of the visited rows
+            const int py = (int)roundf((xy.y - F.min_y) * F.grid_inv_h);
+            if (py < W.cy0 || py > W.cy1) ok = false;
+        }
         if (check_levels) {
             if (o < Q.min_level) ok = false;
             if (Q.max_level >= 0 && o > Q.max_level) ok = false;
@@ -79,14 +112,14 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
     const uint4 qd0 = qdesc[2 * qi], qd1 = qdesc[2 * qi + 1];
     const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int lo = (Q.flags & kQRange) ? Q.c_begin : 0;
-    const int hi = (Q.flags & kQRange) ? Q.c_end : F.n;
+    const CellWindow W = cell_window(F, Q);
+    const int lo = W.lo, hi = W.hi;
     int m = 0;
     for (int base = lo; base < hi; base += 64) {
         const int c = base + lane;
         bool ok = c < hi;
         int dist = 0;
-        if (ok) ok = pair_pred(F, Q, c, check_levels);
+        if (ok) ok = pair_pred(F, Q, W, c, check_levels);
         if (ok) {
             dist = hamming256(F.desc[2 * c], F.desc[2 * c + 1], qd0, qd1);
             if (dist > Q.max_dist) ok = false;
@@ -124,7 +157,7 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
             uint32_t cur = 0xFFFFFFFFu;
             for (int base = lo; base < hi; base += 64) {
                 const int c = base + lane;
-                if (c < hi && pair_pred(F, Q, c, check_levels)) {
+                if (c < hi && pair_pred(F, Q, W, c, check_levels)) {
                     const int dist = hamming256(F.desc[2 * c], F.desc[2 * c + 1], qd0, qd1);
                     if (dist <= Q.max_dist && (!F.limit || dist < F.limit[c])) {
                         const uint32_t key = make_key(Q, dist, c);
@@ -141,6 +174,21 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
             }
         }
     }
+}
+
+// Copy the staged inputs from pinned host memory into HBM with a kernel on the matcher's own queue: a ~100 KB
+// SDMA copy costs a cross-engine dependency (~15 us) in front of a 19 us kernel.
+__global__ __launch_bounds__(256) void stage_in_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
+                                                       size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        dst[i] = src[i];
+}
+
+void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_t s) {
+    const size_t n16 = (bytes + 15) / 16;
+    if (!n16) return;
+    const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 128);
+    hipLaunchKernelGGL(stage_in_kernel, dim3(blocks), dim3(256), 0, s, (uint4*)dst, (const uint4*)src_mapped, n16);
 }
 
 void launch_topk_window(const MatchFrameDev& F, const MatchQuery* d_q, const uint4* d_qdesc, int nq, int K,

@@ -22,7 +22,7 @@ using namespace so;
 
 namespace {
 
-constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS/ROWS, code/include/Frame.h:37-38
+constexpr int kGridCols = so::kMatchGridCols, kGridRows = so::kMatchGridRows;
 constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // code/src/ORBmatcher.cc:37-39
 
 struct DevBuf {
@@ -123,7 +123,7 @@ struct so_matcher {
     PinBuf h_in;
     DevBuf d_in;
     MappedBuf h_out;
-    size_t off_oct = 0, off_desc = 0, off_limit = 0, frame_end = 0, off_q = 0, off_qdesc = 0;
+    size_t off_oct = 0, off_desc = 0, off_limit = 0, off_cols = 0, frame_end = 0, off_q = 0, off_qdesc = 0;
     size_t dirty_from = SIZE_MAX;  // staging bytes from here on are newer than the device copy
     View h_q, h_qdesc, h_keys, h_count;
     DevBuf d_A, d_B, d_res;
@@ -136,6 +136,8 @@ struct so_matcher {
     float inv_sigma2[8] = {0}, sigma2[8] = {0}, scale[8] = {0}, ex = 0.f, ey = 0.f;  // gates of the current candidates
     int n_cand = 0;           // keypoints that are inside the grid (PosInGrid true)
     bool has_limit = false;
+    bool has_cols = false;    // candidates are in grid-traversal order and the column table is staged
+    float min_x = 0.f, min_y = 0.f, grid_inv_w = 0.f, grid_inv_h = 0.f;
     std::vector<int> perm;     // rank -> keypoint index
     std::vector<int> rank_of;  // keypoint index -> rank (-1: not in grid)
     std::vector<int> cell_count;
@@ -167,7 +169,9 @@ int upload_ordered(so_matcher* m, int n, const float* x, const float* y, const i
     m->off_oct = align256(sizeof(float2) * (size_t)nc);
     m->off_desc = align256(m->off_oct + (size_t)nc);
     m->off_limit = align256(m->off_desc + (size_t)nc * 32);
-    m->frame_end = align256(m->off_limit + sizeof(int32_t) * (size_t)nc);
+    m->off_cols = align256(m->off_limit + sizeof(int32_t) * (size_t)nc);
+    m->frame_end = align256(m->off_cols + sizeof(int32_t) * (kGridCols + 1));
+    m->has_cols = false;
     if ((rc = m->h_in.ensure_keep(m->frame_end + 256, 0))) return rc;
     uint8_t* base = (uint8_t*)m->h_in.p;
     float2* hxy = (float2*)base;
@@ -215,7 +219,13 @@ int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_
         for (int i = 0; i < n; i++)
             if (cell[(size_t)i] >= 0) m->perm[(size_t)fill[(size_t)cell[(size_t)i]]++] = i;
     }
-    return upload_ordered(m, n, F->x, F->y, F->octave, F->desc, F->excluded, limit_by_idx);
+    const int rc = upload_ordered(m, n, F->x, F->y, F->octave, F->desc, F->excluded, limit_by_idx);
+    if (rc) return rc;
+    int32_t* cols = (int32_t*)((uint8_t*)m->h_in.p + m->off_cols);
+    for (int px = 0; px <= kGridCols; px++) cols[px] = cc[(size_t)px * kGridRows];
+    m->has_cols = true;
+    m->min_x = F->min_x; m->min_y = F->min_y; m->grid_inv_w = F->grid_inv_w; m->grid_inv_h = F->grid_inv_h;
+    return SO_OK;
 }
 
 inline void init_query(MatchQuery& q) {
@@ -247,6 +257,8 @@ MatchFrameDev frame_dev(const so_matcher* m) {
     }
     F.ex = m->ex;
     F.ey = m->ey;
+    F.col_start = m->has_cols ? (const int32_t*)(base + m->off_cols) : nullptr;
+    F.min_x = m->min_x; F.min_y = m->min_y; F.grid_inv_w = m->grid_inv_w; F.grid_inv_h = m->grid_inv_h;
     return F;
 }
 
@@ -264,8 +276,10 @@ int run_topk(so_matcher* m, int nq, int K) {
     hipStream_t s = m->stream;
     const auto t0 = std::chrono::steady_clock::now();
     const size_t from = std::min(m->dirty_from, m->off_q);
-    SO_HIP(hipMemcpyAsync((uint8_t*)m->d_in.p + from, (const uint8_t*)m->h_in.p + from, total - from,
-                          hipMemcpyHostToDevice, s));
+    {   // staged inputs go up with a copy kernel on this queue (an SDMA copy costs ~10 us more per call, match_kernels.hip)
+        const size_t f16 = from & ~(size_t)15;
+        launch_stage_in((uint8_t*)m->d_in.p + f16, (const uint8_t*)m->h_in.p + f16, total - f16, s);
+    }
     m->dirty_from = SIZE_MAX;
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
     launch_topk_window(frame_dev(m), (const MatchQuery*)((const uint8_t*)m->d_in.p + m->off_q),
@@ -318,11 +332,12 @@ int rerun_single(so_matcher* m, const MatchQuery& q, const uint8_t* qdesc, const
     hipStream_t s = m->stream;
     const auto t0 = std::chrono::steady_clock::now();
     // the limit gate sits at the end of the frame part of the staging block: send it (and whatever else is newer)
-    if (m->dirty_from < m->frame_end)
-        SO_HIP(hipMemcpyAsync((uint8_t*)m->d_in.p + m->dirty_from, (const uint8_t*)m->h_in.p + m->dirty_from,
-                              m->frame_end - m->dirty_from, hipMemcpyHostToDevice, s));
+    if (m->dirty_from < m->frame_end) {
+        const size_t f16 = m->dirty_from & ~(size_t)15;
+        launch_stage_in((uint8_t*)m->d_in.p + f16, (const uint8_t*)m->h_in.p + f16, m->frame_end - f16, s);
+    }
     m->dirty_from = SIZE_MAX;
-    SO_HIP(hipMemcpyAsync(m->d_rq.p, m->h_rq.p, kQ, hipMemcpyHostToDevice, s));
+    launch_stage_in(m->d_rq.p, m->h_rq.p, kQ, s);
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
     launch_topk_window(frame_dev(m), (const MatchQuery*)m->d_rq.p, (const uint4*)((const uint8_t*)m->d_rq.p + 128), 1, K,
                        (uint32_t*)m->h_rout.dev, (int32_t*)((uint8_t*)m->h_rout.dev + 256), s);
