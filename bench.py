@@ -522,10 +522,10 @@ def main():
         fast_ms = stage_ms["fast_score"] / steps
         alg_bytes = level_pixels(ex, w, h) + 8 * n_cand  # every level pixel read once + 8 B per candidate written
         achieved = alg_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
-        traffic = None  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (profiles/)
+        # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (profiles/, tools/profile_round.sh)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("fast_score_kernel", {}).get("hbm_bytes_per_launch")
+        pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        traffic = pmc.get("fast_score_kernel", {}).get("hbm_bytes_per_launch")
         roof_fast = {"bound": "hbm", "kernel": "fast_score_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fast_ms,
@@ -539,7 +539,8 @@ def main():
         solve_ms = acc["solve_ms"] / max(acc["n_solves"], 1)
         solve_tf = solve_flop / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0
         roof_solve = {"bound": "mfma", "kernel": "ba_solve_la_kernel" if n_red <= 180 else "ba_solve_reg_kernel", "achieved": solve_tf, "peak": FP64_PEAK_TF,
-                      "unit": "TFLOP/s", "frac": solve_tf / FP64_PEAK_TF, "traffic": None,
+                      "unit": "TFLOP/s", "frac": solve_tf / FP64_PEAK_TF,
+                      "traffic": pmc.get("ba_solve_la_kernel", {}).get("hbm_bytes_per_launch") if n_red <= 180 else None,
                       "algorithmic_flop_per_launch": solve_flop, "avg_launch_ms": solve_ms,
                       "total_ms_in_timed_region": acc["solve_ms"],
                       "note": "150x150 FP64 system per launch: latency-bound by construction (DESIGN.md 5); peak is "
@@ -551,7 +552,8 @@ def main():
         pose_ms = acc["pose_kernel_ms"] / max(acc["pose_calls"], 1)
         pose_tf = pose_flop / (pose_ms * 1e-3) / 1e12 if pose_ms > 0 else 0.0
         roof_pose = {"bound": "mfma", "kernel": "pose_opt_lds_kernel", "achieved": pose_tf, "peak": FP64_PEAK_TF,
-                     "unit": "TFLOP/s", "frac": pose_tf / FP64_PEAK_TF, "traffic": None,
+                     "unit": "TFLOP/s", "frac": pose_tf / FP64_PEAK_TF,
+                     "traffic": pmc.get("pose_opt_lds_kernel", {}).get("hbm_bytes_per_launch"),
                      "algorithmic_flop_per_launch": pose_flop, "avg_launch_ms": pose_ms,
                      "total_ms_in_timed_region": acc["pose_kernel_ms"],
                      "note": "one workgroup runs g2o's 4 x optimize(10) on one 6-dof vertex with %d unary edges: ~25 "

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the two per-counter summaries tools/profile_round.sh leaves
+(<tag>_pmc_FETCH_SIZE_summary.csv, <tag>_pmc_WRITE_SIZE_summary.csv).  FETCH_SIZE is doubled: on gfx950 the counter
+reads half the streamed bytes (calibrated with tools/pmc_calibrate.py: 2^30 bytes read 524300 KB,
+profiles/r1_pmc/cal_FETCH_SIZE_summary.csv); both counters are in KB.
+Usage: make_pmc_traffic.py <FETCH summary> <WRITE summary> <out.json>"""
+import csv
+import json
+import re
+import sys
+
+KEEP = ("fast_score_kernel", "fast_low_count_kernel", "describe_qt_kernel", "resize_kernel", "topk_window_kernel",
+        "stage_in_kernel", "pose_opt_lds_kernel", "ba_solve_la_kernel", "ba_schur_gather_kernel", "ba_build_kernel",
+        "quadtree_kernel")
+
+
+def load(path):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"so::(\w+)", r["kernel"])
+        if m and m.group(1) in KEEP:
+            out[m.group(1)] = (float(r["mean_per_dispatch"]), int(r["dispatches"]))
+    return out
+
+
+fetch, write = load(sys.argv[1]), load(sys.argv[2])
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (one counter per pass, no other trace domain) of "
+                 "`bench.py --steps 100 --warmup 10 --no-cpu-baseline` on MI355X (tools/profile_round.sh); "
+                 "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH_SIZE x2 per the calibration in "
+                 "profiles/r1_pmc/cal_FETCH_SIZE_summary.csv"}
+for k in KEEP:
+    if k in fetch and k in write:
+        f, w = fetch[k][0], write[k][0]
+        res[k] = {"fetch_kb_per_launch": round(f, 1), "write_kb_per_launch": round(w, 1),
+                  "hbm_bytes_per_launch": int((2 * f + w) * 1024), "dispatches": fetch[k][1]}
+json.dump(res, open(sys.argv[3], "w"), indent=1)
