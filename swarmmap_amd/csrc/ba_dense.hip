@@ -57,32 +57,63 @@ __global__ __launch_bounds__(256) void dense_pad_kernel(double* __restrict__ S, 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < pad; i += gridDim.x * 256) rhs[n + i] = 0.0;
 }
 
-// ---- diagonal block: Cholesky + inverse ----
+// ---- diagonal block: Cholesky + inverse, one workgroup, FP64 matrix cores for everything but the 16x16 pivots ----
+// The 96x96 block lives in LDS (row stride 98 doubles: the 16 rows x 2 k of an MFMA operand fetch hit 32 distinct
+// bank pairs).  Six steps of 16 columns:
+//   (1) wave 0 factors the 16x16 diagonal sub-block, a row per lane, pivots and multipliers by v_readlane (no LDS,
+//       no barrier), and inverts it (lane c solves column c of W = L_dd^-1 against the same registers);
+//   (2) the rows below become A_rd W^T - one 16x16x16 MFMA product per row tile instead of a substitution;
+//   (3) rank-16 update of the remaining lower triangle, one MFMA product per 16x16 tile.
+// Then the inverse of the whole factor, block column by block column (X_ij = -W_i sum_m L_im X_mj): a wave owns
+// a block column, so the recursion needs no barrier.
+constexpr int kPS = 98;
+
+__device__ __forceinline__ void potrf_wave_sync() {
+    // LDS operations of one wave execute in order; this only keeps the compiler from moving accesses across it
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// acc += Pa(16 x klen) * Pb(16 x klen)^T, both row-major in LDS with stride kPS
+__device__ __forceinline__ d4 potrf_mma_nt(const double* Pa, const double* Pb, int klen, d4 acc, int lane) {
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int kk = 0; kk < klen; kk += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[fr * kPS + kk + fk], Pb[fr * kPS + kk + fk], acc, 0, 0, 0);
+    return acc;
+}
+
+// acc += Pa(16 x 16) * Pb(16 x 16), Pb read transposed
+__device__ __forceinline__ d4 potrf_mma_nn(const double* Pa, const double* Pb, d4 acc, int lane) {
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[fr * kPS + kk + fk], Pb[(kk + fk) * kPS + fr], acc, 0, 0, 0);
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
-    __shared__ double A[kDNB][kDNB + 1];
-    __shared__ double X[kDNB][kDNB + 1];
-    __shared__ double s_rinv[kDNB];
+    __shared__ double A[kDNB][kPS];
+    __shared__ double X[kDNB][kPS];
     __shared__ int s_bad;
     if (!d.lm->active) return;
-    const int tid = threadIdx.x, ld = d.ldS;
+    const int tid = threadIdx.x, ld = d.ldS, lane = tid & 63, wave = tid >> 6;
+    const int crow = lane >> 4, ccol = lane & 15;  // MFMA result layout: element (crow + 4 reg, ccol)
     double* Sk = d.S + (size_t)k * kDNB * ld + (size_t)k * kDNB;
     if (tid == 0) s_bad = 0;
-    for (int i = tid; i < kDNB * kDNB; i += 256) {
-        const int r = i / kDNB, c = i - r * kDNB;
-        A[r][c] = Sk[(size_t)r * ld + c];
-        X[r][c] = 0.0;
+    for (int i = tid; i < kDNB * (kDNB / 2); i += 256) {
+        const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
+        const double2 v = *reinterpret_cast<const double2*>(Sk + (size_t)r * ld + c);
+        A[r][c] = v.x; A[r][c + 1] = v.y;
+        X[r][c] = 0.0; X[r][c + 1] = 0.0;
     }
     __syncthreads();
-    // Blocked inside the workgroup, 16 columns at a time: (1) the 16x16 diagonal sub-block on one wave, a row per
-    // lane, pivots and multipliers by v_readlane (no LDS, no barrier); (2) every row below solves against it on its
-    // own thread; (3) rank-16 update of what is left, 5x5 register patches per thread.  Three barriers per 16
-    // columns instead of three per column.
-    const int ty = tid >> 4, tx = tid & 15, lane = tid & 63, wave = tid >> 6;
-    for (int jb = 0; jb < kDNB; jb += 16) {
+    constexpr int NT = kDNB / 16;
+    for (int jb = 0; jb < NT; jb++) {
+        const int cb = 16 * jb;
         if (wave == 0) {
             double x[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) x[c] = lane < 16 ? A[jb + lane][jb + c] : 0.0;
+            for (int c = 0; c < 16; c++) x[c] = lane < 16 ? A[cb + lane][cb + c] : 0.0;
             double ys[16];
             bool bad = false;
 #pragma unroll
@@ -101,110 +132,77 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
                     x[c2] = fma(-x[c], __hiloint2double(l1, l0), x[c2]);
                 }
             }
+            // W = L_dd^-1: lane c holds column c; L[i][m] comes from lane i's registers
+            double w[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double v = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                for (int m = 0; m < i; m++) {
+                    const int l0 = __builtin_amdgcn_readlane(__double2loint(x[m]), i);
+                    const int l1 = __builtin_amdgcn_readlane(__double2hiint(x[m]), i);
+                    v = fma(-__hiloint2double(l1, l0), w[m], v);
+                }
+                w[i] = v * ys[i];
+            }
             if (lane < 16) {
 #pragma unroll
-                for (int c = 0; c < 16; c++) A[jb + lane][jb + c] = (c <= lane) ? x[c] : 0.0;
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int c = 0; c < 16; c++) s_rinv[jb + c] = ys[c];
-                if (bad) s_bad = 1;
-            }
-        }
-        __syncthreads();
-        const int below = kDNB - jb - 16;
-        if (tid < below) {  // x L_dd^T = a for one row
-            const int r = jb + 16 + tid;
-            double x[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) x[c] = A[r][jb + c];
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                double v = x[c];
-#pragma unroll
-                for (int m = 0; m < c; m++) v = fma(-x[m], A[jb + c][jb + m], v);
-                x[c] = v * s_rinv[jb + c];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; c++) A[r][jb + c] = x[c];
-        }
-        __syncthreads();
-        const int nb16 = below / 16, base = jb + 16;
-        if (nb16 > 0) {
-            double acc[5][5];
-#pragma unroll
-            for (int a = 0; a < 5; a++)
-#pragma unroll
-                for (int b = 0; b < 5; b++) acc[a][b] = 0.0;
-            for (int kk = 0; kk < 16; kk++) {
-                double pr[5], pc[5];
-#pragma unroll
-                for (int a = 0; a < 5; a++) {
-                    pr[a] = a < nb16 ? A[base + ty + 16 * a][jb + kk] : 0.0;
-                    pc[a] = a < nb16 ? A[base + tx + 16 * a][jb + kk] : 0.0;
+                for (int c = 0; c < 16; c++) {
+                    A[cb + lane][cb + c] = (c <= lane) ? x[c] : 0.0;
+                    X[cb + c][cb + lane] = w[c];  // zero above the diagonal by construction
                 }
-#pragma unroll
-                for (int a = 0; a < 5; a++)
-#pragma unroll
-                    for (int b = 0; b <= a; b++) acc[a][b] = fma(pr[a], pc[b], acc[a][b]);
             }
+            if (lane == 0 && bad) s_bad = 1;
+        }
+        __syncthreads();
+        // rows below: L_rd = A_rd W^T
+        for (int rt = jb + 1 + wave; rt < NT; rt += 4) {
+            d4 acc = potrf_mma_nt(&A[16 * rt][cb], &X[cb][cb], 16, d4{0.0, 0.0, 0.0, 0.0}, lane);
+            potrf_wave_sync();
 #pragma unroll
-            for (int a = 0; a < 5; a++)
+            for (int reg = 0; reg < 4; reg++) A[16 * rt + crow + 4 * reg][cb + ccol] = acc[reg];
+        }
+        __syncthreads();
+        // trailing update of the lower triangle
+        {
+            const int m = NT - jb - 1;
+            for (int t = wave; t < m * (m + 1) / 2; t += 4) {
+                int ti = 0;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+                const int tj = t - ti * (ti + 1) / 2;
+                const int ri = jb + 1 + ti, ci = jb + 1 + tj;
+                const d4 acc = potrf_mma_nt(&A[16 * ri][cb], &A[16 * ci][cb], 16, d4{0.0, 0.0, 0.0, 0.0}, lane);
 #pragma unroll
-                for (int b = 0; b <= a; b++)
-                    if (a < nb16) A[base + ty + 16 * a][base + tx + 16 * b] -= acc[a][b];
+                for (int reg = 0; reg < 4; reg++) A[16 * ri + crow + 4 * reg][16 * ci + ccol] -= acc[reg];
+            }
         }
         __syncthreads();
     }
-    // inverse of the lower-triangular factor: 6x6 leaves by substitution, then [X11 0; -X22 L21 X11, X22] doubling
-    if (tid < kDNB / 6) {
-        const int o = 6 * tid;
+    // inverse, block column j on one wave: 0, 1, 2 -> waves 0, 1, 2; 3 and 4 -> wave 3
+    for (int j = wave; j < NT - 1; j += (wave == 3 ? 1 : NT)) {
+        for (int i = j + 1; i < NT; i++) {
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            for (int m = j; m < i; m++) acc = potrf_mma_nn(&A[16 * i][16 * m], &X[16 * m][16 * j], acc, lane);
+            potrf_wave_sync();
 #pragma unroll
-        for (int c = 0; c < 6; c++) {
-            double x[6];
+            for (int reg = 0; reg < 4; reg++) X[16 * i + crow + 4 * reg][16 * j + ccol] = acc[reg];  // T, in place of X_ij
+            potrf_wave_sync();
+            acc = potrf_mma_nn(&X[16 * i][16 * i], &X[16 * i][16 * j], d4{0.0, 0.0, 0.0, 0.0}, lane);
+            potrf_wave_sync();
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                if (i < c) { x[i] = 0.0; continue; }
-                double v = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int m = 0; m < 6; m++)
-                    if (m >= c && m < i) v = fma(-A[o + i][o + m], x[m], v);
-                x[i] = v * s_rinv[o + i];
-            }
-#pragma unroll
-            for (int i = 0; i < 6; i++) X[o + i][o + c] = x[i];
+            for (int reg = 0; reg < 4; reg++) X[16 * i + crow + 4 * reg][16 * j + ccol] = -acc[reg];
+            potrf_wave_sync();
         }
     }
     __syncthreads();
-    for (int s = 6; s < kDNB; s *= 2) {  // merge pairs of inverted s-blocks into 2s-blocks
-        const int pairs = kDNB / (2 * s), per = s * s;
-        // T = L21 X11 into the free upper-right block of the pair
-        for (int e = tid; e < pairs * per; e += 256) {
-            const int p = e / per, q = e - p * per, i = q / s, jx = q - i * s, o = 2 * s * p;
-            double v = 0.0;
-            for (int m = jx; m < s; m++) v = fma(A[o + s + i][o + m], X[o + m][o + jx], v);  // X11 lower: m >= jx
-            X[o + i][o + s + jx] = v;
-        }
-        __syncthreads();
-        // X21 = -X22 T
-        for (int e = tid; e < pairs * per; e += 256) {
-            const int p = e / per, q = e - p * per, i = q / s, jx = q - i * s, o = 2 * s * p;
-            double v = 0.0;
-            for (int m = 0; m <= i; m++) v = fma(X[o + s + i][o + s + m], X[o + m][o + s + jx], v);  // X22 lower: m <= i
-            X[o + s + i][o + jx] = -v;
-        }
-        __syncthreads();
-        for (int e = tid; e < pairs * per; e += 256) {  // the scratch block is part of the (zero) upper triangle
-            const int p = e / per, q = e - p * per, i = q / s, jx = q - i * s, o = 2 * s * p;
-            X[o + i][o + s + jx] = 0.0;
-        }
-        __syncthreads();
-    }
     double* Linv = d.dense_ws + (size_t)k * kDNB * kDNB;
-    for (int i = tid; i < kDNB * kDNB; i += 256) {
-        const int r = i / kDNB, c = i - r * kDNB;
-        Sk[(size_t)r * ld + c] = (c <= r) ? A[r][c] : 0.0;
-        Linv[i] = X[r][c];
+    for (int i = tid; i < kDNB * (kDNB / 2); i += 256) {
+        const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
+        double2 l, x;
+        l.x = (c <= r) ? A[r][c] : 0.0; l.y = (c + 1 <= r) ? A[r][c + 1] : 0.0;
+        x.x = X[r][c]; x.y = X[r][c + 1];
+        *reinterpret_cast<double2*>(Sk + (size_t)r * ld + c) = l;
+        *reinterpret_cast<double2*>(Linv + (size_t)r * kDNB + c) = x;
     }
     if (tid == 0 && s_bad) d.partial[kBaSolveOk] = 0.0;
 }
