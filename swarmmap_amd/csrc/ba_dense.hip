@@ -34,15 +34,14 @@ constexpr int kDStride = 50;    // LDS row stride (doubles) of a chunk: 2*50 mod
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// 1/sqrt(v): v_rsq_f64 is good to about 2^-23, so one third-order step y (1 + e/2 + 3 e^2/8), e = 1 - v y^2, reaches
+// double precision with four dependent operations - the pivot chain of the diagonal factor is made of these.
 __device__ __forceinline__ double dense_rsqrt(double v) {
-    double y = __builtin_amdgcn_rsq(v);
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const double t = v * y;
-        const double e = fma(-t, y, 1.0);
-        y = fma(0.5 * y, e, y);
-    }
-    return y;
+    const double y = __builtin_amdgcn_rsq(v);
+    const double t = v * y;
+    const double e = fma(-t, y, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    return fma(y * e, p, y);
 }
 
 // ---- padding: rows / columns n..np-1 form an identity block, the right-hand side is zero there ----
@@ -58,15 +57,23 @@ __global__ __launch_bounds__(256) void dense_pad_kernel(double* __restrict__ S, 
 }
 
 // ---- diagonal block: Cholesky + inverse, one workgroup, FP64 matrix cores for everything but the 16x16 pivots ----
-// The 96x96 block lives in LDS (row stride 98 doubles: the 16 rows x 2 k of an MFMA operand fetch hit 32 distinct
-// bank pairs).  Six steps of 16 columns:
-//   (1) wave 0 factors the 16x16 diagonal sub-block, a row per lane, pivots and multipliers by v_readlane (no LDS,
-//       no barrier), and inverts it (lane c solves column c of W = L_dd^-1 against the same registers);
-//   (2) the rows below become A_rd W^T - one 16x16x16 MFMA product per row tile instead of a substitution;
-//   (3) rank-16 update of the remaining lower triangle, one MFMA product per 16x16 tile.
-// Then the inverse of the whole factor, block column by block column (X_ij = -W_i sum_m L_im X_mj): a wave owns
-// a block column, so the recursion needs no barrier.
+// The lower triangle of the 96x96 block lives in LDS as 16x16 tiles (row stride 98 doubles: the 16 rows x 2 k of
+// an MFMA operand fetch hit 32 distinct bank pairs).  Six steps of 16 columns, two barriers each:
+//   panel   the row tiles below the diagonal tile become A_rd W^T (W = inverse of the 16x16 diagonal factor): one
+//           16x16x16 MFMA product per tile instead of a substitution;
+//   update  rank-16 update of the remaining lower triangle, one MFMA product per tile.  Wave 0 takes the next
+//           diagonal tile first and then factors it - a row per lane, pivots and multipliers by v_readlane (no LDS,
+//           no barrier), W by forward substitution on the same multipliers - while waves 1-3 finish the update and
+//           compute block row jb of the inverse of the whole factor (X_ij = -W_i sum_m L_im X_mj, rows above it
+//           are complete): the serial pivots hide everything else.
+// Only the inverse goes back to HBM: the panel GEMM and both substitutions use Linv_kk, nothing reads L_kk.
 constexpr int kPS = 98;
+constexpr int kPT = kDNB / 16;  // tiles per block edge
+
+// tools/probe/potrf_probe.hip defines SO_POTRF_MARK to log clock64() per phase; the product build compiles it away
+#ifndef SO_POTRF_MARK
+#define SO_POTRF_MARK(i)
+#endif
 
 __device__ __forceinline__ void potrf_wave_sync() {
     // LDS operations of one wave execute in order; this only keeps the compiler from moving accesses across it
@@ -74,10 +81,11 @@ __device__ __forceinline__ void potrf_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// acc += Pa(16 x klen) * Pb(16 x klen)^T, both row-major in LDS with stride kPS
-__device__ __forceinline__ d4 potrf_mma_nt(const double* Pa, const double* Pb, int klen, d4 acc, int lane) {
+// acc += Pa(16 x 16) * Pb(16 x 16)^T, both row-major in LDS with stride kPS
+__device__ __forceinline__ d4 potrf_mma_nt(const double* Pa, const double* Pb, d4 acc, int lane) {
     const int fr = lane & 15, fk = lane >> 4;
-    for (int kk = 0; kk < klen; kk += 4)
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[fr * kPS + kk + fk], Pb[fr * kPS + kk + fk], acc, 0, 0, 0);
     return acc;
 }
@@ -91,6 +99,85 @@ __device__ __forceinline__ d4 potrf_mma_nn(const double* Pa, const double* Pb, d
     return acc;
 }
 
+// Value of lane n of the caller's row of 16 lanes, as one VGPR-to-VGPR DPP move (v_mov_b64_dpp row_newbcast).
+template <int N>
+__device__ __forceinline__ double row_bcast_c(double x) {
+    return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
+}
+// acc -= (lane N of the row of col) * b in ONE instruction: the FP64 FMA takes its first operand through DPP, so a
+// multiplier of the pivot loop costs no broadcast instruction, no scalar register (512 v_readlane per tile ran the
+// SGPR file dry) and no temporary.  `col` must come from potrf_scale (DPP reads need two wait states after the
+// VALU write; the assembler does not see inside these statements).
+template <int N>
+__device__ __forceinline__ void fnma_bcast_c(double& acc, double col, double b) {
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(col), "v"(b), "n"(N));
+}
+__device__ __forceinline__ double potrf_scale(double x, double y) {
+    double r;
+    asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+#define SO_ROW16(F, n, ...)                                                                                          \
+    switch (n) {                                                                                                     \
+        case 0: F<0>(__VA_ARGS__); break;   case 1: F<1>(__VA_ARGS__); break;   case 2: F<2>(__VA_ARGS__); break;     \
+        case 3: F<3>(__VA_ARGS__); break;   case 4: F<4>(__VA_ARGS__); break;   case 5: F<5>(__VA_ARGS__); break;     \
+        case 6: F<6>(__VA_ARGS__); break;   case 7: F<7>(__VA_ARGS__); break;   case 8: F<8>(__VA_ARGS__); break;     \
+        case 9: F<9>(__VA_ARGS__); break;   case 10: F<10>(__VA_ARGS__); break; case 11: F<11>(__VA_ARGS__); break;   \
+        case 12: F<12>(__VA_ARGS__); break; case 13: F<13>(__VA_ARGS__); break; case 14: F<14>(__VA_ARGS__); break;   \
+        default: F<15>(__VA_ARGS__); break;                                                                          \
+    }
+template <int N>
+__device__ __forceinline__ void row_bcast_into(double& out, double x) {
+    out = row_bcast_c<N>(x);
+}
+
+// One wave: Cholesky of the 16x16 tile at A[cb][cb] (in place, zeros above the diagonal) and its inverse into
+// X[cb][cb]; lanes 0-15 hold a row each (lanes 16-63 run the same code on identity rows).  Returns false if a
+// pivot is not positive.
+__device__ __forceinline__ bool potrf_diag16(double (*A)[kPS], double (*X)[kPS], int cb, int lane) {
+    double x[16], v[16], w[16];
+    const int lr = lane & 15;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        x[c] = lane < 16 ? A[cb + lane][cb + c] : (c == lr ? 1.0 : 0.0);
+        v[c] = (c == lr) ? 1.0 : 0.0;  // lane c solves L w = e_c
+    }
+    bool ok = true;
+    double piv = row_bcast_c<0>(x[0]);
+#pragma unroll
+    for (int c = 0; c < 16; c++) {  // n in SO_ROW16 is a constant after unrolling
+        if (!(piv > 0.0)) ok = false;
+        const double y = dense_rsqrt(piv);
+        x[c] = potrf_scale(x[c], y);
+        w[c] = v[c] * y;
+        // the next pivot first: in its own lane the multiplier is the lane's own x[c], no broadcast on the chain
+        if (c + 1 < 16) {
+            const double pn = fma(-x[c], x[c], x[c + 1]);
+            SO_ROW16(row_bcast_into, c + 1, piv, pn);
+        }
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; c2++) {  // L[c2][c] = x[c] in lane c2
+            SO_ROW16(fnma_bcast_c, c2, x[c2], x[c], x[c]);
+            SO_ROW16(fnma_bcast_c, c2, v[c2], x[c], w[c]);
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            A[cb + lane][cb + c] = (c <= lane) ? x[c] : 0.0;
+            X[cb + c][cb + lane] = w[c];  // column `lane` of W; zero above the diagonal by construction
+        }
+    }
+    return ok;
+}
+
+// t-th tile (row-major) of a lower triangle
+__device__ __forceinline__ void potrf_tri(int t, int& ti, int& tj) {
+    ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+    tj = t - ti * (ti + 1) / 2;
+}
+
 __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
     __shared__ double A[kDNB][kPS];
     __shared__ double X[kDNB][kPS];
@@ -98,112 +185,81 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
     if (!d.lm->active) return;
     const int tid = threadIdx.x, ld = d.ldS, lane = tid & 63, wave = tid >> 6;
     const int crow = lane >> 4, ccol = lane & 15;  // MFMA result layout: element (crow + 4 reg, ccol)
-    double* Sk = d.S + (size_t)k * kDNB * ld + (size_t)k * kDNB;
+    const double* Sk = d.S + (size_t)k * kDNB * ld + (size_t)k * kDNB;
     if (tid == 0) s_bad = 0;
-    for (int i = tid; i < kDNB * (kDNB / 2); i += 256) {
-        const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
+    for (int i = tid; i < (kPT * (kPT + 1) / 2) * 128; i += 256) {  // lower tiles only, 128 double2 per tile
+        int ti, tj;
+        potrf_tri(i >> 7, ti, tj);
+        const int e = i & 127, r = 16 * ti + (e >> 3), c = 16 * tj + 2 * (e & 7);
         const double2 v = *reinterpret_cast<const double2*>(Sk + (size_t)r * ld + c);
         A[r][c] = v.x; A[r][c + 1] = v.y;
-        X[r][c] = 0.0; X[r][c + 1] = 0.0;
     }
     __syncthreads();
-    constexpr int NT = kDNB / 16;
-    for (int jb = 0; jb < NT; jb++) {
+    SO_POTRF_MARK(0);
+    if (wave == 0 && !potrf_diag16(A, X, 0, lane) && lane == 0) s_bad = 1;
+    __syncthreads();
+    for (int jb = 0; jb < kPT; jb++) {
         const int cb = 16 * jb;
-        if (wave == 0) {
-            double x[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) x[c] = lane < 16 ? A[cb + lane][cb + c] : 0.0;
-            double ys[16];
-            bool bad = false;
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const int lo = __builtin_amdgcn_readlane(__double2loint(x[c]), c);
-                const int hi = __builtin_amdgcn_readlane(__double2hiint(x[c]), c);
-                const double v = __hiloint2double(hi, lo);
-                if (!(v > 0.0)) bad = true;
-                const double y = dense_rsqrt(v);
-                ys[c] = y;
-                x[c] *= y;
-#pragma unroll
-                for (int c2 = c + 1; c2 < 16; c2++) {
-                    const int l0 = __builtin_amdgcn_readlane(__double2loint(x[c]), c2);
-                    const int l1 = __builtin_amdgcn_readlane(__double2hiint(x[c]), c2);
-                    x[c2] = fma(-x[c], __hiloint2double(l1, l0), x[c2]);
-                }
-            }
-            // W = L_dd^-1: lane c holds column c; L[i][m] comes from lane i's registers
-            double w[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                double v = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-                for (int m = 0; m < i; m++) {
-                    const int l0 = __builtin_amdgcn_readlane(__double2loint(x[m]), i);
-                    const int l1 = __builtin_amdgcn_readlane(__double2hiint(x[m]), i);
-                    v = fma(-__hiloint2double(l1, l0), w[m], v);
-                }
-                w[i] = v * ys[i];
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    A[cb + lane][cb + c] = (c <= lane) ? x[c] : 0.0;
-                    X[cb + c][cb + lane] = w[c];  // zero above the diagonal by construction
-                }
-            }
-            if (lane == 0 && bad) s_bad = 1;
-        }
-        __syncthreads();
-        // rows below: L_rd = A_rd W^T
-        for (int rt = jb + 1 + wave; rt < NT; rt += 4) {
-            d4 acc = potrf_mma_nt(&A[16 * rt][cb], &X[cb][cb], 16, d4{0.0, 0.0, 0.0, 0.0}, lane);
+        SO_POTRF_MARK(1 + 4 * jb);
+        // panel: L_rd = A_rd W^T
+        for (int rt = jb + 1 + wave; rt < kPT; rt += 4) {
+            const d4 acc = potrf_mma_nt(&A[16 * rt][cb], &X[cb][cb], d4{0.0, 0.0, 0.0, 0.0}, lane);
             potrf_wave_sync();
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) A[16 * rt + crow + 4 * reg][cb + ccol] = acc[reg];
         }
-        __syncthreads();
-        // trailing update of the lower triangle
-        {
-            const int m = NT - jb - 1;
-            for (int t = wave; t < m * (m + 1) / 2; t += 4) {
-                int ti = 0;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-                const int tj = t - ti * (ti + 1) / 2;
-                const int ri = jb + 1 + ti, ci = jb + 1 + tj;
-                const d4 acc = potrf_mma_nt(&A[16 * ri][cb], &A[16 * ci][cb], 16, d4{0.0, 0.0, 0.0, 0.0}, lane);
+        if (jb + 1 < kPT) __syncthreads();
+        SO_POTRF_MARK(2 + 4 * jb);
+        const int m = kPT - jb - 1;               // trailing tile rows
+        const bool has_diag = m > 0;              // wave 0: next diagonal tile, then its factor
+        if (has_diag && wave == 0) {
+            const int nb = cb + 16;
+            const d4 acc = potrf_mma_nt(&A[nb][cb], &A[nb][cb], d4{0.0, 0.0, 0.0, 0.0}, lane);
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) A[16 * ri + crow + 4 * reg][16 * ci + ccol] -= acc[reg];
+            for (int reg = 0; reg < 4; reg++) A[nb + crow + 4 * reg][nb + ccol] -= acc[reg];
+            potrf_wave_sync();
+            SO_POTRF_MARK(3 + 4 * jb);
+            if (!potrf_diag16(A, X, nb, lane) && lane == 0) s_bad = 1;
+            SO_POTRF_MARK(4 + 4 * jb);
+        } else {
+            const int nw = has_diag ? 3 : 4, me = has_diag ? wave - 1 : wave;
+            const int n_upd = has_diag ? m * (m + 1) / 2 - 1 : 0;
+            for (int t = me; t < n_upd + jb; t += nw) {
+                if (t < n_upd) {  // A_ij -= L_i L_j^T (tile 0 of the triangle is wave 0's)
+                    int ti, tj;
+                    potrf_tri(t + 1, ti, tj);
+                    const int ri = jb + 1 + ti, ci = jb + 1 + tj;
+                    const d4 acc = potrf_mma_nt(&A[16 * ri][cb], &A[16 * ci][cb], d4{0.0, 0.0, 0.0, 0.0}, lane);
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) A[16 * ri + crow + 4 * reg][16 * ci + ccol] -= acc[reg];
+                } else {          // X_ij = -W_i sum_{m=j}^{i-1} L_im X_mj for i = jb
+                    const int i = jb, j = t - n_upd;
+                    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+                    for (int mm = j; mm < i; mm++) acc = potrf_mma_nn(&A[16 * i][16 * mm], &X[16 * mm][16 * j], acc, lane);
+                    potrf_wave_sync();
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) X[16 * i + crow + 4 * reg][16 * j + ccol] = acc[reg];  // scratch
+                    potrf_wave_sync();
+                    acc = potrf_mma_nn(&X[16 * i][16 * i], &X[16 * i][16 * j], d4{0.0, 0.0, 0.0, 0.0}, lane);
+                    potrf_wave_sync();
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) X[16 * i + crow + 4 * reg][16 * j + ccol] = -acc[reg];
+                    potrf_wave_sync();
+                }
             }
         }
         __syncthreads();
     }
-    // inverse, block column j on one wave: 0, 1, 2 -> waves 0, 1, 2; 3 and 4 -> wave 3
-    for (int j = wave; j < NT - 1; j += (wave == 3 ? 1 : NT)) {
-        for (int i = j + 1; i < NT; i++) {
-            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-            for (int m = j; m < i; m++) acc = potrf_mma_nn(&A[16 * i][16 * m], &X[16 * m][16 * j], acc, lane);
-            potrf_wave_sync();
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) X[16 * i + crow + 4 * reg][16 * j + ccol] = acc[reg];  // T, in place of X_ij
-            potrf_wave_sync();
-            acc = potrf_mma_nn(&X[16 * i][16 * i], &X[16 * i][16 * j], d4{0.0, 0.0, 0.0, 0.0}, lane);
-            potrf_wave_sync();
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) X[16 * i + crow + 4 * reg][16 * j + ccol] = -acc[reg];
-            potrf_wave_sync();
-        }
-    }
-    __syncthreads();
+    SO_POTRF_MARK(25);
     double* Linv = d.dense_ws + (size_t)k * kDNB * kDNB;
     for (int i = tid; i < kDNB * (kDNB / 2); i += 256) {
         const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
-        double2 l, x;
-        l.x = (c <= r) ? A[r][c] : 0.0; l.y = (c + 1 <= r) ? A[r][c + 1] : 0.0;
-        x.x = X[r][c]; x.y = X[r][c + 1];
-        *reinterpret_cast<double2*>(Sk + (size_t)r * ld + c) = l;
+        double2 x;
+        const bool low = (c >> 4) <= (r >> 4);  // tiles above the diagonal are zero (and were never written in LDS)
+        x.x = low ? X[r][c] : 0.0; x.y = low ? X[r][c + 1] : 0.0;
         *reinterpret_cast<double2*>(Linv + (size_t)r * kDNB + c) = x;
     }
+    SO_POTRF_MARK(26);
     if (tid == 0 && s_bad) d.partial[kBaSolveOk] = 0.0;
 }
 
