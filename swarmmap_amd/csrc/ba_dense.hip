@@ -5,7 +5,7 @@
 // single-workgroup solvers in ba_kernels.hip: same solution up to rounding.
 //
 // S (np x np, row-major, leading dimension np = n rounded up to 96; the padding is an identity block) is factored
-// in place, right-looking, in panels of 96 columns.  Per panel k, three launches:
+// in place, right-looking, in panels of 96 columns taken two at a time (dense_chain / launch_ba_dense_solve):
 //   dense_potrf_kernel   one workgroup: Cholesky of the 96x96 diagonal block in LDS, then its inverse by the
 //                        recursive 2x2 block formula (6 -> 12 -> 24 -> 48 -> 96: small GEMMs, no serial solve)
 //   dense_panel_kernel   L_ik = A_ik Linv_kk^T for every 96-row block below the diagonal: a GEMM, not a
@@ -264,10 +264,11 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
 }
 
 // ---- 96x96 tile of C = PA * PB^T on the FP64 matrix cores ----
-// PA, PB: 96 rows x 96 k, row-major with leading dimensions lda / ldb.  acc[rt][ct] is the wave's 48x48 quadrant
+// PA, PB: 96 rows x klen k (96 or 192: one or two panels), row-major with leading dimensions lda / ldb.  acc[rt][ct] is the wave's 48x48 quadrant
 // as 3x3 MFMA tiles; element (row, col) of tile (rt, ct): col = lane & 15, row = (lane >> 4) + 4 * reg.
 __device__ __forceinline__ void dense_tile_nt(const double* __restrict__ PA, int lda, const double* __restrict__ PB,
-                                              int ldb, double (*sA)[kDStride], double (*sB)[kDStride], d4 acc[3][3]) {
+                                              int ldb, double (*sA)[kDStride], double (*sB)[kDStride], d4 acc[3][3],
+                                              int klen = kDNB) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
     const int fr = lane & 15, fk = lane >> 4;
@@ -275,7 +276,7 @@ __device__ __forceinline__ void dense_tile_nt(const double* __restrict__ PA, int
     for (int rt = 0; rt < 3; rt++)
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) acc[rt][ct] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int kc = 0; kc < kDNB; kc += kDChunk) {
+    for (int kc = 0; kc < klen; kc += kDChunk) {
         __syncthreads();  // the previous chunk is no longer read
         for (int idx = tid; idx < kDNB * (kDChunk / 2); idx += 256) {
             const int r = idx / (kDChunk / 2), v = idx - r * (kDChunk / 2);
@@ -338,22 +339,25 @@ __global__ __launch_bounds__(256) void dense_panel_kernel(BaDev d, int k) {
             }
 }
 
-// ---- trailing update: A_ij -= L_ik L_jk^T for i >= j > k; extra blocks: b_j -= L_jk y_k ----
-// mode 0: every tile; mode 1: the tiles of block column k+1 (what the next panel needs) + the right-hand side;
-// mode 2: the rest (runs while the side stream factors panel k+1)
-__global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int n_tiles, int mode) {
+// ---- trailing update: A_ij -= sum over kw panels from k of L_i. L_j.^T; extra blocks: b_j -= L_j,p y_p ----
+// Panels are consumed in pairs (kw = 2, K = 192): every 96x96 tile of the trailing matrix is read and written once
+// per 192 columns instead of once per 96 - that read-modify-write of C, not the MFMA rate, bounds the solve of a
+// 9000 x 9000 system.  Tiles: ncols == 0: every tile I >= J >= j0; ncols > 0: the block columns j0 .. j0+ncols-1
+// only (what the next panels' factor needs first).  rhs_panel >= 0: n_rhs more workgroups apply that panel's y.
+__global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int kw, int j0, int ncols, int n_tiles,
+                                                           int rhs_panel) {
     __shared__ double sA[kDNB][kDStride];
     __shared__ double sB[kDNB][kDStride];
     if (!d.lm->active) return;
     const int tid = threadIdx.x, ld = d.ldS;
-    const int T = d.ldS / kDNB, rem = T - k - 1;  // trailing block rows
-    if ((int)blockIdx.x >= n_tiles) {  // right-hand side rows
+    const int T = d.ldS / kDNB;
+    if ((int)blockIdx.x >= n_tiles) {  // right-hand side rows below panel rhs_panel
         __shared__ double s_y[kDNB];
-        if (tid < kDNB) s_y[tid] = d.bs[(size_t)k * kDNB + tid];
+        if (tid < kDNB) s_y[tid] = d.bs[(size_t)rhs_panel * kDNB + tid];
         __syncthreads();
-        const int row = (k + 1) * kDNB + ((int)blockIdx.x - n_tiles) * 256 + tid;
+        const int row = (rhs_panel + 1) * kDNB + ((int)blockIdx.x - n_tiles) * 256 + tid;
         if (row < ld) {
-            const double* L = d.S + (size_t)row * ld + (size_t)k * kDNB;
+            const double* L = d.S + (size_t)row * ld + (size_t)rhs_panel * kDNB;
             double v = 0.0;
             for (int m = 0; m < kDNB; m += 2) {
                 const double2 l = *reinterpret_cast<const double2*>(L + m);
@@ -364,29 +368,28 @@ __global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int n
         }
         return;
     }
-    // tile index -> (ti >= tj) within the trailing rem x rem block grid
-    int ti, tj;
-    if (mode == 1) {
-        ti = (int)blockIdx.x;
-        tj = 0;
-    } else {
-        int t = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);  // row by row of a lower triangle
+    int I, J;
+    if (ncols == 0) {  // row by row of the lower triangle from block j0
+        int t = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
         while ((t + 1) * (t + 2) / 2 <= (int)blockIdx.x) t++;
         while (t * (t + 1) / 2 > (int)blockIdx.x) t--;
-        ti = t;
-        tj = (int)blockIdx.x - t * (t + 1) / 2;
-        if (mode == 2) {  // the triangle without its first column
-            ti++;
-            tj++;
+        I = j0 + t;
+        J = j0 + (int)blockIdx.x - t * (t + 1) / 2;
+    } else {           // column by column
+        int c = 0, rem = (int)blockIdx.x;
+        while (c + 1 < ncols && rem >= T - (j0 + c)) {
+            rem -= T - (j0 + c);
+            c++;
         }
+        J = j0 + c;
+        I = J + rem;
     }
-    if (ti >= rem) return;
-    const int I = k + 1 + ti, J = k + 1 + tj;
+    if (I >= T || J >= T) return;
     const double* Pi = d.S + (size_t)I * kDNB * ld + (size_t)k * kDNB;
     const double* Pj = d.S + (size_t)J * kDNB * ld + (size_t)k * kDNB;
     double* C = d.S + (size_t)I * kDNB * ld + (size_t)J * kDNB;
     d4 acc[3][3];
-    dense_tile_nt(Pi, ld, Pj, ld, sA, sB, acc);
+    dense_tile_nt(Pi, ld, Pj, ld, sA, sB, acc, kw * kDNB);
     const int lane = tid & 63, wave = tid >> 6, wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
 #pragma unroll
     for (int rt = 0; rt < 3; rt++)
@@ -459,37 +462,51 @@ void launch_ba_dense_pad(const BaDev& d, hipStream_t s) {
     if (np > n) hipLaunchKernelGGL(dense_pad_kernel, dim3(256), dim3(256), 0, s, d.S, d.bs, n, np);
 }
 
-// Look-ahead across launches: the trailing update of panel k is split into the tiles of block column k+1 (U1) and
-// the rest (U2).  As soon as U1 is done the side stream factors the next diagonal block and solves the next panel
-// while the main stream is still busy with U2 - the serial diagonal factor (80 us) hides behind the GEMM work for as
-// long as the trailing matrix is large.  Only for T >= 32 panels: below that the two cross-stream waits per panel
-// (~10 us each) cost more than the overlap returns (measured on GBA-1, 19 panels).
+// One pair of panels: factor + panel solve of k, update of block column k+1 with it (K = 96), factor + panel solve of
+// k+1.  After it the trailing matrix from block k+2 on takes both panels in one K = 192 update.
+static void dense_chain(const BaDev& d, int k, hipStream_t s) {
+    const int T = d.ldS / kDNB;
+    hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, k);
+    hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (T - k - 1)), dim3(256), 0, s, d, k);
+    if (k + 1 >= T) return;
+    const int rem = T - k - 1, rhs_blocks = (rem * kDNB + 255) / 256;
+    hipLaunchKernelGGL(dense_update_kernel, dim3(rem + rhs_blocks), dim3(256), 0, s, d, k, 1, k + 1, 1, rem, k);
+    hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, k + 1);
+    hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (rem - 1)), dim3(256), 0, s, d, k + 1);
+}
+
+// Look-ahead across launches: the K = 192 update of pair (k, k+1) is split into the two block columns the next pair
+// needs (A) and the rest (B).  As soon as A is done the side stream runs the next pair's serial chain (two diagonal
+// factors, two panel solves, one column update) while the main stream is still busy with B - the chain hides behind
+// the GEMM work for as long as the trailing matrix is large.  Only for T >= 32 panels: below that the cross-stream
+// waits (~10 us each) cost more than the overlap returns (measured on GBA-1, 19 panels).
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s) {
     const int T = d.ldS / kDNB;
     hipStream_t side = d.dense_side;
-    hipEvent_t* ev = d.dense_events;  // [0] start, [1 + 2k] U1(k) done, [2 + 2k] panel(k+1) done
+    hipEvent_t* ev = d.dense_events;
     const bool lookahead = side && ev && T >= 32 && T <= kDenseMaxPanels && !getenv("SWARMORB_DENSE_NO_LOOKAHEAD");
     hipLaunchKernelGGL(dense_begin_kernel, dim3(1), dim3(1), 0, s, d);
-    hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, 0);
-    hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (T - 1)), dim3(256), 0, s, d, 0);
-    for (int k = 0; k < T - 1; k++) {
-        const int rem = T - k - 1;
-        const int rhs_blocks = (rem * kDNB + 255) / 256;
-        if (lookahead && rem >= 3) {
-            hipLaunchKernelGGL(dense_update_kernel, dim3(rem + rhs_blocks), dim3(256), 0, s, d, k, rem, 1);
-            (void)hipEventRecord(ev[1 + 2 * k], s);
-            (void)hipStreamWaitEvent(side, ev[1 + 2 * k], 0);
-            hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, side, d, k + 1);
-            hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (rem - 1)), dim3(256), 0, side, d, k + 1);
-            (void)hipEventRecord(ev[2 + 2 * k], side);
-            const int rest = (rem - 1) * rem / 2;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(rest), dim3(256), 0, s, d, k, rest, 2);
-            (void)hipStreamWaitEvent(s, ev[2 + 2 * k], 0);
+    dense_chain(d, 0, s);
+    int n_ev = 0;
+    for (int k = 0; k + 2 < T; k += 2) {
+        const int j0 = k + 2, rem2 = T - j0;  // block rows that take the pair's update
+        const int rhs_blocks = (rem2 * kDNB + 255) / 256;
+        if (lookahead && rem2 >= 4) {
+            const int n_a = rem2 + (rem2 - 1), n_b = (rem2 - 2) * (rem2 - 1) / 2;
+            hipLaunchKernelGGL(dense_update_kernel, dim3(n_a + rhs_blocks), dim3(256), 0, s, d, k, 2, j0, 2, n_a, k + 1);
+            (void)hipEventRecord(ev[n_ev], s);
+            (void)hipStreamWaitEvent(side, ev[n_ev], 0);
+            n_ev++;
+            hipLaunchKernelGGL(dense_update_kernel, dim3(n_b), dim3(256), 0, s, d, k, 2, j0 + 2, 0, n_b, -1);
+            dense_chain(d, j0, side);
+            (void)hipEventRecord(ev[n_ev], side);
+            (void)hipStreamWaitEvent(s, ev[n_ev], 0);
+            n_ev++;
         } else {
-            const int n_tiles = rem * (rem + 1) / 2;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(n_tiles + rhs_blocks), dim3(256), 0, s, d, k, n_tiles, 0);
-            hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, k + 1);
-            hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (rem - 1)), dim3(256), 0, s, d, k + 1);
+            const int n_tiles = rem2 * (rem2 + 1) / 2;
+            hipLaunchKernelGGL(dense_update_kernel, dim3(n_tiles + rhs_blocks), dim3(256), 0, s, d, k, 2, j0, 0, n_tiles,
+                               k + 1);
+            dense_chain(d, j0, s);
         }
     }
     for (int k = T - 1; k >= 0; k--) {
