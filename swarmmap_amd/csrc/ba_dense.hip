@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256) void dense_pad_kernel(double* __restrict__ S, 
 //           compute block row jb of the inverse of the whole factor (X_ij = -W_i sum_m L_im X_mj, rows above it
 //           are complete): the serial pivots hide everything else.
 // Only the inverse goes back to HBM: the panel GEMM and both substitutions use Linv_kk, nothing reads L_kk.
+constexpr int kDenseGroup = 3;   // panels per trailing update (K = 96 * kDenseGroup) when the look-ahead runs; measured on
+                                 // GBA-2 (94 panels): 1 -> 125 ms, 2 -> 106, 3 -> 104, 4 -> 106, 6 -> 115; without look-ahead
+                                 // (GBA-1, 19 panels) the serial chain dominates and single panels are fastest
 constexpr int kPS = 98;
 constexpr int kPT = kDNB / 16;  // tiles per block edge
 
@@ -340,8 +343,8 @@ __global__ __launch_bounds__(256) void dense_panel_kernel(BaDev d, int k) {
 }
 
 // ---- trailing update: A_ij -= sum over kw panels from k of L_i. L_j.^T; extra blocks: b_j -= L_j,p y_p ----
-// Panels are consumed in pairs (kw = 2, K = 192): every 96x96 tile of the trailing matrix is read and written once
-// per 192 columns instead of once per 96 - that read-modify-write of C, not the MFMA rate, bounds the solve of a
+// Panels are consumed in groups (kw panels, K = 96 kw): every 96x96 tile of the trailing matrix is read and written once
+// per group instead of once per 96 columns - that read-modify-write of C, not the MFMA rate, bounds the solve of a
 // 9000 x 9000 system.  Tiles: ncols == 0: every tile I >= J >= j0; ncols > 0: the block columns j0 .. j0+ncols-1
 // only (what the next panels' factor needs first).  rhs_panel >= 0: n_rhs more workgroups apply that panel's y.
 __global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int kw, int j0, int ncols, int n_tiles,
@@ -462,51 +465,58 @@ void launch_ba_dense_pad(const BaDev& d, hipStream_t s) {
     if (np > n) hipLaunchKernelGGL(dense_pad_kernel, dim3(256), dim3(256), 0, s, d.S, d.bs, n, np);
 }
 
-// One pair of panels: factor + panel solve of k, update of block column k+1 with it (K = 96), factor + panel solve of
-// k+1.  After it the trailing matrix from block k+2 on takes both panels in one K = 192 update.
-static void dense_chain(const BaDev& d, int k, hipStream_t s) {
+// One group of g panels from k: for each, [update of its block column with the panels of the group before it,
+// K = 96 p] -> diagonal factor -> panel solve.  After it the trailing matrix from block k+g on takes the whole group
+// in one K = 96 g update.
+static void dense_chain(const BaDev& d, int k, int g, hipStream_t s) {
     const int T = d.ldS / kDNB;
-    hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, k);
-    hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (T - k - 1)), dim3(256), 0, s, d, k);
-    if (k + 1 >= T) return;
-    const int rem = T - k - 1, rhs_blocks = (rem * kDNB + 255) / 256;
-    hipLaunchKernelGGL(dense_update_kernel, dim3(rem + rhs_blocks), dim3(256), 0, s, d, k, 1, k + 1, 1, rem, k);
-    hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, k + 1);
-    hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (rem - 1)), dim3(256), 0, s, d, k + 1);
+    for (int p = 0; p < g && k + p < T; p++) {
+        const int c = k + p, rem = T - c;  // block column c: rem tiles from the diagonal down
+        if (p > 0) {
+            const int rhs_blocks = (rem * kDNB + 255) / 256;
+            hipLaunchKernelGGL(dense_update_kernel, dim3(rem + rhs_blocks), dim3(256), 0, s, d, k, p, c, 1, rem, c - 1);
+        }
+        hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, c);
+        hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (rem - 1)), dim3(256), 0, s, d, c);
+    }
 }
 
-// Look-ahead across launches: the K = 192 update of pair (k, k+1) is split into the two block columns the next pair
-// needs (A) and the rest (B).  As soon as A is done the side stream runs the next pair's serial chain (two diagonal
-// factors, two panel solves, one column update) while the main stream is still busy with B - the chain hides behind
-// the GEMM work for as long as the trailing matrix is large.  Only for T >= 32 panels: below that the cross-stream
-// waits (~10 us each) cost more than the overlap returns (measured on GBA-1, 19 panels).
+// Look-ahead across launches: the K = 96 g update of a group is split into the g block columns the next group needs
+// (A) and the rest (B).  As soon as A is done the side stream runs the next group's serial chain (diagonal factors,
+// panel solves, column updates) while the main stream is still busy with B - the chain hides behind the GEMM work
+// for as long as the trailing matrix is large.  Only for T >= 32 panels: below that the cross-stream waits (~10 us
+// each) cost more than the overlap returns (measured on GBA-1, 19 panels).
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s) {
     const int T = d.ldS / kDNB;
     hipStream_t side = d.dense_side;
     hipEvent_t* ev = d.dense_events;
     const bool lookahead = side && ev && T >= 32 && T <= kDenseMaxPanels && !getenv("SWARMORB_DENSE_NO_LOOKAHEAD");
+    static const int g_env = getenv("SWARMORB_DENSE_GROUP") ? atoi(getenv("SWARMORB_DENSE_GROUP")) : 0;
+    const int G = g_env >= 1 && g_env <= 8 ? g_env : (lookahead ? kDenseGroup : 1);
     hipLaunchKernelGGL(dense_begin_kernel, dim3(1), dim3(1), 0, s, d);
-    dense_chain(d, 0, s);
+    dense_chain(d, 0, G, s);
     int n_ev = 0;
-    for (int k = 0; k + 2 < T; k += 2) {
-        const int j0 = k + 2, rem2 = T - j0;  // block rows that take the pair's update
+    for (int k = 0; k + G < T; k += G) {
+        const int j0 = k + G, rem2 = T - j0;  // block rows that take the group's update
         const int rhs_blocks = (rem2 * kDNB + 255) / 256;
-        if (lookahead && rem2 >= 4) {
-            const int n_a = rem2 + (rem2 - 1), n_b = (rem2 - 2) * (rem2 - 1) / 2;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(n_a + rhs_blocks), dim3(256), 0, s, d, k, 2, j0, 2, n_a, k + 1);
+        if (lookahead && rem2 >= G + 2) {
+            int n_a = 0;
+            for (int c = 0; c < G; c++) n_a += rem2 - c;
+            const int n_b = (rem2 - G) * (rem2 - G + 1) / 2;
+            hipLaunchKernelGGL(dense_update_kernel, dim3(n_a + rhs_blocks), dim3(256), 0, s, d, k, G, j0, G, n_a, j0 - 1);
             (void)hipEventRecord(ev[n_ev], s);
             (void)hipStreamWaitEvent(side, ev[n_ev], 0);
             n_ev++;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(n_b), dim3(256), 0, s, d, k, 2, j0 + 2, 0, n_b, -1);
-            dense_chain(d, j0, side);
+            hipLaunchKernelGGL(dense_update_kernel, dim3(n_b), dim3(256), 0, s, d, k, G, j0 + G, 0, n_b, -1);
+            dense_chain(d, j0, G, side);
             (void)hipEventRecord(ev[n_ev], side);
             (void)hipStreamWaitEvent(s, ev[n_ev], 0);
             n_ev++;
         } else {
             const int n_tiles = rem2 * (rem2 + 1) / 2;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(n_tiles + rhs_blocks), dim3(256), 0, s, d, k, 2, j0, 0, n_tiles,
-                               k + 1);
-            dense_chain(d, j0, s);
+            hipLaunchKernelGGL(dense_update_kernel, dim3(n_tiles + rhs_blocks), dim3(256), 0, s, d, k, G, j0, 0, n_tiles,
+                               j0 - 1);
+            dense_chain(d, j0, G, s);
         }
     }
     for (int k = T - 1; k >= 0; k--) {
