@@ -279,16 +279,33 @@ __device__ __forceinline__ void dense_tile_nt(const double* __restrict__ PA, int
     for (int rt = 0; rt < 3; rt++)
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) acc[rt][ct] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int kc = 0; kc < klen; kc += kDChunk) {
-        __syncthreads();  // the previous chunk is no longer read
-        for (int idx = tid; idx < kDNB * (kDChunk / 2); idx += 256) {
-            const int r = idx / (kDChunk / 2), v = idx - r * (kDChunk / 2);
-            const double2 a = *reinterpret_cast<const double2*>(PA + (size_t)r * lda + kc + 2 * v);
-            const double2 b = *reinterpret_cast<const double2*>(PB + (size_t)r * ldb + kc + 2 * v);
-            sA[r][2 * v] = a.x; sA[r][2 * v + 1] = a.y;
-            sB[r][2 * v] = b.x; sB[r][2 * v + 1] = b.y;
+    // a K-chunk is 96 rows x 24 double2 per operand: 9 double2 per thread and operand.  The next chunk is fetched
+    // into registers while the matrix cores work on the current one (global latency hides behind 108 MFMAs a wave).
+    constexpr int kPer = kDNB * (kDChunk / 2) / 256;
+    double2 ra[kPer], rb[kPer];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int idx = tid + 256 * q, r = idx / (kDChunk / 2), v = idx - r * (kDChunk / 2);
+            ra[q] = *reinterpret_cast<const double2*>(PA + (size_t)r * lda + kc + 2 * v);
+            rb[q] = *reinterpret_cast<const double2*>(PB + (size_t)r * ldb + kc + 2 * v);
         }
-        __syncthreads();
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int idx = tid + 256 * q, r = idx / (kDChunk / 2), v = idx - r * (kDChunk / 2);
+            sA[r][2 * v] = ra[q].x; sA[r][2 * v + 1] = ra[q].y;
+            sB[r][2 * v] = rb[q].x; sB[r][2 * v + 1] = rb[q].y;
+        }
+    };
+    fetch(0);
+    __syncthreads();  // the caller's previous use of sA / sB is over
+    stage();
+    __syncthreads();
+    for (int kc = 0; kc < klen; kc += kDChunk) {
+        const bool more = kc + kDChunk < klen;
+        if (more) fetch(kc + kDChunk);
 #pragma unroll 2
         for (int kk = 0; kk < kDChunk; kk += 4) {
             double a[3], b[3];
@@ -302,6 +319,11 @@ __device__ __forceinline__ void dense_tile_nt(const double* __restrict__ PA, int
 #pragma unroll
                 for (int ct = 0; ct < 3; ct++)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+        }
+        if (more) {
+            __syncthreads();  // everyone is done reading this chunk
+            stage();
+            __syncthreads();
         }
     }
 }
