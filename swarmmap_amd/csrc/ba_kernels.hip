@@ -548,18 +548,26 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d) {
     }
 }
 
-// gather: one wave per upper block (i1 <= i2) of the reduced camera system.  The lanes stride over pose i1's
-//         edges; the partner edge of pose i2 on the same landmark comes from edge_tab (the edge itself on the
-//         diagonal).  Each lane accumulates a full 6x6 partial, then a fixed xor-butterfly sums the lanes:
+// gather: one group of WAVES waves per upper block (i1 <= i2) of the reduced camera system (WAVES = 4: a whole
+//         workgroup, local windows; WAVES = 1: large maps, most blocks are short).  The threads stride over pose
+//         i1's edges; the partner edge of pose i2 on the same landmark comes from edge_tab (the edge itself on the
+//         diagonal).  Each lane accumulates a full 6x6 partial, a fixed xor-butterfly sums the lanes of a wave and
+//         the four waves meet in LDS (fixed order):
 //         S(i1,i2) = [i1 == i2] (Hpp + lambda I) - sum over shared landmarks BDinv_{e1} W_{e2}^T ; mirrored.
-//         extra waves: b_schur(i) = bp(i) - sum over the pose's edges W_e db_{landmark(e)}
+//         A pose of a local window has a few hundred edges: with a wave per block the kernel was five serial rounds
+//         of four dependent global loads (21 us on LBA-M); a workgroup per block needs one or two.
+//         extra workgroups: b_schur(i) = bp(i) - sum over the pose's edges W_e db_{landmark(e)}
 // With pair lists (large maps) only the blocks of big_list are walked here (list_cap = launch bound of the list,
 // *big_n of its entries are real); the others belong to ba_schur_gather_small_kernel.
+template <int WAVES>
 __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_cap) {
+    __shared__ double s_part[4][36];
     if (!d.lm->active) return;
     const double lambda = d.lm->lambda;
-    const int lane = threadIdx.x & 63;
-    int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = WAVES == 4 ? (int)(threadIdx.x >> 6) : 0;
+    const int tid = WAVES == 4 ? (int)threadIdx.x : lane;  // index inside the group
+    constexpr int kStride = 64 * WAVES;
+    int g = WAVES == 4 ? (int)blockIdx.x : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int nf = d.n_free;
     int n_blk = nf * (nf + 1) / 2;
     if (d.use_pairs) {
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
             if (g >= *d.big_n) return;
             g = d.big_list[g];
         } else {
-            g = n_blk + (g - list_cap);  // the right-hand-side waves follow the list
+            g = n_blk + (g - list_cap);  // the right-hand-side workgroups follow the list
         }
     }
     if (g < n_blk) {
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
         const bool from_list = d.use_pairs && i1 != i2;  // large maps: the block's own (landmark-sorted) pair list
         const int p_lo = from_list ? d.pr_off[g] : d.pose_off[i1], p_hi = from_list ? d.pr_off[g + 1] : d.pose_off[i1 + 1];
-        for (int p = p_lo + lane; p < p_hi; p += 64) {
+        for (int p = p_lo + tid; p < p_hi; p += kStride) {
             const int k1 = from_list ? d.ps_k1[p] : d.pose_edges[p];
             if (!d.e_active[k1]) continue;  // dropped between the stages
             const int k2 = from_list ? d.ps_k2[p] : (i1 == i2) ? k1 : d.edge_tab[(size_t)i2 * d.n_points + d.e_point[k1]];
@@ -600,12 +608,17 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = wave_sum(acc[k]);
         if (lane < 36) {
-            const int r = lane / 6, c = lane - 6 * r;
             double v = 0.0;
 #pragma unroll
             for (int k = 0; k < 36; k++) v = (k == lane) ? acc[k] : v;  // select without dynamic register indexing
-            double out = -v;
-            if (i1 == i2) out += d.Hpp[36 * (size_t)i1 + lane] + (r == c ? lambda : 0.0);
+            if (WAVES == 4) s_part[wave][lane] = v;
+            else acc[0] = v;
+        }
+        if (WAVES == 4) __syncthreads();
+        if (tid < 36) {
+            const int r = tid / 6, c = tid - 6 * r;
+            double out = WAVES == 4 ? -(((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid]) : -acc[0];
+            if (i1 == i2) out += d.Hpp[36 * (size_t)i1 + tid] + (r == c ? lambda : 0.0);
             d.S[(size_t)(6 * i1 + r) * d.ldS + 6 * i2 + c] = out;
             if (i1 != i2) d.S[(size_t)(6 * i2 + c) * d.ldS + 6 * i1 + r] = out;
         }
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
     const int hi = g - n_blk;
     if (hi >= d.n_free) return;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = d.pose_off[hi] + lane; k < d.pose_off[hi + 1]; k += 64) {
+    for (int k = d.pose_off[hi] + tid; k < d.pose_off[hi + 1]; k += kStride) {
         const int e = d.pose_edges[k];
         if (!d.e_active[e]) continue;
         const double* W = d.W + 18 * (size_t)e;
@@ -625,7 +638,15 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
 #pragma unroll
     for (int r = 0; r < 6; r++) {
         const double v = wave_sum(acc[r]);
-        if (lane == 0) d.bs[6 * (size_t)hi + r] = d.bp[6 * (size_t)hi + r] - v;
+        if (WAVES == 4) {
+            if (lane == 0) s_part[wave][r] = v;
+        } else if (lane == 0) {
+            d.bs[6 * (size_t)hi + r] = d.bp[6 * (size_t)hi + r] - v;
+        }
+    }
+    if (WAVES == 4) {
+        __syncthreads();
+        if (tid < 6) d.bs[6 * (size_t)hi + tid] = d.bp[6 * (size_t)hi + tid] - (((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid]);
     }
 }
 
@@ -1173,12 +1194,12 @@ static void launch_ba_schur(const BaDev& d, hipStream_t s) {
     const int n_blk = d.n_free * (d.n_free + 1) / 2;
     if (d.use_pairs) {
         if (n_blk > 0) hipLaunchKernelGGL(ba_schur_gather_small_kernel, dim3((n_blk + 255) / 256), dim3(256), 0, s, d, n_blk);
-        const int waves = d.big_cap + d.n_free;  // the walked blocks, then the right-hand-side waves
-        hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d, d.big_cap);
+        const int waves = d.big_cap + d.n_free;  // the walked blocks, then the right-hand sides
+        hipLaunchKernelGGL(ba_schur_gather_kernel<1>, dim3((waves + 3) / 4), dim3(256), 0, s, d, d.big_cap);
         return;
     }
-    const int waves = n_blk + d.n_free;
-    if (waves > 0) hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d, 0);
+    const int groups = n_blk + d.n_free;  // a local window: a workgroup per block
+    if (groups > 0) hipLaunchKernelGGL(ba_schur_gather_kernel<4>, dim3(groups), dim3(256), 0, s, d, 0);
 }
 
 static void launch_ba_solve(const BaDev& d, hipStream_t s) {
