@@ -84,21 +84,23 @@ __device__ __forceinline__ void potrf_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// acc += Pa(16 x 16) * Pb(16 x 16)^T, both row-major in LDS with stride kPS
+// acc += Pa(16 x 16) * Pb(16 x 16)^T, both row-major in LDS with row stride PS
+template <int PS = kPS>
 __device__ __forceinline__ d4 potrf_mma_nt(const double* Pa, const double* Pb, d4 acc, int lane) {
     const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 16; kk += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[fr * kPS + kk + fk], Pb[fr * kPS + kk + fk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[fr * PS + kk + fk], Pb[fr * PS + kk + fk], acc, 0, 0, 0);
     return acc;
 }
 
 // acc += Pa(16 x 16) * Pb(16 x 16), Pb read transposed
+template <int PS = kPS>
 __device__ __forceinline__ d4 potrf_mma_nn(const double* Pa, const double* Pb, d4 acc, int lane) {
     const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 16; kk += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[fr * kPS + kk + fk], Pb[(kk + fk) * kPS + fr], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[fr * PS + kk + fk], Pb[(kk + fk) * PS + fr], acc, 0, 0, 0);
     return acc;
 }
 
@@ -134,15 +136,16 @@ __device__ __forceinline__ void row_bcast_into(double& out, double x) {
     out = row_bcast_c<N>(x);
 }
 
-// One wave: Cholesky of the 16x16 tile at A[cb][cb] (in place, zeros above the diagonal) and its inverse into
-// X[cb][cb]; lanes 0-15 hold a row each (lanes 16-63 run the same code on identity rows).  Returns false if a
-// pivot is not positive.
-__device__ __forceinline__ bool potrf_diag16(double (*A)[kPS], double (*X)[kPS], int cb, int lane) {
+// One wave: Cholesky of the 16x16 tile at At (row stride PS) and its inverse W: the factor goes to Lt (zeros above
+// the diagonal; skipped if Lt is null), W to Wt; either may alias At.  Lanes 0-15 hold a row each (lanes 16-63 run the same code on
+// identity rows).  Returns false if a pivot is not positive.
+template <int PS>
+__device__ __forceinline__ bool potrf_diag16(const double* At, double* Lt, double* Wt, int lane) {
     double x[16], v[16], w[16];
     const int lr = lane & 15;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-        x[c] = lane < 16 ? A[cb + lane][cb + c] : (c == lr ? 1.0 : 0.0);
+        x[c] = lane < 16 ? At[lane * PS + c] : (c == lr ? 1.0 : 0.0);
         v[c] = (c == lr) ? 1.0 : 0.0;  // lane c solves L w = e_c
     }
     bool ok = true;
@@ -164,11 +167,12 @@ __device__ __forceinline__ bool potrf_diag16(double (*A)[kPS], double (*X)[kPS],
             SO_ROW16(fnma_bcast_c, c2, v[c2], x[c], w[c]);
         }
     }
+    potrf_wave_sync();  // every lane has read its row before anything aliasing it is written
     if (lane < 16) {
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            A[cb + lane][cb + c] = (c <= lane) ? x[c] : 0.0;
-            X[cb + c][cb + lane] = w[c];  // column `lane` of W; zero above the diagonal by construction
+            if (Lt) Lt[lane * PS + c] = (c <= lane) ? x[c] : 0.0;
+            Wt[c * PS + lane] = w[c];  // column `lane` of W; zero above the diagonal by construction
         }
     }
     return ok;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
     }
     __syncthreads();
     SO_POTRF_MARK(0);
-    if (wave == 0 && !potrf_diag16(A, X, 0, lane) && lane == 0) s_bad = 1;
+    if (wave == 0 && !potrf_diag16<kPS>(&A[0][0], &A[0][0], &X[0][0], lane) && lane == 0) s_bad = 1;
     __syncthreads();
     for (int jb = 0; jb < kPT; jb++) {
         const int cb = 16 * jb;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
             for (int reg = 0; reg < 4; reg++) A[nb + crow + 4 * reg][nb + ccol] -= acc[reg];
             potrf_wave_sync();
             SO_POTRF_MARK(3 + 4 * jb);
-            if (!potrf_diag16(A, X, nb, lane) && lane == 0) s_bad = 1;
+            if (!potrf_diag16<kPS>(&A[nb][nb], &A[nb][nb], &X[nb][nb], lane) && lane == 0) s_bad = 1;
             SO_POTRF_MARK(4 + 4 * jb);
         } else {
             const int nw = has_diag ? 3 : 4, me = has_diag ? wave - 1 : wave;
@@ -264,6 +268,194 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
     }
     SO_POTRF_MARK(26);
     if (tid == 0 && s_bad) d.partial[kBaSolveOk] = 0.0;
+}
+
+// ---- single-workgroup solve of a reduced camera system of up to 175 unknowns (local windows of 8..29 free keyframes) ----
+// The same machinery as dense_potrf_kernel on the whole system: the lower triangle of [S b; b^T beta] as 16x16 tiles
+// in LDS (row stride 18: conflict-free MFMA operand fetch), the right-hand side riding as one more row so that the
+// forward substitution falls out of the factorisation.  Per 16 columns: the row tiles below the pivot tile become
+// A W^T (MFMA), the trailing tiles take their rank-16 update (MFMA, waves 1-7) while wave 0 updates, factors and
+// inverts the next pivot tile (FP64 DPP multipliers); W replaces the pivot tile - nothing reads L_dd again.  The
+// backward substitution x_k = W_k^T (y_k - sum_{i>k} L_ik^T x_i) runs on the eight waves, one tile each per step.
+// 10 pivot tiles instead of 150 LDS-synchronised pivots: 56 -> 3x us for the 150 unknowns of LBA-M.
+constexpr int kMS = 18;                       // tile row stride (doubles)
+constexpr int kMTile = 16 * kMS;              // doubles per tile
+constexpr int kSolveMfmaMaxTiles = 11;        // 66 tiles = 152 KB of LDS
+constexpr int kSolveMfmaThreads = 512;
+
+__device__ __forceinline__ double* mtile(double* base, int i, int j) { return base + (size_t)(i * (i + 1) / 2 + j) * kMTile; }
+
+// sum over the four 16-lane rows of a wave (every lane gets the total): gfx950's v_permlane32_swap / v_permlane16_swap
+// trade the first operand's upper half (odd rows) with the second operand's lower half (even rows); with both
+// operands equal, a' + b' is the lane's value plus its partner's - two VALU swaps per step, no LDS crossbar
+__device__ __forceinline__ double rows_sum(double v) {
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+__global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev d) {
+    extern __shared__ double s_tiles[];        // NT (NT + 1) / 2 tiles
+    __shared__ double s_lastL[kMTile];         // factor of the last pivot tile: its row rr holds the tail of y
+    __shared__ double s_x[16 * kSolveMfmaMaxTiles];
+    __shared__ double s_z[16];
+    __shared__ unsigned char s_ti[kSolveMfmaMaxTiles * (kSolveMfmaMaxTiles + 1) / 2], s_tj[kSolveMfmaMaxTiles * (kSolveMfmaMaxTiles + 1) / 2];
+    __shared__ int s_bad;
+    if (!d.lm->active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int crow = lane >> 4, ccol = lane & 15;
+    const int n = 6 * d.n_free, ld = d.ldS;
+    const int NT = (n + 1 + 15) / 16, tr = NT - 1, rr = n - 16 * tr;  // the right-hand side is row rr of tile row tr
+    const int n_tiles = NT * (NT + 1) / 2;
+    if (tid == 0) s_bad = 0;
+    if (tid < n_tiles) {
+        int ti, tj;
+        potrf_tri(tid, ti, tj);
+        s_ti[tid] = (unsigned char)ti;
+        s_tj[tid] = (unsigned char)tj;
+    }
+    for (int i = tid; i < NT * 16; i += kSolveMfmaThreads) s_x[i] = 0.0;
+    __syncthreads();
+    // load: 128 double2 per tile (n is even: a pair never straddles the edge of S), seven loads in flight per thread
+    {
+        constexpr int U = 7;
+        const int total = n_tiles * 128;
+        for (int base = 0; base < total; base += kSolveMfmaThreads * U) {
+            double2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = base + u * kSolveMfmaThreads + tid;
+                v[u] = double2{0.0, 0.0};
+                if (e < total) {
+                    const int t = e >> 7, r = (e >> 3) & 15, c = 2 * (e & 7);
+                    const int gr = 16 * s_ti[t] + r, gc = 16 * s_tj[t] + c;
+                    if (gr < n && gc < n) v[u] = *reinterpret_cast<const double2*>(d.S + (size_t)gr * ld + gc);
+                    else if (gr == n && gc < n) v[u] = *reinterpret_cast<const double2*>(d.bs + gc);
+                    else {  // beta (the last pivot only has to stay positive) and the identity padding
+                        if (gr == gc) v[u].x = (gr == n) ? 1e300 : 1.0;
+                        if (gr == gc + 1) v[u].y = (gr == n) ? 1e300 : 1.0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = base + u * kSolveMfmaThreads + tid;
+                if (e < total) {
+                    const int t = e >> 7, r = (e >> 3) & 15, c = 2 * (e & 7);
+                    double* p = s_tiles + (size_t)t * kMTile + r * kMS + c;
+                    p[0] = v[u].x; p[1] = v[u].y;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    SO_POTRF_MARK(0);
+    if (wave == 0) {
+        double* t0 = mtile(s_tiles, 0, 0);
+        if (!potrf_diag16<kMS>(t0, s_lastL, t0, lane) && lane == 0) s_bad = 1;
+    }
+    __syncthreads();
+    // update waves: 1, 2, 3, 5, 6, 7 - wave 4 shares wave 0's SIMD and stays out of the pivot chain's way
+    const int uw = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+    for (int jb = 0; jb < NT; jb++) {
+        SO_POTRF_MARK(1 + 3 * jb);
+        const double* Wj = mtile(s_tiles, jb, jb);
+        for (int rt = jb + 1 + wave; rt < NT; rt += 8) {  // panel: L_rd = A_rd W^T
+            double* t = mtile(s_tiles, rt, jb);
+            const d4 acc = potrf_mma_nt<kMS>(t, Wj, d4{0.0, 0.0, 0.0, 0.0}, lane);
+            potrf_wave_sync();
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) t[(crow + 4 * reg) * kMS + ccol] = acc[reg];
+        }
+        if (jb + 1 >= NT) break;
+        __syncthreads();
+        SO_POTRF_MARK(2 + 3 * jb);
+        const int m = NT - jb - 1;
+        if (wave == 0) {  // next pivot tile: update, factor, invert (W in place)
+            double* t = mtile(s_tiles, jb + 1, jb + 1);
+            const double* p = mtile(s_tiles, jb + 1, jb);
+            const d4 acc = potrf_mma_nt<kMS>(p, p, d4{0.0, 0.0, 0.0, 0.0}, lane);
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) t[(crow + 4 * reg) * kMS + ccol] -= acc[reg];
+            potrf_wave_sync();
+            // (the right-hand-side row's pivot beta - y.y and the identity padding are positive by construction)
+            if (!potrf_diag16<kMS>(t, s_lastL, t, lane) && lane == 0) s_bad = 1;
+            SO_POTRF_MARK(3 + 3 * jb);
+        } else if (uw >= 0) {
+            for (int t = uw; t < m * (m + 1) / 2 - 1; t += 6) {  // tile 0 of the triangle is wave 0's
+                const int ri = jb + 1 + s_ti[t + 1], ci = jb + 1 + s_tj[t + 1];
+                double* c = mtile(s_tiles, ri, ci);
+                const d4 acc = potrf_mma_nt<kMS>(mtile(s_tiles, ri, jb), mtile(s_tiles, ci, jb), d4{0.0, 0.0, 0.0, 0.0}, lane);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) c[(crow + 4 * reg) * kMS + ccol] -= acc[reg];
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    SO_POTRF_MARK(40);
+    // backward substitution x_k = W_k^T (y_k - sum_{i>k} L_ik^T x_i) on one wave, column-oriented: as soon as x_i is
+    // known its contribution goes into the running sums of every block above - only tile (i, i-1) is on the chain.
+    // Lane (crow, ccol) carries rows crow, crow+4, .. of column ccol; rows >= n of x stay zero.
+    if (wave == 0) {
+        double accj[kSolveMfmaMaxTiles];
+#pragma unroll
+        for (int j = 0; j < kSolveMfmaMaxTiles; j++) accj[j] = 0.0;
+#pragma unroll
+        for (int k = kSolveMfmaMaxTiles - 1; k >= 0; k--) {
+            if (k > tr) continue;
+            const int mk = (k == tr) ? rr : 16;
+            const double yk = (k == tr) ? (ccol < rr ? s_lastL[rr * kMS + ccol] : 0.0) : mtile(s_tiles, tr, k)[rr * kMS + ccol];
+            const double z = yk - rows_sum(accj[k]);
+            if (lane < 16) s_z[lane] = z;
+            potrf_wave_sync();
+            const double* W = mtile(s_tiles, k, k);
+            double xv = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = crow + 4 * r;
+                if (row < mk) xv = fma(W[row * kMS + ccol], s_z[row], xv);  // W lower triangular: zero for row < ccol
+            }
+            xv = rows_sum(xv);
+            const bool real = ccol < mk;
+            if (lane < 16) {
+                s_x[16 * k + lane] = real ? xv : 0.0;
+                if (real) d.bs[16 * k + lane] = xv;
+            }
+            potrf_wave_sync();
+            double xr[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) xr[r] = s_x[16 * k + crow + 4 * r];
+#pragma unroll
+            for (int j = kSolveMfmaMaxTiles - 2; j >= 0; j--) {  // nearest block first: it is the next one needed
+                if (j >= k) continue;
+                const double* t = mtile(s_tiles, k, j);
+#pragma unroll
+                for (int r = 0; r < 4; r++) accj[j] = fma(t[(crow + 4 * r) * kMS + ccol], xr[r], accj[j]);
+            }
+        }
+    }
+    SO_POTRF_MARK(41);
+    if (tid == 0) d.partial[kBaSolveOk] = s_bad ? 0.0 : 1.0;
+}
+
+bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s) {
+    const int n = 6 * d.n_free, NT = (n + 1 + 15) / 16;
+    if (NT > kSolveMfmaMaxTiles || NT < 2) return false;
+    const size_t lds = sizeof(double) * (size_t)(NT * (NT + 1) / 2) * kMTile;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(double) * (kSolveMfmaMaxTiles * (kSolveMfmaMaxTiles + 1) / 2) * kMTile));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ba_solve_mfma_kernel, dim3(1), dim3(kSolveMfmaThreads), lds, s, d);
+    return true;
 }
 
 // ---- 96x96 tile of C = PA * PB^T on the FP64 matrix cores ----

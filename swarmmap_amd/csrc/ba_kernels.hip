@@ -1204,7 +1204,9 @@ static void launch_ba_schur(const BaDev& d, hipStream_t s) {
 
 static void launch_ba_solve(const BaDev& d, hipStream_t s) {
     const int NB = d.n_free + 1, nblk = NB * (NB + 1) / 2 - 1, rows = 6 * (d.n_free - 1) + 1;
-    static const bool classic = getenv("SWARMORB_BA_CLASSIC_SOLVER") != nullptr;  // A/B switch for profiling
+    static const bool classic = getenv("SWARMORB_BA_CLASSIC_SOLVER") != nullptr;  // A/B switches for profiling
+    static const bool no_mfma = getenv("SWARMORB_BA_NO_MFMA_SOLVER") != nullptr;
+    if (!classic && !no_mfma && d.n_free >= kBaMfmaSolverMinFree && launch_ba_solve_mfma(d, s)) return;
     if (!classic && nblk <= 256 && rows <= 2 * 58)
         hipLaunchKernelGGL((ba_solve_la_kernel<4, 2>), dim3(1), dim3(6 * 64), 0, s, d);
     else if (!classic && nblk <= 384 && rows <= 3 * 58)
