@@ -1,3 +1,5 @@
+"""Per-call time of the two tracking matchers (M1 / M2) through the ctypes mirror: wall, enqueue, wait, kernel.
+Developer tool:  python tools/match_probe.py  (on the GPU box)."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np

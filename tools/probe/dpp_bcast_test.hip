@@ -1,3 +1,5 @@
+// Checks v_fmac_f64_dpp with row_newbcast and a negated DPP operand on the device (developer tool):
+//   hipcc -O3 --offload-arch=gfx950 tools/probe/dpp_bcast_test.hip -o /tmp/t && /tmp/t     -> "bad 0"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(double* out, const double* in) {
