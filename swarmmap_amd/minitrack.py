@@ -1,5 +1,6 @@
 """A minimal monocular tracking replay over the hot path: extract -> frame post-processing -> SearchByProjection
-(last frame) -> PoseOptimization -> isInFrustum -> SearchByProjection (local map) -> PoseOptimization.
+(last frame) -> PoseOptimization -> isInFrustum -> SearchByProjection (local map) -> PoseOptimization, and, at
+every "keyframe", LocalBundleAdjustment over the recent keyframes.
 
 It is NOT the reference's Tracking state machine (out of scope): it is the shortest host loop that
 chains every per-frame operator the way Tracking::TrackWithMotionModel (code/src/Tracking.cc:984-1050) and
@@ -36,6 +37,7 @@ class HipBackend:
         self.m_last = ORBmatcher(0.9, True, device=device)    # Tracking.cc:998
         self.m_map = ORBmatcher(0.8, True, device=device)     # Tracking.cc:1153
         self.opt = Optimizer(device=device)
+        self.lba = Optimizer(device=device)                   # the local-mapping thread's solver context
 
     def tables(self):
         return (self.ex.GetScaleFactors(), self.ex.GetInverseScaleSigmaSquares())
@@ -60,8 +62,12 @@ class HipBackend:
         n, T, outl, _ = self.opt.PoseOptimization(Tcw, intr, Xw, obs, w)
         return n, T, outl
 
+    def local_ba(self, window):
+        r = self.lba.LocalBundleAdjustment(window)
+        return r["Tcw"], r["Xw"], r["outlier"]
+
     def close(self):
-        for o in (self.ex, self.fp, self.m_last, self.m_map, self.opt):
+        for o in (self.ex, self.fp, self.m_last, self.m_map, self.opt, self.lba):
             o.close()
 
 
@@ -83,8 +89,46 @@ def ground_truth(stream, n_frames, K, plane_z):
     return c
 
 
-def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_ratio=0.7):
-    """Returns dict(centres (n,3), poses (n,12), matches_last, matches_map, inliers, n_map_points)."""
+def _local_window(kfs, mp_X, intr, n_free=6, n_fixed=8):
+    """The window Optimizer::LocalBundleAdjustment gathers (code/src/Optimizer.cc:436-560), flattened: the last
+    n_free keyframes are free (keyframes 0 and 1 never: together they pin the monocular scale, as the initial map
+    does in the reference), the map points they see are the local points, up to n_fixed older keyframes seeing those
+    points are fixed.  Points with a single observation in the window are left out (they
+    were back-projected from one view).  Returns (problem, pose -> keyframe index, point -> map point index,
+    edge -> (keyframe, observation) index) or None."""
+    first_free = max(2, len(kfs) - n_free)
+    free = list(range(first_free, len(kfs)))
+    if not free:
+        return None
+    local = np.unique(np.concatenate([kfs[i]["mp"] for i in free]))
+    older = [i for i in range(first_free - 1, -1, -1) if np.isin(kfs[i]["mp"], local).any()][:n_fixed]
+    if len(older) < 2:
+        older = sorted(set(older) | {0, 1})
+    poses = sorted(older) + free
+    count = np.zeros(len(mp_X), np.int32)
+    for i in poses:
+        np.add.at(count, kfs[i]["mp"][np.isin(kfs[i]["mp"], local)], 1)
+    pts = local[count[local] >= 2]
+    if len(pts) < 10:
+        return None
+    slot = np.full(len(mp_X), -1, np.int64)
+    slot[pts] = np.arange(len(pts))
+    e_pose, e_pt, obs, w, ref = [], [], [], [], []
+    for p, i in enumerate(poses):
+        sel = np.nonzero(slot[kfs[i]["mp"]] >= 0)[0]
+        e_pose.append(np.full(len(sel), p, np.int32)); e_pt.append(slot[kfs[i]["mp"][sel]].astype(np.int32))
+        obs.append(kfs[i]["uv"][sel]); w.append(kfs[i]["w"][sel])
+        ref.append(np.stack([np.full(len(sel), i), sel], 1))
+    prob = dict(Tcw=np.stack([kfs[i]["T"][:3, :4].reshape(12) for i in poses]).astype(np.float32),
+                fixed=np.array([0 if i in free else 1 for i in poses], np.uint8),
+                intr=np.tile(np.asarray(intr, np.float32), (len(poses), 1)), Xw=mp_X[pts].astype(np.float32),
+                edge_pose=np.concatenate(e_pose), edge_point=np.concatenate(e_pt),
+                obs=np.concatenate(obs).astype(np.float32), inv_sigma2=np.concatenate(w).astype(np.float32))
+    return prob, poses, pts, np.concatenate(ref)
+
+
+def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_ratio=0.7, local_ba=False):
+    """Returns dict(centres (n,3), poses (n,12), matches_last, matches_map, inliers, n_map_points[, lba_*])."""
     intr = np.asarray(K, np.float32)
     fx, fy, cx, cy = [float(v) for v in intr]
     sf, inv_sigma2 = backend.tables()
@@ -121,7 +165,8 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
         return first
 
     poses, centres = [], []
-    log = dict(matches_last=[], matches_map=[], inliers=[], n_map_points=[])
+    kfs = []              # keyframes: pose + the observations LocalBundleAdjustment uses
+    log = dict(matches_last=[], matches_map=[], inliers=[], n_map_points=[], lba_edges=[], lba_outliers=[])
     T_last = np.eye(4)
     velocity = np.eye(4)
     last = None           # (xy_un, kps, desc, kp_mp, outlier)
@@ -140,6 +185,7 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
             kp_mp[:] = first + np.arange(n)
             kf_inliers = n
             outlier = np.zeros(n, bool)
+            kfs.append(dict(T=T.copy(), mp=kp_mp.copy(), uv=xy_un.copy(), w=inv_sigma2[kps["octave"]]))
             log["matches_last"].append(0); log["matches_map"].append(0); log["inliers"].append(n)
         else:
             # ---- TrackWithMotionModel: project the last frame's map points with the predicted pose -------------
@@ -197,6 +243,26 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
                     first = add_points(T, xy_un, kps, desc, fresh)
                     kp_mp[fresh] = first + np.arange(int(fresh.sum()))
                 kf_inliers = max(n_in, 1)
+                if local_ba:
+                    keep = (kp_mp >= 0) & ~outlier
+                    kfs.append(dict(T=T.copy(), mp=kp_mp[keep].copy(), uv=xy_un[keep].copy(),
+                                    w=inv_sigma2[kps["octave"][keep]]))
+                    win = _local_window(kfs, mp_X, intr)
+                    if win is not None:
+                        prob, pidx, pts, ref = win
+                        T_out, X_out, e_out = backend.local_ba(prob)
+                        for p, i in enumerate(pidx):          # SetPose of the free keyframes (Optimizer.cc:713-727)
+                            if not prob["fixed"][p]:
+                                kfs[i]["T"] = _T44(np.asarray(T_out[p], np.float32))
+                        mp_X[pts] = np.asarray(X_out, np.float32)            # SetWorldPos
+                        bad = np.asarray(e_out).astype(bool)                 # EraseMapPointMatch / EraseObservation
+                        for i in np.unique(ref[bad, 0]):
+                            drop = ref[bad & (ref[:, 0] == i), 1]
+                            m = np.ones(len(kfs[i]["mp"]), bool); m[drop] = False
+                            for key in ("mp", "uv", "w"):
+                                kfs[i][key] = kfs[i][key][m]
+                        T = kfs[-1]["T"].copy()               # the current frame is the newest keyframe
+                        log["lba_edges"].append(len(bad)); log["lba_outliers"].append(int(bad.sum()))
             velocity = T @ np.linalg.inv(T_last)
 
         poses.append(T[:3, :4].reshape(12).copy())

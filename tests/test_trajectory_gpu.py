@@ -36,3 +36,20 @@ def test_hip_and_oracle_trajectories_agree(size, K, nfeat, n):
     px = PLANE_Z / float(K[0])
     assert minitrack.ate_rmse(a["centres"], gt, align=False) < 0.75 * px
     assert abs(minitrack.ate_rmse(a["centres"], gt) - minitrack.ate_rmse(b["centres"], gt)) < 0.01 * px
+
+
+def test_tracking_plus_local_ba_trajectories_agree():
+    """The metric's second half: tracking + LocalBundleAdjustment.  LBA agrees with the oracle to 2e-5 per window
+    (tests/test_ba_gpu.py), a difference later match decisions can amplify: the bound is 1/40 of a pixel."""
+    n, K = 60, synth.EUROC_K
+    st = synth.FrameStream()
+    hip = minitrack.HipBackend(K, 1000)
+    a = minitrack.track(hip, st, n, K, plane_z=PLANE_Z, local_ba=True)
+    hip.close()
+    b = minitrack.track(OracleBackend(K, 1000), st, n, K, plane_z=PLANE_Z, local_ba=True)
+    gt = minitrack.ground_truth(st, n, K, PLANE_Z)
+    assert len(a["lba_edges"]) >= 5 and np.array_equal(a["lba_edges"], b["lba_edges"])
+    assert minitrack.ate_rmse(a["centres"], b["centres"], align=False) < 1e-4
+    assert np.abs(a["inliers"].astype(int) - b["inliers"].astype(int)).max() <= 5
+    px = PLANE_Z / float(K[0])
+    assert minitrack.ate_rmse(a["centres"], gt, align=False) < px

@@ -30,3 +30,15 @@ def test_oracle_trajectory_follows_ground_truth():
     assert np.abs(r["centres"] - gt).max() < 6e-3
     assert r["inliers"][1:].min() > 400 and r["matches_last"][1:].min() > 300
     assert r["n_map_points"][-1] > r["n_map_points"][0]      # the map grew at "keyframes"
+
+
+def test_oracle_trajectory_with_local_bundle_adjustment():
+    n = 40
+    K = synth.EUROC_K
+    st = synth.FrameStream()
+    r = minitrack.track(OracleBackend(K), st, n, K, plane_z=PLANE_Z, local_ba=True)
+    gt = minitrack.ground_truth(st, n, K, PLANE_Z)
+    assert len(r["lba_edges"]) >= 3 and r["lba_edges"].max() > 1000      # windows were optimised
+    assert r["lba_outliers"].sum() < 0.05 * r["lba_edges"].sum()
+    assert minitrack.ate_rmse(r["centres"], gt, align=False) < 4e-3       # still sub-pixel (4.4 mm)
+    assert r["inliers"][1:].min() > 400

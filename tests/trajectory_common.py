@@ -39,5 +39,9 @@ class OracleBackend:
         n, T, outl, _ = orc.pose_optimization(Tcw, intr, Xw, obs, w)
         return n, T, outl
 
+    def local_ba(self, window):
+        r = orc.bundle_adjust(window)
+        return r["Tcw"], r["Xw"], r["outlier"]
+
     def close(self):
         pass

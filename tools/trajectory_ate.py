@@ -18,15 +18,16 @@ PLANE_Z = 2.0
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    for name, size, K, nfeat in (("euroc_752x480", synth.EUROC, synth.EUROC_K, 1000),
-                                 ("kitti_1241x376", synth.KITTI, synth.KITTI_K, 2000)):
+    for name, size, K, nfeat, lba in (("euroc_752x480", synth.EUROC, synth.EUROC_K, 1000, False),
+                                      ("kitti_1241x376", synth.KITTI, synth.KITTI_K, 2000, False),
+                                      ("euroc_752x480 + LocalBundleAdjustment", synth.EUROC, synth.EUROC_K, 1000, True)):
         st = synth.FrameStream(size=size)
         hip = minitrack.HipBackend(K, nfeat)
         t0 = time.perf_counter()
-        a = minitrack.track(hip, st, n, K, plane_z=PLANE_Z)
+        a = minitrack.track(hip, st, n, K, plane_z=PLANE_Z, local_ba=lba)
         t1 = time.perf_counter()
         hip.close()
-        b = minitrack.track(OracleBackend(K, nfeat), st, n, K, plane_z=PLANE_Z)
+        b = minitrack.track(OracleBackend(K, nfeat), st, n, K, plane_z=PLANE_Z, local_ba=lba)
         t2 = time.perf_counter()
         gt = minitrack.ground_truth(st, n, K, PLANE_Z)
         path = float(np.linalg.norm(np.diff(gt, axis=0), axis=1).sum())
@@ -42,7 +43,8 @@ def main():
                                                     (a["matches_map"] != b["matches_map"])).sum()),
             frames_with_different_inlier_counts=int((a["inliers"] != b["inliers"]).sum()),
             map_points=[int(a["n_map_points"][-1]), int(b["n_map_points"][-1])],
-            mean_inliers=float(a["inliers"][1:].mean()),
+            mean_inliers=float(a["inliers"][1:].mean()), lba_windows=int(len(a["lba_edges"])),
+            lba_edges_mean=float(a["lba_edges"].mean()) if len(a["lba_edges"]) else 0.0,
             python_loop_s=dict(hip=t1 - t0, oracle=t2 - t1))))
 
 
