@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 PLANE_Z = 2.0
 # One pixel is plane_z / fx = 4.4 mm (EuRoC) / 2.8 mm (KITTI).  The two paths may differ by PoseOptimization's
 # floating-point tolerance (2e-5 per call, tests/test_pose_gpu.py) which a later match decision can amplify;
-# measured 1e-8 m over 300 frames (profiles/r1o_ate.jsonl); the bound below is 1/4000 of a pixel.
+# measured 1e-8 m over 300 frames (profiles/r1t_ate.jsonl); the bound below is 1/4000 of a pixel.
 ATE_HIP_VS_ORACLE = 1e-6
 
 
