@@ -273,3 +273,45 @@ def test_distinctive_descriptors_batch_matches_oracle(S, oracle):
     with pytest.raises(S.SwarmOrbError):
         m.ComputeDistinctiveDescriptors([0, 513], np.zeros((513, 32), np.uint8))
     m.close()
+
+
+@pytest.mark.parametrize("seed", [41, 42, 43])
+def test_window_queries_with_distorted_camera_bounds(S, oracle, seed):
+    """A distorted camera: mnMinX / mnMinY are negative, the grid cells are not 11.75 px wide and keypoints lie
+    outside [0, w) x [0, h).  The kernel scans only the grid columns GetFeaturesInArea visits (and tests the cell
+    row): the cell arithmetic has to agree with the reference's for every offset, including windows that leave the
+    grid on either side."""
+    rng = np.random.default_rng(seed)
+    w, h = synth.EUROC
+    bounds = (-41.37, w + 36.81, -27.55, h + 31.02)
+    fr, mps = synth.make_m1_case(seed, 1500, 3000)
+    fr["x"] = rng.uniform(bounds[0] - 1.0, bounds[1] + 1.0, len(fr["x"])).astype(np.float32)  # a few outside the grid
+    fr["y"] = rng.uniform(bounds[2] - 1.0, bounds[3] + 1.0, len(fr["y"])).astype(np.float32)
+    fr["bounds"] = bounds
+    k = rng.integers(0, len(fr["x"]), len(mps["proj_x"]))
+    mps["proj_x"] = (fr["x"][k] + rng.normal(0, 2.0, len(k))).astype(np.float32)
+    mps["proj_y"] = (fr["y"][k] + rng.normal(0, 2.0, len(k))).astype(np.float32)
+    far = rng.random(len(k)) < 0.1                      # windows hanging over / beyond the borders
+    mps["proj_x"][far] = rng.choice([bounds[0] - 30, bounds[0] + 1, bounds[1] - 1, bounds[1] + 30], far.sum()).astype(np.float32)
+    mps["desc"] = synth.flip_bits(rng, fr["desc"][k], 0.12)
+    F = _frame(fr)
+    m = S.ORBmatcher(0.8)
+    for th in (1.0, 4.0):
+        nm, kp_to_mp = m.SearchByProjectionMapPoints(F, mps, th)
+        onm, okp = oracle.search_by_projection_mappoints(F, mps, th, 0.8)
+        assert nm == onm and np.array_equal(kp_to_mp, okp)
+        assert nm > 100
+    fr2, last = synth.make_m2_case(seed + 100, 1500, 1500)
+    fr2["x"], fr2["y"], fr2["bounds"] = fr["x"], fr["y"], bounds
+    k2 = rng.integers(0, len(fr["x"]), len(last["u"]))
+    last["u"] = (fr["x"][k2] + rng.normal(0, 3.0, len(k2))).astype(np.float32)
+    last["v"] = (fr["y"][k2] + rng.normal(0, 3.0, len(k2))).astype(np.float32)
+    last["desc"] = synth.flip_bits(rng, fr2["desc"][k2], 0.1)
+    last["octave"] = np.clip(fr2["octave"][k2] + rng.integers(-1, 2, len(k2)), 0, 7).astype(np.int32)
+    last["angle"] = ((fr2["angle"][k2] + rng.normal(0, 2, len(k2))) % 360).astype(np.float32)
+    F2 = _frame(fr2)
+    nm, kp_to_last = m.SearchByProjectionLastFrame(F2, last, 15.0)
+    onm, okp = oracle.search_by_projection_lastframe(F2, last, 15.0, True)
+    assert nm == onm and np.array_equal(kp_to_last, okp)
+    assert nm > 100
+    m.close()
