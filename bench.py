@@ -302,7 +302,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or bool(os.environ.get("SWARMORB_BENCH_FORCE_DIST"))  # (the latter: 1-rank RCCL self-test)
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        for key, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(key, val)  # torchrun sets all four; the 1-rank self-test runs without it
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = local_rank if distributed else 0
