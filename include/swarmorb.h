@@ -259,6 +259,13 @@ int so_distinctive_descriptors(so_matcher* m, int32_t n_points, const int32_t* o
 /* HIP-event time (ms) of the kernels of the last matcher call on the matcher's stream. */
 int so_matcher_last_kernel_ms(so_matcher* m, float* ms);
 
+/* Tracking searches the same frame twice in a row (SearchByProjection against the last frame, Tracking.cc:1014, then
+ * against the local map, :1153).  Calling this before the second search tells the handle that the next call's frame
+ * view is the one of the previous call (same keypoints, descriptors and bounds; `excluded` may differ and is re-read):
+ * the grid ordering and the candidate upload are skipped.  One-shot: it applies to the next search call only, and
+ * is ignored if the handle no longer holds that frame. */
+int so_matcher_reuse_frame(so_matcher* m);
+
 /* Host-side view of the last matcher call: stats4[0] = ms spent enqueueing (staging copy + launch), [1] = ms
  * blocked in stream syncs, [2] = kernel launches (1 + exact re-runs of single queries), [3] = bytes staged
  * host -> device. */

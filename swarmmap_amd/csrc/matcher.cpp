@@ -137,6 +137,8 @@ struct so_matcher {
     int n_cand = 0;           // keypoints that are inside the grid (PosInGrid true)
     bool has_limit = false;
     bool has_cols = false;    // candidates are in grid-traversal order and the column table is staged
+    int resident_n = -1;      // F->n of the grid-ordered frame resident in the staging / device blocks (-1: none)
+    bool reuse_next = false;  // so_matcher_reuse_frame: the next call's frame is the resident one
     float min_x = 0.f, min_y = 0.f, grid_inv_w = 0.f, grid_inv_h = 0.f;
     std::vector<int> perm;     // rank -> keypoint index
     std::vector<int> rank_of;  // keypoint index -> rank (-1: not in grid)
@@ -172,6 +174,7 @@ int upload_ordered(so_matcher* m, int n, const float* x, const float* y, const i
     m->off_cols = align256(m->off_limit + sizeof(int32_t) * (size_t)nc);
     m->frame_end = align256(m->off_cols + sizeof(int32_t) * (kGridCols + 1));
     m->has_cols = false;
+    m->resident_n = -1;
     if ((rc = m->h_in.ensure_keep(m->frame_end + 256, 0))) return rc;
     uint8_t* base = (uint8_t*)m->h_in.p;
     float2* hxy = (float2*)base;
@@ -201,6 +204,24 @@ int upload_ordered(so_matcher* m, int n, const float* x, const float* y, const i
 // order inside a cell = keypoint index; code/src/Frame.cc:277-292,401-427) and upload the SoA.
 int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_idx) {
     const int n = F->n;
+    const bool reuse = m->reuse_next && m->resident_n == n && m->has_cols;
+    m->reuse_next = false;
+    if (reuse) {  // same frame as the previous call on this handle: only the eligibility gate is re-read
+        const bool want_limit = (F->excluded != nullptr) || (limit_by_idx != nullptr);
+        if (want_limit) {
+            int32_t* hl = (int32_t*)((uint8_t*)m->h_in.p + m->off_limit);
+            for (int r = 0; r < m->n_cand; r++) {
+                const int i = m->perm[(size_t)r];
+                int32_t lim = limit_by_idx ? limit_by_idx[i] : INT_MAX;
+                if (F->excluded && F->excluded[i]) lim = 0;
+                hl[r] = lim;
+            }
+            m->dirty_from = std::min(m->dirty_from, m->off_limit);
+        }
+        m->has_limit = want_limit;
+        m->h_q.p = m->h_qdesc.p = nullptr;
+        return SO_OK;
+    }
     m->cell_count.assign((size_t)kGridCols * kGridRows + 1, 0);
     std::vector<int>& cc = m->cell_count;
     std::vector<int> cell((size_t)n, -1);
@@ -224,6 +245,7 @@ int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_
     int32_t* cols = (int32_t*)((uint8_t*)m->h_in.p + m->off_cols);
     for (int px = 0; px <= kGridCols; px++) cols[px] = cc[(size_t)px * kGridRows];
     m->has_cols = true;
+    m->resident_n = n;
     m->min_x = F->min_x; m->min_y = F->min_y; m->grid_inv_w = F->grid_inv_w; m->grid_inv_h = F->grid_inv_h;
     return SO_OK;
 }
@@ -442,6 +464,12 @@ void so_matcher_destroy(so_matcher* m) {
 int so_matcher_last_kernel_ms(so_matcher* m, float* ms) {
     if (!m || !ms) return SO_ERR_INVALID_ARG;
     *ms = m->last_ms;
+    return SO_OK;
+}
+
+int so_matcher_reuse_frame(so_matcher* m) {
+    if (!m) return SO_ERR_INVALID_ARG;
+    m->reuse_next = true;
     return SO_OK;
 }
 
@@ -815,6 +843,7 @@ int so_distinctive_descriptors(so_matcher* m, int32_t n_points, const int32_t* o
     if ((rc = m->h_in.ensure_keep(in_bytes, 0))) return rc;
     if (m->d_in.cap < in_bytes && (rc = m->d_in.ensure(m->h_in.cap))) return rc;
     m->dirty_from = 0;  // the staging block no longer holds a candidate frame
+    m->resident_n = -1;
     if ((rc = m->h_out.ensure(sizeof(int32_t) * 2 * (size_t)n_points))) return rc;
     memcpy(m->h_in.p, offsets, sizeof(int32_t) * ((size_t)n_points + 1));
     if (total > 0) memcpy((uint8_t*)m->h_in.p + off_bytes, descriptors, (size_t)total * 32);

@@ -12,11 +12,27 @@ static void check(int status, const char* what) {
         throw std::runtime_error(std::string(what) + ": " + so_status_string(status) + " (" + so_last_error() + ")");
 }
 
+namespace {
+constexpr int kMaxDevices = 16;
+thread_local so_matcher* t_context[kMaxDevices] = {};  // one matcher context per (thread, device)
+}  // namespace
+
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri, int device) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
-    check(so_matcher_create(device, &handle_), "so_matcher_create");
+    if (device < 0 || device >= kMaxDevices) throw std::runtime_error("ORBmatcher: device index out of range");
+    if (!t_context[device]) check(so_matcher_create(device, &t_context[device]), "so_matcher_create");
+    handle_ = t_context[device];
 }
 
-ORBmatcher::~ORBmatcher() { so_matcher_destroy(handle_); }
+ORBmatcher::~ORBmatcher() {}  // the context belongs to the thread
+
+void ORBmatcher::ReleaseThreadContext() {
+    for (so_matcher*& h : t_context) {
+        if (h) so_matcher_destroy(h);
+        h = nullptr;
+    }
+}
+
+void ORBmatcher::SameFrameAsPreviousSearch() { check(so_matcher_reuse_frame(handle_), "so_matcher_reuse_frame"); }
 
 int ORBmatcher::DescriptorDistance(const uint8_t* a, const uint8_t* b) {  // ORBmatcher.cc:1511-1525
     int dist = 0;

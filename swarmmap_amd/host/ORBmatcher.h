@@ -29,8 +29,15 @@ class ORBmatcher {
 public:
     static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;  // code/src/ORBmatcher.cc:37-39
 
+    // The reference constructs an ORBmatcher on the stack at every call site (Tracking.cc:470,623,715,998,1153 ...):
+    // construction must be free.  All ORBmatcher objects of a thread share one device context (pinned staging, HBM
+    // buffers, stream), created on the thread's first use of a device and kept until ReleaseThreadContext().
     ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device = 0);
     ~ORBmatcher();
+    static void ReleaseThreadContext();
+    // The next search of this thread looks at the same Frame as its previous one (TrackWithMotionModel's
+    // SearchByProjection followed by SearchLocalPoints' on mCurrentFrame): the candidate upload is skipped.
+    void SameFrameAsPreviousSearch();
     ORBmatcher(const ORBmatcher&) = delete;
     ORBmatcher& operator=(const ORBmatcher&) = delete;
 

@@ -52,8 +52,7 @@ struct BaWindow {
 struct so_replay {
     int device = 0, width = 0, height = 0, lba_every = 5;
     so_extractor* ex = nullptr;
-    so_matcher* m2 = nullptr;
-    so_matcher* m1 = nullptr;
+    so_matcher* matcher = nullptr;  // one per tracking thread: both searches of a frame share its candidate upload
     so_ba* tracker_opt = nullptr;
     so_ba* mapper_opt = nullptr;
     std::vector<const uint8_t*> frames;
@@ -157,8 +156,7 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
     r->lba_every = lba_every > 0 ? lba_every : 5;
     so_extractor_config cfg{nfeatures, 1.2f, 8, 20, 7, device};
     int rc = so_extractor_create(&cfg, &r->ex);
-    if (rc == SO_OK) rc = so_matcher_create(device, &r->m2);
-    if (rc == SO_OK) rc = so_matcher_create(device, &r->m1);
+    if (rc == SO_OK) rc = so_matcher_create(device, &r->matcher);
     if (rc == SO_OK) rc = so_ba_create(device, &r->tracker_opt);
     if (rc == SO_OK) rc = so_ba_create(device, &r->mapper_opt);
     if (rc != SO_OK) {
@@ -191,8 +189,7 @@ void so_replay_destroy(so_replay* r) {
         (void)so_extractor_collect(r->ex, r->kps.data(), r->desc.data(), (int)r->kps.size(), &n);
     }
     so_extractor_destroy(r->ex);
-    so_matcher_destroy(r->m2);
-    so_matcher_destroy(r->m1);
+    so_matcher_destroy(r->matcher);
     so_ba_destroy(r->tracker_opt);
     so_ba_destroy(r->mapper_opt);
     delete r;
@@ -326,17 +323,18 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
         const StepInputs& s = r->steps[(size_t)t];
         int32_t nm2 = 0, nm1 = 0;
         float k2 = 0.f, k1 = 0.f;
-        if (so_search_by_projection_lastframe(r->m2, &F, (int32_t)s.last_u.size(), s.last_valid.data(), s.last_u.data(),
+        if (so_search_by_projection_lastframe(r->matcher, &F, (int32_t)s.last_u.size(), s.last_valid.data(), s.last_u.data(),
                                               s.last_v.data(), s.last_octave.data(), s.last_angle.data(),
                                               s.last_desc.data(), s.last_has_obs.data(), 15.0f, 1, r->kp_to.data(),
                                               &nm2) != SO_OK)
             return fail(r, "so_search_by_projection_lastframe");
-        so_matcher_last_kernel_ms(r->m2, &k2);
-        if (so_search_by_projection_mappoints(r->m1, &F, (int32_t)s.mp_x.size(), s.mp_in_view.data(), s.mp_x.data(),
+        so_matcher_last_kernel_ms(r->matcher, &k2);
+        so_matcher_reuse_frame(r->matcher);  // the local-map search looks at the same frame (Tracking.cc:1014 then :1153)
+        if (so_search_by_projection_mappoints(r->matcher, &F, (int32_t)s.mp_x.size(), s.mp_in_view.data(), s.mp_x.data(),
                                               s.mp_y.data(), s.mp_cos.data(), s.mp_level.data(), s.mp_desc.data(),
                                               s.mp_has_obs.data(), 1.0f, 0.8f, r->kp_to.data(), &nm1) != SO_OK)
             return fail(r, "so_search_by_projection_mappoints");
-        so_matcher_last_kernel_ms(r->m1, &k1);
+        so_matcher_last_kernel_ms(r->matcher, &k1);
         const double t2 = now_ms();
         double pose_kernel = 0.0, pose_trials = 0.0;
         for (int j = 0; j < 3; j++) {
@@ -412,6 +410,6 @@ int so_replay_last_frame(so_replay* r, const uint8_t** desc, int* n) {
     return SO_OK;
 }
 so_extractor* so_replay_extractor(so_replay* r) { return r ? r->ex : nullptr; }
-so_matcher* so_replay_matcher(so_replay* r) { return r ? r->m1 : nullptr; }
+so_matcher* so_replay_matcher(so_replay* r) { return r ? r->matcher : nullptr; }
 
 }  // extern "C"

@@ -61,6 +61,7 @@ def _bind(lib):
     lib.so_hamming_top2_device.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, vp, vp]
     lib.so_matcher_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.so_matcher_last_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.so_matcher_reuse_frame.argtypes = [vp]
 
 
 class ORBmatcher:
@@ -102,6 +103,10 @@ class ORBmatcher:
         self._lib.so_distinctive_descriptors.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.check(self._lib.so_distinctive_descriptors(self._h, n, _vp(off), _vp(d), _vp(idx), _vp(med)))
         return idx, med
+
+    def reuse_frame(self):
+        """The next search looks at the same frame as the previous one on this matcher (one-shot)."""
+        _lib.check(self._lib.so_matcher_reuse_frame(self._h))
 
     def last_stats(self):
         st = (C.c_double * 4)()

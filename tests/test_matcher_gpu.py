@@ -315,3 +315,42 @@ def test_window_queries_with_distorted_camera_bounds(S, oracle, seed):
     assert nm == onm and np.array_equal(kp_to_last, okp)
     assert nm > 100
     m.close()
+
+
+def test_reuse_frame_between_the_two_tracking_searches(S, oracle):
+    """so_matcher_reuse_frame: the second search of a frame skips the candidate upload; `excluded` is re-read."""
+    fr, last = synth.make_m2_case(51, 1200, 1200)
+    _, mps = synth.make_m1_case(52, 1200, 2500)
+    F = _frame(fr, excluded=False)
+    m = S.ORBmatcher(0.9, True)
+    nm2, k2l = m.SearchByProjectionLastFrame(F, last, 15.0)
+    onm2, ok2l = oracle.search_by_projection_lastframe(F, last, 15.0, True)
+    assert nm2 == onm2 and np.array_equal(k2l, ok2l)
+    # keypoints bound by the first search are excluded from the second (Tracking: mvpMapPoints[i] with observations)
+    k = np.random.default_rng(5).integers(0, F.n, len(mps["proj_x"]))
+    mps["proj_x"] = (fr["x"][k] + 1.5).astype(np.float32); mps["proj_y"] = (fr["y"][k] - 1.0).astype(np.float32)
+    mps["desc"] = synth.flip_bits(np.random.default_rng(6), fr["desc"][k], 0.1)
+    F2 = FrameView(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["bounds"], fr["scale_factors"],
+                   (k2l >= 0).astype(np.uint8))
+    staged_full = None
+    for reuse in (False, True):
+        if reuse:
+            m.SearchByProjectionLastFrame(F, last, 15.0)   # the frame is resident again
+            m.reuse_frame()
+        m.mfNNratio = 0.8
+        nm1, k2m = m.SearchByProjectionMapPoints(F2, mps, 1.0)
+        onm1, ok2m = oracle.search_by_projection_mappoints(F2, mps, 1.0, 0.8)
+        assert nm1 == onm1 and np.array_equal(k2m, ok2m) and nm1 > 100
+        staged = m.last_stats()["staged_bytes"]
+        if not reuse:
+            staged_full = staged
+        else:
+            assert staged < staged_full - 32 * F.n          # descriptors and positions were not sent again
+    # a stale request (different frame size) is ignored, not trusted
+    fr3, mps3 = synth.make_m1_case(53, 900, 1500)
+    F3 = _frame(fr3)
+    m.reuse_frame()
+    nm, out = m.SearchByProjectionMapPoints(F3, mps3, 1.0)
+    onm, oout = oracle.search_by_projection_mappoints(F3, mps3, 1.0, 0.8)
+    assert nm == onm and np.array_equal(out, oout)
+    m.close()
