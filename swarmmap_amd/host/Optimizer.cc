@@ -14,6 +14,24 @@ static void check(int status, const char* what) {
 Optimizer::Optimizer(int device) { check(so_ba_create(device, &handle_), "so_ba_create"); }
 Optimizer::~Optimizer() { so_ba_destroy(handle_); }
 
+namespace {
+constexpr int kMaxDevices = 16;
+thread_local Optimizer* t_instance[kMaxDevices] = {};
+}  // namespace
+
+Optimizer& Optimizer::ThreadInstance(int device) {
+    if (device < 0 || device >= kMaxDevices) throw std::runtime_error("Optimizer: device index out of range");
+    if (!t_instance[device]) t_instance[device] = new Optimizer(device);
+    return *t_instance[device];
+}
+
+void Optimizer::ReleaseThreadInstance() {
+    for (Optimizer*& o : t_instance) {
+        delete o;
+        o = nullptr;
+    }
+}
+
 void Optimizer::solve(const BAWindow& w, const so_ba_options& opt, bool* pbStopFlag, BAResult& out) {
     static_assert(sizeof(bool) == 1, "pbStopFlag is polled as a byte");
     so_ba_problem p{};

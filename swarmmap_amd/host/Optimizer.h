@@ -33,6 +33,13 @@ public:
     ~Optimizer();
     Optimizer(const Optimizer&) = delete;
     Optimizer& operator=(const Optimizer&) = delete;
+    // The reference's methods are static (call sites read Optimizer::PoseOptimization(&mCurrentFrame),
+    // Optimizer::LocalBundleAdjustment(mpCurrentKeyFrame, &mbAbortBA, mpMap)); the solver context has to live
+    // somewhere.  ThreadInstance() is the calling thread's context for a device, created on first use and kept until
+    // ReleaseThreadInstance(): Tracking's PoseOptimization and LocalMapping's bundle adjustment get one each (and
+    // with it their own streams), with no object to thread through the reference's call sites.
+    static Optimizer& ThreadInstance(int device = 0);
+    static void ReleaseThreadInstance();
 
     // void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap)
     void LocalBundleAdjustment(const BAWindow& window, bool* pbStopFlag, BAResult& out);

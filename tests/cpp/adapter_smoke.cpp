@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
             win.inv_sigma2.push_back(1.0f);
         }
     }
-    ORB_SLAM2::Optimizer optimizer;
+    ORB_SLAM2::Optimizer& optimizer = ORB_SLAM2::Optimizer::ThreadInstance();  // static call sites, as in the reference
     ORB_SLAM2::BAResult res;
     bool stop = false;
     optimizer.LocalBundleAdjustment(win, &stop, res);
