@@ -11,6 +11,8 @@
 
 namespace ORB_SLAM2 {
 
+// One object per camera and tracking thread, kept for the whole sequence (it owns the device context and the state
+// the reference keeps in Frame's static members: calibration, image bounds, mbInitialComputations) - not one per image.
 class Frame {
 public:
     // K = (fx, fy, cx, cy), distCoef = (k1, k2, p1, p2[, k3]) as read from the settings file (Tracking.cc:60-84)
