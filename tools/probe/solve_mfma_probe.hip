@@ -21,6 +21,7 @@ int main(int argc, char** argv) {
             S[(size_t)i * n + j] = a + (i == j ? n : 0);
         }
     for (auto& v : b) v = (rand() / (double)RAND_MAX) - 0.5;
+    if (argc > 2) S[(size_t)atoi(argv[2]) * n + atoi(argv[2])] = -1.0;  // argv[2]: make this pivot fail
     double *dS, *db, *db0, *dp;
     long long* dm;
     hipMalloc(&dS, sizeof(double) * n * n); hipMalloc(&db, sizeof(double) * n); hipMalloc(&db0, sizeof(double) * n);
@@ -46,7 +47,8 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n; i++) { double a = -b[i]; for (int j = 0; j < n; j++) a += S[(size_t)i * n + j] * x[j]; res = fmax(res, fabs(a)); }
     std::vector<long long> m(64); hipMemcpy(m.data(), dm, sizeof(long long) * 64, hipMemcpyDeviceToHost);
     const int NT = (n + 1 + 15) / 16;
-    printf("nf %d n %d tiles %d: kernel %.2f us, |S x - b| = %.3g\n", nf, n, NT, best * 1e3, res);
+    double okflag = -1; hipMemcpy(&okflag, dp + kBaSolveOk, sizeof(double), hipMemcpyDeviceToHost);
+    printf("nf %d n %d tiles %d: kernel %.2f us, |S x - b| = %.3g, solve_ok %.1f\n", nf, n, NT, best * 1e3, res, okflag);
     printf("diag0 %lld\n", m[1] - m[0]);
     for (int jb = 0; jb + 1 < NT; jb++)
         printf("jb %d: panel+barrier %lld  wave0 tile+diag16 %lld  wait %lld\n", jb, m[2 + 3*jb] - m[1 + 3*jb], m[3 + 3*jb] - m[2 + 3*jb], m[4 + 3*jb] - m[3 + 3*jb]);
