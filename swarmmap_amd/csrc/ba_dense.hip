@@ -448,11 +448,13 @@ bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s) {
     const int n = 6 * d.n_free, NT = (n + 1 + 15) / 16;
     if (NT > kSolveMfmaMaxTiles || NT < 2) return false;
     const size_t lds = sizeof(double) * (size_t)(NT * (NT + 1) / 2) * kMTile;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // the attribute is per device; racing threads set the same value
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(double) * (kSolveMfmaMaxTiles * (kSolveMfmaMaxTiles + 1) / 2) * kMTile));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(ba_solve_mfma_kernel, dim3(1), dim3(kSolveMfmaThreads), lds, s, d);
     return true;

@@ -2047,9 +2047,14 @@ void launch_pose_opt(const PoseOptArgs& a, hipStream_t s) {
     static const bool classic = getenv("SWARMORB_POSE_CLASSIC") != nullptr;  // A/B switch for profiling
     if (a.n <= kPoLdsMax && !classic) {
         const size_t lds = sizeof(double) * 2 * (size_t)a.n + sizeof(float) * 6 * (size_t)a.n + (size_t)a.n + 16;
-        static const hipError_t big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(pose_opt_lds_kernel<512>),
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-        (void)big_lds;  // 41 B per edge: 3072 edges = 126 KB of the CU's 160 KB
+        static bool big_lds[64] = {};  // per device; 41 B per edge: 3072 edges = 126 KB of the CU's 160 KB
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !big_lds[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pose_opt_lds_kernel<512>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            big_lds[dev] = true;
+        }
         // 256 threads (one wave per SIMD, 2-3 edges per thread) up to 640 points: measured 117 us vs 122 us with 512
         // and 144 us with 128 threads at n = 500
         if (a.n <= 640) hipLaunchKernelGGL(pose_opt_lds_kernel<256>, dim3(1), dim3(256), lds, s, a);
