@@ -7,7 +7,7 @@
 //     desc    2 x uint4 (32 B) per keypoint
 //     limit   i32 optional dynamic gate: candidate is eligible iff dist < limit (0 = taken, INT_MAX = free)
 //     cols    i32 x 65 first position of each grid column (window queries scan only their GetFeaturesInArea columns)
-//   queries: MatchQuery (24 B) + 32-B descriptor each; results: K u32 keys (dist << 16 | position) per query.
+//   queries: MatchQuery (56 B) or MatchQueryW (16 B) + 32-B descriptor each; results: K u32 keys (dist << 16 | position) per query.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -51,8 +51,17 @@ struct MatchQuery {
     int32_t pad;
 };
 
+// The two tracking searches (SearchByProjection against the local map / the last frame) only need the window and
+// the level range: 16 B per query instead of 56 on the way up (thousands of queries per call).
+struct MatchQueryW {
+    float u, v, r;
+    int8_t min_level, max_level;
+    uint8_t active, pad;
+};
+
 void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_t s);
-void launch_topk_window(const MatchFrameDev& F, const MatchQuery* d_q, const uint4* d_qdesc, int nq, int K,
+// compact: d_q points to MatchQueryW records instead of MatchQuery
+void launch_topk_window(const MatchFrameDev& F, const void* d_q, bool compact, const uint4* d_qdesc, int nq, int K,
                         uint32_t* d_keys, int32_t* d_count, hipStream_t s);
 constexpr int kDistinctiveMaxObs = 512;
 void launch_distinctive_desc(const uint4* d_desc, const int32_t* d_off, int n_points, int32_t* d_best_idx,

@@ -95,7 +95,8 @@ __device__ __forceinline__ uint32_t make_key(const MatchQuery& Q, int dist, int 
     return ((uint32_t)dist << 16) | (uint32_t)((Q.flags & kQPreferLast) ? (0xFFFF - c) : c);
 }
 
-__global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const MatchQuery* __restrict__ q,
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const void* __restrict__ q,
                                                            const uint4* __restrict__ qdesc, int nq, int K,
                                                            uint32_t* __restrict__ out_keys,
                                                            int32_t* __restrict__ out_count) {
@@ -103,7 +104,17 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int qi = blockIdx.x * 4 + w;
     if (qi >= nq) return;
-    const MatchQuery Q = q[qi];
+    MatchQuery Q;
+    if (COMPACT) {
+        const MatchQueryW c = static_cast<const MatchQueryW*>(q)[qi];
+        Q = MatchQuery{};
+        Q.u = c.u; Q.v = c.v; Q.r = c.r;
+        Q.min_level = c.min_level; Q.max_level = c.max_level;
+        Q.active = c.active;
+        Q.max_dist = 256;
+    } else {
+        Q = static_cast<const MatchQuery*>(q)[qi];
+    }
     if (!Q.active) {
         if (lane == 0) out_count[qi] = 0;
         for (int k = lane; k < K; k += 64) out_keys[(size_t)qi * K + k] = 0xFFFFFFFFu;
@@ -191,11 +202,15 @@ void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_
     hipLaunchKernelGGL(stage_in_kernel, dim3(blocks), dim3(256), 0, s, (uint4*)dst, (const uint4*)src_mapped, n16);
 }
 
-void launch_topk_window(const MatchFrameDev& F, const MatchQuery* d_q, const uint4* d_qdesc, int nq, int K,
+void launch_topk_window(const MatchFrameDev& F, const void* d_q, bool compact, const uint4* d_qdesc, int nq, int K,
                         uint32_t* d_keys, int32_t* d_count, hipStream_t s) {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(topk_window_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, F, d_q, d_qdesc, nq, K, d_keys,
-                       d_count);
+    if (compact)
+        hipLaunchKernelGGL(topk_window_kernel<true>, dim3((nq + 3) / 4), dim3(256), 0, s, F, d_q, d_qdesc, nq, K, d_keys,
+                           d_count);
+    else
+        hipLaunchKernelGGL(topk_window_kernel<false>, dim3((nq + 3) / 4), dim3(256), 0, s, F, d_q, d_qdesc, nq, K, d_keys,
+                           d_count);
 }
 
 // Brute-force best / second-best of each row of A against all rows of B; ties: lowest index in B.

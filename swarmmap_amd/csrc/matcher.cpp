@@ -250,6 +250,18 @@ int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_
     return SO_OK;
 }
 
+inline MatchQuery expand_query(const MatchQueryW& c) {
+    MatchQuery q;
+    memset(&q, 0, sizeof(q));
+    q.u = c.u; q.v = c.v; q.r = c.r;
+    q.min_level = c.min_level; q.max_level = c.max_level;
+    q.active = c.active;
+    q.max_dist = 256;
+    return q;
+}
+
+inline int8_t level8(int l) { return (int8_t)(l < -128 ? -128 : (l > 127 ? 127 : l)); }
+
 inline void init_query(MatchQuery& q) {
     memset(&q, 0, sizeof(q));
     q.max_dist = 256;
@@ -285,7 +297,7 @@ MatchFrameDev frame_dev(const so_matcher* m) {
 }
 
 // queries must already be in m->h_q / m->h_qdesc (ensure_queries).  Results land in m->h_keys / m->h_count.
-int run_topk(so_matcher* m, int nq, int K) {
+int run_topk(so_matcher* m, int nq, int K, bool compact = false) {
     if (nq <= 0) return SO_OK;
     int rc;
     const size_t total = m->off_qdesc + (size_t)nq * 32;
@@ -304,7 +316,7 @@ int run_topk(so_matcher* m, int nq, int K) {
     }
     m->dirty_from = SIZE_MAX;
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
-    launch_topk_window(frame_dev(m), (const MatchQuery*)((const uint8_t*)m->d_in.p + m->off_q),
+    launch_topk_window(frame_dev(m), (const uint8_t*)m->d_in.p + m->off_q, compact,
                        (const uint4*)((const uint8_t*)m->d_in.p + m->off_qdesc), nq, K, (uint32_t*)m->h_out.dev,
                        (int32_t*)((uint8_t*)m->h_out.dev + keys_bytes), s);
     if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
@@ -324,10 +336,10 @@ int run_topk(so_matcher* m, int nq, int K) {
 }
 
 // Reserve the query part of the staging buffer behind the frame part (which is kept).
-int ensure_queries(so_matcher* m, int nq) {
+int ensure_queries(so_matcher* m, int nq, size_t record = sizeof(MatchQuery)) {
     const size_t n = (size_t)(nq > 0 ? nq : 1);
     m->off_q = m->frame_end;
-    m->off_qdesc = align256(m->off_q + sizeof(MatchQuery) * n);
+    m->off_qdesc = align256(m->off_q + record * n);
     int rc = m->h_in.ensure_keep(m->off_qdesc + n * 32 + 256, m->frame_end);
     if (rc) return rc;
     m->h_q.p = (uint8_t*)m->h_in.p + m->off_q;
@@ -361,7 +373,7 @@ int rerun_single(so_matcher* m, const MatchQuery& q, const uint8_t* qdesc, const
     m->dirty_from = SIZE_MAX;
     launch_stage_in(m->d_rq.p, m->h_rq.p, kQ, s);
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
-    launch_topk_window(frame_dev(m), (const MatchQuery*)m->d_rq.p, (const uint4*)((const uint8_t*)m->d_rq.p + 128), 1, K,
+    launch_topk_window(frame_dev(m), m->d_rq.p, false, (const uint4*)((const uint8_t*)m->d_rq.p + 128), 1, K,
                        (uint32_t*)m->h_rout.dev, (int32_t*)((uint8_t*)m->h_rout.dev + 256), s);
     if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
     SO_HIP(hipGetLastError());
@@ -539,28 +551,28 @@ int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int
     constexpr int K = 8;
     int rc = upload_frame(m, F, nullptr);
     if (rc) return rc;
-    if ((rc = ensure_queries(m, n_mp))) return rc;
-    MatchQuery* hq = (MatchQuery*)m->h_q.p;
+    if ((rc = ensure_queries(m, n_mp, sizeof(MatchQueryW)))) return rc;
+    MatchQueryW* hq = (MatchQueryW*)m->h_q.p;
     const bool bFactor = th != 1.0f;
     for (int i = 0; i < n_mp; i++) {
-        MatchQuery& q = hq[i];
-        init_query(q);
-        q.active = in_view[i] != 0;
+        MatchQueryW& q = hq[i];
         const int lvl = pred_level[i];
+        const bool level_ok = lvl >= 0 && lvl < F->nlevels;
+        q.active = (in_view[i] != 0 && level_ok) ? 1 : 0;
         float r = view_cos[i] > 0.998f ? 2.5f : 4.0f;  // RadiusByViewingCos, :123-128
         if (bFactor) r *= th;
         q.u = proj_x[i];
         q.v = proj_y[i];
-        q.r = (q.active && lvl >= 0 && lvl < F->nlevels) ? r * F->scale_factors[lvl] : 0.f;
-        if (!(lvl >= 0 && lvl < F->nlevels)) q.active = 0;
-        q.min_level = lvl - 1;
-        q.max_level = lvl;
+        q.r = q.active ? r * F->scale_factors[lvl] : 0.f;
+        q.min_level = level8(lvl - 1);
+        q.max_level = level8(lvl);
+        q.pad = 0;
     }
     memcpy(m->h_qdesc.p, mp_desc, (size_t)n_mp * 32);
-    if ((rc = run_topk(m, n_mp, K))) return rc;
+    if ((rc = run_topk(m, n_mp, K, true))) return rc;
     const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
     const int32_t* cnt = (const int32_t*)m->h_count.p;
-    const MatchQuery* queries = hq;
+    const MatchQueryW* queries = hq;
     std::vector<int32_t> gate;
     int nm = 0;
     for (int i = 0; i < n_mp; i++) {
@@ -581,7 +593,7 @@ int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int
             gate.assign((size_t)F->n, INT_MAX);
             for (int k = 0; k < F->n; k++)
                 if ((F->excluded && F->excluded[k]) || (kp_to_mp[k] >= 0 && mp_has_obs[kp_to_mp[k]])) gate[(size_t)k] = 0;
-            if ((rc = rerun_single(m, queries[(size_t)i], mp_desc + (size_t)i * 32, gate, 2, e, &found))) return rc;
+            if ((rc = rerun_single(m, expand_query(queries[(size_t)i]), mp_desc + (size_t)i * 32, gate, 2, e, &found))) return rc;
         }
         if (found == 0) continue;
         const int bestDist = e[0].dist, bestIdx = e[0].idx, bestLevel = F->octave[bestIdx];
@@ -615,24 +627,24 @@ int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, i
     constexpr int K = 8;  // deep enough that a list exhausted by already-bound keypoints (exact re-run) is rare
     int rc = upload_frame(m, cur, nullptr);
     if (rc) return rc;
-    if ((rc = ensure_queries(m, n_last))) return rc;
-    MatchQuery* hq = (MatchQuery*)m->h_q.p;
+    if ((rc = ensure_queries(m, n_last, sizeof(MatchQueryW)))) return rc;
+    MatchQueryW* hq = (MatchQueryW*)m->h_q.p;
     for (int i = 0; i < n_last; i++) {
-        MatchQuery& q = hq[i];
-        init_query(q);
+        MatchQueryW& q = hq[i];
         const int oct = last_octave[i];
-        q.active = valid[i] != 0 && oct >= 0 && oct < cur->nlevels;
+        q.active = (valid[i] != 0 && oct >= 0 && oct < cur->nlevels) ? 1 : 0;
         q.u = u[i];
         q.v = v[i];
         q.r = q.active ? th * cur->scale_factors[oct] : 0.f;  // :1276
-        q.min_level = oct - 1;                                 // :1285
-        q.max_level = oct + 1;
+        q.min_level = level8(oct - 1);                         // :1285
+        q.max_level = level8(oct + 1);
+        q.pad = 0;
     }
     memcpy(m->h_qdesc.p, mp_desc, (size_t)n_last * 32);
-    if ((rc = run_topk(m, n_last, K))) return rc;
+    if ((rc = run_topk(m, n_last, K, true))) return rc;
     const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
     const int32_t* cnt = (const int32_t*)m->h_count.p;
-    const MatchQuery* queries = hq;
+    const MatchQueryW* queries = hq;
     std::vector<int32_t> gate;
     std::vector<int> rot_item, rot_b;
     int hist[HISTO_LENGTH] = {0};
@@ -655,7 +667,7 @@ int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, i
             for (int k = 0; k < cur->n; k++)
                 if ((cur->excluded && cur->excluded[k]) || (kp_to_last[k] >= 0 && mp_has_obs[kp_to_last[k]]))
                     gate[(size_t)k] = 0;
-            if ((rc = rerun_single(m, queries[(size_t)i], mp_desc + (size_t)i * 32, gate, 1, e, &found))) return rc;
+            if ((rc = rerun_single(m, expand_query(queries[(size_t)i]), mp_desc + (size_t)i * 32, gate, 1, e, &found))) return rc;
         }
         if (found == 0) continue;
         if (e[0].dist <= TH_HIGH) {
