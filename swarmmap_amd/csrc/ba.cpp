@@ -111,6 +111,7 @@ struct so_ba {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;  // around the PoseOptimization kernel (its own pair: another thread may be in so_bundle_adjust)
     float pose_kernel_ms = 0.f;
+    bool pose_ms_pending = false;  // pe0 / pe1 hold a finished measurement not yet read
     static constexpr int kSolveEvents = 32;  // the first trials of a call are event-timed around the solve kernel
     hipEvent_t ev_solve[2 * kSolveEvents] = {nullptr};
     float solve_ms = 0.f;
@@ -439,7 +440,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         }
     }
     for (int i = 0; i < nL; i++) h_ptact[i] = h_ptoff[i + 1] > h_ptoff[i];
-    const bool trace = getenv("SWARMORB_BA_TRACE") != nullptr;
+    static const bool trace = getenv("SWARMORB_BA_TRACE") != nullptr;
     const double t_staged = now_ms();
 
     if (!b->stream) SO_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
@@ -673,7 +674,8 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     // Frames of ordinary size (<= 3072 matched points) run the LDS-resident kernel, which reads its inputs once and
     // writes three small results: both go through host-mapped memory, so the call is one launch and one sync with
     // no copies to enqueue.  Larger problems re-read the edges every trial and therefore get a device copy.
-    const bool zero_copy = n <= kPoseOptLdsMax && !getenv("SWARMORB_POSE_CLASSIC");
+    static const bool env_classic = getenv("SWARMORB_POSE_CLASSIC") != nullptr, env_trace = getenv("SWARMORB_POSE_TRACE") != nullptr;
+    const bool zero_copy = n <= kPoseOptLdsMax && !env_classic;
     uint8_t* hout = h + in_bytes;
     PoseOptArgs a;
     if (zero_copy) {
@@ -696,14 +698,14 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     pose_from_Tcw(Tcw12, a.init);  // Converter::toSE3Quat(pFrame->mTcw)
     a.n = n;
     a.err = reinterpret_cast<double*>(d + off_err);
-    a.trace = getenv("SWARMORB_POSE_TRACE") ? reinterpret_cast<double*>(d + off_trace) : nullptr;
+    a.trace = env_trace ? reinterpret_cast<double*>(d + off_trace) : nullptr;
     SO_HIP(hipEventRecord(b->pe0, s));
     launch_pose_opt(a, s);
     SO_HIP(hipEventRecord(b->pe1, s));
     SO_HIP(hipGetLastError());
     if (!zero_copy) SO_HIP(hipMemcpyAsync(hout, d + off_pose, 64 + 16 + (size_t)n, hipMemcpyDeviceToHost, s));
     SO_HIP(hipStreamSynchronize(s));
-    (void)hipEventElapsedTime(&b->pose_kernel_ms, b->pe0, b->pe1);
+    b->pose_ms_pending = true;  // both events have completed; the elapsed time is read when somebody asks for it
     BaPose P;
     memcpy(&P, hout, sizeof(BaPose));
     int inf[4];
@@ -726,6 +728,10 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
 
 int so_pose_optimization_last_kernel_ms(so_ba* b, float* ms) {
     if (!b || !ms) return SO_ERR_INVALID_ARG;
+    if (b->pose_ms_pending) {
+        (void)hipEventElapsedTime(&b->pose_kernel_ms, b->pe0, b->pe1);
+        b->pose_ms_pending = false;
+    }
     *ms = b->pose_kernel_ms;
     return SO_OK;
 }

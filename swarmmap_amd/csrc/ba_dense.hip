@@ -706,7 +706,8 @@ void launch_ba_dense_solve(const BaDev& d, hipStream_t s) {
     const int T = d.ldS / kDNB;
     hipStream_t side = d.dense_side;
     hipEvent_t* ev = d.dense_events;
-    const bool lookahead = side && ev && T >= 32 && T <= kDenseMaxPanels && !getenv("SWARMORB_DENSE_NO_LOOKAHEAD");
+    static const bool no_lookahead = getenv("SWARMORB_DENSE_NO_LOOKAHEAD") != nullptr;
+    const bool lookahead = side && ev && T >= 32 && T <= kDenseMaxPanels && !no_lookahead;
     static const int g_env = getenv("SWARMORB_DENSE_GROUP") ? atoi(getenv("SWARMORB_DENSE_GROUP")) : 0;
     const int G = g_env >= 1 && g_env <= 8 ? g_env : (lookahead ? kDenseGroup : 1);
     hipLaunchKernelGGL(dense_begin_kernel, dim3(1), dim3(1), 0, s, d);
