@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
     if (tid == 0 && s_bad) d.partial[kBaSolveOk] = 0.0;
 }
 
-// ---- single-workgroup solve of a reduced camera system of up to 175 unknowns (local windows of 8..29 free keyframes) ----
+// ---- single-workgroup solve of a reduced camera system of up to 175 unknowns (local windows of 4..29 free keyframes) ----
 // The same machinery as dense_potrf_kernel on the whole system: the lower triangle of [S b; b^T beta] as 16x16 tiles
 // in LDS (row stride 18: conflict-free MFMA operand fetch), the right-hand side riding as one more row so that the
 // forward substitution falls out of the factorisation.  Per 16 columns: the row tiles below the pivot tile become

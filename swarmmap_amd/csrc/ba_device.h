@@ -116,9 +116,9 @@ size_t ba_pairs_scan_temp_bytes(int n_blk);
 void launch_ba_build_pairs(const BaDev& d, void* scan_temp, size_t scan_temp_bytes, hipStream_t s);
 // blocked dense path (ba_dense.hip), used when the system is too large for one workgroup (n_free > 43)
 constexpr int kBaSmallSolverMaxFree = 43;
-constexpr int kBaMfmaSolverMinFree = 9;   // below: the register-resident look-ahead solver is as fast
+constexpr int kBaMfmaSolverMinFree = 4;   // below: the register-resident look-ahead solver is as fast (measured 3..16)
 constexpr int kDenseMaxPanels = 128;  // 12288 / 96
-bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solve (9..29 free keyframes); false if it does not apply
+bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solve (4..29 free keyframes); false if it does not apply
 void launch_ba_dense_pad(const BaDev& d, hipStream_t s);    // once per problem: identity padding up to ldS
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s);  // per trial, in place of the single-workgroup solve  // fills edge_tab (memset to -1 beforehand)
 // Optimizer.cc:644-656 on the device: edges of the current estimate with chi2 > threshold or non-positive depth

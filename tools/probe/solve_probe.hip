@@ -1,5 +1,7 @@
 // Phase-level cycle probe of the reduced-camera-system solver (developer tool, not part of the product).
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I swarmmap_amd/csrc tools/probe/solve_probe.hip -o gpurun_out/solve_probe
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I swarmmap_amd/csrc tools/probe/solve_probe.hip -o /tmp/solve_probe
+//   (ba_dense.hip is included as well: launch_ba_solve dispatches into it; SWARMORB_BA_NO_MFMA_SOLVER=1 times the
+//   register-resident solvers for sizes the MFMA kernel would take)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +15,7 @@ __device__ int g_mark_tid;
 __device__ double* g_dbgL;
 #endif
 #include "ba_kernels.hip"
+#include "ba_dense.hip"
 using namespace so;
 int main(int argc, char** argv) {
     const int nf = argc > 1 ? atoi(argv[1]) : 25, n = 6 * nf;
