@@ -444,8 +444,178 @@ __global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev 
     if (tid == 0) d.partial[kBaSolveOk] = s_bad ? 0.0 : 1.0;
 }
 
+// ---- the same solve for 30..43 free keyframes: 259 unknowns + right-hand side = 17 x 17 tiles, 306 KB - more than
+// LDS holds but not more than the register file (512 KB per CU).  Sixteen waves: the strictly-lower tiles live in
+// the MFMA result registers of waves 1-15 (ten tiles each at most), the pivot tiles (then W_k in their place) and the
+// L tiles of the current block column in LDS, where the MFMA operands are fetched from.  Per 16 columns: owners of
+// the column's tiles turn them into L = A W^T (through LDS once: result layout -> operand layout) and leave them in
+// the panel buffer; every owner applies L_i L_j^T to its tiles without touching LDS for the result; wave 0 updates,
+// factors and inverts the next pivot tile meanwhile.  The backward substitution sums each wave's tiles of a block
+// column in registers and meets in LDS once per 16 unknowns.
+constexpr int kRegMaxTiles = 17;
+constexpr int kRegOwners = 15;
+constexpr int kRegSlots = (kRegMaxTiles * (kRegMaxTiles - 1) / 2 + kRegOwners - 1) / kRegOwners;  // 10
+constexpr int kRegThreads = 1024;
+
+__global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d) {
+    __shared__ double s_diag[kRegMaxTiles][kMTile];   // pivot tiles; W_k replaces tile k once it is factored
+    __shared__ double s_panel[kRegMaxTiles][kMTile];  // L_i of the current block column, row-major (operand fetch)
+    __shared__ double s_lastL[kMTile];
+    __shared__ double s_y[kRegMaxTiles][16];          // forward-substituted right-hand side, block by block
+    __shared__ double s_x[16 * kRegMaxTiles];
+    __shared__ double s_zp[16][16];
+    __shared__ double s_z[16];
+    __shared__ unsigned char s_ti[kRegMaxTiles * (kRegMaxTiles - 1) / 2], s_tj[kRegMaxTiles * (kRegMaxTiles - 1) / 2];
+    __shared__ int s_bad;
+    if (!d.lm->active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int crow = lane >> 4, ccol = lane & 15;
+    const int n = 6 * d.n_free, ld = d.ldS;
+    const int NT = (n + 1 + 15) / 16, tr = NT - 1, rr = n - 16 * tr;
+    const int n_off = NT * (NT - 1) / 2;
+    if (tid == 0) s_bad = 0;
+    if (tid < n_off) {  // strictly-lower tile t = (i - 1) i / 2 + j
+        int ti, tj;
+        potrf_tri(tid, ti, tj);
+        s_ti[tid] = (unsigned char)(ti + 1);
+        s_tj[tid] = (unsigned char)tj;
+    }
+    for (int i = tid; i < NT * 16; i += kRegThreads) s_x[i] = 0.0;
+    for (int e = tid; e < NT * 256; e += kRegThreads) {  // pivot tiles
+        const int k = e >> 8, r = (e >> 4) & 15, c = e & 15, gr = 16 * k + r, gc = 16 * k + c;
+        double v = 0.0;
+        if (gr < n && gc < n) v = d.S[(size_t)gr * ld + gc];
+        else if (gr == n && gc < n) v = d.bs[gc];
+        else if (gr == gc) v = (gr == n) ? 1e300 : 1.0;  // beta and the identity padding
+        s_diag[k][r * kMS + c] = v;
+    }
+    __syncthreads();
+    // Two code paths with the same barrier sequence: wave 0 only ever factors pivot tiles and runs the substitution
+    // (its registers belong to potrf_diag16), waves 1-15 only ever hold tiles (their registers belong to C).
+    if (wave == 0) {
+        if (!potrf_diag16<kMS>(s_diag[0], s_lastL, s_diag[0], lane) && lane == 0) s_bad = 1;
+        __syncthreads();
+        for (int jb = 0; jb + 1 < NT; jb++) {
+            __syncthreads();  // the panel of block column jb is in LDS
+            double* t = s_diag[jb + 1];
+            const double* p = s_panel[jb + 1];
+            const d4 acc = potrf_mma_nt<kMS>(p, p, d4{0.0, 0.0, 0.0, 0.0}, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[(crow + 4 * r) * kMS + ccol] -= acc[r];
+            potrf_wave_sync();
+            if (!potrf_diag16<kMS>(t, s_lastL, t, lane) && lane == 0) s_bad = 1;
+            __syncthreads();
+        }
+        __syncthreads();  // the last block column's panel is done
+        // backward substitution x_k = W_k^T (y_k - sum_{i>k} L_ik^T x_i); rows >= n of x stay zero
+        for (int k = tr; k >= 0; k--) {
+            __syncthreads();  // the owners' partial sums for block k are in s_zp
+            const int mk = (k == tr) ? rr : 16;
+            if (lane < 16) {
+                double acc = 0.0;
+#pragma unroll
+                for (int w16 = 1; w16 < 16; w16++) acc += s_zp[w16][lane];
+                const double yk = (k == tr) ? (lane < rr ? s_lastL[rr * kMS + lane] : 0.0) : s_y[k][lane];
+                s_z[lane] = yk - acc;
+            }
+            potrf_wave_sync();
+            const double* W = s_diag[k];
+            double xv = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = crow + 4 * r;
+                if (row < mk) xv = fma(W[row * kMS + ccol], s_z[row], xv);
+            }
+            xv = rows_sum(xv);
+            if (lane < 16) {
+                const bool real = lane < mk;
+                s_x[16 * k + lane] = real ? xv : 0.0;
+                if (real) d.bs[16 * k + lane] = xv;
+            }
+            __syncthreads();
+        }
+        if (lane == 0) d.partial[kBaSolveOk] = s_bad ? 0.0 : 1.0;
+        return;
+    }
+    // owner waves: slot q of wave w (1..15) is tile t = 15 q + (w - 1); tile coordinates are wave-uniform (SGPRs)
+    d4 C[kRegSlots];
+    int my_i[kRegSlots], my_j[kRegSlots];
+#pragma unroll
+    for (int q = 0; q < kRegSlots; q++) {
+        const int t = kRegOwners * q + (wave - 1);
+        const bool have = t < n_off;
+        my_i[q] = __builtin_amdgcn_readfirstlane(have ? (int)s_ti[have ? t : 0] : -1);
+        my_j[q] = __builtin_amdgcn_readfirstlane(have ? (int)s_tj[have ? t : 0] : -1);
+        C[q] = d4{0.0, 0.0, 0.0, 0.0};
+        if (have) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gr = 16 * my_i[q] + crow + 4 * r, gc = 16 * my_j[q] + ccol;  // gc < gr: never on the diagonal
+                double v = 0.0;
+                if (gr < n) v = d.S[(size_t)gr * ld + gc];   // gc < gr < n
+                else if (gr == n) v = d.bs[gc];              // the right-hand side row (gc < n)
+                C[q][r] = v;
+            }
+        }
+    }
+    __syncthreads();  // W_0 is in LDS
+    for (int jb = 0; jb < NT; jb++) {
+        // panel: my tiles of block column jb become L = A W^T, stay in registers and go to the panel buffer
+#pragma unroll
+        for (int q = 0; q < kRegSlots; q++) {
+            if (my_j[q] != jb) continue;
+            double* t = s_panel[my_i[q]];
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[(crow + 4 * r) * kMS + ccol] = C[q][r];
+            potrf_wave_sync();
+            const d4 acc = potrf_mma_nt<kMS>(t, s_diag[jb], d4{0.0, 0.0, 0.0, 0.0}, lane);
+            potrf_wave_sync();
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[(crow + 4 * r) * kMS + ccol] = acc[r];
+            C[q] = acc;
+            if (my_i[q] == tr && crow == (rr & 3)) {  // row rr of tile row tr is the right-hand side: y_jb
+                const int reg = rr >> 2;
+                s_y[jb][ccol] = reg == 0 ? acc[0] : reg == 1 ? acc[1] : reg == 2 ? acc[2] : acc[3];
+            }
+        }
+        if (jb + 1 >= NT) break;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kRegSlots; q++) {  // my tiles to the right of the column
+            if (my_j[q] <= jb) continue;
+            const d4 acc = potrf_mma_nt<kMS>(s_panel[my_i[q]], s_panel[my_j[q]], d4{0.0, 0.0, 0.0, 0.0}, lane);
+            C[q] -= acc;
+        }
+        for (int jj = jb + 1 + wave; jj < NT; jj += kRegOwners) {  // the later pivot tiles (jb + 1 is wave 0's)
+            double* t = s_diag[jj];
+            const d4 acc = potrf_mma_nt<kMS>(s_panel[jj], s_panel[jj], d4{0.0, 0.0, 0.0, 0.0}, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[(crow + 4 * r) * kMS + ccol] -= acc[r];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int k = tr; k >= 0; k--) {
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < kRegSlots; q++) {
+            if (my_j[q] != k) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) part = fma(C[q][r], s_x[16 * my_i[q] + crow + 4 * r], part);
+        }
+        part = rows_sum(part);
+        if (lane < 16) s_zp[wave][lane] = part;
+        __syncthreads();
+        __syncthreads();  // x_k is in LDS
+    }
+}
+
 bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s) {
     const int n = 6 * d.n_free, NT = (n + 1 + 15) / 16;
+    if (NT > kSolveMfmaMaxTiles && NT <= kRegMaxTiles) {
+        hipLaunchKernelGGL(ba_solve_mfma_reg_kernel, dim3(1), dim3(kRegThreads), 0, s, d);
+        return true;
+    }
     if (NT > kSolveMfmaMaxTiles || NT < 2) return false;
     const size_t lds = sizeof(double) * (size_t)(NT * (NT + 1) / 2) * kMTile;
     static bool attr_set[64] = {};  // the attribute is per device; racing threads set the same value
