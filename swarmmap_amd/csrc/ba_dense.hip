@@ -141,13 +141,14 @@ __device__ __forceinline__ void row_bcast_into(double& out, double x) {
 // identity rows).  Returns false if a pivot is not positive.
 template <int PS>
 __device__ __forceinline__ bool potrf_diag16(const double* At, double* Lt, double* Wt, int lane) {
-    double x[16], v[16], w[16];
+    double x[16], v[16];
     const int lr = lane & 15;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
         x[c] = lane < 16 ? At[lane * PS + c] : (c == lr ? 1.0 : 0.0);
         v[c] = (c == lr) ? 1.0 : 0.0;  // lane c solves L w = e_c
     }
+    potrf_wave_sync();  // every lane holds its row: Wt / Lt may alias At from here on
     bool ok = true;
     double piv = row_bcast_c<0>(x[0]);
 #pragma unroll
@@ -155,25 +156,22 @@ __device__ __forceinline__ bool potrf_diag16(const double* At, double* Lt, doubl
         if (!(piv > 0.0)) ok = false;
         const double y = dense_rsqrt(piv);
         x[c] = potrf_scale(x[c], y);
-        w[c] = v[c] * y;
+        const double w = v[c] * y;
         // the next pivot first: in its own lane the multiplier is the lane's own x[c], no broadcast on the chain
         if (c + 1 < 16) {
             const double pn = fma(-x[c], x[c], x[c + 1]);
             SO_ROW16(row_bcast_into, c + 1, piv, pn);
         }
+        if (lane < 16) Wt[c * PS + lane] = w;  // W[c][lane]: final (zero above the diagonal by construction)
 #pragma unroll
         for (int c2 = c + 1; c2 < 16; c2++) {  // L[c2][c] = x[c] in lane c2
             SO_ROW16(fnma_bcast_c, c2, x[c2], x[c], x[c]);
-            SO_ROW16(fnma_bcast_c, c2, v[c2], x[c], w[c]);
+            SO_ROW16(fnma_bcast_c, c2, v[c2], x[c], w);
         }
     }
-    potrf_wave_sync();  // every lane has read its row before anything aliasing it is written
-    if (lane < 16) {
+    if (Lt && lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            if (Lt) Lt[lane * PS + c] = (c <= lane) ? x[c] : 0.0;
-            Wt[c * PS + lane] = w[c];  // column `lane` of W; zero above the diagonal by construction
-        }
+        for (int c = 0; c < 16; c++) Lt[lane * PS + c] = (c <= lane) ? x[c] : 0.0;
     }
     return ok;
 }
