@@ -539,8 +539,10 @@ def main():
         solve_flop = n_red ** 3 / 3.0 + 2.0 * n_red ** 2
         solve_ms = acc["solve_ms"] / max(acc["n_solves"], 1)
         solve_tf = solve_flop / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0
-        # ba_kernels.hip launch_ba_solve: 4..29 free keyframes -> single-workgroup MFMA solver (ba_dense.hip)
-        solve_kernel = "ba_solve_mfma_kernel" if 24 <= n_red <= 174 else "ba_solve_la_kernel"
+        # ba_kernels.hip launch_ba_solve: 4..29 free keyframes -> single-workgroup MFMA solver, 30..43 -> its
+        # register-resident sibling (ba_dense.hip)
+        solve_kernel = ("ba_solve_mfma_kernel" if 24 <= n_red <= 174 else
+                        "ba_solve_mfma_reg_kernel" if 174 < n_red <= 258 else "ba_solve_la_kernel")
         roof_solve = {"bound": "mfma", "kernel": solve_kernel, "achieved": solve_tf, "peak": FP64_PEAK_TF,
                       "unit": "TFLOP/s", "frac": solve_tf / FP64_PEAK_TF,
                       "traffic": pmc.get(solve_kernel, {}).get("hbm_bytes_per_launch"),

@@ -610,7 +610,8 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
 
 bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s) {
     const int n = 6 * d.n_free, NT = (n + 1 + 15) / 16;
-    if (NT > kSolveMfmaMaxTiles && NT <= kRegMaxTiles) {
+    static const bool force_reg = getenv("SWARMORB_MFMA_REG") != nullptr;  // A/B switch for profiling
+    if ((NT > kSolveMfmaMaxTiles || (force_reg && NT >= 2)) && NT <= kRegMaxTiles) {
         hipLaunchKernelGGL(ba_solve_mfma_reg_kernel, dim3(1), dim3(kRegThreads), 0, s, d);
         return true;
     }

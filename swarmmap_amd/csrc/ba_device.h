@@ -118,7 +118,7 @@ void launch_ba_build_pairs(const BaDev& d, void* scan_temp, size_t scan_temp_byt
 constexpr int kBaSmallSolverMaxFree = 43;
 constexpr int kBaMfmaSolverMinFree = 4;   // below: the register-resident look-ahead solver is as fast (measured 3..16)
 constexpr int kDenseMaxPanels = 128;  // 12288 / 96
-bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solve (4..29 free keyframes); false if it does not apply
+bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solves (4..29 free keyframes: tiles in LDS; 30..43: tiles in registers); false if neither applies
 void launch_ba_dense_pad(const BaDev& d, hipStream_t s);    // once per problem: identity padding up to ldS
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s);  // per trial, in place of the single-workgroup solve  // fills edge_tab (memset to -1 beforehand)
 // Optimizer.cc:644-656 on the device: edges of the current estimate with chi2 > threshold or non-positive depth
