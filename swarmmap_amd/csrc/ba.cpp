@@ -481,7 +481,9 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     // pair lists of the large-map gather: capacity from the landmarks' observation counts (an upper bound: fixed
     // keyframes' observations are counted too)
     size_t pair_cap = 0, n_blk = (size_t)nf * ((size_t)nf + 1) / 2, big_cap = 0, scan_bytes = 0;
-    if (dense_path) {
+    static const int pairs_min_env = getenv("SWARMORB_BA_PAIRS_MIN") ? atoi(getenv("SWARMORB_BA_PAIRS_MIN")) : 0;
+    const bool pairs_path = dense_path && nf >= (pairs_min_env > 0 ? pairs_min_env : kBaPairsMinFree);
+    if (pairs_path) {
         for (int i = 0; i < nL; i++) {
             const size_t k = (size_t)(h_ptoff[i + 1] - h_ptoff[i]);
             pair_cap += k * (k - (k > 0 ? 1 : 0)) / 2;
@@ -547,7 +549,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.ldS = (int)ldS;
     d.dense_ws = b->d_dense_ws.as<double>();
     d.dense_x = b->d_dense_x.as<double>();
-    d.use_pairs = dense_path ? 1 : 0;
+    d.use_pairs = pairs_path ? 1 : 0;
     d.pr_off = b->d_pr_off.as<int>();
     d.pr_cur = b->d_pr_cur.as<int>();
     d.pr_l = b->d_pr.as<int>();
@@ -569,10 +571,8 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     r.nb_err = std::min(1024, std::max(1, (nE + 255) / 256));
     r.nb_upd = std::min(1024, std::max(1, (8 * nL + nP + 255) / 256));
     launch_ba_edge_table(d, s);
-    if (dense_path) {
-        launch_ba_dense_pad(d, s);
-        launch_ba_build_pairs(d, b->d_scan_tmp.p, scan_bytes, s);
-    }
+    if (dense_path) launch_ba_dense_pad(d, s);
+    if (pairs_path) launch_ba_build_pairs(d, b->d_scan_tmp.p, scan_bytes, s);
 
     const double t_uploaded = now_ms();
     SO_HIP(hipEventRecord(b->e0, s));

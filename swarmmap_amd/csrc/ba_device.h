@@ -116,6 +116,9 @@ size_t ba_pairs_scan_temp_bytes(int n_blk);
 void launch_ba_build_pairs(const BaDev& d, void* scan_temp, size_t scan_temp_bytes, hipStream_t s);
 // blocked dense path (ba_dense.hip), used when the system is too large for one workgroup (n_free > 43)
 constexpr int kBaSmallSolverMaxFree = 43;
+constexpr int kBaPairsMinFree = 80;       // from here on the Schur gather walks per-block pair lists instead of edge_tab
+                                          // (window wall time, edge_tab vs pair lists: 44 keyframes 3.2 vs 3.7 ms, 64: 6.1 vs 6.3,
+                                          // 96: 9.2 vs 8.9, 128: 12.8 vs 11.7)
 constexpr int kBaMfmaSolverMinFree = 4;   // below: the register-resident look-ahead solver is as fast (measured 3..16)
 constexpr int kDenseMaxPanels = 128;  // 12288 / 96
 bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solves (4..29 free keyframes: tiles in LDS; 30..43: tiles in registers); false if neither applies
