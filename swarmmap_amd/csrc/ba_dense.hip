@@ -444,7 +444,8 @@ __global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev 
 
 // ---- the same solve for 30..43 free keyframes: 259 unknowns + right-hand side = 17 x 17 tiles, 306 KB - more than
 // LDS holds but not more than the register file (512 KB per CU).  Sixteen waves: the strictly-lower tiles live in
-// the MFMA result registers of waves 1-15 (ten tiles each at most), the pivot tiles (then W_k in their place) and the
+// the MFMA result registers of waves 1-15 (ten tiles each at most; the three waves on wave 0's SIMD hold the
+// leftmost block columns, which are final early), the pivot tiles (then W_k in their place) and the
 // L tiles of the current block column in LDS, where the MFMA operands are fetched from.  Per 16 columns: owners of
 // the column's tiles turn them into L = A W^T (through LDS once: result layout -> operand layout) and leave them in
 // the panel buffer; every owner applies L_i L_j^T to its tiles without touching LDS for the result; wave 0 updates,
@@ -454,6 +455,7 @@ constexpr int kRegMaxTiles = 17;
 constexpr int kRegOwners = 15;
 constexpr int kRegSlots = (kRegMaxTiles * (kRegMaxTiles - 1) / 2 + kRegOwners - 1) / kRegOwners;  // 10
 constexpr int kRegThreads = 1024;
+constexpr int kRegEarly = 3 * kRegSlots;  // tiles held by the three waves on wave 0's SIMD
 
 __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d) {
     __shared__ double s_diag[kRegMaxTiles][kMTile];   // pivot tiles; W_k replaces tile k once it is factored
@@ -472,11 +474,14 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
     const int NT = (n + 1 + 15) / 16, tr = NT - 1, rr = n - 16 * tr;
     const int n_off = NT * (NT - 1) / 2;
     if (tid == 0) s_bad = 0;
-    if (tid < n_off) {  // strictly-lower tile t = (i - 1) i / 2 + j
-        int ti, tj;
-        potrf_tri(tid, ti, tj);
-        s_ti[tid] = (unsigned char)(ti + 1);
-        s_tj[tid] = (unsigned char)tj;
+    if (tid < n_off) {  // strictly-lower tiles, block column by block column (j ascending, i = j+1 .. NT-1)
+        int j = 0, rem = tid;
+        while (rem >= NT - 1 - j) {
+            rem -= NT - 1 - j;
+            j++;
+        }
+        s_ti[tid] = (unsigned char)(j + 1 + rem);
+        s_tj[tid] = (unsigned char)j;
     }
     for (int i = tid; i < NT * 16; i += kRegThreads) s_x[i] = 0.0;
     for (int e = tid; e < NT * 256; e += kRegThreads) {  // pivot tiles
@@ -535,13 +540,18 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
         if (lane == 0) d.partial[kBaSolveOk] = s_bad ? 0.0 : 1.0;
         return;
     }
-    // owner waves: slot q of wave w (1..15) is tile t = 15 q + (w - 1); tile coordinates are wave-uniform (SGPRs)
+    // owner waves.  Waves 4, 8, 12 share wave 0's SIMD: they take the first kRegEarly tiles in block-column order -
+    // tiles of the leftmost columns, final after a step or two - so that the pivot chain has its SIMD to itself for
+    // the rest of the factorisation; the other twelve waves share the remaining tiles.  Tile coordinates are
+    // wave-uniform (SGPRs).
+    const bool early = (wave & 3) == 0;
+    const int others = wave - 1 - (wave >> 2);  // 0..11 among the waves with (wave & 3) != 0
     d4 C[kRegSlots];
     int my_i[kRegSlots], my_j[kRegSlots];
 #pragma unroll
     for (int q = 0; q < kRegSlots; q++) {
-        const int t = kRegOwners * q + (wave - 1);
-        const bool have = t < n_off;
+        const int t = early ? 3 * q + (wave >> 2) - 1 : kRegEarly + 12 * q + others;
+        const bool have = early ? t < (n_off < kRegEarly ? n_off : kRegEarly) : t < n_off;
         my_i[q] = __builtin_amdgcn_readfirstlane(have ? (int)s_ti[have ? t : 0] : -1);
         my_j[q] = __builtin_amdgcn_readfirstlane(have ? (int)s_tj[have ? t : 0] : -1);
         C[q] = d4{0.0, 0.0, 0.0, 0.0};
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
             const d4 acc = potrf_mma_nt<kMS>(s_panel[my_i[q]], s_panel[my_j[q]], d4{0.0, 0.0, 0.0, 0.0}, lane);
             C[q] -= acc;
         }
-        for (int jj = jb + 1 + wave; jj < NT; jj += kRegOwners) {  // the later pivot tiles (jb + 1 is wave 0's)
+        for (int jj = jb + 2 + others; !early && jj < NT; jj += 12) {  // the later pivot tiles (jb + 1 is wave 0's)
             double* t = s_diag[jj];
             const d4 acc = potrf_mma_nt<kMS>(s_panel[jj], s_panel[jj], d4{0.0, 0.0, 0.0, 0.0}, lane);
 #pragma unroll
