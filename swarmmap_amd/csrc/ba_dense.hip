@@ -499,7 +499,9 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
         if (!potrf_diag16<kMS>(s_diag[0], s_lastL, s_diag[0], lane) && lane == 0) s_bad = 1;
         __syncthreads();
         for (int jb = 0; jb + 1 < NT; jb++) {
+            SO_POTRF_MARK(1 + 3 * jb);
             __syncthreads();  // the panel of block column jb is in LDS
+            SO_POTRF_MARK(2 + 3 * jb);
             double* t = s_diag[jb + 1];
             const double* p = s_panel[jb + 1];
             const d4 acc = potrf_mma_nt<kMS>(p, p, d4{0.0, 0.0, 0.0, 0.0}, lane);
@@ -507,8 +509,10 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
             for (int r = 0; r < 4; r++) t[(crow + 4 * r) * kMS + ccol] -= acc[r];
             potrf_wave_sync();
             if (!potrf_diag16<kMS>(t, s_lastL, t, lane) && lane == 0) s_bad = 1;
+            SO_POTRF_MARK(3 + 3 * jb);
             __syncthreads();
         }
+        SO_POTRF_MARK(58);
         __syncthreads();  // the last block column's panel is done
         // backward substitution x_k = W_k^T (y_k - sum_{i>k} L_ik^T x_i); rows >= n of x stay zero
         for (int k = tr; k >= 0; k--) {
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
             }
             __syncthreads();
         }
+        SO_POTRF_MARK(59);
         if (lane == 0) d.partial[kBaSolveOk] = s_bad ? 0.0 : 1.0;
         return;
     }

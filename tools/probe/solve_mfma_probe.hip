@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     double *dS, *db, *db0, *dp;
     long long* dm;
     hipMalloc(&dS, sizeof(double) * n * n); hipMalloc(&db, sizeof(double) * n); hipMalloc(&db0, sizeof(double) * n);
-    hipMalloc(&dp, sizeof(double) * kBaPartialCount); hipMalloc(&dm, sizeof(long long) * 64);
+    hipMalloc(&dp, sizeof(double) * kBaPartialCount); hipMalloc(&dm, sizeof(long long) * 64);  // marks 0..63
     hipMemcpy(dS, S.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
     hipMemcpy(db0, b.data(), sizeof(double) * n, hipMemcpyHostToDevice);
     hipMemset(dm, 0, sizeof(long long) * 64);
@@ -49,9 +49,15 @@ int main(int argc, char** argv) {
     const int NT = (n + 1 + 15) / 16;
     double okflag = -1; hipMemcpy(&okflag, dp + kBaSolveOk, sizeof(double), hipMemcpyDeviceToHost);
     printf("nf %d n %d tiles %d: kernel %.2f us, |S x - b| = %.3g, solve_ok %.1f\n", nf, n, NT, best * 1e3, res, okflag);
-    printf("diag0 %lld\n", m[1] - m[0]);
-    for (int jb = 0; jb + 1 < NT; jb++)
+    if (NT <= 11) printf("diag0 %lld\n", m[1] - m[0]);
+    for (int jb = 0; NT <= 11 && jb + 1 < NT; jb++)
         printf("jb %d: panel+barrier %lld  wave0 tile+diag16 %lld  wait %lld\n", jb, m[2 + 3*jb] - m[1 + 3*jb], m[3 + 3*jb] - m[2 + 3*jb], m[4 + 3*jb] - m[3 + 3*jb]);
+    if (NT > 11) {  // register-resident kernel: marks of wave 0
+        for (int jb = 0; jb + 1 < NT; jb += 5)
+            printf("jb %d: wait for panel %lld  tile+diag16 %lld  wait for updates %lld\n", jb, m[2 + 3*jb] - m[1 + 3*jb], m[3 + 3*jb] - m[2 + 3*jb], m[4 + 3*jb] - m[3 + 3*jb]);
+        printf("factor (from first panel wait) %lld  backward %lld  (shader clock cycles)\n", m[58] - m[1], m[59] - m[58]);
+        return 0;
+    }
     printf("factor total %lld  backward %lld  (shader clock cycles)\n", m[40] - m[0], m[41] - m[40]);
     return 0;
 }
