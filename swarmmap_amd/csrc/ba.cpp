@@ -451,7 +451,12 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     if ((rc = b->d_pt1.ensure(sizeof(double) * 3 * sL))) return rc;
     if ((rc = b->d_err.ensure(sizeof(double) * 2 * sE))) return rc;
     if ((rc = b->d_chi2.ensure(sizeof(double) * sE))) return rc;
-    if ((rc = b->d_tab.ensure(sizeof(int) * sL * sF))) return rc;
+    // single-workgroup solvers up to 43 free keyframes, the blocked solver (S padded to a multiple of 96) beyond; from
+    // kBaPairsMinFree free keyframes on the Schur gather walks per-block pair lists and needs no edge table
+    const bool dense_path = nf > kBaSmallSolverMaxFree;
+    static const int pairs_min_env = getenv("SWARMORB_BA_PAIRS_MIN") ? atoi(getenv("SWARMORB_BA_PAIRS_MIN")) : 0;
+    const bool pairs_path = dense_path && nf >= (pairs_min_env > 0 ? pairs_min_env : kBaPairsMinFree);
+    if (!pairs_path && (rc = b->d_tab.ensure(sizeof(int) * sL * sF))) return rc;
     if ((rc = b->d_Hll.ensure(sizeof(double) * 9 * sL))) return rc;
     if ((rc = b->d_bl.ensure(sizeof(double) * 3 * sL))) return rc;
     if ((rc = b->d_Dinv.ensure(sizeof(double) * 9 * sL))) return rc;
@@ -462,8 +467,6 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     if ((rc = b->d_partial.ensure(sizeof(double) * kBaPartialCount))) return rc;
     if ((rc = b->d_Hpp.ensure(sizeof(double) * 36 * sF))) return rc;
     if ((rc = b->d_bp.ensure(sizeof(double) * 6 * sF))) return rc;
-    // single-workgroup solvers up to 43 free keyframes, the blocked solver (S padded to a multiple of 96) beyond
-    const bool dense_path = nf > kBaSmallSolverMaxFree;
     const size_t ldS = dense_path ? (n + 95) / 96 * 96 : n;
     if ((rc = b->d_S.ensure(sizeof(double) * ldS * ldS))) return rc;
     if ((rc = b->d_bs.ensure(sizeof(double) * ldS))) return rc;
@@ -481,8 +484,6 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     // pair lists of the large-map gather: capacity from the landmarks' observation counts (an upper bound: fixed
     // keyframes' observations are counted too)
     size_t pair_cap = 0, n_blk = (size_t)nf * ((size_t)nf + 1) / 2, big_cap = 0, scan_bytes = 0;
-    static const int pairs_min_env = getenv("SWARMORB_BA_PAIRS_MIN") ? atoi(getenv("SWARMORB_BA_PAIRS_MIN")) : 0;
-    const bool pairs_path = dense_path && nf >= (pairs_min_env > 0 ? pairs_min_env : kBaPairsMinFree);
     if (pairs_path) {
         for (int i = 0; i < nL; i++) {
             const size_t k = (size_t)(h_ptoff[i + 1] - h_ptoff[i]);
@@ -505,7 +506,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     SO_HIP(hipMemsetAsync(b->d_err.p, 0, sizeof(double) * 2 * sE, s));   // _error of a fresh edge
     SO_HIP(hipMemsetAsync(b->d_chi2.p, 0, sizeof(double) * sE, s));
     SO_HIP(hipMemsetAsync(b->d_partial.p, 0, sizeof(double) * kBaPartialCount, s));
-    SO_HIP(hipMemsetAsync(b->d_tab.p, 0xFF, sizeof(int) * sL * sF, s));  // -1: keyframe does not observe the landmark
+    if (!pairs_path) SO_HIP(hipMemsetAsync(b->d_tab.p, 0xFF, sizeof(int) * sL * sF, s));  // -1: keyframe does not observe the landmark
     SO_HIP(hipMemsetAsync(b->d_lm.p, 0, sizeof(BaLm), s));  // current estimate = buffer 0, no trials yet
     memset(b->h_lm, 0, sizeof(BaLm));
     *b->h_abort = 0;
@@ -570,7 +571,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.huber_dsqr = (float)((double)opt->huber_delta * (double)opt->huber_delta);  // RobustKernelHuber::setDelta
     r.nb_err = std::min(1024, std::max(1, (nE + 255) / 256));
     r.nb_upd = std::min(1024, std::max(1, (8 * nL + nP + 255) / 256));
-    launch_ba_edge_table(d, s);
+    if (!pairs_path) launch_ba_edge_table(d, s);
     if (dense_path) launch_ba_dense_pad(d, s);
     if (pairs_path) launch_ba_build_pairs(d, b->d_scan_tmp.p, scan_bytes, s);
 
