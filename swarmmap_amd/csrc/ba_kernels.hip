@@ -1663,6 +1663,13 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(PoseOptArgs a) {
 // barriers per trial.
 constexpr int kPoLdsMax = kPoseOptLdsMax;
 
+// tools/probe/pose_probe.hip defines SO_POSE_TICK to accumulate clock64() per phase; the product build compiles it away
+#ifndef SO_POSE_TICK
+#define SO_POSE_TICK(i)
+#define SO_POSE_TICK_DECL
+#define SO_POSE_TICK_FLUSH
+#endif
+
 // the two widest exchanges (lane ^ 32, lane ^ 16) use gfx950's v_permlane32_swap / v_permlane16_swap: the first
 // operand's upper half (odd 16-lane rows) trades places with the second operand's lower half (even rows), so
 // a' + b' is "my half of the values plus my partner's copy of the same half" without touching LDS
@@ -1805,6 +1812,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
     __shared__ int s_info[3];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = a.n;
+    SO_POSE_TICK_DECL;
     double* s_err = s_dyn;                                   // 2n
     float* s_X = reinterpret_cast<float*>(s_dyn + 2 * n);    // 3n
     float* s_obs = s_X + 3 * n;                              // 2n
@@ -1828,6 +1836,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
     // (6) and the number of active edges, reduced into s_sys[which].  One barrier; the caller's barrier after lane 0's
     // decision is the second.
     auto edge_phase = [&](const BaPose& T, int which) {
+        SO_POSE_TICK(6);  // everything since the last tick: lane 0's decision + barrier, round set-up
         double v[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) v[k] = 0.0;
@@ -1881,6 +1890,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
                 v[21 + r] = acc;
             }
         }
+        SO_POSE_TICK(0);  // edge loop
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = po_swap_add32(v[i], v[i + 16]);
 #pragma unroll
@@ -1890,7 +1900,9 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
         po_halve<1>(v, 2, lane);
         const double tot = v[0] + __shfl_xor(v[0], 1);  // lane holds the wave total of value (lane >> 1)
         if ((lane & 1) == 0) s_red[wv][lane >> 1] = tot;
+        SO_POSE_TICK(1);  // wave reduction
         __syncthreads();
+        SO_POSE_TICK(2);  // barrier
         if (tid < 29) {
             double sum = s_red[0][tid];
 #pragma unroll
@@ -1909,6 +1921,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
         // no barrier here: only lane 0 (same wave as the 29 summing lanes, LDS in order) reads s_sys before the
         // barrier that ends lane 0's decision
         __threadfence_block();
+        SO_POSE_TICK(3);  // cross-wave sum into s_sys
     };
 
     // lane 0: solve the current system with the current lambda and publish the trial pose
@@ -2034,6 +2047,8 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
         __syncthreads();
         if (n < 10) break;
     }
+    SO_POSE_TICK(6);
+    SO_POSE_TICK_FLUSH;
     for (int e = tid; e < n; e += kPoThreads) a.outlier[e] = s_out[e];
     if (tid == 0) {
         *a.pose_out = s_cur;
