@@ -1,6 +1,7 @@
 """Global bundle adjustment (BASELINE configs[4]: the whole-map optimisation after a merge / loop closure) on one GPU:
 wall time per BundleAdjustment(10 iterations) and the FP64 rate of the blocked reduced-camera-system solve.
     python tools/gba_bench.py            # GBA-1 and GBA-2 (SURVEY 8d sizes), JSON lines
+    python tools/gba_bench.py max        # + the largest map the blocked solver accepts (2047 free keyframes)
 Not part of bench.py's per-frame metric; the numbers are quoted in DESIGN.md 5."""
 import json
 import os
@@ -15,8 +16,12 @@ FP64_PEAK_TF = 78.6
 
 def main():
     o = swarmmap_amd.Optimizer()
-    for name in ("GBA-1", "GBA-2"):
-        p = synth.make_ba_case(name, 1)
+    cases = ["GBA-1", "GBA-2"] + (["GBA-max"] if "max" in sys.argv[1:] else [])
+    for name in cases:
+        if name == "GBA-max":  # 12288 reduced-system rows = 2048 keyframes, one of them fixed
+            p = synth.make_ba_problem(1, n_free=2047, n_fixed=1, n_points=160000, max_obs="auto")
+        else:
+            p = synth.make_ba_case(name, 1)
         o.BundleAdjustment(p, nIterations=2, bRobust=True)  # warm-up: buffers
         t0 = time.perf_counter()
         r = o.BundleAdjustment(p, nIterations=10, bRobust=True)
