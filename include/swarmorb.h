@@ -306,6 +306,105 @@ int so_frame_is_in_frustum(so_frame_ctx* f, const so_camera* cam, const float* b
                            float* proj_x, float* proj_y, float* view_cos, int32_t* pred_level);
 
 /* ------------------------------------------------------------------------------------------------
+ * Device-resident frame, map-point table and the two tracking searches over them.
+ *
+ * The host-array entry points above hand keypoints / descriptors back to the caller after every operator and take
+ * them in again at the next one.  On the tracking thread that round trip (extractor -> Frame::UndistortKeyPoints /
+ * AssignFeaturesToGrid -> ORBmatcher, code/src/Frame.cc:218-275 -> code/src/Tracking.cc:714-768, 964-1007) is pure
+ * overhead: these entry points keep the frame in HBM from the image upload to the matcher's K-lists.  The host still
+ * receives copies of the keypoints, undistorted positions and descriptors (Frame's members stay usable by the CPU
+ * parts of SLAM), written by the kernels into host-mapped memory.  Results are identical to chaining
+ * so_extractor_run -> so_frame_prepare -> so_frame_is_in_frustum -> so_search_by_projection_*.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct so_dframe so_dframe;
+
+/* One device-resident Frame bound to an extractor (two alternate per agent: frame t+1 is extracted while frame t is
+ * matched).  cam = mK / mDistCoef of the Frame constructor. */
+int so_dframe_create(so_extractor* ex, const so_camera* cam, so_dframe** out);
+void so_dframe_destroy(so_dframe* f);
+
+/* Frame::Frame(imGray, ..., extractor, K, distCoef, ...) monocular (code/src/Frame.cc:218-275), asynchronous:
+ * image upload (host pointer, pinned or pageable; so_dframe_submit_device: image already in HBM) -> ExtractORB ->
+ * UndistortKeyPoints -> ComputeImageBounds -> AssignFeaturesToGrid -> the matcher's candidate layout, enqueued on the
+ * extractor's stream; returns without waiting.  One frame in flight per extractor. */
+int so_dframe_submit(so_dframe* f, const uint8_t* image, int width, int height, int stride);
+int so_dframe_submit_device(so_dframe* f, const uint8_t* d_image, int width, int height, int stride);
+/* Waits for the frame and hands out the host copies: keypoints (mvKeys), xy_un (mvKeysUn[i].pt, 2 floats each; may
+ * be NULL), descriptors (mDescriptors), bounds4 = {mnMinX, mnMaxX, mnMinY, mnMaxY} (may be NULL).
+ * capacity >= so_extractor_capacity(). */
+int so_dframe_collect(so_dframe* f, so_keypoint* keypoints, float* xy_un, uint8_t* descriptors, int capacity,
+                      int* n_out, float* bounds4);
+
+/* Device pointers of a collected frame (valid until the handle's next submit). */
+typedef struct {
+    int32_t n, n_inside;            /* N; keypoints inside the 64 x 48 grid */
+    float bounds[4];
+    const float* xy_un;             /* n x 2, by keypoint index */
+    const int8_t* octave;           /* n */
+    const uint8_t* descriptors;     /* n x 32 */
+    const int32_t* cell_start;      /* 64*48+1, cell = x * 48 + y (mGrid[x][y]) */
+    const int32_t* cell_items;      /* n_inside keypoint indices, cells in order, push_back order inside a cell */
+    const float* sorted_xy;         /* the same keypoints in cell_items order: the matcher's candidate layout */
+    const int8_t* sorted_octave;
+    const uint8_t* sorted_descriptors;
+    const int32_t* col_start;       /* 65: first position of every grid column */
+} so_dframe_view;
+int so_dframe_device_view(const so_dframe* f, so_dframe_view* out);
+/* host copies of the grid lists, for parity tests */
+int so_dframe_get_grid(so_dframe* f, int32_t* cell_start, int32_t* cell_items, int32_t* n_inside);
+
+/* so_search_by_projection_mappoints / _lastframe with the candidates read in place from a device-resident frame
+ * (no host sort, no candidate upload); excluded: n bytes as in so_frame_view, may be NULL. */
+int so_search_by_projection_mappoints_dframe(so_matcher* m, const so_dframe* F, const uint8_t* excluded, int32_t n_mp,
+                                             const uint8_t* in_view, const float* proj_x, const float* proj_y,
+                                             const float* view_cos, const int32_t* pred_level, const uint8_t* mp_desc,
+                                             const uint8_t* mp_has_obs, float th, float nn_ratio, int32_t* kp_to_mp,
+                                             int32_t* nmatches);
+int so_search_by_projection_lastframe_dframe(so_matcher* m, const so_dframe* cur, const uint8_t* excluded,
+                                             int32_t n_last, const uint8_t* valid, const float* u, const float* v,
+                                             const int32_t* last_octave, const float* last_angle,
+                                             const uint8_t* mp_desc, const uint8_t* mp_has_obs, float th,
+                                             int check_orientation, int32_t* kp_to_last, int32_t* nmatches);
+
+/* Device-resident table of the MapPoint fields the per-frame operators read (code/include/MapPoint.h: mWorldPos,
+ * mNormalVector, mfMaxDistance, mfMinDistance, mDescriptor), indexed by a slot the caller assigns (append order).
+ * Written at keyframe rate (new points, SetWorldPos / UpdateNormalAndDepth / ComputeDistinctiveDescriptors results),
+ * read every frame by the tracking searches below.  Writes are complete when the call returns. */
+typedef struct so_map so_map;
+int so_map_create(int device, so_map** out);
+void so_map_destroy(so_map* map);
+int so_map_size(const so_map* map);
+/* slots [first, first + n) <- the given rows; first <= size (rows beyond the current size are appended and must be
+ * given whole; for existing rows any array may be NULL = unchanged). */
+int so_map_write(so_map* map, int32_t first, int32_t n, const float* Xw, const float* normal, const float* max_dist,
+                 const float* min_dist, const uint8_t* desc);
+/* Xw[slots[i]] <- Xw row i (MapPoint::SetWorldPos after bundle adjustment, code/src/Optimizer.cc:729-737) */
+int so_map_write_positions(so_map* map, int32_t n, const int32_t* slots, const float* Xw);
+int so_map_read(so_map* map, int32_t first, int32_t n, float* Xw, uint8_t* desc); /* either may be NULL */
+
+/* TrackWithMotionModel's search: ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono = true) —
+ * code/src/ORBmatcher.cc:1223-1354, the WHOLE function including the projection of the last frame's map points with
+ * the current pose guess (:1242-1276).  Tcw12 = CurrentFrame.mTcw; last_slot[i] (last->n entries) = map slot of
+ * LastFrame.mvpMapPoints[i], or -1 when it is null or mvbOutlier[i]; slot_has_obs[i] = Observations() > 0 of that
+ * point (NULL = all 1); cur_excluded as so_frame_view.excluded (may be NULL).
+ * Out: kp_to_last[k] (cur->n entries) = index in the last frame whose map point is bound to keypoint k, or -1. */
+int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_dframe* last,
+                               const so_map* map, const float* Tcw12, const int32_t* last_slot,
+                               const uint8_t* slot_has_obs, float th, int check_orientation, int32_t* kp_to_last,
+                               int32_t* nmatches);
+
+/* TrackLocalMap's search: Tracking::SearchLocalPoints (code/src/Tracking.cc:1104-1156) — Frame::isInFrustum(pMP,
+ * viewing_cos_limit) (code/src/Frame.cc:316-375, MapPoint::PredictScale code/src/MapPoint.cc:476-485) for each of
+ * the n_local local map points, then ORBmatcher::SearchByProjection(F, vpMapPoints, th) (code/src/ORBmatcher.cc:
+ * 44-121) over the visible ones.  local_slot[i] = map slot of mvpLocalMapPoints[i] (NULL: slots 0..n_local-1);
+ * skip[i] != 0: the point is already in mCurrentFrame.mvpMapPoints or isBad() and is not searched (may be NULL).
+ * Out: in_view[i] = mbTrackInView (may be NULL), kp_to_local[k] = index into the local list bound to keypoint k. */
+int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_map* map,
+                              const float* Tcw12, int32_t n_local, const int32_t* local_slot, const uint8_t* skip,
+                              const uint8_t* slot_has_obs, float th, float nn_ratio, float viewing_cos_limit,
+                              float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local, int32_t* nmatches);
+
+/* ------------------------------------------------------------------------------------------------
  * Keyframe record — the compact binary form of what a peer needs from a keyframe for the
  * loop / merge candidate search, replacing the Boost text archive of code/src/MapUpdater.cc:190-230 /
  * code/include/KeyFrame.h:310-406 on the agent-to-agent path.  Layout (little-endian):

@@ -159,3 +159,28 @@ void orc_is_in_frustum(const orc_camera* cam, const float* b, const float* T, in
         pred_level[i] = nScale;
     }
 }
+
+void orc_project_last_frame(const orc_camera* cam, const float* b, const float* T, int32_t n, const float* Xw,
+                            const uint8_t* has_point, uint8_t* valid, float* u_out, float* v_out) {
+    for (int32_t i = 0; i < n; i++) {
+        valid[i] = 0;
+        if (!has_point[i]) continue; /* pMP && !LastFrame.mvbOutlier[i], ORBmatcher.cc:1248-1250 */
+        const float* P = Xw + 3 * (size_t)i;
+        float Pc[3];
+        for (int r = 0; r < 3; r++) { /* Rcw*x3Dw+tcw, :1253 */
+            const double s = (double)T[4 * r] * (double)P[0] + (double)T[4 * r + 1] * (double)P[1] +
+                             (double)T[4 * r + 2] * (double)P[2];
+            Pc[r] = (float)(s + (double)T[4 * r + 3]);
+        }
+        const float invzc = (float)(1.0 / (double)Pc[2]); /* const float invzc = 1.0/x3Dc.at<float>(2), :1257 */
+        if (!(invzc >= 0.0f)) continue;                    /* if(invzc<0) continue, :1259 (a NaN depth is dropped too) */
+        const float u = cam->fx * Pc[0] * invzc + cam->cx;
+        const float v = cam->fy * Pc[1] * invzc + cam->cy;
+        if (u < b[0] || u > b[1]) continue; /* :1265-1268 */
+        if (v < b[2] || v > b[3]) continue;
+        if (!(u >= b[0] && v >= b[2])) continue; /* NaN coordinates never reach GetFeaturesInArea */
+        valid[i] = 1;
+        u_out[i] = u;
+        v_out[i] = v;
+    }
+}

@@ -56,6 +56,13 @@ void orc_is_in_frustum(const orc_camera* cam, const float* bounds4, const float*
                        float log_scale_factor, int32_t n_scale_levels, uint8_t* in_view, float* proj_x,
                        float* proj_y, float* view_cos, int32_t* pred_level);
 
+/* The projection step of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), code/src/ORBmatcher.cc:
+ * 1251-1270, for a batch of the last frame's map points: x3Dc = Rcw * x3Dw + tcw (cv::Mat algebra: double
+ * accumulation, one rounding), invzc = 1.0 / z, u = fx * xc * invzc + cx; valid[i] = has_point[i] && invzc >= 0 &&
+ * (u, v) inside the image bounds.  u / v are written only where valid[i] = 1. */
+void orc_project_last_frame(const orc_camera* cam, const float* bounds4, const float* Tcw12, int32_t n, const float* Xw,
+                            const uint8_t* has_point, uint8_t* valid, float* u, float* v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -426,6 +426,18 @@ def is_in_frustum(cam, bounds, Tcw, Xw, normal, max_dist, min_dist, viewing_cos_
     return dict(in_view=in_view, proj_x=px, proj_y=py, view_cos=vc, pred_level=lvl)
 
 
+def project_last_frame(cam, bounds, Tcw, Xw, has_point):
+    """Projection step of SearchByProjection(cur, last) (ORBmatcher.cc:1251-1270): (valid, u, v)."""
+    b = np.ascontiguousarray(bounds, np.float32)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    X = np.ascontiguousarray(Xw, np.float32).reshape(-1, 3)
+    hp = np.ascontiguousarray(has_point, np.uint8)
+    n = len(X)
+    valid, u, v = np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lib().orc_project_last_frame(C.byref(cam), _p(b), _p(T), C.c_int32(n), _p(X), _p(hp), _p(valid), _p(u), _p(v))
+    return valid, u, v
+
+
 def distinctive_descriptors(offsets, descriptors):
     """MapPoint::ComputeDistinctiveDescriptors per map point: (best_idx, best_median) arrays, -1 for empty points."""
     off = np.ascontiguousarray(offsets, np.int32)

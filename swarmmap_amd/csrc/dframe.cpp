@@ -1,0 +1,370 @@
+// dframe.cpp — C ABI of the device-resident Frame and of the device-resident map-point table (include/swarmorb.h).
+//
+// so_dframe = what ORB_SLAM2::Frame's constructor produces (code/src/Frame.cc:218-275: ExtractORB ->
+// UndistortKeyPoints -> ComputeImageBounds -> AssignFeaturesToGrid), kept in HBM: the extractor's frame and ONE more
+// kernel on the same stream turn the image into undistorted keypoints, the 64x48 grid and the matcher's candidate
+// layout without a host round trip; the host receives mirrors (keypoints, descriptors, undistorted positions)
+// through host-mapped memory for the parts of SLAM that stay on the CPU.  Two frames alternate per agent: frame t+1
+// is extracted into one while the matcher reads the other.
+// so_map = the MapPoint fields the per-frame operators read (mWorldPos, mNormalVector, mfMaxDistance, mfMinDistance,
+// mDescriptor; code/include/MapPoint.h), indexed by a slot the caller assigns; written at keyframe rate, read by
+// the tracking searches (matcher.cpp) every frame.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "dframe_internal.h"
+#include "extractor_internal.h"
+#include "so_common.h"
+
+using namespace so;
+
+namespace {
+
+size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int allocate(so_dframe* f, int capacity) {
+    constexpr int ncell = kFrameGridCols * kFrameGridRows;
+    const size_t c = (size_t)capacity;
+    size_t o = 0;
+    const size_t o_xy = o; o += up256(8 * c);
+    const size_t o_oct = o; o += up256(c);
+    const size_t o_desc = o; o += up256(32 * c);
+    const size_t o_cs = o; o += up256(4 * (ncell + 1));
+    const size_t o_ci = o; o += up256(4 * c);
+    const size_t o_sxy = o; o += up256(8 * c);
+    const size_t o_soct = o; o += up256(c);
+    const size_t o_sdesc = o; o += up256(32 * c);
+    const size_t o_col = o; o += up256(4 * (kFrameGridCols + 1));
+    const size_t o_ni = o; o += 256;
+    const size_t o_b = o; o += 256;
+    SO_HIP(hipMalloc((void**)&f->d_block, o));
+    SO_HIP(hipMemset(f->d_block, 0, o));
+    uint8_t* d = f->d_block;
+    f->d_xy_un = (float2*)(d + o_xy);
+    f->d_octave = (int8_t*)(d + o_oct);
+    f->d_desc = d + o_desc;
+    f->d_cell_start = (int32_t*)(d + o_cs);
+    f->d_cell_items = (int32_t*)(d + o_ci);
+    f->d_s_xy = (float2*)(d + o_sxy);
+    f->d_s_octave = (int8_t*)(d + o_soct);
+    f->d_s_desc = (uint4*)(d + o_sdesc);
+    f->d_col_start = (int32_t*)(d + o_col);
+    f->d_n_inside = (int32_t*)(d + o_ni);
+    f->d_bounds = (float*)(d + o_b);
+    const size_t h_xy = 0, h_perm = up256(8 * c), h_hdr = h_perm + up256(4 * c), h_total = h_hdr + 256;
+    SO_HIP(hipHostMalloc((void**)&f->h_block, h_total, hipHostMallocMapped));
+    SO_HIP(hipHostGetDevicePointer((void**)&f->h_block_dev, f->h_block, 0));
+    memset(f->h_block, 0, h_total);
+    f->h_xy_un = (float*)(f->h_block + h_xy);
+    f->h_perm = (int32_t*)(f->h_block + h_perm);
+    f->h_header = (int32_t*)(f->h_block + h_hdr);
+    f->capacity = capacity;
+    f->octave.resize(c);
+    f->angle.resize(c);
+    f->allocated = true;
+    return SO_OK;
+}
+
+int submit_impl(so_dframe* f, const uint8_t* image, bool on_device, int w, int h, int stride) {
+    if (!f) return SO_ERR_INVALID_ARG;
+    if (f->in_flight) {
+        last_error_ref() = "so_dframe_submit: the previous frame of this handle has not been collected";
+        return SO_ERR_INVALID_ARG;
+    }
+    f->ready = false;
+    int rc = on_device ? so_extractor_submit_device(f->ex, image, w, h, stride)
+                       : so_extractor_submit(f->ex, image, w, h, stride);
+    if (rc) return rc;
+    f->generation++;
+    f->in_flight = true;
+    if (!image || w <= 0 || h <= 0) return SO_OK;  // empty frame: collect hands out n = 0
+    ExtractorDeviceView V;
+    if ((rc = extractor_device_view(f->ex, &V))) return rc;
+    SO_HIP(hipSetDevice(V.device));
+    if (!f->allocated) {
+        if (V.capacity > kFrameMaxKeypoints) {
+            last_error_ref() = "so_dframe handles at most 16384 keypoints per frame";
+            return SO_ERR_CAPACITY;
+        }
+        f->device = V.device;
+        f->nlevels = V.nlevels;
+        for (int l = 0; l < 8; l++) f->scale[l] = V.scale[l];
+        if ((rc = allocate(f, V.capacity))) return rc;
+    }
+    // Frame.cc:230-274 as one launch behind the extractor's frame, same stream, no host sync in between
+    FramePrepareArgs a{};
+    a.cam = f->cam;
+    a.width = w;
+    a.height = h;
+    a.n = f->capacity;
+    a.do_bounds = 1;
+    a.do_undistort = 1;
+    a.do_grid = 1;
+    a.xy_un = reinterpret_cast<float*>(f->d_xy_un);
+    a.bounds = f->d_bounds;
+    a.cell_of = nullptr;
+    a.cell_start = f->d_cell_start;
+    a.cell_items = f->d_cell_items;
+    a.n_inside = f->d_n_inside;
+    a.ex_meta = V.meta;
+    a.ex_total = V.total;
+    a.ex_desc = V.desc;
+    for (int l = 0; l < 8; l++) a.scale[l] = V.scale[l];
+    a.octave = f->d_octave;
+    a.desc_by_index = reinterpret_cast<uint4*>(f->d_desc);
+    a.xy_un_host = reinterpret_cast<float*>(f->h_block_dev + ((uint8_t*)f->h_xy_un - f->h_block));
+    a.s_xy = f->d_s_xy;
+    a.s_octave = f->d_s_octave;
+    a.s_desc = f->d_s_desc;
+    a.perm_host = reinterpret_cast<int32_t*>(f->h_block_dev + ((uint8_t*)f->h_perm - f->h_block));
+    a.col_start = f->d_col_start;
+    a.header_host = reinterpret_cast<int32_t*>(f->h_block_dev + ((uint8_t*)f->h_header - f->h_block));
+    launch_frame_prepare(a, V.stream);
+    SO_HIP(hipGetLastError());
+    return SO_OK;
+}
+
+}  // namespace
+
+namespace {
+
+template <typename T>
+int grow(T** p, size_t old_elems, size_t new_elems, hipStream_t s) {
+    T* q = nullptr;
+    SO_HIP(hipMalloc((void**)&q, sizeof(T) * new_elems));
+    if (*p && old_elems) SO_HIP(hipMemcpyAsync(q, *p, sizeof(T) * old_elems, hipMemcpyDeviceToDevice, s));
+    SO_HIP(hipStreamSynchronize(s));
+    if (*p) SO_HIP(hipFree(*p));
+    *p = q;
+    return SO_OK;
+}
+
+int reserve(so_map* m, int slots) {
+    if (slots <= m->capacity) return SO_OK;
+    // 288 GB of HBM: the table grows geometrically and is never shrunk (a 10^6-point map is 64 MB)
+    size_t cap = m->capacity ? (size_t)m->capacity : 16384;
+    while (cap < (size_t)slots) cap *= 2;
+    const size_t old = (size_t)m->size;
+    int rc;
+    if ((rc = grow(&m->d_Xw, 3 * old, 3 * cap, m->stream))) return rc;
+    if ((rc = grow(&m->d_normal, 3 * old, 3 * cap, m->stream))) return rc;
+    if ((rc = grow(&m->d_max, old, cap, m->stream))) return rc;
+    if ((rc = grow(&m->d_min, old, cap, m->stream))) return rc;
+    if ((rc = grow(&m->d_desc, 32 * old, 32 * cap, m->stream))) return rc;
+    m->capacity = (int)cap;
+    return SO_OK;
+}
+
+int stage(so_map* m, size_t bytes) {
+    if (bytes <= m->h_stage_cap) return SO_OK;
+    if (m->h_stage) SO_HIP(hipHostFree(m->h_stage));
+    m->h_stage = nullptr;
+    m->h_stage_cap = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    SO_HIP(hipHostMalloc(&m->h_stage, want, hipHostMallocDefault));
+    m->h_stage_cap = want;
+    return SO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int so_dframe_create(so_extractor* ex, const so_camera* cam, so_dframe** out) {
+    if (!ex || !cam || !out) return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    so_dframe* f = new so_dframe();
+    f->ex = ex;
+    f->cam = FrameCam{cam->fx, cam->fy, cam->cx, cam->cy, cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
+    *out = f;
+    return SO_OK;
+}
+
+void so_dframe_destroy(so_dframe* f) {
+    if (!f) return;
+    if (f->allocated) {
+        (void)hipSetDevice(f->device);
+        ExtractorDeviceView V;
+        if (extractor_device_view(f->ex, &V) == SO_OK && V.stream) (void)hipStreamSynchronize(V.stream);
+        if (f->d_block) (void)hipFree(f->d_block);
+        if (f->h_block) (void)hipHostFree(f->h_block);
+    }
+    delete f;
+}
+
+int so_dframe_submit(so_dframe* f, const uint8_t* image, int width, int height, int stride) {
+    return submit_impl(f, image, false, width, height, stride);
+}
+
+int so_dframe_submit_device(so_dframe* f, const uint8_t* d_image, int width, int height, int stride) {
+    return submit_impl(f, d_image, true, width, height, stride);
+}
+
+int so_dframe_collect(so_dframe* f, so_keypoint* keypoints, float* xy_un, uint8_t* descriptors, int capacity,
+                      int* n_out, float* bounds4) {
+    if (!f || !n_out || !keypoints || !descriptors) return SO_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (!f->in_flight) {
+        last_error_ref() = "so_dframe_collect without a submitted frame";
+        return SO_ERR_INVALID_ARG;
+    }
+    int n = 0;
+    const int rc = so_extractor_collect(f->ex, keypoints, descriptors, capacity, &n);  // waits for the stream
+    if (rc) return rc;
+    f->in_flight = false;
+    if (!f->allocated || n == 0) {  // empty image / no keypoints: nothing ran behind the extractor
+        f->n = f->n_inside = 0;
+        f->ready = f->allocated;
+        *n_out = 0;
+        return SO_OK;
+    }
+    // the prepare kernel was enqueued behind the extractor's frame on the same stream; the extractor's collect
+    // waited for the stream on every path but the host-quadtree one, which finishes inside submit
+    ExtractorDeviceView V;
+    if (extractor_device_view(f->ex, &V) == SO_OK) SO_HIP(hipStreamSynchronize(V.stream));
+    if (f->h_header[0] != n) {
+        last_error_ref() = "so_dframe_collect: device and host keypoint counts differ";
+        return SO_ERR_HIP;
+    }
+    f->n = n;
+    f->n_inside = f->h_header[1];
+    memcpy(f->bounds, f->h_header + 4, 16);
+    for (int i = 0; i < n; i++) {
+        f->octave[(size_t)i] = keypoints[i].octave;
+        f->angle[(size_t)i] = keypoints[i].angle;
+    }
+    if (xy_un) memcpy(xy_un, f->h_xy_un, sizeof(float) * 2 * (size_t)n);
+    if (bounds4) memcpy(bounds4, f->bounds, 16);
+    f->ready = true;
+    *n_out = n;
+    return SO_OK;
+}
+
+int so_dframe_device_view(const so_dframe* f, so_dframe_view* v) {
+    if (!f || !v || !f->ready) return SO_ERR_INVALID_ARG;
+    v->n = f->n;
+    v->n_inside = f->n_inside;
+    memcpy(v->bounds, f->bounds, 16);
+    v->xy_un = reinterpret_cast<const float*>(f->d_xy_un);
+    v->octave = f->d_octave;
+    v->descriptors = f->d_desc;
+    v->cell_start = f->d_cell_start;
+    v->cell_items = f->d_cell_items;
+    v->sorted_xy = reinterpret_cast<const float*>(f->d_s_xy);
+    v->sorted_octave = f->d_s_octave;
+    v->sorted_descriptors = reinterpret_cast<const uint8_t*>(f->d_s_desc);
+    v->col_start = f->d_col_start;
+    return SO_OK;
+}
+
+// Host copies of the grid (debug / parity tests): cell_start[64*48+1], cell_items[n_inside].
+int so_dframe_get_grid(so_dframe* f, int32_t* cell_start, int32_t* cell_items, int32_t* n_inside) {
+    if (!f || !f->ready || !cell_start || !cell_items || !n_inside) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(f->device));
+    SO_HIP(hipMemcpy(cell_start, f->d_cell_start, sizeof(int32_t) * (kFrameGridCols * kFrameGridRows + 1),
+                     hipMemcpyDeviceToHost));
+    *n_inside = f->n_inside;
+    if (f->n_inside > 0) memcpy(cell_items, f->h_perm, sizeof(int32_t) * (size_t)f->n_inside);
+    return SO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// map-point table
+// ------------------------------------------------------------------------------------------------
+int so_map_create(int device, so_map** out) {
+    if (!out) return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        last_error_ref() = "no usable HIP device";
+        return SO_ERR_NO_DEVICE;
+    }
+    SO_HIP(hipSetDevice(device));
+    so_map* m = new so_map();
+    m->device = device;
+    const hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete m;
+        return hip_fail(e, "map init", __FILE__, __LINE__);
+    }
+    *out = m;
+    return SO_OK;
+}
+
+void so_map_destroy(so_map* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) {
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipStreamDestroy(m->stream);
+    }
+    for (void* p : {(void*)m->d_Xw, (void*)m->d_normal, (void*)m->d_max, (void*)m->d_min, (void*)m->d_desc})
+        if (p) (void)hipFree(p);
+    if (m->h_stage) (void)hipHostFree(m->h_stage);
+    delete m;
+}
+
+int so_map_size(const so_map* m) { return m ? m->size : 0; }
+
+int so_map_write(so_map* m, int32_t first, int32_t n, const float* Xw, const float* normal, const float* max_dist,
+                 const float* min_dist, const uint8_t* desc) {
+    if (!m || first < 0 || n < 0 || first > m->size) return SO_ERR_INVALID_ARG;
+    if (n == 0) return SO_OK;
+    const bool appending = first + n > m->size;
+    if (appending && (!Xw || !normal || !max_dist || !min_dist || !desc)) return SO_ERR_INVALID_ARG;  // new slots are written whole
+    SO_HIP(hipSetDevice(m->device));
+    int rc;
+    if ((rc = reserve(m, first + n))) return rc;
+    const size_t sn = (size_t)n;
+    if ((rc = stage(m, sn * 64))) return rc;
+    uint8_t* h = (uint8_t*)m->h_stage;
+    hipStream_t s = m->stream;
+    size_t o = 0;
+    auto put = [&](const void* src, size_t bytes, void* dst) -> int {
+        if (!src) return SO_OK;
+        memcpy(h + o, src, bytes);
+        SO_HIP(hipMemcpyAsync(dst, h + o, bytes, hipMemcpyHostToDevice, s));
+        o += bytes;
+        return SO_OK;
+    };
+    if ((rc = put(Xw, 12 * sn, m->d_Xw + 3 * (size_t)first))) return rc;
+    if ((rc = put(normal, 12 * sn, m->d_normal + 3 * (size_t)first))) return rc;
+    if ((rc = put(max_dist, 4 * sn, m->d_max + first))) return rc;
+    if ((rc = put(min_dist, 4 * sn, m->d_min + first))) return rc;
+    if ((rc = put(desc, 32 * sn, m->d_desc + 32 * (size_t)first))) return rc;
+    SO_HIP(hipStreamSynchronize(s));  // keyframe rate; afterwards every stream sees the new rows
+    if (appending) m->size = first + n;
+    return SO_OK;
+}
+
+int so_map_write_positions(so_map* m, int32_t n, const int32_t* slots, const float* Xw) {
+    if (!m || n < 0 || (n > 0 && (!slots || !Xw))) return SO_ERR_INVALID_ARG;
+    if (n == 0) return SO_OK;
+    for (int i = 0; i < n; i++)
+        if (slots[i] < 0 || slots[i] >= m->size) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    int rc;
+    const size_t sn = (size_t)n;
+    if ((rc = stage(m, sn * 16))) return rc;
+    uint8_t* h = (uint8_t*)m->h_stage;
+    memcpy(h, slots, 4 * sn);
+    memcpy(h + 4 * sn, Xw, 12 * sn);
+    // pinned memory is device-visible: the scatter kernel reads the staging block in place
+    launch_map_scatter_positions(m->d_Xw, reinterpret_cast<const int32_t*>(h), reinterpret_cast<const float*>(h + 4 * sn), n,
+                                 m->stream);
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipStreamSynchronize(m->stream));
+    return SO_OK;
+}
+
+int so_map_read(so_map* m, int32_t first, int32_t n, float* Xw, uint8_t* desc) {
+    if (!m || first < 0 || n < 0 || first + n > m->size) return SO_ERR_INVALID_ARG;
+    if (n == 0) return SO_OK;
+    SO_HIP(hipSetDevice(m->device));
+    if (Xw) SO_HIP(hipMemcpy(Xw, m->d_Xw + 3 * (size_t)first, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    if (desc) SO_HIP(hipMemcpy(desc, m->d_desc + 32 * (size_t)first, 32 * (size_t)n, hipMemcpyDeviceToHost));
+    return SO_OK;
+}
+
+}  // extern "C"

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <vector>
 
+#include "extractor_internal.h"
 #include "orb_device.h"
 #include "quadtree.h"
 #include "so_common.h"
@@ -74,6 +75,7 @@ struct so_extractor {
     uint8_t* h_desc = nullptr;        // host-mapped [cap*32 desc][cap*4 angle]
     uint8_t* h_desc_dev = nullptr;
     int out_capacity = 0;
+    DescribeDeviceOut dev_out{};      // HBM-resident copies of desc / angle / meta / total (device-quadtree path)
 
     KeypointQuadtree qt;
     std::vector<int> picked;
@@ -206,6 +208,16 @@ int allocate(so_extractor* ex, int w, int h) {
     SO_HIP(hipHostMalloc((void**)&ex->h_total, 64, hipHostMallocMapped));
     SO_HIP(hipHostGetDevicePointer((void**)&ex->h_total_dev, ex->h_total, 0));
     *ex->h_total = 0;
+    if (ex->device_qt) {
+        rc = dev_alloc(ex, &ex->dev_out.desc, (size_t)ex->out_capacity * 32, true);
+        if (rc) return rc;
+        rc = dev_alloc(ex, &ex->dev_out.angle, sizeof(float) * (size_t)ex->out_capacity, true);
+        if (rc) return rc;
+        rc = dev_alloc(ex, &ex->dev_out.meta, sizeof(SelectedKp) * (size_t)ex->out_capacity, true);
+        if (rc) return rc;
+        rc = dev_alloc(ex, &ex->dev_out.total, 64, true);
+        if (rc) return rc;
+    }
     SO_HIP(hipStreamSynchronize(ex->stream));
     ex->width = w;
     ex->height = h;
@@ -336,7 +348,7 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
                 launch_quadtree(P, ex->features_per_level, ex->qt_stride, ex->d_cands, ex->d_header, ex->d_qt_sel,
                                 ex->d_qt_count, s);
                 launch_describe_qt(P, ex->d_qt_sel, ex->d_qt_count, ex->qt_stride, ex->out_capacity, ex->h_desc_dev,
-                                   angle_dev, ex->h_meta_dev, ex->h_total_dev, s);
+                                   angle_dev, ex->h_meta_dev, ex->h_total_dev, ex->dev_out, s);
                 e = hipStreamEndCapture(s, &ex->graph);
             }
             if (e == hipSuccess) e = hipGraphInstantiate(&ex->graph_exec, ex->graph, nullptr, nullptr, 0);
@@ -373,7 +385,7 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
             if (prof) SO_HIP(hipEventRecord(ex->ev[5], s));
             float* angle_dev = reinterpret_cast<float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);
             launch_describe_qt(P, ex->d_qt_sel, ex->d_qt_count, ex->qt_stride, ex->out_capacity, ex->h_desc_dev,
-                               angle_dev, ex->h_meta_dev, ex->h_total_dev, s);
+                               angle_dev, ex->h_meta_dev, ex->h_total_dev, ex->dev_out, s);
             if (prof) SO_HIP(hipEventRecord(ex->ev[6], s));
             SO_HIP(hipGetLastError());
             ex->t_begin = t_begin;
@@ -421,6 +433,7 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
     }
     const double t_phase2 = now_ms();
     double t_asm = t_phase2;
+    *ex->h_total = n;  // device consumers of this path read the count through the host-mapped word
     if (n > 0) {
         if (prof) SO_HIP(hipEventRecord(ex->ev[5], s));
         float* angle_dev = reinterpret_cast<float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);
@@ -471,6 +484,34 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
 }
 
 }  // namespace
+
+namespace so {
+int extractor_device_view(so_extractor* ex, ExtractorDeviceView* out) {
+    if (!ex || !out) return SO_ERR_INVALID_ARG;
+    out->stream = ex->stream;
+    out->device = ex->cfg.device;
+    out->capacity = so_extractor_capacity(ex);
+    out->nlevels = ex->cfg.nlevels;
+    for (int l = 0; l < kMaxLevels; l++) out->scale[l] = l < ex->cfg.nlevels ? ex->scale[l] : 0.f;
+    out->meta = nullptr;
+    out->angle = nullptr;
+    out->desc = nullptr;
+    out->total = nullptr;
+    if (!ex->allocated) return SO_OK;
+    if (ex->device_qt && ex->P.total_tiles > 0) {
+        out->meta = ex->dev_out.meta;
+        out->angle = ex->dev_out.angle;
+        out->desc = ex->dev_out.desc;
+        out->total = ex->dev_out.total;
+    } else {  // host quadtree: survivors, descriptors and angles live in host-mapped memory
+        out->meta = ex->h_sel_dev;
+        out->angle = reinterpret_cast<const float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);
+        out->desc = ex->h_desc_dev;
+        out->total = ex->h_total_dev;
+    }
+    return SO_OK;
+}
+}  // namespace so
 
 extern "C" {
 

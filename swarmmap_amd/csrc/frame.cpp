@@ -109,7 +109,7 @@ int so_frame_prepare(so_frame_ctx* f, const so_camera* cam, int32_t width, int32
     uint8_t* od = (uint8_t*)f->h_out_dev;
     if (!compute_bounds) memcpy(ho + o_b, bounds4, 16);
     if (n > 0) SO_HIP(hipMemcpyAsync(f->d_in, f->h_in, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, f->stream));
-    FramePrepareArgs a;
+    FramePrepareArgs a{};
     a.cam = to_cam(cam);
     a.width = width;
     a.height = height;

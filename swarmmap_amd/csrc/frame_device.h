@@ -26,6 +26,21 @@ struct FramePrepareArgs {
     int32_t* cell_start;  // 64*48+1
     int32_t* cell_items;  // n
     int32_t* n_inside;
+    // ---- device-resident frame (dframe.cpp): keypoints come straight from the extractor's HBM outputs and the
+    //      matcher's candidate layout is produced here; all null / zero on the host-array path ----
+    const void* ex_meta;       // SelectedKp[n]: (x, y, level, score) in level coordinates; xy = (x, y) * scale[level]
+    const int32_t* ex_total;   // number of keypoints (device word); n above is then the capacity
+    const uint8_t* ex_desc;    // n x 32
+    float scale[8];            // mvScaleFactor
+    int8_t* octave;            // by keypoint index
+    uint4* desc_by_index;      // the frame's own copy of the descriptors (the extractor's buffer is reused by the next frame)
+    float* xy_un_host;         // host-mapped mirror of xy_un (may be null)
+    float2* s_xy;              // candidates in grid-traversal order (cell x, cell y, index): position = tie-break rank
+    int8_t* s_octave;
+    uint4* s_desc;             // 2 per candidate
+    int32_t* perm_host;        // host-mapped mirror of cell_items (position -> keypoint index)
+    int32_t* col_start;        // 65: first position of every grid column
+    int32_t* header_host;      // host-mapped {n, n_inside, 0, 0} + bounds[4] as float bits
 };
 void launch_frame_prepare(const FramePrepareArgs& a, hipStream_t s);
 
@@ -47,5 +62,7 @@ struct FrameFrustumArgs {
     int32_t* pred_level;
 };
 void launch_frame_frustum(const FrameFrustumArgs& a, hipStream_t s);
+// so_map_write_positions: Xw[slots[i]] = X[i] (slots / X may live in pinned host memory)
+void launch_map_scatter_positions(float* d_Xw, const int32_t* slots, const float* X, int n, hipStream_t s);
 
 }  // namespace so

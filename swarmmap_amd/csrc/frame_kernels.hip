@@ -4,6 +4,7 @@
 // Conventions for the arithmetic the reference delegates to un-vendored OpenCV / libm (parity unpinned):
 // see oracle/frame_oracle.h.
 #include "frame_device.h"
+#include "orb_device.h"
 
 namespace so {
 
@@ -61,7 +62,10 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
     __shared__ int s_hist[kFrameGridCols * kFrameGridRows + 1];
     __shared__ int s_scan[1024];
     __shared__ float s_b[4];
-    const int tid = threadIdx.x, n = a.n;
+    const int tid = threadIdx.x;
+    // device-resident frame: the keypoint count is a device word written by the extractor's last kernel
+    const int n = a.ex_total ? min(max(*a.ex_total, 0), a.n) : a.n;
+    const SelectedKp* meta = static_cast<const SelectedKp*>(a.ex_meta);
     constexpr int ncell = kFrameGridCols * kFrameGridRows;
     if (a.do_bounds) {
         __shared__ float s_c[4][2];
@@ -90,12 +94,39 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
     __syncthreads();
     if (a.do_undistort) {
         for (int i = tid; i < n; i += 1024) {
-            float u = a.xy[2 * i], v = a.xy[2 * i + 1];
+            float u, v;
+            if (meta) {  // ORBextractor::operator() (ORBextractor.cc:808-814): level coordinates -> level-0 pixels
+                const SelectedKp k = meta[i];
+                u = (float)k.x;
+                v = (float)k.y;
+                if (k.level != 0) {
+                    u *= a.scale[k.level];
+                    v *= a.scale[k.level];
+                }
+                a.octave[i] = (int8_t)k.level;
+            } else {
+                u = a.xy[2 * i];
+                v = a.xy[2 * i + 1];
+            }
             if (a.cam.k1 != 0.0f) frame_undistort_point(a.cam, u, v, u, v);  // else mvKeysUn = mvKeys
             a.xy_un[2 * i] = u;
             a.xy_un[2 * i + 1] = v;
+            if (a.xy_un_host) {
+                a.xy_un_host[2 * i] = u;
+                a.xy_un_host[2 * i + 1] = v;
+            }
         }
     }
+    if (a.desc_by_index) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.ex_desc);
+        for (int j = tid; j < 2 * n; j += 1024) a.desc_by_index[j] = src[j];
+    }
+    if (a.header_host && tid == 0) {
+        a.header_host[0] = n;
+        a.header_host[2] = 0;
+        a.header_host[3] = 0;
+    }
+    if (a.header_host && tid < 4) a.header_host[4 + tid] = __float_as_int(s_b[tid]);
     if (!a.do_grid) return;
     __threadfence_block();
     __syncthreads();
@@ -114,7 +145,7 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
                 key = ((uint32_t)cell << 14) | (uint32_t)i;
                 atomicAdd(&s_hist[cell], 1);
             }
-            a.cell_of[i] = cell;
+            if (a.cell_of) a.cell_of[i] = cell;
         }
         s_key[i] = key;
     }
@@ -139,6 +170,15 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
     if (tid == 1023) {
         a.cell_start[ncell] = s_scan[1023];
         *a.n_inside = s_scan[1023];
+        if (a.header_host) a.header_host[1] = s_scan[1023];
+        if (a.col_start) a.col_start[kFrameGridCols] = s_scan[1023];
+    }
+    if (a.col_start && 3 * tid < ncell) {  // first position of each grid column = start of its first cell
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int c = 3 * tid + k;
+            if (c % kFrameGridRows == 0) a.col_start[c / kFrameGridRows] = before + (k > 0 ? c0 : 0) + (k > 1 ? c1 : 0);
+        }
     }
     // bitonic sort of the keys (keys are unique; outside keypoints sort to the end)
     for (int k = 2; k <= n2; k <<= 1)
@@ -157,7 +197,19 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
             __syncthreads();
         }
     const int inside = s_scan[1023];
-    for (int i = tid; i < inside; i += 1024) a.cell_items[i] = (int32_t)(s_key[i] & 0x3FFFu);
+    for (int i = tid; i < inside; i += 1024) {
+        const int idx = (int)(s_key[i] & 0x3FFFu);
+        a.cell_items[i] = idx;
+        if (a.perm_host) a.perm_host[i] = idx;
+        if (a.s_xy) {  // the matcher's candidate layout (match_device.h), position = rank in grid-traversal order
+            a.s_xy[i] = make_float2(a.xy_un[2 * idx], a.xy_un[2 * idx + 1]);
+            a.s_octave[i] = a.octave[idx];
+        }
+    }
+    if (a.s_desc) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.ex_desc);
+        for (int j = tid; j < 2 * inside; j += 1024) a.s_desc[j] = src[2 * (int)(s_key[j >> 1] & 0x3FFFu) + (j & 1)];
+    }
 }
 
 void launch_frame_prepare(const FramePrepareArgs& a, hipStream_t s) {
@@ -211,6 +263,21 @@ __global__ __launch_bounds__(256) void frame_frustum_kernel(FrameFrustumArgs a) 
         a.pred_level[i] = nScale;
     } while (false);
     a.in_view[i] = ok;
+}
+
+__global__ __launch_bounds__(256) void map_scatter_positions_kernel(float* __restrict__ Xw, const int32_t* __restrict__ slots,
+                                                                     const float* __restrict__ X, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = slots[i];
+    Xw[3 * (size_t)s] = X[3 * i];
+    Xw[3 * (size_t)s + 1] = X[3 * i + 1];
+    Xw[3 * (size_t)s + 2] = X[3 * i + 2];
+}
+
+void launch_map_scatter_positions(float* d_Xw, const int32_t* slots, const float* X, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(map_scatter_positions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_Xw, slots, X, n);
 }
 
 void launch_frame_frustum(const FrameFrustumArgs& a, hipStream_t s) {

@@ -59,7 +59,37 @@ struct MatchQueryW {
     uint8_t active, pad;
 };
 
+// Tracking searches on device-resident data (so_track_search_*): the query of wave i is not read from a staged
+// record but built in the kernel from the map-point table and the frame pose — the projection of
+// SearchByProjection(cur, last) (code/src/ORBmatcher.cc:1242-1276) or Frame::isInFrustum + the window of
+// SearchByProjection(F, vpMapPoints) (code/src/Frame.cc:316-375, ORBmatcher.cc:52-70).  Same float / double
+// operation sequence as frame_frustum_kernel and the CPU oracle.
+struct TrackQuerySrc {
+    // map-point table (so_map), indexed by slot
+    const float* Xw;
+    const float* normal;
+    const float* max_dist;
+    const float* min_dist;
+    const uint4* desc;
+    // per query
+    const int32_t* slot;         // map slot, < 0: no map point (null = the query index itself)
+    const uint8_t* skip;         // local-map search: 1 = not searched (already matched in this frame / bad); may be null
+    const int8_t* last_octave;   // last-frame search: lastFrame.mvKeys[i].octave
+    uint8_t* in_view_out;        // local-map search: mbTrackInView per query (may be null)
+    float Tcw[12];
+    float fx, fy, cx, cy;
+    float bounds[4];             // mnMinX, mnMaxX, mnMinY, mnMaxY
+    float scale[8];              // mvScaleFactors of the current frame
+    int nlevels;
+    float th;
+    float cos_limit, log_scale_factor;  // local-map search
+    int n_slots;                 // size of the table (slots beyond it are treated as "no map point")
+};
+
 void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_t s);
+// mode 2 = last-frame search, 3 = local-map search; queries [q_first, q_first + nq) write keys / counts at [0, nq)
+void launch_topk_track(const MatchFrameDev& F, const TrackQuerySrc& T, int mode, int q_first, int nq, int K,
+                       uint32_t* d_keys, int32_t* d_count, hipStream_t s);
 // compact: d_q points to MatchQueryW records instead of MatchQuery
 void launch_topk_window(const MatchFrameDev& F, const void* d_q, bool compact, const uint4* d_qdesc, int nq, int K,
                         uint32_t* d_keys, int32_t* d_count, hipStream_t s);

@@ -95,32 +95,154 @@ __device__ __forceinline__ uint32_t make_key(const MatchQuery& Q, int dist, int 
     return ((uint32_t)dist << 16) | (uint32_t)((Q.flags & kQPreferLast) ? (0xFFFF - c) : c);
 }
 
-template <bool COMPACT>
+// Pc = mRcw * P + mtcw the way OpenCV's GEMM evaluates it for CV_32F: double accumulation, one rounding
+__device__ __forceinline__ void track_camera_point(const float* T, const float* P, float* Pc) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double s = (double)T[4 * r] * (double)P[0] + (double)T[4 * r + 1] * (double)P[1] + (double)T[4 * r + 2] * (double)P[2];
+        Pc[r] = (float)(s + (double)T[4 * r + 3]);
+    }
+}
+
+__device__ __forceinline__ double track_log(double x) {  // == frame_log (frame_kernels.hip) == orc_log
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)u);
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e = e + 1;
+    }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+}
+
+// SearchByProjection(cur, last): the projection of one last-frame map point, code/src/ORBmatcher.cc:1251-1276
+__device__ __forceinline__ MatchQuery track_query_last(const TrackQuerySrc& T, int qi, int& slot) {
+    MatchQuery Q = MatchQuery{};
+    Q.max_dist = 256;
+    slot = T.slot ? T.slot[qi] : qi;
+    if (slot < 0 || slot >= T.n_slots) return Q;
+    const int oct = T.last_octave[qi];
+    if (oct < 0 || oct >= T.nlevels) return Q;
+    const float P[3] = {T.Xw[3 * (size_t)slot], T.Xw[3 * (size_t)slot + 1], T.Xw[3 * (size_t)slot + 2]};
+    float Pc[3];
+    track_camera_point(T.Tcw, P, Pc);
+    const float invzc = 1.0f / Pc[2];
+    if (!(invzc >= 0.0f)) return Q;  // "if (invzc < 0) continue" (NaN never passes the bounds tests below either)
+    const float u = T.fx * Pc[0] * invzc + T.cx;
+    const float v = T.fy * Pc[1] * invzc + T.cy;
+    if (u < T.bounds[0] || u > T.bounds[1]) return Q;
+    if (v < T.bounds[2] || v > T.bounds[3]) return Q;
+    if (!(u >= T.bounds[0] && v >= T.bounds[2])) return Q;
+    Q.u = u;
+    Q.v = v;
+    Q.r = T.th * T.scale[oct];
+    Q.min_level = oct - 1;
+    Q.max_level = oct + 1;
+    Q.active = 1;
+    return Q;
+}
+
+// SearchLocalPoints: Frame::isInFrustum + PredictScale for one local map point (code/src/Frame.cc:316-375,
+// code/src/MapPoint.cc:466-485), then the window of SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:52-70)
+__device__ __forceinline__ MatchQuery track_query_local(const TrackQuerySrc& T, int qi, int& slot) {
+    MatchQuery Q = MatchQuery{};
+    Q.max_dist = 256;
+    slot = T.slot ? T.slot[qi] : qi;
+    if (slot < 0 || slot >= T.n_slots) return Q;
+    if (T.skip && T.skip[qi]) return Q;
+    const float* Tc = T.Tcw;
+    float Ow[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const double s = (double)Tc[0 + j] * (double)Tc[3] + (double)Tc[4 + j] * (double)Tc[7] + (double)Tc[8 + j] * (double)Tc[11];
+        Ow[j] = (float)(-s);
+    }
+    const float P[3] = {T.Xw[3 * (size_t)slot], T.Xw[3 * (size_t)slot + 1], T.Xw[3 * (size_t)slot + 2]};
+    float Pc[3];
+    track_camera_point(Tc, P, Pc);
+    if (Pc[2] < 0.0f) return Q;
+    const float invz = 1.0f / Pc[2];
+    const float u = T.fx * Pc[0] * invz + T.cx;
+    const float v = T.fy * Pc[1] * invz + T.cy;
+    if (u < T.bounds[0] || u > T.bounds[1]) return Q;
+    if (v < T.bounds[2] || v > T.bounds[3]) return Q;
+    if (!(u >= T.bounds[0] && v >= T.bounds[2])) return Q;  // NaN
+    const float max_d = T.max_dist[slot], min_d = T.min_dist[slot];
+    const float maxD = 1.2f * max_d, minD = 0.8f * min_d;
+    const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+    const double n2 = (double)PO[0] * (double)PO[0] + (double)PO[1] * (double)PO[1] + (double)PO[2] * (double)PO[2];
+    const float dist = (float)sqrt(n2);
+    if (dist < minD || dist > maxD) return Q;
+    const double dot = (double)PO[0] * (double)T.normal[3 * (size_t)slot] + (double)PO[1] * (double)T.normal[3 * (size_t)slot + 1] +
+                       (double)PO[2] * (double)T.normal[3 * (size_t)slot + 2];
+    const float vc = (float)(dot / (double)dist);
+    if (vc < T.cos_limit) return Q;
+    const float ratio = max_d / dist;
+    const float lr = (float)track_log((double)ratio);
+    int nScale = (int)ceilf(lr / T.log_scale_factor);
+    if (nScale > T.nlevels - 1) nScale = T.nlevels - 1;
+    if (nScale < 0) nScale = 0;
+    float r = vc > 0.998f ? 2.5f : 4.0f;  // RadiusByViewingCos, ORBmatcher.cc:123-128
+    if (T.th != 1.0f) r *= T.th;           // bFactor
+    Q.u = u;
+    Q.v = v;
+    Q.r = r * T.scale[nScale];
+    Q.min_level = nScale - 1;
+    Q.max_level = nScale;
+    Q.active = 1;
+    return Q;
+}
+
+// MODE 0: MatchQuery records, 1: MatchQueryW records, 2: last-frame tracking search, 3: local-map tracking search
+template <int MODE>
 __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const void* __restrict__ q,
                                                            const uint4* __restrict__ qdesc, int nq, int K,
                                                            uint32_t* __restrict__ out_keys,
-                                                           int32_t* __restrict__ out_count) {
+                                                           int32_t* __restrict__ out_count, TrackQuerySrc T,
+                                                           int q_first) {
     __shared__ uint32_t s_keys[4][kListCap];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int qi = blockIdx.x * 4 + w;
     if (qi >= nq) return;
     MatchQuery Q;
-    if (COMPACT) {
+    int slot = -1;
+    if (MODE == 1) {
         const MatchQueryW c = static_cast<const MatchQueryW*>(q)[qi];
         Q = MatchQuery{};
         Q.u = c.u; Q.v = c.v; Q.r = c.r;
         Q.min_level = c.min_level; Q.max_level = c.max_level;
         Q.active = c.active;
         Q.max_dist = 256;
-    } else {
+    } else if (MODE == 0) {
         Q = static_cast<const MatchQuery*>(q)[qi];
+    } else if (MODE == 2) {
+        Q = track_query_last(T, q_first + qi, slot);
+    } else {
+        Q = track_query_local(T, q_first + qi, slot);
+        if (T.in_view_out && lane == 0) T.in_view_out[q_first + qi] = (uint8_t)Q.active;
     }
     if (!Q.active) {
         if (lane == 0) out_count[qi] = 0;
         for (int k = lane; k < K; k += 64) out_keys[(size_t)qi * K + k] = 0xFFFFFFFFu;
         return;
     }
-    const uint4 qd0 = qdesc[2 * qi], qd1 = qdesc[2 * qi + 1];
+    const uint4* qsrc = MODE >= 2 ? T.desc + 2 * (size_t)slot : qdesc + 2 * (size_t)qi;
+    const uint4 qd0 = qsrc[0], qd1 = qsrc[1];
     const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const CellWindow W = cell_window(F, Q);
@@ -205,12 +327,24 @@ void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_
 void launch_topk_window(const MatchFrameDev& F, const void* d_q, bool compact, const uint4* d_qdesc, int nq, int K,
                         uint32_t* d_keys, int32_t* d_count, hipStream_t s) {
     if (nq <= 0) return;
+    const TrackQuerySrc none{};
     if (compact)
-        hipLaunchKernelGGL(topk_window_kernel<true>, dim3((nq + 3) / 4), dim3(256), 0, s, F, d_q, d_qdesc, nq, K, d_keys,
-                           d_count);
+        hipLaunchKernelGGL(topk_window_kernel<1>, dim3((nq + 3) / 4), dim3(256), 0, s, F, d_q, d_qdesc, nq, K, d_keys,
+                           d_count, none, 0);
     else
-        hipLaunchKernelGGL(topk_window_kernel<false>, dim3((nq + 3) / 4), dim3(256), 0, s, F, d_q, d_qdesc, nq, K, d_keys,
-                           d_count);
+        hipLaunchKernelGGL(topk_window_kernel<0>, dim3((nq + 3) / 4), dim3(256), 0, s, F, d_q, d_qdesc, nq, K, d_keys,
+                           d_count, none, 0);
+}
+
+void launch_topk_track(const MatchFrameDev& F, const TrackQuerySrc& T, int mode, int q_first, int nq, int K,
+                       uint32_t* d_keys, int32_t* d_count, hipStream_t s) {
+    if (nq <= 0) return;
+    if (mode == 2)
+        hipLaunchKernelGGL(topk_window_kernel<2>, dim3((nq + 3) / 4), dim3(256), 0, s, F, nullptr, nullptr, nq, K, d_keys,
+                           d_count, T, q_first);
+    else
+        hipLaunchKernelGGL(topk_window_kernel<3>, dim3((nq + 3) / 4), dim3(256), 0, s, F, nullptr, nullptr, nq, K, d_keys,
+                           d_count, T, q_first);
 }
 
 // Brute-force best / second-best of each row of A against all rows of B; ties: lowest index in B.

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <vector>
 
+#include "dframe_internal.h"
 #include "match_device.h"
 #include "so_common.h"
 
@@ -139,9 +140,13 @@ struct so_matcher {
     bool has_cols = false;    // candidates are in grid-traversal order and the column table is staged
     int resident_n = -1;      // F->n of the grid-ordered frame resident in the staging / device blocks (-1: none)
     bool reuse_next = false;  // so_matcher_reuse_frame: the next call's frame is the resident one
+    // identity of the resident frame (so_matcher_reuse_frame only applies when the next view is this very frame)
+    const void *res_desc = nullptr, *res_x = nullptr, *res_y = nullptr;
+    // candidates read in place from a device-resident frame (so_dframe) instead of the staged upload
+    const so_dframe* src = nullptr;
+    size_t off_slot = 0, off_skip = 0, track_end = 0;
     float min_x = 0.f, min_y = 0.f, grid_inv_w = 0.f, grid_inv_h = 0.f;
     std::vector<int> perm;     // rank -> keypoint index
-    std::vector<int> rank_of;  // keypoint index -> rank (-1: not in grid)
     std::vector<int> cell_count;
 };
 
@@ -162,8 +167,8 @@ int upload_ordered(so_matcher* m, int n, const float* x, const float* y, const i
         last_error_ref() = "matcher supports at most 65535 candidates per call";
         return SO_ERR_INVALID_ARG;
     }
-    m->rank_of.assign((size_t)n, -1);
-    for (int r = 0; r < nc; r++) m->rank_of[(size_t)m->perm[(size_t)r]] = r;
+    (void)n;
+    m->src = nullptr;
     m->n_cand = nc;
     const bool want_limit = (excluded != nullptr) || (limit_by_idx != nullptr);
     m->has_limit = want_limit;
@@ -202,10 +207,13 @@ int upload_ordered(so_matcher* m, int n, const float* x, const float* y, const i
 
 // Order the frame's keypoints the way GetFeaturesInArea visits them (cell x outer, cell y inner, insertion
 // order inside a cell = keypoint index; code/src/Frame.cc:277-292,401-427) and upload the SoA.
-int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_idx) {
+// `reuse_requested`: so_matcher_reuse_frame preceded this call (the flag is consumed at the top of every public entry
+// point, take_reuse below); it is honoured only if the view is the very frame the handle holds.
+int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_idx, bool reuse_requested) {
     const int n = F->n;
-    const bool reuse = m->reuse_next && m->resident_n == n && m->has_cols;
-    m->reuse_next = false;
+    const bool reuse = reuse_requested && m->src == nullptr && m->resident_n == n && m->has_cols &&
+                       m->res_desc == F->desc && m->res_x == F->x && m->res_y == F->y && m->min_x == F->min_x &&
+                       m->min_y == F->min_y && m->grid_inv_w == F->grid_inv_w && m->grid_inv_h == F->grid_inv_h;
     if (reuse) {  // same frame as the previous call on this handle: only the eligibility gate is re-read
         const bool want_limit = (F->excluded != nullptr) || (limit_by_idx != nullptr);
         if (want_limit) {
@@ -246,7 +254,53 @@ int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_
     for (int px = 0; px <= kGridCols; px++) cols[px] = cc[(size_t)px * kGridRows];
     m->has_cols = true;
     m->resident_n = n;
+    m->res_desc = F->desc; m->res_x = F->x; m->res_y = F->y;
     m->min_x = F->min_x; m->min_y = F->min_y; m->grid_inv_w = F->grid_inv_w; m->grid_inv_h = F->grid_inv_h;
+    return SO_OK;
+}
+
+// One-shot flag of so_matcher_reuse_frame: read and cleared before anything can return early.
+inline bool take_reuse(so_matcher* m) {
+    const bool r = m->reuse_next;
+    m->reuse_next = false;
+    return r;
+}
+
+// Candidates = a device-resident frame: nothing is sorted or uploaded, the handle only mirrors the position ->
+// keypoint map and stages the optional eligibility gate (by position) at the start of its staging block.
+int use_dframe(so_matcher* m, const so_dframe* f, const uint8_t* excluded) {
+    if (!f || !f->ready) {
+        last_error_ref() = "device-resident frame has not been collected";
+        return SO_ERR_INVALID_ARG;
+    }
+    if (f->device != m->device) {
+        last_error_ref() = "device-resident frame lives on another device";
+        return SO_ERR_INVALID_ARG;
+    }
+    const int nc = f->n_inside;
+    m->src = f;
+    m->n_cand = nc;
+    m->perm.assign(f->h_perm, f->h_perm + nc);
+    m->has_cols = true;
+    m->resident_n = -1;
+    m->min_x = f->bounds[0];
+    m->min_y = f->bounds[2];
+    m->grid_inv_w = (float)kGridCols / (f->bounds[1] - f->bounds[0]);  // Frame.cc:259-260
+    m->grid_inv_h = (float)kGridRows / (f->bounds[3] - f->bounds[2]);
+    m->off_oct = m->off_desc = m->off_cols = 0;
+    m->off_limit = 0;
+    m->frame_end = align256(sizeof(int32_t) * (size_t)(nc > 0 ? nc : 1));
+    int rc;
+    if ((rc = m->h_in.ensure_keep(m->frame_end + 256, 0))) return rc;
+    m->has_limit = excluded != nullptr;
+    if (excluded) {
+        int32_t* hl = (int32_t*)m->h_in.p;
+        for (int r = 0; r < nc; r++) hl[r] = excluded[m->perm[(size_t)r]] ? 0 : INT_MAX;
+        m->dirty_from = 0;
+    } else {
+        m->dirty_from = m->frame_end;
+    }
+    m->h_q.p = m->h_qdesc.p = nullptr;
     return SO_OK;
 }
 
@@ -282,6 +336,11 @@ MatchFrameDev frame_dev(const so_matcher* m) {
     F.xy = (const float2*)base;
     F.octave = (const int8_t*)(base + m->off_oct);
     F.desc = (const uint4*)(base + m->off_desc);
+    if (m->src) {  // the frame's own HBM arrays (dframe_internal.h), already in grid-traversal order
+        F.xy = m->src->d_s_xy;
+        F.octave = m->src->d_s_octave;
+        F.desc = m->src->d_s_desc;
+    }
     F.limit = m->has_limit ? (const int32_t*)(base + m->off_limit) : nullptr;
     F.n = m->n_cand;
     for (int l = 0; l < 8; l++) {
@@ -292,6 +351,7 @@ MatchFrameDev frame_dev(const so_matcher* m) {
     F.ex = m->ex;
     F.ey = m->ey;
     F.col_start = m->has_cols ? (const int32_t*)(base + m->off_cols) : nullptr;
+    if (m->src) F.col_start = m->src->d_col_start;
     F.min_x = m->min_x; F.min_y = m->min_y; F.grid_inv_w = m->grid_inv_w; F.grid_inv_h = m->grid_inv_h;
     return F;
 }
@@ -498,10 +558,11 @@ int so_matcher_topk(so_matcher* m, const so_frame_view* F, const int32_t* limit,
     if (!m || !frame_ok(F) || nq < 0 || K < 1 || K > 64) return SO_ERR_INVALID_ARG;
     if (nq > 0 && (!u || !v || !r || !min_level || !max_level || !qdesc || !out_idx || !out_dist || !out_count))
         return SO_ERR_INVALID_ARG;
+    const bool reuse = take_reuse(m);
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
-    int rc = upload_frame(m, F, limit);
+    int rc = upload_frame(m, F, limit, reuse);
     if (rc) return rc;
     if ((rc = ensure_queries(m, nq))) return rc;
     MatchQuery* hq = (MatchQuery*)m->h_q.p;
@@ -534,14 +595,30 @@ int so_matcher_topk(so_matcher* m, const so_frame_view* F, const int32_t* limit,
     return SO_OK;
 }
 
-// M1 — ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), code/src/ORBmatcher.cc:44-121
-int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int32_t n_mp, const uint8_t* in_view,
-                                      const float* proj_x, const float* proj_y, const float* view_cos,
-                                      const int32_t* pred_level, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
-                                      float th, float nn_ratio, int32_t* kp_to_mp, int32_t* nmatches) {
-    if (!m || !frame_ok(F) || n_mp < 0 || !kp_to_mp || !nmatches || !F->scale_factors) return SO_ERR_INVALID_ARG;
-    if (n_mp > 0 && (!in_view || !proj_x || !proj_y || !view_cos || !pred_level || !mp_desc || !mp_has_obs))
-        return SO_ERR_INVALID_ARG;
+}  // extern "C"
+
+namespace {
+
+// The host-side fields of a device-resident frame as a frame view (x / y stay null: the searches below never read
+// positions on the host).
+so_frame_view view_of(const so_dframe* f, const uint8_t* excluded) {
+    so_frame_view v{};
+    v.n = f->n;
+    v.octave = f->octave.data();
+    v.angle = f->angle.data();
+    v.excluded = excluded;
+    v.min_x = f->bounds[0]; v.max_x = f->bounds[1]; v.min_y = f->bounds[2]; v.max_y = f->bounds[3];
+    v.scale_factors = f->scale;
+    v.nlevels = f->nlevels;
+    return v;
+}
+
+// M1 — ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), code/src/ORBmatcher.cc:44-121.
+// src != null: the candidates are the device-resident frame's (F then only carries its host-side fields).
+int m1_search(so_matcher* m, const so_frame_view* F, const so_dframe* src, bool reuse, int32_t n_mp,
+              const uint8_t* in_view, const float* proj_x, const float* proj_y, const float* view_cos,
+              const int32_t* pred_level, const uint8_t* mp_desc, const uint8_t* mp_has_obs, float th, float nn_ratio,
+              int32_t* kp_to_mp, int32_t* nmatches) {
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
@@ -549,7 +626,7 @@ int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int
     for (int k = 0; k < F->n; k++) kp_to_mp[k] = -1;
     if (n_mp == 0 || F->n == 0) return SO_OK;
     constexpr int K = 8;
-    int rc = upload_frame(m, F, nullptr);
+    int rc = src ? use_dframe(m, src, F->excluded) : upload_frame(m, F, nullptr, reuse);
     if (rc) return rc;
     if ((rc = ensure_queries(m, n_mp, sizeof(MatchQueryW)))) return rc;
     MatchQueryW* hq = (MatchQueryW*)m->h_q.p;
@@ -610,14 +687,10 @@ int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int
 }
 
 // M2 — ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), code/src/ORBmatcher.cc:1223-1354
-int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, int32_t n_last, const uint8_t* valid,
-                                      const float* u, const float* v, const int32_t* last_octave,
-                                      const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
-                                      float th, int check_orientation, int32_t* kp_to_last, int32_t* nmatches) {
-    if (!m || !frame_ok(cur) || n_last < 0 || !kp_to_last || !nmatches || !cur->scale_factors)
-        return SO_ERR_INVALID_ARG;
-    if (n_last > 0 && (!valid || !u || !v || !last_octave || !mp_desc || !mp_has_obs)) return SO_ERR_INVALID_ARG;
-    if (check_orientation && n_last > 0 && (!last_angle || !cur->angle)) return SO_ERR_INVALID_ARG;
+int m2_search(so_matcher* m, const so_frame_view* cur, const so_dframe* src, bool reuse, int32_t n_last,
+              const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave, const float* last_angle,
+              const uint8_t* mp_desc, const uint8_t* mp_has_obs, float th, int check_orientation, int32_t* kp_to_last,
+              int32_t* nmatches) {
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
@@ -625,7 +698,7 @@ int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, i
     for (int k = 0; k < cur->n; k++) kp_to_last[k] = -1;
     if (n_last == 0 || cur->n == 0) return SO_OK;
     constexpr int K = 8;  // deep enough that a list exhausted by already-bound keypoints (exact re-run) is rare
-    int rc = upload_frame(m, cur, nullptr);
+    int rc = src ? use_dframe(m, src, cur->excluded) : upload_frame(m, cur, nullptr, reuse);
     if (rc) return rc;
     if ((rc = ensure_queries(m, n_last, sizeof(MatchQueryW)))) return rc;
     MatchQueryW* hq = (MatchQueryW*)m->h_q.p;
@@ -694,6 +767,66 @@ int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, i
     return SO_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int so_search_by_projection_mappoints(so_matcher* m, const so_frame_view* F, int32_t n_mp, const uint8_t* in_view,
+                                      const float* proj_x, const float* proj_y, const float* view_cos,
+                                      const int32_t* pred_level, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                                      float th, float nn_ratio, int32_t* kp_to_mp, int32_t* nmatches) {
+    if (!m) return SO_ERR_INVALID_ARG;
+    const bool reuse = take_reuse(m);
+    if (!frame_ok(F) || n_mp < 0 || !kp_to_mp || !nmatches || !F->scale_factors) return SO_ERR_INVALID_ARG;
+    if (n_mp > 0 && (!in_view || !proj_x || !proj_y || !view_cos || !pred_level || !mp_desc || !mp_has_obs))
+        return SO_ERR_INVALID_ARG;
+    return m1_search(m, F, nullptr, reuse, n_mp, in_view, proj_x, proj_y, view_cos, pred_level, mp_desc, mp_has_obs, th,
+                     nn_ratio, kp_to_mp, nmatches);
+}
+
+int so_search_by_projection_mappoints_dframe(so_matcher* m, const so_dframe* F, const uint8_t* excluded, int32_t n_mp,
+                                             const uint8_t* in_view, const float* proj_x, const float* proj_y,
+                                             const float* view_cos, const int32_t* pred_level, const uint8_t* mp_desc,
+                                             const uint8_t* mp_has_obs, float th, float nn_ratio, int32_t* kp_to_mp,
+                                             int32_t* nmatches) {
+    if (!m) return SO_ERR_INVALID_ARG;
+    (void)take_reuse(m);
+    if (!F || !F->ready || n_mp < 0 || !kp_to_mp || !nmatches) return SO_ERR_INVALID_ARG;
+    if (n_mp > 0 && (!in_view || !proj_x || !proj_y || !view_cos || !pred_level || !mp_desc || !mp_has_obs))
+        return SO_ERR_INVALID_ARG;
+    const so_frame_view v = view_of(F, excluded);
+    return m1_search(m, &v, F, false, n_mp, in_view, proj_x, proj_y, view_cos, pred_level, mp_desc, mp_has_obs, th,
+                     nn_ratio, kp_to_mp, nmatches);
+}
+
+int so_search_by_projection_lastframe(so_matcher* m, const so_frame_view* cur, int32_t n_last, const uint8_t* valid,
+                                      const float* u, const float* v, const int32_t* last_octave,
+                                      const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                                      float th, int check_orientation, int32_t* kp_to_last, int32_t* nmatches) {
+    if (!m) return SO_ERR_INVALID_ARG;
+    const bool reuse = take_reuse(m);
+    if (!frame_ok(cur) || n_last < 0 || !kp_to_last || !nmatches || !cur->scale_factors) return SO_ERR_INVALID_ARG;
+    if (n_last > 0 && (!valid || !u || !v || !last_octave || !mp_desc || !mp_has_obs)) return SO_ERR_INVALID_ARG;
+    if (check_orientation && n_last > 0 && (!last_angle || !cur->angle)) return SO_ERR_INVALID_ARG;
+    return m2_search(m, cur, nullptr, reuse, n_last, valid, u, v, last_octave, last_angle, mp_desc, mp_has_obs, th,
+                     check_orientation, kp_to_last, nmatches);
+}
+
+int so_search_by_projection_lastframe_dframe(so_matcher* m, const so_dframe* cur, const uint8_t* excluded,
+                                             int32_t n_last, const uint8_t* valid, const float* u, const float* v,
+                                             const int32_t* last_octave, const float* last_angle,
+                                             const uint8_t* mp_desc, const uint8_t* mp_has_obs, float th,
+                                             int check_orientation, int32_t* kp_to_last, int32_t* nmatches) {
+    if (!m) return SO_ERR_INVALID_ARG;
+    (void)take_reuse(m);
+    if (!cur || !cur->ready || n_last < 0 || !kp_to_last || !nmatches) return SO_ERR_INVALID_ARG;
+    if (n_last > 0 && (!valid || !u || !v || !last_octave || !mp_desc || !mp_has_obs)) return SO_ERR_INVALID_ARG;
+    if (check_orientation && n_last > 0 && !last_angle) return SO_ERR_INVALID_ARG;
+    const so_frame_view vw = view_of(cur, excluded);
+    return m2_search(m, &vw, cur, false, n_last, valid, u, v, last_octave, last_angle, mp_desc, mp_has_obs, th,
+                     check_orientation, kp_to_last, nmatches);
+}
+
 // M4 — ORBmatcher::SearchForInitialization, code/src/ORBmatcher.cc:375-479
 int so_search_for_initialization(so_matcher* m, const so_frame_view* F1, const so_frame_view* F2,
                                  float* prev_matched, int window, float nn_ratio, int check_orientation,
@@ -701,6 +834,7 @@ int so_search_for_initialization(so_matcher* m, const so_frame_view* F1, const s
     if (!m || !frame_ok(F1) || !frame_ok(F2) || !matches12 || !nmatches || (F1->n > 0 && !prev_matched))
         return SO_ERR_INVALID_ARG;
     if (check_orientation && ((F1->n > 0 && !F1->angle) || (F2->n > 0 && !F2->angle))) return SO_ERR_INVALID_ARG;
+    const bool reuse = take_reuse(m);
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
@@ -711,7 +845,7 @@ int so_search_for_initialization(so_matcher* m, const so_frame_view* F1, const s
     constexpr int K = 8;
     so_frame_view F2v = *F2;
     F2v.excluded = nullptr;  // SearchForInitialization never looks at mvpMapPoints
-    int rc = upload_frame(m, &F2v, nullptr);
+    int rc = upload_frame(m, &F2v, nullptr, reuse);
     if (rc) return rc;
     if ((rc = ensure_queries(m, n1))) return rc;
     MatchQuery* hq = (MatchQuery*)m->h_q.p;
@@ -823,6 +957,7 @@ int so_hamming_top2(so_matcher* m, const uint8_t* A, int32_t na, const uint8_t* 
                     int32_t* best_dist, int32_t* second_dist) {
     if (!m || na < 0 || nb < 0 || (na > 0 && (!A || !best_idx || !best_dist || !second_dist)) || (nb > 0 && !B))
         return SO_ERR_INVALID_ARG;
+    (void)take_reuse(m);
     if (na == 0) return SO_OK;
     SO_HIP(hipSetDevice(m->device));
     int rc;
@@ -837,6 +972,7 @@ int so_hamming_top2(so_matcher* m, const uint8_t* A, int32_t na, const uint8_t* 
 int so_distinctive_descriptors(so_matcher* m, int32_t n_points, const int32_t* offsets, const uint8_t* descriptors,
                                int32_t* best_idx, int32_t* best_median) {
     if (!m || n_points < 0 || (n_points > 0 && (!offsets || !best_idx))) return SO_ERR_INVALID_ARG;
+    (void)take_reuse(m);
     if (n_points == 0) return SO_OK;
     const int total = offsets[n_points];
     if (offsets[0] != 0 || total < 0 || (total > 0 && !descriptors)) return SO_ERR_INVALID_ARG;
@@ -856,6 +992,7 @@ int so_distinctive_descriptors(so_matcher* m, int32_t n_points, const int32_t* o
     if (m->d_in.cap < in_bytes && (rc = m->d_in.ensure(m->h_in.cap))) return rc;
     m->dirty_from = 0;  // the staging block no longer holds a candidate frame
     m->resident_n = -1;
+    m->src = nullptr;
     if ((rc = m->h_out.ensure(sizeof(int32_t) * 2 * (size_t)n_points))) return rc;
     memcpy(m->h_in.p, offsets, sizeof(int32_t) * ((size_t)n_points + 1));
     if (total > 0) memcpy((uint8_t*)m->h_in.p + off_bytes, descriptors, (size_t)total * 32);
@@ -876,6 +1013,7 @@ int so_hamming_top2_device(so_matcher* m, const uint8_t* d_A, int32_t na, const 
                            int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
     if (!m || na < 0 || nb < 0 || (na > 0 && (!d_A || !best_idx || !best_dist || !second_dist)) || (nb > 0 && !d_B))
         return SO_ERR_INVALID_ARG;
+    (void)take_reuse(m);
     if (na == 0) return SO_OK;
     SO_HIP(hipSetDevice(m->device));
     return top2_common(m, (const uint4*)d_A, na, (const uint4*)d_B, nb, best_idx, best_dist, second_dist);
@@ -960,6 +1098,7 @@ int so_search_by_bow(so_matcher* m, int variant, int32_t n1, const uint8_t* desc
         return SO_ERR_INVALID_ARG;
     if (check_orientation && ((n1 > 0 && !angle1) || (n2 > 0 && !angle2))) return SO_ERR_INVALID_ARG;
     if (!featvec_ok(fv1, n1) || !featvec_ok(fv2, n2)) return SO_ERR_INVALID_ARG;
+    (void)take_reuse(m);
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
@@ -1086,6 +1225,7 @@ int so_search_for_triangulation(so_matcher* m, int32_t n1, const float* x1, cons
         return SO_ERR_INVALID_ARG;
     if (check_orientation && ((n1 > 0 && !angle1) || (n2 > 0 && !angle2))) return SO_ERR_INVALID_ARG;
     if (!featvec_ok(fv1, n1) || !featvec_ok(fv2, n2)) return SO_ERR_INVALID_ARG;
+    (void)take_reuse(m);
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
@@ -1164,6 +1304,7 @@ int so_search_window_best(so_matcher* m, const so_frame_view* KF, int32_t nq, co
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
+    const bool reuse = take_reuse(m);
     for (int i = 0; i < nq; i++) {
         best_idx[i] = -1;
         best_dist[i] = 256;
@@ -1172,7 +1313,7 @@ int so_search_window_best(so_matcher* m, const so_frame_view* KF, int32_t nq, co
     for (int l = 0; l < 8; l++) m->inv_sigma2[l] = (chi2_gate && l < KF->nlevels) ? inv_sigma2[l] : 0.f;
     so_frame_view view = *KF;
     view.excluded = nullptr;  // Fuse / SearchBySim3 look at every keypoint of the keyframe
-    int rc = upload_frame(m, &view, nullptr);
+    int rc = upload_frame(m, &view, nullptr, reuse);
     if (rc) return rc;
     if ((rc = ensure_queries(m, nq))) return rc;
     MatchQuery* hq = (MatchQuery*)m->h_q.p;
@@ -1206,6 +1347,7 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
     if (!m || !frame_ok(F) || nq < 0 || !kp_to_query || !nmatches) return SO_ERR_INVALID_ARG;
     if (nq > 0 && (!valid || !u || !v || !radius || !min_level || !max_level || !qdesc)) return SO_ERR_INVALID_ARG;
     if (check_orientation && nq > 0 && (!q_angle || !F->angle)) return SO_ERR_INVALID_ARG;
+    const bool reuse = take_reuse(m);
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
@@ -1213,7 +1355,7 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
     for (int k = 0; k < F->n; k++) kp_to_query[k] = -1;
     if (nq == 0 || F->n == 0) return SO_OK;
     constexpr int K = 4;
-    int rc = upload_frame(m, F, nullptr);
+    int rc = upload_frame(m, F, nullptr, reuse);
     if (rc) return rc;
     if ((rc = ensure_queries(m, nq))) return rc;
     MatchQuery* hq = (MatchQuery*)m->h_q.p;
@@ -1268,6 +1410,281 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
         }
     }
     if (check_orientation) apply_rot_hist(hist, rot_item, rot_b, kp_to_query, nm);
+    *nmatches = nm;
+    return SO_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Tracking searches on device-resident inputs (so_dframe + so_map): the per-frame path of
+// Tracking::TrackWithMotionModel / TrackLocalMap without a host round trip of keypoints, descriptors or map points.
+// Per call the host sends the pose, one map slot per query (4 B) and the optional gates; projections, frustum
+// tests, window queries and the K-lists are produced by ONE launch; the order-dependent resolve stays here.
+// =====================================================================================================
+namespace {
+
+struct TrackStage {  // staging layout of one tracking search behind the (optional) limit gate
+    size_t off_slot, off_skip, end;
+};
+
+TrackQuerySrc track_src(const so_matcher* m, const so_dframe* cur, const so_map* map, const float* Tcw12, float th) {
+    TrackQuerySrc T{};
+    T.Xw = map->d_Xw;
+    T.normal = map->d_normal;
+    T.max_dist = map->d_max;
+    T.min_dist = map->d_min;
+    T.desc = reinterpret_cast<const uint4*>(map->d_desc);
+    memcpy(T.Tcw, Tcw12, 48);
+    T.fx = cur->cam.fx; T.fy = cur->cam.fy; T.cx = cur->cam.cx; T.cy = cur->cam.cy;
+    memcpy(T.bounds, cur->bounds, 16);
+    for (int l = 0; l < 8; l++) T.scale[l] = cur->scale[l];
+    T.nlevels = cur->nlevels;
+    T.th = th;
+    T.n_slots = map->size;
+    (void)m;
+    return T;
+}
+
+// Stage [limit (if any) | slots | skip] with one copy kernel and run the fused query + top-K launch.
+int run_topk_track(so_matcher* m, TrackQuerySrc T, int mode, int nq, int K, const int32_t* slots, const uint8_t* skip) {
+    int rc;
+    const size_t off_slot = m->frame_end;
+    const size_t off_skip = align256(off_slot + sizeof(int32_t) * (size_t)nq);
+    const size_t end = align256(off_skip + (size_t)nq);
+    if ((rc = m->h_in.ensure_keep(end + 256, m->frame_end))) return rc;
+    uint8_t* h = (uint8_t*)m->h_in.p;
+    if (slots) memcpy(h + off_slot, slots, sizeof(int32_t) * (size_t)nq);
+    if (skip) memcpy(h + off_skip, skip, (size_t)nq);
+    if (m->d_in.cap < end) {
+        if ((rc = m->d_in.ensure(m->h_in.cap))) return rc;
+        m->dirty_from = 0;
+    }
+    m->off_slot = off_slot;
+    m->off_skip = off_skip;
+    m->track_end = end;
+    const size_t keys_bytes = align256(sizeof(uint32_t) * (size_t)nq * K);
+    if ((rc = m->h_out.ensure(keys_bytes + sizeof(int32_t) * (size_t)nq))) return rc;
+    hipStream_t s = m->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    // one contiguous span covers whatever is new: [limit gate (if rewritten) | slots | skip]
+    size_t from = SIZE_MAX, to = 0;
+    if (m->has_limit && m->dirty_from < m->frame_end) { from = m->dirty_from; to = m->frame_end; }
+    if (slots) { from = std::min(from, off_slot); to = off_slot + sizeof(int32_t) * (size_t)nq; }
+    if (skip) { from = std::min(from, off_skip); to = off_skip + (size_t)nq; }
+    if (to > from) {
+        const size_t f16 = from & ~(size_t)15;
+        launch_stage_in((uint8_t*)m->d_in.p + f16, h + f16, to - f16, s);
+    }
+    m->dirty_from = SIZE_MAX;
+    const uint8_t* d = (const uint8_t*)m->d_in.p;
+    T.slot = slots ? reinterpret_cast<const int32_t*>(d + off_slot) : nullptr;
+    T.skip = skip ? d + off_skip : nullptr;
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_topk_track(frame_dev(m), T, mode, 0, nq, K, (uint32_t*)m->h_out.dev,
+                      (int32_t*)((uint8_t*)m->h_out.dev + keys_bytes), s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    const auto t1 = std::chrono::steady_clock::now();
+    SO_HIP(hipStreamSynchronize(s));
+    const auto t2 = std::chrono::steady_clock::now();
+    m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    m->stat[2] += 1.0;
+    m->stat[3] += (double)(to > from ? to - from : 0);
+    m->h_keys.p = m->h_out.p;
+    m->h_count.p = (uint8_t*)m->h_out.p + keys_bytes;
+    float ms = 0.f;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    return SO_OK;
+}
+
+// Exact top-K of ONE tracking query under a dynamic per-keypoint gate (see rerun_single): the query is rebuilt on
+// the device from the same inputs, only the gate is re-sent.
+int rerun_track(so_matcher* m, TrackQuerySrc T, int mode, int qi, bool has_slots, bool has_skip,
+                const std::vector<int32_t>& limit_by_idx, int K, Entry* out, int* n_found) {
+    int rc = upload_limit_only(m, limit_by_idx);
+    if (rc) return rc;
+    if ((rc = m->h_rout.ensure(512))) return rc;
+    hipStream_t s = m->stream;
+    const size_t f16 = m->dirty_from & ~(size_t)15;
+    if (m->dirty_from < m->frame_end)
+        launch_stage_in((uint8_t*)m->d_in.p + f16, (const uint8_t*)m->h_in.p + f16, m->frame_end - f16, s);
+    m->dirty_from = SIZE_MAX;
+    const uint8_t* d = (const uint8_t*)m->d_in.p;
+    T.slot = has_slots ? reinterpret_cast<const int32_t*>(d + m->off_slot) : nullptr;
+    T.skip = has_skip ? d + m->off_skip : nullptr;
+    T.in_view_out = nullptr;
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_topk_track(frame_dev(m), T, mode, qi, 1, K, (uint32_t*)m->h_rout.dev, (int32_t*)((uint8_t*)m->h_rout.dev + 256), s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipStreamSynchronize(s));
+    m->stat[2] += 1.0;
+    float ms = 0.f;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    const uint32_t* keys = (const uint32_t*)m->h_rout.p;
+    *n_found = 0;
+    for (int k = 0; k < K; k++) {
+        if (keys[k] == 0xFFFFFFFFu) break;
+        out[*n_found].dist = (int)(keys[k] >> 16);
+        out[*n_found].idx = m->perm[(size_t)(keys[k] & 0xFFFFu)];
+        (*n_found)++;
+    }
+    return SO_OK;
+}
+
+bool track_args_ok(const so_matcher* m, const so_dframe* cur, const so_map* map, const float* Tcw12) {
+    if (!m || !cur || !cur->ready || !map || !Tcw12) return false;
+    if (map->device != m->device || cur->device != m->device) {
+        last_error_ref() = "matcher, frame and map live on different devices";
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// TrackWithMotionModel's search — ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono = true),
+// code/src/ORBmatcher.cc:1223-1354, whole function (projection :1242-1276 included)
+int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_dframe* last,
+                               const so_map* map, const float* Tcw12, const int32_t* last_slot,
+                               const uint8_t* slot_has_obs, float th, int check_orientation, int32_t* kp_to_last,
+                               int32_t* nmatches) {
+    if (m) (void)take_reuse(m);
+    if (!track_args_ok(m, cur, map, Tcw12) || !last || !last->ready || !kp_to_last || !nmatches) return SO_ERR_INVALID_ARG;
+    const int n_last = last->n;
+    if (n_last > 0 && !last_slot) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
+    *nmatches = 0;
+    for (int k = 0; k < cur->n; k++) kp_to_last[k] = -1;
+    if (n_last == 0 || cur->n == 0) return SO_OK;
+    constexpr int K = 8;
+    int rc = use_dframe(m, cur, cur_excluded);
+    if (rc) return rc;
+    TrackQuerySrc T = track_src(m, cur, map, Tcw12, th);
+    T.last_octave = last->d_octave;
+    if ((rc = run_topk_track(m, T, 2, n_last, K, last_slot, nullptr))) return rc;
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
+    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    auto has_obs = [&](int i) { return !slot_has_obs || slot_has_obs[i]; };
+    std::vector<int32_t> gate;
+    std::vector<int> rot_item, rot_b;
+    int hist[HISTO_LENGTH] = {0};
+    int nm = 0;
+    for (int i = 0; i < n_last; i++) {
+        if (cnt[(size_t)i] == 0) continue;
+        Entry e[1];
+        int found = 0, walked = 0;
+        for (; walked < K && found < 1; walked++) {
+            const uint32_t key = keys[(size_t)i * K + walked];
+            if (key == 0xFFFFFFFFu) break;
+            const int idx = m->perm[(size_t)(key & 0xFFFFu)];
+            if (kp_to_last[idx] >= 0 && has_obs(kp_to_last[idx])) continue;
+            e[0].idx = idx;
+            e[0].dist = (int)(key >> 16);
+            found++;
+        }
+        if (found < 1 && walked == K && cnt[(size_t)i] > K) {
+            gate.assign((size_t)cur->n, INT_MAX);
+            for (int k = 0; k < cur->n; k++)
+                if ((cur_excluded && cur_excluded[k]) || (kp_to_last[k] >= 0 && has_obs(kp_to_last[k]))) gate[(size_t)k] = 0;
+            if ((rc = rerun_track(m, T, 2, i, true, false, gate, 1, e, &found))) return rc;
+        }
+        if (found == 0) continue;
+        if (e[0].dist <= TH_HIGH) {
+            kp_to_last[e[0].idx] = i;
+            nm++;
+            if (check_orientation) {
+                const int b = rot_bin(last->angle[(size_t)i], cur->angle[(size_t)e[0].idx]);
+                rot_item.push_back(e[0].idx);
+                rot_b.push_back(b);
+                hist[b]++;
+            }
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        three_maxima(hist, HISTO_LENGTH, i1, i2, i3);
+        for (size_t j = 0; j < rot_item.size(); j++)
+            if (rot_b[j] != i1 && rot_b[j] != i2 && rot_b[j] != i3) {
+                kp_to_last[rot_item[j]] = -1;
+                nm--;
+            }
+    }
+    *nmatches = nm;
+    return SO_OK;
+}
+
+// TrackLocalMap's search — Tracking::SearchLocalPoints (code/src/Tracking.cc:1104-1156): Frame::isInFrustum(pMP,
+// cos_limit) (code/src/Frame.cc:316-375) for every local map point that is not already matched in this frame, then
+// ORBmatcher::SearchByProjection(F, vpMapPoints, th) (code/src/ORBmatcher.cc:44-121)
+int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_map* map,
+                              const float* Tcw12, int32_t n_local, const int32_t* local_slot, const uint8_t* skip,
+                              const uint8_t* slot_has_obs, float th, float nn_ratio, float viewing_cos_limit,
+                              float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local, int32_t* nmatches) {
+    if (m) (void)take_reuse(m);
+    if (!track_args_ok(m, cur, map, Tcw12) || n_local < 0 || !kp_to_local || !nmatches) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
+    *nmatches = 0;
+    for (int k = 0; k < cur->n; k++) kp_to_local[k] = -1;
+    if (in_view) memset(in_view, 0, (size_t)n_local);
+    if (n_local == 0) return SO_OK;
+    constexpr int K = 8;
+    int rc = use_dframe(m, cur, cur_excluded);
+    if (rc) return rc;
+    TrackQuerySrc T = track_src(m, cur, map, Tcw12, th);
+    T.cos_limit = viewing_cos_limit;
+    T.log_scale_factor = log_scale_factor;
+    // mbTrackInView of every query comes back through host-mapped memory behind the K-lists
+    const size_t keys_bytes = align256(sizeof(uint32_t) * (size_t)n_local * K);
+    const size_t view_off = align256(keys_bytes + sizeof(int32_t) * (size_t)n_local);
+    if ((rc = m->h_out.ensure(view_off + (size_t)n_local))) return rc;
+    T.in_view_out = (uint8_t*)m->h_out.dev + view_off;
+    if ((rc = run_topk_track(m, T, 3, n_local, K, local_slot, skip))) return rc;
+    const uint8_t* view = (const uint8_t*)m->h_out.p + view_off;
+    if (in_view) memcpy(in_view, view, (size_t)n_local);
+    if (cur->n == 0) return SO_OK;
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
+    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    auto has_obs = [&](int i) { return !slot_has_obs || slot_has_obs[i]; };
+    std::vector<int32_t> gate;
+    int nm = 0;
+    for (int i = 0; i < n_local; i++) {
+        if (!view[i] || cnt[(size_t)i] == 0) continue;
+        Entry e[2];
+        int found = 0, walked = 0;
+        for (; walked < K && found < 2; walked++) {
+            const uint32_t key = keys[(size_t)i * K + walked];
+            if (key == 0xFFFFFFFFu) break;
+            const int idx = m->perm[(size_t)(key & 0xFFFFu)];
+            if (kp_to_local[idx] >= 0 && has_obs(kp_to_local[idx])) continue;  // ORBmatcher.cc:83-85
+            e[found].idx = idx;
+            e[found].dist = (int)(key >> 16);
+            found++;
+        }
+        if (found < 2 && walked == K && cnt[(size_t)i] > K) {
+            gate.assign((size_t)cur->n, INT_MAX);
+            for (int k = 0; k < cur->n; k++)
+                if ((cur_excluded && cur_excluded[k]) || (kp_to_local[k] >= 0 && has_obs(kp_to_local[k]))) gate[(size_t)k] = 0;
+            if ((rc = rerun_track(m, T, 3, i, local_slot != nullptr, skip != nullptr, gate, 2, e, &found))) return rc;
+        }
+        if (found == 0) continue;
+        const int bestDist = e[0].dist, bestIdx = e[0].idx, bestLevel = cur->octave[(size_t)bestIdx];
+        const int bestDist2 = found > 1 ? e[1].dist : 256;
+        const int bestLevel2 = found > 1 ? cur->octave[(size_t)e[1].idx] : -1;
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;
+            kp_to_local[bestIdx] = i;
+            nm++;
+        }
+    }
     *nmatches = nm;
     return SO_OK;
 }

@@ -74,8 +74,16 @@ void launch_emit(const PyramidParams& p, const int32_t* d_rowcount, Candidate* c
                  CandidateHeader* hdr_b, int cand_capacity, hipStream_t s);
 void launch_quadtree(const PyramidParams& p, const int* n_target, int sel_stride, const Candidate* d_cands,
                      const CandidateHeader* d_hdr, SelectedKp* d_sel, int32_t* d_count, hipStream_t s);
+// HBM-resident copies of the frame's outputs (read by the device-resident frame, dframe.cpp); members may be null
+struct DescribeDeviceOut {
+    uint8_t* desc;     // capacity x 32
+    float* angle;      // capacity
+    SelectedKp* meta;  // capacity
+    int32_t* total;
+};
 void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, const int32_t* d_qt_count, int qt_stride,
-                        int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total, hipStream_t s);
+                        int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total,
+                        const DescribeDeviceOut& dev, hipStream_t s);
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,
                      hipStream_t s);
 

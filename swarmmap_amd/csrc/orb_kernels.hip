@@ -494,7 +494,9 @@ constexpr int kBlur = 37, kBlurPitch = 40;    // blurred window
 
 __device__ __forceinline__ void describe_body(const PyramidParams& P, const SelectedKp kp, const int id,
                                               uint8_t* __restrict__ desc, float* __restrict__ angle_out,
-                                              uint8_t* patch, float* rowp, uint8_t* blur) {
+                                              uint8_t* patch, float* rowp, uint8_t* blur,
+                                              uint8_t* __restrict__ desc2 = nullptr,
+                                              float* __restrict__ angle2 = nullptr) {
     const int lane = threadIdx.x;
     const LevelDesc& L = P.lv[kp.level];
     const int x = kp.x, y = kp.y;
@@ -564,6 +566,11 @@ __device__ __forceinline__ void describe_body(const PyramidParams& P, const Sele
         unsigned long long* o = reinterpret_cast<unsigned long long*>(desc + (size_t)id * 32);
         o[0] = words[0]; o[1] = words[1]; o[2] = words[2]; o[3] = words[3];
         angle_out[id] = kp_dir;
+        if (desc2) {  // HBM-resident copy for the device-resident frame (dframe.cpp)
+            unsigned long long* o2 = reinterpret_cast<unsigned long long*>(desc2 + (size_t)id * 32);
+            o2[0] = words[0]; o2[1] = words[1]; o2[2] = words[2]; o2[3] = words[3];
+            angle2[id] = kp_dir;
+        }
     }
 }
 
@@ -579,12 +586,13 @@ __global__ __launch_bounds__(64) void describe_kernel(PyramidParams P, const Sel
 
 // Same, fed by the device quadtree: block b finds its (level, k) from the per-level survivor counts, describes
 // qt_sel[level][k] and writes descriptor / angle / keypoint record at the compact output index, straight into
-// host-mapped memory.  Launched with the capacity as grid; surplus blocks exit.
+// host-mapped memory (the caller's copy) and into HBM (`dev`: what the device-resident frame reads).  Launched
+// with the capacity as grid; surplus blocks exit.
 __global__ __launch_bounds__(64) void describe_qt_kernel(PyramidParams P, const SelectedKp* __restrict__ qt_sel,
                                                           const int32_t* __restrict__ qt_count, int qt_stride,
                                                           uint8_t* __restrict__ desc, float* __restrict__ angle_out,
                                                           SelectedKp* __restrict__ meta_out,
-                                                          int32_t* __restrict__ total_out) {
+                                                          int32_t* __restrict__ total_out, DescribeDeviceOut dev) {
     __shared__ uint8_t patch[kPatch * kPatchPitch];
     __shared__ float rowp[kPatch * kBlur];
     __shared__ uint8_t blur[kBlur * kBlurPitch];
@@ -599,17 +607,22 @@ __global__ __launch_bounds__(64) void describe_qt_kernel(PyramidParams P, const 
         int t = 0;
         for (int l = 0; l < P.nlevels; l++) t += qt_count[l];
         *total_out = t;
+        if (dev.total) *dev.total = t;
     }
     if (lvl < 0) return;
     const SelectedKp kp = qt_sel[(size_t)lvl * qt_stride + (id - base)];
-    if (threadIdx.x == 0) meta_out[id] = kp;
-    describe_body(P, kp, id, desc, angle_out, patch, rowp, blur);
+    if (threadIdx.x == 0) {
+        meta_out[id] = kp;
+        if (dev.meta) dev.meta[id] = kp;
+    }
+    describe_body(P, kp, id, desc, angle_out, patch, rowp, blur, dev.desc, dev.angle);
 }
 
 void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, const int32_t* d_qt_count, int qt_stride,
-                        int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total, hipStream_t s) {
+                        int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total,
+                        const DescribeDeviceOut& dev, hipStream_t s) {
     hipLaunchKernelGGL(describe_qt_kernel, dim3(capacity), dim3(64), 0, s, p, d_qt_sel, d_qt_count, qt_stride, desc,
-                       angle, meta, total);
+                       angle, meta, total, dev);
 }
 
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,

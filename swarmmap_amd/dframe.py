@@ -1,0 +1,205 @@
+"""Host mirror of the device-resident frame, the device-resident map-point table and the tracking searches over them
+(so_dframe_* / so_map_* / so_track_search_* in include/swarmorb.h).  Thin ctypes binding; no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .extractor import KP_DTYPE
+from .frame import GRID_COLS, GRID_ROWS, SoCamera
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _bind(lib):
+    if getattr(lib, "_dframe_bound", False):
+        return
+    vp, i32, f, ip = C.c_void_p, C.c_int32, C.c_float, C.POINTER(C.c_int32)
+    lib.so_dframe_create.argtypes = [vp, C.POINTER(SoCamera), C.POINTER(vp)]
+    lib.so_dframe_destroy.argtypes = [vp]
+    lib.so_dframe_destroy.restype = None
+    lib.so_dframe_submit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.so_dframe_submit_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.so_dframe_collect.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int), vp]
+    lib.so_dframe_get_grid.argtypes = [vp, vp, vp, ip]
+    lib.so_map_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.so_map_destroy.argtypes = [vp]
+    lib.so_map_destroy.restype = None
+    lib.so_map_size.argtypes = [vp]
+    lib.so_map_write.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.so_map_write_positions.argtypes = [vp, i32, vp, vp]
+    lib.so_map_read.argtypes = [vp, i32, i32, vp, vp]
+    lib.so_search_by_projection_mappoints_dframe.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, f, f, vp, ip]
+    lib.so_search_by_projection_lastframe_dframe.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, f, C.c_int,
+                                                             vp, ip]
+    lib.so_track_search_last_frame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, f, C.c_int, vp, ip]
+    lib.so_track_search_local_map.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, f, f, f, f, vp, vp, ip]
+    lib._dframe_bound = True
+
+
+class DeviceFrame:
+    """ORB_SLAM2::Frame's constructor (Frame.cc:218-275) with the results kept in HBM; bound to one ORBextractor."""
+
+    def __init__(self, extractor, K, dist=(0, 0, 0, 0, 0)):
+        self._lib = _lib.load_library()
+        _bind(self._lib)
+        self._ex = extractor  # keeps the extractor alive
+        d = list(dist) + [0.0] * (5 - len(dist))
+        self.cam = SoCamera(*[float(v) for v in K], *[float(v) for v in d])
+        self._h = C.c_void_p()
+        _lib.check(self._lib.so_dframe_create(extractor._h, C.byref(self.cam), C.byref(self._h)))
+        cap = extractor._cap
+        self._cap = cap
+        self._kps = np.zeros(cap, KP_DTYPE)
+        self._desc = np.zeros((cap, 32), np.uint8)
+        self._xy_un = np.zeros((cap, 2), np.float32)
+        self.bounds = np.zeros(4, np.float32)
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.so_dframe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def submit(self, image):
+        if image.dtype != np.uint8 or image.ndim != 2 or image.strides[1] != 1:
+            raise ValueError("image must be a row-contiguous CV_8UC1 array")
+        self._inflight = image
+        _lib.check(self._lib.so_dframe_submit(self._h, _vp(image), image.shape[1], image.shape[0], image.strides[0]))
+
+    def submit_device(self, d_ptr, width, height, stride):
+        _lib.check(self._lib.so_dframe_submit_device(self._h, C.c_void_p(d_ptr), width, height, stride))
+
+    def collect(self):
+        """Returns (keypoints, xy_un, descriptors): host copies of mvKeys, mvKeysUn[i].pt and mDescriptors."""
+        n = C.c_int(0)
+        _lib.check(self._lib.so_dframe_collect(self._h, _vp(self._kps), _vp(self._xy_un), _vp(self._desc), self._cap,
+                                               C.byref(n), _vp(self.bounds)))
+        self._inflight = None
+        self.n = n.value
+        return self._kps[:self.n], self._xy_un[:self.n], self._desc[:self.n]
+
+    def __call__(self, image):
+        self.submit(image)
+        return self.collect()
+
+    def grid(self):
+        cs = np.zeros(GRID_COLS * GRID_ROWS + 1, np.int32)
+        items = np.zeros(max(self.n, 1), np.int32)
+        n_in = C.c_int32(0)
+        _lib.check(self._lib.so_dframe_get_grid(self._h, _vp(cs), _vp(items), C.byref(n_in)))
+        return cs, items[:n_in.value].copy()
+
+
+class DeviceMap:
+    """MapPoint fields read by the per-frame operators, resident in HBM, indexed by slot."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load_library()
+        _bind(self._lib)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.so_map_create(int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.so_map_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __len__(self):
+        return int(self._lib.so_map_size(self._h))
+
+    def write(self, first, Xw=None, normal=None, max_dist=None, min_dist=None, desc=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, t) for a, t in
+                ((Xw, np.float32), (normal, np.float32), (max_dist, np.float32), (min_dist, np.float32), (desc, np.uint8))]
+        n = next(len(a.reshape(-1, w)) for a, w in zip(arrs, (3, 3, 1, 1, 32)) if a is not None)
+        _lib.check(self._lib.so_map_write(self._h, int(first), n, *[_vp(a) for a in arrs]))
+
+    def append(self, Xw, normal, max_dist, min_dist, desc):
+        first = len(self)
+        self.write(first, Xw, normal, max_dist, min_dist, desc)
+        return first
+
+    def write_positions(self, slots, Xw):
+        s = np.ascontiguousarray(slots, np.int32)
+        X = np.ascontiguousarray(Xw, np.float32).reshape(-1, 3)
+        _lib.check(self._lib.so_map_write_positions(self._h, len(s), _vp(s), _vp(X)))
+
+    def read(self, first, n):
+        X, d = np.zeros((n, 3), np.float32), np.zeros((n, 32), np.uint8)
+        _lib.check(self._lib.so_map_read(self._h, int(first), int(n), _vp(X), _vp(d)))
+        return X, d
+
+
+def search_last_frame(matcher, cur, last, dmap, Tcw, last_slot, th, excluded=None, has_obs=None):
+    """so_track_search_last_frame: (nmatches, kp_to_last)."""
+    lib = matcher._lib
+    _bind(lib)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    slot = np.ascontiguousarray(last_slot, np.int32)
+    assert len(slot) == last.n
+    ex = None if excluded is None else np.ascontiguousarray(excluded, np.uint8)
+    ho = None if has_obs is None else np.ascontiguousarray(has_obs, np.uint8)
+    out = np.full(cur.n, -1, np.int32)
+    nm = C.c_int32(0)
+    _lib.check(lib.so_track_search_last_frame(matcher._h, cur._h, _vp(ex), last._h, dmap._h, _vp(T), _vp(slot), _vp(ho),
+                                              float(th), int(matcher.mbCheckOrientation), _vp(out), C.byref(nm)))
+    return nm.value, out
+
+
+def search_local_map(matcher, cur, dmap, Tcw, n_local, th, cos_limit, log_scale_factor, local_slot=None, skip=None,
+                     excluded=None, has_obs=None):
+    """so_track_search_local_map: (nmatches, kp_to_local, in_view)."""
+    lib = matcher._lib
+    _bind(lib)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    slot = None if local_slot is None else np.ascontiguousarray(local_slot, np.int32)
+    sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+    ex = None if excluded is None else np.ascontiguousarray(excluded, np.uint8)
+    ho = None if has_obs is None else np.ascontiguousarray(has_obs, np.uint8)
+    in_view = np.zeros(max(n_local, 1), np.uint8)
+    out = np.full(cur.n, -1, np.int32)
+    nm = C.c_int32(0)
+    _lib.check(lib.so_track_search_local_map(matcher._h, cur._h, _vp(ex), dmap._h, _vp(T), int(n_local), _vp(slot),
+                                             _vp(sk), _vp(ho), float(th), float(matcher.mfNNratio), float(cos_limit),
+                                             float(log_scale_factor), _vp(in_view), _vp(out), C.byref(nm)))
+    return nm.value, out, in_view[:n_local]
+
+
+def search_mappoints_dframe(matcher, cur, mps, th, excluded=None):
+    """so_search_by_projection_mappoints_dframe (host-side queries, device-resident candidates)."""
+    lib = matcher._lib
+    _bind(lib)
+    a = {k: np.ascontiguousarray(mps[k], t) for k, t in
+         (("in_view", np.uint8), ("proj_x", np.float32), ("proj_y", np.float32), ("view_cos", np.float32),
+          ("pred_level", np.int32), ("desc", np.uint8), ("has_obs", np.uint8))}
+    ex = None if excluded is None else np.ascontiguousarray(excluded, np.uint8)
+    out = np.full(cur.n, -1, np.int32)
+    nm = C.c_int32(0)
+    _lib.check(lib.so_search_by_projection_mappoints_dframe(
+        matcher._h, cur._h, _vp(ex), len(a["proj_x"]), _vp(a["in_view"]), _vp(a["proj_x"]), _vp(a["proj_y"]),
+        _vp(a["view_cos"]), _vp(a["pred_level"]), _vp(a["desc"]), _vp(a["has_obs"]), float(th),
+        float(matcher.mfNNratio), _vp(out), C.byref(nm)))
+    return nm.value, out
+
+
+def search_lastframe_dframe(matcher, cur, last, th, excluded=None):
+    """so_search_by_projection_lastframe_dframe (host-side queries, device-resident candidates)."""
+    lib = matcher._lib
+    _bind(lib)
+    a = {k: np.ascontiguousarray(last[k], t) for k, t in
+         (("valid", np.uint8), ("u", np.float32), ("v", np.float32), ("octave", np.int32), ("angle", np.float32),
+          ("desc", np.uint8), ("has_obs", np.uint8))}
+    ex = None if excluded is None else np.ascontiguousarray(excluded, np.uint8)
+    out = np.full(cur.n, -1, np.int32)
+    nm = C.c_int32(0)
+    _lib.check(lib.so_search_by_projection_lastframe_dframe(
+        matcher._h, cur._h, _vp(ex), len(a["u"]), _vp(a["valid"]), _vp(a["u"]), _vp(a["v"]), _vp(a["octave"]),
+        _vp(a["angle"]), _vp(a["desc"]), _vp(a["has_obs"]), float(th), int(matcher.mbCheckOrientation), _vp(out),
+        C.byref(nm)))
+    return nm.value, out

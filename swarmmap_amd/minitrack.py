@@ -15,7 +15,6 @@ the same interface and compare trajectories.
 """
 import numpy as np
 
-from .matcher import FrameView
 
 TH_LAST_FRAME = 15.0      # Tracking.cc:1014 (monocular)
 MIN_MATCHES_MOTION = 20   # Tracking.cc:1020
@@ -23,17 +22,20 @@ COS_LIMIT = 0.5           # Tracking.cc:1133 isInFrustum(pMP, 0.5)
 
 
 class HipBackend:
-    """The product's operators (C ABI through the ctypes mirrors)."""
+    """The product's operators (C ABI through the ctypes mirrors), device-resident: two DeviceFrames alternate on one
+    extractor, the map lives in a DeviceMap, the two tracking searches build their queries on the GPU."""
 
     name = "hip"
 
-    def __init__(self, K, nfeatures=1000, device=0):
+    def __init__(self, K, nfeatures=1000, device=0, dist=(0, 0, 0, 0, 0)):
+        from .dframe import DeviceFrame, DeviceMap
         from .extractor import ORBextractor
-        from .frame import FramePostProcessor
         from .matcher import ORBmatcher
         from .optimizer import Optimizer
         self.ex = ORBextractor(nfeatures, 1.2, 8, 20, 7, device=device)
-        self.fp = FramePostProcessor(K, device=device)
+        self.frames = [DeviceFrame(self.ex, K, dist), DeviceFrame(self.ex, K, dist)]
+        self.cur = -1                                          # index of the current frame's handle
+        self.map = DeviceMap(device)
         self.m_last = ORBmatcher(0.9, True, device=device)    # Tracking.cc:998
         self.m_map = ORBmatcher(0.8, True, device=device)     # Tracking.cc:1153
         self.opt = Optimizer(device=device)
@@ -42,21 +44,28 @@ class HipBackend:
     def tables(self):
         return (self.ex.GetScaleFactors(), self.ex.GetInverseScaleSigmaSquares())
 
-    def extract(self, img):
-        return self.ex(img)
+    def new_frame(self, img):
+        self.cur = (self.cur + 1) % 2
+        f = self.frames[self.cur]
+        kps, xy_un, desc = f(img)
+        return kps.copy(), xy_un.copy(), desc.copy(), f.bounds.copy()
 
-    def prepare(self, xy, w, h):
-        r = self.fp.prepare(xy, w, h, grid=False)
-        return r["xy_un"], r["bounds"]
+    def search_last(self, Tcw, last_slot, th):
+        from . import dframe as dfm
+        return dfm.search_last_frame(self.m_last, self.frames[self.cur], self.frames[1 - self.cur], self.map, Tcw,
+                                     last_slot, th)
 
-    def search_last(self, F, last, th):
-        return self.m_last.SearchByProjectionLastFrame(F, last, th)
+    def search_local(self, Tcw, first, n_local, skip, excluded, th, log_sf):
+        from . import dframe as dfm
+        slots = None if first == 0 else np.arange(first, first + n_local, dtype=np.int32)
+        return dfm.search_local_map(self.m_map, self.frames[self.cur], self.map, Tcw, n_local, th, COS_LIMIT, log_sf,
+                                    local_slot=slots, skip=skip, excluded=excluded)
 
-    def frustum(self, bounds, Tcw, Xw, normal, max_d, min_d, log_sf, nlevels):
-        return self.fp.is_in_frustum(Tcw, Xw, normal, max_d, min_d, COS_LIMIT, log_sf, nlevels, bounds=bounds)
+    def map_append(self, X, normal, max_d, min_d, desc):
+        self.map.append(X, normal, max_d, min_d, desc)
 
-    def search_map(self, F, mps, th):
-        return self.m_map.SearchByProjectionMapPoints(F, mps, th)
+    def map_set_positions(self, slots, X):
+        self.map.write_positions(slots, X)
 
     def pose(self, Tcw, intr, Xw, obs, w):
         n, T, outl, _ = self.opt.PoseOptimization(Tcw, intr, Xw, obs, w)
@@ -67,7 +76,7 @@ class HipBackend:
         return r["Tcw"], r["Xw"], r["outlier"]
 
     def close(self):
-        for o in (self.ex, self.fp, self.m_last, self.m_map, self.opt, self.lba):
+        for o in self.frames + [self.map, self.ex, self.m_last, self.m_map, self.opt, self.lba]:
             o.close()
 
 
@@ -127,8 +136,14 @@ def _local_window(kfs, mp_X, intr, n_free=6, n_fixed=8):
     return prob, poses, pts, np.concatenate(ref)
 
 
-def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_ratio=0.7, local_ba=False):
-    """Returns dict(centres (n,3), poses (n,12), matches_last, matches_map, inliers, n_map_points[, lba_*])."""
+def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_ratio=0.7, local_ba=False,
+          local_keyframes=0, third_pose=False, frames=None):
+    """Returns dict(centres (n,3), poses (n,12), matches_last, matches_map, inliers, n_map_points[, lba_*]).
+    local_keyframes > 0: the local map (Tracking::UpdateLocalMap) is the points created at the last that many
+    keyframes instead of the whole map.  third_pose: one more PoseOptimization per frame, from the last frame's pose
+    over the final matches (what Tracking::TrackReferenceKeyFrame does when the motion model fails; the per-frame
+    replay of SURVEY.md 8d counts three calls), result not used.  frames: optional list of images (else
+    stream.frame(t))."""
     intr = np.asarray(K, np.float32)
     fx, fy, cx, cy = [float(v) for v in intr]
     sf, inv_sigma2 = backend.tables()
@@ -136,17 +151,14 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
     inv_sigma2 = np.asarray(inv_sigma2, np.float32)
     nlevels = len(sf)
     log_sf = float(np.log(np.float32(1.2)))
-    w, h = stream.w, stream.h
 
-    # the map: world position, descriptor, reference normal and scale-invariance distances (MapPoint.cc:395-433)
+    # the host's copy of the map: world position, descriptor, reference normal and scale-invariance distances
+    # (MapPoint.cc:395-433); the backend keeps its own (device-resident for the HIP path)
     mp_X = np.zeros((0, 3), np.float32)
-    mp_desc = np.zeros((0, 32), np.uint8)
-    mp_normal = np.zeros((0, 3), np.float32)
-    mp_max = np.zeros(0, np.float32)
-    mp_min = np.zeros(0, np.float32)
+    kf_first_slot = []    # first map slot created at each keyframe
 
     def add_points(T, xy_un, kps, desc, sel):
-        nonlocal mp_X, mp_desc, mp_normal, mp_max, mp_min
+        nonlocal mp_X
         R, t = T[:3, :3], T[:3, 3]
         rays = np.stack([(xy_un[sel, 0] - cx) / fx, (xy_un[sel, 1] - cy) / fy, np.ones(sel.sum())], 1)
         Ow = -R.T @ t
@@ -158,10 +170,11 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
         mx = dist * sf[kps["octave"][sel]]
         first = len(mp_X)
         mp_X = np.concatenate([mp_X, X.astype(np.float32)])
-        mp_desc = np.concatenate([mp_desc, desc[sel]])
-        mp_normal = np.concatenate([mp_normal, (PO / dist[:, None]).astype(np.float32)])
-        mp_max = np.concatenate([mp_max, (1.2 * mx).astype(np.float32)])                    # GetMaxDistanceInvariance
-        mp_min = np.concatenate([mp_min, (0.8 * mx / sf[nlevels - 1]).astype(np.float32)])  # GetMinDistanceInvariance
+        backend.map_append(X.astype(np.float32), (PO / dist[:, None]).astype(np.float32),
+                           (1.2 * mx).astype(np.float32),                    # GetMaxDistanceInvariance
+                           (0.8 * mx / sf[nlevels - 1]).astype(np.float32),  # GetMinDistanceInvariance
+                           desc[sel])
+        kf_first_slot.append(first)
         return first
 
     poses, centres = [], []
@@ -169,14 +182,12 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
     log = dict(matches_last=[], matches_map=[], inliers=[], n_map_points=[], lba_edges=[], lba_outliers=[])
     T_last = np.eye(4)
     velocity = np.eye(4)
-    last = None           # (xy_un, kps, desc, kp_mp, outlier)
+    last = None           # (kps, kp_mp, outlier)
     kf_inliers = 0
 
     for t in range(n_frames):
-        img = stream.frame(t)
-        kps, desc = backend.extract(img)
-        xy = np.stack([kps["x"], kps["y"]], 1).astype(np.float32)
-        xy_un, bounds = backend.prepare(xy, w, h)
+        img = frames[t] if frames is not None else stream.frame(t)
+        kps, xy_un, desc, bounds = backend.new_frame(img)
         n = len(kps)
         kp_mp = np.full(n, -1, np.int64)
         if t == 0:
@@ -191,22 +202,11 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
             # ---- TrackWithMotionModel: project the last frame's map points with the predicted pose -------------
             T_pred = (velocity @ T_last)
             Tp = T_pred[:3, :4].astype(np.float32)
-            lx, lk, ld, lmp, lout = last
-            has = (lmp >= 0) & ~lout
-            Xl = mp_X[np.where(has, lmp, 0)]
-            Xc = Xl @ Tp[:, :3].T + Tp[:, 3]                     # float32, ORBmatcher.cc:1262-1270
-            with np.errstate(divide="ignore", invalid="ignore"):
-                invz = np.float32(1.0) / Xc[:, 2]
-                u = np.float32(fx) * Xc[:, 0] * invz + np.float32(cx)
-                v = np.float32(fy) * Xc[:, 1] * invz + np.float32(cy)
-            valid = has & (invz >= 0) & (u >= bounds[0]) & (u <= bounds[1]) & (v >= bounds[2]) & (v <= bounds[3])
-            u = np.where(valid, u, 0).astype(np.float32); v = np.where(valid, v, 0).astype(np.float32)
-            F = FrameView(xy_un[:, 0], xy_un[:, 1], kps["octave"], kps["angle"], desc, bounds, sf)
-            lastd = dict(valid=valid.astype(np.uint8), u=u, v=v, octave=lk["octave"], angle=lk["angle"],
-                         desc=mp_desc[np.where(has, lmp, 0)], has_obs=np.ones(len(lk), np.uint8))
-            nm, k2l = backend.search_last(F, lastd, TH_LAST_FRAME)
+            lk, lmp, lout = last
+            last_slot = np.where((lmp >= 0) & ~lout, lmp, -1).astype(np.int32)
+            nm, k2l = backend.search_last(Tp.reshape(12), last_slot, TH_LAST_FRAME)
             if nm < MIN_MATCHES_MOTION:
-                nm, k2l = backend.search_last(F, lastd, 2 * TH_LAST_FRAME)
+                nm, k2l = backend.search_last(Tp.reshape(12), last_slot, 2 * TH_LAST_FRAME)
             bound = k2l >= 0
             kp_mp[bound] = lmp[k2l[bound]]
             log["matches_last"].append(int(nm))
@@ -217,20 +217,25 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
             T_a = np.asarray(T12, np.float32).reshape(3, 4)
 
             # ---- TrackLocalMap: SearchLocalPoints + PoseOptimization --------------------------------------------
-            fr = backend.frustum(bounds, T_a.reshape(12), mp_X, mp_normal, mp_max, mp_min, log_sf, nlevels)
-            in_view = fr["in_view"].copy()
-            in_view[kp_mp[kp_mp >= 0]] = 0                  # already matched: mbTrackInView = false (:1117-1124)
+            n_map = len(mp_X)
+            first = 0
+            if local_keyframes > 0 and len(kf_first_slot) > local_keyframes:
+                first = kf_first_slot[-local_keyframes]
+            n_local = n_map - first
+            skip = np.zeros(n_local, np.uint8)
+            cur_mp = kp_mp[kp_mp >= 0]
+            skip[cur_mp[cur_mp >= first] - first] = 1       # already matched: mbTrackInView = false (:1117-1124)
             excluded = (kp_mp >= 0).astype(np.uint8)
-            F2 = FrameView(xy_un[:, 0], xy_un[:, 1], kps["octave"], kps["angle"], desc, bounds, sf, excluded=excluded)
-            mps = dict(in_view=in_view, proj_x=fr["proj_x"], proj_y=fr["proj_y"], view_cos=fr["view_cos"],
-                       pred_level=fr["pred_level"], desc=mp_desc, has_obs=np.ones(len(mp_X), np.uint8))
-            nm2, k2m = backend.search_map(F2, mps, 1.0)
+            nm2, k2m, _ = backend.search_local(T_a.reshape(12), first, n_local, skip, excluded, 1.0, log_sf)
             newly = k2m >= 0
-            kp_mp[newly] = k2m[newly]
+            kp_mp[newly] = first + k2m[newly]
             log["matches_map"].append(int(nm2))
             idx = np.nonzero(kp_mp >= 0)[0]
             n_in, T12, outl = backend.pose(T_a.reshape(12), intr, mp_X[kp_mp[idx]], xy_un[idx],
                                            inv_sigma2[kps["octave"][idx]])
+            if third_pose:
+                backend.pose(T_last[:3, :4].astype(np.float32).reshape(12), intr, mp_X[kp_mp[idx]], xy_un[idx],
+                             inv_sigma2[kps["octave"][idx]])
             outlier = np.zeros(n, bool)
             outlier[idx[outl.astype(bool)]] = True
             T = _T44(np.asarray(T12, np.float32))
@@ -255,6 +260,7 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
                             if not prob["fixed"][p]:
                                 kfs[i]["T"] = _T44(np.asarray(T_out[p], np.float32))
                         mp_X[pts] = np.asarray(X_out, np.float32)            # SetWorldPos
+                        backend.map_set_positions(pts, mp_X[pts])
                         bad = np.asarray(e_out).astype(bool)                 # EraseMapPointMatch / EraseObservation
                         for i in np.unique(ref[bad, 0]):
                             drop = ref[bad & (ref[:, 0] == i), 1]
@@ -268,7 +274,7 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
         poses.append(T[:3, :4].reshape(12).copy())
         centres.append(-T[:3, :3].T @ T[:3, 3])
         log["n_map_points"].append(len(mp_X))
-        last = (xy_un, kps, desc, kp_mp, outlier)
+        last = (kps, kp_mp, outlier)
         T_last = T
     out = dict(centres=np.array(centres), poses=np.array(poses))
     out.update({k: np.array(v) for k, v in log.items()})

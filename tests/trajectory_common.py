@@ -3,37 +3,71 @@ import numpy as np
 
 from oracle import oracle_py as orc
 from swarmmap_amd import minitrack
+from swarmmap_amd.matcher import FrameView
 
 
 class OracleBackend:
+    """Same interface as minitrack.HipBackend, every operator from the CPU oracle, all state in host arrays."""
+
     name = "oracle"
 
-    def __init__(self, K, nfeatures=1000):
+    def __init__(self, K, nfeatures=1000, dist=(0, 0, 0, 0, 0)):
         self.cfg = orc.config(nfeatures, 1.2, 8, 20, 7)
         self.tab = orc.make_tables(self.cfg)
-        self.cam = orc.camera(K)
+        self.cam = orc.camera(K, dist)
         self.bounds = None
+        self.sf = np.array(self.tab.scale[:self.cfg.nlevels], np.float32)
+        self.cur = self.last = None  # (kps, xy_un, desc)
+        self.X = np.zeros((0, 3), np.float32)
+        self.normal = np.zeros((0, 3), np.float32)
+        self.max_d = np.zeros(0, np.float32)
+        self.min_d = np.zeros(0, np.float32)
+        self.desc = np.zeros((0, 32), np.uint8)
 
     def tables(self):
         n = self.cfg.nlevels
-        return (np.array(self.tab.scale[:n], np.float32), np.array(self.tab.inv_sigma2[:n], np.float32))
+        return (self.sf.copy(), np.array(self.tab.inv_sigma2[:n], np.float32))
 
-    def extract(self, img):
-        return orc.extract(self.cfg, img)
-
-    def prepare(self, xy, w, h):
+    def new_frame(self, img):
+        kps, desc = orc.extract(self.cfg, img)
         if self.bounds is None:
-            self.bounds = orc.image_bounds(self.cam, w, h)
-        return orc.undistort_keypoints(self.cam, xy), self.bounds.copy()
+            self.bounds = orc.image_bounds(self.cam, img.shape[1], img.shape[0])
+        xy = np.stack([kps["x"], kps["y"]], 1).astype(np.float32)
+        xy_un = orc.undistort_keypoints(self.cam, xy)
+        self.last, self.cur = self.cur, (kps, xy_un, desc)
+        return kps, xy_un, desc, self.bounds.copy()
 
-    def search_last(self, F, last, th):
-        return orc.search_by_projection_lastframe(F, last, th, True)
+    def _view(self, excluded=None):
+        kps, xy_un, desc = self.cur
+        return FrameView(xy_un[:, 0], xy_un[:, 1], kps["octave"], kps["angle"], desc, self.bounds, self.sf, excluded)
 
-    def frustum(self, bounds, Tcw, Xw, normal, max_d, min_d, log_sf, nlevels):
-        return orc.is_in_frustum(self.cam, bounds, Tcw, Xw, normal, max_d, min_d, minitrack.COS_LIMIT, log_sf, nlevels)
+    def search_last(self, Tcw, last_slot, th):
+        lk = self.last[0]
+        slot = np.asarray(last_slot)
+        has = slot >= 0
+        s0 = np.maximum(slot, 0)
+        valid, u, v = orc.project_last_frame(self.cam, self.bounds, Tcw, self.X[s0], has)
+        lastd = dict(valid=valid, u=u, v=v, octave=lk["octave"], angle=lk["angle"], desc=self.desc[s0],
+                     has_obs=np.ones(len(lk), np.uint8))
+        return orc.search_by_projection_lastframe(self._view(), lastd, th, True)
 
-    def search_map(self, F, mps, th):
-        return orc.search_by_projection_mappoints(F, mps, th, 0.8)
+    def search_local(self, Tcw, first, n_local, skip, excluded, th, log_sf):
+        sl = slice(first, first + n_local)
+        fr = orc.is_in_frustum(self.cam, self.bounds, Tcw, self.X[sl], self.normal[sl], self.max_d[sl], self.min_d[sl],
+                               minitrack.COS_LIMIT, log_sf, self.cfg.nlevels)
+        in_view = fr["in_view"] & (1 - np.asarray(skip, np.uint8))
+        mps = dict(in_view=in_view, proj_x=fr["proj_x"], proj_y=fr["proj_y"], view_cos=fr["view_cos"],
+                   pred_level=fr["pred_level"], desc=self.desc[sl], has_obs=np.ones(n_local, np.uint8))
+        nm, k2m = orc.search_by_projection_mappoints(self._view(excluded), mps, th, 0.8)
+        return nm, k2m, in_view
+
+    def map_append(self, X, normal, max_d, min_d, desc):
+        self.X = np.concatenate([self.X, X]); self.normal = np.concatenate([self.normal, normal])
+        self.max_d = np.concatenate([self.max_d, max_d]); self.min_d = np.concatenate([self.min_d, min_d])
+        self.desc = np.concatenate([self.desc, desc])
+
+    def map_set_positions(self, slots, X):
+        self.X[np.asarray(slots)] = X
 
     def pose(self, Tcw, intr, Xw, obs, w):
         n, T, outl, _ = orc.pose_optimization(Tcw, intr, Xw, obs, w)
