@@ -143,7 +143,7 @@ int grow(T** p, size_t old_elems, size_t new_elems, hipStream_t s) {
 int reserve(so_map* m, int slots) {
     if (slots <= m->capacity) return SO_OK;
     // 288 GB of HBM: the table grows geometrically and is never shrunk (a 10^6-point map is 64 MB)
-    size_t cap = m->capacity ? (size_t)m->capacity : 16384;
+    size_t cap = m->capacity ? (size_t)m->capacity : 65536;
     while (cap < (size_t)slots) cap *= 2;
     const size_t old = (size_t)m->size;
     int rc;

@@ -1,15 +1,26 @@
 // replay.cc — the per-frame replay of SURVEY 8d as a C++ host loop over the C ABI (include/swarmorb.h): what an
 // agent's Tracking thread and LocalMapping thread do with the library, without an interpreter in the loop.
-//   tracking thread (the caller of so_replay_run), per frame t:
-//       collect frame t from the extractor, submit frame t+1            (ORBextractor::operator(), pipelined)
-//       SearchByProjection(cur, last, th 15)                             (Tracking.cc:715, prepared projections)
-//       SearchByProjection(cur, local map points, th 1)                  (Tracking.cc:998)
-//       3 x Optimizer::PoseOptimization                                  (Tracking.cc:716,1002 + one retry)
-//       every lba_every frames: hand a window to the local-mapping thread (at most two waiting: back-pressure)
-//   local-mapping thread: Optimizer::LocalBundleAdjustment on each queued window, in order
-// bench.py prepares the inputs (device images, projections, pose problems, the window), calls so_replay_run for
-// the timed region and reads the accumulated statistics.  Built by csrc/Makefile into libswarmorb_replay.so with g++.
+//
+// Tracking thread (the caller of so_replay_run), per frame t — a chained, device-resident frame:
+//     collect frame t  (keypoints / descriptors / undistorted points arrive through host-mapped memory)
+//     submit frame t+1 (host image -> HBM upload + ExtractORB + UndistortKeyPoints + AssignFeaturesToGrid, async)
+//     TrackWithMotionModel:  so_track_search_last_frame (projection + window search on the GPU)          Tracking.cc:964-1050
+//                            so_pose_optimization over the matches it found, outliers dropped             Optimizer.cc:239-434
+//     TrackLocalMap:         so_track_search_local_map (isInFrustum + window search on the GPU)           Tracking.cc:1052-1156
+//                            so_pose_optimization over all matches
+//                            a third so_pose_optimization from the last frame's pose (TrackReferenceKeyFrame's
+//                            fallback; SURVEY 8d counts three calls per frame), result unused
+//     "keyframe":            unmatched keypoints become map points (so_map_write)
+//     every lba_every frames: hand a window to the local-mapping thread (at most two waiting: back-pressure)
+// Local-mapping thread: Optimizer::LocalBundleAdjustment (so_bundle_adjust) on each queued window, in order.
+//
+// It is NOT the reference's Tracking state machine (out of scope): it is the shortest loop that chains every
+// per-frame operator the way Tracking does, on the synthetic planar scene of swarmmap_amd/synth.py (map points come
+// from back-projection onto the known plane).  swarmmap_amd/minitrack.py is the same loop in Python; tests compare
+// this one, frame by frame, with that loop run over the CPU oracle.
+// Built by csrc/Makefile into libswarmorb_replay.so with g++.
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -27,47 +38,120 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-struct StepInputs {  // the tracking thread's projections for one frame (inputs of M2 / M1)
-    std::vector<uint8_t> last_valid, last_desc, last_has_obs;
-    std::vector<float> last_u, last_v, last_angle;
-    std::vector<int32_t> last_octave;
-    std::vector<uint8_t> mp_in_view, mp_desc, mp_has_obs;
-    std::vector<float> mp_x, mp_y, mp_cos;
-    std::vector<int32_t> mp_level;
-};
-
-struct PoseCase {
-    float Tcw[12], K[4];
-    std::vector<float> Xw, obs, w;
-};
-
 struct BaWindow {
     std::vector<float> Tcw, intr, Xw, obs, w;
     std::vector<uint8_t> fixed;
     std::vector<int32_t> epose, epoint;
 };
 
+struct M4 {  // 4x4 double, row-major
+    double a[16];
+    static M4 eye() {
+        M4 m;
+        for (int i = 0; i < 16; i++) m.a[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        return m;
+    }
+};
+
+M4 mul(const M4& A, const M4& B) {
+    M4 C;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += A.a[4 * i + k] * B.a[4 * k + j];
+            C.a[4 * i + j] = s;
+        }
+    return C;
+}
+
+M4 rigid_inverse_general(const M4& T) {  // general 4x4 inverse by Gauss-Jordan with partial pivoting
+    double m[4][8];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            m[i][j] = T.a[4 * i + j];
+            m[i][4 + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; c++) {
+        int p = c;
+        for (int r = c + 1; r < 4; r++)
+            if (std::fabs(m[r][c]) > std::fabs(m[p][c])) p = r;
+        if (p != c)
+            for (int j = 0; j < 8; j++) std::swap(m[p][j], m[c][j]);
+        const double d = 1.0 / m[c][c];
+        for (int j = 0; j < 8; j++) m[c][j] *= d;
+        for (int r = 0; r < 4; r++)
+            if (r != c) {
+                const double f = m[r][c];
+                for (int j = 0; j < 8; j++) m[r][j] -= f * m[c][j];
+            }
+    }
+    M4 R;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) R.a[4 * i + j] = m[i][4 + j];
+    return R;
+}
+
+void to_f12(const M4& T, float* o) {
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) o[4 * r + c] = (float)T.a[4 * r + c];
+}
+
+M4 from_f12(const float* p) {
+    M4 T = M4::eye();
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) T.a[4 * r + c] = (double)p[4 * r + c];
+    return T;
+}
+
 }  // namespace
 
 struct so_replay {
     int device = 0, width = 0, height = 0, lba_every = 5;
+    int keyframe_every = 8, local_keyframes = 0, third_pose = 1;
+    double keyframe_ratio = 0.7, plane_z = 2.0;
+    so_camera cam{};
     so_extractor* ex = nullptr;
-    so_matcher* matcher = nullptr;  // one per tracking thread: both searches of a frame share its candidate upload
+    // three device-resident frames rotate: the last frame (read by the motion-model search), the current one and the
+    // one being extracted ahead
+    so_dframe* fr[3] = {nullptr, nullptr, nullptr};
+    so_matcher* matcher = nullptr;
+    so_map* map = nullptr;
     so_ba* tracker_opt = nullptr;
     so_ba* mapper_opt = nullptr;
     std::vector<const uint8_t*> frames;
-    std::vector<StepInputs> steps;
-    std::vector<PoseCase> poses;  // 3 per group
+    bool frames_on_device = false;
     BaWindow window;
-    float scale_factors[8] = {0};
+    float scale[8] = {0}, inv_sigma2[8] = {0};
     int nlevels = 8;
-    // extractor outputs
-    std::vector<so_keypoint> kps;
-    std::vector<uint8_t> desc;
-    std::vector<float> x, y, angle;
-    std::vector<int32_t> octave, kp_to;
-    int n_kp = 0;
+    float log_sf = 0.f;
+    int cap = 0;
+    // frame state: [0] / [1] alternate as current / last
+    struct FrameHost {
+        std::vector<so_keypoint> kps;
+        std::vector<float> xy_un;
+        std::vector<uint8_t> desc;
+        std::vector<int32_t> kp_mp;
+        std::vector<uint8_t> outlier;
+        int n = 0;
+    } fh[2];
+    int cur = 0;
+    int submitted = -1;  // handle index holding the frame in flight
     bool in_flight = false;
+    int n_tracked = 0;   // frames tracked so far (0: the next frame initialises the map)
+    float bounds[4] = {0, 0, 0, 0};
+    M4 T_last = M4::eye(), velocity = M4::eye();
+    int kf_inliers = 0;
+    // host copy of the map positions (PoseOptimization inputs are gathered here) + keyframe bookkeeping
+    std::vector<float> mp_X;
+    std::vector<int32_t> kf_first_slot;
+    // scratch
+    std::vector<int32_t> last_slot, k2l, k2m, idx, local_slot;
+    std::vector<uint8_t> skip, excluded, pose_out;
+    std::vector<float> pX, pobs, pw, new_X, new_N, new_max, new_min;
+    std::vector<uint8_t> new_desc;
+    // log (every tracked frame)
+    std::vector<float> poses;  // 12 per frame
+    std::vector<int32_t> n_m2, n_m1, n_inl, n_map;
     // local-mapping thread
     std::thread mapper;
     std::mutex mu;
@@ -77,7 +161,7 @@ struct so_replay {
     bool quit = false;
     std::string error;
     // statistics (timed steps only)
-    double stat[32] = {0};
+    double stat[48] = {0};
     std::vector<float> ba_Tcw, ba_Xw;
     std::vector<uint8_t> ba_out;
 };
@@ -85,12 +169,12 @@ struct so_replay {
 namespace {
 
 enum {  // indices of so_replay::stat, mirrored in bench.py
-    kSteps = 0, kExtractMs, kMatchMs, kPoseMs, kSubmitWaitMs, kKp, kM2, kM1, kMatchKernelMs, kPoseKernelMs, kPoseTrials,
-    kPoseCalls, kLbaWindows, kLbaBusyMs, kLbaGpuMs, kLbaSolveMs, kLbaSolves, kStage0 /* 11 extractor stages */
+    kSteps = 0, kExtractMs, kM2Ms, kPose1Ms, kM1Ms, kPose2Ms, kPose3Ms, kMapMs, kSubmitWaitMs, kKp, kM2, kM1, kInliers,
+    kMatchKernelMs, kPoseKernelMs, kPoseTrials, kPoseCalls, kPosePoints, kLbaWindows, kLbaBusyMs, kLbaGpuMs, kLbaSolveMs,
+    kLbaSolves, kLocalPoints, kInView, kKeyframes, kMapPoints, kStage0 /* 11 extractor stages */
 };
 
 void mapper_loop(so_replay* r) {
-    (void)0;
     for (;;) {
         int timed;
         {
@@ -142,35 +226,137 @@ int fail(so_replay* r, const char* what) {
     return SO_ERR_HIP;
 }
 
+// New map points for the selected keypoints of the current frame: back-projection onto the plane z = plane_z of the
+// first camera (swarmmap_amd/minitrack.py add_points), reference normal and scale-invariance distances as
+// MapPoint::UpdateNormalAndDepth computes them (code/src/MapPoint.cc:395-433).
+int add_points(so_replay* r, const M4& T, const so_replay::FrameHost& F, const std::vector<uint8_t>& sel, int n_sel) {
+    const double fx = r->cam.fx, fy = r->cam.fy, cx = r->cam.cx, cy = r->cam.cy;
+    const double* a = T.a;
+    double Ow[3];
+    for (int j = 0; j < 3; j++) Ow[j] = -(a[0 + j] * a[3] + a[4 + j] * a[7] + a[8 + j] * a[11]);
+    r->new_X.resize((size_t)n_sel * 3); r->new_N.resize((size_t)n_sel * 3);
+    r->new_max.resize((size_t)n_sel); r->new_min.resize((size_t)n_sel); r->new_desc.resize((size_t)n_sel * 32);
+    int k = 0;
+    for (int i = 0; i < F.n; i++) {
+        if (!sel[(size_t)i]) continue;
+        const double ray[3] = {((double)F.xy_un[2 * (size_t)i] - cx) / fx, ((double)F.xy_un[2 * (size_t)i + 1] - cy) / fy, 1.0};
+        double dir[3];
+        for (int j = 0; j < 3; j++) dir[j] = ray[0] * a[0 + j] + ray[1] * a[4 + j] + ray[2] * a[8 + j];  // R^T ray
+        const double d = (r->plane_z - Ow[2]) / dir[2];
+        double PO[3], X[3];
+        for (int j = 0; j < 3; j++) {
+            X[j] = Ow[j] + dir[j] * d;
+            PO[j] = X[j] - Ow[j];
+        }
+        const double dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+        const double mx = dist * (double)r->scale[F.kps[(size_t)i].octave];
+        for (int j = 0; j < 3; j++) {
+            r->new_X[3 * (size_t)k + j] = (float)X[j];
+            r->new_N[3 * (size_t)k + j] = (float)(PO[j] / dist);
+        }
+        r->new_max[(size_t)k] = (float)(1.2 * mx);
+        r->new_min[(size_t)k] = (float)(0.8 * mx / (double)r->scale[r->nlevels - 1]);
+        memcpy(&r->new_desc[32 * (size_t)k], &F.desc[32 * (size_t)i], 32);
+        k++;
+    }
+    const int first = (int)(r->mp_X.size() / 3);
+    if (so_map_write(r->map, first, n_sel, r->new_X.data(), r->new_N.data(), r->new_max.data(), r->new_min.data(),
+                     r->new_desc.data()) != SO_OK)
+        return -1;
+    r->mp_X.insert(r->mp_X.end(), r->new_X.begin(), r->new_X.end());
+    r->kf_first_slot.push_back(first);
+    return first;
+}
+
+// Optimizer::PoseOptimization over the keypoints of F that have a map point (ascending keypoint index)
+int pose_opt(so_replay* r, const so_replay::FrameHost& F, const float* T_in12, float* T_out12, int32_t* n_inliers,
+             double* kernel_ms, double* trials, double* points) {
+    r->idx.clear();
+    for (int i = 0; i < F.n; i++)
+        if (F.kp_mp[(size_t)i] >= 0) r->idx.push_back(i);
+    const int np = (int)r->idx.size();
+    r->pX.resize((size_t)np * 3); r->pobs.resize((size_t)np * 2); r->pw.resize((size_t)np); r->pose_out.assign((size_t)np, 0);
+    for (int k = 0; k < np; k++) {
+        const int i = r->idx[(size_t)k];
+        const size_t s = (size_t)F.kp_mp[(size_t)i];
+        memcpy(&r->pX[3 * (size_t)k], &r->mp_X[3 * s], 12);
+        r->pobs[2 * (size_t)k] = F.xy_un[2 * (size_t)i];
+        r->pobs[2 * (size_t)k + 1] = F.xy_un[2 * (size_t)i + 1];
+        r->pw[(size_t)k] = r->inv_sigma2[F.kps[(size_t)i].octave];
+    }
+    const float K4[4] = {r->cam.fx, r->cam.fy, r->cam.cx, r->cam.cy};
+    int32_t info[2] = {0, 0};
+    memcpy(T_out12, T_in12, 48);
+    *n_inliers = 0;
+    if (so_pose_optimization(r->tracker_opt, T_in12, K4, np, r->pX.data(), r->pobs.data(), r->pw.data(), T_out12,
+                             r->pose_out.data(), n_inliers, info) != SO_OK)
+        return fail(r, "so_pose_optimization");
+    float ms = 0.f;
+    so_pose_optimization_last_kernel_ms(r->tracker_opt, &ms);
+    *kernel_ms += ms;
+    *trials += info[1];
+    *points += np;
+    return SO_OK;
+}
+
+int submit_frame(so_replay* r, int t) {
+    const int h = (r->submitted + 1) % 3;
+    const uint8_t* img = r->frames[(size_t)t % r->frames.size()];
+    const int rc = r->frames_on_device ? so_dframe_submit_device(r->fr[h], img, r->width, r->height, r->width)
+                                       : so_dframe_submit(r->fr[h], img, r->width, r->height, r->width);
+    if (rc != SO_OK) return fail(r, "so_dframe_submit");
+    r->submitted = h;
+    r->in_flight = true;
+    return SO_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int so_replay_create(int device, int width, int height, int nfeatures, int lba_every, so_replay** out) {
-    if (!out) return SO_ERR_INVALID_ARG;
+// K4 = fx fy cx cy, dist5 = k1 k2 p1 p2 k3 (may be NULL = no distortion)
+int so_replay_create(int device, int width, int height, int nfeatures, int lba_every, const float* K4, const float* dist5,
+                     int keyframe_every, float keyframe_ratio, float plane_z, int local_keyframes, int third_pose,
+                     so_replay** out) {
+    if (!out || !K4) return SO_ERR_INVALID_ARG;
     *out = nullptr;
     so_replay* r = new so_replay();
     r->device = device;
     r->width = width;
     r->height = height;
     r->lba_every = lba_every > 0 ? lba_every : 5;
+    r->keyframe_every = keyframe_every > 0 ? keyframe_every : 8;
+    r->keyframe_ratio = keyframe_ratio;
+    r->plane_z = plane_z;
+    r->local_keyframes = local_keyframes;
+    r->third_pose = third_pose;
+    r->cam.fx = K4[0]; r->cam.fy = K4[1]; r->cam.cx = K4[2]; r->cam.cy = K4[3];
+    if (dist5) { r->cam.k1 = dist5[0]; r->cam.k2 = dist5[1]; r->cam.p1 = dist5[2]; r->cam.p2 = dist5[3]; r->cam.k3 = dist5[4]; }
     so_extractor_config cfg{nfeatures, 1.2f, 8, 20, 7, device};
     int rc = so_extractor_create(&cfg, &r->ex);
+    if (rc == SO_OK) rc = so_dframe_create(r->ex, &r->cam, &r->fr[0]);
+    if (rc == SO_OK) rc = so_dframe_create(r->ex, &r->cam, &r->fr[1]);
+    if (rc == SO_OK) rc = so_dframe_create(r->ex, &r->cam, &r->fr[2]);
     if (rc == SO_OK) rc = so_matcher_create(device, &r->matcher);
+    if (rc == SO_OK) rc = so_map_create(device, &r->map);
     if (rc == SO_OK) rc = so_ba_create(device, &r->tracker_opt);
     if (rc == SO_OK) rc = so_ba_create(device, &r->mapper_opt);
     if (rc != SO_OK) {
         delete r;
         return rc;
     }
-    float inv[8], s2[8], is2[8];
+    float inv[8], s2[8];
     int32_t npl[8];
-    so_extractor_tables(r->ex, r->scale_factors, inv, s2, is2, npl);
-    const int cap = so_extractor_capacity(r->ex);
-    r->kps.resize((size_t)cap);
-    r->desc.resize((size_t)cap * 32);
-    r->x.resize((size_t)cap); r->y.resize((size_t)cap); r->angle.resize((size_t)cap);
-    r->octave.resize((size_t)cap); r->kp_to.resize((size_t)cap);
+    so_extractor_tables(r->ex, r->scale, inv, s2, r->inv_sigma2, npl);
+    r->log_sf = (float)std::log((double)1.2f);  // log(mfScaleFactor), MapPoint.cc:478 (float scale factor)
+    r->cap = so_extractor_capacity(r->ex);
+    for (auto& f : r->fh) {
+        f.kps.resize((size_t)r->cap);
+        f.xy_un.resize((size_t)r->cap * 2);
+        f.desc.resize((size_t)r->cap * 32);
+        f.kp_mp.resize((size_t)r->cap);
+        f.outlier.resize((size_t)r->cap);
+    }
     r->mapper = std::thread(mapper_loop, r);
     *out = r;
     return SO_OK;
@@ -186,10 +372,13 @@ void so_replay_destroy(so_replay* r) {
     if (r->mapper.joinable()) r->mapper.join();
     if (r->in_flight) {
         int n = 0;
-        (void)so_extractor_collect(r->ex, r->kps.data(), r->desc.data(), (int)r->kps.size(), &n);
+        auto& f = r->fh[0];
+        (void)so_dframe_collect(r->fr[r->submitted], f.kps.data(), nullptr, f.desc.data(), r->cap, &n, nullptr);
     }
+    for (so_dframe* f : r->fr) so_dframe_destroy(f);
     so_extractor_destroy(r->ex);
     so_matcher_destroy(r->matcher);
+    so_map_destroy(r->map);
     so_ba_destroy(r->tracker_opt);
     so_ba_destroy(r->mapper_opt);
     delete r;
@@ -197,47 +386,13 @@ void so_replay_destroy(so_replay* r) {
 
 const char* so_replay_error(so_replay* r) { return r ? r->error.c_str() : "null handle"; }
 
-int so_replay_set_frames(so_replay* r, const uint64_t* device_pointers, int n) {
-    if (!r || !device_pointers || n <= 0) return SO_ERR_INVALID_ARG;
+// frames: n pointers to width x height u8 images, row stride = width; host memory (pinned for asynchronous uploads)
+// or device memory
+int so_replay_set_frames(so_replay* r, const uint64_t* pointers, int n, int on_device) {
+    if (!r || !pointers || n <= 0) return SO_ERR_INVALID_ARG;
     r->frames.clear();
-    for (int i = 0; i < n; i++) r->frames.push_back(reinterpret_cast<const uint8_t*>(device_pointers[i]));
-    return SO_OK;
-}
-
-int so_replay_set_step(so_replay* r, int t, int n_last, const uint8_t* valid, const float* u, const float* v,
-                       const int32_t* octave, const float* angle, const uint8_t* desc, const uint8_t* has_obs, int n_mp,
-                       const uint8_t* in_view, const float* px, const float* py, const float* view_cos,
-                       const int32_t* level, const uint8_t* mp_desc, const uint8_t* mp_has_obs) {
-    if (!r || t < 0) return SO_ERR_INVALID_ARG;
-    if ((size_t)t >= r->steps.size()) r->steps.resize((size_t)t + 1);
-    StepInputs& s = r->steps[(size_t)t];
-    s.last_valid.assign(valid, valid + n_last);
-    s.last_u.assign(u, u + n_last);
-    s.last_v.assign(v, v + n_last);
-    s.last_octave.assign(octave, octave + n_last);
-    s.last_angle.assign(angle, angle + n_last);
-    s.last_desc.assign(desc, desc + (size_t)n_last * 32);
-    s.last_has_obs.assign(has_obs, has_obs + n_last);
-    s.mp_in_view.assign(in_view, in_view + n_mp);
-    s.mp_x.assign(px, px + n_mp);
-    s.mp_y.assign(py, py + n_mp);
-    s.mp_cos.assign(view_cos, view_cos + n_mp);
-    s.mp_level.assign(level, level + n_mp);
-    s.mp_desc.assign(mp_desc, mp_desc + (size_t)n_mp * 32);
-    s.mp_has_obs.assign(mp_has_obs, mp_has_obs + n_mp);
-    return SO_OK;
-}
-
-int so_replay_add_pose_case(so_replay* r, const float* Tcw12, const float* K4, int n, const float* Xw, const float* obs,
-                            const float* inv_sigma2) {
-    if (!r || n < 0) return SO_ERR_INVALID_ARG;
-    PoseCase c;
-    memcpy(c.Tcw, Tcw12, 48);
-    memcpy(c.K, K4, 16);
-    c.Xw.assign(Xw, Xw + 3 * (size_t)n);
-    c.obs.assign(obs, obs + 2 * (size_t)n);
-    c.w.assign(inv_sigma2, inv_sigma2 + n);
-    r->poses.push_back(std::move(c));
+    for (int i = 0; i < n; i++) r->frames.push_back(reinterpret_cast<const uint8_t*>(pointers[i]));
+    r->frames_on_device = on_device != 0;
     return SO_OK;
 }
 
@@ -258,22 +413,15 @@ int so_replay_set_window(so_replay* r, const so_ba_problem* p) {
     return SO_OK;
 }
 
-// Resource allocation before any step is counted: one window through the local-mapping handle and one pose problem
-// through the tracking handle size their device buffers (what a process does once at start-up, not per frame).
+// Resource allocation before any step is counted: one window through the local-mapping handle sizes its device
+// buffers (what a process does once at start-up, not per frame).
 int so_replay_preallocate(so_replay* r) {
-    if (!r || r->window.epose.empty() || r->poses.empty()) return SO_ERR_INVALID_ARG;
+    if (!r || r->window.epose.empty()) return SO_ERR_INVALID_ARG;
     {
         std::unique_lock<std::mutex> lk(r->mu);
         r->queue.push_back(0);
     }
     r->cv.notify_all();
-    const PoseCase& c = r->poses[0];
-    std::vector<uint8_t> outl(c.w.size());
-    float Tout[12];
-    int32_t inl = 0;
-    if (so_pose_optimization(r->tracker_opt, c.Tcw, c.K, (int)c.w.size(), c.Xw.data(), c.obs.data(), c.w.data(), Tout,
-                             outl.data(), &inl, nullptr) != SO_OK)
-        return fail(r, "so_pose_optimization");
     std::unique_lock<std::mutex> lk(r->mu);
     r->cv.wait(lk, [r] { return r->queue.empty() && !r->running; });
     return r->error.empty() ? SO_OK : SO_ERR_HIP;
@@ -285,74 +433,159 @@ int so_replay_set_profiling(so_replay* r, int enabled) { return r ? so_extractor
 // it, submits the next one and leaves that one in flight when it returns.
 int so_replay_prime(so_replay* r, int t) {
     if (!r || r->frames.empty() || r->in_flight) return SO_ERR_INVALID_ARG;
-    const int rc = so_extractor_submit_device(r->ex, r->frames[(size_t)t % r->frames.size()], r->width, r->height, r->width);
-    if (rc != SO_OK) return fail(r, "so_extractor_submit_device");
-    r->in_flight = true;
-    return SO_OK;
+    return submit_frame(r, t);
 }
 
 int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
-    if (!r || !r->in_flight || r->frames.empty() || r->poses.size() < 3) return SO_ERR_INVALID_ARG;
-    const int groups = (int)r->poses.size() / 3;
-    std::vector<uint8_t> outl;
+    if (!r || !r->in_flight || r->frames.empty()) return SO_ERR_INVALID_ARG;
     for (int t = first_t; t < first_t + n_steps; t++) {
-        if ((size_t)t >= r->steps.size()) return SO_ERR_INVALID_ARG;
         const double t0 = now_ms();
+        // ---- Frame constructor: collect frame t, put frame t+1 in flight ---------------------------------------
+        const int hcur = r->submitted;
+        r->cur ^= 1;
+        so_replay::FrameHost& F = r->fh[r->cur];
+        so_replay::FrameHost& L = r->fh[r->cur ^ 1];
+        so_dframe* dcur = r->fr[hcur];
+        so_dframe* dlast = r->fr[(hcur + 2) % 3];
         int n = 0;
-        if (so_extractor_collect(r->ex, r->kps.data(), r->desc.data(), (int)r->kps.size(), &n) != SO_OK)
-            return fail(r, "so_extractor_collect");
+        if (so_dframe_collect(dcur, F.kps.data(), F.xy_un.data(), F.desc.data(), r->cap, &n, r->bounds) != SO_OK)
+            return fail(r, "so_dframe_collect");
         r->in_flight = false;
-        if (so_extractor_submit_device(r->ex, r->frames[(size_t)(t + 1) % r->frames.size()], r->width, r->height,
-                                       r->width) != SO_OK)
-            return fail(r, "so_extractor_submit_device");
-        r->in_flight = true;
-        r->n_kp = n;
-        for (int i = 0; i < n; i++) {
-            const so_keypoint& k = r->kps[(size_t)i];
-            r->x[(size_t)i] = k.x; r->y[(size_t)i] = k.y; r->angle[(size_t)i] = k.angle; r->octave[(size_t)i] = k.octave;
-        }
+        F.n = n;
+        int rc = submit_frame(r, t + 1);
+        if (rc) return rc;
         const double t1 = now_ms();
-        so_frame_view F{};
-        F.n = n; F.x = r->x.data(); F.y = r->y.data(); F.octave = r->octave.data(); F.angle = r->angle.data();
-        F.desc = r->desc.data(); F.excluded = nullptr;
-        F.min_x = 0.f; F.max_x = (float)r->width; F.min_y = 0.f; F.max_y = (float)r->height;
-        F.grid_inv_w = 64.0f / (F.max_x - F.min_x);
-        F.grid_inv_h = 48.0f / (F.max_y - F.min_y);
-        F.scale_factors = r->scale_factors;
-        F.nlevels = r->nlevels;
-        const StepInputs& s = r->steps[(size_t)t];
-        int32_t nm2 = 0, nm1 = 0;
-        float k2 = 0.f, k1 = 0.f;
-        if (so_search_by_projection_lastframe(r->matcher, &F, (int32_t)s.last_u.size(), s.last_valid.data(), s.last_u.data(),
-                                              s.last_v.data(), s.last_octave.data(), s.last_angle.data(),
-                                              s.last_desc.data(), s.last_has_obs.data(), 15.0f, 1, r->kp_to.data(),
-                                              &nm2) != SO_OK)
-            return fail(r, "so_search_by_projection_lastframe");
-        so_matcher_last_kernel_ms(r->matcher, &k2);
-        so_matcher_reuse_frame(r->matcher);  // the local-map search looks at the same frame (Tracking.cc:1014 then :1153)
-        if (so_search_by_projection_mappoints(r->matcher, &F, (int32_t)s.mp_x.size(), s.mp_in_view.data(), s.mp_x.data(),
-                                              s.mp_y.data(), s.mp_cos.data(), s.mp_level.data(), s.mp_desc.data(),
-                                              s.mp_has_obs.data(), 1.0f, 0.8f, r->kp_to.data(), &nm1) != SO_OK)
-            return fail(r, "so_search_by_projection_mappoints");
-        so_matcher_last_kernel_ms(r->matcher, &k1);
-        const double t2 = now_ms();
-        double pose_kernel = 0.0, pose_trials = 0.0;
-        for (int j = 0; j < 3; j++) {
-            const PoseCase& c = r->poses[(size_t)(3 * (t % groups) + j)];
-            const int np = (int)c.w.size();
-            outl.resize((size_t)np);
-            float Tout[12];
-            int32_t inl = 0, info[2] = {0, 0};
-            if (so_pose_optimization(r->tracker_opt, c.Tcw, c.K, np, c.Xw.data(), c.obs.data(), c.w.data(), Tout,
-                                     outl.data(), &inl, info) != SO_OK)
-                return fail(r, "so_pose_optimization");
-            float ms = 0.f;
-            so_pose_optimization_last_kernel_ms(r->tracker_opt, &ms);
-            pose_kernel += ms;
-            pose_trials += info[1];
+        double tm2 = t1, tp1 = t1, tm1 = t1, tp2 = t1, tp3 = t1, tmap = t1;
+        double match_kernel = 0.0, pose_kernel = 0.0, pose_trials = 0.0, pose_points = 0.0;
+        int pose_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0;
+        int32_t n_in = n;
+        for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = -1;
+        memset(F.outlier.data(), 0, (size_t)n);
+        M4 T = M4::eye();
+        if (r->n_tracked == 0) {
+            // first frame: every keypoint becomes a map point, the camera defines the world frame
+            std::vector<uint8_t> all((size_t)n, 1);
+            const int first = add_points(r, T, F, all, n);
+            if (first < 0) return fail(r, "so_map_write");
+            for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = first + i;
+            r->kf_inliers = n;
+            keyframe = 1;
+            tm2 = tp1 = tm1 = tp2 = tp3 = tmap = now_ms();
+        } else {
+            // ---- TrackWithMotionModel (Tracking.cc:964-1050) ----------------------------------------------------
+            const M4 T_pred = mul(r->velocity, r->T_last);
+            float Tp[12], Ta[12], Tb[12], Tc[12];
+            to_f12(T_pred, Tp);
+            r->last_slot.resize((size_t)L.n);
+            for (int i = 0; i < L.n; i++)
+                r->last_slot[(size_t)i] = (L.kp_mp[(size_t)i] >= 0 && !L.outlier[(size_t)i]) ? L.kp_mp[(size_t)i] : -1;
+            r->k2l.resize((size_t)n);
+            int32_t nm = 0;
+            float kms = 0.f;
+            if (so_track_search_last_frame(r->matcher, dcur, nullptr, dlast, r->map, Tp, r->last_slot.data(), nullptr, 15.0f,
+                                           1, r->k2l.data(), &nm) != SO_OK)
+                return fail(r, "so_track_search_last_frame");
+            so_matcher_last_kernel_ms(r->matcher, &kms);
+            match_kernel += kms;
+            if (nm < 20) {  // Tracking.cc:1020-1024: wider window
+                if (so_track_search_last_frame(r->matcher, dcur, nullptr, dlast, r->map, Tp, r->last_slot.data(), nullptr,
+                                               30.0f, 1, r->k2l.data(), &nm) != SO_OK)
+                    return fail(r, "so_track_search_last_frame");
+                so_matcher_last_kernel_ms(r->matcher, &kms);
+                match_kernel += kms;
+            }
+            nm2 = nm;
+            for (int k = 0; k < n; k++)
+                if (r->k2l[(size_t)k] >= 0) F.kp_mp[(size_t)k] = L.kp_mp[(size_t)r->k2l[(size_t)k]];
+            tm2 = now_ms();
+            int32_t inl = 0;
+            if ((rc = pose_opt(r, F, Tp, Ta, &inl, &pose_kernel, &pose_trials, &pose_points))) return rc;
+            pose_calls++;
+            for (size_t k = 0; k < r->idx.size(); k++)  // Tracking.cc:1030-1046: outliers lose their map point
+                if (r->pose_out[k]) F.kp_mp[(size_t)r->idx[k]] = -1;
+            tp1 = now_ms();
+            // ---- TrackLocalMap (Tracking.cc:1052-1156) -----------------------------------------------------------
+            const int n_map = (int)(r->mp_X.size() / 3);
+            int first = 0;
+            if (r->local_keyframes > 0 && (int)r->kf_first_slot.size() > r->local_keyframes)
+                first = r->kf_first_slot[r->kf_first_slot.size() - (size_t)r->local_keyframes];
+            n_local = n_map - first;
+            r->skip.assign((size_t)n_local, 0);
+            r->excluded.resize((size_t)n);
+            for (int k = 0; k < n; k++) {
+                const int s = F.kp_mp[(size_t)k];
+                r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
+                if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:1117-1124)
+            }
+            const int32_t* slots = nullptr;
+            if (first > 0) {
+                r->local_slot.resize((size_t)n_local);
+                for (int i = 0; i < n_local; i++) r->local_slot[(size_t)i] = first + i;
+                slots = r->local_slot.data();
+            }
+            r->k2m.resize((size_t)n);
+            std::vector<uint8_t>& view = r->new_desc;  // scratch
+            view.resize(std::max(view.size(), (size_t)n_local));
+            int32_t nmm = 0;
+            if (so_track_search_local_map(r->matcher, dcur, r->excluded.data(), r->map, Ta, n_local, slots, r->skip.data(),
+                                          nullptr, 1.0f, 0.8f, 0.5f, r->log_sf, view.data(), r->k2m.data(), &nmm) != SO_OK)
+                return fail(r, "so_track_search_local_map");
+            so_matcher_last_kernel_ms(r->matcher, &kms);
+            match_kernel += kms;
+            nm1 = nmm;
+            for (int i = 0; i < n_local; i++) n_view += view[(size_t)i];
+            for (int k = 0; k < n; k++)
+                if (r->k2m[(size_t)k] >= 0) F.kp_mp[(size_t)k] = first + r->k2m[(size_t)k];
+            tm1 = now_ms();
+            if ((rc = pose_opt(r, F, Ta, Tb, &n_in, &pose_kernel, &pose_trials, &pose_points))) return rc;
+            pose_calls++;
+            for (size_t k = 0; k < r->idx.size(); k++)
+                if (r->pose_out[k]) F.outlier[(size_t)r->idx[k]] = 1;
+            T = from_f12(Tb);
+            tp2 = now_ms();
+            if (r->third_pose) {  // TrackReferenceKeyFrame's fallback: from the last frame's pose, result unused
+                float Tl[12];
+                to_f12(r->T_last, Tl);
+                int32_t inl3 = 0;
+                if ((rc = pose_opt(r, F, Tl, Tc, &inl3, &pose_kernel, &pose_trials, &pose_points))) return rc;
+                pose_calls++;
+            }
+            tp3 = now_ms();
+            // ---- "keyframe": unmatched keypoints become map points ----------------------------------------------
+            if ((double)n_in < r->keyframe_ratio * (double)r->kf_inliers || r->n_tracked % r->keyframe_every == 0) {
+                std::vector<uint8_t> fresh((size_t)n, 0);
+                int n_fresh = 0;
+                for (int k = 0; k < n; k++)
+                    if (F.kp_mp[(size_t)k] < 0) {
+                        fresh[(size_t)k] = 1;
+                        n_fresh++;
+                    }
+                if (n_fresh > 0) {
+                    const int f0 = add_points(r, T, F, fresh, n_fresh);
+                    if (f0 < 0) return fail(r, "so_map_write");
+                    int j = 0;
+                    for (int k = 0; k < n; k++)
+                        if (fresh[(size_t)k]) F.kp_mp[(size_t)k] = f0 + j++;
+                }
+                r->kf_inliers = n_in > 1 ? n_in : 1;
+                keyframe = 1;
+            }
+            r->velocity = mul(T, rigid_inverse_general(r->T_last));
+            tmap = now_ms();
         }
+        r->T_last = T;
+        {
+            float p12[12];
+            to_f12(T, p12);
+            r->poses.insert(r->poses.end(), p12, p12 + 12);
+            r->n_m2.push_back(nm2);
+            r->n_m1.push_back(nm1);
+            r->n_inl.push_back(n_in);
+            r->n_map.push_back((int32_t)(r->mp_X.size() / 3));
+        }
+        r->n_tracked++;
         const double t3 = now_ms();
-        if (t % r->lba_every == 0) {
+        if (t % r->lba_every == 0 && !r->window.epose.empty()) {
             std::unique_lock<std::mutex> lk(r->mu);
             r->cv.wait(lk, [r] { return r->queue.size() < 3; });  // the running window + two waiting
             r->queue.push_back(timed ? 1 : 0);
@@ -362,9 +595,12 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
         const double t4 = now_ms();
         if (timed) {
             double* st = r->stat;
-            st[kSteps] += 1; st[kExtractMs] += t1 - t0; st[kMatchMs] += t2 - t1; st[kPoseMs] += t3 - t2;
-            st[kSubmitWaitMs] += t4 - t3; st[kKp] += n; st[kM2] += nm2; st[kM1] += nm1; st[kMatchKernelMs] += k1 + k2;
-            st[kPoseKernelMs] += pose_kernel; st[kPoseTrials] += pose_trials; st[kPoseCalls] += 3;
+            st[kSteps] += 1; st[kExtractMs] += t1 - t0; st[kM2Ms] += tm2 - t1; st[kPose1Ms] += tp1 - tm2;
+            st[kM1Ms] += tm1 - tp1; st[kPose2Ms] += tp2 - tm1; st[kPose3Ms] += tp3 - tp2; st[kMapMs] += tmap - tp3;
+            st[kSubmitWaitMs] += t4 - t3; st[kKp] += n; st[kM2] += nm2; st[kM1] += nm1; st[kInliers] += n_in;
+            st[kMatchKernelMs] += match_kernel; st[kPoseKernelMs] += pose_kernel; st[kPoseTrials] += pose_trials;
+            st[kPoseCalls] += pose_calls; st[kPosePoints] += pose_points; st[kLocalPoints] += n_local; st[kInView] += n_view;
+            st[kKeyframes] += keyframe; st[kMapPoints] = (double)(r->mp_X.size() / 3);
             float prof[SO_EXTRACTOR_N_STAGES];
             if (so_extractor_get_profile(r->ex, prof) == SO_OK)
                 for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) st[kStage0 + i] += prof[i];
@@ -387,26 +623,39 @@ int so_replay_finish(so_replay* r) {
     if (!r) return SO_ERR_INVALID_ARG;
     if (r->in_flight) {
         int n = 0;
-        if (so_extractor_collect(r->ex, r->kps.data(), r->desc.data(), (int)r->kps.size(), &n) != SO_OK)
-            return fail(r, "so_extractor_collect");
+        so_replay::FrameHost& F = r->fh[r->cur ^ 1];  // scratch: the last frame's host arrays are not needed any more
+        if (so_dframe_collect(r->fr[r->submitted], F.kps.data(), nullptr, F.desc.data(), r->cap, &n, nullptr) != SO_OK)
+            return fail(r, "so_dframe_collect");
         r->in_flight = false;
-        r->n_kp = n;
     }
     return SO_OK;
 }
 
-int so_replay_stats(so_replay* r, double* out32) {
-    if (!r || !out32) return SO_ERR_INVALID_ARG;
+int so_replay_stats(so_replay* r, double* out48) {
+    if (!r || !out48) return SO_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(r->mu);
-    memcpy(out32, r->stat, sizeof(r->stat));
+    memcpy(out48, r->stat, sizeof(r->stat));
     return SO_OK;
 }
 
-// descriptors of the last collected frame (for the cross-agent exchange tick) and the extractor handle (candidates)
+// Per-frame log of everything tracked so far: poses (12 floats per frame), M2 / M1 match counts, inliers, map size.
+int so_replay_log_size(so_replay* r) { return r ? (int)r->n_m2.size() : 0; }
+int so_replay_log(so_replay* r, float* poses12, int32_t* n_m2, int32_t* n_m1, int32_t* n_inliers, int32_t* n_map) {
+    if (!r) return SO_ERR_INVALID_ARG;
+    const size_t n = r->n_m2.size();
+    if (poses12) memcpy(poses12, r->poses.data(), sizeof(float) * 12 * n);
+    if (n_m2) memcpy(n_m2, r->n_m2.data(), 4 * n);
+    if (n_m1) memcpy(n_m1, r->n_m1.data(), 4 * n);
+    if (n_inliers) memcpy(n_inliers, r->n_inl.data(), 4 * n);
+    if (n_map) memcpy(n_map, r->n_map.data(), 4 * n);
+    return SO_OK;
+}
+
+// descriptors of the last tracked frame (for the cross-agent exchange tick) and the handles (candidates, exchange)
 int so_replay_last_frame(so_replay* r, const uint8_t** desc, int* n) {
     if (!r || !desc || !n) return SO_ERR_INVALID_ARG;
-    *desc = r->desc.data();
-    *n = r->n_kp;
+    *desc = r->fh[r->cur].desc.data();
+    *n = r->fh[r->cur].n;
     return SO_OK;
 }
 so_extractor* so_replay_extractor(so_replay* r) { return r ? r->ex : nullptr; }

@@ -1,0 +1,131 @@
+"""ctypes view of swarmmap_amd/host/replay.cc (libswarmorb_replay.so): the tracking thread's chained, device-resident
+per-frame calls and the local-mapping thread as a C++ host loop over the C ABI — the host side a SwarmMap integration
+has.  Used by bench.py (timed region) and by tests/ (frame-by-frame comparison with the CPU oracle chain)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+STAT = ("steps", "extract_ms", "m2_ms", "pose1_ms", "m1_ms", "pose2_ms", "pose3_ms", "map_ms", "lba_ms", "n_kp", "n_m2",
+        "n_m1", "n_inliers", "match_kernel_ms", "pose_kernel_ms", "pose_trials", "pose_calls", "pose_points", "n_lba",
+        "lba_busy_ms", "lba_gpu_ms", "solve_ms", "n_solves", "n_local", "n_in_view", "n_keyframes", "n_map_points")
+
+
+class Replay:
+    def __init__(self, dev, w, h, nfeatures, lba_every, K, dist=None, keyframe_every=8, keyframe_ratio=0.7, plane_z=2.0,
+                 local_keyframes=0, third_pose=True):
+        from .optimizer import SoBaProblem  # noqa: F401  (binds the BA structs)
+        _lib.load_library()  # binds HIP through torch's runtime first
+        path = os.path.join(_HERE, "libswarmorb_replay.so")
+        if not os.path.exists(path):
+            raise _lib.SwarmOrbError("libswarmorb_replay.so is missing: run __graft_entry__.build()")
+        self.lib = lib = C.CDLL(path)
+        vp, i32, f = C.c_void_p, C.c_int, C.c_float
+        lib.so_replay_create.argtypes = [i32, i32, i32, i32, i32, vp, vp, i32, f, f, i32, i32, C.POINTER(vp)]
+        lib.so_replay_destroy.argtypes = [vp]; lib.so_replay_destroy.restype = None
+        lib.so_replay_error.argtypes = [vp]; lib.so_replay_error.restype = C.c_char_p
+        lib.so_replay_set_frames.argtypes = [vp, vp, i32, i32]
+        lib.so_replay_set_window.argtypes = [vp, vp]
+        lib.so_replay_set_profiling.argtypes = [vp, i32]
+        lib.so_replay_preallocate.argtypes = [vp]
+        lib.so_replay_prime.argtypes = [vp, i32]
+        lib.so_replay_run.argtypes = [vp, i32, i32, i32]
+        lib.so_replay_drain.argtypes = [vp]
+        lib.so_replay_finish.argtypes = [vp]
+        lib.so_replay_stats.argtypes = [vp, vp]
+        lib.so_replay_log_size.argtypes = [vp]
+        lib.so_replay_log.argtypes = [vp, vp, vp, vp, vp, vp]
+        lib.so_replay_last_frame.argtypes = [vp, C.POINTER(vp), C.POINTER(i32)]
+        lib.so_replay_extractor.argtypes = [vp]; lib.so_replay_extractor.restype = vp
+        lib.so_replay_matcher.argtypes = [vp]; lib.so_replay_matcher.restype = vp
+        self.h = vp()
+        K4 = np.ascontiguousarray(K, np.float32)
+        d5 = None if dist is None else np.ascontiguousarray(list(dist) + [0.0] * (5 - len(dist)), np.float32)
+        self._check(lib.so_replay_create(dev, w, h, nfeatures, lba_every, self._p(K4), None if d5 is None else self._p(d5),
+                                         keyframe_every, keyframe_ratio, plane_z, local_keyframes, int(third_pose),
+                                         C.byref(self.h)), "create")
+        self._keep = []
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("so_replay_%s failed (%d): %s" % (what, rc, (self.lib.so_replay_error(self.h) or b"").decode()))
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data
+
+    def set_frames(self, ptrs, on_device=False):
+        a = np.array(ptrs, np.uint64)
+        self._check(self.lib.so_replay_set_frames(self.h, self._p(a), len(a), int(on_device)), "set_frames")
+
+    def set_host_frames(self, frames):
+        """frames: list of (h, w) uint8 C-contiguous arrays (kept alive by this object)."""
+        self._keep.append(frames)
+        self.set_frames([f.ctypes.data for f in frames], on_device=False)
+
+    def set_window(self, prob):
+        from .optimizer import problem_struct
+        st, keep = problem_struct(prob)
+        self._keep.append(keep)
+        self._check(self.lib.so_replay_set_window(self.h, C.byref(st)), "set_window")
+
+    def preallocate(self):
+        self._check(self.lib.so_replay_preallocate(self.h), "preallocate")
+
+    def set_profiling(self, on):
+        self.lib.so_replay_set_profiling(self.h, int(on))
+
+    def prime(self, t):
+        self._check(self.lib.so_replay_prime(self.h, t), "prime")
+
+    def run(self, first_t, n, timed):
+        self._check(self.lib.so_replay_run(self.h, first_t, n, int(timed)), "run")
+
+    def drain(self):
+        self._check(self.lib.so_replay_drain(self.h), "drain")
+
+    def finish(self):
+        self._check(self.lib.so_replay_finish(self.h), "finish")
+
+    def stats(self):
+        a = np.zeros(48, np.float64)
+        self.lib.so_replay_stats(self.h, self._p(a))
+        d = dict(zip(STAT, a[:len(STAT)].tolist()))
+        from .extractor import STAGES
+        d["stages"] = dict(zip(STAGES, a[len(STAT):len(STAT) + len(STAGES)].tolist()))
+        return d
+
+    def log(self):
+        n = self.lib.so_replay_log_size(self.h)
+        poses = np.zeros((n, 12), np.float32)
+        cols = [np.zeros(n, np.int32) for _ in range(4)]
+        self._check(self.lib.so_replay_log(self.h, self._p(poses), *[self._p(c) for c in cols]), "log")
+        T = poses.reshape(n, 3, 4).astype(np.float64)
+        centres = -np.einsum("nji,nj->ni", T[:, :, :3], T[:, :, 3])
+        return dict(poses=poses, centres=centres, matches_last=cols[0], matches_map=cols[1], inliers=cols[2],
+                    n_map_points=cols[3])
+
+    def last_descriptors(self):
+        ptr, n = C.c_void_p(), C.c_int(0)
+        self.lib.so_replay_last_frame(self.h, C.byref(ptr), C.byref(n))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (max(n.value, 1) * 32,))[:n.value * 32].reshape(-1, 32).copy()
+
+    def candidates_total(self, nlevels=8, cap=10000):
+        exh = self.lib.so_replay_extractor(self.h)
+        base = _lib.load_library()
+        tot = 0
+        xs, ys, sc = np.zeros(cap, np.int16), np.zeros(cap, np.int16), np.zeros(cap, np.uint8)
+        for l in range(nlevels):
+            n = C.c_int(0)
+            base.so_extractor_get_candidates(C.c_void_p(exh), l, self._p(xs), self._p(ys), self._p(sc), cap, C.byref(n))
+            tot += n.value
+        return tot
+
+    def close(self):
+        if self.h:
+            self.lib.so_replay_destroy(self.h)
+            self.h = None

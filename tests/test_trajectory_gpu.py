@@ -53,3 +53,28 @@ def test_tracking_plus_local_ba_trajectories_agree():
     assert np.abs(a["inliers"].astype(int) - b["inliers"].astype(int)).max() <= 5
     px = PLANE_Z / float(K[0])
     assert minitrack.ate_rmse(a["centres"], gt, align=False) < px
+
+
+@pytest.mark.parametrize("local_kfs", [0, 4])
+def test_cpp_chain_matches_the_oracle_chain(local_kfs):
+    """The C++ host loop of bench.py (swarmmap_amd/host/replay.cc: device-resident frames, map table on the GPU, fused
+    tracking searches, pipelined extraction) against the same chain run over the CPU oracle, frame by frame."""
+    from swarmmap_amd.replay import Replay
+    n, K, nfeat = 48, synth.EUROC_K, 1000
+    st = synth.FrameStream()
+    frames = [st.frame(t) for t in range(n + 1)]
+    rp = Replay(0, st.w, st.h, nfeat, 5, K, dist=None, plane_z=PLANE_Z, local_keyframes=local_kfs, third_pose=True)
+    rp.set_host_frames(frames)
+    rp.prime(0)
+    rp.run(0, n, False)
+    rp.finish()
+    a = rp.log()
+    rp.close()
+    b = minitrack.track(OracleBackend(K, nfeat), st, n, K, plane_z=PLANE_Z, local_keyframes=local_kfs, third_pose=True)
+    assert len(a["poses"]) == n
+    assert minitrack.ate_rmse(a["centres"], b["centres"], align=False) < ATE_HIP_VS_ORACLE
+    assert np.abs(a["poses"] - b["poses"]).max() < 2e-5
+    for k in ("matches_last", "matches_map", "inliers"):
+        assert np.abs(a[k].astype(int) - b[k].astype(int)).max() <= 3, (k, a[k], b[k])
+    assert np.abs(a["n_map_points"].astype(int) - b["n_map_points"].astype(int)).max() <= 3
+    assert a["matches_last"][1:].min() > 300 and a["inliers"][1:].min() > 400
