@@ -700,13 +700,14 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     a.n = n;
     a.err = reinterpret_cast<double*>(d + off_err);
     a.trace = env_trace ? reinterpret_cast<double*>(d + off_trace) : nullptr;
-    SO_HIP(hipEventRecord(b->pe0, s));
+    static const bool no_events = getenv("SWARMORB_NO_EVENTS") != nullptr;  // diagnostic: cost of the two event records
+    if (!no_events) SO_HIP(hipEventRecord(b->pe0, s));
     launch_pose_opt(a, s);
-    SO_HIP(hipEventRecord(b->pe1, s));
+    if (!no_events) SO_HIP(hipEventRecord(b->pe1, s));
     SO_HIP(hipGetLastError());
     if (!zero_copy) SO_HIP(hipMemcpyAsync(hout, d + off_pose, 64 + 16 + (size_t)n, hipMemcpyDeviceToHost, s));
     SO_HIP(hipStreamSynchronize(s));
-    b->pose_ms_pending = true;  // both events have completed; the elapsed time is read when somebody asks for it
+    b->pose_ms_pending = !no_events;  // both events have completed; the elapsed time is read when somebody asks for it
     BaPose P;
     memcpy(&P, hout, sizeof(BaPose));
     int inf[4];

@@ -2058,8 +2058,452 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
     }
 }
 
+// ---- short-dependency-chain versions of the 6x6 solve and of the SE3 update for the register-resident kernel ----
+// Every lane of pose_opt_reg_kernel runs the LM control flow redundantly, so what matters is the LENGTH of the
+// dependent FP64 chain (a dependent DP instruction issues every ~16 cycles with one wave per SIMD), not the
+// operation count.  Cholesky has ~75 dependent steps for a 6x6 system; the block form below has ~40.
+__device__ __forceinline__ double po_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+
+// adjugate of a symmetric 3x3 (m00 m01 m02 m11 m12 m22) and its determinant; pd = all leading minors positive
+__device__ __forceinline__ void po_adj3(const double* m, double* c, double& det, bool& pd) {
+    c[0] = fma(m[3], m[5], -(m[4] * m[4]));
+    c[1] = fma(m[2], m[4], -(m[1] * m[5]));
+    c[2] = fma(m[1], m[4], -(m[2] * m[3]));
+    c[3] = fma(m[0], m[5], -(m[2] * m[2]));
+    c[4] = fma(m[1], m[2], -(m[0] * m[4]));
+    c[5] = fma(m[0], m[3], -(m[1] * m[1]));
+    det = fma(m[0], c[0], fma(m[1], c[1], m[2] * c[2]));
+    pd = m[0] > 0.0 && c[5] > 0.0 && det > 0.0;
+}
+
+// (H + lambda I) x = b for the 6x6 system of PoseOptimization through its 3x3 blocks [[A B],[B^T C]]:
+// A^-1 by adjugate, S = C - B^T A^-1 B, x2 = S^-1 (b2 - B^T A^-1 b1), x1 = A^-1 b1 - A^-1 B x2; also computeScale.
+// S: 21 upper-triangular entries, row-major.  ok = 0 when A or S is not positive definite (then H + lambda I is not).
+__device__ __forceinline__ void po_solve6_blocks(const double* S, const double* b, double lambda, double* x, double& scale,
+                                                 int& ok) {
+    const double A[6] = {S[0] + lambda, S[1], S[2], S[6] + lambda, S[7], S[11] + lambda};
+    const double B[9] = {S[3], S[4], S[5], S[8], S[9], S[10], S[12], S[13], S[14]};  // rows 0-2, columns 3-5
+    const double C[6] = {S[15] + lambda, S[16], S[17], S[18] + lambda, S[19], S[20] + lambda};
+    double aA[6], detA;
+    bool pdA;
+    po_adj3(A, aA, detA, pdA);
+    const double iA = po_rcp(detA);
+    // full symmetric adjugate rows
+    const double a00 = aA[0], a01 = aA[1], a02 = aA[2], a11 = aA[3], a12 = aA[4], a22 = aA[5];
+    double Y[9];  // adj(A) B (unscaled)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        Y[0 + j] = fma(a00, B[j], fma(a01, B[3 + j], a02 * B[6 + j]));
+        Y[3 + j] = fma(a01, B[j], fma(a11, B[3 + j], a12 * B[6 + j]));
+        Y[6 + j] = fma(a02, B[j], fma(a12, B[3 + j], a22 * B[6 + j]));
+    }
+    const double y1[3] = {fma(a00, b[0], fma(a01, b[1], a02 * b[2])), fma(a01, b[0], fma(a11, b[1], a12 * b[2])),
+                          fma(a02, b[0], fma(a12, b[1], a22 * b[2]))};  // adj(A) b1 (unscaled)
+    double Sc[6], r2[3];
+    {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = i; j < 3; j++) {
+                const double d = fma(B[i], Y[j], fma(B[3 + i], Y[3 + j], B[6 + i] * Y[6 + j]));  // (B^T adj(A) B)_ij
+                Sc[t] = fma(-d, iA, C[t]);
+                t++;
+            }
+            const double e = fma(B[i], y1[0], fma(B[3 + i], y1[1], B[6 + i] * y1[2]));
+            r2[i] = fma(-e, iA, b[3 + i]);
+        }
+    }
+    double aS[6], detS;
+    bool pdS;
+    po_adj3(Sc, aS, detS, pdS);
+    const double iS = po_rcp(detS);
+    x[3] = fma(aS[0], r2[0], fma(aS[1], r2[1], aS[2] * r2[2])) * iS;
+    x[4] = fma(aS[1], r2[0], fma(aS[3], r2[1], aS[4] * r2[2])) * iS;
+    x[5] = fma(aS[2], r2[0], fma(aS[4], r2[1], aS[5] * r2[2])) * iS;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double d = fma(Y[3 * i], x[3], fma(Y[3 * i + 1], x[4], Y[3 * i + 2] * x[5]));
+        x[i] = (y1[i] - d) * iA;
+    }
+    ok = (pdA && pdS) ? 1 : 0;
+    double sc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) sc += x[j] * fma(lambda, x[j], b[j]);
+    scale = sc;
+    if (!ok) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) x[j] = 0.0;
+    }
+}
+
+// pose <- SE3Quat::exp(u) * pose with the unit quaternion of exp(omega) written down directly
+// ((sin(t/2)/t) omega, cos(t/2), series in t^2) instead of Rodrigues' matrix turned back into a quaternion
+// (code/Thirdparty/g2o/g2o/types/se3quat.h:223-257): same value up to rounding, half the dependent chain.
+// Steps beyond 0.25 rad take the closed forms of se3_exp_mul.
+__device__ __forceinline__ void se3_exp_mul_direct(const double* u, const BaPose& in, BaPose& out) {
+    const double w0 = u[0], w1 = u[1], w2 = u[2];
+    const double t2 = fma(w0, w0, fma(w1, w1, w2 * w2));
+    if (t2 > 0.0625) {
+        se3_exp_mul(u, in, out);
+        return;
+    }
+    const double h = 0.25 * t2;  // (theta / 2)^2
+    // sin(theta/2)/theta = 1/2 (1 - h/3! + h^2/5! - ...), cos(theta/2) = 1 - h/2! + h^2/4! - ...
+    double sn = -1.0 / 6227020800.0, cs = -1.0 / 87178291200.0;  // -1/13!, -1/14!
+    sn = fma(sn, h, 1.0 / 39916800.0);   cs = fma(cs, h, 1.0 / 479001600.0);
+    sn = fma(sn, h, -1.0 / 362880.0);    cs = fma(cs, h, -1.0 / 3628800.0);
+    sn = fma(sn, h, 1.0 / 5040.0);       cs = fma(cs, h, 1.0 / 40320.0);
+    sn = fma(sn, h, -1.0 / 120.0);       cs = fma(cs, h, -1.0 / 720.0);
+    sn = fma(sn, h, 1.0 / 6.0);          cs = fma(cs, h, 1.0 / 24.0);
+    sn = fma(-sn, h, 1.0);               cs = fma(cs, h, -0.5);
+    sn = 0.5 * sn;                       cs = fma(cs, h, 1.0);
+    // V = I + b Omega + c Omega^2, b = (1 - cos t)/t^2, c = (t - sin t)/t^3
+    double b = 1.0 / 20922789888000.0, c = 1.0 / 355687428096000.0;  // 1/16!, 1/17!
+    b = fma(-b, t2, 1.0 / 87178291200.0);  c = fma(-c, t2, 1.0 / 1307674368000.0);
+    b = fma(-b, t2, 1.0 / 479001600.0);    c = fma(-c, t2, 1.0 / 6227020800.0);
+    b = fma(-b, t2, 1.0 / 3628800.0);      c = fma(-c, t2, 1.0 / 39916800.0);
+    b = fma(-b, t2, 1.0 / 40320.0);        c = fma(-c, t2, 1.0 / 362880.0);
+    b = fma(-b, t2, 1.0 / 720.0);          c = fma(-c, t2, 1.0 / 5040.0);
+    b = fma(-b, t2, 1.0 / 24.0);           c = fma(-c, t2, 1.0 / 120.0);
+    b = fma(-b, t2, 0.5);                  c = fma(-c, t2, 1.0 / 6.0);
+    const double v0 = u[3], v1 = u[4], v2 = u[5];
+    const double k0 = fma(w1, v2, -(w2 * v1)), k1 = fma(w2, v0, -(w0 * v2)), k2 = fma(w0, v1, -(w1 * v0));  // omega x upsilon
+    const double m0 = fma(w1, k2, -(w2 * k1)), m1 = fma(w2, k0, -(w0 * k2)), m2 = fma(w0, k1, -(w1 * k0));  // omega x (omega x upsilon)
+    const double ta[3] = {fma(c, m0, fma(b, k0, v0)), fma(c, m1, fma(b, k1, v1)), fma(c, m2, fma(b, k2, v2))};
+    const double qa[4] = {sn * w0, sn * w1, sn * w2, cs};
+    double rt[3];
+    quat_rotate(qa, in.t, rt);
+    out.t[0] = ta[0] + rt[0]; out.t[1] = ta[1] + rt[1]; out.t[2] = ta[2] + rt[2];
+    const double* q = in.q;
+    double qn[4];
+    qn[3] = fma(qa[3], q[3], -fma(qa[0], q[0], fma(qa[1], q[1], qa[2] * q[2])));
+    qn[0] = fma(qa[3], q[0], fma(qa[0], q[3], fma(qa[1], q[2], -(qa[2] * q[1]))));
+    qn[1] = fma(qa[3], q[1], fma(qa[1], q[3], fma(qa[2], q[0], -(qa[0] * q[2]))));
+    qn[2] = fma(qa[3], q[2], fma(qa[2], q[3], fma(qa[0], q[1], -(qa[1] * q[0]))));
+    double nrm = rsqrt_newton(fma(qn[0], qn[0], fma(qn[1], qn[1], fma(qn[2], qn[2], qn[3] * qn[3]))));
+    if (qn[3] < 0) nrm = -nrm;
+    out.q[0] = qn[0] * nrm; out.q[1] = qn[1] * nrm; out.q[2] = qn[2] * nrm; out.q[3] = qn[3] * nrm;
+    out.pad = 0;
+}
+
+// ---- register-resident version (n <= THREADS x EPT matched points) ----
+// What bounded the LDS-resident kernel above (tools/probe/pose_probe.hip): a dependent FP64 chain per edge with one
+// wave per SIMD, and 3.7 k cycles per pass on lane 0 (decision + 6x6 solve + SE3 exponential) fenced by two barriers
+// while the other 255 threads wait.  Here
+//   * every thread keeps its EPT edges (point, observation, weight, stored error, outlier flag) in registers for the
+//     whole schedule - no LDS traffic and no float -> double conversion per pass - and walks them unrolled, so the
+//     scheduler interleaves the independent chains of different edges;
+//   * the rotation matrix is formed once per pass instead of a quaternion rotation per edge, the Jacobian rows share
+//     their sub-products, Huber's rho and rho' come from ONE reciprocal square root (no division);
+//   * the LM control flow is replicated: after the single barrier of a pass every wave sums the per-wave partials
+//     itself (fixed order: identical in all waves) and EVERY lane decides, solves and exponentiates redundantly in
+//     registers - the SIMD lanes were idle anyway - so the trial pose never travels through LDS and the second
+//     barrier of a pass disappears.  The partial-sum buffer is double-buffered by pass parity: a wave can be at most
+//     one pass ahead of the slowest one.
+// Same schedule, same accept / reject rules, same stored-error semantics as above (g2o's optimize(10) x 4).
+template <int THREADS, int EPT>
+__global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a) {
+    constexpr int NW = THREADS / 64;
+    __shared__ double s_red[2][NW][32];
+    __shared__ double s_sysw[NW][2][32];  // per wave: the two systems; 21 H (upper) | 6 b | chi | n_active
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = a.n;
+    const double delta = (double)sqrtf(5.991f);  // const float deltaMono = sqrt(5.991)
+    const float dsqr = (float)(delta * delta);
+    const double fx = a.K[0], fy = a.K[1], cx = a.K[2], cy = a.K[3];
+    double X[EPT][3], ob[EPT][2], w[EPT], er[EPT][2];
+    bool live[EPT], outl[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int e = tid + k * THREADS;
+        live[k] = e < n;
+        outl[k] = false;
+        const int ee = live[k] ? e : 0;
+        X[k][0] = (double)a.Xw[3 * ee]; X[k][1] = (double)a.Xw[3 * ee + 1]; X[k][2] = (double)a.Xw[3 * ee + 2];
+        ob[k][0] = (double)a.obs[2 * ee]; ob[k][1] = (double)a.obs[2 * ee + 1];
+        w[k] = (double)a.inv_sigma2[ee];
+        er[k][0] = 0.0; er[k][1] = 0.0;
+    }
+    int robust = 1, parity = 0;
+    SO_POSE_TICK_DECL;
+
+    // One pass over the active edges at pose T; the block totals land in this wave's s_sysw[wv][which].
+    auto edge_phase = [&](const BaPose& T, int which) {
+        SO_POSE_TICK(6);  // everything since the last tick: decision + solve + SE3 update, round set-up
+        double R[9];
+        quat_to_R(T.q, R);
+        double v[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) v[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            if (!live[k] || outl[k]) continue;  // level 1
+            const double x = fma(R[0], X[k][0], fma(R[1], X[k][1], fma(R[2], X[k][2], T.t[0])));
+            const double y = fma(R[3], X[k][0], fma(R[4], X[k][1], fma(R[5], X[k][2], T.t[1])));
+            const double z = fma(R[6], X[k][0], fma(R[7], X[k][1], fma(R[8], X[k][2], T.t[2])));
+            double c = __builtin_amdgcn_rcp(z);  // reciprocal + two Newton steps instead of the IEEE division
+            c = fma(fma(-z, c, 1.0), c, c);
+            c = fma(fma(-z, c, 1.0), c, c);
+            const double p = x * c, q = y * c;  // normalised image coordinates
+            const double pf = p * fx, qg = q * fy;
+            const double e0 = ob[k][0] - (pf + cx);
+            const double e1 = ob[k][1] - (qg + cy);
+            er[k][0] = e0;
+            er[k][1] = e1;
+            const double we0 = w[k] * e0, we1 = w[k] * e1;
+            const double chi2 = fma(e0, we0, e1 * we1);
+            // Huber: rho = 2 sqrt(e) delta - delta^2, rho' = delta / sqrt(e), both from one reciprocal square root
+            const bool clipped = robust && !(chi2 <= (double)dsqr);
+            const double rs = rsqrt_newton(clipped ? chi2 : 1.0);
+            v[27] += clipped ? fma(2.0 * delta, chi2 * rs, -(double)dsqr) : chi2;
+            v[28] += 1.0;
+            const double r1 = clipped ? delta * rs : 1.0;
+            const double wo = r1 * w[k];
+            // EdgeSE3ProjectXYZOnlyPose::linearizeOplus (types_six_dof_expmap.cpp:266-288), shared sub-products;
+            // Ju[4] and Jv[3] are structurally zero
+            const double cf = c * fx, cg = c * fy;
+            const double Ju0 = pf * q, Ju1 = -fma(pf, p, fx), Ju2 = q * fx, Ju3 = -cf, Ju5 = pf * c;
+            const double Jv0 = fma(qg, q, fy), Jv1 = -(qg * p), Jv2 = -(p * fy), Jv4 = -cg, Jv5 = qg * c;
+            const double a0 = Ju0 * wo, a1 = Ju1 * wo, a2 = Ju2 * wo, a3 = Ju3 * wo, a5 = Ju5 * wo;
+            const double b0 = Jv0 * wo, b1 = Jv1 * wo, b2 = Jv2 * wo, b4 = Jv4 * wo, b5 = Jv5 * wo;
+            // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+            v[0] = fma(a0, Ju0, fma(b0, Jv0, v[0]));
+            v[1] = fma(a0, Ju1, fma(b0, Jv1, v[1]));
+            v[2] = fma(a0, Ju2, fma(b0, Jv2, v[2]));
+            v[3] = fma(a0, Ju3, v[3]);
+            v[4] = fma(b0, Jv4, v[4]);
+            v[5] = fma(a0, Ju5, fma(b0, Jv5, v[5]));
+            v[6] = fma(a1, Ju1, fma(b1, Jv1, v[6]));
+            v[7] = fma(a1, Ju2, fma(b1, Jv2, v[7]));
+            v[8] = fma(a1, Ju3, v[8]);
+            v[9] = fma(b1, Jv4, v[9]);
+            v[10] = fma(a1, Ju5, fma(b1, Jv5, v[10]));
+            v[11] = fma(a2, Ju2, fma(b2, Jv2, v[11]));
+            v[12] = fma(a2, Ju3, v[12]);
+            v[13] = fma(b2, Jv4, v[13]);
+            v[14] = fma(a2, Ju5, fma(b2, Jv5, v[14]));
+            v[15] = fma(a3, Ju3, v[15]);
+            // (3,4) is structurally zero: v[16] stays 0
+            v[17] = fma(a3, Ju5, v[17]);
+            v[18] = fma(b4, Jv4, v[18]);
+            v[19] = fma(b4, Jv5, v[19]);
+            v[20] = fma(a5, Ju5, fma(b5, Jv5, v[20]));
+            const double g0 = r1 * we0, g1 = r1 * we1;  // -rho' J^T Omega e
+            v[21] = fma(-Ju0, g0, fma(-Jv0, g1, v[21]));
+            v[22] = fma(-Ju1, g0, fma(-Jv1, g1, v[22]));
+            v[23] = fma(-Ju2, g0, fma(-Jv2, g1, v[23]));
+            v[24] = fma(-Ju3, g0, v[24]);
+            v[25] = fma(-Jv4, g1, v[25]);
+            v[26] = fma(-Ju5, g0, fma(-Jv5, g1, v[26]));
+        }
+        SO_POSE_TICK(0);  // edge loop
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = po_swap_add32(v[i], v[i + 16]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = po_swap_add16(v[i], v[i + 8]);
+        po_halve<4>(v, 8, lane);
+        po_halve<2>(v, 4, lane);
+        po_halve<1>(v, 2, lane);
+        const double tot = v[0] + __shfl_xor(v[0], 1);  // lane holds the wave total of value (lane >> 1)
+        if ((lane & 1) == 0) s_red[parity][wv][lane >> 1] = tot;
+        SO_POSE_TICK(1);  // wave reduction
+        __syncthreads();  // the only barrier of a pass
+        SO_POSE_TICK(2);  // barrier
+        if (lane < 32) {
+            double sum = s_red[parity][0][lane];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; w2++) sum += s_red[parity][w2][lane];
+            s_sysw[wv][which][lane] = sum;
+        }
+        parity ^= 1;
+        __threadfence_block();  // wave-private rows: in-order LDS traffic of this wave + completed writes are enough
+        SO_POSE_TICK(3);  // cross-wave sum
+    };
+
+    // replicated LM state (identical in every lane of every wave)
+    BaPose cur = a.init, trial = a.init;
+    double lambda = 0.0, ni = 2.0, currentChi = 0.0, iniChi = 0.0, scale = 1.0, inv_scale = 1.0;
+    int qmax = 0, it = 0, nBadLM = 0, solve_ok = 1, its_total = 0, trials_total = 0, cursys = 0, nbad_total = 0;
+    auto propose = [&]() {
+        SO_POSE_TICK(4);  // decision (since the cross-wave sum)
+        const double* S = s_sysw[wv][cursys];
+        double Su[21], b[6], x[6];
+#pragma unroll
+        for (int r = 0; r < 21; r++) Su[r] = S[r];
+#pragma unroll
+        for (int r = 0; r < 6; r++) b[r] = S[21 + r];
+        po_solve6_blocks(Su, b, lambda, x, scale, solve_ok);
+        inv_scale = po_rcp(scale + 1e-3);  // ready long before the trial's chi2 arrives
+        SO_POSE_TICK(5);  // 6x6 solve
+        se3_exp_mul_direct(x, cur, trial);
+        SO_POSE_TICK(7);  // SE3 update
+
+    };
+
+    // One instance of the edge pass, of the decision and of the proposal in the instruction stream (a small state
+    // machine instead of inlining them at every place of g2o's control flow): the unrolled kernel was ~60 KB of code and
+    // every pass paid instruction-cache misses between its pieces (1.2 k cycles from the end of the proposal to the
+    // first edge, tools/probe/pose_probe.hip).
+    enum { kFirst = 0, kTrial = 1, kReeval = 2 };
+    for (int round = 0; round < 4; round++) {
+        cur = a.init;  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw))
+        cursys = 0;
+        int mode = kFirst, which = 0;
+        BaPose eval = cur;
+        for (;;) {
+            edge_phase(eval, which);
+            bool stop = false, want_proposal = false;
+            if (mode == kFirst) {
+                const double* S = s_sysw[wv][0];
+                if (S[28] > 0.0) {  // optimize(10) with at least one active edge
+                    const double md = fmax(fmax(fmax(fabs(S[0]), fabs(S[6])), fmax(fabs(S[11]), fabs(S[15]))), fmax(fabs(S[18]), fabs(S[20])));
+                    lambda = 1e-5 * md;  // computeLambdaInit
+                    ni = 2.0;
+                    currentChi = iniChi = S[27];
+                    qmax = 0; it = 0; nBadLM = 0;
+                    want_proposal = true;
+                } else {
+                    stop = true;
+                }
+            } else if (mode == kReeval) {  // stored errors are back at the estimate: next iteration's first trial
+                want_proposal = true;
+            } else {
+                const int tsys = cursys ^ 1;
+                const double tempChi = solve_ok ? s_sysw[wv][tsys][27] : 1.7976931348623157e308;
+                const double rho = (currentChi - tempChi) * inv_scale;
+                if (a.trace && tid == 0 && trials_total < 256) {
+                    a.trace[4 * trials_total] = lambda;
+                    a.trace[4 * trials_total + 1] = tempChi;
+                    a.trace[4 * trials_total + 2] = rho;
+                    a.trace[4 * trials_total + 3] = currentChi;
+                }
+                const bool accepted = rho > 0 && isfinite(tempChi);
+                if (accepted) {
+                    const double tr = 2 * rho - 1;
+                    double alpha = 1. - tr * tr * tr;
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2.0;
+                    currentChi = tempChi;
+                    cur = trial;     // discardTop
+                    cursys = tsys;   // the trial's system becomes the current one
+                } else {
+                    lambda *= ni;  // pop
+                    ni *= 2.0;
+                }
+                qmax++;
+                trials_total++;
+                if (rho < 0 && qmax < 10) {
+                    want_proposal = true;  // same system, larger lambda
+                } else {
+                    its_total++;
+                    bool end_it = false;
+                    if (qmax == 10 || rho == 0) {
+                        end_it = true;
+                    } else {
+                        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+                        if (nBadLM >= 3) end_it = true;
+                    }
+                    it++;
+                    if (end_it || it >= 10) {
+                        stop = true;
+                    } else {
+                        qmax = 0;
+                        iniChi = currentChi;
+                        want_proposal = accepted;  // a rejected last trial: re-evaluate the estimate first
+                    }
+                }
+            }
+            if (stop) break;
+            if (want_proposal) {
+                propose();
+                mode = kTrial;
+                eval = trial;
+                which = cursys ^ 1;
+            } else {
+                mode = kReeval;
+                eval = cur;
+                which = cursys;
+            }
+        }
+        // classify (Optimizer.cc:357-380): outliers of the previous round get a fresh error, inliers keep the stored one
+        double R[9];
+        quat_to_R(cur.q, R);
+        double bad_local = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            if (!live[k]) continue;
+            if (outl[k]) {
+                const double x = fma(R[0], X[k][0], fma(R[1], X[k][1], fma(R[2], X[k][2], cur.t[0])));
+                const double y = fma(R[3], X[k][0], fma(R[4], X[k][1], fma(R[5], X[k][2], cur.t[1])));
+                const double z = fma(R[6], X[k][0], fma(R[7], X[k][1], fma(R[8], X[k][2], cur.t[2])));
+                er[k][0] = ob[k][0] - (x / z * fx + cx);
+                er[k][1] = ob[k][1] - (y / z * fy + cy);
+            }
+            const float chi2 = (float)(er[k][0] * (w[k] * er[k][0]) + er[k][1] * (w[k] * er[k][1]));
+            outl[k] = chi2 > 5.991f;
+            bad_local += outl[k] ? 1.0 : 0.0;
+        }
+        // block total in the same replicated fashion (one barrier): every wave ends up with the count
+        {
+            const double wsum = wave_sum(bad_local);
+            if (lane == 0) s_red[parity][wv][0] = wsum;
+            __syncthreads();
+            double tot = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) tot += s_red[parity][w2][0];
+            parity ^= 1;
+            nbad_total = (int)tot;
+        }
+        if (round == 2) robust = 0;
+        if (n < 10) break;
+    }
+    SO_POSE_TICK(6);
+    SO_POSE_TICK_FLUSH;
+#pragma unroll
+    for (int k = 0; k < EPT; k++)
+        if (live[k]) a.outlier[tid + k * THREADS] = outl[k] ? 1 : 0;
+    if (tid == 0) {
+        *a.pose_out = cur;
+        a.info[0] = nbad_total;
+        a.info[1] = its_total;
+        a.info[2] = trials_total;
+    }
+}
+
+template <int THREADS, int EPT>
+static void launch_pose_reg(const PoseOptArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((pose_opt_reg_kernel<THREADS, EPT>), dim3(1), dim3(THREADS), 0, s, a);
+}
+
 void launch_pose_opt(const PoseOptArgs& a, hipStream_t s) {
     static const bool classic = getenv("SWARMORB_POSE_CLASSIC") != nullptr;  // A/B switch for profiling
+    static const bool lds_only = getenv("SWARMORB_POSE_LDS") != nullptr;    // A/B: the LDS-resident kernel for every size
+    static const int force_threads = getenv("SWARMORB_POSE_THREADS") ? atoi(getenv("SWARMORB_POSE_THREADS")) : 0;
+    if (!classic && !lds_only && (a.n <= 1024 || (force_threads == 512 && a.n <= 2048))) {
+        // register-resident kernel, 256 threads and up to 4 edges per thread (measured: beyond 1024 points the
+        // LDS-resident kernel with 512 threads is faster: 157 vs 183 us at 1500); 512 threads only on request
+        const bool wide = force_threads == 512;
+        if (!wide && a.n <= 1024) {
+            const int ept = (a.n + 255) / 256;
+            if (ept <= 1) launch_pose_reg<256, 1>(a, s);
+            else if (ept == 2) launch_pose_reg<256, 2>(a, s);
+            else if (ept == 3) launch_pose_reg<256, 3>(a, s);
+            else launch_pose_reg<256, 4>(a, s);
+        } else {
+            const int ept = (a.n + 511) / 512;
+            if (ept <= 1) launch_pose_reg<512, 1>(a, s);
+            else if (ept == 2) launch_pose_reg<512, 2>(a, s);
+            else if (ept == 3) launch_pose_reg<512, 3>(a, s);
+            else launch_pose_reg<512, 4>(a, s);
+        }
+        return;
+    }
     if (a.n <= kPoLdsMax && !classic) {
         const size_t lds = sizeof(double) * 2 * (size_t)a.n + sizeof(float) * 6 * (size_t)a.n + (size_t)a.n + 16;
         static bool big_lds[64] = {};  // per device; 41 B per edge: 3072 edges = 126 KB of the CU's 160 KB

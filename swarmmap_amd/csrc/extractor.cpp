@@ -76,6 +76,7 @@ struct so_extractor {
     uint8_t* h_desc_dev = nullptr;
     int out_capacity = 0;
     DescribeDeviceOut dev_out{};      // HBM-resident copies of desc / angle / meta / total (device-quadtree path)
+    uint8_t* d_upload = nullptr;      // tightly packed landing buffer of host images (width x height)
 
     KeypointQuadtree qt;
     std::vector<int> picked;
@@ -218,6 +219,8 @@ int allocate(so_extractor* ex, int w, int h) {
         rc = dev_alloc(ex, &ex->dev_out.total, 64, true);
         if (rc) return rc;
     }
+    rc = dev_alloc(ex, &ex->d_upload, (size_t)w * h + 256, false);
+    if (rc) return rc;
     SO_HIP(hipStreamSynchronize(ex->stream));
     ex->width = w;
     ex->height = h;
@@ -333,8 +336,17 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
 
     if (prof) SO_HIP(hipEventRecord(ex->ev[0], s));
     // ComputePyramid, code/src/ORBextractor.cc:837-853
-    SO_HIP(hipMemcpy2DAsync(P.lv[0].img, (size_t)P.lv[0].pitch, image, (size_t)stride, (size_t)w, (size_t)h,
-                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (!on_device && stride == w) {
+        // a pitched host -> device copy is split into one DMA per row when the width is not a multiple of four bytes
+        // (1241-px KITTI rows: 376 copies, 2.2 ms); one linear upload into a packed landing buffer followed by a
+        // device-side repack into the pitched level-0 image costs two enqueues instead
+        SO_HIP(hipMemcpyAsync(ex->d_upload, image, (size_t)w * h, hipMemcpyHostToDevice, s));
+        SO_HIP(hipMemcpy2DAsync(P.lv[0].img, (size_t)P.lv[0].pitch, ex->d_upload, (size_t)w, (size_t)w, (size_t)h,
+                                hipMemcpyDeviceToDevice, s));
+    } else {
+        SO_HIP(hipMemcpy2DAsync(P.lv[0].img, (size_t)P.lv[0].pitch, image, (size_t)stride, (size_t)w, (size_t)h,
+                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    }
     static const bool no_graph = getenv("SWARMORB_NO_GRAPH") != nullptr;
     if (!prof && !no_graph && ex->device_qt && P.total_tiles > 0 && !ex->graph_failed) {
         float* angle_dev = reinterpret_cast<float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -515,6 +516,7 @@ int so_matcher_create(int device, so_matcher** out) {
         delete m;
         return hip_fail(e, "matcher init", __FILE__, __LINE__);
     }
+    m->profile = getenv("SWARMORB_NO_EVENTS") == nullptr;
     *out = m;
     return SO_OK;
 }
@@ -1629,6 +1631,10 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
                               float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local, int32_t* nmatches) {
     if (m) (void)take_reuse(m);
     if (!track_args_ok(m, cur, map, Tcw12) || n_local < 0 || !kp_to_local || !nmatches) return SO_ERR_INVALID_ARG;
+    static const bool trace = getenv("SWARMORB_MATCH_TRACE") != nullptr;
+    static double tacc[6] = {0, 0, 0, 0, 0, 0};
+    static int tcalls = 0;
+    const auto tt0 = std::chrono::steady_clock::now();
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
@@ -1647,7 +1653,9 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
     const size_t view_off = align256(keys_bytes + sizeof(int32_t) * (size_t)n_local);
     if ((rc = m->h_out.ensure(view_off + (size_t)n_local))) return rc;
     T.in_view_out = (uint8_t*)m->h_out.dev + view_off;
+    const auto tt1 = std::chrono::steady_clock::now();
     if ((rc = run_topk_track(m, T, 3, n_local, K, local_slot, skip))) return rc;
+    const auto tt2 = std::chrono::steady_clock::now();
     const uint8_t* view = (const uint8_t*)m->h_out.p + view_off;
     if (in_view) memcpy(in_view, view, (size_t)n_local);
     if (cur->n == 0) return SO_OK;
@@ -1686,6 +1694,17 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
         }
     }
     *nmatches = nm;
+    if (trace) {
+        const auto tt3 = std::chrono::steady_clock::now();
+        tacc[0] += std::chrono::duration<double, std::micro>(tt1 - tt0).count();
+        tacc[1] += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
+        tacc[2] += std::chrono::duration<double, std::micro>(tt3 - tt2).count();
+        tacc[3] += m->stat[0] * 1e3;
+        tacc[4] += m->stat[1] * 1e3;
+        if (++tcalls % 100 == 0)
+            fprintf(stderr, "[m1] setup %.1f us, run_topk_track %.1f us (enqueue %.1f, sync %.1f), resolve %.1f us\n",
+                    tacc[0] / tcalls, tacc[1] / tcalls, tacc[3] / tcalls, tacc[4] / tcalls, tacc[2] / tcalls);
+    }
     return SO_OK;
 }
 

@@ -171,7 +171,8 @@ namespace {
 enum {  // indices of so_replay::stat, mirrored in bench.py
     kSteps = 0, kExtractMs, kM2Ms, kPose1Ms, kM1Ms, kPose2Ms, kPose3Ms, kMapMs, kSubmitWaitMs, kKp, kM2, kM1, kInliers,
     kMatchKernelMs, kPoseKernelMs, kPoseTrials, kPoseCalls, kPosePoints, kLbaWindows, kLbaBusyMs, kLbaGpuMs, kLbaSolveMs,
-    kLbaSolves, kLocalPoints, kInView, kKeyframes, kMapPoints, kStage0 /* 11 extractor stages */
+    kLbaSolves, kLocalPoints, kInView, kKeyframes, kMapPoints, kM2EnqMs, kM2WaitMs, kM1EnqMs, kM1WaitMs,
+    kStage0 /* 11 extractor stages */
 };
 
 void mapper_loop(so_replay* r) {
@@ -457,6 +458,7 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
         const double t1 = now_ms();
         double tm2 = t1, tp1 = t1, tm1 = t1, tp2 = t1, tp3 = t1, tmap = t1;
         double match_kernel = 0.0, pose_kernel = 0.0, pose_trials = 0.0, pose_points = 0.0;
+        double mstat[4] = {0, 0, 0, 0}, ms4[4];  // matcher: enqueue / blocked-in-sync ms of M2 and of M1
         int pose_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0;
         int32_t n_in = n;
         for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = -1;
@@ -487,6 +489,8 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
                 return fail(r, "so_track_search_last_frame");
             so_matcher_last_kernel_ms(r->matcher, &kms);
             match_kernel += kms;
+            so_matcher_last_stats(r->matcher, ms4);
+            mstat[0] += ms4[0]; mstat[1] += ms4[1];
             if (nm < 20) {  // Tracking.cc:1020-1024: wider window
                 if (so_track_search_last_frame(r->matcher, dcur, nullptr, dlast, r->map, Tp, r->last_slot.data(), nullptr,
                                                30.0f, 1, r->k2l.data(), &nm) != SO_OK)
@@ -532,6 +536,8 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
                 return fail(r, "so_track_search_local_map");
             so_matcher_last_kernel_ms(r->matcher, &kms);
             match_kernel += kms;
+            so_matcher_last_stats(r->matcher, ms4);
+            mstat[2] += ms4[0]; mstat[3] += ms4[1];
             nm1 = nmm;
             for (int i = 0; i < n_local; i++) n_view += view[(size_t)i];
             for (int k = 0; k < n; k++)
@@ -601,6 +607,7 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
             st[kMatchKernelMs] += match_kernel; st[kPoseKernelMs] += pose_kernel; st[kPoseTrials] += pose_trials;
             st[kPoseCalls] += pose_calls; st[kPosePoints] += pose_points; st[kLocalPoints] += n_local; st[kInView] += n_view;
             st[kKeyframes] += keyframe; st[kMapPoints] = (double)(r->mp_X.size() / 3);
+            st[kM2EnqMs] += mstat[0]; st[kM2WaitMs] += mstat[1]; st[kM1EnqMs] += mstat[2]; st[kM1WaitMs] += mstat[3];
             float prof[SO_EXTRACTOR_N_STAGES];
             if (so_extractor_get_profile(r->ex, prof) == SO_OK)
                 for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) st[kStage0 + i] += prof[i];

@@ -89,9 +89,7 @@ def _T44(T12):
 def ground_truth(stream, n_frames, K, plane_z):
     """Camera centres of `synth.FrameStream` frames 0..n-1 in the frame-0 camera's coordinates."""
     fx, fy = float(K[0]), float(K[1])
-    m = stream.margin
-    o = np.array([[int(round(m + (m - 1) * np.sin(0.013 * t))), int(round(m + (m - 1) * np.sin(0.021 * t + 0.5)))]
-                  for t in range(n_frames)], np.float64)
+    o = np.array([stream.offset(t) for t in range(n_frames)], np.float64)
     c = np.zeros((n_frames, 3))
     c[:, 0] = (o[:, 0] - o[0, 0]) * plane_z / fx
     c[:, 1] = (o[:, 1] - o[0, 1]) * plane_z / fy
@@ -137,13 +135,13 @@ def _local_window(kfs, mp_X, intr, n_free=6, n_fixed=8):
 
 
 def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_ratio=0.7, local_ba=False,
-          local_keyframes=0, third_pose=False, frames=None):
+          local_keyframes=0, third_pose=False, frames=None, on_frame=None):
     """Returns dict(centres (n,3), poses (n,12), matches_last, matches_map, inliers, n_map_points[, lba_*]).
     local_keyframes > 0: the local map (Tracking::UpdateLocalMap) is the points created at the last that many
     keyframes instead of the whole map.  third_pose: one more PoseOptimization per frame, from the last frame's pose
     over the final matches (what Tracking::TrackReferenceKeyFrame does when the motion model fails; the per-frame
     replay of SURVEY.md 8d counts three calls), result not used.  frames: optional list of images (else
-    stream.frame(t))."""
+    stream.frame(t)).  on_frame(t): called after each tracked frame; returning False ends the run."""
     intr = np.asarray(K, np.float32)
     fx, fy, cx, cy = [float(v) for v in intr]
     sf, inv_sigma2 = backend.tables()
@@ -276,6 +274,8 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
         log["n_map_points"].append(len(mp_X))
         last = (kps, kp_mp, outlier)
         T_last = T
+        if on_frame is not None and on_frame(t) is False:
+            break
     out = dict(centres=np.array(centres), poses=np.array(poses))
     out.update({k: np.array(v) for k, v in log.items()})
     return out

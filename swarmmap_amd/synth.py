@@ -47,18 +47,48 @@ def make_image(seed, size=EUROC):
 
 
 class FrameStream:
-    """Deterministic stream of (h, w) uint8 frames: a window sliding over a canvas."""
+    """Deterministic stream of (h, w) uint8 frames: a window sliding over a canvas.  With K and dist (k1 k2 p1 p2
+    [k3]) the window is seen through that lens: pixel (u, v) of a frame shows the canvas where the pinhole camera K
+    would have put the undistorted point of (u, v) (radial-tangential model, the same five fixed-point iterations as
+    cv::undistortPoints; bilinear sampling), so undistorted keypoints are consistent with the planar scene."""
 
-    def __init__(self, seed=20221001, size=EUROC, margin=160):
+    def __init__(self, seed=20221001, size=EUROC, margin=160, K=None, dist=None):
         self.w, self.h = size
         self.margin = margin
         self.canvas = make_canvas(seed, self.w + 2 * margin, self.h + 2 * margin)
+        self._map = None
+        if K is not None and dist is not None and float(dist[0]) != 0.0:
+            fx, fy, cx, cy = [float(v) for v in K]
+            d = [float(v) for v in dist] + [0.0] * (5 - len(dist))
+            k1, k2, p1, p2, k3 = d
+            v, u = np.mgrid[0:self.h, 0:self.w].astype(np.float64)
+            x0, y0 = (u - cx) / fx, (v - cy) / fy
+            x, y = x0.copy(), y0.copy()
+            for _ in range(5):
+                r2 = x * x + y * y
+                icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+                dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+                dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+                x, y = (x0 - dx) * icd, (y0 - dy) * icd
+            self._map = ((fx * x + cx).astype(np.float32), (fy * y + cy).astype(np.float32))
+
+    def offset(self, t):
+        m = self.margin
+        return (int(round(m + (m - 1) * np.sin(0.013 * t))), int(round(m + (m - 1) * np.sin(0.021 * t + 0.5))))
 
     def frame(self, t):
-        m = self.margin
-        ox = int(round(m + (m - 1) * np.sin(0.013 * t)))
-        oy = int(round(m + (m - 1) * np.sin(0.021 * t + 0.5)))
-        return np.ascontiguousarray(self.canvas[oy:oy + self.h, ox:ox + self.w])
+        ox, oy = self.offset(t)
+        if self._map is None:
+            return np.ascontiguousarray(self.canvas[oy:oy + self.h, ox:ox + self.w])
+        H, W = self.canvas.shape
+        sx = np.clip(self._map[0] + np.float32(ox), 0, W - 1.001)
+        sy = np.clip(self._map[1] + np.float32(oy), 0, H - 1.001)
+        x0, y0 = sx.astype(np.int32), sy.astype(np.int32)
+        ax, ay = sx - x0, sy - y0
+        c = self.canvas.astype(np.float32)
+        top = c[y0, x0] * (1 - ax) + c[y0, x0 + 1] * ax
+        bot = c[y0 + 1, x0] * (1 - ax) + c[y0 + 1, x0 + 1] * ax
+        return np.clip(np.rint(top * (1 - ay) + bot * ay), 0, 255).astype(np.uint8)
 
 
 # ------------------------------------------------------------------------------------------------

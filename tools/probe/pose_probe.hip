@@ -51,6 +51,8 @@ int main(int argc, char** argv) {
     printf("n %d: kernel %.1f us, outliers %d iterations %d trials %d, edge passes %lld\n", n, best * 1e3, info[0], info[1], info[2], t[8]);
     printf("per pass (cycles): edge loop %.0f  wave reduction %.0f  barrier %.0f  cross-wave sum %.0f  decision + solve + barrier + round work %.0f\n",
            t[0] / np, t[1] / np, t[2] / np, t[3] / np, t[6] / np);
-    printf("total cycles %lld\n", t[0] + t[1] + t[2] + t[3] + t[6]);
+    printf("  register-resident kernel only: decision %.0f  6x6 solve %.0f  SE3 update %.0f  (rest of the serial part %.0f)\n",
+           t[4] / np, t[5] / np, t[7] / np, t[6] / np);
+    printf("total cycles %lld\n", t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6] + t[7]);
     return 0;
 }
