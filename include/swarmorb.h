@@ -396,13 +396,15 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
 /* TrackLocalMap's search: Tracking::SearchLocalPoints (code/src/Tracking.cc:1104-1156) — Frame::isInFrustum(pMP,
  * viewing_cos_limit) (code/src/Frame.cc:316-375, MapPoint::PredictScale code/src/MapPoint.cc:476-485) for each of
  * the n_local local map points, then ORBmatcher::SearchByProjection(F, vpMapPoints, th) (code/src/ORBmatcher.cc:
- * 44-121) over the visible ones.  local_slot[i] = map slot of mvpLocalMapPoints[i] (NULL: slots 0..n_local-1);
+ * 44-121) over the visible ones.  local_slot[i] = map slot of mvpLocalMapPoints[i] (NULL: the contiguous slots
+ * first_slot .. first_slot + n_local - 1);
  * skip[i] != 0: the point is already in mCurrentFrame.mvpMapPoints or isBad() and is not searched (may be NULL).
  * Out: in_view[i] = mbTrackInView (may be NULL), kp_to_local[k] = index into the local list bound to keypoint k. */
 int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_map* map,
-                              const float* Tcw12, int32_t n_local, const int32_t* local_slot, const uint8_t* skip,
-                              const uint8_t* slot_has_obs, float th, float nn_ratio, float viewing_cos_limit,
-                              float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local, int32_t* nmatches);
+                              const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
+                              const uint8_t* skip, const uint8_t* slot_has_obs, float th, float nn_ratio,
+                              float viewing_cos_limit, float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local,
+                              int32_t* nmatches);
 
 /* ------------------------------------------------------------------------------------------------
  * Keyframe record — the compact binary form of what a peer needs from a keyframe for the
@@ -479,6 +481,10 @@ typedef struct {
     float wall_ms;      /* host wall time of the call */
     float solve_ms;     /* HIP-event time summed over the reduced-system solve kernel launches */
     int32_t n_solves;
+    /* blocked solver (more than 43 free keyframes), 0 otherwise: FP64 work of ONE solve of the reduced camera system
+     * over the nonzero 96 x 96 tiles of its block skyline, the same for a dense matrix of that size, and the number
+     * of tiles inside the skyline (lower triangle) */
+    double solve_gflop_structural, solve_gflop_dense, nnz_tiles;
 } so_ba_info;
 
 int so_ba_create(int device, so_ba** out);

@@ -15,7 +15,9 @@
 #include <chrono>
 #include <cfloat>
 #include <cmath>
+#include <climits>
 #include <cstdlib>
+#include <thread>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -49,7 +51,8 @@ struct Buf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-constexpr int kMaxReducedDim = 12288;  // dense reduced camera system: 6 * n_free <= this (1.2 GB of FP64 in HBM)
+constexpr int kMaxReducedDim = 96 * kDenseMaxPanels;  // reduced camera system: 6 * n_free <= 49152 (8192 keyframes; S is
+                                                     // stored densely - 19 GB of the 288 GB - but only its block skyline is computed on)
 
 double now_ms() {
     using namespace std::chrono;
@@ -118,6 +121,8 @@ struct so_ba {
     int n_solves = 0;
     hipStream_t dense_side = nullptr;       // blocked dense solver: side stream + events of its look-ahead
     std::vector<hipEvent_t> dense_events;
+    DensePlan plan;                         // blocked solver: tiles of every trailing update for the current structure
+    std::vector<int> tile_first;
     BaLm* h_lm = nullptr;        // host-mapped copy of the LM state, written by the decision kernels
     BaLm* h_lm_dev = nullptr;
     uint8_t* h_abort = nullptr;  // host-mapped forceStopFlag the decision kernel polls
@@ -126,7 +131,7 @@ struct so_ba {
     // d_in: the problem as one block (see Layout in so_bundle_adjust), staged in pinned h_in and moved with one
     // copy; d_out / h_out: the result block coming back the same way; the rest is device-only working storage
     Buf d_in, d_out, d_pose1, d_pt1, d_err, d_chi2, d_tab, d_Hpp, d_bp, d_Hll, d_bl, d_W, d_Dinv, d_db, d_BDinv, d_S,
-        d_bs, d_xl, d_partial, d_po, d_lm, d_dense_ws, d_dense_x, d_pr_off, d_pr_cur, d_pr, d_big, d_scan_tmp;
+        d_bs, d_xl, d_partial, d_po, d_lm, d_dense_ws, d_dense_x, d_pr_off, d_pr_cur, d_pr, d_big, d_scan_tmp, d_plan;
     void* h_in = nullptr;
     size_t h_in_cap = 0;
     void* h_out = nullptr;
@@ -136,7 +141,7 @@ struct so_ba {
     size_t h_po_cap = 0;
     std::vector<Buf*> all() {
         return {&d_in, &d_out, &d_pose1, &d_pt1, &d_err, &d_chi2, &d_tab, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv,
-                &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x, &d_pr_off, &d_pr_cur, &d_pr, &d_big, &d_scan_tmp};
+                &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x, &d_pr_off, &d_pr_cur, &d_pr, &d_big, &d_scan_tmp, &d_plan};
     }
 };
 
@@ -179,11 +184,16 @@ int wait_stream(Run& r) {
         SO_HIP(hipStreamSynchronize(s));
         return SO_OK;
     }
+    // The flag is mirrored, not latched (a stop request withdrawn between two optimize() calls does not abort the next
+    // one), and the poll backs off: the local-mapping thread must not burn a core next to the tracking thread, which
+    // is itself bound by host enqueue latency.  20 us per nap: well below one LM trial of a window (~90 us).
+    int spins = 0;
     for (;;) {
         const hipError_t q = hipStreamQuery(s);
         if (q == hipSuccess) return SO_OK;
         if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
-        if (*r.stop) *r.b->h_abort = 1;
+        *r.b->h_abort = *r.stop ? 1 : 0;
+        if (++spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
 }
 
@@ -359,7 +369,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     int nf = 0;
     for (int i = 0; i < nP; i++) nf += (touched[(size_t)i] && !p->fixed[i]) ? 1 : 0;
     if (6 * nf > kMaxReducedDim) {
-        last_error_ref() = "reduced camera system too large for the dense solver (6*n_free > 12288)";
+        last_error_ref() = "reduced camera system too large for the blocked solver (more than 8192 free keyframes)";
         return SO_ERR_CAPACITY;
     }
     r.n_free = nf;
@@ -480,6 +490,37 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         }
         if ((rc = b->d_dense_ws.ensure(sizeof(double) * (ldS / 96) * 96 * 96))) return rc;
         if ((rc = b->d_dense_x.ensure(sizeof(double) * ldS))) return rc;
+        // Block skyline of S (LinearSolverEigen only ever touches the structural nonzeros, linear_solver_eigen.h:
+        // 147-232; here: 96-row tiles in natural keyframe order).  Block (i1, i2) of S is nonzero iff a landmark is seen
+        // by both keyframes, so row tile I starts at the smallest tile of any keyframe sharing a landmark with one of
+        // I's keyframes; Cholesky fill stays inside that row envelope.
+        const int T = (int)(ldS / 96);
+        b->tile_first.resize((size_t)T);
+        for (int I = 0; I < T; I++) b->tile_first[(size_t)I] = I;
+        for (int l = 0; l < nL; l++) {
+            int lo = INT_MAX;
+            for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
+                const int h = h_hidx[h_epose[k]];
+                if (h >= 0 && h < lo) lo = h;
+            }
+            if (lo == INT_MAX) continue;
+            const int tlo = lo / 16;  // 16 keyframes (96 rows) per tile
+            for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
+                const int h = h_hidx[h_epose[k]];
+                if (h >= 0 && tlo < b->tile_first[(size_t)(h / 16)]) b->tile_first[(size_t)(h / 16)] = tlo;
+            }
+        }
+        static const bool force_dense = getenv("SWARMORB_DENSE_FULL") != nullptr;  // A/B: ignore the structure
+        if (force_dense) std::fill(b->tile_first.begin(), b->tile_first.end(), 0);
+        build_dense_plan(T, b->tile_first.data(), b->dense_side != nullptr, &b->plan);
+        const size_t first_bytes = (sizeof(int) * (size_t)T + 255) & ~(size_t)255;
+        const size_t tiles_bytes = sizeof(int2) * std::max<size_t>(b->plan.tiles.size(), 1);
+        if ((rc = b->d_plan.ensure(first_bytes + tiles_bytes))) return rc;
+        SO_HIP(hipMemcpyAsync(b->d_plan.p, b->tile_first.data(), sizeof(int) * (size_t)T, hipMemcpyHostToDevice, s));
+        if (!b->plan.tiles.empty())
+            SO_HIP(hipMemcpyAsync((uint8_t*)b->d_plan.p + first_bytes, b->plan.tiles.data(), sizeof(int2) * b->plan.tiles.size(),
+                                  hipMemcpyHostToDevice, s));
+        SO_HIP(hipStreamSynchronize(s));  // the host vectors may be rebuilt by the next call
     }
     // pair lists of the large-map gather: capacity from the landmarks' observation counts (an upper bound: fixed
     // keyframes' observations are counted too)
@@ -564,6 +605,9 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.big_cap = (int)big_cap;
     d.dense_side = dense_path ? b->dense_side : nullptr;
     d.dense_events = dense_path ? b->dense_events.data() : nullptr;
+    d.tile_first = dense_path ? b->d_plan.as<int>() : nullptr;
+    d.plan_tiles = dense_path ? reinterpret_cast<const int2*>((const uint8_t*)b->d_plan.p + ((sizeof(int) * (ldS / 96) + 255) & ~(size_t)255)) : nullptr;
+    d.plan = dense_path ? &b->plan : nullptr;
     d.xl = b->d_xl.as<double>();
     d.partial = b->d_partial.as<double>();
     d.robust = opt->robust;
@@ -627,6 +671,11 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     if (hipEventElapsedTime(&ms, b->e0, b->e1) == hipSuccess) inf.gpu_ms = ms;
     inf.solve_ms = b->solve_ms;
     inf.n_solves = b->n_solves;
+    if (r.d.plan) {
+        inf.solve_gflop_structural = r.d.plan->flop_structural * 1e-9;
+        inf.solve_gflop_dense = r.d.plan->flop_dense * 1e-9;
+        inf.nnz_tiles = (double)r.d.plan->nnz_tiles;
+    }
     inf.wall_ms = (float)(now_ms() - t_begin);
     if (trace)
         fprintf(stderr, "[ba] stage %.3f upload+alloc %.3f opt1 %.3f (%d it) opt2 %.3f (%d it) finish %.3f | trials %d blocks %d\n",

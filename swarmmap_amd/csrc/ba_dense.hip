@@ -20,6 +20,7 @@
 // the MFMA operand fetch (16 rows x 2 k per half-wave) hit 64 distinct banks.
 // HBM layout: S is read and written tile by tile exactly once per panel step; at 288 GB the 9000 x 9000 system of
 // an eight-agent map (648 MB) stays resident next to the problem.
+#include <algorithm>
 #include <cstdlib>
 
 #include "ba_device.h"
@@ -726,6 +727,7 @@ __global__ __launch_bounds__(256) void dense_panel_kernel(BaDev d, int k) {
         return;
     }
     const int i = k + blockIdx.x;  // block row
+    if (d.tile_first[i] > k) return;  // A_ik lies left of row i's envelope: structurally zero, and stays zero
     double* Aik = d.S + (size_t)i * kDNB * ld + (size_t)k * kDNB;
     d4 acc[3][3];
     dense_tile_nt(Aik, ld, Linv, kDNB, sA, sB, acc);
@@ -747,52 +749,39 @@ __global__ __launch_bounds__(256) void dense_panel_kernel(BaDev d, int k) {
 // per group instead of once per 96 columns - that read-modify-write of C, not the MFMA rate, bounds the solve of a
 // 9000 x 9000 system.  Tiles: ncols == 0: every tile I >= J >= j0; ncols > 0: the block columns j0 .. j0+ncols-1
 // only (what the next panels' factor needs first).  rhs_panel >= 0: n_rhs more workgroups apply that panel's y.
-__global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int kw, int j0, int ncols, int n_tiles,
-                                                           int rhs_panel) {
+__global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int kw, const int2* __restrict__ tiles,
+                                                           int n_tiles, int rhs_panel) {
     __shared__ double sA[kDNB][kDStride];
     __shared__ double sB[kDNB][kDStride];
     if (!d.lm->active) return;
     const int tid = threadIdx.x, ld = d.ldS;
-    const int T = d.ldS / kDNB;
     if ((int)blockIdx.x >= n_tiles) {  // right-hand side rows below panel rhs_panel
-        __shared__ double s_y[kDNB];
-        if (tid < kDNB) s_y[tid] = d.bs[(size_t)rhs_panel * kDNB + tid];
-        __syncthreads();
-        const int row = (rhs_panel + 1) * kDNB + ((int)blockIdx.x - n_tiles) * 256 + tid;
-        if (row < ld) {
-            const double* L = d.S + (size_t)row * ld + (size_t)rhs_panel * kDNB;
-            double v = 0.0;
-            for (int m = 0; m < kDNB; m += 2) {
-                const double2 l = *reinterpret_cast<const double2*>(L + m);
-                v = fma(l.x, s_y[m], v);
-                v = fma(l.y, s_y[m + 1], v);
-            }
-            d.bs[row] -= v;
+        const int row0 = (rhs_panel + 1) * kDNB + ((int)blockIdx.x - n_tiles) * 256;
+        // the 256 rows of this workgroup span at most four tiles; L(row, rhs_panel) is zero left of the row's envelope
+        const int row = row0 + tid;
+        if (row >= ld || d.tile_first[row / kDNB] > rhs_panel) return;
+        const double* y = d.bs + (size_t)rhs_panel * kDNB;
+        const double* L = d.S + (size_t)row * ld + (size_t)rhs_panel * kDNB;
+        double v = 0.0;
+        for (int m = 0; m < kDNB; m += 2) {
+            const double2 l = *reinterpret_cast<const double2*>(L + m);
+            v = fma(l.x, y[m], v);
+            v = fma(l.y, y[m + 1], v);
         }
+        d.bs[row] -= v;
         return;
     }
-    int I, J;
-    if (ncols == 0) {  // row by row of the lower triangle from block j0
-        int t = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
-        while ((t + 1) * (t + 2) / 2 <= (int)blockIdx.x) t++;
-        while (t * (t + 1) / 2 > (int)blockIdx.x) t--;
-        I = j0 + t;
-        J = j0 + (int)blockIdx.x - t * (t + 1) / 2;
-    } else {           // column by column
-        int c = 0, rem = (int)blockIdx.x;
-        while (c + 1 < ncols && rem >= T - (j0 + c)) {
-            rem -= T - (j0 + c);
-            c++;
-        }
-        J = j0 + c;
-        I = J + rem;
-    }
-    if (I >= T || J >= T) return;
-    const double* Pi = d.S + (size_t)I * kDNB * ld + (size_t)k * kDNB;
-    const double* Pj = d.S + (size_t)J * kDNB * ld + (size_t)k * kDNB;
+    const int2 t = tiles[blockIdx.x];
+    const int I = t.x, J = t.y;
+    // panels of the group both rows have inside their envelopes: [lo, k + kw)
+    const int lo = max(k, max(d.tile_first[I], d.tile_first[J]));
+    const int klen = (k + kw - lo) * kDNB;
+    if (klen <= 0) return;
+    const double* Pi = d.S + (size_t)I * kDNB * ld + (size_t)lo * kDNB;
+    const double* Pj = d.S + (size_t)J * kDNB * ld + (size_t)lo * kDNB;
     double* C = d.S + (size_t)I * kDNB * ld + (size_t)J * kDNB;
     d4 acc[3][3];
-    dense_tile_nt(Pi, ld, Pj, ld, sA, sB, acc, kw * kDNB);
+    dense_tile_nt(Pi, ld, Pj, ld, sA, sB, acc, klen);
     const int lane = tid & 63, wave = tid >> 6, wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
 #pragma unroll
     for (int rt = 0; rt < 3; rt++)
@@ -833,7 +822,7 @@ __global__ __launch_bounds__(256) void dense_backward_kernel(BaDev d, int k) {
     if (tid < kDNB) s_x[tid] = s_part[0][tid] + s_part[1][tid];
     __syncthreads();
     const int c = blockIdx.x * 256 + tid;
-    if (c < k * kDNB) {
+    if (c < k * kDNB && c / kDNB >= d.tile_first[k]) {  // L(k, c / 96) is zero left of row k's envelope
         const double* L = d.S + (size_t)k * kDNB * ld + c;
         double v = 0.0;
         for (int m0 = 0; m0 < kDNB; m0 += 16) {  // 16 independent loads in flight per thread
@@ -865,59 +854,132 @@ void launch_ba_dense_pad(const BaDev& d, hipStream_t s) {
     if (np > n) hipLaunchKernelGGL(dense_pad_kernel, dim3(256), dim3(256), 0, s, d.S, d.bs, n, np);
 }
 
-// One group of g panels from k: for each, [update of its block column with the panels of the group before it,
-// K = 96 p] -> diagonal factor -> panel solve.  After it the trailing matrix from block k+g on takes the whole group
-// in one K = 96 g update.
-static void dense_chain(const BaDev& d, int k, int g, hipStream_t s) {
-    const int T = d.ldS / kDNB;
-    for (int p = 0; p < g && k + p < T; p++) {
-        const int c = k + p, rem = T - c;  // block column c: rem tiles from the diagonal down
-        if (p > 0) {
-            const int rhs_blocks = (rem * kDNB + 255) / 256;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(rem + rhs_blocks), dim3(256), 0, s, d, k, p, c, 1, rem, c - 1);
-        }
-        hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, c);
-        hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (rem - 1)), dim3(256), 0, s, d, c);
+// ---- launch plan ----
+// The factorisation is right-looking in groups of G panels.  Per group: a serial chain over its panels ([update of the
+// panel's block column with the group's earlier panels, K = 96 p] -> diagonal factor -> panel solve), then the
+// trailing matrix from block k + G on takes the whole group in one K = 96 G update.  With look-ahead the trailing
+// update is split into the G block columns the next group needs (A) and the rest (B): as soon as A is done the side
+// stream runs the next group's chain while the main stream is still busy with B.
+// build_dense_plan enumerates, in exactly that order, the tiles every update launch touches: tile (I, J) takes part in
+// the update by panels [k, k + kw) iff it lies inside row I's envelope (J >= first[I]) and both rows have one of those
+// panels inside theirs (max(first[I], first[J]) < k + kw).  A dense matrix (first == 0) reproduces the old launches.
+namespace {
+
+struct PlanBuilder {
+    DensePlan* P;
+    const int* first;
+    void update(int k, int kw, int j0, int ncols, int rhs_panel) {  // ncols == 0: every tile I >= J >= j0
+        DensePlan::Update u;
+        u.k = k; u.kw = kw; u.rhs_panel = rhs_panel;
+        u.first_tile = (int)P->tiles.size();
+        const int T = P->T;
+        const int jend = ncols > 0 ? std::min(T, j0 + ncols) : T;
+        for (int J = j0; J < jend; J++)
+            for (int I = J; I < T; I++) {
+                if (J < first[I]) continue;
+                const int lo = std::max(k, std::max(first[I], first[J]));
+                if (lo >= k + kw) continue;
+                P->tiles.push_back(make_int2(I, J));
+                P->flop_structural += 2.0 * kDNB * kDNB * (double)((k + kw - lo) * kDNB);
+            }
+        u.n_tiles = (int)P->tiles.size() - u.first_tile;
+        u.n_rhs_blocks = rhs_panel >= 0 ? ((T - (rhs_panel + 1)) * kDNB + 255) / 256 : 0;
+        P->updates.push_back(u);
     }
+    void chain(int k, int g) {
+        const int T = P->T;
+        for (int p = 0; p < g && k + p < T; p++) {
+            const int c = k + p;
+            if (p > 0) update(k, p, c, 1, c - 1);
+            P->flop_structural += (double)kDNB * kDNB * kDNB / 3.0;  // diagonal factor
+            for (int i = c + 1; i < T; i++)
+                if (first[i] <= c) P->flop_structural += 2.0 * kDNB * kDNB * kDNB;  // panel solve as a GEMM with Linv
+        }
+    }
+};
+
+}  // namespace
+
+void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DensePlan* plan) {
+    static const bool no_lookahead = getenv("SWARMORB_DENSE_NO_LOOKAHEAD") != nullptr;
+    static const int g_env = getenv("SWARMORB_DENSE_GROUP") ? atoi(getenv("SWARMORB_DENSE_GROUP")) : 0;
+    plan->T = T;
+    plan->lookahead = has_side_stream && T >= 32 && T <= kDenseMaxPanels && !no_lookahead;
+    plan->G = g_env >= 1 && g_env <= 8 ? g_env : (plan->lookahead ? kDenseGroup : 1);
+    plan->updates.clear();
+    plan->tiles.clear();
+    plan->flop_structural = 0.0;
+    const double n = (double)T * kDNB;
+    plan->flop_dense = n * n * n / 3.0 + 2.0 * n * n;
+    plan->nnz_tiles = 0;
+    for (int I = 0; I < T; I++) plan->nnz_tiles += I - tile_first[I] + 1;
+    PlanBuilder B{plan, tile_first};
+    const int G = plan->G;
+    B.chain(0, G);
+    for (int k = 0; k + G < T; k += G) {
+        const int j0 = k + G, rem2 = T - j0;
+        if (plan->lookahead && rem2 >= G + 2) {
+            B.update(k, G, j0, G, j0 - 1);  // A: the next group's block columns (+ right-hand side)
+            B.update(k, G, j0 + G, 0, -1);  // B: the rest
+        } else {
+            B.update(k, G, j0, 0, j0 - 1);
+        }
+        B.chain(j0, G);
+    }
+    plan->flop_structural += 2.0 * 2.0 * kDNB * kDNB * (double)plan->nnz_tiles;  // forward + backward substitution
 }
 
-// Look-ahead across launches: the K = 96 g update of a group is split into the g block columns the next group needs
-// (A) and the rest (B).  As soon as A is done the side stream runs the next group's serial chain (diagonal factors,
-// panel solves, column updates) while the main stream is still busy with B - the chain hides behind the GEMM work
-// for as long as the trailing matrix is large.  Only for T >= 32 panels: below that the cross-stream waits (~10 us
-// each) cost more than the overlap returns (measured on GBA-1, 19 panels).
+namespace {
+
+struct PlanCursor {
+    const BaDev& d;
+    size_t next = 0;
+    void update(hipStream_t s) {
+        const DensePlan::Update& u = d.plan->updates[next++];
+        const int blocks = u.n_tiles + u.n_rhs_blocks;
+        if (blocks > 0)
+            hipLaunchKernelGGL(dense_update_kernel, dim3(blocks), dim3(256), 0, s, d, u.k, u.kw, d.plan_tiles + u.first_tile,
+                               u.n_tiles, u.rhs_panel);
+    }
+    void chain(int k, int g, hipStream_t s) {
+        const int T = d.plan->T;
+        for (int p = 0; p < g && k + p < T; p++) {
+            const int c = k + p, rem = T - c;
+            if (p > 0) update(s);
+            hipLaunchKernelGGL(dense_potrf_kernel, dim3(1), dim3(256), 0, s, d, c);
+            hipLaunchKernelGGL(dense_panel_kernel, dim3(1 + (rem - 1)), dim3(256), 0, s, d, c);
+        }
+    }
+};
+
+}  // namespace
+
+// Look-ahead only for T >= 32 panels: below that the cross-stream waits (~10 us each) cost more than the overlap
+// returns (measured on GBA-1, 19 panels).
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s) {
-    const int T = d.ldS / kDNB;
+    const DensePlan& P = *d.plan;
+    const int T = P.T, G = P.G;
     hipStream_t side = d.dense_side;
     hipEvent_t* ev = d.dense_events;
-    static const bool no_lookahead = getenv("SWARMORB_DENSE_NO_LOOKAHEAD") != nullptr;
-    const bool lookahead = side && ev && T >= 32 && T <= kDenseMaxPanels && !no_lookahead;
-    static const int g_env = getenv("SWARMORB_DENSE_GROUP") ? atoi(getenv("SWARMORB_DENSE_GROUP")) : 0;
-    const int G = g_env >= 1 && g_env <= 8 ? g_env : (lookahead ? kDenseGroup : 1);
+    PlanCursor C{d};
     hipLaunchKernelGGL(dense_begin_kernel, dim3(1), dim3(1), 0, s, d);
-    dense_chain(d, 0, G, s);
+    C.chain(0, G, s);
     int n_ev = 0;
     for (int k = 0; k + G < T; k += G) {
         const int j0 = k + G, rem2 = T - j0;  // block rows that take the group's update
-        const int rhs_blocks = (rem2 * kDNB + 255) / 256;
-        if (lookahead && rem2 >= G + 2) {
-            int n_a = 0;
-            for (int c = 0; c < G; c++) n_a += rem2 - c;
-            const int n_b = (rem2 - G) * (rem2 - G + 1) / 2;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(n_a + rhs_blocks), dim3(256), 0, s, d, k, G, j0, G, n_a, j0 - 1);
+        if (P.lookahead && rem2 >= G + 2) {
+            C.update(s);
             (void)hipEventRecord(ev[n_ev], s);
             (void)hipStreamWaitEvent(side, ev[n_ev], 0);
             n_ev++;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(n_b), dim3(256), 0, s, d, k, G, j0 + G, 0, n_b, -1);
-            dense_chain(d, j0, G, side);
+            C.update(s);
+            C.chain(j0, G, side);
             (void)hipEventRecord(ev[n_ev], side);
             (void)hipStreamWaitEvent(s, ev[n_ev], 0);
             n_ev++;
         } else {
-            const int n_tiles = rem2 * (rem2 + 1) / 2;
-            hipLaunchKernelGGL(dense_update_kernel, dim3(n_tiles + rhs_blocks), dim3(256), 0, s, d, k, G, j0, 0, n_tiles,
-                               j0 - 1);
-            dense_chain(d, j0, G, s);
+            C.update(s);
+            C.chain(j0, G, s);
         }
     }
     for (int k = T - 1; k >= 0; k--) {

@@ -15,6 +15,8 @@
 // deterministic run to run.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <stdint.h>
 
 namespace so {
@@ -86,6 +88,11 @@ struct BaDev {
     double* dense_x;   //                     solution staging (ldS doubles)
     hipStream_t dense_side;     // host-side handles of the blocked path's look-ahead (not read by kernels)
     hipEvent_t* dense_events;   // 1 + 2 * kDenseMaxPanels events
+    // block-skyline structure of S on the blocked path (96-row tiles): tile (I, J), J <= I, can be nonzero in S and
+    // in its Cholesky factor only for J >= tile_first[I] (row envelope; Cholesky fill stays inside it)
+    const int* tile_first;      // ldS / 96 entries (device)
+    const int2* plan_tiles;     // (I, J) tiles of every trailing-update launch, in launch order (device)
+    const struct DensePlan* plan;  // host side of the same (not read by kernels)
     double* partial;  // reduction partials (chi2 | scale) + flags
     int robust;
     double huber_delta;
@@ -120,7 +127,20 @@ constexpr int kBaPairsMinFree = 80;       // from here on the Schur gather walks
                                           // (window wall time, edge_tab vs pair lists: 44 keyframes 3.2 vs 3.7 ms, 64: 6.1 vs 6.3,
                                           // 96: 9.2 vs 8.9, 128: 12.8 vs 11.7)
 constexpr int kBaMfmaSolverMinFree = 4;   // below: the register-resident look-ahead solver is as fast (measured 3..16)
-constexpr int kDenseMaxPanels = 128;  // 12288 / 96
+constexpr int kDenseMaxPanels = 512;  // 49152 / 96: 8192 free keyframes, 19 GB of FP64 when stored densely
+// Launch plan of the blocked solver for one problem structure: which tiles each trailing update touches.  Built on the
+// host once per so_bundle_adjust call (the structure does not change between LM trials).
+struct DensePlan {
+    struct Update { int k, kw, rhs_panel, first_tile, n_tiles, n_rhs_blocks; };
+    int T = 0, G = 1;
+    bool lookahead = false;
+    std::vector<Update> updates;  // in the order launch_ba_dense_solve issues them
+    std::vector<int2> tiles;
+    double flop_structural = 0.0; // FP64 flop of the factorisation + substitutions over nonzero tiles only
+    double flop_dense = 0.0;      // n^3 / 3 + 2 n^2
+    long long nnz_tiles = 0;      // tiles inside the envelope (lower triangle incl. diagonal)
+};
+void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DensePlan* plan);
 bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solves (4..29 free keyframes: tiles in LDS; 30..43: tiles in registers); false if neither applies
 void launch_ba_dense_pad(const BaDev& d, hipStream_t s);    // once per problem: identity padding up to ldS
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s);  // per trial, in place of the single-workgroup solve  // fills edge_tab (memset to -1 beforehand)

@@ -64,6 +64,7 @@ struct MatchQueryW {
 // SearchByProjection(cur, last) (code/src/ORBmatcher.cc:1242-1276) or Frame::isInFrustum + the window of
 // SearchByProjection(F, vpMapPoints) (code/src/Frame.cc:316-375, ORBmatcher.cc:52-70).  Same float / double
 // operation sequence as frame_frustum_kernel and the CPU oracle.
+constexpr int kTrackMaxCandBits = 4096, kTrackMaxQueryBits = 16384;
 struct TrackQuerySrc {
     // map-point table (so_map), indexed by slot
     const float* Xw;
@@ -72,7 +73,9 @@ struct TrackQuerySrc {
     const float* min_dist;
     const uint4* desc;
     // per query
-    const int32_t* slot;         // map slot, < 0: no map point (null = the query index itself)
+    const int32_t* slot;         // map slot, < 0: no map point (null = slot_base + query index); may point into pinned
+                                 // host memory (one read per wave)
+    int slot_base;
     const uint8_t* skip;         // local-map search: 1 = not searched (already matched in this frame / bad); may be null
     const int8_t* last_octave;   // last-frame search: lastFrame.mvKeys[i].octave
     uint8_t* in_view_out;        // local-map search: mbTrackInView per query (may be null)
@@ -84,6 +87,13 @@ struct TrackQuerySrc {
     float th;
     float cos_limit, log_scale_factor;  // local-map search
     int n_slots;                 // size of the table (slots beyond it are treated as "no map point")
+    // Small gates travel in the kernel arguments instead of a staged buffer (no copy launch in front of the search):
+    // bit c of excl_bits = candidate POSITION c is not eligible (bound on entry / taken); bit i of skip_bits = query i
+    // is not searched.  use_bits selects them over `skip` and MatchFrameDev::limit.
+    int use_bits;
+    int keys_soa;                // 1: K-lists are written [k][query] (the host reads ranks 0 and 1 as two streams)
+    uint32_t excl_bits[kTrackMaxCandBits / 32];
+    uint32_t skip_bits[kTrackMaxQueryBits / 32];
 };
 
 void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_t s);

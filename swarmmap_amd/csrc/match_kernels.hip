@@ -134,7 +134,7 @@ __device__ __forceinline__ double track_log(double x) {  // == frame_log (frame_
 __device__ __forceinline__ MatchQuery track_query_last(const TrackQuerySrc& T, int qi, int& slot) {
     MatchQuery Q = MatchQuery{};
     Q.max_dist = 256;
-    slot = T.slot ? T.slot[qi] : qi;
+    slot = T.slot ? T.slot[qi] : T.slot_base + qi;
     if (slot < 0 || slot >= T.n_slots) return Q;
     const int oct = T.last_octave[qi];
     if (oct < 0 || oct >= T.nlevels) return Q;
@@ -162,9 +162,13 @@ __device__ __forceinline__ MatchQuery track_query_last(const TrackQuerySrc& T, i
 __device__ __forceinline__ MatchQuery track_query_local(const TrackQuerySrc& T, int qi, int& slot) {
     MatchQuery Q = MatchQuery{};
     Q.max_dist = 256;
-    slot = T.slot ? T.slot[qi] : qi;
+    slot = T.slot ? T.slot[qi] : T.slot_base + qi;
     if (slot < 0 || slot >= T.n_slots) return Q;
-    if (T.skip && T.skip[qi]) return Q;
+    if (T.use_bits) {
+        if ((T.skip_bits[qi >> 5] >> (qi & 31)) & 1u) return Q;
+    } else if (T.skip && T.skip[qi]) {
+        return Q;
+    }
     const float* Tc = T.Tcw;
     float Ow[3];
 #pragma unroll
@@ -217,8 +221,11 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
                                                            int q_first) {
     __shared__ uint32_t s_keys[4][kListCap];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int qi = blockIdx.x * 4 + w;
+    const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);  // wave-uniform: per-query data through scalar loads
     if (qi >= nq) return;
+    const bool soa = MODE >= 2 && T.keys_soa;
+    const size_t kq = soa ? (size_t)nq : 1, kk = soa ? 1 : (size_t)K;  // key (qi, k) lives at qi * kk + k * kq
+    const bool bits = MODE >= 2 && T.use_bits;
     MatchQuery Q;
     int slot = -1;
     if (MODE == 1) {
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
     }
     if (!Q.active) {
         if (lane == 0) out_count[qi] = 0;
-        for (int k = lane; k < K; k += 64) out_keys[(size_t)qi * K + k] = 0xFFFFFFFFu;
+        for (int k = lane; k < K; k += 64) out_keys[(size_t)qi * kk + k * kq] = 0xFFFFFFFFu;
         return;
     }
     const uint4* qsrc = MODE >= 2 ? T.desc + 2 * (size_t)slot : qdesc + 2 * (size_t)qi;
@@ -256,7 +263,11 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
         if (ok) {
             dist = hamming256(F.desc[2 * c], F.desc[2 * c + 1], qd0, qd1);
             if (dist > Q.max_dist) ok = false;
-            if (F.limit && !(dist < F.limit[c])) ok = false;
+            if (bits) {
+                if ((T.excl_bits[c >> 5] >> (c & 31)) & 1u) ok = false;
+            } else if (F.limit && !(dist < F.limit[c])) {
+                ok = false;
+            }
         }
         const unsigned long long mask = __ballot(ok);
         if (mask) {
@@ -276,9 +287,9 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
                 if ((k == 0 || key > prev) && key < cur) cur = key;
             }
             cur = wave_min_u32(cur);
-            if (lane == 0) out_keys[(size_t)qi * K + k] = cur;
+            if (lane == 0) out_keys[(size_t)qi * kk + k * kq] = cur;
             if (cur == 0xFFFFFFFFu) {
-                for (int k2 = k + 1 + lane; k2 < K; k2 += 64) out_keys[(size_t)qi * K + k2] = 0xFFFFFFFFu;
+                for (int k2 = k + 1 + lane; k2 < K; k2 += 64) out_keys[(size_t)qi * kk + k2 * kq] = 0xFFFFFFFFu;
                 break;
             }
             prev = cur;
@@ -292,17 +303,18 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
                 const int c = base + lane;
                 if (c < hi && pair_pred(F, Q, W, c, check_levels)) {
                     const int dist = hamming256(F.desc[2 * c], F.desc[2 * c + 1], qd0, qd1);
-                    if (dist <= Q.max_dist && (!F.limit || dist < F.limit[c])) {
+                    const bool gate_ok = bits ? !((T.excl_bits[c >> 5] >> (c & 31)) & 1u) : (!F.limit || dist < F.limit[c]);
+                    if (dist <= Q.max_dist && gate_ok) {
                         const uint32_t key = make_key(Q, dist, c);
                         if ((k == 0 || key > prev) && key < cur) cur = key;
                     }
                 }
             }
             cur = wave_min_u32(cur);
-            if (lane == 0) out_keys[(size_t)qi * K + k] = cur;
+            if (lane == 0) out_keys[(size_t)qi * kk + k * kq] = cur;
             prev = cur;
             if (cur == 0xFFFFFFFFu) {
-                for (int k2 = k + 1 + lane; k2 < K; k2 += 64) out_keys[(size_t)qi * K + k2] = 0xFFFFFFFFu;
+                for (int k2 = k + 1 + lane; k2 < K; k2 += 64) out_keys[(size_t)qi * kk + k2 * kq] = 0xFFFFFFFFu;
                 break;
             }
         }

@@ -1448,20 +1448,36 @@ TrackQuerySrc track_src(const so_matcher* m, const so_dframe* cur, const so_map*
     return T;
 }
 
-// Stage [limit (if any) | slots | skip] with one copy kernel and run the fused query + top-K launch.
-int run_topk_track(so_matcher* m, TrackQuerySrc T, int mode, int nq, int K, const int32_t* slots, const uint8_t* skip) {
+// Gates of a tracking search.  Small problems (<= 4096 candidates, <= 16384 queries: every tracking frame) carry them
+// as bit masks inside the kernel arguments and read the per-query map slots straight from pinned host memory: ONE
+// launch per search, nothing staged.  Larger ones stage [limit | slots | skip] with a copy kernel first.
+struct TrackGates {
+    const int32_t* slots;   // per query (host), or null: slot_base + query index
+    int slot_base;
+    const uint8_t* skip;    // per query (host), may be null
+    const uint8_t* excluded;  // per KEYPOINT INDEX (host), may be null
+};
+
+void set_bits_from_excluded(const so_matcher* m, const uint8_t* excluded_by_idx, const std::vector<int32_t>* limit_by_idx,
+                            TrackQuerySrc& T) {
+    memset(T.excl_bits, 0, sizeof(T.excl_bits));
+    const int nc = m->n_cand;
+    for (int r = 0; r < nc; r++) {
+        const int i = m->perm[(size_t)r];
+        const bool ex = limit_by_idx ? (*limit_by_idx)[(size_t)i] == 0 : (excluded_by_idx && excluded_by_idx[i]);
+        if (ex) T.excl_bits[r >> 5] |= 1u << (r & 31);
+    }
+}
+
+int run_topk_track(so_matcher* m, TrackQuerySrc& T, int mode, int nq, int K, const TrackGates& G) {
     int rc;
+    const bool bits = m->n_cand <= kTrackMaxCandBits && nq <= kTrackMaxQueryBits;
     const size_t off_slot = m->frame_end;
     const size_t off_skip = align256(off_slot + sizeof(int32_t) * (size_t)nq);
     const size_t end = align256(off_skip + (size_t)nq);
     if ((rc = m->h_in.ensure_keep(end + 256, m->frame_end))) return rc;
     uint8_t* h = (uint8_t*)m->h_in.p;
-    if (slots) memcpy(h + off_slot, slots, sizeof(int32_t) * (size_t)nq);
-    if (skip) memcpy(h + off_skip, skip, (size_t)nq);
-    if (m->d_in.cap < end) {
-        if ((rc = m->d_in.ensure(m->h_in.cap))) return rc;
-        m->dirty_from = 0;
-    }
+    if (G.slots) memcpy(h + off_slot, G.slots, sizeof(int32_t) * (size_t)nq);
     m->off_slot = off_slot;
     m->off_skip = off_skip;
     m->track_end = end;
@@ -1469,19 +1485,40 @@ int run_topk_track(so_matcher* m, TrackQuerySrc T, int mode, int nq, int K, cons
     if ((rc = m->h_out.ensure(keys_bytes + sizeof(int32_t) * (size_t)nq))) return rc;
     hipStream_t s = m->stream;
     const auto t0 = std::chrono::steady_clock::now();
-    // one contiguous span covers whatever is new: [limit gate (if rewritten) | slots | skip]
-    size_t from = SIZE_MAX, to = 0;
-    if (m->has_limit && m->dirty_from < m->frame_end) { from = m->dirty_from; to = m->frame_end; }
-    if (slots) { from = std::min(from, off_slot); to = off_slot + sizeof(int32_t) * (size_t)nq; }
-    if (skip) { from = std::min(from, off_skip); to = off_skip + (size_t)nq; }
-    if (to > from) {
-        const size_t f16 = from & ~(size_t)15;
-        launch_stage_in((uint8_t*)m->d_in.p + f16, h + f16, to - f16, s);
+    size_t staged = 0;
+    T.slot_base = G.slot_base;
+    T.keys_soa = 1;
+    T.use_bits = bits ? 1 : 0;
+    if (bits) {
+        set_bits_from_excluded(m, G.excluded, nullptr, T);
+        memset(T.skip_bits, 0, sizeof(uint32_t) * (size_t)((nq + 31) / 32));
+        if (G.skip)
+            for (int i = 0; i < nq; i++)
+                if (G.skip[i]) T.skip_bits[i >> 5] |= 1u << (i & 31);
+        T.slot = G.slots ? reinterpret_cast<const int32_t*>(h + off_slot) : nullptr;  // pinned: the kernel reads it in place
+        T.skip = nullptr;
+        m->has_limit = false;
+    } else {
+        if (G.skip) memcpy(h + off_skip, G.skip, (size_t)nq);
+        if (m->d_in.cap < end) {
+            if ((rc = m->d_in.ensure(m->h_in.cap))) return rc;
+            m->dirty_from = 0;
+        }
+        // one contiguous span covers whatever is new: [limit gate (if rewritten) | slots | skip]
+        size_t from = SIZE_MAX, to = 0;
+        if (m->has_limit && m->dirty_from < m->frame_end) { from = m->dirty_from; to = m->frame_end; }
+        if (G.slots) { from = std::min(from, off_slot); to = off_slot + sizeof(int32_t) * (size_t)nq; }
+        if (G.skip) { from = std::min(from, off_skip); to = off_skip + (size_t)nq; }
+        if (to > from) {
+            const size_t f16 = from & ~(size_t)15;
+            launch_stage_in((uint8_t*)m->d_in.p + f16, h + f16, to - f16, s);
+            staged = to - from;
+        }
+        m->dirty_from = SIZE_MAX;
+        const uint8_t* d = (const uint8_t*)m->d_in.p;
+        T.slot = G.slots ? reinterpret_cast<const int32_t*>(d + off_slot) : nullptr;
+        T.skip = G.skip ? d + off_skip : nullptr;
     }
-    m->dirty_from = SIZE_MAX;
-    const uint8_t* d = (const uint8_t*)m->d_in.p;
-    T.slot = slots ? reinterpret_cast<const int32_t*>(d + off_slot) : nullptr;
-    T.skip = skip ? d + off_skip : nullptr;
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
     launch_topk_track(frame_dev(m), T, mode, 0, nq, K, (uint32_t*)m->h_out.dev,
                       (int32_t*)((uint8_t*)m->h_out.dev + keys_bytes), s);
@@ -1493,7 +1530,7 @@ int run_topk_track(so_matcher* m, TrackQuerySrc T, int mode, int nq, int K, cons
     m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
     m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
     m->stat[2] += 1.0;
-    m->stat[3] += (double)(to > from ? to - from : 0);
+    m->stat[3] += (double)staged;
     m->h_keys.p = m->h_out.p;
     m->h_count.p = (uint8_t*)m->h_out.p + keys_bytes;
     float ms = 0.f;
@@ -1503,20 +1540,22 @@ int run_topk_track(so_matcher* m, TrackQuerySrc T, int mode, int nq, int K, cons
 
 // Exact top-K of ONE tracking query under a dynamic per-keypoint gate (see rerun_single): the query is rebuilt on
 // the device from the same inputs, only the gate is re-sent.
-int rerun_track(so_matcher* m, TrackQuerySrc T, int mode, int qi, bool has_slots, bool has_skip,
-                const std::vector<int32_t>& limit_by_idx, int K, Entry* out, int* n_found) {
-    int rc = upload_limit_only(m, limit_by_idx);
-    if (rc) return rc;
+int rerun_track(so_matcher* m, TrackQuerySrc T, int mode, int qi, const std::vector<int32_t>& limit_by_idx, int K,
+                Entry* out, int* n_found) {
+    int rc;
     if ((rc = m->h_rout.ensure(512))) return rc;
     hipStream_t s = m->stream;
-    const size_t f16 = m->dirty_from & ~(size_t)15;
-    if (m->dirty_from < m->frame_end)
-        launch_stage_in((uint8_t*)m->d_in.p + f16, (const uint8_t*)m->h_in.p + f16, m->frame_end - f16, s);
-    m->dirty_from = SIZE_MAX;
-    const uint8_t* d = (const uint8_t*)m->d_in.p;
-    T.slot = has_slots ? reinterpret_cast<const int32_t*>(d + m->off_slot) : nullptr;
-    T.skip = has_skip ? d + m->off_skip : nullptr;
+    if (T.use_bits) {
+        set_bits_from_excluded(m, nullptr, &limit_by_idx, T);
+    } else {
+        if ((rc = upload_limit_only(m, limit_by_idx))) return rc;
+        const size_t f16 = m->dirty_from & ~(size_t)15;
+        if (m->dirty_from < m->frame_end)
+            launch_stage_in((uint8_t*)m->d_in.p + f16, (const uint8_t*)m->h_in.p + f16, m->frame_end - f16, s);
+        m->dirty_from = SIZE_MAX;
+    }
     T.in_view_out = nullptr;
+    T.keys_soa = 0;
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
     launch_topk_track(frame_dev(m), T, mode, qi, 1, K, (uint32_t*)m->h_rout.dev, (int32_t*)((uint8_t*)m->h_rout.dev + 256), s);
     if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
@@ -1570,7 +1609,8 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
     if (rc) return rc;
     TrackQuerySrc T = track_src(m, cur, map, Tcw12, th);
     T.last_octave = last->d_octave;
-    if ((rc = run_topk_track(m, T, 2, n_last, K, last_slot, nullptr))) return rc;
+    const TrackGates G{last_slot, 0, nullptr, cur_excluded};
+    if ((rc = run_topk_track(m, T, 2, n_last, K, G))) return rc;
     const uint32_t* keys = (const uint32_t*)m->h_keys.p;
     const int32_t* cnt = (const int32_t*)m->h_count.p;
     auto has_obs = [&](int i) { return !slot_has_obs || slot_has_obs[i]; };
@@ -1583,7 +1623,7 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
         Entry e[1];
         int found = 0, walked = 0;
         for (; walked < K && found < 1; walked++) {
-            const uint32_t key = keys[(size_t)i * K + walked];
+            const uint32_t key = keys[(size_t)walked * n_last + i];  // [k][query]
             if (key == 0xFFFFFFFFu) break;
             const int idx = m->perm[(size_t)(key & 0xFFFFu)];
             if (kp_to_last[idx] >= 0 && has_obs(kp_to_last[idx])) continue;
@@ -1595,7 +1635,7 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
             gate.assign((size_t)cur->n, INT_MAX);
             for (int k = 0; k < cur->n; k++)
                 if ((cur_excluded && cur_excluded[k]) || (kp_to_last[k] >= 0 && has_obs(kp_to_last[k]))) gate[(size_t)k] = 0;
-            if ((rc = rerun_track(m, T, 2, i, true, false, gate, 1, e, &found))) return rc;
+            if ((rc = rerun_track(m, T, 2, i, gate, 1, e, &found))) return rc;
         }
         if (found == 0) continue;
         if (e[0].dist <= TH_HIGH) {
@@ -1626,9 +1666,10 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
 // cos_limit) (code/src/Frame.cc:316-375) for every local map point that is not already matched in this frame, then
 // ORBmatcher::SearchByProjection(F, vpMapPoints, th) (code/src/ORBmatcher.cc:44-121)
 int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_map* map,
-                              const float* Tcw12, int32_t n_local, const int32_t* local_slot, const uint8_t* skip,
-                              const uint8_t* slot_has_obs, float th, float nn_ratio, float viewing_cos_limit,
-                              float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local, int32_t* nmatches) {
+                              const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
+                              const uint8_t* skip, const uint8_t* slot_has_obs, float th, float nn_ratio,
+                              float viewing_cos_limit, float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local,
+                              int32_t* nmatches) {
     if (m) (void)take_reuse(m);
     if (!track_args_ok(m, cur, map, Tcw12) || n_local < 0 || !kp_to_local || !nmatches) return SO_ERR_INVALID_ARG;
     static const bool trace = getenv("SWARMORB_MATCH_TRACE") != nullptr;
@@ -1654,7 +1695,8 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
     if ((rc = m->h_out.ensure(view_off + (size_t)n_local))) return rc;
     T.in_view_out = (uint8_t*)m->h_out.dev + view_off;
     const auto tt1 = std::chrono::steady_clock::now();
-    if ((rc = run_topk_track(m, T, 3, n_local, K, local_slot, skip))) return rc;
+    const TrackGates G{local_slot, local_slot ? 0 : first_slot, skip, cur_excluded};
+    if ((rc = run_topk_track(m, T, 3, n_local, K, G))) return rc;
     const auto tt2 = std::chrono::steady_clock::now();
     const uint8_t* view = (const uint8_t*)m->h_out.p + view_off;
     if (in_view) memcpy(in_view, view, (size_t)n_local);
@@ -1669,7 +1711,7 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
         Entry e[2];
         int found = 0, walked = 0;
         for (; walked < K && found < 2; walked++) {
-            const uint32_t key = keys[(size_t)i * K + walked];
+            const uint32_t key = keys[(size_t)walked * n_local + i];  // [k][query]
             if (key == 0xFFFFFFFFu) break;
             const int idx = m->perm[(size_t)(key & 0xFFFFu)];
             if (kp_to_local[idx] >= 0 && has_obs(kp_to_local[idx])) continue;  // ORBmatcher.cc:83-85
@@ -1681,7 +1723,7 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
             gate.assign((size_t)cur->n, INT_MAX);
             for (int k = 0; k < cur->n; k++)
                 if ((cur_excluded && cur_excluded[k]) || (kp_to_local[k] >= 0 && has_obs(kp_to_local[k]))) gate[(size_t)k] = 0;
-            if ((rc = rerun_track(m, T, 3, i, local_slot != nullptr, skip != nullptr, gate, 2, e, &found))) return rc;
+            if ((rc = rerun_track(m, T, 3, i, gate, 2, e, &found))) return rc;
         }
         if (found == 0) continue;
         const int bestDist = e[0].dist, bestIdx = e[0].idx, bestLevel = cur->octave[(size_t)bestIdx];

@@ -35,7 +35,7 @@ def _bind(lib):
     lib.so_search_by_projection_lastframe_dframe.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, f, C.c_int,
                                                              vp, ip]
     lib.so_track_search_last_frame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, f, C.c_int, vp, ip]
-    lib.so_track_search_local_map.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, f, f, f, f, vp, vp, ip]
+    lib.so_track_search_local_map.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, f, f, f, f, vp, vp, ip]
     lib._dframe_bound = True
 
 
@@ -153,7 +153,7 @@ def search_last_frame(matcher, cur, last, dmap, Tcw, last_slot, th, excluded=Non
 
 
 def search_local_map(matcher, cur, dmap, Tcw, n_local, th, cos_limit, log_scale_factor, local_slot=None, skip=None,
-                     excluded=None, has_obs=None):
+                     excluded=None, has_obs=None, first_slot=0):
     """so_track_search_local_map: (nmatches, kp_to_local, in_view)."""
     lib = matcher._lib
     _bind(lib)
@@ -166,7 +166,7 @@ def search_local_map(matcher, cur, dmap, Tcw, n_local, th, cos_limit, log_scale_
     out = np.full(cur.n, -1, np.int32)
     nm = C.c_int32(0)
     _lib.check(lib.so_track_search_local_map(matcher._h, cur._h, _vp(ex), dmap._h, _vp(T), int(n_local), _vp(slot),
-                                             _vp(sk), _vp(ho), float(th), float(matcher.mfNNratio), float(cos_limit),
+                                             int(first_slot), _vp(sk), _vp(ho), float(th), float(matcher.mfNNratio), float(cos_limit),
                                              float(log_scale_factor), _vp(in_view), _vp(out), C.byref(nm)))
     return nm.value, out, in_view[:n_local]
 

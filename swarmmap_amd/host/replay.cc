@@ -521,18 +521,13 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
                 r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
                 if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:1117-1124)
             }
-            const int32_t* slots = nullptr;
-            if (first > 0) {
-                r->local_slot.resize((size_t)n_local);
-                for (int i = 0; i < n_local; i++) r->local_slot[(size_t)i] = first + i;
-                slots = r->local_slot.data();
-            }
             r->k2m.resize((size_t)n);
             std::vector<uint8_t>& view = r->new_desc;  // scratch
             view.resize(std::max(view.size(), (size_t)n_local));
             int32_t nmm = 0;
-            if (so_track_search_local_map(r->matcher, dcur, r->excluded.data(), r->map, Ta, n_local, slots, r->skip.data(),
-                                          nullptr, 1.0f, 0.8f, 0.5f, r->log_sf, view.data(), r->k2m.data(), &nmm) != SO_OK)
+            if (so_track_search_local_map(r->matcher, dcur, r->excluded.data(), r->map, Ta, n_local, nullptr, first,
+                                          r->skip.data(), nullptr, 1.0f, 0.8f, 0.5f, r->log_sf, view.data(), r->k2m.data(),
+                                          &nmm) != SO_OK)
                 return fail(r, "so_track_search_local_map");
             so_matcher_last_kernel_ms(r->matcher, &kms);
             match_kernel += kms;

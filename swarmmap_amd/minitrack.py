@@ -57,9 +57,8 @@ class HipBackend:
 
     def search_local(self, Tcw, first, n_local, skip, excluded, th, log_sf):
         from . import dframe as dfm
-        slots = None if first == 0 else np.arange(first, first + n_local, dtype=np.int32)
         return dfm.search_local_map(self.m_map, self.frames[self.cur], self.map, Tcw, n_local, th, COS_LIMIT, log_sf,
-                                    local_slot=slots, skip=skip, excluded=excluded)
+                                    skip=skip, excluded=excluded, first_slot=first)
 
     def map_append(self, X, normal, max_d, min_d, desc):
         self.map.append(X, normal, max_d, min_d, desc)

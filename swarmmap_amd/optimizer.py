@@ -22,7 +22,8 @@ class SoBaInfo(C.Structure):
     _fields_ = [("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
                 ("iterations_stage1", C.c_int32), ("iterations_stage2", C.c_int32), ("lm_trials", C.c_int32),
                 ("aborted", C.c_int32), ("n_outliers", C.c_int32), ("gpu_ms", C.c_float), ("wall_ms", C.c_float),
-                ("solve_ms", C.c_float), ("n_solves", C.c_int32)]
+                ("solve_ms", C.c_float), ("n_solves", C.c_int32), ("solve_gflop_structural", C.c_double),
+                ("solve_gflop_dense", C.c_double), ("nnz_tiles", C.c_double)]
 
 
 def _vp(a):

@@ -253,7 +253,120 @@ def make_ba_problem(seed, n_free=8, n_fixed=10, n_points=800, size=EUROC, K=EURO
                 inv_sigma2=np.array(inv_s2, np.float32), gt_Tcw=Tcw_gt, gt_Xw=X, gt_outlier=np.array(is_out, bool))
 
 
+def make_multiagent_map(seed, n_agents=8, kfs_per_agent=187, n_points=120000, spacing=0.4, view_range=10.0, size=EUROC,
+                        K=EUROC_K, pixel_sigma=1.0, outlier_frac=0.05, pose_noise=(0.02, 0.5), point_noise=0.03):
+    """A merged multi-agent map for global bundle adjustment (BASELINE configs[4]) with the structure real SLAM maps
+    have: every agent drives its own street of a grid (half of them along x, half along y, forward-looking camera,
+    one keyframe every `spacing` metres), map points line the streets, a keyframe sees a point only inside the image
+    and within `view_range` metres, and a point keeps 3-10 of the keyframes that see it.  Covisibility is therefore
+    banded along each trajectory and the agents are linked only where their streets cross - unlike make_ba_problem,
+    whose cameras all look at one cloud (reduced camera system nearly dense).  Keyframes are numbered agent by agent
+    (the order a merged map has: mnId + 1e6 * mapId), only the very first one is fixed.  Same return layout as
+    make_ba_problem.  Vectorised: a 1500-keyframe / 120 k-point map takes a few seconds."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    w, h = size
+    fx, fy, cx, cy = K
+    na_x = (n_agents + 1) // 2      # agents 0 .. na_x-1 drive along x, the others along y
+    spacing = max(spacing, 45.0 / kfs_per_agent)
+    length = spacing * kfs_per_agent
+    D = max(0.53 * length, 2.4 * view_range)  # distance between parallel x-streets: out of each other's sight
+    dx = 1.5 * view_range                     # distance between parallel y-streets
+    centres, Rs, street = [], [], []
+    for a in range(n_agents):
+        t = spacing * np.arange(kfs_per_agent) + rng.normal(0, 0.03, kfs_per_agent)
+        lat = np.cumsum(rng.normal(0, 0.01, kfs_per_agent))  # slow lateral drift
+        hgt = rng.normal(0, 0.03, kfs_per_agent)
+        if a < na_x:     # x-street i at y = D i, x in [0, length]
+            org, fwd = np.array([0.0, D * a, 0.0]), np.array([1.0, 0.0, 0.0])
+        else:            # y-street j crosses the x-streets (j mod (na_x - 1)) and the next one
+            j = a - na_x
+            i0 = j % max(na_x - 1, 1)
+            org = np.array([0.2 * length + dx * j, D * i0 - 0.23 * length, 0.0])
+            fwd = np.array([0.0, 1.0, 0.0])
+        up = np.array([0.0, 0.0, 1.0])
+        right = np.cross(fwd, up)
+        c = org[None, :] + t[:, None] * fwd[None, :] + lat[:, None] * right[None, :] + hgt[:, None] * up[None, :]
+        base = np.stack([right, -up, fwd])  # camera axes (x right, y down, z forward) as rows: Rcw
+        for i in range(kfs_per_agent):
+            Rs.append(_rodrigues(rng.normal(0, 0.02, 3)) @ base)
+        centres.append(c)
+        street.append((org, fwd, right))
+    centres = np.concatenate(centres)
+    Rs = np.stack(Rs)
+    n_poses = len(centres)
+    ts = -np.einsum("nij,nj->ni", Rs, centres)
+    # points along the streets: lateral offset 1.5-4 m on either side, height -1.5..3 m
+    which = rng.integers(0, n_agents, n_points)
+    s_along = rng.uniform(-2.0, length + view_range * 0.5, n_points)
+    lateral = rng.uniform(1.5, 4.0, n_points) * rng.choice([-1.0, 1.0], n_points)
+    height = rng.uniform(-1.5, 3.0, n_points)
+    orgs = np.stack([st[0] for st in street]); fwds = np.stack([st[1] for st in street]); rights = np.stack([st[2] for st in street])
+    X = orgs[which] + s_along[:, None] * fwds[which] + lateral[:, None] * rights[which]
+    X[:, 2] += height
+    tree = cKDTree(X)
+    scale = 1.2 ** np.arange(8)
+    ev_pose, ev_pt, ev_uv, ev_z = [], [], [], []
+    for i in range(n_poses):
+        idx = np.asarray(tree.query_ball_point(centres[i], view_range), np.int64)
+        if len(idx) == 0:
+            continue
+        pc = X[idx] @ Rs[i].T + ts[i]
+        ok = pc[:, 2] > 0.5
+        u = fx * pc[:, 0] / np.where(ok, pc[:, 2], 1.0) + cx
+        v = fy * pc[:, 1] / np.where(ok, pc[:, 2], 1.0) + cy
+        ok &= (u > 20) & (u < w - 20) & (v > 20) & (v < h - 20)
+        sel = np.nonzero(ok)[0]
+        ev_pose.append(np.full(len(sel), i, np.int32)); ev_pt.append(idx[sel].astype(np.int32))
+        ev_uv.append(np.stack([u[sel], v[sel]], 1)); ev_z.append(pc[sel, 2])
+    ev_pose = np.concatenate(ev_pose); ev_pt = np.concatenate(ev_pt)
+    ev_uv = np.concatenate(ev_uv); ev_z = np.concatenate(ev_z)
+    # every point keeps a random 3-10 of its observations (at least 2, else it is dropped)
+    key = rng.random(len(ev_pt))
+    order = np.lexsort((key, ev_pt))
+    ev_pose, ev_pt, ev_uv, ev_z = ev_pose[order], ev_pt[order], ev_uv[order], ev_z[order]
+    start = np.searchsorted(ev_pt, np.arange(n_points))
+    count = np.diff(np.append(start, len(ev_pt)))
+    rank = np.arange(len(ev_pt)) - start[ev_pt]
+    cap = rng.integers(3, 11, n_points)
+    keep = (rank < cap[ev_pt]) & (count[ev_pt] >= 2)
+    ev_pose, ev_pt, ev_uv, ev_z = ev_pose[keep], ev_pt[keep], ev_uv[keep], ev_z[keep]
+    used = np.unique(ev_pt)
+    remap = np.full(n_points, -1, np.int64)
+    remap[used] = np.arange(len(used))
+    ev_pt = remap[ev_pt].astype(np.int32)
+    X = X[used]
+    # the reference iterates a std::map<KeyFrame*, ...>: observation order inside a point is arbitrary
+    shuffle = np.lexsort((rng.random(len(ev_pt)), ev_pt))
+    ev_pose, ev_pt, ev_uv, ev_z = ev_pose[shuffle], ev_pt[shuffle], ev_uv[shuffle], ev_z[shuffle]
+    octave = np.clip(np.floor(np.log(ev_z / 3.0) / np.log(1.2)), 0, 7).astype(int)
+    noise = rng.normal(0, pixel_sigma, (len(ev_pt), 2)) * scale[octave][:, None]
+    is_out = rng.random(len(ev_pt)) < outlier_frac
+    noise[is_out] = rng.uniform(-40, 40, (int(is_out.sum()), 2))
+    fixed = np.zeros(n_poses, np.uint8)
+    fixed[0] = 1
+    Tcw_gt = np.concatenate([Rs, ts[:, :, None]], 2).reshape(n_poses, 12)
+    Tcw0 = Tcw_gt.copy()
+    for i in range(1, n_poses):
+        dR = _rodrigues(rng.normal(0, np.deg2rad(pose_noise[1]), 3))
+        Tcw0[i] = np.hstack([dR @ Rs[i], (dR @ ts[i] + rng.normal(0, pose_noise[0], 3))[:, None]]).reshape(12)
+    X0 = X + rng.normal(0, point_noise, X.shape)
+    return dict(Tcw=Tcw0.astype(np.float32), fixed=fixed, intr=np.tile(np.array(K, np.float32), (n_poses, 1)),
+                Xw=X0.astype(np.float32), edge_pose=ev_pose.astype(np.int32), edge_point=ev_pt,
+                obs=(ev_uv + noise).astype(np.float32), inv_sigma2=(1.0 / scale[octave] ** 2).astype(np.float32),
+                gt_Tcw=Tcw_gt, gt_Xw=X, gt_outlier=is_out, agent_of_pose=np.repeat(np.arange(n_agents), kfs_per_agent))
+
+
+MULTIAGENT_CASES = {  # name: (agents, keyframes per agent, candidate points)
+    "GBA-1r": (4, 75, 30000), "GBA-2r": (8, 188, 120000), "GBA-4k": (8, 512, 330000),
+}
+
+
 def make_ba_case(name, seed=0, **kw):
+    if name in MULTIAGENT_CASES:
+        na, nk, npnt = MULTIAGENT_CASES[name]
+        return make_multiagent_map(seed, na, nk, npnt, **kw)
+
     nf, nx, npnt = BA_CASES[name]
     kw.setdefault("max_obs", "auto")  # ~6.5 observations per point -> the edge counts of SURVEY.md 8d
     return make_ba_problem(seed, nf, nx, npnt, **kw)

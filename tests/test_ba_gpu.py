@@ -51,11 +51,14 @@ def test_local_bundle_adjustment_matches_oracle(opt, oracle, name, seed):
     assert r["info"]["n_outliers"] >= 0.9 * p["gt_outlier"].sum()
 
 
-@pytest.mark.parametrize("n_free", [1, 2, 9, 20, 21, 24, 27, 30, 31, 43, 50])
+@pytest.mark.parametrize("n_free", [1, 2, 3, 4, 9, 20, 21, 24, 27, 29, 30, 31, 43, 44, 50, 79, 80])
 def test_every_reduced_system_solver_path(opt, oracle, n_free):
-    """The dense solve of the reduced camera system switches kernels with the number of free keyframes
-    (look-ahead wave teams <= 30, register-resident <= 43, global beyond): one window per path and boundary."""
-    p = synth.make_ba_problem(100 + n_free, n_free, 3, 500, max_obs="auto")
+    """The solve of the reduced camera system switches kernels with the number of free keyframes (launch_ba_solve,
+    ba_kernels.hip / ba_dense.hip): up to 3 the look-ahead register solver, 4-29 the single-workgroup MFMA solver with
+    its tiles in LDS, 30-43 its register-resident sibling, from 44 on the blocked multi-workgroup Cholesky; from 80 on
+    the Schur gather walks per-block pair lists instead of the edge table.  One window per path and on both sides of
+    every boundary (3|4, 29|30, 43|44, 79|80)."""
+    p = synth.make_ba_problem(100 + n_free, n_free, 3, 500 if n_free < 60 else 1500, max_obs="auto")
     r = opt.LocalBundleAdjustment(p)
     o = oracle.bundle_adjust(p)
     _compare(r, o)
@@ -93,6 +96,80 @@ def test_gba2_eight_agent_map_properties(opt):
     assert np.array_equal(r3["Tcw"], again["Tcw"]) and np.array_equal(r3["Xw"], again["Xw"])
     assert r6["info"]["n_outliers"] >= 0.9 * p["gt_outlier"].sum()
     assert (r6["outlier"].astype(bool) & p["gt_outlier"]).sum() >= 0.9 * p["gt_outlier"].sum()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_sparse_multiagent_map_matches_oracle(opt, oracle, seed):
+    """GBA-1r: four agents, 300 keyframes, street-grid map with range-limited visibility - the reduced camera system
+    is block-banded with a few inter-agent links, and the blocked solver only works on the tiles inside its block
+    skyline (LinearSolverEigen's structural-nonzero solve, linear_solver_eigen.h:147-232).  Against the oracle."""
+    p = synth.make_ba_case("GBA-1r", seed)
+    r = opt.BundleAdjustment(p, nIterations=10, bRobust=True)
+    o = oracle.bundle_adjust(p, its1=10, its2=0, robust=True, huber_delta=np.float32(np.sqrt(np.float32(5.99))))
+    _compare(r, o)
+    inf = r["info"]
+    assert 0 < inf["nnz_tiles"] < 19 * 20 / 2                       # the skyline is a strict subset of the triangle
+    assert inf["solve_gflop_structural"] < inf["solve_gflop_dense"]  # and zero tiles are not computed on
+
+
+def test_gba2r_eight_agent_sparse_map_properties(opt):
+    """GBA-2r (eight agents, 1503 free keyframes, ~110 k points, ~710 k edges) through size-independent properties:
+    chi2 falls with the iteration count, planted outliers are found, the run is deterministic, and most of the
+    dense triangle is never touched."""
+    p = synth.make_ba_case("GBA-2r", 1)
+    r3 = opt.BundleAdjustment(p, nIterations=3, bRobust=True)
+    r6 = opt.BundleAdjustment(p, nIterations=6, bRobust=True)
+    again = opt.BundleAdjustment(p, nIterations=3, bRobust=True)
+    assert r3["info"]["chi2_initial"] == r6["info"]["chi2_initial"]
+    assert r6["info"]["chi2_final"] < r3["info"]["chi2_final"] < 0.7 * r3["info"]["chi2_initial"]
+    assert np.array_equal(r3["Tcw"], again["Tcw"]) and np.array_equal(r3["Xw"], again["Xw"])
+    assert (r6["outlier"].astype(bool) & p["gt_outlier"]).sum() >= 0.9 * p["gt_outlier"].sum()
+    inf = r6["info"]
+    assert inf["nnz_tiles"] < 0.6 * 94 * 95 / 2 and inf["solve_gflop_structural"] < 0.5 * inf["solve_gflop_dense"]
+    free = p["fixed"] == 0
+    assert np.abs(r6["Tcw"][free] - p["gt_Tcw"][free]).max() < np.abs(p["Tcw"][free] - p["gt_Tcw"][free]).max()
+
+
+def test_map_beyond_the_old_2048_keyframe_limit(opt):
+    """2560 free keyframes (15360 unknowns, 160 panels): refused with SO_ERR_CAPACITY before the block-skyline
+    solver; properties as above."""
+    p = synth.make_multiagent_map(3, n_agents=8, kfs_per_agent=320, n_points=200000)
+    assert int((p["fixed"] == 0).sum()) > 2048
+    r = opt.BundleAdjustment(p, nIterations=4, bRobust=True)
+    inf = r["info"]
+    assert inf["chi2_final"] < 0.7 * inf["chi2_initial"] and inf["aborted"] == 0
+    assert (r["outlier"].astype(bool) & p["gt_outlier"]).sum() >= 0.85 * p["gt_outlier"].sum()
+    assert inf["solve_gflop_structural"] < 0.4 * inf["solve_gflop_dense"]
+
+
+def test_stop_flag_flipped_mid_flight(opt):
+    """pbStopFlag may flip at any time (LocalMapping::InsertKeyFrame / InterruptBA, code/src/LocalMapping.cc:118,
+    581-583; polled between LM iterations, optimization_algorithm_levenberg.cpp:149): a second thread sets it while a
+    GBA-1 solve is running - the call returns early, says so, and hands out the last accepted estimate."""
+    import threading
+    import time
+    p = synth.make_ba_case("GBA-1", 1)
+    full = opt.BundleAdjustment(p, nIterations=20, bRobust=True)
+    for delay in (0.002, 0.006):
+        stop = np.zeros(1, np.uint8)
+
+        def flip():
+            time.sleep(delay)
+            stop[0] = 1
+
+        th = threading.Thread(target=flip)
+        th.start()
+        r = opt.BundleAdjustment(p, nIterations=20, bRobust=True, pbStopFlag=stop)
+        th.join()
+        inf = r["info"]
+        assert inf["aborted"] == 1
+        assert inf["iterations_stage1"] < full["info"]["iterations_stage1"]
+        # whatever was accepted before the flag was seen is kept: chi2 of the output = the reported final chi2, which
+        # is no worse than the start and no better than the full run
+        assert full["info"]["chi2_final"] <= inf["chi2_final"] <= inf["chi2_initial"]
+        assert np.isfinite(r["Tcw"]).all() and np.isfinite(r["Xw"]).all()
+        if inf["iterations_stage1"] == 0:
+            assert np.array_equal(r["Xw"], p["Xw"])
 
 
 def test_noise_free_window_recovers_ground_truth(opt):
