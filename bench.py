@@ -164,7 +164,7 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
                     t_ += m_
                     if xchg is not None and a == 0 and (t_ - 1) % exchange_every == 0:
                         tx = time.perf_counter()
-                        xchg.exchange_and_match(rp.last_descriptors(), m1)
+                        xchg.tick(frame_handle=rp.last_dframe())  # slot filled from the frame's HBM descriptors
                         if timed:
                             acc_x["n_xchg"] += 1
                             acc_x["xchg_ms"] += (time.perf_counter() - tx) * 1e3
@@ -385,11 +385,11 @@ def main():
     nfeatures = 1000 if euroc else 2000
     A = max(1, args.agents_per_gpu)
     lba_window = synth.make_ba_case("LBA-M", seed=100 + rank)
-    m1 = swarmmap_amd.ORBmatcher(0.8, True, device=dev) if distributed else None
+    m1 = None
     xchg = None
-    if distributed:
-        from swarmmap_amd.parallel import KeyframeExchange
-        xchg = KeyframeExchange(slot_keypoints=nfeatures + 24, device=dev)
+    if distributed:  # RCCL all-gather + matching behind the C ABI (so_exchange_*); torch.distributed only carries the id
+        from swarmmap_amd.exchange import DeviceExchange
+        xchg = DeviceExchange.from_process_group(dev, nfeatures + 24)
 
     dt, st, n_cand, frames, _ = run_stream(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
                                            lba_window, barrier, A, xchg, args.exchange_every, m1)
@@ -472,9 +472,11 @@ def main():
             out["configs"] = cfgs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, K, dist, nfeatures, lba_window, size)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # C-side stdout (RCCL's version banner) goes out first: the JSON line is the last line
         print(json.dumps(out), flush=True)
-    if m1 is not None:
-        m1.close()
+    if xchg is not None:
+        xchg.close()
     if distributed:
         torch.distributed.destroy_process_group()
 

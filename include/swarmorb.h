@@ -407,6 +407,34 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
                               int32_t* nmatches);
 
 /* ------------------------------------------------------------------------------------------------
+ * Cross-agent keyframe exchange — one agent per GPU, RCCL all-gather over xGMI.  Replaces, for agents
+ * sharded across the GPUs of a node, the server-side candidate query AgentMediator::CheckOverlapCandidates
+ * (code/src/AgentMediator.cc:140-202: every new keyframe is looked up in every other agent's BoW inverted index):
+ * each tick every rank contributes one fixed-capacity slot with its newest keyframe's descriptors, one ncclAllGather
+ * delivers all slots to all ranks, and each rank matches its slot against every peer's with the Hamming top-2
+ * kernel on the gathered buffer.  RCCL is loaded at run time (librccl.so.1).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct so_exchange so_exchange;
+#define SO_EXCHANGE_ID_BYTES 128
+/* ncclGetUniqueId: called by ONE rank; the 128 bytes reach the other ranks by whatever transport the host has
+ * (SwarmMap: its WebSocket layer; bench.py: torch.distributed) */
+int so_exchange_unique_id(uint8_t* id128);
+/* ncclCommInitRank + slot buffers; collective: every rank of the group calls it with the same id.
+ * slot_keypoints = descriptors a slot can hold (nfeatures + 3 * nlevels covers every frame) */
+int so_exchange_create(int device, int rank, int world, const uint8_t* id128, int slot_keypoints, so_exchange** out);
+void so_exchange_destroy(so_exchange* x);
+/* One tick (collective).  The slot is filled on the device from the frame's descriptors (so_exchange_tick_dframe: no
+ * host hop) or from host memory (so_exchange_tick).  Out, both `world` entries and either may be NULL: peer_counts[p]
+ * = keypoints in rank p's slot; peer_candidates[p] = descriptors of this rank's slot whose best match in rank p's slot
+ * has distance <= max_dist and < ratio * second best (0 for p == rank): what the host merger is told. */
+int so_exchange_tick_dframe(so_exchange* x, const so_dframe* f, int max_dist, float ratio, int32_t* peer_counts,
+                            int32_t* peer_candidates);
+int so_exchange_tick(so_exchange* x, const uint8_t* descriptors, int n, int max_dist, float ratio, int32_t* peer_counts,
+                     int32_t* peer_candidates);
+/* rank `peer`'s slot as gathered by the last tick: descriptors (may be NULL), *n_out, header checksum (may be NULL) */
+int so_exchange_read_slot(so_exchange* x, int peer, uint8_t* descriptors, int capacity, int* n_out, uint64_t* checksum);
+
+/* ------------------------------------------------------------------------------------------------
  * Keyframe record — the compact binary form of what a peer needs from a keyframe for the
  * loop / merge candidate search, replacing the Boost text archive of code/src/MapUpdater.cc:190-230 /
  * code/include/KeyFrame.h:310-406 on the agent-to-agent path.  Layout (little-endian):

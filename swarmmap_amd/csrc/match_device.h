@@ -108,5 +108,8 @@ void launch_distinctive_desc(const uint4* d_desc, const int32_t* d_off, int n_po
                              int32_t* d_best_median, hipStream_t s);
 void launch_hamming_top2(const uint4* d_A, int na, const uint4* d_B, int nb, int32_t* d_best_idx, int32_t* d_best_dist,
                          int32_t* d_second_dist, hipStream_t s);
+// exchange slot = [header row: i32 n, i32 rank, u64 checksum, 16 B zero][slot_keypoints x 32 B descriptors, zero padded];
+// checksum = sum over the n x 32 descriptor bytes of byte[i] * ((i mod 65521) + 1), mod 2^61 - 1
+void launch_exchange_fill_slot(const uint4* d_desc, int n, int slot_keypoints, int rank, uint4* d_slot, hipStream_t s);
 
 }  // namespace so

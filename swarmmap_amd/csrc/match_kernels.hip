@@ -454,6 +454,45 @@ void launch_distinctive_desc(const uint4* d_desc, const int32_t* d_off, int n_po
                        d_best_median);
 }
 
+// One workgroup: copy the keyframe's descriptors into the exchange slot (zero padding behind them), checksum them,
+// write the header row.  64 KB at most: a single CU streams it in a few microseconds and no second launch is needed.
+__global__ __launch_bounds__(1024) void exchange_fill_slot_kernel(const uint4* __restrict__ desc, int n, int slot_keypoints,
+                                                                  int rank, uint4* __restrict__ slot) {
+    __shared__ unsigned long long s_part[16];
+    const int tid = threadIdx.x;
+    unsigned long long acc = 0;
+    for (int j = tid; j < 2 * slot_keypoints; j += 1024) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (j < 2 * n) {
+            v = desc[j];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const unsigned long long i = (unsigned long long)j * 16 + q * 4 + b;  // byte index
+                    acc += (unsigned long long)((w[q] >> (8 * b)) & 0xFFu) * (i % 65521ull + 1ull);
+                }
+        }
+        slot[2 + j] = v;  // descriptors start at row 1 (32 B = 2 uint4)
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((tid & 63) == 0) s_part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < 16; w++) tot += s_part[w];
+        tot %= ((1ull << 61) - 1ull);
+        slot[0] = make_uint4((uint32_t)n, (uint32_t)rank, (uint32_t)(tot & 0xFFFFFFFFull), (uint32_t)(tot >> 32));
+        slot[1] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+void launch_exchange_fill_slot(const uint4* d_desc, int n, int slot_keypoints, int rank, uint4* d_slot, hipStream_t s) {
+    hipLaunchKernelGGL(exchange_fill_slot_kernel, dim3(1), dim3(1024), 0, s, d_desc, n, slot_keypoints, rank, d_slot);
+}
+
 void launch_hamming_top2(const uint4* d_A, int na, const uint4* d_B, int nb, int32_t* d_best_idx,
                          int32_t* d_best_dist, int32_t* d_second_dist, hipStream_t s) {
     if (na <= 0) return;

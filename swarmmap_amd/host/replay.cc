@@ -136,6 +136,7 @@ struct so_replay {
     } fh[2];
     int cur = 0;
     int submitted = -1;  // handle index holding the frame in flight
+    int last_tracked = -1;  // handle index of the frame tracked last
     bool in_flight = false;
     int n_tracked = 0;   // frames tracked so far (0: the next frame initialises the map)
     float bounds[4] = {0, 0, 0, 0};
@@ -575,6 +576,7 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
             tmap = now_ms();
         }
         r->T_last = T;
+        r->last_tracked = hcur;
         {
             float p12[12];
             to_f12(T, p12);
@@ -659,6 +661,11 @@ int so_replay_last_frame(so_replay* r, const uint8_t** desc, int* n) {
     *desc = r->fh[r->cur].desc.data();
     *n = r->fh[r->cur].n;
     return SO_OK;
+}
+// the device-resident frame tracked last (the exchange fills its slot from it without a host hop)
+so_dframe* so_replay_last_dframe(so_replay* r) {
+    if (!r || r->n_tracked == 0 || r->last_tracked < 0) return nullptr;
+    return r->fr[r->last_tracked];
 }
 so_extractor* so_replay_extractor(so_replay* r) { return r ? r->ex : nullptr; }
 so_matcher* so_replay_matcher(so_replay* r) { return r ? r->matcher : nullptr; }

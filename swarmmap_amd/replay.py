@@ -43,6 +43,7 @@ class Replay:
         lib.so_replay_last_frame.argtypes = [vp, C.POINTER(vp), C.POINTER(i32)]
         lib.so_replay_extractor.argtypes = [vp]; lib.so_replay_extractor.restype = vp
         lib.so_replay_matcher.argtypes = [vp]; lib.so_replay_matcher.restype = vp
+        lib.so_replay_last_dframe.argtypes = [vp]; lib.so_replay_last_dframe.restype = vp
         self.h = vp()
         K4 = np.ascontiguousarray(K, np.float32)
         d5 = None if dist is None else np.ascontiguousarray(list(dist) + [0.0] * (5 - len(dist)), np.float32)
@@ -114,6 +115,10 @@ class Replay:
         ptr, n = C.c_void_p(), C.c_int(0)
         self.lib.so_replay_last_frame(self.h, C.byref(ptr), C.byref(n))
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (max(n.value, 1) * 32,))[:n.value * 32].reshape(-1, 32).copy()
+
+    def last_dframe(self):
+        """so_dframe handle of the frame tracked last (device-resident descriptors for the exchange tick)."""
+        return C.c_void_p(self.lib.so_replay_last_dframe(self.h))
 
     def candidates_total(self, nlevels=8, cap=10000):
         exh = self.lib.so_replay_extractor(self.h)
