@@ -210,7 +210,8 @@ typedef struct {
  * variant 1 = (KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12), :481-597.  Set 1 is the keyframe whose map points
  * are being matched (valid1[i] = pMP && !pMP->isBad()); set 2 the target (variant 1: valid2[i] likewise; variant
  * 0: ignored, may be NULL).  match_of_2[k2] = index in set 1 bound to target feature k2 (variant 0's
- * vpMapPointMatches), match_of_1[k1] = target feature of k1 (variant 1's vpMatches12); either may be NULL. */
+ * vpMapPointMatches), match_of_1[k1] = target feature of k1 (variant 1's vpMatches12); either may be NULL.  The two
+ * arrays always describe the same set of pairs: a pair dropped by the rotation histogram leaves both. */
 int so_search_by_bow(so_matcher* m, int variant, int32_t n1, const uint8_t* desc1, const float* angle1,
                      const uint8_t* valid1, const so_featvec* fv1, int32_t n2, const uint8_t* desc2,
                      const float* angle2, const uint8_t* valid2, const so_featvec* fv2, float nn_ratio,

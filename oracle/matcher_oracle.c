@@ -465,6 +465,9 @@ int orc_search_by_bow(int variant, int32_t n1, const uint8_t* desc1, const float
             for (int j = 0; j < n_rot; j++) {
                 const int b = rot_bins[j];
                 if (b == ind1 || b == ind2 || b == ind3) continue;
+                /* the reference only clears vpMatches12 (vbMatched2 is a local that dies with the call, :590-594);
+                 * match_of_2 is an output here, so the dropped pair leaves it too */
+                if (m1[rot_items[j]] >= 0) m2[m1[rot_items[j]]] = -1;
                 m1[rot_items[j]] = -1;
                 nmatches--;
             }

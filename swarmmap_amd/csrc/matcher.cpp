@@ -1205,8 +1205,16 @@ int so_search_by_bow(so_matcher* m, int variant, int32_t n1, const uint8_t* desc
                 m2[(size_t)t] = -1;
                 nm--;
             }
-        } else {
-            apply_rot_hist(hist, rot_item, rot_b, m1.data(), nm);
+        } else {  // vbMatched2 is internal to the reference; here both arrays are returned and must agree
+            int a, b, c;
+            three_maxima(hist, HISTO_LENGTH, a, b, c);
+            for (size_t j = 0; j < rot_item.size(); j++) {
+                if (rot_b[j] == a || rot_b[j] == b || rot_b[j] == c) continue;
+                const int i1 = rot_item[j];
+                if (m1[(size_t)i1] >= 0) m2[(size_t)m1[(size_t)i1]] = -1;
+                m1[(size_t)i1] = -1;
+                nm--;
+            }
         }
     }
     finish();

@@ -2,6 +2,7 @@
 // this adapter throws std::runtime_error with the library's status text instead.
 #include "ORBextractor.h"
 
+#include <cassert>
 #include <cstring>
 
 namespace ORB_SLAM2 {

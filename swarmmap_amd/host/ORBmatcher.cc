@@ -103,4 +103,96 @@ void ORBmatcher::SearchWindowBest(const so_frame_view& KF, int nq, const uint8_t
           "so_search_window_best");
 }
 
+int ORBmatcher::SearchForTriangulation(const KeyFrameFeatures& kf1, const so_featvec& fv1, const KeyFrameFeatures& kf2,
+                                       const so_featvec& fv2, const float F12[9], float ex, float ey,
+                                       const std::vector<float>& sf2, const std::vector<float>& ls2,
+                                       std::vector<std::pair<size_t, size_t>>& vMatchedPairs) {
+    std::vector<int32_t> m12((size_t)kf1.n, -1);
+    int32_t nmatches = 0;
+    check(so_search_for_triangulation(handle_, kf1.n, kf1.x, kf1.y, kf1.angle, kf1.desc, kf1.free_, &fv1, kf2.n, kf2.x,
+                                      kf2.y, kf2.octave, kf2.angle, kf2.desc, kf2.free_, &fv2, F12, ex, ey, sf2.data(),
+                                      ls2.data(), (int32_t)sf2.size(), mbCheckOrientation ? 1 : 0, m12.data(), &nmatches),
+          "so_search_for_triangulation");
+    vMatchedPairs.clear();  // :737-745
+    vMatchedPairs.reserve((size_t)nmatches);
+    for (size_t i = 0; i < m12.size(); i++)
+        if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
+    return nmatches;
+}
+
+static int count_within(const std::vector<int32_t>& idx, const std::vector<int32_t>& dist, int th) {
+    int n = 0;
+    for (size_t i = 0; i < idx.size(); i++) n += (idx[i] >= 0 && dist[i] <= th) ? 1 : 0;
+    return n;
+}
+
+int ORBmatcher::Fuse(const so_frame_view& KF, const WindowQueries& q, const std::vector<float>& inv_sigma2,
+                     std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
+    SearchWindowBest(KF, q.size(), q.valid.data(), q.u.data(), q.v.data(), q.radius.data(), q.pred_level.data(),
+                     q.desc.data(), true, inv_sigma2.data(), bestIdx, bestDist);
+    return count_within(bestIdx, bestDist, TH_LOW);  // "if(bestDist<=TH_LOW)", :871
+}
+
+int ORBmatcher::Fuse(const so_frame_view& KF, const WindowQueries& q, std::vector<int32_t>& bestIdx,
+                     std::vector<int32_t>& bestDist) {
+    SearchWindowBest(KF, q.size(), q.valid.data(), q.u.data(), q.v.data(), q.radius.data(), q.pred_level.data(),
+                     q.desc.data(), false, nullptr, bestIdx, bestDist);
+    return count_within(bestIdx, bestDist, TH_LOW);  // :995
+}
+
+int ORBmatcher::SearchBySim3(const so_frame_view& KF1, const so_frame_view& KF2, const WindowQueries& q12,
+                             const WindowQueries& q21, std::vector<int32_t>& vnMatch12) {
+    std::vector<int32_t> i2, d2, i1, d1;
+    SearchWindowBest(KF2, q12.size(), q12.valid.data(), q12.u.data(), q12.v.data(), q12.radius.data(),
+                     q12.pred_level.data(), q12.desc.data(), false, nullptr, i2, d2);
+    SearchWindowBest(KF1, q21.size(), q21.valid.data(), q21.u.data(), q21.v.data(), q21.radius.data(),
+                     q21.pred_level.data(), q21.desc.data(), false, nullptr, i1, d1);
+    std::vector<int32_t> vnMatch1((size_t)q12.size(), -1), vnMatch2((size_t)q21.size(), -1);
+    for (size_t i = 0; i < vnMatch1.size(); i++)
+        if (i2[i] >= 0 && d2[i] <= TH_HIGH) vnMatch1[i] = i2[i];  // :1113-1116
+    for (size_t i = 0; i < vnMatch2.size(); i++)
+        if (i1[i] >= 0 && d1[i] <= TH_HIGH) vnMatch2[i] = i1[i];  // :1192-1194
+    vnMatch12.assign(vnMatch1.size(), -1);
+    int nFound = 0;
+    for (size_t k = 0; k < vnMatch1.size(); k++) {  // "Check agreement", :1199-1211
+        const int idx2 = vnMatch1[k];
+        if (idx2 >= 0 && idx2 < (int)vnMatch2.size() && vnMatch2[(size_t)idx2] == (int)k) {
+            vnMatch12[k] = idx2;
+            nFound++;
+        }
+    }
+    return nFound;
+}
+
+int ORBmatcher::SearchByProjection(const so_frame_view& KF, const WindowQueries& q, std::vector<int32_t>& kp_to_point) {
+    kp_to_point.assign((size_t)KF.n, -1);
+    int32_t nmatches = 0;
+    check(so_search_window_greedy(handle_, &KF, q.size(), q.valid.data(), q.u.data(), q.v.data(), q.radius.data(),
+                                  q.min_level.data(), q.max_level.data(), q.desc.data(), nullptr, TH_LOW, 0,
+                                  kp_to_point.data(), &nmatches),
+          "so_search_window_greedy");
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(const so_frame_view& F, const WindowQueries& q, int ORBdist,
+                                   std::vector<int32_t>& kp_to_point) {
+    kp_to_point.assign((size_t)F.n, -1);
+    int32_t nmatches = 0;
+    check(so_search_window_greedy(handle_, &F, q.size(), q.valid.data(), q.u.data(), q.v.data(), q.radius.data(),
+                                  q.min_level.data(), q.max_level.data(), q.desc.data(), q.angle.data(), ORBdist,
+                                  mbCheckOrientation ? 1 : 0, kp_to_point.data(), &nmatches),
+          "so_search_window_greedy");
+    return nmatches;
+}
+
+std::vector<int32_t> ORBmatcher::ComputeDistinctiveDescriptors(const std::vector<int32_t>& offsets,
+                                                               const std::vector<uint8_t>& descriptors) {
+    const int n = (int)offsets.size() - 1;
+    std::vector<int32_t> best((size_t)(n > 0 ? n : 0), -1);
+    if (n > 0)
+        check(so_distinctive_descriptors(handle_, n, offsets.data(), descriptors.data(), best.data(), nullptr),
+              "so_distinctive_descriptors");
+    return best;
+}
+
 }  // namespace ORB_SLAM2

@@ -4,6 +4,7 @@
 // that fills them from a real Frame).  Constants, constructor arguments and return values are the reference's.
 #pragma once
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 #include "../../include/swarmorb.h"
@@ -62,6 +63,56 @@ public:
                     const so_featvec& vFeatVec1, int n2, const uint8_t* desc2, const float* angle2,
                     const uint8_t* valid2, const so_featvec& vFeatVec2, std::vector<int32_t>& match_of_2,
                     std::vector<int32_t>& match_of_1);
+    // ---- LocalMapping / loop closing / relocalisation routines.  The projections (Rcw * X + tcw, PredictScale,
+    //      IsInImage, the depth / viewing-angle gates) and every object-graph side effect stay with the caller, as in
+    //      INTEGRATION.md; what the reference then does per map point - GetFeaturesInArea, DescriptorDistance, best /
+    //      greedy selection - is what these run on the GPU. ----
+    struct WindowQueries {              // one entry per projected map point
+        std::vector<uint8_t> valid;         // passed the caller's gates
+        std::vector<float> u, v, radius;    // projection and th * mvScaleFactors[nPredictedLevel]
+        std::vector<int32_t> pred_level;    // nPredictedLevel (Fuse / SearchBySim3: octave in [pred - 1, pred])
+        std::vector<int32_t> min_level, max_level;  // greedy searches: explicit octave range
+        std::vector<uint8_t> desc;          // pMP->GetDescriptor(), 32 B each
+        std::vector<float> angle;           // greedy search with orientation check: the map point's keypoint angle
+        int size() const { return (int)u.size(); }
+    };
+    struct KeyFrameFeatures {           // the per-feature fields of a KeyFrame the vocabulary-node routines read
+        int n = 0;
+        const float *x = nullptr, *y = nullptr, *angle = nullptr;  // mvKeysUn
+        const int32_t* octave = nullptr;
+        const uint8_t* desc = nullptr;   // mDescriptors
+        const uint8_t* free_ = nullptr;  // !GetMapPoint(i)
+    };
+
+    // SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, vMatchedPairs, bOnlyStereo = false) —
+    // code/src/ORBmatcher.cc:599-749.  (ex, ey) = the epipole in image 2 (:607-613).
+    int SearchForTriangulation(const KeyFrameFeatures& kf1, const so_featvec& vFeatVec1, const KeyFrameFeatures& kf2,
+                               const so_featvec& vFeatVec2, const float F12[9], float ex, float ey,
+                               const std::vector<float>& mvScaleFactors2, const std::vector<float>& mvLevelSigma2_2,
+                               std::vector<std::pair<size_t, size_t>>& vMatchedPairs);
+    // Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) — :751-891 (chi2 5.99 reprojection gate) and
+    // Fuse(KeyFrame* pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) — :893-1009 (no gate): best keypoint per map
+    // point; returns how many have bestDist <= TH_LOW (the ones the caller AddObservation()s / Replace()s).
+    int Fuse(const so_frame_view& pKF, const WindowQueries& vpMapPoints, const std::vector<float>& mvInvLevelSigma2,
+             std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist);
+    int Fuse(const so_frame_view& pKF, const WindowQueries& vpPointsScw, std::vector<int32_t>& bestIdx,
+             std::vector<int32_t>& bestDist);
+    // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) — :1011-1221: map points of 1 projected into 2 and of 2
+    // into 1 (already-matched ones arrive as valid = 0), best keypoint <= TH_HIGH each way, kept where both agree.
+    // vnMatch12[i1] = i2 or -1.  Returns nFound.
+    int SearchBySim3(const so_frame_view& pKF1, const so_frame_view& pKF2, const WindowQueries& points1_in_2,
+                     const WindowQueries& points2_in_1, std::vector<int32_t>& vnMatch12);
+    // SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) — :264-373: sequential, a keypoint taken
+    // by an earlier point or bound on entry (pKF.excluded) is skipped, TH_LOW, no orientation check
+    int SearchByProjection(const so_frame_view& pKF, const WindowQueries& vpPointsScw, std::vector<int32_t>& kp_to_point);
+    // SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) — :1356-1473
+    int SearchByProjection(const so_frame_view& CurrentFrame, const WindowQueries& vpKFPoints, int ORBdist,
+                           std::vector<int32_t>& kp_to_point);
+    // MapPoint::ComputeDistinctiveDescriptors (code/src/MapPoint.cc:323-392) for a batch: point p owns descriptors
+    // [offsets[p], offsets[p + 1]); best[p] = index inside its own list
+    std::vector<int32_t> ComputeDistinctiveDescriptors(const std::vector<int32_t>& offsets,
+                                                       const std::vector<uint8_t>& descriptors);
+
     // Fuse / SearchBySim3 core: best keypoint of pKF inside the projection window of every map point
     void SearchWindowBest(const so_frame_view& KF, int nq, const uint8_t* valid, const float* u, const float* v,
                           const float* radius, const int32_t* pred_level, const uint8_t* desc, bool chi2_gate,

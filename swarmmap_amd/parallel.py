@@ -90,13 +90,21 @@ def unpack_keyframe_record(rec):
 
 
 class KeyframeExchange:
-    def __init__(self, slot_keypoints=2024, device=None, group=None):
+    """torch.distributed mirror of the exchange (gloo on CPU for the world-size-2 tests, nccl = RCCL on GPUs).  The
+    product path is so_exchange_* behind the C ABI (swarmmap_amd/exchange.py); this class keeps the payload layout
+    testable without GPUs.  A slot holds 1 header row + slot_keypoints descriptor rows of 32 B; pass
+    record_keypoints = n to size it for whole keyframe RECORDS of up to n keypoints instead (128 + 48 n bytes)."""
+
+    def __init__(self, slot_keypoints=2024, device=None, group=None, record_keypoints=None):
         if not dist.is_initialized():
             raise RuntimeError("KeyframeExchange needs an initialised torch.distributed process group")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.slot_keypoints = int(slot_keypoints)
+        if record_keypoints is not None:  # rows needed by a record of that many keypoints (header 128 B + 48 B each)
+            need = RECORD_HEADER_BYTES + 48 * int(record_keypoints)
+            self.slot_keypoints = max(self.slot_keypoints if slot_keypoints != 2024 else 0, (need + 31) // 32 - HEADER_ROWS)
         on_gpu = dist.get_backend(group) == "nccl"
         self.device = torch.device("cuda", device if device is not None else torch.cuda.current_device()) \
             if on_gpu else torch.device("cpu")
@@ -147,9 +155,9 @@ class KeyframeExchange:
 
     # ---- full keyframe records (geometry + pose travel with the descriptors) ----
     def exchange_records(self, record):
-        """All-gather one keyframe RECORD per rank (pack_keyframe_record); the slot must have been created with
-        record slots (slot_keypoints x 48 B + 128 B fit in (HEADER_ROWS + slot_keypoints) x 32 B x 1.5).  Returns the
-        list of unpacked records in rank order (None for a rank whose slot is empty)."""
+        """All-gather one keyframe RECORD per rank (pack_keyframe_record).  A record of n keypoints takes 128 + 48 n
+        bytes: create the exchange with record_keypoints = n (a 1000-keypoint record does NOT fit the descriptor slot
+        of the same keypoint count).  Returns the list of unpacked records in rank order (None for an empty slot)."""
         rec = np.ascontiguousarray(record, np.uint8).reshape(-1)
         cap = self.slot.numel()
         if rec.nbytes > cap:

@@ -1,7 +1,10 @@
-// adapter_smoke.cpp — exercises the C++ adapter classes (the reference's signatures) end to end on the GPU and
-// prints checksums that tests/test_cpp_adapters_gpu.py compares with the same inputs through the Python binding.
+// adapter_smoke.cpp — drives every method of the C++ adapter classes (the reference's signatures, swarmmap_amd/host/)
+// end to end on the GPU.  Inputs are raw arrays written by tests/test_cpp_adapters_gpu.py into a directory; results
+// are printed as "name count fnv-hash" lines (or plain numbers) that the test compares with the CPU ORACLE run on the
+// same inputs.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../../swarmmap_amd/host/ORBextractor.h"
@@ -15,13 +18,72 @@ static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull
     return h;
 }
 
+static std::string g_dir;
+template <typename T>
+static std::vector<T> rd(const char* name) {
+    const std::string path = g_dir + "/" + name + ".bin";
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "missing %s\n", path.c_str()); exit(4); }
+    fseek(f, 0, SEEK_END);
+    const long bytes = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<T> v((size_t)bytes / sizeof(T));
+    if (bytes > 0 && fread(v.data(), 1, (size_t)bytes, f) != (size_t)bytes) exit(5);
+    fclose(f);
+    return v;
+}
+template <typename T>
+static void out(const char* name, const std::vector<T>& v) {
+    printf("%s %zu %016llx\n", name, v.size(), (unsigned long long)fnv(v.data(), v.size() * sizeof(T)));
+}
+
+struct FrameArrays {
+    std::vector<float> x, y, angle, sf;
+    std::vector<int32_t> octave;
+    std::vector<uint8_t> desc, excluded;
+    std::vector<float> bounds;
+    so_frame_view view(bool with_excluded) const {
+        so_frame_view F{};
+        F.n = (int32_t)x.size(); F.x = x.data(); F.y = y.data(); F.octave = octave.data(); F.angle = angle.data();
+        F.desc = desc.data(); F.excluded = with_excluded && !excluded.empty() ? excluded.data() : nullptr;
+        F.min_x = bounds[0]; F.max_x = bounds[1]; F.min_y = bounds[2]; F.max_y = bounds[3];
+        F.grid_inv_w = 64.0f / (bounds[1] - bounds[0]); F.grid_inv_h = 48.0f / (bounds[3] - bounds[2]);
+        F.scale_factors = sf.data(); F.nlevels = (int32_t)sf.size();
+        return F;
+    }
+};
+static FrameArrays frame(const std::string& p) {
+    FrameArrays f;
+    f.x = rd<float>((p + "_x").c_str()); f.y = rd<float>((p + "_y").c_str()); f.angle = rd<float>((p + "_angle").c_str());
+    f.octave = rd<int32_t>((p + "_octave").c_str()); f.desc = rd<uint8_t>((p + "_desc").c_str());
+    f.excluded = rd<uint8_t>((p + "_excluded").c_str()); f.bounds = rd<float>((p + "_bounds").c_str());
+    f.sf = rd<float>("scale_factors");
+    return f;
+}
+static ORB_SLAM2::ORBmatcher::WindowQueries queries(const std::string& p) {
+    ORB_SLAM2::ORBmatcher::WindowQueries q;
+    q.valid = rd<uint8_t>((p + "_valid").c_str()); q.u = rd<float>((p + "_u").c_str()); q.v = rd<float>((p + "_v").c_str());
+    q.radius = rd<float>((p + "_radius").c_str()); q.pred_level = rd<int32_t>((p + "_pred_level").c_str());
+    q.min_level = rd<int32_t>((p + "_min_level").c_str()); q.max_level = rd<int32_t>((p + "_max_level").c_str());
+    q.desc = rd<uint8_t>((p + "_desc").c_str()); q.angle = rd<float>((p + "_angle").c_str());
+    return q;
+}
+struct FeatVec {
+    std::vector<int32_t> node, off, idx;
+    so_featvec view() const { return so_featvec{(int32_t)node.size(), node.data(), off.data(), idx.data()}; }
+};
+static FeatVec featvec(const std::string& p) {
+    FeatVec f;
+    f.node = rd<int32_t>((p + "_node").c_str()); f.off = rd<int32_t>((p + "_off").c_str()); f.idx = rd<int32_t>((p + "_idx").c_str());
+    return f;
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) return 2;
+    g_dir = argv[1];
     const int w = atoi(argv[2]), h = atoi(argv[3]);
-    std::vector<uint8_t> img((size_t)w * h);
-    FILE* f = fopen(argv[1], "rb");
-    if (!f || fread(img.data(), 1, img.size(), f) != img.size()) return 3;
-    fclose(f);
+    // ---- ORBextractor::operator() -----------------------------------------------------------------------------
+    std::vector<uint8_t> img = rd<uint8_t>("image");
     ORB_SLAM2::ORBextractor ex(1000, 1.2f, 8, 20, 7);
     std::vector<swarmorb::KeyPoint> kps;
     swarmorb::Descriptors desc;
@@ -29,77 +91,123 @@ int main(int argc, char** argv) {
     ex(view, mask, kps, desc);
     ex(view, mask, kps, desc);  // the context is reused frame after frame
     printf("levels %d scale7 %.6f\n", ex.GetLevels(), ex.GetScaleFactors()[7]);
-    printf("keypoints %zu %016llx\n", kps.size(), (unsigned long long)fnv(kps.data(), kps.size() * sizeof(kps[0])));
-    printf("descriptors %d %016llx\n", desc.rows, (unsigned long long)fnv(desc.data.data(), desc.data.size()));
+    out("keypoints", kps);
+    out("descriptors", desc.data);
     printf("distance %d\n", ORB_SLAM2::ORBmatcher::DescriptorDistance(desc.ptr(0), desc.ptr(1)));
-    // match the frame against itself shifted by one pixel: every level-0 keypoint must find its twin
-    std::vector<float> x(kps.size()), y(kps.size()), ang(kps.size());
-    std::vector<int32_t> oct(kps.size());
-    for (size_t i = 0; i < kps.size(); i++) {
-        x[i] = kps[i].pt.x; y[i] = kps[i].pt.y; ang[i] = kps[i].angle; oct[i] = kps[i].octave;
-    }
-    std::vector<float> sf = ex.GetScaleFactors();
-    so_frame_view F{};
-    F.n = (int32_t)kps.size(); F.x = x.data(); F.y = y.data(); F.octave = oct.data(); F.angle = ang.data();
-    F.desc = desc.data.data(); F.min_x = 0; F.max_x = (float)w; F.min_y = 0; F.max_y = (float)h;
-    F.grid_inv_w = 64.0f / (float)w; F.grid_inv_h = 48.0f / (float)h; F.scale_factors = sf.data(); F.nlevels = 8;
-    ORB_SLAM2::ORBmatcher matcher(0.9f, true);
-    std::vector<float> prev(2 * kps.size());
-    for (size_t i = 0; i < kps.size(); i++) { prev[2 * i] = x[i] + 1.0f; prev[2 * i + 1] = y[i]; }
-    std::vector<int32_t> m12;
-    const int nm = matcher.SearchForInitialization(F, F, prev, m12, 20);
-    int self = 0, lvl0 = 0;
-    for (size_t i = 0; i < m12.size(); i++) { self += m12[i] == (int)i; lvl0 += oct[i] == 0; }
-    printf("init_matches %d self %d level0 %d\n", nm, self, lvl0);
-    // a tiny BA window: 2 keyframes (one fixed), 4 points seen by both, consistent observations
-    ORB_SLAM2::BAWindow win;
-    const float T0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, T1[12] = {1, 0, 0, -0.5f, 0, 1, 0, 0, 0, 0, 1, 0};
-    win.Tcw.assign(T0, T0 + 12); win.Tcw.insert(win.Tcw.end(), T1, T1 + 12);
-    win.fixed = {1, 0};
-    win.intr = {458.654f, 457.296f, 367.215f, 248.375f, 458.654f, 457.296f, 367.215f, 248.375f};
-    const float P[4][3] = {{-1, -0.5f, 5}, {1, 0.5f, 6}, {0.5f, -1, 4}, {-0.7f, 0.8f, 7}};
-    for (int j = 0; j < 4; j++) {
-        for (int k = 0; k < 3; k++) win.Xw.push_back(P[j][k] + 0.05f * (float)(j - k));
-        for (int i = 0; i < 2; i++) {
-            const float tx = i == 0 ? 0.f : -0.5f;
-            const float u = 458.654f * (P[j][0] + tx) / P[j][2] + 367.215f, v = 457.296f * P[j][1] / P[j][2] + 248.375f;
-            win.edge_kf.push_back(i); win.edge_mp.push_back(j); win.obs.push_back(u); win.obs.push_back(v);
-            win.inv_sigma2.push_back(1.0f);
-        }
-    }
-    ORB_SLAM2::Optimizer& optimizer = ORB_SLAM2::Optimizer::ThreadInstance();  // static call sites, as in the reference
-    ORB_SLAM2::BAResult res;
-    bool stop = false;
-    optimizer.LocalBundleAdjustment(win, &stop, res);
-    printf("ba chi2 %.3e -> %.3e its %d+%d outliers %d\n", res.info.chi2_initial, res.info.chi2_final,
-           res.info.iterations_stage1, res.info.iterations_stage2, res.info.n_outliers);
-    // Frame post-processing on the extracted keypoints with EuRoC's lens
+    // ---- Frame post-processing (EuRoC lens) -------------------------------------------------------------------
     const float K[4] = {458.654f, 457.296f, 367.215f, 248.375f};
-    ORB_SLAM2::Frame frame(K, {-0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f});
+    ORB_SLAM2::Frame fr(K, {-0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f});
     std::vector<swarmorb::KeyPoint> keysUn;
-    frame.UndistortAndAssign(kps, w, h, keysUn);
+    fr.UndistortAndAssign(kps, w, h, keysUn);
     std::vector<float> un(2 * keysUn.size());
     for (size_t i = 0; i < keysUn.size(); i++) { un[2 * i] = keysUn[i].pt.x; un[2 * i + 1] = keysUn[i].pt.y; }
-    printf("undistorted %zu %016llx bounds %.9g %.9g %.9g %.9g grid %zu %016llx\n", keysUn.size(),
-           (unsigned long long)fnv(un.data(), un.size() * 4), frame.mnMinX, frame.mnMaxX, frame.mnMinY, frame.mnMaxY,
-           frame.GridItems().size(), (unsigned long long)fnv(frame.GridItems().data(), frame.GridItems().size() * 4));
-    // PoseOptimization on exact observations of the 4 BA points + 4 more from a perturbed pose
-    std::vector<float> X, ob, iw;
-    std::vector<uint8_t> outl;
-    for (int j = 0; j < 40; j++) {
-        const float px = -2.f + 0.1f * (float)j, py = -1.f + 0.05f * (float)((j * 7) % 40), pz = 4.f + 0.1f * (float)((j * 3) % 30);
-        X.insert(X.end(), {px, py, pz});
-        ob.push_back(K[0] * px / pz + K[2]);
-        ob.push_back(K[1] * py / pz + K[3]);
-        iw.push_back(1.0f);
+    out("undistorted", un);
+    printf("bounds %.9g %.9g %.9g %.9g\n", fr.mnMinX, fr.mnMaxX, fr.mnMinY, fr.mnMaxY);
+    out("grid", fr.GridItems());
+    // ---- ORBmatcher: the ten routines -------------------------------------------------------------------------
+    const FrameArrays F1 = frame("m1f"), F2 = frame("m2f"), I1 = frame("i1"), I2 = frame("i2"), KF = frame("kf");
+    {   // SearchByProjection(Frame&, vpMapPoints, th)
+        ORB_SLAM2::ORBmatcher m(0.8f, true);
+        ORB_SLAM2::MapPointViews mp;
+        mp.in_view = rd<uint8_t>("m1_in_view"); mp.proj_x = rd<float>("m1_proj_x"); mp.proj_y = rd<float>("m1_proj_y");
+        mp.view_cos = rd<float>("m1_view_cos"); mp.pred_level = rd<int32_t>("m1_pred_level"); mp.desc = rd<uint8_t>("m1_desc");
+        mp.has_obs = rd<uint8_t>("m1_has_obs");
+        std::vector<int32_t> k;
+        const int n = m.SearchByProjection(F1.view(true), mp, 1.0f, k);
+        printf("m1_n %d\n", n); out("m1", k);
     }
-    float Tcw[12] = {1, 0, 0, 0.05f, 0, 1, 0, -0.03f, 0, 0, 1, 0.02f};  // start off the true identity pose
-    const int inl = optimizer.PoseOptimization(Tcw, K, X, ob, iw, outl);
-    printf("pose inliers %d t %.4f %.4f %.4f\n", inl, Tcw[3], Tcw[7], Tcw[11]);
-    ORB_SLAM2::DistinctiveDescriptors dd;
-    std::vector<int32_t> off = {0, 3, 3, 8};
-    std::vector<uint8_t> dsc(desc.data.begin(), desc.data.begin() + 8 * 32);
-    const std::vector<int32_t> best = dd.Compute(off, dsc);
-    printf("distinctive %d %d %d\n", best[0], best[1], best[2]);
+    {   // SearchByProjection(CurrentFrame, LastFrame, th, mono)
+        ORB_SLAM2::ORBmatcher m(0.9f, true);
+        ORB_SLAM2::LastFrameViews L;
+        L.valid = rd<uint8_t>("m2_valid"); L.u = rd<float>("m2_u"); L.v = rd<float>("m2_v"); L.angle = rd<float>("m2_angle");
+        L.octave = rd<int32_t>("m2_octave"); L.desc = rd<uint8_t>("m2_desc"); L.has_obs = rd<uint8_t>("m2_has_obs");
+        std::vector<int32_t> k;
+        const int n = m.SearchByProjection(F2.view(true), L, 15.0f, k);
+        printf("m2_n %d\n", n); out("m2", k);
+    }
+    {   // SearchForInitialization
+        ORB_SLAM2::ORBmatcher m(0.9f, true);
+        std::vector<float> prev = rd<float>("i_prev");
+        std::vector<int32_t> m12;
+        const int n = m.SearchForInitialization(I1.view(false), I2.view(false), prev, m12, 100);
+        printf("m4_n %d\n", n); out("m4", m12); out("m4_prev", prev);
+    }
+    const std::vector<float> b1x = rd<float>("b1_x"), b1y = rd<float>("b1_y"), b1a = rd<float>("b1_angle");
+    const std::vector<uint8_t> b1d = rd<uint8_t>("b1_desc"), b1v = rd<uint8_t>("b1_valid"), b1f = rd<uint8_t>("b1_free");
+    const std::vector<float> b2x = rd<float>("b2_x"), b2y = rd<float>("b2_y"), b2a = rd<float>("b2_angle");
+    const std::vector<int32_t> b2o = rd<int32_t>("b2_octave");
+    const std::vector<uint8_t> b2d = rd<uint8_t>("b2_desc"), b2v = rd<uint8_t>("b2_valid"), b2f = rd<uint8_t>("b2_free");
+    const FeatVec fv1 = featvec("fv1"), fv2 = featvec("fv2");
+    for (int variant = 0; variant < 2; variant++) {  // SearchByBoW(KF, F) and (KF, KF)
+        ORB_SLAM2::ORBmatcher m(0.7f, true);
+        std::vector<int32_t> m2, m1;
+        const int n = m.SearchByBoW(variant, (int)b1a.size(), b1d.data(), b1a.data(), b1v.data(), fv1.view(), (int)b2a.size(),
+                                    b2d.data(), b2a.data(), b2v.data(), fv2.view(), m2, m1);
+        printf("m3_%d_n %d\n", variant, n);
+        out(variant ? "m3_1_of2" : "m3_0_of2", m2); out(variant ? "m3_1_of1" : "m3_0_of1", m1);
+    }
+    {   // SearchForTriangulation
+        ORB_SLAM2::ORBmatcher m(0.6f, true);
+        ORB_SLAM2::ORBmatcher::KeyFrameFeatures k1, k2;
+        k1.n = (int)b1x.size(); k1.x = b1x.data(); k1.y = b1y.data(); k1.angle = b1a.data(); k1.desc = b1d.data(); k1.free_ = b1f.data();
+        k2.n = (int)b2x.size(); k2.x = b2x.data(); k2.y = b2y.data(); k2.angle = b2a.data(); k2.octave = b2o.data();
+        k2.desc = b2d.data(); k2.free_ = b2f.data();
+        const std::vector<float> F12 = rd<float>("F12"), sf = rd<float>("scale_factors"), ls = rd<float>("level_sigma2");
+        std::vector<std::pair<size_t, size_t>> pairs;
+        const int n = m.SearchForTriangulation(k1, fv1.view(), k2, fv2.view(), F12.data(), 900.0f, 240.0f, sf, ls, pairs);
+        std::vector<int32_t> m12(b1x.size(), -1);
+        for (auto& pr : pairs) m12[pr.first] = (int32_t)pr.second;
+        printf("m5_n %d\n", n); out("m5", m12);
+    }
+    const ORB_SLAM2::ORBmatcher::WindowQueries q = queries("q"), q21 = queries("q21");
+    const std::vector<float> inv = rd<float>("inv_sigma2");
+    {   // Fuse x 2, SearchBySim3
+        ORB_SLAM2::ORBmatcher m(0.6f, true);
+        std::vector<int32_t> bi, bd;
+        const int n1 = m.Fuse(KF.view(false), q, inv, bi, bd);
+        printf("fuse_gate_n %d\n", n1); out("fuse_gate_idx", bi); out("fuse_gate_dist", bd);
+        const int n2 = m.Fuse(KF.view(false), q, bi, bd);
+        printf("fuse_scw_n %d\n", n2); out("fuse_scw_idx", bi); out("fuse_scw_dist", bd);
+        std::vector<int32_t> m12;
+        const int n3 = m.SearchBySim3(I1.view(false), KF.view(false), q, q21, m12);
+        printf("sim3_n %d\n", n3); out("sim3", m12);
+    }
+    {   // the two sequential SearchByProjection overloads
+        ORB_SLAM2::ORBmatcher m(0.75f, true);
+        std::vector<int32_t> k;
+        const int n1 = m.SearchByProjection(KF.view(true), q, k);
+        printf("greedy_kf_n %d\n", n1); out("greedy_kf", k);
+        const int n2 = m.SearchByProjection(KF.view(true), q, 64, k);
+        printf("greedy_f_n %d\n", n2); out("greedy_f", k);
+        const std::vector<int32_t> off = rd<int32_t>("dd_off");
+        const std::vector<uint8_t> dd = rd<uint8_t>("dd_desc");
+        out("distinctive", m.ComputeDistinctiveDescriptors(off, dd));
+    }
+    // ---- Optimizer ----------------------------------------------------------------------------------------------
+    ORB_SLAM2::Optimizer& optimizer = ORB_SLAM2::Optimizer::ThreadInstance();  // static call sites, as in the reference
+    {
+        ORB_SLAM2::BAWindow win;
+        win.Tcw = rd<float>("ba_Tcw"); win.fixed = rd<uint8_t>("ba_fixed"); win.intr = rd<float>("ba_intr");
+        win.Xw = rd<float>("ba_Xw"); win.edge_kf = rd<int32_t>("ba_edge_pose"); win.edge_mp = rd<int32_t>("ba_edge_point");
+        win.obs = rd<float>("ba_obs"); win.inv_sigma2 = rd<float>("ba_inv_sigma2");
+        ORB_SLAM2::BAResult res;
+        bool stop = false;
+        optimizer.LocalBundleAdjustment(win, &stop, res);
+        printf("ba %.9e %.9e %d %d %d\n", res.info.chi2_initial, res.info.chi2_final, res.info.iterations_stage1,
+               res.info.iterations_stage2, res.info.n_outliers);
+        FILE* f = fopen((g_dir + "/ba_out.bin").c_str(), "wb");
+        fwrite(res.Tcw.data(), 4, res.Tcw.size(), f); fwrite(res.Xw.data(), 4, res.Xw.size(), f);
+        fclose(f);
+        out("ba_outlier", res.edge_outlier);
+    }
+    {
+        std::vector<float> Tcw = rd<float>("po_Tcw");
+        const std::vector<float> X = rd<float>("po_Xw"), ob = rd<float>("po_obs"), iw = rd<float>("po_inv_sigma2");
+        std::vector<uint8_t> outl;
+        const int inl = optimizer.PoseOptimization(Tcw.data(), K, X, ob, iw, outl);
+        printf("pose %d %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", inl, Tcw[0], Tcw[1], Tcw[2], Tcw[3],
+               Tcw[4], Tcw[5], Tcw[6], Tcw[7], Tcw[8], Tcw[9], Tcw[10], Tcw[11]);
+        out("pose_outlier", outl);
+    }
     return 0;
 }

@@ -1,5 +1,5 @@
-"""The C++ adapter classes (reference signatures: ORBextractor / ORBmatcher / Optimizer) compile against the
-C ABI and give the same results as the Python binding on the same inputs."""
+"""The C++ adapter classes (reference signatures: ORBextractor / ORBmatcher / Frame / Optimizer, swarmmap_amd/host/)
+compile with plain g++ against the C ABI, and every method gives the CPU ORACLE's result on the same inputs."""
 import os
 import subprocess
 
@@ -8,6 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "swarmmap_amd", "host")
+SRCS = [os.path.join(HOST, f) for f in ("ORBextractor.cc", "ORBmatcher.cc", "Optimizer.cc", "Frame.cc")]
 
 
 def _fnv(b):
@@ -19,11 +20,9 @@ def _fnv(b):
 
 def _build(tmp_path):
     exe = str(tmp_path / "adapter_smoke")
-    srcs = [os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp")] + \
-           [os.path.join(HOST, f) for f in ("ORBextractor.cc", "ORBmatcher.cc", "Optimizer.cc", "Frame.cc")]
     lib = os.path.join(ROOT, "swarmmap_amd")
-    subprocess.check_call(["g++", "-std=c++14", "-O1", "-o", exe] + srcs +
-                          ["-L" + lib, "-lswarmorb", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp")] +
+                          SRCS + ["-L" + lib, "-lswarmorb", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
@@ -32,35 +31,162 @@ def test_adapters_compile_with_plain_gcc(tmp_path):
     assert os.path.exists(_build(tmp_path))
 
 
+def test_opencv_overload_type_checks(tmp_path):
+    """The cv::InputArray / cv::OutputArray overload of ORBextractor::operator() (code/include/ORBextractor.h:58-60)
+    only exists with -DSWARMORB_WITH_OPENCV, and this image has no OpenCV: compile it (no link) against a
+    compile-only stand-in for the few cv:: members it touches, so that the code path is at least type-checked."""
+    stub = os.path.join(ROOT, "tests", "cpp", "opencv_stub")
+    obj = str(tmp_path / "ORBextractor_cv.o")
+    subprocess.check_call(["g++", "-std=c++14", "-O0", "-Wall", "-DSWARMORB_WITH_OPENCV", "-I" + stub, "-c",
+                           os.path.join(HOST, "ORBextractor.cc"), "-o", obj])
+    sym = subprocess.check_output(["nm", "-C", obj], text=True)
+    assert "cv::_InputArray const&" in sym and "ORB_SLAM2::ORBextractor::operator()" in sym
+
+
+def _w(d, name, arr, dtype):
+    np.ascontiguousarray(arr, dtype).tofile(os.path.join(d, name + ".bin"))
+
+
+def _frame(d, prefix, fr):
+    from swarmmap_amd.matcher import FrameView
+    for k, t in (("x", np.float32), ("y", np.float32), ("angle", np.float32), ("octave", np.int32), ("desc", np.uint8)):
+        _w(d, "%s_%s" % (prefix, k), fr[k], t)
+    _w(d, prefix + "_excluded", fr.get("excluded", np.zeros(0, np.uint8)), np.uint8)
+    _w(d, prefix + "_bounds", fr["bounds"], np.float32)
+    return lambda excl=True: FrameView(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["bounds"],
+                                       fr["scale_factors"], fr.get("excluded") if excl else None)
+
+
+def _queries(d, prefix, q):
+    for k, t in (("valid", np.uint8), ("u", np.float32), ("v", np.float32), ("radius", np.float32), ("pred_level", np.int32),
+                 ("min_level", np.int32), ("max_level", np.int32), ("desc", np.uint8), ("angle", np.float32)):
+        _w(d, "%s_%s" % (prefix, k), q[k], t)
+
+
 @pytest.mark.gpu
-def test_adapters_match_python_binding(tmp_path):
-    import swarmmap_amd
+def test_every_adapter_method_matches_the_oracle(tmp_path, oracle):
     from swarmmap_amd import synth
+    from swarmmap_amd.matcher import FeatureVector
     exe = _build(tmp_path)
+    d = str(tmp_path)
+    rng = np.random.default_rng(12)
+    sf = synth.SCALE_FACTORS
     img = synth.make_image(12, synth.EUROC)
-    raw = tmp_path / "img.raw"
-    raw.write_bytes(img.tobytes())
-    out = subprocess.check_output([exe, str(raw), "752", "480"], text=True)
-    lines = dict(l.split(" ", 1) for l in out.strip().splitlines())
-    ex = swarmmap_amd.ORBextractor(1000, 1.2, 8, 20, 7)
-    kps, desc = ex(img)
-    n, h = lines["keypoints"].split()
-    assert int(n) == len(kps) and h == _fnv(kps.tobytes())
-    n, h = lines["descriptors"].split()
-    assert int(n) == len(desc) and h == _fnv(desc.tobytes())
-    assert int(lines["distance"]) == int(np.unpackbits(desc[0] ^ desc[1]).sum())
-    nm, self_m, lvl0 = [int(v) for v in lines["init_matches"].split()[::2]]
-    assert self_m == nm and nm > 0.8 * lvl0  # level-0 keypoints re-find themselves
-    assert "its" in lines["ba"] and float(lines["ba"].split()[3]) < 1e-3 * float(lines["ba"].split()[1])
-    # Frame post-processing, PoseOptimization, distinctive descriptors through the C++ adapters
-    fp = swarmmap_amd.FramePostProcessor(synth.EUROC_K, synth.EUROC_DIST)
-    pr = fp.prepare(np.stack([kps["x"], kps["y"]], 1), 752, 480)
-    f = lines["undistorted"].split()
-    assert int(f[0]) == len(kps) and f[1] == _fnv(pr["xy_un"].tobytes())
-    assert [np.float32(v) for v in f[3:7]] == pr["bounds"].tolist()
-    assert int(f[8]) == len(pr["cell_items"]) and f[9] == _fnv(pr["cell_items"].tobytes())
-    p = lines["pose"].split()
-    assert int(p[1]) == 40 and max(abs(float(v)) for v in p[3:6]) < 1e-3  # converges back to the identity pose
-    m = swarmmap_amd.ORBmatcher()
-    idx, _ = m.ComputeDistinctiveDescriptors([0, 3, 3, 8], desc[:8])
-    assert [int(v) for v in lines["distinctive"].split()] == idx.tolist()
+    _w(d, "image", img, np.uint8)
+    _w(d, "scale_factors", sf, np.float32); _w(d, "level_sigma2", sf * sf, np.float32)
+    inv = (1.0 / (sf ** 2)).astype(np.float32)
+    _w(d, "inv_sigma2", inv, np.float32)
+    fr1, mps = synth.make_m1_case(1, 1000, 2000)
+    F1 = _frame(d, "m1f", fr1)
+    for k, t in (("in_view", np.uint8), ("proj_x", np.float32), ("proj_y", np.float32), ("view_cos", np.float32),
+                 ("pred_level", np.int32), ("desc", np.uint8), ("has_obs", np.uint8)):
+        _w(d, "m1_" + k, mps[k], t)
+    fr2, last = synth.make_m2_case(11)
+    F2 = _frame(d, "m2f", fr2)
+    for k, t in (("valid", np.uint8), ("u", np.float32), ("v", np.float32), ("angle", np.float32), ("octave", np.int32),
+                 ("desc", np.uint8), ("has_obs", np.uint8)):
+        _w(d, "m2_" + k, last[k], t)
+    i1, i2, prev = synth.make_m4_case(21, 2000)
+    I1, I2 = _frame(d, "i1", i1), _frame(d, "i2", i2)
+    _w(d, "i_prev", prev, np.float32)
+    kf1, node1, kf2, node2, src = synth.make_bow_case(41, 1000, 1000, p_flip=0.06)
+    kf1["y"] = (kf2["y"][src] + rng.normal(0, 0.8, len(src))).astype(np.float32)
+    kf1["x"] = (kf2["x"][src] + rng.uniform(-30, 30, len(src))).astype(np.float32)
+    for p, kf in (("b1", kf1), ("b2", kf2)):
+        for k, t in (("x", np.float32), ("y", np.float32), ("angle", np.float32), ("desc", np.uint8), ("valid", np.uint8),
+                     ("free", np.uint8)):
+            _w(d, "%s_%s" % (p, k), kf[k], t)
+    _w(d, "b2_octave", kf2["octave"], np.int32)
+    fv1, fv2 = FeatureVector(node1), FeatureVector(node2)
+    for p, fv in (("fv1", fv1), ("fv2", fv2)):
+        _w(d, p + "_node", fv.node_id, np.int32); _w(d, p + "_off", fv.off, np.int32); _w(d, p + "_idx", fv.idx, np.int32)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 1e-6, (3, 3)).astype(np.float32)
+    _w(d, "F12", F12, np.float32)
+    kfr = synth.make_frame_arrays(rng, 1500)
+    kfr["excluded"] = (rng.random(1500) < 0.2).astype(np.uint8)
+    KF = _frame(d, "kf", kfr)
+    q = synth.make_window_queries(51, kfr, 2000, jitter=1.5, th=3.0)
+    q21 = synth.make_window_queries(52, i1, 1500, jitter=1.5, th=3.0)   # points of the second keyframe seen in the first
+    _queries(d, "q", q); _queries(d, "q21", q21)
+    counts = np.concatenate([[0, 1, 2, 3, 64, 130], rng.integers(1, 30, 200)])
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    dd = rng.integers(0, 256, (off[-1], 32)).astype(np.uint8)
+    _w(d, "dd_off", off, np.int32); _w(d, "dd_desc", dd, np.uint8)
+    win = synth.make_ba_case("LBA-S", 7)
+    for k, t in (("Tcw", np.float32), ("fixed", np.uint8), ("intr", np.float32), ("Xw", np.float32), ("edge_pose", np.int32),
+                 ("edge_point", np.int32), ("obs", np.float32), ("inv_sigma2", np.float32)):
+        _w(d, "ba_" + k, win[k], t)
+    pc = synth.make_pose_case(5, 400)
+    for k in ("Tcw", "Xw", "obs", "inv_sigma2"):
+        _w(d, "po_" + k, pc[k], np.float32)
+
+    outp = subprocess.check_output([exe, d, "752", "480"], text=True)
+    L = dict(l.split(" ", 1) for l in outp.strip().splitlines())
+
+    def same(name, arr, dtype):
+        n, h = L[name].split()
+        a = np.ascontiguousarray(arr, dtype)
+        assert int(n) == a.size and h == _fnv(a.tobytes()), name
+
+    # extractor + frame post-processing
+    okps, odesc = oracle.extract(oracle.config(1000), img)
+    n, h = L["keypoints"].split()
+    assert int(n) == len(okps) and h == _fnv(okps.tobytes())
+    same("descriptors", odesc, np.uint8)
+    assert int(L["distance"]) == oracle.descriptor_distance(odesc[0], odesc[1])
+    cam = oracle.camera(synth.EUROC_K, synth.EUROC_DIST)
+    oun = oracle.undistort_keypoints(cam, np.stack([okps["x"], okps["y"]], 1))
+    ob = oracle.image_bounds(cam, 752, 480)
+    same("undistorted", oun, np.float32)
+    assert [np.float32(v) for v in L["bounds"].split()] == ob.tolist()
+    same("grid", oracle.assign_features_to_grid(oun, ob)["cell_items"], np.int32)
+    # the ten matcher routines
+    onm, ok = oracle.search_by_projection_mappoints(F1(), mps, 1.0, 0.8)
+    assert int(L["m1_n"]) == onm > 100; same("m1", ok, np.int32)
+    onm, ok = oracle.search_by_projection_lastframe(F2(), last, 15.0, True)
+    assert int(L["m2_n"]) == onm > 50; same("m2", ok, np.int32)
+    onm, om12, opm = oracle.search_for_initialization(I1(False), I2(False), prev, 100, 0.9, True)
+    assert int(L["m4_n"]) == onm > 100; same("m4", om12, np.int32); same("m4_prev", opm, np.float32)
+    for variant in (0, 1):
+        onm, om2, om1 = oracle.search_by_bow(variant, kf1, fv1, kf2, fv2, 0.7, True)
+        assert int(L["m3_%d_n" % variant]) == onm > 50
+        same("m3_%d_of2" % variant, om2, np.int32); same("m3_%d_of1" % variant, om1, np.int32)
+    onm, om12 = oracle.search_for_triangulation(kf1, fv1, kf2, fv2, F12, (900.0, 240.0), sf, sf * sf, True)
+    assert int(L["m5_n"]) == onm > 100; same("m5", om12, np.int32)
+    bi, bd = oracle.search_window_best(KF(False), q, True, inv)
+    assert int(L["fuse_gate_n"]) == int(((bi >= 0) & (bd <= 50)).sum()) > 100
+    same("fuse_gate_idx", bi, np.int32); same("fuse_gate_dist", bd, np.int32)
+    bi2, bd2 = oracle.search_window_best(KF(False), q, False, inv)
+    assert int(L["fuse_scw_n"]) == int(((bi2 >= 0) & (bd2 <= 50)).sum())
+    same("fuse_scw_idx", bi2, np.int32); same("fuse_scw_dist", bd2, np.int32)
+    # SearchBySim3: both directions + agreement (ORBmatcher.cc:1199-1211), restated over the oracle's window search
+    b1, d1 = oracle.search_window_best(I1(False), q21, False, inv)
+    vn1 = np.where((bi2 >= 0) & (bd2 <= 100), bi2, -1)
+    vn2 = np.where((b1 >= 0) & (d1 <= 100), b1, -1)
+    m12 = np.full(len(vn1), -1, np.int32)
+    for k in range(len(vn1)):
+        if 0 <= vn1[k] < len(vn2) and vn2[vn1[k]] == k:
+            m12[k] = vn1[k]
+    assert int(L["sim3_n"]) == int((m12 >= 0).sum()); same("sim3", m12, np.int32)
+    onm, ok = oracle.search_window_greedy(KF(), q, 50, False)
+    assert int(L["greedy_kf_n"]) == onm > 100; same("greedy_kf", ok, np.int32)
+    onm, ok = oracle.search_window_greedy(KF(), q, 64, True)
+    assert int(L["greedy_f_n"]) == onm > 100; same("greedy_f", ok, np.int32)
+    oidx, _ = oracle.distinctive_descriptors(off, dd)
+    same("distinctive", oidx, np.int32)
+    # Optimizer
+    o = oracle.bundle_adjust(win)
+    f = L["ba"].split()
+    assert float(f[0]) == pytest.approx(o["info"]["chi2_initial"], rel=1e-9)
+    assert float(f[1]) == pytest.approx(o["info"]["chi2_final"], rel=1e-6)
+    assert int(f[2]) == o["info"]["iterations_stage1"] and abs(int(f[3]) - o["info"]["iterations_stage2"]) <= 1
+    raw = np.fromfile(os.path.join(d, "ba_out.bin"), np.float32)
+    nT = o["Tcw"].size
+    assert np.abs(raw[:nT].reshape(o["Tcw"].shape) - o["Tcw"]).max() <= 2e-5
+    assert np.abs(raw[nT:].reshape(o["Xw"].shape) - o["Xw"]).max() <= 2e-4
+    n_out, _ = L["ba_outlier"].split()
+    assert int(n_out) == len(o["outlier"])
+    oni, oT, ooutl, _ = oracle.pose_optimization(pc["Tcw"], pc["intr"], pc["Xw"], pc["obs"], pc["inv_sigma2"])
+    p = L["pose"].split()
+    assert int(p[0]) == oni and np.abs(np.array([float(v) for v in p[1:13]], np.float32) - oT).max() <= 2e-5
+    same("pose_outlier", ooutl, np.uint8)

@@ -43,7 +43,8 @@ def _worker(rank, world, port, q):
         results.append((counts.tolist(), [int(s) for s in sums]))
     # full keyframe records (descriptors + geometry + pose) through the same collective
     from swarmmap_amd.parallel import pack_keyframe_record
-    xr = KeyframeExchange(slot_keypoints=1600)  # 1601 rows x 32 B hold a record of up to 1064 keypoints
+    xr = KeyframeExchange(record_keypoints=1000)  # sized for whole records of up to 1000 keypoints (128 + 48 n bytes)
+    assert xr.slot.numel() >= 128 + 48 * 1000
     for tick, n in enumerate([700, 1 + 300 * rank, 0]):
         def make(r, nn):
             g2 = np.random.default_rng(77 * tick + r)
