@@ -336,7 +336,20 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
 
     if (prof) SO_HIP(hipEventRecord(ex->ev[0], s));
     // ComputePyramid, code/src/ORBextractor.cc:837-853
-    if (!on_device && stride == w) {
+    // host images the device can read in place (pinned by the caller: hipHostMalloc / hipHostRegister / a framework's
+    // pinned allocator) skip the DMA engine altogether; pageable ones take the copy path below
+    static const bool no_ingest = getenv("SWARMORB_NO_INGEST_KERNEL") != nullptr;
+    const uint8_t* visible = nullptr;
+    if (!on_device && stride == w && !no_ingest) {
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, image) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer)
+            visible = static_cast<const uint8_t*>(attr.devicePointer);
+        else
+            (void)hipGetLastError();  // pageable memory: not an error
+    }
+    if (visible) {
+        launch_ingest(visible, w, h, P.lv[0], s);
+    } else if (!on_device && stride == w) {
         // a pitched host -> device copy is split into one DMA per row when the width is not a multiple of four bytes
         // (1241-px KITTI rows: 376 copies, 2.2 ms); one linear upload into a packed landing buffer followed by a
         // device-side repack into the pitched level-0 image costs two enqueues instead

@@ -65,6 +65,8 @@ struct SelectedKp {  // host -> device after the quadtree: level coordinates (RO
 };
 
 // launchers (orb_kernels.hip)
+// host_src: width x height bytes, tightly packed, device-visible (pinned / registered host memory)
+void launch_ingest(const uint8_t* host_src, int w, int h, const LevelDesc& level0, hipStream_t s);
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, hipStream_t s);
 void launch_fast_score(const PyramidParams& p, hipStream_t s);
 void launch_fast_low_count(const PyramidParams& p, int32_t* d_rowcount, hipStream_t s);

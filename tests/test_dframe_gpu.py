@@ -59,6 +59,23 @@ def test_device_frame_equals_extract_undistort_grid(S, oracle, size, K, dist, nf
     g.close(); f.close(); ex.close()
 
 
+@pytest.mark.parametrize("size,nfeat", [(synth.EUROC, 1000), (synth.KITTI, 2000), ((751, 333), 700)])
+def test_pinned_host_image_is_ingested_in_place(S, oracle, size, nfeat):
+    """A host image in pinned memory is read by the ingest kernel straight over PCIe (no DMA, no landing buffer), for
+    row lengths of every alignment; a pageable image takes the copy path.  Both give the oracle's frame."""
+    import torch
+    img = synth.make_canvas(9, size[0], size[1])
+    pinned = torch.from_numpy(img.copy()).pin_memory().numpy()
+    ex = S.ORBextractor(nfeat, 1.2, 8, 20, 7)
+    f = S.DeviceFrame(ex, synth.EUROC_K)
+    k1, u1, d1 = [a.copy() for a in f(pinned)]
+    k2, u2, d2 = [a.copy() for a in f(img)]
+    okps, odesc = oracle.extract(oracle.config(nfeat), img)
+    assert k1.tobytes() == okps.tobytes() and np.array_equal(d1, odesc)
+    assert k2.tobytes() == okps.tobytes() and np.array_equal(d2, odesc) and u1.tobytes() == u2.tobytes()
+    f.close(); ex.close()
+
+
 def test_device_frame_flat_image_and_errors(S):
     ex = S.ORBextractor(500, 1.2, 8, 20, 7)
     f = S.DeviceFrame(ex, synth.EUROC_K)
