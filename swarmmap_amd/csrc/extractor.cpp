@@ -10,6 +10,7 @@
 // the host, between two syncs (quadtree.cpp) - with identical output.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -228,6 +229,21 @@ int allocate(so_extractor* ex, int w, int h) {
     return SO_OK;
 }
 
+// ComputePyramid's resizes: one fused launch, or the chained per-level launches (SWARMORB_CHAINED_PYRAMID, or a
+// configuration the fused kernel cannot hold)
+void launch_pyramid(const PyramidParams& P, hipStream_t s) {
+    // Levels 1 .. first take one launch each; the ones behind them can come out of ONE fused launch
+    // (pyramid_fused_kernel, SWARMORB_PYRAMID_FUSE_FROM=first).  Measured on MI355X (752x480, pyramid stage incl. the
+    // 8 us image copy): all seven levels fused 34.5 us, fused from level 1 / 2 / 3: 30.4 / 29.1 / 28.2 us, seven chained
+    // launches inside the frame's hipGraph 25.3 us - a 2.5 us launch of a wide grid beats a workgroup that walks the
+    // levels one after the other, so the chain stays the default and the fused kernel an option.
+    static const int first_env = getenv("SWARMORB_PYRAMID_FUSE_FROM") ? atoi(getenv("SWARMORB_PYRAMID_FUSE_FROM")) : 99;
+    const int first = std::min(std::max(first_env, 0), P.nlevels - 1);
+    for (int l = 1; l <= first; l++) launch_resize(P.lv[l - 1], P.lv[l], s);
+    if (launch_pyramid_fused(P, first, s)) return;
+    for (int l = first + 1; l < P.nlevels; l++) launch_resize(P.lv[l - 1], P.lv[l], s);
+}
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -366,7 +382,7 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
         if (!ex->graph_exec) {  // every launch argument is fixed once the context is sized: capture the chain once
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
-                for (int l = 1; l < P.nlevels; l++) launch_resize(P.lv[l - 1], P.lv[l], s);
+                launch_pyramid(P, s);
                 launch_fast_score(P, s);
                 launch_fast_low_count(P, ex->d_rowcount, s);
                 launch_emit(P, ex->d_rowcount, ex->d_cands, ex->d_header, ex->h_header_dev, ex->cand_capacity, s);
@@ -393,7 +409,7 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
             return collect_impl(ex, kps, desc, capacity, n_out);
         }
     }
-    for (int l = 1; l < P.nlevels; l++) launch_resize(P.lv[l - 1], P.lv[l], s);
+    launch_pyramid(P, s);
     if (prof) SO_HIP(hipEventRecord(ex->ev[1], s));
     // ComputeKeyPointsOctTree, code/src/ORBextractor.cc:691-744 (all levels batched)
     if (P.total_tiles > 0) {

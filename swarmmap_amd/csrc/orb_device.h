@@ -68,6 +68,9 @@ struct SelectedKp {  // host -> device after the quadtree: level coordinates (RO
 // host_src: width x height bytes, tightly packed, device-visible (pinned / registered host memory)
 void launch_ingest(const uint8_t* host_src, int w, int h, const LevelDesc& level0, hipStream_t s);
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, hipStream_t s);
+// levels first_level+1 .. n-1 from level first_level in one launch (bit-identical to chained launch_resize); false if this configuration does
+// not fit the kernel's LDS boxes - the caller then chains launch_resize
+bool launch_pyramid_fused(const PyramidParams& p, int first_level, hipStream_t s);
 void launch_fast_score(const PyramidParams& p, hipStream_t s);
 void launch_fast_low_count(const PyramidParams& p, int32_t* d_rowcount, hipStream_t s);
 // records go to `cands` (device memory for the device quadtree, or host-mapped memory for the host quadtree);

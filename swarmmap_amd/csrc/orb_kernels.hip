@@ -13,6 +13,9 @@
 //   src/ORBextractor.cc:821-855   pyramid (level l from level l-1), Gaussian 7x7 sigma 2
 #include "orb_device.h"
 
+#include <algorithm>
+#include <cmath>
+
 namespace so {
 
 // ------------------------------------------------------------------------------------------------
@@ -62,6 +65,145 @@ void launch_resize(const LevelDesc& s, const LevelDesc& d, hipStream_t st) {
     dim3 grid((d.w + 255) / 256, (d.h + 3) / 4);
     hipLaunchKernelGGL(resize_kernel, grid, block, 0, st, s.img, s.w, s.h, s.pitch, d.img, d.w, d.h, d.pitch, fx,
                        fy);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole pyramid in ONE launch (ORBextractor::ComputePyramid, code/src/ORBextractor.cc:837-853: level l is resized from
+// level l-1, so seven dependent launches of ~4.5 us each used to be 33 us per frame for 1.8 MB of traffic).
+// Every level is cut into the same ntx x nty grid of tiles; workgroup (i, j) OWNS tile (i, j) of every level and writes
+// exactly that to HBM.  To get there it stages, top level first, the bounding box each level must provide -
+// need[l] = own[l] united with the bilinear footprint of need[l+1] - loads need[0] of the level-0 image into LDS and
+// walks down the levels in LDS, ping-ponging between two buffers; pixels outside own[l] are recomputed by the
+// neighbours that own them (the halo is ~1.3x the owned area at level 0).  Same operations in the same order as
+// resize_kernel: bit-identical levels.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPyrTile = 16;   // tile edge at the coarsest level
+constexpr int kPyrBuf = 96;    // LDS region edge (pixels) the kernel can hold per level
+
+struct PyramidFusedArgs {
+    float fx[kMaxLevels], fy[kMaxLevels];  // level l from l-1: source coordinate = destination coordinate * f[l]
+    int ntx, nty;
+    int first;  // levels first+1 .. n-1 are produced from level `first` (already in HBM)
+};
+
+__device__ __forceinline__ void pyr_footprint(int a0, int a1, float f, int smax, int& s0, int& s1) {
+    // source columns (rows) the destination span [a0, a1) reads: floor(a f) .. min(floor((a1-1) f) + 1, smax)
+    s0 = min((int)floorf((float)a0 * f), smax);
+    s1 = min(min((int)floorf((float)(a1 - 1) * f), smax) + 1, smax) + 1;
+}
+
+__global__ __launch_bounds__(256) void pyramid_fused_kernel(PyramidParams P, PyramidFusedArgs A) {
+    __shared__ uint8_t buf[2][kPyrBuf * kPyrBuf];
+    __shared__ int s_box[kMaxLevels][4];  // need[l]: x0, y0, x1, y1 (exclusive)
+    const int tid = threadIdx.x;
+    const int ti = blockIdx.x % A.ntx, tj = blockIdx.x / A.ntx;
+    const int nl = P.nlevels;
+    if (tid == 0) {
+        int nx0 = 0, ny0 = 0, nx1 = 0, ny1 = 0;
+        for (int l = nl - 1; l >= A.first; l--) {
+            const LevelDesc& L = P.lv[l];
+            int x0 = (int)((long long)ti * L.w / A.ntx), x1 = (int)((long long)(ti + 1) * L.w / A.ntx);
+            int y0 = (int)((long long)tj * L.h / A.nty), y1 = (int)((long long)(tj + 1) * L.h / A.nty);
+            if (l == A.first) x1 = x0, y1 = y0;  // the source level is only read: its box is the footprint alone
+            if (l < nl - 1 && nx1 > nx0 && ny1 > ny0) {  // footprint of the coarser level's box in this one
+                int fx0, fx1, fy0, fy1;
+                pyr_footprint(nx0, nx1, A.fx[l + 1], L.w - 1, fx0, fx1);
+                pyr_footprint(ny0, ny1, A.fy[l + 1], L.h - 1, fy0, fy1);
+                if (x1 > x0 && y1 > y0) {
+                    x0 = min(x0, fx0); x1 = max(x1, fx1); y0 = min(y0, fy0); y1 = max(y1, fy1);
+                } else {
+                    x0 = fx0; x1 = fx1; y0 = fy0; y1 = fy1;
+                }
+            }
+            s_box[l][0] = x0; s_box[l][1] = y0; s_box[l][2] = x1; s_box[l][3] = y1;
+            nx0 = x0; ny0 = y0; nx1 = x1; ny1 = y1;
+        }
+    }
+    __syncthreads();
+    {   // the needed box of the source level into LDS
+        const LevelDesc& L = P.lv[A.first];
+        const int x0 = s_box[A.first][0], y0 = s_box[A.first][1], bw = s_box[A.first][2] - x0, bh = s_box[A.first][3] - y0;
+        for (int i = tid; i < bw * bh; i += 256) {
+            const int r = i / bw, c = i - r * bw;
+            buf[A.first & 1][r * kPyrBuf + c] = L.img[(size_t)(y0 + r) * L.pitch + x0 + c];
+        }
+    }
+    __syncthreads();
+    for (int l = A.first + 1; l < nl; l++) {
+        const LevelDesc& S = P.lv[l - 1];
+        const LevelDesc& D = P.lv[l];
+        const uint8_t* src = buf[(l - 1) & 1];
+        uint8_t* dst = buf[l & 1];
+        const int sx0 = s_box[l - 1][0], sy0 = s_box[l - 1][1];
+        const int dx0 = s_box[l][0], dy0 = s_box[l][1], bw = s_box[l][2] - dx0, bh = s_box[l][3] - dy0;
+        const int ox0 = (int)((long long)ti * D.w / A.ntx), ox1 = (int)((long long)(ti + 1) * D.w / A.ntx);
+        const int oy0 = (int)((long long)tj * D.h / A.nty), oy1 = (int)((long long)(tj + 1) * D.h / A.nty);
+        const float fx = A.fx[l], fy = A.fy[l];
+        for (int i = tid; i < bw * bh; i += 256) {
+            const int r = i / bw, c = i - r * bw;
+            const int x = dx0 + c, y = dy0 + r;
+            const float src_y = (float)y * fy;
+            const int y1 = (int)floorf(src_y);
+            const int y2 = y1 + 1;
+            const int y2r = min(y2, S.h - 1);
+            const float wy2 = (float)y2 - src_y;
+            const float wy1 = src_y - (float)y1;
+            const float src_x = (float)x * fx;
+            int x1 = (int)floorf(src_x);
+            x1 = min(x1, S.w - 1);
+            const int x2 = x1 + 1;
+            const int x2r = min(x2, S.w - 1);
+            const float wx2 = (float)x2 - src_x;
+            const float wx1 = src_x - (float)x1;
+            const uint8_t* r1 = src + (y1 - sy0) * kPyrBuf - sx0;
+            const uint8_t* r2 = src + (y2r - sy0) * kPyrBuf - sx0;
+            float out = (float)r1[x1] * (wx2 * wy2);
+            out = out + (float)r1[x2r] * (wx1 * wy2);
+            out = out + (float)r2[x1] * (wx2 * wy1);
+            out = out + (float)r2[x2r] * (wx1 * wy1);
+            int v = (int)__builtin_rintf(out);
+            v = min(max(v, 0), 255);
+            dst[r * kPyrBuf + c] = (uint8_t)v;
+            if (x >= ox0 && x < ox1 && y >= oy0 && y < oy1) D.img[(size_t)y * D.pitch + x] = (uint8_t)v;
+        }
+        __syncthreads();
+    }
+}
+
+// false: the boxes of this configuration do not fit the kernel's LDS regions (the caller chains resize launches)
+bool launch_pyramid_fused(const PyramidParams& P, int first, hipStream_t st) {
+    const int nl = P.nlevels;
+    if (nl - first < 2) return true;
+    PyramidFusedArgs A{};
+    A.first = first;
+    for (int l = 1; l < nl; l++) {
+        A.fx[l] = (float)(1.0 / ((double)P.lv[l].w / (double)P.lv[l - 1].w));
+        A.fy[l] = (float)(1.0 / ((double)P.lv[l].h / (double)P.lv[l - 1].h));
+    }
+    const LevelDesc& top = P.lv[nl - 1];
+    A.ntx = (top.w + kPyrTile - 1) / kPyrTile;
+    A.nty = (top.h + kPyrTile - 1) / kPyrTile;
+    // largest box over all tiles and levels, with the kernel's own arithmetic (worst tile = any: sizes differ by 1)
+    for (int tj = 0; tj < A.nty; tj += (A.nty > 1 ? A.nty - 1 : 1))
+        for (int ti = 0; ti < A.ntx; ti += (A.ntx > 1 ? A.ntx - 1 : 1)) {
+            int nx0 = 0, ny0 = 0, nx1 = 0, ny1 = 0;
+            for (int l = nl - 1; l >= first; l--) {
+                const LevelDesc& L = P.lv[l];
+                int x0 = (int)((long long)ti * L.w / A.ntx), x1 = (int)((long long)(ti + 1) * L.w / A.ntx);
+                int y0 = (int)((long long)tj * L.h / A.nty), y1 = (int)((long long)(tj + 1) * L.h / A.nty);
+                if (l < nl - 1) {
+                    const int fx0 = std::min((int)floorf((float)nx0 * A.fx[l + 1]), L.w - 1);
+                    const int fx1 = std::min(std::min((int)floorf((float)(nx1 - 1) * A.fx[l + 1]), L.w - 1) + 1, L.w - 1) + 1;
+                    const int fy0 = std::min((int)floorf((float)ny0 * A.fy[l + 1]), L.h - 1);
+                    const int fy1 = std::min(std::min((int)floorf((float)(ny1 - 1) * A.fy[l + 1]), L.h - 1) + 1, L.h - 1) + 1;
+                    x0 = std::min(x0, fx0); x1 = std::max(x1, fx1); y0 = std::min(y0, fy0); y1 = std::max(y1, fy1);
+                }
+                if (x1 - x0 + 2 > kPyrBuf || y1 - y0 + 2 > kPyrBuf) return false;
+                nx0 = x0; ny0 = y0; nx1 = x1; ny1 = y1;
+            }
+        }
+    hipLaunchKernelGGL(pyramid_fused_kernel, dim3(A.ntx * A.nty), dim3(256), 0, st, P, A);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -190,7 +332,8 @@ __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
     // NMS at the high threshold: each wave covers two tile rows per round -> one ballot = two bitmap words
     const int lane = tid & 63, wave = tid >> 6;
     unsigned long long keep[4];
-    int any = 0;
+    int any = 0, my_score[4];
+    bool my_kp[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int row = 8 * k + 2 * wave + (lane >> 5), col = lane & 31;
@@ -199,18 +342,34 @@ __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
         const int m = max(max(max((int)q[-kScPitch - 1], (int)q[-kScPitch]), max((int)q[-kScPitch + 1], (int)q[-1])),
                           max(max((int)q[1], (int)q[kScPitch - 1]), max((int)q[kScPitch], (int)q[kScPitch + 1])));
         const bool kp = (s >= th_high) && (s > m);
+        my_kp[k] = kp;
+        my_score[k] = s;
         keep[k] = __ballot(kp);
         any |= (keep[k] != 0ull);
     }
     const int has1 = __syncthreads_or(any);
 
-    // u8 score tile -> global (aligned dword per thread)
+    // u8 score tile -> global (aligned dword per thread).  A tile that kept a high-threshold corner is final: later
+    // stages only ever read (a) its outer ring - the halo of an empty neighbour's low-threshold pass, which looks at
+    // nothing but scores >= th_high there - and (b) the scores of its kept pixels (candidate records).  Only an
+    // empty tile needs its whole score tile (its own low-threshold pass).  Writing ring + kept pixels instead of the
+    // tile cuts the score-map traffic of a textured frame to a third.
     {
         const int row = tid >> 3, c4 = (tid & 7) * 4;
-        const uint8_t* q = ssc + (row + 1) * kScPitch + (c4 + 1);
-        const uint32_t v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-        *reinterpret_cast<uint32_t*>(L.score + (size_t)(ty * kTile + row + 1) * L.spitch + kScoreXOff + tx * kTile +
-                                     c4) = v;
+        if (!has1 || row == 0 || row == kTile - 1 || c4 == 0 || c4 == kTile - 4) {
+            const uint8_t* q = ssc + (row + 1) * kScPitch + (c4 + 1);
+            const uint32_t v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+            *reinterpret_cast<uint32_t*>(L.score + (size_t)(ty * kTile + row + 1) * L.spitch + kScoreXOff + tx * kTile +
+                                         c4) = v;
+        }
+    }
+    if (has1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (my_kp[k]) {
+                const int row = 8 * k + 2 * wave + (lane >> 5), col = lane & 31;
+                L.score[(size_t)(ty * kTile + row + 1) * L.spitch + kScoreXOff + tx * kTile + col] = (uint8_t)my_score[k];
+            }
     }
     if (tid == 0) L.tileflag[t] = (uint8_t)has1;
     if (lane == 0) {

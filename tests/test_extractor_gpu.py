@@ -180,3 +180,29 @@ def test_errors(S):
     assert t.GetLevels() == 8 and abs(t.GetScaleFactors()[7] - 1.2 ** 7) < 1e-5
     assert t.GetFeaturesPerLevel().tolist() == [217, 181, 151, 126, 105, 87, 73, 60]
     t.close()
+
+
+@pytest.mark.parametrize("fuse_from", [0, 2])
+def test_fused_pyramid_option_is_bit_identical(fuse_from):
+    """pyramid_fused_kernel (SWARMORB_PYRAMID_FUSE_FROM, read once per process: hence the child process) produces the
+    same level bytes as the chained resize launches, i.e. as the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, swarmmap_amd\n"
+            "from swarmmap_amd import synth\n"
+            "from oracle import oracle_py as orc\n"
+            "for size, nf in ((synth.EUROC, 1000), (synth.KITTI, 2000), ((377, 241), 500)):\n"
+            "    img = synth.make_canvas(4, size[0], size[1])\n"
+            "    ex = swarmmap_amd.ORBextractor(nf, 1.2, 8, 20, 7)\n"
+            "    k, d = ex(img)\n"
+            "    ok, od, _, lv = orc.extract(orc.config(nf), img, debug=True)\n"
+            "    assert all(np.array_equal(ex.level(l), lv[l]) for l in range(8))\n"
+            "    assert k.tobytes() == ok.tobytes() and np.array_equal(d, od)\n"
+            "    ex.close()\n"
+            "print('ok')\n" % root)
+    env = dict(os.environ, SWARMORB_PYRAMID_FUSE_FROM=str(fuse_from))
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True)
+    assert out.strip().endswith("ok")
