@@ -10,8 +10,8 @@ import re
 import sys
 
 KEEP = ("fast_score_kernel", "fast_low_count_kernel", "describe_qt_kernel", "resize_kernel", "topk_window_kernel",
-        "stage_in_kernel", "pose_opt_lds_kernel", "ba_solve_la_kernel", "ba_solve_mfma_kernel", "ba_schur_gather_kernel", "ba_build_kernel",
-        "quadtree_kernel")
+        "stage_in_kernel", "pose_opt_lds_kernel", "pose_opt_reg_kernel", "ba_solve_la_kernel", "ba_solve_mfma_kernel",
+        "ba_schur_gather_kernel", "ba_build_kernel", "quadtree_kernel", "frame_prepare_kernel", "ingest_kernel", "emit_kernel")
 
 
 def load(path):
@@ -25,7 +25,7 @@ def load(path):
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (one counter per pass, no other trace domain) of "
-                 "`bench.py --steps 100 --warmup 10 --no-cpu-baseline` on MI355X (tools/profile_round.sh); "
+                 "`bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-configs` on MI355X (tools/profile_round.sh); "
                  "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH_SIZE x2 per the calibration in "
                  "profiles/r1_pmc/cal_FETCH_SIZE_summary.csv"}
 for k in KEEP:
