@@ -373,9 +373,14 @@ def main():
     dev = local_rank if distributed else 0
     torch.cuda.set_device(dev)
 
+    import ctypes
+    libc = ctypes.CDLL(None)
+
     def barrier():
         if distributed:
             torch.distributed.barrier()
+            libc.fflush(None)  # RCCL prints a version banner through C stdio when a communicator comes up: out it goes
+                               # now, on every rank, so that rank 0's JSON line stays the last line of the job's stdout
         torch.cuda.synchronize()
 
     euroc = args.size == "euroc"
@@ -472,8 +477,7 @@ def main():
             out["configs"] = cfgs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, K, dist, nfeatures, lba_window, size)
-        import ctypes
-        ctypes.CDLL(None).fflush(None)  # C-side stdout (RCCL's version banner) goes out first: the JSON line is the last line
+        libc.fflush(None)  # C-side stdout (RCCL's version banner) goes out first: the JSON line is the last line
         print(json.dumps(out), flush=True)
     if xchg is not None:
         xchg.close()
