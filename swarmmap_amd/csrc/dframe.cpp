@@ -78,6 +78,7 @@ int submit_impl(so_dframe* f, const uint8_t* image, bool on_device, int w, int h
     if (rc) return rc;
     f->generation++;
     f->in_flight = true;
+    f->launched = false;
     if (!image || w <= 0 || h <= 0) return SO_OK;  // empty frame: collect hands out n = 0
     ExtractorDeviceView V;
     if ((rc = extractor_device_view(f->ex, &V))) return rc;
@@ -122,6 +123,7 @@ int submit_impl(so_dframe* f, const uint8_t* image, bool on_device, int w, int h
     a.header_host = reinterpret_cast<int32_t*>(f->h_block_dev + ((uint8_t*)f->h_header - f->h_block));
     launch_frame_prepare(a, V.stream);
     SO_HIP(hipGetLastError());
+    f->launched = true;
     return SO_OK;
 }
 
@@ -213,9 +215,9 @@ int so_dframe_collect(so_dframe* f, so_keypoint* keypoints, float* xy_un, uint8_
     const int rc = so_extractor_collect(f->ex, keypoints, descriptors, capacity, &n);  // waits for the stream
     if (rc) return rc;
     f->in_flight = false;
-    if (!f->allocated || n == 0) {  // empty image / no keypoints: nothing ran behind the extractor
+    if (!f->allocated || !f->launched) {  // an empty image: nothing ran behind the extractor
         f->n = f->n_inside = 0;
-        f->ready = f->allocated;
+        f->ready = f->allocated;  // (bounds are those of the handle's earlier frames: they depend on the camera only)
         *n_out = 0;
         return SO_OK;
     }

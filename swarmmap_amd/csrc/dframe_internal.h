@@ -27,6 +27,7 @@ struct so_dframe {
     float scale[8] = {0};
     bool allocated = false;
     bool in_flight = false;
+    bool launched = false;  // the frame in flight has a prepare kernel behind it (false for an empty image)
     bool ready = false;  // collected: n / n_inside / bounds and the host mirrors are valid
     uint64_t generation = 0;  // bumped by every submit (the matcher's "same frame as before" check)
     // device

@@ -79,6 +79,8 @@ struct TrackQuerySrc {
     const uint8_t* skip;         // local-map search: 1 = not searched (already matched in this frame / bad); may be null
     const int8_t* last_octave;   // last-frame search: lastFrame.mvKeys[i].octave
     uint8_t* in_view_out;        // local-map search: mbTrackInView per query (may be null)
+    uint8_t* count8_out;         // candidates per query clamped to 255 (0: inactive / none): the one plane the host's
+                                 // resolve scans for every query (may be null)
     float Tcw[12];
     float fx, fy, cx, cy;
     float bounds[4];             // mnMinX, mnMaxX, mnMinY, mnMaxY
@@ -86,6 +88,7 @@ struct TrackQuerySrc {
     int nlevels;
     float th;
     float cos_limit, log_scale_factor;  // local-map search
+    int second_best_bound;       // local-map search: ceil(TH_HIGH / nn_ratio), candidates beyond it cannot matter
     int n_slots;                 // size of the table (slots beyond it are treated as "no map point")
     // Small gates travel in the kernel arguments instead of a staged buffer (no copy launch in front of the search):
     // bit c of excl_bits = candidate POSITION c is not eligible (bound on entry / taken); bit i of skip_bits = query i

@@ -154,6 +154,9 @@ __device__ __forceinline__ MatchQuery track_query_last(const TrackQuerySrc& T, i
     Q.min_level = oct - 1;
     Q.max_level = oct + 1;
     Q.active = 1;
+    // a candidate farther than TH_HIGH can never be bound (ORBmatcher.cc:1311) and, there being no ratio test in this
+    // search, never influences which one is: it need not travel to the host
+    Q.max_dist = 100;
     return Q;
 }
 
@@ -209,6 +212,9 @@ __device__ __forceinline__ MatchQuery track_query_local(const TrackQuerySrc& T, 
     Q.min_level = nScale - 1;
     Q.max_level = nScale;
     Q.active = 1;
+    // the best candidate must be within TH_HIGH = 100 (ORBmatcher.cc:107); a second best beyond 100 / ratio can never
+    // make the ratio test fail (bestDist <= 100 < ratio * second), so candidates beyond that bound are dropped here
+    Q.max_dist = T.second_best_bound;
     return Q;
 }
 
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
     }
     if (!Q.active) {
         if (lane == 0) out_count[qi] = 0;
+        if (MODE >= 2 && T.count8_out && lane == 0) T.count8_out[q_first + qi] = 0;
         for (int k = lane; k < K; k += 64) out_keys[(size_t)qi * kk + k * kq] = 0xFFFFFFFFu;
         return;
     }
@@ -277,6 +284,7 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
         }
     }
     if (lane == 0) out_count[qi] = m;
+    if (MODE >= 2 && T.count8_out && lane == 0) T.count8_out[q_first + qi] = (uint8_t)min(m, 255);
     if (m <= kListCap) {
         // K smallest keys of the list: round k = min over keys greater than the previous minimum (keys are unique)
         uint32_t prev = 0;

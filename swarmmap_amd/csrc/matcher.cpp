@@ -1563,6 +1563,7 @@ int rerun_track(so_matcher* m, TrackQuerySrc T, int mode, int qi, const std::vec
         m->dirty_from = SIZE_MAX;
     }
     T.in_view_out = nullptr;
+    T.count8_out = nullptr;
     T.keys_soa = 0;
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
     launch_topk_track(frame_dev(m), T, mode, qi, 1, K, (uint32_t*)m->h_rout.dev, (int32_t*)((uint8_t*)m->h_rout.dev + 256), s);
@@ -1618,9 +1619,14 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
     TrackQuerySrc T = track_src(m, cur, map, Tcw12, th);
     T.last_octave = last->d_octave;
     const TrackGates G{last_slot, 0, nullptr, cur_excluded};
+    // per-query candidate counts as one byte each behind the K-lists: the only plane the resolve reads for every query
+    const size_t keys_bytes2 = align256(sizeof(uint32_t) * (size_t)n_last * K);
+    const size_t c8_off = align256(keys_bytes2 + sizeof(int32_t) * (size_t)n_last);
+    if ((rc = m->h_out.ensure(c8_off + (size_t)n_last))) return rc;
+    T.count8_out = (uint8_t*)m->h_out.dev + c8_off;
     if ((rc = run_topk_track(m, T, 2, n_last, K, G))) return rc;
     const uint32_t* keys = (const uint32_t*)m->h_keys.p;
-    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    const uint8_t* cnt = (const uint8_t*)m->h_out.p + c8_off;
     auto has_obs = [&](int i) { return !slot_has_obs || slot_has_obs[i]; };
     std::vector<int32_t> gate;
     std::vector<int> rot_item, rot_b;
@@ -1697,11 +1703,18 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
     TrackQuerySrc T = track_src(m, cur, map, Tcw12, th);
     T.cos_limit = viewing_cos_limit;
     T.log_scale_factor = log_scale_factor;
+    {   // smallest integer d with nn_ratio * d >= TH_HIGH in the float arithmetic of the ratio test (ORBmatcher.cc:112)
+        int d = TH_HIGH;
+        while (d < 256 && (float)TH_HIGH > nn_ratio * (float)d) d++;
+        T.second_best_bound = d;
+    }
     // mbTrackInView of every query comes back through host-mapped memory behind the K-lists
     const size_t keys_bytes = align256(sizeof(uint32_t) * (size_t)n_local * K);
     const size_t view_off = align256(keys_bytes + sizeof(int32_t) * (size_t)n_local);
-    if ((rc = m->h_out.ensure(view_off + (size_t)n_local))) return rc;
+    const size_t c8_off = align256(view_off + (size_t)n_local);
+    if ((rc = m->h_out.ensure(c8_off + (size_t)n_local))) return rc;
     T.in_view_out = (uint8_t*)m->h_out.dev + view_off;
+    T.count8_out = (uint8_t*)m->h_out.dev + c8_off;
     const auto tt1 = std::chrono::steady_clock::now();
     const TrackGates G{local_slot, local_slot ? 0 : first_slot, skip, cur_excluded};
     if ((rc = run_topk_track(m, T, 3, n_local, K, G))) return rc;
@@ -1710,12 +1723,12 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
     if (in_view) memcpy(in_view, view, (size_t)n_local);
     if (cur->n == 0) return SO_OK;
     const uint32_t* keys = (const uint32_t*)m->h_keys.p;
-    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    const uint8_t* cnt = (const uint8_t*)m->h_out.p + c8_off;  // 0 for a point that is not in view
     auto has_obs = [&](int i) { return !slot_has_obs || slot_has_obs[i]; };
     std::vector<int32_t> gate;
     int nm = 0;
     for (int i = 0; i < n_local; i++) {
-        if (!view[i] || cnt[(size_t)i] == 0) continue;
+        if (cnt[(size_t)i] == 0) continue;
         Entry e[2];
         int found = 0, walked = 0;
         for (; walked < K && found < 2; walked++) {

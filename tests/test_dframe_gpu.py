@@ -273,3 +273,82 @@ def test_reuse_flag_does_not_leak_to_another_frame(S, oracle):
     onm, ok2m = oracle.search_by_projection_mappoints(F1, mps1, 1.0, 0.8)
     assert nm == onm and np.array_equal(k2m, ok2m)
     m.close()
+
+
+def test_large_frame_and_large_local_map_take_the_staged_paths(S, oracle):
+    """5000 features per frame: the extractor places DistributeOctTree on the host (level quota > 1020), the
+    device-resident frame then reads the host-mapped results, and more than 4096 candidates / 16384 queries make the
+    tracking searches stage their gates with a copy kernel instead of carrying them in the kernel arguments."""
+    rng = np.random.default_rng(71)
+    img = synth.make_canvas(8, 1241, 376)
+    ex = S.ORBextractor(5000, 1.2, 8, 20, 7)
+    cur = S.DeviceFrame(ex, synth.KITTI_K)
+    ck, cxy, cd = [a.copy() for a in cur(img)]
+    assert not ex.quadtree_on_device and len(ck) > 4200
+    okps, odesc = oracle.extract(oracle.config(5000), img)
+    assert ck.tobytes() == okps.tobytes() and np.array_equal(cd, odesc)
+    sf = ex.GetScaleFactors()
+    F = FrameView(cxy[:, 0], cxy[:, 1], ck["octave"], ck["angle"], cd, cur.bounds, sf)
+    Tc = _pose(rng)
+    Xw, normal, mx, mn, md = _make_map(rng, cxy, ck, cd, synth.KITTI_K, Tc, n_extra=500)
+    rep = 4  # 4 x ~5000 map points: more than 16384 queries
+    Xw = np.concatenate([Xw + rng.normal(0, 0.003, Xw.shape).astype(np.float32) for _ in range(rep)])
+    normal = np.tile(normal, (rep, 1)); mx = np.tile(mx, rep); mn = np.tile(mn, rep)
+    md = np.concatenate([synth.flip_bits(rng, md, 0.03) for _ in range(rep)])
+    assert len(Xw) > 16384
+    dmap = S.DeviceMap()
+    dmap.append(Xw, normal, mx, mn, md)
+    excluded = (rng.random(len(ck)) < 0.3).astype(np.uint8)
+    F.excluded = excluded
+    skip = (rng.random(len(Xw)) < 0.1).astype(np.uint8)
+    cam = oracle.camera(synth.KITTI_K)
+    fr = oracle.is_in_frustum(cam, cur.bounds, Tc, Xw, normal, mx, mn, 0.5, LOG_SF, 8)
+    in_view = fr["in_view"] & (1 - skip)
+    mps = dict(in_view=in_view, proj_x=fr["proj_x"], proj_y=fr["proj_y"], view_cos=fr["view_cos"], pred_level=fr["pred_level"],
+               desc=md, has_obs=np.ones(len(Xw), np.uint8))
+    m = S.ORBmatcher(0.8, True)
+    nm, k2m, view = dfm.search_local_map(m, cur, dmap, Tc, len(Xw), 1.0, 0.5, LOG_SF, skip=skip, excluded=excluded)
+    onm, ok2m = oracle.search_by_projection_mappoints(F, mps, 1.0, 0.8)
+    assert np.array_equal(view, in_view) and nm == onm > 500 and np.array_equal(k2m, ok2m)
+    # motion-model search against itself as "last frame" (more than 4096 candidates: staged gate)
+    last = S.DeviceFrame(ex, synth.KITTI_K)
+    lk, lxy, ld = [a.copy() for a in last(img)]
+    slot = np.where(rng.random(len(lk)) < 0.8, np.arange(len(lk)), -1).astype(np.int32)
+    valid, u, v = oracle.project_last_frame(cam, cur.bounds, Tc, Xw[np.maximum(slot, 0)], slot >= 0)
+    lastd = dict(valid=valid, u=u, v=v, octave=lk["octave"], angle=lk["angle"], desc=md[np.maximum(slot, 0)],
+                 has_obs=np.ones(len(lk), np.uint8))
+    m2 = S.ORBmatcher(0.9, True)
+    nm, k2l = dfm.search_last_frame(m2, cur, last, dmap, Tc, slot, 15.0, excluded=excluded)
+    onm, ok2l = oracle.search_by_projection_lastframe(F, lastd, 15.0, True)
+    assert nm == onm > 500 and np.array_equal(k2l, ok2l)
+    m.close(); m2.close(); dmap.close(); last.close(); cur.close(); ex.close()
+
+
+def test_tracking_searches_on_empty_inputs(S):
+    """No map, no local points, a frame without keypoints, a last frame without map points: every combination
+    returns zero matches and touches nothing it should not."""
+    ex = S.ORBextractor(500, 1.2, 8, 20, 7)
+    full, flat = S.DeviceFrame(ex, synth.EUROC_K), S.DeviceFrame(ex, synth.EUROC_K)
+    kps, _, _ = full(synth.make_canvas(2, 376, 240))
+    k0, _, _ = flat(np.full((240, 376), 90, np.uint8))
+    assert len(k0) == 0 and len(kps) > 100
+    dmap = S.DeviceMap()
+    T = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
+    m = S.ORBmatcher(0.8, True)
+    nm, k2m, view = dfm.search_local_map(m, full, dmap, T, 0, 1.0, 0.5, LOG_SF)           # empty map
+    assert nm == 0 and np.all(k2m == -1) and len(view) == 0
+    nm, k2l = dfm.search_last_frame(m, full, full, dmap, T, np.full(len(kps), -1, np.int32), 15.0)  # nothing to project
+    assert nm == 0 and np.all(k2l == -1)
+    X = np.array([[-0.5, -0.3, 3.0]], np.float32)  # projects to (290, 202): inside the 376 x 240 image
+    dmap.append(X, np.array([[0, 0, 1.0]], np.float32), np.array([10.0], np.float32), np.array([0.1], np.float32),
+                np.zeros((1, 32), np.uint8))
+    nm, k2m, view = dfm.search_local_map(m, flat, dmap, T, 1, 1.0, 0.5, LOG_SF)            # a frame without keypoints
+    assert nm == 0 and len(k2m) == 0 and view[0] == 1                                       # ... still sees the point
+    nm, k2l = dfm.search_last_frame(m, flat, full, dmap, T, np.zeros(len(kps), np.int32), 15.0)
+    assert nm == 0 and len(k2l) == 0
+    nm, k2l = dfm.search_last_frame(m, full, flat, dmap, T, np.zeros(0, np.int32), 15.0)    # an empty last frame
+    assert nm == 0 and np.all(k2l == -1)
+    slots = np.full(len(kps), 7, np.int32)  # slots beyond the table are "no map point", not a fault
+    nm, k2l = dfm.search_last_frame(m, full, full, dmap, T, slots, 15.0)
+    assert nm == 0
+    m.close(); dmap.close(); full.close(); flat.close(); ex.close()
