@@ -117,6 +117,45 @@ def cpu_baseline(frames, K, dist, nfeatures, lba_window, size, budget_s=20.0):
                       % (n, size[0], size[1], nfeatures, lm.n, LBA_EVERY, os.cpu_count())}
 
 
+def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, barrier, agents):
+    """A agents of one GPU in lockstep on this thread (so_fleet_run).  Same return values as run_stream."""
+    from swarmmap_amd.replay import private_streams
+    w, h = size
+    n_frames = warmup + steps + 2
+    private_streams(True)
+    fleet, keep = [], []
+    for a in range(agents):
+        stream = synth.FrameStream(seed=seed + 97 * a, size=size, K=K, dist=dist)
+        block, frames = pinned_frames(stream, n_frames)
+        keep.append((block, frames))
+        rp = Replay(dev, w, h, nfeatures, LBA_EVERY, K, dist, plane_z=PLANE_Z, local_keyframes=LOCAL_KEYFRAMES, third_pose=True)
+        rp.set_frames([block.data_ptr() + i * w * h for i in range(n_frames)], on_device=False)
+        rp.set_window(lba_window)
+        rp.preallocate()
+        rp.prime(0)
+        fleet.append(rp)
+    private_streams(False)
+    Replay.fleet_run(fleet, 0, warmup, False)
+    for rp in fleet:
+        rp.drain()
+        rp.set_profiling(False)
+    barrier()
+    t0 = time.perf_counter()
+    Replay.fleet_run(fleet, warmup, steps, True)
+    for rp in fleet:
+        rp.drain()  # every queued window is optimised inside the timed region
+    barrier()
+    dt = time.perf_counter() - t0
+    results = []
+    for rp in fleet:
+        rp.finish()
+        results.append((rp.stats(), rp.candidates_total(), rp.log()))
+        rp.close()
+    stats = {k: sum(r[0][k] for r in results) / agents for k in results[0][0] if k != "stages"}
+    stats.update({"n_xchg": 0, "xchg_ms": 0.0})
+    return dt, stats, results[0][1], keep[0][1], results[0][2]
+
+
 def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, barrier, agents=1, xchg=None,
                exchange_every=20, m1=None):
     """Timed region of the per-frame path on one GPU.  Returns (dt seconds, per-agent stats, candidate count, frames)."""
@@ -356,6 +395,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the configs[3] / configs[4] sub-records (KITTI-sized stream, LBA-S/M/L, global BA)")
+    ap.add_argument("--lockstep", action="store_true",
+                    help="with --agents-per-gpu A > 1: ONE thread drives the A agents frame by frame (so_fleet_run: searches "
+                         "of all agents in flight together, PoseOptimization of all agents in one launch) instead of A "
+                         "independent tracking threads")
     ap.add_argument("--agents-per-gpu", type=int, default=1,
                     help="run this many independent agents (tracking + local-mapping thread pairs, own contexts and "
                          "streams) on each GPU; value stays the aggregate frames/s over all agents")
@@ -396,8 +439,12 @@ def main():
         from swarmmap_amd.exchange import DeviceExchange
         xchg = DeviceExchange.from_process_group(dev, nfeatures + 24)
 
-    dt, st, n_cand, frames, _ = run_stream(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
-                                           lba_window, barrier, A, xchg, args.exchange_every, m1)
+    if args.lockstep and A > 1:
+        dt, st, n_cand, frames, _ = run_fleet(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
+                                              lba_window, barrier, A)
+    else:
+        dt, st, n_cand, frames, _ = run_stream(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
+                                               lba_window, barrier, A, xchg, args.exchange_every, m1)
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -435,7 +482,8 @@ def main():
             "value": steps * world * A / dt, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (extract, match) + f64 (PoseOptimization, local BA)", "data": "synthetic",
-            "host_loop": "c++ (swarmmap_amd/host/replay.cc)",
+            "host_loop": "c++ (swarmmap_amd/host/replay.cc)" + (", %d agents in lockstep on one thread (so_fleet_run)" % A
+                                                                  if args.lockstep and A > 1 else ""),
             "fps_per_agent": steps / dt, "agents_per_gpu": A,
             "config": dict({
                 "workload": ("BASELINE.json configs[1]+[2] on one GPU per agent: 752x480 EuRoC-sized stream seen through "

@@ -36,6 +36,11 @@ const char* so_status_string(int status);
 const char* so_last_error(void);
 /* number of visible HIP devices (0 when there is no GPU); never throws */
 int so_device_count(void);
+/* By default the extractors created by one thread share one HIP stream and its matchers / frame contexts another (the
+ * per-frame path of ONE agent is a chain: more streams only spread it over hardware queues).  A thread that drives
+ * SEVERAL agents in lockstep wants their launches to overlap: after so_runtime_private_streams(1) every extractor and
+ * matcher created (by any thread) gets a stream of its own. */
+int so_runtime_private_streams(int enabled);
 
 /* ------------------------------------------------------------------------------------------------
  * ORB extractor  — replaces ORB_SLAM2::ORBextractor (code/include/ORBextractor.h:49-127,
@@ -394,6 +399,21 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
                                const uint8_t* slot_has_obs, float th, int check_orientation, int32_t* kp_to_last,
                                int32_t* nmatches);
 
+/* The two tracking searches in two halves, for a thread that drives several agents (or that has other work while the
+ * kernel runs): _submit stages the gates and enqueues the launch on the matcher's stream, _wait blocks for it and runs
+ * the order-dependent resolve.  One search in flight per matcher; cur_excluded / the frames / the map must stay
+ * untouched until the wait.  so_track_search_last_frame / _local_map are submit followed by wait. */
+int so_track_search_last_frame_submit(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_dframe* last,
+                                      const so_map* map, const float* Tcw12, const int32_t* last_slot, float th);
+int so_track_search_last_frame_wait(so_matcher* m, const uint8_t* slot_has_obs, int check_orientation, int32_t* kp_to_last,
+                                    int32_t* nmatches);
+int so_track_search_local_map_submit(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_map* map,
+                                     const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
+                                     const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
+                                     float log_scale_factor);
+int so_track_search_local_map_wait(so_matcher* m, const uint8_t* slot_has_obs, uint8_t* in_view, int32_t* kp_to_local,
+                                   int32_t* nmatches);
+
 /* TrackLocalMap's search: Tracking::SearchLocalPoints (code/src/Tracking.cc:1104-1156) — Frame::isInFrustum(pMP,
  * viewing_cos_limit) (code/src/Frame.cc:316-375, MapPoint::PredictScale code/src/MapPoint.cc:476-485) for each of
  * the n_local local map points, then ORBmatcher::SearchByProjection(F, vpMapPoints, th) (code/src/ORBmatcher.cc:
@@ -536,6 +556,22 @@ void so_ba_options_global(so_ba_options* opt, int32_t n_iterations, int32_t robu
 int so_pose_optimization(so_ba* ba, const float* Tcw12, const float* intr, int32_t n, const float* Xw,
                          const float* obs, const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier,
                          int32_t* n_inliers, int32_t* info /* [iterations, lm_trials], may be NULL */);
+/* Several independent PoseOptimization problems in ONE launch (a workgroup per problem), e.g. the frames of several
+ * agents a thread drives in lockstep.  Fields as the arguments of so_pose_optimization; results identical to calling it
+ * per problem. */
+typedef struct {
+    const float* Tcw12;
+    const float* intr;
+    int32_t n;
+    const float* Xw;
+    const float* obs;
+    const float* inv_sigma2;
+    float* Tcw_out12;
+    uint8_t* outlier;
+    int32_t* n_inliers;
+    int32_t* info; /* [iterations, lm_trials], may be NULL */
+} so_pose_problem;
+int so_pose_optimization_batch(so_ba* ba, int32_t n_problems, const so_pose_problem* problems);
 /* HIP-event time (ms) of the kernel of the last so_pose_optimization call on this handle. */
 int so_pose_optimization_last_kernel_ms(so_ba* ba, float* ms);
 

@@ -777,6 +777,100 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     return SO_OK;
 }
 
+// Several independent PoseOptimization problems in ONE launch (a workgroup per problem): the frames of several agents
+// driven in lockstep by one thread.  Inputs and results travel through host-mapped memory like the single call.
+int so_pose_optimization_batch(so_ba* b, int32_t n_problems, const so_pose_problem* problems) {
+    if (!b || n_problems < 0 || (n_problems > 0 && !problems)) return SO_ERR_INVALID_ARG;
+    if (n_problems == 0) return SO_OK;
+    int max_n = 0;
+    size_t total_in = 0, total_out = 0;
+    for (int p = 0; p < n_problems; p++) {
+        const so_pose_problem& q = problems[p];
+        if (!q.Tcw12 || !q.intr || q.n < 0 || !q.Tcw_out12 || !q.n_inliers) return SO_ERR_INVALID_ARG;
+        if (q.n > 0 && (!q.Xw || !q.obs || !q.inv_sigma2 || !q.outlier)) return SO_ERR_INVALID_ARG;
+        max_n = std::max(max_n, (int)q.n);
+        total_in += ((size_t)q.n * 24 + 63) & ~(size_t)63;
+        total_out += (80 + (size_t)q.n + 63) & ~(size_t)63;
+    }
+    if (max_n > 1024) {  // beyond the batched kernel: one call per problem
+        for (int p = 0; p < n_problems; p++) {
+            const so_pose_problem& q = problems[p];
+            const int rc = so_pose_optimization(b, q.Tcw12, q.intr, q.n, q.Xw, q.obs, q.inv_sigma2, q.Tcw_out12, q.outlier,
+                                                q.n_inliers, q.info);
+            if (rc) return rc;
+        }
+        return SO_OK;
+    }
+    SO_HIP(hipSetDevice(b->device));
+    hipStream_t s = nullptr;
+    SO_HIP(tracking_stream(b->device, 1, &s));
+    const size_t args_bytes = (sizeof(PoseOptArgs) * (size_t)n_problems + 255) & ~(size_t)255;
+    const size_t need = args_bytes + total_in + total_out + 256;
+    if (need > b->h_po_cap) {
+        if (b->h_po) SO_HIP(hipHostFree(b->h_po));
+        b->h_po = nullptr;
+        b->h_po_cap = 0;
+        SO_HIP(hipHostMalloc((void**)&b->h_po, need * 2, hipHostMallocMapped));
+        SO_HIP(hipHostGetDevicePointer((void**)&b->h_po_dev, b->h_po, 0));
+        b->h_po_cap = need * 2;
+    }
+    uint8_t* h = b->h_po;
+    uint8_t* d = b->h_po_dev;
+    PoseOptArgs* args = reinterpret_cast<PoseOptArgs*>(h);
+    size_t off = args_bytes;
+    std::vector<size_t> out_off((size_t)n_problems);
+    for (int p = 0; p < n_problems; p++) {
+        const so_pose_problem& q = problems[p];
+        const size_t n = (size_t)q.n;
+        PoseOptArgs& a = args[p];
+        memset(&a, 0, sizeof(a));
+        if (n) {
+            memcpy(h + off, q.Xw, n * 12);
+            memcpy(h + off + n * 12, q.obs, n * 8);
+            memcpy(h + off + n * 20, q.inv_sigma2, n * 4);
+        }
+        a.Xw = reinterpret_cast<const float*>(d + off);
+        a.obs = reinterpret_cast<const float*>(d + off + n * 12);
+        a.inv_sigma2 = reinterpret_cast<const float*>(d + off + n * 20);
+        off += (n * 24 + 63) & ~(size_t)63;
+        out_off[(size_t)p] = off;
+        a.pose_out = reinterpret_cast<BaPose*>(d + off);
+        a.info = reinterpret_cast<int*>(d + off + 64);
+        a.outlier = d + off + 80;
+        off += (80 + n + 63) & ~(size_t)63;
+        for (int k = 0; k < 4; k++) a.K[k] = (double)q.intr[k];
+        pose_from_Tcw(q.Tcw12, a.init);
+        a.n = q.n >= 3 ? q.n : 0;  // n < 3: "return 0" with untouched outputs (Optimizer.cc:344-345); the workgroup idles
+        a.err = nullptr;
+        a.trace = nullptr;
+    }
+    SO_HIP(hipEventRecord(b->pe0, s));
+    if (!launch_pose_opt_batch(reinterpret_cast<const PoseOptArgs*>(d), n_problems, max_n, s)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipEventRecord(b->pe1, s));
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipStreamSynchronize(s));
+    b->pose_ms_pending = true;
+    for (int p = 0; p < n_problems; p++) {
+        const so_pose_problem& q = problems[p];
+        *q.n_inliers = 0;
+        if (q.info) q.info[0] = q.info[1] = 0;
+        if (q.n < 3) continue;
+        const uint8_t* ho = h + out_off[(size_t)p];
+        BaPose P;
+        memcpy(&P, ho, sizeof(BaPose));
+        int inf[4];
+        memcpy(inf, ho + 64, 16);
+        memcpy(q.outlier, ho + 80, (size_t)q.n);
+        pose_to_Tcw(P, q.Tcw_out12);
+        *q.n_inliers = q.n - inf[0];
+        if (q.info) {
+            q.info[0] = inf[1];
+            q.info[1] = inf[2];
+        }
+    }
+    return SO_OK;
+}
+
 int so_pose_optimization_last_kernel_ms(so_ba* b, float* ms) {
     if (!b || !ms) return SO_ERR_INVALID_ARG;
     if (b->pose_ms_pending) {

@@ -167,5 +167,8 @@ struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.
 };
 constexpr int kPoseOptLdsMax = 3072;  // matched points the LDS-resident kernel holds (41 B each)
 void launch_pose_opt(const PoseOptArgs& a, hipStream_t s);
+// n_problems problems in one launch (a workgroup each); d_args must be device-visible.  false: a problem has more than
+// 1024 points (the caller falls back to one launch per problem)
+bool launch_pose_opt_batch(const PoseOptArgs* d_args, int n_problems, int max_n, hipStream_t s);
 
 }  // namespace so

@@ -2207,7 +2207,10 @@ __device__ __forceinline__ void se3_exp_mul_direct(const double* u, const BaPose
 //     one pass ahead of the slowest one.
 // Same schedule, same accept / reject rules, same stored-error semantics as above (g2o's optimize(10) x 4).
 template <int THREADS, int EPT>
-__global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a) {
+__global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, const PoseOptArgs* __restrict__ batch) {
+    // batch != null: workgroup b solves problem batch[b] (so_pose_optimization_batch: several agents' frames, or the
+    // independent problems of one frame, in ONE launch - a workgroup per problem, nothing shared between them)
+    const PoseOptArgs a = batch ? batch[blockIdx.x] : a0;
     constexpr int NW = THREADS / 64;
     __shared__ double s_red[2][NW][32];
     __shared__ double s_sysw[NW][2][32];  // per wave: the two systems; 21 H (upper) | 6 b | chi | n_active
@@ -2478,7 +2481,19 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a) {
 
 template <int THREADS, int EPT>
 static void launch_pose_reg(const PoseOptArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((pose_opt_reg_kernel<THREADS, EPT>), dim3(1), dim3(THREADS), 0, s, a);
+    hipLaunchKernelGGL((pose_opt_reg_kernel<THREADS, EPT>), dim3(1), dim3(THREADS), 0, s, a, (const PoseOptArgs*)nullptr);
+}
+
+bool launch_pose_opt_batch(const PoseOptArgs* d_args, int n_problems, int max_n, hipStream_t s) {
+    if (n_problems <= 0) return true;
+    if (max_n > 1024) return false;  // the register-resident kernel holds 4 edges per thread
+    const PoseOptArgs none{};
+    const int ept = (max_n + 255) / 256;
+    if (ept <= 1) hipLaunchKernelGGL((pose_opt_reg_kernel<256, 1>), dim3(n_problems), dim3(256), 0, s, none, d_args);
+    else if (ept == 2) hipLaunchKernelGGL((pose_opt_reg_kernel<256, 2>), dim3(n_problems), dim3(256), 0, s, none, d_args);
+    else if (ept == 3) hipLaunchKernelGGL((pose_opt_reg_kernel<256, 3>), dim3(n_problems), dim3(256), 0, s, none, d_args);
+    else hipLaunchKernelGGL((pose_opt_reg_kernel<256, 4>), dim3(n_problems), dim3(256), 0, s, none, d_args);
+    return true;
 }
 
 void launch_pose_opt(const PoseOptArgs& a, hipStream_t s) {

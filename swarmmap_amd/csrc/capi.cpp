@@ -1,6 +1,7 @@
 // capi.cpp — library-wide pieces of the C ABI (include/swarmorb.h): status strings, last error, device probe.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 
 #include "so_common.h"
@@ -9,6 +10,18 @@ namespace so {
 std::string& last_error_ref() {
     static thread_local std::string err;
     return err;
+}
+
+static std::atomic<int> g_private_streams{0};
+
+hipError_t context_stream(int device, int role, hipStream_t* s, bool* owned) {
+    *owned = false;
+    if (g_private_streams.load()) {
+        const hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        if (e == hipSuccess) *owned = true;
+        return e;
+    }
+    return tracking_stream(device, role, s);
 }
 
 hipError_t tracking_stream(int device, int role, hipStream_t* s) {
@@ -42,6 +55,11 @@ const char* so_status_string(int status) {
 }
 
 const char* so_last_error(void) { return so::last_error_ref().c_str(); }
+
+int so_runtime_private_streams(int enabled) {
+    so::g_private_streams.store(enabled ? 1 : 0);
+    return SO_OK;
+}
 
 int so_device_count(void) {
     int n = 0;

@@ -30,6 +30,7 @@ struct so_extractor {
     int features_per_level[kMaxLevels]{};
 
     hipStream_t stream = nullptr;
+    bool owns_stream = false;
     hipEvent_t ev[8]{};
     bool profiling = false;
     float prof_ms[SO_EXTRACTOR_N_STAGES]{};
@@ -573,7 +574,7 @@ int so_extractor_create(const so_extractor_config* cfg, so_extractor** out) {
     so_extractor* ex = new so_extractor();
     ex->cfg = *cfg;
     make_tables(ex);
-    hipError_t e = tracking_stream(cfg->device, 0, &ex->stream);
+    hipError_t e = context_stream(cfg->device, 0, &ex->stream, &ex->owns_stream);
     if (e != hipSuccess) {
         delete ex;
         return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
@@ -604,6 +605,7 @@ void so_extractor_destroy(so_extractor* ex) {
     if (ex->graph) (void)hipGraphDestroy(ex->graph);
     for (auto& v : ex->ev)
         if (v) (void)hipEventDestroy(v);
+    if (ex->owns_stream && ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
 }
 

@@ -113,6 +113,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct so_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float last_ms = 0.f;
     bool profile = true;  // event-timed kernels (so_matcher_last_kernel_ms)
@@ -146,6 +147,19 @@ struct so_matcher {
     // candidates read in place from a device-resident frame (so_dframe) instead of the staged upload
     const so_dframe* src = nullptr;
     size_t off_slot = 0, off_skip = 0, track_end = 0;
+    // a tracking search between its submit and its wait (so_track_search_*_submit / _wait)
+    struct PendingTrack {
+        int mode = 0;  // 0: none, 2: last-frame search, 3: local-map search
+        bool empty = true;  // nothing was launched (no queries / no keypoints)
+        TrackQuerySrc T{};
+        int nq = 0;
+        size_t c8_off = 0, view_off = 0;
+        const so_dframe* cur = nullptr;
+        const so_dframe* last = nullptr;
+        const uint8_t* cur_excluded = nullptr;  // caller memory: must stay valid until the wait
+        float nn_ratio = 0.f;
+        std::chrono::steady_clock::time_point t_launched;
+    } pend;
     float min_x = 0.f, min_y = 0.f, grid_inv_w = 0.f, grid_inv_h = 0.f;
     std::vector<int> perm;     // rank -> keypoint index
     std::vector<int> cell_count;
@@ -509,7 +523,7 @@ int so_matcher_create(int device, so_matcher** out) {
     SO_HIP(hipSetDevice(device));
     so_matcher* m = new so_matcher();
     m->device = device;
-    hipError_t e = tracking_stream(device, 1, &m->stream);
+    hipError_t e = context_stream(device, 1, &m->stream, &m->owns_stream);
     if (e == hipSuccess) e = hipEventCreate(&m->e0);
     if (e == hipSuccess) e = hipEventCreate(&m->e1);
     if (e != hipSuccess) {
@@ -532,6 +546,7 @@ void so_matcher_destroy(so_matcher* m) {
     m->h_rout.release();
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
+    if (m->owns_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
 
@@ -1477,7 +1492,10 @@ void set_bits_from_excluded(const so_matcher* m, const uint8_t* excluded_by_idx,
     }
 }
 
-int run_topk_track(so_matcher* m, TrackQuerySrc& T, int mode, int nq, int K, const TrackGates& G) {
+int finish_topk_track(so_matcher* m, int nq, int K);
+
+// launch half: everything up to and including the kernel launch; finish_topk_track waits and maps the results
+int launch_topk_track_async(so_matcher* m, TrackQuerySrc& T, int mode, int nq, int K, const TrackGates& G) {
     int rc;
     const bool bits = m->n_cand <= kTrackMaxCandBits && nq <= kTrackMaxQueryBits;
     const size_t off_slot = m->frame_end;
@@ -1533,12 +1551,18 @@ int run_topk_track(so_matcher* m, TrackQuerySrc& T, int mode, int nq, int K, con
     if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
     SO_HIP(hipGetLastError());
     const auto t1 = std::chrono::steady_clock::now();
-    SO_HIP(hipStreamSynchronize(s));
-    const auto t2 = std::chrono::steady_clock::now();
     m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
-    m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
     m->stat[2] += 1.0;
     m->stat[3] += (double)staged;
+    return SO_OK;
+}
+
+int finish_topk_track(so_matcher* m, int nq, int K) {
+    const size_t keys_bytes = align256(sizeof(uint32_t) * (size_t)nq * K);
+    const auto t1 = std::chrono::steady_clock::now();
+    SO_HIP(hipStreamSynchronize(m->stream));
+    const auto t2 = std::chrono::steady_clock::now();
+    m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
     m->h_keys.p = m->h_out.p;
     m->h_count.p = (uint8_t*)m->h_out.p + keys_bytes;
     float ms = 0.f;
@@ -1598,35 +1622,67 @@ bool track_args_ok(const so_matcher* m, const so_dframe* cur, const so_map* map,
 extern "C" {
 
 // TrackWithMotionModel's search — ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono = true),
-// code/src/ORBmatcher.cc:1223-1354, whole function (projection :1242-1276 included)
-int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_dframe* last,
-                               const so_map* map, const float* Tcw12, const int32_t* last_slot,
-                               const uint8_t* slot_has_obs, float th, int check_orientation, int32_t* kp_to_last,
-                               int32_t* nmatches) {
+// code/src/ORBmatcher.cc:1223-1354, whole function (projection :1242-1276 included).  submit = everything up to the
+// launch; wait = stream sync + the order-dependent resolve.
+int so_track_search_last_frame_submit(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_dframe* last,
+                                      const so_map* map, const float* Tcw12, const int32_t* last_slot, float th) {
     if (m) (void)take_reuse(m);
-    if (!track_args_ok(m, cur, map, Tcw12) || !last || !last->ready || !kp_to_last || !nmatches) return SO_ERR_INVALID_ARG;
+    if (!track_args_ok(m, cur, map, Tcw12) || !last || !last->ready) return SO_ERR_INVALID_ARG;
+    if (m->pend.mode != 0) {
+        last_error_ref() = "a tracking search of this matcher has been submitted and not waited for";
+        return SO_ERR_INVALID_ARG;
+    }
     const int n_last = last->n;
     if (n_last > 0 && !last_slot) return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
-    *nmatches = 0;
-    for (int k = 0; k < cur->n; k++) kp_to_last[k] = -1;
+    so_matcher::PendingTrack& P = m->pend;
+    P = so_matcher::PendingTrack{};
+    P.mode = 2;
+    P.cur = cur;
+    P.last = last;
+    P.cur_excluded = cur_excluded;
+    P.nq = n_last;
     if (n_last == 0 || cur->n == 0) return SO_OK;
     constexpr int K = 8;
     int rc = use_dframe(m, cur, cur_excluded);
-    if (rc) return rc;
-    TrackQuerySrc T = track_src(m, cur, map, Tcw12, th);
-    T.last_octave = last->d_octave;
+    if (rc) { P.mode = 0; return rc; }
+    P.T = track_src(m, cur, map, Tcw12, th);
+    P.T.last_octave = last->d_octave;
     const TrackGates G{last_slot, 0, nullptr, cur_excluded};
     // per-query candidate counts as one byte each behind the K-lists: the only plane the resolve reads for every query
     const size_t keys_bytes2 = align256(sizeof(uint32_t) * (size_t)n_last * K);
-    const size_t c8_off = align256(keys_bytes2 + sizeof(int32_t) * (size_t)n_last);
-    if ((rc = m->h_out.ensure(c8_off + (size_t)n_last))) return rc;
-    T.count8_out = (uint8_t*)m->h_out.dev + c8_off;
-    if ((rc = run_topk_track(m, T, 2, n_last, K, G))) return rc;
+    P.c8_off = align256(keys_bytes2 + sizeof(int32_t) * (size_t)n_last);
+    if ((rc = m->h_out.ensure(P.c8_off + (size_t)n_last))) { P.mode = 0; return rc; }
+    P.T.count8_out = (uint8_t*)m->h_out.dev + P.c8_off;
+    if ((rc = launch_topk_track_async(m, P.T, 2, n_last, K, G))) { P.mode = 0; return rc; }
+    P.empty = false;
+    return SO_OK;
+}
+
+int so_track_search_last_frame_wait(so_matcher* m, const uint8_t* slot_has_obs, int check_orientation, int32_t* kp_to_last,
+                                    int32_t* nmatches) {
+    if (!m || !kp_to_last || !nmatches) return SO_ERR_INVALID_ARG;
+    if (m->pend.mode != 2) {
+        last_error_ref() = "so_track_search_last_frame_wait without a submitted search";
+        return SO_ERR_INVALID_ARG;
+    }
+    so_matcher::PendingTrack P = m->pend;
+    m->pend.mode = 0;
+    const so_dframe* cur = P.cur;
+    const so_dframe* last = P.last;
+    const int n_last = P.nq;
+    *nmatches = 0;
+    for (int k = 0; k < cur->n; k++) kp_to_last[k] = -1;
+    if (P.empty) return SO_OK;
+    constexpr int K = 8;
+    SO_HIP(hipSetDevice(m->device));
+    int rc = finish_topk_track(m, n_last, K);
+    if (rc) return rc;
+    const uint8_t* cur_excluded = P.cur_excluded;
     const uint32_t* keys = (const uint32_t*)m->h_keys.p;
-    const uint8_t* cnt = (const uint8_t*)m->h_out.p + c8_off;
+    const uint8_t* cnt = (const uint8_t*)m->h_out.p + P.c8_off;
     auto has_obs = [&](int i) { return !slot_has_obs || slot_has_obs[i]; };
     std::vector<int32_t> gate;
     std::vector<int> rot_item, rot_b;
@@ -1649,7 +1705,7 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
             gate.assign((size_t)cur->n, INT_MAX);
             for (int k = 0; k < cur->n; k++)
                 if ((cur_excluded && cur_excluded[k]) || (kp_to_last[k] >= 0 && has_obs(kp_to_last[k]))) gate[(size_t)k] = 0;
-            if ((rc = rerun_track(m, T, 2, i, gate, 1, e, &found))) return rc;
+            if ((rc = rerun_track(m, P.T, 2, i, gate, 1, e, &found))) return rc;
         }
         if (found == 0) continue;
         if (e[0].dist <= TH_HIGH) {
@@ -1676,54 +1732,90 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
     return SO_OK;
 }
 
+int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_dframe* last,
+                               const so_map* map, const float* Tcw12, const int32_t* last_slot,
+                               const uint8_t* slot_has_obs, float th, int check_orientation, int32_t* kp_to_last,
+                               int32_t* nmatches) {
+    if (!kp_to_last || !nmatches) return SO_ERR_INVALID_ARG;
+    const int rc = so_track_search_last_frame_submit(m, cur, cur_excluded, last, map, Tcw12, last_slot, th);
+    if (rc) return rc;
+    return so_track_search_last_frame_wait(m, slot_has_obs, check_orientation, kp_to_last, nmatches);
+}
+
 // TrackLocalMap's search — Tracking::SearchLocalPoints (code/src/Tracking.cc:1104-1156): Frame::isInFrustum(pMP,
 // cos_limit) (code/src/Frame.cc:316-375) for every local map point that is not already matched in this frame, then
 // ORBmatcher::SearchByProjection(F, vpMapPoints, th) (code/src/ORBmatcher.cc:44-121)
-int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_map* map,
-                              const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
-                              const uint8_t* skip, const uint8_t* slot_has_obs, float th, float nn_ratio,
-                              float viewing_cos_limit, float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local,
-                              int32_t* nmatches) {
+int so_track_search_local_map_submit(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_map* map,
+                                     const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
+                                     const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
+                                     float log_scale_factor) {
     if (m) (void)take_reuse(m);
-    if (!track_args_ok(m, cur, map, Tcw12) || n_local < 0 || !kp_to_local || !nmatches) return SO_ERR_INVALID_ARG;
-    static const bool trace = getenv("SWARMORB_MATCH_TRACE") != nullptr;
-    static double tacc[6] = {0, 0, 0, 0, 0, 0};
-    static int tcalls = 0;
-    const auto tt0 = std::chrono::steady_clock::now();
+    if (!track_args_ok(m, cur, map, Tcw12) || n_local < 0) return SO_ERR_INVALID_ARG;
+    if (m->pend.mode != 0) {
+        last_error_ref() = "a tracking search of this matcher has been submitted and not waited for";
+        return SO_ERR_INVALID_ARG;
+    }
     SO_HIP(hipSetDevice(m->device));
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
-    *nmatches = 0;
-    for (int k = 0; k < cur->n; k++) kp_to_local[k] = -1;
-    if (in_view) memset(in_view, 0, (size_t)n_local);
+    so_matcher::PendingTrack& P = m->pend;
+    P = so_matcher::PendingTrack{};
+    P.mode = 3;
+    P.cur = cur;
+    P.cur_excluded = cur_excluded;
+    P.nq = n_local;
+    P.nn_ratio = nn_ratio;
     if (n_local == 0) return SO_OK;
     constexpr int K = 8;
     int rc = use_dframe(m, cur, cur_excluded);
-    if (rc) return rc;
-    TrackQuerySrc T = track_src(m, cur, map, Tcw12, th);
-    T.cos_limit = viewing_cos_limit;
-    T.log_scale_factor = log_scale_factor;
+    if (rc) { P.mode = 0; return rc; }
+    P.T = track_src(m, cur, map, Tcw12, th);
+    P.T.cos_limit = viewing_cos_limit;
+    P.T.log_scale_factor = log_scale_factor;
     {   // smallest integer d with nn_ratio * d >= TH_HIGH in the float arithmetic of the ratio test (ORBmatcher.cc:112)
         int d = TH_HIGH;
         while (d < 256 && (float)TH_HIGH > nn_ratio * (float)d) d++;
-        T.second_best_bound = d;
+        P.T.second_best_bound = d;
     }
-    // mbTrackInView of every query comes back through host-mapped memory behind the K-lists
+    // mbTrackInView of every query and the one-byte candidate counts come back through host-mapped memory behind the K-lists
     const size_t keys_bytes = align256(sizeof(uint32_t) * (size_t)n_local * K);
-    const size_t view_off = align256(keys_bytes + sizeof(int32_t) * (size_t)n_local);
-    const size_t c8_off = align256(view_off + (size_t)n_local);
-    if ((rc = m->h_out.ensure(c8_off + (size_t)n_local))) return rc;
-    T.in_view_out = (uint8_t*)m->h_out.dev + view_off;
-    T.count8_out = (uint8_t*)m->h_out.dev + c8_off;
-    const auto tt1 = std::chrono::steady_clock::now();
+    P.view_off = align256(keys_bytes + sizeof(int32_t) * (size_t)n_local);
+    P.c8_off = align256(P.view_off + (size_t)n_local);
+    if ((rc = m->h_out.ensure(P.c8_off + (size_t)n_local))) { P.mode = 0; return rc; }
+    P.T.in_view_out = (uint8_t*)m->h_out.dev + P.view_off;
+    P.T.count8_out = (uint8_t*)m->h_out.dev + P.c8_off;
     const TrackGates G{local_slot, local_slot ? 0 : first_slot, skip, cur_excluded};
-    if ((rc = run_topk_track(m, T, 3, n_local, K, G))) return rc;
-    const auto tt2 = std::chrono::steady_clock::now();
-    const uint8_t* view = (const uint8_t*)m->h_out.p + view_off;
+    if ((rc = launch_topk_track_async(m, P.T, 3, n_local, K, G))) { P.mode = 0; return rc; }
+    P.empty = false;
+    return SO_OK;
+}
+
+int so_track_search_local_map_wait(so_matcher* m, const uint8_t* slot_has_obs, uint8_t* in_view, int32_t* kp_to_local,
+                                   int32_t* nmatches) {
+    if (!m || !kp_to_local || !nmatches) return SO_ERR_INVALID_ARG;
+    if (m->pend.mode != 3) {
+        last_error_ref() = "so_track_search_local_map_wait without a submitted search";
+        return SO_ERR_INVALID_ARG;
+    }
+    so_matcher::PendingTrack P = m->pend;
+    m->pend.mode = 0;
+    const so_dframe* cur = P.cur;
+    const int n_local = P.nq;
+    *nmatches = 0;
+    for (int k = 0; k < cur->n; k++) kp_to_local[k] = -1;
+    if (in_view && n_local > 0) memset(in_view, 0, (size_t)n_local);
+    if (P.empty) return SO_OK;
+    constexpr int K = 8;
+    SO_HIP(hipSetDevice(m->device));
+    int rc = finish_topk_track(m, n_local, K);
+    if (rc) return rc;
+    const uint8_t* cur_excluded = P.cur_excluded;
+    const float nn_ratio = P.nn_ratio;
+    const uint8_t* view = (const uint8_t*)m->h_out.p + P.view_off;
     if (in_view) memcpy(in_view, view, (size_t)n_local);
     if (cur->n == 0) return SO_OK;
     const uint32_t* keys = (const uint32_t*)m->h_keys.p;
-    const uint8_t* cnt = (const uint8_t*)m->h_out.p + c8_off;  // 0 for a point that is not in view
+    const uint8_t* cnt = (const uint8_t*)m->h_out.p + P.c8_off;  // 0 for a point that is not in view
     auto has_obs = [&](int i) { return !slot_has_obs || slot_has_obs[i]; };
     std::vector<int32_t> gate;
     int nm = 0;
@@ -1744,7 +1836,7 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
             gate.assign((size_t)cur->n, INT_MAX);
             for (int k = 0; k < cur->n; k++)
                 if ((cur_excluded && cur_excluded[k]) || (kp_to_local[k] >= 0 && has_obs(kp_to_local[k]))) gate[(size_t)k] = 0;
-            if ((rc = rerun_track(m, T, 3, i, gate, 2, e, &found))) return rc;
+            if ((rc = rerun_track(m, P.T, 3, i, gate, 2, e, &found))) return rc;
         }
         if (found == 0) continue;
         const int bestDist = e[0].dist, bestIdx = e[0].idx, bestLevel = cur->octave[(size_t)bestIdx];
@@ -1757,18 +1849,19 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
         }
     }
     *nmatches = nm;
-    if (trace) {
-        const auto tt3 = std::chrono::steady_clock::now();
-        tacc[0] += std::chrono::duration<double, std::micro>(tt1 - tt0).count();
-        tacc[1] += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
-        tacc[2] += std::chrono::duration<double, std::micro>(tt3 - tt2).count();
-        tacc[3] += m->stat[0] * 1e3;
-        tacc[4] += m->stat[1] * 1e3;
-        if (++tcalls % 100 == 0)
-            fprintf(stderr, "[m1] setup %.1f us, run_topk_track %.1f us (enqueue %.1f, sync %.1f), resolve %.1f us\n",
-                    tacc[0] / tcalls, tacc[1] / tcalls, tacc[3] / tcalls, tacc[4] / tcalls, tacc[2] / tcalls);
-    }
     return SO_OK;
+}
+
+int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_map* map,
+                              const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
+                              const uint8_t* skip, const uint8_t* slot_has_obs, float th, float nn_ratio,
+                              float viewing_cos_limit, float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local,
+                              int32_t* nmatches) {
+    if (!kp_to_local || !nmatches) return SO_ERR_INVALID_ARG;
+    const int rc = so_track_search_local_map_submit(m, cur, cur_excluded, map, Tcw12, n_local, local_slot, first_slot, skip,
+                                                    th, nn_ratio, viewing_cos_limit, log_scale_factor);
+    if (rc) return rc;
+    return so_track_search_local_map_wait(m, slot_has_obs, in_view, kp_to_local, nmatches);
 }
 
 }  // extern "C"

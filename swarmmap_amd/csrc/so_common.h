@@ -24,6 +24,10 @@ inline int hip_fail(hipError_t e, const char* what, const char* file, int line) 
 // device) all extractors share one stream (role 0) and all matchers another (role 1) instead of holding one
 // each; the solver keeps its own.  The shared streams live as long as the process.
 hipError_t tracking_stream(int device, int role, hipStream_t* s);  // capi.cpp
+// The stream a new extractor (role 0) / matcher (role 1) runs on: the calling thread's shared one, or - after
+// so_runtime_private_streams(1), for a thread that drives several agents - a stream of its own (*owned: the handle
+// destroys it).
+hipError_t context_stream(int device, int role, hipStream_t* s, bool* owned);  // capi.cpp
 
 }  // namespace so
 

@@ -161,6 +161,17 @@ struct so_replay {
     int running = 0;
     bool quit = false;
     std::string error;
+    // the frame being tracked (stage functions below)
+    struct Step {
+        double t0 = 0, t1 = 0, tm2 = 0, tp1 = 0, tm1 = 0, tp2 = 0, tp3 = 0, tmap = 0;
+        double match_kernel = 0, pose_kernel = 0, pose_trials = 0, pose_points = 0, mstat[4] = {0, 0, 0, 0};
+        int pose_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0, hcur = 0, first_slot = 0;
+        int32_t n_in = 0;
+        bool first = false;
+        float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
+        M4 T = M4::eye();
+    } step;
+    float K4[4] = {0, 0, 0, 0};
     // statistics (timed steps only)
     double stat[48] = {0};
     std::vector<float> ba_Tcw, ba_Xw;
@@ -268,37 +279,6 @@ int add_points(so_replay* r, const M4& T, const so_replay::FrameHost& F, const s
     r->mp_X.insert(r->mp_X.end(), r->new_X.begin(), r->new_X.end());
     r->kf_first_slot.push_back(first);
     return first;
-}
-
-// Optimizer::PoseOptimization over the keypoints of F that have a map point (ascending keypoint index)
-int pose_opt(so_replay* r, const so_replay::FrameHost& F, const float* T_in12, float* T_out12, int32_t* n_inliers,
-             double* kernel_ms, double* trials, double* points) {
-    r->idx.clear();
-    for (int i = 0; i < F.n; i++)
-        if (F.kp_mp[(size_t)i] >= 0) r->idx.push_back(i);
-    const int np = (int)r->idx.size();
-    r->pX.resize((size_t)np * 3); r->pobs.resize((size_t)np * 2); r->pw.resize((size_t)np); r->pose_out.assign((size_t)np, 0);
-    for (int k = 0; k < np; k++) {
-        const int i = r->idx[(size_t)k];
-        const size_t s = (size_t)F.kp_mp[(size_t)i];
-        memcpy(&r->pX[3 * (size_t)k], &r->mp_X[3 * s], 12);
-        r->pobs[2 * (size_t)k] = F.xy_un[2 * (size_t)i];
-        r->pobs[2 * (size_t)k + 1] = F.xy_un[2 * (size_t)i + 1];
-        r->pw[(size_t)k] = r->inv_sigma2[F.kps[(size_t)i].octave];
-    }
-    const float K4[4] = {r->cam.fx, r->cam.fy, r->cam.cx, r->cam.cy};
-    int32_t info[2] = {0, 0};
-    memcpy(T_out12, T_in12, 48);
-    *n_inliers = 0;
-    if (so_pose_optimization(r->tracker_opt, T_in12, K4, np, r->pX.data(), r->pobs.data(), r->pw.data(), T_out12,
-                             r->pose_out.data(), n_inliers, info) != SO_OK)
-        return fail(r, "so_pose_optimization");
-    float ms = 0.f;
-    so_pose_optimization_last_kernel_ms(r->tracker_opt, &ms);
-    *kernel_ms += ms;
-    *trials += info[1];
-    *points += np;
-    return SO_OK;
 }
 
 int submit_frame(so_replay* r, int t) {
@@ -438,178 +418,363 @@ int so_replay_prime(so_replay* r, int t) {
     return submit_frame(r, t);
 }
 
+}  // extern "C"
+
+// ---- one tracked frame as stages.  so_replay_run chains them for one agent; so_fleet_run walks several agents through
+//      them in lockstep (searches submitted for all agents before any is waited for, PoseOptimization of all agents in
+//      one launch). ----
+namespace {
+
+// Frame constructor: collect frame t, put frame t+1 in flight.  The first frame of a run initialises the map.
+int step_begin(so_replay* r, int t) {
+    so_replay::Step& S = r->step;
+    S = so_replay::Step{};
+    S.t0 = now_ms();
+    S.hcur = r->submitted;
+    r->cur ^= 1;
+    so_replay::FrameHost& F = r->fh[r->cur];
+    int n = 0;
+    if (so_dframe_collect(r->fr[S.hcur], F.kps.data(), F.xy_un.data(), F.desc.data(), r->cap, &n, r->bounds) != SO_OK)
+        return fail(r, "so_dframe_collect");
+    r->in_flight = false;
+    F.n = n;
+    const int rc = submit_frame(r, t + 1);
+    if (rc) return rc;
+    S.t1 = S.tm2 = S.tp1 = S.tm1 = S.tp2 = S.tp3 = S.tmap = now_ms();
+    S.n_in = n;
+    for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = -1;
+    memset(F.outlier.data(), 0, (size_t)n);
+    S.T = M4::eye();
+    S.first = r->n_tracked == 0;
+    if (S.first) {  // every keypoint becomes a map point, the camera defines the world frame
+        std::vector<uint8_t> all((size_t)n, 1);
+        const int first = add_points(r, S.T, F, all, n);
+        if (first < 0) return fail(r, "so_map_write");
+        for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = first + i;
+        r->kf_inliers = n;
+        S.keyframe = 1;
+        S.tm2 = S.tp1 = S.tm1 = S.tp2 = S.tp3 = S.tmap = now_ms();
+    }
+    return SO_OK;
+}
+
+// TrackWithMotionModel's search (Tracking.cc:964-1024)
+int step_m2_submit(so_replay* r) {
+    so_replay::Step& S = r->step;
+    so_replay::FrameHost& L = r->fh[r->cur ^ 1];
+    const M4 T_pred = mul(r->velocity, r->T_last);
+    to_f12(T_pred, S.Tp);
+    r->last_slot.resize((size_t)L.n);
+    for (int i = 0; i < L.n; i++)
+        r->last_slot[(size_t)i] = (L.kp_mp[(size_t)i] >= 0 && !L.outlier[(size_t)i]) ? L.kp_mp[(size_t)i] : -1;
+    if (so_track_search_last_frame_submit(r->matcher, r->fr[S.hcur], nullptr, r->fr[(S.hcur + 2) % 3], r->map, S.Tp,
+                                          r->last_slot.data(), 15.0f) != SO_OK)
+        return fail(r, "so_track_search_last_frame_submit");
+    return SO_OK;
+}
+
+int step_m2_wait(so_replay* r) {
+    so_replay::Step& S = r->step;
+    so_replay::FrameHost& F = r->fh[r->cur];
+    so_replay::FrameHost& L = r->fh[r->cur ^ 1];
+    const int n = F.n;
+    r->k2l.resize((size_t)n);
+    int32_t nm = 0;
+    float kms = 0.f;
+    double ms4[4];
+    if (so_track_search_last_frame_wait(r->matcher, nullptr, 1, r->k2l.data(), &nm) != SO_OK)
+        return fail(r, "so_track_search_last_frame_wait");
+    so_matcher_last_kernel_ms(r->matcher, &kms);
+    S.match_kernel += kms;
+    so_matcher_last_stats(r->matcher, ms4);
+    S.mstat[0] += ms4[0]; S.mstat[1] += ms4[1];
+    if (nm < 20) {  // Tracking.cc:1020-1024: wider window
+        if (so_track_search_last_frame(r->matcher, r->fr[S.hcur], nullptr, r->fr[(S.hcur + 2) % 3], r->map, S.Tp,
+                                       r->last_slot.data(), nullptr, 30.0f, 1, r->k2l.data(), &nm) != SO_OK)
+            return fail(r, "so_track_search_last_frame");
+        so_matcher_last_kernel_ms(r->matcher, &kms);
+        S.match_kernel += kms;
+    }
+    S.nm2 = nm;
+    for (int k = 0; k < n; k++)
+        if (r->k2l[(size_t)k] >= 0) F.kp_mp[(size_t)k] = L.kp_mp[(size_t)r->k2l[(size_t)k]];
+    S.tm2 = now_ms();
+    return SO_OK;
+}
+
+// Optimizer::PoseOptimization inputs of the current frame: the keypoints that have a map point, ascending index
+void pose_gather(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers, int32_t* info2, so_pose_problem* q) {
+    const so_replay::FrameHost& F = r->fh[r->cur];
+    r->idx.clear();
+    for (int i = 0; i < F.n; i++)
+        if (F.kp_mp[(size_t)i] >= 0) r->idx.push_back(i);
+    const int np = (int)r->idx.size();
+    r->pX.resize((size_t)np * 3); r->pobs.resize((size_t)np * 2); r->pw.resize((size_t)np); r->pose_out.assign((size_t)np, 0);
+    for (int k = 0; k < np; k++) {
+        const int i = r->idx[(size_t)k];
+        const size_t s = (size_t)F.kp_mp[(size_t)i];
+        memcpy(&r->pX[3 * (size_t)k], &r->mp_X[3 * s], 12);
+        r->pobs[2 * (size_t)k] = F.xy_un[2 * (size_t)i];
+        r->pobs[2 * (size_t)k + 1] = F.xy_un[2 * (size_t)i + 1];
+        r->pw[(size_t)k] = r->inv_sigma2[F.kps[(size_t)i].octave];
+    }
+    r->K4[0] = r->cam.fx; r->K4[1] = r->cam.fy; r->K4[2] = r->cam.cx; r->K4[3] = r->cam.cy;
+    memcpy(T_out12, T_in12, 48);
+    *n_inliers = 0;
+    info2[0] = info2[1] = 0;
+    q->Tcw12 = T_in12; q->intr = r->K4; q->n = np; q->Xw = r->pX.data(); q->obs = r->pobs.data(); q->inv_sigma2 = r->pw.data();
+    q->Tcw_out12 = T_out12; q->outlier = r->pose_out.data(); q->n_inliers = n_inliers; q->info = info2;
+}
+
+void pose_account(so_replay* r, const so_pose_problem& q, float kernel_ms) {
+    so_replay::Step& S = r->step;
+    S.pose_kernel += kernel_ms;
+    S.pose_trials += q.info[1];
+    S.pose_points += q.n;
+    S.pose_calls++;
+}
+
+int pose_single(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers) {
+    so_pose_problem q;
+    int32_t info2[2];
+    pose_gather(r, T_in12, T_out12, n_inliers, info2, &q);
+    if (so_pose_optimization(r->tracker_opt, q.Tcw12, q.intr, q.n, q.Xw, q.obs, q.inv_sigma2, q.Tcw_out12, q.outlier,
+                             q.n_inliers, q.info) != SO_OK)
+        return fail(r, "so_pose_optimization");
+    float ms = 0.f;
+    so_pose_optimization_last_kernel_ms(r->tracker_opt, &ms);
+    pose_account(r, q, ms);
+    return SO_OK;
+}
+
+void pose1_apply(so_replay* r) {  // Tracking.cc:1030-1046: outliers lose their map point
+    so_replay::FrameHost& F = r->fh[r->cur];
+    for (size_t k = 0; k < r->idx.size(); k++)
+        if (r->pose_out[k]) F.kp_mp[(size_t)r->idx[k]] = -1;
+    r->step.tp1 = now_ms();
+}
+
+// TrackLocalMap's search (Tracking.cc:1052-1156)
+int step_m1_submit(so_replay* r) {
+    so_replay::Step& S = r->step;
+    so_replay::FrameHost& F = r->fh[r->cur];
+    const int n = F.n;
+    const int n_map = (int)(r->mp_X.size() / 3);
+    int first = 0;
+    if (r->local_keyframes > 0 && (int)r->kf_first_slot.size() > r->local_keyframes)
+        first = r->kf_first_slot[r->kf_first_slot.size() - (size_t)r->local_keyframes];
+    S.first_slot = first;
+    S.n_local = n_map - first;
+    r->skip.assign((size_t)S.n_local, 0);
+    r->excluded.resize((size_t)n);
+    for (int k = 0; k < n; k++) {
+        const int s = F.kp_mp[(size_t)k];
+        r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
+        if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:1117-1124)
+    }
+    if (so_track_search_local_map_submit(r->matcher, r->fr[S.hcur], r->excluded.data(), r->map, S.Ta, S.n_local, nullptr, first,
+                                         r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf) != SO_OK)
+        return fail(r, "so_track_search_local_map_submit");
+    return SO_OK;
+}
+
+int step_m1_wait(so_replay* r) {
+    so_replay::Step& S = r->step;
+    so_replay::FrameHost& F = r->fh[r->cur];
+    const int n = F.n;
+    r->k2m.resize((size_t)n);
+    std::vector<uint8_t>& view = r->new_desc;  // scratch
+    view.resize(std::max(view.size(), (size_t)S.n_local));
+    int32_t nmm = 0;
+    float kms = 0.f;
+    double ms4[4];
+    if (so_track_search_local_map_wait(r->matcher, nullptr, view.data(), r->k2m.data(), &nmm) != SO_OK)
+        return fail(r, "so_track_search_local_map_wait");
+    so_matcher_last_kernel_ms(r->matcher, &kms);
+    S.match_kernel += kms;
+    so_matcher_last_stats(r->matcher, ms4);
+    S.mstat[2] += ms4[0]; S.mstat[3] += ms4[1];
+    S.nm1 = nmm;
+    for (int i = 0; i < S.n_local; i++) S.n_view += view[(size_t)i];
+    for (int k = 0; k < n; k++)
+        if (r->k2m[(size_t)k] >= 0) F.kp_mp[(size_t)k] = S.first_slot + r->k2m[(size_t)k];
+    S.tm1 = now_ms();
+    return SO_OK;
+}
+
+void pose2_apply(so_replay* r) {
+    so_replay::Step& S = r->step;
+    so_replay::FrameHost& F = r->fh[r->cur];
+    for (size_t k = 0; k < r->idx.size(); k++)
+        if (r->pose_out[k]) F.outlier[(size_t)r->idx[k]] = 1;
+    S.T = from_f12(S.Tb);
+    S.tp2 = now_ms();
+}
+
+// "keyframe": unmatched keypoints become map points; then the motion model
+int step_keyframe(so_replay* r) {
+    so_replay::Step& S = r->step;
+    so_replay::FrameHost& F = r->fh[r->cur];
+    const int n = F.n;
+    if ((double)S.n_in < r->keyframe_ratio * (double)r->kf_inliers || r->n_tracked % r->keyframe_every == 0) {
+        std::vector<uint8_t> fresh((size_t)n, 0);
+        int n_fresh = 0;
+        for (int k = 0; k < n; k++)
+            if (F.kp_mp[(size_t)k] < 0) {
+                fresh[(size_t)k] = 1;
+                n_fresh++;
+            }
+        if (n_fresh > 0) {
+            const int f0 = add_points(r, S.T, F, fresh, n_fresh);
+            if (f0 < 0) return fail(r, "so_map_write");
+            int j = 0;
+            for (int k = 0; k < n; k++)
+                if (fresh[(size_t)k]) F.kp_mp[(size_t)k] = f0 + j++;
+        }
+        r->kf_inliers = S.n_in > 1 ? S.n_in : 1;
+        S.keyframe = 1;
+    }
+    r->velocity = mul(S.T, rigid_inverse_general(r->T_last));
+    S.tmap = now_ms();
+    return SO_OK;
+}
+
+// log, hand a window to the local-mapping thread every lba_every frames, statistics
+void step_end(so_replay* r, int t, int timed) {
+    so_replay::Step& S = r->step;
+    so_replay::FrameHost& F = r->fh[r->cur];
+    r->T_last = S.T;
+    r->last_tracked = S.hcur;
+    {
+        float p12[12];
+        to_f12(S.T, p12);
+        r->poses.insert(r->poses.end(), p12, p12 + 12);
+        r->n_m2.push_back(S.nm2);
+        r->n_m1.push_back(S.nm1);
+        r->n_inl.push_back(S.n_in);
+        r->n_map.push_back((int32_t)(r->mp_X.size() / 3));
+    }
+    r->n_tracked++;
+    const double t3 = now_ms();
+    if (t % r->lba_every == 0 && !r->window.epose.empty()) {
+        std::unique_lock<std::mutex> lk(r->mu);
+        r->cv.wait(lk, [r] { return r->queue.size() < 3; });  // the running window + two waiting
+        r->queue.push_back(timed ? 1 : 0);
+        lk.unlock();
+        r->cv.notify_all();
+    }
+    const double t4 = now_ms();
+    if (timed) {
+        double* st = r->stat;
+        st[kSteps] += 1; st[kExtractMs] += S.t1 - S.t0; st[kM2Ms] += S.tm2 - S.t1; st[kPose1Ms] += S.tp1 - S.tm2;
+        st[kM1Ms] += S.tm1 - S.tp1; st[kPose2Ms] += S.tp2 - S.tm1; st[kPose3Ms] += S.tp3 - S.tp2; st[kMapMs] += S.tmap - S.tp3;
+        st[kSubmitWaitMs] += t4 - t3; st[kKp] += F.n; st[kM2] += S.nm2; st[kM1] += S.nm1; st[kInliers] += S.n_in;
+        st[kMatchKernelMs] += S.match_kernel; st[kPoseKernelMs] += S.pose_kernel; st[kPoseTrials] += S.pose_trials;
+        st[kPoseCalls] += S.pose_calls; st[kPosePoints] += S.pose_points; st[kLocalPoints] += S.n_local; st[kInView] += S.n_view;
+        st[kKeyframes] += S.keyframe; st[kMapPoints] = (double)(r->mp_X.size() / 3);
+        st[kM2EnqMs] += S.mstat[0]; st[kM2WaitMs] += S.mstat[1]; st[kM1EnqMs] += S.mstat[2]; st[kM1WaitMs] += S.mstat[3];
+        float prof[SO_EXTRACTOR_N_STAGES];
+        if (so_extractor_get_profile(r->ex, prof) == SO_OK)
+            for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) st[kStage0 + i] += prof[i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
 int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
     if (!r || !r->in_flight || r->frames.empty()) return SO_ERR_INVALID_ARG;
     for (int t = first_t; t < first_t + n_steps; t++) {
-        const double t0 = now_ms();
-        // ---- Frame constructor: collect frame t, put frame t+1 in flight ---------------------------------------
-        const int hcur = r->submitted;
-        r->cur ^= 1;
-        so_replay::FrameHost& F = r->fh[r->cur];
-        so_replay::FrameHost& L = r->fh[r->cur ^ 1];
-        so_dframe* dcur = r->fr[hcur];
-        so_dframe* dlast = r->fr[(hcur + 2) % 3];
-        int n = 0;
-        if (so_dframe_collect(dcur, F.kps.data(), F.xy_un.data(), F.desc.data(), r->cap, &n, r->bounds) != SO_OK)
-            return fail(r, "so_dframe_collect");
-        r->in_flight = false;
-        F.n = n;
-        int rc = submit_frame(r, t + 1);
-        if (rc) return rc;
-        const double t1 = now_ms();
-        double tm2 = t1, tp1 = t1, tm1 = t1, tp2 = t1, tp3 = t1, tmap = t1;
-        double match_kernel = 0.0, pose_kernel = 0.0, pose_trials = 0.0, pose_points = 0.0;
-        double mstat[4] = {0, 0, 0, 0}, ms4[4];  // matcher: enqueue / blocked-in-sync ms of M2 and of M1
-        int pose_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0;
-        int32_t n_in = n;
-        for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = -1;
-        memset(F.outlier.data(), 0, (size_t)n);
-        M4 T = M4::eye();
-        if (r->n_tracked == 0) {
-            // first frame: every keypoint becomes a map point, the camera defines the world frame
-            std::vector<uint8_t> all((size_t)n, 1);
-            const int first = add_points(r, T, F, all, n);
-            if (first < 0) return fail(r, "so_map_write");
-            for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = first + i;
-            r->kf_inliers = n;
-            keyframe = 1;
-            tm2 = tp1 = tm1 = tp2 = tp3 = tmap = now_ms();
-        } else {
-            // ---- TrackWithMotionModel (Tracking.cc:964-1050) ----------------------------------------------------
-            const M4 T_pred = mul(r->velocity, r->T_last);
-            float Tp[12], Ta[12], Tb[12], Tc[12];
-            to_f12(T_pred, Tp);
-            r->last_slot.resize((size_t)L.n);
-            for (int i = 0; i < L.n; i++)
-                r->last_slot[(size_t)i] = (L.kp_mp[(size_t)i] >= 0 && !L.outlier[(size_t)i]) ? L.kp_mp[(size_t)i] : -1;
-            r->k2l.resize((size_t)n);
-            int32_t nm = 0;
-            float kms = 0.f;
-            if (so_track_search_last_frame(r->matcher, dcur, nullptr, dlast, r->map, Tp, r->last_slot.data(), nullptr, 15.0f,
-                                           1, r->k2l.data(), &nm) != SO_OK)
-                return fail(r, "so_track_search_last_frame");
-            so_matcher_last_kernel_ms(r->matcher, &kms);
-            match_kernel += kms;
-            so_matcher_last_stats(r->matcher, ms4);
-            mstat[0] += ms4[0]; mstat[1] += ms4[1];
-            if (nm < 20) {  // Tracking.cc:1020-1024: wider window
-                if (so_track_search_last_frame(r->matcher, dcur, nullptr, dlast, r->map, Tp, r->last_slot.data(), nullptr,
-                                               30.0f, 1, r->k2l.data(), &nm) != SO_OK)
-                    return fail(r, "so_track_search_last_frame");
-                so_matcher_last_kernel_ms(r->matcher, &kms);
-                match_kernel += kms;
-            }
-            nm2 = nm;
-            for (int k = 0; k < n; k++)
-                if (r->k2l[(size_t)k] >= 0) F.kp_mp[(size_t)k] = L.kp_mp[(size_t)r->k2l[(size_t)k]];
-            tm2 = now_ms();
+        so_replay::Step& S = r->step;
+        int rc;
+        if ((rc = step_begin(r, t))) return rc;
+        if (!S.first) {
+            if ((rc = step_m2_submit(r))) return rc;
+            if ((rc = step_m2_wait(r))) return rc;
             int32_t inl = 0;
-            if ((rc = pose_opt(r, F, Tp, Ta, &inl, &pose_kernel, &pose_trials, &pose_points))) return rc;
-            pose_calls++;
-            for (size_t k = 0; k < r->idx.size(); k++)  // Tracking.cc:1030-1046: outliers lose their map point
-                if (r->pose_out[k]) F.kp_mp[(size_t)r->idx[k]] = -1;
-            tp1 = now_ms();
-            // ---- TrackLocalMap (Tracking.cc:1052-1156) -----------------------------------------------------------
-            const int n_map = (int)(r->mp_X.size() / 3);
-            int first = 0;
-            if (r->local_keyframes > 0 && (int)r->kf_first_slot.size() > r->local_keyframes)
-                first = r->kf_first_slot[r->kf_first_slot.size() - (size_t)r->local_keyframes];
-            n_local = n_map - first;
-            r->skip.assign((size_t)n_local, 0);
-            r->excluded.resize((size_t)n);
-            for (int k = 0; k < n; k++) {
-                const int s = F.kp_mp[(size_t)k];
-                r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
-                if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:1117-1124)
-            }
-            r->k2m.resize((size_t)n);
-            std::vector<uint8_t>& view = r->new_desc;  // scratch
-            view.resize(std::max(view.size(), (size_t)n_local));
-            int32_t nmm = 0;
-            if (so_track_search_local_map(r->matcher, dcur, r->excluded.data(), r->map, Ta, n_local, nullptr, first,
-                                          r->skip.data(), nullptr, 1.0f, 0.8f, 0.5f, r->log_sf, view.data(), r->k2m.data(),
-                                          &nmm) != SO_OK)
-                return fail(r, "so_track_search_local_map");
-            so_matcher_last_kernel_ms(r->matcher, &kms);
-            match_kernel += kms;
-            so_matcher_last_stats(r->matcher, ms4);
-            mstat[2] += ms4[0]; mstat[3] += ms4[1];
-            nm1 = nmm;
-            for (int i = 0; i < n_local; i++) n_view += view[(size_t)i];
-            for (int k = 0; k < n; k++)
-                if (r->k2m[(size_t)k] >= 0) F.kp_mp[(size_t)k] = first + r->k2m[(size_t)k];
-            tm1 = now_ms();
-            if ((rc = pose_opt(r, F, Ta, Tb, &n_in, &pose_kernel, &pose_trials, &pose_points))) return rc;
-            pose_calls++;
-            for (size_t k = 0; k < r->idx.size(); k++)
-                if (r->pose_out[k]) F.outlier[(size_t)r->idx[k]] = 1;
-            T = from_f12(Tb);
-            tp2 = now_ms();
+            if ((rc = pose_single(r, S.Tp, S.Ta, &inl))) return rc;
+            pose1_apply(r);
+            if ((rc = step_m1_submit(r))) return rc;
+            if ((rc = step_m1_wait(r))) return rc;
+            if ((rc = pose_single(r, S.Ta, S.Tb, &S.n_in))) return rc;
+            pose2_apply(r);
             if (r->third_pose) {  // TrackReferenceKeyFrame's fallback: from the last frame's pose, result unused
-                float Tl[12];
+                float Tl[12], Tc[12];
                 to_f12(r->T_last, Tl);
                 int32_t inl3 = 0;
-                if ((rc = pose_opt(r, F, Tl, Tc, &inl3, &pose_kernel, &pose_trials, &pose_points))) return rc;
-                pose_calls++;
+                if ((rc = pose_single(r, Tl, Tc, &inl3))) return rc;
             }
-            tp3 = now_ms();
-            // ---- "keyframe": unmatched keypoints become map points ----------------------------------------------
-            if ((double)n_in < r->keyframe_ratio * (double)r->kf_inliers || r->n_tracked % r->keyframe_every == 0) {
-                std::vector<uint8_t> fresh((size_t)n, 0);
-                int n_fresh = 0;
-                for (int k = 0; k < n; k++)
-                    if (F.kp_mp[(size_t)k] < 0) {
-                        fresh[(size_t)k] = 1;
-                        n_fresh++;
-                    }
-                if (n_fresh > 0) {
-                    const int f0 = add_points(r, T, F, fresh, n_fresh);
-                    if (f0 < 0) return fail(r, "so_map_write");
-                    int j = 0;
-                    for (int k = 0; k < n; k++)
-                        if (fresh[(size_t)k]) F.kp_mp[(size_t)k] = f0 + j++;
-                }
-                r->kf_inliers = n_in > 1 ? n_in : 1;
-                keyframe = 1;
-            }
-            r->velocity = mul(T, rigid_inverse_general(r->T_last));
-            tmap = now_ms();
+            S.tp3 = now_ms();
+            if ((rc = step_keyframe(r))) return rc;
         }
-        r->T_last = T;
-        r->last_tracked = hcur;
-        {
-            float p12[12];
-            to_f12(T, p12);
-            r->poses.insert(r->poses.end(), p12, p12 + 12);
-            r->n_m2.push_back(nm2);
-            r->n_m1.push_back(nm1);
-            r->n_inl.push_back(n_in);
-            r->n_map.push_back((int32_t)(r->mp_X.size() / 3));
-        }
-        r->n_tracked++;
-        const double t3 = now_ms();
-        if (t % r->lba_every == 0 && !r->window.epose.empty()) {
-            std::unique_lock<std::mutex> lk(r->mu);
-            r->cv.wait(lk, [r] { return r->queue.size() < 3; });  // the running window + two waiting
-            r->queue.push_back(timed ? 1 : 0);
-            lk.unlock();
-            r->cv.notify_all();
-        }
-        const double t4 = now_ms();
-        if (timed) {
-            double* st = r->stat;
-            st[kSteps] += 1; st[kExtractMs] += t1 - t0; st[kM2Ms] += tm2 - t1; st[kPose1Ms] += tp1 - tm2;
-            st[kM1Ms] += tm1 - tp1; st[kPose2Ms] += tp2 - tm1; st[kPose3Ms] += tp3 - tp2; st[kMapMs] += tmap - tp3;
-            st[kSubmitWaitMs] += t4 - t3; st[kKp] += n; st[kM2] += nm2; st[kM1] += nm1; st[kInliers] += n_in;
-            st[kMatchKernelMs] += match_kernel; st[kPoseKernelMs] += pose_kernel; st[kPoseTrials] += pose_trials;
-            st[kPoseCalls] += pose_calls; st[kPosePoints] += pose_points; st[kLocalPoints] += n_local; st[kInView] += n_view;
-            st[kKeyframes] += keyframe; st[kMapPoints] = (double)(r->mp_X.size() / 3);
-            st[kM2EnqMs] += mstat[0]; st[kM2WaitMs] += mstat[1]; st[kM1EnqMs] += mstat[2]; st[kM1WaitMs] += mstat[3];
-            float prof[SO_EXTRACTOR_N_STAGES];
-            if (so_extractor_get_profile(r->ex, prof) == SO_OK)
-                for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) st[kStage0 + i] += prof[i];
-        }
+        step_end(r, t, timed);
         if (!r->error.empty()) return SO_ERR_HIP;
+    }
+    return SO_OK;
+}
+
+// Several agents on one GPU, driven in lockstep by the calling thread: per stage the searches of all agents are
+// submitted before any is waited for (their kernels overlap on the agents' own streams: create the handles after
+// so_runtime_private_streams(1)), and the PoseOptimization problems of all agents go out as ONE launch (a workgroup per
+// agent).  Every agent ends up with exactly the results a solo so_replay_run gives it.
+int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int timed) {
+    if (!agents || n_agents < 1) return SO_ERR_INVALID_ARG;
+    for (int a = 0; a < n_agents; a++)
+        if (!agents[a] || !agents[a]->in_flight || agents[a]->frames.empty()) return SO_ERR_INVALID_ARG;
+    const size_t A = (size_t)n_agents;
+    std::vector<so_pose_problem> probs(A);
+    std::vector<int32_t> inl(A), info(2 * A);
+    std::vector<int> live;
+    so_ba* batch_opt = agents[0]->tracker_opt;
+    auto pose_batch = [&](int which) -> int {  // which: 0 after the motion-model search, 1 after the local map, 2 the third call
+        live.clear();
+        for (int a = 0; a < n_agents; a++)
+            if (!agents[a]->step.first) live.push_back(a);
+        if (live.empty()) return SO_OK;
+        for (size_t k = 0; k < live.size(); k++) {
+            so_replay* r = agents[live[k]];
+            so_replay::Step& S = r->step;
+            if (which == 2) to_f12(r->T_last, S.Tl);
+            const float* Tin = which == 0 ? S.Tp : (which == 1 ? S.Ta : S.Tl);
+            float* Tout = which == 0 ? S.Ta : (which == 1 ? S.Tb : S.Tc);
+            pose_gather(r, Tin, Tout, which == 1 ? &S.n_in : &inl[(size_t)live[k]], &info[2 * (size_t)live[k]], &probs[k]);
+        }
+        if (so_pose_optimization_batch(batch_opt, (int32_t)live.size(), probs.data()) != SO_OK)
+            return fail(agents[0], "so_pose_optimization_batch");
+        float ms = 0.f;
+        so_pose_optimization_last_kernel_ms(batch_opt, &ms);
+        for (size_t k = 0; k < live.size(); k++) pose_account(agents[live[k]], probs[k], ms / (float)live.size());
+        return SO_OK;
+    };
+    for (int t = first_t; t < first_t + n_steps; t++) {
+        int rc;
+        for (int a = 0; a < n_agents; a++)
+            if ((rc = step_begin(agents[a], t))) return rc;
+        for (int a = 0; a < n_agents; a++)
+            if (!agents[a]->step.first && (rc = step_m2_submit(agents[a]))) return rc;
+        for (int a = 0; a < n_agents; a++)
+            if (!agents[a]->step.first && (rc = step_m2_wait(agents[a]))) return rc;
+        if ((rc = pose_batch(0))) return rc;
+        for (int a = 0; a < n_agents; a++)
+            if (!agents[a]->step.first) pose1_apply(agents[a]);
+        for (int a = 0; a < n_agents; a++)
+            if (!agents[a]->step.first && (rc = step_m1_submit(agents[a]))) return rc;
+        for (int a = 0; a < n_agents; a++)
+            if (!agents[a]->step.first && (rc = step_m1_wait(agents[a]))) return rc;
+        if ((rc = pose_batch(1))) return rc;
+        for (int a = 0; a < n_agents; a++)
+            if (!agents[a]->step.first) pose2_apply(agents[a]);
+        if (agents[0]->third_pose && (rc = pose_batch(2))) return rc;
+        for (int a = 0; a < n_agents; a++) {
+            so_replay* r = agents[a];
+            if (!r->step.first) {
+                r->step.tp3 = now_ms();
+                if ((rc = step_keyframe(r))) return rc;
+            }
+            step_end(r, t, timed);
+            if (!r->error.empty()) return SO_ERR_HIP;
+        }
     }
     return SO_OK;
 }

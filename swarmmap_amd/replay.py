@@ -44,6 +44,7 @@ class Replay:
         lib.so_replay_extractor.argtypes = [vp]; lib.so_replay_extractor.restype = vp
         lib.so_replay_matcher.argtypes = [vp]; lib.so_replay_matcher.restype = vp
         lib.so_replay_last_dframe.argtypes = [vp]; lib.so_replay_last_dframe.restype = vp
+        lib.so_fleet_run.argtypes = [vp, i32, i32, i32, i32]
         self.h = vp()
         K4 = np.ascontiguousarray(K, np.float32)
         d5 = None if dist is None else np.ascontiguousarray(list(dist) + [0.0] * (5 - len(dist)), np.float32)
@@ -86,6 +87,16 @@ class Replay:
 
     def run(self, first_t, n, timed):
         self._check(self.lib.so_replay_run(self.h, first_t, n, int(timed)), "run")
+
+    @staticmethod
+    def fleet_run(agents, first_t, n, timed):
+        """so_fleet_run: the agents (Replay objects of one GPU, created after private_streams(True)) walk through n
+        frames in lockstep on the calling thread; PoseOptimization of all agents goes out as one launch."""
+        arr = (C.c_void_p * len(agents))(*[a.h for a in agents])
+        rc = agents[0].lib.so_fleet_run(arr, len(agents), first_t, n, int(timed))
+        if rc != 0:
+            errs = [(a.lib.so_replay_error(a.h) or b"").decode() for a in agents]
+            raise RuntimeError("so_fleet_run failed (%d): %s" % (rc, "; ".join(e for e in errs if e)))
 
     def drain(self):
         self._check(self.lib.so_replay_drain(self.h), "drain")
@@ -135,3 +146,11 @@ class Replay:
         if self.h:
             self.lib.so_replay_destroy(self.h)
             self.h = None
+
+
+def private_streams(enabled=True):
+    """so_runtime_private_streams: extractors / matchers created afterwards get HIP streams of their own (for a thread
+    that drives several agents)."""
+    lib = _lib.load_library()
+    lib.so_runtime_private_streams.argtypes = [C.c_int]
+    _lib.check(lib.so_runtime_private_streams(int(bool(enabled))))

@@ -78,3 +78,41 @@ def test_cpp_chain_matches_the_oracle_chain(local_kfs):
         assert np.abs(a[k].astype(int) - b[k].astype(int)).max() <= 3, (k, a[k], b[k])
     assert np.abs(a["n_map_points"].astype(int) - b["n_map_points"].astype(int)).max() <= 3
     assert a["matches_last"][1:].min() > 300 and a["inliers"][1:].min() > 400
+
+
+def test_lockstep_fleet_gives_every_agent_its_solo_result():
+    """so_fleet_run: three agents of one GPU driven in lockstep by one thread (searches submitted for all agents before
+    any is waited for, PoseOptimization of all agents in one launch) - every agent's trajectory is the one a solo run
+    of the same stream produces."""
+    from swarmmap_amd.replay import Replay, private_streams
+    n, K, nfeat = 40, synth.EUROC_K, 1000
+    streams = [synth.FrameStream(seed=20221001 + 7 * a) for a in range(3)]
+    frames = [[st.frame(t) for t in range(n + 1)] for st in streams]
+    solo = []
+    for a in range(3):
+        rp = Replay(0, streams[a].w, streams[a].h, nfeat, 5, K, plane_z=PLANE_Z, local_keyframes=6, third_pose=True)
+        rp.set_host_frames(frames[a])
+        rp.prime(0)
+        rp.run(0, n, False)
+        rp.finish()
+        solo.append(rp.log())
+        rp.close()
+    private_streams(True)
+    try:
+        fleet = []
+        for a in range(3):
+            rp = Replay(0, streams[a].w, streams[a].h, nfeat, 5, K, plane_z=PLANE_Z, local_keyframes=6, third_pose=True)
+            rp.set_host_frames(frames[a])
+            rp.prime(0)
+            fleet.append(rp)
+        Replay.fleet_run(fleet, 0, n, False)
+        for a, rp in enumerate(fleet):
+            rp.finish()
+            g = rp.log()
+            rp.close()
+            assert len(g["poses"]) == n
+            assert np.abs(g["poses"] - solo[a]["poses"]).max() < 2e-5
+            for k in ("matches_last", "matches_map", "inliers", "n_map_points"):
+                assert np.abs(g[k].astype(int) - solo[a][k].astype(int)).max() <= 3, (a, k)
+    finally:
+        private_streams(False)
