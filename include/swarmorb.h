@@ -83,6 +83,10 @@ int so_extractor_capacity(const so_extractor* ex);
 int so_extractor_submit(so_extractor* ex, const uint8_t* image, int width, int height, int stride);
 int so_extractor_submit_device(so_extractor* ex, const uint8_t* d_image, int width, int height, int stride);
 int so_extractor_collect(so_extractor* ex, so_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out);
+/* collect in two steps: so_extractor_wait blocks until the frame is done and tells the keypoint count; the results stay
+ * in the context until so_extractor_collect copies them out (no further wait).  Lets the caller start work that only
+ * needs the frame on the DEVICE (so_dframe_wait) before spending time on the host copies. */
+int so_extractor_wait(so_extractor* ex, int* n_out);
 
 /* DistributeOctTree (code/src/ORBextractor.cc:534-744) placement after the first frame sized the context:
  * 1 = HIP kernel (one workgroup per level, whole tree in LDS; one host sync per frame), 0 = host tree
@@ -262,8 +266,11 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
 int so_distinctive_descriptors(so_matcher* m, int32_t n_points, const int32_t* offsets, const uint8_t* descriptors,
                                int32_t* best_idx, int32_t* best_median);
 
-/* HIP-event time (ms) of the kernels of the last matcher call on the matcher's stream. */
+/* HIP-event time (ms) of the kernels of the last matcher call on the matcher's stream (0 while the events are switched
+ * off: so_matcher_set_profiling(m, 0) saves the two event records per search, ~2 us of host time each and a
+ * timestamp packet on the queue; on by default). */
 int so_matcher_last_kernel_ms(so_matcher* m, float* ms);
+int so_matcher_set_profiling(so_matcher* m, int enabled);
 
 /* Tracking searches the same frame twice in a row (SearchByProjection against the last frame, Tracking.cc:1014, then
  * against the local map, :1153).  Calling this before the second search tells the handle that the next call's frame
@@ -340,6 +347,12 @@ int so_dframe_submit_device(so_dframe* f, const uint8_t* d_image, int width, int
  * capacity >= so_extractor_capacity(). */
 int so_dframe_collect(so_dframe* f, so_keypoint* keypoints, float* xy_un, uint8_t* descriptors, int capacity,
                       int* n_out, float* bounds4);
+
+/* so_dframe_collect in two steps: so_dframe_wait blocks until the frame is complete on the device - from then on it can
+ * be searched (so_track_search_*_submit) - and so_dframe_collect afterwards only copies the host mirrors out.  The
+ * tracking thread issues the motion-model search between the two: the search kernel runs under the copies and under
+ * the next frame's submission. */
+int so_dframe_wait(so_dframe* f, int* n_out, float* bounds4);
 
 /* Device pointers of a collected frame (valid until the handle's next submit). */
 typedef struct {
@@ -572,6 +585,9 @@ typedef struct {
     int32_t* info; /* [iterations, lm_trials], may be NULL */
 } so_pose_problem;
 int so_pose_optimization_batch(so_ba* ba, int32_t n_problems, const so_pose_problem* problems);
+/* HIP events around the PoseOptimization kernel on / off (on by default; a caller that samples the kernel time on some
+ * frames only switches them off in between: two event records per call). */
+int so_pose_optimization_set_timing(so_ba* ba, int enabled);
 /* HIP-event time (ms) of the kernel of the last so_pose_optimization call on this handle. */
 int so_pose_optimization_last_kernel_ms(so_ba* ba, float* ms);
 

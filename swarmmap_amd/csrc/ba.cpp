@@ -115,6 +115,7 @@ struct so_ba {
     hipEvent_t pe0 = nullptr, pe1 = nullptr;  // around the PoseOptimization kernel (its own pair: another thread may be in so_bundle_adjust)
     float pose_kernel_ms = 0.f;
     bool pose_ms_pending = false;  // pe0 / pe1 hold a finished measurement not yet read
+    bool pose_timing = true;       // HIP events around the PoseOptimization kernel (so_pose_optimization_set_timing)
     static constexpr int kSolveEvents = 32;  // the first trials of a call are event-timed around the solve kernel
     hipEvent_t ev_solve[2 * kSolveEvents] = {nullptr};
     float solve_ms = 0.f;
@@ -749,7 +750,8 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     a.n = n;
     a.err = reinterpret_cast<double*>(d + off_err);
     a.trace = env_trace ? reinterpret_cast<double*>(d + off_trace) : nullptr;
-    static const bool no_events = getenv("SWARMORB_NO_EVENTS") != nullptr;  // diagnostic: cost of the two event records
+    static const bool env_no_events = getenv("SWARMORB_NO_EVENTS") != nullptr;  // diagnostic: cost of the two event records
+    const bool no_events = env_no_events || !b->pose_timing;
     if (!no_events) SO_HIP(hipEventRecord(b->pe0, s));
     launch_pose_opt(a, s);
     if (!no_events) SO_HIP(hipEventRecord(b->pe1, s));
@@ -844,12 +846,12 @@ int so_pose_optimization_batch(so_ba* b, int32_t n_problems, const so_pose_probl
         a.err = nullptr;
         a.trace = nullptr;
     }
-    SO_HIP(hipEventRecord(b->pe0, s));
+    if (b->pose_timing) SO_HIP(hipEventRecord(b->pe0, s));
     if (!launch_pose_opt_batch(reinterpret_cast<const PoseOptArgs*>(d), n_problems, max_n, s)) return SO_ERR_INVALID_ARG;
-    SO_HIP(hipEventRecord(b->pe1, s));
+    if (b->pose_timing) SO_HIP(hipEventRecord(b->pe1, s));
     SO_HIP(hipGetLastError());
     SO_HIP(hipStreamSynchronize(s));
-    b->pose_ms_pending = true;
+    b->pose_ms_pending = b->pose_timing;
     for (int p = 0; p < n_problems; p++) {
         const so_pose_problem& q = problems[p];
         *q.n_inliers = 0;
@@ -867,6 +869,16 @@ int so_pose_optimization_batch(so_ba* b, int32_t n_problems, const so_pose_probl
             q.info[0] = inf[1];
             q.info[1] = inf[2];
         }
+    }
+    return SO_OK;
+}
+
+int so_pose_optimization_set_timing(so_ba* b, int enabled) {
+    if (!b) return SO_ERR_INVALID_ARG;
+    b->pose_timing = enabled != 0;
+    if (!b->pose_timing) {
+        b->pose_ms_pending = false;
+        b->pose_kernel_ms = 0.f;
     }
     return SO_OK;
 }

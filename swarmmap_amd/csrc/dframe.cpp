@@ -73,6 +73,8 @@ int submit_impl(so_dframe* f, const uint8_t* image, bool on_device, int w, int h
         return SO_ERR_INVALID_ARG;
     }
     f->ready = false;
+    f->waited = false;
+    f->mirrors = false;
     int rc = on_device ? so_extractor_submit_device(f->ex, image, w, h, stride)
                        : so_extractor_submit(f->ex, image, w, h, stride);
     if (rc) return rc;
@@ -203,6 +205,48 @@ int so_dframe_submit_device(so_dframe* f, const uint8_t* d_image, int width, int
     return submit_impl(f, d_image, true, width, height, stride);
 }
 
+// first half of collect: wait for the device side, read the header (count, bounds, position -> index map are valid)
+int so_dframe_wait(so_dframe* f, int* n_out, float* bounds4) {
+    if (!f || !n_out) return SO_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (!f->in_flight) {
+        last_error_ref() = "so_dframe_wait without a submitted frame";
+        return SO_ERR_INVALID_ARG;
+    }
+    if (f->waited) {
+        *n_out = f->n;
+        if (bounds4) memcpy(bounds4, f->bounds, 16);
+        return SO_OK;
+    }
+    int n = 0;
+    const int rc = so_extractor_wait(f->ex, &n);  // waits for the extractor's stream (the prepare kernel is behind it)
+    if (rc) return rc;
+    if (!f->allocated || !f->launched) {  // an empty image: nothing ran behind the extractor
+        f->n = f->n_inside = 0;
+        f->ready = f->allocated;  // (bounds are those of the handle's earlier frames: they depend on the camera only)
+        f->waited = true;
+        return SO_OK;
+    }
+    // the prepare kernel was enqueued behind the extractor's frame on the same stream; the extractor's wait covers it
+    // on every path but the host-quadtree one, which finishes inside submit
+    ExtractorDeviceView V;
+    if (extractor_device_view(f->ex, &V) == SO_OK) SO_HIP(hipStreamSynchronize(V.stream));
+    if (f->h_header[0] != n) {
+        last_error_ref() = "so_dframe_wait: device and host keypoint counts differ";
+        return SO_ERR_HIP;
+    }
+    f->n = n;
+    f->n_inside = f->h_header[1];
+    memcpy(f->bounds, f->h_header + 4, 16);
+    // octave / angle mirrors for the matcher's resolve come straight from the extractor's host-mapped results
+    f->waited = true;
+    f->ready = true;
+    f->mirrors = false;
+    *n_out = n;
+    if (bounds4) memcpy(bounds4, f->bounds, 16);
+    return SO_OK;
+}
+
 int so_dframe_collect(so_dframe* f, so_keypoint* keypoints, float* xy_un, uint8_t* descriptors, int capacity,
                       int* n_out, float* bounds4) {
     if (!f || !n_out || !keypoints || !descriptors) return SO_ERR_INVALID_ARG;
@@ -211,34 +255,20 @@ int so_dframe_collect(so_dframe* f, so_keypoint* keypoints, float* xy_un, uint8_
         last_error_ref() = "so_dframe_collect without a submitted frame";
         return SO_ERR_INVALID_ARG;
     }
-    int n = 0;
-    const int rc = so_extractor_collect(f->ex, keypoints, descriptors, capacity, &n);  // waits for the stream
-    if (rc) return rc;
+    int n = 0, rc;
+    if ((rc = so_dframe_wait(f, &n, nullptr))) return rc;
+    int n2 = 0;
+    if ((rc = so_extractor_collect(f->ex, keypoints, descriptors, capacity, &n2))) return rc;  // copies only
     f->in_flight = false;
-    if (!f->allocated || !f->launched) {  // an empty image: nothing ran behind the extractor
-        f->n = f->n_inside = 0;
-        f->ready = f->allocated;  // (bounds are those of the handle's earlier frames: they depend on the camera only)
-        *n_out = 0;
-        return SO_OK;
-    }
-    // the prepare kernel was enqueued behind the extractor's frame on the same stream; the extractor's collect
-    // waited for the stream on every path but the host-quadtree one, which finishes inside submit
-    ExtractorDeviceView V;
-    if (extractor_device_view(f->ex, &V) == SO_OK) SO_HIP(hipStreamSynchronize(V.stream));
-    if (f->h_header[0] != n) {
-        last_error_ref() = "so_dframe_collect: device and host keypoint counts differ";
-        return SO_ERR_HIP;
-    }
-    f->n = n;
-    f->n_inside = f->h_header[1];
-    memcpy(f->bounds, f->h_header + 4, 16);
+    f->waited = false;
+    if (!f->allocated || !f->launched) return SO_OK;
     for (int i = 0; i < n; i++) {
         f->octave[(size_t)i] = keypoints[i].octave;
         f->angle[(size_t)i] = keypoints[i].angle;
     }
+    f->mirrors = true;
     if (xy_un) memcpy(xy_un, f->h_xy_un, sizeof(float) * 2 * (size_t)n);
     if (bounds4) memcpy(bounds4, f->bounds, 16);
-    f->ready = true;
     *n_out = n;
     return SO_OK;
 }

@@ -27,8 +27,10 @@ struct so_dframe {
     float scale[8] = {0};
     bool allocated = false;
     bool in_flight = false;
+    bool waited = false;    // so_dframe_wait has run for the frame in flight: the device side is complete
     bool launched = false;  // the frame in flight has a prepare kernel behind it (false for an empty image)
-    bool ready = false;  // collected: n / n_inside / bounds and the host mirrors are valid
+    bool ready = false;    // the device side is complete: n / n_inside / bounds / position map valid, searches may be submitted
+    bool mirrors = false;  // collected: the host copies of octave / angle (read by the searches' resolve) are valid
     uint64_t generation = 0;  // bumped by every submit (the matcher's "same frame as before" check)
     // device
     uint8_t* d_block = nullptr;

@@ -268,7 +268,7 @@ int collect_impl(so_extractor* ex, so_keypoint* kps, uint8_t* desc, int capacity
     }
     SO_HIP(hipSetDevice(ex->cfg.device));
     const bool prof = ex->pending_prof;
-    SO_HIP(hipStreamSynchronize(ex->stream));  // the only sync of the frame
+    if (ex->pending == 1) SO_HIP(hipStreamSynchronize(ex->stream));  // the only sync of the frame (unless so_extractor_wait did it)
     ex->pending = 0;
     const double t_synced = now_ms();
     ex->cands_on_host = false;
@@ -624,6 +624,24 @@ int so_extractor_submit_device(so_extractor* ex, const uint8_t* d_image, int wid
 
 int so_extractor_collect(so_extractor* ex, so_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out) {
     return collect_impl(ex, keypoints, descriptors, capacity, n_out);
+}
+
+int so_extractor_wait(so_extractor* ex, int* n_out) {
+    if (!ex || !n_out) return SO_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (ex->pending == 0) {
+        last_error_ref() = "so_extractor_wait without a submitted frame";
+        return SO_ERR_INVALID_ARG;
+    }
+    if (ex->pending == 2) {  // finished inside submit (host-quadtree contexts, empty images)
+        *n_out = ex->pend_n;
+        return SO_OK;
+    }
+    SO_HIP(hipSetDevice(ex->cfg.device));
+    if (ex->pending == 1) SO_HIP(hipStreamSynchronize(ex->stream));
+    ex->pending = 3;  // synchronised, results still in the context's host-mapped buffers
+    *n_out = std::min(*ex->h_total, ex->out_capacity);
+    return SO_OK;
 }
 
 int so_extractor_quadtree_on_device(const so_extractor* ex) { return (ex && ex->allocated && ex->device_qt) ? 1 : 0; }

@@ -556,6 +556,13 @@ int so_matcher_last_kernel_ms(so_matcher* m, float* ms) {
     return SO_OK;
 }
 
+int so_matcher_set_profiling(so_matcher* m, int enabled) {
+    if (!m) return SO_ERR_INVALID_ARG;
+    static const bool env_no_events = getenv("SWARMORB_NO_EVENTS") != nullptr;
+    m->profile = enabled != 0 && !env_no_events;
+    return SO_OK;
+}
+
 int so_matcher_reuse_frame(so_matcher* m) {
     if (!m) return SO_ERR_INVALID_ARG;
     m->reuse_next = true;
@@ -808,7 +815,7 @@ int so_search_by_projection_mappoints_dframe(so_matcher* m, const so_dframe* F, 
                                              int32_t* nmatches) {
     if (!m) return SO_ERR_INVALID_ARG;
     (void)take_reuse(m);
-    if (!F || !F->ready || n_mp < 0 || !kp_to_mp || !nmatches) return SO_ERR_INVALID_ARG;
+    if (!F || !F->ready || !F->mirrors || n_mp < 0 || !kp_to_mp || !nmatches) return SO_ERR_INVALID_ARG;
     if (n_mp > 0 && (!in_view || !proj_x || !proj_y || !view_cos || !pred_level || !mp_desc || !mp_has_obs))
         return SO_ERR_INVALID_ARG;
     const so_frame_view v = view_of(F, excluded);
@@ -836,7 +843,7 @@ int so_search_by_projection_lastframe_dframe(so_matcher* m, const so_dframe* cur
                                              int check_orientation, int32_t* kp_to_last, int32_t* nmatches) {
     if (!m) return SO_ERR_INVALID_ARG;
     (void)take_reuse(m);
-    if (!cur || !cur->ready || n_last < 0 || !kp_to_last || !nmatches) return SO_ERR_INVALID_ARG;
+    if (!cur || !cur->ready || !cur->mirrors || n_last < 0 || !kp_to_last || !nmatches) return SO_ERR_INVALID_ARG;
     if (n_last > 0 && (!valid || !u || !v || !last_octave || !mp_desc || !mp_has_obs)) return SO_ERR_INVALID_ARG;
     if (check_orientation && n_last > 0 && !last_angle) return SO_ERR_INVALID_ARG;
     const so_frame_view vw = view_of(cur, excluded);
@@ -1673,6 +1680,11 @@ int so_track_search_last_frame_wait(so_matcher* m, const uint8_t* slot_has_obs, 
     const so_dframe* cur = P.cur;
     const so_dframe* last = P.last;
     const int n_last = P.nq;
+    if (!cur->mirrors || !last->mirrors) {  // the resolve reads the frames' host copies (octave, angle)
+        (void)hipStreamSynchronize(m->stream);
+        last_error_ref() = "so_track_search_last_frame_wait: collect both frames (so_dframe_collect) before waiting for the search";
+        return SO_ERR_INVALID_ARG;
+    }
     *nmatches = 0;
     for (int k = 0; k < cur->n; k++) kp_to_last[k] = -1;
     if (P.empty) return SO_OK;
@@ -1801,6 +1813,11 @@ int so_track_search_local_map_wait(so_matcher* m, const uint8_t* slot_has_obs, u
     m->pend.mode = 0;
     const so_dframe* cur = P.cur;
     const int n_local = P.nq;
+    if (!cur->mirrors) {
+        (void)hipStreamSynchronize(m->stream);
+        last_error_ref() = "so_track_search_local_map_wait: collect the frame (so_dframe_collect) before waiting for the search";
+        return SO_ERR_INVALID_ARG;
+    }
     *nmatches = 0;
     for (int k = 0; k < cur->n; k++) kp_to_local[k] = -1;
     if (in_view && n_local > 0) memset(in_view, 0, (size_t)n_local);

@@ -33,6 +33,8 @@
 
 namespace {
 
+constexpr int kEventEvery = 4;
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -165,9 +167,10 @@ struct so_replay {
     struct Step {
         double t0 = 0, t1 = 0, tm2 = 0, tp1 = 0, tm1 = 0, tp2 = 0, tp3 = 0, tmap = 0;
         double match_kernel = 0, pose_kernel = 0, pose_trials = 0, pose_points = 0, mstat[4] = {0, 0, 0, 0};
-        int pose_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0, hcur = 0, first_slot = 0;
+        int pose_calls = 0, pose_timed_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0, hcur = 0, first_slot = 0;
         int32_t n_in = 0;
-        bool first = false;
+        bool first = false, m2_submitted = false, timed_kernels = true;
+        int m2_rc = 0;
         float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
         M4 T = M4::eye();
     } step;
@@ -183,8 +186,8 @@ namespace {
 enum {  // indices of so_replay::stat, mirrored in bench.py
     kSteps = 0, kExtractMs, kM2Ms, kPose1Ms, kM1Ms, kPose2Ms, kPose3Ms, kMapMs, kSubmitWaitMs, kKp, kM2, kM1, kInliers,
     kMatchKernelMs, kPoseKernelMs, kPoseTrials, kPoseCalls, kPosePoints, kLbaWindows, kLbaBusyMs, kLbaGpuMs, kLbaSolveMs,
-    kLbaSolves, kLocalPoints, kInView, kKeyframes, kMapPoints, kM2EnqMs, kM2WaitMs, kM1EnqMs, kM1WaitMs,
-    kStage0 /* 11 extractor stages */
+    kLbaSolves, kLocalPoints, kInView, kKeyframes, kMapPoints, kM2EnqMs, kM2WaitMs, kM1EnqMs, kM1WaitMs, kPoseTimedCalls,
+    kTimedFrames, kStage0 /* 11 extractor stages */
 };
 
 void mapper_loop(so_replay* r) {
@@ -425,19 +428,32 @@ int so_replay_prime(so_replay* r, int t) {
 //      one launch). ----
 namespace {
 
+int step_m2_submit(so_replay* r);
+
 // Frame constructor: collect frame t, put frame t+1 in flight.  The first frame of a run initialises the map.
 int step_begin(so_replay* r, int t) {
     so_replay::Step& S = r->step;
     S = so_replay::Step{};
     S.t0 = now_ms();
+    // kernel times come from HIP events on every kEventEvery-th frame of the run (two event records per search and
+    // per PoseOptimization call are ~11 us of a 0.43 ms frame when taken on every frame)
+    S.timed_kernels = (t % kEventEvery) == 0;
+    so_matcher_set_profiling(r->matcher, S.timed_kernels);
+    so_pose_optimization_set_timing(r->tracker_opt, S.timed_kernels);
     S.hcur = r->submitted;
     r->cur ^= 1;
     so_replay::FrameHost& F = r->fh[r->cur];
     int n = 0;
+    if (so_dframe_wait(r->fr[S.hcur], &n, r->bounds) != SO_OK) return fail(r, "so_dframe_wait");
+    F.n = n;
+    S.first = r->n_tracked == 0;
+    // the frame is complete on the device: the motion-model search goes out now and runs under the host copies of the
+    // keypoints and under the submission of the next frame
+    if (!S.first && (S.m2_rc = step_m2_submit(r))) return S.m2_rc;
+    S.m2_submitted = !S.first;
     if (so_dframe_collect(r->fr[S.hcur], F.kps.data(), F.xy_un.data(), F.desc.data(), r->cap, &n, r->bounds) != SO_OK)
         return fail(r, "so_dframe_collect");
     r->in_flight = false;
-    F.n = n;
     const int rc = submit_frame(r, t + 1);
     if (rc) return rc;
     S.t1 = S.tm2 = S.tp1 = S.tm1 = S.tp2 = S.tp3 = S.tmap = now_ms();
@@ -445,7 +461,6 @@ int step_begin(so_replay* r, int t) {
     for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = -1;
     memset(F.outlier.data(), 0, (size_t)n);
     S.T = M4::eye();
-    S.first = r->n_tracked == 0;
     if (S.first) {  // every keypoint becomes a map point, the camera defines the world frame
         std::vector<uint8_t> all((size_t)n, 1);
         const int first = add_points(r, S.T, F, all, n);
@@ -528,10 +543,12 @@ void pose_gather(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_i
 
 void pose_account(so_replay* r, const so_pose_problem& q, float kernel_ms) {
     so_replay::Step& S = r->step;
+    S.pose_calls++;
+    if (!S.timed_kernels) return;  // kernel time, trials and points are accumulated over the event-timed calls only
     S.pose_kernel += kernel_ms;
     S.pose_trials += q.info[1];
     S.pose_points += q.n;
-    S.pose_calls++;
+    S.pose_timed_calls++;
 }
 
 int pose_single(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers) {
@@ -670,7 +687,8 @@ void step_end(so_replay* r, int t, int timed) {
         st[kM1Ms] += S.tm1 - S.tp1; st[kPose2Ms] += S.tp2 - S.tm1; st[kPose3Ms] += S.tp3 - S.tp2; st[kMapMs] += S.tmap - S.tp3;
         st[kSubmitWaitMs] += t4 - t3; st[kKp] += F.n; st[kM2] += S.nm2; st[kM1] += S.nm1; st[kInliers] += S.n_in;
         st[kMatchKernelMs] += S.match_kernel; st[kPoseKernelMs] += S.pose_kernel; st[kPoseTrials] += S.pose_trials;
-        st[kPoseCalls] += S.pose_calls; st[kPosePoints] += S.pose_points; st[kLocalPoints] += S.n_local; st[kInView] += S.n_view;
+        st[kPoseCalls] += S.pose_calls; st[kPosePoints] += S.pose_points; st[kPoseTimedCalls] += S.pose_timed_calls;
+        st[kTimedFrames] += S.timed_kernels ? 1 : 0; st[kLocalPoints] += S.n_local; st[kInView] += S.n_view;
         st[kKeyframes] += S.keyframe; st[kMapPoints] = (double)(r->mp_X.size() / 3);
         st[kM2EnqMs] += S.mstat[0]; st[kM2WaitMs] += S.mstat[1]; st[kM1EnqMs] += S.mstat[2]; st[kM1WaitMs] += S.mstat[3];
         float prof[SO_EXTRACTOR_N_STAGES];
@@ -690,8 +708,7 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
         int rc;
         if ((rc = step_begin(r, t))) return rc;
         if (!S.first) {
-            if ((rc = step_m2_submit(r))) return rc;
-            if ((rc = step_m2_wait(r))) return rc;
+            if ((rc = step_m2_wait(r))) return rc;  // submitted inside step_begin
             int32_t inl = 0;
             if ((rc = pose_single(r, S.Tp, S.Ta, &inl))) return rc;
             pose1_apply(r);
@@ -751,9 +768,7 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
         int rc;
         for (int a = 0; a < n_agents; a++)
             if ((rc = step_begin(agents[a], t))) return rc;
-        for (int a = 0; a < n_agents; a++)
-            if (!agents[a]->step.first && (rc = step_m2_submit(agents[a]))) return rc;
-        for (int a = 0; a < n_agents; a++)
+        for (int a = 0; a < n_agents; a++)  // (each agent's motion-model search went out inside its step_begin)
             if (!agents[a]->step.first && (rc = step_m2_wait(agents[a]))) return rc;
         if ((rc = pose_batch(0))) return rc;
         for (int a = 0; a < n_agents; a++)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 STAT = ("steps", "extract_ms", "m2_ms", "pose1_ms", "m1_ms", "pose2_ms", "pose3_ms", "map_ms", "lba_ms", "n_kp", "n_m2",
         "n_m1", "n_inliers", "match_kernel_ms", "pose_kernel_ms", "pose_trials", "pose_calls", "pose_points", "n_lba",
         "lba_busy_ms", "lba_gpu_ms", "solve_ms", "n_solves", "n_local", "n_in_view", "n_keyframes", "n_map_points",
-        "m2_enqueue_ms", "m2_wait_ms", "m1_enqueue_ms", "m1_wait_ms")
+        "m2_enqueue_ms", "m2_wait_ms", "m1_enqueue_ms", "m1_wait_ms", "pose_timed_calls", "timed_frames")
 
 
 class Replay:
