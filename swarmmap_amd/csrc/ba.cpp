@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cfloat>
 #include <cmath>
@@ -53,6 +54,12 @@ struct Buf {
 
 constexpr int kMaxReducedDim = 96 * kDenseMaxPanels;  // reduced camera system: 6 * n_free <= 49152 (8192 keyframes; S is
                                                      // stored densely - 19 GB of the 288 GB - but only its block skyline is computed on)
+
+// dense_flow_kernel's workgroups wait for each other, so every one of a launch must be resident (one per CU: 152 KB of
+// LDS).  The tiles of all solver contexts of this process that are inside so_bundle_adjust at the same time have to fit
+// the budget; a context that does not get its share solves with the multi-launch path for that call.
+constexpr int kFlowResidentBudget = 240;  // of 256 CUs
+std::atomic<int> g_flow_tiles{0};
 
 double now_ms() {
     using namespace std::chrono;
@@ -123,6 +130,8 @@ struct so_ba {
     hipStream_t dense_side = nullptr;       // blocked dense solver: side stream + events of its look-ahead
     std::vector<hipEvent_t> dense_events;
     DensePlan plan;                         // blocked solver: tiles of every trailing update for the current structure
+    unsigned flow_epoch = 0;                // single-launch dataflow solve: stamp of the last solve (never reset)
+    int flow_reserved = 0;                  // tiles this context holds of the process-wide residency budget
     std::vector<int> tile_first;
     BaLm* h_lm = nullptr;        // host-mapped copy of the LM state, written by the decision kernels
     BaLm* h_lm_dev = nullptr;
@@ -132,17 +141,20 @@ struct so_ba {
     // d_in: the problem as one block (see Layout in so_bundle_adjust), staged in pinned h_in and moved with one
     // copy; d_out / h_out: the result block coming back the same way; the rest is device-only working storage
     Buf d_in, d_out, d_pose1, d_pt1, d_err, d_chi2, d_tab, d_Hpp, d_bp, d_Hll, d_bl, d_W, d_Dinv, d_db, d_BDinv, d_S,
-        d_bs, d_xl, d_partial, d_po, d_lm, d_dense_ws, d_dense_x, d_pr_off, d_pr_cur, d_pr, d_big, d_scan_tmp, d_plan;
+        d_bs, d_xl, d_partial, d_po, d_lm, d_dense_ws, d_dense_x, d_pr_off, d_pr_cur, d_pr, d_big, d_scan_tmp, d_plan, d_flow;
     void* h_in = nullptr;
     size_t h_in_cap = 0;
     void* h_out = nullptr;
     size_t h_out_cap = 0;
+    void* h_plan = nullptr;  // pinned staging of the blocked solver's tile_first + tile lists
+    size_t h_plan_cap = 0;
     uint8_t* h_po = nullptr;      // pinned + host-mapped staging for PoseOptimization
     uint8_t* h_po_dev = nullptr;
     size_t h_po_cap = 0;
     std::vector<Buf*> all() {
         return {&d_in, &d_out, &d_pose1, &d_pt1, &d_err, &d_chi2, &d_tab, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv,
-                &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x, &d_pr_off, &d_pr_cur, &d_pr, &d_big, &d_scan_tmp, &d_plan};
+                &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x, &d_pr_off, &d_pr_cur, &d_pr, &d_big, &d_scan_tmp, &d_plan,
+                &d_flow};
     }
 };
 
@@ -288,6 +300,7 @@ void so_ba_destroy(so_ba* b) {
     if (b->h_lm) (void)hipHostFree(b->h_lm);
     if (b->h_in) (void)hipHostFree(b->h_in);
     if (b->h_out) (void)hipHostFree(b->h_out);
+    if (b->h_plan) (void)hipHostFree(b->h_plan);
     if (b->h_abort) (void)hipHostFree(b->h_abort);
     for (hipEvent_t ev : b->ev_solve)
         if (ev) (void)hipEventDestroy(ev);
@@ -340,6 +353,13 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     Run r;
     r.b = b;
     r.stop = stop;
+    struct FlowLease {  // the context's share of the residency budget goes back on every way out
+        so_ba* b;
+        ~FlowLease() {
+            if (b->flow_reserved > 0) g_flow_tiles.fetch_sub(b->flow_reserved);
+            b->flow_reserved = 0;
+        }
+    } flow_lease{b};
 
     auto finish_untouched = [&]() {  // Optimizer.cc:631-633: return before optimising
         for (int i = 0; i < nP; i++) {
@@ -497,8 +517,11 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         // I's keyframes; Cholesky fill stays inside that row envelope.
         const int T = (int)(ldS / 96);
         b->tile_first.resize((size_t)T);
-        for (int I = 0; I < T; I++) b->tile_first[(size_t)I] = I;
-        for (int l = 0; l < nL; l++) {
+        // (a local window of up to 128 keyframes - 8 tiles - is taken as dense: its keyframes are covisible by
+        // construction and the walk over the observations costs more than the few tiles it could drop)
+        constexpr int kSkylineMinTiles = 9;
+        for (int I = 0; I < T; I++) b->tile_first[(size_t)I] = T >= kSkylineMinTiles ? I : 0;
+        for (int l = 0; T >= kSkylineMinTiles && l < nL; l++) {
             int lo = INT_MAX;
             for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
                 const int h = h_hidx[h_epose[k]];
@@ -517,12 +540,25 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         const size_t first_bytes = (sizeof(int) * (size_t)T + 255) & ~(size_t)255;
         const size_t tiles_bytes = sizeof(int2) * std::max<size_t>(b->plan.tiles.size(), 1);
         if ((rc = b->d_plan.ensure(first_bytes + tiles_bytes))) return rc;
-        SO_HIP(hipMemcpyAsync(b->d_plan.p, b->tile_first.data(), sizeof(int) * (size_t)T, hipMemcpyHostToDevice, s));
-        if (!b->plan.tiles.empty())
-            SO_HIP(hipMemcpyAsync((uint8_t*)b->d_plan.p + first_bytes, b->plan.tiles.data(), sizeof(int2) * b->plan.tiles.size(),
-                                  hipMemcpyHostToDevice, s));
-        SO_HIP(hipStreamSynchronize(s));  // the host vectors may be rebuilt by the next call
+        // one copy from pinned memory, no wait: the call does not return before the stream has drained
+        if ((rc = ensure_pinned(&b->h_plan, &b->h_plan_cap, first_bytes + tiles_bytes))) return rc;
+        memcpy(b->h_plan, b->tile_first.data(), sizeof(int) * (size_t)T);
+        if (!b->plan.tiles.empty()) memcpy((uint8_t*)b->h_plan + first_bytes, b->plan.tiles.data(), sizeof(int2) * b->plan.tiles.size());
+        SO_HIP(hipMemcpyAsync(b->d_plan.p, b->h_plan, first_bytes + sizeof(int2) * b->plan.tiles.size(), hipMemcpyHostToDevice, s));
+        if (b->plan.flow_n_tiles > 0) {
+            const int want = b->plan.flow_n_tiles;
+            int cur = g_flow_tiles.load();
+            while (cur + want <= kFlowResidentBudget && !g_flow_tiles.compare_exchange_weak(cur, cur + want)) {
+            }
+            if (cur + want <= kFlowResidentBudget) b->flow_reserved = want;
+        }
+        if (b->flow_reserved > 0 && !b->d_flow.p) {
+            const size_t bytes = sizeof(unsigned) * kFlowFlagWords + sizeof(double) * 2 * 256 * 96;
+            if ((rc = b->d_flow.ensure(bytes))) return rc;
+            SO_HIP(hipMemsetAsync(b->d_flow.p, 0, bytes, s));
+        }
     }
+    const double t_dense_setup = now_ms();
     // pair lists of the large-map gather: capacity from the landmarks' observation counts (an upper bound: fixed
     // keyframes' observations are counted too)
     size_t pair_cap = 0, n_blk = (size_t)nf * ((size_t)nf + 1) / 2, big_cap = 0, scan_bytes = 0;
@@ -609,6 +645,11 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.tile_first = dense_path ? b->d_plan.as<int>() : nullptr;
     d.plan_tiles = dense_path ? reinterpret_cast<const int2*>((const uint8_t*)b->d_plan.p + ((sizeof(int) * (ldS / 96) + 255) & ~(size_t)255)) : nullptr;
     d.plan = dense_path ? &b->plan : nullptr;
+    const bool flow = dense_path && b->flow_reserved > 0;
+    d.flow_tiles = flow ? d.plan_tiles + b->plan.flow_first_tile : nullptr;
+    d.flow_flags = flow ? b->d_flow.as<unsigned>() : nullptr;
+    d.flow_vec = flow ? reinterpret_cast<double*>(b->d_flow.as<unsigned>() + kFlowFlagWords) : nullptr;
+    d.flow_epoch = &b->flow_epoch;
     d.xl = b->d_xl.as<double>();
     d.partial = b->d_partial.as<double>();
     d.robust = opt->robust;
@@ -621,6 +662,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     if (pairs_path) launch_ba_build_pairs(d, b->d_scan_tmp.p, scan_bytes, s);
 
     const double t_uploaded = now_ms();
+    if (trace) fprintf(stderr, "[ba] dense setup done at +%.3f, launches done at +%.3f\n", t_dense_setup - t_staged, t_uploaded - t_staged);
     SO_HIP(hipEventRecord(b->e0, s));
     double chi = 0.0;
     int done = 0;

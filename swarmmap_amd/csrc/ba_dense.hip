@@ -184,23 +184,13 @@ __device__ __forceinline__ void potrf_tri(int t, int& ti, int& tj) {
     tj = t - ti * (ti + 1) / 2;
 }
 
-__global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
-    __shared__ double A[kDNB][kPS];
-    __shared__ double X[kDNB][kPS];
-    __shared__ int s_bad;
-    if (!d.lm->active) return;
-    const int tid = threadIdx.x, ld = d.ldS, lane = tid & 63, wave = tid >> 6;
+// The block's lower 16x16 tiles are in A (LDS); on return X holds the inverse of its Cholesky factor (lower tiles; the
+// diagonal tiles are zero above the diagonal, tiles above the diagonal are never written).  *s_bad must be 0 on entry
+// (and a barrier between that store and the call); it becomes 1 if a pivot is not positive.  Ends with a barrier.
+__device__ __forceinline__ void potrf_block_lds(double (*A)[kPS], double (*X)[kPS], int* s_bad_p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int crow = lane >> 4, ccol = lane & 15;  // MFMA result layout: element (crow + 4 reg, ccol)
-    const double* Sk = d.S + (size_t)k * kDNB * ld + (size_t)k * kDNB;
-    if (tid == 0) s_bad = 0;
-    for (int i = tid; i < (kPT * (kPT + 1) / 2) * 128; i += 256) {  // lower tiles only, 128 double2 per tile
-        int ti, tj;
-        potrf_tri(i >> 7, ti, tj);
-        const int e = i & 127, r = 16 * ti + (e >> 3), c = 16 * tj + 2 * (e & 7);
-        const double2 v = *reinterpret_cast<const double2*>(Sk + (size_t)r * ld + c);
-        A[r][c] = v.x; A[r][c + 1] = v.y;
-    }
-    __syncthreads();
+    int& s_bad = *s_bad_p;
     SO_POTRF_MARK(0);
     if (wave == 0 && !potrf_diag16<kPS>(&A[0][0], &A[0][0], &X[0][0], lane) && lane == 0) s_bad = 1;
     __syncthreads();
@@ -257,14 +247,37 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
         __syncthreads();
     }
     SO_POTRF_MARK(25);
-    double* Linv = d.dense_ws + (size_t)k * kDNB * kDNB;
-    for (int i = tid; i < kDNB * (kDNB / 2); i += 256) {
+}
+
+// the inverse factor as a full row-major 96x96 block in HBM (zeros above the diagonal): what the panel GEMM reads
+__device__ __forceinline__ void potrf_store_inverse(double (*X)[kPS], double* __restrict__ Linv) {
+    for (int i = threadIdx.x; i < kDNB * (kDNB / 2); i += 256) {
         const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
         double2 x;
         const bool low = (c >> 4) <= (r >> 4);  // tiles above the diagonal are zero (and were never written in LDS)
         x.x = low ? X[r][c] : 0.0; x.y = low ? X[r][c + 1] : 0.0;
         *reinterpret_cast<double2*>(Linv + (size_t)r * kDNB + c) = x;
     }
+}
+
+__global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
+    __shared__ double A[kDNB][kPS];
+    __shared__ double X[kDNB][kPS];
+    __shared__ int s_bad;
+    if (!d.lm->active) return;
+    const int tid = threadIdx.x, ld = d.ldS;
+    const double* Sk = d.S + (size_t)k * kDNB * ld + (size_t)k * kDNB;
+    if (tid == 0) s_bad = 0;
+    for (int i = tid; i < (kPT * (kPT + 1) / 2) * 128; i += 256) {  // lower tiles only, 128 double2 per tile
+        int ti, tj;
+        potrf_tri(i >> 7, ti, tj);
+        const int e = i & 127, r = 16 * ti + (e >> 3), c = 16 * tj + 2 * (e & 7);
+        const double2 v = *reinterpret_cast<const double2*>(Sk + (size_t)r * ld + c);
+        A[r][c] = v.x; A[r][c + 1] = v.y;
+    }
+    __syncthreads();
+    potrf_block_lds(A, X, &s_bad);
+    potrf_store_inverse(X, d.dense_ws + (size_t)k * kDNB * kDNB);
     SO_POTRF_MARK(26);
     if (tid == 0 && s_bad) d.partial[kBaSolveOk] = 0.0;
 }
@@ -648,16 +661,19 @@ bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s) {
 // ---- 96x96 tile of C = PA * PB^T on the FP64 matrix cores ----
 // PA, PB: 96 rows x klen k (96 or 192: one or two panels), row-major with leading dimensions lda / ldb.  acc[rt][ct] is the wave's 48x48 quadrant
 // as 3x3 MFMA tiles; element (row, col) of tile (rt, ct): col = lane & 15, row = (lane >> 4) + 4 * reg.
+template <bool ZERO = true>
 __device__ __forceinline__ void dense_tile_nt(const double* __restrict__ PA, int lda, const double* __restrict__ PB,
                                               int ldb, double (*sA)[kDStride], double (*sB)[kDStride], d4 acc[3][3],
                                               int klen = kDNB) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
     const int fr = lane & 15, fk = lane >> 4;
+    if (ZERO) {
 #pragma unroll
-    for (int rt = 0; rt < 3; rt++)
+        for (int rt = 0; rt < 3; rt++)
 #pragma unroll
-        for (int ct = 0; ct < 3; ct++) acc[rt][ct] = d4{0.0, 0.0, 0.0, 0.0};
+            for (int ct = 0; ct < 3; ct++) acc[rt][ct] = d4{0.0, 0.0, 0.0, 0.0};
+    }
     // a K-chunk is 96 rows x 24 double2 per operand: 9 double2 per thread and operand.  The next chunk is fetched
     // into registers while the matrix cores work on the current one (global latency hides behind 108 MFMAs a wave).
     constexpr int kPer = kDNB * (kDChunk / 2) / 256;
@@ -849,6 +865,266 @@ __global__ void dense_begin_kernel(BaDev d) {
     d.partial[kBaSolveOk] = 0.5;  // becomes 0 if a pivot fails, 1 at the end otherwise
 }
 
+// ---- single-launch tile dataflow (mid-size systems: local windows of 44..128 free keyframes, small global maps) ----
+// The blocked factorisation above costs 3 launches per panel plus one per panel for the backward substitution; with 3-8
+// panels every launch is a 5-25 us island and a 64-keyframe window pays 17 of them per LM trial.  Here ONE launch runs
+// the whole solve: a 256-thread workgroup per 96x96 tile of the block skyline, all of them resident at once (at most
+// kFlowMaxTiles, one per CU: 152 KB of LDS each), meeting through epoch-stamped flags in HBM (agent-scope release /
+// acquire; the epoch is a kernel argument that grows with every solve, so nothing is ever reset).
+//   tile (I, J), J < I   left-looking: acc = S_IJ - sum_k L_Ik L_Jk^T as the column tiles k become ready (whatever prefix
+//                        is ready goes through the matrix cores in one K-loop), waits for the inverse factor of diagonal
+//                        block J, L_IJ = acc Linv_J^T straight from LDS, publishes L_IJ; then the two vectors the
+//                        substitutions need from this tile: L_IJ y_J (forward) and, at the very end, L_IJ^T x_I (backward)
+//   tile (J, J)          the same accumulation, Cholesky + inverse in LDS (potrf_block_lds), publishes Linv_J;
+//                        y_J = Linv_J (b_J - sum_k [L_Jk y_k]) from the row's forward vectors in ascending k, then
+//                        x_J = Linv_J^T (y_J - sum_i [L_iJ^T x_i]) from the column's backward vectors in descending i:
+//                        fixed summation orders, deterministic.  b, y and x share d.bs (every reader of y_J is done
+//                        before x_J exists).
+// The critical path is potrf(J) -> L_{J+1,J} -> update of (J+1, J+1) -> potrf(J+1): everything else overlaps with it.
+constexpr int kFlowMaxTiles = 231;   // 21 panels dense (2016 unknowns, 336 keyframes); a skyline may reach further
+constexpr int kFlowSlots = 256;      // flag / vector slots per kind: tile (I, J) -> I (I + 1) / 2 + J
+constexpr int kFlowFlagTile = 0, kFlowFlagFwd = kFlowSlots, kFlowFlagBwd = 2 * kFlowSlots, kFlowFlagY = 3 * kFlowSlots,
+              kFlowFlagX = 3 * kFlowSlots + 32, kFlowFlagBad = 3 * kFlowSlots + 64;
+constexpr int kFlowLdsDoubles = 2 * kDNB * kDStride + kDNB * kPS;  // GEMM chunks + one full tile >= the factor's A and X
+static_assert(kFlowLdsDoubles >= 2 * kDNB * kPS, "potrf_block_lds needs two padded blocks");
+static_assert(kFlowFlagBad < kFlowFlagWords, "flag words");
+static_assert(kFlowMaxTiles <= kFlowSlots && 22 * 21 / 2 <= kFlowSlots, "tile slots");
+
+__device__ __forceinline__ bool flow_ready(const unsigned* f, unsigned epoch) {
+    return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+}
+__device__ __forceinline__ void flow_wait(const unsigned* f, unsigned epoch) {  // one thread; flow_acquire() after the barrier
+    while (!flow_ready(f, epoch)) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void flow_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// every thread's global stores so far become visible device-wide, then the flag goes up
+__device__ __forceinline__ void flow_publish(unsigned* f, unsigned epoch) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// acc = sT (96 x 96 in LDS, row stride kPS) * PB^T, PB row-major in HBM: the panel GEMM with its left operand already on chip
+__device__ __forceinline__ void dense_tile_lds_nt(const double (*sT)[kPS], const double* __restrict__ PB, int ldb,
+                                                  double (*sB)[kDStride], d4 acc[3][3]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) acc[rt][ct] = d4{0.0, 0.0, 0.0, 0.0};
+    constexpr int kPer = kDNB * (kDChunk / 2) / 256;
+    double2 rb[kPer];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int idx = tid + 256 * q, r = idx / (kDChunk / 2), v = idx - r * (kDChunk / 2);
+            rb[q] = *reinterpret_cast<const double2*>(PB + (size_t)r * ldb + kc + 2 * v);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int idx = tid + 256 * q, r = idx / (kDChunk / 2), v = idx - r * (kDChunk / 2);
+            sB[r][2 * v] = rb[q].x; sB[r][2 * v + 1] = rb[q].y;
+        }
+    };
+    fetch(0);
+    __syncthreads();  // the caller's previous use of sB is over, its stores to sT are complete
+    stage();
+    __syncthreads();
+    for (int kc = 0; kc < kDNB; kc += kDChunk) {
+        const bool more = kc + kDChunk < kDNB;
+        if (more) fetch(kc + kDChunk);
+#pragma unroll 2
+        for (int kk = 0; kk < kDChunk; kk += 4) {
+            double a[3], b[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                a[t] = sT[wr + 16 * t + fr][kc + kk + fk];
+                b[t] = sB[wc + 16 * t + fr][kk + fk];
+            }
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+                for (int ct = 0; ct < 3; ct++)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+        }
+        if (more) {
+            __syncthreads();
+            stage();
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch) {
+    extern __shared__ __align__(16) double flow_lds[];
+    __shared__ int s_m, s_bad;
+    __shared__ double s_v[kDNB], s_u[kDNB];
+    if (!d.lm->active) return;
+    const int tid = threadIdx.x, ld = d.ldS, T = ld / kDNB;
+    const int2 t = d.flow_tiles[blockIdx.x];
+    const int I = t.x, J = t.y, self = I * (I + 1) / 2 + J;
+    unsigned* flags = d.flow_flags;
+    double (*sA)[kDStride] = reinterpret_cast<double (*)[kDStride]>(flow_lds);
+    double (*sB)[kDStride] = reinterpret_cast<double (*)[kDStride]>(flow_lds + kDNB * kDStride);
+    const int lane = tid & 63, wave = tid >> 6, wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
+    double* C = d.S + (size_t)I * kDNB * ld + (size_t)J * kDNB;
+    // tot = sum_k L_Ik L_Jk^T - S_IJ (the matrix cores only add)
+    d4 tot[3][3];
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
+                tot[rt][ct][reg] = -C[(size_t)r * ld + c];
+            }
+    const int lo = max(d.tile_first[I], d.tile_first[J]);
+    const double* Pi = d.S + (size_t)I * kDNB * ld;
+    const double* Pj = d.S + (size_t)J * kDNB * ld;
+    for (int k = lo; k < J;) {
+        if (tid == 0) {
+            int m = 0;
+            for (;;) {  // the ready prefix of the remaining column tiles, at least one
+                while (k + m < J && flow_ready(&flags[kFlowFlagTile + I * (I + 1) / 2 + k + m], epoch) &&
+                       flow_ready(&flags[kFlowFlagTile + J * (J + 1) / 2 + k + m], epoch))
+                    m++;
+                if (m > 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_m = m;
+        }
+        __syncthreads();
+        const int m = s_m;  // (the GEMM's barriers separate this read from the next store)
+        flow_acquire();
+        dense_tile_nt<false>(Pi + (size_t)k * kDNB, ld, Pj + (size_t)k * kDNB, ld, sA, sB, tot, m * kDNB);
+        k += m;
+    }
+    double* vec_fwd = d.flow_vec;
+    double* vec_bwd = d.flow_vec + (size_t)kFlowSlots * kDNB;
+    if (I != J) {
+        double (*sT)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds + 2 * kDNB * kDStride);  // disjoint from sA / sB
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
+                    sT[r][c] = -tot[rt][ct][reg];
+                }
+        if (tid == 0) flow_wait(&flags[kFlowFlagTile + J * (J + 1) / 2 + J], epoch);
+        __syncthreads();
+        flow_acquire();
+        d4 acc[3][3];
+        dense_tile_lds_nt(sT, d.dense_ws + (size_t)J * kDNB * kDNB, kDNB, sB, acc);
+        __syncthreads();  // every wave is done reading sT: it now takes L_IJ for the two vectors below
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
+                    C[(size_t)r * ld + c] = acc[rt][ct][reg];
+                    sT[r][c] = acc[rt][ct][reg];
+                }
+        flow_publish(&flags[kFlowFlagTile + self], epoch);
+        // forward: L_IJ y_J
+        if (tid == 0) flow_wait(&flags[kFlowFlagY + J], epoch);
+        __syncthreads();
+        flow_acquire();
+        if (tid < kDNB) s_v[tid] = d.bs[(size_t)J * kDNB + tid];
+        __syncthreads();
+        if (tid < kDNB) {
+            double v = 0.0;
+#pragma unroll 8
+            for (int m = 0; m < kDNB; m++) v = fma(sT[tid][m], s_v[m], v);
+            vec_fwd[(size_t)self * kDNB + tid] = v;
+        }
+        flow_publish(&flags[kFlowFlagFwd + self], epoch);
+        // backward: L_IJ^T x_I
+        if (tid == 0) flow_wait(&flags[kFlowFlagX + I], epoch);
+        __syncthreads();
+        flow_acquire();
+        if (tid < kDNB) s_v[tid] = d.bs[(size_t)I * kDNB + tid];
+        __syncthreads();
+        if (tid < kDNB) {
+            double v = 0.0;
+#pragma unroll 8
+            for (int m = 0; m < kDNB; m++) v = fma(sT[m][tid], s_v[m], v);
+            vec_bwd[(size_t)self * kDNB + tid] = v;
+        }
+        flow_publish(&flags[kFlowFlagBwd + self], epoch);
+        return;
+    }
+    // diagonal tile
+    double (*A)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds);
+    double (*X)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds + kDNB * kPS);
+    __syncthreads();  // the last GEMM's reads of sA / sB (which A overlays) are over
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
+                if ((c >> 4) <= (r >> 4)) A[r][c] = -tot[rt][ct][reg];
+            }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    potrf_block_lds(A, X, &s_bad);
+    potrf_store_inverse(X, d.dense_ws + (size_t)J * kDNB * kDNB);
+    if (tid == 0 && s_bad) __hip_atomic_store(&flags[kFlowFlagBad], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flow_publish(&flags[kFlowFlagTile + self], epoch);
+    // forward substitution of this block row
+    const int first = d.tile_first[J];
+    if (tid == 0)
+        for (int k = first; k < J; k++) flow_wait(&flags[kFlowFlagFwd + J * (J + 1) / 2 + k], epoch);
+    __syncthreads();
+    flow_acquire();
+    if (tid < kDNB) {
+        double v = d.bs[(size_t)J * kDNB + tid];
+        for (int k = first; k < J; k++) v -= vec_fwd[(size_t)(J * (J + 1) / 2 + k) * kDNB + tid];
+        s_v[tid] = v;
+    }
+    __syncthreads();
+    if (tid < kDNB) {
+        double y = 0.0;
+        for (int m = 0; m <= tid; m++) y = fma(X[tid][m], s_v[m], y);
+        d.bs[(size_t)J * kDNB + tid] = y;
+        s_u[tid] = y;
+    }
+    flow_publish(&flags[kFlowFlagY + J], epoch);
+    // backward substitution: the column's tiles from the bottom up
+    if (tid == 0)
+        for (int i = T - 1; i > J; i--)
+            if (d.tile_first[i] <= J) flow_wait(&flags[kFlowFlagBwd + i * (i + 1) / 2 + J], epoch);
+    __syncthreads();
+    flow_acquire();
+    if (tid < kDNB) {
+        double z = s_u[tid];
+        for (int i = T - 1; i > J; i--)
+            if (d.tile_first[i] <= J) z -= vec_bwd[(size_t)(i * (i + 1) / 2 + J) * kDNB + tid];
+        s_v[tid] = z;
+    }
+    __syncthreads();
+    if (tid < kDNB) {
+        double x = 0.0;
+        for (int m = tid; m < kDNB; m++) x = fma(X[m][tid], s_v[m], x);
+        d.bs[(size_t)J * kDNB + tid] = x;
+    }
+    flow_publish(&flags[kFlowFlagX + J], epoch);
+    if (J == 0 && tid == 0) {  // the last block row to finish (every x_J is out before the verdict is written)
+        for (int j = 1; j < T; j++) flow_wait(&flags[kFlowFlagX + j], epoch);
+        d.partial[kBaSolveOk] = flow_ready(&flags[kFlowFlagBad], epoch) ? 0.0 : 1.0;
+    }
+}
+
 void launch_ba_dense_pad(const BaDev& d, hipStream_t s) {
     const int n = 6 * d.n_free, np = d.ldS;
     if (np > n) hipLaunchKernelGGL(dense_pad_kernel, dim3(256), dim3(256), 0, s, d.S, d.bs, n, np);
@@ -927,7 +1203,20 @@ void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DenseP
         B.chain(j0, G);
     }
     plan->flop_structural += 2.0 * 2.0 * kDNB * kDNB * (double)plan->nnz_tiles;  // forward + backward substitution
+    // single-launch dataflow solve: one workgroup per tile of the skyline, column by column (diagonal tile first)
+    static const bool no_flow = getenv("SWARMORB_DENSE_NO_FLOW") != nullptr;
+    static const int flow_max = getenv("SWARMORB_DENSE_FLOW_MAX_TILES") ? atoi(getenv("SWARMORB_DENSE_FLOW_MAX_TILES")) : kFlowDefaultMaxTiles;
+    plan->flow_first_tile = (int)plan->tiles.size();
+    plan->flow_n_tiles = 0;
+    if (!no_flow && T <= 21 && plan->nnz_tiles <= std::min(flow_max, kFlowMaxTiles)) {
+        for (int J = 0; J < T; J++)
+            for (int I = J; I < T; I++)
+                if (J >= tile_first[I]) plan->tiles.push_back(make_int2(I, J));
+        plan->flow_n_tiles = (int)plan->tiles.size() - plan->flow_first_tile;
+    }
 }
+
+int dense_flow_max_tiles() { return kFlowMaxTiles; }
 
 namespace {
 
@@ -958,6 +1247,18 @@ struct PlanCursor {
 // returns (measured on GBA-1, 19 panels).
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s) {
     const DensePlan& P = *d.plan;
+    if (d.flow_tiles) {  // ba.cpp hands the tile list over only when every workgroup of the launch can be resident
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        constexpr int lds = (int)(sizeof(double) * kFlowLdsDoubles);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(dense_flow_kernel, dim3(P.flow_n_tiles), dim3(256), lds, s, d, ++*d.flow_epoch);
+        return;
+    }
     const int T = P.T, G = P.G;
     hipStream_t side = d.dense_side;
     hipEvent_t* ev = d.dense_events;

@@ -93,6 +93,12 @@ struct BaDev {
     const int* tile_first;      // ldS / 96 entries (device)
     const int2* plan_tiles;     // (I, J) tiles of every trailing-update launch, in launch order (device)
     const struct DensePlan* plan;  // host side of the same (not read by kernels)
+    // single-launch dataflow solve (dense_flow_kernel): the skyline's tiles column by column, epoch-stamped ready
+    // flags, the tiles' contributions to the two substitutions; flow_tiles == nullptr: the multi-launch path
+    const int2* flow_tiles;
+    unsigned* flow_flags;       // kFlowFlagWords, zeroed once when allocated
+    double* flow_vec;           // 2 x 256 x 96
+    unsigned* flow_epoch;       // host counter of the solver context, grows with every solve (not read by kernels)
     double* partial;  // reduction partials (chi2 | scale) + flags
     int robust;
     double huber_delta;
@@ -127,6 +133,9 @@ constexpr int kBaPairsMinFree = 80;       // from here on the Schur gather walks
                                           // (window wall time, edge_tab vs pair lists: 44 keyframes 3.2 vs 3.7 ms, 64: 6.1 vs 6.3,
                                           // 96: 9.2 vs 8.9, 128: 12.8 vs 11.7)
 constexpr int kBaMfmaSolverMinFree = 4;   // below: the register-resident look-ahead solver is as fast (measured 3..16)
+constexpr int kFlowFlagWords = 1024;
+constexpr int kFlowDefaultMaxTiles = 231;  // tiles the single-launch solve takes on (all its workgroups must be resident)
+int dense_flow_max_tiles();
 constexpr int kDenseMaxPanels = 512;  // 49152 / 96: 8192 free keyframes, 19 GB of FP64 when stored densely
 // Launch plan of the blocked solver for one problem structure: which tiles each trailing update touches.  Built on the
 // host once per so_bundle_adjust call (the structure does not change between LM trials).
@@ -139,6 +148,7 @@ struct DensePlan {
     double flop_structural = 0.0; // FP64 flop of the factorisation + substitutions over nonzero tiles only
     double flop_dense = 0.0;      // n^3 / 3 + 2 n^2
     long long nnz_tiles = 0;      // tiles inside the envelope (lower triangle incl. diagonal)
+    int flow_first_tile = 0, flow_n_tiles = 0;  // dataflow solve: its tile list inside `tiles` (0 tiles: not eligible)
 };
 void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DensePlan* plan);
 bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solves (4..29 free keyframes: tiles in LDS; 30..43: tiles in registers); false if neither applies

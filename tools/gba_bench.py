@@ -17,6 +17,9 @@ FP64_PEAK_TF = 78.6
 def main():
     o = swarmmap_amd.Optimizer()
     cases = ["GBA-1", "GBA-2", "GBA-1r", "GBA-2r"] + (["GBA-max", "GBA-4k"] if "max" in sys.argv[1:] else [])
+    named = [a for a in sys.argv[1:] if a.startswith("GBA-")]  # python tools/gba_bench.py GBA-1 GBA-1r: those only
+    if named:
+        cases = named
     for name in cases:
         if name == "GBA-max":  # the old dense limit: 12288 reduced-system rows = 2048 keyframes, one of them fixed
             p = synth.make_ba_problem(1, n_free=2047, n_fixed=1, n_points=160000, max_obs="auto")
