@@ -553,7 +553,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
             if (cur + want <= kFlowResidentBudget) b->flow_reserved = want;
         }
         if (b->flow_reserved > 0 && !b->d_flow.p) {
-            const size_t bytes = sizeof(unsigned) * kFlowFlagWords + sizeof(double) * 2 * 256 * 96;
+            const size_t bytes = sizeof(unsigned) * kFlowFlagWords + sizeof(double) * 256 * 96;
             if ((rc = b->d_flow.ensure(bytes))) return rc;
             SO_HIP(hipMemsetAsync(b->d_flow.p, 0, bytes, s));
         }

@@ -873,22 +873,33 @@ __global__ void dense_begin_kernel(BaDev d) {
 // acquire; the epoch is a kernel argument that grows with every solve, so nothing is ever reset).
 //   tile (I, J), J < I   left-looking: acc = S_IJ - sum_k L_Ik L_Jk^T as the column tiles k become ready (whatever prefix
 //                        is ready goes through the matrix cores in one K-loop), waits for the inverse factor of diagonal
-//                        block J, L_IJ = acc Linv_J^T straight from LDS, publishes L_IJ; then the two vectors the
-//                        substitutions need from this tile: L_IJ y_J (forward) and, at the very end, L_IJ^T x_I (backward)
-//   tile (J, J)          the same accumulation, Cholesky + inverse in LDS (potrf_block_lds), publishes Linv_J;
-//                        y_J = Linv_J (b_J - sum_k [L_Jk y_k]) from the row's forward vectors in ascending k, then
-//                        x_J = Linv_J^T (y_J - sum_i [L_iJ^T x_i]) from the column's backward vectors in descending i:
-//                        fixed summation orders, deterministic.  b, y and x share d.bs (every reader of y_J is done
-//                        before x_J exists).
-// The critical path is potrf(J) -> L_{J+1,J} -> update of (J+1, J+1) -> potrf(J+1): everything else overlaps with it.
+//                        block J, L_IJ = acc Linv_J^T straight from LDS, publishes L_IJ; then the vector the forward
+//                        substitution needs from this tile, L_IJ y_J
+//   tile (J, J)          the same accumulation - plus a private copy of the sub-diagonal tile (J, J-1), so that the step
+//                        on the critical path (Linv_{J-1} arrives -> L_{J,J-1} -> rank-96 update of (J, J)) runs from LDS
+//                        without a trip through HBM and a second flag -, Cholesky + inverse in LDS (potrf_block_lds),
+//                        publishes Linv_J; y_J = Linv_J (b_J - sum_k [L_Jk y_k]) from the row's forward vectors in
+//                        ascending k; then x_J = Linv_J^T (y_J - sum_{i>J} L_iJ^T x_i), rows folded in from the bottom up
+//                        as their x_i arrive (the last one, L_{J+1,J}, waits in LDS): fixed summation orders,
+//                        deterministic.  b, y and x share d.bs (every reader of y_J is done before x_J exists).
+// Critical path per panel (tools/flow_probe.py, 64 keyframes): factor + inverse 17 us, inverse to HBM + flag 3 us,
+// L_{J+1,J} 10 us, update 7 us; the substitutions add ~4 us per panel at the end.
 constexpr int kFlowMaxTiles = 231;   // 21 panels dense (2016 unknowns, 336 keyframes); a skyline may reach further
 constexpr int kFlowSlots = 256;      // flag / vector slots per kind: tile (I, J) -> I (I + 1) / 2 + J
-constexpr int kFlowFlagTile = 0, kFlowFlagFwd = kFlowSlots, kFlowFlagBwd = 2 * kFlowSlots, kFlowFlagY = 3 * kFlowSlots,
-              kFlowFlagX = 3 * kFlowSlots + 32, kFlowFlagBad = 3 * kFlowSlots + 64;
+constexpr int kFlowFlagTile = 0, kFlowFlagFwd = kFlowSlots, kFlowFlagY = 2 * kFlowSlots, kFlowFlagX = 2 * kFlowSlots + 32,
+              kFlowFlagBad = 2 * kFlowSlots + 64;
 constexpr int kFlowLdsDoubles = 2 * kDNB * kDStride + kDNB * kPS;  // GEMM chunks + one full tile >= the factor's A and X
 static_assert(kFlowLdsDoubles >= 2 * kDNB * kPS, "potrf_block_lds needs two padded blocks");
 static_assert(kFlowFlagBad < kFlowFlagWords, "flag words");
 static_assert(kFlowMaxTiles <= kFlowSlots && 22 * 21 / 2 <= kFlowSlots, "tile slots");
+
+// -DSO_FLOW_PROBE (developer builds only): wall-clock marks per workgroup and stage, read back by tools/flow_probe.py
+#ifdef SO_FLOW_PROBE
+__device__ unsigned long long g_flow_marks[256][16];
+#define SO_FLOW_MARK(i) do { if (threadIdx.x == 0) g_flow_marks[blockIdx.x][(i)] = wall_clock64(); } while (0)
+#else
+#define SO_FLOW_MARK(i)
+#endif
 
 __device__ __forceinline__ bool flow_ready(const unsigned* f, unsigned epoch) {
     return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
@@ -904,12 +915,25 @@ __device__ __forceinline__ void flow_publish(unsigned* f, unsigned epoch) {
     if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// acc = sT (96 x 96 in LDS, row stride kPS) * PB^T, PB row-major in HBM: the panel GEMM with its left operand already on chip
+// acc = sT (96 x 96 in LDS, row stride kPS) * PB^T with PB = Linv, a lower-triangular 96 x 96 block, row-major in HBM:
+// the panel GEMM with its left operand already on chip.  Column tile c of the product only needs k < 16 (c + 1); to keep
+// the four waves level each wave half takes the column tiles {0, 3, 5} or {1, 2, 4} (11 and 10 sixteenths of the full K
+// instead of 6 and 15): acc[rt][ct] is row tile (wave >> 1) * 3 + rt, column tile flow_trsm_ctile(wave, ct).
+__device__ __forceinline__ int flow_trsm_ctile(int wave, int ct) {
+    return (wave & 1) ? (ct == 0 ? 1 : ct == 1 ? 2 : 4) : (ct == 0 ? 0 : ct == 1 ? 3 : 5);
+}
 __device__ __forceinline__ void dense_tile_lds_nt(const double (*sT)[kPS], const double* __restrict__ PB, int ldb,
                                                   double (*sB)[kDStride], d4 acc[3][3]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
+    const int wr = (wave >> 1) * 48;
     const int fr = lane & 15, fk = lane >> 4;
+    int crow[3], klim[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ct++) {
+        const int c = flow_trsm_ctile(wave, ct);
+        crow[ct] = 16 * c + fr;
+        klim[ct] = 16 * (c + 1);
+    }
 #pragma unroll
     for (int rt = 0; rt < 3; rt++)
 #pragma unroll
@@ -939,23 +963,46 @@ __device__ __forceinline__ void dense_tile_lds_nt(const double (*sT)[kPS], const
         if (more) fetch(kc + kDChunk);
 #pragma unroll 2
         for (int kk = 0; kk < kDChunk; kk += 4) {
-            double a[3], b[3];
+            double a[3];
 #pragma unroll
-            for (int t = 0; t < 3; t++) {
-                a[t] = sT[wr + 16 * t + fr][kc + kk + fk];
-                b[t] = sB[wc + 16 * t + fr][kk + fk];
-            }
+            for (int t = 0; t < 3; t++) a[t] = sT[wr + 16 * t + fr][kc + kk + fk];
 #pragma unroll
-            for (int rt = 0; rt < 3; rt++)
+            for (int ct = 0; ct < 3; ct++)
+                if (kc + kk < klim[ct]) {  // wave-uniform
+                    const double b = sB[crow[ct]][kk + fk];
 #pragma unroll
-                for (int ct = 0; ct < 3; ct++)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+                    for (int rt = 0; rt < 3; rt++)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b, acc[rt][ct], 0, 0, 0);
+                }
         }
         if (more) {
             __syncthreads();
             stage();
             __syncthreads();
         }
+    }
+}
+
+// acc += sT sT^T, both operands from the same 96 x 96 LDS tile: the diagonal tile's last rank-96 update, no staging.
+// (Only the lower triangle is needed; dealing its 21 MFMA tiles out 6 / 6 / 6 / 3 to the waves, each with its own code
+// path, was measured slower - 8.0 against 7.1 us - than the full product in the quadrant layout of the accumulator.)
+__device__ __forceinline__ void dense_tile_lds_syrk(const double (*sT)[kPS], d4 acc[3][3]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll 2
+    for (int kk = 0; kk < kDNB; kk += 4) {
+        double a[3], b[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            a[t] = sT[wr + 16 * t + fr][kk + fk];
+            b[t] = sT[wc + 16 * t + fr][kk + fk];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 3; ct++)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
     }
 }
 
@@ -983,15 +1030,37 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
                 const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
                 tot[rt][ct][reg] = -C[(size_t)r * ld + c];
             }
+    SO_FLOW_MARK(0);
     const int lo = max(d.tile_first[I], d.tile_first[J]);
     const double* Pi = d.S + (size_t)I * kDNB * ld;
     const double* Pj = d.S + (size_t)J * kDNB * ld;
-    for (int k = lo; k < J;) {
+    // The diagonal workgroup owns the step that sits on the critical path: it keeps its own copy of the sub-diagonal
+    // tile (J, J-1) - tot2, the same accumulation workgroup (J, J-1) does - so that when Linv_{J-1} arrives it forms
+    // L_{J,J-1} in LDS and applies it to its tile without a round trip through HBM and a second flag.
+    const bool own_sub = I == J && J > 0 && d.tile_first[J] <= J - 1;
+    const int k_end = own_sub ? J - 1 : J;
+    const int sub_first = own_sub ? d.tile_first[J - 1] : 0;  // tile (J-1, k) exists from here on
+    const double* Ps = own_sub ? d.S + (size_t)(J - 1) * kDNB * ld : nullptr;
+    d4 tot2[3][3];
+    if (own_sub) {
+        const double* C2 = d.S + (size_t)J * kDNB * ld + (size_t)(J - 1) * kDNB;
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
+                    tot2[rt][ct][reg] = -C2[(size_t)r * ld + c];
+                }
+    }
+    for (int k = lo; k < k_end;) {
         if (tid == 0) {
             int m = 0;
             for (;;) {  // the ready prefix of the remaining column tiles, at least one
-                while (k + m < J && flow_ready(&flags[kFlowFlagTile + I * (I + 1) / 2 + k + m], epoch) &&
-                       flow_ready(&flags[kFlowFlagTile + J * (J + 1) / 2 + k + m], epoch))
+                while (k + m < k_end && flow_ready(&flags[kFlowFlagTile + I * (I + 1) / 2 + k + m], epoch) &&
+                       flow_ready(&flags[kFlowFlagTile + J * (J + 1) / 2 + k + m], epoch) &&
+                       (!own_sub || k + m < sub_first || flow_ready(&flags[kFlowFlagTile + (J - 1) * J / 2 + k + m], epoch)))
                     m++;
                 if (m > 0) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -1002,10 +1071,14 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
         const int m = s_m;  // (the GEMM's barriers separate this read from the next store)
         flow_acquire();
         dense_tile_nt<false>(Pi + (size_t)k * kDNB, ld, Pj + (size_t)k * kDNB, ld, sA, sB, tot, m * kDNB);
+        if (own_sub && k + m > sub_first) {
+            const int k2 = max(k, sub_first);
+            dense_tile_nt<false>(Pi + (size_t)k2 * kDNB, ld, Ps + (size_t)k2 * kDNB, ld, sA, sB, tot2, (k + m - k2) * kDNB);
+        }
         k += m;
     }
+    SO_FLOW_MARK(1);
     double* vec_fwd = d.flow_vec;
-    double* vec_bwd = d.flow_vec + (size_t)kFlowSlots * kDNB;
     if (I != J) {
         double (*sT)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds + 2 * kDNB * kDStride);  // disjoint from sA / sB
 #pragma unroll
@@ -1020,20 +1093,23 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
         if (tid == 0) flow_wait(&flags[kFlowFlagTile + J * (J + 1) / 2 + J], epoch);
         __syncthreads();
         flow_acquire();
+        SO_FLOW_MARK(2);
         d4 acc[3][3];
         dense_tile_lds_nt(sT, d.dense_ws + (size_t)J * kDNB * kDNB, kDNB, sB, acc);
         __syncthreads();  // every wave is done reading sT: it now takes L_IJ for the two vectors below
+        SO_FLOW_MARK(3);
 #pragma unroll
         for (int rt = 0; rt < 3; rt++)
 #pragma unroll
             for (int ct = 0; ct < 3; ct++)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
-                    const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
+                    const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = 16 * flow_trsm_ctile(wave, ct) + (lane & 15);
                     C[(size_t)r * ld + c] = acc[rt][ct][reg];
                     sT[r][c] = acc[rt][ct][reg];
                 }
         flow_publish(&flags[kFlowFlagTile + self], epoch);
+        SO_FLOW_MARK(4);
         // forward: L_IJ y_J
         if (tid == 0) flow_wait(&flags[kFlowFlagY + J], epoch);
         __syncthreads();
@@ -1047,25 +1123,44 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
             vec_fwd[(size_t)self * kDNB + tid] = v;
         }
         flow_publish(&flags[kFlowFlagFwd + self], epoch);
-        // backward: L_IJ^T x_I
-        if (tid == 0) flow_wait(&flags[kFlowFlagX + I], epoch);
-        __syncthreads();
-        flow_acquire();
-        if (tid < kDNB) s_v[tid] = d.bs[(size_t)I * kDNB + tid];
-        __syncthreads();
-        if (tid < kDNB) {
-            double v = 0.0;
-#pragma unroll 8
-            for (int m = 0; m < kDNB; m++) v = fma(sT[m][tid], s_v[m], v);
-            vec_bwd[(size_t)self * kDNB + tid] = v;
-        }
-        flow_publish(&flags[kFlowFlagBwd + self], epoch);
+        SO_FLOW_MARK(8);
         return;
     }
     // diagonal tile
+    if (own_sub) {
+        double (*sT)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds + 2 * kDNB * kDStride);
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
+                    sT[r][c] = -tot2[rt][ct][reg];
+                }
+        if (tid == 0) flow_wait(&flags[kFlowFlagTile + (J - 1) * J / 2 + (J - 1)], epoch);
+        __syncthreads();
+        flow_acquire();
+        SO_FLOW_MARK(2);
+        dense_tile_lds_nt(sT, d.dense_ws + (size_t)(J - 1) * kDNB * kDNB, kDNB, sB, tot2);  // L_{J,J-1}
+        SO_FLOW_MARK(3);
+        __syncthreads();  // every wave is done reading sT
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = 16 * flow_trsm_ctile(wave, ct) + (lane & 15);
+                    sT[r][c] = tot2[rt][ct][reg];
+                }
+        __syncthreads();
+        dense_tile_lds_syrk(sT, tot);
+    }
+    SO_FLOW_MARK(5);
     double (*A)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds);
     double (*X)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds + kDNB * kPS);
-    __syncthreads();  // the last GEMM's reads of sA / sB (which A overlays) are over
+    __syncthreads();  // the last GEMM's reads of sA / sB / sT (which A and X overlay) are over
 #pragma unroll
     for (int rt = 0; rt < 3; rt++)
 #pragma unroll
@@ -1078,9 +1173,11 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     if (tid == 0) s_bad = 0;
     __syncthreads();
     potrf_block_lds(A, X, &s_bad);
+    SO_FLOW_MARK(6);
     potrf_store_inverse(X, d.dense_ws + (size_t)J * kDNB * kDNB);
     if (tid == 0 && s_bad) __hip_atomic_store(&flags[kFlowFlagBad], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     flow_publish(&flags[kFlowFlagTile + self], epoch);
+    SO_FLOW_MARK(7);
     // forward substitution of this block row
     const int first = d.tile_first[J];
     if (tid == 0)
@@ -1100,18 +1197,49 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
         s_u[tid] = y;
     }
     flow_publish(&flags[kFlowFlagY + J], epoch);
-    // backward substitution: the column's tiles from the bottom up
-    if (tid == 0)
-        for (int i = T - 1; i > J; i--)
-            if (d.tile_first[i] <= J) flow_wait(&flags[kFlowFlagBwd + i * (i + 1) / 2 + J], epoch);
-    __syncthreads();
-    flow_acquire();
-    if (tid < kDNB) {
-        double z = s_u[tid];
-        for (int i = T - 1; i > J; i--)
-            if (d.tile_first[i] <= J) z -= vec_bwd[(size_t)(i * (i + 1) / 2 + J) * kDNB + tid];
-        s_v[tid] = z;
+    SO_FLOW_MARK(8);
+    // backward substitution: x_J = Linv_J^T (y_J - sum_{i>J} L_iJ^T x_i), rows from the bottom up.  x_{J+1} is the last to
+    // arrive and the only one on the critical path: its tile L_{J+1,J} waits in LDS (the factor's A block is free now),
+    // the rows further down are folded in from HBM as their x_i show up.
+    double (*Lsub)[kPS] = A;
+    const bool has_next = J + 1 < T && d.tile_first[J + 1] <= J;
+    if (has_next) {
+        if (tid == 0) flow_wait(&flags[kFlowFlagTile + (J + 1) * (J + 2) / 2 + J], epoch);
+        __syncthreads();
+        flow_acquire();
+        const double* Ln = d.S + (size_t)(J + 1) * kDNB * ld + (size_t)J * kDNB;
+        for (int i = tid; i < kDNB * (kDNB / 2); i += 256) {
+            const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
+            const double2 v = *reinterpret_cast<const double2*>(Ln + (size_t)r * ld + c);
+            Lsub[r][c] = v.x; Lsub[r][c + 1] = v.y;
+        }
     }
+    double z = tid < kDNB ? s_u[tid] : 0.0;
+    for (int i = T - 1; i > J; i--) {
+        if (d.tile_first[i] > J) continue;
+        if (tid == 0) flow_wait(&flags[kFlowFlagX + i], epoch);
+        __syncthreads();  // (also: Lsub is complete, the previous round's reads of s_v are over)
+        flow_acquire();
+        if (tid < kDNB) s_v[tid] = d.bs[(size_t)i * kDNB + tid];
+        __syncthreads();
+        if (tid < kDNB) {
+            if (i == J + 1) {
+#pragma unroll 8
+                for (int m = 0; m < kDNB; m++) z = fma(-Lsub[m][tid], s_v[m], z);
+            } else {
+                const double* L = d.S + (size_t)i * kDNB * ld + (size_t)J * kDNB + tid;
+                for (int m0 = 0; m0 < kDNB; m0 += 16) {  // 16 independent loads in flight per thread
+                    double l[16];
+#pragma unroll
+                    for (int m = 0; m < 16; m++) l[m] = L[(size_t)(m0 + m) * ld];
+#pragma unroll
+                    for (int m = 0; m < 16; m++) z = fma(-l[m], s_v[m0 + m], z);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < kDNB) s_v[tid] = z;
     __syncthreads();
     if (tid < kDNB) {
         double x = 0.0;
@@ -1119,11 +1247,18 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
         d.bs[(size_t)J * kDNB + tid] = x;
     }
     flow_publish(&flags[kFlowFlagX + J], epoch);
+    SO_FLOW_MARK(9);
     if (J == 0 && tid == 0) {  // the last block row to finish (every x_J is out before the verdict is written)
         for (int j = 1; j < T; j++) flow_wait(&flags[kFlowFlagX + j], epoch);
         d.partial[kBaSolveOk] = flow_ready(&flags[kFlowFlagBad], epoch) ? 0.0 : 1.0;
     }
 }
+
+#ifdef SO_FLOW_PROBE
+extern "C" int so_debug_flow_marks(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_marks), sizeof(unsigned long long) * 256 * 16);
+}
+#endif
 
 void launch_ba_dense_pad(const BaDev& d, hipStream_t s) {
     const int n = 6 * d.n_free, np = d.ldS;

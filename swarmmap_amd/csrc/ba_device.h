@@ -97,7 +97,7 @@ struct BaDev {
     // flags, the tiles' contributions to the two substitutions; flow_tiles == nullptr: the multi-launch path
     const int2* flow_tiles;
     unsigned* flow_flags;       // kFlowFlagWords, zeroed once when allocated
-    double* flow_vec;           // 2 x 256 x 96
+    double* flow_vec;           // 256 x 96: L_IJ y_J of every off-diagonal tile
     unsigned* flow_epoch;       // host counter of the solver context, grows with every solve (not read by kernels)
     double* partial;  // reduction partials (chi2 | scale) + flags
     int robust;
