@@ -404,7 +404,8 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
                  o_ept = L.add(sizeof(int) * (size_t)nE), o_ptoff = L.add(sizeof(int) * ((size_t)nL + 1)),
                  o_hidx = L.add(sizeof(int) * (size_t)nP), o_free = L.add(sizeof(int) * (size_t)std::max(nf, 1)),
                  o_poseoff = L.add(sizeof(int) * ((size_t)nf + 1)), o_pedges = L.add(sizeof(int) * (size_t)nE),
-                 o_eact = L.add((size_t)nE), o_ptact = L.add((size_t)std::max(nL, 1));
+                 o_pepoint = L.add(sizeof(int) * (size_t)nE), o_eact = L.add((size_t)nE),
+                 o_ptact = L.add((size_t)std::max(nL, 1));
     int rc;
     if ((rc = ensure_pinned(&b->h_in, &b->h_in_cap, L.total))) return rc;
     if ((rc = b->d_in.ensure(L.total))) return rc;
@@ -421,6 +422,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     int* h_free = (int*)(hb + o_free);
     int* h_poseoff = (int*)(hb + o_poseoff);
     int* h_pedges = (int*)(hb + o_pedges);
+    int* h_pepoint = (int*)(hb + o_pepoint);
     uint8_t* h_eact = hb + o_eact;
     uint8_t* h_ptact = hb + o_ptact;
 
@@ -467,7 +469,10 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         std::vector<int> fill(h_poseoff, h_poseoff + nf);  // free keyframe -> its edges, ascending (= by landmark)
         for (int k = 0; k < nE; k++) {
             const int h = h_hidx[h_epose[k]];
-            if (h >= 0) h_pedges[fill[(size_t)h]++] = k;
+            if (h >= 0) {
+                h_pepoint[fill[(size_t)h]] = h_ept[k];  // the edge's landmark next to it: one hop less in the Schur gather
+                h_pedges[fill[(size_t)h]++] = k;
+            }
         }
     }
     for (int i = 0; i < nL; i++) h_ptact[i] = h_ptoff[i + 1] > h_ptoff[i];
@@ -612,6 +617,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.free_pose = (const int*)(db + o_free);
     d.pose_off = (const int*)(db + o_poseoff);
     d.pose_edges = (const int*)(db + o_pedges);
+    d.pose_edge_point = (const int*)(db + o_pepoint);
     d.edge_tab = b->d_tab.as<int>();
     d.e_err = b->d_err.as<double>();
     d.e_chi2 = b->d_chi2.as<double>();

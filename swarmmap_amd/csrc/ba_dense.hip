@@ -915,6 +915,23 @@ __device__ __forceinline__ void flow_publish(unsigned* f, unsigned epoch) {
     if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The 96-vectors of the substitutions (y_J, x_J, a tile's L_IJ y_J) travel without cache maintenance: agent-scope atomic
+// stores write through to memory, agent-scope atomic loads read from there, so neither side pays the L2 write-back /
+// invalidate of the tile-sized hand-overs (measured per backward step: 6.5 -> see DESIGN 5).
+__device__ __forceinline__ void flow_vec_store(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double flow_vec_load(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the workgroup's flow_vec_store()s have been acknowledged, then the flag goes up
+__device__ __forceinline__ void flow_publish_vec(unsigned* f, unsigned epoch) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // acc = sT (96 x 96 in LDS, row stride kPS) * PB^T with PB = Linv, a lower-triangular 96 x 96 block, row-major in HBM:
 // the panel GEMM with its left operand already on chip.  Column tile c of the product only needs k < 16 (c + 1); to keep
 // the four waves level each wave half takes the column tiles {0, 3, 5} or {1, 2, 4} (11 and 10 sixteenths of the full K
@@ -1113,16 +1130,15 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
         // forward: L_IJ y_J
         if (tid == 0) flow_wait(&flags[kFlowFlagY + J], epoch);
         __syncthreads();
-        flow_acquire();
-        if (tid < kDNB) s_v[tid] = d.bs[(size_t)J * kDNB + tid];
+        if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)J * kDNB + tid]);
         __syncthreads();
         if (tid < kDNB) {
             double v = 0.0;
 #pragma unroll 8
             for (int m = 0; m < kDNB; m++) v = fma(sT[tid][m], s_v[m], v);
-            vec_fwd[(size_t)self * kDNB + tid] = v;
+            flow_vec_store(&vec_fwd[(size_t)self * kDNB + tid], v);
         }
-        flow_publish(&flags[kFlowFlagFwd + self], epoch);
+        flow_publish_vec(&flags[kFlowFlagFwd + self], epoch);
         SO_FLOW_MARK(8);
         return;
     }
@@ -1183,30 +1199,31 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     if (tid == 0)
         for (int k = first; k < J; k++) flow_wait(&flags[kFlowFlagFwd + J * (J + 1) / 2 + k], epoch);
     __syncthreads();
-    flow_acquire();
     if (tid < kDNB) {
-        double v = d.bs[(size_t)J * kDNB + tid];
-        for (int k = first; k < J; k++) v -= vec_fwd[(size_t)(J * (J + 1) / 2 + k) * kDNB + tid];
+        double v = d.bs[(size_t)J * kDNB + tid];  // b_J: written before the launch
+        for (int k = first; k < J; k++) v -= flow_vec_load(&vec_fwd[(size_t)(J * (J + 1) / 2 + k) * kDNB + tid]);
         s_v[tid] = v;
     }
     __syncthreads();
     if (tid < kDNB) {
         double y = 0.0;
         for (int m = 0; m <= tid; m++) y = fma(X[tid][m], s_v[m], y);
-        d.bs[(size_t)J * kDNB + tid] = y;
+        flow_vec_store(&d.bs[(size_t)J * kDNB + tid], y);
         s_u[tid] = y;
     }
-    flow_publish(&flags[kFlowFlagY + J], epoch);
+    flow_publish_vec(&flags[kFlowFlagY + J], epoch);
     SO_FLOW_MARK(8);
     // backward substitution: x_J = Linv_J^T (y_J - sum_{i>J} L_iJ^T x_i), rows from the bottom up.  x_{J+1} is the last to
     // arrive and the only one on the critical path: its tile L_{J+1,J} waits in LDS (the factor's A block is free now),
     // the rows further down are folded in from HBM as their x_i show up.
     double (*Lsub)[kPS] = A;
     const bool has_next = J + 1 < T && d.tile_first[J + 1] <= J;
+    if (tid == 0)  // every tile of the column (all published long ago): one acquire covers the reads below
+        for (int i = J + 1; i < T; i++)
+            if (d.tile_first[i] <= J) flow_wait(&flags[kFlowFlagTile + i * (i + 1) / 2 + J], epoch);
+    __syncthreads();
+    flow_acquire();
     if (has_next) {
-        if (tid == 0) flow_wait(&flags[kFlowFlagTile + (J + 1) * (J + 2) / 2 + J], epoch);
-        __syncthreads();
-        flow_acquire();
         const double* Ln = d.S + (size_t)(J + 1) * kDNB * ld + (size_t)J * kDNB;
         for (int i = tid; i < kDNB * (kDNB / 2); i += 256) {
             const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
@@ -1219,8 +1236,7 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
         if (d.tile_first[i] > J) continue;
         if (tid == 0) flow_wait(&flags[kFlowFlagX + i], epoch);
         __syncthreads();  // (also: Lsub is complete, the previous round's reads of s_v are over)
-        flow_acquire();
-        if (tid < kDNB) s_v[tid] = d.bs[(size_t)i * kDNB + tid];
+        if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)i * kDNB + tid]);
         __syncthreads();
         if (tid < kDNB) {
             if (i == J + 1) {
@@ -1244,9 +1260,9 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     if (tid < kDNB) {
         double x = 0.0;
         for (int m = tid; m < kDNB; m++) x = fma(X[m][tid], s_v[m], x);
-        d.bs[(size_t)J * kDNB + tid] = x;
+        flow_vec_store(&d.bs[(size_t)J * kDNB + tid], x);
     }
-    flow_publish(&flags[kFlowFlagX + J], epoch);
+    flow_publish_vec(&flags[kFlowFlagX + J], epoch);
     SO_FLOW_MARK(9);
     if (J == 0 && tid == 0) {  // the last block row to finish (every x_J is out before the verdict is written)
         for (int j = 1; j < T; j++) flow_wait(&flags[kFlowFlagX + j], epoch);

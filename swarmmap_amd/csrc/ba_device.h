@@ -69,7 +69,9 @@ struct BaDev {
     const int* free_pose;     // n_free: pose index of hessian index i
     const int* pose_off;      // n_free + 1
     const int* pose_edges;    // edge ids per free pose
-    int* edge_tab;            // n_free x n_points: the edge joining (hessian index, landmark), -1 if none
+    const int* pose_edge_point;  // landmark of each of those edges (= e_point[pose_edges[.]])
+    int* edge_tab;            // n_free x n_points: the ACTIVE edge joining (hessian index, landmark), -1 if none
+                              // (ba_mark_outliers_kernel removes the edges it drops)
     // large maps (blocked-solver path): per upper block (i1 < i2) the (edge, edge) pairs of the landmarks both
     // keyframes see, built on the device; blocks with at most kBaSmallBlockPairs pairs are summed by one thread each
     int use_pairs;

@@ -169,6 +169,31 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// the two widest exchanges (lane ^ 32, lane ^ 16) use gfx950's v_permlane32_swap / v_permlane16_swap: the first
+// operand's upper half (odd 16-lane rows) trades places with the second operand's lower half (even rows), so
+// a' + b' is "my half of the values plus my partner's copy of the same half" without touching LDS
+__device__ __forceinline__ double po_swap_add32(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double po_swap_add16(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+template <int COUNT>
+__device__ __forceinline__ void po_halve(double* v, int off, int lane) {
+    const bool upper = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < COUNT; i++) {
+        const double keep = upper ? v[i + COUNT] : v[i];
+        const double send = upper ? v[i] : v[i + COUNT];
+        v[i] = keep + __shfl_xor(send, off);
+    }
+}
+
 // block-wide deterministic sum (fixed tree: xor-butterfly inside a wave, then waves in index order)
 __device__ __forceinline__ double block_sum(double v, double* s_tmp /* >= 16 doubles */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -356,8 +381,13 @@ __global__ __launch_bounds__(256) void ba_mark_outliers_kernel(BaDev d, double c
         if (!d.e_active[e]) continue;
         double pc[3];
         camera_point(d.pose[cur][d.e_pose[e]], X, pc);
-        if (d.e_chi2[e] > chi2_threshold || !(pc[2] > 0.0)) d.e_active[e] = 0;
-        else alive++;
+        if (d.e_chi2[e] > chi2_threshold || !(pc[2] > 0.0)) {
+            d.e_active[e] = 0;
+            const int h = d.use_pairs ? -1 : d.pose_hidx[d.e_pose[e]];
+            if (h >= 0) d.edge_tab[(size_t)h * d.n_points + il] = -1;  // the table only lists active edges
+        } else {
+            alive++;
+        }
     }
     d.pt_active[il] = alive > 0;
 }
@@ -589,11 +619,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
         const bool from_list = d.use_pairs && i1 != i2;  // large maps: the block's own (landmark-sorted) pair list
         const int p_lo = from_list ? d.pr_off[g] : d.pose_off[i1], p_hi = from_list ? d.pr_off[g + 1] : d.pose_off[i1 + 1];
-        for (int p = p_lo + tid; p < p_hi; p += kStride) {
-            const int k1 = from_list ? d.ps_k1[p] : d.pose_edges[p];
-            if (!d.e_active[k1]) continue;  // dropped between the stages
-            const int k2 = from_list ? d.ps_k2[p] : (i1 == i2) ? k1 : d.edge_tab[(size_t)i2 * d.n_points + d.e_point[k1]];
-            if (k2 < 0 || !d.e_active[k2]) continue;
+        auto add_pair = [&](int k1, int k2) {
             const double* B = d.BDinv + 18 * (size_t)k1;
             const double* W = d.W + 18 * (size_t)k2;
             double b[18], w[18];
@@ -604,15 +630,59 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
 #pragma unroll
                 for (int c = 0; c < 6; c++)
                     acc[r * 6 + c] += b[r * 3] * w[c * 3] + b[r * 3 + 1] * w[c * 3 + 1] + b[r * 3 + 2] * w[c * 3 + 2];
+        };
+        if (from_list) {
+            for (int p = p_lo + tid; p < p_hi; p += kStride) {
+                const int k1 = d.ps_k1[p], k2 = d.ps_k2[p];
+                if (!d.e_active[k1] || !d.e_active[k2]) continue;  // dropped between the stages
+                add_pair(k1, k2);
+            }
+        } else {
+            // pose i1's edges, four per thread and round: the look-ups of a round go out together (edge + landmark ->
+            // partner edge from the table, which only lists active edges), so a round is three dependent loads deep
+            // however few of its edges pose i2 shares
+            const int* tab = d.edge_tab + (size_t)i2 * d.n_points;
+            for (int base = p_lo; base < p_hi; base += 4 * kStride) {
+                int k1[4], k2[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int p = base + u * kStride + tid;
+                    k1[u] = p < p_hi ? d.pose_edges[p] : -1;
+                    k2[u] = p < p_hi ? d.pose_edge_point[p] : 0;  // the landmark for now
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool live = k1[u] >= 0 && d.e_active[k1[u]];
+                    const int partner = (i1 == i2) ? k1[u] : (k1[u] >= 0 ? tab[k2[u]] : -1);
+                    k2[u] = live ? partner : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (k2[u] >= 0) add_pair(k1[u], k2[u]);
+            }
         }
+        // wave totals by transposition (the pose kernel's scheme): values 0..31 end up in lane pairs, 32..35 by butterfly
+        {
 #pragma unroll
-        for (int k = 0; k < 36; k++) acc[k] = wave_sum(acc[k]);
-        if (lane < 36) {
-            double v = 0.0;
+            for (int i = 0; i < 16; i++) acc[i] = po_swap_add32(acc[i], acc[i + 16]);
 #pragma unroll
-            for (int k = 0; k < 36; k++) v = (k == lane) ? acc[k] : v;  // select without dynamic register indexing
-            if (WAVES == 4) s_part[wave][lane] = v;
-            else acc[0] = v;
+            for (int i = 0; i < 8; i++) acc[i] = po_swap_add16(acc[i], acc[i + 8]);
+            po_halve<4>(acc, 8, lane);
+            po_halve<2>(acc, 4, lane);
+            po_halve<1>(acc, 2, lane);
+            const double tot = acc[0] + __shfl_xor(acc[0], 1);  // the wave total of value (lane >> 1)
+#pragma unroll
+            for (int k = 32; k < 36; k++) acc[k] = wave_sum(acc[k]);
+            const double extra = lane == 0 ? acc[32] : lane == 1 ? acc[33] : lane == 2 ? acc[34] : acc[35];
+            if (WAVES == 4) {
+                if ((lane & 1) == 0) s_part[wave][lane >> 1] = tot;
+                if (lane < 4) s_part[wave][32 + lane] = extra;
+            } else {
+                // one wave per block: value k to lane k
+                const double low = __shfl(tot, 2 * (lane & 31));
+                const double high = __shfl(extra, lane & 3);
+                acc[0] = lane < 32 ? low : high;
+            }
         }
         if (WAVES == 4) __syncthreads();
         if (tid < 36) {
@@ -1670,30 +1740,6 @@ constexpr int kPoLdsMax = kPoseOptLdsMax;
 #define SO_POSE_TICK_FLUSH
 #endif
 
-// the two widest exchanges (lane ^ 32, lane ^ 16) use gfx950's v_permlane32_swap / v_permlane16_swap: the first
-// operand's upper half (odd 16-lane rows) trades places with the second operand's lower half (even rows), so
-// a' + b' is "my half of the values plus my partner's copy of the same half" without touching LDS
-__device__ __forceinline__ double po_swap_add32(double a, double b) {
-    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ double po_swap_add16(double a, double b) {
-    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-
-template <int COUNT>
-__device__ __forceinline__ void po_halve(double* v, int off, int lane) {
-    const bool upper = (lane & off) != 0;
-#pragma unroll
-    for (int i = 0; i < COUNT; i++) {
-        const double keep = upper ? v[i + COUNT] : v[i];
-        const double send = upper ? v[i] : v[i + COUNT];
-        v[i] = keep + __shfl_xor(send, off);
-    }
-}
 
 // pose <- SE3Quat::exp(u) * pose for the LM steps of PoseOptimization, off the libm path: lane 0 evaluates this
 // once per trial while 511 threads wait, so sin / cos / sqrt / the divisions of se3_exp_mul are replaced by the
