@@ -547,6 +547,11 @@ typedef struct {
      * over the nonzero 96 x 96 tiles of its block skyline, the same for a dense matrix of that size, and the number
      * of tiles inside the skyline (lower triangle) */
     double solve_gflop_structural, solve_gflop_dense, nnz_tiles;
+    /* which solver factored the reduced camera system: 0 single-workgroup kernels (up to 43 free keyframes), 1 blocked
+     * Cholesky as a chain of launches, 2 blocked Cholesky as ONE launch of tile workgroups (up to 231 skyline tiles, when
+     * the device can keep them all resident) */
+    int32_t solver_path;
+    int32_t reserved;
 } so_ba_info;
 
 int so_ba_create(int device, so_ba** out);

@@ -57,9 +57,25 @@ constexpr int kMaxReducedDim = 96 * kDenseMaxPanels;  // reduced camera system: 
 
 // dense_flow_kernel's workgroups wait for each other, so every one of a launch must be resident (one per CU: 152 KB of
 // LDS).  The tiles of all solver contexts of this process that are inside so_bundle_adjust at the same time have to fit
-// the budget; a context that does not get its share solves with the multi-launch path for that call.
-constexpr int kFlowResidentBudget = 240;  // of 256 CUs
+// the budget (one counter for the process: contexts on different devices share it, which only errs on the safe side);
+// a context that does not get its share solves with the multi-launch path for that call.
 std::atomic<int> g_flow_tiles{0};
+
+// CUs the dataflow launches of this process may occupy together: what the device has (a partitioned MI355X exposes 32
+// or 64 of its 256 per device) minus a reserve for the tracking threads' kernels; 0 when a CU cannot hold a workgroup
+int flow_resident_budget(int device) {
+    static std::atomic<int> cached[64];
+    if (device < 0 || device >= 64) return 0;
+    int v = cached[device].load();
+    if (v != 0) return v > 0 ? v : 0;
+    hipDeviceProp_t prop;
+    int budget = -1;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor >= (size_t)156 * 1024)
+        budget = std::max(prop.multiProcessorCount - 16, 0);
+    if (budget <= 0) budget = -1;
+    cached[device].store(budget);
+    return budget > 0 ? budget : 0;
+}
 
 double now_ms() {
     using namespace std::chrono;
@@ -551,11 +567,11 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         if (!b->plan.tiles.empty()) memcpy((uint8_t*)b->h_plan + first_bytes, b->plan.tiles.data(), sizeof(int2) * b->plan.tiles.size());
         SO_HIP(hipMemcpyAsync(b->d_plan.p, b->h_plan, first_bytes + sizeof(int2) * b->plan.tiles.size(), hipMemcpyHostToDevice, s));
         if (b->plan.flow_n_tiles > 0) {
-            const int want = b->plan.flow_n_tiles;
+            const int want = b->plan.flow_n_tiles, budget = flow_resident_budget(b->device);
             int cur = g_flow_tiles.load();
-            while (cur + want <= kFlowResidentBudget && !g_flow_tiles.compare_exchange_weak(cur, cur + want)) {
+            while (cur + want <= budget && !g_flow_tiles.compare_exchange_weak(cur, cur + want)) {
             }
-            if (cur + want <= kFlowResidentBudget) b->flow_reserved = want;
+            if (cur + want <= budget) b->flow_reserved = want;
         }
         if (b->flow_reserved > 0 && !b->d_flow.p) {
             const size_t bytes = sizeof(unsigned) * kFlowFlagWords + sizeof(double) * 256 * 96;
@@ -724,6 +740,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         inf.solve_gflop_structural = r.d.plan->flop_structural * 1e-9;
         inf.solve_gflop_dense = r.d.plan->flop_dense * 1e-9;
         inf.nnz_tiles = (double)r.d.plan->nnz_tiles;
+        inf.solver_path = r.d.flow_tiles ? 2 : 1;
     }
     inf.wall_ms = (float)(now_ms() - t_begin);
     if (trace)

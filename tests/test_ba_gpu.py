@@ -83,6 +83,90 @@ def test_global_ba_blocked_dense_solver_matches_oracle(opt, oracle, n_free, n_po
     _compare(r, o)  # (no ground-truth check: with one fixed keyframe a monocular map keeps its scale freedom)
 
 
+def _window(n_free, seed=0):
+    return synth.make_ba_problem(seed, n_free, (3 * n_free) // 2, 150 * n_free, max_obs="auto")
+
+
+def test_mid_size_windows_take_the_single_launch_solve(opt, oracle):
+    """44-336 free keyframes (up to 231 skyline tiles): the blocked Cholesky runs as ONE launch of tile workgroups that
+    meet through flags in HBM (dense_flow_kernel).  On a whole MI355X it must be the path taken (so_ba_info.solver_path
+    == 2), agree with the oracle, and be deterministic from call to call (fixed summation orders, epoch-stamped flags)."""
+    p = _window(64)
+    a = opt.LocalBundleAdjustment(p)
+    assert a["info"]["solver_path"] == 2 and a["info"]["nnz_tiles"] == 10
+    _compare(a, oracle.bundle_adjust(p))
+    for _ in range(3):
+        b = opt.LocalBundleAdjustment(p)
+        assert np.array_equal(a["Tcw"], b["Tcw"]) and np.array_equal(a["Xw"], b["Xw"]) and np.array_equal(a["chi2"], b["chi2"])
+    small = opt.LocalBundleAdjustment(synth.make_ba_case("LBA-M", 3))
+    assert small["info"]["solver_path"] == 0
+
+
+def test_single_launch_and_multi_launch_solves_agree():
+    """The same windows through the chain-of-launches blocked solver (SWARMORB_DENSE_NO_FLOW=1, read once per process →
+    a child process) and through the single-launch one: same LM decisions, estimates equal to rounding."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import swarmmap_amd\nfrom swarmmap_amd import synth\n"
+        "o = swarmmap_amd.Optimizer()\n"
+        "for nf in (48, 96, 130):\n"
+        "    p = synth.make_ba_problem(7, nf, (3 * nf) // 2, 100 * nf, max_obs='auto')\n"
+        "    r = o.LocalBundleAdjustment(p)\n"
+        "    np.save(sys.argv[1] + '_%%d_T.npy' %% nf, r['Tcw']); np.save(sys.argv[1] + '_%%d_X.npy' %% nf, r['Xw'])\n"
+        "    print(nf, r['info']['solver_path'], r['info']['lm_trials'], r['info']['iterations_stage2'], repr(r['info']['chi2_final']))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = {}
+        for tag, env in (("flow", {}), ("chain", {"SWARMORB_DENSE_NO_FLOW": "1"})):
+            e = dict(os.environ, **env)
+            res = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, tag)], env=e, capture_output=True, text=True, timeout=300)
+            assert res.returncode == 0, res.stderr[-2000:]
+            out[tag] = [ln.split() for ln in res.stdout.strip().splitlines() if ln and ln[0].isdigit()]
+        assert [r[1] for r in out["flow"]] == ["2", "2", "2"] and [r[1] for r in out["chain"]] == ["1", "1", "1"]
+        for f, c in zip(out["flow"], out["chain"]):
+            assert f[0] == c[0] and f[3] == c[3] and abs(int(f[2]) - int(c[2])) <= 2
+            assert float(f[4]) == pytest.approx(float(c[4]), rel=1e-9)
+            nf = int(f[0])
+            Tf, Tc = np.load(os.path.join(tmp, "flow_%d_T.npy" % nf)), np.load(os.path.join(tmp, "chain_%d_T.npy" % nf))
+            Xf, Xc = np.load(os.path.join(tmp, "flow_%d_X.npy" % nf)), np.load(os.path.join(tmp, "chain_%d_X.npy" % nf))
+            assert np.abs(Tf - Tc).max() <= 2e-6 and np.abs(Xf - Xc).max() <= 2e-5
+
+
+def test_two_solver_contexts_solve_mid_size_windows_concurrently(opt):
+    """Two local-mapping threads (two agents on one GPU), each with its own so_ba, inside so_bundle_adjust at the same
+    time: their single-launch solves share the CUs (the residency budget of ba.cpp decides who may), nobody waits for a
+    workgroup that cannot start, and each gets its solo result."""
+    import threading
+    import swarmmap_amd
+    windows = [_window(64, 1), _window(80, 2)]
+    solo = [opt.LocalBundleAdjustment(w) for w in windows]
+    others = [swarmmap_amd.Optimizer() for _ in windows]
+    got = [[None] * 6 for _ in windows]
+
+    def work(i):
+        for k in range(6):
+            got[i][k] = others[i].LocalBundleAdjustment(windows[i])
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(windows))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths), "a solve did not come back"
+    for i in range(len(windows)):
+        for r in got[i]:
+            assert r["info"]["solver_path"] in (1, 2)
+            assert np.abs(r["Tcw"] - solo[i]["Tcw"]).max() <= 2e-6 and np.abs(r["Xw"] - solo[i]["Xw"]).max() <= 2e-5
+            assert r["info"]["chi2_final"] == pytest.approx(solo[i]["info"]["chi2_final"], rel=1e-9)
+    for o in others:
+        o.close()
+
+
 def test_gba2_eight_agent_map_properties(opt):
     """GBA-2 (1499 free keyframes, 120 k points, ~780 k edges: the eight-agent map of BASELINE configs[4]) is too
     large for the CPU oracle inside a test; size-independent properties instead: chi2 falls monotonically with the
