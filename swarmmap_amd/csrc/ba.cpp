@@ -138,6 +138,7 @@ struct so_ba {
     hipEvent_t pe0 = nullptr, pe1 = nullptr;  // around the PoseOptimization kernel (its own pair: another thread may be in so_bundle_adjust)
     float pose_kernel_ms = 0.f;
     bool pose_ms_pending = false;  // pe0 / pe1 hold a finished measurement not yet read
+    int pose_seq = 0;              // completion stamp of the last PoseOptimization launch (host spins on it)
     bool pose_timing = true;       // HIP events around the PoseOptimization kernel (so_pose_optimization_set_timing)
     static constexpr int kSolveEvents = 32;  // the first trials of a call are event-timed around the solve kernel
     hipEvent_t ev_solve[2 * kSolveEvents] = {nullptr};
@@ -815,6 +816,12 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     a.n = n;
     a.err = reinterpret_cast<double*>(d + off_err);
     a.trace = env_trace ? reinterpret_cast<double*>(d + off_trace) : nullptr;
+    // zero-copy results: the kernel raises a completion word behind them and the host spins on it - the round trip ends
+    // when the results are in host memory, not when the stream's completion signal has made its way back
+    static const bool env_no_spin = getenv("SWARMORB_POSE_NO_SPIN") != nullptr;
+    const bool spin = zero_copy && !env_no_spin;
+    if (spin && ++b->pose_seq == 0) b->pose_seq = 1;
+    a.done_seq = spin ? b->pose_seq : 0;
     static const bool env_no_events = getenv("SWARMORB_NO_EVENTS") != nullptr;  // diagnostic: cost of the two event records
     const bool no_events = env_no_events || !b->pose_timing;
     if (!no_events) SO_HIP(hipEventRecord(b->pe0, s));
@@ -822,8 +829,23 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     if (!no_events) SO_HIP(hipEventRecord(b->pe1, s));
     SO_HIP(hipGetLastError());
     if (!zero_copy) SO_HIP(hipMemcpyAsync(hout, d + off_pose, 64 + 16 + (size_t)n, hipMemcpyDeviceToHost, s));
-    SO_HIP(hipStreamSynchronize(s));
-    b->pose_ms_pending = !no_events;  // both events have completed; the elapsed time is read when somebody asks for it
+    if (spin) {
+        const volatile int* done = reinterpret_cast<const volatile int*>(hout + 64) + 3;
+        for (unsigned long it = 1; *done != a.done_seq; it++) {
+            if ((it & 0xffff) == 0 && hipStreamQuery(s) == hipSuccess) {  // the stream drained: the word must be there
+                if (*done != a.done_seq) {
+                    last_error_ref() = "PoseOptimization kernel finished without publishing its results";
+                    return SO_ERR_HIP;
+                }
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        SO_HIP(hipStreamSynchronize(s));
+    }
+    b->pose_ms_pending = !no_events;  // the elapsed time is read (after the stop event) when somebody asks for it
     BaPose P;
     memcpy(&P, hout, sizeof(BaPose));
     int inf[4];
@@ -910,6 +932,7 @@ int so_pose_optimization_batch(so_ba* b, int32_t n_problems, const so_pose_probl
         a.n = q.n >= 3 ? q.n : 0;  // n < 3: "return 0" with untouched outputs (Optimizer.cc:344-345); the workgroup idles
         a.err = nullptr;
         a.trace = nullptr;
+        a.done_seq = 0;
     }
     if (b->pose_timing) SO_HIP(hipEventRecord(b->pe0, s));
     if (!launch_pose_opt_batch(reinterpret_cast<const PoseOptArgs*>(d), n_problems, max_n, s)) return SO_ERR_INVALID_ARG;
@@ -951,6 +974,7 @@ int so_pose_optimization_set_timing(so_ba* b, int enabled) {
 int so_pose_optimization_last_kernel_ms(so_ba* b, float* ms) {
     if (!b || !ms) return SO_ERR_INVALID_ARG;
     if (b->pose_ms_pending) {
+        (void)hipEventSynchronize(b->pe1);  // the call returned on the kernel's completion word, the event may trail it
         (void)hipEventElapsedTime(&b->pose_kernel_ms, b->pe0, b->pe1);
         b->pose_ms_pending = false;
     }

@@ -176,6 +176,8 @@ struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.
     BaPose* pose_out;
     int* info;         // [0] nBad, [1] LM iterations, [2] LM trials
     double* trace;     // optional: 4 doubles per LM trial (lambda, tempChi, rho, currentChi), 256 trials max
+    int done_seq;      // != 0: the results are in host-mapped memory and info[3] = done_seq is stored behind them
+                       // (system scope), so the host can spin on that word instead of waiting for the stream
 };
 constexpr int kPoseOptLdsMax = 3072;  // matched points the LDS-resident kernel holds (41 B each)
 void launch_pose_opt(const PoseOptArgs& a, hipStream_t s);

@@ -1723,6 +1723,22 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(PoseOptArgs a) {
     }
 }
 
+// results of a PoseOptimization launch are complete in (host-mapped) memory: raise the completion word behind them
+__device__ __forceinline__ void pose_publish(const PoseOptArgs& a, const BaPose& pose, int nbad, int its, int trials) {
+    if (a.done_seq) __threadfence_system();  // this thread's outlier flags
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *a.pose_out = pose;
+        a.info[0] = nbad;
+        a.info[1] = its;
+        a.info[2] = trials;
+        if (a.done_seq) {
+            __threadfence_system();
+            __hip_atomic_store(&a.info[3], a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ---- LDS-resident version (n <= 3072 matched points) ----
 // The kernel above keeps the stored errors and outlier flags in global memory and rebuilds the normal equations
 // in a phase of their own; with ~25 LM trials per call every phase is a memory round trip plus barriers (18 us
@@ -2096,12 +2112,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_lds_kernel(PoseOptArgs a) {
     SO_POSE_TICK(6);
     SO_POSE_TICK_FLUSH;
     for (int e = tid; e < n; e += kPoThreads) a.outlier[e] = s_out[e];
-    if (tid == 0) {
-        *a.pose_out = s_cur;
-        a.info[0] = s_info[0];
-        a.info[1] = its_total;
-        a.info[2] = trials_total;
-    }
+    pose_publish(a, s_cur, s_info[0], its_total, trials_total);
 }
 
 // ---- short-dependency-chain versions of the 6x6 solve and of the SE3 update for the register-resident kernel ----
@@ -2517,12 +2528,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
 #pragma unroll
     for (int k = 0; k < EPT; k++)
         if (live[k]) a.outlier[tid + k * THREADS] = outl[k] ? 1 : 0;
-    if (tid == 0) {
-        *a.pose_out = cur;
-        a.info[0] = nbad_total;
-        a.info[1] = its_total;
-        a.info[2] = trials_total;
-    }
+    pose_publish(a, cur, nbad_total, its_total, trials_total);
 }
 
 template <int THREADS, int EPT>
