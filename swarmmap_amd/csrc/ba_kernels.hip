@@ -2552,6 +2552,17 @@ void launch_pose_opt(const PoseOptArgs& a, hipStream_t s) {
     static const bool classic = getenv("SWARMORB_POSE_CLASSIC") != nullptr;  // A/B switch for profiling
     static const bool lds_only = getenv("SWARMORB_POSE_LDS") != nullptr;    // A/B: the LDS-resident kernel for every size
     static const int force_threads = getenv("SWARMORB_POSE_THREADS") ? atoi(getenv("SWARMORB_POSE_THREADS")) : 0;
+    static const int reg_max = getenv("SWARMORB_POSE_REG_MAX") ? atoi(getenv("SWARMORB_POSE_REG_MAX")) : 3072;  // A/B: 1024 hands 1025..3072 points to the LDS-resident kernel
+    if (!classic && !lds_only && force_threads != 512 && a.n > 1024 && a.n <= reg_max && a.n <= 3072) {
+        const int ept = (a.n + 255) / 256;
+        if (ept == 5) launch_pose_reg<256, 5>(a, s);
+        else if (ept == 6) launch_pose_reg<256, 6>(a, s);
+        else if (ept == 7) launch_pose_reg<256, 7>(a, s);
+        else if (ept == 8) launch_pose_reg<256, 8>(a, s);
+        else if (ept <= 10) launch_pose_reg<256, 10>(a, s);
+        else launch_pose_reg<256, 12>(a, s);
+        return;
+    }
     if (!classic && !lds_only && (a.n <= 1024 || (force_threads == 512 && a.n <= 2048))) {
         // register-resident kernel, 256 threads and up to 4 edges per thread (measured: beyond 1024 points the
         // LDS-resident kernel with 512 threads is faster: 157 vs 183 us at 1500); 512 threads only on request

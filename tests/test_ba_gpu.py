@@ -305,8 +305,11 @@ def test_stop_flag_and_edge_cases(opt, oracle):
 
 
 # ---- Optimizer::PoseOptimization ----------------------------------------------
-@pytest.mark.parametrize("seed,n", [(1, 300), (2, 600), (3, 120), (4, 1000), (5, 9), (6, 3)])
+@pytest.mark.parametrize("seed,n", [(1, 300), (2, 600), (3, 120), (4, 1000), (5, 9), (6, 3), (7, 1024), (8, 1025), (9, 1500),
+                                    (10, 2048), (11, 2400), (12, 3072), (13, 3300)])
 def test_pose_optimization_matches_oracle(opt, oracle, seed, n):
+    """The register-resident kernel keeps 1..12 edges per thread (256 threads: up to 3072 matched points, one template
+    instance per edge count: 1-8, 10, 12); larger frames take the global-memory kernel."""
     c = synth.make_pose_case(seed, n)
     ni, T, outl, info = opt.PoseOptimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
     oni, oT, ooutl, oinfo = oracle.pose_optimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])

@@ -5,7 +5,7 @@ import numpy as np
 from swarmmap_amd import synth
 from swarmmap_amd.optimizer import Optimizer
 o = Optimizer()
-for n in (100, 300, 500, 640, 800, 1000, 1500, 2000, 3000, 4000):
+for n in ([int(a) for a in sys.argv[1:]] or (100, 300, 500, 640, 800, 1000, 1500, 2000, 3000, 4000)):
     c = synth.make_pose_case(7, n=n)
     ks = []
     for _ in range(12):
