@@ -574,6 +574,13 @@ void so_ba_options_global(so_ba_options* opt, int32_t n_iterations, int32_t robu
 int so_pose_optimization(so_ba* ba, const float* Tcw12, const float* intr, int32_t n, const float* Xw,
                          const float* obs, const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier,
                          int32_t* n_inliers, int32_t* info /* [iterations, lm_trials], may be NULL */);
+/* The same call in two halves: _submit stages the inputs and launches, _wait returns the results (one call may be in
+ * flight per handle; SO_ERR_INVALID_ARG otherwise).  What a tracking thread does in between runs under the kernel -
+ * e.g. handing the next frame to the extractor. */
+int so_pose_optimization_submit(so_ba* ba, const float* Tcw12, const float* intr, int32_t n, const float* Xw,
+                                const float* obs, const float* inv_sigma2);
+int so_pose_optimization_wait(so_ba* ba, float* Tcw_out12, uint8_t* outlier, int32_t* n_inliers, int32_t* info);
+
 /* Several independent PoseOptimization problems in ONE launch (a workgroup per problem), e.g. the frames of several
  * agents a thread drives in lockstep.  Fields as the arguments of so_pose_optimization; results identical to calling it
  * per problem. */

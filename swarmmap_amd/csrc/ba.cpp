@@ -139,6 +139,13 @@ struct so_ba {
     float pose_kernel_ms = 0.f;
     bool pose_ms_pending = false;  // pe0 / pe1 hold a finished measurement not yet read
     int pose_seq = 0;              // completion stamp of the last PoseOptimization launch (host spins on it)
+    struct PosePending {           // so_pose_optimization_submit -> _wait
+        bool active = false, launched = false, events = false;
+        int n = 0, done_seq = 0;
+        hipStream_t stream = nullptr;
+        uint8_t* hout = nullptr;
+        double* trace = nullptr;
+    } pose_pending;
     bool pose_timing = true;       // HIP events around the PoseOptimization kernel (so_pose_optimization_set_timing)
     static constexpr int kSolveEvents = 32;  // the first trials of a call are event-timed around the solve kernel
     hipEvent_t ev_solve[2 * kSolveEvents] = {nullptr};
@@ -752,14 +759,16 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     return SO_OK;
 }
 
-// Optimizer::PoseOptimization — code/src/Optimizer.cc:239-434
-int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_t n, const float* Xw, const float* obs,
-                         const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier, int32_t* n_inliers,
-                         int32_t* info) {
-    if (!b || !Tcw12 || !intr || n < 0 || !Tcw_out12 || !n_inliers) return SO_ERR_INVALID_ARG;
-    if (n > 0 && (!Xw || !obs || !inv_sigma2 || !outlier)) return SO_ERR_INVALID_ARG;
-    *n_inliers = 0;
-    if (info) info[0] = info[1] = 0;
+// Optimizer::PoseOptimization — code/src/Optimizer.cc:239-434.  Two halves (the tracking thread has host work that
+// fits under the kernel: submitting the next frame, keyframe bookkeeping); so_pose_optimization = submit + wait.
+int so_pose_optimization_submit(so_ba* b, const float* Tcw12, const float* intr, int32_t n, const float* Xw,
+                                const float* obs, const float* inv_sigma2) {
+    if (!b || !Tcw12 || !intr || n < 0 || b->pose_pending.active) return SO_ERR_INVALID_ARG;
+    if (n > 0 && (!Xw || !obs || !inv_sigma2)) return SO_ERR_INVALID_ARG;
+    so_ba::PosePending& Q = b->pose_pending;
+    Q = so_ba::PosePending{};
+    Q.active = true;
+    Q.n = n;
     if (n < 3) return SO_OK;  // :344-345, nothing is touched
     SO_HIP(hipSetDevice(b->device));
     // PoseOptimization belongs to the tracking thread (Tracking.cc:716,1002): it runs on that thread's matcher
@@ -788,9 +797,9 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     memcpy(h + (size_t)n * 12, obs, (size_t)n * 8);
     memcpy(h + (size_t)n * 20, inv_sigma2, (size_t)n * 4);
     uint8_t* d = b->d_po.as<uint8_t>();
-    // Frames of ordinary size (<= 3072 matched points) run the LDS-resident kernel, which reads its inputs once and
-    // writes three small results: both go through host-mapped memory, so the call is one launch and one sync with
-    // no copies to enqueue.  Larger problems re-read the edges every trial and therefore get a device copy.
+    // Frames of ordinary size (<= 3072 matched points) run the register-resident kernel, which reads its inputs once and
+    // writes three small results: both go through host-mapped memory, so the call is one launch and no copies to
+    // enqueue.  Larger problems re-read the edges every trial and therefore get a device copy.
     static const bool env_classic = getenv("SWARMORB_POSE_CLASSIC") != nullptr, env_trace = getenv("SWARMORB_POSE_TRACE") != nullptr;
     const bool zero_copy = n <= kPoseOptLdsMax && !env_classic;
     uint8_t* hout = h + in_bytes;
@@ -829,11 +838,29 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     if (!no_events) SO_HIP(hipEventRecord(b->pe1, s));
     SO_HIP(hipGetLastError());
     if (!zero_copy) SO_HIP(hipMemcpyAsync(hout, d + off_pose, 64 + 16 + (size_t)n, hipMemcpyDeviceToHost, s));
-    if (spin) {
-        const volatile int* done = reinterpret_cast<const volatile int*>(hout + 64) + 3;
-        for (unsigned long it = 1; *done != a.done_seq; it++) {
-            if ((it & 0xffff) == 0 && hipStreamQuery(s) == hipSuccess) {  // the stream drained: the word must be there
-                if (*done != a.done_seq) {
+    Q.launched = true;
+    Q.stream = s;
+    Q.hout = hout;
+    Q.done_seq = a.done_seq;
+    Q.events = !no_events;
+    Q.trace = a.trace;
+    return SO_OK;
+}
+
+int so_pose_optimization_wait(so_ba* b, float* Tcw_out12, uint8_t* outlier, int32_t* n_inliers, int32_t* info) {
+    if (!b || !b->pose_pending.active || !Tcw_out12 || !n_inliers) return SO_ERR_INVALID_ARG;
+    so_ba::PosePending Q = b->pose_pending;
+    b->pose_pending.active = false;
+    const int n = Q.n;
+    if (n > 0 && !outlier) return SO_ERR_INVALID_ARG;
+    *n_inliers = 0;
+    if (info) info[0] = info[1] = 0;
+    if (!Q.launched) return SO_OK;
+    if (Q.done_seq) {
+        const volatile int* done = reinterpret_cast<const volatile int*>(Q.hout + 64) + 3;
+        for (unsigned long it = 1; *done != Q.done_seq; it++) {
+            if ((it & 0xffff) == 0 && hipStreamQuery(Q.stream) == hipSuccess) {  // the stream drained: the word must be there
+                if (*done != Q.done_seq) {
                     last_error_ref() = "PoseOptimization kernel finished without publishing its results";
                     return SO_ERR_HIP;
                 }
@@ -843,17 +870,17 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     } else {
-        SO_HIP(hipStreamSynchronize(s));
+        SO_HIP(hipStreamSynchronize(Q.stream));
     }
-    b->pose_ms_pending = !no_events;  // the elapsed time is read (after the stop event) when somebody asks for it
+    b->pose_ms_pending = Q.events;  // the elapsed time is read (after the stop event) when somebody asks for it
     BaPose P;
-    memcpy(&P, hout, sizeof(BaPose));
+    memcpy(&P, Q.hout, sizeof(BaPose));
     int inf[4];
-    memcpy(inf, hout + 64, 16);
-    memcpy(outlier, hout + 80, (size_t)n);
-    if (a.trace) {  // debugging aid: dump the LM trial log
+    memcpy(inf, Q.hout + 64, 16);
+    memcpy(outlier, Q.hout + 80, (size_t)n);
+    if (Q.trace) {  // debugging aid: dump the LM trial log
         std::vector<double> tr(4 * 256);
-        SO_HIP(hipMemcpy(tr.data(), a.trace, sizeof(double) * tr.size(), hipMemcpyDeviceToHost));
+        SO_HIP(hipMemcpy(tr.data(), Q.trace, sizeof(double) * tr.size(), hipMemcpyDeviceToHost));
         for (int k = 0; k < inf[2] && k < 256; k++)
             fprintf(stderr, "gpu trial %d lambda %.6e temp %.9e rho %.6e cur %.9e\n", k, tr[4 * k], tr[4 * k + 1], tr[4 * k + 2], tr[4 * k + 3]);
     }
@@ -866,9 +893,23 @@ int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_
     return SO_OK;
 }
 
+int so_pose_optimization(so_ba* b, const float* Tcw12, const float* intr, int32_t n, const float* Xw, const float* obs,
+                         const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier, int32_t* n_inliers,
+                         int32_t* info) {
+    if (!b || !Tcw12 || !intr || n < 0 || !Tcw_out12 || !n_inliers) return SO_ERR_INVALID_ARG;
+    if (n > 0 && (!Xw || !obs || !inv_sigma2 || !outlier)) return SO_ERR_INVALID_ARG;
+    const int rc = so_pose_optimization_submit(b, Tcw12, intr, n, Xw, obs, inv_sigma2);
+    if (rc != SO_OK) {
+        b->pose_pending.active = false;
+        return rc;
+    }
+    return so_pose_optimization_wait(b, Tcw_out12, outlier, n_inliers, info);
+}
+
 // Several independent PoseOptimization problems in ONE launch (a workgroup per problem): the frames of several agents
 // driven in lockstep by one thread.  Inputs and results travel through host-mapped memory like the single call.
 int so_pose_optimization_batch(so_ba* b, int32_t n_problems, const so_pose_problem* problems) {
+    if (b && b->pose_pending.active) return SO_ERR_INVALID_ARG;  // a submitted single problem owns the staging block
     if (!b || n_problems < 0 || (n_problems > 0 && !problems)) return SO_ERR_INVALID_ARG;
     if (n_problems == 0) return SO_OK;
     int max_n = 0;

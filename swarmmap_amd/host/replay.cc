@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -169,7 +170,7 @@ struct so_replay {
         double match_kernel = 0, pose_kernel = 0, pose_trials = 0, pose_points = 0, mstat[4] = {0, 0, 0, 0};
         int pose_calls = 0, pose_timed_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0, hcur = 0, first_slot = 0;
         int32_t n_in = 0;
-        bool first = false, m2_submitted = false, timed_kernels = true;
+        bool first = false, m2_submitted = false, timed_kernels = true, next_submitted = false;
         int m2_rc = 0;
         float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
         M4 T = M4::eye();
@@ -431,7 +432,7 @@ namespace {
 int step_m2_submit(so_replay* r);
 
 // Frame constructor: collect frame t, put frame t+1 in flight.  The first frame of a run initialises the map.
-int step_begin(so_replay* r, int t) {
+int step_begin(so_replay* r, int t, bool submit_next = true) {
     so_replay::Step& S = r->step;
     S = so_replay::Step{};
     S.t0 = now_ms();
@@ -454,8 +455,14 @@ int step_begin(so_replay* r, int t) {
     if (so_dframe_collect(r->fr[S.hcur], F.kps.data(), F.xy_un.data(), F.desc.data(), r->cap, &n, r->bounds) != SO_OK)
         return fail(r, "so_dframe_collect");
     r->in_flight = false;
-    const int rc = submit_frame(r, t + 1);
-    if (rc) return rc;
+    S.first = r->n_tracked == 0;
+    // the next frame goes to the extractor here - or, on the single-agent path, under this frame's first
+    // PoseOptimization kernel, where the tracking thread would only be waiting (so_replay_run)
+    S.next_submitted = submit_next || S.first;
+    if (S.next_submitted) {
+        const int rc = submit_frame(r, t + 1);
+        if (rc) return rc;
+    }
     S.t1 = S.tm2 = S.tp1 = S.tm1 = S.tp2 = S.tp3 = S.tmap = now_ms();
     S.n_in = n;
     for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = -1;
@@ -551,17 +558,26 @@ void pose_account(so_replay* r, const so_pose_problem& q, float kernel_ms) {
     S.pose_timed_calls++;
 }
 
-int pose_single(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers) {
+// under_kernel (may be empty): host work of the tracking thread that does not depend on this call's result; it runs
+// between the launch and the wait
+template <typename F>
+int pose_single(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers, F under_kernel) {
     so_pose_problem q;
     int32_t info2[2];
     pose_gather(r, T_in12, T_out12, n_inliers, info2, &q);
-    if (so_pose_optimization(r->tracker_opt, q.Tcw12, q.intr, q.n, q.Xw, q.obs, q.inv_sigma2, q.Tcw_out12, q.outlier,
-                             q.n_inliers, q.info) != SO_OK)
-        return fail(r, "so_pose_optimization");
+    if (so_pose_optimization_submit(r->tracker_opt, q.Tcw12, q.intr, q.n, q.Xw, q.obs, q.inv_sigma2) != SO_OK)
+        return fail(r, "so_pose_optimization_submit");
+    const int rc = under_kernel();
+    if (so_pose_optimization_wait(r->tracker_opt, q.Tcw_out12, q.outlier, q.n_inliers, q.info) != SO_OK)
+        return fail(r, "so_pose_optimization_wait");
+    if (rc) return rc;
     float ms = 0.f;
-    so_pose_optimization_last_kernel_ms(r->tracker_opt, &ms);
+    if (r->step.timed_kernels) so_pose_optimization_last_kernel_ms(r->tracker_opt, &ms);
     pose_account(r, q, ms);
     return SO_OK;
+}
+int pose_single(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers) {
+    return pose_single(r, T_in12, T_out12, n_inliers, [] { return 0; });
 }
 
 void pose1_apply(so_replay* r) {  // Tracking.cc:1030-1046: outliers lose their map point
@@ -706,11 +722,13 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
     for (int t = first_t; t < first_t + n_steps; t++) {
         so_replay::Step& S = r->step;
         int rc;
-        if ((rc = step_begin(r, t))) return rc;
+        static const bool submit_early = getenv("SWARMORB_REPLAY_SUBMIT_EARLY") != nullptr;  // A/B: next frame at step begin
+        if ((rc = step_begin(r, t, submit_early))) return rc;
         if (!S.first) {
             if ((rc = step_m2_wait(r))) return rc;  // submitted inside step_begin
             int32_t inl = 0;
-            if ((rc = pose_single(r, S.Tp, S.Ta, &inl))) return rc;
+            // frame t+1 goes to the extractor while the GPU runs this frame's first PoseOptimization
+            if ((rc = pose_single(r, S.Tp, S.Ta, &inl, [r, t, &S] { return S.next_submitted ? 0 : submit_frame(r, t + 1); }))) return rc;
             pose1_apply(r);
             if ((rc = step_m1_submit(r))) return rc;
             if ((rc = step_m1_wait(r))) return rc;
@@ -720,10 +738,13 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
                 float Tl[12], Tc[12];
                 to_f12(r->T_last, Tl);
                 int32_t inl3 = 0;
-                if ((rc = pose_single(r, Tl, Tc, &inl3))) return rc;
+                // the keyframe decision and the new map points only need the second result: they run under this kernel
+                if ((rc = pose_single(r, Tl, Tc, &inl3, [r] { return step_keyframe(r); }))) return rc;
+                S.tp3 = S.tmap = now_ms();
+            } else {
+                S.tp3 = now_ms();
+                if ((rc = step_keyframe(r))) return rc;
             }
-            S.tp3 = now_ms();
-            if ((rc = step_keyframe(r))) return rc;
         }
         step_end(r, t, timed);
         if (!r->error.empty()) return SO_ERR_HIP;
