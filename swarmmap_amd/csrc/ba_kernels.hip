@@ -1723,7 +1723,9 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(PoseOptArgs a) {
     }
 }
 
-// results of a PoseOptimization launch are complete in (host-mapped) memory: raise the completion word behind them
+// results of a PoseOptimization launch are complete in (host-mapped) memory: raise the completion word behind them.
+// The system-scope fences are needed: with s_waitcnt + a relaxed store instead (no L2 write-back) the word reaches the
+// host before the results do (tests/test_trajectory_gpu.py fails); they cost ~4 us of kernel time per launch.
 __device__ __forceinline__ void pose_publish(const PoseOptArgs& a, const BaPose& pose, int nbad, int its, int trials) {
     if (a.done_seq) __threadfence_system();  // this thread's outlier flags
     __syncthreads();
