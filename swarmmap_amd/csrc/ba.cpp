@@ -859,12 +859,16 @@ int so_pose_optimization_wait(so_ba* b, float* Tcw_out12, uint8_t* outlier, int3
     if (Q.done_seq) {
         const volatile int* done = reinterpret_cast<const volatile int*>(Q.hout + 64) + 3;
         for (unsigned long it = 1; *done != Q.done_seq; it++) {
-            if ((it & 0xffff) == 0 && hipStreamQuery(Q.stream) == hipSuccess) {  // the stream drained: the word must be there
-                if (*done != Q.done_seq) {
-                    last_error_ref() = "PoseOptimization kernel finished without publishing its results";
-                    return SO_ERR_HIP;
+            if ((it & 0xffff) == 0) {  // every ~65 k polls: is the stream still alive?
+                const hipError_t q = hipStreamQuery(Q.stream);
+                if (q != hipErrorNotReady) {  // drained (the word must be there) or failed
+                    if (q != hipSuccess || *done != Q.done_seq) {
+                        last_error_ref() = q != hipSuccess ? std::string("PoseOptimization: ") + hipGetErrorString(q)
+                                                           : std::string("PoseOptimization kernel finished without publishing its results");
+                        return SO_ERR_HIP;
+                    }
+                    break;
                 }
-                break;
             }
             __builtin_ia32_pause();
         }
@@ -922,7 +926,7 @@ int so_pose_optimization_batch(so_ba* b, int32_t n_problems, const so_pose_probl
         total_in += ((size_t)q.n * 24 + 63) & ~(size_t)63;
         total_out += (80 + (size_t)q.n + 63) & ~(size_t)63;
     }
-    if (max_n > 1024) {  // beyond the batched kernel: one call per problem
+    if (max_n > 3072) {  // beyond the batched kernel: one call per problem
         for (int p = 0; p < n_problems; p++) {
             const so_pose_problem& q = problems[p];
             const int rc = so_pose_optimization(b, q.Tcw12, q.intr, q.n, q.Xw, q.obs, q.inv_sigma2, q.Tcw_out12, q.outlier,

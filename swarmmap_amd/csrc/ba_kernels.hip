@@ -2538,15 +2538,27 @@ static void launch_pose_reg(const PoseOptArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((pose_opt_reg_kernel<THREADS, EPT>), dim3(1), dim3(THREADS), 0, s, a, (const PoseOptArgs*)nullptr);
 }
 
+template <int EPT>
+static void launch_pose_reg_batch(const PoseOptArgs* d_args, int n_problems, hipStream_t s) {
+    const PoseOptArgs none{};
+    hipLaunchKernelGGL((pose_opt_reg_kernel<256, EPT>), dim3(n_problems), dim3(256), 0, s, none, d_args);
+}
+
 bool launch_pose_opt_batch(const PoseOptArgs* d_args, int n_problems, int max_n, hipStream_t s) {
     if (n_problems <= 0) return true;
-    if (max_n > 1024) return false;  // the register-resident kernel holds 4 edges per thread
-    const PoseOptArgs none{};
-    const int ept = (max_n + 255) / 256;
-    if (ept <= 1) hipLaunchKernelGGL((pose_opt_reg_kernel<256, 1>), dim3(n_problems), dim3(256), 0, s, none, d_args);
-    else if (ept == 2) hipLaunchKernelGGL((pose_opt_reg_kernel<256, 2>), dim3(n_problems), dim3(256), 0, s, none, d_args);
-    else if (ept == 3) hipLaunchKernelGGL((pose_opt_reg_kernel<256, 3>), dim3(n_problems), dim3(256), 0, s, none, d_args);
-    else hipLaunchKernelGGL((pose_opt_reg_kernel<256, 4>), dim3(n_problems), dim3(256), 0, s, none, d_args);
+    if (max_n > 3072) return false;  // the register-resident kernel holds 12 edges per thread
+    switch ((max_n + 255) / 256) {
+        case 0: case 1: launch_pose_reg_batch<1>(d_args, n_problems, s); break;
+        case 2: launch_pose_reg_batch<2>(d_args, n_problems, s); break;
+        case 3: launch_pose_reg_batch<3>(d_args, n_problems, s); break;
+        case 4: launch_pose_reg_batch<4>(d_args, n_problems, s); break;
+        case 5: launch_pose_reg_batch<5>(d_args, n_problems, s); break;
+        case 6: launch_pose_reg_batch<6>(d_args, n_problems, s); break;
+        case 7: launch_pose_reg_batch<7>(d_args, n_problems, s); break;
+        case 8: launch_pose_reg_batch<8>(d_args, n_problems, s); break;
+        case 9: case 10: launch_pose_reg_batch<10>(d_args, n_problems, s); break;
+        default: launch_pose_reg_batch<12>(d_args, n_problems, s); break;
+    }
     return true;
 }
 

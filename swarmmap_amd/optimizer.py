@@ -26,6 +26,12 @@ class SoBaInfo(C.Structure):
                 ("solve_gflop_dense", C.c_double), ("nnz_tiles", C.c_double), ("solver_path", C.c_int32), ("reserved", C.c_int32)]
 
 
+class SoPoseProblem(C.Structure):
+    _fields_ = [("Tcw12", C.c_void_p), ("intr", C.c_void_p), ("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("Tcw_out12", C.c_void_p), ("outlier", C.c_void_p), ("n_inliers", C.c_void_p),
+                ("info", C.c_void_p)]
+
+
 def _vp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -121,6 +127,53 @@ class Optimizer:
         n_in = C.c_int32(0)
         _lib.check(lib.so_pose_optimization(self._h, _vp(T), _vp(K), len(X), _vp(X), _vp(O), _vp(W), _vp(Tout),
                                             _vp(outl), C.byref(n_in), _vp(info)))
+        return n_in.value, Tout, outl, {"iterations": int(info[0]), "lm_trials": int(info[1])}
+
+    # so_pose_optimization_batch: several frames' problems (e.g. the agents a thread drives in lockstep) in ONE launch
+    def PoseOptimizationBatch(self, problems):
+        """problems: list of (Tcw, intr, Xw, obs, inv_sigma2); returns the list of PoseOptimization results."""
+        arr = (SoPoseProblem * len(problems))()
+        keep, outs = [], []
+        for k, (Tcw, intr, Xw, obs, w) in enumerate(problems):
+            T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+            K = np.ascontiguousarray(intr, np.float32).reshape(4)
+            X = np.ascontiguousarray(Xw, np.float32).reshape(-1, 3)
+            O = np.ascontiguousarray(obs, np.float32).reshape(-1, 2)
+            W = np.ascontiguousarray(w, np.float32)
+            Tout, outl, info, n_in = T.copy(), np.zeros(len(X), np.uint8), np.zeros(2, np.int32), np.zeros(1, np.int32)
+            keep.append((T, K, X, O, W))
+            outs.append((n_in, Tout, outl, info))
+            arr[k] = SoPoseProblem(T.ctypes.data, K.ctypes.data, len(X), X.ctypes.data, O.ctypes.data, W.ctypes.data,
+                                   Tout.ctypes.data, outl.ctypes.data, n_in.ctypes.data, info.ctypes.data)
+        self._lib.so_pose_optimization_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        _lib.check(self._lib.so_pose_optimization_batch(self._h, len(problems), C.cast(arr, C.c_void_p)))
+        return [(int(n_in[0]), Tout, outl, {"iterations": int(info[0]), "lm_trials": int(info[1])}) for n_in, Tout, outl, info in outs]
+
+    # the same call in two halves (so_pose_optimization_submit / _wait): host work placed between them runs under the kernel
+    def PoseOptimizationSubmit(self, Tcw, intr, Xw, obs, inv_sigma2):
+        lib = self._lib
+        vp = C.c_void_p
+        lib.so_pose_optimization_submit.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+        K = np.ascontiguousarray(intr, np.float32).reshape(4)
+        X = np.ascontiguousarray(Xw, np.float32).reshape(-1, 3)
+        O = np.ascontiguousarray(obs, np.float32).reshape(-1, 2)
+        W = np.ascontiguousarray(inv_sigma2, np.float32)
+        _lib.check(lib.so_pose_optimization_submit(self._h, _vp(T), _vp(K), len(X), _vp(X), _vp(O), _vp(W)))
+        self._pose_pending = (T, len(X))
+
+    def PoseOptimizationWait(self):
+        lib = self._lib
+        vp = C.c_void_p
+        lib.so_pose_optimization_wait.argtypes = [vp, vp, vp, C.POINTER(C.c_int32), vp]
+        pending = getattr(self, "_pose_pending", None)
+        n = pending[1] if pending else 0
+        Tout = pending[0].copy() if pending else np.zeros(12, np.float32)
+        outl = np.zeros(n, np.uint8)
+        info = np.zeros(2, np.int32)
+        n_in = C.c_int32(0)
+        self._pose_pending = None
+        _lib.check(lib.so_pose_optimization_wait(self._h, _vp(Tout), _vp(outl), C.byref(n_in), _vp(info)))
         return n_in.value, Tout, outl, {"iterations": int(info[0]), "lm_trials": int(info[1])}
 
     def pose_kernel_ms(self):

@@ -324,6 +324,35 @@ def test_pose_optimization_matches_oracle(opt, oracle, seed, n):
         assert (outl.astype(bool) & c["gt_outlier"]).sum() >= 0.9 * c["gt_outlier"].sum()
 
 
+def test_pose_optimization_in_two_halves(opt):
+    """so_pose_optimization_submit / _wait return what the one-shot call returns, for the zero-copy kernels (completion
+    word) and for the copy path beyond 3072 points; a second submit, a batch or a wait without a submit are refused."""
+    import swarmmap_amd._lib as L
+    for seed, n in ((21, 700), (22, 2), (23, 3300)):
+        c = synth.make_pose_case(seed, n)
+        args = (c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
+        one = opt.PoseOptimization(*args)
+        opt.PoseOptimizationSubmit(*args)
+        with pytest.raises(L.SwarmOrbError):
+            opt.PoseOptimizationSubmit(*args)  # one call in flight per handle
+        two = opt.PoseOptimizationWait()
+        assert one[0] == two[0] and np.array_equal(one[1], two[1]) and np.array_equal(one[2], two[2]) and one[3] == two[3]
+    with pytest.raises(L.SwarmOrbError):
+        opt.PoseOptimizationWait()  # nothing submitted
+
+
+def test_pose_optimization_batch_matches_single_calls(opt):
+    """so_pose_optimization_batch: a workgroup per problem in one launch, every problem with the result of its own call
+    (sizes on both sides of the per-thread edge counts, an empty-ish problem in the middle)."""
+    cases = [synth.make_pose_case(30 + k, n) for k, n in enumerate((300, 2, 1500, 700, 2600))]
+    args = [(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"]) for c in cases]
+    single = [opt.PoseOptimization(*a) for a in args]
+    batch = opt.PoseOptimizationBatch(args)
+    for s1, b1 in zip(single, batch):
+        assert s1[0] == b1[0] and np.array_equal(s1[2], b1[2])
+        assert np.abs(s1[1] - b1[1]).max() <= 2e-6  # (a different edges-per-thread instance sums in a different order)
+
+
 def test_pose_optimization_too_few_points(opt):
     c = synth.make_pose_case(9, 2)
     ni, T, outl, info = opt.PoseOptimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
