@@ -165,7 +165,7 @@ struct so_ba {
     // d_in: the problem as one block (see Layout in so_bundle_adjust), staged in pinned h_in and moved with one
     // copy; d_out / h_out: the result block coming back the same way; the rest is device-only working storage
     Buf d_in, d_out, d_pose1, d_pt1, d_err, d_chi2, d_tab, d_Hpp, d_bp, d_Hll, d_bl, d_W, d_Dinv, d_db, d_BDinv, d_S,
-        d_bs, d_xl, d_partial, d_po, d_lm, d_dense_ws, d_dense_x, d_pr_off, d_pr_cur, d_pr, d_big, d_scan_tmp, d_plan, d_flow;
+        d_bs, d_xl, d_partial, d_po, d_lm, d_dense_ws, d_dense_x, d_pr_off, d_pr_cur, d_pr, d_big, d_scan_tmp, d_plan, d_flow, d_flow_big;
     void* h_in = nullptr;
     size_t h_in_cap = 0;
     void* h_out = nullptr;
@@ -178,7 +178,7 @@ struct so_ba {
     std::vector<Buf*> all() {
         return {&d_in, &d_out, &d_pose1, &d_pt1, &d_err, &d_chi2, &d_tab, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv,
                 &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x, &d_pr_off, &d_pr_cur, &d_pr, &d_big, &d_scan_tmp, &d_plan,
-                &d_flow};
+                &d_flow, &d_flow_big};
     }
 };
 
@@ -575,16 +575,31 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         if (!b->plan.tiles.empty()) memcpy((uint8_t*)b->h_plan + first_bytes, b->plan.tiles.data(), sizeof(int2) * b->plan.tiles.size());
         SO_HIP(hipMemcpyAsync(b->d_plan.p, b->h_plan, first_bytes + sizeof(int2) * b->plan.tiles.size(), hipMemcpyHostToDevice, s));
         if (b->plan.flow_n_tiles > 0) {
-            const int want = b->plan.flow_n_tiles, budget = flow_resident_budget(b->device);
-            int cur = g_flow_tiles.load();
-            while (cur + want <= budget && !g_flow_tiles.compare_exchange_weak(cur, cur + want)) {
+            const int budget = flow_resident_budget(b->device);
+            if (!b->plan.flow_big) {  // a workgroup per tile: all or nothing
+                const int want = b->plan.flow_n_tiles;
+                int cur = g_flow_tiles.load();
+                while (cur + want <= budget && !g_flow_tiles.compare_exchange_weak(cur, cur + want)) {
+                }
+                if (cur + want <= budget) b->flow_reserved = want;
+            } else {  // ticketed kernel: whatever is free, if that is worth it
+                int cur = g_flow_tiles.load(), take = 0;
+                do {
+                    take = std::min(b->plan.flow_n_tiles, budget - cur);
+                } while (take >= 128 && !g_flow_tiles.compare_exchange_weak(cur, cur + take));
+                if (take >= 128) b->flow_reserved = take;  // (the early tickets of build_dense_plan need room: see there)
             }
-            if (cur + want <= budget) b->flow_reserved = want;
         }
-        if (b->flow_reserved > 0 && !b->d_flow.p) {
-            const size_t bytes = sizeof(unsigned) * kFlowFlagWords + sizeof(double) * 256 * 96;
-            if ((rc = b->d_flow.ensure(bytes))) return rc;
-            SO_HIP(hipMemsetAsync(b->d_flow.p, 0, bytes, s));
+        if (b->flow_reserved > 0) {
+            // small kernel: fixed flag block + the forward vectors; ticketed kernel: a flag per tile slot + 2 x 512 + counters
+            const size_t nslots = b->plan.flow_big ? (size_t)T * (T + 1) / 2 : 0;
+            const size_t bytes = b->plan.flow_big ? sizeof(unsigned) * (nslots + 2 * kDenseMaxPanels + 8)
+                                                  : sizeof(unsigned) * kFlowFlagWords + sizeof(double) * 256 * 96;
+            Buf& fb = b->plan.flow_big ? b->d_flow_big : b->d_flow;
+            if (bytes > fb.cap) {  // stamps of earlier solves live here: a fresh block starts from zero
+                if ((rc = fb.ensure(bytes))) return rc;
+                SO_HIP(hipMemsetAsync(fb.p, 0, fb.cap, s));
+            }
         }
     }
     const double t_dense_setup = now_ms();
@@ -677,9 +692,12 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.plan = dense_path ? &b->plan : nullptr;
     const bool flow = dense_path && b->flow_reserved > 0;
     d.flow_tiles = flow ? d.plan_tiles + b->plan.flow_first_tile : nullptr;
-    d.flow_flags = flow ? b->d_flow.as<unsigned>() : nullptr;
-    d.flow_vec = flow ? reinterpret_cast<double*>(b->d_flow.as<unsigned>() + kFlowFlagWords) : nullptr;
+    const bool flow_big = flow && b->plan.flow_big;
+    d.flow_flags = !flow ? nullptr : flow_big ? b->d_flow_big.as<unsigned>() : b->d_flow.as<unsigned>();
+    d.flow_vec = flow && !flow_big ? reinterpret_cast<double*>(b->d_flow.as<unsigned>() + kFlowFlagWords) : nullptr;
     d.flow_epoch = &b->flow_epoch;
+    d.flow_nslots = flow_big ? (int)((ldS / 96) * (ldS / 96 + 1) / 2) : 0;
+    d.flow_grid = flow_big ? b->flow_reserved : 0;
     d.xl = b->d_xl.as<double>();
     d.partial = b->d_partial.as<double>();
     d.robust = opt->robust;

@@ -22,6 +22,8 @@
 // an eight-agent map (648 MB) stays resident next to the problem.
 #include <algorithm>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
 #include "ba_device.h"
 
@@ -884,6 +886,7 @@ __global__ void dense_begin_kernel(BaDev d) {
 //                        deterministic.  b, y and x share d.bs (every reader of y_J is done before x_J exists).
 // Critical path per panel (tools/flow_probe.py, 64 keyframes): factor + inverse 17 us, inverse to HBM + flag 3 us,
 // L_{J+1,J} 10 us, update 7 us; the substitutions add ~4 us per panel at the end.
+constexpr int kFlowDiagLeadDefault = 12, kFlowDiagLeadMax = 32;  // ticketed kernel: columns a diagonal tile is picked up early
 constexpr int kFlowMaxTiles = 231;   // 21 panels dense (2016 unknowns, 336 keyframes); a skyline may reach further
 constexpr int kFlowSlots = 256;      // flag / vector slots per kind: tile (I, J) -> I (I + 1) / 2 + J
 constexpr int kFlowFlagTile = 0, kFlowFlagFwd = kFlowSlots, kFlowFlagY = 2 * kFlowSlots, kFlowFlagX = 2 * kFlowSlots + 32,
@@ -897,8 +900,15 @@ static_assert(kFlowMaxTiles <= kFlowSlots && 22 * 21 / 2 <= kFlowSlots, "tile sl
 #ifdef SO_FLOW_PROBE
 __device__ unsigned long long g_flow_marks[256][16];
 #define SO_FLOW_MARK(i) do { if (threadIdx.x == 0) g_flow_marks[blockIdx.x][(i)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_flow_diag[10][512];  // per block column: factor published, y published, x published
+#define SO_FLOW_DIAG(which, j) do { if (threadIdx.x == 0) g_flow_diag[(which)][(j)] = wall_clock64(); } while (0)
+#define SO_FLOW_WNOTE(v) do { if ((threadIdx.x & 63) == 0) g_flow_marks[blockIdx.x][12 + (threadIdx.x >> 6)] = (unsigned long long)(v); } while (0)
+#define SO_FLOW_NOTE(i, v) do { if (threadIdx.x == 0) g_flow_marks[blockIdx.x][(i)] = (unsigned long long)(v); } while (0)
 #else
 #define SO_FLOW_MARK(i)
+#define SO_FLOW_NOTE(i, v)
+#define SO_FLOW_WNOTE(v)
+#define SO_FLOW_DIAG(which, j)
 #endif
 
 __device__ __forceinline__ bool flow_ready(const unsigned* f, unsigned epoch) {
@@ -1023,15 +1033,16 @@ __device__ __forceinline__ void dense_tile_lds_syrk(const double (*sT)[kPS], d4 
     }
 }
 
-__global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch) {
-    extern __shared__ __align__(16) double flow_lds[];
-    __shared__ int s_m, s_bad;
-    __shared__ double s_v[kDNB], s_u[kDNB];
-    if (!d.lm->active) return;
-    const int tid = threadIdx.x, ld = d.ldS, T = ld / kDNB;
-    const int2 t = d.flow_tiles[blockIdx.x];
-    const int I = t.x, J = t.y, self = I * (I + 1) / 2 + J;
-    unsigned* flags = d.flow_flags;
+// Tile (I, J) from the accumulation to the published result, shared by the two flow kernels.  On return
+//   J < I   L_IJ is in HBM (flag up) and in LDS (sT = flow_lds + 2 * kDNB * kDStride, row stride kPS)
+//   J == I  Linv_J is in HBM (flag up) and in LDS (X = flow_lds + kDNB * kPS); the A block (flow_lds) is free
+// `flags`: the tile flags, slot I (I + 1) / 2 + J; `bad`: the word a failed pivot stamps.
+__device__ __forceinline__ void flow_factor_tile(const BaDev& d, int I, int J, unsigned epoch, unsigned* flags, unsigned* bad,
+                                                 double* flow_lds, int* s_m_p, int* s_bad_p) {
+    const int tid = threadIdx.x, ld = d.ldS;
+    const int self = I * (I + 1) / 2 + J;
+    int& s_m = *s_m_p;
+    int& s_bad = *s_bad_p;
     double (*sA)[kDStride] = reinterpret_cast<double (*)[kDStride]>(flow_lds);
     double (*sB)[kDStride] = reinterpret_cast<double (*)[kDStride]>(flow_lds + kDNB * kDStride);
     const int lane = tid & 63, wave = tid >> 6, wr = (wave >> 1) * 48, wc = (wave & 1) * 48;
@@ -1048,15 +1059,15 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
                 tot[rt][ct][reg] = -C[(size_t)r * ld + c];
             }
     SO_FLOW_MARK(0);
-    const int lo = max(d.tile_first[I], d.tile_first[J]);
+    const int lo = __builtin_amdgcn_readfirstlane(max(d.tile_first[I], d.tile_first[J]));
     const double* Pi = d.S + (size_t)I * kDNB * ld;
     const double* Pj = d.S + (size_t)J * kDNB * ld;
     // The diagonal workgroup owns the step that sits on the critical path: it keeps its own copy of the sub-diagonal
     // tile (J, J-1) - tot2, the same accumulation workgroup (J, J-1) does - so that when Linv_{J-1} arrives it forms
     // L_{J,J-1} in LDS and applies it to its tile without a round trip through HBM and a second flag.
-    const bool own_sub = I == J && J > 0 && d.tile_first[J] <= J - 1;
+    const bool own_sub = I == J && J > 0 && __builtin_amdgcn_readfirstlane(d.tile_first[J]) <= J - 1;
     const int k_end = own_sub ? J - 1 : J;
-    const int sub_first = own_sub ? d.tile_first[J - 1] : 0;  // tile (J-1, k) exists from here on
+    const int sub_first = own_sub ? __builtin_amdgcn_readfirstlane(d.tile_first[J - 1]) : 0;  // tile (J-1, k) exists from here on
     const double* Ps = own_sub ? d.S + (size_t)(J - 1) * kDNB * ld : nullptr;
     d4 tot2[3][3];
     if (own_sub) {
@@ -1075,9 +1086,9 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
         if (tid == 0) {
             int m = 0;
             for (;;) {  // the ready prefix of the remaining column tiles, at least one
-                while (k + m < k_end && flow_ready(&flags[kFlowFlagTile + I * (I + 1) / 2 + k + m], epoch) &&
-                       flow_ready(&flags[kFlowFlagTile + J * (J + 1) / 2 + k + m], epoch) &&
-                       (!own_sub || k + m < sub_first || flow_ready(&flags[kFlowFlagTile + (J - 1) * J / 2 + k + m], epoch)))
+                while (k + m < k_end && flow_ready(&flags[I * (I + 1) / 2 + k + m], epoch) &&
+                       flow_ready(&flags[J * (J + 1) / 2 + k + m], epoch) &&
+                       (!own_sub || k + m < sub_first || flow_ready(&flags[(J - 1) * J / 2 + k + m], epoch)))
                     m++;
                 if (m > 0) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -1085,17 +1096,20 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
             s_m = m;
         }
         __syncthreads();
-        const int m = s_m;  // (the GEMM's barriers separate this read from the next store)
+        const int m = __builtin_amdgcn_readfirstlane(s_m);  // (the GEMM's barriers separate this read from the next store)
         flow_acquire();
         dense_tile_nt<false>(Pi + (size_t)k * kDNB, ld, Pj + (size_t)k * kDNB, ld, sA, sB, tot, m * kDNB);
         if (own_sub && k + m > sub_first) {
+            // (both products in one pass over K - 18 MFMA per step, the row operand staged once - was measured: 1 % on
+            // the ticketed kernel, which then spills, and -1.5 % on the one-tile-per-workgroup kernel)
             const int k2 = max(k, sub_first);
             dense_tile_nt<false>(Pi + (size_t)k2 * kDNB, ld, Ps + (size_t)k2 * kDNB, ld, sA, sB, tot2, (k + m - k2) * kDNB);
         }
         k += m;
     }
     SO_FLOW_MARK(1);
-    double* vec_fwd = d.flow_vec;
+    if (I == J) SO_FLOW_DIAG(4, J);
+    if (I == J + 1) SO_FLOW_DIAG(7, J);
     if (I != J) {
         double (*sT)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds + 2 * kDNB * kDStride);  // disjoint from sA / sB
 #pragma unroll
@@ -1107,13 +1121,14 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
                     const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
                     sT[r][c] = -tot[rt][ct][reg];
                 }
-        if (tid == 0) flow_wait(&flags[kFlowFlagTile + J * (J + 1) / 2 + J], epoch);
+        if (tid == 0) flow_wait(&flags[J * (J + 1) / 2 + J], epoch);
         __syncthreads();
         flow_acquire();
         SO_FLOW_MARK(2);
+        if (I == J + 1) SO_FLOW_DIAG(8, J);
         d4 acc[3][3];
         dense_tile_lds_nt(sT, d.dense_ws + (size_t)J * kDNB * kDNB, kDNB, sB, acc);
-        __syncthreads();  // every wave is done reading sT: it now takes L_IJ for the two vectors below
+        __syncthreads();  // every wave is done reading sT: it now takes L_IJ
         SO_FLOW_MARK(3);
 #pragma unroll
         for (int rt = 0; rt < 3; rt++)
@@ -1125,21 +1140,9 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
                     C[(size_t)r * ld + c] = acc[rt][ct][reg];
                     sT[r][c] = acc[rt][ct][reg];
                 }
-        flow_publish(&flags[kFlowFlagTile + self], epoch);
+        flow_publish(&flags[self], epoch);
         SO_FLOW_MARK(4);
-        // forward: L_IJ y_J
-        if (tid == 0) flow_wait(&flags[kFlowFlagY + J], epoch);
-        __syncthreads();
-        if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)J * kDNB + tid]);
-        __syncthreads();
-        if (tid < kDNB) {
-            double v = 0.0;
-#pragma unroll 8
-            for (int m = 0; m < kDNB; m++) v = fma(sT[tid][m], s_v[m], v);
-            flow_vec_store(&vec_fwd[(size_t)self * kDNB + tid], v);
-        }
-        flow_publish_vec(&flags[kFlowFlagFwd + self], epoch);
-        SO_FLOW_MARK(8);
+        if (I == J + 1) SO_FLOW_DIAG(9, J);
         return;
     }
     // diagonal tile
@@ -1154,10 +1157,11 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
                     const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
                     sT[r][c] = -tot2[rt][ct][reg];
                 }
-        if (tid == 0) flow_wait(&flags[kFlowFlagTile + (J - 1) * J / 2 + (J - 1)], epoch);
+        if (tid == 0) flow_wait(&flags[(J - 1) * J / 2 + (J - 1)], epoch);
         __syncthreads();
         flow_acquire();
         SO_FLOW_MARK(2);
+        SO_FLOW_DIAG(5, J);
         dense_tile_lds_nt(sT, d.dense_ws + (size_t)(J - 1) * kDNB * kDNB, kDNB, sB, tot2);  // L_{J,J-1}
         SO_FLOW_MARK(3);
         __syncthreads();  // every wave is done reading sT
@@ -1191,9 +1195,50 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     potrf_block_lds(A, X, &s_bad);
     SO_FLOW_MARK(6);
     potrf_store_inverse(X, d.dense_ws + (size_t)J * kDNB * kDNB);
-    if (tid == 0 && s_bad) __hip_atomic_store(&flags[kFlowFlagBad], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flow_publish(&flags[kFlowFlagTile + self], epoch);
+    if (tid == 0 && s_bad) __hip_atomic_store(bad, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flow_publish(&flags[self], epoch);
     SO_FLOW_MARK(7);
+}
+
+// a 96 x 96 tile of S (row-major, leading dimension ld) into LDS (row stride kPS)
+__device__ __forceinline__ void flow_stage_tile(const double* __restrict__ src, int ld, double (*dst)[kPS]) {
+    for (int i = threadIdx.x; i < kDNB * (kDNB / 2); i += 256) {
+        const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
+        const double2 v = *reinterpret_cast<const double2*>(src + (size_t)r * ld + c);
+        dst[r][c] = v.x; dst[r][c + 1] = v.y;
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch) {
+    extern __shared__ __align__(16) double flow_lds[];
+    __shared__ int s_m, s_bad;
+    __shared__ double s_v[kDNB], s_u[kDNB];
+    if (!d.lm->active) return;
+    const int tid = threadIdx.x, ld = d.ldS, T = ld / kDNB;
+    const int2 t = d.flow_tiles[blockIdx.x];
+    const int I = __builtin_amdgcn_readfirstlane(t.x), J = __builtin_amdgcn_readfirstlane(t.y), self = I * (I + 1) / 2 + J;
+    unsigned* flags = d.flow_flags;
+    flow_factor_tile(d, I, J, epoch, flags + kFlowFlagTile, &flags[kFlowFlagBad], flow_lds, &s_m, &s_bad);
+    double* vec_fwd = d.flow_vec;
+    if (I != J) {
+        const double (*sT)[kPS] = reinterpret_cast<const double (*)[kPS]>(flow_lds + 2 * kDNB * kDStride);
+        // forward: L_IJ y_J
+        if (tid == 0) flow_wait(&flags[kFlowFlagY + J], epoch);
+        __syncthreads();
+        if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)J * kDNB + tid]);
+        __syncthreads();
+        if (tid < kDNB) {
+            double v = 0.0;
+#pragma unroll 8
+            for (int m = 0; m < kDNB; m++) v = fma(sT[tid][m], s_v[m], v);
+            flow_vec_store(&vec_fwd[(size_t)self * kDNB + tid], v);
+        }
+        flow_publish_vec(&flags[kFlowFlagFwd + self], epoch);
+        SO_FLOW_MARK(8);
+        return;
+    }
+    double (*A)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds);
+    double (*X)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds + kDNB * kPS);
     // forward substitution of this block row
     const int first = d.tile_first[J];
     if (tid == 0)
@@ -1223,14 +1268,7 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
             if (d.tile_first[i] <= J) flow_wait(&flags[kFlowFlagTile + i * (i + 1) / 2 + J], epoch);
     __syncthreads();
     flow_acquire();
-    if (has_next) {
-        const double* Ln = d.S + (size_t)(J + 1) * kDNB * ld + (size_t)J * kDNB;
-        for (int i = tid; i < kDNB * (kDNB / 2); i += 256) {
-            const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
-            const double2 v = *reinterpret_cast<const double2*>(Ln + (size_t)r * ld + c);
-            Lsub[r][c] = v.x; Lsub[r][c + 1] = v.y;
-        }
-    }
+    if (has_next) flow_stage_tile(d.S + (size_t)(J + 1) * kDNB * ld + (size_t)J * kDNB, ld, Lsub);
     double z = tid < kDNB ? s_u[tid] : 0.0;
     for (int i = T - 1; i > J; i--) {
         if (d.tile_first[i] > J) continue;
@@ -1270,7 +1308,134 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     }
 }
 
+// ---- the same dataflow for a skyline of any size: resident workgroups take the tiles by ticket ----
+// Column by column, diagonal tile first - an order in which every tile's inputs carry smaller tickets, so a workgroup
+// that waits always waits for a tile somebody resident is working on.  The grid is as large as the residency budget
+// allows (one workgroup per CU); a tile costs its whole left-looking K-loop, so late columns keep every CU on the matrix
+// cores while the early ones race ahead of the critical path (diagonal factor -> L_{J+1,J} -> update, 36 us per panel
+// instead of the multi-launch chain's ~80).  Substitutions: the diagonal workgroup finishes y_J right after its factor
+// (row tiles staged through LDS as the y_k arrive); when the tickets run out the workgroups take the block rows of the
+// backward substitution from the bottom up (Linv_J and the column's tiles staged through LDS, x_i as they arrive).
+// flags: [0, nslots) tiles | 512 y | 512 x | failed-pivot stamp | 2 ticket counters (zeroed by the host before the launch)
+__global__ __launch_bounds__(256) void dense_flow_big_kernel(BaDev d, unsigned epoch, int n_tiles) {
+    extern __shared__ __align__(16) double flow_lds[];
+    __shared__ int s_m, s_bad;
+    __shared__ unsigned s_ticket;
+    __shared__ double s_v[kDNB];
+    if (!d.lm->active) return;
+    const int tid = threadIdx.x, ld = d.ldS, T = ld / kDNB;
+    unsigned* flags = d.flow_flags;
+    unsigned* fY = flags + d.flow_nslots;
+    unsigned* fX = fY + kDenseMaxPanels;
+    unsigned* bad = fX + kDenseMaxPanels;
+    unsigned* counter = bad + 1;
+    double (*A)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds);
+    double (*X)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds + kDNB * kPS);
+    for (;;) {  // factorisation + forward substitution
+        if (tid == 0) s_ticket = atomicAdd(&counter[0], 1u);
+        __syncthreads();
+        // (workgroup-uniform values go through readfirstlane: the branches around the barriers below are then scalar
+        // branches - with per-lane copies the compiler predicates them, and the first version of this kernel hung)
+        const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
+        __syncthreads();  // (everybody has read the ticket before thread 0 takes the next one)
+        if (t >= (unsigned)n_tiles) break;
+        const int2 tile = d.flow_tiles[t];
+        const int I = __builtin_amdgcn_readfirstlane(tile.x), J = __builtin_amdgcn_readfirstlane(tile.y);
+        SO_FLOW_NOTE(10, 1000000 + I * 1000 + J);
+        if (I == J) SO_FLOW_DIAG(3, J);
+        if (I == J + 1) SO_FLOW_DIAG(6, J);
+        flow_factor_tile(d, I, J, epoch, flags, bad, flow_lds, &s_m, &s_bad);
+        SO_FLOW_NOTE(10, 2000000 + I * 1000 + J);
+        if (I == J) SO_FLOW_DIAG(0, J);
+        // forward substitution of block row J by its diagonal workgroup.  Every workgroup walks the same barriers (the
+        // off-diagonal ones with an empty range and nothing to store): no barrier sits under a branch.
+        const bool diag = I == J;
+        const int first = diag ? __builtin_amdgcn_readfirstlane(d.tile_first[J]) : 0, last = diag ? J : 0;
+        if (tid == 0)  // (J, J-1) was formed locally: its copy in HBM comes from workgroup (J, J-1)
+            for (int k = first; k < last; k++) flow_wait(&flags[J * (J + 1) / 2 + k], epoch);
+        __syncthreads();
+        flow_acquire();
+        double v = diag && tid < kDNB ? d.bs[(size_t)J * kDNB + tid] : 0.0;  // b_J: written before the launch
+        for (int k = first; k < last; k++) {
+            flow_stage_tile(d.S + (size_t)J * kDNB * ld + (size_t)k * kDNB, ld, A);
+            SO_FLOW_NOTE(10, 3000000 + J * 1000 + k);
+            if (tid == 0) flow_wait(&fY[k], epoch);
+            __syncthreads();
+            if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)k * kDNB + tid]);
+            __syncthreads();
+            if (tid < kDNB) {
+#pragma unroll 8
+                for (int m = 0; m < kDNB; m++) v = fma(-A[tid][m], s_v[m], v);
+            }
+            __syncthreads();  // A and s_v are free again
+        }
+        if (tid < kDNB) s_v[tid] = v;
+        __syncthreads();
+        if (diag && tid < kDNB) {
+            double y = 0.0;
+            for (int m = 0; m <= tid; m++) y = fma(X[tid][m], s_v[m], y);
+            flow_vec_store(&d.bs[(size_t)J * kDNB + tid], y);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (diag && tid == 0) __hip_atomic_store(&fY[J], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (diag) SO_FLOW_DIAG(1, J);
+    }
+    for (;;) {  // backward substitution, block rows from the bottom up
+        if (tid == 0) s_ticket = atomicAdd(&counter[1], 1u);
+        __syncthreads();
+        const unsigned u = __builtin_amdgcn_readfirstlane(s_ticket);
+        __syncthreads();
+        if (u >= (unsigned)T) break;
+        const int J = T - 1 - (int)u;
+        SO_FLOW_NOTE(10, 4000000 + J);
+        if (tid == 0) {  // the factor of block J, its column below, y_J
+            flow_wait(&flags[J * (J + 1) / 2 + J], epoch);
+            for (int i = J + 1; i < T; i++)
+                if (d.tile_first[i] <= J) flow_wait(&flags[i * (i + 1) / 2 + J], epoch);
+            flow_wait(&fY[J], epoch);
+        }
+        __syncthreads();
+        flow_acquire();
+        flow_stage_tile(d.dense_ws + (size_t)J * kDNB * kDNB, kDNB, X);
+        double z = tid < kDNB ? flow_vec_load(&d.bs[(size_t)J * kDNB + tid]) : 0.0;
+        for (int i = T - 1; i > J; i--) {
+            if (__builtin_amdgcn_readfirstlane(d.tile_first[i]) > J) continue;
+            flow_stage_tile(d.S + (size_t)i * kDNB * ld + (size_t)J * kDNB, ld, A);
+            SO_FLOW_NOTE(10, 5000000 + J * 1000 + i);
+            if (tid == 0) flow_wait(&fX[i], epoch);
+            __syncthreads();
+            if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)i * kDNB + tid]);
+            __syncthreads();
+            if (tid < kDNB) {
+#pragma unroll 8
+                for (int m = 0; m < kDNB; m++) z = fma(-A[m][tid], s_v[m], z);
+            }
+            __syncthreads();
+        }
+        if (tid < kDNB) s_v[tid] = z;
+        __syncthreads();  // (also: X is complete)
+        if (tid < kDNB) {
+            double x = 0.0;
+            for (int m = tid; m < kDNB; m++) x = fma(X[m][tid], s_v[m], x);
+            flow_vec_store(&d.bs[(size_t)J * kDNB + tid], x);
+        }
+        flow_publish_vec(&fX[J], epoch);
+        SO_FLOW_DIAG(2, J);
+        if (J == 0 && tid == 0) {  // every x_J is out before the verdict is written
+            for (int j = 1; j < T; j++) flow_wait(&fX[j], epoch);
+            d.partial[kBaSolveOk] = flow_ready(bad, epoch) ? 0.0 : 1.0;
+        }
+        __syncthreads();
+    }
+    SO_FLOW_NOTE(10, 9000000);
+}
+
 #ifdef SO_FLOW_PROBE
+extern "C" int so_debug_flow_diag(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_diag), sizeof(unsigned long long) * 10 * 512);
+}
 extern "C" int so_debug_flow_marks(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_marks), sizeof(unsigned long long) * 256 * 16);
 }
@@ -1357,12 +1522,27 @@ void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DenseP
     // single-launch dataflow solve: one workgroup per tile of the skyline, column by column (diagonal tile first)
     static const bool no_flow = getenv("SWARMORB_DENSE_NO_FLOW") != nullptr;
     static const int flow_max = getenv("SWARMORB_DENSE_FLOW_MAX_TILES") ? atoi(getenv("SWARMORB_DENSE_FLOW_MAX_TILES")) : kFlowDefaultMaxTiles;
+    static const bool no_flow_big = getenv("SWARMORB_DENSE_NO_FLOW_BIG") != nullptr;
     plan->flow_first_tile = (int)plan->tiles.size();
     plan->flow_n_tiles = 0;
-    if (!no_flow && T <= 21 && plan->nnz_tiles <= std::min(flow_max, kFlowMaxTiles)) {
-        for (int J = 0; J < T; J++)
-            for (int I = J; I < T; I++)
+    plan->flow_big = !(T <= 21 && plan->nnz_tiles <= std::min(flow_max, kFlowMaxTiles));
+    if (!no_flow && !(plan->flow_big && no_flow_big)) {
+        // Column by column, diagonal tile first - an order in which every tile's inputs come before it.  In the ticketed
+        // kernel a tile starts from nothing when it is picked up and has its whole left-looking history to catch up on; for
+        // the diagonal tiles, which carry the critical path (and accumulate two tiles' worth), that is too late: they get
+        // their tickets `lead` columns early and grow with the factorisation.  At most `lead` workgroups wait on tiles
+        // with later tickets; everybody else takes tickets whose inputs all precede them, so the launch cannot lock up
+        // while it has more workgroups than that (ba.cpp only takes this path with at least 128 resident workgroups).
+        // (Early tickets for the tiles next to the diagonal as well - a triangle of them - were measured: no better.)
+        static const int lead_env = getenv("SWARMORB_DENSE_FLOW_DIAG_LEAD") ? atoi(getenv("SWARMORB_DENSE_FLOW_DIAG_LEAD")) : -1;
+        const int lead = plan->flow_big ? (lead_env >= 0 ? std::min(lead_env, kFlowDiagLeadMax) : kFlowDiagLeadDefault) : 0;
+        for (int J = 0; J < T; J++) {
+            if (lead > 0 && J + lead < T) plan->tiles.push_back(make_int2(J + lead, J + lead));
+            for (int I = J; I < T; I++) {
+                if (I == J && lead > 0 && J >= lead) continue;  // went out with column J - lead
                 if (J >= tile_first[I]) plan->tiles.push_back(make_int2(I, J));
+            }
+        }
         plan->flow_n_tiles = (int)plan->tiles.size() - plan->flow_first_tile;
     }
 }
@@ -1407,7 +1587,18 @@ void launch_ba_dense_solve(const BaDev& d, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL(dense_flow_kernel, dim3(P.flow_n_tiles), dim3(256), lds, s, d, ++*d.flow_epoch);
+        if (!P.flow_big) {
+            hipLaunchKernelGGL(dense_flow_kernel, dim3(P.flow_n_tiles), dim3(256), lds, s, d, ++*d.flow_epoch);
+            return;
+        }
+        static bool attr_big[64] = {false};
+        if (dev >= 0 && dev < 64 && !attr_big[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_flow_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_big[dev] = true;
+        }
+        unsigned* counters = d.flow_flags + d.flow_nslots + 2 * kDenseMaxPanels + 1;
+        (void)hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), s);
+        hipLaunchKernelGGL(dense_flow_big_kernel, dim3(d.flow_grid), dim3(256), lds, s, d, ++*d.flow_epoch, P.flow_n_tiles);
         return;
     }
     const int T = P.T, G = P.G;

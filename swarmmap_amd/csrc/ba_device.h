@@ -101,6 +101,8 @@ struct BaDev {
     unsigned* flow_flags;       // kFlowFlagWords, zeroed once when allocated
     double* flow_vec;           // 256 x 96: L_IJ y_J of every off-diagonal tile
     unsigned* flow_epoch;       // host counter of the solver context, grows with every solve (not read by kernels)
+    int flow_nslots;            // ticketed kernel (large skylines): tile flag slots, T (T + 1) / 2
+    int flow_grid;              //                  resident workgroups of its launch
     double* partial;  // reduction partials (chi2 | scale) + flags
     int robust;
     double huber_delta;
@@ -151,6 +153,7 @@ struct DensePlan {
     double flop_dense = 0.0;      // n^3 / 3 + 2 n^2
     long long nnz_tiles = 0;      // tiles inside the envelope (lower triangle incl. diagonal)
     int flow_first_tile = 0, flow_n_tiles = 0;  // dataflow solve: its tile list inside `tiles` (0 tiles: not eligible)
+    bool flow_big = false;        // more tiles than one launch can keep resident one per workgroup: the ticketed kernel
 };
 void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DensePlan* plan);
 bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solves (4..29 free keyframes: tiles in LDS; 30..43: tiles in registers); false if neither applies

@@ -122,7 +122,7 @@ def test_single_launch_and_multi_launch_solves_agree():
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         out = {}
-        for tag, env in (("flow", {}), ("chain", {"SWARMORB_DENSE_NO_FLOW": "1"})):
+        for tag, env in (("flow", {}), ("chain", {"SWARMORB_DENSE_NO_FLOW": "1"})):  # (48, 96, 130 keyframes: 3, 6, 9 panels)
             e = dict(os.environ, **env)
             res = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, tag)], env=e, capture_output=True, text=True, timeout=300)
             assert res.returncode == 0, res.stderr[-2000:]
@@ -135,6 +135,41 @@ def test_single_launch_and_multi_launch_solves_agree():
             Tf, Tc = np.load(os.path.join(tmp, "flow_%d_T.npy" % nf)), np.load(os.path.join(tmp, "chain_%d_T.npy" % nf))
             Xf, Xc = np.load(os.path.join(tmp, "flow_%d_X.npy" % nf)), np.load(os.path.join(tmp, "chain_%d_X.npy" % nf))
             assert np.abs(Tf - Tc).max() <= 2e-6 and np.abs(Xf - Xc).max() <= 2e-5
+
+
+def test_ticketed_solve_agrees_with_the_chain_of_launches():
+    """Skylines too large for a workgroup per tile (more than 21 panels or 231 tiles) go to dense_flow_big_kernel: resident workgroups
+    take the tiles by ticket, diagonal tiles a few columns early.  A 450-keyframe map (29 panels) through it and through
+    the chain-of-launches solver, each in its own process (the switch is read once): same LM decisions, estimates equal to
+    rounding.  GBA-2 / GBA-2r / the 2560-keyframe map of the property tests below run through it as well."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import swarmmap_amd\nfrom swarmmap_amd import synth\n"
+        "o = swarmmap_amd.Optimizer()\n"
+        "p = synth.make_ba_problem(11, 450, 1, 30000, max_obs='auto')\n"
+        "r = o.BundleAdjustment(p, nIterations=6, bRobust=True)\n"
+        "np.save(sys.argv[1] + '_T.npy', r['Tcw']); np.save(sys.argv[1] + '_X.npy', r['Xw'])\n"
+        "print('R', r['info']['solver_path'], r['info']['lm_trials'], int(r['info']['nnz_tiles']), repr(r['info']['chi2_final']))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        out = {}
+        for tag, env in (("ticket", {}), ("chain", {"SWARMORB_DENSE_NO_FLOW": "1"})):
+            res = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, tag)], env=dict(os.environ, **env),
+                                 capture_output=True, text=True, timeout=300)
+            assert res.returncode == 0, res.stderr[-2000:]
+            out[tag] = [ln.split() for ln in res.stdout.splitlines() if ln.startswith("R ")][0]
+        # 29 panels: more than the 21 the one-tile-per-workgroup kernel takes, and at least the 128 tiles the ticketed one asks for
+        assert out["ticket"][1] == "2" and out["chain"][1] == "1" and int(out["ticket"][3]) >= 128
+        assert abs(int(out["ticket"][2]) - int(out["chain"][2])) <= 2
+        assert float(out["ticket"][4]) == pytest.approx(float(out["chain"][4]), rel=1e-9)
+        Tt, Tc = np.load(os.path.join(tmp, "ticket_T.npy")), np.load(os.path.join(tmp, "chain_T.npy"))
+        Xt, Xc = np.load(os.path.join(tmp, "ticket_X.npy")), np.load(os.path.join(tmp, "chain_X.npy"))
+        assert np.abs(Tt - Tc).max() <= 2e-6 and np.abs(Xt - Xc).max() <= 2e-5
 
 
 def test_two_solver_contexts_solve_mid_size_windows_concurrently(opt):
