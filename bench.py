@@ -368,7 +368,7 @@ def gba_records(dev, cases):
         r = o.BundleAdjustment(p, nIterations=10, bRobust=True)
         wall = time.perf_counter() - t0
         inf = r["info"]
-        n = 6 * int((p["fixed"] == 0).sum())
+        n = 6 * int(inf["n_free_keyframes"])  # keyframes the solver gave a hessian index (not fixed AND observed)
         flop = n ** 3 / 3.0 + 2.0 * n ** 2
         ms = inf["solve_ms"] / max(inf["n_solves"], 1)
         tf = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

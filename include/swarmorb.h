@@ -551,7 +551,7 @@ typedef struct {
      * Cholesky as a chain of launches, 2 blocked Cholesky as ONE launch of tile workgroups (up to 231 skyline tiles, when
      * the device can keep them all resident) */
     int32_t solver_path;
-    int32_t reserved;
+    int32_t n_free_keyframes; /* keyframes that got a hessian index: not fixed and observed by at least one edge */
 } so_ba_info;
 
 int so_ba_create(int device, so_ba** out);

@@ -768,6 +768,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         inf.nnz_tiles = (double)r.d.plan->nnz_tiles;
         inf.solver_path = r.d.flow_tiles ? 2 : 1;
     }
+    inf.n_free_keyframes = r.n_free;
     inf.wall_ms = (float)(now_ms() - t_begin);
     if (trace)
         fprintf(stderr, "[ba] stage %.3f upload+alloc %.3f opt1 %.3f (%d it) opt2 %.3f (%d it) finish %.3f | trials %d blocks %d\n",

@@ -30,12 +30,12 @@ def main():
         r = o.BundleAdjustment(p, nIterations=10, bRobust=True)
         wall = time.perf_counter() - t0
         inf = r["info"]
-        n = 6 * int((p["fixed"] == 0).sum())
+        n = 6 * int(inf["n_free_keyframes"])  # keyframes the solver gave a hessian index (not fixed AND observed)
         flop = n ** 3 / 3.0 + 2.0 * n ** 2
         sflop = inf["solve_gflop_structural"] * 1e9
         ms = inf["solve_ms"] / max(inf["n_solves"], 1)
         T = (n + 95) // 96
-        print(json.dumps({"case": name, "free_keyframes": n // 6, "points": int(len(p["Xw"])), "edges": int(len(p["edge_pose"])),
+        print(json.dumps({"case": name, "free_keyframes": n // 6, "keyframes_not_fixed": int((p["fixed"] == 0).sum()), "points": int(len(p["Xw"])), "edges": int(len(p["edge_pose"])),
                           "wall_ms": wall * 1e3, "gpu_ms": inf["gpu_ms"], "lm_trials": inf["lm_trials"],
                           "chi2_initial": inf["chi2_initial"], "chi2_final": inf["chi2_final"],
                           "solve": {"n": n, "ms_per_solve": ms, "tiles_in_skyline": inf["nnz_tiles"], "tiles_dense": T * (T + 1) // 2,
