@@ -71,7 +71,7 @@ int flow_resident_budget(int device) {
     hipDeviceProp_t prop;
     int budget = -1;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor >= (size_t)156 * 1024)
-        budget = std::max(prop.multiProcessorCount - 16, 0);
+        budget = std::max(prop.multiProcessorCount - 32, 0);  // 32 CUs stay with the tracking threads (quadtree alone wants 8 whole CUs)
     if (budget <= 0) budget = -1;
     cached[device].store(budget);
     return budget > 0 ? budget : 0;
