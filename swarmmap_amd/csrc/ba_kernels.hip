@@ -2527,10 +2527,30 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
     }
     SO_POSE_TICK(6);
     SO_POSE_TICK_FLUSH;
+    // results: the outlier flags meet in LDS and wave 0 writes everything (flags as dwords, pose, counters), so that ONE
+    // wave pays ONE system-scope fence in front of the completion word instead of every wave one plus thread 0 a second
+    __shared__ uint32_t s_outl[THREADS * EPT / 4];
+    uint8_t* s_outl8 = reinterpret_cast<uint8_t*>(s_outl);
 #pragma unroll
     for (int k = 0; k < EPT; k++)
-        if (live[k]) a.outlier[tid + k * THREADS] = outl[k] ? 1 : 0;
-    pose_publish(a, cur, nbad_total, its_total, trials_total);
+        if (live[k]) s_outl8[tid + k * THREADS] = outl[k] ? 1 : 0;
+    __syncthreads();
+    if (tid < 64) {
+        const int full = n >> 2;  // a.outlier is 16-byte aligned in every caller (offset 80 of a 64-byte aligned block)
+        uint32_t* out32 = reinterpret_cast<uint32_t*>(a.outlier);
+        for (int i = tid; i < full; i += 64) out32[i] = s_outl[i];
+        if (tid < (n & 3)) a.outlier[4 * full + tid] = s_outl8[4 * full + tid];
+        if (tid == 0) {
+            *a.pose_out = cur;
+            a.info[0] = nbad_total;
+            a.info[1] = its_total;
+            a.info[2] = trials_total;
+        }
+        if (a.done_seq) {
+            __threadfence_system();  // (needed: see pose_publish)
+            if (tid == 0) __hip_atomic_store(&a.info[3], a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 template <int THREADS, int EPT>
