@@ -331,8 +331,10 @@ def lba_records(dev):
     Optimizer::LocalBundleAdjustment through the C ABI (median of 5 after 2 warm-up calls)."""
     o = swarmmap_amd.Optimizer(device=dev)
     out = {}
-    for name in ("LBA-S", "LBA-M", "LBA-L"):
-        wnd = synth.make_ba_case(name)
+    for name in ("LBA-S", "LBA-M", "LBA-L", "LBA-64"):
+        # LBA-64: a 64-keyframe window with LBA-L's proportions (150 points and 1.5 fixed keyframes per free one): beyond the
+        # single-workgroup solvers, the size the single-launch tile-dataflow solve was built for (DESIGN.md 5)
+        wnd = synth.make_ba_problem(0, 64, 96, 9600, max_obs="auto") if name == "LBA-64" else synth.make_ba_case(name)
         for _ in range(2):
             o.LocalBundleAdjustment(wnd)
         ts, infos = [], []
@@ -342,15 +344,16 @@ def lba_records(dev):
             ts.append(time.perf_counter() - t0)
             infos.append(r["info"])
         inf = infos[int(np.argsort(ts)[len(ts) // 2])]
-        n = 6 * int((wnd["fixed"] == 0).sum())
+        n = 6 * int(inf["n_free_keyframes"])
         flop = n ** 3 / 3.0 + 2.0 * n ** 2
         ms = inf["solve_ms"] / max(inf["n_solves"], 1)
         tf = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        out[name] = {"free_keyframes": n // 6, "fixed_keyframes": int((wnd["fixed"] != 0).sum()), "points": int(len(wnd["Xw"])),
+        out[name] = {"free_keyframes": n // 6, "solver_path": int(inf["solver_path"]), "fixed_keyframes": int((wnd["fixed"] != 0).sum()), "points": int(len(wnd["Xw"])),
                      "edges": int(len(wnd["edge_pose"])), "wall_ms": float(np.median(ts)) * 1e3, "gpu_ms": inf["gpu_ms"],
                      "lm_trials": inf["lm_trials"], "chi2_final": inf["chi2_final"],
                      "solve": {"n": n, "ms_per_solve": ms, "algorithmic_flop": flop, "achieved_tflops": tf,
-                               "peak_tflops": FP64_PEAK_TF, "frac": tf / FP64_PEAK_TF, "bound": "mfma (latency-bound: one workgroup)"}}
+                               "peak_tflops": FP64_PEAK_TF, "frac": tf / FP64_PEAK_TF,
+                               "bound": "mfma (latency-bound: one workgroup)" if inf["solver_path"] == 0 else "mfma (latency-bound: a chain of 96-column panels)"}}
     o.close()
     return out
 

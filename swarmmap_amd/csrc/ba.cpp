@@ -380,7 +380,12 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     struct FlowLease {  // the context's share of the residency budget goes back on every way out
         so_ba* b;
         ~FlowLease() {
-            if (b->flow_reserved > 0) g_flow_tiles.fetch_sub(b->flow_reserved);
+            if (b->flow_reserved > 0) {
+                // the CUs go back only when this context's launches are over: a no-op on the normal way out (the results
+                // have been copied back), a real wait on an error return
+                if (b->stream) (void)hipStreamSynchronize(b->stream);
+                g_flow_tiles.fetch_sub(b->flow_reserved);
+            }
             b->flow_reserved = 0;
         }
     } flow_lease{b};

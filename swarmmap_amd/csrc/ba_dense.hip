@@ -1071,7 +1071,10 @@ __device__ __forceinline__ void flow_factor_tile(const BaDev& d, int I, int J, u
     const double* Ps = own_sub ? d.S + (size_t)(J - 1) * kDNB * ld : nullptr;
     d4 tot2[3][3];
     if (own_sub) {
-        const double* C2 = d.S + (size_t)J * kDNB * ld + (size_t)(J - 1) * kDNB;
+        // S_{J,J-1} is read from its mirror image in the UPPER triangle (the Schur gather writes both, the factorisation
+        // only ever overwrites lower tiles): workgroup (J, J-1) replaces the lower copy by L_{J,J-1} in place, possibly
+        // before this workgroup gets to run - reading it there was a race that showed as one wrong solve in ~15 test runs
+        const double* C2t = d.S + (size_t)(J - 1) * kDNB * ld + (size_t)J * kDNB;  // tile (J-1, J) = S_{J,J-1}^T
 #pragma unroll
         for (int rt = 0; rt < 3; rt++)
 #pragma unroll
@@ -1079,7 +1082,7 @@ __device__ __forceinline__ void flow_factor_tile(const BaDev& d, int I, int J, u
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
-                    tot2[rt][ct][reg] = -C2[(size_t)r * ld + c];
+                    tot2[rt][ct][reg] = -C2t[(size_t)c * ld + r];
                 }
     }
     for (int k = lo; k < k_end;) {
