@@ -34,4 +34,27 @@ for pair in (("w64", "w128"), ("w128", "GBA-1r"), ("GBA-2r", "w64")):
     [t.start() for t in ths]
     [t.join() for t in ths]
     print("concurrent", pair, "mismatches", len(errs), flush=True)
+# the same solves while another stream keeps the CUs busy (workgroups of the dataflow launches then start late and in
+# odd orders - the condition under which a race between tiles would show)
+import torch
+stop = []
+def noise():
+    x = torch.randn(6144, 6144, device="cuda")
+    while not stop:
+        y = x @ x
+        torch.cuda.synchronize()
+nt = threading.Thread(target=noise)
+nt.start()
+try:
+    for name, p in cases.items():
+        local = name.startswith("w")
+        for k in range(rounds if local else max(3, rounds // 4)):
+            r = o.LocalBundleAdjustment(p) if local else o.BundleAdjustment(p, nIterations=4, bRobust=True)
+            if (r["Tcw"].tobytes(), r["Xw"].tobytes()) != ref[name][:2]:
+                errs.append(("noise", name, k, r["info"]["solver_path"]))
+finally:
+    stop.append(1)
+    nt.join()
+print("under load: mismatches", len(errs), flush=True)
 print("done %.1f s" % (time.time() - t0), "errors", errs[:5], flush=True)
+sys.exit(1 if errs else 0)
