@@ -308,6 +308,7 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
         "keypoints_per_frame": st["n_kp"] / steps, "m2_matches_per_frame": st["n_m2"] / steps,
         "m1_matches_per_frame": st["n_m1"] / steps, "inliers_per_frame": st["n_inliers"] / steps,
         "local_map_points_per_frame": st["n_local"] / steps, "in_view_per_frame": st["n_in_view"] / steps,
+        "search_launches_per_frame": st.get("n_reruns", 0.0) / steps, "wide_window_m2_per_frame": st.get("n_wide_m2", 0.0) / steps,
         "keyframes": st["n_keyframes"], "map_points_at_end": st["n_map_points"],
         "lba_windows": st["n_lba"],
         "host_ms_per_frame": {"collect_and_submit": st["extract_ms"] / steps, "match": (st["m2_ms"] + st["m1_ms"]) / steps,

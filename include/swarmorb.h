@@ -266,6 +266,10 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
 int so_distinctive_descriptors(so_matcher* m, int32_t n_points, const int32_t* offsets, const uint8_t* descriptors,
                                int32_t* best_idx, int32_t* best_median);
 
+/* Allocates the staging of so_track_search_local_map / _last_frame for up to n_queries map points now instead of on
+ * demand (a local map that grows keyframe by keyframe otherwise pays a pinned re-allocation, 0.1-0.3 ms, every time it
+ * outgrows the slack).  Optional; the searches still grow the buffers when a call needs more. */
+int so_matcher_reserve(so_matcher* m, int32_t n_queries);
 /* HIP-event time (ms) of the kernels of the last matcher call on the matcher's stream (0 while the events are switched
  * off: so_matcher_set_profiling(m, 0) saves the two event records per search, ~2 us of host time each and a
  * timestamp packet on the queue; on by default). */

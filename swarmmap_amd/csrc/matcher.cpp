@@ -569,6 +569,24 @@ int so_matcher_reuse_frame(so_matcher* m) {
     return SO_OK;
 }
 
+// Staging for tracking searches of up to n_queries map points (K-lists, in-view flags, slots, gates) allocated now:
+// pinned allocations cost 0.1-0.3 ms each, and a local map that grows keyframe by keyframe would otherwise pay one
+// every time it outgrows the 1.5x slack (the first seconds of a sequence: +25-50 us per frame).
+int so_matcher_reserve(so_matcher* m, int32_t n_queries) {
+    if (!m || n_queries < 0) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    constexpr int K = 8;
+    const size_t nq = (size_t)n_queries;
+    const size_t keys_bytes = align256(sizeof(uint32_t) * nq * K);
+    const size_t view_off = align256(keys_bytes + sizeof(int32_t) * nq), c8_off = align256(view_off + nq);
+    int rc;
+    if ((rc = m->h_out.ensure(c8_off + nq))) return rc;
+    // slots + skip bytes behind the frame block (whatever its size turns out to be: 256 KB covers 4096 keypoints)
+    const size_t in_bytes = align256((size_t)256 * 1024 + sizeof(int32_t) * nq) + align256(nq) + 512;
+    if (in_bytes > m->h_in.cap && (rc = m->h_in.ensure_keep(in_bytes, m->h_in.cap))) return rc;
+    return SO_OK;
+}
+
 int so_matcher_last_stats(so_matcher* m, double* stats4) {
     if (!m || !stats4) return SO_ERR_INVALID_ARG;
     for (int i = 0; i < 4; i++) stats4[i] = m->stat[i];

@@ -167,7 +167,7 @@ struct so_replay {
     // the frame being tracked (stage functions below)
     struct Step {
         double t0 = 0, t1 = 0, tm2 = 0, tp1 = 0, tm1 = 0, tp2 = 0, tp3 = 0, tmap = 0;
-        double match_kernel = 0, pose_kernel = 0, pose_trials = 0, pose_points = 0, mstat[4] = {0, 0, 0, 0};
+        double match_kernel = 0, pose_kernel = 0, pose_trials = 0, pose_points = 0, mstat[4] = {0, 0, 0, 0}, reruns = 0, wide_m2 = 0;
         int pose_calls = 0, pose_timed_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0, hcur = 0, first_slot = 0;
         int32_t n_in = 0;
         bool first = false, m2_submitted = false, timed_kernels = true, next_submitted = false;
@@ -188,7 +188,8 @@ enum {  // indices of so_replay::stat, mirrored in bench.py
     kSteps = 0, kExtractMs, kM2Ms, kPose1Ms, kM1Ms, kPose2Ms, kPose3Ms, kMapMs, kSubmitWaitMs, kKp, kM2, kM1, kInliers,
     kMatchKernelMs, kPoseKernelMs, kPoseTrials, kPoseCalls, kPosePoints, kLbaWindows, kLbaBusyMs, kLbaGpuMs, kLbaSolveMs,
     kLbaSolves, kLocalPoints, kInView, kKeyframes, kMapPoints, kM2EnqMs, kM2WaitMs, kM1EnqMs, kM1WaitMs, kPoseTimedCalls,
-    kTimedFrames, kStage0 /* 11 extractor stages */
+    kTimedFrames, kStage0 /* 11 extractor stages */, kReruns = kStage0 + SO_EXTRACTOR_N_STAGES /* search launches: 2 per frame + exact re-runs of exhausted K-lists */,
+    kWideM2 /* motion-model searches repeated with the wider window */
 };
 
 void mapper_loop(so_replay* r) {
@@ -336,6 +337,20 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
     so_extractor_tables(r->ex, r->scale, inv, s2, r->inv_sigma2, npl);
     r->log_sf = (float)std::log((double)1.2f);  // log(mfScaleFactor), MapPoint.cc:478 (float scale factor)
     r->cap = so_extractor_capacity(r->ex);
+    {   // sized once, like a tracker sizes its buffers for the local map it allows: 12 keyframes' worth of new points,
+        // or 32 k map points when the whole map is searched
+        const int reserve_q = local_keyframes > 0 ? (local_keyframes + 1) * r->cap : 32768;
+        if (so_matcher_reserve(r->matcher, reserve_q) != SO_OK) {
+            delete r;
+            return SO_ERR_HIP;
+        }
+        r->skip.reserve((size_t)reserve_q);
+        r->new_desc.reserve((size_t)reserve_q);
+        r->last_slot.reserve((size_t)r->cap);
+        r->excluded.reserve((size_t)r->cap);
+        r->k2l.reserve((size_t)r->cap);
+        r->k2m.reserve((size_t)r->cap);
+    }
     for (auto& f : r->fh) {
         f.kps.resize((size_t)r->cap);
         f.xy_un.resize((size_t)r->cap * 2);
@@ -510,7 +525,9 @@ int step_m2_wait(so_replay* r) {
     S.match_kernel += kms;
     so_matcher_last_stats(r->matcher, ms4);
     S.mstat[0] += ms4[0]; S.mstat[1] += ms4[1];
+    S.reruns += ms4[2];
     if (nm < 20) {  // Tracking.cc:1020-1024: wider window
+        S.wide_m2 += 1;
         if (so_track_search_last_frame(r->matcher, r->fr[S.hcur], nullptr, r->fr[(S.hcur + 2) % 3], r->map, S.Tp,
                                        r->last_slot.data(), nullptr, 30.0f, 1, r->k2l.data(), &nm) != SO_OK)
             return fail(r, "so_track_search_last_frame");
@@ -627,6 +644,7 @@ int step_m1_wait(so_replay* r) {
     S.match_kernel += kms;
     so_matcher_last_stats(r->matcher, ms4);
     S.mstat[2] += ms4[0]; S.mstat[3] += ms4[1];
+    S.reruns += ms4[2];
     S.nm1 = nmm;
     for (int i = 0; i < S.n_local; i++) S.n_view += view[(size_t)i];
     for (int k = 0; k < n; k++)
@@ -707,6 +725,7 @@ void step_end(so_replay* r, int t, int timed) {
         st[kTimedFrames] += S.timed_kernels ? 1 : 0; st[kLocalPoints] += S.n_local; st[kInView] += S.n_view;
         st[kKeyframes] += S.keyframe; st[kMapPoints] = (double)(r->mp_X.size() / 3);
         st[kM2EnqMs] += S.mstat[0]; st[kM2WaitMs] += S.mstat[1]; st[kM1EnqMs] += S.mstat[2]; st[kM1WaitMs] += S.mstat[3];
+        st[kReruns] += S.reruns; st[kWideM2] += S.wide_m2;
         float prof[SO_EXTRACTOR_N_STAGES];
         if (so_extractor_get_profile(r->ex, prof) == SO_OK)
             for (int i = 0; i < SO_EXTRACTOR_N_STAGES; i++) st[kStage0 + i] += prof[i];

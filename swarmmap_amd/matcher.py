@@ -88,6 +88,11 @@ class ORBmatcher:
                            np.frombuffer(np.ascontiguousarray(b, np.uint8), np.uint8))
         return int(np.unpackbits(x).sum())
 
+    def reserve(self, n_queries):
+        """so_matcher_reserve: staging of the tracking searches for up to n_queries map points, allocated now."""
+        self._lib.so_matcher_reserve.argtypes = [C.c_void_p, C.c_int32]
+        _lib.check(self._lib.so_matcher_reserve(self._h, int(n_queries)))
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         _lib.check(self._lib.so_matcher_last_kernel_ms(self._h, C.byref(ms)))

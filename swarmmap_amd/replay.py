@@ -110,6 +110,7 @@ class Replay:
         d = dict(zip(STAT, a[:len(STAT)].tolist()))
         from .extractor import STAGES
         d["stages"] = dict(zip(STAGES, a[len(STAT):len(STAT) + len(STAGES)].tolist()))
+        d["n_reruns"], d["n_wide_m2"] = a[len(STAT) + len(STAGES)], a[len(STAT) + len(STAGES) + 1]
         return d
 
     def log(self):
