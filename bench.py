@@ -151,7 +151,8 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
         rp.finish()
         results.append((rp.stats(), rp.candidates_total(), rp.log()))
         rp.close()
-    stats = {k: sum(r[0][k] for r in results) / agents for k in results[0][0] if k != "stages"}
+    stats = {k: sum(r[0][k] for r in results) / agents for k in results[0][0] if k not in ("stages", "frame_ms")}
+    stats["frame_ms"] = np.concatenate([np.asarray(r[0]["frame_ms"])[-steps:] for r in results])
     stats.update({"n_xchg": 0, "xchg_ms": 0.0})
     return dt, stats, results[0][1], keep[0][1], results[0][2]
 
@@ -248,7 +249,8 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
             th.join()
         if errors:
             raise errors[0]
-    stats = {k: sum(r[0][k] for r in results) / A for k in results[0][0] if k != "stages"}  # per-agent averages
+    stats = {k: sum(r[0][k] for r in results) / A for k in results[0][0] if k not in ("stages", "frame_ms")}  # per-agent averages
+    stats["frame_ms"] = np.concatenate([np.asarray(r[0]["frame_ms"])[-steps:] for r in results])  # timed frames of every agent
     stats.update(acc_x)
     return dt, stats, results[0][1], frame_sets[0][1], results[0][2]
 
@@ -308,6 +310,8 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
         "keypoints_per_frame": st["n_kp"] / steps, "m2_matches_per_frame": st["n_m2"] / steps,
         "m1_matches_per_frame": st["n_m1"] / steps, "inliers_per_frame": st["n_inliers"] / steps,
         "local_map_points_per_frame": st["n_local"] / steps, "in_view_per_frame": st["n_in_view"] / steps,
+        "frame_ms_percentiles": (lambda f: {k: float(np.percentile(f, q)) for k, q in (("p10", 10), ("p50", 50), ("p90", 90), ("p99", 99), ("max", 100))}
+                                 if len(f) else {})(np.asarray(st.get("frame_ms", []), np.float64)),
         "search_launches_per_frame": st.get("n_reruns", 0.0) / steps, "wide_window_m2_per_frame": st.get("n_wide_m2", 0.0) / steps,
         "keyframes": st["n_keyframes"], "map_points_at_end": st["n_map_points"],
         "lba_windows": st["n_lba"],

@@ -19,6 +19,7 @@
 // from back-projection onto the known plane).  swarmmap_amd/minitrack.py is the same loop in Python; tests compare
 // this one, frame by frame, with that loop run over the CPU oracle.
 // Built by csrc/Makefile into libswarmorb_replay.so with g++.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -178,6 +179,7 @@ struct so_replay {
     float K4[4] = {0, 0, 0, 0};
     // statistics (timed steps only)
     double stat[48] = {0};
+    std::vector<float> frame_ms;
     std::vector<float> ba_Tcw, ba_Xw;
     std::vector<uint8_t> ba_out;
 };
@@ -707,6 +709,7 @@ void step_end(so_replay* r, int t, int timed) {
     }
     r->n_tracked++;
     const double t3 = now_ms();
+    r->frame_ms.push_back((float)(t3 - S.t0));
     if (t % r->lba_every == 0 && !r->window.epose.empty()) {
         std::unique_lock<std::mutex> lk(r->mu);
         r->cv.wait(lk, [r] { return r->queue.size() < 3; });  // the running window + two waiting
@@ -863,6 +866,13 @@ int so_replay_stats(so_replay* r, double* out48) {
 }
 
 // Per-frame log of everything tracked so far: poses (12 floats per frame), M2 / M1 match counts, inliers, map size.
+// wall time of every tracked frame of the log (ms, step_begin to step_end), for looking at the spread
+int so_replay_frame_ms(so_replay* r, float* out, int cap) {
+    if (!r || !out) return SO_ERR_INVALID_ARG;
+    const int n = std::min(cap, (int)r->frame_ms.size());
+    memcpy(out, r->frame_ms.data(), sizeof(float) * (size_t)n);
+    return n;
+}
 int so_replay_log_size(so_replay* r) { return r ? (int)r->n_m2.size() : 0; }
 int so_replay_log(so_replay* r, float* poses12, int32_t* n_m2, int32_t* n_m1, int32_t* n_inliers, int32_t* n_map) {
     if (!r) return SO_ERR_INVALID_ARG;

@@ -111,6 +111,11 @@ class Replay:
         from .extractor import STAGES
         d["stages"] = dict(zip(STAGES, a[len(STAT):len(STAT) + len(STAGES)].tolist()))
         d["n_reruns"], d["n_wide_m2"] = a[len(STAT) + len(STAGES)], a[len(STAT) + len(STAGES) + 1]
+        n = self.lib.so_replay_log_size(self.h)
+        ms = np.zeros(max(n, 1), np.float32)
+        self.lib.so_replay_frame_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        got = self.lib.so_replay_frame_ms(self.h, self._p(ms), n)
+        d["frame_ms"] = ms[:max(got, 0)]  # wall time of every tracked frame so far (warm-up frames first)
         return d
 
     def log(self):

@@ -87,5 +87,5 @@ def test_replay_library_loads_and_exports():
     lib = ctypes.CDLL(os.path.join(root, "swarmmap_amd", "libswarmorb_replay.so"))
     for name in ("so_replay_create", "so_replay_destroy", "so_replay_set_frames", "so_replay_set_window",
                  "so_replay_preallocate", "so_replay_prime", "so_replay_run", "so_replay_drain", "so_replay_finish",
-                 "so_replay_stats", "so_replay_log", "so_replay_log_size", "so_replay_last_frame", "so_replay_last_dframe"):
+                 "so_replay_stats", "so_replay_log", "so_replay_log_size", "so_replay_frame_ms", "so_replay_last_frame", "so_replay_last_dframe"):
         assert hasattr(lib, name), name
