@@ -210,6 +210,7 @@ struct Run {
     int n_free = 0, n_active_edges = 0;
     int nb_err = 1, nb_upd = 1;
     int blocks_enqueued = 0;  // trial blocks of this call so far (indexes the solve-event pool)
+    int n_reordered = 0;  // keyframes moved to the separator block at the end of the elimination order
     const volatile uint8_t* stop = nullptr;
     bool terminate() const { return stop && *stop; }
 };
@@ -474,6 +475,101 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
             h_free[h++] = i;
         }
     }
+    // Large maps: elimination order.  g2o numbers the free keyframes by mnId and leaves the ordering of the reduced
+    // system to the sparse solver (AMD inside SimplicialLDLT, linear_solver_eigen.h:94-124); here the order decides the
+    // block skyline.  A merged multi-agent map in natural order (agent by agent) is banded per agent - until a landmark
+    // seen from two distant places (trajectories crossing, a loop) stretches the row envelope of every later keyframe
+    // that sees it across everything in between, and the factorisation becomes one chain over all panels.  Moving those
+    // keyframes to the end (a separator block, the last rows of an arrowhead) leaves every agent's band on its own and
+    // lets the dataflow solve run their chains side by side: of every landmark whose observers span more than kLinkSpan
+    // keyframes, the observers beyond that span from the first one go to the back; both parts keep their natural order.
+    // A map in which everything sees everything is unaffected (its keyframes all move, i.e. none does).
+    static const bool no_reorder = getenv("SWARMORB_BA_NO_REORDER") != nullptr;
+    constexpr int kReorderMinFree = 9 * 16, kLinkSpan = 48;
+    if (nf >= kReorderMinFree && !no_reorder) {
+        std::vector<uint8_t> back((size_t)nf, 0);
+        std::vector<int> eh;  // hessian index of the keyframe of every (landmark-sorted) edge, filled for the full walks
+        auto eh_at = [&](int k) { return eh.empty() ? h_hidx[p->edge_pose[perm[(size_t)k]]] : eh[(size_t)k]; };
+        auto mark_far = [&](int stride) {  // every stride-th landmark
+            for (int l = 0; l < nL; l += stride) {
+                int lo = INT_MAX;
+                for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
+                    const int h = eh_at(k);
+                    if (h >= 0 && h < lo) lo = h;
+                }
+                if (lo == INT_MAX) continue;
+                for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
+                    const int h = eh_at(k);
+                    if (h >= 0 && h - lo > kLinkSpan) back[(size_t)h] = 1;
+                }
+            }
+            int n = 0;
+            for (int h = 0; h < nf; h++) n += back[(size_t)h];
+            return n;
+        };
+        // a sample of the landmarks first: a map in which everything sees everything (most keyframes far from some
+        // co-observer) keeps its natural order and is spared the full walks over the observations
+        int n_far = mark_far(16);
+        const bool dense_map = 10 * n_far >= 7 * nf;
+        if (dense_map) std::fill(back.begin(), back.end(), 0);
+        else {
+            eh.resize((size_t)nE);
+            for (int k = 0; k < nE; k++) eh[(size_t)k] = h_hidx[p->edge_pose[perm[(size_t)k]]];
+            n_far = mark_far(1);
+        }
+        // The bands that remain must also start on tile boundaries (16 keyframes): a tile that holds the end of one
+        // agent's band and the start of the next couples their chains again.  Where no landmark bridges two neighbours
+        // of the remaining order (a band ends), the last keyframes of the band - fewer than 16 - follow to the back so
+        // that the next band starts a new tile.
+        if (!dense_map && n_far > 0 && 10 * n_far < 7 * nf) {
+            std::vector<int> pos((size_t)nf, -1);  // position in the remaining order
+            int ni = 0;
+            for (int h = 0; h < nf; h++)
+                if (!back[(size_t)h]) pos[(size_t)h] = ni++;
+            std::vector<int> bridge((size_t)ni + 2, 0);  // difference array: a landmark seen from positions lo..hi bridges lo+1..hi
+            for (int l = 0; l < nL; l++) {
+                int lo = INT_MAX, hi = -1;
+                for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
+                    const int h = eh_at(k);
+                    if (h < 0 || back[(size_t)h]) continue;
+                    lo = std::min(lo, pos[(size_t)h]);
+                    hi = std::max(hi, pos[(size_t)h]);
+                }
+                if (hi > lo) {
+                    bridge[(size_t)lo + 1]++;
+                    bridge[(size_t)hi + 1]--;
+                }
+            }
+            std::vector<int> at((size_t)ni, 0);  // keyframe (natural hidx) at each remaining position
+            for (int h = 0; h < nf; h++)
+                if (pos[(size_t)h] >= 0) at[(size_t)pos[(size_t)h]] = h;
+            int run = 0, kept = 0;  // bridges open at the current position; keyframes kept so far
+            for (int q = 0; q < ni; q++) {
+                run += bridge[(size_t)q];
+                if (q > 0 && run == 0) {  // nothing connects position q to anything before it: a band ended at q - 1
+                    const int cut = kept % 16;
+                    for (int c = 1; c <= cut; c++) back[(size_t)at[(size_t)(q - c)]] = 1;  // (cut < band length or the band goes whole)
+                    kept -= cut;
+                }
+                kept++;
+            }
+        }
+        if (!dense_map && 10 * n_far >= 7 * nf) std::fill(back.begin(), back.end(), 0);
+        int n_back = 0;
+        for (int h = 0; h < nf; h++) n_back += back[(size_t)h];
+        if (n_back > 0 && n_back < nf) {
+            std::vector<int> old_free(h_free, h_free + nf);
+            int h = 0;
+            for (int pass = 0; pass < 2; pass++)
+                for (int o = 0; o < nf; o++)
+                    if ((int)back[(size_t)o] == pass) {
+                        const int i = old_free[(size_t)o];
+                        h_hidx[i] = h;
+                        h_free[h++] = i;
+                    }
+        }
+        r.n_reordered = n_back;
+    }
     for (int i = 0; i <= nf; i++) h_poseoff[i] = 0;
     {
         std::vector<int> seen((size_t)nP, -1);  // the edge table holds one edge per (landmark, keyframe)
@@ -715,6 +811,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     if (pairs_path) launch_ba_build_pairs(d, b->d_scan_tmp.p, scan_bytes, s);
 
     const double t_uploaded = now_ms();
+    if (trace) fprintf(stderr, "[ba] %d free keyframes, %d moved to the separator block\n", nf, r.n_reordered);
     if (trace) fprintf(stderr, "[ba] dense setup done at +%.3f, launches done at +%.3f\n", t_dense_setup - t_staged, t_uploaded - t_staged);
     SO_HIP(hipEventRecord(b->e0, s));
     double chi = 0.0;

@@ -21,6 +21,7 @@
 // HBM layout: S is read and written tile by tile exactly once per panel step; at 288 GB the 9000 x 9000 system of
 // an eight-agent map (648 MB) stays resident next to the problem.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <utility>
 #include <vector>
@@ -1391,7 +1392,7 @@ __global__ __launch_bounds__(256) void dense_flow_big_kernel(BaDev d, unsigned e
         const unsigned u = __builtin_amdgcn_readfirstlane(s_ticket);
         __syncthreads();
         if (u >= (unsigned)T) break;
-        const int J = T - 1 - (int)u;
+        const int J = __builtin_amdgcn_readfirstlane(d.flow_tiles[n_tiles + (int)u].x);  // deepest chains first (build_dense_plan)
         SO_FLOW_NOTE(10, 4000000 + J);
         if (tid == 0) {  // the factor of block J, its column below, y_J
             flow_wait(&flags[J * (J + 1) / 2 + J], epoch);
@@ -1530,23 +1531,70 @@ void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DenseP
     plan->flow_n_tiles = 0;
     plan->flow_big = !(T <= 21 && plan->nnz_tiles <= std::min(flow_max, kFlowMaxTiles));
     if (!no_flow && !(plan->flow_big && no_flow_big)) {
-        // Column by column, diagonal tile first - an order in which every tile's inputs come before it.  In the ticketed
-        // kernel a tile starts from nothing when it is picked up and has its whole left-looking history to catch up on; for
-        // the diagonal tiles, which carry the critical path (and accumulate two tiles' worth), that is too late: they get
-        // their tickets `lead` columns early and grow with the factorisation.  At most `lead` workgroups wait on tiles
-        // with later tickets; everybody else takes tickets whose inputs all precede them, so the launch cannot lock up
-        // while it has more workgroups than that (ba.cpp only takes this path with at least 128 resident workgroups).
+        // Ticket order.  level[J] = length of the chain of diagonal factors column J hangs on: 0 if its row has no tile to
+        // the left, else 1 + the highest level inside the row's envelope.  A dense map gives level[J] = J (column by column);
+        // a merged multi-agent map, numbered agent by agent and linked only where trajectories meet, gives every agent's
+        // band its own chain: the columns of all agents at the same depth share a level, and the tickets walk the levels -
+        // eight chains of 12 panels advance together instead of one chain of 94 (LinearSolverEigen gets the same effect
+        // from its elimination tree, linear_solver_eigen.h:94-124).  Every input of a tile lies in a column of a lower
+        // level or is the diagonal tile of its own column (first in the column), so a workgroup that waits always waits
+        // for a tile a resident workgroup holds.  Exception by design: a tile starts from nothing when it is picked up and
+        // has its whole left-looking history to catch up on, which is too late for the diagonal tiles (they carry the
+        // chains and accumulate two tiles' worth): those get their tickets `lead` levels early and grow with the
+        // factorisation.  Early tiles can wait for tickets not yet handed out - at most lead x (columns per level) of them,
+        // which is kept under a third of the 128 workgroups ba.cpp guarantees this path.
         // (Early tickets for the tiles next to the diagonal as well - a triangle of them - were measured: no better.)
         static const int lead_env = getenv("SWARMORB_DENSE_FLOW_DIAG_LEAD") ? atoi(getenv("SWARMORB_DENSE_FLOW_DIAG_LEAD")) : -1;
-        const int lead = plan->flow_big ? (lead_env >= 0 ? std::min(lead_env, kFlowDiagLeadMax) : kFlowDiagLeadDefault) : 0;
+        std::vector<int> level((size_t)T, 0), per_level((size_t)T + 1, 0);
+        int max_cols = 1;
         for (int J = 0; J < T; J++) {
-            if (lead > 0 && J + lead < T) plan->tiles.push_back(make_int2(J + lead, J + lead));
-            for (int I = J; I < T; I++) {
-                if (I == J && lead > 0 && J >= lead) continue;  // went out with column J - lead
-                if (J >= tile_first[I]) plan->tiles.push_back(make_int2(I, J));
-            }
+            int mx = -1;
+            for (int k = tile_first[J]; k < J; k++) mx = std::max(mx, level[(size_t)k]);
+            level[(size_t)J] = mx + 1;
+            max_cols = std::max(max_cols, ++per_level[(size_t)level[(size_t)J]]);
         }
+        int lead = 0;
+        if (plan->flow_big) {
+            lead = lead_env >= 0 ? std::min(lead_env, kFlowDiagLeadMax) : kFlowDiagLeadDefault;
+            lead = std::max(1, std::min(lead, 42 / max_cols));
+            if (lead_env == 0) lead = 0;
+        }
+        if (getenv("SWARMORB_BA_TRACE")) {
+            int depth = 0;
+            for (int J = 0; J < T; J++) depth = std::max(depth, level[(size_t)J]);
+            fprintf(stderr, "[ba] dense plan: %d panels, %lld tiles, chain depth %d, at most %d columns per level, diagonal lead %d; first:", T,
+                    plan->nnz_tiles, depth + 1, max_cols, lead);
+            for (int J = 0; J < T; J++) fprintf(stderr, " %d", tile_first[J]);
+            fprintf(stderr, "\n");
+        }
+        std::vector<std::pair<long long, int2>> order;
+        for (int J = 0; J < T; J++)
+            for (int I = J; I < T; I++)
+                if (J >= tile_first[I]) {
+                    const int lv = level[(size_t)J], key = I == J ? std::max(lv - lead, 0) : lv;
+                    // ticket level, then (within a level) early diagonal tiles of deeper levels after the level's own
+                    // tiles, then column, diagonal first
+                    const long long early = (I == J && key != lv) ? 1 : 0;
+                    order.push_back({((long long)key << 44) | (early << 43) | ((long long)J << 21) | (long long)(I - J), make_int2(I, J)});
+                }
+        std::sort(order.begin(), order.end(), [](const std::pair<long long, int2>& x, const std::pair<long long, int2>& y) { return x.first < y.first; });
+        for (const auto& o : order) plan->tiles.push_back(o.second);
         plan->flow_n_tiles = (int)plan->tiles.size() - plan->flow_first_tile;
+        // backward substitution of the ticketed kernel: block rows by the length of THEIR chain (x_J needs the x_i of the
+        // tiles below it in column J), deepest dependencies first; T more entries (.x = block row) behind the tiles
+        if (plan->flow_big) {
+            std::vector<int> blevel((size_t)T, 0);
+            for (int J = T - 1; J >= 0; J--) {
+                int mx = -1;
+                for (int i = J + 1; i < T; i++)
+                    if (tile_first[i] <= J) mx = std::max(mx, blevel[(size_t)i]);
+                blevel[(size_t)J] = mx + 1;
+            }
+            std::vector<std::pair<int, int>> back;
+            for (int J = 0; J < T; J++) back.push_back({blevel[(size_t)J], -J});  // level, then bottom-up inside a level
+            std::sort(back.begin(), back.end());
+            for (const auto& bj : back) plan->tiles.push_back(make_int2(-bj.second, 0));
+        }
     }
 }
 
