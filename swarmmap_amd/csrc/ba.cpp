@@ -666,7 +666,30 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         }
         static const bool force_dense = getenv("SWARMORB_DENSE_FULL") != nullptr;  // A/B: ignore the structure
         if (force_dense) std::fill(b->tile_first.begin(), b->tile_first.end(), 0);
-        build_dense_plan(T, b->tile_first.data(), b->dense_side != nullptr, &b->plan);
+        // the dataflow solves need their workgroups resident: reserve the CUs first, the plan is built for that many
+        {
+            long long nnz = 0;
+            for (int I = 0; I < T; I++) nnz += I - b->tile_first[(size_t)I] + 1;
+            const int budget = flow_resident_budget(b->device);
+            static const bool no_flow = getenv("SWARMORB_DENSE_NO_FLOW") != nullptr, no_flow_big = getenv("SWARMORB_DENSE_NO_FLOW_BIG") != nullptr;
+            static const int flow_max = getenv("SWARMORB_DENSE_FLOW_MAX_TILES") ? atoi(getenv("SWARMORB_DENSE_FLOW_MAX_TILES")) : kFlowDefaultMaxTiles;
+            const bool big = !(T <= 21 && nnz <= std::min(flow_max, dense_flow_max_tiles()));
+            if (no_flow || (big && no_flow_big)) {
+            } else if (!big) {  // a workgroup per tile: all or nothing
+                const int want = (int)nnz;
+                int cur = g_flow_tiles.load();
+                while (cur + want <= budget && !g_flow_tiles.compare_exchange_weak(cur, cur + want)) {
+                }
+                if (cur + want <= budget) b->flow_reserved = want;
+            } else {  // ticketed kernel: whatever is free, if that is worth it
+                int cur = g_flow_tiles.load(), take = 0;
+                do {
+                    take = (int)std::min<long long>(nnz, budget - cur);
+                } while (take >= 128 && !g_flow_tiles.compare_exchange_weak(cur, cur + take));
+                if (take >= 128) b->flow_reserved = take;  // (the early tickets of build_dense_plan need room: see there)
+            }
+        }
+        build_dense_plan(T, b->tile_first.data(), b->dense_side != nullptr, &b->plan, b->flow_reserved);
         const size_t first_bytes = (sizeof(int) * (size_t)T + 255) & ~(size_t)255;
         const size_t tiles_bytes = sizeof(int2) * std::max<size_t>(b->plan.tiles.size(), 1);
         if ((rc = b->d_plan.ensure(first_bytes + tiles_bytes))) return rc;
@@ -675,22 +698,6 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         memcpy(b->h_plan, b->tile_first.data(), sizeof(int) * (size_t)T);
         if (!b->plan.tiles.empty()) memcpy((uint8_t*)b->h_plan + first_bytes, b->plan.tiles.data(), sizeof(int2) * b->plan.tiles.size());
         SO_HIP(hipMemcpyAsync(b->d_plan.p, b->h_plan, first_bytes + sizeof(int2) * b->plan.tiles.size(), hipMemcpyHostToDevice, s));
-        if (b->plan.flow_n_tiles > 0) {
-            const int budget = flow_resident_budget(b->device);
-            if (!b->plan.flow_big) {  // a workgroup per tile: all or nothing
-                const int want = b->plan.flow_n_tiles;
-                int cur = g_flow_tiles.load();
-                while (cur + want <= budget && !g_flow_tiles.compare_exchange_weak(cur, cur + want)) {
-                }
-                if (cur + want <= budget) b->flow_reserved = want;
-            } else {  // ticketed kernel: whatever is free, if that is worth it
-                int cur = g_flow_tiles.load(), take = 0;
-                do {
-                    take = std::min(b->plan.flow_n_tiles, budget - cur);
-                } while (take >= 128 && !g_flow_tiles.compare_exchange_weak(cur, cur + take));
-                if (take >= 128) b->flow_reserved = take;  // (the early tickets of build_dense_plan need room: see there)
-            }
-        }
         if (b->flow_reserved > 0) {
             // small kernel: fixed flag block + the forward vectors; ticketed kernel: a flag per tile slot + 2 x 512 + counters
             const size_t nslots = b->plan.flow_big ? (size_t)T * (T + 1) / 2 : 0;

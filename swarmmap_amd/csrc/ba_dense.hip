@@ -1496,7 +1496,7 @@ struct PlanBuilder {
 
 }  // namespace
 
-void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DensePlan* plan) {
+void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DensePlan* plan, int flow_grid) {
     static const bool no_lookahead = getenv("SWARMORB_DENSE_NO_LOOKAHEAD") != nullptr;
     static const int g_env = getenv("SWARMORB_DENSE_GROUP") ? atoi(getenv("SWARMORB_DENSE_GROUP")) : 0;
     plan->T = T;
@@ -1530,7 +1530,7 @@ void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DenseP
     plan->flow_first_tile = (int)plan->tiles.size();
     plan->flow_n_tiles = 0;
     plan->flow_big = !(T <= 21 && plan->nnz_tiles <= std::min(flow_max, kFlowMaxTiles));
-    if (!no_flow && !(plan->flow_big && no_flow_big)) {
+    if (flow_grid > 0 && !no_flow && !(plan->flow_big && no_flow_big)) {
         // Ticket order.  level[J] = length of the chain of diagonal factors column J hangs on: 0 if its row has no tile to
         // the left, else 1 + the highest level inside the row's envelope.  A dense map gives level[J] = J (column by column);
         // a merged multi-agent map, numbered agent by agent and linked only where trajectories meet, gives every agent's
@@ -1542,7 +1542,7 @@ void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DenseP
         // has its whole left-looking history to catch up on, which is too late for the diagonal tiles (they carry the
         // chains and accumulate two tiles' worth): those get their tickets `lead` levels early and grow with the
         // factorisation.  Early tiles can wait for tickets not yet handed out - at most lead x (columns per level) of them,
-        // which is kept under a third of the 128 workgroups ba.cpp guarantees this path.
+        // which is kept under a third of the launch's workgroups (flow_grid: ba.cpp reserves them before it asks for the plan).
         // (Early tickets for the tiles next to the diagonal as well - a triangle of them - were measured: no better.)
         static const int lead_env = getenv("SWARMORB_DENSE_FLOW_DIAG_LEAD") ? atoi(getenv("SWARMORB_DENSE_FLOW_DIAG_LEAD")) : -1;
         std::vector<int> level((size_t)T, 0), per_level((size_t)T + 1, 0);
@@ -1556,7 +1556,7 @@ void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DenseP
         int lead = 0;
         if (plan->flow_big) {
             lead = lead_env >= 0 ? std::min(lead_env, kFlowDiagLeadMax) : kFlowDiagLeadDefault;
-            lead = std::max(1, std::min(lead, 42 / max_cols));
+            lead = std::max(1, std::min(lead, (flow_grid / 3) / max_cols));
             if (lead_env == 0) lead = 0;
         }
         if (getenv("SWARMORB_BA_TRACE")) {

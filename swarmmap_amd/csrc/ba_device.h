@@ -155,7 +155,8 @@ struct DensePlan {
     int flow_first_tile = 0, flow_n_tiles = 0;  // dataflow solve: its tile list inside `tiles` (0 tiles: not eligible)
     bool flow_big = false;        // more tiles than one launch can keep resident one per workgroup: the ticketed kernel
 };
-void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DensePlan* plan);
+// flow_grid: workgroups the single-launch solve may keep resident (0: the chain-of-launches plan only)
+void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DensePlan* plan, int flow_grid);
 bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solves (4..29 free keyframes: tiles in LDS; 30..43: tiles in registers); false if neither applies
 void launch_ba_dense_pad(const BaDev& d, hipStream_t s);    // once per problem: identity padding up to ldS
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s);  // per trial, in place of the single-workgroup solve  // fills edge_tab (memset to -1 beforehand)
