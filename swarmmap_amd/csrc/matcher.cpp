@@ -573,7 +573,7 @@ int so_matcher_reuse_frame(so_matcher* m) {
 // pinned allocations cost 0.1-0.3 ms each, and a local map that grows keyframe by keyframe would otherwise pay one
 // every time it outgrows the 1.5x slack (the first seconds of a sequence: +25-50 us per frame).
 int so_matcher_reserve(so_matcher* m, int32_t n_queries) {
-    if (!m || n_queries < 0) return SO_ERR_INVALID_ARG;
+    if (!m || n_queries < 0 || m->pend.mode != 0) return SO_ERR_INVALID_ARG;  // (not while a submitted search owns the buffers)
     SO_HIP(hipSetDevice(m->device));
     constexpr int K = 8;
     const size_t nq = (size_t)n_queries;
