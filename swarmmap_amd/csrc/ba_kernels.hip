@@ -2304,10 +2304,14 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
         for (int k = 0; k < 32; k++) v[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < EPT; k++) {
-            if (!live[k] || outl[k]) continue;  // level 1
+            // Branch-free: an edge that is not active (beyond n, or level 1) runs the same instructions on harmless
+            // values and enters every sum with weight 0.  With `if (!active) continue` every edge was a basic block of
+            // its own behind an exec-mask change, and the scheduler could not interleave the edges' dependent chains.
+            const bool act = live[k] && !outl[k];
             const double x = fma(R[0], X[k][0], fma(R[1], X[k][1], fma(R[2], X[k][2], T.t[0])));
             const double y = fma(R[3], X[k][0], fma(R[4], X[k][1], fma(R[5], X[k][2], T.t[1])));
-            const double z = fma(R[6], X[k][0], fma(R[7], X[k][1], fma(R[8], X[k][2], T.t[2])));
+            const double zr = fma(R[6], X[k][0], fma(R[7], X[k][1], fma(R[8], X[k][2], T.t[2])));
+            const double z = act ? zr : 1.0;
             double c = __builtin_amdgcn_rcp(z);  // reciprocal + two Newton steps instead of the IEEE division
             c = fma(fma(-z, c, 1.0), c, c);
             c = fma(fma(-z, c, 1.0), c, c);
@@ -2315,17 +2319,18 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
             const double pf = p * fx, qg = q * fy;
             const double e0 = ob[k][0] - (pf + cx);
             const double e1 = ob[k][1] - (qg + cy);
-            er[k][0] = e0;
-            er[k][1] = e1;
-            const double we0 = w[k] * e0, we1 = w[k] * e1;
+            er[k][0] = act ? e0 : er[k][0];
+            er[k][1] = act ? e1 : er[k][1];
+            const double wk = act ? w[k] : 0.0;
+            const double we0 = wk * e0, we1 = wk * e1;
             const double chi2 = fma(e0, we0, e1 * we1);
             // Huber: rho = 2 sqrt(e) delta - delta^2, rho' = delta / sqrt(e), both from one reciprocal square root
             const bool clipped = robust && !(chi2 <= (double)dsqr);
             const double rs = rsqrt_newton(clipped ? chi2 : 1.0);
             v[27] += clipped ? fma(2.0 * delta, chi2 * rs, -(double)dsqr) : chi2;
-            v[28] += 1.0;
+            v[28] += act ? 1.0 : 0.0;
             const double r1 = clipped ? delta * rs : 1.0;
-            const double wo = r1 * w[k];
+            const double wo = r1 * wk;
             // EdgeSE3ProjectXYZOnlyPose::linearizeOplus (types_six_dof_expmap.cpp:266-288), shared sub-products;
             // Ju[4] and Jv[3] are structurally zero
             const double cf = c * fx, cg = c * fy;
