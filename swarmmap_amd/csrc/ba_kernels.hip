@@ -2292,6 +2292,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
         er[k][0] = 0.0; er[k][1] = 0.0;
     }
     int robust = 1, parity = 0;
+    double pass_chi = 0.0;  // chi2 total of the last edge pass
     SO_POSE_TICK_DECL;
 
     // One pass over the active edges at pose T; the block totals land in this wave's s_sysw[wv][which].
@@ -2381,11 +2382,13 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
         SO_POSE_TICK(1);  // wave reduction
         __syncthreads();  // the only barrier of a pass
         SO_POSE_TICK(2);  // barrier
-        if (lane < 32) {
-            double sum = s_red[parity][0][lane];
+        {
+            double sum = s_red[parity][0][lane & 31];
 #pragma unroll
-            for (int w2 = 1; w2 < NW; w2++) sum += s_red[parity][w2][lane];
-            s_sysw[wv][which][lane] = sum;
+            for (int w2 = 1; w2 < NW; w2++) sum += s_red[parity][w2][lane & 31];
+            if (lane < 32) s_sysw[wv][which][lane] = sum;
+            // chi2 of this pass straight from lane 27's register: the decision does not wait for the LDS round trip
+            pass_chi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sum), 27), __builtin_amdgcn_readlane(__double2loint(sum), 27));
         }
         parity ^= 1;
         __threadfence_block();  // wave-private rows: in-order LDS traffic of this wave + completed writes are enough
@@ -2441,7 +2444,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
                 want_proposal = true;
             } else {
                 const int tsys = cursys ^ 1;
-                const double tempChi = solve_ok ? s_sysw[wv][tsys][27] : 1.7976931348623157e308;
+                const double tempChi = solve_ok ? pass_chi : 1.7976931348623157e308;
                 const double rho = (currentChi - tempChi) * inv_scale;
                 if (a.trace && tid == 0 && trials_total < 256) {
                     a.trace[4 * trials_total] = lambda;
