@@ -544,14 +544,19 @@ int step_m2_wait(so_replay* r) {
 }
 
 // Optimizer::PoseOptimization inputs of the current frame: the keypoints that have a map point, ascending index
-void pose_gather(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers, int32_t* info2, so_pose_problem* q) {
+// same_edges: the keypoint -> map point bindings have not changed since the last gather of this frame (the third call of
+// a frame runs over the second one's edges from another start pose): the arrays are still right
+void pose_gather(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers, int32_t* info2, so_pose_problem* q,
+                 bool same_edges = false) {
     const so_replay::FrameHost& F = r->fh[r->cur];
-    r->idx.clear();
-    for (int i = 0; i < F.n; i++)
-        if (F.kp_mp[(size_t)i] >= 0) r->idx.push_back(i);
+    if (!same_edges) {
+        r->idx.clear();
+        for (int i = 0; i < F.n; i++)
+            if (F.kp_mp[(size_t)i] >= 0) r->idx.push_back(i);
+    }
     const int np = (int)r->idx.size();
     r->pX.resize((size_t)np * 3); r->pobs.resize((size_t)np * 2); r->pw.resize((size_t)np); r->pose_out.assign((size_t)np, 0);
-    for (int k = 0; k < np; k++) {
+    for (int k = 0; k < (same_edges ? 0 : np); k++) {
         const int i = r->idx[(size_t)k];
         const size_t s = (size_t)F.kp_mp[(size_t)i];
         memcpy(&r->pX[3 * (size_t)k], &r->mp_X[3 * s], 12);
@@ -580,10 +585,10 @@ void pose_account(so_replay* r, const so_pose_problem& q, float kernel_ms) {
 // under_kernel (may be empty): host work of the tracking thread that does not depend on this call's result; it runs
 // between the launch and the wait
 template <typename F>
-int pose_single(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers, F under_kernel) {
+int pose_single(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_inliers, F under_kernel, bool same_edges = false) {
     so_pose_problem q;
     int32_t info2[2];
-    pose_gather(r, T_in12, T_out12, n_inliers, info2, &q);
+    pose_gather(r, T_in12, T_out12, n_inliers, info2, &q, same_edges);
     if (so_pose_optimization_submit(r->tracker_opt, q.Tcw12, q.intr, q.n, q.Xw, q.obs, q.inv_sigma2) != SO_OK)
         return fail(r, "so_pose_optimization_submit");
     const int rc = under_kernel();
@@ -761,7 +766,7 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
                 to_f12(r->T_last, Tl);
                 int32_t inl3 = 0;
                 // the keyframe decision and the new map points only need the second result: they run under this kernel
-                if ((rc = pose_single(r, Tl, Tc, &inl3, [r] { return step_keyframe(r); }))) return rc;
+                if ((rc = pose_single(r, Tl, Tc, &inl3, [r] { return step_keyframe(r); }, true))) return rc;
                 S.tp3 = S.tmap = now_ms();
             } else {
                 S.tp3 = now_ms();
