@@ -886,8 +886,8 @@ __global__ void dense_begin_kernel(BaDev d) {
 //                        as their x_i arrive (the last one, L_{J+1,J}, waits in LDS): fixed summation orders,
 //                        deterministic.  b, y and x share d.bs (every reader of y_J is done before x_J exists).
 // Critical path per panel (tools/flow_probe.py, 64 keyframes): factor + inverse 17 us, inverse to HBM + flag 3 us,
-// L_{J+1,J} 10 us, update 7 us; the substitutions add ~4 us per panel at the end.
-constexpr int kFlowDiagLeadDefault = 12, kFlowDiagLeadMax = 32;  // ticketed kernel: columns a diagonal tile is picked up early
+// L_{J+1,J} 8.4 us, update 7 us; the backward substitution adds ~6.5 us per panel at the end.
+constexpr int kFlowDiagLeadDefault = 12, kFlowDiagLeadMax = 32;  // ticketed kernel: levels a diagonal tile is picked up early
 constexpr int kFlowMaxTiles = 231;   // 21 panels dense (2016 unknowns, 336 keyframes); a skyline may reach further
 constexpr int kFlowSlots = 256;      // flag / vector slots per kind: tile (I, J) -> I (I + 1) / 2 + J
 constexpr int kFlowFlagTile = 0, kFlowFlagFwd = kFlowSlots, kFlowFlagY = 2 * kFlowSlots, kFlowFlagX = 2 * kFlowSlots + 32,
