@@ -77,6 +77,20 @@ int flow_resident_budget(int device) {
     return budget > 0 ? budget : 0;
 }
 
+// Host staging of a large map (hundreds of thousands of observations) on a few threads: fn(part, n_parts) works on its
+// share; small problems (local windows) run inline - starting a thread costs more than their whole staging.
+template <typename F>
+void staging_parallel(int n_parts, F fn) {
+    if (n_parts <= 1) {
+        fn(0, 1);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_parts; t++) th.emplace_back([&fn, t, n_parts] { fn(t, n_parts); });
+    fn(0, n_parts);
+    for (std::thread& x : th) x.join();
+}
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -415,6 +429,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
 
     // SparseOptimizer::initializeOptimization(0) + buildIndexMapping (sparse_optimizer.cpp:166-270): every edge is
     // at level 0, a keyframe gets a hessian index if it is not fixed and has an edge
+    const double tS0 = now_ms();
     std::vector<uint8_t> touched((size_t)nP, 0);
     for (int e = 0; e < nE; e++) touched[(size_t)p->edge_pose[e]] = 1;
     int nf = 0;
@@ -456,9 +471,11 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     uint8_t* h_eact = hb + o_eact;
     uint8_t* h_ptact = hb + o_ptact;
 
+    const double tS1 = now_ms();
     for (int i = 0; i < nP; i++) pose_from_Tcw(p->Tcw + 12 * (size_t)i, h_pose[i]);  // toSE3Quat
     for (size_t i = 0; i < (size_t)nL * 3; i++) h_pt[i] = (double)p->Xw[i];          // toVector3d
     for (size_t i = 0; i < (size_t)nP * 4; i++) h_intr[i] = (double)p->intr[i];
+    const double tS2 = now_ms();
     // stable counting sort of the edges by landmark: a landmark's observations become contiguous
     for (int i = 0; i <= nL; i++) h_ptoff[i] = 0;
     for (int e = 0; e < nE; e++) h_ptoff[p->edge_point[e] + 1]++;
@@ -468,6 +485,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         std::vector<int> fill(h_ptoff, h_ptoff + nL);
         for (int e = 0; e < nE; e++) perm[(size_t)fill[(size_t)p->edge_point[e]]++] = e;
     }
+    const double tS3 = now_ms();
     for (int i = 0, h = 0; i < nP; i++) {
         h_hidx[i] = -1;
         if (touched[(size_t)i] && !p->fixed[i]) {
@@ -490,21 +508,31 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         std::vector<uint8_t> back((size_t)nf, 0);
         std::vector<int> eh;  // hessian index of the keyframe of every (landmark-sorted) edge, filled for the full walks
         auto eh_at = [&](int k) { return eh.empty() ? h_hidx[p->edge_pose[perm[(size_t)k]]] : eh[(size_t)k]; };
+        const int rparts = nE >= 150000 ? 4 : 1;  // threads of the full walks (each with its own flags, merged after)
         auto mark_far = [&](int stride) {  // every stride-th landmark
-            for (int l = 0; l < nL; l += stride) {
-                int lo = INT_MAX;
-                for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
-                    const int h = eh_at(k);
-                    if (h >= 0 && h < lo) lo = h;
+            const int np = stride == 1 ? rparts : 1;
+            std::vector<std::vector<uint8_t>> mine((size_t)np, std::vector<uint8_t>(np > 1 ? (size_t)nf : 0, 0));
+            staging_parallel(np, [&](int t, int) {
+                uint8_t* flag = np > 1 ? mine[(size_t)t].data() : back.data();
+                const int l0 = (int)((long long)nL * t / np), l1 = (int)((long long)nL * (t + 1) / np);
+                for (int l = l0; l < l1; l += stride) {
+                    int lo = INT_MAX;
+                    for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
+                        const int h = eh_at(k);
+                        if (h >= 0 && h < lo) lo = h;
+                    }
+                    if (lo == INT_MAX) continue;
+                    for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
+                        const int h = eh_at(k);
+                        if (h >= 0 && h - lo > kLinkSpan) flag[(size_t)h] = 1;
+                    }
                 }
-                if (lo == INT_MAX) continue;
-                for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
-                    const int h = eh_at(k);
-                    if (h >= 0 && h - lo > kLinkSpan) back[(size_t)h] = 1;
-                }
-            }
+            });
             int n = 0;
-            for (int h = 0; h < nf; h++) n += back[(size_t)h];
+            for (int h = 0; h < nf; h++) {
+                for (int t = 0; t < (np > 1 ? np : 0); t++) back[(size_t)h] |= mine[(size_t)t][(size_t)h];
+                n += back[(size_t)h];
+            }
             return n;
         };
         // a sample of the landmarks first: a map in which everything sees everything (most keyframes far from some
@@ -514,7 +542,10 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         if (dense_map) std::fill(back.begin(), back.end(), 0);
         else {
             eh.resize((size_t)nE);
-            for (int k = 0; k < nE; k++) eh[(size_t)k] = h_hidx[p->edge_pose[perm[(size_t)k]]];
+            staging_parallel(rparts, [&](int t, int np) {
+                const int k0 = (int)((long long)nE * t / np), k1 = (int)((long long)nE * (t + 1) / np);
+                for (int k = k0; k < k1; k++) eh[(size_t)k] = h_hidx[p->edge_pose[perm[(size_t)k]]];
+            });
             n_far = mark_far(1);
         }
         // The bands that remain must also start on tile boundaries (16 keyframes): a tile that holds the end of one
@@ -527,19 +558,26 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
             for (int h = 0; h < nf; h++)
                 if (!back[(size_t)h]) pos[(size_t)h] = ni++;
             std::vector<int> bridge((size_t)ni + 2, 0);  // difference array: a landmark seen from positions lo..hi bridges lo+1..hi
-            for (int l = 0; l < nL; l++) {
-                int lo = INT_MAX, hi = -1;
-                for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
-                    const int h = eh_at(k);
-                    if (h < 0 || back[(size_t)h]) continue;
-                    lo = std::min(lo, pos[(size_t)h]);
-                    hi = std::max(hi, pos[(size_t)h]);
+            std::vector<std::vector<int>> bparts((size_t)rparts, std::vector<int>((size_t)ni + 2, 0));
+            staging_parallel(rparts, [&](int t, int np) {
+                std::vector<int>& br = bparts[(size_t)t];
+                const int l0 = (int)((long long)nL * t / np), l1 = (int)((long long)nL * (t + 1) / np);
+                for (int l = l0; l < l1; l++) {
+                    int lo = INT_MAX, hi = -1;
+                    for (int k = h_ptoff[l]; k < h_ptoff[l + 1]; k++) {
+                        const int h = eh_at(k);
+                        if (h < 0 || back[(size_t)h]) continue;
+                        lo = std::min(lo, pos[(size_t)h]);
+                        hi = std::max(hi, pos[(size_t)h]);
+                    }
+                    if (hi > lo) {
+                        br[(size_t)lo + 1]++;
+                        br[(size_t)hi + 1]--;
+                    }
                 }
-                if (hi > lo) {
-                    bridge[(size_t)lo + 1]++;
-                    bridge[(size_t)hi + 1]--;
-                }
-            }
+            });
+            for (int t = 0; t < rparts; t++)
+                for (int q = 0; q < ni + 2; q++) bridge[(size_t)q] += bparts[(size_t)t][(size_t)q];
             std::vector<int> at((size_t)ni, 0);  // keyframe (natural hidx) at each remaining position
             for (int h = 0; h < nf; h++)
                 if (pos[(size_t)h] >= 0) at[(size_t)pos[(size_t)h]] = h;
@@ -570,10 +608,24 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         }
         r.n_reordered = n_back;
     }
-    for (int i = 0; i <= nf; i++) h_poseoff[i] = 0;
-    {
+    const double tS4 = now_ms();
+    // the observations in landmark order + the per-keyframe lists; big maps on `parts` threads, each owning a range of
+    // landmarks (so a landmark's observations - and the duplicate check - stay with one thread)
+    const int parts = nE >= 150000 ? 4 : 1;
+    std::vector<int> part_lm((size_t)parts + 1, 0);  // landmark ranges with about equal numbers of observations
+    for (int t = 1; t < parts; t++) {
+        const int target = (int)((long long)nE * t / parts);
+        part_lm[(size_t)t] = (int)(std::lower_bound(h_ptoff, h_ptoff + nL + 1, target) - h_ptoff);
+        part_lm[(size_t)t] = std::min(std::max(part_lm[(size_t)t], part_lm[(size_t)t - 1]), nL);
+    }
+    part_lm[(size_t)parts] = nL;
+    std::vector<std::vector<int>> part_cnt((size_t)parts, std::vector<int>((size_t)nf + 1, 0));  // observations per free keyframe and part
+    std::atomic<int> dup{0};
+    staging_parallel(parts, [&](int t, int) {
         std::vector<int> seen((size_t)nP, -1);  // the edge table holds one edge per (landmark, keyframe)
-        for (int k = 0; k < nE; k++) {
+        std::vector<int>& cnt = part_cnt[(size_t)t];
+        const int k0 = h_ptoff[part_lm[(size_t)t]], k1 = h_ptoff[part_lm[(size_t)t + 1]];
+        for (int k = k0; k < k1; k++) {
             const int e = perm[(size_t)k], ip = p->edge_pose[e], il = p->edge_point[e];
             h_epose[k] = ip;
             h_ept[k] = il;
@@ -581,25 +633,42 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
             h_obs[2 * (size_t)k + 1] = (double)p->obs[2 * (size_t)e + 1];
             h_w[k] = (double)p->inv_sigma2[e];
             h_eact[k] = 1;
-            if (seen[(size_t)ip] == il) {
-                last_error_ref() = "a landmark is observed twice by the same keyframe";
-                return SO_ERR_INVALID_ARG;
-            }
+            if (seen[(size_t)ip] == il) dup.store(1);
             seen[(size_t)ip] = il;
-            if (h_hidx[ip] >= 0) h_poseoff[h_hidx[ip] + 1]++;
+            if (h_hidx[ip] >= 0) cnt[(size_t)h_hidx[ip]]++;
+        }
+    });
+    if (dup.load()) {
+        last_error_ref() = "a landmark is observed twice by the same keyframe";
+        return SO_ERR_INVALID_ARG;
+    }
+    h_poseoff[0] = 0;
+    for (int i = 0; i < nf; i++) {
+        int c = 0;
+        for (int t = 0; t < parts; t++) c += part_cnt[(size_t)t][(size_t)i];
+        h_poseoff[i + 1] = h_poseoff[i] + c;
+    }
+    // free keyframe -> its edges, ascending (= by landmark): part t starts behind what the parts before it hold
+    for (int i = 0; i < nf; i++) {
+        int at = h_poseoff[i];
+        for (int t = 0; t < parts; t++) {
+            const int c = part_cnt[(size_t)t][(size_t)i];
+            part_cnt[(size_t)t][(size_t)i] = at;
+            at += c;
         }
     }
-    for (int i = 0; i < nf; i++) h_poseoff[i + 1] += h_poseoff[i];
-    {
-        std::vector<int> fill(h_poseoff, h_poseoff + nf);  // free keyframe -> its edges, ascending (= by landmark)
-        for (int k = 0; k < nE; k++) {
+    staging_parallel(parts, [&](int t, int) {
+        std::vector<int>& fill = part_cnt[(size_t)t];
+        const int k0 = h_ptoff[part_lm[(size_t)t]], k1 = h_ptoff[part_lm[(size_t)t + 1]];
+        for (int k = k0; k < k1; k++) {
             const int h = h_hidx[h_epose[k]];
             if (h >= 0) {
                 h_pepoint[fill[(size_t)h]] = h_ept[k];  // the edge's landmark next to it: one hop less in the Schur gather
                 h_pedges[fill[(size_t)h]++] = k;
             }
         }
-    }
+    });
+    const double tS5 = now_ms();
     for (int i = 0; i < nL; i++) h_ptact[i] = h_ptoff[i + 1] > h_ptoff[i];
     static const bool trace = getenv("SWARMORB_BA_TRACE") != nullptr;
     const double t_staged = now_ms();
@@ -819,6 +888,8 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
 
     const double t_uploaded = now_ms();
     if (trace) fprintf(stderr, "[ba] %d free keyframes, %d moved to the separator block\n", nf, r.n_reordered);
+    if (trace) fprintf(stderr, "[ba] staging: before %.3f touched+layout %.3f convert %.3f sort %.3f order %.3f fill %.3f lists %.3f\n",
+                       tS0 - t_begin, tS1 - tS0, tS2 - tS1, tS3 - tS2, tS4 - tS3, tS5 - tS4, t_staged - tS5);
     if (trace) fprintf(stderr, "[ba] dense setup done at +%.3f, launches done at +%.3f\n", t_dense_setup - t_staged, t_uploaded - t_staged);
     SO_HIP(hipEventRecord(b->e0, s));
     double chi = 0.0;
