@@ -20,6 +20,9 @@
 #include <cstdlib>
 #include <thread>
 #include <cstring>
+#include <mutex>
+#include <functional>
+#include <condition_variable>
 #include <numeric>
 #include <vector>
 
@@ -77,19 +80,73 @@ int flow_resident_budget(int device) {
     return budget > 0 ? budget : 0;
 }
 
-// Host staging of a large map (hundreds of thousands of observations) on a few threads: fn(part, n_parts) works on its
-// share; small problems (local windows) run inline - starting a thread costs more than their whole staging.
-template <typename F>
-void staging_parallel(int n_parts, F fn) {
-    if (n_parts <= 1) {
-        fn(0, 1);
-        return;
+// Host staging on a few threads: fn(part, n_parts) works on its share.  The workers belong to the solver context and
+// are started by the first problem large enough to want them (from ~30 k observations - a 40-keyframe window - the
+// staging is a sixth of the call); handing a job over costs a few microseconds.
+class StagingPool {
+public:
+    ~StagingPool() { stop(); }
+    template <typename F>
+    void run(int n_parts, F fn) {
+        if (n_parts <= 1) {
+            fn(0, 1);
+            return;
+        }
+        start(n_parts - 1);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            job_ = [&fn, n_parts](int t) { fn(t, n_parts); };
+            n_parts_ = n_parts;
+            pending_ = n_parts - 1;
+            generation_++;
+        }
+        cv_.notify_all();
+        fn(0, n_parts);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
     }
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_parts; t++) th.emplace_back([&fn, t, n_parts] { fn(t, n_parts); });
-    fn(0, n_parts);
-    for (std::thread& x : th) x.join();
-}
+    void stop() {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread& t : workers_) t.join();
+        workers_.clear();
+        quit_ = false;
+    }
+
+private:
+    void start(int n) {
+        while ((int)workers_.size() < n) {
+            const int id = (int)workers_.size() + 1;
+            workers_.emplace_back([this, id] {
+                unsigned long seen = 0;
+                for (;;) {
+                    std::function<void(int)> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [&] { return quit_ || (generation_ != seen && id < n_parts_); });
+                        if (quit_) return;
+                        seen = generation_;
+                        job = job_;
+                    }
+                    job(id);
+                    std::unique_lock<std::mutex> lk(mu_);
+                    if (--pending_ == 0) done_.notify_all();
+                }
+            });
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::function<void(int)> job_;
+    unsigned long generation_ = 0;
+    int n_parts_ = 0, pending_ = 0;
+    bool quit_ = false;
+};
 
 double now_ms() {
     using namespace std::chrono;
@@ -168,6 +225,7 @@ struct so_ba {
     hipStream_t dense_side = nullptr;       // blocked dense solver: side stream + events of its look-ahead
     std::vector<hipEvent_t> dense_events;
     DensePlan plan;                         // blocked solver: tiles of every trailing update for the current structure
+    StagingPool staging;                    // host threads of the problem staging (started on demand)
     unsigned flow_epoch = 0;                // single-launch dataflow solve: stamp of the last solve (never reset)
     int flow_reserved = 0;                  // tiles this context holds of the process-wide residency budget
     std::vector<int> tile_first;
@@ -508,11 +566,11 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         std::vector<uint8_t> back((size_t)nf, 0);
         std::vector<int> eh;  // hessian index of the keyframe of every (landmark-sorted) edge, filled for the full walks
         auto eh_at = [&](int k) { return eh.empty() ? h_hidx[p->edge_pose[perm[(size_t)k]]] : eh[(size_t)k]; };
-        const int rparts = nE >= 150000 ? 4 : 1;  // threads of the full walks (each with its own flags, merged after)
+        const int rparts = nE >= 150000 ? 4 : nE >= 30000 ? 3 : 1;  // threads of the full walks (each with its own flags, merged after)
         auto mark_far = [&](int stride) {  // every stride-th landmark
             const int np = stride == 1 ? rparts : 1;
             std::vector<std::vector<uint8_t>> mine((size_t)np, std::vector<uint8_t>(np > 1 ? (size_t)nf : 0, 0));
-            staging_parallel(np, [&](int t, int) {
+            b->staging.run(np, [&](int t, int) {
                 uint8_t* flag = np > 1 ? mine[(size_t)t].data() : back.data();
                 const int l0 = (int)((long long)nL * t / np), l1 = (int)((long long)nL * (t + 1) / np);
                 for (int l = l0; l < l1; l += stride) {
@@ -542,7 +600,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         if (dense_map) std::fill(back.begin(), back.end(), 0);
         else {
             eh.resize((size_t)nE);
-            staging_parallel(rparts, [&](int t, int np) {
+            b->staging.run(rparts, [&](int t, int np) {
                 const int k0 = (int)((long long)nE * t / np), k1 = (int)((long long)nE * (t + 1) / np);
                 for (int k = k0; k < k1; k++) eh[(size_t)k] = h_hidx[p->edge_pose[perm[(size_t)k]]];
             });
@@ -559,7 +617,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
                 if (!back[(size_t)h]) pos[(size_t)h] = ni++;
             std::vector<int> bridge((size_t)ni + 2, 0);  // difference array: a landmark seen from positions lo..hi bridges lo+1..hi
             std::vector<std::vector<int>> bparts((size_t)rparts, std::vector<int>((size_t)ni + 2, 0));
-            staging_parallel(rparts, [&](int t, int np) {
+            b->staging.run(rparts, [&](int t, int np) {
                 std::vector<int>& br = bparts[(size_t)t];
                 const int l0 = (int)((long long)nL * t / np), l1 = (int)((long long)nL * (t + 1) / np);
                 for (int l = l0; l < l1; l++) {
@@ -611,7 +669,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     const double tS4 = now_ms();
     // the observations in landmark order + the per-keyframe lists; big maps on `parts` threads, each owning a range of
     // landmarks (so a landmark's observations - and the duplicate check - stay with one thread)
-    const int parts = nE >= 150000 ? 4 : 1;
+    const int parts = nE >= 150000 ? 4 : nE >= 30000 ? 3 : 1;
     std::vector<int> part_lm((size_t)parts + 1, 0);  // landmark ranges with about equal numbers of observations
     for (int t = 1; t < parts; t++) {
         const int target = (int)((long long)nE * t / parts);
@@ -621,7 +679,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     part_lm[(size_t)parts] = nL;
     std::vector<std::vector<int>> part_cnt((size_t)parts, std::vector<int>((size_t)nf + 1, 0));  // observations per free keyframe and part
     std::atomic<int> dup{0};
-    staging_parallel(parts, [&](int t, int) {
+    b->staging.run(parts, [&](int t, int) {
         std::vector<int> seen((size_t)nP, -1);  // the edge table holds one edge per (landmark, keyframe)
         std::vector<int>& cnt = part_cnt[(size_t)t];
         const int k0 = h_ptoff[part_lm[(size_t)t]], k1 = h_ptoff[part_lm[(size_t)t + 1]];
@@ -657,7 +715,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
             at += c;
         }
     }
-    staging_parallel(parts, [&](int t, int) {
+    b->staging.run(parts, [&](int t, int) {
         std::vector<int>& fill = part_cnt[(size_t)t];
         const int k0 = h_ptoff[part_lm[(size_t)t]], k1 = h_ptoff[part_lm[(size_t)t + 1]];
         for (int k = k0; k < k1; k++) {
