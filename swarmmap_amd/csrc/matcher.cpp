@@ -111,6 +111,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 }  // namespace
 
 struct so_matcher {
+    std::vector<int> scratch_rot_item, scratch_rot_b;  // rotation-histogram bookkeeping of the resolve loops
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
@@ -761,7 +762,9 @@ int m2_search(so_matcher* m, const so_frame_view* cur, const so_dframe* src, boo
     const int32_t* cnt = (const int32_t*)m->h_count.p;
     const MatchQueryW* queries = hq;
     std::vector<int32_t> gate;
-    std::vector<int> rot_item, rot_b;
+    std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
+    rot_item.clear();
+    rot_b.clear();
     int hist[HISTO_LENGTH] = {0};
     int nm = 0;
     for (int i = 0; i < n_last; i++) {
@@ -909,7 +912,9 @@ int so_search_for_initialization(so_matcher* m, const so_frame_view* F1, const s
     const MatchQuery* queries = hq;
     std::vector<int32_t> matched_dist((size_t)n2, INT_MAX);
     std::vector<int32_t> matches21((size_t)n2, -1);
-    std::vector<int> rot_item, rot_b;
+    std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
+    rot_item.clear();
+    rot_b.clear();
     int hist[HISTO_LENGTH] = {0};
     int nm = 0;
     for (int i1 = 0; i1 < n1; i1++) {
@@ -1196,7 +1201,9 @@ int so_search_by_bow(so_matcher* m, int variant, int32_t n1, const uint8_t* desc
     const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
     const int32_t* cnt = (const int32_t*)m->h_count.p;
     std::vector<int32_t> gate;
-    std::vector<int> rot_item, rot_b;
+    std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
+    rot_item.clear();
+    rot_b.clear();
     int hist[HISTO_LENGTH] = {0};
     int nm = 0;
     for (int i = 0; i < nq; i++) {
@@ -1323,7 +1330,9 @@ int so_search_for_triangulation(so_matcher* m, int32_t n1, const float* x1, cons
     for (int i = 0; i < nq; i++) memcpy(hd + (size_t)i * 32, desc1 + (size_t)q_idx1[(size_t)i] * 32, 32);
     if ((rc = run_topk(m, nq, 1))) return rc;
     const uint32_t* keys = (const uint32_t*)m->h_keys.p;
-    std::vector<int> rot_item, rot_b;
+    std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
+    rot_item.clear();
+    rot_b.clear();
     int hist[HISTO_LENGTH] = {0};
     int nm = 0;
     for (int i = 0; i < nq; i++) {
@@ -1425,7 +1434,9 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
     const int32_t* cnt = (const int32_t*)m->h_count.p;
     const MatchQuery* queries = hq;
     std::vector<int32_t> gate;
-    std::vector<int> rot_item, rot_b;
+    std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
+    rot_item.clear();
+    rot_b.clear();
     int hist[HISTO_LENGTH] = {0};
     int nm = 0;
     for (int i = 0; i < nq; i++) {
@@ -1715,7 +1726,9 @@ int so_track_search_last_frame_wait(so_matcher* m, const uint8_t* slot_has_obs, 
     const uint8_t* cnt = (const uint8_t*)m->h_out.p + P.c8_off;
     auto has_obs = [&](int i) { return !slot_has_obs || slot_has_obs[i]; };
     std::vector<int32_t> gate;
-    std::vector<int> rot_item, rot_b;
+    std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
+    rot_item.clear();
+    rot_b.clear();
     int hist[HISTO_LENGTH] = {0};
     int nm = 0;
     for (int i = 0; i < n_last; i++) {
