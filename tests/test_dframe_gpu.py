@@ -231,6 +231,8 @@ def test_track_search_local_map_matches_oracle(S, oracle, seed, dist, th):
         mps = dict(in_view=in_view, proj_x=fr["proj_x"], proj_y=fr["proj_y"], view_cos=fr["view_cos"],
                    pred_level=fr["pred_level"], desc=md[idx], has_obs=np.ones(len(idx), np.uint8))
         m = S.ORBmatcher(0.8, True)
+        if local is not None:
+            m.reserve(4 * n_map)  # so_matcher_reserve: the staging sized up front (one pass with, one without)
         nm, k2m, view = dfm.search_local_map(m, cur, dmap, Tc, len(idx), th, 0.5, LOG_SF, local_slot=local, skip=skip,
                                              excluded=excluded)
         onm, ok2m = oracle.search_by_projection_mappoints(F, mps, th, 0.8)
