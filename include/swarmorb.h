@@ -491,8 +491,11 @@ typedef struct so_keyframe_header {
     uint64_t checksum;     /* of the descriptor + geometry blocks, filled by pack */
     float Tcw[12];         /* pose, 3x4 row-major */
     float K[4];            /* fx fy cx cy */
-    uint8_t reserved[24];
+    uint32_t flags;        /* SO_KF_FLAG_*; 0 in a version-1 record */
+    int32_t n_map_points;  /* version 2: keypoints with map_point_id >= 0, filled by pack2 */
+    uint8_t reserved[16];
 } so_keyframe_header;
+#define SO_KF_FLAG_MAP_POINTS 1u /* a map-point block follows the geometry (record version 2) */
 
 size_t so_keyframe_record_size(int32_t n_keypoints); /* 128 + 48 n */
 int so_keyframe_record_pack(const so_keyframe_header* hdr, const float* xy, const float* angle, const int32_t* octave,
@@ -501,6 +504,98 @@ int so_keyframe_record_pack(const so_keyframe_header* hdr, const float* xy, cons
  * with *hdr filled when the record holds more); output arrays may be NULL. */
 int so_keyframe_record_unpack(const uint8_t* rec, size_t length, so_keyframe_header* hdr, float* xy, float* angle,
                               int32_t* octave, uint8_t* descriptors, int32_t capacity);
+/* Record version 2 = version 1 + one i32 per keypoint behind the geometry: the id of the map point bound to the
+ * keypoint (KeyFrame::mvpMapPoints[i]->mnId, code/include/KeyFrame.h:381; -1 = none or isBad()), padded to a multiple
+ * of 32 bytes.  It is what the candidate search needs beyond version 1: SearchByBoW(KF, KF) only matches keypoints that
+ * carry a good map point (code/src/ORBmatcher.cc:517-521,535-541) and hands back the map points of its pairs. */
+size_t so_keyframe_record_size2(int32_t n_keypoints); /* 128 + 52 n, rounded up to 32 */
+int so_keyframe_record_pack2(const so_keyframe_header* hdr, const float* xy, const float* angle, const int32_t* octave,
+                             const uint8_t* descriptors, const int32_t* map_point_id, uint8_t* out, size_t capacity);
+/* accepts both versions (a version-1 record yields map_point_id[i] = 0: every keypoint counts as bound) */
+int so_keyframe_record_unpack2(const uint8_t* rec, size_t length, so_keyframe_header* hdr, float* xy, float* angle,
+                               int32_t* octave, uint8_t* descriptors, int32_t* map_point_id, int32_t capacity);
+
+/* ------------------------------------------------------------------------------------------------
+ * Keyframe store + cross-agent candidate search — the device-side counterpart of the per-agent
+ * KeyFrameDatabase the reference's server queries (AgentMediator::CheckOverlapCandidates,
+ * code/src/AgentMediator.cc:140-202: EVERY new keyframe is looked up in EVERY other agent's whole database) and of the
+ * per-candidate matching that follows (AgentMediator::GetSim3, :204-262: ORBmatcher(0.75, true).SearchByBoW(pCurrentKF,
+ * pKF, ...) and the `nmatches < 20` gate of :259).
+ *
+ * The store is a ring of keyframe records in HBM (capacity_keyframes x records of up to slot_keypoints keypoints); next
+ * to every record it keeps the descriptors of the keypoints that carry a map point, compacted in keypoint order - the
+ * only ones SearchByBoW(KF, KF) looks at.  A search has two phases:
+ *   1. detection (replaces KeyFrameDatabase::DetectLoopCandidates' BoW scoring; ORBvoc.bin is not part of the
+ *      reference checkout and the north star asks for brute-force Hamming + ratio test instead): ONE scan of the whole
+ *      store; votes[k] = number of the query's bound keypoints whose best match among keyframe k's bound keypoints has
+ *      best < th_low and (float)best < nn_ratio * (float)second  (the acceptance test of ORBmatcher.cc:550-551, first
+ *      minimum wins ties).  Keyframes of the query's own agent are skipped (AgentMediator.cc:186).
+ *   2. the keyframes with votes >= min_votes, by (votes descending, slot ascending), max_candidates at most, are
+ *      matched with the exact SearchByBoW(KF1, KF2) semantics of ORBmatcher.cc:481-597 with every feature in ONE
+ *      vocabulary node (the limit levelsup -> root of KeyFrame::ComputeBoW's transform): sequential over the query's
+ *      keypoints, targets already taken are skipped, `<` TH_LOW, ratio test, rotation histogram.  Candidates with
+ *      n_matches >= min_matches (the 20 of AgentMediator.cc:259) are reported with their pairs.
+ * Distances come from the GPU in both phases; the order-dependent resolve of phase 2 runs on the host inside the
+ * library, like every other matcher routine here.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct so_kfstore so_kfstore;
+typedef struct so_kf_search_params {
+    int32_t th_low;            /* 50: ORBmatcher::TH_LOW, code/src/ORBmatcher.cc:38 */
+    float nn_ratio;            /* 0.75: AgentMediator.cc:210 */
+    int32_t check_orientation; /* 1 */
+    int32_t min_votes;         /* detection gate of phase 1 */
+    int32_t min_matches;       /* 20: AgentMediator.cc:259 */
+    int32_t max_candidates;    /* keyframes phase 2 looks at per query (<= SO_KF_MAX_CANDIDATES) */
+} so_kf_search_params;
+#define SO_KF_MAX_CANDIDATES 64
+typedef struct so_kf_candidate {
+    int32_t slot;         /* position in the store (so_kfstore_read) */
+    int32_t agent_id;     /* header fields of the stored keyframe */
+    uint64_t keyframe_id;
+    int32_t n_keypoints;
+    int32_t votes;        /* phase 1 */
+    int32_t n_matches;    /* phase 2, after the rotation histogram */
+    int32_t reserved;
+} so_kf_candidate;
+int so_kfstore_create(int device, int capacity_keyframes, int slot_keypoints, so_kfstore** out);
+void so_kfstore_destroy(so_kfstore* s);
+/* n version-1/2 records in host memory, `stride` bytes apart; a full store overwrites its oldest keyframes.
+ * slots_out[i] (may be NULL) = where record i went. */
+int so_kfstore_append(so_kfstore* s, const uint8_t* records, size_t stride, int32_t n_records, int32_t* slots_out);
+/* keyframes held, and the bound-keypoint descriptors one scan reads */
+int so_kfstore_size(const so_kfstore* s, int32_t* n_keyframes, int64_t* n_descriptors);
+/* phase 1 alone: votes[slot] for slot < capacity (-1: empty slot or the query's own agent) */
+int so_kfstore_votes(so_kfstore* s, const uint8_t* query_record, size_t length, int32_t th_low, float nn_ratio,
+                     int32_t* votes);
+/* both phases.  out: max_candidates entries; pairs (may be NULL): max_candidates x n_keypoints(query), pairs[c][i1] =
+ * keypoint of candidate c matched to the query's keypoint i1, or -1 (vpMatches12 of ORBmatcher.cc:481 as indices);
+ * *n_out = candidates that passed min_matches.  n_evaluated (may be NULL) = keyframes phase 2 looked at. */
+int so_kfstore_search(so_kfstore* s, const uint8_t* query_record, size_t length, const so_kf_search_params* p,
+                      so_kf_candidate* out, int32_t* pairs, int32_t* n_out, int32_t* n_evaluated);
+/* the record stored at `slot`, as appended (the merger needs the geometry and pose of a candidate) */
+int so_kfstore_read(so_kfstore* s, int32_t slot, uint8_t* record, size_t capacity, size_t* length);
+/* stats of the last search: [0] scan kernel ms (HIP events), [1] descriptor pairs the scan compared, [2] keyframes
+ * scanned, [3] phase-2 kernel ms, [4] keyframes phase 2 evaluated, [5] phase-2 queries re-run on the GPU */
+int so_kfstore_last_stats(so_kfstore* s, double* stats6);
+
+/* The exchange as the reference's candidate search (code/src/AgentMediator.cc:177-191,204-262): a communicator whose
+ * slot holds up to records_per_tick keyframe records (version 2) and which owns a keyframe store of store_keyframes
+ * records.  so_exchange_tick_records (collective): this rank's new keyframes go out, one ncclAllGather delivers every
+ * rank's, the peers' records are appended to the store on the device (no host hop), and each of this rank's new
+ * keyframes is searched against the WHOLE store (everything every peer has sent so far, this tick included) with
+ * so_kfstore_search's two phases.  out / pairs / n_out: n_records blocks of max_candidates entries / max_candidates x
+ * slot_keypoints entries / one count, in record order (pairs may be NULL).  n_records may be 0 (the rank only receives). */
+int so_exchange_create_store(int device, int rank, int world, const uint8_t* id128, int slot_keypoints,
+                             int records_per_tick, int store_keyframes, so_exchange** out);
+int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stride, int32_t n_records,
+                             const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs, int32_t* n_out);
+/* The same for ONE keyframe whose descriptors and undistorted keypoints are device-resident (the frame tracked last):
+ * the record is assembled in the slot by a kernel; hdr supplies ids / pose, map_point_id[n] (host) the bindings. */
+int so_exchange_tick_keyframe(so_exchange* x, const so_dframe* f, const so_keyframe_header* hdr,
+                              const int32_t* map_point_id, const so_kf_search_params* p, so_kf_candidate* out,
+                              int32_t* pairs, int32_t* n_out);
+/* the store behind the communicator (owned by it; NULL for one made by so_exchange_create) */
+so_kfstore* so_exchange_store(so_exchange* x);
 
 /* ------------------------------------------------------------------------------------------------
  * Bundle adjustment — replaces Optimizer::LocalBundleAdjustment / BundleAdjustment / GlobalBundleAdjustment

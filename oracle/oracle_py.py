@@ -453,3 +453,44 @@ def distinctive_descriptors(offsets, descriptors):
             idx[p] = lib().orc_distinctive_descriptor(_p(blk), C.c_int32(k), C.byref(m))
             med[p] = m.value
     return idx, med
+
+
+# ---- cross-agent keyframe candidate search (oracle/kfsearch_oracle.c + orc_search_by_bow) ----------------------
+class _OneNode:
+    """DBoW2::FeatureVector with every feature in ONE node, indices in stored (ascending) order."""
+
+    def __init__(self, n):
+        self.node_id = np.zeros(1, np.int32)
+        self.off = np.array([0, n], np.int32)
+        self.idx = np.arange(n, dtype=np.int32)
+
+
+def kf_votes(query, kf, th_low=50, nn_ratio=0.75):
+    """Detection score of one stored keyframe for one query keyframe; both dicts: desc (n,32) u8, valid (n,) u8."""
+    d1, v1 = np.ascontiguousarray(query["desc"], np.uint8), np.ascontiguousarray(query["valid"], np.uint8)
+    d2, v2 = np.ascontiguousarray(kf["desc"], np.uint8), np.ascontiguousarray(kf["valid"], np.uint8)
+    f = lib().orc_kf_votes
+    f.restype = C.c_int
+    return int(f(C.c_int32(len(d1)), _p(d1), _p(v1), C.c_int32(len(d2)), _p(d2), _p(v2), C.c_int32(int(th_low)),
+                 C.c_float(nn_ratio)))
+
+
+def kf_search(query, store, th_low=50, nn_ratio=0.75, check_ori=True, min_votes=20, min_matches=20, max_candidates=16):
+    """AgentMediator::CheckOverlapCandidates + GetSim3's matching (code/src/AgentMediator.cc:177-191,204-262) over a
+    store = list of keyframe dicts (agent, keyframe_id, desc, angle, valid) in slot order (None = empty slot); query: the
+    same fields.  Returns (votes per slot (-1: empty / own agent), list of (slot, votes, n_matches, match_of_1) for the
+    candidates that reach min_matches, number of keyframes phase 2 looked at)."""
+    assert th_low == 50, "orc_search_by_bow has TH_LOW built in (code/src/ORBmatcher.cc:38)"
+    votes = np.full(len(store), -1, np.int32)
+    for k, kf in enumerate(store):
+        if kf is None or kf["agent"] == query["agent"]:
+            continue
+        votes[k] = kf_votes(query, kf, th_low, nn_ratio)
+    order = [k for k in np.argsort(-votes, kind="stable") if votes[k] >= min_votes and votes[k] > 0][:max_candidates]
+    out = []
+    for k in order:
+        kf = store[k]
+        nm, _, m1 = search_by_bow(1, query, _OneNode(len(query["desc"])), kf, _OneNode(len(kf["desc"])), nn_ratio, check_ori)
+        if nm >= min_matches:
+            out.append((int(k), int(votes[k]), int(nm), m1))
+    return votes, out, len(order)

@@ -1088,6 +1088,12 @@ int so_pose_optimization_submit(so_ba* b, const float* Tcw12, const float* intr,
     const bool spin = zero_copy && !env_no_spin;
     if (spin && ++b->pose_seq == 0) b->pose_seq = 1;
     a.done_seq = spin ? b->pose_seq : 0;
+    // hout moves with n, so the completion word may land on bytes an earlier call left there (outlier flags, batch
+    // arguments): clear it before the launch - pose_seq is never 0, so a stale word can never read as "done"
+    if (spin) {
+        *reinterpret_cast<volatile int*>(hout + 64 + 12) = 0;
+        std::atomic_thread_fence(std::memory_order_release);
+    }
     static const bool env_no_events = getenv("SWARMORB_NO_EVENTS") != nullptr;  // diagnostic: cost of the two event records
     const bool no_events = env_no_events || !b->pose_timing;
     if (!no_events) SO_HIP(hipEventRecord(b->pe0, s));
@@ -1115,17 +1121,17 @@ int so_pose_optimization_wait(so_ba* b, float* Tcw_out12, uint8_t* outlier, int3
     if (!Q.launched) return SO_OK;
     if (Q.done_seq) {
         const volatile int* done = reinterpret_cast<const volatile int*>(Q.hout + 64) + 3;
+        // a kernel of 60-110 us: spin for about twice that, then hand the core back (several agents per GPU put every
+        // tracking thread here at once, against the local-mapping threads) and let the stream's completion wake us
         for (unsigned long it = 1; *done != Q.done_seq; it++) {
-            if ((it & 0xffff) == 0) {  // every ~65 k polls: is the stream still alive?
-                const hipError_t q = hipStreamQuery(Q.stream);
-                if (q != hipErrorNotReady) {  // drained (the word must be there) or failed
-                    if (q != hipSuccess || *done != Q.done_seq) {
-                        last_error_ref() = q != hipSuccess ? std::string("PoseOptimization: ") + hipGetErrorString(q)
-                                                           : std::string("PoseOptimization kernel finished without publishing its results");
-                        return SO_ERR_HIP;
-                    }
-                    break;
+            if ((it & 0x1fff) == 0) {  // every ~8 k polls (~0.2 ms): stop burning the core
+                const hipError_t q = hipStreamSynchronize(Q.stream);
+                if (q != hipSuccess || *done != Q.done_seq) {
+                    last_error_ref() = q != hipSuccess ? std::string("PoseOptimization: ") + hipGetErrorString(q)
+                                                       : std::string("PoseOptimization kernel finished without publishing its results");
+                    return SO_ERR_HIP;
                 }
+                break;
             }
             __builtin_ia32_pause();
         }

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "dframe_internal.h"
+#include "kfstore_internal.h"
 #include "match_device.h"
 #include "so_common.h"
 
@@ -81,6 +82,18 @@ struct so_exchange {
     size_t h_pin_bytes = 0;
     std::vector<int32_t> counts;
     std::vector<uint64_t> sums;
+    // candidate-search mode (so_exchange_create_store): the slot holds records_per_tick keyframe records, rec_stride apart
+    so_kfstore* store = nullptr;
+    int records_per_tick = 0;
+    size_t rec_stride = 0;
+    uint8_t* d_rslot = nullptr;      // this rank's records
+    uint8_t* d_rgathered = nullptr;  // world x records_per_tick records in rank order
+    uint8_t* d_staged = nullptr;     // header + angles + bindings of a device-resident keyframe
+    uint8_t* h_rpin = nullptr;       // pinned: [world x records_per_tick headers | staged block]
+    std::vector<so_keyframe_header> hdrs;
+    std::vector<uint8_t> skip;
+    std::vector<float> q_angle;
+    std::vector<int32_t> q_mp;
 };
 
 namespace {
@@ -102,6 +115,10 @@ int tick_common(so_exchange* x, const uint8_t* d_desc, int n, int max_dist, floa
         int32_t hdr[2];
         memcpy(hdr, x->h_pin + 32 * (size_t)p, 8);
         memcpy(&x->sums[(size_t)p], x->h_pin + 32 * (size_t)p + 8, 8);
+        if (hdr[0] < 0 || hdr[0] > x->slot_keypoints) {  // a peer built with another slot size, or a corrupted header
+            last_error_ref() = "all-gather slot header: keypoint count outside [0, slot_keypoints]";
+            return SO_ERR_INVALID_ARG;
+        }
         x->counts[(size_t)p] = hdr[0];
         if (hdr[1] != p) {
             last_error_ref() = "all-gather slot order does not follow the rank order";
@@ -133,6 +150,37 @@ int tick_common(so_exchange* x, const uint8_t* d_desc, int n, int max_dist, floa
         int c = 0;
         for (int i = 0; i < mine; i++) c += (bd[i] <= max_dist && (float)bd[i] < ratio * (float)sd[i]) ? 1 : 0;
         peer_candidates[p] = c;
+    }
+    return SO_OK;
+}
+
+// Candidate-search tick, common part: this rank's n_mine records are in d_rslot (unused positions zeroed); all-gather,
+// append the peers' records to the store, search every own record against the whole store.
+int tick_store_common(so_exchange* x, int n_mine, const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs,
+                      int32_t* n_out, const std::vector<const float*>& angles, const std::vector<const int32_t*>& mps) {
+    const Rccl& R = rccl();
+    so_kfstore* S = x->store;
+    hipStream_t s = S->stream;
+    const int K = x->records_per_tick, total = x->world * K;
+    const ncclResult_t r = R.AllGather(x->d_rslot, x->d_rgathered, x->rec_stride * (size_t)K, kNcclUint8, x->comm, s);
+    if (r != 0) return rccl_fail(r, "ncclAllGather");
+    so_keyframe_header* hh = reinterpret_cast<so_keyframe_header*>(x->h_rpin);
+    SO_HIP(hipMemcpy2DAsync(hh, sizeof(so_keyframe_header), x->d_rgathered, x->rec_stride, sizeof(so_keyframe_header),
+                            (size_t)total, hipMemcpyDeviceToHost, s));
+    SO_HIP(hipStreamSynchronize(s));
+    x->hdrs.assign(hh, hh + total);
+    x->skip.assign((size_t)total, 0);
+    for (int j = 0; j < total; j++)
+        if (j / K == x->rank || x->hdrs[(size_t)j].magic == 0) x->skip[(size_t)j] = 1;  // own records; empty positions
+    int rc = kfstore_append_device(S, x->d_rgathered, x->rec_stride, x->hdrs.data(), x->skip.data(), total, nullptr, s);
+    if (rc != SO_OK) return rc;
+    for (int j = 0; j < n_mine; j++) {
+        const so_keyframe_header& h = x->hdrs[(size_t)(x->rank * K + j)];
+        rc = kfstore_search_device(S, x->d_rgathered + (size_t)(x->rank * K + j) * x->rec_stride, h, angles[(size_t)j],
+                                   mps[(size_t)j], p, false, nullptr, out + (size_t)j * (size_t)p->max_candidates,
+                                   pairs ? pairs + (size_t)j * (size_t)p->max_candidates * (size_t)x->slot_keypoints : nullptr,
+                                   n_out + j, nullptr);
+        if (rc != SO_OK) return rc;
     }
     return SO_OK;
 }
@@ -206,10 +254,14 @@ void so_exchange_destroy(so_exchange* x) {
     if (!x) return;
     (void)hipSetDevice(x->device);
     if (x->stream) (void)hipStreamSynchronize(x->stream);
+    if (x->store && x->store->stream) (void)hipStreamSynchronize(x->store->stream);
     if (x->comm) (void)rccl().CommDestroy(x->comm);
-    for (void* p : {(void*)x->d_slot, (void*)x->d_gathered, (void*)x->d_stage, (void*)x->d_res})
+    for (void* p : {(void*)x->d_slot, (void*)x->d_gathered, (void*)x->d_stage, (void*)x->d_res, (void*)x->d_rslot,
+                    (void*)x->d_rgathered, (void*)x->d_staged})
         if (p) (void)hipFree(p);
     if (x->h_pin) (void)hipHostFree(x->h_pin);
+    if (x->h_rpin) (void)hipHostFree(x->h_rpin);
+    if (x->store) so_kfstore_destroy(x->store);
     if (x->stream) (void)hipStreamDestroy(x->stream);
     delete x;
 }
@@ -232,6 +284,124 @@ int so_exchange_tick(so_exchange* x, const uint8_t* descriptors, int n, int max_
     const int nk = n < x->slot_keypoints ? n : x->slot_keypoints;
     if (nk > 0) SO_HIP(hipMemcpyAsync(x->d_stage, descriptors, 32 * (size_t)nk, hipMemcpyHostToDevice, x->stream));
     return tick_common(x, x->d_stage, nk, max_dist, ratio, peer_counts, peer_candidates);
+}
+
+int so_exchange_create_store(int device, int rank, int world, const uint8_t* id128, int slot_keypoints,
+                             int records_per_tick, int store_keyframes, so_exchange** out) {
+    if (!out || records_per_tick < 1 || records_per_tick > 64 || store_keyframes < 1) return SO_ERR_INVALID_ARG;
+    int rc = so_exchange_create(device, rank, world, id128, slot_keypoints, out);
+    if (rc != SO_OK) return rc;
+    so_exchange* x = *out;
+    *out = nullptr;
+    rc = so_kfstore_create(device, store_keyframes, slot_keypoints, &x->store);
+    if (rc != SO_OK) {
+        so_exchange_destroy(x);
+        return rc;
+    }
+    x->records_per_tick = records_per_tick;
+    x->rec_stride = x->store->dev.rec_stride;
+    const size_t slot = x->rec_stride * (size_t)records_per_tick;
+    const size_t staged = sizeof(so_keyframe_header) + 8 * (size_t)slot_keypoints;
+    hipError_t e = hipMalloc((void**)&x->d_rslot, slot);
+    if (e == hipSuccess) e = hipMalloc((void**)&x->d_rgathered, slot * (size_t)world);
+    if (e == hipSuccess) e = hipMalloc((void**)&x->d_staged, staged);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&x->h_rpin, sizeof(so_keyframe_header) * (size_t)world * (size_t)records_per_tick + staged,
+                                           hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemset(x->d_rgathered, 0, slot * (size_t)world);
+    if (e != hipSuccess) {
+        so_exchange_destroy(x);
+        return hip_fail(e, "exchange store init", __FILE__, __LINE__);
+    }
+    *out = x;
+    return SO_OK;
+}
+
+so_kfstore* so_exchange_store(so_exchange* x) { return x ? x->store : nullptr; }
+
+int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stride, int32_t n_records,
+                             const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs, int32_t* n_out) {
+    if (!x || !x->store || !p || n_records < 0 || n_records > x->records_per_tick || p->max_candidates < 0 ||
+        p->max_candidates > SO_KF_MAX_CANDIDATES)
+        return SO_ERR_INVALID_ARG;
+    if (n_records > 0 && (!records || !out || !n_out || stride < sizeof(so_keyframe_header))) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(x->device));
+    hipStream_t s = x->store->stream;
+    SO_HIP(hipMemsetAsync(x->d_rslot, 0, x->rec_stride * (size_t)x->records_per_tick, s));
+    std::vector<const float*> angles((size_t)n_records);
+    std::vector<const int32_t*> mps((size_t)n_records);
+    size_t need = 0;
+    for (int j = 0; j < n_records; j++) {
+        so_keyframe_header h;
+        memcpy(&h, records + (size_t)j * stride, sizeof(h));
+        if (h.magic != 0x464B4F53u || h.n_keypoints < 0 || h.n_keypoints > x->slot_keypoints ||
+            !(h.version == 1 || (h.version == 2 && (h.flags & SO_KF_FLAG_MAP_POINTS)))) {
+            last_error_ref() = "exchange tick: not a keyframe record, or more keypoints than the slot holds";
+            return SO_ERR_INVALID_ARG;
+        }
+        need += (size_t)h.n_keypoints;
+    }
+    x->q_angle.resize(need ? need : 1);
+    x->q_mp.resize(need ? need : 1);
+    size_t at = 0;
+    for (int j = 0; j < n_records; j++) {
+        const uint8_t* rec = records + (size_t)j * stride;
+        so_keyframe_header h;
+        memcpy(&h, rec, sizeof(h));
+        const size_t n = (size_t)h.n_keypoints;
+        const size_t bytes = h.version == 2 ? so_keyframe_record_size2(h.n_keypoints) : so_keyframe_record_size(h.n_keypoints);
+        if (bytes > stride) return SO_ERR_INVALID_ARG;
+        const uint8_t* geo = rec + sizeof(so_keyframe_header) + n * 32;
+        for (size_t i = 0; i < n; i++) memcpy(&x->q_angle[at + i], geo + 16 * i + 8, 4);
+        if (h.version == 2) {
+            if (n) memcpy(&x->q_mp[at], geo + 16 * n, 4 * n);
+        } else {
+            for (size_t i = 0; i < n; i++) x->q_mp[at + i] = 0;
+        }
+        angles[(size_t)j] = x->q_angle.data() + at;
+        mps[(size_t)j] = x->q_mp.data() + at;
+        at += n;
+        SO_HIP(hipMemcpyAsync(x->d_rslot + (size_t)j * x->rec_stride, rec, bytes, hipMemcpyHostToDevice, s));
+    }
+    return tick_store_common(x, n_records, p, out, pairs, n_out, angles, mps);
+}
+
+int so_exchange_tick_keyframe(so_exchange* x, const so_dframe* f, const so_keyframe_header* hdr,
+                              const int32_t* map_point_id, const so_kf_search_params* p, so_kf_candidate* out,
+                              int32_t* pairs, int32_t* n_out) {
+    if (!x || !x->store || !f || !f->ready || !f->mirrors || !hdr || !p || !out || !n_out || p->max_candidates < 0 ||
+        p->max_candidates > SO_KF_MAX_CANDIDATES)
+        return SO_ERR_INVALID_ARG;
+    if (f->device != x->device) {
+        last_error_ref() = "frame and exchange live on different devices";
+        return SO_ERR_INVALID_ARG;
+    }
+    const int n = f->n < x->slot_keypoints ? f->n : x->slot_keypoints;
+    if (n > 0 && !map_point_id) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(x->device));
+    hipStream_t s = x->store->stream;
+    // staged block: header | angle f32 n | map_point_id i32 n  (descriptors, undistorted keypoints, octaves stay in HBM)
+    uint8_t* hs = x->h_rpin + sizeof(so_keyframe_header) * (size_t)x->world * (size_t)x->records_per_tick;
+    so_keyframe_header h = *hdr;
+    h.n_keypoints = n;
+    memcpy(hs, &h, sizeof(h));
+    if (n > 0) {
+        memcpy(hs + sizeof(h), f->angle.data(), 4 * (size_t)n);
+        memcpy(hs + sizeof(h) + 4 * (size_t)n, map_point_id, 4 * (size_t)n);
+    }
+    const size_t staged = sizeof(h) + 8 * (size_t)n;
+    SO_HIP(hipMemsetAsync(x->d_rslot, 0, x->rec_stride * (size_t)x->records_per_tick, s));
+    SO_HIP(hipMemcpyAsync(x->d_staged, hs, staged, hipMemcpyHostToDevice, s));
+    launch_kf_pack_record(f->d_desc, f->d_xy_un, f->d_octave, x->d_staged, n, x->d_rslot, so_keyframe_record_size2(n), s);
+    SO_HIP(hipGetLastError());
+    x->q_angle.assign(f->angle.begin(), f->angle.begin() + n);
+    x->q_mp.assign(map_point_id, map_point_id + n);
+    if (n == 0) {
+        x->q_angle.resize(1);
+        x->q_mp.resize(1);
+    }
+    std::vector<const float*> angles{x->q_angle.data()};
+    std::vector<const int32_t*> mps{x->q_mp.data()};
+    return tick_store_common(x, 1, p, out, pairs, n_out, angles, mps);
 }
 
 // Rank `peer`'s slot as gathered by the last tick (tests, host merger): descriptors and the header's checksum.

@@ -36,7 +36,7 @@ class SoKeyframeHeader(_C.Structure):
     _fields_ = [("magic", _C.c_uint32), ("version", _C.c_uint16), ("header_bytes", _C.c_uint16),
                 ("agent_id", _C.c_int32), ("n_keypoints", _C.c_int32), ("keyframe_id", _C.c_uint64),
                 ("timestamp", _C.c_double), ("checksum", _C.c_uint64), ("Tcw", _C.c_float * 12), ("K", _C.c_float * 4),
-                ("reserved", _C.c_uint8 * 24)]
+                ("flags", _C.c_uint32), ("n_map_points", _C.c_int32), ("reserved", _C.c_uint8 * 16)]
 
 
 RECORD_HEADER_BYTES = 128

@@ -447,3 +447,42 @@ def make_frustum_case(seed, n=4000, K=EUROC_K, size=EUROC):
     max_dist = (d * rng.uniform(0.6, 3.0, n)).astype(np.float32)
     min_dist = (max_dist / (1.2 ** 7) * rng.uniform(0.8, 1.3, n)).astype(np.float32)
     return dict(Tcw=Tcw.reshape(12), Xw=Xw, normal=normal, max_dist=max_dist, min_dist=min_dist)
+
+
+def make_kf_store_case(seed, n_agents=3, kfs_per_agent=6, n_kp=300, bound_frac=0.5, n_places=None, p_flip=0.04,
+                       revisit_frac=0.6, ragged=True):
+    """Keyframes of several agents for the cross-agent candidate search: every keyframe looks at one of
+    `n_places` places; a place is a pool of descriptors with orientations, a keyframe sees a random subset of it
+    under bit noise (two views of one feature differ by ~2 p 256 bits) plus clutter, in random keypoint order, rotated
+    as a whole.  Returns a list of dicts (agent, keyframe_id, desc, angle, xy, octave, map_point_id, valid, place) in the
+    order an exchange would deliver them (time-major: keyframe t of every agent, then t + 1)."""
+    rng = np.random.default_rng(seed)
+    n_places = n_places or max(2, (n_agents * kfs_per_agent) // 3)
+    pool = [dict(desc=rng.integers(0, 256, (n_kp, 32)).astype(np.uint8), angle=rng.uniform(0, 360, n_kp).astype(np.float32))
+            for _ in range(n_places)]
+    out = []
+    for t in range(kfs_per_agent):
+        for a in range(n_agents):
+            place = int(rng.integers(0, n_places))
+            n = int(rng.integers(max(1, n_kp // 2), n_kp + 1)) if ragged else n_kp
+            n_seen = int(revisit_frac * n)
+            pick = rng.permutation(n_kp)[:n_seen]
+            desc = np.concatenate([flip_bits(rng, pool[place]["desc"][pick], p_flip),
+                                   rng.integers(0, 256, (n - n_seen, 32)).astype(np.uint8)])
+            roll = np.float32(rng.uniform(0, 360))
+            angle = np.concatenate([pool[place]["angle"][pick] + roll + rng.normal(0, 2.0, n_seen).astype(np.float32),
+                                    rng.uniform(0, 360, n - n_seen).astype(np.float32)])
+            angle = np.mod(angle, np.float32(360)).astype(np.float32)
+            order = rng.permutation(n)
+            desc, angle = np.ascontiguousarray(desc[order]), np.ascontiguousarray(angle[order])
+            seen = np.zeros(n, bool)
+            seen[:n_seen] = True
+            seen = seen[order]
+            # bindings: most of the re-observed features carry a map point, some clutter does too
+            bound = (seen & (rng.random(n) < min(1.0, bound_frac * 1.5))) | (~seen & (rng.random(n) < bound_frac * 0.3))
+            mp = np.where(bound, rng.integers(0, 1 << 30, n), -1).astype(np.int32)
+            out.append(dict(agent=a, keyframe_id=1000 * a + t, desc=desc, angle=angle,
+                            xy=rng.uniform(0, 752, (n, 2)).astype(np.float32), octave=rng.integers(0, 8, n).astype(np.int32),
+                            map_point_id=mp, valid=(mp >= 0).astype(np.uint8), place=place,
+                            Tcw=rng.normal(size=12).astype(np.float32)))
+    return out
