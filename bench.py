@@ -12,8 +12,9 @@ A step = ONE TRACKED FRAME of one agent, chained and device-resident (swarmmap_a
     new map points, and, every 5th frame, one local bundle adjustment of an LBA-M window (B1) on a local-mapping
     thread of the same GPU.  The image starts in pinned host memory: the upload is inside the step.
 Agents are independent: weak scaling, no per-frame collective.  Every `--exchange-every` frames
-the ranks all-gather their newest keyframe's descriptor slot over RCCL and brute-force match it (the cross-agent
-loop/merge candidate search); that exchange is inside the timed region.
+the ranks all-gather their newest keyframe's record over RCCL, append what they receive to a keyframe store in HBM and
+look their own keyframe up in the whole store (the cross-agent loop/merge candidate search of
+code/src/AgentMediator.cc:177-262); that exchange is inside the timed region.
 Rank 0 prints ONE JSON line; with one GPU it also carries `configs`: the KITTI-sized stream, LBA-S/M/L windows and
 global BA (BASELINE.json configs[3], configs[4]) measured once each after the headline region.
 """
@@ -37,6 +38,8 @@ from swarmmap_amd.replay import Replay  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_PEAK_TF = 78.6    # MI355X FP64 vector/matrix peak (AMD datasheet; not tabulated in the guide)
+INT_PEAK_TOPS = 78.6   # 32-bit integer VALU: 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops/s (the guide's execution model)
+STORE_KEYFRAMES = 4096  # keyframe store per rank: 8 agents x 512 keyframes (218 MB of records + 134 MB of search rows)
 # one LBA-M window per ~5 frames (SURVEY.md 8d end-to-end replay); the override is a diagnostic (no local mapping)
 LBA_EVERY = int(os.environ.get("SWARMORB_BENCH_LBA_EVERY", "5"))
 LOCAL_KEYFRAMES = 12   # local map = points created at the last 12 keyframes (~3-5 k map points)
@@ -204,10 +207,20 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
                     t_ += m_
                     if xchg is not None and a == 0 and (t_ - 1) % exchange_every == 0:
                         tx = time.perf_counter()
-                        xchg.tick(frame_handle=rp.last_dframe())  # slot filled from the frame's HBM descriptors
+                        # the frame tracked last goes out as a keyframe record assembled on the device (descriptors and
+                        # undistorted keypoints from HBM, map-point bindings from the tracker), every rank appends what
+                        # it receives to its keyframe store and looks its own keyframe up in the WHOLE store
+                        mp, Tcw = rp.last_bindings()
+                        cands = xchg.tick_keyframe(rp.last_dframe(), len(mp), agent_id=xchg.rank, keyframe_id=t_,
+                                                   map_point_id=mp, timestamp=t_ / 20.0, Tcw=Tcw, K=K)
                         if timed:
                             acc_x["n_xchg"] += 1
                             acc_x["xchg_ms"] += (time.perf_counter() - tx) * 1e3
+                            acc_x["xchg_candidates"] = acc_x.get("xchg_candidates", 0) + len(cands)
+                            st_x = xchg.store.last_stats()
+                            acc_x["xchg_scan_ms"] = acc_x.get("xchg_scan_ms", 0.0) + st_x["scan_ms"]
+                            acc_x["xchg_pairs"] = acc_x.get("xchg_pairs", 0.0) + st_x["pairs"]
+                            acc_x["xchg_store_keyframes"] = xchg.store.size()[0]
 
             rp.prime(0)
             run_span(0, warmup, False)
@@ -331,6 +344,68 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
     return rec, roof_fast, roof_pose
 
 
+def random_keyframe_records(rng, agents, per_agent, n_kp, bound_frac, first_agent=1):
+    """Version-2 keyframe records of random descriptors (no two keyframes look alike: the search finds no candidate and
+    the scan does all of its work), bound_frac of the keypoints carrying a map point."""
+    from swarmmap_amd.kfstore import pack_keyframe_record2
+    recs = []
+    for a in range(agents):
+        for k in range(per_agent):
+            mp = np.where(rng.random(n_kp) < bound_frac, rng.integers(0, 1 << 30, n_kp), -1).astype(np.int32)
+            recs.append(pack_keyframe_record2(first_agent + a, k, 0.0, np.zeros(12, np.float32), synth.EUROC_K,
+                                              rng.uniform(0, 752, (n_kp, 2)).astype(np.float32),
+                                              rng.uniform(0, 360, n_kp).astype(np.float32), rng.integers(0, 8, n_kp).astype(np.int32),
+                                              rng.integers(0, 256, (n_kp, 32), dtype=np.uint8), mp))
+    return recs
+
+
+def prefill_store(store, agents, per_agent, n_kp, bound_frac=0.4, seed=5):
+    rng = np.random.default_rng(seed)
+    for a in range(agents):
+        store.append(random_keyframe_records(rng, 1, per_agent, n_kp, bound_frac, first_agent=1 + a))
+
+
+def candidate_search_records(dev):
+    """SURVEY 8e / BASELINE configs[2]-[4]: the cross-agent candidate search on one GPU - a keyframe store as eight agents
+    fill it (512 keyframes each, 1000 keypoints, 40 % of them bound to map points; `dense`: every keypoint bound), one new
+    keyframe looked up in all of it.  The detection scan is the one throughput kernel of the path: its roofline is the
+    integer VALU rate (16 instructions per descriptor pair at least: 8 v_xor + 8 accumulating v_bcnt)."""
+    from swarmmap_amd.kfstore import KeyframeStore, search_params
+    out = {}
+    for name, per_agent, frac in (("store_8x512_kf_40pct_bound", 512, 0.4), ("store_8x128_kf_all_bound", 128, 1.0)):
+        rng = np.random.default_rng(11)
+        store = KeyframeStore(8 * per_agent, 1024, device=dev)
+        t0 = time.perf_counter()
+        for a in range(8):
+            store.append(random_keyframe_records(rng, 1, per_agent, 1000, frac, first_agent=1 + a))
+        fill_s = time.perf_counter() - t0
+        q = random_keyframe_records(rng, 1, 1, 1000, frac, first_agent=0)[0]
+        p = search_params()
+        for _ in range(3):
+            store.search(q, p, want_pairs=False)
+        scan, wall = [], []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            store.search(q, p, want_pairs=False)
+            wall.append(time.perf_counter() - t0)
+            scan.append(store.last_stats()["scan_ms"])
+        st = store.last_stats()
+        ms = float(np.median(scan))
+        ops = 16.0 * st["pairs"]
+        n_kf, n_desc = store.size()
+        out[name] = {"keyframes": n_kf, "store_descriptors": int(n_desc), "query_descriptors": int(st["pairs"] / max(n_desc, 1)),
+                     "descriptor_pairs": st["pairs"], "scan_kernel_ms": ms, "search_wall_ms": float(np.median(wall)) * 1e3,
+                     "keyframes_per_s": n_kf / (ms * 1e-3) if ms > 0 else 0.0, "store_fill_s": fill_s,
+                     "roofline": {"bound": "int-valu", "kernel": "kf_scan_kernel", "achieved": ops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                                  "peak": INT_PEAK_TOPS, "unit": "Tlane-op/s", "frac": ops / (ms * 1e-3) / 1e12 / INT_PEAK_TOPS if ms > 0 else 0.0,
+                                  "algorithmic_ops_per_pair": 16, "issued_ops_per_pair": 18,
+                                  "hbm_bytes_algorithmic": 32.0 * n_desc, "hbm_gbs": 32.0 * n_desc / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                                  "note": "256-bit Hamming distance = 8 v_xor + 8 v_bcnt (the popcount accumulates); best / "
+                                          "second add v_med3 + v_min; peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz"}}
+        store.close()
+    return out
+
+
 def lba_records(dev):
     """BASELINE configs[2]/[3] local-BA leg: LBA-S / LBA-M / LBA-L windows, wall time of one
     Optimizer::LocalBundleAdjustment through the C ABI (median of 5 after 2 warm-up calls)."""
@@ -447,9 +522,13 @@ def main():
     lba_window = synth.make_ba_case("LBA-M", seed=100 + rank)
     m1 = None
     xchg = None
-    if distributed:  # RCCL all-gather + matching behind the C ABI (so_exchange_*); torch.distributed only carries the id
-        from swarmmap_amd.exchange import DeviceExchange
-        xchg = DeviceExchange.from_process_group(dev, nfeatures + 24)
+    if distributed:  # RCCL all-gather + keyframe store + candidate search behind the C ABI (so_exchange_*);
+        from swarmmap_amd.exchange import StoreExchange  # torch.distributed only carries the communicator's id
+        xchg = StoreExchange.from_process_group(dev, nfeatures + 24, records_per_tick=1, store_keyframes=STORE_KEYFRAMES)
+        if world == 1:
+            # 1-rank self-test: nobody sends anything, so the store gets what seven peers would have sent by now
+            # (SWARMORB_BENCH_PREFILL keyframes each) - the scan inside the tick then has something to read
+            prefill_store(xchg.store, 7, int(os.environ.get("SWARMORB_BENCH_PREFILL", "64")), nfeatures)
 
     if args.lockstep and A > 1:
         dt, st, n_cand, frames, _ = run_fleet(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
@@ -507,7 +586,13 @@ def main():
                              "local-mapping thread, as in the reference" % (nfeatures, LBA_EVERY)) if euroc else
                             "KITTI-sized 1241x376 stream, nFeatures %d, same chained per-frame path" % nfeatures,
                 "agents": world * A, "lba_edges": int(len(lba_window["edge_pose"])),
-                "descriptor_exchanges": st.get("n_xchg", 0)}, **{k: v for k, v in rec.items() if k != "frames_per_s"}),
+                "descriptor_exchanges": st.get("n_xchg", 0),
+                "exchange": {"ticks": st.get("n_xchg", 0), "candidates": st.get("xchg_candidates", 0),
+                             "store_keyframes_at_end": st.get("xchg_store_keyframes", 0),
+                             "scan_kernel_ms_per_tick": st.get("xchg_scan_ms", 0.0) / max(st.get("n_xchg", 0), 1),
+                             "descriptor_pairs_per_tick": st.get("xchg_pairs", 0.0) / max(st.get("n_xchg", 0), 1),
+                             "wall_ms_per_tick": st.get("xchg_ms", 0.0) / max(st.get("n_xchg", 0), 1)}},
+                **{k: v for k, v in rec.items() if k != "frames_per_s"}),
             "roofline": ranked[0][1],
             "roofline_secondary": ranked[1][1],
             "roofline_tertiary": ranked[2][1],
@@ -527,6 +612,7 @@ def main():
                 krec["algorithmic_front_end_bytes_per_frame"] = 11.83e6
                 cfgs["kitti_stream_1241x376"] = krec
                 del kframes
+                cfgs["candidate_search"] = candidate_search_records(dev)
                 cfgs["local_ba_windows"] = lba_records(dev)
                 # GBA-1 / GBA-2: SURVEY 8d's sizes with every camera looking at one cloud (reduced system nearly dense);
                 # GBA-1r / GBA-2r: the same sizes as merged street-grid maps of 4 / 8 agents (banded + inter-agent links)

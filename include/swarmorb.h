@@ -594,6 +594,9 @@ int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stri
 int so_exchange_tick_keyframe(so_exchange* x, const so_dframe* f, const so_keyframe_header* hdr,
                               const int32_t* map_point_id, const so_kf_search_params* p, so_kf_candidate* out,
                               int32_t* pairs, int32_t* n_out);
+/* record `index` (< records_per_tick) of rank `peer` as the last tick's all-gather delivered it; *length = 0 for an
+ * unused position.  record may be NULL (length only). */
+int so_exchange_read_record(so_exchange* x, int peer, int index, uint8_t* record, size_t capacity, size_t* length);
 /* the store behind the communicator (owned by it; NULL for one made by so_exchange_create) */
 so_kfstore* so_exchange_store(so_exchange* x);
 

@@ -318,6 +318,24 @@ int so_exchange_create_store(int device, int rank, int world, const uint8_t* id1
 
 so_kfstore* so_exchange_store(so_exchange* x) { return x ? x->store : nullptr; }
 
+int so_exchange_read_record(so_exchange* x, int peer, int index, uint8_t* record, size_t capacity, size_t* length) {
+    if (!x || !x->store || peer < 0 || peer >= x->world || index < 0 || index >= x->records_per_tick || !length)
+        return SO_ERR_INVALID_ARG;
+    *length = 0;
+    const size_t j = (size_t)peer * (size_t)x->records_per_tick + (size_t)index;
+    if (x->hdrs.size() <= j) return SO_OK;  // no tick yet
+    const so_keyframe_header& h = x->hdrs[j];
+    if (h.magic == 0) return SO_OK;
+    if (h.n_keypoints < 0 || h.n_keypoints > x->slot_keypoints) return SO_ERR_INVALID_ARG;
+    const size_t bytes = h.version == 2 ? so_keyframe_record_size2(h.n_keypoints) : so_keyframe_record_size(h.n_keypoints);
+    *length = bytes;
+    if (!record) return SO_OK;
+    if (capacity < bytes) return SO_ERR_CAPACITY;
+    SO_HIP(hipSetDevice(x->device));
+    SO_HIP(hipMemcpy(record, x->d_rgathered + j * x->rec_stride, bytes, hipMemcpyDeviceToHost));
+    return SO_OK;
+}
+
 int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stride, int32_t n_records,
                              const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs, int32_t* n_out) {
     if (!x || !x->store || !p || n_records < 0 || n_records > x->records_per_tick || p->max_candidates < 0 ||

@@ -347,7 +347,9 @@ void launch_kf_pack_record(const uint8_t* d_desc, const float2* d_xy_un, const i
 void launch_kf_scan(const KfStoreDev& S, int n_slots, const uint32_t* d_qdesc, int nqv, int query_agent, int th_low,
                     float nn_ratio, int32_t* d_votes, int qper, hipStream_t s) {
     if (n_slots <= 0 || nqv <= 0) return;
-    if (qper != 1 && qper != 2 && qper != 4) qper = nqv > 1024 ? 4 : nqv > 256 ? 2 : 1;
+    // one query row per lane measures best or equal at every size tried (tools/kfscan_bench.py): the scalar row loads are
+    // not what bounds the kernel, and fewer rows per lane leave fewer idle lanes in the last wave
+    if (qper != 1 && qper != 2 && qper != 4) qper = 1;
     const int chunks = (nqv + 256 * qper - 1) / (256 * qper);
     const int grid = (n_slots * chunks + 7) / 8 * 8;
 #define SO_KF_SCAN(Q)                                                                                                  \

@@ -26,6 +26,7 @@ def _bind(lib):
     lib.so_exchange_tick_records.argtypes = [vp, vp, C.c_size_t, C.c_int32, vp, vp, vp, vp]
     lib.so_exchange_tick_keyframe.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.so_exchange_store.argtypes = [vp]
+    lib.so_exchange_read_record.argtypes = [vp, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.so_exchange_store.restype = vp
     lib._exchange_bound = True
 
@@ -147,6 +148,16 @@ class StoreExchange:
             pj = pairs[j * mc * self.slot_keypoints:(j + 1) * mc * self.slot_keypoints] if want_pairs else None
             res.append(kfstore.candidates_to_list(out[j * mc:(j + 1) * mc], int(n_out[j]), pj, nq))
         return res
+
+    def read_record(self, peer, index):
+        """Record `index` of rank `peer` as the last tick delivered it (None for an unused position)."""
+        ln = C.c_size_t(0)
+        _lib.check(self._lib.so_exchange_read_record(self._h, int(peer), int(index), None, 0, C.byref(ln)))
+        if ln.value == 0:
+            return None
+        rec = np.zeros(ln.value, np.uint8)
+        _lib.check(self._lib.so_exchange_read_record(self._h, int(peer), int(index), rec.ctypes.data, rec.nbytes, C.byref(ln)))
+        return rec
 
     def tick_keyframe(self, frame_handle, n_keypoints, agent_id, keyframe_id, map_point_id, timestamp=0.0, Tcw=None, K=None,
                       params=None, want_pairs=False):

@@ -897,6 +897,16 @@ int so_replay_last_frame(so_replay* r, const uint8_t** desc, int* n) {
     *n = r->fh[r->cur].n;
     return SO_OK;
 }
+// keypoint -> map slot bindings of the frame tracked last (-1: none; what mvpMapPoints holds when the frame becomes a
+// keyframe, code/src/KeyFrame.cc:47) and its pose: the per-keypoint block of the keyframe record the exchange sends
+int so_replay_last_bindings(so_replay* r, const int32_t** kp_mp, int* n, float* Tcw12) {
+    if (!r || !kp_mp || !n) return SO_ERR_INVALID_ARG;
+    const so_replay::FrameHost& F = r->fh[r->cur];
+    *kp_mp = F.kp_mp.data();
+    *n = std::min(F.n, (int)F.kp_mp.size());
+    if (Tcw12 && !r->poses.empty()) memcpy(Tcw12, r->poses.data() + r->poses.size() - 12, sizeof(float) * 12);
+    return SO_OK;
+}
 // the device-resident frame tracked last (the exchange fills its slot from it without a host hop)
 so_dframe* so_replay_last_dframe(so_replay* r) {
     if (!r || r->n_tracked == 0 || r->last_tracked < 0) return nullptr;

@@ -95,7 +95,7 @@ class KeyframeExchange:
     testable without GPUs.  A slot holds 1 header row + slot_keypoints descriptor rows of 32 B; pass
     record_keypoints = n to size it for whole keyframe RECORDS of up to n keypoints instead (128 + 48 n bytes)."""
 
-    def __init__(self, slot_keypoints=2024, device=None, group=None, record_keypoints=None):
+    def __init__(self, slot_keypoints=2024, device=None, group=None, record_keypoints=None, slot_bytes=None):
         if not dist.is_initialized():
             raise RuntimeError("KeyframeExchange needs an initialised torch.distributed process group")
         self.group = group
@@ -105,6 +105,8 @@ class KeyframeExchange:
         if record_keypoints is not None:  # rows needed by a record of that many keypoints (header 128 B + 48 B each)
             need = RECORD_HEADER_BYTES + 48 * int(record_keypoints)
             self.slot_keypoints = max(self.slot_keypoints if slot_keypoints != 2024 else 0, (need + 31) // 32 - HEADER_ROWS)
+        if slot_bytes is not None:  # an explicit slot size (records_per_tick x record stride of so_exchange_create_store)
+            self.slot_keypoints = (int(slot_bytes) + 31) // 32 - HEADER_ROWS
         on_gpu = dist.get_backend(group) == "nccl"
         self.device = torch.device("cuda", device if device is not None else torch.cuda.current_device()) \
             if on_gpu else torch.device("cpu")
@@ -174,4 +176,36 @@ class KeyframeExchange:
         out = []
         for r in range(self.world):
             out.append(unpack_keyframe_record(flat[r]) if flat[r, :4].tobytes() == b"SOKF" else None)
+        return out
+
+    # ---- the payload of so_exchange_tick_records: records_per_tick fixed-stride record positions per rank ----
+    @staticmethod
+    def record_stride(slot_keypoints):
+        """Stride of a record position = so_keyframe_record_size2(slot_keypoints) rounded up to 256 (kfstore.cpp)."""
+        return (((RECORD_HEADER_BYTES + 52 * int(slot_keypoints) + 31) // 32 * 32) + 255) // 256 * 256
+
+    def exchange_record_slots(self, records, records_per_tick, stride):
+        """All-gather up to records_per_tick version-1/2 records of this rank.  Returns [rank][position] -> raw record
+        bytes (uint8 array) or None for an unused position - what every rank's store append sees."""
+        K, stride = int(records_per_tick), int(stride)
+        assert len(records) <= K and self.slot.numel() >= K * stride
+        hs = self._host_slot.numpy().reshape(-1)
+        hs[:] = 0
+        for j, r in enumerate(records):
+            r = np.ascontiguousarray(r, np.uint8).reshape(-1)
+            assert r.nbytes <= stride
+            hs[j * stride:j * stride + r.nbytes] = r
+        self.slot.copy_(self._host_slot, non_blocking=True)
+        if self.device.type == "cuda":
+            dist.all_gather_into_tensor(self.gathered, self.slot, group=self.group)
+        else:
+            dist.all_gather(list(self.gathered.unbind(0)), self.slot, group=self.group)
+        flat = self.gathered.reshape(self.world, -1).cpu().numpy()
+        out = []
+        for r in range(self.world):
+            row = []
+            for j in range(K):
+                rec = flat[r, j * stride:(j + 1) * stride]
+                row.append(rec.copy() if rec[:4].tobytes() == b"SOKF" else None)
+            out.append(row)
         return out

@@ -137,6 +137,16 @@ class Replay:
         """so_dframe handle of the frame tracked last (device-resident descriptors for the exchange tick)."""
         return C.c_void_p(self.lib.so_replay_last_dframe(self.h))
 
+    def last_bindings(self):
+        """(keypoint -> map slot of the frame tracked last, -1 = none; its pose Tcw as 12 floats)."""
+        ptr, n = C.c_void_p(), C.c_int(0)
+        T = np.zeros(12, np.float32)
+        self.lib.so_replay_last_bindings.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]
+        self._check(self.lib.so_replay_last_bindings(self.h, C.byref(ptr), C.byref(n), self._p(T)), "last_bindings")
+        if n.value <= 0:
+            return np.zeros(0, np.int32), T
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), (n.value,)).copy(), T
+
     def candidates_total(self, nlevels=8, cap=10000):
         exh = self.lib.so_replay_extractor(self.h)
         base = _lib.load_library()

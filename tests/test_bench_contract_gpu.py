@@ -32,3 +32,21 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and "sample" in c
     assert d["value"] > 10 * c["value"]
+
+
+def test_bench_distributed_branch_runs_on_one_rank():
+    """The code the driver's 8-GPU run takes, on one GPU: process group ("nccl" = RCCL), the store exchange behind the
+    C ABI with its ticks INSIDE the timed region, the all_reduce of the elapsed time, the JSON line as the last line of
+    stdout.  With one rank nobody sends keyframes, so bench.py fills the store with what seven peers would have sent:
+    the scan inside every tick has 7 x 16 keyframes to read.  (Reference: one process per agent,
+    code/Examples/Monocular/swarm_map.cc:329-337.)  No scaling curve exists: the lease has one GPU."""
+    env = dict(os.environ, SWARMORB_BENCH_FORCE_DIST="1", SWARMORB_BENCH_PREFILL="16", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "8",
+                                   "--no-configs", "--no-cpu-baseline"], text=True, cwd=ROOT, timeout=900, env=env)
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["value"] > 100
+    x = d["config"]["exchange"]
+    assert d["config"]["descriptor_exchanges"] == x["ticks"] >= 2
+    assert x["store_keyframes_at_end"] == 7 * 16 and x["descriptor_pairs_per_tick"] > 1e6 and x["scan_kernel_ms_per_tick"] > 0
+    assert x["candidates"] == 0  # random peers: nothing looks like the stream

@@ -77,6 +77,41 @@ def test_keyframe_record_round_trip_and_corruption():
         unpack_keyframe_record(np.zeros(128, np.uint8))
 
 
+def test_keyframe_record_v2_round_trip_and_corruption():
+    """Version 2 = version 1 + the map-point id of every keypoint: same descriptor / geometry blocks at the same
+    offsets, ids behind them, length a multiple of 32, header counts the bound keypoints; version-1 records stay
+    readable by the version-2 reader (every keypoint counts as bound)."""
+    import numpy as np
+    import pytest
+    import swarmmap_amd
+    from swarmmap_amd.kfstore import pack_keyframe_record2, record_size2, unpack_keyframe_record2
+    from swarmmap_amd.parallel import pack_keyframe_record
+    rng = np.random.default_rng(6)
+    for n in (0, 1, 7, 1000):
+        xy = rng.uniform(0, 752, (n, 2)).astype(np.float32)
+        ang = rng.uniform(0, 360, n).astype(np.float32)
+        octv = rng.integers(0, 8, n).astype(np.int32)
+        desc = rng.integers(0, 256, (n, 32)).astype(np.uint8)
+        mp = np.where(rng.random(n) < 0.5, rng.integers(0, 1 << 30, n), -1).astype(np.int32)
+        T = rng.normal(size=12).astype(np.float32)
+        rec = pack_keyframe_record2(3, 2 ** 40 + 7, 12.5, T, (1, 2, 3, 4), xy, ang, octv, desc, mp)
+        assert rec.nbytes == record_size2(n) == (128 + 52 * n + 31) // 32 * 32
+        v1 = pack_keyframe_record(3, 2 ** 40 + 7, 12.5, T, (1, 2, 3, 4), xy, ang, octv, desc)
+        assert np.array_equal(rec[128:128 + 48 * n], v1[128:])  # descriptor and geometry blocks are version 1's
+        assert np.array_equal(rec[128 + 48 * n:128 + 52 * n].view(np.int32), mp) and not rec[128 + 52 * n:].any()
+        u = unpack_keyframe_record2(rec)
+        assert u["version"] == 2 and u["n_map_points"] == int((mp >= 0).sum()) and u["agent_id"] == 3
+        for k, want in (("xy", xy), ("angle", ang), ("octave", octv), ("desc", desc), ("map_point_id", mp), ("Tcw", T)):
+            assert np.array_equal(u[k], want), k
+        u1 = unpack_keyframe_record2(v1)
+        assert u1["version"] == 1 and (u1["map_point_id"] == 0).all() and np.array_equal(u1["desc"], desc)
+        if n:
+            bad = rec.copy()
+            bad[128 + 48 * n] ^= 1  # a flipped binding is caught by the checksum
+            with pytest.raises(swarmmap_amd.SwarmOrbError):
+                unpack_keyframe_record2(bad)
+
+
 def test_replay_library_loads_and_exports():
     """The C++ host loop of bench.py (swarmmap_amd/host/replay.cc) is built next to the C-ABI library."""
     import ctypes
@@ -87,5 +122,6 @@ def test_replay_library_loads_and_exports():
     lib = ctypes.CDLL(os.path.join(root, "swarmmap_amd", "libswarmorb_replay.so"))
     for name in ("so_replay_create", "so_replay_destroy", "so_replay_set_frames", "so_replay_set_window",
                  "so_replay_preallocate", "so_replay_prime", "so_replay_run", "so_replay_drain", "so_replay_finish",
-                 "so_replay_stats", "so_replay_log", "so_replay_log_size", "so_replay_frame_ms", "so_replay_last_frame", "so_replay_last_dframe"):
+                 "so_replay_stats", "so_replay_log", "so_replay_log_size", "so_replay_frame_ms", "so_replay_last_frame", "so_replay_last_dframe",
+                 "so_replay_last_bindings"):
         assert hasattr(lib, name), name

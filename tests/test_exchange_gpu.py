@@ -1,7 +1,7 @@
 """The RCCL leg of the cross-agent exchange through the C ABI (so_exchange_*), on one GPU: a world of one rank runs
-the real ncclCommInitRank / ncclAllGather / slot fill / header read-back code; payload semantics across ranks are
-covered by the world-size-2 gloo test (tests/test_exchange_gloo.py), and two communicators in ONE process exercise the
-all-gather with more than one slot where two devices are visible."""
+the real ncclCommInitRank / ncclAllGather / slot fill / header read-back / store append / search code; payload
+semantics across ranks are covered by the world-size-2 gloo test (tests/test_exchange_gloo.py).  More than one rank
+has not run on hardware (the builder's lease has one GPU)."""
 import numpy as np
 import pytest
 
@@ -45,3 +45,76 @@ def test_unique_ids_differ_and_bad_arguments_fail(S):
     assert a.nbytes == 128 and not np.array_equal(a, b)
     with pytest.raises(S.SwarmOrbError):
         DeviceExchange(0, 2, 1, a, 64)  # rank outside the world
+
+
+K_EUROC = (458.654, 457.296, 367.215, 248.375)
+
+
+def _rec(kf):
+    from swarmmap_amd.kfstore import pack_keyframe_record2
+    return pack_keyframe_record2(kf["agent"], kf["keyframe_id"], 0.0, kf["Tcw"], K_EUROC, kf["xy"], kf["angle"], kf["octave"],
+                                 kf["desc"], kf["map_point_id"])
+
+
+def test_store_exchange_single_rank_searches_the_whole_store(S):
+    """so_exchange_tick_records with one rank: the rank's own records travel through ncclAllGather and are NOT stored
+    (the store holds the peers' keyframes); what the peers sent earlier - put there through the store handle, as an
+    earlier tick's append would have - is searched in full: candidates and pairs identical to the oracle, including
+    keyframes that arrived many ticks before the query."""
+    from oracle import oracle_py
+    from swarmmap_amd.exchange import StoreExchange, unique_id
+    from swarmmap_amd.kfstore import search_params
+    kfs = synth.make_kf_store_case(55, n_agents=3, kfs_per_agent=12, n_kp=300, n_places=5)
+    mine = [k for k in kfs if k["agent"] == 0]
+    peers = [k for k in kfs if k["agent"] != 0]
+    x = StoreExchange(0, 0, 1, unique_id(), slot_keypoints=300, records_per_tick=4, store_keyframes=64)
+    x.store.append([_rec(k) for k in peers])
+    p = search_params(min_votes=15, min_matches=15, max_candidates=8)
+    total = 0
+    for base in range(0, len(mine), 3):  # three new keyframes per tick, then an empty tick
+        chunk = mine[base:base + 3]
+        res = x.tick_records([_rec(k) for k in chunk], p)
+        assert len(res) == len(chunk)
+        for q, got in zip(chunk, res):
+            _, ocands, _ = oracle_py.kf_search(q, peers, min_votes=15, min_matches=15, max_candidates=8)
+            assert [(c["slot"], c["votes"], c["n_matches"]) for c in got] == [(s, v, nm) for s, v, nm, _ in ocands]
+            for c, oc in zip(got, ocands):
+                assert np.array_equal(c["match_of_1"], oc[3])
+            total += len(got)
+    assert x.tick_records([], p) == []
+    assert total > 0 and x.store.size()[0] == len(peers)  # own keyframes were not appended
+    x.close()
+
+
+def test_store_exchange_keyframe_assembled_on_the_device(S):
+    """so_exchange_tick_keyframe: the record of a device-resident frame (descriptors, undistorted keypoints, octaves
+    from HBM; angles and bindings staged) equals the host-packed record, and its search equals the store's own."""
+    from swarmmap_amd.exchange import StoreExchange, unique_id
+    from swarmmap_amd.kfstore import pack_keyframe_record2, search_params, unpack_keyframe_record2
+    ex = S.ORBextractor(1000, 1.2, 8, 20, 7)
+    f = S.DeviceFrame(ex, synth.EUROC_K, synth.EUROC_DIST)
+    img = synth.make_canvas(3, 752, 480)
+    kps, un, d = [a.copy() for a in f(img)]
+    n = len(kps)
+    rng = np.random.default_rng(4)
+    mp = np.where(rng.random(n) < 0.5, rng.integers(0, 1 << 20, n), -1).astype(np.int32)
+    x = StoreExchange(0, 0, 1, unique_id(), slot_keypoints=1024, records_per_tick=2, store_keyframes=16)
+    # a peer saw the same image (its keyframe is in the store), another one saw something else
+    twin = pack_keyframe_record2(1, 500, 0.0, np.zeros(12), K_EUROC, un, kps["angle"], kps["octave"], d, mp)
+    kps2, un2, d2 = [a.copy() for a in f(synth.make_canvas(8, 752, 480))]
+    other = pack_keyframe_record2(2, 501, 0.0, np.zeros(12), K_EUROC, un2, kps2["angle"], kps2["octave"], d2,
+                                  np.zeros(len(kps2), np.int32))
+    x.store.append([other, twin])
+    kps_b, _, _ = f(img)  # the frame the tick reads is the one tracked last
+    assert len(kps_b) == n
+    Tcw = np.arange(12, dtype=np.float32)
+    got = x.tick_keyframe(f._h, n, agent_id=0, keyframe_id=77, map_point_id=mp, timestamp=1.5, Tcw=Tcw, K=K_EUROC,
+                          params=search_params(), want_pairs=True)
+    # the record the kernel assembled = the record the host would have packed from the frame's host mirrors
+    want = pack_keyframe_record2(0, 77, 1.5, Tcw, K_EUROC, un, kps["angle"], kps["octave"], d, mp)
+    assert np.array_equal(x.read_record(0, 0), want) and x.read_record(0, 1) is None
+    assert unpack_keyframe_record2(want)["n_map_points"] == int((mp >= 0).sum())
+    nb = int((mp >= 0).sum())
+    assert len(got) == 1 and got[0]["slot"] == 1 and got[0]["keyframe_id"] == 500 and got[0]["n_matches"] == nb
+    assert np.array_equal(got[0]["match_of_1"][:n][mp >= 0], np.nonzero(mp >= 0)[0])
+    f.close(); ex.close(); x.close()
