@@ -41,6 +41,10 @@ int so_device_count(void);
  * SEVERAL agents in lockstep wants their launches to overlap: after so_runtime_private_streams(1) every extractor and
  * matcher created (by any thread) gets a stream of its own. */
 int so_runtime_private_streams(int enabled);
+/* Diagnostic load: `workgroups` workgroups that pin `lds_bytes` of LDS each (152 KB = a whole CU) and busy-wait for
+ * `milliseconds`, on a stream of their own; returns as soon as the launch is queued.  What a second process on the GPU
+ * looks like to the single-launch bundle-adjustment solves, whose workgroups must all be resident (tests). */
+int so_runtime_occupy(int device, int workgroups, int lds_bytes, int milliseconds);
 
 /* ------------------------------------------------------------------------------------------------
  * ORB extractor  — replaces ORB_SLAM2::ORBextractor (code/include/ORBextractor.h:49-127,
@@ -654,6 +658,11 @@ typedef struct {
      * the device can keep them all resident) */
     int32_t solver_path;
     int32_t n_free_keyframes; /* keyframes that got a hessian index: not fixed and observed by at least one edge */
+    /* single-launch solves of this solver context whose workgroups gave up waiting for each other (the launch was not
+     * fully resident: another process on the GPU, a CU mask); the call was then repeated on the multi-launch path, which
+     * the context keeps from then on (solver_path 1) */
+    int32_t flow_timeouts;
+    int32_t reserved;
 } so_ba_info;
 
 int so_ba_create(int device, so_ba** out);

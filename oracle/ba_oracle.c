@@ -278,28 +278,47 @@ static void build_system(ba* s) {
 }
 
 static int cholesky_solve(double* S, double* rhs, int n) { /* in place; returns 0 on a non-positive pivot */
+    /* first[i] = first structurally nonzero column of row i.  Cholesky fill stays inside this row envelope, so every
+     * product the loops below skip has an exact zero factor: the result is bit-identical to the full loops (what
+     * LinearSolverEigen's SimplicialLDLT does with its elimination tree, linear_solver_eigen.h:147-232), and a merged
+     * multi-agent map (block-banded, GBA-2r) costs a fifth of the dense count.  (tools/make_gba_golden.py) */
+    int* first = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        int f = 0;
+        while (f < i && S[i * (size_t)n + f] == 0.0) f++;
+        first[i] = f;
+    }
     for (int j = 0; j < n; j++) {
-        double d = S[j * n + j];
-        for (int k = 0; k < j; k++) d -= S[j * n + k] * S[j * n + k];
-        if (!(d > 0.0)) return 0;
+        double d = S[j * (size_t)n + j];
+        for (int k = first[j]; k < j; k++) d -= S[j * (size_t)n + k] * S[j * (size_t)n + k];
+        if (!(d > 0.0)) {
+            free(first);
+            return 0;
+        }
         d = sqrt(d);
-        S[j * n + j] = d;
+        S[j * (size_t)n + j] = d;
         for (int i = j + 1; i < n; i++) {
-            double v = S[i * n + j];
-            for (int k = 0; k < j; k++) v -= S[i * n + k] * S[j * n + k];
-            S[i * n + j] = v / d;
+            if (first[i] > j) continue; /* S[i][j] is a structural zero and stays one */
+            double v = S[i * (size_t)n + j];
+            const int k0 = first[i] > first[j] ? first[i] : first[j];
+            for (int k = k0; k < j; k++) v -= S[i * (size_t)n + k] * S[j * (size_t)n + k];
+            S[i * (size_t)n + j] = v / d;
         }
     }
     for (int i = 0; i < n; i++) {
         double v = rhs[i];
-        for (int k = 0; k < i; k++) v -= S[i * n + k] * rhs[k];
-        rhs[i] = v / S[i * n + i];
+        for (int k = first[i]; k < i; k++) v -= S[i * (size_t)n + k] * rhs[k];
+        rhs[i] = v / S[i * (size_t)n + i];
     }
     for (int i = n - 1; i >= 0; i--) {
         double v = rhs[i];
-        for (int k = i + 1; k < n; k++) v -= S[k * n + i] * rhs[k];
-        rhs[i] = v / S[i * n + i];
+        for (int k = i + 1; k < n; k++) {
+            if (first[k] > i) continue;
+            v -= S[k * (size_t)n + i] * rhs[k];
+        }
+        rhs[i] = v / S[i * (size_t)n + i];
     }
+    free(first);
     return 1;
 }
 

@@ -71,10 +71,11 @@ int flow_resident_budget(int device) {
     if (device < 0 || device >= 64) return 0;
     int v = cached[device].load();
     if (v != 0) return v > 0 ? v : 0;
-    hipDeviceProp_t prop;
+    // what the runtime's occupancy calculator says the device can hold of these kernels (0: a workgroup does not fit a CU)
     int budget = -1;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor >= (size_t)156 * 1024)
-        budget = std::max(prop.multiProcessorCount - 32, 0);  // 32 CUs stay with the tracking threads (quadtree alone wants 8 whole CUs)
+    const int capacity = dense_flow_resident_capacity(device);
+    if (capacity > 0) budget = std::max(capacity - 32, 0);  // 32 CUs stay with the tracking threads (quadtree alone wants 8 whole CUs)
+    if (const char* e = getenv("SWARMORB_FLOW_BUDGET")) budget = atoi(e);  // diagnostic: claim more (or less) than the device has
     if (budget <= 0) budget = -1;
     cached[device].store(budget);
     return budget > 0 ? budget : 0;
@@ -227,6 +228,10 @@ struct so_ba {
     DensePlan plan;                         // blocked solver: tiles of every trailing update for the current structure
     StagingPool staging;                    // host threads of the problem staging (started on demand)
     unsigned flow_epoch = 0;                // single-launch dataflow solve: stamp of the last solve (never reset)
+    unsigned* h_flow_abort = nullptr;       // host-mapped: stamped by a dataflow workgroup whose wait outlasted its budget
+    unsigned* h_flow_abort_dev = nullptr;
+    bool flow_broken = false;               // a dataflow solve of this context timed out: chain of launches from now on
+    int flow_timeouts = 0;
     int flow_reserved = 0;                  // tiles this context holds of the process-wide residency budget
     std::vector<int> tile_first;
     BaLm* h_lm = nullptr;        // host-mapped copy of the LM state, written by the decision kernels
@@ -287,6 +292,11 @@ struct Run {
     bool terminate() const { return stop && *stop; }
 };
 
+// internal status of so_bundle_adjust's first attempt: a workgroup of a single-launch (dataflow) solve waited longer than
+// its budget for another one - the launch was not fully resident (another process on the GPU, a CU mask, ...).  The call
+// is repeated on the chain-of-launches path; never returned to the caller.
+constexpr int kErrFlowTimeout = 1000;
+
 // Wait for the stream; with a forceStopFlag, poll it meanwhile and forward it to the device.
 int wait_stream(Run& r) {
     hipStream_t s = r.b->stream;
@@ -332,6 +342,7 @@ int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
         }
         SO_HIP(hipGetLastError());
         if ((rc = wait_stream(r))) return rc;
+        if (*(volatile unsigned*)b->h_flow_abort != 0) return kErrFlowTimeout;  // a dataflow solve gave up waiting
         memcpy(&lm, b->h_lm, sizeof(lm));
         if (!lm.active) break;
         budget = std::max(1, lm.iterations - lm.it);
@@ -375,6 +386,9 @@ int so_ba_create(int device, so_ba** out) {
         if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_lm, sizeof(BaLm), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&b->h_lm_dev, b->h_lm, 0);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_flow_abort, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&b->h_flow_abort_dev, b->h_flow_abort, 0);
+    if (e == hipSuccess) *b->h_flow_abort = 0;
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_abort, 64, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&b->h_abort_dev, b->h_abort, 0);
     if (e != hipSuccess) {
@@ -395,6 +409,7 @@ void so_ba_destroy(so_ba* b) {
         if (e) (void)hipEventDestroy(e);
     if (b->dense_side) (void)hipStreamDestroy(b->dense_side);
     if (b->h_lm) (void)hipHostFree(b->h_lm);
+    if (b->h_flow_abort) (void)hipHostFree(b->h_flow_abort);
     if (b->h_in) (void)hipHostFree(b->h_in);
     if (b->h_out) (void)hipHostFree(b->h_out);
     if (b->h_plan) (void)hipHostFree(b->h_plan);
@@ -428,8 +443,46 @@ void so_ba_options_global(so_ba_options* o, int32_t n_iterations, int32_t robust
     o->chi2_threshold = 5.991f;
 }
 
+// Diagnostic: keep `workgroups` workgroups of `lds_bytes` LDS each busy-waiting for `milliseconds` on a stream of their
+// own (asynchronous: returns once the launch is queued; the memory behind it lives as long as the process).
+int so_runtime_occupy(int device, int workgroups, int lds_bytes, int milliseconds) {
+    static hipStream_t stream[64] = {nullptr};
+    static unsigned* sink[64] = {nullptr};
+    if (device < 0 || device >= 64) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(device));
+    if (!stream[device]) {
+        SO_HIP(hipStreamCreateWithFlags(&stream[device], hipStreamNonBlocking));
+        SO_HIP(hipMalloc((void**)&sink[device], 64));
+    }
+    return launch_occupy(workgroups, lds_bytes, milliseconds, sink[device], stream[device]) ? SO_OK : SO_ERR_INVALID_ARG;
+}
+
+static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_options* opt, const volatile uint8_t* stop,
+                              float* Tcw_out, float* Xw_out, uint8_t* edge_outlier, double* edge_chi2, so_ba_info* info);
+
 int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt, const volatile uint8_t* stop,
                      float* Tcw_out, float* Xw_out, uint8_t* edge_outlier, double* edge_chi2, so_ba_info* info) {
+    int rc = bundle_adjust_once(b, p, opt, stop, Tcw_out, Xw_out, edge_outlier, edge_chi2, info);
+    if (rc == kErrFlowTimeout) {
+        // The single-launch solve was not fully resident and its workgroups gave up waiting for each other (the kernels
+        // have run to their end: the stream is drained).  Nothing has been written to the caller's arrays; the inputs
+        // are untouched.  This context solves with the chain of launches from now on, starting with this very call.
+        b->flow_broken = true;
+        b->flow_timeouts++;
+        fprintf(stderr, "[swarmorb] bundle adjustment: the single-launch solve timed out waiting for a workgroup that was "
+                        "not resident (is another process using the GPU?); repeating the call on the multi-launch path, "
+                        "which this solver context keeps from now on (SWARMORB_DENSE_NO_FLOW=1 selects it up front)\n");
+        rc = bundle_adjust_once(b, p, opt, stop, Tcw_out, Xw_out, edge_outlier, edge_chi2, info);
+        if (rc == kErrFlowTimeout) {  // cannot happen: the second attempt launches no dataflow kernel
+            last_error_ref() = "bundle adjustment: dataflow solve timed out twice";
+            rc = SO_ERR_HIP;
+        }
+    }
+    return rc;
+}
+
+static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_options* opt, const volatile uint8_t* stop,
+                              float* Tcw_out, float* Xw_out, uint8_t* edge_outlier, double* edge_chi2, so_ba_info* info) {
     if (!b || !p || !opt || !Tcw_out || !Xw_out) return SO_ERR_INVALID_ARG;
     if (p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0) return SO_ERR_INVALID_ARG;
     if ((p->n_poses > 0 && (!p->Tcw || !p->fixed || !p->intr)) || (p->n_points > 0 && !p->Xw) ||
@@ -445,6 +498,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     SO_HIP(hipSetDevice(b->device));
     b->solve_ms = 0.f;
     b->n_solves = 0;
+    *(volatile unsigned*)b->h_flow_abort = 0;
     so_ba_info inf;
     memset(&inf, 0, sizeof(inf));
     Run r;
@@ -801,7 +855,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
             static const bool no_flow = getenv("SWARMORB_DENSE_NO_FLOW") != nullptr, no_flow_big = getenv("SWARMORB_DENSE_NO_FLOW_BIG") != nullptr;
             static const int flow_max = getenv("SWARMORB_DENSE_FLOW_MAX_TILES") ? atoi(getenv("SWARMORB_DENSE_FLOW_MAX_TILES")) : kFlowDefaultMaxTiles;
             const bool big = !(T <= 21 && nnz <= std::min(flow_max, dense_flow_max_tiles()));
-            if (no_flow || (big && no_flow_big)) {
+            if (no_flow || b->flow_broken || (big && no_flow_big)) {
             } else if (!big) {  // a workgroup per tile: all or nothing
                 const int want = (int)nnz;
                 int cur = g_flow_tiles.load();
@@ -931,6 +985,11 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
     d.flow_flags = !flow ? nullptr : flow_big ? b->d_flow_big.as<unsigned>() : b->d_flow.as<unsigned>();
     d.flow_vec = flow && !flow_big ? reinterpret_cast<double*>(b->d_flow.as<unsigned>() + kFlowFlagWords) : nullptr;
     d.flow_epoch = &b->flow_epoch;
+    d.flow_abort_host = b->h_flow_abort_dev;
+    {
+        static const double timeout_ms = getenv("SWARMORB_FLOW_TIMEOUT_MS") ? atof(getenv("SWARMORB_FLOW_TIMEOUT_MS")) : 500.0;
+        d.flow_timeout_ticks = (unsigned long long)(timeout_ms * 1e5);  // wall_clock64() counts at 100 MHz
+    }
     d.flow_nslots = flow_big ? (int)((ldS / 96) * (ldS / 96 + 1) / 2) : 0;
     d.flow_grid = flow_big ? b->flow_reserved : 0;
     d.xl = b->d_xl.as<double>();
@@ -1007,6 +1066,7 @@ int so_bundle_adjust(so_ba* b, const so_ba_problem* p, const so_ba_options* opt,
         inf.solver_path = r.d.flow_tiles ? 2 : 1;
     }
     inf.n_free_keyframes = r.n_free;
+    inf.flow_timeouts = b->flow_timeouts;
     inf.wall_ms = (float)(now_ms() - t_begin);
     if (trace)
         fprintf(stderr, "[ba] stage %.3f upload+alloc %.3f opt1 %.3f (%d it) opt2 %.3f (%d it) finish %.3f | trials %d blocks %d\n",

@@ -891,10 +891,10 @@ constexpr int kFlowDiagLeadDefault = 12, kFlowDiagLeadMax = 32;  // ticketed ker
 constexpr int kFlowMaxTiles = 231;   // 21 panels dense (2016 unknowns, 336 keyframes); a skyline may reach further
 constexpr int kFlowSlots = 256;      // flag / vector slots per kind: tile (I, J) -> I (I + 1) / 2 + J
 constexpr int kFlowFlagTile = 0, kFlowFlagFwd = kFlowSlots, kFlowFlagY = 2 * kFlowSlots, kFlowFlagX = 2 * kFlowSlots + 32,
-              kFlowFlagBad = 2 * kFlowSlots + 64;
+              kFlowFlagBad = 2 * kFlowSlots + 64, kFlowFlagAbort = 2 * kFlowSlots + 65;
 constexpr int kFlowLdsDoubles = 2 * kDNB * kDStride + kDNB * kPS;  // GEMM chunks + one full tile >= the factor's A and X
 static_assert(kFlowLdsDoubles >= 2 * kDNB * kPS, "potrf_block_lds needs two padded blocks");
-static_assert(kFlowFlagBad < kFlowFlagWords, "flag words");
+static_assert(kFlowFlagAbort < kFlowFlagWords, "flag words");
 static_assert(kFlowMaxTiles <= kFlowSlots && 22 * 21 / 2 <= kFlowSlots, "tile slots");
 
 // -DSO_FLOW_PROBE (developer builds only): wall-clock marks per workgroup and stage, read back by tools/flow_probe.py
@@ -915,8 +915,47 @@ __device__ unsigned long long g_flow_diag[10][512];  // per block column: factor
 __device__ __forceinline__ bool flow_ready(const unsigned* f, unsigned epoch) {
     return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
 }
-__device__ __forceinline__ void flow_wait(const unsigned* f, unsigned epoch) {  // one thread; flow_acquire() after the barrier
-    while (!flow_ready(f, epoch)) __builtin_amdgcn_s_sleep(1);
+// Every wait of the dataflow kernels is bounded.  The workgroups of a launch wait for each other, so all of them must be
+// resident; the host checks that with the runtime's occupancy figure and its own budget (ba.cpp), but neither sees another
+// process on the GPU, a CU mask or a device whose partitioning changed.  So a wait that lasts longer than the budget
+// (wall clock, d.flow_timeout_ticks at 100 MHz) raises the ABORT stamp of this solve - in the flag block, for the other
+// workgroups, and in host-mapped memory, for the host - and returns; from then on every wait of every workgroup returns
+// at once (after at most 256 polls), the kernel runs to its end on whatever it finds in memory, writes "solve failed",
+// and the host repeats the call on the chain-of-launches path (ba.cpp), whose kernels do not wait for each other.
+struct FlowWatch {
+    unsigned* abort_w;           // device word of the flag block: == epoch when some workgroup gave up
+    unsigned* abort_host;        // host-mapped copy (may be null)
+    unsigned long long deadline; // wall_clock64() value after which a wait gives up
+    unsigned epoch;
+    bool dead;
+};
+__device__ __forceinline__ FlowWatch flow_watch(const BaDev& d, unsigned* abort_w, unsigned epoch) {
+    FlowWatch W;
+    W.abort_w = abort_w;
+    W.abort_host = d.flow_abort_host;
+    W.deadline = wall_clock64() + d.flow_timeout_ticks;
+    W.epoch = epoch;
+    W.dead = false;
+    return W;
+}
+// true when the solve has been given up (by this workgroup just now, or by another one): stop waiting
+__device__ __forceinline__ bool flow_expired(FlowWatch& W) {
+    if (flow_ready(W.abort_w, W.epoch)) {
+        W.dead = true;
+    } else if (wall_clock64() > W.deadline) {
+        __hip_atomic_store(W.abort_w, W.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (W.abort_host) __hip_atomic_store(W.abort_host, W.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        W.dead = true;
+    }
+    return W.dead;
+}
+__device__ __forceinline__ void flow_wait(const unsigned* f, unsigned epoch, FlowWatch& W) {  // one thread; flow_acquire() after the barrier
+    if (W.dead) return;
+    unsigned polls = 0;
+    while (!flow_ready(f, epoch)) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 255u) == 0 && flow_expired(W)) return;
+    }
 }
 __device__ __forceinline__ void flow_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 // every thread's global stores so far become visible device-wide, then the flag goes up
@@ -1039,7 +1078,7 @@ __device__ __forceinline__ void dense_tile_lds_syrk(const double (*sT)[kPS], d4 
 //   J == I  Linv_J is in HBM (flag up) and in LDS (X = flow_lds + kDNB * kPS); the A block (flow_lds) is free
 // `flags`: the tile flags, slot I (I + 1) / 2 + J; `bad`: the word a failed pivot stamps.
 __device__ __forceinline__ void flow_factor_tile(const BaDev& d, int I, int J, unsigned epoch, unsigned* flags, unsigned* bad,
-                                                 double* flow_lds, int* s_m_p, int* s_bad_p) {
+                                                 double* flow_lds, int* s_m_p, int* s_bad_p, FlowWatch& W) {
     const int tid = threadIdx.x, ld = d.ldS;
     const int self = I * (I + 1) / 2 + J;
     int& s_m = *s_m_p;
@@ -1089,12 +1128,17 @@ __device__ __forceinline__ void flow_factor_tile(const BaDev& d, int I, int J, u
     for (int k = lo; k < k_end;) {
         if (tid == 0) {
             int m = 0;
+            unsigned polls = 0;
             for (;;) {  // the ready prefix of the remaining column tiles, at least one
                 while (k + m < k_end && flow_ready(&flags[I * (I + 1) / 2 + k + m], epoch) &&
                        flow_ready(&flags[J * (J + 1) / 2 + k + m], epoch) &&
                        (!own_sub || k + m < sub_first || flow_ready(&flags[(J - 1) * J / 2 + k + m], epoch)))
                     m++;
                 if (m > 0) break;
+                if (W.dead || ((++polls & 255u) == 0 && flow_expired(W))) {  // the solve is void: walk through what is left
+                    m = k_end - k;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
             s_m = m;
@@ -1125,7 +1169,7 @@ __device__ __forceinline__ void flow_factor_tile(const BaDev& d, int I, int J, u
                     const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
                     sT[r][c] = -tot[rt][ct][reg];
                 }
-        if (tid == 0) flow_wait(&flags[J * (J + 1) / 2 + J], epoch);
+        if (tid == 0) flow_wait(&flags[J * (J + 1) / 2 + J], epoch, W);
         __syncthreads();
         flow_acquire();
         SO_FLOW_MARK(2);
@@ -1161,7 +1205,7 @@ __device__ __forceinline__ void flow_factor_tile(const BaDev& d, int I, int J, u
                     const int r = wr + 16 * rt + (lane >> 4) + 4 * reg, c = wc + 16 * ct + (lane & 15);
                     sT[r][c] = -tot2[rt][ct][reg];
                 }
-        if (tid == 0) flow_wait(&flags[(J - 1) * J / 2 + (J - 1)], epoch);
+        if (tid == 0) flow_wait(&flags[(J - 1) * J / 2 + (J - 1)], epoch, W);
         __syncthreads();
         flow_acquire();
         SO_FLOW_MARK(2);
@@ -1222,12 +1266,13 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     const int2 t = d.flow_tiles[blockIdx.x];
     const int I = __builtin_amdgcn_readfirstlane(t.x), J = __builtin_amdgcn_readfirstlane(t.y), self = I * (I + 1) / 2 + J;
     unsigned* flags = d.flow_flags;
-    flow_factor_tile(d, I, J, epoch, flags + kFlowFlagTile, &flags[kFlowFlagBad], flow_lds, &s_m, &s_bad);
+    FlowWatch W = flow_watch(d, &flags[kFlowFlagAbort], epoch);
+    flow_factor_tile(d, I, J, epoch, flags + kFlowFlagTile, &flags[kFlowFlagBad], flow_lds, &s_m, &s_bad, W);
     double* vec_fwd = d.flow_vec;
     if (I != J) {
         const double (*sT)[kPS] = reinterpret_cast<const double (*)[kPS]>(flow_lds + 2 * kDNB * kDStride);
         // forward: L_IJ y_J
-        if (tid == 0) flow_wait(&flags[kFlowFlagY + J], epoch);
+        if (tid == 0) flow_wait(&flags[kFlowFlagY + J], epoch, W);
         __syncthreads();
         if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)J * kDNB + tid]);
         __syncthreads();
@@ -1246,7 +1291,7 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     // forward substitution of this block row
     const int first = d.tile_first[J];
     if (tid == 0)
-        for (int k = first; k < J; k++) flow_wait(&flags[kFlowFlagFwd + J * (J + 1) / 2 + k], epoch);
+        for (int k = first; k < J; k++) flow_wait(&flags[kFlowFlagFwd + J * (J + 1) / 2 + k], epoch, W);
     __syncthreads();
     if (tid < kDNB) {
         double v = d.bs[(size_t)J * kDNB + tid];  // b_J: written before the launch
@@ -1269,14 +1314,14 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     const bool has_next = J + 1 < T && d.tile_first[J + 1] <= J;
     if (tid == 0)  // every tile of the column (all published long ago): one acquire covers the reads below
         for (int i = J + 1; i < T; i++)
-            if (d.tile_first[i] <= J) flow_wait(&flags[kFlowFlagTile + i * (i + 1) / 2 + J], epoch);
+            if (d.tile_first[i] <= J) flow_wait(&flags[kFlowFlagTile + i * (i + 1) / 2 + J], epoch, W);
     __syncthreads();
     flow_acquire();
     if (has_next) flow_stage_tile(d.S + (size_t)(J + 1) * kDNB * ld + (size_t)J * kDNB, ld, Lsub);
     double z = tid < kDNB ? s_u[tid] : 0.0;
     for (int i = T - 1; i > J; i--) {
         if (d.tile_first[i] > J) continue;
-        if (tid == 0) flow_wait(&flags[kFlowFlagX + i], epoch);
+        if (tid == 0) flow_wait(&flags[kFlowFlagX + i], epoch, W);
         __syncthreads();  // (also: Lsub is complete, the previous round's reads of s_v are over)
         if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)i * kDNB + tid]);
         __syncthreads();
@@ -1307,8 +1352,8 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     flow_publish_vec(&flags[kFlowFlagX + J], epoch);
     SO_FLOW_MARK(9);
     if (J == 0 && tid == 0) {  // the last block row to finish (every x_J is out before the verdict is written)
-        for (int j = 1; j < T; j++) flow_wait(&flags[kFlowFlagX + j], epoch);
-        d.partial[kBaSolveOk] = flow_ready(&flags[kFlowFlagBad], epoch) ? 0.0 : 1.0;
+        for (int j = 1; j < T; j++) flow_wait(&flags[kFlowFlagX + j], epoch, W);
+        d.partial[kBaSolveOk] = (flow_ready(&flags[kFlowFlagBad], epoch) || flow_ready(&flags[kFlowFlagAbort], epoch)) ? 0.0 : 1.0;
     }
 }
 
@@ -1333,6 +1378,7 @@ __global__ __launch_bounds__(256) void dense_flow_big_kernel(BaDev d, unsigned e
     unsigned* fX = fY + kDenseMaxPanels;
     unsigned* bad = fX + kDenseMaxPanels;
     unsigned* counter = bad + 1;
+    FlowWatch W = flow_watch(d, counter + 2, epoch);  // (the word behind the two ticket counters)
     double (*A)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds);
     double (*X)[kPS] = reinterpret_cast<double (*)[kPS]>(flow_lds + kDNB * kPS);
     for (;;) {  // factorisation + forward substitution
@@ -1348,7 +1394,7 @@ __global__ __launch_bounds__(256) void dense_flow_big_kernel(BaDev d, unsigned e
         SO_FLOW_NOTE(10, 1000000 + I * 1000 + J);
         if (I == J) SO_FLOW_DIAG(3, J);
         if (I == J + 1) SO_FLOW_DIAG(6, J);
-        flow_factor_tile(d, I, J, epoch, flags, bad, flow_lds, &s_m, &s_bad);
+        flow_factor_tile(d, I, J, epoch, flags, bad, flow_lds, &s_m, &s_bad, W);
         SO_FLOW_NOTE(10, 2000000 + I * 1000 + J);
         if (I == J) SO_FLOW_DIAG(0, J);
         // forward substitution of block row J by its diagonal workgroup.  Every workgroup walks the same barriers (the
@@ -1356,14 +1402,14 @@ __global__ __launch_bounds__(256) void dense_flow_big_kernel(BaDev d, unsigned e
         const bool diag = I == J;
         const int first = diag ? __builtin_amdgcn_readfirstlane(d.tile_first[J]) : 0, last = diag ? J : 0;
         if (tid == 0)  // (J, J-1) was formed locally: its copy in HBM comes from workgroup (J, J-1)
-            for (int k = first; k < last; k++) flow_wait(&flags[J * (J + 1) / 2 + k], epoch);
+            for (int k = first; k < last; k++) flow_wait(&flags[J * (J + 1) / 2 + k], epoch, W);
         __syncthreads();
         flow_acquire();
         double v = diag && tid < kDNB ? d.bs[(size_t)J * kDNB + tid] : 0.0;  // b_J: written before the launch
         for (int k = first; k < last; k++) {
             flow_stage_tile(d.S + (size_t)J * kDNB * ld + (size_t)k * kDNB, ld, A);
             SO_FLOW_NOTE(10, 3000000 + J * 1000 + k);
-            if (tid == 0) flow_wait(&fY[k], epoch);
+            if (tid == 0) flow_wait(&fY[k], epoch, W);
             __syncthreads();
             if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)k * kDNB + tid]);
             __syncthreads();
@@ -1395,10 +1441,10 @@ __global__ __launch_bounds__(256) void dense_flow_big_kernel(BaDev d, unsigned e
         const int J = __builtin_amdgcn_readfirstlane(d.flow_tiles[n_tiles + (int)u].x);  // deepest chains first (build_dense_plan)
         SO_FLOW_NOTE(10, 4000000 + J);
         if (tid == 0) {  // the factor of block J, its column below, y_J
-            flow_wait(&flags[J * (J + 1) / 2 + J], epoch);
+            flow_wait(&flags[J * (J + 1) / 2 + J], epoch, W);
             for (int i = J + 1; i < T; i++)
-                if (d.tile_first[i] <= J) flow_wait(&flags[i * (i + 1) / 2 + J], epoch);
-            flow_wait(&fY[J], epoch);
+                if (d.tile_first[i] <= J) flow_wait(&flags[i * (i + 1) / 2 + J], epoch, W);
+            flow_wait(&fY[J], epoch, W);
         }
         __syncthreads();
         flow_acquire();
@@ -1408,7 +1454,7 @@ __global__ __launch_bounds__(256) void dense_flow_big_kernel(BaDev d, unsigned e
             if (__builtin_amdgcn_readfirstlane(d.tile_first[i]) > J) continue;
             flow_stage_tile(d.S + (size_t)i * kDNB * ld + (size_t)J * kDNB, ld, A);
             SO_FLOW_NOTE(10, 5000000 + J * 1000 + i);
-            if (tid == 0) flow_wait(&fX[i], epoch);
+            if (tid == 0) flow_wait(&fX[i], epoch, W);
             __syncthreads();
             if (tid < kDNB) s_v[tid] = flow_vec_load(&d.bs[(size_t)i * kDNB + tid]);
             __syncthreads();
@@ -1428,8 +1474,8 @@ __global__ __launch_bounds__(256) void dense_flow_big_kernel(BaDev d, unsigned e
         flow_publish_vec(&fX[J], epoch);
         SO_FLOW_DIAG(2, J);
         if (J == 0 && tid == 0) {  // every x_J is out before the verdict is written
-            for (int j = 1; j < T; j++) flow_wait(&fX[j], epoch);
-            d.partial[kBaSolveOk] = flow_ready(bad, epoch) ? 0.0 : 1.0;
+            for (int j = 1; j < T; j++) flow_wait(&fX[j], epoch, W);
+            d.partial[kBaSolveOk] = (flow_ready(bad, epoch) || flow_ready(counter + 2, epoch)) ? 0.0 : 1.0;
         }
         __syncthreads();
     }
@@ -1600,6 +1646,21 @@ void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DenseP
 
 int dense_flow_max_tiles() { return kFlowMaxTiles; }
 
+// Workgroups of the dataflow kernels the device can hold at the same time, from the runtime's occupancy calculator
+// (block size, registers and the 152 KB of dynamic LDS against what a CU has) times the CU count - 0 when a workgroup
+// does not fit at all.  ba.cpp never launches more than this (minus its reserve) in one dataflow launch.
+int dense_flow_resident_capacity(int device) {
+    constexpr int lds = (int)(sizeof(double) * kFlowLdsDoubles);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_flow_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int per_cu_small = 0, per_cu_big = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_small, dense_flow_kernel, 256, (size_t)lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_big, dense_flow_big_kernel, 256, (size_t)lds) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+    const int per_cu = per_cu_small < per_cu_big ? per_cu_small : per_cu_big;
+    return per_cu > 0 ? per_cu * cus : 0;
+}
+
 namespace {
 
 struct PlanCursor {
@@ -1681,6 +1742,25 @@ void launch_ba_dense_solve(const BaDev& d, hipStream_t s) {
         hipLaunchKernelGGL(dense_backward_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, d, k);
     }
     hipLaunchKernelGGL(dense_finish_kernel, dim3((6 * d.n_free + 255) / 256), dim3(256), 0, s, d);
+}
+
+
+// Diagnostic load (so_runtime_occupy, include/swarmorb.h): `workgroups` workgroups that each pin `lds_bytes` of LDS - with
+// 152 KB a whole CU - and do nothing but watch the wall clock for `ms` milliseconds.  What another process on the GPU
+// looks like to the dataflow solves; tests/test_ba_gpu.py starts it under a solve to see the time-out path work.
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ unsigned occ_lds[];
+    occ_lds[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (occ_lds[threadIdx.x] == 0xFFFFFFFFu) *sink = 1;  // (keeps the LDS allocation alive)
+}
+
+int launch_occupy(int workgroups, int lds_bytes, int ms, unsigned* d_sink, hipStream_t s) {
+    if (workgroups <= 0 || lds_bytes < 256 || lds_bytes > 160 * 1024 || ms <= 0 || ms > 10000) return 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(64), (size_t)lds_bytes, s, (unsigned long long)ms * 100000ull, d_sink);
+    return hipGetLastError() == hipSuccess ? 1 : 0;
 }
 
 }  // namespace so

@@ -101,6 +101,8 @@ struct BaDev {
     unsigned* flow_flags;       // kFlowFlagWords, zeroed once when allocated
     double* flow_vec;           // 256 x 96: L_IJ y_J of every off-diagonal tile
     unsigned* flow_epoch;       // host counter of the solver context, grows with every solve (not read by kernels)
+    unsigned* flow_abort_host;  // host-mapped word a workgroup stamps with the epoch when a wait outlasts its budget
+    unsigned long long flow_timeout_ticks;  // that budget in wall_clock64() ticks (100 MHz)
     int flow_nslots;            // ticketed kernel (large skylines): tile flag slots, T (T + 1) / 2
     int flow_grid;              //                  resident workgroups of its launch
     double* partial;  // reduction partials (chi2 | scale) + flags
@@ -140,6 +142,8 @@ constexpr int kBaMfmaSolverMinFree = 4;   // below: the register-resident look-a
 constexpr int kFlowFlagWords = 1024;
 constexpr int kFlowDefaultMaxTiles = 231;  // tiles the single-launch solve takes on (all its workgroups must be resident)
 int dense_flow_max_tiles();
+int launch_occupy(int workgroups, int lds_bytes, int ms, unsigned* d_sink, hipStream_t s);  // diagnostic load (so_runtime_occupy)
+int dense_flow_resident_capacity(int device);  // workgroups of a dataflow launch the device can keep resident (occupancy x CUs)
 constexpr int kDenseMaxPanels = 512;  // 49152 / 96: 8192 free keyframes, 19 GB of FP64 when stored densely
 // Launch plan of the blocked solver for one problem structure: which tiles each trailing update touches.  Built on the
 // host once per so_bundle_adjust call (the structure does not change between LM trials).

@@ -23,7 +23,8 @@ class SoBaInfo(C.Structure):
                 ("iterations_stage1", C.c_int32), ("iterations_stage2", C.c_int32), ("lm_trials", C.c_int32),
                 ("aborted", C.c_int32), ("n_outliers", C.c_int32), ("gpu_ms", C.c_float), ("wall_ms", C.c_float),
                 ("solve_ms", C.c_float), ("n_solves", C.c_int32), ("solve_gflop_structural", C.c_double),
-                ("solve_gflop_dense", C.c_double), ("nnz_tiles", C.c_double), ("solver_path", C.c_int32), ("n_free_keyframes", C.c_int32)]
+                ("solve_gflop_dense", C.c_double), ("nnz_tiles", C.c_double), ("solver_path", C.c_int32), ("n_free_keyframes", C.c_int32),
+                ("flow_timeouts", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SoPoseProblem(C.Structure):

@@ -421,3 +421,54 @@ def test_pose_optimization_too_few_points(opt):
     c = synth.make_pose_case(9, 2)
     ni, T, outl, info = opt.PoseOptimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
     assert ni == 0 and np.array_equal(T, c["Tcw"]) and info["iterations"] == 0  # Optimizer.cc:344-345
+
+
+_TIMEOUT_SCRIPT = r'''
+import json, os, sys, time
+import ctypes as C
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import swarmmap_amd
+from swarmmap_amd import synth
+lib = swarmmap_amd.load_library()
+lib.so_runtime_occupy.argtypes = [C.c_int] * 4
+o = swarmmap_amd.Optimizer()
+p = synth.make_ba_problem(0, 64, 96, 9600, max_obs="auto")       # 64 free keyframes: 4 panels, 10 tile workgroups
+ref = o.LocalBundleAdjustment(p)
+assert ref["info"]["solver_path"] == 2 and ref["info"]["flow_timeouts"] == 0
+# a "second process": 250 of the 256 CUs pinned for 1.5 s -> six of the ten tile workgroups become resident and wait for
+# the other four, which cannot start
+assert lib.so_runtime_occupy(0, 250, 152 * 1024, 1500) == 0
+time.sleep(0.05)
+t0 = time.perf_counter()
+r = o.LocalBundleAdjustment(p)
+dt = time.perf_counter() - t0
+again = o.LocalBundleAdjustment(p)
+print(json.dumps({"dt": dt, "path": r["info"]["solver_path"], "timeouts": r["info"]["flow_timeouts"],
+                  "dT": float(np.abs(r["Tcw"] - ref["Tcw"]).max()), "dX": float(np.abs(r["Xw"] - ref["Xw"]).max()),
+                  "chi": [ref["info"]["chi2_final"], r["info"]["chi2_final"]],
+                  "again_path": again["info"]["solver_path"], "again_timeouts": again["info"]["flow_timeouts"],
+                  "again_dT": float(np.abs(again["Tcw"] - r["Tcw"]).max())}))
+o.close()
+'''
+
+
+def test_dataflow_solve_that_is_not_resident_times_out_and_is_repeated():
+    """The single-launch solve needs all its workgroups resident.  With most CUs pinned by somebody else
+    (so_runtime_occupy stands in for a second process) the resident workgroups wait for ones that cannot start: every
+    wait is bounded (here 100 ms), the kernel raises its abort word and runs out, and so_bundle_adjust repeats the call
+    on the chain-of-launches path - same result within rounding, no hang, and the context stays on that path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SWARMORB_FLOW_TIMEOUT_MS="100")
+    out = subprocess.run([sys.executable, "-c", _TIMEOUT_SCRIPT, root], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["timeouts"] == 1 and d["path"] == 1, d
+    assert "timed out waiting for a workgroup" in out.stderr
+    assert d["dT"] <= POSE_TOL and d["dX"] <= POINT_TOL and d["chi"][1] == pytest.approx(d["chi"][0], rel=1e-6)
+    assert 0.1 <= d["dt"] < 5.0                          # one time-out budget, not a hang
+    assert d["again_path"] == 1 and d["again_timeouts"] == 1 and d["again_dT"] == 0.0

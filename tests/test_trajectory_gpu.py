@@ -80,6 +80,49 @@ def test_cpp_chain_matches_the_oracle_chain(local_kfs):
     assert a["matches_last"][1:].min() > 300 and a["inliers"][1:].min() > 400
 
 
+@pytest.mark.parametrize("name", ["euroc", "kitti"])
+def test_cpp_chain_in_the_bench_configuration_matches_the_oracle_chain(name):
+    """Exactly what bench.py times (bench.py run_stream): the EuRoC-sized stream rendered through the EuRoC lens model
+    (UndistortKeyPoints does real work) / the KITTI-sized stream with 2000 features, frames in pinned host memory read
+    by the ingest kernel, the local map limited to the last 12 keyframes, the third PoseOptimization, and the
+    local-mapping thread optimising an LBA-M window every 5th frame on the same GPU while the tracking thread runs -
+    frame by frame against the same chain over the CPU oracle."""
+    import torch
+    from swarmmap_amd.replay import Replay
+    euroc = name == "euroc"
+    size = synth.EUROC if euroc else synth.KITTI
+    K = synth.EUROC_K if euroc else synth.KITTI_K
+    dist = synth.EUROC_DIST if euroc else None
+    nfeat = 1000 if euroc else 2000
+    n = 40 if euroc else 30
+    st = synth.FrameStream(seed=20221001, size=size, K=K, dist=dist)
+    block = torch.empty((n + 2, st.h, st.w), dtype=torch.uint8).pin_memory()
+    view = block.numpy()
+    for t in range(n + 2):
+        view[t] = st.frame(t)
+    frames = [view[t] for t in range(n + 2)]
+    rp = Replay(0, st.w, st.h, nfeat, 5, K, dist, plane_z=PLANE_Z, local_keyframes=12, third_pose=True)
+    rp.set_frames([block.data_ptr() + i * st.w * st.h for i in range(n + 2)], on_device=False)
+    rp.set_window(synth.make_ba_case("LBA-M", seed=100))
+    rp.preallocate()
+    rp.prime(0)
+    rp.run(0, n, True)
+    rp.drain()
+    rp.finish()
+    a, stats = rp.log(), rp.stats()
+    rp.close()
+    assert stats["n_lba"] >= n // 5 - 1, "the local-mapping thread did not run its windows"
+    b = minitrack.track(OracleBackend(K, nfeat, dist if dist is not None else (0, 0, 0, 0, 0)), None, n, K, plane_z=PLANE_Z,
+                        local_keyframes=12, third_pose=True, frames=frames)
+    assert len(a["poses"]) == n
+    assert minitrack.ate_rmse(a["centres"], b["centres"], align=False) < ATE_HIP_VS_ORACLE
+    assert np.abs(a["poses"] - b["poses"]).max() < 2e-5
+    for k in ("matches_last", "matches_map", "inliers"):
+        assert np.abs(a[k].astype(int) - b[k].astype(int)).max() <= 3, (k, a[k], b[k])
+    assert np.abs(a["n_map_points"].astype(int) - b["n_map_points"].astype(int)).max() <= 3
+    assert a["matches_last"][1:].min() > 300 and a["inliers"][1:].min() > 400
+
+
 def test_lockstep_fleet_gives_every_agent_its_solo_result():
     """so_fleet_run: three agents of one GPU driven in lockstep by one thread (searches submitted for all agents before
     any is waited for, PoseOptimization of all agents in one launch) - every agent's trajectory is the one a solo run
