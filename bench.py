@@ -39,6 +39,7 @@ from swarmmap_amd.replay import Replay  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_PEAK_TF = 78.6    # MI355X FP64 vector/matrix peak (AMD datasheet; not tabulated in the guide)
 INT_PEAK_TOPS = 78.6   # 32-bit integer VALU: 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops/s (the guide's execution model)
+LIVE_STEPS = 41        # frames tracked the live way after the timed region (the first one is dropped: it was in flight)
 STORE_KEYFRAMES = 4096  # keyframe store per rank: 8 agents x 512 keyframes (218 MB of records + 134 MB of search rows)
 # one LBA-M window per ~5 frames (SURVEY.md 8d end-to-end replay); the override is a diagnostic (no local mapping)
 LBA_EVERY = int(os.environ.get("SWARMORB_BENCH_LBA_EVERY", "5"))
@@ -107,17 +108,18 @@ def cpu_baseline(frames, K, dist, nfeatures, lba_window, size, budget_s=20.0):
             lm.submit()
         return time.perf_counter() - state["t0"] < budget_s
 
-    minitrack.track(OracleBackend(K, nfeatures, dist), None, len(frames), K, plane_z=PLANE_Z,
+    minitrack.track(OracleBackend(K, nfeatures, dist if dist is not None else (0, 0, 0, 0, 0)), None, len(frames), K, plane_z=PLANE_Z,
                     local_keyframes=LOCAL_KEYFRAMES, third_pose=True, frames=frames, on_frame=on_frame)
     lm.drain()
     dt = time.perf_counter() - state["t0"]
     lm.close()
     n = state["n"]
     return {"value": n / dt, "unit": "frames/s", "cores": 2, "kind": "port",
-            "sample": "%d frames %dx%d of the same stream: CPU oracle chain (extract nFeatures %d + undistort + grid + M2 + "
-                      "isInFrustum + M1 + 3 PoseOptimization per frame on the tracking thread, %d LBA-M windows (1 per %d "
-                      "frames) on a local-mapping thread); gcc -O3; host has %d cores"
-                      % (n, size[0], size[1], nfeatures, lm.n, LBA_EVERY, os.cpu_count())}
+            "sample": "%d frames %dx%d of the same stream in %.1f s: CPU oracle chain (extract nFeatures %d + undistort + grid + "
+                      "M2 + isInFrustum + M1 + 3 PoseOptimization per frame on the tracking thread, %d LBA-M windows (1 per "
+                      "%d frames) on a local-mapping thread); operators in C (gcc -O3), the loop around them python-driven "
+                      "(swarmmap_amd/minitrack.py: ~1-3 %% of a ~30 ms frame) while the HIP arm runs the C++ loop; host has "
+                      "%d cores" % (n, size[0], size[1], dt, nfeatures, lm.n, LBA_EVERY, os.cpu_count())}
 
 
 def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, barrier, agents):
@@ -161,10 +163,12 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
 
 
 def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, barrier, agents=1, xchg=None,
-               exchange_every=20, m1=None):
-    """Timed region of the per-frame path on one GPU.  Returns (dt seconds, per-agent stats, candidate count, frames)."""
+               exchange_every=20, m1=None, live_steps=0):
+    """Timed region of the per-frame path on one GPU.  Returns (dt seconds, per-agent stats, candidate count, frames).
+    live_steps > 0: after the timed region that many more frames are tracked the way a live camera delivers them
+    (so_replay_run_live: nothing extracted ahead) and their image-in -> pose-out latencies land in stats["live_*"]."""
     w, h = size
-    n_frames = warmup + steps + 2
+    n_frames = warmup + steps + 2 + live_steps
     A = max(1, agents)
     gate = threading.Barrier(A + 1)
     results, errors, frame_sets = [None] * A, [], [None] * A
@@ -231,8 +235,13 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
             run_span(warmup, steps, True)
             rp.drain()    # every queued window is optimised inside the timed region
             sync("done")
+            live = None
+            if live_steps > 0 and a == 0:  # (outside the timed region; the first frame of the span is already in flight)
+                live = rp.run_live(warmup + steps, live_steps)
             rp.finish()
             results[a] = (rp.stats(), rp.candidates_total(), rp.log())
+            if live is not None:
+                acc_x["live_pose_ms"], acc_x["live_step_ms"] = live[0][1:], live[1][1:]
             rp.close()
         except Exception as e:  # noqa: BLE001 - reported by the main thread
             errors.append(e)
@@ -325,6 +334,13 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
         "local_map_points_per_frame": st["n_local"] / steps, "in_view_per_frame": st["n_in_view"] / steps,
         "frame_ms_percentiles": (lambda f: {k: float(np.percentile(f, q)) for k, q in (("p10", 10), ("p50", 50), ("p90", 90), ("p99", 99), ("max", 100))}
                                  if len(f) else {})(np.asarray(st.get("frame_ms", []), np.float64)),
+        # a LIVE frame (System::TrackMonocular is synchronous, code/src/System.cc:128-165): the image is handed over when
+        # its step begins, nothing is extracted ahead: upload + extraction + frame post-processing + both searches + the
+        # two PoseOptimization calls that produce the frame's pose, back to back (untimed frames right after the region)
+        "latency_ms_image_to_pose": (lambda f: {k: float(np.percentile(f, q)) for k, q in (("p50", 50), ("p90", 90), ("p99", 99), ("max", 100))}
+                                     if len(f) else None)(np.asarray(st.get("live_pose_ms", []), np.float64)),
+        "latency_ms_live_step": (lambda f: {k: float(np.percentile(f, q)) for k, q in (("p50", 50), ("p99", 99))}
+                                 if len(f) else None)(np.asarray(st.get("live_step_ms", []), np.float64)),
         "search_launches_per_frame": st.get("n_reruns", 0.0) / steps, "wide_window_m2_per_frame": st.get("n_wide_m2", 0.0) / steps,
         "keyframes": st["n_keyframes"], "map_points_at_end": st["n_map_points"],
         "lba_windows": st["n_lba"],
@@ -458,15 +474,22 @@ def gba_records(dev, cases):
         sflop = inf["solve_gflop_structural"] * 1e9  # FP64 work over the nonzero tiles of the block skyline only
         stf = sflop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         T = (n + 95) // 96
+        # the headline is the SMALLER of the two counts: the flop over the skyline's 96x96 tiles include the zero padding
+        # of the last tile row (GBA-1: 1308 unknowns in 14 x 96 = 1344 rows), the dense n^3/3 + 2 n^2 of the un-padded
+        # system exceed what a sparse map needs (GBA-2r) - neither may flatter the kernel
+        atf = min(stf, tf)
         out[name] = {"free_keyframes": n // 6, "points": int(len(p["Xw"])), "edges": int(len(p["edge_pose"])),
                      "wall_ms": wall * 1e3, "gpu_ms": inf["gpu_ms"], "lm_trials": inf["lm_trials"],
                      "chi2_initial": inf["chi2_initial"], "chi2_final": inf["chi2_final"], "generator_s": gen_s,
+                     "solver_path": int(inf["solver_path"]),
                      "solve": {"n": n, "ms_per_solve": ms, "tiles_in_skyline": inf["nnz_tiles"], "tiles_dense": T * (T + 1) // 2,
-                               "structural_flop": sflop, "dense_flop": flop, "achieved_tflops": stf,
-                               "dense_equivalent_tflops": tf, "peak_tflops": FP64_PEAK_TF, "frac": stf / FP64_PEAK_TF,
-                               "bound": "mfma",
-                               "note": "achieved = flop over the nonzero 96x96 tiles of the block skyline / solve time; "
-                                       "dense_equivalent = n^3/3 of a dense matrix of that size / the same time"}}
+                               "structural_flop": sflop, "dense_flop": flop, "achieved_tflops": atf,
+                               "skyline_tiles_tflops": stf, "dense_equivalent_tflops": tf, "peak_tflops": FP64_PEAK_TF,
+                               "frac": atf / FP64_PEAK_TF, "bound": "mfma",
+                               "evidence": "profiles/r3_gba_kernel_stats.csv, profiles/r3_gba_pmc_mfma.json (rocprofv3 "
+                                           "--kernel-trace --stats and separate --pmc passes of tools/gba_bench.py)",
+                               "note": "achieved = min(flop over the nonzero 96x96 tiles of the block skyline, n^3/3 + 2 n^2 "
+                                       "of the un-padded system) / solve time (HIP events around the solve kernel)"}}
         del p
     o.close()
     return out
@@ -535,7 +558,8 @@ def main():
                                               lba_window, barrier, A)
     else:
         dt, st, n_cand, frames, _ = run_stream(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
-                                               lba_window, barrier, A, xchg, args.exchange_every, m1)
+                                               lba_window, barrier, A, xchg, args.exchange_every, m1,
+                                               live_steps=LIVE_STEPS if rank == 0 else 0)
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -605,11 +629,13 @@ def main():
                 k_window = synth.make_ba_case("LBA-M", seed=101)
                 ksteps = 150
                 kdt, kst, kcand, kframes, _ = run_stream(dev, synth.KITTI, synth.KITTI_K, None, 2000, ksteps, 20, 20221001,
-                                                         k_window, barrier)
+                                                         k_window, barrier, live_steps=LIVE_STEPS)
                 kstage, kinv = extractor_stage_profile(dev, kframes, synth.KITTI, 2000, 32)
                 krec, kfast, kpose = stream_record(synth.KITTI, 2000, ksteps, kdt, kst, kcand, kstage, kinv, pmc)
                 krec["roofline_fast_score"] = {k: kfast[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "avg_launch_ms")}
                 krec["algorithmic_front_end_bytes_per_frame"] = 11.83e6
+                if not args.no_cpu_baseline:  # the same KITTI-sized chain through the CPU oracle, a shorter sample
+                    krec["cpu_baseline"] = cpu_baseline(kframes, synth.KITTI_K, None, 2000, k_window, synth.KITTI, budget_s=8.0)
                 cfgs["kitti_stream_1241x376"] = krec
                 del kframes
                 cfgs["candidate_search"] = candidate_search_records(dev)

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "dframe_internal.h"
 #include "extractor_internal.h"
@@ -66,7 +68,27 @@ int allocate(so_dframe* f, int capacity) {
     return SO_OK;
 }
 
+int submit_body(so_dframe* f, const uint8_t* image, bool on_device, int w, int h, int stride);
+
+// An error behind the extractor's own submission (capacity, allocation, the prepare launch) must not leave the handle
+// with a frame "in flight" that nothing will ever collect: the extractor's job is drained and the handle is free again.
 int submit_impl(so_dframe* f, const uint8_t* image, bool on_device, int w, int h, int stride) {
+    const int rc = submit_body(f, image, on_device, w, h, stride);
+    if (rc != SO_OK && f && f->in_flight) {
+        const std::string why = last_error_ref();
+        int n = 0;
+        const int cap = so_extractor_capacity(f->ex);
+        std::vector<so_keypoint> kp((size_t)(cap > 0 ? cap : 1));
+        std::vector<uint8_t> de((size_t)(cap > 0 ? cap : 1) * 32);
+        (void)so_extractor_collect(f->ex, kp.data(), de.data(), cap, &n);  // waits for the frame and frees the extractor
+        f->in_flight = false;
+        f->launched = false;
+        last_error_ref() = why;
+    }
+    return rc;
+}
+
+int submit_body(so_dframe* f, const uint8_t* image, bool on_device, int w, int h, int stride) {
     if (!f) return SO_ERR_INVALID_ARG;
     if (f->in_flight) {
         last_error_ref() = "so_dframe_submit: the previous frame of this handle has not been collected";

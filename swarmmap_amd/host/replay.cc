@@ -142,6 +142,7 @@ struct so_replay {
     int submitted = -1;  // handle index holding the frame in flight
     int last_tracked = -1;  // handle index of the frame tracked last
     bool in_flight = false;
+    bool live = false;   // so_replay_run_live: no frame is extracted ahead
     int n_tracked = 0;   // frames tracked so far (0: the next frame initialises the map)
     float bounds[4] = {0, 0, 0, 0};
     M4 T_last = M4::eye(), velocity = M4::eye();
@@ -476,7 +477,9 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
     // the next frame goes to the extractor here - or, on the single-agent path, under this frame's first
     // PoseOptimization kernel, where the tracking thread would only be waiting (so_replay_run)
     S.next_submitted = submit_next || S.first;
-    if (S.next_submitted) {
+    if (r->live) {  // a live camera has not produced frame t + 1 yet
+        S.next_submitted = true;
+    } else if (S.next_submitted) {
         const int rc = submit_frame(r, t + 1);
         if (rc) return rc;
     }
@@ -744,9 +747,8 @@ void step_end(so_replay* r, int t, int timed) {
 
 extern "C" {
 
-int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
-    if (!r || !r->in_flight || r->frames.empty()) return SO_ERR_INVALID_ARG;
-    for (int t = first_t; t < first_t + n_steps; t++) {
+static int run_one_step(so_replay* r, int t, int timed) {
+    {
         so_replay::Step& S = r->step;
         int rc;
         static const bool submit_early = getenv("SWARMORB_REPLAY_SUBMIT_EARLY") != nullptr;  // A/B: next frame at step begin
@@ -777,6 +779,37 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
         if (!r->error.empty()) return SO_ERR_HIP;
     }
     return SO_OK;
+}
+
+int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
+    if (!r || !r->in_flight || r->frames.empty()) return SO_ERR_INVALID_ARG;
+    for (int t = first_t; t < first_t + n_steps; t++) {
+        const int rc = run_one_step(r, t, timed);
+        if (rc) return rc;
+    }
+    return SO_OK;
+}
+
+// The same frames the way a LIVE camera delivers them (System::TrackMonocular is synchronous,
+// code/src/System.cc:128-165): frame t is handed over when its step begins - nothing is extracted ahead - and the step
+// runs image upload -> extraction -> frame post-processing -> both searches -> PoseOptimization calls back to back.
+// pose_ms[i]: image in -> the frame's pose out (the second PoseOptimization has returned); step_ms[i]: through the third
+// PoseOptimization and the keyframe bookkeeping.  Leaves no frame in flight (so_replay_prime before the next
+// so_replay_run).  Not counted in the statistics.
+int so_replay_run_live(so_replay* r, int first_t, int n_steps, float* pose_ms, float* step_ms) {
+    if (!r || r->frames.empty() || first_t < 0 || first_t + n_steps > (int)r->frames.size()) return SO_ERR_INVALID_ARG;
+    r->live = true;
+    int rc = SO_OK;
+    for (int t = first_t; t < first_t + n_steps && rc == SO_OK; t++) {
+        const double T0 = now_ms();
+        if (!r->in_flight) rc = submit_frame(r, t);  // the image arrives now
+        if (rc == SO_OK) rc = run_one_step(r, t, 0);
+        const so_replay::Step& S = r->step;
+        if (pose_ms) pose_ms[t - first_t] = (float)((S.first ? now_ms() : S.tp2) - T0);
+        if (step_ms) step_ms[t - first_t] = (float)(now_ms() - T0);
+    }
+    r->live = false;
+    return rc;
 }
 
 // Several agents on one GPU, driven in lockstep by the calling thread: per stage the searches of all agents are

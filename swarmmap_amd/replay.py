@@ -88,6 +88,14 @@ class Replay:
     def run(self, first_t, n, timed):
         self._check(self.lib.so_replay_run(self.h, first_t, n, int(timed)), "run")
 
+    def run_live(self, first_t, n):
+        """so_replay_run_live: frames handed over one by one, nothing extracted ahead (a live camera).  Returns
+        (image-in -> pose-out ms per frame, whole-step ms per frame)."""
+        pose, step = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)
+        self.lib.so_replay_run_live.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self._check(self.lib.so_replay_run_live(self.h, first_t, n, self._p(pose), self._p(step)), "run_live")
+        return pose[:n], step[:n]
+
     @staticmethod
     def fleet_run(agents, first_t, n, timed):
         """so_fleet_run: the agents (Replay objects of one GPU, created after private_streams(True)) walk through n

@@ -472,3 +472,38 @@ def test_dataflow_solve_that_is_not_resident_times_out_and_is_repeated():
     assert d["dT"] <= POSE_TOL and d["dX"] <= POINT_TOL and d["chi"][1] == pytest.approx(d["chi"][0], rel=1e-6)
     assert 0.1 <= d["dt"] < 5.0                          # one time-out budget, not a hang
     assert d["again_path"] == 1 and d["again_timeouts"] == 1 and d["again_dT"] == 0.0
+
+
+def _problem_digest(p):
+    import hashlib
+    h = hashlib.sha256()
+    for k in ("Tcw", "Xw", "obs", "edge_pose", "edge_point", "inv_sigma2", "fixed"):
+        h.update(np.ascontiguousarray(p[k]).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name,fixture", [("GBA-2", "gba2.npz"), ("GBA-2r", "gba2r.npz")])
+def test_full_size_global_ba_matches_the_oracle_fixture(opt, name, fixture):
+    """BASELINE configs[4] at full size - GBA-2 (1499 keyframes on one cloud, 780 k observations) and GBA-2r (the 8-agent
+    street-grid map, 1503 keyframes, 710 k observations) - against what the CPU oracle computed for the same problem
+    (Optimizer::BundleAdjustment, code/src/Optimizer.cc:42-237: optimize(10), Huber sqrt(5.99)).  The oracle needs
+    minutes per map, so it ran once in the build container (tools/make_gba_golden.py) and its result is a committed
+    fixture: every pose, every 8th point, all outlier flags, chi2, iteration counts."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture)
+    g = np.load(path)
+    p = synth.make_ba_case(name, 1)
+    assert _problem_digest(p) == str(g["digest"]), "the generator no longer produces the problem the fixture was made from"
+    r = opt.BundleAdjustment(p, nIterations=10, bRobust=True)
+    inf = dict(zip([str(k) for k in g["info_keys"]], g["info_vals"]))
+    assert r["info"]["iterations_stage1"] == int(inf["iterations_stage1"]) == 10
+    assert abs(r["info"]["lm_trials"] - int(inf["lm_trials"])) <= 10
+    assert r["info"]["chi2_initial"] == pytest.approx(inf["chi2_initial"], rel=1e-9)
+    assert r["info"]["chi2_final"] == pytest.approx(inf["chi2_final"], rel=1e-6)
+    assert np.abs(r["Tcw"] - g["Tcw"]).max() <= POSE_TOL
+    assert np.abs(r["Xw"][::8] - g["Xw_every8"]).max() <= POINT_TOL
+    assert np.allclose(r["chi2"][::64], g["chi2"], rtol=1e-5, atol=1e-7)
+    want = np.unpackbits(g["outlier_bits"])[:int(g["n_edges"])]
+    diff = np.nonzero(r["outlier"] != want)[0]
+    assert np.all(np.abs(r["chi2"][diff] - 5.991) <= 1e-5 * 5.991), diff[:10]  # flags differ only on the gate itself
+    assert abs(int(r["info"]["n_outliers"]) - int(inf["n_outliers"])) <= len(diff)
