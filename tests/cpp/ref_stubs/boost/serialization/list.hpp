@@ -1,0 +1,2 @@
+#pragma once
+#include <boost/archive/text_oarchive.hpp>

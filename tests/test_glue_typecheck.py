@@ -1,0 +1,42 @@
+"""The drop-in glue (swarmmap_amd/host/glue/*.cc: the bodies that replace ORBmatcher's and Optimizer's functions inside
+the reference tree, written against the reference's real signatures and classes) type-checks against the reference's
+own headers: g++ -fsyntax-only with include paths into /root/reference/code.  The image has no OpenCV / Eigen / Boost /
+CUDA / Pangolin, so tests/cpp/ref_stubs/ declares the third-party names those headers mention (compile-only: no
+definitions, nothing is linked or run; it is a type-check of OUR files, not a build of the reference).  Skipped where
+/root/reference does not exist (the GPU box)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/code"
+STUBS = os.path.join(ROOT, "tests", "cpp", "ref_stubs")
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "include")), reason="the reference checkout is not on this machine")
+
+
+def _syntax_check(source, extra=()):
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-DEDGE_SLAM_WEBSOCKET_H", "-include", os.path.join(STUBS, "reference_shim.h"),
+           "-I", STUBS, "-I", os.path.join(STUBS, "cfg", "a", "b"), "-I", REF, "-I", os.path.join(REF, "include"),
+           "-I", os.path.join(ROOT, "include"), *extra, source]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+
+
+@pytest.mark.parametrize("name", ["Optimizer_glue.cc", "ORBmatcher_glue.cc"])
+def test_glue_type_checks_against_the_reference_headers(name):
+    r = _syntax_check(os.path.join(ROOT, "swarmmap_amd", "host", "glue", name))
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "warning" not in r.stderr, r.stderr[-2000:]
+
+
+def test_the_check_really_sees_the_reference_classes(tmp_path):
+    """A member the reference does not have, or a signature it does not declare, fails the same command."""
+    bad = tmp_path / "bad.cc"
+    bad.write_text('#include "Optimizer.h"\nnamespace ORB_SLAM2 { void f(KeyFrame* k) { k->NoSuchMember(); } }\n')
+    assert _syntax_check(str(bad)).returncode != 0
+    bad.write_text('#include "ORBmatcher.h"\nnamespace ORB_SLAM2 { int ORBmatcher::SearchByProjection(Frame&, int) { return 0; } }\n')
+    assert _syntax_check(str(bad)).returncode != 0
+    ok = tmp_path / "ok.cc"
+    ok.write_text('#include "Optimizer.h"\n#include "ORBmatcher.h"\nnamespace ORB_SLAM2 { unsigned long g(KeyFrame* k) { return k->mnId; } }\n')
+    assert _syntax_check(str(ok)).returncode == 0
