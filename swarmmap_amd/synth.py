@@ -195,9 +195,13 @@ def _rodrigues(w):
 
 
 def make_ba_problem(seed, n_free=8, n_fixed=10, n_points=800, size=EUROC, K=EUROC_K, pixel_sigma=1.0,
-                    outlier_frac=0.05, pose_noise=(0.02, 0.5), point_noise=0.03, max_obs=None):
+                    outlier_frac=0.05, pose_noise=(0.02, 0.5), point_noise=0.03, max_obs=None, max_yaw=None):
     """A seeded local-BA window: cameras on an arc looking at a point cloud; returns the flattened problem
-    (float32 like the map stores it) plus the generating ground truth."""
+    (float32 like the map stores it) plus the generating ground truth.
+    The cameras turn by 0.02 rad per keyframe: beyond ~150 keyframes the ones at the ends of the arc look away from the
+    cloud and observe nothing - g2o gives such keyframes no Hessian index, and neither does so_bundle_adjust
+    (so_ba_info.n_free_keyframes counts the ones that have one).  max_yaw (rad) caps the total turn so that EVERY
+    keyframe sees points - what the window-size sweeps want (tools/lba_bench.py --sweep)."""
     rng = np.random.default_rng(seed)
     n_poses = n_free + n_fixed
     w, h = size
@@ -205,7 +209,8 @@ def make_ba_problem(seed, n_free=8, n_fixed=10, n_points=800, size=EUROC, K=EURO
     Rs, ts = [], []
     for i in range(n_poses):  # camera centres on a slowly advancing arc, all looking towards +z
         c = np.array([0.25 * i - 0.125 * n_poses + rng.normal(0, 0.05), rng.normal(0, 0.08), rng.normal(0, 0.1)])
-        R = _rodrigues(np.array([rng.normal(0, 0.03), 0.02 * (i - n_poses / 2) + rng.normal(0, 0.02),
+        yaw_rate = 0.02 if max_yaw is None else min(0.02, 2.0 * float(max_yaw) / max(n_poses, 1))
+        R = _rodrigues(np.array([rng.normal(0, 0.03), yaw_rate * (i - n_poses / 2) + rng.normal(0, 0.02),
                                  rng.normal(0, 0.02)]))
         Rs.append(R)  # Rcw
         ts.append(-R @ c)

@@ -20,7 +20,7 @@ def main():
         rng = np.random.default_rng(11)
         recs = [bench.random_keyframe_records(rng, 1, per_agent, n_kp, frac, first_agent=1 + a) for a in range(8)]
         q = bench.random_keyframe_records(rng, 1, 1, n_kp, frac, first_agent=0)[0]
-        for qper in (1, 2, 4):
+        for qper in ((0,) if os.environ.get("SWARMORB_KFSCAN_ONLY_DEFAULT") else (1, 2, 4)):  # 0: the library's choice
             os.environ["SWARMORB_KF_SCAN_QPER"] = str(qper)
             store = KeyframeStore(8 * per_agent, n_kp + 24)
             for r in recs:
