@@ -1207,7 +1207,7 @@ int so_pose_optimization_wait(so_ba* b, float* Tcw_out12, uint8_t* outlier, int3
     memcpy(outlier, Q.hout + 80, (size_t)n);
     if (Q.trace) {  // debugging aid: dump the LM trial log
         std::vector<double> tr(4 * 256);
-        SO_HIP(hipMemcpy(tr.data(), Q.trace, sizeof(double) * tr.size(), hipMemcpyDeviceToHost));
+        SO_HIP(so::memcpy_sync(tr.data(), Q.trace, sizeof(double) * tr.size(), hipMemcpyDeviceToHost));
         for (int k = 0; k < inf[2] && k < 256; k++)
             fprintf(stderr, "gpu trial %d lambda %.6e temp %.9e rho %.6e cur %.9e\n", k, tr[4 * k], tr[4 * k + 1], tr[4 * k + 2], tr[4 * k + 3]);
     }

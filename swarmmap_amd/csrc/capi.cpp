@@ -24,6 +24,36 @@ hipError_t context_stream(int device, int role, hipStream_t* s, bool* owned) {
     return tracking_stream(device, role, s);
 }
 
+static hipError_t utility_stream(hipStream_t* s) {
+    static thread_local hipStream_t streams[64] = {nullptr};
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+    if (!streams[device]) {
+        e = hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *s = streams[device];
+    return hipSuccess;
+}
+
+hipError_t memset_sync(void* dst, int value, size_t bytes) {
+    hipStream_t s = nullptr;
+    hipError_t e = utility_stream(&s);
+    if (e == hipSuccess) e = hipMemsetAsync(dst, value, bytes, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    return e;
+}
+
+hipError_t memcpy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipStream_t s = nullptr;
+    hipError_t e = utility_stream(&s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, kind, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    return e;
+}
+
 hipError_t tracking_stream(int device, int role, hipStream_t* s) {
     static thread_local hipStream_t streams[64][2] = {{nullptr}};
     if (device < 0 || device >= 64 || role < 0 || role > 1) return hipErrorInvalidDevice;

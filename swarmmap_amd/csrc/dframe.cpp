@@ -41,7 +41,7 @@ int allocate(so_dframe* f, int capacity) {
     const size_t o_ni = o; o += 256;
     const size_t o_b = o; o += 256;
     SO_HIP(hipMalloc((void**)&f->d_block, o));
-    SO_HIP(hipMemset(f->d_block, 0, o));
+    SO_HIP(so::memset_sync(f->d_block, 0, o));
     uint8_t* d = f->d_block;
     f->d_xy_un = (float2*)(d + o_xy);
     f->d_octave = (int8_t*)(d + o_oct);
@@ -316,7 +316,7 @@ int so_dframe_device_view(const so_dframe* f, so_dframe_view* v) {
 int so_dframe_get_grid(so_dframe* f, int32_t* cell_start, int32_t* cell_items, int32_t* n_inside) {
     if (!f || !f->ready || !cell_start || !cell_items || !n_inside) return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(f->device));
-    SO_HIP(hipMemcpy(cell_start, f->d_cell_start, sizeof(int32_t) * (kFrameGridCols * kFrameGridRows + 1),
+    SO_HIP(so::memcpy_sync(cell_start, f->d_cell_start, sizeof(int32_t) * (kFrameGridCols * kFrameGridRows + 1),
                      hipMemcpyDeviceToHost));
     *n_inside = f->n_inside;
     if (f->n_inside > 0) memcpy(cell_items, f->h_perm, sizeof(int32_t) * (size_t)f->n_inside);
@@ -416,8 +416,8 @@ int so_map_read(so_map* m, int32_t first, int32_t n, float* Xw, uint8_t* desc) {
     if (!m || first < 0 || n < 0 || first + n > m->size) return SO_ERR_INVALID_ARG;
     if (n == 0) return SO_OK;
     SO_HIP(hipSetDevice(m->device));
-    if (Xw) SO_HIP(hipMemcpy(Xw, m->d_Xw + 3 * (size_t)first, 12 * (size_t)n, hipMemcpyDeviceToHost));
-    if (desc) SO_HIP(hipMemcpy(desc, m->d_desc + 32 * (size_t)first, 32 * (size_t)n, hipMemcpyDeviceToHost));
+    if (Xw) SO_HIP(so::memcpy_sync(Xw, m->d_Xw + 3 * (size_t)first, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    if (desc) SO_HIP(so::memcpy_sync(desc, m->d_desc + 32 * (size_t)first, 32 * (size_t)n, hipMemcpyDeviceToHost));
     return SO_OK;
 }
 

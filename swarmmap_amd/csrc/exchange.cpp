@@ -232,7 +232,7 @@ int so_exchange_create(int device, int rank, int world, const uint8_t* id128, in
     if (e == hipSuccess) e = hipMalloc((void**)&x->d_stage, 32 * (size_t)slot_keypoints);
     if (e == hipSuccess) e = hipMalloc((void**)&x->d_res, sizeof(int32_t) * 3 * (size_t)slot_keypoints * (size_t)world);
     if (e == hipSuccess) e = hipHostMalloc((void**)&x->h_pin, x->h_pin_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMemset(x->d_gathered, 0, x->slot_bytes * (size_t)world);
+    if (e == hipSuccess) e = so::memset_sync(x->d_gathered, 0, x->slot_bytes * (size_t)world);
     if (e != hipSuccess) {
         so_exchange_destroy(x);
         return hip_fail(e, "exchange init", __FILE__, __LINE__);
@@ -307,7 +307,7 @@ int so_exchange_create_store(int device, int rank, int world, const uint8_t* id1
     if (e == hipSuccess) e = hipMalloc((void**)&x->d_staged, staged);
     if (e == hipSuccess) e = hipHostMalloc((void**)&x->h_rpin, sizeof(so_keyframe_header) * (size_t)world * (size_t)records_per_tick + staged,
                                            hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMemset(x->d_rgathered, 0, slot * (size_t)world);
+    if (e == hipSuccess) e = so::memset_sync(x->d_rgathered, 0, slot * (size_t)world);
     if (e != hipSuccess) {
         so_exchange_destroy(x);
         return hip_fail(e, "exchange store init", __FILE__, __LINE__);
@@ -332,7 +332,7 @@ int so_exchange_read_record(so_exchange* x, int peer, int index, uint8_t* record
     if (!record) return SO_OK;
     if (capacity < bytes) return SO_ERR_CAPACITY;
     SO_HIP(hipSetDevice(x->device));
-    SO_HIP(hipMemcpy(record, x->d_rgathered + j * x->rec_stride, bytes, hipMemcpyDeviceToHost));
+    SO_HIP(so::memcpy_sync(record, x->d_rgathered + j * x->rec_stride, bytes, hipMemcpyDeviceToHost));
     return SO_OK;
 }
 
@@ -432,7 +432,7 @@ int so_exchange_read_slot(so_exchange* x, int peer, uint8_t* descriptors, int ca
     if (capacity < n) return SO_ERR_CAPACITY;
     SO_HIP(hipSetDevice(x->device));
     if (n > 0)
-        SO_HIP(hipMemcpy(descriptors, x->d_gathered + (size_t)peer * x->slot_bytes + 32, 32 * (size_t)n, hipMemcpyDeviceToHost));
+        SO_HIP(so::memcpy_sync(descriptors, x->d_gathered + (size_t)peer * x->slot_bytes + 32, 32 * (size_t)n, hipMemcpyDeviceToHost));
     return SO_OK;
 }
 

@@ -696,7 +696,7 @@ int so_extractor_get_candidates(so_extractor* ex, int level, int16_t* xs, int16_
     if (capacity < n) return SO_ERR_CAPACITY;
     if (!ex->cands_on_host && H.total > 0) {  // device-quadtree path: fetch the candidates on demand
         SO_HIP(hipSetDevice(ex->cfg.device));
-        SO_HIP(hipMemcpy(ex->h_cands, ex->d_cands, sizeof(Candidate) * (size_t)H.total, hipMemcpyDeviceToHost));
+        SO_HIP(so::memcpy_sync(ex->h_cands, ex->d_cands, sizeof(Candidate) * (size_t)H.total, hipMemcpyDeviceToHost));
         ex->cands_on_host = true;
     }
     const Candidate* c = ex->h_cands + H.offset[level];

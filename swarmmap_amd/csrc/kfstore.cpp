@@ -318,8 +318,8 @@ int so_kfstore_create(int device, int capacity_keyframes, int slot_keypoints, so
     if (e == hipSuccess) e = dev_alloc(&s->dev.angle, C * KP);
     if (e == hipSuccess) e = dev_alloc(&s->dev.nv, C);
     if (e == hipSuccess) e = dev_alloc(&s->dev.agent, C);
-    if (e == hipSuccess) e = hipMemset(s->dev.nv, 0, sizeof(int32_t) * C);
-    if (e == hipSuccess) e = hipMemset(s->dev.agent, 0xFF, sizeof(int32_t) * C);
+    if (e == hipSuccess) e = so::memset_sync(s->dev.nv, 0, sizeof(int32_t) * C);
+    if (e == hipSuccess) e = so::memset_sync(s->dev.agent, 0xFF, sizeof(int32_t) * C);
     if (e == hipSuccess) e = dev_alloc(&s->d_stage, (size_t)s->stage_records * s->dev.rec_stride);
     if (e == hipSuccess) e = dev_alloc(&s->d_query, s->dev.rec_stride);
     if (e == hipSuccess) e = dev_alloc(&s->d_qdesc, KP * 8);

@@ -22,6 +22,7 @@ namespace so {
 constexpr int kQtThreads = 1024;
 constexpr int kQtMaxKeys = kFastCap;  // 10000 candidates per level at most
 constexpr int kQtMaxNodes = 1024;     // list never exceeds N + 3 (N <= 1020 on this path)
+static_assert((kQtMaxKeys + kQtThreads - 1) / kQtThreads <= 16, "a thread's keys must fit the 4-bit codes of one 64-bit register");
 
 struct QtNode {  // 16 bytes
     int16_t x0, y0, x1, y1;
@@ -74,6 +75,29 @@ __device__ __forceinline__ u64 qt_block_scan64(u64 v, u64* s_w) {
 #pragma unroll
     for (int i = 0; i < kQtThreads / 64; i++)
         if (i < w) base += s_w[i];
+    return base + incl - v;
+}
+
+// the same, also returning the block total
+__device__ __forceinline__ u64 qt_block_scan64_total(u64 v, u64* s_w, u64* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u64 incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 u = (u64)__shfl_up((long long)incl, off);
+        if (lane >= off) incl += u;
+    }
+    __syncthreads();
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    u64 base = 0, t = 0;
+#pragma unroll
+    for (int i = 0; i < kQtThreads / 64; i++) {
+        const u64 x = s_w[i];
+        if (i < w) base += x;
+        t += x;
+    }
+    *total = t;
     return base + incl - v;
 }
 
@@ -177,8 +201,12 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
         QtNode* nnodes = s_nodes[b ^ 1];
         const uint16_t* keys = s_keys[b];
         const uint16_t* knode = s_knode[b];
-        // (B) quadrant of every key that sits in a non-leaf node; packed counts; prefix at the slice borders
-        u64 mine = 0;
+        // (B) quadrant of every key that sits in a non-leaf node; packed counts; prefix at the slice borders.
+        // The quadrant of a key costs a chain of dependent reads (key -> node slot -> node box; key -> candidate in
+        // global memory): it is worked out ONCE per step and kept as a 4-bit code (0 = leaf node, q + 1 otherwise) in a
+        // 64-bit register - a thread owns at most ten keys (10000 candidates / 1024 threads) - for the count, the
+        // prefix and the partition below (three such chains per step before: 42 -> see DESIGN 3)
+        u64 mine = 0, qcode = 0;
         for (int p = p0; p < p1; p++) {
             const QtNode nd = nodes[knode[p]];
             if (nd.n > 1) {
@@ -186,20 +214,19 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
                 const int xm = nd.x0 + (int)ceilf((float)(nd.x1 - nd.x0) / 2), ym = nd.y0 + (int)ceilf((float)(nd.y1 - nd.y0) / 2);
                 const int q = (c.x < xm ? 0 : 1) + (c.y < ym ? 0 : 2);
                 mine += 1ull << (16 * q);
+                qcode |= (u64)(q + 1) << (4 * (p - p0));
             }
         }
         const u64 excl = qt_block_scan64(mine, s_w64);
         {
             u64 run = excl;
             for (int p = p0; p < p1; p++) {
-                const int ni = knode[p];
-                const QtNode nd = nodes[ni];
-                if (nd.n > 1) {
+                const int qc = (int)((qcode >> (4 * (p - p0))) & 15ull);
+                if (qc) {
+                    const int ni = knode[p];
+                    const QtNode nd = nodes[ni];
                     if (p == nd.off) s_pre[ni] = run;
-                    const Candidate c = C[keys[p]];
-                    const int xm = nd.x0 + (int)ceilf((float)(nd.x1 - nd.x0) / 2), ym = nd.y0 + (int)ceilf((float)(nd.y1 - nd.y0) / 2);
-                    const int q = (c.x < xm ? 0 : 1) + (c.y < ym ? 0 : 2);
-                    run += 1ull << (16 * q);
+                    run += 1ull << (16 * (qc - 1));
                     if (p == nd.off + nd.n - 1) s_post[ni] = run;
                 }
             }
@@ -221,11 +248,28 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
                 }
             }
         }
-        // (A/C) which nodes are split, and in which order
-        int nsplit = 0;
+        // (A/C/D) which nodes are split and in which order; children prefix in processing order; rank of the untouched
+        // nodes in list order; how many of the new nodes can be split again
+        const int ne = nonleaf ? (cnt[0] > 1) + (cnt[1] > 1) + (cnt[2] > 1) + (cnt[3] > 1) : 0;
+        int nsplit = 0, cp = 0, ur = 0, total_children = 0, n_untouched = 0, n_to_expand = 0;
+        bool split = false;
         if (!careful) {
-            const int r = qt_block_scan(nonleaf ? 1 : 0, s_wi, &nsplit);
-            if (tid < m) s_proc[tid] = nonleaf ? r : -1;
+            // sweep: every non-leaf node is split, in list order - processing rank, children prefix, untouched rank and the
+            // count of splittable children are four 16-bit fields of ONE block scan (four scans and six barriers before)
+            const u64 v = tid < m ? ((u64)(nonleaf ? 1 : 0) | ((u64)(nonleaf ? k_children : 0) << 16) | ((u64)(nonleaf ? 0 : 1) << 32) |
+                                     ((u64)ne << 48))
+                                  : 0ull;
+            u64 tot = 0;
+            const u64 ex = qt_block_scan64_total(v, s_w64, &tot);
+            nsplit = qt_unpack(tot, 0);
+            total_children = qt_unpack(tot, 1);
+            n_untouched = qt_unpack(tot, 2);
+            n_to_expand = qt_unpack(tot, 3);
+            cp = qt_unpack(ex, 1);
+            ur = qt_unpack(ex, 2);
+            split = tid < m && nonleaf;
+            if (tid < m) s_proc[tid] = nonleaf ? qt_unpack(ex, 0) : -1;
+            __syncthreads();
         } else {
             // rank by (population, seq) descending among the non-leaf nodes (all of them were created last step)
             int rank = -1;
@@ -255,26 +299,25 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
             nsplit = s_misc[2];
             if (tid < m) s_proc[tid] = (nonleaf && rank < nsplit) ? rank : -1;
             __syncthreads();
+            split = tid < m && nonleaf && s_proc[tid] >= 0;
+            // children prefix in processing order
+            if (tid < kQtMaxNodes) s_kv[tid] = 0;
+            __syncthreads();
+            if (split) s_kv[s_proc[tid]] = k_children;
+            __syncthreads();
+            const int kv = tid < nsplit ? s_kv[tid] : 0;
+            const int cpre_sorted = qt_block_scan(kv, s_wi, &total_children);
+            __syncthreads();
+            if (tid < nsplit) s_kv[tid] = cpre_sorted;
+            ur = qt_block_scan((tid < m && !split) ? 1 : 0, s_wi, &n_untouched);
+            __syncthreads();
+            if (split) cp = s_kv[s_proc[tid]];
+            (void)qt_block_scan(split ? ne : 0, s_wi, &n_to_expand);
         }
-        const bool split = tid < m && nonleaf && s_proc[tid] >= 0;
-        // (D) children prefix in processing order; rank of the untouched nodes in list order
-        if (tid < kQtMaxNodes) s_kv[tid] = 0;
-        __syncthreads();
-        if (split) s_kv[s_proc[tid]] = k_children;
-        __syncthreads();
-        int total_children = 0, n_untouched = 0;
-        const int kv = tid < nsplit ? s_kv[tid] : 0;
-        const int cpre_sorted = qt_block_scan(kv, s_wi, &total_children);
-        __syncthreads();
-        if (tid < nsplit) s_kv[tid] = cpre_sorted;
-        const int ur = qt_block_scan((tid < m && !split) ? 1 : 0, s_wi, &n_untouched);
-        __syncthreads();
         const int m_new = total_children + n_untouched;
         // (E) new nodes; slot == position in the new list
-        int n_expand_local = 0;
         if (tid < m) {
             if (split) {
-                const int cp = s_kv[s_proc[tid]];
                 const int hx = (int)ceilf((float)(me.x1 - me.x0) / 2), hy = (int)ceilf((float)(me.y1 - me.y0) / 2);
                 const int xm = me.x0 + hx, ym = me.y0 + hy;
                 int r = 0, o = me.off;
@@ -292,7 +335,6 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
                         nd.seq = seq_base + 4u * (uint32_t)s_proc[tid] + (uint32_t)q;
                         nnodes[pos] = nd;
                         s_child[tid][q] = (uint16_t)pos;
-                        n_expand_local += cnt[q] > 1;
                         r++;
                     }
                     o += cnt[q];
@@ -303,8 +345,6 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
                 s_newslot[tid] = (uint16_t)pos;
             }
         }
-        int n_to_expand = 0;
-        (void)qt_block_scan(n_expand_local, s_wi, &n_to_expand);
         __syncthreads();
         // (F) stable 4-way partition of the keys of the split nodes
         {
@@ -313,13 +353,7 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
             u64 run = excl;
             for (int p = p0; p < p1; p++) {
                 const int ni = knode[p];
-                const QtNode nd = nodes[ni];
-                int q = -1;
-                if (nd.n > 1) {
-                    const Candidate c = C[keys[p]];
-                    const int xm = nd.x0 + (int)ceilf((float)(nd.x1 - nd.x0) / 2), ym = nd.y0 + (int)ceilf((float)(nd.y1 - nd.y0) / 2);
-                    q = (c.x < xm ? 0 : 1) + (c.y < ym ? 0 : 2);
-                }
+                const int q = (int)((qcode >> (4 * (p - p0))) & 15ull) - 1;
                 if (q >= 0 && s_proc[ni] >= 0) {
                     const int slot = s_child[ni][q];
                     const int rank = qt_unpack(run, q) - qt_unpack(s_pre[ni], q);

@@ -28,6 +28,12 @@ hipError_t tracking_stream(int device, int role, hipStream_t* s);  // capi.cpp
 // so_runtime_private_streams(1), for a thread that drives several agents - a stream of its own (*owned: the handle
 // destroys it).
 hipError_t context_stream(int device, int role, hipStream_t* s, bool* owned);  // capi.cpp
+// Blocking fills / copies WITHOUT the legacy default stream: hipMemset / hipMemcpy run on the null stream, which
+// synchronises with every other stream - and fails outright while another thread of the process (another agent) is
+// capturing its frame into a hipGraph ("operation would make the legacy stream depend on a capturing blocking stream").
+// These run on a non-blocking utility stream of the calling thread and wait for it.
+hipError_t memset_sync(void* dst, int value, size_t bytes);                          // capi.cpp
+hipError_t memcpy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);  // capi.cpp
 
 }  // namespace so
 

@@ -190,3 +190,43 @@ def test_every_adapter_method_matches_the_oracle(tmp_path, oracle):
     p = L["pose"].split()
     assert int(p[0]) == oni and np.abs(np.array([float(v) for v in p[1:13]], np.float32) - oT).max() <= 2e-5
     same("pose_outlier", ooutl, np.uint8)
+
+
+def test_agent_mediator_adapter_compiles_with_plain_gcc(tmp_path):
+    assert os.path.exists(_build_mediator(tmp_path))
+
+
+def _build_mediator(tmp_path):
+    exe = str(tmp_path / "mediator_smoke")
+    lib = os.path.join(ROOT, "swarmmap_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "mediator_smoke.cpp"),
+                           os.path.join(HOST, "AgentMediator.cc"), "-L" + lib, "-lswarmorb", "-Wl,-rpath," + lib,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@pytest.mark.gpu
+def test_agent_mediator_adapter_matches_the_oracle(tmp_path, oracle):
+    """AgentMediator::CheckOverlapCandidates + GetSim3's SearchByBoW loop (code/src/AgentMediator.cc:140-262) through the
+    C++ adapter: candidates (agent, keyframe, votes, match count) and vpMatches12 identical to the oracle's."""
+    from swarmmap_amd import synth
+    exe = _build_mediator(tmp_path)
+    d = str(tmp_path)
+    kfs = synth.make_kf_store_case(61, n_agents=3, kfs_per_agent=8, n_kp=250, n_places=4)
+    for k, kf in enumerate(kfs):
+        _w(d, "kf%d_meta" % k, [kf["agent"], kf["keyframe_id"]], np.int32)
+        for key, t in (("xy", np.float32), ("angle", np.float32), ("octave", np.int32), ("desc", np.uint8)):
+            _w(d, "kf%d_%s" % (k, key), kf[key], t)
+        _w(d, "kf%d_mp" % k, kf["map_point_id"], np.int32)
+    nq = 3
+    out = subprocess.check_output([exe, d, str(len(kfs)), str(nq), "250", "12", "12"], text=True, timeout=300).strip().splitlines()
+    assert out[0] == "store %d" % (len(kfs) - nq)
+    want = []
+    for k in range(len(kfs) - nq, len(kfs)):
+        _, cands, _ = oracle.kf_search(kfs[k], kfs[:len(kfs) - nq], min_votes=12, min_matches=12, max_candidates=8)
+        want.append("query %d candidates %d" % (k, len(cands)))
+        for slot, votes, nm, m1 in cands:
+            want.append("cand %d %d %d %d %d %s" % (kfs[slot]["agent"], kfs[slot]["keyframe_id"], slot, votes, nm,
+                                                   _fnv(np.ascontiguousarray(m1, np.int32).tobytes())))
+    assert out[1:] == want
+    assert any(line.startswith("cand") for line in want)
