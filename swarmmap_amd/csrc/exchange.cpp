@@ -345,19 +345,31 @@ int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stri
     SO_HIP(hipSetDevice(x->device));
     hipStream_t s = x->store->stream;
     SO_HIP(hipMemsetAsync(x->d_rslot, 0, x->rec_stride * (size_t)x->records_per_tick, s));
-    std::vector<const float*> angles((size_t)n_records);
-    std::vector<const int32_t*> mps((size_t)n_records);
+    // A tick is COLLECTIVE: a rank that returned before the all-gather because one of ITS records is malformed would
+    // leave every other rank waiting in theirs.  Such a rank takes part with zero records and reports the error afterwards.
+    bool bad_records = false;
     size_t need = 0;
     for (int j = 0; j < n_records; j++) {
         so_keyframe_header h;
         memcpy(&h, records + (size_t)j * stride, sizeof(h));
-        if (h.magic != 0x464B4F53u || h.n_keypoints < 0 || h.n_keypoints > x->slot_keypoints ||
-            !(h.version == 1 || (h.version == 2 && (h.flags & SO_KF_FLAG_MAP_POINTS)))) {
-            last_error_ref() = "exchange tick: not a keyframe record, or more keypoints than the slot holds";
-            return SO_ERR_INVALID_ARG;
-        }
-        need += (size_t)h.n_keypoints;
+        const bool v_ok = h.version == 1 || (h.version == 2 && (h.flags & SO_KF_FLAG_MAP_POINTS));
+        if (h.magic != 0x464B4F53u || h.n_keypoints < 0 || h.n_keypoints > x->slot_keypoints || !v_ok ||
+            (h.version == 2 ? so_keyframe_record_size2(h.n_keypoints) : so_keyframe_record_size(h.n_keypoints)) > stride)
+            bad_records = true;
+        else
+            need += (size_t)h.n_keypoints;
     }
+    if (bad_records) {
+        for (int j = 0; j < n_records; j++) n_out[j] = 0;
+        const std::vector<const float*> none_a;
+        const std::vector<const int32_t*> none_m;
+        const int rc = tick_store_common(x, 0, p, out, pairs, n_out, none_a, none_m);
+        last_error_ref() = "exchange tick: not a keyframe record, or more keypoints than the slot holds (the rank took part in the "
+                           "collective with zero records)";
+        return rc != SO_OK ? rc : SO_ERR_INVALID_ARG;
+    }
+    std::vector<const float*> angles((size_t)n_records);
+    std::vector<const int32_t*> mps((size_t)n_records);
     x->q_angle.resize(need ? need : 1);
     x->q_mp.resize(need ? need : 1);
     size_t at = 0;

@@ -83,6 +83,12 @@ def test_store_exchange_single_rank_searches_the_whole_store(S):
             total += len(got)
     assert x.tick_records([], p) == []
     assert total > 0 and x.store.size()[0] == len(peers)  # own keyframes were not appended
+    # a malformed record must not keep the rank out of the collective (the peers would wait for it forever): the tick
+    # runs with zero records of this rank and THEN reports the error; the next tick works
+    with pytest.raises(S.SwarmOrbError, match="took part in the collective"):
+        x.tick_records([np.zeros(4096, np.uint8)], p)
+    assert x.read_record(0, 0) is None
+    assert len(x.tick_records([_rec(mine[0])], p)) == 1
     x.close()
 
 

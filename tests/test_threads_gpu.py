@@ -62,3 +62,53 @@ def test_four_agents_in_threads_match_sequential_runs():
     assert not errs, errs
     for s in seeds:
         assert par[s] == ref[s], "agent %d: results depend on concurrency" % s
+
+
+def test_agents_started_at_the_same_moment_on_streams_of_their_own():
+    """Eight agents created and run by eight threads at the same time, every handle on a stream of its own
+    (so_runtime_private_streams): each allocates its device-resident frame and captures its frame graph while the others
+    do the same.  (A fill on the legacy default stream used to fail here: "operation would make the legacy stream depend
+    on a capturing blocking stream".)  Every agent's keypoints and descriptors equal a solo run's."""
+    import swarmmap_amd as S
+    from swarmmap_amd.replay import private_streams
+    img = [synth.make_canvas(20 + k, 752, 480) for k in range(3)]
+
+    def work(out, k):
+        ex = S.ORBextractor(1000, 1.2, 8, 20, 7)
+        f = S.DeviceFrame(ex, synth.EUROC_K, synth.EUROC_DIST)
+        res = []
+        for t in range(6):
+            kps, un, d = f(img[(k + t) % 3])
+            res.append((kps.tobytes(), un.tobytes(), d.tobytes()))
+        f.close(); ex.close()
+        out[k] = res
+
+    solo = {}
+    work(solo, 0)
+    private_streams(True)
+    try:
+        par, errs = {}, []
+        gate = threading.Barrier(8)
+
+        def run(k):
+            try:
+                gate.wait(timeout=60)
+                work(par, k)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        ths = [threading.Thread(target=run, args=(k,)) for k in range(8)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+    finally:
+        private_streams(False)
+    assert not errs, errs
+    # every (agent, frame) equals the solo result for the same image
+    by_img = {}
+    for t in range(6):
+        by_img[t % 3] = solo[0][t]
+    for k in range(8):
+        for t in range(6):
+            assert par[k][t] == by_img[(k + t) % 3], (k, t)
