@@ -290,8 +290,12 @@ int kfstore_search_device(so_kfstore* s, const uint8_t* d_query, const so_keyfra
 extern "C" {
 
 int so_kfstore_create(int device, int capacity_keyframes, int slot_keypoints, so_kfstore** out) {
-    if (!out || capacity_keyframes < 1 || slot_keypoints < 1 || slot_keypoints > 65535) return SO_ERR_INVALID_ARG;
+    if (!out || capacity_keyframes < 1 || slot_keypoints < 1) return SO_ERR_INVALID_ARG;
     *out = nullptr;
+    if (slot_keypoints > kKfMaxKeypoints) {  // phase 2 keeps one key per keypoint and wave in LDS (4 waves x 4 B x keypoints)
+        last_error_ref() = "keyframe store: at most 8192 keypoints per keyframe";
+        return SO_ERR_CAPACITY;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
         last_error_ref() = "no usable HIP device";

@@ -15,6 +15,8 @@
 
 namespace so {
 
+constexpr int kKfMaxKeypoints = 8192;  // per keyframe: 128 KB of dynamic LDS in kf_pair_topk_kernel
+
 struct KfStoreDev {
     uint8_t* rec;
     uint32_t* vdesc;

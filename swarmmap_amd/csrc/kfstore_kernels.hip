@@ -364,6 +364,14 @@ void launch_kf_scan(const KfStoreDev& S, int n_slots, const uint32_t* d_qdesc, i
 void launch_kf_pair_topk(const KfStoreDev& S, const int32_t* d_cand, int n_cand, const uint32_t* d_qdesc, int nqv, int K,
                          uint32_t* d_keys, hipStream_t s) {
     if (n_cand <= 0 || nqv <= 0) return;
+    static bool attr_set[64] = {};  // more than 64 KB of dynamic LDS has to be asked for once per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf_pair_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(uint32_t) * 4 * kKfMaxKeypoints));
+        attr_set[dev] = true;
+    }
     hipLaunchKernelGGL(kf_pair_topk_kernel, dim3((nqv + 3) / 4, n_cand), dim3(256), sizeof(uint32_t) * 4 * (size_t)S.kp, s, S,
                        d_cand, d_qdesc, nqv, K, d_keys);
 }

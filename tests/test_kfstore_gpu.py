@@ -202,3 +202,16 @@ def test_full_size_store_properties(S):
     assert st["pairs"] == float(nb) * sum(int((k["map_point_id"] >= 0).sum()) for k, o in zip(kfs, own) if not o)
     assert np.array_equal(store.votes(_rec(q)), v)
     store.close()
+
+
+def test_keyframes_of_kitti_init_size_and_the_keypoint_cap(S):
+    """4024 keypoints per keyframe (the KITTI initialisation extractor's 2 x 2000 + 24): phase 2 needs more than 64 KB of
+    dynamic LDS; beyond 8192 keypoints the store refuses with SO_ERR_CAPACITY."""
+    from swarmmap_amd.kfstore import KeyframeStore, search_params
+    kfs = synth.make_kf_store_case(8, n_agents=2, kfs_per_agent=2, n_kp=4024, n_places=1, ragged=False, bound_frac=0.7)
+    store = KeyframeStore(4, 4024)
+    store.append([_rec(k) for k in kfs[:-1]])
+    _check_search(store, kfs[-1], kfs[:-1], min_votes=20, min_matches=20)
+    store.close()
+    with pytest.raises(S.SwarmOrbError):
+        KeyframeStore(4, 8193)
