@@ -378,18 +378,29 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
     }
 
     // ---------------- best response per node, list order (:667-686) ----------------
+    // The reference keeps the FIRST maximum of `response` in the node's insertion order.  A thread per node walking its
+    // keys would chain one global read per key (16 on average at level 0); instead every key fetches its own score - all
+    // in flight together - and the node's winner is an LDS atomicMax over (score << 16 | 0xFFFF - rank in the node):
+    // highest score, lowest rank on ties.
+    int* s_best = s_proc;  // (dead after the last split step)
+    if (tid < kQtMaxNodes) s_best[tid] = -1;
+    __syncthreads();
+    {
+        const uint16_t* keys = s_keys[b];
+        const uint16_t* knode = s_knode[b];
+        const QtNode* nodes = s_nodes[b];
+        for (int p = p0; p < p1; p++) {
+            const int ni = knode[p];
+            const int sc = C[keys[p]].score;
+            atomicMax(&s_best[ni], (sc << 16) | (0xFFFF - (p - (int)nodes[ni].off)));
+        }
+    }
+    __syncthreads();
     if (tid < m) {
         const QtNode nd = s_nodes[b][tid];
-        int best = s_keys[b][nd.off];
-        int best_score = C[best].score;
-        for (int k = 1; k < nd.n; k++) {
-            const int ci = s_keys[b][nd.off + k];
-            const int sc = C[ci].score;
-            if (sc > best_score) {
-                best = ci;
-                best_score = sc;
-            }
-        }
+        const int v = s_best[tid];
+        const int best = s_keys[b][nd.off + (0xFFFF - (v & 0xFFFF))];
+        const int best_score = v >> 16;
         SelectedKp o;
         o.x = (int16_t)(C[best].x + kFastBorder);  // addBorder_kernel, Fast_gpu.cu:461-470
         o.y = (int16_t)(C[best].y + kFastBorder);
