@@ -591,6 +591,14 @@ int so_kfstore_last_stats(so_kfstore* s, double* stats6);
  * slot_keypoints entries / one count, in record order (pairs may be NULL).  n_records may be 0 (the rank only receives). */
 int so_exchange_create_store(int device, int rank, int world, const uint8_t* id128, int slot_keypoints,
                              int records_per_tick, int store_keyframes, so_exchange** out);
+/* The same exchange over the HOST's transport instead of RCCL - agents that do not share a node (the reference's agents
+ * reach their server over WebSockets, code/src/WebSocket.cc, code/src/ClientService.cc) or a build without RCCL.
+ * allgather(user, send, recv, bytes_per_rank) delivers every rank's `bytes_per_rank` to every rank, in rank order
+ * (recv = world x bytes_per_rank), and returns 0; it is called once per tick, from the ticking thread, with pinned host
+ * buffers.  Everything else (records, store, search, the collective nature of a tick) is as above. */
+typedef int (*so_exchange_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+int so_exchange_create_store_host(int device, int rank, int world, so_exchange_allgather_fn allgather, void* user,
+                                  int slot_keypoints, int records_per_tick, int store_keyframes, so_exchange** out);
 int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stride, int32_t n_records,
                              const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs, int32_t* n_out);
 /* The same for ONE keyframe whose descriptors and undistorted keypoints are device-resident (the frame tracked last):

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "dframe_internal.h"
@@ -90,6 +91,12 @@ struct so_exchange {
     uint8_t* d_rgathered = nullptr;  // world x records_per_tick records in rank order
     uint8_t* d_staged = nullptr;     // header + angles + bindings of a device-resident keyframe
     uint8_t* h_rpin = nullptr;       // pinned: [world x records_per_tick headers | staged block]
+    // transport of the candidate-search mode: RCCL (comm != null) or the host's own all-gather (SwarmMap's WebSocket
+    // layer, MPI, ...: agents that do not share a node), which moves the slot through pinned host memory
+    so_exchange_allgather_fn host_gather = nullptr;
+    void* host_user = nullptr;
+    uint8_t* h_slot = nullptr;      // pinned: this rank's slot
+    uint8_t* h_gathered = nullptr;  // pinned: world slots
     std::vector<so_keyframe_header> hdrs;
     std::vector<uint8_t> skip;
     std::vector<float> q_angle;
@@ -158,12 +165,25 @@ int tick_common(so_exchange* x, const uint8_t* d_desc, int n, int max_dist, floa
 // append the peers' records to the store, search every own record against the whole store.
 int tick_store_common(so_exchange* x, int n_mine, const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs,
                       int32_t* n_out, const std::vector<const float*>& angles, const std::vector<const int32_t*>& mps) {
-    const Rccl& R = rccl();
+    static const Rccl no_rccl;
+    const Rccl& R = x->host_gather ? no_rccl : rccl();
     so_kfstore* S = x->store;
     hipStream_t s = S->stream;
     const int K = x->records_per_tick, total = x->world * K;
-    const ncclResult_t r = R.AllGather(x->d_rslot, x->d_rgathered, x->rec_stride * (size_t)K, kNcclUint8, x->comm, s);
-    if (r != 0) return rccl_fail(r, "ncclAllGather");
+    const size_t slot_bytes = x->rec_stride * (size_t)K;
+    if (x->host_gather) {  // the host's transport: slot down, all-gather on the host, gathered slots up
+        SO_HIP(hipMemcpyAsync(x->h_slot, x->d_rslot, slot_bytes, hipMemcpyDeviceToHost, s));
+        SO_HIP(hipStreamSynchronize(s));
+        const int grc = x->host_gather(x->host_user, x->h_slot, x->h_gathered, slot_bytes);
+        if (grc != 0) {
+            last_error_ref() = "exchange tick: the host all-gather callback failed (" + std::to_string(grc) + ")";
+            return SO_ERR_HIP;
+        }
+        SO_HIP(hipMemcpyAsync(x->d_rgathered, x->h_gathered, slot_bytes * (size_t)x->world, hipMemcpyHostToDevice, s));
+    } else {
+        const ncclResult_t r = R.AllGather(x->d_rslot, x->d_rgathered, slot_bytes, kNcclUint8, x->comm, s);
+        if (r != 0) return rccl_fail(r, "ncclAllGather");
+    }
     so_keyframe_header* hh = reinterpret_cast<so_keyframe_header*>(x->h_rpin);
     SO_HIP(hipMemcpy2DAsync(hh, sizeof(so_keyframe_header), x->d_rgathered, x->rec_stride, sizeof(so_keyframe_header),
                             (size_t)total, hipMemcpyDeviceToHost, s));
@@ -261,6 +281,8 @@ void so_exchange_destroy(so_exchange* x) {
         if (p) (void)hipFree(p);
     if (x->h_pin) (void)hipHostFree(x->h_pin);
     if (x->h_rpin) (void)hipHostFree(x->h_rpin);
+    if (x->h_slot) (void)hipHostFree(x->h_slot);
+    if (x->h_gathered) (void)hipHostFree(x->h_gathered);
     if (x->store) so_kfstore_destroy(x->store);
     if (x->stream) (void)hipStreamDestroy(x->stream);
     delete x;
@@ -268,7 +290,7 @@ void so_exchange_destroy(so_exchange* x) {
 
 int so_exchange_tick_dframe(so_exchange* x, const so_dframe* f, int max_dist, float ratio, int32_t* peer_counts,
                             int32_t* peer_candidates) {
-    if (!x || !f || !f->ready) return SO_ERR_INVALID_ARG;
+    if (!x || !x->comm || !f || !f->ready) return SO_ERR_INVALID_ARG;
     if (f->device != x->device) {
         last_error_ref() = "frame and exchange live on different devices";
         return SO_ERR_INVALID_ARG;
@@ -279,12 +301,15 @@ int so_exchange_tick_dframe(so_exchange* x, const so_dframe* f, int max_dist, fl
 
 int so_exchange_tick(so_exchange* x, const uint8_t* descriptors, int n, int max_dist, float ratio, int32_t* peer_counts,
                      int32_t* peer_candidates) {
-    if (!x || n < 0 || (n > 0 && !descriptors)) return SO_ERR_INVALID_ARG;
+    if (!x || !x->comm || n < 0 || (n > 0 && !descriptors)) return SO_ERR_INVALID_ARG;
     SO_HIP(hipSetDevice(x->device));
     const int nk = n < x->slot_keypoints ? n : x->slot_keypoints;
     if (nk > 0) SO_HIP(hipMemcpyAsync(x->d_stage, descriptors, 32 * (size_t)nk, hipMemcpyHostToDevice, x->stream));
     return tick_common(x, x->d_stage, nk, max_dist, ratio, peer_counts, peer_candidates);
 }
+
+static int attach_store(so_exchange* x, int device, int world, int slot_keypoints, int records_per_tick, int store_keyframes,
+                        so_exchange** out);
 
 int so_exchange_create_store(int device, int rank, int world, const uint8_t* id128, int slot_keypoints,
                              int records_per_tick, int store_keyframes, so_exchange** out) {
@@ -293,7 +318,38 @@ int so_exchange_create_store(int device, int rank, int world, const uint8_t* id1
     if (rc != SO_OK) return rc;
     so_exchange* x = *out;
     *out = nullptr;
-    rc = so_kfstore_create(device, store_keyframes, slot_keypoints, &x->store);
+    return attach_store(x, device, world, slot_keypoints, records_per_tick, store_keyframes, out);
+}
+
+// The same exchange over the HOST's transport instead of RCCL: agents that do not share a node (the reference's robots
+// talk to their server over WebSockets, code/src/WebSocket.cc) or a build without RCCL.  `allgather(user, send, recv,
+// bytes)` must deliver every rank's `bytes` to every rank in rank order (recv = world x bytes) and return 0; it is
+// called once per tick from the ticking thread with pinned host buffers.
+int so_exchange_create_store_host(int device, int rank, int world, so_exchange_allgather_fn allgather, void* user,
+                                  int slot_keypoints, int records_per_tick, int store_keyframes, so_exchange** out) {
+    if (!out || !allgather || world < 1 || rank < 0 || rank >= world || slot_keypoints < 1 || records_per_tick < 1 ||
+        records_per_tick > 64 || store_keyframes < 1)
+        return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        last_error_ref() = "no usable HIP device";
+        return SO_ERR_NO_DEVICE;
+    }
+    SO_HIP(hipSetDevice(device));
+    so_exchange* x = new so_exchange();
+    x->device = device;
+    x->rank = rank;
+    x->world = world;
+    x->slot_keypoints = slot_keypoints;
+    x->host_gather = allgather;
+    x->host_user = user;
+    return attach_store(x, device, world, slot_keypoints, records_per_tick, store_keyframes, out);
+}
+
+static int attach_store(so_exchange* x, int device, int world, int slot_keypoints, int records_per_tick, int store_keyframes,
+                        so_exchange** out) {
+    int rc = so_kfstore_create(device, store_keyframes, slot_keypoints, &x->store);
     if (rc != SO_OK) {
         so_exchange_destroy(x);
         return rc;
@@ -308,6 +364,8 @@ int so_exchange_create_store(int device, int rank, int world, const uint8_t* id1
     if (e == hipSuccess) e = hipHostMalloc((void**)&x->h_rpin, sizeof(so_keyframe_header) * (size_t)world * (size_t)records_per_tick + staged,
                                            hipHostMallocDefault);
     if (e == hipSuccess) e = so::memset_sync(x->d_rgathered, 0, slot * (size_t)world);
+    if (e == hipSuccess && x->host_gather) e = hipHostMalloc((void**)&x->h_slot, slot, hipHostMallocDefault);
+    if (e == hipSuccess && x->host_gather) e = hipHostMalloc((void**)&x->h_gathered, slot * (size_t)world, hipHostMallocDefault);
     if (e != hipSuccess) {
         so_exchange_destroy(x);
         return hip_fail(e, "exchange store init", __FILE__, __LINE__);
@@ -436,7 +494,7 @@ int so_exchange_tick_keyframe(so_exchange* x, const so_dframe* f, const so_keyfr
 
 // Rank `peer`'s slot as gathered by the last tick (tests, host merger): descriptors and the header's checksum.
 int so_exchange_read_slot(so_exchange* x, int peer, uint8_t* descriptors, int capacity, int* n_out, uint64_t* checksum) {
-    if (!x || peer < 0 || peer >= x->world || !n_out) return SO_ERR_INVALID_ARG;
+    if (!x || !x->comm || peer < 0 || peer >= x->world || !n_out) return SO_ERR_INVALID_ARG;
     const int n = x->counts[(size_t)peer];
     *n_out = n;
     if (checksum) *checksum = x->sums[(size_t)peer];

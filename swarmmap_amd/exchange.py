@@ -11,6 +11,9 @@ import numpy as np
 from . import _lib
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
 def _bind(lib):
     if getattr(lib, "_exchange_bound", False):
         return
@@ -25,6 +28,7 @@ def _bind(lib):
     lib.so_exchange_create_store.argtypes = [i32, i32, i32, vp, i32, i32, i32, C.POINTER(vp)]
     lib.so_exchange_tick_records.argtypes = [vp, vp, C.c_size_t, C.c_int32, vp, vp, vp, vp]
     lib.so_exchange_tick_keyframe.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.so_exchange_create_store_host.argtypes = [i32, i32, i32, ALLGATHER_FN, vp, i32, i32, i32, C.POINTER(vp)]
     lib.so_exchange_store.argtypes = [vp]
     lib.so_exchange_read_record.argtypes = [vp, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.so_exchange_store.restype = vp
@@ -109,6 +113,38 @@ class StoreExchange:
         self.store.capacity, self.store.slot_keypoints = int(store_keyframes), self.slot_keypoints
         self.store._h = C.c_void_p(self._lib.so_exchange_store(self._h))
         self.store.close = lambda: None
+
+    @classmethod
+    def over_host_transport(cls, device, rank, world, allgather, slot_keypoints, records_per_tick=4, store_keyframes=4096):
+        """so_exchange_create_store_host: the same exchange over the caller's own all-gather instead of RCCL.
+        allgather(send: uint8 array, recv: writable uint8 array of world x len(send)) -> None."""
+        from . import kfstore
+        self = cls.__new__(cls)
+        self._lib = _lib.load_library()
+        _bind(self._lib)
+        kfstore._bind(self._lib)
+        self.rank, self.world, self.slot_keypoints = int(rank), int(world), int(slot_keypoints)
+        self.records_per_tick = int(records_per_tick)
+
+        def _cb(_user, send, recv, nbytes):
+            try:
+                src = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(send))
+                dst = np.ctypeslib.as_array((C.c_uint8 * (nbytes * self.world)).from_address(recv))
+                allgather(src, dst)
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the status of the tick
+                return 1
+
+        self._cb = ALLGATHER_FN(_cb)  # (kept alive as long as the exchange)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.so_exchange_create_store_host(int(device), self.rank, self.world, self._cb, None, self.slot_keypoints,
+                                                           self.records_per_tick, int(store_keyframes), C.byref(self._h)))
+        self.store = kfstore.KeyframeStore.__new__(kfstore.KeyframeStore)
+        self.store._lib = self._lib
+        self.store.capacity, self.store.slot_keypoints = int(store_keyframes), self.slot_keypoints
+        self.store._h = C.c_void_p(self._lib.so_exchange_store(self._h))
+        self.store.close = lambda: None
+        return self
 
     @classmethod
     def from_process_group(cls, device, slot_keypoints, records_per_tick=4, store_keyframes=4096):

@@ -124,3 +124,68 @@ def test_store_exchange_keyframe_assembled_on_the_device(S):
     assert len(got) == 1 and got[0]["slot"] == 1 and got[0]["keyframe_id"] == 500 and got[0]["n_matches"] == nb
     assert np.array_equal(got[0]["match_of_1"][:n][mp >= 0], np.nonzero(mp >= 0)[0])
     f.close(); ex.close(); x.close()
+
+
+def test_two_ranks_over_the_host_transport_find_each_other(S):
+    """World size 2 on ONE GPU.  RCCL refuses two ranks on one device (tools/two_ranks_one_gpu.py: ncclCommInitRank ->
+    invalid usage), so the two ranks of this test exchange their slots through so_exchange_create_store_host - the
+    transport a deployment without a shared node uses - with a thread rendezvous standing in for the network.  Everything
+    around the all-gather is the code the RCCL path runs: headers of both ranks parsed, own records skipped, the peer's
+    appended to the rank's own store on the device, own keyframes searched against all of it.  Three agents' keyframes
+    revisit a few places; every rank must report exactly what the oracle finds in ITS store, tick by tick - including
+    keyframes the peer sent several ticks earlier."""
+    import threading
+    from oracle import oracle_py
+    from swarmmap_amd.exchange import StoreExchange
+    from swarmmap_amd.kfstore import search_params
+    world, K, kp = 2, 3, 260
+    kfs = synth.make_kf_store_case(73, n_agents=world, kfs_per_agent=9, n_kp=kp, n_places=3)
+    per_tick = [[[k for k in kfs if k["agent"] == r][3 * t:3 * t + 3][:1 + (t + r) % 3] for t in range(3)] for r in range(world)]
+    gate = threading.Barrier(world)
+    bufs = [None] * world
+    errs, got = [], [[] for _ in range(world)]
+
+    def make_gather(rank):
+        def allgather(send, recv):
+            bufs[rank] = send.copy()
+            gate.wait(timeout=60)
+            n = len(send)
+            for r in range(world):
+                recv[r * n:(r + 1) * n] = bufs[r]
+            gate.wait(timeout=60)
+        return allgather
+
+    def run(rank):
+        try:
+            x = StoreExchange.over_host_transport(0, rank, world, make_gather(rank), kp, records_per_tick=K, store_keyframes=32)
+            p = search_params(min_votes=10, min_matches=10, max_candidates=8)
+            for t in range(3):
+                res = x.tick_records([_rec(k) for k in per_tick[rank][t]], p)
+                got[rank].append([[(c["slot"], c["agent_id"], c["keyframe_id"], c["votes"], c["n_matches"], c["match_of_1"].tobytes())
+                                   for c in r] for r in res])
+            got[rank].append(x.store.size()[0])
+            x.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            gate.abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    found = 0
+    for rank in range(world):
+        store = []  # what this rank's store holds, in append order: tick by tick, the peer's records in position order
+        for t in range(3):
+            for r in range(world):
+                if r != rank:
+                    store += per_tick[r][t]
+            for j, q in enumerate(per_tick[rank][t]):
+                _, ocands, _ = oracle_py.kf_search(q, store, min_votes=10, min_matches=10, max_candidates=8)
+                want = [(s, store[s]["agent"], store[s]["keyframe_id"], v, nm, m1.tobytes()) for s, v, nm, m1 in ocands]
+                assert got[rank][t][j] == want, (rank, t, j)
+                found += len(want)
+        assert got[rank][3] == len(store)
+    assert found > 0
