@@ -174,13 +174,14 @@ __global__ __launch_bounds__(256) void kf_scan_kernel(const uint32_t* __restrict
         }
     };
     int t = 0;
-    for (; t + 4 <= n; t += 4) {  // four rows per trip: 32 dwords of scalar loads in flight under 72 Q vector instructions
+    constexpr int kRows = Q == 1 ? 8 : 4;  // rows per trip: 64 / 32 dwords of scalar loads in flight under 144 / 72 Q vector instructions
+    for (; t + kRows <= n; t += kRows) {
         ConstU32Ptr r = T + (size_t)t * 8;
-        uint32_t w[32];
+        uint32_t w[8 * kRows];
 #pragma unroll
-        for (int k = 0; k < 32; k++) w[k] = r[k];
+        for (int k = 0; k < 8 * kRows; k++) w[k] = r[k];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < kRows; u++)
             step(w[8 * u], w[8 * u + 1], w[8 * u + 2], w[8 * u + 3], w[8 * u + 4], w[8 * u + 5], w[8 * u + 6], w[8 * u + 7]);
     }
     for (; t < n; t++) {

@@ -11,3 +11,29 @@ def test_inline_dpp_reads_keep_their_wait_states():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 hazard violations" in r.stdout
+
+
+def test_detection_scan_streams_the_store_through_the_scalar_unit():
+    """kf_scan_kernel<1> (kfstore_kernels.hip) as DESIGN.md 6 describes it: the store's rows arrive by scalar loads
+    (s_load_dwordx16: the rows are SGPR operands of the vector XORs, no LDS, no vector loads in the loop), a descriptor
+    pair costs 8 v_xor + 8 accumulating v_bcnt + v_med3 + v_min, and nothing spills."""
+    import re
+    src = os.path.join(ROOT, "swarmmap_amd", "csrc", "kfstore_kernels.hip")
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only",
+                          "-S", src, "-o", "-"], capture_output=True, text=True, timeout=600)
+    assert asm.returncode == 0, asm.stderr[-2000:]
+    text = asm.stdout
+    m = re.search(r"^(_ZN2so\S*kf_scan_kernelILi1E\w*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert m, "kf_scan_kernel<1> not found in the assembly"
+    body = m.group(2)
+    loops = re.findall(r"^(\.LBB\d+_\d+):.*?Inner Loop Header.*?\n(.*?)s_cbranch_scc\d \1", body, flags=re.S | re.M)
+    assert loops, "no inner loop found"
+    main = max((b for _, b in loops), key=len)  # the 8-rows-per-trip loop
+    n = lambda pat: len(re.findall(pat, main))  # noqa: E731
+    assert n(r"s_load_dwordx16") == 4 and n(r"global_load|buffer_load|ds_read|ds_load") == 0
+    assert n(r"v_bcnt_u32_b32") == 64 and n(r"v_xor_b32") == 64 and n(r"v_med3_i32") == 8 and n(r"v_min_i32") == 8
+    valu = n(r"^\s+v_\w+")
+    assert valu <= 8 * 18 + 6, "more vector instructions per pair than the design says: %d for 8 rows" % valu
+    meta = re.search(r"\.name:\s+%s\b.*?\.vgpr_spill_count:\s+(\d+)" % re.escape(m.group(1)), text, flags=re.S)
+    if meta:
+        assert int(meta.group(1)) == 0
