@@ -576,6 +576,12 @@ int so_kfstore_votes(so_kfstore* s, const uint8_t* query_record, size_t length, 
  * *n_out = candidates that passed min_matches.  n_evaluated (may be NULL) = keyframes phase 2 looked at. */
 int so_kfstore_search(so_kfstore* s, const uint8_t* query_record, size_t length, const so_kf_search_params* p,
                       so_kf_candidate* out, int32_t* pairs, int32_t* n_out, int32_t* n_evaluated);
+/* phase 2 alone on the store slots the caller names (<= SO_KF_MAX_CANDIDATES): for a host that filters the detection
+ * result itself before matching - the reference's covisibility-consistency groups (AgentMediator::DetectLoop,
+ * code/src/AgentMediator.cc:384-456) sit between DetectLoopCandidates and GetSim3.  so_kfstore_votes gives the scores,
+ * the host picks, this matches; out[c].votes is 0.  Same outputs as so_kfstore_search otherwise. */
+int so_kfstore_match(so_kfstore* s, const uint8_t* query_record, size_t length, const int32_t* slots, int32_t n_slots,
+                     const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs, int32_t* n_out);
 /* the record stored at `slot`, as appended (the merger needs the geometry and pose of a candidate) */
 int so_kfstore_read(so_kfstore* s, int32_t slot, uint8_t* record, size_t capacity, size_t* length);
 /* stats of the last search: [0] scan kernel ms (HIP events), [1] descriptor pairs the scan compared, [2] keyframes

@@ -163,10 +163,7 @@ int kfstore_search_device(so_kfstore* s, const uint8_t* d_query, const so_keyfra
     if (n_slots > 0 && nqv > 0 && hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->stats[0] = ms;
     double pairs_cmp = 0.0;
     int scanned = 0;
-    struct Cand {
-        int slot, votes;
-    };
-    std::vector<Cand> cands;
+    std::vector<KfCand> cands;
     for (int k = 0; k < n_slots; k++) {
         const KfMeta& m = s->meta[(size_t)k];
         if (!m.used || m.agent == qh.agent_id) continue;
@@ -180,12 +177,28 @@ int kfstore_search_device(so_kfstore* s, const uint8_t* d_query, const so_keyfra
     s->stats[2] = scanned;
     if (votes_only) return SO_OK;
     // candidates by (votes descending, slot ascending)
-    std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.votes > b.votes; });
+    std::stable_sort(cands.begin(), cands.end(), [](const KfCand& a, const KfCand& b) { return a.votes > b.votes; });
     const int max_c = std::min(std::min(p->max_candidates, (int)SO_KF_MAX_CANDIDATES), (int)cands.size());
     if (max_c <= 0 || nqv == 0) return SO_OK;
     if (n_evaluated) *n_evaluated = max_c;
+    cands.resize((size_t)max_c);
+    return kfstore_match_device(s, qh, q_angle, qidx, cands, p, out, pairs, n_out);
+}
+
+// Phase 2 on a given list of store slots: the exact SearchByBoW(KF1, KF2) of code/src/ORBmatcher.cc:481-597 with all
+// features in one vocabulary node, per candidate.  The query's compacted rows are in s->d_qdesc (kf_compact_query_kernel
+// has run on s->stream), qidx lists their keypoint indices.
+int kfstore_match_device(so_kfstore* s, const so_keyframe_header& qh, const float* q_angle, const std::vector<int>& qidx,
+                         const std::vector<KfCand>& cands, const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs,
+                         int32_t* n_out) {
+    hipStream_t st = s->stream;
+    const int kp = s->dev.kp;
+    const int n1 = qh.n_keypoints, nqv = (int)qidx.size(), max_c = (int)cands.size();
+    float ms = 0.f;
+    if (n_out) *n_out = 0;
+    if (max_c <= 0 || nqv == 0) return SO_OK;
     s->stats[4] = max_c;
-    // phase 2: K-lists of every bound query keypoint against every candidate, the candidates' angles
+    // K-lists of every bound query keypoint against every candidate, the candidates' angles
     for (int c = 0; c < max_c; c++) s->h_cand[c] = cands[(size_t)c].slot;
     SO_HIP(hipMemcpyAsync(s->d_cand, s->h_cand, sizeof(int32_t) * (size_t)max_c, hipMemcpyHostToDevice, st));
     SO_HIP(hipEventRecord(s->ev0, st));
@@ -461,6 +474,34 @@ int so_kfstore_search(so_kfstore* s, const uint8_t* query_record, size_t length,
     if (rc != SO_OK) return rc;
     return kfstore_search_device(s, s->d_query, h, s->scratch_angle.data(), s->scratch_mp.data(), p, false, nullptr, out,
                                  pairs, n_out, n_evaluated);
+}
+
+// Phase 2 alone, on the slots the caller names: what the reference runs AFTER its own filtering of the detection result
+// (AgentMediator::DetectLoop's covisibility-consistency groups, code/src/AgentMediator.cc:384-456, between
+// DetectLoopCandidates and GetSim3).  so_kfstore_votes gives the detection scores, the host picks, this matches.
+int so_kfstore_match(so_kfstore* s, const uint8_t* query_record, size_t length, const int32_t* slots, int32_t n_slots,
+                     const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs, int32_t* n_out) {
+    if (!s || !p || !out || !n_out || n_slots < 0 || n_slots > SO_KF_MAX_CANDIDATES || (n_slots > 0 && !slots)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(s->device));
+    so_keyframe_header h;
+    int rc = stage_query(s, query_record, length, &h, &s->scratch_angle, &s->scratch_mp);
+    if (rc != SO_OK) return rc;
+    for (int k = 0; k < 6; k++) s->stats[k] = 0.0;
+    std::vector<int>& qidx = s->scratch_qidx;
+    qidx.clear();
+    for (int i = 0; i < h.n_keypoints; i++)
+        if (s->scratch_mp[(size_t)i] >= 0) qidx.push_back(i);
+    std::vector<KfCand> cands;
+    for (int c = 0; c < n_slots; c++) {
+        if (slots[c] < 0 || slots[c] >= s->dev.capacity || !s->meta[(size_t)slots[c]].used) {
+            last_error_ref() = "keyframe store: match against an empty or out-of-range slot";
+            return SO_ERR_INVALID_ARG;
+        }
+        cands.push_back({slots[c], 0});
+    }
+    launch_kf_compact_query(s->d_query, s->dev.kp, s->d_qdesc, s->d_qidx, s->d_nqv, s->stream);
+    SO_HIP(hipGetLastError());
+    return kfstore_match_device(s, h, s->scratch_angle.data(), qidx, cands, p, out, pairs, n_out);
 }
 
 int so_kfstore_read(so_kfstore* s, int32_t slot, uint8_t* record, size_t capacity, size_t* length) {

@@ -66,6 +66,12 @@ namespace so {
 
 int kfstore_append_device(so_kfstore* s, const uint8_t* d_src, size_t src_stride, const so_keyframe_header* hdrs,
                           const uint8_t* skip, int n, int32_t* slots_out, hipStream_t stream);
+struct KfCand {
+    int slot, votes;
+};
+int kfstore_match_device(so_kfstore* s, const so_keyframe_header& qh, const float* q_angle, const std::vector<int>& qidx,
+                         const std::vector<KfCand>& cands, const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs,
+                         int32_t* n_out);
 int kfstore_search_device(so_kfstore* s, const uint8_t* d_query, const so_keyframe_header& qh, const float* q_angle,
                           const int32_t* q_mp, const so_kf_search_params* p, bool votes_only, int32_t* votes_out,
                           so_kf_candidate* out, int32_t* pairs, int32_t* n_out, int32_t* n_evaluated);

@@ -42,6 +42,7 @@ def _bind(lib):
     lib.so_kfstore_size.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_int64)]
     lib.so_kfstore_votes.argtypes = [vp, vp, C.c_size_t, i32, C.c_float, vp]
     lib.so_kfstore_search.argtypes = [vp, vp, C.c_size_t, C.POINTER(SoKfSearchParams), vp, vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.so_kfstore_match.argtypes = [vp, vp, C.c_size_t, vp, i32, C.POINTER(SoKfSearchParams), vp, vp, C.POINTER(i32)]
     lib.so_kfstore_read.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.so_kfstore_last_stats.argtypes = [vp, vp]
     lib._kfstore_bound = True
@@ -155,6 +156,19 @@ class KeyframeStore:
         _lib.check(self._lib.so_kfstore_search(self._h, q.ctypes.data, q.nbytes, C.byref(p), out,
                                                pairs.ctypes.data if want_pairs else None, C.byref(n_out), C.byref(n_eval)))
         return candidates_to_list(out, n_out.value, pairs, nq), n_eval.value
+
+    def match(self, query_record, slots, params=None):
+        """Phase 2 alone on the given store slots (the host has filtered the detection result itself)."""
+        p = params if params is not None else search_params()
+        q = np.ascontiguousarray(query_record, np.uint8).reshape(-1)
+        nq = int(q[12:16].view(np.int32)[0])
+        sl = np.ascontiguousarray(slots, np.int32)
+        out = (SoKfCandidate * max(len(sl), 1))()
+        pairs = np.full(max(len(sl), 1) * max(nq, 1), -1, np.int32)
+        n_out = C.c_int32(0)
+        _lib.check(self._lib.so_kfstore_match(self._h, q.ctypes.data, q.nbytes, sl.ctypes.data, len(sl), C.byref(p), out,
+                                              pairs.ctypes.data, C.byref(n_out)))
+        return candidates_to_list(out, n_out.value, pairs, nq)
 
     def read(self, slot):
         ln = C.c_size_t(0)

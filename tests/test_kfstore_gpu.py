@@ -215,3 +215,28 @@ def test_keyframes_of_kitti_init_size_and_the_keypoint_cap(S):
     store.close()
     with pytest.raises(S.SwarmOrbError):
         KeyframeStore(4, 8193)
+
+
+def test_match_alone_on_slots_the_host_picked(S):
+    """so_kfstore_votes -> the host filters (the reference's DetectLoop consistency groups sit here,
+    code/src/AgentMediator.cc:384-456) -> so_kfstore_match: phase 2 on exactly the slots named, whatever their votes,
+    equal to SearchByBoW(KF, KF) of the oracle on each of them."""
+    from swarmmap_amd.kfstore import KeyframeStore, search_params
+    kfs = synth.make_kf_store_case(31, n_agents=3, kfs_per_agent=6, n_kp=220, n_places=3)
+    store = KeyframeStore(32, 220)
+    store.append([_rec(k) for k in kfs[:-1]])
+    q = kfs[-1]
+    votes = store.votes(_rec(q))
+    others = [k for k in range(len(kfs) - 1) if kfs[k]["agent"] != q["agent"]]
+    picked = sorted(others, key=lambda k: -votes[k])[:2] + sorted(others, key=lambda k: votes[k])[:2]  # two good, two hopeless
+    got = store.match(_rec(q), picked, search_params(min_matches=0))
+    assert [c["slot"] for c in got] == picked
+    for c in got:
+        kf = kfs[c["slot"]]
+        nm, _, m1 = oracle_py.search_by_bow(1, q, oracle_py._OneNode(len(q["desc"])), kf, oracle_py._OneNode(len(kf["desc"])), 0.75, True)
+        assert c["n_matches"] == nm and np.array_equal(c["match_of_1"], m1)
+    assert got[0]["n_matches"] >= 15 > got[-1]["n_matches"]
+    assert [c["slot"] for c in store.match(_rec(q), picked, search_params(min_matches=15))] == [c["slot"] for c in got if c["n_matches"] >= 15]
+    with pytest.raises(S.SwarmOrbError):
+        store.match(_rec(q), [31], search_params())  # an empty slot
+    store.close()
