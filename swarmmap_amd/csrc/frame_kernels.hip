@@ -55,18 +55,24 @@ __device__ __forceinline__ void frame_undistort_point(const FrameCam& cam, float
 }
 
 // One workgroup: bounds (4 corner points), undistortion, cell of every keypoint, per-cell histogram + exclusive scan,
-// and the grid lists as a sort of (cell << 14 | index) keys in LDS — a cell's keypoints come out in index order,
-// which is the push_back order of AssignFeaturesToGrid.
+// and the grid lists: a cell's keypoints in index order, which is the push_back order of AssignFeaturesToGrid.
+// The lists are a counting sort: every keypoint takes a slot of its cell's range in arrival order (an LDS atomic), then
+// ranks itself among the cell's handful of entries by index - three barriers where the bitonic sort of
+// (cell << 14 | index) keys this kernel started with needed fifty-five; the cell of a keypoint is worked out in the
+// undistortion loop, from the value still in the register, instead of after a round trip through global memory.
 __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a) {
-    __shared__ uint32_t s_key[kFrameMaxKeypoints];
+    __shared__ int s_slot[kFrameMaxKeypoints];        // arrival-order slot -> keypoint index, then final position -> index
+    __shared__ uint16_t s_cell[kFrameMaxKeypoints];   // cell of every keypoint (0xFFFF: outside the grid)
     __shared__ int s_hist[kFrameGridCols * kFrameGridRows + 1];
-    __shared__ int s_scan[1024];
+    __shared__ int s_start[kFrameGridCols * kFrameGridRows + 1];
+    __shared__ int s_wsum[16];
     __shared__ float s_b[4];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // device-resident frame: the keypoint count is a device word written by the extractor's last kernel
     const int n = a.ex_total ? min(max(*a.ex_total, 0), a.n) : a.n;
     const SelectedKp* meta = static_cast<const SelectedKp*>(a.ex_meta);
     constexpr int ncell = kFrameGridCols * kFrameGridRows;
+    static_assert(ncell == 3 * 1024, "three cells per thread in the scan below");
     if (a.do_bounds) {
         __shared__ float s_c[4][2];
         if (tid < 4) {
@@ -92,9 +98,11 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
     }
     for (int c = tid; c <= ncell; c += 1024) s_hist[c] = 0;
     __syncthreads();
-    if (a.do_undistort) {
-        for (int i = tid; i < n; i += 1024) {
-            float u, v;
+    const float inv_w = (float)kFrameGridCols / (s_b[1] - s_b[0]);  // Frame.cc:259-260
+    const float inv_h = (float)kFrameGridRows / (s_b[3] - s_b[2]);
+    for (int i = tid; i < n; i += 1024) {
+        float u, v;
+        if (a.do_undistort) {
             if (meta) {  // ORBextractor::operator() (ORBextractor.cc:808-814): level coordinates -> level-0 pixels
                 const SelectedKp k = meta[i];
                 u = (float)k.x;
@@ -115,6 +123,20 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
                 a.xy_un_host[2 * i] = u;
                 a.xy_un_host[2 * i + 1] = v;
             }
+        } else {
+            u = a.xy_un[2 * i];
+            v = a.xy_un[2 * i + 1];
+        }
+        if (a.do_grid) {
+            const int px = (int)roundf((u - s_b[0]) * inv_w);  // PosInGrid
+            const int py = (int)roundf((v - s_b[2]) * inv_h);
+            int cell = -1;
+            if (!(px < 0 || px >= kFrameGridCols || py < 0 || py >= kFrameGridRows)) {
+                cell = px * kFrameGridRows + py;
+                atomicAdd(&s_hist[cell], 1);
+            }
+            s_cell[i] = (uint16_t)cell;
+            if (a.cell_of) a.cell_of[i] = cell;
         }
     }
     if (a.desc_by_index) {
@@ -128,77 +150,79 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
     }
     if (a.header_host && tid < 4) a.header_host[4 + tid] = __float_as_int(s_b[tid]);
     if (!a.do_grid) return;
-    __threadfence_block();
+    __threadfence_block();  // (the gathers at the end read xy_un / octave other threads wrote)
     __syncthreads();
-    const float inv_w = (float)kFrameGridCols / (s_b[1] - s_b[0]);  // Frame.cc:259-260
-    const float inv_h = (float)kFrameGridRows / (s_b[3] - s_b[2]);
-    int n2 = 1;
-    while (n2 < n) n2 <<= 1;
-    for (int i = tid; i < n2; i += 1024) {
-        uint32_t key = 0xFFFFFFFFu;
-        if (i < n) {
-            const int px = (int)roundf((a.xy_un[2 * i] - s_b[0]) * inv_w);  // PosInGrid
-            const int py = (int)roundf((a.xy_un[2 * i + 1] - s_b[2]) * inv_h);
-            int cell = -1;
-            if (!(px < 0 || px >= kFrameGridCols || py < 0 || py >= kFrameGridRows)) {
-                cell = px * kFrameGridRows + py;
-                key = ((uint32_t)cell << 14) | (uint32_t)i;
-                atomicAdd(&s_hist[cell], 1);
-            }
-            if (a.cell_of) a.cell_of[i] = cell;
-        }
-        s_key[i] = key;
+    // exclusive scan of the 3072 cell counts: three cells per thread, a wave scan, the sixteen wave totals through LDS
+    const int c0 = s_hist[3 * tid], c1 = s_hist[3 * tid + 1], c2 = s_hist[3 * tid + 2];
+    const int mine = c0 + c1 + c2;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
     }
+    if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
-    // exclusive scan of the 3072 cell counts: 3 cells per thread, then a block scan of the per-thread sums
-    int c0 = 0, c1 = 0, c2 = 0;
-    if (3 * tid < ncell) { c0 = s_hist[3 * tid]; c1 = s_hist[3 * tid + 1]; c2 = s_hist[3 * tid + 2]; }
-    s_scan[tid] = c0 + c1 + c2;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? s_scan[tid - off] : 0;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
+    int base = 0, inside = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const int x = s_wsum[w];
+        if (w < wave) base += x;
+        inside += x;
     }
-    const int before = tid > 0 ? s_scan[tid - 1] : 0;
-    if (3 * tid < ncell) {
-        a.cell_start[3 * tid] = before;
-        a.cell_start[3 * tid + 1] = before + c0;
-        a.cell_start[3 * tid + 2] = before + c0 + c1;
-    }
+    const int before = base + incl - mine;
+    s_start[3 * tid] = before;
+    s_start[3 * tid + 1] = before + c0;
+    s_start[3 * tid + 2] = before + c0 + c1;
+    a.cell_start[3 * tid] = before;
+    a.cell_start[3 * tid + 1] = before + c0;
+    a.cell_start[3 * tid + 2] = before + c0 + c1;
+    s_hist[3 * tid] = 0;  // (re-used as the arrival counters of the counting sort)
+    s_hist[3 * tid + 1] = 0;
+    s_hist[3 * tid + 2] = 0;
     if (tid == 1023) {
-        a.cell_start[ncell] = s_scan[1023];
-        *a.n_inside = s_scan[1023];
-        if (a.header_host) a.header_host[1] = s_scan[1023];
-        if (a.col_start) a.col_start[kFrameGridCols] = s_scan[1023];
+        a.cell_start[ncell] = inside;
+        *a.n_inside = inside;
+        if (a.header_host) a.header_host[1] = inside;
+        if (a.col_start) a.col_start[kFrameGridCols] = inside;
     }
-    if (a.col_start && 3 * tid < ncell) {  // first position of each grid column = start of its first cell
+    if (a.col_start) {  // first position of each grid column = start of its first cell
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int c = 3 * tid + k;
             if (c % kFrameGridRows == 0) a.col_start[c / kFrameGridRows] = before + (k > 0 ? c0 : 0) + (k > 1 ? c1 : 0);
         }
     }
-    // bitonic sort of the keys (keys are unique; outside keypoints sort to the end)
-    for (int k = 2; k <= n2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n2; i += 1024) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t x = s_key[i], y = s_key[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) {
-                        s_key[i] = y;
-                        s_key[ixj] = x;
-                    }
-                }
+    __syncthreads();
+    // counting sort, stable by index: arrival-order slots first ...
+    for (int i = tid; i < n; i += 1024) {
+        const int cell = s_cell[i];
+        if (cell != 0xFFFF) s_slot[s_start[cell] + atomicAdd(&s_hist[cell], 1)] = i;
+    }
+    __syncthreads();
+    // ... then every keypoint ranks itself among its cell's entries (a handful) by index
+    int fin_pos[kFrameMaxKeypoints / 1024];
+#pragma unroll
+    for (int r = 0; r < kFrameMaxKeypoints / 1024; r++) {
+        const int i = tid + 1024 * r;
+        fin_pos[r] = -1;
+        if (i < n) {
+            const int cell = s_cell[i];
+            if (cell != 0xFFFF) {
+                const int lo = s_start[cell], cnt = s_hist[cell];
+                int rank = 0;
+                for (int k = 0; k < cnt; k++) rank += s_slot[lo + k] < i ? 1 : 0;
+                fin_pos[r] = lo + rank;
             }
-            __syncthreads();
         }
-    const int inside = s_scan[1023];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kFrameMaxKeypoints / 1024; r++)
+        if (fin_pos[r] >= 0) s_slot[fin_pos[r]] = tid + 1024 * r;
+    __syncthreads();
     for (int i = tid; i < inside; i += 1024) {
-        const int idx = (int)(s_key[i] & 0x3FFFu);
+        const int idx = s_slot[i];
         a.cell_items[i] = idx;
         if (a.perm_host) a.perm_host[i] = idx;
         if (a.s_xy) {  // the matcher's candidate layout (match_device.h), position = rank in grid-traversal order
@@ -208,7 +232,7 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
     }
     if (a.s_desc) {
         const uint4* src = reinterpret_cast<const uint4*>(a.ex_desc);
-        for (int j = tid; j < 2 * inside; j += 1024) a.s_desc[j] = src[2 * (int)(s_key[j >> 1] & 0x3FFFu) + (j & 1)];
+        for (int j = tid; j < 2 * inside; j += 1024) a.s_desc[j] = src[2 * s_slot[j >> 1] + (j & 1)];
     }
 }
 
