@@ -215,20 +215,45 @@ bool launch_pyramid_fused(const PyramidParams& P, int first, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__ src, int w, int h, uint8_t* __restrict__ dst,
                                                       int pitch) {
+    // (a wave = 64 consecutive dwords of one row: threadIdx.y selects the row)
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x4 >= w || y >= h) return;
-    const size_t off = (size_t)y * w + x4;          // byte offset of the first of the four pixels
+    const bool in = x4 < w && y < h;
+    const size_t off = (size_t)(in ? y : 0) * w + (in ? x4 : 0);  // byte offset of the first of the four pixels
     const size_t a = off & ~(size_t)3;
     const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
     const size_t last = ((size_t)w * h + 3) / 4 - 1;  // last readable dword of the source (rounded-up allocation is not assumed)
-    const uint32_t lo = s32[a >> 2];
-    const uint32_t hi = (a >> 2) < last ? s32[(a >> 2) + 1] : 0u;
-    const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(off & 3));
+    const uint32_t lo = in ? s32[a >> 2] : 0u;
+    // The second source dword of a lane is the first one of its right neighbour: every dword crosses PCIe ONCE (it was
+    // read twice, as `lo` here and as `hi` there - twice the traffic of the one transfer on this path that is bound by
+    // the link).  Rows that start dword-aligned need no second dword at all; the last lane of a wave fetches its own.
+    const uint32_t shift = (uint32_t)(off & 3);
+    uint32_t hi = (uint32_t)__shfl_down((int)lo, 1);
+    if (shift != 0 && (threadIdx.x == 63 || x4 + 4 >= w)) hi = (in && (a >> 2) < last) ? s32[(a >> 2) + 1] : 0u;
+    if (!in) return;
+    const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, shift);
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x4) = v;  // bytes beyond w land in the row's padding
 }
 
+// rows that are a multiple of 16 bytes wide from a 16-byte aligned source (752-px EuRoC rows): one aligned 16-byte read
+// and one aligned 16-byte store per thread - a quarter of the requests on the link
+__global__ __launch_bounds__(256) void ingest16_kernel(const uint4* __restrict__ src, int w16, int h, uint8_t* __restrict__ dst,
+                                                        int pitch) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w16 || y >= h) return;
+    *reinterpret_cast<uint4*>(dst + (size_t)y * pitch + 16 * (size_t)x) = src[(size_t)y * w16 + x];
+}
+
 void launch_ingest(const uint8_t* host_src, int w, int h, const LevelDesc& level0, hipStream_t s) {
+    if ((w & 15) == 0 && (reinterpret_cast<uintptr_t>(host_src) & 15) == 0 && (level0.pitch & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(level0.img) & 15) == 0) {
+        dim3 block16(64, 4);
+        dim3 grid16((w / 16 + 63) / 64, (h + 3) / 4);
+        hipLaunchKernelGGL(ingest16_kernel, grid16, block16, 0, s, reinterpret_cast<const uint4*>(host_src), w / 16, h, level0.img,
+                           level0.pitch);
+        return;
+    }
     dim3 block(64, 4);
     dim3 grid((w + 255) / 256, (h + 3) / 4);
     hipLaunchKernelGGL(ingest_kernel, grid, block, 0, s, host_src, w, h, level0.img, level0.pitch);
