@@ -151,7 +151,7 @@ int allocate(so_extractor* ex, int w, int h) {
             last_error_ref() = "image wider than 4128 pixels is not supported";
             return SO_ERR_INVALID_ARG;
         }
-        L.spitch = round_up(L.ntx * kTile + 8, 64);
+        L.spitch = 0;  // (the score map is tile-major since round 3: no pitch)
         L.tile_base = tile_base;
         L.row_base = row_base;
         tile_base += L.ntx * L.nty;
@@ -159,7 +159,7 @@ int allocate(so_extractor* ex, int w, int h) {
         // +4 rows of slack: FAST tiles at the bottom edge clamp rows, the slack only guards dword over-reads
         int rc = dev_alloc(ex, &L.img, (size_t)L.pitch * (L.h + 4), true);
         if (rc) return rc;
-        rc = dev_alloc(ex, &L.score, (size_t)L.spitch * (L.nty * kTile + 2) + 64, true);
+        rc = dev_alloc(ex, &L.score, (size_t)kScoreBlock * L.ntx * L.nty + 256, true);
         if (rc) return rc;
         rc = dev_alloc(ex, &L.tileflag, (size_t)L.ntx * L.nty + 64, true);
         if (rc) return rc;

@@ -5,11 +5,17 @@
 //   level l image     u8   h_l rows x pitch_l bytes, pitch_l = round_up(w_l + 64, 64), base 256-B aligned
 //                          (un-blurred; the 19-px reflect-101 border the reference materialises is never
 //                          read by FAST / angle / BRIEF — the blur applies reflect-101 by index instead)
-//   level l score map u8   (nty_l*32 + 2) rows x spitch_l bytes; pixel ROI(3+c, 3+r) lives at
-//                          [(r+1)*spitch + 4 + c]; a zero frame (1 row top/bottom, 4 cols left, >=1 right)
-//                          lets the low-threshold pass read neighbours without bounds checks
+//   level l score map u8   TILE-MAJOR: one 1152-byte block per 32 x 32 FAST tile, block (ty, tx) at
+//                          (ty * ntx + tx) * 1152: [ring 128 B][body 32 x 32 B].  The ring holds the tile's border
+//                          pixels apart from the body (top row 32 B | bottom row 32 B | left column rows 1..30 |
+//                          right column rows 1..30): it is ALL a neighbour's low-threshold pass reads of a tile, and
+//                          ALL a tile that kept a high-threshold corner has to write besides the scores of its kept
+//                          pixels - one 128-byte line instead of a partial store into each of the tile's 32 rows
+//                          (the pitched map of rounds 1-2 dirtied every line of every tile: 3.9x the algorithmic
+//                          bytes).  Body pixel (row, col) of the tile = ROI pixel (3 + 32 tx + col, 3 + 32 ty + row).
 //   level l tile flag u8   nty_l x ntx_l  "tile kept a corner at the high threshold"
-//   level l keep bitmap u32 (nty_l*32) rows x ntx_l words, bit c of word (row, tx) = ROI pixel
+//   level l keep bitmap u32 tile-major: 32 words per tile (one 128-byte line), word `row` of tile (ty, tx) at
+//                          ((ty * ntx + tx) * 32 + row); bit c of it = ROI pixel
 //                          (3 + 32*tx + c, 3 + row) survived NMS
 //   candidates        8 B records {i16 x, i16 y, u16 score, u16 level}, levels concatenated, raster order
 #pragma once
@@ -22,19 +28,27 @@ constexpr int kMaxLevels = 8;
 constexpr int kFastBorder = 16;  // ROI origin inside a level (EDGE_THRESHOLD-3, ORBextractor.cc:695)
 constexpr int kTile = 32;        // tileCalcKeypoints_kernel tile (Fast_gpu.cu:373-374)
 constexpr int kFastCap = 10000;  // per-level candidate cap (Fast.hpp:32)
-constexpr int kScoreXOff = 4;    // left zero frame of the score map (keeps dword stores aligned)
+constexpr int kScoreRing = 128;                            // ring part of a tile's score block (124 bytes used)
+constexpr int kScoreBlock = kScoreRing + kTile * kTile;    // 1152 bytes per tile
 
 struct LevelDesc {
     uint8_t* img;       // level image
     uint8_t* score;     // score map (see layout above)
     uint8_t* tileflag;  // nty*ntx
-    uint32_t* bitmap;   // (nty*32)*ntx
+    uint32_t* bitmap;   // nty*ntx tiles x 32 words
     int w, h, pitch;
     int spitch;
     int ntx, nty;
     int tile_base;  // first global tile index of this level
     int row_base;   // first global bitmap row of this level
 };
+
+// position of border pixel (row, col) of a tile inside its ring (row or col is 0 or 31)
+__host__ __device__ inline int score_ring_index(int row, int col) {
+    if (row == 0) return col;
+    if (row == kTile - 1) return kTile + col;
+    return col == 0 ? 2 * kTile + (row - 1) : 2 * kTile + (kTile - 2) + (row - 1);
+}
 
 struct PyramidParams {
     LevelDesc lv[kMaxLevels];

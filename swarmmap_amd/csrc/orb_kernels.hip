@@ -306,17 +306,14 @@ __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
     const uint8_t* simg = reinterpret_cast<const uint8_t*>(simg32);
 
     const int tid = threadIdx.x;
-    // XCD-aware block -> tile map.  Workgroup b runs on XCD b % 8 and each XCD has a private L2; four horizontally
-    // adjacent tiles share their 128-byte image / score lines, so deal tiles to XCDs in groups of four (measured
-    // with FETCH_SIZE / WRITE_SIZE: a plain b -> tile map re-fetched every line once per XCD that touched it).
-    int tile = blockIdx.x;
-    {
-        const int t32 = P.total_tiles & ~31;
-        if (tile < t32) {
-            const int xcd = tile & 7, k = tile >> 3;
-            tile = (((k >> 2) * 8 + xcd) << 2) + (k & 3);
-        }
-    }
+    // XCD-aware block -> tile map.  Workgroup b runs on XCD b % 8 and each XCD has a private L2; a tile shares its
+    // 128-byte image lines with the tiles left and right of it and its 8 halo rows with the tiles above and below.  So
+    // every XCD takes one CONTIGUOUS run of the raster-ordered tiles (an eighth of them, 5-6 bands of level 0) and
+    // walks it in order: lines are shared inside one L2, and only the rows at a run's two ends are fetched twice.
+    // (FETCH_SIZE: a plain b -> tile map read 4.3x the image bytes, groups of four tiles per XCD 2.3x.)
+    const int chunk = (P.total_tiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (tile >= P.total_tiles) return;  // the grid is 8 * chunk workgroups
     const int lvl = find_level_by_tile(P, tile);
     const LevelDesc& L = P.lv[lvl];
     const int t = tile - L.tile_base;
@@ -374,26 +371,36 @@ __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
     }
     const int has1 = __syncthreads_or(any);
 
-    // u8 score tile -> global (aligned dword per thread).  A tile that kept a high-threshold corner is final: later
-    // stages only ever read (a) its outer ring - the halo of an empty neighbour's low-threshold pass, which looks at
-    // nothing but scores >= th_high there - and (b) the scores of its kept pixels (candidate records).  Only an
-    // empty tile needs its whole score tile (its own low-threshold pass).  Writing ring + kept pixels instead of the
-    // tile cuts the score-map traffic of a textured frame to a third.
-    {
-        const int row = tid >> 3, c4 = (tid & 7) * 4;
-        if (!has1 || row == 0 || row == kTile - 1 || c4 == 0 || c4 == kTile - 4) {
-            const uint8_t* q = ssc + (row + 1) * kScPitch + (c4 + 1);
-            const uint32_t v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-            *reinterpret_cast<uint32_t*>(L.score + (size_t)(ty * kTile + row + 1) * L.spitch + kScoreXOff + tx * kTile +
-                                         c4) = v;
+    // u8 score tile -> its block of the tile-major score map.  Later stages read of a tile (a) its border pixels - the
+    // halo of a neighbour's low-threshold pass -, (b) the scores of its kept pixels (candidate records) and, only if the
+    // tile is empty, (c) everything (its own low-threshold pass).  So every tile writes its RING (one 128-byte line), an
+    // empty tile its whole body (1 KB, contiguous), a tile with high-threshold corners just the kept pixels.
+    uint8_t* blk = L.score + (size_t)t * kScoreBlock;
+    if (tid < 31) {  // ring as 31 dwords: 8 top, 8 bottom, 15 of the two columns
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int bidx = 4 * tid + k;
+            int row, col;
+            if (bidx < kTile) { row = 0; col = bidx; }
+            else if (bidx < 2 * kTile) { row = kTile - 1; col = bidx - kTile; }
+            else if (bidx < 2 * kTile + (kTile - 2)) { row = bidx - 2 * kTile + 1; col = 0; }
+            else { row = bidx - (2 * kTile + kTile - 2) + 1; col = kTile - 1; }
+            v |= (uint32_t)ssc[(row + 1) * kScPitch + (col + 1)] << (8 * k);
         }
+        reinterpret_cast<uint32_t*>(blk)[tid] = v;
     }
-    if (has1) {
+    if (!has1) {
+        const int row = tid >> 3, c4 = (tid & 7) * 4;
+        const uint8_t* q = ssc + (row + 1) * kScPitch + (c4 + 1);
+        const uint32_t v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        reinterpret_cast<uint32_t*>(blk + kScoreRing)[tid] = v;  // body (row, c4 .. c4 + 3)
+    } else {
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (my_kp[k]) {
                 const int row = 8 * k + 2 * wave + (lane >> 5), col = lane & 31;
-                L.score[(size_t)(ty * kTile + row + 1) * L.spitch + kScoreXOff + tx * kTile + col] = (uint8_t)my_score[k];
+                blk[kScoreRing + row * kTile + col] = (uint8_t)my_score[k];
             }
     }
     if (tid == 0) L.tileflag[t] = (uint8_t)has1;
@@ -401,9 +408,9 @@ __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int row = 8 * k + 2 * wave;
-            uint32_t* b = L.bitmap + (size_t)(ty * kTile + row) * L.ntx + tx;
+            uint32_t* b = L.bitmap + (size_t)t * kTile + row;  // tile-major: a tile's 32 words are one 128-byte line
             b[0] = has1 ? (uint32_t)keep[k] : 0u;
-            b[L.ntx] = has1 ? (uint32_t)(keep[k] >> 32) : 0u;
+            b[1] = has1 ? (uint32_t)(keep[k] >> 32) : 0u;
         }
     }
 }
@@ -441,37 +448,43 @@ __global__ __launch_bounds__(256) void fast_low_count_kernel(PyramidParams P, in
     const int ty = blockIdx.x - L.row_base / kTile;
     const int th_high = P.th_high;
 
-    // the band's words are contiguous in memory ([row][tile]): one coalesced sweep (empty tiles hold zeros)
+    // the band's words are contiguous in memory ([tile][row]): one coalesced sweep (empty tiles hold zeros)
     for (int i = tid; i < kTile * L.ntx; i += 256) {
-        const int row = i / L.ntx, tx = i - row * L.ntx;
-        sbm[row][tx] = L.bitmap[(size_t)(ty * kTile) * L.ntx + i];
+        const int tx = i >> 5, row = i & 31;
+        sbm[row][tx] = L.bitmap[(size_t)(ty * L.ntx) * kTile + i];
     }
     __syncthreads();
     for (int tx = wave; tx < L.ntx; tx += 4) {  // wave-uniform loop: one tile per wave per round
         if (L.tileflag[ty * L.ntx + tx]) continue;  // kept corners at the high threshold: words are final
-        uint32_t* gb = L.bitmap + (size_t)(ty * kTile) * L.ntx + tx;
+        uint32_t* gb = L.bitmap + (size_t)(ty * L.ntx + tx) * kTile;
         uint32_t* sc32 = ssc32[wave];
         uint8_t* sc = reinterpret_cast<uint8_t*>(sc32);
-        // 34 rows x 10 aligned dwords cover score-map columns [32 tx, 32 tx + 40); window pixel (r, c) of the
-        // 34x34 neighbourhood sits at byte (c + 3) of row r.  All loads are independent -> one memory latency.
-        for (int i = lane; i < kScRows * (kLowPitch / 4); i += 64) {
-            const int r = i / (kLowPitch / 4), dc = i - r * (kLowPitch / 4);
-            sc32[i] = *reinterpret_cast<const uint32_t*>(L.score + (size_t)(ty * kTile + r) * L.spitch + tx * kTile + 4 * dc);
+        // window pixel (r, c) of the 34 x 34 neighbourhood sits at byte (c + 3) of row r (40-byte rows): the tile's body
+        // (1 KB, contiguous) lands dword by dword, the 132 halo pixels come out of the eight neighbours' rings
+        {
+            const uint32_t* body = reinterpret_cast<const uint32_t*>(L.score + (size_t)(ty * L.ntx + tx) * kScoreBlock + kScoreRing);
+            for (int i = lane; i < kTile * (kTile / 4); i += 64) {
+                const int row = i >> 3, d4 = i & 7;
+                sc32[(row + 1) * (kLowPitch / 4) + d4 + 1] = body[i];
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // halo pixels belong to neighbour tiles: one that kept high-threshold corners competes with its
-        // high-threshold score only (132 halo pixels: rows 0 / 33 and columns 0 / 33)
+        // high-threshold score only (132 halo pixels: rows 0 / 33 and columns 0 / 33); outside the grid: 0
         for (int i = lane; i < 4 * kScRows; i += 64) {
             const int side = i / kScRows, k = i - side * kScRows;
             const int r = side == 0 ? 0 : (side == 1 ? kScRows - 1 : k);
             const int c = side == 2 ? 0 : (side == 3 ? kScRows - 1 : k);
             const int tyq = ty + (r == 0 ? -1 : (r == kScRows - 1 ? 1 : 0));
             const int txq = tx + (c == 0 ? -1 : (c == kScRows - 1 ? 1 : 0));
+            int v = 0;
             if (tyq >= 0 && tyq < L.nty && txq >= 0 && txq < L.ntx) {
-                uint8_t* q = sc + r * kLowPitch + c + 3;
-                if (L.tileflag[tyq * L.ntx + txq] && *q < th_high) *q = 0;
+                // the pixel's place inside its own tile: one past the edge wraps to the far edge of the neighbour
+                const int prow = r == 0 ? kTile - 1 : (r == kScRows - 1 ? 0 : r - 1);
+                const int pcol = c == 0 ? kTile - 1 : (c == kScRows - 1 ? 0 : c - 1);
+                v = L.score[(size_t)(tyq * L.ntx + txq) * kScoreBlock + score_ring_index(prow, pcol)];
+                if (L.tileflag[tyq * L.ntx + txq] && v < th_high) v = 0;
             }
+            sc[r * kLowPitch + c + 3] = (uint8_t)v;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -485,8 +498,8 @@ __global__ __launch_bounds__(256) void fast_low_count_kernel(PyramidParams P, in
             if (lane == 0) {
                 sbm[2 * k][tx] = (uint32_t)keep;
                 sbm[2 * k + 1][tx] = (uint32_t)(keep >> 32);
-                gb[(size_t)(2 * k) * L.ntx] = (uint32_t)keep;
-                gb[(size_t)(2 * k + 1) * L.ntx] = (uint32_t)(keep >> 32);
+                gb[2 * k] = (uint32_t)keep;
+                gb[2 * k + 1] = (uint32_t)(keep >> 32);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -524,8 +537,8 @@ __global__ __launch_bounds__(256) void emit_kernel(PyramidParams P, const int32_
 
     for (int g = tid; g < R; g += 256) s_rc[g] = rowcount[g];
     for (int i = tid; i < kTile * L.ntx; i += 256) {
-        const int row = i / L.ntx, tx = i - row * L.ntx;
-        sbm[row][tx] = L.bitmap[(size_t)(ty * kTile) * L.ntx + i];
+        const int tx = i >> 5, row = i & 31;
+        sbm[row][tx] = L.bitmap[(size_t)(ty * L.ntx) * kTile + i];
     }
     __syncthreads();
     // exclusive prefix over all rows (thread t owns a contiguous chunk), redundantly in every band
@@ -604,7 +617,7 @@ __global__ __launch_bounds__(256) void emit_kernel(PyramidParams P, const int32_
         uint32_t word = sbm[rr][w];
         if (!word) continue;
         const int lr = ty * kTile + rr;
-        const uint8_t* srow = L.score + (size_t)(lr + 1) * L.spitch + kScoreXOff + 32 * w;
+        const uint8_t* srow = L.score + (size_t)(ty * L.ntx + w) * kScoreBlock + kScoreRing + rr * kTile;  // body row rr of tile (ty, w)
         int rank = s_rank[rr][w];
         while (word) {
             const int bit = __ffs(word) - 1;
@@ -626,7 +639,7 @@ __global__ __launch_bounds__(256) void emit_kernel(PyramidParams P, const int32_
 }
 
 void launch_fast_score(const PyramidParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(fast_score_kernel, dim3(p.total_tiles), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(fast_score_kernel, dim3(8 * ((p.total_tiles + 7) / 8)), dim3(256), 0, s, p);
 }
 void launch_fast_low_count(const PyramidParams& p, int32_t* d_rowcount, hipStream_t s) {
     hipLaunchKernelGGL(fast_low_count_kernel, dim3(p.total_rows / kTile), dim3(256), 0, s, p, d_rowcount);
