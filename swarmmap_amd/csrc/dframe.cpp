@@ -97,6 +97,10 @@ int submit_body(so_dframe* f, const uint8_t* image, bool on_device, int w, int h
     f->ready = false;
     f->waited = false;
     f->mirrors = false;
+    // from the second frame on the prepare launch below rides at the end of the extractor's frame graph
+    if (f->allocated && f->prep_revision)
+        extractor_set_graph_tail(f->ex, f, f->prep_revision,
+                                 [](void* ctx, hipStream_t s) { launch_frame_prepare(static_cast<so_dframe*>(ctx)->prep, s); });
     int rc = on_device ? so_extractor_submit_device(f->ex, image, w, h, stride)
                        : so_extractor_submit(f->ex, image, w, h, stride);
     if (rc) return rc;
@@ -145,7 +149,11 @@ int submit_body(so_dframe* f, const uint8_t* image, bool on_device, int w, int h
     a.perm_host = reinterpret_cast<int32_t*>(f->h_block_dev + ((uint8_t*)f->h_perm - f->h_block));
     a.col_start = f->d_col_start;
     a.header_host = reinterpret_cast<int32_t*>(f->h_block_dev + ((uint8_t*)f->h_header - f->h_block));
-    launch_frame_prepare(a, V.stream);
+    if (memcmp(&a, &f->prep, sizeof(a)) != 0) {
+        memcpy(&f->prep, &a, sizeof(a));
+        f->prep_revision++;
+    }
+    if (!extractor_tail_launched(f->ex)) launch_frame_prepare(a, V.stream);  // first frame / no graph / profiling
     SO_HIP(hipGetLastError());
     f->launched = true;
     return SO_OK;
@@ -209,6 +217,7 @@ int so_dframe_create(so_extractor* ex, const so_camera* cam, so_dframe** out) {
 
 void so_dframe_destroy(so_dframe* f) {
     if (!f) return;
+    extractor_release_graph_tail(f->ex, f);
     if (f->allocated) {
         (void)hipSetDevice(f->device);
         ExtractorDeviceView V;

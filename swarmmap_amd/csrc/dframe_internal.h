@@ -32,6 +32,8 @@ struct so_dframe {
     bool ready = false;    // the device side is complete: n / n_inside / bounds / position map valid, searches may be submitted
     bool mirrors = false;  // collected: the host copies of octave / angle (read by the searches' resolve) are valid
     uint64_t generation = 0;  // bumped by every submit (the matcher's "same frame as before" check)
+    so::FramePrepareArgs prep{};   // the prepare launch as captured at the end of the extractor's frame graph
+    uint64_t prep_revision = 0;    // bumped when `prep` changes
     // device
     uint8_t* d_block = nullptr;
     float2* d_xy_un = nullptr;

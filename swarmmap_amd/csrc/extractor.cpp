@@ -48,9 +48,20 @@ struct so_extractor {
     // the frame's twelve launches as one hipGraph (captured on the first unprofiled frame of the one-sync path):
     // one runtime call per frame instead of twelve - the calls serialise on the runtime's lock when several agents
     // share a process
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    // A consumer's launch can ride at the end of the graph (extractor_internal.h): one captured graph per (owner,
+    // revision) - three device-resident frames take turns on one extractor in the tracking loop.
+    struct FrameGraph {
+        void* owner;
+        uint64_t revision;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+    };
+    std::vector<FrameGraph> graphs;
     bool graph_failed = false;
+    void* tail_owner = nullptr;
+    uint64_t tail_revision = 0;
+    ExtractorTailFn tail_fn = nullptr;
+    bool tail_launched = false;
     int pending = 0;                   // 1: a submitted frame is in flight on the stream, 2: finished into pend_* below
     double t_begin = 0.0, t_enq = 0.0;
     std::vector<so_keypoint> pend_kps;  // submit on the host-quadtree path runs to completion into these
@@ -230,6 +241,19 @@ int allocate(so_extractor* ex, int w, int h) {
     return SO_OK;
 }
 
+// forget the captured frame graphs of one tail owner (nullptr: the graph without a tail)
+void drop_frame_graphs(so_extractor* ex, void* owner) {
+    for (size_t i = 0; i < ex->graphs.size();) {
+        if (ex->graphs[i].owner == owner) {
+            (void)hipGraphExecDestroy(ex->graphs[i].exec);
+            (void)hipGraphDestroy(ex->graphs[i].graph);
+            ex->graphs.erase(ex->graphs.begin() + (long)i);
+        } else {
+            i++;
+        }
+    }
+}
+
 // ComputePyramid's resizes: one fused launch, or the chained per-level launches (SWARMORB_CHAINED_PYRAMID, or a
 // configuration the fused kernel cannot hold)
 void launch_pyramid(const PyramidParams& P, hipStream_t s) {
@@ -316,6 +340,15 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
         last_error_ref() = "a submitted frame has not been collected";
         return SO_ERR_INVALID_ARG;
     }
+    ex->tail_launched = false;
+    // the tail applies to ONE submit (a direct so_extractor_submit behind a device-resident frame must not run that
+    // frame's prepare launch over the data it holds)
+    void* const tail_owner = ex->tail_owner;
+    const uint64_t tail_revision = ex->tail_revision;
+    const ExtractorTailFn tail_fn = ex->tail_fn;
+    ex->tail_owner = nullptr;
+    ex->tail_revision = 0;
+    ex->tail_fn = nullptr;
     if (n_out) *n_out = 0;
     if (!image || w <= 0 || h <= 0) {  // ORBextractor.cc:750-751
         if (submit_only) {
@@ -380,28 +413,37 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
     static const bool no_graph = getenv("SWARMORB_NO_GRAPH") != nullptr;
     if (!prof && !no_graph && ex->device_qt && P.total_tiles > 0 && !ex->graph_failed) {
         float* angle_dev = reinterpret_cast<float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);
-        if (!ex->graph_exec) {  // every launch argument is fixed once the context is sized: capture the chain once
+        hipGraphExec_t exec = nullptr;
+        for (const auto& g : ex->graphs)
+            if (g.owner == tail_owner && g.revision == tail_revision) exec = g.exec;
+        if (!exec) {  // every launch argument is fixed once the context is sized: capture the chain once per tail
+            hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 launch_pyramid(P, s);
                 launch_fast_score(P, s);
-                launch_fast_low_count(P, ex->d_rowcount, s);
-                launch_emit(P, ex->d_rowcount, ex->d_cands, ex->d_header, ex->h_header_dev, ex->cand_capacity, s);
-                launch_quadtree(P, ex->features_per_level, ex->qt_stride, ex->d_cands, ex->d_header, ex->d_qt_sel,
-                                ex->d_qt_count, s);
+                launch_fast_low(P, s);
+                launch_quadtree(P, ex->features_per_level, ex->qt_stride, ex->d_qt_sel, ex->d_qt_count, s);
                 launch_describe_qt(P, ex->d_qt_sel, ex->d_qt_count, ex->qt_stride, ex->out_capacity, ex->h_desc_dev,
                                    angle_dev, ex->h_meta_dev, ex->h_total_dev, ex->dev_out, s);
-                e = hipStreamEndCapture(s, &ex->graph);
+                if (tail_fn) tail_fn(tail_owner, s);
+                e = hipStreamEndCapture(s, &graph);
             }
-            if (e == hipSuccess) e = hipGraphInstantiate(&ex->graph_exec, ex->graph, nullptr, nullptr, 0);
+            if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             if (e != hipSuccess) {  // run this and later frames launch by launch
                 (void)hipGetLastError();
+                if (graph) (void)hipGraphDestroy(graph);
                 ex->graph_failed = true;
-                ex->graph_exec = nullptr;
+                exec = nullptr;
+            } else {
+                drop_frame_graphs(ex, tail_owner);  // an older revision of the same owner
+                if (ex->graphs.size() >= 8) drop_frame_graphs(ex, ex->graphs.front().owner);
+                ex->graphs.push_back({tail_owner, tail_revision, graph, exec});
             }
         }
-        if (ex->graph_exec) {
-            SO_HIP(hipGraphLaunch(ex->graph_exec, s));
+        if (exec) {
+            SO_HIP(hipGraphLaunch(exec, s));
+            ex->tail_launched = tail_fn != nullptr;
             ex->t_begin = t_begin;
             ex->t_enq = now_ms();
             ex->pending = 1;
@@ -416,14 +458,13 @@ int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int 
     if (P.total_tiles > 0) {
         launch_fast_score(P, s);
         if (prof) SO_HIP(hipEventRecord(ex->ev[2], s));
-        launch_fast_low_count(P, ex->d_rowcount, s);
+        launch_fast_low(P, s);
         if (prof) SO_HIP(hipEventRecord(ex->ev[3], s));
         if (ex->device_qt) {
             // one-sync path: candidates -> device quadtree -> fused describe writing straight to host-mapped memory
-            launch_emit(P, ex->d_rowcount, ex->d_cands, ex->d_header, ex->h_header_dev, ex->cand_capacity, s);
+            // candidates -> device quadtree (reads the keep bitmap itself: no candidate list) -> fused describe
             if (prof) SO_HIP(hipEventRecord(ex->ev[4], s));
-            launch_quadtree(P, ex->features_per_level, ex->qt_stride, ex->d_cands, ex->d_header, ex->d_qt_sel,
-                            ex->d_qt_count, s);
+            launch_quadtree(P, ex->features_per_level, ex->qt_stride, ex->d_qt_sel, ex->d_qt_count, s);
             if (prof) SO_HIP(hipEventRecord(ex->ev[5], s));
             float* angle_dev = reinterpret_cast<float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);
             launch_describe_qt(P, ex->d_qt_sel, ex->d_qt_count, ex->qt_stride, ex->out_capacity, ex->h_desc_dev,
@@ -553,6 +594,23 @@ int extractor_device_view(so_extractor* ex, ExtractorDeviceView* out) {
     }
     return SO_OK;
 }
+
+void extractor_set_graph_tail(so_extractor* ex, void* owner, uint64_t revision, ExtractorTailFn fn) {
+    if (!ex) return;
+    ex->tail_owner = owner;
+    ex->tail_revision = owner ? revision : 0;
+    ex->tail_fn = owner ? fn : nullptr;
+}
+
+void extractor_release_graph_tail(so_extractor* ex, void* owner) {
+    if (!ex || !owner) return;
+    if (ex->tail_owner == owner) extractor_set_graph_tail(ex, nullptr, 0, nullptr);
+    (void)hipSetDevice(ex->cfg.device);
+    if (ex->stream) (void)hipStreamSynchronize(ex->stream);
+    drop_frame_graphs(ex, owner);
+}
+
+bool extractor_tail_launched(const so_extractor* ex) { return ex && ex->tail_launched; }
 }  // namespace so
 
 extern "C" {
@@ -601,8 +659,10 @@ void so_extractor_destroy(so_extractor* ex) {
     if (ex->h_desc) (void)hipHostFree(ex->h_desc);
     if (ex->h_meta) (void)hipHostFree(ex->h_meta);
     if (ex->h_total) (void)hipHostFree(ex->h_total);
-    if (ex->graph_exec) (void)hipGraphExecDestroy(ex->graph_exec);
-    if (ex->graph) (void)hipGraphDestroy(ex->graph);
+    for (auto& g : ex->graphs) {
+        (void)hipGraphExecDestroy(g.exec);
+        (void)hipGraphDestroy(g.graph);
+    }
     for (auto& v : ex->ev)
         if (v) (void)hipEventDestroy(v);
     if (ex->owns_stream && ex->stream) (void)hipStreamDestroy(ex->stream);
@@ -690,15 +750,25 @@ int so_extractor_get_level(so_extractor* ex, int level, uint8_t* out, int out_by
 int so_extractor_get_candidates(so_extractor* ex, int level, int16_t* xs, int16_t* ys, uint8_t* scores, int capacity,
                                 int* n_out) {
     if (!ex || !ex->allocated || level < 0 || level >= ex->cfg.nlevels || !n_out) return SO_ERR_INVALID_ARG;
+    if (!ex->cands_on_host) {
+        // device-quadtree path: the frame never built the candidate list (the quadtree reads the keep bitmap); the
+        // bitmap and the score map of the last frame are still resident, so the list is produced on demand
+        if (ex->pending) {
+            last_error_ref() = "so_extractor_get_candidates: a submitted frame has not been collected";
+            return SO_ERR_INVALID_ARG;
+        }
+        SO_HIP(hipSetDevice(ex->cfg.device));
+        if (ex->P.total_tiles > 0) {
+            launch_emit(ex->P, ex->d_rowcount, ex->h_cands_dev, ex->h_header_dev, nullptr, ex->cand_capacity, ex->stream);
+            SO_HIP(hipGetLastError());
+        }
+        SO_HIP(hipStreamSynchronize(ex->stream));
+        ex->cands_on_host = true;
+    }
     const CandidateHeader& H = *ex->h_header;
     const int n = H.count[level];
     *n_out = n;
     if (capacity < n) return SO_ERR_CAPACITY;
-    if (!ex->cands_on_host && H.total > 0) {  // device-quadtree path: fetch the candidates on demand
-        SO_HIP(hipSetDevice(ex->cfg.device));
-        SO_HIP(so::memcpy_sync(ex->h_cands, ex->d_cands, sizeof(Candidate) * (size_t)H.total, hipMemcpyDeviceToHost));
-        ex->cands_on_host = true;
-    }
     const Candidate* c = ex->h_cands + H.offset[level];
     for (int i = 0; i < n; i++) {
         if (xs) xs[i] = c[i].x;

@@ -26,4 +26,14 @@ struct ExtractorDeviceView {
 
 int extractor_device_view(so_extractor* ex, ExtractorDeviceView* out);
 
+// A consumer's launch captured behind describe in the frame's hipGraph (the device-resident Frame's prepare kernel: a
+// separate launch behind a graph starts ~8 us after the graph's last kernel ends).  `fn(owner, stream)` must enqueue
+// the same work with the same arguments for a given (owner, revision); the extractor keeps one captured graph per
+// owner, re-captured when the revision moves.  The tail set here applies to the NEXT submit only.
+typedef void (*ExtractorTailFn)(void* ctx, hipStream_t s);
+void extractor_set_graph_tail(so_extractor* ex, void* owner, uint64_t revision, ExtractorTailFn fn);
+void extractor_release_graph_tail(so_extractor* ex, void* owner);  // the owner goes away: its graph is dropped
+// true when the frame submitted last ran the tail inside its graph (false: chained launches, profiling, no graph)
+bool extractor_tail_launched(const so_extractor* ex);
+
 }  // namespace so

@@ -86,13 +86,14 @@ void launch_resize(const LevelDesc& src, const LevelDesc& dst, hipStream_t s);
 // not fit the kernel's LDS boxes - the caller then chains launch_resize
 bool launch_pyramid_fused(const PyramidParams& p, int first_level, hipStream_t s);
 void launch_fast_score(const PyramidParams& p, hipStream_t s);
-void launch_fast_low_count(const PyramidParams& p, int32_t* d_rowcount, hipStream_t s);
-// records go to `cands` (device memory for the device quadtree, or host-mapped memory for the host quadtree);
-// the header is written to both hdr_a and hdr_b (device copy + host-mapped copy; either may be null)
-void launch_emit(const PyramidParams& p, const int32_t* d_rowcount, Candidate* cands, CandidateHeader* hdr_a,
+void launch_fast_low(const PyramidParams& p, hipStream_t s);
+// The candidate list (host-quadtree path, so_extractor_get_candidates): d_rowcount is scratch (total_rows ints);
+// records go to `cands` (device or host-mapped memory), the header to both hdr_a and hdr_b (either may be null)
+void launch_emit(const PyramidParams& p, int32_t* d_rowcount, Candidate* cands, CandidateHeader* hdr_a,
                  CandidateHeader* hdr_b, int cand_capacity, hipStream_t s);
-void launch_quadtree(const PyramidParams& p, const int* n_target, int sel_stride, const Candidate* d_cands,
-                     const CandidateHeader* d_hdr, SelectedKp* d_sel, int32_t* d_count, hipStream_t s);
+// DistributeOctTree of every level straight off the keep bitmap and the score map
+void launch_quadtree(const PyramidParams& p, const int* n_target, int sel_stride, SelectedKp* d_sel, int32_t* d_count,
+                     hipStream_t s);
 // HBM-resident copies of the frame's outputs (read by the device-resident frame, dframe.cpp); members may be null
 struct DescribeDeviceOut {
     uint8_t* desc;     // capacity x 32

@@ -416,15 +416,18 @@ __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Band kernels.  A "band" is one row of tiles (32 pixel rows) of one level; all bands of all levels form one
-// grid (72 workgroups for 752x480).  Two launches replace a per-tile low pass + a single-workgroup compaction:
-//   fast_low_count_kernel  low-threshold pass for the band's empty tiles (Fast_gpu.cu:317-339) with the
-//                          deterministic neighbour rule of the oracle (a neighbour in a non-empty tile competes
-//                          with its high-threshold score, one in an empty tile with its low-threshold score),
-//                          then one popcount per pixel row -> rowcount[]
-//   emit_kernel            every band scans rowcount[] (a few thousand ints, L2-resident) to find where its rows
-//                          start in the (level, y, x) raster order, applies the per-level cap of 10000, and writes
-//                          its 8-byte records straight into host-mapped memory.
+// Low-threshold pass and candidate emission.
+//   fast_low_kernel   one WAVE per tile (four tiles per workgroup, all levels in one grid): an empty tile gets its
+//                     low-threshold pass (Fast_gpu.cu:317-339) with the deterministic neighbour rule of the oracle (a
+//                     neighbour in a non-empty tile competes with its high-threshold score, one in an empty tile with
+//                     its low-threshold score) and writes its 32 keep words.  Rounds 1-2 ran this per band, a wave
+//                     walking up to six empty tiles one after the other: 15 us on 72 workgroups.
+// The device quadtree (quadtree_kernel.hip) reads the keep bitmap and the score map itself.  The candidate LIST the
+// reference hands to DistributeOctTree only exists on the host-quadtree path and for so_extractor_get_candidates:
+//   rowcount_kernel   per band (one row of tiles of one level, 72 workgroups for 752x480): keypoints per pixel row
+//   emit_kernel       per band: every band scans rowcount[] (a few thousand ints, L2-resident) to find where its rows
+//                     start in the (level, y, x) raster order, applies the per-level cap of 10000, and writes its
+//                     8-byte records.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int find_level_by_band(const PyramidParams& P, int band) {
     int l = 0;
@@ -439,82 +442,81 @@ constexpr int kMaxRows = 8192;   // bitmap rows over all levels (sum of level he
 
 constexpr int kLowPitch = 40;  // bytes per row of the per-wave score window (10 aligned dwords)
 
-__global__ __launch_bounds__(256) void fast_low_count_kernel(PyramidParams P, int32_t* __restrict__ rowcount) {
+__global__ __launch_bounds__(256) void fast_low_kernel(PyramidParams P) {
     __shared__ uint32_t ssc32[4][kScRows * (kLowPitch / 4)];  // one 34-row score window per wave
-    __shared__ uint32_t sbm[kTile][kMaxTilesX];                // the band's keep-bitmap
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // groups of four tiles, one contiguous run of groups per XCD (same reasoning as fast_score_kernel: the halo comes out
+    // of the neighbours' rings, which the XCD's L2 holds when the neighbours are its own)
+    const int ngroups = (P.total_tiles + 3) >> 2, gchunk = (ngroups + 7) >> 3;
+    const int tile = (((int)(blockIdx.x & 7) * gchunk + (int)(blockIdx.x >> 3)) << 2) + wave;
+    if (tile >= P.total_tiles) return;  // wave-uniform; no workgroup barrier below
+    const int lvl = find_level_by_tile(P, tile);
+    const LevelDesc& L = P.lv[lvl];
+    const int t = tile - L.tile_base;
+    const int ty = t / L.ntx, tx = t - ty * L.ntx;
+    const int th_high = P.th_high;
+    uint32_t* gb = L.bitmap + (size_t)t * kTile;
+    if (L.tileflag[t]) return;  // kept corners at the high threshold: its words are final
+    uint32_t* sc32 = ssc32[wave];
+    uint8_t* sc = reinterpret_cast<uint8_t*>(sc32);
+    // window pixel (r, c) of the 34 x 34 neighbourhood sits at byte (c + 3) of row r (40-byte rows): the tile's body
+    // (1 KB, contiguous) lands dword by dword, the 132 halo pixels come out of the eight neighbours' rings
+    {
+        const uint32_t* body = reinterpret_cast<const uint32_t*>(L.score + (size_t)t * kScoreBlock + kScoreRing);
+#pragma unroll
+        for (int j = 0; j < kTile * (kTile / 4) / 64; j++) {
+            const int i = lane + 64 * j;
+            const int row = i >> 3, d4 = i & 7;
+            sc32[(row + 1) * (kLowPitch / 4) + d4 + 1] = body[i];
+        }
+    }
+    // halo pixels belong to neighbour tiles: one that kept high-threshold corners competes with its
+    // high-threshold score only (132 halo pixels: rows 0 / 33 and columns 0 / 33); outside the grid: 0
+    for (int i = lane; i < 4 * kScRows; i += 64) {
+        const int side = i / kScRows, k = i - side * kScRows;
+        const int r = side == 0 ? 0 : (side == 1 ? kScRows - 1 : k);
+        const int c = side == 2 ? 0 : (side == 3 ? kScRows - 1 : k);
+        const int tyq = ty + (r == 0 ? -1 : (r == kScRows - 1 ? 1 : 0));
+        const int txq = tx + (c == 0 ? -1 : (c == kScRows - 1 ? 1 : 0));
+        int v = 0;
+        if (tyq >= 0 && tyq < L.nty && txq >= 0 && txq < L.ntx) {
+            // the pixel's place inside its own tile: one past the edge wraps to the far edge of the neighbour
+            const int prow = r == 0 ? kTile - 1 : (r == kScRows - 1 ? 0 : r - 1);
+            const int pcol = c == 0 ? kTile - 1 : (c == kScRows - 1 ? 0 : c - 1);
+            v = L.score[(size_t)(tyq * L.ntx + txq) * kScoreBlock + score_ring_index(prow, pcol)];
+            if (L.tileflag[tyq * L.ntx + txq] && v < th_high) v = 0;
+        }
+        sc[r * kLowPitch + c + 3] = (uint8_t)v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t mine = 0;  // lane r < 32 ends up with keep word r
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {  // two tile rows per ballot
+        const int row = 2 * k + (lane >> 5), col = lane & 31;
+        const uint8_t* q = sc + (row + 1) * kLowPitch + (col + 1) + 3;
+        const int s = q[0];
+        const int m = max(max(max((int)q[-kLowPitch - 1], (int)q[-kLowPitch]), max((int)q[-kLowPitch + 1], (int)q[-1])),
+                          max(max((int)q[1], (int)q[kLowPitch - 1]), max((int)q[kLowPitch], (int)q[kLowPitch + 1])));
+        const unsigned long long keep = __ballot(s > 0 && s > m);
+        if (lane == 2 * k) mine = (uint32_t)keep;
+        if (lane == 2 * k + 1) mine = (uint32_t)(keep >> 32);
+    }
+    if (lane < kTile) gb[lane] = mine;  // one 128-byte line
+}
+
+__global__ __launch_bounds__(256) void rowcount_kernel(PyramidParams P, int32_t* __restrict__ rowcount) {
+    const int tid = threadIdx.x;
     const int lvl = find_level_by_band(P, blockIdx.x);
     const LevelDesc& L = P.lv[lvl];
     const int ty = blockIdx.x - L.row_base / kTile;
-    const int th_high = P.th_high;
-
-    // the band's words are contiguous in memory ([tile][row]): one coalesced sweep (empty tiles hold zeros)
-    for (int i = tid; i < kTile * L.ntx; i += 256) {
-        const int tx = i >> 5, row = i & 31;
-        sbm[row][tx] = L.bitmap[(size_t)(ty * L.ntx) * kTile + i];
-    }
-    __syncthreads();
-    for (int tx = wave; tx < L.ntx; tx += 4) {  // wave-uniform loop: one tile per wave per round
-        if (L.tileflag[ty * L.ntx + tx]) continue;  // kept corners at the high threshold: words are final
-        uint32_t* gb = L.bitmap + (size_t)(ty * L.ntx + tx) * kTile;
-        uint32_t* sc32 = ssc32[wave];
-        uint8_t* sc = reinterpret_cast<uint8_t*>(sc32);
-        // window pixel (r, c) of the 34 x 34 neighbourhood sits at byte (c + 3) of row r (40-byte rows): the tile's body
-        // (1 KB, contiguous) lands dword by dword, the 132 halo pixels come out of the eight neighbours' rings
-        {
-            const uint32_t* body = reinterpret_cast<const uint32_t*>(L.score + (size_t)(ty * L.ntx + tx) * kScoreBlock + kScoreRing);
-            for (int i = lane; i < kTile * (kTile / 4); i += 64) {
-                const int row = i >> 3, d4 = i & 7;
-                sc32[(row + 1) * (kLowPitch / 4) + d4 + 1] = body[i];
-            }
-        }
-        // halo pixels belong to neighbour tiles: one that kept high-threshold corners competes with its
-        // high-threshold score only (132 halo pixels: rows 0 / 33 and columns 0 / 33); outside the grid: 0
-        for (int i = lane; i < 4 * kScRows; i += 64) {
-            const int side = i / kScRows, k = i - side * kScRows;
-            const int r = side == 0 ? 0 : (side == 1 ? kScRows - 1 : k);
-            const int c = side == 2 ? 0 : (side == 3 ? kScRows - 1 : k);
-            const int tyq = ty + (r == 0 ? -1 : (r == kScRows - 1 ? 1 : 0));
-            const int txq = tx + (c == 0 ? -1 : (c == kScRows - 1 ? 1 : 0));
-            int v = 0;
-            if (tyq >= 0 && tyq < L.nty && txq >= 0 && txq < L.ntx) {
-                // the pixel's place inside its own tile: one past the edge wraps to the far edge of the neighbour
-                const int prow = r == 0 ? kTile - 1 : (r == kScRows - 1 ? 0 : r - 1);
-                const int pcol = c == 0 ? kTile - 1 : (c == kScRows - 1 ? 0 : c - 1);
-                v = L.score[(size_t)(tyq * L.ntx + txq) * kScoreBlock + score_ring_index(prow, pcol)];
-                if (L.tileflag[tyq * L.ntx + txq] && v < th_high) v = 0;
-            }
-            sc[r * kLowPitch + c + 3] = (uint8_t)v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int k = 0; k < 16; k++) {  // two tile rows per ballot
-            const int row = 2 * k + (lane >> 5), col = lane & 31;
-            const uint8_t* q = sc + (row + 1) * kLowPitch + (col + 1) + 3;
-            const int s = q[0];
-            const int m = max(max(max((int)q[-kLowPitch - 1], (int)q[-kLowPitch]), max((int)q[-kLowPitch + 1], (int)q[-1])),
-                              max(max((int)q[1], (int)q[kLowPitch - 1]), max((int)q[kLowPitch], (int)q[kLowPitch + 1])));
-            const unsigned long long keep = __ballot(s > 0 && s > m);
-            if (lane == 0) {
-                sbm[2 * k][tx] = (uint32_t)keep;
-                sbm[2 * k + 1][tx] = (uint32_t)(keep >> 32);
-                gb[2 * k] = (uint32_t)keep;
-                gb[2 * k + 1] = (uint32_t)(keep >> 32);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // 8 threads per row: popcount of the row's words
-    {
-        const int row = tid >> 3, part = tid & 7;
-        int cnt = 0;
-        for (int w = part; w < L.ntx; w += 8) cnt += __popc(sbm[row][w]);
-        cnt += __shfl_xor(cnt, 1);
-        cnt += __shfl_xor(cnt, 2);
-        cnt += __shfl_xor(cnt, 4);
-        if (part == 0) rowcount[L.row_base + ty * kTile + row] = cnt;
-    }
+    const int row = tid >> 3, part = tid & 7;  // 8 threads per pixel row
+    int cnt = 0;
+    for (int w = part; w < L.ntx; w += 8) cnt += __popc(L.bitmap[(size_t)(ty * L.ntx + w) * kTile + row]);
+    cnt += __shfl_xor(cnt, 1);
+    cnt += __shfl_xor(cnt, 2);
+    cnt += __shfl_xor(cnt, 4);
+    if (part == 0) rowcount[L.row_base + ty * kTile + row] = cnt;
 }
 
 __global__ __launch_bounds__(256) void emit_kernel(PyramidParams P, const int32_t* __restrict__ rowcount,
@@ -611,29 +613,56 @@ __global__ __launch_bounds__(256) void emit_kernel(PyramidParams P, const int32_
         }
     }
     __syncthreads();
-    // emission: every thread takes words round-robin; score gathers and host stores of different threads overlap
-    for (int i = tid; i < kTile * L.ntx; i += 256) {
-        const int rr = i / L.ntx, w = i - rr * L.ntx;
-        uint32_t word = sbm[rr][w];
-        if (!word) continue;
-        const int lr = ty * kTile + rr;
-        const uint8_t* srow = L.score + (size_t)(ty * L.ntx + w) * kScoreBlock + kScoreRing + rr * kTile;  // body row rr of tile (ty, w)
-        int rank = s_rank[rr][w];
-        while (word) {
-            const int bit = __ffs(word) - 1;
-            word &= word - 1;
-            if (rank < kFastCap) {
-                const int o = lvl_out + rank;
-                if (o < cand_capacity) {
-                    Candidate cd;
-                    cd.x = (int16_t)(3 + 32 * w + bit);
-                    cd.y = (int16_t)(3 + lr);
-                    cd.score = srow[bit];
-                    cd.level = (uint16_t)lvl;
-                    h_cands[o] = cd;
+    // emission: every thread takes words round-robin, four at a time: the 32 score bytes behind each non-empty word
+    // (one body row of a tile) are fetched as two 16-byte loads, all eight in flight before the first record is built
+    // (a byte load per kept pixel chained one memory round trip per keypoint)
+    const int nwords = kTile * L.ntx;
+    for (int i0 = tid; i0 < nwords; i0 += 4 * 256) {
+        uint32_t word[4];
+        uint4 lo[4], hi[4];
+        int rr4[4], w4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 256 * u;
+            word[u] = 0;
+            if (i < nwords) {
+                rr4[u] = i / L.ntx;
+                w4[u] = i - rr4[u] * L.ntx;
+                word[u] = sbm[rr4[u]][w4[u]];
+            }
+            if (word[u]) {  // body row rr of tile (ty, w)
+                const uint4* srow = reinterpret_cast<const uint4*>(L.score + (size_t)(ty * L.ntx + w4[u]) * kScoreBlock +
+                                                                    kScoreRing + rr4[u] * kTile);
+                lo[u] = srow[0];
+                hi[u] = srow[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!word[u]) continue;
+            const uint32_t d[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+            int rank = s_rank[rr4[u]][w4[u]];
+            const int y = 3 + ty * kTile + rr4[u], xb = 3 + 32 * w4[u];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint32_t sub = (word[u] >> (4 * j)) & 15u;
+                while (sub) {
+                    const int b = __ffs(sub) - 1;
+                    sub &= sub - 1;
+                    if (rank < kFastCap) {
+                        const int o = lvl_out + rank;
+                        if (o < cand_capacity) {
+                            Candidate cd;
+                            cd.x = (int16_t)(xb + 4 * j + b);
+                            cd.y = (int16_t)y;
+                            cd.score = (uint16_t)((d[j] >> (8 * b)) & 255u);
+                            cd.level = (uint16_t)lvl;
+                            h_cands[o] = cd;
+                        }
+                    }
+                    rank++;
                 }
             }
-            rank++;
         }
     }
 }
@@ -641,11 +670,13 @@ __global__ __launch_bounds__(256) void emit_kernel(PyramidParams P, const int32_
 void launch_fast_score(const PyramidParams& p, hipStream_t s) {
     hipLaunchKernelGGL(fast_score_kernel, dim3(8 * ((p.total_tiles + 7) / 8)), dim3(256), 0, s, p);
 }
-void launch_fast_low_count(const PyramidParams& p, int32_t* d_rowcount, hipStream_t s) {
-    hipLaunchKernelGGL(fast_low_count_kernel, dim3(p.total_rows / kTile), dim3(256), 0, s, p, d_rowcount);
+void launch_fast_low(const PyramidParams& p, hipStream_t s) {
+    const int ngroups = (p.total_tiles + 3) / 4;
+    hipLaunchKernelGGL(fast_low_kernel, dim3(8 * ((ngroups + 7) / 8)), dim3(256), 0, s, p);
 }
-void launch_emit(const PyramidParams& p, const int32_t* d_rowcount, Candidate* cands, CandidateHeader* hdr_a,
+void launch_emit(const PyramidParams& p, int32_t* d_rowcount, Candidate* cands, CandidateHeader* hdr_a,
                  CandidateHeader* hdr_b, int cand_capacity, hipStream_t s) {
+    hipLaunchKernelGGL(rowcount_kernel, dim3(p.total_rows / kTile), dim3(256), 0, s, p, d_rowcount);
     hipLaunchKernelGGL(emit_kernel, dim3(p.total_rows / kTile), dim3(256), 0, s, p, d_rowcount, cands, hdr_a, hdr_b,
                        cand_capacity);
 }

@@ -11,10 +11,17 @@
 // In both cases the reference pushes the non-empty children n1..n4 of each processed node to the FRONT of the
 // list, so after a step the list is [children of the last processed node (n4..n1), ..., children of the first
 // processed node, then the untouched nodes in their old order]; that position is computed with prefix sums and is
-// also the node's slot in LDS (slot == list position).  Keys (candidate indices) stay in one array in which every
-// node owns a contiguous, order-preserving slice; a split is a stable 4-way partition of the parent's slice,
-// ranked with a block-wide scan of packed 4x16-bit quadrant counters.
+// also the node's slot in LDS (slot == list position).  Keys stay in one array in which every node owns a contiguous,
+// order-preserving slice; a split is a stable 4-way partition of the parent's slice, ranked with a block-wide scan of
+// packed 4x16-bit quadrant counters.
 // Output per level: the best-response key of every node in list order (first maximum, :667-686).
+//
+// The candidate list the reference builds in front of this (GpuFast's kpLoc array, raster order, capped at 10000 per
+// level) is never materialised: a key IS the candidate's position (x | y << 16, ROI coordinates), read straight off the
+// keep bitmap in raster order by the level's workgroup, and a key's FAST response is read from the score map once, at
+// the very end.  Rounds 1-2 had a per-band emit kernel write 8-byte records that every split step then gathered from
+// global memory through the key (12-15 us for the launch, a memory round trip per step).  A thread holds the keys of
+// its chunk of positions in registers across a step, so keys, key -> node and the node table are single-buffered.
 #include "orb_device.h"
 
 namespace so {
@@ -22,7 +29,8 @@ namespace so {
 constexpr int kQtThreads = 1024;
 constexpr int kQtMaxKeys = kFastCap;  // 10000 candidates per level at most
 constexpr int kQtMaxNodes = 1024;     // list never exceeds N + 3 (N <= 1020 on this path)
-static_assert((kQtMaxKeys + kQtThreads - 1) / kQtThreads <= 16, "a thread's keys must fit the 4-bit codes of one 64-bit register");
+constexpr int kQtChunk = (kQtMaxKeys + kQtThreads - 1) / kQtThreads;  // positions per thread at most (10)
+static_assert(kQtChunk <= 16, "a thread's keys must fit the 4-bit codes of one 64-bit register");
 
 struct QtNode {  // 16 bytes
     int16_t x0, y0, x1, y1;
@@ -31,6 +39,14 @@ struct QtNode {  // 16 bytes
 };
 
 typedef unsigned long long u64;
+
+// tools/probe/qt_probe.hip builds this file with -DQT_TIMING: shader-clock stamps of the level-0 workgroup
+#ifdef QT_TIMING
+__device__ long long qt_stamps[96];
+#define QT_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) qt_stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QT_T(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ int qt_wave_excl_scan(int v, int lane) {
     int incl = v;
@@ -108,51 +124,120 @@ struct QtLevelArgs {
     int sel_stride;            // slots per level in the output
 };
 
+// LDS map (bytes): keys 40000 | key -> node 2 x 20000 | nodes 16384 | pre, post 2 x 8192 | child 8192 | newslot 2048 |
+// proc 4096 | kv 4096 | scan scratch.  While the key array is built, the level's keep words sit (in raster order) in
+// the space behind the keys.
+constexpr int kQtOffKnode = kQtMaxKeys * 4;
+constexpr int kQtOffNodes = kQtOffKnode + 2 * kQtMaxKeys * 2;
+constexpr int kQtOffPre = kQtOffNodes + kQtMaxNodes * 16;
+constexpr int kQtOffPost = kQtOffPre + kQtMaxNodes * 8;
+constexpr int kQtOffChild = kQtOffPost + kQtMaxNodes * 8;
+constexpr int kQtOffNewslot = kQtOffChild + kQtMaxNodes * 8;
+constexpr int kQtOffProc = kQtOffNewslot + kQtMaxNodes * 2;
+constexpr int kQtOffKv = kQtOffProc + kQtMaxNodes * 4;
+constexpr int kQtSmemBytes = kQtOffKv + kQtMaxNodes * 4;
+constexpr int kQtWordCache = (kQtSmemBytes - kQtOffKnode) / 4;  // keep words the LDS can hold next to the keys
+static_assert(sizeof(QtNode) == 16 && kQtOffKnode % 16 == 0 && kQtOffNodes % 16 == 0 && kQtOffPre % 8 == 0, "LDS map");
+
 __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, QtLevelArgs A,
-                                                               const Candidate* __restrict__ cands,
-                                                               const CandidateHeader* __restrict__ hdr,
                                                                SelectedKp* __restrict__ sel_out,
                                                                int32_t* __restrict__ count_out) {
-    __shared__ uint16_t s_keys[2][kQtMaxKeys];
-    __shared__ uint16_t s_knode[2][kQtMaxKeys];
-    __shared__ QtNode s_nodes[2][kQtMaxNodes];
-    __shared__ u64 s_pre[kQtMaxNodes], s_post[kQtMaxNodes];
-    __shared__ uint16_t s_child[kQtMaxNodes][4];
-    __shared__ uint16_t s_newslot[kQtMaxNodes];
-    __shared__ int s_proc[kQtMaxNodes];     // processing rank of a node in this step, -1 = not split
-    __shared__ int s_kv[kQtMaxNodes];       // by processing rank: number of non-empty children, then its prefix
+    __shared__ __align__(16) unsigned char smem[kQtSmemBytes];
     __shared__ u64 s_w64[kQtThreads / 64];
     __shared__ int s_wi[kQtThreads / 64];
     __shared__ int s_misc[8];
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(smem);                       // x | y << 16 (ROI coordinates, as GpuFast's kpLoc)
+    uint16_t* s_knode2 = reinterpret_cast<uint16_t*>(smem + kQtOffKnode);      // [2][kQtMaxKeys]: key position -> node slot
+    QtNode* nodes = reinterpret_cast<QtNode*>(smem + kQtOffNodes);
+    u64* s_pre = reinterpret_cast<u64*>(smem + kQtOffPre);
+    u64* s_post = reinterpret_cast<u64*>(smem + kQtOffPost);
+    uint16_t(*s_child)[4] = reinterpret_cast<uint16_t(*)[4]>(smem + kQtOffChild);
+    uint16_t* s_newslot = reinterpret_cast<uint16_t*>(smem + kQtOffNewslot);
+    int* s_proc = reinterpret_cast<int*>(smem + kQtOffProc);  // processing rank of a node in this step, -1 = not split
+    int* s_kv = reinterpret_cast<int*>(smem + kQtOffKv);      // by processing rank: number of non-empty children, then its prefix
+    uint32_t* s_words = reinterpret_cast<uint32_t*>(smem + kQtOffKnode);       // (key build only)
 
     const int tid = threadIdx.x;
     const int lvl = blockIdx.x;
     const LevelDesc& L = P.lv[lvl];
-    const int n = hdr->count[lvl];
-    const Candidate* C = cands + hdr->offset[lvl];
     const int N = A.n_target[lvl];
     SelectedKp* out = sel_out + (size_t)lvl * A.sel_stride;
+    const int W = L.w - 2 * kFastBorder, H = L.h - 2 * kFastBorder;
+
+    // ---------------- keys in raster order off the keep bitmap ----------------
+    // Word i of the level in raster order = pixel row i / ntx, tile column i % ntx.  The bitmap is tile-major in memory
+    // ([tile][row]): it is read in memory order (coalesced, every load of a thread in flight at once) and laid down in
+    // LDS in raster order; thread t then owns a contiguous run of raster words.
+    QT_T(0);
+    const int ntx = L.ntx;
+    const int nwords = L.nty * kTile * ntx;
+    const bool cached = nwords <= kQtWordCache;
+    if (cached) {
+        for (int i = tid; i < nwords; i += kQtThreads) {
+            const int tile = i >> 5, r = i & 31;
+            const int ty = tile / ntx, tx = tile - ty * ntx;
+            s_words[(ty * kTile + r) * ntx + tx] = L.bitmap[i];
+        }
+        __syncthreads();
+    }
+    QT_T(1);
+    const int wpt = ((nwords + kQtThreads - 1) / kQtThreads) | 1;  // odd: neighbouring threads start in different banks
+    const int w0 = min(tid * wpt, nwords), w1 = min(w0 + wpt, nwords);
+    const int row_first = ntx > 0 ? w0 / ntx : 0, tx_first = w0 - row_first * ntx;
+    auto word_at = [&](int i, int row, int tx) -> uint32_t {
+        return cached ? s_words[i] : L.bitmap[(size_t)((row >> 5) * ntx + tx) * kTile + (row & 31)];
+    };
+    int total = 0, base = 0;
+    {
+        int cnt = 0, row = row_first, tx = tx_first;
+        for (int i = w0; i < w1; i++) {
+            cnt += __popc(word_at(i, row, tx));
+            if (++tx == ntx) { tx = 0; row++; }
+        }
+        base = qt_block_scan(cnt, s_wi, &total);
+    }
+    QT_T(2);
+    const int n = min(total, kQtMaxKeys);  // the first 10000 in raster order (Fast.hpp:32)
     if (n <= 0) {
         if (tid == 0) count_out[lvl] = 0;
         return;
     }
-    const int W = L.w - 2 * kFastBorder, H = L.h - 2 * kFastBorder;
+    {
+        int rank = base, row = row_first, tx = tx_first;
+        for (int i = w0; i < w1 && rank < n; i++) {
+            uint32_t word = word_at(i, row, tx);
+            while (word && rank < n) {
+                const int bit = __ffs(word) - 1;
+                word &= word - 1;
+                s_key[rank++] = (uint32_t)(3 + 32 * tx + bit) | ((uint32_t)(3 + row) << 16);
+            }
+            if (++tx == ntx) { tx = 0; row++; }
+        }
+    }
+    __syncthreads();  // keys are down; the word cache is dead
+    QT_T(3);
+
     const int chunk = (n + kQtThreads - 1) / kQtThreads;
     const int p0 = min(tid * chunk, n), p1 = min(p0 + chunk, n);
+    int b = 0;  // current key -> node buffer
 
-    // ---------------- roots (:468-511) ----------------
+    // ---------------- roots (:468-511): a stable partition of the raster-ordered keys by root ----------------
     int n_ini = (int)roundf((float)W / (float)H);
     if (n_ini < 1) n_ini = 1;
     const float hX = (float)W / (float)n_ini;
-    int b = 0;  // current buffer
     {
+        uint32_t kreg[kQtChunk];
         u64 mine = 0;
-        for (int p = p0; p < p1; p++) {
-            int r = (int)((float)C[p].x / hX);
-            r = min(r, n_ini - 1);
-            mine += 1ull << (16 * r);
+#pragma unroll
+        for (int j = 0; j < kQtChunk; j++) {
+            kreg[j] = 0;
+            if (p0 + j < p1) {
+                kreg[j] = s_key[p0 + j];
+                const int r = min((int)((float)(int)(kreg[j] & 0xFFFFu) / hX), n_ini - 1);
+                mine += 1ull << (16 * r);
+            }
         }
-        const u64 excl = qt_block_scan64(mine, s_w64);
+        const u64 excl = qt_block_scan64(mine, s_w64);  // (barriers: every thread holds its keys before any is moved)
         if (tid == kQtThreads - 1) s_pre[0] = excl + mine;  // totals per root
         __syncthreads();
         const u64 tot = s_pre[0];
@@ -166,14 +251,15 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
             if (cnt_r[r] > 0) m0++;
         }
         u64 run = excl;
-        for (int p = p0; p < p1; p++) {
-            int r = (int)((float)C[p].x / hX);
-            r = min(r, n_ini - 1);
-            const int pos = off_r[r] + qt_unpack(run, r);
-            s_keys[0][pos] = (uint16_t)p;
-            s_knode[0][pos] = (uint16_t)slot_r[r];
-            run += 1ull << (16 * r);
-        }
+#pragma unroll
+        for (int j = 0; j < kQtChunk; j++)
+            if (p0 + j < p1) {
+                const int r = min((int)((float)(int)(kreg[j] & 0xFFFFu) / hX), n_ini - 1);
+                const int pos = (r == 0 ? off_r[0] : r == 1 ? off_r[1] : r == 2 ? off_r[2] : off_r[3]) + qt_unpack(run, r);
+                s_key[pos] = kreg[j];
+                s_knode2[pos] = (uint16_t)(r == 0 ? slot_r[0] : r == 1 ? slot_r[1] : r == 2 ? slot_r[2] : slot_r[3]);
+                run += 1ull << (16 * r);
+            }
         if (tid < 4 && tid < n_ini && cnt_r[tid] > 0) {
             QtNode nd;
             nd.x0 = (int16_t)(int)(hX * (float)tid);
@@ -183,45 +269,48 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
             nd.off = (uint16_t)off_r[tid];
             nd.n = (uint16_t)cnt_r[tid];
             nd.seq = (uint32_t)tid;
-            s_nodes[0][slot_r[tid]] = nd;
+            nodes[slot_r[tid]] = nd;
         }
-        if (tid == 0) {
-            s_misc[0] = m0;  // list size
-            s_misc[1] = 4;   // next creation sequence
-        }
+        if (tid == 0) s_misc[0] = m0;  // list size
         __syncthreads();
     }
 
     int m = s_misc[0];
     uint32_t seq_base = 4;
     bool careful = false;
+    QT_T(4);
     // ---------------- split steps ----------------
     for (int guard = 0; guard < 64; guard++) {
-        const QtNode* nodes = s_nodes[b];
-        QtNode* nnodes = s_nodes[b ^ 1];
-        const uint16_t* keys = s_keys[b];
-        const uint16_t* knode = s_knode[b];
-        // (B) quadrant of every key that sits in a non-leaf node; packed counts; prefix at the slice borders.
-        // The quadrant of a key costs a chain of dependent reads (key -> node slot -> node box; key -> candidate in
-        // global memory): it is worked out ONCE per step and kept as a 4-bit code (0 = leaf node, q + 1 otherwise) in a
-        // 64-bit register - a thread owns at most ten keys (10000 candidates / 1024 threads) - for the count, the
-        // prefix and the partition below (three such chains per step before: 42 -> see DESIGN 3)
+        const uint16_t* knode = s_knode2 + b * kQtMaxKeys;
+        uint16_t* knode_new = s_knode2 + (b ^ 1) * kQtMaxKeys;
+        // (B) quadrant of every key that sits in a non-leaf node; packed counts; prefix at the slice borders.  The
+        // thread's keys are read ONCE per step into registers (the partition below moves keys in place), the quadrant
+        // is kept as a 4-bit code (0 = leaf node, q + 1 otherwise) in a 64-bit register.
+        uint32_t kreg[kQtChunk];
         u64 mine = 0, qcode = 0;
-        for (int p = p0; p < p1; p++) {
-            const QtNode nd = nodes[knode[p]];
-            if (nd.n > 1) {
-                const Candidate c = C[keys[p]];
-                const int xm = nd.x0 + (int)ceilf((float)(nd.x1 - nd.x0) / 2), ym = nd.y0 + (int)ceilf((float)(nd.y1 - nd.y0) / 2);
-                const int q = (c.x < xm ? 0 : 1) + (c.y < ym ? 0 : 2);
-                mine += 1ull << (16 * q);
-                qcode |= (u64)(q + 1) << (4 * (p - p0));
+#pragma unroll
+        for (int j = 0; j < kQtChunk; j++) {
+            const int p = p0 + j;
+            kreg[j] = 0;
+            if (p < p1) {
+                kreg[j] = s_key[p];
+                const QtNode nd = nodes[knode[p]];
+                if (nd.n > 1) {
+                    const int cx = (int)(kreg[j] & 0xFFFFu), cy = (int)(kreg[j] >> 16);
+                    const int xm = nd.x0 + (int)ceilf((float)(nd.x1 - nd.x0) / 2), ym = nd.y0 + (int)ceilf((float)(nd.y1 - nd.y0) / 2);
+                    const int q = (cx < xm ? 0 : 1) + (cy < ym ? 0 : 2);
+                    mine += 1ull << (16 * q);
+                    qcode |= (u64)(q + 1) << (4 * j);
+                }
             }
         }
         const u64 excl = qt_block_scan64(mine, s_w64);
         {
             u64 run = excl;
-            for (int p = p0; p < p1; p++) {
-                const int qc = (int)((qcode >> (4 * (p - p0))) & 15ull);
+#pragma unroll
+            for (int j = 0; j < kQtChunk; j++) {
+                const int p = p0 + j;
+                const int qc = (int)((qcode >> (4 * j)) & 15ull);
                 if (qc) {
                     const int ni = knode[p];
                     const QtNode nd = nodes[ni];
@@ -232,6 +321,7 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
             }
         }
         __syncthreads();
+        QT_T(8 + 4 * guard + 0);
         // per node: children populations
         int cnt[4] = {0, 0, 0, 0}, k_children = 0;
         bool nonleaf = false;
@@ -314,6 +404,7 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
             if (split) cp = s_kv[s_proc[tid]];
             (void)qt_block_scan(split ? ne : 0, s_wi, &n_to_expand);
         }
+        QT_T(8 + 4 * guard + 1);
         const int m_new = total_children + n_untouched;
         // (E) new nodes; slot == position in the new list
         if (tid < m) {
@@ -333,7 +424,7 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
                         nd.off = (uint16_t)o;
                         nd.n = (uint16_t)cnt[q];
                         nd.seq = seq_base + 4u * (uint32_t)s_proc[tid] + (uint32_t)q;
-                        nnodes[pos] = nd;
+                        nodes[pos] = nd;  // (every thread read its own node before the barriers above)
                         s_child[tid][q] = (uint16_t)pos;
                         r++;
                     }
@@ -341,33 +432,36 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
                 }
             } else {
                 const int pos = total_children + ur;
-                nnodes[pos] = me;
+                nodes[pos] = me;
                 s_newslot[tid] = (uint16_t)pos;
             }
         }
         __syncthreads();
-        // (F) stable 4-way partition of the keys of the split nodes
+        QT_T(8 + 4 * guard + 2);
+        // (F) stable 4-way partition of the keys of the split nodes, in place (the step's keys are in registers)
         {
-            uint16_t* keys2 = s_keys[b ^ 1];
-            uint16_t* knode2 = s_knode[b ^ 1];
             u64 run = excl;
-            for (int p = p0; p < p1; p++) {
-                const int ni = knode[p];
-                const int q = (int)((qcode >> (4 * (p - p0))) & 15ull) - 1;
-                if (q >= 0 && s_proc[ni] >= 0) {
-                    const int slot = s_child[ni][q];
-                    const int rank = qt_unpack(run, q) - qt_unpack(s_pre[ni], q);
-                    const int pos = nnodes[slot].off + rank;
-                    keys2[pos] = keys[p];
-                    knode2[pos] = (uint16_t)slot;
-                } else {
-                    keys2[p] = keys[p];
-                    knode2[p] = s_newslot[ni];
+#pragma unroll
+            for (int j = 0; j < kQtChunk; j++) {
+                const int p = p0 + j;
+                if (p < p1) {
+                    const int ni = knode[p];
+                    const int q = (int)((qcode >> (4 * j)) & 15ull) - 1;
+                    if (q >= 0 && s_proc[ni] >= 0) {
+                        const int slot = s_child[ni][q];
+                        const int rank = qt_unpack(run, q) - qt_unpack(s_pre[ni], q);
+                        const int pos = nodes[slot].off + rank;
+                        s_key[pos] = kreg[j];
+                        knode_new[pos] = (uint16_t)slot;
+                    } else {
+                        knode_new[p] = s_newslot[ni];  // the key stays where it is
+                    }
+                    if (q >= 0) run += 1ull << (16 * q);
                 }
-                if (q >= 0) run += 1ull << (16 * q);
             }
         }
         __syncthreads();
+        QT_T(8 + 4 * guard + 3);
         b ^= 1;
         seq_base += 4u * (uint32_t)nsplit;
         const int m_prev = m;
@@ -378,45 +472,56 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
     }
 
     // ---------------- best response per node, list order (:667-686) ----------------
-    // The reference keeps the FIRST maximum of `response` in the node's insertion order.  A thread per node walking its
-    // keys would chain one global read per key (16 on average at level 0); instead every key fetches its own score - all
-    // in flight together - and the node's winner is an LDS atomicMax over (score << 16 | 0xFFFF - rank in the node):
-    // highest score, lowest rank on ties.
+    // The reference keeps the FIRST maximum of `response` in the node's insertion order.  Every key fetches its own
+    // score from the score map - a thread's loads all in flight together - and the node's winner is an LDS atomicMax
+    // over (score << 16 | 0xFFFF - rank in the node): highest score, lowest rank on ties.
+    QT_T(5);
     int* s_best = s_proc;  // (dead after the last split step)
     if (tid < kQtMaxNodes) s_best[tid] = -1;
     __syncthreads();
     {
-        const uint16_t* keys = s_keys[b];
-        const uint16_t* knode = s_knode[b];
-        const QtNode* nodes = s_nodes[b];
-        for (int p = p0; p < p1; p++) {
-            const int ni = knode[p];
-            const int sc = C[keys[p]].score;
-            atomicMax(&s_best[ni], (sc << 16) | (0xFFFF - (p - (int)nodes[ni].off)));
+        int sc[kQtChunk];
+#pragma unroll
+        for (int j = 0; j < kQtChunk; j++) {
+            sc[j] = 0;
+            if (p0 + j < p1) {
+                const uint32_t k = s_key[p0 + j];
+                const int px = (int)(k & 0xFFFFu) - 3, py = (int)(k >> 16) - 3;  // pixel of the FAST ROI
+                sc[j] = L.score[(size_t)((py >> 5) * ntx + (px >> 5)) * kScoreBlock + kScoreRing + (py & 31) * kTile + (px & 31)];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < kQtChunk; j++)
+            if (p0 + j < p1) {
+                const int ni = s_knode2[b * kQtMaxKeys + p0 + j];
+                atomicMax(&s_best[ni], (sc[j] << 16) | (0xFFFF - (p0 + j - (int)nodes[ni].off)));
+            }
     }
     __syncthreads();
     if (tid < m) {
-        const QtNode nd = s_nodes[b][tid];
+        const QtNode nd = nodes[tid];
         const int v = s_best[tid];
-        const int best = s_keys[b][nd.off + (0xFFFF - (v & 0xFFFF))];
-        const int best_score = v >> 16;
+        const uint32_t best = s_key[nd.off + (0xFFFF - (v & 0xFFFF))];
         SelectedKp o;
-        o.x = (int16_t)(C[best].x + kFastBorder);  // addBorder_kernel, Fast_gpu.cu:461-470
-        o.y = (int16_t)(C[best].y + kFastBorder);
+        o.x = (int16_t)((int)(best & 0xFFFFu) + kFastBorder);  // addBorder_kernel, Fast_gpu.cu:461-470
+        o.y = (int16_t)((int)(best >> 16) + kFastBorder);
         o.level = (uint16_t)lvl;
-        o.score = (uint16_t)best_score;
+        o.score = (uint16_t)(v >> 16);
         if (tid < A.sel_stride) out[tid] = o;
     }
     if (tid == 0) count_out[lvl] = min(m, A.sel_stride);
+    QT_T(6);
+#ifdef QT_TIMING
+    if (blockIdx.x == 0 && tid == 0) { qt_stamps[7] = m; qt_stamps[90] = n; qt_stamps[91] = careful; }
+#endif
 }
 
-void launch_quadtree(const PyramidParams& p, const int* n_target, int sel_stride, const Candidate* d_cands,
-                     const CandidateHeader* d_hdr, SelectedKp* d_sel, int32_t* d_count, hipStream_t s) {
+void launch_quadtree(const PyramidParams& p, const int* n_target, int sel_stride, SelectedKp* d_sel, int32_t* d_count,
+                     hipStream_t s) {
     QtLevelArgs a;
     for (int l = 0; l < kMaxLevels; l++) a.n_target[l] = l < p.nlevels ? n_target[l] : 0;
     a.sel_stride = sel_stride;
-    hipLaunchKernelGGL(quadtree_kernel, dim3(p.nlevels), dim3(kQtThreads), 0, s, p, a, d_cands, d_hdr, d_sel, d_count);
+    hipLaunchKernelGGL(quadtree_kernel, dim3(p.nlevels), dim3(kQtThreads), 0, s, p, a, d_sel, d_count);
 }
 
 }  // namespace so
