@@ -92,14 +92,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(cnt, d_count, 32, hipMemcpyDeviceToHost));
     printf("kernel %.2f us per launch (20 back to back); level 0: n = %lld keys, N = %d, nodes out = %lld (count %d)\n", ms * 50.0, st[90],
            n_target[0], st[7], cnt[0]);
-    // s_memtime ticks at 100 MHz on gfx9: 10 ns per tick
-    auto us = [&](int a, int b) { return (double)(st[b] - st[a]) * 0.01; };
+    // s_memtime ticks with the shader clock: scale the stamps so that the whole workgroup = the measured launch time
+    const double tick_us = (double)ms * 50.0 / (double)(st[6] - st[0]);
+    auto us = [&](int a, int b) { return (double)(st[b] - st[a]) * tick_us; };
     printf("word cache %.2f | count+scan %.2f | keys %.2f | roots %.2f | steps %.2f | best+out %.2f | total %.2f us\n", us(0, 1), us(1, 2),
            us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(0, 6));
     for (int g = 0; g < 20; g++) {
         if (st[8 + 4 * g + 3] <= 0 || (g > 0 && st[8 + 4 * g + 3] < st[8 + 4 * (g - 1) + 3])) break;
         const long long prev = g == 0 ? st[4] : st[8 + 4 * (g - 1) + 3];
-        printf("  step %2d: quadrants+scan %.2f | order %.2f | nodes %.2f | partition %.2f\n", g, (double)(st[8 + 4 * g] - prev) * 0.01,
+        printf("  step %2d: quadrants+scan %.2f | order %.2f | nodes %.2f | partition %.2f\n", g, (double)(st[8 + 4 * g] - prev) * tick_us,
                us(8 + 4 * g, 8 + 4 * g + 1), us(8 + 4 * g + 1, 8 + 4 * g + 2), us(8 + 4 * g + 2, 8 + 4 * g + 3));
     }
     return 0;
