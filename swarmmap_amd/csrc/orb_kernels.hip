@@ -687,13 +687,9 @@ void launch_emit(const PyramidParams& p, int32_t* d_rowcount, Candidate* cands, 
 // once; the blur is evaluated only on the 37x37 window BRIEF can reach, so the full-frame blur pass and its
 // HBM round trip disappear.  256 tests = 4 ballots of 64 lanes -> the four 64-bit descriptor words.
 // ------------------------------------------------------------------------------------------------
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "brief_pattern.inc"
 };
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-__constant__ float c_gauss7[7] = {0x1.1f5f62p-4f, 0x1.0c70fcp-3f, 0x1.869472p-3f, 0x1.ba95c0p-3f,
-                                  0x1.869472p-3f, 0x1.0c70fcp-3f, 0x1.1f5f62p-4f};
-
 __device__ __forceinline__ int reflect101(int p, int n) {
     if (p < 0) p = -p;
     if (p >= n) p = 2 * (n - 1) - p;
@@ -745,31 +741,63 @@ __device__ __forceinline__ void det_sincosf(float a, float& sn, float& cs) {
     cs = (q == 0) ? cosr : (q == 1) ? -sinr : (q == 2) ? -cosr : sinr;
 }
 
-constexpr int kPatch = 43, kPatchPitch = 44;  // source patch
+constexpr int kPatch = 43, kPatchPitch = 48;  // source patch (12 dwords per row: an aligned dword run covers any 43 bytes)
 constexpr int kBlur = 37, kBlurPitch = 40;    // blurred window
+#ifndef SO_DESC_THREADS
+#define SO_DESC_THREADS 64
+#endif
+constexpr int kDescThreads = SO_DESC_THREADS;  // waves per keypoint x 64 (measured on MI355X, 1000 keypoints: one wave
+                                               // 16.2 us, four waves 18.0 us - the barriers and the per-wave set-up cost
+                                               // more than the shorter loops save)
+constexpr int kDescWaves = kDescThreads / 64;
+static_assert(kDescThreads == 64 || kDescThreads == 128 || kDescThreads == 256, "descriptor words are dealt to whole waves");
+
+// radius of the orientation disc at row |v| (ORBextractor.cc umax, HALF_PATCH_SIZE 15): 4 bits per row
+__device__ __forceinline__ int orb_umax(int av) { return (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull); }
 
 __device__ __forceinline__ void describe_body(const PyramidParams& P, const SelectedKp kp, const int id,
                                               uint8_t* __restrict__ desc, float* __restrict__ angle_out,
-                                              uint8_t* patch, float* rowp, uint8_t* blur,
+                                              uint32_t* patch32, float* rowp, uint8_t* blur, int* s_mom,
                                               uint8_t* __restrict__ desc2 = nullptr,
                                               float* __restrict__ angle2 = nullptr) {
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LevelDesc& L = P.lv[kp.level];
     const int x = kp.x, y = kp.y;
+    // this lane's test pairs (one dword each: x0, y0, x1, y1), fetched now - nothing below waits for them until the end
+    uint32_t pat[4 / kDescWaves];
+#pragma unroll
+    for (int q = 0; q < 4 / kDescWaves; q++) pat[q] = reinterpret_cast<const uint32_t*>(c_pattern)[lane + 64 * (wave + kDescWaves * q)];
+    constexpr float g0 = 0x1.1f5f62p-4f, g1 = 0x1.0c70fcp-3f, g2 = 0x1.869472p-3f, g3 = 0x1.ba95c0p-3f;
+    constexpr float gauss7[7] = {g0, g1, g2, g3, g2, g1, g0};
 
-    for (int i = lane; i < kPatch * kPatch; i += 64) {
-        const int r = i / kPatch, c = i - r * kPatch;
-        const int gy = reflect101(y - 21 + r, L.h), gx = reflect101(x - 21 + c, L.w);
-        patch[r * kPatchPitch + c] = L.img[(size_t)gy * L.pitch + gx];
+    // 43 x 43 source patch.  Inside the image (all but keypoints within 21 px of a border) every row is an aligned run
+    // of 12 dwords - 516 loads per keypoint instead of 1849 byte loads; `sh` is where the patch's first column sits in it.
+    int sh = 0;
+    if (x >= 21 && y >= 21 && x + 21 < L.w && y + 21 < L.h) {
+        const int ax = (x - 21) & ~3;
+        sh = (x - 21) & 3;
+        const uint8_t* src = L.img + (size_t)(y - 21) * L.pitch + ax;
+        for (int i = tid; i < kPatch * (kPatchPitch / 4); i += kDescThreads) {
+            const int r = i / (kPatchPitch / 4), d = i - r * (kPatchPitch / 4);
+            patch32[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * L.pitch + 4 * d);
+        }
+    } else {
+        uint8_t* pb = reinterpret_cast<uint8_t*>(patch32);
+        for (int i = tid; i < kPatch * kPatch; i += kDescThreads) {
+            const int r = i / kPatch, c = i - r * kPatch;
+            const int gy = reflect101(y - 21 + r, L.h), gx = reflect101(x - 21 + c, L.w);
+            pb[r * kPatchPitch + c] = L.img[(size_t)gy * L.pitch + gx];
+        }
     }
     __syncthreads();
+    const uint8_t* patch = reinterpret_cast<const uint8_t*>(patch32) + sh;
 
     // intensity centroid over the radius-15 disc (749 px), integer moments
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
+    for (int i = tid; i < 31 * 31; i += kDescThreads) {
         const int r = i / 31, c = i - r * 31;
         const int v = r - 15, u = c - 15;
-        if (abs(u) <= c_umax[abs(v)]) {
+        if (abs(u) <= orb_umax(abs(v))) {
             const int val = patch[(21 + v) * kPatchPitch + 21 + u];
             m10 += u * val;
             m01 += v * val;
@@ -780,25 +808,37 @@ __device__ __forceinline__ void describe_body(const PyramidParams& P, const Sele
         m10 += __shfl_xor(m10, off);
         m01 += __shfl_xor(m01, off);
     }
-    float kp_dir = det_atan2f((float)m01, (float)m10);
-    kp_dir += (float)(kp_dir < 0) * 0x1.921fb6p+2f;
-    kp_dir *= 0x1.ca5dcp+5f;
+    if (lane == 0) {
+        s_mom[2 * wave] = m10;
+        s_mom[2 * wave + 1] = m01;
+    }
 
     // separable Gaussian: row pass (float), column pass, round-half-even
-    for (int i = lane; i < kPatch * kBlur; i += 64) {
+    for (int i = tid; i < kPatch * kBlur; i += kDescThreads) {
         const int r = i / kBlur, c = i - r * kBlur;
         const uint8_t* q = patch + r * kPatchPitch + c;
         float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < 7; k++) sum = sum + (float)q[k] * c_gauss7[k];
+        for (int k = 0; k < 7; k++) sum = sum + (float)q[k] * gauss7[k];
         rowp[i] = sum;
     }
     __syncthreads();
-    for (int i = lane; i < kBlur * kBlur; i += 64) {
+    if (kDescWaves > 1) {
+        m10 = m01 = 0;
+#pragma unroll
+        for (int w = 0; w < kDescWaves; w++) {
+            m10 += s_mom[2 * w];
+            m01 += s_mom[2 * w + 1];
+        }
+    }
+    float kp_dir = det_atan2f((float)m01, (float)m10);
+    kp_dir += (float)(kp_dir < 0) * 0x1.921fb6p+2f;
+    kp_dir *= 0x1.ca5dcp+5f;
+    for (int i = tid; i < kBlur * kBlur; i += kDescThreads) {
         const int r = i / kBlur, c = i - r * kBlur;
         float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < 7; k++) sum = sum + rowp[(r + k) * kBlur + c] * c_gauss7[k];
+        for (int k = 0; k < 7; k++) sum = sum + rowp[(r + k) * kBlur + c] * gauss7[k];
         int v = (int)__builtin_rintf(sum);
         blur[r * kBlurPitch + c] = (uint8_t)min(max(v, 0), 255);
     }
@@ -806,52 +846,51 @@ __device__ __forceinline__ void describe_body(const PyramidParams& P, const Sele
 
     float a, b;  // a = cos, b = sin  (Orb_gpu.cu:77-79)
     det_sincosf(kp_dir * 0x1.1df46ap-6f, b, a);
-    unsigned long long words[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int bit = lane + 64 * q;
-        const int8_t* pp = c_pattern + bit * 4;
-        const float p0x = (float)pp[0], p0y = (float)pp[1], p1x = (float)pp[2], p1y = (float)pp[3];
+    for (int q = 0; q < 4 / kDescWaves; q++) {
+        const int wq = wave + kDescWaves * q;  // descriptor bits 64 wq .. 64 wq + 63
+        const float p0x = (float)(int8_t)(pat[q] & 255u), p0y = (float)(int8_t)((pat[q] >> 8) & 255u);
+        const float p1x = (float)(int8_t)((pat[q] >> 16) & 255u), p1y = (float)(int8_t)(pat[q] >> 24);
         const int r0 = (int)__builtin_rintf(p0x * b + p0y * a), c0 = (int)__builtin_rintf(p0x * a - p0y * b);
         const int r1 = (int)__builtin_rintf(p1x * b + p1y * a), c1 = (int)__builtin_rintf(p1x * a - p1y * b);
         const int t0 = blur[(18 + r0) * kBlurPitch + 18 + c0];
         const int t1 = blur[(18 + r1) * kBlurPitch + 18 + c1];
-        words[q] = __ballot(t0 < t1);
-    }
-    if (lane == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(desc + (size_t)id * 32);
-        o[0] = words[0]; o[1] = words[1]; o[2] = words[2]; o[3] = words[3];
-        angle_out[id] = kp_dir;
-        if (desc2) {  // HBM-resident copy for the device-resident frame (dframe.cpp)
-            unsigned long long* o2 = reinterpret_cast<unsigned long long*>(desc2 + (size_t)id * 32);
-            o2[0] = words[0]; o2[1] = words[1]; o2[2] = words[2]; o2[3] = words[3];
-            angle2[id] = kp_dir;
+        const unsigned long long word = __ballot(t0 < t1);
+        if (lane == 0) {
+            reinterpret_cast<unsigned long long*>(desc + (size_t)id * 32)[wq] = word;
+            if (desc2) reinterpret_cast<unsigned long long*>(desc2 + (size_t)id * 32)[wq] = word;  // HBM-resident copy (dframe.cpp)
         }
+    }
+    if (tid == 0) {
+        angle_out[id] = kp_dir;
+        if (angle2) angle2[id] = kp_dir;
     }
 }
 
-__global__ __launch_bounds__(64) void describe_kernel(PyramidParams P, const SelectedKp* __restrict__ sel, int n,
-                                                       uint8_t* __restrict__ desc, float* __restrict__ angle_out) {
-    __shared__ uint8_t patch[kPatch * kPatchPitch];
+__global__ __launch_bounds__(kDescThreads) void describe_kernel(PyramidParams P, const SelectedKp* __restrict__ sel, int n,
+                                                                 uint8_t* __restrict__ desc, float* __restrict__ angle_out) {
+    __shared__ uint32_t patch[kPatch * (kPatchPitch / 4) + 4];
     __shared__ float rowp[kPatch * kBlur];
     __shared__ uint8_t blur[kBlur * kBlurPitch];
+    __shared__ int s_mom[8];
     const int id = blockIdx.x;
     if (id >= n) return;
-    describe_body(P, sel[id], id, desc, angle_out, patch, rowp, blur);
+    describe_body(P, sel[id], id, desc, angle_out, patch, rowp, blur, s_mom);
 }
 
 // Same, fed by the device quadtree: block b finds its (level, k) from the per-level survivor counts, describes
 // qt_sel[level][k] and writes descriptor / angle / keypoint record at the compact output index, straight into
 // host-mapped memory (the caller's copy) and into HBM (`dev`: what the device-resident frame reads).  Launched
 // with the capacity as grid; surplus blocks exit.
-__global__ __launch_bounds__(64) void describe_qt_kernel(PyramidParams P, const SelectedKp* __restrict__ qt_sel,
-                                                          const int32_t* __restrict__ qt_count, int qt_stride,
-                                                          uint8_t* __restrict__ desc, float* __restrict__ angle_out,
-                                                          SelectedKp* __restrict__ meta_out,
-                                                          int32_t* __restrict__ total_out, DescribeDeviceOut dev) {
-    __shared__ uint8_t patch[kPatch * kPatchPitch];
+__global__ __launch_bounds__(kDescThreads) void describe_qt_kernel(PyramidParams P, const SelectedKp* __restrict__ qt_sel,
+                                                                    const int32_t* __restrict__ qt_count, int qt_stride,
+                                                                    uint8_t* __restrict__ desc, float* __restrict__ angle_out,
+                                                                    SelectedKp* __restrict__ meta_out,
+                                                                    int32_t* __restrict__ total_out, DescribeDeviceOut dev) {
+    __shared__ uint32_t patch[kPatch * (kPatchPitch / 4) + 4];
     __shared__ float rowp[kPatch * kBlur];
     __shared__ uint8_t blur[kBlur * kBlurPitch];
+    __shared__ int s_mom[8];
     int id = blockIdx.x, lvl = -1, base = 0;
 #pragma unroll
     for (int l = 0; l < kMaxLevels; l++) {
@@ -871,20 +910,20 @@ __global__ __launch_bounds__(64) void describe_qt_kernel(PyramidParams P, const 
         meta_out[id] = kp;
         if (dev.meta) dev.meta[id] = kp;
     }
-    describe_body(P, kp, id, desc, angle_out, patch, rowp, blur, dev.desc, dev.angle);
+    describe_body(P, kp, id, desc, angle_out, patch, rowp, blur, s_mom, dev.desc, dev.angle);
 }
 
 void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, const int32_t* d_qt_count, int qt_stride,
                         int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total,
                         const DescribeDeviceOut& dev, hipStream_t s) {
-    hipLaunchKernelGGL(describe_qt_kernel, dim3(capacity), dim3(64), 0, s, p, d_qt_sel, d_qt_count, qt_stride, desc,
+    hipLaunchKernelGGL(describe_qt_kernel, dim3(capacity), dim3(kDescThreads), 0, s, p, d_qt_sel, d_qt_count, qt_stride, desc,
                        angle, meta, total, dev);
 }
 
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,
                      hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(describe_kernel, dim3(n), dim3(64), 0, s, p, d_sel, n, d_desc, d_angle);
+    hipLaunchKernelGGL(describe_kernel, dim3(n), dim3(kDescThreads), 0, s, p, d_sel, n, d_desc, d_angle);
 }
 
 }  // namespace so

@@ -9,9 +9,9 @@ import json
 import re
 import sys
 
-KEEP = ("fast_score_kernel", "fast_low_count_kernel", "describe_qt_kernel", "resize_kernel", "topk_window_kernel",
+KEEP = ("fast_score_kernel", "fast_low_kernel", "describe_qt_kernel", "resize_kernel", "topk_window_kernel",
         "stage_in_kernel", "pose_opt_lds_kernel", "pose_opt_reg_kernel", "ba_solve_la_kernel", "ba_solve_mfma_kernel",
-        "ba_schur_gather_kernel", "ba_build_kernel", "quadtree_kernel", "frame_prepare_kernel", "ingest_kernel", "emit_kernel")
+        "ba_schur_gather_kernel", "ba_build_kernel", "quadtree_kernel", "frame_prepare_kernel", "ingest_kernel", "ingest16_kernel")
 
 
 def load(path):
