@@ -731,6 +731,10 @@ int so_pose_optimization_last_kernel_ms(so_ba* ba, float* ms);
 int so_bundle_adjust(so_ba* ba, const so_ba_problem* problem, const so_ba_options* options,
                      const volatile uint8_t* stop, float* Tcw_out, float* Xw_out, uint8_t* edge_outlier,
                      double* edge_chi2, so_ba_info* info);
+/* HIP events around the reduced-camera-system solve of every LM trial (so_ba_info.solve_ms / n_solves) on / off.  Off by
+ * default: an event record in front of and behind a kernel idles the stream ~6 us each, 4 % of a 64-keyframe window
+ * (profiles/r3_lba_trial_sequence.txt).  With timing off solve_ms and n_solves are 0. */
+int so_bundle_adjust_set_solve_timing(so_ba* ba, int enabled);
 
 #ifdef __cplusplus
 }

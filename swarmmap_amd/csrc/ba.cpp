@@ -219,6 +219,7 @@ struct so_ba {
         double* trace = nullptr;
     } pose_pending;
     bool pose_timing = true;       // HIP events around the PoseOptimization kernel (so_pose_optimization_set_timing)
+    bool solve_timing = false;     // HIP events around every reduced-system solve (so_bundle_adjust_set_solve_timing)
     static constexpr int kSolveEvents = 32;  // the first trials of a call are event-timed around the solve kernel
     hipEvent_t ev_solve[2 * kSolveEvents] = {nullptr};
     float solve_ms = 0.f;
@@ -327,7 +328,6 @@ int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
     if (r.n_free + (r.n_active_edges > 0 ? 1 : 0) == 0) return SO_OK;  // 0 vertices to optimize
     launch_ba_errors(r.d, 0, false, r.nb_err, s);
     launch_ba_build(r.d, false, s);
-    launch_ba_maxdiag(r.d, s);
     launch_ba_stage_begin(r.d, r.nb_err, iterations, b->h_lm_dev, s);
     SO_HIP(hipGetLastError());
     const int trials_before = b->h_lm->trials, first_block = r.blocks_enqueued;  // h_lm: state after the last wait
@@ -336,7 +336,7 @@ int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
     for (;;) {
         for (int i = 0; i < budget; i++) {
             const int k = r.blocks_enqueued++;
-            const bool timed = k < so_ba::kSolveEvents;
+            const bool timed = b->solve_timing && k < so_ba::kSolveEvents;
             launch_ba_trial(r.d, r.nb_err, r.nb_upd, r.stop ? b->h_abort_dev : nullptr, b->h_lm_dev,
                             timed ? b->ev_solve[2 * k] : nullptr, timed ? b->ev_solve[2 * k + 1] : nullptr, s);
         }
@@ -348,7 +348,7 @@ int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
         budget = std::max(1, lm.iterations - lm.it);
     }
     const int real = lm.trials - trials_before;  // the first `real` blocks of this stage ran, the rest returned at once
-    for (int k = first_block; k < first_block + real && k < so_ba::kSolveEvents; k++) {
+    for (int k = first_block; b->solve_timing && k < first_block + real && k < so_ba::kSolveEvents; k++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, b->ev_solve[2 * k], b->ev_solve[2 * k + 1]) == hipSuccess) {
             b->solve_ms += ms;
@@ -914,11 +914,16 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
                  r_chi2 = O.add(sizeof(double) * sE), r_out = O.add(sE);
     if ((rc = ensure_pinned(&b->h_out, &b->h_out_cap, O.total))) return rc;
     if ((rc = b->d_out.ensure(O.total))) return rc;
-    SO_HIP(hipMemsetAsync(b->d_err.p, 0, sizeof(double) * 2 * sE, s));   // _error of a fresh edge
-    SO_HIP(hipMemsetAsync(b->d_chi2.p, 0, sizeof(double) * sE, s));
-    SO_HIP(hipMemsetAsync(b->d_partial.p, 0, sizeof(double) * kBaPartialCount, s));
-    if (!pairs_path) SO_HIP(hipMemsetAsync(b->d_tab.p, 0xFF, sizeof(int) * sL * sF, s));  // -1: keyframe does not observe the landmark
-    SO_HIP(hipMemsetAsync(b->d_lm.p, 0, sizeof(BaLm), s));  // current estimate = buffer 0, no trials yet
+    {
+        BaClearList cl{};
+        cl.item[cl.n++] = {b->d_err.p, sizeof(double) * 2 * sE, 0u};   // _error of a fresh edge
+        cl.item[cl.n++] = {b->d_chi2.p, sizeof(double) * sE, 0u};
+        cl.item[cl.n++] = {b->d_partial.p, sizeof(double) * kBaPartialCount, 0u};
+        if (!pairs_path) cl.item[cl.n++] = {b->d_tab.p, sizeof(int) * sL * sF, 0xFFFFFFFFu};  // -1: keyframe does not observe the landmark
+        static_assert(sizeof(BaLm) % 4 == 0, "cleared as 32-bit words");
+        cl.item[cl.n++] = {b->d_lm.p, sizeof(BaLm), 0u};  // current estimate = buffer 0, no trials yet
+        launch_ba_clear(cl, s);
+    }
     memset(b->h_lm, 0, sizeof(BaLm));
     *b->h_abort = 0;
 
@@ -1326,6 +1331,12 @@ int so_pose_optimization_batch(so_ba* b, int32_t n_problems, const so_pose_probl
             q.info[1] = inf[2];
         }
     }
+    return SO_OK;
+}
+
+int so_bundle_adjust_set_solve_timing(so_ba* b, int enabled) {
+    if (!b) return SO_ERR_INVALID_ARG;
+    b->solve_timing = enabled != 0;
     return SO_OK;
 }
 

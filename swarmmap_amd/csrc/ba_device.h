@@ -118,9 +118,19 @@ constexpr int kBaSolveOk = 2049;       // [2049]: 1.0 if the Cholesky succeeded
 constexpr int kBaPartialCount = 2056;
 
 // which: 0 = current estimate, 1 = trial.  gated: return immediately unless lm->active (and, for build, lm->need_build).
+// several device buffers filled with a 32-bit pattern in one launch (sizes in bytes, multiples of 4; 16-byte aligned)
+struct BaClearItem {
+    void* p;
+    size_t bytes;
+    uint32_t value;
+};
+struct BaClearList {
+    BaClearItem item[6];
+    int n;
+};
+void launch_ba_clear(const BaClearList& L, hipStream_t s);
 void launch_ba_errors(const BaDev& d, int which, bool gated, int n_blocks, hipStream_t s);
 void launch_ba_build(const BaDev& d, bool gated, hipStream_t s);
-void launch_ba_maxdiag(const BaDev& d, hipStream_t s);
 // start of optimize(iterations): currentChi from the error partials, computeLambdaInit from the max diagonal
 void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_host, hipStream_t s);
 // one LM trial, seven launches, no host involvement: [build] -> schur prep -> gather -> solve -> update -> errors

@@ -14,6 +14,7 @@
 //   types/se3quat.h                     SE3Quat exp / product / map
 //   core/base_binary_edge.hpp:55-120    constructQuadraticForm (+ Huber weights, robust_kernel_impl.cpp:78-91)
 //   core/block_solver.hpp:354-486       Schur complement, back-substitution
+#include <algorithm>
 #include <cstdlib>
 
 #include <hipcub/hipcub.hpp>
@@ -243,6 +244,26 @@ __global__ __launch_bounds__(256) void ba_edge_table_kernel(BaDev d) {
     if (e >= d.n_edges) return;
     const int h = d.pose_hidx[d.e_pose[e]];
     if (h >= 0) d.edge_tab[(size_t)h * d.n_points + d.e_point[e]] = e;
+}
+
+// The per-call fills (stored errors, chi2, partials, LM state to zero; edge table to -1) as ONE launch: five runtime
+// fills in a row cost ~5 us each on the stream before the first kernel of the solve can start.
+__global__ __launch_bounds__(256) void ba_clear_kernel(BaClearList L) {
+    for (int k = 0; k < L.n; k++) {
+        const BaClearItem it = L.item[k];
+        uint32_t* p = static_cast<uint32_t*>(it.p);
+        const size_t n4 = it.bytes / 16, words = it.bytes / 4;
+        const uint4 v = make_uint4(it.value, it.value, it.value, it.value);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) reinterpret_cast<uint4*>(p)[i] = v;
+        for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = it.value;
+    }
+}
+
+void launch_ba_clear(const BaClearList& L, hipStream_t s) {
+    size_t most = 0;
+    for (int k = 0; k < L.n; k++) most = L.item[k].bytes > most ? L.item[k].bytes : most;
+    const int blocks = (int)std::min<size_t>(1024, std::max<size_t>(1, most / (16 * 256 * 4)));
+    hipLaunchKernelGGL(ba_clear_kernel, dim3(blocks), dim3(256), 0, s, L);
 }
 
 void launch_ba_edge_table(const BaDev& d, hipStream_t s) {
@@ -514,28 +535,6 @@ void launch_ba_build(const BaDev& d, bool gated, hipStream_t s) {
     const int nb = d.n_free + (d.n_points + 31) / 32;
     if (nb <= 0) return;
     hipLaunchKernelGGL(ba_build_kernel, dim3(nb), dim3(256), 0, s, d, gated ? 1 : 0);
-}
-
-// max |diagonal| over Hpp and Hll (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
-__global__ __launch_bounds__(1024) void ba_maxdiag_kernel(BaDev d) {
-    __shared__ double s_m[16];
-    double m = 0.0;
-    for (int i = threadIdx.x; i < 6 * d.n_free; i += 1024) m = fmax(m, fabs(d.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
-    for (int i = threadIdx.x; i < 3 * d.n_points; i += 1024)
-        if (d.pt_active[i / 3]) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < 16; i++) t = fmax(t, s_m[i]);
-        d.partial[kBaMaxDiag] = t;
-    }
-}
-
-void launch_ba_maxdiag(const BaDev& d, hipStream_t s) {
-    hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(1024), 0, s, d);
 }
 
 // ---------------- Schur complement ----------------
@@ -1367,12 +1366,35 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d) {
 // ---------------- Levenberg-Marquardt control on the device ----------------
 // Start of SparseOptimizer::optimize(iterations): chi2 of the current estimate (the error kernel ran on it),
 // computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180: tau * max diagonal, tau = 1e-5).
-__global__ __launch_bounds__(256) void ba_stage_begin_kernel(BaDev d, int nb_err, int iterations, BaLm* __restrict__ lm_host) {
+// Start of a stage (SparseOptimizer::optimize up to the first solve): chi2 of the estimate from the partials of the
+// error pass, lambda = 1e-5 max |diagonal| over Hpp and Hll (computeLambdaInit,
+// optimization_algorithm_levenberg.cpp:166-180; max is order-independent), LM state reset.  One workgroup; the maximum
+// used to be a launch of its own that walked the 3 n_points diagonal entries one dependent load at a time (19 us for
+// 9600 landmarks) - here a thread takes whole landmarks, three independent loads each.
+__global__ __launch_bounds__(1024) void ba_stage_begin_kernel(BaDev d, int nb_err, int iterations, BaLm* __restrict__ lm_host) {
     __shared__ double s_tmp[16];
-    double v = 0.0;
-    for (int i = threadIdx.x; i < nb_err; i += 256) v += d.partial[kBaPartialChi + i];
-    const double chi = block_sum(v, s_tmp);
+    __shared__ double s_m[16];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < d.n_free; i += 1024) {
+        const double* H = d.Hpp + 36 * (size_t)i;
+        m = fmax(m, fmax(fmax(fmax(fabs(H[0]), fabs(H[7])), fmax(fabs(H[14]), fabs(H[21]))), fmax(fabs(H[28]), fabs(H[35]))));
+    }
+    for (int i = threadIdx.x; i < d.n_points; i += 1024)
+        if (d.pt_active[i]) {
+            const double* H = d.Hll + 9 * (size_t)i;
+            m = fmax(m, fmax(fmax(fabs(H[0]), fabs(H[4])), fabs(H[8])));
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    double v = 0.0;  // summed by the first 256 threads, as when this kernel had 256 (same association, same bits)
+    if (threadIdx.x < 256)
+        for (int i = threadIdx.x; i < nb_err; i += 256) v += d.partial[kBaPartialChi + i];
+    const double chi = block_sum(v, s_tmp);  // (its barriers also cover s_m)
     if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; i++) t = fmax(t, s_m[i]);
+        d.partial[kBaMaxDiag] = t;
         BaLm& lm = *d.lm;
         lm.currentChi = chi;
         lm.iniChi = chi;
@@ -1380,7 +1402,7 @@ __global__ __launch_bounds__(256) void ba_stage_begin_kernel(BaDev d, int nb_err
         lm.chi_out = chi;
         lm.chi_begin = chi;
         lm.rho = 0.0;
-        lm.lambda = 1e-5 * d.partial[kBaMaxDiag];
+        lm.lambda = 1e-5 * t;
         lm.ni = 2.0;
         lm.nBad = 0;
         lm.it = 0;
@@ -1394,7 +1416,7 @@ __global__ __launch_bounds__(256) void ba_stage_begin_kernel(BaDev d, int nb_err
 }
 
 void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_host, hipStream_t s) {
-    hipLaunchKernelGGL(ba_stage_begin_kernel, dim3(1), dim3(256), 0, s, d, nb_err, iterations, lm_host);
+    hipLaunchKernelGGL(ba_stage_begin_kernel, dim3(1), dim3(1024), 0, s, d, nb_err, iterations, lm_host);
 }
 
 // End of a trial: OptimizationAlgorithmLevenberg::solve's accept / reject (optimization_algorithm_levenberg.cpp:

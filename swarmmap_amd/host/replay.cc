@@ -180,6 +180,7 @@ struct so_replay {
     float K4[4] = {0, 0, 0, 0};
     // statistics (timed steps only)
     double stat[48] = {0};
+    unsigned lba_windows_run = 0;  // (local-mapping thread only)
     std::vector<float> frame_ms;
     std::vector<float> ba_Tcw, ba_Xw;
     std::vector<uint8_t> ba_out;
@@ -192,7 +193,8 @@ enum {  // indices of so_replay::stat, mirrored in bench.py
     kMatchKernelMs, kPoseKernelMs, kPoseTrials, kPoseCalls, kPosePoints, kLbaWindows, kLbaBusyMs, kLbaGpuMs, kLbaSolveMs,
     kLbaSolves, kLocalPoints, kInView, kKeyframes, kMapPoints, kM2EnqMs, kM2WaitMs, kM1EnqMs, kM1WaitMs, kPoseTimedCalls,
     kTimedFrames, kStage0 /* 11 extractor stages */, kReruns = kStage0 + SO_EXTRACTOR_N_STAGES /* search launches: 2 per frame + exact re-runs of exhausted K-lists */,
-    kWideM2 /* motion-model searches repeated with the wider window */
+    kWideM2 /* motion-model searches repeated with the wider window */,
+    kLbaTrials /* LM trials (= reduced-system solves) of all windows; kLbaSolves / kLbaSolveMs cover the event-timed ones */
 };
 
 void mapper_loop(so_replay* r) {
@@ -222,6 +224,8 @@ void mapper_loop(so_replay* r) {
         so_ba_options opt;
         so_ba_options_local(&opt);
         so_ba_info info{};
+        // the solve kernel is event-timed on every fourth window only (two event records per LM trial idle the stream)
+        so_bundle_adjust_set_solve_timing(r->mapper_opt, (r->lba_windows_run++ % 4) == 0);
         const int rc = so_bundle_adjust(r->mapper_opt, &p, &opt, nullptr, r->ba_Tcw.data(), r->ba_Xw.data(),
                                         r->ba_out.data(), nullptr, &info);
         const double busy = now_ms() - t0;
@@ -234,6 +238,7 @@ void mapper_loop(so_replay* r) {
                 r->stat[kLbaGpuMs] += info.gpu_ms;
                 r->stat[kLbaSolveMs] += info.solve_ms;
                 r->stat[kLbaSolves] += info.n_solves;
+                r->stat[kLbaTrials] += info.lm_trials;
             }
             r->queue.pop_front();
             r->running = 0;

@@ -67,8 +67,14 @@ class Optimizer:
         lib.so_ba_options_global.restype = None
         lib.so_bundle_adjust.argtypes = [vp, C.POINTER(SoBaProblem), C.POINTER(SoBaOptions), vp, vp, vp, vp, vp,
                                          C.POINTER(SoBaInfo)]
+        lib.so_bundle_adjust_set_solve_timing.argtypes = [vp, C.c_int]
         self._h = vp()
         _lib.check(lib.so_ba_create(int(device), C.byref(self._h)))
+
+    def set_solve_timing(self, enabled):
+        """HIP events around every reduced-system solve (info["solve_ms"], info["n_solves"]); off by default - the two
+        event records idle the stream ~12 us per LM trial."""
+        _lib.check(self._lib.so_bundle_adjust_set_solve_timing(self._h, 1 if enabled else 0))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -119,6 +119,7 @@ class Replay:
         from .extractor import STAGES
         d["stages"] = dict(zip(STAGES, a[len(STAT):len(STAT) + len(STAGES)].tolist()))
         d["n_reruns"], d["n_wide_m2"] = a[len(STAT) + len(STAGES)], a[len(STAT) + len(STAGES) + 1]
+        d["lba_trials"] = a[len(STAT) + len(STAGES) + 2]  # all windows; solve_ms / n_solves cover the event-timed ones (1 in 4)
         n = self.lib.so_replay_log_size(self.h)
         ms = np.zeros(max(n, 1), np.float32)
         self.lib.so_replay_frame_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int]

@@ -16,6 +16,7 @@ FP64_PEAK_TF = 78.6
 
 def main():
     o = swarmmap_amd.Optimizer()
+    o.set_solve_timing(True)
     cases = ["GBA-1", "GBA-2", "GBA-1r", "GBA-2r"] + (["GBA-max", "GBA-4k"] if "max" in sys.argv[1:] else [])
     named = [a for a in sys.argv[1:] if a.startswith("GBA-")]  # python tools/gba_bench.py GBA-1 GBA-1r: those only
     if named:

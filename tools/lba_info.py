@@ -3,6 +3,7 @@ import numpy as np
 from swarmmap_amd import synth
 from swarmmap_amd.optimizer import Optimizer
 o=Optimizer()
+o.set_solve_timing(True)
 for nf in (48,64,72,80,88,96,104,112,128):
     w=synth.make_ba_problem(0, nf, (3*nf)//2, 150*nf, max_obs="auto")
     for _ in range(2): r=o.LocalBundleAdjustment(w)
