@@ -15,7 +15,8 @@ OUT = os.path.join(ROOT, "tools", "probe", "libswarmorb_flowprobe.so")
 def build():
     objs = []
     for src in ("orb_kernels.hip", "quadtree_kernel.hip", "extractor.cpp", "quadtree.cpp", "match_kernels.hip", "matcher.cpp",
-                "frame_kernels.hip", "frame.cpp", "dframe.cpp", "exchange.cpp", "ba_kernels.hip", "ba.cpp", "record.cpp", "capi.cpp"):
+                "frame_kernels.hip", "frame.cpp", "dframe.cpp", "kfstore_kernels.hip", "kfstore.cpp", "exchange.cpp", "ba_kernels.hip",
+                "ba.cpp", "record.cpp", "capi.cpp"):
         objs.append(os.path.join(CSRC, "build", os.path.splitext(src)[0] + ".o"))
     probe_o = os.path.join(ROOT, "tools", "probe", "ba_dense_flowprobe.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
