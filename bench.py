@@ -422,6 +422,51 @@ def candidate_search_records(dev):
     return out
 
 
+def batched_front_end_records(dev, members=(1, 8, 32), reps=40):
+    """Verdict item 9 (round 2): A agents' frames through ONE extraction chain (so_extractor_group + so_dframe_group_submit,
+    every kernel once with the agent as a grid dimension) - wall time from the group submit to the last frame complete on
+    the device, images in pinned host memory (361 KB per frame cross PCIe inside the timed region).  Not the headline's
+    deployment (one agent per GPU); what the front end does when agents share a GPU."""
+    import ctypes as C
+    st = synth.FrameStream(seed=20221001, size=synth.EUROC, K=synth.EUROC_K, dist=synth.EUROC_DIST)
+    nimg = 8
+    block = torch.empty((nimg, st.h, st.w), dtype=torch.uint8).pin_memory()
+    view = block.numpy()
+    for t in range(nimg):
+        view[t] = st.frame(t)
+    out = {}
+    for A in members:
+        exs = [swarmmap_amd.ORBextractor(1000, 1.2, 8, 20, 7, device=dev) for _ in range(A)]
+        frs = [swarmmap_amd.DeviceFrame(ex, synth.EUROC_K, synth.EUROC_DIST) for ex in exs]
+        grp = swarmmap_amd.ExtractorGroup(exs)
+        lib = frs[0]._lib
+        lib.so_dframe_wait.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+        ts = []
+        for r in range(reps + 8):
+            imgs = [view[(r + a) % nimg] for a in range(A)]
+            t0 = time.perf_counter()
+            grp.submit(imgs, frames=frs)
+            nk = C.c_int(0)
+            for f in frs:
+                lib.so_dframe_wait(f._h, C.byref(nk), None)
+            t1 = time.perf_counter()
+            for f in frs:
+                f.collect()
+            if r >= 8:
+                ts.append(t1 - t0)
+        grp.close()
+        for f in frs:
+            f.close()
+        for ex in exs:
+            ex.close()
+        ms = float(np.median(ts)) * 1e3
+        out["agents_%d" % A] = {"ms_per_chain": ms, "frames_per_s": A / (ms * 1e-3),
+                                "algorithmic_gbs": A * 7.96e6 / (ms * 1e-3) / 1e9, "hbm_frac": A * 7.96e6 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    out["note"] = ("752x480, nFeatures 1000, EuRoC lens model; 7.96 MB algorithmic bytes per frame (SURVEY 8d); a lone frame is "
+                   "latency-bound, 32 per chain are bound by PCIe ingest + the FAST and descriptor kernels' ALU work")
+    return out
+
+
 def lba_records(dev):
     """BASELINE configs[2]/[3] local-BA leg: LBA-S / LBA-M / LBA-L windows, wall time of one
     Optimizer::LocalBundleAdjustment through the C ABI (median of 5 after 2 warm-up calls)."""
@@ -644,6 +689,7 @@ def main():
                     krec["cpu_baseline"] = cpu_baseline(kframes, synth.KITTI_K, None, 2000, k_window, synth.KITTI, budget_s=8.0)
                 cfgs["kitti_stream_1241x376"] = krec
                 del kframes
+                cfgs["front_end_batched"] = batched_front_end_records(dev)
                 cfgs["candidate_search"] = candidate_search_records(dev)
                 cfgs["local_ba_windows"] = lba_records(dev)
                 # GBA-1 / GBA-2: SURVEY 8d's sizes with every camera looking at one cloud (reduced system nearly dense);

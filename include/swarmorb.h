@@ -85,6 +85,19 @@ int so_extractor_capacity(const so_extractor* ex);
  * extraction (which depends on nothing but the image) runs under the matcher / PoseOptimization kernels.  One frame
  * in flight per extractor; the image must stay valid until collect.  Results are identical to so_extractor_run. */
 int so_extractor_submit(so_extractor* ex, const uint8_t* image, int width, int height, int stride);
+
+/* Several extractors, ONE chain of launches (in-kernel batching of agents that share a GPU): so_extractor_group_submit is
+ * so_extractor_submit on every member with its own image - each member is collected as usual, results are identical -
+ * but every kernel of the chain runs once, with the member as one more grid dimension.  A lone frame leaves the GPU
+ * nearly idle (one workgroup per pyramid level in the quadtree, ~1000 small workgroups elsewhere), so n frames take
+ * hardly longer than one.  Members: same configuration, same device, device quadtree path; images: tightly packed,
+ * device-visible (pinned host memory or device memory), all of one size; at most SO_EXTRACTOR_GROUP_MAX members.  The
+ * group does not own its members; destroy it before them. */
+#define SO_EXTRACTOR_GROUP_MAX 64
+typedef struct so_extractor_group so_extractor_group;
+int so_extractor_group_create(so_extractor* const* members, int n, so_extractor_group** out);
+void so_extractor_group_destroy(so_extractor_group* group);
+int so_extractor_group_submit(so_extractor_group* group, const uint8_t* const* images, int width, int height, int stride);
 int so_extractor_submit_device(so_extractor* ex, const uint8_t* d_image, int width, int height, int stride);
 int so_extractor_collect(so_extractor* ex, so_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out);
 /* collect in two steps: so_extractor_wait blocks until the frame is done and tells the keypoint count; the results stay
@@ -349,6 +362,10 @@ void so_dframe_destroy(so_dframe* f);
  * UndistortKeyPoints -> ComputeImageBounds -> AssignFeaturesToGrid -> the matcher's candidate layout, enqueued on the
  * extractor's stream; returns without waiting.  One frame in flight per extractor. */
 int so_dframe_submit(so_dframe* f, const uint8_t* image, int width, int height, int stride);
+/* so_dframe_submit for frame i on member i of an extractor group, all in one chain of launches (the Frame constructors'
+ * kernel too: one workgroup per frame).  Every frame is waited for / collected as usual. */
+int so_dframe_group_submit(so_extractor_group* group, so_dframe* const* frames, const uint8_t* const* images, int width,
+                           int height, int stride);
 int so_dframe_submit_device(so_dframe* f, const uint8_t* d_image, int width, int height, int stride);
 /* Waits for the frame and hands out the host copies: keypoints (mvKeys), xy_un (mvKeysUn[i].pt, 2 floats each; may
  * be NULL), descriptors (mDescriptors), bounds4 = {mnMinX, mnMaxX, mnMinY, mnMaxY} (may be NULL).

@@ -88,27 +88,11 @@ int submit_impl(so_dframe* f, const uint8_t* image, bool on_device, int w, int h
     return rc;
 }
 
-int submit_body(so_dframe* f, const uint8_t* image, bool on_device, int w, int h, int stride) {
-    if (!f) return SO_ERR_INVALID_ARG;
-    if (f->in_flight) {
-        last_error_ref() = "so_dframe_submit: the previous frame of this handle has not been collected";
-        return SO_ERR_INVALID_ARG;
-    }
-    f->ready = false;
-    f->waited = false;
-    f->mirrors = false;
-    // from the second frame on the prepare launch below rides at the end of the extractor's frame graph
-    if (f->allocated && f->prep_revision)
-        extractor_set_graph_tail(f->ex, f, f->prep_revision,
-                                 [](void* ctx, hipStream_t s) { launch_frame_prepare(static_cast<so_dframe*>(ctx)->prep, s); });
-    int rc = on_device ? so_extractor_submit_device(f->ex, image, w, h, stride)
-                       : so_extractor_submit(f->ex, image, w, h, stride);
-    if (rc) return rc;
-    f->generation++;
-    f->in_flight = true;
-    f->launched = false;
-    if (!image || w <= 0 || h <= 0) return SO_OK;  // empty frame: collect hands out n = 0
+// Sizes the handle on its first frame and fills in the Frame constructor's launch (Frame.cc:230-274 as one kernel behind
+// the extractor's frame, same stream, no host sync in between) for a w x h image.
+int prepare_args(so_dframe* f, int w, int h, FramePrepareArgs* out) {
     ExtractorDeviceView V;
+    int rc;
     if ((rc = extractor_device_view(f->ex, &V))) return rc;
     SO_HIP(hipSetDevice(V.device));
     if (!f->allocated) {
@@ -121,7 +105,6 @@ int submit_body(so_dframe* f, const uint8_t* image, bool on_device, int w, int h
         for (int l = 0; l < 8; l++) f->scale[l] = V.scale[l];
         if ((rc = allocate(f, V.capacity))) return rc;
     }
-    // Frame.cc:230-274 as one launch behind the extractor's frame, same stream, no host sync in between
     FramePrepareArgs a{};
     a.cam = f->cam;
     a.width = w;
@@ -149,10 +132,38 @@ int submit_body(so_dframe* f, const uint8_t* image, bool on_device, int w, int h
     a.perm_host = reinterpret_cast<int32_t*>(f->h_block_dev + ((uint8_t*)f->h_perm - f->h_block));
     a.col_start = f->d_col_start;
     a.header_host = reinterpret_cast<int32_t*>(f->h_block_dev + ((uint8_t*)f->h_header - f->h_block));
+    memcpy(out, &a, sizeof(a));
+    return SO_OK;
+}
+
+int submit_body(so_dframe* f, const uint8_t* image, bool on_device, int w, int h, int stride) {
+    if (!f) return SO_ERR_INVALID_ARG;
+    if (f->in_flight) {
+        last_error_ref() = "so_dframe_submit: the previous frame of this handle has not been collected";
+        return SO_ERR_INVALID_ARG;
+    }
+    f->ready = false;
+    f->waited = false;
+    f->mirrors = false;
+    // from the second frame on the prepare launch below rides at the end of the extractor's frame graph
+    if (f->allocated && f->prep_revision)
+        extractor_set_graph_tail(f->ex, f, f->prep_revision,
+                                 [](void* ctx, hipStream_t s) { launch_frame_prepare(static_cast<so_dframe*>(ctx)->prep, s); });
+    int rc = on_device ? so_extractor_submit_device(f->ex, image, w, h, stride)
+                       : so_extractor_submit(f->ex, image, w, h, stride);
+    if (rc) return rc;
+    f->generation++;
+    f->in_flight = true;
+    f->launched = false;
+    if (!image || w <= 0 || h <= 0) return SO_OK;  // empty frame: collect hands out n = 0
+    FramePrepareArgs a;
+    if ((rc = prepare_args(f, w, h, &a))) return rc;
     if (memcmp(&a, &f->prep, sizeof(a)) != 0) {
         memcpy(&f->prep, &a, sizeof(a));
         f->prep_revision++;
     }
+    ExtractorDeviceView V;
+    if ((rc = extractor_device_view(f->ex, &V))) return rc;
     if (!extractor_tail_launched(f->ex)) launch_frame_prepare(a, V.stream);  // first frame / no graph / profiling
     SO_HIP(hipGetLastError());
     f->launched = true;
@@ -226,6 +237,40 @@ void so_dframe_destroy(so_dframe* f) {
         if (f->h_block) (void)hipHostFree(f->h_block);
     }
     delete f;
+}
+
+int so_dframe_group_submit(so_extractor_group* g, so_dframe* const* frames, const uint8_t* const* images, int width,
+                           int height, int stride) {
+    if (!g || !frames || !images || width <= 0 || height <= 0) return SO_ERR_INVALID_ARG;
+    const int n = extractor_group_size(g);
+    for (int i = 0; i < n; i++) {
+        so_dframe* f = frames[i];
+        if (!f || f->ex != extractor_group_member(g, i)) {
+            last_error_ref() = "so_dframe_group_submit: frame i must be built on member i of the group";
+            return SO_ERR_INVALID_ARG;
+        }
+        if (f->in_flight) {
+            last_error_ref() = "so_dframe_submit: the previous frame of this handle has not been collected";
+            return SO_ERR_INVALID_ARG;
+        }
+        if (!images[i]) return SO_ERR_INVALID_ARG;
+    }
+    int rc = extractor_group_prepare(g, width, height);  // the members' buffers exist from here on
+    if (rc) return rc;
+    std::vector<FramePrepareArgs> preps((size_t)n);
+    for (int i = 0; i < n; i++)
+        if ((rc = prepare_args(frames[i], width, height, &preps[(size_t)i]))) return rc;
+    if ((rc = extractor_group_submit(g, images, width, height, stride, preps.data()))) return rc;
+    for (int i = 0; i < n; i++) {
+        so_dframe* f = frames[i];
+        f->ready = false;
+        f->waited = false;
+        f->mirrors = false;
+        f->generation++;
+        f->in_flight = true;
+        f->launched = true;
+    }
+    return SO_OK;
 }
 
 int so_dframe_submit(so_dframe* f, const uint8_t* image, int width, int height, int stride) {

@@ -15,9 +15,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "extractor_internal.h"
+#include "frame_device.h"
 #include "orb_device.h"
 #include "quadtree.h"
 #include "so_common.h"
@@ -613,6 +615,204 @@ void extractor_release_graph_tail(so_extractor* ex, void* owner) {
 bool extractor_tail_launched(const so_extractor* ex) { return ex && ex->tail_launched; }
 }  // namespace so
 
+// ---- several extractors, one chain of launches (include/swarmorb.h: so_extractor_group) -----------------------
+struct so_extractor_group {
+    std::vector<so_extractor*> m;
+    int device = 0;
+    hipStream_t stream = nullptr;          // the first member's
+    ExtractBatchMember* d_members = nullptr;
+    std::vector<ExtractBatchMember> h_members;
+    const uint8_t** h_srcs = nullptr;      // host-mapped: this frame's images as the device sees them
+    const uint8_t** h_srcs_dev = nullptr;
+    // One captured chain per set of Frame-constructor launches riding at its end (so_dframe_group_submit: the tracking
+    // loop rotates three device-resident frames per agent) - slot k's launches live at d_prep + k * members.
+    struct Slot {
+        std::vector<FramePrepareArgs> prep;  // empty: the chain without the Frame constructors
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool rows16 = false;
+        unsigned long long last_use = 0;
+    };
+    static constexpr int kSlots = 4;
+    FramePrepareArgs* d_prep = nullptr;    // kSlots x members
+    std::vector<Slot> slots;
+    unsigned long long use_clock = 0;
+    bool graph_failed = false;
+    hipEvent_t done = nullptr;
+    int width = 0, height = 0;
+};
+
+namespace {
+
+void slot_drop_graph(so_extractor_group::Slot& sl) {
+    if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
+    if (sl.graph) (void)hipGraphDestroy(sl.graph);
+    sl.exec = nullptr;
+    sl.graph = nullptr;
+}
+void group_drop_graph(so_extractor_group* g) {
+    for (auto& sl : g->slots) slot_drop_graph(sl);
+}
+
+bool same_config(const so_extractor_config& a, const so_extractor_config& b) {
+    return a.nfeatures == b.nfeatures && a.scale_factor == b.scale_factor && a.nlevels == b.nlevels &&
+           a.ini_th_fast == b.ini_th_fast && a.min_th_fast == b.min_th_fast && a.device == b.device;
+}
+
+}  // namespace
+
+namespace so {
+
+int extractor_group_size(const so_extractor_group* g) { return g ? (int)g->m.size() : 0; }
+so_extractor* extractor_group_member(const so_extractor_group* g, int i) { return g->m[(size_t)i]; }
+
+// Sizes every member for w x h frames (what the first submit of a lone extractor does): the device-resident frames of a
+// group need the members' capacities and output buffers before the first batched launch.
+int extractor_group_prepare(so_extractor_group* g, int w, int h) {
+    if (!g || w <= 0 || h <= 0) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(g->device));
+    bool fresh = g->h_members.empty();
+    for (so_extractor* ex : g->m) {
+        if (!ex->allocated) {
+            const int rc = allocate(ex, w, h);
+            if (rc) return rc;
+            fresh = true;
+        } else if (ex->width != w || ex->height != h) {
+            last_error_ref() = "image size changed between frames";
+            return SO_ERR_SIZE_CHANGED;
+        }
+        if (!(ex->device_qt && ex->P.total_tiles > 0)) {
+            last_error_ref() = "so_extractor_group: every member must run the device quadtree (no SWARMORB_HOST_QUADTREE, quotas <= 1020 "
+                               "per level) on images large enough for FAST tiles";
+            return SO_ERR_INVALID_ARG;
+        }
+    }
+    if (!fresh) return SO_OK;
+    g->width = w;
+    g->height = h;
+    g->h_members.assign(g->m.size(), ExtractBatchMember{});
+    for (size_t i = 0; i < g->m.size(); i++) {
+        so_extractor* ex = g->m[i];
+        ExtractBatchMember& M = g->h_members[i];
+        M.P = ex->P;
+        for (int l = 0; l < kMaxLevels; l++) M.qt.n_target[l] = l < ex->P.nlevels ? ex->features_per_level[l] : 0;
+        M.qt.sel_stride = ex->qt_stride;
+        M.qt_sel = ex->d_qt_sel;
+        M.qt_count = ex->d_qt_count;
+        M.out.desc = ex->h_desc_dev;
+        M.out.angle = reinterpret_cast<float*>(ex->h_desc_dev + (size_t)ex->out_capacity * 32);
+        M.out.meta = ex->h_meta_dev;
+        M.out.total = ex->h_total_dev;
+        M.out.dev = ex->dev_out;
+    }
+    SO_HIP(so::memcpy_sync(g->d_members, g->h_members.data(), sizeof(ExtractBatchMember) * g->m.size(), hipMemcpyHostToDevice));
+    group_drop_graph(g);
+    return SO_OK;
+}
+
+// so_extractor_group_submit; preps (one per member, or null): the members' frame_prepare launches ride at the end of the chain
+int extractor_group_submit(so_extractor_group* g, const uint8_t* const* images, int w, int h, int stride, const FramePrepareArgs* preps) {
+    if (!g || !images || w <= 0 || h <= 0) return SO_ERR_INVALID_ARG;
+    if (stride != w) {
+        last_error_ref() = "so_extractor_group_submit: images must be tightly packed (stride == width)";
+        return SO_ERR_INVALID_ARG;
+    }
+    const double t_begin = now_ms();
+    const int n = (int)g->m.size();
+    for (so_extractor* ex : g->m)
+        if (ex->pending) {
+            last_error_ref() = "a submitted frame has not been collected";
+            return SO_ERR_INVALID_ARG;
+        }
+    int rc = extractor_group_prepare(g, w, h);
+    if (rc) return rc;
+    bool rows16 = (w & 15) == 0;
+    for (int i = 0; i < n; i++) {
+        if (!images[i]) return SO_ERR_INVALID_ARG;
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, images[i]) != hipSuccess || !attr.devicePointer) {
+            (void)hipGetLastError();
+            last_error_ref() = "so_extractor_group_submit: every image must be device-visible (pinned host memory or device memory)";
+            return SO_ERR_INVALID_ARG;
+        }
+        g->h_srcs[i] = static_cast<const uint8_t*>(attr.devicePointer);
+        const LevelDesc& L0 = g->m[(size_t)i]->P.lv[0];
+        rows16 = rows16 && (reinterpret_cast<uintptr_t>(g->h_srcs[i]) & 15) == 0 && (L0.pitch & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(L0.img) & 15) == 0;
+    }
+    // the slot that holds this set of Frame-constructor launches (or none of them)
+    if (g->slots.empty()) g->slots.resize(so_extractor_group::kSlots);
+    so_extractor_group::Slot* sl = nullptr;
+    for (auto& c : g->slots)
+        if (c.last_use && c.prep.size() == (preps ? (size_t)n : 0) &&
+            (!preps || memcmp(c.prep.data(), preps, sizeof(FramePrepareArgs) * (size_t)n) == 0))
+            sl = &c;
+    hipStream_t s = g->stream;
+    if (!sl) {
+        sl = &g->slots[0];
+        for (auto& c : g->slots)
+            if (c.last_use < sl->last_use) sl = &c;  // never used, or used longest ago
+        if (sl->last_use) SO_HIP(hipStreamSynchronize(s));  // a chain that reads the slot's launches may be in flight
+        slot_drop_graph(*sl);
+        sl->prep.clear();
+        if (preps) {
+            sl->prep.assign(preps, preps + n);
+            SO_HIP(so::memcpy_sync(g->d_prep + (size_t)(sl - g->slots.data()) * (size_t)n, preps, sizeof(FramePrepareArgs) * (size_t)n,
+                                   hipMemcpyHostToDevice));
+        }
+    }
+    sl->last_use = ++g->use_clock;
+    const bool with_prep = preps != nullptr;
+    const FramePrepareArgs* d_prep = g->d_prep + (size_t)(sl - g->slots.data()) * (size_t)n;
+    if (sl->exec && sl->rows16 != rows16) slot_drop_graph(*sl);
+    const int capacity = g->m[0]->out_capacity;
+    auto chain = [&]() {
+        launch_extract_batch(g->d_members, g->h_members[0], n, g->h_srcs_dev, w, h, rows16, capacity, s);
+        if (with_prep) launch_frame_prepare_batch(d_prep, n, s);
+    };
+    static const bool no_graph = getenv("SWARMORB_NO_GRAPH") != nullptr;
+    if (!sl->exec && !no_graph && !g->graph_failed) {
+        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            chain();
+            e = hipStreamEndCapture(s, &sl->graph);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&sl->exec, sl->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            slot_drop_graph(*sl);
+            g->graph_failed = true;
+        } else {
+            sl->rows16 = rows16;
+        }
+    }
+    if (sl->exec) SO_HIP(hipGraphLaunch(sl->exec, s));
+    else chain();
+    SO_HIP(hipGetLastError());
+    bool other_streams = false;
+    for (so_extractor* ex : g->m) other_streams = other_streams || ex->stream != s;
+    if (other_streams) {  // a member's collect waits on the member's own stream
+        SO_HIP(hipEventRecord(g->done, s));
+        for (so_extractor* ex : g->m)
+            if (ex->stream != s) SO_HIP(hipStreamWaitEvent(ex->stream, g->done, 0));
+    }
+    const double t_enq = now_ms();
+    for (so_extractor* ex : g->m) {
+        ex->tail_owner = nullptr;
+        ex->tail_revision = 0;
+        ex->tail_fn = nullptr;
+        ex->tail_launched = with_prep;
+        ex->t_begin = t_begin;
+        ex->t_enq = t_enq;
+        ex->pending = 1;
+        ex->pending_prof = false;
+        ex->cands_on_host = false;
+    }
+    return SO_OK;
+}
+
+}  // namespace so
+
 extern "C" {
 
 int so_extractor_create(const so_extractor_config* cfg, so_extractor** out) {
@@ -684,6 +884,53 @@ int so_extractor_submit_device(so_extractor* ex, const uint8_t* d_image, int wid
 
 int so_extractor_collect(so_extractor* ex, so_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out) {
     return collect_impl(ex, keypoints, descriptors, capacity, n_out);
+}
+
+int so_extractor_group_create(so_extractor* const* members, int n, so_extractor_group** out) {
+    if (!members || n <= 0 || n > SO_EXTRACTOR_GROUP_MAX || !out) return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    for (int i = 0; i < n; i++) {
+        if (!members[i] || !same_config(members[i]->cfg, members[0]->cfg)) {
+            last_error_ref() = "so_extractor_group_create: the members must share one configuration and one device";
+            return SO_ERR_INVALID_ARG;
+        }
+        for (int j = 0; j < i; j++)
+            if (members[j] == members[i]) return SO_ERR_INVALID_ARG;
+    }
+    so_extractor_group* g = new so_extractor_group();
+    g->m.assign(members, members + n);
+    g->device = members[0]->cfg.device;
+    g->stream = members[0]->stream;
+    auto fail = [&](hipError_t e) {
+        last_error_ref() = std::string("so_extractor_group_create: ") + hipGetErrorString(e);
+        so_extractor_group_destroy(g);
+        return SO_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(g->device)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&g->d_members, sizeof(ExtractBatchMember) * (size_t)n)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&g->d_prep, sizeof(FramePrepareArgs) * (size_t)n * so_extractor_group::kSlots)) != hipSuccess) return fail(e);
+    if ((e = hipHostMalloc((void**)&g->h_srcs, sizeof(void*) * (size_t)n, hipHostMallocMapped)) != hipSuccess) return fail(e);
+    if ((e = hipHostGetDevicePointer((void**)&g->h_srcs_dev, g->h_srcs, 0)) != hipSuccess) return fail(e);
+    if ((e = hipEventCreateWithFlags(&g->done, hipEventDisableTiming)) != hipSuccess) return fail(e);
+    *out = g;
+    return SO_OK;
+}
+
+void so_extractor_group_destroy(so_extractor_group* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    group_drop_graph(g);
+    if (g->d_members) (void)hipFree(g->d_members);
+    if (g->d_prep) (void)hipFree(g->d_prep);
+    if (g->h_srcs) (void)hipHostFree(g->h_srcs);
+    if (g->done) (void)hipEventDestroy(g->done);
+    delete g;
+}
+
+int so_extractor_group_submit(so_extractor_group* g, const uint8_t* const* images, int width, int height, int stride) {
+    return extractor_group_submit(g, images, width, height, stride, nullptr);
 }
 
 int so_extractor_wait(so_extractor* ex, int* n_out) {

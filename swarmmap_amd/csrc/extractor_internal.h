@@ -7,6 +7,7 @@
 #include "orb_device.h"
 
 struct so_extractor;
+struct so_extractor_group;
 
 namespace so {
 
@@ -35,5 +36,12 @@ void extractor_set_graph_tail(so_extractor* ex, void* owner, uint64_t revision, 
 void extractor_release_graph_tail(so_extractor* ex, void* owner);  // the owner goes away: its graph is dropped
 // true when the frame submitted last ran the tail inside its graph (false: chained launches, profiling, no graph)
 bool extractor_tail_launched(const so_extractor* ex);
+
+// so_extractor_group internals used by the device-resident frames' group submit (dframe.cpp)
+struct FramePrepareArgs;
+int extractor_group_size(const so_extractor_group* g);
+so_extractor* extractor_group_member(const so_extractor_group* g, int i);
+int extractor_group_prepare(so_extractor_group* g, int w, int h);
+int extractor_group_submit(so_extractor_group* g, const uint8_t* const* images, int w, int h, int stride, const FramePrepareArgs* preps);
 
 }  // namespace so

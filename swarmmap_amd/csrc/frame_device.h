@@ -43,6 +43,7 @@ struct FramePrepareArgs {
     int32_t* header_host;      // host-mapped {n, n_inside, 0, 0} + bounds[4] as float bits
 };
 void launch_frame_prepare(const FramePrepareArgs& a, hipStream_t s);
+void launch_frame_prepare_batch(const FramePrepareArgs* d_args, int n, hipStream_t s);  // d_args[n] in device memory
 
 struct FrameFrustumArgs {
     FrameCam cam;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void frame_undistort_point(const FrameCam& cam, float
 // ranks itself among the cell's handful of entries by index - three barriers where the bitonic sort of
 // (cell << 14 | index) keys this kernel started with needed fifty-five; the cell of a keypoint is worked out in the
 // undistortion loop, from the value still in the register, instead of after a round trip through global memory.
-__global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a) {
+__device__ __forceinline__ void frame_prepare_body(const FramePrepareArgs& a) {
     __shared__ int s_slot[kFrameMaxKeypoints];        // arrival-order slot -> keypoint index, then final position -> index
     __shared__ uint16_t s_cell[kFrameMaxKeypoints];   // cell of every keypoint (0xFFFF: outside the grid)
     __shared__ int s_hist[kFrameGridCols * kFrameGridRows + 1];
@@ -236,8 +236,15 @@ __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a)
     }
 }
 
+__global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a) { frame_prepare_body(a); }
+// several frames in one launch (so_dframe_group_submit): workgroup b prepares frame b
+__global__ __launch_bounds__(1024) void frame_prepare_batch_kernel(const FramePrepareArgs* __restrict__ A) { frame_prepare_body(A[blockIdx.x]); }
+
 void launch_frame_prepare(const FramePrepareArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(frame_prepare_kernel, dim3(1), dim3(1024), 0, s, a);
+}
+void launch_frame_prepare_batch(const FramePrepareArgs* d_args, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(frame_prepare_batch_kernel, dim3(n), dim3(1024), 0, s, d_args);
 }
 
 // Frame::isInFrustum + MapPoint::PredictScale, one thread per map point

@@ -78,6 +78,36 @@ struct SelectedKp {  // host -> device after the quadtree: level coordinates (RO
     uint16_t score;  // FAST response (integer valued)
 };
 
+struct QtLevelArgs {
+    int n_target[kMaxLevels];  // mnFeaturesPerLevel
+    int sel_stride;            // slots per level in the output
+};
+
+// HBM-resident copies of the frame's outputs (read by the device-resident frame, dframe.cpp); members may be null
+struct DescribeDeviceOut {
+    uint8_t* desc;     // capacity x 32
+    float* angle;      // capacity
+    SelectedKp* meta;  // capacity
+    int32_t* total;
+};
+
+// One member of an extraction batch (so_extractor_group, verdict item 9 of round 2): several agents' frames go through
+// ONE chain of launches - every kernel of the chain gets one more grid dimension, the member, and reads that member's
+// parameters from a device array of these records instead of from its kernel arguments.
+struct ExtractBatchMember {
+    PyramidParams P;
+    QtLevelArgs qt;
+    SelectedKp* qt_sel;   // the device quadtree's survivors, nlevels x qt.sel_stride
+    int32_t* qt_count;
+    struct {
+        uint8_t* desc;    // host-mapped results, as launch_describe_qt's arguments
+        float* angle;
+        SelectedKp* meta;
+        int32_t* total;
+        DescribeDeviceOut dev;
+    } out;
+};
+
 // launchers (orb_kernels.hip)
 // host_src: width x height bytes, tightly packed, device-visible (pinned / registered host memory)
 void launch_ingest(const uint8_t* host_src, int w, int h, const LevelDesc& level0, hipStream_t s);
@@ -94,17 +124,15 @@ void launch_emit(const PyramidParams& p, int32_t* d_rowcount, Candidate* cands, 
 // DistributeOctTree of every level straight off the keep bitmap and the score map
 void launch_quadtree(const PyramidParams& p, const int* n_target, int sel_stride, SelectedKp* d_sel, int32_t* d_count,
                      hipStream_t s);
-// HBM-resident copies of the frame's outputs (read by the device-resident frame, dframe.cpp); members may be null
-struct DescribeDeviceOut {
-    uint8_t* desc;     // capacity x 32
-    float* angle;      // capacity
-    SelectedKp* meta;  // capacity
-    int32_t* total;
-};
 void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, const int32_t* d_qt_count, int qt_stride,
                         int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total,
                         const DescribeDeviceOut& dev, hipStream_t s);
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,
                      hipStream_t s);
+// The whole chain (ingest .. describe) for n members with pyramids of the same shape as `first`: d_srcs[n] = device-visible
+// pointers to tightly packed w x h images (an array the device can read, e.g. host-mapped), d_members[n] in device memory.
+void launch_extract_batch(const ExtractBatchMember* d_members, const ExtractBatchMember& first, int n, const uint8_t* const* d_srcs,
+                          int w, int h, bool rows16, int capacity, hipStream_t s);
+void launch_quadtree_batch(const ExtractBatchMember* d_members, int n_members, int nlevels, hipStream_t s);
 
 }  // namespace so

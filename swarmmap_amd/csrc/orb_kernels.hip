@@ -22,9 +22,8 @@ namespace so {
 // pyramid: INTER_LINEAR in the OpenCV-CUDA convention (src = dst * (1/f), floor, 4 float taps, rn)
 // one thread = 4 horizontally adjacent destination pixels = one aligned dword store
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
-                                                      uint8_t* __restrict__ dst, int dw, int dh, int dpitch,
-                                                      float fx, float fy) {
+__device__ __forceinline__ void resize_body(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
+                                            uint8_t* __restrict__ dst, int dw, int dh, int dpitch, float fx, float fy) {
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x4 >= dw || y >= dh) return;
@@ -57,6 +56,19 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
     }
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * dpitch + x4) = packed;
 }
+
+__global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
+                                                      uint8_t* __restrict__ dst, int dw, int dh, int dpitch,
+                                                      float fx, float fy) {
+    resize_body(src, sw, sh, spitch, dst, dw, dh, dpitch, fx, fy);
+}
+// several members' pyramids in one launch (so_extractor_group): blockIdx.z = member
+__global__ __launch_bounds__(256) void resize_batch_kernel(const ExtractBatchMember* __restrict__ M, int level, float fx, float fy) {
+    const LevelDesc& S = M[blockIdx.z].P.lv[level - 1];
+    const LevelDesc& D = M[blockIdx.z].P.lv[level];
+    resize_body(S.img, S.w, S.h, S.pitch, D.img, D.w, D.h, D.pitch, fx, fy);
+}
+
 
 void launch_resize(const LevelDesc& s, const LevelDesc& d, hipStream_t st) {
     const float fx = (float)(1.0 / ((double)d.w / (double)s.w));
@@ -213,8 +225,7 @@ bool launch_pyramid_fused(const PyramidParams& P, int first, hipStream_t st) {
 // not a multiple of four bytes (1241-px KITTI rows: 376 copies, 2.2 ms).  Every thread produces one aligned dword of
 // the destination from two aligned dwords of the source (v_alignbyte), whatever the row offset's alignment.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__ src, int w, int h, uint8_t* __restrict__ dst,
-                                                      int pitch) {
+__device__ __forceinline__ void ingest_body(const uint8_t* __restrict__ src, int w, int h, uint8_t* __restrict__ dst, int pitch) {
     // (a wave = 64 consecutive dwords of one row: threadIdx.y selects the row)
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
@@ -235,15 +246,36 @@ __global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x4) = v;  // bytes beyond w land in the row's padding
 }
 
+__global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__ src, int w, int h, uint8_t* __restrict__ dst,
+                                                      int pitch) {
+    ingest_body(src, w, h, dst, pitch);
+}
+__global__ __launch_bounds__(256) void ingest_batch_kernel(const uint8_t* const* __restrict__ srcs, const ExtractBatchMember* __restrict__ M,
+                                                            int w, int h) {
+    const LevelDesc& L0 = M[blockIdx.z].P.lv[0];
+    ingest_body(srcs[blockIdx.z], w, h, L0.img, L0.pitch);
+}
+
+
 // rows that are a multiple of 16 bytes wide from a 16-byte aligned source (752-px EuRoC rows): one aligned 16-byte read
 // and one aligned 16-byte store per thread - a quarter of the requests on the link
-__global__ __launch_bounds__(256) void ingest16_kernel(const uint4* __restrict__ src, int w16, int h, uint8_t* __restrict__ dst,
-                                                        int pitch) {
+__device__ __forceinline__ void ingest16_body(const uint4* __restrict__ src, int w16, int h, uint8_t* __restrict__ dst, int pitch) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w16 || y >= h) return;
     *reinterpret_cast<uint4*>(dst + (size_t)y * pitch + 16 * (size_t)x) = src[(size_t)y * w16 + x];
 }
+
+__global__ __launch_bounds__(256) void ingest16_kernel(const uint4* __restrict__ src, int w16, int h, uint8_t* __restrict__ dst,
+                                                        int pitch) {
+    ingest16_body(src, w16, h, dst, pitch);
+}
+__global__ __launch_bounds__(256) void ingest16_batch_kernel(const uint8_t* const* __restrict__ srcs, const ExtractBatchMember* __restrict__ M,
+                                                              int w16, int h) {
+    const LevelDesc& L0 = M[blockIdx.z].P.lv[0];
+    ingest16_body(reinterpret_cast<const uint4*>(srcs[blockIdx.z]), w16, h, L0.img, L0.pitch);
+}
+
 
 void launch_ingest(const uint8_t* host_src, int w, int h, const LevelDesc& level0, hipStream_t s) {
     if ((w & 15) == 0 && (reinterpret_cast<uintptr_t>(host_src) & 15) == 0 && (level0.pitch & 15) == 0 &&
@@ -300,7 +332,7 @@ constexpr int kScRows = 34, kScPitch = 36;     // 34 x 34 scores (tile + 1-px ha
 // Stage the 40x40 neighbourhood in LDS with aligned dword loads, score the 34x34 halo'd tile, NMS at the
 // high threshold inside LDS (halo scores are recomputed here, which removes the reference's cross-block
 // race on scoreMat), write the u8 score tile + tile flag + keep-bitmap words.
-__global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
+__device__ __forceinline__ void fast_score_body(const PyramidParams& P) {
     __shared__ uint32_t simg32[kImgRows * kImgPitchW];
     __shared__ uint8_t ssc[kScRows * kScPitch];
     const uint8_t* simg = reinterpret_cast<const uint8_t*>(simg32);
@@ -415,6 +447,10 @@ __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) {
     }
 }
 
+__global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) { fast_score_body(P); }
+__global__ __launch_bounds__(256) void fast_score_batch_kernel(const ExtractBatchMember* __restrict__ M) { fast_score_body(M[blockIdx.y].P); }
+
+
 // ------------------------------------------------------------------------------------------------
 // Low-threshold pass and candidate emission.
 //   fast_low_kernel   one WAVE per tile (four tiles per workgroup, all levels in one grid): an empty tile gets its
@@ -442,7 +478,7 @@ constexpr int kMaxRows = 8192;   // bitmap rows over all levels (sum of level he
 
 constexpr int kLowPitch = 40;  // bytes per row of the per-wave score window (10 aligned dwords)
 
-__global__ __launch_bounds__(256) void fast_low_kernel(PyramidParams P) {
+__device__ __forceinline__ void fast_low_body(const PyramidParams& P) {
     __shared__ uint32_t ssc32[4][kScRows * (kLowPitch / 4)];  // one 34-row score window per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // groups of four tiles, one contiguous run of groups per XCD (same reasoning as fast_score_kernel: the halo comes out
@@ -504,6 +540,10 @@ __global__ __launch_bounds__(256) void fast_low_kernel(PyramidParams P) {
     }
     if (lane < kTile) gb[lane] = mine;  // one 128-byte line
 }
+
+__global__ __launch_bounds__(256) void fast_low_kernel(PyramidParams P) { fast_low_body(P); }
+__global__ __launch_bounds__(256) void fast_low_batch_kernel(const ExtractBatchMember* __restrict__ M) { fast_low_body(M[blockIdx.y].P); }
+
 
 __global__ __launch_bounds__(256) void rowcount_kernel(PyramidParams P, int32_t* __restrict__ rowcount) {
     const int tid = threadIdx.x;
@@ -882,11 +922,10 @@ __global__ __launch_bounds__(kDescThreads) void describe_kernel(PyramidParams P,
 // qt_sel[level][k] and writes descriptor / angle / keypoint record at the compact output index, straight into
 // host-mapped memory (the caller's copy) and into HBM (`dev`: what the device-resident frame reads).  Launched
 // with the capacity as grid; surplus blocks exit.
-__global__ __launch_bounds__(kDescThreads) void describe_qt_kernel(PyramidParams P, const SelectedKp* __restrict__ qt_sel,
-                                                                    const int32_t* __restrict__ qt_count, int qt_stride,
-                                                                    uint8_t* __restrict__ desc, float* __restrict__ angle_out,
-                                                                    SelectedKp* __restrict__ meta_out,
-                                                                    int32_t* __restrict__ total_out, DescribeDeviceOut dev) {
+__device__ __forceinline__ void describe_qt_body(const PyramidParams& P, const SelectedKp* __restrict__ qt_sel,
+                                                 const int32_t* __restrict__ qt_count, int qt_stride, uint8_t* __restrict__ desc,
+                                                 float* __restrict__ angle_out, SelectedKp* __restrict__ meta_out,
+                                                 int32_t* __restrict__ total_out, const DescribeDeviceOut& dev) {
     __shared__ uint32_t patch[kPatch * (kPatchPitch / 4) + 4];
     __shared__ float rowp[kPatch * kBlur];
     __shared__ uint8_t blur[kBlur * kBlurPitch];
@@ -913,11 +952,44 @@ __global__ __launch_bounds__(kDescThreads) void describe_qt_kernel(PyramidParams
     describe_body(P, kp, id, desc, angle_out, patch, rowp, blur, s_mom, dev.desc, dev.angle);
 }
 
+__global__ __launch_bounds__(kDescThreads) void describe_qt_kernel(PyramidParams P, const SelectedKp* __restrict__ qt_sel,
+                                                                    const int32_t* __restrict__ qt_count, int qt_stride,
+                                                                    uint8_t* __restrict__ desc, float* __restrict__ angle_out,
+                                                                    SelectedKp* __restrict__ meta_out,
+                                                                    int32_t* __restrict__ total_out, DescribeDeviceOut dev) {
+    describe_qt_body(P, qt_sel, qt_count, qt_stride, desc, angle_out, meta_out, total_out, dev);
+}
+__global__ __launch_bounds__(kDescThreads) void describe_qt_batch_kernel(const ExtractBatchMember* __restrict__ M) {
+    const ExtractBatchMember& m = M[blockIdx.y];
+    describe_qt_body(m.P, m.qt_sel, m.qt_count, m.qt.sel_stride, m.out.desc, m.out.angle, m.out.meta, m.out.total, m.out.dev);
+}
+
+
 void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, const int32_t* d_qt_count, int qt_stride,
                         int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total,
                         const DescribeDeviceOut& dev, hipStream_t s) {
     hipLaunchKernelGGL(describe_qt_kernel, dim3(capacity), dim3(kDescThreads), 0, s, p, d_qt_sel, d_qt_count, qt_stride, desc,
                        angle, meta, total, dev);
+}
+
+void launch_extract_batch(const ExtractBatchMember* d_members, const ExtractBatchMember& first, int n, const uint8_t* const* d_srcs,
+                          int w, int h, bool rows16, int capacity, hipStream_t s) {
+    const PyramidParams& p = first.P;
+    if (rows16)
+        hipLaunchKernelGGL(ingest16_batch_kernel, dim3((w / 16 + 63) / 64, (h + 3) / 4, n), dim3(64, 4), 0, s, d_srcs, d_members, w / 16, h);
+    else
+        hipLaunchKernelGGL(ingest_batch_kernel, dim3((w + 255) / 256, (h + 3) / 4, n), dim3(64, 4), 0, s, d_srcs, d_members, w, h);
+    for (int l = 1; l < p.nlevels; l++) {
+        const LevelDesc& S = p.lv[l - 1];
+        const LevelDesc& D = p.lv[l];
+        const float fx = (float)(1.0 / ((double)D.w / (double)S.w)), fy = (float)(1.0 / ((double)D.h / (double)S.h));
+        hipLaunchKernelGGL(resize_batch_kernel, dim3((D.w + 255) / 256, (D.h + 3) / 4, n), dim3(64, 4), 0, s, d_members, l, fx, fy);
+    }
+    hipLaunchKernelGGL(fast_score_batch_kernel, dim3(8 * ((p.total_tiles + 7) / 8), n), dim3(256), 0, s, d_members);
+    const int ngroups = (p.total_tiles + 3) / 4;
+    hipLaunchKernelGGL(fast_low_batch_kernel, dim3(8 * ((ngroups + 7) / 8), n), dim3(256), 0, s, d_members);
+    launch_quadtree_batch(d_members, n, p.nlevels, s);
+    hipLaunchKernelGGL(describe_qt_batch_kernel, dim3(capacity, n), dim3(kDescThreads), 0, s, d_members);
 }
 
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,

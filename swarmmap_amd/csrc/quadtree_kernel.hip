@@ -117,11 +117,6 @@ __device__ __forceinline__ u64 qt_pack4(int a, int b, int c, int d) {
            ((u64)(uint32_t)(d & 0xFFFF) << 48);
 }
 
-struct QtLevelArgs {
-    int n_target[kMaxLevels];  // mnFeaturesPerLevel
-    int sel_stride;            // slots per level in the output
-};
-
 // ---- LDS map (bytes) --------------------------------------------------------------------------------------------
 // keys 40000 | key -> node 20000 | per node: box 8 B, info 8 B, seq 4 B, pre / post 8 B each, child slots 8 B, child
 // bases 8 B, two 4-byte work words | per thread: exclusive prefix 8 B.  While the key array is built, the level's keep
@@ -461,9 +456,8 @@ __device__ __forceinline__ void qt_run(const QtCtx& c, QtScan& S) {
 #endif
 }
 
-__global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, QtLevelArgs A,
-                                                               SelectedKp* __restrict__ sel_out,
-                                                               int32_t* __restrict__ count_out) {
+__device__ __forceinline__ void quadtree_body(const PyramidParams& P, const QtLevelArgs& A, SelectedKp* __restrict__ sel_out,
+                                              int32_t* __restrict__ count_out) {
     __shared__ __align__(16) unsigned char smem[kQtSmemBytes];
     __shared__ u64 s_w[2][kQtWaves];
     __shared__ int s_misc[8];
@@ -563,6 +557,21 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
     else if (chunk <= 4) qt_run<4>(c, S);
     else if (chunk <= 6) qt_run<6>(c, S);
     else qt_run<kQtChunk>(c, S);
+}
+
+__global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, QtLevelArgs A,
+                                                               SelectedKp* __restrict__ sel_out,
+                                                               int32_t* __restrict__ count_out) {
+    quadtree_body(P, A, sel_out, count_out);
+}
+// several members' pyramids in one launch (so_extractor_group): blockIdx.y = member
+__global__ __launch_bounds__(kQtThreads) void quadtree_batch_kernel(const ExtractBatchMember* __restrict__ M) {
+    const ExtractBatchMember& m = M[blockIdx.y];
+    quadtree_body(m.P, m.qt, m.qt_sel, m.qt_count);
+}
+
+void launch_quadtree_batch(const ExtractBatchMember* d_members, int n_members, int nlevels, hipStream_t s) {
+    hipLaunchKernelGGL(quadtree_batch_kernel, dim3(nlevels, n_members), dim3(kQtThreads), 0, s, d_members);
 }
 
 void launch_quadtree(const PyramidParams& p, const int* n_target, int sel_stride, SelectedKp* d_sel, int32_t* d_count,

@@ -132,3 +132,50 @@ class ORBextractor:
         ms = np.zeros(len(STAGES), np.float32)
         _lib.check(self._lib.so_extractor_get_profile(self._h, _vp(ms)))
         return dict(zip(STAGES, ms.tolist()))
+
+
+class ExtractorGroup:
+    """Several ORBextractors of one GPU whose frames go through ONE chain of launches (so_extractor_group): submit() takes
+    one image per member (pinned host memory, tightly packed, all of one size) and every member is collected as usual.
+    `frames` (optional DeviceFrame per member) adds the Frame constructors' kernel to the chain (so_dframe_group_submit)."""
+
+    def __init__(self, extractors):
+        self._lib = lib = _lib.load_library()
+        self.members = list(extractors)
+        n = len(self.members)
+        lib.so_extractor_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+        lib.so_extractor_group_destroy.argtypes = [C.c_void_p]
+        lib.so_extractor_group_destroy.restype = None
+        lib.so_extractor_group_submit.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+        lib.so_dframe_group_submit.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+        arr = (C.c_void_p * n)(*[e._h for e in self.members])
+        self._h = C.c_void_p()
+        _lib.check(lib.so_extractor_group_create(arr, n, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.so_extractor_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _images(self, images):
+        n = len(self.members)
+        if len(images) != n:
+            raise ValueError("one image per member")
+        h, w = images[0].shape
+        for im in images:
+            if im.dtype != np.uint8 or im.ndim != 2 or im.shape != (h, w) or im.strides != (w, 1):
+                raise ValueError("images must be tightly packed CV_8UC1 arrays of one size")
+        self._inflight = list(images)
+        return (C.c_void_p * n)(*[im.ctypes.data for im in images]), w, h
+
+    def submit(self, images, frames=None):
+        ptrs, w, h = self._images(images)
+        if frames is None:
+            _lib.check(self._lib.so_extractor_group_submit(self._h, ptrs, w, h, w))
+        else:
+            fr = (C.c_void_p * len(frames))(*[f._h for f in frames])
+            for f, im in zip(frames, images):
+                f._inflight = im
+            _lib.check(self._lib.so_dframe_group_submit(self._h, fr, ptrs, w, h, w))

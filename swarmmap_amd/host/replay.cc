@@ -124,6 +124,9 @@ struct so_replay {
     so_ba* mapper_opt = nullptr;
     std::vector<const uint8_t*> frames;
     bool frames_on_device = false;
+    // so_fleet_run: the extractors of the fleet this agent leads, as one group (one extraction chain for all agents)
+    so_extractor_group* fleet_group = nullptr;
+    std::vector<so_extractor*> fleet_members;
     BaWindow window;
     float scale[8] = {0}, inv_sigma2[8] = {0};
     int nlevels = 8;
@@ -384,6 +387,7 @@ void so_replay_destroy(so_replay* r) {
         auto& f = r->fh[0];
         (void)so_dframe_collect(r->fr[r->submitted], f.kps.data(), nullptr, f.desc.data(), r->cap, &n, nullptr);
     }
+    so_extractor_group_destroy(r->fleet_group);
     for (so_dframe* f : r->fr) so_dframe_destroy(f);
     so_extractor_destroy(r->ex);
     so_matcher_destroy(r->matcher);
@@ -850,10 +854,56 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
         for (size_t k = 0; k < live.size(); k++) pose_account(agents[live[k]], probs[k], ms / (float)live.size());
         return SO_OK;
     };
+    // One extraction chain for the whole fleet (so_extractor_group: every kernel once, the agent as a grid dimension)
+    // when the agents' frames are device-visible and of one size; SWARMORB_FLEET_NO_GROUP=1 keeps a chain per agent.
+    static const bool no_group = getenv("SWARMORB_FLEET_NO_GROUP") != nullptr;
+    so_replay* lead = agents[0];
+    bool grouped = !no_group && n_agents > 1 && n_agents <= SO_EXTRACTOR_GROUP_MAX;
+    for (int a = 0; a < n_agents && grouped; a++)
+        grouped = agents[a]->width == lead->width && agents[a]->height == lead->height && !agents[a]->live &&
+                  agents[a]->submitted == lead->submitted;
+    if (grouped) {
+        std::vector<so_extractor*> members(A);
+        for (size_t a = 0; a < A; a++) members[a] = agents[a]->ex;
+        if (members != lead->fleet_members) {
+            so_extractor_group_destroy(lead->fleet_group);
+            lead->fleet_group = nullptr;
+            lead->fleet_members.clear();
+            if (so_extractor_group_create(members.data(), n_agents, &lead->fleet_group) == SO_OK) lead->fleet_members = members;
+        }
+        grouped = lead->fleet_group != nullptr;
+    }
+    std::vector<so_dframe*> gframes(A);
+    std::vector<const uint8_t*> gimages(A);
     for (int t = first_t; t < first_t + n_steps; t++) {
         int rc;
         for (int a = 0; a < n_agents; a++)
-            if ((rc = step_begin(agents[a], t))) return rc;
+            if ((rc = step_begin(agents[a], t, !grouped))) return rc;
+        if (grouped) {  // the agents whose next frame is not out yet (all of them, except on a run's first frame)
+            bool all = true;
+            for (int a = 0; a < n_agents; a++) all = all && !agents[a]->step.next_submitted;
+            if (all) {
+                for (size_t a = 0; a < A; a++) {
+                    so_replay* r = agents[a];
+                    gframes[a] = r->fr[(r->submitted + 1) % 3];
+                    gimages[a] = r->frames[(size_t)(t + 1) % r->frames.size()];
+                }
+                if (so_dframe_group_submit(lead->fleet_group, gframes.data(), gimages.data(), lead->width, lead->height, lead->width) == SO_OK) {
+                    for (size_t a = 0; a < A; a++) {
+                        agents[a]->submitted = (agents[a]->submitted + 1) % 3;
+                        agents[a]->in_flight = true;
+                        agents[a]->step.next_submitted = true;
+                    }
+                } else {
+                    grouped = false;  // (pageable frames: the group wants device-visible images) - a chain per agent from here on
+                }
+            }
+            for (int a = 0; a < n_agents; a++)
+                if (!agents[a]->step.next_submitted) {
+                    if ((rc = submit_frame(agents[a], t + 1))) return rc;
+                    agents[a]->step.next_submitted = true;
+                }
+        }
         for (int a = 0; a < n_agents; a++)  // (each agent's motion-model search went out inside its step_begin)
             if (!agents[a]->step.first && (rc = step_m2_wait(agents[a]))) return rc;
         if ((rc = pose_batch(0))) return rc;

@@ -1,0 +1,101 @@
+"""so_extractor_group / so_dframe_group_submit: several agents' frames through one chain of launches give every member
+exactly what a lone so_extractor_submit / so_dframe_submit gives it."""
+import numpy as np
+import pytest
+
+from swarmmap_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pinned(images):
+    import torch
+    h, w = images[0].shape
+    block = torch.empty((len(images), h, w), dtype=torch.uint8).pin_memory()
+    view = block.numpy()
+    for i, im in enumerate(images):
+        view[i] = im
+    return block, [view[i] for i in range(len(images))]
+
+
+@pytest.mark.parametrize("n_members,size", [(1, (752, 480)), (3, (752, 480)), (4, (1241, 376)), (8, (640, 360))])
+def test_group_extraction_equals_lone_extraction(n_members, size):
+    import swarmmap_amd as S
+    assert S.device_count() > 0, "these tests need a GPU"
+    w, h = size
+    nf = 2000 if w > 1000 else 1000
+    frames = 3
+    imgs = [[synth.make_canvas(100 + 7 * a + t, w, h) for a in range(n_members)] for t in range(frames)]
+    solo = S.ORBextractor(nf, 1.2, 8, 20, 7)
+    ref = [[tuple(x.copy() for x in solo(imgs[t][a])) for a in range(n_members)] for t in range(frames)]
+    solo.close()
+    exs = [S.ORBextractor(nf, 1.2, 8, 20, 7) for _ in range(n_members)]
+    grp = S.ExtractorGroup(exs)
+    for t in range(frames):
+        keep, pinned = _pinned(imgs[t])
+        grp.submit(pinned)
+        for a, ex in enumerate(exs):
+            kps, desc = ex.collect()
+            assert kps.tobytes() == ref[t][a][0].tobytes(), (t, a)
+            assert desc.tobytes() == ref[t][a][1].tobytes(), (t, a)
+        del keep
+    grp.close()
+    for ex in exs:
+        ex.close()
+
+
+def test_group_members_can_still_run_alone_and_pageable_images_are_refused():
+    import swarmmap_amd as S
+    w, h = 752, 480
+    exs = [S.ORBextractor(1000, 1.2, 8, 20, 7) for _ in range(2)]
+    grp = S.ExtractorGroup(exs)
+    imgs = [synth.make_canvas(5 + a, w, h) for a in range(2)]
+    with pytest.raises(S.SwarmOrbError):
+        grp.submit(imgs)  # pageable numpy arrays: not device-visible
+    keep, pinned = _pinned(imgs)
+    grp.submit(pinned)
+    a0 = [tuple(x.copy() for x in ex.collect()) for ex in exs]
+    lone = [tuple(x.copy() for x in ex(im)) for ex, im in zip(exs, imgs)]  # the members' own path, same handles
+    for g, l in zip(a0, lone):
+        assert g[0].tobytes() == l[0].tobytes() and g[1].tobytes() == l[1].tobytes()
+    grp.submit(pinned)  # and the group again after that
+    for ex, l in zip(exs, lone):
+        k, d = ex.collect()
+        assert k.tobytes() == l[0].tobytes() and d.tobytes() == l[1].tobytes()
+    grp.close()
+    for ex in exs:
+        ex.close()
+
+
+def test_group_of_device_resident_frames_equals_lone_frames():
+    """so_dframe_group_submit: keypoints, undistorted positions, descriptors, bounds and the grid of every member equal
+    the lone so_dframe_submit of the same image (EuRoC lens model)."""
+    import swarmmap_amd as S
+    w, h, n_members, frames = 752, 480, 4, 3
+    imgs = [[synth.make_canvas(300 + 5 * a + t, w, h) for a in range(n_members)] for t in range(frames)]
+    ex0 = S.ORBextractor(1000, 1.2, 8, 20, 7)
+    f0 = S.DeviceFrame(ex0, synth.EUROC_K, synth.EUROC_DIST)
+    ref = []
+    for t in range(frames):
+        row = []
+        for a in range(n_members):
+            kps, un, d = f0(imgs[t][a])
+            row.append((kps.tobytes(), un.tobytes(), d.tobytes(), f0.bounds.tobytes(), tuple(x.tobytes() for x in f0.grid())))
+        ref.append(row)
+    f0.close(); ex0.close()
+    exs = [S.ORBextractor(1000, 1.2, 8, 20, 7) for _ in range(n_members)]
+    frs = [S.DeviceFrame(ex, synth.EUROC_K, synth.EUROC_DIST) for ex in exs]
+    grp = S.ExtractorGroup(exs)
+    for t in range(frames):
+        keep, pinned = _pinned(imgs[t])
+        grp.submit(pinned, frames=frs)
+        for a, f in enumerate(frs):
+            kps, un, d = f.collect()
+            got = (kps.tobytes(), un.tobytes(), d.tobytes(), f.bounds.tobytes(), tuple(x.tobytes() for x in f.grid()))
+            assert got == ref[t][a], (t, a)
+        del keep
+    grp.close()
+    for f in frs:
+        f.close()
+    for ex in exs:
+        ex.close()
