@@ -361,25 +361,54 @@ __device__ __forceinline__ void fast_score_body(const PyramidParams& P) {
     __syncthreads();
 
     const int th_low = P.th_low, th_high = P.th_high;
-    for (int p = tid; p < kScRows * kScRows; p += 256) {
-        const int r = p / kScRows, c = p - r * kScRows;
-        const int x = x0 - 1 + c, y = y0 - 1 + r;
-        int score = 0;
-        if (x >= 19 && x < L.w - 19 && y >= 19 && y < L.h - 19) {
-            const uint8_t* ctr = simg + (r + 3) * (kImgPitchW * 4) + (c + 6);
-            constexpr int PW = kImgPitchW * 4;
-            const int v = ctr[0];
-            int d[16];
-            d[0] = ctr[3 * PW + 0] - v;   d[1] = ctr[3 * PW + 1] - v;   d[2] = ctr[2 * PW + 2] - v;
-            d[3] = ctr[1 * PW + 3] - v;   d[4] = ctr[3] - v;            d[5] = ctr[-1 * PW + 3] - v;
-            d[6] = ctr[-2 * PW + 2] - v;  d[7] = ctr[-3 * PW + 1] - v;  d[8] = ctr[-3 * PW + 0] - v;
-            d[9] = ctr[-3 * PW - 1] - v;  d[10] = ctr[-2 * PW - 2] - v; d[11] = ctr[-1 * PW - 3] - v;
-            d[12] = ctr[-3] - v;          d[13] = ctr[1 * PW - 3] - v;  d[14] = ctr[2 * PW - 2] - v;
-            d[15] = ctr[3 * PW - 1] - v;
-            const int s = fast_corner_score(d);
-            score = s >= th_low ? s : 0;
+    // Pass 1 - the four compass points of the ring: a run of nine out of sixteen contains one point of every opposite
+    // pair, so a pixel whose pairs (0, 8) and (4, 12) cannot both supply a point brighter than v + th_low (or both a
+    // darker one) has no score >= th_low: 87 % of the pixels of the benchmark stream stop here with score 0.  The others
+    // are compacted into a list (ballot + one LDS atomic per wave and round) and pass 2 runs the closed-form score on
+    // dense lanes.  (Scoring every pixel made this kernel ALU-bound as soon as several frames shared a launch.)
+    __shared__ uint16_t s_list[kScRows * kScRows];
+    __shared__ int s_nlist;
+    if (tid == 0) s_nlist = 0;
+    __syncthreads();
+    constexpr int PW = kImgPitchW * 4;
+    for (int p0 = 0; p0 < kScRows * kScRows; p0 += 256) {
+        const int p = p0 + tid;
+        bool cand = false;
+        if (p < kScRows * kScRows) {
+            const int r = p / kScRows, c = p - r * kScRows;
+            const int x = x0 - 1 + c, y = y0 - 1 + r;
+            if (x >= 19 && x < L.w - 19 && y >= 19 && y < L.h - 19) {
+                const uint8_t* ctr = simg + (r + 3) * PW + (c + 6);
+                const int v = ctr[0];
+                const int d0 = ctr[3 * PW] - v, d8 = ctr[-3 * PW] - v, d4 = ctr[3] - v, d12 = ctr[-3] - v;
+                const bool bright = (d0 > th_low || d8 > th_low) && (d4 > th_low || d12 > th_low);
+                const bool dark = (d0 < -th_low || d8 < -th_low) && (d4 < -th_low || d12 < -th_low);
+                cand = bright || dark;
+            }
+            if (!cand) ssc[r * kScPitch + c] = 0;
         }
-        ssc[r * kScPitch + c] = (uint8_t)score;
+        const unsigned long long mask = __ballot(cand);
+        int base = 0;
+        if ((tid & 63) == 0 && mask) base = atomicAdd(&s_nlist, __popcll(mask));
+        base = __shfl(base, 0);
+        if (cand) s_list[base + __popcll(mask & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)p;
+    }
+    __syncthreads();
+    const int nlist = s_nlist;
+    for (int i = tid; i < nlist; i += 256) {
+        const int p = s_list[i];
+        const int r = p / kScRows, c = p - r * kScRows;
+        const uint8_t* ctr = simg + (r + 3) * PW + (c + 6);
+        const int v = ctr[0];
+        int d[16];
+        d[0] = ctr[3 * PW + 0] - v;   d[1] = ctr[3 * PW + 1] - v;   d[2] = ctr[2 * PW + 2] - v;
+        d[3] = ctr[1 * PW + 3] - v;   d[4] = ctr[3] - v;            d[5] = ctr[-1 * PW + 3] - v;
+        d[6] = ctr[-2 * PW + 2] - v;  d[7] = ctr[-3 * PW + 1] - v;  d[8] = ctr[-3 * PW + 0] - v;
+        d[9] = ctr[-3 * PW - 1] - v;  d[10] = ctr[-2 * PW - 2] - v; d[11] = ctr[-1 * PW - 3] - v;
+        d[12] = ctr[-3] - v;          d[13] = ctr[1 * PW - 3] - v;  d[14] = ctr[2 * PW - 2] - v;
+        d[15] = ctr[3 * PW - 1] - v;
+        const int s = fast_corner_score(d);
+        ssc[r * kScPitch + c] = (uint8_t)(s >= th_low ? s : 0);
     }
     __syncthreads();
 
