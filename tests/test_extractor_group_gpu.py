@@ -99,3 +99,30 @@ def test_group_of_device_resident_frames_equals_lone_frames():
         f.close()
     for ex in exs:
         ex.close()
+
+
+def test_group_with_members_on_streams_of_their_own():
+    """so_runtime_private_streams: every member has its own stream, the chain runs on the first member's; the others'
+    collects wait for it through an event."""
+    import swarmmap_amd as S
+    from swarmmap_amd.replay import private_streams
+    w, h, n_members = 752, 480, 3
+    imgs = [synth.make_canvas(40 + a, w, h) for a in range(n_members)]
+    solo = S.ORBextractor(1000, 1.2, 8, 20, 7)
+    ref = [tuple(x.copy() for x in solo(im)) for im in imgs]
+    solo.close()
+    private_streams(True)
+    try:
+        exs = [S.ORBextractor(1000, 1.2, 8, 20, 7) for _ in range(n_members)]
+        grp = S.ExtractorGroup(exs)
+        keep, pinned = _pinned(imgs)
+        for _ in range(3):
+            grp.submit(pinned)
+            for a in reversed(range(n_members)):  # the last member first: its stream has nothing of its own to wait for
+                k, d = exs[a].collect()
+                assert k.tobytes() == ref[a][0].tobytes() and d.tobytes() == ref[a][1].tobytes(), a
+        grp.close()
+        for ex in exs:
+            ex.close()
+    finally:
+        private_streams(False)
