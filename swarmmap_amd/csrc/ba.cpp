@@ -321,15 +321,33 @@ int wait_stream(Run& r) {
 // SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg, driven from the device: the host
 // enqueues the prologue (errors, linearisation, lambda init) and `iterations` trials, waits once and only
 // enqueues more if trials were rejected (each rejected trial needs one more than the iteration count).
-int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
+//
+// What follows the stage rides behind its trials instead of waiting for the host to see the stage end (a stream
+// synchronise + the next launches idled the GPU ~35 us at every stage boundary and ~45 us at the end of the call):
+// `after_trials` is enqueued behind every batch of trials.  It is either the NEXT stage's prologue, gated on the device
+// (kBaGateIdle: it takes effect only if this stage is over when it runs - then `*next_begun` is set and this stage's
+// results are the ones ba_stage_begin_kernel saved), or the call's epilogue (finish + copy out), which is harmless to
+// run early and is simply run again behind the extra trials.
+struct StageChain {
+    std::function<void()> after_trials;  // may be empty
+    bool starts_next_stage = false;
+};
+
+int optimize(Run& r, int iterations, bool prologue, const StageChain& chain, int* done_out, double* chi_out, bool* next_begun) {
     so_ba* b = r.b;
     hipStream_t s = b->stream;
     *done_out = 0;
+    if (next_begun) *next_begun = false;
     if (r.n_free + (r.n_active_edges > 0 ? 1 : 0) == 0) return SO_OK;  // 0 vertices to optimize
-    launch_ba_errors(r.d, 0, false, r.nb_err, s);
-    launch_ba_build(r.d, false, s);
-    launch_ba_stage_begin(r.d, r.nb_err, iterations, b->h_lm_dev, s);
-    SO_HIP(hipGetLastError());
+    const uint8_t* abort_dev = r.stop ? b->h_abort_dev : nullptr;
+    if (prologue) {
+        launch_ba_errors(r.d, 0, kBaGateNone, r.nb_err, s);
+        launch_ba_build(r.d, kBaGateNone, s);
+        launch_ba_stage_begin(r.d, r.nb_err, iterations, b->h_lm_dev, kBaGateNone, nullptr, s);
+        SO_HIP(hipGetLastError());
+        b->h_lm->stages_begun++;  // (the host copy trails the device until the next wait)
+    }
+    const int my_stage = b->h_lm->stages_begun;
     const int trials_before = b->h_lm->trials, first_block = r.blocks_enqueued;  // h_lm: state after the last wait
     int budget = iterations, rc;
     BaLm lm;
@@ -337,16 +355,22 @@ int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
         for (int i = 0; i < budget; i++) {
             const int k = r.blocks_enqueued++;
             const bool timed = b->solve_timing && k < so_ba::kSolveEvents;
-            launch_ba_trial(r.d, r.nb_err, r.nb_upd, r.stop ? b->h_abort_dev : nullptr, b->h_lm_dev,
+            launch_ba_trial(r.d, r.nb_err, r.nb_upd, abort_dev, b->h_lm_dev,
                             timed ? b->ev_solve[2 * k] : nullptr, timed ? b->ev_solve[2 * k + 1] : nullptr, s);
         }
+        if (chain.after_trials) chain.after_trials();
         SO_HIP(hipGetLastError());
         if ((rc = wait_stream(r))) return rc;
         if (*(volatile unsigned*)b->h_flow_abort != 0) return kErrFlowTimeout;  // a dataflow solve gave up waiting
         memcpy(&lm, b->h_lm, sizeof(lm));
+        if (lm.stages_begun != my_stage) {  // the chained prologue ran: this stage is over and the next one has begun
+            if (next_begun) *next_begun = true;
+            break;
+        }
         if (!lm.active) break;
         budget = std::max(1, lm.iterations - lm.it);
     }
+    const bool chained = lm.stages_begun != my_stage;
     const int real = lm.trials - trials_before;  // the first `real` blocks of this stage ran, the rest returned at once
     for (int k = first_block; b->solve_timing && k < first_block + real && k < so_ba::kSolveEvents; k++) {
         float ms = 0.f;
@@ -355,8 +379,8 @@ int optimize(Run& r, int iterations, int* done_out, double* chi_out) {
             b->n_solves++;
         }
     }
-    *done_out = lm.done;
-    *chi_out = lm.chi_out;
+    *done_out = chained ? lm.prev_done : lm.done;
+    *chi_out = chained ? lm.prev_chi_out : lm.chi_out;
     return SO_OK;
 }
 
@@ -1000,6 +1024,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     d.xl = b->d_xl.as<double>();
     d.partial = b->d_partial.as<double>();
     d.robust = opt->robust;
+    d.stage = 1;
     d.huber_delta = (double)opt->huber_delta;
     d.huber_dsqr = (float)((double)opt->huber_delta * (double)opt->huber_delta);  // RobustKernelHuber::setDelta
     r.nb_err = std::min(1024, std::max(1, (nE + 255) / 256));
@@ -1016,35 +1041,123 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     SO_HIP(hipEventRecord(b->e0, s));
     double chi = 0.0;
     int done = 0;
-    if ((rc = optimize(r, opt->its_stage1, &done, &chi))) return rc;  // optimizer.optimize(5)
-    inf.iterations_stage1 = done;
-    inf.chi2_initial = b->h_lm->chi_begin;  // chi2 before optimising (information only)
-    inf.chi2_final = done > 0 ? chi : inf.chi2_initial;
-    const double t_opt1 = now_ms();
-    bool do_more = opt->its_stage2 > 0;
-    if (r.terminate()) {
-        do_more = false;
-        inf.aborted = 1;
-    }
-    if (do_more) {
-        // Optimizer.cc:644-656 without leaving the device: outlier edges drop to level 1, the robust kernel goes,
-        // initializeOptimization(0) = the same lists with the dropped edges skipped
-        launch_ba_mark_outliers(r.d, (double)opt->chi2_threshold, s);
-        r.d.robust = 0;  // e->setRobustKernel(nullptr)
-        if ((rc = optimize(r, opt->its_stage2, &done, &chi))) return rc;  // optimizer.optimize(10)
-        inf.iterations_stage2 = done;
-        if (done > 0) inf.chi2_final = chi;
-        if (r.terminate()) inf.aborted = 1;
+    // Optimizer.cc:682-739: outlier flags from the edges' stored errors and isDepthPositive(), optimised data back.
+    // The finish kernel writes the result block straight into pinned host memory (0.65 MB for a 64-keyframe window): no
+    // copy engine behind it - a device-to-host copy enqueued behind a long chain of kernels was seen to start hundreds of
+    // microseconds after the kernel in front of it.
+    uint8_t* ob = nullptr;
+    SO_HIP(hipHostGetDevicePointer((void**)&ob, b->h_out, 0));
+    auto epilogue = [&]() {
+        launch_ba_finish(r.d, (double)opt->chi2_threshold, (BaPose*)(ob + r_pose), (double*)(ob + r_pt), (double*)(ob + r_chi2),
+                         ob + r_out, s);
+        (void)hipEventRecord(b->e1, s);
+    };
+    const bool two_stages = opt->its_stage2 > 0;
+    const uint8_t* abort_dev = r.stop ? b->h_abort_dev : nullptr;
+    BaDev d2 = r.d;
+    d2.robust = 0;  // e->setRobustKernel(nullptr)
+    d2.stage = 2;
+    static const bool no_chain = getenv("SWARMORB_BA_NO_CHAIN") != nullptr;
+    const bool have_work = r.n_free + (r.n_active_edges > 0 ? 1 : 0) != 0;
+    double t_opt1 = now_ms();
+    if (have_work && !b->solve_timing && !no_chain) {
+        // The whole call as ONE enqueue in the usual case (no trial rejected, no stop request): stage 1's prologue and
+        // trials, stage 2's prologue gated on "stage 1 is over" (kBaGateIdle), stage 2's trials - launches carry their
+        // stage's tag and return at once unless lm->active equals it -, finish + copy out.  The host looks once, at the
+        // end; a stream synchronise + the next launches idled the GPU ~35 us at the stage boundary and ~45 us at the end.
+        // If a stage needs more trials than its iteration count (rejected trials), what was enqueued behind it has
+        // returned at once; the host adds the missing trials and the rest of the chain again.
+        auto trials = [&](const BaDev& d, int n) {
+            for (int i = 0; i < n; i++) {
+                r.blocks_enqueued++;
+                launch_ba_trial(d, r.nb_err, r.nb_upd, abort_dev, b->h_lm_dev, nullptr, nullptr, s);
+            }
+        };
+        auto stage2_chained = [&]() {  // Optimizer.cc:644-656 without leaving the device
+            launch_ba_mark_outliers(d2, (double)opt->chi2_threshold, kBaGateIdle, s);
+            launch_ba_errors(d2, 0, kBaGateIdle, r.nb_err, s);
+            launch_ba_build(d2, kBaGateIdle, s);
+            launch_ba_stage_begin(d2, r.nb_err, opt->its_stage2, b->h_lm_dev, kBaGateIdle, abort_dev, s);
+            trials(d2, opt->its_stage2);
+        };
+        launch_ba_errors(r.d, 0, kBaGateNone, r.nb_err, s);
+        launch_ba_build(r.d, kBaGateNone, s);
+        launch_ba_stage_begin(r.d, r.nb_err, opt->its_stage1, b->h_lm_dev, kBaGateNone, nullptr, s);
+        trials(r.d, opt->its_stage1);
+        if (two_stages) stage2_chained();
+        epilogue();
+        BaLm lm;
+        bool stopped_between = false;
+        for (;;) {
+            SO_HIP(hipGetLastError());
+            if ((rc = wait_stream(r))) return rc;
+            if (*(volatile unsigned*)b->h_flow_abort != 0) return kErrFlowTimeout;  // a dataflow solve gave up waiting
+            memcpy(&lm, b->h_lm, sizeof(lm));
+            if (lm.active == 1) {  // stage 1 wants more trials than were enqueued
+                trials(r.d, std::max(1, lm.iterations - lm.it));
+                if (two_stages) stage2_chained();
+                epilogue();
+                continue;
+            }
+            if (lm.active == 2) {
+                trials(d2, std::max(1, lm.iterations - lm.it));
+                epilogue();
+                continue;
+            }
+            if (two_stages && lm.stages_begun == 1 && !stopped_between) {
+                // stage 1 is over and stage 2 did not begin on the device: a stop request was up when its prologue ran
+                if (r.terminate()) {
+                    stopped_between = true;  // Optimizer.cc:641-643: bDoMore = false
+                    break;
+                }
+                launch_ba_mark_outliers(d2, (double)opt->chi2_threshold, kBaGateNone, s);
+                launch_ba_errors(d2, 0, kBaGateNone, r.nb_err, s);
+                launch_ba_build(d2, kBaGateNone, s);
+                launch_ba_stage_begin(d2, r.nb_err, opt->its_stage2, b->h_lm_dev, kBaGateNone, nullptr, s);
+                trials(d2, opt->its_stage2);
+                epilogue();
+                continue;
+            }
+            break;
+        }
+        const bool begun2 = lm.stages_begun >= 2;
+        inf.iterations_stage1 = begun2 ? lm.prev_done : lm.done;
+        inf.chi2_initial = begun2 ? lm.prev_chi_begin : lm.chi_begin;  // chi2 before optimising (information only)
+        const double chi1 = begun2 ? lm.prev_chi_out : lm.chi_out;
+        inf.chi2_final = inf.iterations_stage1 > 0 ? chi1 : inf.chi2_initial;
+        if (begun2) {
+            inf.iterations_stage2 = lm.done;
+            if (lm.done > 0) inf.chi2_final = lm.chi_out;
+        }
+        if (stopped_between || r.terminate()) inf.aborted = 1;
+        r.d.robust = begun2 ? 0 : r.d.robust;
+        t_opt1 = now_ms();
+    } else {
+        // stage by stage (solve events on, SWARMORB_BA_NO_CHAIN, or nothing to optimise): the host sees every stage end
+        StageChain none;
+        if ((rc = optimize(r, opt->its_stage1, true, none, &done, &chi, nullptr))) return rc;  // optimizer.optimize(5)
+        inf.iterations_stage1 = done;
+        inf.chi2_initial = b->h_lm->chi_begin;  // chi2 before optimising (information only)
+        inf.chi2_final = done > 0 ? chi : inf.chi2_initial;
+        t_opt1 = now_ms();
+        bool do_more = two_stages;
+        if (r.terminate()) {
+            do_more = false;
+            inf.aborted = 1;
+        }
+        if (do_more) {
+            launch_ba_mark_outliers(d2, (double)opt->chi2_threshold, kBaGateNone, s);
+            r.d = d2;
+            if ((rc = optimize(r, opt->its_stage2, true, none, &done, &chi, nullptr))) return rc;  // optimizer.optimize(10)
+            inf.iterations_stage2 = done;
+            if (done > 0) inf.chi2_final = chi;
+            if (r.terminate()) inf.aborted = 1;
+        }
+        epilogue();
+        SO_HIP(hipGetLastError());
+        SO_HIP(hipStreamSynchronize(s));
     }
     const double t_opt2 = now_ms();
-    // Optimizer.cc:682-739: outlier flags from the edges' stored errors and isDepthPositive(), optimised data back
-    uint8_t* ob = (uint8_t*)b->d_out.p;
-    launch_ba_finish(r.d, (double)opt->chi2_threshold, (BaPose*)(ob + r_pose), (double*)(ob + r_pt),
-                     (double*)(ob + r_chi2), ob + r_out, s);
-    SO_HIP(hipGetLastError());
-    SO_HIP(hipMemcpyAsync(b->h_out, b->d_out.p, O.total, hipMemcpyDeviceToHost, s));
-    SO_HIP(hipEventRecord(b->e1, s));
-    SO_HIP(hipStreamSynchronize(s));
     const uint8_t* ho = (const uint8_t*)b->h_out;
     const BaPose* o_poses = (const BaPose*)(ho + r_pose);
     const double* o_pts = (const double*)(ho + r_pt);

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
     __shared__ double A[kDNB][kPS];
     __shared__ double X[kDNB][kPS];
     __shared__ int s_bad;
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int tid = threadIdx.x, ld = d.ldS;
     const double* Sk = d.S + (size_t)k * kDNB * ld + (size_t)k * kDNB;
     if (tid == 0) s_bad = 0;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev 
     __shared__ double s_z[16];
     __shared__ unsigned char s_ti[kSolveMfmaMaxTiles * (kSolveMfmaMaxTiles + 1) / 2], s_tj[kSolveMfmaMaxTiles * (kSolveMfmaMaxTiles + 1) / 2];
     __shared__ int s_bad;
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int crow = lane >> 4, ccol = lane & 15;
     const int n = 6 * d.n_free, ld = d.ldS;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
     __shared__ double s_z[16];
     __shared__ unsigned char s_ti[kRegMaxTiles * (kRegMaxTiles - 1) / 2], s_tj[kRegMaxTiles * (kRegMaxTiles - 1) / 2];
     __shared__ int s_bad;
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int crow = lane >> 4, ccol = lane & 15;
     const int n = 6 * d.n_free, ld = d.ldS;
@@ -730,7 +730,7 @@ __device__ __forceinline__ void dense_tile_nt(const double* __restrict__ PA, int
 __global__ __launch_bounds__(256) void dense_panel_kernel(BaDev d, int k) {
     __shared__ double sA[kDNB][kDStride];
     __shared__ double sB[kDNB][kDStride];
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int tid = threadIdx.x, ld = d.ldS;
     const double* Linv = d.dense_ws + (size_t)k * kDNB * kDNB;
     if (blockIdx.x == 0) {
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int k
                                                            int n_tiles, int rhs_panel) {
     __shared__ double sA[kDNB][kDStride];
     __shared__ double sB[kDNB][kDStride];
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int tid = threadIdx.x, ld = d.ldS;
     if ((int)blockIdx.x >= n_tiles) {  // right-hand side rows below panel rhs_panel
         const int row0 = (rhs_panel + 1) * kDNB + ((int)blockIdx.x - n_tiles) * 256;
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void dense_update_kernel(BaDev d, int k, int k
 // the panel: y_c -= sum_m L[k*96+m][c] x_k[m]; workgroup 0 stores x_k.
 __global__ __launch_bounds__(256) void dense_backward_kernel(BaDev d, int k) {
     __shared__ double s_y[kDNB], s_x[kDNB], s_part[2][kDNB];
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int tid = threadIdx.x, ld = d.ldS;
     const double* Linv = d.dense_ws + (size_t)k * kDNB * kDNB;
     if (tid < kDNB) s_y[tid] = d.bs[(size_t)k * kDNB + tid];
@@ -857,14 +857,14 @@ __global__ __launch_bounds__(256) void dense_backward_kernel(BaDev d, int k) {
 }
 
 __global__ __launch_bounds__(256) void dense_finish_kernel(BaDev d) {
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < 6 * d.n_free) d.bs[i] = d.dense_x[i];
     if (i == 0 && !(d.partial[kBaSolveOk] == 0.0)) d.partial[kBaSolveOk] = 1.0;
 }
 
 __global__ void dense_begin_kernel(BaDev d) {
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     d.partial[kBaSolveOk] = 0.5;  // becomes 0 if a pivot fails, 1 at the end otherwise
 }
 
@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(256) void dense_flow_kernel(BaDev d, unsigned epoch
     extern __shared__ __align__(16) double flow_lds[];
     __shared__ int s_m, s_bad;
     __shared__ double s_v[kDNB], s_u[kDNB];
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int tid = threadIdx.x, ld = d.ldS, T = ld / kDNB;
     const int2 t = d.flow_tiles[blockIdx.x];
     const int I = __builtin_amdgcn_readfirstlane(t.x), J = __builtin_amdgcn_readfirstlane(t.y), self = I * (I + 1) / 2 + J;
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(256) void dense_flow_big_kernel(BaDev d, unsigned e
     __shared__ int s_m, s_bad;
     __shared__ unsigned s_ticket;
     __shared__ double s_v[kDNB];
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int tid = threadIdx.x, ld = d.ldS, T = ld / kDNB;
     unsigned* flags = d.flow_flags;
     unsigned* fY = flags + d.flow_nslots;

@@ -41,9 +41,13 @@ struct BaLm {
     int qmax, nBad;
     int done;                   // iterations completed in this optimize()
     int trials;                 // trials since the problem was set up (all stages)
-    int active;                 // 1 while optimize() wants another trial; kernels return immediately when 0
+    int active;                 // the running stage's tag (BaDev::stage) while optimize() wants another trial, 0 otherwise
     int need_build;             // the current estimate changed: re-linearise before the next trial
-    int pad[3];
+    int stages_begun;           // optimize() calls started on this problem (ba_stage_begin_kernel)
+    int prev_done;              // `done` of the stage before the current one, saved when the current one began
+    int pad;
+    double prev_chi_out;        // `chi_out` of the stage before the current one
+    double prev_chi_begin;      // `chi_begin` of the stage before the current one
 };
 
 struct BaDev {
@@ -54,6 +58,7 @@ struct BaDev {
     // problem
     int n_poses, n_points, n_edges;
     int n_free;          // poses with a hessian index in the current stage
+    int stage;           // tag of the optimize() call these launches belong to (1, 2): they run only while lm->active == stage
     int n_active_points;  // informational
     const double* intr;       // n_poses x 4
     const int* e_pose;        // sorted edges
@@ -129,10 +134,13 @@ struct BaClearList {
     int n;
 };
 void launch_ba_clear(const BaClearList& L, hipStream_t s);
-void launch_ba_errors(const BaDev& d, int which, bool gated, int n_blocks, hipStream_t s);
-void launch_ba_build(const BaDev& d, bool gated, hipStream_t s);
+// gate: 0 = run, kBaGateActive = only while optimize() wants another trial, kBaGateIdle = only when no stage is running (a launch
+// chained behind a stage's trials: it takes effect on the device the moment that stage is over, without a host round trip)
+constexpr int kBaGateNone = 0, kBaGateActive = 1, kBaGateIdle = 2;
+void launch_ba_errors(const BaDev& d, int which, int gate, int n_blocks, hipStream_t s);
+void launch_ba_build(const BaDev& d, int gate, hipStream_t s);
 // start of optimize(iterations): currentChi from the error partials, computeLambdaInit from the max diagonal
-void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_host, hipStream_t s);
+void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_host, int gate, const uint8_t* abort_flag, hipStream_t s);
 // one LM trial, seven launches, no host involvement: [build] -> schur prep -> gather -> solve -> update -> errors
 // -> decide.  abort_flag (host-mapped, may be null) = g2o's forceStopFlag; lm_host (host-mapped) receives a copy
 // of the state after every decision; ev0/ev1 (may be null) bracket the solve kernel.
@@ -176,7 +184,7 @@ void launch_ba_dense_pad(const BaDev& d, hipStream_t s);    // once per problem:
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s);  // per trial, in place of the single-workgroup solve  // fills edge_tab (memset to -1 beforehand)
 // Optimizer.cc:644-656 on the device: edges of the current estimate with chi2 > threshold or non-positive depth
 // leave the problem (level 1); landmarks left without an edge become inactive
-void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, hipStream_t s);
+void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, int gate, hipStream_t s);
 // Optimizer.cc:682-739: current estimate, stored chi2 and the outlier flag (chi2 > threshold or depth <= 0) of
 // every edge into the result block
 void launch_ba_finish(const BaDev& d, double chi2_threshold, BaPose* pose_out, double* pt_out, double* chi2_out,

@@ -211,7 +211,8 @@ __device__ __forceinline__ double block_sum(double v, double* s_tmp /* >= 16 dou
 __global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, int which, int gated) {
     __shared__ double s_tmp[16];
     const BaLm lm = *d.lm;
-    if (gated && !lm.active) return;
+    if (gated == 1 && lm.active != d.stage) return;
+    if (gated == 2 && (lm.active || lm.stages_begun != d.stage - 1)) return;  // chained behind the previous stage's trials: only once that stage is over
     const BaPose* __restrict__ poses = d.pose[lm.cur ^ which];
     const double* __restrict__ points = d.pt[lm.cur ^ which];
     double acc = 0.0;
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, int which, int 
     if (threadIdx.x == 0) d.partial[kBaPartialChi + blockIdx.x] = t;
 }
 
-void launch_ba_errors(const BaDev& d, int which, bool gated, int n_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(ba_errors_kernel, dim3(n_blocks), dim3(256), 0, s, d, which, gated ? 1 : 0);
+void launch_ba_errors(const BaDev& d, int which, int gate, int n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(ba_errors_kernel, dim3(n_blocks), dim3(256), 0, s, d, which, gate);
 }
 
 // edge_tab[hessian index][landmark] = the edge joining them (at most one: a keyframe observes a landmark once).
@@ -391,9 +392,10 @@ void launch_ba_finish(const BaDev& d, double chi2_threshold, BaPose* pose_out, d
 // Between the two stages of LocalBundleAdjustment (Optimizer.cc:644-656): one thread per landmark walks its
 // (contiguous) edges; an active edge whose stored chi2 exceeds the threshold or whose point is not in front of
 // the camera in the current estimate is dropped (setLevel(1)); a landmark without active edges drops out too.
-__global__ __launch_bounds__(256) void ba_mark_outliers_kernel(BaDev d, double chi2_threshold) {
+__global__ __launch_bounds__(256) void ba_mark_outliers_kernel(BaDev d, double chi2_threshold, int gate) {
     const int il = blockIdx.x * 256 + threadIdx.x;
     if (il >= d.n_points) return;
+    if (gate == 2 && (d.lm->active || d.lm->stages_begun != d.stage - 1)) return;
     const int cur = d.lm->cur;
     const double* points = d.pt[cur];
     const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
@@ -413,9 +415,9 @@ __global__ __launch_bounds__(256) void ba_mark_outliers_kernel(BaDev d, double c
     d.pt_active[il] = alive > 0;
 }
 
-void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, hipStream_t s) {
+void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, int gate, hipStream_t s) {
     if (d.n_points <= 0) return;
-    hipLaunchKernelGGL(ba_mark_outliers_kernel, dim3((d.n_points + 255) / 256), dim3(256), 0, s, d, chi2_threshold);
+    hipLaunchKernelGGL(ba_mark_outliers_kernel, dim3((d.n_points + 255) / 256), dim3(256), 0, s, d, chi2_threshold, gate);
 }
 
 // ---------------- linearisation: Hpp/bp per free pose (one workgroup each), Hll/bl/W per landmark ----------------
@@ -425,7 +427,8 @@ void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, hipStream_t 
 __global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, int gated) {
     __shared__ double s_red[4][28];
     const BaLm lm = *d.lm;
-    if (gated && !(lm.active && lm.need_build)) return;
+    if (gated == 1 && !(lm.active == d.stage && lm.need_build)) return;
+    if (gated == 2 && (lm.active || lm.stages_begun != d.stage - 1)) return;
     const BaPose* __restrict__ poses = d.pose[lm.cur];
     const double* __restrict__ points = d.pt[lm.cur];
     if ((int)blockIdx.x < d.n_free) {
@@ -531,10 +534,10 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, int gated) {
     }
 }
 
-void launch_ba_build(const BaDev& d, bool gated, hipStream_t s) {
+void launch_ba_build(const BaDev& d, int gate, hipStream_t s) {
     const int nb = d.n_free + (d.n_points + 31) / 32;
     if (nb <= 0) return;
-    hipLaunchKernelGGL(ba_build_kernel, dim3(nb), dim3(256), 0, s, d, gated ? 1 : 0);
+    hipLaunchKernelGGL(ba_build_kernel, dim3(nb), dim3(256), 0, s, d, gate);
 }
 
 // ---------------- Schur complement ----------------
@@ -552,7 +555,7 @@ __device__ __forceinline__ void damped_inverse3(const double* Hl, double lambda,
 //       thread i < n_edges : BDinv_e = W_e Dinv (recomputing the 3x3 inverse of its landmark: no dependency
 //       between the two roles, so everything is one memory latency deep)
 __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d) {
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const double lambda = d.lm->lambda;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < d.n_points && d.pt_active[i]) {
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d) {
 template <int WAVES>
 __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_cap) {
     __shared__ double s_part[4][36];
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const double lambda = d.lm->lambda;
     const int lane = threadIdx.x & 63, wave = WAVES == 4 ? (int)(threadIdx.x >> 6) : 0;
     const int tid = WAVES == 4 ? (int)threadIdx.x : lane;  // index inside the group
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_reg_kernel(BaDev d) {
     __shared__ double s_y[kSolveMaxNB][6];
     __shared__ double s_x[6];
     __shared__ int s_fail;
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     SO_SOLVE_MARK_DECL;
     const int tid = threadIdx.x;
     const int nf = d.n_free, NB = nf + 1, nblk = NB * (NB + 1) / 2;
@@ -986,7 +989,7 @@ __global__ __launch_bounds__((UW + PW) * 64) void ba_solve_la_kernel(BaDev d) {
     __shared__ int s_colcnt[kLaMaxNB + 2];  // update-team waves that have staged their part of column J
     __shared__ int s_updcnt[kLaMaxNB + 2];  // update-team waves that have finished step k
     __shared__ int s_panel_ready, s_fail;
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     SO_SOLVE_MARK_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = d.n_free, NB = nf + 1, nblk = NB * (NB + 1) / 2 - 1;
@@ -1211,7 +1214,7 @@ __global__ __launch_bounds__((UW + PW) * 64) void ba_solve_la_kernel(BaDev d) {
 // One thread per upper block with at most kBaSmallBlockPairs pairs (the common case of a large map, including
 // "no landmark in common"): sums -BDinv W^T over its (landmark-sorted) pairs, writes the block and its mirror.
 __global__ __launch_bounds__(256) void ba_schur_gather_small_kernel(BaDev d, int n_blk) {
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= n_blk) return;
     const int o = d.pr_off[g], np = d.pr_off[g + 1] - o;
@@ -1294,7 +1297,7 @@ static void launch_ba_solve(const BaDev& d, hipStream_t s) {
 __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d) {
     __shared__ double s_tmp[16];
     const BaLm lm = *d.lm;
-    if (!lm.active) return;
+    if (lm.active != d.stage) return;
     const double lambda = lm.lambda;
     const BaPose* __restrict__ poses = d.pose[lm.cur];
     const double* __restrict__ points = d.pt[lm.cur];
@@ -1371,9 +1374,15 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d) {
 // optimization_algorithm_levenberg.cpp:166-180; max is order-independent), LM state reset.  One workgroup; the maximum
 // used to be a launch of its own that walked the 3 n_points diagonal entries one dependent load at a time (19 us for
 // 9600 landmarks) - here a thread takes whole landmarks, three independent loads each.
-__global__ __launch_bounds__(1024) void ba_stage_begin_kernel(BaDev d, int nb_err, int iterations, BaLm* __restrict__ lm_host) {
+__global__ __launch_bounds__(1024) void ba_stage_begin_kernel(BaDev d, int nb_err, int iterations, BaLm* __restrict__ lm_host, int gate,
+                                                               const uint8_t* __restrict__ abort_flag) {
     __shared__ double s_tmp[16];
     __shared__ double s_m[16];
+    // gate 2: chained behind the previous stage's trials - the stage starts on the device as soon as that one is over
+    // (and not at all if it is still running, or a stop was requested: the host then starts it the ordinary way)
+    if (gate == 2 && (d.lm->active || d.lm->stages_begun != d.stage - 1 ||
+                      (abort_flag && *reinterpret_cast<const volatile uint8_t*>(abort_flag))))
+        return;
     double m = 0.0;
     for (int i = threadIdx.x; i < d.n_free; i += 1024) {
         const double* H = d.Hpp + 36 * (size_t)i;
@@ -1396,6 +1405,10 @@ __global__ __launch_bounds__(1024) void ba_stage_begin_kernel(BaDev d, int nb_er
         for (int i = 0; i < 16; i++) t = fmax(t, s_m[i]);
         d.partial[kBaMaxDiag] = t;
         BaLm& lm = *d.lm;
+        lm.prev_done = lm.done;        // what the stage before this one ended with (the host may look only after this launch)
+        lm.prev_chi_out = lm.chi_out;
+        lm.prev_chi_begin = lm.chi_begin;
+        lm.stages_begun++;
         lm.currentChi = chi;
         lm.iniChi = chi;
         lm.tempChi = chi;
@@ -1410,13 +1423,13 @@ __global__ __launch_bounds__(1024) void ba_stage_begin_kernel(BaDev d, int nb_er
         lm.qmax = 0;
         lm.done = 0;
         lm.need_build = 0;
-        lm.active = iterations > 0 ? 1 : 0;
+        lm.active = iterations > 0 ? d.stage : 0;  // the stage's tag: kernels launched for another stage return at once
         if (lm_host) *lm_host = lm;
     }
 }
 
-void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_host, hipStream_t s) {
-    hipLaunchKernelGGL(ba_stage_begin_kernel, dim3(1), dim3(1024), 0, s, d, nb_err, iterations, lm_host);
+void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_host, int gate, const uint8_t* abort_flag, hipStream_t s) {
+    hipLaunchKernelGGL(ba_stage_begin_kernel, dim3(1), dim3(1024), 0, s, d, nb_err, iterations, lm_host, gate, abort_flag);
 }
 
 // End of a trial: OptimizationAlgorithmLevenberg::solve's accept / reject (optimization_algorithm_levenberg.cpp:
@@ -1425,7 +1438,7 @@ __global__ __launch_bounds__(256) void ba_trial_decide_kernel(BaDev d, int nb_er
                                                               const uint8_t* __restrict__ abort_flag,
                                                               BaLm* __restrict__ lm_host) {
     __shared__ double s_tmp[16];
-    if (!d.lm->active) return;
+    if (d.lm->active != d.stage) return;
     double c = 0.0, sc = 0.0;
     for (int i = threadIdx.x; i < nb_err; i += 256) c += d.partial[kBaPartialChi + i];
     for (int i = threadIdx.x; i < nb_upd; i += 256) sc += d.partial[kBaPartialScale + i];
@@ -1480,13 +1493,13 @@ __global__ __launch_bounds__(256) void ba_trial_decide_kernel(BaDev d, int nb_er
 
 void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abort_flag, BaLm* lm_host, hipEvent_t ev0,
                      hipEvent_t ev1, hipStream_t s) {
-    launch_ba_build(d, true, s);
+    launch_ba_build(d, kBaGateActive, s);
     launch_ba_schur(d, s);
     if (ev0) (void)hipEventRecord(ev0, s);
     launch_ba_solve(d, s);
     if (ev1) (void)hipEventRecord(ev1, s);
     hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, s, d);
-    launch_ba_errors(d, 1, true, nb_err, s);
+    launch_ba_errors(d, 1, kBaGateActive, nb_err, s);
     hipLaunchKernelGGL(ba_trial_decide_kernel, dim3(1), dim3(256), 0, s, d, nb_err, nb_upd, abort_flag, lm_host);
 }
 
