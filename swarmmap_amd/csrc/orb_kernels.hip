@@ -882,14 +882,27 @@ __device__ __forceinline__ void describe_body(const PyramidParams& P, const Sele
         s_mom[2 * wave + 1] = m01;
     }
 
-    // separable Gaussian: row pass (float), column pass, round-half-even
-    for (int i = tid; i < kPatch * kBlur; i += kDescThreads) {
-        const int r = i / kBlur, c = i - r * kBlur;
-        const uint8_t* q = patch + r * kPatchPitch + c;
-        float sum = 0.f;
+    // separable Gaussian: row pass (float), column pass, round-half-even.  A lane produces FOUR neighbouring outputs from
+    // the ten source values they share (row pass: four aligned dwords of the patch row, shifted into place; column
+    // pass: ten rows of one column) - 21 instructions per output instead of 43 / 30 with one output per lane and seven
+    // byte (or float) reads each; every output is still the same chain of seven multiply-adds in the same order.
+    constexpr int kGroups = (kBlur + 3) / 4;  // 10 groups of four along a row / a column
+    for (int t = tid; t < kPatch * kGroups; t += kDescThreads) {
+        const int r = t / kGroups, g = t - r * kGroups;
+        const uint32_t* q = patch32 + r * (kPatchPitch / 4) + g;
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)sh),
+                       a2 = __builtin_amdgcn_alignbyte(d3, d2, (uint32_t)sh);
+        const float b[10] = {(float)(a0 & 255u), (float)((a0 >> 8) & 255u), (float)((a0 >> 16) & 255u), (float)(a0 >> 24),
+                             (float)(a1 & 255u), (float)((a1 >> 8) & 255u), (float)((a1 >> 16) & 255u), (float)(a1 >> 24),
+                             (float)(a2 & 255u), (float)((a2 >> 8) & 255u)};
 #pragma unroll
-        for (int k = 0; k < 7; k++) sum = sum + (float)q[k] * gauss7[k];
-        rowp[i] = sum;
+        for (int j = 0; j < 4; j++) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 7; k++) sum = sum + b[j + k] * gauss7[k];
+            if (4 * g + j < kBlur) rowp[r * kBlur + 4 * g + j] = sum;
+        }
     }
     __syncthreads();
     if (kDescWaves > 1) {
@@ -903,13 +916,19 @@ __device__ __forceinline__ void describe_body(const PyramidParams& P, const Sele
     float kp_dir = det_atan2f((float)m01, (float)m10);
     kp_dir += (float)(kp_dir < 0) * 0x1.921fb6p+2f;
     kp_dir *= 0x1.ca5dcp+5f;
-    for (int i = tid; i < kBlur * kBlur; i += kDescThreads) {
-        const int r = i / kBlur, c = i - r * kBlur;
-        float sum = 0.f;
+    for (int t = tid; t < kGroups * kBlur; t += kDescThreads) {
+        const int g = t / kBlur, c = t - g * kBlur;
+        float v[10];
 #pragma unroll
-        for (int k = 0; k < 7; k++) sum = sum + rowp[(r + k) * kBlur + c] * gauss7[k];
-        int v = (int)__builtin_rintf(sum);
-        blur[r * kBlurPitch + c] = (uint8_t)min(max(v, 0), 255);
+        for (int k = 0; k < 10; k++) v[k] = rowp[min(4 * g + k, kPatch - 1) * kBlur + c];  // (rows past the patch feed no valid output)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 7; k++) sum = sum + v[j + k] * gauss7[k];
+            const int o = (int)__builtin_rintf(sum);
+            if (4 * g + j < kBlur) blur[(4 * g + j) * kBlurPitch + c] = (uint8_t)min(max(o, 0), 255);
+        }
     }
     __syncthreads();
 
