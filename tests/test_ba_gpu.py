@@ -507,3 +507,24 @@ def test_full_size_global_ba_matches_the_oracle_fixture(opt, name, fixture):
     diff = np.nonzero(r["outlier"] != want)[0]
     assert np.all(np.abs(r["chi2"][diff] - 5.991) <= 1e-5 * 5.991), diff[:10]  # flags differ only on the gate itself
     assert abs(int(r["info"]["n_outliers"]) - int(inf["n_outliers"])) <= len(diff)
+
+
+@pytest.mark.parametrize("seed,pose_noise", [(2, (1.0, 25.0)), (4, (0.6, 15.0)), (0, (0.3, 8.0))])
+def test_one_enqueue_per_call_equals_stage_by_stage_when_trials_are_rejected(opt, seed, pose_noise):
+    """so_bundle_adjust enqueues both stages and the epilogue at once (stage 2 gated on the device, launches tagged with
+    their stage); windows whose LM rejects trials need more launches than were enqueued and take the host's top-up path.
+    The stage-by-stage flow (taken when the solves are event-timed) must give the same bits, rejected trials or not."""
+    w = synth.make_ba_problem(seed, 8, 10, 800, pose_noise=pose_noise, point_noise=0.4, max_obs="auto")
+    a = opt.LocalBundleAdjustment(w)
+    if seed != 0:
+        assert a["info"]["lm_trials"] > a["info"]["iterations_stage1"] + a["info"]["iterations_stage2"], "no rejected trial: pick another window"
+    opt.set_solve_timing(True)
+    try:
+        b = opt.LocalBundleAdjustment(w)
+    finally:
+        opt.set_solve_timing(False)
+    for k in ("iterations_stage1", "iterations_stage2", "lm_trials", "chi2_initial", "chi2_final", "lambda_final", "n_outliers"):
+        assert a["info"][k] == b["info"][k], k
+    assert a["Tcw"].tobytes() == b["Tcw"].tobytes() and a["Xw"].tobytes() == b["Xw"].tobytes()
+    assert a["chi2"].tobytes() == b["chi2"].tobytes() and a["outlier"].tobytes() == b["outlier"].tobytes()
+    assert b["info"]["n_solves"] == b["info"]["lm_trials"] and a["info"]["n_solves"] == 0
