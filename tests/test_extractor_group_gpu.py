@@ -18,7 +18,7 @@ def _pinned(images):
     return block, [view[i] for i in range(len(images))]
 
 
-@pytest.mark.parametrize("n_members,size", [(1, (752, 480)), (3, (752, 480)), (4, (1241, 376)), (8, (640, 360))])
+@pytest.mark.parametrize("n_members,size", [(1, (752, 480)), (3, (752, 480)), (4, (1241, 376)), (8, (640, 360)), (24, (400, 300))])
 def test_group_extraction_equals_lone_extraction(n_members, size):
     import swarmmap_amd as S
     assert S.device_count() > 0, "these tests need a GPU"
