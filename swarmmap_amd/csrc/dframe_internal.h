@@ -56,6 +56,7 @@ struct so_dframe {
     // host copies filled at collect
     int n = 0, n_inside = 0;
     float bounds[4] = {0, 0, 0, 0};
+    bool bounds_known = false;  // a frame of this handle has completed: bounds[] holds ComputeImageBounds' result
     std::vector<int32_t> octave;
     std::vector<float> angle;
 };

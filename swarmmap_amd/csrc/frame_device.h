@@ -16,12 +16,13 @@ constexpr int kFrameMaxKeypoints = 16384;                // sort capacity of the
 struct FramePrepareArgs {
     FrameCam cam;
     int width, height, n;
-    int do_bounds;     // 1: ComputeImageBounds into bounds[4]; 0: bounds[] is an input
+    int do_bounds;     // 1: ComputeImageBounds into bounds[4]; 0: bounds[] is an input; 2: bounds_value is (and is copied to bounds[])
     int do_undistort;  // 1: xy -> xy_un; 0: xy_un is an input
     int do_grid;       // 1: cell_of / cell_start / cell_items / n_inside
     const float* xy;   // 2n
     float* xy_un;      // 2n
     float* bounds;     // 4: mnMinX, mnMaxX, mnMinY, mnMaxY
+    float bounds_value[4];  // do_bounds == 2
     int32_t* cell_of;     // n
     int32_t* cell_start;  // 64*48+1
     int32_t* cell_items;  // n

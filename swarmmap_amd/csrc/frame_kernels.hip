@@ -73,7 +73,7 @@ __device__ __forceinline__ void frame_prepare_body(const FramePrepareArgs& a) {
     const SelectedKp* meta = static_cast<const SelectedKp*>(a.ex_meta);
     constexpr int ncell = kFrameGridCols * kFrameGridRows;
     static_assert(ncell == 3 * 1024, "three cells per thread in the scan below");
-    if (a.do_bounds) {
+    if (a.do_bounds == 1) {
         __shared__ float s_c[4][2];
         if (tid < 4) {
             if (a.cam.k1 != 0.0f) {
@@ -92,6 +92,11 @@ __device__ __forceinline__ void frame_prepare_body(const FramePrepareArgs& a) {
                 s_b[0] = 0.0f; s_b[1] = (float)a.width; s_b[2] = 0.0f; s_b[3] = (float)a.height;
             }
             for (int i = 0; i < 4; i++) a.bounds[i] = s_b[i];
+        }
+    } else if (a.do_bounds == 2) {  // the caller knows them (they depend on the camera only): no corner undistortion, no load
+        if (tid < 4) {
+            s_b[tid] = a.bounds_value[tid];
+            a.bounds[tid] = a.bounds_value[tid];
         }
     } else if (tid < 4) {
         s_b[tid] = a.bounds[tid];
