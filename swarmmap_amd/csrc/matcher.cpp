@@ -1555,8 +1555,14 @@ int launch_topk_track_async(so_matcher* m, TrackQuerySrc& T, int mode, int nq, i
         set_bits_from_excluded(m, G.excluded, nullptr, T);
         memset(T.skip_bits, 0, sizeof(uint32_t) * (size_t)((nq + 31) / 32));
         if (G.skip)
-            for (int i = 0; i < nq; i++)
-                if (G.skip[i]) T.skip_bits[i >> 5] |= 1u << (i & 31);
+            for (int i = 0; i < nq; i++) {
+                if (G.skip[i]) {
+                    T.skip_bits[i >> 5] |= 1u << (i & 31);
+                } else {  // few queries are skipped: eight clear bytes at a time
+                    uint64_t w8;
+                    while (i + 8 < nq && (memcpy(&w8, G.skip + i + 1, 8), w8 == 0)) i += 8;
+                }
+            }
         T.slot = G.slots ? reinterpret_cast<const int32_t*>(h + off_slot) : nullptr;  // pinned: the kernel reads it in place
         T.skip = nullptr;
         m->has_limit = false;
@@ -1868,7 +1874,12 @@ int so_track_search_local_map_wait(so_matcher* m, const uint8_t* slot_has_obs, u
     std::vector<int32_t> gate;
     int nm = 0;
     for (int i = 0; i < n_local; i++) {
-        if (cnt[(size_t)i] == 0) continue;
+        if (cnt[(size_t)i] == 0) {
+            // most of a local map is out of view: skip eight empty counts at a time
+            uint64_t w8;
+            while (i + 8 < n_local && (memcpy(&w8, cnt + i + 1, 8), w8 == 0)) i += 8;
+            continue;
+        }
         Entry e[2];
         int found = 0, walked = 0;
         for (; walked < K && found < 2; walked++) {
