@@ -126,3 +126,33 @@ def test_group_with_members_on_streams_of_their_own():
             ex.close()
     finally:
         private_streams(False)
+
+
+def test_group_refuses_what_it_cannot_batch():
+    import swarmmap_amd as S
+    a = S.ORBextractor(1000, 1.2, 8, 20, 7)
+    b = S.ORBextractor(500, 1.2, 8, 20, 7)  # another configuration
+    with pytest.raises(S.SwarmOrbError):
+        S.ExtractorGroup([a, b])
+    with pytest.raises(S.SwarmOrbError):
+        S.ExtractorGroup([a, a])  # the same member twice
+    b.close()
+    c = S.ORBextractor(1000, 1.2, 8, 20, 7)
+    grp = S.ExtractorGroup([a, c])
+    keep, pinned = _pinned([synth.make_canvas(1, 752, 480), synth.make_canvas(2, 752, 480)])
+    grp.submit(pinned)
+    with pytest.raises(S.SwarmOrbError):
+        grp.submit(pinned)  # the members' frames have not been collected
+    ka, da = a.collect()
+    kc, dc = c.collect()
+    assert len(ka) > 100 and len(kc) > 100
+    keep2, other = _pinned([synth.make_canvas(1, 640, 360), synth.make_canvas(2, 640, 360)])
+    with pytest.raises(S.SwarmOrbError):
+        grp.submit(other)  # image size changed between frames
+    grp.submit(pinned)  # and the group still works after the refusals
+    assert a.collect()[0].tobytes() == ka.tobytes() and c.collect()[0].tobytes() == kc.tobytes()
+    # the candidate list of the last frame is produced on demand (the device quadtree never builds it)
+    xs, ys, sc = a.candidates(0)
+    assert len(xs) > len(ka) // 8 and len(xs) == len(ys) == len(sc)
+    grp.close()
+    a.close(); c.close()
