@@ -172,7 +172,21 @@ typedef struct {
     float grid_inv_w, grid_inv_h;     /* mfGridElementWidthInv, mfGridElementHeightInv */
     const float* scale_factors;       /* mvScaleFactors */
     int32_t nlevels;
+    /* KeyFrame quirk (code/include/KeyFrame.h:220: `const int mnMinX, mnMinY, mnMaxX, mnMaxY`): a KeyFrame truncates the
+     * Frame's float bounds to int, so its IsInImage / GetFeaturesInArea (code/src/KeyFrame.cc:779-818) work with the
+     * truncated values - pass those as min_x .. max_y - while the grid it searches was copied from the Frame
+     * (KeyFrame.cc:66-72), i.e. filled by Frame::PosInGrid with the float origin.  has_grid_origin != 0: the cells were
+     * assigned with (grid_min_x, grid_min_y) instead of (min_x, min_y).  A keyframe whose grid was rebuilt by
+     * KeyFrame::AssignFeaturesToGrid (KeyFrame.cc:1012-1038, after deserialisation) and every Frame leave it 0. */
+    int32_t has_grid_origin;
+    float grid_min_x, grid_min_y;
 } so_frame_view;
+
+/* Pinhole intrinsics + distortion of a Frame / KeyFrame (mK, mDistCoef). */
+typedef struct so_camera {
+    float fx, fy, cx, cy;     /* mK */
+    float k1, k2, p1, p2, k3; /* mDistCoef; k1 == 0 means "no distortion" exactly like Frame.cc:456,490 */
+} so_camera;
 
 int so_matcher_create(int device, so_matcher** out);
 void so_matcher_destroy(so_matcher* m);
@@ -274,6 +288,74 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
                             const uint8_t* qdesc, const float* q_angle, int32_t max_dist, int check_orientation,
                             int32_t* kp_to_query, int32_t* nmatches);
 
+/* ---- Fuse, SearchBySim3 and the keyframe-side SearchByProjection overloads with the projection on the device ----
+ * The five routines below take the map points as the reference's loops read them and run, in one enqueue without a host
+ * hop in between, (1) the projection + gating statements of the routine for every map point (thread per point:
+ * Rcw * X + tcw or the Scw / Sim3 chain, positive depth, KeyFrame::IsInImage, Get{Min,Max}DistanceInvariance, the
+ * viewing-angle gate PO.dot(Pn) < 0.5 * dist3D, MapPoint::PredictScale, radius = th * mvScaleFactors[level]) and
+ * (2) the window search of so_search_window_best / _greedy over the produced queries.  cv::Mat arithmetic follows the
+ * conventions of oracle/project_oracle.h (one GEMM = double accumulation + one rounding).  Object-graph side effects
+ * (AddObservation / AddMapPoint / Replace, vpReplacePoint, vpMatched, mvpMapPoints) stay with the caller, which walks
+ * the returned bindings in map-point order exactly as the reference's loop does (host/glue/ORBmatcher_glue.cc). */
+
+/* The MapPoint fields these searches read (code/include/MapPoint.h), one entry per element of vpMapPoints. */
+typedef struct so_mappoint_view {
+    int32_t n;
+    const float* Xw;       /* n x 3: GetWorldPos() (GetGlobalPos() where the routine says so) */
+    const float* normal;   /* n x 3: GetNormal(); may be NULL for SearchBySim3 / SearchByProjection(Frame, KeyFrame) */
+    const float* max_dist; /* mfMaxDistance (GetMaxDistanceInvariance() = 1.2f * this) */
+    const float* min_dist; /* mfMinDistance (GetMinDistanceInvariance() = 0.8f * this) */
+    const uint8_t* desc;   /* n x 32: GetDescriptor() */
+    const uint8_t* valid;  /* the routine's object-graph gates (pMP && !isBad() && !IsInKeyFrame ...); NULL = all 1 */
+} so_mappoint_view;
+
+/* Optional diagnostics of stage (1), per map point; any pointer (or the struct) may be NULL.  u / v / radius / level
+ * are 0 where active[i] = 0. */
+typedef struct so_window_queries {
+    uint8_t* active;
+    float* u;
+    float* v;
+    float* radius;  /* th * mvScaleFactors[nPredictedLevel] */
+    int32_t* level; /* nPredictedLevel */
+} so_window_queries;
+
+/* ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) — code/src/ORBmatcher.cc:751-891, up to
+ * the map side effects.  Tcw12 = [pKF->GetRotation() | GetTranslation()] row-major, log_scale_factor =
+ * pKF->mfLogScaleFactor, inv_level_sigma2 = pKF->mvInvLevelSigma2 (KF->nlevels entries), cam: fx fy cx cy of pKF.
+ * best_idx[i] = bestIdx where bestDist <= TH_LOW (:873) else -1; best_dist[i] = bestDist (256: no candidate);
+ * *n_fused = number of i with best_idx[i] >= 0 (the reference's return value when no point turns bad meanwhile). */
+int so_fuse(so_matcher* m, const so_frame_view* KF, const so_camera* cam, const float* Tcw12, float log_scale_factor,
+            const float* inv_level_sigma2, const so_mappoint_view* mp, float th, int32_t* best_idx, int32_t* best_dist,
+            int32_t* n_fused, const so_window_queries* queries_out);
+/* ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) — :893-1009.  Scw12: rows 0-2 of Scw. */
+int so_fuse_sim3(so_matcher* m, const so_frame_view* KF, const so_camera* cam, const float* Scw12, float log_scale_factor,
+                 const so_mappoint_view* mp, float th, int32_t* best_idx, int32_t* best_dist, int32_t* n_fused,
+                 const so_window_queries* queries_out);
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) — :1011-1221.  mp1 = pKF1->GetMapPointMatches()
+ * (n = N1 keypoints of KF1; valid[i1] = pMP && !vbAlreadyMatched1[i1] && !isBad(), :1040-1061), mp2 likewise with
+ * vbAlreadyMatched2; T1w12 / T2w12 the keyframes' poses; R12 3x3 row-major, t12 3; cam = pKF1's intrinsics (used for
+ * both directions, :1013-1016).  match12[i1] = idx2 where both directions agree (:1205-1218) else -1. */
+int so_search_by_sim3(so_matcher* m, const so_frame_view* KF1, const so_frame_view* KF2, const so_camera* cam,
+                      const float* T1w12, const float* T2w12, float s12, const float* R12, const float* t12,
+                      float log_scale_factor1, float log_scale_factor2, const so_mappoint_view* mp1,
+                      const so_mappoint_view* mp2, float th, int32_t* match12, int32_t* n_found,
+                      const so_window_queries* queries1_out, const so_window_queries* queries2_out);
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, int th) — :264-373.
+ * KF->excluded[k] = vpMatched[k] != NULL on entry; mp->valid[i] = !isBad() && !spAlreadyFound.count(pMP).
+ * kp_to_point[k] = index into vpPoints the call binds to keypoint k (vpMatched[k] = vpPoints[...]) or -1. */
+int so_search_by_projection_sim3(so_matcher* m, const so_frame_view* KF, const so_camera* cam, const float* Scw12,
+                                 float log_scale_factor, const so_mappoint_view* mp, int th, int32_t* kp_to_point,
+                                 int32_t* nmatches, const so_window_queries* queries_out);
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist, bGlobal) —
+ * :1356-1473.  mp = pKF->GetMapPointMatches() (valid[i] = pMP && !isBad() && !sAlreadyFound.count(pMP); Xw = GetGlobalPos
+ * when bGlobal), mp_angle[i] = pKF->mvKeysUn[i].angle, Tcw12 = CurrentFrame.mTcw, F->excluded[k] =
+ * CurrentFrame.mvpMapPoints[k] != NULL on entry.  kp_to_point[k] = i bound to keypoint k (after the rotation
+ * histogram) or -1. */
+int so_search_by_projection_keyframe(so_matcher* m, const so_frame_view* F, const so_camera* cam, const float* Tcw12,
+                                     float log_scale_factor, const so_mappoint_view* mp, const float* mp_angle, float th,
+                                     int32_t orb_dist, int check_orientation, int32_t* kp_to_point, int32_t* nmatches,
+                                     const so_window_queries* queries_out);
+
 /* MapPoint::ComputeDistinctiveDescriptors (code/src/MapPoint.cc:323-392) for a batch of map points (SURVEY 8f rank
  * 4): point p owns descriptors [offsets[p], offsets[p+1]) (the rows the reference collects from its observing
  * keyframes, in map order); best_idx[p] = index within the point's own list of the descriptor with the least
@@ -312,10 +394,7 @@ int so_matcher_last_stats(so_matcher* m, double* stats4);
  * MapPoint::PredictScale / Get{Min,Max}DistanceInvariance (code/src/MapPoint.cc:466-485).
  * Conventions for the arithmetic the reference leaves to un-vendored OpenCV / libm: oracle/frame_oracle.h.
  * ------------------------------------------------------------------------------------------------ */
-typedef struct so_camera {
-    float fx, fy, cx, cy;     /* mK */
-    float k1, k2, p1, p2, k3; /* mDistCoef; k1 == 0 means "no distortion" exactly like Frame.cc:456,490 */
-} so_camera;
+/* (so_camera is declared with the matcher's types above) */
 
 typedef struct so_frame_ctx so_frame_ctx;
 int so_frame_create(int device, so_frame_ctx** out);

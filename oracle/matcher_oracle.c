@@ -35,8 +35,10 @@ typedef struct {
 } orc_grid;
 
 static int pos_in_grid(const orc_frame_view* F, int i, int* px, int* py) {
-    *px = (int)roundf((F->x[i] - F->min_x) * F->grid_inv_w);
-    *py = (int)roundf((F->y[i] - F->min_y) * F->grid_inv_h);
+    const float ox = F->has_grid_origin ? F->grid_min_x : F->min_x; /* the origin the cells were assigned with */
+    const float oy = F->has_grid_origin ? F->grid_min_y : F->min_y;
+    *px = (int)roundf((F->x[i] - ox) * F->grid_inv_w);
+    *py = (int)roundf((F->y[i] - oy) * F->grid_inv_h);
     if (*px < 0 || *px >= ORC_GRID_COLS || *py < 0 || *py >= ORC_GRID_ROWS) return 0;
     return 1;
 }

@@ -31,6 +31,11 @@ typedef struct {
     float grid_inv_w, grid_inv_h;     /* mfGridElementWidthInv / HeightInv */
     const float* scale_factors;       /* mvScaleFactors */
     int32_t nlevels;
+    /* A KeyFrame keeps the Frame's grid (filled with the Frame's float origin, KeyFrame.cc:66-72) but queries it with
+     * its own int-truncated bounds (KeyFrame.h:220, KeyFrame.cc:779-818): has_grid_origin != 0 -> PosInGrid used
+     * (grid_min_x, grid_min_y), GetFeaturesInArea / IsInImage use min_x .. max_y. */
+    int32_t has_grid_origin;
+    float grid_min_x, grid_min_y;
 } orc_frame_view;
 
 /* ORBmatcher::DescriptorDistance, code/src/ORBmatcher.cc:1511-1525 (SWAR popcount, literal) */

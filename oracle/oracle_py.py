@@ -172,13 +172,15 @@ class OrcFrameView(C.Structure):
                 ("angle", C.c_void_p), ("desc", C.c_void_p), ("excluded", C.c_void_p),
                 ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
                 ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("scale_factors", C.c_void_p),
-                ("nlevels", C.c_int32)]
+                ("nlevels", C.c_int32), ("has_grid_origin", C.c_int32), ("grid_min_x", C.c_float),
+                ("grid_min_y", C.c_float)]
 
 
 def _fv(F):
     p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
     return OrcFrameView(F.n, p(F.x), p(F.y), p(F.octave), p(F.angle), p(F.desc), p(F.excluded), F.min_x, F.max_x,
-                        F.min_y, F.max_y, F.grid_inv_w, F.grid_inv_h, p(F.scale_factors), len(F.scale_factors))
+                        F.min_y, F.max_y, F.grid_inv_w, F.grid_inv_h, p(F.scale_factors), len(F.scale_factors),
+                        getattr(F, "has_grid_origin", 0), getattr(F, "grid_min_x", 0.0), getattr(F, "grid_min_y", 0.0))
 
 
 def descriptor_distance(a, b):
@@ -494,3 +496,128 @@ def kf_search(query, store, th_low=50, nn_ratio=0.75, check_ori=True, min_votes=
         if nm >= min_matches:
             out.append((int(k), int(votes[k]), int(nm), m1))
     return votes, out, len(order)
+
+
+# ---- projection + gating half of Fuse / SearchBySim3 / keyframe-side SearchByProjection (project_oracle.h) ----------
+class OrcMapPointView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("Xw", C.c_void_p), ("normal", C.c_void_p), ("max_dist", C.c_void_p),
+                ("min_dist", C.c_void_p), ("desc", C.c_void_p), ("valid", C.c_void_p)]
+
+
+class OrcWindowQueries(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("active", "u", "v", "radius", "level")]
+
+
+def _mpv(mp):
+    """mp: dict with Xw, normal, max_dist, min_dist, desc, valid.  Returns (struct, keep-alive arrays)."""
+    a = dict(Xw=np.ascontiguousarray(mp["Xw"], np.float32), normal=np.ascontiguousarray(mp["normal"], np.float32),
+             max_dist=np.ascontiguousarray(mp["max_dist"], np.float32),
+             min_dist=np.ascontiguousarray(mp["min_dist"], np.float32), desc=np.ascontiguousarray(mp["desc"], np.uint8),
+             valid=np.ascontiguousarray(mp["valid"], np.uint8))
+    n = len(a["max_dist"])
+    return OrcMapPointView(n, _p(a["Xw"]), _p(a["normal"]), _p(a["max_dist"]), _p(a["min_dist"]), _p(a["desc"]),
+                           _p(a["valid"])), a
+
+
+def _wq(n):
+    q = dict(active=np.zeros(n, np.uint8), u=np.zeros(n, np.float32), v=np.zeros(n, np.float32),
+             radius=np.zeros(n, np.float32), level=np.zeros(n, np.int32))
+    return OrcWindowQueries(_p(q["active"]), _p(q["u"]), _p(q["v"]), _p(q["radius"]), _p(q["level"])), q
+
+
+def _f12(a, n=12):
+    return np.ascontiguousarray(a, np.float32).reshape(n)
+
+
+def sim3_decompose(Scw):
+    S = _f12(Scw)
+    R, t, Ow = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().orc_sim3_decompose(_p(S), _p(R), _p(t), _p(Ow))
+    return R.reshape(3, 3), t, Ow
+
+
+def fuse_queries(KF, cam, Tcw, log_sf, mp, th):
+    ms, _keep = _mpv(mp)
+    qs, q = _wq(ms.n)
+    fs, T = _fv(KF), _f12(Tcw)
+    lib().orc_fuse_queries(C.byref(fs), C.byref(cam), _p(T), C.c_float(log_sf), C.byref(ms), C.c_float(th), C.byref(qs))
+    return q
+
+
+def sim3_world_queries(KF, cam, Scw, log_sf, mp, th):
+    ms, _keep = _mpv(mp)
+    qs, q = _wq(ms.n)
+    fs, S = _fv(KF), _f12(Scw)
+    lib().orc_sim3_world_queries(C.byref(fs), C.byref(cam), _p(S), C.c_float(log_sf), C.byref(ms), C.c_float(th),
+                                 C.byref(qs))
+    return q
+
+
+def sim3_pair_queries(KF_target, cam, T_src_w, s12, R12, t12, to_2, log_sf, mp, th):
+    """One direction of SearchBySim3: to_2 = True projects keyframe 1's points into keyframe 2 (sR21, t21)."""
+    R, t = _f12(R12, 9), _f12(t12, 3)
+    sR12, sR21, t21 = np.zeros(9, np.float32), np.zeros(9, np.float32), np.zeros(3, np.float32)
+    lib().orc_sim3_relative(C.c_float(s12), _p(R), _p(t), _p(sR12), _p(sR21), _p(t21))
+    ms, _keep = _mpv(mp)
+    qs, q = _wq(ms.n)
+    fs, T = _fv(KF_target), _f12(T_src_w)
+    sR, tt = (sR21, t21) if to_2 else (sR12, t)
+    lib().orc_sim3_pair_queries(C.byref(fs), C.byref(cam), _p(T), _p(sR), _p(tt), C.c_float(log_sf), C.byref(ms),
+                                C.c_float(th), C.byref(qs))
+    return q
+
+
+def frame_kf_queries(F, cam, Tcw, log_sf, mp, th):
+    ms, _keep = _mpv(mp)
+    qs, q = _wq(ms.n)
+    fs, T = _fv(F), _f12(Tcw)
+    lib().orc_frame_kf_queries(C.byref(fs), C.byref(cam), _p(T), C.c_float(log_sf), C.byref(ms), C.c_float(th),
+                               C.byref(qs))
+    return q
+
+
+def fuse(KF, cam, Tcw, log_sf, inv_sigma2, mp, th):
+    """ORBmatcher::Fuse(pKF, vpMapPoints, th) up to the side effects.  Returns (nFused, best_idx, best_dist)."""
+    ms, _keep = _mpv(mp)
+    bi, bd = np.full(ms.n, -1, np.int32), np.full(ms.n, 256, np.int32)
+    fs, T, inv = _fv(KF), _f12(Tcw), np.ascontiguousarray(inv_sigma2, np.float32)
+    n = lib().orc_fuse(C.byref(fs), C.byref(cam), _p(T), C.c_float(log_sf), _p(inv), C.byref(ms), C.c_float(th), _p(bi),
+                       _p(bd))
+    return n, bi, bd
+
+
+def fuse_sim3(KF, cam, Scw, log_sf, mp, th):
+    ms, _keep = _mpv(mp)
+    bi, bd = np.full(ms.n, -1, np.int32), np.full(ms.n, 256, np.int32)
+    fs, S = _fv(KF), _f12(Scw)
+    n = lib().orc_fuse_sim3(C.byref(fs), C.byref(cam), _p(S), C.c_float(log_sf), C.byref(ms), C.c_float(th), _p(bi), _p(bd))
+    return n, bi, bd
+
+
+def search_by_sim3(KF1, KF2, cam, T1w, T2w, s12, R12, t12, log_sf1, log_sf2, mp1, mp2, th):
+    m1, _k1 = _mpv(mp1)
+    m2, _k2 = _mpv(mp2)
+    out = np.full(m1.n, -1, np.int32)
+    f1, f2 = _fv(KF1), _fv(KF2)
+    a, b, R, t = _f12(T1w), _f12(T2w), _f12(R12, 9), _f12(t12, 3)
+    n = lib().orc_search_by_sim3(C.byref(f1), C.byref(f2), C.byref(cam), _p(a), _p(b), C.c_float(s12), _p(R), _p(t),
+                                 C.c_float(log_sf1), C.c_float(log_sf2), C.byref(m1), C.byref(m2), C.c_float(th), _p(out))
+    return n, out
+
+
+def search_by_projection_sim3(KF, cam, Scw, log_sf, mp, th):
+    ms, _keep = _mpv(mp)
+    out = np.full(KF.n, -1, np.int32)
+    fs, S = _fv(KF), _f12(Scw)
+    n = lib().orc_search_by_projection_sim3(C.byref(fs), C.byref(cam), _p(S), C.c_float(log_sf), C.byref(ms), int(th),
+                                            _p(out))
+    return n, out
+
+
+def search_by_projection_frame_kf(F, cam, Tcw, log_sf, mp, mp_angle, th, orb_dist, check_ori=True):
+    ms, _keep = _mpv(mp)
+    out = np.full(F.n, -1, np.int32)
+    fs, T, ang = _fv(F), _f12(Tcw), np.ascontiguousarray(mp_angle, np.float32)
+    n = lib().orc_search_by_projection_frame_kf(C.byref(fs), C.byref(cam), _p(T), C.c_float(log_sf), C.byref(ms), _p(ang),
+                                                C.c_float(th), int(orb_dist), int(check_ori), _p(out))
+    return n, out

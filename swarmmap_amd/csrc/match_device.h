@@ -31,6 +31,7 @@ struct MatchFrameDev {
     // the candidates are in grid-traversal order, else null (vocabulary-node order: queries carry explicit ranges)
     const int32_t* col_start;
     float min_x, min_y, grid_inv_w, grid_inv_h;
+    float grid_min_y;  // origin the cell ROWS were assigned with (differs from min_y only for a KeyFrame's int bounds)
 };
 
 enum : uint32_t {
@@ -98,6 +99,37 @@ struct TrackQuerySrc {
     uint32_t excl_bits[kTrackMaxCandBits / 32];
     uint32_t skip_bits[kTrackMaxQueryBits / 32];
 };
+
+// Projection + gating half of the keyframe-side map-point searches: Fuse (code/src/
+// ORBmatcher.cc:767-815), Fuse / SearchByProjection with a Sim3 (:916-964, :286-333), one direction of SearchBySim3
+// (:1054-1094, :1130-1170) and SearchByProjection(Frame, KeyFrame, ...) (:1374-1410).  project_queries_kernel turns
+// every map point into the MatchQuery topk_window_kernel<0> consumes, in HBM, thread per point; the compact copy
+// (MatchQueryW) goes to host-mapped memory for the host's resolve loops and the parity tests.
+enum : uint32_t {
+    kPChain = 1u,       // SearchBySim3: Pc = B * (A * P + a) + b, dist3D = |Pc|, no viewing-angle gate
+    kPFrameForm = 2u,   // Frame overload: no depth test, u = fx * xc * invzc + cx, closed bounds, no viewing-angle gate
+    kPAngleGate = 4u,   // PO.dot(Pn) < 0.5 * dist3D -> skip
+};
+struct ProjectSrc {
+    const float* Xw;        // n x 3
+    const float* normal;    // n x 3 (kPAngleGate)
+    const float* max_dist;  // mfMaxDistance
+    const float* min_dist;  // mfMinDistance
+    const uint8_t* valid;   // the caller's object-graph gates
+    int n;
+    float A[12], B[12];     // [R | t] rows; B only with kPChain
+    float Ow[3];            // camera centre the distances are measured from (not with kPChain)
+    float fx, fy, cx, cy;
+    float bounds[4];        // mnMinX, mnMaxX, mnMinY, mnMaxY of the target
+    float scale[8];         // mvScaleFactors of the target
+    int nlevels;
+    float log_scale_factor, th;
+    uint32_t flags;
+    int level_above;        // octave window [pred - 1, pred + level_above]
+    uint32_t qflags;        // MatchQuery::flags of the produced queries (kQChi2Gate for Fuse)
+    int q_max_dist;         // MatchQuery::max_dist
+};
+void launch_project_queries(const ProjectSrc& S, MatchQuery* d_q, MatchQueryW* d_qw_mapped, hipStream_t s);
 
 void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_t s);
 // mode 2 = last-frame search, 3 = local-map search; queries [q_first, q_first + nq) write keys / counts at [0, nq)

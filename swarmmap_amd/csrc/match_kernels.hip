@@ -66,7 +66,7 @@ __device__ __forceinline__ bool pair_pred(const MatchFrameDev& F, const MatchQue
         const float dx = xy.x - Q.u, dy = xy.y - Q.v;
         ok = fabsf(dx) < Q.r && fabsf(dy) < Q.r;
         if (F.col_start) {  // the candidate's cell row (Frame::PosInGrid, :433-443) must be one of the visited rows
-            const int py = (int)roundf((xy.y - F.min_y) * F.grid_inv_h);
+            const int py = (int)roundf((xy.y - F.grid_min_y) * F.grid_inv_h);
             if (py < W.cy0 || py > W.cy1) ok = false;
         }
         if (check_levels) {
@@ -327,6 +327,85 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
             }
         }
     }
+}
+
+// ---------------- projection + gating half of Fuse / SearchBySim3 / the keyframe-side SearchByProjection ----------------
+// Thread per map point.  Every float / double operation is written in the order the reference's statements evaluate
+// it (code/src/ORBmatcher.cc:776-815, :923-964, :293-333, :1063-1094, :1380-1410) with the cv::Mat conventions of
+// oracle/project_oracle.h: one GEMM = double accumulation and one rounding, norm / dot in double.  A rejected point
+// leaves an inactive query behind (topk_window_kernel writes "no candidate" for it).
+__global__ __launch_bounds__(256) void project_queries_kernel(ProjectSrc S, MatchQuery* __restrict__ q_out,
+                                                              MatchQueryW* __restrict__ qw_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S.n) return;
+    MatchQuery Q = MatchQuery{};
+    Q.max_dist = S.q_max_dist;
+    Q.flags = S.qflags;
+    bool ok = S.valid[i] != 0;
+    const float P[3] = {S.Xw[3 * (size_t)i], S.Xw[3 * (size_t)i + 1], S.Xw[3 * (size_t)i + 2]};
+    float Pc[3];
+    track_camera_point(S.A, P, Pc);  // Rcw * p3Dw + tcw
+    if (S.flags & kPChain) {         // p3Dc2 = sR21 * p3Dc1 + t21
+        float P2[3];
+        track_camera_point(S.B, Pc, P2);
+        Pc[0] = P2[0]; Pc[1] = P2[1]; Pc[2] = P2[2];
+    }
+    float u, v;
+    if (S.flags & kPFrameForm) {  // :1383-1393
+        const float invzc = 1.0f / Pc[2];
+        u = S.fx * Pc[0] * invzc + S.cx;
+        v = S.fy * Pc[1] * invzc + S.cy;
+        if (u < S.bounds[0] || u > S.bounds[1]) ok = false;
+        if (v < S.bounds[2] || v > S.bounds[3]) ok = false;
+        if (!(u >= S.bounds[0] && v >= S.bounds[2])) ok = false;  // NaN
+    } else {
+        if (Pc[2] < 0.0f) ok = false;  // Depth must be positive
+        const float invz = 1.0f / Pc[2];
+        const float x = Pc[0] * invz;
+        const float y = Pc[1] * invz;
+        u = S.fx * x + S.cx;
+        v = S.fy * y + S.cy;
+        if (!(u >= S.bounds[0] && u < S.bounds[1] && v >= S.bounds[2] && v < S.bounds[3])) ok = false;  // IsInImage
+    }
+    const float max_d = S.max_dist[i], min_d = S.min_dist[i];
+    const float maxD = 1.2f * max_d, minD = 0.8f * min_d;
+    float PO[3] = {Pc[0], Pc[1], Pc[2]};  // SearchBySim3 measures the camera-frame point
+    if (!(S.flags & kPChain)) {
+        PO[0] = P[0] - S.Ow[0]; PO[1] = P[1] - S.Ow[1]; PO[2] = P[2] - S.Ow[2];
+    }
+    const double n2 = (double)PO[0] * (double)PO[0] + (double)PO[1] * (double)PO[1] + (double)PO[2] * (double)PO[2];
+    const float dist = (float)sqrt(n2);
+    if (dist < minD || dist > maxD) ok = false;
+    if (S.flags & kPAngleGate) {
+        const double dot = (double)PO[0] * (double)S.normal[3 * (size_t)i] + (double)PO[1] * (double)S.normal[3 * (size_t)i + 1] +
+                           (double)PO[2] * (double)S.normal[3 * (size_t)i + 2];
+        if (dot < 0.5 * (double)dist) ok = false;
+    }
+    int nScale = 0;
+    if (ok) {  // MapPoint::PredictScale
+        const float ratio = max_d / dist;
+        const float lr = (float)track_log((double)ratio);
+        nScale = (int)ceilf(lr / S.log_scale_factor);
+        if (nScale > S.nlevels - 1) nScale = S.nlevels - 1;
+        if (nScale < 0) nScale = 0;
+        Q.u = u;
+        Q.v = v;
+        Q.r = S.th * S.scale[nScale];
+        Q.min_level = nScale - 1;
+        Q.max_level = nScale + S.level_above;
+        Q.active = 1;
+    }
+    q_out[i] = Q;
+    MatchQueryW W;
+    W.u = Q.u; W.v = Q.v; W.r = Q.r;
+    W.min_level = (int8_t)Q.min_level; W.max_level = (int8_t)Q.max_level;
+    W.active = (uint8_t)Q.active; W.pad = 0;
+    qw_out[i] = W;
+}
+
+void launch_project_queries(const ProjectSrc& S, MatchQuery* d_q, MatchQueryW* d_qw_mapped, hipStream_t s) {
+    if (S.n <= 0) return;
+    hipLaunchKernelGGL(project_queries_kernel, dim3((S.n + 255) / 256), dim3(256), 0, s, S, d_q, d_qw_mapped);
 }
 
 // Copy the staged inputs from pinned host memory into HBM with a kernel on the matcher's own queue: a ~100 KB

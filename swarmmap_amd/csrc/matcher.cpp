@@ -162,6 +162,7 @@ struct so_matcher {
         std::chrono::steady_clock::time_point t_launched;
     } pend;
     float min_x = 0.f, min_y = 0.f, grid_inv_w = 0.f, grid_inv_h = 0.f;
+    float grid_min_y = 0.f, grid_min_x = 0.f;  // origin the resident candidates' cells were assigned with
     std::vector<int> perm;     // rank -> keypoint index
     std::vector<int> cell_count;
 };
@@ -170,8 +171,10 @@ namespace {
 
 // Frame::PosInGrid, code/src/Frame.cc:433-443
 inline bool pos_in_grid(const so_frame_view* F, int i, int& px, int& py) {
-    px = (int)roundf((F->x[i] - F->min_x) * F->grid_inv_w);
-    py = (int)roundf((F->y[i] - F->min_y) * F->grid_inv_h);
+    const float ox = F->has_grid_origin ? F->grid_min_x : F->min_x;  // the origin the cells were assigned with
+    const float oy = F->has_grid_origin ? F->grid_min_y : F->min_y;
+    px = (int)roundf((F->x[i] - ox) * F->grid_inv_w);
+    py = (int)roundf((F->y[i] - oy) * F->grid_inv_h);
     return !(px < 0 || px >= kGridCols || py < 0 || py >= kGridRows);
 }
 
@@ -229,7 +232,9 @@ int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_
     const int n = F->n;
     const bool reuse = reuse_requested && m->src == nullptr && m->resident_n == n && m->has_cols &&
                        m->res_desc == F->desc && m->res_x == F->x && m->res_y == F->y && m->min_x == F->min_x &&
-                       m->min_y == F->min_y && m->grid_inv_w == F->grid_inv_w && m->grid_inv_h == F->grid_inv_h;
+                       m->min_y == F->min_y && m->grid_inv_w == F->grid_inv_w && m->grid_inv_h == F->grid_inv_h &&
+                       m->grid_min_x == (F->has_grid_origin ? F->grid_min_x : F->min_x) &&
+                       m->grid_min_y == (F->has_grid_origin ? F->grid_min_y : F->min_y);
     if (reuse) {  // same frame as the previous call on this handle: only the eligibility gate is re-read
         const bool want_limit = (F->excluded != nullptr) || (limit_by_idx != nullptr);
         if (want_limit) {
@@ -272,6 +277,8 @@ int upload_frame(so_matcher* m, const so_frame_view* F, const int32_t* limit_by_
     m->resident_n = n;
     m->res_desc = F->desc; m->res_x = F->x; m->res_y = F->y;
     m->min_x = F->min_x; m->min_y = F->min_y; m->grid_inv_w = F->grid_inv_w; m->grid_inv_h = F->grid_inv_h;
+    m->grid_min_x = F->has_grid_origin ? F->grid_min_x : F->min_x;
+    m->grid_min_y = F->has_grid_origin ? F->grid_min_y : F->min_y;
     return SO_OK;
 }
 
@@ -301,6 +308,8 @@ int use_dframe(so_matcher* m, const so_dframe* f, const uint8_t* excluded) {
     m->resident_n = -1;
     m->min_x = f->bounds[0];
     m->min_y = f->bounds[2];
+    m->grid_min_x = f->bounds[0];
+    m->grid_min_y = f->bounds[2];
     m->grid_inv_w = (float)kGridCols / (f->bounds[1] - f->bounds[0]);  // Frame.cc:259-260
     m->grid_inv_h = (float)kGridRows / (f->bounds[3] - f->bounds[2]);
     m->off_oct = m->off_desc = m->off_cols = 0;
@@ -369,6 +378,7 @@ MatchFrameDev frame_dev(const so_matcher* m) {
     F.col_start = m->has_cols ? (const int32_t*)(base + m->off_cols) : nullptr;
     if (m->src) F.col_start = m->src->d_col_start;
     F.min_x = m->min_x; F.min_y = m->min_y; F.grid_inv_w = m->grid_inv_w; F.grid_inv_h = m->grid_inv_h;
+    F.grid_min_y = m->grid_min_y;
     return F;
 }
 
@@ -1353,6 +1363,64 @@ int so_search_for_triangulation(so_matcher* m, int32_t n1, const float* x1, cons
     return SO_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// The sequential part of the greedy window searches (ORBmatcher.cc:345-368, :1423-1452) over the K-lists of a finished
+// launch (m->h_keys / m->h_count): a keypoint bound on entry never appears in a list (limit gate), one taken by an
+// earlier query of this call is skipped here; a query whose list is exhausted that way is re-run exactly.
+int resolve_greedy(so_matcher* m, const so_frame_view* F, int nq, const MatchQuery* queries, const uint8_t* qdesc,
+                   const float* q_angle, int32_t max_dist, int check_orientation, int K, int32_t* kp_to_query,
+                   int32_t* nmatches) {
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
+    const int32_t* cnt = (const int32_t*)m->h_count.p;
+    std::vector<int32_t> gate;
+    std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
+    rot_item.clear();
+    rot_b.clear();
+    int hist[HISTO_LENGTH] = {0};
+    int nm = 0, rc;
+    for (int i = 0; i < nq; i++) {
+        if (!queries[(size_t)i].active || cnt[(size_t)i] == 0) continue;
+        Entry e[1];
+        int found = 0, walked = 0;
+        for (; walked < K && found < 1; walked++) {
+            const uint32_t key = keys[(size_t)i * K + walked];
+            if (key == 0xFFFFFFFFu) break;
+            const int idx = m->perm[(size_t)(key & 0xFFFFu)];
+            if (kp_to_query[idx] >= 0) continue;
+            e[0].idx = idx;
+            e[0].dist = (int)(key >> 16);
+            found++;
+        }
+        if (found < 1 && walked == K && cnt[(size_t)i] > K) {
+            gate.assign((size_t)F->n, INT_MAX);
+            for (int k = 0; k < F->n; k++)
+                if ((F->excluded && F->excluded[k]) || kp_to_query[k] >= 0) gate[(size_t)k] = 0;
+            if ((rc = rerun_single(m, queries[(size_t)i], qdesc + (size_t)i * 32, gate, 1, e, &found))) return rc;
+        }
+        if (found == 0) continue;
+        if (e[0].dist <= max_dist) {
+            kp_to_query[e[0].idx] = i;
+            nm++;
+            if (check_orientation) {
+                const int b = rot_bin(q_angle[i], F->angle[e[0].idx]);
+                rot_item.push_back(e[0].idx);
+                rot_b.push_back(b);
+                hist[b]++;
+            }
+        }
+    }
+    if (check_orientation) apply_rot_hist(hist, rot_item, rot_b, kp_to_query, nm);
+    *nmatches = nm;
+    return SO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int so_search_window_best(so_matcher* m, const so_frame_view* KF, int32_t nq, const uint8_t* valid, const float* u,
                           const float* v, const float* radius, const int32_t* pred_level, const uint8_t* qdesc,
                           int chi2_gate, const float* inv_sigma2, int32_t* best_idx, int32_t* best_dist) {
@@ -1430,49 +1498,348 @@ int so_search_window_greedy(so_matcher* m, const so_frame_view* F, int32_t nq, c
     }
     memcpy(m->h_qdesc.p, qdesc, (size_t)nq * 32);
     if ((rc = run_topk(m, nq, K))) return rc;
-    const uint32_t* keys = (const uint32_t*)m->h_keys.p;  // host-mapped, read in place (re-runs use their own staging)
-    const int32_t* cnt = (const int32_t*)m->h_count.p;
-    const MatchQuery* queries = hq;
-    std::vector<int32_t> gate;
-    std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
-    rot_item.clear();
-    rot_b.clear();
-    int hist[HISTO_LENGTH] = {0};
-    int nm = 0;
-    for (int i = 0; i < nq; i++) {
-        if (!queries[(size_t)i].active || cnt[(size_t)i] == 0) continue;
-        Entry e[1];
-        int found = 0, walked = 0;
-        for (; walked < K && found < 1; walked++) {
-            const uint32_t key = keys[(size_t)i * K + walked];
-            if (key == 0xFFFFFFFFu) break;
-            const int idx = m->perm[(size_t)(key & 0xFFFFu)];
-            if (kp_to_query[idx] >= 0) continue;
-            e[0].idx = idx;
-            e[0].dist = (int)(key >> 16);
-            found++;
+    return resolve_greedy(m, F, nq, hq, qdesc, q_angle, max_dist, check_orientation, K, kp_to_query, nmatches);
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Keyframe-side map-point searches with the projection on the device: Fuse x2, SearchBySim3,
+// SearchByProjection(KeyFrame, Scw) and SearchByProjection(Frame, KeyFrame).  Per call: the target's candidates and
+// the map points' fields go up in one staging block; project_queries_kernel (thread per map point) writes the window
+// queries in HBM, topk_window_kernel (wave per query) reads them from there - no host hop between the two - and the
+// host receives the K-lists plus a compact copy of the queries (for the sequential resolve and the parity tests).
+// =====================================================================================================
+namespace {
+
+// cv::Mat conventions of oracle/project_oracle.h, evaluated once per call on the host.
+void sim3_decompose(const float* S, float* A12, float* Ow) {  // ORBmatcher.cc:272-277 = :901-906
+    const double d = (double)S[0] * (double)S[0] + (double)S[1] * (double)S[1] + (double)S[2] * (double)S[2];
+    const float scw = (float)std::sqrt(d);
+    const float inv = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) A12[4 * r + c] = S[4 * r + c] * inv;  // Rcw = sRcw / scw, tcw = Scw.col(3) / scw
+    for (int j = 0; j < 3; j++) {  // Ow = -Rcw.t() * tcw
+        const double s = (double)A12[0 + j] * (double)A12[3] + (double)A12[4 + j] * (double)A12[7] + (double)A12[8 + j] * (double)A12[11];
+        Ow[j] = (float)(-s);
+    }
+}
+
+void camera_center(const float* T, float* Ow) {  // KeyFrame::SetPose / Frame::UpdatePoseMatrices: Ow = -Rcw.t() * tcw
+    for (int j = 0; j < 3; j++) {
+        const double s = (double)T[0 + j] * (double)T[3] + (double)T[4 + j] * (double)T[7] + (double)T[8 + j] * (double)T[11];
+        Ow[j] = (float)(-s);
+    }
+}
+
+// sR12 = s12 * R12, sR21 = (1.0 / s12) * R12.t(), t21 = -sR21 * t12 (ORBmatcher.cc:1027-1029) as [sR | t] rows
+void sim3_relative(float s12, const float* R12, const float* t12, float* B12_12, float* B21_12) {
+    const float inv = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) {
+            B12_12[4 * r + c] = R12[3 * r + c] * s12;
+            B21_12[4 * r + c] = R12[3 * c + r] * inv;
         }
-        if (found < 1 && walked == K && cnt[(size_t)i] > K) {
-            gate.assign((size_t)F->n, INT_MAX);
-            for (int k = 0; k < F->n; k++)
-                if ((F->excluded && F->excluded[k]) || kp_to_query[k] >= 0) gate[(size_t)k] = 0;
-            if ((rc = rerun_single(m, queries[(size_t)i], qdesc + (size_t)i * 32, gate, 1, e, &found))) return rc;
+        B12_12[4 * r + 3] = t12[r];
+    }
+    for (int r = 0; r < 3; r++) {
+        const double s = (double)B21_12[4 * r] * (double)t12[0] + (double)B21_12[4 * r + 1] * (double)t12[1] +
+                         (double)B21_12[4 * r + 2] * (double)t12[2];
+        B21_12[4 * r + 3] = (float)(-s);
+    }
+}
+
+bool mappoints_ok(const so_mappoint_view* mp, bool need_normal) {
+    if (!mp || mp->n < 0) return false;
+    if (mp->n == 0) return true;
+    return mp->Xw && mp->max_dist && mp->min_dist && mp->desc && (!need_normal || mp->normal);
+}
+
+void fill_target(ProjectSrc& S, const so_frame_view* F, const so_camera* cam, float log_scale_factor, float th) {
+    S.fx = cam->fx; S.fy = cam->fy; S.cx = cam->cx; S.cy = cam->cy;
+    S.bounds[0] = F->min_x; S.bounds[1] = F->max_x; S.bounds[2] = F->min_y; S.bounds[3] = F->max_y;
+    for (int l = 0; l < 8; l++) S.scale[l] = l < F->nlevels ? F->scale_factors[l] : 0.f;
+    S.nlevels = F->nlevels;
+    S.log_scale_factor = log_scale_factor;
+    S.th = th;
+}
+
+bool target_ok(const so_frame_view* F, const so_camera* cam) {
+    return frame_ok(F) && cam && F->scale_factors && F->nlevels >= 1 && F->nlevels <= 8;
+}
+
+// Stages the map points behind the resident candidates, runs projection + window search (K-lists of length K) and
+// waits.  Afterwards m->h_keys / m->h_count hold the lists and `qw` points at the compact queries (host-mapped).
+int run_projected(so_matcher* m, const so_mappoint_view* mp, ProjectSrc& S, int K, const MatchQueryW** qw) {
+    const int n = mp->n;
+    const size_t off_qdesc = m->frame_end;
+    const size_t off_xw = align256(off_qdesc + 32 * (size_t)n);
+    const size_t off_nrm = align256(off_xw + 12 * (size_t)n);
+    const size_t off_maxd = align256(off_nrm + 12 * (size_t)n);
+    const size_t off_mind = align256(off_maxd + 4 * (size_t)n);
+    const size_t off_valid = align256(off_mind + 4 * (size_t)n);
+    const size_t staged_end = align256(off_valid + (size_t)n);
+    const size_t off_q = staged_end;  // device only: written by project_queries_kernel
+    const size_t total_dev = off_q + sizeof(MatchQuery) * (size_t)n;
+    int rc;
+    if ((rc = m->h_in.ensure_keep(staged_end + 256, m->frame_end))) return rc;
+    uint8_t* hb = (uint8_t*)m->h_in.p;
+    memcpy(hb + off_qdesc, mp->desc, 32 * (size_t)n);
+    memcpy(hb + off_xw, mp->Xw, 12 * (size_t)n);
+    if (mp->normal) memcpy(hb + off_nrm, mp->normal, 12 * (size_t)n);
+    memcpy(hb + off_maxd, mp->max_dist, 4 * (size_t)n);
+    memcpy(hb + off_mind, mp->min_dist, 4 * (size_t)n);
+    if (mp->valid) memcpy(hb + off_valid, mp->valid, (size_t)n);
+    else memset(hb + off_valid, 1, (size_t)n);
+    if (m->d_in.cap < total_dev) {
+        if ((rc = m->d_in.ensure(std::max(m->h_in.cap, total_dev)))) return rc;
+        m->dirty_from = 0;
+    }
+    m->off_q = off_q;
+    m->off_qdesc = off_qdesc;
+    m->h_q.p = nullptr;
+    m->h_qdesc.p = hb + off_qdesc;
+    const size_t keys_bytes = align256(sizeof(uint32_t) * (size_t)n * K);
+    const size_t cnt_bytes = align256(sizeof(int32_t) * (size_t)n);
+    if ((rc = m->h_out.ensure(keys_bytes + cnt_bytes + sizeof(MatchQueryW) * (size_t)n))) return rc;
+    uint8_t* db = (uint8_t*)m->d_in.p;
+    S.Xw = (const float*)(db + off_xw);
+    S.normal = (const float*)(db + off_nrm);
+    S.max_dist = (const float*)(db + off_maxd);
+    S.min_dist = (const float*)(db + off_mind);
+    S.valid = db + off_valid;
+    S.n = n;
+    hipStream_t s = m->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t from = std::min(m->dirty_from, off_qdesc) & ~(size_t)15;
+    launch_stage_in(db + from, hb + from, staged_end - from, s);
+    m->dirty_from = SIZE_MAX;
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_project_queries(S, (MatchQuery*)(db + off_q), (MatchQueryW*)((uint8_t*)m->h_out.dev + keys_bytes + cnt_bytes), s);
+    launch_topk_window(frame_dev(m), db + off_q, false, (const uint4*)(db + off_qdesc), n, K, (uint32_t*)m->h_out.dev,
+                       (int32_t*)((uint8_t*)m->h_out.dev + keys_bytes), s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    const auto t1 = std::chrono::steady_clock::now();
+    SO_HIP(hipStreamSynchronize(s));
+    const auto t2 = std::chrono::steady_clock::now();
+    m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    m->stat[2] += 2.0;
+    m->stat[3] += (double)(staged_end - from);
+    m->h_keys.p = m->h_out.p;
+    m->h_count.p = (uint8_t*)m->h_out.p + keys_bytes;
+    *qw = (const MatchQueryW*)((const uint8_t*)m->h_out.p + keys_bytes + cnt_bytes);
+    float ms = 0.f;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    return SO_OK;
+}
+
+void export_queries(const so_window_queries* out, const MatchQueryW* qw, int n) {
+    if (!out) return;
+    for (int i = 0; i < n; i++) {
+        if (out->active) out->active[i] = qw[i].active;
+        if (out->u) out->u[i] = qw[i].u;
+        if (out->v) out->v[i] = qw[i].v;
+        if (out->radius) out->radius[i] = qw[i].r;
+        if (out->level) out->level[i] = qw[i].active ? qw[i].min_level + 1 : 0;
+    }
+}
+
+void begin_call(so_matcher* m) {
+    m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
+}
+
+// Best keypoint per projected map point (K = 1): Fuse x2 and each direction of SearchBySim3.
+int projected_best(so_matcher* m, const so_frame_view* KF, const so_mappoint_view* mp, ProjectSrc& S, bool chi2_gate,
+                   const float* inv_sigma2, bool reuse, int32_t* best_idx, int32_t* best_dist,
+                   const so_window_queries* queries_out) {
+    const int n = mp->n;
+    for (int i = 0; i < n; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+    }
+    if (n == 0) return SO_OK;
+    for (int l = 0; l < 8; l++) m->inv_sigma2[l] = (chi2_gate && l < KF->nlevels) ? inv_sigma2[l] : 0.f;
+    so_frame_view view = *KF;
+    view.excluded = nullptr;  // Fuse / SearchBySim3 look at every keypoint of the keyframe
+    int rc = upload_frame(m, &view, nullptr, reuse);
+    if (rc) return rc;
+    S.level_above = 0;
+    S.qflags = chi2_gate ? (uint32_t)kQChi2Gate : 0u;
+    S.q_max_dist = 256;
+    const MatchQueryW* qw = nullptr;
+    if ((rc = run_projected(m, mp, S, 1, &qw))) return rc;
+    export_queries(queries_out, qw, n);
+    if (KF->n == 0) return SO_OK;
+    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
+    for (int i = 0; i < n; i++)
+        if (keys[i] != 0xFFFFFFFFu) {
+            best_idx[i] = m->perm[(size_t)(keys[i] & 0xFFFFu)];
+            best_dist[i] = (int32_t)(keys[i] >> 16);
         }
-        if (found == 0) continue;
-        if (e[0].dist <= max_dist) {
-            kp_to_query[e[0].idx] = i;
-            nm++;
-            if (check_orientation) {
-                const int b = rot_bin(q_angle[i], F->angle[e[0].idx]);
-                rot_item.push_back(e[0].idx);
-                rot_b.push_back(b);
-                hist[b]++;
-            }
+    return SO_OK;
+}
+
+// Sequential greedy binding per projected map point: the two keyframe-side SearchByProjection overloads.
+int projected_greedy(so_matcher* m, const so_frame_view* F, const so_mappoint_view* mp, ProjectSrc& S, int level_above,
+                     const float* q_angle, int max_dist, int check_orientation, bool reuse, int32_t* kp_to_point,
+                     int32_t* nmatches, const so_window_queries* queries_out) {
+    constexpr int K = 4;
+    const int n = mp->n;
+    *nmatches = 0;
+    for (int k = 0; k < F->n; k++) kp_to_point[k] = -1;
+    if (n == 0) return SO_OK;
+    int rc = upload_frame(m, F, nullptr, reuse);
+    if (rc) return rc;
+    S.level_above = level_above;
+    S.qflags = 0;
+    S.q_max_dist = 256;
+    const MatchQueryW* qw = nullptr;
+    if ((rc = run_projected(m, mp, S, K, &qw))) return rc;
+    export_queries(queries_out, qw, n);
+    if (F->n == 0) return SO_OK;
+    std::vector<MatchQuery> hq((size_t)n);
+    for (int i = 0; i < n; i++) hq[(size_t)i] = expand_query(qw[i]);
+    return resolve_greedy(m, F, n, hq.data(), mp->desc, q_angle, max_dist, check_orientation, K, kp_to_point, nmatches);
+}
+
+int keep_within(int n, int32_t* best_idx, const int32_t* best_dist, int th) {
+    int kept = 0;
+    for (int i = 0; i < n; i++) {
+        if (best_idx[i] >= 0 && best_dist[i] <= th) kept++;
+        else best_idx[i] = -1;
+    }
+    return kept;
+}
+
+}  // namespace
+
+extern "C" {
+
+int so_fuse(so_matcher* m, const so_frame_view* KF, const so_camera* cam, const float* Tcw12, float log_scale_factor,
+            const float* inv_level_sigma2, const so_mappoint_view* mp, float th, int32_t* best_idx, int32_t* best_dist,
+            int32_t* n_fused, const so_window_queries* queries_out) {
+    if (!m || !target_ok(KF, cam) || !Tcw12 || !inv_level_sigma2 || !mappoints_ok(mp, true) || !n_fused)
+        return SO_ERR_INVALID_ARG;
+    if (mp->n > 0 && (!best_idx || !best_dist)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    begin_call(m);
+    const bool reuse = take_reuse(m);
+    *n_fused = 0;
+    ProjectSrc S{};
+    memcpy(S.A, Tcw12, sizeof(S.A));
+    camera_center(Tcw12, S.Ow);  // pKF->GetCameraCenter()
+    S.flags = kPAngleGate;
+    fill_target(S, KF, cam, log_scale_factor, th);
+    const int rc = projected_best(m, KF, mp, S, true, inv_level_sigma2, reuse, best_idx, best_dist, queries_out);
+    if (rc) return rc;
+    *n_fused = keep_within(mp->n, best_idx, best_dist, TH_LOW);  // ORBmatcher.cc:873
+    return SO_OK;
+}
+
+int so_fuse_sim3(so_matcher* m, const so_frame_view* KF, const so_camera* cam, const float* Scw12, float log_scale_factor,
+                 const so_mappoint_view* mp, float th, int32_t* best_idx, int32_t* best_dist, int32_t* n_fused,
+                 const so_window_queries* queries_out) {
+    if (!m || !target_ok(KF, cam) || !Scw12 || !mappoints_ok(mp, true) || !n_fused) return SO_ERR_INVALID_ARG;
+    if (mp->n > 0 && (!best_idx || !best_dist)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    begin_call(m);
+    const bool reuse = take_reuse(m);
+    *n_fused = 0;
+    ProjectSrc S{};
+    sim3_decompose(Scw12, S.A, S.Ow);
+    S.flags = kPAngleGate;
+    fill_target(S, KF, cam, log_scale_factor, th);
+    const int rc = projected_best(m, KF, mp, S, false, nullptr, reuse, best_idx, best_dist, queries_out);
+    if (rc) return rc;
+    *n_fused = keep_within(mp->n, best_idx, best_dist, TH_LOW);  // :995
+    return SO_OK;
+}
+
+int so_search_by_sim3(so_matcher* m, const so_frame_view* KF1, const so_frame_view* KF2, const so_camera* cam,
+                      const float* T1w12, const float* T2w12, float s12, const float* R12, const float* t12,
+                      float log_scale_factor1, float log_scale_factor2, const so_mappoint_view* mp1,
+                      const so_mappoint_view* mp2, float th, int32_t* match12, int32_t* n_found,
+                      const so_window_queries* queries1_out, const so_window_queries* queries2_out) {
+    if (!m || !target_ok(KF1, cam) || !target_ok(KF2, cam) || !T1w12 || !T2w12 || !R12 || !t12 ||
+        !mappoints_ok(mp1, false) || !mappoints_ok(mp2, false) || !n_found)
+        return SO_ERR_INVALID_ARG;
+    if (mp1->n > 0 && !match12) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    begin_call(m);
+    (void)take_reuse(m);
+    *n_found = 0;
+    float B12[12], B21[12];
+    sim3_relative(s12, R12, t12, B12, B21);
+    const int N1 = mp1->n, N2 = mp2->n;
+    std::vector<int32_t> vnMatch1((size_t)N1, -1), vnMatch2((size_t)N2, -1), dist((size_t)std::max(N1, N2) + 1);
+    {   // Transform from KF1 to KF2 and search (:1054-1127)
+        ProjectSrc S{};
+        memcpy(S.A, T1w12, sizeof(S.A));
+        memcpy(S.B, B21, sizeof(S.B));
+        S.flags = kPChain;
+        fill_target(S, KF2, cam, log_scale_factor2, th);
+        const int rc = projected_best(m, KF2, mp1, S, false, nullptr, false, vnMatch1.data(), dist.data(), queries1_out);
+        if (rc) return rc;
+        keep_within(N1, vnMatch1.data(), dist.data(), TH_HIGH);
+    }
+    {   // Transform from KF2 to KF1 and search (:1130-1203)
+        ProjectSrc S{};
+        memcpy(S.A, T2w12, sizeof(S.A));
+        memcpy(S.B, B12, sizeof(S.B));
+        S.flags = kPChain;
+        fill_target(S, KF1, cam, log_scale_factor1, th);
+        const int rc = projected_best(m, KF1, mp2, S, false, nullptr, false, vnMatch2.data(), dist.data(), queries2_out);
+        if (rc) return rc;
+        keep_within(N2, vnMatch2.data(), dist.data(), TH_HIGH);
+    }
+    int nFound = 0;  // Check agreement (:1205-1218)
+    for (int i1 = 0; i1 < N1; i1++) {
+        match12[i1] = -1;
+        const int idx2 = vnMatch1[(size_t)i1];
+        if (idx2 >= 0 && idx2 < N2 && vnMatch2[(size_t)idx2] == i1) {
+            match12[i1] = idx2;
+            nFound++;
         }
     }
-    if (check_orientation) apply_rot_hist(hist, rot_item, rot_b, kp_to_query, nm);
-    *nmatches = nm;
+    *n_found = nFound;
     return SO_OK;
+}
+
+int so_search_by_projection_sim3(so_matcher* m, const so_frame_view* KF, const so_camera* cam, const float* Scw12,
+                                 float log_scale_factor, const so_mappoint_view* mp, int th, int32_t* kp_to_point,
+                                 int32_t* nmatches, const so_window_queries* queries_out) {
+    if (!m || !target_ok(KF, cam) || !Scw12 || !mappoints_ok(mp, true) || !kp_to_point || !nmatches)
+        return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    begin_call(m);
+    const bool reuse = take_reuse(m);
+    ProjectSrc S{};
+    sim3_decompose(Scw12, S.A, S.Ow);
+    S.flags = kPAngleGate;
+    fill_target(S, KF, cam, log_scale_factor, (float)th);
+    return projected_greedy(m, KF, mp, S, 0, nullptr, TH_LOW, 0, reuse, kp_to_point, nmatches, queries_out);
+}
+
+int so_search_by_projection_keyframe(so_matcher* m, const so_frame_view* F, const so_camera* cam, const float* Tcw12,
+                                     float log_scale_factor, const so_mappoint_view* mp, const float* mp_angle, float th,
+                                     int32_t orb_dist, int check_orientation, int32_t* kp_to_point, int32_t* nmatches,
+                                     const so_window_queries* queries_out) {
+    if (!m || !target_ok(F, cam) || !Tcw12 || !mappoints_ok(mp, false) || !kp_to_point || !nmatches)
+        return SO_ERR_INVALID_ARG;
+    if (check_orientation && mp->n > 0 && (!mp_angle || !F->angle)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    begin_call(m);
+    const bool reuse = take_reuse(m);
+    ProjectSrc S{};
+    memcpy(S.A, Tcw12, sizeof(S.A));
+    camera_center(Tcw12, S.Ow);  // Ow = -Rcw.t() * tcw, :1362
+    S.flags = kPFrameForm;
+    fill_target(S, F, cam, log_scale_factor, th);
+    return projected_greedy(m, F, mp, S, 1, mp_angle, orb_dist, check_orientation, reuse, kp_to_point, nmatches,
+                            queries_out);
 }
 
 }  // extern "C"

@@ -185,6 +185,75 @@ int ORBmatcher::SearchByProjection(const so_frame_view& F, const WindowQueries& 
     return nmatches;
 }
 
+static so_camera camera_of(const ORBmatcher::Calibration& c) {
+    so_camera cam{};
+    cam.fx = c.fx; cam.fy = c.fy; cam.cx = c.cx; cam.cy = c.cy;
+    return cam;
+}
+
+int ORBmatcher::Fuse(const so_frame_view& KF, const Calibration& cal, const Pose& Tcw, const MapPointFields& mp, float th,
+                     std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
+    const so_camera cam = camera_of(cal);
+    const so_mappoint_view v = mp.view();
+    bestIdx.assign((size_t)mp.size(), -1);
+    bestDist.assign((size_t)mp.size(), 256);
+    int32_t nFused = 0;
+    check(so_fuse(handle_, &KF, &cam, Tcw.m, cal.mfLogScaleFactor, cal.mvInvLevelSigma2.data(), &v, th, bestIdx.data(),
+                  bestDist.data(), &nFused, nullptr),
+          "so_fuse");
+    return nFused;
+}
+
+int ORBmatcher::Fuse(const so_frame_view& KF, const Calibration& cal, const Sim3& Scw, const MapPointFields& mp, float th,
+                     std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
+    const so_camera cam = camera_of(cal);
+    const so_mappoint_view v = mp.view();
+    bestIdx.assign((size_t)mp.size(), -1);
+    bestDist.assign((size_t)mp.size(), 256);
+    int32_t nFused = 0;
+    check(so_fuse_sim3(handle_, &KF, &cam, Scw.m, cal.mfLogScaleFactor, &v, th, bestIdx.data(), bestDist.data(), &nFused,
+                       nullptr),
+          "so_fuse_sim3");
+    return nFused;
+}
+
+int ORBmatcher::SearchBySim3(const so_frame_view& KF1, const Calibration& cal1, const Pose& T1w, const so_frame_view& KF2,
+                             const Calibration& cal2, const Pose& T2w, const MapPointFields& mp1, const MapPointFields& mp2,
+                             float s12, const float R12[9], const float t12[3], float th, std::vector<int32_t>& vnMatch12) {
+    const so_camera cam = camera_of(cal1);  // pKF1's intrinsics serve both directions, :1013-1016
+    const so_mappoint_view v1 = mp1.view(), v2 = mp2.view();
+    vnMatch12.assign((size_t)mp1.size(), -1);
+    int32_t nFound = 0;
+    check(so_search_by_sim3(handle_, &KF1, &KF2, &cam, T1w.m, T2w.m, s12, R12, t12, cal1.mfLogScaleFactor,
+                            cal2.mfLogScaleFactor, &v1, &v2, th, vnMatch12.data(), &nFound, nullptr, nullptr),
+          "so_search_by_sim3");
+    return nFound;
+}
+
+int ORBmatcher::SearchByProjection(const so_frame_view& KF, const Calibration& cal, const Sim3& Scw, const MapPointFields& mp,
+                                   int th, std::vector<int32_t>& kp_to_point) {
+    const so_camera cam = camera_of(cal);
+    const so_mappoint_view v = mp.view();
+    kp_to_point.assign((size_t)KF.n, -1);
+    int32_t nmatches = 0;
+    check(so_search_by_projection_sim3(handle_, &KF, &cam, Scw.m, cal.mfLogScaleFactor, &v, th, kp_to_point.data(), &nmatches,
+                                       nullptr),
+          "so_search_by_projection_sim3");
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(const so_frame_view& F, const Calibration& cal, const Pose& Tcw, const MapPointFields& mp,
+                                   float th, int ORBdist, std::vector<int32_t>& kp_to_point) {
+    const so_camera cam = camera_of(cal);
+    const so_mappoint_view v = mp.view();
+    kp_to_point.assign((size_t)F.n, -1);
+    int32_t nmatches = 0;
+    check(so_search_by_projection_keyframe(handle_, &F, &cam, Tcw.m, cal.mfLogScaleFactor, &v, mp.angle.data(), th, ORBdist,
+                                           mbCheckOrientation ? 1 : 0, kp_to_point.data(), &nmatches, nullptr),
+          "so_search_by_projection_keyframe");
+    return nmatches;
+}
+
 std::vector<int32_t> ORBmatcher::ComputeDistinctiveDescriptors(const std::vector<int32_t>& offsets,
                                                                const std::vector<uint8_t>& descriptors) {
     const int n = (int)offsets.size() - 1;

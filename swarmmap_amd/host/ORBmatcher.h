@@ -108,6 +108,51 @@ public:
     // SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) — :1356-1473
     int SearchByProjection(const so_frame_view& CurrentFrame, const WindowQueries& vpKFPoints, int ORBdist,
                            std::vector<int32_t>& kp_to_point);
+    // ---- the same five routines with the projection on the device (so_fuse, so_fuse_sim3, so_search_by_sim3,
+    //      so_search_by_projection_sim3, so_search_by_projection_keyframe): the caller hands over what the reference's
+    //      loops read from each MapPoint and from the keyframe; projection, gates, PredictScale, window search and the
+    //      routine's thresholds run behind the C ABI.  Map side effects stay with the caller. ----
+    struct MapPointFields {                     // one entry per element of vpMapPoints
+        std::vector<float> Xw, normal;          // GetWorldPos() (GetGlobalPos() where the routine says so), GetNormal()
+        std::vector<float> max_dist, min_dist;  // mfMaxDistance, mfMinDistance
+        std::vector<uint8_t> desc;              // GetDescriptor(), 32 B each
+        std::vector<uint8_t> valid;             // pMP && !pMP->isBad() && the routine's own exclusions
+        std::vector<float> angle;               // SearchByProjection(Frame, KeyFrame): pKF->mvKeysUn[i].angle
+        int size() const { return (int)max_dist.size(); }
+        so_mappoint_view view() const {
+            so_mappoint_view v{};
+            v.n = size(); v.Xw = Xw.data(); v.normal = normal.empty() ? nullptr : normal.data();
+            v.max_dist = max_dist.data(); v.min_dist = min_dist.data(); v.desc = desc.data();
+            v.valid = valid.empty() ? nullptr : valid.data();
+            return v;
+        }
+    };
+    struct Calibration {                        // of the target KeyFrame / Frame
+        float fx, fy, cx, cy;
+        float mfLogScaleFactor;
+        std::vector<float> mvInvLevelSigma2;    // Fuse(pKF, vpMapPoints) only
+    };
+    struct Pose { float m[12]; };               // [Rcw | tcw], row-major 3 x 4
+    struct Sim3 { float m[12]; };               // rows 0-2 of Scw
+    // Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) — :751-891.  bestIdx[i] = keypoint of pKF to fuse map
+    // point i with (bestDist <= TH_LOW) or -1; returns their number.
+    int Fuse(const so_frame_view& pKF, const Calibration& cal, const Pose& Tcw, const MapPointFields& vpMapPoints, float th,
+             std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist);
+    // Fuse(KeyFrame* pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) — :893-1009
+    int Fuse(const so_frame_view& pKF, const Calibration& cal, const Sim3& Scw, const MapPointFields& vpPoints, float th,
+             std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist);
+    // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) — :1011-1221.  vnMatch12[i1] = i2 or -1; returns nFound.
+    int SearchBySim3(const so_frame_view& pKF1, const Calibration& cal1, const Pose& T1w, const so_frame_view& pKF2,
+                     const Calibration& cal2, const Pose& T2w, const MapPointFields& vpMapPoints1,
+                     const MapPointFields& vpMapPoints2, float s12, const float R12[9], const float t12[3], float th,
+                     std::vector<int32_t>& vnMatch12);
+    // SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, int th) — :264-373 (pKF.excluded = vpMatched[k])
+    int SearchByProjection(const so_frame_view& pKF, const Calibration& cal, const Sim3& Scw, const MapPointFields& vpPoints,
+                           int th, std::vector<int32_t>& kp_to_point);
+    // SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist, bGlobal) — :1356-1473
+    int SearchByProjection(const so_frame_view& CurrentFrame, const Calibration& cal, const Pose& Tcw,
+                           const MapPointFields& vpKFPoints, float th, int ORBdist, std::vector<int32_t>& kp_to_point);
+
     // MapPoint::ComputeDistinctiveDescriptors (code/src/MapPoint.cc:323-392) for a batch: point p owns descriptors
     // [offsets[p], offsets[p + 1]); best[p] = index inside its own list
     std::vector<int32_t> ComputeDistinctiveDescriptors(const std::vector<int32_t>& offsets,

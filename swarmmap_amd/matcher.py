@@ -17,7 +17,8 @@ class SoFrameView(C.Structure):
                 ("angle", C.c_void_p), ("desc", C.c_void_p), ("excluded", C.c_void_p),
                 ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
                 ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("scale_factors", C.c_void_p),
-                ("nlevels", C.c_int32)]
+                ("nlevels", C.c_int32), ("has_grid_origin", C.c_int32), ("grid_min_x", C.c_float),
+                ("grid_min_y", C.c_float)]
 
 
 def _vp(a):
@@ -27,7 +28,11 @@ def _vp(a):
 class FrameView:
     """The parts of ORB_SLAM2::Frame the matcher reads (mvKeysUn, mDescriptors, bounds, grid, scale factors)."""
 
-    def __init__(self, x, y, octave, angle, desc, bounds, scale_factors, excluded=None):
+    def __init__(self, x, y, octave, angle, desc, bounds, scale_factors, excluded=None, grid_origin=None,
+                 grid_bounds=None):
+        """grid_bounds: a KeyFrame's case - `bounds` are its int-truncated mnMinX .. mnMaxY (what IsInImage /
+        GetFeaturesInArea use, code/include/KeyFrame.h:220) while the grid and its cell sizes come from the Frame's
+        float bounds `grid_bounds` (code/src/KeyFrame.cc:58-72).  grid_origin: only the origin differs."""
         self.x = np.ascontiguousarray(x, np.float32)
         self.y = np.ascontiguousarray(y, np.float32)
         self.octave = np.ascontiguousarray(octave, np.int32)
@@ -38,13 +43,20 @@ class FrameView:
         self.scale_factors = np.ascontiguousarray(scale_factors, np.float32)
         self.n = len(self.x)
         # Frame ctor, code/src/Frame.cc:259-260
-        self.grid_inv_w = np.float32(FRAME_GRID_COLS) / np.float32(self.max_x - self.min_x)
-        self.grid_inv_h = np.float32(FRAME_GRID_ROWS) / np.float32(self.max_y - self.min_y)
+        gb = [np.float32(b) for b in (grid_bounds if grid_bounds is not None else bounds)]
+        self.grid_inv_w = np.float32(FRAME_GRID_COLS) / np.float32(gb[1] - gb[0])
+        self.grid_inv_h = np.float32(FRAME_GRID_ROWS) / np.float32(gb[3] - gb[2])
+        if grid_bounds is not None and grid_origin is None:
+            grid_origin = (gb[0], gb[2])
+        self.has_grid_origin = 0 if grid_origin is None else 1
+        self.grid_min_x, self.grid_min_y = (np.float32(0), np.float32(0)) if grid_origin is None else \
+            (np.float32(grid_origin[0]), np.float32(grid_origin[1]))
 
     def as_struct(self, cls=SoFrameView):
         return cls(self.n, _vp(self.x), _vp(self.y), _vp(self.octave), _vp(self.angle), _vp(self.desc),
                    _vp(self.excluded), self.min_x, self.max_x, self.min_y, self.max_y, self.grid_inv_w,
-                   self.grid_inv_h, _vp(self.scale_factors), len(self.scale_factors))
+                   self.grid_inv_h, _vp(self.scale_factors), len(self.scale_factors), self.has_grid_origin,
+                   self.grid_min_x, self.grid_min_y)
 
 
 def _bind(lib):
@@ -300,3 +312,125 @@ ORBmatcher.SearchByBoW = _SearchByBoW
 ORBmatcher.SearchForTriangulation = _SearchForTriangulation
 ORBmatcher.SearchWindowBest = _SearchWindowBest
 ORBmatcher.SearchWindowGreedy = _SearchWindowGreedy
+
+
+# ---- Fuse / SearchBySim3 / keyframe-side SearchByProjection with the projection on the device (rows M6 / M7) --------
+class SoMapPointView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("Xw", C.c_void_p), ("normal", C.c_void_p), ("max_dist", C.c_void_p),
+                ("min_dist", C.c_void_p), ("desc", C.c_void_p), ("valid", C.c_void_p)]
+
+
+class SoWindowQueries(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("active", "u", "v", "radius", "level")]
+
+
+class SoCameraM(C.Structure):  # so_camera
+    _fields_ = [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+
+def _bind_proj(lib):
+    vp, ip, f, i32 = C.c_void_p, C.POINTER(C.c_int32), C.c_float, C.c_int32
+    fr, cam = C.POINTER(SoFrameView), C.POINTER(SoCameraM)
+    mp, wq = C.POINTER(SoMapPointView), C.POINTER(SoWindowQueries)
+    lib.so_fuse.argtypes = [vp, fr, cam, vp, f, vp, mp, f, vp, vp, ip, wq]
+    lib.so_fuse_sim3.argtypes = [vp, fr, cam, vp, f, mp, f, vp, vp, ip, wq]
+    lib.so_search_by_sim3.argtypes = [vp, fr, fr, cam, vp, vp, f, vp, vp, f, f, mp, mp, f, vp, ip, wq, wq]
+    lib.so_search_by_projection_sim3.argtypes = [vp, fr, cam, vp, f, mp, C.c_int, vp, ip, wq]
+    lib.so_search_by_projection_keyframe.argtypes = [vp, fr, cam, vp, f, mp, vp, f, i32, C.c_int, vp, ip, wq]
+
+
+def _mp_struct(mp):
+    a = dict(Xw=_f32(mp["Xw"]), normal=_f32(mp["normal"]) if mp.get("normal") is not None else None,
+             max_dist=_f32(mp["max_dist"]), min_dist=_f32(mp["min_dist"]), desc=_u8(mp["desc"]),
+             valid=_u8(mp["valid"]) if mp.get("valid") is not None else None)
+    n = len(a["max_dist"])
+    return SoMapPointView(n, _vp(a["Xw"]), _vp(a["normal"]), _vp(a["max_dist"]), _vp(a["min_dist"]), _vp(a["desc"]),
+                          _vp(a["valid"])), a
+
+
+def _wq_struct(n):
+    q = dict(active=np.zeros(n, np.uint8), u=np.zeros(n, np.float32), v=np.zeros(n, np.float32),
+             radius=np.zeros(n, np.float32), level=np.zeros(n, np.int32))
+    return SoWindowQueries(_vp(q["active"]), _vp(q["u"]), _vp(q["v"]), _vp(q["radius"]), _vp(q["level"])), q
+
+
+def _cam(K):
+    return SoCameraM(float(K[0]), float(K[1]), float(K[2]), float(K[3]), 0, 0, 0, 0, 0)
+
+
+def _Fuse(self, KF, K, Tcw, log_scale_factor, inv_level_sigma2, mp, th=3.0):
+    """ORBmatcher::Fuse(pKF, vpMapPoints, th) up to the map side effects.
+    Returns (nFused, best_idx, best_dist, queries) - queries = the projection half's output per map point."""
+    _bind_proj(self._lib)
+    ms, _keep = _mp_struct(mp)
+    qs, q = _wq_struct(ms.n)
+    bi, bd = np.full(ms.n, -1, np.int32), np.full(ms.n, 256, np.int32)
+    nf = C.c_int32(0)
+    fs, cam, T, inv = KF.as_struct(), _cam(K), _f32(Tcw).reshape(12), _f32(inv_level_sigma2)
+    _lib.check(self._lib.so_fuse(self._h, C.byref(fs), C.byref(cam), _vp(T), float(log_scale_factor), _vp(inv),
+                                 C.byref(ms), float(th), _vp(bi), _vp(bd), C.byref(nf), C.byref(qs)))
+    return nf.value, bi, bd, q
+
+
+def _FuseSim3(self, KF, K, Scw, log_scale_factor, mp, th=4.0):
+    """ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)."""
+    _bind_proj(self._lib)
+    ms, _keep = _mp_struct(mp)
+    qs, q = _wq_struct(ms.n)
+    bi, bd = np.full(ms.n, -1, np.int32), np.full(ms.n, 256, np.int32)
+    nf = C.c_int32(0)
+    fs, cam, S = KF.as_struct(), _cam(K), _f32(Scw).reshape(12)
+    _lib.check(self._lib.so_fuse_sim3(self._h, C.byref(fs), C.byref(cam), _vp(S), float(log_scale_factor), C.byref(ms),
+                                      float(th), _vp(bi), _vp(bd), C.byref(nf), C.byref(qs)))
+    return nf.value, bi, bd, q
+
+
+def _SearchBySim3(self, KF1, KF2, K, T1w, T2w, s12, R12, t12, log_sf1, log_sf2, mp1, mp2, th=7.5):
+    """ORBmatcher::SearchBySim3.  Returns (nFound, match12, queries1_in_2, queries2_in_1)."""
+    _bind_proj(self._lib)
+    m1, _k1 = _mp_struct(mp1)
+    m2, _k2 = _mp_struct(mp2)
+    q1s, q1 = _wq_struct(m1.n)
+    q2s, q2 = _wq_struct(m2.n)
+    out = np.full(m1.n, -1, np.int32)
+    nf = C.c_int32(0)
+    f1, f2, cam = KF1.as_struct(), KF2.as_struct(), _cam(K)
+    a, b, R, t = _f32(T1w).reshape(12), _f32(T2w).reshape(12), _f32(R12).reshape(9), _f32(t12).reshape(3)
+    _lib.check(self._lib.so_search_by_sim3(self._h, C.byref(f1), C.byref(f2), C.byref(cam), _vp(a), _vp(b), float(s12),
+                                           _vp(R), _vp(t), float(log_sf1), float(log_sf2), C.byref(m1), C.byref(m2),
+                                           float(th), _vp(out), C.byref(nf), C.byref(q1s), C.byref(q2s)))
+    return nf.value, out, q1, q2
+
+
+def _SearchByProjectionSim3(self, KF, K, Scw, log_scale_factor, mp, th=10):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th).  Returns (nmatches, kp_to_point, queries)."""
+    _bind_proj(self._lib)
+    ms, _keep = _mp_struct(mp)
+    qs, q = _wq_struct(ms.n)
+    out = np.full(KF.n, -1, np.int32)
+    nm = C.c_int32(0)
+    fs, cam, S = KF.as_struct(), _cam(K), _f32(Scw).reshape(12)
+    _lib.check(self._lib.so_search_by_projection_sim3(self._h, C.byref(fs), C.byref(cam), _vp(S), float(log_scale_factor),
+                                                      C.byref(ms), int(th), _vp(out), C.byref(nm), C.byref(qs)))
+    return nm.value, out, q
+
+
+def _SearchByProjectionKeyFrame(self, F, K, Tcw, log_scale_factor, mp, mp_angle, th, ORBdist):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist, bGlobal)."""
+    _bind_proj(self._lib)
+    ms, _keep = _mp_struct(mp)
+    qs, q = _wq_struct(ms.n)
+    out = np.full(F.n, -1, np.int32)
+    nm = C.c_int32(0)
+    fs, cam, T, ang = F.as_struct(), _cam(K), _f32(Tcw).reshape(12), _f32(mp_angle)
+    _lib.check(self._lib.so_search_by_projection_keyframe(
+        self._h, C.byref(fs), C.byref(cam), _vp(T), float(log_scale_factor), C.byref(ms), _vp(ang), float(th),
+        int(ORBdist), int(self.mbCheckOrientation), _vp(out), C.byref(nm), C.byref(qs)))
+    return nm.value, out, q
+
+
+ORBmatcher.Fuse = _Fuse
+ORBmatcher.FuseSim3 = _FuseSim3
+ORBmatcher.SearchBySim3 = _SearchBySim3
+ORBmatcher.SearchByProjectionSim3 = _SearchByProjectionSim3
+ORBmatcher.SearchByProjectionKeyFrame = _SearchByProjectionKeyFrame

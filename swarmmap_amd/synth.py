@@ -491,3 +491,118 @@ def make_kf_store_case(seed, n_agents=3, kfs_per_agent=6, n_kp=300, bound_frac=0
                             map_point_id=mp, valid=(mp >= 0).astype(np.uint8), place=place,
                             Tcw=rng.normal(size=12).astype(np.float32)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Keyframe-side map-point searches: a target keyframe, a pose (or Sim3) and map points whose
+# projections land near its keypoints - with every gate of the reference's loops exercised: points behind the camera,
+# outside the image, outside their scale-invariance range, seen at grazing angles, flagged bad / already found.
+# ---------------------------------------------------------------------------------------------------------------
+LOG_SCALE_FACTOR = float(np.log(np.float32(1.2)))  # mfLogScaleFactor = log(mfScaleFactor), code/src/Frame.cc:201
+INV_LEVEL_SIGMA2 = (1.0 / (SCALE_FACTORS.astype(np.float32) ** 2)).astype(np.float32)  # mvInvLevelSigma2
+
+
+def _unproject(K, uv, z):
+    fx, fy, cx, cy = K
+    return np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], 1)
+
+
+def _map_points_for(rng, fr, k, Pc, R, t, octave_of, p_flip, level_spread=(-0.6, 0.5), bad_frac=0.1):
+    """Map-point fields for camera-frame points Pc seen near keypoints k: world position through (R, t), a normal around
+    the viewing ray (some grazing), a scale-invariance range that predicts a level around the keypoint's octave (some
+    out of range), the keypoint's descriptor with flipped bits."""
+    n = len(Pc)
+    Xw = (R.T @ (Pc - t).T).T
+    Ow = -R.T @ t
+    view = Xw - Ow
+    d = np.linalg.norm(view, axis=1)
+    view /= d[:, None] + 1e-12
+    tilt = np.where(rng.random(n) < 0.15, 1.2, 0.35)
+    normal = np.stack([_rodrigues(rng.normal(0, s, 3)) @ v for v, s in zip(view, tilt)])
+    max_dist = d * 1.2 ** (octave_of + rng.uniform(level_spread[0], level_spread[1], n))
+    max_dist *= np.where(rng.random(n) < 0.06, 0.3, 1.0)   # beyond 1.2 * mfMaxDistance
+    min_dist = max_dist / (1.2 ** 7) * rng.uniform(0.8, 1.25, n)
+    min_dist *= np.where(rng.random(n) < 0.04, 400.0, 1.0)  # closer than 0.8 * mfMinDistance
+    return dict(Xw=Xw.astype(np.float32), normal=normal.astype(np.float32), max_dist=max_dist.astype(np.float32),
+                min_dist=min_dist.astype(np.float32), desc=flip_bits(rng, fr["desc"][k], p_flip),
+                valid=(rng.random(n) >= bad_frac).astype(np.uint8))
+
+
+EUROC_FRAME_BOUNDS = (-27.3418, 779.6142, -18.7226, 498.4311)  # like Frame::ComputeImageBounds under EuRoC's distortion
+
+
+def as_keyframe_bounds(fr, frame_bounds=EUROC_FRAME_BOUNDS):
+    """Give the frame arrays a KeyFrame's bounds: `bounds` = the Frame's float bounds truncated to int (code/include/
+    KeyFrame.h:220), `grid_bounds` = the float ones the copied grid was filled with (code/src/KeyFrame.cc:58-72)."""
+    fr["grid_bounds"] = tuple(float(np.float32(b)) for b in frame_bounds)
+    fr["bounds"] = tuple(float(int(np.float32(b))) for b in frame_bounds)
+    return fr
+
+
+def make_projection_case(seed, n_kp=1000, n_mp=1200, size=EUROC, K=EUROC_K, p_flip=0.1, jitter=2.5, sim3_scale=None,
+                         prebound_frac=0.0, keyframe_bounds=False):
+    """Target keyframe + pose + map points for Fuse / SearchByProjection(KF, Scw) / SearchByProjection(Frame, KF).
+    sim3_scale: the returned "Scw" is [s R | s t] (the pose itself is [R | t]); prebound_frac: keypoints already bound
+    on entry (vpMatched[k] / mvpMapPoints[k] non-null)."""
+    rng = np.random.default_rng(seed)
+    fr = make_frame_arrays(rng, n_kp, size=size, distort_margin=25.0 if keyframe_bounds else 6.0)
+    if keyframe_bounds:
+        as_keyframe_bounds(fr)
+    if prebound_frac > 0:
+        fr["excluded"] = (rng.random(n_kp) < prebound_frac).astype(np.uint8)
+    R = _rodrigues(rng.normal(0, 0.4, 3))
+    t = rng.normal(0, 1.5, 3)
+    k = rng.integers(0, n_kp, n_mp)
+    uv = np.stack([fr["x"][k], fr["y"][k]], 1) + rng.normal(0, jitter, (n_mp, 2))
+    far = rng.random(n_mp) < 0.08  # projections outside the image
+    uv[far] = np.stack([rng.uniform(-200, size[0] + 200, far.sum()), rng.uniform(-200, size[1] + 200, far.sum())], 1)
+    z = rng.uniform(0.8, 15.0, n_mp) * np.where(rng.random(n_mp) < 0.06, -1.0, 1.0)
+    Pc = _unproject(K, uv, z)
+    mp = _map_points_for(rng, fr, k, Pc, R, t, fr["octave"][k].astype(np.float64), p_flip)
+    mp["angle"] = ((fr["angle"][k] + rng.normal(0, 4.0, n_mp)) % 360).astype(np.float32)  # pKF->mvKeysUn[i].angle
+    s = 1.0 if sim3_scale is None else float(sim3_scale)
+    T = np.hstack([R, t[:, None]])
+    S = np.hstack([s * R, s * t[:, None]])
+    return dict(frame=fr, Tcw=T.astype(np.float32).reshape(12), Scw=S.astype(np.float32).reshape(12), mp=mp,
+                cam=K, log_scale_factor=LOG_SCALE_FACTOR, inv_level_sigma2=INV_LEVEL_SIGMA2)
+
+
+def make_sim3_pair_case(seed, n=900, size=EUROC, K=EUROC_K, p_flip=0.08, s12=1.3, already_frac=0.1, keyframe_bounds=False):
+    """Two keyframes of two maps related by a similarity (SearchBySim3, code/src/ORBmatcher.cc:1011-1221): points seen
+    by keyframe 1 at its keypoints are seen by keyframe 2 where the Sim3 puts them (keypoints of 2 are shuffled), each
+    keyframe's map points live in its own world frame."""
+    rng = np.random.default_rng(seed)
+    w, h = size
+    fx, fy, cx, cy = K
+    fr1 = make_frame_arrays(rng, n, size=size, dup_frac=0.0)
+    z1 = rng.uniform(2.0, 9.0, n)
+    Pc1 = _unproject(K, np.stack([fr1["x"], fr1["y"]], 1).astype(np.float64), z1)
+    R12 = _rodrigues(rng.normal(0, 0.08, 3))
+    t12 = rng.normal(0, 0.25, 3)
+    Pc2 = (R12.T @ (Pc1 - t12).T).T / s12  # p_c2 = sR21 p_c1 + t21
+    u2 = np.stack([fx * Pc2[:, 0] / Pc2[:, 2] + cx, fy * Pc2[:, 1] / Pc2[:, 2] + cy], 1) + rng.normal(0, 1.2, (n, 2))
+    out = (Pc2[:, 2] <= 0) | (u2[:, 0] < 0) | (u2[:, 0] >= w) | (u2[:, 1] < 0) | (u2[:, 1] >= h)
+    u2[out] = np.stack([rng.uniform(0, w, out.sum()), rng.uniform(0, h, out.sum())], 1)
+    d2 = np.linalg.norm(Pc2, axis=1)
+    d1 = np.linalg.norm(Pc1, axis=1)
+    # octave of the point in keyframe 2 follows the distance ratio (closer by 1 / s12 -> coarser level)
+    oct2 = np.clip(np.round(fr1["octave"] + np.log(d1 / d2) / np.log(1.2)), 0, 7).astype(np.int32)
+    perm = rng.permutation(n)  # keypoint j of keyframe 2 shows point perm[j]
+    fr2 = dict(x=u2[perm, 0].astype(np.float32), y=u2[perm, 1].astype(np.float32), octave=oct2[perm],
+               angle=((fr1["angle"][perm] + 5) % 360).astype(np.float32), desc=flip_bits(rng, fr1["desc"][perm], p_flip),
+               bounds=fr1["bounds"], scale_factors=SCALE_FACTORS)
+    if keyframe_bounds:
+        as_keyframe_bounds(fr1)
+        as_keyframe_bounds(fr2)
+    R1 = _rodrigues(rng.normal(0, 0.5, 3)); t1 = rng.normal(0, 2.0, 3)
+    R2 = _rodrigues(rng.normal(0, 0.5, 3)); t2 = rng.normal(0, 2.0, 3)
+    lv = (-0.5, 0.4)
+    # map points of keyframe 1 are searched in keyframe 2: their range must predict the octave seen there, and v.v.
+    mp1 = _map_points_for(rng, fr1, np.arange(n), Pc1, R1, t1, oct2 + np.log(d2 / d1) / np.log(1.2), p_flip, lv, already_frac)
+    # (PredictScale uses mfMaxDistance / |p3Dc2|: max_dist above is d1-based, so shift it by the distance ratio)
+    mp2 = _map_points_for(rng, fr2, np.arange(n), Pc2[perm], R2, t2,
+                          fr1["octave"][perm] + np.log(d1[perm] / d2[perm]) / np.log(1.2), p_flip, lv, already_frac)
+    return dict(frame1=fr1, frame2=fr2, T1w=np.hstack([R1, t1[:, None]]).astype(np.float32).reshape(12),
+                T2w=np.hstack([R2, t2[:, None]]).astype(np.float32).reshape(12), s12=np.float32(s12),
+                R12=R12.astype(np.float32).reshape(9), t12=t12.astype(np.float32), mp1=mp1, mp2=mp2, perm=perm, cam=K,
+                log_scale_factor=LOG_SCALE_FACTOR)

@@ -183,6 +183,44 @@ int main(int argc, char** argv) {
         const std::vector<uint8_t> dd = rd<uint8_t>("dd_desc");
         out("distinctive", m.ComputeDistinctiveDescriptors(off, dd));
     }
+    {   // the same five routines with the projection on the device (map points + pose in, bindings out)
+        typedef ORB_SLAM2::ORBmatcher M;
+        auto points = [](const std::string& p) {
+            M::MapPointFields f;
+            f.Xw = rd<float>((p + "_Xw").c_str()); f.normal = rd<float>((p + "_normal").c_str());
+            f.max_dist = rd<float>((p + "_max_dist").c_str()); f.min_dist = rd<float>((p + "_min_dist").c_str());
+            f.desc = rd<uint8_t>((p + "_desc").c_str()); f.valid = rd<uint8_t>((p + "_valid").c_str());
+            return f;
+        };
+        const std::vector<float> cal4 = rd<float>("pj_cam"), lsf = rd<float>("pj_lsf");
+        M::Calibration cal{cal4[0], cal4[1], cal4[2], cal4[3], lsf[0], inv};
+        const FrameArrays PK = frame("pjf");
+        M::MapPointFields mp = points("pj");
+        mp.angle = rd<float>("pj_angle");
+        M::Pose T; M::Sim3 Sc;
+        const std::vector<float> Tv = rd<float>("pj_Tcw"), Sv = rd<float>("pj_Scw");
+        for (int i = 0; i < 12; i++) { T.m[i] = Tv[i]; Sc.m[i] = Sv[i]; }
+        ORB_SLAM2::ORBmatcher m(0.9f, true);
+        std::vector<int32_t> bi, bd, k;
+        const int n1 = m.Fuse(PK.view(false), cal, T, mp, 3.0f, bi, bd);
+        printf("pfuse_n %d\n", n1); out("pfuse_idx", bi); out("pfuse_dist", bd);
+        const int n2 = m.Fuse(PK.view(false), cal, Sc, mp, 4.0f, bi, bd);
+        printf("pfuse_scw_n %d\n", n2); out("pfuse_scw_idx", bi); out("pfuse_scw_dist", bd);
+        const int n3 = m.SearchByProjection(PK.view(true), cal, Sc, mp, 10, k);
+        printf("pgreedy_kf_n %d\n", n3); out("pgreedy_kf", k);
+        const int n4 = m.SearchByProjection(PK.view(true), cal, T, mp, 10.0f, 100, k);
+        printf("pgreedy_f_n %d\n", n4); out("pgreedy_f", k);
+        const FrameArrays S1 = frame("s1f"), S2 = frame("s2f");
+        const M::MapPointFields mp1 = points("s1"), mp2 = points("s2");
+        const std::vector<float> T1 = rd<float>("s_T1w"), T2 = rd<float>("s_T2w"), R12 = rd<float>("s_R12"), t12 = rd<float>("s_t12"),
+                                 s12 = rd<float>("s_s12");
+        M::Pose P1, P2;
+        for (int i = 0; i < 12; i++) { P1.m[i] = T1[i]; P2.m[i] = T2[i]; }
+        std::vector<int32_t> m12;
+        const int n5 = m.SearchBySim3(S1.view(false), cal, P1, S2.view(false), cal, P2, mp1, mp2, s12[0], R12.data(), t12.data(),
+                                      7.5f, m12);
+        printf("psim3_n %d\n", n5); out("psim3", m12);
+    }
     // ---- Optimizer ----------------------------------------------------------------------------------------------
     ORB_SLAM2::Optimizer& optimizer = ORB_SLAM2::Optimizer::ThreadInstance();  // static call sites, as in the reference
     {

@@ -120,6 +120,23 @@ def test_every_adapter_method_matches_the_oracle(tmp_path, oracle):
     for k in ("Tcw", "Xw", "obs", "inv_sigma2"):
         _w(d, "po_" + k, pc[k], np.float32)
 
+    pj = synth.make_projection_case(71, 1000, 1500, sim3_scale=1.4, prebound_frac=0.1)
+    PJ = _frame(d, "pjf", pj["frame"])
+    for k, t in (("Xw", np.float32), ("normal", np.float32), ("max_dist", np.float32), ("min_dist", np.float32),
+                 ("desc", np.uint8), ("valid", np.uint8), ("angle", np.float32)):
+        _w(d, "pj_" + k, pj["mp"][k], t)
+    _w(d, "pj_cam", pj["cam"], np.float32); _w(d, "pj_lsf", [pj["log_scale_factor"]], np.float32)
+    _w(d, "pj_Tcw", pj["Tcw"], np.float32); _w(d, "pj_Scw", pj["Scw"], np.float32)
+    sp = synth.make_sim3_pair_case(72, 700)
+    SP1, SP2 = _frame(d, "s1f", sp["frame1"]), _frame(d, "s2f", sp["frame2"])
+    for pfx, mpk in (("s1", sp["mp1"]), ("s2", sp["mp2"])):
+        for k, t in (("Xw", np.float32), ("normal", np.float32), ("max_dist", np.float32), ("min_dist", np.float32),
+                     ("desc", np.uint8), ("valid", np.uint8)):
+            _w(d, "%s_%s" % (pfx, k), mpk[k], t)
+    for k in ("T1w", "T2w", "R12", "t12"):
+        _w(d, "s_" + k, sp[k], np.float32)
+    _w(d, "s_s12", [sp["s12"]], np.float32)
+
     outp = subprocess.check_output([exe, d, "752", "480"], text=True)
     L = dict(l.split(" ", 1) for l in outp.strip().splitlines())
 
@@ -174,6 +191,19 @@ def test_every_adapter_method_matches_the_oracle(tmp_path, oracle):
     assert int(L["greedy_f_n"]) == onm > 100; same("greedy_f", ok, np.int32)
     oidx, _ = oracle.distinctive_descriptors(off, dd)
     same("distinctive", oidx, np.int32)
+    # ... and with the projection on the device: map points + pose in, the oracle's end-to-end routines as the checker
+    pcam, lsf = oracle.camera(pj["cam"]), pj["log_scale_factor"]
+    on, obi, obd = oracle.fuse(PJ(False), pcam, pj["Tcw"], lsf, inv, pj["mp"], 3.0)
+    assert int(L["pfuse_n"]) == on > 300; same("pfuse_idx", obi, np.int32); same("pfuse_dist", obd, np.int32)
+    on, obi, obd = oracle.fuse_sim3(PJ(False), pcam, pj["Scw"], lsf, pj["mp"], 4.0)
+    assert int(L["pfuse_scw_n"]) == on > 300; same("pfuse_scw_idx", obi, np.int32); same("pfuse_scw_dist", obd, np.int32)
+    onm, ok = oracle.search_by_projection_sim3(PJ(), pcam, pj["Scw"], lsf, pj["mp"], 10)
+    assert int(L["pgreedy_kf_n"]) == onm > 200; same("pgreedy_kf", ok, np.int32)
+    onm, ok = oracle.search_by_projection_frame_kf(PJ(), pcam, pj["Tcw"], lsf, pj["mp"], pj["mp"]["angle"], 10.0, 100, True)
+    assert int(L["pgreedy_f_n"]) == onm > 200; same("pgreedy_f", ok, np.int32)
+    onf, om12 = oracle.search_by_sim3(SP1(False), SP2(False), pcam, sp["T1w"], sp["T2w"], sp["s12"], sp["R12"], sp["t12"], lsf,
+                                      lsf, sp["mp1"], sp["mp2"], 7.5)
+    assert int(L["psim3_n"]) == onf > 150; same("psim3", om12, np.int32)
     # Optimizer
     o = oracle.bundle_adjust(win)
     f = L["ba"].split()

@@ -1,0 +1,171 @@
+"""GPU parity of Fuse x2, SearchBySim3 and the keyframe-side SearchByProjection overloads
+against oracle/project_oracle.c, through the C ABI: the projection half bit-exact on (active, u, v, radius, level) -
+float work evaluated in the reference's expression order on both sides, tolerance 0 - and the routines' end results
+(best keypoint / distance per map point, bindings per keypoint, agreeing pairs) identical."""
+import numpy as np
+import pytest
+
+from swarmmap_amd import synth
+from swarmmap_amd.matcher import FrameView
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import swarmmap_amd
+    assert swarmmap_amd.device_count() > 0, "these tests need a GPU"
+    return swarmmap_amd
+
+
+def _view(fr, excluded=True):
+    return FrameView(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["bounds"], fr["scale_factors"],
+                     fr.get("excluded") if excluded else None, grid_bounds=fr.get("grid_bounds"))
+
+
+def _same_queries(q, oq):
+    for k in ("active", "u", "v", "radius", "level"):
+        assert q[k].tobytes() == oq[k].tobytes(), k
+
+
+@pytest.mark.parametrize("seed,n_kp,n_mp,th", [(101, 1000, 1200, 3.0), (102, 2000, 4000, 3.0), (103, 300, 5000, 5.0),
+                                               (104, 1000, 1, 3.0)])
+def test_m6_fuse(S, oracle, seed, n_kp, n_mp, th):
+    c = synth.make_projection_case(seed, n_kp, n_mp)
+    KF = _view(c["frame"], False)
+    cam = oracle.camera(c["cam"])
+    m = S.ORBmatcher()
+    n, bi, bd, q = m.Fuse(KF, c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], th)
+    _same_queries(q, oracle.fuse_queries(KF, cam, c["Tcw"], c["log_scale_factor"], c["mp"], th))
+    on, obi, obd = oracle.fuse(KF, cam, c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], th)
+    assert n == on and np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    if n_mp > 100:
+        assert n > 0.3 * n_mp * min(1.0, n_kp / 1000) * 0.5
+        a = q["active"].astype(bool)
+        assert a.sum() > 0.4 * n_mp and (~a).sum() > 0.1 * n_mp
+    m.close()
+
+
+@pytest.mark.parametrize("seed,scale,th", [(111, 1.0, 4.0), (112, 1.37, 4.0), (113, 0.61, 3.0)])
+def test_m6_fuse_with_sim3(S, oracle, seed, scale, th):
+    c = synth.make_projection_case(seed, 1200, 2500, sim3_scale=scale)
+    KF = _view(c["frame"], False)
+    cam = oracle.camera(c["cam"])
+    m = S.ORBmatcher()
+    n, bi, bd, q = m.FuseSim3(KF, c["cam"], c["Scw"], c["log_scale_factor"], c["mp"], th)
+    _same_queries(q, oracle.sim3_world_queries(KF, cam, c["Scw"], c["log_scale_factor"], c["mp"], th))
+    on, obi, obd = oracle.fuse_sim3(KF, cam, c["Scw"], c["log_scale_factor"], c["mp"], th)
+    assert n == on and np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    assert n > 500
+    m.close()
+
+
+@pytest.mark.parametrize("seed,n,s12,th", [(121, 900, 1.3, 7.5), (122, 1500, 0.8, 7.5), (123, 400, 1.0, 5.0)])
+def test_m7_search_by_sim3(S, oracle, seed, n, s12, th):
+    c = synth.make_sim3_pair_case(seed, n, s12=s12)
+    K1, K2 = _view(c["frame1"], False), _view(c["frame2"], False)
+    cam = oracle.camera(c["cam"])
+    lsf = c["log_scale_factor"]
+    m = S.ORBmatcher()
+    nf, m12, q1, q2 = m.SearchBySim3(K1, K2, c["cam"], c["T1w"], c["T2w"], c["s12"], c["R12"], c["t12"], lsf, lsf,
+                                     c["mp1"], c["mp2"], th)
+    _same_queries(q1, oracle.sim3_pair_queries(K2, cam, c["T1w"], c["s12"], c["R12"], c["t12"], True, lsf, c["mp1"], th))
+    _same_queries(q2, oracle.sim3_pair_queries(K1, cam, c["T2w"], c["s12"], c["R12"], c["t12"], False, lsf, c["mp2"], th))
+    onf, om12 = oracle.search_by_sim3(K1, K2, cam, c["T1w"], c["T2w"], c["s12"], c["R12"], c["t12"], lsf, lsf, c["mp1"],
+                                      c["mp2"], th)
+    assert nf == onf and np.array_equal(m12, om12)
+    assert nf > 0.25 * n
+    m.close()
+
+
+@pytest.mark.parametrize("seed,scale,th", [(131, 1.0, 10), (132, 1.9, 10), (133, 0.7, 4)])
+def test_m7_search_by_projection_keyframe_scw(S, oracle, seed, scale, th):
+    c = synth.make_projection_case(seed, 1000, 2500, sim3_scale=scale, prebound_frac=0.15)
+    KF = _view(c["frame"])
+    cam = oracle.camera(c["cam"])
+    m = S.ORBmatcher()
+    nm, k2p, q = m.SearchByProjectionSim3(KF, c["cam"], c["Scw"], c["log_scale_factor"], c["mp"], th)
+    _same_queries(q, oracle.sim3_world_queries(KF, cam, c["Scw"], c["log_scale_factor"], c["mp"], float(th)))
+    onm, ok2p = oracle.search_by_projection_sim3(KF, cam, c["Scw"], c["log_scale_factor"], c["mp"], th)
+    assert nm == onm and np.array_equal(k2p, ok2p)
+    assert nm > 300
+    m.close()
+
+
+@pytest.mark.parametrize("seed,th,orb_dist,ori", [(141, 10.0, 100, True), (142, 3.0, 64, True), (143, 10.0, 100, False)])
+def test_m7_search_by_projection_frame_keyframe(S, oracle, seed, th, orb_dist, ori):
+    c = synth.make_projection_case(seed, 1000, 1000, prebound_frac=0.2)
+    F = _view(c["frame"])
+    cam = oracle.camera(c["cam"])
+    m = S.ORBmatcher(0.9, ori)
+    nm, k2p, q = m.SearchByProjectionKeyFrame(F, c["cam"], c["Tcw"], c["log_scale_factor"], c["mp"], c["mp"]["angle"], th,
+                                              orb_dist)
+    _same_queries(q, oracle.frame_kf_queries(F, cam, c["Tcw"], c["log_scale_factor"], c["mp"], th))
+    onm, ok2p = oracle.search_by_projection_frame_kf(F, cam, c["Tcw"], c["log_scale_factor"], c["mp"], c["mp"]["angle"],
+                                                     th, orb_dist, ori)
+    assert nm == onm and np.array_equal(k2p, ok2p)
+    assert nm > 200
+    m.close()
+
+
+def test_projected_searches_edge_cases(S, oracle):
+    """No map points, no keypoints, nothing valid, a crowded window that exhausts the K-lists of the greedy search."""
+    c = synth.make_projection_case(151, 800, 600)
+    KF = _view(c["frame"], False)
+    cam = oracle.camera(c["cam"])
+    lsf, inv = c["log_scale_factor"], c["inv_level_sigma2"]
+    m = S.ORBmatcher()
+    empty = {k: v[:0] for k, v in c["mp"].items()}
+    n, bi, bd, _ = m.Fuse(KF, c["cam"], c["Tcw"], lsf, inv, empty, 3.0)
+    assert n == 0 and len(bi) == 0
+    none = dict(c["mp"], valid=np.zeros(600, np.uint8))
+    n, bi, bd, q = m.Fuse(KF, c["cam"], c["Tcw"], lsf, inv, none, 3.0)
+    assert n == 0 and (bi == -1).all() and (bd == 256).all() and not q["active"].any()
+    fr0 = {k: (v[:0] if isinstance(v, np.ndarray) and k != "scale_factors" else v) for k, v in c["frame"].items()}
+    n, bi, bd, q = m.Fuse(_view(fr0, False), c["cam"], c["Tcw"], lsf, inv, c["mp"], 3.0)
+    on, obi, obd = oracle.fuse(_view(fr0, False), cam, c["Tcw"], lsf, inv, c["mp"], 3.0)
+    assert n == on == 0 and np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    # crowded: every map point projects onto the same few keypoints, th large -> later points find their K best taken
+    c2 = synth.make_projection_case(152, 60, 900, jitter=0.5)
+    F2 = _view(c2["frame"])
+    nm, k2p, _ = m.SearchByProjectionKeyFrame(F2, c2["cam"], c2["Tcw"], lsf, c2["mp"], c2["mp"]["angle"], 25.0, 100)
+    onm, ok2p = oracle.search_by_projection_frame_kf(F2, oracle.camera(c2["cam"]), c2["Tcw"], lsf, c2["mp"],
+                                                     c2["mp"]["angle"], 25.0, 100, True)
+    assert nm == onm and np.array_equal(k2p, ok2p)
+    m.close()
+
+
+def test_keyframe_int_bounds_quirk(S, oracle):
+    """A KeyFrame queries the grid it copied from its Frame (cells assigned with the Frame's float origin) with its own
+    int-truncated bounds (code/include/KeyFrame.h:220, code/src/KeyFrame.cc:58-72, 779-818): all five routines with such
+    a target, and the quirk must be visible - the same data with one origin for both gives a different answer."""
+    m = S.ORBmatcher()
+    c = synth.make_projection_case(161, 3000, 6000, keyframe_bounds=True, jitter=3.0, prebound_frac=0.1)
+    cam = oracle.camera(c["cam"])
+    lsf, inv = c["log_scale_factor"], c["inv_level_sigma2"]
+    KF = _view(c["frame"], False)
+    assert KF.has_grid_origin == 1 and KF.grid_min_x != KF.min_x
+    n, bi, bd, q = m.Fuse(KF, c["cam"], c["Tcw"], lsf, inv, c["mp"], 3.0)
+    _same_queries(q, oracle.fuse_queries(KF, cam, c["Tcw"], lsf, c["mp"], 3.0))
+    on, obi, obd = oracle.fuse(KF, cam, c["Tcw"], lsf, inv, c["mp"], 3.0)
+    assert n == on and np.array_equal(bi, obi) and np.array_equal(bd, obd) and n > 1000
+    n, bi, bd, q = m.FuseSim3(KF, c["cam"], c["Scw"], lsf, c["mp"], 4.0)
+    on, obi, obd = oracle.fuse_sim3(KF, cam, c["Scw"], lsf, c["mp"], 4.0)
+    assert n == on and np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    KFx = _view(c["frame"])
+    nm, k2p, _ = m.SearchByProjectionSim3(KFx, c["cam"], c["Scw"], lsf, c["mp"], 10)
+    onm, ok2p = oracle.search_by_projection_sim3(KFx, cam, c["Scw"], lsf, c["mp"], 10)
+    assert nm == onm and np.array_equal(k2p, ok2p)
+    # the quirk is observable: with the float origin on both sides some best keypoints differ
+    plain = FrameView(c["frame"]["x"], c["frame"]["y"], c["frame"]["octave"], c["frame"]["angle"], c["frame"]["desc"],
+                      c["frame"]["grid_bounds"], c["frame"]["scale_factors"])
+    _, bi_plain, _ = oracle.fuse_sim3(plain, cam, c["Scw"], lsf, c["mp"], 4.0)
+    assert not np.array_equal(bi_plain, obi)
+    p = synth.make_sim3_pair_case(162, 1500, keyframe_bounds=True)
+    K1, K2 = _view(p["frame1"], False), _view(p["frame2"], False)
+    nf, m12, _, _ = m.SearchBySim3(K1, K2, p["cam"], p["T1w"], p["T2w"], p["s12"], p["R12"], p["t12"], lsf, lsf, p["mp1"],
+                                   p["mp2"], 7.5)
+    onf, om12 = oracle.search_by_sim3(K1, K2, cam, p["T1w"], p["T2w"], p["s12"], p["R12"], p["t12"], lsf, lsf, p["mp1"],
+                                      p["mp2"], 7.5)
+    assert nf == onf and np.array_equal(m12, om12) and nf > 300
+    m.close()
