@@ -34,7 +34,7 @@ import torch  # noqa: E402  (pinned / device memory, barrier, RCCL plumbing only
 
 import swarmmap_amd  # noqa: E402
 from swarmmap_amd import minitrack, synth  # noqa: E402
-from swarmmap_amd.replay import Replay  # noqa: E402
+from swarmmap_amd.replay import Replay, make_vocabulary  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_PEAK_TF = 78.6    # MI355X FP64 vector/matrix peak (AMD datasheet; not tabulated in the guide)
@@ -43,6 +43,10 @@ LIVE_STEPS = 41        # frames tracked the live way after the timed region (the
 STORE_KEYFRAMES = 4096  # keyframe store per rank: 8 agents x 512 keyframes (218 MB of records + 134 MB of search rows)
 # one LBA-M window per ~5 frames (SURVEY.md 8d end-to-end replay); the override is a diagnostic (no local mapping)
 LBA_EVERY = int(os.environ.get("SWARMORB_BENCH_LBA_EVERY", "5"))
+# the local-mapping thread's matcher job per new keyframe (SearchForTriangulation against the last <= 20 keyframes, Fuse
+# into them and back: code/src/LocalMapping.cc:197-246, 451-481) before its window; 0 switches it off
+LM_MATCHER = int(os.environ.get("SWARMORB_BENCH_LM_MATCHER", "1"))
+LM_NEIGHBOURS = 20  # nn = 20, LocalMapping.cc:207,455 (monocular)
 LOCAL_KEYFRAMES = 12   # local map = points created at the last 12 keyframes (~3-5 k map points)
 PLANE_Z = 2.0
 
@@ -99,25 +103,35 @@ def cpu_baseline(frames, K, dist, nfeatures, lba_window, size, budget_s=20.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import oracle_py
     from trajectory_common import OracleBackend
-    lm = LocalMapper(lambda: oracle_py.bundle_adjust(lba_window))
+    jobs = []  # matcher jobs handed over by the tracking loop, run by the local-mapping thread in front of its window
+
+    def window():
+        if jobs:
+            jobs.pop(0)()
+        oracle_py.bundle_adjust(lba_window)
+
+    lm = LocalMapper(window)
     state = {"n": 0, "t0": time.perf_counter()}
 
     def on_frame(t):
         state["n"] = t + 1
-        if t > 0 and t % LBA_EVERY == 0:
+        if t % LBA_EVERY == 0:
             lm.submit()
         return time.perf_counter() - state["t0"] < budget_s
 
     minitrack.track(OracleBackend(K, nfeatures, dist if dist is not None else (0, 0, 0, 0, 0)), None, len(frames), K, plane_z=PLANE_Z,
-                    local_keyframes=LOCAL_KEYFRAMES, third_pose=True, frames=frames, on_frame=on_frame)
+                    local_keyframes=LOCAL_KEYFRAMES, third_pose=True, frames=frames, on_frame=on_frame,
+                    lm_every=LBA_EVERY if LM_MATCHER else 0, vocab=make_vocabulary() if LM_MATCHER else None,
+                    lm_neighbours=LM_NEIGHBOURS, on_keyframe=jobs.append)
     lm.drain()
     dt = time.perf_counter() - state["t0"]
     lm.close()
     n = state["n"]
     return {"value": n / dt, "unit": "frames/s", "cores": 2, "kind": "port",
             "sample": "%d frames %dx%d of the same stream in %.1f s: CPU oracle chain (extract nFeatures %d + undistort + grid + "
-                      "M2 + isInFrustum + M1 + 3 PoseOptimization per frame on the tracking thread, %d LBA-M windows (1 per "
-                      "%d frames) on a local-mapping thread); operators in C (gcc -O3), the loop around them python-driven "
+                      "M2 + isInFrustum + M1 + 3 PoseOptimization per frame on the tracking thread; %d keyframes (1 per "
+                      "%d frames) on a local-mapping thread, each: SearchForTriangulation + Fuse against the last <= 20 "
+                      "keyframes, then an LBA-M window); operators in C (gcc -O3), the loop around them python-driven "
                       "(swarmmap_amd/minitrack.py: ~1-3 %% of a ~30 ms frame) while the HIP arm runs the C++ loop; host has "
                       "%d cores" % (n, size[0], size[1], dt, nfeatures, lm.n, LBA_EVERY, os.cpu_count())}
 
@@ -136,6 +150,8 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
         rp = Replay(dev, w, h, nfeatures, LBA_EVERY, K, dist, plane_z=PLANE_Z, local_keyframes=LOCAL_KEYFRAMES, third_pose=True)
         rp.set_frames([block.data_ptr() + i * w * h for i in range(n_frames)], on_device=False)
         rp.set_window(lba_window)
+        if LM_MATCHER:
+            rp.set_vocabulary(make_vocabulary(), LM_NEIGHBOURS)
         rp.preallocate()
         rp.prime(0)
         fleet.append(rp)
@@ -152,13 +168,14 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
     barrier()
     dt = time.perf_counter() - t0
     results = []
+    fleet_lm = fleet[0].lm_stats()
     for rp in fleet:
         rp.finish()
         results.append((rp.stats(), rp.candidates_total(), rp.log()))
         rp.close()
     stats = {k: sum(r[0][k] for r in results) / agents for k in results[0][0] if k not in ("stages", "frame_ms")}
     stats["frame_ms"] = np.concatenate([np.asarray(r[0]["frame_ms"])[-steps:] for r in results])
-    stats.update({"n_xchg": 0, "xchg_ms": 0.0})
+    stats.update({"n_xchg": 0, "xchg_ms": 0.0, "lm": fleet_lm})
     return dt, stats, results[0][1], keep[0][1], results[0][2]
 
 
@@ -197,6 +214,8 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
                         third_pose=True)
             rp.set_frames([block.data_ptr() + i * w * h for i in range(n_frames)], on_device=False)
             rp.set_window(lba_window)
+            if LM_MATCHER:  # the local-mapping thread's matcher job: SearchForTriangulation + Fuse per new keyframe
+                rp.set_vocabulary(make_vocabulary(), LM_NEIGHBOURS)
             rp.preallocate()  # device buffers of the local-mapping solver sized once, before any step is counted
 
             def run_span(first, n, timed):
@@ -240,6 +259,8 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
                 live = rp.run_live(warmup + steps, live_steps)
             rp.finish()
             results[a] = (rp.stats(), rp.candidates_total(), rp.log())
+            if a == 0:
+                acc_x["lm"] = rp.lm_stats()
             if live is not None:
                 acc_x["live_pose_ms"], acc_x["live_step_ms"] = live[0][1:], live[1][1:]
             rp.close()
@@ -352,7 +373,19 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
                               "keyframe_map_insert": st["map_ms"] / steps, "lba_submit_wait": st["lba_ms"] / steps,
                               "lba_thread_busy": st["lba_busy_ms"] / steps,
                               "exchange_amortised": st.get("xchg_ms", 0.0) / steps},
-        "lba_ms_per_window": {"wall": st["lba_busy_ms"] / max(st["n_lba"], 1), "gpu": st["lba_gpu_ms"] / max(st["n_lba"], 1)},
+        "lba_ms_per_window": {"wall": (st["lba_busy_ms"] - st.get("lm", {}).get("wall_ms", 0.0)) / max(st["n_lba"], 1),
+                              "gpu": st["lba_gpu_ms"] / max(st["n_lba"], 1)},
+        # the local-mapping thread's matcher job in front of every window (inside lba_thread_busy): per new keyframe
+        # SearchForTriangulation against each of the last <= 20 keyframes (M5), Fuse into each and back (M6)
+        "local_mapping_matcher": (lambda L: None if not L or not L.get("jobs") else {
+            "keyframes": L["jobs"], "neighbours": LM_NEIGHBOURS, "wall_ms_per_keyframe": L["wall_ms"] / L["jobs"],
+            "feature_vector_ms_per_keyframe": L["node_ms"] / L["jobs"],
+            "search_for_triangulation": {"calls_per_keyframe": L["tri_calls"] / L["jobs"], "host_ms_per_call": L["tri_ms"] / max(L["tri_calls"], 1),
+                                         "match_kernel_ms_per_call": L["tri_kernel_ms"] / max(L["tri_calls"], 1),
+                                         "matches_per_keyframe": L["tri_matches"] / L["jobs"]},
+            "fuse": {"calls_per_keyframe": L["fuse_calls"] / L["jobs"], "host_ms_per_call": L["fuse_ms"] / max(L["fuse_calls"], 1),
+                     "match_kernel_ms_per_call": L["fuse_kernel_ms"] / max(L["fuse_calls"], 1),
+                     "map_points_per_call": L["fuse_points"] / max(L["fuse_calls"], 1), "fused_per_keyframe": L["fused"] / L["jobs"]}})(st.get("lm")),
         "match_kernel_ms_per_frame": st["match_kernel_ms"] / max(st["timed_frames"], 1),
         "pose_kernel_ms_per_call": pose_ms,
         "extract_stage_ms_per_frame": stage,
@@ -512,9 +545,14 @@ def gba_records(dev, cases):
         t0 = time.perf_counter()
         p = synth.make_ba_case(name, 1)
         gen_s = time.perf_counter() - t0
-        o.BundleAdjustment(p, nIterations=2, bRobust=True)  # warm-up: buffers
+        o.BundleAdjustment(p, nIterations=2, bRobust=False)  # warm-up: buffers
+        # the function's default (Huber on) as a second key; the headline is the reference's own server-side call,
+        # GlobalBundleAdjustemnt(map, 10, &stop, kf, false): code/src/MediatorScheduler.cc:122, LoopClosing.cc:606
         t0 = time.perf_counter()
-        r = o.BundleAdjustment(p, nIterations=10, bRobust=True)
+        rh = o.BundleAdjustment(p, nIterations=10, bRobust=True)
+        wall_huber = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        r = o.BundleAdjustment(p, nIterations=10, bRobust=False)
         wall = time.perf_counter() - t0
         inf = r["info"]
         n = 6 * int(inf["n_free_keyframes"])  # keyframes the solver gave a hessian index (not fixed AND observed)
@@ -529,6 +567,10 @@ def gba_records(dev, cases):
         # system exceed what a sparse map needs (GBA-2r) - neither may flatter the kernel
         atf = min(stf, tf)
         out[name] = {"free_keyframes": n // 6, "points": int(len(p["Xw"])), "edges": int(len(p["edge_pose"])),
+                     "robust": False,
+                     "huber_on": {"wall_ms": wall_huber * 1e3, "gpu_ms": rh["info"]["gpu_ms"], "lm_trials": rh["info"]["lm_trials"],
+                                  "chi2_final": rh["info"]["chi2_final"],
+                                  "ms_per_solve": rh["info"]["solve_ms"] / max(rh["info"]["n_solves"], 1)},
                      "wall_ms": wall * 1e3, "gpu_ms": inf["gpu_ms"], "lm_trials": inf["lm_trials"],
                      "chi2_initial": inf["chi2_initial"], "chi2_final": inf["chi2_final"], "generator_s": gen_s,
                      "solver_path": int(inf["solver_path"]),
@@ -657,8 +699,9 @@ def main():
                              "UndistortKeyPoints/AssignFeaturesToGrid on the device + SearchByProjection(last frame) -> "
                              "PoseOptimization over its matches -> isInFrustum + SearchByProjection(local map) -> "
                              "PoseOptimization -> third PoseOptimization (TrackReferenceKeyFrame fallback) -> keyframe / new "
-                             "map points, chained device-resident; HIP LocalBA (LBA-M window every %d frames) on a "
-                             "local-mapping thread, as in the reference" % (nfeatures, LBA_EVERY)) if euroc else
+                             "map points, chained device-resident; on a local-mapping thread, as in the reference, every "
+                             "%d-th frame becomes a keyframe: SearchForTriangulation against the last <= 20 keyframes, Fuse "
+                             "into them and back, then HIP LocalBA (LBA-M window)" % (nfeatures, LBA_EVERY)) if euroc else
                             "KITTI-sized 1241x376 stream, nFeatures %d, same chained per-frame path" % nfeatures,
                 "agents": world * A, "lba_edges": int(len(lba_window["edge_pose"])),
                 "descriptor_exchanges": st.get("n_xchg", 0),

@@ -12,7 +12,14 @@
 //                            fallback; SURVEY 8d counts three calls per frame), result unused
 //     "keyframe":            unmatched keypoints become map points (so_map_write)
 //     every lba_every frames: hand a window to the local-mapping thread (at most two waiting: back-pressure)
-// Local-mapping thread: Optimizer::LocalBundleAdjustment (so_bundle_adjust) on each queued window, in order.
+// Local-mapping thread, per queued keyframe (every lba_every-th tracked frame), in LocalMapping::Run's order
+// (code/src/LocalMapping.cc:53-110): CreateNewMapPoints' matcher load - SearchForTriangulation of the new keyframe against
+// each of the last <= 20 keyframes (:197-246) -, SearchInNeighbors' - Fuse of its map points into each of them and of
+// theirs into it (:451-481) -, then Optimizer::LocalBundleAdjustment (so_bundle_adjust) on the queued window.  The
+// matcher job works on snapshots of the tracked frames (keypoints, bindings, pose, the bound map points' fields) and
+// needs a vocabulary stand-in (so_replay_set_vocabulary: the feature vector of a keyframe = its descriptors' nearest
+// of ~100 centroid descriptors, found with so_hamming_top2 - DBoW2 itself is out of scope); its
+// results are counted and logged, not fed back into the tracked map (like the window's).
 //
 // It is NOT the reference's Tracking state machine (out of scope): it is the shortest loop that chains every
 // per-frame operator the way Tracking does, on the synthetic planar scene of swarmmap_amd/synth.py (map points come
@@ -26,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -109,6 +117,27 @@ M4 from_f12(const float* p) {
 
 }  // namespace
 
+// What the local-mapping thread keeps of a tracked frame that became a keyframe (KeyFrame::KeyFrame(Frame&, ...),
+// code/src/KeyFrame.cc:47-72): keypoints, descriptors, pose, bindings to map points that existed before the frame
+// (those created AT the frame play the part of the still untriangulated features: -1), the bound points' fields.
+struct KfSnap {
+    int n = 0;
+    std::vector<float> x, y, angle;
+    std::vector<int32_t> octave, mp;
+    std::vector<uint8_t> desc;
+    std::vector<float> mpX, mpN, mpMax, mpMin;
+    std::vector<uint8_t> mpDesc;
+    float T[12] = {0}, bounds[4] = {0, 0, 0, 0};
+    int t = 0;
+    // DBoW2::FeatureVector stand-in, filled by the local-mapping thread
+    std::vector<int32_t> node_id, off, idx;
+};
+
+struct LmJob {
+    int timed = 0;
+    std::shared_ptr<KfSnap> kf;  // null: window only (warm-up / no vocabulary)
+};
+
 struct so_replay {
     int device = 0, width = 0, height = 0, lba_every = 5;
     int keyframe_every = 8, local_keyframes = 0, third_pose = 1;
@@ -122,6 +151,14 @@ struct so_replay {
     so_map* map = nullptr;
     so_ba* tracker_opt = nullptr;
     so_ba* mapper_opt = nullptr;
+    so_matcher* mapper_matcher = nullptr;  // the local-mapping thread's own matcher context
+    std::vector<uint8_t> vocab;            // n_vocab x 32 centroid descriptors (so_replay_set_vocabulary)
+    int lm_neighbours = 20;                // nn = 20, LocalMapping.cc:207,455 (monocular)
+    std::deque<std::shared_ptr<KfSnap>> lm_ring;  // (local-mapping thread only)
+    std::vector<int32_t> lm_stamp, lm_cstamp;     // slot -> id of the keyframe / job that marked it
+    int lm_stamp_id = 0;
+    double lm_stat[16] = {0};
+    std::vector<int32_t> lm_log;           // 5 ints per job: t, neighbours, triangulation matches, fused, fused back
     std::vector<const uint8_t*> frames;
     bool frames_on_device = false;
     // so_fleet_run: the extractors of the fleet this agent leads, as one group (one extraction chain for all agents)
@@ -152,6 +189,8 @@ struct so_replay {
     int kf_inliers = 0;
     // host copy of the map positions (PoseOptimization inputs are gathered here) + keyframe bookkeeping
     std::vector<float> mp_X;
+    std::vector<float> mp_N, mp_max, mp_min;  // normal, mfMaxDistance, mfMinDistance as written to the device table
+    std::vector<uint8_t> mp_desc;
     std::vector<int32_t> kf_first_slot;
     // scratch
     std::vector<int32_t> last_slot, k2l, k2m, idx, local_slot;
@@ -165,7 +204,7 @@ struct so_replay {
     std::thread mapper;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<int> queue;  // 1 = timed window, 0 = warm-up window
+    std::deque<LmJob> queue;  // timed = 1: counted window, 0: warm-up window
     int running = 0;
     bool quit = false;
     std::string error;
@@ -175,6 +214,7 @@ struct so_replay {
         double match_kernel = 0, pose_kernel = 0, pose_trials = 0, pose_points = 0, mstat[4] = {0, 0, 0, 0}, reruns = 0, wide_m2 = 0;
         int pose_calls = 0, pose_timed_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0, hcur = 0, first_slot = 0;
         int32_t n_in = 0;
+        int map_size_at_begin = 0;
         bool first = false, m2_submitted = false, timed_kernels = true, next_submitted = false;
         int m2_rc = 0;
         float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
@@ -200,17 +240,208 @@ enum {  // indices of so_replay::stat, mirrored in bench.py
     kLbaTrials /* LM trials (= reduced-system solves) of all windows; kLbaSolves / kLbaSolveMs cover the event-timed ones */
 };
 
+so_frame_view keyframe_view(const so_replay* r, const KfSnap& k) {
+    so_frame_view v;
+    memset(&v, 0, sizeof(v));
+    v.n = k.n;
+    v.x = k.x.data(); v.y = k.y.data(); v.octave = k.octave.data(); v.angle = k.angle.data(); v.desc = k.desc.data();
+    // a KeyFrame's bounds are the Frame's truncated to int, its grid is the Frame's (include/swarmorb.h, so_frame_view)
+    v.min_x = (float)(int)k.bounds[0]; v.max_x = (float)(int)k.bounds[1];
+    v.min_y = (float)(int)k.bounds[2]; v.max_y = (float)(int)k.bounds[3];
+    v.grid_inv_w = 64.0f / (k.bounds[1] - k.bounds[0]);
+    v.grid_inv_h = 48.0f / (k.bounds[3] - k.bounds[2]);
+    v.has_grid_origin = 1;
+    v.grid_min_x = k.bounds[0];
+    v.grid_min_y = k.bounds[2];
+    v.scale_factors = r->scale;
+    v.nlevels = r->nlevels;
+    return v;
+}
+
+// LocalMapping::ComputeF12 (code/src/LocalMapping.cc:593-609) and the epipole of SearchForTriangulation
+// (code/src/ORBmatcher.cc:605-613) from the two poses; both keyframes share K.
+void fundamental_and_epipole(const so_replay* r, const float* T1, const float* T2, float* F12, float* ex, float* ey) {
+    double R1[9], R2[9], t1[3], t2[3];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) { R1[3 * i + j] = T1[4 * i + j]; R2[3 * i + j] = T2[4 * i + j]; }
+        t1[i] = T1[4 * i + 3]; t2[i] = T2[4 * i + 3];
+    }
+    double R12[9], t12[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R12[3 * i + j] = R1[3 * i] * R2[3 * j] + R1[3 * i + 1] * R2[3 * j + 1] + R1[3 * i + 2] * R2[3 * j + 2];
+    for (int i = 0; i < 3; i++) t12[i] = -(R12[3 * i] * t2[0] + R12[3 * i + 1] * t2[1] + R12[3 * i + 2] * t2[2]) + t1[i];
+    const double tx[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};
+    double A[9];  // t12x * R12
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) A[3 * i + j] = tx[3 * i] * R12[j] + tx[3 * i + 1] * R12[3 + j] + tx[3 * i + 2] * R12[6 + j];
+    const double fx = r->cam.fx, fy = r->cam.fy, cx = r->cam.cx, cy = r->cam.cy;
+    const double Kit[9] = {1 / fx, 0, 0, 0, 1 / fy, 0, -cx / fx, -cy / fy, 1};  // K^-T
+    const double Ki[9] = {1 / fx, 0, -cx / fx, 0, 1 / fy, -cy / fy, 0, 0, 1};   // K^-1
+    double B[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) B[3 * i + j] = Kit[3 * i] * A[j] + Kit[3 * i + 1] * A[3 + j] + Kit[3 * i + 2] * A[6 + j];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) F12[3 * i + j] = (float)(B[3 * i] * Ki[j] + B[3 * i + 1] * Ki[3 + j] + B[3 * i + 2] * Ki[6 + j]);
+    double Cw[3], C2[3];
+    for (int j = 0; j < 3; j++) Cw[j] = -(R1[j] * t1[0] + R1[3 + j] * t1[1] + R1[6 + j] * t1[2]);
+    for (int i = 0; i < 3; i++) C2[i] = R2[3 * i] * Cw[0] + R2[3 * i + 1] * Cw[1] + R2[3 * i + 2] * Cw[2] + t2[i];
+    *ex = (float)(fx * C2[0] / C2[2] + cx);
+    *ey = (float)(fy * C2[1] / C2[2] + cy);
+}
+
+enum { kLmJobs = 0, kLmWallMs, kLmNodeMs, kLmTriCalls, kLmTriMs, kLmTriKernelMs, kLmTriMatches, kLmFuseCalls, kLmFuseMs,
+       kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries };
+
+// CreateNewMapPoints' and SearchInNeighbors' matcher load for the new keyframe `c` (see the file header).
+int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
+    so_matcher* m = r->mapper_matcher;
+    const double t0 = now_ms();
+    const int n = c->n, nv = (int)(r->vocab.size() / 32);
+    double st[16] = {0};
+    float kms = 0.f;
+    so_matcher_set_profiling(m, 1);
+    {   // KeyFrame::ComputeBoW's feature vector, stand-in: node = nearest centroid descriptor (lowest index on ties)
+        std::vector<int32_t> node((size_t)n), bd((size_t)n), sd((size_t)n);
+        if (n > 0 && so_hamming_top2(m, c->desc.data(), n, r->vocab.data(), nv, node.data(), bd.data(), sd.data()) != SO_OK) return SO_ERR_HIP;
+        std::vector<int32_t> count((size_t)nv + 1, 0);
+        for (int i = 0; i < n; i++) count[(size_t)node[(size_t)i] + 1]++;
+        for (int v = 0; v < nv; v++) count[(size_t)v + 1] += count[(size_t)v];
+        std::vector<int32_t> pos(count.begin(), count.end() - 1), by_node((size_t)n);
+        for (int i = 0; i < n; i++) by_node[(size_t)pos[(size_t)node[(size_t)i]]++] = i;  // feature order inside a node
+        c->off.assign(1, 0);
+        for (int v = 0; v < nv; v++)
+            if (count[(size_t)v + 1] > count[(size_t)v]) {
+                c->node_id.push_back(v);
+                for (int a = count[(size_t)v]; a < count[(size_t)v + 1]; a++) c->idx.push_back(by_node[(size_t)a]);
+                c->off.push_back((int32_t)c->idx.size());
+            }
+    }
+    st[kLmNodeMs] = now_ms() - t0;
+    const so_featvec fv1{(int32_t)c->node_id.size(), c->node_id.data(), c->off.data(), c->idx.data()};
+    std::vector<uint8_t> free1((size_t)n), free2, valid;
+    for (int i = 0; i < n; i++) free1[(size_t)i] = c->mp[(size_t)i] < 0 ? 1 : 0;
+    const so_frame_view Vc = keyframe_view(r, *c);
+    float level_sigma2[8];
+    for (int l = 0; l < 8; l++) level_sigma2[l] = r->scale[l] * r->scale[l];
+    int n_tri = 0, n_fused = 0, n_back = 0;
+    std::vector<int32_t> m12((size_t)n), best, dist;
+    // ---- CreateNewMapPoints: SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false) per neighbour
+    for (const auto& kf2 : r->lm_ring) {
+        float F12[9], ex, ey;
+        fundamental_and_epipole(r, c->T, kf2->T, F12, &ex, &ey);
+        free2.resize((size_t)kf2->n);
+        for (int i = 0; i < kf2->n; i++) free2[(size_t)i] = kf2->mp[(size_t)i] < 0 ? 1 : 0;
+        const so_featvec fv2{(int32_t)kf2->node_id.size(), kf2->node_id.data(), kf2->off.data(), kf2->idx.data()};
+        int32_t nm = 0;
+        const double ta = now_ms();
+        if (so_search_for_triangulation(m, n, c->x.data(), c->y.data(), c->angle.data(), c->desc.data(), free1.data(), &fv1, kf2->n,
+                                        kf2->x.data(), kf2->y.data(), kf2->octave.data(), kf2->angle.data(), kf2->desc.data(),
+                                        free2.data(), &fv2, F12, ex, ey, r->scale, level_sigma2, r->nlevels, 1, m12.data(), &nm) != SO_OK)
+            return SO_ERR_HIP;
+        st[kLmTriMs] += now_ms() - ta;
+        so_matcher_last_kernel_ms(m, &kms);
+        st[kLmTriKernelMs] += kms;
+        st[kLmTriCalls] += 1;
+        n_tri += nm;
+    }
+    // ---- SearchInNeighbors: matcher.Fuse(pKFi, vpMapPointMatches) per neighbour (LocalMapping.cc:451-457) ...
+    const size_t map_size = r->lm_stamp.size();
+    auto grow = [&](size_t slots) {
+        if (slots > r->lm_stamp.size()) { r->lm_stamp.resize(slots + slots / 2 + 1024, -1); r->lm_cstamp.resize(r->lm_stamp.size(), -1); }
+    };
+    (void)map_size;
+    int max_slot = -1;
+    for (int i = 0; i < n; i++) max_slot = std::max(max_slot, c->mp[(size_t)i]);
+    for (const auto& k2 : r->lm_ring)
+        for (int i = 0; i < k2->n; i++) max_slot = std::max(max_slot, k2->mp[(size_t)i]);
+    grow((size_t)(max_slot + 1));
+    so_mappoint_view P;
+    memset(&P, 0, sizeof(P));
+    P.n = n; P.Xw = c->mpX.data(); P.normal = c->mpN.data(); P.max_dist = c->mpMax.data(); P.min_dist = c->mpMin.data();
+    P.desc = c->mpDesc.data();
+    valid.resize((size_t)n);
+    best.resize((size_t)n); dist.resize((size_t)n);
+    for (const auto& k2 : r->lm_ring) {
+        const int id = ++r->lm_stamp_id;
+        for (int i = 0; i < k2->n; i++)
+            if (k2->mp[(size_t)i] >= 0) r->lm_stamp[(size_t)k2->mp[(size_t)i]] = id;
+        for (int i = 0; i < n; i++)  // pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKFi), ORBmatcher.cc:770-774
+            valid[(size_t)i] = (c->mp[(size_t)i] >= 0 && r->lm_stamp[(size_t)c->mp[(size_t)i]] != id) ? 1 : 0;
+        P.valid = valid.data();
+        const so_frame_view V2 = keyframe_view(r, *k2);
+        int32_t nf = 0;
+        const double ta = now_ms();
+        if (so_fuse(m, &V2, &r->cam, k2->T, r->log_sf, r->inv_sigma2, &P, 3.0f, best.data(), dist.data(), &nf, nullptr) != SO_OK) return SO_ERR_HIP;
+        st[kLmFuseMs] += now_ms() - ta;
+        so_matcher_last_kernel_ms(m, &kms);
+        st[kLmFuseKernelMs] += kms;
+        st[kLmFuseCalls] += 1;
+        st[kLmFusePoints] += n;
+        n_fused += nf;
+    }
+    // ... then the neighbours' map points into the new keyframe: vpFuseCandidates, once each (:459-481)
+    if (!r->lm_ring.empty()) {
+        const int job = ++r->lm_stamp_id;
+        std::vector<float> X, N, mx, mn;
+        std::vector<uint8_t> D, ok;
+        const int cid = ++r->lm_stamp_id;
+        for (int i = 0; i < n; i++)
+            if (c->mp[(size_t)i] >= 0) r->lm_stamp[(size_t)c->mp[(size_t)i]] = cid;
+        for (const auto& k2 : r->lm_ring)
+            for (int i = 0; i < k2->n; i++) {
+                const int slot = k2->mp[(size_t)i];
+                if (slot < 0 || r->lm_cstamp[(size_t)slot] == job) continue;  // mnFuseCandidateForKF
+                r->lm_cstamp[(size_t)slot] = job;
+                X.insert(X.end(), &k2->mpX[3 * (size_t)i], &k2->mpX[3 * (size_t)i] + 3);
+                N.insert(N.end(), &k2->mpN[3 * (size_t)i], &k2->mpN[3 * (size_t)i] + 3);
+                mx.push_back(k2->mpMax[(size_t)i]);
+                mn.push_back(k2->mpMin[(size_t)i]);
+                D.insert(D.end(), &k2->mpDesc[32 * (size_t)i], &k2->mpDesc[32 * (size_t)i] + 32);
+                ok.push_back(r->lm_stamp[(size_t)slot] != cid ? 1 : 0);  // !IsInKeyFrame(mpCurrentKeyFrame)
+            }
+        so_mappoint_view Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.n = (int32_t)mx.size(); Q.Xw = X.data(); Q.normal = N.data(); Q.max_dist = mx.data(); Q.min_dist = mn.data();
+        Q.desc = D.data(); Q.valid = ok.data();
+        best.resize((size_t)Q.n); dist.resize((size_t)Q.n);
+        int32_t nf = 0;
+        const double ta = now_ms();
+        if (so_fuse(m, &Vc, &r->cam, c->T, r->log_sf, r->inv_sigma2, &Q, 3.0f, best.data(), dist.data(), &nf, nullptr) != SO_OK) return SO_ERR_HIP;
+        st[kLmFuseMs] += now_ms() - ta;
+        so_matcher_last_kernel_ms(m, &kms);
+        st[kLmFuseKernelMs] += kms;
+        st[kLmFuseCalls] += 1;
+        st[kLmFusePoints] += Q.n;
+        n_back = nf;
+    }
+    const int32_t row[5] = {c->t, (int32_t)r->lm_ring.size(), n_tri, n_fused, n_back};
+    r->lm_ring.push_back(c);
+    while ((int)r->lm_ring.size() > r->lm_neighbours) r->lm_ring.pop_front();
+    st[kLmJobs] = 1; st[kLmWallMs] = now_ms() - t0; st[kLmTriMatches] = n_tri; st[kLmFused] = n_fused + n_back;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->lm_log.insert(r->lm_log.end(), row, row + 5);
+        if (timed)
+            for (int i = 0; i < 16; i++) r->lm_stat[i] += st[i];
+    }
+    return SO_OK;
+}
+
 void mapper_loop(so_replay* r) {
     for (;;) {
         int timed;
+        std::shared_ptr<KfSnap> kf;
         {
             std::unique_lock<std::mutex> lk(r->mu);
             r->cv.wait(lk, [r] { return r->quit || !r->queue.empty(); });
             if (r->queue.empty()) return;
-            timed = r->queue.front();
+            timed = r->queue.front().timed;
+            kf = r->queue.front().kf;
             r->running = 1;
         }
         const double t0 = now_ms();
+        int lm_rc = SO_OK;
+        if (kf) lm_rc = lm_matcher_job(r, kf, timed != 0);  // CreateNewMapPoints + SearchInNeighbors before the LBA
         so_ba_problem p{};
         const BaWindow& w = r->window;
         p.n_poses = (int32_t)w.fixed.size();
@@ -235,6 +466,7 @@ void mapper_loop(so_replay* r) {
         {
             std::lock_guard<std::mutex> lk(r->mu);
             if (rc != SO_OK && r->error.empty()) r->error = std::string("so_bundle_adjust: ") + so_last_error();
+            if (lm_rc != SO_OK && r->error.empty()) r->error = std::string("local-mapping matcher job: ") + so_last_error();
             if (timed) {
                 r->stat[kLbaWindows] += 1;
                 r->stat[kLbaBusyMs] += busy;
@@ -293,6 +525,12 @@ int add_points(so_replay* r, const M4& T, const so_replay::FrameHost& F, const s
                      r->new_desc.data()) != SO_OK)
         return -1;
     r->mp_X.insert(r->mp_X.end(), r->new_X.begin(), r->new_X.end());
+    if (!r->vocab.empty()) {  // the local-mapping matcher job reads these through the keyframe snapshots
+        r->mp_N.insert(r->mp_N.end(), r->new_N.begin(), r->new_N.end());
+        r->mp_max.insert(r->mp_max.end(), r->new_max.begin(), r->new_max.end());
+        r->mp_min.insert(r->mp_min.end(), r->new_min.begin(), r->new_min.end());
+        r->mp_desc.insert(r->mp_desc.end(), r->new_desc.begin(), r->new_desc.begin() + 32 * (size_t)n_sel);
+    }
     r->kf_first_slot.push_back(first);
     return first;
 }
@@ -339,6 +577,7 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
     if (rc == SO_OK) rc = so_map_create(device, &r->map);
     if (rc == SO_OK) rc = so_ba_create(device, &r->tracker_opt);
     if (rc == SO_OK) rc = so_ba_create(device, &r->mapper_opt);
+    if (rc == SO_OK) rc = so_matcher_create(device, &r->mapper_matcher);
     if (rc != SO_OK) {
         delete r;
         return rc;
@@ -394,6 +633,7 @@ void so_replay_destroy(so_replay* r) {
     so_map_destroy(r->map);
     so_ba_destroy(r->tracker_opt);
     so_ba_destroy(r->mapper_opt);
+    so_matcher_destroy(r->mapper_matcher);
     delete r;
 }
 
@@ -432,12 +672,36 @@ int so_replay_preallocate(so_replay* r) {
     if (!r || r->window.epose.empty()) return SO_ERR_INVALID_ARG;
     {
         std::unique_lock<std::mutex> lk(r->mu);
-        r->queue.push_back(0);
+        r->queue.push_back(LmJob{});
     }
     r->cv.notify_all();
     std::unique_lock<std::mutex> lk(r->mu);
     r->cv.wait(lk, [r] { return r->queue.empty() && !r->running; });
     return r->error.empty() ? SO_OK : SO_ERR_HIP;
+}
+
+// Vocabulary stand-in for the local-mapping matcher job: n centroid descriptors (32 B each).  Set before the first
+// frame; without it the local-mapping thread only optimises its windows.
+int so_replay_set_vocabulary(so_replay* r, const uint8_t* centroids, int n, int neighbours) {
+    if (!r || !centroids || n <= 0 || r->n_tracked > 0) return SO_ERR_INVALID_ARG;
+    r->vocab.assign(centroids, centroids + 32 * (size_t)n);
+    if (neighbours > 0) r->lm_neighbours = neighbours;
+    return SO_OK;
+}
+// statistics of the timed matcher jobs (indices: the kLm* enumeration above) and the log of every job:
+// 5 ints each = frame index, neighbours, SearchForTriangulation matches, points fused into neighbours, fused back
+int so_replay_lm_stats(so_replay* r, double* out16) {
+    if (!r || !out16) return SO_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(r->mu);
+    memcpy(out16, r->lm_stat, sizeof(r->lm_stat));
+    return SO_OK;
+}
+int so_replay_lm_log(so_replay* r, int32_t* out, int cap_rows) {
+    if (!r) return SO_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(r->mu);
+    const int rows = (int)(r->lm_log.size() / 5);
+    if (out) memcpy(out, r->lm_log.data(), sizeof(int32_t) * 5 * (size_t)std::min(rows, cap_rows));
+    return rows;
 }
 
 int so_replay_set_profiling(so_replay* r, int enabled) { return r ? so_extractor_set_profiling(r->ex, enabled) : SO_ERR_INVALID_ARG; }
@@ -494,6 +758,7 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
     }
     S.t1 = S.tm2 = S.tp1 = S.tm1 = S.tp2 = S.tp3 = S.tmap = now_ms();
     S.n_in = n;
+    S.map_size_at_begin = (int)(r->mp_X.size() / 3);
     for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = -1;
     memset(F.outlier.data(), 0, (size_t)n);
     S.T = M4::eye();
@@ -709,6 +974,39 @@ int step_keyframe(so_replay* r) {
     return SO_OK;
 }
 
+// The tracked frame as the local-mapping thread's new keyframe (KfSnap).
+std::shared_ptr<KfSnap> snapshot_keyframe(so_replay* r, int t) {
+    const so_replay::Step& S = r->step;
+    const so_replay::FrameHost& F = r->fh[r->cur];
+    auto k = std::make_shared<KfSnap>();
+    const int n = F.n;
+    k->n = n;
+    k->t = t;
+    k->x.resize((size_t)n); k->y.resize((size_t)n); k->angle.resize((size_t)n); k->octave.resize((size_t)n); k->mp.resize((size_t)n);
+    k->desc.assign(F.desc.begin(), F.desc.begin() + 32 * (size_t)n);
+    k->mpX.assign(3 * (size_t)n, 0.f); k->mpN.assign(3 * (size_t)n, 0.f);
+    k->mpMax.assign((size_t)n, 0.f); k->mpMin.assign((size_t)n, 0.f); k->mpDesc.assign(32 * (size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        k->x[(size_t)i] = F.xy_un[2 * (size_t)i];
+        k->y[(size_t)i] = F.xy_un[2 * (size_t)i + 1];
+        k->angle[(size_t)i] = F.kps[(size_t)i].angle;
+        k->octave[(size_t)i] = F.kps[(size_t)i].octave;
+        const int slot = F.kp_mp[(size_t)i];
+        const bool bound = slot >= 0 && slot < S.map_size_at_begin && !F.outlier[(size_t)i];
+        k->mp[(size_t)i] = bound ? slot : -1;
+        if (bound) {
+            memcpy(&k->mpX[3 * (size_t)i], &r->mp_X[3 * (size_t)slot], 12);
+            memcpy(&k->mpN[3 * (size_t)i], &r->mp_N[3 * (size_t)slot], 12);
+            k->mpMax[(size_t)i] = r->mp_max[(size_t)slot];
+            k->mpMin[(size_t)i] = r->mp_min[(size_t)slot];
+            memcpy(&k->mpDesc[32 * (size_t)i], &r->mp_desc[32 * (size_t)slot], 32);
+        }
+    }
+    to_f12(S.T, k->T);
+    memcpy(k->bounds, r->bounds, sizeof(k->bounds));
+    return k;
+}
+
 // log, hand a window to the local-mapping thread every lba_every frames, statistics
 void step_end(so_replay* r, int t, int timed) {
     so_replay::Step& S = r->step;
@@ -728,9 +1026,12 @@ void step_end(so_replay* r, int t, int timed) {
     const double t3 = now_ms();
     r->frame_ms.push_back((float)(t3 - S.t0));
     if (t % r->lba_every == 0 && !r->window.epose.empty()) {
+        LmJob job;
+        job.timed = timed ? 1 : 0;
+        if (!r->vocab.empty()) job.kf = snapshot_keyframe(r, t);
         std::unique_lock<std::mutex> lk(r->mu);
         r->cv.wait(lk, [r] { return r->queue.size() < 3; });  // the running window + two waiting
-        r->queue.push_back(timed ? 1 : 0);
+        r->queue.push_back(job);
         lk.unlock();
         r->cv.notify_all();
     }

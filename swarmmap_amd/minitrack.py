@@ -74,9 +74,27 @@ class HipBackend:
         r = self.lba.LocalBundleAdjustment(window)
         return r["Tcw"], r["Xw"], r["outlier"]
 
+    # ---- the local-mapping thread's matcher operators (local_mapping_matcher_job below) ----
+    def _lm(self):
+        if getattr(self, "m_lm", None) is None:
+            from .matcher import ORBmatcher
+            self.m_lm = ORBmatcher(0.6, True)  # LocalMapping.cc:200 / :451: ORBmatcher matcher(0.6, false) / matcher
+        return self.m_lm
+
+    def assign_nodes(self, desc, vocab):
+        return self._lm().hamming_top2(desc, vocab)[0]
+
+    def search_for_triangulation(self, kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2):
+        return self._lm().SearchForTriangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2)[0]
+
+    def fuse(self, KF, K, Tcw, log_sf, inv_sigma2, mp, th):
+        return self._lm().Fuse(KF, K, Tcw, log_sf, inv_sigma2, mp, th)[0]
+
     def close(self):
         for o in self.frames + [self.map, self.ex, self.m_last, self.m_map, self.opt, self.lba]:
             o.close()
+        if getattr(self, "m_lm", None) is not None:
+            self.m_lm.close()
 
 
 def _T44(T12):
@@ -133,14 +151,82 @@ def _local_window(kfs, mp_X, intr, n_free=6, n_fixed=8):
     return prob, poses, pts, np.concatenate(ref)
 
 
+def fundamental_and_epipole(K, T1, T2):
+    """LocalMapping::ComputeF12 (code/src/LocalMapping.cc:593-609) and the epipole of SearchForTriangulation
+    (code/src/ORBmatcher.cc:605-613) from two float poses [R | t] (12 floats each); both keyframes share K."""
+    fx, fy, cx, cy = [float(v) for v in K]
+    T1 = np.asarray(T1, np.float32).astype(np.float64).reshape(3, 4)
+    T2 = np.asarray(T2, np.float32).astype(np.float64).reshape(3, 4)
+    R1, t1, R2, t2 = T1[:, :3], T1[:, 3], T2[:, :3], T2[:, 3]
+    R12 = R1 @ R2.T
+    t12 = -R12 @ t2 + t1
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    Ki = np.array([[1 / fx, 0, -cx / fx], [0, 1 / fy, -cy / fy], [0, 0, 1]])
+    F12 = (Ki.T @ tx @ R12 @ Ki).astype(np.float32)
+    C2 = R2 @ (-R1.T @ t1) + t2
+    return F12, (np.float32(fx * C2[0] / C2[2] + cx), np.float32(fy * C2[1] / C2[2] + cy))
+
+
+def keyframe_view(kf, sf):
+    """FrameView of a keyframe snapshot with a KeyFrame's bounds: the Frame's truncated to int for IsInImage /
+    GetFeaturesInArea, the Frame's float ones for the grid it copied (include/swarmorb.h, so_frame_view)."""
+    from .matcher import FrameView
+    b = [float(v) for v in kf["bounds"]]
+    return FrameView(kf["x"], kf["y"], kf["octave"], kf["angle"], kf["desc"], [float(int(v)) for v in b], sf, grid_bounds=b)
+
+
+def local_mapping_matcher_job(backend, ring, c, K, sf, inv_sigma2, log_sf, vocab):
+    """What the local-mapping thread does with a new keyframe before local BA, operators from `backend`:
+    CreateNewMapPoints' SearchForTriangulation against every neighbour (code/src/LocalMapping.cc:197-246) and
+    SearchInNeighbors' Fuse into every neighbour and back (:451-481).  The same job as swarmmap_amd/host/replay.cc's
+    lm_matcher_job.  c / ring entries: dicts x, y, angle, octave, desc, mp (slot or -1), mpX, mpN, mpMax, mpMin, mpDesc,
+    T (12), bounds.  Returns (triangulation matches, fused into neighbours, fused back)."""
+    from .matcher import FeatureVector
+    c["fv"] = FeatureVector(np.asarray(backend.assign_nodes(c["desc"], vocab), np.int32))
+    kfeat = lambda k: dict(x=k["x"], y=k["y"], angle=k["angle"], octave=k["octave"], desc=k["desc"],  # noqa: E731
+                           free=(k["mp"] < 0).astype(np.uint8))
+    n_tri = n_fused = n_back = 0
+    level_sigma2 = (np.asarray(sf, np.float32) * np.asarray(sf, np.float32)).astype(np.float32)
+    for k2 in ring:
+        F12, epi = fundamental_and_epipole(K, c["T"], k2["T"])
+        n_tri += backend.search_for_triangulation(kfeat(c), c["fv"], kfeat(k2), k2["fv"], F12, epi, sf, level_sigma2)
+    mp_c = dict(Xw=c["mpX"], normal=c["mpN"], max_dist=c["mpMax"], min_dist=c["mpMin"], desc=c["mpDesc"])
+    for k2 in ring:
+        in_kf = np.isin(c["mp"], k2["mp"][k2["mp"] >= 0])
+        mp_c["valid"] = ((c["mp"] >= 0) & ~in_kf).astype(np.uint8)
+        n_fused += backend.fuse(keyframe_view(k2, sf), K, k2["T"], log_sf, inv_sigma2, mp_c, 3.0)
+    if ring:
+        seen, rows = set(), []
+        for k2 in ring:
+            for i in np.nonzero(k2["mp"] >= 0)[0]:
+                s = int(k2["mp"][i])
+                if s not in seen:
+                    seen.add(s)
+                    rows.append((k2, i, s))
+        own = set(int(s) for s in c["mp"][c["mp"] >= 0])
+        cand = dict(Xw=np.array([k["mpX"][i] for k, i, _ in rows], np.float32).reshape(-1, 3),
+                    normal=np.array([k["mpN"][i] for k, i, _ in rows], np.float32).reshape(-1, 3),
+                    max_dist=np.array([k["mpMax"][i] for k, i, _ in rows], np.float32),
+                    min_dist=np.array([k["mpMin"][i] for k, i, _ in rows], np.float32),
+                    desc=np.array([k["mpDesc"][i] for k, i, _ in rows], np.uint8).reshape(-1, 32),
+                    valid=np.array([0 if s in own else 1 for _, _, s in rows], np.uint8))
+        n_back = backend.fuse(keyframe_view(c, sf), K, c["T"], log_sf, inv_sigma2, cand, 3.0)
+    return int(n_tri), int(n_fused), int(n_back)
+
+
 def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_ratio=0.7, local_ba=False,
-          local_keyframes=0, third_pose=False, frames=None, on_frame=None):
+          local_keyframes=0, third_pose=False, frames=None, on_frame=None, lm_every=0, vocab=None, lm_neighbours=20,
+          on_keyframe=None):
     """Returns dict(centres (n,3), poses (n,12), matches_last, matches_map, inliers, n_map_points[, lba_*]).
     local_keyframes > 0: the local map (Tracking::UpdateLocalMap) is the points created at the last that many
     keyframes instead of the whole map.  third_pose: one more PoseOptimization per frame, from the last frame's pose
     over the final matches (what Tracking::TrackReferenceKeyFrame does when the motion model fails; the per-frame
     replay of SURVEY.md 8d counts three calls), result not used.  frames: optional list of images (else
-    stream.frame(t)).  on_frame(t): called after each tracked frame; returning False ends the run."""
+    stream.frame(t)).  on_frame(t): called after each tracked frame; returning False ends the run.
+    lm_every > 0 with a vocabulary (replay.make_vocabulary): every lm_every-th frame is handed to the local-mapping
+    matcher job (local_mapping_matcher_job) as a new keyframe against the last lm_neighbours ones, as the bench's
+    local-mapping thread does; its counts land in out["lm_log"]; results are not fed back.  on_keyframe(job): instead
+    of running the job inline, hand the closure over (the CPU baseline runs it on its local-mapping thread)."""
     intr = np.asarray(K, np.float32)
     fx, fy, cx, cy = [float(v) for v in intr]
     sf, inv_sigma2 = backend.tables()
@@ -152,7 +238,10 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
     # the host's copy of the map: world position, descriptor, reference normal and scale-invariance distances
     # (MapPoint.cc:395-433); the backend keeps its own (device-resident for the HIP path)
     mp_X = np.zeros((0, 3), np.float32)
+    mp_F = dict(N=np.zeros((0, 3), np.float32), mx=np.zeros(0, np.float32), mn=np.zeros(0, np.float32),
+                D=np.zeros((0, 32), np.uint8))  # normal, mfMaxDistance, mfMinDistance, descriptor (matcher job only)
     kf_first_slot = []    # first map slot created at each keyframe
+    lm_ring, lm_log = [], []
 
     def add_points(T, xy_un, kps, desc, sel):
         nonlocal mp_X
@@ -167,10 +256,14 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
         mx = dist * sf[kps["octave"][sel]]
         first = len(mp_X)
         mp_X = np.concatenate([mp_X, X.astype(np.float32)])
-        backend.map_append(X.astype(np.float32), (PO / dist[:, None]).astype(np.float32),
-                           (1.2 * mx).astype(np.float32),                    # GetMaxDistanceInvariance
-                           (0.8 * mx / sf[nlevels - 1]).astype(np.float32),  # GetMinDistanceInvariance
-                           desc[sel])
+        fields = ((PO / dist[:, None]).astype(np.float32),
+                  (1.2 * mx).astype(np.float32),                    # GetMaxDistanceInvariance
+                  (0.8 * mx / sf[nlevels - 1]).astype(np.float32),  # GetMinDistanceInvariance
+                  desc[sel])
+        backend.map_append(X.astype(np.float32), *fields)
+        if lm_every > 0:
+            for key, a in zip(("N", "mx", "mn", "D"), fields):
+                mp_F[key] = np.concatenate([mp_F[key], a])
         kf_first_slot.append(first)
         return first
 
@@ -187,6 +280,7 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
         kps, xy_un, desc, bounds = backend.new_frame(img)
         n = len(kps)
         kp_mp = np.full(n, -1, np.int64)
+        map_size_at_begin = len(mp_X)
         if t == 0:
             T = np.eye(4)
             first = add_points(T, xy_un, kps, desc, np.ones(n, bool))
@@ -268,6 +362,29 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
                         log["lba_edges"].append(len(bad)); log["lba_outliers"].append(int(bad.sum()))
             velocity = T @ np.linalg.inv(T_last)
 
+        if lm_every > 0 and vocab is not None and t % lm_every == 0:
+            # the frame as the local-mapping thread's new keyframe: bindings to map points that existed before it
+            pre = np.where((kp_mp >= 0) & (kp_mp < map_size_at_begin) & ~outlier, kp_mp, -1).astype(np.int64)
+            s0 = np.maximum(pre, 0)
+            has = (pre >= 0)
+            snap = dict(x=xy_un[:, 0].copy(), y=xy_un[:, 1].copy(), angle=kps["angle"].copy(),
+                        octave=kps["octave"].astype(np.int32), desc=desc.copy(), mp=pre,
+                        mpX=np.where(has[:, None], mp_X[s0] if len(mp_X) else 0, 0).astype(np.float32),
+                        mpN=np.where(has[:, None], mp_F["N"][s0] if len(mp_X) else 0, 0).astype(np.float32),
+                        mpMax=np.where(has, mp_F["mx"][s0] if len(mp_X) else 0, 0).astype(np.float32),
+                        mpMin=np.where(has, mp_F["mn"][s0] if len(mp_X) else 0, 0).astype(np.float32),
+                        mpDesc=np.where(has[:, None], mp_F["D"][s0] if len(mp_X) else 0, 0).astype(np.uint8),
+                        T=T[:3, :4].astype(np.float32).reshape(12), bounds=np.asarray(bounds, np.float32), t=t)
+
+            def job(snap=snap):
+                res = local_mapping_matcher_job(backend, list(lm_ring), snap, K, sf, inv_sigma2, log_sf, vocab)
+                lm_log.append((snap["t"], len(lm_ring)) + res)
+                lm_ring.append(snap)
+                del lm_ring[:max(0, len(lm_ring) - lm_neighbours)]
+            if on_keyframe is not None:
+                on_keyframe(job)
+            else:
+                job()
         poses.append(T[:3, :4].reshape(12).copy())
         centres.append(-T[:3, :3].T @ T[:3, 3])
         log["n_map_points"].append(len(mp_X))
@@ -277,6 +394,7 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
             break
     out = dict(centres=np.array(centres), poses=np.array(poses))
     out.update({k: np.array(v) for k, v in log.items()})
+    out["lm_log"] = np.array(lm_log, np.int32).reshape(-1, 5)
     return out
 
 

@@ -16,6 +16,16 @@ STAT = ("steps", "extract_ms", "m2_ms", "pose1_ms", "m1_ms", "pose2_ms", "pose3_
         "m2_enqueue_ms", "m2_wait_ms", "m1_enqueue_ms", "m1_wait_ms", "pose_timed_calls", "timed_frames")
 
 
+LM_STAT = ("jobs", "wall_ms", "node_ms", "tri_calls", "tri_ms", "tri_kernel_ms", "tri_matches", "fuse_calls", "fuse_ms",
+           "fuse_kernel_ms", "fused", "fuse_points", "tri_queries")
+
+
+def make_vocabulary(n=100, seed=20221001):
+    """The vocabulary stand-in of the local-mapping matcher job: n seeded random 256-bit centroids; a feature's node is
+    its nearest centroid (lowest index on ties) - what one level of a DBoW2 tree does with trained centroids."""
+    return np.random.default_rng(seed).integers(0, 256, (n, 32)).astype(np.uint8)
+
+
 class Replay:
     def __init__(self, dev, w, h, nfeatures, lba_every, K, dist=None, keyframe_every=8, keyframe_ratio=0.7, plane_z=2.0,
                  local_keyframes=0, third_pose=True):
@@ -45,6 +55,9 @@ class Replay:
         lib.so_replay_matcher.argtypes = [vp]; lib.so_replay_matcher.restype = vp
         lib.so_replay_last_dframe.argtypes = [vp]; lib.so_replay_last_dframe.restype = vp
         lib.so_fleet_run.argtypes = [vp, i32, i32, i32, i32]
+        lib.so_replay_set_vocabulary.argtypes = [vp, vp, i32, i32]
+        lib.so_replay_lm_stats.argtypes = [vp, vp]
+        lib.so_replay_lm_log.argtypes = [vp, vp, i32]
         self.h = vp()
         K4 = np.ascontiguousarray(K, np.float32)
         d5 = None if dist is None else np.ascontiguousarray(list(dist) + [0.0] * (5 - len(dist)), np.float32)
@@ -75,6 +88,25 @@ class Replay:
         st, keep = problem_struct(prob)
         self._keep.append(keep)
         self._check(self.lib.so_replay_set_window(self.h, C.byref(st)), "set_window")
+
+    def set_vocabulary(self, centroids, neighbours=20):
+        """Switches the local-mapping thread's matcher job on (SearchForTriangulation + Fuse against the last
+        `neighbours` keyframes before every window): centroids = the vocabulary stand-in, n x 32 bytes."""
+        c = np.ascontiguousarray(centroids, np.uint8).reshape(-1, 32)
+        self._check(self.lib.so_replay_set_vocabulary(self.h, self._p(c), len(c), int(neighbours)), "set_vocabulary")
+
+    def lm_stats(self):
+        """Sums over the timed matcher jobs of the local-mapping thread."""
+        a = np.zeros(16, np.float64)
+        self.lib.so_replay_lm_stats(self.h, self._p(a))
+        return dict(zip(LM_STAT, a[:len(LM_STAT)].tolist()))
+
+    def lm_log(self):
+        """Every matcher job so far: rows (frame, neighbours, triangulation matches, fused into neighbours, fused back)."""
+        n = self.lib.so_replay_lm_log(self.h, None, 0)
+        out = np.zeros((max(n, 1), 5), np.int32)
+        n = min(n, self.lib.so_replay_lm_log(self.h, self._p(out), len(out)))
+        return out[:n]
 
     def preallocate(self):
         self._check(self.lib.so_replay_preallocate(self.h), "preallocate")

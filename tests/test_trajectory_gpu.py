@@ -85,8 +85,10 @@ def test_cpp_chain_in_the_bench_configuration_matches_the_oracle_chain(name):
     """Exactly what bench.py times (bench.py run_stream): the EuRoC-sized stream rendered through the EuRoC lens model
     (UndistortKeyPoints does real work) / the KITTI-sized stream with 2000 features, frames in pinned host memory read
     by the ingest kernel, the local map limited to the last 12 keyframes, the third PoseOptimization, and the
-    local-mapping thread optimising an LBA-M window every 5th frame on the same GPU while the tracking thread runs -
-    frame by frame against the same chain over the CPU oracle."""
+    local-mapping thread on the same GPU while the tracking thread runs: every 5th frame becomes its new keyframe -
+    SearchForTriangulation against each of the last <= 20 keyframes, Fuse into each of them and back
+    (code/src/LocalMapping.cc:197-246, 451-481), then an LBA-M window - frame by frame, and matcher job by matcher job,
+    against the same chain over the CPU oracle."""
     import torch
     from swarmmap_amd.replay import Replay
     euroc = name == "euroc"
@@ -103,17 +105,28 @@ def test_cpp_chain_in_the_bench_configuration_matches_the_oracle_chain(name):
     frames = [view[t] for t in range(n + 2)]
     rp = Replay(0, st.w, st.h, nfeat, 5, K, dist, plane_z=PLANE_Z, local_keyframes=12, third_pose=True)
     rp.set_frames([block.data_ptr() + i * st.w * st.h for i in range(n + 2)], on_device=False)
+    from swarmmap_amd.replay import make_vocabulary
+    vocab = make_vocabulary()
     rp.set_window(synth.make_ba_case("LBA-M", seed=100))
+    rp.set_vocabulary(vocab)
     rp.preallocate()
     rp.prime(0)
     rp.run(0, n, True)
     rp.drain()
     rp.finish()
-    a, stats = rp.log(), rp.stats()
+    a, stats, a_lm, lm_stats = rp.log(), rp.stats(), rp.lm_log(), rp.lm_stats()
     rp.close()
     assert stats["n_lba"] >= n // 5 - 1, "the local-mapping thread did not run its windows"
     b = minitrack.track(OracleBackend(K, nfeat, dist if dist is not None else (0, 0, 0, 0, 0)), None, n, K, plane_z=PLANE_Z,
-                        local_keyframes=12, third_pose=True, frames=frames)
+                        local_keyframes=12, third_pose=True, frames=frames, lm_every=5, vocab=vocab)
+    # the local-mapping thread's matcher jobs: same keyframes, same neighbours; match / fuse counts may differ by the
+    # rare decision that flips on the 2e-5 pose difference between the two chains
+    b_lm = b["lm_log"]
+    assert len(a_lm) == len(b_lm) == (n + 4) // 5 and np.array_equal(a_lm[:, :2], b_lm[:, :2])
+    assert np.all(np.abs(a_lm[:, 2:].astype(int) - b_lm[:, 2:].astype(int)) <= 3 + b_lm[:, 2:] // 100), (a_lm, b_lm)
+    assert a_lm[-1, 1] == min(20, len(a_lm) - 1) and a_lm[2:, 2].min() > 20 and a_lm[1:, 3].min() > 100
+    assert lm_stats["jobs"] == len(a_lm) and lm_stats["tri_calls"] == a_lm[:, 1].sum()
+    assert lm_stats["tri_kernel_ms"] > 0 and lm_stats["fuse_kernel_ms"] > 0
     assert len(a["poses"]) == n
     assert minitrack.ate_rmse(a["centres"], b["centres"], align=False) < ATE_HIP_VS_ORACLE
     assert np.abs(a["poses"] - b["poses"]).max() < 2e-5

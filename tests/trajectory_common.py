@@ -77,5 +77,15 @@ class OracleBackend:
         r = orc.bundle_adjust(window)
         return r["Tcw"], r["Xw"], r["outlier"]
 
+    # ---- the local-mapping thread's matcher operators (minitrack.local_mapping_matcher_job) ----
+    def assign_nodes(self, desc, vocab):
+        return orc.hamming_top2(desc, vocab)[0]
+
+    def search_for_triangulation(self, kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2):
+        return orc.search_for_triangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2, True)[0]
+
+    def fuse(self, KF, K, Tcw, log_sf, inv_sigma2, mp, th):
+        return orc.fuse(KF, orc.camera(K), Tcw, log_sf, inv_sigma2, mp, th)[0]
+
     def close(self):
         pass

@@ -4,6 +4,10 @@ build container on the full-size maps - GBA-2 (1499 keyframes looking at one clo
 8-agent street-grid map, 1503 keyframes, 710 k observations) - because it takes minutes per map, not seconds.
     python tools/make_gba_golden.py GBA-2        # -> tests/golden/gba2.npz       (~15 min on one core)
     python tools/make_gba_golden.py GBA-2r       # -> tests/golden/gba2r.npz      (~10 min)
+    python tools/make_gba_golden.py --no-robust GBA-2 GBA-2r   # -> gba2_norobust.npz, gba2r_norobust.npz
+--no-robust is the reference's own server-side call: GlobalBundleAdjustemnt(map, 10, &stop, kf, false)
+(code/src/MediatorScheduler.cc:122, code/src/LoopClosing.cc:606) - no Huber kernel; the default (Huber on) is the
+function's default argument (code/include/Optimizer.h).
 The fixture holds what tests/test_ba_gpu.py compares so_bundle_adjust with: every optimised pose, every 8th point,
 the outlier flags (packed), chi2 before / after, iteration counts - plus a digest of the generated problem, so a
 drifting generator is noticed instead of compared.  Inputs are regenerated in the test from the same seed
@@ -32,15 +36,17 @@ def problem_digest(p):
 
 
 def main():
-    for name in sys.argv[1:]:
+    args = sys.argv[1:]
+    robust = "--no-robust" not in args
+    for name in [a for a in args if not a.startswith("--")]:
         p = synth.make_ba_case(name, 1)
         t0 = time.perf_counter()
-        # Optimizer::BundleAdjustment(..., nIterations = 10, bRobust = true): one optimize(10), thHuber2D = sqrt(5.99)
-        o = oracle_py.bundle_adjust(p, its1=10, its2=0, robust=True, huber_delta=np.float32(np.sqrt(np.float32(5.99))))
+        # Optimizer::BundleAdjustment(..., nIterations = 10, bRobust): one optimize(10), thHuber2D = sqrt(5.99) when robust
+        o = oracle_py.bundle_adjust(p, its1=10, its2=0, robust=robust, huber_delta=np.float32(np.sqrt(np.float32(5.99))))
         dt = time.perf_counter() - t0
-        out = os.path.join(ROOT, "tests", "golden", FILES[name])
+        out = os.path.join(ROOT, "tests", "golden", FILES[name] if robust else FILES[name].replace(".npz", "_norobust.npz"))
         inf = o["info"]
-        np.savez_compressed(out, name=name, seed=1, digest=problem_digest(p), Tcw=o["Tcw"].astype(np.float32),
+        np.savez_compressed(out, name=name, seed=1, robust=int(robust), digest=problem_digest(p), Tcw=o["Tcw"].astype(np.float32),
                             Xw_every8=o["Xw"][::POINT_STRIDE].astype(np.float32), outlier_bits=np.packbits(o["outlier"].astype(np.uint8)),
                             n_edges=len(p["edge_pose"]), chi2=np.asarray(o["chi2"], np.float64)[::64],
                             info_keys=np.array(sorted(inf.keys())), info_vals=np.array([float(inf[k]) for k in sorted(inf.keys())]),
