@@ -379,6 +379,12 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
         # SearchForTriangulation against each of the last <= 20 keyframes (M5), Fuse into each and back (M6)
         "local_mapping_matcher": (lambda L: None if not L or not L.get("jobs") else {
             "keyframes": L["jobs"], "neighbours": LM_NEIGHBOURS, "wall_ms_per_keyframe": L["wall_ms"] / L["jobs"],
+            # all searches of a keyframe go out as one so_matcher batch (one staging copy, one projection launch, one
+            # search launch, one wait); SWARMORB_LM_BATCH=0 issues them one by one (then the per-call kernel times below)
+            "batched": bool(L.get("batch_ms")),
+            "batch": None if not L.get("batch_ms") else {"stage_and_launch_and_resolve_ms_per_keyframe": L["batch_ms"] / L["jobs"],
+                                                          "launch_wait_resolve_ms_per_keyframe": L["batch_end_ms"] / L["jobs"],
+                                                          "kernels_ms_per_keyframe": L["batch_kernel_ms"] / L["jobs"]},
             "feature_vector_ms_per_keyframe": L["node_ms"] / L["jobs"],
             "search_for_triangulation": {"calls_per_keyframe": L["tri_calls"] / L["jobs"], "host_ms_per_call": L["tri_ms"] / max(L["tri_calls"], 1),
                                          "match_kernel_ms_per_call": L["tri_kernel_ms"] / max(L["tri_calls"], 1),

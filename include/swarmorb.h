@@ -356,6 +356,19 @@ int so_search_by_projection_keyframe(so_matcher* m, const so_frame_view* F, cons
                                      int32_t orb_dist, int check_orientation, int32_t* kp_to_point, int32_t* nmatches,
                                      const so_window_queries* queries_out);
 
+/* Batched calls.  LocalMapping handles a new keyframe with one SearchForTriangulation per neighbour (<= 20,
+ * code/src/LocalMapping.cc:197-246) and one Fuse per neighbour plus one back (:451-481): some 40 independent searches of
+ * ~1000 queries each.  Between so_matcher_batch_begin and so_matcher_batch_end the calls so_search_for_triangulation,
+ * so_fuse and so_fuse_sim3 on this handle only stage their inputs and return SO_OK; so_matcher_batch_end enqueues all of
+ * them as ONE staging copy, ONE projection launch and ONE search launch (the job is a grid dimension), waits once and
+ * then writes every call's outputs - the arrays the calls were given, which must stay valid until then (the inputs are
+ * copied at call time, except angle1 / angle2 of so_search_for_triangulation, which the resolve reads).  Results are
+ * identical to the same calls made one by one.  At most 64 calls are held; further ones flush the batch first (their
+ * predecessors' outputs are then complete early).  Any other matcher call inside a batch fails with
+ * SO_ERR_INVALID_ARG.  so_matcher_last_kernel_ms / _last_stats after so_matcher_batch_end cover the whole batch. */
+int so_matcher_batch_begin(so_matcher* m);
+int so_matcher_batch_end(so_matcher* m);
+
 /* MapPoint::ComputeDistinctiveDescriptors (code/src/MapPoint.cc:323-392) for a batch of map points (SURVEY 8f rank
  * 4): point p owns descriptors [offsets[p], offsets[p+1]) (the rows the reference collects from its observing
  * keyframes, in map order); best_idx[p] = index within the point's own list of the descriptor with the least

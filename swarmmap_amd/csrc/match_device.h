@@ -131,6 +131,20 @@ struct ProjectSrc {
 };
 void launch_project_queries(const ProjectSrc& S, MatchQuery* d_q, MatchQueryW* d_qw_mapped, hipStream_t s);
 
+// Batched matcher calls (so_matcher_batch_begin / _end): several independent searches - each with its own candidate
+// frame, queries and outputs - as ONE projection launch and ONE search launch, blockIdx.y = job.  The table sits in HBM.
+struct BatchJobDev {
+    MatchFrameDev F;
+    ProjectSrc S;            // used when project != 0: the job's queries are produced on the device
+    MatchQuery* q;           // nq records (read by the search; written by the projection when project != 0)
+    MatchQueryW* qw;         // compact copies for the host (project != 0), host-mapped
+    const uint4* qdesc;      // nq x 32 B
+    uint32_t* keys;          // nq x K, host-mapped
+    int32_t* count;          // nq, host-mapped
+    int nq, K, project, pad;
+};
+void launch_batch(const BatchJobDev* d_jobs, int n_jobs, int max_project_n, int max_nq, hipStream_t s);
+
 void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_t s);
 // mode 2 = last-frame search, 3 = local-map search; queries [q_first, q_first + nq) write keys / counts at [0, nq)
 void launch_topk_track(const MatchFrameDev& F, const TrackQuerySrc& T, int mode, int q_first, int nq, int K,

@@ -218,9 +218,10 @@ __device__ __forceinline__ MatchQuery track_query_local(const TrackQuerySrc& T, 
     return Q;
 }
 
-// MODE 0: MatchQuery records, 1: MatchQueryW records, 2: last-frame tracking search, 3: local-map tracking search
+// MODE 0: MatchQuery records, 1: MatchQueryW records, 2: last-frame tracking search, 3: local-map tracking search,
+// 4: batched jobs - q points to a BatchJobDev table, blockIdx.y selects the job (frame, queries and outputs from there)
 template <int MODE>
-__global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const void* __restrict__ q,
+__global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F_arg, const void* __restrict__ q,
                                                            const uint4* __restrict__ qdesc, int nq, int K,
                                                            uint32_t* __restrict__ out_keys,
                                                            int32_t* __restrict__ out_count, TrackQuerySrc T,
@@ -228,10 +229,15 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
     __shared__ uint32_t s_keys[4][kListCap];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);  // wave-uniform: per-query data through scalar loads
+    const BatchJobDev* job = MODE == 4 ? static_cast<const BatchJobDev*>(q) + blockIdx.y : nullptr;
+    const MatchFrameDev& F = MODE == 4 ? job->F : F_arg;
+    if (MODE == 4) {
+        nq = job->nq; K = job->K; qdesc = job->qdesc; out_keys = job->keys; out_count = job->count;
+    }
     if (qi >= nq) return;
-    const bool soa = MODE >= 2 && T.keys_soa;
+    const bool soa = (MODE == 2 || MODE == 3) && T.keys_soa;
     const size_t kq = soa ? (size_t)nq : 1, kk = soa ? 1 : (size_t)K;  // key (qi, k) lives at qi * kk + k * kq
-    const bool bits = MODE >= 2 && T.use_bits;
+    const bool bits = (MODE == 2 || MODE == 3) && T.use_bits;
     MatchQuery Q;
     int slot = -1;
     if (MODE == 1) {
@@ -243,6 +249,8 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
         Q.max_dist = 256;
     } else if (MODE == 0) {
         Q = static_cast<const MatchQuery*>(q)[qi];
+    } else if (MODE == 4) {
+        Q = job->q[qi];
     } else if (MODE == 2) {
         Q = track_query_last(T, q_first + qi, slot);
     } else {
@@ -251,11 +259,11 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
     }
     if (!Q.active) {
         if (lane == 0) out_count[qi] = 0;
-        if (MODE >= 2 && T.count8_out && lane == 0) T.count8_out[q_first + qi] = 0;
+        if ((MODE == 2 || MODE == 3) && T.count8_out && lane == 0) T.count8_out[q_first + qi] = 0;
         for (int k = lane; k < K; k += 64) out_keys[(size_t)qi * kk + k * kq] = 0xFFFFFFFFu;
         return;
     }
-    const uint4* qsrc = MODE >= 2 ? T.desc + 2 * (size_t)slot : qdesc + 2 * (size_t)qi;
+    const uint4* qsrc = (MODE == 2 || MODE == 3) ? T.desc + 2 * (size_t)slot : qdesc + 2 * (size_t)qi;
     const uint4 qd0 = qsrc[0], qd1 = qsrc[1];
     const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
         }
     }
     if (lane == 0) out_count[qi] = m;
-    if (MODE >= 2 && T.count8_out && lane == 0) T.count8_out[q_first + qi] = (uint8_t)min(m, 255);
+    if ((MODE == 2 || MODE == 3) && T.count8_out && lane == 0) T.count8_out[q_first + qi] = (uint8_t)min(m, 255);
     if (m <= kListCap) {
         // K smallest keys of the list: round k = min over keys greater than the previous minimum (keys are unique)
         uint32_t prev = 0;
@@ -334,10 +342,8 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F, const
 // it (code/src/ORBmatcher.cc:776-815, :923-964, :293-333, :1063-1094, :1380-1410) with the cv::Mat conventions of
 // oracle/project_oracle.h: one GEMM = double accumulation and one rounding, norm / dot in double.  A rejected point
 // leaves an inactive query behind (topk_window_kernel writes "no candidate" for it).
-__global__ __launch_bounds__(256) void project_queries_kernel(ProjectSrc S, MatchQuery* __restrict__ q_out,
-                                                              MatchQueryW* __restrict__ qw_out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= S.n) return;
+__device__ __forceinline__ void project_one(const ProjectSrc& S, int i, MatchQuery* __restrict__ q_out,
+                                            MatchQueryW* __restrict__ qw_out) {
     MatchQuery Q = MatchQuery{};
     Q.max_dist = S.q_max_dist;
     Q.flags = S.qflags;
@@ -403,6 +409,20 @@ __global__ __launch_bounds__(256) void project_queries_kernel(ProjectSrc S, Matc
     qw_out[i] = W;
 }
 
+__global__ __launch_bounds__(256) void project_queries_kernel(ProjectSrc S, MatchQuery* __restrict__ q_out,
+                                                              MatchQueryW* __restrict__ qw_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S.n) return;
+    project_one(S, i, q_out, qw_out);
+}
+
+__global__ __launch_bounds__(256) void project_queries_batch_kernel(const BatchJobDev* __restrict__ jobs) {
+    const BatchJobDev& J = jobs[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (!J.project || i >= J.S.n) return;
+    project_one(J.S, i, J.q, J.qw);
+}
+
 void launch_project_queries(const ProjectSrc& S, MatchQuery* d_q, MatchQueryW* d_qw_mapped, hipStream_t s) {
     if (S.n <= 0) return;
     hipLaunchKernelGGL(project_queries_kernel, dim3((S.n + 255) / 256), dim3(256), 0, s, S, d_q, d_qw_mapped);
@@ -433,6 +453,18 @@ void launch_topk_window(const MatchFrameDev& F, const void* d_q, bool compact, c
     else
         hipLaunchKernelGGL(topk_window_kernel<0>, dim3((nq + 3) / 4), dim3(256), 0, s, F, d_q, d_qdesc, nq, K, d_keys,
                            d_count, none, 0);
+}
+
+void launch_batch(const BatchJobDev* d_jobs, int n_jobs, int max_project_n, int max_nq, hipStream_t s) {
+    if (n_jobs <= 0) return;
+    if (max_project_n > 0)
+        hipLaunchKernelGGL(project_queries_batch_kernel, dim3((max_project_n + 255) / 256, n_jobs), dim3(256), 0, s, d_jobs);
+    if (max_nq > 0) {
+        const TrackQuerySrc none{};
+        const MatchFrameDev unused{};
+        hipLaunchKernelGGL(topk_window_kernel<4>, dim3((max_nq + 3) / 4, n_jobs), dim3(256), 0, s, unused, (const void*)d_jobs,
+                           (const uint4*)nullptr, 0, 0, (uint32_t*)nullptr, (int32_t*)nullptr, none, 0);
+    }
 }
 
 void launch_topk_track(const MatchFrameDev& F, const TrackQuerySrc& T, int mode, int q_first, int nq, int K,

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "dframe_internal.h"
@@ -165,6 +166,28 @@ struct so_matcher {
     float grid_min_y = 0.f, grid_min_x = 0.f;  // origin the resident candidates' cells were assigned with
     std::vector<int> perm;     // rank -> keypoint index
     std::vector<int> cell_count;
+
+    // ---- so_matcher_batch_begin / _end: independent calls staged side by side, launched together ----
+    struct BatchJob {
+        size_t base = 0;         // of the job's staged block inside hb_in / db_in
+        size_t q_off = 0;        // of its MatchQuery records inside db_q when the projection writes them (else in the block)
+        size_t off_oct = 0, off_desc = 0, off_limit = 0, off_cols = 0, off_q = 0, off_qdesc = 0;
+        size_t keys_off = 0, cnt_off = 0, qw_off = 0;  // inside hb_out
+        int n_cand = 0, nq = 0, K = 1;
+        bool has_limit = false, has_cols = false, project = false;
+        float inv_sigma2[8], sigma2[8], scale[8], ex = 0.f, ey = 0.f, min_x = 0.f, min_y = 0.f, grid_inv_w = 0.f, grid_inv_h = 0.f,
+              grid_min_y = 0.f;
+        so::ProjectSrc S{};
+        size_t off_xw = 0, off_nrm = 0, off_maxd = 0, off_mind = 0, off_valid = 0;
+        std::vector<int> perm;
+        std::function<int(const uint32_t* keys, const int32_t* cnt, const so::MatchQueryW* qw, const std::vector<int>& perm)> resolve;
+    };
+    bool batching = false;
+    std::vector<BatchJob> jobs;
+    PinBuf hb_in;
+    DevBuf db_in, db_q;
+    MappedBuf hb_out;
+    size_t hb_used = 0, dq_used = 0, out_used = 0;
 };
 
 namespace {
@@ -385,6 +408,11 @@ MatchFrameDev frame_dev(const so_matcher* m) {
 // queries must already be in m->h_q / m->h_qdesc (ensure_queries).  Results land in m->h_keys / m->h_count.
 int run_topk(so_matcher* m, int nq, int K, bool compact = false) {
     if (nq <= 0) return SO_OK;
+    if (m->batching) {
+        last_error_ref() = "this call cannot be part of a matcher batch (so_matcher_batch_begin): only so_search_for_triangulation, "
+                           "so_fuse and so_fuse_sim3 can";
+        return SO_ERR_INVALID_ARG;
+    }
     int rc;
     const size_t total = m->off_qdesc + (size_t)nq * 32;
     if (m->d_in.cap < total) {
@@ -431,6 +459,134 @@ int ensure_queries(so_matcher* m, int nq, size_t record = sizeof(MatchQuery)) {
     m->h_q.p = (uint8_t*)m->h_in.p + m->off_q;
     m->h_qdesc.p = (uint8_t*)m->h_in.p + m->off_qdesc;
     return SO_OK;
+}
+
+constexpr size_t kBatchMaxJobs = 64;
+constexpr size_t kBatchTableBytes = ((sizeof(BatchJobDev) * kBatchMaxJobs + 255) / 256) * 256;
+
+int batch_flush(so_matcher* m);
+
+// The call whose inputs sit in m->h_in [0, staged_end) (frame part, then queries / descriptors / map points at the
+// offsets recorded in m) joins the batch: its block is copied behind the others, its outputs are deferred to `resolve`.
+int batch_defer(so_matcher* m, size_t staged_end, int nq, int K, const ProjectSrc* S, const size_t* mp_offsets5,
+                std::function<int(const uint32_t*, const int32_t*, const MatchQueryW*, const std::vector<int>&)> resolve) {
+    int rc;
+    if (m->jobs.size() == kBatchMaxJobs && (rc = batch_flush(m))) return rc;
+    so_matcher::BatchJob J;
+    J.base = m->hb_used;
+    J.off_oct = m->off_oct; J.off_desc = m->off_desc; J.off_limit = m->off_limit; J.off_cols = m->off_cols;
+    J.off_q = m->off_q; J.off_qdesc = m->off_qdesc;
+    J.n_cand = m->n_cand; J.has_limit = m->has_limit; J.has_cols = m->has_cols;
+    memcpy(J.inv_sigma2, m->inv_sigma2, sizeof(J.inv_sigma2));
+    memcpy(J.sigma2, m->sigma2, sizeof(J.sigma2));
+    memcpy(J.scale, m->scale, sizeof(J.scale));
+    J.ex = m->ex; J.ey = m->ey;
+    J.min_x = m->min_x; J.min_y = m->min_y; J.grid_inv_w = m->grid_inv_w; J.grid_inv_h = m->grid_inv_h; J.grid_min_y = m->grid_min_y;
+    J.nq = nq; J.K = K;
+    J.project = S != nullptr;
+    if (S) {
+        J.S = *S;
+        J.off_xw = mp_offsets5[0]; J.off_nrm = mp_offsets5[1]; J.off_maxd = mp_offsets5[2]; J.off_mind = mp_offsets5[3];
+        J.off_valid = mp_offsets5[4];
+        J.q_off = m->dq_used;
+        m->dq_used += align256(sizeof(MatchQuery) * (size_t)nq);
+    }
+    J.perm = m->perm;
+    J.resolve = std::move(resolve);
+    const size_t block = align256(staged_end);
+    if ((rc = m->hb_in.ensure_keep(kBatchTableBytes + J.base + block + 256, kBatchTableBytes + J.base))) return rc;
+    memcpy((uint8_t*)m->hb_in.p + kBatchTableBytes + J.base, m->h_in.p, staged_end);
+    m->hb_used += block;
+    J.keys_off = m->out_used;
+    m->out_used += align256(sizeof(uint32_t) * (size_t)nq * K);
+    J.cnt_off = m->out_used;
+    m->out_used += align256(sizeof(int32_t) * (size_t)nq);
+    J.qw_off = m->out_used;
+    if (S) m->out_used += align256(sizeof(MatchQueryW) * (size_t)nq);
+    m->jobs.push_back(std::move(J));
+    // whatever the handle holds of a frame is not what the next plain call may reuse
+    m->resident_n = -1;
+    m->dirty_from = 0;
+    return SO_OK;
+}
+
+// Launches everything deferred so far (one staging copy, one projection launch, one search launch), waits, resolves.
+int batch_flush(so_matcher* m) {
+    const int nj = (int)m->jobs.size();
+    if (nj == 0) return SO_OK;
+    int rc;
+    const size_t total = kBatchTableBytes + m->hb_used;
+    if ((rc = m->db_in.ensure(total))) return rc;
+    if ((rc = m->db_q.ensure(m->dq_used + 256))) return rc;
+    if ((rc = m->hb_out.ensure(m->out_used + 256))) return rc;
+    BatchJobDev* tab = (BatchJobDev*)m->hb_in.p;
+    uint8_t* dbase = (uint8_t*)m->db_in.p + kBatchTableBytes;
+    int max_n = 0, max_nq = 0;
+    for (int j = 0; j < nj; j++) {
+        const so_matcher::BatchJob& J = m->jobs[(size_t)j];
+        BatchJobDev D;
+        memset(&D, 0, sizeof(D));
+        const uint8_t* b = dbase + J.base;
+        D.F.xy = (const float2*)b;
+        D.F.octave = (const int8_t*)(b + J.off_oct);
+        D.F.desc = (const uint4*)(b + J.off_desc);
+        D.F.limit = J.has_limit ? (const int32_t*)(b + J.off_limit) : nullptr;
+        D.F.n = J.n_cand;
+        memcpy(D.F.inv_sigma2, J.inv_sigma2, sizeof(J.inv_sigma2));
+        memcpy(D.F.sigma2, J.sigma2, sizeof(J.sigma2));
+        memcpy(D.F.scale, J.scale, sizeof(J.scale));
+        D.F.ex = J.ex; D.F.ey = J.ey;
+        D.F.col_start = J.has_cols ? (const int32_t*)(b + J.off_cols) : nullptr;
+        D.F.min_x = J.min_x; D.F.min_y = J.min_y; D.F.grid_inv_w = J.grid_inv_w; D.F.grid_inv_h = J.grid_inv_h;
+        D.F.grid_min_y = J.grid_min_y;
+        D.qdesc = (const uint4*)(b + J.off_qdesc);
+        D.keys = (uint32_t*)((uint8_t*)m->hb_out.dev + J.keys_off);
+        D.count = (int32_t*)((uint8_t*)m->hb_out.dev + J.cnt_off);
+        D.nq = J.nq; D.K = J.K; D.project = J.project ? 1 : 0;
+        if (J.project) {
+            D.S = J.S;
+            D.S.Xw = (const float*)(b + J.off_xw);
+            D.S.normal = (const float*)(b + J.off_nrm);
+            D.S.max_dist = (const float*)(b + J.off_maxd);
+            D.S.min_dist = (const float*)(b + J.off_mind);
+            D.S.valid = b + J.off_valid;
+            D.S.n = J.nq;
+            D.q = (MatchQuery*)((uint8_t*)m->db_q.p + J.q_off);
+            D.qw = (MatchQueryW*)((uint8_t*)m->hb_out.dev + J.qw_off);
+            max_n = std::max(max_n, J.nq);
+        } else {
+            D.q = (MatchQuery*)(dbase + J.base + J.off_q);
+        }
+        max_nq = std::max(max_nq, J.nq);
+        tab[j] = D;
+    }
+    hipStream_t s = m->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    launch_stage_in(m->db_in.p, m->hb_in.p, total, s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_batch((const BatchJobDev*)m->db_in.p, nj, max_n, max_nq, s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    const auto t1 = std::chrono::steady_clock::now();
+    SO_HIP(hipStreamSynchronize(s));
+    const auto t2 = std::chrono::steady_clock::now();
+    m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    m->stat[2] += 2.0;
+    m->stat[3] += (double)total;
+    float ms = 0.f;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    rc = SO_OK;
+    for (int j = 0; j < nj; j++) {
+        const so_matcher::BatchJob& J = m->jobs[(size_t)j];
+        const uint8_t* ob = (const uint8_t*)m->hb_out.p;
+        const int r1 = J.resolve((const uint32_t*)(ob + J.keys_off), (const int32_t*)(ob + J.cnt_off),
+                                 (const MatchQueryW*)(ob + J.qw_off), J.perm);
+        if (r1 && !rc) rc = r1;
+    }
+    m->jobs.clear();
+    m->hb_used = m->dq_used = m->out_used = 0;
+    return rc;
 }
 
 struct Entry {
@@ -555,6 +711,7 @@ void so_matcher_destroy(so_matcher* m) {
     m->d_rq.release();
     m->h_out.release();
     m->h_rout.release();
+    m->hb_in.release(); m->db_in.release(); m->db_q.release(); m->hb_out.release();
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
     if (m->owns_stream && m->stream) (void)hipStreamDestroy(m->stream);
@@ -1338,29 +1495,34 @@ int so_search_for_triangulation(so_matcher* m, int32_t n1, const float* x1, cons
     memcpy(m->h_q.p, queries.data(), sizeof(MatchQuery) * (size_t)nq);
     uint8_t* hd = (uint8_t*)m->h_qdesc.p;
     for (int i = 0; i < nq; i++) memcpy(hd + (size_t)i * 32, desc1 + (size_t)q_idx1[(size_t)i] * 32, 32);
-    if ((rc = run_topk(m, nq, 1))) return rc;
-    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
-    std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
-    rot_item.clear();
-    rot_b.clear();
-    int hist[HISTO_LENGTH] = {0};
-    int nm = 0;
-    for (int i = 0; i < nq; i++) {
-        if (keys[i] == 0xFFFFFFFFu) continue;
-        const int idx1 = q_idx1[(size_t)i];
-        const int idx2 = m->perm[(size_t)(0xFFFF - (keys[i] & 0xFFFFu))];  // prefer-last keys store 0xFFFF - position
-        matches12[idx1] = idx2;
-        nm++;
-        if (check_orientation) {
-            const int b = rot_bin(angle1[idx1], angle2[idx2]);
-            rot_item.push_back(idx1);
-            rot_b.push_back(b);
-            hist[b]++;
+    // the part after the launch: bindings + rotation histogram (ORBmatcher.cc:708-735); deferred inside a batch
+    auto resolve = [m, nq, q_idx1 = std::move(q_idx1), angle1, angle2, check_orientation, matches12, nmatches](
+                       const uint32_t* keys, const int32_t*, const MatchQueryW*, const std::vector<int>& perm) -> int {
+        std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;  // (capacity kept from call to call)
+        rot_item.clear();
+        rot_b.clear();
+        int hist[HISTO_LENGTH] = {0};
+        int nm = 0;
+        for (int i = 0; i < nq; i++) {
+            if (keys[i] == 0xFFFFFFFFu) continue;
+            const int idx1 = q_idx1[(size_t)i];
+            const int idx2 = perm[(size_t)(0xFFFF - (keys[i] & 0xFFFFu))];  // prefer-last keys store 0xFFFF - position
+            matches12[idx1] = idx2;
+            nm++;
+            if (check_orientation) {
+                const int b = rot_bin(angle1[idx1], angle2[idx2]);
+                rot_item.push_back(idx1);
+                rot_b.push_back(b);
+                hist[b]++;
+            }
         }
-    }
-    if (check_orientation) apply_rot_hist(hist, rot_item, rot_b, matches12, nm);
-    *nmatches = nm;
-    return SO_OK;
+        if (check_orientation) apply_rot_hist(hist, rot_item, rot_b, matches12, nm);
+        *nmatches = nm;
+        return SO_OK;
+    };
+    if (m->batching) return batch_defer(m, m->off_qdesc + (size_t)nq * 32, nq, 1, nullptr, nullptr, std::move(resolve));
+    if ((rc = run_topk(m, nq, 1))) return rc;
+    return resolve((const uint32_t*)m->h_keys.p, nullptr, nullptr, m->perm);
 }
 
 }  // extern "C"
@@ -1570,35 +1732,55 @@ bool target_ok(const so_frame_view* F, const so_camera* cam) {
 
 // Stages the map points behind the resident candidates, runs projection + window search (K-lists of length K) and
 // waits.  Afterwards m->h_keys / m->h_count hold the lists and `qw` points at the compact queries (host-mapped).
+struct ProjStage {
+    size_t off_qdesc, off_xw, off_nrm, off_maxd, off_mind, off_valid, staged_end;
+};
+
+// host half: the map points' fields into the staging block behind the candidates
+int stage_projected(so_matcher* m, const so_mappoint_view* mp, ProjStage& P) {
+    const int n = mp->n;
+    P.off_qdesc = m->frame_end;
+    P.off_xw = align256(P.off_qdesc + 32 * (size_t)n);
+    P.off_nrm = align256(P.off_xw + 12 * (size_t)n);
+    P.off_maxd = align256(P.off_nrm + 12 * (size_t)n);
+    P.off_mind = align256(P.off_maxd + 4 * (size_t)n);
+    P.off_valid = align256(P.off_mind + 4 * (size_t)n);
+    P.staged_end = align256(P.off_valid + (size_t)n);
+    int rc;
+    if ((rc = m->h_in.ensure_keep(P.staged_end + 256, m->frame_end))) return rc;
+    uint8_t* hb = (uint8_t*)m->h_in.p;
+    memcpy(hb + P.off_qdesc, mp->desc, 32 * (size_t)n);
+    memcpy(hb + P.off_xw, mp->Xw, 12 * (size_t)n);
+    if (mp->normal) memcpy(hb + P.off_nrm, mp->normal, 12 * (size_t)n);
+    memcpy(hb + P.off_maxd, mp->max_dist, 4 * (size_t)n);
+    memcpy(hb + P.off_mind, mp->min_dist, 4 * (size_t)n);
+    if (mp->valid) memcpy(hb + P.off_valid, mp->valid, (size_t)n);
+    else memset(hb + P.off_valid, 1, (size_t)n);
+    m->off_qdesc = P.off_qdesc;
+    m->off_q = P.staged_end;
+    m->h_q.p = nullptr;
+    m->h_qdesc.p = hb + P.off_qdesc;
+    return SO_OK;
+}
+
 int run_projected(so_matcher* m, const so_mappoint_view* mp, ProjectSrc& S, int K, const MatchQueryW** qw) {
     const int n = mp->n;
-    const size_t off_qdesc = m->frame_end;
-    const size_t off_xw = align256(off_qdesc + 32 * (size_t)n);
-    const size_t off_nrm = align256(off_xw + 12 * (size_t)n);
-    const size_t off_maxd = align256(off_nrm + 12 * (size_t)n);
-    const size_t off_mind = align256(off_maxd + 4 * (size_t)n);
-    const size_t off_valid = align256(off_mind + 4 * (size_t)n);
-    const size_t staged_end = align256(off_valid + (size_t)n);
+    if (m->batching) {
+        last_error_ref() = "this call cannot be part of a matcher batch";
+        return SO_ERR_INVALID_ARG;
+    }
+    ProjStage P;
+    int rc;
+    if ((rc = stage_projected(m, mp, P))) return rc;
+    const size_t off_qdesc = P.off_qdesc, off_xw = P.off_xw, off_nrm = P.off_nrm, off_maxd = P.off_maxd, off_mind = P.off_mind,
+                 off_valid = P.off_valid, staged_end = P.staged_end;
     const size_t off_q = staged_end;  // device only: written by project_queries_kernel
     const size_t total_dev = off_q + sizeof(MatchQuery) * (size_t)n;
-    int rc;
-    if ((rc = m->h_in.ensure_keep(staged_end + 256, m->frame_end))) return rc;
     uint8_t* hb = (uint8_t*)m->h_in.p;
-    memcpy(hb + off_qdesc, mp->desc, 32 * (size_t)n);
-    memcpy(hb + off_xw, mp->Xw, 12 * (size_t)n);
-    if (mp->normal) memcpy(hb + off_nrm, mp->normal, 12 * (size_t)n);
-    memcpy(hb + off_maxd, mp->max_dist, 4 * (size_t)n);
-    memcpy(hb + off_mind, mp->min_dist, 4 * (size_t)n);
-    if (mp->valid) memcpy(hb + off_valid, mp->valid, (size_t)n);
-    else memset(hb + off_valid, 1, (size_t)n);
     if (m->d_in.cap < total_dev) {
         if ((rc = m->d_in.ensure(std::max(m->h_in.cap, total_dev)))) return rc;
         m->dirty_from = 0;
     }
-    m->off_q = off_q;
-    m->off_qdesc = off_qdesc;
-    m->h_q.p = nullptr;
-    m->h_qdesc.p = hb + off_qdesc;
     const size_t keys_bytes = align256(sizeof(uint32_t) * (size_t)n * K);
     const size_t cnt_bytes = align256(sizeof(int32_t) * (size_t)n);
     if ((rc = m->h_out.ensure(keys_bytes + cnt_bytes + sizeof(MatchQueryW) * (size_t)n))) return rc;
@@ -1654,13 +1836,16 @@ void begin_call(so_matcher* m) {
 // Best keypoint per projected map point (K = 1): Fuse x2 and each direction of SearchBySim3.
 int projected_best(so_matcher* m, const so_frame_view* KF, const so_mappoint_view* mp, ProjectSrc& S, bool chi2_gate,
                    const float* inv_sigma2, bool reuse, int32_t* best_idx, int32_t* best_dist,
-                   const so_window_queries* queries_out) {
+                   const so_window_queries* queries_out, std::function<void()> post = nullptr) {
     const int n = mp->n;
     for (int i = 0; i < n; i++) {
         best_idx[i] = -1;
         best_dist[i] = 256;
     }
-    if (n == 0) return SO_OK;
+    if (n == 0) {
+        if (post) post();
+        return SO_OK;
+    }
     for (int l = 0; l < 8; l++) m->inv_sigma2[l] = (chi2_gate && l < KF->nlevels) ? inv_sigma2[l] : 0.f;
     so_frame_view view = *KF;
     view.excluded = nullptr;  // Fuse / SearchBySim3 look at every keypoint of the keyframe
@@ -1669,17 +1854,31 @@ int projected_best(so_matcher* m, const so_frame_view* KF, const so_mappoint_vie
     S.level_above = 0;
     S.qflags = chi2_gate ? (uint32_t)kQChi2Gate : 0u;
     S.q_max_dist = 256;
+    const int n_kf = KF->n;
+    so_window_queries qout{};
+    const bool want_q = queries_out != nullptr;
+    if (want_q) qout = *queries_out;
+    auto resolve = [n, n_kf, want_q, qout, best_idx, best_dist, post](const uint32_t* keys, const int32_t*, const MatchQueryW* qw,
+                                                                     const std::vector<int>& perm) -> int {
+        export_queries(want_q ? &qout : nullptr, qw, n);
+        if (n_kf > 0)
+            for (int i = 0; i < n; i++)
+                if (keys[i] != 0xFFFFFFFFu) {
+                    best_idx[i] = perm[(size_t)(keys[i] & 0xFFFFu)];
+                    best_dist[i] = (int32_t)(keys[i] >> 16);
+                }
+        if (post) post();
+        return SO_OK;
+    };
+    if (m->batching) {
+        ProjStage P;
+        if ((rc = stage_projected(m, mp, P))) return rc;
+        const size_t offs[5] = {P.off_xw, P.off_nrm, P.off_maxd, P.off_mind, P.off_valid};
+        return batch_defer(m, P.staged_end, n, 1, &S, offs, std::move(resolve));
+    }
     const MatchQueryW* qw = nullptr;
     if ((rc = run_projected(m, mp, S, 1, &qw))) return rc;
-    export_queries(queries_out, qw, n);
-    if (KF->n == 0) return SO_OK;
-    const uint32_t* keys = (const uint32_t*)m->h_keys.p;
-    for (int i = 0; i < n; i++)
-        if (keys[i] != 0xFFFFFFFFu) {
-            best_idx[i] = m->perm[(size_t)(keys[i] & 0xFFFFu)];
-            best_dist[i] = (int32_t)(keys[i] >> 16);
-        }
-    return SO_OK;
+    return resolve((const uint32_t*)m->h_keys.p, nullptr, qw, m->perm);
 }
 
 // Sequential greedy binding per projected map point: the two keyframe-side SearchByProjection overloads.
@@ -1733,10 +1932,9 @@ int so_fuse(so_matcher* m, const so_frame_view* KF, const so_camera* cam, const 
     camera_center(Tcw12, S.Ow);  // pKF->GetCameraCenter()
     S.flags = kPAngleGate;
     fill_target(S, KF, cam, log_scale_factor, th);
-    const int rc = projected_best(m, KF, mp, S, true, inv_level_sigma2, reuse, best_idx, best_dist, queries_out);
-    if (rc) return rc;
-    *n_fused = keep_within(mp->n, best_idx, best_dist, TH_LOW);  // ORBmatcher.cc:873
-    return SO_OK;
+    const int n = mp->n;
+    return projected_best(m, KF, mp, S, true, inv_level_sigma2, reuse, best_idx, best_dist, queries_out,
+                          [n, best_idx, best_dist, n_fused] { *n_fused = keep_within(n, best_idx, best_dist, TH_LOW); });  // :873
 }
 
 int so_fuse_sim3(so_matcher* m, const so_frame_view* KF, const so_camera* cam, const float* Scw12, float log_scale_factor,
@@ -1752,10 +1950,9 @@ int so_fuse_sim3(so_matcher* m, const so_frame_view* KF, const so_camera* cam, c
     sim3_decompose(Scw12, S.A, S.Ow);
     S.flags = kPAngleGate;
     fill_target(S, KF, cam, log_scale_factor, th);
-    const int rc = projected_best(m, KF, mp, S, false, nullptr, reuse, best_idx, best_dist, queries_out);
-    if (rc) return rc;
-    *n_fused = keep_within(mp->n, best_idx, best_dist, TH_LOW);  // :995
-    return SO_OK;
+    const int n = mp->n;
+    return projected_best(m, KF, mp, S, false, nullptr, reuse, best_idx, best_dist, queries_out,
+                          [n, best_idx, best_dist, n_fused] { *n_fused = keep_within(n, best_idx, best_dist, TH_LOW); });  // :995
 }
 
 int so_search_by_sim3(so_matcher* m, const so_frame_view* KF1, const so_frame_view* KF2, const so_camera* cam,
@@ -1771,6 +1968,11 @@ int so_search_by_sim3(so_matcher* m, const so_frame_view* KF1, const so_frame_vi
     begin_call(m);
     (void)take_reuse(m);
     *n_found = 0;
+    if (m->batching) {
+        last_error_ref() = "so_search_by_sim3 cannot be part of a matcher batch (its second pass depends on nothing, but the "
+                           "agreement step needs both): call it outside";
+        return SO_ERR_INVALID_ARG;
+    }
     float B12[12], B21[12];
     sim3_relative(s12, R12, t12, B12, B21);
     const int N1 = mp1->n, N2 = mp2->n;
@@ -1840,6 +2042,33 @@ int so_search_by_projection_keyframe(so_matcher* m, const so_frame_view* F, cons
     fill_target(S, F, cam, log_scale_factor, th);
     return projected_greedy(m, F, mp, S, 1, mp_angle, orb_dist, check_orientation, reuse, kp_to_point, nmatches,
                             queries_out);
+}
+
+int so_matcher_batch_begin(so_matcher* m) {
+    if (!m || m->batching) return SO_ERR_INVALID_ARG;
+    if (m->pend.mode != 0) {
+        last_error_ref() = "a tracking search is pending on this handle";
+        return SO_ERR_INVALID_ARG;
+    }
+    SO_HIP(hipSetDevice(m->device));
+    m->batching = true;
+    m->jobs.clear();
+    m->hb_used = m->dq_used = m->out_used = 0;
+    return SO_OK;
+}
+
+int so_matcher_batch_end(so_matcher* m) {
+    if (!m || !m->batching) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
+    const int rc = batch_flush(m);
+    m->batching = false;
+    m->jobs.clear();
+    m->src = nullptr;
+    m->resident_n = -1;
+    m->dirty_from = 0;
+    return rc;
 }
 
 }  // extern "C"

@@ -154,6 +154,7 @@ struct so_replay {
     so_matcher* mapper_matcher = nullptr;  // the local-mapping thread's own matcher context
     std::vector<uint8_t> vocab;            // n_vocab x 32 centroid descriptors (so_replay_set_vocabulary)
     int lm_neighbours = 20;                // nn = 20, LocalMapping.cc:207,455 (monocular)
+    bool lm_batch = true;                  // all searches of a keyframe as one so_matcher batch (SWARMORB_LM_BATCH=0: one by one)
     std::deque<std::shared_ptr<KfSnap>> lm_ring;  // (local-mapping thread only)
     std::vector<int32_t> lm_stamp, lm_cstamp;     // slot -> id of the keyframe / job that marked it
     int lm_stamp_id = 0;
@@ -290,7 +291,7 @@ void fundamental_and_epipole(const so_replay* r, const float* T1, const float* T
 }
 
 enum { kLmJobs = 0, kLmWallMs, kLmNodeMs, kLmTriCalls, kLmTriMs, kLmTriKernelMs, kLmTriMatches, kLmFuseCalls, kLmFuseMs,
-       kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries };
+       kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries, kLmBatchMs, kLmBatchEndMs, kLmBatchKernelMs };
 
 // CreateNewMapPoints' and SearchInNeighbors' matcher load for the new keyframe `c` (see the file header).
 int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
@@ -318,38 +319,49 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
     }
     st[kLmNodeMs] = now_ms() - t0;
     const so_featvec fv1{(int32_t)c->node_id.size(), c->node_id.data(), c->off.data(), c->idx.data()};
-    std::vector<uint8_t> free1((size_t)n), free2, valid;
+    std::vector<uint8_t> free1((size_t)n), free2;
     for (int i = 0; i < n; i++) free1[(size_t)i] = c->mp[(size_t)i] < 0 ? 1 : 0;
     const so_frame_view Vc = keyframe_view(r, *c);
     float level_sigma2[8];
     for (int l = 0; l < 8; l++) level_sigma2[l] = r->scale[l] * r->scale[l];
     int n_tri = 0, n_fused = 0, n_back = 0;
-    std::vector<int32_t> m12((size_t)n), best, dist;
+    // Every search of this keyframe is independent of the others here (nothing is written back into the map), so with
+    // lm_batch they all go out as ONE batch: one staging copy, one projection launch, one search launch, one wait.
+    // Outputs are held per call until the batch ends.
+    const bool batch = r->lm_batch;
+    const size_t nn = r->lm_ring.size();
+    std::vector<std::vector<int32_t>> tri_m12(nn), fuse_best(nn + 1), fuse_dist(nn + 1);
+    std::vector<int32_t> tri_nm(nn, 0), fuse_n(nn + 1, 0);
+    std::vector<std::vector<uint8_t>> fuse_valid(nn);
+    const double tb0 = now_ms();
+    if (batch && so_matcher_batch_begin(m) != SO_OK) return SO_ERR_HIP;
     // ---- CreateNewMapPoints: SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false) per neighbour
+    size_t jn = 0;
     for (const auto& kf2 : r->lm_ring) {
         float F12[9], ex, ey;
         fundamental_and_epipole(r, c->T, kf2->T, F12, &ex, &ey);
         free2.resize((size_t)kf2->n);
         for (int i = 0; i < kf2->n; i++) free2[(size_t)i] = kf2->mp[(size_t)i] < 0 ? 1 : 0;
         const so_featvec fv2{(int32_t)kf2->node_id.size(), kf2->node_id.data(), kf2->off.data(), kf2->idx.data()};
-        int32_t nm = 0;
+        tri_m12[jn].resize((size_t)n);
         const double ta = now_ms();
         if (so_search_for_triangulation(m, n, c->x.data(), c->y.data(), c->angle.data(), c->desc.data(), free1.data(), &fv1, kf2->n,
                                         kf2->x.data(), kf2->y.data(), kf2->octave.data(), kf2->angle.data(), kf2->desc.data(),
-                                        free2.data(), &fv2, F12, ex, ey, r->scale, level_sigma2, r->nlevels, 1, m12.data(), &nm) != SO_OK)
+                                        free2.data(), &fv2, F12, ex, ey, r->scale, level_sigma2, r->nlevels, 1, tri_m12[jn].data(),
+                                        &tri_nm[jn]) != SO_OK)
             return SO_ERR_HIP;
         st[kLmTriMs] += now_ms() - ta;
-        so_matcher_last_kernel_ms(m, &kms);
-        st[kLmTriKernelMs] += kms;
+        if (!batch) {
+            so_matcher_last_kernel_ms(m, &kms);
+            st[kLmTriKernelMs] += kms;
+        }
         st[kLmTriCalls] += 1;
-        n_tri += nm;
+        jn++;
     }
     // ---- SearchInNeighbors: matcher.Fuse(pKFi, vpMapPointMatches) per neighbour (LocalMapping.cc:451-457) ...
-    const size_t map_size = r->lm_stamp.size();
     auto grow = [&](size_t slots) {
         if (slots > r->lm_stamp.size()) { r->lm_stamp.resize(slots + slots / 2 + 1024, -1); r->lm_cstamp.resize(r->lm_stamp.size(), -1); }
     };
-    (void)map_size;
     int max_slot = -1;
     for (int i = 0; i < n; i++) max_slot = std::max(max_slot, c->mp[(size_t)i]);
     for (const auto& k2 : r->lm_ring)
@@ -359,31 +371,36 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
     memset(&P, 0, sizeof(P));
     P.n = n; P.Xw = c->mpX.data(); P.normal = c->mpN.data(); P.max_dist = c->mpMax.data(); P.min_dist = c->mpMin.data();
     P.desc = c->mpDesc.data();
-    valid.resize((size_t)n);
-    best.resize((size_t)n); dist.resize((size_t)n);
+    jn = 0;
     for (const auto& k2 : r->lm_ring) {
         const int id = ++r->lm_stamp_id;
         for (int i = 0; i < k2->n; i++)
             if (k2->mp[(size_t)i] >= 0) r->lm_stamp[(size_t)k2->mp[(size_t)i]] = id;
+        std::vector<uint8_t>& valid = fuse_valid[jn];
+        valid.resize((size_t)n);
         for (int i = 0; i < n; i++)  // pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKFi), ORBmatcher.cc:770-774
             valid[(size_t)i] = (c->mp[(size_t)i] >= 0 && r->lm_stamp[(size_t)c->mp[(size_t)i]] != id) ? 1 : 0;
         P.valid = valid.data();
         const so_frame_view V2 = keyframe_view(r, *k2);
-        int32_t nf = 0;
+        fuse_best[jn].resize((size_t)n); fuse_dist[jn].resize((size_t)n);
         const double ta = now_ms();
-        if (so_fuse(m, &V2, &r->cam, k2->T, r->log_sf, r->inv_sigma2, &P, 3.0f, best.data(), dist.data(), &nf, nullptr) != SO_OK) return SO_ERR_HIP;
+        if (so_fuse(m, &V2, &r->cam, k2->T, r->log_sf, r->inv_sigma2, &P, 3.0f, fuse_best[jn].data(), fuse_dist[jn].data(), &fuse_n[jn],
+                    nullptr) != SO_OK)
+            return SO_ERR_HIP;
         st[kLmFuseMs] += now_ms() - ta;
-        so_matcher_last_kernel_ms(m, &kms);
-        st[kLmFuseKernelMs] += kms;
+        if (!batch) {
+            so_matcher_last_kernel_ms(m, &kms);
+            st[kLmFuseKernelMs] += kms;
+        }
         st[kLmFuseCalls] += 1;
         st[kLmFusePoints] += n;
-        n_fused += nf;
+        jn++;
     }
     // ... then the neighbours' map points into the new keyframe: vpFuseCandidates, once each (:459-481)
+    std::vector<float> X, N, mx, mn;
+    std::vector<uint8_t> D, ok;
     if (!r->lm_ring.empty()) {
         const int job = ++r->lm_stamp_id;
-        std::vector<float> X, N, mx, mn;
-        std::vector<uint8_t> D, ok;
         const int cid = ++r->lm_stamp_id;
         for (int i = 0; i < n; i++)
             if (c->mp[(size_t)i] >= 0) r->lm_stamp[(size_t)c->mp[(size_t)i]] = cid;
@@ -403,17 +420,32 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         memset(&Q, 0, sizeof(Q));
         Q.n = (int32_t)mx.size(); Q.Xw = X.data(); Q.normal = N.data(); Q.max_dist = mx.data(); Q.min_dist = mn.data();
         Q.desc = D.data(); Q.valid = ok.data();
-        best.resize((size_t)Q.n); dist.resize((size_t)Q.n);
-        int32_t nf = 0;
+        fuse_best[nn].resize((size_t)Q.n); fuse_dist[nn].resize((size_t)Q.n);
         const double ta = now_ms();
-        if (so_fuse(m, &Vc, &r->cam, c->T, r->log_sf, r->inv_sigma2, &Q, 3.0f, best.data(), dist.data(), &nf, nullptr) != SO_OK) return SO_ERR_HIP;
+        if (so_fuse(m, &Vc, &r->cam, c->T, r->log_sf, r->inv_sigma2, &Q, 3.0f, fuse_best[nn].data(), fuse_dist[nn].data(), &fuse_n[nn],
+                    nullptr) != SO_OK)
+            return SO_ERR_HIP;
         st[kLmFuseMs] += now_ms() - ta;
-        so_matcher_last_kernel_ms(m, &kms);
-        st[kLmFuseKernelMs] += kms;
+        if (!batch) {
+            so_matcher_last_kernel_ms(m, &kms);
+            st[kLmFuseKernelMs] += kms;
+        }
         st[kLmFuseCalls] += 1;
         st[kLmFusePoints] += Q.n;
-        n_back = nf;
     }
+    if (batch) {
+        const double ta = now_ms();
+        if (so_matcher_batch_end(m) != SO_OK) return SO_ERR_HIP;
+        so_matcher_last_kernel_ms(m, &kms);
+        st[kLmBatchKernelMs] = kms;
+        st[kLmBatchEndMs] = now_ms() - ta;
+        st[kLmBatchMs] = now_ms() - tb0;
+    }
+    for (size_t j = 0; j < nn; j++) {
+        n_tri += tri_nm[j];
+        n_fused += fuse_n[j];
+    }
+    n_back = fuse_n[nn];
     const int32_t row[5] = {c->t, (int32_t)r->lm_ring.size(), n_tri, n_fused, n_back};
     r->lm_ring.push_back(c);
     while ((int)r->lm_ring.size() > r->lm_neighbours) r->lm_ring.pop_front();
@@ -608,6 +640,7 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
         f.kp_mp.resize((size_t)r->cap);
         f.outlier.resize((size_t)r->cap);
     }
+    if (const char* e = getenv("SWARMORB_LM_BATCH")) r->lm_batch = atoi(e) != 0;
     r->mapper = std::thread(mapper_loop, r);
     *out = r;
     return SO_OK;

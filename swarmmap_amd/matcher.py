@@ -273,7 +273,27 @@ def _SearchForTriangulation(self, kf1, fv1, kf2, fv2, F12, epipole, scale_factor
         self._h, len(x1), _vp(x1), _vp(y1), _vp(a1), _vp(d1), _vp(f1), C.byref(s1), len(x2), _vp(x2), _vp(y2), _vp(o2),
         _vp(a2), _vp(d2), _vp(f2), C.byref(s2), _vp(F), float(epipole[0]), float(epipole[1]), _vp(sf), _vp(ls),
         len(sf), int(self.mbCheckOrientation), _vp(out), C.byref(nm)))
+    if getattr(self, "_batching", False):  # outputs are complete after batch_end(); the resolve reads the angle arrays
+        self._batch_keep += [a1, a2, out, nm]
+        return nm, out
     return nm.value, out
+
+
+def _batch_begin(self):
+    """so_matcher_batch_begin: the SearchForTriangulation / Fuse / FuseSim3 calls up to batch_end() are staged and
+    launched together; inside a batch they return their output holders (counts as ctypes ints: read .value afterwards)."""
+    self._lib.so_matcher_batch_begin.argtypes = [C.c_void_p]
+    self._lib.so_matcher_batch_end.argtypes = [C.c_void_p]
+    _lib.check(self._lib.so_matcher_batch_begin(self._h))
+    self._batching, self._batch_keep = True, []
+
+
+def _batch_end(self):
+    self._batching = False
+    try:
+        _lib.check(self._lib.so_matcher_batch_end(self._h))
+    finally:
+        self._batch_keep = []
 
 
 def _SearchWindowBest(self, KF, q, chi2_gate=False, inv_sigma2=None):
@@ -309,6 +329,8 @@ def _SearchWindowGreedy(self, F, q, max_dist):
 
 
 ORBmatcher.SearchByBoW = _SearchByBoW
+ORBmatcher.batch_begin = _batch_begin
+ORBmatcher.batch_end = _batch_end
 ORBmatcher.SearchForTriangulation = _SearchForTriangulation
 ORBmatcher.SearchWindowBest = _SearchWindowBest
 ORBmatcher.SearchWindowGreedy = _SearchWindowGreedy
@@ -369,6 +391,9 @@ def _Fuse(self, KF, K, Tcw, log_scale_factor, inv_level_sigma2, mp, th=3.0):
     fs, cam, T, inv = KF.as_struct(), _cam(K), _f32(Tcw).reshape(12), _f32(inv_level_sigma2)
     _lib.check(self._lib.so_fuse(self._h, C.byref(fs), C.byref(cam), _vp(T), float(log_scale_factor), _vp(inv),
                                  C.byref(ms), float(th), _vp(bi), _vp(bd), C.byref(nf), C.byref(qs)))
+    if getattr(self, "_batching", False):
+        self._batch_keep += [bi, bd, q, nf]
+        return nf, bi, bd, q
     return nf.value, bi, bd, q
 
 
@@ -382,6 +407,9 @@ def _FuseSim3(self, KF, K, Scw, log_scale_factor, mp, th=4.0):
     fs, cam, S = KF.as_struct(), _cam(K), _f32(Scw).reshape(12)
     _lib.check(self._lib.so_fuse_sim3(self._h, C.byref(fs), C.byref(cam), _vp(S), float(log_scale_factor), C.byref(ms),
                                       float(th), _vp(bi), _vp(bd), C.byref(nf), C.byref(qs)))
+    if getattr(self, "_batching", False):
+        self._batch_keep += [bi, bd, q, nf]
+        return nf, bi, bd, q
     return nf.value, bi, bd, q
 
 

@@ -169,3 +169,61 @@ def test_keyframe_int_bounds_quirk(S, oracle):
                                       p["mp2"], 7.5)
     assert nf == onf and np.array_equal(m12, om12) and nf > 300
     m.close()
+
+
+def test_batched_calls_equal_the_same_calls_one_by_one(S, oracle):
+    """so_matcher_batch_begin / _end: a new keyframe's SearchForTriangulation + Fuse calls against its neighbours as one
+    staging copy, one projection launch and one search launch - every output equal to the call made alone (and so to
+    the oracle); any other matcher call inside a batch is refused; more than 64 calls flush and carry on."""
+    from swarmmap_amd.matcher import FeatureVector
+    m = S.ORBmatcher(0.6, True)
+    sf = synth.SCALE_FACTORS
+    fuse_cases = [synth.make_projection_case(200 + i, 600 + 150 * i, 500 + 300 * i, keyframe_bounds=(i % 2 == 0)) for i in range(5)]
+    sim_cases = [synth.make_projection_case(220 + i, 900, 1100, sim3_scale=1.2 + 0.1 * i) for i in range(2)]
+    tri_cases = []
+    for i in range(4):
+        kf1, node1, kf2, node2, src = synth.make_bow_case(240 + i, 800 + 100 * i, 900, p_flip=0.06)
+        rng = np.random.default_rng(i)
+        kf1["y"] = (kf2["y"][src] + rng.normal(0, 0.8, len(src))).astype(np.float32)
+        kf1["x"] = (kf2["x"][src] + rng.uniform(-30, 30, len(src))).astype(np.float32)
+        F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 1e-6, (3, 3)).astype(np.float32)
+        tri_cases.append((kf1, FeatureVector(node1), kf2, FeatureVector(node2), F12))
+    alone = []
+    for c in fuse_cases:
+        alone.append(m.Fuse(_view(c["frame"], False), c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], 3.0))
+    for c in sim_cases:
+        alone.append(m.FuseSim3(_view(c["frame"], False), c["cam"], c["Scw"], c["log_scale_factor"], c["mp"], 4.0))
+    for t in tri_cases:
+        alone.append(m.SearchForTriangulation(t[0], t[1], t[2], t[3], t[4], (900.0, 240.0), sf, sf * sf))
+    for rounds in (1, 6):  # 11 calls, then 66: the 65th flushes the first 64
+        m.batch_begin()
+        held = []
+        for _ in range(rounds):
+            for c in fuse_cases:
+                held.append(m.Fuse(_view(c["frame"], False), c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], 3.0))
+            for c in sim_cases:
+                held.append(m.FuseSim3(_view(c["frame"], False), c["cam"], c["Scw"], c["log_scale_factor"], c["mp"], 4.0))
+            for t in tri_cases:
+                held.append(m.SearchForTriangulation(t[0], t[1], t[2], t[3], t[4], (900.0, 240.0), sf, sf * sf))
+        if rounds == 1:
+            with pytest.raises(Exception):  # not batchable
+                c = fuse_cases[0]
+                m.SearchByProjectionSim3(_view(c["frame"]), c["cam"], c["Scw"], c["log_scale_factor"], c["mp"], 10)
+        m.batch_end()
+        for k, h in enumerate(held):
+            a = alone[k % len(alone)]
+            assert h[0].value == a[0] > 0, k
+            for x, y in zip(h[1:], a[1:]):
+                if isinstance(x, dict):
+                    for key in x:
+                        assert x[key].tobytes() == y[key].tobytes(), (k, key)
+                else:
+                    assert np.array_equal(x, y), k
+    # the handle works as before afterwards
+    c = fuse_cases[1]
+    again = m.Fuse(_view(c["frame"], False), c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], 3.0)
+    assert again[0] == alone[1][0] and np.array_equal(again[1], alone[1][1])
+    on, obi, obd = oracle.fuse(_view(c["frame"], False), oracle.camera(c["cam"]), c["Tcw"], c["log_scale_factor"],
+                               c["inv_level_sigma2"], c["mp"], 3.0)
+    assert again[0] == on and np.array_equal(again[1], obi)
+    m.close()
