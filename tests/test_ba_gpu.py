@@ -504,7 +504,10 @@ def test_full_size_global_ba_matches_the_oracle_fixture(opt, name, fixture, robu
     assert abs(r["info"]["lm_trials"] - int(inf["lm_trials"])) <= 10
     assert r["info"]["chi2_initial"] == pytest.approx(inf["chi2_initial"], rel=1e-9)
     assert r["info"]["chi2_final"] == pytest.approx(inf["chi2_final"], rel=1e-6)
-    assert np.abs(r["Tcw"] - g["Tcw"]).max() <= POSE_TOL
+    # poses travel as float32: a translation of 136 m (these maps span ~300 m) has an ulp of 1.5e-5, so the absolute
+    # tolerance is widened by 4 ulp of the value itself (measured: 3 ulp on one component of GBA-2 without Huber,
+    # chi2_final equal to 5e-10 relative)
+    assert np.all(np.abs(r["Tcw"] - g["Tcw"]) <= POSE_TOL + 4 * np.spacing(np.abs(g["Tcw"]).astype(np.float32)))
     assert np.abs(r["Xw"][::8] - g["Xw_every8"]).max() <= POINT_TOL
     assert np.allclose(r["chi2"][::64], g["chi2"], rtol=1e-5, atol=1e-7)
     want = np.unpackbits(g["outlier_bits"])[:int(g["n_edges"])]
