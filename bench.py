@@ -651,13 +651,23 @@ def main():
             # (SWARMORB_BENCH_PREFILL keyframes each) - the scan inside the tick then has something to read
             prefill_store(xchg.store, 7, int(os.environ.get("SWARMORB_BENCH_PREFILL", "64")), nfeatures)
 
-    if args.lockstep and A > 1:
-        dt, st, n_cand, frames, _ = run_fleet(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
-                                              lba_window, barrier, A)
-    else:
-        dt, st, n_cand, frames, _ = run_stream(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
-                                               lba_window, barrier, A, xchg, args.exchange_every, m1,
-                                               live_steps=LIVE_STEPS if rank == 0 else 0)
+    try:
+        if args.lockstep and A > 1:
+            dt, st, n_cand, frames, _ = run_fleet(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
+                                                  lba_window, barrier, A)
+        else:
+            dt, st, n_cand, frames, _ = run_stream(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
+                                                   lba_window, barrier, A, xchg, args.exchange_every, m1,
+                                                   live_steps=LIVE_STEPS if rank == 0 else 0)
+    except swarmmap_amd.SwarmOrbError as e:
+        if "timed out" not in str(e):
+            raise
+        # a peer did not enter an exchange tick within the budget (SWARMORB_COLLECTIVE_TIMEOUT_MS): the exchange handle
+        # is dead.  No result, no hang, no re-exec of a process that holds the GPU: one JSON line with the error, exit != 0
+        # (os._exit: the other ranks may be stuck in torch.distributed's own barrier, which a normal exit would join)
+        print(json.dumps({"metric": "frames/sec/agent (tracking+localBA)", "value": None, "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "error": "rank %d: %s" % (rank, e)}), flush=True)
+        os._exit(3)
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

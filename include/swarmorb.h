@@ -29,7 +29,8 @@ enum {
     SO_ERR_HIP = 3,          /* HIP runtime error during a call (see so_last_error) */
     SO_ERR_CAPACITY = 4,     /* caller buffer too small */
     SO_ERR_SIZE_CHANGED = 5, /* image size differs from the first frame (reference: "WILL BREAK") */
-    SO_ERR_NUMERIC = 6       /* BA: linear solve failed in every LM trial */
+    SO_ERR_NUMERIC = 6,      /* BA: linear solve failed in every LM trial */
+    SO_ERR_TIMEOUT = 7       /* exchange: the collective of a tick did not complete within the budget; the handle is dead */
 };
 const char* so_status_string(int status);
 /* last HIP error text on the calling thread ("" if none) */
@@ -721,6 +722,17 @@ int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stri
 int so_exchange_tick_keyframe(so_exchange* x, const so_dframe* f, const so_keyframe_header* hdr,
                               const int32_t* map_point_id, const so_kf_search_params* p, so_kf_candidate* out,
                               int32_t* pairs, int32_t* n_out);
+/* Failure behaviour of the ticks (all of them are collective).  A rank-local problem - frame not ready, malformed record,
+ * missing argument - does not keep the rank out of the collective: it takes part with zero records / an empty slot and
+ * returns SO_ERR_INVALID_ARG afterwards, the other ranks are not affected.  Only a null handle returns before the
+ * collective.  The wait for the collective is bounded (so_exchange_set_timeout; default SWARMORB_COLLECTIVE_TIMEOUT_MS
+ * or 5000 ms; 0 = unbounded): when a peer never enters the tick the survivors get SO_ERR_TIMEOUT, the handle is DEAD -
+ * every later tick returns SO_ERR_TIMEOUT at once, so_exchange_destroy does not wait for the stuck stream - and the
+ * group has to be re-created.  so_exchange_debug_stall (test hook) delays this rank's next collective by a spinning
+ * workgroup on the tick's stream. */
+int so_exchange_set_timeout(so_exchange* x, int milliseconds);
+int so_exchange_is_dead(const so_exchange* x);
+int so_exchange_debug_stall(so_exchange* x, int milliseconds);
 /* record `index` (< records_per_tick) of rank `peer` as the last tick's all-gather delivered it; *length = 0 for an
  * unused position.  record may be NULL (length only). */
 int so_exchange_read_record(so_exchange* x, int peer, int index, uint8_t* record, size_t capacity, size_t* length);

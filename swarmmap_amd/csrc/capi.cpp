@@ -80,6 +80,7 @@ const char* so_status_string(int status) {
         case SO_ERR_CAPACITY: return "output buffer too small";
         case SO_ERR_SIZE_CHANGED: return "image size changed between frames";
         case SO_ERR_NUMERIC: return "numeric failure";
+        case SO_ERR_TIMEOUT: return "collective timed out";
         default: return "unknown status";
     }
 }

@@ -12,13 +12,17 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
 #include "dframe_internal.h"
+#include "ba_device.h"
 #include "kfstore_internal.h"
 #include "match_device.h"
 #include "so_common.h"
@@ -38,6 +42,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
@@ -55,6 +60,7 @@ Rccl& rccl() {
         R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(R.lib, "ncclGetUniqueId");
         R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.lib, "ncclCommInitRank");
         R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.lib, "ncclCommDestroy");
+        R.CommAbort = (decltype(R.CommAbort))dlsym(R.lib, "ncclCommAbort");
         R.AllGather = (decltype(R.AllGather))dlsym(R.lib, "ncclAllGather");
         R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.lib, "ncclGetErrorString");
         R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.AllGather;
@@ -97,6 +103,13 @@ struct so_exchange {
     void* host_user = nullptr;
     uint8_t* h_slot = nullptr;      // pinned: this rank's slot
     uint8_t* h_gathered = nullptr;  // pinned: world slots
+    // A tick waits for its collective with a budget (SWARMORB_COLLECTIVE_TIMEOUT_MS, default 5000; 0 = wait for ever):
+    // when a peer never enters the tick the survivors get SO_ERR_TIMEOUT instead of hanging, and the handle is dead -
+    // every later tick returns SO_ERR_TIMEOUT at once, destroy neither waits for the stuck stream nor frees what the
+    // collective may still write.
+    int timeout_ms = 5000;
+    bool dead = false;
+    unsigned* d_stall_sink = nullptr;  // so_exchange_debug_stall
     std::vector<so_keyframe_header> hdrs;
     std::vector<uint8_t> skip;
     std::vector<float> q_angle;
@@ -104,6 +117,33 @@ struct so_exchange {
 };
 
 namespace {
+
+int dead_handle() {
+    last_error_ref() = "exchange: a previous tick's collective timed out; the handle is dead (destroy it, re-create the group)";
+    return SO_ERR_TIMEOUT;
+}
+
+// Waits for everything enqueued on `s` up to the collective, within the handle's budget.
+int wait_collective(so_exchange* x, hipStream_t s) {
+    if (x->timeout_ms <= 0) {
+        SO_HIP(hipStreamSynchronize(s));
+        return SO_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return SO_OK;
+        if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery (exchange tick)", __FILE__, __LINE__);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > (double)x->timeout_ms) {
+            x->dead = true;
+            last_error_ref() = "exchange tick: the collective did not complete within " + std::to_string(x->timeout_ms) +
+                               " ms (a peer is not taking part); the handle is dead";
+            return SO_ERR_TIMEOUT;
+        }
+        if (ms > 0.2) std::this_thread::sleep_for(std::chrono::microseconds(50));  // spin for the common case, then nap
+    }
+}
 
 int tick_common(so_exchange* x, const uint8_t* d_desc, int n, int max_dist, float ratio, int32_t* peer_counts,
                 int32_t* peer_candidates) {
@@ -117,7 +157,10 @@ int tick_common(so_exchange* x, const uint8_t* d_desc, int n, int max_dist, floa
     if (r != 0) return rccl_fail(r, "ncclAllGather");
     // headers of all slots -> host (keypoint counts drive the match launches)
     SO_HIP(hipMemcpy2DAsync(x->h_pin, 32, x->d_gathered, x->slot_bytes, 32, (size_t)x->world, hipMemcpyDeviceToHost, s));
-    SO_HIP(hipStreamSynchronize(s));
+    {
+        const int wrc = wait_collective(x, s);
+        if (wrc != SO_OK) return wrc;
+    }
     for (int p = 0; p < x->world; p++) {
         int32_t hdr[2];
         memcpy(hdr, x->h_pin + 32 * (size_t)p, 8);
@@ -187,7 +230,10 @@ int tick_store_common(so_exchange* x, int n_mine, const so_kf_search_params* p, 
     so_keyframe_header* hh = reinterpret_cast<so_keyframe_header*>(x->h_rpin);
     SO_HIP(hipMemcpy2DAsync(hh, sizeof(so_keyframe_header), x->d_rgathered, x->rec_stride, sizeof(so_keyframe_header),
                             (size_t)total, hipMemcpyDeviceToHost, s));
-    SO_HIP(hipStreamSynchronize(s));
+    {
+        const int wrc = wait_collective(x, s);
+        if (wrc != SO_OK) return wrc;
+    }
     x->hdrs.assign(hh, hh + total);
     x->skip.assign((size_t)total, 0);
     for (int j = 0; j < total; j++)
@@ -203,6 +249,25 @@ int tick_store_common(so_exchange* x, int n_mine, const so_kf_search_params* p, 
         if (rc != SO_OK) return rc;
     }
     return SO_OK;
+}
+
+// A tick is COLLECTIVE: a rank that returned before the all-gather because of something only IT can see (its frame is
+// not ready, one of its records is malformed, ...) would leave every other rank waiting in theirs.  Such a rank takes
+// part with zero records and reports its error afterwards; only a null / dead handle returns before the collective.
+int tick_store_with_nothing(so_exchange* x, const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs, int32_t* n_out,
+                            int n_clear, const char* why) {
+    SO_HIP(hipSetDevice(x->device));
+    SO_HIP(hipMemsetAsync(x->d_rslot, 0, x->rec_stride * (size_t)x->records_per_tick, x->store->stream));
+    if (n_out)
+        for (int j = 0; j < n_clear; j++) n_out[j] = 0;
+    const std::vector<const float*> none_a;
+    const std::vector<const int32_t*> none_m;
+    so_kf_search_params dflt;
+    memset(&dflt, 0, sizeof(dflt));
+    const int rc = tick_store_common(x, 0, p ? p : &dflt, out, pairs, n_out, none_a, none_m);
+    if (rc != SO_OK) return rc;
+    last_error_ref() = std::string("exchange tick: ") + why + " (the rank took part in the collective with zero records)";
+    return SO_ERR_INVALID_ARG;
 }
 
 }  // namespace
@@ -238,6 +303,7 @@ int so_exchange_create(int device, int rank, int world, const uint8_t* id128, in
     }
     SO_HIP(hipSetDevice(device));
     so_exchange* x = new so_exchange();
+    if (const char* e = getenv("SWARMORB_COLLECTIVE_TIMEOUT_MS")) x->timeout_ms = atoi(e) > 0 ? atoi(e) : 0;
     x->device = device;
     x->rank = rank;
     x->world = world;
@@ -273,11 +339,20 @@ int so_exchange_create(int device, int rank, int world, const uint8_t* id128, in
 void so_exchange_destroy(so_exchange* x) {
     if (!x) return;
     (void)hipSetDevice(x->device);
+    if (x->dead) {
+        // the stuck collective may never finish: no stream wait, the communicator is aborted (where RCCL offers it) rather
+        // than destroyed, and the buffers it may still write stay allocated (hipFree would wait for the device)
+        if (x->comm && rccl().CommAbort) (void)rccl().CommAbort(x->comm);
+        if (x->h_slot) (void)hipHostFree(x->h_slot);
+        if (x->h_gathered) (void)hipHostFree(x->h_gathered);
+        delete x;
+        return;
+    }
     if (x->stream) (void)hipStreamSynchronize(x->stream);
     if (x->store && x->store->stream) (void)hipStreamSynchronize(x->store->stream);
     if (x->comm) (void)rccl().CommDestroy(x->comm);
     for (void* p : {(void*)x->d_slot, (void*)x->d_gathered, (void*)x->d_stage, (void*)x->d_res, (void*)x->d_rslot,
-                    (void*)x->d_rgathered, (void*)x->d_staged})
+                    (void*)x->d_rgathered, (void*)x->d_staged, (void*)x->d_stall_sink})
         if (p) (void)hipFree(p);
     if (x->h_pin) (void)hipHostFree(x->h_pin);
     if (x->h_rpin) (void)hipHostFree(x->h_rpin);
@@ -290,19 +365,29 @@ void so_exchange_destroy(so_exchange* x) {
 
 int so_exchange_tick_dframe(so_exchange* x, const so_dframe* f, int max_dist, float ratio, int32_t* peer_counts,
                             int32_t* peer_candidates) {
-    if (!x || !x->comm || !f || !f->ready) return SO_ERR_INVALID_ARG;
-    if (f->device != x->device) {
-        last_error_ref() = "frame and exchange live on different devices";
+    if (!x || !x->comm) return SO_ERR_INVALID_ARG;
+    if (x->dead) return dead_handle();
+    SO_HIP(hipSetDevice(x->device));
+    if (!f || !f->ready || f->device != x->device) {  // rank-local: take part with an empty slot, then report
+        const int rc = tick_common(x, nullptr, 0, max_dist, ratio, peer_counts, peer_candidates);
+        if (rc != SO_OK) return rc;
+        last_error_ref() = "exchange tick: the frame is not ready or lives on another device (the rank took part with an empty slot)";
         return SO_ERR_INVALID_ARG;
     }
-    SO_HIP(hipSetDevice(x->device));
     return tick_common(x, f->d_desc, f->n, max_dist, ratio, peer_counts, peer_candidates);
 }
 
 int so_exchange_tick(so_exchange* x, const uint8_t* descriptors, int n, int max_dist, float ratio, int32_t* peer_counts,
                      int32_t* peer_candidates) {
-    if (!x || !x->comm || n < 0 || (n > 0 && !descriptors)) return SO_ERR_INVALID_ARG;
+    if (!x || !x->comm) return SO_ERR_INVALID_ARG;
+    if (x->dead) return dead_handle();
     SO_HIP(hipSetDevice(x->device));
+    if (n < 0 || (n > 0 && !descriptors)) {  // rank-local: take part with an empty slot, then report
+        const int rc = tick_common(x, nullptr, 0, max_dist, ratio, peer_counts, peer_candidates);
+        if (rc != SO_OK) return rc;
+        last_error_ref() = "exchange tick: no descriptors (the rank took part with an empty slot)";
+        return SO_ERR_INVALID_ARG;
+    }
     const int nk = n < x->slot_keypoints ? n : x->slot_keypoints;
     if (nk > 0) SO_HIP(hipMemcpyAsync(x->d_stage, descriptors, 32 * (size_t)nk, hipMemcpyHostToDevice, x->stream));
     return tick_common(x, x->d_stage, nk, max_dist, ratio, peer_counts, peer_candidates);
@@ -338,6 +423,7 @@ int so_exchange_create_store_host(int device, int rank, int world, so_exchange_a
     }
     SO_HIP(hipSetDevice(device));
     so_exchange* x = new so_exchange();
+    if (const char* e = getenv("SWARMORB_COLLECTIVE_TIMEOUT_MS")) x->timeout_ms = atoi(e) > 0 ? atoi(e) : 0;
     x->device = device;
     x->rank = rank;
     x->world = world;
@@ -396,15 +482,15 @@ int so_exchange_read_record(so_exchange* x, int peer, int index, uint8_t* record
 
 int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stride, int32_t n_records,
                              const so_kf_search_params* p, so_kf_candidate* out, int32_t* pairs, int32_t* n_out) {
-    if (!x || !x->store || !p || n_records < 0 || n_records > x->records_per_tick || p->max_candidates < 0 ||
-        p->max_candidates > SO_KF_MAX_CANDIDATES)
-        return SO_ERR_INVALID_ARG;
-    if (n_records > 0 && (!records || !out || !n_out || stride < sizeof(so_keyframe_header))) return SO_ERR_INVALID_ARG;
+    if (!x || !x->store) return SO_ERR_INVALID_ARG;
+    if (x->dead) return dead_handle();
+    if (!p || n_records < 0 || n_records > x->records_per_tick || p->max_candidates < 0 || p->max_candidates > SO_KF_MAX_CANDIDATES ||
+        (n_records > 0 && (!records || !out || !n_out || stride < sizeof(so_keyframe_header))))
+        return tick_store_with_nothing(x, p, out, pairs, n_out, 0, "bad arguments (record count, stride, outputs or search parameters)");
     SO_HIP(hipSetDevice(x->device));
     hipStream_t s = x->store->stream;
     SO_HIP(hipMemsetAsync(x->d_rslot, 0, x->rec_stride * (size_t)x->records_per_tick, s));
-    // A tick is COLLECTIVE: a rank that returned before the all-gather because one of ITS records is malformed would
-    // leave every other rank waiting in theirs.  Such a rank takes part with zero records and reports the error afterwards.
+    // (a malformed record is a rank-local failure too: zero records, error afterwards - tick_store_with_nothing)
     bool bad_records = false;
     size_t need = 0;
     for (int j = 0; j < n_records; j++) {
@@ -417,15 +503,8 @@ int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stri
         else
             need += (size_t)h.n_keypoints;
     }
-    if (bad_records) {
-        for (int j = 0; j < n_records; j++) n_out[j] = 0;
-        const std::vector<const float*> none_a;
-        const std::vector<const int32_t*> none_m;
-        const int rc = tick_store_common(x, 0, p, out, pairs, n_out, none_a, none_m);
-        last_error_ref() = "exchange tick: not a keyframe record, or more keypoints than the slot holds (the rank took part in the "
-                           "collective with zero records)";
-        return rc != SO_OK ? rc : SO_ERR_INVALID_ARG;
-    }
+    if (bad_records)
+        return tick_store_with_nothing(x, p, out, pairs, n_out, n_records, "not a keyframe record, or more keypoints than the slot holds");
     std::vector<const float*> angles((size_t)n_records);
     std::vector<const int32_t*> mps((size_t)n_records);
     x->q_angle.resize(need ? need : 1);
@@ -456,15 +535,15 @@ int so_exchange_tick_records(so_exchange* x, const uint8_t* records, size_t stri
 int so_exchange_tick_keyframe(so_exchange* x, const so_dframe* f, const so_keyframe_header* hdr,
                               const int32_t* map_point_id, const so_kf_search_params* p, so_kf_candidate* out,
                               int32_t* pairs, int32_t* n_out) {
-    if (!x || !x->store || !f || !f->ready || !f->mirrors || !hdr || !p || !out || !n_out || p->max_candidates < 0 ||
-        p->max_candidates > SO_KF_MAX_CANDIDATES)
-        return SO_ERR_INVALID_ARG;
-    if (f->device != x->device) {
-        last_error_ref() = "frame and exchange live on different devices";
-        return SO_ERR_INVALID_ARG;
-    }
+    if (!x || !x->store) return SO_ERR_INVALID_ARG;
+    if (x->dead) return dead_handle();
+    if (!f || !f->ready || !f->mirrors || !hdr || !p || !out || !n_out || p->max_candidates < 0 || p->max_candidates > SO_KF_MAX_CANDIDATES)
+        return tick_store_with_nothing(x, p, out, pairs, n_out, n_out ? 1 : 0,
+                                       "the frame is not ready / not collected, or header, parameters or outputs are missing");
+    if (f->device != x->device)
+        return tick_store_with_nothing(x, p, out, pairs, n_out, 1, "frame and exchange live on different devices");
     const int n = f->n < x->slot_keypoints ? f->n : x->slot_keypoints;
-    if (n > 0 && !map_point_id) return SO_ERR_INVALID_ARG;
+    if (n > 0 && !map_point_id) return tick_store_with_nothing(x, p, out, pairs, n_out, 1, "map_point_id is missing");
     SO_HIP(hipSetDevice(x->device));
     hipStream_t s = x->store->stream;
     // staged block: header | angle f32 n | map_point_id i32 n  (descriptors, undistorted keypoints, octaves stay in HBM)
@@ -490,6 +569,25 @@ int so_exchange_tick_keyframe(so_exchange* x, const so_dframe* f, const so_keyfr
     std::vector<const float*> angles{x->q_angle.data()};
     std::vector<const int32_t*> mps{x->q_mp.data()};
     return tick_store_common(x, 1, p, out, pairs, n_out, angles, mps);
+}
+
+// Budget of the wait for a tick's collective in ms (0 = wait for ever); the default comes from
+// SWARMORB_COLLECTIVE_TIMEOUT_MS (5000).
+int so_exchange_set_timeout(so_exchange* x, int milliseconds) {
+    if (!x || milliseconds < 0) return SO_ERR_INVALID_ARG;
+    x->timeout_ms = milliseconds;
+    return SO_OK;
+}
+int so_exchange_is_dead(const so_exchange* x) { return x && x->dead ? 1 : 0; }
+// Test hook: one workgroup spins for `milliseconds` on the stream the next tick's collective is enqueued on - what a
+// peer that enters the tick late looks like from this rank (the spin ends by itself; nothing hangs).
+int so_exchange_debug_stall(so_exchange* x, int milliseconds) {
+    if (!x || milliseconds < 0 || milliseconds > 10000) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(x->device));
+    if (!x->d_stall_sink) SO_HIP(hipMalloc((void**)&x->d_stall_sink, 256));
+    hipStream_t s = x->store ? x->store->stream : x->stream;
+    if (milliseconds == 0) return SO_OK;
+    return launch_occupy(1, 256, milliseconds, x->d_stall_sink, s) ? SO_OK : SO_ERR_INVALID_ARG;
 }
 
 // Rank `peer`'s slot as gathered by the last tick (tests, host merger): descriptors and the header's checksum.

@@ -32,6 +32,9 @@ def _bind(lib):
     lib.so_exchange_store.argtypes = [vp]
     lib.so_exchange_read_record.argtypes = [vp, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.so_exchange_store.restype = vp
+    lib.so_exchange_set_timeout.argtypes = [vp, i32]
+    lib.so_exchange_is_dead.argtypes = [vp]
+    lib.so_exchange_debug_stall.argtypes = [vp, i32]
     lib._exchange_bound = True
 
 
@@ -69,6 +72,17 @@ class DeviceExchange:
             self._h = C.c_void_p()
 
     __del__ = close
+
+    def set_timeout(self, milliseconds):
+        """Budget of the wait for a tick's collective (0: unbounded).  On expiry the tick raises 'collective timed out'
+        and the handle is dead."""
+        _lib.check(self._lib.so_exchange_set_timeout(self._h, int(milliseconds)))
+
+    def is_dead(self):
+        return bool(self._lib.so_exchange_is_dead(self._h))
+
+    def debug_stall(self, milliseconds):
+        _lib.check(self._lib.so_exchange_debug_stall(self._h, int(milliseconds)))
 
     def tick(self, desc=None, frame_handle=None, max_dist=50, ratio=0.75):
         """desc: (n, 32) uint8 host array, or frame_handle: a so_dframe handle (device-resident descriptors).
@@ -161,6 +175,10 @@ class StoreExchange:
             self._h = C.c_void_p()
 
     __del__ = close
+
+    set_timeout = DeviceExchange.set_timeout
+    is_dead = DeviceExchange.is_dead
+    debug_stall = DeviceExchange.debug_stall
 
     def tick_records(self, records, params=None, want_pairs=True):
         """records: this rank's new keyframes (list of record arrays, at most records_per_tick; may be empty).

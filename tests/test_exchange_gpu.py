@@ -189,3 +189,95 @@ def test_two_ranks_over_the_host_transport_find_each_other(S):
                 found += len(want)
         assert got[rank][3] == len(store)
     assert found > 0
+
+
+def test_a_tick_whose_collective_does_not_complete_times_out_and_kills_the_handle(S):
+    """A peer that never enters a tick must not hang the survivors: the wait for the collective is bounded
+    (so_exchange_set_timeout / SWARMORB_COLLECTIVE_TIMEOUT_MS).  One rank over RCCL; the peer that is late is a
+    workgroup spinning for 400 ms on the tick's stream in front of the collective (so_exchange_debug_stall - nothing
+    hangs for good).  With a 50 ms budget the tick fails with 'collective timed out', the handle is dead, later ticks
+    fail at once, close() returns; with a budget above the stall the same tick succeeds."""
+    import time
+    from swarmmap_amd import SwarmOrbError
+    from swarmmap_amd.exchange import StoreExchange, unique_id
+    from swarmmap_amd.kfstore import search_params
+    kp = 200
+    kfs = synth.make_kf_store_case(81, n_agents=1, kfs_per_agent=3, n_kp=kp, n_places=1)
+    p = search_params(min_votes=10, min_matches=10, max_candidates=4)
+    x = StoreExchange(0, 0, 1, unique_id(), kp, records_per_tick=2, store_keyframes=16)
+    x.set_timeout(2000)
+    x.debug_stall(300)
+    t0 = time.perf_counter()
+    x.tick_records([_rec(kfs[0])], p)            # late, but inside the budget
+    assert 0.25 < time.perf_counter() - t0 < 1.5 and not x.is_dead()
+    x.set_timeout(50)
+    x.debug_stall(400)
+    t0 = time.perf_counter()
+    with pytest.raises(SwarmOrbError, match="timed out"):
+        x.tick_records([_rec(kfs[1])], p)
+    assert 0.04 < time.perf_counter() - t0 < 0.3 and x.is_dead()
+    t0 = time.perf_counter()
+    with pytest.raises(SwarmOrbError, match="timed out"):
+        x.tick_records([_rec(kfs[2])], p)
+    assert time.perf_counter() - t0 < 0.02
+    x.close()                                    # does not wait for the stalled stream
+    time.sleep(0.5)                              # (let the spinning workgroup end before the next test uses the GPU)
+
+
+def test_a_rank_with_a_local_problem_still_takes_part_in_the_collective(S):
+    """a tick is collective, so a rank whose OWN input is unusable (frame never collected, missing bindings,
+    too many records) must not return before the all-gather - its peer would wait for ever.  Two ranks over the host
+    transport: rank 1 hands in a bad keyframe at every tick and gets 'invalid argument' back; rank 0's ticks complete
+    (its gather callback sees both ranks arrive) and its store simply receives nothing from rank 1."""
+    import threading
+    from swarmmap_amd import SwarmOrbError
+    from swarmmap_amd.exchange import StoreExchange
+    from swarmmap_amd.kfstore import search_params
+    world, kp = 2, 200
+    kfs = synth.make_kf_store_case(83, n_agents=1, kfs_per_agent=4, n_kp=kp, n_places=2)
+    gate = threading.Barrier(world)
+    bufs, errs, bad_errors, sizes = [None] * world, [], [], []
+
+    def make_gather(rank):
+        def allgather(send, recv):
+            bufs[rank] = send.copy()
+            gate.wait(timeout=20)
+            n = len(send)
+            for r in range(world):
+                recv[r * n:(r + 1) * n] = bufs[r]
+            gate.wait(timeout=20)
+        return allgather
+
+    def run(rank):
+        try:
+            x = StoreExchange.over_host_transport(0, rank, world, make_gather(rank), kp, records_per_tick=2, store_keyframes=16)
+            p = search_params(min_votes=10, min_matches=10, max_candidates=4)
+            for t in range(3):
+                if rank == 0:
+                    x.tick_records([_rec(kfs[t])], p)
+                else:
+                    try:
+                        if t == 0:
+                            x.tick_records([_rec(kfs[0])] * 3, p)        # more records than the slot holds
+                        elif t == 1:
+                            bad = _rec(kfs[1]).copy(); bad[:4] = 0       # not a keyframe record
+                            x.tick_records([bad], p)
+                        else:
+                            x.tick_keyframe(None, kp, agent_id=1, keyframe_id=9, map_point_id=np.zeros(kp, np.int32),
+                                            timestamp=0.0, Tcw=np.zeros(12, np.float32), K=K_EUROC)  # no frame at all
+                    except SwarmOrbError as e:
+                        bad_errors.append(str(e))
+            sizes.append((rank, x.store.size()[0]))
+            x.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            gate.abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    assert len(bad_errors) == 3 and all("took part" in e for e in bad_errors), bad_errors
+    assert dict(sizes) == {0: 0, 1: 3}   # rank 1 received rank 0's three keyframes, rank 0 nothing
