@@ -370,6 +370,27 @@ int so_search_by_projection_keyframe(so_matcher* m, const so_frame_view* F, cons
 int so_matcher_batch_begin(so_matcher* m);
 int so_matcher_batch_end(so_matcher* m);
 
+/* HBM-resident keyframes.  A keyframe is searched again and again - by every later keyframe's SearchForTriangulation
+ * and Fuse while it is among the <= 20 covisible neighbours (code/src/LocalMapping.cc:197-246, 451-481) - and its
+ * keypoints never change: so_kframe_create uploads them ONCE, in GetFeaturesInArea order and (with a feature vector)
+ * in vocabulary-node order; the two calls below then stage only the queries.  Same results as so_fuse /
+ * so_search_for_triangulation with the same keyframe as so_frame_view; both may be part of a batch.
+ * KF: the keyframe's view (bounds as a KeyFrame has them, see so_frame_view); fv / level_sigma2 (mvLevelSigma2): needed
+ * for so_search_for_triangulation_kframe only, may be NULL.  The handle only lends its staging; the keyframe may be
+ * used with any so_matcher of the same device and must outlive the batches that reference it. */
+typedef struct so_kframe so_kframe;
+int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* fv, const float* level_sigma2, so_kframe** out);
+void so_kframe_destroy(so_kframe* k);
+int so_fuse_kframe(so_matcher* m, const so_kframe* KF, const so_camera* cam, const float* Tcw12, float log_scale_factor,
+                   const float* inv_level_sigma2, const so_mappoint_view* mp, float th, int32_t* best_idx, int32_t* best_dist,
+                   int32_t* n_fused, const so_window_queries* queries_out);
+/* keyframe 2 resident (its angles, octaves, descriptors, feature vector, scale tables were given at creation); free2[i]
+ * = !pKF2->GetMapPoint(i) at the time of the call */
+int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x1, const float* y1, const float* angle1,
+                                       const uint8_t* desc1, const uint8_t* free1, const so_featvec* fv1, const so_kframe* kf2,
+                                       const uint8_t* free2, const float* F12, float ex, float ey, int check_orientation,
+                                       int32_t* matches12, int32_t* nmatches);
+
 /* MapPoint::ComputeDistinctiveDescriptors (code/src/MapPoint.cc:323-392) for a batch of map points (SURVEY 8f rank
  * 4): point p owns descriptors [offsets[p], offsets[p+1]) (the rows the reference collects from its observing
  * keyframes, in map order); best_idx[p] = index within the point's own list of the descriptor with the least

@@ -621,12 +621,26 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
         const bool from_list = d.use_pairs && i1 != i2;  // large maps: the block's own (landmark-sorted) pair list
         const int p_lo = from_list ? d.pr_off[g] : d.pose_off[i1], p_hi = from_list ? d.pr_off[g + 1] : d.pose_off[i1 + 1];
-        auto add_pair = [&](int k1, int k2) {
-            const double* B = d.BDinv + 18 * (size_t)k1;
+        // lmk >= 0 (local windows: no prep launch): BDinv_{k1} = W_{k1} (Hll + lambda I)^-1 is formed here, by the very
+        // expressions ba_schur_prep_kernel uses (same bits); lmk < 0: read what that kernel stored
+        auto add_pair = [&](int k1, int k2, int lmk) {
             const double* W = d.W + 18 * (size_t)k2;
             double b[18], w[18];
+            if (lmk >= 0) {
+                double Di[9];
+                damped_inverse3(d.Hll + 9 * (size_t)lmk, lambda, Di);
+                const double* W1 = d.W + 18 * (size_t)k1;
 #pragma unroll
-            for (int k = 0; k < 18; k++) { b[k] = B[k]; w[k] = W[k]; }
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) b[r * 3 + c] = W1[r * 3] * Di[c] + W1[r * 3 + 1] * Di[3 + c] + W1[r * 3 + 2] * Di[6 + c];
+            } else {
+                const double* B = d.BDinv + 18 * (size_t)k1;
+#pragma unroll
+                for (int k = 0; k < 18; k++) b[k] = B[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 18; k++) w[k] = W[k];
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -637,7 +651,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
             for (int p = p_lo + tid; p < p_hi; p += kStride) {
                 const int k1 = d.ps_k1[p], k2 = d.ps_k2[p];
                 if (!d.e_active[k1] || !d.e_active[k2]) continue;  // dropped between the stages
-                add_pair(k1, k2);
+                add_pair(k1, k2, -1);
             }
         } else {
             // pose i1's edges, four per thread and round: the look-ups of a round go out together (edge + landmark ->
@@ -645,22 +659,22 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
             // however few of its edges pose i2 shares
             const int* tab = d.edge_tab + (size_t)i2 * d.n_points;
             for (int base = p_lo; base < p_hi; base += 4 * kStride) {
-                int k1[4], k2[4];
+                int k1[4], k2[4], lmk[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int p = base + u * kStride + tid;
                     k1[u] = p < p_hi ? d.pose_edges[p] : -1;
-                    k2[u] = p < p_hi ? d.pose_edge_point[p] : 0;  // the landmark for now
+                    lmk[u] = p < p_hi ? d.pose_edge_point[p] : 0;  // the edge's landmark
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool live = k1[u] >= 0 && d.e_active[k1[u]];
-                    const int partner = (i1 == i2) ? k1[u] : (k1[u] >= 0 ? tab[k2[u]] : -1);
+                    const int partner = (i1 == i2) ? k1[u] : (k1[u] >= 0 ? tab[lmk[u]] : -1);
                     k2[u] = live ? partner : -1;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (k2[u] >= 0) add_pair(k1[u], k2[u]);
+                    if (k2[u] >= 0) add_pair(k1[u], k2[u], d.use_pairs ? -1 : lmk[u]);
             }
         }
         // wave totals by transposition (the pose kernel's scheme): values 0..31 end up in lane pairs, 32..35 by butterfly
@@ -703,7 +717,17 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
         const int e = d.pose_edges[k];
         if (!d.e_active[e]) continue;
         const double* W = d.W + 18 * (size_t)e;
-        const double* db = d.db + 3 * (size_t)d.e_point[e];
+        double db[3];
+        if (d.use_pairs) {
+            const double* dbp = d.db + 3 * (size_t)d.e_point[e];
+            db[0] = dbp[0]; db[1] = dbp[1]; db[2] = dbp[2];
+        } else {  // db = Dinv bl as ba_schur_prep_kernel forms it
+            double Di[9];
+            damped_inverse3(d.Hll + 9 * (size_t)d.e_point[e], lambda, Di);
+            const double* bl = d.bl + 3 * (size_t)d.e_point[e];
+#pragma unroll
+            for (int r = 0; r < 3; r++) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
+        }
 #pragma unroll
         for (int r = 0; r < 6; r++) acc[r] += W[r * 3] * db[0] + W[r * 3 + 1] * db[1] + W[r * 3 + 2] * db[2];
     }
@@ -1260,9 +1284,12 @@ __global__ __launch_bounds__(256) void ba_schur_gather_small_kernel(BaDev d, int
 
 static void launch_ba_schur(const BaDev& d, hipStream_t s) {
     const int nthreads = d.n_points > d.n_edges ? d.n_points : d.n_edges;
-    if (nthreads > 0) hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d);
     const int n_blk = d.n_free * (d.n_free + 1) / 2;
+    // Local windows (no pair lists) have no prep launch: the gather and the update form (Hll + lambda I)^-1, W Dinv and
+    // Dinv bl themselves where they need them - the same expressions, hence the same bits, one launch (9.5 us of an 87 us
+    // trial on LBA-M) less.  Pair-list maps read each product up to hundreds of times: they keep the stored copies.
     if (d.use_pairs) {
+        if (nthreads > 0) hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d);
         if (n_blk > 0) hipLaunchKernelGGL(ba_schur_gather_small_kernel, dim3((n_blk + 255) / 256), dim3(256), 0, s, d, n_blk);
         const int waves = d.big_cap + d.n_free;  // the walked blocks, then the right-hand sides
         hipLaunchKernelGGL(ba_schur_gather_kernel<1>, dim3((waves + 3) / 4), dim3(256), 0, s, d, d.big_cap);
@@ -1335,7 +1362,9 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d) {
                 if (act) {
                     const double* bl = d.bl + 3 * (size_t)il;
                     cl[0] += bl[0]; cl[1] += bl[1]; cl[2] += bl[2];
-                    const double* Di = d.Dinv + 9 * (size_t)il;
+                    double Dloc[9];
+                    if (!d.use_pairs) damped_inverse3(d.Hll + 9 * (size_t)il, lambda, Dloc);  // (no prep launch: same bits)
+                    const double* Di = d.use_pairs ? d.Dinv + 9 * (size_t)il : Dloc;
 #pragma unroll
                     for (int r = 0; r < 3; r++) {
                         const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];

@@ -111,6 +111,27 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
 
+// A keyframe's matcher-side data resident in HBM (so_kframe_create): its keypoints in GetFeaturesInArea order and,
+// when a feature vector came with it, in vocabulary-node order.  Immutable after creation.
+struct so_kframe {
+    int device = 0, n = 0;
+    uint8_t* d = nullptr;
+    // grid layout
+    size_t g_oct = 0, g_desc = 0, g_cols = 0, g_end = 0;
+    int n_grid = 0;
+    std::vector<int> perm_grid;
+    float min_x = 0.f, max_x = 0.f, min_y = 0.f, max_y = 0.f, grid_inv_w = 0.f, grid_inv_h = 0.f, grid_min_y = 0.f;
+    // node layout (behind the grid layout)
+    bool has_nodes = false;
+    size_t n_xy = 0, n_oct = 0, n_desc = 0;
+    int n_node = 0;
+    std::vector<int> perm_node;
+    std::vector<int32_t> node_id, node_off;  // offsets relative to the first node's first feature
+    std::vector<float> angle;                // mvKeysUn[i].angle by keypoint index
+    float scale[8] = {0}, sigma2[8] = {0};
+    int nlevels = 0;
+};
+
 struct so_matcher {
     std::vector<int> scratch_rot_item, scratch_rot_b;  // rotation-histogram bookkeeping of the resolve loops
     int device = 0;
@@ -180,6 +201,8 @@ struct so_matcher {
         so::ProjectSrc S{};
         size_t off_xw = 0, off_nrm = 0, off_maxd = 0, off_mind = 0, off_valid = 0;
         std::vector<int> perm;
+        const so_kframe* ext = nullptr;  // candidates read from an HBM-resident keyframe instead of the staged block
+        int ext_layout = 0;              // 0: grid order, 1: vocabulary-node order
         std::function<int(const uint32_t* keys, const int32_t* cnt, const so::MatchQueryW* qw, const std::vector<int>& perm)> resolve;
     };
     bool batching = false;
@@ -469,10 +492,13 @@ int batch_flush(so_matcher* m);
 // The call whose inputs sit in m->h_in [0, staged_end) (frame part, then queries / descriptors / map points at the
 // offsets recorded in m) joins the batch: its block is copied behind the others, its outputs are deferred to `resolve`.
 int batch_defer(so_matcher* m, size_t staged_end, int nq, int K, const ProjectSrc* S, const size_t* mp_offsets5,
-                std::function<int(const uint32_t*, const int32_t*, const MatchQueryW*, const std::vector<int>&)> resolve) {
+                std::function<int(const uint32_t*, const int32_t*, const MatchQueryW*, const std::vector<int>&)> resolve,
+                const so_kframe* ext = nullptr, int ext_layout = 0) {
     int rc;
     if (m->jobs.size() == kBatchMaxJobs && (rc = batch_flush(m))) return rc;
     so_matcher::BatchJob J;
+    J.ext = ext;
+    J.ext_layout = ext_layout;
     J.base = m->hb_used;
     J.off_oct = m->off_oct; J.off_desc = m->off_desc; J.off_limit = m->off_limit; J.off_cols = m->off_cols;
     J.off_q = m->off_q; J.off_qdesc = m->off_qdesc;
@@ -491,7 +517,7 @@ int batch_defer(so_matcher* m, size_t staged_end, int nq, int K, const ProjectSr
         J.q_off = m->dq_used;
         m->dq_used += align256(sizeof(MatchQuery) * (size_t)nq);
     }
-    J.perm = m->perm;
+    if (!ext) J.perm = m->perm;  // (a resident keyframe carries its own position -> keypoint maps)
     J.resolve = std::move(resolve);
     const size_t block = align256(staged_end);
     if ((rc = m->hb_in.ensure_keep(kBatchTableBytes + J.base + block + 256, kBatchTableBytes + J.base))) return rc;
@@ -537,6 +563,21 @@ int batch_flush(so_matcher* m) {
         memcpy(D.F.scale, J.scale, sizeof(J.scale));
         D.F.ex = J.ex; D.F.ey = J.ey;
         D.F.col_start = J.has_cols ? (const int32_t*)(b + J.off_cols) : nullptr;
+        if (J.ext) {  // candidates of an HBM-resident keyframe; the staged block holds the gate, queries, descriptors
+            const so_kframe* k = J.ext;
+            if (J.ext_layout == 0) {
+                D.F.xy = (const float2*)k->d;
+                D.F.octave = (const int8_t*)(k->d + k->g_oct);
+                D.F.desc = (const uint4*)(k->d + k->g_desc);
+                D.F.col_start = (const int32_t*)(k->d + k->g_cols);
+            } else {
+                D.F.xy = (const float2*)(k->d + k->n_xy);
+                D.F.octave = (const int8_t*)(k->d + k->n_oct);
+                D.F.desc = (const uint4*)(k->d + k->n_desc);
+                D.F.col_start = nullptr;
+            }
+            D.F.limit = J.has_limit ? (const int32_t*)b : nullptr;  // the gate is the first thing in the block
+        }
         D.F.min_x = J.min_x; D.F.min_y = J.min_y; D.F.grid_inv_w = J.grid_inv_w; D.F.grid_inv_h = J.grid_inv_h;
         D.F.grid_min_y = J.grid_min_y;
         D.qdesc = (const uint4*)(b + J.off_qdesc);
@@ -580,8 +621,9 @@ int batch_flush(so_matcher* m) {
     for (int j = 0; j < nj; j++) {
         const so_matcher::BatchJob& J = m->jobs[(size_t)j];
         const uint8_t* ob = (const uint8_t*)m->hb_out.p;
+        const std::vector<int>& perm = J.ext ? (J.ext_layout == 0 ? J.ext->perm_grid : J.ext->perm_node) : J.perm;
         const int r1 = J.resolve((const uint32_t*)(ob + J.keys_off), (const int32_t*)(ob + J.cnt_off),
-                                 (const MatchQueryW*)(ob + J.qw_off), J.perm);
+                                 (const MatchQueryW*)(ob + J.qw_off), perm);
         if (r1 && !rc) rc = r1;
     }
     m->jobs.clear();
@@ -2042,6 +2084,284 @@ int so_search_by_projection_keyframe(so_matcher* m, const so_frame_view* F, cons
     fill_target(S, F, cam, log_scale_factor, th);
     return projected_greedy(m, F, mp, S, 1, mp_angle, orb_dist, check_orientation, reuse, kp_to_point, nmatches,
                             queries_out);
+}
+
+// ---- HBM-resident keyframes -------------------------------------------------------------------------------------
+int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* fv, const float* level_sigma2, so_kframe** out) {
+    if (!m || !out || !frame_ok(KF) || !KF->scale_factors || KF->nlevels < 1 || KF->nlevels > 8 || m->batching) return SO_ERR_INVALID_ARG;
+    if (fv && (!featvec_ok(fv, KF->n) || !level_sigma2)) return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    SO_HIP(hipSetDevice(m->device));
+    (void)take_reuse(m);
+    so_kframe* k = new so_kframe();
+    k->device = m->device;
+    k->n = KF->n;
+    so_frame_view view = *KF;
+    view.excluded = nullptr;
+    int rc = upload_frame(m, &view, nullptr, false);  // the grid layout, staged in m->h_in [0, frame_end)
+    if (rc) { delete k; return rc; }
+    k->g_oct = m->off_oct; k->g_desc = m->off_desc; k->g_cols = m->off_cols; k->g_end = m->frame_end;
+    k->n_grid = m->n_cand;
+    k->perm_grid = m->perm;
+    k->min_x = KF->min_x; k->max_x = KF->max_x; k->min_y = KF->min_y; k->max_y = KF->max_y;
+    k->grid_inv_w = KF->grid_inv_w; k->grid_inv_h = KF->grid_inv_h; k->grid_min_y = m->grid_min_y;
+    k->nlevels = KF->nlevels;
+    for (int l = 0; l < 8; l++) {
+        k->scale[l] = l < KF->nlevels ? KF->scale_factors[l] : 0.f;
+        k->sigma2[l] = (level_sigma2 && l < KF->nlevels) ? level_sigma2[l] : 0.f;
+    }
+    if (KF->angle) k->angle.assign(KF->angle, KF->angle + KF->n);
+    // (no null-stream copies: another thread of the process may be capturing a graph; uploads go through the handle's stream)
+    size_t total = k->g_end;
+    if (fv) {
+        const size_t nn = (size_t)(fv->n_nodes > 0 ? fv->off[fv->n_nodes] - fv->off[0] : 0);
+        total += align256(align256(align256(sizeof(float2) * nn) + nn) + 32 * nn) + 256;
+    }
+    hipError_t e = hipMalloc((void**)&k->d, total + 256);
+    if (e == hipSuccess) e = hipMemcpyAsync(k->d, m->h_in.p, k->g_end, hipMemcpyHostToDevice, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) {
+        if (k->d) (void)hipFree(k->d);
+        delete k;
+        return hip_fail(e, "so_kframe_create", __FILE__, __LINE__);
+    }
+    if (fv) {
+        rc = upload_featvec_candidates(m, KF->n, KF->x, KF->y, KF->octave, KF->desc, fv, nullptr);
+        if (rc) { delete k; return rc; }
+        k->has_nodes = true;
+        k->n_xy = k->g_end;
+        k->n_oct = k->g_end + m->off_oct;
+        k->n_desc = k->g_end + m->off_desc;
+        k->n_node = m->n_cand;
+        k->perm_node = m->perm;
+        k->node_id.assign(fv->node_id, fv->node_id + fv->n_nodes);
+        k->node_off.resize((size_t)fv->n_nodes + 1);
+        for (int a = 0; a <= fv->n_nodes; a++) k->node_off[(size_t)a] = fv->off[a] - fv->off[0];
+        const size_t node_bytes = align256(m->off_desc + 32 * (size_t)k->n_node);
+        if (k->g_end + node_bytes > total) e = hipErrorInvalidValue;
+        if (e == hipSuccess && node_bytes > 0) e = hipMemcpyAsync(k->d + k->g_end, m->h_in.p, node_bytes, hipMemcpyHostToDevice, m->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    }
+    m->resident_n = -1;
+    m->dirty_from = 0;
+    if (e != hipSuccess) {
+        if (k->d) (void)hipFree(k->d);
+        delete k;
+        return hip_fail(e, "so_kframe_create", __FILE__, __LINE__);
+    }
+    *out = k;
+    return SO_OK;
+}
+
+void so_kframe_destroy(so_kframe* k) {
+    if (!k) return;
+    (void)hipSetDevice(k->device);
+    if (k->d) (void)hipFree(k->d);
+    delete k;
+}
+
+}  // extern "C"
+
+namespace {
+// Runs `call` as a one-job batch when the handle is not inside one.
+template <typename F>
+int as_batch(so_matcher* m, F&& call) {
+    if (m->batching) return call();
+    m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
+    m->batching = true;
+    m->jobs.clear();
+    m->hb_used = m->dq_used = m->out_used = 0;
+    int rc = call();
+    const int rc2 = batch_flush(m);
+    m->batching = false;
+    m->jobs.clear();
+    m->src = nullptr;
+    m->resident_n = -1;
+    m->dirty_from = 0;
+    return rc ? rc : rc2;
+}
+
+// what a resident keyframe contributes to the handle's per-call frame state
+void adopt_kframe(so_matcher* m, const so_kframe* k, int layout) {
+    m->src = nullptr;
+    m->n_cand = layout == 0 ? k->n_grid : k->n_node;
+    m->has_cols = layout == 0;
+    m->min_x = k->min_x; m->min_y = k->min_y; m->grid_inv_w = k->grid_inv_w; m->grid_inv_h = k->grid_inv_h;
+    m->grid_min_y = k->grid_min_y;
+    m->off_oct = m->off_desc = m->off_cols = 0;
+    m->resident_n = -1;
+}
+}  // namespace
+
+extern "C" {
+
+int so_fuse_kframe(so_matcher* m, const so_kframe* KF, const so_camera* cam, const float* Tcw12, float log_scale_factor,
+                   const float* inv_level_sigma2, const so_mappoint_view* mp, float th, int32_t* best_idx, int32_t* best_dist,
+                   int32_t* n_fused, const so_window_queries* queries_out) {
+    if (!m || !KF || !cam || !Tcw12 || !inv_level_sigma2 || !mappoints_ok(mp, true) || !n_fused) return SO_ERR_INVALID_ARG;
+    if (mp->n > 0 && (!best_idx || !best_dist)) return SO_ERR_INVALID_ARG;
+    if (KF->device != m->device) {
+        last_error_ref() = "resident keyframe lives on another device";
+        return SO_ERR_INVALID_ARG;
+    }
+    SO_HIP(hipSetDevice(m->device));
+    (void)take_reuse(m);
+    *n_fused = 0;
+    const int n = mp->n;
+    for (int i = 0; i < n; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+    }
+    if (n == 0) return SO_OK;
+    return as_batch(m, [&]() -> int {
+        ProjectSrc S{};
+        memcpy(S.A, Tcw12, sizeof(S.A));
+        camera_center(Tcw12, S.Ow);
+        S.flags = kPAngleGate;
+        S.fx = cam->fx; S.fy = cam->fy; S.cx = cam->cx; S.cy = cam->cy;
+        S.bounds[0] = KF->min_x; S.bounds[1] = KF->max_x; S.bounds[2] = KF->min_y; S.bounds[3] = KF->max_y;
+        for (int l = 0; l < 8; l++) S.scale[l] = KF->scale[l];
+        S.nlevels = KF->nlevels;
+        S.log_scale_factor = log_scale_factor;
+        S.th = th;
+        S.level_above = 0;
+        S.qflags = kQChi2Gate;
+        S.q_max_dist = 256;
+        adopt_kframe(m, KF, 0);
+        m->has_limit = false;
+        for (int l = 0; l < 8; l++) m->inv_sigma2[l] = l < KF->nlevels ? inv_level_sigma2[l] : 0.f;
+        m->frame_end = 0;  // nothing of the frame is staged
+        ProjStage P;
+        int rc = stage_projected(m, mp, P);
+        if (rc) return rc;
+        so_window_queries qout{};
+        const bool want_q = queries_out != nullptr;
+        if (want_q) qout = *queries_out;
+        const int n_kf = KF->n_grid;
+        auto resolve = [n, n_kf, want_q, qout, best_idx, best_dist, n_fused](const uint32_t* keys, const int32_t*, const MatchQueryW* qw,
+                                                                             const std::vector<int>& perm) -> int {
+            export_queries(want_q ? &qout : nullptr, qw, n);
+            if (n_kf > 0)
+                for (int i = 0; i < n; i++)
+                    if (keys[i] != 0xFFFFFFFFu) {
+                        best_idx[i] = perm[(size_t)(keys[i] & 0xFFFFu)];
+                        best_dist[i] = (int32_t)(keys[i] >> 16);
+                    }
+            *n_fused = keep_within(n, best_idx, best_dist, TH_LOW);
+            return SO_OK;
+        };
+        const size_t offs[5] = {P.off_xw, P.off_nrm, P.off_maxd, P.off_mind, P.off_valid};
+        return batch_defer(m, P.staged_end, n, 1, &S, offs, std::move(resolve), KF, 0);
+    });
+}
+
+int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x1, const float* y1, const float* angle1,
+                                       const uint8_t* desc1, const uint8_t* free1, const so_featvec* fv1, const so_kframe* kf2,
+                                       const uint8_t* free2, const float* F12, float ex, float ey, int check_orientation,
+                                       int32_t* matches12, int32_t* nmatches) {
+    if (!m || !kf2 || !kf2->has_nodes || !nmatches || !matches12 || n1 < 0 || !F12) return SO_ERR_INVALID_ARG;
+    if ((n1 > 0 && (!x1 || !y1 || !desc1 || !free1)) || (kf2->n > 0 && !free2)) return SO_ERR_INVALID_ARG;
+    if (check_orientation && ((n1 > 0 && !angle1) || (kf2->n > 0 && kf2->angle.empty()))) return SO_ERR_INVALID_ARG;
+    if (!featvec_ok(fv1, n1)) return SO_ERR_INVALID_ARG;
+    if (kf2->device != m->device) {
+        last_error_ref() = "resident keyframe lives on another device";
+        return SO_ERR_INVALID_ARG;
+    }
+    SO_HIP(hipSetDevice(m->device));
+    (void)take_reuse(m);
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    const so_featvec fv2{(int32_t)kf2->node_id.size(), kf2->node_id.data(), kf2->node_off.data(), nullptr};
+    // (join_nodes only reads node ids)
+    NodeJoin J;
+    {
+        int k1 = 0, k2 = 0;
+        while (k1 < fv1->n_nodes && k2 < fv2.n_nodes) {
+            if (fv1->node_id[k1] == fv2.node_id[k2]) {
+                J.k1.push_back(k1++);
+                J.k2.push_back(k2++);
+            } else if (fv1->node_id[k1] < fv2.node_id[k2]) {
+                k1 = fv_lower_bound(fv1, k1, fv2.node_id[k2]);
+            } else {
+                k2 = fv_lower_bound(&fv2, k2, fv1->node_id[k1]);
+            }
+        }
+    }
+    if (J.k1.empty() || n1 == 0 || kf2->n_node == 0) return SO_OK;
+    return as_batch(m, [&]() -> int {
+        adopt_kframe(m, kf2, 1);
+        for (int l = 0; l < 8; l++) {
+            m->scale[l] = kf2->scale[l];
+            m->sigma2[l] = kf2->sigma2[l];
+        }
+        m->ex = ex;
+        m->ey = ey;
+        // staged block: [gate by position | queries | query descriptors]
+        const int nc = kf2->n_node;
+        m->has_limit = true;
+        m->off_limit = 0;
+        m->frame_end = align256(sizeof(int32_t) * (size_t)nc);
+        int rc;
+        if ((rc = m->h_in.ensure_keep(m->frame_end + 256, 0))) return rc;
+        {
+            int32_t* hl = (int32_t*)m->h_in.p;
+            for (int r = 0; r < nc; r++) hl[r] = free2[kf2->perm_node[(size_t)r]] ? INT_MAX : 0;  // "|| pMP2" (:662)
+        }
+        std::vector<int> q_idx1;
+        std::vector<MatchQuery> queries;
+        for (size_t j = 0; j < J.k1.size(); j++) {
+            const int k1 = J.k1[j], k2 = J.k2[j];
+            for (int a = fv1->off[k1]; a < fv1->off[k1 + 1]; a++) {
+                const int idx1 = fv1->idx[a];
+                if (!free1[idx1]) continue;
+                MatchQuery q;
+                init_query(q);
+                q.active = 1;
+                q.flags = kQRange | kQEpipolar | kQPreferLast;
+                q.max_dist = TH_LOW;
+                q.c_begin = kf2->node_off[(size_t)k2];
+                q.c_end = kf2->node_off[(size_t)k2 + 1];
+                q.la = x1[idx1] * F12[0] + y1[idx1] * F12[3] + F12[6];
+                q.lb = x1[idx1] * F12[1] + y1[idx1] * F12[4] + F12[7];
+                q.lc = x1[idx1] * F12[2] + y1[idx1] * F12[5] + F12[8];
+                queries.push_back(q);
+                q_idx1.push_back(idx1);
+            }
+        }
+        const int nq = (int)queries.size();
+        if (nq == 0) return SO_OK;
+        if ((rc = ensure_queries(m, nq))) return rc;
+        memcpy(m->h_q.p, queries.data(), sizeof(MatchQuery) * (size_t)nq);
+        uint8_t* hd = (uint8_t*)m->h_qdesc.p;
+        for (int i = 0; i < nq; i++) memcpy(hd + (size_t)i * 32, desc1 + (size_t)q_idx1[(size_t)i] * 32, 32);
+        const float* angle2 = kf2->angle.data();
+        auto resolve = [m, nq, q_idx1 = std::move(q_idx1), angle1, angle2, check_orientation, matches12, nmatches](
+                           const uint32_t* keys, const int32_t*, const MatchQueryW*, const std::vector<int>& perm) -> int {
+            std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;
+            rot_item.clear();
+            rot_b.clear();
+            int hist[HISTO_LENGTH] = {0};
+            int nm = 0;
+            for (int i = 0; i < nq; i++) {
+                if (keys[i] == 0xFFFFFFFFu) continue;
+                const int idx1 = q_idx1[(size_t)i];
+                const int idx2 = perm[(size_t)(0xFFFF - (keys[i] & 0xFFFFu))];
+                matches12[idx1] = idx2;
+                nm++;
+                if (check_orientation) {
+                    const int b = rot_bin(angle1[idx1], angle2[idx2]);
+                    rot_item.push_back(idx1);
+                    rot_b.push_back(b);
+                    hist[b]++;
+                }
+            }
+            if (check_orientation) apply_rot_hist(hist, rot_item, rot_b, matches12, nm);
+            *nmatches = nm;
+            return SO_OK;
+        };
+        return batch_defer(m, m->off_qdesc + (size_t)nq * 32, nq, 1, nullptr, nullptr, std::move(resolve), kf2, 1);
+    });
 }
 
 int so_matcher_batch_begin(so_matcher* m) {

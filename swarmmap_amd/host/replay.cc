@@ -131,6 +131,10 @@ struct KfSnap {
     int t = 0;
     // DBoW2::FeatureVector stand-in, filled by the local-mapping thread
     std::vector<int32_t> node_id, off, idx;
+    // the keyframe's matcher-side data in HBM (so_kframe_create), uploaded once when it joins the local-mapping thread's
+    // ring and read by every later keyframe's searches
+    so_kframe* dev = nullptr;
+    ~KfSnap() { so_kframe_destroy(dev); }
 };
 
 struct LmJob {
@@ -154,6 +158,7 @@ struct so_replay {
     so_matcher* mapper_matcher = nullptr;  // the local-mapping thread's own matcher context
     std::vector<uint8_t> vocab;            // n_vocab x 32 centroid descriptors (so_replay_set_vocabulary)
     int lm_neighbours = 20;                // nn = 20, LocalMapping.cc:207,455 (monocular)
+    bool lm_resident = true;               // neighbours are searched in HBM-resident form (SWARMORB_LM_RESIDENT=0: host views)
     bool lm_batch = true;                  // all searches of a keyframe as one so_matcher batch (SWARMORB_LM_BATCH=0: one by one)
     std::deque<std::shared_ptr<KfSnap>> lm_ring;  // (local-mapping thread only)
     std::vector<int32_t> lm_stamp, lm_cstamp;     // slot -> id of the keyframe / job that marked it
@@ -317,13 +322,14 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
                 c->off.push_back((int32_t)c->idx.size());
             }
     }
-    st[kLmNodeMs] = now_ms() - t0;
     const so_featvec fv1{(int32_t)c->node_id.size(), c->node_id.data(), c->off.data(), c->idx.data()};
-    std::vector<uint8_t> free1((size_t)n), free2;
-    for (int i = 0; i < n; i++) free1[(size_t)i] = c->mp[(size_t)i] < 0 ? 1 : 0;
-    const so_frame_view Vc = keyframe_view(r, *c);
     float level_sigma2[8];
     for (int l = 0; l < 8; l++) level_sigma2[l] = r->scale[l] * r->scale[l];
+    const so_frame_view Vc = keyframe_view(r, *c);
+    if (r->lm_resident && so_kframe_create(m, &Vc, &fv1, level_sigma2, &c->dev) != SO_OK) return SO_ERR_HIP;
+    st[kLmNodeMs] = now_ms() - t0;
+    std::vector<uint8_t> free1((size_t)n), free2;
+    for (int i = 0; i < n; i++) free1[(size_t)i] = c->mp[(size_t)i] < 0 ? 1 : 0;
     int n_tri = 0, n_fused = 0, n_back = 0;
     // Every search of this keyframe is independent of the others here (nothing is written back into the map), so with
     // lm_batch they all go out as ONE batch: one staging copy, one projection launch, one search launch, one wait.
@@ -345,11 +351,14 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         const so_featvec fv2{(int32_t)kf2->node_id.size(), kf2->node_id.data(), kf2->off.data(), kf2->idx.data()};
         tri_m12[jn].resize((size_t)n);
         const double ta = now_ms();
-        if (so_search_for_triangulation(m, n, c->x.data(), c->y.data(), c->angle.data(), c->desc.data(), free1.data(), &fv1, kf2->n,
-                                        kf2->x.data(), kf2->y.data(), kf2->octave.data(), kf2->angle.data(), kf2->desc.data(),
-                                        free2.data(), &fv2, F12, ex, ey, r->scale, level_sigma2, r->nlevels, 1, tri_m12[jn].data(),
-                                        &tri_nm[jn]) != SO_OK)
-            return SO_ERR_HIP;
+        const int trc = kf2->dev
+            ? so_search_for_triangulation_kframe(m, n, c->x.data(), c->y.data(), c->angle.data(), c->desc.data(), free1.data(), &fv1,
+                                                 kf2->dev, free2.data(), F12, ex, ey, 1, tri_m12[jn].data(), &tri_nm[jn])
+            : so_search_for_triangulation(m, n, c->x.data(), c->y.data(), c->angle.data(), c->desc.data(), free1.data(), &fv1, kf2->n,
+                                          kf2->x.data(), kf2->y.data(), kf2->octave.data(), kf2->angle.data(), kf2->desc.data(),
+                                          free2.data(), &fv2, F12, ex, ey, r->scale, level_sigma2, r->nlevels, 1, tri_m12[jn].data(),
+                                          &tri_nm[jn]);
+        if (trc != SO_OK) return SO_ERR_HIP;
         st[kLmTriMs] += now_ms() - ta;
         if (!batch) {
             so_matcher_last_kernel_ms(m, &kms);
@@ -384,9 +393,12 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         const so_frame_view V2 = keyframe_view(r, *k2);
         fuse_best[jn].resize((size_t)n); fuse_dist[jn].resize((size_t)n);
         const double ta = now_ms();
-        if (so_fuse(m, &V2, &r->cam, k2->T, r->log_sf, r->inv_sigma2, &P, 3.0f, fuse_best[jn].data(), fuse_dist[jn].data(), &fuse_n[jn],
-                    nullptr) != SO_OK)
-            return SO_ERR_HIP;
+        const int frc = k2->dev
+            ? so_fuse_kframe(m, k2->dev, &r->cam, k2->T, r->log_sf, r->inv_sigma2, &P, 3.0f, fuse_best[jn].data(), fuse_dist[jn].data(),
+                             &fuse_n[jn], nullptr)
+            : so_fuse(m, &V2, &r->cam, k2->T, r->log_sf, r->inv_sigma2, &P, 3.0f, fuse_best[jn].data(), fuse_dist[jn].data(), &fuse_n[jn],
+                      nullptr);
+        if (frc != SO_OK) return SO_ERR_HIP;
         st[kLmFuseMs] += now_ms() - ta;
         if (!batch) {
             so_matcher_last_kernel_ms(m, &kms);
@@ -422,9 +434,12 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         Q.desc = D.data(); Q.valid = ok.data();
         fuse_best[nn].resize((size_t)Q.n); fuse_dist[nn].resize((size_t)Q.n);
         const double ta = now_ms();
-        if (so_fuse(m, &Vc, &r->cam, c->T, r->log_sf, r->inv_sigma2, &Q, 3.0f, fuse_best[nn].data(), fuse_dist[nn].data(), &fuse_n[nn],
-                    nullptr) != SO_OK)
-            return SO_ERR_HIP;
+        const int brc = c->dev
+            ? so_fuse_kframe(m, c->dev, &r->cam, c->T, r->log_sf, r->inv_sigma2, &Q, 3.0f, fuse_best[nn].data(), fuse_dist[nn].data(),
+                             &fuse_n[nn], nullptr)
+            : so_fuse(m, &Vc, &r->cam, c->T, r->log_sf, r->inv_sigma2, &Q, 3.0f, fuse_best[nn].data(), fuse_dist[nn].data(), &fuse_n[nn],
+                      nullptr);
+        if (brc != SO_OK) return SO_ERR_HIP;
         st[kLmFuseMs] += now_ms() - ta;
         if (!batch) {
             so_matcher_last_kernel_ms(m, &kms);
@@ -641,6 +656,7 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
         f.outlier.resize((size_t)r->cap);
     }
     if (const char* e = getenv("SWARMORB_LM_BATCH")) r->lm_batch = atoi(e) != 0;
+    if (const char* e = getenv("SWARMORB_LM_RESIDENT")) r->lm_resident = atoi(e) != 0;
     r->mapper = std::thread(mapper_loop, r);
     *out = r;
     return SO_OK;

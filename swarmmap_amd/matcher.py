@@ -462,3 +462,71 @@ ORBmatcher.FuseSim3 = _FuseSim3
 ORBmatcher.SearchBySim3 = _SearchBySim3
 ORBmatcher.SearchByProjectionSim3 = _SearchByProjectionSim3
 ORBmatcher.SearchByProjectionKeyFrame = _SearchByProjectionKeyFrame
+
+
+# ---- HBM-resident keyframes (so_kframe_*) ---------------------------------------------------------------------------
+class KFrame:
+    """A keyframe's matcher-side data uploaded once (so_kframe_create): FrameView + optional FeatureVector."""
+
+    def __init__(self, matcher, KF, fv=None, level_sigma2=None):
+        self._lib = matcher._lib
+        vp = C.c_void_p
+        self._lib.so_kframe_create.argtypes = [vp, C.POINTER(SoFrameView), C.POINTER(SoFeatVec), vp, C.POINTER(vp)]
+        self._lib.so_kframe_destroy.argtypes = [vp]
+        self._lib.so_kframe_destroy.restype = None
+        self._h = vp()
+        fs = KF.as_struct()
+        fvs = fv.as_struct() if fv is not None else None
+        ls = _f32(level_sigma2) if level_sigma2 is not None else None
+        _lib.check(self._lib.so_kframe_create(matcher._h, C.byref(fs), C.byref(fvs) if fvs is not None else None, _vp(ls),
+                                              C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.so_kframe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def _FuseKFrame(self, kframe, K, Tcw, log_scale_factor, inv_level_sigma2, mp, th=3.0):
+    """so_fuse_kframe: ORBmatcher::Fuse(pKF, vpMapPoints, th) against an HBM-resident keyframe."""
+    _bind_proj(self._lib)
+    vp, f = C.c_void_p, C.c_float
+    self._lib.so_fuse_kframe.argtypes = [vp, vp, C.POINTER(SoCameraM), vp, f, vp, C.POINTER(SoMapPointView), f, vp, vp,
+                                         C.POINTER(C.c_int32), C.POINTER(SoWindowQueries)]
+    ms, _keep = _mp_struct(mp)
+    qs, q = _wq_struct(ms.n)
+    bi, bd = np.full(ms.n, -1, np.int32), np.full(ms.n, 256, np.int32)
+    nf = C.c_int32(0)
+    cam, T, inv = _cam(K), _f32(Tcw).reshape(12), _f32(inv_level_sigma2)
+    _lib.check(self._lib.so_fuse_kframe(self._h, kframe._h, C.byref(cam), _vp(T), float(log_scale_factor), _vp(inv), C.byref(ms),
+                                        float(th), _vp(bi), _vp(bd), C.byref(nf), C.byref(qs)))
+    if getattr(self, "_batching", False):
+        self._batch_keep += [bi, bd, q, nf, kframe]
+        return nf, bi, bd, q
+    return nf.value, bi, bd, q
+
+
+def _SearchForTriangulationKFrame(self, kf1, fv1, kframe2, free2, F12, epipole):
+    """so_search_for_triangulation_kframe: keyframe 2 HBM-resident (created with its feature vector)."""
+    vp, f, i32 = C.c_void_p, C.c_float, C.c_int32
+    self._lib.so_search_for_triangulation_kframe.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.POINTER(SoFeatVec), vp, vp, vp, f, f,
+                                                             C.c_int, vp, C.POINTER(i32)]
+    x1, y1, a1, d1, f1 = _f32(kf1["x"]), _f32(kf1["y"]), _f32(kf1["angle"]), _u8(kf1["desc"]), _u8(kf1["free"])
+    f2 = _u8(free2)
+    F = _f32(F12).reshape(9)
+    out = np.full(len(x1), -1, np.int32)
+    nm = C.c_int32(0)
+    s1 = fv1.as_struct()
+    _lib.check(self._lib.so_search_for_triangulation_kframe(
+        self._h, len(x1), _vp(x1), _vp(y1), _vp(a1), _vp(d1), _vp(f1), C.byref(s1), kframe2._h, _vp(f2), _vp(F),
+        float(epipole[0]), float(epipole[1]), int(self.mbCheckOrientation), _vp(out), C.byref(nm)))
+    if getattr(self, "_batching", False):
+        self._batch_keep += [a1, out, nm, kframe2]
+        return nm, out
+    return nm.value, out
+
+
+ORBmatcher.FuseKFrame = _FuseKFrame
+ORBmatcher.SearchForTriangulationKFrame = _SearchForTriangulationKFrame

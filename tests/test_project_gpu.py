@@ -227,3 +227,55 @@ def test_batched_calls_equal_the_same_calls_one_by_one(S, oracle):
                                c["inv_level_sigma2"], c["mp"], 3.0)
     assert again[0] == on and np.array_equal(again[1], obi)
     m.close()
+
+
+def test_resident_keyframes_give_the_same_answers(S, oracle):
+    """so_kframe_create uploads a keyframe once (grid order + vocabulary-node order); so_fuse_kframe /
+    so_search_for_triangulation_kframe against it equal so_fuse / so_search_for_triangulation with the same keyframe as a
+    host view - alone and inside a batch, with a KeyFrame's int bounds, and with the free mask changing between calls."""
+    from swarmmap_amd.matcher import FeatureVector, KFrame
+    m = S.ORBmatcher(0.6, True)
+    sf = synth.SCALE_FACTORS
+    cases = [synth.make_projection_case(300 + i, 700 + 200 * i, 900 + 250 * i, keyframe_bounds=(i != 1)) for i in range(3)]
+    kframes, want = [], []
+    for c in cases:
+        KF = _view(c["frame"], False)
+        kframes.append(KFrame(m, KF))
+        want.append(m.Fuse(KF, c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], 3.0))
+    for c, k, w in zip(cases, kframes, want):
+        got = m.FuseKFrame(k, c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], 3.0)
+        assert got[0] == w[0] > 100 and np.array_equal(got[1], w[1]) and np.array_equal(got[2], w[2])
+        _same_queries(got[3], w[3])
+    tri = []
+    for i in range(3):
+        kf1, node1, kf2, node2, src = synth.make_bow_case(340 + i, 900, 800 + 100 * i, p_flip=0.06)
+        rng = np.random.default_rng(i)
+        kf1["y"] = (kf2["y"][src] + rng.normal(0, 0.8, len(src))).astype(np.float32)
+        kf1["x"] = (kf2["x"][src] + rng.uniform(-30, 30, len(src))).astype(np.float32)
+        F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 1e-6, (3, 3)).astype(np.float32)
+        fv1, fv2 = FeatureVector(node1), FeatureVector(node2)
+        bounds = (0.0, float(synth.EUROC[0]), 0.0, float(synth.EUROC[1]))
+        V2 = FrameView(kf2["x"], kf2["y"], kf2["octave"], kf2["angle"], kf2["desc"], bounds, sf)
+        k2 = KFrame(m, V2, fv2, sf * sf)
+        for trial in range(2):  # the free mask is per call
+            if trial == 1:
+                kf2 = dict(kf2, free=(rng.random(len(kf2["free"])) < 0.6).astype(np.uint8))
+            w = m.SearchForTriangulation(kf1, fv1, kf2, fv2, F12, (900.0, 240.0), sf, sf * sf)
+            g = m.SearchForTriangulationKFrame(kf1, fv1, k2, kf2["free"], F12, (900.0, 240.0))
+            assert g[0] == w[0] > 50 and np.array_equal(g[1], w[1])
+            ow = oracle.search_for_triangulation(kf1, fv1, kf2, fv2, F12, (900.0, 240.0), sf, sf * sf, True)
+            assert g[0] == ow[0] and np.array_equal(g[1], ow[1])
+        tri.append((kf1, fv1, kf2, k2, F12, w))
+    m.batch_begin()
+    held = [m.FuseKFrame(k, c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], 3.0) for c, k in zip(cases, kframes)]
+    held_t = [m.SearchForTriangulationKFrame(t[0], t[1], t[3], t[2]["free"], t[4], (900.0, 240.0)) for t in tri]
+    mixed = m.Fuse(_view(cases[0]["frame"], False), cases[0]["cam"], cases[0]["Tcw"], cases[0]["log_scale_factor"],
+                   cases[0]["inv_level_sigma2"], cases[0]["mp"], 3.0)   # staged and resident jobs side by side
+    m.batch_end()
+    for h, w in zip(held + [mixed], want + [want[0]]):
+        assert h[0].value == w[0] and np.array_equal(h[1], w[1]) and np.array_equal(h[2], w[2])
+    for h, t in zip(held_t, tri):
+        assert h[0].value == t[5][0] and np.array_equal(h[1], t[5][1])
+    for k in kframes + [t[3] for t in tri]:
+        k.close()
+    m.close()
