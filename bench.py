@@ -47,6 +47,10 @@ LBA_EVERY = int(os.environ.get("SWARMORB_BENCH_LBA_EVERY", "5"))
 # into them and back: code/src/LocalMapping.cc:197-246, 451-481) before its window; 0 switches it off
 LM_MATCHER = int(os.environ.get("SWARMORB_BENCH_LM_MATCHER", "1"))
 LM_NEIGHBOURS = 20  # nn = 20, LocalMapping.cc:207,455 (monocular)
+# Untimed frames tracked before the driver's own warm-up so that the timed region - however short (the driver runs
+# --steps 20 --warmup 5) - sees a local-mapping thread whose keyframe ring is full: 20 neighbours per new keyframe, not the
+# two or three a cold start has.  Makes the timed steps heavier, never lighter.
+LM_PREFILL_FRAMES = LM_NEIGHBOURS * LBA_EVERY if LM_MATCHER else 0
 LOCAL_KEYFRAMES = 12   # local map = points created at the last 12 keyframes (~3-5 k map points)
 PLANE_Z = 2.0
 
@@ -140,6 +144,7 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
     """A agents of one GPU in lockstep on this thread (so_fleet_run).  Same return values as run_stream."""
     from swarmmap_amd.replay import private_streams
     w, h = size
+    warmup = warmup + LM_PREFILL_FRAMES
     n_frames = warmup + steps + 2
     private_streams(True)
     fleet, keep = [], []
@@ -185,6 +190,7 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
     live_steps > 0: after the timed region that many more frames are tracked the way a live camera delivers them
     (so_replay_run_live: nothing extracted ahead) and their image-in -> pose-out latencies land in stats["live_*"]."""
     w, h = size
+    warmup = warmup + LM_PREFILL_FRAMES
     n_frames = warmup + steps + 2 + live_steps
     A = max(1, agents)
     gate = threading.Barrier(A + 1)
@@ -379,6 +385,7 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
         # SearchForTriangulation against each of the last <= 20 keyframes (M5), Fuse into each and back (M6)
         "local_mapping_matcher": (lambda L: None if not L or not L.get("jobs") else {
             "keyframes": L["jobs"], "neighbours": LM_NEIGHBOURS, "wall_ms_per_keyframe": L["wall_ms"] / L["jobs"],
+            "untimed_prefill_frames": LM_PREFILL_FRAMES,  # tracked before the warm-up: the keyframe ring is full when the clock starts
             # all searches of a keyframe go out as one so_matcher batch (one staging copy, one projection launch, one
             # search launch, one wait); SWARMORB_LM_BATCH=0 issues them one by one (then the per-call kernel times below)
             "batched": bool(L.get("batch_ms")),

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "dframe_internal.h"
@@ -116,6 +117,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct so_kframe {
     int device = 0, n = 0;
     uint8_t* d = nullptr;
+    size_t d_cap = 0;
     // grid layout
     size_t g_oct = 0, g_desc = 0, g_cols = 0, g_end = 0;
     int n_grid = 0;
@@ -2087,6 +2089,42 @@ int so_search_by_projection_keyframe(so_matcher* m, const so_frame_view* F, cons
 }
 
 // ---- HBM-resident keyframes -------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+// Device blocks of destroyed keyframes are kept for the next ones (a keyframe leaves the covisibility ring as another
+// enters it; hipMalloc / hipFree cost 50-100 us each and synchronise the device).
+struct KfBlock {
+    uint8_t* p;
+    size_t cap;
+    int device;
+};
+std::mutex g_kf_pool_mu;
+std::vector<KfBlock> g_kf_pool;
+constexpr size_t kKfPoolMax = 48;
+
+uint8_t* kf_block_take(int device, size_t bytes, size_t* cap_out) {
+    std::lock_guard<std::mutex> lk(g_kf_pool_mu);
+    for (size_t i = 0; i < g_kf_pool.size(); i++)
+        if (g_kf_pool[i].device == device && g_kf_pool[i].cap >= bytes && g_kf_pool[i].cap <= 2 * bytes + 65536) {
+            uint8_t* p = g_kf_pool[i].p;
+            *cap_out = g_kf_pool[i].cap;
+            g_kf_pool.erase(g_kf_pool.begin() + (long)i);
+            return p;
+        }
+    return nullptr;
+}
+
+bool kf_block_give(int device, uint8_t* p, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_kf_pool_mu);
+    if (g_kf_pool.size() >= kKfPoolMax) return false;
+    g_kf_pool.push_back(KfBlock{p, cap, device});
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
 int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* fv, const float* level_sigma2, so_kframe** out) {
     if (!m || !out || !frame_ok(KF) || !KF->scale_factors || KF->nlevels < 1 || KF->nlevels > 8 || m->batching) return SO_ERR_INVALID_ARG;
     if (fv && (!featvec_ok(fv, KF->n) || !level_sigma2)) return SO_ERR_INVALID_ARG;
@@ -2117,7 +2155,12 @@ int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* f
         const size_t nn = (size_t)(fv->n_nodes > 0 ? fv->off[fv->n_nodes] - fv->off[0] : 0);
         total += align256(align256(align256(sizeof(float2) * nn) + nn) + 32 * nn) + 256;
     }
-    hipError_t e = hipMalloc((void**)&k->d, total + 256);
+    hipError_t e = hipSuccess;
+    k->d = kf_block_take(m->device, total + 256, &k->d_cap);
+    if (!k->d) {
+        k->d_cap = total + 256 + (total >> 3);  // a little slack: the next keyframe has a few more keypoints inside the grid
+        e = hipMalloc((void**)&k->d, k->d_cap);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(k->d, m->h_in.p, k->g_end, hipMemcpyHostToDevice, m->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     if (e != hipSuccess) {
@@ -2138,7 +2181,7 @@ int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* f
         k->node_off.resize((size_t)fv->n_nodes + 1);
         for (int a = 0; a <= fv->n_nodes; a++) k->node_off[(size_t)a] = fv->off[a] - fv->off[0];
         const size_t node_bytes = align256(m->off_desc + 32 * (size_t)k->n_node);
-        if (k->g_end + node_bytes > total) e = hipErrorInvalidValue;
+        if (k->g_end + node_bytes > k->d_cap) e = hipErrorInvalidValue;
         if (e == hipSuccess && node_bytes > 0) e = hipMemcpyAsync(k->d + k->g_end, m->h_in.p, node_bytes, hipMemcpyHostToDevice, m->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     }
@@ -2155,8 +2198,10 @@ int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* f
 
 void so_kframe_destroy(so_kframe* k) {
     if (!k) return;
-    (void)hipSetDevice(k->device);
-    if (k->d) (void)hipFree(k->d);
+    if (k->d && !kf_block_give(k->device, k->d, k->d_cap)) {
+        (void)hipSetDevice(k->device);
+        (void)hipFree(k->d);
+    }
     delete k;
 }
 
