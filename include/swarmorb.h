@@ -725,7 +725,9 @@ int so_kfstore_last_stats(so_kfstore* s, double* stats6);
  * rank's, the peers' records are appended to the store on the device (no host hop), and each of this rank's new
  * keyframes is searched against the WHOLE store (everything every peer has sent so far, this tick included) with
  * so_kfstore_search's two phases.  out / pairs / n_out: n_records blocks of max_candidates entries / max_candidates x
- * slot_keypoints entries / one count, in record order (pairs may be NULL).  n_records may be 0 (the rank only receives). */
+ * slot_keypoints entries / one count, in record order (pairs may be NULL).  Inside a record's pairs block the rows are
+ * packed by the QUERY's keypoint count, as so_kfstore_search packs them: candidate c's row starts at c x n_keypoints(query
+ * record) - not at c x slot_keypoints - and the rest of the block is unused.  n_records may be 0 (the rank only receives). */
 int so_exchange_create_store(int device, int rank, int world, const uint8_t* id128, int slot_keypoints,
                              int records_per_tick, int store_keyframes, so_exchange** out);
 /* The same exchange over the HOST's transport instead of RCCL - agents that do not share a node (the reference's agents

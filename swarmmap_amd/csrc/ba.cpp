@@ -992,6 +992,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     d.dense_ws = b->d_dense_ws.as<double>();
     d.dense_x = b->d_dense_x.as<double>();
     d.use_pairs = pairs_path ? 1 : 0;
+    d.fold_prep = (!pairs_path && !dense_path) ? 1 : 0;  // measured: beyond 43 free keyframes the stored products win (r4_lba_sweep.txt)
     d.pr_off = b->d_pr_off.as<int>();
     d.pr_cur = b->d_pr_cur.as<int>();
     d.pr_l = b->d_pr.as<int>();

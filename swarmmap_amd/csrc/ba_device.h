@@ -80,6 +80,7 @@ struct BaDev {
     // large maps (blocked-solver path): per upper block (i1 < i2) the (edge, edge) pairs of the landmarks both
     // keyframes see, built on the device; blocks with at most kBaSmallBlockPairs pairs are summed by one thread each
     int use_pairs;
+    int fold_prep;  // local windows (no pair lists, single-workgroup solver): no ba_schur_prep launch, its products are formed by their consumers
     int* pr_off;              // n_blk + 1: exclusive scan of the pair counts (block g = i2 (i2 + 1) / 2 + i1)
     int* pr_cur;              // n_blk: counts, then fill cursors
     int* pr_l; int* pr_k1; int* pr_k2;  // landmark, edge of i1, edge of i2 (arrival order)

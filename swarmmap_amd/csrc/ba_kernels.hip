@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (k2[u] >= 0) add_pair(k1[u], k2[u], d.use_pairs ? -1 : lmk[u]);
+                    if (k2[u] >= 0) add_pair(k1[u], k2[u], d.fold_prep ? lmk[u] : -1);
             }
         }
         // wave totals by transposition (the pose kernel's scheme): values 0..31 end up in lane pairs, 32..35 by butterfly
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
         if (!d.e_active[e]) continue;
         const double* W = d.W + 18 * (size_t)e;
         double db[3];
-        if (d.use_pairs) {
+        if (!d.fold_prep) {
             const double* dbp = d.db + 3 * (size_t)d.e_point[e];
             db[0] = dbp[0]; db[1] = dbp[1]; db[2] = dbp[2];
         } else {  // db = Dinv bl as ba_schur_prep_kernel forms it
@@ -1285,11 +1285,11 @@ __global__ __launch_bounds__(256) void ba_schur_gather_small_kernel(BaDev d, int
 static void launch_ba_schur(const BaDev& d, hipStream_t s) {
     const int nthreads = d.n_points > d.n_edges ? d.n_points : d.n_edges;
     const int n_blk = d.n_free * (d.n_free + 1) / 2;
-    // Local windows (no pair lists) have no prep launch: the gather and the update form (Hll + lambda I)^-1, W Dinv and
+    // Local windows (no pair lists, at most 43 free keyframes: d.fold_prep) have no prep launch: the gather and the update form (Hll + lambda I)^-1, W Dinv and
     // Dinv bl themselves where they need them - the same expressions, hence the same bits, one launch (9.5 us of an 87 us
-    // trial on LBA-M) less.  Pair-list maps read each product up to hundreds of times: they keep the stored copies.
+    // trial on LBA-M) less.  Larger windows and pair-list maps read each product many times over: they keep the stored copies.
+    if (!d.fold_prep && nthreads > 0) hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d);
     if (d.use_pairs) {
-        if (nthreads > 0) hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d);
         if (n_blk > 0) hipLaunchKernelGGL(ba_schur_gather_small_kernel, dim3((n_blk + 255) / 256), dim3(256), 0, s, d, n_blk);
         const int waves = d.big_cap + d.n_free;  // the walked blocks, then the right-hand sides
         hipLaunchKernelGGL(ba_schur_gather_kernel<1>, dim3((waves + 3) / 4), dim3(256), 0, s, d, d.big_cap);
@@ -1363,8 +1363,8 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d) {
                     const double* bl = d.bl + 3 * (size_t)il;
                     cl[0] += bl[0]; cl[1] += bl[1]; cl[2] += bl[2];
                     double Dloc[9];
-                    if (!d.use_pairs) damped_inverse3(d.Hll + 9 * (size_t)il, lambda, Dloc);  // (no prep launch: same bits)
-                    const double* Di = d.use_pairs ? d.Dinv + 9 * (size_t)il : Dloc;
+                    if (d.fold_prep) damped_inverse3(d.Hll + 9 * (size_t)il, lambda, Dloc);  // (no prep launch: same bits)
+                    const double* Di = d.fold_prep ? Dloc : d.Dinv + 9 * (size_t)il;
 #pragma unroll
                     for (int r = 0; r < 3; r++) {
                         const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];

@@ -337,20 +337,22 @@ int collect_impl(so_extractor* ex, so_keypoint* kps, uint8_t* desc, int capacity
 
 int run_impl(so_extractor* ex, const uint8_t* image, bool on_device, int w, int h, int stride, so_keypoint* kps,
              uint8_t* desc, int capacity, int* n_out, bool submit_only = false) {
-    if (!ex || (!submit_only && !n_out)) return SO_ERR_INVALID_ARG;
-    if (ex->pending) {
-        last_error_ref() = "a submitted frame has not been collected";
-        return SO_ERR_INVALID_ARG;
-    }
-    ex->tail_launched = false;
+    if (!ex) return SO_ERR_INVALID_ARG;
     // the tail applies to ONE submit (a direct so_extractor_submit behind a device-resident frame must not run that
-    // frame's prepare launch over the data it holds)
+    // frame's prepare launch over the data it holds): it is consumed before ANY early return - a submit refused
+    // because the extractor is still busy must not leave the frame's launch armed for whoever submits next
     void* const tail_owner = ex->tail_owner;
     const uint64_t tail_revision = ex->tail_revision;
     const ExtractorTailFn tail_fn = ex->tail_fn;
     ex->tail_owner = nullptr;
     ex->tail_revision = 0;
     ex->tail_fn = nullptr;
+    if (!submit_only && !n_out) return SO_ERR_INVALID_ARG;
+    if (ex->pending) {
+        last_error_ref() = "a submitted frame has not been collected";
+        return SO_ERR_INVALID_ARG;
+    }
+    ex->tail_launched = false;
     if (n_out) *n_out = 0;
     if (!image || w <= 0 || h <= 0) {  // ORBextractor.cc:750-751
         if (submit_only) {

@@ -36,8 +36,11 @@ constexpr int kTopK = 8;
 
 bool header_ok(const so_keyframe_header& h, int kp) {
     if (h.magic != kMagic || h.header_bytes != sizeof(so_keyframe_header)) return false;
-    if (h.version == 1) return h.n_keypoints >= 0 && h.n_keypoints <= kp;
-    return h.version == 2 && (h.flags & SO_KF_FLAG_MAP_POINTS) && h.n_keypoints >= 0 && h.n_keypoints <= kp;
+    // the device takes "has map-point ids" from flags & 1, the host from the version: a peer's record in which the two
+    // disagree is refused instead of being interpreted two ways
+    if (h.version == 1) return h.flags == 0 && h.n_keypoints >= 0 && h.n_keypoints <= kp;
+    return h.version == 2 && (h.flags & SO_KF_FLAG_MAP_POINTS) && h.n_keypoints >= 0 && h.n_keypoints <= kp &&
+           h.n_map_points >= 0 && h.n_map_points <= h.n_keypoints;
 }
 
 size_t record_bytes(const so_keyframe_header& h) {
