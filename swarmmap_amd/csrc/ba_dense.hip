@@ -935,7 +935,10 @@ __device__ __forceinline__ FlowWatch flow_watch(const BaDev& d, unsigned* abort_
     W.abort_host = d.flow_abort_host;
     W.deadline = wall_clock64() + d.flow_timeout_ticks;
     W.epoch = epoch;
-    W.dead = false;
+    // A solve of this call that already gave up (the host zeroes the word per call and only looks at it after the whole
+    // chain of enqueued trials): the trials behind it would each wait their full budget again before the host can fall
+    // back - they start dead instead and run through at once.
+    W.dead = W.abort_host != nullptr && __hip_atomic_load(W.abort_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
     return W;
 }
 // true when the solve has been given up (by this workgroup just now, or by another one): stop waiting
