@@ -56,18 +56,34 @@ __device__ __forceinline__ void quat_from_R(const double* R, double* q) {
         q[1] = (R[2] - R[6]) * t;
         q[2] = (R[3] - R[1]) * t;
     } else {
+        // Eigen's i / j = (i + 1) % 3 / k = (j + 1) % 3 walk, written out per case: with run-time indices R and q live in
+        // scratch memory (19 scratch_* instructions in every register-resident PoseOptimization kernel, the stores ahead
+        // of the branch whether it is taken or not); the arithmetic per case is the same, operand for operand
         int i = 0;
         if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 3 + i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
-        double qq[3];
-        qq[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        qq[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        qq[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
-        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2];
+        if (R[8] > (i == 1 ? R[4] : R[0])) i = 2;
+        if (i == 0) {         // j = 1, k = 2
+            t = sqrt(R[0] - R[4] - R[8] + 1.0);
+            q[0] = 0.5 * t;
+            t = 0.5 / t;
+            q[3] = (R[7] - R[5]) * t;
+            q[1] = (R[3] + R[1]) * t;
+            q[2] = (R[6] + R[2]) * t;
+        } else if (i == 1) {  // j = 2, k = 0
+            t = sqrt(R[4] - R[8] - R[0] + 1.0);
+            q[1] = 0.5 * t;
+            t = 0.5 / t;
+            q[3] = (R[2] - R[6]) * t;
+            q[2] = (R[7] + R[5]) * t;
+            q[0] = (R[1] + R[3]) * t;
+        } else {              // j = 0, k = 1
+            t = sqrt(R[8] - R[0] - R[4] + 1.0);
+            q[2] = 0.5 * t;
+            t = 0.5 / t;
+            q[3] = (R[3] - R[1]) * t;
+            q[0] = (R[2] + R[6]) * t;
+            q[1] = (R[5] + R[7]) * t;
+        }
     }
 }
 

@@ -388,6 +388,39 @@ def test_pose_optimization_matches_oracle(opt, oracle, seed, n):
         assert (outl.astype(bool) & c["gt_outlier"]).sum() >= 0.9 * c["gt_outlier"].sum()
 
 
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_poses_beyond_120_degrees_take_the_other_quaternion_branch(opt, oracle, axis):
+    """Quaterniond(R) (Eigen, used by SE3Quat) has a second branch for trace(R) <= 0 that walks i / j / k by the largest
+    diagonal element; the tracked streams never turn that far.  The same problems expressed in a world frame turned by
+    170 degrees about x, y or z put every pose into one of its three cases: PoseOptimization and a local window against
+    the oracle, and against the unrotated solve (the optimum does not depend on the frame)."""
+    G = synth._rodrigues(np.eye(3)[axis] * np.deg2rad(170.0))
+
+    def turn(Tcw, Xw):  # Tcw' = Tcw [G^T | 0], Xw' = G Xw: the same cameras and points in the turned frame
+        T = np.asarray(Tcw, np.float64).reshape(-1, 3, 4)
+        T2 = np.concatenate([T[:, :, :3] @ G.T, T[:, :, 3:]], 2)
+        return T2.astype(np.float32).reshape(np.asarray(Tcw).shape), (np.asarray(Xw, np.float64) @ G.T).astype(np.float32)
+
+    c = synth.make_pose_case(40 + axis, 500)
+    T0, X0 = turn(c["Tcw"], c["Xw"])
+    assert np.trace(T0.reshape(3, 4)[:, :3]) < 0
+    ni, T, outl, _ = opt.PoseOptimization(T0, c["intr"], X0, c["obs"], c["inv_sigma2"])
+    oni, oT, ooutl, _ = oracle.pose_optimization(T0, c["intr"], X0, c["obs"], c["inv_sigma2"])
+    assert ni == oni and np.array_equal(outl, ooutl) and np.abs(T - oT).max() <= 2e-5
+    ni1, T1, _, _ = opt.PoseOptimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
+    back, _ = turn(T, np.zeros((1, 3)))  # undo: multiply the rotation part by G again (G^T^T)
+    Tb = np.concatenate([T.reshape(3, 4)[:, :3].astype(np.float64) @ G, T.reshape(3, 4)[:, 3:].astype(np.float64)], 1)
+    assert ni1 == ni and np.abs(Tb.reshape(12) - T1).max() <= 1e-4
+    del back
+    w = synth.make_ba_problem(50 + axis, 6, 6, 500, max_obs="auto")
+    w = dict(w)
+    w["Tcw"], w["Xw"] = turn(w["Tcw"], w["Xw"])
+    r = opt.LocalBundleAdjustment(w)
+    o = oracle.bundle_adjust(w)
+    assert np.abs(r["Tcw"] - o["Tcw"]).max() <= POSE_TOL and np.abs(r["Xw"] - o["Xw"]).max() <= POINT_TOL
+    assert np.array_equal(r["outlier"], o["outlier"]) or (r["outlier"] != o["outlier"]).sum() <= 2
+
+
 def test_pose_optimization_in_two_halves(opt):
     """so_pose_optimization_submit / _wait return what the one-shot call returns, for the zero-copy kernels (completion
     word) and for the copy path beyond 3072 points; a second submit, a batch or a wait without a submit are refused."""
