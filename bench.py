@@ -251,6 +251,11 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
                             acc_x["xchg_pairs"] = acc_x.get("xchg_pairs", 0.0) + st_x["pairs"]
                             acc_x["xchg_store_keyframes"] = xchg.store.size()[0]
 
+            if xchg is not None and a == 0:
+                # ranks finish rendering their streams at different times: meet before the first (collective) exchange tick,
+                # and give the ticks a budget that start-up skew cannot exhaust (a dead peer is still noticed: SO_ERR_TIMEOUT)
+                barrier()
+                xchg.set_timeout(int(os.environ.get("SWARMORB_COLLECTIVE_TIMEOUT_MS", "30000")))
             rp.prime(0)
             run_span(0, warmup, False)
             rp.drain()
