@@ -162,6 +162,8 @@ struct so_replay {
     bool lm_batch = true;                  // all searches of a keyframe as one so_matcher batch (SWARMORB_LM_BATCH=0: one by one)
     std::deque<std::shared_ptr<KfSnap>> lm_ring;  // (local-mapping thread only)
     std::vector<int32_t> lm_stamp, lm_cstamp;     // slot -> id of the keyframe / job that marked it
+    std::vector<float> lm_cX, lm_cN, lm_cmax, lm_cmin;  // vpFuseCandidates of the keyframe being processed
+    std::vector<uint8_t> lm_cD, lm_cok;
     int lm_stamp_id = 0;
     double lm_stat[16] = {0};
     std::vector<int32_t> lm_log;           // 5 ints per job: t, neighbours, triangulation matches, fused, fused back
@@ -409,28 +411,33 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         jn++;
     }
     // ... then the neighbours' map points into the new keyframe: vpFuseCandidates, once each (:459-481)
-    std::vector<float> X, N, mx, mn;
-    std::vector<uint8_t> D, ok;
+    std::vector<float>&X = r->lm_cX, &N = r->lm_cN, &mx = r->lm_cmax, &mn = r->lm_cmin;  // (capacity kept from keyframe to keyframe)
+    std::vector<uint8_t>&D = r->lm_cD, &ok = r->lm_cok;
     if (!r->lm_ring.empty()) {
         const int job = ++r->lm_stamp_id;
         const int cid = ++r->lm_stamp_id;
         for (int i = 0; i < n; i++)
             if (c->mp[(size_t)i] >= 0) r->lm_stamp[(size_t)c->mp[(size_t)i]] = cid;
+        size_t cap = 0;
+        for (const auto& k2 : r->lm_ring) cap += (size_t)k2->n;
+        X.resize(3 * cap); N.resize(3 * cap); mx.resize(cap); mn.resize(cap); D.resize(32 * cap); ok.resize(cap);
+        size_t q = 0;
         for (const auto& k2 : r->lm_ring)
             for (int i = 0; i < k2->n; i++) {
                 const int slot = k2->mp[(size_t)i];
                 if (slot < 0 || r->lm_cstamp[(size_t)slot] == job) continue;  // mnFuseCandidateForKF
                 r->lm_cstamp[(size_t)slot] = job;
-                X.insert(X.end(), &k2->mpX[3 * (size_t)i], &k2->mpX[3 * (size_t)i] + 3);
-                N.insert(N.end(), &k2->mpN[3 * (size_t)i], &k2->mpN[3 * (size_t)i] + 3);
-                mx.push_back(k2->mpMax[(size_t)i]);
-                mn.push_back(k2->mpMin[(size_t)i]);
-                D.insert(D.end(), &k2->mpDesc[32 * (size_t)i], &k2->mpDesc[32 * (size_t)i] + 32);
-                ok.push_back(r->lm_stamp[(size_t)slot] != cid ? 1 : 0);  // !IsInKeyFrame(mpCurrentKeyFrame)
+                memcpy(&X[3 * q], &k2->mpX[3 * (size_t)i], 12);
+                memcpy(&N[3 * q], &k2->mpN[3 * (size_t)i], 12);
+                mx[q] = k2->mpMax[(size_t)i];
+                mn[q] = k2->mpMin[(size_t)i];
+                memcpy(&D[32 * q], &k2->mpDesc[32 * (size_t)i], 32);
+                ok[q] = r->lm_stamp[(size_t)slot] != cid ? 1 : 0;  // !IsInKeyFrame(mpCurrentKeyFrame)
+                q++;
             }
         so_mappoint_view Q;
         memset(&Q, 0, sizeof(Q));
-        Q.n = (int32_t)mx.size(); Q.Xw = X.data(); Q.normal = N.data(); Q.max_dist = mx.data(); Q.min_dist = mn.data();
+        Q.n = (int32_t)q; Q.Xw = X.data(); Q.normal = N.data(); Q.max_dist = mx.data(); Q.min_dist = mn.data();
         Q.desc = D.data(); Q.valid = ok.data();
         fuse_best[nn].resize((size_t)Q.n); fuse_dist[nn].resize((size_t)Q.n);
         const double ta = now_ms();
