@@ -254,7 +254,8 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
             if xchg is not None and a == 0:
                 # ranks finish rendering their streams at different times: meet before the first (collective) exchange tick,
                 # and give the ticks a budget that start-up skew cannot exhaust (a dead peer is still noticed: SO_ERR_TIMEOUT)
-                barrier()
+                if A == 1:  # (with several agents per GPU this is not the main thread: no process-group call from here)
+                    barrier()
                 xchg.set_timeout(int(os.environ.get("SWARMORB_COLLECTIVE_TIMEOUT_MS", "30000")))
             rp.prime(0)
             run_span(0, warmup, False)
