@@ -143,7 +143,15 @@ struct BatchJobDev {
     int32_t* count;          // nq, host-mapped
     int nq, K, project, pad;
 };
-void launch_batch(const BatchJobDev* d_jobs, int n_jobs, int max_project_n, int max_nq, hipStream_t s);
+// Grid layout of a batch: the jobs' workgroups back to back (a job with 4000 queries next to one with 700 must not make
+// every job launch 1000 workgroups): first_proj / first_topk[j] = first workgroup of job j, [n_jobs] = the grid size.
+constexpr int kBatchMaxJobsDev = 64;
+struct BatchGridDev {
+    int n_jobs, pad[3];
+    int first_proj[kBatchMaxJobsDev + 1];
+    int first_topk[kBatchMaxJobsDev + 1];
+};
+void launch_batch(const BatchGridDev* d_grid, const BatchJobDev* d_jobs, int n_jobs, int proj_blocks, int topk_blocks, hipStream_t s);
 
 void launch_stage_in(void* dst, const void* src_mapped, size_t bytes, hipStream_t s);
 // mode 2 = last-frame search, 3 = local-map search; queries [q_first, q_first + nq) write keys / counts at [0, nq)

@@ -228,8 +228,19 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F_arg, c
                                                            int q_first) {
     __shared__ uint32_t s_keys[4][kListCap];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);  // wave-uniform: per-query data through scalar loads
-    const BatchJobDev* job = MODE == 4 ? static_cast<const BatchJobDev*>(q) + blockIdx.y : nullptr;
+    int blk = blockIdx.x;
+    const BatchJobDev* job = nullptr;
+    if (MODE == 4) {  // qdesc carries the batch's grid table here: which job does this workgroup belong to?
+        const BatchGridDev* G = reinterpret_cast<const BatchGridDev*>(qdesc);
+        int lo = 0, hi = G->n_jobs - 1;
+        while (lo < hi) {  // largest j with first_topk[j] <= blk (uniform: scalar loads from one cached block)
+            const int mid = (lo + hi + 1) >> 1;
+            if (G->first_topk[mid] <= blk) lo = mid; else hi = mid - 1;
+        }
+        job = static_cast<const BatchJobDev*>(q) + lo;
+        blk -= G->first_topk[lo];
+    }
+    const int qi = __builtin_amdgcn_readfirstlane(blk * 4 + w);  // wave-uniform: per-query data through scalar loads
     const MatchFrameDev& F = MODE == 4 ? job->F : F_arg;
     if (MODE == 4) {
         nq = job->nq; K = job->K; qdesc = job->qdesc; out_keys = job->keys; out_count = job->count;
@@ -416,9 +427,15 @@ __global__ __launch_bounds__(256) void project_queries_kernel(ProjectSrc S, Matc
     project_one(S, i, q_out, qw_out);
 }
 
-__global__ __launch_bounds__(256) void project_queries_batch_kernel(const BatchJobDev* __restrict__ jobs) {
-    const BatchJobDev& J = jobs[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void project_queries_batch_kernel(const BatchGridDev* __restrict__ G,
+                                                                    const BatchJobDev* __restrict__ jobs) {
+    int blk = blockIdx.x, lo = 0, hi = G->n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (G->first_proj[mid] <= blk) lo = mid; else hi = mid - 1;
+    }
+    const BatchJobDev& J = jobs[lo];
+    const int i = (blk - G->first_proj[lo]) * 256 + threadIdx.x;
     if (!J.project || i >= J.S.n) return;
     project_one(J.S, i, J.q, J.qw);
 }
@@ -455,15 +472,14 @@ void launch_topk_window(const MatchFrameDev& F, const void* d_q, bool compact, c
                            d_count, none, 0);
 }
 
-void launch_batch(const BatchJobDev* d_jobs, int n_jobs, int max_project_n, int max_nq, hipStream_t s) {
+void launch_batch(const BatchGridDev* d_grid, const BatchJobDev* d_jobs, int n_jobs, int proj_blocks, int topk_blocks, hipStream_t s) {
     if (n_jobs <= 0) return;
-    if (max_project_n > 0)
-        hipLaunchKernelGGL(project_queries_batch_kernel, dim3((max_project_n + 255) / 256, n_jobs), dim3(256), 0, s, d_jobs);
-    if (max_nq > 0) {
+    if (proj_blocks > 0) hipLaunchKernelGGL(project_queries_batch_kernel, dim3(proj_blocks), dim3(256), 0, s, d_grid, d_jobs);
+    if (topk_blocks > 0) {
         const TrackQuerySrc none{};
         const MatchFrameDev unused{};
-        hipLaunchKernelGGL(topk_window_kernel<4>, dim3((max_nq + 3) / 4, n_jobs), dim3(256), 0, s, unused, (const void*)d_jobs,
-                           (const uint4*)nullptr, 0, 0, (uint32_t*)nullptr, (int32_t*)nullptr, none, 0);
+        hipLaunchKernelGGL(topk_window_kernel<4>, dim3(topk_blocks), dim3(256), 0, s, unused, (const void*)d_jobs,
+                           reinterpret_cast<const uint4*>(d_grid), 0, 0, (uint32_t*)nullptr, (int32_t*)nullptr, none, 0);
     }
 }
 

@@ -486,8 +486,9 @@ int ensure_queries(so_matcher* m, int nq, size_t record = sizeof(MatchQuery)) {
     return SO_OK;
 }
 
-constexpr size_t kBatchMaxJobs = 64;
-constexpr size_t kBatchTableBytes = ((sizeof(BatchJobDev) * kBatchMaxJobs + 255) / 256) * 256;
+constexpr size_t kBatchMaxJobs = kBatchMaxJobsDev;
+constexpr size_t kBatchGridBytes = ((sizeof(BatchGridDev) + 255) / 256) * 256;  // the grid table sits in front of the job table
+constexpr size_t kBatchTableBytes = kBatchGridBytes + ((sizeof(BatchJobDev) * kBatchMaxJobs + 255) / 256) * 256;
 
 int batch_flush(so_matcher* m);
 
@@ -547,9 +548,12 @@ int batch_flush(so_matcher* m) {
     if ((rc = m->db_in.ensure(total))) return rc;
     if ((rc = m->db_q.ensure(m->dq_used + 256))) return rc;
     if ((rc = m->hb_out.ensure(m->out_used + 256))) return rc;
-    BatchJobDev* tab = (BatchJobDev*)m->hb_in.p;
+    BatchGridDev* grid = (BatchGridDev*)m->hb_in.p;
+    BatchJobDev* tab = (BatchJobDev*)((uint8_t*)m->hb_in.p + kBatchGridBytes);
     uint8_t* dbase = (uint8_t*)m->db_in.p + kBatchTableBytes;
-    int max_n = 0, max_nq = 0;
+    int proj_blocks = 0, topk_blocks = 0;
+    memset(grid, 0, sizeof(*grid));
+    grid->n_jobs = nj;
     for (int j = 0; j < nj; j++) {
         const so_matcher::BatchJob& J = m->jobs[(size_t)j];
         BatchJobDev D;
@@ -596,18 +600,24 @@ int batch_flush(so_matcher* m) {
             D.S.n = J.nq;
             D.q = (MatchQuery*)((uint8_t*)m->db_q.p + J.q_off);
             D.qw = (MatchQueryW*)((uint8_t*)m->hb_out.dev + J.qw_off);
-            max_n = std::max(max_n, J.nq);
         } else {
             D.q = (MatchQuery*)(dbase + J.base + J.off_q);
         }
-        max_nq = std::max(max_nq, J.nq);
+        grid->first_proj[j] = proj_blocks;
+        grid->first_topk[j] = topk_blocks;
+        if (J.project) proj_blocks += (J.nq + 255) / 256;
+        topk_blocks += (J.nq + 3) / 4;
         tab[j] = D;
+    }
+    for (int j = nj; j <= (int)kBatchMaxJobs; j++) {
+        grid->first_proj[j] = proj_blocks;
+        grid->first_topk[j] = topk_blocks;
     }
     hipStream_t s = m->stream;
     const auto t0 = std::chrono::steady_clock::now();
     launch_stage_in(m->db_in.p, m->hb_in.p, total, s);
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
-    launch_batch((const BatchJobDev*)m->db_in.p, nj, max_n, max_nq, s);
+    launch_batch((const BatchGridDev*)m->db_in.p, (const BatchJobDev*)((const uint8_t*)m->db_in.p + kBatchGridBytes), nj, proj_blocks, topk_blocks, s);
     if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
     SO_HIP(hipGetLastError());
     const auto t1 = std::chrono::steady_clock::now();
