@@ -391,6 +391,36 @@ int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x
                                        const uint8_t* free2, const float* F12, float ex, float ey, int check_orientation,
                                        int32_t* matches12, int32_t* nmatches);
 
+/* ---- the local-mapping thread's two per-point loops between the matcher and local BA (widening beyond SURVEY 8f) ----
+ * What LocalMapping::CreateNewMapPoints reads of a keyframe. */
+typedef struct so_tri_keyframe {
+    float Tcw[12];               /* [GetRotation() | GetTranslation()] row-major */
+    float fx, fy, cx, cy, invfx, invfy;
+    const float* scale_factors;  /* mvScaleFactors */
+    const float* level_sigma2;   /* mvLevelSigma2 */
+    int32_t nlevels;             /* <= 8 */
+} so_tri_keyframe;
+/* The per-match body of LocalMapping::CreateNewMapPoints (code/src/LocalMapping.cc:263-420, monocular), for the matches
+ * of mpCurrentKeyFrame (kf1) with n_kf2 neighbours in ONE launch (thread per match): parallax of the rays (0 < cos <
+ * 0.9998), linear triangulation by cv::SVD::compute of the 4 x 4 system (OpenCV's one-sided Jacobi, restated in
+ * oracle/mapping_oracle.h), positive depth in both cameras, reprojection error <= 5.991 sigma2 in both, scale
+ * consistency with ratio_factor = 1.5f * mfScaleFactor.  Match k pairs keypoint (xy1, octave1)[k] of kf1 with (xy2,
+ * octave2)[k] of kf2[kf2_of_match[k]] (mvKeysUn).  ok[k] = 1 where the reference creates a MapPoint, x3D[3k..] its
+ * position (untouched otherwise).  The baseline / median-depth test per neighbour (:228-241), `new MapPoint`,
+ * AddObservation / AddMapPoint and the bookkeeping stay with the caller. */
+int so_triangulate_matches(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_kf2, const so_tri_keyframe* kf2, float ratio_factor,
+                           int32_t n, const int32_t* kf2_of_match, const float* xy1, const int32_t* octave1, const float* xy2,
+                           const int32_t* octave2, uint8_t* ok, float* x3D);
+/* MapPoint::UpdateNormalAndDepth (code/src/MapPoint.cc:413-465) for a batch of map points (thread per point): point p is
+ * observed from the camera centres obs_Ow[offsets[p] .. offsets[p + 1]) (3 floats each, in the order the caller walks
+ * mObservations - the reference's own order is the pointer order of a std::map and differs from run to run); ref_Ow =
+ * pRefKF->GetCameraCenter(), ref_level_scale = pRefKF->mvScaleFactors[octave of the point's keypoint in pRefKF],
+ * ref_last_scale = pRefKF->mvScaleFactors[mnScaleLevels - 1].  normal / max_dist / min_dist (mNormalVector,
+ * mfMaxDistance, mfMinDistance) are in / out: a point without observations keeps its values. */
+int so_update_normal_and_depth(so_matcher* m, int32_t n_points, const int32_t* offsets, const float* obs_Ow, const float* Xw,
+                               const float* ref_Ow, const float* ref_level_scale, const float* ref_last_scale, float* normal,
+                               float* max_dist, float* min_dist);
+
 /* MapPoint::ComputeDistinctiveDescriptors (code/src/MapPoint.cc:323-392) for a batch of map points (SURVEY 8f rank
  * 4): point p owns descriptors [offsets[p], offsets[p+1]) (the rows the reference collects from its observing
  * keyframes, in map order); best_idx[p] = index within the point's own list of the descriptor with the least

@@ -621,3 +621,49 @@ def search_by_projection_frame_kf(F, cam, Tcw, log_sf, mp, mp_angle, th, orb_dis
     n = lib().orc_search_by_projection_frame_kf(C.byref(fs), C.byref(cam), _p(T), C.c_float(log_sf), C.byref(ms), _p(ang),
                                                 C.c_float(th), int(orb_dist), int(check_ori), _p(out))
     return n, out
+
+
+# ---- the local-mapping thread's per-point loops (mapping_oracle.h) ------------------------------------------------
+class OrcTriKeyframe(C.Structure):
+    _fields_ = [("Tcw", C.c_float * 12)] + [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "invfx", "invfy")] + \
+               [("scale_factors", C.c_void_p), ("level_sigma2", C.c_void_p)]
+
+
+def _tri_kf(kf, keep):
+    sf, ls = np.ascontiguousarray(kf["scale_factors"], np.float32), np.ascontiguousarray(kf["level_sigma2"], np.float32)
+    keep += [sf, ls]
+    fx, fy, cx, cy = [np.float32(v) for v in kf["K"]]
+    s = OrcTriKeyframe()
+    s.Tcw[:] = [float(v) for v in np.asarray(kf["Tcw"], np.float32).reshape(12)]
+    s.fx, s.fy, s.cx, s.cy = float(fx), float(fy), float(cx), float(cy)
+    s.invfx, s.invfy = float(np.float32(1.0) / fx), float(np.float32(1.0) / fy)  # invfx = 1.0f / fx, Frame.cc:266
+    s.scale_factors, s.level_sigma2 = _p(sf), _p(ls)
+    return s
+
+
+def svd4_last_row(A):
+    A = np.ascontiguousarray(A, np.float32).reshape(16)
+    v = np.zeros(4, np.float32)
+    lib().orc_svd4_last_row(_p(A), _p(v))
+    return v
+
+
+def triangulate_matches(kf1, kf2, ratio_factor, xy1, octave1, xy2, octave2):
+    """CreateNewMapPoints' per-match body for the matches of kf1 with ONE neighbour kf2.  Returns (ok, x3D)."""
+    keep = []
+    a, b = _tri_kf(kf1, keep), _tri_kf(kf2, keep)
+    x1, o1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2), np.ascontiguousarray(octave1, np.int32)
+    x2, o2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2), np.ascontiguousarray(octave2, np.int32)
+    n = len(o1)
+    ok, X = np.zeros(n, np.uint8), np.zeros((n, 3), np.float32)
+    lib().orc_triangulate_matches(C.byref(a), C.byref(b), C.c_float(ratio_factor), n, _p(x1), _p(o1), _p(x2), _p(o2), _p(ok), _p(X))
+    return ok, X
+
+
+def update_normal_and_depth(offsets, obs_Ow, Xw, ref_Ow, ref_level_scale, ref_last_scale, normal, max_dist, min_dist):
+    off = np.ascontiguousarray(offsets, np.int32)
+    n = len(off) - 1
+    a = [np.ascontiguousarray(v, np.float32) for v in (obs_Ow, Xw, ref_Ow, ref_level_scale, ref_last_scale)]
+    nrm, mx, mn = [np.array(v, np.float32, copy=True) for v in (normal, max_dist, min_dist)]
+    lib().orc_update_normal_and_depth(n, _p(off), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(nrm), _p(mx), _p(mn))
+    return nrm, mx, mn

@@ -160,6 +160,42 @@ void launch_topk_track(const MatchFrameDev& F, const TrackQuerySrc& T, int mode,
 // compact: d_q points to MatchQueryW records instead of MatchQuery
 void launch_topk_window(const MatchFrameDev& F, const void* d_q, bool compact, const uint4* d_qdesc, int nq, int K,
                         uint32_t* d_keys, int32_t* d_count, hipStream_t s);
+// ---- the local-mapping thread's two per-point loops between the matcher and local BA ----
+// CreateNewMapPoints' per-match body (code/src/LocalMapping.cc:263-420, monocular): thread per match
+struct TriKeyframeDev {
+    float Tcw[12], Ow[3];
+    float fx, fy, cx, cy, invfx, invfy;
+    float scale[8], sigma2[8];
+};
+struct TriArgs {
+    TriKeyframeDev kf1;          // mpCurrentKeyFrame
+    const TriKeyframeDev* kf2;   // the neighbour keyframes of this call
+    const int32_t* kf2_of;       // per match: which neighbour
+    const float2* xy1;           // mvKeysUn[idx1].pt
+    const float2* xy2;
+    const int32_t* oct1;
+    const int32_t* oct2;
+    uint8_t* ok;                 // host-mapped
+    float* x3D;                  // host-mapped, 3 per match
+    float ratio_factor;
+    int n;
+};
+void launch_triangulate(const TriArgs& A, hipStream_t s);
+// MapPoint::UpdateNormalAndDepth (code/src/MapPoint.cc:413-465) for a batch of map points: thread per point
+struct NormalDepthArgs {
+    const int32_t* off;          // n + 1
+    const float* obs_Ow;         // 3 per observation
+    const float* Xw;             // 3 per point
+    const float* ref_Ow;         // 3 per point
+    const float* ref_level_scale;
+    const float* ref_last_scale;
+    float* normal;               // host-mapped, 3 per point
+    float* max_dist;             // host-mapped
+    float* min_dist;             // host-mapped
+    int n;
+};
+void launch_normal_depth(const NormalDepthArgs& A, hipStream_t s);
+
 constexpr int kDistinctiveMaxObs = 512;
 void launch_distinctive_desc(const uint4* d_desc, const int32_t* d_off, int n_points, int32_t* d_best_idx,
                              int32_t* d_best_median, hipStream_t s);

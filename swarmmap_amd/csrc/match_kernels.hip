@@ -445,6 +445,223 @@ void launch_project_queries(const ProjectSrc& S, MatchQuery* d_q, MatchQueryW* d
     hipLaunchKernelGGL(project_queries_kernel, dim3((S.n + 255) / 256), dim3(256), 0, s, S, d_q, d_qw_mapped);
 }
 
+// ---------------- LocalMapping::CreateNewMapPoints, per match (code/src/LocalMapping.cc:263-420, monocular) ----------------
+// Thread per match: parallax of the two rays, the 4 x 4 linear triangulation solved with OpenCV's one-sided Jacobi SVD
+// (cv::SVD::compute, restated in oracle/mapping_oracle.h: the null vector is the row of V^T that ends up last), positive
+// depth in both cameras, reprojection error against 5.991 sigma^2 in both, scale consistency.  Everything lives in
+// registers: the pair loops are unrolled so that no array is indexed at run time; the sweeps diverge per thread.
+__device__ __forceinline__ void tri_swap4(float* a, float* b) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float t = a[k];
+        a[k] = b[k];
+        b[k] = t;
+    }
+}
+
+__device__ __forceinline__ void svd4_last_row(const float* A, float* v4) {
+    float At[4][4], Vt[4][4];
+    double W[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) At[c][r] = A[r * 4 + c];
+    const float eps = 1.1920928955078125e-07f * 2;  // FLT_EPSILON * 2
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sd += (double)At[i][k] * At[i][k];
+        W[i] = sd;
+#pragma unroll
+        for (int k = 0; k < 4; k++) Vt[i][k] = (i == k) ? 1.f : 0.f;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = i + 1; j < 4; j++) {
+                double a = W[i], p = 0, b = W[j];
+#pragma unroll
+                for (int k = 0; k < 4; k++) p += (double)At[i][k] * At[j][k];
+                if (!(fabs(p) <= eps * sqrt(a * b))) {
+                    p *= 2;
+                    const double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                    float c, s;
+                    if (beta < 0) {
+                        const double delta = (gamma - beta) * 0.5;
+                        s = (float)sqrt(delta / gamma);
+                        c = (float)(p / (gamma * s * 2));
+                    } else {
+                        c = (float)sqrt((gamma + beta) / (gamma * 2));
+                        s = (float)(p / (gamma * c * 2));
+                    }
+                    a = b = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float t0 = c * At[i][k] + s * At[j][k];
+                        const float t1 = -s * At[i][k] + c * At[j][k];
+                        At[i][k] = t0;
+                        At[j][k] = t1;
+                        a += (double)t0 * t0;
+                        b += (double)t1 * t1;
+                    }
+                    W[i] = a;
+                    W[j] = b;
+                    changed = true;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float t0 = c * Vt[i][k] + s * Vt[j][k];
+                        const float t1 = -s * Vt[i][k] + c * Vt[j][k];
+                        Vt[i][k] = t0;
+                        Vt[j][k] = t1;
+                    }
+                }
+            }
+        if (!changed) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sd += (double)At[i][k] * At[i][k];
+        W[i] = sqrt(sd);
+    }
+    // the selection sort (descending, first maximum on ties) with the rows of V^T swapped along
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        int j = i;
+#pragma unroll
+        for (int k = i + 1; k < 4; k++) {
+            const double wj = (j == 0) ? W[0] : (j == 1) ? W[1] : (j == 2) ? W[2] : W[3];
+            if (wj < W[k]) j = k;
+        }
+#pragma unroll
+        for (int k = i + 1; k < 4; k++)
+            if (j == k) {
+                const double tw = W[i];
+                W[i] = W[k];
+                W[k] = tw;
+                tri_swap4(Vt[i], Vt[k]);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) v4[k] = Vt[3][k];
+}
+
+__global__ __launch_bounds__(128) void triangulate_kernel(TriArgs A) {
+    const int m = blockIdx.x * 128 + threadIdx.x;
+    if (m >= A.n) return;
+    const TriKeyframeDev& k1 = A.kf1;
+    const TriKeyframeDev& k2 = A.kf2[A.kf2_of[m]];
+    const float* T1 = k1.Tcw;
+    const float* T2 = k2.Tcw;
+    const float2 p1 = A.xy1[m], p2 = A.xy2[m];
+    const int o1 = A.oct1[m], o2 = A.oct2[m];
+    bool ok = true;
+    const float xn1[3] = {(p1.x - k1.cx) * k1.invfx, (p1.y - k1.cy) * k1.invfy, 1.0f};
+    const float xn2[3] = {(p2.x - k2.cx) * k2.invfx, (p2.y - k2.cy) * k2.invfy, 1.0f};
+    float ray1[3], ray2[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        ray1[j] = (float)((double)T1[0 + j] * xn1[0] + (double)T1[4 + j] * xn1[1] + (double)T1[8 + j] * xn1[2]);
+        ray2[j] = (float)((double)T2[0 + j] * xn2[0] + (double)T2[4 + j] * xn2[1] + (double)T2[8 + j] * xn2[2]);
+    }
+    const double dot = (double)ray1[0] * ray2[0] + (double)ray1[1] * ray2[1] + (double)ray1[2] * ray2[2];
+    const double n1 = sqrt((double)ray1[0] * ray1[0] + (double)ray1[1] * ray1[1] + (double)ray1[2] * ray1[2]);
+    const double n2 = sqrt((double)ray2[0] * ray2[0] + (double)ray2[1] * ray2[1] + (double)ray2[2] * ray2[2]);
+    const float cosParallaxRays = (float)(dot / (n1 * n2));
+    const float cosParallaxStereo = cosParallaxRays + 1;
+    if (!(cosParallaxRays < cosParallaxStereo && cosParallaxRays > 0 && (double)cosParallaxRays < 0.9998)) ok = false;
+    float X[3] = {0.f, 0.f, 0.f};
+    if (ok) {
+        float M[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            M[0 + c] = xn1[0] * T1[8 + c] - T1[0 + c];
+            M[4 + c] = xn1[1] * T1[8 + c] - T1[4 + c];
+            M[8 + c] = xn2[0] * T2[8 + c] - T2[0 + c];
+            M[12 + c] = xn2[1] * T2[8 + c] - T2[4 + c];
+        }
+        float v[4];
+        svd4_last_row(M, v);
+        if (v[3] == 0) ok = false;
+        const float iw = (float)(1.0 / (double)v[3]);
+        X[0] = v[0] * iw; X[1] = v[1] * iw; X[2] = v[2] * iw;
+    }
+    if (ok) {
+        const float z1 = (float)(((double)T1[8] * X[0] + (double)T1[9] * X[1] + (double)T1[10] * X[2]) + (double)T1[11]);
+        const float z2 = (float)(((double)T2[8] * X[0] + (double)T2[9] * X[1] + (double)T2[10] * X[2]) + (double)T2[11]);
+        if (z1 <= 0 || z2 <= 0) ok = false;
+        const float x1 = (float)(((double)T1[0] * X[0] + (double)T1[1] * X[1] + (double)T1[2] * X[2]) + (double)T1[3]);
+        const float y1 = (float)(((double)T1[4] * X[0] + (double)T1[5] * X[1] + (double)T1[6] * X[2]) + (double)T1[7]);
+        const float invz1 = (float)(1.0 / (double)z1);
+        const float u1 = k1.fx * x1 * invz1 + k1.cx;
+        const float v1 = k1.fy * y1 * invz1 + k1.cy;
+        const float ex1 = u1 - p1.x, ey1 = v1 - p1.y;
+        if ((double)(ex1 * ex1 + ey1 * ey1) > 5.991 * (double)k1.sigma2[o1]) ok = false;
+        const float x2 = (float)(((double)T2[0] * X[0] + (double)T2[1] * X[1] + (double)T2[2] * X[2]) + (double)T2[3]);
+        const float y2 = (float)(((double)T2[4] * X[0] + (double)T2[5] * X[1] + (double)T2[6] * X[2]) + (double)T2[7]);
+        const float invz2 = (float)(1.0 / (double)z2);
+        const float u2 = k2.fx * x2 * invz2 + k2.cx;
+        const float v2 = k2.fy * y2 * invz2 + k2.cy;
+        const float ex2 = u2 - p2.x, ey2 = v2 - p2.y;
+        if ((double)(ex2 * ex2 + ey2 * ey2) > 5.991 * (double)k2.sigma2[o2]) ok = false;
+        const float a1[3] = {X[0] - k1.Ow[0], X[1] - k1.Ow[1], X[2] - k1.Ow[2]};
+        const float a2[3] = {X[0] - k2.Ow[0], X[1] - k2.Ow[1], X[2] - k2.Ow[2]};
+        const float dist1 = (float)sqrt((double)a1[0] * a1[0] + (double)a1[1] * a1[1] + (double)a1[2] * a1[2]);
+        const float dist2 = (float)sqrt((double)a2[0] * a2[0] + (double)a2[1] * a2[1] + (double)a2[2] * a2[2]);
+        if (dist1 == 0 || dist2 == 0) ok = false;
+        const float ratioDist = dist2 / dist1;
+        const float ratioOctave = k1.scale[o1] / k2.scale[o2];
+        if (ratioDist * A.ratio_factor < ratioOctave || ratioDist > ratioOctave * A.ratio_factor) ok = false;
+    }
+    A.ok[m] = ok ? 1 : 0;
+    if (ok) {
+        A.x3D[3 * (size_t)m] = X[0];
+        A.x3D[3 * (size_t)m + 1] = X[1];
+        A.x3D[3 * (size_t)m + 2] = X[2];
+    }
+}
+
+void launch_triangulate(const TriArgs& A, hipStream_t s) {
+    if (A.n <= 0) return;
+    hipLaunchKernelGGL(triangulate_kernel, dim3((A.n + 127) / 128), dim3(128), 0, s, A);
+}
+
+// ---------------- MapPoint::UpdateNormalAndDepth (code/src/MapPoint.cc:413-465), thread per map point ----------------
+__global__ __launch_bounds__(256) void normal_depth_kernel(NormalDepthArgs A) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= A.n) return;
+    const int a = A.off[p], b = A.off[p + 1];
+    if (b <= a) return;
+    const float Pos[3] = {A.Xw[3 * (size_t)p], A.Xw[3 * (size_t)p + 1], A.Xw[3 * (size_t)p + 2]};
+    float nsum[3] = {0.f, 0.f, 0.f};
+    int n = 0;
+    for (int k = a; k < b; k++) {
+        const float d[3] = {Pos[0] - A.obs_Ow[3 * (size_t)k], Pos[1] - A.obs_Ow[3 * (size_t)k + 1], Pos[2] - A.obs_Ow[3 * (size_t)k + 2]};
+        const double nr = sqrt((double)d[0] * d[0] + (double)d[1] * d[1] + (double)d[2] * d[2]);
+        const float inv = (float)(1.0 / nr);
+#pragma unroll
+        for (int j = 0; j < 3; j++) nsum[j] = nsum[j] + d[j] * inv;
+        n++;
+    }
+    const float PC[3] = {Pos[0] - A.ref_Ow[3 * (size_t)p], Pos[1] - A.ref_Ow[3 * (size_t)p + 1], Pos[2] - A.ref_Ow[3 * (size_t)p + 2]};
+    const float dist = (float)sqrt((double)PC[0] * PC[0] + (double)PC[1] * PC[1] + (double)PC[2] * PC[2]);
+    const float mx = dist * A.ref_level_scale[p];
+    A.max_dist[p] = mx;
+    A.min_dist[p] = mx / A.ref_last_scale[p];
+    const float invn = (float)(1.0 / (double)n);
+#pragma unroll
+    for (int j = 0; j < 3; j++) A.normal[3 * (size_t)p + j] = nsum[j] * invn;
+}
+
+void launch_normal_depth(const NormalDepthArgs& A, hipStream_t s) {
+    if (A.n <= 0) return;
+    hipLaunchKernelGGL(normal_depth_kernel, dim3((A.n + 255) / 256), dim3(256), 0, s, A);
+}
+
 // Copy the staged inputs from pinned host memory into HBM with a kernel on the matcher's own queue: a ~100 KB
 // SDMA copy costs a cross-engine dependency (~15 us) in front of a 19 us kernel.
 __global__ __launch_bounds__(256) void stage_in_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,

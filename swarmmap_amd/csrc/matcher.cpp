@@ -2419,6 +2419,160 @@ int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x
     });
 }
 
+// ---- the local-mapping thread's per-point loops between the matcher and local BA --------------------------------
+int so_triangulate_matches(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_kf2, const so_tri_keyframe* kf2, float ratio_factor,
+                           int32_t n, const int32_t* kf2_of_match, const float* xy1, const int32_t* octave1, const float* xy2,
+                           const int32_t* octave2, uint8_t* ok, float* x3D) {
+    if (!m || !kf1 || n_kf2 < 0 || n < 0 || (n_kf2 > 0 && !kf2)) return SO_ERR_INVALID_ARG;
+    if (n > 0 && (!kf2_of_match || !xy1 || !octave1 || !xy2 || !octave2 || !ok || !x3D || n_kf2 == 0)) return SO_ERR_INVALID_ARG;
+    if (m->batching) {
+        last_error_ref() = "so_triangulate_matches cannot be part of a matcher batch";
+        return SO_ERR_INVALID_ARG;
+    }
+    auto kf_ok = [](const so_tri_keyframe& k) { return k.scale_factors && k.level_sigma2 && k.nlevels >= 1 && k.nlevels <= 8; };
+    if (!kf_ok(*kf1)) return SO_ERR_INVALID_ARG;
+    for (int j = 0; j < n_kf2; j++)
+        if (!kf_ok(kf2[j])) return SO_ERR_INVALID_ARG;
+    for (int k = 0; k < n; k++)
+        if (kf2_of_match[k] < 0 || kf2_of_match[k] >= n_kf2 || octave1[k] < 0 || octave1[k] >= kf1->nlevels || octave2[k] < 0 ||
+            octave2[k] >= kf2[kf2_of_match[k]].nlevels)
+            return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    (void)take_reuse(m);
+    begin_call(m);
+    if (n == 0) return SO_OK;
+    auto fill = [](TriKeyframeDev& D, const so_tri_keyframe& k) {
+        memcpy(D.Tcw, k.Tcw, sizeof(D.Tcw));
+        camera_center(k.Tcw, D.Ow);
+        D.fx = k.fx; D.fy = k.fy; D.cx = k.cx; D.cy = k.cy; D.invfx = k.invfx; D.invfy = k.invfy;
+        for (int l = 0; l < 8; l++) {
+            D.scale[l] = l < k.nlevels ? k.scale_factors[l] : 1.f;
+            D.sigma2[l] = l < k.nlevels ? k.level_sigma2[l] : 1.f;
+        }
+    };
+    const size_t o_kf = 0, o_of = align256(sizeof(TriKeyframeDev) * (size_t)n_kf2), o_xy1 = align256(o_of + 4 * (size_t)n),
+                 o_xy2 = align256(o_xy1 + 8 * (size_t)n), o_o1 = align256(o_xy2 + 8 * (size_t)n), o_o2 = align256(o_o1 + 4 * (size_t)n),
+                 end = align256(o_o2 + 4 * (size_t)n);
+    int rc;
+    if ((rc = m->h_in.ensure_keep(end + 256, 0))) return rc;
+    if ((rc = m->d_in.ensure(end + 256))) return rc;
+    const size_t ok_bytes = align256((size_t)n);
+    if ((rc = m->h_out.ensure(ok_bytes + 12 * (size_t)n))) return rc;
+    uint8_t* hb = (uint8_t*)m->h_in.p;
+    for (int j = 0; j < n_kf2; j++) fill(((TriKeyframeDev*)(hb + o_kf))[j], kf2[j]);
+    memcpy(hb + o_of, kf2_of_match, 4 * (size_t)n);
+    memcpy(hb + o_xy1, xy1, 8 * (size_t)n);
+    memcpy(hb + o_xy2, xy2, 8 * (size_t)n);
+    memcpy(hb + o_o1, octave1, 4 * (size_t)n);
+    memcpy(hb + o_o2, octave2, 4 * (size_t)n);
+    m->resident_n = -1;  // the staging block no longer holds a frame
+    m->dirty_from = 0;
+    m->src = nullptr;
+    uint8_t* db = (uint8_t*)m->d_in.p;
+    TriArgs A;
+    fill(A.kf1, *kf1);
+    A.kf2 = (const TriKeyframeDev*)(db + o_kf);
+    A.kf2_of = (const int32_t*)(db + o_of);
+    A.xy1 = (const float2*)(db + o_xy1);
+    A.xy2 = (const float2*)(db + o_xy2);
+    A.oct1 = (const int32_t*)(db + o_o1);
+    A.oct2 = (const int32_t*)(db + o_o2);
+    A.ok = (uint8_t*)m->h_out.dev;
+    A.x3D = (float*)((uint8_t*)m->h_out.dev + ok_bytes);
+    A.ratio_factor = ratio_factor;
+    A.n = n;
+    hipStream_t s = m->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    launch_stage_in(db, hb, end, s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_triangulate(A, s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    const auto t1 = std::chrono::steady_clock::now();
+    SO_HIP(hipStreamSynchronize(s));
+    const auto t2 = std::chrono::steady_clock::now();
+    m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    m->stat[2] += 1.0;
+    m->stat[3] += (double)end;
+    float ms = 0.f;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    const uint8_t* hok = (const uint8_t*)m->h_out.p;
+    const float* hx = (const float*)((const uint8_t*)m->h_out.p + ok_bytes);
+    for (int k = 0; k < n; k++) {
+        ok[k] = hok[k];
+        if (hok[k]) memcpy(x3D + 3 * (size_t)k, hx + 3 * (size_t)k, 12);
+    }
+    return SO_OK;
+}
+
+int so_update_normal_and_depth(so_matcher* m, int32_t n_points, const int32_t* offsets, const float* obs_Ow, const float* Xw,
+                               const float* ref_Ow, const float* ref_level_scale, const float* ref_last_scale, float* normal,
+                               float* max_dist, float* min_dist) {
+    if (!m || n_points < 0) return SO_ERR_INVALID_ARG;
+    if (n_points > 0 && (!offsets || !Xw || !ref_Ow || !ref_level_scale || !ref_last_scale || !normal || !max_dist || !min_dist))
+        return SO_ERR_INVALID_ARG;
+    if (m->batching) {
+        last_error_ref() = "so_update_normal_and_depth cannot be part of a matcher batch";
+        return SO_ERR_INVALID_ARG;
+    }
+    SO_HIP(hipSetDevice(m->device));
+    (void)take_reuse(m);
+    begin_call(m);
+    if (n_points == 0) return SO_OK;
+    const int n = n_points;
+    for (int p = 0; p < n; p++)
+        if (offsets[p] > offsets[p + 1] || offsets[p] < 0) return SO_ERR_INVALID_ARG;
+    const size_t total = (size_t)offsets[n];
+    if (total > 0 && !obs_Ow) return SO_ERR_INVALID_ARG;
+    const size_t o_off = 0, o_ow = align256(4 * ((size_t)n + 1)), o_x = align256(o_ow + 12 * total), o_r = align256(o_x + 12 * (size_t)n),
+                 o_ls = align256(o_r + 12 * (size_t)n), o_ll = align256(o_ls + 4 * (size_t)n), end = align256(o_ll + 4 * (size_t)n);
+    int rc;
+    if ((rc = m->h_in.ensure_keep(end + 256, 0))) return rc;
+    if ((rc = m->d_in.ensure(end + 256))) return rc;
+    const size_t nb = align256(12 * (size_t)n), sb = align256(4 * (size_t)n);
+    if ((rc = m->h_out.ensure(nb + 2 * sb))) return rc;
+    uint8_t* hb = (uint8_t*)m->h_in.p;
+    memcpy(hb + o_off, offsets, 4 * ((size_t)n + 1));
+    if (total) memcpy(hb + o_ow, obs_Ow, 12 * total);
+    memcpy(hb + o_x, Xw, 12 * (size_t)n);
+    memcpy(hb + o_r, ref_Ow, 12 * (size_t)n);
+    memcpy(hb + o_ls, ref_level_scale, 4 * (size_t)n);
+    memcpy(hb + o_ll, ref_last_scale, 4 * (size_t)n);
+    m->resident_n = -1;
+    m->dirty_from = 0;
+    m->src = nullptr;
+    // a point without observations keeps what the caller passed in (UpdateNormalAndDepth returns early): seed the outputs
+    memcpy(m->h_out.p, normal, 12 * (size_t)n);
+    memcpy((uint8_t*)m->h_out.p + nb, max_dist, 4 * (size_t)n);
+    memcpy((uint8_t*)m->h_out.p + nb + sb, min_dist, 4 * (size_t)n);
+    uint8_t* db = (uint8_t*)m->d_in.p;
+    NormalDepthArgs A;
+    A.off = (const int32_t*)(db + o_off);
+    A.obs_Ow = (const float*)(db + o_ow);
+    A.Xw = (const float*)(db + o_x);
+    A.ref_Ow = (const float*)(db + o_r);
+    A.ref_level_scale = (const float*)(db + o_ls);
+    A.ref_last_scale = (const float*)(db + o_ll);
+    A.normal = (float*)m->h_out.dev;
+    A.max_dist = (float*)((uint8_t*)m->h_out.dev + nb);
+    A.min_dist = (float*)((uint8_t*)m->h_out.dev + nb + sb);
+    A.n = n;
+    hipStream_t s = m->stream;
+    launch_stage_in(db, hb, end, s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_normal_depth(A, s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    memcpy(normal, m->h_out.p, 12 * (size_t)n);
+    memcpy(max_dist, (const uint8_t*)m->h_out.p + nb, 4 * (size_t)n);
+    memcpy(min_dist, (const uint8_t*)m->h_out.p + nb + sb, 4 * (size_t)n);
+    return SO_OK;
+}
+
 int so_matcher_batch_begin(so_matcher* m) {
     if (!m || m->batching) return SO_ERR_INVALID_ARG;
     if (m->pend.mode != 0) {

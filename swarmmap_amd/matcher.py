@@ -530,3 +530,54 @@ def _SearchForTriangulationKFrame(self, kf1, fv1, kframe2, free2, F12, epipole):
 
 ORBmatcher.FuseKFrame = _FuseKFrame
 ORBmatcher.SearchForTriangulationKFrame = _SearchForTriangulationKFrame
+
+
+# ---- the local-mapping thread's per-point loops between the matcher and local BA -----------------------------------
+class SoTriKeyframe(C.Structure):
+    _fields_ = [("Tcw", C.c_float * 12)] + [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "invfx", "invfy")] + \
+               [("scale_factors", C.c_void_p), ("level_sigma2", C.c_void_p), ("nlevels", C.c_int32)]
+
+
+def _so_tri_kf(kf, keep):
+    sf, ls = _f32(kf["scale_factors"]), _f32(kf["level_sigma2"])
+    keep += [sf, ls]
+    fx, fy, cx, cy = [np.float32(v) for v in kf["K"]]
+    s = SoTriKeyframe()
+    s.Tcw[:] = [float(v) for v in _f32(kf["Tcw"]).reshape(12)]
+    s.fx, s.fy, s.cx, s.cy = float(fx), float(fy), float(cx), float(cy)
+    s.invfx, s.invfy = float(np.float32(1.0) / fx), float(np.float32(1.0) / fy)
+    s.scale_factors, s.level_sigma2, s.nlevels = _vp(sf), _vp(ls), len(sf)
+    return s
+
+
+def _TriangulateMatches(self, kf1, kf2_list, ratio_factor, kf2_of_match, xy1, octave1, xy2, octave2):
+    """so_triangulate_matches: CreateNewMapPoints' per-match body for the matches of kf1 with several neighbours in one
+    launch.  kf dicts: Tcw (12), K (fx fy cx cy), scale_factors, level_sigma2.  Returns (ok, x3D)."""
+    vp, i32 = C.c_void_p, C.c_int32
+    self._lib.so_triangulate_matches.argtypes = [vp, C.POINTER(SoTriKeyframe), i32, vp, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp]
+    keep = []
+    a = _so_tri_kf(kf1, keep)
+    arr = (SoTriKeyframe * max(len(kf2_list), 1))(*[_so_tri_kf(k, keep) for k in kf2_list])
+    of = _i32(kf2_of_match)
+    x1, o1, x2, o2 = _f32(xy1).reshape(-1, 2), _i32(octave1), _f32(xy2).reshape(-1, 2), _i32(octave2)
+    n = len(o1)
+    ok, X = np.zeros(n, np.uint8), np.zeros((n, 3), np.float32)
+    _lib.check(self._lib.so_triangulate_matches(self._h, C.byref(a), len(kf2_list), arr, float(ratio_factor), n, _vp(of), _vp(x1),
+                                                _vp(o1), _vp(x2), _vp(o2), _vp(ok), _vp(X)))
+    return ok, X
+
+
+def _UpdateNormalAndDepth(self, offsets, obs_Ow, Xw, ref_Ow, ref_level_scale, ref_last_scale, normal, max_dist, min_dist):
+    """so_update_normal_and_depth: MapPoint::UpdateNormalAndDepth for a batch.  Returns (normal, max_dist, min_dist)."""
+    vp = C.c_void_p
+    self._lib.so_update_normal_and_depth.argtypes = [vp, C.c_int32] + [vp] * 9
+    off = _i32(offsets)
+    a = [_f32(v) for v in (obs_Ow, Xw, ref_Ow, ref_level_scale, ref_last_scale)]
+    nrm, mx, mn = [np.array(v, np.float32, copy=True) for v in (normal, max_dist, min_dist)]
+    _lib.check(self._lib.so_update_normal_and_depth(self._h, len(off) - 1, _vp(off), _vp(a[0]), _vp(a[1]), _vp(a[2]), _vp(a[3]),
+                                                    _vp(a[4]), _vp(nrm), _vp(mx), _vp(mn)))
+    return nrm, mx, mn
+
+
+ORBmatcher.TriangulateMatches = _TriangulateMatches
+ORBmatcher.UpdateNormalAndDepth = _UpdateNormalAndDepth

@@ -606,3 +606,52 @@ def make_sim3_pair_case(seed, n=900, size=EUROC, K=EUROC_K, p_flip=0.08, s12=1.3
                 T2w=np.hstack([R2, t2[:, None]]).astype(np.float32).reshape(12), s12=np.float32(s12),
                 R12=R12.astype(np.float32).reshape(9), t12=t12.astype(np.float32), mp1=mp1, mp2=mp2, perm=perm, cam=K,
                 log_scale_factor=LOG_SCALE_FACTOR)
+
+
+def make_triangulation_case(seed, n=1500, K=EUROC_K, size=EUROC, baseline=0.6, pixel_sigma=0.7):
+    """Two keyframes and their matched keypoints for LocalMapping::CreateNewMapPoints' per-match body: real 3-D points
+    seen by both (pixel noise), plus wrong matches (large reprojection error), low-parallax pairs (far points), points
+    behind a camera and octave pairs that break the scale consistency."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = K
+    R1 = _rodrigues(rng.normal(0, 0.2, 3)); t1 = rng.normal(0, 1.0, 3)
+    dR = _rodrigues(rng.normal(0, 0.05, 3))
+    R2 = dR @ R1
+    t2 = dR @ t1 + np.array([baseline, 0.05 * baseline, 0.1 * baseline]) * rng.choice([-1, 1])
+    uv1 = np.stack([rng.uniform(20, size[0] - 20, n), rng.uniform(20, size[1] - 20, n)], 1)
+    z = rng.uniform(2.0, 12.0, n)
+    far = rng.random(n) < 0.12
+    z[far] = rng.uniform(300.0, 3000.0, far.sum())          # parallax below the 0.9998 bound
+    Pc1 = _unproject(K, uv1, z)
+    Xw = (R1.T @ (Pc1 - t1).T).T
+    Pc2 = (R2 @ Xw.T).T + t2
+    uv2 = np.stack([fx * Pc2[:, 0] / Pc2[:, 2] + cx, fy * Pc2[:, 1] / Pc2[:, 2] + cy], 1)
+    uv1n = uv1 + rng.normal(0, pixel_sigma, (n, 2))
+    uv2n = uv2 + rng.normal(0, pixel_sigma, (n, 2))
+    wrong = rng.random(n) < 0.1
+    uv2n[wrong] += rng.normal(0, 25.0, (wrong.sum(), 2))   # mismatches: reprojection gate
+    o1 = rng.integers(0, 6, n).astype(np.int32)
+    o2 = np.clip(o1 + np.round(np.log(np.linalg.norm(Pc1, axis=1) / np.linalg.norm(Pc2, axis=1)) / np.log(1.2)), 0, 7).astype(np.int32)
+    bad_scale = rng.random(n) < 0.06
+    o2[bad_scale] = np.clip(o1[bad_scale] + rng.choice([-4, 4], bad_scale.sum()), 0, 7)
+    sf = SCALE_FACTORS
+    kf = lambda R, t: dict(Tcw=np.hstack([R, t[:, None]]).astype(np.float32).reshape(12), K=K, scale_factors=sf,  # noqa: E731
+                           level_sigma2=(sf * sf).astype(np.float32))
+    return dict(kf1=kf(R1, t1), kf2=kf(R2, t2), xy1=uv1n.astype(np.float32), xy2=uv2n.astype(np.float32), octave1=o1, octave2=o2,
+                Xw=Xw, clean=~(far | wrong | bad_scale), ratio_factor=float(np.float32(1.5) * np.float32(1.2)))
+
+
+def make_normal_depth_case(seed, n_points=3000, max_obs=12):
+    """Map points with 0..max_obs observing camera centres each for MapPoint::UpdateNormalAndDepth."""
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(0, max_obs + 1, n_points)
+    counts[:5] = np.array([0, 1, 2, max_obs, 0])[:n_points][:5] if n_points >= 5 else np.array([2, 0, 1, max_obs, 0])[:n_points]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    Xw = rng.normal(0, 5.0, (n_points, 3)).astype(np.float32)
+    obs_Ow = (np.repeat(Xw, counts, axis=0) + rng.normal(0, 3.0, (off[-1], 3)) + 2.0).astype(np.float32)
+    ref_Ow = (Xw + rng.normal(0, 3.0, (n_points, 3)) + 1.0).astype(np.float32)
+    lvl = rng.integers(0, 8, n_points)
+    return dict(offsets=off, obs_Ow=obs_Ow, Xw=Xw, ref_Ow=ref_Ow, ref_level_scale=SCALE_FACTORS[lvl].astype(np.float32),
+                ref_last_scale=np.full(n_points, SCALE_FACTORS[7], np.float32),
+                normal=rng.normal(0, 1, (n_points, 3)).astype(np.float32), max_dist=rng.uniform(1, 9, n_points).astype(np.float32),
+                min_dist=rng.uniform(0.1, 1, n_points).astype(np.float32))
