@@ -402,6 +402,11 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
             "search_for_triangulation": {"calls_per_keyframe": L["tri_calls"] / L["jobs"], "host_ms_per_call": L["tri_ms"] / max(L["tri_calls"], 1),
                                          "match_kernel_ms_per_call": L["tri_kernel_ms"] / max(L["tri_calls"], 1),
                                          "matches_per_keyframe": L["tri_matches"] / L["jobs"]},
+            # CreateNewMapPoints' per-match body for the matches of all neighbours (one launch) + UpdateNormalAndDepth of the
+            # new points
+            "triangulation": {"host_ms_per_keyframe": L.get("triangulate_ms", 0.0) / L["jobs"],
+                              "kernel_ms_per_keyframe": L.get("triangulate_kernel_ms", 0.0) / L["jobs"],
+                              "new_map_points_per_keyframe": L.get("new_points", 0.0) / L["jobs"]},
             "fuse": {"calls_per_keyframe": L["fuse_calls"] / L["jobs"], "host_ms_per_call": L["fuse_ms"] / max(L["fuse_calls"], 1),
                      "match_kernel_ms_per_call": L["fuse_kernel_ms"] / max(L["fuse_calls"], 1),
                      "map_points_per_call": L["fuse_points"] / max(L["fuse_calls"], 1), "fused_per_keyframe": L["fused"] / L["jobs"]}})(st.get("lm")),

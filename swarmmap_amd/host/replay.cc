@@ -165,8 +165,11 @@ struct so_replay {
     std::vector<float> lm_cX, lm_cN, lm_cmax, lm_cmin;  // vpFuseCandidates of the keyframe being processed
     std::vector<uint8_t> lm_cD, lm_cok;
     int lm_stamp_id = 0;
-    double lm_stat[16] = {0};
-    std::vector<int32_t> lm_log;           // 5 ints per job: t, neighbours, triangulation matches, fused, fused back
+    double lm_stat[24] = {0};
+    std::vector<int32_t> lm_log;           // 6 ints per job: t, neighbours, triangulation matches, fused, fused back, new map points
+    std::vector<int32_t> lm_tof, lm_to1, lm_to2, lm_noff;  // scratch of the triangulation step (capacity kept)
+    std::vector<float> lm_txy1, lm_txy2, lm_tX, lm_nobs, lm_nX, lm_nref, lm_nls, lm_nll, lm_nnrm, lm_nmax, lm_nmin;
+    std::vector<uint8_t> lm_tok;
     std::vector<const uint8_t*> frames;
     bool frames_on_device = false;
     // so_fleet_run: the extractors of the fleet this agent leads, as one group (one extraction chain for all agents)
@@ -298,14 +301,14 @@ void fundamental_and_epipole(const so_replay* r, const float* T1, const float* T
 }
 
 enum { kLmJobs = 0, kLmWallMs, kLmNodeMs, kLmTriCalls, kLmTriMs, kLmTriKernelMs, kLmTriMatches, kLmFuseCalls, kLmFuseMs,
-       kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries, kLmBatchMs, kLmBatchEndMs, kLmBatchKernelMs };
+       kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries, kLmBatchMs, kLmBatchEndMs, kLmBatchKernelMs, kLmTriangMs, kLmTriangKernelMs, kLmNewPoints };
 
 // CreateNewMapPoints' and SearchInNeighbors' matcher load for the new keyframe `c` (see the file header).
 int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
     so_matcher* m = r->mapper_matcher;
     const double t0 = now_ms();
     const int n = c->n, nv = (int)(r->vocab.size() / 32);
-    double st[16] = {0};
+    double st[24] = {0};
     float kms = 0.f;
     so_matcher_set_profiling(m, 1);
     {   // KeyFrame::ComputeBoW's feature vector, stand-in: node = nearest centroid descriptor (lowest index on ties)
@@ -468,15 +471,98 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         n_fused += fuse_n[j];
     }
     n_back = fuse_n[nn];
-    const int32_t row[5] = {c->t, (int32_t)r->lm_ring.size(), n_tri, n_fused, n_back};
+    // ---- CreateNewMapPoints, the rest of its per-match body (LocalMapping.cc:263-420): the matches of ALL neighbours are
+    //      triangulated and gated in one launch, then the new points get their normal and scale-invariance range
+    //      (MapPoint::UpdateNormalAndDepth, :408: two observations each, the new keyframe is the reference) in another
+    int n_new = 0;
+    {
+        const double ta = now_ms();
+        std::vector<int32_t>&of = r->lm_tof, &o1 = r->lm_to1, &o2 = r->lm_to2;
+        std::vector<float>&p1 = r->lm_txy1, &p2 = r->lm_txy2;
+        of.clear(); o1.clear(); o2.clear(); p1.clear(); p2.clear();
+        size_t j = 0;
+        for (const auto& k2 : r->lm_ring) {
+            const std::vector<int32_t>& m12 = tri_m12[j];
+            for (int i = 0; i < n; i++) {
+                const int i2 = m12[(size_t)i];
+                if (i2 < 0) continue;
+                of.push_back((int32_t)j);
+                p1.push_back(c->x[(size_t)i]); p1.push_back(c->y[(size_t)i]);
+                o1.push_back(c->octave[(size_t)i]);
+                p2.push_back(k2->x[(size_t)i2]); p2.push_back(k2->y[(size_t)i2]);
+                o2.push_back(k2->octave[(size_t)i2]);
+            }
+            j++;
+        }
+        const int nt = (int)of.size();
+        if (nt > 0) {
+            auto tri_kf = [r, level_sigma2 = &level_sigma2[0]](const KfSnap& k) {
+                so_tri_keyframe t;
+                memset(&t, 0, sizeof(t));
+                memcpy(t.Tcw, k.T, sizeof(t.Tcw));
+                t.fx = r->cam.fx; t.fy = r->cam.fy; t.cx = r->cam.cx; t.cy = r->cam.cy;
+                t.invfx = 1.0f / r->cam.fx; t.invfy = 1.0f / r->cam.fy;  // Frame.cc:266
+                t.scale_factors = r->scale;
+                t.level_sigma2 = level_sigma2;
+                t.nlevels = r->nlevels;
+                return t;
+            };
+            const so_tri_keyframe k1 = tri_kf(*c);
+            std::vector<so_tri_keyframe> k2s;
+            for (const auto& k2 : r->lm_ring) k2s.push_back(tri_kf(*k2));
+            std::vector<uint8_t>& okv = r->lm_tok;
+            std::vector<float>& X3 = r->lm_tX;
+            okv.assign((size_t)nt, 0);
+            X3.resize(3 * (size_t)nt);
+            const float ratio_factor = 1.5f * 1.2f;  // 1.5f * mpCurrentKeyFrame->mfScaleFactor, :214
+            if (so_triangulate_matches(m, &k1, (int32_t)k2s.size(), k2s.data(), ratio_factor, nt, of.data(), p1.data(), o1.data(), p2.data(),
+                                       o2.data(), okv.data(), X3.data()) != SO_OK)
+                return SO_ERR_HIP;
+            so_matcher_last_kernel_ms(m, &kms);
+            st[kLmTriangKernelMs] = kms;
+            // the new points: observations = (new keyframe, neighbour), reference keyframe = the new one
+            std::vector<float>&obs = r->lm_nobs, &Xn = r->lm_nX, &rO = r->lm_nref, &ls = r->lm_nls, &ll = r->lm_nll, &nrm = r->lm_nnrm,
+                               &mxd = r->lm_nmax, &mnd = r->lm_nmin;
+            std::vector<int32_t>& off = r->lm_noff;
+            obs.clear(); Xn.clear(); rO.clear(); ls.clear(); ll.clear(); off.assign(1, 0);
+            float Owc[3];
+            auto centre = [](const float* T, float* Ow) {
+                for (int q = 0; q < 3; q++) Ow[q] = (float)(-((double)T[q] * T[3] + (double)T[4 + q] * T[7] + (double)T[8 + q] * T[11]));
+            };
+            centre(c->T, Owc);
+            std::vector<float> Ow2(3 * k2s.size());
+            size_t jj = 0;
+            for (const auto& k2 : r->lm_ring) centre(k2->T, &Ow2[3 * jj++]);
+            for (int k = 0; k < nt; k++) {
+                if (!okv[(size_t)k]) continue;
+                n_new++;
+                obs.insert(obs.end(), Owc, Owc + 3);
+                obs.insert(obs.end(), &Ow2[3 * (size_t)of[(size_t)k]], &Ow2[3 * (size_t)of[(size_t)k]] + 3);
+                off.push_back((int32_t)(obs.size() / 3));
+                Xn.insert(Xn.end(), &X3[3 * (size_t)k], &X3[3 * (size_t)k] + 3);
+                rO.insert(rO.end(), Owc, Owc + 3);
+                ls.push_back(r->scale[o1[(size_t)k]]);
+                ll.push_back(r->scale[r->nlevels - 1]);
+            }
+            if (n_new > 0) {
+                nrm.assign(3 * (size_t)n_new, 0.f); mxd.assign((size_t)n_new, 0.f); mnd.assign((size_t)n_new, 0.f);
+                if (so_update_normal_and_depth(m, n_new, off.data(), obs.data(), Xn.data(), rO.data(), ls.data(), ll.data(), nrm.data(),
+                                               mxd.data(), mnd.data()) != SO_OK)
+                    return SO_ERR_HIP;
+            }
+        }
+        st[kLmTriangMs] = now_ms() - ta;
+        st[kLmNewPoints] = n_new;
+    }
+    const int32_t row[6] = {c->t, (int32_t)r->lm_ring.size(), n_tri, n_fused, n_back, n_new};
     r->lm_ring.push_back(c);
     while ((int)r->lm_ring.size() > r->lm_neighbours) r->lm_ring.pop_front();
     st[kLmJobs] = 1; st[kLmWallMs] = now_ms() - t0; st[kLmTriMatches] = n_tri; st[kLmFused] = n_fused + n_back;
     {
         std::lock_guard<std::mutex> lk(r->mu);
-        r->lm_log.insert(r->lm_log.end(), row, row + 5);
+        r->lm_log.insert(r->lm_log.end(), row, row + 6);
         if (timed)
-            for (int i = 0; i < 16; i++) r->lm_stat[i] += st[i];
+            for (int i = 0; i < 24; i++) r->lm_stat[i] += st[i];
     }
     return SO_OK;
 }
@@ -745,8 +831,8 @@ int so_replay_set_vocabulary(so_replay* r, const uint8_t* centroids, int n, int 
     return SO_OK;
 }
 // statistics of the timed matcher jobs (indices: the kLm* enumeration above) and the log of every job:
-// 5 ints each = frame index, neighbours, SearchForTriangulation matches, points fused into neighbours, fused back
-int so_replay_lm_stats(so_replay* r, double* out16) {
+// 6 ints each = frame index, neighbours, SearchForTriangulation matches, points fused into neighbours, fused back, new map points
+int so_replay_lm_stats(so_replay* r, double* out16) {  // (24 doubles)
     if (!r || !out16) return SO_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(r->mu);
     memcpy(out16, r->lm_stat, sizeof(r->lm_stat));
@@ -755,8 +841,8 @@ int so_replay_lm_stats(so_replay* r, double* out16) {
 int so_replay_lm_log(so_replay* r, int32_t* out, int cap_rows) {
     if (!r) return SO_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(r->mu);
-    const int rows = (int)(r->lm_log.size() / 5);
-    if (out) memcpy(out, r->lm_log.data(), sizeof(int32_t) * 5 * (size_t)std::min(rows, cap_rows));
+    const int rows = (int)(r->lm_log.size() / 6);
+    if (out) memcpy(out, r->lm_log.data(), sizeof(int32_t) * 6 * (size_t)std::min(rows, cap_rows));
     return rows;
 }
 

@@ -85,10 +85,16 @@ class HipBackend:
         return self._lm().hamming_top2(desc, vocab)[0]
 
     def search_for_triangulation(self, kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2):
-        return self._lm().SearchForTriangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2)[0]
+        return self._lm().SearchForTriangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2)
 
     def fuse(self, KF, K, Tcw, log_sf, inv_sigma2, mp, th):
         return self._lm().Fuse(KF, K, Tcw, log_sf, inv_sigma2, mp, th)[0]
+
+    def triangulate(self, kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2):
+        return self._lm().TriangulateMatches(kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2)
+
+    def update_normal_and_depth(self, *a):
+        return self._lm().UpdateNormalAndDepth(*a)
 
     def close(self):
         for o in self.frames + [self.map, self.ex, self.m_last, self.m_map, self.opt, self.lba]:
@@ -180,16 +186,19 @@ def local_mapping_matcher_job(backend, ring, c, K, sf, inv_sigma2, log_sf, vocab
     CreateNewMapPoints' SearchForTriangulation against every neighbour (code/src/LocalMapping.cc:197-246) and
     SearchInNeighbors' Fuse into every neighbour and back (:451-481).  The same job as swarmmap_amd/host/replay.cc's
     lm_matcher_job.  c / ring entries: dicts x, y, angle, octave, desc, mp (slot or -1), mpX, mpN, mpMax, mpMin, mpDesc,
-    T (12), bounds.  Returns (triangulation matches, fused into neighbours, fused back)."""
+    T (12), bounds.  Returns (triangulation matches, fused into neighbours, fused back, new map points)."""
     from .matcher import FeatureVector
     c["fv"] = FeatureVector(np.asarray(backend.assign_nodes(c["desc"], vocab), np.int32))
     kfeat = lambda k: dict(x=k["x"], y=k["y"], angle=k["angle"], octave=k["octave"], desc=k["desc"],  # noqa: E731
                            free=(k["mp"] < 0).astype(np.uint8))
     n_tri = n_fused = n_back = 0
     level_sigma2 = (np.asarray(sf, np.float32) * np.asarray(sf, np.float32)).astype(np.float32)
-    for k2 in ring:
+    tri = []  # (neighbour index, matches12)
+    for j, k2 in enumerate(ring):
         F12, epi = fundamental_and_epipole(K, c["T"], k2["T"])
-        n_tri += backend.search_for_triangulation(kfeat(c), c["fv"], kfeat(k2), k2["fv"], F12, epi, sf, level_sigma2)
+        nm, m12 = backend.search_for_triangulation(kfeat(c), c["fv"], kfeat(k2), k2["fv"], F12, epi, sf, level_sigma2)
+        n_tri += nm
+        tri.append((j, m12))
     mp_c = dict(Xw=c["mpX"], normal=c["mpN"], max_dist=c["mpMax"], min_dist=c["mpMin"], desc=c["mpDesc"])
     for k2 in ring:
         in_kf = np.isin(c["mp"], k2["mp"][k2["mp"] >= 0])
@@ -211,7 +220,35 @@ def local_mapping_matcher_job(backend, ring, c, K, sf, inv_sigma2, log_sf, vocab
                     desc=np.array([k["mpDesc"][i] for k, i, _ in rows], np.uint8).reshape(-1, 32),
                     valid=np.array([0 if s in own else 1 for _, _, s in rows], np.uint8))
         n_back = backend.fuse(keyframe_view(c, sf), K, c["T"], log_sf, inv_sigma2, cand, 3.0)
-    return int(n_tri), int(n_fused), int(n_back)
+    # CreateNewMapPoints' per-match body (LocalMapping.cc:263-420) for the matches of all neighbours, then
+    # MapPoint::UpdateNormalAndDepth of the new points (two observations each, the new keyframe is the reference)
+    n_new = 0
+    if tri:
+        tk = lambda k: dict(Tcw=k["T"], K=K, scale_factors=sf, level_sigma2=level_sigma2)  # noqa: E731
+        of, i1, i2 = [], [], []
+        for j, m12 in tri:
+            sel = np.nonzero(m12 >= 0)[0]
+            of.append(np.full(len(sel), j, np.int32)); i1.append(sel); i2.append(m12[sel])
+        of, i1 = np.concatenate(of), np.concatenate(i1)
+        if len(of):
+            xy1 = np.stack([c["x"][i1], c["y"][i1]], 1)
+            o1 = c["octave"][i1]
+            xy2 = np.concatenate([np.stack([ring[j]["x"][b], ring[j]["y"][b]], 1) for (j, _), b in zip(tri, i2)])
+            o2 = np.concatenate([ring[j]["octave"][b] for (j, _), b in zip(tri, i2)])
+            ok, X = backend.triangulate(tk(c), [tk(k) for k in ring], float(np.float32(1.5) * np.float32(1.2)), of, xy1, o1, xy2, o2)
+            ok = ok.astype(bool)
+            n_new = int(ok.sum())
+            if n_new:
+                centre = lambda T: (-(np.asarray(T, np.float32).astype(np.float64).reshape(3, 4)[:, :3].T  # noqa: E731
+                                      @ np.asarray(T, np.float32).astype(np.float64).reshape(3, 4)[:, 3])).astype(np.float32)
+                Owc = centre(c["T"])
+                Ow2 = np.stack([centre(k["T"]) for k in ring])
+                obs = np.stack([np.tile(Owc, (n_new, 1)), Ow2[of[ok]]], 1).reshape(-1, 3)
+                sfa = np.asarray(sf, np.float32)
+                backend.update_normal_and_depth(np.arange(0, 2 * n_new + 1, 2, dtype=np.int32), obs, X[ok], np.tile(Owc, (n_new, 1)),
+                                                sfa[o1[ok]], np.full(n_new, sfa[-1], np.float32), np.zeros((n_new, 3), np.float32),
+                                                np.zeros(n_new, np.float32), np.zeros(n_new, np.float32))
+    return int(n_tri), int(n_fused), int(n_back), n_new
 
 
 def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_ratio=0.7, local_ba=False,
@@ -394,7 +431,7 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
             break
     out = dict(centres=np.array(centres), poses=np.array(poses))
     out.update({k: np.array(v) for k, v in log.items()})
-    out["lm_log"] = np.array(lm_log, np.int32).reshape(-1, 5)
+    out["lm_log"] = np.array(lm_log, np.int32).reshape(-1, 6)
     return out
 
 

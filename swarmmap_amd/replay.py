@@ -17,7 +17,8 @@ STAT = ("steps", "extract_ms", "m2_ms", "pose1_ms", "m1_ms", "pose2_ms", "pose3_
 
 
 LM_STAT = ("jobs", "wall_ms", "node_ms", "tri_calls", "tri_ms", "tri_kernel_ms", "tri_matches", "fuse_calls", "fuse_ms",
-           "fuse_kernel_ms", "fused", "fuse_points", "tri_queries", "batch_ms", "batch_end_ms", "batch_kernel_ms")
+           "fuse_kernel_ms", "fused", "fuse_points", "tri_queries", "batch_ms", "batch_end_ms", "batch_kernel_ms",
+           "triangulate_ms", "triangulate_kernel_ms", "new_points")
 
 
 def make_vocabulary(n=100, seed=20221001):
@@ -97,14 +98,15 @@ class Replay:
 
     def lm_stats(self):
         """Sums over the timed matcher jobs of the local-mapping thread."""
-        a = np.zeros(16, np.float64)
+        a = np.zeros(24, np.float64)
         self.lib.so_replay_lm_stats(self.h, self._p(a))
         return dict(zip(LM_STAT, a[:len(LM_STAT)].tolist()))
 
     def lm_log(self):
-        """Every matcher job so far: rows (frame, neighbours, triangulation matches, fused into neighbours, fused back)."""
+        """Every matcher job so far: rows (frame, neighbours, triangulation matches, fused into neighbours, fused back, new
+        map points)."""
         n = self.lib.so_replay_lm_log(self.h, None, 0)
-        out = np.zeros((max(n, 1), 5), np.int32)
+        out = np.zeros((max(n, 1), 6), np.int32)
         n = min(n, self.lib.so_replay_lm_log(self.h, self._p(out), len(out)))
         return out[:n]
 

@@ -125,6 +125,7 @@ def test_cpp_chain_in_the_bench_configuration_matches_the_oracle_chain(name):
     assert len(a_lm) == len(b_lm) == (n + 4) // 5 and np.array_equal(a_lm[:, :2], b_lm[:, :2])
     assert np.all(np.abs(a_lm[:, 2:].astype(int) - b_lm[:, 2:].astype(int)) <= 3 + b_lm[:, 2:] // 100), (a_lm, b_lm)
     assert a_lm[-1, 1] == min(20, len(a_lm) - 1) and a_lm[2:, 2].min() > 20 and a_lm[1:, 3].min() > 100
+    assert a_lm.shape[1] == 6 and a_lm[2:, 5].max() > 0  # CreateNewMapPoints' triangulation produces new map points
     assert lm_stats["jobs"] == len(a_lm) and lm_stats["tri_calls"] == a_lm[:, 1].sum()
     # all searches of a keyframe travel as one so_matcher batch (SWARMORB_LM_BATCH=0: one by one, per-call kernel times)
     assert lm_stats["batch_kernel_ms"] > 0 or (lm_stats["tri_kernel_ms"] > 0 and lm_stats["fuse_kernel_ms"] > 0)

@@ -82,10 +82,22 @@ class OracleBackend:
         return orc.hamming_top2(desc, vocab)[0]
 
     def search_for_triangulation(self, kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2):
-        return orc.search_for_triangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2, True)[0]
+        return orc.search_for_triangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2, True)
 
     def fuse(self, KF, K, Tcw, log_sf, inv_sigma2, mp, th):
         return orc.fuse(KF, orc.camera(K), Tcw, log_sf, inv_sigma2, mp, th)[0]
+
+    def triangulate(self, kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2):
+        ok, X = np.zeros(len(o1), np.uint8), np.zeros((len(o1), 3), np.float32)
+        for j, kf2 in enumerate(kf2_list):  # the oracle takes one neighbour at a time
+            sel = np.nonzero(np.asarray(kf2_of) == j)[0]
+            if len(sel):
+                a, b = orc.triangulate_matches(kf1, kf2, ratio_factor, xy1[sel], o1[sel], xy2[sel], o2[sel])
+                ok[sel], X[sel] = a, b
+        return ok, X
+
+    def update_normal_and_depth(self, *a):
+        return orc.update_normal_and_depth(*a)
 
     def close(self):
         pass
