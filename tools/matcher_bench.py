@@ -89,6 +89,15 @@ def main():
     rec("MapPoint::ComputeDistinctiveDescriptors (batch)", "MapPoint.cc:323-392", m, lambda: m.ComputeDistinctiveDescriptors(off, dd),
         map_points=len(counts), observations=int(off[-1]))
 
+    tc = synth.make_triangulation_case(5, 4000)
+    rec("LocalMapping::CreateNewMapPoints per-match body (4000 matches, one neighbour)", "LocalMapping.cc:263-420", m,
+        lambda: m.TriangulateMatches(tc["kf1"], [tc["kf2"]], tc["ratio_factor"], np.zeros(4000, np.int32), tc["xy1"], tc["octave1"],
+                                     tc["xy2"], tc["octave2"]), matches=4000)
+    nd = synth.make_normal_depth_case(7, 20000, 12)
+    rec("MapPoint::UpdateNormalAndDepth (batch)", "MapPoint.cc:413-465", m,
+        lambda: m.UpdateNormalAndDepth(nd["offsets"], nd["obs_Ow"], nd["Xw"], nd["ref_Ow"], nd["ref_level_scale"], nd["ref_last_scale"],
+                                       nd["normal"], nd["max_dist"], nd["min_dist"]), map_points=20000, observations=int(nd["offsets"][-1]))
+
     # ---- a new keyframe's whole matcher load: 20 neighbours ----------------------------------------------------
     nb = 20
     neigh = [synth.make_projection_case(500 + i, 1000, 900, keyframe_bounds=True) for i in range(nb)]
