@@ -11,6 +11,7 @@
 #include "../../swarmmap_amd/host/ORBmatcher.h"
 #include "../../swarmmap_amd/host/Frame.h"
 #include "../../swarmmap_amd/host/Optimizer.h"
+#include "../../swarmmap_amd/host/LocalMapping.h"
 
 static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
     const uint8_t* b = (const uint8_t*)p;
@@ -220,6 +221,30 @@ int main(int argc, char** argv) {
         const int n5 = m.SearchBySim3(S1.view(false), cal, P1, S2.view(false), cal, P2, mp1, mp2, s12[0], R12.data(), t12.data(),
                                       7.5f, m12);
         printf("psim3_n %d\n", n5); out("psim3", m12);
+    }
+    {   // LocalMapping's per-point loops: CreateNewMapPoints' triangulation, MapPoint::UpdateNormalAndDepth
+        ORB_SLAM2::LocalMappingOps ops;
+        auto kf = [](const std::string& p) {
+            ORB_SLAM2::TriangulationKeyFrame k;
+            const std::vector<float> T = rd<float>((p + "_Tcw").c_str()), K4 = rd<float>("tr_K");
+            for (int i = 0; i < 12; i++) k.Tcw[i] = T[i];
+            k.fx = K4[0]; k.fy = K4[1]; k.cx = K4[2]; k.cy = K4[3];
+            k.mvScaleFactors = rd<float>("scale_factors"); k.mvLevelSigma2 = rd<float>("level_sigma2");
+            return k;
+        };
+        ORB_SLAM2::TriangulationMatches mt;
+        mt.xy1 = rd<float>("tr_xy1"); mt.xy2 = rd<float>("tr_xy2"); mt.octave1 = rd<int32_t>("tr_o1"); mt.octave2 = rd<int32_t>("tr_o2");
+        mt.neighbour.assign(mt.octave1.size(), 0);
+        std::vector<uint8_t> ok;
+        std::vector<float> x3D;
+        const int nnew = ops.TriangulateMatches(kf("tr1"), {kf("tr2")}, rd<float>("tr_ratio")[0], mt, ok, x3D);
+        for (size_t k = 0; k < ok.size(); k++)
+            if (!ok[k]) x3D[3 * k] = x3D[3 * k + 1] = x3D[3 * k + 2] = 0.f;
+        printf("tri_n %d\n", nnew); out("tri_ok", ok); out("tri_x3d", x3D);
+        std::vector<float> nrm = rd<float>("nd_normal"), mx = rd<float>("nd_max"), mn = rd<float>("nd_min");
+        ops.UpdateNormalAndDepth(rd<int32_t>("nd_off"), rd<float>("nd_obs"), rd<float>("nd_Xw"), rd<float>("nd_ref"), rd<float>("nd_ls"),
+                                 rd<float>("nd_ll"), nrm, mx, mn);
+        out("nd_normal_out", nrm); out("nd_max_out", mx); out("nd_min_out", mn);
     }
     // ---- Optimizer ----------------------------------------------------------------------------------------------
     ORB_SLAM2::Optimizer& optimizer = ORB_SLAM2::Optimizer::ThreadInstance();  // static call sites, as in the reference

@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "swarmmap_amd", "host")
-SRCS = [os.path.join(HOST, f) for f in ("ORBextractor.cc", "ORBmatcher.cc", "Optimizer.cc", "Frame.cc")]
+SRCS = [os.path.join(HOST, f) for f in ("ORBextractor.cc", "ORBmatcher.cc", "Optimizer.cc", "Frame.cc", "LocalMapping.cc")]
 
 
 def _fnv(b):
@@ -137,6 +137,16 @@ def test_every_adapter_method_matches_the_oracle(tmp_path, oracle):
         _w(d, "s_" + k, sp[k], np.float32)
     _w(d, "s_s12", [sp["s12"]], np.float32)
 
+    tc = synth.make_triangulation_case(81, 900)
+    _w(d, "tr1_Tcw", tc["kf1"]["Tcw"], np.float32); _w(d, "tr2_Tcw", tc["kf2"]["Tcw"], np.float32); _w(d, "tr_K", tc["kf1"]["K"], np.float32)
+    _w(d, "tr_xy1", tc["xy1"], np.float32); _w(d, "tr_xy2", tc["xy2"], np.float32); _w(d, "tr_o1", tc["octave1"], np.int32)
+    _w(d, "tr_o2", tc["octave2"], np.int32); _w(d, "tr_ratio", [tc["ratio_factor"]], np.float32)
+    nd = synth.make_normal_depth_case(82, 2000, 9)
+    for k, key, t in (("off", "offsets", np.int32), ("obs", "obs_Ow", np.float32), ("Xw", "Xw", np.float32), ("ref", "ref_Ow", np.float32),
+                      ("ls", "ref_level_scale", np.float32), ("ll", "ref_last_scale", np.float32), ("normal", "normal", np.float32),
+                      ("max", "max_dist", np.float32), ("min", "min_dist", np.float32)):
+        _w(d, "nd_" + k, nd[key], t)
+
     outp = subprocess.check_output([exe, d, "752", "480"], text=True)
     L = dict(l.split(" ", 1) for l in outp.strip().splitlines())
 
@@ -204,6 +214,13 @@ def test_every_adapter_method_matches_the_oracle(tmp_path, oracle):
     onf, om12 = oracle.search_by_sim3(SP1(False), SP2(False), pcam, sp["T1w"], sp["T2w"], sp["s12"], sp["R12"], sp["t12"], lsf,
                                       lsf, sp["mp1"], sp["mp2"], 7.5)
     assert int(L["psim3_n"]) == onf > 150; same("psim3", om12, np.int32)
+    # LocalMapping's per-point loops
+    ook, oX = oracle.triangulate_matches(tc["kf1"], tc["kf2"], tc["ratio_factor"], tc["xy1"], tc["octave1"], tc["xy2"], tc["octave2"])
+    assert int(L["tri_n"]) == int(ook.sum()) > 300
+    same("tri_ok", ook, np.uint8); same("tri_x3d", np.where(ook[:, None].astype(bool), oX, 0), np.float32)
+    on, omx, omn = oracle.update_normal_and_depth(nd["offsets"], nd["obs_Ow"], nd["Xw"], nd["ref_Ow"], nd["ref_level_scale"],
+                                                  nd["ref_last_scale"], nd["normal"], nd["max_dist"], nd["min_dist"])
+    same("nd_normal_out", on, np.float32); same("nd_max_out", omx, np.float32); same("nd_min_out", omn, np.float32)
     # Optimizer
     o = oracle.bundle_adjust(win)
     f = L["ba"].split()
