@@ -1228,12 +1228,41 @@ int so_hamming_top2(so_matcher* m, const uint8_t* A, int32_t na, const uint8_t* 
     (void)take_reuse(m);
     if (na == 0) return SO_OK;
     SO_HIP(hipSetDevice(m->device));
+    if (m->batching) {
+        last_error_ref() = "so_hamming_top2 cannot be part of a matcher batch";
+        return SO_ERR_INVALID_ARG;
+    }
+    if (nb >= (1 << 20)) return SO_ERR_INVALID_ARG;
+    // like every other call: inputs through the pinned staging block and the copy kernel on the handle's own queue, results
+    // written by the kernel into host-mapped memory (two pageable hipMemcpyAsync + a device-to-host copy cost ~60 us more
+    // per call - it is on the local-mapping thread's path once per keyframe, as the vocabulary stand-in)
     int rc;
-    if ((rc = m->d_A.ensure((size_t)na * 32))) return rc;
-    if ((rc = m->d_B.ensure((size_t)(nb > 0 ? nb : 1) * 32))) return rc;
-    SO_HIP(hipMemcpyAsync(m->d_A.p, A, (size_t)na * 32, hipMemcpyHostToDevice, m->stream));
-    if (nb > 0) SO_HIP(hipMemcpyAsync(m->d_B.p, B, (size_t)nb * 32, hipMemcpyHostToDevice, m->stream));
-    return top2_common(m, (const uint4*)m->d_A.p, na, (const uint4*)m->d_B.p, nb, best_idx, best_dist, second_dist);
+    const size_t o_b = align256((size_t)na * 32), end = align256(o_b + (size_t)(nb > 0 ? nb : 1) * 32);
+    if ((rc = m->h_in.ensure_keep(end + 256, 0))) return rc;
+    if ((rc = m->d_in.ensure(end + 256))) return rc;
+    const size_t rb = align256(sizeof(int32_t) * (size_t)na);
+    if ((rc = m->h_out.ensure(3 * rb))) return rc;
+    memcpy(m->h_in.p, A, (size_t)na * 32);
+    if (nb > 0) memcpy((uint8_t*)m->h_in.p + o_b, B, (size_t)nb * 32);
+    m->resident_n = -1;
+    m->dirty_from = 0;
+    m->src = nullptr;
+    hipStream_t s = m->stream;
+    uint8_t* db = (uint8_t*)m->d_in.p;
+    launch_stage_in(db, m->h_in.p, end, s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_hamming_top2((const uint4*)db, na, (const uint4*)(db + o_b), nb, (int32_t*)m->h_out.dev, (int32_t*)((uint8_t*)m->h_out.dev + rb),
+                        (int32_t*)((uint8_t*)m->h_out.dev + 2 * rb), s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    m->last_ms = 0.f;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms = ms;
+    memcpy(best_idx, m->h_out.p, sizeof(int32_t) * (size_t)na);
+    memcpy(best_dist, (const uint8_t*)m->h_out.p + rb, sizeof(int32_t) * (size_t)na);
+    memcpy(second_dist, (const uint8_t*)m->h_out.p + 2 * rb, sizeof(int32_t) * (size_t)na);
+    return SO_OK;
 }
 
 // MapPoint::ComputeDistinctiveDescriptors for a batch of map points (code/src/MapPoint.cc:323-392)
@@ -2171,8 +2200,15 @@ int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* f
         k->d_cap = total + 256 + (total >> 3);  // a little slack: the next keyframe has a few more keypoints inside the grid
         e = hipMalloc((void**)&k->d, k->d_cap);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(k->d, m->h_in.p, k->g_end, hipMemcpyHostToDevice, m->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    // the grid layout waits in a second pinned block while the staging block takes the node layout; both go up with the
+    // copy kernel on the handle's queue, one wait at the end
+    if (e == hipSuccess && m->h_res.ensure(k->g_end + 256) != SO_OK) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+        memcpy(m->h_res.p, m->h_in.p, k->g_end);
+        launch_stage_in(k->d, m->h_res.p, k->g_end, m->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !fv) e = hipStreamSynchronize(m->stream);
     if (e != hipSuccess) {
         if (k->d) (void)hipFree(k->d);
         delete k;
@@ -2192,7 +2228,10 @@ int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* f
         for (int a = 0; a <= fv->n_nodes; a++) k->node_off[(size_t)a] = fv->off[a] - fv->off[0];
         const size_t node_bytes = align256(m->off_desc + 32 * (size_t)k->n_node);
         if (k->g_end + node_bytes > k->d_cap) e = hipErrorInvalidValue;
-        if (e == hipSuccess && node_bytes > 0) e = hipMemcpyAsync(k->d + k->g_end, m->h_in.p, node_bytes, hipMemcpyHostToDevice, m->stream);
+        if (e == hipSuccess && node_bytes > 0) {
+            launch_stage_in(k->d + k->g_end, m->h_in.p, node_bytes, m->stream);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     }
     m->resident_n = -1;
