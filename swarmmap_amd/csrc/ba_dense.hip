@@ -108,23 +108,29 @@ __device__ __forceinline__ d4 potrf_mma_nn(const double* Pa, const double* Pb, d
     return acc;
 }
 
-// Value of lane n of the caller's row of 16 lanes, as one VGPR-to-VGPR DPP move (v_mov_b64_dpp row_newbcast).
-template <int N>
-__device__ __forceinline__ double row_bcast_c(double x) {
-    return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
-}
+// ---- the 16x16 pivot tile: one wave, everything in registers, the instruction order written down by hand ----
+// What bounds it (tools/probe/dpp_rate_probe.hip, one wave): an FP64 instruction issues every 5.8 cycles whether or
+// not it depends on the previous one (9.6 if it does; v_rsq_f64 25; DPP operands, scalar operands and 32-bit
+// instructions cost the same 5.8-6.3), and the pivot chain alone - rsq, one third-order step, the scaled diagonal, the
+// next pivot, its broadcast - is 89 cycles per pivot.  The tile's 240 eliminations + 160 chain instructions are
+// therefore ~2.3 k cycles of issue, and the rest of the 4.3 k it took was overhead around them: the sixteen loads
+// compiled into sixteen branches (`lane < 16 ? load : constant`), 64 selects, 32 stores of a factor nothing reads,
+// stores and exec-mask changes between the pivots.  Now every lane row loads the same 16 rows (no select, no branch),
+// the factor is stored only for the one tile whose row is read, W is stored after the last pivot, and every
+// instruction of the loop is an `asm volatile` statement (they keep their order: the eliminations of the PREVIOUS
+// pivot sit in the shadow of the chain's operations instead of behind them): 4340 -> 3030 cycles per tile
+// (tools/probe/potrf_probe.hip; bit-identical output), LBA-M's solve 40 -> 35 us.  Tried and measured equal or
+// worse: the factor in lanes 0-15 and the inverse in lanes 16-31 (one elimination serves both, but the column of
+// multipliers has to cross lane rows - v_permlane16_swap + moves - and the pivot needs v_readlane: as many
+// instructions as it saves).  Inline assembly means the hazards are ours: a DPP operand must not be read within two
+// wait states of the VALU write (an elimination or a multiplication sits between), the result of the transcendental
+// unit not within one (pv_rsq).
 // acc -= (lane N of the row of col) * b in ONE instruction: the FP64 FMA takes its first operand through DPP, so a
 // multiplier of the pivot loop costs no broadcast instruction, no scalar register (512 v_readlane per tile ran the
-// SGPR file dry) and no temporary.  `col` must come from potrf_scale (DPP reads need two wait states after the
-// VALU write; the assembler does not see inside these statements).
+// SGPR file dry) and no temporary.
 template <int N>
 __device__ __forceinline__ void fnma_bcast_c(double& acc, double col, double b) {
-    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(col), "v"(b), "n"(N));
-}
-__device__ __forceinline__ double potrf_scale(double x, double y) {
-    double r;
-    asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(x), "v"(y));
-    return r;
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(col), "v"(b), "n"(N));
 }
 #define SO_ROW16(F, n, ...)                                                                                          \
     switch (n) {                                                                                                     \
@@ -135,49 +141,122 @@ __device__ __forceinline__ double potrf_scale(double x, double y) {
         case 12: F<12>(__VA_ARGS__); break; case 13: F<13>(__VA_ARGS__); break; case 14: F<14>(__VA_ARGS__); break;   \
         default: F<15>(__VA_ARGS__); break;                                                                          \
     }
+__device__ __forceinline__ double pv_rsq(double a) {
+    double r;
+    asm volatile("v_rsq_f64 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ double pv_mul(double a, double b) {
+    double r;
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double pv_fma(double a, double b, double c) {
+    double r;
+    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ double pv_fnma(double a, double b, double c) {  // c - a b
+    double r;
+    asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ double pv_one_minus(double a, double b) {  // 1 - a b
+    double r;
+    asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double pv_half_plus(double s, double b) {  // 0.5 + s b, s in scalar registers
+    double r;
+    asm volatile("v_fma_f64 %0, %1, %2, 0.5" : "=v"(r) : "s"(s), "v"(b));
+    return r;
+}
+// Value of lane N of the caller's row of 16 lanes (v_mov_b64_dpp row_newbcast).  The operand must be two wait states old.
 template <int N>
-__device__ __forceinline__ void row_bcast_into(double& out, double x) {
-    out = row_bcast_c<N>(x);
+__device__ __forceinline__ double pv_row_bcast(double x) {
+    double r;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(N));
+    return r;
 }
 
-// One wave: Cholesky of the 16x16 tile at At (row stride PS) and its inverse W: the factor goes to Lt (zeros above
-// the diagonal; skipped if Lt is null), W to Wt; either may alias At.  Lanes 0-15 hold a row each (lanes 16-63 run the same code on
-// identity rows).  Returns false if a pivot is not positive.
+// Pending elimination K of pivot C - 1, factor and inverse alternating (targets C..15 each):
+//   K even: x[C + K/2] -= L[C + K/2][C - 1] * L[lane][C - 1]       K odd: v[C + K/2] -= L[C + K/2][C - 1] * w[C - 1]
+template <int C, int K>
+__device__ __forceinline__ void pv_pend(double (&x)[16], double (&v)[16], double xp, double wp) {
+    if constexpr (C > 0 && C + K / 2 < 16) {
+        if constexpr (K % 2 == 0) fnma_bcast_c<C + K / 2>(x[C + K / 2], xp, xp);
+        else fnma_bcast_c<C + K / 2>(v[C + K / 2], xp, wp);
+    }
+}
+template <int C, int K0, int K1>
+__device__ __forceinline__ void pv_pend_range(double (&x)[16], double (&v)[16], double xp, double wp) {
+    if constexpr (K0 < K1) {
+        pv_pend<C, K0>(x, v, xp, wp);
+        pv_pend_range<C, K0 + 1, K1>(x, v, xp, wp);
+    }
+}
+// Pivot C of the tile and, in the shadow of its chain, the eliminations of pivot C - 1 (a compile-time schedule).
+// piv: the pivot in every lane of the row; xp / wp: the lane's entries of the previous column of L and row of W.
+template <int C>
+__device__ __forceinline__ void pv_step(double (&x)[16], double (&v)[16], double piv, double xp, double wp, double k375,
+                                        double& last_piv) {
+    constexpr int n_pend = C > 0 ? 2 * (16 - C) : 0;
+    constexpr int n_slots = 6;  // issue slots behind the operations of the chain below
+    constexpr int n_first = n_pend - n_slots > 3 ? n_pend - n_slots : 3;
+    if constexpr (C == 15) last_piv = piv;
+    const double y0 = pv_rsq(piv);
+    // x[C], v[C], x[C + 1] first (the chain needs them), then whatever does not fit behind the chain's operations
+    pv_pend_range<C, 0, n_first>(x, v, xp, wp);
+    const double t = pv_mul(piv, y0);
+    pv_pend<C, n_first>(x, v, xp, wp);
+    const double e = pv_one_minus(t, y0);
+    pv_pend<C, n_first + 1>(x, v, xp, wp);
+    const double p = pv_half_plus(k375, e);
+    const double ye = pv_mul(y0, e);
+    pv_pend<C, n_first + 2>(x, v, xp, wp);
+    const double y = pv_fma(ye, p, y0);
+    pv_pend<C, n_first + 3>(x, v, xp, wp);
+    x[C] = pv_mul(x[C], y);
+    pv_pend<C, n_first + 4>(x, v, xp, wp);
+    if constexpr (C + 1 < 16) {
+        // the next pivot: in its own lane the multiplier is the lane's own x[C], no broadcast on the chain
+        const double pn = pv_fnma(x[C], x[C], x[C + 1]);
+        v[C] = pv_mul(v[C], y);  // W[C][lane], final                (two wait states between pn and its DPP read)
+        pv_pend<C, n_first + 5>(x, v, xp, wp);
+        const double piv_next = pv_row_bcast<C + 1>(pn);
+        pv_step<C + 1>(x, v, piv_next, x[C], v[C], k375, last_piv);
+    } else {
+        v[C] = pv_mul(v[C], y);
+    }
+}
+
+// One wave: Cholesky of the 16x16 tile at At (row stride PS) and its inverse W.  W goes to Wt (may alias At; zeros
+// above the diagonal); the factor's rows go to Lt if that is not null (entries above the diagonal unspecified - the
+// one reader takes the part below it of one row).  Lane l holds row l & 15 and solves L w = e_(l & 15) by forward
+// substitution on the same multipliers: the four rows of 16 lanes run the same thing (no selects around the loads,
+// DPP broadcasts stay inside a row of lanes); lanes 0-15 store.  Returns false if a pivot is not positive: a bad
+// pivot turns everything behind it into NaN (rsq of a negative number; 0 x inf), so the last pivot tells.
 template <int PS>
 __device__ __forceinline__ bool potrf_diag16(const double* At, double* Lt, double* Wt, int lane) {
     double x[16], v[16];
     const int lr = lane & 15;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-        x[c] = lane < 16 ? At[lane * PS + c] : (c == lr ? 1.0 : 0.0);
-        v[c] = (c == lr) ? 1.0 : 0.0;  // lane c solves L w = e_c
+        x[c] = At[lr * PS + c];
+        v[c] = (c == lr) ? 1.0 : 0.0;
     }
     potrf_wave_sync();  // every lane holds its row: Wt / Lt may alias At from here on
-    bool ok = true;
-    double piv = row_bcast_c<0>(x[0]);
+    double last_piv = 0.0;
+    pv_step<0>(x, v, __builtin_amdgcn_mov_dpp(x[0], 0x150, 0xf, 0xf, true), 0.0, 0.0, 0.375, last_piv);
+    if (lane < 16) {
 #pragma unroll
-    for (int c = 0; c < 16; c++) {  // n in SO_ROW16 is a constant after unrolling
-        if (!(piv > 0.0)) ok = false;
-        const double y = dense_rsqrt(piv);
-        x[c] = potrf_scale(x[c], y);
-        const double w = v[c] * y;
-        // the next pivot first: in its own lane the multiplier is the lane's own x[c], no broadcast on the chain
-        if (c + 1 < 16) {
-            const double pn = fma(-x[c], x[c], x[c + 1]);
-            SO_ROW16(row_bcast_into, c + 1, piv, pn);
-        }
-        if (lane < 16) Wt[c * PS + lane] = w;  // W[c][lane]: final (zero above the diagonal by construction)
+        for (int c = 0; c < 16; c++) Wt[c * PS + lane] = v[c];  // W[c][lane] (zero above the diagonal by construction)
+        if (Lt) {
 #pragma unroll
-        for (int c2 = c + 1; c2 < 16; c2++) {  // L[c2][c] = x[c] in lane c2
-            SO_ROW16(fnma_bcast_c, c2, x[c2], x[c], x[c]);
-            SO_ROW16(fnma_bcast_c, c2, v[c2], x[c], w);
+            for (int c = 0; c < 16; c++) Lt[lane * PS + c] = x[c];
         }
     }
-    if (Lt && lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) Lt[lane * PS + c] = (c <= lane) ? x[c] : 0.0;
-    }
-    return ok;
+    return last_piv > 0.0;
 }
 
 // t-th tile (row-major) of a lower triangle
@@ -187,15 +266,31 @@ __device__ __forceinline__ void potrf_tri(int t, int& ti, int& tj) {
     tj = t - ti * (ti + 1) / 2;
 }
 
+// Block row i (16 rows) of the inverse factor from LDS to the full row-major 96x96 block in HBM the panel GEMM reads
+// (zeros above the diagonal: those tiles were never written in LDS), by `nthr` threads of which the caller is `t`.
+__device__ __forceinline__ void potrf_store_inverse_row(double (*X)[kPS], double* __restrict__ Linv, int i, int t, int nthr) {
+    for (int e = t; e < 16 * (kDNB / 2); e += nthr) {
+        const int r = 16 * i + e / (kDNB / 2), c = 2 * (e % (kDNB / 2));
+        double2 x;
+        const bool low = (c >> 4) <= i;
+        x.x = low ? X[r][c] : 0.0; x.y = low ? X[r][c + 1] : 0.0;
+        *reinterpret_cast<double2*>(Linv + (size_t)r * kDNB + c) = x;
+    }
+}
+
 // The block's lower 16x16 tiles are in A (LDS); on return X holds the inverse of its Cholesky factor (lower tiles; the
-// diagonal tiles are zero above the diagonal, tiles above the diagonal are never written).  *s_bad must be 0 on entry
-// (and a barrier between that store and the call); it becomes 1 if a pivot is not positive.  Ends with a barrier.
-__device__ __forceinline__ void potrf_block_lds(double (*A)[kPS], double (*X)[kPS], int* s_bad_p) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// diagonal tiles are zero above the diagonal, tiles above the diagonal are never written) and Linv (HBM) the same as
+// a full 96x96 block: block row i leaves for HBM during step i + 1, from the waves that are not factoring, so only
+// the last one's store is exposed (the whole block at the end was 4.2 k cycles of every panel's critical path).
+// *s_bad must be 0 on entry (and a barrier between that store and the call); it becomes 1 if a pivot is not positive.
+__device__ __forceinline__ void potrf_block_lds(double (*A)[kPS], double (*X)[kPS], int* s_bad_p, double* __restrict__ Linv) {
+    // (the wave index as a scalar: what each wave works on is then scalar arithmetic and scalar branches - computed per
+    //  lane, the tile indices of a pair of trailing tiles cost 1.1 k cycles, as much as its eight MFMAs)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int crow = lane >> 4, ccol = lane & 15;  // MFMA result layout: element (crow + 4 reg, ccol)
     int& s_bad = *s_bad_p;
     SO_POTRF_MARK(0);
-    if (wave == 0 && !potrf_diag16<kPS>(&A[0][0], &A[0][0], &X[0][0], lane) && lane == 0) s_bad = 1;
+    if (wave == 0 && !potrf_diag16<kPS>(&A[0][0], nullptr, &X[0][0], lane) && lane == 0) s_bad = 1;
     __syncthreads();
     for (int jb = 0; jb < kPT; jb++) {
         const int cb = 16 * jb;
@@ -218,21 +313,38 @@ __device__ __forceinline__ void potrf_block_lds(double (*A)[kPS], double (*X)[kP
             for (int reg = 0; reg < 4; reg++) A[nb + crow + 4 * reg][nb + ccol] -= acc[reg];
             potrf_wave_sync();
             SO_POTRF_MARK(3 + 4 * jb);
-            if (!potrf_diag16<kPS>(&A[nb][nb], &A[nb][nb], &X[nb][nb], lane) && lane == 0) s_bad = 1;
+            if (!potrf_diag16<kPS>(&A[nb][nb], nullptr, &X[nb][nb], lane) && lane == 0) s_bad = 1;
             SO_POTRF_MARK(4 + 4 * jb);
         } else {
             const int nw = has_diag ? 3 : 4, me = has_diag ? wave - 1 : wave;
-            const int n_upd = has_diag ? m * (m + 1) / 2 - 1 : 0;
-            for (int t = me; t < n_upd + jb; t += nw) {
-                if (t < n_upd) {  // A_ij -= L_i L_j^T (tile 0 of the triangle is wave 0's)
-                    int ti, tj;
-                    potrf_tri(t + 1, ti, tj);
-                    const int ri = jb + 1 + ti, ci = jb + 1 + tj;
-                    const d4 acc = potrf_mma_nt(&A[16 * ri][cb], &A[16 * ci][cb], d4{0.0, 0.0, 0.0, 0.0}, lane);
+            if (jb > 0) potrf_store_inverse_row(X, Linv, jb - 1, 64 * me + lane, 64 * nw);  // complete since the last barrier
+            // Work items of the step, longest first, handed out in snake order (rounds alternate direction):
+            //   m tiles of the trailing matrix (m >= 2): block column jb + 1 below its diagonal tile and the diagonal
+            //     tile (jb + 2, jb + 2) - what the NEXT step reads.  They take all their updates at once,
+            //     A_ij -= L_ik L_jk^T for k = 0..jb (jb + 1 products, one pass over the tile), everything to the right of
+            //     column jb + 1 waits (left-looking).  Updating the whole trailing matrix every step (14 / 9 / 5 / 2
+            //     single products, one read-modify-write and one set of tile indices each) kept three waves busy for
+            //     5.5 k cycles in the first step against the 3.9 k of the wave that factors; this way the steps carry
+            //     5 / 8 / 9 / 8 products in 5 / 4 / 3 / 2 tiles and every step hides behind the pivot tile;
+            //   jb tiles of block row jb of the inverse, X_ij = -W_i sum_{m=j}^{i-1} L_im X_mj (jb - j + 1 products).
+            const int n_upd = m >= 2 ? m : 0;
+            const int n_items = n_upd + jb;
+            for (int r = 0;; r++) {
+                const int u = r * nw + ((r & 1) ? nw - 1 - me : me);
+                if (u >= n_items) break;
+                if (u < n_upd) {
+                    const int ri = u + 1 < n_upd ? jb + 2 + u : jb + 2, ci = u + 1 < n_upd ? jb + 1 : jb + 2;
+                    // (each product from a zero accumulator and subtracted on its own: the same roundings as a rank-16
+                    //  update per step; one accumulator for all of them moved GBA-2's per-edge chi2 past 1e-5 relative)
+                    d4 tot;
 #pragma unroll
-                    for (int reg = 0; reg < 4; reg++) A[16 * ri + crow + 4 * reg][16 * ci + ccol] -= acc[reg];
-                } else {          // X_ij = -W_i sum_{m=j}^{i-1} L_im X_mj for i = jb
-                    const int i = jb, j = t - n_upd;
+                    for (int reg = 0; reg < 4; reg++) tot[reg] = A[16 * ri + crow + 4 * reg][16 * ci + ccol];
+                    for (int k = 0; k <= jb; k++)
+                        tot -= potrf_mma_nt(&A[16 * ri][16 * k], &A[16 * ci][16 * k], d4{0.0, 0.0, 0.0, 0.0}, lane);
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) A[16 * ri + crow + 4 * reg][16 * ci + ccol] = tot[reg];
+                } else {
+                    const int i = jb, j = u - n_upd;
                     d4 acc = d4{0.0, 0.0, 0.0, 0.0};
                     for (int mm = j; mm < i; mm++) acc = potrf_mma_nn(&A[16 * i][16 * mm], &X[16 * mm][16 * j], acc, lane);
                     potrf_wave_sync();
@@ -250,17 +362,7 @@ __device__ __forceinline__ void potrf_block_lds(double (*A)[kPS], double (*X)[kP
         __syncthreads();
     }
     SO_POTRF_MARK(25);
-}
-
-// the inverse factor as a full row-major 96x96 block in HBM (zeros above the diagonal): what the panel GEMM reads
-__device__ __forceinline__ void potrf_store_inverse(double (*X)[kPS], double* __restrict__ Linv) {
-    for (int i = threadIdx.x; i < kDNB * (kDNB / 2); i += 256) {
-        const int r = i / (kDNB / 2), c = 2 * (i - r * (kDNB / 2));
-        double2 x;
-        const bool low = (c >> 4) <= (r >> 4);  // tiles above the diagonal are zero (and were never written in LDS)
-        x.x = low ? X[r][c] : 0.0; x.y = low ? X[r][c + 1] : 0.0;
-        *reinterpret_cast<double2*>(Linv + (size_t)r * kDNB + c) = x;
-    }
+    potrf_store_inverse_row(X, Linv, kPT - 1, tid, 256);
 }
 
 __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
@@ -279,8 +381,7 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
         A[r][c] = v.x; A[r][c + 1] = v.y;
     }
     __syncthreads();
-    potrf_block_lds(A, X, &s_bad);
-    potrf_store_inverse(X, d.dense_ws + (size_t)k * kDNB * kDNB);
+    potrf_block_lds(A, X, &s_bad, d.dense_ws + (size_t)k * kDNB * kDNB);
     SO_POTRF_MARK(26);
     if (tid == 0 && s_bad) d.partial[kBaSolveOk] = 0.0;
 }
@@ -372,7 +473,7 @@ __global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev 
     SO_POTRF_MARK(0);
     if (wave == 0) {
         double* t0 = mtile(s_tiles, 0, 0);
-        if (!potrf_diag16<kMS>(t0, s_lastL, t0, lane) && lane == 0) s_bad = 1;
+        if (!potrf_diag16<kMS>(t0, NT == 1 ? s_lastL : nullptr, t0, lane) && lane == 0) s_bad = 1;
     }
     __syncthreads();
     // update waves: 1, 2, 3, 5, 6, 7 - wave 4 shares wave 0's SIMD and stays out of the pivot chain's way
@@ -399,7 +500,7 @@ __global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev 
             for (int reg = 0; reg < 4; reg++) t[(crow + 4 * reg) * kMS + ccol] -= acc[reg];
             potrf_wave_sync();
             // (the right-hand-side row's pivot beta - y.y and the identity padding are positive by construction)
-            if (!potrf_diag16<kMS>(t, s_lastL, t, lane) && lane == 0) s_bad = 1;
+            if (!potrf_diag16<kMS>(t, jb + 1 == tr ? s_lastL : nullptr, t, lane) && lane == 0) s_bad = 1;
             SO_POTRF_MARK(3 + 3 * jb);
         } else if (uw >= 0) {
             for (int t = uw; t < m * (m + 1) / 2 - 1; t += 6) {  // tile 0 of the triangle is wave 0's
@@ -513,7 +614,7 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
     // Two code paths with the same barrier sequence: wave 0 only ever factors pivot tiles and runs the substitution
     // (its registers belong to potrf_diag16), waves 1-15 only ever hold tiles (their registers belong to C).
     if (wave == 0) {
-        if (!potrf_diag16<kMS>(s_diag[0], s_lastL, s_diag[0], lane) && lane == 0) s_bad = 1;
+        if (!potrf_diag16<kMS>(s_diag[0], NT == 1 ? s_lastL : nullptr, s_diag[0], lane) && lane == 0) s_bad = 1;
         __syncthreads();
         for (int jb = 0; jb + 1 < NT; jb++) {
             SO_POTRF_MARK(1 + 3 * jb);
@@ -525,7 +626,7 @@ __global__ __launch_bounds__(kRegThreads) void ba_solve_mfma_reg_kernel(BaDev d)
 #pragma unroll
             for (int r = 0; r < 4; r++) t[(crow + 4 * r) * kMS + ccol] -= acc[r];
             potrf_wave_sync();
-            if (!potrf_diag16<kMS>(t, s_lastL, t, lane) && lane == 0) s_bad = 1;
+            if (!potrf_diag16<kMS>(t, jb + 1 == tr ? s_lastL : nullptr, t, lane) && lane == 0) s_bad = 1;
             SO_POTRF_MARK(3 + 3 * jb);
             __syncthreads();
         }
@@ -1243,9 +1344,8 @@ __device__ __forceinline__ void flow_factor_tile(const BaDev& d, int I, int J, u
             }
     if (tid == 0) s_bad = 0;
     __syncthreads();
-    potrf_block_lds(A, X, &s_bad);
+    potrf_block_lds(A, X, &s_bad, d.dense_ws + (size_t)J * kDNB * kDNB);
     SO_FLOW_MARK(6);
-    potrf_store_inverse(X, d.dense_ws + (size_t)J * kDNB * kDNB);
     if (tid == 0 && s_bad) __hip_atomic_store(bad, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     flow_publish(&flags[self], epoch);
     SO_FLOW_MARK(7);

@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_marks), &dm, sizeof(dm));
     BaLm hl{}; hl.active = 1;
     BaLm* dl; hipMalloc(&dl, sizeof(BaLm)); hipMemcpy(dl, &hl, sizeof(BaLm), hipMemcpyHostToDevice);
-    BaDev d{}; d.n_free = nf; d.S = dS; d.bs = db; d.partial = dp; d.lm = dl; d.ldS = n;
+    BaDev d{}; d.stage = 1; d.n_free = nf; d.S = dS; d.bs = db; d.partial = dp; d.lm = dl; d.ldS = n;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int it = 0; it < 20; it++) {
