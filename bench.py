@@ -397,7 +397,16 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
             "batched": bool(L.get("batch_ms")),
             "batch": None if not L.get("batch_ms") else {"stage_and_launch_and_resolve_ms_per_keyframe": L["batch_ms"] / L["jobs"],
                                                           "launch_wait_resolve_ms_per_keyframe": L["batch_end_ms"] / L["jobs"],
-                                                          "kernels_ms_per_keyframe": L["batch_kernel_ms"] / L["jobs"]},
+                                                          "kernels_ms_per_keyframe": L["batch_kernel_ms"] / L["jobs"],
+                                                          # where the host time of the batch goes: staging the searches'
+                                                          # inputs (per group of calls), then enqueue / wait / resolve
+                                                          "stage_triangulation_searches_ms": L.get("stage_tri_ms", 0.0) / L["jobs"],
+                                                          "stage_fuse_into_neighbours_ms": L.get("stage_fuse_ms", 0.0) / L["jobs"],
+                                                          "stage_fuse_back_ms": L.get("stage_back_ms", 0.0) / L["jobs"],
+                                                          "enqueue_ms": L.get("batch_enqueue_ms", 0.0) / L["jobs"],
+                                                          "wait_ms": L.get("batch_wait_ms", 0.0) / L["jobs"],
+                                                          "resolve_ms": (L["batch_end_ms"] - L.get("batch_enqueue_ms", 0.0)
+                                                                         - L.get("batch_wait_ms", 0.0)) / L["jobs"]},
             "feature_vector_ms_per_keyframe": L["node_ms"] / L["jobs"],
             "search_for_triangulation": {"calls_per_keyframe": L["tri_calls"] / L["jobs"], "host_ms_per_call": L["tri_ms"] / max(L["tri_calls"], 1),
                                          "match_kernel_ms_per_call": L["tri_kernel_ms"] / max(L["tri_calls"], 1),

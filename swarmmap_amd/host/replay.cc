@@ -301,7 +301,8 @@ void fundamental_and_epipole(const so_replay* r, const float* T1, const float* T
 }
 
 enum { kLmJobs = 0, kLmWallMs, kLmNodeMs, kLmTriCalls, kLmTriMs, kLmTriKernelMs, kLmTriMatches, kLmFuseCalls, kLmFuseMs,
-       kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries, kLmBatchMs, kLmBatchEndMs, kLmBatchKernelMs, kLmTriangMs, kLmTriangKernelMs, kLmNewPoints };
+       kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries, kLmBatchMs, kLmBatchEndMs, kLmBatchKernelMs, kLmTriangMs, kLmTriangKernelMs, kLmNewPoints,
+       kLmStageTriMs, kLmStageFuseMs, kLmStageBackMs, kLmBatchEnqueueMs, kLmBatchWaitMs };
 
 // CreateNewMapPoints' and SearchInNeighbors' matcher load for the new keyframe `c` (see the file header).
 int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
@@ -348,6 +349,7 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
     if (batch && so_matcher_batch_begin(m) != SO_OK) return SO_ERR_HIP;
     // ---- CreateNewMapPoints: SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false) per neighbour
     size_t jn = 0;
+    const double tc0 = now_ms();
     for (const auto& kf2 : r->lm_ring) {
         float F12[9], ex, ey;
         fundamental_and_epipole(r, c->T, kf2->T, F12, &ex, &ey);
@@ -372,6 +374,8 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         st[kLmTriCalls] += 1;
         jn++;
     }
+    st[kLmStageTriMs] = now_ms() - tc0;
+    const double td0 = now_ms();
     // ---- SearchInNeighbors: matcher.Fuse(pKFi, vpMapPointMatches) per neighbour (LocalMapping.cc:451-457) ...
     auto grow = [&](size_t slots) {
         if (slots > r->lm_stamp.size()) { r->lm_stamp.resize(slots + slots / 2 + 1024, -1); r->lm_cstamp.resize(r->lm_stamp.size(), -1); }
@@ -413,6 +417,8 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         st[kLmFusePoints] += n;
         jn++;
     }
+    st[kLmStageFuseMs] = now_ms() - td0;
+    const double te0 = now_ms();
     // ... then the neighbours' map points into the new keyframe: vpFuseCandidates, once each (:459-481)
     std::vector<float>&X = r->lm_cX, &N = r->lm_cN, &mx = r->lm_cmax, &mn = r->lm_cmin;  // (capacity kept from keyframe to keyframe)
     std::vector<uint8_t>&D = r->lm_cD, &ok = r->lm_cok;
@@ -458,9 +464,14 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         st[kLmFuseCalls] += 1;
         st[kLmFusePoints] += Q.n;
     }
+    st[kLmStageBackMs] = now_ms() - te0;
     if (batch) {
         const double ta = now_ms();
         if (so_matcher_batch_end(m) != SO_OK) return SO_ERR_HIP;
+        double ms4[4] = {0};
+        so_matcher_last_stats(m, ms4);
+        st[kLmBatchEnqueueMs] = ms4[0];
+        st[kLmBatchWaitMs] = ms4[1];
         so_matcher_last_kernel_ms(m, &kms);
         st[kLmBatchKernelMs] = kms;
         st[kLmBatchEndMs] = now_ms() - ta;

@@ -18,7 +18,8 @@ STAT = ("steps", "extract_ms", "m2_ms", "pose1_ms", "m1_ms", "pose2_ms", "pose3_
 
 LM_STAT = ("jobs", "wall_ms", "node_ms", "tri_calls", "tri_ms", "tri_kernel_ms", "tri_matches", "fuse_calls", "fuse_ms",
            "fuse_kernel_ms", "fused", "fuse_points", "tri_queries", "batch_ms", "batch_end_ms", "batch_kernel_ms",
-           "triangulate_ms", "triangulate_kernel_ms", "new_points")
+           "triangulate_ms", "triangulate_kernel_ms", "new_points", "stage_tri_ms", "stage_fuse_ms", "stage_back_ms",
+           "batch_enqueue_ms", "batch_wait_ms")
 
 
 def make_vocabulary(n=100, seed=20221001):

@@ -84,7 +84,7 @@ void run(const char* what, int per_iter) {
     const int iters = 500;
     for (int r = 0; r < 2; r++) hipLaunchKernelGGL(rate_kernel<MODE>, dim3(1), dim3(64), 0, 0, out, cyc, 0.5, 1e-3, iters);
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    printf("%-58s %.2f cycles per step of 16\n", what, (double)c / (iters * 16.0));
+    printf("%-58s %.2f cycles per instruction\n", what, (double)c / (iters * 16.0));
 }
 int main() {
     run<0>("v_fmac_f64_dpp row_newbcast, 16 independent:", 16);
