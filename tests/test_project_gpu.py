@@ -279,3 +279,71 @@ def test_resident_keyframes_give_the_same_answers(S, oracle):
     for k in kframes + [t[3] for t in tri]:
         k.close()
     m.close()
+
+
+def test_batch_shares_the_map_points_of_consecutive_fuse_calls(S, oracle):
+    """A keyframe's map points go into every neighbour's Fuse with the same arrays and a different `valid` mask
+    (LocalMapping.cc:451-457): inside a batch such calls refer to ONE staged copy of the arrays.  The answers must be those
+    of the calls made alone - with resident keyframes and host views, with a mask per call, and when the caller changes the
+    arrays in place between two calls of the batch (same pointers, other bytes: no sharing then)."""
+    from swarmmap_amd.matcher import KFrame
+    m = S.ORBmatcher(0.6, True)
+    base = synth.make_projection_case(400, 900, 1000, keyframe_bounds=True)
+    cases = []
+    for i in range(4):  # the same keyframe seen from four slightly different poses: every call has matches to lose
+        c = dict(base)
+        T = np.array(base["Tcw"], np.float32).copy()
+        T.reshape(3, 4)[:, 3] += np.float32(0.004 * i)
+        c["Tcw"] = T
+        cases.append(c)
+    mp = {k: np.ascontiguousarray(v).copy() for k, v in cases[0]["mp"].items()}
+    rng = np.random.default_rng(7)
+    masks = [(rng.random(len(mp["valid"])) < 0.8).astype(np.uint8) for _ in cases]
+    views = [_view(c["frame"], False) for c in cases]
+    kframes = [KFrame(m, v) for v in views]
+
+    def args(i, pts):
+        c = cases[i]
+        return (c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], pts, 3.0)
+
+    def with_mask(i):
+        mp["valid"][:] = masks[i]  # in place: the pointer stays, and `valid` is per call by contract
+        return mp
+
+    alone = [m.Fuse(views[i], *args(i, with_mask(i))) for i in range(4)]
+    for i in range(4):
+        on, obi, obd = oracle.fuse(views[i], oracle.camera(cases[i]["cam"]), cases[i]["Tcw"], cases[i]["log_scale_factor"],
+                                   cases[i]["inv_level_sigma2"], with_mask(i), 3.0)
+        assert alone[i][0] == on and np.array_equal(alone[i][1], obi) and np.array_equal(alone[i][2], obd)
+    assert min(a[0] for a in alone) > 100 and len({a[1].tobytes() for a in alone}) == 4
+    for resident in (True, False):
+        m.batch_begin()
+        held = []
+        for i in range(4):
+            pts = with_mask(i)
+            held.append(m.FuseKFrame(kframes[i], *args(i, pts)) if resident else m.Fuse(views[i], *args(i, pts)))
+        m.batch_end()
+        for h, a in zip(held, alone):
+            assert h[0].value == a[0] and np.array_equal(h[1], a[1]) and np.array_equal(h[2], a[2])
+    # the arrays change in place between two calls of one batch
+    moved = mp["Xw"].copy()
+    moved[::3] += 0.02
+    want_moved = None
+    keep = mp["Xw"].copy()
+    mp["Xw"][:] = moved
+    want_moved = m.Fuse(views[1], *args(1, with_mask(1)))
+    mp["Xw"][:] = keep
+    m.batch_begin()
+    h0 = m.FuseKFrame(kframes[0], *args(0, with_mask(0)))
+    mp["Xw"][:] = moved
+    h1 = m.FuseKFrame(kframes[1], *args(1, with_mask(1)))
+    mp["Xw"][:] = keep
+    h2 = m.FuseKFrame(kframes[2], *args(2, with_mask(2)))
+    m.batch_end()
+    assert h0[0].value == alone[0][0] and np.array_equal(h0[1], alone[0][1])
+    assert h1[0].value == want_moved[0] and np.array_equal(h1[1], want_moved[1]) and not np.array_equal(h1[1], alone[1][1])
+    assert h2[0].value == alone[2][0] and np.array_equal(h2[1], alone[2][1])
+    for k in kframes:
+        k.close()
+    m.close()
+
