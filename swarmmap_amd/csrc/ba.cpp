@@ -82,8 +82,8 @@ int flow_resident_budget(int device) {
 }
 
 // Host staging on a few threads: fn(part, n_parts) works on its share.  The workers belong to the solver context and
-// are started by the first problem large enough to want them (from 6 k observations; at LBA-M's 17-21 k the staging is
-// 0.17 ms of a 1.4 ms call on one thread, 0.12 on four); handing a job over costs a few microseconds.
+// are started by the first problem large enough to want them (from ~30 k observations - a 40-keyframe window - the
+// staging is a sixth of the call); handing a job over costs a few microseconds.
 class StagingPool {
 public:
     ~StagingPool() { stop(); }
@@ -747,10 +747,13 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     const double tS4 = now_ms();
     // the observations in landmark order + the per-keyframe lists; big maps on `parts` threads, each owning a range of
     // landmarks (so a landmark's observations - and the duplicate check - stay with one thread)
-    // (measured on a 21 k-edge window, LBA-M's size: this part of the staging 0.133 ms on one thread, 0.094 on two, 0.075 on
-    //  four, no better on six; 38 k edges: 0.37 / 0.20 / 0.09; SWARMORB_BA_PARTS overrides)
+    // (SWARMORB_BA_PARTS overrides.  On a 21 k-edge window, LBA-M's size, alone on the box this part of the staging is
+    //  0.133 ms on one thread, 0.094 on two, 0.075 on four - but in the bench, next to a tracking thread and the matcher
+    //  job, four threads LOSE: windows 1.40-1.62 ms against 1.44-1.46, the keyframe's matcher job 0.90-0.98 ms against
+    //  0.73-0.82, 2.06 k frames/s against 2.22 k over three runs each: the wake-ups cost the neighbours more than the
+    //  shorter fill returns.  Threads from 30 k observations on, as before.)
     static const int parts_env = getenv("SWARMORB_BA_PARTS") ? atoi(getenv("SWARMORB_BA_PARTS")) : 0;
-    const int parts = parts_env > 0 ? std::min(parts_env, 16) : nE >= 12000 ? 4 : nE >= 6000 ? 2 : 1;
+    const int parts = parts_env > 0 ? std::min(parts_env, 16) : nE >= 150000 ? 4 : nE >= 30000 ? 3 : 1;
     std::vector<int> part_lm((size_t)parts + 1, 0);  // landmark ranges with about equal numbers of observations
     for (int t = 1; t < parts; t++) {
         const int target = (int)((long long)nE * t / parts);
