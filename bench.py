@@ -620,6 +620,21 @@ def gba_records(dev, cases):
     return out
 
 
+def _cpu_ranges(cpus):
+    """{0,1,2,5} -> ["0-2", "5"]"""
+    out, run = [], []
+    for c in sorted(cpus):
+        if run and c == run[-1] + 1:
+            run.append(c)
+        else:
+            if run:
+                out.append("%d-%d" % (run[0], run[-1]) if len(run) > 1 else str(run[0]))
+            run = [c]
+    if run:
+        out.append("%d-%d" % (run[0], run[-1]) if len(run) > 1 else str(run[0]))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -650,6 +665,11 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = local_rank if distributed else 0
     torch.cuda.set_device(dev)
+    torch.cuda.synchronize()  # the runtime's threads exist from here on
+    from swarmmap_amd import _lib as _so_lib
+    # thread placement: this rank's threads behind one L3 (one per agent of the rank) next to its GPU; "pinned_cpus" in
+    # the JSON line says which (null: left to the OS - SWARMORB_NO_PIN=1 or a single-node host)
+    pinned_cpus = _so_lib.pin_process_near_device(dev, max(1, args.agents_per_gpu))
 
     import ctypes
     libc = ctypes.CDLL(None)
@@ -736,6 +756,7 @@ def main():
             "host_loop": "c++ (swarmmap_amd/host/replay.cc)" + (", %d agents in lockstep on one thread (so_fleet_run)" % A
                                                                   if args.lockstep and A > 1 else ""),
             "fps_per_agent": steps / dt, "agents_per_gpu": A,
+            "pinned_cpus": None if not pinned_cpus else ",".join(_cpu_ranges(pinned_cpus)),
             "config": dict({
                 "workload": ("BASELINE.json configs[1]+[2] on one GPU per agent: 752x480 EuRoC-sized stream seen through "
                              "the EuRoC lens model, each step = host->HBM image upload + HIP ORB extract (nFeatures %d) + "

@@ -37,6 +37,17 @@ const char* so_status_string(int status);
 const char* so_last_error(void);
 /* number of visible HIP devices (0 when there is no GPU); never throws */
 int so_device_count(void);
+/* The host CPUs next to a device, as a cpulist ("0-7,128-135").  slot < 0: the whole NUMA node the device's PCI function
+ * hangs off (/sys/bus/pci/devices/<bus id>/numa_node, /sys/devices/system/node/node<N>/cpulist).  slot >= 0: ONE group
+ * of that node's CPUs that share a last-level cache (cache/index3/shared_cpu_list: a CCD of 8 cores on the EPYC hosts),
+ * group number slot modulo the number of groups - so that the threads feeding a GPU (tracking, local mapping, the
+ * runtime's helpers) sit behind one L3 and next to the device, and several agents get different groups.  Measured with
+ * bench.py on a two-socket EPYC 9575F box: unpinned 2.21-2.25 k frames/s, the whole node the same, one CCD 2.34-2.35 k,
+ * and a third of the run-to-run spread.  The replay loop of bench.py pins its two threads this way (SWARMORB_NO_PIN=1:
+ * leave placement to the OS).  SO_ERR_NO_DEVICE if the device does not exist, SO_ERR_INVALID_ARG for a null / too small
+ * buffer, SO_ERR_NUMERIC when the kernel does not say (single-node hosts report node -1: nothing to pin to).  No
+ * reference counterpart (the reference leaves thread placement to the OS). */
+int so_device_host_cpus(int device, int slot, char* cpulist, int capacity);
 /* By default the extractors created by one thread share one HIP stream and its matchers / frame contexts another (the
  * per-frame path of ONE agent is a chain: more streams only spread it over hardware queues).  A thread that drives
  * SEVERAL agents in lockstep wants their launches to overlap: after so_runtime_private_streams(1) every extractor and

@@ -86,3 +86,48 @@ def check(status):
 
 def device_count():
     return int(load_library().so_device_count())
+
+
+def device_host_cpus(device, slot=-1):
+    """cpulist next to a device as a set of CPU numbers: the whole NUMA node (slot < 0) or one last-level-cache group of it
+    (so_device_host_cpus, include/swarmorb.h).  None when the host does not say."""
+    lib = load_library()
+    lib.so_device_host_cpus.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(1024)
+    if lib.so_device_host_cpus(int(device), int(slot), buf, len(buf)) != 0:
+        return None
+    cpus = set()
+    for piece in buf.value.decode().split(","):
+        lo, _, hi = piece.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus or None
+
+
+def pin_process_near_device(device, groups=1):
+    """Every thread of this process (the caller, the HIP runtime's helpers, whatever they start later) onto `groups`
+    last-level-cache groups of the NUMA node next to the device, starting with group number `device`.  Call after the first
+    HIP call of the process, when the runtime's threads exist.  The threads of one agent talk to each other and to the
+    GPU through pinned memory all the time: on a two-socket host with sixteen L3 domains the OS's placement costs ~5 % of
+    bench.py's frame rate and most of its run-to-run spread.  SWARMORB_NO_PIN=1 (or a host that does not say) leaves
+    placement alone.  Returns the CPU set, or None."""
+    import os
+    if os.environ.get("SWARMORB_NO_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = set()
+    for g in range(max(1, int(groups))):
+        got = device_host_cpus(device, int(device) + g)
+        if got:
+            cpus |= got
+    try:
+        cpus &= os.sched_getaffinity(0)  # never ask for CPUs a cgroup / taskset took away from the process
+        if not cpus:
+            return None
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except OSError:
+                pass  # a thread that ended meanwhile, or one the kernel does not let us move
+    except OSError:
+        return None
+    return cpus
+

@@ -2,7 +2,12 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cctype>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
 
 #include "so_common.h"
 
@@ -96,6 +101,63 @@ int so_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int so_device_host_cpus(int device, int slot, char* cpulist, int capacity) {
+    if (!cpulist || capacity < 2) return SO_ERR_INVALID_ARG;
+    cpulist[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SO_ERR_NO_DEVICE;
+    char bus[64] = {0};
+    SO_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device));
+    for (char* c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);  // sysfs spells the bus id in lower case
+    auto read_line = [](const std::string& path, std::string& out) {
+        out.clear();
+        FILE* f = fopen(path.c_str(), "r");
+        if (!f) return false;
+        char buf[1024];
+        const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+        fclose(f);
+        if (!got) return false;
+        out = buf;
+        while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
+        return !out.empty();
+    };
+    std::string line;
+    if (!read_line(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", line)) return SO_ERR_NUMERIC;
+    const int node = atoi(line.c_str());
+    if (node < 0) return SO_ERR_NUMERIC;
+    std::string node_cpus;
+    if (!read_line("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", node_cpus)) return SO_ERR_NUMERIC;
+    std::string chosen = node_cpus;
+    if (slot >= 0) {  // the distinct last-level-cache groups of the node's CPUs, in CPU order
+        std::vector<std::string> groups;
+        const char* p = node_cpus.c_str();
+        while (*p) {
+            char* end = nullptr;
+            const long a = strtol(p, &end, 10);
+            if (end == p) break;
+            long b = a;
+            p = end;
+            if (*p == '-') {
+                b = strtol(p + 1, &end, 10);
+                if (end == p + 1) break;
+                p = end;
+            }
+            for (long c = a; c <= b; c++) {
+                std::string g;
+                if (!read_line("/sys/devices/system/cpu/cpu" + std::to_string(c) + "/cache/index3/shared_cpu_list", g)) continue;
+                bool seen = false;
+                for (const std::string& have : groups) seen = seen || have == g;
+                if (!seen) groups.push_back(g);
+            }
+            if (*p == ',') p++;
+        }
+        if (!groups.empty()) chosen = groups[(size_t)slot % groups.size()];
+    }
+    if ((int)chosen.size() + 1 > capacity) return SO_ERR_INVALID_ARG;
+    memcpy(cpulist, chosen.c_str(), chosen.size() + 1);
+    return SO_OK;
 }
 
 }  // extern "C"

@@ -27,6 +27,7 @@
 // this one, frame by frame, with that loop run over the CPU oracle.
 // Built by csrc/Makefile into libswarmorb_replay.so with g++.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -38,6 +39,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <pthread.h>
+#include <sched.h>
 
 #include "../../include/swarmorb.h"
 
@@ -144,6 +148,7 @@ struct LmJob {
 
 struct so_replay {
     int device = 0, width = 0, height = 0, lba_every = 5;
+    std::string host_cpus;  // the CPUs this agent's threads are pinned to (so_device_host_cpus); empty: no pinning
     int keyframe_every = 8, local_keyframes = 0, third_pose = 1;
     double keyframe_ratio = 0.7, plane_z = 2.0;
     so_camera cam{};
@@ -578,7 +583,48 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
     return SO_OK;
 }
 
+// The calling thread onto the agent's CPUs: one group of cores behind one L3 on the NUMA node next to its GPU.  The
+// loop's two threads hand keyframes to each other and both touch pinned staging memory and ring doorbells all the
+// time; left to the OS on a two-socket, 16-CCD box they cost 5 % of the frame rate and most of the run-to-run spread
+// (include/swarmorb.h, so_device_host_cpus).  SWARMORB_NO_PIN=1 leaves placement to the OS.
+void pin_to_device_node(const so_replay* r) {
+    if (r->host_cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n_set = 0;
+    const char* p = r->host_cpus.c_str();
+    while (*p) {  // "a-b,c,d-e"
+        char* end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            if (end == p + 1) break;
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0) {
+                CPU_SET((int)c, &set);
+                n_set++;
+            }
+        if (*p == ',') p++;
+    }
+    // inside what the thread is allowed already (a harness that placed the whole process knows better than a guess by
+    // creation order: bench.py pins every thread of the rank, the HIP runtime's included, to the agents' groups)
+    cpu_set_t now, both;
+    CPU_ZERO(&now);
+    if (pthread_getaffinity_np(pthread_self(), sizeof(now), &now) == 0) {
+        CPU_AND(&both, &set, &now);
+        if (CPU_COUNT(&both) == 0) return;
+        set = both;
+    }
+    if (n_set > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+}
+
 void mapper_loop(so_replay* r) {
+    pin_to_device_node(r);
     for (;;) {
         int timed;
         std::shared_ptr<KfSnap> kf;
@@ -761,6 +807,13 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
     }
     if (const char* e = getenv("SWARMORB_LM_BATCH")) r->lm_batch = atoi(e) != 0;
     if (const char* e = getenv("SWARMORB_LM_RESIDENT")) r->lm_resident = atoi(e) != 0;
+    if (!getenv("SWARMORB_NO_PIN")) {
+        // one last-level-cache group of the device's NUMA node per agent: GPU d's first agent takes group d, the next
+        // agents of this process the groups behind it
+        static std::atomic<int> created{0};
+        char cpus[512];
+        if (so_device_host_cpus(device, device + created.fetch_add(1), cpus, (int)sizeof(cpus)) == SO_OK) r->host_cpus = cpus;
+    }
     r->mapper = std::thread(mapper_loop, r);
     *out = r;
     return SO_OK;
@@ -1246,6 +1299,7 @@ static int run_one_step(so_replay* r, int t, int timed) {
 
 int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
     if (!r || !r->in_flight || r->frames.empty()) return SO_ERR_INVALID_ARG;
+    pin_to_device_node(r);  // (the tracking thread is whoever calls)
     for (int t = first_t; t < first_t + n_steps; t++) {
         const int rc = run_one_step(r, t, timed);
         if (rc) return rc;
@@ -1262,6 +1316,7 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
 int so_replay_run_live(so_replay* r, int first_t, int n_steps, float* pose_ms, float* step_ms) {
     if (!r || r->frames.empty() || first_t < 0 || first_t + n_steps > (int)r->frames.size()) return SO_ERR_INVALID_ARG;
     r->live = true;
+    pin_to_device_node(r);
     int rc = SO_OK;
     for (int t = first_t; t < first_t + n_steps && rc == SO_OK; t++) {
         const double T0 = now_ms();
@@ -1284,6 +1339,7 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
     for (int a = 0; a < n_agents; a++)
         if (!agents[a] || !agents[a]->in_flight || agents[a]->frames.empty()) return SO_ERR_INVALID_ARG;
     const size_t A = (size_t)n_agents;
+    pin_to_device_node(agents[0]);
     std::vector<so_pose_problem> probs(A);
     std::vector<int32_t> inl(A), info(2 * A);
     std::vector<int> live;
