@@ -395,6 +395,16 @@ void so_kframe_destroy(so_kframe* k);
 int so_fuse_kframe(so_matcher* m, const so_kframe* KF, const so_camera* cam, const float* Tcw12, float log_scale_factor,
                    const float* inv_level_sigma2, const so_mappoint_view* mp, float th, int32_t* best_idx, int32_t* best_dist,
                    int32_t* n_fused, const so_window_queries* queries_out);
+/* so_fuse_kframe with the map points read where they already are: rows slots[i] of a device-resident map table
+ * (so_map below: mWorldPos, mNormalVector, mfMax/MinDistance, mDescriptor by slot).  A keyframe's Fuse calls then stage
+ * 5 bytes per map point (slot + valid) instead of 65.  slots[i] outside [0, so_map_size) makes point i inactive; valid
+ * may be NULL (= all 1).  The map may be written by another thread meanwhile as long as rows this call names are not
+ * (appends are fine; the call holds the table in place while its kernels run).  Same results as so_fuse_kframe with the
+ * rows' values as arrays.  Batchable. */
+typedef struct so_map so_map;
+int so_fuse_kframe_map(so_matcher* m, const so_kframe* KF, const so_camera* cam, const float* Tcw12, float log_scale_factor,
+                       const float* inv_level_sigma2, const so_map* map, int32_t n, const int32_t* slots, const uint8_t* valid,
+                       float th, int32_t* best_idx, int32_t* best_dist, int32_t* n_fused, const so_window_queries* queries_out);
 /* keyframe 2 resident (its angles, octaves, descriptors, feature vector, scale tables were given at creation); free2[i]
  * = !pKF2->GetMapPoint(i) at the time of the call */
 int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x1, const float* y1, const float* angle1,
@@ -569,7 +579,7 @@ int so_search_by_projection_lastframe_dframe(so_matcher* m, const so_dframe* cur
  * mNormalVector, mfMaxDistance, mfMinDistance, mDescriptor), indexed by a slot the caller assigns (append order).
  * Written at keyframe rate (new points, SetWorldPos / UpdateNormalAndDepth / ComputeDistinctiveDescriptors results),
  * read every frame by the tracking searches below.  Writes are complete when the call returns. */
-typedef struct so_map so_map;
+/* (so_map is declared above, with so_fuse_kframe_map) */
 int so_map_create(int device, so_map** out);
 void so_map_destroy(so_map* map);
 int so_map_size(const so_map* map);

@@ -194,7 +194,8 @@ int reserve(so_map* m, int slots) {
     // 288 GB of HBM: the table grows geometrically and is never shrunk (a 10^6-point map is 64 MB)
     size_t cap = m->capacity ? (size_t)m->capacity : 65536;
     while (cap < (size_t)slots) cap *= 2;
-    const size_t old = (size_t)m->size;
+    const size_t old = (size_t)m->size.load();
+    std::unique_lock<std::shared_timed_mutex> moving(m->grow_mu);  // no other thread's search is reading the old tables
     int rc;
     if ((rc = grow(&m->d_Xw, 3 * old, 3 * cap, m->stream))) return rc;
     if ((rc = grow(&m->d_normal, 3 * old, 3 * cap, m->stream))) return rc;
@@ -418,7 +419,7 @@ void so_map_destroy(so_map* m) {
     delete m;
 }
 
-int so_map_size(const so_map* m) { return m ? m->size : 0; }
+int so_map_size(const so_map* m) { return m ? m->size.load() : 0; }
 
 int so_map_write(so_map* m, int32_t first, int32_t n, const float* Xw, const float* normal, const float* max_dist,
                  const float* min_dist, const uint8_t* desc) {

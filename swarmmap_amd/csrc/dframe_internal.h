@@ -11,6 +11,10 @@
 // so_map: SoA table indexed by map slot: Xw float3 | normal float3 | max_dist | min_dist | desc 32 B.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <mutex>
+#include <shared_mutex>
 #include <stdint.h>
 
 #include <vector>
@@ -63,7 +67,12 @@ struct so_dframe {
 
 struct so_map {
     int device = 0;
-    int size = 0, capacity = 0;
+    std::atomic<int> size{0};  // (read by a local-mapping thread's searches while the tracking thread appends)
+    int capacity = 0;
+    // The tables move when they grow.  A search that reads them from ANOTHER thread than the one that writes the map
+    // (so_fuse_kframe_map in a local-mapping thread) holds this shared from taking the pointers until its kernels are
+    // done; reserve() takes it exclusively for a reallocation (rare: the capacity doubles).
+    std::shared_timed_mutex grow_mu;
     float* d_Xw = nullptr;      // 3 per slot
     float* d_normal = nullptr;  // 3 per slot
     float* d_max = nullptr;

@@ -116,6 +116,8 @@ struct ProjectSrc {
     const float* max_dist;  // mfMaxDistance
     const float* min_dist;  // mfMinDistance
     const uint8_t* valid;   // the caller's object-graph gates
+    const int32_t* slot;    // null: point i is row i of the arrays above; else row slot[i] (the arrays are a so_map's
+    int n_rows;             // tables with n_rows rows; a slot outside [0, n_rows) makes the point inactive)
     int n;
     float A[12], B[12];     // [R | t] rows; B only with kPChain
     float Ow[3];            // camera centre the distances are measured from (not with kPChain)
@@ -138,7 +140,8 @@ struct BatchJobDev {
     ProjectSrc S;            // used when project != 0: the job's queries are produced on the device
     MatchQuery* q;           // nq records (read by the search; written by the projection when project != 0)
     MatchQueryW* qw;         // compact copies for the host (project != 0), host-mapped
-    const uint4* qdesc;      // nq x 32 B
+    const uint4* qdesc;      // nq x 32 B (row qslot[i] of it when qslot is not null: a so_map's descriptor table)
+    const int32_t* qslot;
     uint32_t* keys;          // nq x K, host-mapped
     int32_t* count;          // nq, host-mapped
     int nq, K, project, pad;

@@ -274,7 +274,10 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F_arg, c
         for (int k = lane; k < K; k += 64) out_keys[(size_t)qi * kk + k * kq] = 0xFFFFFFFFu;
         return;
     }
-    const uint4* qsrc = (MODE == 2 || MODE == 3) ? T.desc + 2 * (size_t)slot : qdesc + 2 * (size_t)qi;
+    // (a batched job whose map points live in a so_map: the descriptor is row qslot[qi] of the map's table; the query
+    //  is only active when that slot is a row of the table)
+    const size_t qrow = (MODE == 4 && job->qslot) ? (size_t)job->qslot[qi] : (size_t)qi;
+    const uint4* qsrc = (MODE == 2 || MODE == 3) ? T.desc + 2 * (size_t)slot : qdesc + 2 * qrow;
     const uint4 qd0 = qsrc[0], qd1 = qsrc[1];
     const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -359,7 +362,13 @@ __device__ __forceinline__ void project_one(const ProjectSrc& S, int i, MatchQue
     Q.max_dist = S.q_max_dist;
     Q.flags = S.qflags;
     bool ok = S.valid[i] != 0;
-    const float P[3] = {S.Xw[3 * (size_t)i], S.Xw[3 * (size_t)i + 1], S.Xw[3 * (size_t)i + 2]};
+    size_t j = (size_t)i;  // row of the point's fields
+    if (S.slot) {
+        const int sl = S.slot[i];
+        if (sl < 0 || sl >= S.n_rows) ok = false;
+        j = ok ? (size_t)sl : 0;
+    }
+    const float P[3] = {S.Xw[3 * j], S.Xw[3 * j + 1], S.Xw[3 * j + 2]};
     float Pc[3];
     track_camera_point(S.A, P, Pc);  // Rcw * p3Dw + tcw
     if (S.flags & kPChain) {         // p3Dc2 = sR21 * p3Dc1 + t21
@@ -384,7 +393,7 @@ __device__ __forceinline__ void project_one(const ProjectSrc& S, int i, MatchQue
         v = S.fy * y + S.cy;
         if (!(u >= S.bounds[0] && u < S.bounds[1] && v >= S.bounds[2] && v < S.bounds[3])) ok = false;  // IsInImage
     }
-    const float max_d = S.max_dist[i], min_d = S.min_dist[i];
+    const float max_d = S.max_dist[j], min_d = S.min_dist[j];
     const float maxD = 1.2f * max_d, minD = 0.8f * min_d;
     float PO[3] = {Pc[0], Pc[1], Pc[2]};  // SearchBySim3 measures the camera-frame point
     if (!(S.flags & kPChain)) {
@@ -394,8 +403,8 @@ __device__ __forceinline__ void project_one(const ProjectSrc& S, int i, MatchQue
     const float dist = (float)sqrt(n2);
     if (dist < minD || dist > maxD) ok = false;
     if (S.flags & kPAngleGate) {
-        const double dot = (double)PO[0] * (double)S.normal[3 * (size_t)i] + (double)PO[1] * (double)S.normal[3 * (size_t)i + 1] +
-                           (double)PO[2] * (double)S.normal[3 * (size_t)i + 2];
+        const double dot = (double)PO[0] * (double)S.normal[3 * j] + (double)PO[1] * (double)S.normal[3 * j + 1] +
+                           (double)PO[2] * (double)S.normal[3 * j + 2];
         if (dot < 0.5 * (double)dist) ok = false;
     }
     int nScale = 0;

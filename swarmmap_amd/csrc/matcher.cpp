@@ -203,6 +203,8 @@ struct so_matcher {
         so::ProjectSrc S{};
         size_t off_xw = 0, off_nrm = 0, off_maxd = 0, off_mind = 0, off_valid = 0;
         size_t mp_base = 0;      // block that holds the map points' fields and descriptors (an earlier job's when shared)
+        const so_map* map = nullptr;  // the fields and descriptors are rows of this device-resident table instead:
+        size_t off_slot = 0;          // the staged block holds [slots | valid]
         std::vector<int> perm;
         const so_kframe* ext = nullptr;  // candidates read from an HBM-resident keyframe instead of the staged block
         int ext_layout = 0;              // 0: grid order, 1: vocabulary-node order
@@ -506,7 +508,8 @@ int batch_flush(so_matcher* m);
 // offsets recorded in m) joins the batch: its block is copied behind the others, its outputs are deferred to `resolve`.
 int batch_defer(so_matcher* m, size_t staged_end, int nq, int K, const ProjectSrc* S, const size_t* mp_offsets5,
                 std::function<int(const uint32_t*, const int32_t*, const MatchQueryW*, const std::vector<int>&)> resolve,
-                const so_kframe* ext = nullptr, int ext_layout = 0, const so_mappoint_view* mp = nullptr, bool mp_shared = false) {
+                const so_kframe* ext = nullptr, int ext_layout = 0, const so_mappoint_view* mp = nullptr, bool mp_shared = false,
+                const so_map* map = nullptr, size_t off_slot = 0) {
     int rc;
     if (m->jobs.size() == kBatchMaxJobs && (rc = batch_flush(m))) return rc;
     so_matcher::BatchJob J;
@@ -527,6 +530,8 @@ int batch_defer(so_matcher* m, size_t staged_end, int nq, int K, const ProjectSr
         J.S = *S;
         J.off_xw = mp_offsets5[0]; J.off_nrm = mp_offsets5[1]; J.off_maxd = mp_offsets5[2]; J.off_mind = mp_offsets5[3];
         J.off_valid = mp_offsets5[4];
+        J.map = map;
+        J.off_slot = off_slot;
         J.mp_base = mp_shared ? m->mp_share.base : J.base;
         if (mp_shared) {
             J.off_qdesc = m->mp_share.off_qdesc;
@@ -569,6 +574,25 @@ int batch_flush(so_matcher* m) {
     if ((rc = m->db_in.ensure(total))) return rc;
     if ((rc = m->db_q.ensure(m->dq_used + 256))) return rc;
     if ((rc = m->hb_out.ensure(m->out_used + 256))) return rc;
+    // maps read by this batch: their tables stay where they are until the kernels are done
+    std::vector<const so_map*> maps;
+    for (const so_matcher::BatchJob& J : m->jobs)
+        if (J.map && std::find(maps.begin(), maps.end(), J.map) == maps.end()) maps.push_back(J.map);
+    struct MapLocks {
+        std::vector<const so_map*>& v;
+        size_t held = 0;
+        explicit MapLocks(std::vector<const so_map*>& maps_) : v(maps_) {
+            for (const so_map* mp : v) {
+                const_cast<so_map*>(mp)->grow_mu.lock_shared();
+                held++;
+            }
+        }
+        void release() {
+            for (size_t i = 0; i < held; i++) const_cast<so_map*>(v[i])->grow_mu.unlock_shared();
+            held = 0;
+        }
+        ~MapLocks() { release(); }
+    } map_locks(maps);
     BatchGridDev* grid = (BatchGridDev*)m->hb_in.p;
     BatchJobDev* tab = (BatchJobDev*)((uint8_t*)m->hb_in.p + kBatchGridBytes);
     uint8_t* dbase = (uint8_t*)m->db_in.p + kBatchTableBytes;
@@ -609,6 +633,7 @@ int batch_flush(so_matcher* m) {
         D.F.grid_min_y = J.grid_min_y;
         const uint8_t* mb = dbase + J.mp_base;
         D.qdesc = (const uint4*)((J.project ? mb : b) + J.off_qdesc);
+        D.qslot = nullptr;
         D.keys = (uint32_t*)((uint8_t*)m->hb_out.dev + J.keys_off);
         D.count = (int32_t*)((uint8_t*)m->hb_out.dev + J.cnt_off);
         D.nq = J.nq; D.K = J.K; D.project = J.project ? 1 : 0;
@@ -619,6 +644,18 @@ int batch_flush(so_matcher* m) {
             D.S.max_dist = (const float*)(mb + J.off_maxd);
             D.S.min_dist = (const float*)(mb + J.off_mind);
             D.S.valid = b + J.off_valid;
+            D.S.slot = nullptr;
+            D.S.n_rows = 0;
+            if (J.map) {  // (its tables cannot move before the wait below: batch_flush holds the map's grow lock shared)
+                D.S.Xw = J.map->d_Xw;
+                D.S.normal = J.map->d_normal;
+                D.S.max_dist = J.map->d_max;
+                D.S.min_dist = J.map->d_min;
+                D.S.slot = (const int32_t*)(b + J.off_slot);
+                D.S.n_rows = J.map->size.load();
+                D.qdesc = (const uint4*)J.map->d_desc;
+                D.qslot = D.S.slot;
+            }
             D.S.n = J.nq;
             D.q = (MatchQuery*)((uint8_t*)m->db_q.p + J.q_off);
             D.qw = (MatchQueryW*)((uint8_t*)m->hb_out.dev + J.qw_off);
@@ -644,6 +681,7 @@ int batch_flush(so_matcher* m) {
     SO_HIP(hipGetLastError());
     const auto t1 = std::chrono::steady_clock::now();
     SO_HIP(hipStreamSynchronize(s));
+    map_locks.release();
     const auto t2 = std::chrono::steady_clock::now();
     m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
     m->stat[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
@@ -2401,6 +2439,74 @@ int so_fuse_kframe(so_matcher* m, const so_kframe* KF, const so_camera* cam, con
         };
         const size_t offs[5] = {P.off_xw, P.off_nrm, P.off_maxd, P.off_mind, P.off_valid};
         return batch_defer(m, P.staged_end, n, 1, &S, offs, std::move(resolve), KF, 0, mp, P.shared);
+    });
+}
+
+int so_fuse_kframe_map(so_matcher* m, const so_kframe* KF, const so_camera* cam, const float* Tcw12, float log_scale_factor,
+                       const float* inv_level_sigma2, const so_map* map, int32_t n, const int32_t* slots, const uint8_t* valid,
+                       float th, int32_t* best_idx, int32_t* best_dist, int32_t* n_fused, const so_window_queries* queries_out) {
+    if (!m || !KF || !cam || !Tcw12 || !inv_level_sigma2 || !map || n < 0 || !n_fused) return SO_ERR_INVALID_ARG;
+    if (n > 0 && (!slots || !best_idx || !best_dist)) return SO_ERR_INVALID_ARG;
+    if (KF->device != m->device || map->device != m->device) {
+        last_error_ref() = "resident keyframe / map lives on another device";
+        return SO_ERR_INVALID_ARG;
+    }
+    SO_HIP(hipSetDevice(m->device));
+    (void)take_reuse(m);
+    *n_fused = 0;
+    for (int i = 0; i < n; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+    }
+    if (n == 0) return SO_OK;
+    return as_batch(m, [&]() -> int {
+        ProjectSrc S{};
+        memcpy(S.A, Tcw12, sizeof(S.A));
+        camera_center(Tcw12, S.Ow);
+        S.flags = kPAngleGate;
+        S.fx = cam->fx; S.fy = cam->fy; S.cx = cam->cx; S.cy = cam->cy;
+        S.bounds[0] = KF->min_x; S.bounds[1] = KF->max_x; S.bounds[2] = KF->min_y; S.bounds[3] = KF->max_y;
+        for (int l = 0; l < 8; l++) S.scale[l] = KF->scale[l];
+        S.nlevels = KF->nlevels;
+        S.log_scale_factor = log_scale_factor;
+        S.th = th;
+        S.level_above = 0;
+        S.qflags = kQChi2Gate;
+        S.q_max_dist = 256;
+        adopt_kframe(m, KF, 0);
+        m->has_limit = false;
+        for (int l = 0; l < 8; l++) m->inv_sigma2[l] = l < KF->nlevels ? inv_level_sigma2[l] : 0.f;
+        m->frame_end = 0;  // nothing of the frame is staged; the block is [slots | valid]
+        int rc;
+        if (m->jobs.size() == kBatchMaxJobs && (rc = batch_flush(m))) return rc;
+        const size_t sn = (size_t)n, off_valid = align256(4 * sn), staged_end = align256(off_valid + sn);
+        if ((rc = m->h_in.ensure_keep(staged_end + 256, 0))) return rc;
+        uint8_t* hb = (uint8_t*)m->h_in.p;
+        memcpy(hb, slots, 4 * sn);
+        if (valid) memcpy(hb + off_valid, valid, sn);
+        else memset(hb + off_valid, 1, sn);
+        m->off_qdesc = 0;  // (the descriptors are the map's)
+        m->off_q = staged_end;
+        m->h_q.p = nullptr;
+        m->h_qdesc.p = nullptr;
+        so_window_queries qout{};
+        const bool want_q = queries_out != nullptr;
+        if (want_q) qout = *queries_out;
+        const int n_kf = KF->n_grid;
+        auto resolve = [n, n_kf, want_q, qout, best_idx, best_dist, n_fused](const uint32_t* keys, const int32_t*, const MatchQueryW* qw,
+                                                                             const std::vector<int>& perm) -> int {
+            export_queries(want_q ? &qout : nullptr, qw, n);
+            if (n_kf > 0)
+                for (int i = 0; i < n; i++)
+                    if (keys[i] != 0xFFFFFFFFu) {
+                        best_idx[i] = perm[(size_t)(keys[i] & 0xFFFFu)];
+                        best_dist[i] = (int32_t)(keys[i] >> 16);
+                    }
+            *n_fused = keep_within(n, best_idx, best_dist, TH_LOW);
+            return SO_OK;
+        };
+        const size_t offs[5] = {0, 0, 0, 0, off_valid};
+        return batch_defer(m, staged_end, n, 1, &S, offs, std::move(resolve), KF, 0, nullptr, false, map, 0);
     });
 }
 

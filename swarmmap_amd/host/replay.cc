@@ -165,6 +165,8 @@ struct so_replay {
     int lm_neighbours = 20;                // nn = 20, LocalMapping.cc:207,455 (monocular)
     bool lm_resident = true;               // neighbours are searched in HBM-resident form (SWARMORB_LM_RESIDENT=0: host views)
     bool lm_batch = true;                  // all searches of a keyframe as one so_matcher batch (SWARMORB_LM_BATCH=0: one by one)
+    bool lm_from_map = true;               // Fuse reads the map points from the resident map by slot (SWARMORB_LM_MAP=0: staged arrays)
+    std::vector<int32_t> lm_cslot;         // vpFuseCandidates as map slots
     std::deque<std::shared_ptr<KfSnap>> lm_ring;  // (local-mapping thread only)
     std::vector<int32_t> lm_stamp, lm_cstamp;     // slot -> id of the keyframe / job that marked it
     std::vector<float> lm_cX, lm_cN, lm_cmax, lm_cmin;  // vpFuseCandidates of the keyframe being processed
@@ -407,7 +409,12 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         const so_frame_view V2 = keyframe_view(r, *k2);
         fuse_best[jn].resize((size_t)n); fuse_dist[jn].resize((size_t)n);
         const double ta = now_ms();
-        const int frc = k2->dev
+        // (resident keyframe + resident map: the call stages the points' slots and flags, 5 bytes each; their positions,
+        //  normals, distance ranges and descriptors are rows of the map table the tracking searches read as well)
+        const int frc = (k2->dev && r->lm_from_map)
+            ? so_fuse_kframe_map(m, k2->dev, &r->cam, k2->T, r->log_sf, r->inv_sigma2, r->map, n, c->mp.data(), valid.data(), 3.0f,
+                                 fuse_best[jn].data(), fuse_dist[jn].data(), &fuse_n[jn], nullptr)
+            : k2->dev
             ? so_fuse_kframe(m, k2->dev, &r->cam, k2->T, r->log_sf, r->inv_sigma2, &P, 3.0f, fuse_best[jn].data(), fuse_dist[jn].data(),
                              &fuse_n[jn], nullptr)
             : so_fuse(m, &V2, &r->cam, k2->T, r->log_sf, r->inv_sigma2, &P, 3.0f, fuse_best[jn].data(), fuse_dist[jn].data(), &fuse_n[jn],
@@ -434,18 +441,26 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
             if (c->mp[(size_t)i] >= 0) r->lm_stamp[(size_t)c->mp[(size_t)i]] = cid;
         size_t cap = 0;
         for (const auto& k2 : r->lm_ring) cap += (size_t)k2->n;
-        X.resize(3 * cap); N.resize(3 * cap); mx.resize(cap); mn.resize(cap); D.resize(32 * cap); ok.resize(cap);
+        const bool from_map = c->dev && r->lm_from_map;
+        std::vector<int32_t>& cslot = r->lm_cslot;
+        if (from_map) cslot.resize(cap);
+        else { X.resize(3 * cap); N.resize(3 * cap); mx.resize(cap); mn.resize(cap); D.resize(32 * cap); }
+        ok.resize(cap);
         size_t q = 0;
         for (const auto& k2 : r->lm_ring)
             for (int i = 0; i < k2->n; i++) {
                 const int slot = k2->mp[(size_t)i];
                 if (slot < 0 || r->lm_cstamp[(size_t)slot] == job) continue;  // mnFuseCandidateForKF
                 r->lm_cstamp[(size_t)slot] = job;
-                memcpy(&X[3 * q], &k2->mpX[3 * (size_t)i], 12);
-                memcpy(&N[3 * q], &k2->mpN[3 * (size_t)i], 12);
-                mx[q] = k2->mpMax[(size_t)i];
-                mn[q] = k2->mpMin[(size_t)i];
-                memcpy(&D[32 * q], &k2->mpDesc[32 * (size_t)i], 32);
+                if (from_map) {
+                    cslot[q] = slot;
+                } else {
+                    memcpy(&X[3 * q], &k2->mpX[3 * (size_t)i], 12);
+                    memcpy(&N[3 * q], &k2->mpN[3 * (size_t)i], 12);
+                    mx[q] = k2->mpMax[(size_t)i];
+                    mn[q] = k2->mpMin[(size_t)i];
+                    memcpy(&D[32 * q], &k2->mpDesc[32 * (size_t)i], 32);
+                }
                 ok[q] = r->lm_stamp[(size_t)slot] != cid ? 1 : 0;  // !IsInKeyFrame(mpCurrentKeyFrame)
                 q++;
             }
@@ -455,7 +470,10 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         Q.desc = D.data(); Q.valid = ok.data();
         fuse_best[nn].resize((size_t)Q.n); fuse_dist[nn].resize((size_t)Q.n);
         const double ta = now_ms();
-        const int brc = c->dev
+        const int brc = from_map
+            ? so_fuse_kframe_map(m, c->dev, &r->cam, c->T, r->log_sf, r->inv_sigma2, r->map, Q.n, cslot.data(), ok.data(), 3.0f,
+                                 fuse_best[nn].data(), fuse_dist[nn].data(), &fuse_n[nn], nullptr)
+            : c->dev
             ? so_fuse_kframe(m, c->dev, &r->cam, c->T, r->log_sf, r->inv_sigma2, &Q, 3.0f, fuse_best[nn].data(), fuse_dist[nn].data(),
                              &fuse_n[nn], nullptr)
             : so_fuse(m, &Vc, &r->cam, c->T, r->log_sf, r->inv_sigma2, &Q, 3.0f, fuse_best[nn].data(), fuse_dist[nn].data(), &fuse_n[nn],
@@ -807,6 +825,7 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
     }
     if (const char* e = getenv("SWARMORB_LM_BATCH")) r->lm_batch = atoi(e) != 0;
     if (const char* e = getenv("SWARMORB_LM_RESIDENT")) r->lm_resident = atoi(e) != 0;
+    if (const char* e = getenv("SWARMORB_LM_MAP")) r->lm_from_map = atoi(e) != 0;
     if (!getenv("SWARMORB_NO_PIN")) {
         // one last-level-cache group of the device's NUMA node per agent: GPU d's first agent takes group d, the next
         // agents of this process the groups behind it

@@ -528,7 +528,28 @@ def _SearchForTriangulationKFrame(self, kf1, fv1, kframe2, free2, F12, epipole):
     return nm.value, out
 
 
+def _FuseKFrameMap(self, kframe, K, Tcw, log_scale_factor, inv_level_sigma2, dmap, slots, valid=None, th=3.0):
+    """so_fuse_kframe_map: Fuse against an HBM-resident keyframe with the map points read from a DeviceMap by slot."""
+    vp, f, i32 = C.c_void_p, C.c_float, C.c_int32
+    self._lib.so_fuse_kframe_map.argtypes = [vp, vp, C.POINTER(SoCameraM), vp, f, vp, vp, i32, vp, vp, f, vp, vp,
+                                             C.POINTER(i32), C.POINTER(SoWindowQueries)]
+    sl = np.ascontiguousarray(slots, np.int32)
+    n = len(sl)
+    va = None if valid is None else _u8(valid)
+    qs, q = _wq_struct(n)
+    bi, bd = np.full(n, -1, np.int32), np.full(n, 256, np.int32)
+    nf = i32(0)
+    cam, T, inv = _cam(K), _f32(Tcw).reshape(12), _f32(inv_level_sigma2)
+    _lib.check(self._lib.so_fuse_kframe_map(self._h, kframe._h, C.byref(cam), _vp(T), float(log_scale_factor), _vp(inv), dmap._h, n,
+                                            _vp(sl), _vp(va), float(th), _vp(bi), _vp(bd), C.byref(nf), C.byref(qs)))
+    if getattr(self, "_batching", False):
+        self._batch_keep += [bi, bd, q, nf, kframe, dmap]
+        return nf, bi, bd, q
+    return nf.value, bi, bd, q
+
+
 ORBmatcher.FuseKFrame = _FuseKFrame
+ORBmatcher.FuseKFrameMap = _FuseKFrameMap
 ORBmatcher.SearchForTriangulationKFrame = _SearchForTriangulationKFrame
 
 

@@ -347,3 +347,67 @@ def test_batch_shares_the_map_points_of_consecutive_fuse_calls(S, oracle):
         k.close()
     m.close()
 
+
+def test_fuse_from_the_resident_map_equals_fuse_from_arrays(S, oracle):
+    """so_fuse_kframe_map reads the map points' fields and descriptors from a DeviceMap by slot: same answers as
+    so_fuse_kframe with the rows' values as arrays (and so as the oracle) - alone, in a batch next to array jobs, with slots
+    in any order, with slots that do not exist (inactive points), with the map appended to between calls."""
+    from swarmmap_amd.dframe import DeviceMap
+    from swarmmap_amd.matcher import KFrame
+    m = S.ORBmatcher(0.6, True)
+    cases = [synth.make_projection_case(500 + i, 900, 1100, keyframe_bounds=True) for i in range(3)]
+    dmap = DeviceMap(0)
+    rng = np.random.default_rng(11)
+    # the map: junk rows, then every case's points in shuffled order
+    junk = 300
+    dmap.append(rng.normal(0, 5, (junk, 3)).astype(np.float32), rng.normal(0, 1, (junk, 3)).astype(np.float32),
+                np.full(junk, 9.0, np.float32), np.full(junk, 1.0, np.float32), rng.integers(0, 256, (junk, 32)).astype(np.uint8))
+    slots, kframes, want = [], [], []
+    for c in cases:
+        mp = c["mp"]
+        n = len(mp["max_dist"])
+        order = rng.permutation(n)
+        first = dmap.append(np.asarray(mp["Xw"], np.float32).reshape(n, 3)[order], np.asarray(mp["normal"], np.float32).reshape(n, 3)[order],
+                            np.asarray(mp["max_dist"], np.float32)[order], np.asarray(mp["min_dist"], np.float32)[order],
+                            np.asarray(mp["desc"], np.uint8).reshape(n, 32)[order])
+        sl = np.empty(n, np.int32)
+        sl[order] = first + np.arange(n, dtype=np.int32)  # point i lives in row sl[i]
+        slots.append(sl)
+        KF = _view(c["frame"], False)
+        kframes.append(KFrame(m, KF))
+        want.append(m.FuseKFrame(kframes[-1], c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], mp, 3.0))
+        on, obi, obd = oracle.fuse(KF, oracle.camera(c["cam"]), c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], mp, 3.0)
+        assert want[-1][0] == on > 100 and np.array_equal(want[-1][1], obi) and np.array_equal(want[-1][2], obd)
+    for c, k, sl, w in zip(cases, kframes, slots, want):
+        got = m.FuseKFrameMap(k, c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], dmap, sl, c["mp"].get("valid"), 3.0)
+        assert got[0] == w[0] and np.array_equal(got[1], w[1]) and np.array_equal(got[2], w[2])
+        _same_queries(got[3], w[3])
+    # slots that are no rows: those points are inactive, the others unchanged
+    c, k, sl, w = cases[0], kframes[0], slots[0].copy(), want[0]
+    bad = rng.random(len(sl)) < 0.2
+    sl[bad] = np.where(rng.random(bad.sum()) < 0.5, -1, len(dmap) + 7)
+    v = np.asarray(c["mp"]["valid"], np.uint8).copy() if c["mp"].get("valid") is not None else np.ones(len(sl), np.uint8)
+    mp_masked = dict(c["mp"], valid=(v * ~bad).astype(np.uint8))
+    ref = m.FuseKFrame(k, c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], mp_masked, 3.0)
+    got = m.FuseKFrameMap(k, c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], dmap, sl, v, 3.0)
+    assert got[0] == ref[0] < w[0] and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    assert not got[3]["active"][bad].any()
+    # batched, array jobs and map jobs side by side; the map grows in between (appends do not disturb the rows in use)
+    m.batch_begin()
+    held = []
+    for i, (c, k, sl) in enumerate(zip(cases, kframes, slots)):
+        held.append(m.FuseKFrameMap(k, c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], dmap, sl, c["mp"].get("valid"), 3.0))
+        if i == 1:
+            held.append(m.FuseKFrame(kframes[0], cases[0]["cam"], cases[0]["Tcw"], cases[0]["log_scale_factor"],
+                                     cases[0]["inv_level_sigma2"], cases[0]["mp"], 3.0))
+            dmap.append(rng.normal(0, 5, (70000, 3)).astype(np.float32), rng.normal(0, 1, (70000, 3)).astype(np.float32),
+                        np.full(70000, 9.0, np.float32), np.full(70000, 1.0, np.float32),
+                        rng.integers(0, 256, (70000, 32)).astype(np.uint8))  # past the first 65536 rows: the tables move
+    m.batch_end()
+    for h, w in zip(held, [want[0], want[1], want[0], want[2]]):
+        assert h[0].value == w[0] and np.array_equal(h[1], w[1]) and np.array_equal(h[2], w[2])
+    for k in kframes:
+        k.close()
+    dmap.close()
+    m.close()
+
