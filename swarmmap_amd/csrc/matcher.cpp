@@ -2459,6 +2459,17 @@ int so_fuse_kframe_map(so_matcher* m, const so_kframe* KF, const so_camera* cam,
         best_dist[i] = 256;
     }
     if (n == 0) return SO_OK;
+    if (map->size.load() == 0) {  // an empty table has no rows to read (and no storage): every point is inactive
+        if (queries_out)
+            for (int i = 0; i < n; i++) {
+                if (queries_out->active) queries_out->active[i] = 0;
+                if (queries_out->u) queries_out->u[i] = 0.f;
+                if (queries_out->v) queries_out->v[i] = 0.f;
+                if (queries_out->radius) queries_out->radius[i] = 0.f;
+                if (queries_out->level) queries_out->level[i] = 0;
+            }
+        return SO_OK;
+    }
     return as_batch(m, [&]() -> int {
         ProjectSrc S{};
         memcpy(S.A, Tcw12, sizeof(S.A));

@@ -406,6 +406,11 @@ def test_fuse_from_the_resident_map_equals_fuse_from_arrays(S, oracle):
     m.batch_end()
     for h, w in zip(held, [want[0], want[1], want[0], want[2]]):
         assert h[0].value == w[0] and np.array_equal(h[1], w[1]) and np.array_equal(h[2], w[2])
+    empty = DeviceMap(0)  # a table without rows: nothing to read, every point inactive
+    got = m.FuseKFrameMap(kframes[0], cases[0]["cam"], cases[0]["Tcw"], cases[0]["log_scale_factor"], cases[0]["inv_level_sigma2"],
+                          empty, slots[0], None, 3.0)
+    assert got[0] == 0 and (got[1] == -1).all() and not got[3]["active"].any()
+    empty.close()
     for k in kframes:
         k.close()
     dmap.close()
