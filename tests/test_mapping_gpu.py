@@ -66,3 +66,62 @@ def test_update_normal_and_depth(S, oracle, seed, n, max_obs):
     for g, w in zip(got, want):
         assert g.tobytes() == w.tobytes()
     m.close()
+
+
+def test_triangulation_and_normal_depth_edge_cases(S, oracle):
+    """What CreateNewMapPoints / UpdateNormalAndDepth meet at the edges: no matches at all; a neighbour at the same place
+    (zero baseline: every pair of rays is parallel, the parallax gate and the w == 0 test decide); a pure rotation; points
+    behind either camera (the neighbour looking the other way); the same pixel in both views; octaves at both ends of the
+    pyramid; map points without observations (left as they are)."""
+    m = S.ORBmatcher()
+    c = synth.make_triangulation_case(77, 400)
+    # no matches
+    ok, X = m.TriangulateMatches(c["kf1"], [c["kf2"]], c["ratio_factor"], np.zeros(0, np.int32), c["xy1"][:0], c["octave1"][:0],
+                                 c["xy2"][:0], c["octave2"][:0])
+    assert len(ok) == 0 and X.shape == (0, 3)
+
+    def both(kf1, kf2, xy1, o1, xy2, o2):
+        ok, X = m.TriangulateMatches(kf1, [kf2], c["ratio_factor"], np.zeros(len(o1), np.int32), xy1, o1, xy2, o2)
+        ook, oX = oracle.triangulate_matches(kf1, kf2, c["ratio_factor"], xy1, o1, xy2, o2)
+        assert np.array_equal(ok, ook)
+        assert X[ok.astype(bool)].tobytes() == oX[ook.astype(bool)].tobytes()
+        return ok
+
+    # zero baseline: the neighbour IS the keyframe; with the same pixels (exactly parallel rays) and with the case's own
+    ok = both(c["kf1"], c["kf1"], c["xy1"], c["octave1"], c["xy1"], c["octave1"])
+    assert ok.sum() == 0
+    ok = both(c["kf1"], c["kf1"], c["xy1"], c["octave1"], c["xy2"], c["octave2"])
+    assert ok.sum() == 0
+    # pure rotation about the camera centre: no parallax either
+    T1 = np.asarray(c["kf1"]["Tcw"], np.float64).reshape(3, 4)
+    a = 0.03
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    rot = dict(c["kf1"], Tcw=np.hstack([Rz @ T1[:, :3], (Rz @ T1[:, 3])[:, None]]).astype(np.float32).reshape(12))
+    ok = both(c["kf1"], rot, c["xy1"], c["octave1"], c["xy2"], c["octave2"])
+    assert ok.sum() == 0
+    # the neighbour looks the other way: whatever triangulates lies behind one of the two
+    T2 = np.asarray(c["kf2"]["Tcw"], np.float64).reshape(3, 4)
+    flip = np.diag([-1.0, 1.0, -1.0])
+    back = dict(c["kf2"], Tcw=np.hstack([flip @ T2[:, :3], (flip @ T2[:, 3])[:, None]]).astype(np.float32).reshape(12))
+    ok = both(c["kf1"], back, c["xy1"], c["octave1"], c["xy2"], c["octave2"])
+    assert ok.sum() == 0
+    # octaves at the ends of the pyramid on a case that does triangulate
+    lo = np.zeros_like(c["octave1"]); hi = np.full_like(c["octave1"], 7)
+    n_lo = both(c["kf1"], c["kf2"], c["xy1"], lo, c["xy2"], lo).sum()
+    n_hi = both(c["kf1"], c["kf2"], c["xy1"], hi, c["xy2"], hi).sum()
+    n_x = both(c["kf1"], c["kf2"], c["xy1"], lo, c["xy2"], hi).sum()
+    assert n_hi >= n_lo > 50 and n_x < n_lo  # sigma grows with the octave; seven octaves apart breaks the scale gate
+    # UpdateNormalAndDepth: no map points; map points none of which has an observation
+    d = synth.make_normal_depth_case(5, 64, 6)
+    z = np.zeros(65, np.int32)
+    args = (z, d["obs_Ow"][:0], d["Xw"], d["ref_Ow"], d["ref_level_scale"], d["ref_last_scale"], d["normal"], d["max_dist"],
+            d["min_dist"])
+    got, want = m.UpdateNormalAndDepth(*args), oracle.update_normal_and_depth(*args)
+    for g, w, before in zip(got, want, (d["normal"], d["max_dist"], d["min_dist"])):
+        assert g.tobytes() == w.tobytes() == np.asarray(before).tobytes()
+    e = (np.zeros(1, np.int32), d["obs_Ow"][:0], d["Xw"][:0], d["ref_Ow"][:0], d["ref_level_scale"][:0], d["ref_last_scale"][:0],
+         d["normal"][:0], d["max_dist"][:0], d["min_dist"][:0])
+    got = m.UpdateNormalAndDepth(*e)
+    assert all(len(g) == 0 for g in got)
+    m.close()
+
