@@ -110,7 +110,7 @@ def main():
     back = synth.make_projection_case(700, 1000, 4000, keyframe_bounds=True)
     bounds = (0.0, float(synth.EUROC[0]), 0.0, float(synth.EUROC[1]))
 
-    def load(batched, resident=None):
+    def load(batched, resident=None, dmap=None):
         if batched:
             m.batch_begin()
         for i in range(nb):
@@ -121,11 +121,15 @@ def main():
                 m.SearchForTriangulation(a1, f1, a2, f2, F12, (900.0, 240.0), sf, sf * sf)
         for i in range(nb):
             q = neigh[i]
-            if resident:
+            if dmap is not None:
+                m.FuseKFrameMap(resident["fuse"][i], q["cam"], q["Tcw"], lsf, inv, dmap, map_slots[i], q["mp"].get("valid"), 3.0)
+            elif resident:
                 m.FuseKFrame(resident["fuse"][i], q["cam"], q["Tcw"], lsf, inv, q["mp"], 3.0)
             else:
                 m.Fuse(view(q["frame"], False), q["cam"], q["Tcw"], lsf, inv, q["mp"], 3.0)
-        if resident:
+        if dmap is not None:
+            m.FuseKFrameMap(resident["back"], back["cam"], back["Tcw"], lsf, inv, dmap, map_slots[nb], back["mp"].get("valid"), 3.0)
+        elif resident:
             m.FuseKFrame(resident["back"], back["cam"], back["Tcw"], lsf, inv, back["mp"], 3.0)
         else:
             m.Fuse(view(back["frame"], False), back["cam"], back["Tcw"], lsf, inv, back["mp"], 3.0)
@@ -139,7 +143,19 @@ def main():
                     for b in bows],
                fuse=[KFrame(m, view(q["frame"], False)) for q in neigh], back=KFrame(m, view(back["frame"], False)))
     rec("keyframe load, ONE batch (HBM-resident keyframes)", "LocalMapping.cc:197-246,451-481", m, lambda: load(True, res), calls=41)
+    # ... and with the map points where the tracking searches keep them: rows of a device-resident map table
+    from swarmmap_amd.dframe import DeviceMap
+    dmap, map_slots = DeviceMap(0), []
+    for q in neigh + [back]:
+        mp = q["mp"]
+        n_mp = len(mp["max_dist"])
+        first = dmap.append(np.asarray(mp["Xw"], np.float32).reshape(n_mp, 3), np.asarray(mp["normal"], np.float32).reshape(n_mp, 3),
+                            mp["max_dist"], mp["min_dist"], np.asarray(mp["desc"], np.uint8).reshape(n_mp, 32))
+        map_slots.append(first + np.arange(n_mp, dtype=np.int32))
+    rec("keyframe load, ONE batch (HBM-resident keyframes, map points by slot from the resident map)",
+        "LocalMapping.cc:197-246,451-481", m, lambda: load(True, res, dmap), calls=41)
     del one
+    dmap.close()
     m.close()
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r4_matcher.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
