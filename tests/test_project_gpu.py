@@ -325,6 +325,13 @@ def test_batch_shares_the_map_points_of_consecutive_fuse_calls(S, oracle):
         m.batch_end()
         for h, a in zip(held, alone):
             assert h[0].value == a[0] and np.array_equal(h[1], a[1]) and np.array_equal(h[2], a[2])
+    # more calls than a batch holds (64): the flush in the middle takes the shared block with it, the 65th call stages anew
+    m.batch_begin()
+    held = [m.FuseKFrame(kframes[i % 4], *args(i % 4, with_mask(i % 4))) for i in range(70)]
+    m.batch_end()
+    for i, h in enumerate(held):
+        a = alone[i % 4]
+        assert h[0].value == a[0] and np.array_equal(h[1], a[1]) and np.array_equal(h[2], a[2]), i
     # the arrays change in place between two calls of one batch
     moved = mp["Xw"].copy()
     moved[::3] += 0.02
