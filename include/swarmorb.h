@@ -432,6 +432,14 @@ typedef struct so_tri_keyframe {
 int so_triangulate_matches(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_kf2, const so_tri_keyframe* kf2, float ratio_factor,
                            int32_t n, const int32_t* kf2_of_match, const float* xy1, const int32_t* octave1, const float* xy2,
                            const int32_t* octave2, uint8_t* ok, float* x3D);
+/* so_triangulate_matches + what CreateNewMapPoints does with each new point right away (LocalMapping.cc:403-414:
+ * AddObservation x 2, ComputeDistinctiveDescriptors, UpdateNormalAndDepth): mNormalVector, mfMaxDistance and
+ * mfMinDistance of the accepted matches' points in the SAME launch - two observations (kf1, then the neighbour), kf1 the
+ * reference keyframe, level = octave1[k].  Same values as so_update_normal_and_depth on those inputs; normal (3 per
+ * match), max_dist, min_dist are written where ok[k] = 1 only.  One launch and one wait instead of two. */
+int so_triangulate_new_points(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_kf2, const so_tri_keyframe* kf2, float ratio_factor,
+                              int32_t n, const int32_t* kf2_of_match, const float* xy1, const int32_t* octave1, const float* xy2,
+                              const int32_t* octave2, uint8_t* ok, float* x3D, float* normal, float* max_dist, float* min_dist);
 /* MapPoint::UpdateNormalAndDepth (code/src/MapPoint.cc:413-465) for a batch of map points (thread per point): point p is
  * observed from the camera centres obs_Ow[offsets[p] .. offsets[p + 1]) (3 floats each, in the order the caller walks
  * mObservations - the reference's own order is the pointer order of a std::map and differs from run to run); ref_Ow =

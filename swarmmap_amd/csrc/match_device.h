@@ -180,6 +180,12 @@ struct TriArgs {
     const int32_t* oct2;
     uint8_t* ok;                 // host-mapped
     float* x3D;                  // host-mapped, 3 per match
+    // not null: the accepted matches' new map points also get MapPoint::UpdateNormalAndDepth's three fields - two
+    // observations (the keyframe, then the neighbour), the keyframe as reference, its octave `oct1` - in the same launch
+    float* normal;               // host-mapped, 3 per match
+    float* max_dist;             // host-mapped
+    float* min_dist;             // host-mapped
+    float last_scale;            // mvScaleFactors[nLevels - 1] of the keyframe
     float ratio_factor;
     int n;
 };

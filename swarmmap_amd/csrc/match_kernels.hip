@@ -631,6 +631,26 @@ __global__ __launch_bounds__(128) void triangulate_kernel(TriArgs A) {
         A.x3D[3 * (size_t)m] = X[0];
         A.x3D[3 * (size_t)m + 1] = X[1];
         A.x3D[3 * (size_t)m + 2] = X[2];
+        if (A.normal) {  // the statements of normal_depth_kernel for observations (keyframe, neighbour), reference = keyframe
+            float nsum[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const float* Ow = o == 0 ? k1.Ow : k2.Ow;
+                const float d[3] = {X[0] - Ow[0], X[1] - Ow[1], X[2] - Ow[2]};
+                const double nr = sqrt((double)d[0] * d[0] + (double)d[1] * d[1] + (double)d[2] * d[2]);
+                const float inv = (float)(1.0 / nr);
+#pragma unroll
+                for (int j = 0; j < 3; j++) nsum[j] = nsum[j] + d[j] * inv;
+            }
+            const float PC[3] = {X[0] - k1.Ow[0], X[1] - k1.Ow[1], X[2] - k1.Ow[2]};
+            const float dist = (float)sqrt((double)PC[0] * PC[0] + (double)PC[1] * PC[1] + (double)PC[2] * PC[2]);
+            const float mx = dist * k1.scale[o1];
+            A.max_dist[m] = mx;
+            A.min_dist[m] = mx / A.last_scale;
+            const float invn = (float)(1.0 / (double)2);
+#pragma unroll
+            for (int j = 0; j < 3; j++) A.normal[3 * (size_t)m + j] = nsum[j] * invn;
+        }
     }
 }
 

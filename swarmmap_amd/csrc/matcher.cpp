@@ -2630,13 +2630,15 @@ int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x
 }
 
 // ---- the local-mapping thread's per-point loops between the matcher and local BA --------------------------------
-int so_triangulate_matches(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_kf2, const so_tri_keyframe* kf2, float ratio_factor,
-                           int32_t n, const int32_t* kf2_of_match, const float* xy1, const int32_t* octave1, const float* xy2,
-                           const int32_t* octave2, uint8_t* ok, float* x3D) {
+static int triangulate_impl(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_kf2, const so_tri_keyframe* kf2, float ratio_factor,
+                            int32_t n, const int32_t* kf2_of_match, const float* xy1, const int32_t* octave1, const float* xy2,
+                            const int32_t* octave2, uint8_t* ok, float* x3D, float* normal, float* max_dist, float* min_dist) {
     if (!m || !kf1 || n_kf2 < 0 || n < 0 || (n_kf2 > 0 && !kf2)) return SO_ERR_INVALID_ARG;
     if (n > 0 && (!kf2_of_match || !xy1 || !octave1 || !xy2 || !octave2 || !ok || !x3D || n_kf2 == 0)) return SO_ERR_INVALID_ARG;
+    const bool with_fields = normal != nullptr;
+    if (with_fields && n > 0 && (!max_dist || !min_dist)) return SO_ERR_INVALID_ARG;
     if (m->batching) {
-        last_error_ref() = "so_triangulate_matches cannot be part of a matcher batch";
+        last_error_ref() = "so_triangulate_matches / so_triangulate_new_points cannot be part of a matcher batch";
         return SO_ERR_INVALID_ARG;
     }
     auto kf_ok = [](const so_tri_keyframe& k) { return k.scale_factors && k.level_sigma2 && k.nlevels >= 1 && k.nlevels <= 8; };
@@ -2666,8 +2668,8 @@ int so_triangulate_matches(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_
     int rc;
     if ((rc = m->h_in.ensure_keep(end + 256, 0))) return rc;
     if ((rc = m->d_in.ensure(end + 256))) return rc;
-    const size_t ok_bytes = align256((size_t)n);
-    if ((rc = m->h_out.ensure(ok_bytes + 12 * (size_t)n))) return rc;
+    const size_t ok_bytes = align256((size_t)n), x_bytes = align256(12 * (size_t)n), f_bytes = align256(4 * (size_t)n);
+    if ((rc = m->h_out.ensure(ok_bytes + x_bytes + (with_fields ? x_bytes + 2 * f_bytes : 0)))) return rc;
     uint8_t* hb = (uint8_t*)m->h_in.p;
     for (int j = 0; j < n_kf2; j++) fill(((TriKeyframeDev*)(hb + o_kf))[j], kf2[j]);
     memcpy(hb + o_of, kf2_of_match, 4 * (size_t)n);
@@ -2689,6 +2691,10 @@ int so_triangulate_matches(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_
     A.oct2 = (const int32_t*)(db + o_o2);
     A.ok = (uint8_t*)m->h_out.dev;
     A.x3D = (float*)((uint8_t*)m->h_out.dev + ok_bytes);
+    A.normal = with_fields ? (float*)((uint8_t*)m->h_out.dev + ok_bytes + x_bytes) : nullptr;
+    A.max_dist = with_fields ? (float*)((uint8_t*)m->h_out.dev + ok_bytes + 2 * x_bytes) : nullptr;
+    A.min_dist = with_fields ? (float*)((uint8_t*)m->h_out.dev + ok_bytes + 2 * x_bytes + f_bytes) : nullptr;
+    A.last_scale = kf1->scale_factors[kf1->nlevels - 1];
     A.ratio_factor = ratio_factor;
     A.n = n;
     hipStream_t s = m->stream;
@@ -2709,11 +2715,35 @@ int so_triangulate_matches(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_
     if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
     const uint8_t* hok = (const uint8_t*)m->h_out.p;
     const float* hx = (const float*)((const uint8_t*)m->h_out.p + ok_bytes);
+    const float* hn = (const float*)((const uint8_t*)m->h_out.p + ok_bytes + x_bytes);
+    const float* hmx = (const float*)((const uint8_t*)m->h_out.p + ok_bytes + 2 * x_bytes);
+    const float* hmn = (const float*)((const uint8_t*)m->h_out.p + ok_bytes + 2 * x_bytes + f_bytes);
     for (int k = 0; k < n; k++) {
         ok[k] = hok[k];
-        if (hok[k]) memcpy(x3D + 3 * (size_t)k, hx + 3 * (size_t)k, 12);
+        if (!hok[k]) continue;
+        memcpy(x3D + 3 * (size_t)k, hx + 3 * (size_t)k, 12);
+        if (with_fields) {
+            memcpy(normal + 3 * (size_t)k, hn + 3 * (size_t)k, 12);
+            max_dist[k] = hmx[k];
+            min_dist[k] = hmn[k];
+        }
     }
     return SO_OK;
+}
+
+int so_triangulate_matches(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_kf2, const so_tri_keyframe* kf2, float ratio_factor,
+                           int32_t n, const int32_t* kf2_of_match, const float* xy1, const int32_t* octave1, const float* xy2,
+                           const int32_t* octave2, uint8_t* ok, float* x3D) {
+    return triangulate_impl(m, kf1, n_kf2, kf2, ratio_factor, n, kf2_of_match, xy1, octave1, xy2, octave2, ok, x3D, nullptr, nullptr,
+                            nullptr);
+}
+
+int so_triangulate_new_points(so_matcher* m, const so_tri_keyframe* kf1, int32_t n_kf2, const so_tri_keyframe* kf2, float ratio_factor,
+                              int32_t n, const int32_t* kf2_of_match, const float* xy1, const int32_t* octave1, const float* xy2,
+                              const int32_t* octave2, uint8_t* ok, float* x3D, float* normal, float* max_dist, float* min_dist) {
+    if (!normal || !max_dist || !min_dist) return SO_ERR_INVALID_ARG;
+    return triangulate_impl(m, kf1, n_kf2, kf2, ratio_factor, n, kf2_of_match, xy1, octave1, xy2, octave2, ok, x3D, normal, max_dist,
+                            min_dist);
 }
 
 int so_update_normal_and_depth(so_matcher* m, int32_t n_points, const int32_t* offsets, const float* obs_Ow, const float* Xw,

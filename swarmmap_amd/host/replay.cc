@@ -549,40 +549,53 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
             okv.assign((size_t)nt, 0);
             X3.resize(3 * (size_t)nt);
             const float ratio_factor = 1.5f * 1.2f;  // 1.5f * mpCurrentKeyFrame->mfScaleFactor, :214
-            if (so_triangulate_matches(m, &k1, (int32_t)k2s.size(), k2s.data(), ratio_factor, nt, of.data(), p1.data(), o1.data(), p2.data(),
-                                       o2.data(), okv.data(), X3.data()) != SO_OK)
-                return SO_ERR_HIP;
-            so_matcher_last_kernel_ms(m, &kms);
-            st[kLmTriangKernelMs] = kms;
-            // the new points: observations = (new keyframe, neighbour), reference keyframe = the new one
-            std::vector<float>&obs = r->lm_nobs, &Xn = r->lm_nX, &rO = r->lm_nref, &ls = r->lm_nls, &ll = r->lm_nll, &nrm = r->lm_nnrm,
-                               &mxd = r->lm_nmax, &mnd = r->lm_nmin;
-            std::vector<int32_t>& off = r->lm_noff;
-            obs.clear(); Xn.clear(); rO.clear(); ls.clear(); ll.clear(); off.assign(1, 0);
-            float Owc[3];
-            auto centre = [](const float* T, float* Ow) {
-                for (int q = 0; q < 3; q++) Ow[q] = (float)(-((double)T[q] * T[3] + (double)T[4 + q] * T[7] + (double)T[8 + q] * T[11]));
-            };
-            centre(c->T, Owc);
-            std::vector<float> Ow2(3 * k2s.size());
-            size_t jj = 0;
-            for (const auto& k2 : r->lm_ring) centre(k2->T, &Ow2[3 * jj++]);
-            for (int k = 0; k < nt; k++) {
-                if (!okv[(size_t)k]) continue;
-                n_new++;
-                obs.insert(obs.end(), Owc, Owc + 3);
-                obs.insert(obs.end(), &Ow2[3 * (size_t)of[(size_t)k]], &Ow2[3 * (size_t)of[(size_t)k]] + 3);
-                off.push_back((int32_t)(obs.size() / 3));
-                Xn.insert(Xn.end(), &X3[3 * (size_t)k], &X3[3 * (size_t)k] + 3);
-                rO.insert(rO.end(), Owc, Owc + 3);
-                ls.push_back(r->scale[o1[(size_t)k]]);
-                ll.push_back(r->scale[r->nlevels - 1]);
-            }
-            if (n_new > 0) {
-                nrm.assign(3 * (size_t)n_new, 0.f); mxd.assign((size_t)n_new, 0.f); mnd.assign((size_t)n_new, 0.f);
-                if (so_update_normal_and_depth(m, n_new, off.data(), obs.data(), Xn.data(), rO.data(), ls.data(), ll.data(), nrm.data(),
-                                               mxd.data(), mnd.data()) != SO_OK)
+            // triangulation, its gates, and the accepted points' normal / distance range (observations: this keyframe and
+            // the neighbour; reference keyframe: this one) in ONE launch; SWARMORB_LM_TRI_FUSED=0: the two calls of before
+            std::vector<float>&nrm = r->lm_nnrm, &mxd = r->lm_nmax, &mnd = r->lm_nmin;
+            static const bool fused = !(getenv("SWARMORB_LM_TRI_FUSED") && atoi(getenv("SWARMORB_LM_TRI_FUSED")) == 0);
+            if (fused) {
+                nrm.assign(3 * (size_t)nt, 0.f); mxd.assign((size_t)nt, 0.f); mnd.assign((size_t)nt, 0.f);
+                if (so_triangulate_new_points(m, &k1, (int32_t)k2s.size(), k2s.data(), ratio_factor, nt, of.data(), p1.data(), o1.data(),
+                                              p2.data(), o2.data(), okv.data(), X3.data(), nrm.data(), mxd.data(), mnd.data()) != SO_OK)
                     return SO_ERR_HIP;
+                so_matcher_last_kernel_ms(m, &kms);
+                st[kLmTriangKernelMs] = kms;
+                for (int k = 0; k < nt; k++) n_new += okv[(size_t)k] ? 1 : 0;
+            } else {
+                if (so_triangulate_matches(m, &k1, (int32_t)k2s.size(), k2s.data(), ratio_factor, nt, of.data(), p1.data(), o1.data(),
+                                           p2.data(), o2.data(), okv.data(), X3.data()) != SO_OK)
+                    return SO_ERR_HIP;
+                so_matcher_last_kernel_ms(m, &kms);
+                st[kLmTriangKernelMs] = kms;
+                // the new points: observations = (new keyframe, neighbour), reference keyframe = the new one
+                std::vector<float>&obs = r->lm_nobs, &Xn = r->lm_nX, &rO = r->lm_nref, &ls = r->lm_nls, &ll = r->lm_nll;
+                std::vector<int32_t>& off = r->lm_noff;
+                obs.clear(); Xn.clear(); rO.clear(); ls.clear(); ll.clear(); off.assign(1, 0);
+                float Owc[3];
+                auto centre = [](const float* T, float* Ow) {
+                    for (int q = 0; q < 3; q++) Ow[q] = (float)(-((double)T[q] * T[3] + (double)T[4 + q] * T[7] + (double)T[8 + q] * T[11]));
+                };
+                centre(c->T, Owc);
+                std::vector<float> Ow2(3 * k2s.size());
+                size_t jj = 0;
+                for (const auto& k2 : r->lm_ring) centre(k2->T, &Ow2[3 * jj++]);
+                for (int k = 0; k < nt; k++) {
+                    if (!okv[(size_t)k]) continue;
+                    n_new++;
+                    obs.insert(obs.end(), Owc, Owc + 3);
+                    obs.insert(obs.end(), &Ow2[3 * (size_t)of[(size_t)k]], &Ow2[3 * (size_t)of[(size_t)k]] + 3);
+                    off.push_back((int32_t)(obs.size() / 3));
+                    Xn.insert(Xn.end(), &X3[3 * (size_t)k], &X3[3 * (size_t)k] + 3);
+                    rO.insert(rO.end(), Owc, Owc + 3);
+                    ls.push_back(r->scale[o1[(size_t)k]]);
+                    ll.push_back(r->scale[r->nlevels - 1]);
+                }
+                if (n_new > 0) {
+                    nrm.assign(3 * (size_t)n_new, 0.f); mxd.assign((size_t)n_new, 0.f); mnd.assign((size_t)n_new, 0.f);
+                    if (so_update_normal_and_depth(m, n_new, off.data(), obs.data(), Xn.data(), rO.data(), ls.data(), ll.data(), nrm.data(),
+                                                   mxd.data(), mnd.data()) != SO_OK)
+                        return SO_ERR_HIP;
+                }
             }
         }
         st[kLmTriangMs] = now_ms() - ta;

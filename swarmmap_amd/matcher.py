@@ -600,5 +600,24 @@ def _UpdateNormalAndDepth(self, offsets, obs_Ow, Xw, ref_Ow, ref_level_scale, re
     return nrm, mx, mn
 
 
+def _TriangulateNewPoints(self, kf1, kf2_list, ratio_factor, kf2_of_match, xy1, octave1, xy2, octave2):
+    """so_triangulate_new_points: so_triangulate_matches + the new points' normal / distance range in the same launch.
+    Returns (ok, x3D, normal, max_dist, min_dist); the last three are zero where ok is 0."""
+    vp, i32 = C.c_void_p, C.c_int32
+    self._lib.so_triangulate_new_points.argtypes = [vp, C.POINTER(SoTriKeyframe), i32, vp, C.c_float, i32] + [vp] * 10
+    keep = []
+    a = _so_tri_kf(kf1, keep)
+    arr = (SoTriKeyframe * max(len(kf2_list), 1))(*[_so_tri_kf(k, keep) for k in kf2_list])
+    of = _i32(kf2_of_match)
+    x1, o1, x2, o2 = _f32(xy1).reshape(-1, 2), _i32(octave1), _f32(xy2).reshape(-1, 2), _i32(octave2)
+    n = len(o1)
+    ok, X = np.zeros(n, np.uint8), np.zeros((n, 3), np.float32)
+    nrm, mx, mn = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    _lib.check(self._lib.so_triangulate_new_points(self._h, C.byref(a), len(kf2_list), arr, float(ratio_factor), n, _vp(of), _vp(x1),
+                                                   _vp(o1), _vp(x2), _vp(o2), _vp(ok), _vp(X), _vp(nrm), _vp(mx), _vp(mn)))
+    return ok, X, nrm, mx, mn
+
+
 ORBmatcher.TriangulateMatches = _TriangulateMatches
+ORBmatcher.TriangulateNewPoints = _TriangulateNewPoints
 ORBmatcher.UpdateNormalAndDepth = _UpdateNormalAndDepth

@@ -55,6 +55,41 @@ def test_triangulate_matches_of_twenty_neighbours_in_one_launch(S, oracle):
     m.close()
 
 
+def test_new_points_in_one_launch_equal_triangulation_then_normal_and_depth(S, oracle):
+    """so_triangulate_new_points = so_triangulate_matches followed by so_update_normal_and_depth of the accepted matches'
+    points (observations: the keyframe, the neighbour; reference keyframe: the keyframe; level: the keypoint's octave in it)
+    - and so equal to the oracle's two functions."""
+    cases = [synth.make_triangulation_case(60 + j, 200 + 31 * j) for j in range(6)]
+    kf1 = cases[0]["kf1"]
+    of = np.concatenate([np.full(len(c["octave1"]), j, np.int32) for j, c in enumerate(cases)])
+    cat = lambda k: np.concatenate([c[k] for c in cases])  # noqa: E731
+    kf2s = [c["kf2"] for c in cases]
+    m = S.ORBmatcher()
+    ok, X, nrm, mx, mn = m.TriangulateNewPoints(kf1, kf2s, cases[0]["ratio_factor"], of, cat("xy1"), cat("octave1"), cat("xy2"),
+                                                cat("octave2"))
+    ok2, X2 = m.TriangulateMatches(kf1, kf2s, cases[0]["ratio_factor"], of, cat("xy1"), cat("octave1"), cat("xy2"), cat("octave2"))
+    assert np.array_equal(ok, ok2) and X.tobytes() == X2.tobytes() and ok.sum() > 100
+    sel = np.flatnonzero(ok)
+
+    def centre(kf):
+        T = np.asarray(kf["Tcw"], np.float32).reshape(3, 4)
+        R, t = T[:, :3].astype(np.float64), T[:, 3].astype(np.float64)
+        # -Rcw^T tcw in double, summed left to right, rounded once (what the library does: camera_center in matcher.cpp)
+        return np.array([-((R[0, j] * t[0] + R[1, j] * t[1]) + R[2, j] * t[2]) for j in range(3)], np.float64).astype(np.float32)
+
+    O1 = centre(kf1)
+    O2 = np.stack([centre(k) for k in kf2s])
+    obs = np.stack([np.broadcast_to(O1, (len(sel), 3)), O2[of[sel]]], 1).reshape(-1, 3).astype(np.float32)
+    off = (2 * np.arange(len(sel) + 1)).astype(np.int32)
+    sf = np.asarray(kf1["scale_factors"], np.float32)
+    args = (off, obs, X[sel], np.broadcast_to(O1, (len(sel), 3)).copy(), sf[cat("octave1")[sel]], np.full(len(sel), sf[-1], np.float32),
+            np.zeros((len(sel), 3), np.float32), np.zeros(len(sel), np.float32), np.zeros(len(sel), np.float32))
+    for got, sep, orc in zip((nrm[sel], mx[sel], mn[sel]), m.UpdateNormalAndDepth(*args), oracle.update_normal_and_depth(*args)):
+        assert got.tobytes() == sep.tobytes() == orc.tobytes()
+    assert not nrm[ok == 0].any() and not mx[ok == 0].any()
+    m.close()
+
+
 @pytest.mark.parametrize("seed,n,max_obs", [(1, 3000, 12), (2, 20000, 40), (3, 1, 3)])
 def test_update_normal_and_depth(S, oracle, seed, n, max_obs):
     c = synth.make_normal_depth_case(seed, n, max_obs)
