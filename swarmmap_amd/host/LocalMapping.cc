@@ -43,6 +43,27 @@ int LocalMappingOps::TriangulateMatches(const TriangulationKeyFrame& current, co
     return nnew;
 }
 
+int LocalMappingOps::CreateNewPoints(const TriangulationKeyFrame& current, const std::vector<TriangulationKeyFrame>& neighbours,
+                                     float ratioFactor, const TriangulationMatches& mt, std::vector<uint8_t>& ok, std::vector<float>& x3D,
+                                     std::vector<float>& normal, std::vector<float>& maxDistance, std::vector<float>& minDistance) {
+    const so_tri_keyframe k1 = view(current);
+    std::vector<so_tri_keyframe> k2;
+    for (const TriangulationKeyFrame& k : neighbours) k2.push_back(view(k));
+    const int n = mt.size();
+    ok.assign((size_t)n, 0);
+    x3D.assign(3 * (size_t)n, 0.f);
+    normal.assign(3 * (size_t)n, 0.f);
+    maxDistance.assign((size_t)n, 0.f);
+    minDistance.assign((size_t)n, 0.f);
+    check(so_triangulate_new_points(handle_, &k1, (int32_t)k2.size(), k2.data(), ratioFactor, n, mt.neighbour.data(), mt.xy1.data(),
+                                    mt.octave1.data(), mt.xy2.data(), mt.octave2.data(), ok.data(), x3D.data(), normal.data(),
+                                    maxDistance.data(), minDistance.data()),
+          "so_triangulate_new_points");
+    int nnew = 0;
+    for (uint8_t f : ok) nnew += f;
+    return nnew;
+}
+
 void LocalMappingOps::UpdateNormalAndDepth(const std::vector<int32_t>& offsets, const std::vector<float>& obsOw,
                                            const std::vector<float>& Xw, const std::vector<float>& refOw,
                                            const std::vector<float>& refLevelScale, const std::vector<float>& refLastScale,

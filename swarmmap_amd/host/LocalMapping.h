@@ -34,6 +34,12 @@ public:
     // ratioFactor = 1.5f * mpCurrentKeyFrame->mfScaleFactor.  Returns the number of new points.
     int TriangulateMatches(const TriangulationKeyFrame& current, const std::vector<TriangulationKeyFrame>& neighbours,
                            float ratioFactor, const TriangulationMatches& matches, std::vector<uint8_t>& ok, std::vector<float>& x3D);
+    // TriangulateMatches + the new points' mNormalVector / mfMaxDistance / mfMinDistance (what CreateNewMapPoints gets from
+    // pMP->UpdateNormalAndDepth() right after the two AddObservation calls, LocalMapping.cc:403-412) in the same launch:
+    // normal (3 per match), maxDistance, minDistance are set where ok[k] = 1.  Returns the number of new points.
+    int CreateNewPoints(const TriangulationKeyFrame& current, const std::vector<TriangulationKeyFrame>& neighbours, float ratioFactor,
+                        const TriangulationMatches& matches, std::vector<uint8_t>& ok, std::vector<float>& x3D,
+                        std::vector<float>& normal, std::vector<float>& maxDistance, std::vector<float>& minDistance);
     // MapPoint::UpdateNormalAndDepth for points p = 0..n-1: observers' camera centres obsOw[offsets[p] .. offsets[p + 1]),
     // reference keyframe's centre / level scale / last level scale per point; normal, maxDistance, minDistance in / out.
     void UpdateNormalAndDepth(const std::vector<int32_t>& offsets, const std::vector<float>& obsOw, const std::vector<float>& Xw,

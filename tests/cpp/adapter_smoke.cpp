@@ -241,6 +241,14 @@ int main(int argc, char** argv) {
         for (size_t k = 0; k < ok.size(); k++)
             if (!ok[k]) x3D[3 * k] = x3D[3 * k + 1] = x3D[3 * k + 2] = 0.f;
         printf("tri_n %d\n", nnew); out("tri_ok", ok); out("tri_x3d", x3D);
+        {   // the same with the new points' normal / distance range in one launch
+            std::vector<uint8_t> ok2;
+            std::vector<float> x2, nn, mxn, mnn;
+            const int nnew2 = ops.CreateNewPoints(kf("tr1"), {kf("tr2")}, rd<float>("tr_ratio")[0], mt, ok2, x2, nn, mxn, mnn);
+            for (size_t k = 0; k < ok2.size(); k++)
+                if (!ok2[k]) x2[3 * k] = x2[3 * k + 1] = x2[3 * k + 2] = 0.f;
+            printf("new_n %d\n", nnew2); out("new_ok", ok2); out("new_x3d", x2); out("new_normal", nn); out("new_max", mxn); out("new_min", mnn);
+        }
         std::vector<float> nrm = rd<float>("nd_normal"), mx = rd<float>("nd_max"), mn = rd<float>("nd_min");
         ops.UpdateNormalAndDepth(rd<int32_t>("nd_off"), rd<float>("nd_obs"), rd<float>("nd_Xw"), rd<float>("nd_ref"), rd<float>("nd_ls"),
                                  rd<float>("nd_ll"), nrm, mx, mn);

@@ -218,6 +218,24 @@ def test_every_adapter_method_matches_the_oracle(tmp_path, oracle):
     ook, oX = oracle.triangulate_matches(tc["kf1"], tc["kf2"], tc["ratio_factor"], tc["xy1"], tc["octave1"], tc["xy2"], tc["octave2"])
     assert int(L["tri_n"]) == int(ook.sum()) > 300
     same("tri_ok", ook, np.uint8); same("tri_x3d", np.where(ook[:, None].astype(bool), oX, 0), np.float32)
+    # ... and CreateNewPoints: the same + UpdateNormalAndDepth of the new points (observers: kf1, kf2; reference: kf1)
+    assert int(L["new_n"]) == int(ook.sum())
+    same("new_ok", ook, np.uint8); same("new_x3d", np.where(ook[:, None].astype(bool), oX, 0), np.float32)
+
+    def centre(kf):  # -Rcw^T tcw in double, left to right, rounded once (matcher.cpp: camera_center)
+        T = np.asarray(kf["Tcw"], np.float32).reshape(3, 4).astype(np.float64)
+        return np.array([-((T[0, j] * T[0, 3] + T[1, j] * T[1, 3]) + T[2, j] * T[2, 3]) for j in range(3)], np.float64).astype(np.float32)
+
+    sel = np.flatnonzero(ook)
+    O1, O2 = centre(tc["kf1"]), centre(tc["kf2"])
+    obs = np.stack([np.broadcast_to(O1, (len(sel), 3)), np.broadcast_to(O2, (len(sel), 3))], 1).reshape(-1, 3).astype(np.float32)
+    sfs = np.asarray(tc["kf1"]["scale_factors"], np.float32)
+    wn, wmx, wmn = oracle.update_normal_and_depth((2 * np.arange(len(sel) + 1)).astype(np.int32), obs, oX[sel],
+                                                  np.broadcast_to(O1, (len(sel), 3)).copy(), sfs[np.asarray(tc["octave1"])[sel]],
+                                                  np.full(len(sel), sfs[-1], np.float32), np.zeros((len(sel), 3), np.float32),
+                                                  np.zeros(len(sel), np.float32), np.zeros(len(sel), np.float32))
+    full = lambda v, w: (lambda a: (a.__setitem__(sel, v), a)[1])(np.zeros((len(ook),) + w, np.float32))  # noqa: E731
+    same("new_normal", full(wn, (3,)), np.float32); same("new_max", full(wmx, ()), np.float32); same("new_min", full(wmn, ()), np.float32)
     on, omx, omn = oracle.update_normal_and_depth(nd["offsets"], nd["obs_Ow"], nd["Xw"], nd["ref_Ow"], nd["ref_level_scale"],
                                                   nd["ref_last_scale"], nd["normal"], nd["max_dist"], nd["min_dist"])
     same("nd_normal_out", on, np.float32); same("nd_max_out", omx, np.float32); same("nd_min_out", omn, np.float32)
