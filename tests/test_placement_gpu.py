@@ -17,12 +17,13 @@ def test_device_host_cpus_names_cpus_of_this_host():
         pytest.skip("the host does not report a NUMA node for the device")
     online = os.sched_getaffinity(0) | node  # (the test process may itself be restricted)
     assert node and node <= online and max(node) < 4096
-    groups = [_lib.device_host_cpus(0, s) for s in range(64)]
+    groups = [_lib.device_host_cpus(0, s) for s in range(24)]
     assert all(g and g <= node for g in groups)  # every last-level-cache group lies inside the node
     distinct = {frozenset(g) for g in groups}
-    assert 1 <= len(distinct) <= 64
     n = len(distinct)
-    assert groups[0] == groups[n] and (n == 1 or groups[0] != groups[1])  # slots wrap around the node's groups
+    assert n >= 1
+    if n < len(groups):  # (a host with more groups per node than probed here: nothing to say about the wrap)
+        assert groups[0] == groups[n] and (n == 1 or groups[0] != groups[1])  # slots wrap around the node's groups
     # groups partition (part of) the node: pairwise disjoint
     d = list(distinct)
     assert all(a.isdisjoint(b) for i, a in enumerate(d) for b in d[i + 1:])
