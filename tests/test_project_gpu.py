@@ -423,3 +423,57 @@ def test_fuse_from_the_resident_map_equals_fuse_from_arrays(S, oracle):
     dmap.close()
     m.close()
 
+
+def test_fuse_from_the_map_while_another_thread_appends_to_it(S, oracle):
+    """The local-mapping thread reads the map table (so_fuse_kframe_map) while the tracking thread appends to it
+    (so_map_write) - from time to time past the table's capacity, which moves the tables.  The rows a search names are not
+    rewritten, so every search must return what it returns on a quiet map."""
+    import threading
+    from swarmmap_amd.dframe import DeviceMap
+    from swarmmap_amd.matcher import KFrame
+    m = S.ORBmatcher(0.6, True)
+    c = synth.make_projection_case(900, 1000, 1500, keyframe_bounds=True)
+    mp = c["mp"]
+    n = len(mp["max_dist"])
+    dmap = DeviceMap(0)
+    first = dmap.append(np.asarray(mp["Xw"], np.float32).reshape(n, 3), np.asarray(mp["normal"], np.float32).reshape(n, 3),
+                        mp["max_dist"], mp["min_dist"], np.asarray(mp["desc"], np.uint8).reshape(n, 32))
+    slots = (first + np.arange(n)).astype(np.int32)
+    kf = KFrame(m, _view(c["frame"], False))
+    args = (kf, c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], dmap, slots, mp.get("valid"), 3.0)
+    want = m.FuseKFrameMap(*args)
+    assert want[0] > 100
+    stop, errors, appended = threading.Event(), [], [0]
+
+    def writer():
+        rng = np.random.default_rng(3)
+        try:
+            while not stop.is_set() and len(dmap) < 600000:  # 65536 -> 131072 -> ... -> 1048576 rows: four moves
+                k = 9000
+                dmap.append(rng.normal(0, 5, (k, 3)).astype(np.float32), rng.normal(0, 1, (k, 3)).astype(np.float32),
+                            np.full(k, 9.0, np.float32), np.full(k, 1.0, np.float32), rng.integers(0, 256, (k, 32)).astype(np.uint8))
+                appended[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    t = threading.Thread(target=writer)
+    t.start()
+    rounds = 0
+    try:
+        while t.is_alive() and rounds < 2000:
+            m.batch_begin()
+            held = [m.FuseKFrameMap(*args) for _ in range(3)]
+            m.batch_end()
+            for h in held:
+                assert h[0].value == want[0] and np.array_equal(h[1], want[1]) and np.array_equal(h[2], want[2])
+            rounds += 1
+    finally:
+        stop.set()
+        t.join()
+    assert not errors and appended[0] > 20 and rounds > 20
+    got = m.FuseKFrameMap(*args)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    kf.close()
+    dmap.close()
+    m.close()
+
