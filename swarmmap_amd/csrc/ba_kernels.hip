@@ -1378,9 +1378,14 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d) {
                 if (act) {
                     const double* bl = d.bl + 3 * (size_t)il;
                     cl[0] += bl[0]; cl[1] += bl[1]; cl[2] += bl[2];
-                    double Dloc[9];
-                    if (d.fold_prep) damped_inverse3(d.Hll + 9 * (size_t)il, lambda, Dloc);  // (no prep launch: same bits)
-                    const double* Di = d.fold_prep ? Dloc : d.Dinv + 9 * (size_t)il;
+                    double Di[9];  // (a copy in registers either way: a pointer that selects between a local array and
+                                   //  global memory put the array into scratch memory)
+                    if (d.fold_prep) {
+                        damped_inverse3(d.Hll + 9 * (size_t)il, lambda, Di);  // (no prep launch: same bits)
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 9; q++) Di[q] = d.Dinv[9 * (size_t)il + q];
+                    }
 #pragma unroll
                     for (int r = 0; r < 3; r++) {
                         const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
