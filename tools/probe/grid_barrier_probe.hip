@@ -5,7 +5,7 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/probe/grid_barrier_probe.hip -o tools/probe/grid_barrier_bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
-template <bool TWO_LEVEL>
+template <bool TWO_LEVEL, int POLL>
 __global__ __launch_bounds__(512) void barrier_kernel(unsigned* counter, unsigned* sense, int iters, unsigned long long* sink, size_t lds_pad) {
     (void)lds_pad;
     unsigned local = 0;
@@ -32,14 +32,23 @@ __global__ __launch_bounds__(512) void barrier_kernel(unsigned* counter, unsigne
                 __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(sense, local, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                while (__hip_atomic_load(sense, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != local) __builtin_amdgcn_s_sleep(1);
+                if (POLL == 0) {
+                    while (__hip_atomic_load(sense, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != local) __builtin_amdgcn_s_sleep(1);
+                } else if (POLL == 1) {  // no sleep between polls
+                    while (__hip_atomic_load(sense, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != local) {
+                    }
+                } else {                 // relaxed polls, one acquire fence at the end
+                    while (__hip_atomic_load(sense, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != local) {
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
             }
         }
         __syncthreads();
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) *sink = (unsigned long long)acc;
 }
-template <bool TWO_LEVEL>
+template <bool TWO_LEVEL, int POLL>
 static void sweep(unsigned* counter, unsigned* sense, unsigned long long* sink, const char* what) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 2000;
@@ -48,7 +57,7 @@ static void sweep(unsigned* counter, unsigned* sense, unsigned long long* sink, 
         for (int rep = 0; rep < 3; rep++) {
             hipMemset(counter, 0, 64 * 64); hipMemset(sense, 0, 4);
             hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(barrier_kernel<TWO_LEVEL>, dim3(n), dim3(512), 0, 0, counter, sense, iters, sink, (size_t)0);
+            hipLaunchKernelGGL((barrier_kernel<TWO_LEVEL, POLL>), dim3(n), dim3(512), 0, 0, counter, sense, iters, sink, (size_t)0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
         }
@@ -58,7 +67,9 @@ static void sweep(unsigned* counter, unsigned* sense, unsigned long long* sink, 
 int main() {
     unsigned *counter, *sense; unsigned long long* sink;
     hipMalloc(&counter, 64 * 64); hipMalloc(&sense, 64); hipMalloc(&sink, 8);
-    sweep<false>(counter, sense, sink, "one counter");
-    sweep<true>(counter, sense, sink, "groups of 8 + one counter");
+    sweep<false, 0>(counter, sense, sink, "one counter");
+    sweep<true, 0>(counter, sense, sink, "groups of 8 + one counter");
+    sweep<false, 1>(counter, sense, sink, "one counter, polls without s_sleep");
+    sweep<false, 2>(counter, sense, sink, "one counter, relaxed polls + one acquire fence");
     return 0;
 }
