@@ -597,6 +597,11 @@ int so_map_write(so_map* map, int32_t first, int32_t n, const float* Xw, const f
                  const float* min_dist, const uint8_t* desc);
 /* Xw[slots[i]] <- Xw row i (MapPoint::SetWorldPos after bundle adjustment, code/src/Optimizer.cc:729-737) */
 int so_map_write_positions(so_map* map, int32_t n, const int32_t* slots, const float* Xw);
+/* rows slots[i] <- row i of the given arrays, any of which may be NULL = unchanged: the write-back of local bundle
+ * adjustment for the points it moved - SetWorldPos and the UpdateNormalAndDepth that follows it (code/src/Optimizer.cc:
+ * 729-737; mWorldPos, mNormalVector, mfMaxDistance, mfMinDistance) - in one launch */
+int so_map_write_rows(so_map* map, int32_t n, const int32_t* slots, const float* Xw, const float* normal, const float* max_dist,
+                      const float* min_dist);
 int so_map_read(so_map* map, int32_t first, int32_t n, float* Xw, uint8_t* desc); /* either may be NULL */
 
 /* TrackWithMotionModel's search: ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono = true) —

@@ -1,0 +1,571 @@
+"""The closed tracking + local-mapping loop over the hot path's operators: what the keyframes' local-mapping jobs compute
+- new map points from triangulation, fused duplicates, the poses and points local bundle adjustment moved, the
+observations it rejected - flows back into the map the next frames are tracked against, as in the reference
+(code/src/LocalMapping.cc:53-110 LocalMapping::Run; code/src/Optimizer.cc:436-560 window, :713-739 write-back;
+code/src/Tracking.cc UpdateLastFrame / CheckReplacedInLastFrame).
+
+Like `minitrack`, it is the shortest host loop that chains the operators, not the reference's state machine: the
+operators come from a backend (`minitrack.HipBackend`: the product through the C ABI; tests bind the CPU oracle to the same
+interface), the scene is `synth.FrameStream`.  swarmmap_amd/host/replay.cc holds the same loop in C++ (two threads; what
+bench.py times); tests compare the two frame by frame, keyframe by keyframe.
+
+Monocular bookkeeping, as SwarmMap runs it:
+  * frame 0 initialises the map (its keypoints back-projected onto the known plane: the stand-in for the two-view
+    Initializer, out of scope) and is keyframe 0, fixed in every window (KeyFrame::isFirst());
+  * tracking creates no map points afterwards; every new point comes from CreateNewMapPoints' triangulation;
+  * a keyframe is handed to local mapping every `kf_every` frames (or earlier, when the inliers fall below
+    `kf_ratio` of the last keyframe's and local mapping is idle);
+  * per keyframe, in LocalMapping::Run's order: ProcessNewKeyFrame (observations), MapPointCulling (the observation
+    rule; the found / visible ratio needs Tracking's per-frame counters and is left out), CreateNewMapPoints
+    (SearchForTriangulation against the last <= 20 keyframes with the baseline / median-depth gate, triangulation,
+    new points), SearchInNeighbors (Fuse into every neighbour and back, AddObservation / Replace), LocalBundleAdjustment
+    over the keyframe's OWN window (covisible keyframes sharing >= 15 points free - the `n_free` most covisible, the cap
+    standing in for KeyFrameCulling -, every other observer of their points fixed - the `n_fixed` with most
+    observations), write-back (SetPose, SetWorldPos, EraseMapPointMatch / EraseObservation with the <= 2 observations
+    rule, UpdateNormalAndDepth);
+  * the results reach the tracked map between two frames, the way Optimizer.cc:713 takes Map::mMutexMapUpdate that
+    Tracking::Track holds (Tracking.cc:195): at the start of frame kf_t + delay in the deterministic schedule (the
+    tracking thread waits if local mapping is not done - one legal interleaving of the reference's threads, and the
+    same one on every run), or whenever they are ready under the reference's own policy (replay.cc only: keyframes
+    only when local mapping is idle, InterruptBA otherwise, Tracking.cc:810-905).
+
+Deviations of the harness from the reference, on purpose (the operators themselves are exact, call by call): a
+keyframe's searches see the map as it is when their batch is issued - the SearchForTriangulation calls the state after
+ProcessNewKeyFrame, the Fuse calls the state after CreateNewMapPoints - and their results are applied in the
+reference's order against the live state (the reference interleaves search and apply per neighbour); descriptors of map
+points stay the creating keypoint's (ComputeDistinctiveDescriptors exists as an operator, so_distinctive_descriptors, but
+is not part of this loop); the local map Tracking searches is the points of the last `local_keyframes` keyframes, listed
+by local mapping when it finishes a keyframe; a frame's reference keyframe is the last keyframe created.
+"""
+import numpy as np
+
+from . import minitrack as mt
+
+TH_COVISIBLE = 15  # KeyFrame::UpdateConnections th (code/src/KeyFrame.cc:512-525)
+
+
+class LoopMap:
+    """The local-mapping side's map: points by slot (append order), keyframes by id, observations both ways."""
+
+    def __init__(self):
+        self.X = np.zeros((0, 3), np.float32)
+        self.N = np.zeros((0, 3), np.float32)
+        self.mx = np.zeros(0, np.float32)
+        self.mn = np.zeros(0, np.float32)
+        self.D = np.zeros((0, 32), np.uint8)
+        self.bad = np.zeros(0, np.uint8)
+        self.repl = np.zeros(0, np.int32)      # mpReplaced (slot) or -1
+        self.ref_kf = np.zeros(0, np.int32)    # mpRefKF
+        self.first_kf = np.zeros(0, np.int32)  # mnFirstKFid
+        self.obs = []                          # per point: [(keyframe id, keypoint index)] in insertion order
+        self.kfs = []
+        self.recent = []                       # mlpRecentAddedMapPoints
+
+    def __len__(self):
+        return len(self.X)
+
+    def append(self, X, N, mx, mn, D, kf, obs_lists):
+        first = len(self.X)
+        n = len(X)
+        self.X = np.concatenate([self.X, np.asarray(X, np.float32).reshape(-1, 3)])
+        self.N = np.concatenate([self.N, np.asarray(N, np.float32).reshape(-1, 3)])
+        self.mx = np.concatenate([self.mx, np.asarray(mx, np.float32)])
+        self.mn = np.concatenate([self.mn, np.asarray(mn, np.float32)])
+        self.D = np.concatenate([self.D, np.asarray(D, np.uint8).reshape(-1, 32)])
+        self.bad = np.concatenate([self.bad, np.zeros(n, np.uint8)])
+        self.repl = np.concatenate([self.repl, np.full(n, -1, np.int32)])
+        self.ref_kf = np.concatenate([self.ref_kf, np.full(n, kf, np.int32)])
+        self.first_kf = np.concatenate([self.first_kf, np.full(n, kf, np.int32)])
+        self.obs += obs_lists
+        return first
+
+    def resolve(self, s):
+        """The live point a binding stands for: follows mpReplaced (Tracking::CheckReplacedInLastFrame, Tracking.cc:940-955)."""
+        while s >= 0 and self.bad[s]:
+            s = int(self.repl[s])
+        return int(s)
+
+    def in_kf(self, s, kf):
+        return any(k == kf for k, _ in self.obs[s])
+
+    def set_bad(self, s):
+        """MapPoint::SetBadFlag (code/src/MapPoint.cc): the observers lose their match."""
+        for kf, idx in self.obs[s]:
+            self.kfs[kf]["mp"][idx] = -1
+        self.obs[s] = []
+        self.bad[s] = 1
+        self.repl[s] = -1
+
+    def replace(self, a, b):
+        """MapPoint::Replace: a is replaced by b."""
+        if a == b:
+            return
+        obs, self.obs[a] = self.obs[a], []
+        self.bad[a] = 1
+        self.repl[a] = b
+        for kf, idx in obs:
+            if not self.in_kf(b, kf):
+                self.kfs[kf]["mp"][idx] = b
+                self.obs[b].append((kf, idx))
+            else:
+                self.kfs[kf]["mp"][idx] = -1
+
+    def erase_observation(self, s, kf, idx):
+        """KeyFrame::EraseMapPointMatch + MapPoint::EraseObservation (<= 2 observations left: SetBadFlag)."""
+        self.kfs[kf]["mp"][idx] = -1
+        self.obs[s] = [o for o in self.obs[s] if o != (kf, idx)]
+        if int(self.ref_kf[s]) == kf and self.obs[s]:
+            self.ref_kf[s] = self.obs[s][0][0]
+        if len(self.obs[s]) <= 2:
+            self.set_bad(s)
+
+
+def _centre(T12):
+    """Camera centre -R^T t of a float pose, evaluated in double and rounded to float (replay.cc centre())."""
+    T = np.asarray(T12, np.float32).astype(np.float64).reshape(3, 4)
+    return np.array([-(T[0, j] * T[0, 3] + T[1, j] * T[1, 3] + T[2, j] * T[2, 3]) for j in range(3)], np.float64)
+
+
+def _median_depth(M, kf):
+    """KeyFrame::ComputeSceneMedianDepth(2) (code/src/KeyFrame.cc): depth of the keyframe's map points in its camera,
+    element [(n - 1) / 2] of the sorted list; -1 without points."""
+    s = kf["mp"][kf["mp"] >= 0]
+    if len(s) == 0:
+        return -1.0
+    T = np.asarray(kf["T"], np.float32).astype(np.float64).reshape(3, 4)
+    X = M.X[s].astype(np.float64)
+    z = T[2, 0] * X[:, 0] + T[2, 1] * X[:, 1] + T[2, 2] * X[:, 2] + T[2, 3]
+    return float(np.sort(z)[(len(z) - 1) // 2])
+
+
+def _kfeat(k):
+    return dict(x=k["x"], y=k["y"], angle=k["angle"], octave=k["octave"], desc=k["desc"], free=(k["mp"] < 0).astype(np.uint8))
+
+
+def _mp_view(M, slots, valid):
+    s0 = np.maximum(np.asarray(slots, np.int64), 0)
+    return dict(Xw=M.X[s0], normal=M.N[s0], max_dist=M.mx[s0], min_dist=M.mn[s0], desc=M.D[s0],
+                valid=np.asarray(valid, np.uint8))
+
+
+def local_window(M, c, n_free, n_fixed):
+    """The window Optimizer::LocalBundleAdjustment gathers for keyframe c (code/src/Optimizer.cc:436-560), flattened.
+    Returns (problem, window keyframe ids, point slots, edges as (keyframe, keypoint, point row)) or None."""
+    k = c["id"]
+    share = np.zeros(len(M.kfs), np.int64)
+    for s in c["mp"][c["mp"] >= 0]:
+        for kf, _ in M.obs[s]:
+            share[kf] += 1
+    cand = [kf for kf in range(len(M.kfs)) if kf != k and share[kf] >= TH_COVISIBLE]
+    cand.sort(key=lambda kf: (-share[kf], -kf))
+    local = [k] + cand[:max(0, n_free - 1)]
+    is_local = np.zeros(len(M.kfs), bool)
+    is_local[local] = True
+    pts = np.unique(np.concatenate([M.kfs[kf]["mp"][M.kfs[kf]["mp"] >= 0] for kf in local]))
+    count = np.zeros(len(M.kfs), np.int64)
+    for s in pts:
+        for kf, _ in M.obs[s]:
+            if not is_local[kf]:
+                count[kf] += 1
+    fx = [kf for kf in range(len(M.kfs)) if count[kf] > 0]
+    fx.sort(key=lambda kf: (-count[kf], -kf))
+    fixed = fx[:n_fixed]
+    win = sorted(local + fixed)
+    row = np.full(len(M.kfs), -1, np.int64)
+    row[win] = np.arange(len(win))
+    keep, edges = [], []
+    for s in pts:
+        e = [(kf, idx) for kf, idx in M.obs[s] if row[kf] >= 0]
+        if len(e) >= 2:
+            edges += [(kf, idx, len(keep)) for kf, idx in e]
+            keep.append(int(s))
+    if len(keep) < 10:
+        return None
+    pts = np.array(keep, np.int64)
+    e_kf = np.array([e[0] for e in edges], np.int64)
+    e_idx = np.array([e[1] for e in edges], np.int64)
+    e_pt = np.array([e[2] for e in edges], np.int32)
+    is_fixed = np.array([0 if (is_local[kf] and kf != 0) else 1 for kf in win], np.uint8)
+    if not np.any(is_fixed[row[e_kf]] == 0):
+        return None
+    obs = np.stack([np.array([M.kfs[kf]["x"][i] for kf, i in zip(e_kf, e_idx)], np.float32),
+                    np.array([M.kfs[kf]["y"][i] for kf, i in zip(e_kf, e_idx)], np.float32)], 1)
+    w = np.array([M.kfs[kf]["w"][i] for kf, i in zip(e_kf, e_idx)], np.float32)
+    prob = dict(Tcw=np.stack([np.asarray(M.kfs[kf]["T"], np.float32).reshape(12) for kf in win]), fixed=is_fixed,
+                Xw=M.X[pts].astype(np.float32), edge_pose=row[e_kf].astype(np.int32), edge_point=e_pt, obs=obs, inv_sigma2=w)
+    return prob, win, pts, (e_kf, e_idx, e_pt)
+
+
+def lm_job(M, be, c, P):
+    """One keyframe through local mapping.  M: LoopMap (c already appended to M.kfs); be: operator backend; P: dict of
+    K, sf, inv_sigma2, log_sf, vocab, neighbours, n_free, n_fixed, local_keyframes.  Returns the packet the tracking side
+    applies: first_new / n_points (rows [first_new, n_points) are new), moved (slots, X, N, mx, mn), bad (slot, replaced by),
+    kf_T (this keyframe's pose after LBA), local_slots, log (counts)."""
+    from .matcher import FeatureVector
+    k = c["id"]
+    K, sf, inv_sigma2, log_sf = P["K"], P["sf"], P["inv_sigma2"], P["log_sf"]
+    level_sigma2 = (sf * sf).astype(np.float32)
+    n_before = len(M)
+    bad_before = M.bad.copy()
+    # ---- ProcessNewKeyFrame (LocalMapping.cc:134-172): the tracked bindings become observations -------------------------
+    for i in range(len(c["mp"])):
+        s = int(c["mp"][i])
+        if s < 0:
+            continue
+        s = M.resolve(s)
+        if s < 0 or M.in_kf(s, k):
+            c["mp"][i] = -1
+            continue
+        c["mp"][i] = s
+        M.obs[s].append((k, i))
+    # ---- MapPointCulling (:174-205), the observation rule -----------------------------------------------------------
+    recent = []
+    for s in M.recent:
+        if M.bad[s]:
+            continue
+        if k - int(M.first_kf[s]) >= 2 and len(M.obs[s]) <= 2:
+            M.set_bad(s)
+        elif k - int(M.first_kf[s]) >= 3:
+            continue
+        else:
+            recent.append(s)
+    M.recent = recent
+    # ---- KeyFrame::ComputeBoW stand-in ---------------------------------------------------------------------------
+    c["fv"] = FeatureVector(np.asarray(be.assign_nodes(c["desc"], P["vocab"]), np.int32))
+    ring = M.kfs[max(0, k - P["neighbours"]):k]
+    # ---- CreateNewMapPoints (:207-420) ---------------------------------------------------------------------------
+    n_tri = n_new = 0
+    Oc = _centre(c["T"])
+    tri = []
+    for j, k2 in enumerate(ring):
+        O2 = _centre(k2["T"])
+        d = O2 - Oc
+        baseline = float(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))
+        med = _median_depth(M, k2)
+        if baseline / med < 0.01:  # (:236-241, monocular)
+            continue
+        F12, epi = mt.fundamental_and_epipole(K, c["T"], k2["T"])
+        nm, m12 = be.search_for_triangulation(_kfeat(c), c["fv"], _kfeat(k2), k2["fv"], F12, epi, sf, level_sigma2)
+        n_tri += int(nm)
+        tri.append((j, np.asarray(m12)))
+    if tri:
+        of = np.concatenate([np.full(int((m >= 0).sum()), j, np.int32) for j, m in tri])
+        i1 = np.concatenate([np.nonzero(m >= 0)[0] for _, m in tri])
+        i2 = np.concatenate([m[m >= 0] for _, m in tri])
+        if len(of):
+            xy1 = np.stack([c["x"][i1], c["y"][i1]], 1)
+            xy2 = np.stack([np.array([ring[j]["x"][b] for j, b in zip(of, i2)], np.float32),
+                            np.array([ring[j]["y"][b] for j, b in zip(of, i2)], np.float32)], 1)
+            o1 = c["octave"][i1]
+            o2 = np.array([ring[j]["octave"][b] for j, b in zip(of, i2)], np.int32)
+            tk = lambda q: dict(Tcw=q["T"], K=K, scale_factors=sf, level_sigma2=level_sigma2)  # noqa: E731
+            ok, X, nrm, mxd, mnd = be.triangulate_new_points(tk(c), [tk(q) for q in ring], float(np.float32(1.5) * np.float32(1.2)),
+                                                             of, xy1, o1, xy2, o2)
+            rows = []
+            for q in range(len(of)):  # the reference's order: neighbour by neighbour, keypoint by keypoint
+                k2 = ring[of[q]]
+                if not ok[q] or c["mp"][i1[q]] >= 0 or k2["mp"][i2[q]] >= 0:
+                    continue
+                s = n_before + len(rows)
+                rows.append(q)
+                c["mp"][i1[q]] = s
+                k2["mp"][i2[q]] = s
+            if rows:
+                rows = np.array(rows)
+                M.append(X[rows], nrm[rows], mxd[rows], mnd[rows], c["desc"][i1[rows]], k,
+                         [[(k, int(i1[q])), (ring[of[q]]["id"], int(i2[q]))] for q in rows])
+                M.recent += list(range(n_before, len(M)))
+                be.map_append(M.X[n_before:], M.N[n_before:], M.mx[n_before:], M.mn[n_before:], M.D[n_before:])
+                n_new = len(rows)
+    # ---- SearchInNeighbors (:423-498): Fuse into every neighbour, then the neighbours' points into this keyframe ---------
+    n_fused = n_back = 0
+
+    def apply_fuse(target, slots, best):
+        done = 0
+        for i in np.nonzero(best >= 0)[0]:
+            p = M.resolve(int(slots[i]))
+            if p < 0:
+                continue
+            kp = int(best[i])
+            q = int(target["mp"][kp])
+            if q >= 0:
+                q = M.resolve(q)
+            if q >= 0:
+                if q == p:
+                    continue
+                if len(M.obs[q]) > len(M.obs[p]):  # ORBmatcher.cc:873-878
+                    M.replace(p, q)
+                else:
+                    M.replace(q, p)
+                done += 1
+            else:
+                if M.in_kf(p, target["id"]):
+                    continue
+                M.obs[p].append((target["id"], kp))
+                target["mp"][kp] = p
+                done += 1
+        return done
+
+    if ring:
+        cs = c["mp"].copy()
+        res = []
+        for k2 in ring:
+            valid = np.array([1 if (s >= 0 and not M.in_kf(s, k2["id"])) else 0 for s in cs], np.uint8)
+            _, best, _ = be.fuse_idx(mt.keyframe_view(k2, sf), K, k2["T"], log_sf, inv_sigma2, _mp_view(M, cs, valid), 3.0)
+            res.append(best)
+        cand, seen = [], set()
+        for k2 in ring:  # vpFuseCandidates, once each (mnFuseCandidateForKF)
+            for s in k2["mp"]:
+                if s >= 0 and s not in seen:
+                    seen.add(int(s))
+                    cand.append(int(s))
+        cand = np.array(cand, np.int64)
+        validb = np.array([0 if M.in_kf(s, k) else 1 for s in cand], np.uint8)
+        _, bestb, _ = be.fuse_idx(mt.keyframe_view(c, sf), K, c["T"], log_sf, inv_sigma2, _mp_view(M, cand, validb), 3.0)
+        for k2, best in zip(ring, res):
+            n_fused += apply_fuse(k2, cs, best)
+        n_back = apply_fuse(c, cand, bestb)
+    # ---- Optimizer::LocalBundleAdjustment over the keyframe's own window ---------------------------------------------------
+    lba = dict(edges=0, outliers=0, free=0, fixed=0, points=0)
+    moved = np.zeros(0, np.int64)
+    if len(M.kfs) > 2:  # LocalMapping.cc:81
+        win = local_window(M, c, P["n_free"], P["n_fixed"])
+        if win is not None:
+            prob, wkf, pts, (e_kf, e_idx, e_pt) = win
+            prob["intr"] = np.tile(np.asarray(K, np.float32), (len(wkf), 1))
+            T_out, X_out, e_out = be.local_ba(prob)
+            for p, kf in enumerate(wkf):  # SetPose (Optimizer.cc:713-727)
+                if not prob["fixed"][p]:
+                    M.kfs[kf]["T"] = np.asarray(T_out[p], np.float32).reshape(12).copy()
+            M.X[pts] = np.asarray(X_out, np.float32)  # SetWorldPos
+            out = np.nonzero(np.asarray(e_out))[0]
+            for e in out:  # EraseMapPointMatch / EraseObservation (:697-711)
+                s = int(pts[e_pt[e]])
+                if not M.bad[s] and (int(e_kf[e]), int(e_idx[e])) in M.obs[s]:
+                    M.erase_observation(s, int(e_kf[e]), int(e_idx[e]))
+            lba = dict(edges=len(e_kf), outliers=len(out), free=int((prob["fixed"] == 0).sum()), fixed=int(prob["fixed"].sum()),
+                       points=len(pts))
+            # UpdateNormalAndDepth of the window's points (:729-737)
+            live = pts[M.bad[pts] == 0]
+            live = live[[len(M.obs[s]) > 0 for s in live]] if len(live) else live
+            if len(live):
+                off = np.zeros(len(live) + 1, np.int32)
+                ow, ref_o, lvl = [], [], []
+                centres = {}
+                for q, s in enumerate(live):
+                    for kf, _ in M.obs[s]:
+                        if kf not in centres:
+                            centres[kf] = _centre(M.kfs[kf]["T"]).astype(np.float32)
+                        ow.append(centres[kf])
+                    off[q + 1] = len(ow)
+                    rk = int(M.ref_kf[s])
+                    ri = [idx for kf, idx in M.obs[s] if kf == rk]
+                    if not ri:  # (the reference keyframe's observation is gone: the first observer takes over)
+                        rk, ri = M.obs[s][0][0], [M.obs[s][0][1]]
+                        M.ref_kf[s] = rk
+                    if rk not in centres:
+                        centres[rk] = _centre(M.kfs[rk]["T"]).astype(np.float32)
+                    ref_o.append(centres[rk])
+                    lvl.append(sf[M.kfs[rk]["octave"][ri[0]]])
+                nrm, mxd, mnd = be.update_normal_and_depth(off, np.array(ow, np.float32), M.X[live], np.array(ref_o, np.float32),
+                                                           np.array(lvl, np.float32), np.full(len(live), sf[-1], np.float32),
+                                                           M.N[live], M.mx[live], M.mn[live])
+                M.N[live], M.mx[live], M.mn[live] = nrm, mxd, mnd
+            moved = pts
+    # ---- the packet ------------------------------------------------------------------------------------------------
+    newly_bad = np.nonzero(M.bad[:len(bad_before)] != bad_before)[0]
+    newly_bad = np.concatenate([newly_bad, n_before + np.nonzero(M.bad[n_before:])[0]]).astype(np.int64)
+    lk = M.kfs[max(0, len(M.kfs) - P["local_keyframes"]):]
+    local = np.unique(np.concatenate([q["mp"][q["mp"] >= 0] for q in lk])) if lk else np.zeros(0, np.int64)
+    local = local[M.bad[local] == 0] if len(local) else local
+    return dict(kf=k, first_new=n_before, n_points=len(M), new_X=M.X[n_before:].copy(), moved=moved.astype(np.int64),
+                moved_X=M.X[moved].copy(), moved_N=M.N[moved].copy(), moved_mx=M.mx[moved].copy(), moved_mn=M.mn[moved].copy(),
+                bad=newly_bad, bad_repl=M.repl[newly_bad].copy(), kf_T=np.asarray(c["T"], np.float32).copy(),
+                local_slots=local.astype(np.int32),
+                log=(c["t"], len(ring), n_tri, n_new, n_fused, n_back, lba["edges"], lba["outliers"], lba["free"], lba["fixed"],
+                     lba["points"], len(newly_bad)))
+
+
+LM_LOG_COLUMNS = ("t", "neighbours", "tri_matches", "new_points", "fused", "fused_back", "lba_edges", "lba_outliers", "lba_free",
+                  "lba_fixed", "lba_points", "bad_points")
+
+
+def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio=0.7, delay=None, local_keyframes=12,
+          neighbours=20, n_free=25, n_fixed=40, third_pose=False, frames=None, on_frame=None, run_job=None):
+    """The closed loop in the deterministic schedule.  delay: frames between a keyframe and the arrival of its
+    local-mapping results in the tracked map (default kf_every).  run_job(job) -> handle with .result(): runs the
+    local-mapping job elsewhere (the CPU baseline's second thread); default inline.
+    Returns dict(centres, poses, matches_last, matches_map, inliers, n_map_points, ref_kf, Tcr (pose relative to the
+    reference keyframe), lm_log, kf_t, kf_poses (final), final_centres (Tcr x final keyframe pose, System.cc:225-252))."""
+    delay = kf_every if delay is None else delay
+    intr = np.asarray(K, np.float32)
+    fx, fy, cx, cy = [float(v) for v in intr]
+    sf, inv_sigma2 = backend.tables()
+    sf = np.asarray(sf, np.float32)
+    inv_sigma2 = np.asarray(inv_sigma2, np.float32)
+    nlevels = len(sf)
+    log_sf = float(np.log(np.float32(1.2)))
+    P = dict(K=K, sf=sf, inv_sigma2=inv_sigma2, log_sf=log_sf, vocab=vocab, neighbours=neighbours, n_free=n_free, n_fixed=n_fixed,
+             local_keyframes=local_keyframes)
+    M = LoopMap()
+    # the tracking side's view of the map: positions, bad / replaced flags, size, local map, reference keyframe pose
+    tv = dict(X=np.zeros((0, 3), np.float32), bad=np.zeros(0, np.uint8), repl=np.zeros(0, np.int32), local=np.zeros(0, np.int32))
+    pending = None  # (apply at frame, handle)
+    lm_log = []
+    poses, centres, ref_kf, Tcr = [], [], [], []
+    log = dict(matches_last=[], matches_map=[], inliers=[], n_map_points=[])
+    T_last = np.eye(4)
+    velocity = np.eye(4)
+    last = None
+    kf_inliers = 0
+    kf_t = []
+    T_ref = np.eye(4)      # the tracking side's copy of the last keyframe's pose
+    Tlr = np.eye(4)        # last frame relative to it (mlRelativeFramePoses)
+
+    class _Done:
+        def __init__(self, v):
+            self.v = v
+
+        def result(self):
+            return self.v
+
+    def resolve_tv(s):
+        while s >= 0 and tv["bad"][s]:
+            s = int(tv["repl"][s])
+        return int(s)
+
+    def apply(pk):
+        nonlocal T_ref, T_last
+        n_old = len(tv["X"])
+        assert n_old == pk["first_new"]
+        tv["X"] = np.concatenate([tv["X"], pk["new_X"]])
+        tv["bad"] = np.concatenate([tv["bad"], np.zeros(pk["n_points"] - n_old, np.uint8)])
+        tv["repl"] = np.concatenate([tv["repl"], np.full(pk["n_points"] - n_old, -1, np.int32)])
+        if len(pk["moved"]):
+            tv["X"][pk["moved"]] = pk["moved_X"]
+            backend.map_write_rows(pk["moved"], pk["moved_X"], pk["moved_N"], pk["moved_mx"], pk["moved_mn"])
+        tv["bad"][pk["bad"]] = 1
+        tv["repl"][pk["bad"]] = pk["bad_repl"]
+        tv["local"] = pk["local_slots"]
+        # Tracking::UpdateLastFrame (Tracking.cc:920-937): the last frame follows its reference keyframe
+        T_ref = mt._T44(pk["kf_T"])
+        T_last = Tlr @ T_ref
+        # Tracking::CheckReplacedInLastFrame (:940-955)
+        if last is not None:
+            lmp = last[1]
+            for i in np.nonzero(lmp >= 0)[0]:
+                if tv["bad"][lmp[i]]:
+                    lmp[i] = resolve_tv(int(lmp[i]))
+
+    def make_keyframe(t, T, kps, xy_un, desc, kp_mp, outlier, bounds):
+        bind = np.where((kp_mp >= 0) & ~outlier, kp_mp, -1).astype(np.int64)
+        c = dict(id=len(M.kfs), t=t, T=T[:3, :4].astype(np.float32).reshape(12).copy(), x=xy_un[:, 0].copy(), y=xy_un[:, 1].copy(),
+                 angle=kps["angle"].copy(), octave=kps["octave"].astype(np.int32), desc=desc.copy(), w=inv_sigma2[kps["octave"]],
+                 mp=bind, bounds=np.asarray(bounds, np.float32))
+        M.kfs.append(c)
+        kf_t.append(t)
+        return c
+
+    for t in range(n_frames):
+        if pending is not None and pending[0] <= t:
+            pk = pending[1].result()
+            lm_log.append(pk["log"])
+            apply(pk)
+            pending = None
+        img = frames[t] if frames is not None else stream.frame(t)
+        kps, xy_un, desc, bounds = backend.new_frame(img)
+        n = len(kps)
+        kp_mp = np.full(n, -1, np.int64)
+        outlier = np.zeros(n, bool)
+        keyframe = False
+        if t == 0:
+            T = np.eye(4)
+            R, tt = T[:3, :3], T[:3, 3]
+            rays = np.stack([(xy_un[:, 0] - cx) / fx, (xy_un[:, 1] - cy) / fy, np.ones(n)], 1)
+            Ow = -R.T @ tt
+            dirs = rays @ R
+            d = (plane_z - Ow[2]) / dirs[:, 2]
+            X = Ow[None, :] + dirs * d[:, None]
+            PO = X - Ow[None, :]
+            dist = np.linalg.norm(PO, axis=1)
+            mx = dist * sf[kps["octave"]]
+            Xf = X.astype(np.float32)
+            Nf, mxf, mnf = (PO / dist[:, None]).astype(np.float32), (1.2 * mx).astype(np.float32), (0.8 * mx / sf[nlevels - 1]).astype(np.float32)
+            M.append(Xf, Nf, mxf, mnf, desc, 0, [[] for _ in range(n)])
+            backend.map_append(Xf, Nf, mxf, mnf, desc)
+            tv["X"], tv["bad"], tv["repl"] = Xf.copy(), np.zeros(n, np.uint8), np.full(n, -1, np.int32)
+            tv["local"] = np.arange(n, dtype=np.int32)
+            kp_mp[:] = np.arange(n)
+            kf_inliers = n
+            keyframe = True
+            log["matches_last"].append(0); log["matches_map"].append(0); log["inliers"].append(n)
+        else:
+            T_pred = velocity @ T_last
+            Tp = T_pred[:3, :4].astype(np.float32)
+            lk, lmp, lout = last
+            last_slot = np.where((lmp >= 0) & ~lout, lmp, -1).astype(np.int32)
+            nm, k2l = backend.search_last(Tp.reshape(12), last_slot, mt.TH_LAST_FRAME)
+            if nm < mt.MIN_MATCHES_MOTION:
+                nm, k2l = backend.search_last(Tp.reshape(12), last_slot, 2 * mt.TH_LAST_FRAME)
+            bound = k2l >= 0
+            kp_mp[bound] = lmp[k2l[bound]]
+            log["matches_last"].append(int(nm))
+            idx = np.nonzero(kp_mp >= 0)[0]
+            _, T12, outl = backend.pose(Tp.reshape(12), intr, tv["X"][kp_mp[idx]], xy_un[idx], inv_sigma2[kps["octave"][idx]])
+            kp_mp[idx[outl.astype(bool)]] = -1
+            T_a = np.asarray(T12, np.float32).reshape(3, 4)
+            # TrackLocalMap over the local map local mapping listed
+            loc = tv["local"]
+            skip = tv["bad"][loc].copy()
+            bound_now = np.zeros(len(tv["X"]), bool)
+            bound_now[kp_mp[kp_mp >= 0]] = True
+            skip[bound_now[loc]] = 1
+            excluded = (kp_mp >= 0).astype(np.uint8)
+            nm2, k2m, _ = backend.search_local(T_a.reshape(12), 0, len(loc), skip, excluded, 1.0, log_sf, local_slot=loc)
+            newly = k2m >= 0
+            kp_mp[newly] = loc[k2m[newly]]
+            log["matches_map"].append(int(nm2))
+            idx = np.nonzero(kp_mp >= 0)[0]
+            n_in, T12, outl = backend.pose(T_a.reshape(12), intr, tv["X"][kp_mp[idx]], xy_un[idx], inv_sigma2[kps["octave"][idx]])
+            if third_pose:
+                backend.pose(T_last[:3, :4].astype(np.float32).reshape(12), intr, tv["X"][kp_mp[idx]], xy_un[idx],
+                             inv_sigma2[kps["octave"][idx]])
+            outlier[idx[outl.astype(bool)]] = True
+            T = mt._T44(np.asarray(T12, np.float32))
+            log["inliers"].append(int(n_in))
+            since = t - kf_t[-1]
+            if pending is None and (since >= kf_every or (since >= delay and n_in < kf_ratio * kf_inliers)):
+                keyframe = True
+                kf_inliers = max(int(n_in), 1)
+            velocity = T @ np.linalg.inv(T_last)
+        if keyframe:
+            c = make_keyframe(t, T, kps, xy_un, desc, kp_mp, outlier, bounds)
+            T_ref = mt._T44(c["T"])
+            job = (lambda c=c: lm_job(M, backend, c, P))
+            pending = (t + delay, run_job(job) if run_job is not None else _Done(job()))
+        Tlr = T @ np.linalg.inv(T_ref)
+        poses.append(T[:3, :4].reshape(12).copy())
+        centres.append(-T[:3, :3].T @ T[:3, 3])
+        ref_kf.append(len(M.kfs) - 1)
+        Tcr.append(Tlr.copy())
+        log["n_map_points"].append(len(tv["X"]))
+        last = (kps, kp_mp, outlier)
+        T_last = T
+        if on_frame is not None and on_frame(t) is False:
+            break
+    if pending is not None:
+        pk = pending[1].result()
+        lm_log.append(pk["log"])
+    out = dict(centres=np.array(centres), poses=np.array(poses), ref_kf=np.array(ref_kf, np.int32), Tcr=np.array(Tcr),
+               kf_t=np.array(kf_t, np.int32), kf_poses=np.stack([np.asarray(q["T"], np.float32) for q in M.kfs]))
+    out.update({k: np.array(v) for k, v in log.items()})
+    out["lm_log"] = np.array(lm_log, np.int64).reshape(-1, len(LM_LOG_COLUMNS))
+    fin = []
+    for r, Tc in zip(out["ref_kf"], out["Tcr"]):  # System::SaveTrajectoryTUM: Tcw = Tcr * Trw (code/src/System.cc:225-252)
+        Tw = Tc @ mt._T44(out["kf_poses"][r])
+        fin.append(-Tw[:3, :3].T @ Tw[:3, 3])
+    out["final_centres"] = np.array(fin)
+    out["kf_centres"] = np.array([-mt._T44(p)[:3, :3].T @ mt._T44(p)[:3, 3] for p in out["kf_poses"]])
+    out["n_bad_points"] = int(M.bad.sum())
+    out["map"] = M
+    return out

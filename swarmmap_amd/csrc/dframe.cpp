@@ -472,6 +472,37 @@ int so_map_write_positions(so_map* m, int32_t n, const int32_t* slots, const flo
     return SO_OK;
 }
 
+int so_map_write_rows(so_map* m, int32_t n, const int32_t* slots, const float* Xw, const float* normal, const float* max_dist,
+                      const float* min_dist) {
+    if (!m || n < 0 || (n > 0 && !slots)) return SO_ERR_INVALID_ARG;
+    if (n == 0 || (!Xw && !normal && !max_dist && !min_dist)) return SO_OK;
+    for (int i = 0; i < n; i++)
+        if (slots[i] < 0 || slots[i] >= m->size) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    int rc;
+    const size_t sn = (size_t)n;
+    if ((rc = stage(m, sn * 36))) return rc;
+    uint8_t* h = (uint8_t*)m->h_stage;
+    memcpy(h, slots, 4 * sn);
+    size_t o = 4 * sn;
+    auto put = [&](const float* src, size_t bytes) -> const float* {
+        if (!src) return nullptr;
+        memcpy(h + o, src, bytes);
+        const float* p = reinterpret_cast<const float*>(h + o);
+        o += bytes;
+        return p;
+    };
+    const float* pX = put(Xw, 12 * sn);
+    const float* pN = put(normal, 12 * sn);
+    const float* pmx = put(max_dist, 4 * sn);
+    const float* pmn = put(min_dist, 4 * sn);
+    // pinned memory is device-visible: the scatter kernel reads the staging block in place
+    launch_map_scatter_rows(m->d_Xw, m->d_normal, m->d_max, m->d_min, reinterpret_cast<const int32_t*>(h), pX, pN, pmx, pmn, n, m->stream);
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipStreamSynchronize(m->stream));
+    return SO_OK;
+}
+
 int so_map_read(so_map* m, int32_t first, int32_t n, float* Xw, uint8_t* desc) {
     if (!m || first < 0 || n < 0 || first + n > m->size) return SO_ERR_INVALID_ARG;
     if (n == 0) return SO_OK;

@@ -66,5 +66,7 @@ struct FrameFrustumArgs {
 void launch_frame_frustum(const FrameFrustumArgs& a, hipStream_t s);
 // so_map_write_positions: Xw[slots[i]] = X[i] (slots / X may live in pinned host memory)
 void launch_map_scatter_positions(float* d_Xw, const int32_t* slots, const float* X, int n, hipStream_t s);
+void launch_map_scatter_rows(float* d_Xw, float* d_normal, float* d_max, float* d_min, const int32_t* slots, const float* X,
+                             const float* N, const float* mx, const float* mn, int n, hipStream_t s);
 
 }  // namespace so

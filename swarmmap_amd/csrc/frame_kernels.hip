@@ -316,6 +316,26 @@ void launch_map_scatter_positions(float* d_Xw, const int32_t* slots, const float
     hipLaunchKernelGGL(map_scatter_positions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_Xw, slots, X, n);
 }
 
+// rows slots[i] of the map table <- row i of the given arrays (any of X / N / mx / mn may be null = unchanged)
+__global__ __launch_bounds__(256) void map_scatter_rows_kernel(float* __restrict__ Xw, float* __restrict__ normal, float* __restrict__ max_d,
+                                                                float* __restrict__ min_d, const int32_t* __restrict__ slots,
+                                                                const float* __restrict__ X, const float* __restrict__ N,
+                                                                const float* __restrict__ mx, const float* __restrict__ mn, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t s = (size_t)slots[i];
+    if (X) { Xw[3 * s] = X[3 * i]; Xw[3 * s + 1] = X[3 * i + 1]; Xw[3 * s + 2] = X[3 * i + 2]; }
+    if (N) { normal[3 * s] = N[3 * i]; normal[3 * s + 1] = N[3 * i + 1]; normal[3 * s + 2] = N[3 * i + 2]; }
+    if (mx) max_d[s] = mx[i];
+    if (mn) min_d[s] = mn[i];
+}
+
+void launch_map_scatter_rows(float* d_Xw, float* d_normal, float* d_max, float* d_min, const int32_t* slots, const float* X,
+                             const float* N, const float* mx, const float* mn, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(map_scatter_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_Xw, d_normal, d_max, d_min, slots, X, N, mx, mn, n);
+}
+
 void launch_frame_frustum(const FrameFrustumArgs& a, hipStream_t s) {
     if (a.n <= 0) return;
     hipLaunchKernelGGL(frame_frustum_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);

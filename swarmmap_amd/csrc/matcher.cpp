@@ -183,6 +183,9 @@ struct so_matcher {
         const so_dframe* last = nullptr;
         const uint8_t* cur_excluded = nullptr;  // caller memory: must stay valid until the wait
         float nn_ratio = 0.f;
+        // the map whose tables this search reads: held shared (so_map::grow_mu) from the submit to the end of the wait, so
+        // that another thread's append (a local-mapping thread adding triangulated points) cannot move them meanwhile
+        const so_map* held_map = nullptr;
         std::chrono::steady_clock::time_point t_launched;
     } pend;
     float min_x = 0.f, min_y = 0.f, grid_inv_w = 0.f, grid_inv_h = 0.f;
@@ -821,6 +824,10 @@ void so_matcher_destroy(so_matcher* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->pend.held_map) {  // a tracking search was submitted and never waited for
+        const_cast<so_map*>(m->pend.held_map)->grow_mu.unlock_shared();
+        m->pend.held_map = nullptr;
+    }
     for (DevBuf* b : {&m->d_in, &m->d_A, &m->d_B, &m->d_res}) b->release();
     for (PinBuf* b : {&m->h_in, &m->h_res, &m->h_rq}) b->release();
     m->d_rq.release();
@@ -3056,6 +3063,17 @@ int so_track_search_last_frame_submit(so_matcher* m, const so_dframe* cur, const
     constexpr int K = 8;
     int rc = use_dframe(m, cur, cur_excluded);
     if (rc) { P.mode = 0; return rc; }
+    const_cast<so_map*>(map)->grow_mu.lock_shared();
+    P.held_map = map;
+    struct Release {  // (error paths below: nothing stays in flight)
+        so_matcher::PendingTrack& P;
+        ~Release() {
+            if (P.mode == 0 && P.held_map) {
+                const_cast<so_map*>(P.held_map)->grow_mu.unlock_shared();
+                P.held_map = nullptr;
+            }
+        }
+    } release{P};
     P.T = track_src(m, cur, map, Tcw12, th);
     P.T.last_octave = last->d_octave;
     const TrackGates G{last_slot, 0, nullptr, cur_excluded};
@@ -3078,6 +3096,11 @@ int so_track_search_last_frame_wait(so_matcher* m, const uint8_t* slot_has_obs, 
     }
     so_matcher::PendingTrack P = m->pend;
     m->pend.mode = 0;
+    m->pend.held_map = nullptr;
+    struct Unhold {
+        const so_map* mp;
+        ~Unhold() { if (mp) const_cast<so_map*>(mp)->grow_mu.unlock_shared(); }
+    } unhold{P.held_map};
     const so_dframe* cur = P.cur;
     const so_dframe* last = P.last;
     const int n_last = P.nq;
@@ -3184,6 +3207,17 @@ int so_track_search_local_map_submit(so_matcher* m, const so_dframe* cur, const 
     constexpr int K = 8;
     int rc = use_dframe(m, cur, cur_excluded);
     if (rc) { P.mode = 0; return rc; }
+    const_cast<so_map*>(map)->grow_mu.lock_shared();
+    P.held_map = map;
+    struct Release {
+        so_matcher::PendingTrack& P;
+        ~Release() {
+            if (P.mode == 0 && P.held_map) {
+                const_cast<so_map*>(P.held_map)->grow_mu.unlock_shared();
+                P.held_map = nullptr;
+            }
+        }
+    } release{P};
     P.T = track_src(m, cur, map, Tcw12, th);
     P.T.cos_limit = viewing_cos_limit;
     P.T.log_scale_factor = log_scale_factor;
@@ -3214,6 +3248,11 @@ int so_track_search_local_map_wait(so_matcher* m, const uint8_t* slot_has_obs, u
     }
     so_matcher::PendingTrack P = m->pend;
     m->pend.mode = 0;
+    m->pend.held_map = nullptr;
+    struct Unhold {
+        const so_map* mp;
+        ~Unhold() { if (mp) const_cast<so_map*>(mp)->grow_mu.unlock_shared(); }
+    } unhold{P.held_map};
     const so_dframe* cur = P.cur;
     const int n_local = P.nq;
     if (!cur->mirrors) {

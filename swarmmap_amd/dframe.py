@@ -130,6 +130,12 @@ class DeviceMap:
         X = np.ascontiguousarray(Xw, np.float32).reshape(-1, 3)
         _lib.check(self._lib.so_map_write_positions(self._h, len(s), _vp(s), _vp(X)))
 
+    def write_rows(self, slots, Xw=None, normal=None, max_dist=None, min_dist=None):
+        s = np.ascontiguousarray(slots, np.int32)
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float32) for a in (Xw, normal, max_dist, min_dist)]
+        self._lib.so_map_write_rows.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
+        _lib.check(self._lib.so_map_write_rows(self._h, len(s), _vp(s), *[_vp(a) for a in arrs]))
+
     def read(self, first, n):
         X, d = np.zeros((n, 3), np.float32), np.zeros((n, 32), np.uint8)
         _lib.check(self._lib.so_map_read(self._h, int(first), int(n), _vp(X), _vp(d)))

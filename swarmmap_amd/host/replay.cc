@@ -26,237 +26,11 @@
 // from back-projection onto the known plane).  swarmmap_amd/minitrack.py is the same loop in Python; tests compare
 // this one, frame by frame, with that loop run over the CPU oracle.
 // Built by csrc/Makefile into libswarmorb_replay.so with g++.
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <condition_variable>
-#include <cstdlib>
-#include <cstring>
-#include <deque>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
+#include "replay_internal.h"
 
-#include <pthread.h>
-#include <sched.h>
-
-#include "../../include/swarmorb.h"
 
 namespace {
 
-constexpr int kEventEvery = 4;
-
-double now_ms() {
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
-struct BaWindow {
-    std::vector<float> Tcw, intr, Xw, obs, w;
-    std::vector<uint8_t> fixed;
-    std::vector<int32_t> epose, epoint;
-};
-
-struct M4 {  // 4x4 double, row-major
-    double a[16];
-    static M4 eye() {
-        M4 m;
-        for (int i = 0; i < 16; i++) m.a[i] = (i % 5 == 0) ? 1.0 : 0.0;
-        return m;
-    }
-};
-
-M4 mul(const M4& A, const M4& B) {
-    M4 C;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            double s = 0.0;
-            for (int k = 0; k < 4; k++) s += A.a[4 * i + k] * B.a[4 * k + j];
-            C.a[4 * i + j] = s;
-        }
-    return C;
-}
-
-M4 rigid_inverse_general(const M4& T) {  // general 4x4 inverse by Gauss-Jordan with partial pivoting
-    double m[4][8];
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            m[i][j] = T.a[4 * i + j];
-            m[i][4 + j] = i == j ? 1.0 : 0.0;
-        }
-    for (int c = 0; c < 4; c++) {
-        int p = c;
-        for (int r = c + 1; r < 4; r++)
-            if (std::fabs(m[r][c]) > std::fabs(m[p][c])) p = r;
-        if (p != c)
-            for (int j = 0; j < 8; j++) std::swap(m[p][j], m[c][j]);
-        const double d = 1.0 / m[c][c];
-        for (int j = 0; j < 8; j++) m[c][j] *= d;
-        for (int r = 0; r < 4; r++)
-            if (r != c) {
-                const double f = m[r][c];
-                for (int j = 0; j < 8; j++) m[r][j] -= f * m[c][j];
-            }
-    }
-    M4 R;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) R.a[4 * i + j] = m[i][4 + j];
-    return R;
-}
-
-void to_f12(const M4& T, float* o) {
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 4; c++) o[4 * r + c] = (float)T.a[4 * r + c];
-}
-
-M4 from_f12(const float* p) {
-    M4 T = M4::eye();
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 4; c++) T.a[4 * r + c] = (double)p[4 * r + c];
-    return T;
-}
-
-}  // namespace
-
-// What the local-mapping thread keeps of a tracked frame that became a keyframe (KeyFrame::KeyFrame(Frame&, ...),
-// code/src/KeyFrame.cc:47-72): keypoints, descriptors, pose, bindings to map points that existed before the frame
-// (those created AT the frame play the part of the still untriangulated features: -1), the bound points' fields.
-struct KfSnap {
-    int n = 0;
-    std::vector<float> x, y, angle;
-    std::vector<int32_t> octave, mp;
-    std::vector<uint8_t> desc;
-    std::vector<float> mpX, mpN, mpMax, mpMin;
-    std::vector<uint8_t> mpDesc;
-    float T[12] = {0}, bounds[4] = {0, 0, 0, 0};
-    int t = 0;
-    // DBoW2::FeatureVector stand-in, filled by the local-mapping thread
-    std::vector<int32_t> node_id, off, idx;
-    // the keyframe's matcher-side data in HBM (so_kframe_create), uploaded once when it joins the local-mapping thread's
-    // ring and read by every later keyframe's searches
-    so_kframe* dev = nullptr;
-    ~KfSnap() { so_kframe_destroy(dev); }
-};
-
-struct LmJob {
-    int timed = 0;
-    std::shared_ptr<KfSnap> kf;  // null: window only (warm-up / no vocabulary)
-};
-
-struct so_replay {
-    int device = 0, width = 0, height = 0, lba_every = 5;
-    std::string host_cpus;  // the CPUs this agent's threads are pinned to (so_device_host_cpus); empty: no pinning
-    int keyframe_every = 8, local_keyframes = 0, third_pose = 1;
-    double keyframe_ratio = 0.7, plane_z = 2.0;
-    so_camera cam{};
-    so_extractor* ex = nullptr;
-    // three device-resident frames rotate: the last frame (read by the motion-model search), the current one and the
-    // one being extracted ahead
-    so_dframe* fr[3] = {nullptr, nullptr, nullptr};
-    so_matcher* matcher = nullptr;
-    so_map* map = nullptr;
-    so_ba* tracker_opt = nullptr;
-    so_ba* mapper_opt = nullptr;
-    so_matcher* mapper_matcher = nullptr;  // the local-mapping thread's own matcher context
-    std::vector<uint8_t> vocab;            // n_vocab x 32 centroid descriptors (so_replay_set_vocabulary)
-    int lm_neighbours = 20;                // nn = 20, LocalMapping.cc:207,455 (monocular)
-    bool lm_resident = true;               // neighbours are searched in HBM-resident form (SWARMORB_LM_RESIDENT=0: host views)
-    bool lm_batch = true;                  // all searches of a keyframe as one so_matcher batch (SWARMORB_LM_BATCH=0: one by one)
-    bool lm_from_map = true;               // Fuse reads the map points from the resident map by slot (SWARMORB_LM_MAP=0: staged arrays)
-    std::vector<int32_t> lm_cslot;         // vpFuseCandidates as map slots
-    std::deque<std::shared_ptr<KfSnap>> lm_ring;  // (local-mapping thread only)
-    std::vector<int32_t> lm_stamp, lm_cstamp;     // slot -> id of the keyframe / job that marked it
-    std::vector<float> lm_cX, lm_cN, lm_cmax, lm_cmin;  // vpFuseCandidates of the keyframe being processed
-    std::vector<uint8_t> lm_cD, lm_cok;
-    int lm_stamp_id = 0;
-    double lm_stat[24] = {0};
-    std::vector<int32_t> lm_log;           // 6 ints per job: t, neighbours, triangulation matches, fused, fused back, new map points
-    std::vector<int32_t> lm_tof, lm_to1, lm_to2, lm_noff;  // scratch of the triangulation step (capacity kept)
-    std::vector<float> lm_txy1, lm_txy2, lm_tX, lm_nobs, lm_nX, lm_nref, lm_nls, lm_nll, lm_nnrm, lm_nmax, lm_nmin;
-    std::vector<uint8_t> lm_tok;
-    std::vector<const uint8_t*> frames;
-    bool frames_on_device = false;
-    // so_fleet_run: the extractors of the fleet this agent leads, as one group (one extraction chain for all agents)
-    so_extractor_group* fleet_group = nullptr;
-    std::vector<so_extractor*> fleet_members;
-    BaWindow window;
-    float scale[8] = {0}, inv_sigma2[8] = {0};
-    int nlevels = 8;
-    float log_sf = 0.f;
-    int cap = 0;
-    // frame state: [0] / [1] alternate as current / last
-    struct FrameHost {
-        std::vector<so_keypoint> kps;
-        std::vector<float> xy_un;
-        std::vector<uint8_t> desc;
-        std::vector<int32_t> kp_mp;
-        std::vector<uint8_t> outlier;
-        int n = 0;
-    } fh[2];
-    int cur = 0;
-    int submitted = -1;  // handle index holding the frame in flight
-    int last_tracked = -1;  // handle index of the frame tracked last
-    bool in_flight = false;
-    bool live = false;   // so_replay_run_live: no frame is extracted ahead
-    int n_tracked = 0;   // frames tracked so far (0: the next frame initialises the map)
-    float bounds[4] = {0, 0, 0, 0};
-    M4 T_last = M4::eye(), velocity = M4::eye();
-    int kf_inliers = 0;
-    // host copy of the map positions (PoseOptimization inputs are gathered here) + keyframe bookkeeping
-    std::vector<float> mp_X;
-    std::vector<float> mp_N, mp_max, mp_min;  // normal, mfMaxDistance, mfMinDistance as written to the device table
-    std::vector<uint8_t> mp_desc;
-    std::vector<int32_t> kf_first_slot;
-    // scratch
-    std::vector<int32_t> last_slot, k2l, k2m, idx, local_slot;
-    std::vector<uint8_t> skip, excluded, pose_out;
-    std::vector<float> pX, pobs, pw, new_X, new_N, new_max, new_min;
-    std::vector<uint8_t> new_desc;
-    // log (every tracked frame)
-    std::vector<float> poses;  // 12 per frame
-    std::vector<int32_t> n_m2, n_m1, n_inl, n_map;
-    // local-mapping thread
-    std::thread mapper;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<LmJob> queue;  // timed = 1: counted window, 0: warm-up window
-    int running = 0;
-    bool quit = false;
-    std::string error;
-    // the frame being tracked (stage functions below)
-    struct Step {
-        double t0 = 0, t1 = 0, tm2 = 0, tp1 = 0, tm1 = 0, tp2 = 0, tp3 = 0, tmap = 0;
-        double match_kernel = 0, pose_kernel = 0, pose_trials = 0, pose_points = 0, mstat[4] = {0, 0, 0, 0}, reruns = 0, wide_m2 = 0;
-        int pose_calls = 0, pose_timed_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0, hcur = 0, first_slot = 0;
-        int32_t n_in = 0;
-        int map_size_at_begin = 0;
-        bool first = false, m2_submitted = false, timed_kernels = true, next_submitted = false;
-        int m2_rc = 0;
-        float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
-        M4 T = M4::eye();
-    } step;
-    float K4[4] = {0, 0, 0, 0};
-    // statistics (timed steps only)
-    double stat[48] = {0};
-    unsigned lba_windows_run = 0;  // (local-mapping thread only)
-    std::vector<float> frame_ms;
-    std::vector<float> ba_Tcw, ba_Xw;
-    std::vector<uint8_t> ba_out;
-};
-
-namespace {
-
-enum {  // indices of so_replay::stat, mirrored in bench.py
-    kSteps = 0, kExtractMs, kM2Ms, kPose1Ms, kM1Ms, kPose2Ms, kPose3Ms, kMapMs, kSubmitWaitMs, kKp, kM2, kM1, kInliers,
-    kMatchKernelMs, kPoseKernelMs, kPoseTrials, kPoseCalls, kPosePoints, kLbaWindows, kLbaBusyMs, kLbaGpuMs, kLbaSolveMs,
-    kLbaSolves, kLocalPoints, kInView, kKeyframes, kMapPoints, kM2EnqMs, kM2WaitMs, kM1EnqMs, kM1WaitMs, kPoseTimedCalls,
-    kTimedFrames, kStage0 /* 11 extractor stages */, kReruns = kStage0 + SO_EXTRACTOR_N_STAGES /* search launches: 2 per frame + exact re-runs of exhausted K-lists */,
-    kWideM2 /* motion-model searches repeated with the wider window */,
-    kLbaTrials /* LM trials (= reduced-system solves) of all windows; kLbaSolves / kLbaSolveMs cover the event-timed ones */
-};
 
 so_frame_view keyframe_view(const so_replay* r, const KfSnap& k) {
     so_frame_view v;
@@ -307,9 +81,6 @@ void fundamental_and_epipole(const so_replay* r, const float* T1, const float* T
     *ey = (float)(fy * C2[1] / C2[2] + cy);
 }
 
-enum { kLmJobs = 0, kLmWallMs, kLmNodeMs, kLmTriCalls, kLmTriMs, kLmTriKernelMs, kLmTriMatches, kLmFuseCalls, kLmFuseMs,
-       kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries, kLmBatchMs, kLmBatchEndMs, kLmBatchKernelMs, kLmTriangMs, kLmTriangKernelMs, kLmNewPoints,
-       kLmStageTriMs, kLmStageFuseMs, kLmStageBackMs, kLmBatchEnqueueMs, kLmBatchWaitMs };
 
 // CreateNewMapPoints' and SearchInNeighbors' matcher load for the new keyframe `c` (see the file header).
 int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {

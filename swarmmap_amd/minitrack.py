@@ -55,16 +55,19 @@ class HipBackend:
         return dfm.search_last_frame(self.m_last, self.frames[self.cur], self.frames[1 - self.cur], self.map, Tcw,
                                      last_slot, th)
 
-    def search_local(self, Tcw, first, n_local, skip, excluded, th, log_sf):
+    def search_local(self, Tcw, first, n_local, skip, excluded, th, log_sf, local_slot=None):
         from . import dframe as dfm
         return dfm.search_local_map(self.m_map, self.frames[self.cur], self.map, Tcw, n_local, th, COS_LIMIT, log_sf,
-                                    skip=skip, excluded=excluded, first_slot=first)
+                                    local_slot=local_slot, skip=skip, excluded=excluded, first_slot=first)
 
     def map_append(self, X, normal, max_d, min_d, desc):
         self.map.append(X, normal, max_d, min_d, desc)
 
     def map_set_positions(self, slots, X):
         self.map.write_positions(slots, X)
+
+    def map_write_rows(self, slots, X=None, normal=None, max_d=None, min_d=None):
+        self.map.write_rows(slots, X, normal, max_d, min_d)
 
     def pose(self, Tcw, intr, Xw, obs, w):
         n, T, outl, _ = self.opt.PoseOptimization(Tcw, intr, Xw, obs, w)
@@ -92,6 +95,12 @@ class HipBackend:
 
     def triangulate(self, kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2):
         return self._lm().TriangulateMatches(kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2)
+
+    def fuse_idx(self, KF, K, Tcw, log_sf, inv_sigma2, mp, th):
+        return self._lm().Fuse(KF, K, Tcw, log_sf, inv_sigma2, mp, th)[:3]
+
+    def triangulate_new_points(self, kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2):
+        return self._lm().TriangulateNewPoints(kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2)
 
     def update_normal_and_depth(self, *a):
         return self._lm().UpdateNormalAndDepth(*a)

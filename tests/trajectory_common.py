@@ -51,8 +51,8 @@ class OracleBackend:
                      has_obs=np.ones(len(lk), np.uint8))
         return orc.search_by_projection_lastframe(self._view(), lastd, th, True)
 
-    def search_local(self, Tcw, first, n_local, skip, excluded, th, log_sf):
-        sl = slice(first, first + n_local)
+    def search_local(self, Tcw, first, n_local, skip, excluded, th, log_sf, local_slot=None):
+        sl = slice(first, first + n_local) if local_slot is None else np.asarray(local_slot, np.int64)
         fr = orc.is_in_frustum(self.cam, self.bounds, Tcw, self.X[sl], self.normal[sl], self.max_d[sl], self.min_d[sl],
                                minitrack.COS_LIMIT, log_sf, self.cfg.nlevels)
         in_view = fr["in_view"] & (1 - np.asarray(skip, np.uint8))
@@ -68,6 +68,12 @@ class OracleBackend:
 
     def map_set_positions(self, slots, X):
         self.X[np.asarray(slots)] = X
+
+    def map_write_rows(self, slots, X=None, normal=None, max_d=None, min_d=None):
+        s = np.asarray(slots, np.int64)
+        for dst, src in ((self.X, X), (self.normal, normal), (self.max_d, max_d), (self.min_d, min_d)):
+            if src is not None:
+                dst[s] = src
 
     def pose(self, Tcw, intr, Xw, obs, w):
         n, T, outl, _ = orc.pose_optimization(Tcw, intr, Xw, obs, w)
@@ -86,6 +92,30 @@ class OracleBackend:
 
     def fuse(self, KF, K, Tcw, log_sf, inv_sigma2, mp, th):
         return orc.fuse(KF, orc.camera(K), Tcw, log_sf, inv_sigma2, mp, th)[0]
+
+    def fuse_idx(self, KF, K, Tcw, log_sf, inv_sigma2, mp, th):
+        return orc.fuse(KF, orc.camera(K), Tcw, log_sf, inv_sigma2, mp, th)
+
+    def triangulate_new_points(self, kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2):
+        """CreateNewMapPoints' per-match body + the new points' UpdateNormalAndDepth (two observations: kf1, then the
+        neighbour; kf1 the reference keyframe), as so_triangulate_new_points."""
+        ok, X = self.triangulate(kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2)
+        n = len(ok)
+        nrm, mx, mn = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        sel = np.nonzero(ok)[0]
+        if len(sel):
+            centre = lambda T: (-(np.asarray(T, np.float32).astype(np.float64).reshape(3, 4)[:, :3].T  # noqa: E731
+                                  @ np.asarray(T, np.float32).astype(np.float64).reshape(3, 4)[:, 3])).astype(np.float32)
+            O1 = centre(kf1["Tcw"])
+            O2 = np.stack([centre(k["Tcw"]) for k in kf2_list])
+            obs = np.stack([np.tile(O1, (len(sel), 1)), O2[np.asarray(kf2_of)[sel]]], 1).reshape(-1, 3)
+            sfa = np.asarray(kf1["scale_factors"], np.float32)
+            a, b, c = orc.update_normal_and_depth(np.arange(0, 2 * len(sel) + 1, 2, dtype=np.int32), obs, X[sel], np.tile(O1, (len(sel), 1)),
+                                                  sfa[np.asarray(o1)[sel]], np.full(len(sel), sfa[-1], np.float32),
+                                                  np.zeros((len(sel), 3), np.float32), np.zeros(len(sel), np.float32),
+                                                  np.zeros(len(sel), np.float32))
+            nrm[sel], mx[sel], mn[sel] = a, b, c
+        return ok, X, nrm, mx, mn
 
     def triangulate(self, kf1, kf2_list, ratio_factor, kf2_of, xy1, o1, xy2, o2):
         ok, X = np.zeros(len(o1), np.uint8), np.zeros((len(o1), 3), np.float32)
