@@ -380,6 +380,11 @@ int so_search_by_projection_keyframe(so_matcher* m, const so_frame_view* F, cons
  * SO_ERR_INVALID_ARG.  so_matcher_last_kernel_ms / _last_stats after so_matcher_batch_end cover the whole batch. */
 int so_matcher_batch_begin(so_matcher* m);
 int so_matcher_batch_end(so_matcher* m);
+/* Leaves a batch without running it: the deferred calls are dropped (their output arrays stay untouched unless an automatic
+ * flush already completed them) and the handle takes plain calls again.  For the error path of a caller whose call inside
+ * the batch failed; a handle that is not batching is left alone.  so_matcher_batch_end leaves the batch on every path,
+ * failures included. */
+int so_matcher_batch_abort(so_matcher* m);
 
 /* HBM-resident keyframes.  A keyframe is searched again and again - by every later keyframe's SearchForTriangulation
  * and Fuse while it is among the <= 20 covisible neighbours (code/src/LocalMapping.cc:197-246, 451-481) - and its

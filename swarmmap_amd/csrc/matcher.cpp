@@ -2010,6 +2010,7 @@ void export_queries(const so_window_queries* out, const MatchQueryW* qw, int n) 
 }
 
 void begin_call(so_matcher* m) {
+    if (m->batching) return;  // a batch's statistics cover all of its flushes: they are reset by so_matcher_batch_begin only
     m->last_ms = 0.f;
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
 }
@@ -2827,6 +2828,8 @@ int so_matcher_batch_begin(so_matcher* m) {
         return SO_ERR_INVALID_ARG;
     }
     SO_HIP(hipSetDevice(m->device));
+    m->last_ms = 0.f;
+    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     m->batching = true;
     m->mp_share.n = -1;
     m->jobs.clear();
@@ -2834,18 +2837,35 @@ int so_matcher_batch_begin(so_matcher* m) {
     return SO_OK;
 }
 
-int so_matcher_batch_end(so_matcher* m) {
-    if (!m || !m->batching) return SO_ERR_INVALID_ARG;
-    SO_HIP(hipSetDevice(m->device));
-    m->last_ms = 0.f;
-    m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
-    const int rc = batch_flush(m);
+namespace {
+void batch_close(so_matcher* m) {
     m->batching = false;
     m->jobs.clear();
+    m->hb_used = m->dq_used = m->out_used = 0;
+    m->mp_share.n = -1;
     m->src = nullptr;
     m->resident_n = -1;
     m->dirty_from = 0;
+}
+}  // namespace
+
+int so_matcher_batch_end(so_matcher* m) {
+    if (!m || !m->batching) return SO_ERR_INVALID_ARG;
+    int rc = SO_OK;
+    const hipError_t e = hipSetDevice(m->device);
+    if (e != hipSuccess) rc = so::hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
+    else rc = batch_flush(m);  // (statistics accumulate over automatic mid-batch flushes too: reset in batch_begin only)
+    batch_close(m);
     return rc;
+}
+
+int so_matcher_batch_abort(so_matcher* m) {
+    if (!m) return SO_ERR_INVALID_ARG;
+    if (!m->batching) return SO_OK;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);  // an automatic flush may still be running
+    batch_close(m);
+    return SO_OK;
 }
 
 }  // extern "C"

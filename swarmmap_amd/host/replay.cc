@@ -32,56 +32,6 @@
 namespace {
 
 
-so_frame_view keyframe_view(const so_replay* r, const KfSnap& k) {
-    so_frame_view v;
-    memset(&v, 0, sizeof(v));
-    v.n = k.n;
-    v.x = k.x.data(); v.y = k.y.data(); v.octave = k.octave.data(); v.angle = k.angle.data(); v.desc = k.desc.data();
-    // a KeyFrame's bounds are the Frame's truncated to int, its grid is the Frame's (include/swarmorb.h, so_frame_view)
-    v.min_x = (float)(int)k.bounds[0]; v.max_x = (float)(int)k.bounds[1];
-    v.min_y = (float)(int)k.bounds[2]; v.max_y = (float)(int)k.bounds[3];
-    v.grid_inv_w = 64.0f / (k.bounds[1] - k.bounds[0]);
-    v.grid_inv_h = 48.0f / (k.bounds[3] - k.bounds[2]);
-    v.has_grid_origin = 1;
-    v.grid_min_x = k.bounds[0];
-    v.grid_min_y = k.bounds[2];
-    v.scale_factors = r->scale;
-    v.nlevels = r->nlevels;
-    return v;
-}
-
-// LocalMapping::ComputeF12 (code/src/LocalMapping.cc:593-609) and the epipole of SearchForTriangulation
-// (code/src/ORBmatcher.cc:605-613) from the two poses; both keyframes share K.
-void fundamental_and_epipole(const so_replay* r, const float* T1, const float* T2, float* F12, float* ex, float* ey) {
-    double R1[9], R2[9], t1[3], t2[3];
-    for (int i = 0; i < 3; i++) {
-        for (int j = 0; j < 3; j++) { R1[3 * i + j] = T1[4 * i + j]; R2[3 * i + j] = T2[4 * i + j]; }
-        t1[i] = T1[4 * i + 3]; t2[i] = T2[4 * i + 3];
-    }
-    double R12[9], t12[3];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) R12[3 * i + j] = R1[3 * i] * R2[3 * j] + R1[3 * i + 1] * R2[3 * j + 1] + R1[3 * i + 2] * R2[3 * j + 2];
-    for (int i = 0; i < 3; i++) t12[i] = -(R12[3 * i] * t2[0] + R12[3 * i + 1] * t2[1] + R12[3 * i + 2] * t2[2]) + t1[i];
-    const double tx[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};
-    double A[9];  // t12x * R12
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) A[3 * i + j] = tx[3 * i] * R12[j] + tx[3 * i + 1] * R12[3 + j] + tx[3 * i + 2] * R12[6 + j];
-    const double fx = r->cam.fx, fy = r->cam.fy, cx = r->cam.cx, cy = r->cam.cy;
-    const double Kit[9] = {1 / fx, 0, 0, 0, 1 / fy, 0, -cx / fx, -cy / fy, 1};  // K^-T
-    const double Ki[9] = {1 / fx, 0, -cx / fx, 0, 1 / fy, -cy / fy, 0, 0, 1};   // K^-1
-    double B[9];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) B[3 * i + j] = Kit[3 * i] * A[j] + Kit[3 * i + 1] * A[3 + j] + Kit[3 * i + 2] * A[6 + j];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) F12[3 * i + j] = (float)(B[3 * i] * Ki[j] + B[3 * i + 1] * Ki[3 + j] + B[3 * i + 2] * Ki[6 + j]);
-    double Cw[3], C2[3];
-    for (int j = 0; j < 3; j++) Cw[j] = -(R1[j] * t1[0] + R1[3 + j] * t1[1] + R1[6 + j] * t1[2]);
-    for (int i = 0; i < 3; i++) C2[i] = R2[3 * i] * Cw[0] + R2[3 * i + 1] * Cw[1] + R2[3 * i + 2] * Cw[2] + t2[i];
-    *ex = (float)(fx * C2[0] / C2[2] + cx);
-    *ey = (float)(fy * C2[1] / C2[2] + cy);
-}
-
-
 // CreateNewMapPoints' and SearchInNeighbors' matcher load for the new keyframe `c` (see the file header).
 int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
     so_matcher* m = r->mapper_matcher;
@@ -125,6 +75,11 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
     std::vector<std::vector<uint8_t>> fuse_valid(nn);
     const double tb0 = now_ms();
     if (batch && so_matcher_batch_begin(m) != SO_OK) return SO_ERR_HIP;
+    struct BatchGuard {  // an early return below leaves the handle usable (the deferred calls' output arrays die with this frame)
+        so_matcher* m;
+        bool armed;
+        ~BatchGuard() { if (armed) so_matcher_batch_abort(m); }
+    } guard{m, batch};
     // ---- CreateNewMapPoints: SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false) per neighbour
     size_t jn = 0;
     const double tc0 = now_ms();
@@ -261,6 +216,7 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
     st[kLmStageBackMs] = now_ms() - te0;
     if (batch) {
         const double ta = now_ms();
+        guard.armed = false;  // (so_matcher_batch_end leaves the batch on every path)
         if (so_matcher_batch_end(m) != SO_OK) return SO_ERR_HIP;
         double ms4[4] = {0};
         so_matcher_last_stats(m, ms4);
@@ -380,7 +336,7 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
         std::lock_guard<std::mutex> lk(r->mu);
         r->lm_log.insert(r->lm_log.end(), row, row + 6);
         if (timed)
-            for (int i = 0; i < 24; i++) r->lm_stat[i] += st[i];
+            for (int i = 0; i < 24; i++) r->lm_stat[i] += st[i];  // ([24..31]: the closed loop's job)
     }
     return SO_OK;
 }
@@ -440,6 +396,28 @@ void mapper_loop(so_replay* r) {
         }
         const double t0 = now_ms();
         int lm_rc = SO_OK;
+        if (r->cl) {  // the closed loop: the keyframe's whole local-mapping job, results handed back to the tracking side
+            so_ba_info info{};
+            lm_rc = kf ? cl_lm_job(r, kf, timed != 0, &info) : SO_OK;
+            const double busy = now_ms() - t0;
+            {
+                std::lock_guard<std::mutex> lk(r->mu);
+                if (lm_rc != SO_OK && r->error.empty()) r->error = std::string("closed-loop local-mapping job: ") + so_last_error();
+                if (timed) {
+                    r->stat[kLbaWindows] += info.lm_trials > 0 ? 1 : 0;
+                    r->stat[kLbaBusyMs] += busy;
+                    r->stat[kLbaGpuMs] += info.gpu_ms;
+                    r->stat[kLbaSolveMs] += info.solve_ms;
+                    r->stat[kLbaSolves] += info.n_solves;
+                    r->stat[kLbaTrials] += info.lm_trials;
+                }
+                r->queue.pop_front();
+                r->running = 0;
+            }
+            r->cv.notify_all();
+            r->cl->cv.notify_all();  // (an error wakes a tracking thread that waits for the packet)
+            continue;
+        }
         if (kf) lm_rc = lm_matcher_job(r, kf, timed != 0);  // CreateNewMapPoints + SearchInNeighbors before the LBA
         so_ba_problem p{};
         const BaWindow& w = r->window;
@@ -699,7 +677,7 @@ int so_replay_set_vocabulary(so_replay* r, const uint8_t* centroids, int n, int 
 }
 // statistics of the timed matcher jobs (indices: the kLm* enumeration above) and the log of every job:
 // 6 ints each = frame index, neighbours, SearchForTriangulation matches, points fused into neighbours, fused back, new map points
-int so_replay_lm_stats(so_replay* r, double* out16) {  // (24 doubles)
+int so_replay_lm_stats(so_replay* r, double* out16) {  // (32 doubles)
     if (!r || !out16) return SO_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(r->mu);
     memcpy(out16, r->lm_stat, sizeof(r->lm_stat));
@@ -711,6 +689,62 @@ int so_replay_lm_log(so_replay* r, int32_t* out, int cap_rows) {
     const int rows = (int)(r->lm_log.size() / 6);
     if (out) memcpy(out, r->lm_log.data(), sizeof(int32_t) * 6 * (size_t)std::min(rows, cap_rows));
     return rows;
+}
+
+// The closed loop (closedloop.cc): every keyframe's local-mapping results - triangulated points, fused duplicates, the poses
+// and points local BA moved over the keyframe's OWN window, the observations it rejected - flow back into the tracked map.
+// Needs a vocabulary and local_keyframes > 0; set before the first frame.  kf_every: frames between keyframes; delay:
+// frames between a keyframe and the arrival of its results in the tracked map (policy 0, the deterministic schedule:
+// the tracking thread waits for the job if it is not done by then); policy 1: the reference's own policy - results arrive
+// when they are ready, a keyframe is only made while local mapping is idle, a busy local mapper gets InterruptBA
+// (Tracking.cc:893-903, LocalMapping.cc:581-583).  n_free / n_fixed: caps of the window's free / fixed keyframes.
+int so_replay_set_closed_loop(so_replay* r, int kf_every, int delay, int n_free, int n_fixed, int policy) {
+    if (!r || r->n_tracked > 0 || r->vocab.empty() || r->local_keyframes <= 0 || kf_every < 1 || delay < 1 || n_free < 1 || n_fixed < 0)
+        return SO_ERR_INVALID_ARG;
+    r->cl.reset(new ClosedLoop());
+    r->cl->kf_every = kf_every; r->cl->delay = delay; r->cl->n_free = n_free; r->cl->n_fixed = n_fixed; r->cl->policy = policy ? 1 : 0;
+    return SO_OK;
+}
+// counts[0..7]: local-mapping jobs, windows solved, windows aborted by the stop flag, InterruptBA calls, map slots, bad
+// points, keyframes, reserved; wait_ms: time the tracking thread waited for packets (deterministic schedule)
+int so_replay_cl_counts(so_replay* r, int64_t* counts8, double* wait_ms) {
+    if (!r || !r->cl || !counts8) return SO_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(r->mu);  // (call after so_replay_drain: the local-mapping side is read here)
+    ClosedLoop& M = *r->cl;
+    int64_t nbad = 0;
+    for (uint8_t b : M.bad) nbad += b;
+    const int64_t c[8] = {(int64_t)(M.lm_log.size() / 12), M.windows, M.aborted, M.interrupts, (int64_t)M.bad.size(), nbad, (int64_t)M.kfs.size(), 0};
+    memcpy(counts8, c, sizeof(c));
+    if (wait_ms) *wait_ms = M.wait_ms;
+    return SO_OK;
+}
+// the local-mapping log: 12 int64 per job (swarmmap_amd/closedloop.py LM_LOG_COLUMNS); returns the number of rows
+int so_replay_cl_log(so_replay* r, int64_t* out, int cap_rows) {
+    if (!r || !r->cl) return SO_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(r->mu);
+    const int rows = (int)(r->cl->lm_log.size() / 12);
+    if (out) memcpy(out, r->cl->lm_log.data(), sizeof(int64_t) * 12 * (size_t)std::min(rows, cap_rows));
+    return rows;
+}
+// after so_replay_drain: the keyframes' frame indices and final poses (12 floats each), and per tracked frame the id of its
+// reference keyframe and its pose relative to it (16 doubles) - System::SaveTrajectoryTUM composes the two
+// (code/src/System.cc:225-252)
+int so_replay_cl_keyframes(so_replay* r, int32_t* kf_t, float* poses12, int cap) {
+    if (!r || !r->cl) return SO_ERR_INVALID_ARG;
+    const int n = (int)r->cl->kfs.size();
+    for (int i = 0; i < std::min(n, cap); i++) {
+        if (kf_t) kf_t[i] = r->cl->kfs[(size_t)i]->t;
+        if (poses12) memcpy(poses12 + 12 * (size_t)i, r->cl->kfs[(size_t)i]->T, 48);
+    }
+    return n;
+}
+int so_replay_cl_frames(so_replay* r, int32_t* ref_kf, double* Tcr16, int cap) {
+    if (!r || !r->cl) return SO_ERR_INVALID_ARG;
+    const int n = (int)r->cl->ref_log.size();
+    const int m = std::min(n, cap);
+    if (ref_kf) memcpy(ref_kf, r->cl->ref_log.data(), 4 * (size_t)m);
+    if (Tcr16) memcpy(Tcr16, r->cl->Tcr_log.data(), 8 * 16 * (size_t)m);
+    return n;
 }
 
 int so_replay_set_profiling(so_replay* r, int enabled) { return r ? so_extractor_set_profiling(r->ex, enabled) : SO_ERR_INVALID_ARG; }
@@ -735,6 +769,7 @@ int step_m2_submit(so_replay* r);
 int step_begin(so_replay* r, int t, bool submit_next = true) {
     so_replay::Step& S = r->step;
     S = so_replay::Step{};
+    S.t = t;
     S.t0 = now_ms();
     // kernel times come from HIP events on every kEventEvery-th frame of the run (two event records per search and
     // per PoseOptimization call are ~11 us of a 0.43 ms frame when taken on every frame)
@@ -742,6 +777,10 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
     so_matcher_set_profiling(r->matcher, S.timed_kernels);
     so_pose_optimization_set_timing(r->tracker_opt, S.timed_kernels);
     S.hcur = r->submitted;
+    if (r->cl) {  // what local mapping handed back arrives between two frames (Optimizer.cc:713 under Map::mMutexMapUpdate)
+        const int rc = cl_frame_begin(r, t);
+        if (rc) return rc;
+    }
     r->cur ^= 1;
     so_replay::FrameHost& F = r->fh[r->cur];
     int n = 0;
@@ -778,6 +817,12 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
         for (int i = 0; i < n; i++) F.kp_mp[(size_t)i] = first + i;
         r->kf_inliers = n;
         S.keyframe = 1;
+        if (r->cl) {  // the initial map is the local map until the first keyframe's job reports
+            r->cl->tv_bad.assign((size_t)n, 0);
+            r->cl->tv_repl.assign((size_t)n, -1);
+            r->cl->tv_local.resize((size_t)n);
+            for (int i = 0; i < n; i++) r->cl->tv_local[(size_t)i] = first + i;
+        }
         S.tm2 = S.tp1 = S.tm1 = S.tp2 = S.tp3 = S.tmap = now_ms();
     }
     return SO_OK;
@@ -902,6 +947,28 @@ int step_m1_submit(so_replay* r) {
     so_replay::Step& S = r->step;
     so_replay::FrameHost& F = r->fh[r->cur];
     const int n = F.n;
+    if (r->cl) {  // the closed loop's local map: the slots local mapping listed when it finished its last keyframe
+        ClosedLoop& M = *r->cl;
+        const int nl = (int)M.tv_local.size();
+        S.first_slot = 0;
+        S.n_local = nl;
+        r->skip.resize((size_t)nl);
+        for (int i = 0; i < nl; i++) r->skip[(size_t)i] = M.tv_bad[(size_t)M.tv_local[(size_t)i]];
+        r->excluded.resize((size_t)n);
+        std::vector<uint8_t>& bound = r->new_desc;  // scratch: slot -> bound in this frame
+        bound.assign(r->mp_X.size() / 3, 0);
+        for (int k = 0; k < n; k++) {
+            const int s = F.kp_mp[(size_t)k];
+            r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
+            if (s >= 0) bound[(size_t)s] = 1;
+        }
+        for (int i = 0; i < nl; i++)
+            if (bound[(size_t)M.tv_local[(size_t)i]]) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:1117-1124)
+        if (so_track_search_local_map_submit(r->matcher, r->fr[S.hcur], r->excluded.data(), r->map, S.Ta, nl, M.tv_local.data(), 0,
+                                             r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf) != SO_OK)
+            return fail(r, "so_track_search_local_map_submit");
+        return SO_OK;
+    }
     const int n_map = (int)(r->mp_X.size() / 3);
     int first = 0;
     if (r->local_keyframes > 0 && (int)r->kf_first_slot.size() > r->local_keyframes)
@@ -941,7 +1008,8 @@ int step_m1_wait(so_replay* r) {
     S.nm1 = nmm;
     for (int i = 0; i < S.n_local; i++) S.n_view += view[(size_t)i];
     for (int k = 0; k < n; k++)
-        if (r->k2m[(size_t)k] >= 0) F.kp_mp[(size_t)k] = S.first_slot + r->k2m[(size_t)k];
+        if (r->k2m[(size_t)k] >= 0)
+            F.kp_mp[(size_t)k] = r->cl ? r->cl->tv_local[(size_t)r->k2m[(size_t)k]] : S.first_slot + r->k2m[(size_t)k];
     S.tm1 = now_ms();
     return SO_OK;
 }
@@ -960,6 +1028,38 @@ int step_keyframe(so_replay* r) {
     so_replay::Step& S = r->step;
     so_replay::FrameHost& F = r->fh[r->cur];
     const int n = F.n;
+    if (r->cl) {
+        // Tracking::NeedNewKeyFrame, monocular (Tracking.cc:810-905): enough frames since the last keyframe or too few
+        // inliers against it - and local mapping idle; under the reference's policy a busy local mapper gets InterruptBA
+        // instead (:893-903) and the keyframe waits; the deterministic schedule never asks while a job is out
+        ClosedLoop& M = *r->cl;
+        const int t = S.t, since = t - M.last_kf_t;
+        const bool weak = (double)S.n_in < r->keyframe_ratio * (double)r->kf_inliers;
+        bool need;
+        if (M.policy == 0) need = !M.job_pending && (since >= M.kf_every || (since >= M.delay && weak));
+        else {
+            need = since >= M.kf_every || weak;
+            if (need && M.job_pending) {
+                bool done;
+                {
+                    std::lock_guard<std::mutex> lk(M.mu);
+                    done = !M.outbox.empty();
+                }
+                if (!done) {  // mpLocalMapper->InterruptBA()
+                    M.stop = 1;
+                    M.interrupts++;
+                }
+                need = false;
+            }
+        }
+        if (need) {
+            r->kf_inliers = S.n_in > 1 ? S.n_in : 1;
+            S.keyframe = 1;
+        }
+        r->velocity = mul(S.T, rigid_inverse_general(r->T_last));
+        S.tmap = now_ms();
+        return SO_OK;
+    }
     if ((double)S.n_in < r->keyframe_ratio * (double)r->kf_inliers || r->n_tracked % r->keyframe_every == 0) {
         std::vector<uint8_t> fresh((size_t)n, 0);
         int n_fresh = 0;
@@ -993,6 +1093,27 @@ std::shared_ptr<KfSnap> snapshot_keyframe(so_replay* r, int t) {
     k->t = t;
     k->x.resize((size_t)n); k->y.resize((size_t)n); k->angle.resize((size_t)n); k->octave.resize((size_t)n); k->mp.resize((size_t)n);
     k->desc.assign(F.desc.begin(), F.desc.begin() + 32 * (size_t)n);
+    if (r->cl) {  // the closed loop: the bindings Tracking leaves in the frame (inliers only); local mapping has the points
+        const bool init = r->cl->n_kf == 0;
+        for (int i = 0; i < n; i++) {
+            k->x[(size_t)i] = F.xy_un[2 * (size_t)i];
+            k->y[(size_t)i] = F.xy_un[2 * (size_t)i + 1];
+            k->angle[(size_t)i] = F.kps[(size_t)i].angle;
+            k->octave[(size_t)i] = F.kps[(size_t)i].octave;
+            const int slot = F.kp_mp[(size_t)i];
+            k->mp[(size_t)i] = (slot >= 0 && !F.outlier[(size_t)i]) ? slot : -1;
+        }
+        if (init) {  // keyframe 0 carries the initial map (slot i = keypoint i)
+            k->mpX.assign(r->mp_X.begin(), r->mp_X.begin() + 3 * (size_t)n);
+            k->mpN.assign(r->new_N.begin(), r->new_N.begin() + 3 * (size_t)n);
+            k->mpMax.assign(r->new_max.begin(), r->new_max.begin() + (size_t)n);
+            k->mpMin.assign(r->new_min.begin(), r->new_min.begin() + (size_t)n);
+            k->mpDesc.assign(F.desc.begin(), F.desc.begin() + 32 * (size_t)n);
+        }
+        to_f12(S.T, k->T);
+        memcpy(k->bounds, r->bounds, sizeof(k->bounds));
+        return k;
+    }
     k->mpX.assign(3 * (size_t)n, 0.f); k->mpN.assign(3 * (size_t)n, 0.f);
     k->mpMax.assign((size_t)n, 0.f); k->mpMin.assign((size_t)n, 0.f); k->mpDesc.assign(32 * (size_t)n, 0);
     for (int i = 0; i < n; i++) {
@@ -1034,7 +1155,21 @@ void step_end(so_replay* r, int t, int timed) {
     r->n_tracked++;
     const double t3 = now_ms();
     r->frame_ms.push_back((float)(t3 - S.t0));
-    if (t % r->lba_every == 0 && !r->window.epose.empty()) {
+    if (r->cl) {
+        std::shared_ptr<KfSnap> snap;
+        if (S.keyframe) {
+            snap = snapshot_keyframe(r, t);
+            LmJob job;
+            job.timed = timed ? 1 : 0;
+            job.kf = snap;
+            {
+                std::lock_guard<std::mutex> lk(r->mu);
+                r->queue.push_back(job);
+            }
+            r->cv.notify_all();
+        }
+        cl_frame_end(r, t, S.keyframe != 0, snap);
+    } else if (t % r->lba_every == 0 && !r->window.epose.empty()) {
         LmJob job;
         job.timed = timed ? 1 : 0;
         if (!r->vocab.empty()) job.kf = snapshot_keyframe(r, t);

@@ -96,7 +96,48 @@ static inline M4 from_f12(const float* p) {
 
 }  // namespace
 
-struct ClosedLoop;
+// ---- the closed loop (closedloop.cc; swarmmap_amd/closedloop.py is the same logic in Python) ----
+// What a keyframe's local-mapping job hands back to the tracking side; applied between two frames.
+struct LmPacket {
+    int kf = 0, first_new = 0, n_points = 0;  // rows [first_new, n_points) of the map are new
+    std::vector<float> new_X;
+    std::vector<int32_t> moved;  // slots local BA moved (SetWorldPos + UpdateNormalAndDepth)
+    std::vector<float> moved_X, moved_N, moved_mx, moved_mn;
+    std::vector<int32_t> bad, bad_repl;  // points that went bad in this job and what replaced them (-1: nothing)
+    float kf_T[12] = {0};                // the keyframe's pose after local BA
+    std::vector<int32_t> local_slots;    // the local map for Tracking::SearchLocalPoints from now on
+};
+struct KfSnap;
+struct ClosedLoop {
+    int kf_every = 5, delay = 5, n_free = 25, n_fixed = 40;
+    int policy = 0;  // 0: deterministic schedule (results arrive `delay` frames after the keyframe); 1: the reference's policy
+    // ---- the map as local mapping sees it (local-mapping thread only) ----
+    std::vector<float> X, N, mx, mn;
+    std::vector<uint8_t> D, bad;
+    std::vector<int32_t> repl, ref_kf, first_kf;
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> obs;  // per point: (keyframe id, keypoint index), insertion order
+    std::vector<std::shared_ptr<KfSnap>> kfs;
+    std::vector<int32_t> recent;  // mlpRecentAddedMapPoints
+    std::vector<int32_t> newly_bad;
+    std::vector<int32_t> stamp;   // scratch: slot -> id of the pass that marked it
+    int stamp_id = 0;
+    std::vector<int64_t> lm_log;  // 12 per job (closedloop.LM_LOG_COLUMNS)
+    int windows = 0, aborted = 0, skipped = 0;
+    // ---- the tracking side's view (tracking thread only; positions: so_replay::mp_X) ----
+    std::vector<uint8_t> tv_bad;
+    std::vector<int32_t> tv_repl, tv_local;
+    M4 T_ref = M4::eye(), Tlr = M4::eye();
+    int last_kf_t = 0, n_kf = 0, apply_at = 0, interrupts = 0;
+    bool job_pending = false;
+    double wait_ms = 0.0;
+    std::vector<int32_t> ref_log, kf_t;  // per frame: id of its reference keyframe; per keyframe: frame index
+    std::vector<double> Tcr_log;         // per frame: pose relative to the reference keyframe (16)
+    // ---- hand-over ----
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<LmPacket> outbox;
+    volatile uint8_t stop = 0;  // mbAbortBA
+};
 // What the local-mapping thread keeps of a tracked frame that became a keyframe (KeyFrame::KeyFrame(Frame&, ...),
 // code/src/KeyFrame.cc:47-72): keypoints, descriptors, pose, bindings to map points that existed before the frame
 // (those created AT the frame play the part of the still untriangulated features: -1), the bound points' fields.
@@ -109,6 +150,7 @@ struct KfSnap {
     std::vector<uint8_t> mpDesc;
     float T[12] = {0}, bounds[4] = {0, 0, 0, 0};
     int t = 0;
+    int id = 0;  // closed loop: index in ClosedLoop::kfs
     // DBoW2::FeatureVector stand-in, filled by the local-mapping thread
     std::vector<int32_t> node_id, off, idx;
     // the keyframe's matcher-side data in HBM (so_kframe_create), uploaded once when it joins the local-mapping thread's
@@ -148,7 +190,7 @@ struct so_replay {
     std::vector<float> lm_cX, lm_cN, lm_cmax, lm_cmin;  // vpFuseCandidates of the keyframe being processed
     std::vector<uint8_t> lm_cD, lm_cok;
     int lm_stamp_id = 0;
-    double lm_stat[24] = {0};
+    double lm_stat[32] = {0};  // kLm* below; [24..31] closed loop: process, Fuse-batch kernels, apply, window gather, solver call, write-back, local BA, whole job
     std::vector<int32_t> lm_log;           // 6 ints per job: t, neighbours, triangulation matches, fused, fused back, new map points
     std::vector<int32_t> lm_tof, lm_to1, lm_to2, lm_noff;  // scratch of the triangulation step (capacity kept)
     std::vector<float> lm_txy1, lm_txy2, lm_tX, lm_nobs, lm_nX, lm_nref, lm_nls, lm_nll, lm_nnrm, lm_nmax, lm_nmin;
@@ -209,6 +251,7 @@ struct so_replay {
         int pose_calls = 0, pose_timed_calls = 0, nm2 = 0, nm1 = 0, n_local = 0, n_view = 0, keyframe = 0, hcur = 0, first_slot = 0;
         int32_t n_in = 0;
         int map_size_at_begin = 0;
+        int t = 0;  // the frame's index
         bool first = false, m2_submitted = false, timed_kernels = true, next_submitted = false;
         int m2_rc = 0;
         float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
@@ -221,7 +264,13 @@ struct so_replay {
     std::vector<float> frame_ms;
     std::vector<float> ba_Tcw, ba_Xw;
     std::vector<uint8_t> ba_out;
+    std::unique_ptr<ClosedLoop> cl;  // non-null: the closed loop (so_replay_set_closed_loop)
 };
+
+// closedloop.cc
+int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_info* info);  // local-mapping thread
+int cl_frame_begin(so_replay* r, int t);  // tracking thread, before the frame's first search: applies what local mapping handed back
+void cl_frame_end(so_replay* r, int t, bool keyframe, const std::shared_ptr<KfSnap>& snap);
 
 namespace {
 enum {  // indices of so_replay::stat, mirrored in bench.py
@@ -236,3 +285,52 @@ enum { kLmJobs = 0, kLmWallMs, kLmNodeMs, kLmTriCalls, kLmTriMs, kLmTriKernelMs,
        kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries, kLmBatchMs, kLmBatchEndMs, kLmBatchKernelMs, kLmTriangMs, kLmTriangKernelMs, kLmNewPoints,
        kLmStageTriMs, kLmStageFuseMs, kLmStageBackMs, kLmBatchEnqueueMs, kLmBatchWaitMs };
 }  // namespace
+
+static inline so_frame_view keyframe_view(const so_replay* r, const KfSnap& k) {
+    so_frame_view v;
+    memset(&v, 0, sizeof(v));
+    v.n = k.n;
+    v.x = k.x.data(); v.y = k.y.data(); v.octave = k.octave.data(); v.angle = k.angle.data(); v.desc = k.desc.data();
+    // a KeyFrame's bounds are the Frame's truncated to int, its grid is the Frame's (include/swarmorb.h, so_frame_view)
+    v.min_x = (float)(int)k.bounds[0]; v.max_x = (float)(int)k.bounds[1];
+    v.min_y = (float)(int)k.bounds[2]; v.max_y = (float)(int)k.bounds[3];
+    v.grid_inv_w = 64.0f / (k.bounds[1] - k.bounds[0]);
+    v.grid_inv_h = 48.0f / (k.bounds[3] - k.bounds[2]);
+    v.has_grid_origin = 1;
+    v.grid_min_x = k.bounds[0];
+    v.grid_min_y = k.bounds[2];
+    v.scale_factors = r->scale;
+    v.nlevels = r->nlevels;
+    return v;
+}
+
+// LocalMapping::ComputeF12 (code/src/LocalMapping.cc:593-609) and the epipole of SearchForTriangulation
+// (code/src/ORBmatcher.cc:605-613) from the two poses; both keyframes share K.
+static inline void fundamental_and_epipole(const so_replay* r, const float* T1, const float* T2, float* F12, float* ex, float* ey) {
+    double R1[9], R2[9], t1[3], t2[3];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) { R1[3 * i + j] = T1[4 * i + j]; R2[3 * i + j] = T2[4 * i + j]; }
+        t1[i] = T1[4 * i + 3]; t2[i] = T2[4 * i + 3];
+    }
+    double R12[9], t12[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R12[3 * i + j] = R1[3 * i] * R2[3 * j] + R1[3 * i + 1] * R2[3 * j + 1] + R1[3 * i + 2] * R2[3 * j + 2];
+    for (int i = 0; i < 3; i++) t12[i] = -(R12[3 * i] * t2[0] + R12[3 * i + 1] * t2[1] + R12[3 * i + 2] * t2[2]) + t1[i];
+    const double tx[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};
+    double A[9];  // t12x * R12
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) A[3 * i + j] = tx[3 * i] * R12[j] + tx[3 * i + 1] * R12[3 + j] + tx[3 * i + 2] * R12[6 + j];
+    const double fx = r->cam.fx, fy = r->cam.fy, cx = r->cam.cx, cy = r->cam.cy;
+    const double Kit[9] = {1 / fx, 0, 0, 0, 1 / fy, 0, -cx / fx, -cy / fy, 1};  // K^-T
+    const double Ki[9] = {1 / fx, 0, -cx / fx, 0, 1 / fy, -cy / fy, 0, 0, 1};   // K^-1
+    double B[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) B[3 * i + j] = Kit[3 * i] * A[j] + Kit[3 * i + 1] * A[3 + j] + Kit[3 * i + 2] * A[6 + j];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) F12[3 * i + j] = (float)(B[3 * i] * Ki[j] + B[3 * i + 1] * Ki[3 + j] + B[3 * i + 2] * Ki[6 + j]);
+    double Cw[3], C2[3];
+    for (int j = 0; j < 3; j++) Cw[j] = -(R1[j] * t1[0] + R1[3 + j] * t1[1] + R1[6 + j] * t1[2]);
+    for (int i = 0; i < 3; i++) C2[i] = R2[3 * i] * Cw[0] + R2[3 * i + 1] * Cw[1] + R2[3 * i + 2] * Cw[2] + t2[i];
+    *ex = (float)(fx * C2[0] / C2[2] + cx);
+    *ey = (float)(fy * C2[1] / C2[2] + cy);
+}

@@ -296,6 +296,31 @@ def _batch_end(self):
         self._batch_keep = []
 
 
+def _batch_abort(self):
+    """so_matcher_batch_abort: leaves a batch without running it (a call inside it failed)."""
+    self._lib.so_matcher_batch_abort.argtypes = [C.c_void_p]
+    self._batching, self._batch_keep = False, []
+    _lib.check(self._lib.so_matcher_batch_abort(self._h))
+
+
+class _Batch:
+    """`with matcher.batch():` - batch_begin / batch_end, batch_abort when a call inside raises."""
+
+    def __init__(self, m):
+        self.m = m
+
+    def __enter__(self):
+        self.m.batch_begin()
+        return self.m
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            self.m.batch_end()
+        else:
+            self.m.batch_abort()
+        return False
+
+
 def _SearchWindowBest(self, KF, q, chi2_gate=False, inv_sigma2=None):
     """Core of Fuse / SearchBySim3: q has valid, u, v, radius, pred_level, desc."""
     _bind_ext(self._lib)
@@ -331,6 +356,8 @@ def _SearchWindowGreedy(self, F, q, max_dist):
 ORBmatcher.SearchByBoW = _SearchByBoW
 ORBmatcher.batch_begin = _batch_begin
 ORBmatcher.batch_end = _batch_end
+ORBmatcher.batch_abort = _batch_abort
+ORBmatcher.batch = lambda self: _Batch(self)
 ORBmatcher.SearchForTriangulation = _SearchForTriangulation
 ORBmatcher.SearchWindowBest = _SearchWindowBest
 ORBmatcher.SearchWindowGreedy = _SearchWindowGreedy

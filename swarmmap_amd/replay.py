@@ -19,7 +19,11 @@ STAT = ("steps", "extract_ms", "m2_ms", "pose1_ms", "m1_ms", "pose2_ms", "pose3_
 LM_STAT = ("jobs", "wall_ms", "node_ms", "tri_calls", "tri_ms", "tri_kernel_ms", "tri_matches", "fuse_calls", "fuse_ms",
            "fuse_kernel_ms", "fused", "fuse_points", "tri_queries", "batch_ms", "batch_end_ms", "batch_kernel_ms",
            "triangulate_ms", "triangulate_kernel_ms", "new_points", "stage_tri_ms", "stage_fuse_ms", "stage_back_ms",
-           "batch_enqueue_ms", "batch_wait_ms")
+           "batch_enqueue_ms", "batch_wait_ms",
+           # the closed loop's job (closedloop.cc): ProcessNewKeyFrame + culling, the Fuse batch's kernels, applying the Fuse
+           # results, the window gather, the so_bundle_adjust call, its write-back, local BA as a whole, the whole job
+           "cl_process_ms", "cl_fuse_kernel_ms", "cl_apply_ms", "cl_gather_ms", "cl_solver_ms", "cl_writeback_ms", "cl_lba_ms",
+           "cl_job_ms")
 
 
 def make_vocabulary(n=100, seed=20221001):
@@ -99,7 +103,7 @@ class Replay:
 
     def lm_stats(self):
         """Sums over the timed matcher jobs of the local-mapping thread."""
-        a = np.zeros(24, np.float64)
+        a = np.zeros(32, np.float64)
         self.lib.so_replay_lm_stats(self.h, self._p(a))
         return dict(zip(LM_STAT, a[:len(LM_STAT)].tolist()))
 
@@ -110,6 +114,49 @@ class Replay:
         out = np.zeros((max(n, 1), 6), np.int32)
         n = min(n, self.lib.so_replay_lm_log(self.h, self._p(out), len(out)))
         return out[:n]
+
+    def set_closed_loop(self, kf_every=5, delay=None, n_free=25, n_fixed=40, policy=0):
+        """so_replay_set_closed_loop: every keyframe's local-mapping results flow back into the tracked map
+        (swarmmap_amd/closedloop.py is the same loop in Python).  After set_vocabulary, before the first frame."""
+        self.lib.so_replay_set_closed_loop.argtypes = [C.c_void_p] + [C.c_int] * 5
+        self._check(self.lib.so_replay_set_closed_loop(self.h, kf_every, kf_every if delay is None else delay, n_free, n_fixed,
+                                                       policy), "set_closed_loop")
+
+    def closed_loop_log(self):
+        """After drain(): dict(lm_log (rows of closedloop.LM_LOG_COLUMNS), kf_t, kf_poses (final), ref_kf, Tcr,
+        final_centres (System::SaveTrajectoryTUM: Tcr x final keyframe pose), kf_centres, counts)."""
+        vp, i32 = C.c_void_p, C.c_int
+        lib = self.lib
+        lib.so_replay_cl_log.argtypes = [vp, vp, i32]
+        lib.so_replay_cl_keyframes.argtypes = [vp, vp, vp, i32]
+        lib.so_replay_cl_frames.argtypes = [vp, vp, vp, i32]
+        lib.so_replay_cl_counts.argtypes = [vp, vp, vp]
+        n = lib.so_replay_cl_log(self.h, None, 0)
+        lm = np.zeros((max(n, 1), 12), np.int64)
+        n = min(n, lib.so_replay_cl_log(self.h, self._p(lm), len(lm)))
+        nk = lib.so_replay_cl_keyframes(self.h, None, None, 0)
+        kf_t, kf_T = np.zeros(max(nk, 1), np.int32), np.zeros((max(nk, 1), 12), np.float32)
+        lib.so_replay_cl_keyframes(self.h, self._p(kf_t), self._p(kf_T), nk)
+        nf = lib.so_replay_cl_frames(self.h, None, None, 0)
+        ref, Tcr = np.zeros(max(nf, 1), np.int32), np.zeros((max(nf, 1), 4, 4), np.float64)
+        lib.so_replay_cl_frames(self.h, self._p(ref), self._p(Tcr), nf)
+        counts, wait = np.zeros(8, np.int64), C.c_double(0)
+        self._check(lib.so_replay_cl_counts(self.h, self._p(counts), C.byref(wait)), "cl_counts")
+        kf_t, kf_T, ref, Tcr = kf_t[:nk], kf_T[:nk], ref[:nf], Tcr[:nf]
+
+        def t44(p):
+            T = np.eye(4)
+            T[:3, :4] = np.asarray(p, np.float64).reshape(3, 4)
+            return T
+        fin = []
+        for rk, Tc in zip(ref, Tcr):
+            Tw = Tc @ t44(kf_T[rk])
+            fin.append(-Tw[:3, :3].T @ Tw[:3, 3])
+        kfc = [-t44(p)[:3, :3].T @ t44(p)[:3, 3] for p in kf_T]
+        return dict(lm_log=lm[:n], kf_t=kf_t, kf_poses=kf_T, ref_kf=ref, Tcr=Tcr, final_centres=np.array(fin).reshape(-1, 3),
+                    kf_centres=np.array(kfc).reshape(-1, 3),
+                    counts=dict(zip(("jobs", "windows", "windows_aborted", "interrupt_ba", "map_slots", "bad_points", "keyframes"),
+                                    counts[:7].tolist())), wait_ms=wait.value)
 
     def preallocate(self):
         self._check(self.lib.so_replay_preallocate(self.h), "preallocate")

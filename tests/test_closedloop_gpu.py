@@ -47,3 +47,90 @@ def test_python_chain_hip_and_oracle_agree_keyframe_by_keyframe():
     px = PLANE_Z / float(K[0])
     assert minitrack.ate_rmse(a["centres"], gt, align=False) < px
     assert abs(minitrack.ate_rmse(a["final_centres"], gt, with_scale=True) - minitrack.ate_rmse(b["final_centres"], gt, with_scale=True)) < 0.02 * px
+
+
+def _cpp_chain(n, frames_ptrs, st, K, dist, nfeat, vocab, policy=0, **kw):
+    from swarmmap_amd.replay import Replay
+    rp = Replay(0, st.w, st.h, nfeat, 5, K, dist, plane_z=PLANE_Z, local_keyframes=12, third_pose=True)
+    rp.set_frames(frames_ptrs, on_device=False)
+    rp.set_vocabulary(vocab)
+    rp.set_closed_loop(policy=policy, **kw)
+    rp.prime(0)
+    rp.run(0, n, True)
+    rp.drain()
+    rp.finish()
+    a, cl, stats, lm_stats = rp.log(), rp.closed_loop_log(), rp.stats(), rp.lm_stats()
+    rp.close()
+    a.update(cl)
+    return a, stats, lm_stats
+
+
+@pytest.mark.parametrize("name", ["euroc", "kitti"])
+def test_cpp_closed_loop_in_the_bench_configuration_matches_the_oracle_chain(name):
+    """What bench.py times (swarmmap_amd/host/replay.cc + closedloop.cc: tracking thread and local-mapping thread on one
+    GPU, frames in pinned host memory, the local map = the last 12 keyframes' points, three PoseOptimization calls per
+    frame; per keyframe: SearchForTriangulation batch -> triangulation -> new points; Fuse batch over resident keyframes
+    and the resident map -> AddObservation / Replace; local BA over the keyframe's own window -> SetPose / SetWorldPos /
+    EraseObservation / UpdateNormalAndDepth; results in the tracked map five frames later) against the same loop over
+    the CPU oracle: frame by frame (poses, counts), keyframe by keyframe (window sizes, new / fused / bad point counts,
+    final keyframe poses), and the trajectory both ways (online and through the final keyframe poses)."""
+    import torch
+    euroc = name == "euroc"
+    size = synth.EUROC if euroc else synth.KITTI
+    K = synth.EUROC_K if euroc else synth.KITTI_K
+    dist = synth.EUROC_DIST if euroc else None
+    nfeat = 1000 if euroc else 2000
+    n = 62 if euroc else 37
+    st = synth.FrameStream(seed=20221001, size=size, K=K, dist=dist)
+    block = torch.empty((n + 2, st.h, st.w), dtype=torch.uint8).pin_memory()
+    view = block.numpy()
+    for t in range(n + 2):
+        view[t] = st.frame(t)
+    frames = [view[t] for t in range(n + 2)]
+    vocab = make_vocabulary()
+    a, stats, lm_stats = _cpp_chain(n, [block.data_ptr() + i * st.w * st.h for i in range(n + 2)], st, K, dist, nfeat, vocab)
+    b = closedloop.track(OracleBackend(K, nfeat, dist if dist is not None else (0, 0, 0, 0, 0)), None, n, K, vocab, plane_z=PLANE_Z,
+                         third_pose=True, frames=frames)
+    assert len(a["poses"]) == n and a["counts"]["jobs"] == len(b["lm_log"]) == (n + 4) // 5
+    _same_jobs(a["lm_log"], b["lm_log"])
+    assert a["counts"]["windows"] == len(b["lm_log"]) - 2 and a["counts"]["windows_aborted"] == 0
+    assert np.array_equal(a["kf_t"], b["kf_t"]) and np.array_equal(a["ref_kf"], b["ref_kf"])
+    assert np.abs(a["poses"] - b["poses"]).max() < 5e-5
+    assert np.abs(a["kf_poses"] - b["kf_poses"]).max() < 5e-5
+    assert np.abs(a["Tcr"] - b["Tcr"]).max() < 5e-5
+    assert minitrack.ate_rmse(a["centres"], b["centres"], align=False) < 1e-4
+    assert minitrack.ate_rmse(a["final_centres"], b["final_centres"], align=False) < 1e-4
+    for k in ("matches_last", "matches_map", "inliers"):
+        assert np.abs(a[k].astype(int) - b[k].astype(int)).max() <= 5, (k, a[k], b[k])
+    assert np.abs(a["n_map_points"].astype(int) - b["n_map_points"].astype(int)).max() <= 8
+    assert a["inliers"][1:].min() > 300
+    gt = minitrack.ground_truth(st, n, K, PLANE_Z)
+    px = PLANE_Z / float(K[0])
+    # online (poses as they were tracked; the first windows have only keyframe 0 fixed - KeyFrame::isFirst() - and shift the
+    # young map along its scale gauge before later windows pull it back: a transient of a few pixels) and through the final
+    # keyframe poses (what System::SaveTrajectoryTUM writes at shutdown)
+    assert minitrack.ate_rmse(a["centres"], gt, with_scale=True) < 2 * px
+    assert minitrack.ate_rmse(a["final_centres"], gt, with_scale=True) < px
+    assert lm_stats["jobs"] == a["counts"]["jobs"] and lm_stats["cl_solver_ms"] > 0 and lm_stats["batch_kernel_ms"] > 0
+
+
+def test_cpp_closed_loop_under_the_reference_policy_tracks_and_reports_its_interrupts():
+    """policy 1 (Tracking.cc:810-905, LocalMapping.cc:581-583): results arrive when they are ready, a keyframe is made only
+    while local mapping is idle, a busy local mapper gets InterruptBA.  Timing-dependent by construction: the checks are
+    the trajectory against ground truth and the consistency of the counters."""
+    import torch
+    K, dist, nfeat, n = synth.EUROC_K, synth.EUROC_DIST, 1000, 80
+    st = synth.FrameStream(seed=20221001, size=synth.EUROC, K=K, dist=dist)
+    block = torch.empty((n + 2, st.h, st.w), dtype=torch.uint8).pin_memory()
+    view = block.numpy()
+    for t in range(n + 2):
+        view[t] = st.frame(t)
+    a, stats, _ = _cpp_chain(n, [block.data_ptr() + i * st.w * st.h for i in range(n + 2)], st, K, dist, nfeat, make_vocabulary(), policy=1,
+                             kf_every=2)
+    c = a["counts"]
+    assert c["keyframes"] == c["jobs"] >= 5 and c["windows_aborted"] <= c["windows"] <= c["jobs"] and c["windows_aborted"] <= c["interrupt_ba"]
+    assert np.all(np.diff(a["kf_t"]) >= 2)
+    gt = minitrack.ground_truth(st, n, K, PLANE_Z)
+    px = PLANE_Z / float(K[0])
+    assert a["inliers"][1:].min() > 250
+    assert minitrack.ate_rmse(a["centres"], gt, align=False) < 1.5 * px
