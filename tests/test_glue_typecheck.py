@@ -40,3 +40,14 @@ def test_the_check_really_sees_the_reference_classes(tmp_path):
     ok = tmp_path / "ok.cc"
     ok.write_text('#include "Optimizer.h"\n#include "ORBmatcher.h"\nnamespace ORB_SLAM2 { unsigned long g(KeyFrame* k) { return k->mnId; } }\n')
     assert _syntax_check(str(ok)).returncode == 0
+
+
+def test_every_include_directory_of_the_check_is_tracked_by_git():
+    """A fresh clone / `git archive` must be able to run the check: git does not track empty directories, so each -I
+    directory holds at least one tracked file (round 4's verdict: tests/cpp/ref_stubs/cfg/a/b was empty and the check died
+    with `../../config.h: No such file` outside the builder's working tree)."""
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("not a git checkout")
+    for d in (STUBS, os.path.join(STUBS, "cfg", "a", "b")):
+        r = subprocess.run(["git", "-C", ROOT, "ls-files", "--", os.path.relpath(d, ROOT)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and r.stdout.strip(), "no tracked file under %s" % d
