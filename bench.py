@@ -891,6 +891,10 @@ def main():
                              "descriptor_pairs_per_tick": st.get("xchg_pairs", 0.0) / max(st.get("n_xchg", 0), 1),
                              "wall_ms_per_tick": st.get("xchg_ms", 0.0) / max(st.get("n_xchg", 0), 1)}},
                 **{k: v for k, v in rec.items() if k != "frames_per_s"}),
+            "launch": ("torch.distributed, %d rank(s): every %d-th frame is followed by an exchange tick (RCCL all-gather of the "
+                       "newest keyframe record + store append + candidate search) INSIDE the timed region - a 1-rank line "
+                       "launched this way is therefore not the plain `python bench.py` line" % (world, args.exchange_every)
+                       if distributed else "single process, no exchange ticks"),
             "roofline": ranked[0][1],
             "roofline_secondary": ranked[1][1],
             "roofline_tertiary": ranked[2][1],

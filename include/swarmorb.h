@@ -818,9 +818,12 @@ int so_exchange_tick_keyframe(so_exchange* x, const so_dframe* f, const so_keyfr
  * missing argument - does not keep the rank out of the collective: it takes part with zero records / an empty slot and
  * returns SO_ERR_INVALID_ARG afterwards, the other ranks are not affected.  Only a null handle returns before the
  * collective.  The wait for the collective is bounded (so_exchange_set_timeout; default SWARMORB_COLLECTIVE_TIMEOUT_MS
- * or 5000 ms; 0 = unbounded): when a peer never enters the tick the survivors get SO_ERR_TIMEOUT, the handle is DEAD -
- * every later tick returns SO_ERR_TIMEOUT at once, so_exchange_destroy does not wait for the stuck stream - and the
- * group has to be re-created.  so_exchange_debug_stall (test hook) delays this rank's next collective by a spinning
+ * or 30000 ms; 0 = unbounded; a handle's FIRST collective, which also pays RCCL's lazy connection set-up and the ranks'
+ * start-up skew, gets at least 120 s): when a peer never enters the tick the survivors get SO_ERR_TIMEOUT, the handle is
+ * DEAD - every later tick returns SO_ERR_TIMEOUT at once, so_exchange_destroy does not wait for the stuck stream - and
+ * the group has to be re-created (in a fresh child process, never by re-executing one that holds the GPU).  The budget
+ * covers RCCL collectives; with the host transport (so_exchange_create_store_host) the caller's all-gather callback owns
+ * its time-outs.  so_exchange_debug_stall (test hook) delays this rank's next collective by a spinning
  * workgroup on the tick's stream. */
 int so_exchange_set_timeout(so_exchange* x, int milliseconds);
 int so_exchange_is_dead(const so_exchange* x);

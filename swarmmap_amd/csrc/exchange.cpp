@@ -103,11 +103,16 @@ struct so_exchange {
     void* host_user = nullptr;
     uint8_t* h_slot = nullptr;      // pinned: this rank's slot
     uint8_t* h_gathered = nullptr;  // pinned: world slots
-    // A tick waits for its collective with a budget (SWARMORB_COLLECTIVE_TIMEOUT_MS, default 5000; 0 = wait for ever):
-    // when a peer never enters the tick the survivors get SO_ERR_TIMEOUT instead of hanging, and the handle is dead -
-    // every later tick returns SO_ERR_TIMEOUT at once, destroy neither waits for the stuck stream nor frees what the
-    // collective may still write.
-    int timeout_ms = 5000;
+    // A tick waits for its collective with a budget (SWARMORB_COLLECTIVE_TIMEOUT_MS / so_exchange_set_timeout, default
+    // 30000; 0 = wait for ever): when a peer never enters the tick the survivors get SO_ERR_TIMEOUT instead of hanging,
+    // and the handle is dead - every later tick returns SO_ERR_TIMEOUT at once, destroy neither waits for the stuck
+    // stream nor frees what the collective may still write.  The FIRST collective of a handle also pays RCCL's lazy
+    // connection set-up and whatever start-up skew the ranks have (one still renders its stream while another is done):
+    // it gets at least kFirstTickBudgetMs.  The budget covers RCCL collectives only: on the host-transport path
+    // (so_exchange_create_store_host) the wait for this rank's own staging copy and the caller's all-gather callback are
+    // not bounded here - the callback owns its time-outs.
+    int timeout_ms = 30000;
+    int collectives_done = 0;
     bool dead = false;
     unsigned* d_stall_sink = nullptr;  // so_exchange_debug_stall
     std::vector<so_keyframe_header> hdrs;
@@ -129,15 +134,20 @@ int wait_collective(so_exchange* x, hipStream_t s) {
         SO_HIP(hipStreamSynchronize(s));
         return SO_OK;
     }
+    constexpr int kFirstTickBudgetMs = 120000;
+    const int budget_ms = x->collectives_done == 0 ? std::max(x->timeout_ms, kFirstTickBudgetMs) : x->timeout_ms;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
-        if (e == hipSuccess) return SO_OK;
+        if (e == hipSuccess) {
+            x->collectives_done++;
+            return SO_OK;
+        }
         if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery (exchange tick)", __FILE__, __LINE__);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (ms > (double)x->timeout_ms) {
+        if (ms > (double)budget_ms) {
             x->dead = true;
-            last_error_ref() = "exchange tick: the collective did not complete within " + std::to_string(x->timeout_ms) +
+            last_error_ref() = "exchange tick: the collective did not complete within " + std::to_string(budget_ms) +
                                " ms (a peer is not taking part); the handle is dead";
             return SO_ERR_TIMEOUT;
         }

@@ -2309,13 +2309,23 @@ int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* f
     }
     if (e == hipSuccess && !fv) e = hipStreamSynchronize(m->stream);
     if (e != hipSuccess) {
+        (void)hipStreamSynchronize(m->stream);
         if (k->d) (void)hipFree(k->d);
         delete k;
+        m->resident_n = -1;
+        m->dirty_from = 0;
         return hip_fail(e, "so_kframe_create", __FILE__, __LINE__);
     }
     if (fv) {
         rc = upload_featvec_candidates(m, KF->n, KF->x, KF->y, KF->octave, KF->desc, fv, nullptr);
-        if (rc) { delete k; return rc; }
+        if (rc) {  // the copy kernel that reads m->h_res may still be running: wait, then give the block back
+            (void)hipStreamSynchronize(m->stream);
+            if (k->d && !kf_block_give(k->device, k->d, k->d_cap)) (void)hipFree(k->d);
+            delete k;
+            m->resident_n = -1;
+            m->dirty_from = 0;
+            return rc;
+        }
         k->has_nodes = true;
         k->n_xy = k->g_end;
         k->n_oct = k->g_end + m->off_oct;
@@ -2336,6 +2346,7 @@ int so_kframe_create(so_matcher* m, const so_frame_view* KF, const so_featvec* f
     m->resident_n = -1;
     m->dirty_from = 0;
     if (e != hipSuccess) {
+        (void)hipStreamSynchronize(m->stream);
         if (k->d) (void)hipFree(k->d);
         delete k;
         return hip_fail(e, "so_kframe_create", __FILE__, __LINE__);

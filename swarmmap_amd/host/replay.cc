@@ -381,8 +381,40 @@ void pin_to_device_node(const so_replay* r) {
     if (n_set > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
 }
 
+std::mutex g_pin_mu;
+std::vector<uint8_t> g_pin_slots;  // slot -> taken by a live agent of this process
+int take_pin_slot() {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t i = 0; i < g_pin_slots.size(); i++)
+        if (!g_pin_slots[i]) {
+            g_pin_slots[i] = 1;
+            return (int)i;
+        }
+    g_pin_slots.push_back(1);
+    return (int)g_pin_slots.size() - 1;
+}
+void give_pin_slot(int slot) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (slot >= 0 && (size_t)slot < g_pin_slots.size()) g_pin_slots[(size_t)slot] = 0;
+}
+
+// The thread that calls so_replay_run / _run_live / so_fleet_run is the application's: it runs on the agent's CPUs for the
+// duration of the call only.
+struct CallerPin {
+    cpu_set_t saved;
+    bool have = false;
+    explicit CallerPin(const so_replay* r) {
+        CPU_ZERO(&saved);
+        have = !r->host_cpus.empty() && pthread_getaffinity_np(pthread_self(), sizeof(saved), &saved) == 0;
+        pin_to_device_node(r);
+    }
+    ~CallerPin() {
+        if (have) (void)pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved);
+    }
+};
+
 void mapper_loop(so_replay* r) {
-    pin_to_device_node(r);
+    pin_to_device_node(r);  // (the library's own thread: pinned for its lifetime)
     for (;;) {
         int timed;
         std::shared_ptr<KfSnap> kf;
@@ -590,10 +622,11 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
     if (const char* e = getenv("SWARMORB_LM_MAP")) r->lm_from_map = atoi(e) != 0;
     if (!getenv("SWARMORB_NO_PIN")) {
         // one last-level-cache group of the device's NUMA node per agent: GPU d's first agent takes group d, the next
-        // agents of this process the groups behind it
-        static std::atomic<int> created{0};
+        // LIVE agents of this process the groups behind it (a destroyed agent's group is free again: replays that follow
+        // each other in one process - bench configs, a test session - stay on the same groups)
+        r->pin_slot = take_pin_slot();
         char cpus[512];
-        if (so_device_host_cpus(device, device + created.fetch_add(1), cpus, (int)sizeof(cpus)) == SO_OK) r->host_cpus = cpus;
+        if (so_device_host_cpus(device, device + r->pin_slot, cpus, (int)sizeof(cpus)) == SO_OK) r->host_cpus = cpus;
     }
     r->mapper = std::thread(mapper_loop, r);
     *out = r;
@@ -621,6 +654,7 @@ void so_replay_destroy(so_replay* r) {
     so_ba_destroy(r->tracker_opt);
     so_ba_destroy(r->mapper_opt);
     so_matcher_destroy(r->mapper_matcher);
+    give_pin_slot(r->pin_slot);
     delete r;
 }
 
@@ -1237,7 +1271,7 @@ static int run_one_step(so_replay* r, int t, int timed) {
 
 int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
     if (!r || !r->in_flight || r->frames.empty()) return SO_ERR_INVALID_ARG;
-    pin_to_device_node(r);  // (the tracking thread is whoever calls)
+    CallerPin pin(r);  // (the tracking thread is whoever calls; its affinity is restored on return)
     for (int t = first_t; t < first_t + n_steps; t++) {
         const int rc = run_one_step(r, t, timed);
         if (rc) return rc;
@@ -1254,7 +1288,7 @@ int so_replay_run(so_replay* r, int first_t, int n_steps, int timed) {
 int so_replay_run_live(so_replay* r, int first_t, int n_steps, float* pose_ms, float* step_ms) {
     if (!r || r->frames.empty() || first_t < 0 || first_t + n_steps > (int)r->frames.size()) return SO_ERR_INVALID_ARG;
     r->live = true;
-    pin_to_device_node(r);
+    CallerPin pin(r);
     int rc = SO_OK;
     for (int t = first_t; t < first_t + n_steps && rc == SO_OK; t++) {
         const double T0 = now_ms();
@@ -1277,7 +1311,7 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
     for (int a = 0; a < n_agents; a++)
         if (!agents[a] || !agents[a]->in_flight || agents[a]->frames.empty()) return SO_ERR_INVALID_ARG;
     const size_t A = (size_t)n_agents;
-    pin_to_device_node(agents[0]);
+    CallerPin pin(agents[0]);
     std::vector<so_pose_problem> probs(A);
     std::vector<int32_t> inl(A), info(2 * A);
     std::vector<int> live;

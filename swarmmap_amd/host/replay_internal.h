@@ -20,7 +20,6 @@
 
 #include "../../include/swarmorb.h"
 
-namespace {
 
 constexpr int kEventEvery = 4;
 
@@ -94,7 +93,6 @@ static inline M4 from_f12(const float* p) {
     return T;
 }
 
-}  // namespace
 
 // ---- the closed loop (closedloop.cc; swarmmap_amd/closedloop.py is the same logic in Python) ----
 // What a keyframe's local-mapping job hands back to the tracking side; applied between two frames.
@@ -167,6 +165,7 @@ struct LmJob {
 struct so_replay {
     int device = 0, width = 0, height = 0, lba_every = 5;
     std::string host_cpus;  // the CPUs this agent's threads are pinned to (so_device_host_cpus); empty: no pinning
+    int pin_slot = -1;      // which cache group of the device's node (among the live agents of this process)
     int keyframe_every = 8, local_keyframes = 0, third_pose = 1;
     double keyframe_ratio = 0.7, plane_z = 2.0;
     so_camera cam{};
@@ -272,7 +271,6 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
 int cl_frame_begin(so_replay* r, int t);  // tracking thread, before the frame's first search: applies what local mapping handed back
 void cl_frame_end(so_replay* r, int t, bool keyframe, const std::shared_ptr<KfSnap>& snap);
 
-namespace {
 enum {  // indices of so_replay::stat, mirrored in bench.py
     kSteps = 0, kExtractMs, kM2Ms, kPose1Ms, kM1Ms, kPose2Ms, kPose3Ms, kMapMs, kSubmitWaitMs, kKp, kM2, kM1, kInliers,
     kMatchKernelMs, kPoseKernelMs, kPoseTrials, kPoseCalls, kPosePoints, kLbaWindows, kLbaBusyMs, kLbaGpuMs, kLbaSolveMs,
@@ -284,7 +282,6 @@ enum {  // indices of so_replay::stat, mirrored in bench.py
 enum { kLmJobs = 0, kLmWallMs, kLmNodeMs, kLmTriCalls, kLmTriMs, kLmTriKernelMs, kLmTriMatches, kLmFuseCalls, kLmFuseMs,
        kLmFuseKernelMs, kLmFused, kLmFusePoints, kLmTriQueries, kLmBatchMs, kLmBatchEndMs, kLmBatchKernelMs, kLmTriangMs, kLmTriangKernelMs, kLmNewPoints,
        kLmStageTriMs, kLmStageFuseMs, kLmStageBackMs, kLmBatchEnqueueMs, kLmBatchWaitMs };
-}  // namespace
 
 static inline so_frame_view keyframe_view(const so_replay* r, const KfSnap& k) {
     so_frame_view v;

@@ -73,13 +73,16 @@ def test_global_bundle_adjustment_single_stage(opt, oracle):
         assert r["info"]["iterations_stage2"] == 0
 
 
-@pytest.mark.parametrize("n_free,n_points", [(60, 3000), (120, 6000), (299, 30000)])
-def test_global_ba_blocked_dense_solver_matches_oracle(opt, oracle, n_free, n_points):
+@pytest.mark.parametrize("n_free,n_points,robust", [(60, 3000, True), (60, 3000, False), (120, 6000, True), (299, 30000, True),
+                                                    (299, 30000, False)])
+def test_global_ba_blocked_dense_solver_matches_oracle(opt, oracle, n_free, n_points, robust):
     """Maps with more free keyframes than one workgroup holds go through the blocked multi-workgroup Cholesky
-    (ba_dense.hip, FP64 MFMA tiles): 96-wide panels with 1, 2 and 19 panels (the last is BASELINE's GBA-1)."""
+    (ba_dense.hip, FP64 MFMA tiles): 96-wide panels with 1, 2 and 19 panels (the last is BASELINE's GBA-1).  robust =
+    False is how the reference's server calls it (GlobalBundleAdjustemnt(map, 10, &stop, kf, false),
+    code/src/MediatorScheduler.cc:122) and what bench.py's GBA records time."""
     p = synth.make_ba_problem(200 + n_free, n_free, 1, n_points, max_obs="auto")
-    r = opt.BundleAdjustment(p, nIterations=10, bRobust=True)
-    o = oracle.bundle_adjust(p, its1=10, its2=0, robust=True, huber_delta=np.float32(np.sqrt(np.float32(5.99))))
+    r = opt.BundleAdjustment(p, nIterations=10, bRobust=robust)
+    o = oracle.bundle_adjust(p, its1=10, its2=0, robust=robust, huber_delta=np.float32(np.sqrt(np.float32(5.99))))
     _compare(r, o)  # (no ground-truth check: with one fixed keyframe a monocular map keeps its scale freedom)
 
 
@@ -246,14 +249,14 @@ def test_gba2_eight_agent_map_properties(opt):
     assert (r6["outlier"].astype(bool) & p["gt_outlier"]).sum() >= 0.9 * p["gt_outlier"].sum()
 
 
-@pytest.mark.parametrize("seed", [1, 2])
-def test_sparse_multiagent_map_matches_oracle(opt, oracle, seed):
+@pytest.mark.parametrize("seed,robust", [(1, True), (1, False), (2, True)])
+def test_sparse_multiagent_map_matches_oracle(opt, oracle, seed, robust):
     """GBA-1r: four agents, 300 keyframes, street-grid map with range-limited visibility - the reduced camera system
     is block-banded with a few inter-agent links, and the blocked solver only works on the tiles inside its block
     skyline (LinearSolverEigen's structural-nonzero solve, linear_solver_eigen.h:147-232).  Against the oracle."""
     p = synth.make_ba_case("GBA-1r", seed)
-    r = opt.BundleAdjustment(p, nIterations=10, bRobust=True)
-    o = oracle.bundle_adjust(p, its1=10, its2=0, robust=True, huber_delta=np.float32(np.sqrt(np.float32(5.99))))
+    r = opt.BundleAdjustment(p, nIterations=10, bRobust=robust)  # robust = False: the server's call (MediatorScheduler.cc:122)
+    o = oracle.bundle_adjust(p, its1=10, its2=0, robust=robust, huber_delta=np.float32(np.sqrt(np.float32(5.99))))
     _compare(r, o)
     inf = r["info"]
     assert 0 < inf["nnz_tiles"] < 19 * 20 / 2                       # the skyline is a strict subset of the triangle
