@@ -721,6 +721,24 @@ def gba_records(dev, cases):
                                            "--kernel-trace --stats and separate --pmc passes of tools/gba_bench.py)",
                                "note": "achieved = min(flop over the nonzero 96x96 tiles of the block skyline, n^3/3 + 2 n^2 "
                                        "of the un-padded system) / solve time (HIP events around the solve kernel)"}}
+        # north_star's "PCG solve" of the reduced camera system, built and measured (so_ba_set_linear_solver, ba_pcg.hip): block-
+        # Jacobi PCG over the nonzero 6 x 6 blocks of S, |r| / |b| <= 1e-7.  The direct solve stays the default: it is faster
+        # on all four maps (the damped systems of the late LM iterations need hundreds of CG iterations)
+        q = swarmmap_amd.Optimizer(device=dev)
+        q.set_linear_solver("pcg", 1e-7, 4000)
+        q.set_solve_timing(True)
+        q.BundleAdjustment(p, nIterations=2, bRobust=False)
+        t0 = time.perf_counter()
+        rp = q.BundleAdjustment(p, nIterations=10, bRobust=False)
+        wall_pcg = time.perf_counter() - t0
+        pi = rp["info"]
+        out[name]["pcg"] = {"wall_ms": wall_pcg * 1e3, "gpu_ms": pi["gpu_ms"], "lm_trials": pi["lm_trials"], "chi2_final": pi["chi2_final"],
+                            "ms_per_solve": pi["solve_ms"] / max(pi["n_solves"], 1), "cg_iterations_per_solve": pi["pcg_iterations"] / max(pi["lm_trials"], 1),
+                            "nonzero_6x6_blocks": pi["nnz_tiles"], "rel_tolerance": 1e-7,
+                            "max_pose_entry_difference_to_direct": float(np.abs(rp["Tcw"] - r["Tcw"]).max()),
+                            "evidence": "profiles/r5_pcg_bench.jsonl, r5_pcg_iterations.json (CPU study of the iteration counts), "
+                                        "r5_pcg_spmv_probe.txt (time of one iteration on the block structure)"}
+        q.close()
         del p
     o.close()
     return out

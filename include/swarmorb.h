@@ -892,7 +892,8 @@ typedef struct {
      * fully resident: another process on the GPU, a CU mask); the call was then repeated on the multi-launch path, which
      * the context keeps from then on (solver_path 1) */
     int32_t flow_timeouts;
-    int32_t reserved;
+    int32_t pcg_iterations;  /* solver_path 3 (so_ba_set_linear_solver: PCG): conjugate-gradient iterations of all solves of the call
+                              * (n_solves / lm_trials solves; nnz_tiles then holds the nonzero 6 x 6 blocks of S) */
 } so_ba_info;
 
 int so_ba_create(int device, so_ba** out);
@@ -947,6 +948,18 @@ int so_pose_optimization_last_kernel_ms(so_ba* ba, float* ms);
 int so_bundle_adjust(so_ba* ba, const so_ba_problem* problem, const so_ba_options* options,
                      const volatile uint8_t* stop, float* Tcw_out, float* Xw_out, uint8_t* edge_outlier,
                      double* edge_chi2, so_ba_info* info);
+/* How the reduced camera system S x = b of every LM trial is solved on LARGE maps (80 free keyframes and more; smaller
+ * systems always take the single-workgroup / blocked direct solvers).
+ *   SO_BA_SOLVER_DIRECT (default): block-skyline Cholesky on FP64 MFMA tiles - what the reference's LinearSolverEigen /
+ *     SimplicialLDLT computes (code/Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:94-124), to rounding.
+ *   SO_BA_SOLVER_PCG: block-Jacobi preconditioned conjugate gradients over the nonzero 6 x 6 blocks of S (g2o's
+ *     LinearSolverPCG, g2o/solvers/linear_solver_pcg.h; BASELINE.json's north_star names it) down to a relative residual
+ *     |r| / |b| <= rel_tolerance (<= 0: keep, default 1e-7) within max_iterations (<= 0: keep, default 4000; the iterate
+ *     is used as it is when the cap is hit).  An iterative solve: results agree with the direct solver's within the
+ *     tolerance the tests state (tests/test_ba_gpu.py), not to rounding.  Deterministic run to run. */
+#define SO_BA_SOLVER_DIRECT 0
+#define SO_BA_SOLVER_PCG 1
+int so_ba_set_linear_solver(so_ba* ba, int solver, double rel_tolerance, int max_iterations);
 /* HIP events around the reduced-camera-system solve of every LM trial (so_ba_info.solve_ms / n_solves) on / off.  Off by
  * default: an event record in front of and behind a kernel idles the stream ~6 us each, 4 % of a 64-keyframe window
  * (profiles/r3_lba_trial_sequence.txt).  With timing off solve_ms and n_solves are 0. */

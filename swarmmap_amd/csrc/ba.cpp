@@ -235,6 +235,10 @@ struct so_ba {
     int flow_timeouts = 0;
     int flow_reserved = 0;                  // tiles this context holds of the process-wide residency budget
     std::vector<int> tile_first;
+    int linear_solver = 0;                  // so_ba_set_linear_solver: 0 direct (block-skyline Cholesky), 1 block-Jacobi PCG (ba_pcg.hip)
+    BaPcgHost pcg;                          // its tolerance / iteration cap, workspace pointers and counters
+    int pcg_nnz_blocks = 0;                 // nonzero 6 x 6 blocks of S in the last PCG problem
+    Buf d_pcg, d_pcg_idx;
     BaLm* h_lm = nullptr;        // host-mapped copy of the LM state, written by the decision kernels
     BaLm* h_lm_dev = nullptr;
     uint8_t* h_abort = nullptr;  // host-mapped forceStopFlag the decision kernel polls
@@ -256,7 +260,7 @@ struct so_ba {
     std::vector<Buf*> all() {
         return {&d_in, &d_out, &d_pose1, &d_pt1, &d_err, &d_chi2, &d_tab, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv,
                 &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x, &d_pr_off, &d_pr_cur, &d_pr, &d_big, &d_scan_tmp, &d_plan,
-                &d_flow, &d_flow_big};
+                &d_flow, &d_flow_big, &d_pcg, &d_pcg_idx};
     }
 };
 
@@ -1039,6 +1043,43 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     if (!pairs_path) launch_ba_edge_table(d, s);
     if (dense_path) launch_ba_dense_pad(d, s);
     if (pairs_path) launch_ba_build_pairs(d, b->d_scan_tmp.p, scan_bytes, s);
+    d.use_pcg = 0;
+    d.pcg_host = nullptr;
+    b->pcg.iterations = 0;
+    b->pcg.solves = 0;
+    if (pairs_path && b->linear_solver == 1) {
+        // block-Jacobi PCG instead of the blocked Cholesky: the 6 x 6 block structure of S from the pair lists (once per
+        // problem: counts, scan, one look at the total, fill), then the workspace
+        const size_t sNF = (size_t)nf, nA = (sNF + 3) / 4, nB = (sNF + 255) / 256;
+        Layout P;
+        const size_t p_counts = P.add(sizeof(int) * (sNF + 1)), p_indptr = P.add(sizeof(int) * (sNF + 1)), p_Minv = P.add(sizeof(double) * 36 * sNF),
+                     p_x = P.add(sizeof(double) * 6 * sNF), p_r = P.add(sizeof(double) * 6 * sNF), p_z = P.add(sizeof(double) * 6 * sNF),
+                     p_p = P.add(sizeof(double) * 6 * sNF), p_Sp = P.add(sizeof(double) * 6 * sNF), p_A = P.add(sizeof(double) * nA),
+                     p_B = P.add(sizeof(double) * 2 * nB), p_scal = P.add(sizeof(double) * 8), p_status = P.add(sizeof(unsigned long long));
+        if ((rc = b->d_pcg.ensure(P.total))) return rc;
+        uint8_t* pb = (uint8_t*)b->d_pcg.p;
+        int* d_counts = (int*)(pb + p_counts);
+        int* d_indptr = (int*)(pb + p_indptr);
+        launch_ba_pcg_structure(d, d_counts, d_indptr, nullptr, s);
+        int nnzb = 0;
+        SO_HIP(hipMemcpyAsync(&nnzb, d_indptr + nf, sizeof(int), hipMemcpyDeviceToHost, s));
+        SO_HIP(hipStreamSynchronize(s));
+        if ((rc = b->d_pcg_idx.ensure(sizeof(int) * (size_t)std::max(nnzb, 1)))) return rc;
+        launch_ba_pcg_structure(d, d_counts, d_indptr, b->d_pcg_idx.as<int>(), s);
+        BaPcgDev& q = b->pcg.dev;
+        q.indptr = d_indptr;
+        q.indices = b->d_pcg_idx.as<int>();
+        q.Minv = (double*)(pb + p_Minv);
+        q.x = (double*)(pb + p_x); q.r = (double*)(pb + p_r); q.z = (double*)(pb + p_z); q.p = (double*)(pb + p_p); q.Sp = (double*)(pb + p_Sp);
+        q.partA = (double*)(pb + p_A); q.partB = (double*)(pb + p_B); q.scal = (double*)(pb + p_scal);
+        q.status = (unsigned long long*)(pb + p_status);
+        // (the status word shares the context's host-mapped block with the dataflow solves' abort word: bytes 8..15)
+        q.status_host = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(b->h_flow_abort_dev) + 8);
+        b->pcg.status_host = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<uint8_t*>(b->h_flow_abort) + 8);
+        b->pcg_nnz_blocks = nnzb;
+        d.use_pcg = 1;
+        d.pcg_host = &b->pcg;
+    }
 
     const double t_uploaded = now_ms();
     if (trace) fprintf(stderr, "[ba] %d free keyframes, %d moved to the separator block\n", nf, r.n_reordered);
@@ -1189,6 +1230,11 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         inf.solve_gflop_dense = r.d.plan->flop_dense * 1e-9;
         inf.nnz_tiles = (double)r.d.plan->nnz_tiles;
         inf.solver_path = r.d.flow_tiles ? 2 : 1;
+    }
+    if (r.d.use_pcg) {
+        inf.solver_path = 3;
+        inf.pcg_iterations = (int32_t)std::min<long long>(b->pcg.iterations, INT32_MAX);
+        inf.nnz_tiles = (double)b->pcg_nnz_blocks;  // (PCG: nonzero 6 x 6 blocks of S, not 96 x 96 tiles)
     }
     inf.n_free_keyframes = r.n_free;
     inf.flow_timeouts = b->flow_timeouts;
@@ -1451,6 +1497,14 @@ int so_pose_optimization_batch(so_ba* b, int32_t n_problems, const so_pose_probl
             q.info[1] = inf[2];
         }
     }
+    return SO_OK;
+}
+
+int so_ba_set_linear_solver(so_ba* b, int solver, double rel_tolerance, int max_iterations) {
+    if (!b || (solver != 0 && solver != 1)) return SO_ERR_INVALID_ARG;
+    b->linear_solver = solver;
+    if (rel_tolerance > 0.0) b->pcg.tol = rel_tolerance;
+    if (max_iterations > 0) b->pcg.max_it = max_iterations;
     return SO_OK;
 }
 

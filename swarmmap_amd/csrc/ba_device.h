@@ -50,6 +50,29 @@ struct BaLm {
     double prev_chi_begin;      // `chi_begin` of the stage before the current one
 };
 
+// Block-Jacobi PCG on the reduced camera system (ba_pcg.hip): workspace pointers (device) ...
+struct BaPcgDev {
+    const int* indptr;   // n_free + 1: block rows of S - its nonzero 6 x 6 block columns, ascending (diagonal included)
+    const int* indices;
+    double* Minv;        // n_free x 36: inverse of the diagonal blocks
+    double *x, *r, *z, *p, *Sp;  // 6 n_free each
+    double* partA;       // ceil(n_free / 4): partial sums of p.Sp
+    double* partB;       // 2 x ceil(n_free / 256): partial sums of r.z | r.r
+    double* scal;        // rz by iteration parity [0..1], b.b, tol^2 b.b, p.Sp, r.r
+    unsigned long long* status;       // device word: solve sequence number << 32 | iterations << 2 | failed << 1 | converged
+    unsigned long long* status_host;  // the same in host-mapped memory (device-side address)
+};
+// ... and the host side of a solver context's PCG (not read by kernels)
+struct BaPcgHost {
+    BaPcgDev dev{};
+    volatile unsigned long long* status_host = nullptr;
+    unsigned seq = 0;
+    double tol = 1e-7;   // relative residual |r| / |b|
+    int max_it = 4000;
+    long long iterations = 0;  // of this so_bundle_adjust call
+    int solves = 0;
+};
+
 struct BaDev {
     // estimate buffers and LM state
     BaPose* pose[2];
@@ -112,6 +135,8 @@ struct BaDev {
     int flow_nslots;            // ticketed kernel (large skylines): tile flag slots, T (T + 1) / 2
     int flow_grid;              //                  resident workgroups of its launch
     double* partial;  // reduction partials (chi2 | scale) + flags
+    int use_pcg;          // blocked path with pair lists only: the reduced system is solved by block-Jacobi PCG (ba_pcg.hip)
+    BaPcgHost* pcg_host;  // (host side; not read by kernels)
     int robust;
     double huber_delta;
     float huber_dsqr;  // stored as float in the reference (robust_kernel_impl.h:84)
@@ -181,6 +206,10 @@ struct DensePlan {
 // flow_grid: workgroups the single-launch solve may keep resident (0: the chain-of-launches plan only)
 void build_dense_plan(int T, const int* tile_first, bool has_side_stream, DensePlan* plan, int flow_grid);
 bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s);   // single-workgroup MFMA solves (4..29 free keyframes: tiles in LDS; 30..43: tiles in registers); false if neither applies
+// ba_pcg.hip: block structure of S from the pair lists (indices_or_null == nullptr: counts + scan into indptr; otherwise
+// the fill), and one PCG solve (S x = bs, x -> bs; looks at a host-mapped status word between chunks of iterations)
+void launch_ba_pcg_structure(const BaDev& d, int* counts, int* indptr, int* indices_or_null, hipStream_t s);
+void launch_ba_pcg_solve(const BaDev& d, hipStream_t s);
 void launch_ba_dense_pad(const BaDev& d, hipStream_t s);    // once per problem: identity padding up to ldS
 void launch_ba_dense_solve(const BaDev& d, hipStream_t s);  // per trial, in place of the single-workgroup solve  // fills edge_tab (memset to -1 beforehand)
 // Optimizer.cc:644-656 on the device: edges of the current estimate with chi2 > threshold or non-positive depth

@@ -1332,6 +1332,8 @@ static void launch_ba_solve(const BaDev& d, hipStream_t s) {
         hipLaunchKernelGGL((ba_solve_reg_kernel<512, 1>), dim3(1), dim3(512), 0, s, d);
     else if (NB <= kSolveMaxNB)
         hipLaunchKernelGGL((ba_solve_reg_kernel<512, 2>), dim3(1), dim3(512), 0, s, d);
+    else if (d.use_pcg)
+        launch_ba_pcg_solve(d, s);    // ba_pcg.hip: block-Jacobi PCG over the nonzero 6 x 6 blocks (so_ba_set_linear_solver)
     else
         launch_ba_dense_solve(d, s);  // ba_dense.hip: blocked Cholesky on the FP64 matrix cores
 }

@@ -24,7 +24,7 @@ class SoBaInfo(C.Structure):
                 ("aborted", C.c_int32), ("n_outliers", C.c_int32), ("gpu_ms", C.c_float), ("wall_ms", C.c_float),
                 ("solve_ms", C.c_float), ("n_solves", C.c_int32), ("solve_gflop_structural", C.c_double),
                 ("solve_gflop_dense", C.c_double), ("nnz_tiles", C.c_double), ("solver_path", C.c_int32), ("n_free_keyframes", C.c_int32),
-                ("flow_timeouts", C.c_int32), ("reserved", C.c_int32)]
+                ("flow_timeouts", C.c_int32), ("pcg_iterations", C.c_int32)]
 
 
 class SoPoseProblem(C.Structure):
@@ -75,6 +75,12 @@ class Optimizer:
         """HIP events around every reduced-system solve (info["solve_ms"], info["n_solves"]); off by default - the two
         event records idle the stream ~12 us per LM trial."""
         _lib.check(self._lib.so_bundle_adjust_set_solve_timing(self._h, 1 if enabled else 0))
+
+    def set_linear_solver(self, solver="direct", rel_tolerance=0.0, max_iterations=0):
+        """so_ba_set_linear_solver: "direct" (block-skyline Cholesky, default) or "pcg" (block-Jacobi preconditioned conjugate
+        gradients over the nonzero 6 x 6 blocks of the reduced camera system; maps of 80 free keyframes and more)."""
+        self._lib.so_ba_set_linear_solver.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
+        _lib.check(self._lib.so_ba_set_linear_solver(self._h, {"direct": 0, "pcg": 1}[solver], float(rel_tolerance), int(max_iterations)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

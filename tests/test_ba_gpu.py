@@ -552,6 +552,60 @@ def test_full_size_global_ba_matches_the_oracle_fixture(opt, name, fixture, robu
     assert abs(int(r["info"]["n_outliers"]) - int(inf["n_outliers"])) <= len(diff)
 
 
+@pytest.fixture()
+def pcg_opt():
+    """A solver context that solves large reduced camera systems by block-Jacobi PCG (so_ba_set_linear_solver)."""
+    import swarmmap_amd
+    o = swarmmap_amd.Optimizer()
+    o.set_linear_solver("pcg")
+    yield o
+    o.close()
+
+
+# An iterative solve ends within its tolerance of the exact increment, not within rounding of it: with |r| / |b| <= 1e-7 the
+# pose increment of one LM step is off by ~1e-8 (tools/pcg_study.py), ten steps stay far inside the 2e-5 of the direct
+# path's parity bar; chi2 agrees to 1e-6 relative as before.
+def test_pcg_on_a_sparse_multiagent_map_matches_the_oracle(pcg_opt, oracle):
+    """north_star's "PCG solve" of the reduced camera system (ba_pcg.hip) on GBA-1r - four agents, 299 keyframes, 12 % of
+    the 6 x 6 blocks of S set - against the oracle's direct LDLT, with bRobust = false (the server's call) and true."""
+    p = synth.make_ba_case("GBA-1r", 1)
+    for robust in (False, True):
+        r = pcg_opt.BundleAdjustment(p, nIterations=10, bRobust=robust)
+        o = oracle.bundle_adjust(p, its1=10, its2=0, robust=robust, huber_delta=np.float32(np.sqrt(np.float32(5.99))))
+        _compare(r, o)
+        inf = r["info"]
+        assert inf["solver_path"] == 3 and inf["pcg_iterations"] > 10 * inf["lm_trials"]
+        assert 299 < inf["nnz_tiles"] < 0.2 * 299 * 299  # nonzero 6 x 6 blocks: a sparse map
+    again = pcg_opt.BundleAdjustment(p, nIterations=10, bRobust=True)
+    assert np.array_equal(again["Tcw"], r["Tcw"]) and np.array_equal(again["Xw"], r["Xw"]) and again["info"]["pcg_iterations"] == inf["pcg_iterations"]
+
+
+def test_pcg_leaves_small_systems_to_the_direct_solvers(pcg_opt, opt):
+    """Below 80 free keyframes (no pair lists) the single-workgroup and blocked direct solvers are used whatever the setting."""
+    for n_free in (25, 64):
+        p = _window(n_free)
+        a, b = pcg_opt.LocalBundleAdjustment(p), opt.LocalBundleAdjustment(p)
+        assert a["info"]["solver_path"] != 3 and a["info"]["pcg_iterations"] == 0
+        assert np.array_equal(a["Tcw"], b["Tcw"]) and np.array_equal(a["Xw"], b["Xw"])
+
+
+@pytest.mark.parametrize("name,fixture", [("GBA-2", "gba2_norobust.npz"), ("GBA-2r", "gba2r_norobust.npz")])
+def test_pcg_on_the_full_size_maps_matches_the_oracle_fixture(pcg_opt, name, fixture):
+    """BASELINE configs[4] at full size with the PCG solve: the same fixtures the direct solver is checked against."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
+    p = synth.make_ba_case(name, 1)
+    assert _problem_digest(p) == str(g["digest"])
+    r = pcg_opt.BundleAdjustment(p, nIterations=10, bRobust=False)
+    inf = dict(zip([str(k) for k in g["info_keys"]], g["info_vals"]))
+    assert r["info"]["solver_path"] == 3 and r["info"]["iterations_stage1"] == int(inf["iterations_stage1"]) == 10
+    assert abs(r["info"]["lm_trials"] - int(inf["lm_trials"])) <= 10
+    assert r["info"]["chi2_final"] == pytest.approx(inf["chi2_final"], rel=1e-6)
+    assert np.all(np.abs(r["Tcw"] - g["Tcw"]) <= POSE_TOL + 4 * np.spacing(np.abs(g["Tcw"]).astype(np.float32)))
+    assert np.abs(r["Xw"][::8] - g["Xw_every8"]).max() <= POINT_TOL
+    assert np.allclose(r["chi2"][::64], g["chi2"], rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("seed,pose_noise", [(2, (1.0, 25.0)), (4, (0.6, 15.0)), (0, (0.3, 8.0))])
 def test_one_enqueue_per_call_equals_stage_by_stage_when_trials_are_rejected(opt, seed, pose_noise):
     """so_bundle_adjust enqueues both stages and the epilogue at once (stage 2 gated on the device, launches tagged with
