@@ -404,10 +404,14 @@ def closed_loop_record(st, steps):
         "local_mapping_ms_per_keyframe": {
             "whole_job": L.get("cl_job_ms", 0.0) / jobs, "process_new_keyframe_and_culling": L.get("cl_process_ms", 0.0) / jobs,
             "feature_vector_and_upload": L.get("node_ms", 0.0) / jobs,
-            "search_for_triangulation_batch": L.get("stage_tri_ms", 0.0) / jobs, "triangulation_and_new_points": L.get("triangulate_ms", 0.0) / jobs,
+            "search_for_triangulation_batch": L.get("stage_tri_ms", 0.0) / jobs,
+            "search_for_triangulation_batch_launch_wait_resolve": L.get("cl_tri_batch_end_ms", 0.0) / jobs, "triangulation_and_new_points": L.get("triangulate_ms", 0.0) / jobs,
             "fuse_batch_stage": L.get("stage_fuse_ms", 0.0) / jobs, "fuse_batch_launch_wait_resolve": L.get("batch_end_ms", 0.0) / jobs,
             "fuse_apply": L.get("cl_apply_ms", 0.0) / jobs, "window_gather": L.get("cl_gather_ms", 0.0) / jobs,
             "so_bundle_adjust": L.get("cl_solver_ms", 0.0) / jobs, "write_back_and_update_normal_depth": L.get("cl_writeback_ms", 0.0) / jobs,
+            "write_back_split": {"set_pose_set_world_pos_erase": L.get("cl_wb_apply_ms", 0.0) / jobs, "observers_per_point": L.get("cl_und_build_ms", 0.0) / jobs,
+                                 "so_update_normal_and_depth": L.get("cl_und_call_ms", 0.0) / jobs},
+            "packet": L.get("cl_packet_ms", 0.0) / jobs,
             "kernels": {"search_for_triangulation_batch": L.get("batch_kernel_ms", 0.0) / jobs, "triangulation": L.get("triangulate_kernel_ms", 0.0) / jobs,
                         "fuse_batch": L.get("cl_fuse_kernel_ms", 0.0) / jobs},
             "batches_enqueue": L.get("batch_enqueue_ms", 0.0) / jobs, "batches_wait": L.get("batch_wait_ms", 0.0) / jobs},

@@ -235,6 +235,7 @@ struct so_ba {
     int flow_timeouts = 0;
     int flow_reserved = 0;                  // tiles this context holds of the process-wide residency budget
     std::vector<int> tile_first;
+    int stage2_hint = 0;                    // trials to enqueue ahead for the second stage: what the last call needed + 2 (0: all)
     int linear_solver = 0;                  // so_ba_set_linear_solver: 0 direct (block-skyline Cholesky), 1 block-Jacobi PCG (ba_pcg.hip)
     BaPcgHost pcg;                          // its tolerance / iteration cap, workspace pointers and counters
     int pcg_nnz_blocks = 0;                 // nonzero 6 x 6 blocks of S in the last PCG problem
@@ -622,8 +623,14 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     for (int i = 0; i < nL; i++) h_ptoff[i + 1] += h_ptoff[i];
     std::vector<int> perm((size_t)nE);  // sorted position -> original edge index
     {
-        std::vector<int> fill(h_ptoff, h_ptoff + nL);
-        for (int e = 0; e < nE; e++) perm[(size_t)fill[(size_t)p->edge_point[e]]++] = e;
+        bool sorted = true;  // (a caller that walks its map point by point hands the edges over in landmark order already)
+        for (int e = 1; e < nE && sorted; e++) sorted = p->edge_point[e - 1] <= p->edge_point[e];
+        if (sorted) {
+            for (int e = 0; e < nE; e++) perm[(size_t)e] = e;
+        } else {
+            std::vector<int> fill(h_ptoff, h_ptoff + nL);
+            for (int e = 0; e < nE; e++) perm[(size_t)fill[(size_t)p->edge_point[e]]++] = e;
+        }
     }
     const double tS3 = now_ms();
     for (int i = 0, h = 0; i < nP; i++) {
@@ -1126,7 +1133,11 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
             launch_ba_errors(d2, 0, kBaGateIdle, r.nb_err, s);
             launch_ba_build(d2, kBaGateIdle, s);
             launch_ba_stage_begin(d2, r.nb_err, opt->its_stage2, b->h_lm_dev, kBaGateIdle, abort_dev, s);
-            trials(d2, opt->its_stage2);
+            // Stage 2 of a window that is re-optimised keyframe after keyframe ends on g2o's convergence test after a few
+            // iterations (levenberg.cpp:154-161); every trial enqueued beyond that is six launches that return at once, ~15 us
+            // of queue time each.  Enqueue what the context's last call needed plus two; a stage that wants more is
+            // topped up by the loop below (one host round trip).
+            trials(d2, std::min(opt->its_stage2, b->stage2_hint > 0 ? b->stage2_hint : opt->its_stage2));
         };
         launch_ba_errors(r.d, 0, kBaGateNone, r.nb_err, s);
         launch_ba_build(r.d, kBaGateNone, s);
@@ -1176,6 +1187,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         if (begun2) {
             inf.iterations_stage2 = lm.done;
             if (lm.done > 0) inf.chi2_final = lm.chi_out;
+            b->stage2_hint = std::max(2, lm.done + 2);
         }
         if (stopped_between || r.terminate()) inf.aborted = 1;
         r.d.robust = begun2 ? 0 : r.d.robust;

@@ -202,6 +202,11 @@ struct NormalDepthArgs {
     float* max_dist;             // host-mapped
     float* min_dist;             // host-mapped
     int n;
+    // indexed form (so_update_normal_and_depth_indexed): kf_Ow != nullptr - observation k is seen from camera centre
+    // kf_Ow[3 obs_kf[k]], the reference keyframe's centre is kf_Ow[3 ref_kf[p]]; obs_Ow / ref_Ow are not read
+    const float* kf_Ow;
+    const int32_t* obs_kf;
+    const int32_t* ref_kf;
 };
 void launch_normal_depth(const NormalDepthArgs& A, hipStream_t s);
 

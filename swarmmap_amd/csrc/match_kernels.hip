@@ -669,14 +669,16 @@ __global__ __launch_bounds__(256) void normal_depth_kernel(NormalDepthArgs A) {
     float nsum[3] = {0.f, 0.f, 0.f};
     int n = 0;
     for (int k = a; k < b; k++) {
-        const float d[3] = {Pos[0] - A.obs_Ow[3 * (size_t)k], Pos[1] - A.obs_Ow[3 * (size_t)k + 1], Pos[2] - A.obs_Ow[3 * (size_t)k + 2]};
+        const float* O = A.kf_Ow ? A.kf_Ow + 3 * (size_t)A.obs_kf[k] : A.obs_Ow + 3 * (size_t)k;
+        const float d[3] = {Pos[0] - O[0], Pos[1] - O[1], Pos[2] - O[2]};
         const double nr = sqrt((double)d[0] * d[0] + (double)d[1] * d[1] + (double)d[2] * d[2]);
         const float inv = (float)(1.0 / nr);
 #pragma unroll
         for (int j = 0; j < 3; j++) nsum[j] = nsum[j] + d[j] * inv;
         n++;
     }
-    const float PC[3] = {Pos[0] - A.ref_Ow[3 * (size_t)p], Pos[1] - A.ref_Ow[3 * (size_t)p + 1], Pos[2] - A.ref_Ow[3 * (size_t)p + 2]};
+    const float* Or = A.kf_Ow ? A.kf_Ow + 3 * (size_t)A.ref_kf[p] : A.ref_Ow + 3 * (size_t)p;
+    const float PC[3] = {Pos[0] - Or[0], Pos[1] - Or[1], Pos[2] - Or[2]};
     const float dist = (float)sqrt((double)PC[0] * PC[0] + (double)PC[1] * PC[1] + (double)PC[2] * PC[2]);
     const float mx = dist * A.ref_level_scale[p];
     A.max_dist[p] = mx;

@@ -2817,6 +2817,81 @@ int so_update_normal_and_depth(so_matcher* m, int32_t n_points, const int32_t* o
     A.max_dist = (float*)((uint8_t*)m->h_out.dev + nb);
     A.min_dist = (float*)((uint8_t*)m->h_out.dev + nb + sb);
     A.n = n;
+    A.kf_Ow = nullptr;
+    A.obs_kf = A.ref_kf = nullptr;
+    hipStream_t s = m->stream;
+    launch_stage_in(db, hb, end, s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+    launch_normal_depth(A, s);
+    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+    SO_HIP(hipGetLastError());
+    SO_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    if (m->profile && hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    memcpy(normal, m->h_out.p, 12 * (size_t)n);
+    memcpy(max_dist, (const uint8_t*)m->h_out.p + nb, 4 * (size_t)n);
+    memcpy(min_dist, (const uint8_t*)m->h_out.p + nb + sb, 4 * (size_t)n);
+    return SO_OK;
+}
+
+int so_update_normal_and_depth_indexed(so_matcher* m, int32_t n_points, const int32_t* offsets, const int32_t* obs_kf, int32_t n_kf,
+                                       const float* kf_Ow, const float* Xw, const int32_t* ref_kf, const float* ref_level_scale,
+                                       const float* ref_last_scale, float* normal, float* max_dist, float* min_dist) {
+    if (!m || n_points < 0 || n_kf < 0) return SO_ERR_INVALID_ARG;
+    if (n_points > 0 && (!offsets || !Xw || !ref_kf || !kf_Ow || !ref_level_scale || !ref_last_scale || !normal || !max_dist || !min_dist))
+        return SO_ERR_INVALID_ARG;
+    if (m->batching) {
+        last_error_ref() = "so_update_normal_and_depth_indexed cannot be part of a matcher batch";
+        return SO_ERR_INVALID_ARG;
+    }
+    SO_HIP(hipSetDevice(m->device));
+    (void)take_reuse(m);
+    begin_call(m);
+    if (n_points == 0) return SO_OK;
+    const int n = n_points;
+    for (int p = 0; p < n; p++)
+        if (offsets[p] > offsets[p + 1] || offsets[p] < 0 || ref_kf[p] < 0 || ref_kf[p] >= n_kf) return SO_ERR_INVALID_ARG;
+    const size_t total = (size_t)offsets[n];
+    if (total > 0 && !obs_kf) return SO_ERR_INVALID_ARG;
+    for (size_t k = 0; k < total; k++)
+        if (obs_kf[k] < 0 || obs_kf[k] >= n_kf) return SO_ERR_INVALID_ARG;
+    const size_t o_off = 0, o_ok = align256(4 * ((size_t)n + 1)), o_c = align256(o_ok + 4 * total), o_x = align256(o_c + 12 * (size_t)n_kf),
+                 o_r = align256(o_x + 12 * (size_t)n), o_ls = align256(o_r + 4 * (size_t)n), o_ll = align256(o_ls + 4 * (size_t)n),
+                 end = align256(o_ll + 4 * (size_t)n);
+    int rc;
+    if ((rc = m->h_in.ensure_keep(end + 256, 0))) return rc;
+    if ((rc = m->d_in.ensure(end + 256))) return rc;
+    const size_t nb = align256(12 * (size_t)n), sb = align256(4 * (size_t)n);
+    if ((rc = m->h_out.ensure(nb + 2 * sb))) return rc;
+    uint8_t* hb = (uint8_t*)m->h_in.p;
+    memcpy(hb + o_off, offsets, 4 * ((size_t)n + 1));
+    if (total) memcpy(hb + o_ok, obs_kf, 4 * total);
+    memcpy(hb + o_c, kf_Ow, 12 * (size_t)n_kf);
+    memcpy(hb + o_x, Xw, 12 * (size_t)n);
+    memcpy(hb + o_r, ref_kf, 4 * (size_t)n);
+    memcpy(hb + o_ls, ref_level_scale, 4 * (size_t)n);
+    memcpy(hb + o_ll, ref_last_scale, 4 * (size_t)n);
+    m->resident_n = -1;
+    m->dirty_from = 0;
+    m->src = nullptr;
+    memcpy(m->h_out.p, normal, 12 * (size_t)n);
+    memcpy((uint8_t*)m->h_out.p + nb, max_dist, 4 * (size_t)n);
+    memcpy((uint8_t*)m->h_out.p + nb + sb, min_dist, 4 * (size_t)n);
+    uint8_t* db = (uint8_t*)m->d_in.p;
+    NormalDepthArgs A;
+    A.off = (const int32_t*)(db + o_off);
+    A.obs_Ow = nullptr;
+    A.ref_Ow = nullptr;
+    A.Xw = (const float*)(db + o_x);
+    A.ref_level_scale = (const float*)(db + o_ls);
+    A.ref_last_scale = (const float*)(db + o_ll);
+    A.normal = (float*)m->h_out.dev;
+    A.max_dist = (float*)((uint8_t*)m->h_out.dev + nb);
+    A.min_dist = (float*)((uint8_t*)m->h_out.dev + nb + sb);
+    A.n = n;
+    A.kf_Ow = (const float*)(db + o_c);
+    A.obs_kf = (const int32_t*)(db + o_ok);
+    A.ref_kf = (const int32_t*)(db + o_r);
     hipStream_t s = m->stream;
     launch_stage_in(db, hb, end, s);
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));

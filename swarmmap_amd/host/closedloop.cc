@@ -86,21 +86,32 @@ void centre(const float* T, double* Ow) {  // -R^T t of a float pose, in double
     for (int q = 0; q < 3; q++) Ow[q] = -((double)T[q] * T[3] + (double)T[4 + q] * T[7] + (double)T[8 + q] * T[11]);
 }
 
-// KeyFrame::ComputeSceneMedianDepth(2): depth of the keyframe's map points in its camera, element [(n - 1) / 2] of the
-// sorted list; -1 without points
-double median_depth(const ClosedLoop& M, const KfSnap& k, std::vector<double>& z) {
+// the gate of CreateNewMapPoints (LocalMapping.cc:228-241): baseline / median depth of the neighbour < 0.01, the median
+// depth as KeyFrame::ComputeSceneMedianDepth(2) has it (element [(n - 1) / 2] of the sorted depths; -1 without points).  The median
+// is at most the largest depth, so a baseline of 1 % of THAT passes without the selection (same decision, a fifth of the time)
+bool baseline_too_short(const ClosedLoop& M, const KfSnap& k2, double baseline, std::vector<double>& z) {
     z.clear();
-    const float* T = k.T;
-    for (int i = 0; i < k.n; i++) {
-        const int s = k.mp[(size_t)i];
+    const float* T = k2.T;
+    double zmax = 0.0;
+    for (int i = 0; i < k2.n; i++) {
+        const int s = k2.mp[(size_t)i];
         if (s < 0) continue;
         const float* X = &M.X[3 * (size_t)s];
-        z.push_back((double)T[8] * (double)X[0] + (double)T[9] * (double)X[1] + (double)T[10] * (double)X[2] + (double)T[11]);
+        const double d = (double)T[8] * (double)X[0] + (double)T[9] * (double)X[1] + (double)T[10] * (double)X[2] + (double)T[11];
+        z.push_back(d);
+        if (d > zmax) zmax = d;
     }
-    if (z.empty()) return -1.0;
+    if (z.empty()) return baseline / -1.0 < 0.01;
+    if (zmax > 0.0 && baseline / zmax >= 0.01) {
+        // median <= zmax; a non-positive median (most points behind the camera) fails the gate the reference's way - only
+        // possible when at least half of the depths are <= 0
+        size_t nonpos = 0;
+        for (double d : z) nonpos += d <= 0.0 ? 1 : 0;
+        if (2 * nonpos < z.size()) return false;
+    }
     const size_t mid = (z.size() - 1) / 2;
     std::nth_element(z.begin(), z.begin() + (long)mid, z.end());
-    return z[mid];
+    return baseline / z[mid] < 0.01;
 }
 
 struct Window {
@@ -157,40 +168,54 @@ bool local_window(so_replay* r, ClosedLoop& M, const KfSnap& c, Window& W) {
     std::sort(W.kf.begin(), W.kf.end());
     std::vector<int32_t> row((size_t)nkf, -1);
     for (size_t p = 0; p < W.kf.size(); p++) row[(size_t)W.kf[p]] = (int32_t)p;
-    W.pts.clear(); W.e_kf.clear(); W.e_idx.clear(); W.e_pt.clear();
-    for (int s : pts) {
-        int ne = 0;
-        for (const auto& o : M.obs[(size_t)s]) ne += row[(size_t)o.first] >= 0 ? 1 : 0;
-        if (ne < 2) continue;
-        for (const auto& o : M.obs[(size_t)s])
-            if (row[(size_t)o.first] >= 0) {
-                W.e_kf.push_back(o.first);
-                W.e_idx.push_back(o.second);
-                W.e_pt.push_back((int32_t)W.pts.size());
-            }
-        W.pts.push_back(s);
-    }
-    if (W.pts.size() < 10) return false;
+    // one walk over the points' observations: the edges of a point are written as they are found (keypoint coordinates and
+    // weights straight from the keyframes' arrays) and taken back if there are fewer than two
     W.fixed.resize(W.kf.size());
     for (size_t p = 0; p < W.kf.size(); p++) W.fixed[p] = (is_local[(size_t)W.kf[p]] && W.kf[p] != 0) ? 0 : 1;
+    std::vector<const float*> kx((size_t)nkf, nullptr), ky((size_t)nkf, nullptr);
+    std::vector<const int32_t*> ko((size_t)nkf, nullptr);
+    for (int kf : W.kf) {
+        const KfSnap& q = *M.kfs[(size_t)kf];
+        kx[(size_t)kf] = q.x.data(); ky[(size_t)kf] = q.y.data(); ko[(size_t)kf] = q.octave.data();
+    }
+    size_t cap = 0;
+    for (int s : pts) cap += M.obs[(size_t)s].size();
+    W.pts.clear();
+    W.e_kf.resize(cap); W.e_idx.resize(cap); W.e_pt.resize(cap); W.e_pose.resize(cap); W.obs.resize(2 * cap); W.w.resize(cap);
+    size_t ne = 0;
     bool any_free = false;
-    for (size_t e = 0; e < W.e_kf.size() && !any_free; e++) any_free = W.fixed[(size_t)row[(size_t)W.e_kf[e]]] == 0;
-    if (!any_free) return false;
-    const size_t np = W.kf.size(), nl = W.pts.size(), ne = W.e_kf.size();
-    W.Tcw.resize(12 * np); W.intr.resize(4 * np); W.Xw.resize(3 * nl); W.obs.resize(2 * ne); W.w.resize(ne); W.e_pose.resize(ne);
+    for (int s : pts) {
+        const size_t e0 = ne;
+        bool fr = false;
+        for (const auto& o : M.obs[(size_t)s]) {
+            const int p = row[(size_t)o.first];
+            if (p < 0) continue;
+            W.e_kf[ne] = o.first;
+            W.e_idx[ne] = o.second;
+            W.e_pt[ne] = (int32_t)W.pts.size();
+            W.e_pose[ne] = p;
+            W.obs[2 * ne] = kx[(size_t)o.first][o.second];
+            W.obs[2 * ne + 1] = ky[(size_t)o.first][o.second];
+            W.w[ne] = r->inv_sigma2[ko[(size_t)o.first][o.second]];
+            fr = fr || W.fixed[(size_t)p] == 0;
+            ne++;
+        }
+        if (ne - e0 < 2) {
+            ne = e0;
+            continue;
+        }
+        any_free = any_free || fr;
+        W.pts.push_back(s);
+    }
+    W.e_kf.resize(ne); W.e_idx.resize(ne); W.e_pt.resize(ne); W.e_pose.resize(ne); W.obs.resize(2 * ne); W.w.resize(ne);
+    if (W.pts.size() < 10 || !any_free) return false;
+    const size_t np = W.kf.size(), nl = W.pts.size();
+    W.Tcw.resize(12 * np); W.intr.resize(4 * np); W.Xw.resize(3 * nl);
     for (size_t p = 0; p < np; p++) {
         memcpy(&W.Tcw[12 * p], M.kfs[(size_t)W.kf[p]]->T, 48);
         W.intr[4 * p] = r->cam.fx; W.intr[4 * p + 1] = r->cam.fy; W.intr[4 * p + 2] = r->cam.cx; W.intr[4 * p + 3] = r->cam.cy;
     }
     for (size_t q = 0; q < nl; q++) memcpy(&W.Xw[3 * q], &M.X[3 * (size_t)W.pts[q]], 12);
-    for (size_t e = 0; e < ne; e++) {
-        const KfSnap& q = *M.kfs[(size_t)W.e_kf[e]];
-        const size_t i = (size_t)W.e_idx[e];
-        W.obs[2 * e] = q.x[i];
-        W.obs[2 * e + 1] = q.y[i];
-        W.w[e] = r->inv_sigma2[q.octave[i]];
-        W.e_pose[e] = row[(size_t)W.e_kf[e]];
-    }
     return true;
 }
 
@@ -202,7 +227,7 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
     Lm L(M);
     so_matcher* m = r->mapper_matcher;
     const double t0 = now_ms();
-    double st[32] = {0};
+    double st[40] = {0};
     float kms = 0.f;
     so_matcher_set_profiling(m, 1);
     const int k = (int)M.kfs.size(), n = c->n;
@@ -288,8 +313,7 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
             centre(k2.T, O2);
             const double d0 = O2[0] - Oc[0], d1 = O2[1] - Oc[1], d2 = O2[2] - Oc[2];
             const double baseline = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-            const double med = median_depth(M, k2, z);
-            if (baseline / med < 0.01) continue;
+            if (baseline_too_short(M, k2, baseline, z)) continue;
             if (!began) {
                 if (so_matcher_batch_begin(m) != SO_OK) return SO_ERR_HIP;
                 began = true;
@@ -308,7 +332,9 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
             st[kLmTriCalls] += 1;
         }
         if (began) {
+            const double tbe = now_ms();
             if (so_matcher_batch_end(m) != SO_OK) return SO_ERR_HIP;
+            st[36] = now_ms() - tbe;  // launch + wait + resolve of the SearchForTriangulation batch
             double ms4[4] = {0};
             so_matcher_last_stats(m, ms4);
             st[kLmBatchEnqueueMs] += ms4[0];
@@ -524,55 +550,58 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
             }
             lba[0] = (int64_t)W.e_kf.size(); lba[1] = n_out; lba[4] = (int64_t)W.pts.size();
             for (uint8_t f : W.fixed) lba[f ? 3 : 2]++;
+            st[32] = now_ms() - tw0;  // SetPose / SetWorldPos / EraseObservation
+            const double tu0 = now_ms();
             // UpdateNormalAndDepth of the window's points (:729-737)
             std::vector<int32_t> live;
             for (int s : W.pts)
                 if (!M.bad[(size_t)s] && !M.obs[(size_t)s].empty()) live.push_back(s);
             if (!live.empty()) {
-                std::vector<float>&ow = r->lm_nobs, &Xn = r->lm_nX, &rO = r->lm_nref, &ls = r->lm_nls, &ll = r->lm_nll;
+                // observers by index into the window's keyframes (so_update_normal_and_depth_indexed): 4 bytes per observation
+                std::vector<float>&Xn = r->lm_nX, &ls = r->lm_nls, &ll = r->lm_nll, &cen = r->lm_nobs;
                 std::vector<float>&nrm = r->lm_nnrm, &mxd = r->lm_nmax, &mnd = r->lm_nmin;
-                std::vector<int32_t>& off = r->lm_noff;
-                ow.clear(); Xn.clear(); rO.clear(); ls.clear(); ll.clear(); nrm.clear(); mxd.clear(); mnd.clear();
-                off.assign(1, 0);
-                std::vector<float> cen(3 * M.kfs.size());
-                std::vector<uint8_t> have_c(M.kfs.size(), 0);
-                auto cof = [&](int kf) -> const float* {
-                    if (!have_c[(size_t)kf]) {
-                        double O[3];
-                        centre(M.kfs[(size_t)kf]->T, O);
-                        for (int q = 0; q < 3; q++) cen[3 * (size_t)kf + (size_t)q] = (float)O[q];
-                        have_c[(size_t)kf] = 1;
-                    }
-                    return &cen[3 * (size_t)kf];
-                };
-                for (int s : live) {
-                    const auto& o = M.obs[(size_t)s];
+                std::vector<int32_t>&off = r->lm_noff, &okf = r->lm_to1, &rkf = r->lm_to2;
+                const size_t nl = live.size(), nk = M.kfs.size();
+                size_t total = 0;
+                for (int s : live) total += M.obs[(size_t)s].size();
+                off.resize(nl + 1); okf.resize(total); rkf.resize(nl);
+                Xn.resize(3 * nl); ls.resize(nl); ll.assign(nl, r->scale[r->nlevels - 1]); nrm.resize(3 * nl); mxd.resize(nl); mnd.resize(nl);
+                cen.resize(3 * nk);
+                for (size_t kf = 0; kf < nk; kf++) {  // (every keyframe: an observer need not be part of the window)
+                    double O[3];
+                    centre(M.kfs[kf]->T, O);
+                    for (int q = 0; q < 3; q++) cen[3 * kf + (size_t)q] = (float)O[q];
+                }
+                size_t at = 0;
+                for (size_t q = 0; q < nl; q++) {
+                    const size_t s = (size_t)live[q];
+                    const auto& o = M.obs[s];
+                    off[q] = (int32_t)at;
+                    int rk = M.ref_kf[s], ri = -1;
                     for (const auto& e : o) {
-                        const float* C = cof(e.first);
-                        ow.insert(ow.end(), C, C + 3);
+                        okf[at++] = e.first;
+                        if (e.first == rk && ri < 0) ri = e.second;
                     }
-                    off.push_back((int32_t)(ow.size() / 3));
-                    int rk = M.ref_kf[(size_t)s], ri = -1;
-                    for (const auto& e : o)
-                        if (e.first == rk) { ri = e.second; break; }
                     if (ri < 0) {  // the reference keyframe's observation is gone: the first observer takes over
                         rk = o[0].first;
                         ri = o[0].second;
-                        M.ref_kf[(size_t)s] = rk;
+                        M.ref_kf[s] = rk;
                     }
-                    const float* C = cof(rk);
-                    rO.insert(rO.end(), C, C + 3);
-                    ls.push_back(r->scale[M.kfs[(size_t)rk]->octave[(size_t)ri]]);
-                    ll.push_back(r->scale[r->nlevels - 1]);
-                    Xn.insert(Xn.end(), &M.X[3 * (size_t)s], &M.X[3 * (size_t)s] + 3);
-                    nrm.insert(nrm.end(), &M.N[3 * (size_t)s], &M.N[3 * (size_t)s] + 3);
-                    mxd.push_back(M.mx[(size_t)s]);
-                    mnd.push_back(M.mn[(size_t)s]);
+                    rkf[q] = rk;
+                    ls[q] = r->scale[M.kfs[(size_t)rk]->octave[(size_t)ri]];
+                    memcpy(&Xn[3 * q], &M.X[3 * s], 12);
+                    memcpy(&nrm[3 * q], &M.N[3 * s], 12);
+                    mxd[q] = M.mx[s];
+                    mnd[q] = M.mn[s];
                 }
-                if (so_update_normal_and_depth(m, (int32_t)live.size(), off.data(), ow.data(), Xn.data(), rO.data(), ls.data(), ll.data(), nrm.data(),
-                                               mxd.data(), mnd.data()) != SO_OK)
+                off[nl] = (int32_t)at;
+                st[33] = now_ms() - tu0;  // the observers per point
+                const double tv0 = now_ms();
+                if (so_update_normal_and_depth_indexed(m, (int32_t)nl, off.data(), okf.data(), (int32_t)nk, cen.data(), Xn.data(), rkf.data(),
+                                                       ls.data(), ll.data(), nrm.data(), mxd.data(), mnd.data()) != SO_OK)
                     return SO_ERR_HIP;
-                for (size_t q = 0; q < live.size(); q++) {
+                st[34] = now_ms() - tv0;  // the call
+                for (size_t q = 0; q < nl; q++) {
                     const size_t s = (size_t)live[q];
                     memcpy(&M.N[3 * s], &nrm[3 * q], 12);
                     M.mx[s] = mxd[q];
@@ -585,15 +614,21 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
     }
     st[30] = now_ms() - tl0;  // local BA incl. gather and write-back
     // ---- the packet
+    const double tp0 = now_ms();
     pk.kf = k;
     pk.first_new = n_before;
     pk.n_points = L.n_points();
     pk.new_X.assign(M.X.begin() + 3 * (long)n_before, M.X.end());
-    for (int s : pk.moved) {
-        pk.moved_X.insert(pk.moved_X.end(), &M.X[3 * (size_t)s], &M.X[3 * (size_t)s] + 3);
-        pk.moved_N.insert(pk.moved_N.end(), &M.N[3 * (size_t)s], &M.N[3 * (size_t)s] + 3);
-        pk.moved_mx.push_back(M.mx[(size_t)s]);
-        pk.moved_mn.push_back(M.mn[(size_t)s]);
+    {
+        const size_t nm = pk.moved.size();
+        pk.moved_X.resize(3 * nm); pk.moved_N.resize(3 * nm); pk.moved_mx.resize(nm); pk.moved_mn.resize(nm);
+        for (size_t q = 0; q < nm; q++) {
+            const size_t s = (size_t)pk.moved[q];
+            memcpy(&pk.moved_X[3 * q], &M.X[3 * s], 12);
+            memcpy(&pk.moved_N[3 * q], &M.N[3 * s], 12);
+            pk.moved_mx[q] = M.mx[s];
+            pk.moved_mn[q] = M.mn[s];
+        }
     }
     std::sort(M.newly_bad.begin(), M.newly_bad.end());
     pk.bad = M.newly_bad;
@@ -615,13 +650,14 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
         std::sort(pk.local_slots.begin(), pk.local_slots.end());
     }
     const int64_t row[12] = {c->t, nn, n_tri, n_new, n_fused, n_back, lba[0], lba[1], lba[2], lba[3], lba[4], (int64_t)pk.bad.size()};
-    st[31] = now_ms() - t0;  // the whole job
+    st[35] = now_ms() - tp0;  // the packet
+    st[31] = now_ms() - t0;   // the whole job
     if (info_out) *info_out = info;
     {
         std::lock_guard<std::mutex> lk(r->mu);
         M.lm_log.insert(M.lm_log.end(), row, row + 12);
         if (timed)
-            for (int i = 0; i < 32; i++) r->lm_stat[i] += st[i];
+            for (int i = 0; i < 40; i++) r->lm_stat[i] += st[i];
     }
     {
         std::lock_guard<std::mutex> lk(M.mu);

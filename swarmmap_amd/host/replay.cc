@@ -711,7 +711,7 @@ int so_replay_set_vocabulary(so_replay* r, const uint8_t* centroids, int n, int 
 }
 // statistics of the timed matcher jobs (indices: the kLm* enumeration above) and the log of every job:
 // 6 ints each = frame index, neighbours, SearchForTriangulation matches, points fused into neighbours, fused back, new map points
-int so_replay_lm_stats(so_replay* r, double* out16) {  // (32 doubles)
+int so_replay_lm_stats(so_replay* r, double* out16) {  // (40 doubles)
     if (!r || !out16) return SO_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(r->mu);
     memcpy(out16, r->lm_stat, sizeof(r->lm_stat));

@@ -189,7 +189,7 @@ struct so_replay {
     std::vector<float> lm_cX, lm_cN, lm_cmax, lm_cmin;  // vpFuseCandidates of the keyframe being processed
     std::vector<uint8_t> lm_cD, lm_cok;
     int lm_stamp_id = 0;
-    double lm_stat[32] = {0};  // kLm* below; [24..31] closed loop: process, Fuse-batch kernels, apply, window gather, solver call, write-back, local BA, whole job
+    double lm_stat[40] = {0};  // kLm* below; [24..31] closed loop: process, Fuse-batch kernels, apply, window gather, solver call, write-back, local BA, whole job
     std::vector<int32_t> lm_log;           // 6 ints per job: t, neighbours, triangulation matches, fused, fused back, new map points
     std::vector<int32_t> lm_tof, lm_to1, lm_to2, lm_noff;  // scratch of the triangulation step (capacity kept)
     std::vector<float> lm_txy1, lm_txy2, lm_tX, lm_nobs, lm_nX, lm_nref, lm_nls, lm_nll, lm_nnrm, lm_nmax, lm_nmin;

@@ -627,6 +627,18 @@ def _UpdateNormalAndDepth(self, offsets, obs_Ow, Xw, ref_Ow, ref_level_scale, re
     return nrm, mx, mn
 
 
+def _UpdateNormalAndDepthIndexed(self, offsets, obs_kf, kf_Ow, Xw, ref_kf, ref_level_scale, ref_last_scale, normal, max_dist, min_dist):
+    """so_update_normal_and_depth_indexed: the observers as indices into kf_Ow (n_kf x 3 camera centres)."""
+    vp, i32 = C.c_void_p, C.c_int32
+    self._lib.so_update_normal_and_depth_indexed.argtypes = [vp, i32, vp, vp, i32] + [vp] * 8
+    off, ok, rk = _i32(offsets), _i32(obs_kf), _i32(ref_kf)
+    c, X, ls, ll = [_f32(v) for v in (kf_Ow, Xw, ref_level_scale, ref_last_scale)]
+    nrm, mx, mn = [np.array(v, np.float32, copy=True) for v in (normal, max_dist, min_dist)]
+    _lib.check(self._lib.so_update_normal_and_depth_indexed(self._h, len(off) - 1, _vp(off), _vp(ok), len(c.reshape(-1, 3)), _vp(c), _vp(X),
+                                                            _vp(rk), _vp(ls), _vp(ll), _vp(nrm), _vp(mx), _vp(mn)))
+    return nrm, mx, mn
+
+
 def _TriangulateNewPoints(self, kf1, kf2_list, ratio_factor, kf2_of_match, xy1, octave1, xy2, octave2):
     """so_triangulate_new_points: so_triangulate_matches + the new points' normal / distance range in the same launch.
     Returns (ok, x3D, normal, max_dist, min_dist); the last three are zero where ok is 0."""
@@ -648,3 +660,4 @@ def _TriangulateNewPoints(self, kf1, kf2_list, ratio_factor, kf2_of_match, xy1, 
 ORBmatcher.TriangulateMatches = _TriangulateMatches
 ORBmatcher.TriangulateNewPoints = _TriangulateNewPoints
 ORBmatcher.UpdateNormalAndDepth = _UpdateNormalAndDepth
+ORBmatcher.UpdateNormalAndDepthIndexed = _UpdateNormalAndDepthIndexed

@@ -23,7 +23,7 @@ LM_STAT = ("jobs", "wall_ms", "node_ms", "tri_calls", "tri_ms", "tri_kernel_ms",
            # the closed loop's job (closedloop.cc): ProcessNewKeyFrame + culling, the Fuse batch's kernels, applying the Fuse
            # results, the window gather, the so_bundle_adjust call, its write-back, local BA as a whole, the whole job
            "cl_process_ms", "cl_fuse_kernel_ms", "cl_apply_ms", "cl_gather_ms", "cl_solver_ms", "cl_writeback_ms", "cl_lba_ms",
-           "cl_job_ms")
+           "cl_job_ms", "cl_wb_apply_ms", "cl_und_build_ms", "cl_und_call_ms", "cl_packet_ms", "cl_tri_batch_end_ms")
 
 
 def make_vocabulary(n=100, seed=20221001):
@@ -103,7 +103,7 @@ class Replay:
 
     def lm_stats(self):
         """Sums over the timed matcher jobs of the local-mapping thread."""
-        a = np.zeros(32, np.float64)
+        a = np.zeros(40, np.float64)
         self.lib.so_replay_lm_stats(self.h, self._p(a))
         return dict(zip(LM_STAT, a[:len(LM_STAT)].tolist()))
 

@@ -103,6 +103,31 @@ def test_update_normal_and_depth(S, oracle, seed, n, max_obs):
     m.close()
 
 
+def test_update_normal_and_depth_with_the_observers_by_index(S, oracle):
+    """so_update_normal_and_depth_indexed (the write-back of local BA: a window's points seen from a few dozen keyframes):
+    observers as keyframe indices + one table of camera centres - the same bits as the expanded form and the oracle."""
+    rng = np.random.default_rng(11)
+    n_kf, n = 57, 1800
+    centres = rng.normal(0, 1.0, (n_kf, 3)).astype(np.float32)
+    k = rng.integers(0, 16, n)
+    k[:5] = 0  # points without observations keep their values
+    off = np.concatenate([[0], np.cumsum(k)]).astype(np.int32)
+    okf = rng.integers(0, n_kf, int(off[-1])).astype(np.int32)
+    rkf = rng.integers(0, n_kf, n).astype(np.int32)
+    Xw = (rng.normal(0, 1.0, (n, 3)) + [0, 0, 4]).astype(np.float32)
+    ls = (1.2 ** rng.integers(0, 8, n)).astype(np.float32)
+    ll = np.full(n, np.float32(1.2) ** 7, np.float32)
+    nrm, mx, mn = rng.normal(0, 1, (n, 3)).astype(np.float32), rng.uniform(1, 9, n).astype(np.float32), rng.uniform(0.1, 1, n).astype(np.float32)
+    m = S.ORBmatcher()
+    got = m.UpdateNormalAndDepthIndexed(off, okf, centres, Xw, rkf, ls, ll, nrm, mx, mn)
+    want = oracle.update_normal_and_depth(off, centres[okf], Xw, centres[rkf], ls, ll, nrm, mx, mn)
+    same = m.UpdateNormalAndDepth(off, centres[okf], Xw, centres[rkf], ls, ll, nrm, mx, mn)
+    for g, w, e in zip(got, want, same):
+        assert g.tobytes() == w.tobytes() == e.tobytes()
+    assert got[0][:5].tobytes() == nrm[:5].tobytes()
+    m.close()
+
+
 def test_triangulation_and_normal_depth_edge_cases(S, oracle):
     """What CreateNewMapPoints / UpdateNormalAndDepth meet at the edges: no matches at all; a neighbour at the same place
     (zero baseline: every pair of rays is parallel, the parallax gate and the w == 0 test decide); a pure rotation; points
