@@ -408,32 +408,39 @@ void launch_ba_finish(const BaDev& d, double chi2_threshold, BaPose* pose_out, d
 // Between the two stages of LocalBundleAdjustment (Optimizer.cc:644-656): one thread per landmark walks its
 // (contiguous) edges; an active edge whose stored chi2 exceeds the threshold or whose point is not in front of
 // the camera in the current estimate is dropped (setLevel(1)); a landmark without active edges drops out too.
+// (eight lanes per landmark, each looking at every eighth edge: a thread per landmark walked ~15 edges of dependent loads,
+//  32 us on a 26 k-edge window; flags only, so no summation order is involved)
 __global__ __launch_bounds__(256) void ba_mark_outliers_kernel(BaDev d, double chi2_threshold, int gate) {
-    const int il = blockIdx.x * 256 + threadIdx.x;
-    if (il >= d.n_points) return;
+    const int il = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
     if (gate == 2 && (d.lm->active || d.lm->stages_begun != d.stage - 1)) return;
+    const bool live = il < d.n_points;
     const int cur = d.lm->cur;
-    const double* points = d.pt[cur];
-    const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
     int alive = 0;
-    for (int e = d.pt_off[il]; e < d.pt_off[il + 1]; e++) {
-        if (!d.e_active[e]) continue;
-        double pc[3];
-        camera_point(d.pose[cur][d.e_pose[e]], X, pc);
-        if (d.e_chi2[e] > chi2_threshold || !(pc[2] > 0.0)) {
-            d.e_active[e] = 0;
-            const int h = d.use_pairs ? -1 : d.pose_hidx[d.e_pose[e]];
-            if (h >= 0) d.edge_tab[(size_t)h * d.n_points + il] = -1;  // the table only lists active edges
-        } else {
-            alive++;
+    if (live) {
+        const double* points = d.pt[cur];
+        const double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+        for (int e = d.pt_off[il] + sub; e < d.pt_off[il + 1]; e += 8) {
+            if (!d.e_active[e]) continue;
+            double pc[3];
+            camera_point(d.pose[cur][d.e_pose[e]], X, pc);
+            if (d.e_chi2[e] > chi2_threshold || !(pc[2] > 0.0)) {
+                d.e_active[e] = 0;
+                const int h = d.use_pairs ? -1 : d.pose_hidx[d.e_pose[e]];
+                if (h >= 0) d.edge_tab[(size_t)h * d.n_points + il] = -1;  // the table only lists active edges
+            } else {
+                alive++;
+            }
         }
     }
-    d.pt_active[il] = alive > 0;
+    alive += __shfl_xor(alive, 1);
+    alive += __shfl_xor(alive, 2);
+    alive += __shfl_xor(alive, 4);
+    if (live && sub == 0) d.pt_active[il] = alive > 0;
 }
 
 void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, int gate, hipStream_t s) {
     if (d.n_points <= 0) return;
-    hipLaunchKernelGGL(ba_mark_outliers_kernel, dim3((d.n_points + 255) / 256), dim3(256), 0, s, d, chi2_threshold, gate);
+    hipLaunchKernelGGL(ba_mark_outliers_kernel, dim3((d.n_points + 31) / 32), dim3(256), 0, s, d, chi2_threshold, gate);
 }
 
 // ---------------- linearisation: Hpp/bp per free pose (one workgroup each), Hll/bl/W per landmark ----------------

@@ -211,6 +211,11 @@ struct so_matcher {
         std::vector<int> perm;
         const so_kframe* ext = nullptr;  // candidates read from an HBM-resident keyframe instead of the staged block
         int ext_layout = 0;              // 0: grid order, 1: vocabulary-node order
+        // query descriptors by index: row qidx[i] of a descriptor table staged ONCE per batch (a keyframe's twenty
+        // SearchForTriangulation calls query with subsets of the same keypoints' descriptors)
+        bool q_indexed = false;
+        size_t off_qidx = 0;     // of the indices inside the job's block
+        size_t qtab_abs = 0;     // of the table inside hb_in / db_in (behind kBatchTableBytes)
         std::function<int(const uint32_t* keys, const int32_t* cnt, const so::MatchQueryW* qw, const std::vector<int>& perm)> resolve;
     };
     bool batching = false;
@@ -228,6 +233,13 @@ struct so_matcher {
         int n = -1;
         size_t base = 0, off_qdesc = 0, off_xw = 0, off_nrm = 0, off_maxd = 0, off_mind = 0;
     } mp_share;
+    // The keypoint descriptors of the keyframe whose SearchForTriangulation calls this batch holds: staged once, by the
+    // first of them (same pointer, same count AND same bytes as what the next call passes, else that call stages its own)
+    struct TriShare {
+        const uint8_t* desc = nullptr;
+        int n = -1;
+        size_t abs = 0;  // of the staged table inside hb_in (behind kBatchTableBytes)
+    } tri_share;
 };
 
 namespace {
@@ -664,6 +676,10 @@ int batch_flush(so_matcher* m) {
             D.qw = (MatchQueryW*)((uint8_t*)m->hb_out.dev + J.qw_off);
         } else {
             D.q = (MatchQuery*)(dbase + J.base + J.off_q);
+            if (J.q_indexed) {
+                D.qdesc = (const uint4*)(dbase + J.qtab_abs);
+                D.qslot = (const int32_t*)(b + J.off_qidx);
+            }
         }
         grid->first_proj[j] = proj_blocks;
         grid->first_topk[j] = topk_blocks;
@@ -704,6 +720,7 @@ int batch_flush(so_matcher* m) {
     m->jobs.clear();
     m->hb_used = m->dq_used = m->out_used = 0;
     m->mp_share.n = -1;  // (its block went with the flush)
+    m->tri_share.n = -1;
     return rc;
 }
 
@@ -2375,6 +2392,7 @@ int as_batch(so_matcher* m, F&& call) {
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     m->batching = true;
     m->mp_share.n = -1;
+    m->tri_share.n = -1;
     m->jobs.clear();
     m->hb_used = m->dq_used = m->out_used = 0;
     int rc = call();
@@ -2592,33 +2610,58 @@ int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x
             int32_t* hl = (int32_t*)m->h_in.p;
             for (int r = 0; r < nc; r++) hl[r] = free2[kf2->perm_node[(size_t)r]] ? INT_MAX : 0;  // "|| pMP2" (:662)
         }
-        std::vector<int> q_idx1;
-        std::vector<MatchQuery> queries;
+        // the queries are counted first and then written where they are staged (no intermediate vector, no second copy)
+        int nq = 0;
         for (size_t j = 0; j < J.k1.size(); j++) {
-            const int k1 = J.k1[j], k2 = J.k2[j];
-            for (int a = fv1->off[k1]; a < fv1->off[k1 + 1]; a++) {
-                const int idx1 = fv1->idx[a];
-                if (!free1[idx1]) continue;
-                MatchQuery q;
-                init_query(q);
-                q.active = 1;
-                q.flags = kQRange | kQEpipolar | kQPreferLast;
-                q.max_dist = TH_LOW;
-                q.c_begin = kf2->node_off[(size_t)k2];
-                q.c_end = kf2->node_off[(size_t)k2 + 1];
-                q.la = x1[idx1] * F12[0] + y1[idx1] * F12[3] + F12[6];
-                q.lb = x1[idx1] * F12[1] + y1[idx1] * F12[4] + F12[7];
-                q.lc = x1[idx1] * F12[2] + y1[idx1] * F12[5] + F12[8];
-                queries.push_back(q);
-                q_idx1.push_back(idx1);
-            }
+            const int k1 = J.k1[j];
+            for (int a = fv1->off[k1]; a < fv1->off[k1 + 1]; a++) nq += free1[fv1->idx[a]] ? 1 : 0;
         }
-        const int nq = (int)queries.size();
         if (nq == 0) return SO_OK;
         if ((rc = ensure_queries(m, nq))) return rc;
-        memcpy(m->h_q.p, queries.data(), sizeof(MatchQuery) * (size_t)nq);
-        uint8_t* hd = (uint8_t*)m->h_qdesc.p;
-        for (int i = 0; i < nq; i++) memcpy(hd + (size_t)i * 32, desc1 + (size_t)q_idx1[(size_t)i] * 32, 32);
+        std::vector<int> q_idx1((size_t)nq);
+        {
+            MatchQuery* hq = (MatchQuery*)m->h_q.p;
+            int at = 0;
+            for (size_t j = 0; j < J.k1.size(); j++) {
+                const int k1 = J.k1[j], k2 = J.k2[j];
+                const int cb = kf2->node_off[(size_t)k2], ce = kf2->node_off[(size_t)k2 + 1];
+                for (int a = fv1->off[k1]; a < fv1->off[k1 + 1]; a++) {
+                    const int idx1 = fv1->idx[a];
+                    if (!free1[idx1]) continue;
+                    MatchQuery& q = hq[at];
+                    init_query(q);
+                    q.active = 1;
+                    q.flags = kQRange | kQEpipolar | kQPreferLast;
+                    q.max_dist = TH_LOW;
+                    q.c_begin = cb;
+                    q.c_end = ce;
+                    q.la = x1[idx1] * F12[0] + y1[idx1] * F12[3] + F12[6];
+                    q.lb = x1[idx1] * F12[1] + y1[idx1] * F12[4] + F12[7];
+                    q.lc = x1[idx1] * F12[2] + y1[idx1] * F12[5] + F12[8];
+                    q_idx1[(size_t)at++] = idx1;
+                }
+            }
+        }
+        // Query descriptors: 4-byte indices into the keyframe's descriptor table, which the first such call of a batch stages
+        // (32 n1 bytes, once) - a keyframe's twenty calls used to stage ~570 x 32 bytes each, twice.
+        size_t staged_end = 0, off_qidx = 0;
+        off_qidx = m->off_qdesc;
+        {
+            int32_t* hi = (int32_t*)m->h_qdesc.p;  // (ensure_queries left room for nq x 32 bytes here)
+            for (int i = 0; i < nq; i++) hi[i] = q_idx1[(size_t)i];
+        }
+        staged_end = align256(off_qidx + 4 * (size_t)nq);
+        so_matcher::TriShare& sh = m->tri_share;
+        // (a full batch is flushed by batch_defer before this job joins it: whatever was shared goes with the flush)
+        const bool same = m->jobs.size() < kBatchMaxJobs && sh.n == n1 && sh.desc == desc1 &&
+                          memcmp((const uint8_t*)m->hb_in.p + kBatchTableBytes + sh.abs, desc1, 32 * (size_t)n1) == 0;
+        size_t tab_in_block = 0;
+        if (!same) {  // the table rides at the end of this job's block
+            tab_in_block = staged_end;
+            if ((rc = m->h_in.ensure_keep(staged_end + 32 * (size_t)n1 + 256, staged_end))) return rc;
+            memcpy((uint8_t*)m->h_in.p + staged_end, desc1, 32 * (size_t)n1);
+            staged_end += 32 * (size_t)n1;
+        }
         const float* angle2 = kf2->angle.data();
         auto resolve = [m, nq, q_idx1 = std::move(q_idx1), angle1, angle2, check_orientation, matches12, nmatches](
                            const uint32_t* keys, const int32_t*, const MatchQueryW*, const std::vector<int>& perm) -> int {
@@ -2644,7 +2687,19 @@ int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x
             *nmatches = nm;
             return SO_OK;
         };
-        return batch_defer(m, m->off_qdesc + (size_t)nq * 32, nq, 1, nullptr, nullptr, std::move(resolve), kf2, 1);
+        rc = batch_defer(m, staged_end, nq, 1, nullptr, nullptr, std::move(resolve), kf2, 1);
+        if (rc == SO_OK) {
+            so_matcher::BatchJob& J = m->jobs.back();
+            J.q_indexed = true;
+            J.off_qidx = off_qidx;
+            if (!same) {
+                sh.desc = desc1;
+                sh.n = n1;
+                sh.abs = J.base + tab_in_block;
+            }
+            J.qtab_abs = sh.abs;
+        }
+        return rc;
     });
 }
 
@@ -2918,6 +2973,7 @@ int so_matcher_batch_begin(so_matcher* m) {
     m->stat[0] = m->stat[1] = m->stat[2] = m->stat[3] = 0.0;
     m->batching = true;
     m->mp_share.n = -1;
+    m->tri_share.n = -1;
     m->jobs.clear();
     m->hb_used = m->dq_used = m->out_used = 0;
     return SO_OK;
@@ -2929,6 +2985,7 @@ void batch_close(so_matcher* m) {
     m->jobs.clear();
     m->hb_used = m->dq_used = m->out_used = 0;
     m->mp_share.n = -1;
+    m->tri_share.n = -1;
     m->src = nullptr;
     m->resident_n = -1;
     m->dirty_from = 0;

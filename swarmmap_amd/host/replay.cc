@@ -772,6 +772,22 @@ int so_replay_cl_keyframes(so_replay* r, int32_t* kf_t, float* poses12, int cap)
     }
     return n;
 }
+// after so_replay_drain: keyframe `kf`'s keypoint -> map slot bindings as local mapping left them (mvpMapPoints after
+// ProcessNewKeyFrame / CreateNewMapPoints / SearchInNeighbors / local BA's EraseMapPointMatch); returns the keypoint count
+int so_replay_cl_bindings(so_replay* r, int kf, int32_t* mp, int cap) {
+    if (!r || !r->cl || kf < 0 || kf >= (int)r->cl->kfs.size()) return SO_ERR_INVALID_ARG;
+    const KfSnap& k = *r->cl->kfs[(size_t)kf];
+    if (mp) memcpy(mp, k.mp.data(), 4 * (size_t)std::min(k.n, cap));
+    return k.n;
+}
+// ... and the map's bad flags + replaced-by slots (mbBad, mpReplaced); returns the number of slots
+int so_replay_cl_points(so_replay* r, uint8_t* bad, int32_t* replaced_by, int cap) {
+    if (!r || !r->cl) return SO_ERR_INVALID_ARG;
+    const int n = (int)r->cl->bad.size();
+    if (bad) memcpy(bad, r->cl->bad.data(), (size_t)std::min(n, cap));
+    if (replaced_by) memcpy(replaced_by, r->cl->repl.data(), 4 * (size_t)std::min(n, cap));
+    return n;
+}
 int so_replay_cl_frames(so_replay* r, int32_t* ref_kf, double* Tcr16, int cap) {
     if (!r || !r->cl) return SO_ERR_INVALID_ARG;
     const int n = (int)r->cl->ref_log.size();

@@ -153,7 +153,19 @@ class Replay:
             Tw = Tc @ t44(kf_T[rk])
             fin.append(-Tw[:3, :3].T @ Tw[:3, 3])
         kfc = [-t44(p)[:3, :3].T @ t44(p)[:3, 3] for p in kf_T]
+        lib.so_replay_cl_bindings.argtypes = [vp, i32, vp, i32]
+        lib.so_replay_cl_points.argtypes = [vp, vp, vp, i32]
+        binds = []
+        for k in range(nk):
+            m = lib.so_replay_cl_bindings(self.h, k, None, 0)
+            a = np.full(max(m, 1), -1, np.int32)
+            lib.so_replay_cl_bindings(self.h, k, self._p(a), m)
+            binds.append(a[:m])
+        npnt = lib.so_replay_cl_points(self.h, None, None, 0)
+        bad, repl = np.zeros(max(npnt, 1), np.uint8), np.zeros(max(npnt, 1), np.int32)
+        lib.so_replay_cl_points(self.h, self._p(bad), self._p(repl), npnt)
         return dict(lm_log=lm[:n], kf_t=kf_t, kf_poses=kf_T, ref_kf=ref, Tcr=Tcr, final_centres=np.array(fin).reshape(-1, 3),
+                    kf_bindings=binds, point_bad=bad[:npnt], point_replaced_by=repl[:npnt],
                     kf_centres=np.array(kfc).reshape(-1, 3),
                     counts=dict(zip(("jobs", "windows", "windows_aborted", "interrupt_ba", "map_slots", "bad_points", "keyframes"),
                                     counts[:7].tolist())), wait_ms=wait.value)

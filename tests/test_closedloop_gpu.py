@@ -104,6 +104,20 @@ def test_cpp_closed_loop_in_the_bench_configuration_matches_the_oracle_chain(nam
         assert np.abs(a[k].astype(int) - b[k].astype(int)).max() <= 5, (k, a[k], b[k])
     assert np.abs(a["n_map_points"].astype(int) - b["n_map_points"].astype(int)).max() <= 8
     assert a["inliers"][1:].min() > 300
+    # the maps themselves: every keyframe's keypoint -> map point bindings as local mapping left them (tracked bindings,
+    # triangulated points, Fuse's AddObservation / Replace, local BA's erased observations) and the points' bad / replaced
+    # state - slot by slot (a decision that flips on the last bits of a pose would show up here first; none does on these
+    # streams, and the bound leaves room for one)
+    M = b["map"]
+    assert len(a["kf_bindings"]) == len(M.kfs)
+    n_bind = n_diff = 0
+    for ka, kb in zip(a["kf_bindings"], M.kfs):
+        assert len(ka) == len(kb["mp"])
+        n_bind += int((kb["mp"] >= 0).sum())
+        n_diff += int((ka != kb["mp"]).sum())
+    assert n_bind > 5000 and n_diff <= n_bind // 500, (n_diff, n_bind)
+    m = min(len(a["point_bad"]), len(M.bad))
+    assert abs(len(a["point_bad"]) - len(M.bad)) <= 8 and int((a["point_bad"][:m] != M.bad[:m]).sum()) <= 8
     gt = minitrack.ground_truth(st, n, K, PLANE_Z)
     px = PLANE_Z / float(K[0])
     # online (poses as they were tracked; the first windows have only keyframe 0 fixed - KeyFrame::isFirst() - and shift the

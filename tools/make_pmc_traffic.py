@@ -12,15 +12,25 @@ import sys
 KEEP = ("fast_score_kernel", "fast_low_kernel", "describe_qt_kernel", "resize_kernel", "topk_window_kernel",
         "stage_in_kernel", "pose_opt_lds_kernel", "pose_opt_reg_kernel", "ba_solve_la_kernel", "ba_solve_mfma_kernel",
         "ba_schur_gather_kernel", "ba_build_kernel", "ba_update_kernel", "quadtree_kernel", "frame_prepare_kernel", "ingest_kernel", "ingest16_kernel",
-        "project_queries_batch_kernel", "hamming_top2_kernel")
+        "project_queries_batch_kernel", "hamming_top2_kernel", "triangulate_kernel", "normal_depth_kernel", "ba_mark_outliers_kernel",
+        "ba_errors_kernel", "map_scatter_rows_kernel")
 
 
 def load(path):
-    out = {}
+    """by kernel name; template instances also under their own name ("topk_window_kernel<4>": the batched search is not the
+    tracking searches), the bare name holding the dispatch-weighted mean over the instances"""
+    out, acc = {}, {}
     for r in csv.DictReader(open(path)):
-        m = re.search(r"so::(\w+)", r["kernel"])
+        m = re.search(r"so::(\w+)(<[\w, ]+>)?", r["kernel"])
         if m and m.group(1) in KEEP:
-            out[m.group(1)] = (float(r["mean_per_dispatch"]), int(r["dispatches"]))
+            mean, n = float(r["mean_per_dispatch"]), int(r["dispatches"])
+            if m.group(2):
+                out[m.group(1) + m.group(2)] = (mean, n)
+            t = acc.setdefault(m.group(1), [0.0, 0])
+            t[0] += mean * n
+            t[1] += n
+    for k, (tot, n) in acc.items():
+        out[k] = (tot / max(n, 1), n)
     return out
 
 
@@ -29,8 +39,8 @@ res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (one coun
                  "`bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-configs` on MI355X (tools/profile_round.sh); "
                  "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH_SIZE x2 per the calibration in "
                  "profiles/r1_pmc/cal_FETCH_SIZE_summary.csv"}
-for k in KEEP:
-    if k in fetch and k in write:
+for k in sorted(set(fetch) & set(write)):
+    if True:
         f, w = fetch[k][0], write[k][0]
         res[k] = {"fetch_kb_per_launch": round(f, 1), "write_kb_per_launch": round(w, 1),
                   "hbm_bytes_per_launch": int((2 * f + w) * 1024), "dispatches": fetch[k][1]}
