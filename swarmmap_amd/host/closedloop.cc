@@ -221,6 +221,32 @@ bool local_window(so_replay* r, ClosedLoop& M, const KfSnap& c, Window& W) {
 
 }  // namespace
 
+// KeyFrame::ComputeBoW stand-in (node = nearest of the vocabulary's centroid descriptors, lowest index on ties) and the
+// keyframe's upload into HBM (so_kframe_create: both candidate layouts), on whichever thread's matcher handle `m` is
+int cl_keyframe_featvec_upload(so_replay* r, so_matcher* m, KfSnap& c) {
+    const int n = c.n, nv = (int)(r->vocab.size() / 32);
+    std::vector<int32_t> node((size_t)n), bd((size_t)n), sd((size_t)n);
+    if (n > 0 && so_hamming_top2(m, c.desc.data(), n, r->vocab.data(), nv, node.data(), bd.data(), sd.data()) != SO_OK) return SO_ERR_HIP;
+    std::vector<int32_t> count((size_t)nv + 1, 0);
+    for (int i = 0; i < n; i++) count[(size_t)node[(size_t)i] + 1]++;
+    for (int v = 0; v < nv; v++) count[(size_t)v + 1] += count[(size_t)v];
+    std::vector<int32_t> pos(count.begin(), count.end() - 1), by_node((size_t)n);
+    for (int i = 0; i < n; i++) by_node[(size_t)pos[(size_t)node[(size_t)i]]++] = i;
+    c.node_id.clear(); c.idx.clear();
+    c.off.assign(1, 0);
+    for (int v = 0; v < nv; v++)
+        if (count[(size_t)v + 1] > count[(size_t)v]) {
+            c.node_id.push_back(v);
+            for (int a = count[(size_t)v]; a < count[(size_t)v + 1]; a++) c.idx.push_back(by_node[(size_t)a]);
+            c.off.push_back((int32_t)c.idx.size());
+        }
+    const so_featvec fv{(int32_t)c.node_id.size(), c.node_id.data(), c.off.data(), c.idx.data()};
+    float level_sigma2[8];
+    for (int l = 0; l < 8; l++) level_sigma2[l] = r->scale[l] * r->scale[l];
+    const so_frame_view V = keyframe_view(r, c);
+    return so_kframe_create(m, &V, &fv, level_sigma2, &c.dev) == SO_OK ? SO_OK : SO_ERR_HIP;
+}
+
 // One keyframe through local mapping (closedloop.lm_job).  Local-mapping thread.
 int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_info* info_out) {
     ClosedLoop& M = *r->cl;
@@ -263,30 +289,13 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
         M.recent.swap(keep);
     }
     st[24] = now_ms() - t0;  // process + culling
-    // ---- KeyFrame::ComputeBoW stand-in: node = nearest centroid descriptor (lowest index on ties); upload the keyframe
+    // ---- KeyFrame::ComputeBoW stand-in + upload of the keyframe: done by the tracking thread when it made the keyframe (under
+    //      its last PoseOptimization kernel, where it only waits); here only for a keyframe that came without
     const double tn0 = now_ms();
-    const int nv = (int)(r->vocab.size() / 32);
-    {
-        std::vector<int32_t> node((size_t)n), bd((size_t)n), sd((size_t)n);
-        if (n > 0 && so_hamming_top2(m, c->desc.data(), n, r->vocab.data(), nv, node.data(), bd.data(), sd.data()) != SO_OK) return SO_ERR_HIP;
-        std::vector<int32_t> count((size_t)nv + 1, 0);
-        for (int i = 0; i < n; i++) count[(size_t)node[(size_t)i] + 1]++;
-        for (int v = 0; v < nv; v++) count[(size_t)v + 1] += count[(size_t)v];
-        std::vector<int32_t> pos(count.begin(), count.end() - 1), by_node((size_t)n);
-        for (int i = 0; i < n; i++) by_node[(size_t)pos[(size_t)node[(size_t)i]]++] = i;
-        c->off.assign(1, 0);
-        for (int v = 0; v < nv; v++)
-            if (count[(size_t)v + 1] > count[(size_t)v]) {
-                c->node_id.push_back(v);
-                for (int a = count[(size_t)v]; a < count[(size_t)v + 1]; a++) c->idx.push_back(by_node[(size_t)a]);
-                c->off.push_back((int32_t)c->idx.size());
-            }
-    }
+    if (!c->dev && cl_keyframe_featvec_upload(r, m, *c) != SO_OK) return SO_ERR_HIP;
     const so_featvec fv1{(int32_t)c->node_id.size(), c->node_id.data(), c->off.data(), c->idx.data()};
     float level_sigma2[8];
     for (int l = 0; l < 8; l++) level_sigma2[l] = r->scale[l] * r->scale[l];
-    const so_frame_view Vc = keyframe_view(r, *c);
-    if (so_kframe_create(m, &Vc, &fv1, level_sigma2, &c->dev) != SO_OK) return SO_ERR_HIP;
     st[kLmNodeMs] = now_ms() - tn0;
     const int r0 = std::max(0, k - r->lm_neighbours);
     const int nn = k - r0;
@@ -526,7 +535,7 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
             so_ba_options opt;
             so_ba_options_local(&opt);
             r->ba_Tcw.resize(W.Tcw.size()); r->ba_Xw.resize(W.Xw.size()); r->ba_out.resize(W.e_kf.size());
-            so_bundle_adjust_set_solve_timing(r->mapper_opt, (r->lba_windows_run++ % 4) == 0);
+            so_bundle_adjust_set_solve_timing(r->mapper_opt, (r->lba_windows_run++ % 8) == 0);  // (event-timed solves take the stage-by-stage path: one window in eight)
             M.stop = 0;  // mbAbortBA = false (LocalMapping.cc:77)
             const double tb0 = now_ms();
             if (so_bundle_adjust(r->mapper_opt, &p, &opt, &M.stop, r->ba_Tcw.data(), r->ba_Xw.data(), r->ba_out.data(), nullptr, &info) != SO_OK)
@@ -723,17 +732,21 @@ int cl_frame_begin(so_replay* r, int t) {
     return SO_OK;
 }
 
-// Tracking thread, end of a frame: a keyframe goes to local mapping; the frame's pose relative to its reference keyframe
-void cl_frame_end(so_replay* r, int t, bool keyframe, const std::shared_ptr<KfSnap>& snap) {
+// Tracking thread: a keyframe has been handed to local mapping (it is the reference keyframe from now on) ...
+void cl_keyframe_queued(so_replay* r, int t, const std::shared_ptr<KfSnap>& snap) {
     ClosedLoop& M = *r->cl;
-    if (keyframe) {
-        M.T_ref = from_f12(snap->T);
-        M.job_pending = true;
-        M.apply_at = t + M.delay;
-        M.last_kf_t = t;
-        M.kf_t.push_back(t);
-        M.n_kf++;
-    }
+    M.T_ref = from_f12(snap->T);
+    M.job_pending = true;
+    M.apply_at = t + M.delay;
+    M.last_kf_t = t;
+    M.kf_t.push_back(t);
+    M.n_kf++;
+}
+
+// ... and the end of a frame: its pose relative to its reference keyframe (mlRelativeFramePoses)
+void cl_frame_end(so_replay* r, int t) {
+    ClosedLoop& M = *r->cl;
+    (void)t;
     M.Tlr = mul(r->step.T, rigid_inverse_general(M.T_ref));
     M.ref_log.push_back(M.n_kf - 1);
     M.Tcr_log.insert(M.Tcr_log.end(), M.Tlr.a, M.Tlr.a + 16);

@@ -1073,6 +1073,28 @@ void pose2_apply(so_replay* r) {
     S.tp2 = now_ms();
 }
 
+std::shared_ptr<KfSnap> snapshot_keyframe(so_replay* r, int t);
+
+// closed loop: snapshot the tracked frame and hand it to the local-mapping thread
+void queue_keyframe(so_replay* r, int t) {
+    std::shared_ptr<KfSnap> snap = snapshot_keyframe(r, t);
+    // KeyFrame::ComputeBoW + the keyframe's upload on this thread's matcher (no search of the frame is pending any more): a
+    // tenth of a millisecond the local-mapping thread, which bounds the loop, does not spend
+    static const bool lm_does_it = getenv("SWARMORB_CL_FEATVEC_ON_LM") != nullptr;
+    if (!lm_does_it && r->step.kf_under_pose && cl_keyframe_featvec_upload(r, r->matcher, *snap) != SO_OK)
+        r->error = std::string("keyframe feature vector / upload: ") + so_last_error();
+    LmJob job;
+    job.timed = r->step_timed;
+    job.kf = snap;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->queue.push_back(job);
+    }
+    r->cv.notify_all();
+    cl_keyframe_queued(r, t, snap);
+    r->step.kf_queued = true;
+}
+
 // "keyframe": unmatched keypoints become map points; then the motion model
 int step_keyframe(so_replay* r) {
     so_replay::Step& S = r->step;
@@ -1105,6 +1127,10 @@ int step_keyframe(so_replay* r) {
         if (need) {
             r->kf_inliers = S.n_in > 1 ? S.n_in : 1;
             S.keyframe = 1;
+            S.kf_under_pose = true;
+            // the keyframe goes to local mapping NOW - this runs under the frame's last PoseOptimization kernel, whose
+            // result nothing uses - not at the end of the step: its job starts ~80 us earlier
+            queue_keyframe(r, t);
         }
         r->velocity = mul(S.T, rigid_inverse_general(r->T_last));
         S.tmap = now_ms();
@@ -1206,19 +1232,8 @@ void step_end(so_replay* r, int t, int timed) {
     const double t3 = now_ms();
     r->frame_ms.push_back((float)(t3 - S.t0));
     if (r->cl) {
-        std::shared_ptr<KfSnap> snap;
-        if (S.keyframe) {
-            snap = snapshot_keyframe(r, t);
-            LmJob job;
-            job.timed = timed ? 1 : 0;
-            job.kf = snap;
-            {
-                std::lock_guard<std::mutex> lk(r->mu);
-                r->queue.push_back(job);
-            }
-            r->cv.notify_all();
-        }
-        cl_frame_end(r, t, S.keyframe != 0, snap);
+        if (S.keyframe && !S.kf_queued) queue_keyframe(r, t);  // (the run's first frame: keyframe 0)
+        cl_frame_end(r, t);
     } else if (t % r->lba_every == 0 && !r->window.epose.empty()) {
         LmJob job;
         job.timed = timed ? 1 : 0;
@@ -1252,6 +1267,7 @@ void step_end(so_replay* r, int t, int timed) {
 extern "C" {
 
 static int run_one_step(so_replay* r, int t, int timed) {
+    r->step_timed = timed ? 1 : 0;
     {
         so_replay::Step& S = r->step;
         int rc;

@@ -251,6 +251,8 @@ struct so_replay {
         int32_t n_in = 0;
         int map_size_at_begin = 0;
         int t = 0;  // the frame's index
+        bool kf_under_pose = false;  // the keyframe is made on the tracking thread while a PoseOptimization kernel runs
+        bool kf_queued = false;  // closed loop: the frame went to local mapping as a keyframe already (under its last PoseOptimization)
         bool first = false, m2_submitted = false, timed_kernels = true, next_submitted = false;
         int m2_rc = 0;
         float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
@@ -264,12 +266,15 @@ struct so_replay {
     std::vector<float> ba_Tcw, ba_Xw;
     std::vector<uint8_t> ba_out;
     std::unique_ptr<ClosedLoop> cl;  // non-null: the closed loop (so_replay_set_closed_loop)
+    int step_timed = 0;              // the frame being tracked counts for the statistics
 };
 
 // closedloop.cc
 int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_info* info);  // local-mapping thread
 int cl_frame_begin(so_replay* r, int t);  // tracking thread, before the frame's first search: applies what local mapping handed back
-void cl_frame_end(so_replay* r, int t, bool keyframe, const std::shared_ptr<KfSnap>& snap);
+void cl_keyframe_queued(so_replay* r, int t, const std::shared_ptr<KfSnap>& snap);
+int cl_keyframe_featvec_upload(so_replay* r, so_matcher* m, KfSnap& c);
+void cl_frame_end(so_replay* r, int t);
 
 enum {  // indices of so_replay::stat, mirrored in bench.py
     kSteps = 0, kExtractMs, kM2Ms, kPose1Ms, kM1Ms, kPose2Ms, kPose3Ms, kMapMs, kSubmitWaitMs, kKp, kM2, kM1, kInliers,
