@@ -721,7 +721,7 @@ def gba_records(dev, cases):
                                "structural_flop": sflop, "dense_flop": flop, "achieved_tflops": atf,
                                "skyline_tiles_tflops": stf, "dense_equivalent_tflops": tf, "peak_tflops": FP64_PEAK_TF,
                                "frac": atf / FP64_PEAK_TF, "bound": "mfma",
-                               "evidence": "profiles/r3_gba_kernel_stats.csv, profiles/r3_gba_pmc_mfma.json (rocprofv3 "
+                               "evidence": "profiles/r5_gba_kernel_stats.csv, profiles/r5_gba_pmc_mfma.json (rocprofv3 "
                                            "--kernel-trace --stats and separate --pmc passes of tools/gba_bench.py)",
                                "note": "achieved = min(flop over the nonzero 96x96 tiles of the block skyline, n^3/3 + 2 n^2 "
                                        "of the un-padded system) / solve time (HIP events around the solve kernel)"}}

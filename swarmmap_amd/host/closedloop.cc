@@ -154,10 +154,26 @@ bool local_window(so_replay* r, ClosedLoop& M, const KfSnap& c, Window& W) {
         }
     }
     std::sort(pts.begin(), pts.end());
+    // ONE walk over the points' observation lists (a heap block per point: the cache misses of this function) into flat
+    // arrays, counting the observers outside the local set on the way; everything after reads the flat arrays in order
+    static thread_local std::vector<int32_t> t_kf, t_idx, t_first;
+    size_t cap = 0;
+    for (int s : pts) cap += M.obs[(size_t)s].size();
+    t_kf.resize(cap); t_idx.resize(cap); t_first.resize(pts.size() + 1);
     std::vector<int32_t> count((size_t)nkf, 0);
-    for (int s : pts)
-        for (const auto& o : M.obs[(size_t)s])
-            if (!is_local[(size_t)o.first]) count[(size_t)o.first]++;
+    {
+        size_t at = 0;
+        for (size_t q = 0; q < pts.size(); q++) {
+            t_first[q] = (int32_t)at;
+            for (const auto& o : M.obs[(size_t)pts[q]]) {
+                t_kf[at] = o.first;
+                t_idx[at] = o.second;
+                at++;
+                if (!is_local[(size_t)o.first]) count[(size_t)o.first]++;
+            }
+        }
+        t_first[pts.size()] = (int32_t)at;
+    }
     std::vector<int32_t> fx;
     for (int kf = 0; kf < nkf; kf++)
         if (count[(size_t)kf] > 0) fx.push_back(kf);
@@ -168,8 +184,8 @@ bool local_window(so_replay* r, ClosedLoop& M, const KfSnap& c, Window& W) {
     std::sort(W.kf.begin(), W.kf.end());
     std::vector<int32_t> row((size_t)nkf, -1);
     for (size_t p = 0; p < W.kf.size(); p++) row[(size_t)W.kf[p]] = (int32_t)p;
-    // one walk over the points' observations: the edges of a point are written as they are found (keypoint coordinates and
-    // weights straight from the keyframes' arrays) and taken back if there are fewer than two
+    // the edges of a point are written as they are found (keypoint coordinates and weights straight from the keyframes'
+    // arrays) and taken back if there are fewer than two
     W.fixed.resize(W.kf.size());
     for (size_t p = 0; p < W.kf.size(); p++) W.fixed[p] = (is_local[(size_t)W.kf[p]] && W.kf[p] != 0) ? 0 : 1;
     std::vector<const float*> kx((size_t)nkf, nullptr), ky((size_t)nkf, nullptr);
@@ -178,25 +194,24 @@ bool local_window(so_replay* r, ClosedLoop& M, const KfSnap& c, Window& W) {
         const KfSnap& q = *M.kfs[(size_t)kf];
         kx[(size_t)kf] = q.x.data(); ky[(size_t)kf] = q.y.data(); ko[(size_t)kf] = q.octave.data();
     }
-    size_t cap = 0;
-    for (int s : pts) cap += M.obs[(size_t)s].size();
     W.pts.clear();
     W.e_kf.resize(cap); W.e_idx.resize(cap); W.e_pt.resize(cap); W.e_pose.resize(cap); W.obs.resize(2 * cap); W.w.resize(cap);
     size_t ne = 0;
     bool any_free = false;
-    for (int s : pts) {
+    for (size_t q = 0; q < pts.size(); q++) {
         const size_t e0 = ne;
         bool fr = false;
-        for (const auto& o : M.obs[(size_t)s]) {
-            const int p = row[(size_t)o.first];
+        for (int32_t a = t_first[q]; a < t_first[q + 1]; a++) {
+            const int kf = t_kf[(size_t)a], idx = t_idx[(size_t)a];
+            const int p = row[(size_t)kf];
             if (p < 0) continue;
-            W.e_kf[ne] = o.first;
-            W.e_idx[ne] = o.second;
+            W.e_kf[ne] = kf;
+            W.e_idx[ne] = idx;
             W.e_pt[ne] = (int32_t)W.pts.size();
             W.e_pose[ne] = p;
-            W.obs[2 * ne] = kx[(size_t)o.first][o.second];
-            W.obs[2 * ne + 1] = ky[(size_t)o.first][o.second];
-            W.w[ne] = r->inv_sigma2[ko[(size_t)o.first][o.second]];
+            W.obs[2 * ne] = kx[(size_t)kf][idx];
+            W.obs[2 * ne + 1] = ky[(size_t)kf][idx];
+            W.w[ne] = r->inv_sigma2[ko[(size_t)kf][idx]];
             fr = fr || W.fixed[(size_t)p] == 0;
             ne++;
         }
@@ -205,7 +220,7 @@ bool local_window(so_replay* r, ClosedLoop& M, const KfSnap& c, Window& W) {
             continue;
         }
         any_free = any_free || fr;
-        W.pts.push_back(s);
+        W.pts.push_back(pts[q]);
     }
     W.e_kf.resize(ne); W.e_idx.resize(ne); W.e_pt.resize(ne); W.e_pose.resize(ne); W.obs.resize(2 * ne); W.w.resize(ne);
     if (W.pts.size() < 10 || !any_free) return false;
@@ -657,6 +672,12 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
             }
         }
         std::sort(pk.local_slots.begin(), pk.local_slots.end());
+    }
+    // the keyframe that leaves the neighbour ring with this job is never searched again: its HBM block goes back to the pool
+    // (the next keyframe's upload takes it instead of a hipMalloc)
+    if (k >= r->lm_neighbours && M.kfs[(size_t)r0]->dev) {  // (the next job's ring starts at r0 + 1)
+        so_kframe_destroy(M.kfs[(size_t)r0]->dev);
+        M.kfs[(size_t)r0]->dev = nullptr;
     }
     const int64_t row[12] = {c->t, nn, n_tri, n_new, n_fused, n_back, lba[0], lba[1], lba[2], lba[3], lba[4], (int64_t)pk.bad.size()};
     st[35] = now_ms() - tp0;  // the packet
