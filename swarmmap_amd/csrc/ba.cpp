@@ -1137,7 +1137,8 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
             // iterations (levenberg.cpp:154-161); every trial enqueued beyond that is six launches that return at once, ~15 us
             // of queue time each.  Enqueue what the context's last call needed plus two; a stage that wants more is
             // topped up by the loop below (one host round trip).
-            trials(d2, std::min(opt->its_stage2, b->stage2_hint > 0 ? b->stage2_hint : opt->its_stage2));
+            static const bool no_hint = getenv("SWARMORB_BA_NO_STAGE2_HINT") != nullptr;  // A/B: all iterations ahead, as before round 5
+            trials(d2, no_hint ? opt->its_stage2 : std::min(opt->its_stage2, b->stage2_hint > 0 ? b->stage2_hint : opt->its_stage2));
         };
         launch_ba_errors(r.d, 0, kBaGateNone, r.nb_err, s);
         launch_ba_build(r.d, kBaGateNone, s);
