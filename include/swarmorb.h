@@ -417,6 +417,26 @@ int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x
                                        const uint8_t* free2, const float* F12, float ex, float ey, int check_orientation,
                                        int32_t* matches12, int32_t* nmatches);
 
+/* CreateNewMapPoints' searches of ONE new keyframe against its neighbours (code/src/LocalMapping.cc:197-246: up to twenty
+ * SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, ...) calls) with BOTH sides resident: kf1 was created with its feature
+ * vector like the neighbours, and the queries - which of its features have no map point, the vocabulary node each one
+ * searches, its epipolar line in the neighbour's image - are built on the device by the batch's first launch; per neighbour
+ * ~6 KB go up instead of ~40 KB of query records.  free1[i] = !kf1->GetMapPoint(i) for all of them (the caller applies what
+ * changes between neighbours when it walks the results in order); per neighbour: the keyframe, free2 as
+ * in so_search_for_triangulation_kframe, F12 (row-major 3 x 3), the epipole, the outputs.  Results identical to n_neighbours
+ * calls of so_search_for_triangulation_kframe with the same arguments.  Batchable (inside so_matcher_batch_begin / _end the
+ * outputs are complete after _end); outside a batch it is one. */
+typedef struct so_tri_neighbour {
+    const so_kframe* kf2;
+    const uint8_t* free2;
+    float F12[9];
+    float ex, ey;
+    int32_t* matches12; /* kf1->n entries */
+    int32_t* nmatches;
+} so_tri_neighbour;
+int so_search_for_triangulation_kframes(so_matcher* m, const so_kframe* kf1, const uint8_t* free1, int32_t n_neighbours,
+                                        const so_tri_neighbour* neighbours, int check_orientation);
+
 /* ---- the local-mapping thread's two per-point loops between the matcher and local BA (widening beyond SURVEY 8f) ----
  * What LocalMapping::CreateNewMapPoints reads of a keyframe. */
 typedef struct so_tri_keyframe {

@@ -32,7 +32,10 @@ Monocular bookkeeping, as SwarmMap runs it:
 Deviations of the harness from the reference, on purpose (the operators themselves are exact, call by call): a
 keyframe's searches see the map as it is when their batch is issued - the SearchForTriangulation calls the state after
 ProcessNewKeyFrame, the Fuse calls the state after CreateNewMapPoints - and their results are applied in the
-reference's order against the live state (the reference interleaves search and apply per neighbour); descriptors of map
+reference's order against the live state (the reference interleaves search and apply per neighbour; since its
+SearchForTriangulation never sets vbMatched2, ORBmatcher.cc:660-700, a feature's match does not depend on the others', and
+the only thing the interleaving changes for CreateNewMapPoints is which features enter a neighbour's rotation histogram);
+descriptors of map
 points stay the creating keypoint's (ComputeDistinctiveDescriptors exists as an operator, so_distinctive_descriptors, but
 is not part of this loop); the local map Tracking searches is the points of the last `local_keyframes` keyframes, listed
 by local mapping when it finishes a keyframe; a frame's reference keyframe is the last keyframe created.

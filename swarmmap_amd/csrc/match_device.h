@@ -144,7 +144,16 @@ struct BatchJobDev {
     const int32_t* qslot;
     uint32_t* keys;          // nq x K, host-mapped
     int32_t* count;          // nq, host-mapped
-    int nq, K, project, pad;
+    int nq, K, project, pad;  // project: 0 queries staged, 1 projected map points (S), 2 SearchForTriangulation queries (t_*)
+    // project == 2: the queries of SearchForTriangulation(kf1, kf2) are generated on the device from the RESIDENT keyframe 1:
+    // query p = position p of its vocabulary-node order (its descriptor: row p of qdesc = keyframe 1's resident table)
+    const float2* t_xy1;      // keyframe 1's mvKeysUn in that order (resident)
+    const uint8_t* t_free1;   // by position: no map point yet (staged)
+    const uint16_t* t_node;   // by position: which node of keyframe 1's node list (staged)
+    const int2* t_range;      // per node of keyframe 1: its candidates [begin, end) in keyframe 2's node order, begin = end if
+                              // keyframe 2 has no feature in that node (staged)
+    float t_F[9];             // F12
+    int t_pad;
 };
 // Grid layout of a batch: the jobs' workgroups back to back (a job with 4000 queries next to one with 700 must not make
 // every job launch 1000 workgroups): first_proj / first_topk[j] = first workgroup of job j, [n_jobs] = the grid size.

@@ -445,6 +445,35 @@ __global__ __launch_bounds__(256) void project_queries_batch_kernel(const BatchG
     }
     const BatchJobDev& J = jobs[lo];
     const int i = (blk - G->first_proj[lo]) * 256 + threadIdx.x;
+    if (J.project == 2) {
+        // SearchForTriangulation's query of keyframe 1's feature at position i (code/src/ORBmatcher.cc:636-660): only features
+        // without a map point, only against keyframe 2's features of the same vocabulary node; the epipolar line of the
+        // keypoint in image 2 with the float expressions of CheckDistEpipolarLine (:131-137)
+        if (i >= J.nq) return;
+        MatchQuery q;
+        q.u = q.v = q.r = 0.f;
+        q.min_level = q.max_level = 0;
+        q.active = 0;
+        q.c_begin = q.c_end = 0;
+        q.flags = 0;
+        q.max_dist = 256;
+        q.la = q.lb = q.lc = 0.f;
+        q.pad = 0;
+        const int2 cr = J.t_range[J.t_node[i]];
+        if (J.t_free1[i] && cr.y > cr.x) {
+            const float2 p = J.t_xy1[i];
+            q.active = 1;
+            q.flags = kQRange | kQEpipolar | kQPreferLast;
+            q.max_dist = 50;  // TH_LOW
+            q.c_begin = cr.x;
+            q.c_end = cr.y;
+            q.la = p.x * J.t_F[0] + p.y * J.t_F[3] + J.t_F[6];
+            q.lb = p.x * J.t_F[1] + p.y * J.t_F[4] + J.t_F[7];
+            q.lc = p.x * J.t_F[2] + p.y * J.t_F[5] + J.t_F[8];
+        }
+        J.q[i] = q;
+        return;
+    }
     if (!J.project || i >= J.S.n) return;
     project_one(J.S, i, J.q, J.qw);
 }

@@ -211,6 +211,10 @@ struct so_matcher {
         std::vector<int> perm;
         const so_kframe* ext = nullptr;  // candidates read from an HBM-resident keyframe instead of the staged block
         int ext_layout = 0;              // 0: grid order, 1: vocabulary-node order
+        // project == 2 in the device table: SearchForTriangulation queries generated on the device from resident keyframe 1
+        const so_kframe* tri_kf1 = nullptr;
+        size_t off_tfree1 = 0, off_tnode = 0, off_trange = 0;  // inside the job's block
+        float tri_F[9] = {0};
         // query descriptors by index: row qidx[i] of a descriptor table staged ONCE per batch (a keyframe's twenty
         // SearchForTriangulation calls query with subsets of the same keypoints' descriptors)
         bool q_indexed = false;
@@ -674,6 +678,17 @@ int batch_flush(so_matcher* m) {
             D.S.n = J.nq;
             D.q = (MatchQuery*)((uint8_t*)m->db_q.p + J.q_off);
             D.qw = (MatchQueryW*)((uint8_t*)m->hb_out.dev + J.qw_off);
+        } else if (J.tri_kf1) {
+            const so_kframe* k1 = J.tri_kf1;
+            D.project = 2;
+            D.q = (MatchQuery*)((uint8_t*)m->db_q.p + J.q_off);
+            D.qdesc = (const uint4*)(k1->d + k1->n_desc);  // query p's descriptor = row p of keyframe 1's node-ordered table
+            D.qslot = nullptr;
+            D.t_xy1 = (const float2*)(k1->d + k1->n_xy);
+            D.t_free1 = b + J.off_tfree1;
+            D.t_node = (const uint16_t*)(b + J.off_tnode);
+            D.t_range = (const int2*)(b + J.off_trange);
+            memcpy(D.t_F, J.tri_F, sizeof(D.t_F));
         } else {
             D.q = (MatchQuery*)(dbase + J.base + J.off_q);
             if (J.q_indexed) {
@@ -683,7 +698,7 @@ int batch_flush(so_matcher* m) {
         }
         grid->first_proj[j] = proj_blocks;
         grid->first_topk[j] = topk_blocks;
-        if (J.project) proj_blocks += (J.nq + 255) / 256;
+        if (J.project || J.tri_kf1) proj_blocks += (J.nq + 255) / 256;
         topk_blocks += (J.nq + 3) / 4;
         tab[j] = D;
     }
@@ -2700,6 +2715,123 @@ int so_search_for_triangulation_kframe(so_matcher* m, int32_t n1, const float* x
             J.qtab_abs = sh.abs;
         }
         return rc;
+    });
+}
+
+// SearchForTriangulation of ONE resident keyframe against several resident neighbours with the queries built on the device
+// (so_search_for_triangulation_kframes): per neighbour the host stages keyframe 2's gate, keyframe 1's free flags / node
+// index by position and the node join (~6 KB instead of ~40 KB of query records), the projection launch of the batch
+// writes the MatchQuery records into HBM, the search launch reads keyframe 1's descriptors where they are resident.
+int so_search_for_triangulation_kframes(so_matcher* m, const so_kframe* kf1, const uint8_t* free1, int32_t n_neighbours,
+                                        const so_tri_neighbour* nb, int check_orientation) {
+    if (!m || !kf1 || !kf1->has_nodes || n_neighbours < 0 || (n_neighbours > 0 && !nb) || (kf1->n > 0 && !free1)) return SO_ERR_INVALID_ARG;
+    if (kf1->device != m->device) {
+        last_error_ref() = "resident keyframe lives on another device";
+        return SO_ERR_INVALID_ARG;
+    }
+    if (check_orientation && kf1->n > 0 && kf1->angle.empty()) return SO_ERR_INVALID_ARG;
+    for (int j = 0; j < n_neighbours; j++) {
+        const so_tri_neighbour& N = nb[j];
+        if (!N.kf2 || !N.kf2->has_nodes || N.kf2->device != m->device || !N.matches12 || !N.nmatches || (N.kf2->n > 0 && !N.free2)) return SO_ERR_INVALID_ARG;
+        if (check_orientation && N.kf2->n > 0 && N.kf2->angle.empty()) return SO_ERR_INVALID_ARG;
+    }
+    SO_HIP(hipSetDevice(m->device));
+    (void)take_reuse(m);
+    const int n1p = kf1->n_node, nn1 = (int)kf1->node_id.size();
+    if (n1p > 65535 || nn1 > 65535) return SO_ERR_CAPACITY;
+    // keyframe 1 by position of its node order: free flag and node index (the same for every neighbour)
+    std::vector<uint8_t> free1p((size_t)std::max(n1p, 1));
+    std::vector<uint16_t> node_of((size_t)std::max(n1p, 1));
+    for (int a = 0; a < nn1; a++)
+        for (int p = kf1->node_off[(size_t)a]; p < kf1->node_off[(size_t)a + 1]; p++) node_of[(size_t)p] = (uint16_t)a;
+    for (int p = 0; p < n1p; p++) free1p[(size_t)p] = free1[kf1->perm_node[(size_t)p]] ? 1 : 0;
+    return as_batch(m, [&]() -> int {
+        int rc;
+        for (int j = 0; j < n_neighbours; j++) {
+            const so_tri_neighbour& N = nb[j];
+            const so_kframe* kf2 = N.kf2;
+            *N.nmatches = 0;
+            for (int i = 0; i < kf1->n; i++) N.matches12[i] = -1;
+            if (n1p == 0 || kf2->n_node == 0) continue;
+            adopt_kframe(m, kf2, 1);
+            for (int l = 0; l < 8; l++) {
+                m->scale[l] = kf2->scale[l];
+                m->sigma2[l] = kf2->sigma2[l];
+            }
+            m->ex = N.ex;
+            m->ey = N.ey;
+            // staged block: [gate of keyframe 2 by position | free1 by position | node of position | range per node]
+            const int nc = kf2->n_node;
+            m->has_limit = true;
+            m->off_limit = 0;
+            m->frame_end = align256(sizeof(int32_t) * (size_t)nc);
+            const size_t o_free = m->frame_end, o_node = align256(o_free + (size_t)n1p), o_range = align256(o_node + 2 * (size_t)n1p),
+                         end = align256(o_range + 8 * (size_t)std::max(nn1, 1));
+            if ((rc = m->h_in.ensure_keep(end + 256, 0))) return rc;
+            uint8_t* hb = (uint8_t*)m->h_in.p;
+            {
+                int32_t* hl = (int32_t*)hb;
+                for (int r = 0; r < nc; r++) hl[r] = N.free2[kf2->perm_node[(size_t)r]] ? INT_MAX : 0;  // "|| pMP2" (:662)
+            }
+            memcpy(hb + o_free, free1p.data(), (size_t)n1p);
+            memcpy(hb + o_node, node_of.data(), 2 * (size_t)n1p);
+            int32_t* hr = (int32_t*)(hb + o_range);
+            bool any = false;
+            {   // merge join of the two node lists (both ascending by node id)
+                size_t b2 = 0;
+                const size_t nn2 = kf2->node_id.size();
+                for (int a = 0; a < nn1; a++) {
+                    while (b2 < nn2 && kf2->node_id[b2] < kf1->node_id[(size_t)a]) b2++;
+                    if (b2 < nn2 && kf2->node_id[b2] == kf1->node_id[(size_t)a]) {
+                        hr[2 * a] = kf2->node_off[b2];
+                        hr[2 * a + 1] = kf2->node_off[b2 + 1];
+                        any = true;
+                    } else {
+                        hr[2 * a] = hr[2 * a + 1] = 0;
+                    }
+                }
+            }
+            if (!any) continue;
+            m->off_q = m->off_qdesc = end;  // (no query records or descriptors in the block)
+            const float* angle1 = kf1->angle.data();
+            const float* angle2 = kf2->angle.data();
+            int32_t* matches12 = N.matches12;
+            int32_t* nmatches = N.nmatches;
+            auto resolve = [m, n1p, kf1, angle1, angle2, check_orientation, matches12, nmatches](
+                               const uint32_t* keys, const int32_t*, const MatchQueryW*, const std::vector<int>& perm) -> int {
+                std::vector<int>&rot_item = m->scratch_rot_item, &rot_b = m->scratch_rot_b;
+                rot_item.clear();
+                rot_b.clear();
+                int hist[HISTO_LENGTH] = {0};
+                int nm = 0;
+                for (int p = 0; p < n1p; p++) {  // (node order = the order of the reference's two nested loops)
+                    if (keys[p] == 0xFFFFFFFFu) continue;
+                    const int idx1 = kf1->perm_node[(size_t)p];
+                    const int idx2 = perm[(size_t)(0xFFFF - (keys[p] & 0xFFFFu))];
+                    matches12[idx1] = idx2;
+                    nm++;
+                    if (check_orientation) {
+                        const int b = rot_bin(angle1[idx1], angle2[idx2]);
+                        rot_item.push_back(idx1);
+                        rot_b.push_back(b);
+                        hist[b]++;
+                    }
+                }
+                if (check_orientation) apply_rot_hist(hist, rot_item, rot_b, matches12, nm);
+                *nmatches = nm;
+                return SO_OK;
+            };
+            if ((rc = batch_defer(m, end, n1p, 1, nullptr, nullptr, std::move(resolve), kf2, 1))) return rc;
+            so_matcher::BatchJob& J = m->jobs.back();
+            J.tri_kf1 = kf1;
+            J.off_tfree1 = o_free;
+            J.off_tnode = o_node;
+            J.off_trange = o_range;
+            memcpy(J.tri_F, N.F12, sizeof(J.tri_F));
+            J.q_off = m->dq_used;  // the generated records live in db_q, like a projected job's
+            m->dq_used += align256(sizeof(MatchQuery) * (size_t)n1p);
+        }
+        return SO_OK;
     });
 }
 

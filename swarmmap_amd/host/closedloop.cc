@@ -330,7 +330,8 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
         double Oc[3];
         centre(c->T, Oc);
         std::vector<double> z;
-        bool began = false;
+        // one call for all neighbours that pass the gate: both sides resident, the queries built on the device
+        std::vector<so_tri_neighbour> nbs;
         for (int j = 0; j < nn; j++) {
             KfSnap& k2 = ring(j);
             double O2[3];
@@ -338,27 +339,24 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
             const double d0 = O2[0] - Oc[0], d1 = O2[1] - Oc[1], d2 = O2[2] - Oc[2];
             const double baseline = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
             if (baseline_too_short(M, k2, baseline, z)) continue;
-            if (!began) {
-                if (so_matcher_batch_begin(m) != SO_OK) return SO_ERR_HIP;
-                began = true;
-            }
-            float F12[9], ex, ey;
-            fundamental_and_epipole(r, c->T, k2.T, F12, &ex, &ey);
+            so_tri_neighbour N;
+            memset(&N, 0, sizeof(N));
+            fundamental_and_epipole(r, c->T, k2.T, N.F12, &N.ex, &N.ey);
             free2[(size_t)j].resize((size_t)k2.n);
             for (int i = 0; i < k2.n; i++) free2[(size_t)j][(size_t)i] = k2.mp[(size_t)i] < 0 ? 1 : 0;
-            tri_m12[(size_t)j].assign((size_t)n, -1);
-            if (so_search_for_triangulation_kframe(m, n, c->x.data(), c->y.data(), c->angle.data(), c->desc.data(), free1.data(), &fv1, k2.dev,
-                                                   free2[(size_t)j].data(), F12, ex, ey, 1, tri_m12[(size_t)j].data(), &tri_nm[(size_t)j]) != SO_OK) {
-                so_matcher_batch_abort(m);
-                return SO_ERR_HIP;
-            }
+            tri_m12[(size_t)j].resize((size_t)n);
+            N.kf2 = k2.dev;
+            N.free2 = free2[(size_t)j].data();
+            N.matches12 = tri_m12[(size_t)j].data();
+            N.nmatches = &tri_nm[(size_t)j];
+            nbs.push_back(N);
             searched[(size_t)j] = 1;
             st[kLmTriCalls] += 1;
         }
-        if (began) {
+        if (!nbs.empty()) {
             const double tbe = now_ms();
-            if (so_matcher_batch_end(m) != SO_OK) return SO_ERR_HIP;
-            st[36] = now_ms() - tbe;  // launch + wait + resolve of the SearchForTriangulation batch
+            if (so_search_for_triangulation_kframes(m, c->dev, free1.data(), (int32_t)nbs.size(), nbs.data(), 1) != SO_OK) return SO_ERR_HIP;
+            st[36] = now_ms() - tbe;  // staging of all neighbours + launch + wait + resolve
             double ms4[4] = {0};
             so_matcher_last_stats(m, ms4);
             st[kLmBatchEnqueueMs] += ms4[0];

@@ -575,6 +575,37 @@ def _FuseKFrameMap(self, kframe, K, Tcw, log_scale_factor, inv_level_sigma2, dma
     return nf.value, bi, bd, q
 
 
+class SoTriNeighbour(C.Structure):
+    _fields_ = [("kf2", C.c_void_p), ("free2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float),
+                ("matches12", C.c_void_p), ("nmatches", C.c_void_p)]
+
+
+def _SearchForTriangulationKFrames(self, kframe1, free1, neighbours):
+    """so_search_for_triangulation_kframes: one resident keyframe against several resident neighbours, the queries built on
+    the device.  neighbours: list of (kframe2, free2, F12, (ex, ey)).  Returns [(nmatches, matches12)] (inside a batch:
+    ctypes ints, read .value after batch_end())."""
+    self._lib.so_search_for_triangulation_kframes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int]
+    f1 = _u8(free1)
+    arr = (SoTriNeighbour * max(len(neighbours), 1))()
+    keep, outs = [f1], []
+    for j, (k2, free2, F12, epi) in enumerate(neighbours):
+        f2, F = _u8(free2), _f32(F12).reshape(9)
+        m12, nm = np.full(len(f1), -1, np.int32), C.c_int32(0)
+        arr[j].kf2, arr[j].free2 = k2._h, _vp(f2)
+        arr[j].F12[:] = [float(v) for v in F]
+        arr[j].ex, arr[j].ey = float(epi[0]), float(epi[1])
+        arr[j].matches12, arr[j].nmatches = _vp(m12), C.cast(C.pointer(nm), C.c_void_p)
+        keep += [f2, m12, nm, k2]
+        outs.append((nm, m12))
+    _lib.check(self._lib.so_search_for_triangulation_kframes(self._h, kframe1._h, _vp(f1), len(neighbours), C.cast(arr, C.c_void_p),
+                                                             int(self.mbCheckOrientation)))
+    if getattr(self, "_batching", False):
+        self._batch_keep += keep + [arr, kframe1]
+        return outs
+    return [(nm.value, m12) for nm, m12 in outs]
+
+
+ORBmatcher.SearchForTriangulationKFrames = _SearchForTriangulationKFrames
 ORBmatcher.FuseKFrame = _FuseKFrame
 ORBmatcher.FuseKFrameMap = _FuseKFrameMap
 ORBmatcher.SearchForTriangulationKFrame = _SearchForTriangulationKFrame

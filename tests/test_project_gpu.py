@@ -477,3 +477,55 @@ def test_fuse_from_the_map_while_another_thread_appends_to_it(S, oracle):
     dmap.close()
     m.close()
 
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_triangulation_searches_with_device_built_queries(S, oracle, check_ori):
+    """so_search_for_triangulation_kframes: CreateNewMapPoints' searches of one new keyframe against its neighbours with both
+    sides resident and the queries (free features, vocabulary node, epipolar line) built by the batch's first launch.
+    Five neighbours with different sizes, free masks and fundamental matrices, one of them sharing no vocabulary node with
+    the keyframe: the same matches as so_search_for_triangulation_kframe neighbour by neighbour, as the host-view routine
+    and as the oracle - alone and inside a batch next to a Fuse call."""
+    from swarmmap_amd.matcher import FeatureVector, KFrame
+    m = S.ORBmatcher(0.6, check_ori)
+    sf = synth.SCALE_FACTORS
+    bounds = (0.0, float(synth.EUROC[0]), 0.0, float(synth.EUROC[1]))
+    kf1, node1, kf2_0, node2_0, src = synth.make_bow_case(510, 950, 900, p_flip=0.06)
+    rng = np.random.default_rng(5)
+    kf1["y"] = (kf2_0["y"][src] + rng.normal(0, 0.8, len(src))).astype(np.float32)
+    kf1["x"] = (kf2_0["x"][src] + rng.uniform(-30, 30, len(src))).astype(np.float32)
+    fv1 = FeatureVector(node1)
+    k1 = KFrame(m, FrameView(kf1["x"], kf1["y"], np.zeros(len(kf1["x"]), np.int32), kf1["angle"], kf1["desc"], bounds, sf), fv1, sf * sf)
+    nbs, want = [], []
+    for j in range(5):
+        if j == 0:
+            kf2, node2 = kf2_0, node2_0
+        else:  # the same scene seen again: permuted keypoints, other descriptors' noise, fewer / more features
+            keep = rng.permutation(len(kf2_0["x"]))[:700 + 40 * j]
+            kf2 = {k: (v[keep] if isinstance(v, np.ndarray) and len(v) == len(kf2_0["x"]) else v) for k, v in kf2_0.items()}
+            kf2["desc"] = synth.flip_bits(rng, kf2["desc"], 0.03)
+            node2 = node2_0[keep] if j != 3 else node2_0[keep] + 100000  # j = 3: no vocabulary node in common
+        kf2 = dict(kf2, free=(rng.random(len(kf2["x"])) < 0.7).astype(np.uint8))
+        F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 1e-6, (3, 3)).astype(np.float32)
+        fv2 = FeatureVector(node2)
+        k2 = KFrame(m, FrameView(kf2["x"], kf2["y"], kf2["octave"], kf2["angle"], kf2["desc"], bounds, sf), fv2, sf * sf)
+        epi = (900.0 - 10 * j, 240.0 + j)
+        nbs.append((k2, kf2["free"], F12, epi))
+        w = m.SearchForTriangulationKFrame(kf1, fv1, k2, kf2["free"], F12, epi)
+        o = oracle.search_for_triangulation(kf1, fv1, kf2, fv2, F12, epi, sf, sf * sf, check_ori)
+        assert w[0] == o[0] and np.array_equal(w[1], o[1])
+        want.append(w)
+    assert want[0][0] > 50 and want[3][0] == 0 and sum(w[0] for w in want[1:]) > 100
+    got = m.SearchForTriangulationKFrames(k1, kf1["free"], nbs)
+    for g, w in zip(got, want):
+        assert g[0] == w[0] and np.array_equal(g[1], w[1])
+    c = synth.make_projection_case(77, 600, 800, keyframe_bounds=True)
+    with m.batch():
+        held = m.SearchForTriangulationKFrames(k1, kf1["free"], nbs[:3])
+        fz = m.Fuse(_view(c["frame"], False), c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], 3.0)
+        held2 = m.SearchForTriangulationKFrames(k1, kf1["free"], nbs[3:])
+    for g, w in zip(held + held2, want):
+        assert g[0].value == w[0] and np.array_equal(g[1], w[1])
+    alone = m.Fuse(_view(c["frame"], False), c["cam"], c["Tcw"], c["log_scale_factor"], c["inv_level_sigma2"], c["mp"], 3.0)
+    assert fz[0].value == alone[0] and np.array_equal(fz[1], alone[1])
+    m.close()
