@@ -83,7 +83,35 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
     // ---- CreateNewMapPoints: SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false) per neighbour
     size_t jn = 0;
     const double tc0 = now_ms();
+    // both sides resident and inside a batch: ONE call for all neighbours, the queries built on the device (round 5)
+    static const bool tri_multi = !(getenv("SWARMORB_LM_TRI_MULTI") && atoi(getenv("SWARMORB_LM_TRI_MULTI")) == 0);
+    std::vector<std::vector<uint8_t>> free2s;
+    bool multi = tri_multi && batch && c->dev && !r->lm_ring.empty();
+    for (const auto& kf2 : r->lm_ring) multi = multi && kf2->dev;
+    if (multi) {
+        std::vector<so_tri_neighbour> nbs;
+        free2s.resize(nn);
+        for (const auto& kf2 : r->lm_ring) {
+            so_tri_neighbour N;
+            memset(&N, 0, sizeof(N));
+            fundamental_and_epipole(r, c->T, kf2->T, N.F12, &N.ex, &N.ey);
+            free2s[jn].resize((size_t)kf2->n);
+            for (int i = 0; i < kf2->n; i++) free2s[jn][(size_t)i] = kf2->mp[(size_t)i] < 0 ? 1 : 0;
+            tri_m12[jn].resize((size_t)n);
+            N.kf2 = kf2->dev;
+            N.free2 = free2s[jn].data();
+            N.matches12 = tri_m12[jn].data();
+            N.nmatches = &tri_nm[jn];
+            nbs.push_back(N);
+            st[kLmTriCalls] += 1;
+            jn++;
+        }
+        const double ta = now_ms();
+        if (so_search_for_triangulation_kframes(m, c->dev, free1.data(), (int32_t)nbs.size(), nbs.data(), 1) != SO_OK) return SO_ERR_HIP;
+        st[kLmTriMs] += now_ms() - ta;
+    }
     for (const auto& kf2 : r->lm_ring) {
+        if (multi) break;
         float F12[9], ex, ey;
         fundamental_and_epipole(r, c->T, kf2->T, F12, &ex, &ey);
         free2.resize((size_t)kf2->n);
