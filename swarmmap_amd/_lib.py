@@ -114,8 +114,9 @@ def pin_process_near_device(device, groups=1):
     if os.environ.get("SWARMORB_NO_PIN") or not hasattr(os, "sched_setaffinity"):
         return None
     cpus = set()
+    base = int(os.environ.get("SWARMORB_PIN_SLOT_BASE", "0"))  # several PROCESSES on one GPU: each names its own first group
     for g in range(max(1, int(groups))):
-        got = device_host_cpus(device, int(device) + g)
+        got = device_host_cpus(device, int(device) + base + g)
         if got:
             cpus |= got
     try:

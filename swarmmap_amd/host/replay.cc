@@ -654,7 +654,8 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
         // each other in one process - bench configs, a test session - stay on the same groups)
         r->pin_slot = take_pin_slot();
         char cpus[512];
-        if (so_device_host_cpus(device, device + r->pin_slot, cpus, (int)sizeof(cpus)) == SO_OK) r->host_cpus = cpus;
+        const int base = getenv("SWARMORB_PIN_SLOT_BASE") ? atoi(getenv("SWARMORB_PIN_SLOT_BASE")) : 0;  // (several processes on one GPU)
+        if (so_device_host_cpus(device, device + base + r->pin_slot, cpus, (int)sizeof(cpus)) == SO_OK) r->host_cpus = cpus;
     }
     r->mapper = std::thread(mapper_loop, r);
     *out = r;

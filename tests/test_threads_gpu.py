@@ -112,3 +112,60 @@ def test_agents_started_at_the_same_moment_on_streams_of_their_own():
     for k in range(8):
         for t in range(6):
             assert par[k][t] == by_img[(k + t) % 3], (k, t)
+
+
+def test_tracking_searches_while_another_thread_appends_and_the_map_table_moves():
+    """The closed loop's thread pattern: the tracking thread searches the device-resident map (so_track_search_local_map over a
+    slot list) while the local-mapping thread appends new map points to the same so_map - far enough for the table to be
+    reallocated twice (65536 -> 131072 -> 262144 rows).  The searches hold the table in place while their kernels run
+    (so_map's shared lock, taken at submit and released at the end of the wait): every result equals the quiet run's."""
+    import swarmmap_amd as S
+    from swarmmap_amd import dframe as dfm
+    ex = S.ORBextractor(1000, 1.2, 8, 20, 7)
+    f = S.DeviceFrame(ex, synth.EUROC_K, synth.EUROC_DIST)
+    img = synth.make_canvas(5, 752, 480)
+    kps, un, d = [a.copy() for a in f(img)]
+    rng = np.random.default_rng(3)
+    z = rng.uniform(2.0, 8.0, len(kps))
+    fx, fy, cx, cy = [float(v) for v in synth.EUROC_K]
+    Xw = np.stack([(un[:, 0] - cx) / fx * z, (un[:, 1] - cy) / fy * z, z], 1).astype(np.float32)
+    normal = (Xw / np.linalg.norm(Xw, axis=1, keepdims=True)).astype(np.float32)
+    dist = np.linalg.norm(Xw, axis=1).astype(np.float32)
+    sfac = ex.GetScaleFactors()
+    mx, mn = (1.2 * dist * sfac[kps["octave"]]).astype(np.float32), (0.5 * dist / sfac[7]).astype(np.float32)
+    dmap = S.DeviceMap()
+    dmap.append(Xw, normal, mx, mn, d)
+    n0 = len(Xw)
+    Tcw = np.array([1, 0, 0, 0.002, 0, 1, 0, -0.001, 0, 0, 1, 0], np.float32)
+    log_sf = float(np.log(np.float32(1.2)))
+    m = S.ORBmatcher(0.8, True)
+    slots = np.arange(n0, dtype=np.int32)[::-1].copy()  # an explicit slot list, as the closed loop passes it
+    want = dfm.search_local_map(m, f, dmap, Tcw, n0, 1.0, 0.5, log_sf, local_slot=slots)
+    assert want[0] > 300
+    stop, errs, n_search = threading.Event(), [], [0]
+
+    def tracker():
+        try:
+            while not stop.is_set():
+                got = dfm.search_local_map(m, f, dmap, Tcw, n0, 1.0, 0.5, log_sf, local_slot=slots)
+                assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+                n_search[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=tracker)
+    th.start()
+    chunk = 4096
+    junk = [rng.normal(0, 1, (chunk, 3)).astype(np.float32), rng.normal(0, 1, (chunk, 3)).astype(np.float32),
+            np.ones(chunk, np.float32), np.ones(chunk, np.float32), rng.integers(0, 256, (chunk, 32)).astype(np.uint8)]
+    try:
+        while len(dmap) < 140000:  # two reallocations of the table
+            dmap.append(*junk)
+    finally:
+        stop.set()
+        th.join()
+    assert not errs, errs
+    assert n_search[0] >= 5 and len(dmap) >= 140000
+    got = dfm.search_local_map(m, f, dmap, Tcw, n0, 1.0, 0.5, log_sf, local_slot=slots)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    m.close(); dmap.close(); f.close(); ex.close()
