@@ -445,17 +445,39 @@ void mapper_loop(so_replay* r) {
     pin_to_device_node(r);  // (the library's own thread: pinned for its lifetime)
     for (;;) {
         int timed;
+        bool pre = false;
         std::shared_ptr<KfSnap> kf;
         {
             std::unique_lock<std::mutex> lk(r->mu);
+            if (r->cl) {  // closed loop: the next keyframe is at most a frame or two away - spin before sleeping (a futex
+                          // wake-up is 30-60 us of a cycle the local-mapping thread bounds)
+                const double w0 = now_ms();
+                while (!r->quit && r->queue.empty() && now_ms() - w0 < 1.0) {
+                    lk.unlock();
+                    for (int i = 0; i < 64; i++) __builtin_ia32_pause();
+                    lk.lock();
+                }
+            }
             r->cv.wait(lk, [r] { return r->quit || !r->queue.empty(); });
             if (r->queue.empty()) return;
             timed = r->queue.front().timed;
             kf = r->queue.front().kf;
+            pre = r->queue.front().pre;
             r->running = 1;
         }
         const double t0 = now_ms();
         int lm_rc = SO_OK;
+        if (r->cl && pre) {  // the keyframe-to-be's feature vector + upload, while the tracking thread still tracks the frame
+            lm_rc = kf ? cl_keyframe_featvec_upload(r, r->mapper_matcher, *kf) : SO_OK;
+            {
+                std::lock_guard<std::mutex> lk(r->mu);
+                if (lm_rc != SO_OK && r->error.empty()) r->error = std::string("keyframe feature vector / upload: ") + so_last_error();
+                r->queue.pop_front();
+                r->running = 0;
+            }
+            r->cv.notify_all();
+            continue;
+        }
         if (r->cl) {  // the closed loop: the keyframe's whole local-mapping job, results handed back to the tracking side
             so_ba_info info{};
             lm_rc = kf ? cl_lm_job(r, kf, timed != 0, &info) : SO_OK;
@@ -844,6 +866,41 @@ namespace {
 
 int step_m2_submit(so_replay* r);
 
+// Closed loop, deterministic schedule: `kf_every` frames after the last keyframe the frame being tracked WILL be one (local
+// mapping has just handed its results over and is idle).  Its keypoints and descriptors are known as soon as the frame is
+// collected: the local-mapping thread computes the feature vector and uploads the keyframe into HBM now, while this thread
+// runs the frame's searches and PoseOptimization calls; bindings and pose follow when the frame is tracked (queue_keyframe).
+void prepare_keyframe(so_replay* r, int t) {
+    ClosedLoop& M = *r->cl;
+    static const bool off = getenv("SWARMORB_CL_NO_PREPARE") != nullptr;
+    r->pre_kf.reset();
+    if (off || M.policy != 0 || M.job_pending || t - M.last_kf_t < M.kf_every) return;
+    const so_replay::FrameHost& F = r->fh[r->cur];
+    auto k = std::make_shared<KfSnap>();
+    const int n = F.n;
+    k->n = n;
+    k->t = t;
+    k->x.resize((size_t)n); k->y.resize((size_t)n); k->angle.resize((size_t)n); k->octave.resize((size_t)n);
+    k->mp.assign((size_t)n, -1);
+    k->desc.assign(F.desc.begin(), F.desc.begin() + 32 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        k->x[(size_t)i] = F.xy_un[2 * (size_t)i];
+        k->y[(size_t)i] = F.xy_un[2 * (size_t)i + 1];
+        k->angle[(size_t)i] = F.kps[(size_t)i].angle;
+        k->octave[(size_t)i] = F.kps[(size_t)i].octave;
+    }
+    memcpy(k->bounds, r->bounds, sizeof(k->bounds));
+    r->pre_kf = k;
+    LmJob job;
+    job.kf = k;
+    job.pre = true;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->queue.push_back(job);
+    }
+    r->cv.notify_all();
+}
+
 // Frame constructor: collect frame t, put frame t+1 in flight.  The first frame of a run initialises the map.
 int step_begin(so_replay* r, int t, bool submit_next = true) {
     so_replay::Step& S = r->step;
@@ -883,6 +940,7 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
         const int rc = submit_frame(r, t + 1);
         if (rc) return rc;
     }
+    if (r->cl && !S.first) prepare_keyframe(r, t);
     S.t1 = S.tm2 = S.tp1 = S.tm1 = S.tp2 = S.tp3 = S.tmap = now_ms();
     S.n_in = n;
     S.map_size_at_begin = (int)(r->mp_X.size() / 3);
@@ -1106,12 +1164,14 @@ std::shared_ptr<KfSnap> snapshot_keyframe(so_replay* r, int t);
 
 // closed loop: snapshot the tracked frame and hand it to the local-mapping thread
 void queue_keyframe(so_replay* r, int t) {
-    std::shared_ptr<KfSnap> snap = snapshot_keyframe(r, t);
-    // KeyFrame::ComputeBoW + the keyframe's upload on this thread's matcher (no search of the frame is pending any more): a
-    // tenth of a millisecond the local-mapping thread, which bounds the loop, does not spend
+    std::shared_ptr<KfSnap> snap = snapshot_keyframe(r, t);  // (fills the prepared keyframe if there is one)
+    // KeyFrame::ComputeBoW + the keyframe's upload: normally done already - the local-mapping thread, idle since the frame
+    // began, got the keypoints then (prepare_keyframe) -; otherwise on this thread's matcher now (no search of the frame is
+    // pending any more) rather than inside the job: the local-mapping thread bounds the loop
     static const bool lm_does_it = getenv("SWARMORB_CL_FEATVEC_ON_LM") != nullptr;
-    if (!lm_does_it && r->step.kf_under_pose && cl_keyframe_featvec_upload(r, r->matcher, *snap) != SO_OK)
+    if (!r->pre_kf && !lm_does_it && r->step.kf_under_pose && cl_keyframe_featvec_upload(r, r->matcher, *snap) != SO_OK)
         r->error = std::string("keyframe feature vector / upload: ") + so_last_error();
+    r->pre_kf.reset();
     LmJob job;
     job.timed = r->step_timed;
     job.kf = snap;
@@ -1192,8 +1252,21 @@ int step_keyframe(so_replay* r) {
 std::shared_ptr<KfSnap> snapshot_keyframe(so_replay* r, int t) {
     const so_replay::Step& S = r->step;
     const so_replay::FrameHost& F = r->fh[r->cur];
-    auto k = std::make_shared<KfSnap>();
     const int n = F.n;
+    if (r->cl && r->pre_kf) {  // keypoints, descriptors (and, by now, feature vector + upload) are there: bindings and pose
+        std::shared_ptr<KfSnap> k = r->pre_kf;
+        {   // the local-mapping thread may still be at it: wait for its queue to drain (microseconds, if at all)
+            std::unique_lock<std::mutex> lk(r->mu);
+            r->cv.wait(lk, [r] { return r->queue.empty() && !r->running; });
+        }
+        for (int i = 0; i < n; i++) {
+            const int slot = F.kp_mp[(size_t)i];
+            k->mp[(size_t)i] = (slot >= 0 && !F.outlier[(size_t)i]) ? slot : -1;
+        }
+        to_f12(S.T, k->T);
+        return k;
+    }
+    auto k = std::make_shared<KfSnap>();
     k->n = n;
     k->t = t;
     k->x.resize((size_t)n); k->y.resize((size_t)n); k->angle.resize((size_t)n); k->octave.resize((size_t)n); k->mp.resize((size_t)n);

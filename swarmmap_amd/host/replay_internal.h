@@ -160,6 +160,7 @@ struct KfSnap {
 struct LmJob {
     int timed = 0;
     std::shared_ptr<KfSnap> kf;  // null: window only (warm-up / no vocabulary)
+    bool pre = false;            // closed loop: only the keyframe's feature vector + HBM upload (the frame is still being tracked)
 };
 
 struct so_replay {
@@ -267,6 +268,7 @@ struct so_replay {
     std::vector<uint8_t> ba_out;
     std::unique_ptr<ClosedLoop> cl;  // non-null: the closed loop (so_replay_set_closed_loop)
     int step_timed = 0;              // the frame being tracked counts for the statistics
+    std::shared_ptr<KfSnap> pre_kf;  // closed loop: the frame being tracked will be a keyframe; local mapping prepares it meanwhile
 };
 
 // closedloop.cc
