@@ -15,8 +15,9 @@ Monocular bookkeeping, as SwarmMap runs it:
   * tracking creates no map points afterwards; every new point comes from CreateNewMapPoints' triangulation;
   * a keyframe is handed to local mapping every `kf_every` frames (or earlier, when the inliers fall below
     `kf_ratio` of the last keyframe's and local mapping is idle);
-  * per keyframe, in LocalMapping::Run's order: ProcessNewKeyFrame (observations), MapPointCulling (the observation
-    rule; the found / visible ratio needs Tracking's per-frame counters and is left out), CreateNewMapPoints
+  * per keyframe, in LocalMapping::Run's order: ProcessNewKeyFrame (observations), MapPointCulling (found / visible
+    ratio < 0.25 from Tracking's per-frame counters - IncreaseVisible in SearchLocalPoints, IncreaseFound after the second
+    PoseOptimization, as they stand when the keyframe is handed over - and the observation rule), CreateNewMapPoints
     (SearchForTriangulation against the last <= 20 keyframes with the baseline / median-depth gate, triangulation,
     new points), SearchInNeighbors (Fuse into every neighbour and back, AddObservation / Replace), LocalBundleAdjustment
     over the keyframe's OWN window (covisible keyframes sharing >= 15 points free - the `n_free` most covisible, the cap
@@ -223,10 +224,13 @@ def lm_job(M, be, c, P):
         M.obs[s].append((k, i))
     # ---- MapPointCulling (:174-205), the observation rule -----------------------------------------------------------
     recent = []
+    cnt_from = int(c.get("cnt_from", len(M)))
     for s in M.recent:
         if M.bad[s]:
             continue
-        if k - int(M.first_kf[s]) >= 2 and len(M.obs[s]) <= 2:
+        if s >= cnt_from and np.float32(c["found"][s - cnt_from]) / np.float32(c["vis"][s - cnt_from]) < np.float32(0.25):
+            M.set_bad(s)  # GetFoundRatio() < 0.25f (:187-190)
+        elif k - int(M.first_kf[s]) >= 2 and len(M.obs[s]) <= 2:
             M.set_bad(s)
         elif k - int(M.first_kf[s]) >= 3:
             continue
@@ -381,7 +385,8 @@ def lm_job(M, be, c, P):
     lk = M.kfs[max(0, len(M.kfs) - P["local_keyframes"]):]
     local = np.unique(np.concatenate([q["mp"][q["mp"] >= 0] for q in lk])) if lk else np.zeros(0, np.int64)
     local = local[M.bad[local] == 0] if len(local) else local
-    return dict(kf=k, first_new=n_before, n_points=len(M), new_X=M.X[n_before:].copy(), moved=moved.astype(np.int64),
+    return dict(kf=k, first_new=n_before, n_points=len(M), recent_from=(min(M.recent) if M.recent else len(M)),
+                new_X=M.X[n_before:].copy(), moved=moved.astype(np.int64),
                 moved_X=M.X[moved].copy(), moved_N=M.N[moved].copy(), moved_mx=M.mx[moved].copy(), moved_mn=M.mn[moved].copy(),
                 bad=newly_bad, bad_repl=M.repl[newly_bad].copy(), kf_T=np.asarray(c["T"], np.float32).copy(),
                 local_slots=local.astype(np.int32),
@@ -412,7 +417,8 @@ def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio
              local_keyframes=local_keyframes)
     M = LoopMap()
     # the tracking side's view of the map: positions, bad / replaced flags, size, local map, reference keyframe pose
-    tv = dict(X=np.zeros((0, 3), np.float32), bad=np.zeros(0, np.uint8), repl=np.zeros(0, np.int32), local=np.zeros(0, np.int32))
+    tv = dict(X=np.zeros((0, 3), np.float32), bad=np.zeros(0, np.uint8), repl=np.zeros(0, np.int32), local=np.zeros(0, np.int32),
+              vis=np.zeros(0, np.int64), found=np.zeros(0, np.int64), recent_from=0)  # mnVisible / mnFound (start at 1)
     pending = None  # (apply at frame, handle)
     lm_log = []
     poses, centres, ref_kf, Tcr = [], [], [], []
@@ -444,6 +450,13 @@ def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio
         tv["X"] = np.concatenate([tv["X"], pk["new_X"]])
         tv["bad"] = np.concatenate([tv["bad"], np.zeros(pk["n_points"] - n_old, np.uint8)])
         tv["repl"] = np.concatenate([tv["repl"], np.full(pk["n_points"] - n_old, -1, np.int32)])
+        tv["vis"] = np.concatenate([tv["vis"], np.ones(pk["n_points"] - n_old, np.int64)])
+        tv["found"] = np.concatenate([tv["found"], np.ones(pk["n_points"] - n_old, np.int64)])
+        for s, b in zip(pk["bad"], pk["bad_repl"]):  # MapPoint::Replace hands its counters to the survivor (MapPoint.cc:280-281)
+            if b >= 0:
+                tv["vis"][b] += tv["vis"][s]
+                tv["found"][b] += tv["found"][s]
+        tv["recent_from"] = int(pk["recent_from"])
         if len(pk["moved"]):
             tv["X"][pk["moved"]] = pk["moved_X"]
             backend.map_write_rows(pk["moved"], pk["moved_X"], pk["moved_N"], pk["moved_mx"], pk["moved_mn"])
@@ -462,7 +475,9 @@ def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio
 
     def make_keyframe(t, T, kps, xy_un, desc, kp_mp, outlier, bounds):
         bind = np.where((kp_mp >= 0) & ~outlier, kp_mp, -1).astype(np.int64)
-        c = dict(id=len(M.kfs), t=t, T=T[:3, :4].astype(np.float32).reshape(12).copy(), x=xy_un[:, 0].copy(), y=xy_un[:, 1].copy(),
+        f0 = tv["recent_from"]
+        c = dict(id=len(M.kfs), t=t, cnt_from=f0, vis=tv["vis"][f0:].copy(), found=tv["found"][f0:].copy(),
+                 T=T[:3, :4].astype(np.float32).reshape(12).copy(), x=xy_un[:, 0].copy(), y=xy_un[:, 1].copy(),
                  angle=kps["angle"].copy(), octave=kps["octave"].astype(np.int32), desc=desc.copy(), w=inv_sigma2[kps["octave"]],
                  mp=bind, bounds=np.asarray(bounds, np.float32))
         M.kfs.append(c)
@@ -497,6 +512,7 @@ def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio
             M.append(Xf, Nf, mxf, mnf, desc, 0, [[] for _ in range(n)])
             backend.map_append(Xf, Nf, mxf, mnf, desc)
             tv["X"], tv["bad"], tv["repl"] = Xf.copy(), np.zeros(n, np.uint8), np.full(n, -1, np.int32)
+            tv["vis"], tv["found"], tv["recent_from"] = np.ones(n, np.int64), np.ones(n, np.int64), n
             tv["local"] = np.arange(n, dtype=np.int32)
             kp_mp[:] = np.arange(n)
             kf_inliers = n
@@ -524,7 +540,9 @@ def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio
             bound_now[kp_mp[kp_mp >= 0]] = True
             skip[bound_now[loc]] = 1
             excluded = (kp_mp >= 0).astype(np.uint8)
-            nm2, k2m, _ = backend.search_local(T_a.reshape(12), 0, len(loc), skip, excluded, 1.0, log_sf, local_slot=loc)
+            np.add.at(tv["vis"], kp_mp[kp_mp >= 0], 1)  # SearchLocalPoints: points already matched (Tracking.cc:966-975) ...
+            nm2, k2m, in_view = backend.search_local(T_a.reshape(12), 0, len(loc), skip, excluded, 1.0, log_sf, local_slot=loc)
+            np.add.at(tv["vis"], loc[np.asarray(in_view) != 0], 1)  # ... and local points in the frustum (:990-993)
             newly = k2m >= 0
             kp_mp[newly] = loc[k2m[newly]]
             log["matches_map"].append(int(nm2))
@@ -534,6 +552,7 @@ def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio
                 backend.pose(T_last[:3, :4].astype(np.float32).reshape(12), intr, tv["X"][kp_mp[idx]], xy_un[idx],
                              inv_sigma2[kps["octave"][idx]])
             outlier[idx[outl.astype(bool)]] = True
+            np.add.at(tv["found"], kp_mp[idx[~outl.astype(bool)]], 1)  # TrackLocalMap: IncreaseFound (Tracking.cc:783-786)
             T = mt._T44(np.asarray(T12, np.float32))
             log["inliers"].append(int(n_in))
             since = t - kf_t[-1]

@@ -292,12 +292,15 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
         c->mp[(size_t)i] = s;
         M.obs[(size_t)s].emplace_back(k, i);
     }
-    // ---- MapPointCulling (:174-205), the observation rule
+    // ---- MapPointCulling (:174-205): the found / visible ratio Tracking counted, then the observation rule
     {
         std::vector<int32_t> keep;
         for (int s : M.recent) {
             if (M.bad[(size_t)s]) continue;
-            if (k - M.first_kf[(size_t)s] >= 2 && M.obs[(size_t)s].size() <= 2) L.set_bad(s);
+            const int q = s - c->cnt_from;
+            if (q >= 0 && q < (int)c->cnt_vis.size() && (float)c->cnt_found[(size_t)q] / (float)c->cnt_vis[(size_t)q] < 0.25f)
+                L.set_bad(s);  // GetFoundRatio() < 0.25f (:187-190)
+            else if (k - M.first_kf[(size_t)s] >= 2 && M.obs[(size_t)s].size() <= 2) L.set_bad(s);
             else if (k - M.first_kf[(size_t)s] >= 3) continue;
             else keep.push_back(s);
         }
@@ -656,6 +659,7 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
     pk.bad = M.newly_bad;
     for (int s : pk.bad) pk.bad_repl.push_back(M.repl[(size_t)s]);
     memcpy(pk.kf_T, c->T, 48);
+    pk.recent_from = M.recent.empty() ? L.n_points() : *std::min_element(M.recent.begin(), M.recent.end());
     {
         const int id = L.next_stamp();
         const int first = std::max(0, (int)M.kfs.size() - std::max(1, r->local_keyframes));
@@ -730,6 +734,8 @@ int cl_frame_begin(so_replay* r, int t) {
     r->mp_X.insert(r->mp_X.end(), pk.new_X.begin(), pk.new_X.end());
     M.tv_bad.resize((size_t)pk.n_points, 0);
     M.tv_repl.resize((size_t)pk.n_points, -1);
+    M.tv_vis.resize((size_t)pk.n_points, 1);    // a new MapPoint starts with mnVisible = mnFound = 1 (MapPoint.cc:38)
+    M.tv_found.resize((size_t)pk.n_points, 1);
     if (!pk.moved.empty()) {
         for (size_t q = 0; q < pk.moved.size(); q++) memcpy(&r->mp_X[3 * (size_t)pk.moved[q]], &pk.moved_X[3 * q], 12);
         if (so_map_write_rows(r->map, (int32_t)pk.moved.size(), pk.moved.data(), pk.moved_X.data(), pk.moved_N.data(), pk.moved_mx.data(),
@@ -741,7 +747,12 @@ int cl_frame_begin(so_replay* r, int t) {
     for (size_t q = 0; q < pk.bad.size(); q++) {
         M.tv_bad[(size_t)pk.bad[q]] = 1;
         M.tv_repl[(size_t)pk.bad[q]] = pk.bad_repl[q];
+        if (pk.bad_repl[q] >= 0) {  // MapPoint::Replace hands its counters to the survivor (MapPoint.cc:280-281)
+            M.tv_vis[(size_t)pk.bad_repl[q]] += M.tv_vis[(size_t)pk.bad[q]];
+            M.tv_found[(size_t)pk.bad_repl[q]] += M.tv_found[(size_t)pk.bad[q]];
+        }
     }
+    M.recent_from = pk.recent_from;
     M.tv_local.swap(pk.local_slots);
     // Tracking::UpdateLastFrame (Tracking.cc:920-937): the last frame follows its reference keyframe
     M.T_ref = from_f12(pk.kf_T);

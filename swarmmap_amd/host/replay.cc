@@ -957,6 +957,9 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
         if (r->cl) {  // the initial map is the local map until the first keyframe's job reports
             r->cl->tv_bad.assign((size_t)n, 0);
             r->cl->tv_repl.assign((size_t)n, -1);
+            r->cl->tv_vis.assign((size_t)n, 1);
+            r->cl->tv_found.assign((size_t)n, 1);
+            r->cl->recent_from = n;
             r->cl->tv_local.resize((size_t)n);
             for (int i = 0; i < n; i++) r->cl->tv_local[(size_t)i] = first + i;
         }
@@ -1097,7 +1100,10 @@ int step_m1_submit(so_replay* r) {
         for (int k = 0; k < n; k++) {
             const int s = F.kp_mp[(size_t)k];
             r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
-            if (s >= 0) bound[(size_t)s] = 1;
+            if (s >= 0) {
+                bound[(size_t)s] = 1;
+                M.tv_vis[(size_t)s]++;  // SearchLocalPoints: points already matched (Tracking.cc:966-975)
+            }
         }
         for (int i = 0; i < nl; i++)
             if (bound[(size_t)M.tv_local[(size_t)i]]) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:1117-1124)
@@ -1144,6 +1150,9 @@ int step_m1_wait(so_replay* r) {
     S.reruns += ms4[2];
     S.nm1 = nmm;
     for (int i = 0; i < S.n_local; i++) S.n_view += view[(size_t)i];
+    if (r->cl)
+        for (int i = 0; i < S.n_local; i++)
+            if (view[(size_t)i]) r->cl->tv_vis[(size_t)r->cl->tv_local[(size_t)i]]++;  // local points in the frustum (:990-993)
     for (int k = 0; k < n; k++)
         if (r->k2m[(size_t)k] >= 0)
             F.kp_mp[(size_t)k] = r->cl ? r->cl->tv_local[(size_t)r->k2m[(size_t)k]] : S.first_slot + r->k2m[(size_t)k];
@@ -1156,6 +1165,7 @@ void pose2_apply(so_replay* r) {
     so_replay::FrameHost& F = r->fh[r->cur];
     for (size_t k = 0; k < r->idx.size(); k++)
         if (r->pose_out[k]) F.outlier[(size_t)r->idx[k]] = 1;
+        else if (r->cl) r->cl->tv_found[(size_t)F.kp_mp[(size_t)r->idx[k]]]++;  // TrackLocalMap: IncreaseFound (Tracking.cc:783-786)
     S.T = from_f12(S.Tb);
     S.tp2 = now_ms();
 }
@@ -1172,6 +1182,12 @@ void queue_keyframe(so_replay* r, int t) {
     if (!r->pre_kf && !lm_does_it && r->step.kf_under_pose && cl_keyframe_featvec_upload(r, r->matcher, *snap) != SO_OK)
         r->error = std::string("keyframe feature vector / upload: ") + so_last_error();
     r->pre_kf.reset();
+    {   // Tracking's counters of the recently added points, as they stand now (MapPointCulling reads GetFoundRatio())
+        ClosedLoop& M = *r->cl;
+        snap->cnt_from = std::min(M.recent_from, (int)M.tv_vis.size());
+        snap->cnt_vis.assign(M.tv_vis.begin() + snap->cnt_from, M.tv_vis.end());
+        snap->cnt_found.assign(M.tv_found.begin() + snap->cnt_from, M.tv_found.end());
+    }
     LmJob job;
     job.timed = r->step_timed;
     job.kf = snap;

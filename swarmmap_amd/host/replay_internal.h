@@ -104,6 +104,7 @@ struct LmPacket {
     std::vector<int32_t> bad, bad_repl;  // points that went bad in this job and what replaced them (-1: nothing)
     float kf_T[12] = {0};                // the keyframe's pose after local BA
     std::vector<int32_t> local_slots;    // the local map for Tracking::SearchLocalPoints from now on
+    int recent_from = 0;                 // smallest slot still on mlpRecentAddedMapPoints (the counters the next keyframe brings start there)
 };
 struct KfSnap;
 struct ClosedLoop {
@@ -124,6 +125,8 @@ struct ClosedLoop {
     // ---- the tracking side's view (tracking thread only; positions: so_replay::mp_X) ----
     std::vector<uint8_t> tv_bad;
     std::vector<int32_t> tv_repl, tv_local;
+    std::vector<uint32_t> tv_vis, tv_found;  // mnVisible / mnFound (IncreaseVisible in SearchLocalPoints, IncreaseFound after TrackLocalMap)
+    int recent_from = 0;
     M4 T_ref = M4::eye(), Tlr = M4::eye();
     int last_kf_t = 0, n_kf = 0, apply_at = 0, interrupts = 0;
     bool job_pending = false;
@@ -149,6 +152,9 @@ struct KfSnap {
     float T[12] = {0}, bounds[4] = {0, 0, 0, 0};
     int t = 0;
     int id = 0;  // closed loop: index in ClosedLoop::kfs
+    // closed loop: Tracking's mnVisible / mnFound of the slots from cnt_from on, as they stand when the keyframe is handed over
+    int cnt_from = 0;
+    std::vector<uint32_t> cnt_vis, cnt_found;
     // DBoW2::FeatureVector stand-in, filled by the local-mapping thread
     std::vector<int32_t> node_id, off, idx;
     // the keyframe's matcher-side data in HBM (so_kframe_create), uploaded once when it joins the local-mapping thread's
