@@ -625,6 +625,16 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
     int g = WAVES == 4 ? (int)blockIdx.x : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int nf = d.n_free;
     int n_blk = nf * (nf + 1) / 2;
+    if (WAVES == 4) {
+        // Workgroups go to the eight XCDs round-robin, each with its own L2: with g = blockIdx.x every XCD met every
+        // keyframe's W blocks (FETCH_SIZE 4.1x the inputs, round 4).  XCD x takes the x-th eighth of the column-ordered
+        // block list instead - two or three whole columns i2, so W of those keyframes' edges stays in one L2; the i1 side
+        // is shared by all columns whatever the deal (any split of all pairs of 25 keyframes over eight caches re-reads
+        // W about three times: DESIGN.md 5).  S(i1,i2) does not depend on which workgroup forms it.
+        const int total = n_blk + nf, chunk = (total + 7) >> 3, j = (int)(blockIdx.x >> 3);
+        g = (int)(blockIdx.x & 7) * chunk + j;
+        if (j >= chunk || g >= total) return;
+    }
     if (d.use_pairs) {
         if (g < list_cap) {
             if (g >= *d.big_n) return;
@@ -1319,7 +1329,7 @@ static void launch_ba_schur(const BaDev& d, hipStream_t s) {
         return;
     }
     const int groups = n_blk + d.n_free;  // a local window: a workgroup per block
-    if (groups > 0) hipLaunchKernelGGL(ba_schur_gather_kernel<4>, dim3(groups), dim3(256), 0, s, d, 0);
+    if (groups > 0) hipLaunchKernelGGL(ba_schur_gather_kernel<4>, dim3(8 * ((groups + 7) / 8)), dim3(256), 0, s, d, 0);
 }
 
 static void launch_ba_solve(const BaDev& d, hipStream_t s) {

@@ -232,6 +232,14 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F_arg, c
     const BatchJobDev* job = nullptr;
     if (MODE == 4) {  // qdesc carries the batch's grid table here: which job does this workgroup belong to?
         const BatchGridDev* G = reinterpret_cast<const BatchGridDev*>(qdesc);
+        // Workgroups are dealt to the eight XCDs round-robin and every XCD has its own L2: with blk = blockIdx.x the
+        // workgroups of one job (one resident keyframe against one query list) sat on all eight, and each XCD pulled every
+        // keyframe's descriptors and cell tables across the fabric (FETCH_SIZE 4.5x the batch's inputs, round 4).  XCD x
+        // takes the x-th eighth of the batch's workgroups instead - two or three whole jobs - so a keyframe is read by one
+        // XCD, two at a seam.  Results do not depend on which workgroup computes a query.
+        const int total = G->first_topk[G->n_jobs], chunk = (total + 7) >> 3;
+        blk = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= chunk || blk >= total) return;
         int lo = 0, hi = G->n_jobs - 1;
         while (lo < hi) {  // largest j with first_topk[j] <= blk (uniform: scalar loads from one cached block)
             const int mid = (lo + hi + 1) >> 1;
@@ -755,7 +763,7 @@ void launch_batch(const BatchGridDev* d_grid, const BatchJobDev* d_jobs, int n_j
     if (topk_blocks > 0) {
         const TrackQuerySrc none{};
         const MatchFrameDev unused{};
-        hipLaunchKernelGGL(topk_window_kernel<4>, dim3(topk_blocks), dim3(256), 0, s, unused, (const void*)d_jobs,
+        hipLaunchKernelGGL(topk_window_kernel<4>, dim3(8 * ((topk_blocks + 7) / 8)), dim3(256), 0, s, unused, (const void*)d_jobs,
                            reinterpret_cast<const uint4*>(d_grid), 0, 0, (uint32_t*)nullptr, (int32_t*)nullptr, none, 0);
     }
 }

@@ -969,27 +969,38 @@ __global__ __launch_bounds__(kDescThreads) void describe_kernel(PyramidParams P,
 // Same, fed by the device quadtree: block b finds its (level, k) from the per-level survivor counts, describes
 // qt_sel[level][k] and writes descriptor / angle / keypoint record at the compact output index, straight into
 // host-mapped memory (the caller's copy) and into HBM (`dev`: what the device-resident frame reads).  Launched
-// with the capacity as grid; surplus blocks exit.
+// with the capacity (rounded up to a multiple of eight) as grid; surplus blocks exit.
 __device__ __forceinline__ void describe_qt_body(const PyramidParams& P, const SelectedKp* __restrict__ qt_sel,
                                                  const int32_t* __restrict__ qt_count, int qt_stride, uint8_t* __restrict__ desc,
                                                  float* __restrict__ angle_out, SelectedKp* __restrict__ meta_out,
-                                                 int32_t* __restrict__ total_out, const DescribeDeviceOut& dev) {
+                                                 int32_t* __restrict__ total_out, const DescribeDeviceOut& dev, int capacity) {
     __shared__ uint32_t patch[kPatch * (kPatchPitch / 4) + 4];
     __shared__ float rowp[kPatch * kBlur];
     __shared__ uint8_t blur[kBlur * kBlurPitch];
     __shared__ int s_mom[8];
-    int id = blockIdx.x, lvl = -1, base = 0;
+    int cnt[kMaxLevels], total = 0;
 #pragma unroll
     for (int l = 0; l < kMaxLevels; l++) {
-        const int c = l < P.nlevels ? qt_count[l] : 0;
-        if (lvl < 0 && id < base + c) lvl = l;
-        if (lvl < 0) base += c;
+        cnt[l] = l < P.nlevels ? qt_count[l] : 0;
+        total += cnt[l];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int t = 0;
-        for (int l = 0; l < P.nlevels; l++) t += qt_count[l];
-        *total_out = t;
-        if (dev.total) *dev.total = t;
+        *total_out = total;
+        if (dev.total) *dev.total = total;
+    }
+    // Which keypoint this workgroup describes: workgroups are dealt to the eight XCDs round-robin (blockIdx.x % 8) and every
+    // XCD has its own L2, so with id = blockIdx.x each XCD pulled patches from all over all eight levels - the 1.2 MB
+    // pyramid crossed the fabric ~4.5 times per frame (FETCH_SIZE 5.3 MB, rounds 2-4).  XCD x takes the x-th eighth of the
+    // keypoints instead: ids are ordered by level and, inside a level, by quadtree node, so an eighth is a compact region
+    // of one or two levels (measured: DESIGN.md 3).  The output slot is the keypoint's id, as before.
+    const int n_desc = min(total, capacity);  // (the output arrays hold `capacity` records; the quadtree's bound is below it)
+    const int chunk = (n_desc + 7) >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    int id = xcd * chunk + j, lvl = -1, base = 0;
+    if (j >= chunk || id >= n_desc) return;
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; l++) {
+        if (lvl < 0 && id < base + cnt[l]) lvl = l;
+        if (lvl < 0) base += cnt[l];
     }
     if (lvl < 0) return;
     const SelectedKp kp = qt_sel[(size_t)lvl * qt_stride + (id - base)];
@@ -1004,20 +1015,21 @@ __global__ __launch_bounds__(kDescThreads) void describe_qt_kernel(PyramidParams
                                                                     const int32_t* __restrict__ qt_count, int qt_stride,
                                                                     uint8_t* __restrict__ desc, float* __restrict__ angle_out,
                                                                     SelectedKp* __restrict__ meta_out,
-                                                                    int32_t* __restrict__ total_out, DescribeDeviceOut dev) {
-    describe_qt_body(P, qt_sel, qt_count, qt_stride, desc, angle_out, meta_out, total_out, dev);
+                                                                    int32_t* __restrict__ total_out, DescribeDeviceOut dev, int capacity) {
+    describe_qt_body(P, qt_sel, qt_count, qt_stride, desc, angle_out, meta_out, total_out, dev, capacity);
 }
-__global__ __launch_bounds__(kDescThreads) void describe_qt_batch_kernel(const ExtractBatchMember* __restrict__ M) {
+__global__ __launch_bounds__(kDescThreads) void describe_qt_batch_kernel(const ExtractBatchMember* __restrict__ M, int capacity) {
     const ExtractBatchMember& m = M[blockIdx.y];
-    describe_qt_body(m.P, m.qt_sel, m.qt_count, m.qt.sel_stride, m.out.desc, m.out.angle, m.out.meta, m.out.total, m.out.dev);
+    describe_qt_body(m.P, m.qt_sel, m.qt_count, m.qt.sel_stride, m.out.desc, m.out.angle, m.out.meta, m.out.total, m.out.dev, capacity);
 }
 
 
 void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, const int32_t* d_qt_count, int qt_stride,
                         int capacity, uint8_t* desc, float* angle, SelectedKp* meta, int32_t* total,
                         const DescribeDeviceOut& dev, hipStream_t s) {
-    hipLaunchKernelGGL(describe_qt_kernel, dim3(capacity), dim3(kDescThreads), 0, s, p, d_qt_sel, d_qt_count, qt_stride, desc,
-                       angle, meta, total, dev);
+    // (a multiple of eight workgroups: describe_qt_body deals the ids to the XCDs in eighths)
+    hipLaunchKernelGGL(describe_qt_kernel, dim3(8 * ((capacity + 7) / 8)), dim3(kDescThreads), 0, s, p, d_qt_sel, d_qt_count, qt_stride, desc,
+                       angle, meta, total, dev, capacity);
 }
 
 void launch_extract_batch(const ExtractBatchMember* d_members, const ExtractBatchMember& first, int n, const uint8_t* const* d_srcs,
@@ -1037,7 +1049,7 @@ void launch_extract_batch(const ExtractBatchMember* d_members, const ExtractBatc
     const int ngroups = (p.total_tiles + 3) / 4;
     hipLaunchKernelGGL(fast_low_batch_kernel, dim3(8 * ((ngroups + 7) / 8), n), dim3(256), 0, s, d_members);
     launch_quadtree_batch(d_members, n, p.nlevels, s);
-    hipLaunchKernelGGL(describe_qt_batch_kernel, dim3(capacity, n), dim3(kDescThreads), 0, s, d_members);
+    hipLaunchKernelGGL(describe_qt_batch_kernel, dim3(8 * ((capacity + 7) / 8), n), dim3(kDescThreads), 0, s, d_members, capacity);
 }
 
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,

@@ -143,7 +143,9 @@ def test_cpp_closed_loop_under_the_reference_policy_tracks_and_reports_its_inter
                              kf_every=2)
     c = a["counts"]
     assert c["keyframes"] == c["jobs"] >= 5 and c["windows_aborted"] <= c["windows"] <= c["jobs"] and c["windows_aborted"] <= c["interrupt_ba"]
-    assert np.all(np.diff(a["kf_t"]) >= 2)
+    # a keyframe every kf_every frames - or earlier when the frame's inliers fall below keyframe_ratio x the last keyframe's
+    # (NeedNewKeyFrame's c2), which a map thinned by an interrupted local mapper can trigger on the very next frame
+    assert np.all(np.diff(a["kf_t"]) >= 1) and np.median(np.diff(a["kf_t"])) >= 2
     gt = minitrack.ground_truth(st, n, K, PLANE_Z)
     px = PLANE_Z / float(K[0])
     assert a["inliers"][1:].min() > 250
