@@ -677,6 +677,46 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
                               float viewing_cos_limit, float log_scale_factor, uint8_t* in_view, int32_t* kp_to_local,
                               int32_t* nmatches);
 
+/* A tracking stage WITHOUT a host hop between the search and the pose: what Tracking::TrackWithMotionModel
+ * (code/src/Tracking.cc:964-1046: SearchByProjection(mCurrentFrame, mLastFrame, th, mono) then
+ * Optimizer::PoseOptimization(&mCurrentFrame)) and Tracking::TrackLocalMap (:766-803: SearchLocalPoints() then
+ * PoseOptimization) do back to back, as one chain of launches on the matcher's stream:
+ *   search (the same kernel as so_track_search_*) -> the order-dependent resolve ON THE DEVICE (an exact parallel form of
+ *   the reference's sequential walk, code/src/ORBmatcher.cc:83-85 and :1294-1296, incl. the rotation histogram of
+ *   :1319-1350) -> PoseOptimization (code/src/Optimizer.cc:239-434) over the frame's bindings, its edges read in place from
+ *   the device-resident frame and map table.
+ * The host waits ONCE, for the pose.  Semantics of the arguments as in so_track_search_last_frame / _local_map and
+ * so_pose_optimization; additionally
+ *   intr4 = fx, fy, cx, cy;  level_inv_sigma2 = mvInvLevelSigma2 (cur's number of levels);
+ *   kp_slot (local-map stage, cur->n entries) = map slot bound to keypoint k on entry, < 0: none - those keypoints are the
+ *   search's `excluded` set AND edges of the pose problem; bound points must carry skip[] = 1 as for the plain search.
+ * All map points are taken to have observations (slot_has_obs = NULL of the plain calls).
+ * so_track_stage_wait - out, all required unless noted:
+ *   kp_to_q[k] (cur->n) = query (index into the last frame / the local list) matched to keypoint k by THIS stage's search;
+ *   in_view (local-map stage; may be NULL);  n_edges, edge_kp[e] = keypoint of edge e (ascending), edge_outlier[e]
+ *   (capacity cur->n each);  Tcw_out12, n_inliers, info2 as so_pose_optimization_wait.
+ * Returns SO_OK, or SO_RETRY_ON_HOST (100, not an error; nothing but kp_to_q = -1 is defined then): the stage could not be
+ * finished on the device - a query ran out of K-list entries with more candidates in its window, more than 4096 keypoints /
+ * 2048 queries with candidates, or more edges than the launched PoseOptimization variant holds - and the caller runs
+ * so_track_search_* + so_pose_optimization instead (same results by construction: tests/test_track_chain_gpu.py).
+ * so_track_stage_pose_again_submit: PoseOptimization over the SAME edges from another start pose (the edge list of the
+ * last stage is still on the device); wait with so_track_stage_wait (kp_to_q / in_view are not written). */
+#define SO_RETRY_ON_HOST 100
+int so_track_stage_last_frame_submit(so_matcher* m, const so_dframe* cur, const so_dframe* last, const so_map* map,
+                                     const float* Tcw12, const int32_t* last_slot, float th, int check_orientation,
+                                     const float* intr4, const float* level_inv_sigma2);
+int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const int32_t* kp_slot, const so_map* map,
+                                    const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
+                                    const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
+                                    float log_scale_factor, const float* intr4, const float* level_inv_sigma2);
+int so_track_stage_pose_again_submit(so_matcher* m, const float* Tcw12);
+int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint8_t* in_view, int32_t* n_edges,
+                        int32_t* edge_kp, uint8_t* edge_outlier, float* Tcw_out12, int32_t* n_inliers, int32_t* info2);
+/* rounds the last stage's device resolve took, and how many of its queries had candidates (diagnostics) */
+int so_track_stage_last_rounds(so_matcher* m, int32_t* rounds, int32_t* active_queries);
+/* HIP-event time of the stage's PoseOptimization kernel (0 unless so_matcher_set_profiling is on) */
+int so_track_stage_last_pose_kernel_ms(so_matcher* m, float* ms);
+
 /* ------------------------------------------------------------------------------------------------
  * Cross-agent keyframe exchange — one agent per GPU, RCCL all-gather over xGMI.  Replaces, for agents
  * sharded across the GPUs of a node, the server-side candidate query AgentMediator::CheckOverlapCandidates

@@ -203,6 +203,11 @@ void pose_to_Tcw(const BaPose& P, float* T) {  // to_homogeneous_matrix cast to 
 
 }  // namespace
 
+namespace so {  // (for matcher.cpp's tracking stages, which launch the indexed PoseOptimization kernel themselves)
+void pose_from_Tcw12(const float* T, BaPose& P) { pose_from_Tcw(T, P); }
+void pose_to_Tcw12(const BaPose& P, float* T) { pose_to_Tcw(P, T); }
+}  // namespace so
+
 struct so_ba {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -234,7 +234,25 @@ struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.
     double* trace;     // optional: 4 doubles per LM trial (lambda, tempChi, rho, currentChi), 256 trials max
     int done_seq;      // != 0: the results are in host-mapped memory and info[3] = done_seq is stored behind them
                        // (system scope), so the host can spin on that word instead of waiting for the stream
+    // Indexed inputs (pose_opt_chain_kernel: a tracking stage whose matches were resolved on the device, match_device.h
+    // TrackResolveArgs): edge e = keypoint e_kp[e] of the frame against map slot e_slot[e]; head[0] = number of edges,
+    // head[2] != 0 = the resolve gave up (the kernel then only publishes info[0] = -1).  All null / zero otherwise.
+    const int32_t* e_kp = nullptr;
+    const int32_t* e_slot = nullptr;
+    const int32_t* head = nullptr;
+    const float* map_Xw = nullptr;      // the map table's positions, 3 per slot
+    const float2* kp_xy_un = nullptr;   // the frame's undistorted keypoints by index
+    const int8_t* kp_octave = nullptr;
+    float lvl_inv_sigma2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+// the indexed form, one launch: reads the edge count on the device and runs the register-resident body that fits it.
+// range 0: up to 1024 edges, 1: 1025 .. 1792; a count outside the launched range, or a resolve that gave up: info[0] = -1
+// and the caller takes the host path (fewer than three edges: -2, nothing to optimise)
+void launch_pose_opt_chain(const PoseOptArgs& a, int range, hipStream_t s);
+constexpr int kPoseChainMaxEdges = 1792;
+// Converter::toSE3Quat(Tcw) / Converter::toCvMat(SE3Quat) as so_pose_optimization applies them (ba.cpp)
+void pose_from_Tcw12(const float* Tcw12, BaPose& P);
+void pose_to_Tcw12(const BaPose& P, float* Tcw12);
 constexpr int kPoseOptLdsMax = 3072;  // matched points the LDS-resident kernel holds (41 B each)
 void launch_pose_opt(const PoseOptArgs& a, hipStream_t s);
 // n_problems problems in one launch (a workgroup each); d_args must be device-visible.  false: a problem has more than

@@ -2370,15 +2370,11 @@ __device__ __forceinline__ void se3_exp_mul_direct(const double* u, const BaPose
 //     one pass ahead of the slowest one.
 // Same schedule, same accept / reject rules, same stored-error semantics as above (g2o's optimize(10) x 4).
 template <int THREADS, int EPT>
-__global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, const PoseOptArgs* __restrict__ batch) {
-    // batch != null: workgroup b solves problem batch[b] (so_pose_optimization_batch: several agents' frames, or the
-    // independent problems of one frame, in ONE launch - a workgroup per problem, nothing shared between them)
-    const PoseOptArgs a = batch ? batch[blockIdx.x] : a0;
+__device__ __forceinline__ void pose_opt_reg_body(const PoseOptArgs& a, const int n) {
     constexpr int NW = THREADS / 64;
     __shared__ double s_red[2][NW][32];
     __shared__ double s_sysw[NW][2][32];  // per wave: the two systems; 21 H (upper) | 6 b | chi | n_active
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = a.n;
     const double delta = (double)sqrtf(5.991f);  // const float deltaMono = sqrt(5.991)
     const float dsqr = (float)(delta * delta);
     const double fx = a.K[0], fy = a.K[1], cx = a.K[2], cy = a.K[3];
@@ -2390,9 +2386,21 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
         live[k] = e < n;
         outl[k] = false;
         const int ee = live[k] ? e : 0;
-        X[k][0] = (double)a.Xw[3 * ee]; X[k][1] = (double)a.Xw[3 * ee + 1]; X[k][2] = (double)a.Xw[3 * ee + 2];
-        ob[k][0] = (double)a.obs[2 * ee]; ob[k][1] = (double)a.obs[2 * ee + 1];
-        w[k] = (double)a.inv_sigma2[ee];
+        if (a.e_kp) {  // indexed: the frame's keypoint and the map table's row, in place
+            const int kp = a.e_kp[ee], sl = a.e_slot[ee];
+            X[k][0] = (double)a.map_Xw[3 * (size_t)sl]; X[k][1] = (double)a.map_Xw[3 * (size_t)sl + 1]; X[k][2] = (double)a.map_Xw[3 * (size_t)sl + 2];
+            const float2 o = a.kp_xy_un[kp];
+            ob[k][0] = (double)o.x; ob[k][1] = (double)o.y;
+            const int oc = a.kp_octave[kp];
+            float ws = a.lvl_inv_sigma2[0];  // (a select chain: a run-time index into the argument block would go through scratch)
+#pragma unroll
+            for (int l = 1; l < 8; l++) ws = oc == l ? a.lvl_inv_sigma2[l] : ws;
+            w[k] = (double)ws;
+        } else {
+            X[k][0] = (double)a.Xw[3 * ee]; X[k][1] = (double)a.Xw[3 * ee + 1]; X[k][2] = (double)a.Xw[3 * ee + 2];
+            ob[k][0] = (double)a.obs[2 * ee]; ob[k][1] = (double)a.obs[2 * ee + 1];
+            w[k] = (double)a.inv_sigma2[ee];
+        }
         er[k][0] = 0.0; er[k][1] = 0.0;
     }
     int robust = 1, parity = 0;
@@ -2400,7 +2408,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
     SO_POSE_TICK_DECL;
 
     // One pass over the active edges at pose T; the block totals land in this wave's s_sysw[wv][which].
-    auto edge_phase = [&](const BaPose& T, int which) {
+    auto edge_phase = [&](const BaPose& T, int which) __attribute__((always_inline)) {
         SO_POSE_TICK(6);  // everything since the last tick: decision + solve + SE3 update, round set-up
         double R[9];
         quat_to_R(T.q, R);
@@ -2503,7 +2511,7 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
     BaPose cur = a.init, trial = a.init;
     double lambda = 0.0, ni = 2.0, currentChi = 0.0, iniChi = 0.0, scale = 1.0, inv_scale = 1.0;
     int qmax = 0, it = 0, nBadLM = 0, solve_ok = 1, its_total = 0, trials_total = 0, cursys = 0, nbad_total = 0;
-    auto propose = [&]() {
+    auto propose = [&]() __attribute__((always_inline)) {
         SO_POSE_TICK(4);  // decision (since the cross-wave sum)
         const double* S = s_sysw[wv][cursys];
         double Su[21], b[6], x[6];
@@ -2666,6 +2674,56 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
 }
 
 template <int THREADS, int EPT>
+__global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, const PoseOptArgs* __restrict__ batch) {
+    // batch != null: workgroup b solves problem batch[b] (so_pose_optimization_batch: several agents' frames, or the
+    // independent problems of one frame, in ONE launch - a workgroup per problem, nothing shared between them)
+    const PoseOptArgs a = batch ? batch[blockIdx.x] : a0;
+    pose_opt_reg_body<THREADS, EPT>(a, a.n);
+}
+
+// The PoseOptimization call of a tracking stage whose search was resolved on the device: the number of edges is a device
+// word (TrackResolveArgs::head), so the body that fits it is chosen here instead of at the launch.  Three bodies per
+// kernel: with four and more in one function the compiler no longer keeps the 256-byte argument block out of scratch
+// memory.  RANGE 0: up to 1024 edges (2 / 3 / 4 per thread), RANGE 1: 1025 .. 1792 (5 / 6 / 7); the host launches the range
+// the stage's last call needed, and a count outside it is answered with info[0] = -1 (the caller takes the host path).
+template <int RANGE>
+__global__ __launch_bounds__(256) void pose_opt_chain_kernel(PoseOptArgs a0) {
+    const PoseOptArgs a = a0;
+    const int n = a0.head[0];
+    const bool fits = RANGE == 0 ? n <= 1024 : (n > 1024 && n <= kPoseChainMaxEdges);
+    if (a0.head[2] != 0 || n < 3 || !fits) {
+        // nothing optimised: the resolve gave up / the count is outside this kernel's range (-1), or fewer than three
+        // edges (-2: Optimizer.cc:344-345 returns without touching the frame)
+        if (threadIdx.x == 0) {
+            *a.pose_out = a.init;
+            a.info[0] = (a0.head[2] == 0 && n < 3) ? -2 : -1;
+            a.info[1] = 0;
+            a.info[2] = 0;
+            if (a.done_seq) {
+                __threadfence_system();
+                __hip_atomic_store(&a.info[3], a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    const int ept = (n + 255) >> 8;
+    if (RANGE == 0) {
+        if (ept <= 2) pose_opt_reg_body<256, 2>(a, n);
+        else if (ept == 3) pose_opt_reg_body<256, 3>(a, n);
+        else pose_opt_reg_body<256, 4>(a, n);
+    } else {
+        if (ept == 5) pose_opt_reg_body<256, 5>(a, n);
+        else if (ept == 6) pose_opt_reg_body<256, 6>(a, n);
+        else pose_opt_reg_body<256, 7>(a, n);
+    }
+}
+
+void launch_pose_opt_chain(const PoseOptArgs& a, int range, hipStream_t s) {
+    if (range == 0) hipLaunchKernelGGL(pose_opt_chain_kernel<0>, dim3(1), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pose_opt_chain_kernel<1>, dim3(1), dim3(256), 0, s, a);
+}
+
+template <int THREADS, int EPT>
 static void launch_pose_reg(const PoseOptArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((pose_opt_reg_kernel<THREADS, EPT>), dim3(1), dim3(THREADS), 0, s, a, (const PoseOptArgs*)nullptr);
 }
@@ -2680,8 +2738,9 @@ bool launch_pose_opt_batch(const PoseOptArgs* d_args, int n_problems, int max_n,
     if (n_problems <= 0) return true;
     if (max_n > 3072) return false;  // the register-resident kernel holds 12 edges per thread
     switch ((max_n + 255) / 256) {
-        case 0: case 1: launch_pose_reg_batch<1>(d_args, n_problems, s); break;
-        case 2: launch_pose_reg_batch<2>(d_args, n_problems, s); break;
+        // (up to 512 points: two edges per thread - pose_opt_chain_kernel has no one-edge body, and the single, the batched
+        //  and the chained launch of a problem must add their sums in the same order: the lockstep / chain tests compare bits)
+        case 0: case 1: case 2: launch_pose_reg_batch<2>(d_args, n_problems, s); break;
         case 3: launch_pose_reg_batch<3>(d_args, n_problems, s); break;
         case 4: launch_pose_reg_batch<4>(d_args, n_problems, s); break;
         case 5: launch_pose_reg_batch<5>(d_args, n_problems, s); break;
@@ -2715,8 +2774,7 @@ void launch_pose_opt(const PoseOptArgs& a, hipStream_t s) {
         const bool wide = force_threads == 512;
         if (!wide && a.n <= 1024) {
             const int ept = (a.n + 255) / 256;
-            if (ept <= 1) launch_pose_reg<256, 1>(a, s);
-            else if (ept == 2) launch_pose_reg<256, 2>(a, s);
+            if (ept <= 2) launch_pose_reg<256, 2>(a, s);  // (<= 256 points too: see launch_pose_opt_batch)
             else if (ept == 3) launch_pose_reg<256, 3>(a, s);
             else launch_pose_reg<256, 4>(a, s);
         } else {

@@ -40,6 +40,7 @@ int allocate(so_dframe* f, int capacity) {
     const size_t o_col = o; o += up256(4 * (kFrameGridCols + 1));
     const size_t o_ni = o; o += 256;
     const size_t o_b = o; o += 256;
+    const size_t o_ang = o; o += up256(4 * c);
     SO_HIP(hipMalloc((void**)&f->d_block, o));
     SO_HIP(so::memset_sync(f->d_block, 0, o));
     uint8_t* d = f->d_block;
@@ -54,6 +55,7 @@ int allocate(so_dframe* f, int capacity) {
     f->d_col_start = (int32_t*)(d + o_col);
     f->d_n_inside = (int32_t*)(d + o_ni);
     f->d_bounds = (float*)(d + o_b);
+    f->d_angle = (float*)(d + o_ang);
     const size_t h_xy = 0, h_perm = up256(8 * c), h_hdr = h_perm + up256(4 * c), h_total = h_hdr + 256;
     SO_HIP(hipHostMalloc((void**)&f->h_block, h_total, hipHostMallocMapped));
     SO_HIP(hipHostGetDevicePointer((void**)&f->h_block_dev, f->h_block, 0));
@@ -129,6 +131,8 @@ int prepare_args(so_dframe* f, int w, int h, FramePrepareArgs* out) {
     for (int l = 0; l < 8; l++) a.scale[l] = V.scale[l];
     a.octave = f->d_octave;
     a.desc_by_index = reinterpret_cast<uint4*>(f->d_desc);
+    a.ex_angle = V.angle;
+    a.angle_by_index = f->d_angle;
     a.xy_un_host = reinterpret_cast<float*>(f->h_block_dev + ((uint8_t*)f->h_xy_un - f->h_block));
     a.s_xy = f->d_s_xy;
     a.s_octave = f->d_s_octave;

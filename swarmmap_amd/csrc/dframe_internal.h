@@ -43,6 +43,7 @@ struct so_dframe {
     float2* d_xy_un = nullptr;
     int8_t* d_octave = nullptr;
     uint8_t* d_desc = nullptr;
+    float* d_angle = nullptr;   // by keypoint index
     int32_t* d_cell_start = nullptr;
     int32_t* d_cell_items = nullptr;
     float2* d_s_xy = nullptr;

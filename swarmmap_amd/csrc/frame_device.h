@@ -35,6 +35,8 @@ struct FramePrepareArgs {
     float scale[8];            // mvScaleFactor
     int8_t* octave;            // by keypoint index
     uint4* desc_by_index;      // the frame's own copy of the descriptors (the extractor's buffer is reused by the next frame)
+    const float* ex_angle;     // n: the extractor's keypoint angles (may be null)
+    float* angle_by_index;     // the frame's own copy (the device-side resolve of TrackWithMotionModel's rotation check reads it)
     float* xy_un_host;         // host-mapped mirror of xy_un (may be null)
     float2* s_xy;              // candidates in grid-traversal order (cell x, cell y, index): position = tie-break rank
     int8_t* s_octave;

@@ -148,6 +148,8 @@ __device__ __forceinline__ void frame_prepare_body(const FramePrepareArgs& a) {
         const uint4* src = reinterpret_cast<const uint4*>(a.ex_desc);
         for (int j = tid; j < 2 * n; j += 1024) a.desc_by_index[j] = src[j];
     }
+    if (a.angle_by_index && a.ex_angle)
+        for (int j = tid; j < n; j += 1024) a.angle_by_index[j] = a.ex_angle[j];
     if (a.header_host && tid == 0) {
         a.header_host[0] = n;
         a.header_host[2] = 0;

@@ -100,6 +100,47 @@ struct TrackQuerySrc {
     uint32_t skip_bits[kTrackMaxQueryBits / 32];
 };
 
+// The order-dependent half of the two tracking searches on the device (round 5).  The reference walks the map points in order and
+// a point takes the best candidate keypoint no EARLIER point has taken (ORBmatcher.cc:83-85 in SearchByProjection(Frame,
+// vpMapPoints), :1294-1296 in SearchByProjection(CurrentFrame, LastFrame)); the host loops of so_track_search_*_wait do
+// exactly that over the K-lists.  track_resolve_kernel reproduces the sequential result in parallel rounds:
+//   every unresolved query claims all the still-free entries of its K-list (atomicMin of its rank); a query whose first
+//   one / two free entries - the ones its decision reads - are claimed by no query of lower rank cannot be affected by
+//   anything still undecided (taken entries only accumulate, and a lower query can only ever take an entry it claims), so
+//   its decision is final: distance / ratio / level tests as in the reference, and its keypoint is marked taken.  The lowest
+//   unresolved query is always final, so the rounds end; conflicts are local (queries whose windows overlap), a handful of
+//   rounds in practice.  A query that runs out of list entries with more candidates in its window raises `fallback`
+//   (the host then resolves the call the old way).
+// Behind the matches: TrackWithMotionModel's rotation-consistency check (ORBmatcher.cc:1319-1350), the frame's bindings
+// (entry bindings + new matches) and the edge list of the PoseOptimization call that follows (keypoints with a map point,
+// ascending index - pose_opt_chain_kernel reads it in place).
+constexpr int kResolveMaxCand = 4096;     // keypoints of the current frame the kernel holds in LDS
+constexpr int kResolveMaxQueries = 4096;  // queries (map points of the last frame / of the local map) of one search
+struct TrackResolveArgs {
+    const uint32_t* keys;        // [K][nq]
+    const uint8_t* cnt8;         // candidates per query, clamped to 255
+    int nq, K;
+    int mode;                    // 2: last-frame search (one candidate, <= TH_HIGH), 3: local-map search (two + ratio / level test)
+    float nn_ratio;
+    int n_cand;                  // candidate positions (the current frame's keypoints inside the grid)
+    int n_kp;                    // keypoints of the current frame
+    const int8_t* s_octave;      // by candidate position
+    const int32_t* cell_items;   // candidate position -> keypoint index
+    int check_orientation;
+    const float* q_angle;        // last frame's keypoint angles (query i = keypoint i of the last frame)
+    const float* cur_angle;      // current frame's, by keypoint index
+    const int32_t* q_slot;       // query -> map slot (null: slot_base + query)
+    int slot_base;
+    const int32_t* kp_slot_in;   // bindings on entry by keypoint index (null: none)
+    int32_t* kp_to_q;            // [n_kp] out (host-mapped): query matched to keypoint k, -1 none
+    int32_t* e_kp;               // edge list out (device)
+    int32_t* e_slot;
+    int32_t* e_kp_host;          // host-mapped copy of e_kp
+    int32_t* head;               // device: {n_edges, nmatches, fallback, rounds}
+    int32_t* head_host;          // host-mapped copy
+};
+void launch_track_resolve(const TrackResolveArgs& a, hipStream_t s);
+
 // Projection + gating half of the keyframe-side map-point searches: Fuse (code/src/
 // ORBmatcher.cc:767-815), Fuse / SearchByProjection with a Sim3 (:916-964, :286-333), one direction of SearchBySim3
 // (:1054-1094, :1130-1170) and SearchByProjection(Frame, KeyFrame, ...) (:1374-1410).  project_queries_kernel turns

@@ -913,6 +913,285 @@ void launch_exchange_fill_slot(const uint4* d_desc, int n, int slot_keypoints, i
     hipLaunchKernelGGL(exchange_fill_slot_kernel, dim3(1), dim3(1024), 0, s, d_desc, n, slot_keypoints, rank, d_slot);
 }
 
+// ---------------- the tracking searches' order-dependent resolve on the device (match_device.h: TrackResolveArgs) ----------------
+// One workgroup of 1024 threads; thread t owns the queries t, t + 1024, ... (a query's rank in the reference's walk is its
+// index) and keeps their K-lists in registers for all rounds.  Everything the kernel reads from memory - the lists, the
+// counts, the position -> keypoint map, the angles, the map slots, the bindings on entry (some of it in pinned host
+// memory) - is requested up front, so the launch pays ONE memory latency before the rounds and none after them (the first
+// version read them where it needed them: seven dependent latencies, 22 us per launch).
+// LDS: claim / taken per candidate position (2 x 16 KB), the current frame's angle per position (16 KB), keypoint index per
+// position (8 KB).
+namespace {
+constexpr int kResK = 8;
+constexpr int kResTH_HIGH = 100, kResHisto = 30;  // ORBmatcher.cc:37-39
+
+// ordered compaction helper: exclusive rank of `flag` among the threads of the block (thread order), block total in *total
+template <int kResThreads>
+__device__ __forceinline__ int block_rank(bool flag, int* s_wave /* >= 17 ints */, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s_wave[w] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < kResThreads / 64; i++) {
+        const int c = s_wave[i];
+        if (i < w) base += c;
+        tot += c;
+    }
+    *total = tot;
+    return base + before;
+}
+}  // namespace
+
+// kResThreads x kResQPT queries: the host launches the instance that holds the search (1024 threads up to 2048 queries;
+// beyond, 512 threads with twice the registers each - the K-lists of six or eight queries per thread stay out of scratch)
+template <int kResThreads, int kResQPT>
+__global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolveArgs a) {
+    constexpr int kResPPT = kResolveMaxCand / kResThreads;
+    __shared__ int s_claim[kResolveMaxCand];
+    __shared__ int s_taken[kResolveMaxCand];
+    __shared__ float s_angle[kResolveMaxCand];
+    __shared__ uint16_t s_item[kResolveMaxCand];
+    __shared__ int s_wave[kResThreads / 64 + 1];
+    __shared__ int s_hist[kResHisto];
+    __shared__ int s_flags[2];  // 0: a query ran out of list entries
+    __shared__ int s_keep[3];
+    const int tid = threadIdx.x;
+    const int nc = a.n_cand, nk = a.n_kp, nq = a.nq;
+    unsigned long long tk[6];  // (diagnostics: 100 MHz ticks at the phase boundaries, head_host[8..12])
+    tk[0] = wall_clock64();
+    const bool orient = a.mode == 2 && a.check_orientation != 0;
+    const int F = a.mode == 3 ? 2 : 1;
+    bool fallback = nc > kResolveMaxCand || nk > kResolveMaxCand || nq > kResQPT * kResThreads || a.K != kResK;
+    // ---- the loads from device memory, issued together: K-lists, counts, position -> keypoint map, angles
+    uint32_t key[kResQPT][kResK];
+    bool un[kResQPT], many[kResQPT];
+    float qang[kResQPT];
+    int qslot[kResQPT], took[kResQPT];
+    int n_active_local = 0;
+#pragma unroll
+    for (int u = 0; u < kResQPT; u++) {
+        const int i = tid + u * kResThreads;
+        const bool in = !fallback && i < nq;
+        const int c8 = in ? (int)a.cnt8[i] : 0;
+#pragma unroll
+        for (int k = 0; k < kResK; k++) key[u][k] = in ? a.keys[(size_t)k * nq + i] : 0xFFFFFFFFu;
+        qang[u] = (orient && in) ? a.q_angle[i] : 0.f;
+        un[u] = c8 != 0;
+        many[u] = c8 > kResK;
+        took[u] = -1;
+        n_active_local += un[u] ? 1 : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < kResPPT; j++) {
+        const int p = tid + j * kResThreads;
+        int item = 0;
+        float ang = 0.f;
+        if (!fallback && p < nc) {
+            item = a.cell_items[p];
+            if (orient) ang = a.cur_angle[item];
+        }
+        s_item[p] = (uint16_t)item;
+        s_angle[p] = ang;
+        s_claim[p] = 0x7FFFFFFF;
+        s_taken[p] = -1;
+    }
+    if (tid < 2) s_flags[tid] = 0;
+    if (tid < kResHisto) s_hist[tid] = 0;
+    __syncthreads();
+    // ---- the loads from HOST memory (the queries' map slots sit in the search's pinned staging, the bindings on entry in the
+    //      stage's host-mapped block): requested now, needed after the rounds - a PCIe read is 3-4 us, and waiting for a
+    //      device load issued behind it would wait for it too (loads complete in order)
+    int slot_in[kResPPT];
+#pragma unroll
+    for (int u = 0; u < kResQPT; u++) {
+        const int i = tid + u * kResThreads;
+        qslot[u] = (!fallback && i < nq) ? (a.q_slot ? a.q_slot[i] : a.slot_base + i) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kResPPT; j++) {
+        const int p = tid + j * kResThreads;
+        slot_in[j] = (a.kp_slot_in && p < nk) ? a.kp_slot_in[p] : -1;
+    }
+    if (n_active_local) atomicAdd(&s_flags[1], n_active_local);
+    tk[1] = wall_clock64();
+    int rounds = 0;
+    while (!fallback) {
+        // A: every unresolved query looks its list entries up (all reads in flight together) and claims the free ones
+        bool fr[kResQPT][kResK];
+#pragma unroll
+        for (int u = 0; u < kResQPT; u++) {
+            const int rank = tid + u * kResThreads;
+            int tk8[kResK];
+            bool ended = false;
+#pragma unroll
+            for (int k = 0; k < kResK; k++) {
+                const uint32_t kk = key[u][k];
+                ended = ended || kk == 0xFFFFFFFFu;
+                fr[u][k] = un[u] && !ended;
+                tk8[k] = s_taken[fr[u][k] ? (int)(kk & 0xFFFFu) : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < kResK; k++) {
+                fr[u][k] = fr[u][k] && tk8[k] < 0;  // ORBmatcher.cc:83-85 / 1294-1296: a taken keypoint is passed over
+                if (fr[u][k]) atomicMin(&s_claim[key[u][k] & 0xFFFFu], rank);
+            }
+        }
+        __syncthreads();
+        // B: decisions of the queries nothing undecided can reach (`taken` has not changed since A).  No early exits: every
+        // entry is looked at under predicates (a loop with break / continue over the register-resident K-list came out of
+        // the compiler deciding "no candidate" for every two-candidate query).
+        int take[kResQPT];
+#pragma unroll
+        for (int u = 0; u < kResQPT; u++) {
+            const int rank = tid + u * kResThreads;
+            int found = 0, pos0 = 0, pos1 = 0, d0 = 256, d1 = 256;
+            bool ended = false;
+#pragma unroll
+            for (int k = 0; k < kResK; k++) {
+                const uint32_t kk = key[u][k];
+                ended = ended || kk == 0xFFFFFFFFu;
+                const bool free_ = fr[u][k] && found < F;
+                if (free_ && found == 0) { pos0 = (int)(kk & 0xFFFFu); d0 = (int)(kk >> 16); }
+                if (free_ && found == 1) { pos1 = (int)(kk & 0xFFFFu); d1 = (int)(kk >> 16); }
+                found += free_ ? 1 : 0;
+            }
+            // fewer candidates than the decision reads, all K entries real, more in the window: the list is too short
+            const bool exhausted = un[u] && found < F && !ended && many[u];
+            if (exhausted) atomicOr(&s_flags[0], 1);
+            const int cl0 = s_claim[found >= 1 ? pos0 : 0], cl1 = s_claim[found >= 2 ? pos1 : 0];
+            const bool c0 = found >= 1 && cl0 == rank, c1 = found >= 2 && cl1 == rank;
+            const bool stable = un[u] && !exhausted && (found == 0 || (c0 && (found < 2 || c1)));
+            bool ok = stable && found >= 1 && d0 <= kResTH_HIGH;
+            if (F == 2 && ok) {
+                const int l0 = a.s_octave[pos0], l1 = found > 1 ? (int)a.s_octave[pos1] : -1;
+                if (l0 == l1 && (float)d0 > a.nn_ratio * (float)d1) ok = false;  // ORBmatcher.cc:112-113
+            }
+            if (stable || exhausted) un[u] = false;
+            take[u] = ok ? pos0 : -1;
+        }
+        __syncthreads();
+        // C: the final queries take their keypoints; every query clears what it claimed
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < kResQPT; u++) {
+            if (take[u] >= 0) {
+                s_taken[take[u]] = tid + u * kResThreads;
+                took[u] = take[u];
+            }
+#pragma unroll
+            for (int k = 0; k < kResK; k++)
+                if (fr[u][k]) s_claim[key[u][k] & 0xFFFFu] = 0x7FFFFFFF;
+            any = any || un[u];
+        }
+        rounds++;
+        if (!__syncthreads_or(any ? 1 : 0)) break;
+        if (s_flags[0]) break;
+    }
+    __syncthreads();
+    tk[2] = wall_clock64();
+    fallback = fallback || s_flags[0] != 0;
+    // ---- TrackWithMotionModel's rotation check (ORBmatcher.cc:1319-1350) by the queries' owners
+    if (!fallback && orient) {
+        int bin[kResQPT];
+#pragma unroll
+        for (int u = 0; u < kResQPT; u++) {
+            bin[u] = -1;
+            if (took[u] < 0) continue;
+            float rot = qang[u] - s_angle[took[u]];
+            if (rot < 0.0f) rot += 360.0f;
+            int b = (int)roundf(rot * (1.0f / kResHisto));
+            if (b == kResHisto) b = 0;
+            bin[u] = b;
+            atomicAdd(&s_hist[b], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // ComputeThreeMaxima (ORBmatcher.cc:1629-1688): its strict comparisons pick the three largest non-empty bins,
+            // the earlier bin first among equals - lane i ranks bin i against the others instead of one lane walking all thirty
+            const int mine = tid < kResHisto ? s_hist[tid] : 0;
+            int rank = 0;
+            for (int j = 0; j < kResHisto; j++) {
+                const int o = s_hist[j];
+                rank += (o > mine || (o == mine && j < tid)) ? 1 : 0;
+            }
+            if (tid < 3) s_keep[tid] = -1;
+            __builtin_amdgcn_wave_barrier();
+            if (tid < kResHisto && mine > 0 && rank < 3) s_keep[rank] = tid;
+            __builtin_amdgcn_wave_barrier();
+            if (tid == 0) {
+                const int i1 = s_keep[0], i2 = s_keep[1], i3 = s_keep[2];
+                const int max1 = i1 >= 0 ? s_hist[i1] : 0, max2 = i2 >= 0 ? s_hist[i2] : 0, max3 = i3 >= 0 ? s_hist[i3] : 0;
+                if ((float)max2 < 0.1f * (float)max1) { s_keep[1] = -1; s_keep[2] = -1; }
+                else if ((float)max3 < 0.1f * (float)max1) { s_keep[2] = -1; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kResQPT; u++)
+            if (bin[u] >= 0 && bin[u] != s_keep[0] && bin[u] != s_keep[1] && bin[u] != s_keep[2]) took[u] = -1;
+    }
+    // ---- by keypoint index: the query matched to it (s_claim) and that query's map slot (s_taken)
+    __syncthreads();
+    tk[3] = wall_clock64();
+#pragma unroll
+    for (int j = 0; j < kResPPT; j++) {
+        s_claim[tid + j * kResThreads] = -1;
+        s_taken[tid + j * kResThreads] = -1;
+    }
+    __syncthreads();
+    if (!fallback) {
+#pragma unroll
+        for (int u = 0; u < kResQPT; u++)
+            if (took[u] >= 0) {
+                const int kp = s_item[took[u]];
+                s_claim[kp] = tid + u * kResThreads;
+                s_taken[kp] = qslot[u];
+            }
+    }
+    __syncthreads();
+    // ---- kp_to_q out, the frame's bindings, the edge list (keypoints with a map point, ascending index)
+    tk[4] = wall_clock64();
+    int n_edges = 0, n_match = 0;
+#pragma unroll
+    for (int j = 0; j < kResPPT; j++) {
+        const int k = tid + j * kResThreads;
+        if (j * kResThreads >= nk) break;  // (uniform)
+        int q = -1, slot = -1;
+        if (k < nk) {
+            q = s_claim[k];
+            a.kp_to_q[k] = q;
+            slot = slot_in[j] >= 0 ? slot_in[j] : (q >= 0 ? s_taken[k] : -1);
+        }
+        int tot_e, tot_m;
+        const int re = block_rank<kResThreads>(slot >= 0, s_wave, &tot_e);
+        if (slot >= 0) {
+            a.e_kp[n_edges + re] = k;
+            a.e_slot[n_edges + re] = slot;
+            a.e_kp_host[n_edges + re] = k;
+        }
+        (void)block_rank<kResThreads>(q >= 0, s_wave, &tot_m);
+        n_edges += tot_e;
+        n_match += tot_m;
+    }
+    if (tid == 0) {
+        a.head[0] = n_edges; a.head[1] = n_match; a.head[2] = fallback ? 1 : 0; a.head[3] = rounds;
+        a.head_host[0] = n_edges; a.head_host[1] = n_match; a.head_host[2] = fallback ? 1 : 0; a.head_host[3] = rounds;
+        a.head_host[4] = s_flags[1];  // (diagnostics: queries with candidates)
+        tk[5] = wall_clock64();
+        for (int i = 0; i < 5; i++) a.head_host[8 + i] = (int)(tk[i + 1] - tk[i]);
+    }
+}
+
+void launch_track_resolve(const TrackResolveArgs& a, hipStream_t s) {
+    if (a.nq <= 1024) hipLaunchKernelGGL((track_resolve_kernel<1024, 1>), dim3(1), dim3(1024), 0, s, a);
+    else if (a.nq <= 2048) hipLaunchKernelGGL((track_resolve_kernel<1024, 2>), dim3(1), dim3(1024), 0, s, a);
+    else if (a.nq <= 3072) hipLaunchKernelGGL((track_resolve_kernel<512, 6>), dim3(1), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((track_resolve_kernel<512, 8>), dim3(1), dim3(512), 0, s, a);  // (more than 4096 queries: the kernel reports fallback)
+}
+
 void launch_hamming_top2(const uint4* d_A, int na, const uint4* d_B, int nb, int32_t* d_best_idx,
                          int32_t* d_best_dist, int32_t* d_second_dist, hipStream_t s) {
     if (na <= 0) return;

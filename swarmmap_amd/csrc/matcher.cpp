@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <climits>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include <mutex>
 #include <vector>
 
+#include "ba_device.h"
 #include "dframe_internal.h"
 #include "match_device.h"
 #include "so_common.h"
@@ -191,6 +193,25 @@ struct so_matcher {
     float min_x = 0.f, min_y = 0.f, grid_inv_w = 0.f, grid_inv_h = 0.f;
     float grid_min_y = 0.f, grid_min_x = 0.f;  // origin the resident candidates' cells were assigned with
     std::vector<int> perm;     // rank -> keypoint index
+    // ---- a tracking stage resolved on the device (so_track_stage_*): search -> track_resolve_kernel -> pose_opt_chain_kernel
+    DevBuf d_chain;     // [K-lists | counts | edge keypoints | edge slots | head]
+    MappedBuf h_chain;  // [kp_to_q | edge keypoints | head | pose 64 | info 16 | outlier flags | bindings on entry]
+    uint32_t* keys_dev_override = nullptr;  // where the next tracking search writes its K-lists instead of h_out
+    uint8_t* cnt8_dev_override = nullptr;   // ... and its one-byte candidate counts
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    int chain_seq = 0;
+    int chain_range[2] = {0, 0};  // PoseOptimization variant (0: <= 1024 edges, 1: more) each stage kind needed last time
+    struct ChainPending {
+        bool active = false;
+        int kind = 0;  // 0: last-frame stage, 1: local-map stage, 2: the pose again over the same edges
+        int n_kp = 0, nq = 0, seq = 0;
+        bool events = false, valid_edges = false;
+        size_t h_k2q = 0, h_ekp = 0, h_head = 0, h_pose = 0, h_info = 0, h_outl = 0, h_slot_in = 0;
+        float Tcw_in[12];
+        const so_map* map = nullptr;  // the table the pose kernel reads its points from
+        bool holds_map = false;       // pose_again: held shared until the wait (a stage holds it through its search)
+    } chain;
+    so::PoseOptArgs chain_pose;  // the last stage's PoseOptimization launch (pose_again: another start pose, same edges)
     std::vector<int> cell_count;
 
     // ---- so_matcher_batch_begin / _end: independent calls staged side by side, launched together ----
@@ -866,6 +887,10 @@ void so_matcher_destroy(so_matcher* m) {
     m->h_out.release();
     m->h_rout.release();
     m->hb_in.release(); m->db_in.release(); m->db_q.release(); m->hb_out.release();
+    m->d_chain.release();
+    m->h_chain.release();
+    if (m->pe0) (void)hipEventDestroy(m->pe0);
+    if (m->pe1) (void)hipEventDestroy(m->pe1);
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
     if (m->owns_stream && m->stream) (void)hipStreamDestroy(m->stream);
@@ -3256,7 +3281,7 @@ int launch_topk_track_async(so_matcher* m, TrackQuerySrc& T, int mode, int nq, i
         T.skip = G.skip ? d + off_skip : nullptr;
     }
     if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
-    launch_topk_track(frame_dev(m), T, mode, 0, nq, K, (uint32_t*)m->h_out.dev,
+    launch_topk_track(frame_dev(m), T, mode, 0, nq, K, m->keys_dev_override ? m->keys_dev_override : (uint32_t*)m->h_out.dev,
                       (int32_t*)((uint8_t*)m->h_out.dev + keys_bytes), s);
     if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
     SO_HIP(hipGetLastError());
@@ -3376,7 +3401,7 @@ int so_track_search_last_frame_submit(so_matcher* m, const so_dframe* cur, const
     const size_t keys_bytes2 = align256(sizeof(uint32_t) * (size_t)n_last * K);
     P.c8_off = align256(keys_bytes2 + sizeof(int32_t) * (size_t)n_last);
     if ((rc = m->h_out.ensure(P.c8_off + (size_t)n_last))) { P.mode = 0; return rc; }
-    P.T.count8_out = (uint8_t*)m->h_out.dev + P.c8_off;
+    P.T.count8_out = m->cnt8_dev_override ? m->cnt8_dev_override : (uint8_t*)m->h_out.dev + P.c8_off;
     if ((rc = launch_topk_track_async(m, P.T, 2, n_last, K, G))) { P.mode = 0; return rc; }
     P.empty = false;
     return SO_OK;
@@ -3527,7 +3552,7 @@ int so_track_search_local_map_submit(so_matcher* m, const so_dframe* cur, const 
     P.c8_off = align256(P.view_off + (size_t)n_local);
     if ((rc = m->h_out.ensure(P.c8_off + (size_t)n_local))) { P.mode = 0; return rc; }
     P.T.in_view_out = (uint8_t*)m->h_out.dev + P.view_off;
-    P.T.count8_out = (uint8_t*)m->h_out.dev + P.c8_off;
+    P.T.count8_out = m->cnt8_dev_override ? m->cnt8_dev_override : (uint8_t*)m->h_out.dev + P.c8_off;
     const TrackGates G{local_slot, local_slot ? 0 : first_slot, skip, cur_excluded};
     if ((rc = launch_topk_track_async(m, P.T, 3, n_local, K, G))) { P.mode = 0; return rc; }
     P.empty = false;
@@ -3621,6 +3646,345 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
                                                     th, nn_ratio, viewing_cos_limit, log_scale_factor);
     if (rc) return rc;
     return so_track_search_local_map_wait(m, slot_has_obs, in_view, kp_to_local, nmatches);
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// A tracking stage without a host hop (include/swarmorb.h: so_track_stage_*): the plain search's launch, then the
+// order-dependent resolve on the device (match_kernels.hip: track_resolve_kernel) and the PoseOptimization kernel over
+// the edges it lists (ba_kernels.hip: pose_opt_chain_kernel), all on the matcher's stream; the host waits for the pose's
+// completion word.
+// =====================================================================================================
+namespace {
+
+struct ChainOffsets {
+    size_t d_keys, d_cnt8, d_ekp, d_eslot, d_head, d_total;
+    size_t h_k2q, h_ekp, h_head, h_pose, h_info, h_outl, h_slot_in, h_total;
+};
+
+ChainOffsets chain_offsets(int nq, int K, int nk) {
+    ChainOffsets o{};
+    size_t d = 0;
+    o.d_keys = d; d += align256(sizeof(uint32_t) * (size_t)nq * (size_t)K);
+    o.d_cnt8 = d; d += align256((size_t)nq);
+    o.d_ekp = d; d += align256(sizeof(int32_t) * (size_t)nk);
+    o.d_eslot = d; d += align256(sizeof(int32_t) * (size_t)nk);
+    o.d_head = d; d += 256;
+    o.d_total = d;
+    size_t h = 0;
+    o.h_k2q = h; h += align256(sizeof(int32_t) * (size_t)nk);
+    o.h_ekp = h; h += align256(sizeof(int32_t) * (size_t)nk);
+    o.h_head = h; h += 256;
+    o.h_pose = h; h += 256;
+    o.h_info = h; h += 256;
+    o.h_outl = h; h += align256((size_t)nk + 16);
+    o.h_slot_in = h; h += align256(sizeof(int32_t) * (size_t)nk);
+    o.h_total = h;
+    return o;
+}
+
+// resolve + pose behind a search that has just been launched (m->pend holds it)
+int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe* cur, const so_dframe* last, const so_map* map,
+                 const float* Tcw12, int check_orientation, const int32_t* kp_slot_in_dev, const float* intr4,
+                 const float* level_inv_sigma2) {
+    so_matcher::PendingTrack& P = m->pend;
+    uint8_t* d = (uint8_t*)m->d_chain.p;
+    uint8_t* hd = (uint8_t*)m->h_chain.dev;
+    hipStream_t s = m->stream;
+    so::TrackResolveArgs R{};
+    R.keys = (const uint32_t*)(d + O.d_keys);
+    R.cnt8 = d + O.d_cnt8;
+    R.nq = P.nq;
+    R.K = 8;
+    R.mode = P.mode;
+    R.nn_ratio = P.nn_ratio;
+    R.n_cand = m->n_cand;
+    R.n_kp = cur->n;
+    R.s_octave = cur->d_s_octave;
+    R.cell_items = cur->d_cell_items;
+    R.check_orientation = check_orientation;
+    R.q_angle = last ? last->d_angle : nullptr;
+    R.cur_angle = cur->d_angle;
+    R.q_slot = P.T.slot;
+    R.slot_base = P.T.slot_base;
+    R.kp_slot_in = kp_slot_in_dev;
+    R.kp_to_q = (int32_t*)(hd + O.h_k2q);
+    R.e_kp = (int32_t*)(d + O.d_ekp);
+    R.e_slot = (int32_t*)(d + O.d_eslot);
+    R.e_kp_host = (int32_t*)(hd + O.h_ekp);
+    R.head = (int32_t*)(d + O.d_head);
+    R.head_host = (int32_t*)(hd + O.h_head);
+    so::launch_track_resolve(R, s);
+    so::PoseOptArgs& A = m->chain_pose;
+    A = so::PoseOptArgs{};
+    A.Xw = nullptr; A.obs = nullptr; A.inv_sigma2 = nullptr;
+    for (int k = 0; k < 4; k++) A.K[k] = (double)intr4[k];
+    so::pose_from_Tcw12(Tcw12, A.init);
+    A.n = 0;
+    A.err = nullptr;
+    A.outlier = hd + O.h_outl;
+    A.pose_out = reinterpret_cast<so::BaPose*>(hd + O.h_pose);
+    A.info = reinterpret_cast<int*>(hd + O.h_info);
+    A.trace = nullptr;
+    A.e_kp = R.e_kp;
+    A.e_slot = R.e_slot;
+    A.head = R.head;
+    A.map_Xw = map->d_Xw;
+    A.kp_xy_un = cur->d_xy_un;
+    A.kp_octave = cur->d_octave;
+    for (int l = 0; l < 8; l++) A.lvl_inv_sigma2[l] = l < cur->nlevels ? level_inv_sigma2[l] : 0.f;
+    so_matcher::ChainPending& C = m->chain;
+    C = so_matcher::ChainPending{};
+    C.active = true;
+    C.kind = kind;
+    C.n_kp = cur->n;
+    C.nq = P.nq;
+    C.h_k2q = O.h_k2q; C.h_ekp = O.h_ekp; C.h_head = O.h_head; C.h_pose = O.h_pose; C.h_info = O.h_info; C.h_outl = O.h_outl;
+    C.h_slot_in = O.h_slot_in;
+    memcpy(C.Tcw_in, Tcw12, 48);
+    C.map = map;
+    if (++m->chain_seq == 0) m->chain_seq = 1;
+    C.seq = m->chain_seq;
+    A.done_seq = C.seq;
+    reinterpret_cast<volatile int*>((uint8_t*)m->h_chain.p + O.h_info)[3] = 0;
+    memset((uint8_t*)m->h_chain.p + O.h_head, 0, 64);
+    std::atomic_thread_fence(std::memory_order_release);
+    C.events = m->profile;
+    if (C.events) {
+        if (!m->pe0) SO_HIP(hipEventCreate(&m->pe0));
+        if (!m->pe1) SO_HIP(hipEventCreate(&m->pe1));
+        SO_HIP(hipEventRecord(m->pe0, s));
+    }
+    so::launch_pose_opt_chain(A, m->chain_range[kind], s);
+    if (C.events) SO_HIP(hipEventRecord(m->pe1, s));
+    SO_HIP(hipGetLastError());
+    return SO_OK;
+}
+
+int chain_prepare(so_matcher* m, int nq, int nk, ChainOffsets* O) {
+    *O = chain_offsets(nq, 8, nk);
+    int rc;
+    if ((rc = m->d_chain.ensure(O->d_total))) return rc;
+    if ((rc = m->h_chain.ensure(O->h_total))) return rc;
+    m->keys_dev_override = (uint32_t*)((uint8_t*)m->d_chain.p + O->d_keys);
+    m->cnt8_dev_override = (uint8_t*)m->d_chain.p + O->d_cnt8;
+    return SO_OK;
+}
+
+void chain_drop_search(so_matcher* m) {  // a submitted search that will not be waited for by so_track_search_*_wait
+    if (m->pend.held_map) const_cast<so_map*>(m->pend.held_map)->grow_mu.unlock_shared();
+    m->pend.held_map = nullptr;
+    m->pend.mode = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int so_track_stage_last_frame_submit(so_matcher* m, const so_dframe* cur, const so_dframe* last, const so_map* map,
+                                     const float* Tcw12, const int32_t* last_slot, float th, int check_orientation,
+                                     const float* intr4, const float* level_inv_sigma2) {
+    if (!m || !cur || !last || !map || !Tcw12 || !intr4 || !level_inv_sigma2 || m->chain.active) return SO_ERR_INVALID_ARG;
+    if (!cur->ready || !last->ready || last->n <= 0 || cur->n <= 0) return SO_RETRY_ON_HOST;  // nothing to chain: the plain calls handle it
+    SO_HIP(hipSetDevice(m->device));
+    ChainOffsets O;
+    int rc = chain_prepare(m, last->n, cur->n, &O);
+    if (rc == SO_OK) rc = so_track_search_last_frame_submit(m, cur, nullptr, last, map, Tcw12, last_slot, th);
+    m->keys_dev_override = nullptr;
+    m->cnt8_dev_override = nullptr;
+    if (rc != SO_OK) return rc;
+    if (m->pend.empty) {  // nothing was launched
+        chain_drop_search(m);
+        return SO_RETRY_ON_HOST;
+    }
+    rc = chain_launch(m, 0, O, cur, last, map, Tcw12, check_orientation, nullptr, intr4, level_inv_sigma2);
+    if (rc != SO_OK) {
+        (void)hipStreamSynchronize(m->stream);
+        chain_drop_search(m);
+        m->chain.active = false;
+    }
+    return rc;
+}
+
+int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const int32_t* kp_slot, const so_map* map,
+                                    const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
+                                    const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
+                                    float log_scale_factor, const float* intr4, const float* level_inv_sigma2) {
+    if (!m || !cur || !kp_slot || !map || !Tcw12 || !intr4 || !level_inv_sigma2 || n_local < 0 || m->chain.active)
+        return SO_ERR_INVALID_ARG;
+    if (!cur->ready || n_local <= 0 || cur->n <= 0) return SO_RETRY_ON_HOST;
+    SO_HIP(hipSetDevice(m->device));
+    ChainOffsets O;
+    int rc = chain_prepare(m, n_local, cur->n, &O);
+    if (rc != SO_OK) {
+        m->keys_dev_override = nullptr;
+        m->cnt8_dev_override = nullptr;
+        return rc;
+    }
+    // the bindings on entry: the search's excluded set, and edges of the pose problem (the resolve kernel reads them in place)
+    int32_t* slot_in = (int32_t*)((uint8_t*)m->h_chain.p + O.h_slot_in);
+    memcpy(slot_in, kp_slot, sizeof(int32_t) * (size_t)cur->n);
+    static thread_local std::vector<uint8_t> excluded;
+    excluded.resize((size_t)cur->n);
+    for (int k = 0; k < cur->n; k++) excluded[(size_t)k] = kp_slot[k] >= 0 ? 1 : 0;
+    rc = so_track_search_local_map_submit(m, cur, excluded.data(), map, Tcw12, n_local, local_slot, first_slot, skip, th, nn_ratio,
+                                          viewing_cos_limit, log_scale_factor);
+    m->keys_dev_override = nullptr;
+    m->cnt8_dev_override = nullptr;
+    if (rc != SO_OK) return rc;
+    if (m->pend.empty) {
+        chain_drop_search(m);
+        return SO_RETRY_ON_HOST;
+    }
+    rc = chain_launch(m, 1, O, cur, nullptr, map, Tcw12, 0, (const int32_t*)((uint8_t*)m->h_chain.dev + O.h_slot_in), intr4,
+                      level_inv_sigma2);
+    if (rc != SO_OK) {
+        (void)hipStreamSynchronize(m->stream);
+        chain_drop_search(m);
+        m->chain.active = false;
+    }
+    return rc;
+}
+
+int so_track_stage_pose_again_submit(so_matcher* m, const float* Tcw12) {
+    if (!m || !Tcw12 || m->chain.active || !m->chain.valid_edges) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    so_matcher::ChainPending& C = m->chain;
+    so::PoseOptArgs& A = m->chain_pose;
+    so::pose_from_Tcw12(Tcw12, A.init);
+    memcpy(C.Tcw_in, Tcw12, 48);
+    if (++m->chain_seq == 0) m->chain_seq = 1;
+    C.seq = m->chain_seq;
+    A.done_seq = C.seq;
+    reinterpret_cast<volatile int*>((uint8_t*)m->h_chain.p + C.h_info)[3] = 0;
+    std::atomic_thread_fence(std::memory_order_release);
+    const int range_kind = C.kind == 2 ? 1 : C.kind;  // (the edges are the last stage's)
+    C.kind = 2;
+    C.active = true;
+    // the kernel reads the map table in place: no reallocation by another thread's append until the wait
+    const_cast<so_map*>(C.map)->grow_mu.lock_shared();
+    C.holds_map = true;
+    A.map_Xw = C.map->d_Xw;
+    C.events = m->profile;
+    hipStream_t s = m->stream;
+    if (C.events) {
+        if (!m->pe0) SO_HIP(hipEventCreate(&m->pe0));
+        if (!m->pe1) SO_HIP(hipEventCreate(&m->pe1));
+        SO_HIP(hipEventRecord(m->pe0, s));
+    }
+    so::launch_pose_opt_chain(A, m->chain_range[range_kind], s);
+    if (C.events) SO_HIP(hipEventRecord(m->pe1, s));
+    SO_HIP(hipGetLastError());
+    return SO_OK;
+}
+
+int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint8_t* in_view, int32_t* n_edges, int32_t* edge_kp,
+                        uint8_t* edge_outlier, float* Tcw_out12, int32_t* n_inliers, int32_t* info2) {
+    if (!m || !m->chain.active || !n_edges || !edge_kp || !edge_outlier || !Tcw_out12 || !n_inliers) return SO_ERR_INVALID_ARG;
+    so_matcher::ChainPending& C = m->chain;
+    const bool again = C.kind == 2;
+    if (!again && (!kp_to_q || !nmatches)) return SO_ERR_INVALID_ARG;
+    C.active = false;
+    const uint8_t* h = (const uint8_t*)m->h_chain.p;
+    const volatile int* done = reinterpret_cast<const volatile int*>(h + C.h_info) + 3;
+    const auto t1 = std::chrono::steady_clock::now();
+    int rc = SO_OK;
+    for (unsigned long it = 1; *done != C.seq; it++) {
+        if ((it & 0x1fff) == 0) {  // ~0.2 ms of polling: let the stream's completion wake us instead
+            const hipError_t q = hipStreamSynchronize(m->stream);
+            if (q != hipSuccess || *done != C.seq) {
+                last_error_ref() = q != hipSuccess ? std::string("tracking stage: ") + hipGetErrorString(q)
+                                                   : std::string("tracking stage: the pose kernel finished without publishing its results");
+                rc = SO_ERR_HIP;
+            }
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    m->stat[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    so_matcher::PendingTrack P = m->pend;
+    if (!again) chain_drop_search(m);  // the search and everything behind it are done: the map may grow again
+    if (C.holds_map) {
+        const_cast<so_map*>(C.map)->grow_mu.unlock_shared();
+        C.holds_map = false;
+    }
+    if (rc != SO_OK) {
+        C.valid_edges = false;
+        return rc;
+    }
+    if (!again && m->profile) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
+    }
+    int head[4], inf[4];
+    memcpy(head, h + C.h_head, 16);
+    memcpy(inf, h + C.h_info, 16);
+    static const bool stage_debug = getenv("SWARMORB_STAGE_DEBUG") != nullptr;
+    if (stage_debug && !again) {
+        const int* hh = (const int*)(h + C.h_head);
+        fprintf(stderr, "[stage %d] edges %d matches %d fallback %d rounds %d active %d | ticks (10 ns): loads %d rounds %d rotation %d by-keypoint %d out %d\n",
+                C.kind, hh[0], hh[1], hh[2], hh[3], hh[4], hh[8], hh[9], hh[10], hh[11], hh[12]);
+    }
+    const int kind = again ? 1 : C.kind;
+    if (!again) m->chain_range[kind] = head[0] > 1024 ? 1 : 0;  // what the next call of this stage launches
+    *n_edges = 0;
+    *n_inliers = 0;
+    if (info2) info2[0] = info2[1] = 0;
+    if (!again) {
+        *nmatches = 0;
+        if (in_view && P.mode == 3) memcpy(in_view, (const uint8_t*)m->h_out.p + P.view_off, (size_t)P.nq);
+    }
+    if (head[2] != 0 || inf[0] == -1) {  // the resolve gave up, or more edges than the launched variant holds
+        if (!again)
+            for (int k = 0; k < C.n_kp; k++) kp_to_q[k] = -1;
+        C.valid_edges = false;
+        return SO_RETRY_ON_HOST;
+    }
+    C.valid_edges = true;
+    if (!again) {
+        memcpy(kp_to_q, h + C.h_k2q, sizeof(int32_t) * (size_t)C.n_kp);
+        *nmatches = head[1];
+    }
+    const int ne = head[0];
+    *n_edges = ne;
+    memcpy(edge_kp, h + C.h_ekp, sizeof(int32_t) * (size_t)ne);
+    if (inf[0] == -2) {  // fewer than three edges: PoseOptimization returns 0 and touches nothing (Optimizer.cc:344-345)
+        memset(edge_outlier, 0, (size_t)ne);
+        memcpy(Tcw_out12, C.Tcw_in, 48);
+        return SO_OK;
+    }
+    memcpy(edge_outlier, h + C.h_outl, (size_t)ne);
+    so::BaPose Pz;
+    memcpy(&Pz, h + C.h_pose, sizeof(Pz));
+    so::pose_to_Tcw12(Pz, Tcw_out12);
+    *n_inliers = ne - inf[0];
+    if (info2) {
+        info2[0] = inf[1];
+        info2[1] = inf[2];
+    }
+    return SO_OK;
+}
+
+int so_track_stage_last_rounds(so_matcher* m, int32_t* rounds, int32_t* active_queries) {
+    if (!m || !rounds || !m->h_chain.p || m->chain.active) return SO_ERR_INVALID_ARG;
+    const int32_t* head = (const int32_t*)((const uint8_t*)m->h_chain.p + m->chain.h_head);
+    *rounds = head[3];
+    if (active_queries) *active_queries = head[4];
+    if (getenv("SWARMORB_STAGE_DEBUG"))
+        fprintf(stderr, "[stage] edges %d matches %d fallback %d rounds %d active %d | ticks (10 ns): loads %d rounds %d rotation %d by-keypoint %d out %d\n",
+                head[0], head[1], head[2], head[3], head[4], head[8], head[9], head[10], head[11], head[12]);
+    return SO_OK;
+}
+
+int so_track_stage_last_pose_kernel_ms(so_matcher* m, float* ms) {
+    if (!m || !ms) return SO_ERR_INVALID_ARG;
+    *ms = 0.f;
+    // (the wait returns on the kernel's completion word, which precedes the stop event's own completion)
+    if (m->pe0 && m->pe1 && m->chain.events && !m->chain.active && hipEventSynchronize(m->pe1) == hipSuccess)
+        (void)hipEventElapsedTime(ms, m->pe0, m->pe1);
+    return SO_OK;
 }
 
 }  // extern "C"

@@ -36,6 +36,10 @@ def _bind(lib):
                                                              vp, ip]
     lib.so_track_search_last_frame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, f, C.c_int, vp, ip]
     lib.so_track_search_local_map.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, f, f, f, f, vp, vp, ip]
+    lib.so_track_stage_last_frame_submit.argtypes = [vp, vp, vp, vp, vp, vp, f, C.c_int, vp, vp]
+    lib.so_track_stage_local_map_submit.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, vp, f, f, f, f, vp, vp]
+    lib.so_track_stage_pose_again_submit.argtypes = [vp, vp]
+    lib.so_track_stage_wait.argtypes = [vp, vp, ip, vp, ip, vp, vp, vp, ip, vp]
     lib._dframe_bound = True
 
 
@@ -175,6 +179,76 @@ def search_local_map(matcher, cur, dmap, Tcw, n_local, th, cos_limit, log_scale_
                                              int(first_slot), _vp(sk), _vp(ho), float(th), float(matcher.mfNNratio), float(cos_limit),
                                              float(log_scale_factor), _vp(in_view), _vp(out), C.byref(nm)))
     return nm.value, out, in_view[:n_local]
+
+
+SO_RETRY_ON_HOST = 100
+
+
+def _stage_wait(matcher, n_kp, n_local=0, again=False):
+    """so_track_stage_wait: None when the stage was not finished on the device (SO_RETRY_ON_HOST), else a dict."""
+    lib = matcher._lib
+    k2q = np.full(n_kp, -1, np.int32)
+    view = np.zeros(max(n_local, 1), np.uint8)
+    edge_kp, edge_out = np.zeros(n_kp, np.int32), np.zeros(n_kp, np.uint8)
+    T = np.zeros(12, np.float32)
+    nm, ne, ninl = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    info2 = np.zeros(2, np.int32)
+    rc = lib.so_track_stage_wait(matcher._h, None if again else _vp(k2q), None if again else C.byref(nm), _vp(view) if n_local else None,
+                                 C.byref(ne), _vp(edge_kp), _vp(edge_out), _vp(T), C.byref(ninl), _vp(info2))
+    if rc == SO_RETRY_ON_HOST:
+        return None
+    _lib.check(rc)
+    rounds, active = C.c_int32(0), C.c_int32(0)
+    lib.so_track_stage_last_rounds.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.so_track_stage_last_rounds(matcher._h, C.byref(rounds), C.byref(active))
+    return dict(rounds=rounds.value, active_queries=active.value, nmatches=nm.value, kp_to_q=k2q, in_view=view[:n_local], n_edges=ne.value, edge_kp=edge_kp[:ne.value].copy(),
+                edge_outlier=edge_out[:ne.value].copy(), Tcw=T.reshape(3, 4), n_inliers=ninl.value, iterations=int(info2[0]),
+                trials=int(info2[1]))
+
+
+def track_stage_last_frame(matcher, cur, last, dmap, Tcw, last_slot, th, K4, level_inv_sigma2):
+    """so_track_stage_last_frame_submit + so_track_stage_wait: TrackWithMotionModel's search, resolve and PoseOptimization as one
+    chain of launches.  None: the caller takes search_last_frame + PoseOptimization."""
+    lib = matcher._lib
+    _bind(lib)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    slot = np.ascontiguousarray(last_slot, np.int32)
+    assert len(slot) == last.n
+    k4, ls = np.ascontiguousarray(K4, np.float32), np.ascontiguousarray(level_inv_sigma2, np.float32)
+    rc = lib.so_track_stage_last_frame_submit(matcher._h, cur._h, last._h, dmap._h, _vp(T), _vp(slot), float(th),
+                                              int(matcher.mbCheckOrientation), _vp(k4), _vp(ls))
+    if rc == SO_RETRY_ON_HOST:
+        return None
+    _lib.check(rc)
+    return _stage_wait(matcher, cur.n)
+
+
+def track_stage_local_map(matcher, cur, kp_slot, dmap, Tcw, n_local, th, cos_limit, log_scale_factor, K4, level_inv_sigma2,
+                          local_slot=None, skip=None, first_slot=0):
+    """so_track_stage_local_map_submit + so_track_stage_wait (TrackLocalMap: SearchLocalPoints + PoseOptimization)."""
+    lib = matcher._lib
+    _bind(lib)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    ks = np.ascontiguousarray(kp_slot, np.int32)
+    assert len(ks) == cur.n
+    slot = None if local_slot is None else np.ascontiguousarray(local_slot, np.int32)
+    sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+    k4, ls = np.ascontiguousarray(K4, np.float32), np.ascontiguousarray(level_inv_sigma2, np.float32)
+    rc = lib.so_track_stage_local_map_submit(matcher._h, cur._h, _vp(ks), dmap._h, _vp(T), int(n_local), _vp(slot), int(first_slot),
+                                             _vp(sk), float(th), float(matcher.mfNNratio), float(cos_limit), float(log_scale_factor),
+                                             _vp(k4), _vp(ls))
+    if rc == SO_RETRY_ON_HOST:
+        return None
+    _lib.check(rc)
+    return _stage_wait(matcher, cur.n, n_local)
+
+
+def track_stage_pose_again(matcher, cur, Tcw):
+    """so_track_stage_pose_again_submit + wait: PoseOptimization over the last stage's edges from another start pose."""
+    lib = matcher._lib
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    _lib.check(lib.so_track_stage_pose_again_submit(matcher._h, _vp(T)))
+    return _stage_wait(matcher, cur.n, again=True)
 
 
 def search_mappoints_dframe(matcher, cur, mps, th, excluded=None):

@@ -969,6 +969,12 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
 }
 
 // TrackWithMotionModel's search (Tracking.cc:964-1024)
+// SWARMORB_TRACK_CHAIN=0: the tracking stages as separate calls with the resolve and the pose-problem gather on the host (rounds 2-4)
+bool track_chain_on() {
+    static const bool on = !(getenv("SWARMORB_TRACK_CHAIN") && atoi(getenv("SWARMORB_TRACK_CHAIN")) == 0);
+    return on;
+}
+
 int step_m2_submit(so_replay* r) {
     so_replay::Step& S = r->step;
     so_replay::FrameHost& L = r->fh[r->cur ^ 1];
@@ -977,6 +983,17 @@ int step_m2_submit(so_replay* r) {
     r->last_slot.resize((size_t)L.n);
     for (int i = 0; i < L.n; i++)
         r->last_slot[(size_t)i] = (L.kp_mp[(size_t)i] >= 0 && !L.outlier[(size_t)i]) ? L.kp_mp[(size_t)i] : -1;
+    if (track_chain_on() && !r->lockstep) {
+        // the whole stage as one chain of launches: search -> resolve on the device -> PoseOptimization; one wait (step_stage1_wait)
+        r->K4[0] = r->cam.fx; r->K4[1] = r->cam.fy; r->K4[2] = r->cam.cx; r->K4[3] = r->cam.cy;
+        const int rc = so_track_stage_last_frame_submit(r->matcher, r->fr[S.hcur], r->fr[(S.hcur + 2) % 3], r->map, S.Tp,
+                                                        r->last_slot.data(), 15.0f, 1, r->K4, r->inv_sigma2);
+        if (rc == SO_OK) {
+            S.stage1_dev = true;
+            return SO_OK;
+        }
+        if (rc != SO_RETRY_ON_HOST) return fail(r, "so_track_stage_last_frame_submit");
+    }
     if (so_track_search_last_frame_submit(r->matcher, r->fr[S.hcur], nullptr, r->fr[(S.hcur + 2) % 3], r->map, S.Tp,
                                           r->last_slot.data(), 15.0f) != SO_OK)
         return fail(r, "so_track_search_last_frame_submit");
@@ -1075,6 +1092,80 @@ int pose_single(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_in
     return pose_single(r, T_in12, T_out12, n_inliers, [] { return 0; });
 }
 
+// A stage that ran on the device: the matches, the edge list (= the keypoints with a map point, ascending: what pose_gather
+// builds), the outlier flags and the pose come back together.  false: not finished on the device - the caller repeats the
+// stage with the separate calls.
+bool stage_collect(so_replay* r, std::vector<int32_t>& kp_to_q, int32_t* nm, uint8_t* in_view, float* T_out12, int32_t* n_inliers,
+                   int* rc_out) {
+    so_replay::Step& S = r->step;
+    const so_replay::FrameHost& F = r->fh[r->cur];
+    kp_to_q.resize((size_t)F.n);
+    r->idx.resize((size_t)F.n);
+    r->pose_out.resize((size_t)F.n);
+    int32_t ne = 0, info2[2] = {0, 0};
+    const int rc = so_track_stage_wait(r->matcher, kp_to_q.data(), nm, in_view, &ne, r->idx.data(), r->pose_out.data(), T_out12,
+                                       n_inliers, info2);
+    *rc_out = SO_OK;
+    if (rc == SO_RETRY_ON_HOST) return false;
+    if (rc != SO_OK) {
+        *rc_out = fail(r, "so_track_stage_wait");
+        return false;
+    }
+    r->idx.resize((size_t)ne);
+    r->pose_out.resize((size_t)ne);
+    S.pose_calls++;
+    if (S.timed_kernels) {
+        float kms = 0.f;
+        so_track_stage_last_pose_kernel_ms(r->matcher, &kms);
+        S.pose_kernel += kms;
+        S.pose_trials += info2[1];
+        S.pose_points += ne;
+        S.pose_timed_calls++;
+    }
+    return true;
+}
+
+// TrackWithMotionModel on the device chain: the matches of so_track_search_last_frame + the first PoseOptimization
+int step_stage1_wait(so_replay* r, int32_t* inl) {
+    so_replay::Step& S = r->step;
+    so_replay::FrameHost& F = r->fh[r->cur];
+    so_replay::FrameHost& L = r->fh[r->cur ^ 1];
+    int32_t nm = 0;
+    int rc = SO_OK;
+    const bool ok = stage_collect(r, r->k2l, &nm, nullptr, S.Ta, inl, &rc);
+    if (rc) return rc;
+    float kms = 0.f;
+    double ms4[4];
+    so_matcher_last_kernel_ms(r->matcher, &kms);
+    S.match_kernel += kms;
+    so_matcher_last_stats(r->matcher, ms4);
+    S.mstat[0] += ms4[0]; S.mstat[1] += ms4[1];
+    S.reruns += ms4[2];
+    if (!ok || nm < 20) {  // not finished on the device, or Tracking.cc:1020-1024's wider window: the separate calls
+        S.stage1_dev = false;
+        const float th = ok ? 30.0f : 15.0f;
+        if (ok) S.wide_m2 += 1;
+        r->k2l.resize((size_t)F.n);
+        if (so_track_search_last_frame(r->matcher, r->fr[S.hcur], nullptr, r->fr[(S.hcur + 2) % 3], r->map, S.Tp, r->last_slot.data(),
+                                       nullptr, th, 1, r->k2l.data(), &nm) != SO_OK)
+            return fail(r, "so_track_search_last_frame");
+        so_matcher_last_kernel_ms(r->matcher, &kms);
+        S.match_kernel += kms;
+        if (!ok && nm < 20) {
+            S.wide_m2 += 1;
+            if (so_track_search_last_frame(r->matcher, r->fr[S.hcur], nullptr, r->fr[(S.hcur + 2) % 3], r->map, S.Tp,
+                                           r->last_slot.data(), nullptr, 30.0f, 1, r->k2l.data(), &nm) != SO_OK)
+                return fail(r, "so_track_search_last_frame");
+        }
+    }
+    S.nm2 = nm;
+    for (int k = 0; k < F.n; k++)
+        if (r->k2l[(size_t)k] >= 0) F.kp_mp[(size_t)k] = L.kp_mp[(size_t)r->k2l[(size_t)k]];
+    S.tm2 = now_ms();
+    if (!S.stage1_dev) return pose_single(r, S.Tp, S.Ta, inl);
+    return SO_OK;
+}
+
 void pose1_apply(so_replay* r) {  // Tracking.cc:1030-1046: outliers lose their map point
     so_replay::FrameHost& F = r->fh[r->cur];
     for (size_t k = 0; k < r->idx.size(); k++)
@@ -1107,6 +1198,15 @@ int step_m1_submit(so_replay* r) {
         }
         for (int i = 0; i < nl; i++)
             if (bound[(size_t)M.tv_local[(size_t)i]]) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:1117-1124)
+        if (track_chain_on() && !r->lockstep) {
+            const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), r->map, S.Ta, nl, M.tv_local.data(), 0,
+                                                           r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
+            if (rc == SO_OK) {
+                S.stage2_dev = true;
+                return SO_OK;
+            }
+            if (rc != SO_RETRY_ON_HOST) return fail(r, "so_track_stage_local_map_submit");
+        }
         if (so_track_search_local_map_submit(r->matcher, r->fr[S.hcur], r->excluded.data(), r->map, S.Ta, nl, M.tv_local.data(), 0,
                                              r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf) != SO_OK)
             return fail(r, "so_track_search_local_map_submit");
@@ -1125,6 +1225,15 @@ int step_m1_submit(so_replay* r) {
         r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
         if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:1117-1124)
     }
+    if (track_chain_on() && !r->lockstep) {
+        const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), r->map, S.Ta, S.n_local, nullptr, first,
+                                                       r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
+        if (rc == SO_OK) {
+            S.stage2_dev = true;
+            return SO_OK;
+        }
+        if (rc != SO_RETRY_ON_HOST) return fail(r, "so_track_stage_local_map_submit");
+    }
     if (so_track_search_local_map_submit(r->matcher, r->fr[S.hcur], r->excluded.data(), r->map, S.Ta, S.n_local, nullptr, first,
                                          r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf) != SO_OK)
         return fail(r, "so_track_search_local_map_submit");
@@ -1141,8 +1250,19 @@ int step_m1_wait(so_replay* r) {
     int32_t nmm = 0;
     float kms = 0.f;
     double ms4[4];
-    if (so_track_search_local_map_wait(r->matcher, nullptr, view.data(), r->k2m.data(), &nmm) != SO_OK)
+    if (S.stage2_dev) {  // search, resolve and the second PoseOptimization came back together
+        int rc = SO_OK;
+        if (!stage_collect(r, r->k2m, &nmm, view.data(), S.Tb, &S.n_in, &rc)) {
+            if (rc) return rc;
+            S.stage2_dev = false;  // not finished on the device: the separate calls, from the search on
+            if (so_track_search_local_map(r->matcher, r->fr[S.hcur], r->excluded.data(), r->map, S.Ta, S.n_local,
+                                          r->cl ? r->cl->tv_local.data() : nullptr, r->cl ? 0 : S.first_slot, r->skip.data(), nullptr, 1.0f,
+                                          0.8f, 0.5f, r->log_sf, view.data(), r->k2m.data(), &nmm) != SO_OK)
+                return fail(r, "so_track_search_local_map");
+        }
+    } else if (so_track_search_local_map_wait(r->matcher, nullptr, view.data(), r->k2m.data(), &nmm) != SO_OK) {
         return fail(r, "so_track_search_local_map_wait");
+    }
     so_matcher_last_kernel_ms(r->matcher, &kms);
     S.match_kernel += kms;
     so_matcher_last_stats(r->matcher, ms4);
@@ -1386,27 +1506,57 @@ extern "C" {
 
 static int run_one_step(so_replay* r, int t, int timed) {
     r->step_timed = timed ? 1 : 0;
+    r->lockstep = false;
     {
         so_replay::Step& S = r->step;
         int rc;
         static const bool submit_early = getenv("SWARMORB_REPLAY_SUBMIT_EARLY") != nullptr;  // A/B: next frame at step begin
         if ((rc = step_begin(r, t, submit_early))) return rc;
         if (!S.first) {
-            if ((rc = step_m2_wait(r))) return rc;  // submitted inside step_begin
             int32_t inl = 0;
-            // frame t+1 goes to the extractor while the GPU runs this frame's first PoseOptimization
-            if ((rc = pose_single(r, S.Tp, S.Ta, &inl, [r, t, &S] { return S.next_submitted ? 0 : submit_frame(r, t + 1); }))) return rc;
+            if (S.stage1_dev) {  // search -> resolve -> PoseOptimization are in flight as one chain (submitted inside step_begin)
+                // frame t+1 goes to the extractor while the GPU runs them
+                if (!S.next_submitted && (rc = submit_frame(r, t + 1))) return rc;
+                if ((rc = step_stage1_wait(r, &inl))) return rc;
+            } else {
+                if ((rc = step_m2_wait(r))) return rc;  // submitted inside step_begin
+                // frame t+1 goes to the extractor while the GPU runs this frame's first PoseOptimization
+                if ((rc = pose_single(r, S.Tp, S.Ta, &inl, [r, t, &S] { return S.next_submitted ? 0 : submit_frame(r, t + 1); }))) return rc;
+            }
             pose1_apply(r);
             if ((rc = step_m1_submit(r))) return rc;
             if ((rc = step_m1_wait(r))) return rc;
-            if ((rc = pose_single(r, S.Ta, S.Tb, &S.n_in))) return rc;
+            if (!S.stage2_dev && (rc = pose_single(r, S.Ta, S.Tb, &S.n_in))) return rc;
             pose2_apply(r);
             if (r->third_pose) {  // TrackReferenceKeyFrame's fallback: from the last frame's pose, result unused
                 float Tl[12], Tc[12];
                 to_f12(r->T_last, Tl);
                 int32_t inl3 = 0;
                 // the keyframe decision and the new map points only need the second result: they run under this kernel
-                if ((rc = pose_single(r, Tl, Tc, &inl3, [r] { return step_keyframe(r); }, true))) return rc;
+                bool done3 = false;
+                if (S.stage2_dev && so_track_stage_pose_again_submit(r->matcher, Tl) == SO_OK) {  // the same edges, still on the device
+                    if ((rc = step_keyframe(r))) return rc;
+                    std::vector<int32_t>& ek = r->k2l;  // scratch: the edge list comes back unchanged
+                    std::vector<uint8_t>& eo = r->excluded;
+                    ek.resize((size_t)r->fh[r->cur].n);
+                    eo.resize((size_t)r->fh[r->cur].n);
+                    int32_t ne = 0, info2[2] = {0, 0};
+                    const int rc3 = so_track_stage_wait(r->matcher, nullptr, nullptr, nullptr, &ne, ek.data(), eo.data(), Tc, &inl3, info2);
+                    if (rc3 != SO_OK && rc3 != SO_RETRY_ON_HOST) return fail(r, "so_track_stage_wait");
+                    done3 = true;
+                    if (rc3 == SO_OK) {
+                        S.pose_calls++;
+                        if (S.timed_kernels) {
+                            float kms = 0.f;
+                            so_track_stage_last_pose_kernel_ms(r->matcher, &kms);
+                            S.pose_kernel += kms;
+                            S.pose_trials += info2[1];
+                            S.pose_points += ne;
+                            S.pose_timed_calls++;
+                        }
+                    }
+                }
+                if (!done3 && (rc = pose_single(r, Tl, Tc, &inl3, [r] { return step_keyframe(r); }, !S.stage2_dev))) return rc;
                 S.tp3 = S.tmap = now_ms();
             } else {
                 S.tp3 = now_ms();
@@ -1509,8 +1659,10 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
     std::vector<const uint8_t*> gimages(A);
     for (int t = first_t; t < first_t + n_steps; t++) {
         int rc;
-        for (int a = 0; a < n_agents; a++)
+        for (int a = 0; a < n_agents; a++) {
+            agents[a]->lockstep = true;
             if ((rc = step_begin(agents[a], t, !grouped))) return rc;
+        }
         if (grouped) {  // the agents whose next frame is not out yet (all of them, except on a run's first frame)
             bool all = true;
             for (int a = 0; a < n_agents; a++) all = all && !agents[a]->step.next_submitted;

@@ -225,6 +225,7 @@ struct so_replay {
     int last_tracked = -1;  // handle index of the frame tracked last
     bool in_flight = false;
     bool live = false;   // so_replay_run_live: no frame is extracted ahead
+    bool lockstep = false;  // so_fleet_run drives this agent: its stages stay separate calls (the fleet batches the PoseOptimization calls of all agents)
     int n_tracked = 0;   // frames tracked so far (0: the next frame initialises the map)
     float bounds[4] = {0, 0, 0, 0};
     M4 T_last = M4::eye(), velocity = M4::eye();
@@ -261,6 +262,7 @@ struct so_replay {
         bool kf_under_pose = false;  // the keyframe is made on the tracking thread while a PoseOptimization kernel runs
         bool kf_queued = false;  // closed loop: the frame went to local mapping as a keyframe already (under its last PoseOptimization)
         bool first = false, m2_submitted = false, timed_kernels = true, next_submitted = false;
+        bool stage1_dev = false, stage2_dev = false;  // the stage's search -> resolve -> pose chain is on the device (so_track_stage_*)
         int m2_rc = 0;
         float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
         M4 T = M4::eye();

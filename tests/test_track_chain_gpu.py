@@ -1,0 +1,143 @@
+"""A tracking stage as ONE chain of launches (so_track_stage_*: search -> the order-dependent resolve on the device ->
+PoseOptimization over edges read in place) against the separate calls it replaces and against the CPU oracle: the matches
+are the oracle's sequential result (bit-exact: the parallel rounds reproduce ORBmatcher.cc:83-85 / 1294-1296 exactly, also
+where many map points compete for the same keypoints), the pose is so_pose_optimization's on the same bindings to the bit."""
+import numpy as np
+import pytest
+
+from swarmmap_amd import dframe as dfm
+from swarmmap_amd import synth
+from swarmmap_amd.matcher import FrameView
+from test_dframe_gpu import LOG_SF, S, _frame_and_view, _make_map, _pose  # noqa: F401 (S is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+K4 = np.asarray(synth.EUROC_K, np.float32)
+INV_SIGMA2 = (1.0 / (synth.SCALE_FACTORS.astype(np.float32) ** 2)).astype(np.float32)
+
+
+def _host_pose(S, Tcw, kp_slot, xy_un, octave, Xw):
+    """Optimizer::PoseOptimization the way the host chain gathers it: the keypoints with a map point, ascending."""
+    idx = np.nonzero(kp_slot >= 0)[0]
+    opt = S.Optimizer()
+    n_in, T, outl, info = opt.PoseOptimization(Tcw, K4, Xw[kp_slot[idx]], xy_un[idx], INV_SIGMA2[octave[idx]])
+    opt.close()
+    return idx, n_in, T.reshape(3, 4), outl, info
+
+
+@pytest.mark.parametrize("seed,dist", [(41, synth.EUROC_DIST), (43, (0, 0, 0, 0))])
+def test_last_frame_stage_equals_search_plus_pose(S, oracle, seed, dist):
+    rng = np.random.default_rng(seed)
+    ex, last, lk, lxy, ld, _ = _frame_and_view(S, oracle, seed, dist=dist)
+    Tl = _pose(rng)
+    Xw, normal, mx, mn, md = _make_map(rng, lxy, lk, ld, synth.EUROC_K, Tl)
+    dmap = S.DeviceMap()
+    dmap.append(Xw, normal, mx, mn, md)
+    cur = S.DeviceFrame(ex, synth.EUROC_K, dist)
+    ck, cxy, cd = [a.copy() for a in cur(synth.make_canvas(seed, 752, 480))]
+    F = FrameView(cxy[:, 0], cxy[:, 1], ck["octave"], ck["angle"], cd, cur.bounds, ex.GetScaleFactors())
+    n_last = len(lk)
+    slot = np.where(rng.random(n_last) < 0.75, np.arange(n_last), -1).astype(np.int32)
+    Tc = Tl.copy()
+    Tc[3] += 0.004; Tc[7] -= 0.003
+    cam = oracle.camera(synth.EUROC_K, dist)
+    valid, u, v = oracle.project_last_frame(cam, cur.bounds, Tc, Xw[np.maximum(slot, 0)], slot >= 0)
+    lastd = dict(valid=valid, u=u, v=v, octave=lk["octave"], angle=lk["angle"], desc=md[np.maximum(slot, 0)],
+                 has_obs=np.ones(n_last, np.uint8))
+    for th, ori in ((15.0, True), (30.0, False)):
+        m = S.ORBmatcher(0.9, ori)
+        r = dfm.track_stage_last_frame(m, cur, last, dmap, Tc, slot, th, K4, INV_SIGMA2)
+        assert r is not None
+        onm, ok2l = oracle.search_by_projection_lastframe(F, lastd, th, ori)
+        assert r["nmatches"] == onm > 200 and np.array_equal(r["kp_to_q"], ok2l)
+        # the plain call on the same handle afterwards: same matches, and the pose over them
+        nm, k2l = dfm.search_last_frame(m, cur, last, dmap, Tc, slot, th)
+        assert nm == onm and np.array_equal(k2l, ok2l)
+        kp_slot = np.where(k2l >= 0, slot[np.maximum(k2l, 0)], -1)
+        idx, n_in, T, outl, info = _host_pose(S, Tc, kp_slot, cxy, ck["octave"], Xw)
+        assert r["n_edges"] == len(idx) and np.array_equal(r["edge_kp"], idx)
+        assert np.array_equal(r["Tcw"], T) and np.array_equal(r["edge_outlier"], outl) and r["n_inliers"] == n_in
+        assert r["iterations"] == info["iterations"] and r["trials"] == info["lm_trials"]
+        # the same edges from another start pose
+        T2 = Tc.copy(); T2[3] -= 0.01
+        again = dfm.track_stage_pose_again(m, cur, T2)
+        _, n_in2, Tb, outl2, _ = _host_pose(S, T2, kp_slot, cxy, ck["octave"], Xw)
+        assert again is not None and np.array_equal(again["Tcw"], Tb) and np.array_equal(again["edge_outlier"], outl2)
+        assert again["n_inliers"] == n_in2 and np.array_equal(again["edge_kp"], idx)
+        m.close()
+    dmap.close(); cur.close(); last.close(); ex.close()
+
+
+@pytest.mark.parametrize("seed,dist,th", [(51, synth.EUROC_DIST, 1.0), (52, (0, 0, 0, 0), 3.0)])
+def test_local_map_stage_with_competing_points_equals_search_plus_pose(S, oracle, seed, dist, th):
+    """800 duplicated map points compete for the keypoints of their originals, a third of the keypoints is bound on entry."""
+    rng = np.random.default_rng(seed)
+    ex, cur, ck, cxy, cd, F = _frame_and_view(S, oracle, seed, dist=dist)
+    Tc = _pose(rng)
+    Xw, normal, mx, mn, md = _make_map(rng, cxy, ck, cd, synth.EUROC_K, Tc)
+    dup = rng.integers(0, len(ck), 800)
+    Xw = np.concatenate([Xw, Xw[dup] + rng.normal(0, 0.004, (800, 3)).astype(np.float32)])
+    normal = np.concatenate([normal, normal[dup]]); mx = np.concatenate([mx, mx[dup]]); mn = np.concatenate([mn, mn[dup]])
+    md = np.concatenate([md, synth.flip_bits(rng, md[dup], 0.05)])
+    dmap = S.DeviceMap()
+    dmap.append(Xw, normal, mx, mn, md)
+    n_map = len(Xw)
+    # bindings on entry: a third of the keypoints hold "their" map point (slot = keypoint index in _make_map)
+    kp_slot = np.where(rng.random(len(ck)) < 0.35, np.arange(len(ck)), -1).astype(np.int32)
+    excluded = (kp_slot >= 0).astype(np.uint8)
+    F.excluded = excluded
+    cam = oracle.camera(synth.EUROC_K, dist)
+    for local in (None, rng.permutation(n_map)[: n_map * 2 // 3].astype(np.int32)):
+        idx = np.arange(n_map) if local is None else local
+        bound = np.zeros(n_map, np.uint8); bound[kp_slot[kp_slot >= 0]] = 1
+        skip = ((rng.random(len(idx)) < 0.1) | (bound[idx] == 1)).astype(np.uint8)
+        fr = oracle.is_in_frustum(cam, cur.bounds, Tc, Xw[idx], normal[idx], mx[idx], mn[idx], 0.5, LOG_SF, 8)
+        in_view = fr["in_view"] & (1 - skip)
+        mps = dict(in_view=in_view, proj_x=fr["proj_x"], proj_y=fr["proj_y"], view_cos=fr["view_cos"],
+                   pred_level=fr["pred_level"], desc=md[idx], has_obs=np.ones(len(idx), np.uint8))
+        m = S.ORBmatcher(0.8, True)
+        r = dfm.track_stage_local_map(m, cur, kp_slot, dmap, Tc, len(idx), th, 0.5, LOG_SF, K4, INV_SIGMA2, local_slot=local, skip=skip)
+        assert r is not None
+        onm, ok2m = oracle.search_by_projection_mappoints(F, mps, th, 0.8)
+        assert np.array_equal(r["in_view"], in_view)
+        assert r["nmatches"] == onm > 100 and np.array_equal(r["kp_to_q"], ok2m)
+        after = np.where(kp_slot >= 0, kp_slot, np.where(ok2m >= 0, idx[np.maximum(ok2m, 0)], -1)).astype(np.int32)
+        eidx, n_in, T, outl, info = _host_pose(S, Tc, after, cxy, ck["octave"], Xw)
+        assert np.array_equal(r["edge_kp"], eidx) and r["n_edges"] > 400
+        assert np.array_equal(r["Tcw"], T) and np.array_equal(r["edge_outlier"], outl) and r["n_inliers"] == n_in
+        m.close()
+    dmap.close(); cur.close(); ex.close()
+
+
+def test_stage_that_runs_out_of_list_entries_hands_the_call_back(S, oracle):
+    """Forty copies of each of fifty map points land in the same windows: the later copies find all eight entries of their
+    K-list taken while the window holds more candidates - the stage answers SO_RETRY_ON_HOST, the separate calls (whose host
+    resolve re-runs such a query exactly) still give the oracle's matches, and the handle is usable afterwards."""
+    rng = np.random.default_rng(77)
+    ex, cur, ck, cxy, cd, F = _frame_and_view(S, oracle, 77)
+    Tc = _pose(rng)
+    Xw, normal, mx, mn, md = _make_map(rng, cxy, ck, cd, synth.EUROC_K, Tc, n_extra=0)
+    base = rng.permutation(len(ck))[:50]
+    rep = np.repeat(base, 40)
+    Xw = np.concatenate([Xw[rep] + rng.normal(0, 0.002, (len(rep), 3)).astype(np.float32)])
+    normal, mx, mn = normal[rep], mx[rep], mn[rep]
+    md = synth.flip_bits(rng, md[rep], 0.02)
+    dmap = S.DeviceMap()
+    dmap.append(Xw, normal, mx, mn, md)
+    kp_slot = np.full(len(ck), -1, np.int32)
+    m = S.ORBmatcher(0.8, True)
+    r = dfm.track_stage_local_map(m, cur, kp_slot, dmap, Tc, len(Xw), 6.0, 0.5, LOG_SF, K4, INV_SIGMA2)
+    cam = oracle.camera(synth.EUROC_K, synth.EUROC_DIST)
+    fr = oracle.is_in_frustum(cam, cur.bounds, Tc, Xw, normal, mx, mn, 0.5, LOG_SF, 8)
+    mps = dict(in_view=fr["in_view"], proj_x=fr["proj_x"], proj_y=fr["proj_y"], view_cos=fr["view_cos"], pred_level=fr["pred_level"],
+               desc=md, has_obs=np.ones(len(Xw), np.uint8))
+    onm, ok2m = oracle.search_by_projection_mappoints(F, mps, 6.0, 0.8)
+    nm, k2m, _ = dfm.search_local_map(m, cur, dmap, Tc, len(Xw), 6.0, 0.5, LOG_SF)
+    assert nm == onm and np.array_equal(k2m, ok2m)
+    if r is not None:  # (the lists happened to suffice: then the stage must agree as well)
+        assert np.array_equal(r["kp_to_q"], ok2m)
+    else:
+        assert m.last_stats()["launches"] > 1  # the host resolve re-ran at least one exhausted query
+    r2 = dfm.track_stage_local_map(m, cur, kp_slot, dmap, Tc, 60, 1.0, 0.5, LOG_SF, K4, INV_SIGMA2)
+    assert r2 is not None and r2["nmatches"] <= 60
+    m.close(); dmap.close(); cur.close(); ex.close()
