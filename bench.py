@@ -468,9 +468,14 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
     pose_ms = st["pose_kernel_ms"] / calls
     pose_total_ms = pose_ms * st["pose_calls"]
     pose_tf = pose_flop / (pose_ms * 1e-3) / 1e12 if pose_ms > 0 else 0.0
-    roof_pose = {"bound": "fp64-valu (latency: one workgroup, no MFMA)", "kernel": "pose_opt_reg_kernel", "achieved": pose_tf,
+    chain = os.environ.get("SWARMORB_TRACK_CHAIN", "1") != "0" and not (agents > 1 and "--lockstep" in sys.argv)
+    pose_kernel = "pose_opt_chain_kernel" if chain else "pose_opt_reg_kernel"
+    roof_pose = {"bound": "fp64-valu (latency: one workgroup, no MFMA)", "kernel": pose_kernel, "achieved": pose_tf,
                  "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": pose_tf / FP64_PEAK_TF,
-                 "traffic": pmc.get("pose_opt_reg_kernel", pmc.get("pose_opt_lds_kernel", {})).get("hbm_bytes_per_launch"),
+                 "traffic": pmc.get(pose_kernel, pmc.get("pose_opt_reg_kernel", pmc.get("pose_opt_lds_kernel", {}))).get("hbm_bytes_per_launch"),
+                 "launched_as": ("the last launch of a tracking stage's chain (search -> resolve on the device -> this kernel, edges read in "
+                                 "place from the device-resident frame and map table; so_track_stage_*)" if chain else
+                                 "so_pose_optimization after a host-side resolve and gather"),
                  "algorithmic_flop_per_launch": pose_flop, "avg_launch_ms": pose_ms, "avg_points": n_pose,
                  "avg_lm_trials": st["pose_trials"] / calls, "event_timed_launches": st["pose_timed_calls"],
                  "launches_in_timed_region": st["pose_calls"], "total_ms_in_timed_region": pose_total_ms,

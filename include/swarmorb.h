@@ -690,6 +690,9 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
  *   intr4 = fx, fy, cx, cy;  level_inv_sigma2 = mvInvLevelSigma2 (cur's number of levels);
  *   kp_slot (local-map stage, cur->n entries) = map slot bound to keypoint k on entry, < 0: none - those keypoints are the
  *   search's `excluded` set AND edges of the pose problem; bound points must carry skip[] = 1 as for the plain search.
+ *   kp_slot_is_last_stage != 0: kp_slot is exactly what this matcher's last stage left for this frame - the bindings it
+ *   reported, minus the outliers of its pose when it was the last-frame stage (code/src/Tracking.cc:1030-1046) - so the device
+ *   copy of that stage is used and nothing is read from host memory inside the chain (ignored when no such copy exists).
  * All map points are taken to have observations (slot_has_obs = NULL of the plain calls).
  * so_track_stage_wait - out, all required unless noted:
  *   kp_to_q[k] (cur->n) = query (index into the last frame / the local list) matched to keypoint k by THIS stage's search;
@@ -705,9 +708,9 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
 int so_track_stage_last_frame_submit(so_matcher* m, const so_dframe* cur, const so_dframe* last, const so_map* map,
                                      const float* Tcw12, const int32_t* last_slot, float th, int check_orientation,
                                      const float* intr4, const float* level_inv_sigma2);
-int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const int32_t* kp_slot, const so_map* map,
-                                    const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
-                                    const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
+int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const int32_t* kp_slot, int kp_slot_is_last_stage,
+                                    const so_map* map, const float* Tcw12, int32_t n_local, const int32_t* local_slot,
+                                    int32_t first_slot, const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
                                     float log_scale_factor, const float* intr4, const float* level_inv_sigma2);
 int so_track_stage_pose_again_submit(so_matcher* m, const float* Tcw12);
 int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint8_t* in_view, int32_t* n_edges,

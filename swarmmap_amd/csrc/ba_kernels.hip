@@ -2653,7 +2653,10 @@ __device__ __forceinline__ void pose_opt_reg_body(const PoseOptArgs& a, const in
     uint8_t* s_outl8 = reinterpret_cast<uint8_t*>(s_outl);
 #pragma unroll
     for (int k = 0; k < EPT; k++)
-        if (live[k]) s_outl8[tid + k * THREADS] = outl[k] ? 1 : 0;
+        if (live[k]) {
+            s_outl8[tid + k * THREADS] = outl[k] ? 1 : 0;
+            if (a.kp_slot_clear && outl[k]) a.kp_slot_clear[a.e_kp[tid + k * THREADS]] = -1;
+        }
     __syncthreads();
     if (tid < 64) {
         const int full = n >> 2;  // a.outlier is 16-byte aligned in every caller (offset 80 of a 64-byte aligned block)

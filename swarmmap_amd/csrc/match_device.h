@@ -82,6 +82,8 @@ struct TrackQuerySrc {
     uint8_t* in_view_out;        // local-map search: mbTrackInView per query (may be null)
     uint8_t* count8_out;         // candidates per query clamped to 255 (0: inactive / none): the one plane the host's
                                  // resolve scans for every query (may be null)
+    int32_t* slot_out;           // the query's map slot as the search read it (device memory; may be null): the device-side
+                                 // resolve takes it from here instead of reading the pinned host list again
     float Tcw[12];
     float fx, fy, cx, cy;
     float bounds[4];             // mnMinX, mnMaxX, mnMinY, mnMaxY
@@ -132,6 +134,7 @@ struct TrackResolveArgs {
     const int32_t* q_slot;       // query -> map slot (null: slot_base + query)
     int slot_base;
     const int32_t* kp_slot_in;   // bindings on entry by keypoint index (null: none)
+    int32_t* kp_slot_out;        // bindings behind this stage by keypoint index (device; the next stage's kp_slot_in)
     int32_t* kp_to_q;            // [n_kp] out (host-mapped): query matched to keypoint k, -1 none
     int32_t* e_kp;               // edge list out (device)
     int32_t* e_slot;

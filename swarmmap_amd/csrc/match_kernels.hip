@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F_arg, c
         Q = track_query_local(T, q_first + qi, slot);
         if (T.in_view_out && lane == 0) T.in_view_out[q_first + qi] = (uint8_t)Q.active;
     }
+    if ((MODE == 2 || MODE == 3) && T.slot_out && lane == 0) T.slot_out[q_first + qi] = slot;
     if (!Q.active) {
         if (lane == 0) out_count[qi] = 0;
         if ((MODE == 2 || MODE == 3) && T.count8_out && lane == 0) T.count8_out[q_first + qi] = 0;
@@ -954,6 +955,8 @@ __global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolve
     __shared__ int s_taken[kResolveMaxCand];
     __shared__ float s_angle[kResolveMaxCand];
     __shared__ uint16_t s_item[kResolveMaxCand];
+    __shared__ int8_t s_oct[kResolveMaxCand];
+    __shared__ int s_unres[2];
     __shared__ int s_wave[kResThreads / 64 + 1];
     __shared__ int s_hist[kResHisto];
     __shared__ int s_flags[2];  // 0: a query ran out of list entries
@@ -987,18 +990,23 @@ __global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolve
 #pragma unroll
     for (int j = 0; j < kResPPT; j++) {
         const int p = tid + j * kResThreads;
-        int item = 0;
+        int item = 0, oc = 0;
         float ang = 0.f;
         if (!fallback && p < nc) {
             item = a.cell_items[p];
+            oc = a.s_octave[p];
             if (orient) ang = a.cur_angle[item];
         }
         s_item[p] = (uint16_t)item;
+        s_oct[p] = (int8_t)oc;
         s_angle[p] = ang;
-        s_claim[p] = 0x7FFFFFFF;
+        s_claim[p] = 0;
         s_taken[p] = -1;
     }
-    if (tid < 2) s_flags[tid] = 0;
+    if (tid < 2) {
+        s_flags[tid] = 0;
+        s_unres[tid] = 0;
+    }
     if (tid < kResHisto) s_hist[tid] = 0;
     __syncthreads();
     // ---- the loads from HOST memory (the queries' map slots sit in the search's pinned staging, the bindings on entry in the
@@ -1019,11 +1027,13 @@ __global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolve
     tk[1] = wall_clock64();
     int rounds = 0;
     while (!fallback) {
-        // A: every unresolved query looks its list entries up (all reads in flight together) and claims the free ones
+        // A: every unresolved query looks its list entries up (all reads in flight together) and claims the free ones.
+        // A claim is (round, lowest rank) under atomicMax - the round in the high bits, so last round's claims need no clearing
+        const int tag = (rounds + 1) << 13;
         bool fr[kResQPT][kResK];
 #pragma unroll
         for (int u = 0; u < kResQPT; u++) {
-            const int rank = tid + u * kResThreads;
+            const int mine = tag | (8191 - (tid + u * kResThreads));
             int tk8[kResK];
             bool ended = false;
 #pragma unroll
@@ -1036,17 +1046,19 @@ __global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolve
 #pragma unroll
             for (int k = 0; k < kResK; k++) {
                 fr[u][k] = fr[u][k] && tk8[k] < 0;  // ORBmatcher.cc:83-85 / 1294-1296: a taken keypoint is passed over
-                if (fr[u][k]) atomicMin(&s_claim[key[u][k] & 0xFFFFu], rank);
+                if (fr[u][k]) atomicMax(&s_claim[key[u][k] & 0xFFFFu], mine);
             }
         }
+        if (tid == 0) s_unres[(rounds + 1) & 1] = 0;  // (the other parity's counter: read last round, written next round)
         __syncthreads();
-        // B: decisions of the queries nothing undecided can reach (`taken` has not changed since A).  No early exits: every
-        // entry is looked at under predicates (a loop with break / continue over the register-resident K-list came out of
-        // the compiler deciding "no candidate" for every two-candidate query).
-        int take[kResQPT];
+        // B: decisions of the queries nothing undecided can reach, applied at once (`taken` is only read again in the next
+        // round's A, behind the barrier; claims are not touched here).  No early exits: every entry is looked at under
+        // predicates (a loop with break / continue over the register-resident K-list came out of the compiler deciding
+        // "no candidate" for every two-candidate query).
+        bool any = false;
 #pragma unroll
         for (int u = 0; u < kResQPT; u++) {
-            const int rank = tid + u * kResThreads;
+            const int mine = tag | (8191 - (tid + u * kResThreads));
             int found = 0, pos0 = 0, pos1 = 0, d0 = 256, d1 = 256;
             bool ended = false;
 #pragma unroll
@@ -1062,32 +1074,23 @@ __global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolve
             const bool exhausted = un[u] && found < F && !ended && many[u];
             if (exhausted) atomicOr(&s_flags[0], 1);
             const int cl0 = s_claim[found >= 1 ? pos0 : 0], cl1 = s_claim[found >= 2 ? pos1 : 0];
-            const bool c0 = found >= 1 && cl0 == rank, c1 = found >= 2 && cl1 == rank;
+            const int l0 = s_oct[found >= 1 ? pos0 : 0], l1 = found >= 2 ? (int)s_oct[pos1] : -1;
+            const bool c0 = found >= 1 && cl0 == mine, c1 = found >= 2 && cl1 == mine;
             const bool stable = un[u] && !exhausted && (found == 0 || (c0 && (found < 2 || c1)));
             bool ok = stable && found >= 1 && d0 <= kResTH_HIGH;
-            if (F == 2 && ok) {
-                const int l0 = a.s_octave[pos0], l1 = found > 1 ? (int)a.s_octave[pos1] : -1;
-                if (l0 == l1 && (float)d0 > a.nn_ratio * (float)d1) ok = false;  // ORBmatcher.cc:112-113
-            }
+            if (F == 2 && ok && l0 == l1 && (float)d0 > a.nn_ratio * (float)d1) ok = false;  // ORBmatcher.cc:112-113
             if (stable || exhausted) un[u] = false;
-            take[u] = ok ? pos0 : -1;
-        }
-        __syncthreads();
-        // C: the final queries take their keypoints; every query clears what it claimed
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < kResQPT; u++) {
-            if (take[u] >= 0) {
-                s_taken[take[u]] = tid + u * kResThreads;
-                took[u] = take[u];
+            if (ok) {
+                s_taken[pos0] = tid + u * kResThreads;
+                took[u] = pos0;
             }
-#pragma unroll
-            for (int k = 0; k < kResK; k++)
-                if (fr[u][k]) s_claim[key[u][k] & 0xFFFFu] = 0x7FFFFFFF;
             any = any || un[u];
         }
         rounds++;
-        if (!__syncthreads_or(any ? 1 : 0)) break;
+        // anybody left?  (one counter per round parity, one barrier)
+        if (__ballot(any) != 0ull && (tid & 63) == 0) atomicAdd(&s_unres[rounds & 1], 1);
+        __syncthreads();
+        if (s_unres[rounds & 1] == 0) break;
         if (s_flags[0]) break;
     }
     __syncthreads();
@@ -1164,6 +1167,7 @@ __global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolve
             q = s_claim[k];
             a.kp_to_q[k] = q;
             slot = slot_in[j] >= 0 ? slot_in[j] : (q >= 0 ? s_taken[k] : -1);
+            a.kp_slot_out[k] = slot;
         }
         int tot_e, tot_m;
         const int re = block_rank<kResThreads>(slot >= 0, s_wave, &tot_e);

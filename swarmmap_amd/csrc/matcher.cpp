@@ -198,6 +198,10 @@ struct so_matcher {
     MappedBuf h_chain;  // [kp_to_q | edge keypoints | head | pose 64 | info 16 | outlier flags | bindings on entry]
     uint32_t* keys_dev_override = nullptr;  // where the next tracking search writes its K-lists instead of h_out
     uint8_t* cnt8_dev_override = nullptr;   // ... and its one-byte candidate counts
+    int32_t* slot_out_override = nullptr;   // ... and, per query, the map slot it searched with
+    DevBuf d_kpslot;                        // the frame's bindings behind the last stage, by keypoint index (read by the next stage)
+    const so_dframe* kpslot_frame = nullptr;  // the frame they belong to (null: not valid)
+    uint64_t kpslot_generation = 0;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     int chain_seq = 0;
     int chain_range[2] = {0, 0};  // PoseOptimization variant (0: <= 1024 edges, 1: more) each stage kind needed last time
@@ -209,6 +213,7 @@ struct so_matcher {
         size_t h_k2q = 0, h_ekp = 0, h_head = 0, h_pose = 0, h_info = 0, h_outl = 0, h_slot_in = 0;
         float Tcw_in[12];
         const so_map* map = nullptr;  // the table the pose kernel reads its points from
+        const so_dframe* frame = nullptr;
         bool holds_map = false;       // pose_again: held shared until the wait (a stage holds it through its search)
     } chain;
     so::PoseOptArgs chain_pose;  // the last stage's PoseOptimization launch (pose_again: another start pose, same edges)
@@ -888,6 +893,7 @@ void so_matcher_destroy(so_matcher* m) {
     m->h_rout.release();
     m->hb_in.release(); m->db_in.release(); m->db_q.release(); m->hb_out.release();
     m->d_chain.release();
+    m->d_kpslot.release();
     m->h_chain.release();
     if (m->pe0) (void)hipEventDestroy(m->pe0);
     if (m->pe1) (void)hipEventDestroy(m->pe1);
@@ -3402,6 +3408,7 @@ int so_track_search_last_frame_submit(so_matcher* m, const so_dframe* cur, const
     P.c8_off = align256(keys_bytes2 + sizeof(int32_t) * (size_t)n_last);
     if ((rc = m->h_out.ensure(P.c8_off + (size_t)n_last))) { P.mode = 0; return rc; }
     P.T.count8_out = m->cnt8_dev_override ? m->cnt8_dev_override : (uint8_t*)m->h_out.dev + P.c8_off;
+    P.T.slot_out = m->slot_out_override;
     if ((rc = launch_topk_track_async(m, P.T, 2, n_last, K, G))) { P.mode = 0; return rc; }
     P.empty = false;
     return SO_OK;
@@ -3553,6 +3560,7 @@ int so_track_search_local_map_submit(so_matcher* m, const so_dframe* cur, const 
     if ((rc = m->h_out.ensure(P.c8_off + (size_t)n_local))) { P.mode = 0; return rc; }
     P.T.in_view_out = (uint8_t*)m->h_out.dev + P.view_off;
     P.T.count8_out = m->cnt8_dev_override ? m->cnt8_dev_override : (uint8_t*)m->h_out.dev + P.c8_off;
+    P.T.slot_out = m->slot_out_override;
     const TrackGates G{local_slot, local_slot ? 0 : first_slot, skip, cur_excluded};
     if ((rc = launch_topk_track_async(m, P.T, 3, n_local, K, G))) { P.mode = 0; return rc; }
     P.empty = false;
@@ -3659,7 +3667,7 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
 namespace {
 
 struct ChainOffsets {
-    size_t d_keys, d_cnt8, d_ekp, d_eslot, d_head, d_total;
+    size_t d_keys, d_cnt8, d_qslot, d_ekp, d_eslot, d_head, d_total;
     size_t h_k2q, h_ekp, h_head, h_pose, h_info, h_outl, h_slot_in, h_total;
 };
 
@@ -3668,6 +3676,7 @@ ChainOffsets chain_offsets(int nq, int K, int nk) {
     size_t d = 0;
     o.d_keys = d; d += align256(sizeof(uint32_t) * (size_t)nq * (size_t)K);
     o.d_cnt8 = d; d += align256((size_t)nq);
+    o.d_qslot = d; d += align256(sizeof(int32_t) * (size_t)nq);
     o.d_ekp = d; d += align256(sizeof(int32_t) * (size_t)nk);
     o.d_eslot = d; d += align256(sizeof(int32_t) * (size_t)nk);
     o.d_head = d; d += 256;
@@ -3706,9 +3715,10 @@ int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe
     R.check_orientation = check_orientation;
     R.q_angle = last ? last->d_angle : nullptr;
     R.cur_angle = cur->d_angle;
-    R.q_slot = P.T.slot;
-    R.slot_base = P.T.slot_base;
+    R.q_slot = (const int32_t*)(d + O.d_qslot);  // written by the search (TrackQuerySrc::slot_out)
+    R.slot_base = 0;
     R.kp_slot_in = kp_slot_in_dev;
+    R.kp_slot_out = (int32_t*)m->d_kpslot.p;
     R.kp_to_q = (int32_t*)(hd + O.h_k2q);
     R.e_kp = (int32_t*)(d + O.d_ekp);
     R.e_slot = (int32_t*)(d + O.d_eslot);
@@ -3734,6 +3744,9 @@ int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe
     A.kp_xy_un = cur->d_xy_un;
     A.kp_octave = cur->d_octave;
     for (int l = 0; l < 8; l++) A.lvl_inv_sigma2[l] = l < cur->nlevels ? level_inv_sigma2[l] : 0.f;
+    // TrackWithMotionModel: the outliers of its pose lose their map point (Tracking.cc:1030-1046) - also in the bindings
+    // the next stage reads from the device
+    A.kp_slot_clear = kind == 0 ? (int32_t*)m->d_kpslot.p : nullptr;
     so_matcher::ChainPending& C = m->chain;
     C = so_matcher::ChainPending{};
     C.active = true;
@@ -3744,6 +3757,8 @@ int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe
     C.h_slot_in = O.h_slot_in;
     memcpy(C.Tcw_in, Tcw12, 48);
     C.map = map;
+    C.frame = cur;
+    m->kpslot_frame = nullptr;  // (valid again when this stage has come back complete)
     if (++m->chain_seq == 0) m->chain_seq = 1;
     C.seq = m->chain_seq;
     A.done_seq = C.seq;
@@ -3767,8 +3782,10 @@ int chain_prepare(so_matcher* m, int nq, int nk, ChainOffsets* O) {
     int rc;
     if ((rc = m->d_chain.ensure(O->d_total))) return rc;
     if ((rc = m->h_chain.ensure(O->h_total))) return rc;
+    if ((rc = m->d_kpslot.ensure(sizeof(int32_t) * (size_t)std::max(nk, (int)so::kResolveMaxCand)))) return rc;
     m->keys_dev_override = (uint32_t*)((uint8_t*)m->d_chain.p + O->d_keys);
     m->cnt8_dev_override = (uint8_t*)m->d_chain.p + O->d_cnt8;
+    m->slot_out_override = (int32_t*)((uint8_t*)m->d_chain.p + O->d_qslot);
     return SO_OK;
 }
 
@@ -3792,7 +3809,7 @@ int so_track_stage_last_frame_submit(so_matcher* m, const so_dframe* cur, const 
     int rc = chain_prepare(m, last->n, cur->n, &O);
     if (rc == SO_OK) rc = so_track_search_last_frame_submit(m, cur, nullptr, last, map, Tcw12, last_slot, th);
     m->keys_dev_override = nullptr;
-    m->cnt8_dev_override = nullptr;
+    m->cnt8_dev_override = nullptr;  m->slot_out_override = nullptr;
     if (rc != SO_OK) return rc;
     if (m->pend.empty) {  // nothing was launched
         chain_drop_search(m);
@@ -3807,9 +3824,9 @@ int so_track_stage_last_frame_submit(so_matcher* m, const so_dframe* cur, const 
     return rc;
 }
 
-int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const int32_t* kp_slot, const so_map* map,
-                                    const float* Tcw12, int32_t n_local, const int32_t* local_slot, int32_t first_slot,
-                                    const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
+int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const int32_t* kp_slot, int kp_slot_is_last_stage,
+                                    const so_map* map, const float* Tcw12, int32_t n_local, const int32_t* local_slot,
+                                    int32_t first_slot, const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
                                     float log_scale_factor, const float* intr4, const float* level_inv_sigma2) {
     if (!m || !cur || !kp_slot || !map || !Tcw12 || !intr4 || !level_inv_sigma2 || n_local < 0 || m->chain.active)
         return SO_ERR_INVALID_ARG;
@@ -3819,25 +3836,29 @@ int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const i
     int rc = chain_prepare(m, n_local, cur->n, &O);
     if (rc != SO_OK) {
         m->keys_dev_override = nullptr;
-        m->cnt8_dev_override = nullptr;
+        m->cnt8_dev_override = nullptr;  m->slot_out_override = nullptr;
         return rc;
     }
-    // the bindings on entry: the search's excluded set, and edges of the pose problem (the resolve kernel reads them in place)
+    // the bindings on entry: the search's excluded set, and edges of the pose problem.  The resolve kernel reads them from
+    // the host-mapped copy - or, when they are what the last stage left on the device (its matches, minus its pose's
+    // outliers), from there: no read across PCIe inside the chain
+    const bool on_device = kp_slot_is_last_stage && m->kpslot_frame == cur && m->kpslot_generation == cur->generation;
     int32_t* slot_in = (int32_t*)((uint8_t*)m->h_chain.p + O.h_slot_in);
-    memcpy(slot_in, kp_slot, sizeof(int32_t) * (size_t)cur->n);
+    if (!on_device) memcpy(slot_in, kp_slot, sizeof(int32_t) * (size_t)cur->n);
     static thread_local std::vector<uint8_t> excluded;
     excluded.resize((size_t)cur->n);
     for (int k = 0; k < cur->n; k++) excluded[(size_t)k] = kp_slot[k] >= 0 ? 1 : 0;
     rc = so_track_search_local_map_submit(m, cur, excluded.data(), map, Tcw12, n_local, local_slot, first_slot, skip, th, nn_ratio,
                                           viewing_cos_limit, log_scale_factor);
     m->keys_dev_override = nullptr;
-    m->cnt8_dev_override = nullptr;
+    m->cnt8_dev_override = nullptr;  m->slot_out_override = nullptr;
     if (rc != SO_OK) return rc;
     if (m->pend.empty) {
         chain_drop_search(m);
         return SO_RETRY_ON_HOST;
     }
-    rc = chain_launch(m, 1, O, cur, nullptr, map, Tcw12, 0, (const int32_t*)((uint8_t*)m->h_chain.dev + O.h_slot_in), intr4,
+    rc = chain_launch(m, 1, O, cur, nullptr, map, Tcw12, 0,
+                      on_device ? (const int32_t*)m->d_kpslot.p : (const int32_t*)((uint8_t*)m->h_chain.dev + O.h_slot_in), intr4,
                       level_inv_sigma2);
     if (rc != SO_OK) {
         (void)hipStreamSynchronize(m->stream);
@@ -3853,6 +3874,7 @@ int so_track_stage_pose_again_submit(so_matcher* m, const float* Tcw12) {
     so_matcher::ChainPending& C = m->chain;
     so::PoseOptArgs& A = m->chain_pose;
     so::pose_from_Tcw12(Tcw12, A.init);
+    A.kp_slot_clear = nullptr;
     memcpy(C.Tcw_in, Tcw12, 48);
     if (++m->chain_seq == 0) m->chain_seq = 1;
     C.seq = m->chain_seq;
@@ -3946,6 +3968,8 @@ int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint
     if (!again) {
         memcpy(kp_to_q, h + C.h_k2q, sizeof(int32_t) * (size_t)C.n_kp);
         *nmatches = head[1];
+        m->kpslot_frame = C.frame;  // d_kpslot holds this frame's bindings behind this stage
+        m->kpslot_generation = C.frame->generation;
     }
     const int ne = head[0];
     *n_edges = ne;

@@ -37,7 +37,7 @@ def _bind(lib):
     lib.so_track_search_last_frame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, f, C.c_int, vp, ip]
     lib.so_track_search_local_map.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, f, f, f, f, vp, vp, ip]
     lib.so_track_stage_last_frame_submit.argtypes = [vp, vp, vp, vp, vp, vp, f, C.c_int, vp, vp]
-    lib.so_track_stage_local_map_submit.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, vp, f, f, f, f, vp, vp]
+    lib.so_track_stage_local_map_submit.argtypes = [vp, vp, vp, C.c_int, vp, vp, i32, vp, i32, vp, f, f, f, f, vp, vp]
     lib.so_track_stage_pose_again_submit.argtypes = [vp, vp]
     lib.so_track_stage_wait.argtypes = [vp, vp, ip, vp, ip, vp, vp, vp, ip, vp]
     lib._dframe_bound = True
@@ -224,7 +224,7 @@ def track_stage_last_frame(matcher, cur, last, dmap, Tcw, last_slot, th, K4, lev
 
 
 def track_stage_local_map(matcher, cur, kp_slot, dmap, Tcw, n_local, th, cos_limit, log_scale_factor, K4, level_inv_sigma2,
-                          local_slot=None, skip=None, first_slot=0):
+                          local_slot=None, skip=None, first_slot=0, kp_slot_is_last_stage=False):
     """so_track_stage_local_map_submit + so_track_stage_wait (TrackLocalMap: SearchLocalPoints + PoseOptimization)."""
     lib = matcher._lib
     _bind(lib)
@@ -234,7 +234,8 @@ def track_stage_local_map(matcher, cur, kp_slot, dmap, Tcw, n_local, th, cos_lim
     slot = None if local_slot is None else np.ascontiguousarray(local_slot, np.int32)
     sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
     k4, ls = np.ascontiguousarray(K4, np.float32), np.ascontiguousarray(level_inv_sigma2, np.float32)
-    rc = lib.so_track_stage_local_map_submit(matcher._h, cur._h, _vp(ks), dmap._h, _vp(T), int(n_local), _vp(slot), int(first_slot),
+    rc = lib.so_track_stage_local_map_submit(matcher._h, cur._h, _vp(ks), int(bool(kp_slot_is_last_stage)), dmap._h, _vp(T), int(n_local),
+                                             _vp(slot), int(first_slot),
                                              _vp(sk), float(th), float(matcher.mfNNratio), float(cos_limit), float(log_scale_factor),
                                              _vp(k4), _vp(ls))
     if rc == SO_RETRY_ON_HOST:

@@ -1199,7 +1199,7 @@ int step_m1_submit(so_replay* r) {
         for (int i = 0; i < nl; i++)
             if (bound[(size_t)M.tv_local[(size_t)i]]) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:1117-1124)
         if (track_chain_on() && !r->lockstep) {
-            const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), r->map, S.Ta, nl, M.tv_local.data(), 0,
+            const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, nl, M.tv_local.data(), 0,
                                                            r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
             if (rc == SO_OK) {
                 S.stage2_dev = true;
@@ -1226,7 +1226,7 @@ int step_m1_submit(so_replay* r) {
         if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:1117-1124)
     }
     if (track_chain_on() && !r->lockstep) {
-        const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), r->map, S.Ta, S.n_local, nullptr, first,
+        const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, S.n_local, nullptr, first,
                                                        r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
         if (rc == SO_OK) {
             S.stage2_dev = true;

@@ -64,6 +64,19 @@ def test_last_frame_stage_equals_search_plus_pose(S, oracle, seed, dist):
         _, n_in2, Tb, outl2, _ = _host_pose(S, T2, kp_slot, cxy, ck["octave"], Xw)
         assert again is not None and np.array_equal(again["Tcw"], Tb) and np.array_equal(again["edge_outlier"], outl2)
         assert again["n_inliers"] == n_in2 and np.array_equal(again["edge_kp"], idx)
+        # the local-map stage behind it, with the bindings the last-frame stage left ON THE DEVICE (its matches minus its pose's
+        # outliers: Tracking.cc:1030-1046) against the same stage fed the host copy of those bindings
+        r = dfm.track_stage_last_frame(m, cur, last, dmap, Tc, slot, th, K4, INV_SIGMA2)
+        bound = kp_slot.copy()
+        bound[r["edge_kp"][r["edge_outlier"] != 0]] = -1
+        skip = np.zeros(len(Xw), np.uint8); skip[bound[bound >= 0]] = 1
+        a_dev = dfm.track_stage_local_map(m, cur, bound, dmap, r["Tcw"], len(Xw), 1.0, 0.5, LOG_SF, K4, INV_SIGMA2, skip=skip,
+                                          kp_slot_is_last_stage=True)
+        a_host = dfm.track_stage_local_map(m, cur, bound, dmap, r["Tcw"], len(Xw), 1.0, 0.5, LOG_SF, K4, INV_SIGMA2, skip=skip)
+        assert a_dev is not None and a_host is not None and a_dev["n_edges"] > (bound >= 0).sum() > 100
+        for k in ("kp_to_q", "edge_kp", "edge_outlier", "Tcw", "in_view"):
+            assert np.array_equal(a_dev[k], a_host[k]), k
+        assert a_dev["nmatches"] == a_host["nmatches"] and a_dev["n_inliers"] == a_host["n_inliers"]
         m.close()
     dmap.close(); cur.close(); last.close(); ex.close()
 
