@@ -240,7 +240,10 @@ struct so_ba {
     int flow_timeouts = 0;
     int flow_reserved = 0;                  // tiles this context holds of the process-wide residency budget
     std::vector<int> tile_first;
-    int stage2_hint = 0;                    // trials to enqueue ahead for the second stage: what the last call needed + 2 (0: all)
+    int stage2_hint = 0;                    // trials the second stage of the last call needed (0: unknown, all are enqueued ahead)
+    int done_seq = 0;                       // tags the completion words of a call (h_abort + 16)
+    bool leftover_launches = false;         // the last call returned on its early completion word: launches may still be draining
+    hipEvent_t e1a = nullptr;               // behind the early epilogue
     int linear_solver = 0;                  // so_ba_set_linear_solver: 0 direct (block-skyline Cholesky), 1 block-Jacobi PCG (ba_pcg.hip)
     BaPcgHost pcg;                          // its tolerance / iteration cap, workspace pointers and counters
     int pcg_nnz_blocks = 0;                 // nonzero 6 x 6 blocks of S in the last PCG problem
@@ -301,6 +304,7 @@ struct Run {
     int n_reordered = 0;  // keyframes moved to the separator block at the end of the elimination order
     const volatile uint8_t* stop = nullptr;
     bool terminate() const { return stop && *stop; }
+    bool returned_early = false;  // the results were taken behind the early epilogue (its stop event is e1a)
 };
 
 // internal status of so_bundle_adjust's first attempt: a workgroup of a single-launch (dataflow) solve waited longer than
@@ -414,6 +418,7 @@ int so_ba_create(int device, so_ba** out) {
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipEventCreate(&b->e0);
     if (e == hipSuccess) e = hipEventCreate(&b->e1);
+    if (e == hipSuccess) e = hipEventCreate(&b->e1a);
     if (e == hipSuccess) e = hipEventCreate(&b->pe0);
     if (e == hipSuccess) e = hipEventCreate(&b->pe1);
     for (hipEvent_t& ev : b->ev_solve)
@@ -453,6 +458,7 @@ void so_ba_destroy(so_ba* b) {
     if (b->h_po) (void)hipHostFree(b->h_po);
     if (b->e0) (void)hipEventDestroy(b->e0);
     if (b->e1) (void)hipEventDestroy(b->e1);
+    if (b->e1a) (void)hipEventDestroy(b->e1a);
     if (b->pe0) (void)hipEventDestroy(b->pe0);
     if (b->pe1) (void)hipEventDestroy(b->pe1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -530,6 +536,10 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         }
     const double t_begin = now_ms();
     SO_HIP(hipSetDevice(b->device));
+    if (b->leftover_launches) {  // the last call returned on its early completion word: let what was queued behind it drain
+        SO_HIP(hipStreamSynchronize(b->stream));
+        b->leftover_launches = false;
+    }
     b->solve_ms = 0.f;
     b->n_solves = 0;
     *(volatile unsigned*)b->h_flow_abort = 0;
@@ -1112,6 +1122,34 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
                          ob + r_out, s);
         (void)hipEventRecord(b->e1, s);
     };
+    // Completion words (single-enqueue path): the host spins on a word in host-mapped memory instead of polling the stream
+    // (hipStreamQuery + 20 us naps saw the end of a window tens of microseconds late), and the call's results can be
+    // picked up BEFORE the launches enqueued as a reserve have drained: [stage 2's trials as the last call needed them]
+    // [finish + word 1] [two more trials] [finish + word 2].  Word 1 with the LM state "over": the reserve trials return
+    // at once (they drain under the caller's write-back), the second finish rewrites the same bytes.
+    if (++b->done_seq >= (1 << 20)) b->done_seq = 1;
+    int* done_word_dev = reinterpret_cast<int*>(b->h_abort_dev + 16);
+    volatile int* done_word = reinterpret_cast<volatile int*>(b->h_abort + 16);
+    *done_word = 0;
+    int phases = 0, early_phase = 0;
+    auto signal = [&]() { launch_ba_signal(done_word_dev, (b->done_seq << 8) | ++phases, s); };
+    auto wait_word = [&](int phase) -> int {
+        const int want_seq = b->done_seq;
+        for (unsigned long it = 1;; it++) {
+            const int w = *done_word;
+            if ((w >> 8) == want_seq && (w & 255) >= phase) break;
+            if (r.stop) *b->h_abort = *r.stop ? 1 : 0;  // forceStopFlag forwarded to the decision kernels
+            if ((it & 0xfff) == 0) {  // every ~0.1 ms: has the stream died or drained without the word?
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+                if (it > 0x40000) std::this_thread::sleep_for(std::chrono::microseconds(20));  // a global map: seconds, not a window
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return SO_OK;
+    };
     const bool two_stages = opt->its_stage2 > 0;
     const uint8_t* abort_dev = r.stop ? b->h_abort_dev : nullptr;
     BaDev d2 = r.d;
@@ -1143,7 +1181,19 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
             // of queue time each.  Enqueue what the context's last call needed plus two; a stage that wants more is
             // topped up by the loop below (one host round trip).
             static const bool no_hint = getenv("SWARMORB_BA_NO_STAGE2_HINT") != nullptr;  // A/B: all iterations ahead, as before round 5
-            trials(d2, no_hint ? opt->its_stage2 : std::min(opt->its_stage2, b->stage2_hint > 0 ? b->stage2_hint : opt->its_stage2));
+            const int ahead = no_hint ? opt->its_stage2 : std::min(opt->its_stage2, b->stage2_hint > 0 ? b->stage2_hint : opt->its_stage2);
+            trials(d2, ahead);
+            early_phase = 0;
+            static const bool no_early = getenv("SWARMORB_BA_NO_EARLY") != nullptr;  // A/B: the reserve in front of the only epilogue
+            if (no_early) trials(d2, std::min(2, opt->its_stage2 - ahead));
+            if (ahead < opt->its_stage2 && !no_early) {  // results out as soon as the stage is over; two trials in reserve behind them
+                launch_ba_finish(r.d, (double)opt->chi2_threshold, (BaPose*)(ob + r_pose), (double*)(ob + r_pt), (double*)(ob + r_chi2),
+                                 ob + r_out, s);
+                (void)hipEventRecord(b->e1a, s);
+                signal();
+                early_phase = phases;
+                trials(d2, std::min(2, opt->its_stage2 - ahead));
+            }
         };
         launch_ba_errors(r.d, 0, kBaGateNone, r.nb_err, s);
         launch_ba_build(r.d, kBaGateNone, s);
@@ -1151,22 +1201,36 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         trials(r.d, opt->its_stage1);
         if (two_stages) stage2_chained();
         epilogue();
+        signal();
         BaLm lm;
-        bool stopped_between = false;
+        bool stopped_between = false, returned_early = false;
         for (;;) {
             SO_HIP(hipGetLastError());
-            if ((rc = wait_stream(r))) return rc;
+            if (early_phase > 0) {  // the results may be out before the reserve has drained
+                if ((rc = wait_word(early_phase))) return rc;
+                if (*(volatile unsigned*)b->h_flow_abort != 0) return kErrFlowTimeout;
+                memcpy(&lm, b->h_lm, sizeof(lm));
+                early_phase = 0;
+                if (lm.active == 0 && lm.stages_begun >= 2) {
+                    returned_early = true;
+                    b->leftover_launches = true;
+                    break;
+                }
+            }
+            if ((rc = wait_word(phases))) return rc;
             if (*(volatile unsigned*)b->h_flow_abort != 0) return kErrFlowTimeout;  // a dataflow solve gave up waiting
             memcpy(&lm, b->h_lm, sizeof(lm));
             if (lm.active == 1) {  // stage 1 wants more trials than were enqueued
                 trials(r.d, std::max(1, lm.iterations - lm.it));
                 if (two_stages) stage2_chained();
                 epilogue();
+                signal();
                 continue;
             }
             if (lm.active == 2) {
                 trials(d2, std::max(1, lm.iterations - lm.it));
                 epilogue();
+                signal();
                 continue;
             }
             if (two_stages && lm.stages_begun == 1 && !stopped_between) {
@@ -1181,10 +1245,12 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
                 launch_ba_stage_begin(d2, r.nb_err, opt->its_stage2, b->h_lm_dev, kBaGateNone, nullptr, s);
                 trials(d2, opt->its_stage2);
                 epilogue();
+                signal();
                 continue;
             }
             break;
         }
+        r.returned_early = returned_early;
         const bool begun2 = lm.stages_begun >= 2;
         inf.iterations_stage1 = begun2 ? lm.prev_done : lm.done;
         inf.chi2_initial = begun2 ? lm.prev_chi_begin : lm.chi_begin;  // chi2 before optimising (information only)
@@ -1193,7 +1259,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         if (begun2) {
             inf.iterations_stage2 = lm.done;
             if (lm.done > 0) inf.chi2_final = lm.chi_out;
-            b->stage2_hint = std::max(2, lm.done + 2);
+            b->stage2_hint = std::max(1, (int)lm.done);  // (+ two in reserve behind the early epilogue)
         }
         if (stopped_between || r.terminate()) inf.aborted = 1;
         r.d.robust = begun2 ? 0 : r.d.robust;
@@ -1240,7 +1306,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     inf.lambda_final = b->h_lm->lambda;
     inf.lm_trials = b->h_lm->trials;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, b->e0, b->e1) == hipSuccess) inf.gpu_ms = ms;
+    if (hipEventElapsedTime(&ms, b->e0, r.returned_early ? b->e1a : b->e1) == hipSuccess) inf.gpu_ms = ms;
     inf.solve_ms = b->solve_ms;
     inf.n_solves = b->n_solves;
     if (r.d.plan) {

@@ -219,6 +219,7 @@ void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, int gate, hi
 // every edge into the result block
 void launch_ba_finish(const BaDev& d, double chi2_threshold, BaPose* pose_out, double* pt_out, double* chi2_out,
                       uint8_t* outlier_out, hipStream_t s);
+void launch_ba_signal(int* word_host_mapped, int value, hipStream_t s);  // the word is stored when everything before it is done
 
 struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.hip)
     const float* Xw;          // n x 3

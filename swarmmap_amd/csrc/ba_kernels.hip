@@ -396,6 +396,17 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaDev d, double chi2_thr
     if (i < 3 * d.n_points) pt_out[i] = points[i];
 }
 
+// Completion word behind an epilogue: everything enqueued before this launch has run and its writes into host-mapped memory
+// are out, so the host can spin on the word instead of querying the stream.
+__global__ void ba_signal_kernel(int* __restrict__ word, int value) {
+    __threadfence_system();
+    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void launch_ba_signal(int* word_host_mapped, int value, hipStream_t s) {
+    hipLaunchKernelGGL(ba_signal_kernel, dim3(1), dim3(1), 0, s, word_host_mapped, value);
+}
+
 void launch_ba_finish(const BaDev& d, double chi2_threshold, BaPose* pose_out, double* pt_out, double* chi2_out,
                       uint8_t* outlier_out, hipStream_t s) {
     int nthreads = d.n_edges > d.n_poses ? d.n_edges : d.n_poses;
