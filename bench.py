@@ -815,12 +815,27 @@ def main():
     import ctypes
     libc = ctypes.CDLL(None)
 
+    # Independent bench PROCESSES sharing one GPU (tools/agents_processes.py) meet at the same points through a directory:
+    # BENCH_FILE_BARRIER="dir:index:count" - every process drops a file per barrier and waits until all of them are there, so
+    # that the timed regions of all processes cover the same interval and their rates may be added
+    fb = os.environ.get("BENCH_FILE_BARRIER")
+    fb_state = {"n": 0}
+
     def barrier():
         if distributed:
             torch.distributed.barrier()
             libc.fflush(None)  # RCCL prints a version banner through C stdio when a communicator comes up: out it goes
                                # now, on every rank, so that rank 0's JSON line stays the last line of the job's stdout
         torch.cuda.synchronize()
+        if fb:
+            d, idx, cnt = fb.rsplit(":", 2)
+            fb_state["n"] += 1
+            open(os.path.join(d, "b%d.%s" % (fb_state["n"], idx)), "w").close()
+            t_end = time.time() + 600.0
+            while sum(os.path.exists(os.path.join(d, "b%d.%d" % (fb_state["n"], i))) for i in range(int(cnt))) < int(cnt):
+                if time.time() > t_end:
+                    raise RuntimeError("file barrier: a peer process did not arrive")
+                time.sleep(0.0005)
 
     euroc = args.size == "euroc"
     size = synth.EUROC if euroc else synth.KITTI

@@ -886,6 +886,10 @@ void so_matcher_destroy(so_matcher* m) {
         const_cast<so_map*>(m->pend.held_map)->grow_mu.unlock_shared();
         m->pend.held_map = nullptr;
     }
+    if (m->chain.holds_map && m->chain.map) {  // ... or a stage's repeated pose
+        const_cast<so_map*>(m->chain.map)->grow_mu.unlock_shared();
+        m->chain.holds_map = false;
+    }
     for (DevBuf* b : {&m->d_in, &m->d_A, &m->d_B, &m->d_res}) b->release();
     for (PinBuf* b : {&m->h_in, &m->h_res, &m->h_rq}) b->release();
     m->d_rq.release();
