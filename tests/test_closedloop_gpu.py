@@ -150,3 +150,50 @@ def test_cpp_closed_loop_under_the_reference_policy_tracks_and_reports_its_inter
     px = PLANE_Z / float(K[0])
     assert a["inliers"][1:].min() > 250
     assert minitrack.ate_rmse(a["centres"], gt, align=False) < 1.5 * px
+
+
+def test_three_closed_loop_agents_in_threads_equal_their_solo_runs():
+    """Agents sharing a GPU (bench.py --agents-per-gpu: a tracking thread + a local-mapping thread each, all in one process):
+    every agent's trajectory, local-mapping log and final bindings are those of the same agent run alone - to the bit, the
+    C++ loop being deterministic under the deterministic schedule."""
+    import threading
+
+    import torch
+    K, dist, nfeat, n = synth.EUROC_K, synth.EUROC_DIST, 1000, 37
+    vocab = make_vocabulary()
+    streams, blocks = [], []
+    for a in range(3):
+        st = synth.FrameStream(seed=20221001 + 97 * a, size=synth.EUROC, K=K, dist=dist)
+        block = torch.empty((n + 2, st.h, st.w), dtype=torch.uint8).pin_memory()
+        view = block.numpy()
+        for t in range(n + 2):
+            view[t] = st.frame(t)
+        streams.append(st); blocks.append(block)
+
+    def run(a, out):
+        st, block = streams[a], blocks[a]
+        out[a] = _cpp_chain(n, [block.data_ptr() + i * st.w * st.h for i in range(n + 2)], st, K, dist, nfeat, vocab)[0]
+
+    solo, par, errs = {}, {}, []
+    for a in range(3):
+        run(a, solo)
+
+    def guarded(a):
+        try:
+            run(a, par)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=guarded, args=(a,)) for a in range(3)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    for a in range(3):
+        s, p = solo[a], par[a]
+        assert np.array_equal(s["poses"], p["poses"]) and np.array_equal(s["kf_poses"], p["kf_poses"]), a
+        assert np.array_equal(s["lm_log"], p["lm_log"]) and np.array_equal(s["inliers"], p["inliers"]), a
+        assert all(np.array_equal(x, y) for x, y in zip(s["kf_bindings"], p["kf_bindings"])), a
+        assert s["inliers"][1:].min() > 300
+    assert not np.array_equal(solo[0]["poses"], solo[1]["poses"])  # (different streams)
