@@ -726,6 +726,7 @@ int cl_frame_begin(so_replay* r, int t) {
         M.outbox.pop_front();
     }
     M.job_pending = false;
+    const double a0 = now_ms();
     const size_t n_old = r->mp_X.size() / 3;
     if ((int)n_old != pk.first_new) {
         r->error = "closed loop: the tracking side's map size and the packet disagree";
@@ -766,6 +767,7 @@ int cl_frame_begin(so_replay* r, int t) {
             Lf.kp_mp[(size_t)i] = s;
         }
     }
+    M.apply_ms += now_ms() - a0;
     return SO_OK;
 }
 

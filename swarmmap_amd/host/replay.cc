@@ -791,14 +791,14 @@ int so_replay_set_closed_loop(so_replay* r, int kf_every, int delay, int n_free,
     return SO_OK;
 }
 // counts[0..7]: local-mapping jobs, windows solved, windows aborted by the stop flag, InterruptBA calls, map slots, bad
-// points, keyframes, reserved; wait_ms: time the tracking thread waited for packets (deterministic schedule)
+// points, keyframes, microseconds the tracking thread spent applying packets; wait_ms: time the tracking thread waited for packets (deterministic schedule)
 int so_replay_cl_counts(so_replay* r, int64_t* counts8, double* wait_ms) {
     if (!r || !r->cl || !counts8) return SO_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(r->mu);  // (call after so_replay_drain: the local-mapping side is read here)
     ClosedLoop& M = *r->cl;
     int64_t nbad = 0;
     for (uint8_t b : M.bad) nbad += b;
-    const int64_t c[8] = {(int64_t)(M.lm_log.size() / 12), M.windows, M.aborted, M.interrupts, (int64_t)M.bad.size(), nbad, (int64_t)M.kfs.size(), 0};
+    const int64_t c[8] = {(int64_t)(M.lm_log.size() / 12), M.windows, M.aborted, M.interrupts, (int64_t)M.bad.size(), nbad, (int64_t)M.kfs.size(), (int64_t)(M.apply_ms * 1e3)};
     memcpy(counts8, c, sizeof(c));
     if (wait_ms) *wait_ms = M.wait_ms;
     return SO_OK;

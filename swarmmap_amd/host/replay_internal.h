@@ -131,6 +131,7 @@ struct ClosedLoop {
     int last_kf_t = 0, n_kf = 0, apply_at = 0, interrupts = 0;
     bool job_pending = false;
     double wait_ms = 0.0;
+    double apply_ms = 0.0;  // tracking thread: applying the packets (map rows, flags, last-frame fix-ups)
     std::vector<int32_t> ref_log, kf_t;  // per frame: id of its reference keyframe; per keyframe: frame index
     std::vector<double> Tcr_log;         // per frame: pose relative to the reference keyframe (16)
     // ---- hand-over ----

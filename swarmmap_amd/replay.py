@@ -167,8 +167,8 @@ class Replay:
         return dict(lm_log=lm[:n], kf_t=kf_t, kf_poses=kf_T, ref_kf=ref, Tcr=Tcr, final_centres=np.array(fin).reshape(-1, 3),
                     kf_bindings=binds, point_bad=bad[:npnt], point_replaced_by=repl[:npnt],
                     kf_centres=np.array(kfc).reshape(-1, 3),
-                    counts=dict(zip(("jobs", "windows", "windows_aborted", "interrupt_ba", "map_slots", "bad_points", "keyframes"),
-                                    counts[:7].tolist())), wait_ms=wait.value)
+                    counts=dict(zip(("jobs", "windows", "windows_aborted", "interrupt_ba", "map_slots", "bad_points", "keyframes",
+                                     "packet_apply_us"), counts[:8].tolist())), wait_ms=wait.value)
 
     def preallocate(self):
         self._check(self.lib.so_replay_preallocate(self.h), "preallocate")
