@@ -27,10 +27,15 @@ def opt():
 
 
 def _compare(r, o, thr=5.991):
+    import os
+    if os.environ.get("BA_DIFF_LOG"):
+        print("BADIFF trials %d it2 %d" % (r["info"]["lm_trials"] - o["info"]["lm_trials"], r["info"]["iterations_stage2"] - o["info"]["iterations_stage2"]))
+    # the Levenberg-Marquardt PATH, not only its end point: the same iterations in both stages and the same trials (accept /
+    # reject decisions) as the oracle - on every problem of this file the differences are 0 and 0 (round 5, BA_DIFF_LOG=1);
+    # one trial of slack for a rejection that sits on rounding noise near convergence (see the pose-optimisation test)
     assert r["info"]["iterations_stage1"] == o["info"]["iterations_stage1"]
-    assert abs(r["info"]["iterations_stage2"] - o["info"]["iterations_stage2"]) <= 1
-    # trial counts may differ by rounding-noise rejections near convergence (see the pose-optimisation test)
-    assert abs(r["info"]["lm_trials"] - o["info"]["lm_trials"]) <= 10
+    assert r["info"]["iterations_stage2"] == o["info"]["iterations_stage2"]
+    assert abs(r["info"]["lm_trials"] - o["info"]["lm_trials"]) <= 1
     assert r["info"]["chi2_initial"] == pytest.approx(o["info"]["chi2_initial"], rel=1e-9)
     assert r["info"]["chi2_final"] == pytest.approx(o["info"]["chi2_final"], rel=1e-6)
     assert np.abs(r["Tcw"] - o["Tcw"]).max() <= POSE_TOL
