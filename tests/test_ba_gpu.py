@@ -542,7 +542,9 @@ def test_full_size_global_ba_matches_the_oracle_fixture(opt, name, fixture, robu
     r = opt.BundleAdjustment(p, nIterations=10, bRobust=robust)
     inf = dict(zip([str(k) for k in g["info_keys"]], g["info_vals"]))
     assert r["info"]["iterations_stage1"] == int(inf["iterations_stage1"]) == 10
-    assert abs(r["info"]["lm_trials"] - int(inf["lm_trials"])) <= 10
+    if os.environ.get("BA_DIFF_LOG"):
+        print("BADIFF-GBA %s robust %d trials %d" % (name, int(robust), r["info"]["lm_trials"] - int(inf["lm_trials"])))
+    assert abs(r["info"]["lm_trials"] - int(inf["lm_trials"])) <= 1  # (observed: 0 on all six; the accept / reject path of the oracle)
     assert r["info"]["chi2_initial"] == pytest.approx(inf["chi2_initial"], rel=1e-9)
     assert r["info"]["chi2_final"] == pytest.approx(inf["chi2_final"], rel=1e-6)
     # poses travel as float32: a translation of 136 m (these maps span ~300 m) has an ulp of 1.5e-5, so the absolute
@@ -604,7 +606,9 @@ def test_pcg_on_the_full_size_maps_matches_the_oracle_fixture(pcg_opt, name, fix
     r = pcg_opt.BundleAdjustment(p, nIterations=10, bRobust=False)
     inf = dict(zip([str(k) for k in g["info_keys"]], g["info_vals"]))
     assert r["info"]["solver_path"] == 3 and r["info"]["iterations_stage1"] == int(inf["iterations_stage1"]) == 10
-    assert abs(r["info"]["lm_trials"] - int(inf["lm_trials"])) <= 10
+    if os.environ.get("BA_DIFF_LOG"):
+        print("BADIFF-PCG %s trials %d" % (name, r["info"]["lm_trials"] - int(inf["lm_trials"])))
+    assert abs(r["info"]["lm_trials"] - int(inf["lm_trials"])) <= 1  # (observed: 0 on all six; the accept / reject path of the oracle)
     assert r["info"]["chi2_final"] == pytest.approx(inf["chi2_final"], rel=1e-6)
     assert np.all(np.abs(r["Tcw"] - g["Tcw"]) <= POSE_TOL + 4 * np.spacing(np.abs(g["Tcw"]).astype(np.float32)))
     assert np.abs(r["Xw"][::8] - g["Xw_every8"]).max() <= POINT_TOL
