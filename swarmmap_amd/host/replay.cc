@@ -373,11 +373,14 @@ int lm_matcher_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed) {
 // loop's two threads hand keyframes to each other and both touch pinned staging memory and ring doorbells all the
 // time; left to the OS on a two-socket, 16-CCD box they cost 5 % of the frame rate and most of the run-to-run spread
 // (include/swarmorb.h, so_device_host_cpus).  SWARMORB_NO_PIN=1 leaves placement to the OS.
-void pin_to_device_node(const so_replay* r) {
+// role >= 0 with SWARMORB_PIN_CORES=1 (A/B): the thread gets ONE cpu of the group - the role-th of its first half, i.e. a
+// physical core of its own (the second half of a group are the SMT siblings) - instead of the whole group
+void pin_to_device_node(const so_replay* r, int role = -1) {
     if (r->host_cpus.empty()) return;
     cpu_set_t set;
     CPU_ZERO(&set);
     int n_set = 0;
+    std::vector<int> listed;
     const char* p = r->host_cpus.c_str();
     while (*p) {  // "a-b,c,d-e"
         char* end = nullptr;
@@ -393,6 +396,7 @@ void pin_to_device_node(const so_replay* r) {
         for (long c = a; c <= b && c < CPU_SETSIZE; c++)
             if (c >= 0) {
                 CPU_SET((int)c, &set);
+                listed.push_back((int)c);
                 n_set++;
             }
         if (*p == ',') p++;
@@ -405,6 +409,14 @@ void pin_to_device_node(const so_replay* r) {
         CPU_AND(&both, &set, &now);
         if (CPU_COUNT(&both) == 0) return;
         set = both;
+    }
+    static const bool cores = getenv("SWARMORB_PIN_CORES") && atoi(getenv("SWARMORB_PIN_CORES")) != 0;
+    if (cores && role >= 0 && listed.size() >= 4) {
+        const int half = (int)listed.size() / 2, cpu = listed[(size_t)(role % half)];
+        if (CPU_ISSET(cpu, &set)) {
+            CPU_ZERO(&set);
+            CPU_SET(cpu, &set);
+        }
     }
     if (n_set > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
 }
@@ -434,7 +446,7 @@ struct CallerPin {
     explicit CallerPin(const so_replay* r) {
         CPU_ZERO(&saved);
         have = !r->host_cpus.empty() && pthread_getaffinity_np(pthread_self(), sizeof(saved), &saved) == 0;
-        pin_to_device_node(r);
+        pin_to_device_node(r, 0);
     }
     ~CallerPin() {
         if (have) (void)pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved);
@@ -442,7 +454,7 @@ struct CallerPin {
 };
 
 void mapper_loop(so_replay* r) {
-    pin_to_device_node(r);  // (the library's own thread: pinned for its lifetime)
+    pin_to_device_node(r, 1);  // (the library's own thread: pinned for its lifetime)
     for (;;) {
         int timed;
         bool pre = false;
