@@ -438,19 +438,24 @@ int so_map_write(so_map* m, int32_t first, int32_t n, const float* Xw, const flo
     if ((rc = stage(m, sn * 64))) return rc;
     uint8_t* h = (uint8_t*)m->h_stage;
     hipStream_t s = m->stream;
+    // the five columns side by side in the pinned staging block; ONE kernel reads them in place (pinned memory is
+    // device-visible) instead of five host-to-device copies
     size_t o = 0;
-    auto put = [&](const void* src, size_t bytes, void* dst) -> int {
-        if (!src) return SO_OK;
+    auto put = [&](const void* src, size_t bytes) -> const uint8_t* {
+        if (!src) return nullptr;
         memcpy(h + o, src, bytes);
-        SO_HIP(hipMemcpyAsync(dst, h + o, bytes, hipMemcpyHostToDevice, s));
-        o += bytes;
-        return SO_OK;
+        const uint8_t* at = h + o;
+        o += bytes;  // (all sizes are multiples of four)
+        return at;
     };
-    if ((rc = put(Xw, 12 * sn, m->d_Xw + 3 * (size_t)first))) return rc;
-    if ((rc = put(normal, 12 * sn, m->d_normal + 3 * (size_t)first))) return rc;
-    if ((rc = put(max_dist, 4 * sn, m->d_max + first))) return rc;
-    if ((rc = put(min_dist, 4 * sn, m->d_min + first))) return rc;
-    if ((rc = put(desc, 32 * sn, m->d_desc + 32 * (size_t)first))) return rc;
+    const uint8_t* sX = put(Xw, 12 * sn);
+    const uint8_t* sN = put(normal, 12 * sn);
+    const uint8_t* sMx = put(max_dist, 4 * sn);
+    const uint8_t* sMn = put(min_dist, 4 * sn);
+    const uint8_t* sD = put(desc, 32 * sn);
+    launch_map_write_range(m->d_Xw, m->d_normal, m->d_max, m->d_min, m->d_desc, (const float*)sX, (const float*)sN, (const float*)sMx,
+                           (const float*)sMn, sD, first, n, s);
+    SO_HIP(hipGetLastError());
     SO_HIP(hipStreamSynchronize(s));  // keyframe rate; afterwards every stream sees the new rows
     if (appending) m->size = first + n;
     return SO_OK;

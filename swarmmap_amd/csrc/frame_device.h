@@ -70,5 +70,8 @@ void launch_frame_frustum(const FrameFrustumArgs& a, hipStream_t s);
 void launch_map_scatter_positions(float* d_Xw, const int32_t* slots, const float* X, int n, hipStream_t s);
 void launch_map_scatter_rows(float* d_Xw, float* d_normal, float* d_max, float* d_min, const int32_t* slots, const float* X,
                              const float* N, const float* mx, const float* mn, int n, hipStream_t s);
+// so_map_write: rows first .. first + n - 1 <- the given arrays (pinned host memory, 4-byte aligned; null = column untouched)
+void launch_map_write_range(float* d_Xw, float* d_normal, float* d_max, float* d_min, uint8_t* d_desc, const float* X, const float* N,
+                            const float* mx, const float* mn, const uint8_t* D, int first, int n, hipStream_t s);
 
 }  // namespace so

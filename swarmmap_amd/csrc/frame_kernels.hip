@@ -338,6 +338,30 @@ void launch_map_scatter_rows(float* d_Xw, float* d_normal, float* d_max, float* 
     hipLaunchKernelGGL(map_scatter_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_Xw, d_normal, d_max, d_min, slots, X, N, mx, mn, n);
 }
 
+// rows first .. first + n - 1 of the map table <- the five arrays of so_map_write, read in place from its pinned staging block
+// (dword copies: 3 + 3 + 1 + 1 + 8 per row; any source may be null = that column is left alone).  One launch instead of five
+// hipMemcpyAsync calls (five ~5 us copy kernels + their bookkeeping per keyframe).
+__global__ __launch_bounds__(256) void map_write_range_kernel(uint32_t* __restrict__ Xw, uint32_t* __restrict__ normal, uint32_t* __restrict__ max_d,
+                                                               uint32_t* __restrict__ min_d, uint32_t* __restrict__ desc,
+                                                               const uint32_t* __restrict__ X, const uint32_t* __restrict__ N,
+                                                               const uint32_t* __restrict__ mx, const uint32_t* __restrict__ mn,
+                                                               const uint32_t* __restrict__ D, int first, int n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, f = (size_t)first, sn = (size_t)n;
+    if (X && i < 3 * sn) Xw[3 * f + i] = X[i];
+    if (N && i < 3 * sn) normal[3 * f + i] = N[i];
+    if (mx && i < sn) max_d[f + i] = mx[i];
+    if (mn && i < sn) min_d[f + i] = mn[i];
+    if (D && i < 8 * sn) desc[8 * f + i] = D[i];
+}
+
+void launch_map_write_range(float* d_Xw, float* d_normal, float* d_max, float* d_min, uint8_t* d_desc, const float* X, const float* N,
+                            const float* mx, const float* mn, const uint8_t* D, int first, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(map_write_range_kernel, dim3((8 * n + 255) / 256), dim3(256), 0, s, (uint32_t*)d_Xw, (uint32_t*)d_normal, (uint32_t*)d_max,
+                       (uint32_t*)d_min, (uint32_t*)d_desc, (const uint32_t*)X, (const uint32_t*)N, (const uint32_t*)mx, (const uint32_t*)mn,
+                       (const uint32_t*)D, first, n);
+}
+
 void launch_frame_frustum(const FrameFrustumArgs& a, hipStream_t s) {
     if (a.n <= 0) return;
     hipLaunchKernelGGL(frame_frustum_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
