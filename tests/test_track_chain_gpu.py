@@ -154,3 +154,61 @@ def test_stage_that_runs_out_of_list_entries_hands_the_call_back(S, oracle):
     r2 = dfm.track_stage_local_map(m, cur, kp_slot, dmap, Tc, 60, 1.0, 0.5, LOG_SF, K4, INV_SIGMA2)
     assert r2 is not None and r2["nmatches"] <= 60
     m.close(); dmap.close(); cur.close(); ex.close()
+
+
+def test_stages_beyond_the_kernels_sizes_hand_the_call_back(S, oracle):
+    """More keypoints (> 4096) or more queries (> 4096) than track_resolve_kernel holds, more edges than the launched
+    PoseOptimization variant, and a KITTI-sized stage (2000 features, 2500 local points: the 512-thread resolve instance, the
+    second PoseOptimization range): the first three answer SO_RETRY_ON_HOST and leave the handle usable, the last runs on the
+    device and equals the separate calls."""
+    rng = np.random.default_rng(91)
+    img = synth.make_canvas(8, 1241, 376)
+    K4k = np.asarray(synth.KITTI_K, np.float32)
+    # --- 5000 features: more keypoints than the resolve holds
+    ex = S.ORBextractor(5000, 1.2, 8, 20, 7)
+    cur = S.DeviceFrame(ex, synth.KITTI_K)
+    ck, cxy, cd = [a.copy() for a in cur(img)]
+    assert len(ck) > 4096
+    Tc = _pose(rng)
+    Xw, normal, mx, mn, md = _make_map(rng, cxy, ck, cd, synth.KITTI_K, Tc, n_extra=0)
+    dmap = S.DeviceMap()
+    dmap.append(Xw, normal, mx, mn, md)
+    m = S.ORBmatcher(0.8, True)
+    none = np.full(len(ck), -1, np.int32)
+    assert dfm.track_stage_local_map(m, cur, none, dmap, Tc, 2000, 1.0, 0.5, LOG_SF, K4k, INV_SIGMA2) is None
+    nm, k2m, _ = dfm.search_local_map(m, cur, dmap, Tc, 2000, 1.0, 0.5, LOG_SF)  # the separate call on the same handle
+    assert nm > 500
+    m.close(); dmap.close(); cur.close(); ex.close()
+    # --- 2000 features (KITTI's setting)
+    ex = S.ORBextractor(2000, 1.2, 8, 20, 7)
+    cur = S.DeviceFrame(ex, synth.KITTI_K)
+    ck, cxy, cd = [a.copy() for a in cur(img)]
+    F = FrameView(cxy[:, 0], cxy[:, 1], ck["octave"], ck["angle"], cd, cur.bounds, ex.GetScaleFactors())
+    Xw, normal, mx, mn, md = _make_map(rng, cxy, ck, cd, synth.KITTI_K, Tc, n_extra=500)
+    dmap = S.DeviceMap()
+    dmap.append(Xw, normal, mx, mn, md)
+    rep = np.concatenate([np.arange(len(Xw))] * 3)  # 3 x ~2500 = more than 4096 queries through a slot list
+    m = S.ORBmatcher(0.8, True)
+    none = np.full(len(ck), -1, np.int32)
+    assert len(rep) > 4096
+    assert dfm.track_stage_local_map(m, cur, none, dmap, Tc, len(rep), 1.0, 0.5, LOG_SF, K4k, INV_SIGMA2, local_slot=rep.astype(np.int32)) is None
+    # the whole map once (~2500 queries: the 512-thread resolve): ~1700 matches = more edges than the first launch's range
+    # (the hint starts at "up to 1024") -> handed back once, then the handle launches the larger range
+    cam = oracle.camera(synth.KITTI_K)
+    fr = oracle.is_in_frustum(cam, cur.bounds, Tc, Xw, normal, mx, mn, 0.5, LOG_SF, 8)
+    mps = dict(in_view=fr["in_view"], proj_x=fr["proj_x"], proj_y=fr["proj_y"], view_cos=fr["view_cos"], pred_level=fr["pred_level"], desc=md,
+               has_obs=np.ones(len(Xw), np.uint8))
+    onm, ok2m = oracle.search_by_projection_mappoints(F, mps, 1.0, 0.8)
+    assert 1024 < onm <= 1792
+    first = dfm.track_stage_local_map(m, cur, none, dmap, Tc, len(Xw), 1.0, 0.5, LOG_SF, K4k, INV_SIGMA2)
+    assert first is None
+    r = dfm.track_stage_local_map(m, cur, none, dmap, Tc, len(Xw), 1.0, 0.5, LOG_SF, K4k, INV_SIGMA2)
+    assert r is not None and r["nmatches"] == onm and np.array_equal(r["kp_to_q"], ok2m)
+    after = np.where(ok2m >= 0, ok2m, -1).astype(np.int32)
+    idx = np.nonzero(after >= 0)[0]
+    opt = S.Optimizer()
+    n_in, T, outl, _ = opt.PoseOptimization(Tc, K4k, Xw[after[idx]], cxy[idx], INV_SIGMA2[ck["octave"][idx]])
+    opt.close()
+    assert np.array_equal(r["edge_kp"], idx) and np.array_equal(r["Tcw"], T.reshape(3, 4)) and np.array_equal(r["edge_outlier"], outl)
+    assert r["n_inliers"] == n_in
+    m.close(); dmap.close(); cur.close(); ex.close()
