@@ -972,7 +972,7 @@ def main():
                 cfgs["kitti_stream_1241x376"] = krec
                 del kframes
                 if st.get("closed"):
-                    # the reference's own policy when tracking outpaces mapping (Tracking.cc:810-905, LocalMapping.cc:581-583):
+                    # the reference's own policy when tracking outpaces mapping (Tracking.cc:810-892, LocalMapping.cc:581-583):
                     # results arrive when ready, a keyframe only while local mapping is idle, InterruptBA otherwise -
                     # timing-dependent by construction, so it is a second key, not the headline
                     psteps = 200

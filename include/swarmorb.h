@@ -503,8 +503,8 @@ int so_matcher_reserve(so_matcher* m, int32_t n_queries);
 int so_matcher_last_kernel_ms(so_matcher* m, float* ms);
 int so_matcher_set_profiling(so_matcher* m, int enabled);
 
-/* Tracking searches the same frame twice in a row (SearchByProjection against the last frame, Tracking.cc:1014, then
- * against the local map, :1153).  Calling this before the second search tells the handle that the next call's frame
+/* Tracking searches the same frame twice in a row (SearchByProjection against the last frame, Tracking.cc:731, then
+ * against the local map, :1006).  Calling this before the second search tells the handle that the next call's frame
  * view is the one of the previous call (same keypoints, descriptors and bounds; `excluded` may differ and is re-read):
  * the grid ordering and the candidate upload are skipped.  One-shot: it applies to the next search call only, and
  * is ignored if the handle no longer holds that frame. */
@@ -664,7 +664,7 @@ int so_track_search_local_map_submit(so_matcher* m, const so_dframe* cur, const 
 int so_track_search_local_map_wait(so_matcher* m, const uint8_t* slot_has_obs, uint8_t* in_view, int32_t* kp_to_local,
                                    int32_t* nmatches);
 
-/* TrackLocalMap's search: Tracking::SearchLocalPoints (code/src/Tracking.cc:1104-1156) — Frame::isInFrustum(pMP,
+/* TrackLocalMap's search: Tracking::SearchLocalPoints (code/src/Tracking.cc:964-1007) — Frame::isInFrustum(pMP,
  * viewing_cos_limit) (code/src/Frame.cc:316-375, MapPoint::PredictScale code/src/MapPoint.cc:476-485) for each of
  * the n_local local map points, then ORBmatcher::SearchByProjection(F, vpMapPoints, th) (code/src/ORBmatcher.cc:
  * 44-121) over the visible ones.  local_slot[i] = map slot of mvpLocalMapPoints[i] (NULL: the contiguous slots
@@ -678,8 +678,8 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
                               int32_t* nmatches);
 
 /* A tracking stage WITHOUT a host hop between the search and the pose: what Tracking::TrackWithMotionModel
- * (code/src/Tracking.cc:964-1046: SearchByProjection(mCurrentFrame, mLastFrame, th, mono) then
- * Optimizer::PoseOptimization(&mCurrentFrame)) and Tracking::TrackLocalMap (:766-803: SearchLocalPoints() then
+ * (code/src/Tracking.cc:714-768: SearchByProjection(mCurrentFrame, mLastFrame, th, mono) then
+ * Optimizer::PoseOptimization(&mCurrentFrame)) and Tracking::TrackLocalMap (:770-807: SearchLocalPoints() then
  * PoseOptimization) do back to back, as one chain of launches on the matcher's stream:
  *   search (the same kernel as so_track_search_*) -> the order-dependent resolve ON THE DEVICE (an exact parallel form of
  *   the reference's sequential walk, code/src/ORBmatcher.cc:83-85 and :1294-1296, incl. the rotation histogram of
@@ -691,7 +691,7 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
  *   kp_slot (local-map stage, cur->n entries) = map slot bound to keypoint k on entry, < 0: none - those keypoints are the
  *   search's `excluded` set AND edges of the pose problem; bound points must carry skip[] = 1 as for the plain search.
  *   kp_slot_is_last_stage != 0: kp_slot is exactly what this matcher's last stage left for this frame - the bindings it
- *   reported, minus the outliers of its pose when it was the last-frame stage (code/src/Tracking.cc:1030-1046) - so the device
+ *   reported, minus the outliers of its pose when it was the last-frame stage (code/src/Tracking.cc:745-760) - so the device
  *   copy of that stage is used and nothing is read from host memory inside the chain (ignored when no such copy exists).
  * All map points are taken to have observations (slot_has_obs = NULL of the plain calls).
  * so_track_stage_wait - out, all required unless noted:

@@ -697,7 +697,7 @@ static int po_optimize(po_t* s, int iterations, int* its_done, int* trials) {
 int orc_pose_optimization(const float* Tcw12, const float* intr, int32_t n, const float* Xw, const float* obs,
                           const float* inv_sigma2, float* Tcw_out12, uint8_t* outlier, int32_t* info) {
     if (info) info[0] = info[1] = 0;
-    if (n < 3) return 0; /* Optimizer.cc:344-345 */
+    if (n < 3) return 0; /* Optimizer.cc:358-359 */
     po_t s;
     memset(&s, 0, sizeof(s));
     s.n = n;

@@ -28,7 +28,7 @@ Monocular bookkeeping, as SwarmMap runs it:
     Tracking::Track holds (Tracking.cc:195): at the start of frame kf_t + delay in the deterministic schedule (the
     tracking thread waits if local mapping is not done - one legal interleaving of the reference's threads, and the
     same one on every run), or whenever they are ready under the reference's own policy (replay.cc only: keyframes
-    only when local mapping is idle, InterruptBA otherwise, Tracking.cc:810-905).
+    only when local mapping is idle, InterruptBA otherwise, Tracking.cc:810-892).
 
 Deviations of the harness from the reference, on purpose (the operators themselves are exact, call by call): a
 keyframe's searches see the map as it is when their batch is issued - the SearchForTriangulation calls the state after
@@ -84,7 +84,7 @@ class LoopMap:
         return first
 
     def resolve(self, s):
-        """The live point a binding stands for: follows mpReplaced (Tracking::CheckReplacedInLastFrame, Tracking.cc:940-955)."""
+        """The live point a binding stands for: follows mpReplaced (Tracking::CheckReplacedInLastFrame, Tracking.cc:603-614)."""
         while s >= 0 and self.bad[s]:
             s = int(self.repl[s])
         return int(s)
@@ -229,7 +229,7 @@ def lm_job(M, be, c, P):
         if M.bad[s]:
             continue
         if s >= cnt_from and np.float32(c["found"][s - cnt_from]) / np.float32(c["vis"][s - cnt_from]) < np.float32(0.25):
-            M.set_bad(s)  # GetFoundRatio() < 0.25f (:187-190)
+            M.set_bad(s)  # GetFoundRatio() < 0.25f (:177-178)
         elif k - int(M.first_kf[s]) >= 2 and len(M.obs[s]) <= 2:
             M.set_bad(s)
         elif k - int(M.first_kf[s]) >= 3:
@@ -463,7 +463,7 @@ def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio
         tv["bad"][pk["bad"]] = 1
         tv["repl"][pk["bad"]] = pk["bad_repl"]
         tv["local"] = pk["local_slots"]
-        # Tracking::UpdateLastFrame (Tracking.cc:920-937): the last frame follows its reference keyframe
+        # Tracking::UpdateLastFrame (Tracking.cc:656-662): the last frame follows its reference keyframe
         T_ref = mt._T44(pk["kf_T"])
         T_last = Tlr @ T_ref
         # Tracking::CheckReplacedInLastFrame (:940-955)

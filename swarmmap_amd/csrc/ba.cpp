@@ -1341,9 +1341,9 @@ int so_pose_optimization_submit(so_ba* b, const float* Tcw12, const float* intr,
     Q = so_ba::PosePending{};
     Q.active = true;
     Q.n = n;
-    if (n < 3) return SO_OK;  // :344-345, nothing is touched
+    if (n < 3) return SO_OK;  // :358-359, nothing is touched
     SO_HIP(hipSetDevice(b->device));
-    // PoseOptimization belongs to the tracking thread (Tracking.cc:716,1002): it runs on that thread's matcher
+    // PoseOptimization belongs to the tracking thread (Tracking.cc:743,779): it runs on that thread's matcher
     // stream, never on the solver's own stream where a local-mapping window may have ~100 launches queued
     hipStream_t s = nullptr;
     SO_HIP(tracking_stream(b->device, 1, &s));
@@ -1552,7 +1552,7 @@ int so_pose_optimization_batch(so_ba* b, int32_t n_problems, const so_pose_probl
         off += (80 + n + 63) & ~(size_t)63;
         for (int k = 0; k < 4; k++) a.K[k] = (double)q.intr[k];
         pose_from_Tcw(q.Tcw12, a.init);
-        a.n = q.n >= 3 ? q.n : 0;  // n < 3: "return 0" with untouched outputs (Optimizer.cc:344-345); the workgroup idles
+        a.n = q.n >= 3 ? q.n : 0;  // n < 3: "return 0" with untouched outputs (Optimizer.cc:358-359); the workgroup idles
         a.err = nullptr;
         a.trace = nullptr;
         a.done_seq = 0;

@@ -246,7 +246,7 @@ struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.
     const int8_t* kp_octave = nullptr;
     float lvl_inv_sigma2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t* kp_slot_clear = nullptr;   // != null: bindings by keypoint index; the outlier edges' entries are set to -1 at the end
-                                        // (Tracking.cc:1030-1046: an outlier of TrackWithMotionModel's pose loses its map point)
+                                        // (Tracking.cc:745-760: an outlier of TrackWithMotionModel's pose loses its map point)
 };
 // the indexed form, one launch: reads the edge count on the device and runs the register-resident body that fits it.
 // range 0: up to 1024 edges, 1: 1025 .. 1792; a count outside the launched range, or a resolve that gave up: info[0] = -1

@@ -2707,7 +2707,7 @@ __global__ __launch_bounds__(256) void pose_opt_chain_kernel(PoseOptArgs a0) {
     const bool fits = RANGE == 0 ? n <= 1024 : (n > 1024 && n <= kPoseChainMaxEdges);
     if (a0.head[2] != 0 || n < 3 || !fits) {
         // nothing optimised: the resolve gave up / the count is outside this kernel's range (-1), or fewer than three
-        // edges (-2: Optimizer.cc:344-345 returns without touching the frame)
+        // edges (-2: Optimizer.cc:358-359 returns without touching the frame)
         if (threadIdx.x == 0) {
             *a.pose_out = a.init;
             a.info[0] = (a0.head[2] == 0 && n < 3) ? -2 : -1;

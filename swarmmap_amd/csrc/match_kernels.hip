@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolve
         }
         __syncthreads();
         if (tid < 64) {
-            // ComputeThreeMaxima (ORBmatcher.cc:1629-1688): its strict comparisons pick the three largest non-empty bins,
+            // ComputeThreeMaxima (ORBmatcher.cc:1475-1506): its strict comparisons pick the three largest non-empty bins,
             // the earlier bin first among equals - lane i ranks bin i against the others instead of one lane walking all thirty
             const int mine = tid < kResHisto ? s_hist[tid] : 0;
             int rank = 0;

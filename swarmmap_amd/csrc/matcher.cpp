@@ -3511,7 +3511,7 @@ int so_track_search_last_frame(so_matcher* m, const so_dframe* cur, const uint8_
     return so_track_search_last_frame_wait(m, slot_has_obs, check_orientation, kp_to_last, nmatches);
 }
 
-// TrackLocalMap's search — Tracking::SearchLocalPoints (code/src/Tracking.cc:1104-1156): Frame::isInFrustum(pMP,
+// TrackLocalMap's search — Tracking::SearchLocalPoints (code/src/Tracking.cc:964-1007): Frame::isInFrustum(pMP,
 // cos_limit) (code/src/Frame.cc:316-375) for every local map point that is not already matched in this frame, then
 // ORBmatcher::SearchByProjection(F, vpMapPoints, th) (code/src/ORBmatcher.cc:44-121)
 int so_track_search_local_map_submit(so_matcher* m, const so_dframe* cur, const uint8_t* cur_excluded, const so_map* map,
@@ -3748,7 +3748,7 @@ int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe
     A.kp_xy_un = cur->d_xy_un;
     A.kp_octave = cur->d_octave;
     for (int l = 0; l < 8; l++) A.lvl_inv_sigma2[l] = l < cur->nlevels ? level_inv_sigma2[l] : 0.f;
-    // TrackWithMotionModel: the outliers of its pose lose their map point (Tracking.cc:1030-1046) - also in the bindings
+    // TrackWithMotionModel: the outliers of its pose lose their map point (Tracking.cc:745-760) - also in the bindings
     // the next stage reads from the device
     A.kp_slot_clear = kind == 0 ? (int32_t*)m->d_kpslot.p : nullptr;
     so_matcher::ChainPending& C = m->chain;
@@ -3978,7 +3978,7 @@ int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint
     const int ne = head[0];
     *n_edges = ne;
     memcpy(edge_kp, h + C.h_ekp, sizeof(int32_t) * (size_t)ne);
-    if (inf[0] == -2) {  // fewer than three edges: PoseOptimization returns 0 and touches nothing (Optimizer.cc:344-345)
+    if (inf[0] == -2) {  // fewer than three edges: PoseOptimization returns 0 and touches nothing (Optimizer.cc:358-359)
         memset(edge_outlier, 0, (size_t)ne);
         memcpy(Tcw_out12, C.Tcw_in, 48);
         return SO_OK;

@@ -1,7 +1,7 @@
 // closedloop.cc — the closed tracking + local-mapping loop of the replay harness: what a keyframe's local-mapping job
 // computes flows back into the map the next frames are tracked against (code/src/LocalMapping.cc:53-110 LocalMapping::Run;
 // code/src/Optimizer.cc:436-560 the window, :713-739 the write-back; Tracking::UpdateLastFrame / CheckReplacedInLastFrame,
-// code/src/Tracking.cc:920-955).  swarmmap_amd/closedloop.py is the same logic in Python, statement by statement: its module
+// code/src/Tracking.cc:603-614, 656-662).  swarmmap_amd/closedloop.py is the same logic in Python, statement by statement: its module
 // text says what is kept of the reference and what the harness simplifies; tests compare the two chains frame by frame and
 // keyframe by keyframe (tests/test_closedloop_gpu.py).
 //
@@ -299,7 +299,7 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
             if (M.bad[(size_t)s]) continue;
             const int q = s - c->cnt_from;
             if (q >= 0 && q < (int)c->cnt_vis.size() && (float)c->cnt_found[(size_t)q] / (float)c->cnt_vis[(size_t)q] < 0.25f)
-                L.set_bad(s);  // GetFoundRatio() < 0.25f (:187-190)
+                L.set_bad(s);  // GetFoundRatio() < 0.25f (:177-178)
             else if (k - M.first_kf[(size_t)s] >= 2 && M.obs[(size_t)s].size() <= 2) L.set_bad(s);
             else if (k - M.first_kf[(size_t)s] >= 3) continue;
             else keep.push_back(s);
@@ -755,7 +755,7 @@ int cl_frame_begin(so_replay* r, int t) {
     }
     M.recent_from = pk.recent_from;
     M.tv_local.swap(pk.local_slots);
-    // Tracking::UpdateLastFrame (Tracking.cc:920-937): the last frame follows its reference keyframe
+    // Tracking::UpdateLastFrame (Tracking.cc:656-662): the last frame follows its reference keyframe
     M.T_ref = from_f12(pk.kf_T);
     r->T_last = mul(M.Tlr, M.T_ref);
     // Tracking::CheckReplacedInLastFrame (:940-955)

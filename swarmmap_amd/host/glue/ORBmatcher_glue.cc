@@ -221,7 +221,7 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     return nmatches;
 }
 
-// code/src/ORBmatcher.cc:1223-1354 (TrackWithMotionModel, Tracking.cc:998,1014), monocular
+// code/src/ORBmatcher.cc:1223-1354 (TrackWithMotionModel, Tracking.cc:731,735), monocular
 int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
     so_matcher* h = thread_matcher();
     if (!h || !bMono) return 0;  // SwarmMap builds Examples/Monocular only

@@ -285,7 +285,7 @@ int Optimizer::PoseOptimization(Frame* pFrame, const bool bGlobal) {
         }
     }
     const int n = (int)idx.size();
-    if (n < 3) return 0;  // :344-345
+    if (n < 3) return 0;  // :358-359
     so_ba* h = thread_solver();
     if (!h) return 0;
     std::vector<float> Tin, Tout(12);

@@ -4,9 +4,9 @@
 // Tracking thread (the caller of so_replay_run), per frame t — a chained, device-resident frame:
 //     collect frame t  (keypoints / descriptors / undistorted points arrive through host-mapped memory)
 //     submit frame t+1 (host image -> HBM upload + ExtractORB + UndistortKeyPoints + AssignFeaturesToGrid, async)
-//     TrackWithMotionModel:  so_track_search_last_frame (projection + window search on the GPU)          Tracking.cc:964-1050
+//     TrackWithMotionModel:  so_track_search_last_frame (projection + window search on the GPU)          Tracking.cc:714-768
 //                            so_pose_optimization over the matches it found, outliers dropped             Optimizer.cc:239-434
-//     TrackLocalMap:         so_track_search_local_map (isInFrustum + window search on the GPU)           Tracking.cc:1052-1156
+//     TrackLocalMap:         so_track_search_local_map (isInFrustum + window search on the GPU)           Tracking.cc:770-807, 964-1007
 //                            so_pose_optimization over all matches
 //                            a third so_pose_optimization from the last frame's pose (TrackReferenceKeyFrame's
 //                            fallback; SURVEY 8d counts three calls per frame), result unused
@@ -794,7 +794,7 @@ int so_replay_lm_log(so_replay* r, int32_t* out, int cap_rows) {
 // frames between a keyframe and the arrival of its results in the tracked map (policy 0, the deterministic schedule:
 // the tracking thread waits for the job if it is not done by then); policy 1: the reference's own policy - results arrive
 // when they are ready, a keyframe is only made while local mapping is idle, a busy local mapper gets InterruptBA
-// (Tracking.cc:893-903, LocalMapping.cc:581-583).  n_free / n_fixed: caps of the window's free / fixed keyframes.
+// (Tracking.cc:880-890, LocalMapping.cc:581-583).  n_free / n_fixed: caps of the window's free / fixed keyframes.
 int so_replay_set_closed_loop(so_replay* r, int kf_every, int delay, int n_free, int n_fixed, int policy) {
     if (!r || r->n_tracked > 0 || r->vocab.empty() || r->local_keyframes <= 0 || kf_every < 1 || delay < 1 || n_free < 1 || n_fixed < 0)
         return SO_ERR_INVALID_ARG;
@@ -980,7 +980,7 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
     return SO_OK;
 }
 
-// TrackWithMotionModel's search (Tracking.cc:964-1024)
+// TrackWithMotionModel's search (Tracking.cc:714-741)
 // SWARMORB_TRACK_CHAIN=0: the tracking stages as separate calls with the resolve and the pose-problem gather on the host (rounds 2-4)
 bool track_chain_on() {
     static const bool on = !(getenv("SWARMORB_TRACK_CHAIN") && atoi(getenv("SWARMORB_TRACK_CHAIN")) == 0);
@@ -1028,7 +1028,7 @@ int step_m2_wait(so_replay* r) {
     so_matcher_last_stats(r->matcher, ms4);
     S.mstat[0] += ms4[0]; S.mstat[1] += ms4[1];
     S.reruns += ms4[2];
-    if (nm < 20) {  // Tracking.cc:1020-1024: wider window
+    if (nm < 20) {  // Tracking.cc:733-737: wider window
         S.wide_m2 += 1;
         if (so_track_search_last_frame(r->matcher, r->fr[S.hcur], nullptr, r->fr[(S.hcur + 2) % 3], r->map, S.Tp,
                                        r->last_slot.data(), nullptr, 30.0f, 1, r->k2l.data(), &nm) != SO_OK)
@@ -1153,7 +1153,7 @@ int step_stage1_wait(so_replay* r, int32_t* inl) {
     so_matcher_last_stats(r->matcher, ms4);
     S.mstat[0] += ms4[0]; S.mstat[1] += ms4[1];
     S.reruns += ms4[2];
-    if (!ok || nm < 20) {  // not finished on the device, or Tracking.cc:1020-1024's wider window: the separate calls
+    if (!ok || nm < 20) {  // not finished on the device, or Tracking.cc:733-737's wider window: the separate calls
         S.stage1_dev = false;
         const float th = ok ? 30.0f : 15.0f;
         if (ok) S.wide_m2 += 1;
@@ -1178,14 +1178,14 @@ int step_stage1_wait(so_replay* r, int32_t* inl) {
     return SO_OK;
 }
 
-void pose1_apply(so_replay* r) {  // Tracking.cc:1030-1046: outliers lose their map point
+void pose1_apply(so_replay* r) {  // Tracking.cc:745-760: outliers lose their map point
     so_replay::FrameHost& F = r->fh[r->cur];
     for (size_t k = 0; k < r->idx.size(); k++)
         if (r->pose_out[k]) F.kp_mp[(size_t)r->idx[k]] = -1;
     r->step.tp1 = now_ms();
 }
 
-// TrackLocalMap's search (Tracking.cc:1052-1156)
+// TrackLocalMap's search (Tracking.cc:770-807, 964-1007)
 int step_m1_submit(so_replay* r) {
     so_replay::Step& S = r->step;
     so_replay::FrameHost& F = r->fh[r->cur];
@@ -1209,7 +1209,7 @@ int step_m1_submit(so_replay* r) {
             }
         }
         for (int i = 0; i < nl; i++)
-            if (bound[(size_t)M.tv_local[(size_t)i]]) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:1117-1124)
+            if (bound[(size_t)M.tv_local[(size_t)i]]) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:966-978)
         if (track_chain_on() && !r->lockstep) {
             const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, nl, M.tv_local.data(), 0,
                                                            r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
@@ -1235,7 +1235,7 @@ int step_m1_submit(so_replay* r) {
     for (int k = 0; k < n; k++) {
         const int s = F.kp_mp[(size_t)k];
         r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
-        if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:1117-1124)
+        if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:966-978)
     }
     if (track_chain_on() && !r->lockstep) {
         const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, S.n_local, nullptr, first,
@@ -1338,7 +1338,7 @@ int step_keyframe(so_replay* r) {
     so_replay::FrameHost& F = r->fh[r->cur];
     const int n = F.n;
     if (r->cl) {
-        // Tracking::NeedNewKeyFrame, monocular (Tracking.cc:810-905): enough frames since the last keyframe or too few
+        // Tracking::NeedNewKeyFrame, monocular (Tracking.cc:810-892): enough frames since the last keyframe or too few
         // inliers against it - and local mapping idle; under the reference's policy a busy local mapper gets InterruptBA
         // instead (:893-903) and the keyframe waits; the deterministic schedule never asks while a job is out
         ClosedLoop& M = *r->cl;

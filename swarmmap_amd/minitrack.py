@@ -3,8 +3,8 @@
 every "keyframe", LocalBundleAdjustment over the recent keyframes.
 
 It is NOT the reference's Tracking state machine (out of scope): it is the shortest host loop that
-chains every per-frame operator the way Tracking::TrackWithMotionModel (code/src/Tracking.cc:984-1050) and
-Tracking::TrackLocalMap (:1052-1100) do, so that a *trajectory* can be produced from images alone and compared
+chains every per-frame operator the way Tracking::TrackWithMotionModel (code/src/Tracking.cc:714-768) and
+Tracking::TrackLocalMap (:770-807) do, so that a *trajectory* can be produced from images alone and compared
 between two implementations of the operators ("ATE").  The scene is the synthetic stream of
 `synth.FrameStream`: a textured plane at depth `plane_z` seen by a camera translating parallel to it, so map points
 are created by back-projecting keypoints onto the known plane (as an RGB-D front-end would) and ground truth is
@@ -16,9 +16,9 @@ the same interface and compare trajectories.
 import numpy as np
 
 
-TH_LAST_FRAME = 15.0      # Tracking.cc:1014 (monocular)
-MIN_MATCHES_MOTION = 20   # Tracking.cc:1020
-COS_LIMIT = 0.5           # Tracking.cc:1133 isInFrustum(pMP, 0.5)
+TH_LAST_FRAME = 15.0      # Tracking.cc:731 (monocular)
+MIN_MATCHES_MOTION = 20   # Tracking.cc:734
+COS_LIMIT = 0.5           # Tracking.cc:991 isInFrustum(pMP, 0.5)
 
 
 class HipBackend:
@@ -350,7 +350,7 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
             idx = np.nonzero(kp_mp >= 0)[0]
             _, T12, outl = backend.pose(Tp.reshape(12), intr, mp_X[kp_mp[idx]], xy_un[idx],
                                         inv_sigma2[kps["octave"][idx]])
-            kp_mp[idx[outl.astype(bool)]] = -1              # Tracking.cc:1030-1046 (outliers dropped)
+            kp_mp[idx[outl.astype(bool)]] = -1              # Tracking.cc:745-760 (outliers dropped)
             T_a = np.asarray(T12, np.float32).reshape(3, 4)
 
             # ---- TrackLocalMap: SearchLocalPoints + PoseOptimization --------------------------------------------
@@ -361,7 +361,7 @@ def track(backend, stream, n_frames, K, plane_z=2.0, keyframe_every=8, keyframe_
             n_local = n_map - first
             skip = np.zeros(n_local, np.uint8)
             cur_mp = kp_mp[kp_mp >= 0]
-            skip[cur_mp[cur_mp >= first] - first] = 1       # already matched: mbTrackInView = false (:1117-1124)
+            skip[cur_mp[cur_mp >= first] - first] = 1       # already matched: mbTrackInView = false (:966-978)
             excluded = (kp_mp >= 0).astype(np.uint8)
             nm2, k2m, _ = backend.search_local(T_a.reshape(12), first, n_local, skip, excluded, 1.0, log_sf)
             newly = k2m >= 0

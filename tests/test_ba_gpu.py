@@ -461,7 +461,7 @@ def test_pose_optimization_batch_matches_single_calls(opt):
 def test_pose_optimization_too_few_points(opt):
     c = synth.make_pose_case(9, 2)
     ni, T, outl, info = opt.PoseOptimization(c["Tcw"], c["intr"], c["Xw"], c["obs"], c["inv_sigma2"])
-    assert ni == 0 and np.array_equal(T, c["Tcw"]) and info["iterations"] == 0  # Optimizer.cc:344-345
+    assert ni == 0 and np.array_equal(T, c["Tcw"]) and info["iterations"] == 0  # Optimizer.cc:358-359
 
 
 _TIMEOUT_SCRIPT = r'''

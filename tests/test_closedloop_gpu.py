@@ -129,7 +129,7 @@ def test_cpp_closed_loop_in_the_bench_configuration_matches_the_oracle_chain(nam
 
 
 def test_cpp_closed_loop_under_the_reference_policy_tracks_and_reports_its_interrupts():
-    """policy 1 (Tracking.cc:810-905, LocalMapping.cc:581-583): results arrive when they are ready, a keyframe is made only
+    """policy 1 (Tracking.cc:810-892, LocalMapping.cc:581-583): results arrive when they are ready, a keyframe is made only
     while local mapping is idle, a busy local mapper gets InterruptBA.  Timing-dependent by construction: the checks are
     the trajectory against ground truth and the consistency of the counters."""
     import torch

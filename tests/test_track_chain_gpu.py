@@ -65,7 +65,7 @@ def test_last_frame_stage_equals_search_plus_pose(S, oracle, seed, dist):
         assert again is not None and np.array_equal(again["Tcw"], Tb) and np.array_equal(again["edge_outlier"], outl2)
         assert again["n_inliers"] == n_in2 and np.array_equal(again["edge_kp"], idx)
         # the local-map stage behind it, with the bindings the last-frame stage left ON THE DEVICE (its matches minus its pose's
-        # outliers: Tracking.cc:1030-1046) against the same stage fed the host copy of those bindings
+        # outliers: Tracking.cc:745-760) against the same stage fed the host copy of those bindings
         r = dfm.track_stage_last_frame(m, cur, last, dmap, Tc, slot, th, K4, INV_SIGMA2)
         bound = kp_slot.copy()
         bound[r["edge_kp"][r["edge_outlier"] != 0]] = -1
