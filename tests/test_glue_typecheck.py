@@ -1,5 +1,5 @@
-"""The drop-in glue (swarmmap_amd/host/glue/*.cc: the bodies that replace ORBmatcher's and Optimizer's functions inside
-the reference tree, written against the reference's real signatures and classes) type-checks against the reference's
+"""The drop-in glue (swarmmap_amd/host/glue/*.cc: the bodies that replace ORBmatcher's and Optimizer's functions - and, for the
+tracking stages chained on the device, Tracking::TrackWithMotionModel / TrackLocalMap - inside the reference tree, written against the reference's real signatures and classes) type-checks against the reference's
 own headers: g++ -fsyntax-only with include paths into /root/reference/code.  The image has no OpenCV / Eigen / Boost /
 CUDA / Pangolin, so tests/cpp/ref_stubs/ declares the third-party names those headers mention (compile-only: no
 definitions, nothing is linked or run; it is a type-check of OUR files, not a build of the reference).  Skipped where
@@ -23,7 +23,7 @@ def _syntax_check(source, extra=()):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=300)
 
 
-@pytest.mark.parametrize("name", ["Optimizer_glue.cc", "ORBmatcher_glue.cc"])
+@pytest.mark.parametrize("name", ["Optimizer_glue.cc", "ORBmatcher_glue.cc", "Tracking_glue.cc"])
 def test_glue_type_checks_against_the_reference_headers(name):
     r = _syntax_check(os.path.join(ROOT, "swarmmap_amd", "host", "glue", name))
     assert r.returncode == 0, r.stderr[-4000:]
