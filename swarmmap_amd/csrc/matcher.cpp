@@ -3807,6 +3807,7 @@ int so_track_stage_last_frame_submit(so_matcher* m, const so_dframe* cur, const 
                                      const float* Tcw12, const int32_t* last_slot, float th, int check_orientation,
                                      const float* intr4, const float* level_inv_sigma2) {
     if (!m || !cur || !last || !map || !Tcw12 || !intr4 || !level_inv_sigma2 || m->chain.active) return SO_ERR_INVALID_ARG;
+    m->chain.valid_edges = false;  // (whatever happens below: the edge list of an earlier stage is not this frame's)
     if (!cur->ready || !last->ready || last->n <= 0 || cur->n <= 0) return SO_RETRY_ON_HOST;  // nothing to chain: the plain calls handle it
     SO_HIP(hipSetDevice(m->device));
     ChainOffsets O;
@@ -3834,6 +3835,7 @@ int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const i
                                     float log_scale_factor, const float* intr4, const float* level_inv_sigma2) {
     if (!m || !cur || !kp_slot || !map || !Tcw12 || !intr4 || !level_inv_sigma2 || n_local < 0 || m->chain.active)
         return SO_ERR_INVALID_ARG;
+    m->chain.valid_edges = false;
     if (!cur->ready || n_local <= 0 || cur->n <= 0) return SO_RETRY_ON_HOST;
     SO_HIP(hipSetDevice(m->device));
     ChainOffsets O;
