@@ -795,6 +795,14 @@ int so_replay_lm_log(so_replay* r, int32_t* out, int cap_rows) {
 // the tracking thread waits for the job if it is not done by then); policy 1: the reference's own policy - results arrive
 // when they are ready, a keyframe is only made while local mapping is idle, a busy local mapper gets InterruptBA
 // (Tracking.cc:880-890, LocalMapping.cc:581-583).  n_free / n_fixed: caps of the window's free / fixed keyframes.
+// The tracking stages as one chain of launches each (so_track_stage_*: the default) or as the separate calls with the resolve
+// and the pose-problem gather on the host: same results to the bit (tests/test_closedloop_gpu.py), different latency
+int so_replay_set_track_chain(so_replay* r, int on) {
+    if (!r) return SO_ERR_INVALID_ARG;
+    r->track_chain = on ? 1 : 0;
+    return SO_OK;
+}
+
 int so_replay_set_closed_loop(so_replay* r, int kf_every, int delay, int n_free, int n_fixed, int policy) {
     if (!r || r->n_tracked > 0 || r->vocab.empty() || r->local_keyframes <= 0 || kf_every < 1 || delay < 1 || n_free < 1 || n_fixed < 0)
         return SO_ERR_INVALID_ARG;
@@ -982,9 +990,9 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
 
 // TrackWithMotionModel's search (Tracking.cc:714-741)
 // SWARMORB_TRACK_CHAIN=0: the tracking stages as separate calls with the resolve and the pose-problem gather on the host (rounds 2-4)
-bool track_chain_on() {
+bool track_chain_on(const so_replay* r) {
     static const bool on = !(getenv("SWARMORB_TRACK_CHAIN") && atoi(getenv("SWARMORB_TRACK_CHAIN")) == 0);
-    return on;
+    return r->track_chain >= 0 ? r->track_chain != 0 : on;
 }
 
 int step_m2_submit(so_replay* r) {
@@ -995,7 +1003,7 @@ int step_m2_submit(so_replay* r) {
     r->last_slot.resize((size_t)L.n);
     for (int i = 0; i < L.n; i++)
         r->last_slot[(size_t)i] = (L.kp_mp[(size_t)i] >= 0 && !L.outlier[(size_t)i]) ? L.kp_mp[(size_t)i] : -1;
-    if (track_chain_on() && !r->lockstep) {
+    if (track_chain_on(r) && !r->lockstep) {
         // the whole stage as one chain of launches: search -> resolve on the device -> PoseOptimization; one wait (step_stage1_wait)
         r->K4[0] = r->cam.fx; r->K4[1] = r->cam.fy; r->K4[2] = r->cam.cx; r->K4[3] = r->cam.cy;
         const int rc = so_track_stage_last_frame_submit(r->matcher, r->fr[S.hcur], r->fr[(S.hcur + 2) % 3], r->map, S.Tp,
@@ -1210,7 +1218,7 @@ int step_m1_submit(so_replay* r) {
         }
         for (int i = 0; i < nl; i++)
             if (bound[(size_t)M.tv_local[(size_t)i]]) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:966-978)
-        if (track_chain_on() && !r->lockstep) {
+        if (track_chain_on(r) && !r->lockstep) {
             const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, nl, M.tv_local.data(), 0,
                                                            r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
             if (rc == SO_OK) {
@@ -1237,7 +1245,7 @@ int step_m1_submit(so_replay* r) {
         r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
         if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:966-978)
     }
-    if (track_chain_on() && !r->lockstep) {
+    if (track_chain_on(r) && !r->lockstep) {
         const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, S.n_local, nullptr, first,
                                                        r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
         if (rc == SO_OK) {

@@ -226,6 +226,7 @@ struct so_replay {
     int last_tracked = -1;  // handle index of the frame tracked last
     bool in_flight = false;
     bool live = false;   // so_replay_run_live: no frame is extracted ahead
+    int track_chain = -1;   // so_replay_set_track_chain: 1 / 0 = the tracking stages as device chains / as separate calls; -1: SWARMORB_TRACK_CHAIN (default on)
     bool lockstep = false;  // so_fleet_run drives this agent: its stages stay separate calls (the fleet batches the PoseOptimization calls of all agents)
     int n_tracked = 0;   // frames tracked so far (0: the next frame initialises the map)
     float bounds[4] = {0, 0, 0, 0};

@@ -122,6 +122,11 @@ class Replay:
         self._check(self.lib.so_replay_set_closed_loop(self.h, kf_every, kf_every if delay is None else delay, n_free, n_fixed,
                                                        policy), "set_closed_loop")
 
+    def set_track_chain(self, on):
+        """so_replay_set_track_chain: the tracking stages as device chains (default) or as separate calls (same results)."""
+        self.lib.so_replay_set_track_chain.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.so_replay_set_track_chain(self.h, int(bool(on))), "set_track_chain")
+
     def closed_loop_log(self):
         """After drain(): dict(lm_log (rows of closedloop.LM_LOG_COLUMNS), kf_t, kf_poses (final), ref_kf, Tcr,
         final_centres (System::SaveTrajectoryTUM: Tcr x final keyframe pose), kf_centres, counts)."""

@@ -49,10 +49,12 @@ def test_python_chain_hip_and_oracle_agree_keyframe_by_keyframe():
     assert abs(minitrack.ate_rmse(a["final_centres"], gt, with_scale=True) - minitrack.ate_rmse(b["final_centres"], gt, with_scale=True)) < 0.02 * px
 
 
-def _cpp_chain(n, frames_ptrs, st, K, dist, nfeat, vocab, policy=0, **kw):
+def _cpp_chain(n, frames_ptrs, st, K, dist, nfeat, vocab, policy=0, track_chain=None, **kw):
     from swarmmap_amd.replay import Replay
     rp = Replay(0, st.w, st.h, nfeat, 5, K, dist, plane_z=PLANE_Z, local_keyframes=12, third_pose=True)
     rp.set_frames(frames_ptrs, on_device=False)
+    if track_chain is not None:
+        rp.set_track_chain(track_chain)
     rp.set_vocabulary(vocab)
     rp.set_closed_loop(policy=policy, **kw)
     rp.prime(0)
@@ -197,3 +199,29 @@ def test_three_closed_loop_agents_in_threads_equal_their_solo_runs():
         assert all(np.array_equal(x, y) for x, y in zip(s["kf_bindings"], p["kf_bindings"])), a
         assert s["inliers"][1:].min() > 300
     assert not np.array_equal(solo[0]["poses"], solo[1]["poses"])  # (different streams)
+
+
+@pytest.mark.parametrize("name,n", [("euroc", 122), ("kitti", 42)])
+def test_stages_chained_on_the_device_equal_the_separate_calls_over_a_whole_run(name, n):
+    """so_track_stage_* (search -> resolve on the device -> PoseOptimization, one wait) against so_track_search_* + host resolve
+    + host gather + so_pose_optimization inside the same closed loop: every pose, every count, the local-mapping log and the
+    final bindings to the bit - the device-side resolve is exact and the pose kernel adds its sums in the same order."""
+    import torch
+    euroc = name == "euroc"
+    size = synth.EUROC if euroc else synth.KITTI
+    K = synth.EUROC_K if euroc else synth.KITTI_K
+    dist = synth.EUROC_DIST if euroc else None
+    nfeat = 1000 if euroc else 2000
+    st = synth.FrameStream(seed=20221001, size=size, K=K, dist=dist)
+    block = torch.empty((n + 2, st.h, st.w), dtype=torch.uint8).pin_memory()
+    view = block.numpy()
+    for t in range(n + 2):
+        view[t] = st.frame(t)
+    ptrs = [block.data_ptr() + i * st.w * st.h for i in range(n + 2)]
+    vocab = make_vocabulary()
+    a = _cpp_chain(n, ptrs, st, K, dist, nfeat, vocab, track_chain=True)[0]
+    b = _cpp_chain(n, ptrs, st, K, dist, nfeat, vocab, track_chain=False)[0]
+    for k in ("poses", "kf_poses", "Tcr", "lm_log", "matches_last", "matches_map", "inliers", "n_map_points", "point_bad"):
+        assert np.array_equal(a[k], b[k]), k
+    assert all(np.array_equal(x, y) for x, y in zip(a["kf_bindings"], b["kf_bindings"]))
+    assert a["inliers"][1:].min() > 300
