@@ -212,3 +212,32 @@ def test_stages_beyond_the_kernels_sizes_hand_the_call_back(S, oracle):
     assert np.array_equal(r["edge_kp"], idx) and np.array_equal(r["Tcw"], T.reshape(3, 4)) and np.array_equal(r["edge_outlier"], outl)
     assert r["n_inliers"] == n_in
     m.close(); dmap.close(); cur.close(); ex.close()
+
+
+def test_stages_with_nothing_to_match(S, oracle):
+    """A last frame without map points, a local list that is skipped entirely, fewer than three edges: the chains run, report
+    no matches, and the pose comes back as it went in (Optimizer.cc:358-359: PoseOptimization returns 0 and touches nothing);
+    empty lists are handed back at the submit."""
+    rng = np.random.default_rng(5)
+    ex, last, lk, lxy, ld, _ = _frame_and_view(S, oracle, 5)
+    Tc = _pose(rng)
+    Xw, normal, mx, mn, md = _make_map(rng, lxy, lk, ld, synth.EUROC_K, Tc, n_extra=0)
+    dmap = S.DeviceMap()
+    dmap.append(Xw, normal, mx, mn, md)
+    cur = S.DeviceFrame(ex, synth.EUROC_K, synth.EUROC_DIST)
+    cur(synth.make_canvas(5, 752, 480))
+    m = S.ORBmatcher(0.9, True)
+    none_last = np.full(len(lk), -1, np.int32)
+    r = dfm.track_stage_last_frame(m, cur, last, dmap, Tc, none_last, 15.0, K4, INV_SIGMA2)
+    assert r is not None and r["nmatches"] == 0 and r["n_edges"] == 0 and r["n_inliers"] == 0 and (r["kp_to_q"] == -1).all()
+    assert np.array_equal(r["Tcw"].reshape(12), Tc)
+    two = none_last.copy(); two[:2] = [0, 1]  # at most two matches: still no optimisation
+    r = dfm.track_stage_last_frame(m, cur, last, dmap, Tc, two, 15.0, K4, INV_SIGMA2)
+    assert r is not None and r["n_edges"] == r["nmatches"] <= 2 and r["n_inliers"] == 0 and np.array_equal(r["Tcw"].reshape(12), Tc)
+    kp_slot = np.full(cur.n, -1, np.int32)
+    r = dfm.track_stage_local_map(m, cur, kp_slot, dmap, Tc, len(Xw), 1.0, 0.5, LOG_SF, K4, INV_SIGMA2, skip=np.ones(len(Xw), np.uint8))
+    assert r is not None and r["nmatches"] == 0 and r["n_edges"] == 0 and not r["in_view"].any()
+    assert dfm.track_stage_local_map(m, cur, kp_slot, dmap, Tc, 0, 1.0, 0.5, LOG_SF, K4, INV_SIGMA2) is None  # nothing to search: the plain calls
+    nm, k2m, _ = dfm.search_local_map(m, cur, dmap, Tc, len(Xw), 1.0, 0.5, LOG_SF)
+    assert nm > 200  # the handle is fine
+    m.close(); dmap.close(); cur.close(); last.close(); ex.close()
