@@ -58,6 +58,7 @@ PLANE_Z = 2.0
 # the keyframe's OWN window - is in the tracked map five frames later.  "open": round 4's workload (a fixed synthetic LBA-M
 # window per keyframe, nothing fed back), kept as configs.open_loop_synthetic_window.
 LOOP = os.environ.get("SWARMORB_BENCH_LOOP", "closed")
+SEED_BASE = int(os.environ.get("SWARMORB_BENCH_SEED", "20221001"))  # the synthetic stream of rank r is FrameStream(seed = SEED_BASE + r)
 CL_N_FREE, CL_N_FIXED = 25, 40  # caps of a window's free / fixed keyframes (LBA-M's proportions)
 
 
@@ -856,10 +857,10 @@ def main():
 
     try:
         if args.lockstep and A > 1:
-            dt, st, n_cand, frames, log0 = run_fleet(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
+            dt, st, n_cand, frames, log0 = run_fleet(dev, size, K, dist, nfeatures, args.steps, args.warmup, SEED_BASE + rank,
                                                      lba_window, barrier, A)
         else:
-            dt, st, n_cand, frames, log0 = run_stream(dev, size, K, dist, nfeatures, args.steps, args.warmup, 20221001 + rank,
+            dt, st, n_cand, frames, log0 = run_stream(dev, size, K, dist, nfeatures, args.steps, args.warmup, SEED_BASE + rank,
                                                       lba_window, barrier, A, xchg, args.exchange_every, m1,
                                                       live_steps=LIVE_STEPS if rank == 0 else 0)
     except swarmmap_amd.SwarmOrbError as e:
