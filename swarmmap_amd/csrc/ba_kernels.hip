@@ -1446,6 +1446,109 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d) {
     if (threadIdx.x == 0) d.partial[kBaPartialScale + blockIdx.x] = t;
 }
 
+// ---------------- the same + the trial's residuals in ONE launch (local windows) ----------------
+// ba_update_kernel followed by ba_errors_kernel(which = 1) costs two launch floors (~4.5 us each on a 7 + 5 us pair); the
+// residuals of an edge need the TRIAL pose and the TRIAL point of its two ends, which the update writes from different
+// workgroups.  Here every workgroup forms all trial poses itself (a window has at most 128 keyframes: 25 exponential maps by
+// 25 threads, the fixed ones copied) into LDS, then walks landmarks the way the update does - eight lanes each - and, once the
+// landmark's trial position is known, the same eight lanes compute the residuals of that landmark's edges.  Same
+// expressions per pose / point / edge as the two kernels (same bits in the trial buffers, e_err, e_chi2); the chi2
+// partials are per workgroup of THIS grid (the decision kernel sums nb_upd of them, in index order: deterministic).
+constexpr int kBaFusedMaxPoses = 128;
+__global__ __launch_bounds__(256) void ba_update_errors_kernel(BaDev d) {
+    __shared__ BaPose s_pose[kBaFusedMaxPoses];
+    __shared__ double s_tmp[16];
+    const BaLm lm = *d.lm;
+    if (lm.active != d.stage) return;
+    const double lambda = lm.lambda;
+    const BaPose* __restrict__ poses = d.pose[lm.cur];
+    const double* __restrict__ points = d.pt[lm.cur];
+    BaPose* __restrict__ poses_trial = d.pose[lm.cur ^ 1];
+    double* __restrict__ points_trial = d.pt[lm.cur ^ 1];
+    const double* xp = d.bs;
+    double scale = 0.0, chi = 0.0;
+    for (int ip = threadIdx.x; ip < d.n_poses; ip += 256) {
+        const int hi = d.pose_hidx[ip];
+        BaPose out = poses[ip];
+        if (hi >= 0) {
+            const double* x = xp + 6 * (size_t)hi;
+            const double u[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
+            se3_exp_mul(u, poses[ip], out);
+            if (blockIdx.x == 0) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) scale += u[r] * (lambda * u[r] + d.bp[6 * (size_t)hi + r]);
+            }
+        }
+        s_pose[ip] = out;
+        if (blockIdx.x == 0) poses_trial[ip] = out;
+    }
+    __syncthreads();
+    const int total = 8 * d.n_points;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int il = i >> 3, sub = i & 7;
+        const bool act = d.pt_active[il];
+        double cl[3] = {0, 0, 0};
+        if (act) {
+            for (int e = d.pt_off[il] + sub; e < d.pt_off[il + 1]; e += 8) {
+                if (!d.e_active[e]) continue;
+                const int hi = d.pose_hidx[d.e_pose[e]];
+                if (hi < 0) continue;
+                const double* W = d.W + 18 * (size_t)e;
+                const double* x = xp + 6 * (size_t)hi;
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int r = 0; r < 6; r++) cl[c] -= W[r * 3 + c] * x[r];
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) cl[c] += __shfl_xor(cl[c], off);
+        }
+        double X[3] = {points[3 * il], points[3 * il + 1], points[3 * il + 2]};
+        if (sub == 0) {
+            if (act) {
+                const double* bl = d.bl + 3 * (size_t)il;
+                cl[0] += bl[0]; cl[1] += bl[1]; cl[2] += bl[2];
+                double Di[9];
+                damped_inverse3(d.Hll + 9 * (size_t)il, lambda, Di);  // (local windows: no prep launch, as in ba_update_kernel)
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
+                    d.xl[3 * (size_t)il + r] = xl;
+                    scale += xl * (lambda * xl + bl[r]);
+                    X[r] += xl;
+                }
+            }
+            points_trial[3 * il] = X[0]; points_trial[3 * il + 1] = X[1]; points_trial[3 * il + 2] = X[2];
+        }
+        // the landmark's trial position to its eight lanes, then its edges' residuals at the trial state
+        const int lead = (int)(threadIdx.x & 63) & ~7;
+#pragma unroll
+        for (int c = 0; c < 3; c++) X[c] = __shfl(X[c], lead);
+        for (int e = d.pt_off[il] + sub; e < d.pt_off[il + 1]; e += 8) {
+            if (!d.e_active[e]) continue;
+            const int ip = d.e_pose[e];
+            double e0, e1;
+            const double obs[2] = {d.e_obs[2 * e], d.e_obs[2 * e + 1]};
+            edge_error(s_pose[ip], X, obs, d.intr + 4 * ip, e0, e1);
+            const double w = d.e_w[e];
+            const double chi2 = e0 * (w * e0) + e1 * (w * e1);
+            d.e_err[2 * e] = e0;
+            d.e_err[2 * e + 1] = e1;
+            d.e_chi2[e] = chi2;
+            chi += d.robust ? huber_rho0(chi2, d.huber_delta, d.huber_dsqr) : chi2;
+        }
+    }
+    const double ts = block_sum(scale, s_tmp);
+    const double tc = block_sum(chi, s_tmp);
+    if (threadIdx.x == 0) {
+        d.partial[kBaPartialScale + blockIdx.x] = ts;
+        d.partial[kBaPartialChi + blockIdx.x] = tc;
+    }
+}
+
 // ---------------- Levenberg-Marquardt control on the device ----------------
 // Start of SparseOptimizer::optimize(iterations): chi2 of the current estimate (the error kernel ran on it),
 // computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180: tau * max diagonal, tau = 1e-5).
@@ -1578,6 +1681,14 @@ void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abor
     if (ev0) (void)hipEventRecord(ev0, s);
     launch_ba_solve(d, s);
     if (ev1) (void)hipEventRecord(ev1, s);
+    // local windows: back-substitution, manifold update and the trial's residuals in one launch (SWARMORB_BA_FUSE_UPDATE=0:
+    // the two kernels)
+    static const bool fuse_env = !(getenv("SWARMORB_BA_FUSE_UPDATE") && atoi(getenv("SWARMORB_BA_FUSE_UPDATE")) == 0);
+    if (fuse_env && d.fold_prep && d.n_poses <= kBaFusedMaxPoses && !d.use_pairs) {
+        hipLaunchKernelGGL(ba_update_errors_kernel, dim3(nb_upd), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(ba_trial_decide_kernel, dim3(1), dim3(256), 0, s, d, nb_upd, nb_upd, abort_flag, lm_host);
+        return;
+    }
     hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, s, d);
     launch_ba_errors(d, 1, kBaGateActive, nb_err, s);
     hipLaunchKernelGGL(ba_trial_decide_kernel, dim3(1), dim3(256), 0, s, d, nb_err, nb_upd, abort_flag, lm_host);
