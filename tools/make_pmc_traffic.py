@@ -11,7 +11,7 @@ import sys
 
 KEEP = ("fast_score_kernel", "fast_low_kernel", "describe_qt_kernel", "resize_kernel", "topk_window_kernel",
         "stage_in_kernel", "pose_opt_lds_kernel", "pose_opt_reg_kernel", "pose_opt_chain_kernel", "track_resolve_kernel", "ba_solve_la_kernel", "ba_solve_mfma_kernel",
-        "ba_schur_gather_kernel", "ba_build_kernel", "ba_update_kernel", "quadtree_kernel", "frame_prepare_kernel", "ingest_kernel", "ingest16_kernel",
+        "ba_schur_gather_kernel", "ba_build_kernel", "ba_update_kernel", "ba_update_errors_kernel", "quadtree_kernel", "frame_prepare_kernel", "ingest_kernel", "ingest16_kernel",
         "project_queries_batch_kernel", "hamming_top2_kernel", "triangulate_kernel", "normal_depth_kernel", "ba_mark_outliers_kernel",
         "ba_errors_kernel", "map_scatter_rows_kernel")
 
