@@ -3786,7 +3786,9 @@ int chain_prepare(so_matcher* m, int nq, int nk, ChainOffsets* O) {
     int rc;
     if ((rc = m->d_chain.ensure(O->d_total))) return rc;
     if ((rc = m->h_chain.ensure(O->h_total))) return rc;
+    const void* kpslot_before = m->d_kpslot.p;
     if ((rc = m->d_kpslot.ensure(sizeof(int32_t) * (size_t)std::max(nk, (int)so::kResolveMaxCand)))) return rc;
+    if (m->d_kpslot.p != kpslot_before) m->kpslot_frame = nullptr;  // (a new block: the last stage's bindings are gone)
     m->keys_dev_override = (uint32_t*)((uint8_t*)m->d_chain.p + O->d_keys);
     m->cnt8_dev_override = (uint8_t*)m->d_chain.p + O->d_cnt8;
     m->slot_out_override = (int32_t*)((uint8_t*)m->d_chain.p + O->d_qslot);
