@@ -1206,18 +1206,19 @@ int step_m1_submit(so_replay* r) {
         r->skip.resize((size_t)nl);
         for (int i = 0; i < nl; i++) r->skip[(size_t)i] = M.tv_bad[(size_t)M.tv_local[(size_t)i]];
         r->excluded.resize((size_t)n);
-        std::vector<uint8_t>& bound = r->new_desc;  // scratch: slot -> bound in this frame
-        bound.assign(r->mp_X.size() / 3, 0);
+        // slot -> bound in this frame, as the reference marks it: mnLastFrameSeen = the frame's id (a table cleared per frame
+        // would cost a memset of the whole map's size on every frame)
+        if (M.tv_seen.size() < r->mp_X.size() / 3) M.tv_seen.resize(r->mp_X.size() / 3, -1);
         for (int k = 0; k < n; k++) {
             const int s = F.kp_mp[(size_t)k];
             r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
             if (s >= 0) {
-                bound[(size_t)s] = 1;
+                M.tv_seen[(size_t)s] = S.t;
                 M.tv_vis[(size_t)s]++;  // SearchLocalPoints: points already matched (Tracking.cc:966-975)
             }
         }
         for (int i = 0; i < nl; i++)
-            if (bound[(size_t)M.tv_local[(size_t)i]]) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:966-978)
+            if (M.tv_seen[(size_t)M.tv_local[(size_t)i]] == S.t) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:966-978)
         if (track_chain_on(r) && !r->lockstep) {
             const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, nl, M.tv_local.data(), 0,
                                                            r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);

@@ -126,6 +126,7 @@ struct ClosedLoop {
     std::vector<uint8_t> tv_bad;
     std::vector<int32_t> tv_repl, tv_local;
     std::vector<uint32_t> tv_vis, tv_found;  // mnVisible / mnFound (IncreaseVisible in SearchLocalPoints, IncreaseFound after TrackLocalMap)
+    std::vector<int32_t> tv_seen;            // slot -> index of the frame that holds it already (MapPoint::mnLastFrameSeen): no per-frame clearing
     int recent_from = 0;
     M4 T_ref = M4::eye(), Tlr = M4::eye();
     int last_kf_t = 0, n_kf = 0, apply_at = 0, interrupts = 0;
