@@ -692,15 +692,22 @@ int so_track_search_local_map(so_matcher* m, const so_dframe* cur, const uint8_t
  *   search's `excluded` set AND edges of the pose problem; bound points must carry skip[] = 1 as for the plain search.
  *   kp_slot_is_last_stage != 0: kp_slot is exactly what this matcher's last stage left for this frame - the bindings it
  *   reported, minus the outliers of its pose when it was the last-frame stage (code/src/Tracking.cc:745-760) - so the device
- *   copy of that stage is used and nothing is read from host memory inside the chain (ignored when no such copy exists).
- * All map points are taken to have observations (slot_has_obs = NULL of the plain calls).
+ *   copy of that stage is used and nothing is read from host memory inside the chain.  The library can only tell that a copy
+ *   for THIS frame exists, not that the caller's bindings still equal it: pass 0 (or call so_track_stage_invalidate first)
+ *   whenever mvpMapPoints changed on the host since that stage - a host re-search with a wider window, a fall-back onto
+ *   TrackReferenceKeyFrame / Relocalization (code/src/Tracking.cc:321-327), a binding nulled by the isBad() test of
+ *   SearchLocalPoints (:972-975).  With 0 the bindings are uploaded from kp_slot.
+ * All map points are taken to have observations (slot_has_obs = NULL of the plain calls): the stage API is MONOCULAR-only -
+ * the temporal points UpdateLastFrame creates for stereo / RGB-D (Observations() == 0, code/src/Tracking.cc:664-711) must go
+ * through so_track_search_* with a slot_has_obs plane.
  * so_track_stage_wait - out, all required unless noted:
  *   kp_to_q[k] (cur->n) = query (index into the last frame / the local list) matched to keypoint k by THIS stage's search;
  *   in_view (local-map stage; may be NULL);  n_edges, edge_kp[e] = keypoint of edge e (ascending), edge_outlier[e]
  *   (capacity cur->n each);  Tcw_out12, n_inliers, info2 as so_pose_optimization_wait.
  * Returns SO_OK, or SO_RETRY_ON_HOST (100, not an error; nothing but kp_to_q = -1 is defined then): the stage could not be
- * finished on the device - a query ran out of K-list entries with more candidates in its window, more than 4096 keypoints /
- * 2048 queries with candidates, or more edges than the launched PoseOptimization variant holds - and the caller runs
+ * finished on the device - a query ran out of K-list entries with more candidates in its window, more than 4096 keypoints or
+ * more than 4096 queries in all (kResolveMaxQueries, csrc/match_device.h; the count is of queries, with or without candidates),
+ * or more edges than the launched PoseOptimization variant holds - and the caller runs
  * so_track_search_* + so_pose_optimization instead (same results by construction: tests/test_track_chain_gpu.py).
  * so_track_stage_pose_again_submit: PoseOptimization over the SAME edges from another start pose (the edge list of the
  * last stage is still on the device); wait with so_track_stage_wait (kp_to_q / in_view are not written). */
@@ -713,6 +720,8 @@ int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const i
                                     int32_t first_slot, const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
                                     float log_scale_factor, const float* intr4, const float* level_inv_sigma2);
 int so_track_stage_pose_again_submit(so_matcher* m, const float* Tcw12);
+/* Forget the device copy of the last stage's bindings: the next local-map stage uploads kp_slot whatever its flag says. */
+int so_track_stage_invalidate(so_matcher* m);
 int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint8_t* in_view, int32_t* n_edges,
                         int32_t* edge_kp, uint8_t* edge_outlier, float* Tcw_out12, int32_t* n_inliers, int32_t* info2);
 /* rounds the last stage's device resolve took, and how many of its queries had candidates (diagnostics) */

@@ -39,7 +39,12 @@ the only thing the interleaving changes for CreateNewMapPoints is which features
 descriptors of map
 points stay the creating keypoint's (ComputeDistinctiveDescriptors exists as an operator, so_distinctive_descriptors, but
 is not part of this loop); the local map Tracking searches is the points of the last `local_keyframes` keyframes, listed
-by local mapping when it finishes a keyframe; a frame's reference keyframe is the last keyframe created.
+by local mapping when it finishes a keyframe; a frame's reference keyframe is the last keyframe created;
+CheckReplacedInLastFrame follows the replacement chain to its end and DROPS the last frame's binding to a bad point that
+has no replacement (a culled point), where the reference (Tracking.cc:603-614) swaps only when GetReplaced() != NULL and
+otherwise keeps the bad point bound - SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:1245-1250) has no isBad
+test, so the reference still projects such a point in TrackWithMotionModel and SearchLocalPoints' isBad rule
+(Tracking.cc:972-975) drops it one stage later.  Both chains (this module and host/closedloop.cc) do the same.
 """
 import numpy as np
 

@@ -1069,6 +1069,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     d.pcg_host = nullptr;
     b->pcg.iterations = 0;
     b->pcg.solves = 0;
+    b->pcg.fault = 0;
     if (pairs_path && b->linear_solver == 1) {
         // block-Jacobi PCG instead of the blocked Cholesky: the 6 x 6 block structure of S from the pair lists (once per
         // problem: counts, scan, one look at the total, fill), then the workspace
@@ -1186,7 +1187,8 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
             early_phase = 0;
             static const bool no_early = getenv("SWARMORB_BA_NO_EARLY") != nullptr;  // A/B: the reserve in front of the only epilogue
             if (no_early) trials(d2, std::min(2, opt->its_stage2 - ahead));
-            if (ahead < opt->its_stage2 && !no_early) {  // results out as soon as the stage is over; two trials in reserve behind them
+            // (not with PCG: its solve keeps the host in a loop per enqueued trial, a reserve would block the return it is for)
+            if (ahead < opt->its_stage2 && !no_early && !r.d.use_pcg) {  // results out as soon as the stage is over; two trials in reserve behind them
                 launch_ba_finish(r.d, (double)opt->chi2_threshold, (BaPose*)(ob + r_pose), (double*)(ob + r_pt), (double*)(ob + r_chi2),
                                  ob + r_out, s);
                 (void)hipEventRecord(b->e1a, s);
@@ -1219,6 +1221,10 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
             }
             if ((rc = wait_word(phases))) return rc;
             if (*(volatile unsigned*)b->h_flow_abort != 0) return kErrFlowTimeout;  // a dataflow solve gave up waiting
+            if (b->pcg.fault) {  // a PCG solve was abandoned by its host loop (ba_pcg.hip): the trial it fed is not a result
+                last_error_ref() = b->pcg.fault == 1 ? "so_bundle_adjust: a PCG solve did not finish within 30 s" : "so_bundle_adjust: the stream failed during a PCG solve";
+                return b->pcg.fault == 1 ? SO_ERR_TIMEOUT : SO_ERR_HIP;
+            }
             memcpy(&lm, b->h_lm, sizeof(lm));
             if (lm.active == 1) {  // stage 1 wants more trials than were enqueued
                 trials(r.d, std::max(1, lm.iterations - lm.it));

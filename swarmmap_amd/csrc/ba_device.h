@@ -71,6 +71,7 @@ struct BaPcgHost {
     int max_it = 4000;
     long long iterations = 0;  // of this so_bundle_adjust call
     int solves = 0;
+    int fault = 0;             // of this call: 1 = a solve did not finish within 30 s, 2 = the stream failed / drained mid-solve
 };
 
 struct BaDev {

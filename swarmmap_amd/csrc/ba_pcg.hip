@@ -263,11 +263,12 @@ __global__ __launch_bounds__(256) void pcg_direction_kernel(BaDev d, BaPcgDev q,
     }
 }
 
-__global__ __launch_bounds__(256) void pcg_finish_kernel(BaDev d, BaPcgDev q) {
+__global__ __launch_bounds__(256) void pcg_finish_kernel(BaDev d, BaPcgDev q, int host_gave_up) {
     if (d.lm->active != d.stage) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < 6 * d.n_free) d.bs[i] = q.x[i];
-    if (i == 0) d.partial[kBaSolveOk] = (*q.status & kStFailed) ? 0.0 : 1.0;
+    // (host_gave_up: the host loop left without seeing a flag - x is whatever iteration it had reached: not a solve)
+    if (i == 0) d.partial[kBaSolveOk] = ((*q.status & kStFailed) || host_gave_up) ? 0.0 : 1.0;
 }
 
 }  // namespace
@@ -307,7 +308,7 @@ void launch_ba_pcg_solve(const BaDev& d, hipStream_t s) {
     int waited_for = kChunk;  // iterations the host has seen complete (or the solve end)
     unsigned it_seen = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    int spins = 0;
+    int spins = 0, gave_up = 0;
     for (;;) {
         const unsigned long long v = *st;
         if ((unsigned)(v >> 32) == seq) {
@@ -322,13 +323,29 @@ void launch_ba_pcg_solve(const BaDev& d, hipStream_t s) {
         }
         if (++spins > 2000) {  // not a busy spin for ever: nap, and give up on a dead stream
             std::this_thread::sleep_for(std::chrono::microseconds(5));
-            if (hipStreamQuery(s) != hipErrorNotReady) break;
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) break;
+            const hipError_t qs = hipStreamQuery(s);
+            if (qs == hipSuccess) {
+                // the stream has drained without this solve's stamp: either the stamp landed after the read above, or
+                // the launches belonged to a stage that is over (every kernel returned at once: nothing to solve)
+                const unsigned long long v2 = *st;
+                if ((unsigned)(v2 >> 32) == seq && !(v2 & (kStConverged | kStFailed))) gave_up = 2;  // begun, never finished
+                if ((unsigned)(v2 >> 32) == seq) it_seen = (unsigned)((v2 >> 2) & 0x3FFFFFFFu);
+                break;
+            }
+            if (qs != hipErrorNotReady) {  // the stream is in error
+                gave_up = 2;
+                break;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+                gave_up = 1;
+                break;
+            }
         }
     }
+    if (gave_up && !H.fault) H.fault = gave_up;  // surfaced by so_bundle_adjust as SO_ERR_TIMEOUT / SO_ERR_HIP
     H.iterations += (long long)it_seen;
     H.solves++;
-    hipLaunchKernelGGL(pcg_finish_kernel, dim3(nC), dim3(256), 0, s, d, q);
+    hipLaunchKernelGGL(pcg_finish_kernel, dim3(nC), dim3(256), 0, s, d, q, gave_up);
 }
 
 }  // namespace so

@@ -3999,6 +3999,12 @@ int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint
     return SO_OK;
 }
 
+int so_track_stage_invalidate(so_matcher* m) {
+    if (!m) return SO_ERR_INVALID_ARG;
+    m->kpslot_frame = nullptr;
+    return SO_OK;
+}
+
 int so_track_stage_last_rounds(so_matcher* m, int32_t* rounds, int32_t* active_queries) {
     if (!m || !rounds || !m->h_chain.p || m->chain.active) return SO_ERR_INVALID_ARG;
     const int32_t* head = (const int32_t*)((const uint8_t*)m->h_chain.p + m->chain.h_head);

@@ -711,12 +711,12 @@ int cl_frame_begin(so_replay* r, int t) {
             const double w0 = now_ms();
             // (deterministic schedule: wait for the job.  Spin first - the job is usually a few hundred microseconds from its
             //  end and a futex wake-up costs 30-60 us of the cycle -, sleep on the condition variable after 2 ms)
-            while (M.outbox.empty() && r->error.empty() && now_ms() - w0 < 2.0) {
+            while (M.outbox.empty() && !M.failed && now_ms() - w0 < 2.0) {
                 lk.unlock();
                 for (int i = 0; i < 64; i++) __builtin_ia32_pause();
                 lk.lock();
             }
-            M.cv.wait(lk, [&] { return !M.outbox.empty() || !r->error.empty(); });
+            M.cv.wait(lk, [&] { return !M.outbox.empty() || M.failed; });
             M.wait_ms += now_ms() - w0;
             if (M.outbox.empty()) return SO_ERR_HIP;
         } else if (M.outbox.empty()) {

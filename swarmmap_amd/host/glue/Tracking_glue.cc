@@ -31,6 +31,13 @@ struct DeviceSide {  // what Frame / Map / MapPoint would carry as members
     so_map* map = nullptr;                         // the device table of mpMap's points
     std::unordered_map<long unsigned int, so_dframe*> frame;  // Frame::mnId -> its device-resident twin
     std::unordered_map<MapPoint*, int32_t> slot;   // MapPoint -> row of the table (so_map_write when the point is created / moved)
+    // The frame whose bindings TrackWithMotionModel's stage left on the device AND whose host bindings still equal them
+    // (what host/replay.cc keeps as S.stage1_dev): set only when that stage ran on the device, its result was applied and the
+    // function returned true; anything that rebinds mvpMapPoints afterwards - the wider host re-search, Track()'s fall-back
+    // onto TrackReferenceKeyFrame / Relocalization (code/src/Tracking.cc:321-327), the isBad() test of SearchLocalPoints -
+    // leaves it unset or clears it, and TrackLocalMap then uploads the host bindings.
+    bool stage1_dev = false;
+    long unsigned int stage1_frame = 0;
     int32_t slot_of(MapPoint* p) const {
         if (!p) return -1;
         auto it = slot.find(p);
@@ -66,6 +73,7 @@ void apply_pose(Frame& F, const float* Tcw12, int n_edges, const int32_t* edge_k
 // code/src/Tracking.cc:714-768
 bool Tracking::TrackWithMotionModel() {
     DeviceSide& D = device_side();
+    D.stage1_dev = false;
     UpdateLastFrame();                                            // :719
     mCurrentFrame.SetPose(mVelocity * mLastFrame.mTcw);           // :721
     std::fill(mCurrentFrame.mvpMapPoints.begin(), mCurrentFrame.mvpMapPoints.end(), static_cast<MapPoint*>(NULL));  // :723
@@ -120,11 +128,15 @@ bool Tracking::TrackWithMotionModel() {
             nmatchesMap++;
         }
     }
-    if (mbOnlyTracking) {                                         // :762-765
-        mbVO = nmatchesMap < 10;
+    if (mbOnlyTracking) {                                         // :762-765 (localisation mode may run Relocalization beside this
+        mbVO = nmatchesMap < 10;                                  //  function and keep either result, :348-391: no device copy is trusted)
         return nmatches > 20;
     }
-    return nmatchesMap >= 10;
+    const bool ok = nmatchesMap >= 10;
+    // a false return sends Track() to TrackReferenceKeyFrame, which rebinds the frame (:321-327)
+    D.stage1_dev = on_device && ok;
+    D.stage1_frame = mCurrentFrame.mnId;
+    return ok;
 }
 
 // code/src/Tracking.cc:770-807 with SearchLocalPoints (:964-1007) folded in: the frustum test of every local point, the search
@@ -135,11 +147,15 @@ bool Tracking::TrackLocalMap() {
     const int N = mCurrentFrame.N;
     // :966-978: points already matched are not searched again; they are edges of the pose problem and `excluded` keypoints
     std::vector<int32_t> kp_slot((size_t)N, -1);
+    // the last-frame stage's device copy of the bindings is good for THIS frame only, and only while the host agrees with it
+    bool kp_slot_on_device = D.stage1_dev && D.stage1_frame == mCurrentFrame.mnId;
+    D.stage1_dev = false;
     for (int i = 0; i < N; i++) {
         MapPoint* pMP = mCurrentFrame.mvpMapPoints[i];
         if (!pMP) continue;
         if (pMP->isBad()) {
             mCurrentFrame.mvpMapPoints[i] = static_cast<MapPoint*>(NULL);
+            kp_slot_on_device = false;  // (the device copy still carries this binding)
         } else {
             pMP->IncreaseVisible();
             pMP->mnLastFrameSeen = mCurrentFrame.mnId;
@@ -165,9 +181,9 @@ bool Tracking::TrackLocalMap() {
     std::vector<int32_t> kp_to_local((size_t)N, -1), edge_kp((size_t)N);
     std::vector<uint8_t> edge_outlier((size_t)N), excluded((size_t)N);
     int32_t nmatches = 0, n_edges = 0, n_inliers = 0, info2[2];
-    // kp_slot is what TrackWithMotionModel's stage left on the device when that stage ran there for this frame: flag 1 lets
-    // the chain read it in place (the library ignores the flag when it holds no such copy)
-    int rc = so_track_stage_local_map_submit(D.matcher, cur, kp_slot.data(), 1, D.map, Tcw, n_local, local_slot.data(), 0, skip.data(), th, 0.8f,
+    // when kp_slot is exactly what TrackWithMotionModel's stage left on the device for this frame the chain reads it in
+    // place; otherwise (host re-search, another tracking routine bound the frame, a bad point dropped) it is uploaded
+    int rc = so_track_stage_local_map_submit(D.matcher, cur, kp_slot.data(), kp_slot_on_device ? 1 : 0, D.map, Tcw, n_local, local_slot.data(), 0, skip.data(), th, 0.8f,
                                              0.5f, std::log(mCurrentFrame.mfScaleFactor), K4, mCurrentFrame.mvInvLevelSigma2.data());
     if (rc == SO_OK)
         rc = so_track_stage_wait(D.matcher, kp_to_local.data(), &nmatches, in_view.data(), &n_edges, edge_kp.data(), edge_outlier.data(), Tout,

@@ -509,7 +509,12 @@ void mapper_loop(so_replay* r) {
                 r->running = 0;
             }
             r->cv.notify_all();
-            r->cl->cv.notify_all();  // (an error wakes a tracking thread that waits for the packet)
+            if (lm_rc != SO_OK) {  // an error wakes a tracking thread that waits for the packet: the flag is set under the
+                                   // mutex its predicate is evaluated under, so the wake-up cannot fall between test and sleep
+                std::lock_guard<std::mutex> lk(r->cl->mu);
+                r->cl->failed = true;
+            }
+            r->cl->cv.notify_all();
             continue;
         }
         if (kf) lm_rc = lm_matcher_job(r, kf, timed != 0);  // CreateNewMapPoints + SearchInNeighbors before the LBA

@@ -139,6 +139,8 @@ struct ClosedLoop {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<LmPacket> outbox;
+    bool failed = false;        // under `mu`: a local-mapping job ended in an error (so_replay::error, written under so_replay::mu,
+                                // is NOT read by the waiting tracking thread: that was a race on a std::string and a lost wake-up)
     volatile uint8_t stop = 0;  // mbAbortBA
 };
 // What the local-mapping thread keeps of a tracked frame that became a keyframe (KeyFrame::KeyFrame(Frame&, ...),

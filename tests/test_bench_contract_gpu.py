@@ -11,28 +11,46 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _no_constants(name):
+    raise ValueError("not strict JSON: %s" % name)
+
+
 def test_bench_prints_one_json_line_with_the_contract_keys():
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "8", "--no-configs"],
-                                  text=True, cwd=ROOT, timeout=900)
+    """The driver's own command line (--steps 20 --warmup 5, configs included).  Round 5's line had grown to 27.9 KB and the
+    driver recorded `parsed: null`: the LAST stdout line is now a headline of at most 6000 bytes, strict JSON (no NaN /
+    Infinity), and the whole record goes to profiles/last_bench_full.json."""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                                  text=True, cwd=ROOT, timeout=1500)
     line = out.strip().splitlines()[-1]
-    d = json.loads(line)
+    assert len(line.encode()) < 6000, len(line)
+    d = json.loads(line, parse_constant=_no_constants)
+    full = json.load(open(os.path.join(ROOT, d["full_record"])), parse_constant=_no_constants)
+    assert full["value"] == pytest.approx(d["value"], rel=1e-4) and "configs" in full and "error" not in full["configs"], full.get("configs", {}).get("error")
+    oc = d["other_configs"]
+    assert oc["error"] is None and oc["steady_state_frames_per_s"] > 100 and oc["kitti_frames_per_s"] > 100
+    assert set(oc["gba_solve_ms"]) == {"GBA-1", "GBA-2", "GBA-1r", "GBA-2r"} and oc["steady_state_steps"] == 400
+    assert d["ate_rmse_vs_ground_truth"] < 0.01 and d["ate_rmse_vs_oracle_chain"] < 1e-3
+    assert d["roofline"]["evidence"].startswith("profiles/") and d["roofline"]["avg_launch_ms"] > 0
+    steps, warmup = 20, 5
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 8 and d["unit"] == "frames/s"
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["unit"] == "frames/s"
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]  # (the headline carries five significant digits)
     w = d["config"]["workload"]
-    assert "upload" in w and "UndistortKeyPoints" in w and "isInFrustum" in w and "PoseOptimization over its matches" in w
+    assert "upload" in w and "ORB extract" in w and "SearchByProjection(local map)" in w and "LocalBundleAdjustment" in w and "closed loop" in w
+    wf = full["config"]["workload"]  # the long form stays in the full record
+    assert "UndistortKeyPoints" in wf and "isInFrustum" in wf and "PoseOptimization over its matches" in wf
     assert d["config"]["m2_matches_per_frame"] > 300 and d["config"]["inliers_per_frame"] > 400   # real matches feed the pose
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 * r["frac"]
     lat = d["config"]["latency_ms_image_to_pose"]  # unpipelined: a live frame, nothing extracted ahead
     assert 0.1 < lat["p50"] <= lat["p99"] < 20.0  # (no relation to ms_per_step is asserted: the pipelined rate may be bound by the local-mapping thread)
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and "python-driven" in c["sample"]
+    assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and "python-driven" in c["sample"] and c["unit"] == "frames/s"
     assert d["value"] > 10 * c["value"]
 
 
@@ -46,7 +64,9 @@ def test_bench_distributed_branch_runs_on_one_rank():
                MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "8",
                                    "--no-configs", "--no-cpu-baseline"], text=True, cwd=ROOT, timeout=900, env=env)
-    d = json.loads(out.strip().splitlines()[-1])
+    line = out.strip().splitlines()[-1]
+    assert len(line.encode()) < 6000
+    d = json.loads(line, parse_constant=_no_constants)
     assert d["n_gpus"] == 1 and d["steps"] == 40 and d["value"] > 100
     x = d["config"]["exchange"]
     assert d["config"]["descriptor_exchanges"] == x["ticks"] >= 2
