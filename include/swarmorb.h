@@ -724,6 +724,27 @@ int so_track_stage_pose_again_submit(so_matcher* m, const float* Tcw12);
 int so_track_stage_invalidate(so_matcher* m);
 int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint8_t* in_view, int32_t* n_edges,
                         int32_t* edge_kp, uint8_t* edge_outlier, float* Tcw_out12, int32_t* n_inliers, int32_t* info2);
+/* The tracking stages of SEVERAL agents in one chain of launches - several agents per GPU, the concurrency of one process per
+ * agent (code/Examples/Monocular/swarm_map.cc:329-337) brought inside the launches: a frame's chain is three kernels of one
+ * workgroup (resolve, pose) or a few hundred (search) on a chip of 256 CUs, and chains of different agents on different
+ * streams take turns on the hardware queues.  A matcher that is a member of a group (so_matcher_set_track_group) RECORDS the
+ * launches of its so_track_stage_last_frame_submit / _local_map_submit / _pose_again_submit instead of issuing them - inputs
+ * staged, completion word armed, map table held as always -; so_track_group_launch then issues, for all members recorded
+ * since the last launch: one copy of their argument rows into HBM, ONE search launch (blockIdx.y = member), ONE resolve launch
+ * and ONE PoseOptimization launch (a workgroup per member).  Every member waits with its own so_track_stage_wait and gets
+ * exactly the results of a solo stage (same kernels' bodies, same summation orders: tests/test_track_group_gpu.py).
+ * Rules: the members' matchers share one stream (create them on one thread, without so_runtime_private_streams); the rows of
+ * one launch are stages of one kind (all last-frame, all local-map or all pose-again); a member whose submit returns
+ * SO_RETRY_ON_HOST is not in the launch - its caller runs the plain calls, which launch at once on the same stream.
+ * so_track_group_last_kernel_ms: HIP-event times of the last launch's search and PoseOptimization kernels (0 unless a
+ * member's profiling is on); the members' own kernel times are not recorded for grouped stages. */
+typedef struct so_track_group so_track_group;
+int so_track_group_create(int device, so_track_group** out);
+void so_track_group_destroy(so_track_group* g);
+int so_matcher_set_track_group(so_matcher* m, so_track_group* g_or_null);
+int so_track_group_pending(so_track_group* g);
+int so_track_group_launch(so_track_group* g);
+int so_track_group_last_kernel_ms(so_track_group* g, float* search_ms, float* pose_ms);
 /* rounds the last stage's device resolve took, and how many of its queries had candidates (diagnostics) */
 int so_track_stage_last_rounds(so_matcher* m, int32_t* rounds, int32_t* active_queries);
 /* HIP-event time of the stage's PoseOptimization kernel (0 unless so_matcher_set_profiling is on) */

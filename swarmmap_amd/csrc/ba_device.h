@@ -253,6 +253,8 @@ struct PoseOptArgs {  // Optimizer::PoseOptimization, one workgroup (ba_kernels.
 // range 0: up to 1024 edges, 1: 1025 .. 1792; a count outside the launched range, or a resolve that gave up: info[0] = -1
 // and the caller takes the host path (fewer than three edges: -2, nothing to optimise)
 void launch_pose_opt_chain(const PoseOptArgs& a, int range, hipStream_t s);
+// rows of a so_track_group's table in HBM; range_mask bit r: a member's stage needed RANGE r last time
+void launch_pose_opt_chain_group(const PoseOptArgs* d_tab, int n, int range_mask, hipStream_t s);
 constexpr int kPoseChainMaxEdges = 1792;
 // Converter::toSE3Quat(Tcw) / Converter::toCvMat(SE3Quat) as so_pose_optimization applies them (ba.cpp)
 void pose_from_Tcw12(const float* Tcw12, BaPose& P);

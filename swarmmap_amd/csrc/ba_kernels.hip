@@ -2811,11 +2811,13 @@ __global__ __launch_bounds__(THREADS) void pose_opt_reg_kernel(PoseOptArgs a0, c
 // kernel: with four and more in one function the compiler no longer keeps the 256-byte argument block out of scratch
 // memory.  RANGE 0: up to 1024 edges (2 / 3 / 4 per thread), RANGE 1: 1025 .. 1792 (5 / 6 / 7); the host launches the range
 // the stage's last call needed, and a count outside it is answered with info[0] = -1 (the caller takes the host path).
+// other_range_launched (grouped launches): the group also launches the other RANGE, which takes the counts this one does not
 template <int RANGE>
-__global__ __launch_bounds__(256) void pose_opt_chain_kernel(PoseOptArgs a0) {
+__device__ __forceinline__ void pose_opt_chain_body(const PoseOptArgs& a0, bool other_range_launched) {
     const PoseOptArgs a = a0;
     const int n = a0.head[0];
     const bool fits = RANGE == 0 ? n <= 1024 : (n > 1024 && n <= kPoseChainMaxEdges);
+    if (!fits && other_range_launched && a0.head[2] == 0 && n >= 3 && n <= kPoseChainMaxEdges) return;
     if (a0.head[2] != 0 || n < 3 || !fits) {
         // nothing optimised: the resolve gave up / the count is outside this kernel's range (-1), or fewer than three
         // edges (-2: Optimizer.cc:358-359 returns without touching the frame)
@@ -2841,6 +2843,27 @@ __global__ __launch_bounds__(256) void pose_opt_chain_kernel(PoseOptArgs a0) {
         else if (ept == 6) pose_opt_reg_body<256, 6>(a, n);
         else pose_opt_reg_body<256, 7>(a, n);
     }
+}
+
+template <int RANGE>
+__global__ __launch_bounds__(256) void pose_opt_chain_kernel(PoseOptArgs a0) {
+    pose_opt_chain_body<RANGE>(a0, false);
+}
+
+// a GROUP of agents' PoseOptimization calls behind their resolves (so_track_group): workgroup x = row x of the table
+template <int RANGE>
+__global__ __launch_bounds__(256) void pose_opt_chain_group_kernel(const PoseOptArgs* __restrict__ tab, int other_range_launched) {
+    const PoseOptArgs a0 = tab[blockIdx.x];
+    pose_opt_chain_body<RANGE>(a0, other_range_launched != 0);
+}
+
+// range_mask: bit r = some member's stage needed RANGE r last time; both bits: two launches, each problem runs in one
+void launch_pose_opt_chain_group(const PoseOptArgs* d_tab, int n, int range_mask, hipStream_t s) {
+    if (n <= 0) return;
+    const int both = (range_mask & 3) == 3 ? 1 : 0;
+    if ((range_mask & 1) || !(range_mask & 2))
+        hipLaunchKernelGGL(pose_opt_chain_group_kernel<0>, dim3(n), dim3(256), 0, s, d_tab, both);
+    if (range_mask & 2) hipLaunchKernelGGL(pose_opt_chain_group_kernel<1>, dim3(n), dim3(256), 0, s, d_tab, both);
 }
 
 void launch_pose_opt_chain(const PoseOptArgs& a, int range, hipStream_t s) {

@@ -143,6 +143,19 @@ struct TrackResolveArgs {
     int32_t* head_host;          // host-mapped copy
 };
 void launch_track_resolve(const TrackResolveArgs& a, hipStream_t s);
+// one row per agent of a so_track_group, table in HBM; the instance is chosen for the largest search of the group (the
+// resolve is exact: its result does not depend on the instance)
+void launch_track_resolve_group(const TrackResolveArgs* d_tab, int n, int max_nq, hipStream_t s);
+
+// The tracking search of one agent inside a grouped launch (topk_window_kernel<5 / 6>, blockIdx.y = row)
+struct TrackGroupJob {
+    MatchFrameDev F;
+    TrackQuerySrc T;
+    uint32_t* keys;
+    int32_t* count;
+    int nq, K;
+};
+void launch_topk_track_group(const TrackGroupJob* d_jobs, int n_jobs, int mode, int max_nq, hipStream_t s);
 
 // Projection + gating half of the keyframe-side map-point searches: Fuse (code/src/
 // ORBmatcher.cc:767-815), Fuse / SearchByProjection with a Sim3 (:916-964, :286-333), one direction of SearchBySim3

@@ -220,15 +220,21 @@ __device__ __forceinline__ MatchQuery track_query_local(const TrackQuerySrc& T, 
 
 // MODE 0: MatchQuery records, 1: MatchQueryW records, 2: last-frame tracking search, 3: local-map tracking search,
 // 4: batched jobs - q points to a BatchJobDev table, blockIdx.y selects the job (frame, queries and outputs from there)
+// 5 / 6: modes 2 / 3 for a GROUP of agents (so_track_group): q points to a TrackGroupJob table in HBM, blockIdx.y selects the
+// agent - its frame, its query source with the gates, its outputs; one launch searches for all of them
 template <int MODE>
 __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F_arg, const void* __restrict__ q,
                                                            const uint4* __restrict__ qdesc, int nq, int K,
                                                            uint32_t* __restrict__ out_keys,
-                                                           int32_t* __restrict__ out_count, TrackQuerySrc T,
+                                                           int32_t* __restrict__ out_count, TrackQuerySrc T_arg,
                                                            int q_first) {
     __shared__ uint32_t s_keys[4][kListCap];
+    constexpr bool kTrack = MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6;
+    constexpr bool kTrackLast = MODE == 2 || MODE == 5;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int blk = blockIdx.x;
+    const TrackGroupJob* gj = MODE >= 5 ? static_cast<const TrackGroupJob*>(q) + blockIdx.y : nullptr;
+    const TrackQuerySrc& T = MODE >= 5 ? gj->T : T_arg;
     const BatchJobDev* job = nullptr;
     if (MODE == 4) {  // qdesc carries the batch's grid table here: which job does this workgroup belong to?
         const BatchGridDev* G = reinterpret_cast<const BatchGridDev*>(qdesc);
@@ -249,14 +255,17 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F_arg, c
         blk -= G->first_topk[lo];
     }
     const int qi = __builtin_amdgcn_readfirstlane(blk * 4 + w);  // wave-uniform: per-query data through scalar loads
-    const MatchFrameDev& F = MODE == 4 ? job->F : F_arg;
+    const MatchFrameDev& F = MODE == 4 ? job->F : (MODE >= 5 ? gj->F : F_arg);
     if (MODE == 4) {
         nq = job->nq; K = job->K; qdesc = job->qdesc; out_keys = job->keys; out_count = job->count;
     }
+    if (MODE >= 5) {
+        nq = gj->nq; K = gj->K; out_keys = gj->keys; out_count = gj->count; q_first = 0;
+    }
     if (qi >= nq) return;
-    const bool soa = (MODE == 2 || MODE == 3) && T.keys_soa;
+    const bool soa = kTrack && T.keys_soa;
     const size_t kq = soa ? (size_t)nq : 1, kk = soa ? 1 : (size_t)K;  // key (qi, k) lives at qi * kk + k * kq
-    const bool bits = (MODE == 2 || MODE == 3) && T.use_bits;
+    const bool bits = kTrack && T.use_bits;
     MatchQuery Q;
     int slot = -1;
     if (MODE == 1) {
@@ -270,23 +279,23 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F_arg, c
         Q = static_cast<const MatchQuery*>(q)[qi];
     } else if (MODE == 4) {
         Q = job->q[qi];
-    } else if (MODE == 2) {
+    } else if (kTrackLast) {
         Q = track_query_last(T, q_first + qi, slot);
     } else {
         Q = track_query_local(T, q_first + qi, slot);
         if (T.in_view_out && lane == 0) T.in_view_out[q_first + qi] = (uint8_t)Q.active;
     }
-    if ((MODE == 2 || MODE == 3) && T.slot_out && lane == 0) T.slot_out[q_first + qi] = slot;
+    if (kTrack && T.slot_out && lane == 0) T.slot_out[q_first + qi] = slot;
     if (!Q.active) {
         if (lane == 0) out_count[qi] = 0;
-        if ((MODE == 2 || MODE == 3) && T.count8_out && lane == 0) T.count8_out[q_first + qi] = 0;
+        if (kTrack && T.count8_out && lane == 0) T.count8_out[q_first + qi] = 0;
         for (int k = lane; k < K; k += 64) out_keys[(size_t)qi * kk + k * kq] = 0xFFFFFFFFu;
         return;
     }
     // (a batched job whose map points live in a so_map: the descriptor is row qslot[qi] of the map's table; the query
     //  is only active when that slot is a row of the table)
     const size_t qrow = (MODE == 4 && job->qslot) ? (size_t)job->qslot[qi] : (size_t)qi;
-    const uint4* qsrc = (MODE == 2 || MODE == 3) ? T.desc + 2 * (size_t)slot : qdesc + 2 * qrow;
+    const uint4* qsrc = kTrack ? T.desc + 2 * (size_t)slot : qdesc + 2 * qrow;
     const uint4 qd0 = qsrc[0], qd1 = qsrc[1];
     const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(256) void topk_window_kernel(MatchFrameDev F_arg, c
         }
     }
     if (lane == 0) out_count[qi] = m;
-    if ((MODE == 2 || MODE == 3) && T.count8_out && lane == 0) T.count8_out[q_first + qi] = (uint8_t)min(m, 255);
+    if (kTrack && T.count8_out && lane == 0) T.count8_out[q_first + qi] = (uint8_t)min(m, 255);
     if (m <= kListCap) {
         // K smallest keys of the list: round k = min over keys greater than the previous minimum (keys are unique)
         uint32_t prev = 0;
@@ -780,6 +789,20 @@ void launch_topk_track(const MatchFrameDev& F, const TrackQuerySrc& T, int mode,
                            d_count, T, q_first);
 }
 
+// the tracking search of a GROUP of agents: grid (workgroups of the largest search, agents); a member with fewer queries
+// leaves its surplus workgroups at once
+void launch_topk_track_group(const TrackGroupJob* d_jobs, int n_jobs, int mode, int max_nq, hipStream_t s) {
+    if (n_jobs <= 0 || max_nq <= 0) return;
+    const MatchFrameDev none{};
+    static const TrackQuerySrc zero{};  // (the by-value argument of the single-agent modes: not read by the group modes)
+    if (mode == 2)
+        hipLaunchKernelGGL(topk_window_kernel<5>, dim3((max_nq + 3) / 4, n_jobs), dim3(256), 0, s, none, (const void*)d_jobs, nullptr, 0, 0,
+                           nullptr, nullptr, zero, 0);
+    else
+        hipLaunchKernelGGL(topk_window_kernel<6>, dim3((max_nq + 3) / 4, n_jobs), dim3(256), 0, s, none, (const void*)d_jobs, nullptr, 0, 0,
+                           nullptr, nullptr, zero, 0);
+}
+
 // Brute-force best / second-best of each row of A against all rows of B; ties: lowest index in B.
 // One wave per query row; each lane strides over B keeping its own (best, second) keys, then a wave merge.
 __global__ __launch_bounds__(256) void hamming_top2_kernel(const uint4* __restrict__ A, int na,
@@ -949,7 +972,7 @@ __device__ __forceinline__ int block_rank(bool flag, int* s_wave /* >= 17 ints *
 // kResThreads x kResQPT queries: the host launches the instance that holds the search (1024 threads up to 2048 queries;
 // beyond, 512 threads with twice the registers each - the K-lists of six or eight queries per thread stay out of scratch)
 template <int kResThreads, int kResQPT>
-__global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolveArgs a) {
+__device__ __forceinline__ void track_resolve_body(const TrackResolveArgs& a) {
     constexpr int kResPPT = kResolveMaxCand / kResThreads;
     __shared__ int s_claim[kResolveMaxCand];
     __shared__ int s_taken[kResolveMaxCand];
@@ -1187,6 +1210,26 @@ __global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolve
         tk[5] = wall_clock64();
         for (int i = 0; i < 5; i++) a.head_host[8 + i] = (int)(tk[i + 1] - tk[i]);
     }
+}
+
+template <int kResThreads, int kResQPT>
+__global__ __launch_bounds__(kResThreads) void track_resolve_kernel(TrackResolveArgs a) {
+    track_resolve_body<kResThreads, kResQPT>(a);
+}
+
+// a GROUP of agents' resolves in one launch (so_track_group): workgroup x works on row x of the table
+template <int kResThreads, int kResQPT>
+__global__ __launch_bounds__(kResThreads) void track_resolve_group_kernel(const TrackResolveArgs* __restrict__ tab) {
+    const TrackResolveArgs a = tab[blockIdx.x];
+    track_resolve_body<kResThreads, kResQPT>(a);
+}
+
+void launch_track_resolve_group(const TrackResolveArgs* d_tab, int n, int max_nq, hipStream_t s) {
+    if (n <= 0) return;
+    if (max_nq <= 1024) hipLaunchKernelGGL((track_resolve_group_kernel<1024, 1>), dim3(n), dim3(1024), 0, s, d_tab);
+    else if (max_nq <= 2048) hipLaunchKernelGGL((track_resolve_group_kernel<1024, 2>), dim3(n), dim3(1024), 0, s, d_tab);
+    else if (max_nq <= 3072) hipLaunchKernelGGL((track_resolve_group_kernel<512, 6>), dim3(n), dim3(512), 0, s, d_tab);
+    else hipLaunchKernelGGL((track_resolve_group_kernel<512, 8>), dim3(n), dim3(512), 0, s, d_tab);
 }
 
 void launch_track_resolve(const TrackResolveArgs& a, hipStream_t s) {

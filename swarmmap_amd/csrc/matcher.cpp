@@ -136,6 +136,8 @@ struct so_kframe {
     int nlevels = 0;
 };
 
+struct so_track_group;
+
 struct so_matcher {
     std::vector<int> scratch_rot_item, scratch_rot_b;  // rotation-histogram bookkeeping of the resolve loops
     int device = 0;
@@ -210,6 +212,7 @@ struct so_matcher {
         int kind = 0;  // 0: last-frame stage, 1: local-map stage, 2: the pose again over the same edges
         int n_kp = 0, nq = 0, seq = 0;
         bool events = false, valid_edges = false;
+        bool grouped = false;  // launched by the matcher's so_track_group: no per-member events
         size_t h_k2q = 0, h_ekp = 0, h_head = 0, h_pose = 0, h_info = 0, h_outl = 0, h_slot_in = 0;
         float Tcw_in[12];
         const so_map* map = nullptr;  // the table the pose kernel reads its points from
@@ -217,6 +220,10 @@ struct so_matcher {
         bool holds_map = false;       // pose_again: held shared until the wait (a stage holds it through its search)
     } chain;
     so::PoseOptArgs chain_pose;  // the last stage's PoseOptimization launch (pose_again: another start pose, same edges)
+    // ---- member of a so_track_group: the launches of its tracking stages are RECORDED (while group_recording, i.e. inside
+    //      so_track_stage_*_submit) and go out with the other members' as three launches (so_track_group_launch)
+    so_track_group* group = nullptr;
+    bool group_recording = false;
     std::vector<int> cell_count;
 
     // ---- so_matcher_batch_begin / _end: independent calls staged side by side, launched together ----
@@ -3234,6 +3241,46 @@ void set_bits_from_excluded(const so_matcher* m, const uint8_t* excluded_by_idx,
 int finish_topk_track(so_matcher* m, int nq, int K);
 
 // launch half: everything up to and including the kernel launch; finish_topk_track waits and maps the results
+}  // namespace
+
+// Tracking stages of SEVERAL agents as one chain of launches (include/swarmorb.h: so_track_group_*).  Each member's
+// so_track_stage_*_submit stages its inputs as always and records what it would launch; so_track_group_launch copies the
+// recorded argument rows into HBM and launches search / resolve / PoseOptimization ONCE each with the agent as a grid
+// dimension.  Members share one stream (handles created on one thread without private streams).
+struct so_track_group {
+    int device = 0;
+    struct Rec {
+        so_matcher* m = nullptr;
+        bool search = false, resolve = false, pose = false;
+        int mode = 0, range = 0;
+        so::TrackGroupJob job;
+        so::TrackResolveArgs res;
+        so::PoseOptArgs pose_args;
+    };
+    std::vector<Rec> recs;
+    int n_recs = 0;              // rows recorded since the last launch (recs keeps its capacity)
+    PinBuf h_tab[2];
+    DevBuf d_tab[2];
+    int flip = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr, pe0 = nullptr, pe1 = nullptr;
+    bool timed_search = false, timed_pose = false;
+    int launches = 0;
+};
+
+namespace {
+
+so_track_group::Rec& group_rec(so_matcher* m) {
+    so_track_group* g = m->group;
+    for (int i = 0; i < g->n_recs; i++)
+        if (g->recs[(size_t)i].m == m) return g->recs[(size_t)i];
+    if ((int)g->recs.size() <= g->n_recs) g->recs.emplace_back();
+    so_track_group::Rec& r = g->recs[(size_t)g->n_recs++];
+    r.m = m;
+    r.search = r.resolve = r.pose = false;
+    r.mode = r.range = 0;
+    return r;
+}
+
 int launch_topk_track_async(so_matcher* m, TrackQuerySrc& T, int mode, int nq, int K, const TrackGates& G) {
     int rc;
     const bool bits = m->n_cand <= kTrackMaxCandBits && nq <= kTrackMaxQueryBits;
@@ -3254,6 +3301,7 @@ int launch_topk_track_async(so_matcher* m, TrackQuerySrc& T, int mode, int nq, i
     T.slot_base = G.slot_base;
     T.keys_soa = 1;
     T.use_bits = bits ? 1 : 0;
+    if (!bits && m->group_recording) return SO_RETRY_ON_HOST;  // (gates too large for the argument block: the plain calls run it)
     if (bits) {
         set_bits_from_excluded(m, G.excluded, nullptr, T);
         memset(T.skip_bits, 0, sizeof(uint32_t) * (size_t)((nq + 31) / 32));
@@ -3290,11 +3338,23 @@ int launch_topk_track_async(so_matcher* m, TrackQuerySrc& T, int mode, int nq, i
         T.slot = G.slots ? reinterpret_cast<const int32_t*>(d + off_slot) : nullptr;
         T.skip = G.skip ? d + off_skip : nullptr;
     }
-    if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
-    launch_topk_track(frame_dev(m), T, mode, 0, nq, K, m->keys_dev_override ? m->keys_dev_override : (uint32_t*)m->h_out.dev,
-                      (int32_t*)((uint8_t*)m->h_out.dev + keys_bytes), s);
-    if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
-    SO_HIP(hipGetLastError());
+    if (m->group_recording) {  // a member of a so_track_group inside a stage submit: the search goes out with the group's
+        so_track_group::Rec& r = group_rec(m);
+        r.job.F = frame_dev(m);
+        r.job.T = T;
+        r.job.keys = m->keys_dev_override ? m->keys_dev_override : (uint32_t*)m->h_out.dev;
+        r.job.count = (int32_t*)((uint8_t*)m->h_out.dev + keys_bytes);
+        r.job.nq = nq;
+        r.job.K = K;
+        r.search = true;
+        r.mode = mode;
+    } else {
+        if (m->profile) SO_HIP(hipEventRecord(m->e0, s));
+        launch_topk_track(frame_dev(m), T, mode, 0, nq, K, m->keys_dev_override ? m->keys_dev_override : (uint32_t*)m->h_out.dev,
+                          (int32_t*)((uint8_t*)m->h_out.dev + keys_bytes), s);
+        if (m->profile) SO_HIP(hipEventRecord(m->e1, s));
+        SO_HIP(hipGetLastError());
+    }
     const auto t1 = std::chrono::steady_clock::now();
     m->stat[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
     m->stat[2] += 1.0;
@@ -3729,7 +3789,13 @@ int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe
     R.e_kp_host = (int32_t*)(hd + O.h_ekp);
     R.head = (int32_t*)(d + O.d_head);
     R.head_host = (int32_t*)(hd + O.h_head);
-    so::launch_track_resolve(R, s);
+    if (m->group_recording) {
+        so_track_group::Rec& r = group_rec(m);
+        r.res = R;
+        r.resolve = true;
+    } else {
+        so::launch_track_resolve(R, s);
+    }
     so::PoseOptArgs& A = m->chain_pose;
     A = so::PoseOptArgs{};
     A.Xw = nullptr; A.obs = nullptr; A.inv_sigma2 = nullptr;
@@ -3769,7 +3835,15 @@ int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe
     reinterpret_cast<volatile int*>((uint8_t*)m->h_chain.p + O.h_info)[3] = 0;
     memset((uint8_t*)m->h_chain.p + O.h_head, 0, 64);
     std::atomic_thread_fence(std::memory_order_release);
-    C.events = m->profile;
+    C.grouped = m->group_recording;
+    C.events = m->profile && !C.grouped;
+    if (C.grouped) {
+        so_track_group::Rec& r = group_rec(m);
+        r.pose_args = A;
+        r.pose = true;
+        r.range = m->chain_range[kind];
+        return SO_OK;
+    }
     if (C.events) {
         if (!m->pe0) SO_HIP(hipEventCreate(&m->pe0));
         if (!m->pe1) SO_HIP(hipEventCreate(&m->pe1));
@@ -3795,6 +3869,27 @@ int chain_prepare(so_matcher* m, int nq, int nk, ChainOffsets* O) {
     return SO_OK;
 }
 
+// Scope of a stage submit by a member of a so_track_group: launches are recorded while it lives; drop() takes the member's
+// row out again when the stage is handed back (the caller then runs the plain calls, which launch at once).
+struct GroupRecording {
+    so_matcher* m;
+    explicit GroupRecording(so_matcher* m_) : m(m_) { m->group_recording = m->group != nullptr; }
+    ~GroupRecording() { m->group_recording = false; }
+    int drop(int rc) {
+        if (m->group) {
+            so_track_group* g = m->group;
+            for (int i = 0; i < g->n_recs; i++)
+                if (g->recs[(size_t)i].m == m) {
+                    for (int j = i; j + 1 < g->n_recs; j++) std::swap(g->recs[(size_t)j], g->recs[(size_t)j + 1]);
+                    g->n_recs--;
+                    break;
+                }
+        }
+        m->group_recording = false;
+        return rc;
+    }
+};
+
 void chain_drop_search(so_matcher* m) {  // a submitted search that will not be waited for by so_track_search_*_wait
     if (m->pend.held_map) const_cast<so_map*>(m->pend.held_map)->grow_mu.unlock_shared();
     m->pend.held_map = nullptr;
@@ -3814,16 +3909,18 @@ int so_track_stage_last_frame_submit(so_matcher* m, const so_dframe* cur, const 
     SO_HIP(hipSetDevice(m->device));
     ChainOffsets O;
     int rc = chain_prepare(m, last->n, cur->n, &O);
+    GroupRecording recording(m);  // (a member of a so_track_group: what follows records its launches instead of issuing them)
     if (rc == SO_OK) rc = so_track_search_last_frame_submit(m, cur, nullptr, last, map, Tcw12, last_slot, th);
     m->keys_dev_override = nullptr;
     m->cnt8_dev_override = nullptr;  m->slot_out_override = nullptr;
-    if (rc != SO_OK) return rc;
+    if (rc != SO_OK) return recording.drop(rc);
     if (m->pend.empty) {  // nothing was launched
         chain_drop_search(m);
-        return SO_RETRY_ON_HOST;
+        return recording.drop(SO_RETRY_ON_HOST);
     }
     rc = chain_launch(m, 0, O, cur, last, map, Tcw12, check_orientation, nullptr, intr4, level_inv_sigma2);
     if (rc != SO_OK) {
+        recording.drop(rc);
         (void)hipStreamSynchronize(m->stream);
         chain_drop_search(m);
         m->chain.active = false;
@@ -3856,19 +3953,21 @@ int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const i
     static thread_local std::vector<uint8_t> excluded;
     excluded.resize((size_t)cur->n);
     for (int k = 0; k < cur->n; k++) excluded[(size_t)k] = kp_slot[k] >= 0 ? 1 : 0;
+    GroupRecording recording(m);
     rc = so_track_search_local_map_submit(m, cur, excluded.data(), map, Tcw12, n_local, local_slot, first_slot, skip, th, nn_ratio,
                                           viewing_cos_limit, log_scale_factor);
     m->keys_dev_override = nullptr;
     m->cnt8_dev_override = nullptr;  m->slot_out_override = nullptr;
-    if (rc != SO_OK) return rc;
+    if (rc != SO_OK) return recording.drop(rc);
     if (m->pend.empty) {
         chain_drop_search(m);
-        return SO_RETRY_ON_HOST;
+        return recording.drop(SO_RETRY_ON_HOST);
     }
     rc = chain_launch(m, 1, O, cur, nullptr, map, Tcw12, 0,
                       on_device ? (const int32_t*)m->d_kpslot.p : (const int32_t*)((uint8_t*)m->h_chain.dev + O.h_slot_in), intr4,
                       level_inv_sigma2);
     if (rc != SO_OK) {
+        recording.drop(rc);
         (void)hipStreamSynchronize(m->stream);
         chain_drop_search(m);
         m->chain.active = false;
@@ -3896,8 +3995,18 @@ int so_track_stage_pose_again_submit(so_matcher* m, const float* Tcw12) {
     const_cast<so_map*>(C.map)->grow_mu.lock_shared();
     C.holds_map = true;
     A.map_Xw = C.map->d_Xw;
-    C.events = m->profile;
+    C.grouped = m->group != nullptr;
+    C.events = m->profile && !C.grouped;
     hipStream_t s = m->stream;
+    if (C.grouped) {
+        m->group_recording = true;
+        so_track_group::Rec& r = group_rec(m);
+        m->group_recording = false;
+        r.pose_args = A;
+        r.pose = true;
+        r.range = m->chain_range[range_kind];
+        return SO_OK;
+    }
     if (C.events) {
         if (!m->pe0) SO_HIP(hipEventCreate(&m->pe0));
         if (!m->pe1) SO_HIP(hipEventCreate(&m->pe1));
@@ -3944,7 +4053,7 @@ int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint
         C.valid_edges = false;
         return rc;
     }
-    if (!again && m->profile) {
+    if (!again && m->profile && !C.grouped) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, m->e0, m->e1) == hipSuccess) m->last_ms += ms;
     }
@@ -4013,6 +4122,140 @@ int so_track_stage_last_rounds(so_matcher* m, int32_t* rounds, int32_t* active_q
     if (getenv("SWARMORB_STAGE_DEBUG"))
         fprintf(stderr, "[stage] edges %d matches %d fallback %d rounds %d active %d | ticks (10 ns): loads %d rounds %d rotation %d by-keypoint %d out %d\n",
                 head[0], head[1], head[2], head[3], head[4], head[8], head[9], head[10], head[11], head[12]);
+    return SO_OK;
+}
+
+int so_track_group_create(int device, so_track_group** out) {
+    if (!out) return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        last_error_ref() = "no usable HIP device";
+        return SO_ERR_NO_DEVICE;
+    }
+    so_track_group* g = new so_track_group();
+    g->device = device;
+    *out = g;
+    return SO_OK;
+}
+
+void so_track_group_destroy(so_track_group* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    for (int i = 0; i < 2; i++) {
+        g->h_tab[i].release();
+        g->d_tab[i].release();
+    }
+    for (hipEvent_t e : {g->e0, g->e1, g->pe0, g->pe1})
+        if (e) (void)hipEventDestroy(e);
+    delete g;
+}
+
+int so_matcher_set_track_group(so_matcher* m, so_track_group* g) {
+    if (!m || m->chain.active || m->pend.mode != 0) return SO_ERR_INVALID_ARG;
+    if (g && g->device != m->device) return SO_ERR_INVALID_ARG;
+    if (m->group && m->group != g) {  // leaving a group: a row recorded and never launched goes with it
+        so_track_group* old = m->group;
+        for (int i = 0; i < old->n_recs; i++)
+            if (old->recs[(size_t)i].m == m) {
+                for (int j = i; j + 1 < old->n_recs; j++) std::swap(old->recs[(size_t)j], old->recs[(size_t)j + 1]);
+                old->n_recs--;
+                break;
+            }
+    }
+    m->group = g;
+    return SO_OK;
+}
+
+int so_track_group_pending(so_track_group* g) { return g ? g->n_recs : 0; }
+
+int so_track_group_launch(so_track_group* g) {
+    if (!g) return SO_ERR_INVALID_ARG;
+    const int n = g->n_recs;
+    if (n == 0) return SO_OK;
+    g->n_recs = 0;
+    const so_track_group::Rec& r0 = g->recs[0];
+    hipStream_t s = r0.m->stream;
+    bool want_events = false;
+    int max_nq = 0, range_mask = 0;
+    for (int i = 0; i < n; i++) {
+        const so_track_group::Rec& r = g->recs[(size_t)i];
+        // one stream (the members' handles come from one thread), one kind of stage per launch
+        if (r.m->stream != s || r.search != r0.search || r.resolve != r0.resolve || r.pose != r0.pose || (r.search && r.mode != r0.mode)) {
+            last_error_ref() = "so_track_group_launch: the members' recorded stages differ in kind, or their matchers do not share a stream "
+                               "(create the handles on one thread, without so_runtime_private_streams)";
+            // the members' waits must not spin for a launch that never comes
+            (void)hipStreamSynchronize(s);
+            for (int j = 0; j < n; j++) {
+                so_matcher* m = g->recs[(size_t)j].m;
+                if (!g->recs[(size_t)j].search) continue;
+                chain_drop_search(m);
+            }
+            for (int j = 0; j < n; j++) {
+                so_matcher* m = g->recs[(size_t)j].m;
+                if (m->chain.holds_map) {
+                    const_cast<so_map*>(m->chain.map)->grow_mu.unlock_shared();
+                    m->chain.holds_map = false;
+                }
+                m->chain.active = false;
+                m->chain.valid_edges = false;
+            }
+            return SO_ERR_INVALID_ARG;
+        }
+        want_events = want_events || r.m->profile;
+        if (r.search) max_nq = std::max(max_nq, r.job.nq);
+        range_mask |= 1 << (r.range ? 1 : 0);
+    }
+    SO_HIP(hipSetDevice(g->device));
+    // rows -> one pinned block -> HBM (one copy launch): [pose rows | resolve rows | search rows]
+    const size_t off_pose = 0;
+    const size_t off_res = align256(off_pose + sizeof(so::PoseOptArgs) * (size_t)n);
+    const size_t off_job = align256(off_res + (r0.resolve ? sizeof(so::TrackResolveArgs) * (size_t)n : 0));
+    const size_t total = align256(off_job + (r0.search ? sizeof(so::TrackGroupJob) * (size_t)n : 0));
+    g->flip ^= 1;
+    PinBuf& H = g->h_tab[g->flip];
+    DevBuf& D = g->d_tab[g->flip];
+    int rc;
+    if ((rc = H.ensure(total)) || (rc = D.ensure(total))) return rc;
+    uint8_t* h = (uint8_t*)H.p;
+    for (int i = 0; i < n; i++) {
+        const so_track_group::Rec& r = g->recs[(size_t)i];
+        if (r.pose) memcpy(h + off_pose + sizeof(so::PoseOptArgs) * (size_t)i, &r.pose_args, sizeof(so::PoseOptArgs));
+        if (r.resolve) memcpy(h + off_res + sizeof(so::TrackResolveArgs) * (size_t)i, &r.res, sizeof(so::TrackResolveArgs));
+        if (r.search) memcpy(h + off_job + sizeof(so::TrackGroupJob) * (size_t)i, &r.job, sizeof(so::TrackGroupJob));
+    }
+    std::atomic_thread_fence(std::memory_order_release);
+    launch_stage_in(D.p, h, total, s);
+    const uint8_t* d = (const uint8_t*)D.p;
+    g->timed_search = g->timed_pose = false;
+    if (want_events) {
+        for (hipEvent_t* e : {&g->e0, &g->e1, &g->pe0, &g->pe1})
+            if (!*e) SO_HIP(hipEventCreate(e));
+    }
+    if (r0.search) {
+        if (want_events) SO_HIP(hipEventRecord(g->e0, s));
+        so::launch_topk_track_group((const so::TrackGroupJob*)(d + off_job), n, r0.mode, max_nq, s);
+        if (want_events) SO_HIP(hipEventRecord(g->e1, s));
+        g->timed_search = want_events;
+    }
+    if (r0.resolve) so::launch_track_resolve_group((const so::TrackResolveArgs*)(d + off_res), n, max_nq, s);
+    if (r0.pose) {
+        if (want_events) SO_HIP(hipEventRecord(g->pe0, s));
+        so::launch_pose_opt_chain_group((const so::PoseOptArgs*)(d + off_pose), n, range_mask, s);
+        if (want_events) SO_HIP(hipEventRecord(g->pe1, s));
+        g->timed_pose = want_events;
+    }
+    SO_HIP(hipGetLastError());
+    g->launches++;
+    return SO_OK;
+}
+
+int so_track_group_last_kernel_ms(so_track_group* g, float* search_ms, float* pose_ms) {
+    if (!g) return SO_ERR_INVALID_ARG;
+    if (search_ms) *search_ms = 0.f;
+    if (pose_ms) *pose_ms = 0.f;
+    if (search_ms && g->timed_search && hipEventSynchronize(g->e1) == hipSuccess) (void)hipEventElapsedTime(search_ms, g->e0, g->e1);
+    if (pose_ms && g->timed_pose && hipEventSynchronize(g->pe1) == hipSuccess) (void)hipEventElapsedTime(pose_ms, g->pe0, g->pe1);
     return SO_OK;
 }
 

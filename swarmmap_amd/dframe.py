@@ -206,9 +206,48 @@ def _stage_wait(matcher, n_kp, n_local=0, again=False):
                 trials=int(info2[1]))
 
 
-def track_stage_last_frame(matcher, cur, last, dmap, Tcw, last_slot, th, K4, level_inv_sigma2):
+class TrackGroup:
+    """so_track_group: the tracking stages of several agents' matchers as one chain of launches.  Members record their
+    stages (track_stage_*(..., wait=False) returns the wait as a callable), launch() issues them."""
+
+    def __init__(self, matchers, device=0):
+        self._lib = _lib.load_library()
+        self._h = C.c_void_p()
+        self._lib.so_track_group_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        self._lib.so_matcher_set_track_group.argtypes = [C.c_void_p, C.c_void_p]
+        self._lib.so_track_group_launch.argtypes = [C.c_void_p]
+        self._lib.so_track_group_pending.argtypes = [C.c_void_p]
+        self._lib.so_track_group_destroy.argtypes = [C.c_void_p]
+        self._lib.so_track_group_destroy.restype = None
+        self._lib.so_track_group_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _lib.check(self._lib.so_track_group_create(device, C.byref(self._h)))
+        self.members = list(matchers)
+        for m in self.members:
+            _lib.check(self._lib.so_matcher_set_track_group(m._h, self._h))
+
+    def pending(self):
+        return self._lib.so_track_group_pending(self._h)
+
+    def launch(self):
+        _lib.check(self._lib.so_track_group_launch(self._h))
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _lib.check(self._lib.so_track_group_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            for m in self.members:
+                if m._h:
+                    self._lib.so_matcher_set_track_group(m._h, None)
+            self._lib.so_track_group_destroy(self._h)
+            self._h = None
+
+
+def track_stage_last_frame(matcher, cur, last, dmap, Tcw, last_slot, th, K4, level_inv_sigma2, wait=True):
     """so_track_stage_last_frame_submit + so_track_stage_wait: TrackWithMotionModel's search, resolve and PoseOptimization as one
-    chain of launches.  None: the caller takes search_last_frame + PoseOptimization."""
+    chain of launches.  None: the caller takes search_last_frame + PoseOptimization.  wait=False: the wait as a callable."""
     lib = matcher._lib
     _bind(lib)
     T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
@@ -220,11 +259,12 @@ def track_stage_last_frame(matcher, cur, last, dmap, Tcw, last_slot, th, K4, lev
     if rc == SO_RETRY_ON_HOST:
         return None
     _lib.check(rc)
-    return _stage_wait(matcher, cur.n)
+    n = cur.n
+    return _stage_wait(matcher, n) if wait else (lambda: _stage_wait(matcher, n))
 
 
 def track_stage_local_map(matcher, cur, kp_slot, dmap, Tcw, n_local, th, cos_limit, log_scale_factor, K4, level_inv_sigma2,
-                          local_slot=None, skip=None, first_slot=0, kp_slot_is_last_stage=False):
+                          local_slot=None, skip=None, first_slot=0, kp_slot_is_last_stage=False, wait=True):
     """so_track_stage_local_map_submit + so_track_stage_wait (TrackLocalMap: SearchLocalPoints + PoseOptimization)."""
     lib = matcher._lib
     _bind(lib)
@@ -241,15 +281,17 @@ def track_stage_local_map(matcher, cur, kp_slot, dmap, Tcw, n_local, th, cos_lim
     if rc == SO_RETRY_ON_HOST:
         return None
     _lib.check(rc)
-    return _stage_wait(matcher, cur.n, n_local)
+    n = cur.n
+    return _stage_wait(matcher, n, n_local) if wait else (lambda: _stage_wait(matcher, n, n_local))
 
 
-def track_stage_pose_again(matcher, cur, Tcw):
+def track_stage_pose_again(matcher, cur, Tcw, wait=True):
     """so_track_stage_pose_again_submit + wait: PoseOptimization over the last stage's edges from another start pose."""
     lib = matcher._lib
     T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
     _lib.check(lib.so_track_stage_pose_again_submit(matcher._h, _vp(T)))
-    return _stage_wait(matcher, cur.n, again=True)
+    n = cur.n
+    return _stage_wait(matcher, n, again=True) if wait else (lambda: _stage_wait(matcher, n, again=True))
 
 
 def search_mappoints_dframe(matcher, cur, mps, th, excluded=None):
