@@ -217,48 +217,105 @@ def ate_records(log, cl, stream, K, oracle=None):
     return out
 
 
-def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, barrier, agents):
-    """A agents of one GPU in lockstep on this thread (so_fleet_run).  Same return values as run_stream."""
-    from swarmmap_amd.replay import private_streams
+def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, barrier, agents, closed=None, fleet_threads=1):
+    """A agents of one GPU in lockstep: ONE thread drives their tracking frame by frame (so_fleet_run) - the tracking stages of
+    all agents are one chain of launches per stage (so_track_group), their frames one extraction chain (so_extractor_group) -
+    and every agent keeps its own local-mapping thread.  Same return values as run_stream."""
     w, h = size
+    closed = (LOOP == "closed") if closed is None else closed
     warmup = warmup + LM_PREFILL_FRAMES
     n_frames = warmup + steps + 2
-    private_streams(True)
-    fleet, keep = [], []
+    fleet, keep, streams = [], [], []
     for a in range(agents):
         stream = synth.FrameStream(seed=seed + 97 * a, size=size, K=K, dist=dist)
         block, frames = pinned_frames(stream, n_frames)
         keep.append((block, frames))
+        streams.append(stream)
         rp = Replay(dev, w, h, nfeatures, LBA_EVERY, K, dist, plane_z=PLANE_Z, local_keyframes=LOCAL_KEYFRAMES, third_pose=True)
         rp.set_frames([block.data_ptr() + i * w * h for i in range(n_frames)], on_device=False)
-        rp.set_window(lba_window)
-        if LM_MATCHER:
+        if closed:
             rp.set_vocabulary(make_vocabulary(), LM_NEIGHBOURS)
-        rp.preallocate()
+            rp.set_closed_loop(kf_every=LBA_EVERY, delay=LBA_EVERY, n_free=CL_N_FREE, n_fixed=CL_N_FIXED, policy=0)
+        else:
+            rp.set_window(lba_window)
+            if LM_MATCHER:
+                rp.set_vocabulary(make_vocabulary(), LM_NEIGHBOURS)
+            rp.preallocate()
         rp.prime(0)
         fleet.append(rp)
-    private_streams(False)
-    Replay.fleet_run(fleet, 0, warmup, False)
-    for rp in fleet:
-        rp.drain()
-        rp.set_profiling(False)
-    barrier()
-    t0 = time.perf_counter()
-    Replay.fleet_run(fleet, warmup, steps, True)
-    for rp in fleet:
-        rp.drain()  # every queued window is optimised inside the timed region
-    barrier()
-    dt = time.perf_counter() - t0
+    # `fleet_threads` driving threads, each with an equal share of the agents in lockstep (its own so_track_group and stream:
+    # the handles a thread uses were created by it).  One thread: everything above ran on this one.
+    T = max(1, min(fleet_threads, agents))
+    if T == 1:
+        Replay.fleet_run(fleet, 0, warmup, False)
+        for rp in fleet:
+            rp.drain()
+            rp.set_profiling(False)
+        barrier()
+        t0 = time.perf_counter()
+        Replay.fleet_run(fleet, warmup, steps, True)
+        for rp in fleet:
+            rp.drain()  # every queued window is optimised inside the timed region
+        barrier()
+        dt = time.perf_counter() - t0
+    else:
+        raise RuntimeError("internal: fleets of several driving threads are built by run_fleet_threads")
     results = []
     fleet_lm = fleet[0].lm_stats()
+    cl0 = fleet[0].closed_loop_log() if closed else None
     for rp in fleet:
         rp.finish()
         results.append((rp.stats(), rp.candidates_total(), rp.log()))
+    if closed:
+        cl0 = fleet[0].closed_loop_log()
+    for rp in fleet:
         rp.close()
     stats = {k: sum(r[0][k] for r in results) / agents for k in results[0][0] if k not in ("stages", "frame_ms")}
     stats["frame_ms"] = np.concatenate([np.asarray(r[0]["frame_ms"])[-steps:] for r in results])
-    stats.update({"n_xchg": 0, "xchg_ms": 0.0, "lm": fleet_lm})
+    stats.update({"n_xchg": 0, "xchg_ms": 0.0, "lm": fleet_lm, "closed": closed})
+    if closed:
+        stats.update({"cl": cl0, "stream": streams[0], "timed_from": warmup})
     return dt, stats, results[0][1], keep[0][1], results[0][2]
+
+
+def run_fleet_threads(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, barrier, agents, fleet_threads, closed=None):
+    """`fleet_threads` lockstep fleets side by side (agents split evenly), one driving thread each; the clock runs from the
+    moment all fleets are warm until the last one has drained.  Returns what run_fleet returns (statistics averaged over fleets)."""
+    T = max(1, min(fleet_threads, agents))
+    share = [agents // T + (1 if i < agents % T else 0) for i in range(T)]
+    first = [sum(share[:i]) for i in range(T)]
+    gate = threading.Barrier(T + 1)
+    out, errors = [None] * T, []
+
+    def fleet_barrier():
+        gate.wait()   # all fleets warm / all drained
+        gate.wait()   # the main thread has read the clock
+
+    def run(i):
+        try:
+            out[i] = run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed + 97 * first[i], lba_window, fleet_barrier, share[i], closed)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            gate.abort()
+
+    ths = [threading.Thread(target=run, args=(i,), daemon=True) for i in range(T)]
+    for th in ths:
+        th.start()
+    try:
+        gate.wait(); barrier(); t0 = time.perf_counter(); gate.wait()
+        gate.wait(); barrier(); dt = time.perf_counter() - t0; gate.wait()
+    except threading.BrokenBarrierError:
+        raise errors[0] if errors else RuntimeError("a fleet thread failed")
+    for th in ths:
+        th.join()
+    if errors:
+        raise errors[0]
+    st = dict(out[0][1])
+    for k, v in st.items():
+        if isinstance(v, float):
+            st[k] = sum(o[1][k] * share[i] for i, o in enumerate(out)) / agents
+    st["frame_ms"] = np.concatenate([o[1]["frame_ms"] for o in out])
+    return dt, st, out[0][2], out[0][3], out[0][4]
 
 
 def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, barrier, agents=1, xchg=None,
@@ -472,11 +529,14 @@ def stream_record(size, nfeatures, steps, dt, st, n_cand, stage, inv_scale, pmc,
     calls = max(st["pose_timed_calls"], 1)
     n_pose = st["pose_points"] / calls
     pose_flop = 250.0 * n_pose * (st["pose_trials"] / calls + 4)  # +4: one pass per round
+    # (lockstep with grouped stages: one launch optimises the poses of all agents - every agent is dealt 1/A of the launch's
+    #  time per call, so flop / ms below is the launch's flop over all its workgroups divided by the launch's duration)
     pose_ms = st["pose_kernel_ms"] / calls
     pose_total_ms = pose_ms * st["pose_calls"]
     pose_tf = pose_flop / (pose_ms * 1e-3) / 1e12 if pose_ms > 0 else 0.0
-    chain = os.environ.get("SWARMORB_TRACK_CHAIN", "1") != "0" and not (agents > 1 and "--lockstep" in sys.argv)
-    pose_kernel = "pose_opt_chain_kernel" if chain else "pose_opt_reg_kernel"
+    chain = os.environ.get("SWARMORB_TRACK_CHAIN", "1") != "0"
+    grouped = chain and agents > 1 and "--lockstep" in sys.argv and not os.environ.get("SWARMORB_FLEET_NO_TRACK_GROUP")
+    pose_kernel = "pose_opt_chain_group_kernel" if grouped else ("pose_opt_chain_kernel" if chain else "pose_opt_reg_kernel")
     roof_pose = {"bound": "fp64-valu (latency: one workgroup, no MFMA)", "kernel": pose_kernel, "achieved": pose_tf,
                  "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": pose_tf / FP64_PEAK_TF,
                  "traffic": pmc.get(pose_kernel, pmc.get("pose_opt_reg_kernel", pmc.get("pose_opt_lds_kernel", {}))).get("hbm_bytes_per_launch"),
@@ -923,6 +983,8 @@ def main():
                     help="with --agents-per-gpu A > 1: ONE thread drives the A agents frame by frame (so_fleet_run: searches "
                          "of all agents in flight together, PoseOptimization of all agents in one launch) instead of A "
                          "independent tracking threads")
+    ap.add_argument("--fleet-threads", type=int, default=1,
+                    help="with --lockstep: split the agents of a GPU over this many driving threads (a lockstep fleet each)")
     ap.add_argument("--agents-per-gpu", type=int, default=1,
                     help="run this many independent agents (tracking + local-mapping thread pairs, own contexts and "
                          "streams) on each GPU; value stays the aggregate frames/s over all agents")
@@ -988,7 +1050,10 @@ def main():
             prefill_store(xchg.store, 7, int(os.environ.get("SWARMORB_BENCH_PREFILL", "64")), nfeatures)
 
     try:
-        if args.lockstep and A > 1:
+        if args.lockstep and A > 1 and args.fleet_threads > 1:
+            dt, st, n_cand, frames, log0 = run_fleet_threads(dev, size, K, dist, nfeatures, args.steps, args.warmup, SEED_BASE + rank,
+                                                             lba_window, barrier, A, args.fleet_threads)
+        elif args.lockstep and A > 1:
             dt, st, n_cand, frames, log0 = run_fleet(dev, size, K, dist, nfeatures, args.steps, args.warmup, SEED_BASE + rank,
                                                      lba_window, barrier, A)
         else:

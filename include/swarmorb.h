@@ -743,6 +743,9 @@ int so_track_group_create(int device, so_track_group** out);
 void so_track_group_destroy(so_track_group* g);
 int so_matcher_set_track_group(so_matcher* m, so_track_group* g_or_null);
 int so_track_group_pending(so_track_group* g);
+/* An opaque number that is equal for two matchers exactly when they issue their work on the same HIP stream (the rule for
+ * members of one group); 0 for a null handle. */
+uint64_t so_matcher_stream_id(const so_matcher* m);
 int so_track_group_launch(so_track_group* g);
 int so_track_group_last_kernel_ms(so_track_group* g, float* search_ms, float* pose_ms);
 /* rounds the last stage's device resolve took, and how many of its queries had candidates (diagnostics) */

@@ -4169,6 +4169,8 @@ int so_matcher_set_track_group(so_matcher* m, so_track_group* g) {
 
 int so_track_group_pending(so_track_group* g) { return g ? g->n_recs : 0; }
 
+uint64_t so_matcher_stream_id(const so_matcher* m) { return m ? (uint64_t)(uintptr_t)m->stream : 0; }
+
 int so_track_group_launch(so_track_group* g) {
     if (!g) return SO_ERR_INVALID_ARG;
     const int n = g->n_recs;

@@ -715,6 +715,7 @@ void so_replay_destroy(so_replay* r) {
         (void)so_dframe_collect(r->fr[r->submitted], f.kps.data(), nullptr, f.desc.data(), r->cap, &n, nullptr);
     }
     so_extractor_group_destroy(r->fleet_group);
+    so_track_group_destroy(r->fleet_track_group);
     for (so_dframe* f : r->fr) so_dframe_destroy(f);
     so_extractor_destroy(r->ex);
     so_matcher_destroy(r->matcher);
@@ -1008,7 +1009,7 @@ int step_m2_submit(so_replay* r) {
     r->last_slot.resize((size_t)L.n);
     for (int i = 0; i < L.n; i++)
         r->last_slot[(size_t)i] = (L.kp_mp[(size_t)i] >= 0 && !L.outlier[(size_t)i]) ? L.kp_mp[(size_t)i] : -1;
-    if (track_chain_on(r) && !r->lockstep) {
+    if (track_chain_on(r) && (!r->lockstep || r->fleet_chain)) {
         // the whole stage as one chain of launches: search -> resolve on the device -> PoseOptimization; one wait (step_stage1_wait)
         r->K4[0] = r->cam.fx; r->K4[1] = r->cam.fy; r->K4[2] = r->cam.cx; r->K4[3] = r->cam.cy;
         const int rc = so_track_stage_last_frame_submit(r->matcher, r->fr[S.hcur], r->fr[(S.hcur + 2) % 3], r->map, S.Tp,
@@ -1224,7 +1225,7 @@ int step_m1_submit(so_replay* r) {
         }
         for (int i = 0; i < nl; i++)
             if (M.tv_seen[(size_t)M.tv_local[(size_t)i]] == S.t) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:966-978)
-        if (track_chain_on(r) && !r->lockstep) {
+        if (track_chain_on(r) && (!r->lockstep || r->fleet_chain)) {
             const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, nl, M.tv_local.data(), 0,
                                                            r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
             if (rc == SO_OK) {
@@ -1251,7 +1252,7 @@ int step_m1_submit(so_replay* r) {
         r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
         if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:966-978)
     }
-    if (track_chain_on(r) && !r->lockstep) {
+    if (track_chain_on(r) && (!r->lockstep || r->fleet_chain)) {
         const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, S.n_local, nullptr, first,
                                                        r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
         if (rc == SO_OK) {
@@ -1683,10 +1684,155 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
     }
     std::vector<so_dframe*> gframes(A);
     std::vector<const uint8_t*> gimages(A);
+    // The tracking stages of all agents as ONE chain of launches per stage (so_track_group: search with the agent as
+    // blockIdx.y, one resolve and one PoseOptimization workgroup per agent) when the stages are chained on the device and the
+    // agents' matchers share a stream (handles created on one thread without so_runtime_private_streams); otherwise the
+    // separate calls with the PoseOptimization calls batched (round 3's lockstep).
+    static const bool no_track_group = getenv("SWARMORB_FLEET_NO_TRACK_GROUP") != nullptr;
+    bool chained = !no_track_group && track_chain_on(lead);
+    for (int a = 0; a < n_agents && chained; a++)
+        chained = track_chain_on(agents[a]) && so_matcher_stream_id(agents[a]->matcher) == so_matcher_stream_id(lead->matcher);
+    if (chained && !lead->fleet_track_group && so_track_group_create(lead->device, &lead->fleet_track_group) != SO_OK) chained = false;
+    struct LeaveGroup {  // the agents are solo again when the call returns (whatever way)
+        so_replay** ag; int n; bool on;
+        ~LeaveGroup() {
+            for (int a = 0; a < n; a++) {
+                ag[a]->fleet_chain = false;
+                if (on) so_matcher_set_track_group(ag[a]->matcher, nullptr);
+            }
+        }
+    } leave{agents, n_agents, chained};
+    for (int a = 0; a < n_agents && chained; a++) {
+        if (so_matcher_set_track_group(agents[a]->matcher, lead->fleet_track_group) != SO_OK) return fail(agents[a], "so_matcher_set_track_group");
+        agents[a]->fleet_chain = true;
+    }
+    so_track_group* tg = chained ? lead->fleet_track_group : nullptr;
+    auto group_launch = [&]() -> int {
+        if (so_track_group_pending(tg) > 0 && so_track_group_launch(tg) != SO_OK) return fail(lead, "so_track_group_launch");
+        return SO_OK;
+    };
+    auto group_pose_ms = [&](int n_members) -> float {  // the group's PoseOptimization kernel, dealt to its members
+        float sm = 0.f, pm = 0.f;
+        if (n_members > 0 && lead->step.timed_kernels) so_track_group_last_kernel_ms(tg, &sm, &pm);
+        return n_members > 0 ? pm / (float)n_members : 0.f;
+    };
+    for (int t = first_t; t < first_t + n_steps && chained; t++) {
+        int rc;
+        for (int a = 0; a < n_agents; a++) {
+            agents[a]->lockstep = true;
+            agents[a]->step_timed = timed ? 1 : 0;
+            if ((rc = step_begin(agents[a], t, !grouped))) return rc;  // (records the agent's last-frame stage)
+        }
+        if ((rc = group_launch())) return rc;
+        if (grouped) {  // the next frames of all agents as one extraction chain, under the stage that was just launched
+            bool all = true;
+            for (int a = 0; a < n_agents; a++) all = all && !agents[a]->step.next_submitted;
+            if (all) {
+                for (size_t a = 0; a < A; a++) {
+                    so_replay* r = agents[a];
+                    gframes[a] = r->fr[(r->submitted + 1) % 3];
+                    gimages[a] = r->frames[(size_t)(t + 1) % r->frames.size()];
+                }
+                if (so_dframe_group_submit(lead->fleet_group, gframes.data(), gimages.data(), lead->width, lead->height, lead->width) == SO_OK) {
+                    for (size_t a = 0; a < A; a++) {
+                        agents[a]->submitted = (agents[a]->submitted + 1) % 3;
+                        agents[a]->in_flight = true;
+                        agents[a]->step.next_submitted = true;
+                    }
+                } else {
+                    grouped = false;
+                }
+            }
+        }
+        for (int a = 0; a < n_agents; a++)
+            if (!agents[a]->step.next_submitted) {
+                if ((rc = submit_frame(agents[a], t + 1))) return rc;
+                agents[a]->step.next_submitted = true;
+            }
+        // stage 1 back, stage 2 recorded - agent by agent: the host part of one agent runs under the kernels of the others
+        int n_dev = 0;
+        for (int a = 0; a < n_agents; a++) n_dev += (!agents[a]->step.first && agents[a]->step.stage1_dev) ? 1 : 0;
+        for (int a = 0; a < n_agents; a++) {
+            so_replay* r = agents[a];
+            so_replay::Step& S = r->step;
+            if (S.first) continue;
+            int32_t inl1 = 0;
+            const bool dev = S.stage1_dev;
+            if (dev) {
+                if ((rc = step_stage1_wait(r, &inl1))) return rc;  // (falls back onto the separate calls by itself)
+                if (S.timed_kernels && S.stage1_dev) S.pose_kernel += group_pose_ms(n_dev);
+            } else {
+                if ((rc = step_m2_wait(r))) return rc;
+                if ((rc = pose_single(r, S.Tp, S.Ta, &inl1))) return rc;
+            }
+            pose1_apply(r);
+            if ((rc = step_m1_submit(r))) return rc;
+        }
+        if ((rc = group_launch())) return rc;
+        n_dev = 0;
+        for (int a = 0; a < n_agents; a++) n_dev += (!agents[a]->step.first && agents[a]->step.stage2_dev) ? 1 : 0;
+        int n_again = 0;
+        for (int a = 0; a < n_agents; a++) {
+            so_replay* r = agents[a];
+            so_replay::Step& S = r->step;
+            if (S.first) continue;
+            const bool dev = S.stage2_dev;
+            if ((rc = step_m1_wait(r))) return rc;
+            if (dev && S.stage2_dev && S.timed_kernels) S.pose_kernel += group_pose_ms(n_dev);
+            if (!S.stage2_dev && (rc = pose_single(r, S.Ta, S.Tb, &S.n_in))) return rc;
+            pose2_apply(r);
+            S.third_dev = false;
+            if (r->third_pose) {
+                to_f12(r->T_last, S.Tl);
+                if (S.stage2_dev && so_track_stage_pose_again_submit(r->matcher, S.Tl) == SO_OK) {
+                    S.third_dev = true;
+                    n_again++;
+                }
+            }
+        }
+        if ((rc = group_launch())) return rc;
+        for (int a = 0; a < n_agents; a++) {
+            so_replay* r = agents[a];
+            so_replay::Step& S = r->step;
+            if (!S.first) {
+                if (r->third_pose && S.third_dev) {
+                    if ((rc = step_keyframe(r))) return rc;  // (under the third PoseOptimization, whose result nothing uses)
+                    std::vector<int32_t>& ek = r->k2l;
+                    std::vector<uint8_t>& eo = r->excluded;
+                    ek.resize((size_t)r->fh[r->cur].n);
+                    eo.resize((size_t)r->fh[r->cur].n);
+                    int32_t ne = 0, inl3 = 0, info2[2] = {0, 0};
+                    const int rc3 = so_track_stage_wait(r->matcher, nullptr, nullptr, nullptr, &ne, ek.data(), eo.data(), S.Tc, &inl3, info2);
+                    if (rc3 != SO_OK && rc3 != SO_RETRY_ON_HOST) return fail(r, "so_track_stage_wait");
+                    if (rc3 == SO_OK) {
+                        S.pose_calls++;
+                        if (S.timed_kernels) {
+                            S.pose_kernel += group_pose_ms(n_again);
+                            S.pose_trials += info2[1];
+                            S.pose_points += ne;
+                            S.pose_timed_calls++;
+                        }
+                    }
+                    S.tp3 = S.tmap = now_ms();
+                } else if (r->third_pose) {
+                    int32_t inl3 = 0;
+                    if ((rc = pose_single(r, S.Tl, S.Tc, &inl3, [r] { return step_keyframe(r); }, false))) return rc;
+                    S.tp3 = S.tmap = now_ms();
+                } else {
+                    S.tp3 = now_ms();
+                    if ((rc = step_keyframe(r))) return rc;
+                }
+            }
+            step_end(r, t, timed);
+            if (!r->error.empty()) return SO_ERR_HIP;
+        }
+    }
+    if (chained) return SO_OK;
     for (int t = first_t; t < first_t + n_steps; t++) {
         int rc;
         for (int a = 0; a < n_agents; a++) {
             agents[a]->lockstep = true;
+            agents[a]->step_timed = timed ? 1 : 0;
             if ((rc = step_begin(agents[a], t, !grouped))) return rc;
         }
         if (grouped) {  // the agents whose next frame is not out yet (all of them, except on a run's first frame)

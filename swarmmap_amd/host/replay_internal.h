@@ -209,6 +209,8 @@ struct so_replay {
     bool frames_on_device = false;
     // so_fleet_run: the extractors of the fleet this agent leads, as one group (one extraction chain for all agents)
     so_extractor_group* fleet_group = nullptr;
+    so_track_group* fleet_track_group = nullptr;  // (owned by the fleet's first agent) the agents' tracking stages as one chain of launches
+    bool fleet_chain = false;                     // so_fleet_run drives this agent AND its stages go out with the fleet's group
     std::vector<so_extractor*> fleet_members;
     BaWindow window;
     float scale[8] = {0}, inv_sigma2[8] = {0};
@@ -270,6 +272,7 @@ struct so_replay {
         bool stage1_dev = false, stage2_dev = false;  // the stage's search -> resolve -> pose chain is on the device (so_track_stage_*)
         int m2_rc = 0;
         float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
+        bool third_dev = false;  // fleet: the third PoseOptimization went out with the group (so_track_stage_pose_again_submit)
         M4 T = M4::eye();
     } step;
     float K4[4] = {0, 0, 0, 0};

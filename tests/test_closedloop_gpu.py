@@ -201,6 +201,52 @@ def test_three_closed_loop_agents_in_threads_equal_their_solo_runs():
     assert not np.array_equal(solo[0]["poses"], solo[1]["poses"])  # (different streams)
 
 
+def test_closed_loop_agents_in_lockstep_with_grouped_stages_equal_their_solo_runs():
+    """bench.py --agents-per-gpu A --lockstep: ONE thread drives the agents' tracking frame by frame, the tracking stages of all
+    agents go out as one chain of launches per stage (so_track_group: the agent is a grid dimension of the search, the resolve
+    and the PoseOptimization kernel), every agent keeps its own local-mapping thread.  Every agent's poses, counts,
+    local-mapping log and keyframe bindings are those of its solo run, to the bit.  Reference concurrency: one process per agent,
+    code/Examples/Monocular/swarm_map.cc:329-337."""
+    import torch
+    from swarmmap_amd.replay import Replay
+    K, dist, nfeat, n, A = synth.EUROC_K, synth.EUROC_DIST, 1000, 42, 4
+    vocab = make_vocabulary()
+    streams, blocks, ptrs = [], [], []
+    for a in range(A):
+        st = synth.FrameStream(seed=20221001 + 97 * a, size=synth.EUROC, K=K, dist=dist)
+        block = torch.empty((n + 2, st.h, st.w), dtype=torch.uint8).pin_memory()
+        view = block.numpy()
+        for t in range(n + 2):
+            view[t] = st.frame(t)
+        streams.append(st); blocks.append(block)
+        ptrs.append([block.data_ptr() + i * st.w * st.h for i in range(n + 2)])
+    solo = [_cpp_chain(n, ptrs[a], streams[a], K, dist, nfeat, vocab)[0] for a in range(A)]
+    fleet = []
+    for a in range(A):
+        rp = Replay(0, streams[a].w, streams[a].h, nfeat, 5, K, dist, plane_z=PLANE_Z, local_keyframes=12, third_pose=True)
+        rp.set_frames(ptrs[a], on_device=False)
+        rp.set_vocabulary(vocab)
+        rp.set_closed_loop(policy=0)
+        rp.prime(0)
+        fleet.append(rp)
+    Replay.fleet_run(fleet, 0, 17, True)   # (two calls: the agents join and leave the group per call)
+    Replay.fleet_run(fleet, 17, n - 17, True)
+    for a, rp in enumerate(fleet):
+        rp.drain()
+        rp.finish()
+        p = rp.log()
+        p.update(rp.closed_loop_log())
+        st = rp.stats()
+        rp.close()
+        s = solo[a]
+        for k in ("poses", "kf_poses", "Tcr", "lm_log", "matches_last", "matches_map", "inliers", "n_map_points", "point_bad"):
+            assert np.array_equal(s[k], p[k]), (a, k)
+        assert all(np.array_equal(x, y) for x, y in zip(s["kf_bindings"], p["kf_bindings"])), a
+        assert s["inliers"][1:].min() > 300
+        assert st["pose_calls"] == 3 * (n - 1) and st["pose_kernel_ms"] > 0
+    assert not np.array_equal(solo[0]["poses"], solo[1]["poses"])
+
+
 @pytest.mark.parametrize("name,n", [("euroc", 122), ("kitti", 42)])
 def test_stages_chained_on_the_device_equal_the_separate_calls_over_a_whole_run(name, n):
     """so_track_stage_* (search -> resolve on the device -> PoseOptimization, one wait) against so_track_search_* + host resolve
