@@ -1053,6 +1053,25 @@ int so_pose_optimization_last_kernel_ms(so_ba* ba, float* ms);
 int so_bundle_adjust(so_ba* ba, const so_ba_problem* problem, const so_ba_options* options,
                      const volatile uint8_t* stop, float* Tcw_out, float* Xw_out, uint8_t* edge_outlier,
                      double* edge_chi2, so_ba_info* info);
+
+/* Local bundle adjustments of SEVERAL agents as one chain of launches (several agents per GPU; the reference runs one
+ * LocalMapping thread per agent process, code/Examples/Monocular/swarm_map.cc:329-337, code/src/LocalMapping.cc:53-110).  A
+ * window's Levenberg-Marquardt chain is ~65 small dependent launches; eight agents' chains on eight streams are bound by the
+ * rate at which the GPU's command processor dispatches kernels, not by its CUs.  Members of a group (one so_ba per agent, each
+ * called from its own thread as before) stage and upload their windows on their own streams, RECORD the launches of the chain
+ * and hand the list in; the first member of a round waits `window_us` (<= 0: 250) for the others, merges the lists phase by
+ * phase - launches of one kind become ONE launch with the member as blockIdx.y, their argument blocks rows of a table in HBM
+ * - and issues the round on the group's stream.  Every member waits for its own completion word and gets the results of a
+ * solo call bit by bit (same kernel bodies, same grids per member, same summation orders: tests/test_ba_group_gpu.py).
+ * A member that arrives late makes the next round; nobody waits for a member that does not come.  Grouped: local windows
+ * (<= 43 free keyframes, edge-table gather); larger problems, solve timing and SWARMORB_BA_NO_CHAIN run ungrouped.
+ * so_ba_group_stats: rounds, members summed over rounds, grouped launches, ungrouped launches, rows summed over grouped
+ * launches, members registered, window_us, 0. */
+typedef struct so_ba_group so_ba_group;
+int so_ba_group_create(int device, double window_us, so_ba_group** out);
+void so_ba_group_destroy(so_ba_group* g);
+int so_ba_set_group(so_ba* b, so_ba_group* g_or_null);
+int so_ba_group_stats(so_ba_group* g, double* out8);
 /* How the reduced camera system S x = b of every LM trial is solved on LARGE maps (80 free keyframes and more; smaller
  * systems always take the single-workgroup / blocked direct solvers).
  *   SO_BA_SOLVER_DIRECT (default): block-skyline Cholesky on FP64 MFMA tiles - what the reference's LinearSolverEigen /

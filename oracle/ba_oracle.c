@@ -3,6 +3,7 @@
  * TEST INFRASTRUCTURE ONLY; never linked into the product.  All arithmetic in double like g2o.
  */
 #include "ba_oracle.h"
+#include "orb_oracle.h" /* orc_get_convention: tools/convention_sensitivity.py */
 
 #include <float.h>
 #include <math.h>
@@ -23,6 +24,26 @@ static void quat_normalize_rotation(double* q) { /* SE3Quat::normalizeRotation, 
  * (quaternionbase_assign_impl<Other,3,3>), restated; R row-major. */
 static void quat_from_R(const double* R, double* q) {
     double t = R[0] + R[4] + R[8];
+    if (orc_get_convention() & ORC_CONV_QUAT_LARGEST) {
+        /* alternative: Shepperd's method with the largest of (trace, R00, R11, R22) as the pivot */
+        int best = 3;
+        double bv = t;
+        for (int i = 0; i < 3; i++)
+            if (R[i * 3 + i] > bv) { bv = R[i * 3 + i]; best = i; }
+        if (best == 3) {
+            const double w4 = 2.0 * sqrt(t + 1.0);
+            q[3] = 0.25 * w4;
+            q[0] = (R[7] - R[5]) / w4; q[1] = (R[2] - R[6]) / w4; q[2] = (R[3] - R[1]) / w4;
+        } else {
+            const int i = best, j = (i + 1) % 3, k = (j + 1) % 3;
+            const double s4 = 2.0 * sqrt(1.0 + R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k]);
+            q[i] = 0.25 * s4;
+            q[3] = (R[k * 3 + j] - R[j * 3 + k]) / s4;
+            q[j] = (R[j * 3 + i] + R[i * 3 + j]) / s4;
+            q[k] = (R[k * 3 + i] + R[i * 3 + k]) / s4;
+        }
+        return;
+    }
     if (t > 0.0) {
         t = sqrt(t + 1.0);
         q[3] = 0.5 * t;
@@ -277,7 +298,43 @@ static void build_system(ba* s) {
     }
 }
 
+/* alternative (ORC_CONV_LDLT_REVERSED): S = P^T L D L^T P with P the reversal of the unknowns, no square roots - another
+ * elimination order and another factorisation than the Cholesky below, the kind of difference a fill-reducing
+ * SimplicialLDLT has against it */
+static int ldlt_reversed_solve(double* S, double* rhs, int n) {
+    double* A = (double*)malloc(sizeof(double) * (size_t)n * n);
+    double* b = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        b[i] = rhs[n - 1 - i];
+        for (int j = 0; j < n; j++) {  /* the caller fills the lower triangle (row >= col) */
+            const int r = n - 1 - i, c = n - 1 - j;
+            A[i * (size_t)n + j] = r >= c ? S[r * (size_t)n + c] : S[c * (size_t)n + r];
+        }
+    }
+    int ok = 1;
+    for (int j = 0; j < n && ok; j++) {  /* A = L D L^T, L unit lower in the strict lower triangle, D on the diagonal */
+        double d = A[j * (size_t)n + j];
+        for (int k = 0; k < j; k++) d -= A[j * (size_t)n + k] * A[j * (size_t)n + k] * A[k * (size_t)n + k];
+        if (!(d > 0.0)) { ok = 0; break; }
+        A[j * (size_t)n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double v = A[i * (size_t)n + j];
+            for (int k = 0; k < j; k++) v -= A[i * (size_t)n + k] * A[j * (size_t)n + k] * A[k * (size_t)n + k];
+            A[i * (size_t)n + j] = v / d;
+        }
+    }
+    if (ok) {
+        for (int i = 0; i < n; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= A[i * (size_t)n + k] * b[k]; b[i] = v; }
+        for (int i = 0; i < n; i++) b[i] /= A[i * (size_t)n + i];
+        for (int i = n - 1; i >= 0; i--) { double v = b[i]; for (int k = i + 1; k < n; k++) v -= A[k * (size_t)n + i] * b[k]; b[i] = v; }
+        for (int i = 0; i < n; i++) rhs[n - 1 - i] = b[i];
+    }
+    free(A); free(b);
+    return ok;
+}
+
 static int cholesky_solve(double* S, double* rhs, int n) { /* in place; returns 0 on a non-positive pivot */
+    if (orc_get_convention() & ORC_CONV_LDLT_REVERSED) return ldlt_reversed_solve(S, rhs, n);
     /* first[i] = first structurally nonzero column of row i.  Cholesky fill stays inside this row envelope, so every
      * product the loops below skip has an exact zero factor: the result is bit-identical to the full loops (what
      * LinearSolverEigen's SimplicialLDLT does with its elimination tree, linear_solver_eigen.h:147-232), and a merged

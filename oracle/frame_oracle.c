@@ -1,5 +1,6 @@
 /* frame_oracle.c — see frame_oracle.h.  Plain C, scalar, no libm in the arithmetic that must match the GPU. */
 #include "frame_oracle.h"
+#include "orb_oracle.h" /* orc_get_convention: tools/convention_sensitivity.py */
 
 #include <math.h>
 #include <string.h>
@@ -43,7 +44,8 @@ static void undistort_point(const orc_camera* cam, float u, float v, float* uo, 
     const double ifx = 1.0 / fx, ify = 1.0 / fy;
     double x = ((double)u - cx) * ifx, y = ((double)v - cy) * ify;
     const double x0 = x, y0 = y;
-    for (int j = 0; j < 5; j++) {
+    const int iters = (orc_get_convention() & ORC_CONV_UNDISTORT_20) ? 20 : 5;
+    for (int j = 0; j < iters; j++) {
         const double r2 = x * x + y * y;
         const double icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2);
         const double deltaX = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);

@@ -69,6 +69,16 @@ void orc_make_tables(const orc_config* cfg, orc_tables* t) {
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * CONVENTION SWITCH (test infrastructure of test infrastructure): the arithmetic this oracle DEFINES where the reference's
+ * lives in un-vendored OpenCV-CUDA / Eigen / nvcc fast-math (parity unpinned, header of this file) can be swapped, one piece at
+ * a time, for its plausible alternative - tools/convention_sensitivity.py runs the whole closed loop under each swap and
+ * records how far the trajectory moves.  0 = the conventions every test and the product are held to.
+ * ---------------------------------------------------------------------------------------------- */
+static int g_convention = 0;
+void orc_set_convention(int flags) { g_convention = flags; }
+int orc_get_convention(void) { return g_convention; }
+
 void orc_level_size(int w, int h, float inv_scale, int* lw, int* lh) {
     *lw = cv_round_f((float)w * inv_scale); /* :825 */
     *lh = cv_round_f((float)h * inv_scale);
@@ -84,6 +94,33 @@ void orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t*
                        int dstride) {
     const float fx = (float)(1.0 / ((double)dw / (double)sw));
     const float fy = (float)(1.0 / ((double)dh / (double)sh));
+    if (g_convention & ORC_CONV_RESIZE_HALF_PIXEL) {
+        /* alternative: pixel CENTRES map onto each other, src = (dst + 0.5) / f - 0.5, clamped at the border (cv::resize on
+         * the CPU; the CUDA kernel restated below samples at dst / f) */
+        for (int y = 0; y < dh; y++) {
+            float src_y = ((float)y + 0.5f) * fy - 0.5f;
+            if (src_y < 0.f) src_y = 0.f;
+            int y1 = (int)floorf(src_y);
+            if (y1 > sh - 1) y1 = sh - 1;
+            const int y2r = y1 + 1 < sh ? y1 + 1 : sh - 1;
+            const float wy1 = src_y - (float)y1, wy2 = 1.0f - wy1;
+            for (int x = 0; x < dw; x++) {
+                float src_x = ((float)x + 0.5f) * fx - 0.5f;
+                if (src_x < 0.f) src_x = 0.f;
+                int x1 = (int)floorf(src_x);
+                if (x1 > sw - 1) x1 = sw - 1;
+                const int x2r = x1 + 1 < sw ? x1 + 1 : sw - 1;
+                const float wx1 = src_x - (float)x1, wx2 = 1.0f - wx1;
+                float out = (float)src[y1 * sstride + x1] * (wx2 * wy2);
+                out = out + (float)src[y1 * sstride + x2r] * (wx1 * wy2);
+                out = out + (float)src[y2r * sstride + x1] * (wx2 * wy1);
+                out = out + (float)src[y2r * sstride + x2r] * (wx1 * wy1);
+                int v = (int)lrintf(out);
+                dst[y * dstride + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+        }
+        return;
+    }
     for (int y = 0; y < dh; y++) {
         const float src_y = (float)y * fy;
         const int y1 = (int)floorf(src_y);
@@ -139,6 +176,29 @@ static const float k_gauss7[7] = {0x1.1f5f62p-4f, 0x1.0c70fcp-3f, 0x1.869472p-3f
                                   0x1.869472p-3f, 0x1.0c70fcp-3f, 0x1.1f5f62p-4f};
 
 void orc_gaussian7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+    if (g_convention & ORC_CONV_GAUSS_FIXED8) {
+        /* alternative: 8-bit fixed-point weights (sum 256), integer accumulation, one rounding at the end - the form OpenCV's
+         * 8-bit filters take on the CPU */
+        static const int kq[7] = {18, 34, 49, 54, 49, 34, 18};
+        int32_t* ib = (int32_t*)malloc(sizeof(int32_t) * (size_t)w * h);
+        for (int y = 0; y < h; y++) {
+            const uint8_t* row = src + y * sstride;
+            for (int x = 0; x < w; x++) {
+                int32_t sum = 0;
+                for (int k = 0; k < 7; k++) sum += (int32_t)row[reflect101(x + k - 3, w)] * kq[k];
+                ib[y * w + x] = sum;
+            }
+        }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t sum = 0;
+                for (int k = 0; k < 7; k++) sum += ib[reflect101(y + k - 3, h) * w + x] * kq[k];
+                const int v = (sum + 32768) >> 16;
+                dst[y * dstride + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+        free(ib);
+        return;
+    }
     float* buf = (float*)malloc(sizeof(float) * (size_t)w * h);
     for (int y = 0; y < h; y++) {
         const uint8_t* row = src + y * sstride;
@@ -542,6 +602,7 @@ int orc_distribute_octree(const int16_t* xs, const int16_t* ys, const uint8_t* s
  * gfx950 agree bit for bit; |error| < 2e-7 rad (tests/test_oracle_kat.py checks against libm).
  * ---------------------------------------------------------------------------------------------- */
 float orc_atan2f(float y, float x) {
+    if (g_convention & ORC_CONV_TRIG_LIBM) return atan2f(y, x); /* alternative: libm (correctly rounded to ~1 ulp) */
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
     if (mx == 0.f) return 0.f;
@@ -564,6 +625,11 @@ float orc_atan2f(float y, float x) {
 }
 
 static void orc_sincosf(float a, float* sn, float* cs) {
+    if (g_convention & ORC_CONV_TRIG_LIBM) {
+        *sn = sinf(a);
+        *cs = cosf(a);
+        return;
+    }
     const float k = rintf(a * 0x1.45f306p-1f); /* 2/pi */
     float r = fmaf(-k, 0x1.921fb6p+0f, a);
     r = fmaf(-k, -0x1.777a5cp-25f, r);

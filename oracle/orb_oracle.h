@@ -23,6 +23,19 @@
 extern "C" {
 #endif
 
+/* Convention switch (tools/convention_sensitivity.py only; 0 everywhere else): each bit swaps ONE of the conventions this oracle
+ * defines for arithmetic the reference keeps in un-vendored libraries for its plausible alternative. */
+enum {
+    ORC_CONV_RESIZE_HALF_PIXEL = 1,  /* bilinear resize samples at (dst + 0.5) / f - 0.5 instead of dst / f */
+    ORC_CONV_GAUSS_FIXED8 = 2,       /* 7x7 Gaussian in 8-bit fixed point instead of float */
+    ORC_CONV_TRIG_LIBM = 4,          /* libm atan2f / sinf / cosf instead of the shared polynomials */
+    ORC_CONV_QUAT_LARGEST = 8,       /* Quaterniond(R): Shepperd's largest-of-four pivot instead of Eigen's trace-first branches */
+    ORC_CONV_LDLT_REVERSED = 16,     /* reduced system: square-root-free LDL^T in reversed elimination order instead of Cholesky */
+    ORC_CONV_UNDISTORT_20 = 32       /* cv::undistortPoints: 20 fixed-point iterations instead of 5 */
+};
+void orc_set_convention(int flags);
+int orc_get_convention(void);
+
 /* Same 28-byte layout as cv::KeyPoint. */
 typedef struct {
     float x, y, size, angle, response;

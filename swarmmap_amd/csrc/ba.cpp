@@ -208,6 +208,8 @@ void pose_from_Tcw12(const float* T, BaPose& P) { pose_from_Tcw(T, P); }
 void pose_to_Tcw12(const BaPose& P, float* T) { pose_to_Tcw(P, T); }
 }  // namespace so
 
+struct so_ba_group;
+
 struct so_ba {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -241,6 +243,12 @@ struct so_ba {
     int flow_reserved = 0;                  // tiles this context holds of the process-wide residency budget
     std::vector<int> tile_first;
     int stage2_hint = 0;                    // trials the second stage of the last call needed (0: unknown, all are enqueued ahead)
+    // ---- member of a so_ba_group: the LM chain of a local window is recorded and goes out merged with the other members' ----
+    so_ba_group* group = nullptr;
+    BaRecorder rec;
+    hipEvent_t grp_uploaded = nullptr;      // on the member's own stream: its problem is in HBM
+    bool grp_launched = false;              // (under the group's mutex) the round this member submitted to has been issued
+    int grp_event_slot = 0;                 // which of the group's event pairs bracket that round's chain
     int done_seq = 0;                       // tags the completion words of a call (h_abort + 16)
     bool leftover_launches = false;         // the last call returned on its early completion word: launches may still be draining
     hipEvent_t e1a = nullptr;               // behind the early epilogue
@@ -273,7 +281,196 @@ struct so_ba {
     }
 };
 
+// Local bundle adjustments of several agents (one so_ba each, each on its own local-mapping thread) as ONE chain of
+// launches: include/swarmorb.h, so_ba_group_*.  A member's so_bundle_adjust stages and uploads its window on its own stream,
+// records the launches of its LM chain (ba_device.h: BaRecorder) and hands the list in; the first member to arrive waits a
+// short window for the others, merges the lists phase by phase - launches of the same kind become one launch with the member
+// as blockIdx.y - and issues everything on the group's stream.  Every member then waits for its own completion word.
+struct so_ba_group {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_members = 0;          // members registered (so_ba_set_group)
+    double window_us = 250.0;   // how long the first arrival of a round waits for the rest
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<so_ba*> waiting;  // this round's arrivals (under mu)
+    bool launching = false;       // a leader is issuing a round (the table blocks are its own until it is done)
+    void* h_rows = nullptr;       // pinned staging of the BaDev table, two halves
+    void* d_rows = nullptr;
+    size_t rows_cap = 0;          // rows per half
+    int flip = 0;
+    static constexpr int kEventPairs = 4;
+    hipEvent_t ev[2 * kEventPairs] = {};
+    int ev_next = 0;
+    // statistics
+    long long rounds = 0, members_total = 0, grouped_launches = 0, solo_launches = 0, rows_launched = 0;
+};
+
 namespace {
+
+// Issue one round: the recorded chains of `mem` merged phase by phase on the group's stream.
+int ba_group_issue(so_ba_group* g, const std::vector<so_ba*>& mem) {
+    SO_HIP(hipSetDevice(g->device));
+    hipStream_t gs = g->stream;
+    const int M = (int)mem.size();
+    // stage 2: enqueue what the members' last calls needed + 2 (a stage that wants more tops itself up after its wait)
+    int ahead2 = 1;
+    bool any_hint_unknown = false;
+    for (so_ba* b : mem) {
+        if (b->stage2_hint <= 0) any_hint_unknown = true;
+        ahead2 = std::max(ahead2, b->stage2_hint + 2);
+    }
+    static const bool no_hint = getenv("SWARMORB_BA_NO_STAGE2_HINT") != nullptr;
+    const int last_phase2 = (any_hint_unknown || no_hint) ? kBaPhaseEpilogue - 1 : kBaPhaseStage2 + ahead2;
+    // the BaDev table: the distinct argument blocks of every member (its stage-1 and stage-2 views)
+    std::vector<std::vector<int>> row_of((size_t)M);
+    std::vector<BaDev> rows;
+    for (int m = 0; m < M; m++) {
+        const std::vector<BaLaunchRec>& L = mem[(size_t)m]->rec.list;
+        row_of[(size_t)m].assign(L.size(), -1);
+        const size_t first_row = rows.size();
+        for (size_t i = 0; i < L.size(); i++) {
+            if (L[i].kind == kBaKSolo || L[i].kind == kBaKSignal) continue;
+            int found = -1;
+            for (size_t q = first_row; q < rows.size() && found < 0; q++)
+                if (memcmp(&rows[q], &L[i].d, sizeof(BaDev)) == 0) found = (int)q;
+            if (found < 0) {
+                rows.push_back(L[i].d);
+                found = (int)rows.size() - 1;
+            }
+            row_of[(size_t)m][i] = found;
+        }
+    }
+    if (rows.size() > g->rows_cap) {
+        SO_HIP(hipStreamSynchronize(gs));  // (an earlier round may still read the old blocks)
+        if (g->h_rows) (void)hipHostFree(g->h_rows);
+        if (g->d_rows) (void)hipFree(g->d_rows);
+        g->h_rows = g->d_rows = nullptr;
+        g->rows_cap = 0;
+        const size_t cap = rows.size() + 16;
+        SO_HIP(hipHostMalloc(&g->h_rows, 2 * cap * sizeof(BaDev), hipHostMallocDefault));
+        SO_HIP(hipMalloc(&g->d_rows, 2 * cap * sizeof(BaDev)));
+        g->rows_cap = cap;
+    }
+    g->flip ^= 1;
+    BaDev* h_rows = (BaDev*)g->h_rows + (size_t)g->flip * g->rows_cap;
+    BaDev* d_rows = (BaDev*)g->d_rows + (size_t)g->flip * g->rows_cap;
+    memcpy(h_rows, rows.data(), rows.size() * sizeof(BaDev));
+    const int slot = g->ev_next;
+    g->ev_next = (g->ev_next + 1) % so_ba_group::kEventPairs;
+    for (so_ba* b : mem) {
+        SO_HIP(hipStreamWaitEvent(gs, b->grp_uploaded, 0));  // the member's problem is in HBM before its chain starts
+        b->grp_event_slot = slot;
+    }
+    SO_HIP(hipMemcpyAsync(d_rows, h_rows, rows.size() * sizeof(BaDev), hipMemcpyHostToDevice, gs));
+    SO_HIP(hipEventRecord(g->ev[2 * slot], gs));
+    // merge: phases in ascending order; inside a phase the members' launches are aligned by their position in it
+    std::vector<size_t> pos((size_t)M, 0);
+    for (;;) {
+        int phase = INT_MAX;
+        for (int m = 0; m < M; m++) {
+            const std::vector<BaLaunchRec>& L = mem[(size_t)m]->rec.list;
+            if (pos[(size_t)m] < L.size()) phase = std::min(phase, L[pos[(size_t)m]].phase);
+        }
+        if (phase == INT_MAX) break;
+        const bool skip = phase > last_phase2 && phase < kBaPhaseEpilogue;  // stage-2 trials beyond what the members' last calls needed
+        for (int step = 0;; step++) {
+            // the launches at position `step` of this phase, member by member
+            int kinds_present = 0;
+            bool any = false;
+            for (int m = 0; m < M; m++) {
+                const std::vector<BaLaunchRec>& L = mem[(size_t)m]->rec.list;
+                const size_t i = pos[(size_t)m] + (size_t)step;
+                if (i < L.size() && L[i].phase == phase) {
+                    any = true;
+                    kinds_present |= 1 << L[i].kind;
+                }
+            }
+            if (!any) {
+                for (int m = 0; m < M; m++) {  // the phase is over for everybody: move on
+                    const std::vector<BaLaunchRec>& L = mem[(size_t)m]->rec.list;
+                    while (pos[(size_t)m] < L.size() && L[pos[(size_t)m]].phase == phase) pos[(size_t)m]++;
+                }
+                break;
+            }
+            if (skip) continue;
+            for (int kind = 0; kind < kBaKCount; kind++) {
+                if (!(kinds_present & (1 << kind))) continue;
+                BaGroupArgs A{};
+                int max_grid = 1;
+                size_t lds = 0;
+                for (int m = 0; m < M; m++) {
+                    const std::vector<BaLaunchRec>& L = mem[(size_t)m]->rec.list;
+                    const size_t i = pos[(size_t)m] + (size_t)step;
+                    if (i >= L.size() || L[i].phase != phase || L[i].kind != kind) continue;
+                    const BaLaunchRec& R = L[i];
+                    if (kind == kBaKSolo) {
+                        R.solo(gs);
+                        g->solo_launches++;
+                        continue;
+                    }
+                    const int k = A.n++;
+                    A.grid[k] = R.grid;
+                    A.row[k] = row_of[(size_t)m][i] < 0 ? 0 : row_of[(size_t)m][i];
+                    A.i0[k] = R.i0; A.i1[k] = R.i1; A.i2[k] = R.i2;
+                    A.f0[k] = R.f0;
+                    A.p0[k] = R.p0; A.p1[k] = R.p1; A.p2[k] = R.p2; A.p3[k] = R.p3;
+                    max_grid = std::max(max_grid, R.grid);
+                    lds = std::max(lds, R.lds);
+                    if (A.n == kBaGroupMax) {  // (more members than an argument block holds: another launch)
+                        launch_ba_group(kind, d_rows, A, max_grid, lds, gs);
+                        g->grouped_launches++;
+                        g->rows_launched += A.n;
+                        A = BaGroupArgs{};
+                        max_grid = 1;
+                        lds = 0;
+                    }
+                }
+                if (kind != kBaKSolo && A.n > 0) {
+                    launch_ba_group(kind, d_rows, A, max_grid, lds, gs);
+                    g->grouped_launches++;
+                    g->rows_launched += A.n;
+                }
+            }
+        }
+    }
+    SO_HIP(hipEventRecord(g->ev[2 * slot + 1], gs));
+    SO_HIP(hipGetLastError());
+    g->rounds++;
+    g->members_total += M;
+    return SO_OK;
+}
+
+// A member hands its recorded chain in and returns once the round it belongs to has been issued.
+int ba_group_submit(so_ba* b) {
+    so_ba_group* g = b->group;
+    std::unique_lock<std::mutex> lk(g->mu);
+    b->grp_launched = false;
+    g->waiting.push_back(b);
+    if (g->waiting.size() > 1) {  // somebody is collecting this round already
+        g->cv.notify_all();
+        g->cv.wait(lk, [b] { return b->grp_launched; });
+        return b->rec.list.empty() ? SO_OK : SO_ERR_HIP;  // (the leader empties the lists it has issued; a failed round leaves them)
+    }
+    // first of a round: wait for the other members, but not for long
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds((long long)g->window_us);
+    g->cv.wait_until(lk, deadline, [g] { return (int)g->waiting.size() >= g->n_members; });
+    g->cv.wait(lk, [g] { return !g->launching; });  // (the round before is still being issued)
+    std::vector<so_ba*> mem;
+    mem.swap(g->waiting);
+    g->launching = true;
+    lk.unlock();
+    const int rc = ba_group_issue(g, mem);
+    lk.lock();
+    g->launching = false;
+    for (so_ba* m : mem) {
+        if (rc == SO_OK) m->rec.list.clear();
+        m->grp_launched = true;
+    }
+    lk.unlock();
+    g->cv.notify_all();
+    return rc;
+}
 
 int ensure_pinned(void** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return SO_OK;
@@ -440,6 +637,7 @@ int so_ba_create(int device, so_ba** out) {
 
 void so_ba_destroy(so_ba* b) {
     if (!b) return;
+    if (b->group) so_ba_set_group(b, nullptr);
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (Buf* q : b->all()) q->release();
@@ -459,10 +657,69 @@ void so_ba_destroy(so_ba* b) {
     if (b->e0) (void)hipEventDestroy(b->e0);
     if (b->e1) (void)hipEventDestroy(b->e1);
     if (b->e1a) (void)hipEventDestroy(b->e1a);
+    if (b->grp_uploaded) (void)hipEventDestroy(b->grp_uploaded);
     if (b->pe0) (void)hipEventDestroy(b->pe0);
     if (b->pe1) (void)hipEventDestroy(b->pe1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
+}
+
+int so_ba_group_create(int device, double window_us, so_ba_group** out) {
+    if (!out) return SO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        last_error_ref() = "no usable HIP device";
+        return SO_ERR_NO_DEVICE;
+    }
+    SO_HIP(hipSetDevice(device));
+    so_ba_group* g = new so_ba_group();
+    g->device = device;
+    if (window_us > 0.0) g->window_us = window_us;
+    hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    for (hipEvent_t& ev : g->ev)
+        if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        delete g;
+        return hip_fail(e, "ba group init", __FILE__, __LINE__);
+    }
+    *out = g;
+    return SO_OK;
+}
+
+void so_ba_group_destroy(so_ba_group* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (hipEvent_t ev : g->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (g->h_rows) (void)hipHostFree(g->h_rows);
+    if (g->d_rows) (void)hipFree(g->d_rows);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+int so_ba_set_group(so_ba* b, so_ba_group* g) {
+    if (!b || (g && g->device != b->device)) return SO_ERR_INVALID_ARG;
+    if (b->group == g) return SO_OK;
+    if (b->group) {
+        std::lock_guard<std::mutex> lk(b->group->mu);
+        b->group->n_members--;
+    }
+    b->group = g;
+    if (g) {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->n_members++;
+    }
+    return SO_OK;
+}
+
+int so_ba_group_stats(so_ba_group* g, double* out8) {
+    if (!g || !out8) return SO_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(g->mu);
+    out8[0] = (double)g->rounds; out8[1] = (double)g->members_total; out8[2] = (double)g->grouped_launches;
+    out8[3] = (double)g->solo_launches; out8[4] = (double)g->rows_launched; out8[5] = (double)g->n_members; out8[6] = g->window_us; out8[7] = 0.0;
+    return SO_OK;
 }
 
 void so_ba_options_local(so_ba_options* o) {
@@ -1109,6 +1366,21 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     if (trace) fprintf(stderr, "[ba] staging: before %.3f touched+layout %.3f convert %.3f sort %.3f order %.3f fill %.3f lists %.3f\n",
                        tS0 - t_begin, tS1 - tS0, tS2 - tS1, tS3 - tS2, tS4 - tS3, tS5 - tS4, t_staged - tS5);
     if (trace) fprintf(stderr, "[ba] dense setup done at +%.3f, launches done at +%.3f\n", t_dense_setup - t_staged, t_uploaded - t_staged);
+    // A member of a so_ba_group with a local window: the chain below is recorded, not launched, and goes out merged with the
+    // other members' on the group's stream (ba_group_submit); this member's uploads above stay on its own stream.
+    const bool grouped = b->group != nullptr && !b->solve_timing && getenv("SWARMORB_BA_NO_CHAIN") == nullptr && !dense_path &&
+                         !pairs_path && (r.n_free + (r.n_active_edges > 0 ? 1 : 0)) != 0;
+    struct RecorderScope {  // (whatever way this function is left, the thread's launches are real again)
+        ~RecorderScope() { g_ba_recorder = nullptr; }
+    } recorder_scope;
+    if (grouped) {
+        if (!b->grp_uploaded) SO_HIP(hipEventCreateWithFlags(&b->grp_uploaded, hipEventDisableTiming));
+        SO_HIP(hipEventRecord(b->grp_uploaded, s));
+        s = b->group->stream;
+        b->rec.list.clear();
+        b->rec.phase = 0;
+        g_ba_recorder = &b->rec;
+    }
     SO_HIP(hipEventRecord(b->e0, s));
     double chi = 0.0;
     int done = 0;
@@ -1119,9 +1391,10 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     uint8_t* ob = nullptr;
     SO_HIP(hipHostGetDevicePointer((void**)&ob, b->h_out, 0));
     auto epilogue = [&]() {
+        b->rec.phase = kBaPhaseEpilogue;
         launch_ba_finish(r.d, (double)opt->chi2_threshold, (BaPose*)(ob + r_pose), (double*)(ob + r_pt), (double*)(ob + r_chi2),
                          ob + r_out, s);
-        (void)hipEventRecord(b->e1, s);
+        if (!g_ba_recorder) (void)hipEventRecord(b->e1, s);
     };
     // Completion words (single-enqueue path): the host spins on a word in host-mapped memory instead of polling the stream
     // (hipStreamQuery + 20 us naps saw the end of a window tens of microseconds late), and the call's results can be
@@ -1169,10 +1442,12 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         auto trials = [&](const BaDev& d, int n) {
             for (int i = 0; i < n; i++) {
                 r.blocks_enqueued++;
+                b->rec.phase = (d.stage == 2 ? kBaPhaseStage2 : 0) + 1 + i;  // (only read while the chain is being recorded)
                 launch_ba_trial(d, r.nb_err, r.nb_upd, abort_dev, b->h_lm_dev, nullptr, nullptr, s);
             }
         };
         auto stage2_chained = [&]() {  // Optimizer.cc:644-656 without leaving the device
+            b->rec.phase = kBaPhaseStage2;
             launch_ba_mark_outliers(d2, (double)opt->chi2_threshold, kBaGateIdle, s);
             launch_ba_errors(d2, 0, kBaGateIdle, r.nb_err, s);
             launch_ba_build(d2, kBaGateIdle, s);
@@ -1182,7 +1457,8 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
             // of queue time each.  Enqueue what the context's last call needed plus two; a stage that wants more is
             // topped up by the loop below (one host round trip).
             static const bool no_hint = getenv("SWARMORB_BA_NO_STAGE2_HINT") != nullptr;  // A/B: all iterations ahead, as before round 5
-            const int ahead = no_hint ? opt->its_stage2 : std::min(opt->its_stage2, b->stage2_hint > 0 ? b->stage2_hint : opt->its_stage2);
+            // (a group member records all of them: the group enqueues what its members' last calls needed + 2, for everybody)
+            const int ahead = (no_hint || grouped) ? opt->its_stage2 : std::min(opt->its_stage2, b->stage2_hint > 0 ? b->stage2_hint : opt->its_stage2);
             trials(d2, ahead);
             early_phase = 0;
             static const bool no_early = getenv("SWARMORB_BA_NO_EARLY") != nullptr;  // A/B: the reserve in front of the only epilogue
@@ -1204,6 +1480,10 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         if (two_stages) stage2_chained();
         epilogue();
         signal();
+        if (grouped) {  // hand the recorded chain in; back when the round it belongs to has been issued on the group's stream
+            g_ba_recorder = nullptr;
+            if ((rc = ba_group_submit(b))) return rc;
+        }
         BaLm lm;
         bool stopped_between = false, returned_early = false;
         for (;;) {
@@ -1312,7 +1592,12 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     inf.lambda_final = b->h_lm->lambda;
     inf.lm_trials = b->h_lm->trials;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, b->e0, r.returned_early ? b->e1a : b->e1) == hipSuccess) inf.gpu_ms = ms;
+    if (grouped) {  // the span of the merged chain this window was part of
+        so_ba_group* g = b->group;
+        if (hipEventSynchronize(g->ev[2 * b->grp_event_slot + 1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, g->ev[2 * b->grp_event_slot], g->ev[2 * b->grp_event_slot + 1]) == hipSuccess)
+            inf.gpu_ms = ms;
+    } else if (hipEventElapsedTime(&ms, b->e0, r.returned_early ? b->e1a : b->e1) == hipSuccess) inf.gpu_ms = ms;
     inf.solve_ms = b->solve_ms;
     inf.n_solves = b->n_solves;
     if (r.d.plan) {

@@ -415,8 +415,7 @@ __device__ __forceinline__ double rows_sum(double v) {
     return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
 
-__global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev d) {
-    extern __shared__ double s_tiles[];        // NT (NT + 1) / 2 tiles
+__device__ __forceinline__ void ba_solve_mfma_body(const BaDev& d, double* __restrict__ s_tiles) {
     __shared__ double s_lastL[kMTile];         // factor of the last pivot tile: its row rr holds the tail of y
     __shared__ double s_x[16 * kSolveMfmaMaxTiles];
     __shared__ double s_z[16];
@@ -559,6 +558,30 @@ __global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev 
     SO_POTRF_MARK(41);
     if (tid == 0) d.partial[kBaSolveOk] = s_bad ? 0.0 : 1.0;
 }
+__global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev d) {
+    extern __shared__ double s_tiles[];        // NT (NT + 1) / 2 tiles
+    ba_solve_mfma_body(d, s_tiles);
+}
+
+// the single-workgroup solves of a GROUP of windows (so_ba_group): workgroup y solves the system of member y
+__global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
+    extern __shared__ double s_tiles[];
+    const BaDev d = rows[A.row[blockIdx.y]];
+    ba_solve_mfma_body(d, s_tiles);
+}
+
+void launch_ba_solve_mfma_group(const BaDev* d_rows, const BaGroupArgs& A, size_t lds, hipStream_t s) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_mfma_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(double) * (kSolveMfmaMaxTiles * (kSolveMfmaMaxTiles + 1) / 2) * kMTile));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(ba_solve_mfma_group_kernel, dim3(1, A.n), dim3(kSolveMfmaThreads), lds, s, d_rows, A);
+}
+
 
 // ---- the same solve for 30..43 free keyframes: 259 unknowns + right-hand side = 17 x 17 tiles, 306 KB - more than
 // LDS holds but not more than the register file (512 KB per CU).  Sixteen waves: the strictly-lower tiles live in
@@ -745,11 +768,30 @@ bool launch_ba_solve_mfma(const BaDev& d, hipStream_t s) {
     const int n = 6 * d.n_free, NT = (n + 1 + 15) / 16;
     static const bool force_reg = getenv("SWARMORB_MFMA_REG") != nullptr;  // A/B switch for profiling
     if ((NT > kSolveMfmaMaxTiles || (force_reg && NT >= 2)) && NT <= kRegMaxTiles) {
+        if (g_ba_recorder) {
+            BaLaunchRec rec;
+            rec.kind = kBaKSolo;
+            rec.d = d;
+            rec.solo = [d](hipStream_t st) { hipLaunchKernelGGL(ba_solve_mfma_reg_kernel, dim3(1), dim3(kRegThreads), 0, st, d); };
+            rec.phase = g_ba_recorder->phase;
+            g_ba_recorder->list.push_back(rec);
+            return true;
+        }
         hipLaunchKernelGGL(ba_solve_mfma_reg_kernel, dim3(1), dim3(kRegThreads), 0, s, d);
         return true;
     }
     if (NT > kSolveMfmaMaxTiles || NT < 2) return false;
     const size_t lds = sizeof(double) * (size_t)(NT * (NT + 1) / 2) * kMTile;
+    if (g_ba_recorder) {  // a member of a so_ba_group: the solve goes out with the other members' (ba_kernels.hip)
+        BaLaunchRec rec;
+        rec.kind = kBaKSolveMfma;
+        rec.d = d;
+        rec.grid = 1;
+        rec.lds = lds;
+        rec.phase = g_ba_recorder->phase;
+        g_ba_recorder->list.push_back(rec);
+        return true;
+    }
     static bool attr_set[64] = {};  // the attribute is per device; racing threads set the same value
     int dev = 0;
     (void)hipGetDevice(&dev);

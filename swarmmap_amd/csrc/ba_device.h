@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <vector>
 #include <stdint.h>
 
@@ -142,6 +143,48 @@ struct BaDev {
     double huber_delta;
     float huber_dsqr;  // stored as float in the reference (robust_kernel_impl.h:84)
 };
+
+// ---- local bundle adjustments of SEVERAL agents as one chain of launches (so_ba_group, ba.cpp) ----
+// A member's so_bundle_adjust records the launches of its LM chain (launch_ba_* below append to g_ba_recorder instead of
+// launching); the group merges the members' lists step by step: launches of the same kind go out as ONE launch with the
+// member as blockIdx.y (rows of a BaDev table in HBM + per-member scalars in the argument block), the others one by one.
+constexpr int kBaGroupMax = 8;
+struct BaGroupArgs {
+    int n;
+    int grid[kBaGroupMax];  // the member's own gridDim.x: workgroups beyond it return; grid-stride loops and per-workgroup partials use it
+    int row[kBaGroupMax];   // its row of the BaDev table
+    int i0[kBaGroupMax], i1[kBaGroupMax], i2[kBaGroupMax];
+    double f0[kBaGroupMax];
+    void* p0[kBaGroupMax];
+    void* p1[kBaGroupMax];
+    void* p2[kBaGroupMax];
+    void* p3[kBaGroupMax];
+};
+enum BaLaunchKind {
+    kBaKErrors, kBaKBuild, kBaKStageBegin, kBaKGather4, kBaKSolveMfma, kBaKUpdateErrors, kBaKDecide, kBaKMarkOutliers, kBaKFinish,
+    kBaKSignal, kBaKSolo, kBaKCount
+};
+struct BaLaunchRec {
+    int kind = kBaKSolo;
+    BaDev d{};
+    int grid = 1;
+    int i0 = 0, i1 = 0, i2 = 0;
+    double f0 = 0.0;
+    void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
+    size_t lds = 0;
+    int phase = 0;  // BaRecorder::phase when it was recorded: the group merges the members' lists phase by phase
+    std::function<void(hipStream_t)> solo;  // kBaKSolo: a launch that has no grouped form, issued as it is
+};
+// phases of a call's chain: 0 stage 1's prologue, 1 + k its trial k, 100 stage 2's prologue, 101 + k its trial k, 1000 the epilogue
+constexpr int kBaPhaseStage2 = 100, kBaPhaseEpilogue = 1000;
+struct BaRecorder {
+    std::vector<BaLaunchRec> list;
+    int phase = 0;
+};
+extern thread_local BaRecorder* g_ba_recorder;  // non-null: the calling thread's launch_ba_* record instead of launching
+// one grouped launch: `kind` for the members of A (rows of d_rows), grid (max_grid, A.n)
+void launch_ba_group(int kind, const BaDev* d_rows, const BaGroupArgs& A, int max_grid, size_t lds, hipStream_t s);
+void launch_ba_solve_mfma_group(const BaDev* d_rows, const BaGroupArgs& A, size_t lds, hipStream_t s);
 
 constexpr int kBaPartialChi = 0;       // [0, 1024): chi2 partials of the error kernel
 constexpr int kBaPartialScale = 1024;  // [1024, 2048): scale partials of the update kernel

@@ -224,7 +224,7 @@ __device__ __forceinline__ double block_sum(double v, double* s_tmp /* >= 16 dou
 }
 
 // ---------------- residuals + chi2 (computeActiveErrors + activeRobustChi2) ----------------
-__global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, int which, int gated) {
+__device__ __forceinline__ void ba_errors_body(const BaDev& d, int which, int gated, const unsigned BX, const unsigned GX) {
     __shared__ double s_tmp[16];
     const BaLm lm = *d.lm;
     if (gated == 1 && lm.active != d.stage) return;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, int which, int 
     const BaPose* __restrict__ poses = d.pose[lm.cur ^ which];
     const double* __restrict__ points = d.pt[lm.cur ^ which];
     double acc = 0.0;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < d.n_edges; e += gridDim.x * 256) {
+    for (int e = BX * 256 + threadIdx.x; e < d.n_edges; e += GX * 256) {
         if (!d.e_active[e]) continue;
         const int ip = d.e_pose[e], il = d.e_point[e];
         double e0, e1;
@@ -247,10 +247,34 @@ __global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, int which, int 
         acc += d.robust ? huber_rho0(chi2, d.huber_delta, d.huber_dsqr) : chi2;
     }
     const double t = block_sum(acc, s_tmp);
-    if (threadIdx.x == 0) d.partial[kBaPartialChi + blockIdx.x] = t;
+    if (threadIdx.x == 0) d.partial[kBaPartialChi + BX] = t;
+}
+__global__ __launch_bounds__(256) void ba_errors_kernel(BaDev d, int which, int gated) {
+    ba_errors_body(d, which, gated, blockIdx.x, gridDim.x);
 }
 
+
+thread_local BaRecorder* g_ba_recorder = nullptr;
+
+namespace {
+BaLaunchRec& ba_record(int kind, const BaDev& d, int grid) {
+    g_ba_recorder->list.emplace_back();
+    BaLaunchRec& r = g_ba_recorder->list.back();
+    r.kind = kind;
+    r.d = d;
+    r.grid = grid;
+    r.phase = g_ba_recorder->phase;
+    return r;
+}
+}  // namespace
+
 void launch_ba_errors(const BaDev& d, int which, int gate, int n_blocks, hipStream_t s) {
+    if (g_ba_recorder) {
+        BaLaunchRec& r = ba_record(kBaKErrors, d, n_blocks);
+        r.i0 = which;
+        r.i1 = gate;
+        return;
+    }
     hipLaunchKernelGGL(ba_errors_kernel, dim3(n_blocks), dim3(256), 0, s, d, which, gate);
 }
 
@@ -376,10 +400,10 @@ void launch_ba_build_pairs(const BaDev& d, void* scan_temp, size_t scan_temp_byt
     hipLaunchKernelGGL(ba_pairs_sort_kernel, dim3(n_blk), dim3(64), 0, s, d, n_blk, d.ps_l, d.ps_k1, d.ps_k2);
 }
 
-__global__ __launch_bounds__(256) void ba_finish_kernel(BaDev d, double chi2_threshold, BaPose* __restrict__ pose_out,
+__device__ __forceinline__ void ba_finish_body(const BaDev& d, double chi2_threshold, BaPose* __restrict__ pose_out,
                                                          double* __restrict__ pt_out, double* __restrict__ chi2_out,
-                                                         uint8_t* __restrict__ outlier_out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                         uint8_t* __restrict__ outlier_out, const unsigned BX, const unsigned GX) {
+    const int i = BX * 256 + threadIdx.x;
     const int cur = d.lm->cur;
     const BaPose* poses = d.pose[cur];
     const double* points = d.pt[cur];
@@ -395,6 +419,12 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaDev d, double chi2_thr
     if (i < d.n_poses) pose_out[i] = poses[i];
     if (i < 3 * d.n_points) pt_out[i] = points[i];
 }
+__global__ __launch_bounds__(256) void ba_finish_kernel(BaDev d, double chi2_threshold, BaPose* __restrict__ pose_out,
+                                                         double* __restrict__ pt_out, double* __restrict__ chi2_out,
+                                                         uint8_t* __restrict__ outlier_out) {
+    ba_finish_body(d, chi2_threshold, pose_out, pt_out, chi2_out, outlier_out, blockIdx.x, gridDim.x);
+}
+
 
 // Completion word behind an epilogue: everything enqueued before this launch has run and its writes into host-mapped memory
 // are out, so the host can spin on the word instead of querying the stream.
@@ -404,6 +434,12 @@ __global__ void ba_signal_kernel(int* __restrict__ word, int value) {
 }
 
 void launch_ba_signal(int* word_host_mapped, int value, hipStream_t s) {
+    if (g_ba_recorder) {
+        BaLaunchRec& r = ba_record(kBaKSignal, BaDev{}, 1);
+        r.p0 = word_host_mapped;
+        r.i0 = value;
+        return;
+    }
     hipLaunchKernelGGL(ba_signal_kernel, dim3(1), dim3(1), 0, s, word_host_mapped, value);
 }
 
@@ -412,6 +448,12 @@ void launch_ba_finish(const BaDev& d, double chi2_threshold, BaPose* pose_out, d
     int nthreads = d.n_edges > d.n_poses ? d.n_edges : d.n_poses;
     if (3 * d.n_points > nthreads) nthreads = 3 * d.n_points;
     if (nthreads <= 0) return;
+    if (g_ba_recorder) {
+        BaLaunchRec& r = ba_record(kBaKFinish, d, (nthreads + 255) / 256);
+        r.f0 = chi2_threshold;
+        r.p0 = pose_out; r.p1 = pt_out; r.p2 = chi2_out; r.p3 = outlier_out;
+        return;
+    }
     hipLaunchKernelGGL(ba_finish_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, d, chi2_threshold, pose_out,
                        pt_out, chi2_out, outlier_out);
 }
@@ -421,8 +463,8 @@ void launch_ba_finish(const BaDev& d, double chi2_threshold, BaPose* pose_out, d
 // the camera in the current estimate is dropped (setLevel(1)); a landmark without active edges drops out too.
 // (eight lanes per landmark, each looking at every eighth edge: a thread per landmark walked ~15 edges of dependent loads,
 //  32 us on a 26 k-edge window; flags only, so no summation order is involved)
-__global__ __launch_bounds__(256) void ba_mark_outliers_kernel(BaDev d, double chi2_threshold, int gate) {
-    const int il = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+__device__ __forceinline__ void ba_mark_outliers_body(const BaDev& d, double chi2_threshold, int gate, const unsigned BX, const unsigned GX) {
+    const int il = BX * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
     if (gate == 2 && (d.lm->active || d.lm->stages_begun != d.stage - 1)) return;
     const bool live = il < d.n_points;
     const int cur = d.lm->cur;
@@ -448,9 +490,19 @@ __global__ __launch_bounds__(256) void ba_mark_outliers_kernel(BaDev d, double c
     alive += __shfl_xor(alive, 4);
     if (live && sub == 0) d.pt_active[il] = alive > 0;
 }
+__global__ __launch_bounds__(256) void ba_mark_outliers_kernel(BaDev d, double chi2_threshold, int gate) {
+    ba_mark_outliers_body(d, chi2_threshold, gate, blockIdx.x, gridDim.x);
+}
+
 
 void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, int gate, hipStream_t s) {
     if (d.n_points <= 0) return;
+    if (g_ba_recorder) {
+        BaLaunchRec& r = ba_record(kBaKMarkOutliers, d, (d.n_points + 31) / 32);
+        r.f0 = chi2_threshold;
+        r.i0 = gate;
+        return;
+    }
     hipLaunchKernelGGL(ba_mark_outliers_kernel, dim3((d.n_points + 31) / 32), dim3(256), 0, s, d, chi2_threshold, gate);
 }
 
@@ -458,16 +510,16 @@ void launch_ba_mark_outliers(const BaDev& d, double chi2_threshold, int gate, hi
 // The residuals are recomputed here from the current estimate (the same function on the same state as
 // computeActiveErrors, so the same values) rather than read from the stored errors, which describe the last
 // TRIAL and are stale after a rejected one.
-__global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, int gated) {
+__device__ __forceinline__ void ba_build_body(const BaDev& d, int gated, const unsigned BX, const unsigned GX) {
     __shared__ double s_red[4][28];
     const BaLm lm = *d.lm;
     if (gated == 1 && !(lm.active == d.stage && lm.need_build)) return;
     if (gated == 2 && (lm.active || lm.stages_begun != d.stage - 1)) return;
     const BaPose* __restrict__ poses = d.pose[lm.cur];
     const double* __restrict__ points = d.pt[lm.cur];
-    if ((int)blockIdx.x < d.n_free) {
+    if ((int)BX < d.n_free) {
         // pose role: reduce J_c^T w J_c (upper 21) and J_c^T omega_r (6) over this pose's active edges
-        const int hi = blockIdx.x, ip = d.free_pose[hi];
+        const int hi = BX, ip = d.free_pose[hi];
         const BaPose P = poses[ip];
         const double* K = d.intr + 4 * ip;
         double acc[27];
@@ -517,7 +569,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, int gated) {
     }
     // landmark role: 8 lanes per landmark (32 landmarks per workgroup); a landmark's edges are contiguous, each
     // lane linearises every 8th one, then a fixed xor-butterfly over the 8 lanes sums Hll (6 unique) and bl (3)
-    const int il = (blockIdx.x - d.n_free) * 32 + (threadIdx.x >> 3);
+    const int il = (BX - d.n_free) * 32 + (threadIdx.x >> 3);
     const int sub = threadIdx.x & 7;
     const bool live = il < d.n_points && d.pt_active[il];
     double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -567,10 +619,18 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, int gated) {
         d.bl[3 * (size_t)il] = b[0]; d.bl[3 * (size_t)il + 1] = b[1]; d.bl[3 * (size_t)il + 2] = b[2];
     }
 }
+__global__ __launch_bounds__(256) void ba_build_kernel(BaDev d, int gated) {
+    ba_build_body(d, gated, blockIdx.x, gridDim.x);
+}
+
 
 void launch_ba_build(const BaDev& d, int gate, hipStream_t s) {
     const int nb = d.n_free + (d.n_points + 31) / 32;
     if (nb <= 0) return;
+    if (g_ba_recorder) {
+        ba_record(kBaKBuild, d, nb).i0 = gate;
+        return;
+    }
     hipLaunchKernelGGL(ba_build_kernel, dim3(nb), dim3(256), 0, s, d, gate);
 }
 
@@ -626,24 +686,24 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDev d) {
 // With pair lists (large maps) only the blocks of big_list are walked here (list_cap = launch bound of the list,
 // *big_n of its entries are real); the others belong to ba_schur_gather_small_kernel.
 template <int WAVES>
-__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_cap) {
+__device__ __forceinline__ void ba_schur_gather_body(const BaDev& d, int list_cap, const unsigned BX, const unsigned GX) {
     __shared__ double s_part[4][36];
     if (d.lm->active != d.stage) return;
     const double lambda = d.lm->lambda;
     const int lane = threadIdx.x & 63, wave = WAVES == 4 ? (int)(threadIdx.x >> 6) : 0;
     const int tid = WAVES == 4 ? (int)threadIdx.x : lane;  // index inside the group
     constexpr int kStride = 64 * WAVES;
-    int g = WAVES == 4 ? (int)blockIdx.x : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    int g = WAVES == 4 ? (int)BX : (int)(BX * 4 + (threadIdx.x >> 6));
     const int nf = d.n_free;
     int n_blk = nf * (nf + 1) / 2;
     if (WAVES == 4) {
-        // Workgroups go to the eight XCDs round-robin, each with its own L2: with g = blockIdx.x every XCD met every
+        // Workgroups go to the eight XCDs round-robin, each with its own L2: with g = BX every XCD met every
         // keyframe's W blocks (FETCH_SIZE 4.1x the inputs, round 4).  XCD x takes the x-th eighth of the column-ordered
         // block list instead - two or three whole columns i2, so W of those keyframes' edges stays in one L2; the i1 side
         // is shared by all columns whatever the deal (any split of all pairs of 25 keyframes over eight caches re-reads
         // W about three times: DESIGN.md 5).  S(i1,i2) does not depend on which workgroup forms it.
-        const int total = n_blk + nf, chunk = (total + 7) >> 3, j = (int)(blockIdx.x >> 3);
-        g = (int)(blockIdx.x & 7) * chunk + j;
+        const int total = n_blk + nf, chunk = (total + 7) >> 3, j = (int)(BX >> 3);
+        g = (int)(BX & 7) * chunk + j;
         if (j >= chunk || g >= total) return;
     }
     if (d.use_pairs) {
@@ -789,6 +849,11 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_
         if (tid < 6) d.bs[6 * (size_t)hi + tid] = d.bp[6 * (size_t)hi + tid] - (((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid]);
     }
 }
+template <int WAVES>
+__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaDev d, int list_cap) {
+    ba_schur_gather_body<WAVES>(d, list_cap, blockIdx.x, gridDim.x);
+}
+
 
 // ---------------- dense Cholesky solve of the reduced camera system (single workgroup) ----------------
 // Replaces LinearSolverEigen's SimplicialLDLT (linear_solver_eigen.h:94-124): same solution up to rounding.
@@ -1329,6 +1394,18 @@ __global__ __launch_bounds__(256) void ba_schur_gather_small_kernel(BaDev d, int
 static void launch_ba_schur(const BaDev& d, hipStream_t s) {
     const int nthreads = d.n_points > d.n_edges ? d.n_points : d.n_edges;
     const int n_blk = d.n_free * (d.n_free + 1) / 2;
+    if (g_ba_recorder) {
+        const int groups = n_blk + d.n_free;
+        if (d.fold_prep && !d.use_pairs && groups > 0) {  // a local window: the one launch that has a grouped form
+            ba_record(kBaKGather4, d, 8 * ((groups + 7) / 8));
+        } else {
+            BaRecorder* rec = g_ba_recorder;
+            BaLaunchRec& r = ba_record(kBaKSolo, d, 1);
+            r.solo = [d](hipStream_t st) { launch_ba_schur(d, st); };
+            (void)rec;
+        }
+        return;
+    }
     // Local windows (no pair lists, at most 43 free keyframes: d.fold_prep) have no prep launch: the gather and the update form (Hll + lambda I)^-1, W Dinv and
     // Dinv bl themselves where they need them - the same expressions, hence the same bits, one launch (9.5 us of an 87 us
     // trial on LBA-M) less.  Larger windows and pair-list maps read each product many times over: they keep the stored copies.
@@ -1347,7 +1424,12 @@ static void launch_ba_solve(const BaDev& d, hipStream_t s) {
     const int NB = d.n_free + 1, nblk = NB * (NB + 1) / 2 - 1, rows = 6 * (d.n_free - 1) + 1;
     static const bool classic = getenv("SWARMORB_BA_CLASSIC_SOLVER") != nullptr;  // A/B switches for profiling
     static const bool no_mfma = getenv("SWARMORB_BA_NO_MFMA_SOLVER") != nullptr;
-    if (!classic && !no_mfma && d.n_free >= kBaMfmaSolverMinFree && launch_ba_solve_mfma(d, s)) return;
+    if (!classic && !no_mfma && d.n_free >= kBaMfmaSolverMinFree && launch_ba_solve_mfma(d, s)) return;  // (records by itself)
+    if (g_ba_recorder) {  // every other solver: as it is, behind the group's grouped launches
+        BaLaunchRec& r = ba_record(kBaKSolo, d, 1);
+        r.solo = [d](hipStream_t st) { launch_ba_solve(d, st); };
+        return;
+    }
     if (!classic && nblk <= 256 && rows <= 2 * 58)
         hipLaunchKernelGGL((ba_solve_la_kernel<4, 2>), dim3(1), dim3(6 * 64), 0, s, d);
     else if (!classic && nblk <= 384 && rows <= 3 * 58)
@@ -1455,7 +1537,7 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDev d) {
 // expressions per pose / point / edge as the two kernels (same bits in the trial buffers, e_err, e_chi2); the chi2
 // partials are per workgroup of THIS grid (the decision kernel sums nb_upd of them, in index order: deterministic).
 constexpr int kBaFusedMaxPoses = 128;
-__global__ __launch_bounds__(256) void ba_update_errors_kernel(BaDev d) {
+__device__ __forceinline__ void ba_update_errors_body(const BaDev& d, const unsigned BX, const unsigned GX) {
     __shared__ BaPose s_pose[kBaFusedMaxPoses];
     __shared__ double s_tmp[16];
     const BaLm lm = *d.lm;
@@ -1474,17 +1556,17 @@ __global__ __launch_bounds__(256) void ba_update_errors_kernel(BaDev d) {
             const double* x = xp + 6 * (size_t)hi;
             const double u[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
             se3_exp_mul(u, poses[ip], out);
-            if (blockIdx.x == 0) {
+            if (BX == 0) {
 #pragma unroll
                 for (int r = 0; r < 6; r++) scale += u[r] * (lambda * u[r] + d.bp[6 * (size_t)hi + r]);
             }
         }
         s_pose[ip] = out;
-        if (blockIdx.x == 0) poses_trial[ip] = out;
+        if (BX == 0) poses_trial[ip] = out;
     }
     __syncthreads();
     const int total = 8 * d.n_points;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    for (int i = BX * 256 + threadIdx.x; i < total; i += GX * 256) {
         const int il = i >> 3, sub = i & 7;
         const bool act = d.pt_active[il];
         double cl[3] = {0, 0, 0};
@@ -1544,10 +1626,14 @@ __global__ __launch_bounds__(256) void ba_update_errors_kernel(BaDev d) {
     const double ts = block_sum(scale, s_tmp);
     const double tc = block_sum(chi, s_tmp);
     if (threadIdx.x == 0) {
-        d.partial[kBaPartialScale + blockIdx.x] = ts;
-        d.partial[kBaPartialChi + blockIdx.x] = tc;
+        d.partial[kBaPartialScale + BX] = ts;
+        d.partial[kBaPartialChi + BX] = tc;
     }
 }
+__global__ __launch_bounds__(256) void ba_update_errors_kernel(BaDev d) {
+    ba_update_errors_body(d, blockIdx.x, gridDim.x);
+}
+
 
 // ---------------- Levenberg-Marquardt control on the device ----------------
 // Start of SparseOptimizer::optimize(iterations): chi2 of the current estimate (the error kernel ran on it),
@@ -1557,8 +1643,8 @@ __global__ __launch_bounds__(256) void ba_update_errors_kernel(BaDev d) {
 // optimization_algorithm_levenberg.cpp:166-180; max is order-independent), LM state reset.  One workgroup; the maximum
 // used to be a launch of its own that walked the 3 n_points diagonal entries one dependent load at a time (19 us for
 // 9600 landmarks) - here a thread takes whole landmarks, three independent loads each.
-__global__ __launch_bounds__(1024) void ba_stage_begin_kernel(BaDev d, int nb_err, int iterations, BaLm* __restrict__ lm_host, int gate,
-                                                               const uint8_t* __restrict__ abort_flag) {
+__device__ __forceinline__ void ba_stage_begin_body(const BaDev& d, int nb_err, int iterations, BaLm* __restrict__ lm_host, int gate,
+                                                               const uint8_t* __restrict__ abort_flag, const unsigned BX, const unsigned GX) {
     __shared__ double s_tmp[16];
     __shared__ double s_m[16];
     // gate 2: chained behind the previous stage's trials - the stage starts on the device as soon as that one is over
@@ -1610,16 +1696,27 @@ __global__ __launch_bounds__(1024) void ba_stage_begin_kernel(BaDev d, int nb_er
         if (lm_host) *lm_host = lm;
     }
 }
+__global__ __launch_bounds__(1024) void ba_stage_begin_kernel(BaDev d, int nb_err, int iterations, BaLm* __restrict__ lm_host, int gate,
+                                                               const uint8_t* __restrict__ abort_flag) {
+    ba_stage_begin_body(d, nb_err, iterations, lm_host, gate, abort_flag, blockIdx.x, gridDim.x);
+}
+
 
 void launch_ba_stage_begin(const BaDev& d, int nb_err, int iterations, BaLm* lm_host, int gate, const uint8_t* abort_flag, hipStream_t s) {
+    if (g_ba_recorder) {
+        BaLaunchRec& r = ba_record(kBaKStageBegin, d, 1);
+        r.i0 = nb_err; r.i1 = iterations; r.i2 = gate;
+        r.p0 = lm_host; r.p1 = const_cast<uint8_t*>(abort_flag);
+        return;
+    }
     hipLaunchKernelGGL(ba_stage_begin_kernel, dim3(1), dim3(1024), 0, s, d, nb_err, iterations, lm_host, gate, abort_flag);
 }
 
 // End of a trial: OptimizationAlgorithmLevenberg::solve's accept / reject (optimization_algorithm_levenberg.cpp:
 // 95-148) and SparseOptimizer::optimize's stopping rules (sparse_optimizer.cpp:355-420).
-__global__ __launch_bounds__(256) void ba_trial_decide_kernel(BaDev d, int nb_err, int nb_upd,
+__device__ __forceinline__ void ba_trial_decide_body(const BaDev& d, int nb_err, int nb_upd,
                                                               const uint8_t* __restrict__ abort_flag,
-                                                              BaLm* __restrict__ lm_host) {
+                                                              BaLm* __restrict__ lm_host, const unsigned BX, const unsigned GX) {
     __shared__ double s_tmp[16];
     if (d.lm->active != d.stage) return;
     double c = 0.0, sc = 0.0;
@@ -1673,6 +1770,12 @@ __global__ __launch_bounds__(256) void ba_trial_decide_kernel(BaDev d, int nb_er
     *d.lm = lm;
     if (lm_host) *lm_host = lm;
 }
+__global__ __launch_bounds__(256) void ba_trial_decide_kernel(BaDev d, int nb_err, int nb_upd,
+                                                              const uint8_t* __restrict__ abort_flag,
+                                                              BaLm* __restrict__ lm_host) {
+    ba_trial_decide_body(d, nb_err, nb_upd, abort_flag, lm_host, blockIdx.x, gridDim.x);
+}
+
 
 void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abort_flag, BaLm* lm_host, hipEvent_t ev0,
                      hipEvent_t ev1, hipStream_t s) {
@@ -1685,13 +1788,94 @@ void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abor
     // the two kernels)
     static const bool fuse_env = !(getenv("SWARMORB_BA_FUSE_UPDATE") && atoi(getenv("SWARMORB_BA_FUSE_UPDATE")) == 0);
     if (fuse_env && d.fold_prep && d.n_poses <= kBaFusedMaxPoses && !d.use_pairs) {
+        if (g_ba_recorder) {
+            ba_record(kBaKUpdateErrors, d, nb_upd);
+            BaLaunchRec& r = ba_record(kBaKDecide, d, 1);
+            r.i0 = nb_upd; r.i1 = nb_upd;
+            r.p0 = const_cast<uint8_t*>(abort_flag); r.p1 = lm_host;
+            return;
+        }
         hipLaunchKernelGGL(ba_update_errors_kernel, dim3(nb_upd), dim3(256), 0, s, d);
         hipLaunchKernelGGL(ba_trial_decide_kernel, dim3(1), dim3(256), 0, s, d, nb_upd, nb_upd, abort_flag, lm_host);
+        return;
+    }
+    if (g_ba_recorder) {
+        BaLaunchRec& u = ba_record(kBaKSolo, d, 1);
+        u.solo = [d, nb_upd](hipStream_t st) { hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, st, d); };
+        launch_ba_errors(d, 1, kBaGateActive, nb_err, s);
+        BaLaunchRec& r = ba_record(kBaKDecide, d, 1);
+        r.i0 = nb_err; r.i1 = nb_upd;
+        r.p0 = const_cast<uint8_t*>(abort_flag); r.p1 = lm_host;
         return;
     }
     hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, s, d);
     launch_ba_errors(d, 1, kBaGateActive, nb_err, s);
     hipLaunchKernelGGL(ba_trial_decide_kernel, dim3(1), dim3(256), 0, s, d, nb_err, nb_upd, abort_flag, lm_host);
+}
+
+// ---- grouped forms (so_ba_group): member y of the launch = row A.row[y] of the BaDev table, its own grid A.grid[y] ----
+#define BA_GROUP_PROLOGUE                                    \
+    const int m_ = blockIdx.y;                               \
+    if ((int)blockIdx.x >= A.grid[m_]) return;               \
+    const BaDev d = rows[A.row[m_]];                         \
+    const unsigned BX = blockIdx.x, GX = (unsigned)A.grid[m_];
+
+__global__ __launch_bounds__(256) void ba_errors_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
+    BA_GROUP_PROLOGUE
+    ba_errors_body(d, A.i0[m_], A.i1[m_], BX, GX);
+}
+__global__ __launch_bounds__(256) void ba_build_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
+    BA_GROUP_PROLOGUE
+    ba_build_body(d, A.i0[m_], BX, GX);
+}
+__global__ __launch_bounds__(1024) void ba_stage_begin_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
+    BA_GROUP_PROLOGUE
+    ba_stage_begin_body(d, A.i0[m_], A.i1[m_], static_cast<BaLm*>(A.p0[m_]), A.i2[m_], static_cast<const uint8_t*>(A.p1[m_]), BX, GX);
+}
+__global__ __launch_bounds__(256) void ba_schur_gather4_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
+    BA_GROUP_PROLOGUE
+    ba_schur_gather_body<4>(d, 0, BX, GX);
+}
+__global__ __launch_bounds__(256) void ba_update_errors_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
+    BA_GROUP_PROLOGUE
+    ba_update_errors_body(d, BX, GX);
+}
+__global__ __launch_bounds__(256) void ba_trial_decide_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
+    BA_GROUP_PROLOGUE
+    ba_trial_decide_body(d, A.i0[m_], A.i1[m_], static_cast<const uint8_t*>(A.p0[m_]), static_cast<BaLm*>(A.p1[m_]), BX, GX);
+}
+__global__ __launch_bounds__(256) void ba_mark_outliers_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
+    BA_GROUP_PROLOGUE
+    ba_mark_outliers_body(d, A.f0[m_], A.i0[m_], BX, GX);
+}
+__global__ __launch_bounds__(256) void ba_finish_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
+    BA_GROUP_PROLOGUE
+    ba_finish_body(d, A.f0[m_], static_cast<BaPose*>(A.p0[m_]), static_cast<double*>(A.p1[m_]), static_cast<double*>(A.p2[m_]),
+                   static_cast<uint8_t*>(A.p3[m_]), BX, GX);
+}
+__global__ void ba_signal_group_kernel(BaGroupArgs A) {
+    const int m_ = threadIdx.x;
+    if (m_ >= A.n) return;
+    __threadfence_system();
+    __hip_atomic_store(static_cast<int*>(A.p0[m_]), A.i0[m_], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#undef BA_GROUP_PROLOGUE
+
+void launch_ba_group(int kind, const BaDev* d_rows, const BaGroupArgs& A, int max_grid, size_t lds, hipStream_t s) {
+    const dim3 grid((unsigned)std::max(max_grid, 1), (unsigned)A.n);
+    switch (kind) {
+        case kBaKErrors: hipLaunchKernelGGL(ba_errors_group_kernel, grid, dim3(256), 0, s, d_rows, A); break;
+        case kBaKBuild: hipLaunchKernelGGL(ba_build_group_kernel, grid, dim3(256), 0, s, d_rows, A); break;
+        case kBaKStageBegin: hipLaunchKernelGGL(ba_stage_begin_group_kernel, grid, dim3(1024), 0, s, d_rows, A); break;
+        case kBaKGather4: hipLaunchKernelGGL(ba_schur_gather4_group_kernel, grid, dim3(256), 0, s, d_rows, A); break;
+        case kBaKSolveMfma: launch_ba_solve_mfma_group(d_rows, A, lds, s); break;
+        case kBaKUpdateErrors: hipLaunchKernelGGL(ba_update_errors_group_kernel, grid, dim3(256), 0, s, d_rows, A); break;
+        case kBaKDecide: hipLaunchKernelGGL(ba_trial_decide_group_kernel, grid, dim3(256), 0, s, d_rows, A); break;
+        case kBaKMarkOutliers: hipLaunchKernelGGL(ba_mark_outliers_group_kernel, grid, dim3(256), 0, s, d_rows, A); break;
+        case kBaKFinish: hipLaunchKernelGGL(ba_finish_group_kernel, grid, dim3(256), 0, s, d_rows, A); break;
+        case kBaKSignal: hipLaunchKernelGGL(ba_signal_group_kernel, dim3(1), dim3(64), 0, s, A); break;
+        default: break;
+    }
 }
 
 }  // namespace so

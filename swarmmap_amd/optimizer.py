@@ -52,6 +52,30 @@ def problem_struct(prob):
     return P, a
 
 
+class BaGroup:
+    """so_ba_group: the local bundle adjustments of several Optimizer contexts (one per agent, each called from its own
+    thread) as one chain of launches."""
+
+    def __init__(self, device=0, window_us=0.0):
+        self._lib = lib = _lib.load_library()
+        lib.so_ba_group_create.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_void_p)]
+        lib.so_ba_group_destroy.argtypes = [C.c_void_p]
+        lib.so_ba_group_destroy.restype = None
+        lib.so_ba_group_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self._h = C.c_void_p()
+        _lib.check(lib.so_ba_group_create(int(device), float(window_us), C.byref(self._h)))
+
+    def stats(self):
+        a = np.zeros(8, np.float64)
+        _lib.check(self._lib.so_ba_group_stats(self._h, _vp(a)))
+        return dict(zip(("rounds", "members_total", "grouped_launches", "ungrouped_launches", "rows_launched", "members", "window_us"), a.tolist()))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.so_ba_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 class Optimizer:
     """One solver context per LocalMapping thread (device buffers are reused from call to call)."""
 
@@ -88,6 +112,11 @@ class Optimizer:
             self._h = C.c_void_p()
 
     __del__ = close
+
+    def set_group(self, group):
+        """so_ba_set_group: this context's local bundle adjustments go out merged with the other members' (None: leave)."""
+        self._lib.so_ba_set_group.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.check(self._lib.so_ba_set_group(self._h, group._h if group is not None else None))
 
     def _solve(self, prob, opt, pbStopFlag):
         a = dict(Tcw=np.ascontiguousarray(prob["Tcw"], np.float32).reshape(-1, 12),

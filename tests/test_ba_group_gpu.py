@@ -1,0 +1,86 @@
+"""Local bundle adjustments of SEVERAL agents as one chain of launches (so_ba_group: every kernel of the Levenberg-Marquardt
+chain once, with the window as blockIdx.y) against the same windows optimised one by one: poses, points, outlier flags, chi2
+per edge, iteration and trial counts are those of the solo call, to the bit.  Solo calls are pinned to the oracle by
+tests/test_ba_gpu.py (Optimizer::LocalBundleAdjustment, code/src/Optimizer.cc:436-740).  Concurrency model: one LocalMapping
+thread per agent (code/src/LocalMapping.cc:53-110), one process per agent (code/Examples/Monocular/swarm_map.cc:329-337)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import swarmmap_amd
+from swarmmap_amd import synth
+from swarmmap_amd.optimizer import BaGroup
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEYS = ("iterations_stage1", "iterations_stage2", "lm_trials", "chi2_initial", "chi2_final", "n_free_keyframes", "lambda_final")
+
+
+def _windows():
+    w = [synth.make_ba_case("LBA-M", seed=100 + i) for i in range(3)]
+    w.append(synth.make_ba_case("LBA-S", seed=7))                      # 8 free keyframes: another tile count of the MFMA solver
+    w.append(synth.make_ba_problem(3, 3, 6, 300, max_obs="auto"))      # 3 free keyframes: the look-ahead solver (no grouped form)
+    w.append(synth.make_ba_case("LBA-L", seed=5))                      # 40 free keyframes: the register-resident MFMA solver
+    z = np.load(os.path.join(GOLDEN, "closed_loop_window.npz"))        # a window of the closed loop (25 free + 36 fixed keyframes)
+    w.append({k: z[k] for k in ("Tcw", "fixed", "intr", "Xw", "edge_pose", "edge_point", "obs", "inv_sigma2")})
+    return w
+
+
+def _same(a, b, what):
+    for k in ("Tcw", "Xw", "outlier", "chi2"):
+        assert np.array_equal(a[k], b[k]), "%s: %s differs" % (what, k)
+    for k in KEYS:
+        assert a["info"][k] == b["info"][k], "%s: info.%s %r != %r" % (what, k, a["info"][k], b["info"][k])
+
+
+def _run_grouped(opts, windows, reps):
+    out, errs = [[None] * reps for _ in windows], []
+
+    def worker(i):
+        try:
+            for r in range(reps):
+                out[i][r] = opts[i].LocalBundleAdjustment(windows[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(windows))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    return out
+
+
+def test_grouped_local_bundle_adjustments_equal_the_solo_calls():
+    windows = _windows()
+    n = len(windows)
+    opts = [swarmmap_amd.Optimizer() for _ in range(n)]
+    solo = [[o.LocalBundleAdjustment(w) for _ in range(3)] for o, w in zip(opts, windows)]  # (a context's 2nd / 3rd call: the stage-2 hint is set)
+    for i in range(n):
+        _same(solo[i][1], solo[i][0], "solo call repeated")
+    g = BaGroup(window_us=20000.0)  # (python threads arrive far apart: a generous window so that the rounds really are shared)
+    for o in opts:
+        o.set_group(g)
+    grp = _run_grouped(opts, windows, 3)
+    st = g.stats()
+    for i in range(n):
+        for r in range(3):
+            _same(grp[i][r], solo[i][0], "window %d, grouped call %d" % (i, r))
+    assert st["members"] == n and st["members_total"] == 3 * n
+    assert st["rounds"] < 3 * n, st                          # members did share rounds ...
+    assert st["rows_launched"] > 1.5 * st["grouped_launches"], st   # ... and launches
+    assert st["ungrouped_launches"] > 0                      # (the 3- and 40-keyframe windows' solves have no grouped form)
+    # a member that leaves the group is a solo context again, with the same bits
+    opts[0].set_group(None)
+    _same(opts[0].LocalBundleAdjustment(windows[0]), solo[0][0], "after leaving the group")
+    # a group of one: every launch goes through the grouped kernels with a grid of one member
+    g1 = BaGroup(window_us=50.0)
+    opts[1].set_group(g1)
+    _same(opts[1].LocalBundleAdjustment(windows[1]), solo[1][0], "group of one")
+    for o in opts:
+        o.close()
+    g.close()
+    g1.close()
