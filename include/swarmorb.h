@@ -746,6 +746,13 @@ int so_track_group_pending(so_track_group* g);
 /* An opaque number that is equal for two matchers exactly when they issue their work on the same HIP stream (the rule for
  * members of one group); 0 for a null handle. */
 uint64_t so_matcher_stream_id(const so_matcher* m);
+/* Stream placement of a matcher (idle handles only).  By default the handles a thread creates share that thread's stream.
+ * so_matcher_private_stream: the handle gets a new stream of its own.  so_matcher_share_stream: the handle issues its work on
+ * `other`'s stream from now on (`other` must outlive it) - e.g. the local-mapping matchers of the agents of one GPU on ONE stream
+ * beside the tracking stream: a handful of busy streams map onto the GPU's few hardware queues without sharing one with a
+ * long chain of another agent. */
+int so_matcher_private_stream(so_matcher* m);
+int so_matcher_share_stream(so_matcher* m, const so_matcher* other);
 int so_track_group_launch(so_track_group* g);
 int so_track_group_last_kernel_ms(so_track_group* g, float* search_ms, float* pose_ms);
 /* rounds the last stage's device resolve took, and how many of its queries had candidates (diagnostics) */

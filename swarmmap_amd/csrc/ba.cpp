@@ -247,6 +247,7 @@ struct so_ba {
     so_ba_group* group = nullptr;
     BaRecorder rec;
     hipEvent_t grp_uploaded = nullptr;      // on the member's own stream: its problem is in HBM
+    hipStream_t grp_stream = nullptr;       // the group stream its round was issued on (top-ups and polls go there)
     bool grp_launched = false;              // (under the group's mutex) the round this member submitted to has been issued
     int grp_event_slot = 0;                 // which of the group's event pairs bracket that round's chain
     int done_seq = 0;                       // tags the completion words of a call (h_abort + 16)
@@ -288,22 +289,29 @@ struct so_ba {
 // as blockIdx.y - and issues everything on the group's stream.  Every member then waits for its own completion word.
 struct so_ba_group {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // rounds are issued on `streams` in turn (stream = streams[0]): a round whose members arrived
+    static constexpr int kMaxStreams = 4;  // late does not queue behind the chain of the round before
+    hipStream_t streams[kMaxStreams] = {};
+    int n_streams = 1, next_stream = 0;
     int n_members = 0;          // members registered (so_ba_set_group)
     double window_us = 250.0;   // how long the first arrival of a round waits for the rest
     std::mutex mu;
     std::condition_variable cv;
     std::vector<so_ba*> waiting;  // this round's arrivals (under mu)
     bool launching = false;       // a leader is issuing a round (the table blocks are its own until it is done)
-    void* h_rows = nullptr;       // pinned staging of the BaDev table, two halves
+    static constexpr int kRowSlots = 4;
+    void* h_rows = nullptr;       // pinned staging of the BaDev table, kRowSlots blocks used in turn
     void* d_rows = nullptr;
-    size_t rows_cap = 0;          // rows per half
+    size_t rows_cap = 0;          // rows per block
     int flip = 0;
+    hipEvent_t row_copied[kRowSlots] = {};  // behind the LAST launch of the round that used block i: both its pinned and its device half are free again
+    bool row_used[kRowSlots] = {};
     static constexpr int kEventPairs = 4;
     hipEvent_t ev[2 * kEventPairs] = {};
     int ev_next = 0;
     // statistics
     long long rounds = 0, members_total = 0, grouped_launches = 0, solo_launches = 0, rows_launched = 0;
+    bool released = false;  // so_ba_group_destroy was called: the last member to leave frees the group
 };
 
 namespace {
@@ -311,8 +319,10 @@ namespace {
 // Issue one round: the recorded chains of `mem` merged phase by phase on the group's stream.
 int ba_group_issue(so_ba_group* g, const std::vector<so_ba*>& mem) {
     SO_HIP(hipSetDevice(g->device));
-    hipStream_t gs = g->stream;
+    hipStream_t gs = g->streams[g->next_stream];
+    g->next_stream = (g->next_stream + 1) % g->n_streams;
     const int M = (int)mem.size();
+    for (so_ba* b : mem) b->grp_stream = gs;
     // stage 2: enqueue what the members' last calls needed + 2 (a stage that wants more tops itself up after its wait)
     int ahead2 = 1;
     bool any_hint_unknown = false;
@@ -343,16 +353,22 @@ int ba_group_issue(so_ba_group* g, const std::vector<so_ba*>& mem) {
     }
     if (rows.size() > g->rows_cap) {
         SO_HIP(hipStreamSynchronize(gs));  // (an earlier round may still read the old blocks)
+        for (int i = 0; i < g->n_streams; i++) SO_HIP(hipStreamSynchronize(g->streams[i]));
         if (g->h_rows) (void)hipHostFree(g->h_rows);
         if (g->d_rows) (void)hipFree(g->d_rows);
         g->h_rows = g->d_rows = nullptr;
         g->rows_cap = 0;
         const size_t cap = rows.size() + 16;
-        SO_HIP(hipHostMalloc(&g->h_rows, 2 * cap * sizeof(BaDev), hipHostMallocDefault));
-        SO_HIP(hipMalloc(&g->d_rows, 2 * cap * sizeof(BaDev)));
+        SO_HIP(hipHostMalloc(&g->h_rows, so_ba_group::kRowSlots * cap * sizeof(BaDev), hipHostMallocDefault));
+        SO_HIP(hipMalloc(&g->d_rows, so_ba_group::kRowSlots * cap * sizeof(BaDev)));
         g->rows_cap = cap;
+        for (bool& u : g->row_used) u = false;
     }
-    g->flip ^= 1;
+    // Rounds are issued without waiting for the ones before (members of different rounds overlap on the GPU's queue): a
+    // pinned block is rewritten only when the copy that read it has run, a device block only behind the kernels that read it
+    // (same stream).
+    g->flip = (g->flip + 1) % so_ba_group::kRowSlots;
+    if (g->row_used[g->flip]) SO_HIP(hipEventSynchronize(g->row_copied[g->flip]));
     BaDev* h_rows = (BaDev*)g->h_rows + (size_t)g->flip * g->rows_cap;
     BaDev* d_rows = (BaDev*)g->d_rows + (size_t)g->flip * g->rows_cap;
     memcpy(h_rows, rows.data(), rows.size() * sizeof(BaDev));
@@ -435,6 +451,8 @@ int ba_group_issue(so_ba_group* g, const std::vector<so_ba*>& mem) {
         }
     }
     SO_HIP(hipEventRecord(g->ev[2 * slot + 1], gs));
+    SO_HIP(hipEventRecord(g->row_copied[g->flip], gs));
+    g->row_used[g->flip] = true;
     SO_HIP(hipGetLastError());
     g->rounds++;
     g->members_total += M;
@@ -676,9 +694,14 @@ int so_ba_group_create(int device, double window_us, so_ba_group** out) {
     so_ba_group* g = new so_ba_group();
     g->device = device;
     if (window_us > 0.0) g->window_us = window_us;
-    hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    g->n_streams = getenv("SWARMORB_BA_GROUP_STREAMS") ? std::min((int)so_ba_group::kMaxStreams, std::max(1, atoi(getenv("SWARMORB_BA_GROUP_STREAMS")))) : 1;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < g->n_streams && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&g->streams[i], hipStreamNonBlocking);
+    g->stream = g->streams[0];
     for (hipEvent_t& ev : g->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);
+    for (hipEvent_t& ev : g->row_copied)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete g;
         return hip_fail(e, "ba group init", __FILE__, __LINE__);
@@ -687,15 +710,30 @@ int so_ba_group_create(int device, double window_us, so_ba_group** out) {
     return SO_OK;
 }
 
+static void ba_group_free(so_ba_group* g);
+
 void so_ba_group_destroy(so_ba_group* g) {
     if (!g) return;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->released = true;
+        if (g->n_members > 0) return;  // members (other threads' solver contexts) still refer to it: the last one to leave frees it
+    }
+    ba_group_free(g);
+}
+
+static void ba_group_free(so_ba_group* g) {
     (void)hipSetDevice(g->device);
-    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (int i = 0; i < g->n_streams; i++)
+        if (g->streams[i]) (void)hipStreamSynchronize(g->streams[i]);
     for (hipEvent_t ev : g->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : g->row_copied)
         if (ev) (void)hipEventDestroy(ev);
     if (g->h_rows) (void)hipHostFree(g->h_rows);
     if (g->d_rows) (void)hipFree(g->d_rows);
-    if (g->stream) (void)hipStreamDestroy(g->stream);
+    for (int i = 0; i < g->n_streams; i++)
+        if (g->streams[i]) (void)hipStreamDestroy(g->streams[i]);
     delete g;
 }
 
@@ -703,8 +741,12 @@ int so_ba_set_group(so_ba* b, so_ba_group* g) {
     if (!b || (g && g->device != b->device)) return SO_ERR_INVALID_ARG;
     if (b->group == g) return SO_OK;
     if (b->group) {
-        std::lock_guard<std::mutex> lk(b->group->mu);
-        b->group->n_members--;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(b->group->mu);
+            last = --b->group->n_members == 0 && b->group->released;
+        }
+        if (last) ba_group_free(b->group);
     }
     b->group = g;
     if (g) {
@@ -1376,7 +1418,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     if (grouped) {
         if (!b->grp_uploaded) SO_HIP(hipEventCreateWithFlags(&b->grp_uploaded, hipEventDisableTiming));
         SO_HIP(hipEventRecord(b->grp_uploaded, s));
-        s = b->group->stream;
+        s = b->group->stream;  // (until the round is issued: nothing is launched meanwhile, the chain is recorded)
         b->rec.list.clear();
         b->rec.phase = 0;
         g_ba_recorder = &b->rec;
@@ -1483,6 +1525,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         if (grouped) {  // hand the recorded chain in; back when the round it belongs to has been issued on the group's stream
             g_ba_recorder = nullptr;
             if ((rc = ba_group_submit(b))) return rc;
+            s = b->grp_stream;  // (the round's stream: what this call still launches or polls goes there)
         }
         BaLm lm;
         bool stopped_between = false, returned_early = false;

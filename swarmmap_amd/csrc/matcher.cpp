@@ -4171,6 +4171,30 @@ int so_track_group_pending(so_track_group* g) { return g ? g->n_recs : 0; }
 
 uint64_t so_matcher_stream_id(const so_matcher* m) { return m ? (uint64_t)(uintptr_t)m->stream : 0; }
 
+static int matcher_idle(so_matcher* m) { return m && !m->chain.active && m->pend.mode == 0 && !m->batching; }
+
+int so_matcher_private_stream(so_matcher* m) {
+    if (!matcher_idle(m)) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    if (m->stream) SO_HIP(hipStreamSynchronize(m->stream));
+    hipStream_t s = nullptr;
+    SO_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (m->owns_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    m->stream = s;
+    m->owns_stream = true;
+    return SO_OK;
+}
+
+int so_matcher_share_stream(so_matcher* m, const so_matcher* other) {
+    if (!matcher_idle(m) || !other || other->device != m->device || other == m) return SO_ERR_INVALID_ARG;
+    SO_HIP(hipSetDevice(m->device));
+    if (m->stream) SO_HIP(hipStreamSynchronize(m->stream));
+    if (m->owns_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    m->stream = other->stream;
+    m->owns_stream = false;
+    return SO_OK;
+}
+
 int so_track_group_launch(so_track_group* g) {
     if (!g) return SO_ERR_INVALID_ARG;
     const int n = g->n_recs;

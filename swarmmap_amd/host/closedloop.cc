@@ -685,6 +685,12 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
     st[35] = now_ms() - tp0;  // the packet
     st[31] = now_ms() - t0;   // the whole job
     if (info_out) *info_out = info;
+    static const bool job_trace = getenv("SWARMORB_CL_TRACE") != nullptr;
+    if (job_trace && timed)  // one line per job: when it began (ms, process clock) and where its time went
+        fprintf(stderr, "[job] agent %p kf_t %d begin %.3f | process %.3f tri_stage %.3f (end %.3f) triangulate %.3f fuse_stage %.3f fuse_end %.3f apply %.3f "
+                        "gather %.3f ba %.3f (gpu %.3f, trials %d) writeback %.3f (und %.3f) packet %.3f | job %.3f\n",
+                (void*)r, c->t, t0, st[24], st[kLmStageTriMs], st[36], st[kLmTriangMs], st[kLmStageFuseMs], st[kLmBatchEndMs], st[26], st[27], st[28],
+                (double)info.gpu_ms, (int)info.lm_trials, st[29], st[34], st[35], st[31]);
     {
         std::lock_guard<std::mutex> lk(r->mu);
         M.lm_log.insert(M.lm_log.end(), row, row + 12);

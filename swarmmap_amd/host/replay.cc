@@ -716,6 +716,7 @@ void so_replay_destroy(so_replay* r) {
     }
     so_extractor_group_destroy(r->fleet_group);
     so_track_group_destroy(r->fleet_track_group);
+    so_ba_group_destroy(r->fleet_ba_group);  // (freed when the last agent's solver has left it)
     for (so_dframe* f : r->fr) so_dframe_destroy(f);
     so_extractor_destroy(r->ex);
     so_matcher_destroy(r->matcher);
@@ -1633,6 +1634,8 @@ int so_replay_run_live(so_replay* r, int first_t, int n_steps, float* pose_ms, f
 // submitted before any is waited for (their kernels overlap on the agents' own streams: create the handles after
 // so_runtime_private_streams(1)), and the PoseOptimization problems of all agents go out as ONE launch (a workgroup per
 // agent).  Every agent ends up with exactly the results a solo so_replay_run gives it.
+int so_replay_drain(so_replay* r);
+
 int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int timed) {
     if (!agents || n_agents < 1) return SO_ERR_INVALID_ARG;
     for (int a = 0; a < n_agents; a++)
@@ -1705,6 +1708,23 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
     for (int a = 0; a < n_agents && chained; a++) {
         if (so_matcher_set_track_group(agents[a]->matcher, lead->fleet_track_group) != SO_OK) return fail(agents[a], "so_matcher_set_track_group");
         agents[a]->fleet_chain = true;
+    }
+    // ... and their local bundle adjustments: the agents' local-mapping threads reach so_bundle_adjust at about the same time
+    // (keyframes fall on the same frames), their LM chains go out merged (so_ba_group).  Joined once, on the fleet's first run.
+    static const bool no_ba_group = getenv("SWARMORB_FLEET_NO_BA_GROUP") != nullptr;
+    if (chained && !no_ba_group && n_agents > 1 && !lead->fleet_ba_group) {
+        const double window_us = getenv("SWARMORB_FLEET_BA_WINDOW_US") ? atof(getenv("SWARMORB_FLEET_BA_WINDOW_US")) : 600.0;
+        if (so_ba_group_create(lead->device, window_us, &lead->fleet_ba_group) == SO_OK)
+            for (int a = 0; a < n_agents; a++) so_ba_set_group(agents[a]->mapper_opt, lead->fleet_ba_group);
+    }
+    // The agents' local-mapping matchers (searches, triangulation, UpdateNormalAndDepth of all jobs) on ONE stream of their own,
+    // beside the tracking stream: created on the caller's thread they would otherwise all share the tracking stream itself.
+    static const bool no_lm_stream = getenv("SWARMORB_FLEET_NO_LM_STREAM") != nullptr;
+    if (chained && !no_lm_stream && n_agents > 1 && !lead->fleet_lm_stream_set) {
+        lead->fleet_lm_stream_set = true;
+        for (int a = 0; a < n_agents; a++) so_replay_drain(agents[a]);  // (the local-mapping threads are idle: their matchers may move)
+        if (so_matcher_private_stream(lead->mapper_matcher) == SO_OK)
+            for (int a = 1; a < n_agents; a++) so_matcher_share_stream(agents[a]->mapper_matcher, lead->mapper_matcher);
     }
     so_track_group* tg = chained ? lead->fleet_track_group : nullptr;
     auto group_launch = [&]() -> int {
@@ -1826,6 +1846,8 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
             step_end(r, t, timed);
             if (!r->error.empty()) return SO_ERR_HIP;
         }
+        static const bool tick_trace = getenv("SWARMORB_CL_TRACE") != nullptr;
+        if (tick_trace && timed) fprintf(stderr, "[tick] t %d begin %.3f end %.3f\n", t, agents[0]->step.t0, now_ms());
     }
     if (chained) return SO_OK;
     for (int t = first_t; t < first_t + n_steps; t++) {

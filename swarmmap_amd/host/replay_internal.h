@@ -210,6 +210,8 @@ struct so_replay {
     // so_fleet_run: the extractors of the fleet this agent leads, as one group (one extraction chain for all agents)
     so_extractor_group* fleet_group = nullptr;
     so_track_group* fleet_track_group = nullptr;  // (owned by the fleet's first agent) the agents' tracking stages as one chain of launches
+    so_ba_group* fleet_ba_group = nullptr;        // (owned by the fleet's first agent) the agents' local bundle adjustments as one chain of launches
+    bool fleet_lm_stream_set = false;
     bool fleet_chain = false;                     // so_fleet_run drives this agent AND its stages go out with the fleet's group
     std::vector<so_extractor*> fleet_members;
     BaWindow window;

@@ -231,13 +231,17 @@ def test_closed_loop_agents_in_lockstep_with_grouped_stages_equal_their_solo_run
         fleet.append(rp)
     Replay.fleet_run(fleet, 0, 17, True)   # (two calls: the agents join and leave the group per call)
     Replay.fleet_run(fleet, 17, n - 17, True)
-    for a, rp in enumerate(fleet):
+    for rp in fleet:
         rp.drain()
         rp.finish()
+    results = []
+    for rp in fleet:
         p = rp.log()
         p.update(rp.closed_loop_log())
-        st = rp.stats()
+        results.append((p, rp.stats()))
+    for rp in reversed(fleet):  # (the first agent owns what the fleet shares)
         rp.close()
+    for a, (p, st) in enumerate(results):
         s = solo[a]
         for k in ("poses", "kf_poses", "Tcr", "lm_log", "matches_last", "matches_map", "inliers", "n_map_points", "point_bad"):
             assert np.array_equal(s[k], p[k]), (a, k)
