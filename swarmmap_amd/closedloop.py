@@ -30,16 +30,22 @@ Monocular bookkeeping, as SwarmMap runs it:
     same one on every run), or whenever they are ready under the reference's own policy (replay.cc only: keyframes
     only when local mapping is idle, InterruptBA otherwise, Tracking.cc:810-892).
 
-Deviations of the harness from the reference, on purpose (the operators themselves are exact, call by call): a
-keyframe's searches see the map as it is when their batch is issued - the SearchForTriangulation calls the state after
-ProcessNewKeyFrame, the Fuse calls the state after CreateNewMapPoints - and their results are applied in the
-reference's order against the live state (the reference interleaves search and apply per neighbour; since its
-SearchForTriangulation never sets vbMatched2, ORBmatcher.cc:660-700, a feature's match does not depend on the others', and
-the only thing the interleaving changes for CreateNewMapPoints is which features enter a neighbour's rotation histogram);
-descriptors of map
+Batches, not deviations: a keyframe's twenty SearchForTriangulation calls and its twenty-one Fuse calls are issued against ONE
+snapshot of the map (two batches) and their results are walked in the reference's order with the reference's gates evaluated
+on the live state.  That is the reference's neighbour-by-neighbour computation (LocalMapping.cc:219-416, 451-481), not an
+approximation of it: CreateNewMapPoints' matcher is ORBmatcher(0.6, false) (:197) - no rotation histogram - and vbMatched2 is
+never set (ORBmatcher.cc:660-700), so a feature's match depends on nothing another feature or an earlier neighbour does, only
+whether the feature is still searched at all (:638-641) - the walk drops the matches of a keypoint bound earlier; Fuse's search
+(:767-861) reads positions, descriptors and keypoints, none of which SearchInNeighbors changes, and its gates (isBad,
+IsInKeyFrame, what sits at the keypoint found) are monotone, so the snapshot's valid pairs are a superset of every later
+target's.  `lm_job(..., interleaved=True)` is the literal form; tests/test_closedloop_oracle.py holds the two equal.
+
+Deviations of the harness from the reference, on purpose (the operators themselves are exact, call by call): descriptors of map
 points stay the creating keypoint's (ComputeDistinctiveDescriptors exists as an operator, so_distinctive_descriptors, but
 is not part of this loop); the local map Tracking searches is the points of the last `local_keyframes` keyframes, listed
-by local mapping when it finishes a keyframe; a frame's reference keyframe is the last keyframe created;
+by local mapping when it finishes a keyframe; a frame's reference keyframe is the last keyframe created; SearchInNeighbors'
+closing pass over the keyframe's points (ComputeDistinctiveDescriptors + UpdateNormalAndDepth, LocalMapping.cc:484-495) is left
+to local BA's write-back, which updates the normals and depths of every point it moved;
 CheckReplacedInLastFrame follows the replacement chain to its end and DROPS the last frame's binding to a bad point that
 has no replacement (a culled point), where the reference (Tracking.cc:603-614) swaps only when GetReplaced() != NULL and
 otherwise keeps the bad point bound - SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:1245-1250) has no isBad
@@ -205,7 +211,7 @@ def local_window(M, c, n_free, n_fixed):
     return prob, win, pts, (e_kf, e_idx, e_pt)
 
 
-def lm_job(M, be, c, P):
+def lm_job(M, be, c, P, interleaved=False):
     """One keyframe through local mapping.  M: LoopMap (c already appended to M.kfs); be: operator backend; P: dict of
     K, sf, inv_sigma2, log_sf, vocab, neighbours, n_free, n_fixed, local_keyframes.  Returns the packet the tracking side
     applies: first_new / n_points (rows [first_new, n_points) are new), moved (slots, X, N, mx, mn), bad (slot, replaced by),
@@ -246,92 +252,147 @@ def lm_job(M, be, c, P):
     c["fv"] = FeatureVector(np.asarray(be.assign_nodes(c["desc"], P["vocab"]), np.int32))
     ring = M.kfs[max(0, k - P["neighbours"]):k]
     # ---- CreateNewMapPoints (:207-420) ---------------------------------------------------------------------------
+    # The reference goes neighbour by neighbour: search, triangulate, AddMapPoint, next neighbour (:219-416) - a keypoint bound
+    # against neighbour j is not searched against j + 1 (ORBmatcher.cc:638-641).  Its matcher is ORBmatcher(0.6, false)
+    # (:197): no rotation histogram, and vbMatched2 is never set (ORBmatcher.cc:660-700), so a feature's match depends on
+    # nothing but the feature itself and the neighbour's bindings, which only the neighbour's own turn changes.  Searching all
+    # neighbours against ONE snapshot and creating points in the reference's order, a keypoint keeping the first point it gets,
+    # is therefore the same computation (`interleaved`: the literal form, tests/test_closedloop_oracle.py compares the two).
     n_tri = n_new = 0
     Oc = _centre(c["T"])
-    tri = []
-    for j, k2 in enumerate(ring):
+    tk = lambda q: dict(Tcw=q["T"], K=K, scale_factors=sf, level_sigma2=level_sigma2)  # noqa: E731
+    ratio_factor = float(np.float32(1.5) * np.float32(1.2))
+
+    def searchable(k2):
         O2 = _centre(k2["T"])
         d = O2 - Oc
         baseline = float(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))
-        med = _median_depth(M, k2)
-        if baseline / med < 0.01:  # (:236-241, monocular)
-            continue
+        return not (baseline / _median_depth(M, k2) < 0.01)  # (:236-241, monocular)
+
+    def search(k2):
         F12, epi = mt.fundamental_and_epipole(K, c["T"], k2["T"])
-        nm, m12 = be.search_for_triangulation(_kfeat(c), c["fv"], _kfeat(k2), k2["fv"], F12, epi, sf, level_sigma2)
-        n_tri += int(nm)
-        tri.append((j, np.asarray(m12)))
-    if tri:
+        nm, m12 = be.search_for_triangulation(_kfeat(c), c["fv"], _kfeat(k2), k2["fv"], F12, epi, sf, level_sigma2, check_ori=False)
+        return int(nm), np.asarray(m12)
+
+    def triangulate(tri):  # tri: [(neighbour index, matches12)] -> rows of accepted matches, in the reference's order
         of = np.concatenate([np.full(int((m >= 0).sum()), j, np.int32) for j, m in tri])
         i1 = np.concatenate([np.nonzero(m >= 0)[0] for _, m in tri])
         i2 = np.concatenate([m[m >= 0] for _, m in tri])
-        if len(of):
-            xy1 = np.stack([c["x"][i1], c["y"][i1]], 1)
-            xy2 = np.stack([np.array([ring[j]["x"][b] for j, b in zip(of, i2)], np.float32),
-                            np.array([ring[j]["y"][b] for j, b in zip(of, i2)], np.float32)], 1)
-            o1 = c["octave"][i1]
-            o2 = np.array([ring[j]["octave"][b] for j, b in zip(of, i2)], np.int32)
-            tk = lambda q: dict(Tcw=q["T"], K=K, scale_factors=sf, level_sigma2=level_sigma2)  # noqa: E731
-            ok, X, nrm, mxd, mnd = be.triangulate_new_points(tk(c), [tk(q) for q in ring], float(np.float32(1.5) * np.float32(1.2)),
-                                                             of, xy1, o1, xy2, o2)
-            rows = []
-            for q in range(len(of)):  # the reference's order: neighbour by neighbour, keypoint by keypoint
-                k2 = ring[of[q]]
-                if not ok[q] or c["mp"][i1[q]] >= 0 or k2["mp"][i2[q]] >= 0:
-                    continue
-                s = n_before + len(rows)
-                rows.append(q)
-                c["mp"][i1[q]] = s
-                k2["mp"][i2[q]] = s
-            if rows:
-                rows = np.array(rows)
-                M.append(X[rows], nrm[rows], mxd[rows], mnd[rows], c["desc"][i1[rows]], k,
-                         [[(k, int(i1[q])), (ring[of[q]]["id"], int(i2[q]))] for q in rows])
-                M.recent += list(range(n_before, len(M)))
-                be.map_append(M.X[n_before:], M.N[n_before:], M.mx[n_before:], M.mn[n_before:], M.D[n_before:])
-                n_new = len(rows)
+        if not len(of):
+            return of, i1, i2, None
+        xy1 = np.stack([c["x"][i1], c["y"][i1]], 1)
+        xy2 = np.stack([np.array([ring[j]["x"][b] for j, b in zip(of, i2)], np.float32),
+                        np.array([ring[j]["y"][b] for j, b in zip(of, i2)], np.float32)], 1)
+        o1 = c["octave"][i1]
+        o2 = np.array([ring[j]["octave"][b] for j, b in zip(of, i2)], np.int32)
+        return of, i1, i2, be.triangulate_new_points(tk(c), [tk(q) for q in ring], ratio_factor, of, xy1, o1, xy2, o2)
+
+    def create(of, i1, i2, res):
+        """:403-416: every match that passed the gates becomes a MapPoint observed by both keyframes.  No test of the neighbour's
+        keypoint here: two features of the keyframe matched to ONE keypoint of the neighbour both create their point and the
+        second AddMapPoint takes the neighbour's binding, as in the reference."""
+        ok, X, nrm, mxd, mnd = res
+        first = len(M)
+        rows = []
+        for q in range(len(of)):
+            if not ok[q] or c["mp"][i1[q]] >= 0:
+                continue
+            s = first + len(rows)
+            rows.append(q)
+            c["mp"][i1[q]] = s
+            ring[of[q]]["mp"][i2[q]] = s
+        if rows:
+            rows = np.array(rows)
+            M.append(X[rows], nrm[rows], mxd[rows], mnd[rows], c["desc"][i1[rows]], k,
+                     [[(k, int(i1[q])), (ring[of[q]]["id"], int(i2[q]))] for q in rows])
+            M.recent += list(range(first, len(M)))
+            be.map_append(M.X[first:], M.N[first:], M.mx[first:], M.mn[first:], M.D[first:])
+        return len(rows)
+
+    if interleaved:  # LocalMapping.cc:219-416 literally
+        for j, k2 in enumerate(ring):
+            if not searchable(k2):
+                continue
+            nm, m12 = search(k2)
+            n_tri += nm
+            of, i1, i2, res = triangulate([(j, m12)])
+            if res is not None:
+                n_new += create(of, i1, i2, res)
+    else:
+        tri = []
+        for j, k2 in enumerate(ring):
+            if searchable(k2):
+                nm, m12 = search(k2)
+                tri.append((j, m12))
+        # (a keypoint bound against an earlier neighbour would not have been searched by the reference: its later matches do
+        #  not count either)
+        if tri:
+            of, i1, i2, res = triangulate(tri)
+            taken = c["mp"] >= 0
+            for j, m12 in tri:
+                n_tri += int(((m12 >= 0) & ~taken).sum())
+                if res is not None:
+                    sel = of == j
+                    got = i1[sel][np.asarray(res[0])[sel] != 0]
+                    taken = taken.copy()
+                    taken[got] = True
+            if res is not None:
+                n_new = create(of, i1, i2, res)
     # ---- SearchInNeighbors (:423-498): Fuse into every neighbour, then the neighbours' points into this keyframe ---------
+    # ORBmatcher::Fuse's search (projection, window, best descriptor, ORBmatcher.cc:767-861) reads nothing the loop changes - a
+    # point's position and descriptor, the target's keypoints -; what changes from neighbour to neighbour is which points are
+    # still looked at (`isBad() || IsInKeyFrame(pKF)`, :782-784) and what sits at the keypoint found (:863-880).  A point valid
+    # later was valid before (bad flags and observations only grow here), so: search every (point, target) pair that is valid
+    # on the snapshot as one batch, then walk the results in the reference's order with the gates evaluated on the LIVE state.
     n_fused = n_back = 0
 
     def apply_fuse(target, slots, best):
         done = 0
         for i in np.nonzero(best >= 0)[0]:
-            p = M.resolve(int(slots[i]))
-            if p < 0:
+            p = int(slots[i])
+            if p < 0 or M.bad[p] or M.in_kf(p, target["id"]):  # ORBmatcher.cc:778-784 on the live state
                 continue
             kp = int(best[i])
             q = int(target["mp"][kp])
             if q >= 0:
-                q = M.resolve(q)
-            if q >= 0:
-                if q == p:
-                    continue
-                if len(M.obs[q]) > len(M.obs[p]):  # ORBmatcher.cc:873-878
-                    M.replace(p, q)
-                else:
-                    M.replace(q, p)
-                done += 1
+                if not M.bad[q]:
+                    if len(M.obs[q]) > len(M.obs[p]):  # :873-878
+                        M.replace(p, q)
+                    else:
+                        M.replace(q, p)
             else:
-                if M.in_kf(p, target["id"]):
-                    continue
                 M.obs[p].append((target["id"], kp))
                 target["mp"][kp] = p
-                done += 1
+            done += 1
         return done
 
-    if ring:
+    def candidates():
+        cand, seen = [], set()
+        for k2 in ring:  # vpFuseCandidates, once each (mnFuseCandidateForKF)
+            for s in k2["mp"]:
+                if s >= 0 and not M.bad[s] and s not in seen:
+                    seen.add(int(s))
+                    cand.append(int(s))
+        return np.array(cand, np.int64)
+
+    if ring and interleaved:  # LocalMapping.cc:451-481 literally: search, apply, next target
+        cs = c["mp"].copy()
+        for k2 in ring:
+            valid = np.array([1 if (s >= 0 and not M.bad[s] and not M.in_kf(s, k2["id"])) else 0 for s in cs], np.uint8)
+            _, best, _ = be.fuse_idx(mt.keyframe_view(k2, sf), K, k2["T"], log_sf, inv_sigma2, _mp_view(M, cs, valid), 3.0)
+            n_fused += apply_fuse(k2, cs, best)
+        cand = candidates()
+        validb = np.array([0 if M.in_kf(s, k) else 1 for s in cand], np.uint8)
+        _, bestb, _ = be.fuse_idx(mt.keyframe_view(c, sf), K, c["T"], log_sf, inv_sigma2, _mp_view(M, cand, validb), 3.0)
+        n_back = apply_fuse(c, cand, bestb)
+    elif ring:
         cs = c["mp"].copy()
         res = []
         for k2 in ring:
             valid = np.array([1 if (s >= 0 and not M.in_kf(s, k2["id"])) else 0 for s in cs], np.uint8)
             _, best, _ = be.fuse_idx(mt.keyframe_view(k2, sf), K, k2["T"], log_sf, inv_sigma2, _mp_view(M, cs, valid), 3.0)
             res.append(best)
-        cand, seen = [], set()
-        for k2 in ring:  # vpFuseCandidates, once each (mnFuseCandidateForKF)
-            for s in k2["mp"]:
-                if s >= 0 and s not in seen:
-                    seen.add(int(s))
-                    cand.append(int(s))
-        cand = np.array(cand, np.int64)
+        cand = candidates()
         validb = np.array([0 if M.in_kf(s, k) else 1 for s in cand], np.uint8)
         _, bestb, _ = be.fuse_idx(mt.keyframe_view(c, sf), K, c["T"], log_sf, inv_sigma2, _mp_view(M, cand, validb), 3.0)
         for k2, best in zip(ring, res):
@@ -404,7 +465,7 @@ LM_LOG_COLUMNS = ("t", "neighbours", "tri_matches", "new_points", "fused", "fuse
 
 
 def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio=0.7, delay=None, local_keyframes=12,
-          neighbours=20, n_free=25, n_fixed=40, third_pose=False, frames=None, on_frame=None, run_job=None):
+          neighbours=20, n_free=25, n_fixed=40, third_pose=False, frames=None, on_frame=None, run_job=None, interleaved=False):
     """The closed loop in the deterministic schedule.  delay: frames between a keyframe and the arrival of its
     local-mapping results in the tracked map (default kf_every).  run_job(job) -> handle with .result(): runs the
     local-mapping job elsewhere (the CPU baseline's second thread); default inline.
@@ -568,7 +629,7 @@ def track(backend, stream, n_frames, K, vocab, plane_z=2.0, kf_every=5, kf_ratio
         if keyframe:
             c = make_keyframe(t, T, kps, xy_un, desc, kp_mp, outlier, bounds)
             T_ref = mt._T44(c["T"])
-            job = (lambda c=c: lm_job(M, backend, c, P))
+            job = (lambda c=c: lm_job(M, backend, c, P, interleaved))
             pending = (t + delay, run_job(job) if run_job is not None else _Done(job()))
         Tlr = T @ np.linalg.inv(T_ref)
         poses.append(T[:3, :4].reshape(12).copy())

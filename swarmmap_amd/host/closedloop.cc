@@ -358,7 +358,11 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
         }
         if (!nbs.empty()) {
             const double tbe = now_ms();
-            if (so_search_for_triangulation_kframes(m, c->dev, free1.data(), (int32_t)nbs.size(), nbs.data(), 1) != SO_OK) return SO_ERR_HIP;
+            // mbCheckOrientation = false: CreateNewMapPoints' matcher is ORBmatcher(0.6, false), LocalMapping.cc:197 - no rotation
+            // histogram, so a feature's match depends on nothing the other features do, and the searches of all neighbours against
+            // one snapshot + creation in the reference's order below ARE the reference's neighbour-by-neighbour loop (:219-416;
+            // swarmmap_amd/closedloop.py, tests/test_closedloop_oracle.py::test_batched_searches_equal_the_reference_interleaving)
+            if (so_search_for_triangulation_kframes(m, c->dev, free1.data(), (int32_t)nbs.size(), nbs.data(), 0) != SO_OK) return SO_ERR_HIP;
             st[36] = now_ms() - tbe;  // staging of all neighbours + launch + wait + resolve
             double ms4[4] = {0};
             so_matcher_last_stats(m, ms4);
@@ -377,7 +381,6 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
         of.clear(); o1.clear(); o2.clear(); p1.clear(); p2.clear();
         for (int j = 0; j < nn; j++) {
             if (!searched[(size_t)j]) continue;
-            n_tri += tri_nm[(size_t)j];
             const KfSnap& k2 = ring(j);
             const std::vector<int32_t>& m12 = tri_m12[(size_t)j];
             for (int i = 0; i < n; i++) {
@@ -420,7 +423,13 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
             for (int q = 0; q < nt; q++) {
                 KfSnap& k2 = ring(of[(size_t)q]);
                 const size_t i1 = (size_t)i1s[(size_t)q], i2 = (size_t)i2s[(size_t)q];
-                if (!okv[(size_t)q] || c->mp[i1] >= 0 || k2.mp[i2] >= 0) continue;
+                // a keypoint bound against an earlier neighbour would not have been searched again (ORBmatcher.cc:638-641): its
+                // later matches do not exist for the reference - neither as matches (the log's count) nor as points.  No test of
+                // the neighbour's keypoint: two features matched to ONE keypoint of a neighbour both create their point, the second
+                // AddMapPoint takes the neighbour's binding (LocalMapping.cc:403-416)
+                if (c->mp[i1] >= 0) continue;
+                n_tri++;
+                if (!okv[(size_t)q]) continue;
                 const int s = L.append(&X3[3 * (size_t)q], &nrm[3 * (size_t)q], mxd[(size_t)q], mnd[(size_t)q], &c->desc[32 * i1], k);
                 M.obs[(size_t)s].emplace_back(k, (int32_t)i1);
                 M.obs[(size_t)s].emplace_back(k2.id, (int32_t)i2);
@@ -466,7 +475,7 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
                 const KfSnap& k2 = ring(j);
                 for (int i = 0; i < k2.n; i++) {
                     const int s = k2.mp[(size_t)i];
-                    if (s < 0 || M.stamp[(size_t)s] == job) continue;
+                    if (s < 0 || M.bad[(size_t)s] || M.stamp[(size_t)s] == job) continue;
                     M.stamp[(size_t)s] = job;
                     cand.push_back(s);
                 }
@@ -500,26 +509,28 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
         }
         st[kLmBatchEndMs] = now_ms() - te0;
         const double tf0 = now_ms();
+        // ORBmatcher::Fuse's search reads nothing the loop over the targets changes; what changes is which points are still looked
+        // at (isBad() || IsInKeyFrame(pKF), ORBmatcher.cc:778-784) and what sits at the keypoint found (:863-880): the batch searched
+        // every pair valid on the snapshot (a superset: bad flags and observations only grow here), the walk below applies the
+        // gates on the LIVE state in the reference's order = LocalMapping.cc:451-481 target by target
         auto apply_fuse = [&](KfSnap& target, const std::vector<int32_t>& slots, const std::vector<int32_t>& bst) {
             int64_t done = 0;
             for (size_t i = 0; i < bst.size(); i++) {
                 if (bst[i] < 0) continue;
-                const int p = L.resolve(slots[i]);
-                if (p < 0) continue;
+                const int p = slots[i];
+                if (p < 0 || M.bad[(size_t)p] || L.in_kf(p, target.id)) continue;
                 const size_t kp = (size_t)bst[i];
-                int q = target.mp[kp];
-                if (q >= 0) q = L.resolve(q);
+                const int q = target.mp[kp];
                 if (q >= 0) {
-                    if (q == p) continue;
-                    if (M.obs[(size_t)q].size() > M.obs[(size_t)p].size()) L.replace(p, q);  // ORBmatcher.cc:873-878
-                    else L.replace(q, p);
-                    done++;
+                    if (!M.bad[(size_t)q]) {
+                        if (M.obs[(size_t)q].size() > M.obs[(size_t)p].size()) L.replace(p, q);  // ORBmatcher.cc:873-878
+                        else L.replace(q, p);
+                    }
                 } else {
-                    if (L.in_kf(p, target.id)) continue;
                     M.obs[(size_t)p].emplace_back(target.id, (int32_t)kp);
                     target.mp[kp] = p;
-                    done++;
                 }
+                done++;
             }
             return done;
         };

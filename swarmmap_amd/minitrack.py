@@ -87,7 +87,12 @@ class HipBackend:
     def assign_nodes(self, desc, vocab):
         return self._lm().hamming_top2(desc, vocab)[0]
 
-    def search_for_triangulation(self, kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2):
+    def search_for_triangulation(self, kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2, check_ori=True):
+        if not check_ori:  # CreateNewMapPoints' matcher: ORBmatcher(0.6, false), LocalMapping.cc:197
+            if getattr(self, "m_tri", None) is None:
+                from .matcher import ORBmatcher
+                self.m_tri = ORBmatcher(0.6, False)
+            return self.m_tri.SearchForTriangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2)
         return self._lm().SearchForTriangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2)
 
     def fuse(self, KF, K, Tcw, log_sf, inv_sigma2, mp, th):
@@ -110,6 +115,8 @@ class HipBackend:
             o.close()
         if getattr(self, "m_lm", None) is not None:
             self.m_lm.close()
+        if getattr(self, "m_tri", None) is not None:
+            self.m_tri.close()
 
 
 def _T44(T12):

@@ -36,12 +36,18 @@ def test_closed_loop_over_the_oracle_tracks_and_keeps_its_map_consistent():
         for i in np.nonzero(kf["mp"] >= 0)[0]:
             s = int(kf["mp"][i])
             assert not M.bad[s] and (kf["id"], int(i)) in M.obs[s]
+    n_obs = n_stray = 0
     for s in range(len(M)):
         if M.bad[s]:
             assert M.obs[s] == []
         for kf, i in M.obs[s]:
-            assert M.kfs[kf]["mp"][i] == s
+            # Two features of a new keyframe matched to ONE keypoint of a neighbour both create their point (LocalMapping.cc:403-416
+            # has no test for it): the keypoint's binding is the later point's, both keep the observation, and when one of the two
+            # goes bad the binding goes with it (MapPoint::SetBadFlag -> EraseMapPointMatch(idx)).  Rare, and the reference's own.
+            n_obs += 1
+            n_stray += int(M.kfs[kf]["mp"][i]) != s
         assert len({kf for kf, _ in M.obs[s]}) == len(M.obs[s])  # one observation per keyframe
+    assert n_stray <= 0.01 * n_obs, (n_stray, n_obs)
     # the points tracking sees arrive `delay` frames after their keyframe
     assert o["n_map_points"][14] == o["n_map_points"][10] and o["n_map_points"][15] > o["n_map_points"][14]
 
@@ -59,3 +65,23 @@ def test_local_window_follows_the_reference_rules():
         s = int(pts[e_pt[e]])
         assert (int(e_kf[e]), int(e_idx[e])) in M.obs[s]
         assert prob["obs"][e, 0] == M.kfs[e_kf[e]]["x"][e_idx[e]]
+
+
+def test_batched_searches_equal_the_reference_interleaving():
+    """LocalMapping::CreateNewMapPoints searches, triangulates and binds neighbour by neighbour (code/src/LocalMapping.cc:219-416),
+    SearchInNeighbors fuses target by target with Replace / AddObservation visible to the next target (:451-481).  The product's
+    loop issues a keyframe's searches as batches against ONE snapshot and walks the results in the reference's order with the
+    gates on the live state (swarmmap_amd/closedloop.py: why that is the same computation).  Here both forms run over the CPU
+    oracle - `interleaved` is the literal one: every search sees the map as the applies before it left it - and must agree in
+    everything: poses, every row of the local-mapping log, every keyframe's final bindings, every point's flags and position."""
+    n = 62
+    _, a = _run(n, third_pose=True)
+    _, b = _run(n, third_pose=True, interleaved=True)
+    for k in ("poses", "kf_poses", "Tcr", "lm_log", "matches_last", "matches_map", "inliers", "n_map_points"):
+        assert np.array_equal(a[k], b[k]), k
+    Ma, Mb = a["map"], b["map"]
+    assert len(Ma) == len(Mb) and np.array_equal(Ma.bad, Mb.bad) and np.array_equal(Ma.repl, Mb.repl) and np.array_equal(Ma.X, Mb.X)
+    assert all(np.array_equal(x["mp"], y["mp"]) for x, y in zip(Ma.kfs, Mb.kfs))
+    assert all(x == y for x, y in zip(Ma.obs, Mb.obs))
+    lm = {k: a["lm_log"][:, i] for i, k in enumerate(closedloop.LM_LOG_COLUMNS)}
+    assert lm["tri_matches"][2:].min() > 100 and lm["fused"][3:].min() > 50 and lm["fused_back"][3:].max() > 0  # (the steps did something)

@@ -87,8 +87,8 @@ class OracleBackend:
     def assign_nodes(self, desc, vocab):
         return orc.hamming_top2(desc, vocab)[0]
 
-    def search_for_triangulation(self, kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2):
-        return orc.search_for_triangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2, True)
+    def search_for_triangulation(self, kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2, check_ori=True):
+        return orc.search_for_triangulation(kf1, fv1, kf2, fv2, F12, epipole, sf, level_sigma2, bool(check_ori))
 
     def fuse(self, KF, K, Tcw, log_sf, inv_sigma2, mp, th):
         return orc.fuse(KF, orc.camera(K), Tcw, log_sf, inv_sigma2, mp, th)[0]

@@ -83,13 +83,15 @@ def main():
     ap.add_argument("--frames-euroc", type=int, default=400)
     ap.add_argument("--frames-kitti", type=int, default=300)
     ap.add_argument("--only", default="")
+    ap.add_argument("--seed", type=int, default=20221001, help="seed of the synthetic stream (the bench's: 20221001)")
+    ap.add_argument("--swaps", default="", help="comma-separated labels to run beside as_defined (default: all)")
     args = ap.parse_args()
-    out = {"what": __doc__.split("\n\n")[1].replace("\n", " "), "streams": {}}
+    out = {"what": __doc__.split("\n\n")[1].replace("\n", " "), "seed": args.seed, "streams": {}}
     for name, size, K, dist, nfeat, n in (("euroc_752x480", synth.EUROC, synth.EUROC_K, synth.EUROC_DIST, 1000, args.frames_euroc),
                                           ("kitti_1241x376", synth.KITTI, synth.KITTI_K, None, 2000, args.frames_kitti)):
         if args.only and args.only not in name:
             continue
-        st = synth.FrameStream(seed=20221001, size=size, K=K, dist=dist)
+        st = synth.FrameStream(seed=args.seed, size=size, K=K, dist=dist)
         frames = [st.frame(t) for t in range(n)]
         gt = minitrack.ground_truth(st, n, K, PLANE_Z)
         px = PLANE_Z / float(K[0])
@@ -98,6 +100,8 @@ def main():
         for label, flags, text in SWAPS:
             if dist is None and flags == 32:
                 continue  # (no lens model: nothing to undistort)
+            if args.swaps and flags != 0 and label not in args.swaps.split(","):
+                continue
             t0 = time.perf_counter()
             set_convention(flags)
             tr = run_chain(frames, K, dist, nfeat)
