@@ -565,7 +565,7 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
             so_bundle_adjust_set_solve_timing(r->mapper_opt, (r->lba_windows_run++ % 8) == 0);  // (event-timed solves take the stage-by-stage path: one window in eight)
             M.stop = 0;  // mbAbortBA = false (LocalMapping.cc:77)
             const double tb0 = now_ms();
-            if (so_bundle_adjust(r->mapper_opt, &p, &opt, &M.stop, r->ba_Tcw.data(), r->ba_Xw.data(), r->ba_out.data(), nullptr, &info) != SO_OK)
+            if (so_bundle_adjust(r->mapper_opt, &p, &opt, M.stop_flag(), r->ba_Tcw.data(), r->ba_Xw.data(), r->ba_out.data(), nullptr, &info) != SO_OK)
                 return SO_ERR_HIP;
             st[28] = now_ms() - tb0;  // the solver call
             const double tw0 = now_ms();

@@ -813,8 +813,12 @@ int so_replay_set_track_chain(so_replay* r, int on) {
 int so_replay_set_closed_loop(so_replay* r, int kf_every, int delay, int n_free, int n_fixed, int policy) {
     if (!r || r->n_tracked > 0 || r->vocab.empty() || r->local_keyframes <= 0 || kf_every < 1 || delay < 1 || n_free < 1 || n_fixed < 0)
         return SO_ERR_INVALID_ARG;
-    r->cl.reset(new ClosedLoop());
-    r->cl->kf_every = kf_every; r->cl->delay = delay; r->cl->n_free = n_free; r->cl->n_fixed = n_fixed; r->cl->policy = policy ? 1 : 0;
+    std::unique_ptr<ClosedLoop> cl(new ClosedLoop());
+    cl->kf_every = kf_every; cl->delay = delay; cl->n_free = n_free; cl->n_fixed = n_fixed; cl->policy = policy ? 1 : 0;
+    {   // the local-mapping thread exists since so_replay_create and looks at r->cl under this mutex (found by `make host-tsan`)
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->cl = std::move(cl);
+    }
     return SO_OK;
 }
 // counts[0..7]: local-mapping jobs, windows solved, windows aborted by the stop flag, InterruptBA calls, map slots, bad

@@ -141,7 +141,9 @@ struct ClosedLoop {
     std::deque<LmPacket> outbox;
     bool failed = false;        // under `mu`: a local-mapping job ended in an error (so_replay::error, written under so_replay::mu,
                                 // is NOT read by the waiting tracking thread: that was a race on a std::string and a lost wake-up)
-    volatile uint8_t stop = 0;  // mbAbortBA
+    std::atomic<uint8_t> stop{0};  // mbAbortBA: set by the tracking thread (InterruptBA), cleared by the local-mapping thread before a window,
+                                   // polled by so_bundle_adjust through the ABI's `const volatile uint8_t*` (stop_flag())
+    const volatile uint8_t* stop_flag() const { return reinterpret_cast<const volatile uint8_t*>(&stop); }
 };
 // What the local-mapping thread keeps of a tracked frame that became a keyframe (KeyFrame::KeyFrame(Frame&, ...),
 // code/src/KeyFrame.cc:47-72): keypoints, descriptors, pose, bindings to map points that existed before the frame
