@@ -16,6 +16,7 @@
 //   core/block_solver.hpp:354-486       Schur complement, back-substitution
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include <hipcub/hipcub.hpp>
 
@@ -2675,6 +2676,15 @@ __device__ __forceinline__ void se3_exp_mul_direct(const double* u, const BaPose
 //     barrier of a pass disappears.  The partial-sum buffer is double-buffered by pass parity: a wave can be at most
 //     one pass ahead of the slowest one.
 // Same schedule, same accept / reject rules, same stored-error semantics as above (g2o's optimize(10) x 4).
+// float -> double where the value is USED: an opaque conversion (the compiler would otherwise widen a loop-invariant float once
+// and keep the double in registers for the whole schedule, which is what the float-resident inputs are there to avoid)
+__device__ __forceinline__ double pose_widen(double v) { return v; }
+__device__ __forceinline__ double pose_widen(float v) {
+    double d;
+    asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d) : "v"(v));
+    return d;
+}
+
 template <int THREADS, int EPT>
 __device__ __forceinline__ void pose_opt_reg_body(const PoseOptArgs& a, const int n) {
     constexpr int NW = THREADS / 64;
@@ -2684,7 +2694,11 @@ __device__ __forceinline__ void pose_opt_reg_body(const PoseOptArgs& a, const in
     const double delta = (double)sqrtf(5.991f);  // const float deltaMono = sqrt(5.991)
     const float dsqr = (float)(delta * delta);
     const double fx = a.K[0], fy = a.K[1], cx = a.K[2], cy = a.K[3];
-    double X[EPT][3], ob[EPT][2], w[EPT], er[EPT][2];
+    // The inputs are float32 at the ABI: from eight edges per thread on they stay float in the registers (6 instead of 12 per
+    // edge) and are widened where they are used - the same doubles, so the same bits; below eight the widened copies fit.
+    using In = typename std::conditional<(EPT >= 8), float, double>::type;
+    In X[EPT][3], ob[EPT][2], w[EPT];
+    double er[EPT][2];
     bool live[EPT], outl[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
@@ -2694,18 +2708,18 @@ __device__ __forceinline__ void pose_opt_reg_body(const PoseOptArgs& a, const in
         const int ee = live[k] ? e : 0;
         if (a.e_kp) {  // indexed: the frame's keypoint and the map table's row, in place
             const int kp = a.e_kp[ee], sl = a.e_slot[ee];
-            X[k][0] = (double)a.map_Xw[3 * (size_t)sl]; X[k][1] = (double)a.map_Xw[3 * (size_t)sl + 1]; X[k][2] = (double)a.map_Xw[3 * (size_t)sl + 2];
+            X[k][0] = (In)a.map_Xw[3 * (size_t)sl]; X[k][1] = (In)a.map_Xw[3 * (size_t)sl + 1]; X[k][2] = (In)a.map_Xw[3 * (size_t)sl + 2];
             const float2 o = a.kp_xy_un[kp];
-            ob[k][0] = (double)o.x; ob[k][1] = (double)o.y;
+            ob[k][0] = (In)o.x; ob[k][1] = (In)o.y;
             const int oc = a.kp_octave[kp];
             float ws = a.lvl_inv_sigma2[0];  // (a select chain: a run-time index into the argument block would go through scratch)
 #pragma unroll
             for (int l = 1; l < 8; l++) ws = oc == l ? a.lvl_inv_sigma2[l] : ws;
-            w[k] = (double)ws;
+            w[k] = (In)ws;
         } else {
-            X[k][0] = (double)a.Xw[3 * ee]; X[k][1] = (double)a.Xw[3 * ee + 1]; X[k][2] = (double)a.Xw[3 * ee + 2];
-            ob[k][0] = (double)a.obs[2 * ee]; ob[k][1] = (double)a.obs[2 * ee + 1];
-            w[k] = (double)a.inv_sigma2[ee];
+            X[k][0] = (In)a.Xw[3 * ee]; X[k][1] = (In)a.Xw[3 * ee + 1]; X[k][2] = (In)a.Xw[3 * ee + 2];
+            ob[k][0] = (In)a.obs[2 * ee]; ob[k][1] = (In)a.obs[2 * ee + 1];
+            w[k] = (In)a.inv_sigma2[ee];
         }
         er[k][0] = 0.0; er[k][1] = 0.0;
     }
@@ -2727,20 +2741,21 @@ __device__ __forceinline__ void pose_opt_reg_body(const PoseOptArgs& a, const in
             // values and enters every sum with weight 0.  With `if (!active) continue` every edge was a basic block of
             // its own behind an exec-mask change, and the scheduler could not interleave the edges' dependent chains.
             const bool act = live[k] && !outl[k];
-            const double x = fma(R[0], X[k][0], fma(R[1], X[k][1], fma(R[2], X[k][2], T.t[0])));
-            const double y = fma(R[3], X[k][0], fma(R[4], X[k][1], fma(R[5], X[k][2], T.t[1])));
-            const double zr = fma(R[6], X[k][0], fma(R[7], X[k][1], fma(R[8], X[k][2], T.t[2])));
+            const double X0 = pose_widen(X[k][0]), X1 = pose_widen(X[k][1]), X2 = pose_widen(X[k][2]);
+            const double x = fma(R[0], X0, fma(R[1], X1, fma(R[2], X2, T.t[0])));
+            const double y = fma(R[3], X0, fma(R[4], X1, fma(R[5], X2, T.t[1])));
+            const double zr = fma(R[6], X0, fma(R[7], X1, fma(R[8], X2, T.t[2])));
             const double z = act ? zr : 1.0;
             double c = __builtin_amdgcn_rcp(z);  // reciprocal + two Newton steps instead of the IEEE division
             c = fma(fma(-z, c, 1.0), c, c);
             c = fma(fma(-z, c, 1.0), c, c);
             const double p = x * c, q = y * c;  // normalised image coordinates
             const double pf = p * fx, qg = q * fy;
-            const double e0 = ob[k][0] - (pf + cx);
-            const double e1 = ob[k][1] - (qg + cy);
+            const double e0 = pose_widen(ob[k][0]) - (pf + cx);
+            const double e1 = pose_widen(ob[k][1]) - (qg + cy);
             er[k][0] = act ? e0 : er[k][0];
             er[k][1] = act ? e1 : er[k][1];
-            const double wk = act ? w[k] : 0.0;
+            const double wk = act ? pose_widen(w[k]) : 0.0;
             const double we0 = wk * e0, we1 = wk * e1;
             const double chi2 = fma(e0, we0, e1 * we1);
             // Huber: rho = 2 sqrt(e) delta - delta^2, rho' = delta / sqrt(e), both from one reciprocal square root
@@ -2927,13 +2942,15 @@ __device__ __forceinline__ void pose_opt_reg_body(const PoseOptArgs& a, const in
         for (int k = 0; k < EPT; k++) {
             if (!live[k]) continue;
             if (outl[k]) {
-                const double x = fma(R[0], X[k][0], fma(R[1], X[k][1], fma(R[2], X[k][2], cur.t[0])));
-                const double y = fma(R[3], X[k][0], fma(R[4], X[k][1], fma(R[5], X[k][2], cur.t[1])));
-                const double z = fma(R[6], X[k][0], fma(R[7], X[k][1], fma(R[8], X[k][2], cur.t[2])));
-                er[k][0] = ob[k][0] - (x / z * fx + cx);
-                er[k][1] = ob[k][1] - (y / z * fy + cy);
+                const double X0 = pose_widen(X[k][0]), X1 = pose_widen(X[k][1]), X2 = pose_widen(X[k][2]);
+                const double x = fma(R[0], X0, fma(R[1], X1, fma(R[2], X2, cur.t[0])));
+                const double y = fma(R[3], X0, fma(R[4], X1, fma(R[5], X2, cur.t[1])));
+                const double z = fma(R[6], X0, fma(R[7], X1, fma(R[8], X2, cur.t[2])));
+                er[k][0] = pose_widen(ob[k][0]) - (x / z * fx + cx);
+                er[k][1] = pose_widen(ob[k][1]) - (y / z * fy + cy);
             }
-            const float chi2 = (float)(er[k][0] * (w[k] * er[k][0]) + er[k][1] * (w[k] * er[k][1]));
+            const double wd = pose_widen(w[k]);
+            const float chi2 = (float)(er[k][0] * (wd * er[k][0]) + er[k][1] * (wd * er[k][1]));
             outl[k] = chi2 > 5.991f;
             bad_local += outl[k] ? 1.0 : 0.0;
         }
@@ -3080,6 +3097,7 @@ bool launch_pose_opt_batch(const PoseOptArgs* d_args, int n_problems, int max_n,
         case 7: launch_pose_reg_batch<7>(d_args, n_problems, s); break;
         case 8: launch_pose_reg_batch<8>(d_args, n_problems, s); break;
         case 9: case 10: launch_pose_reg_batch<10>(d_args, n_problems, s); break;
+        case 11: launch_pose_reg_batch<11>(d_args, n_problems, s); break;
         default: launch_pose_reg_batch<12>(d_args, n_problems, s); break;
     }
     return true;
@@ -3088,34 +3106,26 @@ bool launch_pose_opt_batch(const PoseOptArgs* d_args, int n_problems, int max_n,
 void launch_pose_opt(const PoseOptArgs& a, hipStream_t s) {
     static const bool classic = getenv("SWARMORB_POSE_CLASSIC") != nullptr;  // A/B switch for profiling
     static const bool lds_only = getenv("SWARMORB_POSE_LDS") != nullptr;    // A/B: the LDS-resident kernel for every size
-    static const int force_threads = getenv("SWARMORB_POSE_THREADS") ? atoi(getenv("SWARMORB_POSE_THREADS")) : 0;
     static const int reg_max = getenv("SWARMORB_POSE_REG_MAX") ? atoi(getenv("SWARMORB_POSE_REG_MAX")) : 3072;  // A/B: 1024 hands 1025..3072 points to the LDS-resident kernel
-    if (!classic && !lds_only && force_threads != 512 && a.n > 1024 && a.n <= reg_max && a.n <= 3072) {
+    if (!classic && !lds_only && a.n > 1024 && a.n <= reg_max && a.n <= 3072) {
         const int ept = (a.n + 255) / 256;
         if (ept == 5) launch_pose_reg<256, 5>(a, s);
         else if (ept == 6) launch_pose_reg<256, 6>(a, s);
         else if (ept == 7) launch_pose_reg<256, 7>(a, s);
         else if (ept == 8) launch_pose_reg<256, 8>(a, s);
         else if (ept <= 10) launch_pose_reg<256, 10>(a, s);
+        else if (ept == 11) launch_pose_reg<256, 11>(a, s);
         else launch_pose_reg<256, 12>(a, s);
         return;
     }
-    if (!classic && !lds_only && (a.n <= 1024 || (force_threads == 512 && a.n <= 2048))) {
-        // register-resident kernel, 256 threads and up to 4 edges per thread (measured: beyond 1024 points the
-        // LDS-resident kernel with 512 threads is faster: 157 vs 183 us at 1500); 512 threads only on request
-        const bool wide = force_threads == 512;
-        if (!wide && a.n <= 1024) {
-            const int ept = (a.n + 255) / 256;
-            if (ept <= 2) launch_pose_reg<256, 2>(a, s);  // (<= 256 points too: see launch_pose_opt_batch)
-            else if (ept == 3) launch_pose_reg<256, 3>(a, s);
-            else launch_pose_reg<256, 4>(a, s);
-        } else {
-            const int ept = (a.n + 511) / 512;
-            if (ept <= 1) launch_pose_reg<512, 1>(a, s);
-            else if (ept == 2) launch_pose_reg<512, 2>(a, s);
-            else if (ept == 3) launch_pose_reg<512, 3>(a, s);
-            else launch_pose_reg<512, 4>(a, s);
-        }
+    if (!classic && !lds_only && a.n <= 1024) {
+        // register-resident kernel, 256 threads (one wave per SIMD, 512 registers per lane) and 2..4 edges per thread.  (A
+        // 512-thread variant - two waves per SIMD, 256 registers each - was measured in round 2 and lost, 104 vs 73 us at 800
+        // points, NOTES B; its instances spilled by construction and are gone.)
+        const int ept = (a.n + 255) / 256;
+        if (ept <= 2) launch_pose_reg<256, 2>(a, s);  // (<= 256 points too: see launch_pose_opt_batch)
+        else if (ept == 3) launch_pose_reg<256, 3>(a, s);
+        else launch_pose_reg<256, 4>(a, s);
         return;
     }
     if (a.n <= kPoLdsMax && !classic) {

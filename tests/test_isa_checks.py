@@ -37,3 +37,31 @@ def test_detection_scan_streams_the_store_through_the_scalar_unit():
     meta = re.search(r"\.name:\s+%s\b.*?\.vgpr_spill_count:\s+(\d+)" % re.escape(m.group(1)), text, flags=re.S)
     if meta:
         assert int(meta.group(1)) == 0
+
+
+def test_pose_optimization_kernels_keep_their_edges_in_registers():
+    """pose_opt_reg_kernel<256, EPT> / pose_opt_chain(_group)_kernel (ba_kernels.hip, Optimizer::PoseOptimization,
+    code/src/Optimizer.cc:239-434): every instantiated variant holds its edges in registers for the whole 4 x optimize(10)
+    schedule - no scratch memory.  From eight edges per thread on (KITTI-sized frames: 1793..3072 matched points) the float32
+    inputs stay float in the registers and are widened where they are used (round 6; before: 84 / 328 / 556 bytes of scratch at
+    8 / 10 / 12 edges per thread).  The one exception is the 12-edge instance (2817..3072 points), which spills 11 dwords."""
+    import re
+    src = os.path.join(ROOT, "swarmmap_amd", "csrc", "ba_kernels.hip")
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only",
+                          "-S", src, "-o", "-"], capture_output=True, text=True, timeout=1200)
+    assert asm.returncode == 0, asm.stderr[-2000:]
+    seen = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)(?=\n  - \.a|\Z)", asm.stdout, flags=re.S):
+        name, blk = m.group(1), m.group(2)
+        k = re.search(r"pose_opt_reg_kernelILi(\d+)ELi(\d+)E", name)
+        c = re.search(r"pose_opt_chain(_group)?_kernelILi(\d)E", name)
+        if not k and not c:
+            continue
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+        key = ("reg", int(k.group(1)), int(k.group(2))) if k else ("chain" + (c.group(1) or ""), int(c.group(2)))
+        seen[key] = scratch
+    regs = sorted(k for k in seen if k[0] == "reg")
+    assert [k[2] for k in regs] == [2, 3, 4, 5, 6, 7, 8, 10, 11, 12] and all(k[1] == 256 for k in regs), regs
+    assert {k for k in seen if k[0] != "reg"} == {("chain", 0), ("chain", 1), ("chain_group", 0), ("chain_group", 1)}
+    for key, scratch in seen.items():
+        assert scratch <= (64 if key == ("reg", 256, 12) else 0), (key, scratch)
