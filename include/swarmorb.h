@@ -752,6 +752,7 @@ uint64_t so_matcher_stream_id(const so_matcher* m);
  * beside the tracking stream: a handful of busy streams map onto the GPU's few hardware queues without sharing one with a
  * long chain of another agent. */
 int so_matcher_private_stream(so_matcher* m);
+int so_map_share_stream(so_map* map, const so_matcher* with); /* the table's (synchronous) writes go out on that matcher's stream */
 int so_matcher_share_stream(so_matcher* m, const so_matcher* other);
 int so_track_group_launch(so_track_group* g);
 int so_track_group_last_kernel_ms(so_track_group* g, float* search_ms, float* pose_ms);

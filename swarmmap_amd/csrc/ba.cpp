@@ -1142,6 +1142,14 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
 
     if (!b->stream) SO_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     hipStream_t s = b->stream;
+    // A member of a so_ba_group uploads on the group's stream (stream order puts the upload in front of its chain; one busy stream
+    // fewer per agent: INTEGRATION.md 3e).  SWARMORB_BA_GROUP_OWN_UPLOAD=1: on the member's own stream, behind an event.
+    static const bool own_upload = getenv("SWARMORB_BA_GROUP_OWN_UPLOAD") != nullptr;
+    // (the same conditions as `grouped` below: a local window - at most 43 free keyframes, hence neither the blocked nor the
+    //  pair-list path - on the single-enqueue path)
+    const bool upload_on_group = b->group != nullptr && !own_upload && !b->solve_timing && getenv("SWARMORB_BA_NO_CHAIN") == nullptr &&
+                                 nf <= kBaSmallSolverMaxFree && (nf + (nE > 0 ? 1 : 0)) != 0;
+    if (upload_on_group) s = b->group->stream;
     SO_HIP(hipMemcpyAsync(b->d_in.p, b->h_in, L.total, hipMemcpyHostToDevice, s));
     const size_t sE = (size_t)nE, sL = (size_t)std::max(nL, 1), sF = (size_t)std::max(nf, 1), n = 6 * sF;
     if ((rc = b->d_pose1.ensure(sizeof(BaPose) * (size_t)std::max(nP, 1)))) return rc;
@@ -1417,7 +1425,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     } recorder_scope;
     if (grouped) {
         if (!b->grp_uploaded) SO_HIP(hipEventCreateWithFlags(&b->grp_uploaded, hipEventDisableTiming));
-        SO_HIP(hipEventRecord(b->grp_uploaded, s));
+        SO_HIP(hipEventRecord(b->grp_uploaded, s));  // (on the group's stream already unless SWARMORB_BA_GROUP_OWN_UPLOAD: then the round waits for it)
         s = b->group->stream;  // (until the round is issued: nothing is launched meanwhile, the chain is recorded)
         b->rec.list.clear();
         b->rec.phase = 0;

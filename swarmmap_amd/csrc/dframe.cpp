@@ -410,10 +410,26 @@ int so_map_create(int device, so_map** out) {
     return SO_OK;
 }
 
+// The table's writes (so_map_write / _write_positions / _write_rows: a copy or one launch, synchronous) on a matcher's stream
+// instead of a stream of the table's own: with several agents per GPU every busy stream beyond the runtime's hardware queues
+// shares a queue with somebody's long chain of launches.  The matcher must outlive the table's last write.
+int so_map_share_stream(so_map* m, const so_matcher* with) {
+    if (!m || !with) return SO_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)(uintptr_t)so_matcher_stream_id(with);
+    if (!s) return SO_ERR_INVALID_ARG;
+    (void)hipSetDevice(m->device);
+    std::unique_lock<std::shared_timed_mutex> lk(m->grow_mu);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->stream && m->owns_stream) (void)hipStreamDestroy(m->stream);
+    m->stream = s;
+    m->owns_stream = false;
+    return SO_OK;
+}
+
 void so_map_destroy(so_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    if (m->stream) {
+    if (m->stream && m->owns_stream) {
         (void)hipStreamSynchronize(m->stream);
         (void)hipStreamDestroy(m->stream);
     }

@@ -82,4 +82,5 @@ struct so_map {
     void* h_stage = nullptr;    // pinned
     size_t h_stage_cap = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;    // false after so_map_share_stream: the writes go out on a matcher's stream
 };

@@ -1727,8 +1727,12 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
     if (chained && !no_lm_stream && n_agents > 1 && !lead->fleet_lm_stream_set) {
         lead->fleet_lm_stream_set = true;
         for (int a = 0; a < n_agents; a++) so_replay_drain(agents[a]);  // (the local-mapping threads are idle: their matchers may move)
-        if (so_matcher_private_stream(lead->mapper_matcher) == SO_OK)
+        if (so_matcher_private_stream(lead->mapper_matcher) == SO_OK) {
             for (int a = 1; a < n_agents; a++) so_matcher_share_stream(agents[a]->mapper_matcher, lead->mapper_matcher);
+            // ... and the map tables' (synchronous, rare) writes with them: a stream per table is eight more busy streams
+            static const bool own_map_streams = getenv("SWARMORB_FLEET_MAP_STREAMS") != nullptr;
+            for (int a = 0; a < n_agents && !own_map_streams; a++) so_map_share_stream(agents[a]->map, lead->mapper_matcher);
+        }
     }
     so_track_group* tg = chained ? lead->fleet_track_group : nullptr;
     auto group_launch = [&]() -> int {
