@@ -161,6 +161,7 @@ int so_matcher_reserve(so_matcher*, int32_t) { return SO_OK; }
 int so_matcher_set_profiling(so_matcher*, int) { return SO_OK; }
 int so_matcher_private_stream(so_matcher*) { return SO_OK; }
 int so_matcher_share_stream(so_matcher*, const so_matcher*) { return SO_OK; }
+int so_map_share_stream(so_map*, const so_matcher*) { return SO_OK; }
 uint64_t so_matcher_stream_id(const so_matcher*) { return 1; }
 int so_matcher_set_track_group(so_matcher*, so_track_group*) { return SO_OK; }
 int so_matcher_batch_begin(so_matcher* m) { m->batching = true; return SO_OK; }
