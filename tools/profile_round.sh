@@ -7,6 +7,8 @@ out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+cp profiles/last_bench_full.json $out/${tag}_bench_full.json   # (the profiler passes below overwrite profiles/last_bench_full.json with their own, slower, runs)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_driver_args.json 2>> $out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag} -- python3 bench.py --steps 200 --no-cpu-baseline --no-configs > $out/${tag}_prof.log 2>&1
 f=$(find $out/prof_${tag} -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats.csv
