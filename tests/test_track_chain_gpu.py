@@ -77,6 +77,23 @@ def test_last_frame_stage_equals_search_plus_pose(S, oracle, seed, dist):
         for k in ("kp_to_q", "edge_kp", "edge_outlier", "Tcw", "in_view"):
             assert np.array_equal(a_dev[k], a_host[k]), k
         assert a_dev["nmatches"] == a_host["nmatches"] and a_dev["n_inliers"] == a_host["n_inliers"]
+        # The host changed the bindings after the last-frame stage (a bad point dropped by SearchLocalPoints' isBad test, a
+        # fall-back onto TrackReferenceKeyFrame, a wider re-search: host/glue/Tracking_glue.cc): the device copy is stale.  With
+        # so_track_stage_invalidate the flag no longer matters - the stage uploads the host bindings - and the result is the one
+        # of an honest flag 0; WITHOUT it a flag 1 would silently optimise over the stale edges (the advisor's round-5 finding).
+        r = dfm.track_stage_last_frame(m, cur, last, dmap, Tc, slot, th, K4, INV_SIGMA2)
+        changed = bound.copy()
+        changed[np.nonzero(changed >= 0)[0][::3]] = -1
+        skip2 = np.zeros(len(Xw), np.uint8); skip2[changed[changed >= 0]] = 1
+        m._lib.so_track_stage_invalidate.argtypes = [__import__("ctypes").c_void_p]
+        assert m._lib.so_track_stage_invalidate(m._h) == 0
+        a_inv = dfm.track_stage_local_map(m, cur, changed, dmap, r["Tcw"], len(Xw), 1.0, 0.5, LOG_SF, K4, INV_SIGMA2, skip=skip2,
+                                          kp_slot_is_last_stage=True)
+        r = dfm.track_stage_last_frame(m, cur, last, dmap, Tc, slot, th, K4, INV_SIGMA2)
+        a_ref = dfm.track_stage_local_map(m, cur, changed, dmap, r["Tcw"], len(Xw), 1.0, 0.5, LOG_SF, K4, INV_SIGMA2, skip=skip2)
+        for k in ("kp_to_q", "edge_kp", "edge_outlier", "Tcw", "in_view"):
+            assert np.array_equal(a_inv[k], a_ref[k]), k
+        assert not np.array_equal(a_ref["edge_kp"], a_host["edge_kp"])  # (the changed bindings are a different pose problem)
         m.close()
     dmap.close(); cur.close(); last.close(); ex.close()
 
