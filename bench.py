@@ -62,6 +62,29 @@ SEED_BASE = int(os.environ.get("SWARMORB_BENCH_SEED", "20221001"))  # the synthe
 CL_N_FREE, CL_N_FIXED = 25, 40  # caps of a window's free / fixed keyframes (LBA-M's proportions)
 
 
+def cgroup_cpu():
+    """(usage_usec, nr_throttled, throttled_usec) of this container's CPU controller, or None: the GPU boxes cap a container at
+    a CPU quota (cpu.max), and threads that spin while they wait count against it."""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d["usage_usec"]), int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def cgroup_delta(a, b, dt):
+    if a is None or b is None:
+        return None
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return {"cpu_cores_used": (b[0] - a[0]) * 1e-6 / dt, "cpu_quota_cores": quota, "throttled_periods": b[1] - a[1],
+            "throttled_thread_ms": (b[2] - a[2]) * 1e-3}
+
+
 def level_pixels(inv_scale, w, h):
     """Sum of pyramid level pixels = bytes the FAST kernel must read at least once."""
     return int(sum(int(np.rint(np.float32(w) * s)) * int(np.rint(np.float32(h) * s)) for s in inv_scale))
@@ -252,12 +275,14 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
             rp.drain()
             rp.set_profiling(False)
         barrier()
+        cg0 = cgroup_cpu()
         t0 = time.perf_counter()
         Replay.fleet_run(fleet, warmup, steps, True)
         for rp in fleet:
             rp.drain()  # every queued window is optimised inside the timed region
         barrier()
         dt = time.perf_counter() - t0
+        cg = cgroup_delta(cg0, cgroup_cpu(), dt)
     else:
         raise RuntimeError("internal: fleets of several driving threads are built by run_fleet_threads")
     results = []
@@ -272,7 +297,7 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
         rp.close()
     stats = {k: sum(r[0][k] for r in results) / agents for k in results[0][0] if k not in ("stages", "frame_ms")}
     stats["frame_ms"] = np.concatenate([np.asarray(r[0]["frame_ms"])[-steps:] for r in results])
-    stats.update({"n_xchg": 0, "xchg_ms": 0.0, "lm": fleet_lm, "closed": closed})
+    stats.update({"n_xchg": 0, "xchg_ms": 0.0, "lm": fleet_lm, "closed": closed, "cgroup": cg})
     if closed:
         stats.update({"cl": cl0, "stream": streams[0], "timed_from": warmup})
     return dt, stats, results[0][1], keep[0][1], results[0][2]
@@ -340,10 +365,12 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
             gate.wait()
         elif tag == "warm":
             barrier()
+            clock["cg0"] = cgroup_cpu()
             clock["t0"] = time.perf_counter()
         elif tag == "done":
             barrier()  # (the frame submitted ahead by the last step finishes inside the timed region too)
             clock["dt"] = time.perf_counter() - clock["t0"]
+            clock["cg"] = cgroup_delta(clock["cg0"], cgroup_cpu(), clock["dt"])
 
     def agent(a):
         # created in the thread that runs it: the library gives every thread its own tracking streams
@@ -436,11 +463,13 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
         try:
             gate.wait()
             barrier()
+            clock["cg0"] = cgroup_cpu()
             t0 = time.perf_counter()
             gate.wait()
             gate.wait()
             barrier()  # (the frames submitted ahead by the last steps finish inside the timed region too)
             dt = time.perf_counter() - t0
+            clock["cg"] = cgroup_delta(clock["cg0"], cgroup_cpu(), dt)
         except threading.BrokenBarrierError:
             raise errors[0] if errors else RuntimeError("an agent thread failed")
         for th in threads:
@@ -451,6 +480,7 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
     stats["frame_ms"] = np.concatenate([np.asarray(r[0]["frame_ms"])[-steps:] for r in results])  # timed frames of every agent
     stats.update(acc_x)
     stats["closed"] = closed
+    stats["cgroup"] = clock.get("cg")
     return dt, stats, results[0][1], frame_sets[0][1], results[0][2]
 
 
@@ -903,7 +933,7 @@ def headline(full, full_path):
                        for r in (full["roofline_secondary"], full["roofline_tertiary"])}
     head = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data")}
-    head.update({"fps_per_agent": full["fps_per_agent"], "agents_per_gpu": full["agents_per_gpu"], "host_loop": full["host_loop"],
+    head.update({"fps_per_agent": full["fps_per_agent"], "agents_per_gpu": full["agents_per_gpu"], "host_loop": full["host_loop"], "host_cpu": full.get("host_cpu"),
                  "launch": full["launch"][:120], "config": hconfig, "roofline": hroof})
     if "cpu_baseline" in full:
         c = full["cpu_baseline"]
@@ -1109,6 +1139,7 @@ def main():
             "host_loop": "c++ (swarmmap_amd/host/replay.cc)" + (", %d agents in lockstep on one thread (so_fleet_run)" % A
                                                                   if args.lockstep and A > 1 else ""),
             "fps_per_agent": steps / dt, "agents_per_gpu": A,
+            "host_cpu": st.get("cgroup"),  # cores used / the container's quota / CFS throttling inside the timed region
             "pinned_cpus": None if not pinned_cpus else ",".join(_cpu_ranges(pinned_cpus)),
             "config": dict({
                 "workload": ("BASELINE.json configs[1]+[2] on one GPU per agent: 752x480 EuRoC-sized stream seen through "

@@ -382,6 +382,7 @@ int ba_group_issue(so_ba_group* g, const std::vector<so_ba*>& mem) {
     SO_HIP(hipEventRecord(g->ev[2 * slot], gs));
     // merge: phases in ascending order; inside a phase the members' launches are aligned by their position in it
     std::vector<size_t> pos((size_t)M, 0);
+    long long n_grouped = 0, n_solo = 0, n_rows = 0;
     for (;;) {
         int phase = INT_MAX;
         for (int m = 0; m < M; m++) {
@@ -422,7 +423,7 @@ int ba_group_issue(so_ba_group* g, const std::vector<so_ba*>& mem) {
                     const BaLaunchRec& R = L[i];
                     if (kind == kBaKSolo) {
                         R.solo(gs);
-                        g->solo_launches++;
+                        n_solo++;
                         continue;
                     }
                     const int k = A.n++;
@@ -435,8 +436,8 @@ int ba_group_issue(so_ba_group* g, const std::vector<so_ba*>& mem) {
                     lds = std::max(lds, R.lds);
                     if (A.n == kBaGroupMax) {  // (more members than an argument block holds: another launch)
                         launch_ba_group(kind, d_rows, A, max_grid, lds, gs);
-                        g->grouped_launches++;
-                        g->rows_launched += A.n;
+                        n_grouped++;
+                        n_rows += A.n;
                         A = BaGroupArgs{};
                         max_grid = 1;
                         lds = 0;
@@ -444,8 +445,8 @@ int ba_group_issue(so_ba_group* g, const std::vector<so_ba*>& mem) {
                 }
                 if (kind != kBaKSolo && A.n > 0) {
                     launch_ba_group(kind, d_rows, A, max_grid, lds, gs);
-                    g->grouped_launches++;
-                    g->rows_launched += A.n;
+                    n_grouped++;
+                    n_rows += A.n;
                 }
             }
         }
@@ -454,8 +455,14 @@ int ba_group_issue(so_ba_group* g, const std::vector<so_ba*>& mem) {
     SO_HIP(hipEventRecord(g->row_copied[g->flip], gs));
     g->row_used[g->flip] = true;
     SO_HIP(hipGetLastError());
-    g->rounds++;
-    g->members_total += M;
+    {   // (so_ba_group_stats reads these under the mutex)
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->rounds++;
+        g->members_total += M;
+        g->grouped_launches += n_grouped;
+        g->solo_launches += n_solo;
+        g->rows_launched += n_rows;
+    }
     return SO_OK;
 }
 
