@@ -720,6 +720,24 @@ int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const i
                                     int32_t first_slot, const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
                                     float log_scale_factor, const float* intr4, const float* level_inv_sigma2);
 int so_track_stage_pose_again_submit(so_matcher* m, const float* Tcw12);
+/* The local-map stage enqueued BEHIND the last-frame stage without the host in between (round 6): `first` is another matcher of
+ * the same stream (created on the same thread) whose so_track_stage_last_frame_submit for `cur` is in flight.  What the host did
+ * between the two stages of a frame (code/src/Tracking.cc:743-760, :964-1007, :779) happens on the device, in one small launch
+ * between the chains: stage 1's pose becomes the float pose Frame::SetPose would hold and, converted back, the start of stage 2's
+ * PoseOptimization (Converter::toCvMat / toSE3Quat, the same double operations as on the host); the keypoints bound behind stage 1
+ * - its matches minus its pose's outliers - are the search's excluded set and edges of the pose problem; the local points whose map
+ * slot is bound already are not searched.  skip_static[i] != 0: local point i is not searched for a reason the host knows
+ * beforehand (isBad()); may be NULL.  Everything else as so_track_stage_local_map_submit.  Wait for `first` (so_track_stage_wait:
+ * its results are complete long before), hand its pose to so_track_stage_set_start_pose(m, Tcw12) - only used when the stage has
+ * fewer than three edges - and wait for `m`; results equal those of the two stages run one after the other with the host in
+ * between, to the bit (tests/test_track_chain_gpu.py).  If the first stage turns out unusable (SO_RETRY_ON_HOST, or fewer than
+ * 20 matches and the caller wants the wider window), wait for `m` anyway, discard its result and run the stages the plain way.
+ * SO_RETRY_ON_HOST at submit (nothing enqueued): gates too large for the argument block. */
+int so_track_stage_local_map_submit_after(so_matcher* m, so_matcher* first, const so_dframe* cur, const so_map* map, int32_t n_local,
+                                          const int32_t* local_slot, int32_t first_slot, const uint8_t* skip_static, float th,
+                                          float nn_ratio, float viewing_cos_limit, float log_scale_factor, const float* intr4,
+                                          const float* level_inv_sigma2);
+int so_track_stage_set_start_pose(so_matcher* m, const float* Tcw12);
 /* Forget the device copy of the last stage's bindings: the next local-map stage uploads kp_slot whatever its flag says. */
 int so_track_stage_invalidate(so_matcher* m);
 int so_track_stage_wait(so_matcher* m, int32_t* kp_to_q, int32_t* nmatches, uint8_t* in_view, int32_t* n_edges,

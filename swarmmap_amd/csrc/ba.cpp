@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "ba_device.h"
+#include "pose_convert.h"
 #include "so_common.h"
 
 using namespace so;
@@ -154,52 +155,13 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-// ---- host copies of the SE3Quat conversions at the map boundary (Converter.cc:37-47,49-74; se3quat.h:58-60) ----
-void quat_from_R(const double* R, double* q) {  // Eigen::Quaterniond(Matrix3d), published algorithm
-    double t = R[0] + R[4] + R[8];
-    if (t > 0.0) {
-        t = std::sqrt(t + 1.0);
-        q[3] = 0.5 * t;
-        t = 0.5 / t;
-        q[0] = (R[7] - R[5]) * t;
-        q[1] = (R[2] - R[6]) * t;
-        q[2] = (R[3] - R[1]) * t;
-    } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 3 + i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = std::sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
-        q[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
-    }
-}
-
+// ---- the SE3Quat conversions at the map boundary (Converter.cc:37-47,49-74; se3quat.h:58-60): pose_convert.h, shared with the device ----
 void pose_from_Tcw(const float* T, BaPose& P) {
-    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
-    quat_from_R(R, P.q);
-    if (P.q[3] < 0) for (double& v : P.q) v = -v;  // normalizeRotation
-    const double n = std::sqrt(P.q[0] * P.q[0] + P.q[1] * P.q[1] + P.q[2] * P.q[2] + P.q[3] * P.q[3]);
-    for (double& v : P.q) v /= n;
-    P.t[0] = T[3];
-    P.t[1] = T[7];
-    P.t[2] = T[11];
+    so::pose_from_T12_hd(T, P.q, P.t);
     P.pad = 0;
 }
 
-void pose_to_Tcw(const BaPose& P, float* T) {  // to_homogeneous_matrix cast to float
-    const double* q = P.q;
-    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
-    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
-    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
-    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
-    T[0] = (float)(1 - (tyy + tzz)); T[1] = (float)(txy - twz);       T[2] = (float)(txz + twy);        T[3] = (float)P.t[0];
-    T[4] = (float)(txy + twz);       T[5] = (float)(1 - (txx + tzz)); T[6] = (float)(tyz - twx);        T[7] = (float)P.t[1];
-    T[8] = (float)(txz - twy);       T[9] = (float)(tyz + twx);       T[10] = (float)(1 - (txx + tyy)); T[11] = (float)P.t[2];
-}
+void pose_to_Tcw(const BaPose& P, float* T) { so::pose_to_T12_hd(P.q, P.t, T); }
 
 }  // namespace
 

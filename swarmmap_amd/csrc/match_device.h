@@ -157,6 +157,26 @@ struct TrackGroupJob {
 };
 void launch_topk_track_group(const TrackGroupJob* d_jobs, int n_jobs, int mode, int max_nq, hipStream_t s);
 
+// The first tracking stage hands over to the second ON THE DEVICE (so_track_stage_local_map_submit_after): between the two
+// chains of a frame the host used to wait for stage 1's pose, drop its outliers' bindings, mark the keypoints that are bound and the
+// local points that are matched already, and pass the pose on as the start of stage 2 (code/src/Tracking.cc:743-760 ->
+// :964-1007 -> :779).  track_link_kernel (one workgroup) does that hand-over on the stage-2 rows that are already in HBM:
+//   T.Tcw of the search row   = stage 1's pose as the float [R|t] Frame::SetPose would hold (pose_convert.h),
+//   init of the pose row      = that float pose back as an SE3Quat (Converter::toSE3Quat), the start of PoseOptimization,
+//   T.excl_bits               = candidate positions whose keypoint is bound behind stage 1 (minus its pose's outliers),
+//   T.skip_bits              |= local points whose map slot is bound in this frame already (mbTrackInView = false, :966-978).
+struct TrackLinkArgs {
+    const double* pose1;         // stage 1's result: q[4] (x y z w), t[3] - host-mapped memory its pose kernel wrote
+    const int32_t* kp_slot;      // bindings by keypoint index behind stage 1 (device)
+    const int32_t* cell_items;   // candidate position -> keypoint index
+    int n_cand, n_kp;
+    const int32_t* local_slot;   // n_local map slots (null: first_slot + i); may be pinned host memory
+    int first_slot, n_local;
+    TrackGroupJob* job;          // stage 2's search row (device)
+    double* pose2_init;          // &PoseOptArgs::init of stage 2's pose row (device): q[4], t[3]
+};
+void launch_track_link(const TrackLinkArgs& a, hipStream_t s);
+
 // Projection + gating half of the keyframe-side map-point searches: Fuse (code/src/
 // ORBmatcher.cc:767-815), Fuse / SearchByProjection with a Sim3 (:916-964, :286-333), one direction of SearchBySim3
 // (:1054-1094, :1130-1170) and SearchByProjection(Frame, KeyFrame, ...) (:1374-1410).  project_queries_kernel turns

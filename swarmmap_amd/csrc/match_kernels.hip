@@ -12,6 +12,7 @@
 // Candidates are stored in grid-traversal order (cell x, cell y, keypoint index) by the host, so a candidate's
 // array position IS its tie-break rank and key = dist << 16 | position sorts exactly like the reference visits.
 #include "match_device.h"
+#include "pose_convert.h"
 #include <algorithm>
 
 namespace so {
@@ -1222,6 +1223,69 @@ template <int kResThreads, int kResQPT>
 __global__ __launch_bounds__(kResThreads) void track_resolve_group_kernel(const TrackResolveArgs* __restrict__ tab) {
     const TrackResolveArgs a = tab[blockIdx.x];
     track_resolve_body<kResThreads, kResQPT>(a);
+}
+
+// ---- stage 1 -> stage 2 on the device (match_device.h: TrackLinkArgs) ----
+constexpr int kLinkHash = 8192;  // >= 2 x kResolveMaxCand: open addressing over the map slots bound in this frame
+__global__ __launch_bounds__(1024) void track_link_kernel(TrackLinkArgs a) {
+    __shared__ int s_key[kLinkHash];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kLinkHash; i += 1024) s_key[i] = -1;
+    __syncthreads();
+    // the slots bound behind stage 1 -> hash set
+    for (int k = tid; k < a.n_kp; k += 1024) {
+        const int slot = a.kp_slot[k];
+        if (slot < 0) continue;
+        unsigned h = ((unsigned)slot * 2654435761u) >> 19;
+        for (;;) {
+            const int old = atomicCAS(&s_key[h], -1, slot);
+            if (old == -1 || old == slot) break;
+            h = (h + 1) & (kLinkHash - 1);
+        }
+    }
+    if (tid == 0) {  // the pose: double quaternion -> the frame's float pose -> the SE3Quat PoseOptimization starts from
+        double q[4], t3[3];
+        for (int i = 0; i < 4; i++) q[i] = a.pose1[i];
+        for (int i = 0; i < 3; i++) t3[i] = a.pose1[4 + i];
+        float T[12];
+        pose_to_T12_hd(q, t3, T);
+        for (int i = 0; i < 12; i++) a.job->T.Tcw[i] = T[i];
+        pose_from_T12_hd(T, q, t3);
+        for (int i = 0; i < 4; i++) a.pose2_init[i] = q[i];
+        for (int i = 0; i < 3; i++) a.pose2_init[4 + i] = t3[i];
+    }
+    // candidate positions whose keypoint carries a map point: not eligible in SearchByProjection (ORBmatcher.cc:83-85)
+    for (int w = tid; w < kTrackMaxCandBits / 32; w += 1024) {
+        unsigned bits = 0;
+        for (int b = 0; b < 32; b++) {
+            const int p = 32 * w + b;
+            if (p < a.n_cand && a.kp_slot[a.cell_items[p]] >= 0) bits |= 1u << b;
+        }
+        a.job->T.excl_bits[w] = bits;
+    }
+    __syncthreads();
+    // local points that are bound in this frame already: not searched (Tracking.cc:966-978)
+    for (int w = tid; w < (a.n_local + 31) / 32; w += 1024) {
+        unsigned bits = 0;
+        for (int b = 0; b < 32; b++) {
+            const int i = 32 * w + b;
+            if (i >= a.n_local) break;
+            const int slot = a.local_slot ? a.local_slot[i] : a.first_slot + i;
+            if (slot < 0) continue;
+            unsigned h = ((unsigned)slot * 2654435761u) >> 19;
+            for (;;) {
+                const int v = s_key[h];
+                if (v == slot) { bits |= 1u << b; break; }
+                if (v == -1) break;
+                h = (h + 1) & (kLinkHash - 1);
+            }
+        }
+        if (bits) a.job->T.skip_bits[w] |= bits;
+    }
+}
+
+void launch_track_link(const TrackLinkArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(track_link_kernel, dim3(1), dim3(1024), 0, s, a);
 }
 
 void launch_track_resolve_group(const TrackResolveArgs* d_tab, int n, int max_nq, hipStream_t s) {

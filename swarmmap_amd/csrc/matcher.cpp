@@ -137,6 +137,8 @@ struct so_kframe {
 };
 
 struct so_track_group;
+struct LinkRec;
+static void link_rec_free(LinkRec* r);  // (defined behind the type, further down)
 
 struct so_matcher {
     std::vector<int> scratch_rot_item, scratch_rot_b;  // rotation-histogram bookkeeping of the resolve loops
@@ -213,6 +215,7 @@ struct so_matcher {
         int n_kp = 0, nq = 0, seq = 0;
         bool events = false, valid_edges = false;
         bool grouped = false;  // launched by the matcher's so_track_group: no per-member events
+        bool linked = false;   // so_track_stage_local_map_submit_after
         size_t h_k2q = 0, h_ekp = 0, h_head = 0, h_pose = 0, h_info = 0, h_outl = 0, h_slot_in = 0;
         float Tcw_in[12];
         const so_map* map = nullptr;  // the table the pose kernel reads its points from
@@ -224,6 +227,12 @@ struct so_matcher {
     //      so_track_stage_*_submit) and go out with the other members' as three launches (so_track_group_launch)
     so_track_group* group = nullptr;
     bool group_recording = false;
+    // ---- the local-map stage LINKED behind another matcher's last-frame stage (so_track_stage_local_map_submit_after): its three
+    //      launches are recorded into `link_rec` and go out as one-row tables that track_link_kernel patches on the device
+    bool link_recording = false;
+    struct LinkRec* link_rec = nullptr;
+    PinBuf h_link;
+    DevBuf d_link;
     std::vector<int> cell_count;
 
     // ---- so_matcher_batch_begin / _end: independent calls staged side by side, launched together ----
@@ -897,7 +906,9 @@ void so_matcher_destroy(so_matcher* m) {
         const_cast<so_map*>(m->chain.map)->grow_mu.unlock_shared();
         m->chain.holds_map = false;
     }
-    for (DevBuf* b : {&m->d_in, &m->d_A, &m->d_B, &m->d_res}) b->release();
+    for (DevBuf* b : {&m->d_in, &m->d_A, &m->d_B, &m->d_res, &m->d_link}) b->release();
+    m->h_link.release();
+    link_rec_free(m->link_rec);
     for (PinBuf* b : {&m->h_in, &m->h_res, &m->h_rq}) b->release();
     m->d_rq.release();
     m->h_out.release();
@@ -3269,7 +3280,13 @@ struct so_track_group {
 
 namespace {
 
+}  // namespace
+struct LinkRec : so_track_group::Rec {};
+static void link_rec_free(LinkRec* r) { delete r; }
+namespace {
+
 so_track_group::Rec& group_rec(so_matcher* m) {
+    if (m->link_recording) return *m->link_rec;
     so_track_group* g = m->group;
     for (int i = 0; i < g->n_recs; i++)
         if (g->recs[(size_t)i].m == m) return g->recs[(size_t)i];
@@ -3301,7 +3318,7 @@ int launch_topk_track_async(so_matcher* m, TrackQuerySrc& T, int mode, int nq, i
     T.slot_base = G.slot_base;
     T.keys_soa = 1;
     T.use_bits = bits ? 1 : 0;
-    if (!bits && m->group_recording) return SO_RETRY_ON_HOST;  // (gates too large for the argument block: the plain calls run it)
+    if (!bits && (m->group_recording || m->link_recording)) return SO_RETRY_ON_HOST;  // (gates too large for the argument block: the plain calls run it)
     if (bits) {
         set_bits_from_excluded(m, G.excluded, nullptr, T);
         memset(T.skip_bits, 0, sizeof(uint32_t) * (size_t)((nq + 31) / 32));
@@ -3338,7 +3355,7 @@ int launch_topk_track_async(so_matcher* m, TrackQuerySrc& T, int mode, int nq, i
         T.slot = G.slots ? reinterpret_cast<const int32_t*>(d + off_slot) : nullptr;
         T.skip = G.skip ? d + off_skip : nullptr;
     }
-    if (m->group_recording) {  // a member of a so_track_group inside a stage submit: the search goes out with the group's
+    if (m->group_recording || m->link_recording) {  // a member of a so_track_group inside a stage submit (or a linked stage): the search goes out with the group's / the link's
         so_track_group::Rec& r = group_rec(m);
         r.job.F = frame_dev(m);
         r.job.T = T;
@@ -3789,7 +3806,7 @@ int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe
     R.e_kp_host = (int32_t*)(hd + O.h_ekp);
     R.head = (int32_t*)(d + O.d_head);
     R.head_host = (int32_t*)(hd + O.h_head);
-    if (m->group_recording) {
+    if (m->group_recording || m->link_recording) {
         so_track_group::Rec& r = group_rec(m);
         r.res = R;
         r.resolve = true;
@@ -3835,7 +3852,7 @@ int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe
     reinterpret_cast<volatile int*>((uint8_t*)m->h_chain.p + O.h_info)[3] = 0;
     memset((uint8_t*)m->h_chain.p + O.h_head, 0, 64);
     std::atomic_thread_fence(std::memory_order_release);
-    C.grouped = m->group_recording;
+    C.grouped = m->group_recording || m->link_recording;
     C.events = m->profile && !C.grouped;
     if (C.grouped) {
         so_track_group::Rec& r = group_rec(m);
@@ -3928,10 +3945,14 @@ int so_track_stage_last_frame_submit(so_matcher* m, const so_dframe* cur, const 
     return rc;
 }
 
-int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const int32_t* kp_slot, int kp_slot_is_last_stage,
-                                    const so_map* map, const float* Tcw12, int32_t n_local, const int32_t* local_slot,
-                                    int32_t first_slot, const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
-                                    float log_scale_factor, const float* intr4, const float* level_inv_sigma2) {
+}  // extern "C"
+
+// kp_slot_dev != null (linked stage): the bindings on entry are read from THAT device array (another matcher's d_kpslot), the
+// host array kp_slot only says "nothing is known here" (all -1: the excluded set is formed on the device)
+static int stage_local_map_submit(so_matcher* m, const so_dframe* cur, const int32_t* kp_slot, int kp_slot_is_last_stage,
+                                  const int32_t* kp_slot_dev, const so_map* map, const float* Tcw12, int32_t n_local,
+                                  const int32_t* local_slot, int32_t first_slot, const uint8_t* skip, float th, float nn_ratio,
+                                  float viewing_cos_limit, float log_scale_factor, const float* intr4, const float* level_inv_sigma2) {
     if (!m || !cur || !kp_slot || !map || !Tcw12 || !intr4 || !level_inv_sigma2 || n_local < 0 || m->chain.active)
         return SO_ERR_INVALID_ARG;
     m->chain.valid_edges = false;
@@ -3947,7 +3968,7 @@ int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const i
     // the bindings on entry: the search's excluded set, and edges of the pose problem.  The resolve kernel reads them from
     // the host-mapped copy - or, when they are what the last stage left on the device (its matches, minus its pose's
     // outliers), from there: no read across PCIe inside the chain
-    const bool on_device = kp_slot_is_last_stage && m->kpslot_frame == cur && m->kpslot_generation == cur->generation;
+    const bool on_device = kp_slot_dev != nullptr || (kp_slot_is_last_stage && m->kpslot_frame == cur && m->kpslot_generation == cur->generation);
     int32_t* slot_in = (int32_t*)((uint8_t*)m->h_chain.p + O.h_slot_in);
     if (!on_device) memcpy(slot_in, kp_slot, sizeof(int32_t) * (size_t)cur->n);
     static thread_local std::vector<uint8_t> excluded;
@@ -3964,7 +3985,7 @@ int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const i
         return recording.drop(SO_RETRY_ON_HOST);
     }
     rc = chain_launch(m, 1, O, cur, nullptr, map, Tcw12, 0,
-                      on_device ? (const int32_t*)m->d_kpslot.p : (const int32_t*)((uint8_t*)m->h_chain.dev + O.h_slot_in), intr4,
+                      kp_slot_dev ? kp_slot_dev : on_device ? (const int32_t*)m->d_kpslot.p : (const int32_t*)((uint8_t*)m->h_chain.dev + O.h_slot_in), intr4,
                       level_inv_sigma2);
     if (rc != SO_OK) {
         recording.drop(rc);
@@ -3973,6 +3994,91 @@ int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const i
         m->chain.active = false;
     }
     return rc;
+}
+
+extern "C" {
+
+int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const int32_t* kp_slot, int kp_slot_is_last_stage,
+                                    const so_map* map, const float* Tcw12, int32_t n_local, const int32_t* local_slot,
+                                    int32_t first_slot, const uint8_t* skip, float th, float nn_ratio, float viewing_cos_limit,
+                                    float log_scale_factor, const float* intr4, const float* level_inv_sigma2) {
+    return stage_local_map_submit(m, cur, kp_slot, kp_slot_is_last_stage, nullptr, map, Tcw12, n_local, local_slot, first_slot, skip, th, nn_ratio,
+                                  viewing_cos_limit, log_scale_factor, intr4, level_inv_sigma2);
+}
+
+// TrackLocalMap's stage enqueued BEHIND TrackWithMotionModel's (`first`: another matcher of the same stream whose last-frame
+// stage for `cur` is in flight) without waiting for it: include/swarmorb.h.
+int so_track_stage_local_map_submit_after(so_matcher* m, so_matcher* first, const so_dframe* cur, const so_map* map, int32_t n_local,
+                                          const int32_t* local_slot, int32_t first_slot, const uint8_t* skip_static, float th, float nn_ratio,
+                                          float viewing_cos_limit, float log_scale_factor, const float* intr4, const float* level_inv_sigma2) {
+    if (!m || !first || m == first || !cur || !map || !intr4 || !level_inv_sigma2 || m->chain.active || m->group || first->group)
+        return SO_ERR_INVALID_ARG;
+    if (!first->chain.active || first->chain.kind != 0 || first->chain.frame != cur || first->stream != m->stream || first->device != m->device) {
+        last_error_ref() = "so_track_stage_local_map_submit_after: `first` must have the last-frame stage of this frame in flight on the same stream";
+        return SO_ERR_INVALID_ARG;
+    }
+    if (cur->n > so::kResolveMaxCand) return SO_RETRY_ON_HOST;
+    static thread_local std::vector<int32_t> none;
+    none.assign((size_t)cur->n, -1);
+    if (!m->link_rec) m->link_rec = new LinkRec();
+    so_track_group::Rec& R = *m->link_rec;
+    R.search = R.resolve = R.pose = false;
+    R.m = m;
+    m->link_recording = true;
+    const int rc = stage_local_map_submit(m, cur, none.data(), 0, (const int32_t*)first->d_kpslot.p, map, first->chain.Tcw_in, n_local, local_slot,
+                                          first_slot, skip_static, th, nn_ratio, viewing_cos_limit, log_scale_factor, intr4, level_inv_sigma2);
+    m->link_recording = false;
+    if (rc != SO_OK) return rc;
+    if (!R.search || !R.resolve || !R.pose) {  // (cannot happen: SO_OK means the three launches were recorded)
+        (void)hipStreamSynchronize(m->stream);
+        chain_drop_search(m);
+        m->chain.active = false;
+        return SO_ERR_HIP;
+    }
+    // the three one-row tables -> HBM; the link kernel patches pose, gates and start pose in place; the grouped kernels read them
+    const size_t off_pose = 0, off_res = align256(sizeof(so::PoseOptArgs)), off_job = align256(off_res + sizeof(so::TrackResolveArgs));
+    const size_t total = align256(off_job + sizeof(so::TrackGroupJob));
+    int rc2;
+    if ((rc2 = m->h_link.ensure(total)) || (rc2 = m->d_link.ensure(total))) {
+        (void)hipStreamSynchronize(m->stream);
+        chain_drop_search(m);
+        m->chain.active = false;
+        return rc2;
+    }
+    uint8_t* h = (uint8_t*)m->h_link.p;
+    uint8_t* d = (uint8_t*)m->d_link.p;
+    memcpy(h + off_pose, &R.pose_args, sizeof(so::PoseOptArgs));
+    memcpy(h + off_res, &R.res, sizeof(so::TrackResolveArgs));
+    memcpy(h + off_job, &R.job, sizeof(so::TrackGroupJob));
+    std::atomic_thread_fence(std::memory_order_release);
+    hipStream_t s = m->stream;
+    launch_stage_in(d, h, total, s);
+    so::TrackLinkArgs L{};
+    L.pose1 = reinterpret_cast<const double*>(first->chain_pose.pose_out);
+    L.kp_slot = (const int32_t*)first->d_kpslot.p;
+    L.cell_items = cur->d_cell_items;
+    L.n_cand = m->n_cand;
+    L.n_kp = cur->n;
+    L.local_slot = R.job.T.slot;
+    L.first_slot = R.job.T.slot_base;
+    L.n_local = n_local;
+    L.job = reinterpret_cast<so::TrackGroupJob*>(d + off_job);
+    L.pose2_init = reinterpret_cast<double*>(d + off_pose + offsetof(so::PoseOptArgs, init));
+    so::launch_track_link(L, s);
+    so::launch_topk_track_group(reinterpret_cast<const so::TrackGroupJob*>(d + off_job), 1, 3, R.job.nq, s);
+    so::launch_track_resolve_group(reinterpret_cast<const so::TrackResolveArgs*>(d + off_res), 1, R.job.nq, s);
+    so::launch_pose_opt_chain_group(reinterpret_cast<const so::PoseOptArgs*>(d + off_pose), 1, 1 << (R.range ? 1 : 0), s);
+    SO_HIP(hipGetLastError());
+    m->chain.linked = true;
+    return SO_OK;
+}
+
+// The start pose of a linked stage as the host knows it once the first stage has been waited for (what so_track_stage_wait hands
+// back when the stage has fewer than three edges: Optimizer.cc:358-359 leaves the frame's pose alone).
+int so_track_stage_set_start_pose(so_matcher* m, const float* Tcw12) {
+    if (!m || !Tcw12 || !m->chain.active) return SO_ERR_INVALID_ARG;
+    memcpy(m->chain.Tcw_in, Tcw12, 48);
+    return SO_OK;
 }
 
 int so_track_stage_pose_again_submit(so_matcher* m, const float* Tcw12) {

@@ -285,6 +285,33 @@ def track_stage_local_map(matcher, cur, kp_slot, dmap, Tcw, n_local, th, cos_lim
     return _stage_wait(matcher, n, n_local) if wait else (lambda: _stage_wait(matcher, n, n_local))
 
 
+def track_stage_local_map_after(matcher, first, cur, dmap, n_local, th, cos_limit, log_scale_factor, K4, level_inv_sigma2, local_slot=None,
+                                skip_static=None, first_slot=0):
+    """so_track_stage_local_map_submit_after: TrackLocalMap's stage enqueued behind `first`'s in-flight last-frame stage (no host
+    in between).  Returns the wait as a callable taking the first stage's pose (so_track_stage_set_start_pose), or None."""
+    lib = matcher._lib
+    _bind(lib)
+    vp, i32, f = C.c_void_p, C.c_int32, C.c_float
+    lib.so_track_stage_local_map_submit_after.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, f, f, f, f, vp, vp]
+    lib.so_track_stage_set_start_pose.argtypes = [vp, vp]
+    slot = None if local_slot is None else np.ascontiguousarray(local_slot, np.int32)
+    sk = None if skip_static is None else np.ascontiguousarray(skip_static, np.uint8)
+    k4, ls = np.ascontiguousarray(K4, np.float32), np.ascontiguousarray(level_inv_sigma2, np.float32)
+    rc = lib.so_track_stage_local_map_submit_after(matcher._h, first._h, cur._h, dmap._h, int(n_local), _vp(slot), int(first_slot), _vp(sk), float(th),
+                                                   float(matcher.mfNNratio), float(cos_limit), float(log_scale_factor), _vp(k4), _vp(ls))
+    if rc == SO_RETRY_ON_HOST:
+        return None
+    _lib.check(rc)
+    n = cur.n
+    keep = (slot, sk, k4, ls)  # (the submit read them in place: alive until the wait)
+
+    def wait(first_Tcw, _keep=keep):
+        T = np.ascontiguousarray(first_Tcw, np.float32).reshape(12)
+        _lib.check(lib.so_track_stage_set_start_pose(matcher._h, _vp(T)))
+        return _stage_wait(matcher, n, n_local)
+    return wait
+
+
 def track_stage_pose_again(matcher, cur, Tcw, wait=True):
     """so_track_stage_pose_again_submit + wait: PoseOptimization over the last stage's edges from another start pose."""
     lib = matcher._lib

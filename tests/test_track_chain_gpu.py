@@ -258,3 +258,55 @@ def test_stages_with_nothing_to_match(S, oracle):
     nm, k2m, _ = dfm.search_local_map(m, cur, dmap, Tc, len(Xw), 1.0, 0.5, LOG_SF)
     assert nm > 200  # the handle is fine
     m.close(); dmap.close(); cur.close(); last.close(); ex.close()
+
+
+@pytest.mark.parametrize("seed,dist", [(41, synth.EUROC_DIST), (45, (0, 0, 0, 0)), (46, synth.EUROC_DIST)])
+def test_linked_stages_equal_the_stages_with_the_host_in_between(S, oracle, seed, dist):
+    """so_track_stage_local_map_submit_after: both stages of a frame enqueued at once - stage 1's pose, its outliers' bindings,
+    the excluded keypoints and the already-matched local points travel on the device (track_link_kernel) - against the same two
+    stages with the host in between (which test_last_frame_stage_equals_search_plus_pose pins to the oracle): matches, bindings,
+    edges, poses, outlier flags, iteration and trial counts of BOTH stages, and the pose repeated over stage 2's edges, to the bit.
+    Reference: Tracking::TrackWithMotionModel -> TrackLocalMap, code/src/Tracking.cc:714-807."""
+    rng = np.random.default_rng(seed)
+    ex, last, lk, lxy, ld, _ = _frame_and_view(S, oracle, seed, dist=dist)
+    Tl = _pose(rng)
+    Xw, normal, mx, mn, md = _make_map(rng, lxy, lk, ld, synth.EUROC_K, Tl)
+    dmap = S.DeviceMap()
+    dmap.append(Xw, normal, mx, mn, md)
+    cur = S.DeviceFrame(ex, synth.EUROC_K, dist)
+    cur(synth.make_canvas(seed, 752, 480))
+    n_last = len(lk)
+    slot = np.where(rng.random(n_last) < 0.6, np.arange(n_last), -1).astype(np.int32)  # 40 % of the last frame's keypoints unbound:
+    Tc = Tl.copy()                                                                        # the local-map stage has points left to find
+    Tc[3] += 0.004; Tc[7] -= 0.003
+    local = rng.permutation(len(Xw))[: len(Xw) * 3 // 4].astype(np.int32)
+    bad = (rng.random(len(local)) < 0.05).astype(np.uint8)  # isBad(): known to the host beforehand
+    m1, m2, ms = S.ORBmatcher(0.9, True), S.ORBmatcher(0.8, True), S.ORBmatcher(0.8, True)
+    # the two stages with the host in between
+    r1 = dfm.track_stage_last_frame(m1, cur, last, dmap, Tc, slot, 15.0, K4, INV_SIGMA2)
+    assert r1 is not None and r1["nmatches"] > 150
+    k2l = r1["kp_to_q"]
+    bound = np.where(k2l >= 0, slot[np.maximum(k2l, 0)], -1).astype(np.int32)
+    bound[r1["edge_kp"][r1["edge_outlier"] != 0]] = -1
+    seen = np.zeros(len(Xw), bool); seen[bound[bound >= 0]] = True
+    skip = (bad.astype(bool) | seen[local]).astype(np.uint8)
+    r2 = dfm.track_stage_local_map(ms, cur, bound, dmap, r1["Tcw"], len(local), 1.0, 0.5, LOG_SF, K4, INV_SIGMA2, local_slot=local, skip=skip)
+    assert r2 is not None and r2["nmatches"] > 50 and r2["n_edges"] > r1["n_edges"] - int((r1["edge_outlier"] != 0).sum())
+    T3 = Tc.copy(); T3[3] -= 0.01
+    r3 = dfm.track_stage_pose_again(ms, cur, T3)
+    # both stages enqueued at once, twice (the link's tables are reused)
+    for rep in range(2):
+        w1 = dfm.track_stage_last_frame(m1, cur, last, dmap, Tc, slot, 15.0, K4, INV_SIGMA2, wait=False)
+        w2 = dfm.track_stage_local_map_after(m2, m1, cur, dmap, len(local), 1.0, 0.5, LOG_SF, K4, INV_SIGMA2, local_slot=local, skip_static=bad)
+        assert w1 is not None and w2 is not None
+        a1 = w1()
+        a2 = w2(a1["Tcw"])
+        for k in ("kp_to_q", "edge_kp", "edge_outlier", "Tcw", "nmatches", "n_edges", "n_inliers", "iterations", "trials"):
+            assert np.array_equal(a1[k], r1[k]), ("stage 1", k)
+            assert np.array_equal(a2[k], r2[k]), ("stage 2", k)
+        assert np.array_equal(a2["in_view"], r2["in_view"])
+        a3 = dfm.track_stage_pose_again(m2, cur, T3)
+        for k in ("edge_kp", "edge_outlier", "Tcw", "n_inliers", "iterations", "trials"):
+            assert np.array_equal(a3[k], r3[k]), ("pose again", k)
+    for h in (m1, m2, ms, dmap, cur, last, ex):
+        h.close()
