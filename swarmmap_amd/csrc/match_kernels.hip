@@ -1229,8 +1229,21 @@ __global__ __launch_bounds__(kResThreads) void track_resolve_group_kernel(const 
 constexpr int kLinkHash = 8192;  // >= 2 x kResolveMaxCand: open addressing over the map slots bound in this frame
 __global__ __launch_bounds__(1024) void track_link_kernel(TrackLinkArgs a) {
     __shared__ int s_key[kLinkHash];
+    __shared__ unsigned s_skip[kTrackMaxQueryBits / 32];
+    __shared__ unsigned s_excl[kTrackMaxCandBits / 32];
     const int tid = threadIdx.x;
+    // the local points' slots may sit in pinned host memory (the search reads them there, one per wave): requested first, one
+    // coalesced request per 1024 points, and needed last - a PCIe read is microseconds, a dependent chain of them per thread tens
+    constexpr int kMaxPerThread = kTrackMaxQueryBits / 1024;
+    int lslot[kMaxPerThread];
+#pragma unroll
+    for (int j = 0; j < kMaxPerThread; j++) {
+        const int i = tid + j * 1024;
+        lslot[j] = i < a.n_local ? (a.local_slot ? a.local_slot[i] : a.first_slot + i) : -1;
+    }
     for (int i = tid; i < kLinkHash; i += 1024) s_key[i] = -1;
+    for (int i = tid; i < kTrackMaxQueryBits / 32; i += 1024) s_skip[i] = 0;
+    for (int i = tid; i < kTrackMaxCandBits / 32; i += 1024) s_excl[i] = 0;
     __syncthreads();
     // the slots bound behind stage 1 -> hash set
     for (int k = tid; k < a.n_kp; k += 1024) {
@@ -1255,33 +1268,27 @@ __global__ __launch_bounds__(1024) void track_link_kernel(TrackLinkArgs a) {
         for (int i = 0; i < 3; i++) a.pose2_init[4 + i] = t3[i];
     }
     // candidate positions whose keypoint carries a map point: not eligible in SearchByProjection (ORBmatcher.cc:83-85)
-    for (int w = tid; w < kTrackMaxCandBits / 32; w += 1024) {
-        unsigned bits = 0;
-        for (int b = 0; b < 32; b++) {
-            const int p = 32 * w + b;
-            if (p < a.n_cand && a.kp_slot[a.cell_items[p]] >= 0) bits |= 1u << b;
-        }
-        a.job->T.excl_bits[w] = bits;
-    }
+    for (int p = tid; p < a.n_cand && p < kTrackMaxCandBits; p += 1024)
+        if (a.kp_slot[a.cell_items[p]] >= 0) atomicOr(&s_excl[p >> 5], 1u << (p & 31));
     __syncthreads();
     // local points that are bound in this frame already: not searched (Tracking.cc:966-978)
-    for (int w = tid; w < (a.n_local + 31) / 32; w += 1024) {
-        unsigned bits = 0;
-        for (int b = 0; b < 32; b++) {
-            const int i = 32 * w + b;
-            if (i >= a.n_local) break;
-            const int slot = a.local_slot ? a.local_slot[i] : a.first_slot + i;
-            if (slot < 0) continue;
-            unsigned h = ((unsigned)slot * 2654435761u) >> 19;
-            for (;;) {
-                const int v = s_key[h];
-                if (v == slot) { bits |= 1u << b; break; }
-                if (v == -1) break;
-                h = (h + 1) & (kLinkHash - 1);
-            }
+#pragma unroll
+    for (int j = 0; j < kMaxPerThread; j++) {
+        const int slot = lslot[j];
+        if (slot < 0) continue;
+        const int i = tid + j * 1024;
+        unsigned h = ((unsigned)slot * 2654435761u) >> 19;
+        for (;;) {
+            const int v = s_key[h];
+            if (v == slot) { atomicOr(&s_skip[i >> 5], 1u << (i & 31)); break; }
+            if (v == -1) break;
+            h = (h + 1) & (kLinkHash - 1);
         }
-        if (bits) a.job->T.skip_bits[w] |= bits;
     }
+    __syncthreads();
+    for (int w = tid; w < kTrackMaxCandBits / 32; w += 1024) a.job->T.excl_bits[w] = s_excl[w];
+    for (int w = tid; w < (a.n_local + 31) / 32; w += 1024)
+        if (s_skip[w]) a.job->T.skip_bits[w] |= s_skip[w];
 }
 
 void launch_track_link(const TrackLinkArgs& a, hipStream_t s) {

@@ -947,6 +947,8 @@ int so_matcher_reuse_frame(so_matcher* m) {
 // Staging for tracking searches of up to n_queries map points (K-lists, in-view flags, slots, gates) allocated now:
 // pinned allocations cost 0.1-0.3 ms each, and a local map that grows keyframe by keyframe would otherwise pay one
 // every time it outgrows the 1.5x slack (the first seconds of a sequence: +25-50 us per frame).
+static int chain_reserve(so_matcher* m, int nq);  // (the tracking stages' device / host-mapped blocks: defined with them, below)
+
 int so_matcher_reserve(so_matcher* m, int32_t n_queries) {
     if (!m || n_queries < 0 || m->pend.mode != 0) return SO_ERR_INVALID_ARG;  // (not while a submitted search owns the buffers)
     SO_HIP(hipSetDevice(m->device));
@@ -959,7 +961,7 @@ int so_matcher_reserve(so_matcher* m, int32_t n_queries) {
     // slots + skip bytes behind the frame block (whatever its size turns out to be: 256 KB covers 4096 keypoints)
     const size_t in_bytes = align256((size_t)256 * 1024 + sizeof(int32_t) * nq) + align256(nq) + 512;
     if (in_bytes > m->h_in.cap && (rc = m->h_in.ensure_keep(in_bytes, m->h_in.cap))) return rc;
-    return SO_OK;
+    return chain_reserve(m, n_queries);
 }
 
 int so_matcher_last_stats(so_matcher* m, double* stats4) {
@@ -3871,6 +3873,21 @@ int chain_launch(so_matcher* m, int kind, const ChainOffsets& O, const so_dframe
     SO_HIP(hipGetLastError());
     return SO_OK;
 }
+
+}  // namespace
+
+static int chain_reserve(so_matcher* m, int nq) {
+    if (m->chain.active) return SO_OK;
+    const ChainOffsets O = chain_offsets(nq, 8, (int)so::kResolveMaxCand);
+    int rc;
+    if ((rc = m->d_chain.ensure(O.d_total)) || (rc = m->h_chain.ensure(O.h_total))) return rc;
+    const void* before = m->d_kpslot.p;
+    if ((rc = m->d_kpslot.ensure(sizeof(int32_t) * (size_t)so::kResolveMaxCand))) return rc;
+    if (m->d_kpslot.p != before) m->kpslot_frame = nullptr;
+    return SO_OK;
+}
+
+namespace {
 
 int chain_prepare(so_matcher* m, int nq, int nk, ChainOffsets* O) {
     *O = chain_offsets(nq, 8, nk);

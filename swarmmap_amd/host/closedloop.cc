@@ -735,6 +735,7 @@ int cl_frame_begin(so_replay* r, int t) {
             }
             M.cv.wait(lk, [&] { return !M.outbox.empty() || M.failed; });
             M.wait_ms += now_ms() - w0;
+            M.t_packet = now_ms();
             if (M.outbox.empty()) return SO_ERR_HIP;
         } else if (M.outbox.empty()) {
             return SO_OK;
@@ -797,6 +798,11 @@ void cl_keyframe_queued(so_replay* r, int t, const std::shared_ptr<KfSnap>& snap
     M.last_kf_t = t;
     M.kf_t.push_back(t);
     M.n_kf++;
+    if (M.t_packet > 0.0) {  // (diagnostics: the part of the cycle that is not the job)
+        M.handover_ms += now_ms() - M.t_packet;
+        M.n_handover++;
+        M.t_packet = 0.0;
+    }
 }
 
 // ... and the end of a frame: its pose relative to its reference keyframe (mlRelativeFramePoses)

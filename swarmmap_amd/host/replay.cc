@@ -650,6 +650,7 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
     if (rc == SO_OK) rc = so_dframe_create(r->ex, &r->cam, &r->fr[1]);
     if (rc == SO_OK) rc = so_dframe_create(r->ex, &r->cam, &r->fr[2]);
     if (rc == SO_OK) rc = so_matcher_create(device, &r->matcher);
+    if (rc == SO_OK) rc = so_matcher_create(device, &r->matcher2);  // (same thread: same stream as `matcher`)
     if (rc == SO_OK) rc = so_map_create(device, &r->map);
     if (rc == SO_OK) rc = so_ba_create(device, &r->tracker_opt);
     if (rc == SO_OK) rc = so_ba_create(device, &r->mapper_opt);
@@ -666,7 +667,7 @@ int so_replay_create(int device, int width, int height, int nfeatures, int lba_e
     {   // sized once, like a tracker sizes its buffers for the local map it allows: 12 keyframes' worth of new points,
         // or 32 k map points when the whole map is searched
         const int reserve_q = local_keyframes > 0 ? (local_keyframes + 1) * r->cap : 32768;
-        if (so_matcher_reserve(r->matcher, reserve_q) != SO_OK) {
+        if (so_matcher_reserve(r->matcher, reserve_q) != SO_OK || so_matcher_reserve(r->matcher2, reserve_q) != SO_OK) {
             delete r;
             return SO_ERR_HIP;
         }
@@ -720,6 +721,7 @@ void so_replay_destroy(so_replay* r) {
     for (so_dframe* f : r->fr) so_dframe_destroy(f);
     so_extractor_destroy(r->ex);
     so_matcher_destroy(r->matcher);
+    so_matcher_destroy(r->matcher2);
     so_map_destroy(r->map);
     so_ba_destroy(r->tracker_opt);
     so_ba_destroy(r->mapper_opt);
@@ -896,6 +898,7 @@ int so_replay_prime(so_replay* r, int t) {
 namespace {
 
 int step_m2_submit(so_replay* r);
+void step_m1_submit_linked(so_replay* r);
 
 // Closed loop, deterministic schedule: `kf_every` frames after the last keyframe the frame being tracked WILL be one (local
 // mapping has just handed its results over and is idle).  Its keypoints and descriptors are known as soon as the frame is
@@ -942,6 +945,7 @@ int step_begin(so_replay* r, int t, bool submit_next = true) {
     // per PoseOptimization call are ~11 us of a 0.43 ms frame when taken on every frame)
     S.timed_kernels = (t % kEventEvery) == 0;
     so_matcher_set_profiling(r->matcher, S.timed_kernels);
+    so_matcher_set_profiling(r->matcher2, S.timed_kernels);
     so_pose_optimization_set_timing(r->tracker_opt, S.timed_kernels);
     S.hcur = r->submitted;
     if (r->cl) {  // what local mapping handed back arrives between two frames (Optimizer.cc:713 under Map::mMutexMapUpdate)
@@ -1006,6 +1010,37 @@ bool track_chain_on(const so_replay* r) {
     return r->track_chain >= 0 ? r->track_chain != 0 : on;
 }
 
+// TrackLocalMap's stage enqueued behind TrackWithMotionModel's (so_track_stage_local_map_submit_after): what the stage needs from
+// the first one - pose, bindings, excluded keypoints, already-matched local points - is handed over on the device; the host's
+// share is the list of local points and their bad flags, both known when the frame begins.  SWARMORB_TRACK_LINK=0: off.
+void step_m1_submit_linked(so_replay* r) {
+    static const bool off = getenv("SWARMORB_TRACK_LINK") && atoi(getenv("SWARMORB_TRACK_LINK")) == 0;
+    so_replay::Step& S = r->step;
+    if (off || r->lockstep) return;
+    int rc;
+    if (r->cl) {
+        ClosedLoop& M = *r->cl;
+        // Not on the frame that is about to become a keyframe under the deterministic schedule: there the local-mapping thread
+        // prepares the keyframe (feature vector + upload, prepare_keyframe) while this frame is tracked, and its few kernels then
+        // queue behind the back-to-back chain of both stages instead of slipping into the gap between them - the keyframe was
+        // handed over 80 us later (0.374 against 0.294 ms after the packet, measured) on the one path that bounds the loop.
+        if (M.policy == 0 && !M.job_pending && S.t - M.last_kf_t >= M.kf_every) return;
+        const int nl = (int)M.tv_local.size();
+        r->skip_static.resize((size_t)nl);
+        for (int i = 0; i < nl; i++) r->skip_static[(size_t)i] = M.tv_bad[(size_t)M.tv_local[(size_t)i]];
+        rc = so_track_stage_local_map_submit_after(r->matcher2, r->matcher, r->fr[S.hcur], r->map, nl, M.tv_local.data(), 0, r->skip_static.data(),
+                                                   1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
+    } else {
+        const int n_map = (int)(r->mp_X.size() / 3);
+        int first = 0;
+        if (r->local_keyframes > 0 && (int)r->kf_first_slot.size() > r->local_keyframes)
+            first = r->kf_first_slot[r->kf_first_slot.size() - (size_t)r->local_keyframes];
+        rc = so_track_stage_local_map_submit_after(r->matcher2, r->matcher, r->fr[S.hcur], r->map, n_map - first, nullptr, first, nullptr, 1.0f, 0.8f,
+                                                   0.5f, r->log_sf, r->K4, r->inv_sigma2);
+    }
+    S.stage2_linked = rc == SO_OK;  // (anything else: nothing was enqueued, the stage goes out after the first one as before)
+}
+
 int step_m2_submit(so_replay* r) {
     so_replay::Step& S = r->step;
     so_replay::FrameHost& L = r->fh[r->cur ^ 1];
@@ -1021,6 +1056,7 @@ int step_m2_submit(so_replay* r) {
                                                         r->last_slot.data(), 15.0f, 1, r->K4, r->inv_sigma2);
         if (rc == SO_OK) {
             S.stage1_dev = true;
+            step_m1_submit_linked(r);  // (TrackLocalMap's stage right behind it, when it can be: no host between the stages)
             return SO_OK;
         }
         if (rc != SO_RETRY_ON_HOST) return fail(r, "so_track_stage_last_frame_submit");
@@ -1127,14 +1163,16 @@ int pose_single(so_replay* r, const float* T_in12, float* T_out12, int32_t* n_in
 // builds), the outlier flags and the pose come back together.  false: not finished on the device - the caller repeats the
 // stage with the separate calls.
 bool stage_collect(so_replay* r, std::vector<int32_t>& kp_to_q, int32_t* nm, uint8_t* in_view, float* T_out12, int32_t* n_inliers,
-                   int* rc_out) {
+                   int* rc_out, so_matcher* sm = nullptr) {
     so_replay::Step& S = r->step;
+    const bool linked = sm != nullptr && sm != r->matcher;
+    if (!sm) sm = r->matcher;
     const so_replay::FrameHost& F = r->fh[r->cur];
     kp_to_q.resize((size_t)F.n);
     r->idx.resize((size_t)F.n);
     r->pose_out.resize((size_t)F.n);
     int32_t ne = 0, info2[2] = {0, 0};
-    const int rc = so_track_stage_wait(r->matcher, kp_to_q.data(), nm, in_view, &ne, r->idx.data(), r->pose_out.data(), T_out12,
+    const int rc = so_track_stage_wait(sm, kp_to_q.data(), nm, in_view, &ne, r->idx.data(), r->pose_out.data(), T_out12,
                                        n_inliers, info2);
     *rc_out = SO_OK;
     if (rc == SO_RETRY_ON_HOST) return false;
@@ -1145,9 +1183,9 @@ bool stage_collect(so_replay* r, std::vector<int32_t>& kp_to_q, int32_t* nm, uin
     r->idx.resize((size_t)ne);
     r->pose_out.resize((size_t)ne);
     S.pose_calls++;
-    if (S.timed_kernels) {
+    if (S.timed_kernels && !linked) {  // (a linked stage carries no events: its pose kernel is timed on the frames that are not linked... see kEventEvery)
         float kms = 0.f;
-        so_track_stage_last_pose_kernel_ms(r->matcher, &kms);
+        so_track_stage_last_pose_kernel_ms(sm, &kms);
         S.pose_kernel += kms;
         S.pose_trials += info2[1];
         S.pose_points += ne;
@@ -1172,6 +1210,17 @@ int step_stage1_wait(so_replay* r, int32_t* inl) {
     so_matcher_last_stats(r->matcher, ms4);
     S.mstat[0] += ms4[0]; S.mstat[1] += ms4[1];
     S.reruns += ms4[2];
+    if ((!ok || nm < 20) && S.stage2_linked) {
+        // the stage enqueued behind this one ran on what this one left: wait for it, drop its result
+        std::vector<int32_t> k2((size_t)F.n), ek((size_t)F.n);
+        std::vector<uint8_t> eo((size_t)F.n), vw((size_t)std::max(1, (int)r->skip_static.size() + (int)(r->mp_X.size() / 3)));
+        int32_t nm2 = 0, ne2 = 0, inl2 = 0, info2[2];
+        float T2[12];
+        so_track_stage_set_start_pose(r->matcher2, S.Tp);
+        const int rc2 = so_track_stage_wait(r->matcher2, k2.data(), &nm2, vw.data(), &ne2, ek.data(), eo.data(), T2, &inl2, info2);
+        if (rc2 != SO_OK && rc2 != SO_RETRY_ON_HOST) return fail(r, "so_track_stage_wait (linked stage)");
+        S.stage2_linked = false;
+    }
     if (!ok || nm < 20) {  // not finished on the device, or Tracking.cc:733-737's wider window: the separate calls
         S.stage1_dev = false;
         const float th = ok ? 30.0f : 15.0f;
@@ -1230,6 +1279,10 @@ int step_m1_submit(so_replay* r) {
         }
         for (int i = 0; i < nl; i++)
             if (M.tv_seen[(size_t)M.tv_local[(size_t)i]] == S.t) r->skip[(size_t)i] = 1;  // already matched: mbTrackInView = false (:966-978)
+        if (S.stage2_linked) {  // in flight behind stage 1 already (step_m1_submit_linked): the arrays above are the host's own bookkeeping
+            S.stage2_dev = true;  // and the inputs of the separate calls should the stage be handed back
+            return SO_OK;
+        }
         if (track_chain_on(r) && (!r->lockstep || r->fleet_chain)) {
             const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, nl, M.tv_local.data(), 0,
                                                            r->skip.data(), 1.0f, 0.8f, 0.5f, r->log_sf, r->K4, r->inv_sigma2);
@@ -1256,6 +1309,10 @@ int step_m1_submit(so_replay* r) {
         const int s = F.kp_mp[(size_t)k];
         r->excluded[(size_t)k] = s >= 0 ? 1 : 0;
         if (s >= first) r->skip[(size_t)(s - first)] = 1;  // already matched: mbTrackInView = false (:966-978)
+    }
+    if (S.stage2_linked) {
+        S.stage2_dev = true;
+        return SO_OK;
     }
     if (track_chain_on(r) && (!r->lockstep || r->fleet_chain)) {
         const int rc = so_track_stage_local_map_submit(r->matcher, r->fr[S.hcur], F.kp_mp.data(), S.stage1_dev ? 1 : 0, r->map, S.Ta, S.n_local, nullptr, first,
@@ -1284,7 +1341,8 @@ int step_m1_wait(so_replay* r) {
     double ms4[4];
     if (S.stage2_dev) {  // search, resolve and the second PoseOptimization came back together
         int rc = SO_OK;
-        if (!stage_collect(r, r->k2m, &nmm, view.data(), S.Tb, &S.n_in, &rc)) {
+        if (S.stage2_linked) so_track_stage_set_start_pose(r->matcher2, S.Ta);
+        if (!stage_collect(r, r->k2m, &nmm, view.data(), S.Tb, &S.n_in, &rc, S.stage2_linked ? r->matcher2 : r->matcher)) {
             if (rc) return rc;
             S.stage2_dev = false;  // not finished on the device: the separate calls, from the search on
             if (so_track_search_local_map(r->matcher, r->fr[S.hcur], r->excluded.data(), r->map, S.Ta, S.n_local,
@@ -1566,21 +1624,22 @@ static int run_one_step(so_replay* r, int t, int timed) {
                 int32_t inl3 = 0;
                 // the keyframe decision and the new map points only need the second result: they run under this kernel
                 bool done3 = false;
-                if (S.stage2_dev && so_track_stage_pose_again_submit(r->matcher, Tl) == SO_OK) {  // the same edges, still on the device
+                so_matcher* sm = S.stage2_linked ? r->matcher2 : r->matcher;
+                if (S.stage2_dev && so_track_stage_pose_again_submit(sm, Tl) == SO_OK) {  // the same edges, still on the device
                     if ((rc = step_keyframe(r))) return rc;
                     std::vector<int32_t>& ek = r->k2l;  // scratch: the edge list comes back unchanged
                     std::vector<uint8_t>& eo = r->excluded;
                     ek.resize((size_t)r->fh[r->cur].n);
                     eo.resize((size_t)r->fh[r->cur].n);
                     int32_t ne = 0, info2[2] = {0, 0};
-                    const int rc3 = so_track_stage_wait(r->matcher, nullptr, nullptr, nullptr, &ne, ek.data(), eo.data(), Tc, &inl3, info2);
+                    const int rc3 = so_track_stage_wait(sm, nullptr, nullptr, nullptr, &ne, ek.data(), eo.data(), Tc, &inl3, info2);
                     if (rc3 != SO_OK && rc3 != SO_RETRY_ON_HOST) return fail(r, "so_track_stage_wait");
                     done3 = true;
                     if (rc3 == SO_OK) {
                         S.pose_calls++;
                         if (S.timed_kernels) {
                             float kms = 0.f;
-                            so_track_stage_last_pose_kernel_ms(r->matcher, &kms);
+                            so_track_stage_last_pose_kernel_ms(sm, &kms);
                             S.pose_kernel += kms;
                             S.pose_trials += info2[1];
                             S.pose_points += ne;
@@ -1927,6 +1986,9 @@ int so_replay_drain(so_replay* r) {
 // Collects the frame left in flight by so_replay_run (end of a run; its extraction was part of the timed region).
 int so_replay_finish(so_replay* r) {
     if (!r) return SO_ERR_INVALID_ARG;
+    if (r->cl && r->cl->n_handover > 0 && getenv("SWARMORB_CL_TRACE"))
+        fprintf(stderr, "[cycle] packet arrival -> next keyframe handed over: %.3f ms mean over %d keyframes; tracking thread waited %.3f ms per keyframe\n",
+                r->cl->handover_ms / r->cl->n_handover, r->cl->n_handover, r->cl->wait_ms / r->cl->n_handover);
     if (r->in_flight) {
         int n = 0;
         so_replay::FrameHost& F = r->fh[r->cur ^ 1];  // scratch: the last frame's host arrays are not needed any more

@@ -132,6 +132,8 @@ struct ClosedLoop {
     int last_kf_t = 0, n_kf = 0, apply_at = 0, interrupts = 0;
     bool job_pending = false;
     double wait_ms = 0.0;
+    double t_packet = 0.0, handover_ms = 0.0;  // when the last packet arrived; summed time from there to the next keyframe's hand-over
+    int n_handover = 0;
     double apply_ms = 0.0;  // tracking thread: applying the packets (map rows, flags, last-frame fix-ups)
     std::vector<int32_t> ref_log, kf_t;  // per frame: id of its reference keyframe; per keyframe: frame index
     std::vector<double> Tcr_log;         // per frame: pose relative to the reference keyframe (16)
@@ -187,6 +189,7 @@ struct so_replay {
     // one being extracted ahead
     so_dframe* fr[3] = {nullptr, nullptr, nullptr};
     so_matcher* matcher = nullptr;
+    so_matcher* matcher2 = nullptr;  // the local-map stage when it is enqueued behind the last-frame stage (so_track_stage_local_map_submit_after)
     so_map* map = nullptr;
     so_ba* tracker_opt = nullptr;
     so_ba* mapper_opt = nullptr;
@@ -248,7 +251,7 @@ struct so_replay {
     std::vector<int32_t> kf_first_slot;
     // scratch
     std::vector<int32_t> last_slot, k2l, k2m, idx, local_slot;
-    std::vector<uint8_t> skip, excluded, pose_out;
+    std::vector<uint8_t> skip, skip_static, excluded, pose_out;
     std::vector<float> pX, pobs, pw, new_X, new_N, new_max, new_min;
     std::vector<uint8_t> new_desc;
     // log (every tracked frame)
@@ -274,6 +277,7 @@ struct so_replay {
         bool kf_queued = false;  // closed loop: the frame went to local mapping as a keyframe already (under its last PoseOptimization)
         bool first = false, m2_submitted = false, timed_kernels = true, next_submitted = false;
         bool stage1_dev = false, stage2_dev = false;  // the stage's search -> resolve -> pose chain is on the device (so_track_stage_*)
+        bool stage2_linked = false;  // ... and stage 2 went out right behind stage 1, on matcher2, before stage 1 was waited for
         int m2_rc = 0;
         float Tp[12] = {0}, Ta[12] = {0}, Tb[12] = {0}, Tc[12] = {0}, Tl[12] = {0};
         bool third_dev = false;  // fleet: the third PoseOptimization went out with the group (so_track_stage_pose_again_submit)

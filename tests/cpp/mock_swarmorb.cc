@@ -48,11 +48,12 @@ struct so_dframe { so_camera cam; int n = 0; bool ready = false; };
 struct so_matcher {
     const so_dframe* cur = nullptr;
     const so_map* map = nullptr;
-    std::vector<int32_t> slots, kp_slot;
+    std::vector<int32_t> slots, kp_slot, last_slots;
     std::vector<uint8_t> skip, excluded;
     int mode = 0, n_local = 0, first_slot = 0;
     float T[12];
     bool stage = false, again = false;
+    const so_matcher* linked_to = nullptr;  // so_track_stage_local_map_submit_after: the bindings come from that matcher's stage
     std::vector<int32_t> edges;
     bool batching = false;
 };
@@ -262,6 +263,18 @@ int so_track_stage_local_map_submit(so_matcher* m, const so_dframe* cur, const i
     memcpy(m->T, T, 48);
     return SO_OK;
 }
+int so_track_stage_local_map_submit_after(so_matcher* m, so_matcher* first, const so_dframe* cur, const so_map* map, int32_t n_local, const int32_t* local_slot,
+                                          int32_t first_slot, const uint8_t* skip, float, float, float, float, const float*, const float*) {
+    if (!first->stage || first->mode != 2) return SO_ERR_INVALID_ARG;
+    m->cur = cur; m->map = map; m->stage = true; m->again = false; m->mode = 3; m->n_local = n_local; m->first_slot = first_slot;
+    m->linked_to = first;
+    m->kp_slot.assign((size_t)cur->n, -1);
+    if (local_slot) m->slots.assign(local_slot, local_slot + n_local); else m->slots.clear();
+    if (skip) m->skip.assign(skip, skip + n_local); else m->skip.clear();
+    memcpy(m->T, first->T, 48);
+    return SO_OK;
+}
+int so_track_stage_set_start_pose(so_matcher* m, const float* T) { memcpy(m->T, T, 48); return SO_OK; }
 int so_track_stage_pose_again_submit(so_matcher* m, const float* T) {
     if (m->edges.empty()) return SO_ERR_INVALID_ARG;
     m->again = true;
@@ -274,6 +287,7 @@ int so_track_stage_wait(so_matcher* m, int32_t* k2q, int32_t* nm, uint8_t* in_vi
     if (!m->again) {
         m->edges.clear();
         if (m->mode == 2) {
+            m->last_slots = m->slots;
             int c = 0;
             for (int k = 0; k < n; k++) {
                 const bool ok = k < (int)m->slots.size() && m->slots[(size_t)k] >= 0 && (k % 11) != 0 && !(m->slots[(size_t)k] < kN && (k % 7) == 3);
@@ -283,6 +297,18 @@ int so_track_stage_wait(so_matcher* m, int32_t* k2q, int32_t* nm, uint8_t* in_vi
             }
             *nm = c;
         } else {
+            if (m->linked_to) {  // the bindings the first stage left: its matches minus its pose's outliers; already-bound local points are skipped
+                const so_matcher* f = m->linked_to;
+                for (int e : f->edges)
+                    if ((e % 97) != 5 && e < (int)f->last_slots.size()) m->kp_slot[(size_t)e] = f->last_slots[(size_t)e];
+                if (m->skip.empty()) m->skip.assign((size_t)m->n_local, 0);
+                for (int i = 0; i < m->n_local; i++) {
+                    const int slot = m->slots.empty() ? m->first_slot + i : m->slots[(size_t)i];
+                    for (int k = 0; k < n; k++)
+                        if (m->kp_slot[(size_t)k] == slot) { m->skip[(size_t)i] = 1; break; }
+                }
+                m->linked_to = nullptr;
+            }
             std::vector<uint8_t> excl((size_t)n);
             for (int k = 0; k < n; k++) excl[(size_t)k] = m->kp_slot[(size_t)k] >= 0;
             local_search(m->cur, excl.data(), m->map, m->n_local, m->slots.empty() ? nullptr : m->slots.data(), m->first_slot,
