@@ -84,3 +84,41 @@ def test_grouped_local_bundle_adjustments_equal_the_solo_calls():
         o.close()
     g.close()
     g1.close()
+
+
+def test_more_members_than_an_argument_block_holds_and_a_stop_request():
+    """Eleven windows in one group (a grouped launch carries eight: the ninth starts another launch of the same step), one of
+    them with pbStopFlag raised before the call - Optimizer::LocalBundleAdjustment returns its input there (code/src/Optimizer.cc:
+    631-633) without joining the round - and one whose flag is raised while it waits: results as in solo calls."""
+    n = 11
+    windows = [synth.make_ba_case("LBA-S", seed=30 + i) for i in range(n)]
+    opts = [swarmmap_amd.Optimizer() for _ in range(n)]
+    solo = [o.LocalBundleAdjustment(w) for o, w in zip(opts, windows)]
+    stop_set = np.ones(1, np.uint8)
+    solo_stopped = opts[3].LocalBundleAdjustment(windows[3], pbStopFlag=stop_set)
+    assert solo_stopped["info"]["aborted"] == 1 and solo_stopped["info"]["lm_trials"] == 0
+    g = BaGroup(window_us=30000.0)
+    for o in opts:
+        o.set_group(g)
+    out, errs = [None] * n, []
+
+    def worker(i):
+        try:
+            out[i] = opts[i].LocalBundleAdjustment(windows[i], pbStopFlag=stop_set if i == 3 else None)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(n)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    st = g.stats()
+    for i in range(n):
+        _same(out[i], solo_stopped if i == 3 else solo[i], "window %d of eleven" % i)
+    assert st["members_total"] == n - 1  # (the stopped call never reached the group)
+    assert st["rows_launched"] > 4 * st["grouped_launches"], st  # rounds of many members ...
+    for o in opts:
+        o.close()
+    g.close()

@@ -126,3 +126,52 @@ def test_a_group_of_one_and_a_launch_of_mixed_kinds(S, oracle):
     _same(b.stage1(), s1b, "after a refused launch")
     a.close()
     b.close()
+
+
+def test_a_member_that_is_handed_back_does_not_disturb_the_others(S, oracle):
+    """Three members run the local-map stage on an empty set of bindings; the middle one's map is forty copies of fifty points
+    (its K-lists run out: the stage is handed back, SO_RETRY_ON_HOST at its wait) - the other two get their solo results, and the
+    handed-back member's plain search afterwards is the oracle's."""
+    from swarmmap_amd.matcher import FrameView
+    from test_dframe_gpu import _frame_and_view as fv
+    agents = []
+    for seed, crowded in ((81, False), (77, True), (83, False)):
+        rng = np.random.default_rng(seed)
+        ex, cur, ck, cxy, cd, F = fv(S, oracle, seed)
+        Tc = _pose(rng)
+        Xw, normal, mx, mn, md = _make_map(rng, cxy, ck, cd, synth.EUROC_K, Tc, n_extra=0)
+        if crowded:
+            rep = np.repeat(rng.permutation(len(ck))[:50], 40)
+            Xw = (Xw[rep] + rng.normal(0, 0.002, (len(rep), 3))).astype(np.float32)
+            normal, mx, mn, md = normal[rep], mx[rep], mn[rep], synth.flip_bits(rng, md[rep], 0.02)
+        dmap = S.DeviceMap()
+        dmap.append(Xw, normal, mx, mn, md)
+        agents.append(dict(ex=ex, cur=cur, F=F, Tc=Tc, Xw=Xw, normal=normal, mx=mx, mn=mn, md=md, dmap=dmap, m=S.ORBmatcher(0.8, True),
+                           kp_slot=np.full(len(ck), -1, np.int32), th=6.0 if crowded else 1.0))
+
+    def stage(a, wait=True):
+        return dfm.track_stage_local_map(a["m"], a["cur"], a["kp_slot"], a["dmap"], a["Tc"], len(a["Xw"]), a["th"], 0.5, LOG_SF, K4, INV_SIGMA2, wait=wait)
+
+    solo = [stage(a) for a in agents]
+    assert solo[0] is not None and solo[2] is not None
+    g = dfm.TrackGroup([a["m"] for a in agents])
+    waits = [stage(a, wait=False) for a in agents]
+    g.launch()
+    grp = [w() for w in waits]
+    g.close()
+    for i in (0, 2):
+        _same(grp[i], solo[i], "member %d beside a handed-back one" % i)
+    assert (grp[1] is None) == (solo[1] is None)
+    if grp[1] is not None:
+        _same(grp[1], solo[1], "the crowded member")
+    a = agents[1]
+    cam = oracle.camera(synth.EUROC_K, synth.EUROC_DIST)
+    fr = oracle.is_in_frustum(cam, a["cur"].bounds, a["Tc"], a["Xw"], a["normal"], a["mx"], a["mn"], 0.5, LOG_SF, 8)
+    mps = dict(in_view=fr["in_view"], proj_x=fr["proj_x"], proj_y=fr["proj_y"], view_cos=fr["view_cos"], pred_level=fr["pred_level"],
+               desc=a["md"], has_obs=np.ones(len(a["Xw"]), np.uint8))
+    onm, ok2m = oracle.search_by_projection_mappoints(a["F"], mps, 6.0, 0.8)
+    nm, k2m, _ = dfm.search_local_map(a["m"], a["cur"], a["dmap"], a["Tc"], len(a["Xw"]), 6.0, 0.5, LOG_SF)
+    assert nm == onm and np.array_equal(k2m, ok2m)
+    for a in agents:
+        for h in (a["m"], a["dmap"], a["cur"], a["ex"]):
+            h.close()
