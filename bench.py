@@ -247,7 +247,7 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
     w, h = size
     closed = (LOOP == "closed") if closed is None else closed
     warmup = warmup + LM_PREFILL_FRAMES
-    n_frames = warmup + steps + 2
+    n_frames = warmup + steps + 2 + LBA_EVERY
     fleet, keep, streams = [], [], []
     for a in range(agents):
         stream = synth.FrameStream(seed=seed + 97 * a, size=size, K=K, dist=dist)
@@ -266,6 +266,19 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
             rp.preallocate()
         rp.prime(0)
         fleet.append(rp)
+    # Staggered keyframes: agent a is run alone for (a mod kf_every) frames first, so that inside the fleet it is that many frames
+    # ahead of the clock and its keyframes - every kf_every-th frame of ITS stream, as in its solo run - fall on other ticks than
+    # its neighbours': the local-mapping jobs of the agents do not all start (and queue their kernels) in the same instant, and no
+    # tick waits for the slowest of eight jobs.  Real agents are not synchronised either.  Opt-in (SWARMORB_FLEET_STAGGER=1): measured
+    # at 8 agents it removes the trackers' waits (141 -> 5-20 ms per agent) but a lockstep tick then stalls on whichever agent's job is
+    # late, 5.6-5.9 k frames/s against 6.3 k in step (NOTES.md G.8).
+    stagger = closed and bool(os.environ.get("SWARMORB_FLEET_STAGGER"))
+    if stagger:
+        for a, rp in enumerate(fleet):
+            off = a % LBA_EVERY
+            if off:
+                rp.run(0, off, False)
+                rp.set_fleet_offset(off)
     # `fleet_threads` driving threads, each with an equal share of the agents in lockstep (its own so_track_group and stream:
     # the handles a thread uses were created by it).  One thread: everything above ran on this one.
     T = max(1, min(fleet_threads, agents))
@@ -288,6 +301,7 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
     results = []
     fleet_lm = fleet[0].lm_stats()
     cl0 = fleet[0].closed_loop_log() if closed else None
+    ticks = fleet[0].fleet_ticks()  # (elastic ticks: how many there were and how many agent places they filled - warm-up included)
     for rp in fleet:
         rp.finish()
         results.append((rp.stats(), rp.candidates_total(), rp.log()))
@@ -297,7 +311,8 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
         rp.close()
     stats = {k: sum(r[0][k] for r in results) / agents for k in results[0][0] if k not in ("stages", "frame_ms")}
     stats["frame_ms"] = np.concatenate([np.asarray(r[0]["frame_ms"])[-steps:] for r in results])
-    stats.update({"n_xchg": 0, "xchg_ms": 0.0, "lm": fleet_lm, "closed": closed, "cgroup": cg})
+    stats.update({"n_xchg": 0, "xchg_ms": 0.0, "lm": fleet_lm, "closed": closed, "cgroup": cg,
+                  "fleet_ticks": {"ticks": ticks[0], "agents_per_tick": round(ticks[1] / max(ticks[0], 1), 3), "staggered": bool(stagger)}})
     if closed:
         stats.update({"cl": cl0, "stream": streams[0], "timed_from": warmup})
     return dt, stats, results[0][1], keep[0][1], results[0][2]
@@ -933,7 +948,7 @@ def headline(full, full_path):
                        for r in (full["roofline_secondary"], full["roofline_tertiary"])}
     head = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data")}
-    head.update({"fps_per_agent": full["fps_per_agent"], "agents_per_gpu": full["agents_per_gpu"], "host_loop": full["host_loop"], "host_cpu": full.get("host_cpu"),
+    head.update({"fps_per_agent": full["fps_per_agent"], "agents_per_gpu": full["agents_per_gpu"], "host_loop": full["host_loop"], "host_cpu": full.get("host_cpu"), "fleet_ticks": full.get("fleet_ticks"),
                  "launch": full["launch"][:120], "config": hconfig, "roofline": hroof})
     if "cpu_baseline" in full:
         c = full["cpu_baseline"]
@@ -1139,6 +1154,7 @@ def main():
             "host_loop": "c++ (swarmmap_amd/host/replay.cc)" + (", %d agents in lockstep on one thread (so_fleet_run)" % A
                                                                   if args.lockstep and A > 1 else ""),
             "fps_per_agent": steps / dt, "agents_per_gpu": A,
+            "fleet_ticks": st.get("fleet_ticks"),
             "host_cpu": st.get("cgroup"),  # cores used / the container's quota / CFS throttling inside the timed region
             "pinned_cpus": None if not pinned_cpus else ",".join(_cpu_ranges(pinned_cpus)),
             "config": dict({
@@ -1238,10 +1254,14 @@ def main():
                     # drives the agents' tracking with the stages of all agents as one chain of launches per stage
                     # (so_track_group), their local bundle adjustments merged per round (so_ba_group), a local-mapping thread each
                     apg = {"1": cfgs["steady_state"]["frames_per_s"]}
-                    for A_ in (4, 8):
+                    fill = {}
+                    for A_ in (4, 8, 16):
                         fdt, fst, _, _, _ = run_fleet(dev, size, K, dist, nfeatures, 200, 20, SEED_BASE, lba_window, barrier, A_)
                         apg[str(A_)] = 200 * A_ / fdt
-                    cfgs["agents_per_gpu"] = dict(apg, note="aggregate frames/s, closed loop, --lockstep; 1 = the headline's steady-state figure")
+                        fill[str(A_)] = fst["fleet_ticks"]["agents_per_tick"]
+                    cfgs["agents_per_gpu"] = dict(apg, note="aggregate frames/s, closed loop, --lockstep (elastic ticks: an agent whose frame "
+                                                            "waits for its local-mapping packet sits the tick out); 1 = the headline's steady-state figure")
+                    cfgs["agents_per_gpu_tick_fill"] = fill  # agents a tick took on average
                 cfgs["front_end_batched"] = batched_front_end_records(dev)
                 cfgs["candidate_search"] = candidate_search_records(dev)
                 cfgs["local_ba_windows"] = lba_records(dev)

@@ -104,7 +104,8 @@ int so_extractor_submit(so_extractor* ex, const uint8_t* image, int width, int h
  * nearly idle (one workgroup per pyramid level in the quadtree, ~1000 small workgroups elsewhere), so n frames take
  * hardly longer than one.  Members: same configuration, same device, device quadtree path; images: tightly packed,
  * device-visible (pinned host memory or device memory), all of one size; at most SO_EXTRACTOR_GROUP_MAX members.  The
- * group does not own its members; destroy it before them. */
+ * group does not own its members; destroy it before them.  images[i] == NULL: member i sits this chain out (nothing of it
+ * is read, written or expected back - its earlier frame may still be uncollected); at least one member must take part. */
 #define SO_EXTRACTOR_GROUP_MAX 64
 typedef struct so_extractor_group so_extractor_group;
 int so_extractor_group_create(so_extractor* const* members, int n, so_extractor_group** out);
@@ -570,7 +571,8 @@ void so_dframe_destroy(so_dframe* f);
  * extractor's stream; returns without waiting.  One frame in flight per extractor. */
 int so_dframe_submit(so_dframe* f, const uint8_t* image, int width, int height, int stride);
 /* so_dframe_submit for frame i on member i of an extractor group, all in one chain of launches (the Frame constructors'
- * kernel too: one workgroup per frame).  Every frame is waited for / collected as usual. */
+ * kernel too: one workgroup per frame).  Every frame is waited for / collected as usual.  images[i] == NULL: member i sits
+ * this chain out and frames[i] is ignored (agents that share a GPU but not a clock: so_fleet_run's elastic ticks). */
 int so_dframe_group_submit(so_extractor_group* group, so_dframe* const* frames, const uint8_t* const* images, int width,
                            int height, int stride);
 int so_dframe_submit_device(so_dframe* f, const uint8_t* d_image, int width, int height, int stride);

@@ -252,7 +252,10 @@ int so_dframe_group_submit(so_extractor_group* g, so_dframe* const* frames, cons
                            int height, int stride) {
     if (!g || !frames || !images || width <= 0 || height <= 0) return SO_ERR_INVALID_ARG;
     const int n = extractor_group_size(g);
+    int n_in = 0;
     for (int i = 0; i < n; i++) {
+        if (!images[i]) continue;  // member i sits this chain out (frames[i] is not looked at)
+        n_in++;
         so_dframe* f = frames[i];
         if (!f || f->ex != extractor_group_member(g, i)) {
             last_error_ref() = "so_dframe_group_submit: frame i must be built on member i of the group";
@@ -262,15 +265,16 @@ int so_dframe_group_submit(so_extractor_group* g, so_dframe* const* frames, cons
             last_error_ref() = "so_dframe_submit: the previous frame of this handle has not been collected";
             return SO_ERR_INVALID_ARG;
         }
-        if (!images[i]) return SO_ERR_INVALID_ARG;
     }
+    if (n_in == 0) return SO_ERR_INVALID_ARG;
     int rc = extractor_group_prepare(g, width, height);  // the members' buffers exist from here on
     if (rc) return rc;
     std::vector<FramePrepareArgs> preps((size_t)n);
     for (int i = 0; i < n; i++)
-        if ((rc = prepare_args(frames[i], width, height, &preps[(size_t)i]))) return rc;
+        if (images[i] && (rc = prepare_args(frames[i], width, height, &preps[(size_t)i]))) return rc;
     if ((rc = extractor_group_submit(g, images, width, height, stride, preps.data()))) return rc;
     for (int i = 0; i < n; i++) {
+        if (!images[i]) continue;
         so_dframe* f = frames[i];
         f->ready = false;
         f->waited = false;

@@ -624,23 +624,29 @@ struct so_extractor_group {
     hipStream_t stream = nullptr;          // the first member's
     ExtractBatchMember* d_members = nullptr;
     std::vector<ExtractBatchMember> h_members;
-    const uint8_t** h_srcs = nullptr;      // host-mapped: this frame's images as the device sees them
+    // Host-mapped, rewritten per submit and read by the chain's first kernel only (which leaves what the later kernels need in
+    // d_members): this frame's images as the device sees them - null: the member sits this chain out - and which of the member's
+    // Frame-constructor launches rides at the end of the chain.  One captured chain therefore serves every set of members and
+    // every combination of the frames they rotate.
+    const uint8_t** h_srcs = nullptr;
     const uint8_t** h_srcs_dev = nullptr;
-    // One captured chain per set of Frame-constructor launches riding at its end (so_dframe_group_submit: the tracking
-    // loop rotates three device-resident frames per agent) - slot k's launches live at d_prep + k * members.
-    struct Slot {
-        std::vector<FramePrepareArgs> prep;  // empty: the chain without the Frame constructors
+    int32_t* h_sel = nullptr;
+    int32_t* h_sel_dev = nullptr;
+    // The Frame-constructor launches (so_dframe_group_submit: the tracking loop rotates three device-resident frames per agent):
+    // kRot rows per member in HBM, a row per frame handle the member has been submitted with (least recently used row replaced).
+    static constexpr int kRot = 4;
+    FramePrepareArgs* d_prep = nullptr;    // members x kRot
+    std::vector<FramePrepareArgs> h_prep;  // what the rows hold
+    std::vector<unsigned long long> prep_use;  // 0: row never written
+    struct Slot {                          // index: rows16 * 2 + with_prep
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        bool rows16 = false;
-        unsigned long long last_use = 0;
     };
-    static constexpr int kSlots = 4;
-    FramePrepareArgs* d_prep = nullptr;    // kSlots x members
     std::vector<Slot> slots;
     unsigned long long use_clock = 0;
     bool graph_failed = false;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;             // behind the last chain: h_srcs / h_sel / a prep row may be rewritten once it has fired
+    bool launched = false;
     int width = 0, height = 0;
 };
 
@@ -712,7 +718,8 @@ int extractor_group_prepare(so_extractor_group* g, int w, int h) {
     return SO_OK;
 }
 
-// so_extractor_group_submit; preps (one per member, or null): the members' frame_prepare launches ride at the end of the chain
+// so_extractor_group_submit; preps (one per member, or null): the members' frame_prepare launches ride at the end of the chain.
+// images[i] == null: member i sits this chain out (nothing of it is read, written or expected back)
 int extractor_group_submit(so_extractor_group* g, const uint8_t* const* images, int w, int h, int stride, const FramePrepareArgs* preps) {
     if (!g || !images || w <= 0 || h <= 0) return SO_ERR_INVALID_ARG;
     if (stride != w) {
@@ -721,56 +728,64 @@ int extractor_group_submit(so_extractor_group* g, const uint8_t* const* images, 
     }
     const double t_begin = now_ms();
     const int n = (int)g->m.size();
-    for (so_extractor* ex : g->m)
-        if (ex->pending) {
+    int n_in = 0;
+    for (int i = 0; i < n; i++) {
+        if (!images[i]) continue;
+        n_in++;
+        if (g->m[(size_t)i]->pending) {
             last_error_ref() = "a submitted frame has not been collected";
             return SO_ERR_INVALID_ARG;
         }
+    }
+    if (n_in == 0) return SO_ERR_INVALID_ARG;
     int rc = extractor_group_prepare(g, w, h);
     if (rc) return rc;
     bool rows16 = (w & 15) == 0;
+    std::vector<const uint8_t*> srcs((size_t)n, nullptr);
     for (int i = 0; i < n; i++) {
-        if (!images[i]) return SO_ERR_INVALID_ARG;
+        if (!images[i]) continue;
         hipPointerAttribute_t attr{};
         if (hipPointerGetAttributes(&attr, images[i]) != hipSuccess || !attr.devicePointer) {
             (void)hipGetLastError();
             last_error_ref() = "so_extractor_group_submit: every image must be device-visible (pinned host memory or device memory)";
             return SO_ERR_INVALID_ARG;
         }
-        g->h_srcs[i] = static_cast<const uint8_t*>(attr.devicePointer);
+        srcs[(size_t)i] = static_cast<const uint8_t*>(attr.devicePointer);
         const LevelDesc& L0 = g->m[(size_t)i]->P.lv[0];
-        rows16 = rows16 && (reinterpret_cast<uintptr_t>(g->h_srcs[i]) & 15) == 0 && (L0.pitch & 15) == 0 &&
+        rows16 = rows16 && (reinterpret_cast<uintptr_t>(srcs[(size_t)i]) & 15) == 0 && (L0.pitch & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(L0.img) & 15) == 0;
     }
-    // the slot that holds this set of Frame-constructor launches (or none of them)
-    if (g->slots.empty()) g->slots.resize(so_extractor_group::kSlots);
-    so_extractor_group::Slot* sl = nullptr;
-    for (auto& c : g->slots)
-        if (c.last_use && c.prep.size() == (preps ? (size_t)n : 0) &&
-            (!preps || memcmp(c.prep.data(), preps, sizeof(FramePrepareArgs) * (size_t)n) == 0))
-            sl = &c;
     hipStream_t s = g->stream;
-    if (!sl) {
-        sl = &g->slots[0];
-        for (auto& c : g->slots)
-            if (c.last_use < sl->last_use) sl = &c;  // never used, or used longest ago
-        if (sl->last_use) SO_HIP(hipStreamSynchronize(s));  // a chain that reads the slot's launches may be in flight
-        slot_drop_graph(*sl);
-        sl->prep.clear();
-        if (preps) {
-            sl->prep.assign(preps, preps + n);
-            SO_HIP(so::memcpy_sync(g->d_prep + (size_t)(sl - g->slots.data()) * (size_t)n, preps, sizeof(FramePrepareArgs) * (size_t)n,
-                                   hipMemcpyHostToDevice));
-        }
-    }
-    sl->last_use = ++g->use_clock;
+    // the chain before this one has read its rows of the host-mapped tables (it went out a whole frame ago: this does not wait)
+    if (g->launched) SO_HIP(hipEventSynchronize(g->done));
     const bool with_prep = preps != nullptr;
-    const FramePrepareArgs* d_prep = g->d_prep + (size_t)(sl - g->slots.data()) * (size_t)n;
-    if (sl->exec && sl->rows16 != rows16) slot_drop_graph(*sl);
+    constexpr int kRot = so_extractor_group::kRot;
+    for (int i = 0; i < n; i++) {
+        g->h_srcs[i] = srcs[(size_t)i];
+        g->h_sel[i] = 0;
+        if (!with_prep || !srcs[(size_t)i]) continue;
+        // the member's row that holds this frame handle's launch (written once per handle: the arguments do not change)
+        int row = -1, lru = 0;
+        for (int k = 0; k < kRot; k++) {
+            const size_t q = (size_t)i * kRot + (size_t)k;
+            if (g->prep_use[q] && memcmp(&g->h_prep[q], &preps[i], sizeof(FramePrepareArgs)) == 0) row = k;
+            if (g->prep_use[q] < g->prep_use[(size_t)i * kRot + (size_t)lru]) lru = k;
+        }
+        if (row < 0) {
+            row = lru;
+            const size_t q = (size_t)i * kRot + (size_t)row;
+            g->h_prep[q] = preps[i];
+            SO_HIP(so::memcpy_sync(g->d_prep + q, &preps[i], sizeof(FramePrepareArgs), hipMemcpyHostToDevice));
+        }
+        g->prep_use[(size_t)i * kRot + (size_t)row] = ++g->use_clock;
+        g->h_sel[i] = row;
+    }
+    if (g->slots.empty()) g->slots.resize(4);
+    so_extractor_group::Slot* sl = &g->slots[(rows16 ? 2 : 0) + (with_prep ? 1 : 0)];
     const int capacity = g->m[0]->out_capacity;
     auto chain = [&]() {
-        launch_extract_batch(g->d_members, g->h_members[0], n, g->h_srcs_dev, w, h, rows16, capacity, s);
-        if (with_prep) launch_frame_prepare_batch(d_prep, n, s);
+        launch_extract_batch(g->d_members, g->h_members[0], n, g->h_srcs_dev, g->h_sel_dev, w, h, rows16, capacity, s);
+        if (with_prep) launch_frame_prepare_batch(g->d_prep, kRot, g->d_members, n, s);
     };
     static const bool no_graph = getenv("SWARMORB_NO_GRAPH") != nullptr;
     if (!sl->exec && !no_graph && !g->graph_failed) {
@@ -784,22 +799,21 @@ int extractor_group_submit(so_extractor_group* g, const uint8_t* const* images, 
             (void)hipGetLastError();
             slot_drop_graph(*sl);
             g->graph_failed = true;
-        } else {
-            sl->rows16 = rows16;
         }
     }
     if (sl->exec) SO_HIP(hipGraphLaunch(sl->exec, s));
     else chain();
     SO_HIP(hipGetLastError());
-    bool other_streams = false;
-    for (so_extractor* ex : g->m) other_streams = other_streams || ex->stream != s;
-    if (other_streams) {  // a member's collect waits on the member's own stream
-        SO_HIP(hipEventRecord(g->done, s));
-        for (so_extractor* ex : g->m)
-            if (ex->stream != s) SO_HIP(hipStreamWaitEvent(ex->stream, g->done, 0));
+    SO_HIP(hipEventRecord(g->done, s));
+    g->launched = true;
+    for (int i = 0; i < n; i++) {  // a member's collect waits on the member's own stream
+        so_extractor* ex = g->m[(size_t)i];
+        if (srcs[(size_t)i] && ex->stream != s) SO_HIP(hipStreamWaitEvent(ex->stream, g->done, 0));
     }
     const double t_enq = now_ms();
-    for (so_extractor* ex : g->m) {
+    for (int i = 0; i < n; i++) {
+        so_extractor* ex = g->m[(size_t)i];
+        if (!srcs[(size_t)i]) continue;
         ex->tail_owner = nullptr;
         ex->tail_revision = 0;
         ex->tail_fn = nullptr;
@@ -911,9 +925,13 @@ int so_extractor_group_create(so_extractor* const* members, int n, so_extractor_
     hipError_t e;
     if ((e = hipSetDevice(g->device)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void**)&g->d_members, sizeof(ExtractBatchMember) * (size_t)n)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&g->d_prep, sizeof(FramePrepareArgs) * (size_t)n * so_extractor_group::kSlots)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&g->d_prep, sizeof(FramePrepareArgs) * (size_t)n * so_extractor_group::kRot)) != hipSuccess) return fail(e);
+    g->h_prep.resize((size_t)n * so_extractor_group::kRot);
+    g->prep_use.assign((size_t)n * so_extractor_group::kRot, 0);
     if ((e = hipHostMalloc((void**)&g->h_srcs, sizeof(void*) * (size_t)n, hipHostMallocMapped)) != hipSuccess) return fail(e);
     if ((e = hipHostGetDevicePointer((void**)&g->h_srcs_dev, g->h_srcs, 0)) != hipSuccess) return fail(e);
+    if ((e = hipHostMalloc((void**)&g->h_sel, sizeof(int32_t) * (size_t)n, hipHostMallocMapped)) != hipSuccess) return fail(e);
+    if ((e = hipHostGetDevicePointer((void**)&g->h_sel_dev, g->h_sel, 0)) != hipSuccess) return fail(e);
     if ((e = hipEventCreateWithFlags(&g->done, hipEventDisableTiming)) != hipSuccess) return fail(e);
     *out = g;
     return SO_OK;
@@ -927,6 +945,7 @@ void so_extractor_group_destroy(so_extractor_group* g) {
     if (g->d_members) (void)hipFree(g->d_members);
     if (g->d_prep) (void)hipFree(g->d_prep);
     if (g->h_srcs) (void)hipHostFree(g->h_srcs);
+    if (g->h_sel) (void)hipHostFree(g->h_sel);
     if (g->done) (void)hipEventDestroy(g->done);
     delete g;
 }

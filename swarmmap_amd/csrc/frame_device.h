@@ -46,7 +46,9 @@ struct FramePrepareArgs {
     int32_t* header_host;      // host-mapped {n, n_inside, 0, 0} + bounds[4] as float bits
 };
 void launch_frame_prepare(const FramePrepareArgs& a, hipStream_t s);
-void launch_frame_prepare_batch(const FramePrepareArgs* d_args, int n, hipStream_t s);  // d_args[n] in device memory
+struct ExtractBatchMember;
+// d_args[n * rot] in device memory: member b's launch is row (b * rot + d_members[b].prep_sel), skipped when d_members[b].skip
+void launch_frame_prepare_batch(const FramePrepareArgs* d_args, int rot, const ExtractBatchMember* d_members, int n, hipStream_t s);
 
 struct FrameFrustumArgs {
     FrameCam cam;

@@ -244,14 +244,20 @@ __device__ __forceinline__ void frame_prepare_body(const FramePrepareArgs& a) {
 }
 
 __global__ __launch_bounds__(1024) void frame_prepare_kernel(FramePrepareArgs a) { frame_prepare_body(a); }
-// several frames in one launch (so_dframe_group_submit): workgroup b prepares frame b
-__global__ __launch_bounds__(1024) void frame_prepare_batch_kernel(const FramePrepareArgs* __restrict__ A) { frame_prepare_body(A[blockIdx.x]); }
+// several frames in one launch (so_dframe_group_submit): workgroup b prepares the frame of the extraction group's member b - row
+// prep_sel of the member's `rot` rows, unless the member sat the chain out
+__global__ __launch_bounds__(1024) void frame_prepare_batch_kernel(const FramePrepareArgs* __restrict__ A, int rot,
+                                                                    const ExtractBatchMember* __restrict__ M) {
+    const ExtractBatchMember& m = M[blockIdx.x];
+    if (m.skip) return;
+    frame_prepare_body(A[blockIdx.x * rot + m.prep_sel]);
+}
 
 void launch_frame_prepare(const FramePrepareArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(frame_prepare_kernel, dim3(1), dim3(1024), 0, s, a);
 }
-void launch_frame_prepare_batch(const FramePrepareArgs* d_args, int n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(frame_prepare_batch_kernel, dim3(n), dim3(1024), 0, s, d_args);
+void launch_frame_prepare_batch(const FramePrepareArgs* d_args, int rot, const ExtractBatchMember* d_members, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(frame_prepare_batch_kernel, dim3(n), dim3(1024), 0, s, d_args, rot, d_members);
 }
 
 // Frame::isInFrustum + MapPoint::PredictScale, one thread per map point

@@ -106,6 +106,10 @@ struct ExtractBatchMember {
         int32_t* total;
         DescribeDeviceOut dev;
     } out;
+    // != 0: this member sits the current chain out (so_dframe_group_submit with a null image for it: an agent whose next frame is
+    // extracted already).  Written by the chain's first kernel (the ingest) from the image table, read by every kernel behind it.
+    int skip;
+    int prep_sel;  // which of the member's Frame-constructor launches rides at the chain's end (frame_prepare_batch_kernel)
 };
 
 // launchers (orb_kernels.hip)
@@ -130,9 +134,10 @@ void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, cons
 void launch_describe(const PyramidParams& p, const SelectedKp* d_sel, int n, uint8_t* d_desc, float* d_angle,
                      hipStream_t s);
 // The whole chain (ingest .. describe) for n members with pyramids of the same shape as `first`: d_srcs[n] = device-visible
-// pointers to tightly packed w x h images (an array the device can read, e.g. host-mapped), d_members[n] in device memory.
+// pointers to tightly packed w x h images (an array the device can read, e.g. host-mapped; a null entry: the member sits the
+// chain out), d_sel[n] (may be null): copied to d_members[i].prep_sel by the first kernel; d_members[n] in device memory.
 void launch_extract_batch(const ExtractBatchMember* d_members, const ExtractBatchMember& first, int n, const uint8_t* const* d_srcs,
-                          int w, int h, bool rows16, int capacity, hipStream_t s);
+                          const int32_t* d_sel, int w, int h, bool rows16, int capacity, hipStream_t s);
 void launch_quadtree_batch(const ExtractBatchMember* d_members, int n_members, int nlevels, hipStream_t s);
 
 }  // namespace so

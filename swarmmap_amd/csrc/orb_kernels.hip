@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
 }
 // several members' pyramids in one launch (so_extractor_group): blockIdx.z = member
 __global__ __launch_bounds__(256) void resize_batch_kernel(const ExtractBatchMember* __restrict__ M, int level, float fx, float fy) {
+    if (M[blockIdx.z].skip) return;
     const LevelDesc& S = M[blockIdx.z].P.lv[level - 1];
     const LevelDesc& D = M[blockIdx.z].P.lv[level];
     resize_body(S.img, S.w, S.h, S.pitch, D.img, D.w, D.h, D.pitch, fx, fy);
@@ -250,10 +251,21 @@ __global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__
                                                       int pitch) {
     ingest_body(src, w, h, dst, pitch);
 }
-__global__ __launch_bounds__(256) void ingest_batch_kernel(const uint8_t* const* __restrict__ srcs, const ExtractBatchMember* __restrict__ M,
-                                                            int w, int h) {
+// (a null image: the member sits this chain out - the flag every later kernel of the chain tests is set here)
+__device__ __forceinline__ bool ingest_member_skips(const uint8_t* src, const int32_t* sel, const ExtractBatchMember* M) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) {
+        ExtractBatchMember& m = const_cast<ExtractBatchMember*>(M)[blockIdx.z];
+        m.skip = src == nullptr ? 1 : 0;
+        m.prep_sel = sel ? sel[blockIdx.z] : 0;
+    }
+    return src == nullptr;
+}
+__global__ __launch_bounds__(256) void ingest_batch_kernel(const uint8_t* const* __restrict__ srcs, const int32_t* __restrict__ sel,
+                                                            const ExtractBatchMember* M, int w, int h) {
+    const uint8_t* src = srcs[blockIdx.z];
+    if (ingest_member_skips(src, sel, M)) return;
     const LevelDesc& L0 = M[blockIdx.z].P.lv[0];
-    ingest_body(srcs[blockIdx.z], w, h, L0.img, L0.pitch);
+    ingest_body(src, w, h, L0.img, L0.pitch);
 }
 
 
@@ -270,10 +282,12 @@ __global__ __launch_bounds__(256) void ingest16_kernel(const uint4* __restrict__
                                                         int pitch) {
     ingest16_body(src, w16, h, dst, pitch);
 }
-__global__ __launch_bounds__(256) void ingest16_batch_kernel(const uint8_t* const* __restrict__ srcs, const ExtractBatchMember* __restrict__ M,
-                                                              int w16, int h) {
+__global__ __launch_bounds__(256) void ingest16_batch_kernel(const uint8_t* const* __restrict__ srcs, const int32_t* __restrict__ sel,
+                                                              const ExtractBatchMember* M, int w16, int h) {
+    const uint8_t* src = srcs[blockIdx.z];
+    if (ingest_member_skips(src, sel, M)) return;
     const LevelDesc& L0 = M[blockIdx.z].P.lv[0];
-    ingest16_body(reinterpret_cast<const uint4*>(srcs[blockIdx.z]), w16, h, L0.img, L0.pitch);
+    ingest16_body(reinterpret_cast<const uint4*>(src), w16, h, L0.img, L0.pitch);
 }
 
 
@@ -477,7 +491,10 @@ __device__ __forceinline__ void fast_score_body(const PyramidParams& P) {
 }
 
 __global__ __launch_bounds__(256) void fast_score_kernel(PyramidParams P) { fast_score_body(P); }
-__global__ __launch_bounds__(256) void fast_score_batch_kernel(const ExtractBatchMember* __restrict__ M) { fast_score_body(M[blockIdx.y].P); }
+__global__ __launch_bounds__(256) void fast_score_batch_kernel(const ExtractBatchMember* __restrict__ M) {
+    if (M[blockIdx.y].skip) return;
+    fast_score_body(M[blockIdx.y].P);
+}
 
 
 // ------------------------------------------------------------------------------------------------
@@ -571,7 +588,10 @@ __device__ __forceinline__ void fast_low_body(const PyramidParams& P) {
 }
 
 __global__ __launch_bounds__(256) void fast_low_kernel(PyramidParams P) { fast_low_body(P); }
-__global__ __launch_bounds__(256) void fast_low_batch_kernel(const ExtractBatchMember* __restrict__ M) { fast_low_body(M[blockIdx.y].P); }
+__global__ __launch_bounds__(256) void fast_low_batch_kernel(const ExtractBatchMember* __restrict__ M) {
+    if (M[blockIdx.y].skip) return;
+    fast_low_body(M[blockIdx.y].P);
+}
 
 
 __global__ __launch_bounds__(256) void rowcount_kernel(PyramidParams P, int32_t* __restrict__ rowcount) {
@@ -1020,6 +1040,7 @@ __global__ __launch_bounds__(kDescThreads) void describe_qt_kernel(PyramidParams
 }
 __global__ __launch_bounds__(kDescThreads) void describe_qt_batch_kernel(const ExtractBatchMember* __restrict__ M, int capacity) {
     const ExtractBatchMember& m = M[blockIdx.y];
+    if (m.skip) return;
     describe_qt_body(m.P, m.qt_sel, m.qt_count, m.qt.sel_stride, m.out.desc, m.out.angle, m.out.meta, m.out.total, m.out.dev, capacity);
 }
 
@@ -1033,12 +1054,12 @@ void launch_describe_qt(const PyramidParams& p, const SelectedKp* d_qt_sel, cons
 }
 
 void launch_extract_batch(const ExtractBatchMember* d_members, const ExtractBatchMember& first, int n, const uint8_t* const* d_srcs,
-                          int w, int h, bool rows16, int capacity, hipStream_t s) {
+                          const int32_t* d_sel, int w, int h, bool rows16, int capacity, hipStream_t s) {
     const PyramidParams& p = first.P;
     if (rows16)
-        hipLaunchKernelGGL(ingest16_batch_kernel, dim3((w / 16 + 63) / 64, (h + 3) / 4, n), dim3(64, 4), 0, s, d_srcs, d_members, w / 16, h);
+        hipLaunchKernelGGL(ingest16_batch_kernel, dim3((w / 16 + 63) / 64, (h + 3) / 4, n), dim3(64, 4), 0, s, d_srcs, d_sel, d_members, w / 16, h);
     else
-        hipLaunchKernelGGL(ingest_batch_kernel, dim3((w + 255) / 256, (h + 3) / 4, n), dim3(64, 4), 0, s, d_srcs, d_members, w, h);
+        hipLaunchKernelGGL(ingest_batch_kernel, dim3((w + 255) / 256, (h + 3) / 4, n), dim3(64, 4), 0, s, d_srcs, d_sel, d_members, w, h);
     for (int l = 1; l < p.nlevels; l++) {
         const LevelDesc& S = p.lv[l - 1];
         const LevelDesc& D = p.lv[l];

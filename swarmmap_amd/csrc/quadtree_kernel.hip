@@ -567,6 +567,7 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(PyramidParams P, Q
 // several members' pyramids in one launch (so_extractor_group): blockIdx.y = member
 __global__ __launch_bounds__(kQtThreads) void quadtree_batch_kernel(const ExtractBatchMember* __restrict__ M) {
     const ExtractBatchMember& m = M[blockIdx.y];
+    if (m.skip) return;
     quadtree_body(m.P, m.qt, m.qt_sel, m.qt_count);
 }
 

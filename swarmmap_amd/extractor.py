@@ -163,19 +163,24 @@ class ExtractorGroup:
         n = len(self.members)
         if len(images) != n:
             raise ValueError("one image per member")
-        h, w = images[0].shape
-        for im in images:
+        present = [im for im in images if im is not None]
+        if not present:
+            raise ValueError("at least one member must take part")
+        h, w = present[0].shape
+        for im in present:
             if im.dtype != np.uint8 or im.ndim != 2 or im.shape != (h, w) or im.strides != (w, 1):
                 raise ValueError("images must be tightly packed CV_8UC1 arrays of one size")
         self._inflight = list(images)
-        return (C.c_void_p * n)(*[im.ctypes.data for im in images]), w, h
+        return (C.c_void_p * n)(*[None if im is None else im.ctypes.data for im in images]), w, h
 
     def submit(self, images, frames=None):
+        """images[i] None: member i sits this chain out (its frames[i], if given, is ignored)."""
         ptrs, w, h = self._images(images)
         if frames is None:
             _lib.check(self._lib.so_extractor_group_submit(self._h, ptrs, w, h, w))
         else:
-            fr = (C.c_void_p * len(frames))(*[f._h for f in frames])
+            fr = (C.c_void_p * len(frames))(*[None if f is None else f._h for f in frames])
             for f, im in zip(frames, images):
-                f._inflight = im
+                if im is not None:
+                    f._inflight = im
             _lib.check(self._lib.so_dframe_group_submit(self._h, fr, ptrs, w, h, w))

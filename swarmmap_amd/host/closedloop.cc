@@ -716,6 +716,16 @@ int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_
     return SO_OK;
 }
 
+// Tracking thread: frame t can start without waiting (no job out, its packet not due yet, or the packet is there; a failed job
+// counts as ready - cl_frame_begin reports it).  so_fleet_run's elastic ticks ask before they take an agent into a tick.
+bool cl_frame_ready(so_replay* r, int t) {
+    if (!r->cl) return true;
+    ClosedLoop& M = *r->cl;
+    if (!M.job_pending || M.policy != 0 || t < M.apply_at) return true;
+    std::lock_guard<std::mutex> lk(M.mu);
+    return !M.outbox.empty() || M.failed;
+}
+
 // Tracking thread, before the frame's first search: what local mapping handed back arrives in the tracked map.
 int cl_frame_begin(so_replay* r, int t) {
     ClosedLoop& M = *r->cl;

@@ -806,6 +806,24 @@ int so_replay_lm_log(so_replay* r, int32_t* out, int cap_rows) {
 // (Tracking.cc:880-890, LocalMapping.cc:581-583).  n_free / n_fixed: caps of the window's free / fixed keyframes.
 // The tracking stages as one chain of launches each (so_track_stage_*: the default) or as the separate calls with the resolve
 // and the pose-problem gather on the host: same results to the bit (tests/test_closedloop_gpu.py), different latency
+// so_fleet_run tracks frame (tick + offset) of this agent at every tick: agents that were run on their own for `offset` frames first
+// (so_replay_run(r, 0, offset)) are that many frames ahead of the fleet's clock, so their keyframes - one every kf_every frames
+// of their OWN stream - fall on different ticks and their local-mapping jobs do not all start in the same instant.
+int so_replay_set_fleet_offset(so_replay* r, int offset) {
+    if (!r || offset < 0) return SO_ERR_INVALID_ARG;
+    r->fleet_offset = offset;
+    return SO_OK;
+}
+
+// Elastic ticks of the fleet this agent leads (agents[0] of so_fleet_run): ticks driven so far and the agents they took in
+// total - slots / (ticks * agents) is the share of tick places that were filled.
+int so_replay_fleet_ticks(so_replay* r, long long* ticks, long long* slots) {
+    if (!r) return SO_ERR_INVALID_ARG;
+    if (ticks) *ticks = r->fleet_ticks;
+    if (slots) *slots = r->fleet_tick_slots;
+    return SO_OK;
+}
+
 int so_replay_set_track_chain(so_replay* r, int on) {
     if (!r) return SO_ERR_INVALID_ARG;
     r->track_chain = on ? 1 : 0;
@@ -1735,8 +1753,8 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
     so_replay* lead = agents[0];
     bool grouped = !no_group && n_agents > 1 && n_agents <= SO_EXTRACTOR_GROUP_MAX;
     for (int a = 0; a < n_agents && grouped; a++)
-        grouped = agents[a]->width == lead->width && agents[a]->height == lead->height && !agents[a]->live &&
-                  agents[a]->submitted == lead->submitted;
+        grouped = agents[a]->width == lead->width && agents[a]->height == lead->height && !agents[a]->live;  // (every agent's next frame
+                                                                                                          //  goes into ITS next handle: the rotation need not agree)
     if (grouped) {
         std::vector<so_extractor*> members(A);
         for (size_t a = 0; a < A; a++) members[a] = agents[a]->ex;
@@ -1800,28 +1818,56 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
     };
     auto group_pose_ms = [&](int n_members) -> float {  // the group's PoseOptimization kernel, dealt to its members
         float sm = 0.f, pm = 0.f;
-        if (n_members > 0 && lead->step.timed_kernels) so_track_group_last_kernel_ms(tg, &sm, &pm);
+        if (n_members > 0) so_track_group_last_kernel_ms(tg, &sm, &pm);  // (0 unless a member of the launch asked for events: the asking agent did)
         return n_members > 0 ? pm / (float)n_members : 0.f;
     };
-    for (int t = first_t; t < first_t + n_steps && chained; t++) {
-        int rc;
+    // Elastic ticks: the agents share the launches, not a clock.  A tick takes every agent whose next frame can start now; an
+    // agent whose frame has to wait for its local-mapping job (deterministic schedule: the packet of keyframe k is applied at
+    // frame k + delay) sits the tick out - its neighbours do not wait with it, it rejoins when the packet is there, and every
+    // agent still tracks exactly its own sequence of frames (bit-equal to its solo run, tests/test_closedloop_gpu.py).  Each
+    // agent tracks n_steps frames per call; SWARMORB_FLEET_RIGID=1: every tick takes all agents (waits inside step_begin).
+    const bool rigid_env = getenv("SWARMORB_FLEET_RIGID") != nullptr;  // (read per call: tests switch it)
+    bool any_cl = false;
+    for (int a = 0; a < n_agents; a++) any_cl = any_cl || agents[a]->cl != nullptr;
+    const bool elastic = chained && !rigid_env && any_cl && n_agents > 1;
+    std::vector<int> done(A, 0);
+    std::vector<char> act(A, 1);
+    int n_ticks = 0, n_slots = 0;
+    while (chained) {
+        int rc, n_act = 0, n_left = 0;
+        for (int a = 0; a < n_agents; a++) n_left += done[(size_t)a] < n_steps ? 1 : 0;
+        if (n_left == 0) break;
+        for (int spin = 0; n_act == 0; spin++) {
+            for (int a = 0; a < n_agents; a++) {
+                act[(size_t)a] = done[(size_t)a] < n_steps &&
+                                 (!elastic || cl_frame_ready(agents[a], first_t + agents[a]->fleet_offset + done[(size_t)a]));
+                n_act += act[(size_t)a] ? 1 : 0;
+            }
+            if (n_act == 0)  // every agent left is waiting for its job: the first packet to arrive starts the next tick
+                for (int i = 0; i < 32; i++) __builtin_ia32_pause();
+        }
+        n_ticks++;
+        n_slots += n_act;
+        auto tf = [&](int a) { return first_t + agents[a]->fleet_offset + done[(size_t)a]; };  // the frame agent a tracks in this tick
         for (int a = 0; a < n_agents; a++) {
+            if (!act[(size_t)a]) continue;
             agents[a]->lockstep = true;
             agents[a]->step_timed = timed ? 1 : 0;
-            if ((rc = step_begin(agents[a], t, !grouped))) return rc;  // (records the agent's last-frame stage)
+            if ((rc = step_begin(agents[a], tf(a), !grouped))) return rc;  // (records the agent's last-frame stage)
         }
         if ((rc = group_launch())) return rc;
-        if (grouped) {  // the next frames of all agents as one extraction chain, under the stage that was just launched
+        if (grouped) {  // the next frames of the tick's agents as one extraction chain, under the stage that was just launched
             bool all = true;
-            for (int a = 0; a < n_agents; a++) all = all && !agents[a]->step.next_submitted;
+            for (int a = 0; a < n_agents; a++) all = all && (!act[(size_t)a] || !agents[a]->step.next_submitted);
             if (all) {
                 for (size_t a = 0; a < A; a++) {
                     so_replay* r = agents[a];
                     gframes[a] = r->fr[(r->submitted + 1) % 3];
-                    gimages[a] = r->frames[(size_t)(t + 1) % r->frames.size()];
+                    gimages[a] = act[a] ? r->frames[(size_t)(tf((int)a) + 1) % r->frames.size()] : nullptr;  // (null: sits out)
                 }
                 if (so_dframe_group_submit(lead->fleet_group, gframes.data(), gimages.data(), lead->width, lead->height, lead->width) == SO_OK) {
                     for (size_t a = 0; a < A; a++) {
+                        if (!act[a]) continue;
                         agents[a]->submitted = (agents[a]->submitted + 1) % 3;
                         agents[a]->in_flight = true;
                         agents[a]->step.next_submitted = true;
@@ -1832,17 +1878,17 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
             }
         }
         for (int a = 0; a < n_agents; a++)
-            if (!agents[a]->step.next_submitted) {
-                if ((rc = submit_frame(agents[a], t + 1))) return rc;
+            if (act[(size_t)a] && !agents[a]->step.next_submitted) {
+                if ((rc = submit_frame(agents[a], tf(a) + 1))) return rc;
                 agents[a]->step.next_submitted = true;
             }
         // stage 1 back, stage 2 recorded - agent by agent: the host part of one agent runs under the kernels of the others
         int n_dev = 0;
-        for (int a = 0; a < n_agents; a++) n_dev += (!agents[a]->step.first && agents[a]->step.stage1_dev) ? 1 : 0;
+        for (int a = 0; a < n_agents; a++) n_dev += (act[(size_t)a] && !agents[a]->step.first && agents[a]->step.stage1_dev) ? 1 : 0;
         for (int a = 0; a < n_agents; a++) {
             so_replay* r = agents[a];
             so_replay::Step& S = r->step;
-            if (S.first) continue;
+            if (!act[(size_t)a] || S.first) continue;
             int32_t inl1 = 0;
             const bool dev = S.stage1_dev;
             if (dev) {
@@ -1857,12 +1903,12 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
         }
         if ((rc = group_launch())) return rc;
         n_dev = 0;
-        for (int a = 0; a < n_agents; a++) n_dev += (!agents[a]->step.first && agents[a]->step.stage2_dev) ? 1 : 0;
+        for (int a = 0; a < n_agents; a++) n_dev += (act[(size_t)a] && !agents[a]->step.first && agents[a]->step.stage2_dev) ? 1 : 0;
         int n_again = 0;
         for (int a = 0; a < n_agents; a++) {
             so_replay* r = agents[a];
             so_replay::Step& S = r->step;
-            if (S.first) continue;
+            if (!act[(size_t)a] || S.first) continue;
             const bool dev = S.stage2_dev;
             if ((rc = step_m1_wait(r))) return rc;
             if (dev && S.stage2_dev && S.timed_kernels) S.pose_kernel += group_pose_ms(n_dev);
@@ -1881,6 +1927,7 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
         for (int a = 0; a < n_agents; a++) {
             so_replay* r = agents[a];
             so_replay::Step& S = r->step;
+            if (!act[(size_t)a]) continue;
             if (!S.first) {
                 if (r->third_pose && S.third_dev) {
                     if ((rc = step_keyframe(r))) return rc;  // (under the third PoseOptimization, whose result nothing uses)
@@ -1910,11 +1957,20 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
                     if ((rc = step_keyframe(r))) return rc;
                 }
             }
-            step_end(r, t, timed);
+            step_end(r, tf(a), timed);
             if (!r->error.empty()) return SO_ERR_HIP;
         }
         static const bool tick_trace = getenv("SWARMORB_CL_TRACE") != nullptr;
-        if (tick_trace && timed) fprintf(stderr, "[tick] t %d begin %.3f end %.3f\n", t, agents[0]->step.t0, now_ms());
+        if (tick_trace && timed) {
+            int first_act = 0;
+            while (!act[(size_t)first_act]) first_act++;
+            fprintf(stderr, "[tick] %d agents %d begin %.3f end %.3f\n", n_ticks, n_act, agents[first_act]->step.t0, now_ms());
+        }
+        for (int a = 0; a < n_agents; a++) done[(size_t)a] += act[(size_t)a] ? 1 : 0;
+    }
+    if (chained) {
+        lead->fleet_ticks += n_ticks;
+        lead->fleet_tick_slots += n_slots;
     }
     if (chained) return SO_OK;
     for (int t = first_t; t < first_t + n_steps; t++) {
@@ -1922,7 +1978,7 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
         for (int a = 0; a < n_agents; a++) {
             agents[a]->lockstep = true;
             agents[a]->step_timed = timed ? 1 : 0;
-            if ((rc = step_begin(agents[a], t, !grouped))) return rc;
+            if ((rc = step_begin(agents[a], t + agents[a]->fleet_offset, !grouped))) return rc;
         }
         if (grouped) {  // the agents whose next frame is not out yet (all of them, except on a run's first frame)
             bool all = true;
@@ -1931,7 +1987,7 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
                 for (size_t a = 0; a < A; a++) {
                     so_replay* r = agents[a];
                     gframes[a] = r->fr[(r->submitted + 1) % 3];
-                    gimages[a] = r->frames[(size_t)(t + 1) % r->frames.size()];
+                    gimages[a] = r->frames[(size_t)(t + r->fleet_offset + 1) % r->frames.size()];
                 }
                 if (so_dframe_group_submit(lead->fleet_group, gframes.data(), gimages.data(), lead->width, lead->height, lead->width) == SO_OK) {
                     for (size_t a = 0; a < A; a++) {
@@ -1945,7 +2001,7 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
             }
             for (int a = 0; a < n_agents; a++)
                 if (!agents[a]->step.next_submitted) {
-                    if ((rc = submit_frame(agents[a], t + 1))) return rc;
+                    if ((rc = submit_frame(agents[a], t + agents[a]->fleet_offset + 1))) return rc;
                     agents[a]->step.next_submitted = true;
                 }
         }
@@ -1968,7 +2024,7 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
                 r->step.tp3 = now_ms();
                 if ((rc = step_keyframe(r))) return rc;
             }
-            step_end(r, t, timed);
+            step_end(r, t + r->fleet_offset, timed);
             if (!r->error.empty()) return SO_ERR_HIP;
         }
     }

@@ -217,6 +217,8 @@ struct so_replay {
     so_track_group* fleet_track_group = nullptr;  // (owned by the fleet's first agent) the agents' tracking stages as one chain of launches
     so_ba_group* fleet_ba_group = nullptr;        // (owned by the fleet's first agent) the agents' local bundle adjustments as one chain of launches
     bool fleet_lm_stream_set = false;
+    int fleet_offset = 0;  // so_replay_set_fleet_offset: this agent's frame index = the fleet's tick + offset
+    long long fleet_ticks = 0, fleet_tick_slots = 0;  // (fleet lead) ticks so_fleet_run has driven, agents they took (so_replay_fleet_ticks)
     bool fleet_chain = false;                     // so_fleet_run drives this agent AND its stages go out with the fleet's group
     std::vector<so_extractor*> fleet_members;
     BaWindow window;
@@ -297,6 +299,7 @@ struct so_replay {
 
 // closedloop.cc
 int cl_lm_job(so_replay* r, const std::shared_ptr<KfSnap>& c, bool timed, so_ba_info* info);  // local-mapping thread
+bool cl_frame_ready(so_replay* r, int t);  // tracking thread: would cl_frame_begin(r, t) return without waiting for a packet?
 int cl_frame_begin(so_replay* r, int t);  // tracking thread, before the frame's first search: applies what local mapping handed back
 void cl_keyframe_queued(so_replay* r, int t, const std::shared_ptr<KfSnap>& snap);
 int cl_keyframe_featvec_upload(so_replay* r, so_matcher* m, KfSnap& c);

@@ -122,6 +122,18 @@ class Replay:
         self._check(self.lib.so_replay_set_closed_loop(self.h, kf_every, kf_every if delay is None else delay, n_free, n_fixed,
                                                        policy), "set_closed_loop")
 
+    def set_fleet_offset(self, offset):
+        """so_replay_set_fleet_offset: inside fleet_run this agent tracks frame (tick + offset) - run it alone for `offset` frames first."""
+        self.lib.so_replay_set_fleet_offset.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.so_replay_set_fleet_offset(self.h, int(offset)), "set_fleet_offset")
+
+    def fleet_ticks(self):
+        """so_replay_fleet_ticks (on the fleet's first agent): (ticks driven, agent places filled) of fleet_run's elastic ticks."""
+        t, n = C.c_longlong(0), C.c_longlong(0)
+        self.lib.so_replay_fleet_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        self._check(self.lib.so_replay_fleet_ticks(self.h, C.byref(t), C.byref(n)), "fleet_ticks")
+        return int(t.value), int(n.value)
+
     def set_track_chain(self, on):
         """so_replay_set_track_chain: the tracking stages as device chains (default) or as separate calls (same results)."""
         self.lib.so_replay_set_track_chain.argtypes = [C.c_void_p, C.c_int]

@@ -111,7 +111,8 @@ int so_dframe_submit(so_dframe* f, const uint8_t* image, int w, int h, int) {
 }
 int so_dframe_submit_device(so_dframe* f, const uint8_t* img, int w, int h, int s) { return so_dframe_submit(f, img, w, h, s); }
 int so_dframe_group_submit(so_extractor_group* g, so_dframe* const* frames, const uint8_t* const* images, int w, int h, int s) {
-    for (int i = 0; i < g->n; i++) so_dframe_submit(frames[i], images[i], w, h, s);
+    for (int i = 0; i < g->n; i++)
+        if (images[i]) so_dframe_submit(frames[i], images[i], w, h, s);  // (null: the member sits the chain out)
     return SO_OK;
 }
 static void bounds_of(float* b) { if (b) { b[0] = 0.f; b[1] = 752.f; b[2] = 0.f; b[3] = 480.f; } }

@@ -201,15 +201,25 @@ def test_three_closed_loop_agents_in_threads_equal_their_solo_runs():
     assert not np.array_equal(solo[0]["poses"], solo[1]["poses"])  # (different streams)
 
 
-def test_closed_loop_agents_in_lockstep_with_grouped_stages_equal_their_solo_runs():
+@pytest.mark.parametrize("mode", ["elastic", "elastic-staggered", "rigid"])
+def test_closed_loop_agents_in_lockstep_with_grouped_stages_equal_their_solo_runs(mode, monkeypatch):
     """bench.py --agents-per-gpu A --lockstep: ONE thread drives the agents' tracking frame by frame, the tracking stages of all
     agents go out as one chain of launches per stage (so_track_group: the agent is a grid dimension of the search, the resolve
     and the PoseOptimization kernel), every agent keeps its own local-mapping thread.  Every agent's poses, counts,
     local-mapping log and keyframe bindings are those of its solo run, to the bit.  Reference concurrency: one process per agent,
-    code/Examples/Monocular/swarm_map.cc:329-337."""
+    code/Examples/Monocular/swarm_map.cc:329-337.
+    elastic (the default): a tick takes the agents whose next frame does not have to wait for its local-mapping packet - the others
+    sit it out (so_dframe_group_submit with a null image, no row in the track group) and catch up; staggered: agent a has been
+    run alone for a frames first, so the agents' keyframes fall on different ticks; rigid (SWARMORB_FLEET_RIGID=1): every tick
+    takes every agent."""
     import torch
     from swarmmap_amd.replay import Replay
+    if mode == "rigid":
+        monkeypatch.setenv("SWARMORB_FLEET_RIGID", "1")
+    else:
+        monkeypatch.delenv("SWARMORB_FLEET_RIGID", raising=False)
     K, dist, nfeat, n, A = synth.EUROC_K, synth.EUROC_DIST, 1000, 42, 4
+    offs = [a if mode == "elastic-staggered" else 0 for a in range(A)]
     vocab = make_vocabulary()
     streams, blocks, ptrs = [], [], []
     for a in range(A):
@@ -229,8 +239,20 @@ def test_closed_loop_agents_in_lockstep_with_grouped_stages_equal_their_solo_run
         rp.set_closed_loop(policy=0)
         rp.prime(0)
         fleet.append(rp)
+    for rp, off in zip(fleet, offs):
+        if off:
+            rp.run(0, off, True)
+            rp.set_fleet_offset(off)
+    m = n - max(offs)                      # frames per agent inside the fleet
     Replay.fleet_run(fleet, 0, 17, True)   # (two calls: the agents join and leave the group per call)
-    Replay.fleet_run(fleet, 17, n - 17, True)
+    Replay.fleet_run(fleet, 17, m - 17, True)
+    for rp, off in zip(fleet, offs):       # (the staggered agents' last frames, alone again: n frames each in all)
+        if off + m < n:
+            rp.run(off + m, n - off - m, True)
+    ticks, places = fleet[0].fleet_ticks()
+    assert ticks >= m and places == A * m
+    if mode == "rigid":
+        assert ticks == m
     for rp in fleet:
         rp.drain()
         rp.finish()
@@ -247,7 +269,8 @@ def test_closed_loop_agents_in_lockstep_with_grouped_stages_equal_their_solo_run
             assert np.array_equal(s[k], p[k]), (a, k)
         assert all(np.array_equal(x, y) for x, y in zip(s["kf_bindings"], p["kf_bindings"])), a
         assert s["inliers"][1:].min() > 300
-        assert st["pose_calls"] == 3 * (n - 1) and st["pose_kernel_ms"] > 0
+        assert st["pose_calls"] == 3 * (n - 1), (a, st["pose_calls"])
+        assert st["pose_kernel_ms"] > 0, (a, st["pose_kernel_ms"])
     assert not np.array_equal(solo[0]["poses"], solo[1]["poses"])
 
 

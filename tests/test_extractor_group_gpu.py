@@ -101,6 +101,64 @@ def test_group_of_device_resident_frames_equals_lone_frames():
         ex.close()
 
 
+def test_members_that_sit_a_chain_out_are_left_alone():
+    """images[i] == NULL: member i takes no part in the chain (so_fleet_run's elastic ticks: an agent whose next frame is extracted
+    already, and not collected yet).  Four members rotate three device-resident frames each and take part in different ticks -
+    every frame that is collected equals the lone so_dframe_submit of its image, including one that was submitted two chains
+    before it is collected while its neighbours went on."""
+    import swarmmap_amd as S
+    w, h, n_members, ticks = 752, 480, 4, 7
+    # which members take part in which tick (member 3 sits out ticks 2 and 3 with its tick-1 frame uncollected)
+    takes = [[1, 1, 1, 1], [1, 0, 1, 1], [0, 1, 1, 0], [1, 1, 0, 0], [1, 1, 1, 1], [0, 0, 0, 1], [1, 1, 1, 1]]
+    imgs = {(t, a): synth.make_canvas(700 + 11 * a + t, w, h) for t in range(ticks) for a in range(n_members) if takes[t][a]}
+    ex0 = S.ORBextractor(1000, 1.2, 8, 20, 7)
+    f0 = S.DeviceFrame(ex0, synth.EUROC_K, synth.EUROC_DIST)
+    ref = {}
+    for key, im in imgs.items():
+        kps, un, d = f0(im)
+        ref[key] = (kps.tobytes(), un.tobytes(), d.tobytes(), f0.bounds.tobytes(), tuple(x.tobytes() for x in f0.grid()))
+    f0.close(); ex0.close()
+    exs = [S.ORBextractor(1000, 1.2, 8, 20, 7) for _ in range(n_members)]
+    frs = [[S.DeviceFrame(ex, synth.EUROC_K, synth.EUROC_DIST) for _ in range(3)] for ex in exs]
+    grp = S.ExtractorGroup(exs)
+    rot = [0] * n_members
+    pending = [None] * n_members   # (tick, frame) submitted and not collected
+    keeps = []
+
+    def collect(a):
+        t0, f = pending[a]
+        kps, un, d = f.collect()
+        got = (kps.tobytes(), un.tobytes(), d.tobytes(), f.bounds.tobytes(), tuple(x.tobytes() for x in f.grid()))
+        assert got == ref[(t0, a)], (t0, a)
+        pending[a] = None
+
+    for t in range(ticks):
+        for a in range(n_members):  # a member collects its earlier frame right before it submits the next one
+            if takes[t][a] and pending[a]:
+                collect(a)
+        present = [a for a in range(n_members) if takes[t][a]]
+        keep, pinned = _pinned([imgs[(t, a)] for a in present])
+        keeps.append(keep)
+        images, frames = [None] * n_members, [None] * n_members
+        for a, im in zip(present, pinned):
+            images[a] = im
+            frames[a] = frs[a][rot[a]]
+            pending[a] = (t, frames[a])
+            rot[a] = (rot[a] + 1) % 3
+        grp.submit(images, frames=frames)
+    for a in range(n_members):
+        if pending[a]:
+            collect(a)
+    with pytest.raises(Exception):
+        grp.submit([None] * n_members)  # nobody takes part
+    grp.close()
+    for row in frs:
+        for f in row:
+            f.close()
+    for ex in exs:
+        ex.close()
+
+
 def test_group_with_members_on_streams_of_their_own():
     """so_runtime_private_streams: every member has its own stream, the chain runs on the first member's; the others'
     collects wait for it through an event."""
