@@ -72,6 +72,75 @@ def cgroup_cpu():
         return None
 
 
+class GpuBusy:
+    """Samples the driver's busy figure of the GPU (sysfs gpu_busy_percent: share of the last sampling period with anything running
+    on the device) every few milliseconds over a timed region: mean / max / samples, or None where the file is not readable.  It is
+    coarse (the SMU's own period) and says "something was running", not how many CUs - the per-kernel times are in `roofline`."""
+
+    def __init__(self, device_index=0, period_s=0.004):
+        self.path, self.period, self.vals, self.th, self.stop_flag = None, period_s, [], None, False
+        self.device_index = device_index
+
+    def locate(self):
+        """The sysfs node of the HIP device: the card whose PCI address is the device's (a box shows every GPU of the node in sysfs,
+        the container sees one of them)."""
+        if self.path is not None:
+            return
+        self.path = ""
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(self.device_index)) != 0:
+                return
+            bus = buf.value.decode().lower()
+            for c in os.listdir("/sys/class/drm"):
+                if not (c.startswith("card") and c[4:].isdigit()):
+                    continue
+                dev = os.path.join("/sys/class/drm", c, "device")
+                if os.path.basename(os.path.realpath(dev)).lower() == bus and os.path.exists(os.path.join(dev, "gpu_busy_percent")):
+                    self.path = os.path.join(dev, "gpu_busy_percent")
+                    return
+        except (OSError, AttributeError):
+            pass
+
+    def _read(self):
+        try:
+            with open(self.path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        self.locate()
+        if not self.path or self._read() is None:
+            return
+        self.vals, self.stop_flag = [], False
+
+        def loop():
+            while not self.stop_flag:
+                v = self._read()
+                if v is not None:
+                    self.vals.append(v)
+                time.sleep(self.period)
+        self.th = threading.Thread(target=loop, daemon=True)
+        self.th.start()
+
+    def stop(self):
+        if not self.th:
+            return None
+        self.stop_flag = True
+        self.th.join()
+        self.th = None
+        if not self.vals:
+            return None
+        return {"mean_percent": round(float(np.mean(self.vals)), 1), "max_percent": float(np.max(self.vals)), "samples": len(self.vals),
+                "source": "sysfs gpu_busy_percent, sampled every %d ms over the timed region" % int(self.period * 1e3)}
+
+
+GPU_BUSY = GpuBusy()
+
+
 def cgroup_delta(a, b, dt):
     if a is None or b is None:
         return None
@@ -289,12 +358,14 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
             rp.set_profiling(False)
         barrier()
         cg0 = cgroup_cpu()
+        GPU_BUSY.start()
         t0 = time.perf_counter()
         Replay.fleet_run(fleet, warmup, steps, True)
         for rp in fleet:
             rp.drain()  # every queued window is optimised inside the timed region
         barrier()
         dt = time.perf_counter() - t0
+        busy = GPU_BUSY.stop()
         cg = cgroup_delta(cg0, cgroup_cpu(), dt)
     else:
         raise RuntimeError("internal: fleets of several driving threads are built by run_fleet_threads")
@@ -311,7 +382,7 @@ def run_fleet(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, ba
         rp.close()
     stats = {k: sum(r[0][k] for r in results) / agents for k in results[0][0] if k not in ("stages", "frame_ms")}
     stats["frame_ms"] = np.concatenate([np.asarray(r[0]["frame_ms"])[-steps:] for r in results])
-    stats.update({"n_xchg": 0, "xchg_ms": 0.0, "lm": fleet_lm, "closed": closed, "cgroup": cg,
+    stats.update({"n_xchg": 0, "xchg_ms": 0.0, "lm": fleet_lm, "closed": closed, "cgroup": cg, "gpu_busy": busy,
                   "fleet_ticks": {"ticks": ticks[0], "agents_per_tick": round(ticks[1] / max(ticks[0], 1), 3), "staggered": bool(stagger)}})
     if closed:
         stats.update({"cl": cl0, "stream": streams[0], "timed_from": warmup})
@@ -381,10 +452,12 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
         elif tag == "warm":
             barrier()
             clock["cg0"] = cgroup_cpu()
+            GPU_BUSY.start()
             clock["t0"] = time.perf_counter()
         elif tag == "done":
             barrier()  # (the frame submitted ahead by the last step finishes inside the timed region too)
             clock["dt"] = time.perf_counter() - clock["t0"]
+            clock["busy"] = GPU_BUSY.stop()
             clock["cg"] = cgroup_delta(clock["cg0"], cgroup_cpu(), clock["dt"])
 
     def agent(a):
@@ -479,11 +552,13 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
             gate.wait()
             barrier()
             clock["cg0"] = cgroup_cpu()
+            GPU_BUSY.start()
             t0 = time.perf_counter()
             gate.wait()
             gate.wait()
             barrier()  # (the frames submitted ahead by the last steps finish inside the timed region too)
             dt = time.perf_counter() - t0
+            clock["busy"] = GPU_BUSY.stop()
             clock["cg"] = cgroup_delta(clock["cg0"], cgroup_cpu(), dt)
         except threading.BrokenBarrierError:
             raise errors[0] if errors else RuntimeError("an agent thread failed")
@@ -496,6 +571,7 @@ def run_stream(dev, size, K, dist, nfeatures, steps, warmup, seed, lba_window, b
     stats.update(acc_x)
     stats["closed"] = closed
     stats["cgroup"] = clock.get("cg")
+    stats["gpu_busy"] = clock.get("busy")
     return dt, stats, results[0][1], frame_sets[0][1], results[0][2]
 
 
@@ -948,7 +1024,7 @@ def headline(full, full_path):
                        for r in (full["roofline_secondary"], full["roofline_tertiary"])}
     head = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data")}
-    head.update({"fps_per_agent": full["fps_per_agent"], "agents_per_gpu": full["agents_per_gpu"], "host_loop": full["host_loop"], "host_cpu": full.get("host_cpu"), "fleet_ticks": full.get("fleet_ticks"),
+    head.update({"fps_per_agent": full["fps_per_agent"], "agents_per_gpu": full["agents_per_gpu"], "host_loop": full["host_loop"], "host_cpu": full.get("host_cpu"), "fleet_ticks": full.get("fleet_ticks"), "gpu_busy": full.get("gpu_busy"),
                  "launch": full["launch"][:120], "config": hconfig, "roofline": hroof})
     if "cpu_baseline" in full:
         c = full["cpu_baseline"]
@@ -977,6 +1053,7 @@ def headline(full, full_path):
             "reference_policy_frames_per_s": g(cf, "reference_policy", "frames_per_s"),
             "open_loop_frames_per_s": g(cf, "open_loop_synthetic_window", "frames_per_s"),
             "agents_per_gpu_frames_per_s": {k: v for k, v in (cf.get("agents_per_gpu") or {}).items() if k != "note"} or None,
+            "agents_per_gpu_busy_percent": cf.get("agents_per_gpu_busy_percent"),
             "front_end_batched_frames_per_s": {k[7:]: v["frames_per_s"] for k, v in (cf.get("front_end_batched") or {}).items() if k.startswith("agents_")},
             "kf_scan_frac_int_valu": g(cf, "candidate_search", "store_8x512_kf_40pct_bound", "roofline", "frac"),
             "kf_scan_ms_4096_keyframes": g(cf, "candidate_search", "store_8x512_kf_40pct_bound", "scan_kernel_ms"),
@@ -1046,6 +1123,7 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = local_rank if distributed else 0
     torch.cuda.set_device(dev)
+    GPU_BUSY.device_index = dev
     torch.cuda.synchronize()  # the runtime's threads exist from here on
     from swarmmap_amd import _lib as _so_lib
     # thread placement: this rank's threads behind one L3 (one per agent of the rank) next to its GPU; "pinned_cpus" in
@@ -1155,6 +1233,7 @@ def main():
                                                                   if args.lockstep and A > 1 else ""),
             "fps_per_agent": steps / dt, "agents_per_gpu": A,
             "fleet_ticks": st.get("fleet_ticks"),
+            "gpu_busy": st.get("gpu_busy"),  # the driver's busy figure over the timed region (coarse: "something was running")
             "host_cpu": st.get("cgroup"),  # cores used / the container's quota / CFS throttling inside the timed region
             "pinned_cpus": None if not pinned_cpus else ",".join(_cpu_ranges(pinned_cpus)),
             "config": dict({
@@ -1254,14 +1333,16 @@ def main():
                     # drives the agents' tracking with the stages of all agents as one chain of launches per stage
                     # (so_track_group), their local bundle adjustments merged per round (so_ba_group), a local-mapping thread each
                     apg = {"1": cfgs["steady_state"]["frames_per_s"]}
-                    fill = {}
+                    fill, busy_apg = {}, {}
                     for A_ in (4, 8, 16):
                         fdt, fst, _, _, _ = run_fleet(dev, size, K, dist, nfeatures, 200, 20, SEED_BASE, lba_window, barrier, A_)
                         apg[str(A_)] = 200 * A_ / fdt
                         fill[str(A_)] = fst["fleet_ticks"]["agents_per_tick"]
+                        busy_apg[str(A_)] = (fst.get("gpu_busy") or {}).get("mean_percent")
                     cfgs["agents_per_gpu"] = dict(apg, note="aggregate frames/s, closed loop, --lockstep (elastic ticks: an agent whose frame "
                                                             "waits for its local-mapping packet sits the tick out); 1 = the headline's steady-state figure")
                     cfgs["agents_per_gpu_tick_fill"] = fill  # agents a tick took on average
+                    cfgs["agents_per_gpu_busy_percent"] = busy_apg  # sysfs gpu_busy_percent, mean over the fleet's timed region
                 cfgs["front_end_batched"] = batched_front_end_records(dev)
                 cfgs["candidate_search"] = candidate_search_records(dev)
                 cfgs["local_ba_windows"] = lba_records(dev)
