@@ -15,6 +15,9 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <chrono>
+#include <thread>
+#include <cstdlib>
 #include <vector>
 
 #include "swarmorb.h"
@@ -455,6 +458,8 @@ void so_ba_options_local(so_ba_options* o) { o->its_stage1 = 5; o->its_stage2 = 
 int so_bundle_adjust_set_solve_timing(so_ba*, int) { return SO_OK; }
 int so_bundle_adjust(so_ba*, const so_ba_problem* p, const so_ba_options*, const volatile uint8_t* stop, float* T_out, float* X_out, uint8_t* outl, double* chi2,
                      so_ba_info* info) {
+    static const int nap_us = getenv("MOCK_BA_SLEEP_US") ? atoi(getenv("MOCK_BA_SLEEP_US")) : 0;  // a job longer than five ticks: agents sit ticks out
+    if (nap_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
     for (int e = 0; e < p->n_edges; e++) {  // (every index the harness gathered must be in range)
         if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) return SO_ERR_INVALID_ARG;
         if (outl) outl[e] = (e % 211) == 7;

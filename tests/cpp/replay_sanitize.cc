@@ -25,6 +25,8 @@ int so_replay_prime(so_replay* r, int t);
 int so_replay_run(so_replay* r, int first_t, int n_steps, int timed);
 int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int timed);
 int so_replay_drain(so_replay* r);
+int so_replay_fleet_ticks(so_replay* r, long long* ticks, long long* slots);
+int so_replay_set_fleet_offset(so_replay* r, int offset);
 int so_replay_finish(so_replay* r);
 int so_replay_cl_counts(so_replay* r, int64_t* counts8, double* wait_ms);
 int so_replay_log_size(so_replay* r);
@@ -109,9 +111,28 @@ int main(int argc, char** argv) {
             if (int e = make_agent(a, frames, 0, 1)) return 20 + e;
             hs.push_back(a.r);
         }
-        int rc = so_fleet_run(hs.data(), (int)hs.size(), 0, frames / 2, 1);
-        if (rc == SO_OK) rc = so_fleet_run(hs.data(), (int)hs.size(), frames / 2, frames - frames / 2, 1);
+        // (MOCK_BA_SLEEP_US makes the local-mapping jobs longer than five ticks: the elastic ticks leave agents out and take them
+        //  back in; two of the agents are a frame / two frames ahead of the fleet's clock, as bench.py's staggered fleets are)
+        for (size_t i = 1; i < ag.size(); i += 2) {
+            const int off = (int)i / 2 + 1;
+            if (so_replay_run(ag[i].r, 0, off, 1) != SO_OK || so_replay_set_fleet_offset(ag[i].r, off) != SO_OK) return 30;
+        }
+        const int m = frames - 4;  // frames per agent inside the fleet (the run-ahead agents track theirs from their offset on)
+        int rc = so_fleet_run(hs.data(), (int)hs.size(), 0, m / 2, 1);
+        if (rc == SO_OK) rc = so_fleet_run(hs.data(), (int)hs.size(), m / 2, m - m / 2, 1);
         if (rc != SO_OK) printf("so_fleet_run: %d %s\n", rc, so_replay_error(hs[0]));
+        long long ticks = 0, places = 0;
+        so_replay_fleet_ticks(hs[0], &ticks, &places);
+        printf("fleet: %lld ticks, %lld agent places (%d agents x %d frames)\n", ticks, places, (int)ag.size(), m);
+        if (places != (long long)ag.size() * m) fails++;
+        if (getenv("MOCK_BA_SLEEP_US") && ticks <= m) {
+            printf("the elastic path was not exercised: every tick took every agent\n");
+            fails++;
+        }
+        for (size_t i = 0; i < ag.size(); i++) {  // the agents' last frames, alone again: `frames` each in all
+            const int off = (i & 1) ? (int)i / 2 + 1 : 0;
+            if (off + m < frames && so_replay_run(ag[i].r, off + m, frames - off - m, 1) != SO_OK) fails++;
+        }
         for (size_t i = ag.size(); i-- > 0;) fails += finish_agent(ag[i], "agent of the fleet", frames);
     } else {
         fprintf(stderr, "unknown mode %s\n", mode);
