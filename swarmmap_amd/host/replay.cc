@@ -1792,8 +1792,12 @@ int so_fleet_run(so_replay** agents, int n_agents, int first_t, int n_steps, int
     }
     // ... and their local bundle adjustments: the agents' local-mapping threads reach so_bundle_adjust at about the same time
     // (keyframes fall on the same frames), their LM chains go out merged (so_ba_group).  Joined once, on the fleet's first run.
+    // (from five agents on: with four the merged rounds - a window waits for the others, the round is as slow as its slowest member -
+    //  cost more than four separate chains do, 4.4 against 4.9 k frames/s; at eight it is a tie, beyond that the group wins: NOTES G.8.
+    //  SWARMORB_FLEET_BA_GROUP_MIN=n moves the threshold.)
     static const bool no_ba_group = getenv("SWARMORB_FLEET_NO_BA_GROUP") != nullptr;
-    if (chained && !no_ba_group && n_agents > 1 && !lead->fleet_ba_group) {
+    const int ba_group_min = getenv("SWARMORB_FLEET_BA_GROUP_MIN") ? atoi(getenv("SWARMORB_FLEET_BA_GROUP_MIN")) : 5;  // (per call: tests switch it)
+    if (chained && !no_ba_group && n_agents >= std::max(2, ba_group_min) && !lead->fleet_ba_group) {
         const double window_us = getenv("SWARMORB_FLEET_BA_WINDOW_US") ? atof(getenv("SWARMORB_FLEET_BA_WINDOW_US")) : 600.0;
         if (so_ba_group_create(lead->device, window_us, &lead->fleet_ba_group) == SO_OK)
             for (int a = 0; a < n_agents; a++) so_ba_set_group(agents[a]->mapper_opt, lead->fleet_ba_group);

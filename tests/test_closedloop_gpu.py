@@ -216,8 +216,10 @@ def test_closed_loop_agents_in_lockstep_with_grouped_stages_equal_their_solo_run
     from swarmmap_amd.replay import Replay
     if mode == "rigid":
         monkeypatch.setenv("SWARMORB_FLEET_RIGID", "1")
+        monkeypatch.delenv("SWARMORB_FLEET_BA_GROUP_MIN", raising=False)  # four agents: a chain per window (the default below five)
     else:
         monkeypatch.delenv("SWARMORB_FLEET_RIGID", raising=False)
+        monkeypatch.setenv("SWARMORB_FLEET_BA_GROUP_MIN", "2")            # the agents' windows as merged rounds (so_ba_group)
     K, dist, nfeat, n, A = synth.EUROC_K, synth.EUROC_DIST, 1000, 42, 4
     offs = [a if mode == "elastic-staggered" else 0 for a in range(A)]
     vocab = make_vocabulary()
