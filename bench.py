@@ -1334,7 +1334,7 @@ def main():
                     # (so_track_group), their local bundle adjustments merged per round (so_ba_group), a local-mapping thread each
                     apg = {"1": cfgs["steady_state"]["frames_per_s"]}
                     fill, busy_apg = {}, {}
-                    for A_ in (4, 8, 16):
+                    for A_ in (2, 4, 8, 16):
                         fdt, fst, _, _, _ = run_fleet(dev, size, K, dist, nfeatures, 200, 20, SEED_BASE, lba_window, barrier, A_)
                         apg[str(A_)] = 200 * A_ / fdt
                         fill[str(A_)] = fst["fleet_ticks"]["agents_per_tick"]
