@@ -1100,6 +1100,12 @@ int so_ba_group_create(int device, double window_us, so_ba_group** out);
 void so_ba_group_destroy(so_ba_group* g);
 int so_ba_set_group(so_ba* b, so_ba_group* g_or_null);
 int so_ba_group_stats(so_ba_group* g, double* out8);
+/* Experiment kept for the record (NOTES.md G.10), off by default: SWARMORB_BA_RESIDENT=1 runs the Levenberg-Marquardt trials of a
+ * local window's stage (<= 26 free keyframes, ungrouped) as ONE resident launch - workgroups that walk the phases' virtual blocks
+ * and meet at grid barriers, the MFMA solve on four waves of workgroup 0 - instead of five launches per trial.  Same bits
+ * (tests/test_ba_group_gpu.py), but slower on this hardware, alone and next to other agents.  so_ba_resident_stages: stages of
+ * this context that ran that way. */
+int so_ba_resident_stages(const so_ba* b, long long* n_out);
 /* How the reduced camera system S x = b of every LM trial is solved on LARGE maps (80 free keyframes and more; smaller
  * systems always take the single-workgroup / blocked direct solvers).
  *   SO_BA_SOLVER_DIRECT (default): block-skyline Cholesky on FP64 MFMA tiles - what the reference's LinearSolverEigen /

@@ -201,6 +201,9 @@ struct so_ba {
     unsigned* h_flow_abort = nullptr;       // host-mapped: stamped by a dataflow workgroup whose wait outlasted its budget
     unsigned* h_flow_abort_dev = nullptr;
     bool flow_broken = false;               // a dataflow solve of this context timed out: chain of launches from now on
+    BaResidentSync* d_rsync = nullptr;      // the resident trial loop's meeting words (ba_kernels.hip: ba_lm_resident_kernel), lazily
+    unsigned resident_epoch = 0;            // one per resident launch of this context (20 bits)
+    long long resident_launches = 0;        // stages of this context that ran resident
     int flow_timeouts = 0;
     int flow_reserved = 0;                  // tiles this context holds of the process-wide residency budget
     std::vector<int> tile_first;
@@ -496,6 +499,27 @@ struct Run {
 // is repeated on the chain-of-launches path; never returned to the caller.
 constexpr int kErrFlowTimeout = 1000;
 
+// Windows whose trials run as resident launches (ba_lm_resident_kernel), per device: their workgroups hold a CU's LDS each for the
+// length of a stage, so only so many may run at once (the next caller takes the chain of launches; nobody waits).
+// SWARMORB_BA_RESIDENT=1 switches the path on, SWARMORB_BA_RESIDENT_WGS=g the workgroups per window (default 32),
+// SWARMORB_BA_RESIDENT_MAX=n the windows per device (default 6: 192 of 256 CUs at 32 workgroups).
+std::atomic<int> g_resident_in_flight[64];
+struct ResidentSlot {
+    int device = -1;
+    bool take(int dev, int limit) {
+        if (dev < 0 || dev >= 64) return false;
+        if (g_resident_in_flight[dev].fetch_add(1) >= limit) {
+            g_resident_in_flight[dev].fetch_sub(1);
+            return false;
+        }
+        device = dev;
+        return true;
+    }
+    ~ResidentSlot() {
+        if (device >= 0) g_resident_in_flight[device].fetch_sub(1);
+    }
+};
+
 // Wait for the stream; with a forceStopFlag, poll it meanwhile and forward it to the device.
 int wait_stream(Run& r) {
     hipStream_t s = r.b->stream;
@@ -634,6 +658,7 @@ void so_ba_destroy(so_ba* b) {
     if (b->dense_side) (void)hipStreamDestroy(b->dense_side);
     if (b->h_lm) (void)hipHostFree(b->h_lm);
     if (b->h_flow_abort) (void)hipHostFree(b->h_flow_abort);
+    if (b->d_rsync) (void)hipFree(b->d_rsync);
     if (b->h_in) (void)hipHostFree(b->h_in);
     if (b->h_out) (void)hipHostFree(b->h_out);
     if (b->h_plan) (void)hipHostFree(b->h_plan);
@@ -722,6 +747,12 @@ int so_ba_set_group(so_ba* b, so_ba_group* g) {
         std::lock_guard<std::mutex> lk(g->mu);
         g->n_members++;
     }
+    return SO_OK;
+}
+
+int so_ba_resident_stages(const so_ba* b, long long* n_out) {
+    if (!b || !n_out) return SO_ERR_INVALID_ARG;
+    *n_out = b->resident_launches;
     return SO_OK;
 }
 
@@ -1458,7 +1489,31 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         // end; a stream synchronise + the next launches idled the GPU ~35 us at the stage boundary and ~45 us at the end.
         // If a stage needs more trials than its iteration count (rejected trials), what was enqueued behind it has
         // returned at once; the host adds the missing trials and the rest of the chain again.
+        // The stage's trials as ONE resident launch where the window allows it (ba_kernels.hip): it ends by itself when the stage
+        // is over, so all of a stage's trials - rejected ones included - are "enqueued" at once and nothing is held in reserve.
+        // (an experiment's switches, read per call so that the tests can flip them: NOTES G.10)
+        const bool resident_env = getenv("SWARMORB_BA_RESIDENT") && atoi(getenv("SWARMORB_BA_RESIDENT")) != 0;
+        const int resident_wgs = getenv("SWARMORB_BA_RESIDENT_WGS") ? atoi(getenv("SWARMORB_BA_RESIDENT_WGS")) : 32;
+        const int resident_max = getenv("SWARMORB_BA_RESIDENT_MAX") ? atoi(getenv("SWARMORB_BA_RESIDENT_MAX")) : 6;
+        ResidentSlot resident_slot;
+        bool resident = resident_env && !grouped && !b->flow_broken && !r.d.use_pcg && !r.d.plan && resident_slot.take(b->device, resident_max);
+        if (resident && !b->d_rsync) {
+            if (hipMalloc((void**)&b->d_rsync, sizeof(BaResidentSync)) != hipSuccess || so::memset_sync(b->d_rsync, 0, sizeof(BaResidentSync)) != hipSuccess) {
+                (void)hipGetLastError();
+                resident = false;
+            }
+        }
         auto trials = [&](const BaDev& d, int n) {
+            if (resident) {
+                if (++b->resident_epoch >= (1u << 20)) b->resident_epoch = 1;
+                b->rec.phase = (d.stage == 2 ? kBaPhaseStage2 : 0) + 1;
+                if (launch_ba_trials_resident(d, r.nb_upd, kBaResidentMaxTrials, abort_dev, b->h_lm_dev, b->d_rsync, b->resident_epoch, resident_wgs, s)) {
+                    r.blocks_enqueued += n;
+                    b->resident_launches++;
+                    return;
+                }
+                resident = false;  // (not a window the resident loop covers: the chain, for the rest of this call)
+            }
             for (int i = 0; i < n; i++) {
                 r.blocks_enqueued++;
                 b->rec.phase = (d.stage == 2 ? kBaPhaseStage2 : 0) + 1 + i;  // (only read while the chain is being recorded)
@@ -1477,7 +1532,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
             // topped up by the loop below (one host round trip).
             static const bool no_hint = getenv("SWARMORB_BA_NO_STAGE2_HINT") != nullptr;  // A/B: all iterations ahead, as before round 5
             // (a group member records all of them: the group enqueues what its members' last calls needed + 2, for everybody)
-            const int ahead = (no_hint || grouped) ? opt->its_stage2 : std::min(opt->its_stage2, b->stage2_hint > 0 ? b->stage2_hint : opt->its_stage2);
+            const int ahead = (no_hint || grouped || resident) ? opt->its_stage2 : std::min(opt->its_stage2, b->stage2_hint > 0 ? b->stage2_hint : opt->its_stage2);
             trials(d2, ahead);
             early_phase = 0;
             static const bool no_early = getenv("SWARMORB_BA_NO_EARLY") != nullptr;  // A/B: the reserve in front of the only epilogue

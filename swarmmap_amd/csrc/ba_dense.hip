@@ -36,17 +36,7 @@ constexpr int kDNB = 96;        // panel width = tile edge
 constexpr int kDChunk = 48;     // K-chunk staged in LDS
 constexpr int kDStride = 50;    // LDS row stride (doubles) of a chunk: 2*50 mod 64 = 36 -> 16 rows x 2 k conflict-free
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-// 1/sqrt(v): v_rsq_f64 is good to about 2^-23, so one third-order step y (1 + e/2 + 3 e^2/8), e = 1 - v y^2, reaches
-// double precision with four dependent operations - the pivot chain of the diagonal factor is made of these.
-__device__ __forceinline__ double dense_rsqrt(double v) {
-    const double y = __builtin_amdgcn_rsq(v);
-    const double t = v * y;
-    const double e = fma(-t, y, 1.0);
-    const double p = fma(0.375, e, 0.5);
-    return fma(y * e, p, y);
-}
+#include "ba_solve_mfma.inc"  // d4, dense_rsqrt, kPS, the pivot-tile machinery, ba_solve_mfma_body
 
 // ---- padding: rows / columns n..np-1 form an identity block, the right-hand side is zero there ----
 __global__ __launch_bounds__(256) void dense_pad_kernel(double* __restrict__ S, double* __restrict__ rhs, int n, int np) {
@@ -74,197 +64,7 @@ __global__ __launch_bounds__(256) void dense_pad_kernel(double* __restrict__ S, 
 constexpr int kDenseGroup = 3;   // panels per trailing update (K = 96 * kDenseGroup) when the look-ahead runs; measured on
                                  // GBA-2 (94 panels): 1 -> 125 ms, 2 -> 106, 3 -> 104, 4 -> 106, 6 -> 115; without look-ahead
                                  // (GBA-1, 19 panels) the serial chain dominates and single panels are fastest
-constexpr int kPS = 98;
 constexpr int kPT = kDNB / 16;  // tiles per block edge
-
-// tools/probe/potrf_probe.hip defines SO_POTRF_MARK to log clock64() per phase; the product build compiles it away
-#ifndef SO_POTRF_MARK
-#define SO_POTRF_MARK(i)
-#endif
-
-__device__ __forceinline__ void potrf_wave_sync() {
-    // LDS operations of one wave execute in order; this only keeps the compiler from moving accesses across it
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// acc += Pa(16 x 16) * Pb(16 x 16)^T, both row-major in LDS with row stride PS
-template <int PS = kPS>
-__device__ __forceinline__ d4 potrf_mma_nt(const double* Pa, const double* Pb, d4 acc, int lane) {
-    const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[fr * PS + kk + fk], Pb[fr * PS + kk + fk], acc, 0, 0, 0);
-    return acc;
-}
-
-// acc += Pa(16 x 16) * Pb(16 x 16), Pb read transposed
-template <int PS = kPS>
-__device__ __forceinline__ d4 potrf_mma_nn(const double* Pa, const double* Pb, d4 acc, int lane) {
-    const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[fr * PS + kk + fk], Pb[(kk + fk) * PS + fr], acc, 0, 0, 0);
-    return acc;
-}
-
-// ---- the 16x16 pivot tile: one wave, everything in registers, the instruction order written down by hand ----
-// What bounds it (tools/probe/dpp_rate_probe.hip, one wave): an FP64 instruction issues every 5.8 cycles whether or
-// not it depends on the previous one (9.6 if it does; v_rsq_f64 25; DPP operands, scalar operands and 32-bit
-// instructions cost the same 5.8-6.3), and the pivot chain alone - rsq, one third-order step, the scaled diagonal, the
-// next pivot, its broadcast - is 89 cycles per pivot.  The tile's 240 eliminations + 160 chain instructions are
-// therefore ~2.3 k cycles of issue, and the rest of the 4.3 k it took was overhead around them: the sixteen loads
-// compiled into sixteen branches (`lane < 16 ? load : constant`), 64 selects, 32 stores of a factor nothing reads,
-// stores and exec-mask changes between the pivots.  Now every lane row loads the same 16 rows (no select, no branch),
-// the factor is stored only for the one tile whose row is read, W is stored after the last pivot, and every
-// instruction of the loop is an `asm volatile` statement (they keep their order: the eliminations of the PREVIOUS
-// pivot sit in the shadow of the chain's operations instead of behind them): 4340 -> 3030 cycles per tile
-// (tools/probe/potrf_probe.hip; bit-identical output), LBA-M's solve 40 -> 35 us.  Tried and measured equal or
-// worse: the factor in lanes 0-15 and the inverse in lanes 16-31 (one elimination serves both, but the column of
-// multipliers has to cross lane rows - v_permlane16_swap + moves - and the pivot needs v_readlane: as many
-// instructions as it saves).  Inline assembly means the hazards are ours: a DPP operand must not be read within two
-// wait states of the VALU write (an elimination or a multiplication sits between), the result of the transcendental
-// unit not within one (pv_rsq).
-// acc -= (lane N of the row of col) * b in ONE instruction: the FP64 FMA takes its first operand through DPP, so a
-// multiplier of the pivot loop costs no broadcast instruction, no scalar register (512 v_readlane per tile ran the
-// SGPR file dry) and no temporary.
-template <int N>
-__device__ __forceinline__ void fnma_bcast_c(double& acc, double col, double b) {
-    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(col), "v"(b), "n"(N));
-}
-#define SO_ROW16(F, n, ...)                                                                                          \
-    switch (n) {                                                                                                     \
-        case 0: F<0>(__VA_ARGS__); break;   case 1: F<1>(__VA_ARGS__); break;   case 2: F<2>(__VA_ARGS__); break;     \
-        case 3: F<3>(__VA_ARGS__); break;   case 4: F<4>(__VA_ARGS__); break;   case 5: F<5>(__VA_ARGS__); break;     \
-        case 6: F<6>(__VA_ARGS__); break;   case 7: F<7>(__VA_ARGS__); break;   case 8: F<8>(__VA_ARGS__); break;     \
-        case 9: F<9>(__VA_ARGS__); break;   case 10: F<10>(__VA_ARGS__); break; case 11: F<11>(__VA_ARGS__); break;   \
-        case 12: F<12>(__VA_ARGS__); break; case 13: F<13>(__VA_ARGS__); break; case 14: F<14>(__VA_ARGS__); break;   \
-        default: F<15>(__VA_ARGS__); break;                                                                          \
-    }
-__device__ __forceinline__ double pv_rsq(double a) {
-    double r;
-    asm volatile("v_rsq_f64 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(a));
-    return r;
-}
-__device__ __forceinline__ double pv_mul(double a, double b) {
-    double r;
-    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double pv_fma(double a, double b, double c) {
-    double r;
-    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ double pv_fnma(double a, double b, double c) {  // c - a b
-    double r;
-    asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ double pv_one_minus(double a, double b) {  // 1 - a b
-    double r;
-    asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double pv_half_plus(double s, double b) {  // 0.5 + s b, s in scalar registers
-    double r;
-    asm volatile("v_fma_f64 %0, %1, %2, 0.5" : "=v"(r) : "s"(s), "v"(b));
-    return r;
-}
-// Value of lane N of the caller's row of 16 lanes (v_mov_b64_dpp row_newbcast).  The operand must be two wait states old.
-template <int N>
-__device__ __forceinline__ double pv_row_bcast(double x) {
-    double r;
-    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(N));
-    return r;
-}
-
-// Pending elimination K of pivot C - 1, factor and inverse alternating (targets C..15 each):
-//   K even: x[C + K/2] -= L[C + K/2][C - 1] * L[lane][C - 1]       K odd: v[C + K/2] -= L[C + K/2][C - 1] * w[C - 1]
-template <int C, int K>
-__device__ __forceinline__ void pv_pend(double (&x)[16], double (&v)[16], double xp, double wp) {
-    if constexpr (C > 0 && C + K / 2 < 16) {
-        if constexpr (K % 2 == 0) fnma_bcast_c<C + K / 2>(x[C + K / 2], xp, xp);
-        else fnma_bcast_c<C + K / 2>(v[C + K / 2], xp, wp);
-    }
-}
-template <int C, int K0, int K1>
-__device__ __forceinline__ void pv_pend_range(double (&x)[16], double (&v)[16], double xp, double wp) {
-    if constexpr (K0 < K1) {
-        pv_pend<C, K0>(x, v, xp, wp);
-        pv_pend_range<C, K0 + 1, K1>(x, v, xp, wp);
-    }
-}
-// Pivot C of the tile and, in the shadow of its chain, the eliminations of pivot C - 1 (a compile-time schedule).
-// piv: the pivot in every lane of the row; xp / wp: the lane's entries of the previous column of L and row of W.
-template <int C>
-__device__ __forceinline__ void pv_step(double (&x)[16], double (&v)[16], double piv, double xp, double wp, double k375,
-                                        double& last_piv) {
-    constexpr int n_pend = C > 0 ? 2 * (16 - C) : 0;
-    constexpr int n_slots = 6;  // issue slots behind the operations of the chain below
-    constexpr int n_first = n_pend - n_slots > 3 ? n_pend - n_slots : 3;
-    if constexpr (C == 15) last_piv = piv;
-    const double y0 = pv_rsq(piv);
-    // x[C], v[C], x[C + 1] first (the chain needs them), then whatever does not fit behind the chain's operations
-    pv_pend_range<C, 0, n_first>(x, v, xp, wp);
-    const double t = pv_mul(piv, y0);
-    pv_pend<C, n_first>(x, v, xp, wp);
-    const double e = pv_one_minus(t, y0);
-    pv_pend<C, n_first + 1>(x, v, xp, wp);
-    const double p = pv_half_plus(k375, e);
-    const double ye = pv_mul(y0, e);
-    pv_pend<C, n_first + 2>(x, v, xp, wp);
-    const double y = pv_fma(ye, p, y0);
-    pv_pend<C, n_first + 3>(x, v, xp, wp);
-    x[C] = pv_mul(x[C], y);
-    pv_pend<C, n_first + 4>(x, v, xp, wp);
-    if constexpr (C + 1 < 16) {
-        // the next pivot: in its own lane the multiplier is the lane's own x[C], no broadcast on the chain
-        const double pn = pv_fnma(x[C], x[C], x[C + 1]);
-        v[C] = pv_mul(v[C], y);  // W[C][lane], final                (two wait states between pn and its DPP read)
-        pv_pend<C, n_first + 5>(x, v, xp, wp);
-        const double piv_next = pv_row_bcast<C + 1>(pn);
-        pv_step<C + 1>(x, v, piv_next, x[C], v[C], k375, last_piv);
-    } else {
-        v[C] = pv_mul(v[C], y);
-    }
-}
-
-// One wave: Cholesky of the 16x16 tile at At (row stride PS) and its inverse W.  W goes to Wt (may alias At; zeros
-// above the diagonal); the factor's rows go to Lt if that is not null (entries above the diagonal unspecified - the
-// one reader takes the part below it of one row).  Lane l holds row l & 15 and solves L w = e_(l & 15) by forward
-// substitution on the same multipliers: the four rows of 16 lanes run the same thing (no selects around the loads,
-// DPP broadcasts stay inside a row of lanes); lanes 0-15 store.  Returns false if a pivot is not positive: a bad
-// pivot turns everything behind it into NaN (rsq of a negative number; 0 x inf), so the last pivot tells.
-template <int PS>
-__device__ __forceinline__ bool potrf_diag16(const double* At, double* Lt, double* Wt, int lane) {
-    double x[16], v[16];
-    const int lr = lane & 15;
-#pragma unroll
-    for (int c = 0; c < 16; c++) {
-        x[c] = At[lr * PS + c];
-        v[c] = (c == lr) ? 1.0 : 0.0;
-    }
-    potrf_wave_sync();  // every lane holds its row: Wt / Lt may alias At from here on
-    double last_piv = 0.0;
-    pv_step<0>(x, v, __builtin_amdgcn_mov_dpp(x[0], 0x150, 0xf, 0xf, true), 0.0, 0.0, 0.375, last_piv);
-    if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) Wt[c * PS + lane] = v[c];  // W[c][lane] (zero above the diagonal by construction)
-        if (Lt) {
-#pragma unroll
-            for (int c = 0; c < 16; c++) Lt[lane * PS + c] = x[c];
-        }
-    }
-    return last_piv > 0.0;
-}
-
-// t-th tile (row-major) of a lower triangle
-__device__ __forceinline__ void potrf_tri(int t, int& ti, int& tj) {
-    ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-    tj = t - ti * (ti + 1) / 2;
-}
 
 // Block row i (16 rows) of the inverse factor from LDS to the full row-major 96x96 block in HBM the panel GEMM reads
 // (zeros above the diagonal: those tiles were never written in LDS), by `nthr` threads of which the caller is `t`.
@@ -386,188 +186,17 @@ __global__ __launch_bounds__(256) void dense_potrf_kernel(BaDev d, int k) {
     if (tid == 0 && s_bad) d.partial[kBaSolveOk] = 0.0;
 }
 
-// ---- single-workgroup solve of a reduced camera system of up to 175 unknowns (local windows of 4..29 free keyframes) ----
-// The same machinery as dense_potrf_kernel on the whole system: the lower triangle of [S b; b^T beta] as 16x16 tiles
-// in LDS (row stride 18: conflict-free MFMA operand fetch), the right-hand side riding as one more row so that the
-// forward substitution falls out of the factorisation.  Per 16 columns: the row tiles below the pivot tile become
-// A W^T (MFMA), the trailing tiles take their rank-16 update (MFMA, waves 1-7) while wave 0 updates, factors and
-// inverts the next pivot tile (FP64 DPP multipliers); W replaces the pivot tile - nothing reads L_dd again.  The
-// backward substitution x_k = W_k^T (y_k - sum_{i>k} L_ik^T x_i) runs on the eight waves, one tile each per step.
-// 10 pivot tiles instead of 150 LDS-synchronised pivots: 56 -> 3x us for the 150 unknowns of LBA-M.
-constexpr int kMS = 18;                       // tile row stride (doubles)
-constexpr int kMTile = 16 * kMS;              // doubles per tile
-constexpr int kSolveMfmaMaxTiles = 11;        // 66 tiles = 152 KB of LDS
-constexpr int kSolveMfmaThreads = 512;
-
-__device__ __forceinline__ double* mtile(double* base, int i, int j) { return base + (size_t)(i * (i + 1) / 2 + j) * kMTile; }
-
-// sum over the four 16-lane rows of a wave (every lane gets the total): gfx950's v_permlane32_swap / v_permlane16_swap
-// trade the first operand's upper half (odd rows) with the second operand's lower half (even rows); with both
-// operands equal, a' + b' is the lane's value plus its partner's - two VALU swaps per step, no LDS crossbar
-__device__ __forceinline__ double rows_sum(double v) {
-    {
-        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
-        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-    }
-    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-
-__device__ __forceinline__ void ba_solve_mfma_body(const BaDev& d, double* __restrict__ s_tiles) {
-    __shared__ double s_lastL[kMTile];         // factor of the last pivot tile: its row rr holds the tail of y
-    __shared__ double s_x[16 * kSolveMfmaMaxTiles];
-    __shared__ double s_z[16];
-    __shared__ unsigned char s_ti[kSolveMfmaMaxTiles * (kSolveMfmaMaxTiles + 1) / 2], s_tj[kSolveMfmaMaxTiles * (kSolveMfmaMaxTiles + 1) / 2];
-    __shared__ int s_bad;
-    if (d.lm->active != d.stage) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int crow = lane >> 4, ccol = lane & 15;
-    const int n = 6 * d.n_free, ld = d.ldS;
-    const int NT = (n + 1 + 15) / 16, tr = NT - 1, rr = n - 16 * tr;  // the right-hand side is row rr of tile row tr
-    const int n_tiles = NT * (NT + 1) / 2;
-    if (tid == 0) s_bad = 0;
-    if (tid < n_tiles) {
-        int ti, tj;
-        potrf_tri(tid, ti, tj);
-        s_ti[tid] = (unsigned char)ti;
-        s_tj[tid] = (unsigned char)tj;
-    }
-    for (int i = tid; i < NT * 16; i += kSolveMfmaThreads) s_x[i] = 0.0;
-    __syncthreads();
-    // load: 128 double2 per tile (n is even: a pair never straddles the edge of S), seven loads in flight per thread
-    {
-        constexpr int U = 7;
-        const int total = n_tiles * 128;
-        for (int base = 0; base < total; base += kSolveMfmaThreads * U) {
-            double2 v[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int e = base + u * kSolveMfmaThreads + tid;
-                v[u] = double2{0.0, 0.0};
-                if (e < total) {
-                    const int t = e >> 7, r = (e >> 3) & 15, c = 2 * (e & 7);
-                    const int gr = 16 * s_ti[t] + r, gc = 16 * s_tj[t] + c;
-                    if (gr < n && gc < n) v[u] = *reinterpret_cast<const double2*>(d.S + (size_t)gr * ld + gc);
-                    else if (gr == n && gc < n) v[u] = *reinterpret_cast<const double2*>(d.bs + gc);
-                    else {  // beta (the last pivot only has to stay positive) and the identity padding
-                        if (gr == gc) v[u].x = (gr == n) ? 1e300 : 1.0;
-                        if (gr == gc + 1) v[u].y = (gr == n) ? 1e300 : 1.0;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int e = base + u * kSolveMfmaThreads + tid;
-                if (e < total) {
-                    const int t = e >> 7, r = (e >> 3) & 15, c = 2 * (e & 7);
-                    double* p = s_tiles + (size_t)t * kMTile + r * kMS + c;
-                    p[0] = v[u].x; p[1] = v[u].y;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    SO_POTRF_MARK(0);
-    if (wave == 0) {
-        double* t0 = mtile(s_tiles, 0, 0);
-        if (!potrf_diag16<kMS>(t0, NT == 1 ? s_lastL : nullptr, t0, lane) && lane == 0) s_bad = 1;
-    }
-    __syncthreads();
-    // update waves: 1, 2, 3, 5, 6, 7 - wave 4 shares wave 0's SIMD and stays out of the pivot chain's way
-    const int uw = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
-    for (int jb = 0; jb < NT; jb++) {
-        SO_POTRF_MARK(1 + 3 * jb);
-        const double* Wj = mtile(s_tiles, jb, jb);
-        for (int rt = jb + 1 + wave; rt < NT; rt += 8) {  // panel: L_rd = A_rd W^T
-            double* t = mtile(s_tiles, rt, jb);
-            const d4 acc = potrf_mma_nt<kMS>(t, Wj, d4{0.0, 0.0, 0.0, 0.0}, lane);
-            potrf_wave_sync();
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) t[(crow + 4 * reg) * kMS + ccol] = acc[reg];
-        }
-        if (jb + 1 >= NT) break;
-        __syncthreads();
-        SO_POTRF_MARK(2 + 3 * jb);
-        const int m = NT - jb - 1;
-        if (wave == 0) {  // next pivot tile: update, factor, invert (W in place)
-            double* t = mtile(s_tiles, jb + 1, jb + 1);
-            const double* p = mtile(s_tiles, jb + 1, jb);
-            const d4 acc = potrf_mma_nt<kMS>(p, p, d4{0.0, 0.0, 0.0, 0.0}, lane);
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) t[(crow + 4 * reg) * kMS + ccol] -= acc[reg];
-            potrf_wave_sync();
-            // (the right-hand-side row's pivot beta - y.y and the identity padding are positive by construction)
-            if (!potrf_diag16<kMS>(t, jb + 1 == tr ? s_lastL : nullptr, t, lane) && lane == 0) s_bad = 1;
-            SO_POTRF_MARK(3 + 3 * jb);
-        } else if (uw >= 0) {
-            for (int t = uw; t < m * (m + 1) / 2 - 1; t += 6) {  // tile 0 of the triangle is wave 0's
-                const int ri = jb + 1 + s_ti[t + 1], ci = jb + 1 + s_tj[t + 1];
-                double* c = mtile(s_tiles, ri, ci);
-                const d4 acc = potrf_mma_nt<kMS>(mtile(s_tiles, ri, jb), mtile(s_tiles, ci, jb), d4{0.0, 0.0, 0.0, 0.0}, lane);
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) c[(crow + 4 * reg) * kMS + ccol] -= acc[reg];
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    SO_POTRF_MARK(40);
-    // backward substitution x_k = W_k^T (y_k - sum_{i>k} L_ik^T x_i) on one wave, column-oriented: as soon as x_i is
-    // known its contribution goes into the running sums of every block above - only tile (i, i-1) is on the chain.
-    // Lane (crow, ccol) carries rows crow, crow+4, .. of column ccol; rows >= n of x stay zero.
-    if (wave == 0) {
-        double accj[kSolveMfmaMaxTiles];
-#pragma unroll
-        for (int j = 0; j < kSolveMfmaMaxTiles; j++) accj[j] = 0.0;
-#pragma unroll
-        for (int k = kSolveMfmaMaxTiles - 1; k >= 0; k--) {
-            if (k > tr) continue;
-            const int mk = (k == tr) ? rr : 16;
-            const double yk = (k == tr) ? (ccol < rr ? s_lastL[rr * kMS + ccol] : 0.0) : mtile(s_tiles, tr, k)[rr * kMS + ccol];
-            const double z = yk - rows_sum(accj[k]);
-            if (lane < 16) s_z[lane] = z;
-            potrf_wave_sync();
-            const double* W = mtile(s_tiles, k, k);
-            double xv = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = crow + 4 * r;
-                if (row < mk) xv = fma(W[row * kMS + ccol], s_z[row], xv);  // W lower triangular: zero for row < ccol
-            }
-            xv = rows_sum(xv);
-            const bool real = ccol < mk;
-            if (lane < 16) {
-                s_x[16 * k + lane] = real ? xv : 0.0;
-                if (real) d.bs[16 * k + lane] = xv;
-            }
-            potrf_wave_sync();
-            double xr[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) xr[r] = s_x[16 * k + crow + 4 * r];
-#pragma unroll
-            for (int j = kSolveMfmaMaxTiles - 2; j >= 0; j--) {  // nearest block first: it is the next one needed
-                if (j >= k) continue;
-                const double* t = mtile(s_tiles, k, j);
-#pragma unroll
-                for (int r = 0; r < 4; r++) accj[j] = fma(t[(crow + 4 * r) * kMS + ccol], xr[r], accj[j]);
-            }
-        }
-    }
-    SO_POTRF_MARK(41);
-    if (tid == 0) d.partial[kBaSolveOk] = s_bad ? 0.0 : 1.0;
-}
+// (the single-workgroup MFMA solve of a local window, ba_solve_mfma_body<THREADS>: ba_solve_mfma.inc)
 __global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_kernel(BaDev d) {
     extern __shared__ double s_tiles[];        // NT (NT + 1) / 2 tiles
-    ba_solve_mfma_body(d, s_tiles);
+    ba_solve_mfma_body<kSolveMfmaThreads>(d, s_tiles);
 }
 
 // the single-workgroup solves of a GROUP of windows (so_ba_group): workgroup y solves the system of member y
 __global__ __launch_bounds__(kSolveMfmaThreads) void ba_solve_mfma_group_kernel(const BaDev* __restrict__ rows, BaGroupArgs A) {
     extern __shared__ double s_tiles[];
     const BaDev d = rows[A.row[blockIdx.y]];
-    ba_solve_mfma_body(d, s_tiles);
+    ba_solve_mfma_body<kSolveMfmaThreads>(d, s_tiles);
 }
 
 void launch_ba_solve_mfma_group(const BaDev* d_rows, const BaGroupArgs& A, size_t lds, hipStream_t s) {

@@ -181,6 +181,19 @@ struct BaRecorder {
     std::vector<BaLaunchRec> list;
     int phase = 0;
 };
+// ---- a stage's Levenberg-Marquardt trials as ONE resident launch (ba_kernels.hip: ba_lm_resident_kernel) ----
+// Device words the workgroups of such a launch meet at; one block per solver context, zeroed at creation.
+struct BaResidentSync {
+    unsigned arrive;   // grid barrier: workgroups that have arrived (back to 0 when the barrier opens)
+    unsigned gen;      // grid barrier: (launch epoch << 11) | ordinal of the last barrier that opened
+    unsigned abort_w;  // epoch of a launch in which a workgroup gave up waiting (BaDev::flow_timeout_ticks)
+    unsigned pad;
+};
+constexpr int kBaResidentMaxTrials = 400;  // (4 barriers... 5 per trial: the ordinal has 11 bits)
+// false: this window cannot run resident (solver class, size); nothing was launched
+bool launch_ba_trials_resident(const BaDev& d, int nb_upd, int max_trials, const uint8_t* abort_flag, BaLm* lm_host,
+                               BaResidentSync* sync, unsigned epoch, int n_workgroups, hipStream_t s);
+
 extern thread_local BaRecorder* g_ba_recorder;  // non-null: the calling thread's launch_ba_* record instead of launching
 // one grouped launch: `kind` for the members of A (rows of d_rows), grid (max_grid, A.n)
 void launch_ba_group(int kind, const BaDev* d_rows, const BaGroupArgs& A, int max_grid, size_t lds, hipStream_t s);

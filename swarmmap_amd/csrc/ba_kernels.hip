@@ -28,6 +28,8 @@
 
 namespace so {
 
+#include "ba_solve_mfma.inc"  // ba_solve_mfma_body<256> for the resident trial loop (the solve's own kernels: ba_dense.hip)
+
 // ---------------- SE3Quat pieces (se3quat.h), same formulas as the CPU oracle ----------------
 __device__ __forceinline__ void quat_rotate(const double* q, const double* v, double* out) {
     double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
@@ -1777,6 +1779,127 @@ __global__ __launch_bounds__(256) void ba_trial_decide_kernel(BaDev d, int nb_er
     ba_trial_decide_body(d, nb_err, nb_upd, abort_flag, lm_host, blockIdx.x, gridDim.x);
 }
 
+
+// =====================================================================================================
+// A stage's trials as ONE resident launch.  The chain above costs a window ~70 dependent launches; alone on the GPU they follow
+// each other within a microsecond or two, but with several agents' chains, tracking stages and extraction chains on the same
+// device every one of them queues behind whatever the command processor is dispatching, and a window that takes 1.0 ms alone
+// takes 3 ms next to seven others (NOTES G.8).  Here the workgroups stay: n_workgroups of 256 threads walk the virtual blocks of
+// each phase (the bodies take their block index as an argument: same partial sums, same bits as the launches), meet at a grid
+// barrier (device-scope release / acquire around an arrival counter), workgroup 0 runs the MFMA solve on four waves and the
+// decision, and the loop goes on until the stage is over - lm->active leaves the stage's tag - or max_trials are done.
+// Every wait is bounded (BaDev::flow_timeout_ticks, as in the dataflow solves of ba_dense.hip): a workgroup that is not resident
+// makes the others give up, the host repeats the call on the chain of launches and keeps that path (so_bundle_adjust).
+// Residency is the caller's business: the workgroups hold the solve's LDS (one per CU), ba.cpp limits how many windows run
+// resident at once.
+// =====================================================================================================
+struct ResWatch {
+    BaResidentSync* y;
+    unsigned* abort_host;
+    unsigned long long deadline;
+    unsigned epoch;
+};
+__device__ __forceinline__ bool res_expired(const ResWatch& W) {  // one thread
+    if (__hip_atomic_load(&W.y->abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == W.epoch) return true;
+    if (wall_clock64() > W.deadline) {
+        __hip_atomic_store(&W.y->abort_w, W.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (W.abort_host) __hip_atomic_store(W.abort_host, W.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return true;
+    }
+    return false;
+}
+// every thread of every workgroup; `ordinal` counts the launch's barriers from 1.  Returns false once the launch has been given up.
+__device__ __forceinline__ bool res_barrier(const ResWatch& W, unsigned n_wg, unsigned ordinal, int* s_dead) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this workgroup's part of the phase is out ...
+    __syncthreads();
+    if (threadIdx.x == 0 && !*s_dead) {
+        const unsigned target = (W.epoch << 11) | ordinal;
+        if (__hip_atomic_fetch_add(&W.y->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_wg - 1) {
+            __hip_atomic_store(&W.y->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&W.y->gen, target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned polls = 0;
+            while (__hip_atomic_load(&W.y->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++polls & 255u) == 0 && res_expired(W)) {
+                    *s_dead = 1;
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and everybody else's is visible
+    return !*s_dead;
+}
+
+__global__ __launch_bounds__(256) void ba_lm_resident_kernel(BaDev d, int nb_build, int nb_gather, int nb_upd, int max_trials,
+                                                             const uint8_t* __restrict__ abort_flag, BaLm* __restrict__ lm_host,
+                                                             BaResidentSync* __restrict__ sync, unsigned epoch) {
+    extern __shared__ double s_tiles[];  // the solve's tiles (workgroup 0; the others carry the allocation: one workgroup per CU)
+    __shared__ int s_dead;
+    const unsigned G = gridDim.x;
+    ResWatch W;
+    W.y = sync;
+    W.abort_host = d.flow_abort_host;
+    W.deadline = wall_clock64() + d.flow_timeout_ticks;
+    W.epoch = epoch;
+    if (threadIdx.x == 0)  // (a launch of this call that gave up already: run through)
+        s_dead = W.abort_host != nullptr && __hip_atomic_load(W.abort_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u ? 1 : 0;
+    __syncthreads();
+    unsigned ordinal = 0;
+    for (int t = 0; t < max_trials && !s_dead; t++) {
+        // the LM state as of the last barrier (the launch boundary for the first trial): the same value in every workgroup
+        if (__hip_atomic_load(&d.lm->active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != d.stage) break;
+        for (unsigned bx = blockIdx.x; bx < (unsigned)nb_build; bx += G) {
+            ba_build_body(d, kBaGateActive, bx, (unsigned)nb_build);
+            __syncthreads();  // (the bodies' LDS scratch is reused by the next virtual block)
+        }
+        if (!res_barrier(W, G, ++ordinal, &s_dead)) break;
+        for (unsigned bx = blockIdx.x; bx < (unsigned)nb_gather; bx += G) {
+            ba_schur_gather_body<4>(d, 0, bx, (unsigned)nb_gather);
+            __syncthreads();
+        }
+        if (!res_barrier(W, G, ++ordinal, &s_dead)) break;
+        if (blockIdx.x == 0) ba_solve_mfma_body<256>(d, s_tiles);
+        if (!res_barrier(W, G, ++ordinal, &s_dead)) break;
+        for (unsigned bx = blockIdx.x; bx < (unsigned)nb_upd; bx += G) {
+            ba_update_errors_body(d, bx, (unsigned)nb_upd);
+            __syncthreads();
+        }
+        if (!res_barrier(W, G, ++ordinal, &s_dead)) break;
+        if (blockIdx.x == 0) ba_trial_decide_body(d, nb_upd, nb_upd, abort_flag, lm_host, 0, 1);
+        if (!res_barrier(W, G, ++ordinal, &s_dead)) break;
+    }
+}
+
+bool launch_ba_trials_resident(const BaDev& d, int nb_upd, int max_trials, const uint8_t* abort_flag, BaLm* lm_host,
+                               BaResidentSync* sync, unsigned epoch, int n_workgroups, hipStream_t s) {
+    // the windows the fused update + the MFMA solve in LDS cover (what launch_ba_trial sends down the five-launch path)
+    if (!(d.fold_prep && d.n_poses <= kBaFusedMaxPoses && !d.use_pairs && !d.use_pcg) || d.n_free < kBaMfmaSolverMinFree) return false;
+    const int n = 6 * d.n_free, NT = (n + 1 + 15) / 16;
+    constexpr int kResidentMaxTiles = 10;  // 55 tiles = 127 KB beside the bodies' ~20 KB of static LDS
+    if (NT < 2 || NT > kResidentMaxTiles || n_workgroups < 2 || !sync) return false;
+    const int nb_build = d.n_free + (d.n_points + 31) / 32;
+    const int groups = d.n_free * (d.n_free + 1) / 2 + d.n_free, nb_gather = 8 * ((groups + 7) / 8);
+    if (nb_build <= 0 || nb_upd <= 0) return false;
+    const size_t lds = sizeof(double) * (size_t)(NT * (NT + 1) / 2) * kMTile;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ba_lm_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(double) * (kResidentMaxTiles * (kResidentMaxTiles + 1) / 2) * kMTile)) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set[dev] = true;
+    }
+    max_trials = std::min(max_trials, kBaResidentMaxTrials);
+    hipLaunchKernelGGL(ba_lm_resident_kernel, dim3((unsigned)n_workgroups), dim3(256), lds, s, d, nb_build, nb_gather, nb_upd, max_trials,
+                       abort_flag, lm_host, sync, epoch);
+    return true;
+}
 
 void launch_ba_trial(const BaDev& d, int nb_err, int nb_upd, const uint8_t* abort_flag, BaLm* lm_host, hipEvent_t ev0,
                      hipEvent_t ev1, hipStream_t s) {

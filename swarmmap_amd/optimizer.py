@@ -113,6 +113,13 @@ class Optimizer:
 
     __del__ = close
 
+    def resident_stages(self):
+        """so_ba_resident_stages: LM stages of this context that ran as one resident launch (SWARMORB_BA_RESIDENT=1, an experiment)."""
+        n = C.c_longlong(0)
+        self._lib.so_ba_resident_stages.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        _lib.check(self._lib.so_ba_resident_stages(self._h, C.byref(n)))
+        return int(n.value)
+
     def set_group(self, group):
         """so_ba_set_group: this context's local bundle adjustments go out merged with the other members' (None: leave)."""
         self._lib.so_ba_set_group.argtypes = [C.c_void_p, C.c_void_p]

@@ -122,3 +122,24 @@ def test_more_members_than_an_argument_block_holds_and_a_stop_request():
     for o in opts:
         o.close()
     g.close()
+
+
+def test_resident_trial_loop_equals_the_chain_of_launches(monkeypatch):
+    """SWARMORB_BA_RESIDENT=1 (an experiment, off by default: NOTES.md G.10): a stage's LM trials as ONE resident launch - workgroups
+    that walk the virtual blocks of build / Schur gather / update + errors, meet at grid barriers, the MFMA solve on four waves of
+    workgroup 0 - against the five launches per trial: every output to the bit, with 8, 32 and 100 workgroups; windows the loop does
+    not cover (3 and 40 free keyframes) take the chain by themselves."""
+    windows = _windows()
+    opt = swarmmap_amd.Optimizer()
+    monkeypatch.delenv("SWARMORB_BA_RESIDENT", raising=False)
+    ref = [opt.LocalBundleAdjustment(w) for w in windows]
+    assert opt.resident_stages() == 0
+    monkeypatch.setenv("SWARMORB_BA_RESIDENT", "1")
+    for wgs in ("8", "32", "100"):
+        monkeypatch.setenv("SWARMORB_BA_RESIDENT_WGS", wgs)
+        before = opt.resident_stages()
+        for i, w in enumerate(windows):
+            _same(opt.LocalBundleAdjustment(w), ref[i], "window %d resident on %s workgroups" % (i, wgs))
+        assert opt.resident_stages() - before == 2 * 5  # both stages of the five windows with 8 / 25 free keyframes
+    opt.close()
+
