@@ -189,7 +189,7 @@ struct BaResidentSync {
     unsigned abort_w;  // epoch of a launch in which a workgroup gave up waiting (BaDev::flow_timeout_ticks)
     unsigned pad;
 };
-constexpr int kBaResidentMaxTrials = 400;  // (4 barriers... 5 per trial: the ordinal has 11 bits)
+constexpr int kBaResidentMaxTrials = 400;  // (five barriers per trial, and the barrier's ordinal has 11 bits beside the epoch's 20)
 // false: this window cannot run resident (solver class, size); nothing was launched
 bool launch_ba_trials_resident(const BaDev& d, int nb_upd, int max_trials, const uint8_t* abort_flag, BaLm* lm_host,
                                BaResidentSync* sync, unsigned epoch, int n_workgroups, hipStream_t s);
