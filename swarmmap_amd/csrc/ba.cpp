@@ -221,7 +221,7 @@ struct so_ba {
     int linear_solver = 0;                  // so_ba_set_linear_solver: 0 direct (block-skyline Cholesky), 1 block-Jacobi PCG (ba_pcg.hip)
     BaPcgHost pcg;                          // its tolerance / iteration cap, workspace pointers and counters
     int pcg_nnz_blocks = 0;                 // nonzero 6 x 6 blocks of S in the last PCG problem
-    Buf d_pcg, d_pcg_idx;
+    Buf d_pcg, d_pcg_idx, d_pcg_val;
     BaLm* h_lm = nullptr;        // host-mapped copy of the LM state, written by the decision kernels
     BaLm* h_lm_dev = nullptr;
     uint8_t* h_abort = nullptr;  // host-mapped forceStopFlag the decision kernel polls
@@ -243,7 +243,7 @@ struct so_ba {
     std::vector<Buf*> all() {
         return {&d_in, &d_out, &d_pose1, &d_pt1, &d_err, &d_chi2, &d_tab, &d_Hpp, &d_bp, &d_Hll, &d_bl, &d_W, &d_Dinv,
                 &d_db, &d_BDinv, &d_S, &d_bs, &d_xl, &d_partial, &d_po, &d_lm, &d_dense_ws, &d_dense_x, &d_pr_off, &d_pr_cur, &d_pr, &d_big, &d_scan_tmp, &d_plan,
-                &d_flow, &d_flow_big, &d_pcg, &d_pcg_idx};
+                &d_flow, &d_flow_big, &d_pcg, &d_pcg_idx, &d_pcg_val};
     }
 };
 
@@ -1399,6 +1399,13 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         BaPcgDev& q = b->pcg.dev;
         q.indptr = d_indptr;
         q.indices = b->d_pcg_idx.as<int>();
+        // the blocks' values side by side for the products (SWARMORB_PCG_DENSE_READ=1: read them where they lie in S, as before round 6)
+        static const bool dense_read = getenv("SWARMORB_PCG_DENSE_READ") != nullptr;
+        q.Sc = nullptr;
+        if (!dense_read) {
+            if ((rc = b->d_pcg_val.ensure(sizeof(double) * 36 * (size_t)std::max(nnzb, 1)))) return rc;
+            q.Sc = b->d_pcg_val.as<double>();
+        }
         q.Minv = (double*)(pb + p_Minv);
         q.x = (double*)(pb + p_x); q.r = (double*)(pb + p_r); q.z = (double*)(pb + p_z); q.p = (double*)(pb + p_p); q.Sp = (double*)(pb + p_Sp);
         q.partA = (double*)(pb + p_A); q.partB = (double*)(pb + p_B); q.scal = (double*)(pb + p_scal);

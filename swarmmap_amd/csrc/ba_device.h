@@ -55,6 +55,7 @@ struct BaLm {
 struct BaPcgDev {
     const int* indptr;   // n_free + 1: block rows of S - its nonzero 6 x 6 block columns, ascending (diagonal included)
     const int* indices;
+    double* Sc;          // the nonzero blocks of S, 36 doubles each in the order of `indices` (copied per solve; null: read S itself)
     double* Minv;        // n_free x 36: inverse of the diagonal blocks
     double *x, *r, *z, *p, *Sp;  // 6 n_free each
     double* partA;       // ceil(n_free / 4): partial sums of p.Sp

@@ -14,7 +14,10 @@
 // along streets has 3 % of its blocks set (GBA-2r: 77 k of 2.26 M), and only those are touched.  One iteration = three
 // launches, scalars stay on the device:
 //   spmv       a wavefront per block row: lane l takes block (l / 6) of a group of ten, row (l % 6) of it - 48 contiguous
-//              bytes per lane -, fixed summation order; + the partial sums of p.Sp
+//              bytes per lane -, fixed summation order; + the partial sums of p.Sp.  The blocks are read from a COMPACT copy
+//              (36 doubles per nonzero block, in index order, made once per solve by pcg_compact_kernel): in S itself the six rows
+//              of a block are ldS doubles apart (72 KB on GBA-2r), so a wavefront's ten blocks were sixty separate 48-byte
+//              pieces; compact they are 2.9 KB in a row (NOTES F.3 measured 110 -> 45 us per iteration on the probe)
 //   update     alpha = rz / p.Sp; x += alpha p; r -= alpha Sp; z = M^-1 r (6 x 6 blocks); partial sums of r.z and r.r
 //   direction  beta = rz' / rz; p = z + beta p; convergence: r.r <= tol^2 b.b; the status word goes to host-mapped memory
 // The host keeps two chunks of iterations enqueued and looks at the status word between chunks (a converged or failed
@@ -158,6 +161,23 @@ __global__ __launch_bounds__(64) void pcg_init2_kernel(BaDev d, BaPcgDev q, int 
     __hip_atomic_store(q.status_host, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- the nonzero blocks of this trial's S side by side (same lane layout as the product that reads them) ----
+__global__ __launch_bounds__(256) void pcg_compact_kernel(BaDev d, BaPcgDev q) {
+    if (d.lm->active != d.stage) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    const int sub = lane / 6, r = lane % 6;
+    if (row >= d.n_free || lane >= 60) return;
+    const int lo = q.indptr[row], hi = q.indptr[row + 1];
+    const double* Srow = d.S + (size_t)(6 * row + r) * d.ldS;
+    for (int k = lo + sub; k < hi; k += 10) {
+        const double2* B = reinterpret_cast<const double2*>(Srow + 6 * (size_t)q.indices[k]);
+        double2* C = reinterpret_cast<double2*>(q.Sc + 36 * (size_t)k + 6 * r);
+        const double2 b0 = B[0], b1 = B[1], b2 = B[2];
+        C[0] = b0; C[1] = b1; C[2] = b2;
+    }
+}
+
 // ---- one iteration ----
 __global__ __launch_bounds__(256) void pcg_spmv_kernel(BaDev d, BaPcgDev q) {
     if (pcg_done(q)) return;
@@ -170,7 +190,8 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(BaDev d, BaPcgDev q) {
         const double* Srow = d.S + (size_t)(6 * row + r) * d.ldS;
         for (int k = lo + sub; k < hi; k += 10) {
             const int j = q.indices[k];
-            const double2* B = reinterpret_cast<const double2*>(Srow + 6 * (size_t)j);
+            const double2* B = q.Sc ? reinterpret_cast<const double2*>(q.Sc + 36 * (size_t)k + 6 * r)
+                                    : reinterpret_cast<const double2*>(Srow + 6 * (size_t)j);
             const double2* x = reinterpret_cast<const double2*>(q.p + 6 * (size_t)j);
             const double2 b0 = B[0], b1 = B[1], b2 = B[2], x0 = x[0], x1 = x[1], x2 = x[2];
             acc += ((b0.x * x0.x + b0.y * x0.y) + (b1.x * x1.x + b1.y * x1.y)) + (b2.x * x2.x + b2.y * x2.y);
@@ -289,6 +310,7 @@ void launch_ba_pcg_solve(const BaDev& d, hipStream_t s) {
     const BaPcgDev& q = H.dev;
     const int nf = d.n_free, nA = (nf + 3) / 4, nB = (nf + 255) / 256, nC = (6 * nf + 255) / 256;
     const unsigned seq = ++H.seq;
+    if (q.Sc) hipLaunchKernelGGL(pcg_compact_kernel, dim3(nA), dim3(256), 0, s, d, q);
     hipLaunchKernelGGL(pcg_init_kernel, dim3(nB), dim3(256), 0, s, d, q);
     hipLaunchKernelGGL(pcg_init2_kernel, dim3(1), dim3(64), 0, s, d, q, nB, seq, H.tol);
     constexpr int kChunk = 8;
