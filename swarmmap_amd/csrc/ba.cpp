@@ -1380,7 +1380,7 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
     if (pairs_path && b->linear_solver == 1) {
         // block-Jacobi PCG instead of the blocked Cholesky: the 6 x 6 block structure of S from the pair lists (once per
         // problem: counts, scan, one look at the total, fill), then the workspace
-        const size_t sNF = (size_t)nf, nA = (sNF + 3) / 4, nB = (sNF + 255) / 256;
+        const size_t sNF = (size_t)nf, nA = sNF, nB = (sNF + 255) / 256;  // (partA: a partial per block row at most)
         Layout P;
         const size_t p_counts = P.add(sizeof(int) * (sNF + 1)), p_indptr = P.add(sizeof(int) * (sNF + 1)), p_Minv = P.add(sizeof(double) * 36 * sNF),
                      p_x = P.add(sizeof(double) * 6 * sNF), p_r = P.add(sizeof(double) * 6 * sNF), p_z = P.add(sizeof(double) * 6 * sNF),
@@ -1414,6 +1414,10 @@ static int bundle_adjust_once(so_ba* b, const so_ba_problem* p, const so_ba_opti
         q.status_host = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(b->h_flow_abort_dev) + 8);
         b->pcg.status_host = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<uint8_t*>(b->h_flow_abort) + 8);
         b->pcg_nnz_blocks = nnzb;
+        // a workgroup per block row from 20 blocks per row on (measured: GBA-2, 516 per row, 7.5 -> 4.4 ms per solve; GBA-2r, 51 per
+        // row, 13.0 -> 12.3; GBA-1r, 37 per row, 6.0 -> 5.4); SWARMORB_PCG_WIDE=0/1 forces one or the other
+        static const int wide_env = getenv("SWARMORB_PCG_WIDE") ? atoi(getenv("SWARMORB_PCG_WIDE")) : -1;
+        b->pcg.wide = wide_env >= 0 ? (wide_env != 0) : ((long long)nnzb >= 20ll * nf);
         d.use_pcg = 1;
         d.pcg_host = &b->pcg;
     }

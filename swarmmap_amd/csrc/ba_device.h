@@ -74,6 +74,7 @@ struct BaPcgHost {
     long long iterations = 0;  // of this so_bundle_adjust call
     int solves = 0;
     int fault = 0;             // of this call: 1 = a solve did not finish within 30 s, 2 = the stream failed / drained mid-solve
+    int wide = 0;              // 1: a block row of S holds enough blocks for a whole workgroup (pcg_spmv_wide_kernel); partA then has n_free entries
 };
 
 struct BaDev {

@@ -214,6 +214,46 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(BaDev d, BaPcgDev q) {
     if (threadIdx.x == 0) q.partA[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
+// The same product with a WORKGROUP per block row (dense maps: GBA-2 has 516 blocks per row, and 1108 wavefronts walking 52
+// steps each do not keep enough loads in flight): wave w takes the groups of ten w, w + 4, ...; the four waves' sums of a row
+// are added as (w0 + w1) + (w2 + w3).  Fixed order, so deterministic - but not the order of the one-wave kernel: which of the
+// two a problem gets depends on its structure only (BaPcgHost::wide), never on timing.
+__global__ __launch_bounds__(256) void pcg_spmv_wide_kernel(BaDev d, BaPcgDev q) {
+    if (pcg_done(q)) return;
+    __shared__ double s_tot[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x;
+    const int sub = lane / 6, r = lane % 6;
+    double acc = 0.0;
+    if (lane < 60) {
+        const int lo = q.indptr[row], hi = q.indptr[row + 1];
+        const double* Srow = d.S + (size_t)(6 * row + r) * d.ldS;
+        for (int k = lo + sub + 10 * wave; k < hi; k += 40) {
+            const int j = q.indices[k];
+            const double2* B = q.Sc ? reinterpret_cast<const double2*>(q.Sc + 36 * (size_t)k + 6 * r)
+                                    : reinterpret_cast<const double2*>(Srow + 6 * (size_t)j);
+            const double2* x = reinterpret_cast<const double2*>(q.p + 6 * (size_t)j);
+            const double2 b0 = B[0], b1 = B[1], b2 = B[2], x0 = x[0], x1 = x[1], x2 = x[2];
+            acc += ((b0.x * x0.x + b0.y * x0.y) + (b1.x * x1.x + b1.y * x1.y)) + (b2.x * x2.x + b2.y * x2.y);
+        }
+    }
+    double tot = 0.0;
+    for (int s = 0; s < 10; s++) tot += __shfl(acc, r + 6 * s);
+    if (lane < 6) s_tot[wave][lane] = tot;
+    __syncthreads();
+    if (wave != 0) return;
+    double dot = 0.0;
+    if (lane < 6) {
+        const double t = (s_tot[0][lane] + s_tot[1][lane]) + (s_tot[2][lane] + s_tot[3][lane]);
+        q.Sp[6 * (size_t)row + lane] = t;
+        dot = t * q.p[6 * (size_t)row + lane];
+    }
+    dot += __shfl_down(dot, 4);  // lanes 0..5 -> lane 0 (fixed tree)
+    dot += __shfl_down(dot, 2);
+    dot += __shfl_down(dot, 1);
+    if (lane == 0) q.partA[row] = dot;
+}
+
 __device__ __forceinline__ double block_sum_256(double v, double* sh) {
     sh[threadIdx.x] = v;
     __syncthreads();
@@ -308,9 +348,9 @@ void launch_ba_pcg_structure(const BaDev& d, int* counts, int* indptr, int* indi
 void launch_ba_pcg_solve(const BaDev& d, hipStream_t s) {
     BaPcgHost& H = *d.pcg_host;
     const BaPcgDev& q = H.dev;
-    const int nf = d.n_free, nA = (nf + 3) / 4, nB = (nf + 255) / 256, nC = (6 * nf + 255) / 256;
+    const int nf = d.n_free, nA = H.wide ? nf : (nf + 3) / 4, nB = (nf + 255) / 256, nC = (6 * nf + 255) / 256;
     const unsigned seq = ++H.seq;
-    if (q.Sc) hipLaunchKernelGGL(pcg_compact_kernel, dim3(nA), dim3(256), 0, s, d, q);
+    if (q.Sc) hipLaunchKernelGGL(pcg_compact_kernel, dim3((nf + 3) / 4), dim3(256), 0, s, d, q);
     hipLaunchKernelGGL(pcg_init_kernel, dim3(nB), dim3(256), 0, s, d, q);
     hipLaunchKernelGGL(pcg_init2_kernel, dim3(1), dim3(64), 0, s, d, q, nB, seq, H.tol);
     constexpr int kChunk = 8;
@@ -319,7 +359,8 @@ void launch_ba_pcg_solve(const BaDev& d, hipStream_t s) {
     auto chunk = [&]() {
         for (int c = 0; c < kChunk && enq < max_it; c++, enq++) {
             const int par = enq & 1;
-            hipLaunchKernelGGL(pcg_spmv_kernel, dim3(nA), dim3(256), 0, s, d, q);
+            if (H.wide) hipLaunchKernelGGL(pcg_spmv_wide_kernel, dim3(nA), dim3(256), 0, s, d, q);
+            else hipLaunchKernelGGL(pcg_spmv_kernel, dim3(nA), dim3(256), 0, s, d, q);
             hipLaunchKernelGGL(pcg_update_kernel, dim3(nB), dim3(256), 0, s, d, q, nA, par);
             hipLaunchKernelGGL(pcg_direction_kernel, dim3(nC), dim3(256), 0, s, d, q, nB, par, seq, (unsigned)(enq + 1), enq + 1 == max_it ? 1 : 0);
         }

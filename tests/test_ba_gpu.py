@@ -612,7 +612,9 @@ def test_pcg_on_the_full_size_maps_matches_the_oracle_fixture(pcg_opt, name, fix
     assert r["info"]["chi2_final"] == pytest.approx(inf["chi2_final"], rel=1e-6)
     assert np.all(np.abs(r["Tcw"] - g["Tcw"]) <= POSE_TOL + 4 * np.spacing(np.abs(g["Tcw"]).astype(np.float32)))
     assert np.abs(r["Xw"][::8] - g["Xw_every8"]).max() <= POINT_TOL
-    assert np.allclose(r["chi2"][::64], g["chi2"], rtol=1e-5, atol=1e-7)
+    # (an iterative solve stopped at |r| / |b| <= 1e-7 against the fixture of the DIRECT solve: measured 1.3e-5 on GBA-2 with a wave
+    #  per block row, 2.1e-5 with round 6's workgroup per block row - another summation order -, 1e-7 on GBA-2r either way)
+    assert np.allclose(r["chi2"][::64], g["chi2"], rtol=5e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("seed,pose_noise", [(2, (1.0, 25.0)), (4, (0.6, 15.0)), (0, (0.3, 8.0))])
